@@ -1,0 +1,466 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the product path.
+// extern "C" surface of the CPU restatement, loaded with ctypes by tests/, smoke() and the
+// cpu_baseline leg of bench.py. Field elements cross as uint64[4] Montgomery limbs (the reference's
+// in-memory form, SURVEY.md section 8 conventions); affine points as uint64[8] = x limbs | y limbs,
+// (0,0) for the identity.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "spartan.hpp"
+
+using namespace oracle;
+
+static thread_local std::string g_err;
+#define ORC_TRY try {
+#define ORC_CATCH                   \
+  }                                 \
+  catch (const std::exception& e) { \
+    g_err = e.what();               \
+    return -1;                      \
+  }                                 \
+  return 0;
+
+template <class F>
+static std::vector<F> load(const uint64_t* p, size_t n) {
+  std::vector<F> v(n);
+  for (size_t i = 0; i < n; ++i) memcpy(v[i].l, p + 4 * i, 32);
+  return v;
+}
+template <class F>
+static void store(uint64_t* p, const std::vector<F>& v) {
+  for (size_t i = 0; i < v.size(); ++i) memcpy(p + 4 * i, v[i].l, 32);
+}
+static Affine load_aff(const uint64_t* p) {
+  Affine a;
+  memcpy(a.x.l, p, 32);
+  memcpy(a.y.l, p + 4, 32);
+  return a;
+}
+static void store_aff(uint64_t* p, const Affine& a) {
+  memcpy(p, a.x.l, 32);
+  memcpy(p + 4, a.y.l, 32);
+}
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+// ---- field ------------------------------------------------------------------------------------
+// field_id: 0 = T256 scalar (P-256 base prime), 1 = T256 base, 2 = Pallas scalar
+#define FIELD_DISPATCH(id, ...)                        \
+  switch (id) {                                        \
+    case 0: { typedef Fq F; __VA_ARGS__; break; }       \
+    case 1: { typedef Fp F; __VA_ARGS__; break; }       \
+    case 2: { typedef FqPallas F; __VA_ARGS__; break; } \
+    default: return -1;                                \
+  }
+
+int orc_field_modulus(int id, uint64_t* out) {
+  FIELD_DISPATCH(id, memcpy(out, F::P().p.l, 32));
+  return 0;
+}
+int orc_field_binop(int id, int op, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  FIELD_DISPATCH(id, {
+    F x = F::from_raw_mont(a), y = F::from_raw_mont(b), r;
+    switch (op) {
+      case 0: r = x + y; break;
+      case 1: r = x - y; break;
+      case 2: r = x * y; break;
+      case 3: r = x.inv(); break;
+      case 4: r = x.neg(); break;
+      default: return -1;
+    }
+    memcpy(out, r.l, 32);
+  });
+  return 0;
+}
+int orc_field_from_canonical(int id, const uint64_t* v, uint64_t* out) {
+  FIELD_DISPATCH(id, { F r = F::from_canonical(v); memcpy(out, r.l, 32); });
+  return 0;
+}
+int orc_field_to_canonical(int id, const uint64_t* v, uint64_t* out) {
+  FIELD_DISPATCH(id, { F::from_raw_mont(v).to_canonical(out); });
+  return 0;
+}
+int orc_field_from_uniform(int id, const uint8_t* bytes64, uint64_t* out) {
+  FIELD_DISPATCH(id, { F r = F::from_uniform(bytes64); memcpy(out, r.l, 32); });
+  return 0;
+}
+// value contract of DelayedReduction (src/big_num/delayed_reduction.rs:41-84): reduce(sum a_i b_i)
+int orc_field_dot(int id, const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  FIELD_DISPATCH(id, {
+    F acc = F::zero();
+    for (size_t i = 0; i < n; ++i) acc = acc + F::from_raw_mont(a + 4 * i) * F::from_raw_mont(b + 4 * i);
+    memcpy(out, acc.l, 32);
+  });
+  return 0;
+}
+
+// ---- hashing / transcript ---------------------------------------------------------------------
+int orc_keccak256(const uint8_t* data, size_t n, uint8_t* out32) {
+  Keccak256 h;
+  h.update(data, n);
+  h.finalize(out32);
+  return 0;
+}
+int orc_shake256(const uint8_t* data, size_t n, uint8_t* out, size_t outlen) {
+  Shake256 s;
+  s.update(data, n);
+  s.read(out, outlen);
+  return 0;
+}
+void* orc_transcript_new(const char* label) { return new Transcript(label); }
+void orc_transcript_free(void* t) { delete (Transcript*)t; }
+int orc_transcript_absorb(void* t, const char* label, const uint8_t* bytes, size_t n) {
+  ((Transcript*)t)->absorb_bytes(label, bytes, n);
+  return 0;
+}
+int orc_transcript_dom_sep(void* t, const char* bytes) {
+  ((Transcript*)t)->dom_sep(bytes);
+  return 0;
+}
+int orc_transcript_squeeze(void* t, const char* label, int field_id, uint64_t* out) {
+  uint8_t b[64];
+  ((Transcript*)t)->squeeze_bytes(label, b);
+  return orc_field_from_uniform(field_id, b, out);
+}
+// scalar absorbed with its transcript encoding (BE), field_id as above
+int orc_transcript_absorb_scalar(void* t, const char* label, int field_id, const uint64_t* s) {
+  FIELD_DISPATCH(field_id, ((Transcript*)t)->absorb_scalar(label, F::from_raw_mont(s)));
+  return 0;
+}
+
+// ---- polynomials ------------------------------------------------------------------------------
+int orc_eq_evals(const uint64_t* r, size_t ell, uint64_t* out) {
+  store(out, eq_evals_from_points(load<Fq>(r, ell)));
+  return 0;
+}
+int orc_bind_top(uint64_t* Z, size_t len, size_t* lo_eff, size_t* hi_eff, const uint64_t* r) {
+  ORC_TRY
+  MultilinearPolynomial<Fq> p(load<Fq>(Z, len), *lo_eff, *hi_eff);
+  p.bind_poly_var_top(Fq::from_raw_mont(r));
+  store(Z, p.Z);
+  *lo_eff = p.lo_eff;
+  *hi_eff = p.hi_eff;
+  ORC_CATCH
+}
+int orc_multilinear_evaluate(const uint64_t* Z, size_t len, const uint64_t* r, size_t ell, uint64_t* out) {
+  Fq v = multilinear_evaluate(load<Fq>(Z, len), load<Fq>(r, ell));
+  memcpy(out, v.l, 32);
+  return 0;
+}
+int orc_sparse_poly_evaluate(size_t num_vars, const uint64_t* Z, size_t zlen, const uint64_t* r, uint64_t* out) {
+  ORC_TRY
+  Fq v = sparse_poly_evaluate(num_vars, load<Fq>(Z, zlen), load<Fq>(r, num_vars));
+  memcpy(out, v.l, 32);
+  ORC_CATCH
+}
+int orc_unipoly_from_evals(const uint64_t* evals, size_t n, uint64_t* coeffs) {
+  ORC_TRY
+  store(coeffs, UniPoly<Fq>::from_evals(load<Fq>(evals, n)).coeffs);
+  ORC_CATCH
+}
+int orc_unipoly_evaluate(const uint64_t* coeffs, size_t n, const uint64_t* r, uint64_t* out) {
+  UniPoly<Fq> p;
+  p.coeffs = load<Fq>(coeffs, n);
+  Fq v = p.evaluate(Fq::from_raw_mont(r));
+  memcpy(out, v.l, 32);
+  return 0;
+}
+
+// ---- sum-check --------------------------------------------------------------------------------
+int orc_sumcheck_cubic3(const uint64_t* claim, const uint64_t* taus, size_t ell, uint64_t* A, uint64_t* B, uint64_t* C, void* tr,
+                        uint64_t* out_polys /*ell*3*/, uint64_t* out_r /*ell*/, uint64_t* out_final /*3*/) {
+  ORC_TRY
+  size_t len = (size_t)1 << ell;
+  MultilinearPolynomial<Fq> a(load<Fq>(A, len)), b(load<Fq>(B, len)), c(load<Fq>(C, len));
+  SumcheckProof<Fq> pf;
+  std::vector<Fq> r, fin;
+  prove_cubic_with_three_inputs(Fq::from_raw_mont(claim), load<Fq>(taus, ell), a, b, c, *(Transcript*)tr, &pf, &r, &fin);
+  for (size_t i = 0; i < ell; ++i) store(out_polys + 12 * i, pf.compressed_polys[i]);
+  store(out_r, r);
+  store(out_final, fin);
+  ORC_CATCH
+}
+int orc_sumcheck_quad(const uint64_t* claim, size_t rounds, uint64_t* A, size_t loA, size_t hiA, uint64_t* B, size_t loB, size_t hiB, void* tr,
+                      uint64_t* out_polys /*rounds*2*/, uint64_t* out_r, uint64_t* out_final /*2*/) {
+  ORC_TRY
+  size_t len = (size_t)1 << rounds;
+  MultilinearPolynomial<Fq> a(load<Fq>(A, len), loA, hiA), b(load<Fq>(B, len), loB, hiB);
+  SumcheckProof<Fq> pf;
+  std::vector<Fq> r, fin;
+  prove_quad(Fq::from_raw_mont(claim), rounds, a, b, *(Transcript*)tr, &pf, &r, &fin);
+  for (size_t i = 0; i < rounds; ++i) store(out_polys + 8 * i, pf.compressed_polys[i]);
+  store(out_r, r);
+  store(out_final, fin);
+  ORC_CATCH
+}
+// src/sumcheck.rs:67-114. polys: rounds x (degree) compressed coefficients. returns 0 ok / 1 reject.
+int orc_sumcheck_verify(const uint64_t* claim, size_t rounds, size_t degree, const uint64_t* polys, void* tr, uint64_t* out_e, uint64_t* out_r) {
+  SumcheckProof<Fq> pf;
+  for (size_t i = 0; i < rounds; ++i) pf.compressed_polys.push_back(load<Fq>(polys + 4 * degree * i, degree));
+  Fq e;
+  std::vector<Fq> r;
+  if (!pf.verify(Fq::from_raw_mont(claim), rounds, degree, *(Transcript*)tr, &e, &r)) return 1;
+  memcpy(out_e, e.l, 32);
+  store(out_r, r);
+  return 0;
+}
+
+// ---- curve / msm ------------------------------------------------------------------------------
+int orc_curve_generator(uint64_t* out) {
+  store_aff(out, T256Curve::generator());
+  return 0;
+}
+int orc_on_curve(const uint64_t* p) { return on_curve(load_aff(p)) ? 1 : 0; }
+int orc_point_add(const uint64_t* a, const uint64_t* b, uint64_t* out) {
+  store_aff(out, Jac::from_affine(load_aff(a)).add(Jac::from_affine(load_aff(b))).to_affine());
+  return 0;
+}
+int orc_point_mul(const uint64_t* a, const uint64_t* k, uint64_t* out) {
+  store_aff(out, scalar_mul(Jac::from_affine(load_aff(a)), Fq::from_raw_mont(k)).to_affine());
+  return 0;
+}
+int orc_from_label(const char* label, size_t n, uint64_t* out) {
+  std::vector<Affine> g = from_label(label, n);
+  for (size_t i = 0; i < n; ++i) store_aff(out + 8 * i, g[i]);
+  return 0;
+}
+static std::vector<Affine> load_bases(const uint64_t* b, size_t n) {
+  std::vector<Affine> v(n);
+  for (size_t i = 0; i < n; ++i) v[i] = load_aff(b + 8 * i);
+  return v;
+}
+int orc_msm(const uint64_t* scalars, const uint64_t* bases, size_t n, size_t threads, uint64_t* out) {
+  std::vector<Fq> s = load<Fq>(scalars, n);
+  std::vector<Affine> b = load_bases(bases, n);
+  store_aff(out, msm(s.data(), b.data(), n, threads).to_affine());
+  return 0;
+}
+int orc_msm_naive(const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t* out) {  // test-side naive sum (msm.rs:878-901)
+  Jac acc = Jac::identity();
+  for (size_t i = 0; i < n; ++i) acc = acc.add(scalar_mul(Jac::from_affine(load_aff(bases + 8 * i)), Fq::from_raw_mont(scalars + 4 * i)));
+  store_aff(out, acc.to_affine());
+  return 0;
+}
+int orc_msm_small(const uint64_t* scalars_u64, const uint64_t* bases, size_t n, uint64_t* out) {
+  std::vector<Affine> b = load_bases(bases, n);
+  store_aff(out, msm_small(scalars_u64, b.data(), n).to_affine());
+  return 0;
+}
+int orc_fixed_base_mul(const uint64_t* base, const uint64_t* scalars, size_t n, uint64_t* out) {
+  FixedBaseMul t = FixedBaseMul::precompute(Jac::from_affine(load_aff(base)), 8);
+  for (size_t i = 0; i < n; ++i) store_aff(out + 8 * i, t.mul(Fq::from_raw_mont(scalars + 4 * i)).to_affine());
+  return 0;
+}
+
+// ---- Hyrax ------------------------------------------------------------------------------------
+void* orc_hyrax_setup(const char* label, size_t width) { return new HyraxKey(HyraxKey::setup(label, width)); }
+void orc_hyrax_free(void* k) { delete (HyraxKey*)k; }
+int orc_hyrax_key_export(void* k, uint64_t* ck_out /*width*8*/, uint64_t* h_out /*8*/) {
+  HyraxKey* key = (HyraxKey*)k;
+  for (size_t i = 0; i < key->ck.size(); ++i) store_aff(ck_out + 8 * i, key->ck[i]);
+  store_aff(h_out, key->h.to_affine());
+  return 0;
+}
+int orc_hyrax_commit(void* k, const uint64_t* v, size_t n, const uint64_t* blinds, int is_small, uint64_t* out_rows) {
+  ORC_TRY
+  HyraxKey* key = (HyraxKey*)k;
+  std::vector<Fq> vv = load<Fq>(v, n);
+  HyraxBlind b = load<Fq>(blinds, div_ceil(n, key->num_cols));
+  HyraxCommitment c = hyrax_commit(*key, vv.data(), n, b, is_small != 0);
+  std::vector<Affine> a = batch_affine(c);
+  for (size_t i = 0; i < a.size(); ++i) store_aff(out_rows + 8 * i, a[i]);
+  ORC_CATCH
+}
+int orc_rowmat_vec(const uint64_t* poly, const uint64_t* l, size_t rows, size_t cols, uint64_t* out) {  // bind_with_delayed
+  std::vector<Fq> p = load<Fq>(poly, rows * cols), L = load<Fq>(l, rows);
+  store(out, bind_with_delayed(p.data(), L, cols));
+  return 0;
+}
+
+// ---- R1CS shape -------------------------------------------------------------------------------
+struct IntCsr {
+  const int64_t* data;
+  const uint32_t* indices;
+  const uint64_t* indptr;
+};
+static SparseMatrix<Fq> to_matrix(const IntCsr& m, size_t rows, size_t cols) {
+  SparseMatrix<Fq> M;
+  size_t nnz = m.indptr[rows];
+  M.data.resize(nnz);
+  M.indices.resize(nnz);
+  for (size_t i = 0; i < nnz; ++i) {
+    M.data[i] = Fq::from_i64(m.data[i]);
+    M.indices[i] = m.indices[i];
+  }
+  M.indptr.assign(m.indptr, m.indptr + rows + 1);
+  M.cols = cols;
+  return M;
+}
+// arguments == SplitR1CSShape::new (src/r1cs/mod.rs:810-820) with int64 coefficients
+void* orc_shape_new(size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges,
+                    const int64_t* Ad, const uint32_t* Ai, const uint64_t* Ap, const int64_t* Bd, const uint32_t* Bi, const uint64_t* Bp,
+                    const int64_t* Cd, const uint32_t* Ci, const uint64_t* Cp) {
+  try {
+    size_t cols = num_shared + num_precommitted + num_rest + 1 + num_public + num_challenges;
+    auto* S = new SplitR1CSShape<Fq>(SplitR1CSShape<Fq>::make(num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges,
+                                                              to_matrix(IntCsr{Ad, Ai, Ap}, num_cons, cols), to_matrix(IntCsr{Bd, Bi, Bp}, num_cons, cols),
+                                                              to_matrix(IntCsr{Cd, Ci, Cp}, num_cons, cols)));
+    return S;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void orc_shape_free(void* s) { delete (SplitR1CSShape<Fq>*)s; }
+int orc_shape_sizes(void* s, uint64_t* out10) {  // SplitR1CSShape::sizes (src/r1cs/mod.rs:1008-1021)
+  auto* S = (SplitR1CSShape<Fq>*)s;
+  uint64_t v[10] = {S->num_cons_unpadded, S->num_shared_unpadded, S->num_precommitted_unpadded, S->num_rest_unpadded, S->num_cons,
+                    S->num_shared,        S->num_precommitted,    S->num_rest,                  S->num_public,        S->num_challenges};
+  memcpy(out10, v, sizeof v);
+  return 0;
+}
+int orc_shape_multiply_vec(void* s, const uint64_t* z, uint64_t* az, uint64_t* bz, uint64_t* cz) {
+  ORC_TRY
+  auto* S = (SplitR1CSShape<Fq>*)s;
+  std::vector<Fq> a, b, c;
+  S->multiply_vec(load<Fq>(z, S->num_vars() + S->num_extra()), &a, &b, &c);
+  store(az, a);
+  store(bz, b);
+  store(cz, c);
+  ORC_CATCH
+}
+int orc_shape_multiply_vec_incremental(void* s, const uint64_t* z, const uint64_t* caz, const uint64_t* cbz, const uint64_t* ccz, uint64_t* az,
+                                       uint64_t* bz, uint64_t* cz) {
+  ORC_TRY
+  auto* S = (SplitR1CSShape<Fq>*)s;
+  std::vector<Fq> a, b, c;
+  S->multiply_vec_incremental_into(load<Fq>(z, S->num_vars() + S->num_extra()), load<Fq>(caz, S->num_cons), load<Fq>(cbz, S->num_cons),
+                                   load<Fq>(ccz, S->num_cons), &a, &b, &c);
+  store(az, a);
+  store(bz, b);
+  store(cz, c);
+  ORC_CATCH
+}
+int orc_shape_poly_abc(void* s, const uint64_t* rx, const uint64_t* r, size_t out_len, uint64_t* out) {
+  ORC_TRY
+  auto* S = (SplitR1CSShape<Fq>*)s;
+  store(out, S->bind_and_prepare_poly_ABC_inner(load<Fq>(rx, S->num_cons), Fq::from_raw_mont(r), out_len));
+  ORC_CATCH
+}
+
+// ---- Spartan ----------------------------------------------------------------------------------
+void* orc_spartan_setup(void* shape) {
+  try {
+    return new SpartanProverKey(spartan_setup(*(SplitR1CSShape<Fq>*)shape));
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void orc_spartan_pk_free(void* pk) { delete (SpartanProverKey*)pk; }
+int orc_spartan_pk_export(void* pk, uint64_t* ck /*2048*8*/, uint64_t* h /*8*/, uint64_t* ck_s /*8*/, uint64_t* h_s /*8*/, uint8_t* digest32) {
+  auto* k = (SpartanProverKey*)pk;
+  for (size_t i = 0; i < k->ck.ck.size(); ++i) store_aff(ck + 8 * i, k->ck.ck[i]);
+  store_aff(h, k->ck.h.to_affine());
+  store_aff(ck_s, k->ck_s.ck[0]);
+  store_aff(h_s, k->ck_s.h.to_affine());
+  memcpy(digest32, k->vk_digest, 32);
+  return 0;
+}
+static std::vector<Fq> from_u64s(const uint64_t* v, size_t n) {
+  std::vector<Fq> out(n);
+  for (size_t i = 0; i < n; ++i) out[i] = Fq::from_u64(v[i]);
+  return out;
+}
+void* orc_spartan_prep_prove(void* pk, const uint64_t* witness_u64, size_t n, int is_small, const uint8_t* tape, size_t tape_blocks, size_t* tape_used) {
+  try {
+    Tape t(tape, tape_blocks);
+    auto* ps = new SpartanPrep(spartan_prep_prove(*(SpartanProverKey*)pk, from_u64s(witness_u64, n), is_small != 0, t));
+    if (tape_used) *tape_used = t.pos;
+    return ps;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void orc_spartan_prep_free(void* ps) { delete (SpartanPrep*)ps; }
+int orc_spartan_prep_export(void* ps_, uint64_t* comm_rows, uint64_t* caz, uint64_t* cbz, uint64_t* ccz) {
+  auto* ps = (SpartanPrep*)ps_;
+  if (comm_rows) {
+    std::vector<Affine> a = batch_affine(ps->comm_W_precommitted);
+    for (size_t i = 0; i < a.size(); ++i) store_aff(comm_rows + 8 * i, a[i]);
+  }
+  if (caz) store(caz, ps->cached_az);
+  if (cbz) store(cbz, ps->cached_bz);
+  if (ccz) store(ccz, ps->cached_cz);
+  return 0;
+}
+void* orc_spartan_prove(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used,
+                        double* seconds) {
+  try {
+    Tape t(tape, tape_blocks);
+    auto t0 = std::chrono::steady_clock::now();
+    auto* pf = new SpartanProof(spartan_prove(*(SpartanProverKey*)pk, *(SpartanPrep*)ps, from_u64s(publics_u64, npub), t));
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (tape_used) *tape_used = t.pos;
+    return pf;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void orc_spartan_proof_free(void* pf) { delete (SpartanProof*)pf; }
+size_t orc_spartan_proof_words(void* pf) { return ((SpartanProof*)pf)->serialize().size(); }
+int orc_spartan_proof_serialize(void* pf, uint64_t* out) {
+  std::vector<uint64_t> v = ((SpartanProof*)pf)->serialize();
+  memcpy(out, v.data(), v.size() * 8);
+  return 0;
+}
+int orc_spartan_verify(void* pk, void* pf) {
+  try {
+    return spartan_verify(*(SpartanProverKey*)pk, *(SpartanProof*)pf);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+// Rebuild a proof from the canonical flat layout (SpartanProof::serialize) — used to run the
+// restated verifier on proofs produced by the HIP library.
+void* orc_spartan_proof_from_words(void* pk_, const uint64_t* w, size_t nwords) {
+  try {
+    auto* pk = (SpartanProverKey*)pk_;
+    const SplitR1CSShape<Fq>& S = pk->S;
+    size_t rows_pre = div_ceil(S.num_precommitted, pk->ck.num_cols), rows_rest = div_ceil(S.num_rest, pk->ck.num_cols);
+    size_t lx = log2_exact(S.num_cons), ly = log2_exact(S.num_vars()) + 1, nz = pk->ck.num_cols;
+    if (S.num_vars() < nz) nz = S.num_vars();
+    size_t expect = 8 * (rows_pre + rows_rest) + 4 * S.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
+    if (nwords != expect) throw std::runtime_error("proof_from_words: length mismatch");
+    auto* pf = new SpartanProof();
+    size_t o = 0;
+    auto gf = [&]() { Fq f = Fq::from_raw_mont(w + o); o += 4; return f; };
+    auto gp = [&]() { Affine a = load_aff(w + o); o += 8; return Jac::from_affine(a); };
+    for (size_t i = 0; i < rows_pre + rows_rest; ++i) pf->comm_W.push_back(gp());
+    pf->rows_precommitted = rows_pre;
+    for (size_t i = 0; i < S.num_public; ++i) pf->public_values.push_back(gf());
+    for (size_t i = 0; i < lx; ++i) pf->sc_proof_outer.compressed_polys.push_back({gf(), gf(), gf()});
+    for (int i = 0; i < 3; ++i) pf->claims_outer[i] = gf();
+    for (size_t i = 0; i < ly; ++i) pf->sc_proof_inner.compressed_polys.push_back({gf(), gf()});
+    pf->eval_W = gf();
+    pf->blind_eval_W = gf();
+    pf->eval_arg.delta = gp();
+    pf->eval_arg.beta = gp();
+    for (size_t i = 0; i < nz; ++i) pf->eval_arg.z_vec.push_back(gf());
+    pf->eval_arg.z_delta = gf();
+    pf->eval_arg.z_beta = gf();
+    return pf;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""ctypes view of the integer R1CS generators (spartan2_amd/frontend/r1cs_builder.hpp)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "libsp_frontend.so")
+
+
+def build():
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", _LIB, os.path.join(_DIR, "frontend_capi.cpp")])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = ctypes.CDLL(_LIB)
+        L.spf_sha256_circuit.restype = ctypes.c_void_p
+        L.spf_synthetic_circuit.restype = ctypes.c_void_p
+        L.spf_witness.restype = ctypes.POINTER(ctypes.c_uint64)
+        L.spf_publics.restype = ctypes.POINTER(ctypes.c_uint64)
+        L.spf_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+class R1CSInstanceInt:
+    """Integer R1CS + satisfying assignment; the arguments of SplitR1CSShape::new (src/r1cs/mod.rs:810-820)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError(lib().spf_last_error().decode())
+        self._h = ctypes.c_void_p(handle)
+        d = (ctypes.c_uint64 * 9)()
+        lib().spf_dims(self._h, d)
+        (self.num_cons, self.num_shared, self.num_precommitted, self.num_rest, self.num_public, self.num_challenges, nnzA, nnzB, nnzC) = [int(x) for x in d]
+        self.num_aux = self.num_shared + self.num_precommitted + self.num_rest
+        self.csr = []
+        for which, nnz in enumerate((nnzA, nnzB, nnzC)):
+            data = ctypes.POINTER(ctypes.c_int64)()
+            idx = ctypes.POINTER(ctypes.c_uint32)()
+            ptr = ctypes.POINTER(ctypes.c_uint64)()
+            lib().spf_csr(self._h, which, ctypes.byref(data), ctypes.byref(idx), ctypes.byref(ptr))
+            self.csr.append((np.ctypeslib.as_array(data, (max(nnz, 1),))[:nnz].copy(), np.ctypeslib.as_array(idx, (max(nnz, 1),))[:nnz].copy(),
+                             np.ctypeslib.as_array(ptr, (self.num_cons + 1,)).copy()))
+        self.witness = np.ctypeslib.as_array(lib().spf_witness(self._h), (max(self.num_aux, 1),))[: self.num_aux].copy()
+        self.publics = np.ctypeslib.as_array(lib().spf_publics(self._h), (max(self.num_public, 1),))[: self.num_public].copy()
+        lib().spf_free(self._h)
+        self._h = None
+
+
+def sha256_circuit(preimage: bytes) -> R1CSInstanceInt:
+    """Sha256Circuit of benches/sha256_spartan.rs:36-152 for the given preimage."""
+    return R1CSInstanceInt(lib().spf_sha256_circuit(preimage, ctypes.c_size_t(len(preimage))))
+
+
+def synthetic_circuit(n_groups: int, seed: int, num_public: int = 4) -> R1CSInstanceInt:
+    return R1CSInstanceInt(lib().spf_synthetic_circuit(ctypes.c_size_t(n_groups), ctypes.c_uint64(seed), ctypes.c_size_t(num_public)))
