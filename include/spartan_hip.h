@@ -1,0 +1,140 @@
+/* spartan_hip.h — C ABI of libspartan_hip.so, the MI355X (gfx950) implementation of the Spartan2 prover
+ * hot path. Plain pointers and sizes only; no C++/torch types. Each entry point cites the reference
+ * interface (path:line in microsoft/Spartan2) it replaces; INTEGRATION.md shows the Rust `extern "C"`
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions:
+ *   F    = uint64_t[4], little-endian limbs, Montgomery form (x * 2^256 mod p), canonical — the in-memory
+ *          form of halo2curves field elements the reference reaches through `.0` (src/big_num/macros.rs:59-72).
+ *          Scalars are in the engine's scalar field (T256: the P-256 base prime, src/provider/pt256.rs:55).
+ *   Aff  = uint64_t[8] = x | y in the engine's base field (pt256.rs:56); (0,0) encodes the identity.
+ *   Jacobian results are always returned normalised to Aff (canonical), never as raw (X,Y,Z).
+ *   Return value: 0 = ok; negative = -(error class) mirroring `enum SpartanError` (src/errors.rs:13-110);
+ *   sp_last_error() gives the message for the calling thread.
+ *   Host buffers are caller-owned and only read/written during the call. sp_* handles own device memory;
+ *   a handle may be used from one thread at a time, distinct handles concurrently.
+ *   There is NO CPU fallback: every entry point fails with SP_ERR_NO_DEVICE if no gfx950 device is usable.
+ */
+#ifndef SPARTAN_HIP_H
+#define SPARTAN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_ERR_INVALID_INPUT_LENGTH (-1) /* SpartanError::InvalidInputLength   (errors.rs) */
+#define SP_ERR_INVALID_WITNESS_LENGTH (-2) /* SpartanError::InvalidWitnessLength */
+#define SP_ERR_DIVISION_BY_ZERO (-3)     /* SpartanError::DivisionByZero       */
+#define SP_ERR_INTERNAL_TRANSCRIPT (-4)  /* SpartanError::InternalTranscriptError */
+#define SP_ERR_INTERNAL (-5)             /* SpartanError::InternalError        */
+#define SP_ERR_NO_DEVICE (-100)          /* no usable gfx950 device / HIP failure */
+
+typedef struct sp_ctx sp_ctx;               /* one device + stream + scratch */
+typedef struct sp_table sp_table;           /* MultilinearPolynomial<Scalar> resident in HBM */
+typedef struct sp_transcript sp_transcript; /* Keccak256Transcript */
+typedef struct sp_shape sp_shape;           /* SplitR1CSShape with PrecomputedSparseMatrix / FilteredSpmv */
+typedef struct sp_ck sp_ck;                 /* HyraxCommitmentKey: bases + h + FixedBaseMul table of h */
+
+const char* sp_last_error(void);
+
+/* one context per GPU; device = HIP ordinal (LOCAL_RANK under torch.distributed.run). */
+int sp_ctx_create(int device, sp_ctx** out);
+void sp_ctx_destroy(sp_ctx* ctx);
+int sp_ctx_synchronize(sp_ctx* ctx);
+/* time of the most recent instrumented kernel class, measured with hipEvents on the context's stream
+ * (what = "bind", "eval_cubic", "eval_quad", ...): accumulated milliseconds, launches and algorithmic bytes. */
+int sp_ctx_kernel_stats(sp_ctx* ctx, const char* what, double* ms, uint64_t* launches, uint64_t* alg_bytes);
+int sp_ctx_reset_stats(sp_ctx* ctx, int enable_timing);
+
+/* ---- MultilinearPolynomial (src/polys/multilinear.rs:34-164) ------------------------------------- */
+/* MultilinearPolynomial::new / new_with_halves (:62-75). lo_eff/hi_eff = SIZE_MAX for "unknown". */
+int sp_table_from_host(sp_ctx* ctx, const uint64_t* z, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out);
+/* zero-filled table of `len` elements with the given zero-structure hints */
+int sp_table_zeros(sp_ctx* ctx, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out);
+/* host -> device write of cnt elements at element offset off */
+int sp_table_write(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* z, size_t cnt);
+/* device -> device copy */
+int sp_table_copy(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt);
+/* Index / into_vec (:166-173, :87-89) */
+int sp_table_read(sp_ctx* ctx, const sp_table* t, size_t off, size_t cnt, uint64_t* out);
+int sp_table_info(const sp_table* t, size_t* len, size_t* lo_eff, size_t* hi_eff);
+int sp_table_set_len(sp_table* t, size_t len, size_t lo_eff, size_t hi_eff);
+void sp_table_free(sp_table* t);
+/* MultilinearPolynomial::bind_poly_var_top(&r) (:95-164): in place, len halves, all three zero-structure branches */
+int sp_table_bind_top(sp_ctx* ctx, sp_table* t, const uint64_t r[4]);
+/* EqPolynomial::evals_from_points[_into] (src/polys/eq.rs:59-117): table of 2^ell evaluations, r[0] on the index MSB */
+int sp_eq_table(sp_ctx* ctx, const uint64_t* r, size_t ell, sp_table** out);
+
+/* ---- Keccak256Transcript (src/provider/keccak.rs:18-105, trait src/traits/transcript.rs:21-33) ----- */
+int sp_transcript_new(sp_ctx* ctx, const uint8_t* label, size_t n, sp_transcript** out);
+int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n);
+int sp_transcript_dom_sep(sp_transcript* t, const uint8_t* bytes, size_t n);
+int sp_transcript_squeeze(sp_transcript* t, const uint8_t* label, size_t ln, uint64_t out[4]);
+void sp_transcript_free(sp_transcript* t);
+
+/* ---- sum-check (src/sumcheck.rs) -------------------------------------------------------------------- */
+/* SumcheckProof::prove_cubic_with_three_inputs (:502-571) incl. eq_sumcheck::EqSumCheckInstance (:920-1429).
+ * Tables are bound in place down to length 1. out_cpolys: ell x 3 F (compressed polys: c0, c2, c3). */
+int sp_sumcheck_cubic3(sp_ctx* ctx, const uint64_t claim[4], const uint64_t* taus, size_t ell, sp_table* A, sp_table* B, sp_table* C,
+                       sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]);
+/* SumcheckProof::prove_quad (:190-247) with compute_eval_points_quad's eff_pairs bound (:128-174).
+ * out_cpolys: rounds x 2 F (c0, c2). */
+int sp_sumcheck_quad(sp_ctx* ctx, const uint64_t claim[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
+                     uint64_t* out_r, uint64_t out_final[8]);
+/* DelayedReduction dot product reduce(sum a_i * b_i) over the first n elements (src/big_num/delayed_reduction.rs:41-84;
+ * call sites src/spartan.rs:330-341) */
+int sp_table_dot(sp_ctx* ctx, const sp_table* a, const sp_table* b, size_t n, uint64_t out[4]);
+
+/* ---- R1CS (src/r1cs/sparse.rs, src/r1cs/mod.rs) ------------------------------------------------------- */
+typedef struct sp_csr {
+  const uint64_t* data;    /* nnz F */
+  const uint32_t* indices; /* nnz column ids (already padded layout, SplitR1CSShape::new :855-881) */
+  const uint64_t* indptr;  /* rows+1 */
+} sp_csr;
+typedef struct sp_dims {
+  uint64_t num_cons, num_cons_unpadded;
+  uint64_t num_shared, num_precommitted, num_rest; /* padded */
+  uint64_t num_shared_unpadded, num_precommitted_unpadded, num_rest_unpadded;
+  uint64_t num_public, num_challenges;
+} sp_dims;
+/* SplitR1CSShape::precompute (src/r1cs/mod.rs:1059-1073): classify entries (+1 / -1 / small / general,
+ * src/r1cs/sparse.rs:49-134), build the filtered COO (:305-358) and the column-major copy used by poly_ABC. */
+int sp_shape_from_csr(sp_ctx* ctx, const sp_csr* A, const sp_csr* B, const sp_csr* C, const sp_dims* dims, sp_shape** out);
+void sp_shape_free(sp_shape* s);
+/* SplitR1CSShape::multiply_vec (:1075-1107). z has num_vars + 1 + num_public + num_challenges elements. */
+int sp_multiply_vec(sp_ctx* ctx, const sp_shape* s, const sp_table* z, sp_table* az, sp_table* bz, sp_table* cz);
+/* SplitR1CSShape::multiply_vec_incremental_into (:1170-1211) */
+int sp_multiply_vec_incremental(sp_ctx* ctx, const sp_shape* s, const sp_table* z, const sp_table* caz, const sp_table* cbz, const sp_table* ccz,
+                                sp_table* az, sp_table* bz, sp_table* cz);
+/* SplitR1CSShape::bind_and_prepare_poly_ABC[_full] (:1235-1321): out[col] = sum_row rx[row] (A + r B + r^2 C)[row,col],
+ * written into the first out_len elements of `out` */
+int sp_poly_abc(sp_ctx* ctx, const sp_shape* s, const sp_table* rx, const uint64_t r[4], size_t out_len, sp_table* out);
+
+/* ---- group / MSM (src/provider/traits.rs:118-162 DlogGroupExt, src/provider/msm.rs) --------------------- */
+/* DlogGroupExt::vartime_multiscalar_mul (msm.rs:187-222): sum s_i * g_i. scalars / bases on the host. */
+int sp_msm(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_aff[8]);
+/* DlogGroupExt::vartime_multiscalar_mul_small (msm.rs:367-409) */
+int sp_msm_small_u64(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_aff[8]);
+
+/* ---- Hyrax PCS (src/provider/pcs/hyrax_pc.rs, src/provider/pcs/ipa.rs) ------------------------------------ */
+/* HyraxCommitmentKey from explicit generators (PCS::setup derives them with a third-party hash-to-curve,
+ * hyrax_pc.rs:152-177 — the caller supplies them) + precompute_ck (:179-190): uploads the bases and builds the
+ * 8-bit FixedBaseMul table of h on the device (msm.rs:653-689). */
+int sp_ck_create(sp_ctx* ctx, const uint64_t* ck_aff, size_t num_cols, const uint64_t h_aff[8], sp_ck** out);
+void sp_ck_free(sp_ck* ck);
+/* PCS::commit (:207-303) on n elements of a device table starting at `off`; one Aff per row of num_cols */
+int sp_hyrax_commit(sp_ctx* ctx, const sp_ck* ck, const sp_table* v, size_t off, size_t n, const uint64_t* blinds, int is_small, uint64_t* out_rows_aff);
+/* PCS::commit_zeros (:305-319) and the per-row h * blind of rerandomize (:321-344): FixedBaseMul::mul (msm.rs:691-725) */
+int sp_fixed_base_mul_h(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t* out_aff);
+/* bind_with_delayed (:38-54): out[i] = sum_j L[j] * poly[j*cols + i]; out has `cols` F on the host */
+int sp_rowmat_vec(sp_ctx* ctx, const sp_table* poly, size_t rows, size_t cols, const uint64_t* L, uint64_t* out);
+/* MSM of host scalars against the first n bases of a device-resident key (hyrax_pc.rs:454-455, ipa.rs:147) */
+int sp_msm_ck(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t out_aff[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

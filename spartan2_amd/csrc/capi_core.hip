@@ -1,0 +1,563 @@
+// libspartan_hip.so — context, device tables, transcript and the sum-check entry points of include/spartan_hip.h.
+// The round loop lives below the C ABI: per round the device computes the evaluation sums (K2/K3), the host
+// finishes the O(1) part (claim-derived evaluations, UniPoly, Keccak transcript), and the challenge goes back
+// as a kernel argument of the bind (K1).
+#include <cstdio>
+#include <cstring>
+
+#include "core.hpp"
+#include "kernels_poly.cuh"
+
+namespace sp {
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+int fail(int code, const std::string& m) {
+  g_err = m;
+  return code;
+}
+int alloc_table(sp_ctx* ctx, size_t len, sp_table** out) {
+  sp_table* t = new sp_table();
+  t->ctx = ctx;
+  t->cap = len ? len : 1;
+  t->len = len;
+  hipError_t e = hipMalloc((void**)&t->d, t->cap * sizeof(fe_t));
+  if (e != hipSuccess) {
+    delete t;
+    return fail(SP_ERR_NO_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  *out = t;
+  return SP_OK;
+}
+}  // namespace sp
+
+using sp::fail;
+typedef FqP S;
+
+hipEvent_t sp_ctx::get_event() {
+  if (!event_pool.empty()) {
+    hipEvent_t e = event_pool.back();
+    event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+int sp_ctx::ensure_scratch(size_t elems) {
+  if (elems <= scratch_elems) return SP_OK;
+  if (d_scratch) hipFree(d_scratch);
+  d_scratch = nullptr;
+  scratch_elems = 0;
+  SP_HIP(hipMalloc((void**)&d_scratch, elems * sizeof(fe_t)));
+  scratch_elems = elems;
+  return SP_OK;
+}
+void sp_ctx::drain_stats() {
+  for (auto& kv : stats) {
+    for (auto& pr : kv.second.pending) {
+      float ms = 0;
+      hipEventSynchronize(pr.second);
+      hipEventElapsedTime(&ms, pr.first, pr.second);
+      kv.second.ms += ms;
+      event_pool.push_back(pr.first);
+      event_pool.push_back(pr.second);
+    }
+    kv.second.pending.clear();
+  }
+}
+
+static inline fe_t load_fe(const uint64_t* p) {
+  fe_t r;
+  memcpy(&r, p, 32);
+  return r;
+}
+static inline void store_fe(uint64_t* p, const fe_t& a) { memcpy(p, &a, 32); }
+
+extern "C" {
+
+const char* sp_last_error(void) { return sp::g_err.c_str(); }
+
+int sp_ctx_create(int device, sp_ctx** out) {
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) return fail(SP_ERR_NO_DEVICE, "no HIP device visible: libspartan_hip has no CPU fallback");
+  if (device < 0 || device >= count) return fail(SP_ERR_NO_DEVICE, "device ordinal out of range");
+  SP_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SP_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(SP_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+  sp_ctx* c = new sp_ctx();
+  c->device = device;
+  SP_HIP(hipStreamCreate(&c->stream));
+  c->pinned_elems = 64;
+  SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t)));
+  int rc = c->ensure_scratch(1 << 16);
+  if (rc) return rc;
+  *out = c;
+  return SP_OK;
+}
+void sp_ctx_destroy(sp_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  c->drain_stats();
+  for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
+  if (c->d_scratch) hipFree(c->d_scratch);
+  if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+int sp_ctx_synchronize(sp_ctx* c) {
+  SP_HIP(hipStreamSynchronize(c->stream));
+  return SP_OK;
+}
+int sp_ctx_reset_stats(sp_ctx* c, int enable) {
+  c->drain_stats();
+  c->stats.clear();
+  c->timing = enable != 0;
+  return SP_OK;
+}
+int sp_ctx_kernel_stats(sp_ctx* c, const char* what, double* ms, uint64_t* launches, uint64_t* alg_bytes) {
+  SP_HIP(hipStreamSynchronize(c->stream));
+  c->drain_stats();
+  auto it = c->stats.find(what);
+  if (it == c->stats.end()) {
+    *ms = 0;
+    *launches = 0;
+    *alg_bytes = 0;
+    return SP_OK;
+  }
+  *ms = it->second.ms;
+  *launches = it->second.launches;
+  *alg_bytes = it->second.bytes;
+  return SP_OK;
+}
+
+// ---- tables ---------------------------------------------------------------------------------------------------
+int sp_table_from_host(sp_ctx* c, const uint64_t* z, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out) {
+  sp_table* t;
+  int rc = sp::alloc_table(c, len, &t);
+  if (rc) return rc;
+  t->lo_eff = lo_eff;
+  t->hi_eff = hi_eff;
+  if (len) SP_HIP(hipMemcpyAsync(t->d, z, len * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  *out = t;
+  return SP_OK;
+}
+int sp_table_zeros(sp_ctx* c, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out) {
+  sp_table* t;
+  int rc = sp::alloc_table(c, len, &t);
+  if (rc) return rc;
+  t->lo_eff = lo_eff;
+  t->hi_eff = hi_eff;
+  if (len) SP_HIP(hipMemsetAsync(t->d, 0, len * sizeof(fe_t), c->stream));
+  *out = t;
+  return SP_OK;
+}
+int sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, size_t cnt) {
+  if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write: range exceeds the table");
+  if (cnt) SP_HIP(hipMemcpyAsync(t->d + off, z, cnt * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the duration of the call
+  return SP_OK;
+}
+int sp_table_copy(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt) {
+  if (dst_off + cnt > dst->cap || src_off + cnt > src->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_copy: range exceeds a table");
+  if (cnt) SP_HIP(hipMemcpyAsync(dst->d + dst_off, src->d + src_off, cnt * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
+  return SP_OK;
+}
+int sp_table_read(sp_ctx* c, const sp_table* t, size_t off, size_t cnt, uint64_t* out) {
+  if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_read: range exceeds the table");
+  if (cnt) SP_HIP(hipMemcpyAsync(out, t->d + off, cnt * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  return SP_OK;
+}
+int sp_table_info(const sp_table* t, size_t* len, size_t* lo_eff, size_t* hi_eff) {
+  if (len) *len = t->len;
+  if (lo_eff) *lo_eff = t->lo_eff;
+  if (hi_eff) *hi_eff = t->hi_eff;
+  return SP_OK;
+}
+int sp_table_set_len(sp_table* t, size_t len, size_t lo_eff, size_t hi_eff) {
+  if (len > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_set_len: longer than the allocation");
+  t->len = len;
+  t->lo_eff = lo_eff;
+  t->hi_eff = hi_eff;
+  return SP_OK;
+}
+void sp_table_free(sp_table* t) {
+  if (!t) return;
+  if (t->d) hipFree(t->d);
+  delete t;
+}
+
+}  // extern "C"
+
+// bind up to 4 tables with one launch
+static int launch_bind(sp_ctx* c, sp_table** tabs, int nt, const fe_t& r) {
+  spk::BindArgs a;
+  size_t max_eff = 0;
+  uint64_t bytes = 0;
+  for (int i = 0; i < nt; ++i) {
+    sp_table* t = tabs[i];
+    if (t->len < 2) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_poly_var_top: table must have at least two elements");
+    a.z[i] = t->d;
+    a.n[i] = t->len / 2;
+    a.lo[i] = sp::eff_lo(t);
+    a.hi[i] = sp::eff_hi(t);
+    size_t eff = sp::eff_pairs(t);
+    if (eff > max_eff) max_eff = eff;
+    bytes += 48ull * t->len;  // read 32*len, write 16*len per table per round
+  }
+  a.r = r;
+  a.one_minus_r = fe_sub<S>(fe_one<S>(), r);
+  if (max_eff > 0) {
+    size_t blocks = (max_eff + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks, (unsigned)nt);
+    c->timed("bind", bytes, [&] { hipLaunchKernelGGL(spk::k_bind_top, grid, dim3(256), 0, c->stream, a); });
+  }
+  for (int i = 0; i < nt; ++i) sp::after_bind(tabs[i]);
+  return SP_OK;
+}
+
+// second-stage reduction of `nblocks` x nacc block partials in d_scratch -> host
+static int reduce_partials(sp_ctx* c, size_t nblocks, int nacc, fe_t* out_host) {
+  fe_t* d_out = c->d_scratch + c->scratch_elems - 8;
+  hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, d_out);
+  SP_HIP(hipMemcpyAsync(c->h_pinned, d_out, nacc * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < nacc; ++k) out_host[k] = c->h_pinned[k];
+  return SP_OK;
+}
+
+// ---- host-side O(1) glue: UniPoly (src/polys/univariate.rs) ----------------------------------------------------------
+namespace {
+struct UniPoly {
+  fe_t c[4];
+  int n;
+};
+fe_t two_inv() {
+  static fe_t v = fe_inv<S>(fe_from_u64<S>(2));
+  return v;
+}
+fe_t six_inv() {
+  static fe_t v = fe_inv<S>(fe_from_u64<S>(6));
+  return v;
+}
+UniPoly from_evals_deg2(const fe_t e[3]) {  // univariate.rs:84-93
+  UniPoly p;
+  p.n = 3;
+  fe_t c0 = e[0];
+  fe_t a = fe_mul<S>(fe_add<S>(fe_sub<S>(e[0], fe_dbl<S>(e[1])), e[2]), two_inv());
+  fe_t b = fe_sub<S>(fe_sub<S>(e[1], c0), a);
+  p.c[0] = c0;
+  p.c[1] = b;
+  p.c[2] = a;
+  return p;
+}
+UniPoly from_evals_deg3(const fe_t e[4]) {  // univariate.rs:102-118
+  UniPoly p;
+  p.n = 4;
+  fe_t d = e[0];
+  fe_t e1_3 = fe_add<S>(fe_dbl<S>(e[1]), e[1]), e2_3 = fe_add<S>(fe_dbl<S>(e[2]), e[2]);
+  fe_t delta3 = fe_sub<S>(fe_add<S>(fe_sub<S>(e[3], e2_3), e1_3), e[0]);
+  fe_t a = fe_mul<S>(delta3, six_inv());
+  fe_t delta2 = fe_add<S>(fe_sub<S>(e[2], fe_dbl<S>(e[1])), e[0]);
+  fe_t b = fe_sub<S>(fe_mul<S>(delta2, two_inv()), fe_add<S>(fe_dbl<S>(a), a));
+  fe_t c1 = fe_sub<S>(fe_sub<S>(fe_sub<S>(e[1], d), b), a);
+  p.c[0] = d;
+  p.c[1] = c1;
+  p.c[2] = b;
+  p.c[3] = a;
+  return p;
+}
+fe_t poly_eval(const UniPoly& p, const fe_t& r) {  // univariate.rs:136-144
+  fe_t ev = p.c[0], pw = r;
+  for (int i = 1; i < p.n; ++i) {
+    ev = fe_add<S>(ev, fe_mul<S>(pw, p.c[i]));
+    pw = fe_mul<S>(pw, r);
+  }
+  return ev;
+}
+// absorb(b"p", &poly): compressed coefficients, to_repr LE each (univariate.rs:182-190)
+void absorb_poly(sp::Transcript& t, const UniPoly& p) {
+  uint8_t buf[32 * 3];
+  int k = 0;
+  sp::fe_to_le_bytes<S>(p.c[0], buf);
+  k = 1;
+  for (int i = 2; i < p.n; ++i) sp::fe_to_le_bytes<S>(p.c[i], buf + 32 * k++);
+  const uint8_t lbl[1] = {'p'};
+  t.absorb(lbl, 1, buf, 32 * k);
+}
+}  // namespace
+
+extern "C" {
+
+int sp_table_bind_top(sp_ctx* c, sp_table* t, const uint64_t r[4]) {
+  sp_table* tabs[1] = {t};
+  return launch_bind(c, tabs, 1, load_fe(r));
+}
+
+int sp_eq_table(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
+  if (ell > 40) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table: ell too large");
+  sp_table* t;
+  size_t total = (size_t)1 << ell;
+  int rc = sp::alloc_table(c, total, &t);
+  if (rc) return rc;
+  // split the variables: low part <= 10 bits built by one block, high part likewise (ell <= 20), else recursive outer products
+  int lo_bits = (int)(ell > 10 ? 10 : ell), hi_bits = (int)ell - lo_bits;
+  if (hi_bits > 10) {  // > 2^20 entries: build the low 2^20 by outer product first, then widen once more
+    lo_bits = (int)ell - 10;
+    hi_bits = 10;
+  }
+  // scratch: r (ell), level pyramids
+  size_t need = ell + 2 * (((size_t)1 << 11)) + 64 + (lo_bits > 10 ? ((size_t)1 << lo_bits) : 0);
+  rc = c->ensure_scratch(need + 8);
+  if (rc) return rc;
+  fe_t* d_r = c->d_scratch;
+  fe_t* d_hi = d_r + ell;
+  fe_t* d_lo = d_hi + ((size_t)1 << 11);
+  fe_t* d_lowbig = d_lo + ((size_t)1 << 11);
+  if (ell) SP_HIP(hipMemcpyAsync(d_r, r, ell * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  if (ell <= 10) {
+    hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r, (int)ell, d_lo);
+    SP_HIP(hipMemcpyAsync(t->d, d_lo + spk::eq_level_offset((int)ell), total * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
+  } else if (lo_bits <= 10) {
+    hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r, hi_bits, d_hi);
+    hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r + hi_bits, lo_bits, d_lo);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    c->timed("eq_table", 32ull * total, [&] {
+      hipLaunchKernelGGL(spk::k_eq_outer, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_hi + spk::eq_level_offset(hi_bits),
+                         d_lo + spk::eq_level_offset(lo_bits), lo_bits, total, t->d);
+    });
+  } else {
+    // ell in (20, 30]: low (ell-10) bits = outer product of two <=10-bit tables, then one more outer product
+    int l2 = lo_bits - 10;  // in (0, 10]
+    hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r + hi_bits, l2, d_hi);
+    hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r + hi_bits + l2, 10, d_lo);
+    size_t lowtotal = (size_t)1 << lo_bits;
+    hipLaunchKernelGGL(spk::k_eq_outer, dim3(4096), dim3(256), 0, c->stream, d_hi + spk::eq_level_offset(l2), d_lo + spk::eq_level_offset(10), 10,
+                       lowtotal, d_lowbig);
+    hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r, hi_bits, d_hi);
+    hipLaunchKernelGGL(spk::k_eq_outer, dim3(8192), dim3(256), 0, c->stream, d_hi + spk::eq_level_offset(hi_bits), d_lowbig, lo_bits, total, t->d);
+  }
+  SP_HIP(hipStreamSynchronize(c->stream));  // r is a borrowed host buffer
+  *out = t;
+  return SP_OK;
+}
+
+// ---- transcript ---------------------------------------------------------------------------------------------------
+int sp_transcript_new(sp_ctx*, const uint8_t* label, size_t n, sp_transcript** out) {
+  sp_transcript* t = new sp_transcript();
+  t->t.init(label, n);
+  *out = t;
+  return SP_OK;
+}
+int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n) {
+  t->t.absorb(label, ln, bytes, n);
+  return SP_OK;
+}
+int sp_transcript_dom_sep(sp_transcript* t, const uint8_t* bytes, size_t n) {
+  t->t.dom_sep(bytes, n);
+  return SP_OK;
+}
+int sp_transcript_squeeze(sp_transcript* t, const uint8_t* label, size_t ln, uint64_t out[4]) {
+  fe_t f;
+  if (!t->t.squeeze<S>(label, ln, &f)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+  store_fe(out, f);
+  return SP_OK;
+}
+void sp_transcript_free(sp_transcript* t) { delete t; }
+
+// ---- sum-check ------------------------------------------------------------------------------------------------------
+int sp_table_dot(sp_ctx* c, const sp_table* a, const sp_table* b, size_t n, uint64_t out[4]) {
+  if (n > a->cap || n > b->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_dot: n exceeds a table");
+  size_t blocks = (n + 1023) / 1024;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks == 0) blocks = 1;
+  int rc = c->ensure_scratch(blocks + 16);
+  if (rc) return rc;
+  c->timed("dot", 64ull * n, [&] { hipLaunchKernelGGL(spk::k_dot, dim3((unsigned)blocks), dim3(256), 0, c->stream, a->d, b->d, n, c->d_scratch); });
+  fe_t r;
+  rc = reduce_partials(c, blocks, 1, &r);
+  if (rc) return rc;
+  store_fe(out, r);
+  return SP_OK;
+}
+
+int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
+                     uint64_t* out_r, uint64_t out_final[8]) {
+  if (A->len != B->len || A->len != ((size_t)1 << rounds)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: tables must have 2^rounds elements");
+  fe_t claim = load_fe(claim_);
+  const uint8_t lbl_c[1] = {'c'};
+  for (size_t round = 0; round < rounds; ++round) {
+    size_t half = A->len / 2;
+    size_t len = sp::eff_pairs(A);
+    if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
+    if (half < len) len = half;
+    fe_t sums[2] = {fe_zero(), fe_zero()};
+    if (len > 0) {
+      size_t chunk = 256 * spk::EVAL_PPT, blocks = (len + chunk - 1) / chunk;
+      int rc = c->ensure_scratch(blocks * 2 + 16);
+      if (rc) return rc;
+      c->timed("eval_quad", 128ull * len,
+               [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch); });
+      rc = reduce_partials(c, blocks, 2, sums);
+      if (rc) return rc;
+    }
+    // BDDT: eval_2 = 2 claim - 3 eval_0 + 2 t_inf (src/sumcheck.rs:211-215)
+    fe_t e0 = sums[0], tinf = sums[1];
+    fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
+    fe_t e2 = fe_add<S>(fe_add<S>(fe_sub<S>(fe_add<S>(claim, claim), three_e0), tinf), tinf);
+    fe_t ev[3] = {e0, fe_sub<S>(claim, e0), e2};
+    UniPoly poly = from_evals_deg2(ev);
+    absorb_poly(tr->t, poly);
+    fe_t r_i;
+    if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+    store_fe(out_r + 4 * round, r_i);
+    store_fe(out_cpolys + 8 * round, poly.c[0]);
+    store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
+    claim = poly_eval(poly, r_i);
+    sp_table* tabs[2] = {A, B};
+    int rc = launch_bind(c, tabs, 2, r_i);
+    if (rc) return rc;
+  }
+  int rc = sp_table_read(c, A, 0, 1, out_final);
+  if (rc) return rc;
+  return sp_table_read(c, B, 0, 1, out_final + 4);
+}
+
+int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
+                       uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
+  const size_t N = (size_t)1 << ell;
+  if (A->len != N || B->len != N || C->len != N) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: tables must have 2^ell elements");
+  if (ell == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: no rounds");
+  // EqSumCheckInstance::new (src/sumcheck.rs:956-1016)
+  const size_t first_half = ell / 2, second_half = ell - first_half;
+  std::vector<fe_t> taus(ell);
+  for (size_t i = 0; i < ell; ++i) taus[i] = load_fe(taus_ + 4 * i);
+  // device pyramids: left over taus[1..first_half), right over taus[first_half..ell)
+  const size_t nleft = first_half > 0 ? first_half - 1 : 0;
+  size_t pyr_left = (size_t)2 << nleft, pyr_right = (size_t)2 << second_half;
+  size_t max_blocks = (N / 2 + 1023) / 1024 + 1;
+  size_t need = ell + pyr_left + pyr_right + max_blocks * 3 + 32;
+  int rc = c->ensure_scratch(need);
+  if (rc) return rc;
+  // layout: [partials (max_blocks*3)] [taus_left][taus_right][pyr_left][pyr_right] ... [result (last 8)]
+  fe_t* d_part = c->d_scratch;
+  fe_t* d_tl = d_part + max_blocks * 3;
+  fe_t* d_trt = d_tl + nleft;
+  fe_t* d_pl = d_trt + second_half;
+  fe_t* d_pr = d_pl + pyr_left;
+  if (nleft > 10 || second_half > 10) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sum-check over more than 2^21 rows: eq pyramid kernel needs widening");
+  if (nleft) SP_HIP(hipMemcpyAsync(d_tl, taus.data() + 1, nleft * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  SP_HIP(hipMemcpyAsync(d_trt, taus.data() + first_half, second_half * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_tl, (int)nleft, d_pl);
+  hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_trt, (int)second_half, d_pr);
+
+  fe_t claim = load_fe(claim_);
+  fe_t eval_eq_left = fe_one<S>();
+  const fe_t one = fe_one<S>();
+  const uint8_t lbl_c[1] = {'c'};
+  for (size_t rnd = 1; rnd <= ell; ++rnd) {  // `round` of the reference starts at 1 (:1011)
+    const size_t half = A->len / 2;
+    const bool in_first = rnd < first_half;
+    const fe_t* eq_in;
+    const fe_t* eq_out = nullptr;
+    int s;
+    int mode;
+    const size_t chunk = 256 * spk::EVAL_PPT;
+    if (in_first) {  // poly_eqs_first_half (:1407-1420)
+      eq_out = d_pl + spk::eq_level_offset((int)(first_half - rnd));
+      eq_in = d_pr + spk::eq_level_offset((int)second_half);
+      s = (int)second_half;
+      mode = (((size_t)1 << s) >= chunk) ? 1 : 2;
+    } else {  // poly_eq_right_last_half (:1422-1428)
+      eq_in = d_pr + spk::eq_level_offset((int)(ell - rnd));
+      s = 63;
+      mode = 0;
+    }
+    size_t blocks = (half + chunk - 1) / chunk;
+    auto launch = [&](bool with_m1) {
+      dim3 g((unsigned)blocks), b(256);
+#define SP_LAUNCH_EVAL(MODE, M1) \
+  hipLaunchKernelGGL((spk::k_eval_cubic<MODE, M1>), g, b, 0, c->stream, A->d, B->d, C->d, half, eq_in, eq_out, s, d_part)
+      if (!with_m1) {
+        if (mode == 0) SP_LAUNCH_EVAL(0, false);
+        else if (mode == 1) SP_LAUNCH_EVAL(1, false);
+        else SP_LAUNCH_EVAL(2, false);
+      } else {
+        if (mode == 0) SP_LAUNCH_EVAL(0, true);
+        else if (mode == 1) SP_LAUNCH_EVAL(1, true);
+        else SP_LAUNCH_EVAL(2, true);
+      }
+#undef SP_LAUNCH_EVAL
+    };
+    fe_t sums[3];
+    c->timed("eval_cubic", 160ull * half, [&] { launch(false); });
+    rc = reduce_partials(c, blocks, 2, sums);
+    if (rc) return rc;
+    fe_t t0 = sums[0], tinf = sums[1];
+    // derive_from_claim (:1276-1324)
+    const fe_t tau = taus[rnd - 1];
+    const fe_t eq0 = fe_sub<S>(one, tau);            // eq(tau, 0)
+    const fe_t slope = fe_sub<S>(tau, eq0);          // 2 tau - 1
+    const fe_t eqm1 = fe_sub<S>(eq0, slope);         // 2 - 3 tau
+    const fe_t p = eval_eq_left;
+    const fe_t l_0_p = fe_mul<S>(eq0, p);
+    const fe_t l_1_p = fe_mul<S>(fe_add<S>(eq0, slope), p);
+    fe_t s_0, s_1, s_leading, s_m1;
+    if (!fe_is_zero(l_1_p)) {
+      const fe_t l_1_p_inv = fe_inv<S>(l_1_p);
+      s_0 = fe_mul<S>(l_0_p, t0);
+      s_1 = fe_sub<S>(claim, s_0);
+      const fe_t t_1 = fe_mul<S>(s_1, l_1_p_inv);
+      s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
+      const fe_t t_m1 = fe_sub<S>(fe_add<S>(fe_dbl<S>(tinf), fe_dbl<S>(t0)), t_1);
+      s_m1 = fe_mul<S>(fe_mul<S>(eqm1, p), t_m1);
+    } else {  // fallback_three_inputs (:1327-1396): third sum t(-1) computed directly
+      c->timed("eval_cubic", 192ull * half, [&] { launch(true); });
+      rc = reduce_partials(c, blocks, 3, sums);
+      if (rc) return rc;
+      s_0 = fe_mul<S>(fe_mul<S>(eq0, p), t0);
+      s_1 = fe_sub<S>(claim, s_0);
+      s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
+      s_m1 = fe_mul<S>(fe_mul<S>(eqm1, p), sums[2]);
+    }
+    // (s(0), s_leading, s(-1)) -> (eval_0, eval_2, eval_3) (:1303-1320)
+    const fe_t halfc = two_inv();
+    const fe_t c1 = fe_sub<S>(fe_mul<S>(fe_sub<S>(s_1, s_m1), halfc), s_leading);
+    const fe_t c2 = fe_sub<S>(fe_mul<S>(fe_add<S>(s_1, s_m1), halfc), s_0);
+    const fe_t inner_2 = fe_add<S>(c2, fe_dbl<S>(s_leading));
+    const fe_t eval_2 = fe_add<S>(s_0, fe_dbl<S>(fe_add<S>(c1, fe_dbl<S>(inner_2))));
+    const fe_t c3_3 = fe_add<S>(fe_dbl<S>(s_leading), s_leading);
+    const fe_t inner_3 = fe_add<S>(c2, c3_3);
+    const fe_t mid_3 = fe_add<S>(fe_add<S>(c1, fe_dbl<S>(inner_3)), inner_3);
+    const fe_t eval_3 = fe_add<S>(fe_add<S>(s_0, fe_dbl<S>(mid_3)), mid_3);
+    fe_t ev[4] = {s_0, fe_sub<S>(claim, s_0), eval_2, eval_3};
+    UniPoly poly = from_evals_deg3(ev);
+    absorb_poly(tr->t, poly);
+    fe_t r_i;
+    if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+    const size_t ri = rnd - 1;
+    store_fe(out_r + 4 * ri, r_i);
+    store_fe(out_cpolys + 12 * ri, poly.c[0]);
+    store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
+    store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
+    claim = poly_eval(poly, r_i);
+    sp_table* tabs[3] = {A, B, C};
+    rc = launch_bind(c, tabs, 3, r_i);
+    if (rc) return rc;
+    // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
+    eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
+  }
+  rc = sp_table_read(c, A, 0, 1, out_final);
+  if (rc) return rc;
+  rc = sp_table_read(c, B, 0, 1, out_final + 4);
+  if (rc) return rc;
+  return sp_table_read(c, C, 0, 1, out_final + 8);
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Host-side plumbing shared by the translation units of libspartan_hip.so: context, device tables,
+// error reporting, per-kernel-class HIP-event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/spartan_hip.h"
+#include "field.cuh"
+#include "keccak.cuh"
+
+namespace sp {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define SP_HIP(expr)                                                                               \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return sp::fail(SP_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+struct KStat {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double ms = 0;
+  uint64_t launches = 0, bytes = 0;
+};
+
+}  // namespace sp
+
+struct sp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  fe_t* d_scratch = nullptr;  // block partials etc.
+  size_t scratch_elems = 0;
+  fe_t* h_pinned = nullptr;  // small result buffer, pinned
+  size_t pinned_elems = 0;
+  bool timing = false;
+  std::map<std::string, sp::KStat> stats;
+  std::vector<hipEvent_t> event_pool;
+
+  hipEvent_t get_event();
+  int ensure_scratch(size_t elems);
+  // records (start, stop) events around `launch` when timing is enabled
+  template <class L>
+  void timed(const char* what, uint64_t alg_bytes, L&& launch) {
+    if (!timing) {
+      launch();
+      return;
+    }
+    hipEvent_t a = get_event(), b = get_event();
+    hipEventRecord(a, stream);
+    launch();
+    hipEventRecord(b, stream);
+    sp::KStat& s = stats[what];
+    s.pending.emplace_back(a, b);
+    s.launches += 1;
+    s.bytes += alg_bytes;
+  }
+  void drain_stats();
+};
+
+struct sp_table {
+  sp_ctx* ctx = nullptr;
+  fe_t* d = nullptr;
+  size_t cap = 0;  // allocated elements
+  size_t len = 0;  // logical length (power of two while used as a multilinear table)
+  size_t lo_eff = (size_t)-1, hi_eff = (size_t)-1;
+};
+
+struct sp_transcript {
+  sp::Transcript t;
+};
+
+namespace sp {
+inline size_t eff_lo(const sp_table* t) {
+  size_t n = t->len / 2;
+  return t->lo_eff < n ? t->lo_eff : n;
+}
+inline size_t eff_hi(const sp_table* t) {
+  size_t n = t->len / 2;
+  return t->hi_eff < n ? t->hi_eff : n;
+}
+inline size_t eff_pairs(const sp_table* t) {  // MultilinearPolynomial::eff_pairs (src/polys/multilinear.rs:78-84)
+  size_t lo = eff_lo(t), hi = eff_hi(t);
+  return lo > hi ? lo : hi;
+}
+inline void after_bind(sp_table* t) {  // multilinear.rs:160-163
+  size_t n = t->len / 2, eff = eff_pairs(t);
+  t->len = n;
+  t->lo_eff = eff < n / 2 ? eff : n / 2;
+  t->hi_eff = eff > n / 2 ? eff - n / 2 : 0;
+}
+int alloc_table(sp_ctx* ctx, size_t len, sp_table** out);
+}  // namespace sp

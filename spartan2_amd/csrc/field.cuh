@@ -1,0 +1,413 @@
+// 256-bit prime-field arithmetic for gfx950 (and for the host-side protocol glue — every function is
+// __host__ __device__). Elements are 8 x u32 little-endian limbs in Montgomery form (x * 2^256 mod p),
+// canonical < p: byte-identical to the reference's halo2curves 4 x u64 limbs, so
+// tables cross the C ABI without conversion.
+//
+// Two fields:
+//   FqP  = T256 scalar field = NIST P-256 prime 2^256 - 2^224 + 2^192 + 2^96 - 1 (src/provider/pt256.rs:55).
+//          -p^-1 mod 2^96 == 1, so Montgomery's quotient digits are the running low words themselves and
+//          q*p is shifts/adds: the reduction is ~75 add-with-carry instructions, no multiplies. This is
+//          what replaces the reference's x86 mulx/adcx REDC (src/big_num/limbs.rs:200-331, montgomery.rs).
+//   FpP  = T256 base field (pt256.rs:56), generic modulus -> word-serial Montgomery (CIOS).
+//
+// The 256x256 product is 64 v_mad_u64_u32 (row-wise: 8 independent mads, then one v_addc chain per row).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#define SP_HD __host__ __device__ __forceinline__
+
+struct alignas(16) fe_t {
+  uint32_t v[8];
+};
+
+SP_HD uint32_t sp_addc(uint32_t a, uint32_t b, uint32_t& c) {
+  unsigned co;
+  uint32_t r = __builtin_addc(a, b, c, &co);
+  c = co;
+  return r;
+}
+SP_HD uint32_t sp_subb(uint32_t a, uint32_t b, uint32_t& bw) {
+  unsigned bo;
+  uint32_t r = __builtin_subc(a, b, bw, &bo);
+  bw = bo;
+  return r;
+}
+
+// ---- field parameter packs ------------------------------------------------------------------------
+struct FqP {
+  static constexpr bool P256_PRIME = true;
+  static constexpr uint32_t INV32 = 1u;
+  static constexpr uint64_t INV64 = 1ull;
+  static constexpr SP_HD uint32_t P(int i) {
+    constexpr uint32_t t[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0xffffffffu};
+    return t[i];
+  }
+  static constexpr SP_HD uint32_t R1(int i) {  // 2^256 mod p
+    constexpr uint32_t t[8] = {0x00000001u, 0x00000000u, 0x00000000u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xfffffffeu, 0x00000000u};
+    return t[i];
+  }
+  static constexpr SP_HD uint32_t R2(int i) {  // 2^512 mod p
+    constexpr uint32_t t[8] = {0x00000003u, 0x00000000u, 0xffffffffu, 0xfffffffbu, 0xfffffffeu, 0xffffffffu, 0xfffffffdu, 0x00000004u};
+    return t[i];
+  }
+  static constexpr SP_HD uint32_t R3(int i) {  // 2^768 mod p
+    constexpr uint32_t t[8] = {0x0000000au, 0xfffffffdu, 0xfffffff7u, 0xffffffedu, 0xfffffffcu, 0x00000005u, 0x00000001u, 0x00000018u};
+    return t[i];
+  }
+};
+struct FpP {
+  static constexpr bool P256_PRIME = false;
+  static constexpr uint32_t INV32 = 0x0f646959u;  // -p^-1 mod 2^32
+  static constexpr uint64_t INV64 = 0xe0a2f6a60f646959ull;
+  static constexpr SP_HD uint32_t P(int i) {
+    constexpr uint32_t t[8] = {0xb1c4b117u, 0x93135661u, 0x30e73177u, 0x7e72b42bu, 0x00000001u, 0x00000000u, 0x00000001u, 0xffffffffu};
+    return t[i];
+  }
+  static constexpr SP_HD uint32_t R1(int i) {
+    constexpr uint32_t t[8] = {0x4e3b4ee9u, 0x6ceca99eu, 0xcf18ce88u, 0x818d4bd4u, 0xfffffffeu, 0xffffffffu, 0xfffffffeu, 0x00000000u};
+    return t[i];
+  }
+  static constexpr SP_HD uint32_t R2(int i) {
+    constexpr uint32_t t[8] = {0x910d33ecu, 0xbc7ba9fcu, 0x07eae97fu, 0xd8488344u, 0xa0ed6777u, 0x362b66e6u, 0x21d30291u, 0xa057002au};
+    return t[i];
+  }
+  static constexpr SP_HD uint32_t R3(int i) {
+    constexpr uint32_t t[8] = {0x56eb5134u, 0x67cff92eu, 0xd91eb940u, 0x4a49f97du, 0x0a676baeu, 0xb3d51283u, 0x79d924a0u, 0xcae090c9u};
+    return t[i];
+  }
+};
+
+// ---- basic predicates / constants -------------------------------------------------------------------
+SP_HD fe_t fe_zero() {
+  fe_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = 0;
+  return r;
+}
+template <class FP>
+SP_HD fe_t fe_one() {
+  fe_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = FP::R1(i);
+  return r;
+}
+SP_HD bool fe_is_zero(const fe_t& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o |= a.v[i];
+  return o == 0;
+}
+SP_HD bool fe_eq(const fe_t& a, const fe_t& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+  return o == 0;
+}
+
+// r = (carry:x) - p if (carry:x) >= p else x   (one conditional subtraction, branch-free)
+template <class FP>
+SP_HD fe_t fe_cond_sub_p(const uint32_t x[8], uint32_t carry) {
+  uint32_t d[8], bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = sp_subb(x[i], FP::P(i), bw);
+  // take the difference when the subtraction did not borrow past the carry word
+  bool take = carry >= bw;  // carry:x - p >= 0  <=>  carry - bw >= 0
+  fe_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = take ? d[i] : x[i];
+  return r;
+}
+
+// in-place variant tracking the word above 2^256: (top:x) -= p when (top:x) >= p
+template <class FP>
+SP_HD void fe_cond_sub_p_top(uint32_t x[8], uint32_t& top) {
+  uint32_t d[8], bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = sp_subb(x[i], FP::P(i), bw);
+  bool take = top >= bw;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = take ? d[i] : x[i];
+  top = take ? top - bw : top;
+}
+
+template <class FP>
+SP_HD fe_t fe_add(const fe_t& a, const fe_t& b) {
+  uint32_t s[8], c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = sp_addc(a.v[i], b.v[i], c);
+  return fe_cond_sub_p<FP>(s, c);
+}
+template <class FP>
+SP_HD fe_t fe_sub(const fe_t& a, const fe_t& b) {
+  uint32_t d[8], bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = sp_subb(a.v[i], b.v[i], bw);
+  uint32_t mask = 0u - bw, c = 0;
+  fe_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = sp_addc(d[i], FP::P(i) & mask, c);
+  return r;
+}
+template <class FP>
+SP_HD fe_t fe_neg(const fe_t& a) {
+  return fe_sub<FP>(fe_zero(), a);
+}
+template <class FP>
+SP_HD fe_t fe_dbl(const fe_t& a) {
+  return fe_add<FP>(a, a);
+}
+
+// ---- 256 x 256 -> 512 product -------------------------------------------------------------------------
+SP_HD void fe_mul_wide(uint32_t t[16], const fe_t& a, const fe_t& b) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = (uint64_t)a.v[j] * b.v[i] + t[i + j];  // v_mad_u64_u32, independent
+    uint32_t c = 0;
+    t[i] = (uint32_t)p[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t[i + j] = sp_addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c);
+    t[i + 8] = (uint32_t)(p[7] >> 32) + c;  // cannot overflow: row sum < 2^(32*9)
+  }
+}
+
+// ---- Montgomery reduction of a 512-bit value ------------------------------------------------------------
+// P-256 prime: quotient M solves M = T_lo + (M<<96) + (M<<192) - (M<<224) (mod 2^256); then
+// (T + M p) / 2^256 = T_hi + M - (M>>32) + (M>>64) + (M>>160) + k, k = signed carry-out of the M recurrence.
+// Output < 2^257; `extra_subs` conditional subtractions bring it to canonical form (1 for a single
+// product of canonical inputs, 2 for any 512-bit lazy sum).
+template <int EXTRA_SUBS>
+SP_HD fe_t fe_redc_p256(const uint32_t t[16]) {
+  uint32_t m[8];
+  m[0] = t[0];
+  m[1] = t[1];
+  m[2] = t[2];
+  uint32_t c = 0;
+  m[3] = sp_addc(t[3], m[0], c);
+  m[4] = sp_addc(t[4], m[1], c);
+  m[5] = sp_addc(t[5], m[2], c);
+  uint32_t x6 = sp_addc(t[6], m[3], c);
+  uint32_t x7 = sp_addc(t[7], m[4], c);
+  int32_t k = (int32_t)c;
+  c = 0;
+  x6 = sp_addc(x6, m[0], c);
+  x7 = sp_addc(x7, m[1], c);
+  k += (int32_t)c;
+  uint32_t bw = 0;
+  x7 = sp_subb(x7, m[0], bw);
+  k -= (int32_t)bw;
+  m[6] = x6;
+  m[7] = x7;
+  // r = T_hi + M            (top word tracked in `top`, signed)
+  uint32_t r[8];
+  int32_t top = k;
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = sp_addc(t[8 + i], m[i], c);
+  int32_t hi = (int32_t)c;
+  // r -= M >> 32
+  bw = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) r[i] = sp_subb(r[i], m[i + 1], bw);
+  r[7] = sp_subb(r[7], 0u, bw);
+  hi -= (int32_t)bw;
+  // r += M >> 64
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r[i] = sp_addc(r[i], m[i + 2], c);
+  r[6] = sp_addc(r[6], 0u, c);
+  r[7] = sp_addc(r[7], 0u, c);
+  hi += (int32_t)c;
+  // r += M >> 160
+  c = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r[i] = sp_addc(r[i], m[i + 5], c);
+#pragma unroll
+  for (int i = 3; i < 8; ++i) r[i] = sp_addc(r[i], 0u, c);
+  hi += (int32_t)c;
+  // r += k  (k in [-1, 2]): add the sign-extended constant
+  uint32_t kk = (uint32_t)top, ext = (uint32_t)(top >> 31);
+  c = 0;
+  r[0] = sp_addc(r[0], kk, c);
+#pragma unroll
+  for (int i = 1; i < 8; ++i) r[i] = sp_addc(r[i], ext, c);
+  hi += (int32_t)c + (int32_t)ext;  // ext is 0 or 0xffffffff == -1
+  uint32_t topw = (uint32_t)hi;  // value = topw * 2^256 + r, in [0, 2^257)
+#pragma unroll
+  for (int s = 0; s < EXTRA_SUBS; ++s) fe_cond_sub_p_top<FqP>(r, topw);
+  fe_t out;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out.v[i] = r[i];
+  return out;
+}
+
+// Generic word-serial Montgomery reduction (CIOS second half) for FpP: 8 rounds of m = t0 * INV32; t += m*p; t >>= 32.
+template <class FP>
+SP_HD fe_t fe_redc_generic(const uint32_t tin[16]) {
+  uint32_t t[17];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = tin[i];
+  t[16] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t m = t[i] * FP::INV32;
+    uint64_t p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = (uint64_t)m * FP::P(j) + t[i + j];
+    uint32_t c = 0;
+    // t[i] becomes 0; carry the high halves up
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t[i + j] = sp_addc((uint32_t)p[j], (uint32_t)(p[j - 1] >> 32), c);
+    t[i + 8] = sp_addc(t[i + 8], (uint32_t)(p[7] >> 32), c);
+#pragma unroll
+    for (int j = i + 9; j < 17; ++j) t[j] = sp_addc(t[j], 0u, c);
+  }
+  return fe_cond_sub_p<FP>(t + 8, t[16]);
+}
+
+template <class FP>
+SP_HD fe_t fe_redc(const uint32_t t[16]) {
+  if constexpr (FP::P256_PRIME) {
+    return fe_redc_p256<1>(t);
+  } else {
+    return fe_redc_generic<FP>(t);
+  }
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host-side product for the O(1) protocol glue (claims, UniPoly, inversions): 4 x u64 CIOS with __int128.
+// Same canonical results as the device path; never used inside a kernel.
+template <class FP>
+inline fe_t fe_mul_host64(const fe_t& a, const fe_t& b) {
+  typedef unsigned __int128 u128;
+  uint64_t A[4], B[4], Pm[4], t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+    B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+    Pm[i] = (uint64_t)FP::P(2 * i) | ((uint64_t)FP::P(2 * i + 1) << 32);
+  }
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) {
+      c += (u128)A[j] * B[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * FP::INV64;
+    c = ((u128)m * Pm[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; ++j) {
+      c += (u128)m * Pm[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  // conditional subtraction
+  uint64_t d[4];
+  unsigned __int128 bw = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 x = (u128)t[i] - Pm[i] - (uint64_t)bw;
+    d[i] = (uint64_t)x;
+    bw = (x >> 64) & 1;
+  }
+  bool take = t[4] >= (uint64_t)bw;
+  fe_t r;
+  for (int i = 0; i < 4; ++i) {
+    uint64_t w = take ? d[i] : t[i];
+    r.v[2 * i] = (uint32_t)w;
+    r.v[2 * i + 1] = (uint32_t)(w >> 32);
+  }
+  return r;
+}
+#endif
+
+template <class FP>
+SP_HD fe_t fe_mul(const fe_t& a, const fe_t& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return fe_mul_host64<FP>(a, b);
+#else
+  uint32_t t[16];
+  fe_mul_wide(t, a, b);
+  return fe_redc<FP>(t);
+#endif
+}
+// the 32-bit-limb device algorithm, callable on the host too (unit tests exercise it without a GPU)
+template <class FP>
+SP_HD fe_t fe_mul_limb32(const fe_t& a, const fe_t& b) {
+  uint32_t t[16];
+  fe_mul_wide(t, a, b);
+  return fe_redc<FP>(t);
+}
+template <class FP>
+SP_HD fe_t fe_sqr(const fe_t& a) {
+  return fe_mul<FP>(a, a);
+}
+
+// ---- conversions / host-side helpers (O(1) glue; never in a kernel's inner loop) -----------------------
+template <class FP>
+SP_HD fe_t fe_from_canonical(const fe_t& c) {
+  fe_t r2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r2.v[i] = FP::R2(i);
+  return fe_mul<FP>(c, r2);
+}
+template <class FP>
+SP_HD fe_t fe_to_canonical(const fe_t& a) {
+  fe_t one = fe_zero();
+  one.v[0] = 1;
+  return fe_mul<FP>(a, one);
+}
+template <class FP>
+SP_HD fe_t fe_from_u64(uint64_t x) {
+  fe_t c = fe_zero();
+  c.v[0] = (uint32_t)x;
+  c.v[1] = (uint32_t)(x >> 32);
+  return fe_from_canonical<FP>(c);
+}
+template <class FP>
+SP_HD fe_t fe_from_i64(int64_t x) {
+  if (x >= 0) return fe_from_u64<FP>((uint64_t)x);
+  return fe_neg<FP>(fe_from_u64<FP>((uint64_t)(-(x + 1)) + 1));
+}
+// halo2curves from_uniform_bytes (src/provider/traits.rs:275-280): 64 bytes LE mod p
+template <class FP>
+SP_HD fe_t fe_from_uniform(const uint8_t* b64) {
+  fe_t lo, hi, r2, r3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    lo.v[i] = (uint32_t)b64[4 * i] | ((uint32_t)b64[4 * i + 1] << 8) | ((uint32_t)b64[4 * i + 2] << 16) | ((uint32_t)b64[4 * i + 3] << 24);
+    hi.v[i] = (uint32_t)b64[32 + 4 * i] | ((uint32_t)b64[32 + 4 * i + 1] << 8) | ((uint32_t)b64[32 + 4 * i + 2] << 16) | ((uint32_t)b64[32 + 4 * i + 3] << 24);
+    r2.v[i] = FP::R2(i);
+    r3.v[i] = FP::R3(i);
+  }
+  // lo / hi may be >= p: the Montgomery product still reduces correctly (inputs < 2^256, output canonical after
+  // the conditional subtraction because lo*R2 < 2^256 * p).
+  return fe_add<FP>(fe_mul<FP>(lo, r2), fe_mul<FP>(hi, r3));
+}
+// x^e, e given as canonical limbs (not a hot-path op)
+template <class FP>
+SP_HD fe_t fe_pow(const fe_t& x, const uint32_t e[8]) {
+  fe_t acc = fe_one<FP>();
+  for (int i = 255; i >= 0; --i) {
+    acc = fe_sqr<FP>(acc);
+    if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul<FP>(acc, x);
+  }
+  return acc;
+}
+template <class FP>
+SP_HD fe_t fe_inv(const fe_t& x) {  // Fermat; inv(0) == 0
+  uint32_t e[8], bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = sp_subb(FP::P(i), i == 0 ? 2u : 0u, bw);
+  return fe_pow<FP>(x, e);
+}

@@ -1,0 +1,154 @@
+// Keccak-f[1600] / Keccak-256 and the Fiat-Shamir transcript of the reference
+// (src/provider/keccak.rs:18-105) for the product path. __host__ __device__ so the same sponge can run in a
+// single-wave device kernel (SURVEY.md kernel K15) as well as in the host-side round loop.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "field.cuh"
+
+namespace sp {
+
+SP_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// Plane-per-plane formulation (theta, then rho+pi into a second state, then chi+iota).
+SP_HD void keccak_permute(uint64_t a[25]) {
+  constexpr uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+                               0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+                               0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+                               0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                               0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  // rotation offsets r[x][y] indexed as [x + 5*y]
+  constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  for (int rnd = 0; rnd < 24; ++rnd) {
+    uint64_t c[5], d[5], b[25];
+    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+    for (int x = 0; x < 5; ++x) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+    for (int y = 0; y < 5; ++y)
+      for (int x = 0; x < 5; ++x) {
+        uint64_t v = a[x + 5 * y] ^ d[x];
+        int r = RHO[x + 5 * y];
+        // pi: B[y][2x+3y] = rot(A[x][y])
+        b[y + 5 * ((2 * x + 3 * y) % 5)] = r ? rotl64(v, r) : v;
+      }
+    for (int y = 0; y < 5; ++y)
+      for (int x = 0; x < 5; ++x) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+    a[0] ^= RC[rnd];
+  }
+}
+
+// Incremental Keccak-256 (rate 136, pad 0x01 .. 0x80 — the pre-NIST padding sha3::Keccak256 uses).
+struct Keccak256State {
+  uint64_t a[25];
+  uint8_t buf[136];
+  uint32_t fill;
+  SP_HD void init() {
+    for (int i = 0; i < 25; ++i) a[i] = 0;
+    fill = 0;
+  }
+  SP_HD void block() {
+    for (int i = 0; i < 17; ++i) {
+      uint64_t w = 0;
+      for (int k = 0; k < 8; ++k) w |= (uint64_t)buf[8 * i + k] << (8 * k);
+      a[i] ^= w;
+    }
+    keccak_permute(a);
+    fill = 0;
+  }
+  SP_HD void update(const uint8_t* p, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+      buf[fill++] = p[i];
+      if (fill == 136) block();
+    }
+  }
+  SP_HD void finish(uint8_t out[32]) {
+    for (uint32_t i = fill; i < 136; ++i) buf[i] = 0;
+    buf[fill] ^= 0x01;
+    buf[135] ^= 0x80;
+    block();
+    for (int i = 0; i < 32; ++i) out[i] = (uint8_t)(a[i >> 3] >> (8 * (i & 7)));
+  }
+};
+
+// Keccak256Transcript<E> (src/provider/keccak.rs:26-105)
+struct Transcript {
+  uint16_t round;
+  uint8_t state[64];
+  Keccak256State h;
+
+  // compute_updated_state (keccak.rs:33-54): Keccak(running || input || 0) || Keccak(running || input || 1)
+  SP_HD static void updated_state(Keccak256State base, const uint8_t* in, size_t n, uint8_t out[64]) {
+    base.update(in, n);
+    Keccak256State lo = base, hi = base;
+    const uint8_t z = 0, o = 1;
+    lo.update(&z, 1);
+    hi.update(&o, 1);
+    lo.finish(out);
+    hi.finish(out + 32);
+  }
+  SP_HD void init(const uint8_t* label, size_t n) {  // new (keccak.rs:57-68): state = f("NoTR" || label)
+    Keccak256State k;
+    k.init();
+    const uint8_t tag[4] = {'N', 'o', 'T', 'R'};
+    k.update(tag, 4);
+    updated_state(k, label, n, state);
+    round = 0;
+    h.init();
+  }
+  SP_HD void absorb(const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n) {  // keccak.rs:96-99
+    h.update(label, ln);
+    h.update(bytes, n);
+  }
+  SP_HD void dom_sep(const uint8_t* bytes, size_t n) {  // keccak.rs:101-104
+    const uint8_t tag[4] = {'N', 'o', 'D', 'S'};
+    h.update(tag, 4);
+    h.update(bytes, n);
+  }
+  // squeeze (keccak.rs:70-94). Returns false on round-counter overflow (InternalTranscriptError).
+  SP_HD bool squeeze_bytes(const uint8_t* label, size_t ln, uint8_t out[64]) {
+    Keccak256State k = h;
+    const uint8_t hdr[6] = {'N', 'o', 'D', 'S', (uint8_t)(round & 0xff), (uint8_t)(round >> 8)};
+    k.update(hdr, 6);
+    k.update(state, 64);
+    updated_state(k, label, ln, out);
+    if (round == 0xffff) return false;
+    round = (uint16_t)(round + 1);
+    for (int i = 0; i < 64; ++i) state[i] = out[i];
+    h.init();
+    return true;
+  }
+  template <class FP>
+  SP_HD bool squeeze(const uint8_t* label, size_t ln, fe_t* out) {
+    uint8_t b[64];
+    if (!squeeze_bytes(label, ln, b)) return false;
+    *out = fe_from_uniform<FP>(b);  // PrimeFieldExt::from_uniform (src/provider/traits.rs:275-280)
+    return true;
+  }
+};
+
+// scalar -> transcript bytes: to_repr reversed, i.e. big-endian canonical (src/provider/traits.rs:282-286)
+template <class FP>
+SP_HD void fe_to_be_bytes(const fe_t& a, uint8_t out[32]) {
+  fe_t c = fe_to_canonical<FP>(a);
+  for (int i = 0; i < 8; ++i) {
+    uint32_t w = c.v[7 - i];
+    out[4 * i] = (uint8_t)(w >> 24);
+    out[4 * i + 1] = (uint8_t)(w >> 16);
+    out[4 * i + 2] = (uint8_t)(w >> 8);
+    out[4 * i + 3] = (uint8_t)w;
+  }
+}
+// to_repr(): little-endian canonical (UniPoly coefficients enter the transcript this way, src/polys/univariate.rs:182-190)
+template <class FP>
+SP_HD void fe_to_le_bytes(const fe_t& a, uint8_t out[32]) {
+  fe_t c = fe_to_canonical<FP>(a);
+  for (int i = 0; i < 8; ++i) {
+    uint32_t w = c.v[i];
+    out[4 * i] = (uint8_t)w;
+    out[4 * i + 1] = (uint8_t)(w >> 8);
+    out[4 * i + 2] = (uint8_t)(w >> 16);
+    out[4 * i + 3] = (uint8_t)(w >> 24);
+  }
+}
+
+}  // namespace sp

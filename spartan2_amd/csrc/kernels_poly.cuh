@@ -1,0 +1,206 @@
+// HIP kernels for the multilinear-table side of the sum-check (gfx950, wave64).
+//   k_bind_top      K1  MultilinearPolynomial::bind_poly_var_top        src/polys/multilinear.rs:95-164
+//   k_eval_cubic    K2  EqSumCheckInstance::evaluation_points_cubic...   src/sumcheck.rs:1025-1156 (+ t(-1) of :1327-1396)
+//   k_eval_quad     K3  compute_eval_points_quad                         src/sumcheck.rs:128-174
+//   k_eq_levels/k_eq_outer  K8  EqPolynomial::evals_from_points, EqSumCheckInstance::new tables  src/polys/eq.rs:59-117, src/sumcheck.rs:956-992
+//   k_sum_partials       second stage of every block-partial reduction
+// All arithmetic is 256-bit modular integer work on VALU (v_mad_u64_u32 + carry chains); there is no MFMA
+// anywhere. Tables are arrays of 32-byte elements; lane l touches element base+l, so a wave reads/writes
+// 2 KiB contiguous per table access (two dwordx4 per lane).
+#pragma once
+#include "field.cuh"
+
+namespace spk {
+
+typedef FqP S;  // scalar field of the bench engine
+
+__device__ __forceinline__ fe_t shfl_xor_fe(const fe_t& a, int mask) {
+  fe_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = __shfl_xor(a.v[i], mask, 64);
+  return r;
+}
+__device__ __forceinline__ fe_t wave_sum(fe_t a) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a = fe_add<S>(a, shfl_xor_fe(a, m));
+  return a;
+}
+// Sum NACC accumulators over a 256-thread block; result valid in thread 0. smem: NACC * 4 elements.
+template <int NACC>
+__device__ __forceinline__ void block_sum(fe_t (&acc)[NACC], fe_t* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) smem[k * 4 + wave] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      fe_t s = smem[k * 4];
+      for (int w = 1; w < nwaves; ++w) s = fe_add<S>(s, smem[k * 4 + w]);
+      acc[k] = s;
+    }
+  }
+}
+
+// ---- K1: bind the top variable of up to 4 tables with the same challenge -----------------------------------
+struct BindArgs {
+  fe_t* z[4];
+  unsigned long long n[4];   // half length of each table
+  unsigned long long lo[4];  // min(lo_eff, n)
+  unsigned long long hi[4];  // min(hi_eff, n)
+  fe_t r;
+  fe_t one_minus_r;
+};
+// grid = (blocks, ntables). In place: thread i reads Z[i], Z[n+i], writes Z[i].
+__global__ void __launch_bounds__(256) k_bind_top(BindArgs a) {
+  const int t = blockIdx.y;
+  fe_t* __restrict__ Z = a.z[t];
+  const unsigned long long n = a.n[t], lo = a.lo[t], hi = a.hi[t];
+  const unsigned long long eff = lo > hi ? lo : hi;
+  const unsigned long long both = lo < hi ? lo : hi;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < eff; i += (unsigned long long)gridDim.x * blockDim.x) {
+    fe_t out;
+    if (i < both) {  // a + r (b - a)
+      fe_t lo_v = Z[i], hi_v = Z[n + i];
+      out = fe_add<S>(lo_v, fe_mul<S>(a.r, fe_sub<S>(hi_v, lo_v)));
+    } else if (i < lo) {  // high half known zero: a (1 - r)
+      out = fe_mul<S>(Z[i], a.one_minus_r);
+    } else {  // low half known zero: r b
+      out = fe_mul<S>(a.r, Z[n + i]);
+    }
+    Z[i] = out;
+  }
+}
+
+// ---- K8: eq tables -------------------------------------------------------------------------------------------
+// One block builds every prefix level of the eq table over v[0..m): level k (2^k entries, at out + 2^k - 1 ... see
+// level_offset) is the table over the LAST k variables, with the earliest of them on the index MSB
+// (compute_eq_polynomials, src/sumcheck.rs:960-979; EqPolynomial::evals_from_points, src/polys/eq.rs:66-76).
+__host__ __device__ __forceinline__ size_t eq_level_offset(int k) { return ((size_t)1 << k) - 1; }
+__global__ void __launch_bounds__(1024) k_eq_levels(const fe_t* __restrict__ v, int m, fe_t* __restrict__ out) {
+  if (threadIdx.x == 0) out[0] = fe_one<S>();
+  __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    const fe_t r = v[m - 1 - k];
+    const fe_t* prev = out + eq_level_offset(k);
+    fe_t* next = out + eq_level_offset(k + 1);
+    const size_t size = (size_t)1 << k;
+    for (size_t i = threadIdx.x; i < size; i += blockDim.x) {
+      fe_t e = prev[i];
+      fe_t y = fe_mul<S>(e, r);
+      next[size + i] = y;
+      next[i] = fe_sub<S>(e, y);
+    }
+    __syncthreads();
+  }
+}
+// out[(hi << lo_bits) | lo] = T_hi[hi] * T_lo[lo]
+__global__ void __launch_bounds__(256) k_eq_outer(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int lo_bits, size_t total,
+                                                  fe_t* __restrict__ out) {
+  const size_t mask = ((size_t)1 << lo_bits) - 1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = fe_mul<S>(t_hi[i >> lo_bits], t_lo[i & mask]);
+}
+
+// ---- K2: cubic evaluation sums with split-eq weights ------------------------------------------------------------
+// For pair index id in [0, half): weight E(id) = eq_out[id >> s] * eq_in[id & (2^s - 1)].
+//   t0   = sum E (A0 B0 - C0)
+//   tinf = sum E (A1 - A0)(B1 - B0)
+//   tm1  = sum E ((2A0 - A1)(2B0 - B1) - (2C0 - C1))      [only when WITH_M1: the tau == 0 fallback]
+// MODE 0: one table, E = eq_in[id]                       (second-half rounds, src/sumcheck.rs:1107-1147)
+// MODE 1: factored — a block's chunk lies inside one x_out, block sum is multiplied by eq_out once
+// MODE 2: direct — per-pair product eq_out * eq_in (tiny tables where a chunk spans several x_out)
+constexpr int EVAL_PPT = 4;  // pairs per thread
+template <int MODE, bool WITH_M1>
+__global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
+                                                    const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
+                                                    fe_t* __restrict__ partials) {
+  constexpr int NACC = WITH_M1 ? 3 : 2;
+  __shared__ fe_t smem[NACC * 4];
+  const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
+  const size_t base = (size_t)blockIdx.x * chunk;
+  const size_t mask = ((size_t)1 << s) - 1;
+  fe_t acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = fe_zero();
+#pragma unroll 1
+  for (int k = 0; k < EVAL_PPT; ++k) {
+    const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
+    if (id < half) {
+      const fe_t a0 = A[id], a1 = A[id + half], b0 = B[id], b1 = B[id + half], c0 = C[id];
+      fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
+      if (MODE == 2) w = fe_mul<S>(w, eq_out[id >> s]);
+      const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+      const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+      acc[0] = fe_add<S>(acc[0], fe_mul<S>(w, t0e));
+      acc[1] = fe_add<S>(acc[1], fe_mul<S>(w, tie));
+      if (WITH_M1) {
+        const fe_t c1 = C[id + half];
+        const fe_t ma = fe_sub<S>(fe_dbl<S>(a0), a1), mb = fe_sub<S>(fe_dbl<S>(b0), b1), mc = fe_sub<S>(fe_dbl<S>(c0), c1);
+        acc[NACC - 1] = fe_add<S>(acc[NACC - 1], fe_mul<S>(w, fe_sub<S>(fe_mul<S>(ma, mb), mc)));
+      }
+    }
+  }
+  block_sum<NACC>(acc, smem);
+  if (threadIdx.x == 0) {
+    if (MODE == 1) {
+      const fe_t eo = eq_out[base >> s];
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] = fe_mul<S>(acc[k], eo);
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) partials[(size_t)blockIdx.x * NACC + k] = acc[k];
+  }
+}
+
+// ---- K3: quadratic evaluation sums ---------------------------------------------------------------------------------
+//   eval0 = sum_{i < len} A0 B0 ; tinf = sum_{i < len} (A1 - A0)(B1 - B0), len = min(eff_pairs(A), eff_pairs(B), half)
+__global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t len,
+                                                   fe_t* __restrict__ partials) {
+  __shared__ fe_t smem[2 * 4];
+  const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
+  const size_t base = (size_t)blockIdx.x * chunk;
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+#pragma unroll 1
+  for (int k = 0; k < EVAL_PPT; ++k) {
+    const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
+    if (id < len) {
+      const fe_t a0 = A[id], a1 = A[id + half], b0 = B[id], b1 = B[id + half];
+      acc[0] = fe_add<S>(acc[0], fe_mul<S>(a0, b0));
+      acc[1] = fe_add<S>(acc[1], fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)));
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    partials[(size_t)blockIdx.x * 2] = acc[0];
+    partials[(size_t)blockIdx.x * 2 + 1] = acc[1];
+  }
+}
+
+// dot product of the first n elements (value of DelayedReduction::reduce(sum a_i b_i))
+__global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t n, fe_t* __restrict__ partials) {
+  __shared__ fe_t smem[4];
+  fe_t acc[1] = {fe_zero()};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc[0] = fe_add<S>(acc[0], fe_mul<S>(A[i], B[i]));
+  block_sum<1>(acc, smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+
+// out[k] = sum_b partials[b * nacc + k]; one block
+__global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ partials, size_t nblocks, int nacc, fe_t* __restrict__ out) {
+  __shared__ fe_t smem[4];
+  for (int k = 0; k < nacc; ++k) {
+    fe_t acc[1] = {fe_zero()};
+    for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc[0] = fe_add<S>(acc[0], partials[b * nacc + k]);
+    block_sum<1>(acc, smem);
+    if (threadIdx.x == 0) out[k] = acc[0];
+    __syncthreads();
+  }
+}
+
+}  // namespace spk

@@ -1,0 +1,221 @@
+"""ctypes loader for libspartan_hip.so (include/spartan_hip.h). Harness glue only: tests and bench.py use it
+to call the C ABI exactly as a Rust `extern "C"` block would. There is no fallback: if the
+library is missing or no gfx950 device is present, calls raise.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_PKG)
+LIB_DIR = os.path.join(_PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libspartan_hip.so")
+HEADER = os.path.join(ROOT, "include", "spartan_hip.h")
+
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+SIZE_MAX = (1 << 64) - 1
+
+
+def build(jobs: int = 8):
+    env = dict(os.environ)
+    subprocess.check_call(["make", "-s", "-j", str(jobs), "-C", os.path.join(_PKG, "csrc")], env=env)
+
+
+def declared_symbols():
+    """Every function name declared in include/spartan_hip.h."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.sp_last_error.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+class SpartanHipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise SpartanHipError(f"rc={rc}: {lib().sp_last_error().decode()}")
+
+
+def p64(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(c_u64p)
+
+
+def p8(a):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_u8p)
+
+
+def _bytes(b: bytes):
+    arr = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(1, dtype=np.uint8)
+    return arr, ctypes.c_size_t(len(b))
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.h = ctypes.c_void_p()
+        check(lib().sp_ctx_create(int(device), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().sp_ctx_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def synchronize(self):
+        check(lib().sp_ctx_synchronize(self.h))
+
+    def reset_stats(self, enable=True):
+        check(lib().sp_ctx_reset_stats(self.h, int(enable)))
+
+    def kernel_stats(self, what: str):
+        ms = ctypes.c_double()
+        n = ctypes.c_uint64()
+        b = ctypes.c_uint64()
+        check(lib().sp_ctx_kernel_stats(self.h, what.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(b)))
+        return ms.value, n.value, b.value
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Table:
+    """MultilinearPolynomial resident in HBM (src/polys/multilinear.rs:34-44)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    @classmethod
+    def from_host(cls, ctx, z: np.ndarray, lo_eff=SIZE_MAX, hi_eff=SIZE_MAX):
+        z = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 4)
+        h = ctypes.c_void_p()
+        check(lib().sp_table_from_host(ctx.h, p64(z), ctypes.c_size_t(z.shape[0]), ctypes.c_size_t(lo_eff), ctypes.c_size_t(hi_eff), ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def zeros(cls, ctx, n, lo_eff=SIZE_MAX, hi_eff=SIZE_MAX):
+        h = ctypes.c_void_p()
+        check(lib().sp_table_zeros(ctx.h, ctypes.c_size_t(n), ctypes.c_size_t(lo_eff), ctypes.c_size_t(hi_eff), ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def eq(cls, ctx, r: np.ndarray):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        h = ctypes.c_void_p()
+        check(lib().sp_eq_table(ctx.h, p64(r) if r.shape[0] else None, ctypes.c_size_t(r.shape[0]), ctypes.byref(h)))
+        return cls(ctx, h)
+
+    def info(self):
+        n, lo, hi = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        check(lib().sp_table_info(self.h, ctypes.byref(n), ctypes.byref(lo), ctypes.byref(hi)))
+        return n.value, lo.value, hi.value
+
+    def __len__(self):
+        return self.info()[0]
+
+    def read(self, off=0, cnt=None):
+        if cnt is None:
+            cnt = len(self) - off
+        out = np.zeros((cnt, 4), dtype=np.uint64)
+        check(lib().sp_table_read(self.ctx.h, self.h, ctypes.c_size_t(off), ctypes.c_size_t(cnt), p64(out)))
+        return out
+
+    def write(self, off, z):
+        z = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 4)
+        check(lib().sp_table_write(self.ctx.h, self.h, ctypes.c_size_t(off), p64(z), ctypes.c_size_t(z.shape[0])))
+
+    def bind_top(self, r):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        check(lib().sp_table_bind_top(self.ctx.h, self.h, p64(r)))
+
+    def free(self):
+        if self.h:
+            lib().sp_table_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Transcript:
+    """Keccak256Transcript (src/provider/keccak.rs:26-105)."""
+
+    def __init__(self, ctx, label: bytes):
+        self.h = ctypes.c_void_p()
+        a, n = _bytes(label)
+        check(lib().sp_transcript_new(ctx.h if ctx else None, p8(a), n, ctypes.byref(self.h)))
+
+    def absorb(self, label: bytes, data: bytes):
+        la, ln = _bytes(label)
+        da, dn = _bytes(data)
+        check(lib().sp_transcript_absorb(self.h, p8(la), ln, p8(da), dn))
+
+    def dom_sep(self, data: bytes):
+        da, dn = _bytes(data)
+        check(lib().sp_transcript_dom_sep(self.h, p8(da), dn))
+
+    def squeeze(self, label: bytes):
+        la, ln = _bytes(label)
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib().sp_transcript_squeeze(self.h, p8(la), ln, p64(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().sp_transcript_free(self.h)
+        except Exception:
+            pass
+
+
+def sumcheck_cubic3(ctx, claim, taus, A: Table, B: Table, C: Table, tr: Transcript):
+    """SumcheckProof::prove_cubic_with_three_inputs (src/sumcheck.rs:502-571)."""
+    taus = np.ascontiguousarray(taus, dtype=np.uint64).reshape(-1, 4)
+    ell = taus.shape[0]
+    claim = np.ascontiguousarray(claim, dtype=np.uint64).reshape(4)
+    polys = np.zeros((ell, 3, 4), dtype=np.uint64)
+    r = np.zeros((ell, 4), dtype=np.uint64)
+    fin = np.zeros((3, 4), dtype=np.uint64)
+    check(lib().sp_sumcheck_cubic3(ctx.h, p64(claim), p64(taus), ctypes.c_size_t(ell), A.h, B.h, C.h, tr.h, p64(polys), p64(r), p64(fin)))
+    return polys, r, fin
+
+
+def sumcheck_quad(ctx, claim, rounds, A: Table, B: Table, tr: Transcript):
+    """SumcheckProof::prove_quad (src/sumcheck.rs:190-247)."""
+    claim = np.ascontiguousarray(claim, dtype=np.uint64).reshape(4)
+    polys = np.zeros((rounds, 2, 4), dtype=np.uint64)
+    r = np.zeros((rounds, 4), dtype=np.uint64)
+    fin = np.zeros((2, 4), dtype=np.uint64)
+    check(lib().sp_sumcheck_quad(ctx.h, p64(claim), ctypes.c_size_t(rounds), A.h, B.h, tr.h, p64(polys), p64(r), p64(fin)))
+    return polys, r, fin
+
+
+def table_dot(ctx, a: Table, b: Table, n: int):
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib().sp_table_dot(ctx.h, a.h, b.h, ctypes.c_size_t(n), p64(out)))
+    return out
