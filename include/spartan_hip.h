@@ -56,6 +56,8 @@ int sp_table_from_host(sp_ctx* ctx, const uint64_t* z, size_t len, size_t lo_eff
 int sp_table_zeros(sp_ctx* ctx, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out);
 /* host -> device write of cnt elements at element offset off */
 int sp_table_write(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* z, size_t cnt);
+/* zero cnt elements starting at element offset off (device memset) */
+int sp_table_zero(sp_ctx* ctx, sp_table* t, size_t off, size_t cnt);
 /* device -> device copy */
 int sp_table_copy(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt);
 /* Index / into_vec (:166-173, :87-89) */
@@ -67,6 +69,8 @@ void sp_table_free(sp_table* t);
 int sp_table_bind_top(sp_ctx* ctx, sp_table* t, const uint64_t r[4]);
 /* EqPolynomial::evals_from_points[_into] (src/polys/eq.rs:59-117): table of 2^ell evaluations, r[0] on the index MSB */
 int sp_eq_table(sp_ctx* ctx, const uint64_t* r, size_t ell, sp_table** out);
+/* the `_into` form (src/polys/eq.rs:96-117) reusing an existing allocation of at least 2^ell elements */
+int sp_eq_table_into(sp_ctx* ctx, const uint64_t* r, size_t ell, sp_table* out);
 
 /* ---- Keccak256Transcript (src/provider/keccak.rs:18-105, trait src/traits/transcript.rs:21-33) ----- */
 int sp_transcript_new(sp_ctx* ctx, const uint8_t* label, size_t n, sp_transcript** out);
@@ -131,8 +135,12 @@ int sp_hyrax_commit(sp_ctx* ctx, const sp_ck* ck, const sp_table* v, size_t off,
 int sp_fixed_base_mul_h(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t* out_aff);
 /* bind_with_delayed (:38-54): out[i] = sum_j L[j] * poly[j*cols + i]; out has `cols` F on the host */
 int sp_rowmat_vec(sp_ctx* ctx, const sp_table* poly, size_t rows, size_t cols, const uint64_t* L, uint64_t* out);
-/* MSM of host scalars against the first n bases of a device-resident key (hyrax_pc.rs:454-455, ipa.rs:147) */
-int sp_msm_ck(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t out_aff[8]);
+/* vartime_multiscalar_mul(scalars, ck[..n]) + h * blind against a device-resident key (hyrax_pc.rs:454-455, ipa.rs:147);
+ * blind may be NULL for the bare MSM */
+int sp_msm_ck(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t* blind, uint64_t out_aff[8]);
+/* PCS::commit for keys of width <= 64, where the reference uses per-base FixedBaseMul tables (hyrax_pc.rs:221-260,
+ * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
+int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,23 @@ int sp_ctx::ensure_scratch(size_t elems) {
   scratch_elems = elems;
   return SP_OK;
 }
+void* sp_ctx::workspace(int slot, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (bytes <= ws_bytes[slot]) return ws_ptr[slot];
+  if (ws_ptr[slot]) {
+    hipStreamSynchronize(stream);
+    hipFree(ws_ptr[slot]);
+    ws_ptr[slot] = nullptr;
+    ws_bytes[slot] = 0;
+  }
+  size_t want = bytes + bytes / 4;
+  if (hipMalloc(&ws_ptr[slot], want) != hipSuccess) {
+    sp::set_error("hipMalloc failed for a workspace buffer");
+    return nullptr;
+  }
+  ws_bytes[slot] = want;
+  return ws_ptr[slot];
+}
 void sp_ctx::drain_stats() {
   for (auto& kv : stats) {
     for (auto& pr : kv.second.pending) {
@@ -103,6 +120,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   c->drain_stats();
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
   if (c->d_scratch) hipFree(c->d_scratch);
+  for (int i = 0; i < sp_ctx::WS_SLOTS; ++i)
+    if (c->ws_ptr[i]) hipFree(c->ws_ptr[i]);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -159,6 +178,11 @@ int sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, size_t
   if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write: range exceeds the table");
   if (cnt) SP_HIP(hipMemcpyAsync(t->d + off, z, cnt * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
   SP_HIP(hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the duration of the call
+  return SP_OK;
+}
+int sp_table_zero(sp_ctx* c, sp_table* t, size_t off, size_t cnt) {
+  if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_zero: range exceeds the table");
+  if (cnt) SP_HIP(hipMemsetAsync(t->d + off, 0, cnt * sizeof(fe_t), c->stream));
   return SP_OK;
 }
 int sp_table_copy(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt) {
@@ -300,11 +324,26 @@ int sp_table_bind_top(sp_ctx* c, sp_table* t, const uint64_t r[4]) {
 }
 
 int sp_eq_table(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
-  if (ell > 40) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table: ell too large");
+  if (ell > 30) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table: ell too large");
   sp_table* t;
-  size_t total = (size_t)1 << ell;
-  int rc = sp::alloc_table(c, total, &t);
+  int rc = sp::alloc_table(c, (size_t)1 << ell, &t);
   if (rc) return rc;
+  rc = sp_eq_table_into(c, r, ell, t);
+  if (rc) {
+    sp_table_free(t);
+    return rc;
+  }
+  *out = t;
+  return SP_OK;
+}
+
+int sp_eq_table_into(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
+  if (ell > 30) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table: ell too large");
+  size_t total = (size_t)1 << ell;
+  if (t->cap < total) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table_into: table too short");
+  t->len = total;
+  t->lo_eff = t->hi_eff = (size_t)-1;
+  int rc;
   // split the variables: low part <= 10 bits built by one block, high part likewise (ell <= 20), else recursive outer products
   int lo_bits = (int)(ell > 10 ? 10 : ell), hi_bits = (int)ell - lo_bits;
   if (hi_bits > 10) {  // > 2^20 entries: build the low 2^20 by outer product first, then widen once more
@@ -344,7 +383,6 @@ int sp_eq_table(sp_ctx* c, const uint64_t* r, size_t ell, sp_table** out) {
     hipLaunchKernelGGL(spk::k_eq_outer, dim3(8192), dim3(256), 0, c->stream, d_hi + spk::eq_level_offset(hi_bits), d_lowbig, lo_bits, total, t->d);
   }
   SP_HIP(hipStreamSynchronize(c->stream));  // r is a borrowed host buffer
-  *out = t;
   return SP_OK;
 }
 

@@ -1,0 +1,341 @@
+// libspartan_hip.so — R1CS sparse kernels and entry points of include/spartan_hip.h.
+//   k_spmv3     K5/K6  PrecomputedSparseMatrix::multiply_vec (src/r1cs/sparse.rs:194-233) for A, B, C in one launch, and
+//                      multiply_vec_incremental_into (src/r1cs/mod.rs:1170-1211) = cached + filtered rows (sparse.rs:305-380)
+//   k_polyabc*  K7     bind_and_prepare_poly_ABC / accumulate_rows (src/r1cs/mod.rs:1235-1398) as a column-major GATHER
+//                      (no 256-bit atomics): short columns one lane each, long columns (the constant-1 column of the
+//                      booleanity rows) one block each.
+// Entries keep the reference's classes: +-1 and |k| in 2..7 as an int8 code (add / sub / double-add chains, sparse.rs:137-155),
+// everything else as a full field coefficient.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "core.hpp"
+#include "device_utils.cuh"
+
+using sp::fail;
+typedef FqP S;
+
+namespace spk {
+
+struct SplitDev {          // major-ordered sparse structure, entries split by coefficient class
+  const unsigned* sptr;    // [n_major + 1] small-class offsets
+  const unsigned* sidx;    // minor index of each small-class entry
+  const signed char* scode;  // +-1 .. +-7
+  const unsigned* gptr;    // [n_major + 1] general-class offsets
+  const unsigned* gidx;
+  const fe_t* gval;
+};
+
+__device__ __forceinline__ fe_t small_mul(int code, const fe_t& x) {  // sparse.rs:137-155
+  const int a = code < 0 ? -code : code;
+  fe_t r;
+  switch (a) {
+    case 1: r = x; break;
+    case 2: r = fe_dbl<S>(x); break;
+    case 3: r = fe_add<S>(fe_dbl<S>(x), x); break;
+    case 4: r = fe_dbl<S>(fe_dbl<S>(x)); break;
+    case 5: r = fe_add<S>(fe_dbl<S>(fe_dbl<S>(x)), x); break;
+    case 6: { fe_t d = fe_dbl<S>(x); r = fe_add<S>(fe_dbl<S>(d), d); break; }
+    default: { fe_t d = fe_dbl<S>(x); r = fe_add<S>(fe_add<S>(fe_dbl<S>(d), d), x); break; }
+  }
+  return r;
+}
+__device__ __forceinline__ fe_t acc_small(const fe_t& acc, int code, const fe_t& x) {
+  if (code == 1) return fe_add<S>(acc, x);
+  if (code == -1) return fe_sub<S>(acc, x);
+  fe_t m = small_mul(code, x);
+  return code < 0 ? fe_sub<S>(acc, m) : fe_add<S>(acc, m);
+}
+// sum over the entries of one major index, strided (first, step) so a block can share a long list
+__device__ __forceinline__ fe_t gather_major(const SplitDev& m, size_t major, const fe_t* __restrict__ x, unsigned first, unsigned step) {
+  fe_t acc = fe_zero();
+  for (unsigned k = m.sptr[major] + first, e = m.sptr[major + 1]; k < e; k += step) acc = acc_small(acc, m.scode[k], x[m.sidx[k]]);
+  for (unsigned k = m.gptr[major] + first, e = m.gptr[major + 1]; k < e; k += step) acc = fe_add<S>(acc, fe_mul<S>(m.gval[k], x[m.gidx[k]]));
+  return acc;
+}
+
+struct Spmv3Args {
+  SplitDev m[3];
+  const fe_t* base[3];  // cached products to add (nullptr for a plain multiply_vec)
+  fe_t* out[3];
+};
+__global__ void __launch_bounds__(256) k_spmv3(Spmv3Args a, const fe_t* __restrict__ z, size_t nrows) {
+  const int which = blockIdx.y;
+  const SplitDev m = a.m[which];
+  const fe_t* base = a.base[which];
+  fe_t* out = a.out[which];
+  for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
+    fe_t acc = gather_major(m, row, z, 0, 1);
+    if (base) acc = fe_add<S>(acc, base[row]);
+    out[row] = acc;
+  }
+}
+
+struct PolyAbcArgs {
+  SplitDev m[3];  // column-major A, B, C
+  fe_t r, r2;
+};
+constexpr unsigned LONG_COLUMN = 512;
+__device__ __forceinline__ unsigned col_len(const PolyAbcArgs& a, size_t col) {
+  unsigned n = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) n += (a.m[i].sptr[col + 1] - a.m[i].sptr[col]) + (a.m[i].gptr[col + 1] - a.m[i].gptr[col]);
+  return n;
+}
+__global__ void __launch_bounds__(256) k_polyabc_short(PolyAbcArgs a, const fe_t* __restrict__ rx, size_t ncols, fe_t* __restrict__ out) {
+  for (size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x; col < ncols; col += (size_t)gridDim.x * blockDim.x) {
+    if (col_len(a, col) >= LONG_COLUMN) continue;  // handled by k_polyabc_long
+    fe_t sa = gather_major(a.m[0], col, rx, 0, 1), sb = gather_major(a.m[1], col, rx, 0, 1), sc = gather_major(a.m[2], col, rx, 0, 1);
+    out[col] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(a.r, sb)), fe_mul<S>(a.r2, sc));
+  }
+}
+__global__ void __launch_bounds__(256) k_polyabc_long(PolyAbcArgs a, const fe_t* __restrict__ rx, const unsigned* __restrict__ long_cols,
+                                                      fe_t* __restrict__ out) {
+  __shared__ fe_t smem[3 * 4];
+  const size_t col = long_cols[blockIdx.x];
+  fe_t acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = gather_major(a.m[i], col, rx, threadIdx.x, blockDim.x);
+  block_sum<3>(acc, smem);
+  if (threadIdx.x == 0) out[col] = fe_add<S>(fe_add<S>(acc[0], fe_mul<S>(a.r, acc[1])), fe_mul<S>(a.r2, acc[2]));
+}
+
+}  // namespace spk
+
+// ---- host side: classification and upload ---------------------------------------------------------------------------
+namespace {
+
+struct SplitHost {
+  std::vector<unsigned> sptr, sidx, gptr, gidx;
+  std::vector<signed char> scode;
+  std::vector<fe_t> gval;
+};
+struct SplitOnDevice {
+  unsigned *sptr = nullptr, *sidx = nullptr, *gptr = nullptr, *gidx = nullptr;
+  signed char* scode = nullptr;
+  fe_t* gval = nullptr;
+  spk::SplitDev view() const { return spk::SplitDev{sptr, sidx, scode, gptr, gidx, gval}; }
+  void release() {
+    hipFree(sptr);
+    hipFree(sidx);
+    hipFree(gptr);
+    hipFree(gidx);
+    hipFree(scode);
+    hipFree(gval);
+  }
+};
+
+struct Classifier {  // from_sparse (sparse.rs:49-134)
+  fe_t pos[8], neg[8];
+  Classifier() {
+    for (int k = 1; k <= 7; ++k) {
+      pos[k] = fe_from_u64<S>(k);
+      neg[k] = fe_neg<S>(pos[k]);
+    }
+  }
+  int code(const fe_t& v) const {
+    for (int k = 1; k <= 7; ++k) {
+      if (fe_eq(v, pos[k])) return k;
+      if (fe_eq(v, neg[k])) return -k;
+    }
+    return 0;
+  }
+};
+
+template <class T>
+int upload(T** dst, const std::vector<T>& src) {
+  size_t bytes = (src.empty() ? 1 : src.size()) * sizeof(T);
+  hipError_t e = hipMalloc((void**)dst, bytes);
+  if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+  if (!src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+  return SP_OK;
+}
+int upload_split(const SplitHost& h, SplitOnDevice* d) {
+  int rc;
+  if ((rc = upload(&d->sptr, h.sptr))) return rc;
+  if ((rc = upload(&d->sidx, h.sidx))) return rc;
+  if ((rc = upload(&d->scode, h.scode))) return rc;
+  if ((rc = upload(&d->gptr, h.gptr))) return rc;
+  if ((rc = upload(&d->gidx, h.gidx))) return rc;
+  return upload(&d->gval, h.gval);
+}
+
+struct Entry {
+  unsigned major, minor;
+  int code;
+  fe_t val;
+};
+// build a major-ordered split structure from (major, minor) entries already grouped by major
+SplitHost build_split(size_t n_major, const std::vector<Entry>& es) {
+  SplitHost h;
+  h.sptr.assign(n_major + 1, 0);
+  h.gptr.assign(n_major + 1, 0);
+  for (const Entry& e : es) (e.code ? h.sptr : h.gptr)[e.major + 1]++;
+  for (size_t i = 0; i < n_major; ++i) {
+    h.sptr[i + 1] += h.sptr[i];
+    h.gptr[i + 1] += h.gptr[i];
+  }
+  h.sidx.resize(h.sptr[n_major]);
+  h.scode.resize(h.sptr[n_major]);
+  h.gidx.resize(h.gptr[n_major]);
+  h.gval.resize(h.gptr[n_major]);
+  std::vector<unsigned> sc(h.sptr.begin(), h.sptr.end() - 1), gc(h.gptr.begin(), h.gptr.end() - 1);
+  for (const Entry& e : es) {
+    if (e.code) {
+      unsigned p = sc[e.major]++;
+      h.sidx[p] = e.minor;
+      h.scode[p] = (signed char)e.code;
+    } else {
+      unsigned p = gc[e.major]++;
+      h.gidx[p] = e.minor;
+      h.gval[p] = e.val;
+    }
+  }
+  return h;
+}
+
+}  // namespace
+
+struct sp_shape {
+  sp_dims dims;
+  size_t num_vars = 0, num_cols = 0;
+  SplitOnDevice row[3];       // full CSR (multiply_vec)
+  SplitOnDevice filtered[3];  // FilteredSpmv rows: col >= num_shared + num_precommitted, row < num_cons_unpadded
+  SplitOnDevice col[3];       // column-major, rows < num_cons_unpadded (accumulate_rows)
+  unsigned* d_long_cols = nullptr;
+  size_t n_long_cols = 0;
+  uint64_t nnz[3] = {0, 0, 0}, nnz_filtered[3] = {0, 0, 0};
+};
+
+extern "C" {
+
+int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr* C, const sp_dims* dims, sp_shape** out) {
+  (void)c;
+  sp_shape* s = new sp_shape();
+  s->dims = *dims;
+  s->num_vars = dims->num_shared + dims->num_precommitted + dims->num_rest;
+  s->num_cols = s->num_vars + 1 + dims->num_public + dims->num_challenges;
+  const size_t nrows = dims->num_cons, col_min = dims->num_shared + dims->num_precommitted, nr_used = dims->num_cons_unpadded;
+  const sp_csr* M[3] = {A, Bm, C};
+  Classifier cls;
+  std::vector<unsigned> col_count(s->num_cols, 0);
+  for (int m = 0; m < 3; ++m) {
+    const size_t nnz = M[m]->indptr[nrows];
+    s->nnz[m] = nnz;
+    std::vector<Entry> all, filt, bycol;
+    all.reserve(nnz);
+    for (size_t r = 0; r < nrows; ++r) {
+      for (uint64_t k = M[m]->indptr[r]; k < M[m]->indptr[r + 1]; ++k) {
+        Entry e;
+        e.major = (unsigned)r;
+        e.minor = M[m]->indices[k];
+        if (e.minor >= s->num_cols) {
+          delete s;
+          return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_shape_from_csr: column index out of range");
+        }
+        memcpy(&e.val, M[m]->data + 4 * k, 32);
+        e.code = cls.code(e.val);
+        all.push_back(e);
+        if (r < nr_used && e.minor >= col_min) filt.push_back(e);
+      }
+    }
+    s->nnz_filtered[m] = filt.size();
+    // column-major copy of the rows accumulate_rows visits
+    std::vector<unsigned> cptr(s->num_cols + 1, 0);
+    for (const Entry& e : all)
+      if (e.major < nr_used) cptr[e.minor + 1]++;
+    for (size_t i = 0; i < s->num_cols; ++i) cptr[i + 1] += cptr[i];
+    bycol.resize(cptr[s->num_cols]);
+    {
+      std::vector<unsigned> cur(cptr.begin(), cptr.end() - 1);
+      for (const Entry& e : all)
+        if (e.major < nr_used) {
+          Entry t = e;
+          t.major = e.minor;
+          t.minor = e.major;
+          bycol[cur[e.minor]++] = t;
+        }
+    }
+    for (size_t i = 0; i < s->num_cols; ++i) col_count[i] += cptr[i + 1] - cptr[i];
+    int rc;
+    if ((rc = upload_split(build_split(nrows, all), &s->row[m])) || (rc = upload_split(build_split(nrows, filt), &s->filtered[m])) ||
+        (rc = upload_split(build_split(s->num_cols, bycol), &s->col[m]))) {
+      delete s;
+      return rc;
+    }
+  }
+  std::vector<unsigned> long_cols;
+  for (size_t i = 0; i < s->num_cols; ++i)
+    if (col_count[i] >= spk::LONG_COLUMN) long_cols.push_back((unsigned)i);
+  s->n_long_cols = long_cols.size();
+  int rc = upload(&s->d_long_cols, long_cols);
+  if (rc) return rc;
+  *out = s;
+  return SP_OK;
+}
+void sp_shape_free(sp_shape* s) {
+  if (!s) return;
+  for (int m = 0; m < 3; ++m) {
+    s->row[m].release();
+    s->filtered[m].release();
+    s->col[m].release();
+  }
+  hipFree(s->d_long_cols);
+  delete s;
+}
+
+static int spmv3(sp_ctx* c, const sp_shape* s, const SplitOnDevice* mats, const uint64_t* nnz, const sp_table* z, const sp_table* const* base,
+                 sp_table** outs, const char* what) {
+  const size_t nrows = s->dims.num_cons;
+  if (z->len != s->num_cols) return fail(SP_ERR_INVALID_WITNESS_LENGTH, "multiply_vec: z has the wrong length");
+  spk::Spmv3Args a;
+  for (int m = 0; m < 3; ++m) {
+    if (outs[m]->cap < nrows) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multiply_vec: output table too short");
+    if (base && base[m]->cap < nrows) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multiply_vec_incremental: cached table too short");
+    a.m[m] = mats[m].view();
+    a.base[m] = base ? base[m]->d : nullptr;
+    a.out[m] = outs[m]->d;
+    outs[m]->len = nrows;
+    outs[m]->lo_eff = outs[m]->hi_eff = (size_t)-1;
+  }
+  size_t blocks = (nrows + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  // sum_nnz (4 + 32) [+32 per general coefficient, ignored] + 3*32*N outputs (+ cached reads when incremental)
+  uint64_t bytes = 36ull * (nnz[0] + nnz[1] + nnz[2]) + 96ull * nrows * (base ? 2 : 1);
+  c->timed(what, bytes, [&] { hipLaunchKernelGGL(spk::k_spmv3, dim3((unsigned)blocks, 3), dim3(256), 0, c->stream, a, z->d, nrows); });
+  return SP_OK;
+}
+
+int sp_multiply_vec(sp_ctx* c, const sp_shape* s, const sp_table* z, sp_table* az, sp_table* bz, sp_table* cz) {
+  sp_table* outs[3] = {az, bz, cz};
+  return spmv3(c, s, s->row, s->nnz, z, nullptr, outs, "spmv");
+}
+int sp_multiply_vec_incremental(sp_ctx* c, const sp_shape* s, const sp_table* z, const sp_table* caz, const sp_table* cbz, const sp_table* ccz,
+                                sp_table* az, sp_table* bz, sp_table* cz) {
+  sp_table* outs[3] = {az, bz, cz};
+  const sp_table* base[3] = {caz, cbz, ccz};
+  return spmv3(c, s, s->filtered, s->nnz_filtered, z, base, outs, "spmv_incremental");
+}
+
+int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t r_[4], size_t out_len, sp_table* out) {
+  if (rx->len != s->dims.num_cons) return fail(SP_ERR_INVALID_INPUT_LENGTH, "poly_ABC: rx must have num_cons elements");
+  if (out_len < s->num_cols || out->cap < out_len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "poly_ABC: output too short");
+  spk::PolyAbcArgs a;
+  for (int m = 0; m < 3; ++m) a.m[m] = s->col[m].view();
+  memcpy(&a.r, r_, 32);
+  a.r2 = fe_mul<S>(a.r, a.r);
+  if (out_len > s->num_cols) SP_HIP(hipMemsetAsync(out->d + s->num_cols, 0, (out_len - s->num_cols) * sizeof(fe_t), c->stream));
+  size_t blocks = (s->num_cols + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  uint64_t bytes = 36ull * (s->nnz[0] + s->nnz[1] + s->nnz[2]) + 32ull * out_len;
+  c->timed("poly_abc", bytes, [&] {
+    hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->num_cols, out->d);
+    if (s->n_long_cols)
+      hipLaunchKernelGGL(spk::k_polyabc_long, dim3((unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, rx->d, s->d_long_cols, out->d);
+  });
+  return SP_OK;
+}
+
+}  // extern "C"

@@ -41,6 +41,13 @@ struct sp_ctx {
   std::map<std::string, sp::KStat> stats;
   std::vector<hipEvent_t> event_pool;
 
+  // grow-only persistent device buffers, one per slot, so hot-path calls never hipMalloc/hipFree
+  enum { WS_MSM_ORDER = 0, WS_MSM_START, WS_MSM_BUCKETS, WS_MSM_WSUM, WS_SCALARS_RAW, WS_SCALARS_CANON, WS_FB_SCALARS, WS_FB_OUT, WS_ROWMAT_L,
+         WS_ROWMAT_PART, WS_ROWMAT_OUT, WS_COMMIT_CANON, WS_COMMIT_FLAGS, WS_COMMIT_ROWS, WS_BASES_TMP, WS_SLOTS };
+  void* ws_ptr[WS_SLOTS] = {};
+  size_t ws_bytes[WS_SLOTS] = {};
+  void* workspace(int slot, size_t bytes);
+
   hipEvent_t get_event();
   int ensure_scratch(size_t elems);
   // records (start, stop) events around `launch` when timing is enabled

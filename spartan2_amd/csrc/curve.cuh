@@ -1,0 +1,124 @@
+// Short-Weierstrass group arithmetic for the bench engine's curve T256 (halo2curves::t256 = "Tom-256":
+// y^2 = x^3 - 3x + b over the field of src/provider/pt256.rs:56, group order = the P-256 base prime).
+// Jacobian coordinates, __host__ __device__: kernels use it for bucket/tree sums, the host side of the library
+// for the short sequential tails (window Horner, normalisation), where one CPU core beats one GPU lane.
+// Replaces CurveExt::{add_mixed_vartime, double, +} and Curve::batch_normalize as used by src/provider/msm.rs:24-57,
+// :150-175 and src/provider/traits.rs:194-198.
+#pragma once
+#include "field.cuh"
+
+typedef FpP B;  // base field
+
+struct aff_t {
+  fe_t x, y;  // (0,0) == identity
+};
+struct jac_t {
+  fe_t x, y, z;  // z == 0 -> identity
+};
+
+struct T256 {
+  static SP_HD fe_t b() {  // 0xb441071b12f4a0366fb552f8e21ed4ac36b06aceeb354224863e60f20219fc56 in Montgomery form
+    fe_t c;
+    c.v[0] = 0x0219fc56u; c.v[1] = 0x863e60f2u; c.v[2] = 0xeb354224u; c.v[3] = 0x36b06aceu;
+    c.v[4] = 0xe21ed4acu; c.v[5] = 0x6fb552f8u; c.v[6] = 0x12f4a036u; c.v[7] = 0xb441071bu;
+    return fe_from_canonical<B>(c);
+  }
+};
+
+SP_HD bool aff_is_identity(const aff_t& p) { return fe_is_zero(p.x) && fe_is_zero(p.y); }
+SP_HD bool jac_is_identity(const jac_t& p) { return fe_is_zero(p.z); }
+SP_HD jac_t jac_identity() {
+  jac_t r;
+  r.x = fe_one<B>();
+  r.y = fe_one<B>();
+  r.z = fe_zero();
+  return r;
+}
+SP_HD jac_t jac_from_affine(const aff_t& p) {
+  if (aff_is_identity(p)) return jac_identity();
+  jac_t r;
+  r.x = p.x;
+  r.y = p.y;
+  r.z = fe_one<B>();
+  return r;
+}
+SP_HD aff_t aff_neg(const aff_t& p) {
+  aff_t r;
+  r.x = p.x;
+  r.y = fe_neg<B>(p.y);  // neg(0) == 0 keeps the identity encoding
+  return r;
+}
+
+// a = -3 doubling (dbl-2001-b): 3M + 5S
+SP_HD jac_t jac_dbl(const jac_t& p) {
+  if (jac_is_identity(p) || fe_is_zero(p.y)) return jac_identity();
+  fe_t delta = fe_sqr<B>(p.z), gamma = fe_sqr<B>(p.y), beta = fe_mul<B>(p.x, gamma);
+  fe_t t = fe_mul<B>(fe_sub<B>(p.x, delta), fe_add<B>(p.x, delta));
+  fe_t alpha = fe_add<B>(fe_dbl<B>(t), t);
+  fe_t beta4 = fe_dbl<B>(fe_dbl<B>(beta));
+  jac_t r;
+  r.x = fe_sub<B>(fe_sqr<B>(alpha), fe_dbl<B>(beta4));
+  r.z = fe_sub<B>(fe_sub<B>(fe_sqr<B>(fe_add<B>(p.y, p.z)), gamma), delta);
+  fe_t g2 = fe_sqr<B>(gamma);
+  fe_t g8 = fe_dbl<B>(fe_dbl<B>(fe_dbl<B>(g2)));
+  r.y = fe_sub<B>(fe_mul<B>(alpha, fe_sub<B>(beta4, r.x)), g8);
+  return r;
+}
+
+// Jacobian + affine (madd-2007-bl): 7M + 4S, all special cases handled
+SP_HD jac_t jac_add_mixed(const jac_t& p, const aff_t& q) {
+  if (aff_is_identity(q)) return p;
+  if (jac_is_identity(p)) return jac_from_affine(q);
+  fe_t z1z1 = fe_sqr<B>(p.z);
+  fe_t u2 = fe_mul<B>(q.x, z1z1), s2 = fe_mul<B>(fe_mul<B>(q.y, p.z), z1z1);
+  fe_t h = fe_sub<B>(u2, p.x), rr = fe_dbl<B>(fe_sub<B>(s2, p.y));
+  if (fe_is_zero(h)) {
+    if (fe_is_zero(rr)) return jac_dbl(p);
+    return jac_identity();
+  }
+  fe_t hh = fe_sqr<B>(h), i = fe_dbl<B>(fe_dbl<B>(hh)), j = fe_mul<B>(h, i), v = fe_mul<B>(p.x, i);
+  jac_t r;
+  r.x = fe_sub<B>(fe_sub<B>(fe_sqr<B>(rr), j), fe_dbl<B>(v));
+  r.y = fe_sub<B>(fe_mul<B>(rr, fe_sub<B>(v, r.x)), fe_dbl<B>(fe_mul<B>(p.y, j)));
+  r.z = fe_sub<B>(fe_sub<B>(fe_sqr<B>(fe_add<B>(p.z, h)), z1z1), hh);
+  return r;
+}
+
+// Jacobian + Jacobian (add-2007-bl): 11M + 5S
+SP_HD jac_t jac_add(const jac_t& p, const jac_t& q) {
+  if (jac_is_identity(p)) return q;
+  if (jac_is_identity(q)) return p;
+  fe_t z1z1 = fe_sqr<B>(p.z), z2z2 = fe_sqr<B>(q.z);
+  fe_t u1 = fe_mul<B>(p.x, z2z2), u2 = fe_mul<B>(q.x, z1z1);
+  fe_t s1 = fe_mul<B>(fe_mul<B>(p.y, q.z), z2z2), s2 = fe_mul<B>(fe_mul<B>(q.y, p.z), z1z1);
+  fe_t h = fe_sub<B>(u2, u1), rr = fe_dbl<B>(fe_sub<B>(s2, s1));
+  if (fe_is_zero(h)) {
+    if (fe_is_zero(rr)) return jac_dbl(p);
+    return jac_identity();
+  }
+  fe_t i = fe_sqr<B>(fe_dbl<B>(h)), j = fe_mul<B>(h, i), v = fe_mul<B>(u1, i);
+  jac_t r;
+  r.x = fe_sub<B>(fe_sub<B>(fe_sqr<B>(rr), j), fe_dbl<B>(v));
+  r.y = fe_sub<B>(fe_mul<B>(rr, fe_sub<B>(v, r.x)), fe_dbl<B>(fe_mul<B>(s1, j)));
+  r.z = fe_mul<B>(fe_sub<B>(fe_sub<B>(fe_sqr<B>(fe_add<B>(p.z, q.z)), z1z1), z2z2), h);
+  return r;
+}
+
+SP_HD aff_t jac_to_affine(const jac_t& p) {
+  aff_t r;
+  if (jac_is_identity(p)) {
+    r.x = fe_zero();
+    r.y = fe_zero();
+    return r;
+  }
+  fe_t zi = fe_inv<B>(p.z), zi2 = fe_sqr<B>(zi);
+  r.x = fe_mul<B>(p.x, zi2);
+  r.y = fe_mul<B>(fe_mul<B>(p.y, zi2), zi);
+  return r;
+}
+SP_HD bool aff_on_curve(const aff_t& p) {
+  if (aff_is_identity(p)) return true;
+  fe_t x3 = fe_mul<B>(fe_sqr<B>(p.x), p.x);
+  fe_t rhs = fe_add<B>(fe_sub<B>(x3, fe_add<B>(fe_dbl<B>(p.x), p.x)), T256::b());
+  return fe_eq(fe_sqr<B>(p.y), rhs);
+}

@@ -70,6 +70,37 @@ struct Keccak256State {
   }
 };
 
+// SHAKE256 (rate 136, pad 0x1f): the XOF stream generators are derived from (src/provider/traits.rs:205-214)
+struct Shake256State {
+  Keccak256State k;
+  bool squeezing;
+  uint32_t pos;
+  SP_HD void init() {
+    k.init();
+    squeezing = false;
+    pos = 0;
+  }
+  SP_HD void update(const uint8_t* p, size_t n) { k.update(p, n); }
+  SP_HD void read(uint8_t* out, size_t n) {
+    if (!squeezing) {
+      for (uint32_t i = k.fill; i < 136; ++i) k.buf[i] = 0;
+      k.buf[k.fill] ^= 0x1f;
+      k.buf[135] ^= 0x80;
+      k.block();
+      squeezing = true;
+      pos = 0;
+    }
+    for (size_t i = 0; i < n; ++i) {
+      if (pos == 136) {
+        keccak_permute(k.a);
+        pos = 0;
+      }
+      out[i] = (uint8_t)(k.a[pos >> 3] >> (8 * (pos & 7)));
+      ++pos;
+    }
+  }
+};
+
 // Keccak256Transcript<E> (src/provider/keccak.rs:26-105)
 struct Transcript {
   uint16_t round;

@@ -1,0 +1,242 @@
+// HIP kernels for the group side (Hyrax commitments) on gfx950:
+//   k_to_canonical        to_repr() of a scalar array (Montgomery -> canonical), also flags "all small / all bits"
+//   k_msm_sort            K11 stage 1: signed 8-bit digits (msm.rs:110-145) + LDS counting sort by bucket, one block per window
+//   k_msm_bucket_sum      K11 stage 2: bucket accumulation, 8 lanes per bucket, mixed adds + shuffle tree
+//   k_msm_window_reduce   K11 stage 3: sum_k k*B_k per window by suffix scan + tree in LDS (summation by parts, msm.rs:169-174)
+//   k_msm_binary_rows     K10 msm_binary per Hyrax row (msm.rs:418-451 via hyrax_pc.rs:230-300)
+//   k_fixed_base_rows     K12 FixedBaseMul::mul per scalar (msm.rs:691-725): 32 table lookups + wave tree
+//   k_fixed_base_table    FixedBaseMul::precompute (msm.rs:653-689)
+//   k_rowmat_vec          K9  bind_with_delayed (hyrax_pc.rs:38-54)
+// The window Horner (256 doublings) and the final normalisation are short sequential tails done by the host side
+// of the library (capi_group.hip) — one CPU core is ~20x faster than one GPU lane at a dependent chain.
+// Results are group elements; parity is on canonical affine coordinates, so summation order is free.
+#pragma once
+#include "curve.cuh"
+
+namespace spk {
+
+typedef FqP SF;  // scalar field
+
+__device__ __forceinline__ jac_t shfl_down_jac(const jac_t& a, int delta) {
+  jac_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.x.v[i] = __shfl_down(a.x.v[i], delta, 64);
+    r.y.v[i] = __shfl_down(a.y.v[i], delta, 64);
+    r.z.v[i] = __shfl_down(a.z.v[i], delta, 64);
+  }
+  return r;
+}
+
+// canonical (non-Montgomery) limbs of each scalar
+__global__ void __launch_bounds__(256) k_to_canonical(const fe_t* __restrict__ in, size_t n, fe_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fe_to_canonical<SF>(in[i]);
+}
+// per-row classification for PCS::commit (hyrax_pc.rs:243-292): bit0 = row has a non-zero, bit1 = some value > 1,
+// bit2 = some value >= 2^64. rows of `cols` canonical scalars, last row may be short.
+__global__ void __launch_bounds__(256) k_classify_rows(const fe_t* __restrict__ canon, size_t n, size_t cols, unsigned* __restrict__ flags) {
+  const size_t row = blockIdx.x;
+  const size_t lo = row * cols, hi = (lo + cols < n) ? lo + cols : n;
+  unsigned f = 0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const fe_t c = canon[i];
+    unsigned upper = c.v[2] | c.v[3] | c.v[4] | c.v[5] | c.v[6] | c.v[7];
+    if (upper) f |= 7u;
+    else if (c.v[1] || c.v[0] > 1) f |= 3u;
+    else if (c.v[0]) f |= 1u;
+  }
+  if (f) atomicOr(&flags[row], f);
+}
+
+// ---- K11 signed-digit Pippenger, window c = 8 ---------------------------------------------------------------------
+constexpr int MSM_C = 8;
+constexpr int MSM_BUCKETS = 1 << (MSM_C - 1);  // 128 signed buckets per window
+constexpr int MSM_MAX_WINDOWS = 33;            // 32 byte windows + the carry window (msm.rs:137-145)
+
+// signed digit of window w: d = ((s + sum_j 2^(8j+7)) >> 8w & 255) - 128 restated without big-integer adds:
+// raw byte + carry-in, carry-in(w) = 1 iff the lower windows recoded with a carry — computed by scanning bytes.
+__device__ __forceinline__ int signed_digit(const fe_t& c, int w) {
+  // carry into window w: propagate from window 0 (cheap: <= 32 steps, scalars are read once per block pass)
+  int carry = 0;
+  int d = 0;
+  for (int k = 0; k <= w; ++k) {
+    int raw = (k < 32) ? (int)((c.v[k >> 2] >> (8 * (k & 3))) & 0xff) : 0;
+    raw += carry;
+    if (raw >= 128) {
+      d = raw - 256;
+      carry = 1;
+    } else {
+      d = raw;
+      carry = 0;
+    }
+  }
+  return d;
+}
+
+// One block per window. Outputs, per window w: order[w*n + pos] = base index | (negate << 31), grouped by bucket;
+// start[w*(BUCKETS+1) + k] = first position of bucket k+1's list (k = |digit| - 1).
+__global__ void __launch_bounds__(256) k_msm_sort(const fe_t* __restrict__ canon, unsigned n, unsigned* __restrict__ order,
+                                                  unsigned* __restrict__ start) {
+  __shared__ unsigned hist[MSM_BUCKETS + 1];
+  __shared__ unsigned cursor[MSM_BUCKETS];
+  const int w = blockIdx.x;
+  for (int k = threadIdx.x; k <= MSM_BUCKETS; k += blockDim.x) hist[k] = 0;
+  __syncthreads();
+  for (unsigned j = threadIdx.x; j < n; j += blockDim.x) {
+    int d = signed_digit(canon[j], w);
+    if (d) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int k = 0; k < MSM_BUCKETS; ++k) {
+      unsigned cnt = hist[k];
+      hist[k] = run;
+      cursor[k] = run;
+      run += cnt;
+    }
+    hist[MSM_BUCKETS] = run;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= MSM_BUCKETS; k += blockDim.x) start[(size_t)w * (MSM_BUCKETS + 1) + k] = hist[k];
+  for (unsigned j = threadIdx.x; j < n; j += blockDim.x) {
+    int d = signed_digit(canon[j], w);
+    if (d) {
+      unsigned pos = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
+      order[(size_t)w * n + pos] = j | (d < 0 ? 0x80000000u : 0u);
+    }
+  }
+}
+
+// 8 lanes per bucket; grid covers windows * 128 buckets * 8 lanes.
+constexpr int MSM_LANES_PER_BUCKET = 8;
+__global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict__ bases, unsigned n, const unsigned* __restrict__ order,
+                                                        const unsigned* __restrict__ start, int windows, jac_t* __restrict__ buckets) {
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned bucket = gid / MSM_LANES_PER_BUCKET, sub = gid % MSM_LANES_PER_BUCKET;
+  const unsigned total = (unsigned)windows * MSM_BUCKETS;
+  jac_t acc = jac_identity();
+  if (bucket < total) {
+    const unsigned w = bucket / MSM_BUCKETS, k = bucket % MSM_BUCKETS;
+    const unsigned lo = start[(size_t)w * (MSM_BUCKETS + 1) + k], hi = start[(size_t)w * (MSM_BUCKETS + 1) + k + 1];
+    for (unsigned p = lo + sub; p < hi; p += MSM_LANES_PER_BUCKET) {
+      const unsigned e = order[(size_t)w * n + p];
+      aff_t q = bases[e & 0x7fffffffu];
+      if (e & 0x80000000u) q = aff_neg(q);
+      acc = jac_add_mixed(acc, q);
+    }
+  }
+#pragma unroll
+  for (int d = MSM_LANES_PER_BUCKET / 2; d >= 1; d >>= 1) {
+    jac_t o = shfl_down_jac(acc, d);
+    if (sub < (unsigned)d) acc = jac_add(acc, o);
+  }
+  if (bucket < total && sub == 0) buckets[bucket] = acc;
+}
+
+// per window: W = sum_{k=1..128} k * B_k = sum_k S_k with S_k = sum_{j >= k} B_j (suffix scan, then tree)
+__global__ void __launch_bounds__(MSM_BUCKETS) k_msm_window_reduce(const jac_t* __restrict__ buckets, jac_t* __restrict__ window_sums) {
+  __shared__ jac_t s[MSM_BUCKETS];
+  const int w = blockIdx.x, k = threadIdx.x;
+  s[k] = buckets[(size_t)w * MSM_BUCKETS + k];
+  __syncthreads();
+  for (int off = 1; off < MSM_BUCKETS; off <<= 1) {  // Hillis-Steele suffix scan
+    jac_t o = (k + off < MSM_BUCKETS) ? s[k + off] : jac_identity();
+    __syncthreads();
+    if (k + off < MSM_BUCKETS) s[k] = jac_add(s[k], o);
+    __syncthreads();
+  }
+  for (int off = MSM_BUCKETS / 2; off >= 1; off >>= 1) {
+    if (k < off) s[k] = jac_add(s[k], s[k + off]);
+    __syncthreads();
+  }
+  if (k == 0) window_sums[w] = s[0];
+}
+
+// ---- K10: binary rows ------------------------------------------------------------------------------------------------
+// One block per Hyrax row: sum of bases[j] where the canonical scalar of column j equals 1.
+__global__ void __launch_bounds__(256) k_msm_binary_rows(const fe_t* __restrict__ canon, size_t n, size_t cols, const aff_t* __restrict__ bases,
+                                                         const unsigned* __restrict__ row_flags, jac_t* __restrict__ out) {
+  __shared__ jac_t s[256];
+  const size_t row = blockIdx.x;
+  const size_t lo = row * cols, hi = (lo + cols < n) ? lo + cols : n;
+  jac_t acc = jac_identity();
+  if (row_flags[row] == 1u) {  // only rows that really are 0/1 valued; others are handled by the digit path
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+      if (canon[i].v[0] & 1u) acc = jac_add_mixed(acc, bases[i - lo]);
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) s[threadIdx.x] = jac_add(s[threadIdx.x], s[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[row] = s[0];
+}
+
+// ---- K12: fixed-base multiples of h --------------------------------------------------------------------------------------
+// table[j*255 + d-1] = d * 2^(8j) * h (affine). Stage 1: thread j builds its window's 255 Jacobian multiples.
+__global__ void k_fixed_base_table(aff_t h, jac_t* __restrict__ table_jac) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 32) return;
+  jac_t base = jac_from_affine(h);
+  for (int k = 0; k < 8 * j; ++k) base = jac_dbl(base);
+  jac_t acc = base;
+  table_jac[(size_t)j * 255] = acc;
+  for (int d = 1; d < 255; ++d) {
+    acc = jac_add(acc, base);
+    table_jac[(size_t)j * 255 + d] = acc;
+  }
+}
+__global__ void __launch_bounds__(256) k_jac_to_affine(const jac_t* __restrict__ in, size_t n, aff_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = jac_to_affine(in[i]);
+}
+// One 32-lane half-wave per scalar: lane j adds table[j][byte j], then a 5-level tree.
+// `tables` holds ntables consecutive 32*255-entry tables; scalar idx uses table idx % ntables.
+__global__ void __launch_bounds__(256) k_fixed_base_rows(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
+                                                         jac_t* __restrict__ out) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t idx = gid >> 5;
+  const int j = (int)(gid & 31);
+  jac_t acc = jac_identity();
+  if (idx < n) {
+    const fe_t c = fe_to_canonical<SF>(scalars[idx]);
+    const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    if (digit) acc = jac_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
+  }
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+    jac_t o = shfl_down_jac(acc, d);
+    if (j < d) acc = jac_add(acc, o);
+  }
+  if (idx < n && j == 0) out[idx] = acc;
+}
+
+// ---- K9: LZ[i] = sum_j L[j] * poly[j*cols + i] ---------------------------------------------------------------------------
+// grid = (cols/64, row_splits): each block handles 64 columns x a slice of rows with 256 threads = 4 row-lanes per column.
+__global__ void __launch_bounds__(256) k_rowmat_vec(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L,
+                                                    fe_t* __restrict__ partial /* [row_splits][cols] */) {
+  __shared__ fe_t s[256];
+  const size_t col = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;  // 0..3
+  const size_t splits = gridDim.y, per = (rows + splits - 1) / splits;
+  const size_t r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+  fe_t acc = fe_zero();
+  if (col < cols)
+    for (size_t r = r0 + rl; r < r1; r += 4) acc = fe_add<SF>(acc, fe_mul<SF>(L[r], poly[r * cols + col]));
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0 && col < cols) {
+    fe_t t = fe_add<SF>(fe_add<SF>(s[threadIdx.x], s[threadIdx.x + 64]), fe_add<SF>(s[threadIdx.x + 128], s[threadIdx.x + 192]));
+    partial[(size_t)blockIdx.y * cols + col] = t;
+  }
+}
+__global__ void __launch_bounds__(256) k_sum_columns(const fe_t* __restrict__ partial, size_t splits, size_t cols, fe_t* __restrict__ out) {
+  const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  fe_t acc = partial[col];
+  for (size_t s = 1; s < splits; ++s) acc = fe_add<SF>(acc, partial[s * cols + col]);
+  out[col] = acc;
+}
+
+}  // namespace spk

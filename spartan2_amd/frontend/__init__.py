@@ -48,10 +48,11 @@ class R1CSInstanceInt:
             idx = ctypes.POINTER(ctypes.c_uint32)()
             ptr = ctypes.POINTER(ctypes.c_uint64)()
             lib().spf_csr(self._h, which, ctypes.byref(data), ctypes.byref(idx), ctypes.byref(ptr))
-            self.csr.append((np.ctypeslib.as_array(data, (max(nnz, 1),))[:nnz].copy(), np.ctypeslib.as_array(idx, (max(nnz, 1),))[:nnz].copy(),
-                             np.ctypeslib.as_array(ptr, (self.num_cons + 1,)).copy()))
-        self.witness = np.ctypeslib.as_array(lib().spf_witness(self._h), (max(self.num_aux, 1),))[: self.num_aux].copy()
-        self.publics = np.ctypeslib.as_array(lib().spf_publics(self._h), (max(self.num_public, 1),))[: self.num_public].copy()
+            d = np.ctypeslib.as_array(data, (nnz,)).copy() if nnz else np.zeros(0, dtype=np.int64)
+            i = np.ctypeslib.as_array(idx, (nnz,)).copy() if nnz else np.zeros(0, dtype=np.uint32)
+            self.csr.append((d, i, np.ctypeslib.as_array(ptr, (self.num_cons + 1,)).copy()))
+        self.witness = np.ctypeslib.as_array(lib().spf_witness(self._h), (self.num_aux,)).copy() if self.num_aux else np.zeros(0, dtype=np.uint64)
+        self.publics = np.ctypeslib.as_array(lib().spf_publics(self._h), (self.num_public,)).copy() if self.num_public else np.zeros(0, dtype=np.uint64)
         lib().spf_free(self._h)
         self._h = None
 

@@ -219,3 +219,123 @@ def table_dot(ctx, a: Table, b: Table, n: int):
     out = np.zeros(4, dtype=np.uint64)
     check(lib().sp_table_dot(ctx.h, a.h, b.h, ctypes.c_size_t(n), p64(out)))
     return out
+
+
+# ---- group / MSM / Hyrax -----------------------------------------------------------------------------------------
+def msm(ctx, scalars, bases):
+    """DlogGroupExt::vartime_multiscalar_mul (src/provider/msm.rs:187-222); returns the affine result (8 limbs)."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+    assert scalars.shape[0] == bases.shape[0]
+    out = np.zeros(8, dtype=np.uint64)
+    n = scalars.shape[0]
+    check(lib().sp_msm(ctx.h, p64(scalars) if n else None, p64(bases) if n else None, ctypes.c_size_t(n), p64(out)))
+    return out
+
+
+def msm_small(ctx, scalars_u64, bases):
+    scalars_u64 = np.ascontiguousarray(scalars_u64, dtype=np.uint64).reshape(-1)
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib().sp_msm_small_u64(ctx.h, p64(scalars_u64), p64(bases), ctypes.c_size_t(len(scalars_u64)), p64(out)))
+    return out
+
+
+class CommitmentKey:
+    """HyraxCommitmentKey (src/provider/pcs/hyrax_pc.rs:56-72) resident on the device."""
+
+    def __init__(self, ctx, ck_aff, h_aff):
+        ck_aff = np.ascontiguousarray(ck_aff, dtype=np.uint64).reshape(-1, 8)
+        h_aff = np.ascontiguousarray(h_aff, dtype=np.uint64).reshape(8)
+        self.ctx = ctx
+        self.num_cols = ck_aff.shape[0]
+        self.h = ctypes.c_void_p()
+        check(lib().sp_ck_create(ctx.h, p64(ck_aff), ctypes.c_size_t(self.num_cols), p64(h_aff), ctypes.byref(self.h)))
+
+    def commit(self, table: Table, off, n, blinds, is_small=True):
+        rows = (n + self.num_cols - 1) // self.num_cols
+        blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
+        out = np.zeros((rows, 8), dtype=np.uint64)
+        check(lib().sp_hyrax_commit(self.ctx.h, self.h, table.h, ctypes.c_size_t(off), ctypes.c_size_t(n), p64(blinds), int(is_small), p64(out)))
+        return out
+
+    def fixed_base_mul_h(self, scalars):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros((scalars.shape[0], 8), dtype=np.uint64)
+        check(lib().sp_fixed_base_mul_h(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(out)))
+        return out
+
+    def msm(self, scalars, blind=None):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(8, dtype=np.uint64)
+        b = None if blind is None else p64(np.ascontiguousarray(blind, dtype=np.uint64).reshape(4))
+        check(lib().sp_msm_ck(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), b, p64(out)))
+        return out
+
+    def commit_small(self, scalars, blind):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        blind = np.ascontiguousarray(blind, dtype=np.uint64).reshape(4)
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().sp_hyrax_commit_small(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(blind), p64(out)))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().sp_ck_free(self.h)
+        except Exception:
+            pass
+
+
+def rowmat_vec(ctx, poly: Table, rows, cols, L):
+    """bind_with_delayed (src/provider/pcs/hyrax_pc.rs:38-54)."""
+    L = np.ascontiguousarray(L, dtype=np.uint64).reshape(rows, 4)
+    out = np.zeros((cols, 4), dtype=np.uint64)
+    check(lib().sp_rowmat_vec(ctx.h, poly.h, ctypes.c_size_t(rows), ctypes.c_size_t(cols), p64(L), p64(out)))
+    return out
+
+
+# ---- R1CS ----------------------------------------------------------------------------------------------------------
+class _Csr(ctypes.Structure):
+    _fields_ = [("data", c_u64p), ("indices", ctypes.POINTER(ctypes.c_uint32)), ("indptr", c_u64p)]
+
+
+class _Dims(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("num_cons", "num_cons_unpadded", "num_shared", "num_precommitted", "num_rest", "num_shared_unpadded",
+                                               "num_precommitted_unpadded", "num_rest_unpadded", "num_public", "num_challenges")]
+
+
+class Shape:
+    """SplitR1CSShape on the device. mats: 3 x (data F (nnz,4) uint64, indices uint32, indptr uint64) in the padded layout."""
+
+    def __init__(self, ctx, mats, dims: dict):
+        self.ctx = ctx
+        self._keep = []
+        cs = []
+        for d, i, p_ in mats:
+            d = np.ascontiguousarray(d, dtype=np.uint64).reshape(-1, 4)
+            i = np.ascontiguousarray(i, dtype=np.uint32)
+            p_ = np.ascontiguousarray(p_, dtype=np.uint64)
+            self._keep += [d, i, p_]
+            cs.append(_Csr(p64(d) if d.shape[0] else None, i.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), p64(p_)))
+        dd = _Dims(**{k: int(v) for k, v in dims.items()})
+        self.dims = dims
+        self.h = ctypes.c_void_p()
+        check(lib().sp_shape_from_csr(ctx.h, ctypes.byref(cs[0]), ctypes.byref(cs[1]), ctypes.byref(cs[2]), ctypes.byref(dd), ctypes.byref(self.h)))
+
+    def multiply_vec(self, z: Table, az: Table, bz: Table, cz: Table):
+        check(lib().sp_multiply_vec(self.ctx.h, self.h, z.h, az.h, bz.h, cz.h))
+
+    def multiply_vec_incremental(self, z, caz, cbz, ccz, az, bz, cz):
+        check(lib().sp_multiply_vec_incremental(self.ctx.h, self.h, z.h, caz.h, cbz.h, ccz.h, az.h, bz.h, cz.h))
+
+    def poly_abc(self, rx: Table, r, out_len, out: Table):
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+        check(lib().sp_poly_abc(self.ctx.h, self.h, rx.h, p64(r), ctypes.c_size_t(out_len), out.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().sp_shape_free(self.h)
+        except Exception:
+            pass

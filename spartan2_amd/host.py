@@ -1,0 +1,140 @@
+"""ctypes view of libspartan_host.so — the C++ host side above the C ABI (spartan2_amd/host/spartan_snark.cpp), which mirrors
+SpartanSNARK::{setup, prep_prove, prove} (src/spartan.rs:146-466) and calls only include/spartan_hip.h."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import hip
+
+LIB_PATH = os.path.join(hip.LIB_DIR, "libspartan_host.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        hip.lib()  # libspartan_hip.so first (rpath $ORIGIN resolves it too)
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
+        L = ctypes.CDLL(LIB_PATH)
+        L.ss_last_error.restype = ctypes.c_char_p
+        L.ss_proof_words.restype = ctypes.c_size_t
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise hip.SpartanHipError(f"rc={rc}: {lib().ss_last_error().decode()}")
+
+
+def _inst_args(inst):
+    args = [ctypes.c_size_t(inst.num_cons), ctypes.c_size_t(inst.num_shared), ctypes.c_size_t(inst.num_precommitted), ctypes.c_size_t(inst.num_rest),
+            ctypes.c_size_t(inst.num_public), ctypes.c_size_t(inst.num_challenges)]
+    keep = []
+    for d, i, p_ in inst.csr:
+        d = np.ascontiguousarray(d, dtype=np.int64)
+        i = np.ascontiguousarray(i, dtype=np.uint32)
+        p_ = np.ascontiguousarray(p_, dtype=np.uint64)
+        keep += [d, i, p_]
+        args += [d.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), i.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), hip.p64(p_)]
+    return args, keep
+
+
+DIM_NAMES = ("num_cons", "num_cons_unpadded", "num_shared", "num_precommitted", "num_rest", "num_shared_unpadded", "num_precommitted_unpadded",
+             "num_rest_unpadded", "num_public", "num_challenges")
+
+
+def pad_shape(inst):
+    """SplitR1CSShape::new (src/r1cs/mod.rs:810-911): padded CSR matrices with field coefficients + dims dict."""
+    args, keep = _inst_args(inst)
+    h = ctypes.c_void_p()
+    _check(lib().ss_pad_shape(*args, ctypes.byref(h)))
+    d = (ctypes.c_uint64 * 10)()
+    lib().ss_padded_dims(h, d)
+    dims = {k: int(v) for k, v in zip(DIM_NAMES, d)}
+    mats = []
+    for which in range(3):
+        data = hip.c_u64p()
+        idx = ctypes.POINTER(ctypes.c_uint32)()
+        ptr = hip.c_u64p()
+        nnz = ctypes.c_uint64()
+        lib().ss_padded_csr(h, which, ctypes.byref(data), ctypes.byref(idx), ctypes.byref(ptr), ctypes.byref(nnz))
+        n = int(nnz.value)
+        mats.append((np.ctypeslib.as_array(data, (max(n, 1) * 4,))[: n * 4].reshape(n, 4).copy(), np.ctypeslib.as_array(idx, (max(n, 1),))[:n].copy(),
+                     np.ctypeslib.as_array(ptr, (dims["num_cons"] + 1,)).copy()))
+    lib().ss_padded_free(h)
+    return mats, dims
+
+
+def from_label(label: bytes, n: int):
+    out = np.zeros((n, 8), dtype=np.uint64)
+    _check(lib().ss_from_label(label, ctypes.c_size_t(n), hip.p64(out)))
+    return out
+
+
+PHASES = ("witness_commit", "matrix_vector_multiply", "outer_sumcheck", "prepare_poly_ABC", "inner_sumcheck", "pcs_prove", "total")
+
+
+class SpartanSNARK:
+    """setup -> prep_prove -> prove, as benches/sha256_spartan.rs:171-243 drives them."""
+
+    def __init__(self, ctx: hip.Context, inst):
+        self.ctx = ctx
+        self.inst = inst
+        args, keep = _inst_args(inst)
+        self.pk = ctypes.c_void_p()
+        _check(lib().ss_setup(ctx.h, *args, ctypes.byref(self.pk)))
+        d = (ctypes.c_uint64 * 10)()
+        dig = np.zeros(32, dtype=np.uint8)
+        lib().ss_pk_info(self.pk, d, hip.p8(dig))
+        self.dims = {k: int(v) for k, v in zip(DIM_NAMES, d)}
+        self.vk_digest = dig
+        self.ps = None
+
+    def prep_prove(self, tape: np.ndarray, is_small=True):
+        used = ctypes.c_size_t(0)
+        w = np.ascontiguousarray(self.inst.witness, dtype=np.uint64)
+        ps = ctypes.c_void_p()
+        _check(lib().ss_prep_prove(self.pk, hip.p64(w), ctypes.c_size_t(len(w)), int(is_small), hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used),
+                                   ctypes.byref(ps)))
+        if self.ps:
+            lib().ss_prep_free(self.ps)
+        self.ps = ps
+        return used.value
+
+    def prep_export(self):
+        rows = (self.dims["num_precommitted"] + 2047) // 2048
+        N = self.dims["num_cons"]
+        comm = np.zeros((rows, 8), dtype=np.uint64)
+        caz = np.zeros((N, 4), dtype=np.uint64)
+        cbz = np.zeros_like(caz)
+        ccz = np.zeros_like(caz)
+        _check(lib().ss_prep_export(self.pk, self.ps, hip.p64(comm), hip.p64(caz), hip.p64(cbz), hip.p64(ccz)))
+        return comm, caz, cbz, ccz
+
+    def prove(self, tape: np.ndarray):
+        """Returns (proof words in the canonical layout, tape blocks used, {phase: ms})."""
+        n = lib().ss_proof_words(self.pk)
+        words = np.zeros(n, dtype=np.uint64)
+        used = ctypes.c_size_t(0)
+        ms = (ctypes.c_double * 7)()
+        pub = np.ascontiguousarray(self.inst.publics, dtype=np.uint64)
+        _check(lib().ss_prove(self.pk, self.ps, hip.p64(pub) if len(pub) else None, ctypes.c_size_t(len(pub)), hip.p8(tape), ctypes.c_size_t(tape.shape[0]),
+                              ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
+        return words, used.value, dict(zip(PHASES, list(ms)))
+
+    def close(self):
+        if self.ps:
+            lib().ss_prep_free(self.ps)
+            self.ps = None
+        if self.pk:
+            lib().ss_pk_free(self.pk)
+            self.pk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

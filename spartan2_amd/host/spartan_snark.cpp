@@ -1,0 +1,650 @@
+// Host side ABOVE the C ABI: the protocol driver of the reference restated in C++ and calling ONLY the entry points of
+// include/spartan_hip.h for everything that scales with the instance — exactly what the reference's Rust drivers would do
+// through an `extern "C"` block. Mirrors
+//   SplitR1CSShape::new            src/r1cs/mod.rs:810-911      (padding / column remap)
+//   SpartanSNARK::setup            src/spartan.rs:146-173
+//   SpartanSNARK::prep_prove       src/spartan.rs:176-216       (+ bellpepper/r1cs.rs:359-409 precommitted_witness)
+//   SpartanSNARK::prove            src/spartan.rs:219-466       (+ bellpepper/r1cs.rs:411-538, hyrax_pc.rs:387-478, ipa.rs:125-170)
+// for circuits with no shared / rest variables and no challenges (both bench circuits; the skip_synthesize path :443).
+// Verification is not restated here: the reference verifier is CPU code outside the accelerated path;
+// tests verify with the oracle's restated verifier.
+//
+// Randomness is injected: every blind / mask is the next 64-byte block of a caller-supplied tape reduced with from_uniform,
+// in the reference's call order.
+// Generators: this build's own derivation (the reference's is a third-party hash-to-curve): PARITY UNPINNED, see DESIGN.md.
+#include <chrono>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/spartan_hip.h"
+#include "../csrc/curve.cuh"
+#include "../csrc/keccak.cuh"
+
+namespace spartan2 {
+
+typedef FqP S;
+static const size_t DEFAULT_COMMITMENT_WIDTH = 2048;  // src/lib.rs:63
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+static void ck(int rc, const char* what) {
+  if (rc != SP_OK) throw Error(rc, std::string(what) + ": " + sp_last_error());
+}
+
+static inline const uint64_t* u64p(const fe_t* p) { return reinterpret_cast<const uint64_t*>(p); }
+static inline uint64_t* u64p(fe_t* p) { return reinterpret_cast<uint64_t*>(p); }
+
+// ---- integer R1CS as produced by the frontend (arguments of SplitR1CSShape::new) ---------------------------------------
+struct CsrIntView {
+  const int64_t* data;
+  const uint32_t* indices;
+  const uint64_t* indptr;
+};
+struct R1CSIntView {
+  size_t num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges;
+  CsrIntView m[3];
+};
+
+struct PaddedShape {
+  sp_dims dims;
+  std::vector<fe_t> data[3];
+  std::vector<uint32_t> idx[3];
+  std::vector<uint64_t> ptr[3];
+  size_t num_vars() const { return dims.num_shared + dims.num_precommitted + dims.num_rest; }
+  size_t num_cols() const { return num_vars() + 1 + dims.num_public + dims.num_challenges; }
+};
+
+static size_t pad_to_width(size_t w, size_t n) { return (n + w - 1) / w * w; }
+static size_t next_pow2(size_t n) {
+  size_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+static size_t log2_ceil(size_t n) {
+  size_t l = 0;
+  while (((size_t)1 << l) < n) ++l;
+  return l;
+}
+
+// SplitR1CSShape::new (src/r1cs/mod.rs:810-911)
+PaddedShape pad_shape(const R1CSIntView& R) {
+  const size_t width = DEFAULT_COMMITMENT_WIDTH;
+  size_t sp_ = pad_to_width(width, R.num_shared), pp = pad_to_width(width, R.num_precommitted), rp = pad_to_width(width, R.num_rest);
+  size_t nvp = sp_ + pp + rp;
+  if (nvp < R.num_public + R.num_challenges + 1) rp = std::max(R.num_public + R.num_challenges + 1, nvp) - (sp_ + pp);
+  nvp = sp_ + pp + rp;
+  if (next_pow2(nvp) != nvp) rp = next_pow2(nvp) - (sp_ + pp);
+  nvp = sp_ + pp + rp;
+  const size_t num_vars = R.num_shared + R.num_precommitted + R.num_rest;
+  const size_t ncp = next_pow2(R.num_cons);
+  PaddedShape P;
+  P.dims.num_cons = ncp;
+  P.dims.num_cons_unpadded = R.num_cons;
+  P.dims.num_shared = sp_;
+  P.dims.num_precommitted = pp;
+  P.dims.num_rest = rp;
+  P.dims.num_shared_unpadded = R.num_shared;
+  P.dims.num_precommitted_unpadded = R.num_precommitted;
+  P.dims.num_rest_unpadded = R.num_rest;
+  P.dims.num_public = R.num_public;
+  P.dims.num_challenges = R.num_challenges;
+  // small coefficient cache: the SHA circuits only use +-2^k
+  for (int m = 0; m < 3; ++m) {
+    const size_t nnz = R.m[m].indptr[R.num_cons];
+    P.data[m].resize(nnz);
+    P.idx[m].resize(nnz);
+    for (size_t k = 0; k < nnz; ++k) {
+      P.data[m][k] = fe_from_i64<S>(R.m[m].data[k]);
+      size_t c = R.m[m].indices[k];
+      if (c >= R.num_shared && c < R.num_shared + R.num_precommitted) c += sp_ - R.num_shared;
+      else if (c >= R.num_shared + R.num_precommitted && c < num_vars) c += sp_ + pp - R.num_shared - R.num_precommitted;
+      else if (c >= num_vars) c += nvp - num_vars;
+      P.idx[m][k] = (uint32_t)c;
+    }
+    P.ptr[m].assign(R.m[m].indptr, R.m[m].indptr + R.num_cons + 1);
+    P.ptr[m].resize(ncp + 1, nnz);
+  }
+  return P;
+}
+
+// vk digest substitute (see oracle/spartan.hpp header): Keccak-256 over S.write_bytes() (src/r1cs/mod.rs:775-794, sparse.rs:398-417)
+static void shape_digest(const PaddedShape& P, uint8_t out[32]) {
+  sp::Keccak256State h;
+  h.init();
+  auto w64 = [&](uint64_t v) {
+    uint8_t b[8];
+    for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(v >> (8 * i));
+    h.update(b, 8);
+  };
+  const sp_dims& d = P.dims;
+  w64(d.num_cons);
+  w64(d.num_cons_unpadded);
+  w64(d.num_shared_unpadded);
+  w64(d.num_precommitted_unpadded);
+  w64(d.num_rest_unpadded);
+  w64(d.num_shared);
+  w64(d.num_precommitted);
+  w64(d.num_rest);
+  w64(d.num_public);
+  w64(d.num_challenges);
+  for (int m = 0; m < 3; ++m) {
+    w64(P.data[m].size());
+    w64(P.idx[m].size());
+    w64(P.ptr[m].size());
+    w64(P.num_cols());
+    for (const fe_t& f : P.data[m]) {
+      uint8_t b[32];
+      sp::fe_to_le_bytes<S>(f, b);
+      h.update(b, 32);
+    }
+    for (uint32_t i : P.idx[m]) w64(i);
+    for (uint64_t p : P.ptr[m]) w64(p);
+  }
+  h.finish(out);
+}
+
+// This build's generator derivation (documented in DESIGN.md; shape of src/provider/traits.rs:205-249):
+// SHAKE256(label) stream, 32 bytes per generator -> x = bytes LE mod p; increment x until x^3 - 3x + b is a non-zero square;
+// y = rhs^((p+1)/4), take the root with even canonical value.
+std::vector<aff_t> from_label(const char* label, size_t n) {
+  sp::Shake256State sh;
+  sh.init();
+  sh.update((const uint8_t*)label, strlen(label));
+  uint32_t e[8], c = 0;
+  for (int i = 0; i < 8; ++i) e[i] = sp_addc(FpP::P(i), i == 0 ? 1u : 0u, c);  // p + 1
+  for (int i = 0; i < 7; ++i) e[i] = (e[i] >> 2) | (e[i + 1] << 30);
+  e[7] >>= 2;
+  std::vector<aff_t> out(n);
+  const fe_t b = T256::b(), one = fe_one<B>();
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t buf[64];
+    memset(buf, 0, 64);
+    sh.read(buf, 32);
+    fe_t x = fe_from_uniform<B>(buf);
+    for (;;) {
+      fe_t rhs = fe_add<B>(fe_sub<B>(fe_mul<B>(fe_sqr<B>(x), x), fe_add<B>(fe_dbl<B>(x), x)), b);
+      fe_t y = fe_pow<B>(rhs, e);
+      if (!fe_is_zero(rhs) && fe_eq(fe_sqr<B>(y), rhs)) {
+        fe_t yc = fe_to_canonical<B>(y);
+        if (yc.v[0] & 1u) y = fe_neg<B>(y);
+        out[i].x = x;
+        out[i].y = y;
+        break;
+      }
+      x = fe_add<B>(x, one);
+    }
+  }
+  return out;
+}
+
+// ---- transcript helpers over the C ABI ---------------------------------------------------------------------------------
+struct Tr {
+  sp_transcript* t = nullptr;
+  explicit Tr(sp_ctx* ctx, const char* label) { ck(sp_transcript_new(ctx, (const uint8_t*)label, strlen(label), &t), "transcript_new"); }
+  ~Tr() { sp_transcript_free(t); }
+  void absorb(const char* label, const uint8_t* b, size_t n) { ck(sp_transcript_absorb(t, (const uint8_t*)label, strlen(label), b, n), "absorb"); }
+  void absorb_scalars(const char* label, const fe_t* s, size_t n) {  // BE encoding (src/provider/traits.rs:282-286), slices concatenated
+    std::vector<uint8_t> b(32 * n);
+    for (size_t i = 0; i < n; ++i) sp::fe_to_be_bytes<S>(s[i], b.data() + 32 * i);
+    absorb(label, b.data(), b.size());
+  }
+  fe_t squeeze(const char* label) {
+    fe_t f;
+    ck(sp_transcript_squeeze(t, (const uint8_t*)label, strlen(label), u64p(&f)), "squeeze");
+    return f;
+  }
+  void dom_sep(const char* s) { ck(sp_transcript_dom_sep(t, (const uint8_t*)s, strlen(s)), "dom_sep"); }
+};
+// point -> x BE || y BE (src/provider/traits.rs:288-305)
+static void point_bytes(const aff_t& a, uint8_t out[64]) {
+  sp::fe_to_be_bytes<B>(a.x, out);
+  sp::fe_to_be_bytes<B>(a.y, out + 32);
+}
+// HyraxCommitment::to_transcript_bytes (src/provider/pcs/hyrax_pc.rs:714-729)
+static std::vector<uint8_t> commitment_bytes(const aff_t* rows, size_t n) {
+  static const char* b = "poly_commitment_begin";
+  static const char* e = "poly_commitment_end";
+  std::vector<uint8_t> v(b, b + strlen(b));
+  v.resize(v.size() + 64 * n);
+  for (size_t i = 0; i < n; ++i) point_bytes(rows[i], v.data() + strlen(b) + 64 * i);
+  v.insert(v.end(), e, e + strlen(e));
+  return v;
+}
+
+struct Tape {
+  const uint8_t* bytes;
+  size_t blocks, pos = 0;
+  fe_t next() {
+    if (pos >= blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
+    return fe_from_uniform<S>(bytes + 64 * pos++);
+  }
+};
+
+// EqPolynomial::evals_from_points on the host for the O(sqrt N) tables of the opening (src/polys/eq.rs:59-92)
+static std::vector<fe_t> eq_evals_host(const fe_t* r, size_t ell) {
+  std::vector<fe_t> ev((size_t)1 << ell, fe_zero());
+  ev[0] = fe_one<S>();
+  size_t size = 1;
+  for (size_t k = ell; k-- > 0;) {
+    for (size_t i = 0; i < size; ++i) {
+      fe_t y = fe_mul<S>(ev[i], r[k]);
+      ev[size + i] = y;
+      ev[i] = fe_sub<S>(ev[i], y);
+    }
+    size *= 2;
+  }
+  return ev;
+}
+// SparsePolynomial::evaluate (src/polys/multilinear.rs:190-207)
+static fe_t sparse_poly_evaluate(size_t num_vars, const std::vector<fe_t>& Z, const fe_t* r) {
+  size_t nvz = log2_ceil(Z.size());
+  std::vector<fe_t> chis = eq_evals_host(r + (num_vars - 1 - nvz), nvz + 1);
+  fe_t partial = fe_zero();
+  for (size_t i = 0; i < Z.size(); ++i) partial = fe_add<S>(partial, fe_mul<S>(Z[i], chis[i]));
+  fe_t common = fe_one<S>();
+  for (size_t i = 0; i < num_vars - 1 - nvz; ++i) common = fe_mul<S>(common, fe_sub<S>(fe_one<S>(), r[i]));
+  return fe_mul<S>(common, partial);
+}
+
+// ---- keys / state ----------------------------------------------------------------------------------------------------------
+struct SpartanProverKey {  // src/spartan.rs:30-58
+  sp_ctx* ctx = nullptr;
+  sp_shape* S = nullptr;
+  sp_ck *ck = nullptr, *ck_s = nullptr;
+  sp_dims dims;
+  size_t num_vars = 0, num_extra = 0, num_cols = 0;
+  uint8_t vk_digest[32];
+  std::vector<aff_t> gens, gens_s;
+  ~SpartanProverKey() {
+    sp_shape_free(S);
+    sp_ck_free(ck);
+    sp_ck_free(ck_s);
+  }
+};
+
+struct SpartanPrepSNARK {  // src/spartan.rs:107-124
+  sp_table *W = nullptr, *caz = nullptr, *cbz = nullptr, *ccz = nullptr;      // witness + cached partial products
+  sp_table *az = nullptr, *bz = nullptr, *cz = nullptr, *z = nullptr;          // scratch reused across prove calls
+  sp_table *rx = nullptr, *abc = nullptr;
+  std::vector<aff_t> comm_W_precommitted;
+  std::vector<fe_t> r_W_precommitted;
+  std::vector<uint8_t> comm_pre_bytes;
+  ~SpartanPrepSNARK() {
+    for (sp_table* t : {W, caz, cbz, ccz, az, bz, cz, z, rx, abc}) sp_table_free(t);
+  }
+};
+
+struct SpartanProofBuf {  // SpartanSNARK (src/spartan.rs:130-138) in the canonical flat layout of DESIGN.md
+  std::vector<uint64_t> words;
+  void pf(const fe_t& f) { words.insert(words.end(), u64p(&f), u64p(&f) + 4); }
+  void pp(const aff_t& a) {
+    pf(a.x);
+    pf(a.y);
+  }
+};
+
+struct PhaseTimes {
+  double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // witness_commit, matvec, outer, poly_abc, inner, pcs, total, (spare)
+};
+
+// SpartanSNARK::setup (src/spartan.rs:146-173)
+SpartanProverKey* setup(sp_ctx* ctx, const R1CSIntView& R) {
+  auto* pk = new SpartanProverKey();
+  try {
+    pk->ctx = ctx;
+    PaddedShape P = pad_shape(R);
+    pk->dims = P.dims;
+    pk->num_vars = P.num_vars();
+    pk->num_extra = 1 + P.dims.num_public + P.dims.num_challenges;
+    pk->num_cols = P.num_cols();
+    sp_csr cs[3];
+    for (int m = 0; m < 3; ++m) cs[m] = sp_csr{u64p(P.data[m].data()), P.idx[m].data(), P.ptr[m].data()};
+    ck(sp_shape_from_csr(ctx, &cs[0], &cs[1], &cs[2], &P.dims, &pk->S), "shape_from_csr");
+    pk->gens = from_label("ck", DEFAULT_COMMITMENT_WIDTH + 1);  // commitment_key (src/r1cs/mod.rs:1031-1043) -> PCS::setup(b"ck", ., 2048)
+    pk->gens_s = from_label("ck_s", 2);                          // PCS::setup(b"ck_s", 1, 1)
+    ck(sp_ck_create(ctx, u64p(&pk->gens[0].x), DEFAULT_COMMITMENT_WIDTH, u64p(&pk->gens[DEFAULT_COMMITMENT_WIDTH].x), &pk->ck), "ck_create");
+    ck(sp_ck_create(ctx, u64p(&pk->gens_s[0].x), 1, u64p(&pk->gens_s[1].x), &pk->ck_s), "ck_s_create");
+    shape_digest(P, pk->vk_digest);
+  } catch (...) {
+    delete pk;
+    throw;
+  }
+  return pk;
+}
+
+// SpartanSNARK::prep_prove (src/spartan.rs:176-216)
+SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness_u64, size_t n_witness, bool is_small, Tape& tape) {
+  const sp_dims& d = pk.dims;
+  if (d.num_shared_unpadded != 0 || d.num_rest_unpadded != 0 || d.num_challenges != 0)
+    throw Error(SP_ERR_INTERNAL, "only precommitted-only circuits (the bench circuits) are driven by this host layer");
+  if (n_witness != d.num_precommitted_unpadded) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
+  auto* ps = new SpartanPrepSNARK();
+  try {
+    sp_ctx* ctx = pk.ctx;
+    const size_t M = pk.num_vars, N = d.num_cons;
+    // precommitted_witness (bellpepper/r1cs.rs:359-409): W[num_shared .. num_shared + unpadded] = aux assignment
+    std::vector<fe_t> W(M, fe_zero());
+    const fe_t one = fe_one<S>();
+    for (size_t i = 0; i < n_witness; ++i) {
+      uint64_t v = witness_u64[i];
+      W[d.num_shared + i] = v == 0 ? fe_zero() : (v == 1 ? one : fe_from_u64<S>(v));
+    }
+    ck(sp_table_from_host(ctx, u64p(W.data()), M, (size_t)-1, (size_t)-1, &ps->W), "upload W");
+    const size_t rows_pre = (d.num_precommitted + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH;
+    ps->r_W_precommitted.resize(rows_pre);  // PCS::blind (hyrax_pc.rs:192-205)
+    for (auto& b : ps->r_W_precommitted) b = tape.next();
+    ps->comm_W_precommitted.resize(rows_pre);
+    ck(sp_hyrax_commit(ctx, pk.ck, ps->W, d.num_shared, d.num_precommitted, u64p(ps->r_W_precommitted.data()), is_small ? 1 : 0,
+                       u64p(&ps->comm_W_precommitted[0].x)),
+       "commit precommitted");
+    ps->comm_pre_bytes = commitment_bytes(ps->comm_W_precommitted.data(), rows_pre);
+    // multiply_vec_precommitted (src/r1cs/mod.rs:1112-1128): z = [W_cached | 0 ...]
+    ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->z), "alloc z");
+    ck(sp_table_copy(ctx, ps->z, 0, ps->W, 0, d.num_shared + d.num_precommitted), "copy W");
+    ck(sp_table_set_len(ps->z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
+    for (sp_table** t : {&ps->caz, &ps->cbz, &ps->ccz, &ps->az, &ps->bz, &ps->cz}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc Az");
+    ck(sp_multiply_vec(ctx, pk.S, ps->z, ps->caz, ps->cbz, ps->ccz), "multiply_vec_precommitted");
+    ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &ps->rx), "alloc rx");
+    ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->abc), "alloc poly_ABC");
+    ck(sp_ctx_synchronize(ctx), "sync");
+  } catch (...) {
+    delete ps;
+    throw;
+  }
+  return ps;
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// SpartanSNARK::prove (src/spartan.rs:219-466)
+SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, PhaseTimes* pt) {
+  const sp_dims& d = pk.dims;
+  sp_ctx* ctx = pk.ctx;
+  const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
+  if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
+  const double t_start = now_ms();
+  std::vector<fe_t> publics(npub);
+  for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
+
+  Tr tr(ctx, "SpartanSNARK");
+  tr.absorb("vk", pk.vk_digest, 32);
+  tr.absorb_scalars("public_values", publics.data(), npub);
+  // r1cs_instance_and_witness (bellpepper/r1cs.rs:411-538), skip_synthesize path
+  tr.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
+  const size_t rows_pre = ps.comm_W_precommitted.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
+  std::vector<fe_t> r_W_rest(rows_rest);
+  for (auto& b : r_W_rest) b = tape.next();
+  std::vector<aff_t> comm_W(rows_pre + rows_rest);
+  std::copy(ps.comm_W_precommitted.begin(), ps.comm_W_precommitted.end(), comm_W.begin());
+  if (rows_rest) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, u64p(&comm_W[rows_pre].x)), "commit_zeros");  // hyrax_pc.rs:305-319
+  {
+    std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
+    tr.absorb("comm_W_rest", b.data(), b.size());
+  }
+  std::vector<fe_t> r_W = ps.r_W_precommitted;  // combine_blinds
+  r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
+  const double t_wit = now_ms();
+
+  // z = [W | 1 | public]   (src/spartan.rs:246-253); the table is 2M long so the inner sum-check can run in place
+  ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
+  ck(sp_table_copy(ctx, ps.z, 0, ps.W, 0, M), "z <- W");
+  {
+    ck(sp_table_zero(ctx, ps.z, M, M), "clear z high half");  // what the previous prove left there
+    std::vector<fe_t> tail(pk.num_extra);
+    tail[0] = fe_one<S>();
+    std::copy(publics.begin(), publics.end(), tail.begin() + 1);
+    ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
+  }
+  ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
+  const size_t num_rounds_x = log2_ceil(N), num_rounds_y = log2_ceil(M) + 1;
+  std::vector<fe_t> tau(num_rounds_x);
+  for (auto& t : tau) t = tr.squeeze("t");
+
+  ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
+  const double t_mv = now_ms();
+
+  SpartanProofBuf proof;
+  for (const aff_t& a : comm_W) proof.pp(a);
+  for (const fe_t& f : publics) proof.pf(f);
+  // outer sum-check (src/spartan.rs:291-310)
+  std::vector<fe_t> outer_polys(3 * num_rounds_x), r_x(num_rounds_x);
+  fe_t claims_outer[3];
+  const fe_t zero = fe_zero();
+  ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, tr.t, u64p(outer_polys.data()), u64p(r_x.data()),
+                        u64p(claims_outer)),
+     "outer sum-check");
+  tr.absorb_scalars("claims_outer", claims_outer, 3);
+  for (const fe_t& f : outer_polys) proof.pf(f);
+  for (int i = 0; i < 3; ++i) proof.pf(claims_outer[i]);
+  const double t_outer = now_ms();
+
+  const fe_t r = tr.squeeze("r");
+  const fe_t claim_inner_joint = fe_add<S>(fe_add<S>(claims_outer[0], fe_mul<S>(r, claims_outer[1])), fe_mul<S>(fe_mul<S>(r, r), claims_outer[2]));
+  // evals_rx + bind_and_prepare_poly_ABC (src/spartan.rs:316-322)
+  ck(sp_eq_table_into(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");
+  ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
+  const double t_abc = now_ms();
+
+  // inner sum-check. The reference runs round 0 by hand on the compact vectors (src/spartan.rs:323-384); that round is
+  // value-identical to a generic prove_quad round on the 2M-long tables with (lo_eff, hi_eff) = (M, num_extra).
+  ck(sp_table_set_len(ps.abc, 2 * M, M, pk.num_extra), "abc len");
+  ck(sp_table_set_len(ps.z, 2 * M, M, pk.num_extra), "z len");
+  std::vector<fe_t> inner_polys(2 * num_rounds_y), r_y(num_rounds_y);
+  fe_t claims_inner[2];
+  ck(sp_sumcheck_quad(ctx, u64p(&claim_inner_joint), num_rounds_y, ps.abc, ps.z, tr.t, u64p(inner_polys.data()), u64p(r_y.data()), u64p(claims_inner)),
+     "inner sum-check");
+  for (const fe_t& f : inner_polys) proof.pf(f);
+  const fe_t eval_Z = claims_inner[1];
+  // eval_W = (eval_Z - r_y0 eval_X) / (1 - r_y0)   (src/spartan.rs:411-421)
+  std::vector<fe_t> X;
+  X.push_back(fe_one<S>());
+  X.insert(X.end(), publics.begin(), publics.end());
+  const fe_t eval_X = sparse_poly_evaluate(num_rounds_y - 1, X, r_y.data() + 1);
+  const fe_t denom = fe_sub<S>(fe_one<S>(), r_y[0]);
+  if (fe_is_zero(denom)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
+  const fe_t eval_W = fe_mul<S>(fe_sub<S>(eval_Z, fe_mul<S>(r_y[0], eval_X)), fe_inv<S>(denom));
+  const double t_inner = now_ms();
+
+  // pcs (src/spartan.rs:423-437)
+  const fe_t blind_eval_W = tape.next();
+  aff_t comm_eval_W;
+  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
+  proof.pf(eval_W);
+  proof.pf(blind_eval_W);
+  // HyraxPCS::prove (hyrax_pc.rs:387-478)
+  {
+    std::vector<uint8_t> b = commitment_bytes(comm_W.data(), comm_W.size());
+    tr.absorb("poly_com", b.data(), b.size());
+  }
+  const fe_t* point = r_y.data() + 1;
+  const size_t npoint = num_rounds_y - 1;
+  const size_t num_rows = (M + W_ - 1) / W_, nvr = log2_ceil(num_rows);
+  aff_t comm_LZ;
+  std::vector<fe_t> R, LZ;
+  fe_t r_LZ;
+  if (nvr == 0) {
+    comm_LZ = comm_W[0];
+    R = eq_evals_host(point, npoint);
+    LZ.resize(M);
+    ck(sp_table_read(ctx, ps.W, 0, M, u64p(LZ.data())), "read W");
+    r_LZ = r_W[0];
+  } else {
+    std::vector<fe_t> L = eq_evals_host(point, nvr);
+    R = eq_evals_host(point + nvr, npoint - nvr);
+    LZ.resize(R.size());
+    ck(sp_rowmat_vec(ctx, ps.W, L.size(), R.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
+    r_LZ = fe_zero();
+    for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], r_W[i]));
+    ck(sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ");
+  }
+  // InnerProductArgumentLinear::prove (ipa.rs:125-170)
+  tr.dom_sep("inner product argument (linear)");
+  {
+    uint8_t b[128];
+    point_bytes(comm_LZ, b);
+    point_bytes(comm_eval_W, b + 64);
+    tr.absorb("U", b, 128);
+  }
+  const size_t n = R.size();
+  std::vector<fe_t> dvec(n);
+  for (auto& x : dvec) x = tape.next();
+  const fe_t r_delta = tape.next(), r_beta = tape.next();
+  aff_t delta, beta;
+  ck(sp_msm_ck(ctx, pk.ck, u64p(dvec.data()), n, u64p(&r_delta), u64p(&delta.x)), "delta");
+  fe_t ip = fe_zero();
+  for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
+  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
+  {
+    uint8_t b[64];
+    point_bytes(delta, b);
+    tr.absorb("delta", b, 64);
+    point_bytes(beta, b);
+    tr.absorb("beta", b, 64);
+  }
+  const fe_t rr = tr.squeeze("r");
+  proof.pp(delta);
+  proof.pp(beta);
+  for (size_t i = 0; i < n; ++i) proof.pf(fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]));
+  proof.pf(fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta));
+  proof.pf(fe_add<S>(fe_mul<S>(rr, blind_eval_W), r_beta));
+  const double t_end = now_ms();
+  if (pt) {
+    pt->ms[0] = t_wit - t_start;
+    pt->ms[1] = t_mv - t_wit;
+    pt->ms[2] = t_outer - t_mv;
+    pt->ms[3] = t_abc - t_outer;
+    pt->ms[4] = t_inner - t_abc;
+    pt->ms[5] = t_end - t_inner;
+    pt->ms[6] = t_end - t_start;
+  }
+  return proof;
+}
+
+}  // namespace spartan2
+
+// ---- C surface for the harness (tests, bench.py) -----------------------------------------------------------------------------
+using namespace spartan2;
+static thread_local std::string g_err;
+static int catch_all() {
+  try {
+    throw;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return SP_ERR_INTERNAL;
+  }
+}
+
+extern "C" {
+const char* ss_last_error() { return g_err.c_str(); }
+
+static R1CSIntView make_view(size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges,
+                             const int64_t* Ad, const uint32_t* Ai, const uint64_t* Ap, const int64_t* Bd, const uint32_t* Bi, const uint64_t* Bp,
+                             const int64_t* Cd, const uint32_t* Ci, const uint64_t* Cp) {
+  R1CSIntView R{num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges, {{Ad, Ai, Ap}, {Bd, Bi, Bp}, {Cd, Ci, Cp}}};
+  return R;
+}
+
+// SplitR1CSShape::new for callers that drive the sparse kernels directly. Returns an opaque PaddedShape.
+int ss_pad_shape(size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges, const int64_t* Ad,
+                 const uint32_t* Ai, const uint64_t* Ap, const int64_t* Bd, const uint32_t* Bi, const uint64_t* Bp, const int64_t* Cd, const uint32_t* Ci,
+                 const uint64_t* Cp, void** out) {
+  try {
+    *out = new PaddedShape(pad_shape(make_view(num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges, Ad, Ai, Ap, Bd, Bi, Bp, Cd, Ci, Cp)));
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+void ss_padded_free(void* p) { delete (PaddedShape*)p; }
+void ss_padded_dims(void* p, uint64_t out[10]) { memcpy(out, &((PaddedShape*)p)->dims, sizeof(sp_dims)); }
+void ss_padded_csr(void* p, int which, const uint64_t** data, const uint32_t** idx, const uint64_t** ptr, uint64_t* nnz) {
+  auto* P = (PaddedShape*)p;
+  *data = u64p(P->data[which].data());
+  *idx = P->idx[which].data();
+  *ptr = P->ptr[which].data();
+  *nnz = P->data[which].size();
+}
+int ss_from_label(const char* label, size_t n, uint64_t* out) {
+  try {
+    std::vector<aff_t> g = from_label(label, n);
+    memcpy(out, g.data(), n * sizeof(aff_t));
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+
+int ss_setup(sp_ctx* ctx, size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges,
+             const int64_t* Ad, const uint32_t* Ai, const uint64_t* Ap, const int64_t* Bd, const uint32_t* Bi, const uint64_t* Bp, const int64_t* Cd,
+             const uint32_t* Ci, const uint64_t* Cp, void** out_pk) {
+  try {
+    *out_pk = setup(ctx, make_view(num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges, Ad, Ai, Ap, Bd, Bi, Bp, Cd, Ci, Cp));
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+void ss_pk_free(void* pk) { delete (SpartanProverKey*)pk; }
+void ss_pk_info(void* pk_, uint64_t dims_out[10], uint8_t digest[32]) {
+  auto* pk = (SpartanProverKey*)pk_;
+  memcpy(dims_out, &pk->dims, sizeof(sp_dims));
+  memcpy(digest, pk->vk_digest, 32);
+}
+int ss_prep_prove(void* pk, const uint64_t* witness_u64, size_t n, int is_small, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, void** out_ps) {
+  try {
+    Tape t{tape, tape_blocks};
+    *out_ps = prep_prove(*(SpartanProverKey*)pk, witness_u64, n, is_small != 0, t);
+    if (tape_used) *tape_used = t.pos;
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+void ss_prep_free(void* ps) { delete (SpartanPrepSNARK*)ps; }
+// comm_W_precommitted rows (affine) and the cached Az/Bz/Cz for parity checks
+int ss_prep_export(void* pk_, void* ps_, uint64_t* comm_rows, uint64_t* caz, uint64_t* cbz, uint64_t* ccz) {
+  try {
+    auto* pk = (SpartanProverKey*)pk_;
+    auto* ps = (SpartanPrepSNARK*)ps_;
+    if (comm_rows) memcpy(comm_rows, ps->comm_W_precommitted.data(), ps->comm_W_precommitted.size() * sizeof(aff_t));
+    const size_t N = pk->dims.num_cons;
+    if (caz) ck(sp_table_read(pk->ctx, ps->caz, 0, N, caz), "read caz");
+    if (cbz) ck(sp_table_read(pk->ctx, ps->cbz, 0, N, cbz), "read cbz");
+    if (ccz) ck(sp_table_read(pk->ctx, ps->ccz, 0, N, ccz), "read ccz");
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+size_t ss_proof_words(void* pk_) {
+  auto* pk = (SpartanProverKey*)pk_;
+  const sp_dims& d = pk->dims;
+  size_t rows = (d.num_precommitted + 2047) / 2048 + (d.num_rest + 2047) / 2048;
+  size_t lx = log2_ceil(d.num_cons), ly = log2_ceil(pk->num_vars) + 1, nz = pk->num_vars < 2048 ? pk->num_vars : 2048;
+  return 8 * rows + 4 * d.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
+}
+// prove() — writes the proof in the canonical layout; phase_ms[7]: witness_commit, matrix_vector_multiply, outer_sumcheck,
+// prepare_poly_ABC, inner_sumcheck, pcs_prove, total (the reference's span names, src/spartan.rs:267-437)
+int ss_prove(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words,
+             size_t out_cap, double* phase_ms) {
+  try {
+    Tape t{tape, tape_blocks};
+    PhaseTimes pt;
+    SpartanProofBuf pf = prove(*(SpartanProverKey*)pk, *(SpartanPrepSNARK*)ps, publics_u64, npub, t, &pt);
+    if (pf.words.size() > out_cap) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "proof buffer too small");
+    memcpy(out_words, pf.words.data(), pf.words.size() * 8);
+    if (tape_used) *tape_used = t.pos;
+    if (phase_ms) memcpy(phase_ms, pt.ms, 7 * sizeof(double));
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+}

@@ -1,0 +1,178 @@
+"""GPU parity for the group side: MSM variants, Hyrax row commitments, fixed-base multiples, the row-matrix product —
+through the C ABI vs the CPU oracle, bit-exact on canonical affine coordinates. Mirrors src/provider/msm.rs:878-934
+(naive vs msm, msm vs msm_small at nine bit widths)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from oracle_lib import lib as olib, p64, to_mont
+from spartan2_amd import hip
+
+pytestmark = pytest.mark.gpu
+SEED = 0xDEADBEEF
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def gens():
+    g = np.zeros((2049, 8), dtype=np.uint64)
+    olib().orc_from_label(b"ck", ctypes.c_size_t(2049), p64(g))
+    return g
+
+
+def oracle_msm(scalars, bases):
+    out = np.zeros(8, dtype=np.uint64)
+    olib().orc_msm(p64(scalars), p64(bases), ctypes.c_size_t(len(scalars)), ctypes.c_size_t(1), p64(out))
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 31, 33, 100, 1000, 2048])
+def test_msm_matches_oracle(ctx, gens, n):
+    rng = np.random.default_rng(SEED + n)
+    scalars = ol.random_field_array(rng, n)
+    if n > 8:
+        scalars[1] = to_mont(1)  # scalar == 1 peel (msm.rs:93-95)
+        scalars[2] = 0
+        scalars[3] = to_mont(ol.MODULI[0] - 1)  # all-ones-ish digits exercise the carry window (msm.rs:137-145)
+    bases = np.ascontiguousarray(gens[:n])
+    assert (hip.msm(ctx, scalars, bases) == oracle_msm(scalars, bases)).all()
+
+
+def test_msm_naive_sum_small_n(ctx, gens):
+    # naive sum_i s_i * P_i, n = 8 (msm.rs:878-901)
+    rng = np.random.default_rng(SEED)
+    scalars = ol.random_field_array(rng, 8)
+    bases = np.ascontiguousarray(gens[:8])
+    naive = np.zeros(8, dtype=np.uint64)
+    olib().orc_msm_naive(p64(scalars), p64(bases), ctypes.c_size_t(8), p64(naive))
+    assert (hip.msm(ctx, scalars, bases) == naive).all()
+
+
+def test_msm_with_repeated_and_opposite_bases(ctx, gens):
+    """P + P (doubling inside a bucket) and P + (-P) (identity) must be handled exactly (vartime add special cases)."""
+    rng = np.random.default_rng(SEED + 5)
+    n = 64
+    bases = np.ascontiguousarray(gens[:n]).copy()
+    bases[1] = bases[0]
+    neg = bases[2].copy()
+    y = ol.from_mont(neg[4:], 1)
+    neg[4:] = ol.to_mont((-y) % ol.MODULI[1], 1)
+    bases[3] = neg
+    scalars = ol.random_field_array(rng, n)
+    scalars[1] = scalars[0]
+    scalars[3] = scalars[2]
+    assert (hip.msm(ctx, scalars, bases) == oracle_msm(scalars, bases)).all()
+
+
+@pytest.mark.parametrize("bits", [1, 4, 8, 10, 16, 20, 32, 40, 64])
+def test_msm_small_matches_full_msm(ctx, gens, bits):
+    # msm.rs:903-934
+    rng = np.random.default_rng(SEED + bits)
+    n = 300
+    small = rng.integers(0, 2**bits if bits < 64 else 2**63, size=n, dtype=np.uint64)
+    if bits == 64:
+        small = small * np.uint64(2) + np.uint64(1)
+    bases = np.ascontiguousarray(gens[:n])
+    want = np.zeros(8, dtype=np.uint64)
+    olib().orc_msm_small(p64(small), p64(bases), ctypes.c_size_t(n), p64(want))
+    assert (hip.msm_small(ctx, small, bases) == want).all()
+    sc = ol.mont_array([int(v) for v in small])
+    assert (hip.msm(ctx, sc, bases) == want).all()
+
+
+@pytest.fixture(scope="module")
+def key(ctx, gens):
+    return hip.CommitmentKey(ctx, gens[:2048], gens[2048])
+
+
+def oracle_key():
+    return ctypes.c_void_p(olib().orc_hyrax_setup(b"ck", ctypes.c_size_t(2048)))
+
+
+def test_fixed_base_mul_h(ctx, key, gens):
+    rng = np.random.default_rng(SEED + 100)
+    ks = ol.random_field_array(rng, 70)
+    ks[0] = 0
+    ks[1] = to_mont(1)
+    ks[2] = to_mont(255)
+    ks[3] = to_mont(256)
+    want = np.zeros((70, 8), dtype=np.uint64)
+    olib().orc_fixed_base_mul(p64(np.ascontiguousarray(gens[2048])), p64(ks), ctypes.c_size_t(70), p64(want))
+    assert (key.fixed_base_mul_h(ks) == want).all()
+
+
+@pytest.mark.parametrize("kind", ["bits", "small", "full", "mixed_rows"])
+def test_hyrax_commit_matches_oracle(ctx, key, kind):
+    # PCS::commit (hyrax_pc.rs:207-303): zero rows, trailing zeros, binary / small / full scalar rows
+    rng = np.random.default_rng(SEED + 200)
+    n = 2048 * 3 + 100  # ragged last row
+    v = np.zeros((n, 4), dtype=np.uint64)
+    one = to_mont(1)
+    if kind == "bits":
+        bits = rng.integers(0, 2, size=n)
+        v[bits == 1] = one
+        v[2048:4096] = 0  # an all-zero row
+        v[5000:6144] = 0  # trailing zeros in row 2
+    elif kind == "small":
+        vals = rng.integers(0, 1 << 20, size=n)
+        v[:] = ol.mont_array([int(x) for x in vals])
+    elif kind == "full":
+        v[:] = ol.random_field_array(rng, n)
+    else:
+        bits = rng.integers(0, 2, size=2048)
+        v[:2048][bits == 1] = one
+        v[2048:4096] = ol.mont_array([int(x) for x in rng.integers(0, 1 << 9, size=2048)])
+        v[4096:6144] = ol.random_field_array(rng, 2048)
+    rows = (n + 2047) // 2048
+    blinds = ol.random_field_array(rng, rows)
+    ok = oracle_key()
+    want = np.zeros((rows, 8), dtype=np.uint64)
+    assert olib().orc_hyrax_commit(ok, p64(v), ctypes.c_size_t(n), p64(blinds), 1 if kind in ("bits", "small") else 0, p64(want)) == 0
+    olib().orc_hyrax_free(ok)
+    t = hip.Table.from_host(ctx, np.concatenate([np.zeros((7, 4), dtype=np.uint64), v]))  # commit at an offset inside a table
+    got = key.commit(t, 7, n, blinds)
+    assert (got == want).all()
+
+
+def test_rowmat_vec(ctx):
+    # bind_with_delayed (hyrax_pc.rs:38-54)
+    rng = np.random.default_rng(SEED + 300)
+    for rows, cols in ((1, 64), (8, 2048), (37, 256)):
+        poly = ol.random_field_array(rng, rows * cols)
+        L = ol.random_field_array(rng, rows)
+        want = np.zeros((cols, 4), dtype=np.uint64)
+        olib().orc_rowmat_vec(p64(poly), p64(L), ctypes.c_size_t(rows), ctypes.c_size_t(cols), p64(want))
+        got = hip.rowmat_vec(ctx, hip.Table.from_host(ctx, poly), rows, cols, L)
+        assert (got == want).all()
+
+
+def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):
+    rng = np.random.default_rng(SEED + 400)
+    sc = ol.random_field_array(rng, 2048)
+    blind = ol.random_field_array(rng, 1)[0]
+    msm_part = oracle_msm(sc, np.ascontiguousarray(gens[:2048]))
+    hb = np.zeros((1, 8), dtype=np.uint64)
+    olib().orc_fixed_base_mul(p64(np.ascontiguousarray(gens[2048])), p64(blind.reshape(1, 4)), ctypes.c_size_t(1), p64(hb))
+    want = np.zeros(8, dtype=np.uint64)
+    olib().orc_point_add(p64(msm_part), p64(hb[0]), p64(want))
+    assert (key.msm(sc, blind) == want).all()
+    assert (key.msm(sc) == msm_part).all()
+    # width-1 key (ck_s of src/spartan.rs:151): value * g + blind * h
+    gs = np.zeros((2, 8), dtype=np.uint64)
+    olib().orc_from_label(b"ck_s", ctypes.c_size_t(2), p64(gs))
+    ks = hip.CommitmentKey(ctx, gs[:1], gs[1])
+    val = ol.random_field_array(rng, 1)
+    a = np.zeros(8, dtype=np.uint64)
+    b = np.zeros(8, dtype=np.uint64)
+    olib().orc_point_mul(p64(np.ascontiguousarray(gs[0])), p64(val[0]), p64(a))
+    olib().orc_point_mul(p64(np.ascontiguousarray(gs[1])), p64(blind), p64(b))
+    olib().orc_point_add(p64(a), p64(b), p64(want))
+    assert (ks.commit_small(val, blind) == want).all()

@@ -1,0 +1,56 @@
+"""CPU-side checks of the host layer above the C ABI (no GPU): shape padding, generator derivation and the integer R1CS
+frontend, each against the oracle's independent restatement."""
+import ctypes
+import hashlib
+
+import numpy as np
+
+import oracle_lib as ol
+from oracle_lib import lib as olib, p64
+from spartan2_amd import frontend, host
+
+
+def test_from_label_matches_oracle_derivation():
+    for label, n in ((b"ck", 40), (b"ck_s", 2)):
+        want = np.zeros((n, 8), dtype=np.uint64)
+        olib().orc_from_label(label, ctypes.c_size_t(n), p64(want))
+        assert (host.from_label(label, n) == want).all()
+
+
+def test_pad_shape_matches_oracle_shape():
+    # SplitR1CSShape::new (src/r1cs/mod.rs:810-911)
+    for inst in (frontend.synthetic_circuit(7, 1, num_public=3), frontend.sha256_circuit(b"abc")):
+        mats, dims = host.pad_shape(inst)
+        o = ol.OracleShape(inst)
+        assert dims["num_cons"] == o.num_cons and dims["num_cons_unpadded"] == inst.num_cons
+        assert (dims["num_shared"], dims["num_precommitted"], dims["num_rest"]) == (o.num_shared, o.num_precommitted, o.num_rest)
+        assert dims["num_precommitted"] % 2048 == 0
+        M = dims["num_shared"] + dims["num_precommitted"] + dims["num_rest"]
+        assert M & (M - 1) == 0 and dims["num_cons"] & (dims["num_cons"] - 1) == 0
+        for (d, i, p_), (di, ii, pi) in zip(mats, inst.csr):
+            assert len(p_) == dims["num_cons"] + 1 and p_[-1] == len(d) == len(di)
+            # aux columns keep their index (no shared part), inputs move behind the padded variables
+            aux = ii < inst.num_aux
+            assert (i[aux] == ii[aux]).all() and (i[~aux] == ii[~aux] + (M - inst.num_aux)).all()
+            assert ol.ints_of(d[:50]) == [int(v) % ol.MODULI[0] for v in di[:50]]
+
+
+def test_sha256_frontend_against_hashlib_and_reference_constraint_count():
+    for msg in (b"", b"abc", bytes(range(64)), bytes(200)):
+        inst = frontend.sha256_circuit(msg)
+        digest = hashlib.sha256(msg).digest()
+        bits = [(digest[i // 8] >> (7 - i % 8)) & 1 for i in range(256)]
+        assert list(inst.publics) == bits  # public_values of benches/sha256_spartan.rs:53-69
+        assert set(np.unique(inst.witness)) <= {0, 1}  # is_small = true holds: every witness value is a bit
+    # one compression with constant IV over 512 allocated bits is "~26,352" constraints (benches/sha256_neutronnova.rs:159)
+    one = frontend.sha256_circuit(bytes(55))  # 440 message bits + padding in one block
+    assert abs((one.num_cons - 256 - 440 + 512) - 26352) < 100
+
+
+def test_vk_digest_substitute_matches_oracle():
+    import torch
+
+    if not torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("setup uploads the shape to the device")
