@@ -48,6 +48,8 @@ int sp_ctx_synchronize(sp_ctx* ctx);
  * (what = "bind", "eval_cubic", "eval_quad", ...): accumulated milliseconds, launches and algorithmic bytes. */
 int sp_ctx_kernel_stats(sp_ctx* ctx, const char* what, double* ms, uint64_t* launches, uint64_t* alg_bytes);
 int sp_ctx_reset_stats(sp_ctx* ctx, int enable_timing);
+/* restrict the instrumentation to one kernel class (NULL or "" = all) */
+int sp_ctx_stats_filter(sp_ctx* ctx, const char* only);
 
 /* ---- MultilinearPolynomial (src/polys/multilinear.rs:34-164) ------------------------------------- */
 /* MultilinearPolynomial::new / new_with_halves (:62-75). lo_eff/hi_eff = SIZE_MAX for "unknown". */
@@ -138,6 +140,11 @@ int sp_rowmat_vec(sp_ctx* ctx, const sp_table* poly, size_t rows, size_t cols, c
 /* vartime_multiscalar_mul(scalars, ck[..n]) + h * blind against a device-resident key (hyrax_pc.rs:454-455, ipa.rs:147);
  * blind may be NULL for the bare MSM */
 int sp_msm_ck(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t* blind, uint64_t out_aff[8]);
+/* The same MSM split in two so it can overlap other work (the reference gets this overlap from rayon): begin() enqueues the
+ * device part on the context's auxiliary stream and returns; finish() waits, adds h * blind (may be NULL) and frees the job. */
+typedef struct sp_msm_job sp_msm_job;
+int sp_msm_ck_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_msm_job** job);
+int sp_msm_ck_finish(sp_ctx* ctx, const sp_ck* ck, sp_msm_job* job, const uint64_t* blind, uint64_t out_aff[8]);
 /* PCS::commit for keys of width <= 64, where the reference uses per-base FixedBaseMul tables (hyrax_pc.rs:221-260,
  * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
 int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);

@@ -52,11 +52,13 @@ int sp_ctx::ensure_scratch(size_t elems) {
   scratch_elems = elems;
   return SP_OK;
 }
-void* sp_ctx::workspace(int slot, size_t bytes) {
+void* sp_ctx::workspace(int slot, size_t bytes, int lane) {
+  slot += lane * WS_PER_LANE;
   if (bytes == 0) bytes = 16;
   if (bytes <= ws_bytes[slot]) return ws_ptr[slot];
   if (ws_ptr[slot]) {
     hipStreamSynchronize(stream);
+    hipStreamSynchronize(stream2);
     hipFree(ws_ptr[slot]);
     ws_ptr[slot] = nullptr;
     ws_bytes[slot] = 0;
@@ -107,8 +109,10 @@ int sp_ctx_create(int device, sp_ctx** out) {
   sp_ctx* c = new sp_ctx();
   c->device = device;
   SP_HIP(hipStreamCreate(&c->stream));
+  SP_HIP(hipStreamCreate(&c->stream2));
   c->pinned_elems = 64;
-  SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t)));
+  SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
+  SP_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
   int rc = c->ensure_scratch(1 << 16);
   if (rc) return rc;
   *out = c;
@@ -124,6 +128,7 @@ void sp_ctx_destroy(sp_ctx* c) {
     if (c->ws_ptr[i]) hipFree(c->ws_ptr[i]);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->stream) hipStreamDestroy(c->stream);
+  if (c->stream2) hipStreamDestroy(c->stream2);
   delete c;
 }
 int sp_ctx_synchronize(sp_ctx* c) {
@@ -134,6 +139,10 @@ int sp_ctx_reset_stats(sp_ctx* c, int enable) {
   c->drain_stats();
   c->stats.clear();
   c->timing = enable != 0;
+  return SP_OK;
+}
+int sp_ctx_stats_filter(sp_ctx* c, const char* only) {
+  c->timing_only = only ? only : "";
   return SP_OK;
 }
 int sp_ctx_kernel_stats(sp_ctx* c, const char* what, double* ms, uint64_t* launches, uint64_t* alg_bytes) {
@@ -245,14 +254,18 @@ static int launch_bind(sp_ctx* c, sp_table** tabs, int nt, const fe_t& r) {
   return SP_OK;
 }
 
-// second-stage reduction of `nblocks` x nacc block partials in d_scratch -> host
-static int reduce_partials(sp_ctx* c, size_t nblocks, int nacc, fe_t* out_host) {
-  fe_t* d_out = c->d_scratch + c->scratch_elems - 8;
-  hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, d_out);
-  SP_HIP(hipMemcpyAsync(c->h_pinned, d_out, nacc * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
+// second-stage reduction of `nblocks` x nacc block partials in d_scratch, written straight into mapped pinned host memory
+static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
+  hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned);
+}
+static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host) {
   SP_HIP(hipStreamSynchronize(c->stream));
   for (int k = 0; k < nacc; ++k) out_host[k] = c->h_pinned[k];
   return SP_OK;
+}
+static int reduce_partials(sp_ctx* c, size_t nblocks, int nacc, fe_t* out_host) {
+  reduce_partials_launch(c, nblocks, nacc);
+  return reduce_partials_wait(c, nacc, out_host);
 }
 
 // ---- host-side O(1) glue: UniPoly (src/polys/univariate.rs) ----------------------------------------------------------
@@ -425,26 +438,37 @@ int sp_table_dot(sp_ctx* c, const sp_table* a, const sp_table* b, size_t n, uint
   return SP_OK;
 }
 
+static bool table_dense(const sp_table* t) { return sp::eff_lo(t) == t->len / 2 && sp::eff_hi(t) == t->len / 2; }
+
 int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
                      uint64_t* out_r, uint64_t out_final[8]) {
   if (A->len != B->len || A->len != ((size_t)1 << rounds)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: tables must have 2^rounds elements");
   fe_t claim = load_fe(claim_);
   const uint8_t lbl_c[1] = {'c'};
+  const size_t chunk = 256 * spk::EVAL_PPT;
+  int rc = c->ensure_scratch((A->len / 2 + chunk - 1) / chunk * 2 + 32);
+  if (rc) return rc;
+  bool have_sums = false;  // true when the previous fused launch already produced this round's sums
+  size_t pending_blocks = 0;
   for (size_t round = 0; round < rounds; ++round) {
-    size_t half = A->len / 2;
-    size_t len = sp::eff_pairs(A);
-    if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
-    if (half < len) len = half;
+    const size_t half = A->len / 2;
     fe_t sums[2] = {fe_zero(), fe_zero()};
-    if (len > 0) {
-      size_t chunk = 256 * spk::EVAL_PPT, blocks = (len + chunk - 1) / chunk;
-      int rc = c->ensure_scratch(blocks * 2 + 16);
-      if (rc) return rc;
-      c->timed("eval_quad", 128ull * len,
-               [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch); });
-      rc = reduce_partials(c, blocks, 2, sums);
+    if (!have_sums) {  // compute_eval_points_quad on the current tables (src/sumcheck.rs:128-174)
+      size_t len = sp::eff_pairs(A);
+      if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
+      if (half < len) len = half;
+      if (len > 0) {
+        size_t blocks = (len + chunk - 1) / chunk;
+        c->timed("eval_quad", 128ull * len,
+                 [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch); });
+        rc = reduce_partials(c, blocks, 2, sums);
+        if (rc) return rc;
+      }
+    } else {
+      rc = reduce_partials_wait(c, 2, sums);
       if (rc) return rc;
     }
+    (void)pending_blocks;
     // BDDT: eval_2 = 2 claim - 3 eval_0 + 2 t_inf (src/sumcheck.rs:211-215)
     fe_t e0 = sums[0], tinf = sums[1];
     fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
@@ -459,10 +483,24 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
     store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
     claim = poly_eval(poly, r_i);
     sp_table* tabs[2] = {A, B};
-    int rc = launch_bind(c, tabs, 2, r_i);
-    if (rc) return rc;
+    have_sums = false;
+    if (round + 1 < rounds && table_dense(A) && table_dense(B)) {
+      // fused: bind this round, evaluate the next (K1 + K3 in one pass over the tables)
+      const size_t q = A->len / 4;
+      size_t blocks = (q + chunk - 1) / chunk;
+      c->timed("bind", 48ull * A->len * 2, [&] {
+        hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch);
+      });
+      sp::after_bind(A);
+      sp::after_bind(B);
+      reduce_partials_launch(c, blocks, 2);
+      have_sums = true;
+    } else {
+      rc = launch_bind(c, tabs, 2, r_i);
+      if (rc) return rc;
+    }
   }
-  int rc = sp_table_read(c, A, 0, 1, out_final);
+  rc = sp_table_read(c, A, 0, 1, out_final);
   if (rc) return rc;
   return sp_table_read(c, B, 0, 1, out_final + 4);
 }
@@ -479,11 +517,12 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   // device pyramids: left over taus[1..first_half), right over taus[first_half..ell)
   const size_t nleft = first_half > 0 ? first_half - 1 : 0;
   size_t pyr_left = (size_t)2 << nleft, pyr_right = (size_t)2 << second_half;
-  size_t max_blocks = (N / 2 + 1023) / 1024 + 1;
+  const size_t chunk = 256 * spk::EVAL_PPT;
+  size_t max_blocks = (N / 2 + chunk - 1) / chunk + 1;
   size_t need = ell + pyr_left + pyr_right + max_blocks * 3 + 32;
   int rc = c->ensure_scratch(need);
   if (rc) return rc;
-  // layout: [partials (max_blocks*3)] [taus_left][taus_right][pyr_left][pyr_right] ... [result (last 8)]
+  // layout: [partials (max_blocks*3)] [taus_left][taus_right][pyr_left][pyr_right]
   fe_t* d_part = c->d_scratch;
   fe_t* d_tl = d_part + max_blocks * 3;
   fe_t* d_trt = d_tl + nleft;
@@ -495,68 +534,83 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_tl, (int)nleft, d_pl);
   hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_trt, (int)second_half, d_pr);
 
+  // eq tables of round `rnd` (1-based, src/sumcheck.rs:1011) for `half` pairs
+  struct EqSel {
+    const fe_t* eq_in;
+    const fe_t* eq_out;
+    int s, mode;
+  };
+  auto select_eq = [&](size_t rnd) {
+    EqSel e;
+    if (rnd < first_half) {  // poly_eqs_first_half (:1407-1420)
+      e.eq_out = d_pl + spk::eq_level_offset((int)(first_half - rnd));
+      e.eq_in = d_pr + spk::eq_level_offset((int)second_half);
+      e.s = (int)second_half;
+      e.mode = (((size_t)1 << e.s) >= chunk) ? 1 : 2;
+    } else {  // poly_eq_right_last_half (:1422-1428)
+      e.eq_in = d_pr + spk::eq_level_offset((int)(ell - rnd));
+      e.eq_out = nullptr;
+      e.s = 63;
+      e.mode = 0;
+    }
+    return e;
+  };
+  auto launch_eval = [&](size_t rnd, bool with_m1) {
+    const size_t half = A->len / 2;
+    const EqSel e = select_eq(rnd);
+    dim3 g((unsigned)((half + chunk - 1) / chunk)), b(256);
+#define SP_LAUNCH_EVAL(MODE, M1) \
+  hipLaunchKernelGGL((spk::k_eval_cubic<MODE, M1>), g, b, 0, c->stream, A->d, B->d, C->d, half, e.eq_in, e.eq_out, e.s, d_part)
+    if (!with_m1) {
+      if (e.mode == 0) SP_LAUNCH_EVAL(0, false);
+      else if (e.mode == 1) SP_LAUNCH_EVAL(1, false);
+      else SP_LAUNCH_EVAL(2, false);
+    } else {
+      if (e.mode == 0) SP_LAUNCH_EVAL(0, true);
+      else if (e.mode == 1) SP_LAUNCH_EVAL(1, true);
+      else SP_LAUNCH_EVAL(2, true);
+    }
+#undef SP_LAUNCH_EVAL
+    return (size_t)g.x;
+  };
+
   fe_t claim = load_fe(claim_);
   fe_t eval_eq_left = fe_one<S>();
   const fe_t one = fe_one<S>();
   const uint8_t lbl_c[1] = {'c'};
-  for (size_t rnd = 1; rnd <= ell; ++rnd) {  // `round` of the reference starts at 1 (:1011)
-    const size_t half = A->len / 2;
-    const bool in_first = rnd < first_half;
-    const fe_t* eq_in;
-    const fe_t* eq_out = nullptr;
-    int s;
-    int mode;
-    const size_t chunk = 256 * spk::EVAL_PPT;
-    if (in_first) {  // poly_eqs_first_half (:1407-1420)
-      eq_out = d_pl + spk::eq_level_offset((int)(first_half - rnd));
-      eq_in = d_pr + spk::eq_level_offset((int)second_half);
-      s = (int)second_half;
-      mode = (((size_t)1 << s) >= chunk) ? 1 : 2;
-    } else {  // poly_eq_right_last_half (:1422-1428)
-      eq_in = d_pr + spk::eq_level_offset((int)(ell - rnd));
-      s = 63;
-      mode = 0;
-    }
-    size_t blocks = (half + chunk - 1) / chunk;
-    auto launch = [&](bool with_m1) {
-      dim3 g((unsigned)blocks), b(256);
-#define SP_LAUNCH_EVAL(MODE, M1) \
-  hipLaunchKernelGGL((spk::k_eval_cubic<MODE, M1>), g, b, 0, c->stream, A->d, B->d, C->d, half, eq_in, eq_out, s, d_part)
-      if (!with_m1) {
-        if (mode == 0) SP_LAUNCH_EVAL(0, false);
-        else if (mode == 1) SP_LAUNCH_EVAL(1, false);
-        else SP_LAUNCH_EVAL(2, false);
-      } else {
-        if (mode == 0) SP_LAUNCH_EVAL(0, true);
-        else if (mode == 1) SP_LAUNCH_EVAL(1, true);
-        else SP_LAUNCH_EVAL(2, true);
-      }
-#undef SP_LAUNCH_EVAL
-    };
-    fe_t sums[3];
-    c->timed("eval_cubic", 160ull * half, [&] { launch(false); });
-    rc = reduce_partials(c, blocks, 2, sums);
-    if (rc) return rc;
-    fe_t t0 = sums[0], tinf = sums[1];
-    // derive_from_claim (:1276-1324)
+  // round 1 sums from a plain evaluation pass; later rounds get theirs from the fused bind+eval of the previous round
+  {
+    size_t blocks = 0;
+    c->timed("eval_cubic", 160ull * (A->len / 2), [&] { blocks = launch_eval(1, false); });
+    reduce_partials_launch(c, blocks, 2);
+  }
+  for (size_t rnd = 1; rnd <= ell; ++rnd) {
+    // host work that only needs earlier challenges runs while the device computes this round's sums
     const fe_t tau = taus[rnd - 1];
-    const fe_t eq0 = fe_sub<S>(one, tau);            // eq(tau, 0)
-    const fe_t slope = fe_sub<S>(tau, eq0);          // 2 tau - 1
-    const fe_t eqm1 = fe_sub<S>(eq0, slope);         // 2 - 3 tau
+    const fe_t eq0 = fe_sub<S>(one, tau);     // eq(tau, 0)
+    const fe_t slope = fe_sub<S>(tau, eq0);   // 2 tau - 1
+    const fe_t eqm1 = fe_sub<S>(eq0, slope);  // 2 - 3 tau
     const fe_t p = eval_eq_left;
     const fe_t l_0_p = fe_mul<S>(eq0, p);
     const fe_t l_1_p = fe_mul<S>(fe_add<S>(eq0, slope), p);
+    const bool invertible = !fe_is_zero(l_1_p);
+    const fe_t l_1_p_inv = invertible ? fe_inv<S>(l_1_p) : fe_zero();
+    fe_t sums[3];
+    rc = reduce_partials_wait(c, 2, sums);
+    if (rc) return rc;
+    const fe_t t0 = sums[0], tinf = sums[1];
+    // derive_from_claim (:1276-1324)
     fe_t s_0, s_1, s_leading, s_m1;
-    if (!fe_is_zero(l_1_p)) {
-      const fe_t l_1_p_inv = fe_inv<S>(l_1_p);
+    if (invertible) {
       s_0 = fe_mul<S>(l_0_p, t0);
       s_1 = fe_sub<S>(claim, s_0);
       const fe_t t_1 = fe_mul<S>(s_1, l_1_p_inv);
       s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
       const fe_t t_m1 = fe_sub<S>(fe_add<S>(fe_dbl<S>(tinf), fe_dbl<S>(t0)), t_1);
       s_m1 = fe_mul<S>(fe_mul<S>(eqm1, p), t_m1);
-    } else {  // fallback_three_inputs (:1327-1396): third sum t(-1) computed directly
-      c->timed("eval_cubic", 192ull * half, [&] { launch(true); });
+    } else {  // fallback_three_inputs (:1327-1396): third sum t(-1) computed directly on the (still unbound) tables
+      size_t blocks = 0;
+      c->timed("eval_cubic", 192ull * (A->len / 2), [&] { blocks = launch_eval(rnd, true); });
       rc = reduce_partials(c, blocks, 3, sums);
       if (rc) return rc;
       s_0 = fe_mul<S>(fe_mul<S>(eq0, p), t0);
@@ -585,9 +639,25 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
     store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
     store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
     claim = poly_eval(poly, r_i);
-    sp_table* tabs[3] = {A, B, C};
-    rc = launch_bind(c, tabs, 3, r_i);
-    if (rc) return rc;
+    if (rnd < ell) {
+      // K1 fused with next round's K2: bind with r_i, evaluate round rnd+1 from registers
+      const size_t q = A->len / 4;
+      const EqSel e = select_eq(rnd + 1);
+      dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
+      c->timed("bind", 48ull * A->len * 3, [&] {
+        if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part);
+        else if (e.mode == 1) hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part);
+        else hipLaunchKernelGGL((spk::k_bind_eval_cubic<2>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part);
+      });
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+      reduce_partials_launch(c, g.x, 2);
+    } else {
+      sp_table* tabs[3] = {A, B, C};
+      rc = launch_bind(c, tabs, 3, r_i);
+      if (rc) return rc;
+    }
     // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
   }

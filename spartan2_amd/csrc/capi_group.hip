@@ -17,6 +17,10 @@ struct sp_ck {
   aff_t h;
   aff_t* d_htable = nullptr;  // 32 * 255 affine multiples of h
   aff_t* d_cktables = nullptr;  // num_cols <= 64: one 32*255 table per base (hyrax_pc.rs:81-96 ck_tables)
+  std::vector<aff_t> h_tables;  // host copy of all tables (bases..., h): single multiplications are latency-bound -> host
+  size_t n_tables = 0;
+  const aff_t* host_table(size_t t) const { return h_tables.data() + t * 32 * 255; }
+  const aff_t* host_htable() const { return host_table(n_tables - 1); }
 };
 
 namespace {
@@ -62,50 +66,82 @@ void normalize_batch(const std::vector<jac_t>& pts, aff_t* out) {
   }
 }
 
-// Pippenger on the device for n canonical scalars already in HBM; returns the Jacobian sum on the host.
-int msm_device(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, size_t n, int windows, jac_t* result) {
-  *result = jac_identity();
+// Pippenger on the device for n canonical scalars already in HBM. `lane` selects the stream + workspace set.
+// msm_launch enqueues everything up to the device->host copy of the per-window sums; msm_finish waits and runs the window Horner.
+struct MsmPending {
+  int windows = 0;
+  int lane = 0;
+  std::vector<jac_t> w;
+};
+static hipStream_t lane_stream(sp_ctx* c, int lane) { return lane ? c->stream2 : c->stream; }
+
+int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n, int windows, int lane, MsmPending* pend) {
+  pend->windows = 0;
+  pend->lane = lane;
   if (n == 0) return SP_OK;
   if (n >= (1u << 31)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "msm: n too large");
-  unsigned* order = (unsigned*)c->workspace(sp_ctx::WS_MSM_ORDER, (size_t)windows * n * 4);
-  unsigned* start = (unsigned*)c->workspace(sp_ctx::WS_MSM_START, (size_t)windows * (spk::MSM_BUCKETS + 1) * 4);
-  jac_t* buckets = (jac_t*)c->workspace(sp_ctx::WS_MSM_BUCKETS, (size_t)windows * spk::MSM_BUCKETS * sizeof(jac_t));
-  jac_t* wsum = (jac_t*)c->workspace(sp_ctx::WS_MSM_WSUM, (size_t)windows * sizeof(jac_t));
+  hipStream_t st = lane_stream(c, lane);
+  const fe_t* d_canon = d_canon_in;
+  if (windows == spk::MSM_MAX_WINDOWS) {  // full-width scalars: fold signs so the top window is balanced
+    fe_t* folded = (fe_t*)c->workspace(sp_ctx::WS_MSM_FOLDED, n * sizeof(fe_t), lane);
+    if (!folded) return SP_ERR_NO_DEVICE;
+    size_t fb = (n + 255) / 256;
+    if (fb > 4096) fb = 4096;
+    hipLaunchKernelGGL(spk::k_fold_sign, dim3((unsigned)fb), dim3(256), 0, st, d_canon_in, n, folded);
+    d_canon = folded;
+  }
+  unsigned* order = (unsigned*)c->workspace(sp_ctx::WS_MSM_ORDER, (size_t)windows * n * 4, lane);
+  unsigned* start = (unsigned*)c->workspace(sp_ctx::WS_MSM_START, (size_t)windows * (spk::MSM_BUCKETS + 1) * 4, lane);
+  jac_t* buckets = (jac_t*)c->workspace(sp_ctx::WS_MSM_BUCKETS, (size_t)windows * spk::MSM_BUCKETS * sizeof(jac_t), lane);
+  jac_t* wsum = (jac_t*)c->workspace(sp_ctx::WS_MSM_WSUM, (size_t)windows * sizeof(jac_t), lane);
   if (!order || !start || !buckets || !wsum) return SP_ERR_NO_DEVICE;
-  c->timed("msm_sort", 32ull * n, [&] {
-    hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, c->stream, d_canon, (unsigned)n, order, start);
-  });
+  auto run = [&](const char* what, uint64_t bytes, auto&& f) {
+    if (lane == 0) c->timed(what, bytes, f);
+    else f();
+  };
+  run("msm_sort", 32ull * n, [&] { hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, st, d_canon, (unsigned)n, order, start); });
   unsigned lanes = (unsigned)windows * spk::MSM_BUCKETS * spk::MSM_LANES_PER_BUCKET;
-  c->timed("msm_bucket_sum", 96ull * n, [&] {
-    hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256), dim3(256), 0, c->stream, d_bases, (unsigned)n, order, start, windows, buckets);
+  run("msm_bucket_sum", 96ull * n, [&] {
+    hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256), dim3(256), 0, st, d_bases, (unsigned)n, order, start, windows, buckets);
   });
-  c->timed("msm_window_reduce", 0, [&] {
-    hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
-  });
-  std::vector<jac_t> w(windows);
-  SP_HIP(hipMemcpyAsync(w.data(), wsum, windows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  run("msm_window_reduce", 0, [&] { hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows), dim3(spk::MSM_BUCKETS), 0, st, buckets, wsum); });
+  pend->w.resize(windows);
+  pend->windows = windows;
+  SP_HIP(hipMemcpyAsync(pend->w.data(), wsum, windows * sizeof(jac_t), hipMemcpyDeviceToHost, st));
+  return SP_OK;
+}
+int msm_finish(sp_ctx* c, MsmPending* pend, jac_t* result) {
+  *result = jac_identity();
+  if (pend->windows == 0) return SP_OK;
+  SP_HIP(hipStreamSynchronize(lane_stream(c, pend->lane)));
   // Horner over windows, high to low (msm.rs:150-175): acc = 2^8 acc + W_w
   jac_t acc = jac_identity();
-  for (int i = windows - 1; i >= 0; --i) {
+  for (int i = pend->windows - 1; i >= 0; --i) {
     for (int k = 0; k < spk::MSM_C; ++k) acc = jac_dbl(acc);
-    acc = jac_add(acc, w[i]);
+    acc = jac_add(acc, pend->w[i]);
   }
   *result = acc;
   return SP_OK;
 }
+int msm_device(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, size_t n, int windows, jac_t* result) {
+  MsmPending pend;
+  int rc = msm_launch(c, d_canon, d_bases, n, windows, 0, &pend);
+  if (rc) return rc;
+  return msm_finish(c, &pend, result);
+}
 
-int upload_canonical(sp_ctx* c, const uint64_t* scalars, size_t n, fe_t** canon_out) {
-  fe_t* raw = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_RAW, n * sizeof(fe_t));
-  fe_t* canon = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_CANON, n * sizeof(fe_t));
+int upload_canonical(sp_ctx* c, const uint64_t* scalars, size_t n, fe_t** canon_out, int lane = 0) {
+  fe_t* raw = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_RAW, n * sizeof(fe_t), lane);
+  fe_t* canon = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_CANON, n * sizeof(fe_t), lane);
   if (!raw || !canon) return SP_ERR_NO_DEVICE;
+  hipStream_t st = lane ? c->stream2 : c->stream;
   if (n) {
-    SP_HIP(hipMemcpyAsync(raw, scalars, n * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+    SP_HIP(hipMemcpyAsync(raw, scalars, n * sizeof(fe_t), hipMemcpyHostToDevice, st));
     size_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(spk::k_to_canonical, dim3((unsigned)blocks), dim3(256), 0, c->stream, raw, n, canon);
+    hipLaunchKernelGGL(spk::k_to_canonical, dim3((unsigned)blocks), dim3(256), 0, st, raw, n, canon);
   }
-  SP_HIP(hipStreamSynchronize(c->stream));  // `scalars` is a borrowed host buffer
+  SP_HIP(hipStreamSynchronize(st));  // `scalars` is a borrowed host buffer (pageable: the copy is staged synchronously anyway)
   *canon_out = canon;
   return SP_OK;
 }
@@ -178,6 +214,9 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
   }
   hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), ntab * per, tables);
   SP_HIP(hipStreamSynchronize(c->stream));
+  k->n_tables = ntab;
+  k->h_tables.resize(ntab * per);
+  SP_HIP(hipMemcpy(k->h_tables.data(), tables, ntab * per * sizeof(aff_t), hipMemcpyDeviceToHost));
   if (ntab > 1) {
     k->d_cktables = tables;
     k->d_htable = tables + (ntab - 1) * per;
@@ -194,6 +233,18 @@ void sp_ck_free(sp_ck* k) {
   else if (k->d_htable) hipFree(k->d_htable);
   delete k;
 }
+
+// FixedBaseMul::mul on the host (msm.rs:691-725): <= 32 mixed additions
+static jac_t fixed_base_mul_host(const aff_t* table, const fe_t& scalar) {
+  const fe_t c = fe_to_canonical<S>(scalar);
+  jac_t acc = jac_identity();
+  for (int j = 0; j < 32; ++j) {
+    unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
+    if (digit) acc = jac_add_mixed(acc, table[(size_t)j * 255 + digit - 1]);
+  }
+  return acc;
+}
+static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU core beats the launch + single-wave latency
 
 // table[i % ntables] * scalars[i] on the device (Jacobian results in host memory); ntables == 1 for h
 static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n, std::vector<jac_t>& out) {
@@ -214,8 +265,17 @@ static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, con
 
 int sp_fixed_base_mul_h(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t* out_aff) {
   std::vector<jac_t> pts;
-  int rc = fixed_base_rows(c, ck->d_htable, 1, scalars, n, pts);
-  if (rc) return rc;
+  if (n <= FIXED_BASE_HOST_MAX) {
+    pts.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      fe_t sc;
+      memcpy(&sc, scalars + 4 * i, 32);
+      pts[i] = fixed_base_mul_host(ck->host_htable(), sc);
+    }
+  } else {
+    int rc = fixed_base_rows(c, ck->d_htable, 1, scalars, n, pts);
+    if (rc) return rc;
+  }
   std::vector<aff_t> a(n);
   normalize_batch(pts, a.data());
   if (n) memcpy(out_aff, a.data(), n * sizeof(aff_t));
@@ -289,9 +349,41 @@ int sp_msm_ck(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, con
   jac_t r;
   if ((rc = msm_device(c, canon, ck->d_bases, n, spk::MSM_MAX_WINDOWS, &r))) return rc;
   if (blind) {
-    std::vector<jac_t> hb;
-    if ((rc = fixed_base_rows(c, ck->d_htable, 1, blind, 1, hb))) return rc;
-    r = jac_add(r, hb[0]);
+    fe_t b;
+    memcpy(&b, blind, 32);
+    r = jac_add(r, fixed_base_mul_host(ck->host_htable(), b));
+  }
+  store_aff(out_aff, jac_to_affine(r));
+  return SP_OK;
+}
+
+// Asynchronous form of sp_msm_ck on the auxiliary stream: begin() enqueues the device work and returns, finish() waits,
+// runs the host-side Horner tail and adds h * blind.
+struct sp_msm_job {
+  MsmPending pend;
+};
+int sp_msm_ck_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_msm_job** out) {
+  if (n > ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "MSM: Coefficients and bases must have the same length");
+  fe_t* canon;
+  int rc;
+  if ((rc = upload_canonical(c, scalars, n, &canon, 1))) return rc;
+  sp_msm_job* job = new sp_msm_job();
+  if ((rc = msm_launch(c, canon, ck->d_bases, n, spk::MSM_MAX_WINDOWS, 1, &job->pend))) {
+    delete job;
+    return rc;
+  }
+  *out = job;
+  return SP_OK;
+}
+int sp_msm_ck_finish(sp_ctx* c, const sp_ck* ck, sp_msm_job* job, const uint64_t* blind, uint64_t out_aff[8]) {
+  jac_t r;
+  int rc = msm_finish(c, &job->pend, &r);
+  delete job;
+  if (rc) return rc;
+  if (blind) {
+    fe_t b;
+    memcpy(&b, blind, 32);
+    r = jac_add(r, fixed_base_mul_host(ck->host_htable(), b));
   }
   store_aff(out_aff, jac_to_affine(r));
   return SP_OK;
@@ -299,22 +391,19 @@ int sp_msm_ck(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, con
 
 int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]) {
   if (!ck->d_cktables || n > ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_small: key wider than 64 or too many scalars");
-  // one launch: n lookups in the per-base tables + 1 in the h table (tables are contiguous: bases then h)
-  std::vector<uint64_t> sc((n + 1) * 4);
-  memcpy(sc.data(), scalars, n * 32);
-  memcpy(sc.data() + 4 * n, blind, 32);
+  // FixedBaseMul::multi_mul (msm.rs:727-773) + h_table.mul(blind); n <= 64 single lookups chains: host
   std::vector<jac_t> parts;
-  // table index for element i is (ck->num_cols - n + i) ... simpler: run the bases and h separately when n < num_cols
-  int rc;
-  if (n == ck->num_cols) {
-    if ((rc = fixed_base_rows(c, ck->d_cktables, ck->num_cols + 1, sc.data(), n + 1, parts))) return rc;
-  } else {
-    std::vector<jac_t> a, b;
-    if ((rc = fixed_base_rows(c, ck->d_cktables, ck->num_cols + 1, sc.data(), n, a))) return rc;
-    if ((rc = fixed_base_rows(c, ck->d_htable, 1, blind, 1, b))) return rc;
-    parts = a;
-    parts.push_back(b[0]);
+  for (size_t i = 0; i < n; ++i) {
+    fe_t sc;
+    memcpy(&sc, scalars + 4 * i, 32);
+    parts.push_back(fixed_base_mul_host(ck->host_table(i), sc));
   }
+  {
+    fe_t b;
+    memcpy(&b, blind, 32);
+    parts.push_back(fixed_base_mul_host(ck->host_htable(), b));
+  }
+  (void)c;
   jac_t acc = jac_identity();
   for (const jac_t& p : parts) acc = jac_add(acc, p);
   store_aff(out_aff, jac_to_affine(acc));

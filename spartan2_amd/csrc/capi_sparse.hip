@@ -90,13 +90,36 @@ __global__ void __launch_bounds__(256) k_polyabc_short(PolyAbcArgs a, const fe_t
     out[col] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(a.r, sb)), fe_mul<S>(a.r2, sc));
   }
 }
+// Long columns (the constant-1 column has ~one entry per booleanity row): NB blocks share a column, each striding
+// over its entry lists; a second one-block pass per column adds the NB partial triples and applies (1, r, r^2).
+constexpr unsigned LONG_NB_MAX = 128;
+__device__ __forceinline__ unsigned long_nb(unsigned len) {
+  unsigned nb = (len + 2047) / 2048;
+  return nb < 1 ? 1 : (nb > LONG_NB_MAX ? LONG_NB_MAX : nb);
+}
 __global__ void __launch_bounds__(256) k_polyabc_long(PolyAbcArgs a, const fe_t* __restrict__ rx, const unsigned* __restrict__ long_cols,
-                                                      fe_t* __restrict__ out) {
+                                                      fe_t* __restrict__ partials) {
   __shared__ fe_t smem[3 * 4];
-  const size_t col = long_cols[blockIdx.x];
+  const size_t col = long_cols[blockIdx.y];
+  const unsigned nb = long_nb(col_len(a, col));
+  if (blockIdx.x >= nb) return;
   fe_t acc[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) acc[i] = gather_major(a.m[i], col, rx, threadIdx.x, blockDim.x);
+  for (int i = 0; i < 3; ++i) acc[i] = gather_major(a.m[i], col, rx, blockIdx.x * blockDim.x + threadIdx.x, nb * blockDim.x);
+  block_sum<3>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) partials[((size_t)blockIdx.y * LONG_NB_MAX + blockIdx.x) * 3 + i] = acc[i];
+  }
+}
+__global__ void __launch_bounds__(256) k_polyabc_long_final(PolyAbcArgs a, const unsigned* __restrict__ long_cols, const fe_t* __restrict__ partials,
+                                                            fe_t* __restrict__ out) {
+  __shared__ fe_t smem[3 * 4];
+  const size_t col = long_cols[blockIdx.x];
+  const unsigned nb = long_nb(col_len(a, col));
+  fe_t acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = threadIdx.x < nb ? partials[((size_t)blockIdx.x * LONG_NB_MAX + threadIdx.x) * 3 + i] : fe_zero();
   block_sum<3>(acc, smem);
   if (threadIdx.x == 0) out[col] = fe_add<S>(fe_add<S>(acc[0], fe_mul<S>(a.r, acc[1])), fe_mul<S>(a.r2, acc[2]));
 }
@@ -205,6 +228,7 @@ struct sp_shape {
   SplitOnDevice filtered[3];  // FilteredSpmv rows: col >= num_shared + num_precommitted, row < num_cons_unpadded
   SplitOnDevice col[3];       // column-major, rows < num_cons_unpadded (accumulate_rows)
   unsigned* d_long_cols = nullptr;
+  fe_t* d_long_partials = nullptr;
   size_t n_long_cols = 0;
   uint64_t nnz[3] = {0, 0, 0}, nnz_filtered[3] = {0, 0, 0};
 };
@@ -272,6 +296,7 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
   s->n_long_cols = long_cols.size();
   int rc = upload(&s->d_long_cols, long_cols);
   if (rc) return rc;
+  SP_HIP(hipMalloc((void**)&s->d_long_partials, (long_cols.size() + 1) * spk::LONG_NB_MAX * 3 * sizeof(fe_t)));
   *out = s;
   return SP_OK;
 }
@@ -283,6 +308,7 @@ void sp_shape_free(sp_shape* s) {
     s->col[m].release();
   }
   hipFree(s->d_long_cols);
+  hipFree(s->d_long_partials);
   delete s;
 }
 
@@ -332,8 +358,12 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
   uint64_t bytes = 36ull * (s->nnz[0] + s->nnz[1] + s->nnz[2]) + 32ull * out_len;
   c->timed("poly_abc", bytes, [&] {
     hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->num_cols, out->d);
-    if (s->n_long_cols)
-      hipLaunchKernelGGL(spk::k_polyabc_long, dim3((unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, rx->d, s->d_long_cols, out->d);
+    if (s->n_long_cols) {
+      hipLaunchKernelGGL(spk::k_polyabc_long, dim3(spk::LONG_NB_MAX, (unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, rx->d, s->d_long_cols,
+                         s->d_long_partials);
+      hipLaunchKernelGGL(spk::k_polyabc_long_final, dim3((unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, s->d_long_cols, s->d_long_partials,
+                         out->d);
+    }
   });
   return SP_OK;
 }

@@ -33,27 +33,31 @@ struct KStat {
 struct sp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // auxiliary stream: work that does not depend on the transcript (ipa.rs:139-147 delta) overlaps the sum-checks
   fe_t* d_scratch = nullptr;  // block partials etc.
   size_t scratch_elems = 0;
-  fe_t* h_pinned = nullptr;  // small result buffer, pinned
+  fe_t* h_pinned = nullptr;  // small result buffer, pinned + mapped
+  fe_t* d_pinned = nullptr;  // device-side address of h_pinned
   size_t pinned_elems = 0;
   bool timing = false;
+  std::string timing_only;  // when non-empty, only this kernel class is instrumented (keeps event overhead out of a timed region)
   std::map<std::string, sp::KStat> stats;
   std::vector<hipEvent_t> event_pool;
 
   // grow-only persistent device buffers, one per slot, so hot-path calls never hipMalloc/hipFree
   enum { WS_MSM_ORDER = 0, WS_MSM_START, WS_MSM_BUCKETS, WS_MSM_WSUM, WS_SCALARS_RAW, WS_SCALARS_CANON, WS_FB_SCALARS, WS_FB_OUT, WS_ROWMAT_L,
-         WS_ROWMAT_PART, WS_ROWMAT_OUT, WS_COMMIT_CANON, WS_COMMIT_FLAGS, WS_COMMIT_ROWS, WS_BASES_TMP, WS_SLOTS };
+         WS_ROWMAT_PART, WS_ROWMAT_OUT, WS_COMMIT_CANON, WS_COMMIT_FLAGS, WS_COMMIT_ROWS, WS_BASES_TMP, WS_MSM_FOLDED, WS_PER_LANE,
+         WS_SLOTS = 2 * WS_PER_LANE };  // lane 1 = the auxiliary stream used by asynchronous MSM jobs
   void* ws_ptr[WS_SLOTS] = {};
   size_t ws_bytes[WS_SLOTS] = {};
-  void* workspace(int slot, size_t bytes);
+  void* workspace(int slot, size_t bytes, int lane = 0);
 
   hipEvent_t get_event();
   int ensure_scratch(size_t elems);
   // records (start, stop) events around `launch` when timing is enabled
   template <class L>
   void timed(const char* what, uint64_t alg_bytes, L&& launch) {
-    if (!timing) {
+    if (!timing || (!timing_only.empty() && timing_only != what)) {
       launch();
       return;
     }

@@ -32,6 +32,26 @@ __device__ __forceinline__ jac_t shfl_down_jac(const jac_t& a, int delta) {
 __global__ void __launch_bounds__(256) k_to_canonical(const fe_t* __restrict__ in, size_t n, fe_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fe_to_canonical<SF>(in[i]);
 }
+// Sign folding for the digit path: s -> (min(s, n - s), sign) with n the group order, so every folded scalar is < 2^255:
+// the top byte is < 128, the carry window (msm.rs:137-145) stays almost empty and buckets are balanced. s*P == (n-s)*(-P).
+// The sign lives in bit 31 of limb 7 of the output.
+__global__ void __launch_bounds__(256) k_fold_sign(const fe_t* __restrict__ canon, size_t n, fe_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const fe_t c = canon[i];
+    fe_t d;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d.v[k] = sp_subb(SF::P(k), c.v[k], bw);  // n - c (c canonical, so no borrow)
+    uint32_t lt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) (void)sp_subb(d.v[k], c.v[k], lt);  // lt == 1 iff d < c
+    fe_t r = lt ? d : c;
+    if (fe_is_zero(c)) r = c;  // n - 0 == n is not a scalar
+    r.v[7] |= (lt && !fe_is_zero(c)) ? 0x80000000u : 0u;
+    out[i] = r;
+  }
+}
+
 // per-row classification for PCS::commit (hyrax_pc.rs:243-292): bit0 = row has a non-zero, bit1 = some value > 1,
 // bit2 = some value >= 2^64. rows of `cols` canonical scalars, last row may be short.
 __global__ void __launch_bounds__(256) k_classify_rows(const fe_t* __restrict__ canon, size_t n, size_t cols, unsigned* __restrict__ flags) {
@@ -60,7 +80,7 @@ __device__ __forceinline__ int signed_digit(const fe_t& c, int w) {
   int carry = 0;
   int d = 0;
   for (int k = 0; k <= w; ++k) {
-    int raw = (k < 32) ? (int)((c.v[k >> 2] >> (8 * (k & 3))) & 0xff) : 0;
+    int raw = (k < 32) ? (int)((c.v[k >> 2] >> (8 * (k & 3))) & (k == 31 ? 0x7f : 0xff)) : 0;  // bit 255 is the fold sign
     raw += carry;
     if (raw >= 128) {
       d = raw - 256;
@@ -100,10 +120,12 @@ __global__ void __launch_bounds__(256) k_msm_sort(const fe_t* __restrict__ canon
   __syncthreads();
   for (int k = threadIdx.x; k <= MSM_BUCKETS; k += blockDim.x) start[(size_t)w * (MSM_BUCKETS + 1) + k] = hist[k];
   for (unsigned j = threadIdx.x; j < n; j += blockDim.x) {
-    int d = signed_digit(canon[j], w);
+    const fe_t c = canon[j];
+    int d = signed_digit(c, w);
     if (d) {
       unsigned pos = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
-      order[(size_t)w * n + pos] = j | (d < 0 ? 0x80000000u : 0u);
+      const bool neg = (d < 0) != ((c.v[7] >> 31) != 0);
+      order[(size_t)w * n + pos] = j | (neg ? 0x80000000u : 0u);
     }
   }
 }

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_eq_outer(const fe_t* __restrict__ t_hi,
 // MODE 0: one table, E = eq_in[id]                       (second-half rounds, src/sumcheck.rs:1107-1147)
 // MODE 1: factored — a block's chunk lies inside one x_out, block sum is multiplied by eq_out once
 // MODE 2: direct — per-pair product eq_out * eq_in (tiny tables where a chunk spans several x_out)
-constexpr int EVAL_PPT = 4;  // pairs per thread
+constexpr int EVAL_PPT = 1;  // pairs per thread (1: the kernels are latency-bound per lane; more waves hide it better than more work per lane)
 template <int MODE, bool WITH_M1>
 __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
                                                     const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
@@ -120,6 +120,86 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
     }
 #pragma unroll
     for (int k = 0; k < NACC; ++k) partials[(size_t)blockIdx.x * NACC + k] = acc[k];
+  }
+}
+
+// ---- K1+K2 fused: bind round i with challenge r, evaluate round i+1 on the values just produced ------------------------
+// Tables have length L = 4q before the bind. Thread id in [0, q) owns the new pair (Z'[id], Z'[id+q]):
+//   Z'[x] = Z[x] + r (Z[x + 2q] - Z[x]),  x in {id, id + q}
+// reads 4 elements and writes 2 per table (in place, disjoint across threads), i.e. exactly the 48 L bytes/table of an
+// unfused bind; the next round's sums come from registers for free.
+__device__ __forceinline__ fe_t bind1(const fe_t& lo, const fe_t& hi, const fe_t& r) { return fe_add<S>(lo, fe_mul<S>(r, fe_sub<S>(hi, lo))); }
+template <int MODE>
+__global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r,
+                                                         const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
+                                                         fe_t* __restrict__ partials) {
+  __shared__ fe_t smem[2 * 4];
+  const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
+  const size_t base = (size_t)blockIdx.x * chunk;
+  const size_t mask = ((size_t)1 << s) - 1;
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+#pragma unroll 1
+  for (int k = 0; k < EVAL_PPT; ++k) {
+    const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
+    if (id < q) {
+      // issue all twelve element loads before any arithmetic: memory-level parallelism per lane is what fills HBM
+      const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+      const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+      const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
+      const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+      const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+      const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
+      A[id] = a0;
+      A[id + q] = a1;
+      B[id] = b0;
+      B[id + q] = b1;
+      C[id] = c0;
+      C[id + q] = c1;
+      fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
+      if (MODE == 2) w = fe_mul<S>(w, eq_out[id >> s]);
+      const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+      const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+      acc[0] = fe_add<S>(acc[0], fe_mul<S>(w, t0e));
+      acc[1] = fe_add<S>(acc[1], fe_mul<S>(w, tie));
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    if (MODE == 1) {
+      const fe_t eo = eq_out[base >> s];
+      acc[0] = fe_mul<S>(acc[0], eo);
+      acc[1] = fe_mul<S>(acc[1], eo);
+    }
+    partials[(size_t)blockIdx.x * 2] = acc[0];
+    partials[(size_t)blockIdx.x * 2 + 1] = acc[1];
+  }
+}
+// dense quadratic variant (both tables fully non-zero)
+__global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, fe_t* __restrict__ partials) {
+  __shared__ fe_t smem[2 * 4];
+  const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
+  const size_t base = (size_t)blockIdx.x * chunk;
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+#pragma unroll 1
+  for (int k = 0; k < EVAL_PPT; ++k) {
+    const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
+    if (id < q) {
+      const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+      const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+      const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+      const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+      A[id] = a0;
+      A[id + q] = a1;
+      B[id] = b0;
+      B[id + q] = b1;
+      acc[0] = fe_add<S>(acc[0], fe_mul<S>(a0, b0));
+      acc[1] = fe_add<S>(acc[1], fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)));
+    }
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    partials[(size_t)blockIdx.x * 2] = acc[0];
+    partials[(size_t)blockIdx.x * 2 + 1] = acc[1];
   }
 }
 

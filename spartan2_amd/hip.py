@@ -86,6 +86,9 @@ class Context:
     def reset_stats(self, enable=True):
         check(lib().sp_ctx_reset_stats(self.h, int(enable)))
 
+    def stats_filter(self, only: str = ""):
+        check(lib().sp_ctx_stats_filter(self.h, only.encode()))
+
     def kernel_stats(self, what: str):
         ms = ctypes.c_double()
         n = ctypes.c_uint64()

@@ -222,6 +222,10 @@ struct Tape {
     if (pos >= blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
     return fe_from_uniform<S>(bytes + 64 * pos++);
   }
+  void skip(size_t n) {
+    if (pos + n > blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
+    pos += n;
+  }
 };
 
 // EqPolynomial::evals_from_points on the host for the O(sqrt N) tables of the opening (src/polys/eq.rs:59-92)
@@ -385,6 +389,16 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
   }
+  // The IPA mask d_vec (ipa.rs:139-145) does not depend on the transcript: draw it now from its tape position and let
+  // delta's MSM (ipa.rs:147) run on the auxiliary stream underneath the two sum-checks.
+  const size_t n_ipa = M < W_ ? M : W_;
+  std::vector<fe_t> dvec(n_ipa);
+  {
+    Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
+    for (auto& x : dvec) x = peek.next();
+  }
+  sp_msm_job* delta_job = nullptr;
+  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
   std::vector<fe_t> r_W = ps.r_W_precommitted;  // combine_blinds
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
   const double t_wit = now_ms();
@@ -490,11 +504,11 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     tr.absorb("U", b, 128);
   }
   const size_t n = R.size();
-  std::vector<fe_t> dvec(n);
-  for (auto& x : dvec) x = tape.next();
+  if (n != n_ipa) throw Error(SP_ERR_INTERNAL, "IPA width mismatch");
+  tape.skip(n);  // the blocks that were peeked at the start
   const fe_t r_delta = tape.next(), r_beta = tape.next();
   aff_t delta, beta;
-  ck(sp_msm_ck(ctx, pk.ck, u64p(dvec.data()), n, u64p(&r_delta), u64p(&delta.x)), "delta");
+  ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
   fe_t ip = fe_zero();
   for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
