@@ -113,6 +113,8 @@ int sp_ctx_create(int device, sp_ctx** out) {
   c->pinned_elems = 64;
   SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
   SP_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
+  SP_HIP(hipHostMalloc(&c->h_pinned_lane[0], 8192));
+  SP_HIP(hipHostMalloc(&c->h_pinned_lane[1], 8192));
   int rc = c->ensure_scratch(1 << 16);
   if (rc) return rc;
   *out = c;
@@ -127,6 +129,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   for (int i = 0; i < sp_ctx::WS_SLOTS; ++i)
     if (c->ws_ptr[i]) hipFree(c->ws_ptr[i]);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  for (int i = 0; i < 2; ++i)
+    if (c->h_pinned_lane[i]) hipHostFree(c->h_pinned_lane[i]);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
   delete c;
@@ -256,6 +260,7 @@ static int launch_bind(sp_ctx* c, sp_table** tabs, int nt, const fe_t& r) {
 
 // second-stage reduction of `nblocks` x nacc block partials in d_scratch, written straight into mapped pinned host memory
 static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
+  if (nblocks == 1) return;  // a one-block evaluation wrote its sums straight to the pinned buffer
   hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned);
 }
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host) {
@@ -430,7 +435,7 @@ int sp_table_dot(sp_ctx* c, const sp_table* a, const sp_table* b, size_t n, uint
   if (blocks == 0) blocks = 1;
   int rc = c->ensure_scratch(blocks + 16);
   if (rc) return rc;
-  c->timed("dot", 64ull * n, [&] { hipLaunchKernelGGL(spk::k_dot, dim3((unsigned)blocks), dim3(256), 0, c->stream, a->d, b->d, n, c->d_scratch); });
+  c->timed("dot", 64ull * n, [&] { hipLaunchKernelGGL(spk::k_dot, dim3((unsigned)blocks), dim3(256), 0, c->stream, a->d, b->d, n, c->d_scratch, c->d_pinned); });
   fe_t r;
   rc = reduce_partials(c, blocks, 1, &r);
   if (rc) return rc;
@@ -460,7 +465,7 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       if (len > 0) {
         size_t blocks = (len + chunk - 1) / chunk;
         c->timed("eval_quad", 128ull * len,
-                 [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch); });
+                 [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch, c->d_pinned); });
         rc = reduce_partials(c, blocks, 2, sums);
         if (rc) return rc;
       }
@@ -489,7 +494,7 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       const size_t q = A->len / 4;
       size_t blocks = (q + chunk - 1) / chunk;
       c->timed("bind", 48ull * A->len * 2, [&] {
-        hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch);
+        hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch, c->d_pinned);
       });
       sp::after_bind(A);
       sp::after_bind(B);
@@ -560,7 +565,7 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
     const EqSel e = select_eq(rnd);
     dim3 g((unsigned)((half + chunk - 1) / chunk)), b(256);
 #define SP_LAUNCH_EVAL(MODE, M1) \
-  hipLaunchKernelGGL((spk::k_eval_cubic<MODE, M1>), g, b, 0, c->stream, A->d, B->d, C->d, half, e.eq_in, e.eq_out, e.s, d_part)
+  hipLaunchKernelGGL((spk::k_eval_cubic<MODE, M1>), g, b, 0, c->stream, A->d, B->d, C->d, half, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned)
     if (!with_m1) {
       if (e.mode == 0) SP_LAUNCH_EVAL(0, false);
       else if (e.mode == 1) SP_LAUNCH_EVAL(1, false);
@@ -645,9 +650,9 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
       const EqSel e = select_eq(rnd + 1);
       dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
       c->timed("bind", 48ull * A->len * 3, [&] {
-        if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part);
-        else if (e.mode == 1) hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part);
-        else hipLaunchKernelGGL((spk::k_bind_eval_cubic<2>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part);
+        if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned);
+        else if (e.mode == 1) hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned);
+        else hipLaunchKernelGGL((spk::k_bind_eval_cubic<2>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned);
       });
       sp::after_bind(A);
       sp::after_bind(B);

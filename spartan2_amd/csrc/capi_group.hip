@@ -105,15 +105,17 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
     hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256), dim3(256), 0, st, d_bases, (unsigned)n, order, start, windows, buckets);
   });
   run("msm_window_reduce", 0, [&] { hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows), dim3(spk::MSM_BUCKETS), 0, st, buckets, wsum); });
-  pend->w.resize(windows);
   pend->windows = windows;
-  SP_HIP(hipMemcpyAsync(pend->w.data(), wsum, windows * sizeof(jac_t), hipMemcpyDeviceToHost, st));
+  // pinned landing buffer: a device->host copy into pageable memory would block the host until the MSM is done
+  SP_HIP(hipMemcpyAsync(c->h_pinned_lane[lane], wsum, windows * sizeof(jac_t), hipMemcpyDeviceToHost, st));
   return SP_OK;
 }
 int msm_finish(sp_ctx* c, MsmPending* pend, jac_t* result) {
   *result = jac_identity();
   if (pend->windows == 0) return SP_OK;
   SP_HIP(hipStreamSynchronize(lane_stream(c, pend->lane)));
+  pend->w.resize(pend->windows);
+  memcpy(pend->w.data(), c->h_pinned_lane[pend->lane], pend->windows * sizeof(jac_t));
   // Horner over windows, high to low (msm.rs:150-175): acc = 2^8 acc + W_w
   jac_t acc = jac_identity();
   for (int i = pend->windows - 1; i >= 0; --i) {

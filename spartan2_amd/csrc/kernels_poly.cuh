@@ -84,7 +84,7 @@ constexpr int EVAL_PPT = 1;  // pairs per thread (1: the kernels are latency-bou
 template <int MODE, bool WITH_M1>
 __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
                                                     const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
-                                                    fe_t* __restrict__ partials) {
+                                                    fe_t* __restrict__ partials, fe_t* __restrict__ single_out) {
   constexpr int NACC = WITH_M1 ? 3 : 2;
   __shared__ fe_t smem[NACC * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
@@ -118,8 +118,9 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
 #pragma unroll
       for (int k = 0; k < NACC; ++k) acc[k] = fe_mul<S>(acc[k], eo);
     }
+    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * NACC;  // one block: its sums are the result
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) partials[(size_t)blockIdx.x * NACC + k] = acc[k];
+    for (int k = 0; k < NACC; ++k) dst[k] = acc[k];
   }
 }
 
@@ -132,7 +133,7 @@ __device__ __forceinline__ fe_t bind1(const fe_t& lo, const fe_t& hi, const fe_t
 template <int MODE>
 __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r,
                                                          const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
-                                                         fe_t* __restrict__ partials) {
+                                                         fe_t* __restrict__ partials, fe_t* __restrict__ single_out) {
   __shared__ fe_t smem[2 * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
@@ -170,12 +171,14 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, f
       acc[0] = fe_mul<S>(acc[0], eo);
       acc[1] = fe_mul<S>(acc[1], eo);
     }
-    partials[(size_t)blockIdx.x * 2] = acc[0];
-    partials[(size_t)blockIdx.x * 2 + 1] = acc[1];
+    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
+    dst[0] = acc[0];
+    dst[1] = acc[1];
   }
 }
 // dense quadratic variant (both tables fully non-zero)
-__global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, fe_t* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, fe_t* __restrict__ partials,
+                                                        fe_t* __restrict__ single_out) {
   __shared__ fe_t smem[2 * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
@@ -198,15 +201,16 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
-    partials[(size_t)blockIdx.x * 2] = acc[0];
-    partials[(size_t)blockIdx.x * 2 + 1] = acc[1];
+    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
+    dst[0] = acc[0];
+    dst[1] = acc[1];
   }
 }
 
 // ---- K3: quadratic evaluation sums ---------------------------------------------------------------------------------
 //   eval0 = sum_{i < len} A0 B0 ; tinf = sum_{i < len} (A1 - A0)(B1 - B0), len = min(eff_pairs(A), eff_pairs(B), half)
 __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t len,
-                                                   fe_t* __restrict__ partials) {
+                                                   fe_t* __restrict__ partials, fe_t* __restrict__ single_out) {
   __shared__ fe_t smem[2 * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
@@ -222,19 +226,21 @@ __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, c
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
-    partials[(size_t)blockIdx.x * 2] = acc[0];
-    partials[(size_t)blockIdx.x * 2 + 1] = acc[1];
+    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
+    dst[0] = acc[0];
+    dst[1] = acc[1];
   }
 }
 
 // dot product of the first n elements (value of DelayedReduction::reduce(sum a_i b_i))
-__global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t n, fe_t* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t n, fe_t* __restrict__ partials,
+                                             fe_t* __restrict__ single_out) {
   __shared__ fe_t smem[4];
   fe_t acc[1] = {fe_zero()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     acc[0] = fe_add<S>(acc[0], fe_mul<S>(A[i], B[i]));
   block_sum<1>(acc, smem);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+  if (threadIdx.x == 0) (gridDim.x == 1 ? single_out : partials + blockIdx.x)[0] = acc[0];
 }
 
 // out[k] = sum_b partials[b * nacc + k]; one block

@@ -13,6 +13,8 @@
 // in the reference's call order.
 // Generators: this build's own derivation (the reference's is a third-party hash-to-curve): PARITY UNPINNED, see DESIGN.md.
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -293,6 +295,7 @@ struct SpartanProofBuf {  // SpartanSNARK (src/spartan.rs:130-138) in the canoni
 
 struct PhaseTimes {
   double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // witness_commit, matvec, outer, poly_abc, inner, pcs, total, (spare)
+  std::vector<std::pair<std::string, double>> laps;  // fine-grained host-side laps (diagnostics)
 };
 
 // SpartanSNARK::setup (src/spartan.rs:146-173)
@@ -371,6 +374,13 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
   if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
   const double t_start = now_ms();
+  double t_lap = t_start;
+  auto lap = [&](const char* name) {
+    if (!pt) return;
+    double t = now_ms();
+    pt->laps.emplace_back(name, t - t_lap);
+    t_lap = t;
+  };
   std::vector<fe_t> publics(npub);
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
 
@@ -379,12 +389,14 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   tr.absorb_scalars("public_values", publics.data(), npub);
   // r1cs_instance_and_witness (bellpepper/r1cs.rs:411-538), skip_synthesize path
   tr.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
+  lap("transcript_prefix");
   const size_t rows_pre = ps.comm_W_precommitted.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
   std::vector<fe_t> r_W_rest(rows_rest);
   for (auto& b : r_W_rest) b = tape.next();
   std::vector<aff_t> comm_W(rows_pre + rows_rest);
   std::copy(ps.comm_W_precommitted.begin(), ps.comm_W_precommitted.end(), comm_W.begin());
   if (rows_rest) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, u64p(&comm_W[rows_pre].x)), "commit_zeros");  // hyrax_pc.rs:305-319
+  lap("commit_zeros");
   {
     std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
@@ -399,6 +411,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   }
   sp_msm_job* delta_job = nullptr;
   ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
+  lap("dvec_draw+delta_begin");
   std::vector<fe_t> r_W = ps.r_W_precommitted;  // combine_blinds
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
   const double t_wit = now_ms();
@@ -417,6 +430,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const size_t num_rounds_x = log2_ceil(N), num_rounds_y = log2_ceil(M) + 1;
   std::vector<fe_t> tau(num_rounds_x);
   for (auto& t : tau) t = tr.squeeze("t");
+  lap("z_build+tau");
 
   ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
   const double t_mv = now_ms();
@@ -461,6 +475,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t denom = fe_sub<S>(fe_one<S>(), r_y[0]);
   if (fe_is_zero(denom)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
   const fe_t eval_W = fe_mul<S>(fe_sub<S>(eval_Z, fe_mul<S>(r_y[0], eval_X)), fe_inv<S>(denom));
+  lap("inner+eval_W");
   const double t_inner = now_ms();
 
   // pcs (src/spartan.rs:423-437)
@@ -474,6 +489,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     std::vector<uint8_t> b = commitment_bytes(comm_W.data(), comm_W.size());
     tr.absorb("poly_com", b.data(), b.size());
   }
+  lap("commit_eval+poly_com_absorb");
   const fe_t* point = r_y.data() + 1;
   const size_t npoint = num_rounds_y - 1;
   const size_t num_rows = (M + W_ - 1) / W_, nvr = log2_ceil(num_rows);
@@ -491,9 +507,11 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     R = eq_evals_host(point + nvr, npoint - nvr);
     LZ.resize(R.size());
     ck(sp_rowmat_vec(ctx, ps.W, L.size(), R.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
+    lap("eq_LR+rowmat_vec");
     r_LZ = fe_zero();
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], r_W[i]));
     ck(sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ");
+    lap("comm_LZ_msm");
   }
   // InnerProductArgumentLinear::prove (ipa.rs:125-170)
   tr.dom_sep("inner product argument (linear)");
@@ -509,9 +527,11 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t r_delta = tape.next(), r_beta = tape.next();
   aff_t delta, beta;
   ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
+  lap("delta_finish");
   fe_t ip = fe_zero();
   for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
+  lap("ip+beta");
   {
     uint8_t b[64];
     point_bytes(delta, b);
@@ -525,6 +545,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   for (size_t i = 0; i < n; ++i) proof.pf(fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]));
   proof.pf(fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta));
   proof.pf(fe_add<S>(fe_mul<S>(rr, blind_eval_W), r_beta));
+  lap("z_vec");
   const double t_end = now_ms();
   if (pt) {
     pt->ms[0] = t_wit - t_start;
@@ -656,6 +677,9 @@ int ss_prove(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const
     memcpy(out_words, pf.words.data(), pf.words.size() * 8);
     if (tape_used) *tape_used = t.pos;
     if (phase_ms) memcpy(phase_ms, pt.ms, 7 * sizeof(double));
+    if (getenv("SPARTAN_HOST_LAPS")) {
+      for (auto& l : pt.laps) fprintf(stderr, "lap %-28s %.3f ms\n", l.first.c_str(), l.second);
+    }
     return 0;
   } catch (...) {
     return catch_all();
