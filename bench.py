@@ -33,19 +33,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from spartan2_amd import dist as spd
+
+    rank, local_rank, world = spd.env_rank()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libspartan_hip has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    group = spd.Group(backend="nccl")  # RCCL; used only for the barrier and the max-over-ranks of the timed region
 
     from spartan2_amd import frontend, hip, host
 
@@ -62,10 +58,7 @@ def main():
     t_prep = time.time() - t0
     step_tape = np.random.default_rng(rng_seed + 1).integers(0, 256, size=(4096, 64), dtype=np.uint8)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = group.barrier  # dist.barrier() + torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         words, _, _ = snark.prove(step_tape)
@@ -80,10 +73,7 @@ def main():
             phase_acc[k] = phase_acc.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = group.max_over_ranks(elapsed)
     bind_ms, bind_launches, bind_bytes = ctx.kernel_stats("bind")
     # untimed extra pass with every kernel class instrumented, for the per-kernel breakdown
     ctx.reset_stats(True)
@@ -98,7 +88,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         ncons = inst.num_cons
-        value = world * ncons / (elapsed / args.steps)
+        value = spd.whole_job_throughput(ncons, args.steps, elapsed, world)
         achieved = (bind_bytes / bind_launches) / (bind_ms / bind_launches * 1e-3) / 1e9 if bind_launches else 0.0
         out = {
             "metric": "sha256_spartan prove(): R1CS constraints/sec (prove wall-clock in ms_per_step)",
@@ -140,8 +130,7 @@ def main():
         print(json.dumps(out))
     snark.close()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,76 @@
+"""Builds the frozen vectors under tests/golden/ from the CPU oracle (which tests/test_oracle_kats.py pins against the
+reference's own KATs). The reference itself is Rust and cannot run in this image, so these are oracle outputs frozen as data:
+inputs are derived from fixed seeds, outputs are hex strings of canonical Montgomery limbs."""
+import ctypes
+import hashlib
+
+import numpy as np
+
+import oracle_lib as ol
+from oracle_lib import lib as olib, p64
+
+
+def _hex(arr):
+    return np.ascontiguousarray(arr, dtype=np.uint64).tobytes().hex()
+
+
+def _field_from_seed(seed: bytes, n: int):
+    """n field elements: element i = from_uniform(SHAKE256(seed || i)[:64]) — reproducible without numpy's RNG."""
+    out = np.zeros((n, 4), dtype=np.uint64)
+    for i in range(n):
+        raw = np.frombuffer(hashlib.shake_256(seed + i.to_bytes(4, "little")).digest(64), dtype=np.uint8).copy()
+        olib().orc_field_from_uniform(0, ol.p8(raw), p64(out[i]))
+    return out
+
+
+def sumcheck_inputs(ell):
+    n = 1 << ell
+    A = _field_from_seed(b"golden-A", n)
+    B = _field_from_seed(b"golden-B", n)
+    C = np.zeros_like(A)
+    for i in range(n):
+        olib().orc_field_binop(0, 2, p64(A[i]), p64(B[i]), p64(C[i]))
+    taus = _field_from_seed(b"golden-tau", ell)
+    return A, B, C, taus
+
+
+def sumcheck_small():
+    out = {"note": "oracle outputs (oracle/sumcheck.hpp) on SHAKE256-derived inputs; see tests/make_golden_impl.py", "cases": []}
+    for ell in (3, 6, 9):
+        A, B, C, taus = sumcheck_inputs(ell)
+        claim = np.zeros(4, dtype=np.uint64)
+        tr = ol.Transcript(b"golden")
+        polys = np.zeros((ell, 3, 4), dtype=np.uint64)
+        r = np.zeros((ell, 4), dtype=np.uint64)
+        fin = np.zeros((3, 4), dtype=np.uint64)
+        a, b, c = A.copy(), B.copy(), C.copy()
+        assert olib().orc_sumcheck_cubic3(p64(claim), p64(taus), ctypes.c_size_t(ell), p64(a), p64(b), p64(c), tr.h, p64(polys), p64(r), p64(fin)) == 0
+        after = tr.squeeze(b"after")
+        # quadratic: claim = <A, B>
+        qclaim = np.zeros(4, dtype=np.uint64)
+        olib().orc_field_dot(0, p64(A), p64(B), ctypes.c_size_t(1 << ell), p64(qclaim))
+        trq = ol.Transcript(b"golden-quad")
+        qpolys = np.zeros((ell, 2, 4), dtype=np.uint64)
+        qr = np.zeros((ell, 4), dtype=np.uint64)
+        qfin = np.zeros((2, 4), dtype=np.uint64)
+        a, b = A.copy(), B.copy()
+        full = ctypes.c_size_t(2**64 - 1)
+        assert olib().orc_sumcheck_quad(p64(qclaim), ctypes.c_size_t(ell), p64(a), full, full, p64(b), full, full, trq.h, p64(qpolys), p64(qr), p64(qfin)) == 0
+        out["cases"].append({"ell": ell, "cubic_polys": _hex(polys), "cubic_r": _hex(r), "cubic_final": _hex(fin), "transcript_after": _hex(after),
+                             "quad_claim": _hex(qclaim), "quad_polys": _hex(qpolys), "quad_r": _hex(qr), "quad_final": _hex(qfin)})
+    return out
+
+
+def spartan_small():
+    """One full proof of a seeded synthetic circuit: digest of the proof words + the first words, enough to pin the whole path."""
+    from spartan2_amd import frontend
+
+    inst = frontend.synthetic_circuit(6, 0xDEADBEEF, num_public=3)
+    tape = np.frombuffer(hashlib.shake_256(b"golden-tape").digest(64 * 4096), dtype=np.uint8).reshape(4096, 64).copy()
+    sp = ol.OracleSpartan(inst)
+    used = sp.prep_prove(tape)
+    words, used2, _ = sp.prove(tape[used:])
+    assert sp.verify_words(words) == 0
+    return {"note": "oracle proof (oracle/spartan.hpp) of frontend.synthetic_circuit(6, 0xDEADBEEF, 3) with tape = SHAKE256('golden-tape')",
+            "num_cons": inst.num_cons, "num_aux": inst.num_aux, "tape_blocks_prep": used, "tape_blocks_prove": used2, "proof_words": len(words),
+            "proof_sha256": hashlib.sha256(words.tobytes()).hexdigest(), "proof_head": _hex(words[:64]), "proof_tail": _hex(words[-16:])}

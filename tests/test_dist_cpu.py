@@ -1,0 +1,66 @@
+"""N > 1 path on CPU: two gloo ranks exercise the sharding + barrier + max-over-ranks logic bench.py uses on the GPUs."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from spartan2_amd import dist as spd, frontend
+
+    g = spd.Group(backend="gloo")
+    lo, hi = spd.shard_range(5, g.rank, g.world)  # 5 step instances over 2 ranks: 3 + 2
+    # each rank builds only its own instances (per-instance sharding, no exchange of R1CS data)
+    sizes = [frontend.synthetic_circuit(2 + i, 100 + i, num_public=1).num_cons for i in range(lo, hi)]
+    g.barrier()
+    elapsed = 0.5 + 0.25 * g.rank  # pretend rank 1 is the slow one
+    emax = g.max_over_ranks(elapsed)
+    total_units = g.sum_over_ranks(float(sum(sizes)))
+    value = total_units / emax
+    q.put((g.rank, lo, hi, emax, total_units, value))
+    g.close()
+
+
+def test_two_rank_gloo_sharding_and_timing():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(0, 3), (3, 5)]
+    assert res[0][3] == res[1][3] == 0.75  # max over ranks
+    assert res[0][4] == res[1][4] and res[0][5] == res[1][5] == res[0][4] / 0.75
+
+
+def test_shard_range_is_a_partition():
+    from spartan2_amd.dist import shard_range, whole_job_throughput
+
+    for n in (0, 1, 7, 8, 256):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                cover += list(range(lo, hi))
+                assert 0 <= hi - lo <= (n + world - 1) // world
+            assert cover == list(range(n))
+    assert whole_job_throughput(100.0, 10, 2.0, 8) == 4000.0

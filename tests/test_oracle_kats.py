@@ -410,13 +410,21 @@ def test_fixed_base_mul_vs_scalar_mul():
 
 
 def test_golden_fixtures_match_oracle():
-    """tests/golden/*.json were produced by tests/golden/make_golden.py from this oracle after it was
-    pinned by the KATs above; they freeze the oracle so later refactors cannot drift silently."""
-    path = os.path.join(GOLD, "sumcheck_small.json")
-    if not os.path.exists(path):
-        pytest.skip("golden fixtures not generated yet")
+    """tests/golden/{sumcheck_small,spartan_small}.json were produced by tests/golden/make_golden.py from this oracle after it
+    was pinned by the KATs above; they freeze the oracle so later refactors cannot drift silently."""
     import make_golden_impl
 
-    fresh = make_golden_impl.sumcheck_small()
-    with open(path) as f:
-        assert json.load(f) == fresh
+    for name, fn in (("sumcheck_small.json", make_golden_impl.sumcheck_small), ("spartan_small.json", make_golden_impl.spartan_small)):
+        with open(os.path.join(GOLD, name)) as f:
+            assert json.load(f) == fn(), name
+
+
+def test_reference_kat_file_is_what_the_tests_above_use():
+    with open(os.path.join(GOLD, "reference_kats.json")) as f:
+        k = json.load(f)
+    data = np.frombuffer(bytes.fromhex(k["keccak256"]["input_hex"]), dtype=np.uint8).copy()
+    out = np.zeros(32, dtype=np.uint8)
+    lib().orc_keccak256(p8(data), ctypes.c_size_t(len(data)), p8(out))
+    assert out.tobytes().hex() == k["keccak256"]["digest_hex"]
+    assert ints_of(unipoly_from_evals(k["unipoly"]["cubic_evals"])) == k["unipoly"]["cubic_coeffs"]
+    assert int(k["moduli"]["t256_scalar"], 16) == MODULI[0] and int(k["moduli"]["t256_base"], 16) == MODULI[1]
