@@ -2,6 +2,7 @@
 // The round loop lives below the C ABI: per round the device computes the evaluation sums (K2/K3), the host
 // finishes the O(1) part (claim-derived evaluations, UniPoly, Keccak transcript), and the challenge goes back
 // as a kernel argument of the bind (K1).
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -112,6 +113,7 @@ int sp_ctx_create(int device, sp_ctx** out) {
   SP_HIP(hipStreamCreate(&c->stream2));
   c->pinned_elems = 64;
   SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
+  memset(c->h_pinned, 0, c->pinned_elems * sizeof(fe_t));
   SP_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
   SP_HIP(hipHostMalloc(&c->h_pinned_lane[0], 8192));
   SP_HIP(hipHostMalloc(&c->h_pinned_lane[1], 8192));
@@ -258,13 +260,27 @@ static int launch_bind(sp_ctx* c, sp_table** tabs, int nt, const fe_t& r) {
   return SP_OK;
 }
 
-// second-stage reduction of `nblocks` x nacc block partials in d_scratch, written straight into mapped pinned host memory
+// second-stage reduction of `nblocks` x nacc block partials in d_scratch, written straight into mapped pinned host memory.
+// Every evaluation launch is given c->result_seq (bumped by next_seq() just before the launch); whichever kernel produces the
+// final sums publishes that number after the data, and the host polls for it.
+static unsigned next_seq(sp_ctx* c) { return ++c->result_seq; }
 static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
-  if (nblocks == 1) return;  // a one-block evaluation wrote its sums straight to the pinned buffer
-  hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned);
+  if (nblocks == 1) return;  // a one-block evaluation wrote its sums (and the sequence number) straight to the pinned buffer
+  hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
 }
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host) {
-  SP_HIP(hipStreamSynchronize(c->stream));
+  volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->h_pinned + spk::RESULT_FLAG_ELEM);
+  const unsigned want = c->result_seq;
+  bool seen = false;
+  for (int spin = 0; spin < 200000; ++spin) {  // ~ a few ms worst case, then fall back to a real synchronise
+    if (*flag == want) {
+      seen = true;
+      break;
+    }
+    __builtin_ia32_pause();
+  }
+  if (!seen) SP_HIP(hipStreamSynchronize(c->stream));
+  std::atomic_thread_fence(std::memory_order_acquire);
   for (int k = 0; k < nacc; ++k) out_host[k] = c->h_pinned[k];
   return SP_OK;
 }
@@ -435,7 +451,7 @@ int sp_table_dot(sp_ctx* c, const sp_table* a, const sp_table* b, size_t n, uint
   if (blocks == 0) blocks = 1;
   int rc = c->ensure_scratch(blocks + 16);
   if (rc) return rc;
-  c->timed("dot", 64ull * n, [&] { hipLaunchKernelGGL(spk::k_dot, dim3((unsigned)blocks), dim3(256), 0, c->stream, a->d, b->d, n, c->d_scratch, c->d_pinned); });
+  c->timed("dot", 64ull * n, [&] { hipLaunchKernelGGL(spk::k_dot, dim3((unsigned)blocks), dim3(256), 0, c->stream, a->d, b->d, n, c->d_scratch, c->d_pinned, next_seq(c)); });
   fe_t r;
   rc = reduce_partials(c, blocks, 1, &r);
   if (rc) return rc;
@@ -465,7 +481,7 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       if (len > 0) {
         size_t blocks = (len + chunk - 1) / chunk;
         c->timed("eval_quad", 128ull * len,
-                 [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch, c->d_pinned); });
+                 [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch, c->d_pinned, next_seq(c)); });
         rc = reduce_partials(c, blocks, 2, sums);
         if (rc) return rc;
       }
@@ -494,7 +510,7 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       const size_t q = A->len / 4;
       size_t blocks = (q + chunk - 1) / chunk;
       c->timed("bind", 48ull * A->len * 2, [&] {
-        hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch, c->d_pinned);
+        hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch, c->d_pinned, next_seq(c));
       });
       sp::after_bind(A);
       sp::after_bind(B);
@@ -564,8 +580,9 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
     const size_t half = A->len / 2;
     const EqSel e = select_eq(rnd);
     dim3 g((unsigned)((half + chunk - 1) / chunk)), b(256);
+    const unsigned seq = next_seq(c);
 #define SP_LAUNCH_EVAL(MODE, M1) \
-  hipLaunchKernelGGL((spk::k_eval_cubic<MODE, M1>), g, b, 0, c->stream, A->d, B->d, C->d, half, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned)
+  hipLaunchKernelGGL((spk::k_eval_cubic<MODE, M1>), g, b, 0, c->stream, A->d, B->d, C->d, half, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq)
     if (!with_m1) {
       if (e.mode == 0) SP_LAUNCH_EVAL(0, false);
       else if (e.mode == 1) SP_LAUNCH_EVAL(1, false);
@@ -649,10 +666,11 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
       const size_t q = A->len / 4;
       const EqSel e = select_eq(rnd + 1);
       dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
+      const unsigned seq = next_seq(c);
       c->timed("bind", 48ull * A->len * 3, [&] {
-        if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned);
-        else if (e.mode == 1) hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned);
-        else hipLaunchKernelGGL((spk::k_bind_eval_cubic<2>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned);
+        if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
+        else if (e.mode == 1) hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
+        else hipLaunchKernelGGL((spk::k_bind_eval_cubic<2>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
       });
       sp::after_bind(A);
       sp::after_bind(B);

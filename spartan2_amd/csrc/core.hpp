@@ -38,6 +38,7 @@ struct sp_ctx {
   size_t scratch_elems = 0;
   fe_t* h_pinned = nullptr;  // small result buffer, pinned + mapped
   fe_t* d_pinned = nullptr;  // device-side address of h_pinned
+  unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.cuh publish_result)
   void* h_pinned_lane[2] = {nullptr, nullptr};  // pinned landing buffers for per-window MSM sums (one per stream), 8 KiB each
   size_t pinned_elems = 0;
   bool timing = false;

@@ -12,6 +12,14 @@
 
 namespace spk {
 
+// Round results land in a mapped, pinned host buffer: elements [0..3) = sums, word 0 of element RESULT_FLAG_ELEM = sequence
+// number, stored with system-scope release after the data so the host can poll it instead of paying a stream synchronise.
+constexpr int RESULT_FLAG_ELEM = 7;
+__device__ __forceinline__ void publish_result(fe_t* result, unsigned seq) {
+  __threadfence_system();
+  __hip_atomic_store(reinterpret_cast<unsigned*>(result + RESULT_FLAG_ELEM), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- K1: bind the top variable of up to 4 tables with the same challenge -----------------------------------
 struct BindArgs {
   fe_t* z[4];
@@ -84,7 +92,7 @@ constexpr int EVAL_PPT = 1;  // pairs per thread (1: the kernels are latency-bou
 template <int MODE, bool WITH_M1>
 __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
                                                     const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
-                                                    fe_t* __restrict__ partials, fe_t* __restrict__ single_out) {
+                                                    fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq) {
   constexpr int NACC = WITH_M1 ? 3 : 2;
   __shared__ fe_t smem[NACC * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
@@ -121,6 +129,7 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
     fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * NACC;  // one block: its sums are the result
 #pragma unroll
     for (int k = 0; k < NACC; ++k) dst[k] = acc[k];
+    if (gridDim.x == 1) publish_result(single_out, seq);
   }
 }
 
@@ -133,7 +142,7 @@ __device__ __forceinline__ fe_t bind1(const fe_t& lo, const fe_t& hi, const fe_t
 template <int MODE>
 __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r,
                                                          const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
-                                                         fe_t* __restrict__ partials, fe_t* __restrict__ single_out) {
+                                                         fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq) {
   __shared__ fe_t smem[2 * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
@@ -174,11 +183,12 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, f
     fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
     dst[0] = acc[0];
     dst[1] = acc[1];
+    if (gridDim.x == 1) publish_result(single_out, seq);
   }
 }
 // dense quadratic variant (both tables fully non-zero)
 __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, fe_t* __restrict__ partials,
-                                                        fe_t* __restrict__ single_out) {
+                                                        fe_t* __restrict__ single_out, unsigned seq) {
   __shared__ fe_t smem[2 * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
@@ -204,13 +214,14 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe
     fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
     dst[0] = acc[0];
     dst[1] = acc[1];
+    if (gridDim.x == 1) publish_result(single_out, seq);
   }
 }
 
 // ---- K3: quadratic evaluation sums ---------------------------------------------------------------------------------
 //   eval0 = sum_{i < len} A0 B0 ; tinf = sum_{i < len} (A1 - A0)(B1 - B0), len = min(eff_pairs(A), eff_pairs(B), half)
 __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t len,
-                                                   fe_t* __restrict__ partials, fe_t* __restrict__ single_out) {
+                                                   fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq) {
   __shared__ fe_t smem[2 * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
@@ -229,22 +240,26 @@ __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, c
     fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
     dst[0] = acc[0];
     dst[1] = acc[1];
+    if (gridDim.x == 1) publish_result(single_out, seq);
   }
 }
 
 // dot product of the first n elements (value of DelayedReduction::reduce(sum a_i b_i))
 __global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t n, fe_t* __restrict__ partials,
-                                             fe_t* __restrict__ single_out) {
+                                             fe_t* __restrict__ single_out, unsigned seq) {
   __shared__ fe_t smem[4];
   fe_t acc[1] = {fe_zero()};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     acc[0] = fe_add<S>(acc[0], fe_mul<S>(A[i], B[i]));
   block_sum<1>(acc, smem);
-  if (threadIdx.x == 0) (gridDim.x == 1 ? single_out : partials + blockIdx.x)[0] = acc[0];
+  if (threadIdx.x == 0) {
+    (gridDim.x == 1 ? single_out : partials + blockIdx.x)[0] = acc[0];
+    if (gridDim.x == 1) publish_result(single_out, seq);
+  }
 }
 
 // out[k] = sum_b partials[b * nacc + k]; one block
-__global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ partials, size_t nblocks, int nacc, fe_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ partials, size_t nblocks, int nacc, fe_t* __restrict__ out, unsigned seq) {
   __shared__ fe_t smem[4];
   for (int k = 0; k < nacc; ++k) {
     fe_t acc[1] = {fe_zero()};
@@ -253,6 +268,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
     if (threadIdx.x == 0) out[k] = acc[0];
     __syncthreads();
   }
+  if (threadIdx.x == 0) publish_result(out, seq);
 }
 
 }  // namespace spk
