@@ -79,6 +79,8 @@ int sp_transcript_new(sp_ctx* ctx, const uint8_t* label, size_t n, sp_transcript
 int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n);
 int sp_transcript_dom_sep(sp_transcript* t, const uint8_t* bytes, size_t n);
 int sp_transcript_squeeze(sp_transcript* t, const uint8_t* label, size_t ln, uint64_t out[4]);
+/* Keccak256Transcript derives Clone (keccak.rs:25); lets a caller keep the state after a prefix that repeats across proves */
+int sp_transcript_clone(const sp_transcript* t, sp_transcript** out);
 void sp_transcript_free(sp_transcript* t);
 
 /* ---- sum-check (src/sumcheck.rs) -------------------------------------------------------------------- */
@@ -135,6 +137,10 @@ void sp_ck_free(sp_ck* ck);
 int sp_hyrax_commit(sp_ctx* ctx, const sp_ck* ck, const sp_table* v, size_t off, size_t n, const uint64_t* blinds, int is_small, uint64_t* out_rows_aff);
 /* PCS::commit_zeros (:305-319) and the per-row h * blind of rerandomize (:321-344): FixedBaseMul::mul (msm.rs:691-725) */
 int sp_fixed_base_mul_h(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t* out_aff);
+/* asynchronous form: begin() enqueues upload + kernel + download and returns, finish() waits and normalises */
+typedef struct sp_fb_job sp_fb_job;
+int sp_fixed_base_mul_h_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_fb_job** job);
+int sp_fixed_base_mul_h_finish(sp_ctx* ctx, sp_fb_job* job, uint64_t* out_aff);
 /* bind_with_delayed (:38-54): out[i] = sum_j L[j] * poly[j*cols + i]; out has `cols` F on the host */
 int sp_rowmat_vec(sp_ctx* ctx, const sp_table* poly, size_t rows, size_t cols, const uint64_t* L, uint64_t* out);
 /* vartime_multiscalar_mul(scalars, ck[..n]) + h * blind against a device-resident key (hyrax_pc.rs:454-455, ipa.rs:147);

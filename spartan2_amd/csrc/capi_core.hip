@@ -133,6 +133,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->h_pinned) hipHostFree(c->h_pinned);
   for (int i = 0; i < 2; ++i)
     if (c->h_pinned_lane[i]) hipHostFree(c->h_pinned_lane[i]);
+  if (c->h_pinned_fb) hipHostFree(c->h_pinned_fb);
+  if (c->fb_ev) hipEventDestroy(c->fb_ev);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
   delete c;
@@ -439,6 +441,10 @@ int sp_transcript_squeeze(sp_transcript* t, const uint8_t* label, size_t ln, uin
   fe_t f;
   if (!t->t.squeeze<S>(label, ln, &f)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
   store_fe(out, f);
+  return SP_OK;
+}
+int sp_transcript_clone(const sp_transcript* t, sp_transcript** out) {
+  *out = new sp_transcript(*t);
   return SP_OK;
 }
 void sp_transcript_free(sp_transcript* t) { delete t; }

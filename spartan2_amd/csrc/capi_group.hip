@@ -71,8 +71,10 @@ void normalize_batch(const std::vector<jac_t>& pts, aff_t* out) {
 struct MsmPending {
   int windows = 0;
   int lane = 0;
+  int slot = 0;  // landing slot inside the lane's pinned buffer: several jobs may be in flight on one stream
   std::vector<jac_t> w;
 };
+static const int MSM_LANDING_SLOTS = 2;  // 8192-byte pinned buffer / (33 * 96 B) per job
 static hipStream_t lane_stream(sp_ctx* c, int lane) { return lane ? c->stream2 : c->stream; }
 
 int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n, int windows, int lane, MsmPending* pend) {
@@ -106,8 +108,9 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
   });
   run("msm_window_reduce", 0, [&] { hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows), dim3(spk::MSM_BUCKETS), 0, st, buckets, wsum); });
   pend->windows = windows;
+  pend->slot = (int)(c->msm_jobs_issued[lane]++ % MSM_LANDING_SLOTS);
   // pinned landing buffer: a device->host copy into pageable memory would block the host until the MSM is done
-  SP_HIP(hipMemcpyAsync(c->h_pinned_lane[lane], wsum, windows * sizeof(jac_t), hipMemcpyDeviceToHost, st));
+  SP_HIP(hipMemcpyAsync((char*)c->h_pinned_lane[lane] + pend->slot * 4096, wsum, windows * sizeof(jac_t), hipMemcpyDeviceToHost, st));
   return SP_OK;
 }
 int msm_finish(sp_ctx* c, MsmPending* pend, jac_t* result) {
@@ -115,7 +118,7 @@ int msm_finish(sp_ctx* c, MsmPending* pend, jac_t* result) {
   if (pend->windows == 0) return SP_OK;
   SP_HIP(hipStreamSynchronize(lane_stream(c, pend->lane)));
   pend->w.resize(pend->windows);
-  memcpy(pend->w.data(), c->h_pinned_lane[pend->lane], pend->windows * sizeof(jac_t));
+  memcpy(pend->w.data(), (char*)c->h_pinned_lane[pend->lane] + pend->slot * 4096, pend->windows * sizeof(jac_t));
   // Horner over windows, high to low (msm.rs:150-175): acc = 2^8 acc + W_w
   jac_t acc = jac_identity();
   for (int i = pend->windows - 1; i >= 0; --i) {
@@ -262,6 +265,64 @@ static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, con
   });
   SP_HIP(hipMemcpyAsync(out.data(), dout, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
   SP_HIP(hipStreamSynchronize(c->stream));
+  return SP_OK;
+}
+
+struct sp_fb_job {
+  size_t n = 0;
+  std::vector<jac_t> host_pts;  // filled directly for small n
+  bool on_device = false;
+  jac_t* pinned = nullptr;
+};
+int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_fb_job** out) {
+  sp_fb_job* job = new sp_fb_job();
+  job->n = n;
+  if (n <= FIXED_BASE_HOST_MAX) {
+    job->host_pts.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      fe_t sc;
+      memcpy(&sc, scalars + 4 * i, 32);
+      job->host_pts[i] = fixed_base_mul_host(ck->host_htable(), sc);
+    }
+  } else {
+    if (n * sizeof(jac_t) > 4096 * sizeof(jac_t)) {
+      delete job;
+      return fail(SP_ERR_INVALID_INPUT_LENGTH, "fixed_base_mul_h_begin: at most 4096 scalars per asynchronous job");
+    }
+    if (!c->h_pinned_fb) SP_HIP(hipHostMalloc(&c->h_pinned_fb, 4096 * (sizeof(jac_t) + sizeof(fe_t))));
+    fe_t* stage = (fe_t*)((char*)c->h_pinned_fb + 4096 * sizeof(jac_t));
+    memcpy(stage, scalars, n * sizeof(fe_t));  // pinned staging: the caller's buffer is released on return
+    // auxiliary stream: the job overlaps whatever the caller does next on the main stream
+    fe_t* ds = (fe_t*)c->workspace(sp_ctx::WS_FB_SCALARS, n * sizeof(fe_t), 1);
+    jac_t* dout = (jac_t*)c->workspace(sp_ctx::WS_FB_OUT, n * sizeof(jac_t), 1);
+    if (!ds || !dout) {
+      delete job;
+      return SP_ERR_NO_DEVICE;
+    }
+    SP_HIP(hipMemcpyAsync(ds, stage, n * sizeof(fe_t), hipMemcpyHostToDevice, c->stream2));
+    size_t threads = n * 32;
+    hipLaunchKernelGGL(spk::k_fixed_base_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream2, ds, n, ck->d_htable, (size_t)1, dout);
+    SP_HIP(hipMemcpyAsync(c->h_pinned_fb, dout, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream2));
+    SP_HIP(hipEventRecord(c->fb_event(), c->stream2));
+    job->on_device = true;
+    job->pinned = (jac_t*)c->h_pinned_fb;
+  }
+  *out = job;
+  return SP_OK;
+}
+int sp_fixed_base_mul_h_finish(sp_ctx* c, sp_fb_job* job, uint64_t* out_aff) {
+  std::vector<jac_t> pts;
+  if (job->on_device) {
+    SP_HIP(hipEventSynchronize(c->fb_event()));
+    pts.assign(job->pinned, job->pinned + job->n);
+  } else {
+    pts.swap(job->host_pts);
+  }
+  const size_t n = job->n;
+  delete job;
+  std::vector<aff_t> a(n);
+  normalize_batch(pts, a.data());
+  if (n) memcpy(out_aff, a.data(), n * sizeof(aff_t));
   return SP_OK;
 }
 

@@ -38,7 +38,14 @@ struct sp_ctx {
   size_t scratch_elems = 0;
   fe_t* h_pinned = nullptr;  // small result buffer, pinned + mapped
   fe_t* d_pinned = nullptr;  // device-side address of h_pinned
+  void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs
+  hipEvent_t fb_ev = nullptr;
+  hipEvent_t fb_event() {
+    if (!fb_ev) hipEventCreateWithFlags(&fb_ev, hipEventDisableTiming);
+    return fb_ev;
+  }
   unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.cuh publish_result)
+  unsigned long long msm_jobs_issued[2] = {0, 0};
   void* h_pinned_lane[2] = {nullptr, nullptr};  // pinned landing buffers for per-window MSM sums (one per stream), 8 KiB each
   size_t pinned_elems = 0;
   bool timing = false;

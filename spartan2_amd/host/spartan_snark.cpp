@@ -187,6 +187,7 @@ std::vector<aff_t> from_label(const char* label, size_t n) {
 struct Tr {
   sp_transcript* t = nullptr;
   explicit Tr(sp_ctx* ctx, const char* label) { ck(sp_transcript_new(ctx, (const uint8_t*)label, strlen(label), &t), "transcript_new"); }
+  explicit Tr(const sp_transcript* prefix) { ck(sp_transcript_clone(prefix, &t), "transcript_clone"); }
   ~Tr() { sp_transcript_free(t); }
   void absorb(const char* label, const uint8_t* b, size_t n) { ck(sp_transcript_absorb(t, (const uint8_t*)label, strlen(label), b, n), "absorb"); }
   void absorb_scalars(const char* label, const fe_t* s, size_t n) {  // BE encoding (src/provider/traits.rs:282-286), slices concatenated
@@ -279,7 +280,10 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   std::vector<aff_t> comm_W_precommitted;
   std::vector<fe_t> r_W_precommitted;
   std::vector<uint8_t> comm_pre_bytes;
+  sp_transcript* tr_prefix = nullptr;  // transcript state after the per-instance prefix (see prove)
+  std::vector<fe_t> tr_publics;
   ~SpartanPrepSNARK() {
+    sp_transcript_free(tr_prefix);
     for (sp_table* t : {W, caz, cbz, ccz, az, bz, cz, z, rx, abc}) sp_table_free(t);
   }
 };
@@ -384,37 +388,32 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> publics(npub);
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
 
-  Tr tr(ctx, "SpartanSNARK");
-  tr.absorb("vk", pk.vk_digest, 32);
-  tr.absorb_scalars("public_values", publics.data(), npub);
-  // r1cs_instance_and_witness (bellpepper/r1cs.rs:411-538), skip_synthesize path
-  tr.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
-  lap("transcript_prefix");
+  // commit_zeros for the all-padding rest segment (hyrax_pc.rs:305-319): started first, collected after the host work below
   const size_t rows_pre = ps.comm_W_precommitted.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
   std::vector<fe_t> r_W_rest(rows_rest);
   for (auto& b : r_W_rest) b = tape.next();
   std::vector<aff_t> comm_W(rows_pre + rows_rest);
   std::copy(ps.comm_W_precommitted.begin(), ps.comm_W_precommitted.end(), comm_W.begin());
-  if (rows_rest) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, u64p(&comm_W[rows_pre].x)), "commit_zeros");  // hyrax_pc.rs:305-319
-  lap("commit_zeros");
-  {
-    std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
-    tr.absorb("comm_W_rest", b.data(), b.size());
+  sp_fb_job* rest_job = nullptr;
+  if (rows_rest) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
+  lap("commit_zeros_begin");
+
+  // transcript prefix: new + vk + public_values + comm_W_precommitted repeats for every prove on this prep state, so its
+  // hash state is computed once and cloned (Keccak256Transcript is Clone, keccak.rs:25)
+  if (!ps.tr_prefix) {
+    Tr t0(ctx, "SpartanSNARK");
+    t0.absorb("vk", pk.vk_digest, 32);
+    t0.absorb_scalars("public_values", publics.data(), npub);
+    // r1cs_instance_and_witness (bellpepper/r1cs.rs:411-538), skip_synthesize path
+    t0.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
+    ps.tr_prefix = t0.t;
+    t0.t = nullptr;
+    ps.tr_publics = publics;
+  } else if (ps.tr_publics.size() != publics.size() || memcmp(ps.tr_publics.data(), publics.data(), publics.size() * sizeof(fe_t)) != 0) {
+    throw Error(SP_ERR_INTERNAL, "public values changed between proves on one prep state");
   }
-  // The IPA mask d_vec (ipa.rs:139-145) does not depend on the transcript: draw it now from its tape position and let
-  // delta's MSM (ipa.rs:147) run on the auxiliary stream underneath the two sum-checks.
-  const size_t n_ipa = M < W_ ? M : W_;
-  std::vector<fe_t> dvec(n_ipa);
-  {
-    Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
-    for (auto& x : dvec) x = peek.next();
-  }
-  sp_msm_job* delta_job = nullptr;
-  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
-  lap("dvec_draw+delta_begin");
-  std::vector<fe_t> r_W = ps.r_W_precommitted;  // combine_blinds
-  r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
-  const double t_wit = now_ms();
+  Tr tr(ps.tr_prefix);
+  lap("transcript_prefix");
 
   // z = [W | 1 | public]   (src/spartan.rs:246-253); the table is 2M long so the inner sum-check can run in place
   ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
@@ -427,10 +426,34 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
   }
   ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
+  lap("z_build");
+
+  // The IPA mask d_vec (ipa.rs:139-145) does not depend on the transcript: draw it now from its tape position and let
+  // delta's MSM (ipa.rs:147) run on the auxiliary stream underneath the two sum-checks.
+  const size_t n_ipa = M < W_ ? M : W_;
+  std::vector<fe_t> dvec(n_ipa);
+  {
+    Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
+    for (auto& x : dvec) x = peek.next();
+  }
+  sp_msm_job* delta_job = nullptr;
+  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
+  lap("dvec_draw+delta_begin");
+
+  if (rows_rest) ck(sp_fixed_base_mul_h_finish(ctx, rest_job, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
+  {
+    std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
+    tr.absorb("comm_W_rest", b.data(), b.size());
+  }
+  lap("commit_zeros_finish+absorb");
+  std::vector<fe_t> r_W = ps.r_W_precommitted;  // combine_blinds
+  r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
+  const double t_wit = now_ms();
+
   const size_t num_rounds_x = log2_ceil(N), num_rounds_y = log2_ceil(M) + 1;
   std::vector<fe_t> tau(num_rounds_x);
   for (auto& t : tau) t = tr.squeeze("t");
-  lap("z_build+tau");
+  lap("tau");
 
   ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
   const double t_mv = now_ms();
@@ -478,24 +501,19 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   lap("inner+eval_W");
   const double t_inner = now_ms();
 
-  // pcs (src/spartan.rs:423-437)
+  // pcs (src/spartan.rs:423-437) -> HyraxPCS::prove (hyrax_pc.rs:387-478) -> InnerProductArgumentLinear::prove (ipa.rs:125-170).
+  // Device work is issued first (row-matrix product, comm_LZ's MSM on the auxiliary stream); the host-side pieces that do not
+  // depend on it (commitment to eval_W, hashing comm_W, <R, d>, beta) run underneath. Transcript ORDER is the reference's.
   const fe_t blind_eval_W = tape.next();
-  aff_t comm_eval_W;
-  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
   proof.pf(eval_W);
   proof.pf(blind_eval_W);
-  // HyraxPCS::prove (hyrax_pc.rs:387-478)
-  {
-    std::vector<uint8_t> b = commitment_bytes(comm_W.data(), comm_W.size());
-    tr.absorb("poly_com", b.data(), b.size());
-  }
-  lap("commit_eval+poly_com_absorb");
   const fe_t* point = r_y.data() + 1;
   const size_t npoint = num_rounds_y - 1;
   const size_t num_rows = (M + W_ - 1) / W_, nvr = log2_ceil(num_rows);
   aff_t comm_LZ;
   std::vector<fe_t> R, LZ;
   fe_t r_LZ;
+  sp_msm_job* lz_job = nullptr;
   if (nvr == 0) {
     comm_LZ = comm_W[0];
     R = eq_evals_host(point, npoint);
@@ -504,34 +522,40 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     r_LZ = r_W[0];
   } else {
     std::vector<fe_t> L = eq_evals_host(point, nvr);
+    LZ.resize((size_t)1 << (npoint - nvr));
+    ck(sp_rowmat_vec(ctx, ps.W, L.size(), LZ.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
+    ck(sp_msm_ck_begin(ctx, pk.ck, u64p(LZ.data()), LZ.size(), &lz_job), "comm_LZ (begin)");
+    lap("eq_L+rowmat_vec+msm_begin");
     R = eq_evals_host(point + nvr, npoint - nvr);
-    LZ.resize(R.size());
-    ck(sp_rowmat_vec(ctx, ps.W, L.size(), R.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
-    lap("eq_LR+rowmat_vec");
     r_LZ = fe_zero();
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], r_W[i]));
-    ck(sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ");
-    lap("comm_LZ_msm");
   }
-  // InnerProductArgumentLinear::prove (ipa.rs:125-170)
+  aff_t comm_eval_W;
+  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
+  {
+    std::vector<uint8_t> b = commitment_bytes(comm_W.data(), comm_W.size());
+    tr.absorb("poly_com", b.data(), b.size());
+  }
   tr.dom_sep("inner product argument (linear)");
+  const size_t n = R.size();
+  if (n != n_ipa) throw Error(SP_ERR_INTERNAL, "IPA width mismatch");
+  tape.skip(n);  // the d_vec blocks that were peeked at the start
+  const fe_t r_delta = tape.next(), r_beta = tape.next();
+  fe_t ip = fe_zero();
+  for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
+  aff_t delta, beta;
+  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
+  lap("host_side_under_msm");
+  if (lz_job) ck(sp_msm_ck_finish(ctx, pk.ck, lz_job, u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ (finish)");
+  lap("comm_LZ_finish");
   {
     uint8_t b[128];
     point_bytes(comm_LZ, b);
     point_bytes(comm_eval_W, b + 64);
     tr.absorb("U", b, 128);
   }
-  const size_t n = R.size();
-  if (n != n_ipa) throw Error(SP_ERR_INTERNAL, "IPA width mismatch");
-  tape.skip(n);  // the blocks that were peeked at the start
-  const fe_t r_delta = tape.next(), r_beta = tape.next();
-  aff_t delta, beta;
   ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
   lap("delta_finish");
-  fe_t ip = fe_zero();
-  for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
-  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
-  lap("ip+beta");
   {
     uint8_t b[64];
     point_bytes(delta, b);
