@@ -63,7 +63,7 @@ def main():
     for _ in range(args.warmup):
         words, _, _ = snark.prove(step_tape)
     ctx.reset_stats(True)
-    ctx.stats_filter("bind")  # only the roofline kernel carries HIP events inside the timed region
+    ctx.stats_filter("bind_stream_cubic")  # only the roofline kernel carries HIP events inside the timed region
     barrier()
     t0 = time.perf_counter()
     phase_acc = {}
@@ -74,14 +74,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = group.max_over_ranks(elapsed)
-    bind_ms, bind_launches, bind_bytes = ctx.kernel_stats("bind")
+    bind_ms, bind_launches, bind_bytes = ctx.kernel_stats("bind_stream_cubic")
     # untimed extra pass with every kernel class instrumented, for the per-kernel breakdown
     ctx.reset_stats(True)
     ctx.stats_filter("")
     nb = 3
     for _ in range(nb):
         snark.prove(step_tape)
-    kstats = {k: ctx.kernel_stats(k) for k in ("bind", "eval_cubic", "eval_quad", "spmv_incremental", "poly_abc", "eq_table", "rowmat_vec", "msm_sort",
+    kstats = {k: ctx.kernel_stats(k) for k in ("bind_stream_cubic", "bind_stream_quad", "bind", "eval_cubic", "eval_quad", "spmv_incremental", "poly_abc", "eq_table", "rowmat_vec", "msm_sort",
                                                 "msm_bucket_sum", "msm_window_reduce", "fixed_base")}
     ctx.reset_stats(False)
 
@@ -90,6 +90,16 @@ def main():
         ncons = inst.num_cons
         value = spd.whole_job_throughput(ncons, args.steps, elapsed, world)
         achieved = (bind_bytes / bind_launches) / (bind_ms / bind_launches * 1e-3) / 1e9 if bind_launches else 0.0
+        # HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024); null if absent
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and args.message_bytes == 2048:
+            with open(pmc) as f:
+                tj = json.load(f)
+            key = "void spk::k_bind_eval_cubic_stream<1>@262144"
+            if key in tj:
+                traffic, traffic_src = tj[key]["traffic_bytes"], "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes of this command)"
         out = {
             "metric": "sha256_spartan prove(): R1CS constraints/sec (prove wall-clock in ms_per_step)",
             "value": value,
@@ -106,9 +116,12 @@ def main():
             "config": {"workload": f"sha256_spartan {args.message_bytes} B, SpartanSNARK::prove on T256HyraxEngine shapes", "num_cons_unpadded": ncons,
                        "num_cons": snark.dims["num_cons"], "num_vars": snark.dims["num_shared"] + snark.dims["num_precommitted"] + snark.dims["num_rest"],
                        "parallelism": f"{world} independent proofs (one per GPU)"},
-            "roofline": {"bound": "hbm", "kernel": "k_bind_top (sum-check bind, all rounds)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None, "launches": bind_launches, "avg_launch_us": bind_ms / max(bind_launches, 1) * 1e3,
-                         "alg_bytes_per_launch": bind_bytes / max(bind_launches, 1)},
+            "roofline": {"bound": "hbm", "kernel": "k_bind_eval_cubic_stream<1> (outer sum-check: bind round 1 fused with the evaluation of round 2, 3 tables of 2^20)",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": traffic_src, "launches": bind_launches, "avg_launch_us": bind_ms / max(bind_launches, 1) * 1e3,
+                         "alg_bytes_per_launch": bind_bytes / max(bind_launches, 1),
+                         "other_sumcheck_kernels": {k: {"launches_per_step": kstats[k][1] / nb, "avg_us": kstats[k][0] / max(kstats[k][1], 1) * 1e3,
+                                                        "alg_GBps": (kstats[k][2] / max(kstats[k][0], 1e-9)) / 1e6} for k in ("bind_stream_quad", "bind")}},
             "phases_ms": {k: v / args.steps for k, v in phase_acc.items()},
             "kernel_ms_per_step": {k: v[0] / nb for k, v in kstats.items()},
             "setup_s": t_setup,

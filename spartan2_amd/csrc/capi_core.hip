@@ -465,6 +465,10 @@ int sp_table_dot(sp_ctx* c, const sp_table* a, const sp_table* b, size_t n, uint
   return SP_OK;
 }
 
+// Fused launches with at least this many pairs per table quarter take the streaming kernels (>= 2^20-entry tables: 64 MiB+ per launch,
+// beyond the aggregate L2; at config 2 that is the first fused launch of each sum-check).
+static const size_t STREAM_MIN_Q = (size_t)1 << 18;
+
 static bool table_dense(const sp_table* t) { return sp::eff_lo(t) == t->len / 2 && sp::eff_hi(t) == t->len / 2; }
 
 int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
@@ -473,7 +477,7 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
   fe_t claim = load_fe(claim_);
   const uint8_t lbl_c[1] = {'c'};
   const size_t chunk = 256 * spk::EVAL_PPT;
-  int rc = c->ensure_scratch((A->len / 2 + chunk - 1) / chunk * 2 + 32);
+  int rc = c->ensure_scratch((A->len / 2 + chunk - 1) / chunk * 2 + (A->len / 4 / 64) * 3 + 64);  // block partials or 72-byte lazy wave partials
   if (rc) return rc;
   bool have_sums = false;  // true when the previous fused launch already produced this round's sums
   size_t pending_blocks = 0;
@@ -515,12 +519,21 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       // fused: bind this round, evaluate the next (K1 + K3 in one pass over the tables)
       const size_t q = A->len / 4;
       size_t blocks = (q + chunk - 1) / chunk;
-      c->timed("bind", 48ull * A->len * 2, [&] {
-        hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch, c->d_pinned, next_seq(c));
-      });
+      if (q >= STREAM_MIN_Q) {  // streaming regime: wave-level lazy partials + lazy second stage
+        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
+        const unsigned seq = next_seq(c);
+        c->timed("bind_stream_quad", 48ull * A->len * 2, [&] {
+          hipLaunchKernelGGL(spk::k_bind_eval_quad_stream, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, r_i, lp);
+        });
+        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+      } else {
+        c->timed("bind", 48ull * A->len * 2, [&] {
+          hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch, c->d_pinned, next_seq(c));
+        });
+        reduce_partials_launch(c, blocks, 2);
+      }
       sp::after_bind(A);
       sp::after_bind(B);
-      reduce_partials_launch(c, blocks, 2);
       have_sums = true;
     } else {
       rc = launch_bind(c, tabs, 2, r_i);
@@ -546,6 +559,7 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   size_t pyr_left = (size_t)2 << nleft, pyr_right = (size_t)2 << second_half;
   const size_t chunk = 256 * spk::EVAL_PPT;
   size_t max_blocks = (N / 2 + chunk - 1) / chunk + 1;
+  if (max_blocks * 3 * 32 < (N / 4 / 64) * 72 + 64) max_blocks = ((N / 4 / 64) * 72 + 64 + 95) / 96;  // room for lazy wave partials too
   size_t need = ell + pyr_left + pyr_right + max_blocks * 3 + 32;
   int rc = c->ensure_scratch(need);
   if (rc) return rc;
@@ -673,6 +687,19 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
       const EqSel e = select_eq(rnd + 1);
       dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
       const unsigned seq = next_seq(c);
+      if (q >= STREAM_MIN_Q && (e.mode == 0 || (e.mode == 1 && e.s >= 8))) {
+        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
+        c->timed("bind_stream_cubic", 48ull * A->len * 3, [&] {
+          if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<0>), dim3((unsigned)(q / 256)), b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.s, lp);
+          else hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<1>), dim3((unsigned)(q / 256)), b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.s, lp);
+        });
+        // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
+        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
+                           c->d_pinned, seq);
+        sp::after_bind(A);
+        sp::after_bind(B);
+        sp::after_bind(C);
+      } else {
       c->timed("bind", 48ull * A->len * 3, [&] {
         if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
         else if (e.mode == 1) hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
@@ -682,6 +709,7 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
       sp::after_bind(B);
       sp::after_bind(C);
       reduce_partials_launch(c, g.x, 2);
+      }
     } else {
       sp_table* tabs[3] = {A, B, C};
       rc = launch_bind(c, tabs, 3, r_i);

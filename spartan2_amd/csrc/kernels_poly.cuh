@@ -218,6 +218,88 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe
   }
 }
 
+// ---- streaming variants (tables beyond the L2s: L*T*32 B >= 48 MiB) -----------------------------------------------------------
+// Same data movement as the fused kernels above; the reduction is per WAVE and lazy (9-word sums, no modular adds, no LDS, no
+// barrier), and the eq_left factor / modular reduction happen once per x_out group in k_sum_partials_lazy. On a 30 us kernel the
+// block-level modular tree was a quarter of the time (tools/fused_bench.hip).
+// wave sums -> LDS -> one lazy block partial pair per 256-thread block (plain multiword adds: no modular arithmetic here)
+__device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const lazy9_t& s1, lazy9_t* __restrict__ partials) {
+  __shared__ lazy9_t sm[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sm[wave][0] = s0;
+    sm[wave][1] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {  // thread 0 -> accumulator 0, thread 1 -> accumulator 1
+    lazy9_t t = lazy_add(lazy_add(sm[0][threadIdx.x], sm[1][threadIdx.x]), lazy_add(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+    partials[(size_t)blockIdx.x * 2 + threadIdx.x] = t;
+  }
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r,
+                                                                const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // q is a multiple of the block size here
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
+  const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+  const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+  const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
+  A[id] = a0;
+  A[id + q] = a1;
+  B[id] = b0;
+  B[id + q] = b1;
+  C[id] = c0;
+  C[id + q] = c1;
+  const fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+__global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+  const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+  A[id] = a0;
+  A[id + q] = a1;
+  B[id] = b0;
+  B[id + q] = b1;
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(a0, b0))), lazy_wave_sum(lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)))), partials);
+}
+// Second stage for the streaming kernels: per group of 2^group_log2 consecutive blocks, lazy-sum, reduce mod p, multiply by
+// eq_out[group] (when given), then a modular block sum over groups. One block.
+__global__ void __launch_bounds__(256) k_sum_partials_lazy(const lazy9_t* __restrict__ partials, size_t nparts, int group_log2,
+                                                           const fe_t* __restrict__ eq_out, fe_t* __restrict__ out, unsigned seq) {
+  __shared__ fe_t smem[2 * 4];
+  const size_t ngroups = nparts >> group_log2, per = (size_t)1 << group_log2;
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+  for (size_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
+    lazy9_t l0 = partials[(g * per) * 2], l1 = partials[(g * per) * 2 + 1];
+    for (size_t k = 1; k < per; ++k) {
+      l0 = lazy_add(l0, partials[(g * per + k) * 2]);
+      l1 = lazy_add(l1, partials[(g * per + k) * 2 + 1]);
+    }
+    fe_t f0 = lazy_reduce(l0), f1 = lazy_reduce(l1);
+    if (eq_out) {
+      const fe_t eo = eq_out[g];
+      f0 = fe_mul<S>(f0, eo);
+      f1 = fe_mul<S>(f1, eo);
+    }
+    acc[0] = fe_add<S>(acc[0], f0);
+    acc[1] = fe_add<S>(acc[1], f1);
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    out[0] = acc[0];
+    out[1] = acc[1];
+    publish_result(out, seq);
+  }
+}
+
 // ---- K3: quadratic evaluation sums ---------------------------------------------------------------------------------
 //   eval0 = sum_{i < len} A0 B0 ; tinf = sum_{i < len} (A1 - A0)(B1 - B0), len = min(eff_pairs(A), eff_pairs(B), half)
 __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t len,

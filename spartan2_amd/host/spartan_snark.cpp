@@ -428,17 +428,16 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
   lap("z_build");
 
-  // The IPA mask d_vec (ipa.rs:139-145) does not depend on the transcript: draw it now from its tape position and let
-  // delta's MSM (ipa.rs:147) run on the auxiliary stream underneath the two sum-checks.
+  // The IPA mask d_vec (ipa.rs:139-145) does not depend on the transcript: draw it now from its tape position (host work that
+  // overlaps commit_zeros); delta's MSM (ipa.rs:147) is issued on the auxiliary stream right before the inner sum-check, whose
+  // latency-bound rounds leave the device mostly idle (the outer sum-check's streaming rounds are left undisturbed).
   const size_t n_ipa = M < W_ ? M : W_;
   std::vector<fe_t> dvec(n_ipa);
   {
     Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
     for (auto& x : dvec) x = peek.next();
   }
-  sp_msm_job* delta_job = nullptr;
-  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
-  lap("dvec_draw+delta_begin");
+  lap("dvec_draw");
 
   if (rows_rest) ck(sp_fixed_base_mul_h_finish(ctx, rest_job, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
   {
@@ -480,6 +479,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
   const double t_abc = now_ms();
 
+  sp_msm_job* delta_job = nullptr;
+  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
   // inner sum-check. The reference runs round 0 by hand on the compact vectors (src/spartan.rs:323-384); that round is
   // value-identical to a generic prove_quad round on the 2M-long tables with (lo_eff, hi_eff) = (M, num_extra).
   ck(sp_table_set_len(ps.abc, 2 * M, M, pk.num_extra), "abc len");

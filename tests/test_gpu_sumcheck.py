@@ -141,6 +141,29 @@ def test_sumcheck_cubic_matches_oracle(ctx, ell):
     assert (rr == r).all()
 
 
+def test_sumcheck_large_tables_take_the_streaming_kernels(ctx):
+    """2^19-entry tables: the first fused launches run k_bind_eval_*_stream (wave-level lazy partials + k_sum_partials_lazy)."""
+    rng = np.random.default_rng(SEED + 77)
+    ell = 19
+    n = 1 << ell
+    A, B = rand_table(rng, n), rand_table(rng, n)
+    C = rand_table(rng, n)  # not a satisfying triple: the claim below is simply whatever the honest sum is NOT; parity still must hold
+    taus = rand_table(rng, ell)
+    claim = rand_table(rng, 1)[0]
+    want_polys, want_r, want_fin, _ = oracle_cubic(claim, taus, A, B, C)
+    tr = hip.Transcript(ctx, b"sc")
+    polys, r, fin = hip.sumcheck_cubic3(ctx, claim, taus, *(hip.Table.from_host(ctx, x) for x in (A, B, C)), tr)
+    assert (polys == want_polys).all() and (r == want_r).all() and (fin == want_fin).all()
+    qclaim = np.zeros(4, dtype=np.uint64)
+    olib().orc_field_dot(0, p64(A), p64(B), ctypes.c_size_t(n), p64(qclaim))
+    full = (hip.SIZE_MAX, hip.SIZE_MAX)
+    want = oracle_quad(qclaim, ell, A, full, B, full)
+    trq = hip.Transcript(ctx, b"sq")
+    got = hip.sumcheck_quad(ctx, qclaim, ell, hip.Table.from_host(ctx, A), hip.Table.from_host(ctx, B), trq)
+    for g, w in zip(got, want):
+        assert (g == w).all()
+
+
 def test_sumcheck_cubic_tau_zero_fallback(ctx):
     # derive_from_claim returns None when tau_i == 0 (src/sumcheck.rs:1289-1291) -> third sum computed directly
     rng = np.random.default_rng(SEED + 30)

@@ -1,0 +1,110 @@
+// Experiment harness for the fused bind+eval kernel (K1+K2): times variants on 3 tables of length L and prints algorithmic
+// GB/s (48*L bytes per table per launch). Build:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ispartan2_amd/csrc -Iinclude tools/fused_bench.hip -o tools/fused_bench
+#include <cstdio>
+#include <vector>
+
+#include "kernels_poly.cuh"
+
+using namespace spk;
+
+__device__ __forceinline__ fe_t ld_nt(const fe_t* p) {
+  fe_t r;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u* q = reinterpret_cast<const v4u*>(p);
+  v4u a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+
+// VAR 1: nontemporal loads; VAR 2: bind only (no eval) ; VAR 3: eval arithmetic but no block_sum
+template <int VAR, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_var(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r,
+                                                const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s, fe_t* __restrict__ partials) {
+  __shared__ fe_t smem[2 * 4];
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+  if (id < q) {
+    fe_t la0, la1, la2, la3, lb0, lb1, lb2, lb3, lc0, lc1, lc2, lc3;
+    if (VAR == 1) {
+      la0 = ld_nt(A + id); la1 = ld_nt(A + id + q); la2 = ld_nt(A + id + 2 * q); la3 = ld_nt(A + id + 3 * q);
+      lb0 = ld_nt(B + id); lb1 = ld_nt(B + id + q); lb2 = ld_nt(B + id + 2 * q); lb3 = ld_nt(B + id + 3 * q);
+      lc0 = ld_nt(C + id); lc1 = ld_nt(C + id + q); lc2 = ld_nt(C + id + 2 * q); lc3 = ld_nt(C + id + 3 * q);
+    } else {
+      la0 = A[id]; la1 = A[id + q]; la2 = A[id + 2 * q]; la3 = A[id + 3 * q];
+      lb0 = B[id]; lb1 = B[id + q]; lb2 = B[id + 2 * q]; lb3 = B[id + 3 * q];
+      lc0 = C[id]; lc1 = C[id + q]; lc2 = C[id + 2 * q]; lc3 = C[id + 3 * q];
+    }
+    const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+    const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+    const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
+    A[id] = a0; A[id + q] = a1; B[id] = b0; B[id + q] = b1; C[id] = c0; C[id + q] = c1;
+    if (VAR != 2) {
+      fe_t w = eq_in[id & mask];
+      const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+      const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+      acc[0] = fe_mul<S>(w, t0e);
+      acc[1] = fe_mul<S>(w, tie);
+    }
+  }
+  if (VAR == 2) return;
+  if (VAR == 3) {
+    if (id < q && (acc[0].v[0] ^ acc[1].v[0]) == 0x12345u) partials[0] = acc[0];
+    return;
+  }
+  if (BLOCK == 256) {
+    block_sum<2>(acc, smem);
+  } else {
+    acc[0] = wave_sum(acc[0]);
+    acc[1] = wave_sum(acc[1]);
+  }
+  if (threadIdx.x == 0) {
+    const fe_t eo = eq_out[((size_t)blockIdx.x * blockDim.x) >> s];
+    partials[(size_t)blockIdx.x * 2] = fe_mul<S>(acc[0], eo);
+    partials[(size_t)blockIdx.x * 2 + 1] = fe_mul<S>(acc[1], eo);
+  }
+}
+
+template <class L>
+static float time_us(L&& f, int reps) {
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  f();
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int i = 0; i < reps; ++i) {
+    hipEventRecord(a);
+    f();
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    if (ms < best) best = ms;
+  }
+  return best * 1e3f;
+}
+
+int main() {
+  for (int logL : {20, 22, 24}) {
+    const size_t L = (size_t)1 << logL, q = L / 4;
+    fe_t *A, *B, *C, *eq, *eo, *part;
+    hipMalloc(&A, L * 32); hipMalloc(&B, L * 32); hipMalloc(&C, L * 32);
+    hipMalloc(&eq, 1024 * 32); hipMalloc(&eo, ((q >> 10) + 1) * 32); hipMalloc(&part, (q / 64 + 16) * 64);
+    hipMemset(A, 0x11, L * 32); hipMemset(B, 0x22, L * 32); hipMemset(C, 0x33, L * 32);
+    hipMemset(eq, 0x05, 1024 * 32); hipMemset(eo, 0x07, ((q >> 10) + 1) * 32);
+    fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = 0x01234567u * (i + 1);
+    const double bytes = 48.0 * L * 3;
+    auto report = [&](const char* name, float us) { printf("L=2^%d %-34s %8.1f us  %7.0f GB/s (%.1f%% of 8 TB/s)\n", logL, name, us, bytes / us / 1e3, bytes / us / 1e3 / 80.0); };
+    report("library k_bind_eval_cubic<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic<1>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part, part, 1u); }, 10));
+    report("var0 block256", time_us([&] { hipLaunchKernelGGL((k_var<0, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
+    report("var1 nontemporal loads", time_us([&] { hipLaunchKernelGGL((k_var<1, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
+    report("var0 block64 (wave-only reduce)", time_us([&] { hipLaunchKernelGGL((k_var<0, 64>), dim3((q + 63) / 64), dim3(64), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
+    report("var2 bind only", time_us([&] { hipLaunchKernelGGL((k_var<2, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
+    report("var3 bind+eval, no block reduce", time_us([&] { hipLaunchKernelGGL((k_var<3, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
+    hipFree(A); hipFree(B); hipFree(C); hipFree(eq); hipFree(eo); hipFree(part);
+  }
+  return 0;
+}
