@@ -391,7 +391,9 @@ void orc_spartan_prep_free(void* ps) { delete (SpartanPrep*)ps; }
 int orc_spartan_prep_export(void* ps_, uint64_t* comm_rows, uint64_t* caz, uint64_t* cbz, uint64_t* ccz) {
   auto* ps = (SpartanPrep*)ps_;
   if (comm_rows) {
-    std::vector<Affine> a = batch_affine(ps->comm_W_precommitted);
+    HyraxCommitment both = ps->comm_W_shared;
+    both.insert(both.end(), ps->comm_W_precommitted.begin(), ps->comm_W_precommitted.end());
+    std::vector<Affine> a = batch_affine(both);
     for (size_t i = 0; i < a.size(); ++i) store_aff(comm_rows + 8 * i, a[i]);
   }
   if (caz) store(caz, ps->cached_az);
@@ -434,16 +436,18 @@ void* orc_spartan_proof_from_words(void* pk_, const uint64_t* w, size_t nwords) 
   try {
     auto* pk = (SpartanProverKey*)pk_;
     const SplitR1CSShape<Fq>& S = pk->S;
+    size_t rows_sh = div_ceil(S.num_shared, pk->ck.num_cols);
     size_t rows_pre = div_ceil(S.num_precommitted, pk->ck.num_cols), rows_rest = div_ceil(S.num_rest, pk->ck.num_cols);
     size_t lx = log2_exact(S.num_cons), ly = log2_exact(S.num_vars()) + 1, nz = pk->ck.num_cols;
     if (S.num_vars() < nz) nz = S.num_vars();
-    size_t expect = 8 * (rows_pre + rows_rest) + 4 * S.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
+    size_t expect = 8 * (rows_sh + rows_pre + rows_rest) + 4 * S.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
     if (nwords != expect) throw std::runtime_error("proof_from_words: length mismatch");
     auto* pf = new SpartanProof();
     size_t o = 0;
     auto gf = [&]() { Fq f = Fq::from_raw_mont(w + o); o += 4; return f; };
     auto gp = [&]() { Affine a = load_aff(w + o); o += 8; return Jac::from_affine(a); };
-    for (size_t i = 0; i < rows_pre + rows_rest; ++i) pf->comm_W.push_back(gp());
+    for (size_t i = 0; i < rows_sh + rows_pre + rows_rest; ++i) pf->comm_W.push_back(gp());
+    pf->rows_shared = rows_sh;
     pf->rows_precommitted = rows_pre;
     for (size_t i = 0; i < S.num_public; ++i) pf->public_values.push_back(gf());
     for (size_t i = 0; i < lx; ++i) pf->sc_proof_outer.compressed_polys.push_back({gf(), gf(), gf()});

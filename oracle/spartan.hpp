@@ -2,9 +2,9 @@
 //
 // Restates the protocol driver src/spartan.rs: setup (:146-173), prep_prove (:176-216),
 // prove (:219-466), verify (:469-578), with the witness staging of src/bellpepper/r1cs.rs
-// (precommitted_witness :359-409, r1cs_instance_and_witness :411-538) for circuits with no shared
-// variables, no rest variables and no challenges (both BASELINE.json bench circuits,
-// benches/sha256_spartan.rs:71-76,139-151) — the `skip_synthesize` fast path (:443).
+// (shared_witness :306-357, precommitted_witness :359-409, r1cs_instance_and_witness :411-538) for circuits
+// without verifier challenges: any mix of shared / precommitted / rest variables (the bench circuits are precommitted-only and take the
+// `skip_synthesize` + commit_zeros path :443,:468; the reference's own e2e test circuit, src/spartan.rs:587-651, is rest-only).
 //
 // Substitution (documented): the verifier-key digest. The reference
 // hashes bincode(vk_ee) || bincode(ck_s) || S.write_bytes() with SHA-256 (src/spartan.rs:73-104,
@@ -68,32 +68,42 @@ inline SpartanProverKey spartan_setup(SplitR1CSShape<Fq> S) {  // src/spartan.rs
   return pk;
 }
 
-struct SpartanPrep {  // SpartanPrepSNARK, src/spartan.rs:107-124
-  std::vector<Fq> W;  // padded witness (shared | precommitted | rest)
-  HyraxCommitment comm_W_precommitted;
-  HyraxBlind r_W_precommitted;
+struct SpartanPrep {  // SpartanPrepSNARK, src/spartan.rs:107-124 (+ PrecommittedState, bellpepper/r1cs.rs:290-301)
+  std::vector<Fq> W;  // padded witness (shared | precommitted | rest); the rest values are known up front (no challenges)
+  HyraxCommitment comm_W_shared, comm_W_precommitted;  // empty when the segment is empty
+  HyraxBlind r_W_shared, r_W_precommitted;
   std::vector<Fq> cached_az, cached_bz, cached_cz;
+  bool is_small = true;
 };
 
-// src/spartan.rs:176-216 + bellpepper/r1cs.rs:359-409. `witness` = unpadded aux assignment.
+// src/spartan.rs:176-216 + bellpepper/r1cs.rs:306-409 (shared_witness, precommitted_witness).
+// `witness` = unpadded aux assignment, shared | precommitted | rest. Circuits with verifier challenges are not restated.
 inline SpartanPrep spartan_prep_prove(const SpartanProverKey& pk, const std::vector<Fq>& witness, bool is_small, Tape& tape) {
   const SplitR1CSShape<Fq>& S = pk.S;
-  if (S.num_shared_unpadded != 0 || S.num_rest_unpadded != 0 || S.num_challenges != 0)
-    throw std::runtime_error("oracle restates only the precommitted-only circuits of the benches");
-  if (witness.size() != S.num_precommitted_unpadded) throw std::runtime_error("InvalidWitnessLength");
+  if (S.num_challenges != 0) throw std::runtime_error("oracle restates circuits without verifier challenges only");
+  if (witness.size() != S.num_shared_unpadded + S.num_precommitted_unpadded + S.num_rest_unpadded) throw std::runtime_error("InvalidWitnessLength");
   SpartanPrep ps;
+  ps.is_small = is_small;
   ps.W.assign(S.num_vars(), Fq::zero());
-  std::copy(witness.begin(), witness.end(), ps.W.begin() + S.num_shared);
-  ps.r_W_precommitted = hyrax_blind(pk.ck, S.num_precommitted, tape);
-  ps.comm_W_precommitted = hyrax_commit(pk.ck, ps.W.data() + S.num_shared, S.num_precommitted, ps.r_W_precommitted, is_small);
+  std::copy(witness.begin(), witness.begin() + S.num_shared_unpadded, ps.W.begin());
+  std::copy(witness.begin() + S.num_shared_unpadded, witness.begin() + S.num_shared_unpadded + S.num_precommitted_unpadded, ps.W.begin() + S.num_shared);
+  std::copy(witness.begin() + S.num_shared_unpadded + S.num_precommitted_unpadded, witness.end(), ps.W.begin() + S.num_shared + S.num_precommitted);
+  if (S.num_shared_unpadded > 0) {  // r1cs.rs:337-344
+    ps.r_W_shared = hyrax_blind(pk.ck, S.num_shared, tape);
+    ps.comm_W_shared = hyrax_commit(pk.ck, ps.W.data(), S.num_shared, ps.r_W_shared, is_small);
+  }
+  if (S.num_precommitted_unpadded > 0) {  // r1cs.rs:388-399
+    ps.r_W_precommitted = hyrax_blind(pk.ck, S.num_precommitted, tape);
+    ps.comm_W_precommitted = hyrax_commit(pk.ck, ps.W.data() + S.num_shared, S.num_precommitted, ps.r_W_precommitted, is_small);
+  }
   std::vector<Fq> zc(ps.W.begin(), ps.W.begin() + S.num_shared + S.num_precommitted);
   S.multiply_vec_precommitted(zc, &ps.cached_az, &ps.cached_bz, &ps.cached_cz);
   return ps;
 }
 
 struct SpartanProof {  // SpartanSNARK, src/spartan.rs:130-138
-  HyraxCommitment comm_W;  // precommitted rows then rest rows (to_regular_instance, src/r1cs/mod.rs:1535-1550)
-  size_t rows_precommitted = 0;
+  HyraxCommitment comm_W;  // shared rows, precommitted rows, rest rows (to_regular_instance, src/r1cs/mod.rs:1535-1550)
+  size_t rows_shared = 0, rows_precommitted = 0;
   std::vector<Fq> public_values;
   SumcheckProof<Fq> sc_proof_outer, sc_proof_inner;
   Fq claims_outer[3];
@@ -134,19 +144,30 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   tr.absorb_bytes("vk", pk.vk_digest, 32);
   tr.absorb_scalars("public_values", public_values.data(), public_values.size());
   // r1cs_instance_and_witness (bellpepper/r1cs.rs:411-538)
-  {
+  if (!ps.comm_W_shared.empty()) {
+    std::vector<uint8_t> b = commitment_transcript_bytes(ps.comm_W_shared);
+    tr.absorb_bytes("comm_W_shared", b.data(), b.size());
+  }
+  if (!ps.comm_W_precommitted.empty()) {
     std::vector<uint8_t> b = commitment_transcript_bytes(ps.comm_W_precommitted);
     tr.absorb_bytes("comm_W_precommitted", b.data(), b.size());
   }
   HyraxBlind r_W_rest = hyrax_blind(pk.ck, S.num_rest, tape);
-  HyraxCommitment comm_W_rest = hyrax_commit_zeros(pk.ck, S.num_rest, r_W_rest);
+  HyraxCommitment comm_W_rest;
+  if (S.num_rest_unpadded == 0) {
+    comm_W_rest = hyrax_commit_zeros(pk.ck, S.num_rest, r_W_rest);  // r1cs.rs:468-470
+  } else {  // r1cs.rs:471-489: is_small hint, or detection over the non-padding part (hyrax_commit detects per row: same value)
+    comm_W_rest = hyrax_commit(pk.ck, ps.W.data() + S.num_shared + S.num_precommitted, S.num_rest, r_W_rest, ps.is_small);
+  }
   {
     std::vector<uint8_t> b = commitment_transcript_bytes(comm_W_rest);
     tr.absorb_bytes("comm_W_rest", b.data(), b.size());
   }
-  HyraxBlind r_W = ps.r_W_precommitted;
+  HyraxBlind r_W = ps.r_W_shared;  // combine_blinds (r1cs.rs:515-524)
+  r_W.insert(r_W.end(), ps.r_W_precommitted.begin(), ps.r_W_precommitted.end());
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
-  HyraxCommitment comm_W = ps.comm_W_precommitted;
+  HyraxCommitment comm_W = ps.comm_W_shared;
+  comm_W.insert(comm_W.end(), ps.comm_W_precommitted.begin(), ps.comm_W_precommitted.end());
   comm_W.insert(comm_W.end(), comm_W_rest.begin(), comm_W_rest.end());
 
   size_t num_vars = S.num_vars();
@@ -164,6 +185,7 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
 
   SpartanProof proof;
   proof.comm_W = comm_W;
+  proof.rows_shared = ps.comm_W_shared.size();
   proof.rows_precommitted = ps.comm_W_precommitted.size();
   proof.public_values = public_values;
   std::vector<Fq> r_x, claims_outer;
@@ -236,14 +258,22 @@ inline int spartan_verify(const SpartanProverKey& vk, const SpartanProof& pf) {
   Transcript tr("SpartanSNARK");
   tr.absorb_bytes("vk", vk.vk_digest, 32);
   tr.absorb_scalars("public_values", pf.public_values.data(), pf.public_values.size());
-  // SplitR1CSInstance::validate (src/r1cs/mod.rs): commitment lengths + transcript absorption
-  size_t rows_pre = div_ceil(S.num_precommitted, vk.ck.num_cols), rows_rest = div_ceil(S.num_rest, vk.ck.num_cols);
-  if (pf.rows_precommitted != rows_pre || pf.comm_W.size() != rows_pre + rows_rest) return 1;
+  // SplitR1CSInstance::validate (src/r1cs/mod.rs:1490-1533): commitment lengths + transcript absorption
+  size_t rows_sh = div_ceil(S.num_shared, vk.ck.num_cols), rows_pre = div_ceil(S.num_precommitted, vk.ck.num_cols), rows_rest = div_ceil(S.num_rest, vk.ck.num_cols);
+  if (pf.rows_shared != rows_sh || pf.rows_precommitted != rows_pre || pf.comm_W.size() != rows_sh + rows_pre + rows_rest) return 1;
   if (pf.public_values.size() != S.num_public) return 1;
   {
-    HyraxCommitment pre(pf.comm_W.begin(), pf.comm_W.begin() + rows_pre), rest(pf.comm_W.begin() + rows_pre, pf.comm_W.end());
-    std::vector<uint8_t> b = commitment_transcript_bytes(pre);
-    tr.absorb_bytes("comm_W_precommitted", b.data(), b.size());
+    HyraxCommitment sh(pf.comm_W.begin(), pf.comm_W.begin() + rows_sh), pre(pf.comm_W.begin() + rows_sh, pf.comm_W.begin() + rows_sh + rows_pre),
+        rest(pf.comm_W.begin() + rows_sh + rows_pre, pf.comm_W.end());
+    std::vector<uint8_t> b;
+    if (S.num_shared > 0) {
+      b = commitment_transcript_bytes(sh);
+      tr.absorb_bytes("comm_W_shared", b.data(), b.size());
+    }
+    if (S.num_precommitted > 0) {
+      b = commitment_transcript_bytes(pre);
+      tr.absorb_bytes("comm_W_precommitted", b.data(), b.size());
+    }
     b = commitment_transcript_bytes(rest);
     tr.absorb_bytes("comm_W_rest", b.data(), b.size());
   }

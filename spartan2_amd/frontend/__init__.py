@@ -24,6 +24,7 @@ def lib():
         L = ctypes.CDLL(_LIB)
         L.spf_sha256_circuit.restype = ctypes.c_void_p
         L.spf_synthetic_circuit.restype = ctypes.c_void_p
+        L.spf_cubic_circuit.restype = ctypes.c_void_p
         L.spf_witness.restype = ctypes.POINTER(ctypes.c_uint64)
         L.spf_publics.restype = ctypes.POINTER(ctypes.c_uint64)
         L.spf_last_error.restype = ctypes.c_char_p
@@ -62,5 +63,12 @@ def sha256_circuit(preimage: bytes) -> R1CSInstanceInt:
     return R1CSInstanceInt(lib().spf_sha256_circuit(preimage, ctypes.c_size_t(len(preimage))))
 
 
-def synthetic_circuit(n_groups: int, seed: int, num_public: int = 4) -> R1CSInstanceInt:
-    return R1CSInstanceInt(lib().spf_synthetic_circuit(ctypes.c_size_t(n_groups), ctypes.c_uint64(seed), ctypes.c_size_t(num_public)))
+def synthetic_circuit(n_groups: int, seed: int, num_public: int = 4, shared_permille: int = 0, precommitted_permille: int = 1000) -> R1CSInstanceInt:
+    """Seeded SHA-like circuit; the permille arguments cut the aux list into shared | precommitted | rest segments."""
+    return R1CSInstanceInt(lib().spf_synthetic_circuit(ctypes.c_size_t(n_groups), ctypes.c_uint64(seed), ctypes.c_size_t(num_public),
+                                                       ctypes.c_uint(shared_permille), ctypes.c_uint(precommitted_permille)))
+
+
+def cubic_circuit() -> R1CSInstanceInt:
+    """CubicCircuit of the reference's own end-to-end test (src/spartan.rs:587-651): rest-only, public output 15."""
+    return R1CSInstanceInt(lib().spf_cubic_circuit())

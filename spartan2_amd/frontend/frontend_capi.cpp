@@ -19,9 +19,17 @@ void* spf_sha256_circuit(const uint8_t* msg, size_t n) {
     return nullptr;
   }
 }
-void* spf_synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public) {
+void* spf_synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public, unsigned shared_permille, unsigned precommitted_permille) {
   try {
-    return new R1CSInstanceInt(synthetic_circuit(n_groups, seed, num_public));
+    return new R1CSInstanceInt(synthetic_circuit(n_groups, seed, num_public, shared_permille, precommitted_permille));
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void* spf_cubic_circuit() {
+  try {
+    return new R1CSInstanceInt(cubic_circuit());
   } catch (const std::exception& e) {
     g_err = e.what();
     return nullptr;

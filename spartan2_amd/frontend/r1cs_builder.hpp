@@ -420,7 +420,10 @@ inline uint64_t splitmix64(uint64_t& s) {
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
   return z ^ (z >> 31);
 }
-inline R1CSInstanceInt synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public) {
+// `shared_permille` / `precommitted_permille`: where to cut the aux list into shared | precommitted | rest segments (the
+// segments of SpartanCircuit::{shared, precommitted, synthesize}, src/traits/circuit.rs); 0/1000 = everything precommitted.
+inline R1CSInstanceInt synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public, unsigned shared_permille = 0,
+                                         unsigned precommitted_permille = 1000) {
   ConstraintSystem cs;
   uint64_t s = seed;
   std::vector<Boolean> pool;
@@ -451,7 +454,22 @@ inline R1CSInstanceInt synthetic_circuit(size_t n_groups, uint64_t seed, size_t 
     cs.enforce(la, {{ConstraintSystem::one(), 1}}, {{n, 1}});
   }
   size_t num_aux = cs.aux.size();
-  return finalize(cs, 0, num_aux);
+  size_t ns = num_aux * shared_permille / 1000, np = num_aux * precommitted_permille / 1000;
+  if (ns + np > num_aux) np = num_aux - ns;
+  return finalize(cs, ns, np);
+}
+
+// CubicCircuit of the reference's end-to-end test (src/spartan.rs:587-651): x^3 + x + 5 = y with x = 2; every variable is
+// allocated in `synthesize`, i.e. in the REST segment; one public output (15).
+inline R1CSInstanceInt cubic_circuit() {
+  ConstraintSystem cs;
+  const uint32_t x = cs.alloc_aux(2), x_sq = cs.alloc_aux(4), x_cu = cs.alloc_aux(8), y = cs.alloc_aux(15);
+  cs.enforce({{x, 1}}, {{x, 1}}, {{x_sq, 1}});        // AllocatedNum::square
+  cs.enforce({{x_sq, 1}}, {{x, 1}}, {{x_cu, 1}});     // AllocatedNum::mul
+  cs.enforce({{x_cu, 1}, {x, 1}, {ConstraintSystem::one(), 5}}, {{ConstraintSystem::one(), 1}}, {{y, 1}});  // y = x^3 + x + 5
+  const uint32_t out = cs.alloc_input(15);             // AllocatedNum::inputize
+  cs.enforce({{out, 1}}, {{ConstraintSystem::one(), 1}}, {{y, 1}});
+  return finalize(cs, 0, 0);
 }
 
 }  // namespace sp_frontend

@@ -105,13 +105,14 @@ class SpartanSNARK:
         return used.value
 
     def prep_export(self):
-        rows = (self.dims["num_precommitted"] + 2047) // 2048
+        d = self.dims
+        rows = ((d["num_shared"] + 2047) // 2048 if d["num_shared_unpadded"] else 0) + ((d["num_precommitted"] + 2047) // 2048 if d["num_precommitted_unpadded"] else 0)
         N = self.dims["num_cons"]
         comm = np.zeros((rows, 8), dtype=np.uint64)
         caz = np.zeros((N, 4), dtype=np.uint64)
         cbz = np.zeros_like(caz)
         ccz = np.zeros_like(caz)
-        _check(lib().ss_prep_export(self.pk, self.ps, hip.p64(comm), hip.p64(caz), hip.p64(cbz), hip.p64(ccz)))
+        _check(lib().ss_prep_export(self.pk, self.ps, hip.p64(comm) if rows else None, hip.p64(caz), hip.p64(cbz), hip.p64(ccz)))
         return comm, caz, cbz, ccz
 
     def prove(self, tape: np.ndarray):

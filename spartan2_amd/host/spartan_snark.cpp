@@ -5,7 +5,8 @@
 //   SpartanSNARK::setup            src/spartan.rs:146-173
 //   SpartanSNARK::prep_prove       src/spartan.rs:176-216       (+ bellpepper/r1cs.rs:359-409 precommitted_witness)
 //   SpartanSNARK::prove            src/spartan.rs:219-466       (+ bellpepper/r1cs.rs:411-538, hyrax_pc.rs:387-478, ipa.rs:125-170)
-// for circuits with no shared / rest variables and no challenges (both bench circuits; the skip_synthesize path :443).
+// for circuits without verifier challenges: any mix of shared / precommitted / rest variables (bench circuits: precommitted-only,
+// skip_synthesize + commit_zeros path :443; the reference's e2e CubicCircuit src/spartan.rs:587-651: rest-only).
 // Verification is not restated here: the reference verifier is CPU code outside the accelerated path;
 // tests verify with the oracle's restated verifier.
 //
@@ -277,9 +278,11 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   sp_table *W = nullptr, *caz = nullptr, *cbz = nullptr, *ccz = nullptr;      // witness + cached partial products
   sp_table *az = nullptr, *bz = nullptr, *cz = nullptr, *z = nullptr;          // scratch reused across prove calls
   sp_table *rx = nullptr, *abc = nullptr;
-  std::vector<aff_t> comm_W_precommitted;
-  std::vector<fe_t> r_W_precommitted;
-  std::vector<uint8_t> comm_pre_bytes;
+  std::vector<aff_t> comm_W_fixed;  // rows committed at prep time: shared rows, then precommitted rows
+  std::vector<fe_t> r_W_fixed;      // their blinds, same order
+  size_t rows_shared = 0, rows_precommitted = 0;
+  std::vector<uint8_t> comm_shared_bytes, comm_pre_bytes;  // transcript encodings (hyrax_pc.rs:714-729)
+  bool is_small = true;
   sp_transcript* tr_prefix = nullptr;  // transcript state after the per-instance prefix (see prove)
   std::vector<fe_t> tr_publics;
   ~SpartanPrepSNARK() {
@@ -330,29 +333,43 @@ SpartanProverKey* setup(sp_ctx* ctx, const R1CSIntView& R) {
 // SpartanSNARK::prep_prove (src/spartan.rs:176-216)
 SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness_u64, size_t n_witness, bool is_small, Tape& tape) {
   const sp_dims& d = pk.dims;
-  if (d.num_shared_unpadded != 0 || d.num_rest_unpadded != 0 || d.num_challenges != 0)
-    throw Error(SP_ERR_INTERNAL, "only precommitted-only circuits (the bench circuits) are driven by this host layer");
-  if (n_witness != d.num_precommitted_unpadded) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
+  if (d.num_challenges != 0) throw Error(SP_ERR_INTERNAL, "circuits with verifier challenges are not driven by this host layer");
+  if (n_witness != d.num_shared_unpadded + d.num_precommitted_unpadded + d.num_rest_unpadded) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
   auto* ps = new SpartanPrepSNARK();
   try {
     sp_ctx* ctx = pk.ctx;
     const size_t M = pk.num_vars, N = d.num_cons;
-    // precommitted_witness (bellpepper/r1cs.rs:359-409): W[num_shared .. num_shared + unpadded] = aux assignment
+    ps->is_small = is_small;
+    // shared_witness / precommitted_witness (bellpepper/r1cs.rs:306-409): each segment starts at its padded offset. The rest
+    // segment is filled here as well: without verifier challenges it does not change between proves.
     std::vector<fe_t> W(M, fe_zero());
     const fe_t one = fe_one<S>();
-    for (size_t i = 0; i < n_witness; ++i) {
-      uint64_t v = witness_u64[i];
-      W[d.num_shared + i] = v == 0 ? fe_zero() : (v == 1 ? one : fe_from_u64<S>(v));
-    }
+    auto put = [&](size_t dst, size_t src, size_t cnt) {
+      for (size_t i = 0; i < cnt; ++i) {
+        uint64_t v = witness_u64[src + i];
+        W[dst + i] = v == 0 ? fe_zero() : (v == 1 ? one : fe_from_u64<S>(v));
+      }
+    };
+    put(0, 0, d.num_shared_unpadded);
+    put(d.num_shared, d.num_shared_unpadded, d.num_precommitted_unpadded);
+    put(d.num_shared + d.num_precommitted, d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded);
     ck(sp_table_from_host(ctx, u64p(W.data()), M, (size_t)-1, (size_t)-1, &ps->W), "upload W");
-    const size_t rows_pre = (d.num_precommitted + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH;
-    ps->r_W_precommitted.resize(rows_pre);  // PCS::blind (hyrax_pc.rs:192-205)
-    for (auto& b : ps->r_W_precommitted) b = tape.next();
-    ps->comm_W_precommitted.resize(rows_pre);
-    ck(sp_hyrax_commit(ctx, pk.ck, ps->W, d.num_shared, d.num_precommitted, u64p(ps->r_W_precommitted.data()), is_small ? 1 : 0,
-                       u64p(&ps->comm_W_precommitted[0].x)),
-       "commit precommitted");
-    ps->comm_pre_bytes = commitment_bytes(ps->comm_W_precommitted.data(), rows_pre);
+    const size_t CW = DEFAULT_COMMITMENT_WIDTH;
+    ps->rows_shared = d.num_shared_unpadded ? (d.num_shared + CW - 1) / CW : 0;
+    ps->rows_precommitted = d.num_precommitted_unpadded ? (d.num_precommitted + CW - 1) / CW : 0;
+    ps->r_W_fixed.resize(ps->rows_shared + ps->rows_precommitted);  // PCS::blind (hyrax_pc.rs:192-205), shared first
+    for (auto& b : ps->r_W_fixed) b = tape.next();
+    ps->comm_W_fixed.resize(ps->r_W_fixed.size());
+    if (ps->rows_shared) {
+      ck(sp_hyrax_commit(ctx, pk.ck, ps->W, 0, d.num_shared, u64p(ps->r_W_fixed.data()), is_small ? 1 : 0, u64p(&ps->comm_W_fixed[0].x)), "commit shared");
+      ps->comm_shared_bytes = commitment_bytes(ps->comm_W_fixed.data(), ps->rows_shared);
+    }
+    if (ps->rows_precommitted) {
+      ck(sp_hyrax_commit(ctx, pk.ck, ps->W, d.num_shared, d.num_precommitted, u64p(ps->r_W_fixed.data() + ps->rows_shared), is_small ? 1 : 0,
+                         u64p(&ps->comm_W_fixed[ps->rows_shared].x)),
+         "commit precommitted");
+      ps->comm_pre_bytes = commitment_bytes(ps->comm_W_fixed.data() + ps->rows_shared, ps->rows_precommitted);
+    }
     // multiply_vec_precommitted (src/r1cs/mod.rs:1112-1128): z = [W_cached | 0 ...]
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->z), "alloc z");
     ck(sp_table_copy(ctx, ps->z, 0, ps->W, 0, d.num_shared + d.num_precommitted), "copy W");
@@ -388,14 +405,15 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> publics(npub);
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
 
-  // commit_zeros for the all-padding rest segment (hyrax_pc.rs:305-319): started first, collected after the host work below
-  const size_t rows_pre = ps.comm_W_precommitted.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
+  // commitment to the rest segment (bellpepper/r1cs.rs:463-491): commit_zeros (hyrax_pc.rs:305-319) when it is all padding —
+  // started first on the auxiliary stream, collected after the host work below — else PCS::commit on the resident witness.
+  const size_t rows_pre = ps.comm_W_fixed.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
   std::vector<fe_t> r_W_rest(rows_rest);
   for (auto& b : r_W_rest) b = tape.next();
   std::vector<aff_t> comm_W(rows_pre + rows_rest);
-  std::copy(ps.comm_W_precommitted.begin(), ps.comm_W_precommitted.end(), comm_W.begin());
+  std::copy(ps.comm_W_fixed.begin(), ps.comm_W_fixed.end(), comm_W.begin());
   sp_fb_job* rest_job = nullptr;
-  if (rows_rest) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
+  if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
   lap("commit_zeros_begin");
 
   // transcript prefix: new + vk + public_values + comm_W_precommitted repeats for every prove on this prep state, so its
@@ -404,8 +422,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     Tr t0(ctx, "SpartanSNARK");
     t0.absorb("vk", pk.vk_digest, 32);
     t0.absorb_scalars("public_values", publics.data(), npub);
-    // r1cs_instance_and_witness (bellpepper/r1cs.rs:411-538), skip_synthesize path
-    t0.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
+    // r1cs_instance_and_witness (bellpepper/r1cs.rs:422-427)
+    if (ps.rows_shared) t0.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
+    if (ps.rows_precommitted) t0.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
     ps.tr_prefix = t0.t;
     t0.t = nullptr;
     ps.tr_publics = publics;
@@ -439,13 +458,16 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   }
   lap("dvec_draw");
 
-  if (rows_rest) ck(sp_fixed_base_mul_h_finish(ctx, rest_job, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
+  if (rest_job) ck(sp_fixed_base_mul_h_finish(ctx, rest_job, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
+  else if (rows_rest)
+    ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)),
+       "commit rest");
   {
     std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
   }
   lap("commit_zeros_finish+absorb");
-  std::vector<fe_t> r_W = ps.r_W_precommitted;  // combine_blinds
+  std::vector<fe_t> r_W = ps.r_W_fixed;  // combine_blinds (bellpepper/r1cs.rs:515-524)
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
   const double t_wit = now_ms();
 
@@ -673,7 +695,7 @@ int ss_prep_export(void* pk_, void* ps_, uint64_t* comm_rows, uint64_t* caz, uin
   try {
     auto* pk = (SpartanProverKey*)pk_;
     auto* ps = (SpartanPrepSNARK*)ps_;
-    if (comm_rows) memcpy(comm_rows, ps->comm_W_precommitted.data(), ps->comm_W_precommitted.size() * sizeof(aff_t));
+    if (comm_rows && !ps->comm_W_fixed.empty()) memcpy(comm_rows, ps->comm_W_fixed.data(), ps->comm_W_fixed.size() * sizeof(aff_t));
     const size_t N = pk->dims.num_cons;
     if (caz) ck(sp_table_read(pk->ctx, ps->caz, 0, N, caz), "read caz");
     if (cbz) ck(sp_table_read(pk->ctx, ps->cbz, 0, N, cbz), "read cbz");
@@ -686,7 +708,7 @@ int ss_prep_export(void* pk_, void* ps_, uint64_t* comm_rows, uint64_t* caz, uin
 size_t ss_proof_words(void* pk_) {
   auto* pk = (SpartanProverKey*)pk_;
   const sp_dims& d = pk->dims;
-  size_t rows = (d.num_precommitted + 2047) / 2048 + (d.num_rest + 2047) / 2048;
+  size_t rows = (d.num_shared_unpadded ? (d.num_shared + 2047) / 2048 : 0) + (d.num_precommitted_unpadded ? (d.num_precommitted + 2047) / 2048 : 0) + (d.num_rest + 2047) / 2048;
   size_t lx = log2_ceil(d.num_cons), ly = log2_ceil(pk->num_vars) + 1, nz = pk->num_vars < 2048 ? pk->num_vars : 2048;
   return 8 * rows + 4 * d.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
 }

@@ -181,12 +181,13 @@ class OracleSpartan:
         return used.value
 
     def prep_export(self):
-        rows = (self.shape.num_precommitted + 2047) // 2048
+        sh = self.shape
+        rows = ((sh.num_shared + 2047) // 2048 if sh.num_shared_unpadded else 0) + ((sh.num_precommitted + 2047) // 2048 if sh.num_precommitted_unpadded else 0)
         comm = np.zeros((rows, 8), dtype=np.uint64)
         caz = np.zeros((self.shape.num_cons, 4), dtype=np.uint64)
         cbz = np.zeros_like(caz)
         ccz = np.zeros_like(caz)
-        lib().orc_spartan_prep_export(self.ps, p64(comm), p64(caz), p64(cbz), p64(ccz))
+        lib().orc_spartan_prep_export(self.ps, p64(comm) if rows else None, p64(caz), p64(cbz), p64(ccz))
         return comm, caz, cbz, ccz
 
     def prove(self, tape):

@@ -56,6 +56,33 @@ def test_prove_matches_oracle_bit_exact(ctx, which):
     assert osp.verify_words(got2) == 0
 
 
+def test_reference_e2e_cubic_circuit_on_the_gpu(ctx):
+    """The reference's own end-to-end test (src/spartan.rs:653-688, T256HyraxEngine): rest-only CubicCircuit, is_small = false,
+    verify() must return the public output [15]."""
+    inst = frontend.cubic_circuit()
+    tape = ol.make_tape(3, 4096)
+    osp = ol.OracleSpartan(inst)
+    assert osp.prep_prove(tape, is_small=False) == 0
+    want = osp.prove(tape)[0]
+    gsp = host.SpartanSNARK(ctx, inst)
+    assert gsp.prep_prove(tape, is_small=False) == 0
+    got = gsp.prove(tape)[0]
+    assert (got == want).all()
+    assert osp.verify_words(got) == 0
+    assert ol.from_mont(got[8:12]) == 15
+
+
+@pytest.mark.parametrize("cut", [(300, 400), (0, 0), (1000, 0), (250, 0), (0, 600)])
+def test_shared_precommitted_rest_segments_match_oracle(ctx, cut):
+    # shared_witness / precommitted_witness / rest commitments (bellpepper/r1cs.rs:306-538) in every combination
+    inst = frontend.synthetic_circuit(6, 21, num_public=2, shared_permille=cut[0], precommitted_permille=cut[1])
+    osp, gsp, want, got, _, _ = run_both(ctx, inst, 4)
+    for a, b in zip(gsp.prep_export(), osp.prep_export()):
+        assert (a == b).all()
+    assert (got == want).all()
+    assert osp.verify_words(got) == 0
+
+
 def test_tampered_gpu_proof_is_rejected(ctx):
     inst = frontend.synthetic_circuit(9, 3, num_public=2)
     osp, gsp, want, got, _, _ = run_both(ctx, inst, 5)

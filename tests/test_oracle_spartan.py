@@ -57,3 +57,34 @@ def test_oracle_sha256_one_block_prove_verify():
     used = sp.prep_prove(tape)
     words, _, _ = sp.prove(tape[used:])
     assert sp.verify_words(words) == 0
+
+
+def test_reference_e2e_cubic_circuit_public_output_15():
+    """KAT (6) of SURVEY 8c: the reference's test_snark (src/spartan.rs:653-688) on T256HyraxEngine proves the rest-only
+    CubicCircuit x^3 + x + 5 = y, x = 2 and expects verify() to return [15]."""
+    inst = frontend.cubic_circuit()
+    assert (inst.num_cons, inst.num_shared, inst.num_precommitted, inst.num_rest, inst.num_public) == (4, 0, 0, 4, 1)
+    assert list(inst.publics) == [15]
+    sp = ol.OracleSpartan(inst)
+    assert (sp.shape.num_cons, sp.shape.num_vars) == (4, 2048)
+    tape = ol.make_tape(3, 4096)
+    used = sp.prep_prove(tape, is_small=False)
+    assert used == 0  # nothing to commit at prep time: no shared / precommitted variables
+    words, _, _ = sp.prove(tape)
+    assert sp.verify_words(words) == 0
+    # public values travel in the proof; the verifier returns them (src/spartan.rs:577)
+    rows = 1
+    assert ol.from_mont(words[8 * rows : 8 * rows + 4]) == 15
+
+
+@pytest.mark.parametrize("cut", [(300, 400), (0, 0), (1000, 0), (250, 0), (0, 600)])
+def test_oracle_prove_verify_with_shared_precommitted_rest_segments(cut):
+    inst = frontend.synthetic_circuit(6, 21, num_public=2, shared_permille=cut[0], precommitted_permille=cut[1])
+    sp = ol.OracleSpartan(inst)
+    tape = ol.make_tape(4, 8192)
+    used = sp.prep_prove(tape)
+    words, _, _ = sp.prove(tape[used:])
+    assert sp.verify_words(words) == 0
+    bad = words.copy()
+    bad[3] ^= np.uint64(1)
+    assert sp.verify_words(bad) != 0
