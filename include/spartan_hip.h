@@ -127,6 +127,10 @@ int sp_msm(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n
 /* DlogGroupExt::vartime_multiscalar_mul_small (msm.rs:367-409) */
 int sp_msm_small_u64(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_aff[8]);
 
+/* sum of n affine points (host side of the library; the combine step of a point-range-sharded MSM: RCCL has no EC-add reduction,
+ * so ranks all-gather their partial points and add them locally — SURVEY.md 8(e)) */
+int sp_point_sum(const uint64_t* points_aff, size_t n, uint64_t out_aff[8]);
+
 /* ---- Hyrax PCS (src/provider/pcs/hyrax_pc.rs, src/provider/pcs/ipa.rs) ------------------------------------ */
 /* HyraxCommitmentKey from explicit generators (PCS::setup derives them with a third-party hash-to-curve,
  * hyrax_pc.rs:152-177 — the caller supplies them) + precompute_ck (:179-190): uploads the bases and builds the

@@ -175,6 +175,17 @@ int sp_msm(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, 
   return SP_OK;
 }
 
+int sp_point_sum(const uint64_t* points_aff, size_t n, uint64_t out_aff[8]) {
+  jac_t acc = jac_identity();
+  for (size_t i = 0; i < n; ++i) {
+    aff_t p = load_aff(points_aff + 8 * i);
+    if (!aff_on_curve(p)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_point_sum: point not on the curve");
+    acc = jac_add_mixed(acc, p);
+  }
+  store_aff(out_aff, jac_to_affine(acc));
+  return SP_OK;
+}
+
 int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_aff[8]) {
   // u64 scalars are canonical 256-bit values with zero upper limbs: 8 byte windows + the carry window
   std::vector<fe_t> canon_h(n);

@@ -63,3 +63,42 @@ class Group:
 def whole_job_throughput(units_per_rank_step: float, steps: int, elapsed_max: float, world: int) -> float:
     """value of bench.py: units all ranks processed / max-over-ranks time."""
     return world * units_per_rank_step * steps / elapsed_max
+
+
+# ---- sharded group work (SURVEY.md 8(e)) ---------------------------------------------------------------------------------------
+import numpy as np
+
+
+def _all_gather_rows(group: Group, local: np.ndarray, counts):
+    """all-gather of variable-length (rows, 8) uint64 blocks; `counts[r]` rows come from rank r."""
+    if group.dist is None:
+        return local
+    width = local.shape[1]
+    mx = max(counts) if counts else 0
+    dev = "cuda" if (torch.cuda.is_available() and group.dist.get_backend() == "nccl") else "cpu"
+    buf = torch.zeros((mx, width), dtype=torch.int64, device=dev)
+    if local.shape[0]:
+        buf[: local.shape[0]] = torch.from_numpy(local.view(np.int64).copy()).to(dev)
+    outs = [torch.zeros_like(buf) for _ in range(group.world)]
+    group.dist.all_gather(outs, buf)
+    parts = [o[:c].cpu().numpy().view(np.uint64) for o, c in zip(outs, counts)]
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, width), dtype=np.uint64)
+
+
+def commit_rows_sharded(group: Group, n_rows: int, commit_rows_fn):
+    """Hyrax commitment of n_rows rows sharded BY ROW (independent units, bases replicated): rank r commits rows
+    [lo_r, hi_r) with commit_rows_fn(lo, hi) -> (hi-lo, 8) affine rows; one all-gather of 64-byte rows assembles the commitment
+    on every rank. No reduction is needed (PCS::commit's rows are independent, hyrax_pc.rs:230-300)."""
+    lo, hi = shard_range(n_rows, group.rank, group.world)
+    local = np.ascontiguousarray(commit_rows_fn(lo, hi), dtype=np.uint64).reshape(hi - lo, 8)
+    counts = [shard_range(n_rows, r, group.world)[1] - shard_range(n_rows, r, group.world)[0] for r in range(group.world)]
+    return _all_gather_rows(group, local, counts)
+
+
+def msm_point_range_sharded(group: Group, n_points: int, msm_fn, point_sum_fn):
+    """One large MSM sharded BY POINT RANGE: rank r computes the partial sum over points [lo_r, hi_r) with msm_fn(lo, hi) -> (8,)
+    affine; partials are all-gathered (RCCL has no EC-add op) and added locally with point_sum_fn((world, 8)) -> (8,)."""
+    lo, hi = shard_range(n_points, group.rank, group.world)
+    part = np.ascontiguousarray(msm_fn(lo, hi), dtype=np.uint64).reshape(1, 8)
+    allp = _all_gather_rows(group, part, [1] * group.world)
+    return point_sum_fn(allp)

@@ -244,6 +244,14 @@ def msm_small(ctx, scalars_u64, bases):
     return out
 
 
+def point_sum(points):
+    """Sum of affine points (combine step of a point-range-sharded MSM)."""
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib().sp_point_sum(p64(points) if points.shape[0] else None, ctypes.c_size_t(points.shape[0]), p64(out)))
+    return out
+
+
 class CommitmentKey:
     """HyraxCommitmentKey (src/provider/pcs/hyrax_pc.rs:56-72) resident on the device."""
 

@@ -52,6 +52,77 @@ def test_two_rank_gloo_sharding_and_timing():
     assert res[0][4] == res[1][4] and res[0][5] == res[1][5] == res[0][4] / 0.75
 
 
+def _worker_group_ops(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes
+
+    import numpy as np
+
+    import oracle_lib as ol
+    from oracle_lib import lib as olib, p64
+    from spartan2_amd import dist as spd
+
+    g = spd.Group(backend="gloo")
+    rng = np.random.default_rng(5)  # same data on every rank (bases replicated, witness rows addressed by range)
+    rows, cols = 5, 2048
+    v = np.zeros((rows * cols, 4), dtype=np.uint64)
+    v[rng.integers(0, 2, size=rows * cols) == 1] = ol.to_mont(1)
+    blinds = ol.random_field_array(rng, rows)
+    key = ctypes.c_void_p(olib().orc_hyrax_setup(b"ck", ctypes.c_size_t(cols)))
+
+    def commit_rows(lo, hi):  # the CPU oracle stands in for CommitmentKey.commit (tests may use the oracle; the product path uses the GPU)
+        out = np.zeros((hi - lo, 8), dtype=np.uint64)
+        if hi > lo:
+            olib().orc_hyrax_commit(key, p64(np.ascontiguousarray(v[lo * cols : hi * cols])), ctypes.c_size_t((hi - lo) * cols),
+                                    p64(np.ascontiguousarray(blinds[lo:hi])), 1, p64(out))
+        return out
+
+    full = spd.commit_rows_sharded(g, rows, commit_rows)
+    want = commit_rows(0, rows)
+    ok_commit = bool((full == want).all())
+    # point-range sharded MSM
+    n = 300
+    gens = np.zeros((n, 8), dtype=np.uint64)
+    olib().orc_from_label(b"ck", ctypes.c_size_t(n), p64(gens))
+    sc = ol.random_field_array(rng, n)
+
+    def msm(lo, hi):
+        out = np.zeros(8, dtype=np.uint64)
+        olib().orc_msm(p64(np.ascontiguousarray(sc[lo:hi])), p64(np.ascontiguousarray(gens[lo:hi])), ctypes.c_size_t(hi - lo), ctypes.c_size_t(1), p64(out))
+        return out
+
+    def point_sum(pts):
+        acc = np.zeros(8, dtype=np.uint64)
+        for p_ in pts:
+            nxt = np.zeros(8, dtype=np.uint64)
+            olib().orc_point_add(p64(acc), p64(np.ascontiguousarray(p_)), p64(nxt))
+            acc = nxt
+        return acc
+
+    got = spd.msm_point_range_sharded(g, n, msm, point_sum)
+    ok_msm = bool((got == msm(0, n)).all())
+    q.put((g.rank, ok_commit, ok_msm))
+    g.close()
+
+
+def test_two_rank_row_sharded_commit_and_point_range_msm():
+    """Hyrax rows shard by row (all-gather of rows, no reduction); a single MSM shards by point range
+    (all-gather of partial points + local adds). Exercised with two gloo ranks; per-rank compute is the CPU oracle here."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_group_ops, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)]
+
+
 def test_shard_range_is_a_partition():
     from spartan2_amd.dist import shard_range, whole_job_throughput
 

@@ -176,3 +176,23 @@ def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):
     olib().orc_point_mul(p64(np.ascontiguousarray(gs[1])), p64(blind), p64(b))
     olib().orc_point_add(p64(a), p64(b), p64(want))
     assert (ks.commit_small(val, blind) == want).all()
+
+
+def test_row_range_commits_and_point_sum_compose(ctx, key, gens):
+    """Multi-GPU building blocks on one GPU: committing row ranges separately equals the full commitment, and the
+    sum of point-range partial MSMs (sp_point_sum) equals the full MSM."""
+    rng = np.random.default_rng(SEED + 500)
+    rows = 6
+    v = np.zeros((rows * 2048, 4), dtype=np.uint64)
+    v[rng.integers(0, 2, size=rows * 2048) == 1] = to_mont(1)
+    blinds = ol.random_field_array(rng, rows)
+    t = hip.Table.from_host(ctx, v)
+    full = key.commit(t, 0, rows * 2048, blinds)
+    parts = [key.commit(t, lo * 2048, (hi - lo) * 2048, blinds[lo:hi]) for lo, hi in ((0, 2), (2, 3), (3, 6))]
+    assert (np.concatenate(parts) == full).all()
+    sc = ol.random_field_array(rng, 900)
+    bases = np.ascontiguousarray(gens[:900])
+    whole = hip.msm(ctx, sc, bases)
+    partials = np.stack([hip.msm(ctx, sc[lo:hi], bases[lo:hi]) for lo, hi in ((0, 113), (113, 450), (450, 900))])
+    assert (hip.point_sum(partials) == whole).all()
+    assert (hip.point_sum(np.zeros((0, 8), dtype=np.uint64)) == 0).all()
