@@ -96,6 +96,16 @@ int sp_sumcheck_quad(sp_ctx* ctx, const uint64_t claim[4], size_t rounds, sp_tab
  * call sites src/spartan.rs:330-341) */
 int sp_table_dot(sp_ctx* ctx, const sp_table* a, const sp_table* b, size_t n, uint64_t out[4]);
 
+/* compute_eval_points_cubic_with_additive_term_with_outer_pow (src/sumcheck.rs:366-498; NeutronNova batched outer rounds):
+ * out = evaluations at 0, 2, 3 (3 F). pow_left/pow_right are the two halves of the power-of-tau table (PowPolynomial::split_evals,
+ * src/polys/power.rs:65-86); when len(A)/2 < len(pow_left) the reference's 4-table fallback (:262-342) is taken. */
+int sp_eval_cubic_outer_pow(sp_ctx* ctx, const sp_table* pow_left, const sp_table* pow_right, const sp_table* A, const sp_table* B, const sp_table* C,
+                            uint64_t out[12]);
+/* R1CSWitness::fold_multiple (src/r1cs/mod.rs:570-660): out[j] = sum_i weights[i] * Ws[i][j] for j < len */
+int sp_fold_tables(sp_ctx* ctx, const sp_table* const* Ws, size_t n, const uint64_t* weights, size_t len, sp_table* out);
+/* weights_from_r (src/r1cs/mod.rs:153-166): n weights from ell challenges (host-side, O(n ell)) */
+int sp_weights_from_r(const uint64_t* r_bs, size_t ell, size_t n, uint64_t* out);
+
 /* ---- R1CS (src/r1cs/sparse.rs, src/r1cs/mod.rs) ------------------------------------------------------- */
 typedef struct sp_csr {
   const uint64_t* data;    /* nnz F */
@@ -127,6 +137,10 @@ int sp_msm(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n
 /* DlogGroupExt::vartime_multiscalar_mul_small (msm.rs:367-409) */
 int sp_msm_small_u64(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_aff[8]);
 
+/* DlogGroupExt::vartime_multiscalar_mul_shared_weights (src/provider/traits.rs:158-161 -> msm.rs:228-356): one weight vector,
+ * `rows` base rows of n affine points each (row-major); one affine result per row. FoldingEngineTrait::fold_commitments
+ * (hyrax_pc.rs:737-793) is this call on the instances' commitment rows. */
+int sp_msm_shared_weights(sp_ctx* ctx, const uint64_t* weights, size_t n, const uint64_t* bases_rows_aff, size_t rows, uint64_t* out_rows_aff);
 /* sum of n affine points (host side of the library; the combine step of a point-range-sharded MSM: RCCL has no EC-add reduction,
  * so ranks all-gather their partial points and add them locally — SURVEY.md 8(e)) */
 int sp_point_sum(const uint64_t* points_aff, size_t n, uint64_t out_aff[8]);

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 
+#include "neutronnova.hpp"
 #include "spartan.hpp"
 
 using namespace oracle;
@@ -278,6 +279,39 @@ int orc_hyrax_commit(void* k, const uint64_t* v, size_t n, const uint64_t* blind
 int orc_rowmat_vec(const uint64_t* poly, const uint64_t* l, size_t rows, size_t cols, uint64_t* out) {  // bind_with_delayed
   std::vector<Fq> p = load<Fq>(poly, rows * cols), L = load<Fq>(l, rows);
   store(out, bind_with_delayed(p.data(), L, cols));
+  return 0;
+}
+
+// ---- NeutronNova kernel-level rows (oracle/neutronnova.hpp) ---------------------------------------------------
+int orc_weights_from_r(const uint64_t* r_bs, size_t ell, size_t n, uint64_t* out) {
+  store(out, weights_from_r(load<Fq>(r_bs, ell), n));
+  return 0;
+}
+// Ws: n_inst tables of `dim` elements, concatenated
+int orc_fold_witnesses(const uint64_t* weights, const uint64_t* Ws, size_t n_inst, size_t dim, uint64_t* out) {
+  std::vector<Fq> w = load<Fq>(weights, n_inst), all = load<Fq>(Ws, n_inst * dim);
+  std::vector<const Fq*> ptrs;
+  for (size_t i = 0; i < n_inst; ++i) ptrs.push_back(all.data() + i * dim);
+  store(out, fold_witnesses(w, ptrs, dim));
+  return 0;
+}
+// bases_rows: rows x n affine points, row-major; out: rows affine points
+int orc_msm_shared_weights(const uint64_t* weights, size_t n, const uint64_t* bases_rows, size_t rows, uint64_t* out) {
+  std::vector<Fq> w = load<Fq>(weights, n);
+  std::vector<std::vector<Affine>> br(rows);
+  for (size_t r = 0; r < rows; ++r) br[r] = load_bases(bases_rows + 8 * r * n, n);
+  std::vector<Jac> res = msm_shared_weights(w, br);
+  std::vector<Affine> a = batch_affine(res);
+  for (size_t r = 0; r < rows; ++r) store_aff(out + 8 * r, a[r]);
+  return 0;
+}
+int orc_eval_cubic_outer_pow(const uint64_t* pow_left, size_t nleft, const uint64_t* pow_right, size_t nright, const uint64_t* A, const uint64_t* B,
+                             const uint64_t* C, size_t len2, uint64_t* out3) {
+  Fq e0, e2, e3;
+  eval_points_cubic_outer_pow(load<Fq>(pow_left, nleft), load<Fq>(pow_right, nright), load<Fq>(A, len2), load<Fq>(B, len2), load<Fq>(C, len2), &e0, &e2, &e3);
+  memcpy(out3, e0.l, 32);
+  memcpy(out3 + 4, e2.l, 32);
+  memcpy(out3 + 8, e3.l, 32);
   return 0;
 }
 

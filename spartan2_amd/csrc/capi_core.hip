@@ -469,6 +469,37 @@ int sp_table_dot(sp_ctx* c, const sp_table* a, const sp_table* b, size_t n, uint
 // beyond the aggregate L2; at config 2 that is the first fused launch of each sum-check).
 static const size_t STREAM_MIN_Q = (size_t)1 << 18;
 
+int sp_eval_cubic_outer_pow(sp_ctx* c, const sp_table* pl, const sp_table* pr, const sp_table* A, const sp_table* B, const sp_table* C, uint64_t out[12]) {
+  if (A->len != B->len || A->len != C->len || A->len < 2) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: tables must have equal even length");
+  const size_t len = A->len / 2, left = pl->len;
+  const bool fallback = len < left;
+  size_t right = 0;
+  if (fallback) {
+    if (left != 2 * len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: fallback needs a pow table as long as A");
+  } else {
+    if (left == 0 || len % left) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: len must be a multiple of the left table");
+    right = len / left;
+    if (pr->len != 2 * right) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: right table must have 2 * len / left entries");
+  }
+  size_t blocks = (len + 255) / 256;
+  int rc = c->ensure_scratch(blocks * 3 + 32);
+  if (rc) return rc;
+  const unsigned seq = next_seq(c);
+  c->timed("eval_cubic_pow", 224ull * len, [&] {
+    if (fallback)
+      hipLaunchKernelGGL((spk::k_eval_cubic_outer_pow<true>), dim3((unsigned)blocks), dim3(256), 0, c->stream, pl->d, left, pr ? pr->d : nullptr, right, A->d, B->d,
+                         C->d, len, c->d_scratch, c->d_pinned, seq);
+    else
+      hipLaunchKernelGGL((spk::k_eval_cubic_outer_pow<false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, pl->d, left, pr->d, right, A->d, B->d, C->d, len,
+                         c->d_scratch, c->d_pinned, seq);
+  });
+  fe_t sums[3];
+  rc = reduce_partials(c, blocks, 3, sums);
+  if (rc) return rc;
+  memcpy(out, sums, 96);
+  return SP_OK;
+}
+
 static bool table_dense(const sp_table* t) { return sp::eff_lo(t) == t->len / 2 && sp::eff_hi(t) == t->len / 2; }
 
 int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,

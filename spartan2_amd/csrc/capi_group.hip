@@ -175,6 +175,82 @@ int sp_msm(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, 
   return SP_OK;
 }
 
+int sp_weights_from_r(const uint64_t* r_bs, size_t ell, size_t n, uint64_t* out) {  // src/r1cs/mod.rs:153-166
+  const fe_t one = fe_one<S>();
+  for (size_t i = 0; i < n; ++i) {
+    fe_t wi = one;
+    size_t k = i;
+    for (size_t t = 0; t < ell; ++t) {
+      fe_t r;
+      memcpy(&r, r_bs + 4 * t, 32);
+      wi = fe_mul<S>(wi, (k & 1) ? r : fe_sub<S>(one, r));
+      k >>= 1;
+    }
+    memcpy(out + 4 * i, &wi, 32);
+  }
+  return SP_OK;
+}
+
+int sp_fold_tables(sp_ctx* c, const sp_table* const* Ws, size_t n, const uint64_t* weights, size_t len, sp_table* out) {
+  if (n == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "fold_multiple: empty witness list");
+  if (out->cap < len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "fold_multiple: output too short");
+  std::vector<const fe_t*> ptrs(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (Ws[i]->cap < len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "fold_multiple: all W vectors must have the same length");
+    ptrs[i] = Ws[i]->d;
+  }
+  DevBuf dp, dw;
+  int rc;
+  if ((rc = dp.alloc(n * sizeof(fe_t*)))) return rc;
+  if ((rc = dw.alloc(n * sizeof(fe_t)))) return rc;
+  SP_HIP(hipMemcpyAsync(dp.p, ptrs.data(), n * sizeof(fe_t*), hipMemcpyHostToDevice, c->stream));
+  SP_HIP(hipMemcpyAsync(dw.p, weights, n * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  size_t blocks = (len + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  c->timed("fold_tables", 32ull * (n + 1) * len, [&] {
+    hipLaunchKernelGGL(spk::k_fold_tables, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const fe_t* const*)dp.p, dw.as<fe_t>(), n, len, out->d);
+  });
+  SP_HIP(hipStreamSynchronize(c->stream));
+  out->len = len;
+  out->lo_eff = out->hi_eff = (size_t)-1;
+  return SP_OK;
+}
+
+int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const uint64_t* bases_rows, size_t rows, uint64_t* out_rows_aff) {
+  if (rows == 0) return SP_OK;
+  if (n == 0) {
+    memset(out_rows_aff, 0, rows * sizeof(aff_t));
+    return SP_OK;
+  }
+  const int windows = spk::MSM_MAX_WINDOWS;
+  fe_t* canon;
+  int rc;
+  if ((rc = upload_canonical(c, weights, n, &canon))) return rc;
+  DevBuf dbases, folded, order, start, buckets, wsum, drows;
+  if ((rc = dbases.alloc(rows * n * sizeof(aff_t))) || (rc = folded.alloc(n * sizeof(fe_t))) || (rc = order.alloc((size_t)windows * n * 4)) ||
+      (rc = start.alloc((size_t)windows * (spk::MSM_BUCKETS + 1) * 4)) || (rc = buckets.alloc(rows * windows * spk::MSM_BUCKETS * sizeof(jac_t))) ||
+      (rc = wsum.alloc(rows * windows * sizeof(jac_t))) || (rc = drows.alloc(rows * sizeof(jac_t))))
+    return rc;
+  SP_HIP(hipMemcpyAsync(dbases.p, bases_rows, rows * n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(spk::k_fold_sign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, canon, n, folded.as<fe_t>());
+  // the digit decomposition / bucket order is shared by every row (msm.rs:266-300); buckets and window sums are per row
+  hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, c->stream, folded.as<fe_t>(), (unsigned)n, order.as<unsigned>(), start.as<unsigned>());
+  unsigned lanes = (unsigned)windows * spk::MSM_BUCKETS * spk::MSM_LANES_PER_BUCKET;
+  c->timed("msm_shared_bucket_sum", 64ull * n * rows, [&] {
+    hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, c->stream, dbases.as<aff_t>(), (unsigned)n,
+                       order.as<unsigned>(), start.as<unsigned>(), windows, buckets.as<jac_t>());
+  });
+  hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets.as<jac_t>(), wsum.as<jac_t>());
+  hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, wsum.as<jac_t>(), windows, rows, drows.as<jac_t>());
+  std::vector<jac_t> res(rows);
+  SP_HIP(hipMemcpyAsync(res.data(), drows.p, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  std::vector<aff_t> a(rows);
+  normalize_batch(res, a.data());
+  memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
+  return SP_OK;
+}
+
 int sp_point_sum(const uint64_t* points_aff, size_t n, uint64_t out_aff[8]) {
   jac_t acc = jac_identity();
   for (size_t i = 0; i < n; ++i) {

@@ -134,6 +134,9 @@ __global__ void __launch_bounds__(256) k_msm_sort(const fe_t* __restrict__ canon
 constexpr int MSM_LANES_PER_BUCKET = 8;
 __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict__ bases, unsigned n, const unsigned* __restrict__ order,
                                                         const unsigned* __restrict__ start, int windows, jac_t* __restrict__ buckets) {
+  // blockIdx.y = row of a shared-weights batch (msm.rs:228-356): same digits, different bases; 0 for a plain MSM
+  bases += (size_t)blockIdx.y * n;
+  buckets += (size_t)blockIdx.y * windows * MSM_BUCKETS;
   const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned bucket = gid / MSM_LANES_PER_BUCKET, sub = gid % MSM_LANES_PER_BUCKET;
   const unsigned total = (unsigned)windows * MSM_BUCKETS;
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict_
 // per window: W = sum_{k=1..128} k * B_k = sum_k S_k with S_k = sum_{j >= k} B_j (suffix scan, then tree)
 __global__ void __launch_bounds__(MSM_BUCKETS) k_msm_window_reduce(const jac_t* __restrict__ buckets, jac_t* __restrict__ window_sums) {
   __shared__ jac_t s[MSM_BUCKETS];
-  const int w = blockIdx.x, k = threadIdx.x;
+  const int w = blockIdx.x + blockIdx.y * gridDim.x, k = threadIdx.x;  // blockIdx.y = row of a shared-weights batch
   s[k] = buckets[(size_t)w * MSM_BUCKETS + k];
   __syncthreads();
   for (int off = 1; off < MSM_BUCKETS; off <<= 1) {  // Hillis-Steele suffix scan
@@ -173,6 +176,35 @@ __global__ void __launch_bounds__(MSM_BUCKETS) k_msm_window_reduce(const jac_t* 
     __syncthreads();
   }
   if (k == 0) window_sums[w] = s[0];
+}
+
+// Window Horner on the device for batches (one lane per row): acc = 2^8 acc + W_w, high to low (msm.rs:150-175). A single MSM
+// leaves this 256-doubling chain to the host; with hundreds of rows the lanes run it in parallel.
+__global__ void __launch_bounds__(64) k_msm_horner_rows(const jac_t* __restrict__ window_sums, int windows, size_t rows, jac_t* __restrict__ out) {
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  jac_t acc = jac_identity();
+  for (int w = windows - 1; w >= 0; --w) {
+    for (int k = 0; k < MSM_C; ++k) acc = jac_dbl(acc);
+    acc = jac_add(acc, window_sums[row * windows + w]);
+  }
+  out[row] = acc;
+}
+
+// ---- K14: R1CSWitness::fold_multiple (src/r1cs/mod.rs:570-660): out[j] = sum_i w[i] * Ws[i][j] ---------------------------------
+// The small-value fast path of the reference (skip zeros, add w_i for ones, :615-631) is kept: SHA witnesses are bits.
+__global__ void __launch_bounds__(256) k_fold_tables(const fe_t* const* __restrict__ tables, const fe_t* __restrict__ weights, size_t n, size_t len,
+                                                     fe_t* __restrict__ out) {
+  const fe_t one = fe_one<SF>();
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < len; j += (size_t)gridDim.x * blockDim.x) {
+    fe_t acc = fe_zero();
+    for (size_t i = 0; i < n; ++i) {
+      const fe_t x = tables[i][j];
+      if (fe_is_zero(x)) continue;
+      acc = fe_add<SF>(acc, fe_eq(x, one) ? weights[i] : fe_mul<SF>(weights[i], x));
+    }
+    out[j] = acc;
+  }
 }
 
 // ---- K10: binary rows ------------------------------------------------------------------------------------------------

@@ -326,6 +326,49 @@ __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, c
   }
 }
 
+// ---- K4: NeutronNova outer rounds: sums at 0, 2, 3 of pow_tau * (A B - C) with pow_tau = left (x) right ---------------------------
+// compute_eval_points_cubic_with_additive_term_with_outer_pow (src/sumcheck.rs:366-498): pair low = i + j*left, weight
+// left[i] * right[j] (low end) / left[i] * right[j + right] (high end); FALLBACK (len < left, :262-342): the pow table itself is
+// a fourth bound table, weight ends left[low] / left[low + len]. Per-pair weights (two extra products per pair vs the
+// reference's per-i factoring; same values).
+template <bool FALLBACK>
+__global__ void __launch_bounds__(256) k_eval_cubic_outer_pow(const fe_t* __restrict__ pleft, size_t left, const fe_t* __restrict__ pright, size_t right,
+                                                              const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t len,
+                                                              fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq) {
+  __shared__ fe_t smem[3 * 4];
+  fe_t acc[3] = {fe_zero(), fe_zero(), fe_zero()};
+  const size_t low = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (low < len) {
+    fe_t tl, th;
+    if (FALLBACK) {
+      tl = pleft[low];
+      th = pleft[low + len];
+    } else {
+      const size_t i = low % left, j = low / left;
+      const fe_t pl = pleft[i];
+      tl = fe_mul<S>(pl, pright[j]);
+      th = fe_mul<S>(pl, pright[j + right]);
+    }
+    const fe_t al = A[low], ah = A[low + len], bl = B[low], bh = B[low + len], cl = C[low], ch = C[low + len];
+    acc[0] = fe_mul<S>(tl, fe_sub<S>(fe_mul<S>(al, bl), cl));
+    fe_t tb = fe_sub<S>(fe_dbl<S>(th), tl), ab = fe_sub<S>(fe_dbl<S>(ah), al), bb = fe_sub<S>(fe_dbl<S>(bh), bl), cb = fe_sub<S>(fe_dbl<S>(ch), cl);
+    acc[1] = fe_mul<S>(tb, fe_sub<S>(fe_mul<S>(ab, bb), cb));
+    tb = fe_sub<S>(fe_add<S>(tb, th), tl);
+    ab = fe_sub<S>(fe_add<S>(ab, ah), al);
+    bb = fe_sub<S>(fe_add<S>(bb, bh), bl);
+    cb = fe_sub<S>(fe_add<S>(cb, ch), cl);
+    acc[2] = fe_mul<S>(tb, fe_sub<S>(fe_mul<S>(ab, bb), cb));
+  }
+  block_sum<3>(acc, smem);
+  if (threadIdx.x == 0) {
+    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 3;
+    dst[0] = acc[0];
+    dst[1] = acc[1];
+    dst[2] = acc[2];
+    if (gridDim.x == 1) publish_result(single_out, seq);
+  }
+}
+
 // dot product of the first n elements (value of DelayedReduction::reduce(sum a_i b_i))
 __global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t n, fe_t* __restrict__ partials,
                                              fe_t* __restrict__ single_out, unsigned seq) {

@@ -350,3 +350,36 @@ class Shape:
                 lib().sp_shape_free(self.h)
         except Exception:
             pass
+
+
+# ---- NeutronNova kernel-level rows ------------------------------------------------------------------------------------------
+def weights_from_r(r_bs, n: int):
+    """weights_from_r (src/r1cs/mod.rs:153-166)."""
+    r_bs = np.ascontiguousarray(r_bs, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((n, 4), dtype=np.uint64)
+    check(lib().sp_weights_from_r(p64(r_bs) if r_bs.shape[0] else None, ctypes.c_size_t(r_bs.shape[0]), ctypes.c_size_t(n), p64(out)))
+    return out
+
+
+def fold_tables(ctx, tables, weights, length: int, out: Table):
+    """R1CSWitness::fold_multiple (src/r1cs/mod.rs:570-660): out[j] = sum_i weights[i] * tables[i][j]."""
+    weights = np.ascontiguousarray(weights, dtype=np.uint64).reshape(len(tables), 4)
+    arr = (ctypes.c_void_p * len(tables))(*[t.h for t in tables])
+    check(lib().sp_fold_tables(ctx.h, arr, ctypes.c_size_t(len(tables)), p64(weights), ctypes.c_size_t(length), out.h))
+
+
+def msm_shared_weights(ctx, weights, bases_rows):
+    """vartime_multiscalar_mul_shared_weights (src/provider/msm.rs:228-356); bases_rows: (rows, n, 8)."""
+    bases_rows = np.ascontiguousarray(bases_rows, dtype=np.uint64)
+    rows, n = bases_rows.shape[0], bases_rows.shape[1]
+    weights = np.ascontiguousarray(weights, dtype=np.uint64).reshape(n, 4)
+    out = np.zeros((rows, 8), dtype=np.uint64)
+    check(lib().sp_msm_shared_weights(ctx.h, p64(weights), ctypes.c_size_t(n), p64(bases_rows.reshape(-1)), ctypes.c_size_t(rows), p64(out)))
+    return out
+
+
+def eval_cubic_outer_pow(ctx, pow_left: Table, pow_right, A: Table, B: Table, C: Table):
+    """compute_eval_points_cubic_with_additive_term_with_outer_pow (src/sumcheck.rs:366-498) -> (eval0, eval2, eval3)."""
+    out = np.zeros((3, 4), dtype=np.uint64)
+    check(lib().sp_eval_cubic_outer_pow(ctx.h, pow_left.h, pow_right.h if pow_right is not None else None, A.h, B.h, C.h, p64(out)))
+    return out
