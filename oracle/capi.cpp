@@ -9,6 +9,7 @@
 #include <string>
 
 #include "neutronnova.hpp"
+#include "nifs.hpp"
 #include "spartan.hpp"
 
 using namespace oracle;
@@ -313,6 +314,68 @@ int orc_eval_cubic_outer_pow(const uint64_t* pow_left, size_t nleft, const uint6
   memcpy(out3 + 4, e2.l, 32);
   memcpy(out3 + 8, e3.l, 32);
   return 0;
+}
+
+// ---- NeutronNova NIFS data path (oracle/nifs.hpp) ------------------------------------------------------------
+// out_i64[n], out_large[n] (0/1 flags); returns the number of large positions
+long orc_to_small_vec_or_zero(const uint64_t* v, size_t n, int64_t* out_i64, uint8_t* out_large) {
+  std::vector<Fq> f = load<Fq>(v, n);
+  std::vector<int64_t> o;
+  std::vector<size_t> l;
+  to_small_vec_or_zero(f.data(), n, o, l);
+  memcpy(out_i64, o.data(), 8 * n);
+  memset(out_large, 0, n);
+  for (size_t k : l) out_large[k] = 1;
+  return (long)l.size();
+}
+// sum_i f_i * (a_i * b_i) through SmallAccumulator (small_value.rs:254-403 property tests)
+int orc_small_acc_dot(const uint64_t* f, const int64_t* a, const int64_t* b, size_t n, uint64_t* out) {
+  ORC_TRY
+  std::vector<Fq> fv = load<Fq>(f, n);
+  SmallAccumulator acc;
+  for (size_t i = 0; i < n; ++i) acc.accumulate(fv[i], (__int128)a[i] * (__int128)b[i]);
+  Fq r = acc.reduce();
+  memcpy(out, r.l, 32);
+  ORC_CATCH
+}
+int orc_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right) {
+  compute_tensor_decomp(n, ell, left, right);
+  return 0;
+}
+int orc_pow_split_evals(const uint64_t* tau, size_t ell, size_t left, size_t right, uint64_t* out) {
+  ORC_TRY
+  store(out, pow_split_evals(load<Fq>(tau, 1)[0], ell, left, right));
+  ORC_CATCH
+}
+typedef void (*orc_nifs_hook)(void* user, size_t t, const uint64_t* coeffs16, uint64_t* r_b);
+// A, B, C: n_padded layers of left*right elements, concatenated. out_polys: ell_b x 4 coefficients [d, c, b, a]; out_tail = T_out | eq_rho_at_rb
+int orc_nifs_prove_core(size_t n_padded, size_t left, size_t right, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, const uint64_t* A,
+                        const uint64_t* B, const uint64_t* C, int use_i64, orc_nifs_hook hook, void* user, uint64_t* out_polys, uint64_t* out_r_bs,
+                        uint64_t* out_A, uint64_t* out_B, uint64_t* out_C, uint64_t* out_tail) {
+  ORC_TRY
+  size_t total = left * right;
+  std::vector<Layer> a(n_padded), b(n_padded), c(n_padded);
+  for (size_t i = 0; i < n_padded; ++i) {
+    a[i] = load<Fq>(A + 4 * i * total, total);
+    b[i] = load<Fq>(B + 4 * i * total, total);
+    c[i] = load<Fq>(C + 4 * i * total, total);
+  }
+  NifsRoundHook h = [&](size_t t, const std::array<Fq, 4>& co) {
+    uint64_t buf[16], r[4];
+    for (int i = 0; i < 4; ++i) memcpy(buf + 4 * i, co[i].l, 32);
+    hook(user, t, buf, r);
+    return Fq::from_raw_mont(r);
+  };
+  NifsCoreOutput o = nifs_prove_core(left, right, load<Fq>(E_eq, left + right), load<Fq>(rhos, ell_b), std::move(a), std::move(b), std::move(c), use_i64 != 0, h);
+  for (size_t t = 0; t < ell_b; ++t)
+    for (int i = 0; i < 4; ++i) memcpy(out_polys + 16 * t + 4 * i, o.polys[t][i].l, 32);
+  store(out_r_bs, o.r_bs);
+  store(out_A, o.A);
+  store(out_B, o.B);
+  store(out_C, o.C);
+  memcpy(out_tail, o.T_out.l, 32);
+  memcpy(out_tail + 4, o.eq_rho_at_rb.l, 32);
+  ORC_CATCH
 }
 
 // ---- R1CS shape -------------------------------------------------------------------------------

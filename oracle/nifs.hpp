@@ -1,0 +1,442 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the product path.
+//
+// CPU restatement of the NeutronNova NIFS data path:
+//   to_small_vec_or_zero, SmallAccumulator                        src/big_num/small_value.rs:31-222
+//   PowPolynomial::split_evals                                    src/polys/power.rs:64-87
+//   compute_tensor_decomp, suffix_weight_full                     src/neutronnova_zk.rs:56-87
+//   NeutronNovaNIFS::{prove_helper, prove_helper_ab_only, prove_helper_small, prove_helper_ab_cross}   :98-432
+//   NeutronNovaNIFS::prove  (both the cached-i64 "small value" branch and the field branch)            :511-1273
+// The per-round `process_round` of the ZK verifier circuit (src/zk.rs, bellpepper multi-round witness commit; SURVEY 8(f)
+// rank 1) is NOT restated: it enters here as a caller-supplied hook `poly coefficients -> r_b`, exactly where the reference
+// calls it (`finish_round!`, :703-735). Parity for the ZK wrapper is therefore unpinned; the data path below is pinned by value
+// against the reference's own property tests (small_value.rs:254-403) and by the two branches agreeing with each other.
+#pragma once
+#include <array>
+#include <functional>
+#include <set>
+#include <stdexcept>
+#include <vector>
+
+#include "neutronnova.hpp"
+#include "polys.hpp"
+
+namespace oracle {
+
+constexpr uint64_t SMALL_VALUE_MAX = (1ull << 62) - 1;  // small_value.rs:31
+
+// small_value.rs:41-86 — i64 image of a field element, 0 + recorded position when |v| does not fit
+inline void to_small_vec_or_zero(const Fq* poly, size_t n, std::vector<int64_t>& out, std::vector<size_t>& large) {
+  out.resize(n);
+  large.clear();
+  const uint64_t* p = Fq::P().p.l;
+  for (size_t idx = 0; idx < n; ++idx) {
+    uint64_t v[4];
+    poly[idx].to_canonical(v);
+    if (v[1] == 0 && v[2] == 0 && v[3] == 0 && v[0] <= SMALL_VALUE_MAX) {
+      out[idx] = (int64_t)v[0];
+      continue;
+    }
+    uint64_t d[4];
+    sub256(d, p, v);
+    if (d[1] == 0 && d[2] == 0 && d[3] == 0 && d[0] > 0 && d[0] <= SMALL_VALUE_MAX) {
+      out[idx] = -(int64_t)d[0];
+      continue;
+    }
+    out[idx] = 0;
+    large.push_back(idx);
+  }
+}
+
+// small_value.rs:88-222 — separate 448-bit positive / negative buckets of (Montgomery limbs) x (|i128|); reduce = pos - neg, each bucket
+// taken mod p and read back as Montgomery limbs.
+struct SmallAccumulator {
+  uint64_t pos[7] = {0, 0, 0, 0, 0, 0, 0}, neg[7] = {0, 0, 0, 0, 0, 0, 0};
+  void accumulate(const Fq& f, __int128 val) {
+    if (val == 0) return;
+    unsigned __int128 a = val > 0 ? (unsigned __int128)val : (unsigned __int128)(-val);
+    uint64_t* t = val > 0 ? pos : neg;
+    uint64_t parts[2] = {(uint64_t)a, (uint64_t)(a >> 64)};
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1 && parts[1] == 0) break;
+      unsigned __int128 carry = 0;
+      for (int j = 0; j < 4; ++j) {
+        unsigned __int128 prod = (unsigned __int128)f.l[j] * parts[h] + t[j + h] + carry;
+        t[j + h] = (uint64_t)prod;
+        carry = prod >> 64;
+      }
+      for (int j = 4 + h; j < 7; ++j) {
+        unsigned __int128 s = (unsigned __int128)t[j] + carry;
+        t[j] = (uint64_t)s;
+        carry = s >> 64;
+      }
+      if (carry) throw std::runtime_error("SmallAccumulator overflow");
+    }
+  }
+  static Fq reduce7(const uint64_t a[7]) {
+    // value N < 2^448; result = the element whose Montgomery limbs are N mod p = (N mod p as a canonical value) * R^-1
+    uint8_t bytes[64] = {0};
+    for (int i = 0; i < 7; ++i)
+      for (int b = 0; b < 8; ++b) bytes[8 * i + b] = (uint8_t)(a[i] >> (8 * b));
+    static const Fq r_inv = [] {
+      uint64_t one[4] = {1, 0, 0, 0};
+      return Fq::from_raw_mont(one);
+    }();
+    return Fq::from_uniform(bytes) * r_inv;
+  }
+  Fq reduce() const { return reduce7(pos) - reduce7(neg); }
+};
+
+// src/neutronnova_zk.rs:56-67
+inline void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right) {
+  size_t l = 0;
+  while ((size_t(1) << l) < n) ++l;  // n.next_power_of_two().log_2()
+  *ell = l;
+  *left = size_t(1) << ((l + 1) / 2);
+  *right = size_t(1) << (l / 2);
+}
+
+// src/polys/power.rs:64-87
+inline std::vector<Fq> pow_split_evals(const Fq& t, size_t ell, size_t len_left, size_t len_right) {
+  if (len_left * len_right != (size_t(1) << ell)) throw std::runtime_error("split_evals: bad lengths");
+  std::vector<Fq> out(len_left + len_right);
+  Fq p = Fq::one();
+  for (size_t i = 0; i < len_left; ++i) {
+    out[i] = p;
+    p = p * t;
+  }
+  Fq step = out[len_left - 1] * t;
+  out[len_left] = Fq::one();
+  if (len_right > 1) out[len_left + 1] = step;
+  for (size_t i = 2; i < len_right; ++i) out[len_left + i] = out[len_left + i - 1] * step;
+  return out;
+}
+
+// :77-87
+inline Fq suffix_weight_full(size_t t, size_t ell_b, size_t pair_idx, const std::vector<Fq>& rhos) {
+  Fq w = Fq::one();
+  size_t k = pair_idx;
+  for (size_t s = t + 1; s < ell_b; ++s) {
+    w = w * ((k & 1) ? rhos[s] : (Fq::one() - rhos[s]));
+    k >>= 1;
+  }
+  return w;
+}
+
+using Layer = std::vector<Fq>;
+using Layer64 = std::vector<int64_t>;
+
+// prove_helper (:98-181): (e0, quad) of one instance pair; e0 is skipped (zero) in round 0
+inline void nifs_prove_helper(size_t round, size_t left, size_t right, const std::vector<Fq>& e, const Layer& Az1, const Layer& Bz1, const Layer& Cz1,
+                              const Layer& Az2, const Layer& Bz2, Fq* e0, Fq* quad) {
+  const Fq* e_left = e.data();
+  const Fq* f = e.data() + left;
+  Fq acc_e0 = Fq::zero(), acc_q = Fq::zero();
+  for (size_t i = 0; i < right; ++i) {
+    Fq in_e0 = Fq::zero(), in_q = Fq::zero();
+    for (size_t j = 0; j < left; ++j) {
+      size_t k = i * left + j;
+      if (round != 0) in_e0 = in_e0 + e_left[j] * (Az1[k] * Bz1[k] - Cz1[k]);
+      in_q = in_q + e_left[j] * ((Az2[k] - Az1[k]) * (Bz2[k] - Bz1[k]));
+    }
+    acc_e0 = acc_e0 + f[i] * in_e0;
+    acc_q = acc_q + f[i] * in_q;
+  }
+  *e0 = acc_e0;
+  *quad = acc_q;
+}
+
+// prove_helper_ab_only (:186-246)
+inline void nifs_prove_helper_ab_only(size_t left, size_t right, const std::vector<Fq>& e, const Layer& Az1, const Layer& Bz1, const Layer& Az2,
+                                      const Layer& Bz2, Fq* e0_ab, Fq* quad) {
+  const Fq* e_left = e.data();
+  const Fq* f = e.data() + left;
+  Fq acc_e0 = Fq::zero(), acc_q = Fq::zero();
+  for (size_t i = 0; i < right; ++i) {
+    Fq in_e0 = Fq::zero(), in_q = Fq::zero();
+    for (size_t j = 0; j < left; ++j) {
+      size_t k = i * left + j;
+      in_e0 = in_e0 + e_left[j] * (Az1[k] * Bz1[k]);
+      in_q = in_q + e_left[j] * ((Az2[k] - Az1[k]) * (Bz2[k] - Bz1[k]));
+    }
+    acc_e0 = acc_e0 + f[i] * in_e0;
+    acc_q = acc_q + f[i] * in_q;
+  }
+  *e0_ab = acc_e0;
+  *quad = acc_q;
+}
+
+// prove_helper_small (:255-320)
+inline Fq nifs_prove_helper_small(size_t left, size_t right, const std::vector<Fq>& e, const Layer& Az1, const Layer& Bz1, const Layer& Az2, const Layer& Bz2,
+                                  const Layer64& a1, const Layer64& b1, const Layer64& a2, const Layer64& b2, const std::vector<size_t>& large) {
+  const Fq* e_left = e.data();
+  const Fq* f = e.data() + left;
+  size_t total = left * right;
+  Fq quad = Fq::zero();
+  for (size_t i = 0; i < right; ++i) {
+    SmallAccumulator inner;
+    for (size_t j = 0; j < left; ++j) {
+      size_t k = i * left + j;
+      __int128 da = (__int128)a2[k] - (__int128)a1[k], db = (__int128)b2[k] - (__int128)b1[k];
+      inner.accumulate(e_left[j], da * db);
+    }
+    quad = quad + f[i] * inner.reduce();
+  }
+  for (size_t k : large) {
+    if (k >= total) continue;
+    size_t i = k / left, j = k % left;
+    quad = quad + f[i] * e_left[j] * (Az2[k] - Az1[k]) * (Bz2[k] - Bz1[k]);
+  }
+  return quad;
+}
+
+// prove_helper_ab_cross (:322-432)
+inline void nifs_prove_helper_ab_cross(size_t left, size_t right, const std::vector<Fq>& e, const Layer64* a64[4], const Layer64* b64[4], const Layer* af[4],
+                                       const Layer* bf[4], const Fq& c00, const Fq& c01, const Fq& c11, const Fq& r0, const std::vector<size_t>& large,
+                                       Fq* e0_out, Fq* quad_out) {
+  const Fq* e_left = e.data();
+  const Fq* f = e.data() + left;
+  size_t total = left * right;
+  Fq e0 = Fq::zero(), quad = Fq::zero();
+  for (size_t i = 0; i < right; ++i) {
+    SmallAccumulator s00, s01, s11, q00, q01, q11;
+    for (size_t j = 0; j < left; ++j) {
+      size_t k = i * left + j;
+      __int128 a0 = (*a64[0])[k], a1 = (*a64[1])[k], b0 = (*b64[0])[k], b1 = (*b64[1])[k];
+      s00.accumulate(e_left[j], a0 * b0);
+      s01.accumulate(e_left[j], a0 * b1 + a1 * b0);
+      s11.accumulate(e_left[j], a1 * b1);
+      __int128 da0 = (__int128)(*a64[2])[k] - a0, da1 = (__int128)(*a64[3])[k] - a1;
+      __int128 db0 = (__int128)(*b64[2])[k] - b0, db1 = (__int128)(*b64[3])[k] - b1;
+      q00.accumulate(e_left[j], da0 * db0);
+      q01.accumulate(e_left[j], da0 * db1 + da1 * db0);
+      q11.accumulate(e_left[j], da1 * db1);
+    }
+    e0 = e0 + f[i] * (c00 * s00.reduce() + c01 * s01.reduce() + c11 * s11.reduce());
+    quad = quad + f[i] * (c00 * q00.reduce() + c01 * q01.reduce() + c11 * q11.reduce());
+  }
+  Fq omr = Fq::one() - r0;
+  for (size_t k : large) {
+    if (k >= total) continue;
+    size_t i = k / left, j = k % left;
+    Fq ef = e_left[j] * f[i];
+    Fq az_lo = omr * (*af[0])[k] + r0 * (*af[1])[k], az_hi = omr * (*af[2])[k] + r0 * (*af[3])[k];
+    Fq bz_lo = omr * (*bf[0])[k] + r0 * (*bf[1])[k], bz_hi = omr * (*bf[2])[k] + r0 * (*bf[3])[k];
+    e0 = e0 + ef * az_lo * bz_lo;
+    quad = quad + ef * (az_hi - az_lo) * (bz_hi - bz_lo);
+  }
+  *e0_out = e0;
+  *quad_out = quad;
+}
+
+struct NifsCoreOutput {
+  std::vector<std::array<Fq, 4>> polys;  // coefficients [d, c, b, a] = UniPoly.coeffs (:719-721)
+  std::vector<Fq> r_bs;
+  Layer A, B, C;  // final folded layers
+  Fq T_out, eq_rho_at_rb;
+};
+
+// hook(t, coeffs) -> r_b: the `process_round` call of finish_round! (:723-727)
+using NifsRoundHook = std::function<Fq(size_t, const std::array<Fq, 4>&)>;
+
+inline void fold_layer(Layer& lo, const Layer& hi, const Fq& r) {
+  for (size_t k = 0; k < lo.size(); ++k) lo[k] = lo[k] + r * (hi[k] - lo[k]);
+}
+
+// NeutronNovaNIFS::prove, :648-1207 (after tau / rhos are squeezed and the layers exist). `use_i64` selects the cached-i64 branch: the i64
+// mirrors and the global large_positions are derived here exactly as prep_prove derives them (:1548-1586).
+inline NifsCoreOutput nifs_prove_core(size_t left, size_t right, const std::vector<Fq>& E_eq, const std::vector<Fq>& rhos, std::vector<Layer> A,
+                                      std::vector<Layer> B, std::vector<Layer> C, bool use_i64, const NifsRoundHook& hook) {
+  size_t n_padded = A.size(), ell_b = rhos.size();
+  if ((size_t(1) << ell_b) != n_padded || ell_b == 0) throw std::runtime_error("nifs: n_padded != 2^ell_b");
+  size_t total = left * right;
+  std::vector<Layer64> A64, B64, C64;
+  std::vector<size_t> large;
+  if (use_i64) {
+    std::set<size_t> lp;
+    A64.resize(n_padded);
+    B64.resize(n_padded);
+    C64.resize(n_padded);
+    for (size_t b = 0; b < n_padded; ++b) {
+      std::vector<size_t> l;
+      to_small_vec_or_zero(A[b].data(), total, A64[b], l);
+      lp.insert(l.begin(), l.end());
+      to_small_vec_or_zero(B[b].data(), total, B64[b], l);
+      lp.insert(l.begin(), l.end());
+      to_small_vec_or_zero(C[b].data(), total, C64[b], l);
+      lp.insert(l.begin(), l.end());
+    }
+    large.assign(lp.begin(), lp.end());
+    for (size_t b = 0; b < n_padded; ++b)
+      for (size_t pos : large) A64[b][pos] = B64[b][pos] = C64[b][pos] = 0;
+  }
+  const Fq* e_left = E_eq.data();
+  const Fq* f = E_eq.data() + left;
+
+  // c_vals[b] = sum_k E[k] * Cz_b[k]  (:652-703)
+  std::vector<Fq> c_vals;
+  if (use_i64) {
+    c_vals.resize(n_padded);
+    for (size_t b = 0; b < n_padded; ++b) {
+      Fq acc = Fq::zero();
+      for (size_t i = 0; i < right; ++i) {
+        SmallAccumulator inner;
+        for (size_t j = 0; j < left; ++j) inner.accumulate(e_left[j], (__int128)C64[b][i * left + j]);
+        acc = acc + f[i] * inner.reduce();
+      }
+      c_vals[b] = acc;
+    }
+    for (size_t k : large) {
+      if (k >= total) continue;
+      Fq ef = e_left[k % left] * f[k / left];
+      for (size_t b = 0; b < n_padded; ++b) c_vals[b] = c_vals[b] + ef * C[b][k];
+    }
+  }
+
+  NifsCoreOutput out;
+  Fq T_cur = Fq::zero(), acc_eq = Fq::one();
+  size_t m = n_padded;
+
+  auto finish_round = [&](size_t t, const Fq& e0, const Fq& quad_coeff) -> Fq {  // :703-735
+    Fq rho_t = rhos[t];
+    Fq one_minus_rho = Fq::one() - rho_t, two_rho_minus_one = rho_t - one_minus_rho;
+    Fq c = e0 * acc_eq, a = quad_coeff * acc_eq;
+    if (rho_t == Fq::zero()) throw std::runtime_error("DivisionByZero");
+    Fq a_b_c = (T_cur - c * one_minus_rho) * rho_t.inv();
+    Fq b = a_b_c - a - c;
+    std::array<Fq, 4> co = {c * one_minus_rho, c * two_rho_minus_one + b * one_minus_rho, b * two_rho_minus_one + a * one_minus_rho, a * two_rho_minus_one};
+    out.polys.push_back(co);
+    Fq r_b = hook(t, co);
+    out.r_bs.push_back(r_b);
+    acc_eq = acc_eq * ((Fq::one() - r_b) * (Fq::one() - rho_t) + r_b * rho_t);
+    UniPoly<Fq> p;
+    p.coeffs = {co[0], co[1], co[2], co[3]};
+    T_cur = p.evaluate(r_b);
+    return r_b;
+  };
+  auto fold_pair = [&](size_t even, size_t odd, size_t dest, const Fq& r) {  // fold_ab_pair! / fold_abc_pair! (:739-775)
+    fold_layer(A[even], A[odd], r);
+    fold_layer(B[even], B[odd], r);
+    if (dest != even) {
+      A[dest] = std::move(A[even]);
+      B[dest] = std::move(B[even]);
+    }
+    if (!use_i64) {
+      fold_layer(C[even], C[odd], r);
+      if (dest != even) C[dest] = std::move(C[even]);
+    }
+  };
+
+  {  // round 0 (:779-851)
+    size_t pairs = m / 2;
+    Fq e0 = Fq::zero(), quad = Fq::zero();
+    for (size_t p = 0; p < pairs; ++p) {
+      Fq w = suffix_weight_full(0, ell_b, p, rhos);
+      if (use_i64) {
+        quad = quad + w * nifs_prove_helper_small(left, right, E_eq, A[2 * p], B[2 * p], A[2 * p + 1], B[2 * p + 1], A64[2 * p], B64[2 * p], A64[2 * p + 1],
+                                                  B64[2 * p + 1], large);
+      } else {
+        Fq pe0, pq;
+        nifs_prove_helper(0, left, right, E_eq, A[2 * p], B[2 * p], C[2 * p], A[2 * p + 1], B[2 * p + 1], &pe0, &pq);
+        e0 = e0 + pe0 * w;
+        quad = quad + pq * w;
+      }
+    }
+    Fq r_b = finish_round(0, e0, quad);
+    if (ell_b == 1) {
+      for (size_t i = 0; i < pairs; ++i) fold_pair(2 * i, 2 * i + 1, i, r_b);
+      m = pairs;
+    }
+  }
+
+  if (ell_b > 1) {  // :855-1165
+    Fq prev_r_b = out.r_bs[0];
+    std::vector<Fq> prefix;
+    if (use_i64) prefix = {Fq::one() - prev_r_b, prev_r_b};
+    for (size_t t = 1; t < ell_b; ++t) {
+      size_t fold_pairs = m / 2, prove_pairs = fold_pairs / 2;
+      Fq e0_acc = Fq::zero(), quad_acc = Fq::zero();
+      size_t n_prefix = prefix.size();
+      auto c_val_lo = [&](size_t j) {
+        Fq s = Fq::zero();
+        for (size_t v = 0; v < n_prefix; ++v) s = s + prefix[v] * c_vals[(2 * j) * n_prefix + v];
+        return s;
+      };
+      if (use_i64 && t == 1) {
+        Fq r0 = prev_r_b, omr = Fq::one() - r0;
+        Fq c00 = omr * omr, c01 = omr * r0, c11 = r0 * r0;
+        for (size_t j = 0; j < prove_pairs; ++j) {
+          const Layer64 *a64[4], *b64[4];
+          const Layer *af[4], *bf[4];
+          for (int q = 0; q < 4; ++q) {
+            a64[q] = &A64[4 * j + q];
+            b64[q] = &B64[4 * j + q];
+            af[q] = &A[4 * j + q];
+            bf[q] = &B[4 * j + q];
+          }
+          Fq e0_ab, qc;
+          nifs_prove_helper_ab_cross(left, right, E_eq, a64, b64, af, bf, c00, c01, c11, r0, large, &e0_ab, &qc);
+          Fq w = suffix_weight_full(t, ell_b, j, rhos);
+          e0_acc = e0_acc + (e0_ab - c_val_lo(j)) * w;
+          quad_acc = quad_acc + qc * w;
+        }
+        for (size_t i = 0; i < fold_pairs; ++i) fold_pair(2 * i, 2 * i + 1, i, prev_r_b);  // par_fold_ab_chunks + compact (:949-961)
+      } else {
+        // merged fold (previous challenge) + prove from the folded positions (:963-1097); folding first and proving on the compacted layers is
+        // the same computation
+        for (size_t i = 0; i < fold_pairs; ++i) fold_pair(2 * i, 2 * i + 1, i, prev_r_b);
+        for (size_t j = 0; j < prove_pairs; ++j) {
+          Fq w = suffix_weight_full(t, ell_b, j, rhos);
+          if (use_i64) {
+            Fq e0_ab, qc;
+            nifs_prove_helper_ab_only(left, right, E_eq, A[2 * j], B[2 * j], A[2 * j + 1], B[2 * j + 1], &e0_ab, &qc);
+            e0_acc = e0_acc + (e0_ab - c_val_lo(j)) * w;
+            quad_acc = quad_acc + qc * w;
+          } else {
+            Fq e0, qc;
+            nifs_prove_helper(t, left, right, E_eq, A[2 * j], B[2 * j], C[2 * j], A[2 * j + 1], B[2 * j + 1], &e0, &qc);
+            e0_acc = e0_acc + e0 * w;
+            quad_acc = quad_acc + qc * w;
+          }
+        }
+      }
+      m = fold_pairs;
+      prev_r_b = finish_round(t, e0_acc, quad_acc);
+      if (use_i64) {  // :1103-1119
+        std::vector<Fq> old = std::move(prefix);
+        prefix.clear();
+        for (const Fq& c : old) prefix.push_back(c * (Fq::one() - prev_r_b));
+        for (const Fq& c : old) prefix.push_back(c * prev_r_b);
+      }
+    }
+    size_t final_pairs = m / 2;  // :1122-1165
+    for (size_t i = 0; i < final_pairs; ++i) fold_pair(2 * i, 2 * i + 1, i, prev_r_b);
+    m = final_pairs;
+  }
+
+  if (use_i64) {  // final Cz from the i64 mirrors (:1168-1203)
+    std::vector<Fq> fw = weights_from_r(out.r_bs, n_padded);
+    Layer cz(total);
+    for (size_t k = 0; k < total; ++k) {
+      SmallAccumulator sa;
+      for (size_t b = 0; b < n_padded; ++b) sa.accumulate(fw[b], (__int128)C64[b][k]);
+      cz[k] = sa.reduce();
+    }
+    for (size_t k : large) {
+      if (k >= total) continue;
+      Fq v = Fq::zero();
+      for (size_t b = 0; b < n_padded; ++b) v = v + fw[b] * C[b][k];
+      cz[k] = v;
+    }
+    C.clear();
+    C.push_back(std::move(cz));
+  }
+  if (acc_eq == Fq::zero()) throw std::runtime_error("DivisionByZero");
+  out.T_out = T_cur * acc_eq.inv();  // :1205-1206
+  out.eq_rho_at_rb = acc_eq;
+  out.A = std::move(A[0]);
+  out.B = std::move(B[0]);
+  out.C = std::move(C[0]);
+  return out;
+}
+
+}  // namespace oracle

@@ -214,3 +214,69 @@ class OracleSpartan:
         rc = lib().orc_spartan_verify(self.pk, pf)
         lib().orc_spartan_proof_free(pf)
         return rc
+
+
+# ---- NeutronNova NIFS data path (oracle/nifs.hpp) -----------------------------------------------
+NIFS_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, c_u64p, c_u64p)
+
+
+def transcript_round_hook(tr):
+    """Stand-in for the ZK `process_round` (src/neutronnova_zk.rs:723-727): absorb the four coefficients, squeeze r_b.
+    The real hook commits a verifier-circuit round witness — outside the data path, supplied by the caller."""
+
+    def hook(t, coeffs):
+        for i in range(4):
+            tr.absorb_scalar(b"p", coeffs[i])
+        return tr.squeeze(b"c")
+
+    return hook
+
+
+def c_hook(py_hook):
+    def raw(_user, t, coeffs_ptr, out_ptr):
+        coeffs = np.ctypeslib.as_array(coeffs_ptr, shape=(16,)).reshape(4, 4).copy()
+        r = np.ascontiguousarray(py_hook(int(t), coeffs), dtype=np.uint64)
+        for i in range(4):
+            out_ptr[i] = int(r[i])
+
+    return NIFS_HOOK(raw)
+
+
+def to_small_vec_or_zero(v):
+    v = np.ascontiguousarray(v, dtype=np.uint64)
+    n = v.shape[0]
+    out = np.zeros(n, dtype=np.int64)
+    large = np.zeros(n, dtype=np.uint8)
+    lib().orc_to_small_vec_or_zero.restype = ctypes.c_long
+    lib().orc_to_small_vec_or_zero(p64(v), ctypes.c_size_t(n), out.ctypes.data_as(ctypes.c_void_p), p8(large))
+    return out, np.nonzero(large)[0]
+
+
+def pow_split_evals(tau, ell, left, right):
+    out = np.zeros((left + right, 4), dtype=np.uint64)
+    rc = lib().orc_pow_split_evals(p64(np.ascontiguousarray(tau)), ctypes.c_size_t(ell), ctypes.c_size_t(left), ctypes.c_size_t(right), p64(out))
+    assert rc == 0, lib().orc_last_error()
+    return out
+
+
+def tensor_decomp(n):
+    e, l, r = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    lib().orc_tensor_decomp(ctypes.c_size_t(n), ctypes.byref(e), ctypes.byref(l), ctypes.byref(r))
+    return e.value, l.value, r.value
+
+
+def nifs_prove_core(left, right, E_eq, rhos, A, B, C, use_i64, py_hook):
+    """A, B, C: (n_padded, left*right, 4). Returns dict(polys (ell_b,4,4), r_bs, A, B, C, T_out, eq_rho_at_rb)."""
+    n_padded, total = A.shape[0], left * right
+    ell_b = rhos.shape[0]
+    polys = np.zeros((ell_b, 4, 4), dtype=np.uint64)
+    r_bs = np.zeros((ell_b, 4), dtype=np.uint64)
+    oA, oB, oC = (np.zeros((total, 4), dtype=np.uint64) for _ in range(3))
+    tail = np.zeros((2, 4), dtype=np.uint64)
+    cb = c_hook(py_hook)
+    rc = lib().orc_nifs_prove_core(ctypes.c_size_t(n_padded), ctypes.c_size_t(left), ctypes.c_size_t(right), p64(np.ascontiguousarray(E_eq)),
+                                   p64(np.ascontiguousarray(rhos)), ctypes.c_size_t(ell_b), p64(np.ascontiguousarray(A)), p64(np.ascontiguousarray(B)),
+                                   p64(np.ascontiguousarray(C)), ctypes.c_int(1 if use_i64 else 0), cb, None, p64(polys), p64(r_bs), p64(oA), p64(oB), p64(oC),
+                                   p64(tail))
+    assert rc == 0, lib().orc_last_error()
+    return dict(polys=polys, r_bs=r_bs, A=oA, B=oB, C=oC, T_out=tail[0], eq_rho_at_rb=tail[1])
