@@ -173,6 +173,35 @@ int sp_msm_ck_finish(sp_ctx* ctx, const sp_ck* ck, sp_msm_job* job, const uint64
  * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
 int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);
 
+/* ---- NeutronNova NIFS rounds (src/neutronnova_zk.rs:511-1273, NeutronNovaNIFS::prove) ---------------------
+ * The layers Az_b, Bz_b, Cz_b of the n_padded (power of two) instances live in three contiguous device arrays [layer][left*right];
+ * sp_nifs_layer hands out non-owning sp_table views so sp_multiply_vec can write a layer in place (:576-596). Per round the reference
+ * computes (e0, quad_coeff) over all instance pairs (:779-1097), builds the cubic in `finish_round!` (:703-735), obtains r_b from the
+ * verifier-circuit `process_round` (which stays on the caller's side of the ABI: it is a transcript/commit step, not data-parallel
+ * work), and folds the layers with r_b merged into the next round. The calls map one to one:
+ *   sp_nifs_begin      E_eq = PowPolynomial::split_evals(tau) (left | right entries, :563-566), rhos (:568-571); resets the state and
+ *                      computes c_vals[b] = sum_k E[k] Cz_b[k] (:652-703). small_values != 0 additionally builds the i64 mirrors
+ *                      (to_small_vec_or_zero, src/big_num/small_value.rs:41-86, global large positions as :1548-1586) and takes
+ *                      round 0 / c_vals from them (prove_helper_small :255-320) — same values, a quarter of the bytes.
+ *   sp_nifs_round      (t) -> the four coefficients [d, c, b, a] of poly_t (:719-721)
+ *   sp_nifs_challenge  (r_b): acc_eq *= eq(r_b, rho_t), T_cur = poly_t(r_b) (:729-731)
+ *   sp_nifs_finish     final fold of A, B (:1122-1165), Cz = sum_b w_b Cz_b with w = weights_from_r(r_bs) (:1168-1203),
+ *                      T_out = T_cur / acc_eq (:1205-1206, DivisionByZero when acc_eq = 0), eq_rho_at_rb = acc_eq.
+ * Witness / instance folding after the rounds is sp_fold_tables, sp_msm_shared_weights and sp_fixed_base_mul_h. */
+typedef struct sp_nifs sp_nifs;
+int sp_nifs_create(sp_ctx* ctx, size_t n_padded, size_t left, size_t right, sp_nifs** out);
+void sp_nifs_free(sp_nifs* n);
+/* which: 0 = Az, 1 = Bz, 2 = Cz. The view is valid until sp_nifs_free; free it with sp_table_free (does not release the storage). */
+int sp_nifs_layer(sp_nifs* n, int which, size_t idx, sp_table** view);
+int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, int small_values);
+int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]);
+int sp_nifs_challenge(sp_nifs* n, const uint64_t r_b[4]);
+int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out, uint64_t out_T_out[4], uint64_t out_eq_rho_at_rb[4]);
+/* to_small_vec_or_zero (src/big_num/small_value.rs:41-86) of a resident table: out_i64[cnt] and out_large[cnt] (0/1) on the host */
+int sp_to_small_vec_or_zero(sp_ctx* ctx, const sp_table* t, size_t cnt, int64_t* out_i64, uint8_t* out_large);
+/* PowPolynomial::split_evals (src/polys/power.rs:64-87), host side: left | right entries */
+int sp_pow_split_evals(const uint64_t tau[4], size_t ell, size_t left, size_t right, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

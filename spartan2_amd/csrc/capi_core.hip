@@ -228,7 +228,7 @@ int sp_table_set_len(sp_table* t, size_t len, size_t lo_eff, size_t hi_eff) {
 }
 void sp_table_free(sp_table* t) {
   if (!t) return;
-  if (t->d) hipFree(t->d);
+  if (t->d && !t->view) hipFree(t->d);
   delete t;
 }
 

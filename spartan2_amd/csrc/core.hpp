@@ -88,6 +88,7 @@ struct sp_table {
   size_t cap = 0;  // allocated elements
   size_t len = 0;  // logical length (power of two while used as a multilinear table)
   size_t lo_eff = (size_t)-1, hi_eff = (size_t)-1;
+  bool view = false;  // non-owning window onto storage owned by another object (sp_nifs layers)
 };
 
 struct sp_transcript {

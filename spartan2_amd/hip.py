@@ -383,3 +383,63 @@ def eval_cubic_outer_pow(ctx, pow_left: Table, pow_right, A: Table, B: Table, C:
     out = np.zeros((3, 4), dtype=np.uint64)
     check(lib().sp_eval_cubic_outer_pow(ctx.h, pow_left.h, pow_right.h if pow_right is not None else None, A.h, B.h, C.h, p64(out)))
     return out
+
+
+# ---- NeutronNova NIFS rounds (src/neutronnova_zk.rs:511-1273) ----------------------------------------------------------------
+def pow_split_evals(tau, ell: int, left: int, right: int):
+    """PowPolynomial::split_evals (src/polys/power.rs:64-87)."""
+    out = np.zeros((left + right, 4), dtype=np.uint64)
+    check(lib().sp_pow_split_evals(p64(np.ascontiguousarray(tau, dtype=np.uint64).reshape(4)), ctypes.c_size_t(ell), ctypes.c_size_t(left), ctypes.c_size_t(right),
+                                   p64(out)))
+    return out
+
+
+def to_small_vec_or_zero(ctx, table: Table, cnt: int):
+    """to_small_vec_or_zero (src/big_num/small_value.rs:41-86) -> (i64 values, indices of the large positions)."""
+    out = np.zeros(cnt, dtype=np.int64)
+    large = np.zeros(cnt, dtype=np.uint8)
+    check(lib().sp_to_small_vec_or_zero(ctx.h, table.h, ctypes.c_size_t(cnt), out.ctypes.data_as(ctypes.c_void_p), p8(large) if cnt else None))
+    return out, np.nonzero(large)[0]
+
+
+class Nifs:
+    """Device state of NeutronNovaNIFS::prove: instance layers Az/Bz/Cz, the rounds, the final folded layers."""
+
+    def __init__(self, ctx: Context, n_padded: int, left: int, right: int):
+        self.ctx, self.n_padded, self.left, self.right = ctx, n_padded, left, right
+        self.h = ctypes.c_void_p()
+        check(lib().sp_nifs_create(ctx.h, ctypes.c_size_t(n_padded), ctypes.c_size_t(left), ctypes.c_size_t(right), ctypes.byref(self.h)))
+
+    def layer(self, which: int, idx: int) -> Table:
+        h = ctypes.c_void_p()
+        check(lib().sp_nifs_layer(self.h, int(which), ctypes.c_size_t(idx), ctypes.byref(h)))
+        return Table(self.ctx, h)
+
+    def begin(self, E_eq, rhos, small_values=False):
+        E_eq = np.ascontiguousarray(E_eq, dtype=np.uint64).reshape(self.left + self.right, 4)
+        rhos = np.ascontiguousarray(rhos, dtype=np.uint64).reshape(-1, 4)
+        check(lib().sp_nifs_begin(self.h, p64(E_eq), p64(rhos), ctypes.c_size_t(rhos.shape[0]), 1 if small_values else 0))
+
+    def round(self, t: int):
+        out = np.zeros((4, 4), dtype=np.uint64)
+        check(lib().sp_nifs_round(self.h, ctypes.c_size_t(t), p64(out)))
+        return out
+
+    def challenge(self, r_b):
+        check(lib().sp_nifs_challenge(self.h, p64(np.ascontiguousarray(r_b, dtype=np.uint64).reshape(4))))
+
+    def finish(self, A: Table, B: Table, C: Table):
+        T, eq = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        check(lib().sp_nifs_finish(self.h, A.h, B.h, C.h, p64(T), p64(eq)))
+        return T, eq
+
+    def free(self):
+        if self.h:
+            lib().sp_nifs_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
