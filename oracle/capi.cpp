@@ -564,4 +564,46 @@ void* orc_spartan_proof_from_words(void* pk_, const uint64_t* w, size_t nwords) 
   }
 }
 
+// NeutronNovaNIFS::prove as a whole (oracle/nifs.hpp). Instances: comm rows (n x rows x affine), X (n x d), W (n x num_vars), r_W (n x rows).
+// Outputs: polys (ell_b x 4), r_bs, E_eq (left + right), final layers A, B, C (num_cons each), tail = T_out | eq_rho_at_rb,
+// folded W (num_vars), folded r_W (rows), folded X (d), folded comm (rows affine).
+int orc_nifs_prove(void* shape, void* key, size_t n, size_t rows, size_t d, const uint64_t* comms, const uint64_t* X, const uint64_t* W, const uint64_t* r_W,
+                   int use_i64, void* transcript, orc_nifs_hook hook, void* user, uint64_t* out_polys, uint64_t* out_r_bs, uint64_t* out_E, uint64_t* out_A,
+                   uint64_t* out_B, uint64_t* out_C, uint64_t* out_tail, uint64_t* out_W, uint64_t* out_rW, uint64_t* out_X, uint64_t* out_comm) {
+  ORC_TRY
+  auto* S = (SplitR1CSShape<Fq>*)shape;
+  auto* ck = (HyraxKey*)key;
+  size_t nv = S->num_vars();
+  std::vector<NifsInstance> Us(n);
+  std::vector<NifsWitness> Ws(n);
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t r = 0; r < rows; ++r) Us[i].comm_W.push_back(Jac::from_affine(load_aff(comms + 8 * (i * rows + r))));
+    Us[i].X = load<Fq>(X + 4 * i * d, d);
+    Ws[i].W = load<Fq>(W + 4 * i * nv, nv);
+    Ws[i].r_W = load<Fq>(r_W + 4 * i * rows, rows);
+  }
+  NifsRoundHook h = [&](size_t t, const std::array<Fq, 4>& co) {
+    uint64_t buf[16], r[4] = {0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q) memcpy(buf + 4 * q, co[q].l, 32);
+    hook(user, t, buf, r);
+    return Fq::from_raw_mont(r);
+  };
+  NifsProveOutput o = nifs_prove(*S, *ck, std::move(Us), std::move(Ws), use_i64 != 0, *(Transcript*)transcript, h);
+  for (size_t t = 0; t < o.core.polys.size(); ++t)
+    for (int q = 0; q < 4; ++q) memcpy(out_polys + 16 * t + 4 * q, o.core.polys[t][q].l, 32);
+  store(out_r_bs, o.core.r_bs);
+  store(out_E, o.E_eq);
+  store(out_A, o.core.A);
+  store(out_B, o.core.B);
+  store(out_C, o.core.C);
+  memcpy(out_tail, o.core.T_out.l, 32);
+  memcpy(out_tail + 4, o.core.eq_rho_at_rb.l, 32);
+  store(out_W, o.folded_W.W);
+  store(out_rW, o.folded_W.r_W);
+  store(out_X, o.folded_U.X);
+  std::vector<Affine> a = batch_affine(o.folded_U.comm_W);
+  for (size_t r = 0; r < a.size(); ++r) store_aff(out_comm + 8 * r, a[r]);
+  ORC_CATCH
+}
+
 }  // extern "C"

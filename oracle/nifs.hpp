@@ -19,6 +19,7 @@
 
 #include "neutronnova.hpp"
 #include "polys.hpp"
+#include "sparse.hpp"
 
 namespace oracle {
 
@@ -436,6 +437,99 @@ inline NifsCoreOutput nifs_prove_core(size_t left, size_t right, const std::vect
   out.A = std::move(A[0]);
   out.B = std::move(B[0]);
   out.C = std::move(C[0]);
+  return out;
+}
+
+// ---- NeutronNovaNIFS::prove as a whole (src/neutronnova_zk.rs:511-1273): transcript preamble, layers, rounds, witness / instance folding ----
+struct NifsInstance {  // R1CSInstance (src/r1cs/mod.rs:664-736)
+  HyraxCommitment comm_W;
+  std::vector<Fq> X;
+};
+struct NifsWitness {  // R1CSWitness (:545-568)
+  std::vector<Fq> W;
+  HyraxBlind r_W;
+};
+struct NifsProveOutput {
+  NifsCoreOutput core;
+  std::vector<Fq> E_eq;
+  NifsWitness folded_W;
+  NifsInstance folded_U;
+};
+
+inline void absorb_instance(Transcript& tr, const char* label, const NifsInstance& U) {  // TranscriptReprTrait for R1CSInstance (:728-736)
+  std::vector<uint8_t> b = commitment_transcript_bytes(U.comm_W);
+  for (const Fq& x : U.X) {
+    uint8_t be[32];
+    x.to_be_bytes(be);
+    b.insert(b.end(), be, be + 32);
+  }
+  tr.absorb_bytes(label, b.data(), b.size());
+}
+
+// hook(t, coeffs) for t < ell_b is `process_round` of round t; the reference calls it once more after the rounds with t = ell_b
+// (vc.t_out_step, vc.eq_rho_at_rb set, :1207-1210): here coeffs = {T_out, eq_rho_at_rb, 0, 0} and the return value is ignored.
+inline NifsProveOutput nifs_prove(const SplitR1CSShape<Fq>& S, const HyraxKey& ck, std::vector<NifsInstance> Us, std::vector<NifsWitness> Ws, bool use_i64,
+                                  Transcript& tr, const NifsRoundHook& hook) {
+  size_t n = Us.size(), n_padded = 1;
+  while (n_padded < n) n_padded <<= 1;
+  if (n_padded < 2) n_padded = 2;  // ell_b = 0 is not reachable in the reference's use (at least two step instances)
+  size_t ell_b = 0;
+  while ((size_t(1) << ell_b) < n_padded) ++ell_b;
+  while (Us.size() < n_padded) {  // :549-552
+    Us.push_back(Us[0]);
+    Ws.push_back(Ws[0]);
+  }
+  for (const auto& U : Us) absorb_instance(tr, "U", U);  // :553-555
+  Fq T = Fq::zero();
+  tr.absorb_scalars("T", &T, 1);
+  size_t ell_cons, left, right;
+  compute_tensor_decomp(S.num_cons, &ell_cons, &left, &right);
+  Fq tau = tr.squeeze<Fq>("tau");
+  NifsProveOutput out;
+  out.E_eq = pow_split_evals(tau, ell_cons, left, right);
+  std::vector<Fq> rhos;
+  for (size_t i = 0; i < ell_b; ++i) rhos.push_back(tr.squeeze<Fq>("rho"));
+  std::vector<Layer> A(n_padded), B(n_padded), C(n_padded);
+  for (size_t i = 0; i < n_padded; ++i) {  // :583-596
+    std::vector<Fq> z = Ws[i].W;
+    z.push_back(Fq::one());
+    z.insert(z.end(), Us[i].X.begin(), Us[i].X.end());
+    S.multiply_vec(z, &A[i], &B[i], &C[i]);
+  }
+  out.core = nifs_prove_core(left, right, out.E_eq, rhos, std::move(A), std::move(B), std::move(C), use_i64, hook);
+  hook(ell_b, {out.core.T_out, out.core.eq_rho_at_rb, Fq::zero(), Fq::zero()});
+  // witness fold (:1212-1231): only the shared + precommitted prefix is folded when it is non-empty, the rest segment is re-zeroed
+  size_t effective_len = S.num_shared + S.num_precommitted, full_dim = effective_len + S.num_rest;
+  bool truncated = effective_len > 0;
+  size_t dim = truncated ? effective_len : Ws[0].W.size();
+  std::vector<Fq> w = weights_from_r(out.core.r_bs, n_padded);
+  std::vector<const Fq*> ptrs;
+  std::vector<HyraxBlind> blinds;
+  for (const auto& W : Ws) {
+    ptrs.push_back(W.W.data());
+    blinds.push_back(W.r_W);
+  }
+  out.folded_W.W = fold_witnesses(w, ptrs, dim);
+  if (truncated) out.folded_W.W.resize(full_dim, Fq::zero());
+  out.folded_W.r_W = fold_blinds(blinds, w);
+  // instance fold (:1233-1261)
+  size_t d = Us[0].X.size();
+  out.folded_U.X.assign(d, Fq::zero());
+  for (size_t i = 0; i < Us.size(); ++i)
+    for (size_t j = 0; j < d; ++j) out.folded_U.X[j] = out.folded_U.X[j] + w[i] * Us[i].X[j];
+  std::vector<HyraxCommitment> comms;
+  for (const auto& U : Us) comms.push_back(U.comm_W);
+  size_t total_rows = comms[0].size();
+  size_t num_data_rows = truncated ? div_ceil(effective_len, DEFAULT_COMMITMENT_WIDTH) : total_rows;
+  if (num_data_rows >= total_rows) {
+    out.folded_U.comm_W = fold_commitments(comms, w);
+  } else {  // fold_commitments_partial (hyrax_pc.rs:820-874)
+    std::vector<HyraxCommitment> data;
+    for (const auto& c : comms) data.emplace_back(c.begin(), c.begin() + num_data_rows);
+    out.folded_U.comm_W = fold_commitments(data, w);
+    FixedBaseMul fb = FixedBaseMul::precompute(ck.h);
+    for (size_t row = num_data_rows; row < total_rows; ++row) out.folded_U.comm_W.push_back(fb.mul(out.folded_W.r_W[row]));
+  }
   return out;
 }
 

@@ -63,10 +63,12 @@ def sha256_circuit(preimage: bytes) -> R1CSInstanceInt:
     return R1CSInstanceInt(lib().spf_sha256_circuit(preimage, ctypes.c_size_t(len(preimage))))
 
 
-def synthetic_circuit(n_groups: int, seed: int, num_public: int = 4, shared_permille: int = 0, precommitted_permille: int = 1000) -> R1CSInstanceInt:
-    """Seeded SHA-like circuit; the permille arguments cut the aux list into shared | precommitted | rest segments."""
+def synthetic_circuit(n_groups: int, seed: int, num_public: int = 4, shared_permille: int = 0, precommitted_permille: int = 1000,
+                      witness_seed: int = 0) -> R1CSInstanceInt:
+    """Seeded SHA-like circuit; the permille arguments cut the aux list into shared | precommitted | rest segments.
+    witness_seed != 0: same matrices, a different satisfying assignment."""
     return R1CSInstanceInt(lib().spf_synthetic_circuit(ctypes.c_size_t(n_groups), ctypes.c_uint64(seed), ctypes.c_size_t(num_public),
-                                                       ctypes.c_uint(shared_permille), ctypes.c_uint(precommitted_permille)))
+                                                       ctypes.c_uint(shared_permille), ctypes.c_uint(precommitted_permille), ctypes.c_uint64(witness_seed)))
 
 
 def cubic_circuit() -> R1CSInstanceInt:

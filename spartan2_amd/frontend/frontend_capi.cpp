@@ -19,9 +19,10 @@ void* spf_sha256_circuit(const uint8_t* msg, size_t n) {
     return nullptr;
   }
 }
-void* spf_synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public, unsigned shared_permille, unsigned precommitted_permille) {
+void* spf_synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public, unsigned shared_permille, unsigned precommitted_permille,
+                            uint64_t witness_seed) {
   try {
-    return new R1CSInstanceInt(synthetic_circuit(n_groups, seed, num_public, shared_permille, precommitted_permille));
+    return new R1CSInstanceInt(synthetic_circuit(n_groups, seed, num_public, shared_permille, precommitted_permille, witness_seed));
   } catch (const std::exception& e) {
     g_err = e.what();
     return nullptr;

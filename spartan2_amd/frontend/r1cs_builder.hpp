@@ -422,12 +422,17 @@ inline uint64_t splitmix64(uint64_t& s) {
 }
 // `shared_permille` / `precommitted_permille`: where to cut the aux list into shared | precommitted | rest segments (the
 // segments of SpartanCircuit::{shared, precommitted, synthesize}, src/traits/circuit.rs); 0/1000 = everything precommitted.
+// `witness_seed` != 0 draws the 64 free input bits from a second stream: same matrices, a different satisfying assignment
+// (several instances of one step shape, as NeutronNova folds them).
 inline R1CSInstanceInt synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public, unsigned shared_permille = 0,
-                                         unsigned precommitted_permille = 1000) {
+                                         unsigned precommitted_permille = 1000, uint64_t witness_seed = 0) {
   ConstraintSystem cs;
-  uint64_t s = seed;
+  uint64_t s = seed, ws = witness_seed;
   std::vector<Boolean> pool;
-  for (int i = 0; i < 64; ++i) pool.push_back(alloc_bit(cs, splitmix64(s) & 1));
+  for (int i = 0; i < 64; ++i) {
+    const uint64_t structural = splitmix64(s);
+    pool.push_back(alloc_bit(cs, (witness_seed ? splitmix64(ws) : structural) & 1));
+  }
   for (size_t g = 0; g < n_groups; ++g) {
     for (int k = 0; k < 30; ++k) {
       Boolean a = pool[splitmix64(s) % pool.size()], b = pool[splitmix64(s) % pool.size()];

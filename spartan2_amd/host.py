@@ -139,3 +139,53 @@ class SpartanSNARK:
             self.close()
         except Exception:
             pass
+
+
+# ---- NeutronNovaNIFS::prove (spartan2_amd/host/neutronnova_nifs.cpp) ----------------------------------------------------------
+NIFS_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, hip.c_u64p, hip.c_u64p)
+
+
+def _c_hook(py_hook):
+    def raw(_user, t, coeffs_ptr, out_ptr):
+        coeffs = np.ctypeslib.as_array(coeffs_ptr, shape=(16,)).reshape(4, 4).copy()
+        r = py_hook(int(t), coeffs)
+        if r is not None:
+            r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+            for i in range(4):
+                out_ptr[i] = int(r[i])
+
+    return NIFS_HOOK(raw)
+
+
+def tensor_decomp(n: int):
+    """compute_tensor_decomp (src/neutronnova_zk.rs:56-67)."""
+    ell = max(n - 1, 0).bit_length()
+    return ell, 1 << ((ell + 1) // 2), 1 << (ell // 2)
+
+
+def nifs_prove(ctx: hip.Context, shape: hip.Shape, dims: dict, ck: hip.CommitmentKey, comms, X, W_tables, r_W, small_values: bool, tr: hip.Transcript, py_hook):
+    """NeutronNovaNIFS::prove (src/neutronnova_zk.rs:511-1273). comms (n, rows, 8), X (n, d, 4), W_tables: n resident witness tables,
+    r_W (n, rows, 4); py_hook(t, coeffs (4,4)) -> r_b is the caller's `process_round`. Returns a dict of host arrays and device tables."""
+    comms = np.ascontiguousarray(comms, dtype=np.uint64)
+    n, rows = comms.shape[0], comms.shape[1]
+    d = dims["num_public"]
+    X = np.ascontiguousarray(X, dtype=np.uint64).reshape(n, d, 4)
+    r_W = np.ascontiguousarray(r_W, dtype=np.uint64).reshape(n, rows, 4)
+    n_padded = max(2, 1 << (n - 1).bit_length())
+    ell_b = n_padded.bit_length() - 1
+    _, left, right = tensor_decomp(dims["num_cons"])
+    N, nv = dims["num_cons"], dims["num_shared"] + dims["num_precommitted"] + dims["num_rest"]
+    out = dict(polys=np.zeros((ell_b, 4, 4), dtype=np.uint64), r_bs=np.zeros((ell_b, 4), dtype=np.uint64), E_eq=np.zeros((left + right, 4), dtype=np.uint64),
+               tail=np.zeros((2, 4), dtype=np.uint64), folded_rW=np.zeros((rows, 4), dtype=np.uint64), folded_X=np.zeros((max(d, 1), 4), dtype=np.uint64),
+               folded_comm=np.zeros((rows, 8), dtype=np.uint64))
+    tabs = dict(A=hip.Table.zeros(ctx, N), B=hip.Table.zeros(ctx, N), C=hip.Table.zeros(ctx, N), folded_W=hip.Table.zeros(ctx, nv))
+    d10 = (ctypes.c_uint64 * 10)(*[dims[k] for k in DIM_NAMES])
+    warr = (ctypes.c_void_p * n)(*[t.h for t in W_tables])
+    cb = _c_hook(py_hook)
+    _check(lib().nn_nifs_prove(ctx.h, shape.h, d10, ck.h, ctypes.c_size_t(n), ctypes.c_size_t(rows), hip.p64(comms.reshape(-1)), hip.p64(X.reshape(-1)) if d else None,
+                               warr, hip.p64(r_W.reshape(-1)), 1 if small_values else 0, tr.h, cb, None, hip.p64(out["polys"]), hip.p64(out["r_bs"]),
+                               hip.p64(out["E_eq"]), hip.p64(out["tail"]), hip.p64(out["folded_rW"]), hip.p64(out["folded_X"]), hip.p64(out["folded_comm"]),
+                               tabs["A"].h, tabs["B"].h, tabs["C"].h, tabs["folded_W"].h))
+    out["folded_X"] = out["folded_X"][:d]
+    out.update(tabs)
+    return out

@@ -1,0 +1,80 @@
+// Helpers shared by the host-side drivers above the C ABI (spartan_snark.cpp, neutronnova_nifs.cpp): error plumbing, the transcript wrapper over
+// sp_transcript_*, the transcript encodings of points / commitments, the randomness tape.
+#pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/spartan_hip.h"
+#include "../csrc/curve.cuh"
+#include "../csrc/keccak.cuh"
+
+namespace spartan2 {
+
+typedef FqP S;
+static const size_t DEFAULT_COMMITMENT_WIDTH = 2048;  // src/lib.rs:63
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+static void ck(int rc, const char* what) {
+  if (rc != SP_OK) throw Error(rc, std::string(what) + ": " + sp_last_error());
+}
+
+static inline const uint64_t* u64p(const fe_t* p) { return reinterpret_cast<const uint64_t*>(p); }
+static inline uint64_t* u64p(fe_t* p) { return reinterpret_cast<uint64_t*>(p); }
+
+// ---- transcript helpers over the C ABI ---------------------------------------------------------------------------------
+struct Tr {
+  sp_transcript* t = nullptr;
+  explicit Tr(sp_ctx* ctx, const char* label) { ck(sp_transcript_new(ctx, (const uint8_t*)label, strlen(label), &t), "transcript_new"); }
+  explicit Tr(const sp_transcript* prefix) { ck(sp_transcript_clone(prefix, &t), "transcript_clone"); }
+  ~Tr() { sp_transcript_free(t); }
+  void absorb(const char* label, const uint8_t* b, size_t n) { ck(sp_transcript_absorb(t, (const uint8_t*)label, strlen(label), b, n), "absorb"); }
+  void absorb_scalars(const char* label, const fe_t* s, size_t n) {  // BE encoding (src/provider/traits.rs:282-286), slices concatenated
+    std::vector<uint8_t> b(32 * n);
+    for (size_t i = 0; i < n; ++i) sp::fe_to_be_bytes<S>(s[i], b.data() + 32 * i);
+    absorb(label, b.data(), b.size());
+  }
+  fe_t squeeze(const char* label) {
+    fe_t f;
+    ck(sp_transcript_squeeze(t, (const uint8_t*)label, strlen(label), u64p(&f)), "squeeze");
+    return f;
+  }
+  void dom_sep(const char* s) { ck(sp_transcript_dom_sep(t, (const uint8_t*)s, strlen(s)), "dom_sep"); }
+};
+// point -> x BE || y BE (src/provider/traits.rs:288-305)
+static void point_bytes(const aff_t& a, uint8_t out[64]) {
+  sp::fe_to_be_bytes<B>(a.x, out);
+  sp::fe_to_be_bytes<B>(a.y, out + 32);
+}
+// HyraxCommitment::to_transcript_bytes (src/provider/pcs/hyrax_pc.rs:714-729)
+static std::vector<uint8_t> commitment_bytes(const aff_t* rows, size_t n) {
+  static const char* b = "poly_commitment_begin";
+  static const char* e = "poly_commitment_end";
+  std::vector<uint8_t> v(b, b + strlen(b));
+  v.resize(v.size() + 64 * n);
+  for (size_t i = 0; i < n; ++i) point_bytes(rows[i], v.data() + strlen(b) + 64 * i);
+  v.insert(v.end(), e, e + strlen(e));
+  return v;
+}
+
+struct Tape {
+  const uint8_t* bytes;
+  size_t blocks, pos = 0;
+  fe_t next() {
+    if (pos >= blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
+    return fe_from_uniform<S>(bytes + 64 * pos++);
+  }
+  void skip(size_t n) {
+    if (pos + n > blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
+    pos += n;
+  }
+};
+
+}  // namespace spartan2

@@ -1,0 +1,159 @@
+// Host side ABOVE the C ABI: NeutronNovaNIFS::prove (src/neutronnova_zk.rs:511-1273) restated in C++ over include/spartan_hip.h.
+// What stays with the caller, exactly as in the reference: the per-round `process_round` of the ZK verifier circuit
+// (SatisfyingAssignment::process_round, called from `finish_round!` :723-727 and once more after the rounds :1207-1210) — a
+// verifier-circuit witness commit + transcript step, not data-parallel work. It enters as a callback
+// `hook(user, t, coeffs[4 F], r_b out)`; for t == ell_b the coefficients are {T_out, eq_rho_at_rb, 0, 0} and r_b is ignored.
+// Everything that scales with the instances runs on the device: the matrix-vector products into the NIFS layers, the rounds, the witness
+// fold (fold_multiple), the commitment fold (fold_commitments[_partial]).
+#include "host_common.hpp"
+
+namespace spartan2 {
+
+typedef void (*nn_round_hook)(void* user, size_t t, const uint64_t* coeffs16, uint64_t* r_b);
+
+static void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right) {  // src/neutronnova_zk.rs:56-67
+  size_t l = 0;
+  while ((size_t(1) << l) < n) ++l;
+  *ell = l;
+  *left = size_t(1) << ((l + 1) / 2);
+  *right = size_t(1) << (l / 2);
+}
+
+struct NifsOutputs {
+  uint64_t *polys, *r_bs, *E_eq, *tail, *folded_rW, *folded_X, *folded_comm;
+  sp_table *A, *B, *C, *folded_W;
+};
+
+// Us: comm rows (n x rows affine) + X (n x d); Ws: resident witness tables (num_vars each) + blinds (n x rows)
+static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const sp_ck* ckey, size_t n, size_t rows, const aff_t* comms, const fe_t* X,
+                       const sp_table* const* Ws, const fe_t* r_W, bool small_values, sp_transcript* tr, nn_round_hook hook, void* user, NifsOutputs& out) {
+  if (n == 0) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NIFS prove: no instances");
+  const size_t d = dims.num_public, num_vars = dims.num_shared + dims.num_precommitted + dims.num_rest;
+  size_t n_padded = 2;
+  while (n_padded < n) n_padded <<= 1;
+  size_t ell_b = 0;
+  while ((size_t(1) << ell_b) < n_padded) ++ell_b;
+  auto inst = [&](size_t i) { return i < n ? i : 0; };  // padding clones instance 0 (:549-552)
+
+  auto absorb = [&](const char* label, const uint8_t* b, size_t len) { ck(sp_transcript_absorb(tr, (const uint8_t*)label, strlen(label), b, len), "absorb"); };
+  auto squeeze = [&](const char* label) {
+    fe_t f;
+    ck(sp_transcript_squeeze(tr, (const uint8_t*)label, strlen(label), u64p(&f)), "squeeze");
+    return f;
+  };
+  for (size_t i = 0; i < n_padded; ++i) {  // transcript.absorb(b"U", U) (:553-555; R1CSInstance bytes = comm_W || X, src/r1cs/mod.rs:728-736)
+    std::vector<uint8_t> b = commitment_bytes(comms + inst(i) * rows, rows);
+    const size_t off = b.size();
+    b.resize(off + 32 * d);
+    for (size_t j = 0; j < d; ++j) sp::fe_to_be_bytes<S>(X[inst(i) * d + j], b.data() + off + 32 * j);
+    absorb("U", b.data(), b.size());
+  }
+  {
+    uint8_t zero_be[32] = {0};  // T = 0 (:556-557)
+    absorb("T", zero_be, 32);
+  }
+  size_t ell_cons, left, right;
+  compute_tensor_decomp(dims.num_cons, &ell_cons, &left, &right);
+  const fe_t tau = squeeze("tau");
+  ck(sp_pow_split_evals(u64p(&tau), ell_cons, left, right, out.E_eq), "split_evals");
+  std::vector<fe_t> rhos(ell_b);
+  for (auto& r : rhos) r = squeeze("rho");
+
+  sp_nifs* nifs = nullptr;
+  ck(sp_nifs_create(ctx, n_padded, left, right, &nifs), "nifs_create");
+  sp_table* z = nullptr;
+  struct Guard {
+    sp_nifs*& n;
+    sp_table*& z;
+    ~Guard() {
+      sp_nifs_free(n);
+      sp_table_free(z);
+    }
+  } guard{nifs, z};
+  ck(sp_table_zeros(ctx, num_vars + 1 + d, (size_t)-1, (size_t)-1, &z), "z alloc");
+  const fe_t one = fe_one<S>();
+  for (size_t i = 0; i < n_padded; ++i) {  // z = [W | 1 | X]; (Az, Bz, Cz) straight into layer i (:583-596)
+    ck(sp_table_copy(ctx, z, 0, Ws[inst(i)], 0, num_vars), "z <- W");
+    std::vector<fe_t> tail(1 + d);
+    tail[0] = one;
+    for (size_t j = 0; j < d; ++j) tail[1 + j] = X[inst(i) * d + j];
+    ck(sp_table_write(ctx, z, num_vars, u64p(tail.data()), 1 + d), "z tail");
+    sp_table* v[3];
+    for (int q = 0; q < 3; ++q) ck(sp_nifs_layer(nifs, q, i, &v[q]), "nifs_layer");
+    int rc = sp_multiply_vec(ctx, shape, z, v[0], v[1], v[2]);
+    for (int q = 0; q < 3; ++q) sp_table_free(v[q]);
+    ck(rc, "multiply_vec");
+  }
+  ck(sp_nifs_begin(nifs, out.E_eq, u64p(rhos.data()), ell_b, small_values ? 1 : 0), "nifs_begin");
+  std::vector<fe_t> r_bs(ell_b);
+  for (size_t t = 0; t < ell_b; ++t) {
+    uint64_t* co = out.polys + 16 * t;
+    ck(sp_nifs_round(nifs, t, co), "nifs_round");
+    hook(user, t, co, u64p(&r_bs[t]));
+    ck(sp_nifs_challenge(nifs, u64p(&r_bs[t])), "nifs_challenge");
+  }
+  memcpy(out.r_bs, r_bs.data(), ell_b * sizeof(fe_t));
+  ck(sp_nifs_finish(nifs, out.A, out.B, out.C, out.tail, out.tail + 4), "nifs_finish");
+  {
+    uint64_t fin[16] = {0}, ignored[4];
+    memcpy(fin, out.tail, 64);
+    hook(user, ell_b, fin, ignored);
+  }
+  // fold_witnesses (:1212-1231): truncated to shared + precommitted when that prefix is non-empty, rest re-zeroed
+  const size_t effective_len = dims.num_shared + dims.num_precommitted;
+  const bool truncated = effective_len > 0;
+  const size_t dim = truncated ? effective_len : num_vars;
+  std::vector<fe_t> w(n_padded);
+  ck(sp_weights_from_r(u64p(r_bs.data()), ell_b, n_padded, u64p(w.data())), "weights_from_r");
+  std::vector<const sp_table*> wt(n_padded);
+  for (size_t i = 0; i < n_padded; ++i) wt[i] = Ws[inst(i)];
+  ck(sp_fold_tables(ctx, wt.data(), n_padded, u64p(w.data()), dim, out.folded_W), "fold_multiple");
+  if (dim < num_vars) ck(sp_table_zero(ctx, out.folded_W, dim, num_vars - dim), "zero rest");
+  ck(sp_table_set_len(out.folded_W, num_vars, (size_t)-1, (size_t)-1), "set_len");
+  std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());  // fold_blinds (hyrax_pc.rs:795-818), X fold (:1236-1245)
+  for (size_t i = 0; i < n_padded; ++i) {
+    for (size_t r = 0; r < rows; ++r) f_rW[r] = fe_add<S>(f_rW[r], fe_mul<S>(r_W[inst(i) * rows + r], w[i]));
+    for (size_t j = 0; j < d; ++j) f_X[j] = fe_add<S>(f_X[j], fe_mul<S>(w[i], X[inst(i) * d + j]));
+  }
+  memcpy(out.folded_rW, f_rW.data(), rows * sizeof(fe_t));
+  memcpy(out.folded_X, f_X.data(), d * sizeof(fe_t));
+  // fold_commitments_partial / fold_commitments (:1247-1261, hyrax_pc.rs:737-793, 820-874)
+  size_t data_rows = truncated ? (effective_len + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH : rows;
+  if (data_rows > rows) data_rows = rows;
+  std::vector<aff_t> bases(data_rows * n_padded);
+  for (size_t r = 0; r < data_rows; ++r)
+    for (size_t i = 0; i < n_padded; ++i) bases[r * n_padded + i] = comms[inst(i) * rows + r];
+  if (data_rows) ck(sp_msm_shared_weights(ctx, u64p(w.data()), n_padded, (const uint64_t*)bases.data(), data_rows, out.folded_comm), "fold_commitments");
+  if (data_rows < rows)  // rest rows: folded_blind[row] * h
+    ck(sp_fixed_base_mul_h(ctx, ckey, u64p(f_rW.data() + data_rows), rows - data_rows, out.folded_comm + 8 * data_rows), "rest rows");
+}
+
+}  // namespace spartan2
+
+using namespace spartan2;
+
+extern "C" {
+const char* ss_last_error();
+void ss_set_error(const char* msg);
+
+// dims10 = sp_dims as ten uint64 (ss_padded_dims order). comms: n x rows affine; X: n x num_public; Ws: n resident witness tables; r_W: n x rows.
+// out_* buffers: polys ell_b x 16, r_bs ell_b x 4, E_eq (left + right) x 4, tail 8, folded_rW rows x 4, folded_X d x 4, folded_comm rows x 8.
+int nn_nifs_prove(sp_ctx* ctx, const sp_shape* S, const uint64_t dims10[10], const sp_ck* ckey, size_t n, size_t rows, const uint64_t* comms, const uint64_t* X,
+                  const sp_table* const* Ws, const uint64_t* r_W, int small_values, sp_transcript* tr, nn_round_hook hook, void* user, uint64_t* out_polys,
+                  uint64_t* out_r_bs, uint64_t* out_E, uint64_t* out_tail, uint64_t* out_folded_rW, uint64_t* out_folded_X, uint64_t* out_folded_comm,
+                  sp_table* out_A, sp_table* out_B, sp_table* out_C, sp_table* out_folded_W) {
+  try {
+    sp_dims dims;
+    memcpy(&dims, dims10, sizeof(sp_dims));
+    NifsOutputs o{out_polys, out_r_bs, out_E, out_tail, out_folded_rW, out_folded_X, out_folded_comm, out_A, out_B, out_C, out_folded_W};
+    nifs_prove(ctx, S, dims, ckey, n, rows, (const aff_t*)comms, (const fe_t*)X, Ws, (const fe_t*)r_W, small_values != 0, tr, hook, user, o);
+    return SP_OK;
+  } catch (const Error& e) {
+    ss_set_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    ss_set_error(e.what());
+    return SP_ERR_INTERNAL;
+  }
+}
+}

@@ -13,33 +13,9 @@
 // Randomness is injected: every blind / mask is the next 64-byte block of a caller-supplied tape reduced with from_uniform,
 // in the reference's call order.
 // Generators: this build's own derivation (the reference's is a third-party hash-to-curve): PARITY UNPINNED, see DESIGN.md.
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <stdexcept>
-#include <string>
-#include <vector>
-
-#include "../../include/spartan_hip.h"
-#include "../csrc/curve.cuh"
-#include "../csrc/keccak.cuh"
+#include "host_common.hpp"
 
 namespace spartan2 {
-
-typedef FqP S;
-static const size_t DEFAULT_COMMITMENT_WIDTH = 2048;  // src/lib.rs:63
-
-struct Error : std::runtime_error {
-  int code;
-  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
-};
-static void ck(int rc, const char* what) {
-  if (rc != SP_OK) throw Error(rc, std::string(what) + ": " + sp_last_error());
-}
-
-static inline const uint64_t* u64p(const fe_t* p) { return reinterpret_cast<const uint64_t*>(p); }
-static inline uint64_t* u64p(fe_t* p) { return reinterpret_cast<uint64_t*>(p); }
 
 // ---- integer R1CS as produced by the frontend (arguments of SplitR1CSShape::new) ---------------------------------------
 struct CsrIntView {
@@ -183,54 +159,6 @@ std::vector<aff_t> from_label(const char* label, size_t n) {
   }
   return out;
 }
-
-// ---- transcript helpers over the C ABI ---------------------------------------------------------------------------------
-struct Tr {
-  sp_transcript* t = nullptr;
-  explicit Tr(sp_ctx* ctx, const char* label) { ck(sp_transcript_new(ctx, (const uint8_t*)label, strlen(label), &t), "transcript_new"); }
-  explicit Tr(const sp_transcript* prefix) { ck(sp_transcript_clone(prefix, &t), "transcript_clone"); }
-  ~Tr() { sp_transcript_free(t); }
-  void absorb(const char* label, const uint8_t* b, size_t n) { ck(sp_transcript_absorb(t, (const uint8_t*)label, strlen(label), b, n), "absorb"); }
-  void absorb_scalars(const char* label, const fe_t* s, size_t n) {  // BE encoding (src/provider/traits.rs:282-286), slices concatenated
-    std::vector<uint8_t> b(32 * n);
-    for (size_t i = 0; i < n; ++i) sp::fe_to_be_bytes<S>(s[i], b.data() + 32 * i);
-    absorb(label, b.data(), b.size());
-  }
-  fe_t squeeze(const char* label) {
-    fe_t f;
-    ck(sp_transcript_squeeze(t, (const uint8_t*)label, strlen(label), u64p(&f)), "squeeze");
-    return f;
-  }
-  void dom_sep(const char* s) { ck(sp_transcript_dom_sep(t, (const uint8_t*)s, strlen(s)), "dom_sep"); }
-};
-// point -> x BE || y BE (src/provider/traits.rs:288-305)
-static void point_bytes(const aff_t& a, uint8_t out[64]) {
-  sp::fe_to_be_bytes<B>(a.x, out);
-  sp::fe_to_be_bytes<B>(a.y, out + 32);
-}
-// HyraxCommitment::to_transcript_bytes (src/provider/pcs/hyrax_pc.rs:714-729)
-static std::vector<uint8_t> commitment_bytes(const aff_t* rows, size_t n) {
-  static const char* b = "poly_commitment_begin";
-  static const char* e = "poly_commitment_end";
-  std::vector<uint8_t> v(b, b + strlen(b));
-  v.resize(v.size() + 64 * n);
-  for (size_t i = 0; i < n; ++i) point_bytes(rows[i], v.data() + strlen(b) + 64 * i);
-  v.insert(v.end(), e, e + strlen(e));
-  return v;
-}
-
-struct Tape {
-  const uint8_t* bytes;
-  size_t blocks, pos = 0;
-  fe_t next() {
-    if (pos >= blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
-    return fe_from_uniform<S>(bytes + 64 * pos++);
-  }
-  void skip(size_t n) {
-    if (pos + n > blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
-    pos += n;
-  }
-};
 
 // EqPolynomial::evals_from_points on the host for the O(sqrt N) tables of the opening (src/polys/eq.rs:59-92)
 static std::vector<fe_t> eq_evals_host(const fe_t* r, size_t ell) {
@@ -625,6 +553,7 @@ static int catch_all() {
 
 extern "C" {
 const char* ss_last_error() { return g_err.c_str(); }
+void ss_set_error(const char* msg) { g_err = msg; }
 
 static R1CSIntView make_view(size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges,
                              const int64_t* Ad, const uint32_t* Ai, const uint64_t* Ap, const int64_t* Bd, const uint32_t* Bi, const uint64_t* Bp,

@@ -280,3 +280,35 @@ def nifs_prove_core(left, right, E_eq, rhos, A, B, C, use_i64, py_hook):
                                    p64(tail))
     assert rc == 0, lib().orc_last_error()
     return dict(polys=polys, r_bs=r_bs, A=oA, B=oB, C=oC, T_out=tail[0], eq_rho_at_rb=tail[1])
+
+
+def nifs_prove(oshape, okey, comms, X, W, r_W, use_i64, tr, py_hook):
+    """oracle NeutronNovaNIFS::prove (oracle/nifs.hpp nifs_prove). oshape: OracleShape, okey: handle from orc_hyrax_setup.
+    comms (n, rows, 8), X (n, d, 4), W (n, num_vars, 4), r_W (n, rows, 4)."""
+    comms = np.ascontiguousarray(comms, dtype=np.uint64)
+    n, rows = comms.shape[0], comms.shape[1]
+    X = np.ascontiguousarray(X, dtype=np.uint64)
+    d = X.shape[1]
+    W = np.ascontiguousarray(W, dtype=np.uint64)
+    r_W = np.ascontiguousarray(r_W, dtype=np.uint64)
+    n_padded = max(2, 1 << (n - 1).bit_length())
+    ell_b = n_padded.bit_length() - 1
+    N, nv = oshape.num_cons, oshape.num_vars
+    _, left, right = tensor_decomp(N)
+    out = dict(polys=np.zeros((ell_b, 4, 4), dtype=np.uint64), r_bs=np.zeros((ell_b, 4), dtype=np.uint64), E_eq=np.zeros((left + right, 4), dtype=np.uint64),
+               A=np.zeros((N, 4), dtype=np.uint64), B=np.zeros((N, 4), dtype=np.uint64), C=np.zeros((N, 4), dtype=np.uint64), tail=np.zeros((2, 4), dtype=np.uint64),
+               folded_W=np.zeros((nv, 4), dtype=np.uint64), folded_rW=np.zeros((rows, 4), dtype=np.uint64), folded_X=np.zeros((max(d, 1), 4), dtype=np.uint64),
+               folded_comm=np.zeros((rows, 8), dtype=np.uint64))
+
+    def hook(t, coeffs):
+        r = py_hook(t, coeffs)
+        return r if r is not None else np.zeros(4, dtype=np.uint64)
+
+    cb = c_hook(hook)
+    rc = lib().orc_nifs_prove(oshape.h, okey, ctypes.c_size_t(n), ctypes.c_size_t(rows), ctypes.c_size_t(d), p64(comms.reshape(-1)), p64(X.reshape(-1)) if d else None,
+                              p64(W.reshape(-1)), p64(r_W.reshape(-1)), ctypes.c_int(1 if use_i64 else 0), tr.h, cb, None, p64(out["polys"]), p64(out["r_bs"]),
+                              p64(out["E_eq"]), p64(out["A"]), p64(out["B"]), p64(out["C"]), p64(out["tail"]), p64(out["folded_W"]), p64(out["folded_rW"]),
+                              p64(out["folded_X"]), p64(out["folded_comm"]))
+    assert rc == 0, lib().orc_last_error()
+    out["folded_X"] = out["folded_X"][:d]
+    return out

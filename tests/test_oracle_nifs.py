@@ -122,3 +122,34 @@ def test_nifs_i64_branch_equals_field_branch_and_claim_holds(n_padded, num_cons,
         T = sum(co[i] * pow(r[t], i, P) for i in range(4)) % P
         acc = acc * ((1 - r[t]) * (1 - rho[t]) + r[t] * rho[t]) % P
     assert T * pow(acc, -1, P) % P == ol.from_mont(f["T_out"]) and acc == ol.from_mont(f["eq_rho_at_rb"])
+
+
+def test_nifs_prove_whole_both_branches_agree():
+    """oracle nifs_prove (preamble + rounds + witness / instance folds) on 3 synthetic instances: both branches give the same transcript-driven
+    outputs; instance 3 is the padding clone of instance 0."""
+    from spartan2_amd import frontend
+
+    L = ol.lib()
+    okey = ctypes.c_void_p(L.orc_hyrax_setup(b"ck", ctypes.c_size_t(2048)))
+    insts = [frontend.synthetic_circuit(20, 5, num_public=2, shared_permille=0, precommitted_permille=1000, witness_seed=s) for s in (1, 2, 3)]
+    osh = ol.OracleShape(insts[0])
+    rows = osh.num_vars // 2048
+    rng = np.random.default_rng(3)
+    Ws = np.zeros((3, osh.num_vars, 4), dtype=np.uint64)
+    for k, inst in enumerate(insts):
+        Ws[k, : len(inst.witness)] = ol.mont_array([int(x) for x in inst.witness])
+    X = np.stack([ol.mont_array([int(x) for x in i.publics]) for i in insts])
+    r_W = np.stack([ol.random_field_array(rng, rows) for _ in insts])
+    comms = np.zeros((3, rows, 8), dtype=np.uint64)
+    for k in range(3):
+        assert L.orc_hyrax_commit(okey, ol.p64(Ws[k]), ctypes.c_size_t(osh.num_vars), ol.p64(r_W[k]), 1, ol.p64(comms[k])) == 0
+    outs = [ol.nifs_prove(osh, okey, comms, X, Ws, r_W, use, ol.Transcript(b"nn"), ol.transcript_round_hook(ol.Transcript(b"vc"))) for use in (False, True)]
+    for key in outs[0]:
+        assert (outs[0][key] == outs[1][key]).all(), key
+    o = outs[0]
+    assert o["polys"].shape[0] == 2
+    # folded commitment opens to the folded witness under the folded blind (no rest segment here)
+    recommit = np.zeros_like(o["folded_comm"])
+    assert L.orc_hyrax_commit(okey, ol.p64(o["folded_W"]), ctypes.c_size_t(osh.num_vars), ol.p64(o["folded_rW"]), 0, ol.p64(recommit)) == 0
+    assert (recommit == o["folded_comm"]).all()
+    L.orc_hyrax_free(okey)
