@@ -173,6 +173,21 @@ int sp_msm_ck_finish(sp_ctx* ctx, const sp_ck* ck, sp_msm_job* job, const uint64
  * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
 int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);
 
+/* ---- NeutronNova batched ZK sum-checks (src/sumcheck.rs:702-917) --------------------------------------------------------------------
+ * The reference obtains each round's challenge from the ZK verifier circuit (`SatisfyingAssignment::process_round`, :747-755, :864-872) —
+ * a commit + transcript step that stays with the caller. It enters as a callback: hook(user, round, coeffs_step, coeffs_core, ncoeffs,
+ * r_out) receives the UniPoly coefficients (degree order, ncoeffs = 3 or 4) of both branches and writes the challenge; a non-zero
+ * return aborts the sum-check with that code. */
+typedef int (*sp_round_hook)(void* user, size_t round, const uint64_t* coeffs_step, const uint64_t* coeffs_core, size_t ncoeffs, uint64_t r_out[4]);
+/* prove_quad_batched_zk (:702-782). claims = {step, core}; tables are bound in place; out_final = {A0[0], A1[0], B0[0], B1[0]} */
+int sp_sumcheck_quad_batched(sp_ctx* ctx, const uint64_t claims[8], size_t num_rounds, sp_table* A0, sp_table* A1, sp_table* B0, sp_table* B1, size_t start_round,
+                             sp_round_hook hook, void* user, uint64_t* out_r, uint64_t out_final[16]);
+/* prove_cubic_with_additive_term_batched_zk (:786-917). pow_left / pow_right = PowPolynomial::split_evals halves as tables; the step and
+ * core tables are bound in place (their element 0 holds the final claims); element 0 of pow_left receives base_tau (:913). */
+int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* ctx, size_t num_rounds, sp_table* pow_left, const sp_table* pow_right, sp_table* A_step, sp_table* B_step,
+                                        sp_table* C_step, sp_table* A_core, sp_table* B_core, sp_table* C_core, const uint64_t t_out_step[4], size_t start_round,
+                                        sp_round_hook hook, void* user, uint64_t* out_r);
+
 /* ---- NeutronNova NIFS rounds (src/neutronnova_zk.rs:511-1273, NeutronNovaNIFS::prove) ---------------------
  * The layers Az_b, Bz_b, Cz_b of the n_padded (power of two) instances live in three contiguous device arrays [layer][left*right];
  * sp_nifs_layer hands out non-owning sp_table views so sp_multiply_vec can write a layer in place (:576-596). Per round the reference

@@ -606,4 +606,48 @@ int orc_nifs_prove(void* shape, void* key, size_t n, size_t rows, size_t d, cons
   ORC_CATCH
 }
 
+// ---- batched ZK sum-check drivers (oracle/neutronnova.hpp) -----------------------------------------------------------------
+typedef void (*orc_batched_hook)(void* user, size_t round, const uint64_t* coeffs_step, const uint64_t* coeffs_core, size_t ncoeffs, uint64_t* r_out);
+static BatchedRoundHook wrap_batched(orc_batched_hook hook, void* user) {
+  return [=](size_t round, const std::vector<Fq>& cs, const std::vector<Fq>& cc) {
+    uint64_t a[16], b[16], r[4];
+    for (size_t i = 0; i < cs.size(); ++i) {
+      memcpy(a + 4 * i, cs[i].l, 32);
+      memcpy(b + 4 * i, cc[i].l, 32);
+    }
+    hook(user, round, a, b, cs.size(), r);
+    return Fq::from_raw_mont(r);
+  };
+}
+// tables: A0 | A1 | B0 | B1, each 2^num_rounds elements; out_finals: 4 F
+int orc_prove_quad_batched(const uint64_t* claims2, size_t num_rounds, const uint64_t* tables, size_t start_round, orc_batched_hook hook, void* user,
+                           uint64_t* out_r, uint64_t* out_finals) {
+  ORC_TRY
+  size_t n = (size_t)1 << num_rounds;
+  MultilinearPolynomial<Fq> A0(load<Fq>(tables, n)), A1(load<Fq>(tables + 4 * n, n)), B0(load<Fq>(tables + 8 * n, n)), B1(load<Fq>(tables + 12 * n, n));
+  Fq claims[2] = {load<Fq>(claims2, 2)[0], load<Fq>(claims2, 2)[1]};
+  std::vector<Fq> r, fin;
+  prove_quad_batched(claims, num_rounds, A0, A1, B0, B1, start_round, wrap_batched(hook, user), &r, &fin);
+  store(out_r, r);
+  store(out_finals, fin);
+  ORC_CATCH
+}
+// tables: A_step | B_step | C_step | A_core | B_core | C_core, each 2^num_rounds; out_finals: those six at index 0; out_base_tau: pow_left[0] at the end
+int orc_prove_cubic_outer_pow_batched(size_t num_rounds, const uint64_t* pow_left, size_t nleft, const uint64_t* pow_right, size_t nright, const uint64_t* tables,
+                                      const uint64_t* t_out_step, size_t start_round, orc_batched_hook hook, void* user, uint64_t* out_r, uint64_t* out_finals,
+                                      uint64_t* out_base_tau) {
+  ORC_TRY
+  size_t n = (size_t)1 << num_rounds;
+  std::vector<MultilinearPolynomial<Fq>> t;
+  for (int q = 0; q < 6; ++q) t.emplace_back(load<Fq>(tables + 4 * q * n, n));
+  MultilinearPolynomial<Fq>* step[3] = {&t[0], &t[1], &t[2]};
+  MultilinearPolynomial<Fq>* core[3] = {&t[3], &t[4], &t[5]};
+  std::vector<Fq> pl = load<Fq>(pow_left, nleft), pr = load<Fq>(pow_right, nright);
+  std::vector<Fq> r = prove_cubic_outer_pow_batched(num_rounds, pl, pr, step, core, load<Fq>(t_out_step, 1)[0], start_round, wrap_batched(hook, user));
+  store(out_r, r);
+  for (int q = 0; q < 6; ++q) memcpy(out_finals + 4 * q, t[q].Z[0].l, 32);
+  memcpy(out_base_tau, pl[0].l, 32);
+  ORC_CATCH
+}
+
 }  // extern "C"

@@ -5,11 +5,15 @@
 //   msm_shared_weights                                   src/provider/msm.rs:228-356                 (a16)
 //   HyraxPCS::fold_commitments / fold_blinds             src/provider/pcs/hyrax_pc.rs:737-818        (a20)
 //   compute_eval_points_cubic_with_additive_term[_with_outer_pow]   src/sumcheck.rs:262-498          (a6)
-// The NIFS round logic and the ZK wrapper around them (src/neutronnova_zk.rs) are not restated yet.
+//   prove_cubic_with_additive_term_batched_zk, prove_quad_batched_zk                        src/sumcheck.rs:702-917           (a6 drivers)
+// The NIFS rounds are in nifs.hpp. The ZK verifier circuit's `process_round` is a caller-supplied hook everywhere.
 #pragma once
 #include <vector>
 
+#include <functional>
+
 #include "hyrax.hpp"
+#include "sumcheck.hpp"
 
 namespace oracle {
 
@@ -105,6 +109,66 @@ inline void eval_points_cubic_outer_pow(const std::vector<Fq>& pow_left, const s
   *e0 = a0;
   *e2 = a2;
   *e3 = a3;
+}
+
+// hook(round, coeffs_step, coeffs_core) -> challenge: `process_round` of the verifier circuit (src/sumcheck.rs:747-755, :864-872)
+using BatchedRoundHook = std::function<Fq(size_t, const std::vector<Fq>&, const std::vector<Fq>&)>;
+
+// prove_quad_batched_zk (src/sumcheck.rs:702-782): returns r_y and {A0[0], A1[0], B0[0], B1[0]}
+inline void prove_quad_batched(const Fq claims[2], size_t num_rounds, MultilinearPolynomial<Fq>& A0, MultilinearPolynomial<Fq>& A1, MultilinearPolynomial<Fq>& B0,
+                               MultilinearPolynomial<Fq>& B1, size_t start_round, const BatchedRoundHook& hook, std::vector<Fq>* r_y, std::vector<Fq>* finals) {
+  Fq claim_s = claims[0], claim_c = claims[1];
+  r_y->clear();
+  for (size_t j = 0; j < num_rounds; ++j) {
+    Fq e0s, tis, e0c, tic;
+    compute_eval_points_quad(A0, B0, &e0s, &tis);
+    compute_eval_points_quad(A1, B1, &e0c, &tic);
+    UniPoly<Fq> ps = UniPoly<Fq>::from_evals({e0s, claim_s - e0s, claim_s + claim_s - (e0s + e0s + e0s) + tis + tis});
+    UniPoly<Fq> pc = UniPoly<Fq>::from_evals({e0c, claim_c - e0c, claim_c + claim_c - (e0c + e0c + e0c) + tic + tic});
+    Fq r = hook(start_round + j, ps.coeffs, pc.coeffs);
+    r_y->push_back(r);
+    A0.bind_poly_var_top(r);
+    B0.bind_poly_var_top(r);
+    A1.bind_poly_var_top(r);
+    B1.bind_poly_var_top(r);
+    claim_s = ps.evaluate(r);
+    claim_c = pc.evaluate(r);
+  }
+  *finals = {A0.Z[0], A1.Z[0], B0.Z[0], B1.Z[0]};
+}
+
+// prove_cubic_with_additive_term_batched_zk (src/sumcheck.rs:786-917). pow_left[0] receives base_tau at the end (:913).
+inline std::vector<Fq> prove_cubic_outer_pow_batched(size_t num_rounds, std::vector<Fq>& pow_left, const std::vector<Fq>& pow_right, MultilinearPolynomial<Fq>* step[3],
+                                                     MultilinearPolynomial<Fq>* core[3], const Fq& t_out_step, size_t start_round, const BatchedRoundHook& hook) {
+  Fq base_tau = Fq::one();
+  size_t len_pow_tau = pow_left.size() * pow_right.size();
+  std::vector<Fq> r_x;
+  Fq claim_s = t_out_step, claim_c = Fq::zero();
+  for (size_t i = 0; i < num_rounds; ++i) {
+    Fq es[3], ec[3];
+    eval_points_cubic_outer_pow(pow_left, pow_right, step[0]->Z, step[1]->Z, step[2]->Z, &es[0], &es[1], &es[2]);
+    eval_points_cubic_outer_pow(pow_left, pow_right, core[0]->Z, core[1]->Z, core[2]->Z, &ec[0], &ec[1], &ec[2]);
+    for (int q = 0; q < 3; ++q) {
+      es[q] = es[q] * base_tau;
+      ec[q] = ec[q] * base_tau;
+    }
+    UniPoly<Fq> ps = UniPoly<Fq>::from_evals({es[0], claim_s - es[0], es[1], es[2]});
+    UniPoly<Fq> pc = UniPoly<Fq>::from_evals({ec[0], claim_c - ec[0], ec[1], ec[2]});
+    Fq r = hook(start_round + i, ps.coeffs, pc.coeffs);
+    r_x.push_back(r);
+    claim_s = ps.evaluate(r);
+    claim_c = pc.evaluate(r);
+    for (int q = 0; q < 3; ++q) {
+      step[q]->bind_poly_var_top(r);
+      core[q]->bind_poly_var_top(r);
+    }
+    len_pow_tau >>= 1;
+    size_t left = pow_left.size();
+    Fq pw = pow_left[len_pow_tau % left] * pow_right[len_pow_tau / left];
+    base_tau = base_tau * ((pw - Fq::one()) * r + Fq::one());
+  }
+  pow_left[0] = base_tau;
+  return r_x;
 }
 
 }  // namespace oracle

@@ -475,11 +475,11 @@ int sp_eval_cubic_outer_pow(sp_ctx* c, const sp_table* pl, const sp_table* pr, c
   const bool fallback = len < left;
   size_t right = 0;
   if (fallback) {
-    if (left != 2 * len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: fallback needs a pow table as long as A");
+    if (left < 2 * len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: fallback needs a pow table at least as long as A");
   } else {
     if (left == 0 || len % left) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: len must be a multiple of the left table");
     right = len / left;
-    if (pr->len != 2 * right) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: right table must have 2 * len / left entries");
+    if (pr->len < 2 * right) return fail(SP_ERR_INVALID_INPUT_LENGTH, "eval_cubic_outer_pow: right table must have at least 2 * len / left entries");
   }
   size_t blocks = (len + 255) / 256;
   int rc = c->ensure_scratch(blocks * 3 + 32);
@@ -574,6 +574,111 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
   rc = sp_table_read(c, A, 0, 1, out_final);
   if (rc) return rc;
   return sp_table_read(c, B, 0, 1, out_final + 4);
+}
+
+// compute_eval_points_quad (src/sumcheck.rs:128-174) of the current tables -> (eval0, t_inf)
+static int eval_quad_sums(sp_ctx* c, const sp_table* A, const sp_table* B, fe_t sums[2]) {
+  const size_t chunk = 256 * spk::EVAL_PPT, half = A->len / 2;
+  sums[0] = sums[1] = fe_zero();
+  size_t len = sp::eff_pairs(A);
+  if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
+  if (half < len) len = half;
+  if (len == 0) return SP_OK;
+  size_t blocks = (len + chunk - 1) / chunk;
+  int rc = c->ensure_scratch(blocks * 2 + 64);
+  if (rc) return rc;
+  c->timed("eval_quad", 128ull * len,
+           [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch, c->d_pinned, next_seq(c)); });
+  return reduce_partials(c, blocks, 2, sums);
+}
+
+// prove_quad_batched_zk (src/sumcheck.rs:702-782): two quadratic sum-checks (step, core) driven by one challenge per round; the challenge
+// comes from the caller's `process_round` hook (:747-755).
+int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_rounds, sp_table* A0, sp_table* A1, sp_table* B0, sp_table* B1, size_t start_round,
+                             sp_round_hook hook, void* user, uint64_t* out_r, uint64_t out_final[16]) {
+  const size_t n = (size_t)1 << num_rounds;
+  if (A0->len != n || A1->len != n || B0->len != n || B1->len != n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad_batched: tables must have 2^num_rounds elements");
+  fe_t claim[2] = {load_fe(claims_), load_fe(claims_ + 4)};
+  sp_table* br[2][2] = {{A0, B0}, {A1, B1}};
+  for (size_t j = 0; j < num_rounds; ++j) {
+    UniPoly poly[2];
+    uint64_t co[2][12];
+    for (int b = 0; b < 2; ++b) {
+      fe_t sums[2];
+      int rc = eval_quad_sums(c, br[b][0], br[b][1], sums);
+      if (rc) return rc;
+      const fe_t e0 = sums[0], tinf = sums[1];
+      const fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
+      fe_t ev[3] = {e0, fe_sub<S>(claim[b], e0), fe_add<S>(fe_add<S>(fe_sub<S>(fe_add<S>(claim[b], claim[b]), three_e0), tinf), tinf)};
+      poly[b] = from_evals_deg2(ev);
+      for (int q = 0; q < 3; ++q) store_fe(co[b] + 4 * q, poly[b].c[q]);
+    }
+    uint64_t r_raw[4];
+    int hrc = hook(user, start_round + j, co[0], co[1], 3, r_raw);
+    if (hrc) return fail(hrc, "prove_quad_batched: the round hook failed");
+    const fe_t r_j = load_fe(r_raw);
+    store_fe(out_r + 4 * j, r_j);
+    sp_table* tabs[4] = {A0, B0, A1, B1};
+    int rc = launch_bind(c, tabs, 4, r_j);
+    if (rc) return rc;
+    claim[0] = poly_eval(poly[0], r_j);
+    claim[1] = poly_eval(poly[1], r_j);
+  }
+  sp_table* fin[4] = {A0, A1, B0, B1};
+  for (int q = 0; q < 4; ++q) {
+    int rc = sp_table_read(c, fin[q], 0, 1, out_final + 4 * q);
+    if (rc) return rc;
+  }
+  return SP_OK;
+}
+
+// prove_cubic_with_additive_term_batched_zk (src/sumcheck.rs:786-917): the batched NeutronNova outer sum-check over the folded step layers and the
+// core layers with the split power-of-tau table; element 0 of pow_left receives base_tau at the end (:913).
+int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* pow_left, const sp_table* pow_right, sp_table* A_step, sp_table* B_step,
+                                        sp_table* C_step, sp_table* A_core, sp_table* B_core, sp_table* C_core, const uint64_t t_out_step[4], size_t start_round,
+                                        sp_round_hook hook, void* user, uint64_t* out_r) {
+  const size_t n = (size_t)1 << num_rounds;
+  sp_table* step[3] = {A_step, B_step, C_step};
+  sp_table* core[3] = {A_core, B_core, C_core};
+  for (int q = 0; q < 3; ++q)
+    if (step[q]->len != n || core[q]->len != n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_batched: tables must have 2^num_rounds elements");
+  const size_t left = pow_left->len, right = pow_right->len;
+  if (left * right != n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_batched: pow tables must factor 2^num_rounds");
+  std::vector<fe_t> pl(left), pr(right);
+  int rc = sp_table_read(c, pow_left, 0, left, reinterpret_cast<uint64_t*>(pl.data()));
+  if (rc) return rc;
+  if ((rc = sp_table_read(c, pow_right, 0, right, reinterpret_cast<uint64_t*>(pr.data())))) return rc;
+  const fe_t one = fe_one<S>();
+  fe_t base_tau = one, claim[2] = {load_fe(t_out_step), fe_zero()};
+  size_t len_pow_tau = n;
+  for (size_t i = 0; i < num_rounds; ++i) {
+    UniPoly poly[2];
+    uint64_t co[2][16];
+    for (int b = 0; b < 2; ++b) {
+      sp_table** t = b == 0 ? step : core;
+      uint64_t raw[12];
+      if ((rc = sp_eval_cubic_outer_pow(c, pow_left, pow_right, t[0], t[1], t[2], raw))) return rc;
+      const fe_t e0 = fe_mul<S>(load_fe(raw), base_tau), e2 = fe_mul<S>(load_fe(raw + 4), base_tau), e3 = fe_mul<S>(load_fe(raw + 8), base_tau);
+      fe_t ev[4] = {e0, fe_sub<S>(claim[b], e0), e2, e3};
+      poly[b] = from_evals_deg3(ev);
+      for (int q = 0; q < 4; ++q) store_fe(co[b] + 4 * q, poly[b].c[q]);
+    }
+    uint64_t r_raw[4];
+    int hrc = hook(user, start_round + i, co[0], co[1], 4, r_raw);
+    if (hrc) return fail(hrc, "prove_cubic_batched: the round hook failed");
+    const fe_t r_i = load_fe(r_raw);
+    store_fe(out_r + 4 * i, r_i);
+    claim[0] = poly_eval(poly[0], r_i);
+    claim[1] = poly_eval(poly[1], r_i);
+    sp_table* t1[4] = {A_step, A_core, B_step, B_core};
+    sp_table* t2[2] = {C_step, C_core};
+    if ((rc = launch_bind(c, t1, 4, r_i))) return rc;
+    if ((rc = launch_bind(c, t2, 2, r_i))) return rc;
+    len_pow_tau >>= 1;
+    const fe_t pw = fe_mul<S>(pl[len_pow_tau % left], pr[len_pow_tau / left]);
+    base_tau = fe_mul<S>(base_tau, fe_add<S>(fe_mul<S>(fe_sub<S>(pw, one), r_i), one));
+  }
+  return sp_table_write(c, pow_left, 0, reinterpret_cast<const uint64_t*>(&base_tau), 1);
 }
 
 int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,

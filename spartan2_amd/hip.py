@@ -443,3 +443,43 @@ class Nifs:
             self.free()
         except Exception:
             pass
+
+
+# ---- NeutronNova batched ZK sum-checks (src/sumcheck.rs:702-917) ---------------------------------------------------------------
+ROUND_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, c_u64p, c_u64p, ctypes.c_size_t, c_u64p)
+
+
+def _round_hook(py_hook):
+    def raw(_user, rnd, cs, cc, ncoeffs, out_ptr):
+        try:
+            s = np.ctypeslib.as_array(cs, shape=(4 * ncoeffs,)).reshape(ncoeffs, 4).copy()
+            k = np.ctypeslib.as_array(cc, shape=(4 * ncoeffs,)).reshape(ncoeffs, 4).copy()
+            r = np.ascontiguousarray(py_hook(int(rnd), s, k), dtype=np.uint64).reshape(4)
+            for i in range(4):
+                out_ptr[i] = int(r[i])
+            return 0
+        except Exception:  # surfaces as SP_ERR_INTERNAL from the sum-check
+            return -5
+
+    return ROUND_HOOK(raw)
+
+
+def sumcheck_quad_batched(ctx, claims, num_rounds, A0: Table, A1: Table, B0: Table, B1: Table, start_round, py_hook):
+    """prove_quad_batched_zk (src/sumcheck.rs:702-782) -> (r_y, [A0[0], A1[0], B0[0], B1[0]])."""
+    claims = np.ascontiguousarray(claims, dtype=np.uint64).reshape(2, 4)
+    out_r = np.zeros((num_rounds, 4), dtype=np.uint64)
+    fin = np.zeros((4, 4), dtype=np.uint64)
+    cb = _round_hook(py_hook)
+    check(lib().sp_sumcheck_quad_batched(ctx.h, p64(claims), ctypes.c_size_t(num_rounds), A0.h, A1.h, B0.h, B1.h, ctypes.c_size_t(start_round), cb, None, p64(out_r),
+                                         p64(fin)))
+    return out_r, fin
+
+
+def sumcheck_cubic_outer_pow_batched(ctx, num_rounds, pow_left: Table, pow_right: Table, step, core, t_out_step, start_round, py_hook):
+    """prove_cubic_with_additive_term_batched_zk (src/sumcheck.rs:786-917); step / core = (A, B, C) tables -> r_x."""
+    out_r = np.zeros((num_rounds, 4), dtype=np.uint64)
+    cb = _round_hook(py_hook)
+    t = np.ascontiguousarray(t_out_step, dtype=np.uint64).reshape(4)
+    check(lib().sp_sumcheck_cubic_outer_pow_batched(ctx.h, ctypes.c_size_t(num_rounds), pow_left.h, pow_right.h, step[0].h, step[1].h, step[2].h, core[0].h, core[1].h,
+                                                    core[2].h, p64(t), ctypes.c_size_t(start_round), cb, None, p64(out_r)))
+    return out_r

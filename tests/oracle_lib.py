@@ -312,3 +312,54 @@ def nifs_prove(oshape, okey, comms, X, W, r_W, use_i64, tr, py_hook):
     assert rc == 0, lib().orc_last_error()
     out["folded_X"] = out["folded_X"][:d]
     return out
+
+
+# ---- batched ZK sum-check drivers (oracle/neutronnova.hpp) ---------------------------------------------------------------------
+BATCHED_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, c_u64p, c_u64p, ctypes.c_size_t, c_u64p)
+
+
+def batched_transcript_hook(tr):
+    """Stand-in for the verifier circuit's process_round: absorb both branches' coefficients, squeeze the challenge."""
+
+    def hook(rnd, cs, cc):
+        for row in list(cs) + list(cc):
+            tr.absorb_scalar(b"p", row)
+        return tr.squeeze(b"c")
+
+    return hook
+
+
+def _c_batched(py_hook):
+    def raw(_user, rnd, cs, cc, ncoeffs, out_ptr):
+        s = np.ctypeslib.as_array(cs, shape=(4 * ncoeffs,)).reshape(ncoeffs, 4).copy()
+        k = np.ctypeslib.as_array(cc, shape=(4 * ncoeffs,)).reshape(ncoeffs, 4).copy()
+        r = np.ascontiguousarray(py_hook(int(rnd), s, k), dtype=np.uint64)
+        for i in range(4):
+            out_ptr[i] = int(r[i])
+
+    return BATCHED_HOOK(raw)
+
+
+def prove_quad_batched(claims, num_rounds, A0, A1, B0, B1, start_round, py_hook):
+    tables = np.ascontiguousarray(np.concatenate([A0, A1, B0, B1]), dtype=np.uint64)
+    out_r = np.zeros((num_rounds, 4), dtype=np.uint64)
+    fin = np.zeros((4, 4), dtype=np.uint64)
+    cb = _c_batched(py_hook)
+    rc = lib().orc_prove_quad_batched(p64(np.ascontiguousarray(claims, dtype=np.uint64).reshape(2, 4)), ctypes.c_size_t(num_rounds), p64(tables),
+                                      ctypes.c_size_t(start_round), cb, None, p64(out_r), p64(fin))
+    assert rc == 0, lib().orc_last_error()
+    return out_r, fin
+
+
+def prove_cubic_outer_pow_batched(num_rounds, pow_left, pow_right, step, core, t_out_step, start_round, py_hook):
+    tables = np.ascontiguousarray(np.concatenate(list(step) + list(core)), dtype=np.uint64)
+    out_r = np.zeros((num_rounds, 4), dtype=np.uint64)
+    fin = np.zeros((6, 4), dtype=np.uint64)
+    base = np.zeros(4, dtype=np.uint64)
+    cb = _c_batched(py_hook)
+    pl, pr = np.ascontiguousarray(pow_left, dtype=np.uint64), np.ascontiguousarray(pow_right, dtype=np.uint64)
+    rc = lib().orc_prove_cubic_outer_pow_batched(ctypes.c_size_t(num_rounds), p64(pl), ctypes.c_size_t(pl.shape[0]), p64(pr), ctypes.c_size_t(pr.shape[0]), p64(tables),
+                                                 p64(np.ascontiguousarray(t_out_step, dtype=np.uint64)), ctypes.c_size_t(start_round), cb, None, p64(out_r), p64(fin),
+                                                 p64(base))
+    assert rc == 0, lib().orc_last_error()
+    return out_r, fin, base
