@@ -1,6 +1,7 @@
 // C ABI of the NeutronNova NIFS data path (include/spartan_hip.h, "NeutronNova NIFS rounds"): device-resident instance layers, the per-round
 // (e0, quad) sums with the fold of the previous round merged in, the O(1) `finish_round!` algebra on the host side of the library.
 // Reference: src/neutronnova_zk.rs:511-1273. gfx950 only; no CPU fallback.
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -185,11 +186,9 @@ int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t
     const fe_t* src[3] = {n->A[0], n->B[0], n->C};
     long long* dst[3] = {n->A64, n->B64, n->C64};
     for (int q = 0; q < 3; ++q)
-      for (size_t b = 0; b < np; ++b)
-        c->timed("nifs_to_small", 40ull * n->total, [&] {
-          hipLaunchKernelGGL(spk::k_to_small, dim3(blocks), dim3(256), 0, c->stream, src[q] + b * n->total, (unsigned long long)n->total, dst[q] + b * n->total,
-                             n->d_flags);
-        });
+      c->timed("nifs_to_small", 40ull * n->total * np, [&] {
+        hipLaunchKernelGGL(spk::k_to_small, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, src[q], (unsigned long long)n->total, dst[q], n->d_flags);
+      });
     std::vector<unsigned char> flags(n->total);
     SP_HIP(hipMemcpyAsync(flags.data(), n->d_flags, n->total, hipMemcpyDeviceToHost, c->stream));
     SP_HIP(hipStreamSynchronize(c->stream));
@@ -206,12 +205,15 @@ int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t
   }
   // c_vals (:652-703)
   n->c_vals.assign(np, fe_zero());
+  // small kernels: a block owns 256 * ppt consecutive k (within one x_out when factored)
+  const int ppt = n->factored ? (int)std::min<size_t>(8, n->left / 256) : 1;
+  const unsigned sblocks = (unsigned)((n->total + 256 * ppt - 1) / (256 * ppt));
   if (n->small) {
     c->timed("nifs_cvals", 8ull * np * n->total, [&] {
       if (n->factored)
-        hipLaunchKernelGGL(spk::k_nifs_cvals_small<true>, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, n->C64, g, n->d_part);
+        hipLaunchKernelGGL(spk::k_nifs_cvals_small<true>, dim3(sblocks, (unsigned)np), dim3(256), 0, c->stream, n->C64, g, n->d_part, ppt);
       else
-        hipLaunchKernelGGL(spk::k_nifs_cvals_small<false>, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, n->C64, g, n->d_part);
+        hipLaunchKernelGGL(spk::k_nifs_cvals_small<false>, dim3(sblocks, (unsigned)np), dim3(256), 0, c->stream, n->C64, g, n->d_part, ppt);
     });
   } else {
     c->timed("nifs_cvals", 32ull * np * n->total, [&] {
@@ -221,7 +223,7 @@ int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t
         hipLaunchKernelGGL(spk::k_nifs_cvals<false>, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, n->C, g, n->d_part);
     });
   }
-  int rc = sum_partials<1>(n, np, blocks, n->c_vals.data());
+  int rc = sum_partials<1>(n, np, n->small ? sblocks : blocks, n->c_vals.data());
   if (rc) return rc;
   if (n->small && n->nlarge) {
     const unsigned lb = (n->nlarge + 255) / 256;
@@ -245,13 +247,15 @@ int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]) {
     if ((rc = upload_weights(n, 0, pairs))) return rc;
     fe_t q[1];
     if (n->small) {
+      const int ppt = n->factored ? (int)std::min<size_t>(8, n->left / 256) : 1;
+      const unsigned sblocks = (unsigned)((n->total + 256 * ppt - 1) / (256 * ppt));
       c->timed("nifs_round0_small", 32ull * pairs * n->total, [&] {
         if (n->factored)
-          hipLaunchKernelGGL(spk::k_nifs_round0_small<true>, dim3(blocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w, n->d_part);
+          hipLaunchKernelGGL(spk::k_nifs_round0_small<true>, dim3(sblocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w, n->d_part, ppt);
         else
-          hipLaunchKernelGGL(spk::k_nifs_round0_small<false>, dim3(blocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w, n->d_part);
+          hipLaunchKernelGGL(spk::k_nifs_round0_small<false>, dim3(sblocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w, n->d_part, ppt);
       });
-      if ((rc = sum_partials<1>(n, 1, (size_t)blocks * pairs, q))) return rc;
+      if ((rc = sum_partials<1>(n, 1, (size_t)sblocks * pairs, q))) return rc;
       quad = q[0];
       if (n->nlarge) {
         const unsigned lb = (n->nlarge + 255) / 256;

@@ -146,9 +146,12 @@ constexpr unsigned long long SMALL_VALUE_MAX = (1ull << 62) - 1;  // small_value
 
 // to_small_vec_or_zero (small_value.rs:41-86): i64 image of each element, 0 + flag when neither v nor p - v is <= 2^62 - 1.
 // `flags` is OR-ed into (callers accumulate the union over several tables, :1548-1572).
+// blockIdx.y = layer: layer b reads in[b * n + i], writes out[b * n + i], and ORs into the SAME flags[i] (one launch for all instances).
 __global__ void __launch_bounds__(256) k_to_small(const fe_t* __restrict__ in, unsigned long long n, long long* __restrict__ out, unsigned char* __restrict__ flags) {
   const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  in += (unsigned long long)blockIdx.y * n;
+  out += (unsigned long long)blockIdx.y * n;
   const fe_t c = fe_to_canonical<S>(in[i]);
   const unsigned long long lo = (unsigned long long)c.v[0] | ((unsigned long long)c.v[1] << 32);
   long long r = 0;
@@ -242,27 +245,33 @@ __device__ __forceinline__ lazy13_t lazy13_block_sum(lazy13_t a, lazy13_t* smem)
 __device__ __forceinline__ unsigned long long abs64(long long v) { return v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v; }
 
 // Round 0 from the i64 mirrors (prove_helper_small, :255-320): 32 B read per k and pair instead of 128 B, no modular product in the loop.
+// A block owns 256 * ppt consecutive k (ppt <= left / 256 when FACTORED, so they share x_out): the 13-word cross-lane reduction, which costs more
+// than the 32-mad product itself, is paid once per ppt terms.
 template <bool FACTORED>
 __global__ void __launch_bounds__(256) k_nifs_round0_small(const long long* __restrict__ A, const long long* __restrict__ B, NifsGeom g,
-                                                           const fe_t* __restrict__ w, fe_t* __restrict__ partials) {
+                                                           const fe_t* __restrict__ w, fe_t* __restrict__ partials, int ppt) {
   __shared__ lazy13_t smem[4];
-  const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long base = (unsigned long long)blockIdx.x * 256 * ppt;
   const unsigned long long p = blockIdx.y;
   lazy13_t acc = lazy13_zero();
-  if (k < g.total) {
-    const long long da = A[(2 * p + 1) * g.total + k] - A[(2 * p) * g.total + k];
-    const long long db = B[(2 * p + 1) * g.total + k] - B[(2 * p) * g.total + k];
-    if (da != 0 && db != 0) {
-      const unsigned long long ua = abs64(da), ub = abs64(db);
-      fe_t e = nifs_e(g, k, FACTORED);
-      if ((da < 0) != (db < 0)) e = fe_neg<S>(e);
-      acc = mul_small(e, ua * ub, __umul64hi(ua, ub));
+#pragma unroll 1
+  for (int q = 0; q < ppt; ++q) {
+    const unsigned long long k = base + (unsigned long long)q * 256 + threadIdx.x;
+    if (k < g.total) {
+      const long long da = A[(2 * p + 1) * g.total + k] - A[(2 * p) * g.total + k];
+      const long long db = B[(2 * p + 1) * g.total + k] - B[(2 * p) * g.total + k];
+      if (da != 0 && db != 0) {
+        const unsigned long long ua = abs64(da), ub = abs64(db);
+        fe_t e = nifs_e(g, k, FACTORED);
+        if ((da < 0) != (db < 0)) e = fe_neg<S>(e);
+        acc = lazy13_add(acc, mul_small(e, ua * ub, __umul64hi(ua, ub)));
+      }
     }
   }
   acc = lazy13_block_sum(acc, smem);
   if (threadIdx.x == 0) {
     fe_t s = lazy13_reduce(acc);
-    if (FACTORED) s = fe_mul<S>(s, g.f[((unsigned long long)blockIdx.x * 256) >> g.left_log2]);
+    if (FACTORED) s = fe_mul<S>(s, g.f[base >> g.left_log2]);
     partials[p * gridDim.x + blockIdx.x] = fe_mul<S>(s, w[p]);
   }
 }
@@ -284,23 +293,27 @@ __global__ void __launch_bounds__(256) k_nifs_round0_large(const fe_t* __restric
 }
 // c_vals from the i64 mirror of C (:652-676) — the large positions are added by k_nifs_cvals_large
 template <bool FACTORED>
-__global__ void __launch_bounds__(256) k_nifs_cvals_small(const long long* __restrict__ C, NifsGeom g, fe_t* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_nifs_cvals_small(const long long* __restrict__ C, NifsGeom g, fe_t* __restrict__ partials, int ppt) {
   __shared__ lazy13_t smem[4];
-  const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long base = (unsigned long long)blockIdx.x * 256 * ppt;
   const unsigned long long b = blockIdx.y;
   lazy13_t acc = lazy13_zero();
-  if (k < g.total) {
-    const long long c = C[b * g.total + k];
-    if (c != 0) {
-      fe_t e = nifs_e(g, k, FACTORED);
-      if (c < 0) e = fe_neg<S>(e);
-      acc = mul_small(e, abs64(c), 0);
+#pragma unroll 1
+  for (int q = 0; q < ppt; ++q) {
+    const unsigned long long k = base + (unsigned long long)q * 256 + threadIdx.x;
+    if (k < g.total) {
+      const long long c = C[b * g.total + k];
+      if (c != 0) {
+        fe_t e = nifs_e(g, k, FACTORED);
+        if (c < 0) e = fe_neg<S>(e);
+        acc = lazy13_add(acc, mul_small(e, abs64(c), 0));
+      }
     }
   }
   acc = lazy13_block_sum(acc, smem);
   if (threadIdx.x == 0) {
     fe_t s = lazy13_reduce(acc);
-    if (FACTORED) s = fe_mul<S>(s, g.f[((unsigned long long)blockIdx.x * 256) >> g.left_log2]);
+    if (FACTORED) s = fe_mul<S>(s, g.f[base >> g.left_log2]);
     partials[b * gridDim.x + blockIdx.x] = s;
   }
 }
