@@ -3,6 +3,8 @@
 // finishes the O(1) part (claim-derived evaluations, UniPoly, Keccak transcript), and the challenge goes back
 // as a kernel argument of the bind (K1).
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -291,6 +293,50 @@ static int reduce_partials(sp_ctx* c, size_t nblocks, int nacc, fe_t* out_host) 
   return reduce_partials_wait(c, nacc, out_host);
 }
 
+// SPARTAN_ROUND_TRACE=1: per-round host timeline of the sum-check loops on stderr (wait = result not yet visible, host = finish + transcript)
+static bool round_trace() {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_ROUND_TRACE");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- persistent tail (kernels_poly.cuh k_sumcheck_tail): host half of the mailbox ------------------------------------------------------
+static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident tail, 2..11 caps the table length it takes over
+  static const size_t v = [] {
+    const char* e = getenv("SPARTAN_TAIL_LOG2");
+    size_t lg = e ? (size_t)atoi(e) : 11;
+    if (lg > 11) lg = 11;
+    return lg < 2 ? (size_t)0 : (size_t)1 << lg;
+  }();
+  return v;
+}
+#define TAIL_MAX_LEN tail_max_len()
+static bool tail_enabled() { return tail_max_len() != 0; }
+// mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 = check word
+// (sequence + sum of the challenge words) so a poll that straddles the host's stores is recognised and retried.
+static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) {
+  volatile uint32_t* dst = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_CHAL_ELEM);
+  uint32_t chk = answers_seq;
+  for (int i = 0; i < 8; ++i) {
+    dst[i] = r.v[i];
+    chk += r.v[i];
+  }
+  dst[9] = chk;
+  std::atomic_thread_fence(std::memory_order_release);
+  dst[8] = answers_seq;
+}
+static int tail_check(sp_ctx* c) {
+  volatile uint32_t* err = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM);
+  if (*err) {
+    *err = 0;
+    return fail(SP_ERR_INTERNAL, "sum-check tail kernel timed out waiting for a challenge");
+  }
+  return SP_OK;
+}
+
 // ---- host-side O(1) glue: UniPoly (src/polys/univariate.rs) ----------------------------------------------------------
 namespace {
 struct UniPoly {
@@ -511,9 +557,11 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
   int rc = c->ensure_scratch((A->len / 2 + chunk - 1) / chunk * 2 + (A->len / 4 / 64) * 3 + 64);  // block partials or 72-byte lazy wave partials
   if (rc) return rc;
   bool have_sums = false;  // true when the previous fused launch already produced this round's sums
+  bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
   size_t pending_blocks = 0;
   for (size_t round = 0; round < rounds; ++round) {
     const size_t half = A->len / 2;
+    const double tr0 = round_trace() ? now_us() : 0;
     fe_t sums[2] = {fe_zero(), fe_zero()};
     if (!have_sums) {  // compute_eval_points_quad on the current tables (src/sumcheck.rs:128-174)
       size_t len = sp::eff_pairs(A);
@@ -531,6 +579,7 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       if (rc) return rc;
     }
     (void)pending_blocks;
+    const double tr1 = round_trace() ? now_us() : 0;
     // BDDT: eval_2 = 2 claim - 3 eval_0 + 2 t_inf (src/sumcheck.rs:211-215)
     fe_t e0 = sums[0], tinf = sums[1];
     fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
@@ -546,7 +595,30 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
     claim = poly_eval(poly, r_i);
     sp_table* tabs[2] = {A, B};
     have_sums = false;
-    if (round + 1 < rounds && table_dense(A) && table_dense(B)) {
+    if (in_tail) {  // the resident kernel binds (and evaluates the next round) as soon as it sees the challenge
+      tail_post_challenge(c, r_i, c->result_seq);
+      if (round + 1 < rounds) {
+        next_seq(c);
+        have_sums = true;
+      }
+      sp::after_bind(A);
+      sp::after_bind(B);
+    } else if (tail_enabled() && round + 1 < rounds && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B)) {
+      spk::TailArgs ta;
+      ta.A = A->d;
+      ta.B = B->d;
+      ta.C = nullptr;
+      ta.len = A->len;
+      ta.r0 = r_i;
+      ta.eq_pyr = nullptr;
+      ta.mapped = c->d_pinned;
+      ta.seq0 = next_seq(c);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(1), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      in_tail = true;
+      have_sums = true;
+      sp::after_bind(A);
+      sp::after_bind(B);
+    } else if (round + 1 < rounds && table_dense(A) && table_dense(B)) {
       // fused: bind this round, evaluate the next (K1 + K3 in one pass over the tables)
       const size_t q = A->len / 4;
       size_t blocks = (q + chunk - 1) / chunk;
@@ -570,10 +642,13 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       rc = launch_bind(c, tabs, 2, r_i);
       if (rc) return rc;
     }
+    if (round_trace()) fprintf(stderr, "quad round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", round, A->len * 2, (int)in_tail, tr1 - tr0, now_us() - tr1);
   }
   rc = sp_table_read(c, A, 0, 1, out_final);
   if (rc) return rc;
-  return sp_table_read(c, B, 0, 1, out_final + 4);
+  rc = sp_table_read(c, B, 0, 1, out_final + 4);
+  if (rc) return rc;
+  return in_tail ? tail_check(c) : SP_OK;
 }
 
 // compute_eval_points_quad (src/sumcheck.rs:128-174) of the current tables -> (eval0, t_inf)
@@ -753,6 +828,7 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   };
 
   fe_t claim = load_fe(claim_);
+  bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
   fe_t eval_eq_left = fe_one<S>();
   const fe_t one = fe_one<S>();
   const uint8_t lbl_c[1] = {'c'};
@@ -772,14 +848,19 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
     const fe_t l_0_p = fe_mul<S>(eq0, p);
     const fe_t l_1_p = fe_mul<S>(fe_add<S>(eq0, slope), p);
     const bool invertible = !fe_is_zero(l_1_p);
-    const fe_t l_1_p_inv = invertible ? fe_inv<S>(l_1_p) : fe_zero();
+    const fe_t l_1_p_inv = invertible ? fe_inv<S>(l_1_p) : fe_zero();  // runs while the device computes this round's sums
     fe_t sums[3];
-    rc = reduce_partials_wait(c, 2, sums);
+    rc = reduce_partials_wait(c, in_tail ? 3 : 2, sums);
     if (rc) return rc;
     const fe_t t0 = sums[0], tinf = sums[1];
     // derive_from_claim (:1276-1324)
     fe_t s_0, s_1, s_leading, s_m1;
-    if (invertible) {
+    if (in_tail && !invertible) {  // fallback_three_inputs (:1327-1396): the resident tail kernel always delivers t(-1) as its third sum
+      s_0 = fe_mul<S>(fe_mul<S>(eq0, p), t0);
+      s_1 = fe_sub<S>(claim, s_0);
+      s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
+      s_m1 = fe_mul<S>(fe_mul<S>(eqm1, p), sums[2]);
+    } else if (invertible) {
       s_0 = fe_mul<S>(l_0_p, t0);
       s_1 = fe_sub<S>(claim, s_0);
       const fe_t t_1 = fe_mul<S>(s_1, l_1_p_inv);
@@ -817,7 +898,28 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
     store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
     store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
     claim = poly_eval(poly, r_i);
-    if (rnd < ell) {
+    if (in_tail) {
+      tail_post_challenge(c, r_i, c->result_seq);
+      if (rnd < ell) next_seq(c);
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+    } else if (tail_enabled() && rnd < ell && A->len <= TAIL_MAX_LEN && rnd + 1 >= first_half) {
+      spk::TailArgs ta;
+      ta.A = A->d;
+      ta.B = B->d;
+      ta.C = C->d;
+      ta.len = A->len;
+      ta.r0 = r_i;
+      ta.eq_pyr = d_pr;
+      ta.mapped = c->d_pinned;
+      ta.seq0 = next_seq(c);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(1), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      in_tail = true;
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+    } else if (rnd < ell) {
       // K1 fused with next round's K2: bind with r_i, evaluate round rnd+1 from registers
       const size_t q = A->len / 4;
       const EqSel e = select_eq(rnd + 1);
@@ -858,7 +960,9 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   if (rc) return rc;
   rc = sp_table_read(c, B, 0, 1, out_final + 4);
   if (rc) return rc;
-  return sp_table_read(c, C, 0, 1, out_final + 8);
+  rc = sp_table_read(c, C, 0, 1, out_final + 8);
+  if (rc) return rc;
+  return in_tail ? tail_check(c) : SP_OK;
 }
 
 }  // extern "C"

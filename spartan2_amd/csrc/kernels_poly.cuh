@@ -396,4 +396,141 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
   if (threadIdx.x == 0) publish_result(out, seq);
 }
 
+// ---- persistent tail of a sum-check: the last log2(len) rounds in ONE single-block launch ---------------------------------------------
+// Below ~2^11 elements a round is pure latency: kernel launch + second-stage launch + host wake-up cost more than the arithmetic. This kernel
+// stays resident for all remaining rounds: per round it binds with the challenge, evaluates the next round from registers, publishes the
+// sums to mapped pinned host memory (publish_result) and then POLLS a mapped host slot for the next challenge, which the host writes after
+// its transcript step. Cubic mode also delivers the third sum t(-1) (fallback_three_inputs, src/sumcheck.rs:1327-1396): the host uses it only
+// when tau * p is not invertible, otherwise it derives the evaluations from the claim exactly as the reference does (:1276-1324).
+// Slots in the mapped buffer: TAIL_CHAL_ELEM = the 64-byte mailbox line (challenge | sequence | check word), word 0 of TAIL_ERR_ELEM = error.
+constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10;
+constexpr int TAIL_THREADS = 512;
+struct TailArgs {
+  fe_t *A, *B, *C;          // C unused in quadratic mode
+  unsigned long long len;   // table length at entry, power of two, 2 <= len <= 4 * TAIL_THREADS
+  fe_t r0;                  // challenge of the round whose sums were produced before the launch
+  const fe_t* eq_pyr;       // cubic: single-table eq pyramid (second-half rounds); level(log2(pairs)) is the table of a round with `pairs` pairs
+  fe_t* mapped;             // device address of the mapped pinned buffer (results at [0..3), flag at RESULT_FLAG_ELEM)
+  unsigned seq0;            // sequence number of the first result this kernel publishes
+};
+// Lanes 0..9 of wave 0 each read one word of the mailbox line (8 challenge words, the sequence word, a check word = sequence + sum of the
+// challenge words) in the SAME instruction, so a poll is one PCIe round trip; a poll that straddles the host's stores fails the check and
+// is simply repeated.
+__device__ __forceinline__ bool tail_wait_challenge(fe_t* mapped, unsigned want, fe_t* r_smem) {
+  __shared__ int ok;
+  if (threadIdx.x < 64) {
+    const unsigned* base = reinterpret_cast<const unsigned*>(mapped + TAIL_CHAL_ELEM);
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    int good = 0;
+    unsigned w = 0;
+    while (true) {
+      if (lane < 10) w = __hip_atomic_load(base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned flag = __shfl(w, 8, 64), chk = __shfl(w, 9, 64);
+      if (flag == want) {
+        unsigned sum = lane < 8 ? w : 0u;
+#pragma unroll
+        for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+        sum = __shfl(sum, 0, 64) + flag;
+        if (sum == chk) {
+          good = 1;
+          break;
+        }
+      }
+      if (wall_clock64() - t0 > 200000000ull) break;  // 2 s at 100 MHz: the host went away; never hang the device
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (good) {
+      if (lane < 8) r_smem->v[lane] = w;
+    } else if (lane == 0) {
+      __hip_atomic_store(reinterpret_cast<unsigned*>(mapped + TAIL_ERR_ELEM), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane == 0) ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+template <int NACC>
+__device__ __forceinline__ void tail_block_sum(fe_t (&acc)[NACC], fe_t* smem /* NACC * 8 */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) smem[k * 8 + wave] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      fe_t s = smem[k * 8];
+      for (int w = 1; w < TAIL_THREADS / 64; ++w) s = fe_add<S>(s, smem[k * 8 + w]);
+      acc[k] = s;
+    }
+  }
+}
+template <bool CUBIC>
+__global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
+  constexpr int NACC = CUBIC ? 3 : 2;
+  __shared__ fe_t smem[NACC * 8];
+  __shared__ fe_t r_sh;
+  unsigned long long len = a.len;
+  unsigned seq = a.seq0;
+  fe_t r = a.r0;
+  bool first = true;
+  while (true) {
+    if (!first) {
+      if (!tail_wait_challenge(a.mapped, seq - 1, &r_sh)) return;
+      r = r_sh;
+    }
+    first = false;
+    if (len == 2) {  // last round: bind only
+      if (threadIdx.x == 0) {
+        a.A[0] = bind1(a.A[0], a.A[1], r);
+        a.B[0] = bind1(a.B[0], a.B[1], r);
+        if (CUBIC) a.C[0] = bind1(a.C[0], a.C[1], r);
+      }
+      return;
+    }
+    const unsigned long long q = len / 4;
+    int lq = 0;
+    while ((1ull << lq) < q) ++lq;
+    const fe_t* eq_in = CUBIC ? a.eq_pyr + eq_level_offset(lq) : nullptr;
+    fe_t acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = fe_zero();
+    const unsigned long long id = threadIdx.x;
+    if (id < q) {
+      const fe_t a0 = bind1(a.A[id], a.A[id + 2 * q], r), a1 = bind1(a.A[id + q], a.A[id + 3 * q], r);
+      const fe_t b0 = bind1(a.B[id], a.B[id + 2 * q], r), b1 = bind1(a.B[id + q], a.B[id + 3 * q], r);
+      a.A[id] = a0;
+      a.A[id + q] = a1;
+      a.B[id] = b0;
+      a.B[id + q] = b1;
+      if (CUBIC) {
+        const fe_t c0 = bind1(a.C[id], a.C[id + 2 * q], r), c1 = bind1(a.C[id + q], a.C[id + 3 * q], r);
+        a.C[id] = c0;
+        a.C[id + q] = c1;
+        const fe_t w = eq_in[id];
+        acc[0] = fe_mul<S>(w, fe_sub<S>(fe_mul<S>(a0, b0), c0));
+        acc[1] = fe_mul<S>(w, fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)));
+        const fe_t ma = fe_sub<S>(fe_dbl<S>(a0), a1), mb = fe_sub<S>(fe_dbl<S>(b0), b1), mc = fe_sub<S>(fe_dbl<S>(c0), c1);
+        acc[2] = fe_mul<S>(w, fe_sub<S>(fe_mul<S>(ma, mb), mc));
+      } else {
+        acc[0] = fe_mul<S>(a0, b0);
+        acc[1] = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+      }
+    }
+    tail_block_sum<NACC>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) a.mapped[k] = acc[k];
+      publish_result(a.mapped, seq);
+    }
+    ++seq;
+    len /= 2;
+    __syncthreads();  // smem reuse + table writes visible to the whole block before the next round reads them
+  }
+}
+
 }  // namespace spk
