@@ -307,8 +307,8 @@ static double now_us() { return std::chrono::duration<double, std::micro>(std::c
 static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident tail, 2..11 caps the table length it takes over
   static const size_t v = [] {
     const char* e = getenv("SPARTAN_TAIL_LOG2");
-    size_t lg = e ? (size_t)atoi(e) : 11;
-    if (lg > 11) lg = 11;
+    size_t lg = e ? (size_t)atoi(e) : 10;
+    if (lg > 12) lg = 12;
     return lg < 2 ? (size_t)0 : (size_t)1 << lg;
   }();
   return v;

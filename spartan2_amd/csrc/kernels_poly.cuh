@@ -404,7 +404,8 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
 // when tau * p is not invertible, otherwise it derives the evaluations from the claim exactly as the reference does (:1276-1324).
 // Slots in the mapped buffer: TAIL_CHAL_ELEM = the 64-byte mailbox line (challenge | sequence | check word), word 0 of TAIL_ERR_ELEM = error.
 constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10;
-constexpr int TAIL_THREADS = 512;
+constexpr int TAIL_THREADS = 1024;
+constexpr unsigned long long TAIL_WIDE_Q = 256;  // rounds with at most this many pairs use one lane per product (3 * 256 <= TAIL_THREADS)
 struct TailArgs {
   fe_t *A, *B, *C;          // C unused in quadratic mode
   unsigned long long len;   // table length at entry, power of two, 2 <= len <= 4 * TAIL_THREADS
@@ -451,20 +452,20 @@ __device__ __forceinline__ bool tail_wait_challenge(fe_t* mapped, unsigned want,
   return ok != 0;
 }
 template <int NACC>
-__device__ __forceinline__ void tail_block_sum(fe_t (&acc)[NACC], fe_t* smem /* NACC * 8 */) {
+__device__ __forceinline__ void tail_block_sum(fe_t (&acc)[NACC], fe_t* smem /* NACC * 16 */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = wave_sum(acc[k]);
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) smem[k * 8 + wave] = acc[k];
+    for (int k = 0; k < NACC; ++k) smem[k * 16 + wave] = acc[k];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
-      fe_t s = smem[k * 8];
-      for (int w = 1; w < TAIL_THREADS / 64; ++w) s = fe_add<S>(s, smem[k * 8 + w]);
+      fe_t s = smem[k * 16];
+      for (int w = 1; w < TAIL_THREADS / 64; ++w) s = fe_add<S>(s, smem[k * 16 + w]);
       acc[k] = s;
     }
   }
@@ -472,7 +473,7 @@ __device__ __forceinline__ void tail_block_sum(fe_t (&acc)[NACC], fe_t* smem /* 
 template <bool CUBIC>
 __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   constexpr int NACC = CUBIC ? 3 : 2;
-  __shared__ fe_t smem[NACC * 8];
+  __shared__ fe_t smem[NACC * 16];
   __shared__ fe_t r_sh;
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
@@ -496,36 +497,82 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     int lq = 0;
     while ((1ull << lq) < q) ++lq;
     const fe_t* eq_in = CUBIC ? a.eq_pyr + eq_level_offset(lq) : nullptr;
-    fe_t acc[NACC];
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] = fe_zero();
-    const unsigned long long id = threadIdx.x;
-    if (id < q) {
-      const fe_t a0 = bind1(a.A[id], a.A[id + 2 * q], r), a1 = bind1(a.A[id + q], a.A[id + 3 * q], r);
-      const fe_t b0 = bind1(a.B[id], a.B[id + 2 * q], r), b1 = bind1(a.B[id + q], a.B[id + 3 * q], r);
-      a.A[id] = a0;
-      a.A[id + q] = a1;
-      a.B[id] = b0;
-      a.B[id + q] = b1;
-      if (CUBIC) {
-        const fe_t c0 = bind1(a.C[id], a.C[id + 2 * q], r), c1 = bind1(a.C[id + q], a.C[id + 3 * q], r);
-        a.C[id] = c0;
-        a.C[id + q] = c1;
-        const fe_t w = eq_in[id];
-        acc[0] = fe_mul<S>(w, fe_sub<S>(fe_mul<S>(a0, b0), c0));
-        acc[1] = fe_mul<S>(w, fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)));
-        const fe_t ma = fe_sub<S>(fe_dbl<S>(a0), a1), mb = fe_sub<S>(fe_dbl<S>(b0), b1), mc = fe_sub<S>(fe_dbl<S>(c0), c1);
-        acc[2] = fe_mul<S>(w, fe_sub<S>(fe_mul<S>(ma, mb), mc));
-      } else {
-        acc[0] = fe_mul<S>(a0, b0);
-        acc[1] = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+    if (q <= TAIL_WIDE_Q) {
+      // Wide form for the smallest rounds: a lone lane issues one 256-bit product in ~0.8 us, so the per-pair form (6-13 products in a row per
+      // lane) is pure issue latency. Here every product gets its own lane: phase A binds one element per lane, phase B forms one (sum, pair)
+      // product per lane — two to three dependent products per round instead of a dozen.
+      const unsigned nt = CUBIC ? 3 : 2;
+      const unsigned long long half = 2 * q;  // new table length
+      for (unsigned long long idx = threadIdx.x; idx < nt * half; idx += TAIL_THREADS) {
+        fe_t* Z = idx < half ? a.A : (idx < 2 * half ? a.B : a.C);
+        const unsigned long long x = idx % half;
+        Z[x] = bind1(Z[x], Z[x + half], r);
       }
-    }
-    tail_block_sum<NACC>(acc, smem);
-    if (threadIdx.x == 0) {
+      __syncthreads();
+      const unsigned seg = q < 64 ? 64u : (unsigned)q;  // keep `which` wave-uniform
+      const unsigned which = threadIdx.x / seg, id = threadIdx.x % seg;
+      fe_t v = fe_zero();
+      if (which < (unsigned)NACC && id < q) {
+        const fe_t a0 = a.A[id], a1 = a.A[id + q], b0 = a.B[id], b1 = a.B[id + q];
+        if (which == 0) v = fe_mul<S>(a0, b0);
+        else if (which == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+        else v = fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1));
+        if (CUBIC) {
+          const fe_t c0 = a.C[id], c1 = a.C[id + q];
+          if (which == 0) v = fe_sub<S>(v, c0);
+          else if (which == 2) v = fe_sub<S>(v, fe_sub<S>(fe_dbl<S>(c0), c1));
+          v = fe_mul<S>(eq_in[id], v);
+        }
+      }
+      v = wave_sum(v);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      if (lane == 0) smem[wave] = v;
+      __syncthreads();
+      if (threadIdx.x < (unsigned)NACC) {  // thread k adds the waves of sum k and stores it
+        const unsigned wps = seg / 64;
+        fe_t t = smem[threadIdx.x * wps];
+        for (unsigned w = 1; w < wps; ++w) t = fe_add<S>(t, smem[threadIdx.x * wps + w]);
+        a.mapped[threadIdx.x] = t;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) publish_result(a.mapped, seq);
+    } else {
+      // q = 256 or 512: same two phases, several items per lane; a lane's items may belong to different sums, so it keeps NACC accumulators
+      const unsigned nt = CUBIC ? 3 : 2;
+      const unsigned long long half = 2 * q;
+      for (unsigned long long idx = threadIdx.x; idx < nt * half; idx += TAIL_THREADS) {
+        fe_t* Z = idx < half ? a.A : (idx < 2 * half ? a.B : a.C);
+        const unsigned long long x = idx % half;
+        Z[x] = bind1(Z[x], Z[x + half], r);
+      }
+      __syncthreads();
+      fe_t acc[NACC];
 #pragma unroll
-      for (int k = 0; k < NACC; ++k) a.mapped[k] = acc[k];
-      publish_result(a.mapped, seq);
+      for (int k = 0; k < NACC; ++k) acc[k] = fe_zero();
+      for (unsigned long long idx = threadIdx.x; idx < (unsigned long long)NACC * q; idx += TAIL_THREADS) {
+        const unsigned which = (unsigned)(idx / q);
+        const unsigned long long id = idx % q;
+        const fe_t a0 = a.A[id], a1 = a.A[id + q], b0 = a.B[id], b1 = a.B[id + q];
+        fe_t v;
+        if (which == 0) v = fe_mul<S>(a0, b0);
+        else if (which == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+        else v = fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1));
+        if (CUBIC) {
+          const fe_t c0 = a.C[id], c1 = a.C[id + q];
+          if (which == 0) v = fe_sub<S>(v, c0);
+          else if (which == 2) v = fe_sub<S>(v, fe_sub<S>(fe_dbl<S>(c0), c1));
+          v = fe_mul<S>(eq_in[id], v);
+        }
+#pragma unroll
+        for (int k = 0; k < NACC; ++k)
+          if (which == (unsigned)k) acc[k] = fe_add<S>(acc[k], v);
+      }
+      tail_block_sum<NACC>(acc, smem);
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) a.mapped[k] = acc[k];
+        publish_result(a.mapped, seq);
+      }
     }
     ++seq;
     len /= 2;
