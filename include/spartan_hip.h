@@ -212,6 +212,27 @@ int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t
 int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]);
 int sp_nifs_challenge(sp_nifs* n, const uint64_t r_b[4]);
 int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out, uint64_t out_T_out[4], uint64_t out_eq_rho_at_rb[4]);
+/* Sharded batches (instances / N per GPU, one process per GPU). Each rank holds an aligned block of the 2^ell_b instances:
+ *   sp_nifs_begin_shard     like sp_nifs_begin for instances [first_instance, first_instance + n_padded) of the batch
+ *   sp_nifs_cvals / _set_cvals   the shard's c_vals out / the all-gathered batch-wide vector in
+ *   sp_nifs_round_sums      this shard's part of (e0, quad_coeff) of round t (pair weights use the batch-wide pair index); the caller adds
+ *                           the parts of all ranks (field additions, any order) and hands the totals to
+ *   sp_nifs_round_finish    the `finish_round!` algebra -> the four coefficients (sp_nifs_round = both calls in one)
+ *   after log2(n_padded) rounds a shard has no local pair left:
+ *   sp_nifs_fold_pending    applies the last challenge's fold; sp_nifs_current_layer then exposes the single remaining A / B layer, which the
+ *                           ranks gather on one of them (the only bulk exchange of the path: 2 layers per rank, once);
+ *   sp_nifs_resume          on that rank: a fresh sp_nifs with one layer per rank continues at round t_start with the state of sp_nifs_state.
+ * sp_nifs_finish(C_out = NULL) skips the C fold; each rank folds its C layers with its slice of weights_from_r (sp_fold_tables). */
+int sp_nifs_begin_shard(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, size_t first_instance, int small_values);
+int sp_nifs_cvals(const sp_nifs* n, uint64_t* out_local);
+int sp_nifs_set_cvals(sp_nifs* n, const uint64_t* all, size_t count);
+int sp_nifs_round_sums(sp_nifs* n, size_t t, uint64_t out_sums[8]);
+int sp_nifs_round_finish(sp_nifs* n, size_t t, const uint64_t sums[8], uint64_t out_coeffs[16]);
+int sp_nifs_fold_pending(sp_nifs* n);
+int sp_nifs_current_layer(sp_nifs* n, int which, size_t idx, sp_table** view);
+int sp_nifs_state(const sp_nifs* n, uint64_t out_T_cur[4], uint64_t out_acc_eq[4]);
+int sp_nifs_resume(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, size_t t_start, const uint64_t* r_bs, const uint64_t T_cur[4],
+                   const uint64_t acc_eq[4], const uint64_t* c_vals_all);
 /* to_small_vec_or_zero (src/big_num/small_value.rs:41-86) of a resident table: out_i64[cnt] and out_large[cnt] (0/1) on the host */
 int sp_to_small_vec_or_zero(sp_ctx* ctx, const sp_table* t, size_t cnt, int64_t* out_i64, uint8_t* out_large);
 /* PowPolynomial::split_evals (src/polys/power.rs:64-87), host side: left | right entries */

@@ -31,8 +31,11 @@ struct sp_nifs {
   size_t rounds_done = 0;
   bool have_poly = false;
   bool small = false;
-  std::vector<fe_t> rhos, r_bs, c_vals, prefix;
+  std::vector<fe_t> rhos, r_bs, c_vals, prefix;  // c_vals: one entry per instance of the WHOLE batch (2^ell_b)
   fe_t T_cur, acc_eq, poly[4];
+  // sharding: this object holds instances [first, first + n_padded) of a batch of 2^ell_b; ell_b = log2(n_padded), first = 0 when unsharded
+  size_t first = 0;
+  bool fold_pending = false;  // a challenge has been received whose fold has not been applied to the layers yet
 };
 
 namespace {
@@ -85,9 +88,12 @@ fe_t suffix_weight_full(size_t t, size_t ell_b, size_t pair_idx, const std::vect
   return w;
 }
 
+// global index of local pair 0 at round t: a round-t pair covers 2^(t+1) instances
+size_t pair_base(const sp_nifs* n, size_t t) { return n->first >> (t + 1); }
+
 int upload_weights(sp_nifs* n, size_t t, size_t pairs) {
   std::vector<fe_t> w(pairs);
-  for (size_t p = 0; p < pairs; ++p) w[p] = suffix_weight_full(t, n->ell_b, p, n->rhos);
+  for (size_t p = 0; p < pairs; ++p) w[p] = suffix_weight_full(t, n->ell_b, pair_base(n, t) + p, n->rhos);
   SP_HIP(hipMemcpyAsync(n->d_w, w.data(), pairs * sizeof(fe_t), hipMemcpyHostToDevice, n->ctx->stream));
   SP_HIP(hipStreamSynchronize(n->ctx->stream));  // w is a stack-lifetime host buffer
   return SP_OK;
@@ -153,9 +159,17 @@ int sp_nifs_layer(sp_nifs* n, int which, size_t idx, sp_table** view) {
 }
 
 int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, int small_values) {
-  sp_ctx* c = n->ctx;
   if ((size_t(1) << ell_b) != n->n_padded) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_begin: expected log2(n_padded) rhos");
+  return sp_nifs_begin_shard(n, E_eq, rhos, ell_b, 0, small_values);
+}
+
+int sp_nifs_begin_shard(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, size_t first_instance, int small_values) {
+  sp_ctx* c = n->ctx;
+  if (ell_b > 40 || (size_t(1) << ell_b) < n->n_padded || first_instance % n->n_padded || first_instance + n->n_padded > (size_t(1) << ell_b))
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_begin_shard: the shard must be an aligned block of the 2^ell_b instances");
   n->ell_b = ell_b;
+  n->first = first_instance;
+  n->fold_pending = false;
   n->rhos.resize(ell_b);
   for (size_t i = 0; i < ell_b; ++i) n->rhos[i] = load_fe(rhos + 4 * i);
   n->r_bs.clear();
@@ -203,8 +217,9 @@ int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t
       SP_HIP(hipStreamSynchronize(c->stream));
     }
   }
-  // c_vals (:652-703)
-  n->c_vals.assign(np, fe_zero());
+  // c_vals (:652-703): the local entries of the batch-wide vector (a sharded caller all-gathers the rest, sp_nifs_set_cvals)
+  n->c_vals.assign(size_t(1) << ell_b, fe_zero());
+  fe_t* cv_local = n->c_vals.data() + n->first;
   // small kernels: a block owns 256 * ppt consecutive k (within one x_out when factored)
   const int ppt = n->factored ? (int)std::min<size_t>(8, n->left / 256) : 1;
   const unsigned sblocks = (unsigned)((n->total + 256 * ppt - 1) / (256 * ppt));
@@ -223,19 +238,26 @@ int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t
         hipLaunchKernelGGL(spk::k_nifs_cvals<false>, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, n->C, g, n->d_part);
     });
   }
-  int rc = sum_partials<1>(n, np, n->small ? sblocks : blocks, n->c_vals.data());
+  int rc = sum_partials<1>(n, np, n->small ? sblocks : blocks, cv_local);
   if (rc) return rc;
   if (n->small && n->nlarge) {
     const unsigned lb = (n->nlarge + 255) / 256;
     hipLaunchKernelGGL(spk::k_nifs_cvals_large, dim3(lb, (unsigned)np), dim3(256), 0, c->stream, n->C, g, n->d_large, n->nlarge, n->d_part);
     std::vector<fe_t> corr(np);
     if ((rc = sum_partials<1>(n, np, lb, corr.data()))) return rc;
-    for (size_t b = 0; b < np; ++b) n->c_vals[b] = fe_add<SF>(n->c_vals[b], corr[b]);
+    for (size_t b = 0; b < np; ++b) cv_local[b] = fe_add<SF>(cv_local[b], corr[b]);
   }
   return SP_OK;
 }
 
 int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]) {
+  uint64_t sums[8];
+  int rc = sp_nifs_round_sums(n, t, sums);
+  if (rc) return rc;
+  return sp_nifs_round_finish(n, t, sums, out_coeffs);
+}
+
+int sp_nifs_round_sums(sp_nifs* n, size_t t, uint64_t out_sums[8]) {
   sp_ctx* c = n->ctx;
   if (t != n->rounds_done || t >= n->ell_b || n->have_poly) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_round: rounds must be driven in order, each followed by sp_nifs_challenge");
   const spk::NifsGeom g = geom(n);
@@ -275,28 +297,39 @@ int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]) {
       quad = q[0];
     }
   } else {  // merged fold (previous challenge) + prove (:855-1097)
-    const size_t fold_pairs = n->m / 2, prove_pairs = fold_pairs / 2;
-    if (prove_pairs == 0) return fail(SP_ERR_INTERNAL, "sp_nifs_round: no pair left to prove");
+    const size_t fold_pairs = n->fold_pending ? n->m / 2 : n->m, prove_pairs = fold_pairs / 2;
+    if (prove_pairs == 0) return fail(SP_ERR_INTERNAL, "sp_nifs_round: no local pair left to prove (a sharded batch continues on the gathered layers)");
     if ((rc = upload_weights(n, t, prove_pairs))) return rc;
-    const fe_t r = n->r_bs[t - 1];
-    const int src = n->cur, dst = 1 - n->cur;
-    c->timed("nifs_fold_prove", 384ull * prove_pairs * n->total, [&] {
-      if (n->factored)
-        hipLaunchKernelGGL(spk::k_nifs_fold_prove<true>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst], g,
-                           r, n->d_w, n->d_part);
-      else
-        hipLaunchKernelGGL(spk::k_nifs_fold_prove<false>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst], g,
-                           r, n->d_w, n->d_part);
-    });
     fe_t s[2];
+    if (n->fold_pending) {
+      const fe_t r = n->r_bs[t - 1];
+      const int src = n->cur, dst = 1 - n->cur;
+      c->timed("nifs_fold_prove", 384ull * prove_pairs * n->total, [&] {
+        if (n->factored)
+          hipLaunchKernelGGL(spk::k_nifs_fold_prove<true>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst],
+                             g, r, n->d_w, n->d_part);
+        else
+          hipLaunchKernelGGL(spk::k_nifs_fold_prove<false>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst],
+                             g, r, n->d_w, n->d_part);
+      });
+      n->cur = dst;
+      n->m = fold_pairs;
+      n->fold_pending = false;
+    } else {  // the layers are already folded (sp_nifs_fold_pending / sp_nifs_resume): evaluate only
+      c->timed("nifs_prove_pairs", 128ull * prove_pairs * n->total, [&] {
+        if (n->factored)
+          hipLaunchKernelGGL(spk::k_nifs_prove_pairs<true>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[n->cur], n->B[n->cur], g, n->d_w, n->d_part);
+        else
+          hipLaunchKernelGGL(spk::k_nifs_prove_pairs<false>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[n->cur], n->B[n->cur], g, n->d_w, n->d_part);
+      });
+    }
     if ((rc = sum_partials<2>(n, 1, (size_t)blocks * prove_pairs, s))) return rc;
-    n->cur = dst;
-    n->m = fold_pairs;
     // e0 = sum_j w_j (e0_ab_j - sum_v prefix[v] c_vals[2 j n_prefix + v])  (:919-925, :1016-1022); prefix = eq table of the challenges so far,
     // bit t in the upper half (:1103-1119)
     const size_t n_prefix = n->prefix.size();
     fe_t csum = fe_zero();
-    for (size_t j = 0; j < prove_pairs; ++j) {
+    for (size_t jl = 0; jl < prove_pairs; ++jl) {
+      const size_t j = pair_base(n, t) + jl;  // global pair index
       fe_t cv = fe_zero();
       for (size_t v = 0; v < n_prefix; ++v) cv = fe_add<SF>(cv, fe_mul<SF>(n->prefix[v], n->c_vals[(2 * j) * n_prefix + v]));
       csum = fe_add<SF>(csum, fe_mul<SF>(cv, suffix_weight_full(t, n->ell_b, j, n->rhos)));
@@ -304,6 +337,14 @@ int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]) {
     e0 = fe_sub<SF>(s[0], csum);
     quad = s[1];
   }
+  store_fe(out_sums, e0);
+  store_fe(out_sums + 4, quad);
+  return SP_OK;
+}
+
+int sp_nifs_round_finish(sp_nifs* n, size_t t, const uint64_t sums[8], uint64_t out_coeffs[16]) {
+  if (t != n->rounds_done || t >= n->ell_b || n->have_poly) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_round_finish: out of order");
+  const fe_t e0 = load_fe(sums), quad = load_fe(sums + 4);
   // finish_round! (:703-721)
   const fe_t rho_t = n->rhos[t], one = h_one();
   const fe_t one_minus_rho = fe_sub<SF>(one, rho_t), two_rho_minus_one = fe_sub<SF>(rho_t, one_minus_rho);
@@ -345,24 +386,110 @@ int sp_nifs_challenge(sp_nifs* n, const uint64_t r_b_in[4]) {
   }
   n->rounds_done = t + 1;
   n->have_poly = false;
+  n->fold_pending = true;
+  return SP_OK;
+}
+
+// ---- sharded batches: hand-off between the shard-local rounds and the rounds on the gathered layers ------------------------
+int sp_nifs_cvals(const sp_nifs* n, uint64_t* out_local) {
+  memcpy(out_local, n->c_vals.data() + n->first, n->n_padded * sizeof(fe_t));
+  return SP_OK;
+}
+int sp_nifs_set_cvals(sp_nifs* n, const uint64_t* all, size_t count) {
+  if (count != n->c_vals.size()) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_set_cvals: expected one value per instance of the batch");
+  memcpy(n->c_vals.data(), all, count * sizeof(fe_t));
+  return SP_OK;
+}
+int sp_nifs_fold_pending(sp_nifs* n) {
+  sp_ctx* c = n->ctx;
+  if (!n->fold_pending || n->m < 2) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_fold_pending: nothing to fold");
+  const unsigned blocks = (unsigned)((n->total + 255) / 256);
+  const size_t pairs = n->m / 2;
+  const int src = n->cur, dst = 1 - n->cur;
+  const fe_t r = n->r_bs.back();
+  c->timed("nifs_fold", 96ull * 2 * pairs * n->total, [&] {
+    hipLaunchKernelGGL(spk::k_nifs_fold, dim3(blocks, (unsigned)pairs, 2), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst], (unsigned long long)n->total, r);
+  });
+  n->cur = dst;
+  n->m = pairs;
+  n->fold_pending = false;
+  return SP_OK;
+}
+// view of current layer `idx` (after sp_nifs_fold_pending) of A (which = 0) or B (1), to ship it to the rank that continues
+int sp_nifs_current_layer(sp_nifs* n, int which, size_t idx, sp_table** view) {
+  if (which < 0 || which > 1 || idx >= n->m) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_current_layer: bad matrix or layer index");
+  sp_table* t = new sp_table();
+  t->ctx = n->ctx;
+  t->d = (which == 0 ? n->A[n->cur] : n->B[n->cur]) + idx * n->total;
+  t->cap = t->len = n->total;
+  t->view = true;
+  *view = t;
+  return SP_OK;
+}
+int sp_nifs_state(const sp_nifs* n, uint64_t out_T_cur[4], uint64_t out_acc_eq[4]) {
+  store_fe(out_T_cur, n->T_cur);
+  store_fe(out_acc_eq, n->acc_eq);
+  return SP_OK;
+}
+// Continue a batch on gathered layers: `n` holds n_padded already-folded layers of A and B (written through sp_nifs_layer views), each the
+// fold of 2^t_start consecutive instances; rounds t_start .. ell_b-1 follow. c_vals = the batch-wide vector, r_bs = the t_start challenges so far.
+int sp_nifs_resume(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, size_t t_start, const uint64_t* r_bs, const uint64_t T_cur[4],
+                   const uint64_t acc_eq[4], const uint64_t* c_vals_all) {
+  sp_ctx* c = n->ctx;
+  if (t_start == 0 || t_start >= ell_b || (n->n_padded << t_start) != (size_t(1) << ell_b))
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_resume: n_padded layers of 2^t_start instances must make up the 2^ell_b batch");
+  n->ell_b = ell_b;
+  n->first = 0;
+  n->rhos.resize(ell_b);
+  for (size_t i = 0; i < ell_b; ++i) n->rhos[i] = load_fe(rhos + 4 * i);
+  n->r_bs.resize(t_start);
+  for (size_t i = 0; i < t_start; ++i) n->r_bs[i] = load_fe(r_bs + 4 * i);
+  n->c_vals.resize(size_t(1) << ell_b);
+  memcpy(n->c_vals.data(), c_vals_all, n->c_vals.size() * sizeof(fe_t));
+  // prefix = eq table of the challenges so far, later challenges in the upper half (:863-868, :1103-1119)
+  const fe_t one = h_one();
+  n->prefix = {fe_sub<SF>(one, n->r_bs[0]), n->r_bs[0]};
+  for (size_t i = 1; i < t_start; ++i) {
+    std::vector<fe_t> old = n->prefix;
+    n->prefix.clear();
+    for (const fe_t& x : old) n->prefix.push_back(fe_mul<SF>(x, fe_sub<SF>(one, n->r_bs[i])));
+    for (const fe_t& x : old) n->prefix.push_back(fe_mul<SF>(x, n->r_bs[i]));
+  }
+  n->T_cur = load_fe(T_cur);
+  n->acc_eq = load_fe(acc_eq);
+  n->cur = 0;
+  n->m = n->n_padded;
+  n->rounds_done = t_start;
+  n->have_poly = false;
+  n->fold_pending = false;
+  n->small = false;
+  n->nlarge = 0;
+  // NOTE: weights of round t use pair indices relative to layers of 2^t instances; with first = 0 and m layers of 2^t_start they coincide
+  SP_HIP(hipMemcpyAsync(n->d_E, E_eq, (n->left + n->right) * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
   return SP_OK;
 }
 
 int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out, uint64_t out_T_out[4], uint64_t out_eq[4]) {
   sp_ctx* c = n->ctx;
   if (n->rounds_done != n->ell_b || n->have_poly) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_finish: rounds not complete");
-  if (A_out->cap < n->total || B_out->cap < n->total || C_out->cap < n->total) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_finish: output tables too short");
-  if (n->m != 2) return fail(SP_ERR_INTERNAL, "sp_nifs_finish: expected two layers before the final fold");
+  if (A_out->cap < n->total || B_out->cap < n->total || (C_out && C_out->cap < n->total)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_finish: output tables too short");
+  if (n->m != 2 || !n->fold_pending) return fail(SP_ERR_INTERNAL, "sp_nifs_finish: expected two layers and a pending fold before the final fold");
   const unsigned blocks = (unsigned)((n->total + 255) / 256);
   const fe_t r = n->r_bs.back();
   // final fold of the last pair (:1122-1165), straight into the caller's tables
   c->timed("nifs_fold", 96ull * 2 * n->total, [&] {
     hipLaunchKernelGGL(spk::k_nifs_fold, dim3(blocks, 1, 2), dim3(256), 0, c->stream, n->A[n->cur], n->B[n->cur], A_out->d, B_out->d, (unsigned long long)n->total, r);
   });
-  // Cz = sum_b w_b Cz_b with w = weights_from_r(r_bs) (:1168-1203); the C layers were never folded (c_vals carried their contribution)
+  n->fold_pending = false;
+  int rc = SP_OK;
+  if (C_out) {
+  // Cz = sum_b w_b Cz_b with w = weights_from_r(r_bs) (:1168-1203); the C layers were never folded (c_vals carried their contribution).
+  // (A sharded batch passes C_out = NULL here and folds each shard's C layers with its slice of the weights.)
+  if ((size_t(1) << n->ell_b) != n->n_padded) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_finish: the C fold needs every instance in this object");
   std::vector<uint64_t> rb(4 * n->ell_b), w(4 * n->n_padded);
   for (size_t i = 0; i < n->ell_b; ++i) store_fe(rb.data() + 4 * i, n->r_bs[i]);
-  int rc = sp_weights_from_r(rb.data(), n->ell_b, n->n_padded, w.data());
+  rc = sp_weights_from_r(rb.data(), n->ell_b, n->n_padded, w.data());
   if (rc) return rc;
   std::vector<sp_table> views(n->n_padded);
   std::vector<const sp_table*> ptrs(n->n_padded);
@@ -374,6 +501,7 @@ int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out
     ptrs[b] = &views[b];
   }
   if ((rc = sp_fold_tables(c, ptrs.data(), n->n_padded, w.data(), n->total, C_out))) return rc;
+  }
   SP_HIP(hipStreamSynchronize(c->stream));
   for (sp_table* t : {A_out, B_out}) {
     t->len = n->total;

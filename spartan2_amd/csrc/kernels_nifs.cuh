@@ -86,6 +86,35 @@ __global__ void __launch_bounds__(256) k_nifs_fold_prove(const fe_t* __restrict_
   }
 }
 
+// Evaluate pairs (2j, 2j+1) of already-folded layers (first round after a shard hand-off): same sums as k_nifs_fold_prove without the fold.
+template <bool FACTORED>
+__global__ void __launch_bounds__(256) k_nifs_prove_pairs(const fe_t* __restrict__ A, const fe_t* __restrict__ B, NifsGeom g, const fe_t* __restrict__ w,
+                                                          fe_t* __restrict__ partials) {
+  __shared__ fe_t smem[8];
+  const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long j = blockIdx.y;
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+  if (k < g.total) {
+    const fe_t la = A[(2 * j) * g.total + k], ha = A[(2 * j + 1) * g.total + k];
+    const fe_t lb = B[(2 * j) * g.total + k], hb = B[(2 * j + 1) * g.total + k];
+    const fe_t e = nifs_e(g, k, FACTORED);
+    acc[0] = fe_mul<S>(e, fe_mul<S>(la, lb));
+    acc[1] = fe_mul<S>(e, fe_mul<S>(fe_sub<S>(ha, la), fe_sub<S>(hb, lb)));
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) {
+    fe_t s0 = acc[0], s1 = acc[1];
+    if (FACTORED) {
+      const fe_t fi = g.f[((unsigned long long)blockIdx.x * 256) >> g.left_log2];
+      s0 = fe_mul<S>(s0, fi);
+      s1 = fe_mul<S>(s1, fi);
+    }
+    fe_t* dst = partials + 2 * (j * gridDim.x + blockIdx.x);
+    dst[0] = fe_mul<S>(s0, w[j]);
+    dst[1] = fe_mul<S>(s1, w[j]);
+  }
+}
+
 // Plain fold of layer pairs (fold_ab_pair!, :739-760): out[i] = in[2i] + r (in[2i+1] - in[2i]); blockIdx.z selects the matrix.
 __global__ void __launch_bounds__(256) k_nifs_fold(const fe_t* __restrict__ A, const fe_t* __restrict__ B, fe_t* __restrict__ A_out, fe_t* __restrict__ B_out,
                                                    unsigned long long total, fe_t r) {

@@ -102,3 +102,71 @@ def msm_point_range_sharded(group: Group, n_points: int, msm_fn, point_sum_fn):
     part = np.ascontiguousarray(msm_fn(lo, hi), dtype=np.uint64).reshape(1, 8)
     allp = _all_gather_rows(group, part, [1] * group.world)
     return point_sum_fn(allp)
+
+
+def _field_sum(parts: np.ndarray, add_fn):
+    """sum of (world, k, 4) field elements over axis 0 with the caller's field addition (RCCL has no modular-add reduction: ranks all-gather
+    their few elements and add locally, in rank order — exact arithmetic, so every rank gets identical totals)."""
+    acc = parts[0]
+    for r in range(1, parts.shape[0]):
+        acc = add_fn(acc, parts[r])
+    return acc
+
+
+def nifs_rounds_sharded(group: Group, nifs, make_nifs, E_eq, rhos, n_local: int, small_values: bool, hook, add_fn, read_layer, write_layer):
+    """NeutronNovaNIFS::prove rounds (src/neutronnova_zk.rs:779-1206) with the 2^ell_b instances sharded over the ranks, n_local (a power of
+    two >= 2) consecutive instances per rank — SURVEY.md 8(e), one process per GPU.
+
+    Per round of the first log2(n_local) rounds every rank evaluates its own instance pairs (`nifs.round_sums`, the data-parallel part) and
+    the ranks exchange 2 field elements (all-gather + local adds); every rank then runs the O(1) finish and the deterministic `hook`
+    (the caller's process_round) redundantly, so no broadcast is needed. After those rounds each rank is left with ONE folded layer per
+    matrix; they are gathered on rank 0 (the only bulk exchange: 2 layers per rank, once), which runs the remaining log2(world) rounds on
+    a fresh object from `make_nifs(world)`. Returns on rank 0 (nifs_root, r_bs, polys); on other ranks (None, r_bs_local, polys_local)
+    where the lists stop at the hand-off. `nifs` must have its A/B/C layers filled. add_fn(a, b): field addition on (k, 4) limb arrays;
+    read_layer(table) -> (total, 4) array and write_layer(table, array) move a layer through the host (gloo) or could stay on device (RCCL)."""
+    world, rank = group.world, group.rank
+    ell_b = rhos.shape[0]
+    assert n_local >= 2 and n_local & (n_local - 1) == 0 and n_local * world == 1 << ell_b
+    nifs.begin_shard(E_eq, rhos, rank * n_local, small_values)
+    cv = _all_gather_rows(group, nifs.cvals(), [n_local] * world)
+    nifs.set_cvals(cv)
+    local_rounds = n_local.bit_length() - 1
+    polys, r_bs = [], []
+    for t in range(local_rounds):
+        part = nifs.round_sums(t).reshape(1, 8)
+        allp = _all_gather_rows(group, part, [1] * world).reshape(world, 2, 4)
+        sums = _field_sum(allp, add_fn)
+        co = nifs.round_finish(t, sums)
+        polys.append(co)
+        r = np.ascontiguousarray(hook(t, co), dtype=np.uint64)
+        r_bs.append(r)
+        nifs.challenge(r)
+    if world == 1:
+        return nifs, r_bs, polys
+    # hand-off: apply the pending fold, ship the single remaining A / B layer of every rank to rank 0
+    nifs.fold_pending()
+    layers = []
+    for which in (0, 1):
+        v = nifs.current_layer(which, 0)
+        layers.append(read_layer(v))
+        v.free()
+    total = layers[0].shape[0]
+    mine = np.concatenate(layers).reshape(2 * total, 4)
+    gathered = _all_gather_rows(group, mine, [2 * total] * world).reshape(world, 2, total, 4)
+    T_cur, acc_eq = nifs.state()
+    if rank != 0:
+        return None, r_bs, polys
+    root = make_nifs(world)
+    for b in range(world):
+        for which in (0, 1):
+            v = root.layer(which, b)
+            write_layer(v, gathered[b, which])
+            v.free()
+    root.resume(E_eq, rhos, local_rounds, np.stack(r_bs), T_cur, acc_eq, cv)
+    for t in range(local_rounds, ell_b):
+        co = root.round(t)
+        polys.append(co)
+        r = np.ascontiguousarray(hook(t, co), dtype=np.uint64)
+        r_bs.append(r)
+        root.challenge(r)
+    return root, r_bs, polys

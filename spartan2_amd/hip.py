@@ -428,10 +428,57 @@ class Nifs:
     def challenge(self, r_b):
         check(lib().sp_nifs_challenge(self.h, p64(np.ascontiguousarray(r_b, dtype=np.uint64).reshape(4))))
 
-    def finish(self, A: Table, B: Table, C: Table):
+    def finish(self, A: Table, B: Table, C: Table = None):
+        """C = None skips the C fold (sharded batches fold C per shard)."""
         T, eq = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
-        check(lib().sp_nifs_finish(self.h, A.h, B.h, C.h, p64(T), p64(eq)))
+        check(lib().sp_nifs_finish(self.h, A.h, B.h, C.h if C is not None else None, p64(T), p64(eq)))
         return T, eq
+
+    # ---- sharded batches (SURVEY 8(e)) ----
+    def begin_shard(self, E_eq, rhos, first_instance: int, small_values=False):
+        E_eq = np.ascontiguousarray(E_eq, dtype=np.uint64).reshape(self.left + self.right, 4)
+        rhos = np.ascontiguousarray(rhos, dtype=np.uint64).reshape(-1, 4)
+        check(lib().sp_nifs_begin_shard(self.h, p64(E_eq), p64(rhos), ctypes.c_size_t(rhos.shape[0]), ctypes.c_size_t(first_instance), 1 if small_values else 0))
+
+    def cvals(self):
+        out = np.zeros((self.n_padded, 4), dtype=np.uint64)
+        check(lib().sp_nifs_cvals(self.h, p64(out)))
+        return out
+
+    def set_cvals(self, allv):
+        allv = np.ascontiguousarray(allv, dtype=np.uint64).reshape(-1, 4)
+        check(lib().sp_nifs_set_cvals(self.h, p64(allv), ctypes.c_size_t(allv.shape[0])))
+
+    def round_sums(self, t: int):
+        out = np.zeros((2, 4), dtype=np.uint64)
+        check(lib().sp_nifs_round_sums(self.h, ctypes.c_size_t(t), p64(out)))
+        return out
+
+    def round_finish(self, t: int, sums):
+        out = np.zeros((4, 4), dtype=np.uint64)
+        check(lib().sp_nifs_round_finish(self.h, ctypes.c_size_t(t), p64(np.ascontiguousarray(sums, dtype=np.uint64).reshape(2, 4)), p64(out)))
+        return out
+
+    def fold_pending(self):
+        check(lib().sp_nifs_fold_pending(self.h))
+
+    def current_layer(self, which: int, idx: int) -> Table:
+        h = ctypes.c_void_p()
+        check(lib().sp_nifs_current_layer(self.h, int(which), ctypes.c_size_t(idx), ctypes.byref(h)))
+        return Table(self.ctx, h)
+
+    def state(self):
+        T, eq = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        check(lib().sp_nifs_state(self.h, p64(T), p64(eq)))
+        return T, eq
+
+    def resume(self, E_eq, rhos, t_start: int, r_bs, T_cur, acc_eq, c_vals_all):
+        E_eq = np.ascontiguousarray(E_eq, dtype=np.uint64).reshape(self.left + self.right, 4)
+        rhos = np.ascontiguousarray(rhos, dtype=np.uint64).reshape(-1, 4)
+        r_bs = np.ascontiguousarray(r_bs, dtype=np.uint64).reshape(t_start, 4)
+        cv = np.ascontiguousarray(c_vals_all, dtype=np.uint64).reshape(-1, 4)
+        check(lib().sp_nifs_resume(self.h, p64(E_eq), p64(rhos), ctypes.c_size_t(rhos.shape[0]), ctypes.c_size_t(t_start), p64(r_bs),
+                                   p64(np.ascontiguousarray(T_cur, dtype=np.uint64).reshape(4)), p64(np.ascontiguousarray(acc_eq, dtype=np.uint64).reshape(4)), p64(cv)))
 
     def free(self):
         if self.h:

@@ -135,3 +135,60 @@ def test_shard_range_is_a_partition():
                 assert 0 <= hi - lo <= (n + world - 1) // world
             assert cover == list(range(n))
     assert whole_job_throughput(100.0, 10, 2.0, 8) == 4000.0
+
+
+def _worker_nifs(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+
+    import oracle_lib as ol
+    from pynifs import P, PyNifs
+    from spartan2_amd import dist as spd
+
+    g = spd.Group(backend="gloo")
+    n_inst, num_cons = 8, 16
+    n_local = n_inst // world
+    ell, left, right = ol.tensor_decomp(num_cons)
+    total = left * right
+    rng = np.random.default_rng(42)  # every rank derives the same batch and keeps only its shard
+    a = rng.integers(-3, 4, size=(n_inst, total)).astype(object)
+    b = rng.integers(0, 2, size=(n_inst, total)).astype(object)
+    c = (a * b) % P
+    arr = lambda m: np.stack([ol.mont_array([int(v) % P for v in row]) for row in m])
+    A, B, C = arr(a), arr(b), arr(c)
+    E = ol.pow_split_evals(ol.to_mont(123456789), ell, left, right)
+    rhos = ol.mont_array([1000003 + 17 * i for i in range(3)])
+    nifs = PyNifs(n_local, left, right)
+    for i in range(n_local):
+        for which, M in enumerate((A, B, C)):
+            PyNifs.write_layer(nifs.layer(which, i), M[rank * n_local + i])
+    add = lambda x, y: ol.mont_array([(u + v) % P for u, v in zip(ol.ints_of(x), ol.ints_of(y))])
+    hook = ol.transcript_round_hook(ol.Transcript(b"vc"))  # deterministic: every rank runs it
+    root, r_bs, polys = spd.nifs_rounds_sharded(g, nifs, lambda n: PyNifs(n, left, right), E, rhos, n_local, False, hook, add, PyNifs.read_layer, PyNifs.write_layer)
+    out = None
+    if rank == 0:
+        fa, fb, T_out, eq = root.finish_ab()
+        want = ol.nifs_prove_core(left, right, E, rhos, A, B, C, False, ol.transcript_round_hook(ol.Transcript(b"vc")))
+        out = (bool((np.stack(polys) == want["polys"]).all()), bool((np.stack(r_bs) == want["r_bs"]).all()), bool((fa == want["A"]).all()),
+               bool((fb == want["B"]).all()), bool((T_out == want["T_out"]).all()), bool((eq == want["eq_rho_at_rb"]).all()), len(polys))
+    q.put((rank, out))
+    g.close()
+
+
+def test_two_rank_gloo_nifs_rounds_sharded_match_the_unsharded_oracle():
+    """8 instances over 2 ranks: two shard-local rounds with a 2-element exchange each, hand-off of one layer pair per rank, last round on
+    rank 0 — round polynomials, challenges, folded layers and T_out equal the oracle's unsharded NeutronNovaNIFS::prove."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nifs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    assert res[0] == (True, True, True, True, True, True, 3)
