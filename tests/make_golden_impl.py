@@ -74,3 +74,39 @@ def spartan_small():
     return {"note": "oracle proof (oracle/spartan.hpp) of frontend.synthetic_circuit(6, 0xDEADBEEF, 3) with tape = SHAKE256('golden-tape')",
             "num_cons": inst.num_cons, "num_aux": inst.num_aux, "tape_blocks_prep": used, "tape_blocks_prove": used2, "proof_words": len(words),
             "proof_sha256": hashlib.sha256(words.tobytes()).hexdigest(), "proof_head": _hex(words[:64]), "proof_tail": _hex(words[-16:])}
+
+
+# ---- NeutronNova NIFS rounds (oracle/nifs.hpp) -----------------------------------------------------------------------------------
+def nifs_inputs(n_inst, num_cons):
+    """Layers with SHA-like small entries (A in {-2..2}, B bits, C = A o B) and a few full-size ones; E from a SHAKE-derived tau."""
+    ell, left, right = ol.tensor_decomp(num_cons)
+    total = left * right
+    P = ol.MODULI[0]
+    raw = np.frombuffer(hashlib.shake_256(b"golden-nifs-%d-%d" % (n_inst, num_cons)).digest(2 * n_inst * total), dtype=np.uint8).reshape(2, n_inst, total)
+    a = (raw[0] % 5).astype(np.int64) - 2
+    b = (raw[1] & 1).astype(np.int64)
+    lut = {v: ol.to_mont(v % P) for v in range(-2, 3)}
+    A = np.stack([np.stack([lut[int(v)] for v in row]) for row in a])
+    B = np.stack([np.stack([lut[int(v)] for v in row]) for row in b])
+    C = np.stack([np.stack([lut[int(v)] for v in row]) for row in a * b])
+    big = _field_from_seed(b"golden-nifs-big", 4)  # two full-size pairs: positions that take the large-value corrections
+    for j, (i, k) in enumerate(((0, 1), (n_inst - 1, total - 2))):
+        A[i, k], B[i, k] = big[2 * j], big[2 * j + 1]
+        olib().orc_field_binop(0, 2, p64(A[i, k]), p64(B[i, k]), p64(C[i, k]))
+    tau = _field_from_seed(b"golden-nifs-tau", 1)[0]
+    E = ol.pow_split_evals(tau, ell, left, right)
+    rhos = _field_from_seed(b"golden-nifs-rho", n_inst.bit_length() - 1)
+    return left, right, E, rhos, A, B, C
+
+
+def nifs_small():
+    out = {"note": "oracle outputs (oracle/nifs.hpp nifs_prove_core, cached-i64 branch) on SHAKE256-derived inputs; round hook = transcript "
+                   "b'golden-nifs': absorb the 4 coefficients under b'p', squeeze b'c' (tests/oracle_lib.py transcript_round_hook)", "cases": []}
+    for n_inst, num_cons in ((4, 64), (8, 512)):
+        left, right, E, rhos, A, B, C = nifs_inputs(n_inst, num_cons)
+        o = ol.nifs_prove_core(left, right, E, rhos, A, B, C, True, ol.transcript_round_hook(ol.Transcript(b"golden-nifs")))
+        out["cases"].append({"n_inst": n_inst, "num_cons": num_cons, "polys": _hex(o["polys"]), "r_bs": _hex(o["r_bs"]), "T_out": _hex(o["T_out"]),
+                             "eq_rho_at_rb": _hex(o["eq_rho_at_rb"]), "A_sha256": hashlib.sha256(o["A"].tobytes()).hexdigest(),
+                             "B_sha256": hashlib.sha256(o["B"].tobytes()).hexdigest(), "C_sha256": hashlib.sha256(o["C"].tobytes()).hexdigest(),
+                             "A_head": _hex(o["A"][:2]), "C_head": _hex(o["C"][:2])})
+    return out

@@ -60,3 +60,42 @@ def test_spartan_proof_against_golden(ctx):
     assert (used, used2, len(words)) == (gold["tape_blocks_prep"], gold["tape_blocks_prove"], gold["proof_words"])
     assert hashlib.sha256(words.tobytes()).hexdigest() == gold["proof_sha256"]
     assert words[:64].tobytes().hex() == gold["proof_head"] and words[-16:].tobytes().hex() == gold["proof_tail"]
+
+
+def test_nifs_rounds_against_golden(ctx):
+    """sp_nifs_* with the round hook run on the PRODUCT's transcript (hip.Transcript): polynomials, challenges, T_out and the folded layers
+    match the frozen vectors — both value paths (field layers, i64 mirrors)."""
+    import make_golden_impl
+    import oracle_lib as ol  # pure-Python Montgomery helpers only (from_mont)
+
+    with open(os.path.join(GOLD, "nifs_small.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        n_inst, num_cons = case["n_inst"], case["num_cons"]
+        left, right, E, rhos, A, B, C = make_golden_impl.nifs_inputs(n_inst, num_cons)
+        total, ell_b = left * right, rhos.shape[0]
+        for small in (False, True):
+            nifs = hip.Nifs(ctx, n_inst, left, right)
+            for which, M in enumerate((A, B, C)):
+                for b in range(n_inst):
+                    v = nifs.layer(which, b)
+                    v.write(0, M[b])
+                    v.free()
+            nifs.begin(E, rhos, small_values=small)
+            tr = hip.Transcript(ctx, b"golden-nifs")
+            polys, r_bs = [], []
+            for t in range(ell_b):
+                co = nifs.round(t)
+                for i in range(4):  # a scalar enters the transcript as its canonical value, 32 bytes big-endian (src/provider/traits.rs:282-286)
+                    tr.absorb(b"p", ol.from_mont(co[i]).to_bytes(32, "big"))
+                r = tr.squeeze(b"c")
+                nifs.challenge(r)
+                polys.append(co)
+                r_bs.append(r)
+            oa, ob, oc = (hip.Table.zeros(ctx, total) for _ in range(3))
+            T_out, eq = nifs.finish(oa, ob, oc)
+            assert (np.stack(polys) == _arr(case["polys"], (ell_b, 4, 4))).all() and (np.stack(r_bs) == _arr(case["r_bs"], (ell_b, 4))).all()
+            assert (T_out == _arr(case["T_out"], (4,))).all() and (eq == _arr(case["eq_rho_at_rb"], (4,))).all()
+            for name, tab in (("A", oa), ("B", ob), ("C", oc)):
+                assert hashlib.sha256(tab.read(0, total).tobytes()).hexdigest() == case[name + "_sha256"], name
+            nifs.free()

@@ -153,3 +153,21 @@ def test_nifs_prove_whole_both_branches_agree():
     assert L.orc_hyrax_commit(okey, ol.p64(o["folded_W"]), ctypes.c_size_t(osh.num_vars), ol.p64(o["folded_rW"]), 0, ol.p64(recommit)) == 0
     assert (recommit == o["folded_comm"]).all()
     L.orc_hyrax_free(okey)
+
+
+def test_oracle_reproduces_the_frozen_nifs_vectors():
+    """tests/golden/nifs_small.json regenerates bit-for-bit from the oracle (both branches)."""
+    import hashlib
+    import json
+    import os
+
+    import make_golden_impl
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nifs_small.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        left, right, E, rhos, A, B, C = make_golden_impl.nifs_inputs(case["n_inst"], case["num_cons"])
+        for use_i64 in (True, False):
+            o = ol.nifs_prove_core(left, right, E, rhos, A, B, C, use_i64, ol.transcript_round_hook(ol.Transcript(b"golden-nifs")))
+            assert o["polys"].tobytes().hex() == case["polys"] and o["T_out"].tobytes().hex() == case["T_out"]
+            assert hashlib.sha256(o["C"].tobytes()).hexdigest() == case["C_sha256"]
