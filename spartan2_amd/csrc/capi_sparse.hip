@@ -83,9 +83,12 @@ __device__ __forceinline__ unsigned col_len(const PolyAbcArgs& a, size_t col) {
   for (int i = 0; i < 3; ++i) n += (a.m[i].sptr[col + 1] - a.m[i].sptr[col]) + (a.m[i].gptr[col + 1] - a.m[i].gptr[col]);
   return n;
 }
-__global__ void __launch_bounds__(256) k_polyabc_short(PolyAbcArgs a, const fe_t* __restrict__ rx, size_t ncols, fe_t* __restrict__ out) {
-  for (size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x; col < ncols; col += (size_t)gridDim.x * blockDim.x) {
-    if (col_len(a, col) >= LONG_COLUMN) continue;  // handled by k_polyabc_long
+// `order` lists the short columns by decreasing entry count, so the 64 columns of a wave have (nearly) the same length: a wave costs its longest
+// column, and SHA circuits mix 1-entry columns with columns of dozens of entries.
+__global__ void __launch_bounds__(256) k_polyabc_short(PolyAbcArgs a, const fe_t* __restrict__ rx, const unsigned* __restrict__ order, size_t n_short,
+                                                       fe_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_short; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t col = order[i];
     fe_t sa = gather_major(a.m[0], col, rx, 0, 1), sb = gather_major(a.m[1], col, rx, 0, 1), sc = gather_major(a.m[2], col, rx, 0, 1);
     out[col] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(a.r, sb)), fe_mul<S>(a.r2, sc));
   }
@@ -228,6 +231,8 @@ struct sp_shape {
   SplitOnDevice filtered[3];  // FilteredSpmv rows: col >= num_shared + num_precommitted, row < num_cons_unpadded
   SplitOnDevice col[3];       // column-major, rows < num_cons_unpadded (accumulate_rows)
   unsigned* d_long_cols = nullptr;
+  unsigned* d_short_order = nullptr;  // short columns by decreasing entry count (k_polyabc_short)
+  size_t n_short = 0;
   fe_t* d_long_partials = nullptr;
   size_t n_long_cols = 0;
   uint64_t nnz[3] = {0, 0, 0}, nnz_filtered[3] = {0, 0, 0};
@@ -296,6 +301,15 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
   s->n_long_cols = long_cols.size();
   int rc = upload(&s->d_long_cols, long_cols);
   if (rc) return rc;
+  {
+    std::vector<unsigned> order;
+    order.reserve(s->num_cols);
+    for (size_t i = 0; i < s->num_cols; ++i)
+      if (col_count[i] < spk::LONG_COLUMN) order.push_back((unsigned)i);
+    std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return col_count[x] > col_count[y]; });
+    s->n_short = order.size();
+    if ((rc = upload(&s->d_short_order, order))) return rc;
+  }
   SP_HIP(hipMalloc((void**)&s->d_long_partials, (long_cols.size() + 1) * spk::LONG_NB_MAX * 3 * sizeof(fe_t)));
   *out = s;
   return SP_OK;
@@ -308,6 +322,7 @@ void sp_shape_free(sp_shape* s) {
     s->col[m].release();
   }
   hipFree(s->d_long_cols);
+  hipFree(s->d_short_order);
   hipFree(s->d_long_partials);
   delete s;
 }
@@ -353,11 +368,12 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
   memcpy(&a.r, r_, 32);
   a.r2 = fe_mul<S>(a.r, a.r);
   if (out_len > s->num_cols) SP_HIP(hipMemsetAsync(out->d + s->num_cols, 0, (out_len - s->num_cols) * sizeof(fe_t), c->stream));
-  size_t blocks = (s->num_cols + 255) / 256;
+  size_t blocks = (s->n_short + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
   uint64_t bytes = 36ull * (s->nnz[0] + s->nnz[1] + s->nnz[2]) + 32ull * out_len;
   c->timed("poly_abc", bytes, [&] {
-    hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->num_cols, out->d);
+    hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short, out->d);
     if (s->n_long_cols) {
       hipLaunchKernelGGL(spk::k_polyabc_long, dim3(spk::LONG_NB_MAX, (unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, rx->d, s->d_long_cols,
                          s->d_long_partials);
