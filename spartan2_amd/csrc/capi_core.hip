@@ -133,6 +133,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   for (int i = 0; i < sp_ctx::WS_SLOTS; ++i)
     if (c->ws_ptr[i]) hipFree(c->ws_ptr[i]);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  for (auto& lane : c->msm_ev)
+    for (hipEvent_t& e : lane)
+      if (e) hipEventDestroy(e);
   for (int i = 0; i < 2; ++i)
     if (c->h_pinned_lane[i]) hipHostFree(c->h_pinned_lane[i]);
   if (c->h_pinned_fb) hipHostFree(c->h_pinned_fb);

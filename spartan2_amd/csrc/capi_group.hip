@@ -111,12 +111,16 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
   pend->slot = (int)(c->msm_jobs_issued[lane]++ % MSM_LANDING_SLOTS);
   // pinned landing buffer: a device->host copy into pageable memory would block the host until the MSM is done
   SP_HIP(hipMemcpyAsync((char*)c->h_pinned_lane[lane] + pend->slot * 4096, wsum, windows * sizeof(jac_t), hipMemcpyDeviceToHost, st));
+  // one event per in-flight job: finishing an early job must not wait for later work queued on the same stream
+  hipEvent_t& ev = c->msm_ev[lane][pend->slot];
+  if (!ev) SP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  SP_HIP(hipEventRecord(ev, st));
   return SP_OK;
 }
 int msm_finish(sp_ctx* c, MsmPending* pend, jac_t* result) {
   *result = jac_identity();
   if (pend->windows == 0) return SP_OK;
-  SP_HIP(hipStreamSynchronize(lane_stream(c, pend->lane)));
+  SP_HIP(hipEventSynchronize(c->msm_ev[pend->lane][pend->slot]));
   pend->w.resize(pend->windows);
   memcpy(pend->w.data(), (char*)c->h_pinned_lane[pend->lane] + pend->slot * 4096, pend->windows * sizeof(jac_t));
   // Horner over windows, high to low (msm.rs:150-175): acc = 2^8 acc + W_w

@@ -46,6 +46,7 @@ struct sp_ctx {
   }
   unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.cuh publish_result)
   unsigned long long msm_jobs_issued[2] = {0, 0};
+  hipEvent_t msm_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // completion event of the MSM job in each landing slot
   void* h_pinned_lane[2] = {nullptr, nullptr};  // pinned landing buffers for per-window MSM sums (one per stream), 8 KiB each
   size_t pinned_elems = 0;
   bool timing = false;

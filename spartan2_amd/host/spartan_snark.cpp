@@ -500,6 +500,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
   aff_t delta, beta;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
+  // delta's device part finished long ago (it was issued before the inner sum-check): its window Horner runs on the host while the device
+  // still works on comm_LZ
+  ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
   lap("host_side_under_msm");
   if (lz_job) ck(sp_msm_ck_finish(ctx, pk.ck, lz_job, u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ (finish)");
   lap("comm_LZ_finish");
@@ -509,8 +512,6 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     point_bytes(comm_eval_W, b + 64);
     tr.absorb("U", b, 128);
   }
-  ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
-  lap("delta_finish");
   {
     uint8_t b[64];
     point_bytes(delta, b);
