@@ -139,6 +139,59 @@ int msm_device(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, size_t n, i
   return msm_finish(c, &pend, result);
 }
 
+// Digit-path MSMs of many rows over one base vector (kernels_msm.cuh "batched row MSMs"): rows `sel` of the row-major canonical scalar
+// array `canon` (cols per row, n scalars in all), `windows` = 33 (full scalars, signs folded) or 9 (values < 2^64). Results -> out[sel[i]].
+int msm_rows_batched(sp_ctx* c, const fe_t* canon, size_t cols, size_t n, const std::vector<unsigned>& sel, int windows, const aff_t* d_bases,
+                     std::vector<jac_t>& out) {
+  if (sel.empty()) return SP_OK;
+  const size_t CH = 512;  // rows per pass: 512 x 33 windows x (2048 x 4 B order + 128 x 96 B buckets) = ~350 MB of scratch
+  const size_t ch = sel.size() < CH ? sel.size() : CH;
+  DevBuf dsel, dscal, dorder, dstart, dbuckets, dwsum, drows;
+  int rc;
+  if ((rc = dsel.alloc(ch * 4)) || (rc = dscal.alloc(ch * cols * sizeof(fe_t))) || (rc = dorder.alloc(ch * windows * cols * 4)) ||
+      (rc = dstart.alloc(ch * windows * (spk::MSM_BUCKETS + 1) * 4)) || (rc = dbuckets.alloc(ch * windows * spk::MSM_BUCKETS * sizeof(jac_t))) ||
+      (rc = dwsum.alloc(sel.size() * windows * sizeof(jac_t))) || (rc = drows.alloc(sel.size() * sizeof(jac_t))))
+    return rc;
+  for (size_t base = 0; base < sel.size(); base += CH) {
+    const size_t cnt = sel.size() - base < CH ? sel.size() - base : CH;
+    SP_HIP(hipMemcpyAsync(dsel.p, sel.data() + base, cnt * 4, hipMemcpyHostToDevice, c->stream));
+    if (windows == spk::MSM_MAX_WINDOWS) {
+      hipLaunchKernelGGL(spk::k_fold_sign_rows, dim3((unsigned)((cols + 255) / 256), (unsigned)cnt), dim3(256), 0, c->stream, canon, dsel.as<unsigned>(), cols, n,
+                         dscal.as<fe_t>());
+    } else {  // narrow scalars: no folding, copy the rows into the dense [cnt][cols] layout the sort expects
+      for (size_t i = 0; i < cnt; ++i) {
+        const size_t lo = (size_t)sel[base + i] * cols, len = (lo + cols <= n) ? cols : n - lo;
+        SP_HIP(hipMemcpyAsync(dscal.as<fe_t>() + i * cols, canon + lo, len * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
+      }
+    }
+    c->timed("msm_rows_sort", 32ull * cnt * cols, [&] {
+      hipLaunchKernelGGL(spk::k_msm_sort_rows, dim3(windows, (unsigned)cnt), dim3(256), 0, c->stream, dscal.as<fe_t>(), dsel.as<unsigned>(), cols, n,
+                         dorder.as<unsigned>(), dstart.as<unsigned>());
+    });
+    const size_t total_buckets = cnt * windows * spk::MSM_BUCKETS;
+    c->timed("msm_rows_bucket_sum", 96ull * cnt * cols, [&] {
+      hipLaunchKernelGGL(spk::k_msm_bucket_sum_rows, dim3((unsigned)((total_buckets + 255) / 256)), dim3(256), 0, c->stream, d_bases, cols, dorder.as<unsigned>(),
+                         dstart.as<unsigned>(), total_buckets, dbuckets.as<jac_t>());
+    });
+    const size_t nwin = cnt * windows;
+    c->timed("msm_rows_window_reduce", 0, [&] {
+      hipLaunchKernelGGL(spk::k_msm_window_reduce_seg, dim3((unsigned)((nwin * 8 + 255) / 256)), dim3(256), 0, c->stream, dbuckets.as<jac_t>(), nwin,
+                         dwsum.as<jac_t>() + base * windows);
+    });
+    // the next pass reuses dsel / dscal / dorder: same stream, so it is ordered behind these kernels
+  }
+  // one Horner pass for all rows (one lane per row: 8 x 32 doublings + 33 additions, latency-bound, so it is worth doing once)
+  c->timed("msm_rows_horner", 0, [&] {
+    hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((sel.size() + 63) / 64)), dim3(64), 0, c->stream, dwsum.as<jac_t>(), windows, sel.size(),
+                       drows.as<jac_t>());
+  });
+  std::vector<jac_t> res(sel.size());
+  SP_HIP(hipMemcpyAsync(res.data(), drows.p, sel.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < sel.size(); ++i) out[sel[i]] = res[i];
+  return SP_OK;
+}
+
 int upload_canonical(sp_ctx* c, const uint64_t* scalars, size_t n, fe_t** canon_out, int lane = 0) {
   fe_t* raw = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_RAW, n * sizeof(fe_t), lane);
   fe_t* canon = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_CANON, n * sizeof(fe_t), lane);
@@ -461,10 +514,21 @@ int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, s
   SP_HIP(hipMemcpyAsync(hflags.data(), flags, rows * 4, hipMemcpyDeviceToHost, c->stream));
   SP_HIP(hipMemcpyAsync(msm_rows.data(), rowsum, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
   SP_HIP(hipStreamSynchronize(c->stream));
-  for (size_t r = 0; r < rows; ++r) {
-    if (hflags[r] > 1u) {  // msm_10 / msm_small_rest / full msm rows (msm.rs:367-409, :187-222): digit path
-      size_t lo = r * cols, len = (lo + cols <= n) ? cols : n - lo;
-      if ((rc = msm_device(c, canon + lo, ck->d_bases, len, (hflags[r] & 4u) ? spk::MSM_MAX_WINDOWS : 9, &msm_rows[r]))) return rc;
+  // msm_10 / msm_small_rest / full msm rows (msm.rs:367-409, :187-222): digit path. One or two such rows take the single-MSM (latency) path;
+  // more are batched over the row dimension (throughput path).
+  std::vector<unsigned> full_rows, narrow_rows;
+  for (size_t r = 0; r < rows; ++r)
+    if (hflags[r] > 1u) ((hflags[r] & 4u) ? full_rows : narrow_rows).push_back((unsigned)r);
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::vector<unsigned>& sel = pass == 0 ? full_rows : narrow_rows;
+    const int windows = pass == 0 ? spk::MSM_MAX_WINDOWS : 9;
+    if (sel.size() > 2) {
+      if ((rc = msm_rows_batched(c, canon, cols, n, sel, windows, ck->d_bases, msm_rows))) return rc;
+    } else {
+      for (unsigned r : sel) {
+        size_t lo = (size_t)r * cols, len = (lo + cols <= n) ? cols : n - lo;
+        if ((rc = msm_device(c, canon + lo, ck->d_bases, len, windows, &msm_rows[r]))) return rc;
+      }
     }
   }
   std::vector<jac_t> hb;

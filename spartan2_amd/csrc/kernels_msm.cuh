@@ -178,6 +178,126 @@ __global__ void __launch_bounds__(MSM_BUCKETS) k_msm_window_reduce(const jac_t* 
   if (k == 0) window_sums[w] = s[0];
 }
 
+// ---- batched row MSMs: many rows, ONE base vector, different scalars (PCS::commit on non-small witnesses, hyrax_pc.rs:230-300; the 2048 x 2048
+// full-scalar row MSMs of BASELINE config 4). Throughput regime — every (row, window, bucket) gets its own lane and plain sequential mixed
+// additions (no shuffle trees: the machine is full); sort and window reduction are the single-MSM kernels with a row dimension.
+// rows[y] = index of the y-th selected row; its scalars are canon[rows[y] * cols .. + len(y)).
+__device__ __forceinline__ unsigned batched_row_len(size_t row, size_t cols, size_t n) {
+  const size_t lo = row * cols;
+  return (unsigned)((lo + cols <= n) ? cols : n - lo);
+}
+__global__ void __launch_bounds__(256) k_fold_sign_rows(const fe_t* __restrict__ canon, const unsigned* __restrict__ rows, size_t cols, size_t n,
+                                                        fe_t* __restrict__ out /* [nrows][cols] */) {
+  const size_t row = rows[blockIdx.y];
+  const unsigned len = batched_row_len(row, cols, n);
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x) {
+    const fe_t c = canon[row * cols + i];
+    fe_t d;
+    uint32_t bw = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d.v[k] = sp_subb(SF::P(k), c.v[k], bw);
+    uint32_t lt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) (void)sp_subb(d.v[k], c.v[k], lt);
+    fe_t o = lt ? d : c;
+    if (lt) o.v[7] |= 0x80000000u;
+    out[(size_t)blockIdx.y * cols + i] = o;
+  }
+}
+// grid (windows, nrows): LDS counting sort of one (row, window), as k_msm_sort
+__global__ void __launch_bounds__(256) k_msm_sort_rows(const fe_t* __restrict__ scal /* [nrows][cols] or canon when rows != null */, const unsigned* __restrict__ rows,
+                                                       size_t cols, size_t n, unsigned* __restrict__ order, unsigned* __restrict__ start) {
+  __shared__ unsigned hist[MSM_BUCKETS + 1];
+  __shared__ unsigned cursor[MSM_BUCKETS];
+  const int w = blockIdx.x, windows = gridDim.x;
+  const size_t y = blockIdx.y;
+  const size_t row = rows[y];
+  const unsigned len = batched_row_len(row, cols, n);
+  const fe_t* src = scal + y * cols;
+  order += (y * windows + w) * cols;
+  start += (y * windows + w) * (MSM_BUCKETS + 1);
+  for (int k = threadIdx.x; k <= MSM_BUCKETS; k += blockDim.x) hist[k] = 0;
+  __syncthreads();
+  for (unsigned j = threadIdx.x; j < len; j += blockDim.x) {
+    int d = signed_digit(src[j], w);
+    if (d) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int k = 0; k < MSM_BUCKETS; ++k) {
+      unsigned cnt = hist[k];
+      hist[k] = run;
+      cursor[k] = run;
+      run += cnt;
+    }
+    hist[MSM_BUCKETS] = run;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= MSM_BUCKETS; k += blockDim.x) start[k] = hist[k];
+  for (unsigned j = threadIdx.x; j < len; j += blockDim.x) {
+    const fe_t c = src[j];
+    int d = signed_digit(c, w);
+    if (d) {
+      unsigned pos = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
+      const bool neg = (d < 0) != ((c.v[7] >> 31) != 0);
+      order[pos] = j | (neg ? 0x80000000u : 0u);
+    }
+  }
+}
+// one lane per (row, window, bucket)
+__global__ void __launch_bounds__(256) k_msm_bucket_sum_rows(const aff_t* __restrict__ bases, size_t cols, const unsigned* __restrict__ order,
+                                                             const unsigned* __restrict__ start, size_t total_buckets, jac_t* __restrict__ buckets) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= total_buckets) return;
+  const size_t rw = b / MSM_BUCKETS, k = b % MSM_BUCKETS;  // rw = row-slot * windows + window
+  const unsigned lo = start[rw * (MSM_BUCKETS + 1) + k], hi = start[rw * (MSM_BUCKETS + 1) + k + 1];
+  jac_t acc = jac_identity();
+  for (unsigned p = lo; p < hi; ++p) {
+    const unsigned e = order[rw * cols + p];
+    aff_t q = bases[e & 0x7fffffffu];
+    if (e & 0x80000000u) q = aff_neg(q);
+    acc = jac_add_mixed(acc, q);
+  }
+  buckets[b] = acc;
+}
+
+// Window sums for the batched path, work-efficient form: 8 adjacent lanes per (row, window); lane s runs the classical running sum over its 16
+// buckets (acc_s = sum_i (i+1) B_{16s+i}, run_s = sum_i B_{16s+i}: 32 additions), then W = sum_s acc_s + 16 * sum_s s * run_s.
+// ~280 additions per window instead of the 128 x 14 of the scan form (which is the right shape only when a single MSM must finish fast).
+__global__ void __launch_bounds__(256) k_msm_window_reduce_seg(const jac_t* __restrict__ buckets, size_t nwin, jac_t* __restrict__ window_sums) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t win = gid >> 3;
+  const int seg = (int)(gid & 7);
+  jac_t run = jac_identity(), acc = jac_identity();
+  if (win < nwin) {
+    const jac_t* b = buckets + win * MSM_BUCKETS + seg * 16;
+    for (int i = 15; i >= 0; --i) {
+      run = jac_add(run, b[i]);
+      acc = jac_add(acc, run);
+    }
+  }
+  // X = sum_s acc_s (3-level tree over the 8 lanes); Y = sum_s s * run_s by a running sum in lane 0 of the group
+  jac_t x = acc;
+#pragma unroll
+  for (int d = 4; d >= 1; d >>= 1) {
+    jac_t o = shfl_down_jac(x, d);
+    if (seg < d) x = jac_add(x, o);
+  }
+  jac_t rr = jac_identity(), y = jac_identity();
+  for (int s = 7; s >= 1; --s) {
+    jac_t rs = shfl_down_jac(run, s);  // lane 0 of the group receives run_s
+    if (seg == 0) {
+      rr = jac_add(rr, rs);
+      y = jac_add(y, rr);
+    }
+  }
+  if (win < nwin && seg == 0) {
+    for (int k = 0; k < 4; ++k) y = jac_dbl(y);
+    window_sums[win] = jac_add(x, y);
+  }
+}
+
 // Window Horner on the device for batches (one lane per row): acc = 2^8 acc + W_w, high to low (msm.rs:150-175). A single MSM
 // leaves this 256-doubling chain to the host; with hundreds of rows the lanes run it in parallel.
 __global__ void __launch_bounds__(64) k_msm_horner_rows(const jac_t* __restrict__ window_sums, int windows, size_t rows, jac_t* __restrict__ out) {

@@ -142,6 +142,23 @@ def test_hyrax_commit_matches_oracle(ctx, key, kind):
     assert (got == want).all()
 
 
+def test_hyrax_commit_many_full_rows_take_the_batched_path(ctx, key):
+    """20 full-scalar rows + a ragged narrow tail: the row-batched digit path (one lane per (row, window, bucket)) against the oracle."""
+    rng = np.random.default_rng(SEED + 300)
+    n = 2048 * 21 + 5
+    v = ol.random_field_array(rng, n)
+    v[2048 * 20 :] = ol.mont_array([int(x) for x in rng.integers(0, 1 << 40, size=n - 2048 * 20)])  # last two rows: 64-bit values
+    v[2048 * 3 : 2048 * 4] = 0  # a zero row in the middle
+    rows = (n + 2047) // 2048
+    blinds = ol.random_field_array(rng, rows)
+    ok = oracle_key()
+    want = np.zeros((rows, 8), dtype=np.uint64)
+    assert olib().orc_hyrax_commit(ok, p64(v), ctypes.c_size_t(n), p64(blinds), 0, p64(want)) == 0
+    olib().orc_hyrax_free(ok)
+    got = key.commit(hip.Table.from_host(ctx, v), 0, n, blinds)
+    assert (got == want).all()
+
+
 def test_rowmat_vec(ctx):
     # bind_with_delayed (hyrax_pc.rs:38-54)
     rng = np.random.default_rng(SEED + 300)
