@@ -173,6 +173,21 @@ int sp_msm_ck_finish(sp_ctx* ctx, const sp_ck* ck, sp_msm_job* job, const uint64
  * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
 int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);
 
+/* ---- sum-checks on a table slice ("sum-check by evaluation-table slice, one reduce per round") -----------------------------
+ * Tables sharded on their LAST k variables: rank g holds Z_g[j] = Z[(j << k) | g], so the pairs (i, i + n/2) of the first ell - k rounds are
+ * rank-local. Each rank calls the _sharded form on its slice with taus[0 .. ell-k): per round the slice's sums are multiplied by
+ * scale = eq(taus[ell-k .. ell), bits of g) (cubic only) and handed to `reduce` (user, sums, count) which must return the field sum over all
+ * ranks in place (RCCL has no modular-add reduction: all-gather + local adds; ~100 B per round). Every rank then derives the same round
+ * polynomial and runs the transcript redundantly. claim_io / p_io carry the running claim and the eq(tau, r) product across calls: after the
+ * local rounds the ranks gather their final (A, B, C) values into 2^k-element tables and EVERY rank finishes the last k rounds with a second,
+ * unsharded call (scale = NULL, reduce = NULL) on taus[ell-k .. ell) continuing from claim_io / p_io. */
+typedef int (*sp_reduce_hook)(void* user, uint64_t* sums, size_t count);
+int sp_sumcheck_cubic3_sharded(sp_ctx* ctx, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus, size_t ell, sp_table* A, sp_table* B, sp_table* C,
+                               sp_transcript* tr, const uint64_t* scale, sp_reduce_hook reduce, void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r,
+                               uint64_t out_final[12]);
+int sp_sumcheck_quad_sharded(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce,
+                             void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
+
 /* ---- NeutronNova batched ZK sum-checks (src/sumcheck.rs:702-917) --------------------------------------------------------------------
  * The reference obtains each round's challenge from the ZK verifier circuit (`SatisfyingAssignment::process_round`, :747-755, :864-872) —
  * a commit + transcript step that stays with the caller. It enters as a callback: hook(user, round, coeffs_step, coeffs_core, ncoeffs,

@@ -553,6 +553,15 @@ static bool table_dense(const sp_table* t) { return sp::eff_lo(t) == t->len / 2 
 
 int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
                      uint64_t* out_r, uint64_t out_final[8]) {
+  uint64_t claim_io[4];
+  memcpy(claim_io, claim_, 32);
+  return sp_sumcheck_quad_sharded(c, claim_io, rounds, A, B, tr, nullptr, nullptr, out_cpolys, out_r, out_final);
+}
+
+// prove_quad on a slice of the tables (see sp_sumcheck_cubic3_sharded): per round the slice's (eval0, t_inf) are combined across ranks by `reduce`
+int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
+                             uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
+  const uint64_t* claim_ = claim_io;
   if (A->len != B->len || A->len != ((size_t)1 << rounds)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: tables must have 2^rounds elements");
   fe_t claim = load_fe(claim_);
   const uint8_t lbl_c[1] = {'c'};
@@ -582,6 +591,10 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
       if (rc) return rc;
     }
     (void)pending_blocks;
+    if (reduce) {
+      int hrc = reduce(reduce_user, reinterpret_cast<uint64_t*>(sums), 2);
+      if (hrc) return fail(hrc, "prove_quad: the reduce hook failed");
+    }
     const double tr1 = round_trace() ? now_us() : 0;
     // BDDT: eval_2 = 2 claim - 3 eval_0 + 2 t_inf (src/sumcheck.rs:211-215)
     fe_t e0 = sums[0], tinf = sums[1];
@@ -651,6 +664,7 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
   if (rc) return rc;
   rc = sp_table_read(c, B, 0, 1, out_final + 4);
   if (rc) return rc;
+  store_fe(claim_io, claim);
   return in_tail ? tail_check(c) : SP_OK;
 }
 
@@ -761,6 +775,23 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
 
 int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                        uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
+  uint64_t claim_io[4], p_io[4];
+  memcpy(claim_io, claim_, 32);
+  const fe_t one = fe_one<S>();
+  store_fe(p_io, one);
+  return sp_sumcheck_cubic3_sharded(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final);
+}
+
+// The same rounds on a SLICE of the tables (tables sharded on their last k variables, rank g holds Z[(j << k) | g]): the slice's
+// sums are scaled by `scale` = eq(tau[ell..ell+k), bits of g) and combined across ranks by `reduce` before the claim algebra, so every rank
+// derives the same polynomial and challenge. `claim_io` / `p_io` carry the running claim and eq(tau, r) product in and out, so the caller can
+// finish the last k rounds on the gathered 2^k-element tables with a second call (scale = reduce = NULL there).
+int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C,
+                               sp_transcript* tr, const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r,
+                               uint64_t out_final[12]) {
+  const uint64_t* claim_ = claim_io;
+  const bool have_scale = scale_ != nullptr;
+  const fe_t scale = have_scale ? load_fe(scale_) : fe_one<S>();
   const size_t N = (size_t)1 << ell;
   if (A->len != N || B->len != N || C->len != N) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: tables must have 2^ell elements");
   if (ell == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: no rounds");
@@ -832,8 +863,18 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
 
   fe_t claim = load_fe(claim_);
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
-  fe_t eval_eq_left = fe_one<S>();
+  fe_t eval_eq_left = load_fe(p_io);
   const fe_t one = fe_one<S>();
+  // slice sums -> batch sums (no-op for an unsharded call)
+  auto combine = [&](fe_t* sums, int k) -> int {
+    if (have_scale)
+      for (int i = 0; i < k; ++i) sums[i] = fe_mul<S>(sums[i], scale);
+    if (reduce) {
+      int hrc = reduce(reduce_user, reinterpret_cast<uint64_t*>(sums), (size_t)k);
+      if (hrc) return fail(hrc, "sum-check: the reduce hook failed");
+    }
+    return SP_OK;
+  };
   const uint8_t lbl_c[1] = {'c'};
   // round 1 sums from a plain evaluation pass; later rounds get theirs from the fused bind+eval of the previous round
   {
@@ -855,6 +896,7 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
     fe_t sums[3];
     rc = reduce_partials_wait(c, in_tail ? 3 : 2, sums);
     if (rc) return rc;
+    if ((rc = combine(sums, in_tail ? 3 : 2))) return rc;
     const fe_t t0 = sums[0], tinf = sums[1];
     // derive_from_claim (:1276-1324)
     fe_t s_0, s_1, s_leading, s_m1;
@@ -875,6 +917,7 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
       c->timed("eval_cubic", 192ull * (A->len / 2), [&] { blocks = launch_eval(rnd, true); });
       rc = reduce_partials(c, blocks, 3, sums);
       if (rc) return rc;
+      if ((rc = combine(sums, 3))) return rc;
       s_0 = fe_mul<S>(fe_mul<S>(eq0, p), t0);
       s_1 = fe_sub<S>(claim, s_0);
       s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
@@ -965,6 +1008,8 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   if (rc) return rc;
   rc = sp_table_read(c, C, 0, 1, out_final + 8);
   if (rc) return rc;
+  store_fe(claim_io, claim);
+  store_fe(p_io, eval_eq_left);
   return in_tail ? tail_check(c) : SP_OK;
 }
 

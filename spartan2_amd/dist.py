@@ -170,3 +170,78 @@ def nifs_rounds_sharded(group: Group, nifs, make_nifs, E_eq, rhos, n_local: int,
         r_bs.append(r)
         root.challenge(r)
     return root, r_bs, polys
+
+
+# ---- sum-check by evaluation-table slice ----------------------------------------------------------------------------
+_P = 0xFFFFFFFF00000001000000000000000000000000FFFFFFFFFFFFFFFFFFFFFFFF  # scalar field of the bench engine (src/provider/pt256.rs:55)
+_R = 1 << 256
+
+
+def _to_int(limbs):  # Montgomery limbs -> integer value
+    v = sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(limbs, dtype=np.uint64).reshape(4)))
+    return v * pow(_R, -1, _P) % _P
+
+
+def _to_limbs(v):
+    m = v % _P * _R % _P
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def slice_of(table: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """Rank `rank`'s slice of a table sharded on its last log2(world) variables: Z_g[j] = Z[(j << k) | g]."""
+    return np.ascontiguousarray(table[rank::world])
+
+
+def sumcheck_cubic3_sharded(group: Group, cubic_fn, claim, taus, A, B, C, make_table):
+    """SumcheckProof::prove_cubic_with_three_inputs (src/sumcheck.rs:502-571) with the three tables sharded by slice over the ranks.
+
+    cubic_fn(claim, p, taus, A, B, C, scale, reduce) -> (polys, r, final (3,4), claim_out, p_out) is sp_sumcheck_cubic3_sharded bound to the
+    rank's context and transcript (every rank runs the same deterministic transcript). Per round the ranks exchange 2-3 field elements
+    (all-gather + local adds in rank order). After the ell - k local rounds each rank holds one value per table; they are gathered into
+    2^k-element tables on EVERY rank (`make_table(array)`), which all finish the last k rounds redundantly — no further exchange.
+    Returns (polys, r, final) of the whole ell-round sum-check."""
+    world, rank = group.world, group.rank
+    k = world.bit_length() - 1
+    assert 1 << k == world
+    taus = np.ascontiguousarray(taus, dtype=np.uint64).reshape(-1, 4)
+    ell = taus.shape[0]
+    one = _to_limbs(1)
+    if world == 1:
+        polys, r, fin, _, _ = cubic_fn(claim, one, taus, A, B, C, None, None)
+        return polys, r, fin
+    # scale = eq(taus[ell-k..ell), bits of rank), MSB of the k-bit rank index = first of those variables
+    sc = 1
+    for i in range(k):
+        t = _to_int(taus[ell - k + i])
+        sc = sc * (t if (rank >> (k - 1 - i)) & 1 else (1 - t)) % _P
+
+    def reduce(sums):
+        allp = _all_gather_rows(group, np.ascontiguousarray(sums, dtype=np.uint64).reshape(1, -1), [1] * world).reshape(world, -1, 4)
+        return np.stack([_to_limbs(sum(_to_int(allp[g, i]) for g in range(world))) for i in range(allp.shape[1])])
+
+    polys1, r1, fin_loc, claim1, p1 = cubic_fn(claim, one, taus[: ell - k], A, B, C, _to_limbs(sc), reduce)
+    gathered = _all_gather_rows(group, fin_loc.reshape(1, 12), [1] * world).reshape(world, 3, 4)
+    TA, TB, TC = (make_table(np.ascontiguousarray(gathered[:, q])) for q in range(3))
+    polys2, r2, fin, _, _ = cubic_fn(claim1, p1, taus[ell - k :], TA, TB, TC, None, None)
+    return np.concatenate([polys1, polys2]), np.concatenate([r1, r2]), fin
+
+
+def sumcheck_quad_sharded(group: Group, quad_fn, claim, rounds, A, B, make_table):
+    """SumcheckProof::prove_quad (src/sumcheck.rs:190-247) on tables sharded by slice; quad_fn(claim, rounds, A, B, reduce) ->
+    (polys, r, final (2,4), claim_out) = sp_sumcheck_quad_sharded."""
+    world = group.world
+    k = world.bit_length() - 1
+    assert 1 << k == world
+    if world == 1:
+        polys, r, fin, _ = quad_fn(claim, rounds, A, B, None)
+        return polys, r, fin
+
+    def reduce(sums):
+        allp = _all_gather_rows(group, np.ascontiguousarray(sums, dtype=np.uint64).reshape(1, -1), [1] * world).reshape(world, -1, 4)
+        return np.stack([_to_limbs(sum(_to_int(allp[g, i]) for g in range(world))) for i in range(allp.shape[1])])
+
+    polys1, r1, fin_loc, claim1 = quad_fn(claim, rounds - k, A, B, reduce)
+    gathered = _all_gather_rows(group, fin_loc.reshape(1, 8), [1] * world).reshape(world, 2, 4)
+    TA, TB = (make_table(np.ascontiguousarray(gathered[:, q])) for q in range(2))
+    polys2, r2, fin, _ = quad_fn(claim1, k, TA, TB, None)
+    return np.concatenate([polys1, polys2]), np.concatenate([r1, r2]), fin

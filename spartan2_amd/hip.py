@@ -530,3 +530,48 @@ def sumcheck_cubic_outer_pow_batched(ctx, num_rounds, pow_left: Table, pow_right
     check(lib().sp_sumcheck_cubic_outer_pow_batched(ctx.h, ctypes.c_size_t(num_rounds), pow_left.h, pow_right.h, step[0].h, step[1].h, step[2].h, core[0].h, core[1].h,
                                                     core[2].h, p64(t), ctypes.c_size_t(start_round), cb, None, p64(out_r)))
     return out_r
+
+
+# ---- sum-checks on a table slice -----------------------------------------------------------------------------------
+REDUCE_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, c_u64p, ctypes.c_size_t)
+
+
+def _reduce_hook(py_reduce):
+    def raw(_user, sums_ptr, count):
+        try:
+            arr = np.ctypeslib.as_array(sums_ptr, shape=(4 * count,)).reshape(count, 4)
+            out = np.ascontiguousarray(py_reduce(arr.copy()), dtype=np.uint64).reshape(count, 4)
+            arr[:] = out
+            return 0
+        except Exception:
+            return -5
+
+    return REDUCE_HOOK(raw)
+
+
+def sumcheck_cubic3_sharded(ctx, claim, p, taus, A: Table, B: Table, C: Table, tr: Transcript, scale=None, py_reduce=None):
+    """sp_sumcheck_cubic3_sharded -> (polys (ell,3,4), r (ell,4), final (3,4), claim_out, p_out)."""
+    taus = np.ascontiguousarray(taus, dtype=np.uint64).reshape(-1, 4)
+    ell = taus.shape[0]
+    claim_io = np.ascontiguousarray(claim, dtype=np.uint64).reshape(4).copy()
+    p_io = np.ascontiguousarray(p, dtype=np.uint64).reshape(4).copy()
+    polys = np.zeros((ell, 3, 4), dtype=np.uint64)
+    r = np.zeros((ell, 4), dtype=np.uint64)
+    fin = np.zeros((3, 4), dtype=np.uint64)
+    cb = _reduce_hook(py_reduce) if py_reduce is not None else None
+    sc = np.ascontiguousarray(scale, dtype=np.uint64).reshape(4) if scale is not None else None
+    check(lib().sp_sumcheck_cubic3_sharded(ctx.h, p64(claim_io), p64(p_io), p64(taus), ctypes.c_size_t(ell), A.h, B.h, C.h, tr.h, p64(sc) if sc is not None else None,
+                                           cb if cb is not None else ctypes.cast(None, REDUCE_HOOK), None, p64(polys), p64(r), p64(fin)))
+    return polys, r, fin, claim_io, p_io
+
+
+def sumcheck_quad_sharded(ctx, claim, rounds, A: Table, B: Table, tr: Transcript, py_reduce=None):
+    """sp_sumcheck_quad_sharded -> (polys (rounds,2,4), r, final (2,4), claim_out)."""
+    claim_io = np.ascontiguousarray(claim, dtype=np.uint64).reshape(4).copy()
+    polys = np.zeros((rounds, 2, 4), dtype=np.uint64)
+    r = np.zeros((rounds, 4), dtype=np.uint64)
+    fin = np.zeros((2, 4), dtype=np.uint64)
+    cb = _reduce_hook(py_reduce) if py_reduce is not None else None
+    check(lib().sp_sumcheck_quad_sharded(ctx.h, p64(claim_io), ctypes.c_size_t(rounds), A.h, B.h, tr.h, cb if cb is not None else ctypes.cast(None, REDUCE_HOOK), None,
+                                         p64(polys), p64(r), p64(fin)))
+    return polys, r, fin, claim_io

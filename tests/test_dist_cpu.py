@@ -192,3 +192,65 @@ def test_two_rank_gloo_nifs_rounds_sharded_match_the_unsharded_oracle():
         assert p.exitcode == 0
     assert res[1] is None
     assert res[0] == (True, True, True, True, True, True, 3)
+
+
+def _worker_sumcheck(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes
+
+    import numpy as np
+
+    import oracle_lib as ol
+    import pysumcheck as ps
+    from oracle_lib import lib as olib, p64
+    from spartan2_amd import dist as spd
+
+    g = spd.Group(backend="gloo")
+    ell = 5
+    n = 1 << ell
+    rng = np.random.default_rng(99)
+    A, B = ol.random_field_array(rng, n), ol.random_field_array(rng, n)
+    C = ol.mont_array([x * y % ps.P for x, y in zip(ol.ints_of(A), ol.ints_of(B))])
+    taus = ol.random_field_array(rng, ell)
+    claim = np.zeros(4, dtype=np.uint64)
+    tr = ol.Transcript(b"sc")
+    cubic = lambda cl, p, ts, a, b, c, sc, red: ps.cubic_sharded(tr, cl, p, ts, a, b, c, sc, red)
+    polys, r, fin = spd.sumcheck_cubic3_sharded(g, cubic, claim, taus, *(spd.slice_of(T, rank, world) for T in (A, B, C)), lambda arr: arr)
+    qclaim = np.zeros(4, dtype=np.uint64)
+    olib().orc_field_dot(0, p64(A), p64(B), ctypes.c_size_t(n), p64(qclaim))
+    trq = ol.Transcript(b"sq")
+    quad = lambda cl, rounds, a, b, red: ps.quad_sharded(trq, cl, rounds, a, b, red)
+    qpolys, qr, qfin = spd.sumcheck_quad_sharded(g, quad, qclaim, ell, *(spd.slice_of(T, rank, world) for T in (A, B)), lambda arr: arr)
+    # the oracle's unsharded sum-checks on the full tables
+    otr = ol.Transcript(b"sc")
+    wp, wr, wf = np.zeros((ell, 3, 4), dtype=np.uint64), np.zeros((ell, 4), dtype=np.uint64), np.zeros((3, 4), dtype=np.uint64)
+    a, b, c = A.copy(), B.copy(), C.copy()
+    assert olib().orc_sumcheck_cubic3(p64(claim), p64(taus), ctypes.c_size_t(ell), p64(a), p64(b), p64(c), otr.h, p64(wp), p64(wr), p64(wf)) == 0
+    oq = ol.Transcript(b"sq")
+    qp, qrr, qf = np.zeros((ell, 2, 4), dtype=np.uint64), np.zeros((ell, 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64)
+    a, b = A.copy(), B.copy()
+    full = ctypes.c_size_t((1 << 64) - 1)
+    assert olib().orc_sumcheck_quad(p64(qclaim), ctypes.c_size_t(ell), p64(a), full, full, p64(b), full, full, oq.h, p64(qp), p64(qrr), p64(qf)) == 0
+    q.put((rank, tuple(bool(x) for x in ((polys == wp).all(), (r == wr).all(), (fin == wf).all(), (tr.squeeze(b"z") == otr.squeeze(b"z")).all(),
+                                         (qpolys == qp).all(), (qr == qrr).all(), (qfin == qf).all()))))
+    g.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sumcheck_by_table_slice_matches_the_unsharded_oracle(world):
+    """Tables sharded on their last log2(world) variables; one 2-element exchange per round; every rank finishes the last rounds on the gathered
+    values and ends with the same polynomials, challenges, final evaluations and transcript state as the oracle's unsharded sum-checks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sumcheck, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r] == (True,) * 7, (r, res[r])
