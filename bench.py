@@ -84,6 +84,10 @@ def main():
     kstats = {k: ctx.kernel_stats(k) for k in ("bind_stream_cubic", "bind_stream_quad", "bind", "eval_cubic", "eval_quad", "spmv_incremental", "poly_abc", "eq_table", "rowmat_vec", "msm_sort",
                                                 "msm_bucket_sum", "msm_window_reduce", "fixed_base")}
     ctx.reset_stats(False)
+    # SpartanSNARK::verify on the device-backed path (reported separately, as the reference's bench does: benches/sha256_spartan.rs:245-262)
+    t0 = time.perf_counter()
+    v_ok = all(snark.verify(words) == 0 for _ in range(3))
+    t_verify = (time.perf_counter() - t0) / 3
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -126,6 +130,8 @@ def main():
             "kernel_ms_per_step": {k: v[0] / nb for k, v in kstats.items()},
             "setup_s": t_setup,
             "prep_prove_s": t_prep,
+            "verify_ms": t_verify * 1e3,
+            "verify_accepts": v_ok,
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib as ol  # test infrastructure, used here only as the reported CPU baseline

@@ -126,6 +126,14 @@ class SpartanSNARK:
                               ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
         return words, used.value, dict(zip(PHASES, list(ms)))
 
+    def verify(self, words: np.ndarray) -> int:
+        """SpartanSNARK::verify (src/spartan.rs:469-578) with the matrix evaluations and MSMs on the device: 0 = accept, 1..6 = failed check."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        rc = lib().ss_verify(self.pk, hip.p64(words), ctypes.c_size_t(words.shape[0]))
+        if rc < 0:
+            _check(rc)
+        return rc
+
     def close(self):
         if self.ps:
             lib().ss_prep_free(self.ps)
