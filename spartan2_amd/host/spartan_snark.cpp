@@ -5,10 +5,9 @@
 //   SpartanSNARK::setup            src/spartan.rs:146-173
 //   SpartanSNARK::prep_prove       src/spartan.rs:176-216       (+ bellpepper/r1cs.rs:359-409 precommitted_witness)
 //   SpartanSNARK::prove            src/spartan.rs:219-466       (+ bellpepper/r1cs.rs:411-538, hyrax_pc.rs:387-478, ipa.rs:125-170)
+//   SpartanSNARK::verify           src/spartan.rs:469-578       (matrix evaluations and opening MSMs on the device)
 // for circuits without verifier challenges: any mix of shared / precommitted / rest variables (bench circuits: precommitted-only,
 // skip_synthesize + commit_zeros path :443; the reference's e2e CubicCircuit src/spartan.rs:587-651: rest-only).
-// Verification is not restated here: the reference verifier is CPU code outside the accelerated path;
-// tests verify with the oracle's restated verifier.
 //
 // Randomness is injected: every blind / mask is the next 64-byte block of a caller-supplied tape reduced with from_uniform,
 // in the reference's call order.
