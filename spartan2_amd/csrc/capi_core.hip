@@ -275,7 +275,9 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
   if (nblocks == 1) return;  // a one-block evaluation wrote its sums (and the sequence number) straight to the pinned buffer
   hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
 }
-static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host) {
+// `resident`: the result comes from the resident tail kernel, which is itself waiting for the host's next challenge — a stream synchronise
+// would never return, so the host keeps polling (bounded by wall-clock; the kernel gives up after 2 s as well).
+static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false) {
   volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->h_pinned + spk::RESULT_FLAG_ELEM);
   const unsigned want = c->result_seq;
   bool seen = false;
@@ -285,6 +287,14 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host) {
       break;
     }
     __builtin_ia32_pause();
+  }
+  if (!seen && resident) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (*flag != want) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
+      __builtin_ia32_pause();
+    }
+    seen = true;
   }
   if (!seen) SP_HIP(hipStreamSynchronize(c->stream));
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -587,7 +597,7 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
         if (rc) return rc;
       }
     } else {
-      rc = reduce_partials_wait(c, 2, sums);
+      rc = reduce_partials_wait(c, 2, sums, in_tail);
       if (rc) return rc;
     }
     (void)pending_blocks;
@@ -894,7 +904,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     const bool invertible = !fe_is_zero(l_1_p);
     const fe_t l_1_p_inv = invertible ? fe_inv<S>(l_1_p) : fe_zero();  // runs while the device computes this round's sums
     fe_t sums[3];
-    rc = reduce_partials_wait(c, in_tail ? 3 : 2, sums);
+    rc = reduce_partials_wait(c, in_tail ? 3 : 2, sums, in_tail);
     if (rc) return rc;
     if ((rc = combine(sums, in_tail ? 3 : 2))) return rc;
     const fe_t t0 = sums[0], tinf = sums[1];
