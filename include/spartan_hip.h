@@ -223,7 +223,10 @@ int sp_nifs_create(sp_ctx* ctx, size_t n_padded, size_t left, size_t right, sp_n
 void sp_nifs_free(sp_nifs* n);
 /* which: 0 = Az, 1 = Bz, 2 = Cz. The view is valid until sp_nifs_free; free it with sp_table_free (does not release the storage). */
 int sp_nifs_layer(sp_nifs* n, int which, size_t idx, sp_table** view);
+/* small_values: 0 = field layers only; 1 = build the i64 mirrors now; 2 = use the mirrors sp_nifs_prepare_small built on these layers (the
+ * reference's split: cached_step_i64 is made in prep_prove, src/neutronnova_zk.rs:1548-1586, and only consumed by prove) */
 int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, int small_values);
+int sp_nifs_prepare_small(sp_nifs* n);
 int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]);
 int sp_nifs_challenge(sp_nifs* n, const uint64_t r_b[4]);
 int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out, uint64_t out_T_out[4], uint64_t out_eq_rho_at_rb[4]);

@@ -283,25 +283,43 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
   fe_t* canon;
   int rc;
   if ((rc = upload_canonical(c, weights, n, &canon))) return rc;
-  DevBuf dbases, folded, order, start, buckets, wsum, drows;
-  if ((rc = dbases.alloc(rows * n * sizeof(aff_t))) || (rc = folded.alloc(n * sizeof(fe_t))) || (rc = order.alloc((size_t)windows * n * 4)) ||
-      (rc = start.alloc((size_t)windows * (spk::MSM_BUCKETS + 1) * 4)) || (rc = buckets.alloc(rows * windows * spk::MSM_BUCKETS * sizeof(jac_t))) ||
-      (rc = wsum.alloc(rows * windows * sizeof(jac_t))) || (rc = drows.alloc(rows * sizeof(jac_t))))
-    return rc;
-  SP_HIP(hipMemcpyAsync(dbases.p, bases_rows, rows * n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(spk::k_fold_sign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, canon, n, folded.as<fe_t>());
+  // grow-only context workspaces (no hipMalloc / hipFree on the path)
+  aff_t* dbases = (aff_t*)c->workspace(sp_ctx::WS_BASES_TMP, rows * n * sizeof(aff_t));
+  fe_t* folded = (fe_t*)c->workspace(sp_ctx::WS_MSM_FOLDED, n * sizeof(fe_t));
+  unsigned* order = (unsigned*)c->workspace(sp_ctx::WS_MSM_ORDER, (size_t)windows * n * 4);
+  unsigned* start = (unsigned*)c->workspace(sp_ctx::WS_MSM_START, (size_t)windows * (spk::MSM_BUCKETS + 1) * 4);
+  jac_t* buckets = (jac_t*)c->workspace(sp_ctx::WS_MSM_BUCKETS, rows * windows * spk::MSM_BUCKETS * sizeof(jac_t));
+  jac_t* wsum = (jac_t*)c->workspace(sp_ctx::WS_MSM_WSUM, rows * windows * sizeof(jac_t));
+  jac_t* drows = (jac_t*)c->workspace(sp_ctx::WS_COMMIT_ROWS, rows * sizeof(jac_t));
+  if (!dbases || !folded || !order || !start || !buckets || !wsum || !drows) return SP_ERR_NO_DEVICE;
+  SP_HIP(hipMemcpyAsync(dbases, bases_rows, rows * n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(spk::k_fold_sign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, canon, n, folded);
   // the digit decomposition / bucket order is shared by every row (msm.rs:266-300); buckets and window sums are per row
-  hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, c->stream, folded.as<fe_t>(), (unsigned)n, order.as<unsigned>(), start.as<unsigned>());
+  hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, c->stream, folded, (unsigned)n, order, start);
   unsigned lanes = (unsigned)windows * spk::MSM_BUCKETS * spk::MSM_LANES_PER_BUCKET;
   c->timed("msm_shared_bucket_sum", 64ull * n * rows, [&] {
-    hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, c->stream, dbases.as<aff_t>(), (unsigned)n,
-                       order.as<unsigned>(), start.as<unsigned>(), windows, buckets.as<jac_t>());
+    hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, c->stream, dbases, (unsigned)n, order, start, windows, buckets);
   });
-  hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets.as<jac_t>(), wsum.as<jac_t>());
-  hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, wsum.as<jac_t>(), windows, rows, drows.as<jac_t>());
+  hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
   std::vector<jac_t> res(rows);
-  SP_HIP(hipMemcpyAsync(res.data(), drows.p, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  if (rows <= 64) {
+    // few rows: the 256-doubling window Horner is a latency chain (~3 ms for one lane per row on the device, ~60 us per row on the host)
+    std::vector<jac_t> ws(rows * windows);
+    SP_HIP(hipMemcpyAsync(ws.data(), wsum, ws.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP(hipStreamSynchronize(c->stream));
+    for (size_t r = 0; r < rows; ++r) {
+      jac_t acc = jac_identity();
+      for (int w = windows - 1; w >= 0; --w) {
+        for (int k = 0; k < spk::MSM_C; ++k) acc = jac_dbl(acc);
+        acc = jac_add(acc, ws[r * windows + w]);
+      }
+      res[r] = acc;
+    }
+  } else {
+    hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, wsum, windows, rows, drows);
+    SP_HIP(hipMemcpyAsync(res.data(), drows, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP(hipStreamSynchronize(c->stream));
+  }
   std::vector<aff_t> a(rows);
   normalize_batch(res, a.data());
   memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));

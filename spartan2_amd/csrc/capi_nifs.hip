@@ -36,6 +36,7 @@ struct sp_nifs {
   // sharding: this object holds instances [first, first + n_padded) of a batch of 2^ell_b; ell_b = log2(n_padded), first = 0 when unsharded
   size_t first = 0;
   bool fold_pending = false;  // a challenge has been received whose fold has not been applied to the layers yet
+  bool mirrors_ready = false; // sp_nifs_prepare_small has run on the current layers
 };
 
 namespace {
@@ -154,7 +155,47 @@ int sp_nifs_layer(sp_nifs* n, int which, size_t idx, sp_table** view) {
   t->d = (which == 0 ? n->A[0] : which == 1 ? n->B[0] : n->C) + idx * n->total;
   t->cap = t->len = n->total;
   t->view = true;
+  n->mirrors_ready = false;  // the caller is about to (re)write this layer
   *view = t;
+  return SP_OK;
+}
+
+// The i64 mirrors and the global large-position list of the current layers (prep_prove's cached_step_i64, src/neutronnova_zk.rs:1548-1586):
+// transcript-independent, so a caller that follows the reference builds them at prep time and passes small_values = 2 to sp_nifs_begin.
+int sp_nifs_prepare_small(sp_nifs* n) {
+  sp_ctx* c = n->ctx;
+  const size_t np = n->n_padded;
+  const unsigned blocks = (unsigned)((n->total + 255) / 256);
+  if (!n->A64) {
+    hipError_t e = hipMalloc((void**)&n->A64, np * n->total * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&n->B64, np * n->total * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&n->C64, np * n->total * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&n->d_flags, n->total);
+    if (e == hipSuccess) e = hipMalloc((void**)&n->d_large, n->total * 4);
+    if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("sp_nifs_prepare_small: hipMalloc: ") + hipGetErrorString(e));
+  }
+  SP_HIP(hipMemsetAsync(n->d_flags, 0, n->total, c->stream));
+  // every layer's flags are OR-ed into one array: the global large_positions of prep_prove (:1548-1572)
+  const fe_t* src[3] = {n->A[0], n->B[0], n->C};
+  long long* dst[3] = {n->A64, n->B64, n->C64};
+  for (int q = 0; q < 3; ++q)
+    c->timed("nifs_to_small", 40ull * n->total * np, [&] {
+      hipLaunchKernelGGL(spk::k_to_small, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, src[q], (unsigned long long)n->total, dst[q], n->d_flags);
+    });
+  std::vector<unsigned char> flags(n->total);
+  SP_HIP(hipMemcpyAsync(flags.data(), n->d_flags, n->total, hipMemcpyDeviceToHost, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  std::vector<unsigned> large;
+  for (size_t k = 0; k < n->total; ++k)
+    if (flags[k]) large.push_back((unsigned)k);
+  n->nlarge = (unsigned)large.size();
+  if (n->nlarge) {
+    SP_HIP(hipMemcpyAsync(n->d_large, large.data(), large.size() * 4, hipMemcpyHostToDevice, c->stream));
+    for (int q = 0; q < 3; ++q)
+      hipLaunchKernelGGL(spk::k_small_mask, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, dst[q], (unsigned long long)n->total, n->d_flags);
+    SP_HIP(hipStreamSynchronize(c->stream));
+  }
+  n->mirrors_ready = true;
   return SP_OK;
 }
 
@@ -185,38 +226,11 @@ int sp_nifs_begin_shard(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, 
   const spk::NifsGeom g = geom(n);
   const unsigned blocks = (unsigned)((n->total + 255) / 256);
   const size_t np = n->n_padded;
-  n->nlarge = 0;
-  if (n->small) {
-    if (!n->A64) {
-      hipError_t e = hipMalloc((void**)&n->A64, np * n->total * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&n->B64, np * n->total * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&n->C64, np * n->total * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&n->d_flags, n->total);
-      if (e == hipSuccess) e = hipMalloc((void**)&n->d_large, n->total * 4);
-      if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("sp_nifs_begin: hipMalloc: ") + hipGetErrorString(e));
-    }
-    SP_HIP(hipMemsetAsync(n->d_flags, 0, n->total, c->stream));
-    // every layer's flags are OR-ed into one array: the global large_positions of prep_prove (:1548-1572)
-    const fe_t* src[3] = {n->A[0], n->B[0], n->C};
-    long long* dst[3] = {n->A64, n->B64, n->C64};
-    for (int q = 0; q < 3; ++q)
-      c->timed("nifs_to_small", 40ull * n->total * np, [&] {
-        hipLaunchKernelGGL(spk::k_to_small, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, src[q], (unsigned long long)n->total, dst[q], n->d_flags);
-      });
-    std::vector<unsigned char> flags(n->total);
-    SP_HIP(hipMemcpyAsync(flags.data(), n->d_flags, n->total, hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(hipStreamSynchronize(c->stream));
-    std::vector<unsigned> large;
-    for (size_t k = 0; k < n->total; ++k)
-      if (flags[k]) large.push_back((unsigned)k);
-    n->nlarge = (unsigned)large.size();
-    if (n->nlarge) {
-      SP_HIP(hipMemcpyAsync(n->d_large, large.data(), large.size() * 4, hipMemcpyHostToDevice, c->stream));
-      for (int q = 0; q < 3; ++q)
-        hipLaunchKernelGGL(spk::k_small_mask, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, dst[q], (unsigned long long)n->total, n->d_flags);
-      SP_HIP(hipStreamSynchronize(c->stream));
-    }
+  if (small_values == 1 || (small_values == 2 && !n->mirrors_ready)) {
+    int prc = sp_nifs_prepare_small(n);
+    if (prc) return prc;
   }
+  if (!n->small) n->nlarge = 0;
   // c_vals (:652-703): the local entries of the batch-wide vector (a sharded caller all-gathers the rest, sp_nifs_set_cvals)
   n->c_vals.assign(size_t(1) << ell_b, fe_zero());
   fe_t* cv_local = n->c_vals.data() + n->first;

@@ -149,6 +149,13 @@ class Table:
         z = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 4)
         check(lib().sp_table_write(self.ctx.h, self.h, ctypes.c_size_t(off), p64(z), ctypes.c_size_t(z.shape[0])))
 
+    def set_len(self, n, lo_eff=SIZE_MAX, hi_eff=SIZE_MAX):
+        """logical length + MultilinearPolynomial::new_with_halves bounds (src/polys/multilinear.rs:62-76)"""
+        check(lib().sp_table_set_len(self.h, ctypes.c_size_t(n), ctypes.c_size_t(lo_eff), ctypes.c_size_t(hi_eff)))
+
+    def copy_from(self, dst_off, src: "Table", src_off, cnt):
+        check(lib().sp_table_copy(self.ctx.h, self.h, ctypes.c_size_t(dst_off), src.h, ctypes.c_size_t(src_off), ctypes.c_size_t(cnt)))
+
     def bind_top(self, r):
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
         check(lib().sp_table_bind_top(self.ctx.h, self.h, p64(r)))

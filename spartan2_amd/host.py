@@ -171,7 +171,25 @@ def tensor_decomp(n: int):
     return ell, 1 << ((ell + 1) // 2), 1 << (ell // 2)
 
 
-def nifs_prove(ctx: hip.Context, shape: hip.Shape, dims: dict, ck: hip.CommitmentKey, comms, X, W_tables, r_W, small_values: bool, tr: hip.Transcript, py_hook):
+def nifs_prepare(ctx: hip.Context, shape: hip.Shape, dims: dict, X, W_tables, small_values: bool):
+    """The prep_prove part of the NIFS (cached_step_matvec / cached_step_i64, src/neutronnova_zk.rs:1520-1600): layers (+ i64 mirrors) of the
+    instances. Returns an opaque handle for nifs_prove(prepared=...); free with nifs_free."""
+    n = len(W_tables)
+    d = dims["num_public"]
+    X = np.ascontiguousarray(X, dtype=np.uint64).reshape(n, d, 4)
+    d10 = (ctypes.c_uint64 * 10)(*[dims[k] for k in DIM_NAMES])
+    warr = (ctypes.c_void_p * n)(*[t.h for t in W_tables])
+    h = ctypes.c_void_p()
+    _check(lib().nn_nifs_prepare(ctx.h, shape.h, d10, ctypes.c_size_t(n), hip.p64(X.reshape(-1)) if d else None, warr, 1 if small_values else 0, ctypes.byref(h)))
+    return h
+
+
+def nifs_free(handle):
+    hip.lib().sp_nifs_free(handle)
+
+
+def nifs_prove(ctx: hip.Context, shape: hip.Shape, dims: dict, ck: hip.CommitmentKey, comms, X, W_tables, r_W, small_values: bool, tr: hip.Transcript, py_hook,
+               prepared=None):
     """NeutronNovaNIFS::prove (src/neutronnova_zk.rs:511-1273). comms (n, rows, 8), X (n, d, 4), W_tables: n resident witness tables,
     r_W (n, rows, 4); py_hook(t, coeffs (4,4)) -> r_b is the caller's `process_round`. Returns a dict of host arrays and device tables."""
     comms = np.ascontiguousarray(comms, dtype=np.uint64)
@@ -191,7 +209,7 @@ def nifs_prove(ctx: hip.Context, shape: hip.Shape, dims: dict, ck: hip.Commitmen
     warr = (ctypes.c_void_p * n)(*[t.h for t in W_tables])
     cb = _c_hook(py_hook)
     _check(lib().nn_nifs_prove(ctx.h, shape.h, d10, ck.h, ctypes.c_size_t(n), ctypes.c_size_t(rows), hip.p64(comms.reshape(-1)), hip.p64(X.reshape(-1)) if d else None,
-                               warr, hip.p64(r_W.reshape(-1)), 1 if small_values else 0, tr.h, cb, None, hip.p64(out["polys"]), hip.p64(out["r_bs"]),
+                               warr, hip.p64(r_W.reshape(-1)), 1 if small_values else 0, prepared, tr.h, cb, None, hip.p64(out["polys"]), hip.p64(out["r_bs"]),
                                hip.p64(out["E_eq"]), hip.p64(out["tail"]), hip.p64(out["folded_rW"]), hip.p64(out["folded_X"]), hip.p64(out["folded_comm"]),
                                tabs["A"].h, tabs["B"].h, tabs["C"].h, tabs["folded_W"].h))
     out["folded_X"] = out["folded_X"][:d]

@@ -25,9 +25,61 @@ struct NifsOutputs {
 };
 
 // Us: comm rows (n x rows affine) + X (n x d); Ws: resident witness tables (num_vars each) + blinds (n x rows)
+// Layers Az_b, Bz_b, Cz_b of every (padded) instance and, for small_values, their i64 mirrors: the transcript-independent part that the reference
+// caches in prep_prove (cached_step_matvec / cached_step_i64, src/neutronnova_zk.rs:1520-1600).
+static sp_nifs* nifs_prepare(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, size_t n, const fe_t* X, const sp_table* const* Ws, bool small_values) {
+  if (n == 0) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NIFS prepare: no instances");
+  const size_t d = dims.num_public, num_vars = dims.num_shared + dims.num_precommitted + dims.num_rest;
+  size_t n_padded = 2;
+  while (n_padded < n) n_padded <<= 1;
+  auto inst = [&](size_t i) { return i < n ? i : 0; };
+  size_t ell_cons, left, right;
+  compute_tensor_decomp(dims.num_cons, &ell_cons, &left, &right);
+  sp_nifs* nifs = nullptr;
+  ck(sp_nifs_create(ctx, n_padded, left, right, &nifs), "nifs_create");
+  sp_table* z = nullptr;
+  try {
+    ck(sp_table_zeros(ctx, num_vars + 1 + d, (size_t)-1, (size_t)-1, &z), "z alloc");
+    const fe_t one = fe_one<S>();
+    for (size_t i = 0; i < n_padded; ++i) {  // z = [W | 1 | X]; (Az, Bz, Cz) straight into layer i (:583-596)
+      ck(sp_table_copy(ctx, z, 0, Ws[inst(i)], 0, num_vars), "z <- W");
+      std::vector<fe_t> tail(1 + d);
+      tail[0] = one;
+      for (size_t j = 0; j < d; ++j) tail[1 + j] = X[inst(i) * d + j];
+      ck(sp_table_write(ctx, z, num_vars, u64p(tail.data()), 1 + d), "z tail");
+      sp_table* v[3];
+      for (int q = 0; q < 3; ++q) ck(sp_nifs_layer(nifs, q, i, &v[q]), "nifs_layer");
+      int rc = sp_multiply_vec(ctx, shape, z, v[0], v[1], v[2]);
+      for (int q = 0; q < 3; ++q) sp_table_free(v[q]);
+      ck(rc, "multiply_vec");
+    }
+    if (small_values) ck(sp_nifs_prepare_small(nifs), "prepare_small");
+  } catch (...) {
+    sp_table_free(z);
+    sp_nifs_free(nifs);
+    throw;
+  }
+  sp_table_free(z);
+  return nifs;
+}
+
 static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const sp_ck* ckey, size_t n, size_t rows, const aff_t* comms, const fe_t* X,
-                       const sp_table* const* Ws, const fe_t* r_W, bool small_values, sp_transcript* tr, nn_round_hook hook, void* user, NifsOutputs& out) {
+                       const sp_table* const* Ws, const fe_t* r_W, bool small_values, sp_nifs* prepared, sp_transcript* tr, nn_round_hook hook, void* user,
+                       NifsOutputs& out) {
   if (n == 0) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NIFS prove: no instances");
+  static const bool trace = [] {
+    const char* e = getenv("SPARTAN_HOST_LAPS");
+    return e && e[0] == '1';
+  }();
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_lap = now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    sp_ctx_synchronize(ctx);
+    const double t = now();
+    fprintf(stderr, "nifs lap %-28s %8.3f ms\n", what, t - t_lap);
+    t_lap = t;
+  };
   const size_t d = dims.num_public, num_vars = dims.num_shared + dims.num_precommitted + dims.num_rest;
   size_t n_padded = 2;
   while (n_padded < n) n_padded <<= 1;
@@ -59,32 +111,15 @@ static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, 
   std::vector<fe_t> rhos(ell_b);
   for (auto& r : rhos) r = squeeze("rho");
 
-  sp_nifs* nifs = nullptr;
-  ck(sp_nifs_create(ctx, n_padded, left, right, &nifs), "nifs_create");
-  sp_table* z = nullptr;
+  lap("transcript preamble");
+  sp_nifs* nifs = prepared;
   struct Guard {
-    sp_nifs*& n;
-    sp_table*& z;
-    ~Guard() {
-      sp_nifs_free(n);
-      sp_table_free(z);
-    }
-  } guard{nifs, z};
-  ck(sp_table_zeros(ctx, num_vars + 1 + d, (size_t)-1, (size_t)-1, &z), "z alloc");
-  const fe_t one = fe_one<S>();
-  for (size_t i = 0; i < n_padded; ++i) {  // z = [W | 1 | X]; (Az, Bz, Cz) straight into layer i (:583-596)
-    ck(sp_table_copy(ctx, z, 0, Ws[inst(i)], 0, num_vars), "z <- W");
-    std::vector<fe_t> tail(1 + d);
-    tail[0] = one;
-    for (size_t j = 0; j < d; ++j) tail[1 + j] = X[inst(i) * d + j];
-    ck(sp_table_write(ctx, z, num_vars, u64p(tail.data()), 1 + d), "z tail");
-    sp_table* v[3];
-    for (int q = 0; q < 3; ++q) ck(sp_nifs_layer(nifs, q, i, &v[q]), "nifs_layer");
-    int rc = sp_multiply_vec(ctx, shape, z, v[0], v[1], v[2]);
-    for (int q = 0; q < 3; ++q) sp_table_free(v[q]);
-    ck(rc, "multiply_vec");
-  }
-  ck(sp_nifs_begin(nifs, out.E_eq, u64p(rhos.data()), ell_b, small_values ? 1 : 0), "nifs_begin");
+    sp_nifs* n;
+    ~Guard() { sp_nifs_free(n); }
+  } guard{prepared ? nullptr : (nifs = nifs_prepare(ctx, shape, dims, n, X, Ws, small_values))};
+  lap("layers");
+  ck(sp_nifs_begin(nifs, out.E_eq, u64p(rhos.data()), ell_b, small_values ? 2 : 0), "nifs_begin");
+  lap("begin (mirrors, c_vals)");
   std::vector<fe_t> r_bs(ell_b);
   for (size_t t = 0; t < ell_b; ++t) {
     uint64_t* co = out.polys + 16 * t;
@@ -92,6 +127,7 @@ static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, 
     hook(user, t, co, u64p(&r_bs[t]));
     ck(sp_nifs_challenge(nifs, u64p(&r_bs[t])), "nifs_challenge");
   }
+  lap("rounds");
   memcpy(out.r_bs, r_bs.data(), ell_b * sizeof(fe_t));
   ck(sp_nifs_finish(nifs, out.A, out.B, out.C, out.tail, out.tail + 4), "nifs_finish");
   {
@@ -99,6 +135,7 @@ static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, 
     memcpy(fin, out.tail, 64);
     hook(user, ell_b, fin, ignored);
   }
+  lap("finish");
   // fold_witnesses (:1212-1231): truncated to shared + precommitted when that prefix is non-empty, rest re-zeroed
   const size_t effective_len = dims.num_shared + dims.num_precommitted;
   const bool truncated = effective_len > 0;
@@ -110,6 +147,7 @@ static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, 
   ck(sp_fold_tables(ctx, wt.data(), n_padded, u64p(w.data()), dim, out.folded_W), "fold_multiple");
   if (dim < num_vars) ck(sp_table_zero(ctx, out.folded_W, dim, num_vars - dim), "zero rest");
   ck(sp_table_set_len(out.folded_W, num_vars, (size_t)-1, (size_t)-1), "set_len");
+  lap("fold_multiple");
   std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());  // fold_blinds (hyrax_pc.rs:795-818), X fold (:1236-1245)
   for (size_t i = 0; i < n_padded; ++i) {
     for (size_t r = 0; r < rows; ++r) f_rW[r] = fe_add<S>(f_rW[r], fe_mul<S>(r_W[inst(i) * rows + r], w[i]));
@@ -126,6 +164,7 @@ static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, 
   if (data_rows) ck(sp_msm_shared_weights(ctx, u64p(w.data()), n_padded, (const uint64_t*)bases.data(), data_rows, out.folded_comm), "fold_commitments");
   if (data_rows < rows)  // rest rows: folded_blind[row] * h
     ck(sp_fixed_base_mul_h(ctx, ckey, u64p(f_rW.data() + data_rows), rows - data_rows, out.folded_comm + 8 * data_rows), "rest rows");
+  lap("fold_commitments");
 }
 
 }  // namespace spartan2
@@ -136,17 +175,34 @@ extern "C" {
 const char* ss_last_error();
 void ss_set_error(const char* msg);
 
+// the prep_prove part of the NIFS: layers (and i64 mirrors) of the instances; free with sp_nifs_free
+int nn_nifs_prepare(sp_ctx* ctx, const sp_shape* S, const uint64_t dims10[10], size_t n, const uint64_t* X, const sp_table* const* Ws, int small_values, sp_nifs** out) {
+  try {
+    sp_dims dims;
+    memcpy(&dims, dims10, sizeof(sp_dims));
+    *out = nifs_prepare(ctx, S, dims, n, (const fe_t*)X, Ws, small_values != 0);
+    return SP_OK;
+  } catch (const Error& e) {
+    ss_set_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    ss_set_error(e.what());
+    return SP_ERR_INTERNAL;
+  }
+}
+
 // dims10 = sp_dims as ten uint64 (ss_padded_dims order). comms: n x rows affine; X: n x num_public; Ws: n resident witness tables; r_W: n x rows.
 // out_* buffers: polys ell_b x 16, r_bs ell_b x 4, E_eq (left + right) x 4, tail 8, folded_rW rows x 4, folded_X d x 4, folded_comm rows x 8.
+// prepared: the object nn_nifs_prepare returned for these instances (consumed by the rounds; the caller frees it), or NULL to build the layers here
 int nn_nifs_prove(sp_ctx* ctx, const sp_shape* S, const uint64_t dims10[10], const sp_ck* ckey, size_t n, size_t rows, const uint64_t* comms, const uint64_t* X,
-                  const sp_table* const* Ws, const uint64_t* r_W, int small_values, sp_transcript* tr, nn_round_hook hook, void* user, uint64_t* out_polys,
+                  const sp_table* const* Ws, const uint64_t* r_W, int small_values, sp_nifs* prepared, sp_transcript* tr, nn_round_hook hook, void* user, uint64_t* out_polys,
                   uint64_t* out_r_bs, uint64_t* out_E, uint64_t* out_tail, uint64_t* out_folded_rW, uint64_t* out_folded_X, uint64_t* out_folded_comm,
                   sp_table* out_A, sp_table* out_B, sp_table* out_C, sp_table* out_folded_W) {
   try {
     sp_dims dims;
     memcpy(&dims, dims10, sizeof(sp_dims));
     NifsOutputs o{out_polys, out_r_bs, out_E, out_tail, out_folded_rW, out_folded_X, out_folded_comm, out_A, out_B, out_C, out_folded_W};
-    nifs_prove(ctx, S, dims, ckey, n, rows, (const aff_t*)comms, (const fe_t*)X, Ws, (const fe_t*)r_W, small_values != 0, tr, hook, user, o);
+    nifs_prove(ctx, S, dims, ckey, n, rows, (const aff_t*)comms, (const fe_t*)X, Ws, (const fe_t*)r_W, small_values != 0, prepared, tr, hook, user, o);
     return SP_OK;
   } catch (const Error& e) {
     ss_set_error(e.what());
