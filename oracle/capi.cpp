@@ -48,6 +48,16 @@ static void store_aff(uint64_t* p, const Affine& a) {
 extern "C" {
 
 const char* orc_last_error() { return g_err.c_str(); }
+// thread count of the OpenMP loops (0 = all host cores); returns the count in effect. Results never depend on it (exact arithmetic).
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  static const int all = omp_get_max_threads() < 64 ? omp_get_max_threads() : 64;  // beyond this the short loops only pay for the fork/join
+  omp_set_num_threads(n > 0 ? n : all);
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 // ---- field ------------------------------------------------------------------------------------
 // field_id: 0 = T256 scalar (P-256 base prime), 1 = T256 base, 2 = Pallas scalar

@@ -13,6 +13,9 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <string>
 #include <vector>
 
@@ -257,5 +260,27 @@ struct FqPallasTag {
 typedef Fe<FqT256Tag> Fq;  // scalars of the bench engine
 typedef Fe<FpT256Tag> Fp;  // curve coordinates of the bench engine
 typedef Fe<FqPallasTag> FqPallas;
+
+// Parallel sum of K field accumulators over i in [0, n): body(i, acc) adds item i into acc[0..K). Field addition is exact, so the thread
+// count never changes the result (the reference's rayon fold/reduce, e.g. src/sumcheck.rs:1045-1100).
+template <class F, int K, class Body>
+inline void par_sum(size_t n, size_t min_parallel, Body body, F (&out)[K]) {
+  for (int k = 0; k < K; ++k) out[k] = F::zero();
+#ifdef _OPENMP
+  if (n >= min_parallel && omp_get_max_threads() > 1) {
+#pragma omp parallel
+    {
+      F local[K];
+      for (int k = 0; k < K; ++k) local[k] = F::zero();
+#pragma omp for schedule(static) nowait
+      for (size_t i = 0; i < n; ++i) body(i, local);
+#pragma omp critical
+      for (int k = 0; k < K; ++k) out[k] = out[k] + local[k];
+    }
+    return;
+  }
+#endif
+  for (size_t i = 0; i < n; ++i) body(i, out);
+}
 
 }  // namespace oracle

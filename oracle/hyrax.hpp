@@ -58,6 +58,7 @@ inline HyraxBlind hyrax_blind(const HyraxKey& ck, size_t n, Tape& tape) {  // hy
 inline HyraxCommitment hyrax_commit(const HyraxKey& ck, const Fq* v, size_t n, const HyraxBlind& r, bool is_small) {
   size_t num_rows = div_ceil(n, ck.num_cols);
   HyraxCommitment comm(num_rows);
+#pragma omp parallel for schedule(dynamic) if (num_rows >= 4)  // rows are independent (hyrax_pc.rs:230: par_iter over rows)
   for (size_t i = 0; i < num_rows; ++i) {
     size_t lower = i * ck.num_cols, upper = std::min(lower + ck.num_cols, n);
     const Fq* sc = v + lower;
@@ -194,8 +195,12 @@ inline bool ipa_verify(const IpaProof& pf, const std::vector<Affine>& ck, const 
 // hyrax_pc.rs:38-54
 inline std::vector<Fq> bind_with_delayed(const Fq* poly, const std::vector<Fq>& l, size_t r_len) {
   std::vector<Fq> acc(r_len, Fq::zero());
-  for (size_t j = 0; j < l.size(); ++j)
-    for (size_t i = 0; i < r_len; ++i) acc[i] = acc[i] + l[j] * poly[j * r_len + i];
+#pragma omp parallel for schedule(static) if (r_len * l.size() >= 65536)
+  for (size_t i = 0; i < r_len; ++i) {
+    Fq a = Fq::zero();
+    for (size_t j = 0; j < l.size(); ++j) a = a + l[j] * poly[j * r_len + i];
+    acc[i] = a;
+  }
   return acc;
 }
 

@@ -73,21 +73,27 @@ inline Jac cpu_msm_serial(const Fq* coeffs, const Affine* bases, size_t len) {
     for (size_t j = 0; j < n; ++j) digits[segments * n + j] = carry[j];
     total_segments = segments + 1;
   }
-  std::vector<Jac> buckets(half);
-  Jac acc = Jac::identity();
-  for (size_t seg = total_segments; seg-- > 0;) {
-    for (size_t k = 0; k < c; ++k) acc = acc.dbl();
-    for (auto& b : buckets) b = Jac::identity();
+  // window sums (independent, so they may run on several threads), then the Horner over windows (:150-175)
+  std::vector<Jac> wsum(total_segments);
+#pragma omp parallel for schedule(dynamic) if (n >= 256)
+  for (size_t seg = 0; seg < total_segments; ++seg) {
+    std::vector<Jac> buckets(half, Jac::identity());
     for (size_t j = 0; j < n; ++j) {
       int d = digits[seg * n + j];
       if (d > 0) buckets[d - 1] = buckets[d - 1].add_mixed(nb[j]);
       else if (d < 0) buckets[-d - 1] = buckets[-d - 1].add_mixed(affine_neg(nb[j]));
     }
-    Jac running = Jac::identity();
+    Jac running = Jac::identity(), w = Jac::identity();
     for (size_t k = half; k-- > 0;) {
       running = running.add(buckets[k]);
-      acc = acc.add(running);
+      w = w.add(running);
     }
+    wsum[seg] = w;
+  }
+  Jac acc = Jac::identity();
+  for (size_t seg = total_segments; seg-- > 0;) {
+    for (size_t k = 0; k < c; ++k) acc = acc.dbl();
+    acc = acc.add(wsum[seg]);
   }
   return boolean_sum.add(acc);
 }

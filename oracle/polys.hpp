@@ -20,6 +20,7 @@ std::vector<F> eq_evals_from_points(const std::vector<F>& r) {
   size_t size = 1;
   evals[0] = F::one();
   for (size_t k = ell; k-- > 0;) {
+#pragma omp parallel for schedule(static) if (size >= 8192)
     for (size_t i = 0; i < size; ++i) {
       F y = evals[i] * r[k];
       evals[size + i] = y;
@@ -58,13 +59,19 @@ struct MultilinearPolynomial {
     size_t lo = std::min(lo_eff, n), hi = std::min(hi_eff, n);
     size_t eff = std::max(lo, hi);
     F one_minus_r = F::one() - r;
+    // (the OpenMP loops mirror the reference's rayon par_iter_mut, :130-136; element-wise, so the result is thread-count independent)
     if (hi == 0) {
+#pragma omp parallel for schedule(static) if (lo >= 4096)
       for (size_t i = 0; i < lo; ++i) Z[i] = Z[i] * one_minus_r;
     } else if (hi <= lo) {
+#pragma omp parallel for schedule(static) if (hi >= 4096)
       for (size_t i = 0; i < hi; ++i) Z[i] = Z[i] + r * (Z[n + i] - Z[i]);
+#pragma omp parallel for schedule(static) if (lo - hi >= 4096)
       for (size_t i = hi; i < lo; ++i) Z[i] = Z[i] * one_minus_r;
     } else {
+#pragma omp parallel for schedule(static) if (lo >= 4096)
       for (size_t i = 0; i < lo; ++i) Z[i] = Z[i] + r * (Z[n + i] - Z[i]);
+#pragma omp parallel for schedule(static) if (hi - lo >= 4096)
       for (size_t i = lo; i < hi; ++i) Z[i] = r * Z[n + i];
     }
     Z.resize(n);

@@ -6,6 +6,7 @@
 // multiply_vec_incremental_into :1170-1211, bind_and_prepare_poly_ABC :1235-1398,
 // evaluate_with_tables_fast :1216-1226 by value).
 #pragma once
+#include <algorithm>
 #include <stdexcept>
 #include <vector>
 
@@ -112,6 +113,7 @@ struct PrecomputedSparseMatrix {  // sparse.rs:29-45
   std::vector<F> multiply_vec(const std::vector<F>& v) const {  // sparse.rs:221-233
     if (v.size() != num_cols) throw std::runtime_error("multiply_vec: invalid shape");
     std::vector<F> out(num_rows);
+#pragma omp parallel for schedule(static) if (num_rows >= 4096)  // rows parallel above 4096 (sparse.rs:223)
     for (size_t r = 0; r < num_rows; ++r) out[r] = compute_row_single(r, v);
     return out;
   }
@@ -238,6 +240,30 @@ struct SplitR1CSShape {  // src/r1cs/mod.rs:743-773
     if (rx.size() != num_cons) throw std::runtime_error("poly_ABC: rx length");
     F r2 = r * r;
     std::vector<F> out(out_len, F::zero());
+#ifdef _OPENMP
+    const int T = num_cons_unpadded >= 8192 ? std::min(omp_get_max_threads(), 16) : 1;  // full-length accumulator per thread: keep it bounded
+    if (T > 1) {  // per-thread full-length accumulators, then a vector reduce — the reference's structure (:1299-1319)
+      std::vector<std::vector<F>> part(T, std::vector<F>(out_len, F::zero()));
+#pragma omp parallel num_threads(T)
+      {
+        std::vector<F>& mine = part[omp_get_thread_num()];
+#pragma omp for schedule(static)
+        for (size_t row = 0; row < num_cons_unpadded; ++row) {
+          F rx_row = rx[row];
+          accumulate_matrix(pa, row, rx_row, mine);
+          accumulate_matrix(pb, row, rx_row * r, mine);
+          accumulate_matrix(pc, row, rx_row * r2, mine);
+        }
+      }
+#pragma omp parallel for schedule(static)
+      for (size_t j = 0; j < out_len; ++j) {
+        F a = F::zero();
+        for (int t = 0; t < T; ++t) a = a + part[t][j];
+        out[j] = a;
+      }
+      return out;
+    }
+#endif
     for (size_t row = 0; row < num_cons_unpadded; ++row) {
       F rx_row = rx[row];
       accumulate_matrix(pa, row, rx_row, out);

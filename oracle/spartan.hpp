@@ -12,6 +12,9 @@
 // digest is Keccak-256 over the S.write_bytes() stream only (src/r1cs/mod.rs:775-794,
 // src/r1cs/sparse.rs:398-417), absorbed as 32 raw bytes under the same label "vk".
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <vector>
 
@@ -140,6 +143,14 @@ struct SpartanProof {  // SpartanSNARK, src/spartan.rs:130-138
 // src/spartan.rs:219-466
 inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep& ps, const std::vector<Fq>& public_values, Tape& tape) {
   const SplitR1CSShape<Fq>& S = pk.S;
+  static const bool trace = getenv("ORACLE_TRACE") != nullptr;  // phase timeline on stderr
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "oracle lap %-22s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   Transcript tr("SpartanSNARK");
   tr.absorb_bytes("vk", pk.vk_digest, 32);
   tr.absorb_scalars("public_values", public_values.data(), public_values.size());
@@ -179,9 +190,11 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   std::vector<Fq> tau(num_rounds_x);
   for (auto& t : tau) t = tr.squeeze<Fq>("t");
 
+  lap("witness_commit");
   std::vector<Fq> az, bz, cz;
   S.multiply_vec_incremental_into(z, ps.cached_az, ps.cached_bz, ps.cached_cz, &az, &bz, &cz);
   MultilinearPolynomial<Fq> pAz(az), pBz(bz), pCz(cz);
+  lap("matvec");
 
   SpartanProof proof;
   proof.comm_W = comm_W;
@@ -192,11 +205,13 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   prove_cubic_with_three_inputs(Fq::zero(), tau, pAz, pBz, pCz, tr, &proof.sc_proof_outer, &r_x, &claims_outer);
   for (int i = 0; i < 3; ++i) proof.claims_outer[i] = claims_outer[i];
   tr.absorb_scalars("claims_outer", claims_outer.data(), 3);
+  lap("outer_sumcheck");
 
   Fq r = tr.squeeze<Fq>("r");
   Fq claim_inner_joint = claims_outer[0] + r * claims_outer[1] + r * r * claims_outer[2];
   std::vector<Fq> evals_rx = eq_evals_from_points(r_x);
   std::vector<Fq> poly_ABC = S.bind_and_prepare_poly_ABC(evals_rx, r);
+  lap("eq + poly_ABC");
 
   // manual inner round 0 (src/spartan.rs:323-384)
   size_t num_extra = S.num_extra();
@@ -245,10 +260,12 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   if (denom.is_zero()) throw std::runtime_error("DivisionByZero");
   proof.eval_W = (eval_Z - r_y[0] * eval_X) * denom.inv();
 
+  lap("inner_sumcheck");
   HyraxBlind blind_eval_W = hyrax_blind(pk.ck_s, 1, tape);
   proof.blind_eval_W = blind_eval_W[0];
   HyraxCommitment comm_eval_W = hyrax_commit(pk.ck_s, &proof.eval_W, 1, blind_eval_W, false);
   proof.eval_arg = hyrax_prove(pk.ck, pk.ck_s, tr, comm_W, ps.W, r_W, r_y_tail, comm_eval_W, blind_eval_W, tape);
+  lap("pcs_prove");
   return proof;
 }
 

@@ -41,13 +41,13 @@ template <class F>
 void compute_eval_points_quad(const MultilinearPolynomial<F>& A, const MultilinearPolynomial<F>& B, F* eval0, F* tinf) {
   size_t full_len = A.Z.size() / 2;
   size_t len = std::min(std::min(A.eff_pairs(), B.eff_pairs()), full_len);
-  F a0 = F::zero(), ai = F::zero();
-  for (size_t i = 0; i < len; ++i) {
-    a0 = a0 + A.Z[i] * B.Z[i];
-    ai = ai + (A.Z[full_len + i] - A.Z[i]) * (B.Z[full_len + i] - B.Z[i]);
-  }
-  *eval0 = a0;
-  *tinf = ai;
+  F tot[2];
+  par_sum<F, 2>(len, 4096, [&](size_t i, F* acc) {
+    acc[0] = acc[0] + A.Z[i] * B.Z[i];
+    acc[1] = acc[1] + (A.Z[full_len + i] - A.Z[i]) * (B.Z[full_len + i] - B.Z[i]);
+  }, tot);
+  *eval0 = tot[0];
+  *tinf = tot[1];
 }
 
 // src/sumcheck.rs:190-247
@@ -132,10 +132,11 @@ struct EqSumCheckInstance {
         *em = ma * mb - mc;
       }
     };
+    F tot[3];
     if (round < first_half) {  // :1041-1105
       const std::vector<F>& el = poly_eq_left[first_half - round];
       const std::vector<F>& er = poly_eq_right[second_half];
-      for (size_t x_out = 0; x_out < el.size(); ++x_out) {
+      par_sum<F, 3>(el.size(), 4, [&](size_t x_out, F* acc) {
         F i0 = F::zero(), ii = F::zero(), im = F::zero();
         for (size_t x_in = 0; x_in < er.size(); ++x_in) {
           size_t id = (x_out << second_half) | x_in;
@@ -145,20 +146,23 @@ struct EqSumCheckInstance {
           ii = ii + er[x_in] * ei;
           if (tm1) im = im + er[x_in] * em;
         }
-        a0 = a0 + el[x_out] * i0;
-        ai = ai + el[x_out] * ii;
-        if (tm1) am = am + el[x_out] * im;
-      }
+        acc[0] = acc[0] + el[x_out] * i0;
+        acc[1] = acc[1] + el[x_out] * ii;
+        if (tm1) acc[2] = acc[2] + el[x_out] * im;
+      }, tot);
     } else {  // :1107-1147
       const std::vector<F>& er = poly_eq_right[init_num_vars - round];
-      for (size_t id = 0; id < half_p; ++id) {
+      par_sum<F, 3>(half_p, 4096, [&](size_t id, F* acc) {
         F e0, ei, em;
         elem(id, &e0, &ei, &em);
-        a0 = a0 + er[id] * e0;
-        ai = ai + er[id] * ei;
-        if (tm1) am = am + er[id] * em;
-      }
+        acc[0] = acc[0] + er[id] * e0;
+        acc[1] = acc[1] + er[id] * ei;
+        if (tm1) acc[2] = acc[2] + er[id] * em;
+      }, tot);
     }
+    a0 = tot[0];
+    ai = tot[1];
+    am = tot[2];
     *t0 = a0;
     *tinf = ai;
     if (tm1) *tm1 = am;
