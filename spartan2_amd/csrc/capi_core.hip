@@ -113,7 +113,7 @@ int sp_ctx_create(int device, sp_ctx** out) {
   c->device = device;
   SP_HIP(hipStreamCreate(&c->stream));
   SP_HIP(hipStreamCreate(&c->stream2));
-  c->pinned_elems = 64;
+  c->pinned_elems = spk::SLOT_BASE_ELEM + 4 * spk::HOST_SUM_MAX_BLOCKS;
   SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
   memset(c->h_pinned, 0, c->pinned_elems * sizeof(fe_t));
   SP_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
@@ -272,14 +272,39 @@ static int launch_bind(sp_ctx* c, sp_table** tabs, int nt, const fe_t& r) {
 // final sums publishes that number after the data, and the host polls for it.
 static unsigned next_seq(sp_ctx* c) { return ++c->result_seq; }
 static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
-  if (nblocks == 1) return;  // a one-block evaluation wrote its sums (and the sequence number) straight to the pinned buffer
+  if (nblocks <= (size_t)spk::HOST_SUM_MAX_BLOCKS) {  // the blocks write their sums into host slots; reduce_partials_wait adds them
+    c->pending_slots = (unsigned)nblocks;
+    return;
+  }
+  c->pending_slots = 0;
   hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
 }
 // `resident`: the result comes from the resident tail kernel, which is itself waiting for the host's next challenge — a stream synchronise
 // would never return, so the host keeps polling (bounded by wall-clock; the kernel gives up after 2 s as well).
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false) {
-  volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->h_pinned + spk::RESULT_FLAG_ELEM);
   const unsigned want = c->result_seq;
+  if (c->pending_slots && !resident) {  // per-block slots: wait for every block's sequence word, add on the host
+    const unsigned nb = c->pending_slots;
+    c->pending_slots = 0;
+    for (int k = 0; k < nacc; ++k) out_host[k] = fe_zero();
+    long spins = 0;
+    for (unsigned b = 0; b < nb; ++b) {
+      const fe_t* slot = c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b;
+      volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
+      while (*fl != want) {
+        if (++spins > 400000) {  // a few ms: fall back to a real synchronise (e.g. under a profiler)
+          SP_HIP(hipStreamSynchronize(c->stream));
+          if (*fl != want) return fail(SP_ERR_INTERNAL, "evaluation kernel did not deliver its block sums");
+        }
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], slot[k]);
+    }
+    return SP_OK;
+  }
+  c->pending_slots = 0;
+  volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(c->h_pinned + spk::RESULT_FLAG_ELEM);
   bool seen = false;
   for (int spin = 0; spin < 200000; ++spin) {  // ~ a few ms worst case, then fall back to a real synchronise
     if (*flag == want) {

@@ -44,6 +44,7 @@ struct sp_ctx {
     if (!fb_ev) hipEventCreateWithFlags(&fb_ev, hipEventDisableTiming);
     return fb_ev;
   }
+  unsigned pending_slots = 0;  // > 0: the launch in flight delivers per-block sums in that many host slots (kernels_poly.cuh emit_partials)
   unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.cuh publish_result)
   unsigned long long msm_jobs_issued[2] = {0, 0};
   hipEvent_t msm_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // completion event of the MSM job in each landing slot

@@ -20,6 +20,25 @@ __device__ __forceinline__ void publish_result(fe_t* result, unsigned seq) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(result + RESULT_FLAG_ELEM), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Block partials of an evaluation launch. Up to HOST_SUM_MAX_BLOCKS blocks: every block writes its NACC sums and the sequence number into its own
+// 128-byte slot of the mapped pinned buffer and the HOST adds them (a few dozen 256-bit additions) — no second-stage launch on the per-round
+// critical path. Larger grids store to device memory for k_sum_partials.
+constexpr int HOST_SUM_MAX_BLOCKS = 64;
+constexpr int SLOT_BASE_ELEM = 64;  // element index of slot 0 in the mapped buffer; slot b = 4 elements: sums[0..3), word 0 of the 4th = sequence
+template <int NACC>
+__device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __restrict__ partials, fe_t* __restrict__ mapped, unsigned seq) {
+  if (gridDim.x <= HOST_SUM_MAX_BLOCKS) {
+    fe_t* slot = mapped + SLOT_BASE_ELEM + 4 * blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) slot[k] = acc[k];
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned*>(slot + 3), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) partials[(size_t)blockIdx.x * NACC + k] = acc[k];
+  }
+}
+
 // ---- K1: bind the top variable of up to 4 tables with the same challenge -----------------------------------
 struct BindArgs {
   fe_t* z[4];
@@ -126,10 +145,7 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
 #pragma unroll
       for (int k = 0; k < NACC; ++k) acc[k] = fe_mul<S>(acc[k], eo);
     }
-    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * NACC;  // one block: its sums are the result
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) dst[k] = acc[k];
-    if (gridDim.x == 1) publish_result(single_out, seq);
+    emit_partials<NACC>(acc, partials, single_out, seq);
   }
 }
 
@@ -180,10 +196,7 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, f
       acc[0] = fe_mul<S>(acc[0], eo);
       acc[1] = fe_mul<S>(acc[1], eo);
     }
-    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
-    dst[0] = acc[0];
-    dst[1] = acc[1];
-    if (gridDim.x == 1) publish_result(single_out, seq);
+    emit_partials<2>(acc, partials, single_out, seq);
   }
 }
 // dense quadratic variant (both tables fully non-zero)
@@ -211,10 +224,7 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
-    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
-    dst[0] = acc[0];
-    dst[1] = acc[1];
-    if (gridDim.x == 1) publish_result(single_out, seq);
+    emit_partials<2>(acc, partials, single_out, seq);
   }
 }
 
@@ -319,10 +329,7 @@ __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, c
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
-    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 2;
-    dst[0] = acc[0];
-    dst[1] = acc[1];
-    if (gridDim.x == 1) publish_result(single_out, seq);
+    emit_partials<2>(acc, partials, single_out, seq);
   }
 }
 
@@ -361,11 +368,7 @@ __global__ void __launch_bounds__(256) k_eval_cubic_outer_pow(const fe_t* __rest
   }
   block_sum<3>(acc, smem);
   if (threadIdx.x == 0) {
-    fe_t* dst = gridDim.x == 1 ? single_out : partials + (size_t)blockIdx.x * 3;
-    dst[0] = acc[0];
-    dst[1] = acc[1];
-    dst[2] = acc[2];
-    if (gridDim.x == 1) publish_result(single_out, seq);
+    emit_partials<3>(acc, partials, single_out, seq);
   }
 }
 
@@ -378,8 +381,7 @@ __global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const f
     acc[0] = fe_add<S>(acc[0], fe_mul<S>(A[i], B[i]));
   block_sum<1>(acc, smem);
   if (threadIdx.x == 0) {
-    (gridDim.x == 1 ? single_out : partials + blockIdx.x)[0] = acc[0];
-    if (gridDim.x == 1) publish_result(single_out, seq);
+    emit_partials<1>(acc, partials, single_out, seq);
   }
 }
 
