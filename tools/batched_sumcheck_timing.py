@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+"""Per-round cost of the batched ZK sum-check drivers (sp_sumcheck_cubic_outer_pow_batched / sp_sumcheck_quad_batched) with a trivial hook."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 from spartan2_amd import hip, host
 ctx=hip.Context(0)

@@ -1,6 +1,6 @@
 import sys, os
 os.environ["SPARTAN_ROUND_TRACE"]="1"
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np
 from spartan2_amd import frontend, hip, host
 inst=frontend.sha256_circuit(bytes(2048))
