@@ -101,7 +101,12 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
     if (lane == 0) c->timed(what, bytes, f);
     else f();
   };
-  run("msm_sort", 32ull * n, [&] { hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, st, d_canon, (unsigned)n, order, start); });
+  signed char* digits = (signed char*)c->workspace(sp_ctx::WS_MSM_DIGITS, (size_t)windows * n, lane);
+  if (!digits) return SP_ERR_NO_DEVICE;
+  run("msm_sort", 32ull * n, [&] {
+    hipLaunchKernelGGL(spk::k_msm_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_canon, (unsigned)n, windows, digits);
+    hipLaunchKernelGGL(spk::k_msm_sort_digits, dim3(windows), dim3(256), 0, st, digits, d_canon, (unsigned)n, order, start);
+  });
   unsigned lanes = (unsigned)windows * spk::MSM_BUCKETS * spk::MSM_LANES_PER_BUCKET;
   run("msm_bucket_sum", 96ull * n, [&] {
     hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256), dim3(256), 0, st, d_bases, (unsigned)n, order, start, windows, buckets);

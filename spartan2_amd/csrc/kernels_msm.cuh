@@ -93,6 +93,71 @@ __device__ __forceinline__ int signed_digit(const fe_t& c, int w) {
   return d;
 }
 
+// All signed digits of a scalar in one pass (the carry is a sequential chain over the windows): digits[w * n + j], bit 7 of the SIGN byte array is not
+// needed — the fold sign lives in the scalar. Fully unrolled, so the limbs stay in registers (the per-window form above indexes them dynamically).
+__global__ void __launch_bounds__(256) k_msm_digits(const fe_t* __restrict__ canon, unsigned n, int windows, signed char* __restrict__ digits) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const fe_t c = canon[j];
+  int carry = 0;
+#pragma unroll
+  for (int k = 0; k < MSM_MAX_WINDOWS; ++k) {
+    if (k < windows) {
+      int raw = (k < 32) ? (int)((c.v[k >> 2] >> (8 * (k & 3))) & (k == 31 ? 0x7f : 0xff)) : 0;
+      raw += carry;
+      int d;
+      if (raw >= 128) {
+        d = raw - 256;
+        carry = 1;
+      } else {
+        d = raw;
+        carry = 0;
+      }
+      digits[(size_t)k * n + j] = (signed char)d;
+    }
+  }
+}
+// k_msm_sort on precomputed digits
+__global__ void __launch_bounds__(256) k_msm_sort_digits(const signed char* __restrict__ digits, const fe_t* __restrict__ canon, unsigned n,
+                                                         unsigned* __restrict__ order, unsigned* __restrict__ start) {
+  __shared__ unsigned hist[MSM_BUCKETS + 1];
+  __shared__ unsigned cursor[MSM_BUCKETS];
+  const int w = blockIdx.x;
+  const signed char* dg = digits + (size_t)w * n;
+  for (int k = threadIdx.x; k <= MSM_BUCKETS; k += blockDim.x) hist[k] = 0;
+  __syncthreads();
+  for (unsigned j = threadIdx.x; j < n; j += blockDim.x) {
+    const int d = dg[j];
+    if (d) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // exclusive prefix over the 128 counts by one wave (two per lane + a shuffle scan)
+    const unsigned a = hist[2 * threadIdx.x], b = hist[2 * threadIdx.x + 1];
+    unsigned incl = a + b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off, 64);
+      if ((int)threadIdx.x >= off) incl += o;
+    }
+    const unsigned excl = incl - (a + b);
+    hist[2 * threadIdx.x] = excl;
+    hist[2 * threadIdx.x + 1] = excl + a;
+    cursor[2 * threadIdx.x] = excl;
+    cursor[2 * threadIdx.x + 1] = excl + a;
+    if (threadIdx.x == 63) hist[MSM_BUCKETS] = incl;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k <= MSM_BUCKETS; k += blockDim.x) start[(size_t)w * (MSM_BUCKETS + 1) + k] = hist[k];
+  for (unsigned j = threadIdx.x; j < n; j += blockDim.x) {
+    const int d = dg[j];
+    if (d) {
+      unsigned pos = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
+      const bool neg = (d < 0) != ((canon[j].v[7] >> 31) != 0);
+      order[(size_t)w * n + pos] = j | (neg ? 0x80000000u : 0u);
+    }
+  }
+}
+
 // One block per window. Outputs, per window w: order[w*n + pos] = base index | (negate << 31), grouped by bucket;
 // start[w*(BUCKETS+1) + k] = first position of bucket k+1's list (k = |digit| - 1).
 __global__ void __launch_bounds__(256) k_msm_sort(const fe_t* __restrict__ canon, unsigned n, unsigned* __restrict__ order,
