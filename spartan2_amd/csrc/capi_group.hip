@@ -1,6 +1,7 @@
 // libspartan_hip.so — group / MSM / Hyrax entry points of include/spartan_hip.h.
 // Device: digit sort, bucket accumulation, per-window weighted reduction, binary row sums, fixed-base lookups,
 // row-matrix product. Host (inside the library): window Horner, adding the blind term, batch normalisation.
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -111,7 +112,14 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
   run("msm_bucket_sum", 96ull * n, [&] {
     hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256), dim3(256), 0, st, d_bases, (unsigned)n, order, start, windows, buckets);
   });
-  run("msm_window_reduce", 0, [&] { hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows), dim3(spk::MSM_BUCKETS), 0, st, buckets, wsum); });
+  static const bool coop = [] {
+    const char* e = getenv("SPARTAN_MSM_COOP");
+    return !(e && e[0] == '0');
+  }();
+  run("msm_window_reduce", 0, [&] {
+    if (coop) hipLaunchKernelGGL(spk::k_msm_window_reduce_coop, dim3(windows), dim3(4 * spk::MSM_BUCKETS), 0, st, buckets, wsum);
+    else hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows), dim3(spk::MSM_BUCKETS), 0, st, buckets, wsum);
+  });
   pend->windows = windows;
   pend->slot = (int)(c->msm_jobs_issued[lane]++ % MSM_LANDING_SLOTS);
   // pinned landing buffer: a device->host copy into pageable memory would block the host until the MSM is done

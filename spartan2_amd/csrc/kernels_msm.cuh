@@ -224,6 +224,127 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict_
   if (bucket < total && sub == 0) buckets[bucket] = acc;
 }
 
+// ---- block-cooperative Jacobian addition ----------------------------------------------------------------------------------------------------
+// The MSM tail is a chain of DEPENDENT additions on few points; a lone wave issues the ~16 base-field products of one addition back to back
+// (~1 us each: the SIMD is saturated by one wave's quarter-rate 64-bit multiply-adds), ~15 us per addition. Here FOUR wave groups ("roles", each on
+// its own SIMD) share every addition: the products are scheduled in 5 dependency levels of <= 4, each role computes one product per level for
+// all ITEMS point pairs and the levels meet in LDS. Same add-2007-bl formula, same result; ~2.3x shorter chain.
+template <int ITEMS>
+struct CoopAdd {
+  fe_t t[9][ITEMS];   // z1z1 | z2z2 -> m1 | zz -> z3 | a -> s2 | u1 | u2 -> j | s1 | b -> v | i -> m2     (rr2 reuses slot 0)
+  jac_t fix[ITEMS];   // results of the special cases (identity operand, P = +-Q), computed while the inputs are still intact
+  int flag[ITEMS];
+};
+// All ITEMS * 4 threads of the block call this (it synchronises). role = threadIdx / ITEMS, i = threadIdx % ITEMS; P[i] += Q index given by the
+// caller as pointers into LDS; `active` = this item takes part. The sum is written to dst[i] (may alias P).
+template <int ITEMS>
+__device__ __forceinline__ void jac_add_block4(CoopAdd<ITEMS>& L, const jac_t* P, const jac_t* Q, jac_t* dst, int role, int i, bool active) {
+  fe_t(*t)[ITEMS] = L.t;
+  // level 1
+  if (active) {
+    if (role == 0) {
+      int f = 0;
+      if (jac_is_identity(*P)) {
+        L.fix[i] = *Q;
+        f = 1;
+      } else if (jac_is_identity(*Q)) {
+        L.fix[i] = *P;
+        f = 1;
+      }
+      L.flag[i] = f;
+      t[0][i] = fe_sqr<B>(P->z);
+    } else if (role == 1) {
+      t[1][i] = fe_sqr<B>(Q->z);
+    } else if (role == 2) {
+      t[2][i] = fe_sqr<B>(fe_add<B>(P->z, Q->z));
+    } else {
+      t[3][i] = fe_mul<B>(P->y, Q->z);
+    }
+  }
+  __syncthreads();
+  // level 2
+  if (active) {
+    if (role == 0) t[4][i] = fe_mul<B>(P->x, t[1][i]);
+    else if (role == 1) t[5][i] = fe_mul<B>(Q->x, t[0][i]);
+    else if (role == 2) t[6][i] = fe_mul<B>(t[3][i], t[1][i]);
+    else t[7][i] = fe_mul<B>(Q->y, P->z);
+  }
+  __syncthreads();
+  // level 3: s2 | i | z3
+  if (active) {
+    if (role == 0) {
+      t[3][i] = fe_mul<B>(t[7][i], t[0][i]);
+    } else if (role == 1) {
+      const fe_t h2 = fe_dbl<B>(fe_sub<B>(t[5][i], t[4][i]));
+      t[8][i] = fe_sqr<B>(h2);
+    } else if (role == 2) {
+      const fe_t h = fe_sub<B>(t[5][i], t[4][i]);
+      t[2][i] = fe_mul<B>(fe_sub<B>(fe_sub<B>(t[2][i], t[0][i]), t[1][i]), h);
+    }
+  }
+  __syncthreads();
+  // level 4: j | v | rr^2  (+ the P = +-Q case, inputs still intact)
+  if (active) {
+    if (role == 0) {
+      const fe_t h = fe_sub<B>(t[5][i], t[4][i]);
+      if (fe_is_zero(h) && !L.flag[i]) {
+        const fe_t rr = fe_sub<B>(t[3][i], t[6][i]);
+        L.fix[i] = fe_is_zero(rr) ? jac_dbl(*P) : jac_identity();
+        L.flag[i] = 1;
+      }
+      t[5][i] = fe_mul<B>(h, t[8][i]);
+    } else if (role == 1) {
+      t[7][i] = fe_mul<B>(t[4][i], t[8][i]);
+    } else if (role == 2) {
+      const fe_t rr = fe_dbl<B>(fe_sub<B>(t[3][i], t[6][i]));
+      t[0][i] = fe_sqr<B>(rr);
+    }
+  }
+  __syncthreads();
+  // level 5: m1 | m2
+  if (active) {
+    if (role == 0) {
+      const fe_t rr = fe_dbl<B>(fe_sub<B>(t[3][i], t[6][i]));
+      const fe_t x3 = fe_sub<B>(fe_sub<B>(t[0][i], t[5][i]), fe_dbl<B>(t[7][i]));
+      t[1][i] = fe_mul<B>(rr, fe_sub<B>(t[7][i], x3));
+    } else if (role == 1) {
+      t[8][i] = fe_mul<B>(t[6][i], t[5][i]);
+    }
+  }
+  __syncthreads();
+  if (active && role == 0) {
+    jac_t r;
+    if (L.flag[i]) {
+      r = L.fix[i];
+    } else {
+      r.x = fe_sub<B>(fe_sub<B>(t[0][i], t[5][i]), fe_dbl<B>(t[7][i]));
+      r.y = fe_sub<B>(t[1][i], fe_dbl<B>(t[8][i]));
+      r.z = t[2][i];
+    }
+    dst[i] = r;
+  }
+  __syncthreads();
+}
+
+// per window: W = sum_k k B_k by suffix scan + tree as below, every addition shared by four wave groups (512 threads per window)
+__global__ void __launch_bounds__(4 * MSM_BUCKETS) k_msm_window_reduce_coop(const jac_t* __restrict__ buckets, jac_t* __restrict__ window_sums) {
+  __shared__ CoopAdd<MSM_BUCKETS> L;
+  __shared__ jac_t s[MSM_BUCKETS];
+  const int w = blockIdx.x + blockIdx.y * gridDim.x;
+  const int role = threadIdx.x / MSM_BUCKETS, k = threadIdx.x % MSM_BUCKETS;
+  if (role == 0) s[k] = buckets[(size_t)w * MSM_BUCKETS + k];
+  __syncthreads();
+  for (int off = 1; off < MSM_BUCKETS; off <<= 1) {  // suffix scan: s_k += s_{k+off}; in place is safe, inputs are read in levels 1-2 only
+    const bool active = k + off < MSM_BUCKETS;
+    jac_add_block4<MSM_BUCKETS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+  }
+  for (int off = MSM_BUCKETS / 2; off >= 1; off >>= 1) {
+    const bool active = k < off;
+    jac_add_block4<MSM_BUCKETS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+  }
+  if (threadIdx.x == 0) window_sums[w] = s[0];
+}
+
 // per window: W = sum_{k=1..128} k * B_k = sum_k S_k with S_k = sum_{j >= k} B_j (suffix scan, then tree)
 __global__ void __launch_bounds__(MSM_BUCKETS) k_msm_window_reduce(const jac_t* __restrict__ buckets, jac_t* __restrict__ window_sums) {
   __shared__ jac_t s[MSM_BUCKETS];
