@@ -331,7 +331,10 @@ __global__ void __launch_bounds__(4 * MSM_BUCKETS) k_msm_window_reduce_coop(cons
   __shared__ CoopAdd<MSM_BUCKETS> L;
   __shared__ jac_t s[MSM_BUCKETS];
   const int w = blockIdx.x + blockIdx.y * gridDim.x;
-  const int role = threadIdx.x / MSM_BUCKETS, k = threadIdx.x % MSM_BUCKETS;
+  // wave -> (role, item block): wave % 4 is the SIMD a wave lands on, so the four roles of an item block sit on four different SIMDs and a level
+  // with <= 64 active items costs ONE product time; the second item block rotates its roles by two so the short levels (3 and 2 products) balance.
+  const int wave = threadIdx.x >> 6, blk = wave >> 2;
+  const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);
   if (role == 0) s[k] = buckets[(size_t)w * MSM_BUCKETS + k];
   __syncthreads();
   for (int off = 1; off < MSM_BUCKETS; off <<= 1) {  // suffix scan: s_k += s_{k+off}; in place is safe, inputs are read in levels 1-2 only
