@@ -180,16 +180,9 @@ def _worker_nifs(rank, world, port, q):
 def test_two_rank_gloo_nifs_rounds_sharded_match_the_unsharded_oracle():
     """8 instances over 2 ranks: two shard-local rounds with a 2-element exchange each, hand-off of one layer pair per rank, last round on
     rank 0 — round polynomials, challenges, folded layers and T_out equal the oracle's unsharded NeutronNovaNIFS::prove."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_nifs, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=300) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    import mp_util
+
+    res = mp_util.run_ranks(_worker_nifs, 2, timeout=300)
     assert res[1] is None
     assert res[0] == (True, True, True, True, True, True, 3)
 
@@ -242,15 +235,8 @@ def _worker_sumcheck(rank, world, port, q):
 def test_gloo_sumcheck_by_table_slice_matches_the_unsharded_oracle(world):
     """Tables sharded on their last log2(world) variables; one 2-element exchange per round; every rank finishes the last rounds on the gathered
     values and ends with the same polynomials, challenges, final evaluations and transcript state as the oracle's unsharded sum-checks."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_sumcheck, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=300) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    import mp_util
+
+    res = mp_util.run_ranks(_worker_sumcheck, world, timeout=300)
     for r in range(world):
         assert res[r] == (True,) * 7, (r, res[r])

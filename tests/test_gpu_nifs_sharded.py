@@ -79,14 +79,7 @@ def _worker(rank, world, port, q, n_inst, num_cons, small):
 
 @pytest.mark.parametrize("n_inst,num_cons,small", [(8, 64, False), (8, 1 << 16, True), (4, 1 << 9, False)])
 def test_two_ranks_on_one_gpu(n_inst, num_cons, small):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, n_inst, num_cons, small)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    import mp_util
+
+    res = mp_util.run_ranks(_worker, 2, (n_inst, num_cons, small))
     assert res[1] is None and res[0] == (True,) * 7

@@ -71,14 +71,7 @@ def _worker(rank, world, port, q, ell):
 
 @pytest.mark.parametrize("ell", [4, 12, 16])
 def test_two_ranks_on_one_gpu(ell):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, ell)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    import mp_util
+
+    res = mp_util.run_ranks(_worker, 2, (ell,))
     assert res[1] is None and res[0] == (True,) * 7
