@@ -689,6 +689,21 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
       sp::after_bind(A);
       sp::after_bind(B);
       have_sums = true;
+    } else if (round + 1 < rounds && A->len / 4 >= STREAM_MIN_Q && sp::eff_lo(A) == A->len / 2 && sp::eff_lo(B) == B->len / 2 && sp::eff_hi(A) <= A->len / 4 &&
+               sp::eff_hi(B) <= B->len / 4) {
+      // full low half, (almost) empty high half: bind without reading the zeros, evaluate the next round from registers
+      const size_t q = A->len / 4;
+      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
+      const unsigned seq = next_seq(c);
+      const fe_t one_minus_r = fe_sub<S>(fe_one<S>(), r_i);
+      c->timed("bind_stream_quad_sparse", 64ull * (A->len / 2) * 2, [&] {
+        hipLaunchKernelGGL(spk::k_bind_eval_quad_stream_sparse, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, r_i, one_minus_r, sp::eff_hi(A),
+                           sp::eff_hi(B), lp);
+      });
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+      sp::after_bind(A);
+      sp::after_bind(B);
+      have_sums = true;
     } else {
       rc = launch_bind(c, tabs, 2, r_i);
       if (rc) return rc;

@@ -280,6 +280,22 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict_
   B[id + q] = b1;
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(a0, b0))), lazy_wave_sum(lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)))), partials);
 }
+// The same for tables whose high half is zero beyond the first hiA / hiB entries (hi* <= q): the inner sum-check's first bind on z and poly_ABC
+// (2M long, non-zero up to M + num_extra; bind_poly_var_top's `hi <= lo` branch, src/polys/multilinear.rs:118-141). The high half is not read at
+// all except for those few entries, and the evaluation of the next round still comes from registers.
+__global__ void __launch_bounds__(256) k_bind_eval_quad_stream_sparse(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, fe_t one_minus_r, size_t hiA,
+                                                                      size_t hiB, lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const fe_t la0 = A[id], la1 = A[id + q], lb0 = B[id], lb1 = B[id + q];
+  const fe_t a0 = id < hiA ? bind1(la0, A[id + 2 * q], r) : fe_mul<S>(la0, one_minus_r);
+  const fe_t b0 = id < hiB ? bind1(lb0, B[id + 2 * q], r) : fe_mul<S>(lb0, one_minus_r);
+  const fe_t a1 = fe_mul<S>(la1, one_minus_r), b1 = fe_mul<S>(lb1, one_minus_r);  // id + q >= q >= hi*: partner is zero
+  A[id] = a0;
+  A[id + q] = a1;
+  B[id] = b0;
+  B[id + q] = b1;
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(a0, b0))), lazy_wave_sum(lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)))), partials);
+}
 // Second stage for the streaming kernels: per group of 2^group_log2 consecutive blocks, lazy-sum, reduce mod p, multiply by
 // eq_out[group] (when given), then a modular block sum over groups. One block.
 __global__ void __launch_bounds__(256) k_sum_partials_lazy(const lazy9_t* __restrict__ partials, size_t nparts, int group_log2,
