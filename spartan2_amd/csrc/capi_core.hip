@@ -283,7 +283,7 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
 // would never return, so the host keeps polling (bounded by wall-clock; the kernel gives up after 2 s as well).
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false) {
   const unsigned want = c->result_seq;
-  if (c->pending_slots && !resident) {  // per-block slots: wait for every block's sequence word, add on the host
+  if (c->pending_slots) {  // per-block slots: wait for every block's sequence word, add on the host
     const unsigned nb = c->pending_slots;
     c->pending_slots = 0;
     for (int k = 0; k < nacc; ++k) out_host[k] = fe_zero();
@@ -292,14 +292,36 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
       const fe_t* slot = c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b;
       volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
       while (*fl != want) {
-        if (++spins > 400000) {  // a few ms: fall back to a real synchronise (e.g. under a profiler)
-          SP_HIP(hipStreamSynchronize(c->stream));
+        if (++spins > 400000) {  // a few ms
+          if (resident) {        // the tail kernel is itself waiting for the host: keep polling, bounded by wall-clock
+            const auto t0 = std::chrono::steady_clock::now();
+            while (*fl != want) {
+              if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
+              __builtin_ia32_pause();
+            }
+            break;
+          }
+          SP_HIP(hipStreamSynchronize(c->stream));  // e.g. under a profiler
           if (*fl != want) return fail(SP_ERR_INTERNAL, "evaluation kernel did not deliver its block sums");
         }
         __builtin_ia32_pause();
       }
-      std::atomic_thread_fence(std::memory_order_acquire);
-      for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], slot[k]);
+      // the slot is valid once its check word matches the data (kernels_poly.cuh slot_store_tag): re-read until it does
+      fe_t v[3];
+      for (long tries = 0;; ++tries) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        uint32_t chk = want;
+        for (int k = 0; k < nacc; ++k) {
+          for (int i = 0; i < 8; ++i) {
+            v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
+            chk += v[k].v[i];
+          }
+        }
+        if (fl[1] == chk) break;
+        if (tries > 4000000) return fail(SP_ERR_INTERNAL, "evaluation kernel delivered an inconsistent result slot");
+        __builtin_ia32_pause();
+      }
+      for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], v[k]);
     }
     return SP_OK;
   }
@@ -342,11 +364,11 @@ static bool round_trace() {
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---- persistent tail (kernels_poly.cuh k_sumcheck_tail): host half of the mailbox ------------------------------------------------------
-static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident tail, 2..11 caps the table length it takes over
+static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident tail, 2..16 caps the table length it takes over
   static const size_t v = [] {
     const char* e = getenv("SPARTAN_TAIL_LOG2");
-    size_t lg = e ? (size_t)atoi(e) : 10;
-    if (lg > 12) lg = 12;
+    size_t lg = e ? (size_t)atoi(e) : 15;
+    if (lg > 16) lg = 16;  // 4 * TAIL_WIDE_Q pairs-of-pairs per block, HOST_SUM_MAX_BLOCKS result slots
     return lg < 2 ? (size_t)0 : (size_t)1 << lg;
   }();
   return v;
@@ -365,6 +387,11 @@ static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) 
   dst[9] = chk;
   std::atomic_thread_fence(std::memory_order_release);
   dst[8] = answers_seq;
+}
+// result slots (= resident blocks still active) of the evaluation over a table of `len` elements
+static unsigned tail_blocks(size_t len) {
+  const size_t q = len / 2;
+  return q <= spk::TAIL_WIDE_Q ? 1u : (unsigned)(q / spk::TAIL_WIDE_Q);
 }
 static int tail_check(sp_ctx* c) {
   volatile uint32_t* err = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM);
@@ -648,12 +675,13 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
     have_sums = false;
     if (in_tail) {  // the resident kernel binds (and evaluates the next round) as soon as it sees the challenge
       tail_post_challenge(c, r_i, c->result_seq);
+      sp::after_bind(A);
+      sp::after_bind(B);
       if (round + 1 < rounds) {
         next_seq(c);
         have_sums = true;
+        c->pending_slots = tail_blocks(A->len);
       }
-      sp::after_bind(A);
-      sp::after_bind(B);
     } else if (tail_enabled() && round + 1 < rounds && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B)) {
       spk::TailArgs ta;
       ta.A = A->d;
@@ -661,14 +689,16 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
       ta.C = nullptr;
       ta.len = A->len;
       ta.r0 = r_i;
-      ta.eq_pyr = nullptr;
+      ta.eq_pl = ta.eq_pr = nullptr;
+      ta.ell = ta.first_half = ta.rnd0 = 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
-      hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(1), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
       in_tail = true;
       have_sums = true;
       sp::after_bind(A);
       sp::after_bind(B);
+      c->pending_slots = tail_blocks(A->len);
     } else if (round + 1 < rounds && table_dense(A) && table_dense(B)) {
       // fused: bind this round, evaluate the next (K1 + K3 in one pass over the tables)
       const size_t q = A->len / 4;
@@ -996,25 +1026,33 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     claim = poly_eval(poly, r_i);
     if (in_tail) {
       tail_post_challenge(c, r_i, c->result_seq);
-      if (rnd < ell) next_seq(c);
       sp::after_bind(A);
       sp::after_bind(B);
       sp::after_bind(C);
-    } else if (tail_enabled() && rnd < ell && A->len <= TAIL_MAX_LEN && rnd + 1 >= first_half) {
+      if (rnd < ell) {
+        next_seq(c);
+        c->pending_slots = tail_blocks(A->len);
+      }
+    } else if (tail_enabled() && rnd < ell && A->len <= TAIL_MAX_LEN) {
       spk::TailArgs ta;
       ta.A = A->d;
       ta.B = B->d;
       ta.C = C->d;
       ta.len = A->len;
       ta.r0 = r_i;
-      ta.eq_pyr = d_pr;
+      ta.eq_pl = d_pl;
+      ta.eq_pr = d_pr;
+      ta.ell = (int)ell;
+      ta.first_half = (int)first_half;
+      ta.rnd0 = (int)rnd + 1;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
-      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(1), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
       in_tail = true;
       sp::after_bind(A);
       sp::after_bind(B);
       sp::after_bind(C);
+      c->pending_slots = tail_blocks(A->len);
     } else if (rnd < ell) {
       // K1 fused with next round's K2: bind with r_i, evaluate round rnd+1 from registers
       const size_t q = A->len / 4;

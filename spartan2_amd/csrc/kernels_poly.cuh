@@ -25,14 +25,31 @@ __device__ __forceinline__ void publish_result(fe_t* result, unsigned seq) {
 // critical path. Larger grids store to device memory for k_sum_partials.
 constexpr int HOST_SUM_MAX_BLOCKS = 64;
 constexpr int SLOT_BASE_ELEM = 64;  // element index of slot 0 in the mapped buffer; slot b = 4 elements: sums[0..3), word 0 of the 4th = sequence
+// A slot is self-validating: element 3 carries the sequence number (word 0) and a check word (word 1) = sequence + sum of the data words, so the
+// host accepts a slot only when all of it has landed, whatever order the stores reach host memory in, and the producer needs no fence for it.
+__device__ __forceinline__ unsigned slot_check_word(const fe_t& v) {
+  unsigned s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += v.v[i];
+  return s;
+}
+// (mapped host memory is uncached on the device side: plain stores go straight out, as two 16-byte writes per element and one 8-byte tag)
+__device__ __forceinline__ void slot_store_elem(fe_t* dst, const fe_t& v) { *dst = v; }
+__device__ __forceinline__ void slot_store_tag(fe_t* slot, unsigned seq, unsigned data_sum) {
+  const unsigned long long tag = ((unsigned long long)(seq + data_sum) << 32) | seq;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot[3].v[0]), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <int NACC>
 __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __restrict__ partials, fe_t* __restrict__ mapped, unsigned seq) {
   if (gridDim.x <= HOST_SUM_MAX_BLOCKS) {
     fe_t* slot = mapped + SLOT_BASE_ELEM + 4 * blockIdx.x;
+    unsigned chk = 0;
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) slot[k] = acc[k];
-    __threadfence_system();
-    __hip_atomic_store(reinterpret_cast<unsigned*>(slot + 3), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int k = 0; k < NACC; ++k) {
+      slot_store_elem(slot + k, acc[k]);
+      chk += slot_check_word(acc[k]);
+    }
+    slot_store_tag(slot, seq, chk);
   } else {
 #pragma unroll
     for (int k = 0; k < NACC; ++k) partials[(size_t)blockIdx.x * NACC + k] = acc[k];
@@ -423,13 +440,16 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
 // Slots in the mapped buffer: TAIL_CHAL_ELEM = the 64-byte mailbox line (challenge | sequence | check word), word 0 of TAIL_ERR_ELEM = error.
 constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10;
 constexpr int TAIL_THREADS = 1024;
-constexpr unsigned long long TAIL_WIDE_Q = 256;  // rounds with at most this many pairs use one lane per product (3 * 256 <= TAIL_THREADS)
+constexpr unsigned long long TAIL_WIDE_Q = 256;  // pairs per resident block and round: every product gets its own lane (3 * 256 <= TAIL_THREADS)
 struct TailArgs {
   fe_t *A, *B, *C;          // C unused in quadratic mode
-  unsigned long long len;   // table length at entry, power of two, 2 <= len <= 4 * TAIL_THREADS
+  unsigned long long len;   // table length at entry, power of two, 2 <= len <= 4 * TAIL_WIDE_Q * gridDim.x
   fe_t r0;                  // challenge of the round whose sums were produced before the launch
-  const fe_t* eq_pyr;       // cubic: single-table eq pyramid (second-half rounds); level(log2(pairs)) is the table of a round with `pairs` pairs
-  fe_t* mapped;             // device address of the mapped pinned buffer (results at [0..3), flag at RESULT_FLAG_ELEM)
+  // cubic: the split-eq tables of EqSumCheckInstance (src/sumcheck.rs:956-1016): pyramids over taus[1..first_half) and taus[first_half..ell);
+  // rnd0 = 1-based index of the first round this kernel EVALUATES
+  const fe_t *eq_pl, *eq_pr;
+  int ell, first_half, rnd0;
+  fe_t* mapped;             // device address of the mapped pinned buffer (per-block result slots at SLOT_BASE_ELEM, mailbox at TAIL_CHAL_ELEM)
   unsigned seq0;            // sequence number of the first result this kernel publishes
 };
 // Lanes 0..9 of wave 0 each read one word of the mailbox line (8 challenge words, the sequence word, a check word = sequence + sum of the
@@ -469,39 +489,45 @@ __device__ __forceinline__ bool tail_wait_challenge(fe_t* mapped, unsigned want,
   __syncthreads();
   return ok != 0;
 }
-template <int NACC>
-__device__ __forceinline__ void tail_block_sum(fe_t (&acc)[NACC], fe_t* smem /* NACC * 16 */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ fe_t load_agent(const fe_t* p) {
+  fe_t v;
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(p);
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) acc[k] = wave_sum(acc[k]);
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) smem[k * 16 + wave] = acc[k];
+  for (int i = 0; i < 4; ++i) {
+    const unsigned long long t = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.v[2 * i] = (unsigned)t;
+    v.v[2 * i + 1] = (unsigned)(t >> 32);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-      fe_t s = smem[k * 16];
-      for (int w = 1; w < TAIL_THREADS / 64; ++w) s = fe_add<S>(s, smem[k * 16 + w]);
-      acc[k] = s;
-    }
-  }
+  return v;
 }
+// One resident block per TAIL_WIDE_Q pairs. A block owns the pairs [b * TAIL_WIDE_Q, ...) of every round (its range only shrinks, so a block whose
+// range is empty leaves for good); pairs are block-local, so there is no barrier between blocks — the ordering between rounds comes from the
+// host, which posts the next challenge only after every active block has published its slot (each behind an agent-scope release of its table
+// writes), and from reading other blocks' elements with agent-scope loads.
 template <bool CUBIC>
 __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   constexpr int NACC = CUBIC ? 3 : 2;
-  __shared__ fe_t smem[NACC * 16];
+  __shared__ fe_t smem[16];
   __shared__ fe_t r_sh;
+  __shared__ unsigned chk_sh[4];
+  const unsigned long long base = (unsigned long long)blockIdx.x * TAIL_WIDE_Q;
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
+  int rnd = a.rnd0;
   fe_t r = a.r0;
   bool first = true;
+  fe_t* slot = a.mapped + SLOT_BASE_ELEM + 4 * blockIdx.x;
   while (true) {
+    const unsigned long long q = len / 4;
+    if (len > 2 ? base >= q : blockIdx.x != 0) return;
     if (!first) {
       if (!tail_wait_challenge(a.mapped, seq - 1, &r_sh)) return;
       r = r_sh;
     }
+    // the previous round had 2q pairs: while that is more than one block's worth, the elements bound below were written by other blocks
+    // (other XCDs, other L2s). They are read with agent-scope loads, which go past this XCD's L2, instead of an acquire fence, which would
+    // invalidate it (measured: 4 us per round).
+    const bool foreign = 2 * q > TAIL_WIDE_Q;
     first = false;
     if (len == 2) {  // last round: bind only
       if (threadIdx.x == 0) {
@@ -511,90 +537,65 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       }
       return;
     }
-    const unsigned long long q = len / 4;
-    int lq = 0;
-    while ((1ull << lq) < q) ++lq;
-    const fe_t* eq_in = CUBIC ? a.eq_pyr + eq_level_offset(lq) : nullptr;
-    if (q <= TAIL_WIDE_Q) {
-      // Wide form for the smallest rounds: a lone lane issues one 256-bit product in ~0.8 us, so the per-pair form (6-13 products in a row per
-      // lane) is pure issue latency. Here every product gets its own lane: phase A binds one element per lane, phase B forms one (sum, pair)
-      // product per lane — two to three dependent products per round instead of a dozen.
-      const unsigned nt = CUBIC ? 3 : 2;
-      const unsigned long long half = 2 * q;  // new table length
-      for (unsigned long long idx = threadIdx.x; idx < nt * half; idx += TAIL_THREADS) {
-        fe_t* Z = idx < half ? a.A : (idx < 2 * half ? a.B : a.C);
-        const unsigned long long x = idx % half;
-        Z[x] = bind1(Z[x], Z[x + half], r);
-      }
-      __syncthreads();
-      const unsigned seg = q < 64 ? 64u : (unsigned)q;  // keep `which` wave-uniform
-      const unsigned which = threadIdx.x / seg, id = threadIdx.x % seg;
-      fe_t v = fe_zero();
-      if (which < (unsigned)NACC && id < q) {
-        const fe_t a0 = a.A[id], a1 = a.A[id + q], b0 = a.B[id], b1 = a.B[id + q];
-        if (which == 0) v = fe_mul<S>(a0, b0);
-        else if (which == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
-        else v = fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1));
-        if (CUBIC) {
-          const fe_t c0 = a.C[id], c1 = a.C[id + q];
-          if (which == 0) v = fe_sub<S>(v, c0);
-          else if (which == 2) v = fe_sub<S>(v, fe_sub<S>(fe_dbl<S>(c0), c1));
-          v = fe_mul<S>(eq_in[id], v);
+    const unsigned qb = (unsigned)(q - base < TAIL_WIDE_Q ? q - base : TAIL_WIDE_Q);  // pairs of this block (a power of two)
+    // phase A: one bind per lane. New element x takes old x and x + 2q; this block owns x in [base, base + qb) and [q + base, q + base + qb).
+    const unsigned nt = CUBIC ? 3 : 2;
+    for (unsigned idx = threadIdx.x; idx < nt * 2 * qb; idx += TAIL_THREADS) {
+      const unsigned t = idx / (2 * qb), e = idx % (2 * qb);
+      fe_t* Z = t == 0 ? a.A : (t == 1 ? a.B : a.C);
+      const unsigned long long x = e < qb ? base + e : q + base + (e - qb);
+      Z[x] = foreign ? bind1(load_agent(Z + x), load_agent(Z + x + 2 * q), r) : bind1(Z[x], Z[x + 2 * q], r);
+    }
+    __syncthreads();
+    // phase B: one (sum, pair) product per lane; `which` is wave-uniform
+    const unsigned seg = qb < 64 ? 64u : qb;
+    const unsigned which = threadIdx.x / seg, il = threadIdx.x % seg;
+    fe_t v = fe_zero();
+    if (which < (unsigned)NACC && il < qb) {
+      const unsigned long long id = base + il;
+      const fe_t a0 = a.A[id], a1 = a.A[id + q], b0 = a.B[id], b1 = a.B[id + q];
+      if (which == 0) v = fe_mul<S>(a0, b0);
+      else if (which == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+      else v = fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1));
+      if (CUBIC) {
+        const fe_t c0 = a.C[id], c1 = a.C[id + q];
+        if (which == 0) v = fe_sub<S>(v, c0);
+        else if (which == 2) v = fe_sub<S>(v, fe_sub<S>(fe_dbl<S>(c0), c1));
+        // E(id) of round `rnd` (select_eq in capi_core.hip; src/sumcheck.rs:1041-1147)
+        fe_t w;
+        if (rnd < a.first_half) {
+          const int s2 = a.ell - a.first_half;
+          w = fe_mul<S>(a.eq_pr[eq_level_offset(s2) + (id & ((1ull << s2) - 1))], a.eq_pl[eq_level_offset(a.first_half - rnd) + (id >> s2)]);
+        } else {
+          w = a.eq_pr[eq_level_offset(a.ell - rnd) + id];
         }
-      }
-      v = wave_sum(v);
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      if (lane == 0) smem[wave] = v;
-      __syncthreads();
-      if (threadIdx.x < (unsigned)NACC) {  // thread k adds the waves of sum k and stores it
-        const unsigned wps = seg / 64;
-        fe_t t = smem[threadIdx.x * wps];
-        for (unsigned w = 1; w < wps; ++w) t = fe_add<S>(t, smem[threadIdx.x * wps + w]);
-        a.mapped[threadIdx.x] = t;
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) publish_result(a.mapped, seq);
-    } else {
-      // q = 256 or 512: same two phases, several items per lane; a lane's items may belong to different sums, so it keeps NACC accumulators
-      const unsigned nt = CUBIC ? 3 : 2;
-      const unsigned long long half = 2 * q;
-      for (unsigned long long idx = threadIdx.x; idx < nt * half; idx += TAIL_THREADS) {
-        fe_t* Z = idx < half ? a.A : (idx < 2 * half ? a.B : a.C);
-        const unsigned long long x = idx % half;
-        Z[x] = bind1(Z[x], Z[x + half], r);
-      }
-      __syncthreads();
-      fe_t acc[NACC];
-#pragma unroll
-      for (int k = 0; k < NACC; ++k) acc[k] = fe_zero();
-      for (unsigned long long idx = threadIdx.x; idx < (unsigned long long)NACC * q; idx += TAIL_THREADS) {
-        const unsigned which = (unsigned)(idx / q);
-        const unsigned long long id = idx % q;
-        const fe_t a0 = a.A[id], a1 = a.A[id + q], b0 = a.B[id], b1 = a.B[id + q];
-        fe_t v;
-        if (which == 0) v = fe_mul<S>(a0, b0);
-        else if (which == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
-        else v = fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1));
-        if (CUBIC) {
-          const fe_t c0 = a.C[id], c1 = a.C[id + q];
-          if (which == 0) v = fe_sub<S>(v, c0);
-          else if (which == 2) v = fe_sub<S>(v, fe_sub<S>(fe_dbl<S>(c0), c1));
-          v = fe_mul<S>(eq_in[id], v);
-        }
-#pragma unroll
-        for (int k = 0; k < NACC; ++k)
-          if (which == (unsigned)k) acc[k] = fe_add<S>(acc[k], v);
-      }
-      tail_block_sum<NACC>(acc, smem);
-      if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) a.mapped[k] = acc[k];
-        publish_result(a.mapped, seq);
+        v = fe_mul<S>(w, v);
       }
     }
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    if (threadIdx.x < (unsigned)NACC) {  // thread k adds the waves of sum k into this block's result slot
+      const unsigned wps = seg / 64;
+      fe_t t = smem[threadIdx.x * wps];
+      for (unsigned w = 1; w < wps; ++w) t = fe_add<S>(t, smem[threadIdx.x * wps + w]);
+      slot_store_elem(slot + threadIdx.x, t);
+      chk_sh[threadIdx.x] = slot_check_word(t);
+    }
+    // while several blocks are active the next round reads other blocks' elements: one agent-scope release of the block's table writes
+    // (they are complete at the barrier) before the host can see this block's slot. The single-block rounds need no fence at all.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (q > TAIL_WIDE_Q) __threadfence();
+      unsigned chk = 0;
+      for (int k = 0; k < NACC; ++k) chk += chk_sh[k];
+      slot_store_tag(slot, seq, chk);
+    }
     ++seq;
+    ++rnd;
     len /= 2;
-    __syncthreads();  // smem reuse + table writes visible to the whole block before the next round reads them
+    __syncthreads();  // smem reuse
   }
 }
 
