@@ -393,6 +393,27 @@ static unsigned tail_blocks(size_t len) {
   const size_t q = len / 2;
   return q <= spk::TAIL_WIDE_Q ? 1u : (unsigned)(q / spk::TAIL_WIDE_Q);
 }
+// Resident blocks occupy their CU (1024 threads) until the host has driven every round. If the tails of several contexts together asked for
+// more blocks than the chip holds, each could sit on CUs the other needs for blocks its host is waiting for: a multi-block tail therefore
+// leases its blocks from a process-wide budget and, when the budget is short, the sum-check simply keeps launching ordinary rounds until
+// the tail it needs is small enough. Single-block tails (one per context) are not counted.
+static std::atomic<int> g_tail_resident{0};
+constexpr int TAIL_BLOCK_BUDGET = 256;  // one 1024-thread block per CU
+struct TailLease {
+  int n = 0;
+  bool take(unsigned blocks) {
+    if (blocks <= 1) return true;
+    if (g_tail_resident.fetch_add((int)blocks) + (int)blocks > TAIL_BLOCK_BUDGET) {
+      g_tail_resident.fetch_sub((int)blocks);
+      return false;
+    }
+    n = (int)blocks;
+    return true;
+  }
+  ~TailLease() {
+    if (n) g_tail_resident.fetch_sub(n);
+  }
+};
 static int tail_check(sp_ctx* c) {
   volatile uint32_t* err = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM);
   if (*err) {
@@ -632,6 +653,7 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
   if (rc) return rc;
   bool have_sums = false;  // true when the previous fused launch already produced this round's sums
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
+  TailLease lease;
   size_t pending_blocks = 0;
   for (size_t round = 0; round < rounds; ++round) {
     const size_t half = A->len / 2;
@@ -682,7 +704,7 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
         have_sums = true;
         c->pending_slots = tail_blocks(A->len);
       }
-    } else if (tail_enabled() && round + 1 < rounds && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B)) {
+    } else if (tail_enabled() && round + 1 < rounds && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B) && lease.take(tail_blocks(A->len / 2))) {
       spk::TailArgs ta;
       ta.A = A->d;
       ta.B = B->d;
@@ -943,6 +965,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
 
   fe_t claim = load_fe(claim_);
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
+  TailLease lease;
   fe_t eval_eq_left = load_fe(p_io);
   const fe_t one = fe_one<S>();
   // slice sums -> batch sums (no-op for an unsharded call)
@@ -974,8 +997,10 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     const bool invertible = !fe_is_zero(l_1_p);
     const fe_t l_1_p_inv = invertible ? fe_inv<S>(l_1_p) : fe_zero();  // runs while the device computes this round's sums
     fe_t sums[3];
+    const double tr0 = round_trace() ? now_us() : 0;
     rc = reduce_partials_wait(c, in_tail ? 3 : 2, sums, in_tail);
     if (rc) return rc;
+    const double tr1 = round_trace() ? now_us() : 0;
     if ((rc = combine(sums, in_tail ? 3 : 2))) return rc;
     const fe_t t0 = sums[0], tinf = sums[1];
     // derive_from_claim (:1276-1324)
@@ -1033,7 +1058,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
         next_seq(c);
         c->pending_slots = tail_blocks(A->len);
       }
-    } else if (tail_enabled() && rnd < ell && A->len <= TAIL_MAX_LEN) {
+    } else if (tail_enabled() && rnd < ell && A->len <= TAIL_MAX_LEN && lease.take(tail_blocks(A->len / 2))) {
       spk::TailArgs ta;
       ta.A = A->d;
       ta.B = B->d;
@@ -1089,6 +1114,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     }
     // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
+    if (round_trace()) fprintf(stderr, "cubic round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", rnd, A->len * 2, (int)in_tail, tr1 - tr0, now_us() - tr1);
   }
   rc = sp_table_read(c, A, 0, 1, out_final);
   if (rc) return rc;
