@@ -79,6 +79,15 @@ int sp_transcript_new(sp_ctx* ctx, const uint8_t* label, size_t n, sp_transcript
 int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n);
 int sp_transcript_dom_sep(sp_transcript* t, const uint8_t* bytes, size_t n);
 int sp_transcript_squeeze(sp_transcript* t, const uint8_t* label, size_t ln, uint64_t out[4]);
+/* absorb(label, bytes) (keccak.rs:96-99) split in two for long inputs that are known early (comm_W is 64 KiB = 480 Keccak blocks, 0.2 ms of a
+ * 1.9 ms prove): sp_transcript_preabsorb hashes label || bytes into a sponge state on any thread, without a transcript;
+ * sp_transcript_absorb_prepared installs it. The running hasher restarts at every squeeze (keccak.rs:92), so the result equals the plain absorb
+ * exactly when nothing has been absorbed since the last squeeze (or since new) — otherwise the call fails with SP_ERR_INTERNAL_TRANSCRIPT and
+ * changes nothing. */
+typedef struct sp_absorb_state sp_absorb_state;
+int sp_transcript_preabsorb(const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n, sp_absorb_state** out);
+int sp_transcript_absorb_prepared(sp_transcript* t, const sp_absorb_state* s);
+void sp_absorb_state_free(sp_absorb_state* s);
 /* Keccak256Transcript derives Clone (keccak.rs:25); lets a caller keep the state after a prefix that repeats across proves */
 int sp_transcript_clone(const sp_transcript* t, sp_transcript** out);
 void sp_transcript_free(sp_transcript* t);
@@ -90,6 +99,11 @@ int sp_sumcheck_cubic3(sp_ctx* ctx, const uint64_t claim[4], const uint64_t* tau
                        sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]);
 /* SumcheckProof::prove_quad (:190-247) with compute_eval_points_quad's eff_pairs bound (:128-174).
  * out_cpolys: rounds x 2 F (c0, c2). */
+/* sp_sumcheck_quad_observed additionally calls observe(user, round, r) right after the challenge of each round (0-based) has been drawn, so the
+ * caller can start work that needs only a prefix of the challenges (the driver starts comm_LZ's MSM once the row variables are bound). */
+typedef void (*sp_challenge_hook)(void* user, size_t round, const uint64_t r[4]);
+int sp_sumcheck_quad_observed(sp_ctx* ctx, const uint64_t claim[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_challenge_hook observe,
+                              void* user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
 int sp_sumcheck_quad(sp_ctx* ctx, const uint64_t claim[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
                      uint64_t* out_r, uint64_t out_final[8]);
 /* DelayedReduction dot product reduce(sum a_i * b_i) over the first n elements (src/big_num/delayed_reduction.rs:41-84;
@@ -167,6 +181,23 @@ int sp_msm_ck(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, c
 /* The same MSM split in two so it can overlap other work (the reference gets this overlap from rayon): begin() enqueues the
  * device part on the context's auxiliary stream and returns; finish() waits, adds h * blind (may be NULL) and frees the job. */
 typedef struct sp_msm_job sp_msm_job;
+/* comm_LZ of HyraxPCS::prove (hyrax_pc.rs:430-455) is commit(L . W; <L, r_W>) with L = eq(point[..nvr]); by the homomorphism of the Pedersen
+ * commitment it equals sum_i L[i] * comm_W[i] — the same group element, so the same affine bytes — an MSM over the ROW COMMITMENTS that needs
+ * only the challenges of the row variables, which the inner sum-check has produced half-way through its rounds. sp_points_upload puts a
+ * point vector (x || y Montgomery limbs, (0, 0) = identity) on the device, reusing *io when it is large enough; sp_msm_eq_begin enqueues
+ * sum_i eq(r, i) * pts[i] (2^ell points, r[0] on the index MSB as EqPolynomial::evals_from_points, src/polys/eq.rs:59-93) on the auxiliary
+ * stream; sp_msm_job_finish = sp_msm_ck_finish without a blind. These three touch only the auxiliary stream's state, so ONE other thread may
+ * call them while the context's owner runs a sum-check on the main stream, provided no other *_begin / *_finish call overlaps them. */
+typedef struct sp_points sp_points;
+int sp_points_upload(sp_ctx* ctx, const uint64_t* aff, size_t n, sp_points** io);
+void sp_points_free(sp_points* p);
+int sp_msm_eq_begin(sp_ctx* ctx, const sp_points* pts, const uint64_t* r, size_t ell, sp_msm_job** job);
+int sp_msm_job_finish(sp_ctx* ctx, sp_msm_job* job, uint64_t out_aff[8]);
+/* bind_with_delayed (hyrax_pc.rs:38-54) with L = eq(r, .) (ell <= 10 row variables) formed on the device, on a stream of its own, so that LZ —
+ * needed only for the IPA's z vector — is computed beside comm_LZ's MSM rather than before it. One job at a time; same threading rule as above. */
+typedef struct sp_vec_job sp_vec_job;
+int sp_rowmat_vec_eq_begin(sp_ctx* ctx, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** job);
+int sp_rowmat_vec_eq_finish(sp_ctx* ctx, sp_vec_job* job, uint64_t* out);
 int sp_msm_ck_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_msm_job** job);
 int sp_msm_ck_finish(sp_ctx* ctx, const sp_ck* ck, sp_msm_job* job, const uint64_t* blind, uint64_t out_aff[8]);
 /* PCS::commit for keys of width <= 64, where the reference uses per-base FixedBaseMul tables (hyrax_pc.rs:221-260,

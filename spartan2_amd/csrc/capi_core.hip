@@ -133,6 +133,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   for (int i = 0; i < sp_ctx::WS_SLOTS; ++i)
     if (c->ws_ptr[i]) hipFree(c->ws_ptr[i]);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->h_pinned_vec) hipHostFree(c->h_pinned_vec);
+  if (c->vec_ev) hipEventDestroy(c->vec_ev);
+  if (c->stream3) hipStreamDestroy(c->stream3);
   for (auto& lane : c->msm_ev)
     for (hipEvent_t& e : lane)
       if (e) hipEventDestroy(e);
@@ -565,6 +568,24 @@ int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, cons
   t->t.absorb(label, ln, bytes, n);
   return SP_OK;
 }
+int sp_transcript_preabsorb(const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n, sp_absorb_state** out) {
+  if (!out || (!label && ln) || (!bytes && n)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_transcript_preabsorb: null argument");
+  sp_absorb_state* s = new sp_absorb_state;
+  s->h.init();
+  s->h.update(label, ln);
+  s->h.update(bytes, n);
+  *out = s;
+  return SP_OK;
+}
+int sp_transcript_absorb_prepared(sp_transcript* t, const sp_absorb_state* s) {
+  if (!t || !s) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_transcript_absorb_prepared: null argument");
+  bool fresh = t->t.h.fill == 0;
+  for (int i = 0; i < 25 && fresh; ++i) fresh = t->t.h.a[i] == 0;
+  if (!fresh) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "sp_transcript_absorb_prepared: the transcript has absorbed input since its last squeeze");
+  t->t.h = s->h;
+  return SP_OK;
+}
+void sp_absorb_state_free(sp_absorb_state* s) { delete s; }
 int sp_transcript_dom_sep(sp_transcript* t, const uint8_t* bytes, size_t n) {
   t->t.dom_sep(bytes, n);
   return SP_OK;
@@ -634,16 +655,28 @@ int sp_eval_cubic_outer_pow(sp_ctx* c, const sp_table* pl, const sp_table* pr, c
 
 static bool table_dense(const sp_table* t) { return sp::eff_lo(t) == t->len / 2 && sp::eff_hi(t) == t->len / 2; }
 
+static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
+                     sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
 int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
                      uint64_t* out_r, uint64_t out_final[8]) {
   uint64_t claim_io[4];
   memcpy(claim_io, claim_, 32);
-  return sp_sumcheck_quad_sharded(c, claim_io, rounds, A, B, tr, nullptr, nullptr, out_cpolys, out_r, out_final);
+  return quad_impl(c, claim_io, rounds, A, B, tr, nullptr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final);
+}
+int sp_sumcheck_quad_observed(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_challenge_hook observe,
+                              void* user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
+  uint64_t claim_io[4];
+  memcpy(claim_io, claim_, 32);
+  return quad_impl(c, claim_io, rounds, A, B, tr, nullptr, nullptr, observe, user, out_cpolys, out_r, out_final);
+}
+int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
+                             uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
+  return quad_impl(c, claim_io, rounds, A, B, tr, reduce, reduce_user, nullptr, nullptr, out_cpolys, out_r, out_final);
 }
 
 // prove_quad on a slice of the tables (see sp_sumcheck_cubic3_sharded): per round the slice's (eval0, t_inf) are combined across ranks by `reduce`
-int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
-                             uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
+static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
+                     sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
   const uint64_t* claim_ = claim_io;
   if (A->len != B->len || A->len != ((size_t)1 << rounds)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: tables must have 2^rounds elements");
   fe_t claim = load_fe(claim_);
@@ -759,6 +792,11 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
     } else {
       rc = launch_bind(c, tabs, 2, r_i);
       if (rc) return rc;
+    }
+    if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
+      uint64_t rw[4];
+      store_fe(rw, r_i);
+      observe(observe_user, round, rw);
     }
     if (round_trace()) fprintf(stderr, "quad round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", round, A->len * 2, (int)in_tail, tr1 - tr0, now_us() - tr1);
   }

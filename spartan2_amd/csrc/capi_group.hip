@@ -638,6 +638,136 @@ int sp_msm_ck_finish(sp_ctx* c, const sp_ck* ck, sp_msm_job* job, const uint64_t
   return SP_OK;
 }
 
+// ---- MSM over caller-supplied points with eq-table weights (the homomorphic form of HyraxPCS::prove's comm_LZ) ---------------------------
+struct sp_points {
+  aff_t* d = nullptr;
+  size_t n = 0, cap = 0;
+};
+int sp_points_upload(sp_ctx* c, const uint64_t* aff, size_t n, sp_points** io) {
+  if (!io || (!aff && n)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_points_upload: null argument");
+  sp_points* p = *io ? *io : new sp_points();
+  if (p->cap < n) {
+    if (p->d) {
+      hipStreamSynchronize(c->stream2);
+      hipFree(p->d);
+      p->d = nullptr;
+      p->cap = 0;
+    }
+    if (hipMalloc((void**)&p->d, (n ? n : 1) * sizeof(aff_t)) != hipSuccess) {
+      if (!*io) delete p;
+      return fail(SP_ERR_NO_DEVICE, "hipMalloc failed for a point vector");
+    }
+    p->cap = n ? n : 1;
+  }
+  p->n = n;
+  *io = p;
+  if (n) {
+    SP_HIP(hipMemcpyAsync(p->d, aff, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream2));
+    SP_HIP(hipStreamSynchronize(c->stream2));  // `aff` is a borrowed host buffer
+  }
+  return SP_OK;
+}
+void sp_points_free(sp_points* p) {
+  if (!p) return;
+  if (p->d) hipFree(p->d);
+  delete p;
+}
+// eq table of k variables on the host, r[0] on the index MSB (EqPolynomial::evals_from_points, src/polys/eq.rs:59-93)
+static void eq_table_host(const fe_t* r, size_t k, fe_t* out) {
+  out[0] = fe_one<spk::SF>();
+  for (size_t j = 0; j < k; ++j) {
+    const size_t half = (size_t)1 << j;
+    for (size_t i = half; i-- > 0;) {
+      const fe_t hi = fe_mul<spk::SF>(out[i], r[j]);
+      out[2 * i] = fe_sub<spk::SF>(out[i], hi);
+      out[2 * i + 1] = hi;
+    }
+  }
+}
+int sp_msm_eq_begin(sp_ctx* c, const sp_points* pts, const uint64_t* r, size_t ell, sp_msm_job** out) {
+  if (!pts || !out || (!r && ell)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_msm_eq_begin: null argument");
+  if (ell > 20) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_msm_eq_begin: more than 2^20 points");
+  const size_t n = (size_t)1 << ell;
+  if (n != pts->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "MSM: Coefficients and bases must have the same length");
+  std::vector<fe_t> rr(ell);
+  for (size_t i = 0; i < ell; ++i) memcpy(&rr[i], r + 4 * i, 32);
+  fe_t* canon = nullptr;
+  int rc;
+  if (ell <= 10) {
+    canon = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_CANON, n * sizeof(fe_t), 1);
+    if (!canon) return SP_ERR_NO_DEVICE;
+    spk::EqTensorArgs a;
+    const size_t hb = ell / 2, lb = ell - hb;
+    eq_table_host(rr.data(), hb, a.left);
+    eq_table_host(rr.data() + hb, lb, a.right);
+    a.lo_bits = (int)lb;
+    a.n = (unsigned)n;
+    hipLaunchKernelGGL(spk::k_eq_tensor<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream2, a, canon);
+  } else {
+    std::vector<fe_t> w(n);
+    eq_table_host(rr.data(), ell, w.data());
+    if ((rc = upload_canonical(c, reinterpret_cast<const uint64_t*>(w.data()), n, &canon, 1))) return rc;
+  }
+  sp_msm_job* job = new sp_msm_job();
+  if ((rc = msm_launch(c, canon, pts->d, n, spk::MSM_MAX_WINDOWS, 1, &job->pend))) {
+    delete job;
+    return rc;
+  }
+  *out = job;
+  return SP_OK;
+}
+// bind_with_delayed with L = eq(r, .) generated on the device, on a stream of its own; the result lands in pinned memory
+struct sp_vec_job {
+  size_t cols = 0;
+};
+int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** out) {
+  if (!poly || !out || (!r && ell)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: null argument");
+  if (ell > 10) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: more than 2^10 rows");
+  const size_t rows = (size_t)1 << ell;
+  if (rows * cols > poly->cap || cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed: poly shorter than rows*cols");
+  if (!c->stream3) SP_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+  if (!c->vec_ev) SP_HIP(hipEventCreateWithFlags(&c->vec_ev, hipEventDisableTiming));
+  if (c->h_pinned_vec_bytes < cols * sizeof(fe_t)) {
+    if (c->h_pinned_vec) hipHostFree(c->h_pinned_vec);
+    c->h_pinned_vec = nullptr;
+    c->h_pinned_vec_bytes = 0;
+    SP_HIP(hipHostMalloc(&c->h_pinned_vec, cols * sizeof(fe_t)));
+    c->h_pinned_vec_bytes = cols * sizeof(fe_t);
+  }
+  const size_t splits = rows < 64 ? rows : 64;
+  fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, rows * sizeof(fe_t), 1);
+  fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
+  fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, cols * sizeof(fe_t), 1);
+  if (!dL || !part || !dout) return SP_ERR_NO_DEVICE;
+  spk::EqTensorArgs a;
+  const size_t hb = ell / 2, lb = ell - hb;
+  fe_t rr[10];
+  for (size_t i = 0; i < ell; ++i) memcpy(&rr[i], r + 4 * i, 32);
+  eq_table_host(rr, hb, a.left);
+  eq_table_host(rr + hb, lb, a.right);
+  a.lo_bits = (int)lb;
+  a.n = (unsigned)rows;
+  hipStream_t st = c->stream3;
+  hipLaunchKernelGGL(spk::k_eq_tensor<false>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, a, dL);
+  hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly->d, rows, cols, dL, part);
+  hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, splits, cols, dout);
+  SP_HIP(hipMemcpyAsync(c->h_pinned_vec, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, st));
+  SP_HIP(hipEventRecord(c->vec_ev, st));
+  sp_vec_job* job = new sp_vec_job();
+  job->cols = cols;
+  *out = job;
+  return SP_OK;
+}
+int sp_rowmat_vec_eq_finish(sp_ctx* c, sp_vec_job* job, uint64_t* out) {
+  if (!job || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish: null argument");
+  const size_t cols = job->cols;
+  delete job;
+  SP_HIP(hipEventSynchronize(c->vec_ev));
+  memcpy(out, c->h_pinned_vec, cols * sizeof(fe_t));
+  return SP_OK;
+}
+int sp_msm_job_finish(sp_ctx* c, sp_msm_job* job, uint64_t out_aff[8]) { return sp_msm_ck_finish(c, nullptr, job, nullptr, out_aff); }
+
 int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]) {
   if (!ck->d_cktables || n > ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_small: key wider than 64 or too many scalars");
   // FixedBaseMul::multi_mul (msm.rs:727-773) + h_table.mul(blind); n <= 64 single lookups chains: host

@@ -48,6 +48,10 @@ struct sp_ctx {
   unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.cuh publish_result)
   unsigned long long msm_jobs_issued[2] = {0, 0};
   hipEvent_t msm_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // completion event of the MSM job in each landing slot
+  hipStream_t stream3 = nullptr;     // second auxiliary stream (sp_rowmat_vec_eq_begin), created on first use
+  void* h_pinned_vec = nullptr;      // pinned landing buffer of sp_rowmat_vec_eq jobs, grow-only
+  size_t h_pinned_vec_bytes = 0;
+  hipEvent_t vec_ev = nullptr;
   void* h_pinned_lane[2] = {nullptr, nullptr};  // pinned landing buffers for per-window MSM sums (one per stream), 8 KiB each
   size_t pinned_elems = 0;
   bool timing = false;
@@ -95,6 +99,9 @@ struct sp_table {
 
 struct sp_transcript {
   sp::Transcript t;
+};
+struct sp_absorb_state {
+  sp::Keccak256State h;
 };
 
 namespace sp {

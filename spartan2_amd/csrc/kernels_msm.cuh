@@ -32,6 +32,20 @@ __device__ __forceinline__ jac_t shfl_down_jac(const jac_t& a, int delta) {
 __global__ void __launch_bounds__(256) k_to_canonical(const fe_t* __restrict__ in, size_t n, fe_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fe_to_canonical<SF>(in[i]);
 }
+// eq(r, i) = left[i >> lo_bits] * right[i & mask] (canonical limbs for MSM scalars, Montgomery form for field work): an eq table of up to 10 variables formed from its
+// two half tables (<= 32 entries each, passed by value — no upload, no synchronisation)
+struct EqTensorArgs {
+  fe_t left[32], right[32];
+  int lo_bits;
+  unsigned n;
+};
+template <bool CANONICAL>
+__global__ void __launch_bounds__(256) k_eq_tensor(EqTensorArgs a, fe_t* __restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const fe_t w = fe_mul<SF>(a.left[i >> a.lo_bits], a.right[i & ((1u << a.lo_bits) - 1)]);
+  out[i] = CANONICAL ? fe_to_canonical<SF>(w) : w;
+}
 // Sign folding for the digit path: s -> (min(s, n - s), sign) with n the group order, so every folded scalar is < 2^255:
 // the top byte is < 128, the carry window (msm.rs:137-145) stays almost empty and buckets are balanced. s*P == (n-s)*(-P).
 // The sign lives in bit 31 of limb 7 of the output.

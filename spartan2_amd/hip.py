@@ -189,6 +189,17 @@ class Transcript:
         da, dn = _bytes(data)
         check(lib().sp_transcript_dom_sep(self.h, p8(da), dn))
 
+    def absorb_prepared(self, label: bytes, data: bytes):
+        """absorb() through sp_transcript_preabsorb + sp_transcript_absorb_prepared (valid right after new / squeeze only)."""
+        la, ln = _bytes(label)
+        da, dn = _bytes(data)
+        st = ctypes.c_void_p()
+        check(lib().sp_transcript_preabsorb(p8(la), ln, p8(da), dn, ctypes.byref(st)))
+        try:
+            check(lib().sp_transcript_absorb_prepared(self.h, st))
+        finally:
+            lib().sp_absorb_state_free(st)
+
     def squeeze(self, label: bytes):
         la, ln = _bytes(label)
         out = np.zeros(4, dtype=np.uint64)
@@ -240,6 +251,24 @@ def msm(ctx, scalars, bases):
     out = np.zeros(8, dtype=np.uint64)
     n = scalars.shape[0]
     check(lib().sp_msm(ctx.h, p64(scalars) if n else None, p64(bases) if n else None, ctypes.c_size_t(n), p64(out)))
+    return out
+
+
+def msm_eq(ctx, points, r):
+    """sum_i eq(r, i) * points[i] through sp_points_upload + sp_msm_eq_begin + sp_msm_job_finish (the homomorphic form of comm_LZ)."""
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    pts = ctypes.c_void_p()
+    job = ctypes.c_void_p()
+    out = np.zeros(8, dtype=np.uint64)
+    L = lib()
+    L.sp_points_free.argtypes = [ctypes.c_void_p]
+    check(L.sp_points_upload(ctx.h, p64(points), ctypes.c_size_t(points.shape[0]), ctypes.byref(pts)))
+    try:
+        check(L.sp_msm_eq_begin(ctx.h, pts, p64(r) if r.shape[0] else None, ctypes.c_size_t(r.shape[0]), ctypes.byref(job)))
+        check(L.sp_msm_job_finish(ctx.h, job, p64(out)))
+    finally:
+        L.sp_points_free(pts)
     return out
 
 

@@ -1,12 +1,18 @@
 // Helpers shared by the host-side drivers above the C ABI (spartan_snark.cpp, neutronnova_nifs.cpp): error plumbing, the transcript wrapper over
 // sp_transcript_*, the transcript encodings of points / commitments, the randomness tape.
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spartan_hip.h"
@@ -63,6 +69,74 @@ static std::vector<uint8_t> commitment_bytes(const aff_t* rows, size_t n) {
   v.insert(v.end(), e, e + strlen(e));
   return v;
 }
+
+// One helper thread per prover for host work whose inputs are known long before its result is needed (hashing the 64 KiB encoding of comm_W:
+// 0.3 ms that used to sit on the critical path of the PCS phase). The thread sleeps between jobs; the prover picks the result up with a short spin,
+// by which time the job has normally been finished for hundreds of microseconds.
+class Background {
+  std::thread th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool posted_ = false, stop_ = false;
+  std::atomic<int> pending_{0};
+  std::exception_ptr err_;
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return posted_ || stop_; });
+        if (stop_) return;
+        f.swap(job_);
+        posted_ = false;
+      }
+      try {
+        f();
+      } catch (...) {
+        err_ = std::current_exception();
+      }
+      pending_.store(0, std::memory_order_release);
+    }
+  }
+
+ public:
+  Background() = default;
+  Background(const Background&) = delete;
+  Background& operator=(const Background&) = delete;
+  ~Background() {
+    if (!th_.joinable()) return;
+    wait_nothrow();
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_one();
+    th_.join();
+  }
+  void submit(std::function<void()> f) {  // one job at a time
+    wait();
+    pending_.store(1, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> l(m_);
+      job_ = std::move(f);
+      posted_ = true;
+    }
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    cv_.notify_one();
+  }
+  void wait_nothrow() {
+    while (pending_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+  }
+  void wait() {  // rethrows what the job threw
+    wait_nothrow();
+    if (err_) {
+      std::exception_ptr e = err_;
+      err_ = nullptr;
+      std::rethrow_exception(e);
+    }
+  }
+};
 
 struct Tape {
   const uint8_t* bytes;

@@ -212,7 +212,13 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   bool is_small = true;
   sp_transcript* tr_prefix = nullptr;  // transcript state after the per-instance prefix (see prove)
   std::vector<fe_t> tr_publics;
+  Background bg;                        // hashes comm_W for the PCS transcript step while the sum-checks run, then starts comm_LZ's MSM
+  sp_absorb_state* poly_com = nullptr;  // its result
+  sp_points* comm_pts = nullptr;        // comm_W on the device: the bases of comm_LZ's MSM
   ~SpartanPrepSNARK() {
+    bg.wait_nothrow();
+    sp_points_free(comm_pts);
+    sp_absorb_state_free(poly_com);
     sp_transcript_free(tr_prefix);
     for (sp_table* t : {W, caz, cbz, ccz, az, bz, cz, z, rx, abc}) sp_table_free(t);
   }
@@ -384,9 +390,11 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   // latency-bound rounds leave the device mostly idle (the outer sum-check's streaming rounds are left undisturbed).
   const size_t n_ipa = M < W_ ? M : W_;
   std::vector<fe_t> dvec(n_ipa);
+  fe_t r_delta_ahead;
   {
     Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
     for (auto& x : dvec) x = peek.next();
+    r_delta_ahead = peek.next();  // ipa.rs:146: the blind of delta follows d_vec on the tape
   }
   lap("dvec_draw");
 
@@ -401,6 +409,87 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   lap("commit_zeros_finish+absorb");
   std::vector<fe_t> r_W = ps.r_W_fixed;  // combine_blinds (bellpepper/r1cs.rs:515-524)
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
+  // comm_W is complete: its transcript encoding (64 B per row, Montgomery -> canonical) and the Keccak blocks of absorb("poly_com", ..), the
+  // first absorb after the inner sum-check's last squeeze (hyrax_pc.rs:387-400), are computed on the helper thread from here on
+  sp_absorb_state_free(ps.poly_com);
+  ps.poly_com = nullptr;
+  // The same helper then computes comm_LZ = sum_i L[i] comm_W[i] (= commit(L . W; <L, r_W>), hyrax_pc.rs:430-455, by the homomorphism of the
+  // commitment) as soon as the inner sum-check has bound the row variables: the MSM runs under the remaining rounds instead of after them.
+  const size_t lz_rows = (M + W_ - 1) / W_, lz_nvr = log2_ceil(lz_rows);
+  static const bool lz_direct = [] {  // SPARTAN_LZ_DIRECT=1: the reference's own order (bind W with L first, then MSM over the key)
+    const char* e = getenv("SPARTAN_LZ_DIRECT");
+    return e && e[0] == '1';
+  }();
+  struct LzAhead {
+    std::atomic<int> state{0};  // 0: row challenges not drawn yet, 1: drawn, 2: abandoned
+    size_t nvr = 0;
+    fe_t r[24];
+    sp_msm_job* job = nullptr;
+    sp_vec_job* vec = nullptr;
+    fe_t r_LZ;
+    std::atomic<int> delta_state{0};  // 0: delta's MSM not issued yet, 1: issued, 2: abandoned
+    sp_msm_job* delta_job = nullptr;
+    fe_t r_delta;
+    aff_t delta;
+    bool delta_done = false;
+  } lz;
+  lz.r_delta = r_delta_ahead;
+  lz.nvr = lz_nvr;
+  const bool lz_ahead = !lz_direct && lz_nvr > 0 && lz_nvr <= 10 && comm_W.size() == ((size_t)1 << lz_nvr) && r_W.size() == comm_W.size();
+  const size_t lz_cols = (size_t)1 << (log2_ceil(M) - lz_nvr);
+  {
+    const aff_t* rows = comm_W.data();
+    const size_t nrows = comm_W.size();
+    SpartanPrepSNARK* psp = &ps;
+    const fe_t* blinds = r_W.data();
+    LzAhead* lzp = lz_ahead ? &lz : nullptr;
+    const sp_ck* key = pk.ck;
+    const size_t cols = lz_cols;
+    ps.bg.submit([ctx, rows, nrows, psp, blinds, lzp, key, cols] {
+      const std::vector<uint8_t> b = commitment_bytes(rows, nrows);
+      ck(sp_transcript_preabsorb((const uint8_t*)"poly_com", 8, b.data(), b.size(), &psp->poly_com), "poly_com (prepare)");
+      if (!lzp) return;
+      ck(sp_points_upload(ctx, u64p(&rows[0].x), nrows, &psp->comm_pts), "comm_W (upload)");
+      const auto t0 = std::chrono::steady_clock::now();
+      auto wait_for = [&](std::atomic<int>& flag) {
+        int st;
+        while ((st = flag.load(std::memory_order_acquire)) == 0) {
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return 2;  // the prover never got there
+          __builtin_ia32_pause();
+        }
+        return st;
+      };
+      // delta (ipa.rs:147): its MSM was issued before the inner sum-check; the window Horner and h * r_delta run here
+      if (wait_for(lzp->delta_state) != 1) return;
+      ck(sp_msm_ck_finish(ctx, key, lzp->delta_job, u64p(&lzp->r_delta), u64p(&lzp->delta.x)), "delta (finish)");
+      lzp->delta_job = nullptr;
+      lzp->delta_done = true;
+      if (wait_for(lzp->state) != 1) return;
+      ck(sp_msm_eq_begin(ctx, psp->comm_pts, u64p(lzp->r), lzp->nvr, &lzp->job), "comm_LZ (begin)");
+      ck(sp_rowmat_vec_eq_begin(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, &lzp->vec), "bind_with_delayed (begin)");
+      // r_LZ = <L, r_W> with L = eq(r) = left (x) right: 2^nvr + 2^(nvr/2) products instead of 2 * 2^nvr
+      const size_t hb = lzp->nvr / 2, lb = lzp->nvr - hb;
+      const std::vector<fe_t> left = eq_evals_host(lzp->r, hb), right = eq_evals_host(lzp->r + hb, lb);
+      fe_t acc = fe_zero();
+      for (size_t a = 0; a < left.size(); ++a) {
+        fe_t inner = fe_zero();
+        for (size_t c2 = 0; c2 < right.size(); ++c2) inner = fe_add<S>(inner, fe_mul<S>(right[c2], blinds[a * right.size() + c2]));
+        acc = fe_add<S>(acc, fe_mul<S>(left[a], inner));
+      }
+      lzp->r_LZ = acc;
+    });
+  }
+  struct BgJoin {  // comm_W, r_W and lz must outlive the job on every exit path
+    Background& b;
+    std::atomic<int>&st, &st2;
+    ~BgJoin() {
+      int zero = 0;
+      st2.compare_exchange_strong(zero, 2);
+      zero = 0;
+      st.compare_exchange_strong(zero, 2);
+      b.wait_nothrow();
+    }
+  } bg_join{ps.bg, lz.state, lz.delta_state};
   const double t_wit = now_ms();
 
   const size_t num_rounds_x = log2_ceil(N), num_rounds_y = log2_ceil(M) + 1;
@@ -434,13 +523,30 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
 
   sp_msm_job* delta_job = nullptr;
   ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
+  if (lz_ahead) {  // the helper finishes it (see above)
+    lz.delta_job = delta_job;
+    delta_job = nullptr;
+    lz.delta_state.store(1, std::memory_order_release);
+  }
   // inner sum-check. The reference runs round 0 by hand on the compact vectors (src/spartan.rs:323-384); that round is
   // value-identical to a generic prove_quad round on the 2M-long tables with (lo_eff, hi_eff) = (M, num_extra).
   ck(sp_table_set_len(ps.abc, 2 * M, M, pk.num_extra), "abc len");
   ck(sp_table_set_len(ps.z, 2 * M, M, pk.num_extra), "z len");
   std::vector<fe_t> inner_polys(2 * num_rounds_y), r_y(num_rounds_y);
   fe_t claims_inner[2];
-  ck(sp_sumcheck_quad(ctx, u64p(&claim_inner_joint), num_rounds_y, ps.abc, ps.z, tr.t, u64p(inner_polys.data()), u64p(r_y.data()), u64p(claims_inner)),
+  // r_y[0] selects W against (1, X); r_y[1 ..= nvr] are the row variables of W (MSB first): once they are drawn the helper can start comm_LZ
+  struct Obs {
+    decltype(lz)* lz;
+    bool on;
+    static void fn(void* u, size_t round, const uint64_t r[4]) {
+      Obs* o = (Obs*)u;
+      if (!o->on || round == 0 || round > o->lz->nvr) return;
+      memcpy(&o->lz->r[round - 1], r, 32);
+      if (round == o->lz->nvr) o->lz->state.store(1, std::memory_order_release);
+    }
+  } obs{&lz, lz_ahead};
+  ck(sp_sumcheck_quad_observed(ctx, u64p(&claim_inner_joint), num_rounds_y, ps.abc, ps.z, tr.t, &Obs::fn, &obs, u64p(inner_polys.data()), u64p(r_y.data()),
+                               u64p(claims_inner)),
      "inner sum-check");
   for (const fe_t& f : inner_polys) proof.pf(f);
   const fe_t eval_Z = claims_inner[1];
@@ -474,36 +580,58 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     LZ.resize(M);
     ck(sp_table_read(ctx, ps.W, 0, M, u64p(LZ.data())), "read W");
     r_LZ = r_W[0];
+  } else if (lz_ahead) {
+    // comm_LZ's MSM and the row-matrix product have been running since round nvr of the inner sum-check
+    LZ.resize(lz_cols);
+    ps.bg.wait();
+    if (!lz.job || !lz.vec || !lz.delta_done) throw Error(SP_ERR_INTERNAL, "comm_LZ was not started");
+    lz_job = lz.job;
+    r_LZ = lz.r_LZ;
+    lap("helper_join");
   } else {
     std::vector<fe_t> L = eq_evals_host(point, nvr);
     LZ.resize((size_t)1 << (npoint - nvr));
     ck(sp_rowmat_vec(ctx, ps.W, L.size(), LZ.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
     ck(sp_msm_ck_begin(ctx, pk.ck, u64p(LZ.data()), LZ.size(), &lz_job), "comm_LZ (begin)");
     lap("eq_L+rowmat_vec+msm_begin");
-    R = eq_evals_host(point + nvr, npoint - nvr);
     r_LZ = fe_zero();
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], r_W[i]));
   }
   aff_t comm_eval_W;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
-  {
-    std::vector<uint8_t> b = commitment_bytes(comm_W.data(), comm_W.size());
-    tr.absorb("poly_com", b.data(), b.size());
-  }
+  ps.bg.wait();
+  ck(sp_transcript_absorb_prepared(tr.t, ps.poly_com), "poly_com");
   tr.dom_sep("inner product argument (linear)");
-  const size_t n = R.size();
+  const size_t n = (size_t)1 << (nvr == 0 ? npoint : npoint - nvr);  // |R|
   if (n != n_ipa) throw Error(SP_ERR_INTERNAL, "IPA width mismatch");
   tape.skip(n);  // the d_vec blocks that were peeked at the start
   const fe_t r_delta = tape.next(), r_beta = tape.next();
+  // <R, d> (ipa.rs:148) with R = eq(point[nvr..]) = left (x) right: n + sqrt(n) products, R itself is never needed
   fe_t ip = fe_zero();
-  for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
+  if (R.empty()) {
+    const size_t k = npoint - nvr, hb = k / 2;
+    const std::vector<fe_t> left = eq_evals_host(point + nvr, hb), right = eq_evals_host(point + nvr + hb, k - hb);
+    for (size_t a = 0; a < left.size(); ++a) {
+      fe_t inner = fe_zero();
+      for (size_t b = 0; b < right.size(); ++b) inner = fe_add<S>(inner, fe_mul<S>(right[b], dvec[a * right.size() + b]));
+      ip = fe_add<S>(ip, fe_mul<S>(left[a], inner));
+    }
+  } else {
+    for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
+  }
   aff_t delta, beta;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
-  // delta's device part finished long ago (it was issued before the inner sum-check): its window Horner runs on the host while the device
-  // still works on comm_LZ
-  ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
+  if (lz_ahead) {
+    delta = lz.delta;  // finished by the helper with the blind peeked from the same tape position
+    if (memcmp(&r_delta, &lz.r_delta, sizeof(fe_t)) != 0) throw Error(SP_ERR_INTERNAL, "tape positions of r_delta disagree");
+  } else {
+    // delta's device part finished long ago (it was issued before the inner sum-check): its window Horner runs on the host while the device
+    // still works on comm_LZ
+    ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
+  }
   lap("host_side_under_msm");
-  if (lz_job) ck(sp_msm_ck_finish(ctx, pk.ck, lz_job, u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ (finish)");
+  if (lz_job && lz_ahead) ck(sp_msm_job_finish(ctx, lz_job, u64p(&comm_LZ.x)), "comm_LZ (finish)");  // the blinds are inside the row commitments
+  else if (lz_job) ck(sp_msm_ck_finish(ctx, pk.ck, lz_job, u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ (finish)");
   lap("comm_LZ_finish");
   {
     uint8_t b[128];
@@ -521,6 +649,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t rr = tr.squeeze("r");
   proof.pp(delta);
   proof.pp(beta);
+  if (lz_ahead) ck(sp_rowmat_vec_eq_finish(ctx, lz.vec, u64p(LZ.data())), "bind_with_delayed (finish)");
   for (size_t i = 0; i < n; ++i) proof.pf(fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]));
   proof.pf(fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta));
   proof.pf(fe_add<S>(fe_mul<S>(rr, blind_eval_W), r_beta));

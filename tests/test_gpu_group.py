@@ -213,3 +213,26 @@ def test_row_range_commits_and_point_sum_compose(ctx, key, gens):
     partials = np.stack([hip.msm(ctx, sc[lo:hi], bases[lo:hi]) for lo, hi in ((0, 113), (113, 450), (450, 900))])
     assert (hip.point_sum(partials) == whole).all()
     assert (hip.point_sum(np.zeros((0, 8), dtype=np.uint64)) == 0).all()
+
+
+@pytest.mark.parametrize("ell", [0, 1, 3, 7, 10, 11])
+def test_msm_eq_weights_matches_oracle(ctx, gens, ell):
+    """sp_points_upload + sp_msm_eq_begin + sp_msm_job_finish: sum_i eq(r, i) P_i (comm_LZ as an MSM over the row commitments) equals the
+    oracle's MSM with the oracle's eq table as scalars; ell = 11 takes the uploaded-scalars branch, the others the two-half-tables kernel."""
+    rng = np.random.default_rng(SEED + 77 + ell)
+    n = 1 << ell
+    r = ol.random_field_array(rng, max(ell, 1))[:ell]
+    w = np.zeros((n, 4), dtype=np.uint64)
+    olib().orc_eq_evals(p64(r) if ell else None, ctypes.c_size_t(ell), p64(w))
+    pts = np.ascontiguousarray(gens[:n]).copy()
+    if n >= 8:
+        pts[5] = 0  # the identity among the row commitments
+        pts[6] = pts[2]  # a repeated row
+    assert (hip.msm_eq(ctx, pts, r) == oracle_msm(w, pts)).all()
+
+
+def test_msm_eq_rejects_length_mismatch(ctx, gens):
+    rng = np.random.default_rng(SEED)
+    r = ol.random_field_array(rng, 3)
+    with pytest.raises(hip.SpartanHipError):
+        hip.msm_eq(ctx, np.ascontiguousarray(gens[:7]), r)

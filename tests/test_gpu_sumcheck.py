@@ -235,3 +235,25 @@ def test_bind_kernel_reports_algorithmic_bytes(ctx):
     ms, launches, nbytes = ctx.kernel_stats("bind")
     ctx.reset_stats(False)
     assert launches == 1 and nbytes == 48 * n and ms > 0
+
+
+def test_transcript_prepared_absorb_equals_plain_absorb(ctx):
+    """sp_transcript_preabsorb + sp_transcript_absorb_prepared (the 64 KiB comm_W absorb hashed off the critical path) give the very same
+    challenges as absorb(); installing a prepared state into a transcript that has absorbed something since its last squeeze is refused."""
+    rng = np.random.default_rng(SEED + 9)
+    data = rng.integers(0, 256, size=70001, dtype=np.uint8).tobytes()
+    a, b = hip.Transcript(ctx, b"t"), hip.Transcript(ctx, b"t")
+    a.absorb(b"poly_com", data)
+    b.absorb_prepared(b"poly_com", data)
+    assert (a.squeeze(b"r") == b.squeeze(b"r")).all()
+    # after a squeeze the running hasher is fresh again
+    a.absorb(b"x", b"")
+    b.absorb_prepared(b"x", b"")
+    a.dom_sep(b"sep")
+    b.dom_sep(b"sep")
+    assert (a.squeeze(b"r") == b.squeeze(b"r")).all()
+    b.absorb(b"y", b"123")
+    with pytest.raises(hip.SpartanHipError):
+        b.absorb_prepared(b"poly_com", data)
+    a.absorb(b"y", b"123")
+    assert (a.squeeze(b"r") == b.squeeze(b"r")).all()  # the refused call changed nothing
