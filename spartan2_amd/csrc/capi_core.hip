@@ -119,6 +119,20 @@ int sp_ctx_create(int device, sp_ctx** out) {
   SP_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
   SP_HIP(hipHostMalloc(&c->h_pinned_lane[0], 8192));
   SP_HIP(hipHostMalloc(&c->h_pinned_lane[1], 8192));
+  c->h_mail = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_CHAL_ELEM);
+  c->d_mail = reinterpret_cast<const unsigned*>(c->d_pinned + spk::TAIL_CHAL_ELEM);
+  {  // SPARTAN_MAIL_DEV=0 keeps the mailbox in host memory (and with it the launch-after-challenge round loop)
+    const char* e = getenv("SPARTAN_MAIL_DEV");
+    int large_bar = 0;
+    if (!(e && e[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
+        hipExtMallocWithFlags(&c->mail_alloc, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+      SP_HIP(hipMemset(c->mail_alloc, 0, 4096));
+      SP_HIP(hipDeviceSynchronize());
+      c->h_mail = reinterpret_cast<volatile uint32_t*>(c->mail_alloc);  // the host stores straight into device memory over the BAR
+      c->d_mail = reinterpret_cast<const unsigned*>(c->mail_alloc);
+      c->mail_dev = true;
+    }
+  }
   int rc = c->ensure_scratch(1 << 16);
   if (rc) return rc;
   *out = c;
@@ -133,6 +147,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   for (int i = 0; i < sp_ctx::WS_SLOTS; ++i)
     if (c->ws_ptr[i]) hipFree(c->ws_ptr[i]);
   if (c->h_pinned) hipHostFree(c->h_pinned);
+  if (c->mail_alloc) hipFree(c->mail_alloc);
   if (c->h_pinned_vec) hipHostFree(c->h_pinned_vec);
   if (c->vec_ev) hipEventDestroy(c->vec_ev);
   if (c->stream3) hipStreamDestroy(c->stream3);
@@ -381,7 +396,7 @@ static bool tail_enabled() { return tail_max_len() != 0; }
 // mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 = check word
 // (sequence + sum of the challenge words) so a poll that straddles the host's stores is recognised and retried.
 static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) {
-  volatile uint32_t* dst = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_CHAL_ELEM);
+  volatile uint32_t* dst = c->h_mail;
   uint32_t chk = answers_seq;
   for (int i = 0; i < 8; ++i) {
     dst[i] = r.v[i];
@@ -390,6 +405,23 @@ static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) 
   dst[9] = chk;
   std::atomic_thread_fence(std::memory_order_release);
   dst[8] = answers_seq;
+  if (c->mail_dev) __builtin_ia32_sfence();  // BAR memory is write-combining: push the line out now
+}
+static spk::MailRef mail_ref(sp_ctx* c, bool ahead, unsigned answers) {
+  spk::MailRef m;
+  m.mail = ahead ? c->d_mail : nullptr;
+  m.mapped = c->d_pinned;
+  m.answers = answers;
+  return m;
+}
+// a fused bind+evaluate launch may be issued AHEAD of its challenge (the kernel waits at the mailbox) when the mailbox is in device memory.
+// The largest tables are left alone: their kernels are the bandwidth-bound ones whose durations the roofline is measured on.
+static bool launch_ahead_ok(sp_ctx* c, size_t table_len) {
+  static const size_t max_len = [] {
+    const char* e = getenv("SPARTAN_AHEAD_LOG2");
+    return (size_t)1 << (e ? atoi(e) : 19);
+  }();
+  return c->mail_dev && table_len <= max_len;
 }
 // result slots (= resident blocks still active) of the evaluation over a table of `len` elements
 static unsigned tail_blocks(size_t len) {
@@ -684,14 +716,106 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
   const size_t chunk = 256 * spk::EVAL_PPT;
   int rc = c->ensure_scratch((A->len / 2 + chunk - 1) / chunk * 2 + (A->len / 4 / 64) * 3 + 64);  // block partials or 72-byte lazy wave partials
   if (rc) return rc;
-  bool have_sums = false;  // true when the previous fused launch already produced this round's sums
+  bool have_sums = false;  // true when a launch already in flight produces this round's sums
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
   TailLease lease;
-  size_t pending_blocks = 0;
+  // What follows round `round`'s challenge r: the resident tail takes it from the mailbox, a fused launch binds with it and evaluates round + 1, or
+  // (last round, irregular zero structure) a plain bind. `r` == nullptr issues the work AHEAD of the challenge (mailbox in device memory): the
+  // launch overhead and the kernel's table loads then overlap the host's transcript step. Returns 1 = issued, 0 = needs r on the host, < 0 error.
+  auto issue = [&](size_t round, const fe_t* r, unsigned answers) -> int {
+    const bool ahead = r == nullptr;
+    const fe_t rv = r ? *r : fe_zero();
+    if (in_tail) {  // the resident kernel binds (and evaluates the next round) as soon as it sees the challenge
+      sp::after_bind(A);
+      sp::after_bind(B);
+      have_sums = false;
+      if (round + 1 < rounds) {
+        next_seq(c);
+        have_sums = true;
+        c->pending_slots = tail_blocks(A->len);
+      }
+      return 1;
+    }
+    if (round + 1 >= rounds) {
+      if (ahead) return 0;
+      sp_table* tabs[2] = {A, B};
+      have_sums = false;
+      int rc2 = launch_bind(c, tabs, 2, rv);
+      return rc2 ? rc2 : 1;
+    }
+    if (ahead && !launch_ahead_ok(c, A->len)) return 0;
+    if (tail_enabled() && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B) && lease.take(tail_blocks(A->len / 2))) {
+      spk::TailArgs ta;
+      ta.A = A->d;
+      ta.B = B->d;
+      ta.C = nullptr;
+      ta.len = A->len;
+      ta.r0 = rv;
+      ta.eq_pl = ta.eq_pr = nullptr;
+      ta.ell = ta.first_half = ta.rnd0 = 0;
+      ta.mail = c->d_mail;
+      ta.r0_from_mail = ahead ? 1 : 0;
+      ta.mapped = c->d_pinned;
+      ta.seq0 = next_seq(c);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      in_tail = true;
+      have_sums = true;
+      sp::after_bind(A);
+      sp::after_bind(B);
+      c->pending_slots = tail_blocks(A->len);
+      return 1;
+    }
+    const spk::MailRef mref = mail_ref(c, ahead, answers);
+    if (table_dense(A) && table_dense(B)) {
+      // fused: bind this round, evaluate the next (K1 + K3 in one pass over the tables)
+      const size_t q = A->len / 4;
+      size_t blocks = (q + chunk - 1) / chunk;
+      if (q >= STREAM_MIN_Q) {  // streaming regime: wave-level lazy partials + lazy second stage
+        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
+        const unsigned seq = next_seq(c);
+        c->timed("bind_stream_quad", 48ull * A->len * 2, [&] {
+          hipLaunchKernelGGL(spk::k_bind_eval_quad_stream, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, lp, mref);
+        });
+        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+        c->pending_slots = 0;
+      } else {
+        c->timed("bind", 48ull * A->len * 2, [&] {
+          hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, rv, c->d_scratch, c->d_pinned, next_seq(c), mref);
+        });
+        reduce_partials_launch(c, blocks, 2);
+      }
+      sp::after_bind(A);
+      sp::after_bind(B);
+      have_sums = true;
+      return 1;
+    }
+    if (A->len / 4 >= STREAM_MIN_Q && sp::eff_lo(A) == A->len / 2 && sp::eff_lo(B) == B->len / 2 && sp::eff_hi(A) <= A->len / 4 && sp::eff_hi(B) <= B->len / 4) {
+      // full low half, (almost) empty high half: bind without reading the zeros, evaluate the next round from registers
+      const size_t q = A->len / 4;
+      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
+      const unsigned seq = next_seq(c);
+      c->timed("bind_stream_quad_sparse", 64ull * (A->len / 2) * 2, [&] {
+        hipLaunchKernelGGL(spk::k_bind_eval_quad_stream_sparse, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, sp::eff_hi(A), sp::eff_hi(B), lp,
+                           mref);
+      });
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+      c->pending_slots = 0;
+      sp::after_bind(A);
+      sp::after_bind(B);
+      have_sums = true;
+      return 1;
+    }
+    if (ahead) return 0;
+    sp_table* tabs[2] = {A, B};
+    have_sums = false;
+    int rc2 = launch_bind(c, tabs, 2, rv);
+    return rc2 ? rc2 : 1;
+  };
   for (size_t round = 0; round < rounds; ++round) {
-    const size_t half = A->len / 2;
+    const size_t half = A->len / 2, len_now = A->len;
     const double tr0 = round_trace() ? now_us() : 0;
     fe_t sums[2] = {fe_zero(), fe_zero()};
+    bool waiting = have_sums;
     if (!have_sums) {  // compute_eval_points_quad on the current tables (src/sumcheck.rs:128-174)
       size_t len = sp::eff_pairs(A);
       if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
@@ -700,14 +824,29 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
         size_t blocks = (len + chunk - 1) / chunk;
         c->timed("eval_quad", 128ull * len,
                  [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch, c->d_pinned, next_seq(c)); });
-        rc = reduce_partials(c, blocks, 2, sums);
-        if (rc) return rc;
+        reduce_partials_launch(c, blocks, 2);
+        waiting = true;
       }
-    } else {
-      rc = reduce_partials_wait(c, 2, sums, in_tail);
+    }
+    // this round's sums are in flight: remember how to wait for them, then issue the next launch ahead of the challenge where that is possible
+    const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
+    const bool wait_resident = in_tail;
+    int issued = 0;
+    if (waiting && (in_tail || c->mail_dev)) {
+      issued = issue(round, nullptr, wait_seq);
+      if (issued < 0) return issued;
+    }
+    if (waiting) {
+      const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
+      c->result_seq = wait_seq;
+      c->pending_slots = wait_slots;
+      rc = reduce_partials_wait(c, 2, sums, wait_resident);
+      if (issued) {  // back to the state of the launch issued ahead
+        c->result_seq = cur_seq;
+        c->pending_slots = cur_slots;
+      }
       if (rc) return rc;
     }
-    (void)pending_blocks;
     if (reduce) {
       int hrc = reduce(reduce_user, reinterpret_cast<uint64_t*>(sums), 2);
       if (hrc) return fail(hrc, "prove_quad: the reduce hook failed");
@@ -726,79 +865,19 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     store_fe(out_cpolys + 8 * round, poly.c[0]);
     store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
     claim = poly_eval(poly, r_i);
-    sp_table* tabs[2] = {A, B};
-    have_sums = false;
-    if (in_tail) {  // the resident kernel binds (and evaluates the next round) as soon as it sees the challenge
-      tail_post_challenge(c, r_i, c->result_seq);
-      sp::after_bind(A);
-      sp::after_bind(B);
-      if (round + 1 < rounds) {
-        next_seq(c);
-        have_sums = true;
-        c->pending_slots = tail_blocks(A->len);
-      }
-    } else if (tail_enabled() && round + 1 < rounds && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B) && lease.take(tail_blocks(A->len / 2))) {
-      spk::TailArgs ta;
-      ta.A = A->d;
-      ta.B = B->d;
-      ta.C = nullptr;
-      ta.len = A->len;
-      ta.r0 = r_i;
-      ta.eq_pl = ta.eq_pr = nullptr;
-      ta.ell = ta.first_half = ta.rnd0 = 0;
-      ta.mapped = c->d_pinned;
-      ta.seq0 = next_seq(c);
-      hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
-      in_tail = true;
-      have_sums = true;
-      sp::after_bind(A);
-      sp::after_bind(B);
-      c->pending_slots = tail_blocks(A->len);
-    } else if (round + 1 < rounds && table_dense(A) && table_dense(B)) {
-      // fused: bind this round, evaluate the next (K1 + K3 in one pass over the tables)
-      const size_t q = A->len / 4;
-      size_t blocks = (q + chunk - 1) / chunk;
-      if (q >= STREAM_MIN_Q) {  // streaming regime: wave-level lazy partials + lazy second stage
-        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
-        const unsigned seq = next_seq(c);
-        c->timed("bind_stream_quad", 48ull * A->len * 2, [&] {
-          hipLaunchKernelGGL(spk::k_bind_eval_quad_stream, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, r_i, lp);
-        });
-        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
-      } else {
-        c->timed("bind", 48ull * A->len * 2, [&] {
-          hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, r_i, c->d_scratch, c->d_pinned, next_seq(c));
-        });
-        reduce_partials_launch(c, blocks, 2);
-      }
-      sp::after_bind(A);
-      sp::after_bind(B);
-      have_sums = true;
-    } else if (round + 1 < rounds && A->len / 4 >= STREAM_MIN_Q && sp::eff_lo(A) == A->len / 2 && sp::eff_lo(B) == B->len / 2 && sp::eff_hi(A) <= A->len / 4 &&
-               sp::eff_hi(B) <= B->len / 4) {
-      // full low half, (almost) empty high half: bind without reading the zeros, evaluate the next round from registers
-      const size_t q = A->len / 4;
-      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
-      const unsigned seq = next_seq(c);
-      const fe_t one_minus_r = fe_sub<S>(fe_one<S>(), r_i);
-      c->timed("bind_stream_quad_sparse", 64ull * (A->len / 2) * 2, [&] {
-        hipLaunchKernelGGL(spk::k_bind_eval_quad_stream_sparse, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, r_i, one_minus_r, sp::eff_hi(A),
-                           sp::eff_hi(B), lp);
-      });
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
-      sp::after_bind(A);
-      sp::after_bind(B);
-      have_sums = true;
+    if (issued) {
+      tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this
     } else {
-      rc = launch_bind(c, tabs, 2, r_i);
-      if (rc) return rc;
+      issued = issue(round, &r_i, wait_seq);
+      if (issued < 0) return issued;
+      if (wait_resident) tail_post_challenge(c, r_i, wait_seq);
     }
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];
       store_fe(rw, r_i);
       observe(observe_user, round, rw);
     }
-    if (round_trace()) fprintf(stderr, "quad round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", round, A->len * 2, (int)in_tail, tr1 - tr0, now_us() - tr1);
+    if (round_trace()) fprintf(stderr, "quad round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", round, len_now, (int)wait_resident, tr1 - tr0, now_us() - tr1);
   }
   rc = sp_table_read(c, A, 0, 1, out_final);
   if (rc) return rc;
@@ -955,10 +1034,16 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
   fe_t* d_pl = d_trt + second_half;
   fe_t* d_pr = d_pl + pyr_left;
   if (nleft > 10 || second_half > 10) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sum-check over more than 2^21 rows: eq pyramid kernel needs widening");
-  if (nleft) SP_HIP(hipMemcpyAsync(d_tl, taus.data() + 1, nleft * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-  SP_HIP(hipMemcpyAsync(d_trt, taus.data() + first_half, second_half * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_tl, (int)nleft, d_pl);
-  hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_trt, (int)second_half, d_pr);
+  {
+    spk::EqPairArgs ea;
+    for (size_t i = 0; i < nleft; ++i) ea.v[0][i] = taus[1 + i];
+    for (size_t i = 0; i < second_half; ++i) ea.v[1][i] = taus[first_half + i];
+    ea.m[0] = (int)nleft;
+    ea.m[1] = (int)second_half;
+    ea.out[0] = d_pl;
+    ea.out[1] = d_pr;
+    hipLaunchKernelGGL(spk::k_eq_levels_pair, dim3(2), dim3(1024), 0, c->stream, ea);
+  }
 
   // eq tables of round `rnd` (1-based, src/sumcheck.rs:1011) for `half` pairs
   struct EqSel {
@@ -1017,6 +1102,90 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     return SP_OK;
   };
   const uint8_t lbl_c[1] = {'c'};
+  // What follows round `rnd`'s challenge r (see the quadratic loop): the tail's bookkeeping, the tail launch, a fused bind + evaluation of round
+  // rnd + 1, or the last plain bind. r == nullptr issues it ahead of the challenge. Returns 1 = issued, 0 = needs r on the host, < 0 error.
+  auto issue = [&](size_t rnd, const fe_t* r, unsigned answers) -> int {
+    const bool ahead = r == nullptr;
+    const fe_t rv = r ? *r : fe_zero();
+    if (in_tail) {
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+      if (rnd < ell) {
+        next_seq(c);
+        c->pending_slots = tail_blocks(A->len);
+      }
+      return 1;
+    }
+    if (rnd >= ell) {
+      if (ahead) return 0;
+      sp_table* tabs[3] = {A, B, C};
+      int rc2 = launch_bind(c, tabs, 3, rv);
+      return rc2 ? rc2 : 1;
+    }
+    if (ahead && !launch_ahead_ok(c, A->len)) return 0;
+    if (tail_enabled() && A->len <= TAIL_MAX_LEN && lease.take(tail_blocks(A->len / 2))) {
+      spk::TailArgs ta;
+      ta.A = A->d;
+      ta.B = B->d;
+      ta.C = C->d;
+      ta.len = A->len;
+      ta.r0 = rv;
+      ta.eq_pl = d_pl;
+      ta.eq_pr = d_pr;
+      ta.ell = (int)ell;
+      ta.first_half = (int)first_half;
+      ta.rnd0 = (int)rnd + 1;
+      ta.mail = c->d_mail;
+      ta.r0_from_mail = ahead ? 1 : 0;
+      ta.mapped = c->d_pinned;
+      ta.seq0 = next_seq(c);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      in_tail = true;
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+      c->pending_slots = tail_blocks(A->len);
+      return 1;
+    }
+    // K1 fused with next round's K2: bind with r, evaluate round rnd+1 from registers
+    const spk::MailRef mref = mail_ref(c, ahead, answers);
+    const size_t q = A->len / 4;
+    const EqSel e = select_eq(rnd + 1);
+    dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
+    const unsigned seq = next_seq(c);
+    if (q >= STREAM_MIN_Q && (e.mode == 0 || (e.mode == 1 && e.s >= 8))) {
+      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
+      c->timed("bind_stream_cubic", 48ull * A->len * 3, [&] {
+        const dim3 gs((unsigned)(q / 256));
+        if (e.mode == 0 && ahead) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<0, true>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
+        else if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<0, false>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
+        else if (ahead) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<1, true>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
+        else hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<1, false>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
+      });
+      // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
+                         c->d_pinned, seq);
+      c->pending_slots = 0;
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+    } else {
+      c->timed("bind", 48ull * A->len * 3, [&] {
+        if (e.mode == 0)
+          hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq, mref);
+        else if (e.mode == 1)
+          hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq, mref);
+        else
+          hipLaunchKernelGGL((spk::k_bind_eval_cubic<2>), g, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq, mref);
+      });
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+      reduce_partials_launch(c, g.x, 2);
+    }
+    return 1;
+  };
   // round 1 sums from a plain evaluation pass; later rounds get theirs from the fused bind+eval of the previous round
   {
     size_t blocks = 0;
@@ -1033,17 +1202,34 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     const fe_t l_0_p = fe_mul<S>(eq0, p);
     const fe_t l_1_p = fe_mul<S>(fe_add<S>(eq0, slope), p);
     const bool invertible = !fe_is_zero(l_1_p);
+    // this round's sums are in flight: remember how to wait for them, then issue the next launch ahead of the challenge where that is possible.
+    // Not when tau * p vanishes: that round re-evaluates with a third sum (fallback_three_inputs), which must not queue behind a waiting kernel.
+    const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
+    const bool wait_resident = in_tail;
+    int issued = 0;
+    if (in_tail || (c->mail_dev && invertible)) {
+      issued = issue(rnd, nullptr, wait_seq);
+      if (issued < 0) return issued;
+    }
+    const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
+    c->result_seq = wait_seq;
+    c->pending_slots = wait_slots;
     const fe_t l_1_p_inv = invertible ? fe_inv<S>(l_1_p) : fe_zero();  // runs while the device computes this round's sums
     fe_t sums[3];
     const double tr0 = round_trace() ? now_us() : 0;
-    rc = reduce_partials_wait(c, in_tail ? 3 : 2, sums, in_tail);
+    const size_t len_now = A->len;
+    rc = reduce_partials_wait(c, wait_resident ? 3 : 2, sums, wait_resident);
+    if (issued) {  // back to the state of the launch issued ahead
+      c->result_seq = cur_seq;
+      c->pending_slots = cur_slots;
+    }
     if (rc) return rc;
     const double tr1 = round_trace() ? now_us() : 0;
-    if ((rc = combine(sums, in_tail ? 3 : 2))) return rc;
+    if ((rc = combine(sums, wait_resident ? 3 : 2))) return rc;
     const fe_t t0 = sums[0], tinf = sums[1];
     // derive_from_claim (:1276-1324)
     fe_t s_0, s_1, s_leading, s_m1;
-    if (in_tail && !invertible) {  // fallback_three_inputs (:1327-1396): the resident tail kernel always delivers t(-1) as its third sum
+    if (wait_resident && !invertible) {  // fallback_three_inputs (:1327-1396): the resident tail kernel always delivers t(-1) as its third sum
       s_0 = fe_mul<S>(fe_mul<S>(eq0, p), t0);
       s_1 = fe_sub<S>(claim, s_0);
       s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
@@ -1087,72 +1273,15 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
     store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
     claim = poly_eval(poly, r_i);
-    if (in_tail) {
-      tail_post_challenge(c, r_i, c->result_seq);
-      sp::after_bind(A);
-      sp::after_bind(B);
-      sp::after_bind(C);
-      if (rnd < ell) {
-        next_seq(c);
-        c->pending_slots = tail_blocks(A->len);
-      }
-    } else if (tail_enabled() && rnd < ell && A->len <= TAIL_MAX_LEN && lease.take(tail_blocks(A->len / 2))) {
-      spk::TailArgs ta;
-      ta.A = A->d;
-      ta.B = B->d;
-      ta.C = C->d;
-      ta.len = A->len;
-      ta.r0 = r_i;
-      ta.eq_pl = d_pl;
-      ta.eq_pr = d_pr;
-      ta.ell = (int)ell;
-      ta.first_half = (int)first_half;
-      ta.rnd0 = (int)rnd + 1;
-      ta.mapped = c->d_pinned;
-      ta.seq0 = next_seq(c);
-      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
-      in_tail = true;
-      sp::after_bind(A);
-      sp::after_bind(B);
-      sp::after_bind(C);
-      c->pending_slots = tail_blocks(A->len);
-    } else if (rnd < ell) {
-      // K1 fused with next round's K2: bind with r_i, evaluate round rnd+1 from registers
-      const size_t q = A->len / 4;
-      const EqSel e = select_eq(rnd + 1);
-      dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
-      const unsigned seq = next_seq(c);
-      if (q >= STREAM_MIN_Q && (e.mode == 0 || (e.mode == 1 && e.s >= 8))) {
-        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
-        c->timed("bind_stream_cubic", 48ull * A->len * 3, [&] {
-          if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<0>), dim3((unsigned)(q / 256)), b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.s, lp);
-          else hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<1>), dim3((unsigned)(q / 256)), b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.s, lp);
-        });
-        // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
-        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
-                           c->d_pinned, seq);
-        sp::after_bind(A);
-        sp::after_bind(B);
-        sp::after_bind(C);
-      } else {
-      c->timed("bind", 48ull * A->len * 3, [&] {
-        if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic<0>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
-        else if (e.mode == 1) hipLaunchKernelGGL((spk::k_bind_eval_cubic<1>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
-        else hipLaunchKernelGGL((spk::k_bind_eval_cubic<2>), g, b, 0, c->stream, A->d, B->d, C->d, q, r_i, e.eq_in, e.eq_out, e.s, d_part, c->d_pinned, seq);
-      });
-      sp::after_bind(A);
-      sp::after_bind(B);
-      sp::after_bind(C);
-      reduce_partials_launch(c, g.x, 2);
-      }
+    if (issued) {
+      tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this
     } else {
-      sp_table* tabs[3] = {A, B, C};
-      rc = launch_bind(c, tabs, 3, r_i);
-      if (rc) return rc;
+      issued = issue(rnd, &r_i, wait_seq);
+      if (issued < 0) return issued;
     }
     // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
-    if (round_trace()) fprintf(stderr, "cubic round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", rnd, A->len * 2, (int)in_tail, tr1 - tr0, now_us() - tr1);
+    if (round_trace()) fprintf(stderr, "cubic round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", rnd, len_now, (int)wait_resident, tr1 - tr0, now_us() - tr1);
   }
   rc = sp_table_read(c, A, 0, 1, out_final);
   if (rc) return rc;

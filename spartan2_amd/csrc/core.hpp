@@ -38,6 +38,12 @@ struct sp_ctx {
   size_t scratch_elems = 0;
   fe_t* h_pinned = nullptr;  // small result buffer, pinned + mapped
   fe_t* d_pinned = nullptr;  // device-side address of h_pinned
+  // challenge mailbox (kernels_poly.cuh mail_wait): in fine-grained device memory written through the PCIe BAR when the system has a large BAR
+  // (mail_dev), otherwise inside h_pinned. h_mail / d_mail = host-side / device-side address of the same 64-byte line.
+  volatile uint32_t* h_mail = nullptr;
+  const unsigned* d_mail = nullptr;
+  void* mail_alloc = nullptr;
+  bool mail_dev = false;
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs
   hipEvent_t fb_ev = nullptr;
   hipEvent_t fb_event() {

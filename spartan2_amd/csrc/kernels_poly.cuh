@@ -56,6 +56,57 @@ __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __r
   }
 }
 
+// ---- challenge mailbox ------------------------------------------------------------------------------------------------------------------
+// A kernel that binds with a challenge the host has not drawn yet is launched AHEAD of it and picks the challenge up from a 64-byte mailbox line:
+// words 0..7 = challenge, 8 = the result sequence number it answers, 9 = check word (sequence + sum of the challenge words). The line lives in
+// fine-grained DEVICE memory that the host writes through the PCIe BAR (capi_core.hip post_challenge) — so a thousand blocks can poll it without
+// touching the bus — or, without a large BAR, in mapped host memory (resident tail only). Lanes 0..9 of wave 0 read the ten words in ONE
+// instruction; a poll that straddles the host's stores fails the check and is repeated. Never hangs: after 2 s the error word in the mapped
+// result buffer is set and the kernel carries on with whatever it read.
+constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10;
+struct MailRef {
+  const unsigned* mail;  // nullptr: the challenge is the kernel argument
+  fe_t* mapped;          // mapped pinned result buffer (error word at TAIL_ERR_ELEM)
+  unsigned answers;      // sequence number of the round result the awaited challenge answers
+};
+__device__ __forceinline__ bool mail_wait(const unsigned* mail, fe_t* mapped, unsigned want, fe_t* r_smem) {
+  __shared__ int ok;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    int good = 0;
+    unsigned w = 0;
+    while (true) {
+      if (lane < 10) w = __hip_atomic_load(mail + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned flag = __shfl(w, 8, 64), chk = __shfl(w, 9, 64);
+      if (flag == want) {
+        unsigned sum = lane < 8 ? w : 0u;
+#pragma unroll
+        for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+        sum = __shfl(sum, 0, 64) + flag;
+        if (sum == chk) {
+          good = 1;
+          break;
+        }
+      }
+      if (wall_clock64() - t0 > 200000000ull) break;  // 2 s at 100 MHz: the host went away; never hang the device
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane < 8) r_smem->v[lane] = w;
+    if (!good && lane == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(mapped + TAIL_ERR_ELEM), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) ok = good;
+  }
+  __syncthreads();
+  return ok != 0;
+}
+// the challenge of a fused bind+evaluate kernel: its argument, or the mailbox when it was launched ahead (all threads of the block must call)
+__device__ __forceinline__ fe_t challenge_or(const MailRef& m, const fe_t& r_arg) {
+  if (!m.mail) return r_arg;
+  __shared__ fe_t r_sh;
+  mail_wait(m.mail, m.mapped, m.answers, &r_sh);
+  return r_sh;
+}
+
 // ---- K1: bind the top variable of up to 4 tables with the same challenge -----------------------------------
 struct BindArgs {
   fe_t* z[4];
@@ -96,6 +147,33 @@ __global__ void __launch_bounds__(1024) k_eq_levels(const fe_t* __restrict__ v, 
   __syncthreads();
   for (int k = 0; k < m; ++k) {
     const fe_t r = v[m - 1 - k];
+    const fe_t* prev = out + eq_level_offset(k);
+    fe_t* next = out + eq_level_offset(k + 1);
+    const size_t size = (size_t)1 << k;
+    for (size_t i = threadIdx.x; i < size; i += blockDim.x) {
+      fe_t e = prev[i];
+      fe_t y = fe_mul<S>(e, r);
+      next[size + i] = y;
+      next[i] = fe_sub<S>(e, y);
+    }
+    __syncthreads();
+  }
+}
+// both pyramids of EqSumCheckInstance::new (src/sumcheck.rs:956-992) in one launch: block 0 the left one, block 1 the right one, the taus by value
+// (no upload in front of the first evaluation)
+struct EqPairArgs {
+  fe_t v[2][11];
+  int m[2];
+  fe_t* out[2];
+};
+__global__ void __launch_bounds__(1024) k_eq_levels_pair(EqPairArgs a) {
+  const int b = blockIdx.x;
+  const int m = a.m[b];
+  fe_t* out = a.out[b];
+  if (threadIdx.x == 0) out[0] = fe_one<S>();
+  __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    const fe_t r = a.v[b][m - 1 - k];
     const fe_t* prev = out + eq_level_offset(k);
     fe_t* next = out + eq_level_offset(k + 1);
     const size_t size = (size_t)1 << k;
@@ -173,10 +251,11 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
 // unfused bind; the next round's sums come from registers for free.
 __device__ __forceinline__ fe_t bind1(const fe_t& lo, const fe_t& hi, const fe_t& r) { return fe_add<S>(lo, fe_mul<S>(r, fe_sub<S>(hi, lo))); }
 template <int MODE>
-__global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r,
+__global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r_arg,
                                                          const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
-                                                         fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq) {
+                                                         fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq, MailRef mref) {
   __shared__ fe_t smem[2 * 4];
+  const fe_t r = challenge_or(mref, r_arg);
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
   const size_t mask = ((size_t)1 << s) - 1;
@@ -217,9 +296,10 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, f
   }
 }
 // dense quadratic variant (both tables fully non-zero)
-__global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, fe_t* __restrict__ partials,
-                                                        fe_t* __restrict__ single_out, unsigned seq) {
+__global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, fe_t* __restrict__ partials,
+                                                        fe_t* __restrict__ single_out, unsigned seq, MailRef mref) {
   __shared__ fe_t smem[2 * 4];
+  const fe_t r = challenge_or(mref, r_arg);
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
   const size_t base = (size_t)blockIdx.x * chunk;
   fe_t acc[2] = {fe_zero(), fe_zero()};
@@ -263,14 +343,18 @@ __device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const l
     partials[(size_t)blockIdx.x * 2 + threadIdx.x] = t;
   }
 }
-template <int MODE>
-__global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r,
-                                                                const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials) {
+// AHEAD: launched before its challenge is known (waits at the mailbox). A separate instantiation so that the ordinary form keeps its register
+// budget (128 VGPRs, 4 waves per SIMD): holding the twelve loaded elements across the mailbox barrier costs 20 more.
+template <int MODE, bool AHEAD>
+__global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r_arg,
+                                                                const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials, MailRef mref) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // q is a multiple of the block size here
   const size_t mask = ((size_t)1 << s) - 1;
   const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
   const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
   const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
+  fe_t r = r_arg;
+  if (AHEAD) r = challenge_or(mref, r_arg);  // after the loads: a kernel launched ahead fetches its tables while the host draws the challenge
   const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
   const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
   const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
@@ -285,10 +369,12 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict
   const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
 }
-__global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, lazy9_t* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, lazy9_t* __restrict__ partials,
+                                                               MailRef mref) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
   const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  const fe_t r = challenge_or(mref, r_arg);
   const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
   const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
   A[id] = a0;
@@ -300,10 +386,12 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict_
 // The same for tables whose high half is zero beyond the first hiA / hiB entries (hi* <= q): the inner sum-check's first bind on z and poly_ABC
 // (2M long, non-zero up to M + num_extra; bind_poly_var_top's `hi <= lo` branch, src/polys/multilinear.rs:118-141). The high half is not read at
 // all except for those few entries, and the evaluation of the next round still comes from registers.
-__global__ void __launch_bounds__(256) k_bind_eval_quad_stream_sparse(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, fe_t one_minus_r, size_t hiA,
-                                                                      size_t hiB, lazy9_t* __restrict__ partials) {
+__global__ void __launch_bounds__(256) k_bind_eval_quad_stream_sparse(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, size_t hiA, size_t hiB,
+                                                                      lazy9_t* __restrict__ partials, MailRef mref) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const fe_t la0 = A[id], la1 = A[id + q], lb0 = B[id], lb1 = B[id + q];
+  const fe_t r = challenge_or(mref, r_arg);
+  const fe_t one_minus_r = fe_sub<S>(fe_one<S>(), r);
   const fe_t a0 = id < hiA ? bind1(la0, A[id + 2 * q], r) : fe_mul<S>(la0, one_minus_r);
   const fe_t b0 = id < hiB ? bind1(lb0, B[id + 2 * q], r) : fe_mul<S>(lb0, one_minus_r);
   const fe_t a1 = fe_mul<S>(la1, one_minus_r), b1 = fe_mul<S>(lb1, one_minus_r);  // id + q >= q >= hi*: partner is zero
@@ -438,7 +526,6 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
 // its transcript step. Cubic mode also delivers the third sum t(-1) (fallback_three_inputs, src/sumcheck.rs:1327-1396): the host uses it only
 // when tau * p is not invertible, otherwise it derives the evaluations from the claim exactly as the reference does (:1276-1324).
 // Slots in the mapped buffer: TAIL_CHAL_ELEM = the 64-byte mailbox line (challenge | sequence | check word), word 0 of TAIL_ERR_ELEM = error.
-constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10;
 constexpr int TAIL_THREADS = 1024;
 constexpr unsigned long long TAIL_WIDE_Q = 256;  // pairs per resident block and round: every product gets its own lane (3 * 256 <= TAIL_THREADS)
 struct TailArgs {
@@ -449,46 +536,11 @@ struct TailArgs {
   // rnd0 = 1-based index of the first round this kernel EVALUATES
   const fe_t *eq_pl, *eq_pr;
   int ell, first_half, rnd0;
-  fe_t* mapped;             // device address of the mapped pinned buffer (per-block result slots at SLOT_BASE_ELEM, mailbox at TAIL_CHAL_ELEM)
+  const unsigned* mail;     // the challenge mailbox (see mail_wait)
+  int r0_from_mail;         // launched ahead of r0: the first round waits for the mailbox too
+  fe_t* mapped;             // device address of the mapped pinned buffer (per-block result slots at SLOT_BASE_ELEM, error word)
   unsigned seq0;            // sequence number of the first result this kernel publishes
 };
-// Lanes 0..9 of wave 0 each read one word of the mailbox line (8 challenge words, the sequence word, a check word = sequence + sum of the
-// challenge words) in the SAME instruction, so a poll is one PCIe round trip; a poll that straddles the host's stores fails the check and
-// is simply repeated.
-__device__ __forceinline__ bool tail_wait_challenge(fe_t* mapped, unsigned want, fe_t* r_smem) {
-  __shared__ int ok;
-  if (threadIdx.x < 64) {
-    const unsigned* base = reinterpret_cast<const unsigned*>(mapped + TAIL_CHAL_ELEM);
-    const int lane = threadIdx.x;
-    const unsigned long long t0 = wall_clock64();
-    int good = 0;
-    unsigned w = 0;
-    while (true) {
-      if (lane < 10) w = __hip_atomic_load(base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const unsigned flag = __shfl(w, 8, 64), chk = __shfl(w, 9, 64);
-      if (flag == want) {
-        unsigned sum = lane < 8 ? w : 0u;
-#pragma unroll
-        for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-        sum = __shfl(sum, 0, 64) + flag;
-        if (sum == chk) {
-          good = 1;
-          break;
-        }
-      }
-      if (wall_clock64() - t0 > 200000000ull) break;  // 2 s at 100 MHz: the host went away; never hang the device
-      __builtin_amdgcn_s_sleep(1);
-    }
-    if (good) {
-      if (lane < 8) r_smem->v[lane] = w;
-    } else if (lane == 0) {
-      __hip_atomic_store(reinterpret_cast<unsigned*>(mapped + TAIL_ERR_ELEM), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (lane == 0) ok = good;
-  }
-  __syncthreads();
-  return ok != 0;
-}
 __device__ __forceinline__ fe_t load_agent(const fe_t* p) {
   fe_t v;
   const unsigned long long* w = reinterpret_cast<const unsigned long long*>(p);
@@ -520,8 +572,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   while (true) {
     const unsigned long long q = len / 4;
     if (len > 2 ? base >= q : blockIdx.x != 0) return;
-    if (!first) {
-      if (!tail_wait_challenge(a.mapped, seq - 1, &r_sh)) return;
+    if (!first || a.r0_from_mail) {
+      if (!mail_wait(a.mail, a.mapped, seq - 1, &r_sh)) return;
       r = r_sh;
     }
     // the previous round had 2q pairs: while that is more than one block's worth, the elements bound below were written by other blocks
