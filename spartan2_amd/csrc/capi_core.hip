@@ -299,6 +299,38 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
 }
 // `resident`: the result comes from the resident tail kernel, which is itself waiting for the host's next challenge — a stream synchronise
 // would never return, so the host keeps polling (bounded by wall-clock; the kernel gives up after 2 s as well).
+// one self-validating slot (kernels_poly.cuh slot_store_tag): wait for its sequence word, then re-read until the check word matches the data
+static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t* v, bool resident, long* spins) {
+  volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
+  while (*fl != want) {
+    if (++*spins > 400000) {  // a few ms
+      if (resident) {        // the tail kernel is itself waiting for the host: keep polling, bounded by wall-clock
+        const auto t0 = std::chrono::steady_clock::now();
+        while (*fl != want) {
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
+          __builtin_ia32_pause();
+        }
+        break;
+      }
+      SP_HIP(hipStreamSynchronize(c->stream));  // e.g. under a profiler
+      if (*fl != want) return fail(SP_ERR_INTERNAL, "evaluation kernel did not deliver its block sums");
+    }
+    __builtin_ia32_pause();
+  }
+  for (long tries = 0;; ++tries) {
+    std::atomic_thread_fence(std::memory_order_acquire);
+    uint32_t chk = want;
+    for (int k = 0; k < nvals; ++k) {
+      for (int i = 0; i < 8; ++i) {
+        v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
+        chk += v[k].v[i];
+      }
+    }
+    if (fl[1] == chk) return SP_OK;
+    if (tries > 4000000) return fail(SP_ERR_INTERNAL, "evaluation kernel delivered an inconsistent result slot");
+    __builtin_ia32_pause();
+  }
+}
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false) {
   const unsigned want = c->result_seq;
   if (c->pending_slots) {  // per-block slots: wait for every block's sequence word, add on the host
@@ -307,38 +339,9 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
     for (int k = 0; k < nacc; ++k) out_host[k] = fe_zero();
     long spins = 0;
     for (unsigned b = 0; b < nb; ++b) {
-      const fe_t* slot = c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b;
-      volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
-      while (*fl != want) {
-        if (++spins > 400000) {  // a few ms
-          if (resident) {        // the tail kernel is itself waiting for the host: keep polling, bounded by wall-clock
-            const auto t0 = std::chrono::steady_clock::now();
-            while (*fl != want) {
-              if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
-              __builtin_ia32_pause();
-            }
-            break;
-          }
-          SP_HIP(hipStreamSynchronize(c->stream));  // e.g. under a profiler
-          if (*fl != want) return fail(SP_ERR_INTERNAL, "evaluation kernel did not deliver its block sums");
-        }
-        __builtin_ia32_pause();
-      }
-      // the slot is valid once its check word matches the data (kernels_poly.cuh slot_store_tag): re-read until it does
       fe_t v[3];
-      for (long tries = 0;; ++tries) {
-        std::atomic_thread_fence(std::memory_order_acquire);
-        uint32_t chk = want;
-        for (int k = 0; k < nacc; ++k) {
-          for (int i = 0; i < 8; ++i) {
-            v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
-            chk += v[k].v[i];
-          }
-        }
-        if (fl[1] == chk) break;
-        if (tries > 4000000) return fail(SP_ERR_INTERNAL, "evaluation kernel delivered an inconsistent result slot");
-        __builtin_ia32_pause();
-      }
+      int rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b, want, nacc, v, resident, &spins);
+      if (rc) return rc;
       for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], v[k]);
     }
     return SP_OK;
@@ -718,6 +721,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
   if (rc) return rc;
   bool have_sums = false;  // true when a launch already in flight produces this round's sums
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
+  unsigned last_answered = 0;  // sequence number answered by the most recent challenge
   TailLease lease;
   // What follows round `round`'s challenge r: the resident tail takes it from the mailbox, a fused launch binds with it and evaluates round + 1, or
   // (last round, irregular zero structure) a plain bind. `r` == nullptr issues the work AHEAD of the challenge (mailbox in device memory): the
@@ -865,6 +869,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     store_fe(out_cpolys + 8 * round, poly.c[0]);
     store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
     claim = poly_eval(poly, r_i);
+    last_answered = wait_seq;
     if (issued) {
       tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this
     } else {
@@ -879,10 +884,18 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     }
     if (round_trace()) fprintf(stderr, "quad round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", round, len_now, (int)wait_resident, tr1 - tr0, now_us() - tr1);
   }
-  rc = sp_table_read(c, A, 0, 1, out_final);
-  if (rc) return rc;
-  rc = sp_table_read(c, B, 0, 1, out_final + 4);
-  if (rc) return rc;
+  if (in_tail) {  // the resident kernel hands the final claims over itself
+    fe_t fin[3];
+    long spins = 0;
+    if ((rc = wait_slot(c, c->h_pinned + spk::TAIL_FINAL_ELEM, last_answered, 2, fin, true, &spins))) return rc;
+    store_fe(out_final, fin[0]);
+    store_fe(out_final + 4, fin[1]);
+  } else {
+    rc = sp_table_read(c, A, 0, 1, out_final);
+    if (rc) return rc;
+    rc = sp_table_read(c, B, 0, 1, out_final + 4);
+    if (rc) return rc;
+  }
   store_fe(claim_io, claim);
   return in_tail ? tail_check(c) : SP_OK;
 }
@@ -1088,6 +1101,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
 
   fe_t claim = load_fe(claim_);
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
+  unsigned last_answered = 0;
   TailLease lease;
   fe_t eval_eq_left = load_fe(p_io);
   const fe_t one = fe_one<S>();
@@ -1273,6 +1287,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
     store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
     claim = poly_eval(poly, r_i);
+    last_answered = wait_seq;
     if (issued) {
       tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this
     } else {
@@ -1283,12 +1298,21 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
     if (round_trace()) fprintf(stderr, "cubic round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", rnd, len_now, (int)wait_resident, tr1 - tr0, now_us() - tr1);
   }
-  rc = sp_table_read(c, A, 0, 1, out_final);
-  if (rc) return rc;
-  rc = sp_table_read(c, B, 0, 1, out_final + 4);
-  if (rc) return rc;
-  rc = sp_table_read(c, C, 0, 1, out_final + 8);
-  if (rc) return rc;
+  if (in_tail) {  // the resident kernel hands the final claims over itself
+    fe_t fin[3];
+    long spins = 0;
+    if ((rc = wait_slot(c, c->h_pinned + spk::TAIL_FINAL_ELEM, last_answered, 3, fin, true, &spins))) return rc;
+    store_fe(out_final, fin[0]);
+    store_fe(out_final + 4, fin[1]);
+    store_fe(out_final + 8, fin[2]);
+  } else {
+    rc = sp_table_read(c, A, 0, 1, out_final);
+    if (rc) return rc;
+    rc = sp_table_read(c, B, 0, 1, out_final + 4);
+    if (rc) return rc;
+    rc = sp_table_read(c, C, 0, 1, out_final + 8);
+    if (rc) return rc;
+  }
   store_fe(claim_io, claim);
   store_fe(p_io, eval_eq_left);
   return in_tail ? tail_check(c) : SP_OK;

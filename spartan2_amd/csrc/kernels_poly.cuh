@@ -63,7 +63,7 @@ __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __r
 // touching the bus — or, without a large BAR, in mapped host memory (resident tail only). Lanes 0..9 of wave 0 read the ten words in ONE
 // instruction; a poll that straddles the host's stores fails the check and is repeated. Never hangs: after 2 s the error word in the mapped
 // result buffer is set and the kernel carries on with whatever it read.
-constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10;
+constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in the mapped result buffer
 struct MailRef {
   const unsigned* mail;  // nullptr: the challenge is the kernel argument
   fe_t* mapped;          // mapped pinned result buffer (error word at TAIL_ERR_ELEM)
@@ -581,11 +581,22 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     // invalidate it (measured: 4 us per round).
     const bool foreign = 2 * q > TAIL_WIDE_Q;
     first = false;
-    if (len == 2) {  // last round: bind only
+    if (len == 2) {  // last round: bind only; the final claims also go to the host in a slot of their own (saves three synchronous reads)
       if (threadIdx.x == 0) {
-        a.A[0] = bind1(a.A[0], a.A[1], r);
-        a.B[0] = bind1(a.B[0], a.B[1], r);
-        if (CUBIC) a.C[0] = bind1(a.C[0], a.C[1], r);
+        fe_t* fin = a.mapped + TAIL_FINAL_ELEM;
+        const fe_t fa = bind1(a.A[0], a.A[1], r), fb = bind1(a.B[0], a.B[1], r);
+        a.A[0] = fa;
+        a.B[0] = fb;
+        slot_store_elem(fin, fa);
+        slot_store_elem(fin + 1, fb);
+        unsigned chk = slot_check_word(fa) + slot_check_word(fb);
+        if (CUBIC) {
+          const fe_t fc = bind1(a.C[0], a.C[1], r);
+          a.C[0] = fc;
+          slot_store_elem(fin + 2, fc);
+          chk += slot_check_word(fc);
+        }
+        slot_store_tag(fin, seq - 1, chk);  // tagged with the result number the last challenge answered
       }
       return;
     }
