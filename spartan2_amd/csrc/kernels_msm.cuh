@@ -210,7 +210,10 @@ __global__ void __launch_bounds__(256) k_msm_sort(const fe_t* __restrict__ canon
 }
 
 // 8 lanes per bucket; grid covers windows * 128 buckets * 8 lanes.
-constexpr int MSM_LANES_PER_BUCKET = 8;
+#ifndef MSM_LPB
+#define MSM_LPB 8
+#endif
+constexpr int MSM_LANES_PER_BUCKET = MSM_LPB;
 __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict__ bases, unsigned n, const unsigned* __restrict__ order,
                                                         const unsigned* __restrict__ start, int windows, jac_t* __restrict__ buckets) {
   // blockIdx.y = row of a shared-weights batch (msm.rs:228-356): same digits, different bases; 0 for a plain MSM

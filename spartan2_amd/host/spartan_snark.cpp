@@ -391,11 +391,20 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const size_t n_ipa = M < W_ ? M : W_;
   std::vector<fe_t> dvec(n_ipa);
   fe_t r_delta_ahead;
-  {
+  {  // on the helper thread (1024 wide reductions, 70 us): nothing needs d_vec before delta's MSM is issued
     Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
-    for (auto& x : dvec) x = peek.next();
-    r_delta_ahead = peek.next();  // ipa.rs:146: the blind of delta follows d_vec on the tape
+    fe_t* dv = dvec.data();
+    const size_t dn = dvec.size();
+    fe_t* rd = &r_delta_ahead;
+    ps.bg.submit([peek, dv, dn, rd]() mutable {
+      for (size_t i = 0; i < dn; ++i) dv[i] = peek.next();
+      *rd = peek.next();  // ipa.rs:146: the blind of delta follows d_vec on the tape
+    });
   }
+  struct DrawJoin {  // dvec must outlive the job on every exit path
+    Background& b;
+    ~DrawJoin() { b.wait_nothrow(); }
+  } draw_join{ps.bg};
   lap("dvec_draw");
 
   if (rest_job) ck(sp_fixed_base_mul_h_finish(ctx, rest_job, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
@@ -411,12 +420,13 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
   // comm_W is complete: its transcript encoding (64 B per row, Montgomery -> canonical) and the Keccak blocks of absorb("poly_com", ..), the
   // first absorb after the inner sum-check's last squeeze (hyrax_pc.rs:387-400), are computed on the helper thread from here on
+  ps.bg.wait();  // d_vec and r_delta are drawn
   sp_absorb_state_free(ps.poly_com);
   ps.poly_com = nullptr;
   // The same helper then computes comm_LZ = sum_i L[i] comm_W[i] (= commit(L . W; <L, r_W>), hyrax_pc.rs:430-455, by the homomorphism of the
   // commitment) as soon as the inner sum-check has bound the row variables: the MSM runs under the remaining rounds instead of after them.
   const size_t lz_rows = (M + W_ - 1) / W_, lz_nvr = log2_ceil(lz_rows);
-  static const bool lz_direct = [] {  // SPARTAN_LZ_DIRECT=1: the reference's own order (bind W with L first, then MSM over the key)
+  const bool lz_direct = [] {  // SPARTAN_LZ_DIRECT=1: the reference's own order (bind W with L first, then MSM over the key); read per call
     const char* e = getenv("SPARTAN_LZ_DIRECT");
     return e && e[0] == '1';
   }();

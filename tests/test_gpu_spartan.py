@@ -100,3 +100,31 @@ def test_wrong_witness_length_is_an_error(ctx):
     with pytest.raises(hip.SpartanHipError) as e:
         gsp.prep_prove(ol.make_tape(1, 64))
     assert "rc=-2" in str(e.value)  # SpartanError::InvalidWitnessLength
+
+
+def test_prove_is_identical_on_every_driver_path(ctx, monkeypatch):
+    """The latency machinery must not change a single proof word: the default driver (comm_LZ as an MSM over the row commitments started
+    mid-sum-check by the helper thread, rounds launched ahead of their challenge through the device-memory mailbox, resident tail) against
+    SPARTAN_LZ_DIRECT=1 (the reference's order: bind W with L, then the MSM over the key) and SPARTAN_MAIL_DEV=0 (launch after each
+    challenge, host-memory mailbox). Several rows of W so that the row variables exist."""
+    inst = frontend.sha256_circuit(bytes(range(150)))
+    tape = ol.make_tape(23, 8192)
+
+    def prove_with(c):
+        sn = host.SpartanSNARK(c, inst)
+        used = sn.prep_prove(tape)
+        words, _, _ = sn.prove(tape[used:])
+        again, _, _ = sn.prove(tape[used:])  # the prep state is reusable: second prove on it is the same proof
+        assert (words == again).all()
+        return words
+
+    base = prove_with(ctx)
+    monkeypatch.setenv("SPARTAN_LZ_DIRECT", "1")
+    assert (prove_with(ctx) == base).all()
+    monkeypatch.delenv("SPARTAN_LZ_DIRECT")
+    monkeypatch.setenv("SPARTAN_MAIL_DEV", "0")  # read when a context is created
+    c2 = hip.Context(0)
+    try:
+        assert (prove_with(c2) == base).all()
+    finally:
+        c2.close()
