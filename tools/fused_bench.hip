@@ -67,6 +67,45 @@ __global__ void __launch_bounds__(BLOCK) k_var(fe_t* __restrict__ A, fe_t* __res
   }
 }
 
+// VAR 5/6: the production streaming kernel body, but each block walks ITER chunks (grid = q / 256 / ITER): after the first chunk the waves of a
+// SIMD are no longer in lock step, so loads of one overlap arithmetic of another. PREFETCH issues the next chunk's loads before the arithmetic.
+struct Chunk {
+  fe_t a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+};
+__device__ __forceinline__ Chunk load_chunk(const fe_t* A, const fe_t* B, const fe_t* C, size_t id, size_t q) {
+  Chunk k;
+  k.a0 = A[id]; k.a1 = A[id + q]; k.a2 = A[id + 2 * q]; k.a3 = A[id + 3 * q];
+  k.b0 = B[id]; k.b1 = B[id + q]; k.b2 = B[id + 2 * q]; k.b3 = B[id + 3 * q];
+  k.c0 = C[id]; k.c1 = C[id + q]; k.c2 = C[id + 2 * q]; k.c3 = C[id + 3 * q];
+  return k;
+}
+template <int ITER, bool PREFETCH>
+__global__ void __launch_bounds__(256) k_iter(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in,
+                                              int s, lazy9_t* __restrict__ partials) {
+  const size_t mask = ((size_t)1 << s) - 1;
+  lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
+  size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  Chunk cur = load_chunk(A, B, C, id, q);
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    Chunk nxt;
+    if (PREFETCH && it + 1 < ITER) nxt = load_chunk(A, B, C, id + step, q);
+    const fe_t a0 = bind1(cur.a0, cur.a2, r), a1 = bind1(cur.a1, cur.a3, r);
+    const fe_t b0 = bind1(cur.b0, cur.b2, r), b1 = bind1(cur.b1, cur.b3, r);
+    const fe_t c0 = bind1(cur.c0, cur.c2, r), c1 = bind1(cur.c1, cur.c3, r);
+    A[id] = a0; A[id + q] = a1; B[id] = b0; B[id + q] = b1; C[id] = c0; C[id + q] = c1;
+    const fe_t w = eq_in[id & mask];
+    const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+    const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+    l0 = lazy_add(l0, lazy_from(fe_mul<S>(w, t0e)));
+    l1 = lazy_add(l1, lazy_from(fe_mul<S>(w, tie)));
+    id += step;
+    if (it + 1 < ITER) cur = PREFETCH ? nxt : load_chunk(A, B, C, id, q);
+  }
+  stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
+}
+
 template <class L>
 static float time_us(L&& f, int reps) {
   hipEvent_t a, b;
@@ -88,17 +127,24 @@ static float time_us(L&& f, int reps) {
 }
 
 int main() {
-  for (int logL : {20, 22, 24}) {
+  for (int logL : {20, 22}) {
     const size_t L = (size_t)1 << logL, q = L / 4;
     fe_t *A, *B, *C, *eq, *eo, *part;
     hipMalloc(&A, L * 32); hipMalloc(&B, L * 32); hipMalloc(&C, L * 32);
-    hipMalloc(&eq, 1024 * 32); hipMalloc(&eo, ((q >> 10) + 1) * 32); hipMalloc(&part, (q / 64 + 16) * 64);
+    hipMalloc(&eq, 1024 * 32); hipMalloc(&eo, ((q >> 10) + 1) * 32); hipMalloc(&part, (q / 64 + 16) * 96);
     hipMemset(A, 0x11, L * 32); hipMemset(B, 0x22, L * 32); hipMemset(C, 0x33, L * 32);
     hipMemset(eq, 0x05, 1024 * 32); hipMemset(eo, 0x07, ((q >> 10) + 1) * 32);
     fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = 0x01234567u * (i + 1);
     const double bytes = 48.0 * L * 3;
     auto report = [&](const char* name, float us) { printf("L=2^%d %-34s %8.1f us  %7.0f GB/s (%.1f%% of 8 TB/s)\n", logL, name, us, bytes / us / 1e3, bytes / us / 1e3 / 80.0); };
-    report("library k_bind_eval_cubic<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic<1>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part, part, 1u); }, 10));
+    const MailRef nomail{nullptr, nullptr, 0u};
+    lazy9_t* lp = reinterpret_cast<lazy9_t*>(part);
+    report("library k_bind_eval_cubic<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic<1>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part, part, 1u, nomail); }, 10));
+    report("library k_bind_eval_cubic_stream<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic_stream<1, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp, nomail); }, 20));
+    report("stream body, 2 chunks per block", time_us([&] { hipLaunchKernelGGL((k_iter<2, false>), dim3(q / 256 / 2), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stream body, 4 chunks per block", time_us([&] { hipLaunchKernelGGL((k_iter<4, false>), dim3(q / 256 / 4), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stream body, 2 chunks, prefetch", time_us([&] { hipLaunchKernelGGL((k_iter<2, true>), dim3(q / 256 / 2), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stream body, 4 chunks, prefetch", time_us([&] { hipLaunchKernelGGL((k_iter<4, true>), dim3(q / 256 / 4), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("var0 block256", time_us([&] { hipLaunchKernelGGL((k_var<0, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
     report("var1 nontemporal loads", time_us([&] { hipLaunchKernelGGL((k_var<1, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
     report("var0 block64 (wave-only reduce)", time_us([&] { hipLaunchKernelGGL((k_var<0, 64>), dim3((q + 63) / 64), dim3(64), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
