@@ -424,6 +424,20 @@ static jac_t fixed_base_mul_host(const aff_t* table, const fe_t& scalar) {
   }
   return acc;
 }
+// few scalars (the latency case: the blinds of the zero rows): block-cooperative additions; many: one half-wave per scalar (throughput).
+// SPARTAN_FB_COOP=0 forces the half-wave form.
+static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, const aff_t* tables, size_t ntables, jac_t* dout) {
+  static const bool coop = [] {
+    const char* e = getenv("SPARTAN_FB_COOP");
+    return !(e && e[0] == '0');
+  }();
+  if (coop && n <= 1024) {
+    hipLaunchKernelGGL(spk::k_fixed_base_rows_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, tables, ntables, dout);
+  } else {
+    const size_t threads = n * 32;
+    hipLaunchKernelGGL(spk::k_fixed_base_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, ds, n, tables, ntables, dout);
+  }
+}
 static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU core beats the launch + single-wave latency
 
 // table[i % ntables] * scalars[i] on the device (Jacobian results in host memory); ntables == 1 for h
@@ -434,9 +448,8 @@ static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, con
   jac_t* dout = (jac_t*)c->workspace(sp_ctx::WS_FB_OUT, n * sizeof(jac_t));
   if (!ds || !dout) return SP_ERR_NO_DEVICE;
   SP_HIP(hipMemcpyAsync(ds, scalars, n * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-  size_t threads = n * 32;
   c->timed("fixed_base", 32ull * n, [&] {
-    hipLaunchKernelGGL(spk::k_fixed_base_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, ds, n, d_tables, ntables, dout);
+    launch_fixed_base_rows(c->stream, ds, n, d_tables, ntables, dout);
   });
   SP_HIP(hipMemcpyAsync(out.data(), dout, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
   SP_HIP(hipStreamSynchronize(c->stream));
@@ -475,8 +488,7 @@ int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalar
       return SP_ERR_NO_DEVICE;
     }
     SP_HIP(hipMemcpyAsync(ds, stage, n * sizeof(fe_t), hipMemcpyHostToDevice, c->stream2));
-    size_t threads = n * 32;
-    hipLaunchKernelGGL(spk::k_fixed_base_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream2, ds, n, ck->d_htable, (size_t)1, dout);
+    launch_fixed_base_rows(c->stream2, ds, n, ck->d_htable, (size_t)1, dout);
     SP_HIP(hipMemcpyAsync(c->h_pinned_fb, dout, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream2));
     SP_HIP(hipEventRecord(c->fb_event(), c->stream2));
     job->on_device = true;

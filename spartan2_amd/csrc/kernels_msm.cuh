@@ -592,6 +592,33 @@ __global__ void __launch_bounds__(256) k_fixed_base_rows(const fe_t* __restrict_
   if (idx < n && j == 0) out[idx] = acc;
 }
 
+// The same with the block-cooperative addition: four scalars per 512-thread block, their 4 x 32 table entries are the 128 items; the five tree
+// levels cost ~11 us each instead of ~15 (the chain of dependent additions is all there is: 84 scalars do not fill the chip either way).
+__global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
+                                                                  jac_t* __restrict__ out) {
+  __shared__ CoopAdd<128> L;
+  __shared__ jac_t s[128];
+  const int wave = threadIdx.x >> 6, blk = wave >> 2;
+  const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);  // roles of an item block on four different SIMDs (see k_msm_window_reduce_coop)
+  const size_t idx = (size_t)blockIdx.x * 4 + (k >> 5);
+  const int j = k & 31;
+  if (role == 0) {
+    jac_t acc = jac_identity();
+    if (idx < n) {
+      const fe_t c = fe_to_canonical<SF>(scalars[idx]);
+      const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      if (digit) acc = jac_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
+    }
+    s[k] = acc;
+  }
+  __syncthreads();
+  for (int off = 16; off >= 1; off >>= 1) {  // in place is safe: inputs are read in levels 1-2 of the addition only
+    const bool active = j < off;
+    jac_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+  }
+  if (role == 0 && j == 0 && idx < n) out[idx] = s[k];
+}
+
 // ---- K9: LZ[i] = sum_j L[j] * poly[j*cols + i] ---------------------------------------------------------------------------
 // grid = (cols/64, row_splits): each block handles 64 columns x a slice of rows with 256 threads = 4 row-lanes per column.
 __global__ void __launch_bounds__(256) k_rowmat_vec(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L,
