@@ -824,10 +824,20 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       size_t len = sp::eff_pairs(A);
       if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
       if (half < len) len = half;
-      if (len > 0) {
+      if (len >= STREAM_MIN_Q && len % 1024 == 0) {  // streaming form: lazy sums, lazy second stage
+        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
+        const unsigned seq = next_seq(c);
+        const size_t blocks = len / 1024;
+        c->timed("eval_quad", 64ull * len + 32ull * ((sp::eff_hi(A) < len ? sp::eff_hi(A) : len) + (sp::eff_hi(B) < len ? sp::eff_hi(B) : len)), [&] {
+          hipLaunchKernelGGL((spk::k_eval_quad_stream<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
+        });
+        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, blocks, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+        c->pending_slots = 0;
+        waiting = true;
+      } else if (len > 0) {
         size_t blocks = (len + chunk - 1) / chunk;
-        c->timed("eval_quad", 128ull * len,
-                 [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch, c->d_pinned, next_seq(c)); });
+        c->timed("eval_quad", 64ull * len + 32ull * ((sp::eff_hi(A) < len ? sp::eff_hi(A) : len) + (sp::eff_hi(B) < len ? sp::eff_hi(B) : len)),
+                 [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, sp::eff_hi(A), sp::eff_hi(B), c->d_scratch, c->d_pinned, next_seq(c)); });
         reduce_partials_launch(c, blocks, 2);
         waiting = true;
       }
@@ -911,8 +921,8 @@ static int eval_quad_sums(sp_ctx* c, const sp_table* A, const sp_table* B, fe_t 
   size_t blocks = (len + chunk - 1) / chunk;
   int rc = c->ensure_scratch(blocks * 2 + 64);
   if (rc) return rc;
-  c->timed("eval_quad", 128ull * len,
-           [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, c->d_scratch, c->d_pinned, next_seq(c)); });
+  c->timed("eval_quad", 64ull * len + 32ull * ((sp::eff_hi(A) < len ? sp::eff_hi(A) : len) + (sp::eff_hi(B) < len ? sp::eff_hi(B) : len)),
+           [&] { hipLaunchKernelGGL(spk::k_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, len, sp::eff_hi(A), sp::eff_hi(B), c->d_scratch, c->d_pinned, next_seq(c)); });
   return reduce_partials(c, blocks, 2, sums);
 }
 

@@ -401,6 +401,24 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad_stream_sparse(fe_t* __re
   B[id + q] = b1;
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(a0, b0))), lazy_wave_sum(lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)))), partials);
 }
+// compute_eval_points_quad (src/sumcheck.rs:128-174) in the streaming form: PPT pairs per lane accumulated lazily (9-word sums, no modular
+// reduction), one lazy wave sum per wave. k_eval_quad spends more issue slots on its per-wave modular reduction tree than on the two products of
+// a pair (50 us for 2^20 pairs, compute-bound); this form is bound by the 64 MB it reads. len must be a multiple of 256 * PPT.
+template <int PPT>
+__global__ void __launch_bounds__(256) k_eval_quad_stream(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t hiA, size_t hiB,
+                                                          lazy9_t* __restrict__ partials) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
+#pragma unroll
+  for (int k = 0; k < PPT; ++k, id += stride) {
+    const fe_t a0 = A[id], b0 = B[id];
+    const fe_t a1 = id < hiA ? A[id + half] : fe_zero(), b1 = id < hiB ? B[id + half] : fe_zero();
+    l0 = lazy_add(l0, lazy_from(fe_mul<S>(a0, b0)));
+    l1 = lazy_add(l1, lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0))));
+  }
+  stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
+}
 // Second stage for the streaming kernels: per group of 2^group_log2 consecutive blocks, lazy-sum, reduce mod p, multiply by
 // eq_out[group] (when given), then a modular block sum over groups. One block.
 __global__ void __launch_bounds__(256) k_sum_partials_lazy(const lazy9_t* __restrict__ partials, size_t nparts, int group_log2,
@@ -433,7 +451,9 @@ __global__ void __launch_bounds__(256) k_sum_partials_lazy(const lazy9_t* __rest
 
 // ---- K3: quadratic evaluation sums ---------------------------------------------------------------------------------
 //   eval0 = sum_{i < len} A0 B0 ; tinf = sum_{i < len} (A1 - A0)(B1 - B0), len = min(eff_pairs(A), eff_pairs(B), half)
-__global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t len,
+// hiA / hiB = eff_hi of the tables: the high half is zero from there on and is not read (the inner sum-check's round 0 runs on 2M-long tables whose
+// high halves hold num_extra entries: half the traffic)
+__global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t len, size_t hiA, size_t hiB,
                                                    fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq) {
   __shared__ fe_t smem[2 * 4];
   const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
@@ -443,7 +463,8 @@ __global__ void __launch_bounds__(256) k_eval_quad(const fe_t* __restrict__ A, c
   for (int k = 0; k < EVAL_PPT; ++k) {
     const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
     if (id < len) {
-      const fe_t a0 = A[id], a1 = A[id + half], b0 = B[id], b1 = B[id + half];
+      const fe_t a0 = A[id], b0 = B[id];
+      const fe_t a1 = id < hiA ? A[id + half] : fe_zero(), b1 = id < hiB ? B[id + half] : fe_zero();
       acc[0] = fe_add<S>(acc[0], fe_mul<S>(a0, b0));
       acc[1] = fe_add<S>(acc[1], fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)));
     }
