@@ -226,6 +226,23 @@ def test_sumcheck_quad_with_zero_structure_like_spartan_inner(ctx):
         assert (g == w).all()
 
 
+def test_sumcheck_quad_zero_structure_at_streaming_size(ctx):
+    """The same shape at 2M = 2^20: round 0 runs k_eval_quad_stream (lazy sums, the zero high halves are not read) and the first bind
+    k_bind_eval_quad_stream_sparse — the kernels of the sha256_spartan 2 KiB inner sum-check, here against the oracle."""
+    rng = np.random.default_rng(SEED + 51)
+    rounds, M, extra = 20, 1 << 19, 257
+    A, B = rand_table(rng, 2 * M), rand_table(rng, 2 * M)
+    A[M + extra :] = 0
+    B[M + extra :] = 0
+    claim = np.zeros(4, dtype=np.uint64)
+    olib().orc_field_dot(0, p64(A), p64(B), ctypes.c_size_t(2 * M), p64(claim))
+    want = oracle_quad(claim, rounds, A, (M, extra), B, (M, extra))
+    tr = hip.Transcript(ctx, b"sq")
+    got = hip.sumcheck_quad(ctx, claim, rounds, hip.Table.from_host(ctx, A, M, extra), hip.Table.from_host(ctx, B, M, extra), tr)
+    for g, w in zip(got, want):
+        assert (g == w).all()
+
+
 def test_bind_kernel_reports_algorithmic_bytes(ctx):
     rng = np.random.default_rng(SEED + 60)
     n = 1 << 14
