@@ -274,3 +274,38 @@ def test_transcript_prepared_absorb_equals_plain_absorb(ctx):
         b.absorb_prepared(b"poly_com", data)
     a.absorb(b"y", b"123")
     assert (a.squeeze(b"r") == b.squeeze(b"r")).all()  # the refused call changed nothing
+
+
+def test_sumchecks_randomised_shapes_stay_bit_exact(ctx):
+    """Seeded sweep over the regimes of the round loop — plain launches, launches issued ahead of their challenge, per-block host slots, the
+    multi-block and the single-block resident tail, the tau = 0 fallback, zero structure — with dishonest claims (parity, not soundness,
+    is what is checked): every (ell, zero structure, tau pattern) must reproduce the oracle's polynomials, challenges and final claims, and
+    reuse of one context across all of them must not leak sequence numbers or mailbox state from one sum-check into the next."""
+    rng = np.random.default_rng(SEED + 4242)
+    for case in range(24):
+        ell = int(rng.integers(1, 18))
+        n = 1 << ell
+        A, B, C = rand_table(rng, n), rand_table(rng, n), rand_table(rng, n)
+        taus = rand_table(rng, ell)
+        for j in range(ell):
+            if rng.random() < 0.08:
+                taus[j] = 0  # three-sum fallback round in the middle of rounds launched ahead / inside the tail
+        claim = rand_table(rng, 1)[0]
+        want_polys, want_r, want_fin, _ = oracle_cubic(claim, taus, A, B, C)
+        tr = hip.Transcript(ctx, b"sc")
+        polys, r, fin = hip.sumcheck_cubic3(ctx, claim, taus, *(hip.Table.from_host(ctx, x) for x in (A, B, C)), tr)
+        assert (polys == want_polys).all() and (r == want_r).all() and (fin == want_fin).all(), f"cubic case {case}: ell={ell}"
+        # quadratic, with a random zero structure of the kind bind_poly_var_top tracks (lo_eff / hi_eff)
+        half = n // 2
+        lo = int(rng.integers(0, half + 1)) if rng.random() < 0.6 else half
+        hi = int(rng.integers(0, half + 1)) if rng.random() < 0.6 else half
+        A2, B2 = A.copy(), B.copy()
+        for t in (A2, B2):
+            t[lo:half] = 0
+            t[half + hi :] = 0
+        qclaim = rand_table(rng, 1)[0]
+        want = oracle_quad(qclaim, ell, A2, (lo, hi), B2, (lo, hi))
+        trq = hip.Transcript(ctx, b"sq")
+        got = hip.sumcheck_quad(ctx, qclaim, ell, hip.Table.from_host(ctx, A2, lo, hi), hip.Table.from_host(ctx, B2, lo, hi), trq)
+        for g, w in zip(got, want):
+            assert (g == w).all(), f"quad case {case}: ell={ell} lo={lo} hi={hi}"
