@@ -42,6 +42,9 @@ const char* sp_last_error(void);
 
 /* one context per GPU; device = HIP ordinal (LOCAL_RANK under torch.distributed.run). */
 int sp_ctx_create(int device, sp_ctx** out);
+/* Makes the context's device current for the CALLING thread (HIP keeps a current device per thread; a new thread starts on device 0). The thread that
+ * created the context needs no call; a helper thread (see sp_points_upload) calls this once before its first call on the context. */
+int sp_ctx_bind_thread(sp_ctx* ctx);
 void sp_ctx_destroy(sp_ctx* ctx);
 int sp_ctx_synchronize(sp_ctx* ctx);
 /* time of the most recent instrumented kernel class, measured with hipEvents on the context's stream

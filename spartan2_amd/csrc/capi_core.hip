@@ -138,6 +138,11 @@ int sp_ctx_create(int device, sp_ctx** out) {
   *out = c;
   return SP_OK;
 }
+int sp_ctx_bind_thread(sp_ctx* c) {
+  if (!c) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_ctx_bind_thread: null context");
+  SP_HIP(hipSetDevice(c->device));
+  return SP_OK;
+}
 void sp_ctx_destroy(sp_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);

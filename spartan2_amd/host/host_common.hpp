@@ -125,11 +125,12 @@ class Background {
     if (!th_.joinable()) th_ = std::thread([this] { loop(); });
     cv_.notify_one();
   }
-  void wait_nothrow() {
+  void wait_nothrow() {  // for exit paths: also drops what the job threw, so that it cannot resurface in a later submit()
     while (pending_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    err_ = nullptr;
   }
   void wait() {  // rethrows what the job threw
-    wait_nothrow();
+    while (pending_.load(std::memory_order_acquire)) __builtin_ia32_pause();
     if (err_) {
       std::exception_ptr e = err_;
       err_ = nullptr;

@@ -327,6 +327,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   sp_ctx* ctx = pk.ctx;
   const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
   if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
+  ck(sp_ctx_bind_thread(ctx), "device");  // the caller may be a thread other than the one that created the context
   const double t_start = now_ms();
   double t_lap = t_start;
   auto lap = [&](const char* name) {
@@ -459,6 +460,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       const std::vector<uint8_t> b = commitment_bytes(rows, nrows);
       ck(sp_transcript_preabsorb((const uint8_t*)"poly_com", 8, b.data(), b.size(), &psp->poly_com), "poly_com (prepare)");
       if (!lzp) return;
+      ck(sp_ctx_bind_thread(ctx), "helper thread: device");  // a new thread starts on device 0; the context may live on another GPU
       ck(sp_points_upload(ctx, u64p(&rows[0].x), nrows, &psp->comm_pts), "comm_W (upload)");
       const auto t0 = std::chrono::steady_clock::now();
       auto wait_for = [&](std::atomic<int>& flag) {
