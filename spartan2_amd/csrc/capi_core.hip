@@ -851,7 +851,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
     int issued = 0;
-    if (waiting && (in_tail || c->mail_dev)) {
+    if (waiting && (in_tail || (c->mail_dev && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(round, nullptr, wait_seq);
       if (issued < 0) return issued;
     }
@@ -1255,7 +1255,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
     int issued = 0;
-    if (in_tail || (c->mail_dev && invertible)) {
+    if (in_tail || (c->mail_dev && invertible && !reduce)) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(rnd, nullptr, wait_seq);
       if (issued < 0) return issued;
     }
