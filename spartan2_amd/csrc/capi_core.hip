@@ -569,6 +569,25 @@ int sp_eq_table_into(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
   fe_t* d_hi = d_r + ell;
   fe_t* d_lo = d_hi + ((size_t)1 << 11);
   fe_t* d_lowbig = d_lo + ((size_t)1 << 11);
+  if (ell > 10 && lo_bits <= 10) {
+    // 2^11 .. 2^20 entries (evals_rx of the prover): both half pyramids in one launch with the challenges by value, then the outer product —
+    // no upload of r, so nothing to wait for: the caller's next launches queue right behind
+    spk::EqPairArgs ea;
+    for (int i = 0; i < hi_bits; ++i) ea.v[0][i] = load_fe(r + 4 * i);
+    for (int i = 0; i < lo_bits; ++i) ea.v[1][i] = load_fe(r + 4 * (hi_bits + i));
+    ea.m[0] = hi_bits;
+    ea.m[1] = lo_bits;
+    ea.out[0] = d_hi;
+    ea.out[1] = d_lo;
+    hipLaunchKernelGGL(spk::k_eq_levels_pair, dim3(2), dim3(1024), 0, c->stream, ea);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    c->timed("eq_table", 32ull * total, [&] {
+      hipLaunchKernelGGL(spk::k_eq_outer, dim3((unsigned)blocks), dim3(256), 0, c->stream, d_hi + spk::eq_level_offset(hi_bits),
+                         d_lo + spk::eq_level_offset(lo_bits), lo_bits, total, t->d);
+    });
+    return SP_OK;
+  }
   if (ell) SP_HIP(hipMemcpyAsync(d_r, r, ell * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
   if (ell <= 10) {
     hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r, (int)ell, d_lo);
