@@ -338,16 +338,56 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
 }
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false) {
   const unsigned want = c->result_seq;
-  if (c->pending_slots) {  // per-block slots: wait for every block's sequence word, add on the host
+  if (c->pending_slots) {  // per-block slots: add them on the host as they become valid
     const unsigned nb = c->pending_slots;
     c->pending_slots = 0;
     for (int k = 0; k < nacc; ++k) out_host[k] = fe_zero();
-    long spins = 0;
-    for (unsigned b = 0; b < nb; ++b) {
+    if (nb == 1) {
       fe_t v[3];
-      int rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b, want, nacc, v, resident, &spins);
+      long spins = 0;
+      int rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM, want, nacc, v, resident, &spins);
       if (rc) return rc;
-      for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], v[k]);
+      for (int k = 0; k < nacc; ++k) out_host[k] = v[k];
+      return SP_OK;
+    }
+    // Several slots: every pass first reads the tags of all outstanding slots (independent loads: their cache misses — the lines were just written
+    // by the device — overlap instead of costing 0.2 us each in turn), then takes the ones that are complete.
+    bool done[spk::HOST_SUM_MAX_BLOCKS] = {};
+    uint64_t tags[spk::HOST_SUM_MAX_BLOCKS];
+    unsigned remaining = nb;
+    long passes = 0;
+    std::chrono::steady_clock::time_point t0;
+    while (remaining) {
+      for (unsigned b = 0; b < nb; ++b)
+        if (!done[b]) tags[b] = *reinterpret_cast<volatile const uint64_t*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b + 3);
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (unsigned b = 0; b < nb; ++b) {
+        if (done[b] || (uint32_t)tags[b] != want) continue;
+        const fe_t* slot = c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b;
+        fe_t v[3];
+        uint32_t chk = want;
+        for (int k = 0; k < nacc; ++k)
+          for (int i = 0; i < 8; ++i) {
+            v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
+            chk += v[k].v[i];
+          }
+        if ((uint32_t)(tags[b] >> 32) != chk) continue;  // data still landing: next pass
+        for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], v[k]);
+        done[b] = true;
+        --remaining;
+      }
+      if (!remaining) break;
+      if (++passes == 200000) {  // a few ms without completion
+        if (!resident) {
+          SP_HIP(hipStreamSynchronize(c->stream));  // e.g. under a profiler
+        }
+        t0 = std::chrono::steady_clock::now();
+      } else if (passes > 200000) {
+        if (!resident && passes > 200002) return fail(SP_ERR_INTERNAL, "evaluation kernel did not deliver its block sums");
+        if (resident && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4))
+          return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
+      }
+      __builtin_ia32_pause();
     }
     return SP_OK;
   }
