@@ -196,7 +196,7 @@ int sp_points_upload(sp_ctx* ctx, const uint64_t* aff, size_t n, sp_points** io)
 void sp_points_free(sp_points* p);
 int sp_msm_eq_begin(sp_ctx* ctx, const sp_points* pts, const uint64_t* r, size_t ell, sp_msm_job** job);
 int sp_msm_job_finish(sp_ctx* ctx, sp_msm_job* job, uint64_t out_aff[8]);
-/* bind_with_delayed (hyrax_pc.rs:38-54) with L = eq(r, .) (ell <= 10 row variables) formed on the device, on a stream of its own, so that LZ —
+/* bind_with_delayed (hyrax_pc.rs:38-54) with L = eq(r, .) (ell <= 20 row variables; up to 10 formed on the device, more uploaded), on a stream of its own, so that LZ —
  * needed only for the IPA's z vector — is computed beside comm_LZ's MSM rather than before it. One job at a time; same threading rule as above. */
 typedef struct sp_vec_job sp_vec_job;
 int sp_rowmat_vec_eq_begin(sp_ctx* ctx, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** job);

@@ -1121,7 +1121,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
   fe_t* d_trt = d_tl + nleft;
   fe_t* d_pl = d_trt + second_half;
   fe_t* d_pr = d_pl + pyr_left;
-  if (nleft > 10 || second_half > 10) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sum-check over more than 2^21 rows: eq pyramid kernel needs widening");
+  if (nleft > 16 || second_half > 16) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sum-check over more than 2^32 rows");
   {
     spk::EqPairArgs ea;
     for (size_t i = 0; i < nleft; ++i) ea.v[0][i] = taus[1 + i];

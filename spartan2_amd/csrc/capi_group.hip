@@ -734,7 +734,7 @@ struct sp_vec_job {
 };
 int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** out) {
   if (!poly || !out || (!r && ell)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: null argument");
-  if (ell > 10) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: more than 2^10 rows");
+  if (ell > 20) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: more than 2^20 rows");
   const size_t rows = (size_t)1 << ell;
   if (rows * cols > poly->cap || cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed: poly shorter than rows*cols");
   if (!c->stream3) SP_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
@@ -751,16 +751,23 @@ int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, s
   fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
   fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, cols * sizeof(fe_t), 1);
   if (!dL || !part || !dout) return SP_ERR_NO_DEVICE;
-  spk::EqTensorArgs a;
-  const size_t hb = ell / 2, lb = ell - hb;
-  fe_t rr[10];
+  fe_t rr[20];
   for (size_t i = 0; i < ell; ++i) memcpy(&rr[i], r + 4 * i, 32);
-  eq_table_host(rr, hb, a.left);
-  eq_table_host(rr + hb, lb, a.right);
-  a.lo_bits = (int)lb;
-  a.n = (unsigned)rows;
   hipStream_t st = c->stream3;
-  hipLaunchKernelGGL(spk::k_eq_tensor<false>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, a, dL);
+  if (ell <= 10) {  // two half tables by value, the product on the device
+    spk::EqTensorArgs a;
+    const size_t hb = ell / 2, lb = ell - hb;
+    eq_table_host(rr, hb, a.left);
+    eq_table_host(rr + hb, lb, a.right);
+    a.lo_bits = (int)lb;
+    a.n = (unsigned)rows;
+    hipLaunchKernelGGL(spk::k_eq_tensor<false>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, a, dL);
+  } else {  // more rows than the argument block holds halves for: the table from the host
+    std::vector<fe_t> w(rows);
+    eq_table_host(rr, ell, w.data());
+    SP_HIP(hipMemcpyAsync(dL, w.data(), rows * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    SP_HIP(hipStreamSynchronize(st));  // w is a local
+  }
   hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly->d, rows, cols, dL, part);
   hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, splits, cols, dout);
   SP_HIP(hipMemcpyAsync(c->h_pinned_vec, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, st));

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(1024) k_eq_levels(const fe_t* __restrict__ v, 
 // both pyramids of EqSumCheckInstance::new (src/sumcheck.rs:956-992) in one launch: block 0 the left one, block 1 the right one, the taus by value
 // (no upload in front of the first evaluation)
 struct EqPairArgs {
-  fe_t v[2][11];
+  fe_t v[2][16];
   int m[2];
   fe_t* out[2];
 };

@@ -446,7 +446,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   } lz;
   lz.r_delta = r_delta_ahead;
   lz.nvr = lz_nvr;
-  const bool lz_ahead = !lz_direct && lz_nvr > 0 && lz_nvr <= 10 && comm_W.size() == ((size_t)1 << lz_nvr) && r_W.size() == comm_W.size();
+  const bool lz_ahead = !lz_direct && lz_nvr > 0 && lz_nvr <= 20 && comm_W.size() == ((size_t)1 << lz_nvr) && r_W.size() == comm_W.size();
   const size_t lz_cols = (size_t)1 << (log2_ceil(M) - lz_nvr);
   {
     const aff_t* rows = comm_W.data();

@@ -164,6 +164,21 @@ def test_sumcheck_large_tables_take_the_streaming_kernels(ctx):
         assert (g == w).all()
 
 
+def test_sumcheck_cubic_2_pow_21_rows(ctx):
+    """One size up from the bench shape (a 4 KiB SHA-256 message pads to 2^21 constraints): eq pyramids of 10 and 11 variables, every kernel
+    regime from the streaming ones down to the single-block tail."""
+    rng = np.random.default_rng(SEED + 2121)
+    ell = 21
+    n = 1 << ell
+    A, B, C = rand_table(rng, n), rand_table(rng, n), rand_table(rng, n)
+    taus = rand_table(rng, ell)
+    claim = rand_table(rng, 1)[0]
+    want_polys, want_r, want_fin, _ = oracle_cubic(claim, taus, A, B, C)
+    tr = hip.Transcript(ctx, b"sc")
+    polys, r, fin = hip.sumcheck_cubic3(ctx, claim, taus, *(hip.Table.from_host(ctx, x) for x in (A, B, C)), tr)
+    assert (polys == want_polys).all() and (r == want_r).all() and (fin == want_fin).all()
+
+
 def test_sumcheck_cubic_tau_zero_fallback(ctx):
     # derive_from_claim returns None when tau_i == 0 (src/sumcheck.rs:1289-1291) -> third sum computed directly
     rng = np.random.default_rng(SEED + 30)
