@@ -501,7 +501,7 @@ static int tail_check(sp_ctx* c) {
   volatile uint32_t* err = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM);
   if (*err) {
     *err = 0;
-    return fail(SP_ERR_INTERNAL, "sum-check tail kernel timed out waiting for a challenge");
+    return fail(SP_ERR_INTERNAL, "a sum-check kernel timed out waiting for its challenge");
   }
   return SP_OK;
 }
@@ -971,7 +971,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     if (rc) return rc;
   }
   store_fe(claim_io, claim);
-  return in_tail ? tail_check(c) : SP_OK;
+  return tail_check(c);  // also set by a kernel launched ahead that gave up waiting for its challenge
 }
 
 // compute_eval_points_quad (src/sumcheck.rs:128-174) of the current tables -> (eval0, t_inf)
@@ -1411,7 +1411,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
   store_fe(claim_io, claim);
   store_fe(p_io, eval_eq_left);
   if (round_trace()) fprintf(stderr, "cubic total %7.1f us\n", now_us() - tr_entry);
-  return in_tail ? tail_check(c) : SP_OK;
+  return tail_check(c);  // also set by a kernel launched ahead that gave up waiting for its challenge
 }
 
 }  // extern "C"
