@@ -1245,13 +1245,15 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     const unsigned seq = next_seq(c);
     if (q >= STREAM_MIN_Q && (e.mode == 0 || (e.mode == 1 && e.s >= 8))) {
       spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
-      c->timed("bind_stream_cubic", 48ull * A->len * 3, [&] {
+      {
         const dim3 gs((unsigned)(q / 256));
-        if (e.mode == 0 && ahead) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<0, true>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
-        else if (e.mode == 0) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<0, false>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
-        else if (ahead) hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<1, true>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
-        else hipLaunchKernelGGL((spk::k_bind_eval_cubic_stream<1, false>), gs, b, 0, c->stream, A->d, B->d, C->d, q, rv, e.eq_in, e.s, lp, mref);
-      });
+        const uint64_t bytes = 48ull * A->len * 3;
+        fe_t *pa = A->d, *pb = B->d, *pc = C->d;
+        if (e.mode == 0 && ahead) c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<0, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else if (e.mode == 0) c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<0, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else if (ahead) c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<1, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<1, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+      }
       // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
       hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
                          c->d_pinned, seq);
