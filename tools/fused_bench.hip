@@ -106,6 +106,34 @@ __global__ void __launch_bounds__(256) k_iter(fe_t* __restrict__ A, fe_t* __rest
   stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
 }
 
+// VAR 7: the production streaming body with non-temporal STORES (the bound values are not re-read before the next launch), block size BLOCK
+__device__ __forceinline__ void st_nt(fe_t* p, const fe_t& v) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u a = {v.v[0], v.v[1], v.v[2], v.v[3]}, b = {v.v[4], v.v[5], v.v[6], v.v[7]};
+  v4u* q = reinterpret_cast<v4u*>(p);
+  __builtin_nontemporal_store(a, q);
+  __builtin_nontemporal_store(b, q + 1);
+}
+template <bool NT>
+__global__ void __launch_bounds__(256) k_nt(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in, int s,
+                                            lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const Chunk k = load_chunk(A, B, C, id, q);
+  const fe_t a0 = bind1(k.a0, k.a2, r), a1 = bind1(k.a1, k.a3, r);
+  const fe_t b0 = bind1(k.b0, k.b2, r), b1 = bind1(k.b1, k.b3, r);
+  const fe_t c0 = bind1(k.c0, k.c2, r), c1 = bind1(k.c1, k.c3, r);
+  if (NT) {
+    st_nt(A + id, a0); st_nt(A + id + q, a1); st_nt(B + id, b0); st_nt(B + id + q, b1); st_nt(C + id, c0); st_nt(C + id + q, c1);
+  } else {
+    A[id] = a0; A[id + q] = a1; B[id] = b0; B[id + q] = b1; C[id] = c0; C[id + q] = c1;
+  }
+  const fe_t w = eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+
 template <class L>
 static float time_us(L&& f, int reps) {
   hipEvent_t a, b;
@@ -141,6 +169,8 @@ int main() {
     lazy9_t* lp = reinterpret_cast<lazy9_t*>(part);
     report("library k_bind_eval_cubic<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic<1>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part, part, 1u, nomail); }, 10));
     report("library k_bind_eval_cubic_stream<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic_stream<1, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp, nomail); }, 20));
+    report("stream body, plain stores", time_us([&] { hipLaunchKernelGGL((k_nt<false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stream body, non-temporal stores", time_us([&] { hipLaunchKernelGGL((k_nt<true>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, 2 chunks per block", time_us([&] { hipLaunchKernelGGL((k_iter<2, false>), dim3(q / 256 / 2), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, 4 chunks per block", time_us([&] { hipLaunchKernelGGL((k_iter<4, false>), dim3(q / 256 / 4), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, 2 chunks, prefetch", time_us([&] { hipLaunchKernelGGL((k_iter<2, true>), dim3(q / 256 / 2), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
