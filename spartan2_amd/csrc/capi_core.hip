@@ -472,9 +472,9 @@ static bool launch_ahead_ok(sp_ctx* c, size_t table_len) {
   return c->mail_dev && table_len <= max_len;
 }
 // result slots (= resident blocks still active) of the evaluation over a table of `len` elements
-static unsigned tail_blocks(size_t len) {
-  const size_t q = len / 2;
-  return q <= spk::TAIL_WIDE_Q ? 1u : (unsigned)(q / spk::TAIL_WIDE_Q);
+static unsigned tail_blocks(size_t len, bool cubic = false) {
+  const size_t q = len / 2, wq = cubic ? spk::TAIL_WIDE_Q_CUBIC : spk::TAIL_WIDE_Q;
+  return q <= wq ? 1u : (unsigned)(q / wq);
 }
 // Resident blocks occupy their CU (1024 threads) until the host has driven every round. If the tails of several contexts together asked for
 // more blocks than the chip holds, each could sit on CUs the other needs for blocks its host is waiting for: a multi-block tail therefore
@@ -1202,7 +1202,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
       sp::after_bind(C);
       if (rnd < ell) {
         next_seq(c);
-        c->pending_slots = tail_blocks(A->len);
+        c->pending_slots = tail_blocks(A->len, true);
       }
       return 1;
     }
@@ -1213,7 +1213,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
       return rc2 ? rc2 : 1;
     }
     if (ahead && !launch_ahead_ok(c, A->len)) return 0;
-    if (tail_enabled() && A->len <= TAIL_MAX_LEN && lease.take(tail_blocks(A->len / 2))) {
+    if (tail_enabled() && A->len <= TAIL_MAX_LEN && tail_blocks(A->len / 2, true) <= (unsigned)spk::HOST_SUM_MAX_BLOCKS && lease.take(tail_blocks(A->len / 2, true))) {
       spk::TailArgs ta;
       ta.A = A->d;
       ta.B = B->d;
@@ -1229,12 +1229,12 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
       ta.r0_from_mail = ahead ? 1 : 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
-      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_blocks(A->len / 2, true)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
       in_tail = true;
       sp::after_bind(A);
       sp::after_bind(B);
       sp::after_bind(C);
-      c->pending_slots = tail_blocks(A->len);
+      c->pending_slots = tail_blocks(A->len, true);
       return 1;
     }
     // K1 fused with next round's K2: bind with r, evaluate round rnd+1 from registers

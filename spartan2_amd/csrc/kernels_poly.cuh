@@ -548,6 +548,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
 // when tau * p is not invertible, otherwise it derives the evaluations from the claim exactly as the reference does (:1276-1324).
 // Slots in the mapped buffer: TAIL_CHAL_ELEM = the 64-byte mailbox line (challenge | sequence | check word), word 0 of TAIL_ERR_ELEM = error.
 constexpr int TAIL_THREADS = 1024;
+constexpr unsigned long long TAIL_WIDE_Q_CUBIC = 128;  // the cubic rounds bind three tables and weight every product: half the pairs per block keep its bind phase to one pass
 constexpr unsigned long long TAIL_WIDE_Q = 256;  // pairs per resident block and round: every product gets its own lane (3 * 256 <= TAIL_THREADS)
 struct TailArgs {
   fe_t *A, *B, *C;          // C unused in quadratic mode
@@ -580,10 +581,11 @@ __device__ __forceinline__ fe_t load_agent(const fe_t* p) {
 template <bool CUBIC>
 __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   constexpr int NACC = CUBIC ? 3 : 2;
+  constexpr unsigned long long WQ = CUBIC ? TAIL_WIDE_Q_CUBIC : TAIL_WIDE_Q;
   __shared__ fe_t smem[16];
   __shared__ fe_t r_sh;
   __shared__ unsigned chk_sh[4];
-  const unsigned long long base = (unsigned long long)blockIdx.x * TAIL_WIDE_Q;
+  const unsigned long long base = (unsigned long long)blockIdx.x * WQ;
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
   int rnd = a.rnd0;
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     // the previous round had 2q pairs: while that is more than one block's worth, the elements bound below were written by other blocks
     // (other XCDs, other L2s). They are read with agent-scope loads, which go past this XCD's L2, instead of an acquire fence, which would
     // invalidate it (measured: 4 us per round).
-    const bool foreign = 2 * q > TAIL_WIDE_Q;
+    const bool foreign = 2 * q > WQ;
     first = false;
     if (len == 2) {  // last round: bind only; the final claims also go to the host in a slot of their own (saves three synchronous reads)
       if (threadIdx.x == 0) {
@@ -621,7 +623,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       }
       return;
     }
-    const unsigned qb = (unsigned)(q - base < TAIL_WIDE_Q ? q - base : TAIL_WIDE_Q);  // pairs of this block (a power of two)
+    const unsigned qb = (unsigned)(q - base < WQ ? q - base : WQ);  // pairs of this block (a power of two)
     // phase A: one bind per lane. New element x takes old x and x + 2q; this block owns x in [base, base + qb) and [q + base, q + base + qb).
     const unsigned nt = CUBIC ? 3 : 2;
     for (unsigned idx = threadIdx.x; idx < nt * 2 * qb; idx += TAIL_THREADS) {
@@ -671,7 +673,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     // (they are complete at the barrier) before the host can see this block's slot. The single-block rounds need no fence at all.
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (q > TAIL_WIDE_Q) __threadfence();
+      if (q > WQ) __threadfence();
       unsigned chk = 0;
       for (int k = 0; k < NACC; ++k) chk += chk_sh[k];
       slot_store_tag(slot, seq, chk);
