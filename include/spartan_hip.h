@@ -65,6 +65,9 @@ int sp_table_write(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* z, size
 int sp_table_zero(sp_ctx* ctx, sp_table* t, size_t off, size_t cnt);
 /* device -> device copy */
 int sp_table_copy(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt);
+/* dst[dst_off + j] = src[src_off + j * stride], j < cnt (device -> device). The slice of a table sharded on its LAST k variables (rank g of 2^k
+ * holds Z[(j << k) | g]: src_off = g, stride = 2^k) — SURVEY.md 8(e), "sum-check by evaluation-table slice". */
+int sp_table_gather_strided(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t stride, size_t cnt);
 /* Index / into_vec (:166-173, :87-89) */
 int sp_table_read(sp_ctx* ctx, const sp_table* t, size_t off, size_t cnt, uint64_t* out);
 int sp_table_info(const sp_table* t, size_t* len, size_t* lo_eff, size_t* hi_eff);

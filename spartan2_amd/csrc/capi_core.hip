@@ -235,6 +235,13 @@ int sp_table_copy(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src,
   if (cnt) SP_HIP(hipMemcpyAsync(dst->d + dst_off, src->d + src_off, cnt * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
   return SP_OK;
 }
+int sp_table_gather_strided(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t stride, size_t cnt) {
+  if (stride == 0 || dst_off + cnt > dst->cap || (cnt && src_off + (cnt - 1) * stride >= src->cap))
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_gather_strided: range exceeds a table");
+  if (cnt)
+    SP_HIP(hipMemcpy2DAsync(dst->d + dst_off, sizeof(fe_t), src->d + src_off, stride * sizeof(fe_t), sizeof(fe_t), cnt, hipMemcpyDeviceToDevice, c->stream));
+  return SP_OK;
+}
 int sp_table_read(sp_ctx* c, const sp_table* t, size_t off, size_t cnt, uint64_t* out) {
   if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_read: range exceeds the table");
   if (cnt) SP_HIP(hipMemcpyAsync(out, t->d + off, cnt * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
@@ -324,14 +331,12 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
   }
   for (long tries = 0;; ++tries) {
     std::atomic_thread_fence(std::memory_order_acquire);
-    uint32_t chk = want;
+    spk::slot_chk chk = {want, want * spk::SLOT_CHK_K};
     for (int k = 0; k < nvals; ++k) {
-      for (int i = 0; i < 8; ++i) {
-        v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
-        chk += v[k].v[i];
-      }
+      for (int i = 0; i < 8; ++i) v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
+      spk::slot_chk_add(chk, v[k], k);
     }
-    if (fl[1] == chk) return SP_OK;
+    if (fl[0] == want && fl[1] == chk.a && fl[2] == chk.b && fl[3] == want) return SP_OK;
     if (tries > 4000000) return fail(SP_ERR_INTERNAL, "evaluation kernel delivered an inconsistent result slot");
     __builtin_ia32_pause();
   }
@@ -353,25 +358,28 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
     // Several slots: every pass first reads the tags of all outstanding slots (independent loads: their cache misses — the lines were just written
     // by the device — overlap instead of costing 0.2 us each in turn), then takes the ones that are complete.
     bool done[spk::HOST_SUM_MAX_BLOCKS] = {};
-    uint64_t tags[spk::HOST_SUM_MAX_BLOCKS];
+    uint64_t tags[spk::HOST_SUM_MAX_BLOCKS], tags2[spk::HOST_SUM_MAX_BLOCKS];
     unsigned remaining = nb;
     long passes = 0;
     std::chrono::steady_clock::time_point t0;
     while (remaining) {
       for (unsigned b = 0; b < nb; ++b)
-        if (!done[b]) tags[b] = *reinterpret_cast<volatile const uint64_t*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b + 3);
+        if (!done[b]) {
+          const volatile uint64_t* tg = reinterpret_cast<volatile const uint64_t*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b + 3);
+          tags[b] = tg[0];
+          tags2[b] = tg[1];
+        }
       std::atomic_thread_fence(std::memory_order_acquire);
       for (unsigned b = 0; b < nb; ++b) {
-        if (done[b] || (uint32_t)tags[b] != want) continue;
+        if (done[b] || (uint32_t)tags[b] != want || (uint32_t)(tags2[b] >> 32) != want) continue;
         const fe_t* slot = c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b;
         fe_t v[3];
-        uint32_t chk = want;
-        for (int k = 0; k < nacc; ++k)
-          for (int i = 0; i < 8; ++i) {
-            v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
-            chk += v[k].v[i];
-          }
-        if ((uint32_t)(tags[b] >> 32) != chk) continue;  // data still landing: next pass
+        spk::slot_chk chk = {want, want * spk::SLOT_CHK_K};
+        for (int k = 0; k < nacc; ++k) {
+          for (int i = 0; i < 8; ++i) v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
+          spk::slot_chk_add(chk, v[k], k);
+        }
+        if ((uint32_t)(tags[b] >> 32) != chk.a || (uint32_t)tags2[b] != chk.b) continue;  // data still landing: next pass
         for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], v[k]);
         done[b] = true;
         --remaining;
@@ -441,20 +449,45 @@ static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident t
 }
 #define TAIL_MAX_LEN tail_max_len()
 static bool tail_enabled() { return tail_max_len() != 0; }
-// mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 = check word
-// (sequence + sum of the challenge words) so a poll that straddles the host's stores is recognised and retried.
+// mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 / 10 = two independent
+// check words (sequence + plain sum, sequence * K + position-weighted sum), 11 = the sequence number again, so a poll that straddles the host's
+// stores is recognised and retried (mail_wait in kernels_poly.cuh).
 static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) {
   volatile uint32_t* dst = c->h_mail;
-  uint32_t chk = answers_seq;
+  uint32_t chk = answers_seq, chk2 = answers_seq * spk::SLOT_CHK_K;
   for (int i = 0; i < 8; ++i) {
     dst[i] = r.v[i];
     chk += r.v[i];
+    chk2 += (uint32_t)(i + 1) * r.v[i];
   }
   dst[9] = chk;
+  dst[10] = chk2;
+  dst[11] = answers_seq;
   std::atomic_thread_fence(std::memory_order_release);
   dst[8] = answers_seq;
   if (c->mail_dev) __builtin_ia32_sfence();  // BAR memory is write-combining: push the line out now
 }
+// Error exits of a round loop: kernels issued ahead of their challenge (and the resident tail) are still waiting at the mailbox and would hold
+// their CUs for the 2 s watchdog, then trip the sticky error word under the next, unrelated sum-check. The abort word of the mailbox line makes
+// them leave at once; the stream is drained and both words are cleared so that the next sum-check on this context starts clean.
+static void tail_abort(sp_ctx* c) {
+  volatile uint32_t* dst = c->h_mail;
+  dst[12] = 1;
+  if (c->mail_dev) __builtin_ia32_sfence();
+  hipStreamSynchronize(c->stream);
+  dst[12] = 0;
+  if (c->mail_dev) __builtin_ia32_sfence();
+  *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
+}
+// armed while a launch issued ahead of its challenge (or the resident tail) waits at the mailbox; an early return aborts it
+struct AheadGuard {
+  sp_ctx* c;
+  bool armed = false;
+  explicit AheadGuard(sp_ctx* ctx) : c(ctx) {}
+  ~AheadGuard() {
+    if (armed) tail_abort(c);
+  }
+};
 static spk::MailRef mail_ref(sp_ctx* c, bool ahead, unsigned answers) {
   spk::MailRef m;
   m.mail = ahead ? c->d_mail : nullptr;
@@ -500,8 +533,14 @@ struct TailLease {
 static int tail_check(sp_ctx* c) {
   volatile uint32_t* err = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM);
   if (*err) {
+    char buf[320];
+    const volatile uint32_t* seen = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM + 1);
+    snprintf(buf, sizeof buf,
+             "a sum-check kernel timed out waiting for its challenge (wanted seq %u, block %u of %u; mailbox as last polled: seq %u / %u, checks %08x %08x, abort %u; "
+             "host result_seq %u)",
+             err[1], err[2], err[3], seen[8], seen[11], seen[9], seen[10], seen[12], c->result_seq);
     *err = 0;
-    return fail(SP_ERR_INTERNAL, "a sum-check kernel timed out waiting for its challenge");
+    return fail(SP_ERR_INTERNAL, buf);
   }
   return SP_OK;
 }
@@ -787,6 +826,8 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
   unsigned last_answered = 0;  // sequence number answered by the most recent challenge
   TailLease lease;
+  AheadGuard guard(c);
+  *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
   // What follows round `round`'s challenge r: the resident tail takes it from the mailbox, a fused launch binds with it and evaluates round + 1, or
   // (last round, irregular zero structure) a plain bind. `r` == nullptr issues the work AHEAD of the challenge (mailbox in device memory): the
   // launch overhead and the kernel's table loads then overlap the host's transcript step. Returns 1 = issued, 0 = needs r on the host, < 0 error.
@@ -913,6 +954,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     if (waiting && (in_tail || (c->mail_dev && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(round, nullptr, wait_seq);
       if (issued < 0) return issued;
+      guard.armed = issued != 0;
     }
     if (waiting) {
       const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
@@ -951,6 +993,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       if (issued < 0) return issued;
       if (wait_resident) tail_post_challenge(c, r_i, wait_seq);
     }
+    guard.armed = in_tail && round + 1 < rounds;  // the resident kernel now waits for the next challenge
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];
       store_fe(rw, r_i);
@@ -1178,6 +1221,8 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
   unsigned last_answered = 0;
   TailLease lease;
+  AheadGuard guard(c);
+  *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
   fe_t eval_eq_left = load_fe(p_io);
   const fe_t one = fe_one<S>();
   // slice sums -> batch sums (no-op for an unsharded call)
@@ -1319,6 +1364,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
     if (in_tail || (c->mail_dev && invertible && !reduce)) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(rnd, nullptr, wait_seq);
       if (issued < 0) return issued;
+      guard.armed = issued != 0;
     }
     const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
     c->result_seq = wait_seq;
@@ -1390,6 +1436,7 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
       issued = issue(rnd, &r_i, wait_seq);
       if (issued < 0) return issued;
     }
+    guard.armed = in_tail && rnd < ell;  // the resident kernel now waits for the next challenge
     // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
     if (round_trace())

@@ -25,29 +25,39 @@ __device__ __forceinline__ void publish_result(fe_t* result, unsigned seq) {
 // critical path. Larger grids store to device memory for k_sum_partials.
 constexpr int HOST_SUM_MAX_BLOCKS = 64;
 constexpr int SLOT_BASE_ELEM = 64;  // element index of slot 0 in the mapped buffer; slot b = 4 elements: sums[0..3), word 0 of the 4th = sequence
-// A slot is self-validating: element 3 carries the sequence number (word 0) and a check word (word 1) = sequence + sum of the data words, so the
-// host accepts a slot only when all of it has landed, whatever order the stores reach host memory in, and the producer needs no fence for it.
-__device__ __forceinline__ unsigned slot_check_word(const fe_t& v) {
-  unsigned s = 0;
+// A slot is self-validating: element 3 carries the sequence number TWICE (words 0 and 3) and two independent check words over the data
+// (word 1 = sequence + plain sum, word 2 = sequence * K + position-weighted sum), so the host accepts a slot only when all of it has landed,
+// whatever order the stores reach host memory in, and the producer needs no fence for it. A torn read would have to match both 32-bit
+// checks (2^-64 for unrelated stale words) and both copies of the sequence number.
+struct slot_chk {
+  unsigned a, b;
+};
+constexpr unsigned SLOT_CHK_K = 0x9E3779B1u;
+// the same arithmetic on the host side of capi_core.hip (wait_slot / reduce_partials_wait)
+__host__ __device__ __forceinline__ void slot_chk_add(slot_chk& c, const fe_t& v, int k) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += v.v[i];
-  return s;
+  for (int i = 0; i < 8; ++i) {
+    c.a += v.v[i];
+    c.b += (unsigned)(8 * k + i + 1) * v.v[i];
+  }
 }
-// (mapped host memory is uncached on the device side: plain stores go straight out, as two 16-byte writes per element and one 8-byte tag)
+// (mapped host memory is uncached on the device side: plain stores go straight out, as two 16-byte writes per element and two 8-byte tag halves)
 __device__ __forceinline__ void slot_store_elem(fe_t* dst, const fe_t& v) { *dst = v; }
-__device__ __forceinline__ void slot_store_tag(fe_t* slot, unsigned seq, unsigned data_sum) {
-  const unsigned long long tag = ((unsigned long long)(seq + data_sum) << 32) | seq;
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot[3].v[0]), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+__device__ __forceinline__ void slot_store_tag(fe_t* slot, unsigned seq, const slot_chk& c) {
+  const unsigned long long hi = ((unsigned long long)seq << 32) | (seq * SLOT_CHK_K + c.b);  // words 2, 3
+  const unsigned long long lo = ((unsigned long long)(seq + c.a) << 32) | seq;               // words 0, 1 (word 0 is what the host polls)
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot[3].v[2]), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot[3].v[0]), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 template <int NACC>
 __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __restrict__ partials, fe_t* __restrict__ mapped, unsigned seq) {
   if (gridDim.x <= HOST_SUM_MAX_BLOCKS) {
     fe_t* slot = mapped + SLOT_BASE_ELEM + 4 * blockIdx.x;
-    unsigned chk = 0;
+    slot_chk chk = {0u, 0u};
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
       slot_store_elem(slot + k, acc[k]);
-      chk += slot_check_word(acc[k]);
+      slot_chk_add(chk, acc[k], k);
     }
     slot_store_tag(slot, seq, chk);
   } else {
@@ -58,9 +68,10 @@ __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __r
 
 // ---- challenge mailbox ------------------------------------------------------------------------------------------------------------------
 // A kernel that binds with a challenge the host has not drawn yet is launched AHEAD of it and picks the challenge up from a 64-byte mailbox line:
-// words 0..7 = challenge, 8 = the result sequence number it answers, 9 = check word (sequence + sum of the challenge words). The line lives in
+// words 0..7 = challenge, 8 = the result sequence number it answers, 9 = check word (sequence + sum of the challenge words), 10 = second check
+// word (sequence * K + position-weighted sum), 11 = the sequence number again, 12 = abort (the host gave the sum-check up: stop waiting). The line lives in
 // fine-grained DEVICE memory that the host writes through the PCIe BAR (capi_core.hip post_challenge) — so a thousand blocks can poll it without
-// touching the bus — or, without a large BAR, in mapped host memory (resident tail only). Lanes 0..9 of wave 0 read the ten words in ONE
+// touching the bus — or, without a large BAR, in mapped host memory (resident tail only). Lanes 0..12 of wave 0 read the thirteen words in ONE
 // instruction; a poll that straddles the host's stores fails the check and is repeated. Never hangs: after 2 s the error word in the mapped
 // result buffer is set and the kernel carries on with whatever it read.
 constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in the mapped result buffer
@@ -74,17 +85,25 @@ __device__ __forceinline__ bool mail_wait(const unsigned* mail, fe_t* mapped, un
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
-    int good = 0;
+    int good = 0, aborted = 0;
     unsigned w = 0;
     while (true) {
-      if (lane < 10) w = __hip_atomic_load(mail + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const unsigned flag = __shfl(w, 8, 64), chk = __shfl(w, 9, 64);
-      if (flag == want) {
-        unsigned sum = lane < 8 ? w : 0u;
+      if (lane < 13) w = __hip_atomic_load(mail + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned flag = __shfl(w, 8, 64), chk = __shfl(w, 9, 64), chk2 = __shfl(w, 10, 64), flag2 = __shfl(w, 11, 64);
+      if (__shfl(w, 12, 64) != 0u) {  // aborted by the host (error exit of the round loop): leave without raising the watchdog error
+        aborted = 1;
+        break;
+      }
+      if (flag == want && flag2 == want) {
+        unsigned sum = lane < 8 ? w : 0u, wsum = lane < 8 ? (unsigned)(lane + 1) * w : 0u;
 #pragma unroll
-        for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+        for (int m = 4; m >= 1; m >>= 1) {
+          sum += __shfl_xor(sum, m, 64);
+          wsum += __shfl_xor(wsum, m, 64);
+        }
         sum = __shfl(sum, 0, 64) + flag;
-        if (sum == chk) {
+        wsum = __shfl(wsum, 0, 64) + flag * SLOT_CHK_K;
+        if (sum == chk && wsum == chk2) {
           good = 1;
           break;
         }
@@ -93,7 +112,17 @@ __device__ __forceinline__ bool mail_wait(const unsigned* mail, fe_t* mapped, un
       __builtin_amdgcn_s_sleep(1);
     }
     if (lane < 8) r_smem->v[lane] = w;
-    if (!good && lane == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(mapped + TAIL_ERR_ELEM), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!good && !aborted) {  // watchdog: leave what this poll saw next to the error word (diagnostics for the host's error message)
+      const unsigned seen = lane < 13 ? w : 0u;
+      if (lane < 13) reinterpret_cast<unsigned*>(mapped + TAIL_ERR_ELEM + 1)[lane] = seen;
+      if (lane == 0) {
+        unsigned* e = reinterpret_cast<unsigned*>(mapped + TAIL_ERR_ELEM);
+        e[1] = want;
+        e[2] = blockIdx.x;
+        e[3] = gridDim.x;
+        __hip_atomic_store(e, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (lane == 0) ok = good;
   }
   __syncthreads();
@@ -584,7 +613,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   constexpr unsigned long long WQ = CUBIC ? TAIL_WIDE_Q_CUBIC : TAIL_WIDE_Q;
   __shared__ fe_t smem[16];
   __shared__ fe_t r_sh;
-  __shared__ unsigned chk_sh[4];
+  __shared__ slot_chk chk_sh[4];
   const unsigned long long base = (unsigned long long)blockIdx.x * WQ;
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
@@ -612,12 +641,14 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
         a.B[0] = fb;
         slot_store_elem(fin, fa);
         slot_store_elem(fin + 1, fb);
-        unsigned chk = slot_check_word(fa) + slot_check_word(fb);
+        slot_chk chk = {0u, 0u};
+        slot_chk_add(chk, fa, 0);
+        slot_chk_add(chk, fb, 1);
         if (CUBIC) {
           const fe_t fc = bind1(a.C[0], a.C[1], r);
           a.C[0] = fc;
           slot_store_elem(fin + 2, fc);
-          chk += slot_check_word(fc);
+          slot_chk_add(chk, fc, 2);
         }
         slot_store_tag(fin, seq - 1, chk);  // tagged with the result number the last challenge answered
       }
@@ -667,15 +698,23 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       fe_t t = smem[threadIdx.x * wps];
       for (unsigned w = 1; w < wps; ++w) t = fe_add<S>(t, smem[threadIdx.x * wps + w]);
       slot_store_elem(slot + threadIdx.x, t);
-      chk_sh[threadIdx.x] = slot_check_word(t);
+      slot_chk ck = {0u, 0u};
+      slot_chk_add(ck, t, (int)threadIdx.x);
+      chk_sh[threadIdx.x] = ck;
     }
-    // while several blocks are active the next round reads other blocks' elements: one agent-scope release of the block's table writes
-    // (they are complete at the barrier) before the host can see this block's slot. The single-block rounds need no fence at all.
+    // while several blocks are active the next round reads other blocks' elements (other XCDs, other L2s): every wave first waits until its own
+    // table stores of phase A have been acknowledged by the L2 (outside tgsplit mode the workgroup barrier alone does not wait for other
+    // waves' stores), then — behind the barrier — thread 0 issues ONE agent-scope release (L2 write-back) for the whole block before the host
+    // can see this block's slot. The single-block rounds need no fence at all.
+    if (q > WQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (q > WQ) __threadfence();
-      unsigned chk = 0;
-      for (int k = 0; k < NACC; ++k) chk += chk_sh[k];
+      if (q > WQ) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      slot_chk chk = {0u, 0u};
+      for (int k = 0; k < NACC; ++k) {
+        chk.a += chk_sh[k].a;
+        chk.b += chk_sh[k].b;
+      }
       slot_store_tag(slot, seq, chk);
     }
     ++seq;

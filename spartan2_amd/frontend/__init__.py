@@ -25,6 +25,7 @@ def lib():
         L.spf_sha256_circuit.restype = ctypes.c_void_p
         L.spf_synthetic_circuit.restype = ctypes.c_void_p
         L.spf_cubic_circuit.restype = ctypes.c_void_p
+        L.spf_sha256_step_circuit.restype = ctypes.c_void_p
         L.spf_witness.restype = ctypes.POINTER(ctypes.c_uint64)
         L.spf_publics.restype = ctypes.POINTER(ctypes.c_uint64)
         L.spf_last_error.restype = ctypes.c_char_p
@@ -74,3 +75,10 @@ def synthetic_circuit(n_groups: int, seed: int, num_public: int = 4, shared_perm
 def cubic_circuit() -> R1CSInstanceInt:
     """CubicCircuit of the reference's own end-to-end test (src/spartan.rs:587-651): rest-only, public output 15."""
     return R1CSInstanceInt(lib().spf_cubic_circuit())
+
+
+def sha256_step_circuit(block: bytes) -> R1CSInstanceInt:
+    """Sha256StepCircuit (benches/sha256_neutronnova.rs:49-133) on a 64-byte block: one compression with the constant IV, x = 0 inputized.
+    The bench's CoreCircuit (:139-183) is the same shape on bytes(64)."""
+    assert len(block) == 64
+    return R1CSInstanceInt(lib().spf_sha256_step_circuit(bytes(block)))

@@ -28,6 +28,14 @@ void* spf_synthetic_circuit(size_t n_groups, uint64_t seed, size_t num_public, u
     return nullptr;
   }
 }
+void* spf_sha256_step_circuit(const uint8_t* block64) {
+  try {
+    return new R1CSInstanceInt(sha256_step_circuit(block64));
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
 void* spf_cubic_circuit() {
   try {
     return new R1CSInstanceInt(cubic_circuit());

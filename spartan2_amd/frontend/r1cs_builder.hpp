@@ -412,6 +412,24 @@ inline R1CSInstanceInt sha256_spartan_circuit(const std::vector<uint8_t>& preima
   return finalize(cs, 0, num_aux);  // shared = 0, everything precommitted, rest = 0 (benches :71-76,139-151)
 }
 
+// Sha256StepCircuit / CoreCircuit of benches/sha256_neutronnova.rs:49-183: the 512 block bits (MSB first per byte) are precommitted witness bits,
+// the chaining value is the constant IV, ONE compression (no padding block), then x = 0 allocated and inputized (AllocatedNum::inputize:
+// input * 1 = x). The core circuit is the same shape on 512 zero bits (:161-182).
+inline R1CSInstanceInt sha256_step_circuit(const uint8_t block[64]) {
+  ConstraintSystem cs;
+  std::vector<Boolean> bits;
+  for (int k = 0; k < 64; ++k)
+    for (int i = 7; i >= 0; --i) bits.push_back(alloc_bit(cs, (block[k] >> i) & 1));
+  UInt32 state[8];
+  for (int i = 0; i < 8; ++i) state[i] = UInt32::constant(SHA256_IV[i]);
+  sha256_compression(cs, bits.data(), state);
+  const uint32_t x = cs.alloc_aux(0);
+  const uint32_t in = cs.alloc_input(0);
+  cs.enforce({{in, 1}}, {{ConstraintSystem::one(), 1}}, {{x, 1}});
+  size_t num_aux = cs.aux.size();
+  return finalize(cs, 0, num_aux);
+}
+
 // Small seeded synthetic circuit in SHA-like proportions (SURVEY.md 8(d) fallback shapes):
 // booleanity, AND, XOR and 32-bit pack rows over random bits; `n_groups` groups of 100 rows.
 inline uint64_t splitmix64(uint64_t& s) {

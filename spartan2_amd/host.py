@@ -215,3 +215,148 @@ def nifs_prove(ctx: hip.Context, shape: hip.Shape, dims: dict, ck: hip.Commitmen
     out["folded_X"] = out["folded_X"][:d]
     out.update(tabs)
     return out
+
+
+# ---- multi-GPU: the exchange layer and the sharded prover (spartan2_amd/host/{comm.hpp, sharded_snark.cpp}) -----------------------------
+_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class Comm:
+    """One all-gather primitive over the ranks of the job. backend "rccl": ncclAllGather from C++ on a communicator of its own
+    (the unique id travels through torch.distributed once, at creation); backend "torch": a callback into torch.distributed.all_gather (gloo in
+    the tests, where the ranks share one GPU and RCCL cannot be used); world 1 without torch.distributed: "rccl" still creates a one-rank
+    communicator so that the production path is the one exercised."""
+
+    def __init__(self, rank: int, world: int, backend: str, device: int = 0):
+        import torch
+
+        self.rank, self.world, self.backend = rank, world, backend
+        self.h = ctypes.c_void_p()
+        self._cb = None
+        if backend == "rccl":
+            uid = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                _check(lib().ssc_rccl_unique_id(hip.p8(uid)))
+            if world > 1:
+                import torch.distributed as dist
+
+                t = torch.from_numpy(uid)
+                if dist.get_backend() == "nccl":
+                    t = t.cuda()
+                dist.broadcast(t, src=0)
+                uid = t.cpu().numpy().copy()
+            _check(lib().ssc_comm_rccl(int(device), int(rank), int(world), hip.p8(uid), ctypes.byref(self.h)))
+        elif backend == "torch":
+            import torch.distributed as dist
+
+            def raw(_user, send, nbytes, recv):
+                try:
+                    src = np.ctypeslib.as_array(ctypes.cast(send, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+                    mine = torch.from_numpy(src.copy())
+                    outs = [torch.empty_like(mine) for _ in range(world)]
+                    dist.all_gather(outs, mine)
+                    dst = np.ctypeslib.as_array(ctypes.cast(recv, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes * world,))
+                    for r, o in enumerate(outs):
+                        dst[r * nbytes : (r + 1) * nbytes] = o.numpy()
+                    return 0
+                except Exception:  # noqa: BLE001 — an exception must not unwind through the C frames
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            self._cb = _ALLGATHER_FN(raw)
+            _check(lib().ssc_comm_callback(int(rank), int(world), self._cb, None, ctypes.byref(self.h)))
+        else:
+            raise ValueError(backend)
+
+    def allgather(self, arr: np.ndarray) -> np.ndarray:
+        arr = np.ascontiguousarray(arr)
+        out = np.zeros((self.world,) + arr.shape, dtype=arr.dtype)
+        _check(lib().ssc_comm_allgather(self.h, arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(arr.nbytes), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def stats(self):
+        s = (ctypes.c_uint64 * 2)()
+        lib().ssc_comm_stats(self.h, s)
+        return {"exchanges": int(s[0]), "bytes_gathered": int(s[1])}
+
+    def close(self):
+        if self.h:
+            lib().ssc_comm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+SHARDED_PHASES = PHASES + ("exchanges",)
+
+
+class ShardedSpartanSNARK:
+    """ONE proof over all ranks of `comm` (row-sharded commitment and Az/Bz/Cz, slice-sharded sum-checks, column-sharded poly_ABC, point-range
+    MSMs); every rank calls every method with the same arguments and receives the same proof words."""
+
+    def __init__(self, ctx: hip.Context, comm: Comm, inst):
+        self.ctx, self.comm, self.inst = ctx, comm, inst
+        args, keep = _inst_args(inst)
+        self.pk = ctypes.c_void_p()
+        _check(lib().ssd_setup(ctx.h, comm.h, *args, ctypes.byref(self.pk)))
+        d = (ctypes.c_uint64 * 10)()
+        lib().ssd_pk_info(self.pk, d)
+        self.dims = {k: int(v) for k, v in zip(DIM_NAMES, d)}
+        self.ps = None
+
+    def prep_prove(self, tape: np.ndarray, is_small=True):
+        used = ctypes.c_size_t(0)
+        w = np.ascontiguousarray(self.inst.witness, dtype=np.uint64)
+        ps = ctypes.c_void_p()
+        _check(lib().ssd_prep_prove(self.pk, hip.p64(w), ctypes.c_size_t(len(w)), int(is_small), hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used),
+                                    ctypes.byref(ps)))
+        if self.ps:
+            lib().ssd_prep_free(self.ps)
+        self.ps = ps
+        return used.value
+
+    def proof_words(self):
+        d = self.dims
+        M = d["num_shared"] + d["num_precommitted"] + d["num_rest"]
+        lx, ly = d["num_cons"].bit_length() - 1, M.bit_length()
+        return 8 * (M // 2048) + 4 * d["num_public"] + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * 2048 + 8
+
+    def prove(self, tape: np.ndarray):
+        n = self.proof_words()
+        words = np.zeros(n, dtype=np.uint64)
+        used = ctypes.c_size_t(0)
+        ms = (ctypes.c_double * 8)()
+        pub = np.ascontiguousarray(self.inst.publics, dtype=np.uint64)
+        _check(lib().ssd_prove(self.pk, self.ps, hip.p64(pub) if len(pub) else None, ctypes.c_size_t(len(pub)), hip.p8(tape), ctypes.c_size_t(tape.shape[0]),
+                               ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
+        return words, used.value, dict(zip(SHARDED_PHASES, list(ms)))
+
+    def close(self):
+        if self.ps:
+            lib().ssd_prep_free(self.ps)
+            self.ps = None
+        if self.pk:
+            lib().ssd_pk_free(self.pk)
+            self.pk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sharded_commit(ctx: hip.Context, comm: Comm, key: hip.CommitmentKey, table: hip.Table, n_local: int, blinds_local, is_small=False):
+    """PCS::commit with the rows sharded by row over the ranks (BASELINE config 4's MSM leg): this rank's rows are resident in `table`;
+    returns all rows (world * rows_local, 8), rank-major."""
+    rows_local = (n_local + 2047) // 2048
+    blinds_local = np.ascontiguousarray(blinds_local, dtype=np.uint64).reshape(rows_local, 4)
+    out = np.zeros((comm.world * rows_local, 8), dtype=np.uint64)
+    _check(lib().ssd_commit(ctx.h, comm.h, key.h, table.h, ctypes.c_size_t(n_local), hip.p64(blinds_local), int(is_small), hip.p64(out)))
+    return out

@@ -1,0 +1,125 @@
+// The exchange layer of the multi-GPU drivers: one process per GPU, and ONE primitive — an all-gather of a small fixed-size
+// record per rank — because nothing this path exchanges is an elementwise reduction RCCL knows: field sums are modular, group sums are elliptic-curve
+// additions. Every rank gathers everyone's record and combines locally in rank order (exact arithmetic: all ranks obtain identical values and run
+// the deterministic transcript redundantly, so nothing is ever broadcast).
+//   * RCCL backend (production: xGMI between the GPUs of a node): ncclAllGather on a device staging buffer on a stream of its own, bracketed by
+//     pinned-host copies. librccl is resolved with dlopen at first use, so the one copy already in the process (torch ships its own) is shared.
+//   * callback backend (tests: gloo ranks that share one GPU; RCCL refuses two ranks on one device).
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_common.hpp"
+
+namespace spartan2 {
+
+typedef int (*ssc_allgather_fn)(void* user, const void* send, size_t bytes_per_rank, void* recv);
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  static RcclApi& get() {
+    static RcclApi api = [] {
+      RcclApi a;
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (a.handle) break;
+      }
+      if (!a.handle) return a;
+      a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+      a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+      a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
+      a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+      a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+      return a;
+    }();
+    return api;
+  }
+  bool ok() const { return handle && GetUniqueId && CommInitRank && AllGather && CommDestroy && GetErrorString; }
+};
+
+struct Comm {
+  int rank = 0, world = 1;
+  // callback backend
+  ssc_allgather_fn fn = nullptr;
+  void* user = nullptr;
+  // RCCL backend
+  ncclComm_t nc = nullptr;
+  int device = 0;
+  hipStream_t st = nullptr;
+  void *d_send = nullptr, *d_recv = nullptr, *h_send = nullptr, *h_recv = nullptr;
+  size_t cap = 0;  // bytes per rank the staging buffers hold
+  uint64_t calls = 0, bytes_moved = 0;
+
+  ~Comm() {
+    if (nc) RcclApi::get().CommDestroy(nc);
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    if (h_send) (void)hipHostFree(h_send);
+    if (h_recv) (void)hipHostFree(h_recv);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  void hipck(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(SP_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+  }
+  void reserve(size_t bytes) {
+    if (bytes <= cap) return;
+    size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    if (h_send) (void)hipHostFree(h_send);
+    if (h_recv) (void)hipHostFree(h_recv);
+    d_send = d_recv = h_send = h_recv = nullptr;
+    hipck(hipMalloc(&d_send, want), "comm: hipMalloc");
+    hipck(hipMalloc(&d_recv, want * world), "comm: hipMalloc");
+    hipck(hipHostMalloc(&h_send, want), "comm: hipHostMalloc");
+    hipck(hipHostMalloc(&h_recv, want * world), "comm: hipHostMalloc");
+    cap = want;
+  }
+  // recv[r * bytes .. (r + 1) * bytes) = rank r's `send`
+  void allgather(const void* send, size_t bytes, void* recv) {
+    ++calls;
+    bytes_moved += bytes * world;
+    if (fn) {
+      int rc = fn(user, send, bytes, recv);
+      if (rc) throw Error(SP_ERR_INTERNAL, "comm: the all-gather callback failed");
+      return;
+    }
+    if (!nc) {  // a world of one without a backend
+      if (world != 1) throw Error(SP_ERR_INTERNAL, "comm: no backend");
+      memcpy(recv, send, bytes);
+      return;
+    }
+    hipck(hipSetDevice(device), "comm: hipSetDevice");
+    reserve(bytes);
+    memcpy(h_send, send, bytes);
+    hipck(hipMemcpyAsync(d_send, h_send, bytes, hipMemcpyHostToDevice, st), "comm: H2D");
+    ncclResult_t r = RcclApi::get().AllGather(d_send, d_recv, bytes, ncclUint8, nc, st);
+    if (r != ncclSuccess) throw Error(SP_ERR_INTERNAL, std::string("ncclAllGather: ") + RcclApi::get().GetErrorString(r));
+    hipck(hipMemcpyAsync(h_recv, d_recv, bytes * world, hipMemcpyDeviceToHost, st), "comm: D2H");
+    hipck(hipStreamSynchronize(st), "comm: synchronize");
+    memcpy(recv, h_recv, bytes * world);
+  }
+  // field sum over ranks of `count` elements, in rank order, in place (the reduce step of a slice-sharded sum-check round)
+  void field_sum(fe_t* vals, size_t count) {
+    if (world == 1) return;
+    std::vector<fe_t> all(count * world);
+    allgather(vals, count * sizeof(fe_t), all.data());
+    for (size_t i = 0; i < count; ++i) {
+      fe_t acc = all[i];
+      for (int r = 1; r < world; ++r) acc = fe_add<S>(acc, all[(size_t)r * count + i]);
+      vals[i] = acc;
+    }
+  }
+};
+
+}  // namespace spartan2

@@ -1,0 +1,194 @@
+// Pieces shared by the host-side protocol drivers above the C ABI (spartan_snark.cpp, sharded_snark.cpp): the integer R1CS view and
+// SplitR1CSShape::new padding, this build's generator derivation and vk digest substitute, the O(sqrt N) host-side eq tables.
+#pragma once
+#include "host_common.hpp"
+
+namespace spartan2 {
+
+// ---- integer R1CS as produced by the frontend (arguments of SplitR1CSShape::new) ---------------------------------------
+struct CsrIntView {
+  const int64_t* data;
+  const uint32_t* indices;
+  const uint64_t* indptr;
+};
+struct R1CSIntView {
+  size_t num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges;
+  CsrIntView m[3];
+};
+
+struct PaddedShape {
+  sp_dims dims;
+  std::vector<fe_t> data[3];
+  std::vector<uint32_t> idx[3];
+  std::vector<uint64_t> ptr[3];
+  size_t num_vars() const { return dims.num_shared + dims.num_precommitted + dims.num_rest; }
+  size_t num_cols() const { return num_vars() + 1 + dims.num_public + dims.num_challenges; }
+};
+
+inline size_t pad_to_width(size_t w, size_t n) { return (n + w - 1) / w * w; }
+inline size_t next_pow2(size_t n) {
+  size_t p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+inline size_t log2_ceil(size_t n) {
+  size_t l = 0;
+  while (((size_t)1 << l) < n) ++l;
+  return l;
+}
+
+// SplitR1CSShape::new (src/r1cs/mod.rs:810-911)
+inline PaddedShape pad_shape(const R1CSIntView& R) {
+  const size_t width = DEFAULT_COMMITMENT_WIDTH;
+  size_t sp_ = pad_to_width(width, R.num_shared), pp = pad_to_width(width, R.num_precommitted), rp = pad_to_width(width, R.num_rest);
+  size_t nvp = sp_ + pp + rp;
+  if (nvp < R.num_public + R.num_challenges + 1) rp = std::max(R.num_public + R.num_challenges + 1, nvp) - (sp_ + pp);
+  nvp = sp_ + pp + rp;
+  if (next_pow2(nvp) != nvp) rp = next_pow2(nvp) - (sp_ + pp);
+  nvp = sp_ + pp + rp;
+  const size_t num_vars = R.num_shared + R.num_precommitted + R.num_rest;
+  const size_t ncp = next_pow2(R.num_cons);
+  PaddedShape P;
+  P.dims.num_cons = ncp;
+  P.dims.num_cons_unpadded = R.num_cons;
+  P.dims.num_shared = sp_;
+  P.dims.num_precommitted = pp;
+  P.dims.num_rest = rp;
+  P.dims.num_shared_unpadded = R.num_shared;
+  P.dims.num_precommitted_unpadded = R.num_precommitted;
+  P.dims.num_rest_unpadded = R.num_rest;
+  P.dims.num_public = R.num_public;
+  P.dims.num_challenges = R.num_challenges;
+  // small coefficient cache: the SHA circuits only use +-2^k
+  for (int m = 0; m < 3; ++m) {
+    const size_t nnz = R.m[m].indptr[R.num_cons];
+    P.data[m].resize(nnz);
+    P.idx[m].resize(nnz);
+    for (size_t k = 0; k < nnz; ++k) {
+      P.data[m][k] = fe_from_i64<S>(R.m[m].data[k]);
+      size_t c = R.m[m].indices[k];
+      if (c >= R.num_shared && c < R.num_shared + R.num_precommitted) c += sp_ - R.num_shared;
+      else if (c >= R.num_shared + R.num_precommitted && c < num_vars) c += sp_ + pp - R.num_shared - R.num_precommitted;
+      else if (c >= num_vars) c += nvp - num_vars;
+      P.idx[m][k] = (uint32_t)c;
+    }
+    P.ptr[m].assign(R.m[m].indptr, R.m[m].indptr + R.num_cons + 1);
+    P.ptr[m].resize(ncp + 1, nnz);
+  }
+  return P;
+}
+
+// vk digest substitute (see oracle/spartan.hpp header): Keccak-256 over S.write_bytes() (src/r1cs/mod.rs:775-794, sparse.rs:398-417)
+inline void shape_digest(const PaddedShape& P, uint8_t out[32]) {
+  sp::Keccak256State h;
+  h.init();
+  auto w64 = [&](uint64_t v) {
+    uint8_t b[8];
+    for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(v >> (8 * i));
+    h.update(b, 8);
+  };
+  const sp_dims& d = P.dims;
+  w64(d.num_cons);
+  w64(d.num_cons_unpadded);
+  w64(d.num_shared_unpadded);
+  w64(d.num_precommitted_unpadded);
+  w64(d.num_rest_unpadded);
+  w64(d.num_shared);
+  w64(d.num_precommitted);
+  w64(d.num_rest);
+  w64(d.num_public);
+  w64(d.num_challenges);
+  for (int m = 0; m < 3; ++m) {
+    w64(P.data[m].size());
+    w64(P.idx[m].size());
+    w64(P.ptr[m].size());
+    w64(P.num_cols());
+    for (const fe_t& f : P.data[m]) {
+      uint8_t b[32];
+      sp::fe_to_le_bytes<S>(f, b);
+      h.update(b, 32);
+    }
+    for (uint32_t i : P.idx[m]) w64(i);
+    for (uint64_t p : P.ptr[m]) w64(p);
+  }
+  h.finish(out);
+}
+
+// This build's generator derivation (documented in DESIGN.md; shape of src/provider/traits.rs:205-249):
+// SHAKE256(label) stream, 32 bytes per generator -> x = bytes LE mod p; increment x until x^3 - 3x + b is a non-zero square;
+// y = rhs^((p+1)/4), take the root with even canonical value.
+inline std::vector<aff_t> from_label(const char* label, size_t n) {
+  sp::Shake256State sh;
+  sh.init();
+  sh.update((const uint8_t*)label, strlen(label));
+  uint32_t e[8], c = 0;
+  for (int i = 0; i < 8; ++i) e[i] = sp_addc(FpP::P(i), i == 0 ? 1u : 0u, c);  // p + 1
+  for (int i = 0; i < 7; ++i) e[i] = (e[i] >> 2) | (e[i + 1] << 30);
+  e[7] >>= 2;
+  std::vector<aff_t> out(n);
+  const fe_t b = T256::b(), one = fe_one<B>();
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t buf[64];
+    memset(buf, 0, 64);
+    sh.read(buf, 32);
+    fe_t x = fe_from_uniform<B>(buf);
+    for (;;) {
+      fe_t rhs = fe_add<B>(fe_sub<B>(fe_mul<B>(fe_sqr<B>(x), x), fe_add<B>(fe_dbl<B>(x), x)), b);
+      fe_t y = fe_pow<B>(rhs, e);
+      if (!fe_is_zero(rhs) && fe_eq(fe_sqr<B>(y), rhs)) {
+        fe_t yc = fe_to_canonical<B>(y);
+        if (yc.v[0] & 1u) y = fe_neg<B>(y);
+        out[i].x = x;
+        out[i].y = y;
+        break;
+      }
+      x = fe_add<B>(x, one);
+    }
+  }
+  return out;
+}
+
+// EqPolynomial::evals_from_points on the host for the O(sqrt N) tables of the opening (src/polys/eq.rs:59-92)
+inline std::vector<fe_t> eq_evals_host(const fe_t* r, size_t ell) {
+  std::vector<fe_t> ev((size_t)1 << ell, fe_zero());
+  ev[0] = fe_one<S>();
+  size_t size = 1;
+  for (size_t k = ell; k-- > 0;) {
+    for (size_t i = 0; i < size; ++i) {
+      fe_t y = fe_mul<S>(ev[i], r[k]);
+      ev[size + i] = y;
+      ev[i] = fe_sub<S>(ev[i], y);
+    }
+    size *= 2;
+  }
+  return ev;
+}
+// SparsePolynomial::evaluate (src/polys/multilinear.rs:190-207)
+inline fe_t sparse_poly_evaluate(size_t num_vars, const std::vector<fe_t>& Z, const fe_t* r) {
+  size_t nvz = log2_ceil(Z.size());
+  std::vector<fe_t> chis = eq_evals_host(r + (num_vars - 1 - nvz), nvz + 1);
+  fe_t partial = fe_zero();
+  for (size_t i = 0; i < Z.size(); ++i) partial = fe_add<S>(partial, fe_mul<S>(Z[i], chis[i]));
+  fe_t common = fe_one<S>();
+  for (size_t i = 0; i < num_vars - 1 - nvz; ++i) common = fe_mul<S>(common, fe_sub<S>(fe_one<S>(), r[i]));
+  return fe_mul<S>(common, partial);
+}
+
+
+struct SpartanProofBuf {  // SpartanSNARK (src/spartan.rs:130-138) in the canonical flat layout of DESIGN.md
+  std::vector<uint64_t> words;
+  void pf(const fe_t& f) { words.insert(words.end(), u64p(&f), u64p(&f) + 4); }
+  void pp(const aff_t& a) {
+    pf(a.x);
+    pf(a.y);
+  }
+};
+
+inline R1CSIntView make_view(size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges,
+                             const int64_t* Ad, const uint32_t* Ai, const uint64_t* Ap, const int64_t* Bd, const uint32_t* Bi, const uint64_t* Bp,
+                             const int64_t* Cd, const uint32_t* Ci, const uint64_t* Cp) {
+  R1CSIntView R{num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges, {{Ad, Ai, Ap}, {Bd, Bi, Bp}, {Cd, Ci, Cp}}};
+  return R;
+}
+
+}  // namespace spartan2

@@ -1,0 +1,295 @@
+"""Every BASELINE.json configuration under GPU parity AT ITS OWN SIZE (VERDICT r1 "configs_untested"):
+
+  C1  sha256_spartan 1 KiB message              whole prove, bit-exact vs the oracle
+  C2  sha256_spartan 2 KiB message              whole prove, bit-exact vs the oracle (also tests/test_gpu_verify.py + the bench run)
+  C3  sha256_neutronnova, 32 step circuits      NIFS + folds + both batched sum-checks, every challenge / claim vs the oracle's composition
+                                                 (the full NeutronNovaZkSNARK::prove with the verifier circuit is tests/test_gpu_neutronnova_zk.py)
+  C4  synthetic R1CS 2^22 (seed 0xDEADBEEF)      whole prove bit-exact vs the oracle + the 2048 x 2048 full-scalar Hyrax commit vs orc_hyrax_commit
+  C5  NeutronNova 256 step instances             256 instances at 2^13 constraints vs the oracle (small-value mode, the oracle finishes in seconds), and
+                                                 256 x 2^20 (24 GiB of layers) through the size-independent identity T_out = sum_k E[k] (A B - C)[k]
+                                                 of the folded instance plus the NIFS round-polynomial consistency poly_t(0) + poly_t(1) = T_cur.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from spartan2_amd import frontend, hip, host
+
+pytestmark = pytest.mark.gpu
+P = ol.MODULI[0]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _prove_both(ctx, inst, seed, tape_blocks=8192):
+    tape = ol.make_tape(seed, tape_blocks)
+    osp = ol.OracleSpartan(inst)
+    used_o = osp.prep_prove(tape)
+    want, used_o2, _ = osp.prove(tape[used_o:])
+    gsp = host.SpartanSNARK(ctx, inst)
+    used_g = gsp.prep_prove(tape)
+    got, used_g2, phases = gsp.prove(tape[used_g:])
+    assert (used_g, used_g2) == (used_o, used_o2)
+    return osp, gsp, want, got, phases
+
+
+@pytest.mark.parametrize("msg_bytes,log_n", [(1024, 19), (2048, 20)])
+def test_c1_c2_sha256_spartan_prove_bit_exact(ctx, msg_bytes, log_n):
+    inst = frontend.sha256_circuit(bytes(msg_bytes))  # benches/sha256_spartan.rs:167,172: vec![0u8; size]
+    osp, gsp, want, got, phases = _prove_both(ctx, inst, 1000 + msg_bytes)
+    assert gsp.dims["num_cons"] == 1 << log_n
+    assert (got == want).all()
+    assert osp.verify_words(got) == 0 and gsp.verify(got) == 0
+    gsp.close()
+
+
+def test_c4_synthetic_2p22_prove_bit_exact(ctx):
+    """synthetic satisfiable R1CS, N = M = 2^22, seed 0xDEADBEEF, SHA-like row mix, Bernoulli(1/2) witness bits."""
+    inst = frontend.synthetic_circuit(45000, 0xDEADBEEF, num_public=8)
+    assert 1 << 21 < inst.num_cons <= 1 << 22
+    osp, gsp, want, got, phases = _prove_both(ctx, inst, 0xDEADBEEF)
+    assert gsp.dims["num_cons"] == 1 << 22 and gsp.dims["num_precommitted"] + gsp.dims["num_rest"] == 1 << 22
+    assert (got == want).all()
+    assert osp.verify_words(got) == 0 and gsp.verify(got) == 0
+    gsp.close()
+
+
+def test_c4_full_scalar_commit_2048_rows_matches_oracle(ctx):
+    """The MSM side of config 4: PCS::commit of 2^22 full-width scalars = 2048 row MSMs of 2048 points over one key (hyrax_pc.rs:230-300)."""
+    L = ol.lib()
+    okey = ctypes.c_void_p(L.orc_hyrax_setup(b"ck", ctypes.c_size_t(2048)))
+    ck_aff = np.zeros((2048, 8), dtype=np.uint64)
+    h_aff = np.zeros(8, dtype=np.uint64)
+    L.orc_hyrax_key_export(okey, ol.p64(ck_aff), ol.p64(h_aff))
+    key = hip.CommitmentKey(ctx, ck_aff, h_aff)
+    rng = np.random.default_rng(0xDEADBEEF)
+    n = 1 << 22
+    v = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    v[:, 3] &= np.uint64((1 << 63) - 1)  # < 2^255 < p: canonical limbs (read as Montgomery form: uniform elements)
+    # structure the reference's commit special-cases: an all-zero row, a row of ones (msm peels scalars == 1), a short row, a small-valued row
+    one = ol.to_mont(1)
+    v[5 * 2048 : 6 * 2048] = 0
+    v[6 * 2048 : 7 * 2048] = one
+    v[7 * 2048 + 100 : 8 * 2048] = 0
+    v[8 * 2048 : 9 * 2048] = ol.mont_array([int(x) for x in rng.integers(0, 1 << 20, size=2048)])
+    blinds = ol.random_field_array(rng, 2048)
+    want = np.zeros((2048, 8), dtype=np.uint64)
+    assert L.orc_hyrax_commit(okey, ol.p64(v), ctypes.c_size_t(n), ol.p64(blinds), 0, ol.p64(want)) == 0
+    t = hip.Table.from_host(ctx, v)
+    got = key.commit(t, 0, n, blinds, is_small=False)
+    assert (got == want).all()
+    t.free()
+    L.orc_hyrax_free(okey)
+
+
+# ---- NeutronNova configurations ------------------------------------------------------------------------------------------------
+def _padded_witness(dims, inst):
+    M = dims["num_shared"] + dims["num_precommitted"] + dims["num_rest"]
+    W = np.zeros((M, 4), dtype=np.uint64)
+    w = np.asarray(inst.witness, dtype=np.uint64)
+    one = ol.to_mont(1)
+    s, p = dims["num_shared_unpadded"], dims["num_precommitted_unpadded"]
+
+    def put(dst, vals):
+        seg = W[dst : dst + len(vals)]
+        seg[vals == 1] = one
+        for k in np.nonzero(vals > 1)[0]:
+            seg[k] = ol.to_mont(int(vals[k]))
+
+    put(0, w[:s])
+    put(dims["num_shared"], w[s : s + p])
+    put(dims["num_shared"] + dims["num_precommitted"], w[s + p :])
+    return W
+
+
+def _neutronnova_env(ctx):
+    L = ol.lib()
+    okey = ctypes.c_void_p(L.orc_hyrax_setup(b"ck", ctypes.c_size_t(2048)))
+    ck_aff = np.zeros((2048, 8), dtype=np.uint64)
+    h_aff = np.zeros(8, dtype=np.uint64)
+    L.orc_hyrax_key_export(okey, ol.p64(ck_aff), ol.p64(h_aff))
+    return okey, hip.CommitmentKey(ctx, ck_aff, h_aff)
+
+
+def test_c3_sha256_neutronnova_32_steps_datapath(ctx):
+    """benches/sha256_neutronnova.rs shapes: 32 one-compression step instances (2^15 constraints each) + a core instance; NIFS (small-value
+    round 0), witness / commitment / blind folds, batched outer sum-check with the split power table, both poly_ABC, batched inner sum-check.
+    Every output of every stage equals the oracle's composition of the same stages; process_round is the same transcript hook on both sides."""
+    steps = 32
+    okey, key = _neutronnova_env(ctx)
+    insts = [frontend.sha256_step_circuit(bytes([i]) * 64) for i in range(steps)]  # block [i as u8; 64] (benches/sha256_neutronnova.rs:219-223)
+    core_inst = frontend.sha256_step_circuit(bytes(64))  # CoreCircuit (:139-183)
+    mats, dims = host.pad_shape(insts[0])
+    oshape = ol.OracleShape(insts[0])
+    shape = hip.Shape(ctx, mats, dims)
+    N, M, d = dims["num_cons"], oshape.num_vars, dims["num_public"]
+    assert N == 1 << 15 and M == 1 << 15
+    rows = M // 2048
+    rng = np.random.default_rng(33)
+    Wh = np.stack([_padded_witness(dims, i) for i in insts])
+    X = np.stack([ol.mont_array([int(x) for x in i.publics]) for i in insts])
+    r_W = np.stack([ol.random_field_array(rng, rows) for _ in insts])
+    Wt = [hip.Table.from_host(ctx, w) for w in Wh]
+    comms = np.stack([key.commit(Wt[k], 0, M, r_W[k]) for k in range(steps)])
+    want_c = np.zeros((rows, 8), dtype=np.uint64)
+    assert ol.lib().orc_hyrax_commit(okey, ol.p64(Wh[7]), ctypes.c_size_t(M), ol.p64(r_W[7]), 1, ol.p64(want_c)) == 0
+    assert (comms[7] == want_c).all()
+    Wc_h = _padded_witness(dims, core_inst)
+    Xc = ol.mont_array([int(x) for x in core_inst.publics])
+    one = ol.to_mont(1).reshape(1, 4)
+    ell_x, ell_y = N.bit_length() - 1, M.bit_length()
+    _, left, right = ol.tensor_decomp(N)
+
+    # ---- oracle composition
+    want = ol.nifs_prove(oshape, okey, comms, X, Wh, r_W, True, ol.Transcript(b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+    zc = np.concatenate([Wc_h, one, Xc])
+    core_o = [np.zeros((N, 4), dtype=np.uint64) for _ in range(3)]
+    assert ol.lib().orc_shape_multiply_vec(oshape.h, ol.p64(zc), *(ol.p64(w) for w in core_o)) == 0
+    otr = ol.Transcript(b"vc2")
+    ohook = ol.batched_transcript_hook(otr)
+    o_rx, o_fin, o_base = ol.prove_cubic_outer_pow_batched(ell_x, want["E_eq"][:left].copy(), want["E_eq"][left:].copy(), [want["A"], want["B"], want["C"]], core_o,
+                                                           want["tail"][0], 0, ohook)
+    o_r = ohook(99, o_fin[:3], o_fin[3:])
+    ri = ol.from_mont(o_r)
+    cl = [ol.from_mont(c) for c in o_fin]
+    joint = np.stack([ol.to_mont((cl[0] + ri * cl[1] + ri * ri * cl[2]) % P), ol.to_mont((cl[3] + ri * cl[4] + ri * ri * cl[5]) % P)])
+    o_evals_rx = np.zeros((N, 4), dtype=np.uint64)
+    ol.lib().orc_eq_evals(ol.p64(o_rx), ctypes.c_size_t(ell_x), ol.p64(o_evals_rx))
+    o_abc = np.zeros((2 * M, 4), dtype=np.uint64)
+    assert ol.lib().orc_shape_poly_abc(oshape.h, ol.p64(o_evals_rx), ol.p64(o_r), ctypes.c_size_t(2 * M), ol.p64(o_abc)) == 0
+    z_step = np.zeros((2 * M, 4), dtype=np.uint64)
+    z_step[:M] = want["folded_W"]
+    z_step[M : M + 1 + d] = np.concatenate([one, want["folded_X"]])
+    z_core = np.zeros((2 * M, 4), dtype=np.uint64)
+    z_core[: M + 1 + d] = zc
+    o_ry, o_fin2 = ol.prove_quad_batched(joint, ell_y, o_abc, o_abc.copy(), z_step, z_core, 100, ohook)
+
+    # ---- device path
+    got = host.nifs_prove(ctx, shape, dims, key, comms, X, Wt, r_W, True, hip.Transcript(ctx, b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+    for k in ("polys", "r_bs", "E_eq", "tail", "folded_rW", "folded_X", "folded_comm"):
+        assert (want[k] == got[k]).all(), k
+    for k, n in (("A", N), ("B", N), ("C", N), ("folded_W", M)):
+        assert (want[k] == got[k].read(0, n)).all(), k
+    ghook = ol.batched_transcript_hook(ol.Transcript(b"vc2"))
+    zct = hip.Table.from_host(ctx, zc)
+    core_g = [hip.Table.zeros(ctx, N) for _ in range(3)]
+    shape.multiply_vec(zct, *core_g)
+    pl, pr = hip.Table.from_host(ctx, got["E_eq"][:left]), hip.Table.from_host(ctx, got["E_eq"][left:])
+    g_rx = hip.sumcheck_cubic_outer_pow_batched(ctx, ell_x, pl, pr, [got["A"], got["B"], got["C"]], core_g, got["tail"][0], 0, ghook)
+    assert (g_rx == o_rx).all()
+    g_fin = np.stack([t.read(0, 1)[0] for t in (got["A"], got["B"], got["C"], *core_g)])
+    assert (g_fin == o_fin).all() and (pl.read(0, 1)[0] == o_base).all()
+    g_r = ghook(99, g_fin[:3], g_fin[3:])
+    assert (g_r == o_r).all()
+    rx = hip.Table.eq(ctx, g_rx)
+    abc_s, abc_c = hip.Table.zeros(ctx, 2 * M), hip.Table.zeros(ctx, 2 * M)
+    shape.poly_abc(rx, g_r, 2 * M, abc_s)
+    shape.poly_abc(rx, g_r, 2 * M, abc_c)
+    assert (abc_s.read(0, 2 * M) == o_abc).all()
+    zs, zcc = hip.Table.from_host(ctx, z_step), hip.Table.from_host(ctx, z_core)
+    for t in (abc_s, abc_c, zs, zcc):
+        t.set_len(2 * M, M, 1 + d)
+    g_ry, g_fin2 = hip.sumcheck_quad_batched(ctx, joint, ell_y, abc_s, abc_c, zs, zcc, 100, ghook)
+    assert (g_ry == o_ry).all() and (g_fin2 == o_fin2).all()
+    ol.lib().orc_hyrax_free(okey)
+
+
+def _synthetic_steps(n_inst, n_groups, distinct):
+    """n_inst instances of one synthetic step shape; `distinct` different satisfying assignments reused cyclically (the generator is the slow part)."""
+    base = [frontend.synthetic_circuit(n_groups, 0xC5, num_public=2, witness_seed=100 + s) for s in range(distinct)]
+    return [base[i % distinct] for i in range(n_inst)], base
+
+
+def test_c5_256_instances_scaled_matches_oracle(ctx):
+    """256 instances (ell_b = 8) at 2^13 constraints each, small-value mode: the whole NeutronNovaNIFS::prove vs the oracle."""
+    okey, key = _neutronnova_env(ctx)
+    insts, _ = _synthetic_steps(256, 60, 256)
+    mats, dims = host.pad_shape(insts[0])
+    oshape = ol.OracleShape(insts[0])
+    shape = hip.Shape(ctx, mats, dims)
+    N, M = dims["num_cons"], oshape.num_vars
+    assert N == 1 << 13
+    rows = M // 2048
+    rng = np.random.default_rng(55)
+    Wh = np.stack([_padded_witness(dims, i) for i in insts])
+    X = np.stack([ol.mont_array([int(x) for x in i.publics]) for i in insts])
+    r_W = np.stack([ol.random_field_array(rng, rows) for _ in insts])
+    Wt = [hip.Table.from_host(ctx, w) for w in Wh]
+    comms = np.stack([key.commit(Wt[k], 0, M, r_W[k]) for k in range(len(insts))])
+    want = ol.nifs_prove(oshape, okey, comms, X, Wh, r_W, True, ol.Transcript(b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+    got = host.nifs_prove(ctx, shape, dims, key, comms, X, Wt, r_W, True, hip.Transcript(ctx, b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+    assert want["r_bs"].shape[0] == 8
+    for k in ("polys", "r_bs", "E_eq", "tail", "folded_rW", "folded_X", "folded_comm"):
+        assert (want[k] == got[k]).all(), k
+    for k, n in (("A", N), ("B", N), ("C", N), ("folded_W", M)):
+        assert (want[k] == got[k].read(0, n)).all(), k
+    ol.lib().orc_hyrax_free(okey)
+
+
+def test_c5_256_instances_full_size_fold_identity(ctx):
+    """256 instances x 2^20 constraints (A, B, C layers: 24 GiB resident). No oracle at this size; the domain's own identities instead:
+    every round polynomial satisfies poly_t(0) + poly_t(1) = T_cur * (the eq factor the reference folds in, checked through the final
+    T_out = T_cur / acc_eq) and the folded instance satisfies T_out = sum_k E[k] (A B - C)[k] with E = left (x) right — evaluated on the
+    device with sp_eval_cubic_outer_pow's first sum (the same kernel the batched outer sum-check opens with)."""
+    n_inst, distinct = 256, 8
+    insts, base = _synthetic_steps(n_inst, 9800, distinct)
+    mats, dims = host.pad_shape(base[0])
+    assert dims["num_cons"] == 1 << 20
+    shape = hip.Shape(ctx, mats, dims)
+    N = dims["num_cons"]
+    M = dims["num_shared"] + dims["num_precommitted"] + dims["num_rest"]
+    d = dims["num_public"]
+    one = ol.to_mont(1).reshape(1, 4)
+    ell, left, right = ol.tensor_decomp(N)
+    ell_b = 8
+    nifs = hip.Nifs(ctx, n_inst, left, right)
+    # layers by sp_multiply_vec straight into the NIFS arrays (src/neutronnova_zk.rs:576-596); distinct witnesses are multiplied once and copied
+    for s, inst in enumerate(base):
+        z = hip.Table.from_host(ctx, np.concatenate([_padded_witness(dims, inst), one, ol.mont_array([int(x) for x in inst.publics])]))
+        views = [nifs.layer(w, s) for w in range(3)]
+        shape.multiply_vec(z, *views)
+        for k in range(s + distinct, n_inst, distinct):
+            for w in range(3):
+                nifs.layer(w, k).copy_from(0, views[w], 0, N)
+        z.free()
+    rng = np.random.default_rng(77)
+    tau = ol.random_field_array(rng, 1)[0]
+    E = ol.pow_split_evals(tau, ell, left, right)
+    rhos = ol.random_field_array(rng, ell_b)
+    nifs.begin(E, rhos, small_values=1)
+    tr = ol.Transcript(b"c5")
+    T_cur = 0
+    acc_eq = 1
+    for t in range(ell_b):
+        co = nifs.round(t)  # [d, c, b, a] of poly_t (:719-721)
+        c = [ol.from_mont(x) for x in co]
+        assert (c[0] + sum(c)) % P == T_cur, f"round {t}: poly_t(0) + poly_t(1) != T_cur"
+        for row in co:
+            tr.absorb_scalar(b"p", row)
+        r_b = tr.squeeze(b"c")
+        nifs.challenge(r_b)
+        r = ol.from_mont(r_b)
+        rho = ol.from_mont(rhos[t])
+        T_cur = (c[0] + c[1] * r + c[2] * r * r + c[3] * r * r * r) % P
+        acc_eq = acc_eq * ((1 - rho) * (1 - r) + rho * r) % P
+    A, B, C = hip.Table.zeros(ctx, N), hip.Table.zeros(ctx, N), hip.Table.zeros(ctx, N)
+    T_out, eq_rho = nifs.finish(A, B, C)
+    assert ol.from_mont(eq_rho) == acc_eq
+    assert ol.from_mont(T_out) * acc_eq % P == T_cur
+    # folded claim on the device: first sum of the outer-pow evaluation over virtual 2N-long tables [layer | 0] is sum_k E[k] (A B - C)[k]
+    pl, pr = hip.Table.from_host(ctx, E[:left]), hip.Table.from_host(ctx, np.concatenate([E[left:], np.zeros((right, 4), dtype=np.uint64)]))
+    ext = []
+    for tb in (A, B, C):
+        e2 = hip.Table.zeros(ctx, 2 * N)
+        e2.copy_from(0, tb, 0, N)
+        ext.append(e2)
+    sums = hip.eval_cubic_outer_pow(ctx, pl, pr, *ext)
+    assert (sums[0] == T_out).all()
+    nifs.free()
