@@ -104,6 +104,17 @@ class SpartanSNARK:
         self.ps = ps
         return used.value
 
+    def set_flags(self, prefix_cache=None, lz_direct=None):
+        """Driver options of the current prep state (spartan_snark.cpp FLAG_*): prefix_cache = keep the transcript prefix's sponge state across
+        proves instead of re-hashing it in every prove (the reference re-hashes); lz_direct = the opening in the reference's own order."""
+        lib().ss_prep_get_flags.restype = ctypes.c_uint
+        f = lib().ss_prep_get_flags(self.ps)
+        if prefix_cache is not None:
+            f = (f | 1) if prefix_cache else (f & ~1)
+        if lz_direct is not None:
+            f = (f | 2) if lz_direct else (f & ~2)
+        lib().ss_prep_set_flags(self.ps, ctypes.c_uint(f))
+
     def prep_export(self):
         d = self.dims
         rows = ((d["num_shared"] + 2047) // 2048 if d["num_shared_unpadded"] else 0) + ((d["num_precommitted"] + 2047) // 2048 if d["num_precommitted_unpadded"] else 0)
@@ -129,9 +140,11 @@ class SpartanSNARK:
     def verify(self, words: np.ndarray) -> int:
         """SpartanSNARK::verify (src/spartan.rs:469-578) with the matrix evaluations and MSMs on the device: 0 = accept, 1..6 = failed check."""
         words = np.ascontiguousarray(words, dtype=np.uint64)
-        rc = lib().ss_verify(self.pk, hip.p64(words), ctypes.c_size_t(words.shape[0]))
+        pub = np.zeros((max(self.dims["num_public"], 1), 4), dtype=np.uint64)
+        rc = lib().ss_verify(self.pk, hip.p64(words), ctypes.c_size_t(words.shape[0]), hip.p64(pub))
         if rc < 0:
             _check(rc)
+        self.verified_publics = pub[: self.dims["num_public"]] if rc == 0 else None  # what verify() returns in the reference (src/spartan.rs:577)
         return rc
 
     def close(self):

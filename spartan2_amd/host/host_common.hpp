@@ -40,6 +40,10 @@ struct Tr {
   sp_transcript* t = nullptr;
   explicit Tr(sp_ctx* ctx, const char* label) { ck(sp_transcript_new(ctx, (const uint8_t*)label, strlen(label), &t), "transcript_new"); }
   explicit Tr(const sp_transcript* prefix) { ck(sp_transcript_clone(prefix, &t), "transcript_clone"); }
+  struct Adopt {};
+  Tr(sp_transcript* owned, Adopt) : t(owned) {}
+  Tr(const Tr&) = delete;
+  Tr& operator=(const Tr&) = delete;
   ~Tr() { sp_transcript_free(t); }
   void absorb(const char* label, const uint8_t* b, size_t n) { ck(sp_transcript_absorb(t, (const uint8_t*)label, strlen(label), b, n), "absorb"); }
   void absorb_scalars(const char* label, const fe_t* s, size_t n) {  // BE encoding (src/provider/traits.rs:282-286), slices concatenated

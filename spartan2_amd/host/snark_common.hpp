@@ -166,6 +166,9 @@ inline std::vector<fe_t> eq_evals_host(const fe_t* r, size_t ell) {
 // SparsePolynomial::evaluate (src/polys/multilinear.rs:190-207)
 inline fe_t sparse_poly_evaluate(size_t num_vars, const std::vector<fe_t>& Z, const fe_t* r) {
   size_t nvz = log2_ceil(Z.size());
+  // the reference asserts the same relation (SparsePolynomial::evaluate, multilinear.rs:196); an instance with log2(M) == log2_ceil(1 + num_public)
+  // has no room for the (1, X) block beside W
+  if (num_vars < nvz + 1) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "SparsePolynomial::evaluate: too many public values for this many variables");
   std::vector<fe_t> chis = eq_evals_host(r + (num_vars - 1 - nvz), nvz + 1);
   fe_t partial = fe_zero();
   for (size_t i = 0; i < Z.size(); ++i) partial = fe_add<S>(partial, fe_mul<S>(Z[i], chis[i]));

@@ -32,6 +32,14 @@ struct SpartanProverKey {  // src/spartan.rs:30-58
   }
 };
 
+// Per-prep-state driver options (ss_prep_set_flags; defaults from the environment at prep_prove time).
+//   FLAG_PREFIX_CACHE: the transcript prefix new + vk + public_values + comm_W_shared / comm_W_precommitted is the same for every prove on one prep
+//     state; with this flag its sponge state is computed once and cloned (Keccak256Transcript is Clone, keccak.rs:25) — an API-level optimisation
+//     the reference does not make (it re-hashes the prefix in every prove, src/spartan.rs:226-236, r1cs.rs:422-427). Default OFF: the prefix is
+//     re-hashed inside every prove (on a helper thread, under commit_zeros), so the timed region does the reference's work.
+//   FLAG_LZ_DIRECT: the opening in the reference's own order (bind W with L, then the MSM over the key) instead of the MSM over the row commitments.
+enum : unsigned { FLAG_PREFIX_CACHE = 1u, FLAG_LZ_DIRECT = 2u };
+
 struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   sp_table *W = nullptr, *caz = nullptr, *cbz = nullptr, *ccz = nullptr;      // witness + cached partial products
   sp_table *az = nullptr, *bz = nullptr, *cz = nullptr, *z = nullptr;          // scratch reused across prove calls
@@ -41,13 +49,18 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   size_t rows_shared = 0, rows_precommitted = 0;
   std::vector<uint8_t> comm_shared_bytes, comm_pre_bytes;  // transcript encodings (hyrax_pc.rs:714-729)
   bool is_small = true;
-  sp_transcript* tr_prefix = nullptr;  // transcript state after the per-instance prefix (see prove)
+  sp_transcript* tr_prefix = nullptr;  // FLAG_PREFIX_CACHE: transcript state after the per-instance prefix (see prove)
   std::vector<fe_t> tr_publics;
+  sp_transcript* tr_fresh = nullptr;   // default: the prefix re-hashed for this prove by the second helper
+  Background bg2;
+  unsigned flags = 0;
   Background bg;                        // hashes comm_W for the PCS transcript step while the sum-checks run, then starts comm_LZ's MSM
   sp_absorb_state* poly_com = nullptr;  // its result
   sp_points* comm_pts = nullptr;        // comm_W on the device: the bases of comm_LZ's MSM
   ~SpartanPrepSNARK() {
     bg.wait_nothrow();
+    bg2.wait_nothrow();
+    sp_transcript_free(tr_fresh);
     sp_points_free(comm_pts);
     sp_absorb_state_free(poly_com);
     sp_transcript_free(tr_prefix);
@@ -95,6 +108,12 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
     sp_ctx* ctx = pk.ctx;
     const size_t M = pk.num_vars, N = d.num_cons;
     ps->is_small = is_small;
+    {
+      const char* e = getenv("SPARTAN_LZ_DIRECT");
+      if (e && e[0] == '1') ps->flags |= FLAG_LZ_DIRECT;
+      e = getenv("SPARTAN_PREFIX_CACHE");
+      if (e && e[0] == '1') ps->flags |= FLAG_PREFIX_CACHE;
+    }
     // shared_witness / precommitted_witness (bellpepper/r1cs.rs:306-409): each segment starts at its padded offset. The rest
     // segment is filled here as well: without verifier challenges it does not change between proves.
     std::vector<fe_t> W(M, fe_zero());
@@ -172,22 +191,43 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
   lap("commit_zeros_begin");
 
-  // transcript prefix: new + vk + public_values + comm_W_precommitted repeats for every prove on this prep state, so its
-  // hash state is computed once and cloned (Keccak256Transcript is Clone, keccak.rs:25)
-  if (!ps.tr_prefix) {
-    Tr t0(ctx, "SpartanSNARK");
-    t0.absorb("vk", pk.vk_digest, 32);
-    t0.absorb_scalars("public_values", publics.data(), npub);
-    // r1cs_instance_and_witness (bellpepper/r1cs.rs:422-427)
-    if (ps.rows_shared) t0.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
-    if (ps.rows_precommitted) t0.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
-    ps.tr_prefix = t0.t;
-    t0.t = nullptr;
-    ps.tr_publics = publics;
-  } else if (ps.tr_publics.size() != publics.size() || memcmp(ps.tr_publics.data(), publics.data(), publics.size() * sizeof(fe_t)) != 0) {
-    throw Error(SP_ERR_INTERNAL, "public values changed between proves on one prep state");
+  // transcript prefix (src/spartan.rs:226-236, bellpepper/r1cs.rs:422-427): new + vk + public_values + comm_W_shared + comm_W_precommitted — about 300
+  // Keccak blocks at config 2. Re-hashed in every prove, as the reference does, on the second helper thread: nothing needs the transcript before
+  // comm_W_rest is absorbed, i.e. before commit_zeros has come back from the device. FLAG_PREFIX_CACHE keeps the sponge state across proves instead.
+  const bool prefix_cached = (ps.flags & FLAG_PREFIX_CACHE) != 0;
+  if (prefix_cached) {
+    if (!ps.tr_prefix) {
+      Tr t0(ctx, "SpartanSNARK");
+      t0.absorb("vk", pk.vk_digest, 32);
+      t0.absorb_scalars("public_values", publics.data(), npub);
+      if (ps.rows_shared) t0.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
+      if (ps.rows_precommitted) t0.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
+      ps.tr_prefix = t0.t;
+      t0.t = nullptr;
+      ps.tr_publics = publics;
+    } else if (ps.tr_publics.size() != publics.size() || memcmp(ps.tr_publics.data(), publics.data(), publics.size() * sizeof(fe_t)) != 0) {
+      throw Error(SP_ERR_INTERNAL, "public values changed between proves on one prep state");
+    }
+  } else {
+    SpartanPrepSNARK* psp = &ps;
+    const SpartanProverKey* pkp = &pk;
+    const fe_t* pub = publics.data();
+    ps.bg2.submit([ctx, psp, pkp, pub, npub] {
+      sp_transcript_free(psp->tr_fresh);
+      psp->tr_fresh = nullptr;
+      Tr t0(ctx, "SpartanSNARK");
+      t0.absorb("vk", pkp->vk_digest, 32);
+      t0.absorb_scalars("public_values", pub, npub);
+      if (psp->rows_shared) t0.absorb("comm_W_shared", psp->comm_shared_bytes.data(), psp->comm_shared_bytes.size());
+      if (psp->rows_precommitted) t0.absorb("comm_W_precommitted", psp->comm_pre_bytes.data(), psp->comm_pre_bytes.size());
+      psp->tr_fresh = t0.t;
+      t0.t = nullptr;
+    });
   }
-  Tr tr(ps.tr_prefix);
+  struct PrefixJoin {  // publics must outlive the job on every exit path
+    Background& b;
+    ~PrefixJoin() { b.wait_nothrow(); }
+  } prefix_join{ps.bg2};
   lap("transcript_prefix");
 
   // z = [W | 1 | public]   (src/spartan.rs:246-253); the table is 2M long so the inner sum-check can run in place
@@ -234,6 +274,15 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   else if (rows_rest)
     ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)),
        "commit rest");
+  sp_transcript* tr_owned = nullptr;
+  if (prefix_cached) ck(sp_transcript_clone(ps.tr_prefix, &tr_owned), "transcript_clone");
+  else {
+    ps.bg2.wait();
+    tr_owned = ps.tr_fresh;
+    ps.tr_fresh = nullptr;
+    if (!tr_owned) throw Error(SP_ERR_INTERNAL, "transcript prefix was not prepared");
+  }
+  Tr tr(tr_owned, Tr::Adopt{});
   {
     std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
@@ -249,10 +298,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   // The same helper then computes comm_LZ = sum_i L[i] comm_W[i] (= commit(L . W; <L, r_W>), hyrax_pc.rs:430-455, by the homomorphism of the
   // commitment) as soon as the inner sum-check has bound the row variables: the MSM runs under the remaining rounds instead of after them.
   const size_t lz_rows = (M + W_ - 1) / W_, lz_nvr = log2_ceil(lz_rows);
-  const bool lz_direct = [] {  // SPARTAN_LZ_DIRECT=1: the reference's own order (bind W with L first, then MSM over the key); read per call
-    const char* e = getenv("SPARTAN_LZ_DIRECT");
-    return e && e[0] == '1';
-  }();
+  const bool lz_direct = (ps.flags & FLAG_LZ_DIRECT) != 0;  // the reference's own order (bind W with L first, then the MSM over the key)
   struct LzAhead {
     std::atomic<int> state{0};  // 0: row challenges not drawn yet, 1: drawn, 2: abandoned
     size_t nvr = 0;
@@ -316,14 +362,27 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   struct BgJoin {  // comm_W, r_W and lz must outlive the job on every exit path
     Background& b;
     std::atomic<int>&st, &st2;
+    sp_ctx* ctx;
+    sp_msm_job *&j1, *&j2;
+    sp_vec_job*& v1;
     ~BgJoin() {
       int zero = 0;
       st2.compare_exchange_strong(zero, 2);
       zero = 0;
       st.compare_exchange_strong(zero, 2);
       b.wait_nothrow();
+      // an abandoned prove (error exit) still owns whatever the helper had started: finish the jobs to release them
+      uint64_t sink[8];
+      if (j1) sp_msm_job_finish(ctx, j1, sink);
+      if (j2) sp_msm_job_finish(ctx, j2, sink);
+      if (v1) {
+        std::vector<uint64_t> big(4 * 2048);
+        sp_rowmat_vec_eq_finish(ctx, v1, big.data());
+      }
+      j1 = j2 = nullptr;
+      v1 = nullptr;
     }
-  } bg_join{ps.bg, lz.state, lz.delta_state};
+  } bg_join{ps.bg, lz.state, lz.delta_state, ctx, lz.job, lz.delta_job, lz.vec};
   const double t_wit = now_ms();
 
   const size_t num_rounds_x = log2_ceil(N), num_rounds_y = log2_ceil(M) + 1;
@@ -420,6 +479,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     ps.bg.wait();
     if (!lz.job || !lz.vec || !lz.delta_done) throw Error(SP_ERR_INTERNAL, "comm_LZ was not started");
     lz_job = lz.job;
+    lz.job = nullptr;
     r_LZ = lz.r_LZ;
     lap("helper_join");
   } else {
@@ -483,7 +543,11 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t rr = tr.squeeze("r");
   proof.pp(delta);
   proof.pp(beta);
-  if (lz_ahead) ck(sp_rowmat_vec_eq_finish(ctx, lz.vec, u64p(LZ.data())), "bind_with_delayed (finish)");
+  if (lz_ahead) {
+    sp_vec_job* vj = lz.vec;
+    lz.vec = nullptr;
+    ck(sp_rowmat_vec_eq_finish(ctx, vj, u64p(LZ.data())), "bind_with_delayed (finish)");
+  }
   for (size_t i = 0; i < n; ++i) proof.pf(fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]));
   proof.pf(fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta));
   proof.pf(fe_add<S>(fe_mul<S>(rr, blind_eval_W), r_beta));
@@ -545,9 +609,21 @@ static bool sumcheck_verify(Tr& tr, const fe_t& claim, size_t rounds, size_t deg
   return true;
 }
 
-int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords) {
+// every scalar / coordinate of an untrusted proof must be a canonical residue: the reference's deserialisation rejects anything >= the modulus,
+// and x and x + p would otherwise be two encodings of one proof (same transcript bytes, same group elements)
+template <class F>
+static bool limbs_canonical(const fe_t& v) {
+  for (int i = 7; i >= 0; --i) {
+    if (v.v[i] < F::P(i)) return true;
+    if (v.v[i] > F::P(i)) return false;
+  }
+  return false;  // == p
+}
+
+int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uint64_t* out_publics) {
   sp_ctx* ctx = pk.ctx;
   const sp_dims& d = pk.dims;
+  if (d.num_challenges != 0) return 1;  // this driver does not restate circuits with verifier challenges (prep_prove refuses them as well)
   const size_t W_ = DEFAULT_COMMITMENT_WIDTH, N = d.num_cons, M = pk.num_vars;
   const size_t rows_sh = d.num_shared_unpadded ? (d.num_shared + W_ - 1) / W_ : 0, rows_pre = d.num_precommitted_unpadded ? (d.num_precommitted + W_ - 1) / W_ : 0;
   const size_t rows_rest = (d.num_rest + W_ - 1) / W_, rows = rows_sh + rows_pre + rows_rest;
@@ -571,6 +647,14 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords) {
   const fe_t* z_vec = w;
   w += nz;
   const fe_t z_delta = w[0], z_beta = w[1];
+  {
+    const fe_t* all = reinterpret_cast<const fe_t*>(words);
+    const size_t n_el = nwords / 4, p0 = 2 * rows, p1 = p0 + d.num_public + 3 * lx + 3 + 2 * ly + 2;  // [0, p0): comm_W coordinates; [p1, p1 + 4): delta, beta
+    for (size_t i = 0; i < n_el; ++i) {
+      const bool coord = i < p0 || (i >= p1 && i < p1 + 4);
+      if (!(coord ? limbs_canonical<B>(all[i]) : limbs_canonical<S>(all[i]))) return 1;
+    }
+  }
   for (size_t i = 0; i < rows; ++i)
     if (!aff_on_curve(comm_W[i])) return 1;
   if (!aff_on_curve(delta) || !aff_on_curve(beta)) return 1;
@@ -668,7 +752,9 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords) {
   for (size_t i = 0; i < nz; ++i) ip = fe_add<S>(ip, fe_mul<S>(z_vec[i], R[i]));
   const jac_t lhs2 = jac_add(scalar_mul_host(jac_from_affine(comm_eval_W), rr), jac_from_affine(beta));
   const jac_t rhs2 = jac_add(scalar_mul_host(ck_c, ip), scalar_mul_host(h_c, z_beta));
-  return same_point(lhs2, rhs2) ? 0 : 6;
+  if (!same_point(lhs2, rhs2)) return 6;
+  if (out_publics) memcpy(out_publics, publics, d.num_public * sizeof(fe_t));  // verify() returns the public values it accepted (src/spartan.rs:577)
+  return 0;
 }
 
 }  // namespace spartan2
@@ -749,6 +835,9 @@ int ss_prep_prove(void* pk, const uint64_t* witness_u64, size_t n, int is_small,
   }
 }
 void ss_prep_free(void* ps) { delete (SpartanPrepSNARK*)ps; }
+// driver options of one prep state: bit 0 = cache the transcript prefix across proves, bit 1 = opening in the reference's order (see FLAG_*)
+void ss_prep_set_flags(void* ps, unsigned flags) { ((SpartanPrepSNARK*)ps)->flags = flags; }
+unsigned ss_prep_get_flags(void* ps) { return ((SpartanPrepSNARK*)ps)->flags; }
 // comm_W_precommitted rows (affine) and the cached Az/Bz/Cz for parity checks
 int ss_prep_export(void* pk_, void* ps_, uint64_t* comm_rows, uint64_t* caz, uint64_t* cbz, uint64_t* ccz) {
   try {
@@ -765,9 +854,10 @@ int ss_prep_export(void* pk_, void* ps_, uint64_t* comm_rows, uint64_t* caz, uin
   }
 }
 // SpartanSNARK::verify on the device-backed path: 0 = accept, 1..6 = the failed check (see spartan2::verify); < 0 = library error
-int ss_verify(void* pk, const uint64_t* words, size_t nwords) {
+// out_publics (may be NULL): num_public scalars (Montgomery limbs) of the statement that was accepted
+int ss_verify(void* pk, const uint64_t* words, size_t nwords, uint64_t* out_publics) {
   try {
-    return verify(*(SpartanProverKey*)pk, words, nwords);
+    return verify(*(SpartanProverKey*)pk, words, nwords, out_publics);
   } catch (...) {
     return catch_all();
   }
