@@ -61,6 +61,9 @@ int sp_table_from_host(sp_ctx* ctx, const uint64_t* z, size_t len, size_t lo_eff
 int sp_table_zeros(sp_ctx* ctx, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out);
 /* host -> device write of cnt elements at element offset off */
 int sp_table_write(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* z, size_t cnt);
+/* the same without waiting for the copy: the elements (at most 2048) are staged in pinned memory owned by the context, so the caller's buffer is free
+ * on return and the write is ordered on the context's stream like every other table operation */
+int sp_table_write_async(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* z, size_t cnt);
 /* zero cnt elements starting at element offset off (device memset) */
 int sp_table_zero(sp_ctx* ctx, sp_table* t, size_t off, size_t cnt);
 /* device -> device copy */
@@ -103,6 +106,10 @@ void sp_transcript_free(sp_transcript* t);
  * Tables are bound in place down to length 1. out_cpolys: ell x 3 F (compressed polys: c0, c2, c3). */
 int sp_sumcheck_cubic3(sp_ctx* ctx, const uint64_t claim[4], const uint64_t* taus, size_t ell, sp_table* A, sp_table* B, sp_table* C,
                        sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]);
+/* The same prover with the per-pair products of round 1 supplied by sp_multiply_vec_incremental_round0 (p0, p1: N/2 elements each): round 1's
+ * sums are then t0 = sum E(x) p0[x], t_inf = sum E(x) p1[x]. Bit-identical output. */
+int sp_sumcheck_cubic3_round0(sp_ctx* ctx, const uint64_t claim[4], const uint64_t* taus, size_t ell, sp_table* A, sp_table* B, sp_table* C, const sp_table* p0,
+                              const sp_table* p1, sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]);
 /* SumcheckProof::prove_quad (:190-247) with compute_eval_points_quad's eff_pairs bound (:128-174).
  * out_cpolys: rounds x 2 F (c0, c2). */
 /* sp_sumcheck_quad_observed additionally calls observe(user, round, r) right after the challenge of each round (0-based) has been drawn, so the
@@ -112,6 +119,11 @@ int sp_sumcheck_quad_observed(sp_ctx* ctx, const uint64_t claim[4], size_t round
                               void* user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
 int sp_sumcheck_quad(sp_ctx* ctx, const uint64_t claim[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
                      uint64_t* out_r, uint64_t out_final[8]);
+/* EqSumCheckInstance::evaluation_points_zero_check_round0 (src/sumcheck.rs:1163-1271; the round-0 shortcut of the *_zk cubic provers, :595): on a
+ * zero-check (claim 0, A o B = C on the hypercube) t(0) vanishes, so only t_inf = sum E(x) (A1 - A0)(B1 - B0) is computed (C is not read) and the
+ * evaluations (s(0), s(2), s(3)) of the round polynomial are derived from it (derive_from_claim :1276-1324, or the tau = 0 fallback :1244-1268).
+ * out = {eval_0, eval_2, eval_3}; the tables are not modified. */
+int sp_eval_cubic_zero_check_round0(sp_ctx* ctx, const uint64_t* taus, size_t ell, const sp_table* A, const sp_table* B, uint64_t out[12]);
 /* DelayedReduction dot product reduce(sum a_i * b_i) over the first n elements (src/big_num/delayed_reduction.rs:41-84;
  * call sites src/spartan.rs:330-341) */
 int sp_table_dot(sp_ctx* ctx, const sp_table* a, const sp_table* b, size_t n, uint64_t out[4]);
@@ -142,11 +154,23 @@ typedef struct sp_dims {
  * src/r1cs/sparse.rs:49-134), build the filtered COO (:305-358) and the column-major copy used by poly_ABC. */
 int sp_shape_from_csr(sp_ctx* ctx, const sp_csr* A, const sp_csr* B, const sp_csr* C, const sp_dims* dims, sp_shape** out);
 void sp_shape_free(sp_shape* s);
+/* entry counts of the precomputed structures: out = {nnz A, B, C (multiply_vec / poly_ABC), filtered nnz A, B, C (multiply_vec_incremental_into),
+ * long columns, short columns} — the algorithmic-byte accounting of SURVEY.md 8(d) needs them */
+int sp_shape_info(const sp_shape* s, uint64_t out[8]);
 /* SplitR1CSShape::multiply_vec (:1075-1107). z has num_vars + 1 + num_public + num_challenges elements. */
 int sp_multiply_vec(sp_ctx* ctx, const sp_shape* s, const sp_table* z, sp_table* az, sp_table* bz, sp_table* cz);
+/* SplitR1CSShape::multiply_vec_batched (:1130-1166 -> PrecomputedSparseMatrix::multiply_vec_batched, sparse.rs:237-302): the three products for
+ * `count` vectors z_k; az / bz / cz are arrays of `count` output tables */
+int sp_multiply_vec_batched(sp_ctx* ctx, const sp_shape* s, const sp_table* const* zs, size_t count, sp_table* const* az, sp_table* const* bz, sp_table* const* cz);
 /* SplitR1CSShape::multiply_vec_incremental_into (:1170-1211) */
 int sp_multiply_vec_incremental(sp_ctx* ctx, const sp_shape* s, const sp_table* z, const sp_table* caz, const sp_table* cbz, const sp_table* ccz,
                                 sp_table* az, sp_table* bz, sp_table* cz);
+/* multiply_vec_incremental_into (:1170-1211) that also emits the tau-independent halves of the outer sum-check's first evaluation
+ * (evaluation_points_cubic_with_three_inputs, src/sumcheck.rs:1041-1105): p0[i] = Az[i] Bz[i] - Cz[i] and p1[i] = (Az[i + N/2] - Az[i])(Bz[i + N/2] - Bz[i])
+ * for i < N/2, in a second streaming pass queued right behind the product. sp_sumcheck_cubic3_round0 consumes them; the values of every proof element are
+ * unchanged (the weighting by the eq tables, which needs tau, stays in the sum-check). */
+int sp_multiply_vec_incremental_round0(sp_ctx* ctx, const sp_shape* s, const sp_table* z, const sp_table* caz, const sp_table* cbz, const sp_table* ccz,
+                                       sp_table* az, sp_table* bz, sp_table* cz, sp_table* p0, sp_table* p1);
 /* SplitR1CSShape::bind_and_prepare_poly_ABC[_full] (:1235-1321): out[col] = sum_row rx[row] (A + r B + r^2 C)[row,col],
  * written into the first out_len elements of `out` */
 int sp_poly_abc(sp_ctx* ctx, const sp_shape* s, const sp_table* rx, const uint64_t r[4], size_t out_len, sp_table* out);
@@ -161,6 +185,12 @@ int sp_msm_small_u64(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases
  * `rows` base rows of n affine points each (row-major); one affine result per row. FoldingEngineTrait::fold_commitments
  * (hyrax_pc.rs:737-793) is this call on the instances' commitment rows. */
 int sp_msm_shared_weights(sp_ctx* ctx, const uint64_t* weights, size_t n, const uint64_t* bases_rows_aff, size_t rows, uint64_t* out_rows_aff);
+/* vartime_scalar_mul (src/provider/msm.rs:779-867, width-5 wNAF) of n points by ONE scalar: out[i] = scalar * points[i]. The call site is the
+ * two-term fold with a unit weight (hyrax_pc.rs:757-776): see sp_fold_commitments2. Few points run on the host side of the library (a dependent
+ * chain of ~300 group operations: one CPU core finishes it 40x sooner than one GPU lane), many on the device, one lane per point. */
+int sp_vartime_scalar_mul(sp_ctx* ctx, const uint64_t* points_aff, size_t n, const uint64_t scalar[4], uint64_t* out_aff);
+/* FoldingEngineTrait::fold_commitments for two commitments with weights (1, w) (hyrax_pc.rs:757-776): out[i] = p[i] + w * q[i] per row */
+int sp_fold_commitments2(sp_ctx* ctx, const uint64_t* p_rows_aff, const uint64_t* q_rows_aff, size_t rows, const uint64_t w[4], uint64_t* out_rows_aff);
 /* sum of n affine points (host side of the library; the combine step of a point-range-sharded MSM: RCCL has no EC-add reduction,
  * so ranks all-gather their partial points and add them locally — SURVEY.md 8(e)) */
 int sp_point_sum(const uint64_t* points_aff, size_t n, uint64_t out_aff[8]);
@@ -175,6 +205,8 @@ void sp_ck_free(sp_ck* ck);
 int sp_hyrax_commit(sp_ctx* ctx, const sp_ck* ck, const sp_table* v, size_t off, size_t n, const uint64_t* blinds, int is_small, uint64_t* out_rows_aff);
 /* PCS::commit_zeros (:305-319) and the per-row h * blind of rerandomize (:321-344): FixedBaseMul::mul (msm.rs:691-725) */
 int sp_fixed_base_mul_h(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t* out_aff);
+/* PCS::rerandomize_commitment (hyrax_pc.rs:321-344): out[i] = comm[i] + h * (r_new[i] - r_old[i]) (FixedBaseMul::mul per row) */
+int sp_hyrax_rerandomize(sp_ctx* ctx, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const uint64_t* r_old, const uint64_t* r_new, uint64_t* out_rows_aff);
 /* asynchronous form: begin() enqueues upload + kernel + download and returns, finish() waits and normalises */
 typedef struct sp_fb_job sp_fb_job;
 int sp_fixed_base_mul_h_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_fb_job** job);

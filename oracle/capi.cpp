@@ -459,6 +459,17 @@ int orc_shape_poly_abc(void* s, const uint64_t* rx, const uint64_t* r, size_t ou
   ORC_CATCH
 }
 
+int orc_zero_check_round0(const uint64_t* taus, size_t ell, const uint64_t* A, const uint64_t* B, uint64_t* out3) {
+  ORC_TRY
+  std::vector<Fq> t = load<Fq>(taus, ell);
+  MultilinearPolynomial<Fq> pa(load<Fq>(A, (size_t)1 << ell)), pb(load<Fq>(B, (size_t)1 << ell));
+  EqSumCheckInstance<Fq> eq(t);
+  Fq e0, e2, e3;
+  eq.evaluation_points_zero_check_round0(pa, pb, &e0, &e2, &e3);
+  store(out3, std::vector<Fq>{e0, e2, e3});
+  ORC_CATCH
+}
+
 // ---- Spartan ----------------------------------------------------------------------------------
 void* orc_spartan_setup(void* shape) {
   try {
@@ -508,12 +519,29 @@ int orc_spartan_prep_export(void* ps_, uint64_t* comm_rows, uint64_t* caz, uint6
   if (ccz) store(ccz, ps->cached_cz);
   return 0;
 }
+// synthesize callback of a circuit with verifier challenges: (user, challenges (nch x 4 limbs), nch, out rest witness (num_rest_unpadded x 4 limbs))
+typedef void (*orc_rest_hook)(void* user, const uint64_t* challenges, size_t nch, uint64_t* out_rest);
+void* orc_spartan_prove_hook(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used,
+                             double* seconds, orc_rest_hook hook, void* user);
 void* orc_spartan_prove(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used,
                         double* seconds) {
+  return orc_spartan_prove_hook(pk, ps, publics_u64, npub, tape, tape_blocks, tape_used, seconds, nullptr, nullptr);
+}
+void* orc_spartan_prove_hook(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used,
+                             double* seconds, orc_rest_hook hook, void* user) {
   try {
     Tape t(tape, tape_blocks);
     auto t0 = std::chrono::steady_clock::now();
-    auto* pf = new SpartanProof(spartan_prove(*(SpartanProverKey*)pk, *(SpartanPrep*)ps, from_u64s(publics_u64, npub), t));
+    const size_t nrest = ((SpartanProverKey*)pk)->S.num_rest_unpadded;
+    RestSynth synth;
+    if (hook)
+      synth = [hook, user, nrest](const std::vector<Fq>& ch) {
+        std::vector<uint64_t> raw(4 * ch.size() + 4), out(4 * nrest + 4);
+        for (size_t i = 0; i < ch.size(); ++i) memcpy(&raw[4 * i], ch[i].l, 32);
+        hook(user, raw.data(), ch.size(), out.data());
+        return load<Fq>(out.data(), nrest);
+      };
+    auto* pf = new SpartanProof(spartan_prove(*(SpartanProverKey*)pk, *(SpartanPrep*)ps, from_u64s(publics_u64, npub), t, synth));
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (tape_used) *tape_used = t.pos;
     return pf;
@@ -547,7 +575,7 @@ void* orc_spartan_proof_from_words(void* pk_, const uint64_t* w, size_t nwords) 
     size_t rows_pre = div_ceil(S.num_precommitted, pk->ck.num_cols), rows_rest = div_ceil(S.num_rest, pk->ck.num_cols);
     size_t lx = log2_exact(S.num_cons), ly = log2_exact(S.num_vars()) + 1, nz = pk->ck.num_cols;
     if (S.num_vars() < nz) nz = S.num_vars();
-    size_t expect = 8 * (rows_sh + rows_pre + rows_rest) + 4 * S.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
+    size_t expect = 8 * (rows_sh + rows_pre + rows_rest) + 4 * (S.num_public + S.num_challenges) + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
     if (nwords != expect) throw std::runtime_error("proof_from_words: length mismatch");
     auto* pf = new SpartanProof();
     size_t o = 0;
@@ -557,6 +585,7 @@ void* orc_spartan_proof_from_words(void* pk_, const uint64_t* w, size_t nwords) 
     pf->rows_shared = rows_sh;
     pf->rows_precommitted = rows_pre;
     for (size_t i = 0; i < S.num_public; ++i) pf->public_values.push_back(gf());
+    for (size_t i = 0; i < S.num_challenges; ++i) pf->challenges.push_back(gf());
     for (size_t i = 0; i < lx; ++i) pf->sc_proof_outer.compressed_polys.push_back({gf(), gf(), gf()});
     for (int i = 0; i < 3; ++i) pf->claims_outer[i] = gf();
     for (size_t i = 0; i < ly; ++i) pf->sc_proof_inner.compressed_polys.push_back({gf(), gf()});

@@ -2,9 +2,10 @@
 //
 // Restates the protocol driver src/spartan.rs: setup (:146-173), prep_prove (:176-216),
 // prove (:219-466), verify (:469-578), with the witness staging of src/bellpepper/r1cs.rs
-// (shared_witness :306-357, precommitted_witness :359-409, r1cs_instance_and_witness :411-538) for circuits
-// without verifier challenges: any mix of shared / precommitted / rest variables (the bench circuits are precommitted-only and take the
-// `skip_synthesize` + commit_zeros path :443,:468; the reference's own e2e test circuit, src/spartan.rs:587-651, is rest-only).
+// (shared_witness :306-357, precommitted_witness :359-409, r1cs_instance_and_witness :411-538): any mix of shared / precommitted / rest
+// variables (the bench circuits are precommitted-only and take the `skip_synthesize` + commit_zeros path :443,:468; the reference's own e2e test
+// circuit, src/spartan.rs:587-651, is rest-only), and circuits with verifier challenges (:429-431, :443-461): the challenges are squeezed after
+// the precommitted commitment and the rest of the witness is re-synthesized from them — `circuit.synthesize` is the caller's callback here.
 //
 // Substitution (documented): the verifier-key digest. The reference
 // hashes bincode(vk_ee) || bincode(ck_s) || S.write_bytes() with SHA-256 (src/spartan.rs:73-104,
@@ -15,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <stdexcept>
 #include <vector>
 
@@ -83,7 +85,6 @@ struct SpartanPrep {  // SpartanPrepSNARK, src/spartan.rs:107-124 (+ Precommitte
 // `witness` = unpadded aux assignment, shared | precommitted | rest. Circuits with verifier challenges are not restated.
 inline SpartanPrep spartan_prep_prove(const SpartanProverKey& pk, const std::vector<Fq>& witness, bool is_small, Tape& tape) {
   const SplitR1CSShape<Fq>& S = pk.S;
-  if (S.num_challenges != 0) throw std::runtime_error("oracle restates circuits without verifier challenges only");
   if (witness.size() != S.num_shared_unpadded + S.num_precommitted_unpadded + S.num_rest_unpadded) throw std::runtime_error("InvalidWitnessLength");
   SpartanPrep ps;
   ps.is_small = is_small;
@@ -107,7 +108,7 @@ inline SpartanPrep spartan_prep_prove(const SpartanProverKey& pk, const std::vec
 struct SpartanProof {  // SpartanSNARK, src/spartan.rs:130-138
   HyraxCommitment comm_W;  // shared rows, precommitted rows, rest rows (to_regular_instance, src/r1cs/mod.rs:1535-1550)
   size_t rows_shared = 0, rows_precommitted = 0;
-  std::vector<Fq> public_values;
+  std::vector<Fq> public_values, challenges;  // SplitR1CSInstance (src/r1cs/mod.rs:1423-1437)
   SumcheckProof<Fq> sc_proof_outer, sc_proof_inner;
   Fq claims_outer[3];
   Fq eval_W, blind_eval_W;
@@ -124,6 +125,7 @@ struct SpartanProof {  // SpartanSNARK, src/spartan.rs:130-138
     };
     for (const Affine& a : batch_affine(comm_W)) pp(a);
     for (const Fq& f : public_values) pf(f);
+    for (const Fq& f : challenges) pf(f);
     for (const auto& p : sc_proof_outer.compressed_polys)
       for (const Fq& f : p) pf(f);
     for (int i = 0; i < 3; ++i) pf(claims_outer[i]);
@@ -140,9 +142,16 @@ struct SpartanProof {  // SpartanSNARK, src/spartan.rs:130-138
   }
 };
 
+// circuit.synthesize(.., Some(&challenges)) of a circuit with verifier challenges (bellpepper/r1cs.rs:443-461): challenges -> the unpadded rest
+// segment of the witness (num_rest_unpadded values)
+typedef std::function<std::vector<Fq>(const std::vector<Fq>&)> RestSynth;
+
 // src/spartan.rs:219-466
-inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep& ps, const std::vector<Fq>& public_values, Tape& tape) {
+inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep& ps_in, const std::vector<Fq>& public_values, Tape& tape,
+                                  const RestSynth& synth = RestSynth()) {
   const SplitR1CSShape<Fq>& S = pk.S;
+  SpartanPrep ps_local;
+  const SpartanPrep* psp = &ps_in;
   static const bool trace = getenv("ORACLE_TRACE") != nullptr;  // phase timeline on stderr
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -155,14 +164,26 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   tr.absorb_bytes("vk", pk.vk_digest, 32);
   tr.absorb_scalars("public_values", public_values.data(), public_values.size());
   // r1cs_instance_and_witness (bellpepper/r1cs.rs:411-538)
-  if (!ps.comm_W_shared.empty()) {
-    std::vector<uint8_t> b = commitment_transcript_bytes(ps.comm_W_shared);
+  if (!ps_in.comm_W_shared.empty()) {
+    std::vector<uint8_t> b = commitment_transcript_bytes(ps_in.comm_W_shared);
     tr.absorb_bytes("comm_W_shared", b.data(), b.size());
   }
-  if (!ps.comm_W_precommitted.empty()) {
-    std::vector<uint8_t> b = commitment_transcript_bytes(ps.comm_W_precommitted);
+  if (!ps_in.comm_W_precommitted.empty()) {
+    std::vector<uint8_t> b = commitment_transcript_bytes(ps_in.comm_W_precommitted);
     tr.absorb_bytes("comm_W_precommitted", b.data(), b.size());
   }
+  // challenges (r1cs.rs:429-431) and the re-synthesized rest segment (:443-461)
+  std::vector<Fq> challenges(S.num_challenges);
+  for (auto& c : challenges) c = tr.squeeze<Fq>("challenge");
+  if (S.num_challenges != 0) {
+    if (!synth) throw std::runtime_error("a circuit with verifier challenges needs its synthesize callback");
+    std::vector<Fq> rest = synth(challenges);
+    if (rest.size() != S.num_rest_unpadded) throw std::runtime_error("synthesize returned the wrong number of rest variables");
+    ps_local = ps_in;
+    std::copy(rest.begin(), rest.end(), ps_local.W.begin() + S.num_shared + S.num_precommitted);
+    psp = &ps_local;
+  }
+  const SpartanPrep& ps = *psp;
   HyraxBlind r_W_rest = hyrax_blind(pk.ck, S.num_rest, tape);
   HyraxCommitment comm_W_rest;
   if (S.num_rest_unpadded == 0) {
@@ -185,6 +206,7 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   std::vector<Fq> z = ps.W;
   z.push_back(Fq::one());
   z.insert(z.end(), public_values.begin(), public_values.end());
+  z.insert(z.end(), challenges.begin(), challenges.end());
   size_t num_rounds_x = log2_exact(S.num_cons), num_rounds_y = log2_exact(num_vars) + 1;
 
   std::vector<Fq> tau(num_rounds_x);
@@ -201,6 +223,7 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   proof.rows_shared = ps.comm_W_shared.size();
   proof.rows_precommitted = ps.comm_W_precommitted.size();
   proof.public_values = public_values;
+  proof.challenges = challenges;
   std::vector<Fq> r_x, claims_outer;
   prove_cubic_with_three_inputs(Fq::zero(), tau, pAz, pBz, pCz, tr, &proof.sc_proof_outer, &r_x, &claims_outer);
   for (int i = 0; i < 3; ++i) proof.claims_outer[i] = claims_outer[i];
@@ -254,6 +277,7 @@ inline SpartanProof spartan_prove(const SpartanProverKey& pk, const SpartanPrep&
   std::vector<Fq> X;
   X.push_back(Fq::one());
   X.insert(X.end(), public_values.begin(), public_values.end());
+  X.insert(X.end(), challenges.begin(), challenges.end());  // to_regular_instance: X = public_values ++ challenges (src/r1cs/mod.rs:1546-1549)
   std::vector<Fq> r_y_tail(r_y.begin() + 1, r_y.end());
   Fq eval_X = sparse_poly_evaluate(num_rounds_y - 1, X, r_y_tail);
   Fq denom = Fq::one() - r_y[0];
@@ -291,6 +315,10 @@ inline int spartan_verify(const SpartanProverKey& vk, const SpartanProof& pf) {
       b = commitment_transcript_bytes(pre);
       tr.absorb_bytes("comm_W_precommitted", b.data(), b.size());
     }
+    // challenges are re-derived and must match the instance's (validate, src/r1cs/mod.rs:1516-1526)
+    if (pf.challenges.size() != S.num_challenges) return 1;
+    for (size_t i = 0; i < S.num_challenges; ++i)
+      if (tr.squeeze<Fq>("challenge") != pf.challenges[i]) return 1;
     b = commitment_transcript_bytes(rest);
     tr.absorb_bytes("comm_W_rest", b.data(), b.size());
   }
@@ -312,6 +340,7 @@ inline int spartan_verify(const SpartanProverKey& vk, const SpartanProof& pf) {
   std::vector<Fq> X;
   X.push_back(Fq::one());
   X.insert(X.end(), pf.public_values.begin(), pf.public_values.end());
+  X.insert(X.end(), pf.challenges.begin(), pf.challenges.end());
   std::vector<Fq> r_y_tail(r_y.begin() + 1, r_y.end());
   Fq eval_X = sparse_poly_evaluate(log2_exact(num_vars), X, r_y_tail);
   Fq eval_Z = (Fq::one() - r_y[0]) * pf.eval_W + r_y[0] * eval_X;

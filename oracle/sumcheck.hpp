@@ -179,6 +179,39 @@ struct EqSumCheckInstance {
     *ev3 = s_0 + mid_3.dbl() + mid_3;
     *ev0 = s_0;
   }
+  // evaluation_points_zero_check_round0 (:1163-1271): only t_inf is summed (C is not read), t(0) = 0 and the claim is 0
+  void evaluation_points_zero_check_round0(const MultilinearPolynomial<F>& A, const MultilinearPolynomial<F>& B, F* ev0, F* ev2, F* ev3) const {
+    if (round != 1) throw std::runtime_error("zero-check round-0 skip is only valid at round 0");
+    size_t half_p = A.Z.size() / 2;
+    F tinf = F::zero();
+    if (round < first_half) {
+      const std::vector<F>& el = poly_eq_left[first_half - round];
+      const std::vector<F>& er = poly_eq_right[second_half];
+      for (size_t x_out = 0; x_out < el.size(); ++x_out) {
+        F inner = F::zero();
+        for (size_t x_in = 0; x_in < er.size(); ++x_in) {
+          size_t id = (x_out << second_half) | x_in;
+          inner = inner + er[x_in] * ((A.Z[id + half_p] - A.Z[id]) * (B.Z[id + half_p] - B.Z[id]));
+        }
+        tinf = tinf + el[x_out] * inner;
+      }
+    } else {
+      const std::vector<F>& er = poly_eq_right[init_num_vars - round];
+      for (size_t id = 0; id < half_p; ++id) tinf = tinf + er[id] * ((A.Z[id + half_p] - A.Z[id]) * (B.Z[id + half_p] - B.Z[id]));
+    }
+    F p = eval_eq_left;
+    const Triple& T = eq_tau[round - 1];
+    F l_1_p = (T.eq0 + T.slope) * p;
+    F s_0 = F::zero(), s_1 = F::zero(), s_leading = T.slope * p * tinf, s_m1;
+    if (!l_1_p.is_zero()) {  // derive_from_claim with t_0 = 0, claim = 0
+      F t_1 = s_1 * l_1_p.inv();
+      F t_m1 = tinf.dbl() + F::zero() - t_1;
+      s_m1 = T.eqm1 * p * t_m1;
+    } else {  // :1244-1268
+      s_m1 = T.eqm1 * p * tinf.dbl();
+    }
+    finish(s_0, s_1, s_leading, s_m1, ev0, ev2, ev3);
+  }
   // :1025-1156 + derive_from_claim :1277-1324 + fallback :1327-1396
   void evaluation_points_cubic_with_three_inputs(const MultilinearPolynomial<F>& A, const MultilinearPolynomial<F>& B,
                                                  const MultilinearPolynomial<F>& C, const F& claim, F* ev0, F* ev2, F* ev3) const {

@@ -1,5 +1,7 @@
-"""spartan2_amd — MI355X-native Spartan prover hot path (HIP kernels behind a C ABI).
+"""MI355X-native Spartan2 prover hot path.
 
-Python here is only the loader/harness glue (ctypes over include/spartan_hip.h); the host side
-above the C ABI is C++ (spartan2_amd/csrc/host_*.cpp), as the reference is compiled code.
+  csrc/      HIP kernels (kernels_*.cuh) and the C ABI of include/spartan_hip.h (capi_*.hip) -> lib/libspartan_hip.so
+  host/      C++ protocol drivers above the ABI (spartan_snark.cpp, neutronnova_nifs.cpp, sharded_snark.cpp + comm.hpp) -> lib/libspartan_host.so
+  frontend/  integer R1CS generators for the bench circuits (inputs only)
+  hip.py, host.py, dist.py   ctypes views of the two libraries and the torch.distributed plumbing of the harness
 """

@@ -75,6 +75,7 @@ void* sp_ctx::workspace(int slot, size_t bytes, int lane) {
   return ws_ptr[slot];
 }
 void sp_ctx::drain_stats() {
+  std::lock_guard<std::mutex> l(stats_mu);
   for (auto& kv : stats) {
     for (auto& pr : kv.second.pending) {
       float ms = 0;
@@ -162,6 +163,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   for (int i = 0; i < 2; ++i)
     if (c->h_pinned_lane[i]) hipHostFree(c->h_pinned_lane[i]);
   if (c->h_pinned_fb) hipHostFree(c->h_pinned_fb);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  for (hipEvent_t e : c->stage_ev)
+    if (e) hipEventDestroy(e);
   if (c->fb_ev) hipEventDestroy(c->fb_ev);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -183,6 +187,8 @@ int sp_ctx_stats_filter(sp_ctx* c, const char* only) {
 }
 int sp_ctx_kernel_stats(sp_ctx* c, const char* what, double* ms, uint64_t* launches, uint64_t* alg_bytes) {
   SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream2));
+  if (c->stream3) SP_HIP(hipStreamSynchronize(c->stream3));
   c->drain_stats();
   auto it = c->stats.find(what);
   if (it == c->stats.end()) {
@@ -223,6 +229,22 @@ int sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, size_t
   if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write: range exceeds the table");
   if (cnt) SP_HIP(hipMemcpyAsync(t->d + off, z, cnt * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
   SP_HIP(hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the duration of the call
+  return SP_OK;
+}
+int sp_table_write_async(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, size_t cnt) {
+  if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write_async: range exceeds the table");
+  if (cnt > 2048) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write_async: at most 2048 elements per call");
+  if (cnt == 0) return SP_OK;
+  if (!c->h_stage) {
+    SP_HIP(hipHostMalloc(&c->h_stage, 4 * 65536));
+    for (hipEvent_t& e : c->stage_ev) SP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const unsigned slot = c->stage_next++ & 3u;
+  SP_HIP(hipEventSynchronize(c->stage_ev[slot]));  // the copy that used this slot four writes ago (long finished)
+  void* stage = (char*)c->h_stage + (size_t)slot * 65536;
+  memcpy(stage, z, cnt * sizeof(fe_t));
+  SP_HIP(hipMemcpyAsync(t->d + off, stage, cnt * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  SP_HIP(hipEventRecord(c->stage_ev[slot], c->stream));
   return SP_OK;
 }
 int sp_table_zero(sp_ctx* c, sp_table* t, size_t off, size_t cnt) {
@@ -791,6 +813,76 @@ int sp_eval_cubic_outer_pow(sp_ctx* c, const sp_table* pl, const sp_table* pr, c
   return SP_OK;
 }
 
+// evaluation_points_zero_check_round0 (src/sumcheck.rs:1163-1271)
+int sp_eval_cubic_zero_check_round0(sp_ctx* c, const uint64_t* taus_, size_t ell, const sp_table* A, const sp_table* B, uint64_t out[12]) {
+  const size_t N = (size_t)1 << ell;
+  if (ell == 0 || A->len != N || B->len != N) return fail(SP_ERR_INVALID_INPUT_LENGTH, "zero_check_round0: tables must have 2^ell elements");
+  const size_t first_half = ell / 2, second_half = ell - first_half;
+  const size_t nleft = first_half > 0 ? first_half - 1 : 0;
+  if (nleft > 16 || second_half > 16) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sum-check over more than 2^32 rows");
+  const size_t pyr_left = (size_t)2 << nleft, pyr_right = (size_t)2 << second_half;
+  const size_t chunk = 256 * spk::EVAL_PPT, half = N / 2, blocks = (half + chunk - 1) / chunk;
+  int rc = c->ensure_scratch(blocks * 3 + pyr_left + pyr_right + 64);
+  if (rc) return rc;
+  fe_t* d_part = c->d_scratch;
+  fe_t* d_pl = d_part + blocks * 3;
+  fe_t* d_pr = d_pl + pyr_left;
+  std::vector<fe_t> taus(ell);
+  for (size_t i = 0; i < ell; ++i) taus[i] = load_fe(taus_ + 4 * i);
+  {
+    spk::EqPairArgs ea;
+    for (size_t i = 0; i < nleft; ++i) ea.v[0][i] = taus[1 + i];
+    for (size_t i = 0; i < second_half; ++i) ea.v[1][i] = taus[first_half + i];
+    ea.m[0] = (int)nleft;
+    ea.m[1] = (int)second_half;
+    ea.out[0] = d_pl;
+    ea.out[1] = d_pr;
+    hipLaunchKernelGGL(spk::k_eq_levels_pair, dim3(2), dim3(1024), 0, c->stream, ea);
+  }
+  // round 1 tables (poly_eqs_first_half / poly_eq_right_last_half, :1407-1428)
+  const fe_t *eq_in, *eq_out = nullptr;
+  int sbits, mode;
+  if (1 < first_half) {
+    eq_out = d_pl + spk::eq_level_offset((int)(first_half - 1));
+    eq_in = d_pr + spk::eq_level_offset((int)second_half);
+    sbits = (int)second_half;
+    mode = (((size_t)1 << sbits) >= chunk) ? 1 : 2;
+  } else {
+    eq_in = d_pr + spk::eq_level_offset((int)(ell - 1));
+    sbits = 63;
+    mode = 0;
+  }
+  const unsigned seq = next_seq(c);
+  const dim3 g((unsigned)blocks), b(256);
+  c->timed("eval_cubic", 128ull * half, [&] {
+    if (mode == 0) hipLaunchKernelGGL((spk::k_eval_cubic<0, false, true>), g, b, 0, c->stream, A->d, B->d, (const fe_t*)nullptr, half, eq_in, eq_out, sbits, d_part, c->d_pinned, seq);
+    else if (mode == 1) hipLaunchKernelGGL((spk::k_eval_cubic<1, false, true>), g, b, 0, c->stream, A->d, B->d, (const fe_t*)nullptr, half, eq_in, eq_out, sbits, d_part, c->d_pinned, seq);
+    else hipLaunchKernelGGL((spk::k_eval_cubic<2, false, true>), g, b, 0, c->stream, A->d, B->d, (const fe_t*)nullptr, half, eq_in, eq_out, sbits, d_part, c->d_pinned, seq);
+  });
+  fe_t sums[2];
+  if ((rc = reduce_partials(c, blocks, 2, sums))) return rc;
+  const fe_t tinf = sums[1], one = fe_one<S>(), tau = taus[0];
+  const fe_t eq0 = fe_sub<S>(one, tau), slope = fe_sub<S>(tau, eq0), eqm1 = fe_sub<S>(eq0, slope);
+  // t(0) = 0 and the claim is 0, p = 1: s(0) = s(1) = 0, s_leading = slope * t_inf; t(-1) = 2 t_inf + 2 t(0) - t(1) = 2 t_inf in both branches
+  // (derive_from_claim with tau != 0: t(1) = s(1) / (tau p) = 0; the tau = 0 fallback states it directly, :1244-1268)
+  const fe_t s_0 = fe_zero(), s_1 = fe_zero();
+  const fe_t s_leading = fe_mul<S>(slope, tinf);
+  const fe_t s_m1 = fe_mul<S>(eqm1, fe_dbl<S>(tinf));
+  const fe_t halfc = two_inv();
+  const fe_t c1 = fe_sub<S>(fe_mul<S>(fe_sub<S>(s_1, s_m1), halfc), s_leading);
+  const fe_t c2 = fe_sub<S>(fe_mul<S>(fe_add<S>(s_1, s_m1), halfc), s_0);
+  const fe_t inner_2 = fe_add<S>(c2, fe_dbl<S>(s_leading));
+  const fe_t eval_2 = fe_add<S>(s_0, fe_dbl<S>(fe_add<S>(c1, fe_dbl<S>(inner_2))));
+  const fe_t c3_3 = fe_add<S>(fe_dbl<S>(s_leading), s_leading);
+  const fe_t inner_3 = fe_add<S>(c2, c3_3);
+  const fe_t mid_3 = fe_add<S>(fe_add<S>(c1, fe_dbl<S>(inner_3)), inner_3);
+  const fe_t eval_3 = fe_add<S>(fe_add<S>(s_0, fe_dbl<S>(mid_3)), mid_3);
+  store_fe(out, s_0);
+  store_fe(out + 4, eval_2);
+  store_fe(out + 8, eval_3);
+  return SP_OK;
+}
+
 static bool table_dense(const sp_table* t) { return sp::eff_lo(t) == t->len / 2 && sp::eff_hi(t) == t->len / 2; }
 
 static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
@@ -1122,13 +1214,26 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
   return sp_table_write(c, pow_left, 0, reinterpret_cast<const uint64_t*>(&base_tau), 1);
 }
 
+static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
+                      const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
+                      uint64_t* out_r, uint64_t out_final[12]);
 int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                        uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
   uint64_t claim_io[4], p_io[4];
   memcpy(claim_io, claim_, 32);
   const fe_t one = fe_one<S>();
   store_fe(p_io, one);
-  return sp_sumcheck_cubic3_sharded(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final);
+  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final);
+}
+int sp_sumcheck_cubic3_round0(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, const sp_table* p0,
+                              const sp_table* p1, sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
+  if (!p0 || !p1 || ell == 0 || p0->len != ((size_t)1 << ell) / 2 || p1->len != p0->len)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (round-0 products): product tables must have 2^(ell-1) elements");
+  uint64_t claim_io[4], p_io[4];
+  memcpy(claim_io, claim_, 32);
+  const fe_t one = fe_one<S>();
+  store_fe(p_io, one);
+  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, p0, p1, out_cpolys, out_r, out_final);
 }
 
 // The same rounds on a SLICE of the tables (tables sharded on their last k variables, rank g holds Z[(j << k) | g]): the slice's
@@ -1138,6 +1243,11 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
 int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C,
                                sp_transcript* tr, const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r,
                                uint64_t out_final[12]) {
+  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, scale_, reduce, reduce_user, nullptr, nullptr, out_cpolys, out_r, out_final);
+}
+static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
+                      const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
+                      uint64_t* out_r, uint64_t out_final[12]) {
   const uint64_t* claim_ = claim_io;
   const bool have_scale = scale_ != nullptr;
   const fe_t scale = have_scale ? load_fe(scale_) : fe_one<S>();
@@ -1294,10 +1404,12 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
         const dim3 gs((unsigned)(q / 256));
         const uint64_t bytes = 48ull * A->len * 3;
         fe_t *pa = A->d, *pb = B->d, *pc = C->d;
-        if (e.mode == 0 && ahead) c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<0, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
-        else if (e.mode == 0) c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<0, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
-        else if (ahead) c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<1, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
-        else c->timed_kernel("bind_stream_cubic", bytes, spk::k_bind_eval_cubic_stream<1, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        // tables of 2^23 and more (3 x 256 MiB: past the 256 MiB Infinity Cache) are accounted separately: their GB/s is unambiguously HBM
+        const char* kname = A->len >= ((size_t)1 << 23) ? "bind_stream_cubic_hbm" : "bind_stream_cubic";
+        if (e.mode == 0 && ahead) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<0, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else if (e.mode == 0) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<0, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else if (ahead) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
       }
       // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
       hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
@@ -1324,9 +1436,25 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
   };
   // round 1 sums from a plain evaluation pass; later rounds get theirs from the fused bind+eval of the previous round
   {
-    size_t blocks = 0;
-    c->timed("eval_cubic", 160ull * (A->len / 2), [&] { blocks = launch_eval(1, false); });
-    reduce_partials_launch(c, blocks, 2);
+    const size_t half = A->len / 2;
+    const EqSel e1 = select_eq(1);
+    if (prod0 && prod1 && half % 256 == 0 && (e1.mode == 0 || (e1.mode == 1 && e1.s >= 8))) {
+      // the per-pair products came with the matrix-vector product: weight them with the eq tables (2 x 32 B per pair instead of 5 x 32 B)
+      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
+      const unsigned seq = next_seq(c);
+      const dim3 gs((unsigned)(half / 256)), bs(256);
+      c->timed("eval_cubic", 64ull * half, [&] {
+        if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_products_stream<0>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
+        else hipLaunchKernelGGL((spk::k_eval_products_stream<1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
+      });
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
+                         c->d_pinned, seq);
+      c->pending_slots = 0;
+    } else {
+      size_t blocks = 0;
+      c->timed("eval_cubic", 160ull * (A->len / 2), [&] { blocks = launch_eval(1, false); });
+      reduce_partials_launch(c, blocks, 2);
+    }
   }
   // 1 / tau_k for every round by one inversion (Montgomery's trick); zeros stay zero (those rounds take the three-sum fallback)
   std::vector<fe_t> inv_tau(ell, fe_zero());

@@ -11,37 +11,9 @@
 using sp::fail;
 typedef FqP S;
 
-struct sp_ck {
-  sp_ctx* ctx = nullptr;
-  size_t num_cols = 0;
-  aff_t* d_bases = nullptr;
-  aff_t h;
-  aff_t* d_htable = nullptr;  // 32 * 255 affine multiples of h
-  aff_t* d_cktables = nullptr;  // num_cols <= 64: one 32*255 table per base (hyrax_pc.rs:81-96 ck_tables)
-  std::vector<aff_t> h_tables;  // host copy of all tables (bases..., h): single multiplications are latency-bound -> host
-  size_t n_tables = 0;
-  const aff_t* host_table(size_t t) const { return h_tables.data() + t * 32 * 255; }
-  const aff_t* host_htable() const { return host_table(n_tables - 1); }
-};
+#include "group_common.hpp"
 
 namespace {
-
-struct DevBuf {  // RAII device allocation
-  void* p = nullptr;
-  ~DevBuf() {
-    if (p) hipFree(p);
-  }
-  int alloc(size_t bytes) {
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
-    return SP_OK;
-  }
-  template <class T>
-  T* as() {
-    return (T*)p;
-  }
-};
 
 // Montgomery's trick on the host (DlogGroup::batch_affine, src/provider/traits.rs:194-198)
 void normalize_batch(const std::vector<jac_t>& pts, aff_t* out) {
@@ -98,10 +70,7 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
   jac_t* buckets = (jac_t*)c->workspace(sp_ctx::WS_MSM_BUCKETS, (size_t)windows * spk::MSM_BUCKETS * sizeof(jac_t), lane);
   jac_t* wsum = (jac_t*)c->workspace(sp_ctx::WS_MSM_WSUM, (size_t)windows * sizeof(jac_t), lane);
   if (!order || !start || !buckets || !wsum) return SP_ERR_NO_DEVICE;
-  auto run = [&](const char* what, uint64_t bytes, auto&& f) {
-    if (lane == 0) c->timed(what, bytes, f);
-    else f();
-  };
+  auto run = [&](const char* what, uint64_t bytes, auto&& f) { c->timed_on(st, what, bytes, f); };
   signed char* digits = (signed char*)c->workspace(sp_ctx::WS_MSM_DIGITS, (size_t)windows * n, lane);
   if (!digits) return SP_ERR_NO_DEVICE;
   run("msm_sort", 32ull * n, [&] {
@@ -409,6 +378,7 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
 void sp_ck_free(sp_ck* k) {
   if (!k) return;
   if (k->d_bases) hipFree(k->d_bases);
+  if (k->d_comb) hipFree(k->d_comb);
   if (k->d_cktables) hipFree(k->d_cktables);
   else if (k->d_htable) hipFree(k->d_htable);
   delete k;
@@ -488,7 +458,7 @@ int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalar
       return SP_ERR_NO_DEVICE;
     }
     SP_HIP(hipMemcpyAsync(ds, stage, n * sizeof(fe_t), hipMemcpyHostToDevice, c->stream2));
-    launch_fixed_base_rows(c->stream2, ds, n, ck->d_htable, (size_t)1, dout);
+    c->timed_on(c->stream2, "fixed_base", 32ull * n, [&] { launch_fixed_base_rows(c->stream2, ds, n, ck->d_htable, (size_t)1, dout); });
     SP_HIP(hipMemcpyAsync(c->h_pinned_fb, dout, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream2));
     SP_HIP(hipEventRecord(c->fb_event(), c->stream2));
     job->on_device = true;
@@ -566,7 +536,15 @@ int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, s
     const std::vector<unsigned>& sel = pass == 0 ? full_rows : narrow_rows;
     const int windows = pass == 0 ? spk::MSM_MAX_WINDOWS : 9;
     if (sel.size() > 2) {
-      if ((rc = msm_rows_batched(c, canon, cols, n, sel, windows, ck->d_bases, msm_rows))) return rc;
+      // many rows over the one key: the fixed-base comb table (built once per key) when this commit alone justifies it or it exists already
+      int have = 1;
+      if (ck->d_comb || full_rows.size() + narrow_rows.size() >= sp::comb_min_rows()) {
+        have = sp::comb_ensure(c, ck);
+        if (have < 0) return have;
+      }
+      if (have == 0) rc = sp::comb_rows(c, ck, canon, cols, n, sel, pass == 0 ? 256 : 64, msm_rows);
+      else rc = msm_rows_batched(c, canon, cols, n, sel, windows, ck->d_bases, msm_rows);
+      if (rc) return rc;
     } else {
       for (unsigned r : sel) {
         size_t lo = (size_t)r * cols, len = (lo + cols <= n) ? cols : n - lo;
@@ -580,6 +558,122 @@ int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, s
   std::vector<aff_t> a(rows);
   normalize_batch(msm_rows, a.data());
   memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
+  return SP_OK;
+}
+
+// ---- vartime_scalar_mul / two-term fold / rerandomize ---------------------------------------------------------------------------------------
+// wNAF-5 digits of a canonical scalar, least significant first (msm.rs:796-846)
+static int wnaf5_digits(const fe_t& canon, signed char out[260]) {
+  uint64_t limbs[4];
+  for (int i = 0; i < 4; ++i) limbs[i] = (uint64_t)canon.v[2 * i] | ((uint64_t)canon.v[2 * i + 1] << 32);
+  int len = 0;
+  while (limbs[0] | limbs[1] | limbs[2] | limbs[3]) {
+    int digit = 0;
+    if (limbs[0] & 1) {
+      digit = (int)(limbs[0] & 31);
+      if (digit >= 16) {
+        digit -= 32;
+        uint64_t add = (uint64_t)(-digit), old = limbs[0];
+        limbs[0] += add;
+        if (limbs[0] < old)
+          for (int k = 1; k < 4; ++k)
+            if (++limbs[k] != 0) break;
+      } else {
+        limbs[0] -= (uint64_t)digit;
+      }
+    }
+    out[len++] = (signed char)digit;
+    for (int i = 0; i < 3; ++i) limbs[i] = (limbs[i] >> 1) | (limbs[i + 1] << 63);
+    limbs[3] >>= 1;
+  }
+  return len;
+}
+static jac_t wnaf_mul_host(const aff_t& p, const signed char* d, int len) {
+  jac_t tab[16];
+  tab[0] = jac_from_affine(p);
+  const jac_t dbl = jac_dbl(tab[0]);
+  for (int k = 1; k < 16; ++k) tab[k] = jac_add(tab[k - 1], dbl);
+  jac_t acc = jac_identity();
+  bool started = false;
+  for (int k = len - 1; k >= 0; --k) {
+    if (started) acc = jac_dbl(acc);
+    if (d[k] > 0) {
+      started = true;
+      acc = jac_add(acc, tab[(d[k] - 1) / 2]);
+    } else if (d[k] < 0) {
+      started = true;
+      jac_t q = tab[(-d[k] - 1) / 2];
+      q.y = fe_neg<B>(q.y);
+      acc = jac_add(acc, q);
+    }
+  }
+  return acc;
+}
+static const size_t WNAF_HOST_MAX = 48;  // below this many points the host side finishes sooner than one device lane per point
+static int scalar_mul_rows(sp_ctx* c, const uint64_t* points_aff, size_t n, const uint64_t scalar[4], std::vector<jac_t>& out) {
+  out.assign(n, jac_identity());
+  if (n == 0) return SP_OK;
+  fe_t sc;
+  memcpy(&sc, scalar, 32);
+  spk::WnafArgs w;
+  w.len = wnaf5_digits(fe_to_canonical<S>(sc), w.d);
+  const aff_t* pts = reinterpret_cast<const aff_t*>(points_aff);
+  if (n <= WNAF_HOST_MAX) {
+    for (size_t i = 0; i < n; ++i) out[i] = wnaf_mul_host(pts[i], w.d, w.len);
+    return SP_OK;
+  }
+  DevBuf dp, dout;
+  int rc;
+  if ((rc = dp.alloc(n * sizeof(aff_t))) || (rc = dout.alloc(n * sizeof(jac_t)))) return rc;
+  SP_HIP(hipMemcpyAsync(dp.p, pts, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
+  c->timed("wnaf_rows", 64ull * n, [&] { hipLaunchKernelGGL(spk::k_wnaf_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, dp.as<aff_t>(), n, w, dout.as<jac_t>()); });
+  SP_HIP(hipMemcpyAsync(out.data(), dout.p, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  return SP_OK;
+}
+int sp_vartime_scalar_mul(sp_ctx* c, const uint64_t* points_aff, size_t n, const uint64_t scalar[4], uint64_t* out_aff) {
+  if (n && (!points_aff || !scalar || !out_aff)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_vartime_scalar_mul: null argument");
+  std::vector<jac_t> pts;
+  int rc = scalar_mul_rows(c, points_aff, n, scalar, pts);
+  if (rc) return rc;
+  std::vector<aff_t> a(n);
+  normalize_batch(pts, a.data());
+  if (n) memcpy(out_aff, a.data(), n * sizeof(aff_t));
+  return SP_OK;
+}
+int sp_fold_commitments2(sp_ctx* c, const uint64_t* p_rows_aff, const uint64_t* q_rows_aff, size_t rows, const uint64_t w[4], uint64_t* out_rows_aff) {
+  if (rows && (!p_rows_aff || !q_rows_aff || !w || !out_rows_aff)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fold_commitments2: null argument");
+  std::vector<jac_t> pts;
+  int rc = scalar_mul_rows(c, q_rows_aff, rows, w, pts);
+  if (rc) return rc;
+  const aff_t* p = reinterpret_cast<const aff_t*>(p_rows_aff);
+  for (size_t i = 0; i < rows; ++i) pts[i] = jac_add_mixed(pts[i], p[i]);
+  std::vector<aff_t> a(rows);
+  normalize_batch(pts, a.data());
+  if (rows) memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
+  return SP_OK;
+}
+int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const uint64_t* r_old, const uint64_t* r_new, uint64_t* out_rows_aff) {
+  if (rows && (!comm_rows_aff || !r_old || !r_new || !out_rows_aff)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "rerandomize_commitment: null argument");
+  std::vector<fe_t> diff(rows);
+  for (size_t i = 0; i < rows; ++i) {
+    fe_t a, b;
+    memcpy(&a, r_new + 4 * i, 32);
+    memcpy(&b, r_old + 4 * i, 32);
+    diff[i] = fe_sub<S>(a, b);
+  }
+  std::vector<jac_t> pts(rows);
+  if (rows <= FIXED_BASE_HOST_MAX) {
+    for (size_t i = 0; i < rows; ++i) pts[i] = fixed_base_mul_host(ck->host_htable(), diff[i]);
+  } else {
+    int rc = fixed_base_rows(c, ck->d_htable, 1, reinterpret_cast<const uint64_t*>(diff.data()), rows, pts);
+    if (rc) return rc;
+  }
+  const aff_t* p = reinterpret_cast<const aff_t*>(comm_rows_aff);
+  for (size_t i = 0; i < rows; ++i) pts[i] = jac_add_mixed(pts[i], p[i]);
+  std::vector<aff_t> a(rows);
+  normalize_batch(pts, a.data());
+  if (rows) memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
   return SP_OK;
 }
 
@@ -768,8 +862,10 @@ int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, s
     SP_HIP(hipMemcpyAsync(dL, w.data(), rows * sizeof(fe_t), hipMemcpyHostToDevice, st));
     SP_HIP(hipStreamSynchronize(st));  // w is a local
   }
-  hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly->d, rows, cols, dL, part);
-  hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, splits, cols, dout);
+  c->timed_on(st, "rowmat_vec", 32ull * (rows * cols + rows + cols), [&] {
+    hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly->d, rows, cols, dL, part);
+    hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, splits, cols, dout);
+  });
   SP_HIP(hipMemcpyAsync(c->h_pinned_vec, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, st));
   SP_HIP(hipEventRecord(c->vec_ev, st));
   sp_vec_job* job = new sp_vec_job();

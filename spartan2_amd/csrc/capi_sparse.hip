@@ -55,6 +55,35 @@ __device__ __forceinline__ fe_t gather_major(const SplitDev& m, size_t major, co
   return acc;
 }
 
+// The same sum with FOUR entries in flight: index / code loads first, then the four gathers, then the four accumulations. One lane walking a
+// column otherwise pays two dependent memory latencies (index, then x[index]) per entry, and the column kernels are bound by exactly that chain
+// (k_polyabc_short: 82 us for 5 M entries at config 2, nowhere near a bandwidth limit).
+__device__ __forceinline__ fe_t gather_major_x4(const SplitDev& m, size_t major, const fe_t* __restrict__ x) {
+  fe_t acc = fe_zero();
+  unsigned k = m.sptr[major];
+  const unsigned e = m.sptr[major + 1];
+  for (; k + 4 <= e; k += 4) {
+    const unsigned i0 = m.sidx[k], i1 = m.sidx[k + 1], i2 = m.sidx[k + 2], i3 = m.sidx[k + 3];
+    const int c0 = m.scode[k], c1 = m.scode[k + 1], c2 = m.scode[k + 2], c3 = m.scode[k + 3];
+    const fe_t x0 = x[i0], x1 = x[i1], x2 = x[i2], x3 = x[i3];
+    acc = acc_small(acc, c0, x0);
+    acc = acc_small(acc, c1, x1);
+    acc = acc_small(acc, c2, x2);
+    acc = acc_small(acc, c3, x3);
+  }
+  if (k + 2 <= e) {
+    const unsigned i0 = m.sidx[k], i1 = m.sidx[k + 1];
+    const int c0 = m.scode[k], c1 = m.scode[k + 1];
+    const fe_t x0 = x[i0], x1 = x[i1];
+    acc = acc_small(acc, c0, x0);
+    acc = acc_small(acc, c1, x1);
+    k += 2;
+  }
+  if (k < e) acc = acc_small(acc, m.scode[k], x[m.sidx[k]]);
+  for (unsigned g = m.gptr[major], ge = m.gptr[major + 1]; g < ge; ++g) acc = fe_add<S>(acc, fe_mul<S>(m.gval[g], x[m.gidx[g]]));
+  return acc;
+}
+
 struct Spmv3Args {
   SplitDev m[3];
   const fe_t* base[3];  // cached products to add (nullptr for a plain multiply_vec)
@@ -69,6 +98,20 @@ __global__ void __launch_bounds__(256) k_spmv3(Spmv3Args a, const fe_t* __restri
     fe_t acc = gather_major(m, row, z, 0, 1);
     if (base) acc = fe_add<S>(acc, base[row]);
     out[row] = acc;
+  }
+}
+
+// The tau-independent halves of the outer sum-check's FIRST evaluation (evaluation_points_cubic_with_three_inputs, src/sumcheck.rs:1041-1105), formed
+// right behind the matrix-vector product while both run in the shadow of commit_zeros: P0[i] = A0 B0 - C0, P1[i] = (A1 - A0)(B1 - B0) for the pair
+// (i, i + N/2) the top variable joins (src/polys/multilinear.rs:101). The first evaluation on the critical path then reads 2 x 16 MiB instead of
+// 84 MiB. (A fused form — one thread computing both rows of all three products — was measured: its six row walks per thread cost more than this
+// second streaming pass, 116 us against 50 + 25 us.)
+__global__ void __launch_bounds__(256) k_round0_products(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
+                                                         fe_t* __restrict__ p0, fe_t* __restrict__ p1) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    const fe_t a0 = A[i], a1 = A[i + half], b0 = B[i], b1 = B[i + half], c0 = C[i];
+    p0[i] = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+    p1[i] = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
   }
 }
 
@@ -89,7 +132,7 @@ __global__ void __launch_bounds__(256) k_polyabc_short(PolyAbcArgs a, const fe_t
                                                        fe_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_short; i += (size_t)gridDim.x * blockDim.x) {
     const size_t col = order[i];
-    fe_t sa = gather_major(a.m[0], col, rx, 0, 1), sb = gather_major(a.m[1], col, rx, 0, 1), sc = gather_major(a.m[2], col, rx, 0, 1);
+    fe_t sa = gather_major_x4(a.m[0], col, rx), sb = gather_major_x4(a.m[1], col, rx), sc = gather_major_x4(a.m[2], col, rx);
     out[col] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(a.r, sb)), fe_mul<S>(a.r2, sc));
   }
 }
@@ -327,6 +370,17 @@ void sp_shape_free(sp_shape* s) {
   delete s;
 }
 
+int sp_shape_info(const sp_shape* s, uint64_t out[8]) {
+  if (!s || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_shape_info: null argument");
+  for (int m = 0; m < 3; ++m) {
+    out[m] = s->nnz[m];
+    out[3 + m] = s->nnz_filtered[m];
+  }
+  out[6] = s->n_long_cols;
+  out[7] = s->n_short;
+  return SP_OK;
+}
+
 static int spmv3(sp_ctx* c, const sp_shape* s, const SplitOnDevice* mats, const uint64_t* nnz, const sp_table* z, const sp_table* const* base,
                  sp_table** outs, const char* what) {
   const size_t nrows = s->dims.num_cons;
@@ -353,11 +407,37 @@ int sp_multiply_vec(sp_ctx* c, const sp_shape* s, const sp_table* z, sp_table* a
   sp_table* outs[3] = {az, bz, cz};
   return spmv3(c, s, s->row, s->nnz, z, nullptr, outs, "spmv");
 }
+int sp_multiply_vec_batched(sp_ctx* c, const sp_shape* s, const sp_table* const* zs, size_t count, sp_table* const* az, sp_table* const* bz, sp_table* const* cz) {
+  if (count && (!zs || !az || !bz || !cz)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multiply_vec_batched: null argument");
+  // one launch per vector: the matrices (a few MB of indices) stay in the L2s between launches, which is what the reference's single pass over the
+  // matrix for all vectors buys on a CPU
+  for (size_t k = 0; k < count; ++k) {
+    sp_table* outs[3] = {az[k], bz[k], cz[k]};
+    int rc = spmv3(c, s, s->row, s->nnz, zs[k], nullptr, outs, "spmv");
+    if (rc) return rc;
+  }
+  return SP_OK;
+}
 int sp_multiply_vec_incremental(sp_ctx* c, const sp_shape* s, const sp_table* z, const sp_table* caz, const sp_table* cbz, const sp_table* ccz,
                                 sp_table* az, sp_table* bz, sp_table* cz) {
   sp_table* outs[3] = {az, bz, cz};
   const sp_table* base[3] = {caz, cbz, ccz};
   return spmv3(c, s, s->filtered, s->nnz_filtered, z, base, outs, "spmv_incremental");
+}
+
+int sp_multiply_vec_incremental_round0(sp_ctx* c, const sp_shape* s, const sp_table* z, const sp_table* caz, const sp_table* cbz, const sp_table* ccz, sp_table* az,
+                                       sp_table* bz, sp_table* cz, sp_table* p0, sp_table* p1) {
+  const size_t nrows = s->dims.num_cons, half = nrows / 2;
+  if (nrows < 2) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multiply_vec_incremental_round0: needs at least two rows");
+  if (p0->cap < half || p1->cap < half) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multiply_vec_incremental_round0: product tables too short");
+  int rc = sp_multiply_vec_incremental(c, s, z, caz, cbz, ccz, az, bz, cz);
+  if (rc) return rc;
+  p0->len = p1->len = half;
+  p0->lo_eff = p0->hi_eff = p1->lo_eff = p1->hi_eff = (size_t)-1;
+  size_t blocks = (half + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  c->timed("round0_products", 224ull * half, [&] { hipLaunchKernelGGL(spk::k_round0_products, dim3((unsigned)blocks), dim3(256), 0, c->stream, az->d, bz->d, cz->d, half, p0->d, p1->d); });
+  return SP_OK;
 }
 
 int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t r_[4], size_t out_len, sp_table* out) {

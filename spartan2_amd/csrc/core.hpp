@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -51,6 +52,9 @@ struct sp_ctx {
     if (!fb_ev) hipEventCreateWithFlags(&fb_ev, hipEventDisableTiming);
     return fb_ev;
   }
+  void* h_stage = nullptr;  // pinned staging of sp_table_write_async: STAGE_SLOTS x 64 KiB, reused round-robin behind an event per slot
+  hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned stage_next = 0;
   unsigned pending_slots = 0;  // > 0: the launch in flight delivers per-block sums in that many host slots (kernels_poly.cuh emit_partials)
   unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.cuh publish_result)
   unsigned long long msm_jobs_issued[2] = {0, 0};
@@ -76,21 +80,32 @@ struct sp_ctx {
 
   hipEvent_t get_event();
   int ensure_scratch(size_t elems);
-  // records (start, stop) events around `launch` when timing is enabled
+  std::mutex stats_mu;  // the helper thread instruments the auxiliary streams while the owner instruments the main one
+  // records (start, stop) events around `launch` on stream `st` when timing is enabled
   template <class L>
-  void timed(const char* what, uint64_t alg_bytes, L&& launch) {
+  void timed_on(hipStream_t st, const char* what, uint64_t alg_bytes, L&& launch) {
     if (!timing || (!timing_only.empty() && timing_only != what)) {
       launch();
       return;
     }
-    hipEvent_t a = get_event(), b = get_event();
-    hipEventRecord(a, stream);
+    hipEvent_t a, b;
+    {
+      std::lock_guard<std::mutex> l(stats_mu);
+      a = get_event();
+      b = get_event();
+    }
+    hipEventRecord(a, st);
     launch();
-    hipEventRecord(b, stream);
+    hipEventRecord(b, st);
+    std::lock_guard<std::mutex> l(stats_mu);
     sp::KStat& s = stats[what];
     s.pending.emplace_back(a, b);
     s.launches += 1;
     s.bytes += alg_bytes;
+  }
+  template <class L>
+  void timed(const char* what, uint64_t alg_bytes, L&& launch) {
+    timed_on(stream, what, alg_bytes, launch);
   }
   // one kernel: the events are attached to the dispatch itself (hipExtLaunchKernelGGL), so the pair brackets the kernel's execution and not the
   // launch latency of an idle stream as well — this is what the roofline kernel's duration is measured with
@@ -100,8 +115,14 @@ struct sp_ctx {
       hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
       return;
     }
-    hipEvent_t a = get_event(), b = get_event();
+    hipEvent_t a, b;
+    {
+      std::lock_guard<std::mutex> l(stats_mu);
+      a = get_event();
+      b = get_event();
+    }
     hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, a, b, 0, args...);
+    std::lock_guard<std::mutex> l(stats_mu);
     sp::KStat& s = stats[what];
     s.pending.emplace_back(a, b);
     s.launches += 1;

@@ -1,0 +1,50 @@
+// Shared by the group-side translation units of libspartan_hip.so (capi_group.hip, capi_comb.hip).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "core.hpp"
+#include "curve.cuh"
+
+struct sp_ck {
+  sp_ctx* ctx = nullptr;
+  size_t num_cols = 0;
+  aff_t* d_bases = nullptr;
+  aff_t h;
+  aff_t* d_htable = nullptr;  // 32 * 255 affine multiples of h
+  aff_t* d_cktables = nullptr;  // num_cols <= 64: one 32*255 table per base (hyrax_pc.rs:81-96 ck_tables)
+  std::vector<aff_t> h_tables;  // host copy of all tables (bases..., h): single multiplications are latency-bound -> host
+  size_t n_tables = 0;
+  const aff_t* host_table(size_t t) const { return h_tables.data() + t * 32 * 255; }
+  const aff_t* host_htable() const { return host_table(n_tables - 1); }
+  // fixed-base comb table of the whole key (kernels_msm.cuh k_comb_*), built on first use by a commitment of many non-small rows
+  mutable aff_t* d_comb = nullptr;
+  mutable int comb_c = 0, comb_windows = 0;
+  mutable bool comb_failed = false;
+};
+
+
+struct DevBuf {  // RAII device allocation
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return sp::fail(SP_ERR_NO_DEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return SP_OK;
+  }
+  template <class T>
+  T* as() {
+    return (T*)p;
+  }
+};
+
+
+namespace sp {
+// capi_comb.hip: the fixed-base comb table of a key (built on first use) and row commitments over it
+size_t comb_min_rows();
+int comb_ensure(sp_ctx* c, const sp_ck* ck);  // 0 = table ready, 1 = not available (take the bucket path), < 0 = error
+int comb_rows(sp_ctx* c, const sp_ck* ck, const fe_t* canon, size_t cols, size_t n, const std::vector<unsigned>& sel, int nbits, std::vector<jac_t>& out);
+}  // namespace sp

@@ -517,6 +517,38 @@ __global__ void __launch_bounds__(64) k_msm_horner_rows(const jac_t* __restrict_
   out[row] = acc;
 }
 
+// ---- vartime_scalar_mul (src/provider/msm.rs:779-867): width-5 wNAF, one lane per point, the digits of the ONE scalar by value ---------------
+struct WnafArgs {
+  signed char d[260];
+  int len;
+};
+__global__ void __launch_bounds__(64) k_wnaf_rows(const aff_t* __restrict__ pts, size_t n, WnafArgs w, jac_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const aff_t p = pts[i];
+  // odd multiples P, 3P, ..., 31P (msm.rs:788-794), kept affine-free: Jacobian table in registers/scratch
+  jac_t tab[16];
+  tab[0] = jac_from_affine(p);
+  const jac_t dbl = jac_dbl(tab[0]);
+  for (int k = 1; k < 16; ++k) tab[k] = jac_add(tab[k - 1], dbl);
+  jac_t acc = jac_identity();
+  bool started = false;
+  for (int k = w.len - 1; k >= 0; --k) {
+    if (started) acc = jac_dbl(acc);
+    const int d = w.d[k];
+    if (d > 0) {
+      started = true;
+      acc = jac_add(acc, tab[(d - 1) / 2]);
+    } else if (d < 0) {
+      started = true;
+      jac_t q = tab[(-d - 1) / 2];
+      q.y = fe_neg<B>(q.y);
+      acc = jac_add(acc, q);
+    }
+  }
+  out[i] = acc;
+}
+
 // ---- K14: R1CSWitness::fold_multiple (src/r1cs/mod.rs:570-660): out[j] = sum_i w[i] * Ws[i][j] ---------------------------------
 // The small-value fast path of the reference (skip zeros, add w_i for ones, :615-631) is kept: SHA witnesses are bits.
 __global__ void __launch_bounds__(256) k_fold_tables(const fe_t* const* __restrict__ tables, const fe_t* __restrict__ weights, size_t n, size_t len,

@@ -232,7 +232,8 @@ __global__ void __launch_bounds__(256) k_eq_outer(const fe_t* __restrict__ t_hi,
 // MODE 1: factored — a block's chunk lies inside one x_out, block sum is multiplied by eq_out once
 // MODE 2: direct — per-pair product eq_out * eq_in (tiny tables where a chunk spans several x_out)
 constexpr int EVAL_PPT = 1;  // pairs per thread (1: the kernels are latency-bound per lane; more waves hide it better than more work per lane)
-template <int MODE, bool WITH_M1>
+// ZC: the zero-check round-0 form (evaluation_points_zero_check_round0, src/sumcheck.rs:1163-1271): only t_inf is computed, C is not read, t0 = 0.
+template <int MODE, bool WITH_M1, bool ZC = false>
 __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
                                                     const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
                                                     fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq) {
@@ -248,12 +249,14 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
   for (int k = 0; k < EVAL_PPT; ++k) {
     const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
     if (id < half) {
-      const fe_t a0 = A[id], a1 = A[id + half], b0 = B[id], b1 = B[id + half], c0 = C[id];
+      const fe_t a0 = A[id], a1 = A[id + half], b0 = B[id], b1 = B[id + half], c0 = ZC ? fe_zero() : C[id];
       fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
       if (MODE == 2) w = fe_mul<S>(w, eq_out[id >> s]);
-      const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
       const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
-      acc[0] = fe_add<S>(acc[0], fe_mul<S>(w, t0e));
+      if (!ZC) {
+        const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+        acc[0] = fe_add<S>(acc[0], fe_mul<S>(w, t0e));
+      }
       acc[1] = fe_add<S>(acc[1], fe_mul<S>(w, tie));
       if (WITH_M1) {
         const fe_t c1 = C[id + half];
@@ -272,6 +275,13 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
     emit_partials<NACC>(acc, partials, single_out, seq);
   }
 }
+
+// Round 1 of the cubic sum-check from precomputed per-pair products (k_spmv3_pairs): t0 = sum E(id) P0[id], t_inf = sum E(id) P1[id].
+// Streaming form (lazy wave sums, second stage k_sum_partials_lazy applies eq_out per group): half must be a multiple of 256 and, in factored
+// mode, 2^s >= 256.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __restrict__ P0, const fe_t* __restrict__ P1, const fe_t* __restrict__ eq_in, int s,
+                                                              lazy9_t* __restrict__ partials);
 
 // ---- K1+K2 fused: bind round i with challenge r, evaluate round i+1 on the values just produced ------------------------
 // Tables have length L = 4q before the bind. Thread id in [0, q) owns the new pair (Z'[id], Z'[id+q]):
@@ -397,6 +407,15 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict
   const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
   const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __restrict__ P0, const fe_t* __restrict__ P1, const fe_t* __restrict__ eq_in, int s,
+                                                              lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t p0 = P0[id], p1 = P1[id];
+  const fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, p0))), lazy_wave_sum(lazy_from(fe_mul<S>(w, p1))), partials);
 }
 __global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, lazy9_t* __restrict__ partials,
                                                                MailRef mref) {

@@ -1,6 +1,10 @@
-"""Multi-GPU plumbing: one process per GPU under torch.distributed.run; the path shards by independent units (whole proofs
-at config 2, step instances at the NeutronNova configs) with no data-path collective. torch.distributed is used only for the
-barrier and the max-over-ranks of the timed region ("nccl" = RCCL on the GPUs, "gloo" in the CPU tests)."""
+"""Multi-GPU plumbing for the Python harness: one process per GPU under torch.distributed.run. torch.distributed carries the barrier / max-over-ranks of
+the timed region ("nccl" = RCCL on the GPUs, "gloo" in the CPU tests) and hands the C++ exchange layer its RCCL unique id once.
+
+The DATA-PATH exchanges of the sharded prover (per-round sums of the slice-sharded sum-checks, commitment rows, partial MSM points) do not go
+through this module: they are ncclAllGather calls made from C++ (spartan2_amd/host/comm.hpp, driven by sharded_snark.cpp). The functions below that
+exchange through torch.distributed + numpy (`*_sharded`) are the round-1 prototypes, kept as the gloo-testable reference of the same partitioning
+(tests/test_dist_cpu.py, tests/test_gpu_{nifs,sumcheck,commit}_sharded.py)."""
 import os
 
 import torch

@@ -226,6 +226,18 @@ def sumcheck_cubic3(ctx, claim, taus, A: Table, B: Table, C: Table, tr: Transcri
     return polys, r, fin
 
 
+def sumcheck_cubic3_round0(ctx, claim, taus, A: Table, B: Table, C: Table, p0: Table, p1: Table, tr: Transcript):
+    """sp_sumcheck_cubic3_round0: the cubic prover with round 1's per-pair products supplied (Shape.multiply_vec_incremental_round0)."""
+    taus = np.ascontiguousarray(taus, dtype=np.uint64).reshape(-1, 4)
+    ell = taus.shape[0]
+    polys = np.zeros((ell, 3, 4), dtype=np.uint64)
+    r = np.zeros((ell, 4), dtype=np.uint64)
+    fin = np.zeros((3, 4), dtype=np.uint64)
+    check(lib().sp_sumcheck_cubic3_round0(ctx.h, p64(np.ascontiguousarray(claim, dtype=np.uint64).reshape(4)), p64(taus), ctypes.c_size_t(ell), A.h, B.h, C.h, p0.h, p1.h,
+                                          tr.h, p64(polys), p64(r), p64(fin)))
+    return polys, r, fin
+
+
 def sumcheck_quad(ctx, claim, rounds, A: Table, B: Table, tr: Transcript):
     """SumcheckProof::prove_quad (src/sumcheck.rs:190-247)."""
     claim = np.ascontiguousarray(claim, dtype=np.uint64).reshape(4)
@@ -280,6 +292,31 @@ def msm_small(ctx, scalars_u64, bases):
     return out
 
 
+def vartime_scalar_mul(ctx, points, scalar):
+    """vartime_scalar_mul (src/provider/msm.rs:779-867) of every point by one scalar."""
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros_like(points)
+    check(lib().sp_vartime_scalar_mul(ctx.h, p64(points), ctypes.c_size_t(points.shape[0]), p64(np.ascontiguousarray(scalar, dtype=np.uint64).reshape(4)), p64(out)))
+    return out
+
+
+def fold_commitments2(ctx, p_rows, q_rows, w):
+    """FoldingEngineTrait::fold_commitments for weights (1, w) (hyrax_pc.rs:757-776): p[i] + w * q[i]."""
+    p_rows = np.ascontiguousarray(p_rows, dtype=np.uint64).reshape(-1, 8)
+    q_rows = np.ascontiguousarray(q_rows, dtype=np.uint64).reshape(-1, 8)
+    out = np.zeros_like(p_rows)
+    check(lib().sp_fold_commitments2(ctx.h, p64(p_rows), p64(q_rows), ctypes.c_size_t(p_rows.shape[0]), p64(np.ascontiguousarray(w, dtype=np.uint64).reshape(4)), p64(out)))
+    return out
+
+
+def eval_cubic_zero_check_round0(ctx, taus, A, B):
+    """EqSumCheckInstance::evaluation_points_zero_check_round0 (src/sumcheck.rs:1163-1271) -> (eval_0, eval_2, eval_3)."""
+    taus = np.ascontiguousarray(taus, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((3, 4), dtype=np.uint64)
+    check(lib().sp_eval_cubic_zero_check_round0(ctx.h, p64(taus), ctypes.c_size_t(taus.shape[0]), A.h, B.h, p64(out)))
+    return out
+
+
 def point_sum(points):
     """Sum of affine points (combine step of a point-range-sharded MSM)."""
     points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
@@ -304,6 +341,15 @@ class CommitmentKey:
         blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
         out = np.zeros((rows, 8), dtype=np.uint64)
         check(lib().sp_hyrax_commit(self.ctx.h, self.h, table.h, ctypes.c_size_t(off), ctypes.c_size_t(n), p64(blinds), int(is_small), p64(out)))
+        return out
+
+    def rerandomize(self, comm_rows, r_old, r_new):
+        """PCS::rerandomize_commitment (hyrax_pc.rs:321-344)."""
+        comm_rows = np.ascontiguousarray(comm_rows, dtype=np.uint64).reshape(-1, 8)
+        rows = comm_rows.shape[0]
+        out = np.zeros_like(comm_rows)
+        check(lib().sp_hyrax_rerandomize(self.ctx.h, self.h, p64(comm_rows), ctypes.c_size_t(rows), p64(np.ascontiguousarray(r_old, dtype=np.uint64).reshape(rows, 4)),
+                                         p64(np.ascontiguousarray(r_new, dtype=np.uint64).reshape(rows, 4)), p64(out)))
         return out
 
     def fixed_base_mul_h(self, scalars):
@@ -372,6 +418,15 @@ class Shape:
 
     def multiply_vec(self, z: Table, az: Table, bz: Table, cz: Table):
         check(lib().sp_multiply_vec(self.ctx.h, self.h, z.h, az.h, bz.h, cz.h))
+
+    def multiply_vec_batched(self, zs, azs, bzs, czs):
+        """SplitR1CSShape::multiply_vec_batched (src/r1cs/mod.rs:1130-1166): the three products for every z in zs."""
+        n = len(zs)
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.h for t in ts])
+        check(lib().sp_multiply_vec_batched(self.ctx.h, self.h, arr(zs), ctypes.c_size_t(n), arr(azs), arr(bzs), arr(czs)))
+
+    def multiply_vec_incremental_round0(self, z, caz, cbz, ccz, az, bz, cz, p0, p1):
+        check(lib().sp_multiply_vec_incremental_round0(self.ctx.h, self.h, z.h, caz.h, cbz.h, ccz.h, az.h, bz.h, cz.h, p0.h, p1.h))
 
     def multiply_vec_incremental(self, z, caz, cbz, ccz, az, bz, cz):
         check(lib().sp_multiply_vec_incremental(self.ctx.h, self.h, z.h, caz.h, cbz.h, ccz.h, az.h, bz.h, cz.h))

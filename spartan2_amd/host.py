@@ -74,6 +74,7 @@ def from_label(label: bytes, n: int):
     return out
 
 
+REST_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, hip.c_u64p, ctypes.c_size_t, hip.c_u64p)
 PHASES = ("witness_commit", "matrix_vector_multiply", "outer_sumcheck", "prepare_poly_ABC", "inner_sumcheck", "pcs_prove", "total")
 
 
@@ -92,6 +93,10 @@ class SpartanSNARK:
         self.dims = {k: int(v) for k, v in zip(DIM_NAMES, d)}
         self.vk_digest = dig
         self.ps = None
+        si = (ctypes.c_uint64 * 8)()
+        _check(lib().ss_pk_shape_info(self.pk, si))
+        self.shape_info = {"nnz": [int(si[i]) for i in range(3)], "nnz_filtered": [int(si[3 + i]) for i in range(3)], "long_columns": int(si[6]),
+                           "short_columns": int(si[7])}
 
     def prep_prove(self, tape: np.ndarray, is_small=True):
         used = ctypes.c_size_t(0)
@@ -126,15 +131,33 @@ class SpartanSNARK:
         _check(lib().ss_prep_export(self.pk, self.ps, hip.p64(comm) if rows else None, hip.p64(caz), hip.p64(cbz), hip.p64(ccz)))
         return comm, caz, cbz, ccz
 
-    def prove(self, tape: np.ndarray):
-        """Returns (proof words in the canonical layout, tape blocks used, {phase: ms})."""
+    def prove(self, tape: np.ndarray, synthesize=None):
+        """Returns (proof words in the canonical layout, tape blocks used, {phase: ms}). Circuits with verifier challenges pass
+        synthesize(challenges (k, 4)) -> rest witness (num_rest_unpadded, 4) Montgomery limbs (circuit.synthesize, bellpepper/r1cs.rs:443-461)."""
         n = lib().ss_proof_words(self.pk)
         words = np.zeros(n, dtype=np.uint64)
         used = ctypes.c_size_t(0)
         ms = (ctypes.c_double * 7)()
         pub = np.ascontiguousarray(self.inst.publics, dtype=np.uint64)
-        _check(lib().ss_prove(self.pk, self.ps, hip.p64(pub) if len(pub) else None, ctypes.c_size_t(len(pub)), hip.p8(tape), ctypes.c_size_t(tape.shape[0]),
-                              ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
+        cb = None
+        if synthesize is not None:
+            nrest = self.dims["num_rest_unpadded"]
+
+            def raw(_user, ch_ptr, nch, out_ptr):
+                try:
+                    ch = np.ctypeslib.as_array(ch_ptr, shape=(4 * nch,)).reshape(nch, 4).copy()
+                    rest = np.ascontiguousarray(synthesize(ch), dtype=np.uint64).reshape(nrest, 4)
+                    np.ctypeslib.as_array(out_ptr, shape=(4 * max(nrest, 1),))[: 4 * nrest] = rest.reshape(-1)
+                    return 0
+                except Exception:  # noqa: BLE001
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            cb = REST_HOOK(raw)
+        _check(lib().ss_prove_hook(self.pk, self.ps, hip.p64(pub) if len(pub) else None, ctypes.c_size_t(len(pub)), hip.p8(tape), ctypes.c_size_t(tape.shape[0]),
+                                   ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms, cb, None))
         return words, used.value, dict(zip(PHASES, list(ms)))
 
     def verify(self, words: np.ndarray) -> int:

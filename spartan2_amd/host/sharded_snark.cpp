@@ -15,6 +15,8 @@
 //   * opening (hyrax_pc.rs:387-478, ipa.rs:125-170): L . W BY ROW BLOCK (partial 2048-vectors all-gathered and added), comm_LZ = sum_i L_i comm_W[i]
 //     and delta = <d, ck> BY POINT RANGE (partial points all-gathered and added with the group law: RCCL has no such reduction).
 // Everything that does not scale with the instance (transcript, claims, eq tables of the opening) runs redundantly on every rank.
+#include <unistd.h>
+
 #include "comm.hpp"
 #include "snark_common.hpp"
 
@@ -540,7 +542,17 @@ int ssc_comm_rccl(int device, int rank, int world, const uint8_t id_bytes[128], 
     c->hipck(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking), "comm: stream");
     ncclUniqueId id;
     memcpy(&id, id_bytes, 128);
+    // RCCL prints a version banner on stdout when a communicator is created; stdout belongs to the caller (bench.py prints one JSON line there),
+    // so the banner is sent to stderr
+    fflush(stdout);
+    const int saved_stdout = dup(1);
+    if (saved_stdout >= 0) dup2(2, 1);
     ncclResult_t r = api.CommInitRank(&c->nc, world, id, rank);
+    fflush(stdout);
+    if (saved_stdout >= 0) {
+      dup2(saved_stdout, 1);
+      close(saved_stdout);
+    }
     if (r != ncclSuccess) throw Error(SP_ERR_INTERNAL, std::string("ncclCommInitRank: ") + api.GetErrorString(r));
     *out = c.release();
     return 0;

@@ -44,6 +44,7 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   sp_table *W = nullptr, *caz = nullptr, *cbz = nullptr, *ccz = nullptr;      // witness + cached partial products
   sp_table *az = nullptr, *bz = nullptr, *cz = nullptr, *z = nullptr;          // scratch reused across prove calls
   sp_table *rx = nullptr, *abc = nullptr;
+  sp_table *p0 = nullptr, *p1 = nullptr;  // per-pair products of the outer sum-check's first round (sp_multiply_vec_incremental_round0)
   std::vector<aff_t> comm_W_fixed;  // rows committed at prep time: shared rows, then precommitted rows
   std::vector<fe_t> r_W_fixed;      // their blinds, same order
   size_t rows_shared = 0, rows_precommitted = 0;
@@ -64,7 +65,7 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
     sp_points_free(comm_pts);
     sp_absorb_state_free(poly_com);
     sp_transcript_free(tr_prefix);
-    for (sp_table* t : {W, caz, cbz, ccz, az, bz, cz, z, rx, abc}) sp_table_free(t);
+    for (sp_table* t : {W, caz, cbz, ccz, az, bz, cz, z, rx, abc, p0, p1}) sp_table_free(t);
   }
 };
 
@@ -101,7 +102,6 @@ SpartanProverKey* setup(sp_ctx* ctx, const R1CSIntView& R) {
 // SpartanSNARK::prep_prove (src/spartan.rs:176-216)
 SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness_u64, size_t n_witness, bool is_small, Tape& tape) {
   const sp_dims& d = pk.dims;
-  if (d.num_challenges != 0) throw Error(SP_ERR_INTERNAL, "circuits with verifier challenges are not driven by this host layer");
   if (n_witness != d.num_shared_unpadded + d.num_precommitted_unpadded + d.num_rest_unpadded) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
   auto* ps = new SpartanPrepSNARK();
   try {
@@ -126,7 +126,8 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
     };
     put(0, 0, d.num_shared_unpadded);
     put(d.num_shared, d.num_shared_unpadded, d.num_precommitted_unpadded);
-    put(d.num_shared + d.num_precommitted, d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded);
+    // (with verifier challenges the rest segment is synthesized inside every prove, after the challenges are drawn: bellpepper/r1cs.rs:443-461)
+    if (d.num_challenges == 0) put(d.num_shared + d.num_precommitted, d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded);
     ck(sp_table_from_host(ctx, u64p(W.data()), M, (size_t)-1, (size_t)-1, &ps->W), "upload W");
     const size_t CW = DEFAULT_COMMITMENT_WIDTH;
     ps->rows_shared = d.num_shared_unpadded ? (d.num_shared + CW - 1) / CW : 0;
@@ -151,6 +152,10 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
     for (sp_table** t : {&ps->caz, &ps->cbz, &ps->ccz, &ps->az, &ps->bz, &ps->cz}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc Az");
     ck(sp_multiply_vec(ctx, pk.S, ps->z, ps->caz, ps->cbz, ps->ccz), "multiply_vec_precommitted");
     ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &ps->rx), "alloc rx");
+    if (N >= 2) {
+      ck(sp_table_zeros(ctx, N / 2, (size_t)-1, (size_t)-1, &ps->p0), "alloc round-0 products");
+      ck(sp_table_zeros(ctx, N / 2, (size_t)-1, (size_t)-1, &ps->p1), "alloc round-0 products");
+    }
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->abc), "alloc poly_ABC");
     ck(sp_ctx_synchronize(ctx), "sync");
   } catch (...) {
@@ -163,7 +168,11 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // SpartanSNARK::prove (src/spartan.rs:219-466)
-SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, PhaseTimes* pt) {
+// `synth`: circuit.synthesize(.., Some(&challenges)) for circuits with verifier challenges (bellpepper/r1cs.rs:443-461): receives the challenges and
+// writes the num_rest_unpadded values of the rest segment (Montgomery limbs); non-zero return = SynthesisError
+typedef int (*ss_rest_hook)(void* user, const uint64_t* challenges, size_t num_challenges, uint64_t* out_rest);
+SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, PhaseTimes* pt, ss_rest_hook synth = nullptr,
+                      void* synth_user = nullptr) {
   const sp_dims& d = pk.dims;
   sp_ctx* ctx = pk.ctx;
   const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
@@ -229,8 +238,30 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     ~PrefixJoin() { b.wait_nothrow(); }
   } prefix_join{ps.bg2};
   lap("transcript_prefix");
+  Tr tr(nullptr, Tr::Adopt{});
+  auto acquire_transcript = [&] {
+    if (tr.t) return;
+    if (prefix_cached) ck(sp_transcript_clone(ps.tr_prefix, &tr.t), "transcript_clone");
+    else {
+      ps.bg2.wait();
+      tr.t = ps.tr_fresh;
+      ps.tr_fresh = nullptr;
+      if (!tr.t) throw Error(SP_ERR_INTERNAL, "transcript prefix was not prepared");
+    }
+  };
+  // verifier challenges (bellpepper/r1cs.rs:429-431) and the rest of the witness that depends on them (:443-461): squeezed right after the
+  // precommitted commitment, before anything that needs z
+  std::vector<fe_t> challenges(d.num_challenges);
+  if (d.num_challenges) {
+    if (!synth) throw Error(SP_ERR_INTERNAL, "a circuit with verifier challenges needs its synthesize callback");
+    acquire_transcript();
+    for (auto& c : challenges) c = tr.squeeze("challenge");
+    std::vector<fe_t> rest(d.num_rest_unpadded + 1);
+    if (synth(synth_user, u64p(challenges.data()), challenges.size(), u64p(rest.data())) != 0) throw Error(SP_ERR_INTERNAL, "SynthesisError: the circuit's synthesize callback failed");
+    if (d.num_rest_unpadded) ck(sp_table_write(ctx, ps.W, d.num_shared + d.num_precommitted, u64p(rest.data()), d.num_rest_unpadded), "W rest");
+  }
 
-  // z = [W | 1 | public]   (src/spartan.rs:246-253); the table is 2M long so the inner sum-check can run in place
+  // z = [W | 1 | public | challenges]   (src/spartan.rs:246-253); the table is 2M long so the inner sum-check can run in place
   ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
   ck(sp_table_copy(ctx, ps.z, 0, ps.W, 0, M), "z <- W");
   {
@@ -238,14 +269,17 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     std::vector<fe_t> tail(pk.num_extra);
     tail[0] = fe_one<S>();
     std::copy(publics.begin(), publics.end(), tail.begin() + 1);
-    ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
+    std::copy(challenges.begin(), challenges.end(), tail.begin() + 1 + npub);
+    if (tail.size() <= 2048) ck(sp_table_write_async(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");  // no synchronisation in front of the matrix-vector product
+    else ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
   }
   ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
   lap("z_build");
   // Az, Bz, Cz (src/spartan.rs:271-279) depend only on z: issue the product now so that it runs under the commit_zeros job and the host work
   // below instead of after them (the reference computes it after the commitments; the values are the same)
   const double t_mv0 = now_ms();
-  ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
+  if (ps.p0) ck(sp_multiply_vec_incremental_round0(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz, ps.p0, ps.p1), "multiply_vec_incremental");
+  else ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
   const double t_mv_issue = now_ms() - t_mv0;
 
   // The IPA mask d_vec (ipa.rs:139-145) does not depend on the transcript: draw it now from its tape position (host work that
@@ -274,15 +308,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   else if (rows_rest)
     ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)),
        "commit rest");
-  sp_transcript* tr_owned = nullptr;
-  if (prefix_cached) ck(sp_transcript_clone(ps.tr_prefix, &tr_owned), "transcript_clone");
-  else {
-    ps.bg2.wait();
-    tr_owned = ps.tr_fresh;
-    ps.tr_fresh = nullptr;
-    if (!tr_owned) throw Error(SP_ERR_INTERNAL, "transcript prefix was not prepared");
-  }
-  Tr tr(tr_owned, Tr::Adopt{});
+  acquire_transcript();
   {
     std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
@@ -395,13 +421,19 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   SpartanProofBuf proof;
   for (const aff_t& a : comm_W) proof.pp(a);
   for (const fe_t& f : publics) proof.pf(f);
+  for (const fe_t& f : challenges) proof.pf(f);  // SplitR1CSInstance carries them (src/r1cs/mod.rs:1423-1437)
   // outer sum-check (src/spartan.rs:291-310)
   std::vector<fe_t> outer_polys(3 * num_rounds_x), r_x(num_rounds_x);
   fe_t claims_outer[3];
   const fe_t zero = fe_zero();
-  ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, tr.t, u64p(outer_polys.data()), u64p(r_x.data()),
-                        u64p(claims_outer)),
-     "outer sum-check");
+  if (ps.p0)
+    ck(sp_sumcheck_cubic3_round0(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p1, tr.t, u64p(outer_polys.data()), u64p(r_x.data()),
+                                 u64p(claims_outer)),
+       "outer sum-check");
+  else
+    ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, tr.t, u64p(outer_polys.data()), u64p(r_x.data()),
+                          u64p(claims_outer)),
+       "outer sum-check");
   tr.absorb_scalars("claims_outer", claims_outer, 3);
   for (const fe_t& f : outer_polys) proof.pf(f);
   for (int i = 0; i < 3; ++i) proof.pf(claims_outer[i]);
@@ -447,6 +479,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> X;
   X.push_back(fe_one<S>());
   X.insert(X.end(), publics.begin(), publics.end());
+  X.insert(X.end(), challenges.begin(), challenges.end());  // to_regular_instance: X = public_values ++ challenges (src/r1cs/mod.rs:1546-1549)
   const fe_t eval_X = sparse_poly_evaluate(num_rounds_y - 1, X, r_y.data() + 1);
   const fe_t denom = fe_sub<S>(fe_one<S>(), r_y[0]);
   if (fe_is_zero(denom)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
@@ -623,17 +656,19 @@ static bool limbs_canonical(const fe_t& v) {
 int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uint64_t* out_publics) {
   sp_ctx* ctx = pk.ctx;
   const sp_dims& d = pk.dims;
-  if (d.num_challenges != 0) return 1;  // this driver does not restate circuits with verifier challenges (prep_prove refuses them as well)
+
   const size_t W_ = DEFAULT_COMMITMENT_WIDTH, N = d.num_cons, M = pk.num_vars;
   const size_t rows_sh = d.num_shared_unpadded ? (d.num_shared + W_ - 1) / W_ : 0, rows_pre = d.num_precommitted_unpadded ? (d.num_precommitted + W_ - 1) / W_ : 0;
   const size_t rows_rest = (d.num_rest + W_ - 1) / W_, rows = rows_sh + rows_pre + rows_rest;
   const size_t lx = log2_ceil(N), ly = log2_ceil(M) + 1, nz = M < W_ ? M : W_;
-  if (nwords != 8 * rows + 4 * d.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8) return 1;
+  if (nwords != 8 * rows + 4 * (d.num_public + d.num_challenges) + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8) return 1;
   const fe_t* w = reinterpret_cast<const fe_t*>(words);
   const aff_t* comm_W = reinterpret_cast<const aff_t*>(w);
   w += 2 * rows;
   const fe_t* publics = w;
   w += d.num_public;
+  const fe_t* challenges = w;
+  w += d.num_challenges;
   const fe_t* outer = w;
   w += 3 * lx;
   const fe_t* claims = w;
@@ -649,7 +684,7 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uin
   const fe_t z_delta = w[0], z_beta = w[1];
   {
     const fe_t* all = reinterpret_cast<const fe_t*>(words);
-    const size_t n_el = nwords / 4, p0 = 2 * rows, p1 = p0 + d.num_public + 3 * lx + 3 + 2 * ly + 2;  // [0, p0): comm_W coordinates; [p1, p1 + 4): delta, beta
+    const size_t n_el = nwords / 4, p0 = 2 * rows, p1 = p0 + d.num_public + d.num_challenges + 3 * lx + 3 + 2 * ly + 2;  // [0, p0): comm_W coordinates; [p1, p1 + 4): delta, beta
     for (size_t i = 0; i < n_el; ++i) {
       const bool coord = i < p0 || (i >= p1 && i < p1 + 4);
       if (!(coord ? limbs_canonical<B>(all[i]) : limbs_canonical<S>(all[i]))) return 1;
@@ -668,6 +703,8 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uin
   };
   if (rows_sh) absorb_rows("comm_W_shared", 0, rows_sh);
   if (rows_pre) absorb_rows("comm_W_precommitted", rows_sh, rows_pre);
+  for (size_t i = 0; i < d.num_challenges; ++i)  // validate (src/r1cs/mod.rs:1516-1526): the instance's challenges must be the transcript's
+    if (!fe_eq(tr.squeeze("challenge"), challenges[i])) return 1;
   absorb_rows("comm_W_rest", rows_sh + rows_pre, rows_rest);
   std::vector<fe_t> tau(lx);
   for (auto& t : tau) t = tr.squeeze("t");
@@ -684,9 +721,9 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uin
   const fe_t claim_inner_joint = fe_add<S>(fe_add<S>(claims[0], fe_mul<S>(r, claims[1])), fe_mul<S>(r2, claims[2]));
   fe_t claim_inner_final;
   if (!sumcheck_verify(tr, claim_inner_joint, ly, 2, inner, &claim_inner_final, &r_y)) return 4;
-  std::vector<fe_t> X(1 + d.num_public);
+  std::vector<fe_t> X(1 + d.num_public + d.num_challenges);
   X[0] = one;
-  std::copy(publics, publics + d.num_public, X.begin() + 1);
+  std::copy(publics, publics + d.num_public + d.num_challenges, X.begin() + 1);  // challenges follow the public values in the buffer and in X
   const fe_t eval_X = sparse_poly_evaluate(ly - 1, X, r_y.data() + 1);
   const fe_t eval_Z = fe_add<S>(fe_mul<S>(fe_sub<S>(one, r_y[0]), eval_W), fe_mul<S>(r_y[0], eval_X));
   // A(rx,ry), B(rx,ry), C(rx,ry) = T_x^T (M T_y): one SpMV against T_y, three dot products with T_x
@@ -819,6 +856,7 @@ int ss_setup(sp_ctx* ctx, size_t num_cons, size_t num_shared, size_t num_precomm
   }
 }
 void ss_pk_free(void* pk) { delete (SpartanProverKey*)pk; }
+int ss_pk_shape_info(void* pk_, uint64_t out[8]) { return sp_shape_info(((SpartanProverKey*)pk_)->S, out); }
 void ss_pk_info(void* pk_, uint64_t dims_out[10], uint8_t digest[32]) {
   auto* pk = (SpartanProverKey*)pk_;
   memcpy(dims_out, &pk->dims, sizeof(sp_dims));
@@ -867,16 +905,23 @@ size_t ss_proof_words(void* pk_) {
   const sp_dims& d = pk->dims;
   size_t rows = (d.num_shared_unpadded ? (d.num_shared + 2047) / 2048 : 0) + (d.num_precommitted_unpadded ? (d.num_precommitted + 2047) / 2048 : 0) + (d.num_rest + 2047) / 2048;
   size_t lx = log2_ceil(d.num_cons), ly = log2_ceil(pk->num_vars) + 1, nz = pk->num_vars < 2048 ? pk->num_vars : 2048;
-  return 8 * rows + 4 * d.num_public + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
+  return 8 * rows + 4 * (d.num_public + d.num_challenges) + 12 * lx + 12 + 8 * ly + 8 + 16 + 4 * nz + 8;
 }
 // prove() — writes the proof in the canonical layout; phase_ms[7]: witness_commit, matrix_vector_multiply, outer_sumcheck,
 // prepare_poly_ABC, inner_sumcheck, pcs_prove, total (the reference's span names, src/spartan.rs:267-437)
+int ss_prove_hook(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words,
+                  size_t out_cap, double* phase_ms, ss_rest_hook synth, void* synth_user);
 int ss_prove(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words,
              size_t out_cap, double* phase_ms) {
+  return ss_prove_hook(pk, ps, publics_u64, npub, tape, tape_blocks, tape_used, out_words, out_cap, phase_ms, nullptr, nullptr);
+}
+// the same for circuits with verifier challenges: `synth` is the circuit's synthesize callback (see prove)
+int ss_prove_hook(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words,
+                  size_t out_cap, double* phase_ms, ss_rest_hook synth, void* synth_user) {
   try {
     Tape t{tape, tape_blocks};
     PhaseTimes pt;
-    SpartanProofBuf pf = prove(*(SpartanProverKey*)pk, *(SpartanPrepSNARK*)ps, publics_u64, npub, t, &pt);
+    SpartanProofBuf pf = prove(*(SpartanProverKey*)pk, *(SpartanPrepSNARK*)ps, publics_u64, npub, t, &pt, synth, synth_user);
     if (pf.words.size() > out_cap) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "proof buffer too small");
     memcpy(out_words, pf.words.data(), pf.words.size() * 8);
     if (tape_used) *tape_used = t.pos;

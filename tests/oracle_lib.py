@@ -190,12 +190,23 @@ class OracleSpartan:
         lib().orc_spartan_prep_export(self.ps, p64(comm) if rows else None, p64(caz), p64(cbz), p64(ccz))
         return comm, caz, cbz, ccz
 
-    def prove(self, tape):
+    def prove(self, tape, synthesize=None):
         used = ctypes.c_size_t(0)
         secs = ctypes.c_double(0)
         pub = np.ascontiguousarray(self.inst.publics, dtype=np.uint64)
-        pf = lib().orc_spartan_prove(self.pk, self.ps, p64(pub) if len(pub) else None, ctypes.c_size_t(len(pub)), p8(tape), ctypes.c_size_t(tape.shape[0]),
-                                     ctypes.byref(used), ctypes.byref(secs))
+        cb = None
+        if synthesize is not None:
+            nrest = self.shape.num_rest_unpadded
+
+            def raw(_user, ch_ptr, nch, out_ptr):
+                ch = np.ctypeslib.as_array(ch_ptr, shape=(4 * nch,)).reshape(nch, 4).copy()
+                rest = np.ascontiguousarray(synthesize(ch), dtype=np.uint64).reshape(nrest, 4)
+                np.ctypeslib.as_array(out_ptr, shape=(4 * max(nrest, 1),))[: 4 * nrest] = rest.reshape(-1)
+
+            cb = ctypes.CFUNCTYPE(None, ctypes.c_void_p, c_u64p, ctypes.c_size_t, c_u64p)(raw)
+        lib().orc_spartan_prove_hook.restype = ctypes.c_void_p
+        pf = lib().orc_spartan_prove_hook(self.pk, self.ps, p64(pub) if len(pub) else None, ctypes.c_size_t(len(pub)), p8(tape), ctypes.c_size_t(tape.shape[0]),
+                                          ctypes.byref(used), ctypes.byref(secs), cb, None)
         if not pf:
             raise RuntimeError(lib().orc_last_error().decode())
         pf = ctypes.c_void_p(pf)

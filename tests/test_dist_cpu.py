@@ -240,3 +240,38 @@ def test_gloo_sumcheck_by_table_slice_matches_the_unsharded_oracle(world):
     res = mp_util.run_ranks(_worker_sumcheck, world, timeout=300)
     for r in range(world):
         assert res[r] == (True,) * 7, (r, res[r])
+
+
+# ---- the C++ exchange layer's callback backend (spartan2_amd/host/comm.hpp) over gloo ---------------------------------------------------------
+def _comm_worker(rank, world, port, q):
+    import os
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import numpy as np
+
+    from spartan2_amd import dist as spd, host
+
+    g = spd.Group(backend="gloo")
+    comm = host.Comm(rank, world, "torch")
+    small = np.arange(12, dtype=np.uint64) + 1000 * rank  # a round's three field elements
+    got = comm.allgather(small)
+    ok = all((got[r] == np.arange(12, dtype=np.uint64) + 1000 * r).all() for r in range(world))
+    big = np.full(2048 * 4 + 16, rank + 7, dtype=np.uint64)  # the opening's record: partial L.W + two partial points
+    got = comm.allgather(big)
+    ok = ok and all((got[r] == r + 7).all() for r in range(world))
+    st = comm.stats()
+    q.put((rank, (bool(ok), st["exchanges"], st["bytes_gathered"])))
+    comm.close()
+    g.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cpp_exchange_layer_all_gather_over_gloo(world):
+    import mp_util
+
+    res = mp_util.run_ranks(_comm_worker, world)
+    for r in range(world):
+        assert res[r] == (True, 2, (12 * 8 + (2048 * 4 + 16) * 8) * world)

@@ -31,7 +31,7 @@ for log_n, kind in ((18, "full"), (22, "full"), (20, "bits")):
     t0 = time.perf_counter()
     key.commit(t, 0, n, blinds)
     dt = time.perf_counter() - t0
-    ks = {k: ctx.kernel_stats(k)[0] for k in ("msm_rows_sort", "msm_rows_bucket_sum", "msm_rows_window_reduce", "msm_rows_horner", "msm_binary_rows", "fixed_base")}
+    ks = {k: ctx.kernel_stats(k)[0] for k in ("msm_rows_comb", "msm_rows_sort", "msm_rows_bucket_sum", "msm_rows_window_reduce", "msm_rows_horner", "msm_binary_rows", "fixed_base")}
     ctx.reset_stats(False)
     print(f"commit 2^{log_n} {kind}: {rows} rows, {dt*1e3:.1f} ms, {n/dt/1e6:.1f} M (scalar, base) pairs/s; kernel ms: " + ", ".join(f"{k}={v:.2f}" for k, v in ks.items() if v))
     t.free()
