@@ -11,6 +11,7 @@
 #include "neutronnova.hpp"
 #include "nifs.hpp"
 #include "spartan.hpp"
+#include "neutronnova_zk.hpp"
 
 using namespace oracle;
 
@@ -689,4 +690,126 @@ int orc_prove_cubic_outer_pow_batched(size_t num_rounds, const uint64_t* pow_lef
   ORC_CATCH
 }
 
+
+// ---- NeutronNovaZkSNARK (oracle/neutronnova_zk.hpp) ---------------------------------------------------------------------------------------------
+void* orc_nn_setup(void* shape_step, void* shape_core, size_t num_steps) {
+  try {
+    return nn_setup(*(SplitR1CSShape<Fq>*)shape_step, *(SplitR1CSShape<Fq>*)shape_core, num_steps).release();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void orc_nn_free(void* k) { delete (NNKey*)k; }
+// out: nb, nx, ny, vc rounds, vc total vars, vc num_cons, vc num_cons_unpadded, vc num_public
+void orc_nn_info(void* k, uint64_t out[8]) {
+  auto* pk = (NNKey*)k;
+  uint64_t v[8] = {pk->nb, pk->nx, pk->ny, pk->vc_shape->num_rounds, pk->vc_shape->total_vars(), pk->vc_shape->num_cons, pk->vc_shape->num_cons_unpadded, pk->vc_shape->num_public};
+  memcpy(out, v, sizeof v);
+}
+void orc_nn_digest(void* k, uint8_t out[32]) { memcpy(out, ((NNKey*)k)->vk_digest, 32); }
+// prep_prove + prove. step_wit: n x wit_len u64 (unpadded aux: shared | precommitted), step_pub: n x npub u64; tape_used[0] = blocks used by prep_prove, [1] = by prove
+void* orc_nn_prove(void* k, size_t n, const uint64_t* step_wit, size_t wit_len, const uint64_t* step_pub, size_t npub, const uint64_t* core_wit, const uint64_t* core_pub,
+                   int is_small, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, double* seconds) {
+  try {
+    auto* pk = (NNKey*)k;
+    std::vector<std::vector<Fq>> sw(n), sp(n);
+    for (size_t i = 0; i < n; ++i) {
+      sw[i] = from_u64s(step_wit + i * wit_len, wit_len);
+      sp[i] = from_u64s(step_pub + i * npub, npub);
+    }
+    Tape t(tape, tape_blocks);
+    NNPrep ps = nn_prep_prove(*pk, sw, sp, from_u64s(core_wit, wit_len), from_u64s(core_pub, npub), is_small != 0, t);
+    if (tape_used) tape_used[0] = t.pos;
+    auto t0 = std::chrono::steady_clock::now();
+    auto* pf = new NNProof(nn_prove(*pk, ps, is_small != 0, t));
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (tape_used) tape_used[1] = t.pos - tape_used[0];
+    return pf;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void orc_nn_proof_free(void* pf) { delete (NNProof*)pf; }
+size_t orc_nn_proof_words(void* pf) { return ((NNProof*)pf)->serialize().size(); }
+int orc_nn_proof_serialize(void* pf, uint64_t* out) {
+  std::vector<uint64_t> v = ((NNProof*)pf)->serialize();
+  memcpy(out, v.data(), v.size() * 8);
+  return 0;
+}
+int orc_nn_verify(void* k, void* pf) {
+  try {
+    return nn_verify(*(NNKey*)k, *(NNProof*)pf);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+// rebuild a proof from the canonical flat layout (NNProof::serialize), for the verifier-side tests of device-produced proofs
+void* orc_nn_proof_from_words(void* k, const uint64_t* w, size_t nwords) {
+  try {
+    auto* pk = (NNKey*)k;
+    const SplitR1CSShape<Fq>& S = pk->S_step;
+    const MultiRoundShape& vs = *pk->vc_shape;
+    const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = div_ceil(S.num_shared, CW), rows_pre = div_ceil(S.num_precommitted, CW), rows_rest = div_ceil(S.num_rest, CW);
+    size_t o = 0;
+    auto need = [&](size_t k_) {
+      if (o + k_ > nwords) throw std::runtime_error("nn_proof_from_words: buffer too short");
+    };
+    auto gf = [&]() { need(4); Fq f = Fq::from_raw_mont(w + o); o += 4; return f; };
+    auto gc = [&](size_t rows) {
+      HyraxCommitment c;
+      for (size_t i = 0; i < rows; ++i) {
+        need(8);
+        c.push_back(Jac::from_affine(load_aff(w + o)));
+        o += 8;
+      }
+      return c;
+    };
+    auto* pf = new NNProof();
+    std::unique_ptr<NNProof> guard(pf);
+    pf->comm_W_shared = gc(rows_sh);
+    auto ginst = [&](size_t npub) {
+      NNSplitInstance u;
+      u.comm_pre = gc(rows_pre);
+      u.comm_rest = gc(rows_rest);
+      for (size_t i = 0; i < npub; ++i) u.publics.push_back(gf());
+      return u;
+    };
+    for (size_t i = 0; i < pk->num_steps; ++i) pf->step_instances.push_back(ginst(S.num_public));
+    pf->core_instance = ginst(pk->S_core.num_public);
+    HyraxCommitment db = gc(2);
+    pf->eval_arg.delta = db[0];
+    pf->eval_arg.beta = db[1];
+    for (size_t i = 0; i < CW; ++i) pf->eval_arg.z_vec.push_back(gf());
+    pf->eval_arg.z_delta = gf();
+    pf->eval_arg.z_beta = gf();
+    for (size_t r = 0; r < vs.num_rounds; ++r) pf->U_verifier.comm_w_per_round.push_back(gc(vs.vars_padded[r] / vs.width));
+    for (size_t i = 0; i < vs.num_public; ++i) pf->U_verifier.public_values.push_back(gf());
+    for (size_t r = 0; r < vs.num_rounds; ++r) {
+      std::vector<Fq> c;
+      for (size_t i = 0; i < vs.chals_per_round[r]; ++i) c.push_back(gf());
+      pf->U_verifier.challenges_per_round.push_back(c);
+    }
+    pf->nifs_comm_T = gc(vs.num_cons / vs.width);
+    pf->random_U.comm_W = gc(vs.total_vars() / vs.width);
+    pf->random_U.comm_E = gc(vs.num_cons / vs.width);
+    pf->random_U.u = gf();
+    for (size_t i = 0; i < vs.num_io(); ++i) pf->random_U.X.push_back(gf());
+    const size_t lx = log2_exact(vs.num_cons), ly = log2_exact(next_pow2(vs.total_vars())) + 1;
+    for (size_t i = 0; i < lx; ++i) pf->relaxed.sc_outer.compressed_polys.push_back({gf(), gf(), gf()});
+    for (int i = 0; i < 3; ++i) pf->relaxed.claims_outer[i] = gf();
+    for (size_t i = 0; i < ly; ++i) pf->relaxed.sc_inner.compressed_polys.push_back({gf(), gf()});
+    for (size_t i = 0; i < vs.width; ++i) pf->relaxed.v_W.push_back(gf());
+    pf->relaxed.blind_W = gf();
+    for (size_t i = 0; i < vs.width; ++i) pf->relaxed.v_E.push_back(gf());
+    pf->relaxed.blind_E = gf();
+    if (o != nwords) throw std::runtime_error("nn_proof_from_words: trailing words");
+    return guard.release();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
 }  // extern "C"

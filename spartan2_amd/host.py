@@ -396,3 +396,62 @@ def sharded_commit(ctx: hip.Context, comm: Comm, key: hip.CommitmentKey, table: 
     out = np.zeros((comm.world * rows_local, 8), dtype=np.uint64)
     _check(lib().ssd_commit(ctx.h, comm.h, key.h, table.h, ctypes.c_size_t(n_local), hip.p64(blinds_local), int(is_small), hip.p64(out)))
     return out
+
+
+# ---- NeutronNovaZkSNARK (spartan2_amd/host/neutronnova_zk.cpp) ---------------------------------------------------------------------------------
+NN_PHASES = ("instances", "nifs", "outer_sumcheck", "inner_sumcheck", "verifier_circuit_instance", "pcs_prove", "total")
+
+
+class NeutronNovaZkSNARK:
+    """setup -> prep_prove -> prove (src/neutronnova_zk.rs:1394-2093) for step / core circuits of one padded shape without rest variables or challenges
+    (the bench circuits: benches/sha256_neutronnova.rs). step_insts / core_inst: frontend.R1CSInstanceInt."""
+
+    def __init__(self, ctx: hip.Context, step_insts, core_inst):
+        self.ctx, self.steps, self.core = ctx, step_insts, core_inst
+        a1, k1 = _inst_args(step_insts[0])
+        a2, k2 = _inst_args(core_inst)
+        self.pk = ctypes.c_void_p()
+        _check(lib().nnz_setup(ctx.h, ctypes.c_size_t(len(step_insts)), *a1, *a2, ctypes.byref(self.pk)))
+        info = (ctypes.c_uint64 * 8)()
+        dig = np.zeros(32, dtype=np.uint8)
+        lib().nnz_pk_info(self.pk, info, hip.p8(dig))
+        self.info = dict(zip(("nb", "nx", "ny", "vc_rounds", "vc_vars", "vc_cons", "vc_cons_unpadded", "vc_public"), [int(x) for x in info]))
+        self.vk_digest = dig
+        self.ps = None
+        lib().nnz_proof_words.restype = ctypes.c_size_t
+
+    def prep_prove(self, tape: np.ndarray, is_small=True):
+        sw = np.ascontiguousarray(np.stack([np.asarray(i.witness, dtype=np.uint64) for i in self.steps]))
+        sp = np.ascontiguousarray(np.stack([np.asarray(i.publics, dtype=np.uint64) for i in self.steps]))
+        cw = np.ascontiguousarray(self.core.witness, dtype=np.uint64)
+        cp = np.ascontiguousarray(self.core.publics, dtype=np.uint64)
+        used = ctypes.c_size_t(0)
+        ps = ctypes.c_void_p()
+        _check(lib().nnz_prep_prove(self.pk, ctypes.c_size_t(len(self.steps)), hip.p64(sw), ctypes.c_size_t(sw.shape[1]), hip.p64(sp), ctypes.c_size_t(sp.shape[1]), hip.p64(cw),
+                                    hip.p64(cp), int(is_small), hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used), ctypes.byref(ps)))
+        if self.ps:
+            lib().nnz_prep_free(self.ps)
+        self.ps = ps
+        return used.value
+
+    def prove(self, tape: np.ndarray):
+        n = lib().nnz_proof_words(self.pk)
+        words = np.zeros(n, dtype=np.uint64)
+        used = ctypes.c_size_t(0)
+        ms = (ctypes.c_double * 7)()
+        _check(lib().nnz_prove(self.pk, self.ps, hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
+        return words, used.value, dict(zip(NN_PHASES, list(ms)))
+
+    def close(self):
+        if self.ps:
+            lib().nnz_prep_free(self.ps)
+            self.ps = None
+        if self.pk:
+            lib().nnz_pk_free(self.pk)
+            self.pk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -5,13 +5,11 @@
 // `hook(user, t, coeffs[4 F], r_b out)`; for t == ell_b the coefficients are {T_out, eq_rho_at_rb, 0, 0} and r_b is ignored.
 // Everything that scales with the instances runs on the device: the matrix-vector products into the NIFS layers, the rounds, the witness
 // fold (fold_multiple), the commitment fold (fold_commitments[_partial]).
-#include "host_common.hpp"
+#include "neutronnova_nifs.hpp"
 
 namespace spartan2 {
 
-typedef void (*nn_round_hook)(void* user, size_t t, const uint64_t* coeffs16, uint64_t* r_b);
-
-static void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right) {  // src/neutronnova_zk.rs:56-67
+void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right) {  // src/neutronnova_zk.rs:56-67
   size_t l = 0;
   while ((size_t(1) << l) < n) ++l;
   *ell = l;
@@ -19,15 +17,10 @@ static void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* r
   *right = size_t(1) << (l / 2);
 }
 
-struct NifsOutputs {
-  uint64_t *polys, *r_bs, *E_eq, *tail, *folded_rW, *folded_X, *folded_comm;
-  sp_table *A, *B, *C, *folded_W;
-};
-
 // Us: comm rows (n x rows affine) + X (n x d); Ws: resident witness tables (num_vars each) + blinds (n x rows)
 // Layers Az_b, Bz_b, Cz_b of every (padded) instance and, for small_values, their i64 mirrors: the transcript-independent part that the reference
 // caches in prep_prove (cached_step_matvec / cached_step_i64, src/neutronnova_zk.rs:1520-1600).
-static sp_nifs* nifs_prepare(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, size_t n, const fe_t* X, const sp_table* const* Ws, bool small_values) {
+sp_nifs* nifs_prepare(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, size_t n, const fe_t* X, const sp_table* const* Ws, bool small_values) {
   if (n == 0) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NIFS prepare: no instances");
   const size_t d = dims.num_public, num_vars = dims.num_shared + dims.num_precommitted + dims.num_rest;
   size_t n_padded = 2;
@@ -63,7 +56,7 @@ static sp_nifs* nifs_prepare(sp_ctx* ctx, const sp_shape* shape, const sp_dims& 
   return nifs;
 }
 
-static void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const sp_ck* ckey, size_t n, size_t rows, const aff_t* comms, const fe_t* X,
+void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const sp_ck* ckey, size_t n, size_t rows, const aff_t* comms, const fe_t* X,
                        const sp_table* const* Ws, const fe_t* r_W, bool small_values, sp_nifs* prepared, sp_transcript* tr, nn_round_hook hook, void* user,
                        NifsOutputs& out) {
   if (n == 0) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NIFS prove: no instances");

@@ -1,0 +1,723 @@
+// NeutronNovaZkSNARK::{setup, prep_prove, prove} (src/neutronnova_zk.rs:1394-2093) above the C ABI — SURVEY.md 8(f) rank 1, BASELINE config 3 as a real
+// prove(): rerandomization, the step / core instances, NeutronNovaNIFS::prove with the verifier circuit's `process_round` as its round hook, the batched
+// outer and inner sum-checks (process_round again), the verifier-circuit instance folded with a fresh random relaxed instance (NovaNIFS::prove,
+// src/nifs.rs:34-61 + commit_T, src/r1cs/folds.rs:28-88), RelaxedR1CSSpartanProof::prove (src/spartan_relaxed.rs:98-213) and the folded Hyrax opening.
+// Everything that scales with the step instances runs on the device through include/spartan_hip.h; the verifier-circuit instance (a few hundred
+// constraints, ~1.3 k variables) is host-side algebra except its commitments (sp_hyrax_commit_small / sp_hyrax_commit on the width-32 key) and its
+// two sum-checks (sp_sumcheck_cubic3 / sp_sumcheck_quad).
+// Scope = the bench circuits' class: step and core circuits without rest variables and without verifier challenges (`can_cache_matvec`, :1520).
+// The proof layout is the oracle's NNProof::serialize (oracle/neutronnova_zk.hpp); parity = word-for-word equality on the same inputs and tape.
+#include "neutronnova_nifs.hpp"
+#include "snark_common.hpp"
+#include "verifier_circuit.hpp"
+
+namespace spartan2 {
+
+struct NNZkKey {
+  sp_ctx* ctx = nullptr;
+  sp_shape *S_step = nullptr, *S_core = nullptr;
+  sp_dims dims, dims_core;
+  sp_ck *ck = nullptr, *vc_ck = nullptr;
+  std::vector<aff_t> gens;  // "ck": 2048 bases + h; the width-32 key is its first 32 bases with gens[32] as h (PCS::setup(b"ck", ., 32), src/r1cs/mod.rs:1690-1693)
+  vcirc::Shape vc;
+  size_t nb = 0, nx = 0, ny = 0, num_steps = 0, num_vars = 0;
+  uint8_t vk_digest[32];
+  ~NNZkKey() {
+    sp_shape_free(S_step);
+    sp_shape_free(S_core);
+    sp_ck_free(ck);
+    sp_ck_free(vc_ck);
+  }
+};
+
+struct NNPre {  // PrecommittedState, values only
+  sp_table* W = nullptr;
+  std::vector<aff_t> comm_pre;
+  std::vector<fe_t> r_pre, publics;
+};
+struct NNZkPrep {
+  std::vector<NNPre> steps;
+  NNPre core;
+  std::vector<aff_t> comm_shared;
+  std::vector<fe_t> r_shared;
+  bool is_small = true;
+  ~NNZkPrep() {
+    for (auto& s : steps) sp_table_free(s.W);
+    sp_table_free(core.W);
+  }
+};
+
+static NNZkKey* nn_setup(sp_ctx* ctx, const R1CSIntView& Rs, const R1CSIntView& Rc, size_t num_steps) {
+  auto* pk = new NNZkKey();
+  try {
+    pk->ctx = ctx;
+    pk->num_steps = num_steps;
+    PaddedShape Ps = pad_shape(Rs), Pc = pad_shape(Rc);
+    if (Ps.dims.num_cons != Pc.dims.num_cons || Ps.dims.num_shared != Pc.dims.num_shared || Ps.dims.num_precommitted != Pc.dims.num_precommitted ||
+        Ps.dims.num_rest != Pc.dims.num_rest)
+      throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: step and core shapes must have equal padded dimensions (SplitR1CSShape::equalize is not driven here)");
+    if (Ps.dims.num_rest_unpadded || Ps.dims.num_challenges || Pc.dims.num_rest_unpadded || Pc.dims.num_challenges)
+      throw Error(SP_ERR_INTERNAL, "NeutronNova: step / core circuits with rest variables or verifier challenges are not driven by this layer");
+    pk->dims = Ps.dims;
+    pk->dims_core = Pc.dims;
+    pk->num_vars = Ps.num_vars();
+    auto mk = [&](const PaddedShape& P, sp_shape** out) {
+      sp_csr cs[3];
+      for (int m = 0; m < 3; ++m) cs[m] = sp_csr{u64p(P.data[m].data()), P.idx[m].data(), P.ptr[m].data()};
+      ck(sp_shape_from_csr(ctx, &cs[0], &cs[1], &cs[2], &P.dims, out), "shape_from_csr");
+    };
+    mk(Ps, &pk->S_step);
+    mk(Pc, &pk->S_core);
+    pk->gens = from_label("ck", DEFAULT_COMMITMENT_WIDTH + 1);
+    ck(sp_ck_create(ctx, u64p(&pk->gens[0].x), DEFAULT_COMMITMENT_WIDTH, u64p(&pk->gens[DEFAULT_COMMITMENT_WIDTH].x), &pk->ck), "ck_create");
+    ck(sp_ck_create(ctx, u64p(&pk->gens[0].x), 32, u64p(&pk->gens[32].x), &pk->vc_ck), "vc_ck_create");
+    size_t np = 1;
+    while (np < num_steps) np <<= 1;
+    pk->nb = log2_ceil(np);
+    pk->nx = log2_ceil(Ps.dims.num_cons);
+    pk->ny = log2_ceil(pk->num_vars) + 1;
+    pk->vc = vcirc::Shape::from_circuit(vcirc::Circuit(pk->nb, pk->nx, pk->ny, 32));
+    uint8_t d[96];
+    shape_digest(Ps, d);
+    shape_digest(Pc, d + 32);
+    pk->vc.digest(d + 64);
+    sp::Keccak256State h;
+    h.init();
+    h.update(d, 96);
+    h.finish(pk->vk_digest);
+  } catch (...) {
+    delete pk;
+    throw;
+  }
+  return pk;
+}
+
+static std::vector<fe_t> padded_witness(const sp_dims& d, const uint64_t* w) {
+  std::vector<fe_t> W(d.num_shared + d.num_precommitted + d.num_rest, fe_zero());
+  const fe_t one = fe_one<S>();
+  auto put = [&](size_t dst, size_t src, size_t cnt) {
+    for (size_t i = 0; i < cnt; ++i) {
+      const uint64_t v = w[src + i];
+      W[dst + i] = v == 0 ? fe_zero() : (v == 1 ? one : fe_from_u64<S>(v));
+    }
+  };
+  put(0, 0, d.num_shared_unpadded);
+  put(d.num_shared, d.num_shared_unpadded, d.num_precommitted_unpadded);
+  return W;
+}
+
+// prep_prove (:1477-1603): shared commitment from step 0's witness, one precommitted commitment per step and for the core
+static NNZkPrep* nn_prep_prove(const NNZkKey& pk, size_t n, const uint64_t* step_wit, size_t wit_len, const uint64_t* step_pub, size_t npub, const uint64_t* core_wit,
+                               const uint64_t* core_pub, bool is_small, Tape& tape) {
+  const sp_dims& d = pk.dims;
+  if (n != pk.num_steps || wit_len != d.num_shared_unpadded + d.num_precommitted_unpadded || npub != d.num_public) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
+  auto* ps = new NNZkPrep();
+  try {
+    sp_ctx* ctx = pk.ctx;
+    const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared / CW, rows_pre = d.num_precommitted / CW;
+    ps->is_small = is_small;
+    ps->steps.resize(n);
+    std::vector<fe_t> W0 = padded_witness(d, step_wit);
+    if (d.num_shared_unpadded) {
+      ps->r_shared.resize(rows_sh);
+      for (auto& b : ps->r_shared) b = tape.next();
+      sp_table* t = nullptr;
+      ck(sp_table_from_host(ctx, u64p(W0.data()), d.num_shared, (size_t)-1, (size_t)-1, &t), "upload shared");
+      ps->comm_shared.resize(rows_sh);
+      int rc = sp_hyrax_commit(ctx, pk.ck, t, 0, d.num_shared, u64p(ps->r_shared.data()), is_small ? 1 : 0, u64p(&ps->comm_shared[0].x));
+      sp_table_free(t);
+      ck(rc, "commit shared");
+    }
+    auto precommit = [&](const sp_dims& dd, const uint64_t* wit, const uint64_t* pub, NNPre* p) {
+      std::vector<fe_t> W = padded_witness(dd, wit);
+      std::copy(W0.begin(), W0.begin() + dd.num_shared, W.begin());  // every circuit shares step 0's shared witness (:1485-1488)
+      ck(sp_table_from_host(ctx, u64p(W.data()), W.size(), (size_t)-1, (size_t)-1, &p->W), "upload W");
+      p->publics.resize(dd.num_public);
+      for (size_t i = 0; i < dd.num_public; ++i) p->publics[i] = fe_from_u64<S>(pub[i]);
+      if (dd.num_precommitted_unpadded) {
+        p->r_pre.resize(rows_pre);
+        for (auto& b : p->r_pre) b = tape.next();
+        p->comm_pre.resize(rows_pre);
+        ck(sp_hyrax_commit(ctx, pk.ck, p->W, dd.num_shared, dd.num_precommitted, u64p(p->r_pre.data()), is_small ? 1 : 0, u64p(&p->comm_pre[0].x)), "commit precommitted");
+      }
+    };
+    for (size_t i = 0; i < n; ++i) precommit(d, step_wit + i * wit_len, step_pub + i * npub, &ps->steps[i]);
+    precommit(pk.dims_core, core_wit, core_pub, &ps->core);
+  } catch (...) {
+    delete ps;
+    throw;
+  }
+  return ps;
+}
+
+struct ProofBuf {
+  std::vector<uint64_t> words;
+  void pf(const fe_t& f) { words.insert(words.end(), u64p(&f), u64p(&f) + 4); }
+  void pp(const aff_t& a) {
+    pf(a.x);
+    pf(a.y);
+  }
+  void pc(const std::vector<aff_t>& c) {
+    for (const aff_t& a : c) pp(a);
+  }
+};
+
+static void absorb_instance(Tr& tr, const char* label, const std::vector<aff_t>& comm, const std::vector<fe_t>& X) {  // R1CSInstance bytes (src/r1cs/mod.rs:728-736)
+  std::vector<uint8_t> b = commitment_bytes(comm.data(), comm.size());
+  const size_t off = b.size();
+  b.resize(off + 32 * X.size());
+  for (size_t j = 0; j < X.size(); ++j) sp::fe_to_be_bytes<S>(X[j], b.data() + off + 32 * j);
+  tr.absorb(label, b.data(), b.size());
+}
+static std::vector<fe_t> eq_evals(const fe_t* r, size_t ell) {  // EqPolynomial::evals_from_points (src/polys/eq.rs:59-92), host side for O(sqrt) tables
+  std::vector<fe_t> ev((size_t)1 << ell, fe_zero());
+  ev[0] = fe_one<S>();
+  size_t size = 1;
+  for (size_t k = ell; k-- > 0;) {
+    for (size_t i = 0; i < size; ++i) {
+      const fe_t y = fe_mul<S>(ev[i], r[k]);
+      ev[size + i] = y;
+      ev[i] = fe_sub<S>(ev[i], y);
+    }
+    size *= 2;
+  }
+  return ev;
+}
+// rows of `n` host scalars committed with the width-32 key in one device call (many rows: T, the random instance)
+static std::vector<aff_t> commit_rows32(sp_ctx* ctx, const sp_ck* vc_ck, const std::vector<fe_t>& v, const std::vector<fe_t>& blinds) {
+  sp_table* t = nullptr;
+  ck(sp_table_from_host(ctx, u64p(v.data()), v.size(), (size_t)-1, (size_t)-1, &t), "upload");
+  std::vector<aff_t> out(blinds.size());
+  int rc = sp_hyrax_commit(ctx, vc_ck, t, 0, v.size(), u64p(blinds.data()), 0, u64p(&out[0].x));
+  sp_table_free(t);
+  ck(rc, "commit (width 32)");
+  return out;
+}
+// prove_direct (hyrax_pc.rs:609-652) on host vectors
+static void prove_direct(size_t num_cols, const std::vector<fe_t>& poly, const std::vector<fe_t>& blind, const fe_t* point, size_t npoint, std::vector<fe_t>* v, fe_t* cb) {
+  const size_t n = (size_t)1 << npoint, rows = (n + num_cols - 1) / num_cols;
+  if (rows == 1) {
+    *v = poly;
+    v->resize(num_cols, fe_zero());
+    *cb = blind[0];
+    return;
+  }
+  const size_t nvr = log2_ceil(rows);
+  const std::vector<fe_t> L = eq_evals(point, nvr);
+  v->assign(num_cols, fe_zero());
+  for (size_t j = 0; j < L.size(); ++j)
+    for (size_t i = 0; i < num_cols; ++i) {
+      const size_t k = j * num_cols + i;
+      if (k < poly.size()) (*v)[i] = fe_add<S>((*v)[i], fe_mul<S>(L[j], poly[k]));
+    }
+  *cb = fe_zero();
+  for (size_t i = 0; i < blind.size() && i < L.size(); ++i) *cb = fe_add<S>(*cb, fe_mul<S>(L[i], blind[i]));
+}
+
+// prove (:1609-2093)
+static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* phase_ms) {
+  sp_ctx* ctx = pk.ctx;
+  const sp_dims& d = pk.dims;
+  const size_t CW = DEFAULT_COMMITMENT_WIDTH, n = ps.steps.size(), nv = pk.num_vars, N = d.num_cons;
+  const size_t rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0, rows_rest = d.num_rest / CW;
+  const size_t rows = rows_sh + rows_pre + rows_rest, dpub = d.num_public;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  ck(sp_ctx_bind_thread(ctx), "device");
+  // rerandomize (:1619-1627, hyrax_pc.rs:321-344): core (shared, precommitted), then every step's precommitted commitment
+  auto rerand = [&](std::vector<aff_t>& comm, std::vector<fe_t>& r_old) {
+    if (comm.empty()) return;
+    std::vector<fe_t> rn(comm.size());
+    for (auto& b : rn) b = tape.next();
+    std::vector<aff_t> out(comm.size());
+    ck(sp_hyrax_rerandomize(ctx, pk.ck, u64p(&comm[0].x), comm.size(), u64p(r_old.data()), u64p(rn.data()), u64p(&out[0].x)), "rerandomize_commitment");
+    comm = out;
+    r_old = rn;
+  };
+  rerand(ps.comm_shared, ps.r_shared);
+  rerand(ps.core.comm_pre, ps.core.r_pre);
+  for (auto& st : ps.steps) rerand(st.comm_pre, st.r_pre);
+  // instances and witnesses (:1662-1719): rest rows = commit_zeros (h * blind); no challenges for these circuits
+  ProofBuf proof;
+  proof.pc(ps.comm_shared);
+  std::vector<aff_t> comms(n * rows);
+  std::vector<fe_t> X(n * dpub), r_W(n * rows);
+  std::vector<const sp_table*> Ws(n);
+  auto instance = [&](NNPre& p, aff_t* comm_out, fe_t* r_out) {
+    std::vector<fe_t> r_rest(rows_rest);
+    for (auto& b : r_rest) b = tape.next();
+    std::vector<aff_t> c_rest(rows_rest);
+    if (rows_rest) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_rest.data()), rows_rest, u64p(&c_rest[0].x)), "commit_zeros");
+    std::copy(ps.comm_shared.begin(), ps.comm_shared.end(), comm_out);
+    std::copy(p.comm_pre.begin(), p.comm_pre.end(), comm_out + rows_sh);
+    std::copy(c_rest.begin(), c_rest.end(), comm_out + rows_sh + rows_pre);
+    std::copy(ps.r_shared.begin(), ps.r_shared.end(), r_out);
+    std::copy(p.r_pre.begin(), p.r_pre.end(), r_out + rows_sh);
+    std::copy(r_rest.begin(), r_rest.end(), r_out + rows_sh + rows_pre);
+    proof.pc(p.comm_pre);
+    proof.pc(c_rest);
+    for (const fe_t& f : p.publics) proof.pf(f);
+  };
+  for (size_t i = 0; i < n; ++i) {
+    instance(ps.steps[i], &comms[i * rows], &r_W[i * rows]);
+    std::copy(ps.steps[i].publics.begin(), ps.steps[i].publics.end(), X.begin() + i * dpub);
+    Ws[i] = ps.steps[i].W;
+  }
+  std::vector<aff_t> core_comm(rows);
+  std::vector<fe_t> core_rW(rows);
+  instance(ps.core, core_comm.data(), core_rW.data());
+  const double t_inst = now();
+
+  Tr tr(ctx, "neutronnova_prove");
+  tr.absorb("vk", pk.vk_digest, 32);
+  absorb_instance(tr, "core_instance", core_comm, ps.core.publics);
+  vcirc::Circuit vc(pk.nb, pk.nx, pk.ny, 32);
+  vcirc::State vst(pk.vc);
+  struct HookCtx {
+    const NNZkKey* pk;
+    vcirc::Circuit* vc;
+    vcirc::State* st;
+    Tr* tr;
+    Tape* tape;
+    size_t outer_start, inner_start;
+    std::exception_ptr err;
+  } hc{&pk, &vc, &vst, &tr, &tape, pk.nb + 1, pk.nb + 1 + pk.nx + 1, nullptr};
+  // NIFS (:1770-1783): finish_round! = vc.nifs_polys[t] <- coefficients, then process_round (:703-735); once more after the rounds (:1207-1210)
+  auto nifs_hook = [](void* u, size_t t, const uint64_t* co, uint64_t* r_b) {
+    HookCtx* h = (HookCtx*)u;
+    if (h->err) return;
+    try {
+      if (t < h->pk->nb) {
+        for (int q = 0; q < 4; ++q) memcpy(&h->vc->nifs_polys[t][q], co + 4 * q, 32);
+        const fe_t r = vcirc::process_round(h->pk->ctx, *h->st, h->pk->vc, h->pk->vc_ck, *h->vc, t, *h->tr, *h->tape)[0];
+        memcpy(r_b, &r, 32);
+      } else {
+        memcpy(&h->vc->t_out_step, co, 32);
+        memcpy(&h->vc->eq_rho_at_rb, co + 4, 32);
+        vcirc::process_round(h->pk->ctx, *h->st, h->pk->vc, h->pk->vc_ck, *h->vc, t, *h->tr, *h->tape);
+      }
+    } catch (...) {
+      h->err = std::current_exception();
+    }
+  };
+  size_t ell, left, right;
+  compute_tensor_decomp(N, &ell, &left, &right);
+  const size_t nb = pk.nb;
+  std::vector<uint64_t> polys(16 * std::max<size_t>(nb, 1)), r_bs(4 * std::max<size_t>(nb, 1)), E_eq(4 * (left + right)), tail(8), f_rW(4 * rows), f_X(4 * std::max<size_t>(dpub, 1));
+  std::vector<aff_t> f_comm(rows);
+  sp_table *A = nullptr, *B = nullptr, *C = nullptr, *fW = nullptr, *core_abc[3] = {nullptr, nullptr, nullptr}, *zc = nullptr, *pl = nullptr, *pr = nullptr, *rx = nullptr;
+  sp_table *abc_s = nullptr, *abc_c = nullptr, *zs = nullptr, *zcc = nullptr, *Wf = nullptr;
+  struct Free {
+    std::vector<sp_table**> t;
+    ~Free() {
+      for (sp_table** p : t) sp_table_free(*p);
+    }
+  } freer{{&A, &B, &C, &fW, &core_abc[0], &core_abc[1], &core_abc[2], &zc, &pl, &pr, &rx, &abc_s, &abc_c, &zs, &zcc, &Wf}};
+  for (sp_table** t : {&A, &B, &C}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc");
+  ck(sp_table_zeros(ctx, nv, (size_t)-1, (size_t)-1, &fW), "alloc");
+  NifsOutputs no{polys.data(), r_bs.data(), E_eq.data(), tail.data(), f_rW.data(), f_X.data(), (uint64_t*)f_comm.data(), A, B, C, fW};
+  nifs_prove(ctx, pk.S_step, d, pk.ck, n, rows, comms.data(), X.data(), Ws.data(), r_W.data(), true, nullptr, tr.t, nifs_hook, &hc, no);
+  if (hc.err) std::rethrow_exception(hc.err);
+  const double t_nifs = now();
+
+  // core products, batched outer sum-check (:1786-1850)
+  const fe_t one = fe_one<S>();
+  {
+    ck(sp_table_zeros(ctx, nv + 1 + dpub, (size_t)-1, (size_t)-1, &zc), "alloc");
+    ck(sp_table_copy(ctx, zc, 0, ps.core.W, 0, nv), "z <- W");
+    std::vector<fe_t> tl(1 + dpub);
+    tl[0] = one;
+    std::copy(ps.core.publics.begin(), ps.core.publics.end(), tl.begin() + 1);
+    ck(sp_table_write(ctx, zc, nv, u64p(tl.data()), tl.size()), "z tail");
+    for (int q = 0; q < 3; ++q) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &core_abc[q]), "alloc");
+    ck(sp_multiply_vec(ctx, pk.S_core, zc, core_abc[0], core_abc[1], core_abc[2]), "multiply_vec (core)");
+  }
+  ck(sp_table_from_host(ctx, E_eq.data(), left, (size_t)-1, (size_t)-1, &pl), "pow left");
+  ck(sp_table_from_host(ctx, E_eq.data() + 4 * left, right, (size_t)-1, (size_t)-1, &pr), "pow right");
+  auto batched_hook = [](void* u, size_t round, const uint64_t* cs_, const uint64_t* cc_, size_t ncoeffs, uint64_t r_out[4]) -> int {
+    HookCtx* h = (HookCtx*)u;
+    try {
+      if (ncoeffs == 4) {
+        const size_t i = round - h->outer_start;
+        for (int q = 0; q < 4; ++q) {
+          memcpy(&h->vc->outer_step[i][q], cs_ + 4 * q, 32);
+          memcpy(&h->vc->outer_core[i][q], cc_ + 4 * q, 32);
+        }
+      } else {
+        const size_t j = round - h->inner_start;
+        for (int q = 0; q < 3; ++q) {
+          memcpy(&h->vc->inner_step[j][q], cs_ + 4 * q, 32);
+          memcpy(&h->vc->inner_core[j][q], cc_ + 4 * q, 32);
+        }
+      }
+      const fe_t r = vcirc::process_round(h->pk->ctx, *h->st, h->pk->vc, h->pk->vc_ck, *h->vc, round, *h->tr, *h->tape)[0];
+      memcpy(r_out, &r, 32);
+      return 0;
+    } catch (...) {
+      h->err = std::current_exception();
+      return SP_ERR_INTERNAL;
+    }
+  };
+  std::vector<fe_t> r_x(pk.nx);
+  {
+    int rc = sp_sumcheck_cubic_outer_pow_batched(ctx, pk.nx, pl, pr, A, B, C, core_abc[0], core_abc[1], core_abc[2], tail.data(), hc.outer_start, batched_hook, &hc, u64p(r_x.data()));
+    if (hc.err) std::rethrow_exception(hc.err);
+    ck(rc, "outer sum-check (batched)");
+  }
+  {
+    sp_table* cl[6] = {A, B, C, core_abc[0], core_abc[1], core_abc[2]};
+    fe_t v[6];
+    for (int q = 0; q < 6; ++q) ck(sp_table_read(ctx, cl[q], 0, 1, u64p(&v[q])), "claims");
+    for (int q = 0; q < 3; ++q) {
+      vc.claim_step[q] = v[q];
+      vc.claim_core[q] = v[3 + q];
+    }
+    ck(sp_table_read(ctx, pl, 0, 1, u64p(&vc.tau_at_rx)), "tau_at_rx");
+  }
+  const fe_t r = vcirc::process_round(ctx, vst, pk.vc, pk.vc_ck, vc, hc.outer_start + pk.nx, tr, tape)[0];
+  const double t_outer = now();
+  const fe_t r2 = fe_mul<S>(r, r);
+  fe_t claims[2] = {fe_add<S>(fe_add<S>(vc.claim_step[0], fe_mul<S>(r, vc.claim_step[1])), fe_mul<S>(r2, vc.claim_step[2])),
+                    fe_add<S>(fe_add<S>(vc.claim_core[0], fe_mul<S>(r, vc.claim_core[1])), fe_mul<S>(r2, vc.claim_core[2]))};
+  // evals_rx, both poly_ABC, the z tables, batched inner sum-check (:1852-1945)
+  ck(sp_eq_table(ctx, u64p(r_x.data()), pk.nx, &rx), "evals_rx");
+  for (sp_table** t : {&abc_s, &abc_c, &zs, &zcc}) ck(sp_table_zeros(ctx, 2 * nv, (size_t)-1, (size_t)-1, t), "alloc");
+  ck(sp_poly_abc(ctx, pk.S_step, rx, u64p(&r), 2 * nv, abc_s), "poly_ABC (step)");
+  ck(sp_poly_abc(ctx, pk.S_core, rx, u64p(&r), 2 * nv, abc_c), "poly_ABC (core)");
+  std::vector<fe_t> folded_X(dpub);
+  memcpy(folded_X.data(), f_X.data(), dpub * sizeof(fe_t));
+  auto fill_z = [&](sp_table* z, const sp_table* W, const std::vector<fe_t>& Xv) {
+    ck(sp_table_copy(ctx, z, 0, W, 0, nv), "z <- W");
+    std::vector<fe_t> tl(1 + Xv.size());
+    tl[0] = one;
+    std::copy(Xv.begin(), Xv.end(), tl.begin() + 1);
+    ck(sp_table_write(ctx, z, nv, u64p(tl.data()), tl.size()), "z tail");
+  };
+  fill_z(zs, fW, folded_X);
+  fill_z(zcc, ps.core.W, ps.core.publics);
+  for (sp_table* t : {abc_s, abc_c, zs, zcc}) ck(sp_table_set_len(t, 2 * nv, nv, 1 + dpub), "halves");
+  std::vector<fe_t> r_y(pk.ny);
+  fe_t fin[4];
+  {
+    int rc = sp_sumcheck_quad_batched(ctx, u64p(claims), pk.ny, abc_s, abc_c, zs, zcc, hc.inner_start, batched_hook, &hc, u64p(r_y.data()), u64p(fin));
+    if (hc.err) std::rethrow_exception(hc.err);
+    ck(rc, "inner sum-check (batched)");
+  }
+  auto eval_X = [&](const std::vector<fe_t>& Xv) {
+    std::vector<fe_t> v{one};
+    v.insert(v.end(), Xv.begin(), Xv.end());
+    return sparse_poly_evaluate(pk.ny - 1, v, r_y.data() + 1);
+  };
+  vc.eval_X_step = eval_X(folded_X);
+  vc.eval_X_core = eval_X(ps.core.publics);
+  const fe_t den = fe_sub<S>(one, r_y[0]);
+  if (fe_is_zero(den)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
+  const fe_t inv = fe_inv<S>(den);
+  vc.eval_W_step = fe_mul<S>(fe_sub<S>(fin[2], fe_mul<S>(r_y[0], vc.eval_X_step)), inv);
+  vc.eval_W_core = fe_mul<S>(fe_sub<S>(fin[3], fe_mul<S>(r_y[0], vc.eval_X_core)), inv);
+  const size_t inner_final = hc.inner_start + pk.ny;
+  for (size_t k = 0; k < 3; ++k) vcirc::process_round(ctx, vst, pk.vc, pk.vc_ck, vc, inner_final + k, tr, tape);
+  const double t_inner = now();
+
+  // finalize_multiround_witness (:1948-1952): U_verifier, its regular form, W_verifier
+  const vcirc::Shape& vs = pk.vc;
+  std::vector<fe_t> vpub(vst.cs.inputs.begin() + 1 + vs.total_challenges, vst.cs.inputs.end());
+  std::vector<aff_t> Uv_comm;
+  std::vector<fe_t> Uv_X, Wv_r;
+  for (const auto& c : vst.comm_per_round) Uv_comm.insert(Uv_comm.end(), c.begin(), c.end());
+  for (const auto& c : vst.challenges) Uv_X.insert(Uv_X.end(), c.begin(), c.end());
+  Uv_X.insert(Uv_X.end(), vpub.begin(), vpub.end());
+  for (const auto& b : vst.blind_per_round) Wv_r.insert(Wv_r.end(), b.begin(), b.end());
+  // sample_random_instance_witness (src/r1cs/mod.rs:474-531) on the verifier-circuit shape
+  const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io();
+  std::vector<fe_t> Z(vnv + vio + 1);
+  for (auto& z : Z) z = tape.next();
+  std::vector<fe_t> rnd_rW(vnv / 32), rnd_rE(vcons / 32);
+  for (auto& b : rnd_rW) b = tape.next();
+  for (auto& b : rnd_rE) b = tape.next();
+  const fe_t rnd_u = Z[vnv];
+  std::vector<fe_t> mv[3];
+  vs.multiply_vec(Z, mv);
+  std::vector<fe_t> rnd_E(vcons), rnd_W(Z.begin(), Z.begin() + vnv), rnd_X(Z.begin() + vnv + 1, Z.end());
+  for (size_t i = 0; i < vcons; ++i) rnd_E[i] = fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(rnd_u, mv[2][i]));
+  const std::vector<aff_t> rnd_comm_W = commit_rows32(ctx, pk.vc_ck, rnd_W, rnd_rW), rnd_comm_E = commit_rows32(ctx, pk.vc_ck, rnd_E, rnd_rE);
+  // NovaNIFS::prove (src/nifs.rs:34-61)
+  {
+    std::vector<uint8_t> b = commitment_bytes(rnd_comm_W.data(), rnd_comm_W.size()), e = commitment_bytes(rnd_comm_E.data(), rnd_comm_E.size());
+    b.insert(b.end(), e.begin(), e.end());
+    const size_t off = b.size();
+    b.resize(off + 32 * (1 + rnd_X.size()));
+    sp::fe_to_be_bytes<S>(rnd_u, b.data() + off);
+    for (size_t j = 0; j < rnd_X.size(); ++j) sp::fe_to_be_bytes<S>(rnd_X[j], b.data() + off + 32 * (1 + j));
+    tr.absorb("U1", b.data(), b.size());
+  }
+  absorb_instance(tr, "U2", Uv_comm, Uv_X);
+  std::vector<fe_t> r_T(vcons / 32);
+  for (auto& b : r_T) b = tape.next();
+  std::vector<fe_t> Zs(vnv + 1 + vio);
+  for (size_t i = 0; i < vnv; ++i) Zs[i] = fe_add<S>(rnd_W[i], vst.w[i]);
+  const fe_t u1 = fe_add<S>(rnd_u, one);
+  Zs[vnv] = u1;
+  for (size_t i = 0; i < vio; ++i) Zs[vnv + 1 + i] = fe_add<S>(rnd_X[i], Uv_X[i]);
+  vs.multiply_vec(Zs, mv);
+  std::vector<fe_t> T(vcons);
+  for (size_t i = 0; i < vcons; ++i) T[i] = fe_sub<S>(fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(u1, mv[2][i])), rnd_E[i]);
+  const std::vector<aff_t> comm_T = commit_rows32(ctx, pk.vc_ck, T, r_T);
+  {
+    const std::vector<uint8_t> b = commitment_bytes(comm_T.data(), comm_T.size());
+    tr.absorb("comm_T", b.data(), b.size());
+  }
+  const fe_t rf = tr.squeeze("r");
+  std::vector<fe_t> Wfold(vnv), Efold(vcons), rWfold(rnd_rW.size()), rEfold(rnd_rE.size()), Xfold(vio);
+  for (size_t i = 0; i < vnv; ++i) Wfold[i] = fe_add<S>(rnd_W[i], fe_mul<S>(rf, vst.w[i]));
+  for (size_t i = 0; i < vcons; ++i) Efold[i] = fe_add<S>(rnd_E[i], fe_mul<S>(rf, T[i]));
+  for (size_t i = 0; i < rWfold.size(); ++i) rWfold[i] = fe_add<S>(rnd_rW[i], fe_mul<S>(rf, Wv_r[i]));
+  for (size_t i = 0; i < rEfold.size(); ++i) rEfold[i] = fe_add<S>(rnd_rE[i], fe_mul<S>(rf, r_T[i]));
+  for (size_t i = 0; i < vio; ++i) Xfold[i] = fe_add<S>(rnd_X[i], fe_mul<S>(rf, Uv_X[i]));
+  const fe_t ufold = fe_add<S>(rnd_u, rf);
+  // RelaxedR1CSSpartanProof::prove (src/spartan_relaxed.rs:98-213)
+  tr.absorb_scalars("u_relaxed", &ufold, 1);
+  tr.absorb_scalars("X_relaxed", Xfold.data(), Xfold.size());
+  const size_t vlx = log2_ceil(vcons), vnvp = next_pow2(vnv), vly = log2_ceil(vnvp) + 1, vz_len = 2 * vnvp;
+  std::vector<fe_t> zr = Wfold;
+  zr.push_back(ufold);
+  zr.insert(zr.end(), Xfold.begin(), Xfold.end());
+  vs.multiply_vec(zr, mv);
+  std::vector<fe_t> vtau(vlx);
+  for (auto& t : vtau) t = tr.squeeze("t");
+  std::vector<fe_t> uczE(vcons);
+  for (size_t i = 0; i < vcons; ++i) uczE[i] = fe_add<S>(fe_mul<S>(ufold, mv[2][i]), Efold[i]);
+  std::vector<fe_t> v_outer(3 * vlx), v_rx(vlx), v_inner(2 * vly), v_ry(vly);
+  fe_t v_claims[3];
+  {
+    sp_table *ta = nullptr, *tb = nullptr, *tc = nullptr;
+    struct G {
+      sp_table *&a, *&b, *&c;
+      ~G() {
+        sp_table_free(a);
+        sp_table_free(b);
+        sp_table_free(c);
+      }
+    } g{ta, tb, tc};
+    ck(sp_table_from_host(ctx, u64p(mv[0].data()), vcons, (size_t)-1, (size_t)-1, &ta), "upload");
+    ck(sp_table_from_host(ctx, u64p(mv[1].data()), vcons, (size_t)-1, (size_t)-1, &tb), "upload");
+    ck(sp_table_from_host(ctx, u64p(uczE.data()), vcons, (size_t)-1, (size_t)-1, &tc), "upload");
+    const fe_t zero = fe_zero();
+    ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(vtau.data()), vlx, ta, tb, tc, tr.t, u64p(v_outer.data()), u64p(v_rx.data()), u64p(v_claims)), "relaxed outer sum-check");
+  }
+  tr.absorb_scalars("claims_outer", v_claims, 3);
+  const fe_t vr = tr.squeeze("r"), vr2 = fe_mul<S>(vr, vr);
+  const std::vector<fe_t> v_evals_rx = eq_evals(v_rx.data(), vlx);
+  fe_t claim_E = fe_zero();
+  for (size_t i = 0; i < vcons; ++i) claim_E = fe_add<S>(claim_E, fe_mul<S>(Efold[i], v_evals_rx[i]));
+  const fe_t v_claim_inner = fe_add<S>(fe_add<S>(v_claims[0], fe_mul<S>(vr, v_claims[1])), fe_mul<S>(vr2, fe_sub<S>(v_claims[2], claim_E)));
+  const size_t vcols = vs.num_cols();
+  std::vector<fe_t> vabc(vz_len, fe_zero());
+  {
+    std::vector<fe_t> ev[3];
+    for (int m = 0; m < 3; ++m) {  // bind_matrix_row_vars (:22-41)
+      ev[m].assign(vcols, fe_zero());
+      for (size_t row = 0; row < vcons; ++row) {
+        if (fe_is_zero(v_evals_rx[row])) continue;
+        for (uint64_t k = vs.M[m].ptr[row]; k < vs.M[m].ptr[row + 1]; ++k)
+          ev[m][vs.M[m].idx[k]] = fe_add<S>(ev[m][vs.M[m].idx[k]], fe_mul<S>(v_evals_rx[row], vs.M[m].data[k]));
+      }
+    }
+    const fe_t r2u = fe_mul<S>(vr2, ufold);
+    for (size_t i = 0; i < vcols; ++i) vabc[i] = fe_add<S>(fe_add<S>(ev[0][i], fe_mul<S>(vr, ev[1][i])), fe_mul<S>(r2u, ev[2][i]));
+  }
+  zr.resize(vz_len, fe_zero());
+  {
+    sp_table *ta = nullptr, *tb = nullptr;
+    struct G {
+      sp_table *&a, *&b;
+      ~G() {
+        sp_table_free(a);
+        sp_table_free(b);
+      }
+    } g{ta, tb};
+    ck(sp_table_from_host(ctx, u64p(vabc.data()), vz_len, (size_t)-1, (size_t)-1, &ta), "upload");
+    ck(sp_table_from_host(ctx, u64p(zr.data()), vz_len, (size_t)-1, (size_t)-1, &tb), "upload");
+    fe_t ci[2];
+    ck(sp_sumcheck_quad(ctx, u64p(&v_claim_inner), vly, ta, tb, tr.t, u64p(v_inner.data()), u64p(v_ry.data()), u64p(ci)), "relaxed inner sum-check");
+  }
+  std::vector<fe_t> v_W, v_E;
+  fe_t blind_vW, blind_vE;
+  prove_direct(32, Wfold, rWfold, v_ry.data() + 1, vly - 1, &v_W, &blind_vW);
+  prove_direct(32, Efold, rEfold, v_rx.data(), vlx, &v_E, &blind_vE);
+  tr.absorb_scalars("v_W", v_W.data(), v_W.size());
+  tr.absorb_scalars("v_E", v_E.data(), v_E.size());
+  const double t_vc = now();
+
+  // fold the two evaluation claims (:2019-2051) and open (:2054-2065)
+  const std::vector<aff_t>& comm_eW_s = vst.comm_per_round[inner_final + 1];
+  const std::vector<aff_t>& comm_eW_c = vst.comm_per_round[inner_final + 2];
+  const fe_t c_eval = tr.squeeze("c_eval");
+  std::vector<aff_t> comm(rows);
+  ck(sp_fold_commitments2(ctx, u64p(&f_comm[0].x), u64p(&core_comm[0].x), rows, u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
+  std::vector<fe_t> blind(rows);
+  for (size_t i = 0; i < rows; ++i) {
+    fe_t a;
+    memcpy(&a, f_rW.data() + 4 * i, 32);
+    blind[i] = fe_add<S>(a, fe_mul<S>(c_eval, core_rW[i]));
+  }
+  ck(sp_table_zeros(ctx, nv, (size_t)-1, (size_t)-1, &Wf), "alloc");
+  {
+    const sp_table* two[2] = {fW, ps.core.W};
+    const fe_t wts[2] = {one, c_eval};
+    ck(sp_fold_tables(ctx, two, 2, u64p(wts), nv, Wf), "W = folded_W + c_eval * core_W");
+  }
+  aff_t comm_eval;
+  ck(sp_fold_commitments2(ctx, u64p(&comm_eW_s[0].x), u64p(&comm_eW_c[0].x), 1, u64p(&c_eval), u64p(&comm_eval.x)), "fold eval commitments");
+  const fe_t blind_eval = fe_add<S>(vst.blind_per_round[inner_final + 1][0], fe_mul<S>(c_eval, vst.blind_per_round[inner_final + 2][0]));
+  // HyraxPCS::prove (hyrax_pc.rs:387-478) + InnerProductArgumentLinear::prove (ipa.rs:125-170); ck_eval = the width-32 key (ck_c = its first base, its h)
+  aff_t delta, beta;
+  std::vector<fe_t> z_vec(CW);
+  fe_t z_delta, z_beta;
+  {
+    const std::vector<uint8_t> b = commitment_bytes(comm.data(), comm.size());
+    tr.absorb("poly_com", b.data(), b.size());
+    const fe_t* point = r_y.data() + 1;
+    const size_t npoint = pk.ny - 1, nvr = log2_ceil(rows);
+    const std::vector<fe_t> L = eq_evals(point, nvr), Rv = eq_evals(point + nvr, npoint - nvr);
+    std::vector<fe_t> LZ(Rv.size());
+    ck(sp_rowmat_vec(ctx, Wf, L.size(), Rv.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
+    fe_t r_LZ = fe_zero();
+    for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], blind[i]));
+    aff_t comm_LZ;
+    ck(sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ");
+    tr.dom_sep("inner product argument (linear)");
+    std::vector<fe_t> dv(Rv.size());
+    for (auto& x : dv) x = tape.next();
+    const fe_t r_delta = tape.next(), r_beta = tape.next();
+    ck(sp_msm_ck(ctx, pk.ck, u64p(dv.data()), dv.size(), u64p(&r_delta), u64p(&delta.x)), "delta");
+    fe_t ip = fe_zero();
+    for (size_t i = 0; i < Rv.size(); ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], dv[i]));
+    ck(sp_hyrax_commit_small(ctx, pk.vc_ck, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
+    uint8_t pb[128];
+    point_bytes(comm_LZ, pb);
+    point_bytes(comm_eval, pb + 64);
+    tr.absorb("U", pb, 128);
+    point_bytes(delta, pb);
+    tr.absorb("delta", pb, 64);
+    point_bytes(beta, pb);
+    tr.absorb("beta", pb, 64);
+    const fe_t rr = tr.squeeze("r");
+    for (size_t i = 0; i < Rv.size(); ++i) z_vec[i] = fe_add<S>(fe_mul<S>(rr, LZ[i]), dv[i]);
+    z_delta = fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta);
+    z_beta = fe_add<S>(fe_mul<S>(rr, blind_eval), r_beta);
+  }
+  const double t_end = now();
+  // the rest of the proof in the canonical layout
+  proof.pp(delta);
+  proof.pp(beta);
+  for (const fe_t& f : z_vec) proof.pf(f);
+  proof.pf(z_delta);
+  proof.pf(z_beta);
+  for (const auto& c : vst.comm_per_round) proof.pc(c);
+  for (const fe_t& f : vpub) proof.pf(f);
+  for (const auto& cr : vst.challenges)
+    for (const fe_t& f : cr) proof.pf(f);
+  proof.pc(comm_T);
+  proof.pc(rnd_comm_W);
+  proof.pc(rnd_comm_E);
+  proof.pf(rnd_u);
+  for (const fe_t& f : rnd_X) proof.pf(f);
+  for (const fe_t& f : v_outer) proof.pf(f);
+  for (int i = 0; i < 3; ++i) proof.pf(v_claims[i]);
+  for (const fe_t& f : v_inner) proof.pf(f);
+  for (const fe_t& f : v_W) proof.pf(f);
+  proof.pf(blind_vW);
+  for (const fe_t& f : v_E) proof.pf(f);
+  proof.pf(blind_vE);
+  if (phase_ms) {
+    phase_ms[0] = t_inst - t_start;   // rerandomize + instances
+    phase_ms[1] = t_nifs - t_inst;    // NIFS (layers, rounds, folds, process_round per round)
+    phase_ms[2] = t_outer - t_nifs;   // core products + batched outer sum-check
+    phase_ms[3] = t_inner - t_outer;  // poly_ABC x 2 + batched inner sum-check
+    phase_ms[4] = t_vc - t_inner;     // verifier-circuit instance: random instance, NovaNIFS, relaxed Spartan
+    phase_ms[5] = t_end - t_vc;       // folded opening
+    phase_ms[6] = t_end - t_start;
+  }
+  return proof;
+}
+
+}  // namespace spartan2
+
+using namespace spartan2;
+extern "C" void ss_set_error(const char* msg);
+static int catch_all_nn() {
+  try {
+    throw;
+  } catch (const Error& e) {
+    ss_set_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    ss_set_error(e.what());
+    return SP_ERR_INTERNAL;
+  }
+}
+
+extern "C" {
+// args: the integer R1CS of the step circuit and of the core circuit (same padded dimensions), as for ss_setup
+int nnz_setup(sp_ctx* ctx, size_t num_steps, size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges,
+              const int64_t* Ad, const uint32_t* Ai, const uint64_t* Ap, const int64_t* Bd, const uint32_t* Bi, const uint64_t* Bp, const int64_t* Cd, const uint32_t* Ci,
+              const uint64_t* Cp, size_t c_num_cons, size_t c_num_shared, size_t c_num_precommitted, size_t c_num_rest, size_t c_num_public, size_t c_num_challenges,
+              const int64_t* cAd, const uint32_t* cAi, const uint64_t* cAp, const int64_t* cBd, const uint32_t* cBi, const uint64_t* cBp, const int64_t* cCd,
+              const uint32_t* cCi, const uint64_t* cCp, void** out_pk) {
+  try {
+    *out_pk = nn_setup(ctx, make_view(num_cons, num_shared, num_precommitted, num_rest, num_public, num_challenges, Ad, Ai, Ap, Bd, Bi, Bp, Cd, Ci, Cp),
+                       make_view(c_num_cons, c_num_shared, c_num_precommitted, c_num_rest, c_num_public, c_num_challenges, cAd, cAi, cAp, cBd, cBi, cBp, cCd, cCi, cCp),
+                       num_steps);
+    return 0;
+  } catch (...) {
+    return catch_all_nn();
+  }
+}
+void nnz_pk_free(void* pk) { delete (NNZkKey*)pk; }
+// out: nb, nx, ny, vc rounds, vc total vars, vc num_cons, vc num_cons_unpadded, vc num_public; digest = the vk digest substitute
+void nnz_pk_info(void* pk_, uint64_t out[8], uint8_t digest[32]) {
+  auto* pk = (NNZkKey*)pk_;
+  uint64_t v[8] = {pk->nb, pk->nx, pk->ny, pk->vc.num_rounds, pk->vc.total_vars, pk->vc.num_cons, pk->vc.num_cons_unpadded, pk->vc.num_public};
+  memcpy(out, v, sizeof v);
+  memcpy(digest, pk->vk_digest, 32);
+}
+size_t nnz_proof_words(void* pk_) {
+  auto* pk = (NNZkKey*)pk_;
+  const sp_dims& d = pk->dims;
+  const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0,
+               rows_rest = d.num_rest / CW;
+  const vcirc::Shape& vs = pk->vc;
+  const size_t vlx = log2_ceil(vs.num_cons), vly = log2_ceil(next_pow2(vs.total_vars)) + 1;
+  size_t w = 8 * rows_sh + (pk->num_steps + 1) * (8 * (rows_pre + rows_rest) + 4 * d.num_public) + 16 + 4 * CW + 8;
+  w += 8 * (vs.total_vars / 32) + 4 * vs.num_public + 4 * vs.total_challenges;
+  w += 8 * (vs.num_cons / 32) + 8 * (vs.total_vars / 32) + 8 * (vs.num_cons / 32) + 4 + 4 * vs.num_io();
+  w += 12 * vlx + 12 + 8 * vly + 4 * 32 + 4 + 4 * 32 + 4;
+  return w;
+}
+int nnz_prep_prove(void* pk, size_t n, const uint64_t* step_wit, size_t wit_len, const uint64_t* step_pub, size_t npub, const uint64_t* core_wit, const uint64_t* core_pub,
+                   int is_small, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, void** out_ps) {
+  try {
+    Tape t{tape, tape_blocks};
+    *out_ps = nn_prep_prove(*(NNZkKey*)pk, n, step_wit, wit_len, step_pub, npub, core_wit, core_pub, is_small != 0, t);
+    if (tape_used) *tape_used = t.pos;
+    return 0;
+  } catch (...) {
+    return catch_all_nn();
+  }
+}
+void nnz_prep_free(void* ps) { delete (NNZkPrep*)ps; }
+// phase_ms[7]: instances, nifs, outer, inner, verifier-circuit instance, opening, total
+int nnz_prove(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words, size_t out_cap, double* phase_ms) {
+  try {
+    Tape t{tape, tape_blocks};
+    ProofBuf pf = nn_prove(*(NNZkKey*)pk, *(NNZkPrep*)ps, t, phase_ms);
+    if (pf.words.size() > out_cap) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "proof buffer too small");
+    memcpy(out_words, pf.words.data(), pf.words.size() * 8);
+    if (tape_used) *tape_used = t.pos;
+    return 0;
+  } catch (...) {
+    return catch_all_nn();
+  }
+}
+}

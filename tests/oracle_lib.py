@@ -374,3 +374,58 @@ def prove_cubic_outer_pow_batched(num_rounds, pow_left, pow_right, step, core, t
                                                  p64(base))
     assert rc == 0, lib().orc_last_error()
     return out_r, fin, base
+
+
+# ---- NeutronNovaZkSNARK (oracle/neutronnova_zk.hpp) -------------------------------------------------------------------------------------------
+class OracleNeutronNova:
+    """setup -> prep_prove + prove -> verify on the CPU oracle. step_insts / core_inst: spartan2_amd.frontend.R1CSInstanceInt of ONE shape."""
+
+    def __init__(self, step_insts, core_inst):
+        L = lib()
+        for name in ("orc_nn_setup", "orc_nn_prove", "orc_nn_proof_from_words"):
+            getattr(L, name).restype = ctypes.c_void_p
+        L.orc_nn_proof_words.restype = ctypes.c_size_t
+        self.steps, self.core = step_insts, core_inst
+        self.shape_step, self.shape_core = OracleShape(step_insts[0]), OracleShape(core_inst)
+        k = L.orc_nn_setup(self.shape_step.h, self.shape_core.h, ctypes.c_size_t(len(step_insts)))
+        if not k:
+            raise RuntimeError(L.orc_last_error().decode())
+        self.k = ctypes.c_void_p(k)
+        info = (ctypes.c_uint64 * 8)()
+        L.orc_nn_info(self.k, info)
+        self.info = dict(zip(("nb", "nx", "ny", "vc_rounds", "vc_vars", "vc_cons", "vc_cons_unpadded", "vc_public"), [int(x) for x in info]))
+
+    def digest(self):
+        d = np.zeros(32, dtype=np.uint8)
+        lib().orc_nn_digest(self.k, p8(d))
+        return d
+
+    def prove(self, tape, is_small=True):
+        """-> (proof words, (tape blocks used by prep_prove, by prove), seconds of prove)"""
+        n = len(self.steps)
+        sw = np.ascontiguousarray(np.stack([np.asarray(i.witness, dtype=np.uint64) for i in self.steps]))
+        sp = np.ascontiguousarray(np.stack([np.asarray(i.publics, dtype=np.uint64) for i in self.steps]))
+        cw = np.ascontiguousarray(self.core.witness, dtype=np.uint64)
+        cp = np.ascontiguousarray(self.core.publics, dtype=np.uint64)
+        used = (ctypes.c_size_t * 2)()
+        secs = ctypes.c_double(0)
+        pf = lib().orc_nn_prove(self.k, ctypes.c_size_t(n), p64(sw), ctypes.c_size_t(sw.shape[1]), p64(sp), ctypes.c_size_t(sp.shape[1]), p64(cw), p64(cp), int(is_small),
+                                p8(tape), ctypes.c_size_t(tape.shape[0]), used, ctypes.byref(secs))
+        if not pf:
+            raise RuntimeError(lib().orc_last_error().decode())
+        pf = ctypes.c_void_p(pf)
+        nw = lib().orc_nn_proof_words(pf)
+        words = np.zeros(nw, dtype=np.uint64)
+        lib().orc_nn_proof_serialize(pf, p64(words))
+        lib().orc_nn_proof_free(pf)
+        return words, (int(used[0]), int(used[1])), secs.value
+
+    def verify_words(self, words):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        pf = lib().orc_nn_proof_from_words(self.k, p64(words), ctypes.c_size_t(len(words)))
+        if not pf:
+            return -2
+        pf = ctypes.c_void_p(pf)
+        rc = lib().orc_nn_verify(self.k, pf)
+        lib().orc_nn_proof_free(pf)
+        return rc
