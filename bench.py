@@ -3,13 +3,15 @@
 (benches/sha256_spartan.rs:166-268: message vec![0u8; 2048], is_small = true, prove timed after warm-up proves on the same prep state). One prove
 per "step"; the prep state (witness, cached Az/Bz/Cz, keys, matrices) is resident in HBM when the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c4]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4]
 
 One process per GPU (torch.distributed.run for N > 1); the timed region is bracketed by barrier + torch.cuda.synchronize(), max over ranks.
 
   workload c2 (default)  every rank proves its own copy of the config-2 instance: N independent proofs, no data-path collective ("weak");
                          value = N * constraints / max-over-ranks time per step. The timed prove() does the reference's work: the transcript
                          prefix is re-hashed in every prove (the cached-prefix variant is reported beside it, never as `value`).
+  workload c3            every rank proves its own batch of 32 Sha256StepCircuit instances + the core circuit through NeutronNovaZkSNARK::prove
+                         (BASELINE config 3, benches/sha256_neutronnova.rs); "weak", no data-path collective;
   workload c4            ONE proof of the synthetic 2^22 instance (BASELINE config 4, seed 0xDEADBEEF) sharded over the N ranks
                          (spartan2_amd/host/sharded_snark.cpp): rows/N Hyrax commitment, row-sliced Az/Bz/Cz, slice-sharded sum-checks with
                          one RCCL all-gather per round, column-sliced poly_ABC, point-range MSMs ("strong"); value = constraints / time.
@@ -136,7 +138,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("c2", "c4"), default="c2")
+    ap.add_argument("--workload", choices=("c2", "c3", "c4"), default="c2")
     ap.add_argument("--message-bytes", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true", help="skip the config-4 sharded legs (profiling runs)")
@@ -159,6 +161,44 @@ def main():
     ctx = hip.Context(local_rank)
     comm = host.Comm(rank, world, "rccl", device=local_rank)  # the data-path exchange layer: ncclAllGather from C++ on its own communicator
     barrier = group.barrier  # dist.barrier() + torch.cuda.synchronize()
+
+    if args.workload == "c3":
+        # ---- 32 step circuits + core through NeutronNovaZkSNARK::prove on every rank (weak scaling, independent batches)
+        nsteps = 32
+        circs = [frontend.sha256_step_circuit(bytes([(i + 37 * rank) & 0xFF]) * 64) for i in range(nsteps)]
+        core = frontend.sha256_step_circuit(bytes(64))
+        nn = host.NeutronNovaZkSNARK(ctx, circs, core)
+        tape = np.random.default_rng(0xC3 + rank).integers(0, 256, size=(32768, 64), dtype=np.uint8)
+        used = nn.prep_prove(tape)
+        step_tape = tape[used:]
+        for _ in range(args.warmup):
+            words, _, _ = nn.prove(step_tape)
+        barrier()
+        t0 = time.perf_counter()
+        acc = {}
+        for _ in range(args.steps):
+            words, _, ph = nn.prove(step_tape)
+            for k_, v_ in ph.items():
+                acc[k_] = acc.get(k_, 0.0) + v_
+        barrier()
+        elapsed = group.max_over_ranks(time.perf_counter() - t0)
+        ncons = circs[0].num_cons * nsteps + core.num_cons
+        if rank == 0:
+            out = {"metric": "sha256_neutronnova 32 step circuits, NeutronNovaZkSNARK::prove: R1CS constraints/sec (all step + core constraints of one batch per prove)",
+                   "value": ncons * world * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "u256 modular integer (8 x u32 Montgomery limbs; T256 scalar/base fields)",
+                   "data": "synthetic: Sha256StepCircuit over constant 64-byte blocks, seeded randomness tape",
+                   "config": {"workload": "sha256_neutronnova 32 step circuits (BASELINE config 3), NeutronNovaZkSNARK::prove", "num_steps": nsteps,
+                              "num_cons_unpadded_per_step": circs[0].num_cons, "num_cons_per_step": 1 << nn.info["nx"],
+                              "parallelism": f"{world} independent batches, one per GPU"},
+                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "sharded": None, "roofline": None, "cpu_baseline": None}
+            print(json.dumps(out))
+        nn.close()
+        comm.close()
+        ctx.close()
+        group.close()
+        return
 
     if args.workload == "c4":
         # ---- ONE 2^22 proof over all ranks (strong scaling): the timed region is the sharded prove

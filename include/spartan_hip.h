@@ -296,6 +296,9 @@ int sp_nifs_layer(sp_nifs* n, int which, size_t idx, sp_table** view);
  * reference's split: cached_step_i64 is made in prep_prove, src/neutronnova_zk.rs:1548-1586, and only consumed by prove) */
 int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, int small_values);
 int sp_nifs_prepare_small(sp_nifs* n);
+/* dst <- the prepared layers (and i64 mirrors) of src, same context and geometry: prep_prove's cached_step_matvec / cached_step_i64
+ * (src/neutronnova_zk.rs:1520-1590) are built once into `src`; every prove restores a working object from it before sp_nifs_begin. */
+int sp_nifs_restore(sp_nifs* dst, const sp_nifs* src);
 int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]);
 int sp_nifs_challenge(sp_nifs* n, const uint64_t r_b[4]);
 int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out, uint64_t out_T_out[4], uint64_t out_eq_rho_at_rb[4]);

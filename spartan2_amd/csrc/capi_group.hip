@@ -508,6 +508,34 @@ int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, s
   const size_t cols = ck->num_cols, rows = (n + cols - 1) / cols;
   if (rows == 0) return SP_OK;
   int rc;
+  if (ck->d_cktables) {
+    // keys of <= 64 bases: per-base FixedBaseMul tables, as the reference does (hyrax_pc.rs:221-260 -> multi_mul, msm.rs:727-773): every
+    // (row, column) scalar and every row blind walks its own table in ONE launch; the cols + 1 points of a row are added on the host side
+    const size_t per = cols + 1, total = rows * per;
+    DevBuf ds, dout, dbl;
+    if ((rc = ds.alloc(total * sizeof(fe_t))) || (rc = dout.alloc(total * sizeof(jac_t))) || (rc = dbl.alloc(rows * sizeof(fe_t)))) return rc;
+    SP_HIP(hipMemsetAsync(ds.p, 0, total * sizeof(fe_t), c->stream));
+    const size_t full_rows = n / cols;
+    if (full_rows) SP_HIP(hipMemcpy2DAsync(ds.p, per * sizeof(fe_t), v->d + off, cols * sizeof(fe_t), cols * sizeof(fe_t), full_rows, hipMemcpyDeviceToDevice, c->stream));
+    if (n % cols) SP_HIP(hipMemcpyAsync(ds.as<fe_t>() + full_rows * per, v->d + off + full_rows * cols, (n % cols) * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
+    SP_HIP(hipMemcpyAsync(dbl.p, blinds, rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+    SP_HIP(hipMemcpy2DAsync(ds.as<fe_t>() + cols, per * sizeof(fe_t), dbl.p, sizeof(fe_t), sizeof(fe_t), rows, hipMemcpyDeviceToDevice, c->stream));
+    c->timed("fixed_base", 32ull * total, [&] { launch_fixed_base_rows(c->stream, ds.as<fe_t>(), total, ck->d_cktables, per, dout.as<jac_t>()); });
+    std::vector<jac_t> pts(total);
+    SP_HIP(hipMemcpyAsync(pts.data(), dout.p, total * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP(hipStreamSynchronize(c->stream));
+    std::vector<jac_t> sums(rows);
+    for (size_t r = 0; r < rows; ++r) {
+      jac_t acc = jac_identity();
+      for (size_t k = 0; k < per; ++k)
+        if (!jac_is_identity(pts[r * per + k])) acc = jac_add(acc, pts[r * per + k]);
+      sums[r] = acc;
+    }
+    std::vector<aff_t> a(rows);
+    normalize_batch(sums, a.data());
+    memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
+    return SP_OK;
+  }
   fe_t* canon = (fe_t*)c->workspace(sp_ctx::WS_COMMIT_CANON, n * sizeof(fe_t));
   unsigned* flags = (unsigned*)c->workspace(sp_ctx::WS_COMMIT_FLAGS, rows * 4);
   jac_t* rowsum = (jac_t*)c->workspace(sp_ctx::WS_COMMIT_ROWS, rows * sizeof(jac_t));
@@ -885,7 +913,23 @@ int sp_msm_job_finish(sp_ctx* c, sp_msm_job* job, uint64_t out_aff[8]) { return 
 
 int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]) {
   if (!ck->d_cktables || n > ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_small: key wider than 64 or too many scalars");
-  // FixedBaseMul::multi_mul (msm.rs:727-773) + h_table.mul(blind); n <= 64 single lookups chains: host
+  // FixedBaseMul::multi_mul (msm.rs:727-773) + h_table.mul(blind). A handful of scalars: host (single lookup chains). More (a round of the ZK
+  // verifier circuit commits up to 32 values, 41 times per NeutronNova proof): every scalar's table walk on its own device lanes, one launch.
+  size_t nonzero = 0;
+  for (size_t i = 0; i < n; ++i) nonzero += (scalars[4 * i] | scalars[4 * i + 1] | scalars[4 * i + 2] | scalars[4 * i + 3]) != 0;
+  if (nonzero > 6) {
+    const size_t cols = ck->num_cols;
+    std::vector<fe_t> sc(cols + 1, fe_zero());
+    memcpy(sc.data(), scalars, n * sizeof(fe_t));
+    memcpy(&sc[cols], blind, sizeof(fe_t));
+    std::vector<jac_t> pts;
+    int rc = fixed_base_rows(c, ck->d_cktables, cols + 1, reinterpret_cast<const uint64_t*>(sc.data()), cols + 1, pts);
+    if (rc) return rc;
+    jac_t acc = jac_identity();
+    for (const jac_t& p : pts) acc = jac_add(acc, p);
+    store_aff(out_aff, jac_to_affine(acc));
+    return SP_OK;
+  }
   std::vector<jac_t> parts;
   for (size_t i = 0; i < n; ++i) {
     fe_t sc;

@@ -199,6 +199,39 @@ int sp_nifs_prepare_small(sp_nifs* n) {
   return SP_OK;
 }
 
+// prep_prove caches the step circuits' (Az, Bz, Cz) and their i64 mirrors when z is fully known (cached_step_matvec / cached_step_i64,
+// src/neutronnova_zk.rs:1520-1590); prove starts from a copy because the rounds fold the layers in place. `dst` and `src` have one geometry.
+int sp_nifs_restore(sp_nifs* dst, const sp_nifs* src) {
+  if (!dst || !src || dst == src || dst->n_padded != src->n_padded || dst->left != src->left || dst->right != src->right || dst->ctx != src->ctx)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_restore: the two objects must share context and geometry");
+  sp_ctx* c = dst->ctx;
+  const size_t np = src->n_padded, bytes = np * src->total * sizeof(fe_t);
+  c->timed("nifs_restore", 2ull * 3 * bytes, [&] {
+    (void)hipMemcpyAsync(dst->A[0], src->A[0], bytes, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(dst->B[0], src->B[0], bytes, hipMemcpyDeviceToDevice, c->stream);
+    (void)hipMemcpyAsync(dst->C, src->C, bytes, hipMemcpyDeviceToDevice, c->stream);
+  });
+  dst->mirrors_ready = false;
+  if (src->mirrors_ready) {
+    if (!dst->A64) {
+      hipError_t e = hipMalloc((void**)&dst->A64, np * src->total * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&dst->B64, np * src->total * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&dst->C64, np * src->total * 8);
+      if (e == hipSuccess) e = hipMalloc((void**)&dst->d_flags, src->total);
+      if (e == hipSuccess) e = hipMalloc((void**)&dst->d_large, src->total * 4);
+      if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("sp_nifs_restore: hipMalloc: ") + hipGetErrorString(e));
+    }
+    SP_HIP(hipMemcpyAsync(dst->A64, src->A64, np * src->total * 8, hipMemcpyDeviceToDevice, c->stream));
+    SP_HIP(hipMemcpyAsync(dst->B64, src->B64, np * src->total * 8, hipMemcpyDeviceToDevice, c->stream));
+    SP_HIP(hipMemcpyAsync(dst->C64, src->C64, np * src->total * 8, hipMemcpyDeviceToDevice, c->stream));
+    SP_HIP(hipMemcpyAsync(dst->d_flags, src->d_flags, src->total, hipMemcpyDeviceToDevice, c->stream));
+    SP_HIP(hipMemcpyAsync(dst->d_large, src->d_large, src->total * 4, hipMemcpyDeviceToDevice, c->stream));
+    dst->nlarge = src->nlarge;
+    dst->mirrors_ready = true;
+  }
+  return SP_OK;
+}
+
 int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, int small_values) {
   if ((size_t(1) << ell_b) != n->n_padded) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_begin: expected log2(n_padded) rhos");
   return sp_nifs_begin_shard(n, E_eq, rhos, ell_b, 0, small_values);

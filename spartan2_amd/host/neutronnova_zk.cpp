@@ -41,9 +41,13 @@ struct NNZkPrep {
   std::vector<aff_t> comm_shared;
   std::vector<fe_t> r_shared;
   bool is_small = true;
+  // cached_step_matvec / cached_step_i64 (:1520-1590): the step instances' (Az, Bz, Cz) layers and their i64 mirrors, and the working copy each prove folds
+  sp_nifs *nifs_cached = nullptr, *nifs_work = nullptr;
   ~NNZkPrep() {
     for (auto& s : steps) sp_table_free(s.W);
     sp_table_free(core.W);
+    sp_nifs_free(nifs_cached);
+    sp_nifs_free(nifs_work);
   }
 };
 
@@ -143,6 +147,19 @@ static NNZkPrep* nn_prep_prove(const NNZkKey& pk, size_t n, const uint64_t* step
     };
     for (size_t i = 0; i < n; ++i) precommit(d, step_wit + i * wit_len, step_pub + i * npub, &ps->steps[i]);
     precommit(pk.dims_core, core_wit, core_pub, &ps->core);
+    {  // can_cache_matvec (:1523) always holds here: nn_setup rejects rest variables and challenges, so z = [W | 1 | X] is fully known
+      std::vector<fe_t> X(n * d.num_public);
+      std::vector<const sp_table*> Ws(n);
+      for (size_t i = 0; i < n; ++i) {
+        std::copy(ps->steps[i].publics.begin(), ps->steps[i].publics.end(), X.begin() + i * d.num_public);
+        Ws[i] = ps->steps[i].W;
+      }
+      ps->nifs_cached = nifs_prepare(ctx, pk.S_step, d, n, X.data(), Ws.data(), true);
+      size_t n_padded = 2, ell, left, right;
+      while (n_padded < n) n_padded <<= 1;
+      compute_tensor_decomp(d.num_cons, &ell, &left, &right);
+      ck(sp_nifs_create(ctx, n_padded, left, right, &ps->nifs_work), "nifs_create");
+    }
   } catch (...) {
     delete ps;
     throw;
@@ -224,48 +241,64 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
   ck(sp_ctx_bind_thread(ctx), "device");
-  // rerandomize (:1619-1627, hyrax_pc.rs:321-344): core (shared, precommitted), then every step's precommitted commitment
-  auto rerand = [&](std::vector<aff_t>& comm, std::vector<fe_t>& r_old) {
-    if (comm.empty()) return;
-    std::vector<fe_t> rn(comm.size());
-    for (auto& b : rn) b = tape.next();
-    std::vector<aff_t> out(comm.size());
-    ck(sp_hyrax_rerandomize(ctx, pk.ck, u64p(&comm[0].x), comm.size(), u64p(r_old.data()), u64p(rn.data()), u64p(&out[0].x)), "rerandomize_commitment");
-    comm = out;
-    r_old = rn;
-  };
-  rerand(ps.comm_shared, ps.r_shared);
-  rerand(ps.core.comm_pre, ps.core.r_pre);
-  for (auto& st : ps.steps) rerand(st.comm_pre, st.r_pre);
-  // instances and witnesses (:1662-1719): rest rows = commit_zeros (h * blind); no challenges for these circuits
+  // rerandomize (:1619-1627, hyrax_pc.rs:321-344): core (shared, precommitted), then every step's precommitted commitment. The new blinds are
+  // drawn in the reference's order; the row updates are independent, so all of them go through ONE sp_hyrax_rerandomize call.
+  {
+    std::vector<std::pair<std::vector<aff_t>*, std::vector<fe_t>*>> parts;
+    parts.push_back({&ps.comm_shared, &ps.r_shared});
+    parts.push_back({&ps.core.comm_pre, &ps.core.r_pre});
+    for (auto& st : ps.steps) parts.push_back({&st.comm_pre, &st.r_pre});
+    std::vector<aff_t> all_c;
+    std::vector<fe_t> all_old, all_new;
+    for (auto& pr_ : parts)
+      for (size_t i = 0; i < pr_.first->size(); ++i) {
+        all_c.push_back((*pr_.first)[i]);
+        all_old.push_back((*pr_.second)[i]);
+        all_new.push_back(tape.next());
+      }
+    if (!all_c.empty()) {
+      std::vector<aff_t> out(all_c.size());
+      ck(sp_hyrax_rerandomize(ctx, pk.ck, u64p(&all_c[0].x), all_c.size(), u64p(all_old.data()), u64p(all_new.data()), u64p(&out[0].x)), "rerandomize_commitment");
+      size_t o = 0;
+      for (auto& pr_ : parts)
+        for (size_t i = 0; i < pr_.first->size(); ++i, ++o) {
+          (*pr_.first)[i] = out[o];
+          (*pr_.second)[i] = all_new[o];
+        }
+    }
+  }
+  // instances and witnesses (:1662-1719): rest rows = commit_zeros (h * blind) — one sp_fixed_base_mul_h call for the rest rows of all instances;
+  // no challenges for these circuits
   ProofBuf proof;
   proof.pc(ps.comm_shared);
   std::vector<aff_t> comms(n * rows);
   std::vector<fe_t> X(n * dpub), r_W(n * rows);
   std::vector<const sp_table*> Ws(n);
-  auto instance = [&](NNPre& p, aff_t* comm_out, fe_t* r_out) {
-    std::vector<fe_t> r_rest(rows_rest);
-    for (auto& b : r_rest) b = tape.next();
-    std::vector<aff_t> c_rest(rows_rest);
-    if (rows_rest) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_rest.data()), rows_rest, u64p(&c_rest[0].x)), "commit_zeros");
+  std::vector<fe_t> all_rest((n + 1) * rows_rest);
+  for (auto& b : all_rest) b = tape.next();  // steps in order, then the core: the reference's call order
+  std::vector<aff_t> all_c_rest(all_rest.size());
+  if (!all_rest.empty()) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(all_rest.data()), all_rest.size(), u64p(&all_c_rest[0].x)), "commit_zeros");
+  auto instance = [&](NNPre& p, size_t which, aff_t* comm_out, fe_t* r_out) {
+    const fe_t* r_rest = all_rest.data() + which * rows_rest;
+    const aff_t* c_rest = all_c_rest.data() + which * rows_rest;
     std::copy(ps.comm_shared.begin(), ps.comm_shared.end(), comm_out);
     std::copy(p.comm_pre.begin(), p.comm_pre.end(), comm_out + rows_sh);
-    std::copy(c_rest.begin(), c_rest.end(), comm_out + rows_sh + rows_pre);
+    std::copy(c_rest, c_rest + rows_rest, comm_out + rows_sh + rows_pre);
     std::copy(ps.r_shared.begin(), ps.r_shared.end(), r_out);
     std::copy(p.r_pre.begin(), p.r_pre.end(), r_out + rows_sh);
-    std::copy(r_rest.begin(), r_rest.end(), r_out + rows_sh + rows_pre);
+    std::copy(r_rest, r_rest + rows_rest, r_out + rows_sh + rows_pre);
     proof.pc(p.comm_pre);
-    proof.pc(c_rest);
+    for (size_t i = 0; i < rows_rest; ++i) proof.pp(c_rest[i]);
     for (const fe_t& f : p.publics) proof.pf(f);
   };
   for (size_t i = 0; i < n; ++i) {
-    instance(ps.steps[i], &comms[i * rows], &r_W[i * rows]);
+    instance(ps.steps[i], i, &comms[i * rows], &r_W[i * rows]);
     std::copy(ps.steps[i].publics.begin(), ps.steps[i].publics.end(), X.begin() + i * dpub);
     Ws[i] = ps.steps[i].W;
   }
   std::vector<aff_t> core_comm(rows);
   std::vector<fe_t> core_rW(rows);
-  instance(ps.core, core_comm.data(), core_rW.data());
+  instance(ps.core, n, core_comm.data(), core_rW.data());
   const double t_inst = now();
 
   Tr tr(ctx, "neutronnova_prove");
@@ -316,7 +349,8 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   for (sp_table** t : {&A, &B, &C}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc");
   ck(sp_table_zeros(ctx, nv, (size_t)-1, (size_t)-1, &fW), "alloc");
   NifsOutputs no{polys.data(), r_bs.data(), E_eq.data(), tail.data(), f_rW.data(), f_X.data(), (uint64_t*)f_comm.data(), A, B, C, fW};
-  nifs_prove(ctx, pk.S_step, d, pk.ck, n, rows, comms.data(), X.data(), Ws.data(), r_W.data(), true, nullptr, tr.t, nifs_hook, &hc, no);
+  ck(sp_nifs_restore(ps.nifs_work, ps.nifs_cached), "nifs_restore");
+  nifs_prove(ctx, pk.S_step, d, pk.ck, n, rows, comms.data(), X.data(), Ws.data(), r_W.data(), true, ps.nifs_work, tr.t, nifs_hook, &hc, no);
   if (hc.err) std::rethrow_exception(hc.err);
   const double t_nifs = now();
 

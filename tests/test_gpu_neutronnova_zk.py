@@ -48,7 +48,7 @@ def test_prove_matches_oracle_synthetic_steps(ctx, n, groups):
 
 
 def test_shared_and_precommitted_segments(ctx):
-    mk = lambda ws: frontend.synthetic_circuit(30, 0x77, num_public=2, shared_permille=300, precommitted_permille=700, witness_seed=ws)
+    mk = lambda ws: frontend.synthetic_circuit(30, 0x77, num_public=2, shared_permille=300, precommitted_permille=1000, witness_seed=ws)
     # every circuit shares step 0's shared witness (src/neutronnova_zk.rs:1485-1488): build the others with the same shared segment
     steps = [mk(5), mk(5), mk(5)]
     core = mk(5)
