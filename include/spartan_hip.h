@@ -75,6 +75,12 @@ int sp_table_gather_strided(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp
 int sp_table_read(sp_ctx* ctx, const sp_table* t, size_t off, size_t cnt, uint64_t* out);
 int sp_table_info(const sp_table* t, size_t* len, size_t* lo_eff, size_t* hi_eff);
 int sp_table_set_len(sp_table* t, size_t len, size_t lo_eff, size_t hi_eff);
+/* Non-owning window [off, off + len) onto t's storage (valid while t lives; free with sp_table_free, which leaves the storage alone): the slices
+ * of an all-gathered buffer handed to sp_fold_tables, a row block of a witness. */
+int sp_table_view(const sp_table* t, size_t off, size_t len, sp_table** out);
+/* The device address of the table (and the bytes allocated behind it) for a collective the caller issues itself (ncclAllGather on layers:
+ * SURVEY.md 8(e)); work queued on the context must be complete (sp_ctx_synchronize) before another stream touches it. */
+int sp_table_device_ptr(const sp_table* t, void** out, size_t* cap_bytes);
 void sp_table_free(sp_table* t);
 /* MultilinearPolynomial::bind_poly_var_top(&r) (:95-164): in place, len halves, all three zero-structure branches */
 int sp_table_bind_top(sp_ctx* ctx, sp_table* t, const uint64_t r[4]);

@@ -13,7 +13,9 @@
 //
 // Constraint ORDER inside the verifier circuit follows the reference's synthesis order statement by statement (it fixes the matrices, hence the
 // vc witness layout and every commitment). bellpepper's AllocatedNum::{mul, square, inputize} are restated as: allocate, then one constraint.
-// PARITY: pinned only through the restated verifier (prove -> verify accepts, tampering is rejected) — the reference cannot be run here.
+// PARITY UNPINNED against the reference: no golden vector of this wrapper exists in the reference tree and the reference cannot be run here. What
+// holds it in place is the restated verifier (prove -> verify accepts, tampering is rejected) and the pinned pieces underneath (transcript,
+// sum-checks, NIFS rounds, Hyrax: oracle/spartan.hpp, oracle/nifs.hpp).
 // Substitution: the vk digest is Keccak-256 over the digests of S_step, S_core and the vc shape (reference: SHA-256 over bincode, unpinned).
 #pragma once
 #include <array>

@@ -283,6 +283,22 @@ int sp_table_set_len(sp_table* t, size_t len, size_t lo_eff, size_t hi_eff) {
   t->hi_eff = hi_eff;
   return SP_OK;
 }
+int sp_table_view(const sp_table* t, size_t off, size_t len, sp_table** out) {
+  if (!t || off > t->cap || len > t->cap - off) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_view: window outside the allocation");
+  sp_table* v = new sp_table();
+  v->ctx = t->ctx;
+  v->d = t->d + off;
+  v->cap = v->len = len;
+  v->view = true;
+  *out = v;
+  return SP_OK;
+}
+int sp_table_device_ptr(const sp_table* t, void** out, size_t* cap_bytes) {
+  if (!t || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_device_ptr: null argument");
+  *out = t->d;
+  if (cap_bytes) *cap_bytes = t->cap * sizeof(fe_t);
+  return SP_OK;
+}
 void sp_table_free(sp_table* t) {
   if (!t) return;
   if (t->d && !t->view) hipFree(t->d);
@@ -1024,9 +1040,23 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       if (len >= STREAM_MIN_Q && len % 1024 == 0) {  // streaming form: lazy sums, lazy second stage
         spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
         const unsigned seq = next_seq(c);
-        const size_t blocks = len / 1024;
+        static const int lowhi_ppt = [] {
+          const char* e = getenv("SPARTAN_EQ_PPT");
+          const int v = e ? atoi(e) : 4;
+          return v == 1 || v == 2 ? v : 4;
+        }();
+        const size_t hi_max = sp::eff_hi(A) > sp::eff_hi(B) ? sp::eff_hi(A) : sp::eff_hi(B);
+        const bool lowhi = hi_max <= len / 2;  // short non-zero prefix in the high halves: dot-product form
+        const size_t blocks = len / (256 * (size_t)(lowhi ? lowhi_ppt : 4));
         c->timed("eval_quad", 64ull * len + 32ull * ((sp::eff_hi(A) < len ? sp::eff_hi(A) : len) + (sp::eff_hi(B) < len ? sp::eff_hi(B) : len)), [&] {
-          hipLaunchKernelGGL((spk::k_eval_quad_stream<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
+          if (lowhi && lowhi_ppt == 1)
+            hipLaunchKernelGGL((spk::k_eval_quad_stream_lowhi<1>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
+          else if (lowhi && lowhi_ppt == 2)
+            hipLaunchKernelGGL((spk::k_eval_quad_stream_lowhi<2>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
+          else if (lowhi)
+            hipLaunchKernelGGL((spk::k_eval_quad_stream_lowhi<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
+          else
+            hipLaunchKernelGGL((spk::k_eval_quad_stream<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
         });
         hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, blocks, 2, (const fe_t*)nullptr, c->d_pinned, seq);
         c->pending_slots = 0;
@@ -1446,6 +1476,17 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       c->timed("eval_cubic", 64ull * half, [&] {
         if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_products_stream<0>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
         else hipLaunchKernelGGL((spk::k_eval_products_stream<1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
+      });
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
+                         c->d_pinned, seq);
+      c->pending_slots = 0;
+    } else if (half >= STREAM_MIN_Q && half % 256 == 0 && (e1.mode == 0 || (e1.mode == 1 && e1.s >= 8))) {
+      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
+      const unsigned seq = next_seq(c);
+      const dim3 gs((unsigned)(half / 256)), bs(256);
+      c->timed("eval_cubic", 160ull * half, [&] {
+        if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_cubic_stream<0>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
+        else hipLaunchKernelGGL((spk::k_eval_cubic_stream<1>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
       });
       hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
                          c->d_pinned, seq);

@@ -408,6 +408,20 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict
   const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
 }
+// Round 1 of the cubic sum-check straight from the tables, streaming form (one pair per lane, all five element loads and the weight issued before
+// the first product, lazy wave sums; k_sum_partials_lazy applies eq_out per group): for tables past the L2s, where k_eval_cubic's modular
+// block tree and 8-pair loop leave it at 42-44 % of the HBM rate. half must be a multiple of 256 and, in factored mode, 2^s >= 256.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_eval_cubic_stream(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
+                                                           const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t a0 = A[id], a1 = A[id + half], b0 = B[id], b1 = B[id + half], c0 = C[id];
+  const fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
 template <int MODE>
 __global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __restrict__ P0, const fe_t* __restrict__ P1, const fe_t* __restrict__ eq_in, int s,
                                                               lazy9_t* __restrict__ partials) {
@@ -465,6 +479,35 @@ __global__ void __launch_bounds__(256) k_eval_quad_stream(const fe_t* __restrict
     l0 = lazy_add(l0, lazy_from(fe_mul<S>(a0, b0)));
     l1 = lazy_add(l1, lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0))));
   }
+  stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
+}
+// The same sums when the high halves are zero beyond a short prefix (hi = max(hiA, hiB) << half: the inner sum-check's round 0 on z = [W | 1 | X | 0...]
+// and poly_ABC, src/spartan.rs:323-384). A pair whose partners are both zero contributes a0 b0 to BOTH sums, so the pass is one product per pair
+// - a dot product of the low halves - and only the lanes below hi pay the second product; their term enters as (a1 - a0)(b1 - b0) - a0 b0 and the
+// dot is added to the second accumulator once at the end. All 2 PPT element loads of a lane are issued before the first product.
+template <int PPT>
+__global__ void __launch_bounds__(256) k_eval_quad_stream_lowhi(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t hiA, size_t hiB,
+                                                                lazy9_t* __restrict__ partials) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t id0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  fe_t a0[PPT], b0[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    a0[k] = A[id0 + k * stride];
+    b0[k] = B[id0 + k * stride];
+  }
+  lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const size_t id = id0 + k * stride;
+    const fe_t p = fe_mul<S>(a0[k], b0[k]);
+    l0 = lazy_add(l0, lazy_from(p));
+    if (id < hiA || id < hiB) {
+      const fe_t a1 = id < hiA ? A[id + half] : fe_zero(), b1 = id < hiB ? B[id + half] : fe_zero();
+      l1 = lazy_add(l1, lazy_from(fe_sub<S>(fe_mul<S>(fe_sub<S>(a1, a0[k]), fe_sub<S>(b1, b0[k])), p)));
+    }
+  }
+  l1 = lazy_add(l1, l0);
   stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
 }
 // Second stage for the streaming kernels: per group of 2^group_log2 consecutive blocks, lazy-sum, reduce mod p, multiply by

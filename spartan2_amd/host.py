@@ -253,6 +253,35 @@ def nifs_prove(ctx: hip.Context, shape: hip.Shape, dims: dict, ck: hip.Commitmen
     return out
 
 
+def nifs_prove_sharded(ctx: hip.Context, comm, shape: hip.Shape, dims: dict, ck: hip.CommitmentKey, comms_local, X_local, W_tables_local, r_W_local, small_values: bool,
+                       tr: hip.Transcript, py_hook):
+    """NeutronNovaNIFS::prove with the instances sharded over the ranks of `comm` (spartan2_amd/host/neutronnova_nifs.cpp nifs_prove_sharded,
+    SURVEY.md 8(e)): this rank passes its n_local consecutive instances; every rank returns the same outputs as `nifs_prove` on the whole batch."""
+    comms_local = np.ascontiguousarray(comms_local, dtype=np.uint64)
+    n_local, rows = comms_local.shape[0], comms_local.shape[1]
+    d = dims["num_public"]
+    X_local = np.ascontiguousarray(X_local, dtype=np.uint64).reshape(n_local, d, 4)
+    r_W_local = np.ascontiguousarray(r_W_local, dtype=np.uint64).reshape(n_local, rows, 4)
+    n = n_local * comm.world
+    ell_b = n.bit_length() - 1
+    _, left, right = tensor_decomp(dims["num_cons"])
+    N, nv = dims["num_cons"], dims["num_shared"] + dims["num_precommitted"] + dims["num_rest"]
+    out = dict(polys=np.zeros((ell_b, 4, 4), dtype=np.uint64), r_bs=np.zeros((ell_b, 4), dtype=np.uint64), E_eq=np.zeros((left + right, 4), dtype=np.uint64),
+               tail=np.zeros((2, 4), dtype=np.uint64), folded_rW=np.zeros((rows, 4), dtype=np.uint64), folded_X=np.zeros((max(d, 1), 4), dtype=np.uint64),
+               folded_comm=np.zeros((rows, 8), dtype=np.uint64))
+    tabs = dict(A=hip.Table.zeros(ctx, N), B=hip.Table.zeros(ctx, N), C=hip.Table.zeros(ctx, N), folded_W=hip.Table.zeros(ctx, nv))
+    d10 = (ctypes.c_uint64 * 10)(*[dims[k] for k in DIM_NAMES])
+    warr = (ctypes.c_void_p * n_local)(*[t.h for t in W_tables_local])
+    cb = _c_hook(py_hook)
+    _check(lib().nn_nifs_prove_sharded(ctx.h, comm.h, shape.h, d10, ck.h, ctypes.c_size_t(n_local), ctypes.c_size_t(rows), hip.p64(comms_local.reshape(-1)),
+                                       hip.p64(X_local.reshape(-1)) if d else None, warr, hip.p64(r_W_local.reshape(-1)), 1 if small_values else 0, tr.h, cb, None,
+                                       hip.p64(out["polys"]), hip.p64(out["r_bs"]), hip.p64(out["E_eq"]), hip.p64(out["tail"]), hip.p64(out["folded_rW"]),
+                                       hip.p64(out["folded_X"]), hip.p64(out["folded_comm"]), tabs["A"].h, tabs["B"].h, tabs["C"].h, tabs["folded_W"].h))
+    out["folded_X"] = out["folded_X"][:d]
+    out.update(tabs)
+    return out
+
+
 # ---- multi-GPU: the exchange layer and the sharded prover (spartan2_amd/host/{comm.hpp, sharded_snark.cpp}) -----------------------------
 _ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 

@@ -109,6 +109,30 @@ struct Comm {
     hipck(hipStreamSynchronize(st), "comm: synchronize");
     memcpy(recv, h_recv, bytes * world);
   }
+  // The same for buffers that live in device memory (the layer hand-off of the sharded NIFS rounds: tens of MiB per rank): RCCL gathers straight
+  // from / into them over xGMI; the callback backend stages through the host. The caller has synchronised the stream that produced d_src, and
+  // the call returns with d_dst complete. d_dst must not overlap d_src.
+  void allgather_device(const void* d_src, size_t bytes, void* d_dst) {
+    ++calls;
+    bytes_moved += bytes * world;
+    if (fn) {
+      std::vector<uint8_t> hs(bytes), hr(bytes * world);
+      hipck(hipMemcpy(hs.data(), d_src, bytes, hipMemcpyDeviceToHost), "comm: D2H");
+      int rc = fn(user, hs.data(), bytes, hr.data());
+      if (rc) throw Error(SP_ERR_INTERNAL, "comm: the all-gather callback failed");
+      hipck(hipMemcpy(d_dst, hr.data(), bytes * world, hipMemcpyHostToDevice), "comm: H2D");
+      return;
+    }
+    if (!nc) {
+      if (world != 1) throw Error(SP_ERR_INTERNAL, "comm: no backend");
+      hipck(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice), "comm: D2D");
+      return;
+    }
+    hipck(hipSetDevice(device), "comm: hipSetDevice");
+    ncclResult_t r = RcclApi::get().AllGather(d_src, d_dst, bytes, ncclUint8, nc, st);
+    if (r != ncclSuccess) throw Error(SP_ERR_INTERNAL, std::string("ncclAllGather: ") + RcclApi::get().GetErrorString(r));
+    hipck(hipStreamSynchronize(st), "comm: synchronize");
+  }
   // field sum over ranks of `count` elements, in rank order, in place (the reduce step of a slice-sharded sum-check round)
   void field_sum(fe_t* vals, size_t count) {
     if (world == 1) return;

@@ -7,6 +7,8 @@
 // fold (fold_multiple), the commitment fold (fold_commitments[_partial]).
 #include "neutronnova_nifs.hpp"
 
+#include "comm.hpp"
+
 namespace spartan2 {
 
 void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right) {  // src/neutronnova_zk.rs:56-67
@@ -160,6 +162,203 @@ void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const s
   lap("fold_commitments");
 }
 
+
+// NeutronNovaNIFS::prove with the 2^ell_b instances sharded over the ranks of `comm` (BASELINE config 5): rank g holds the
+// n_local = n / world consecutive instances [g n_local, (g + 1) n_local) - their witness tables, commitments, publics, blinds - and builds only
+// their (Az, Bz, Cz) layers. Exchanges: the instances' commitments / publics / blinds once (the transcript absorbs every U), c_vals once, TWO field
+// elements per round for the first log2(n_local) rounds (all-gather + modular adds in rank order: every rank holds identical totals and runs the
+// O(1) finish and the deterministic hook redundantly, no broadcast), then ONE bulk exchange - each rank's single remaining A / B layer, gathered
+// by every rank (device to device over the collective) - after which all ranks run the last log2(world) rounds on identical data, and the
+// partial C / witness folds (one layer / one witness per rank) summed on every rank. Results are identical on all ranks and bit-identical to
+// nifs_prove on the whole batch. n must be a power of two and n_local >= 2.
+void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp_dims& dims, const sp_ck* ckey, size_t n_local, size_t rows, const aff_t* comms_local,
+                        const fe_t* X_local, const sp_table* const* Ws_local, const fe_t* r_W_local, bool small_values, sp_transcript* tr, nn_round_hook hook, void* user,
+                        NifsOutputs& out) {
+  const size_t world = (size_t)comm.world, rank = (size_t)comm.rank, n = n_local * world;
+  if (n_local < 2 || (n_local & (n_local - 1)) || (world & (world - 1)))
+    throw Error(SP_ERR_INVALID_INPUT_LENGTH, "sharded NIFS: instances per rank and ranks must be powers of two, at least two instances per rank");
+  const size_t d = dims.num_public, num_vars = dims.num_shared + dims.num_precommitted + dims.num_rest;
+  size_t ell_b = 0, local_rounds = 0;
+  while ((size_t(1) << ell_b) < n) ++ell_b;
+  while ((size_t(1) << local_rounds) < n_local) ++local_rounds;
+
+  // every instance's U = (comm_W, X) and blinds on every rank (64 rows + 32 d + 32 rows bytes per instance)
+  const size_t rec = rows * sizeof(aff_t) + d * sizeof(fe_t) + rows * sizeof(fe_t);
+  std::vector<uint8_t> mine(n_local * rec), all(n * rec);
+  for (size_t i = 0; i < n_local; ++i) {
+    uint8_t* p = mine.data() + i * rec;
+    memcpy(p, comms_local + i * rows, rows * sizeof(aff_t));
+    if (d) memcpy(p + rows * sizeof(aff_t), X_local + i * d, d * sizeof(fe_t));
+    memcpy(p + rows * sizeof(aff_t) + d * sizeof(fe_t), r_W_local + i * rows, rows * sizeof(fe_t));
+  }
+  comm.allgather(mine.data(), mine.size(), all.data());
+  std::vector<aff_t> comms(n * rows);
+  std::vector<fe_t> X(n * d), r_W(n * rows);
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t* p = all.data() + i * rec;
+    memcpy(&comms[i * rows], p, rows * sizeof(aff_t));
+    if (d) memcpy(&X[i * d], p + rows * sizeof(aff_t), d * sizeof(fe_t));
+    memcpy(&r_W[i * rows], p + rows * sizeof(aff_t) + d * sizeof(fe_t), rows * sizeof(fe_t));
+  }
+
+  auto absorb = [&](const char* label, const uint8_t* b, size_t len) { ck(sp_transcript_absorb(tr, (const uint8_t*)label, strlen(label), b, len), "absorb"); };
+  auto squeeze = [&](const char* label) {
+    fe_t f;
+    ck(sp_transcript_squeeze(tr, (const uint8_t*)label, strlen(label), u64p(&f)), "squeeze");
+    return f;
+  };
+  for (size_t i = 0; i < n; ++i) {  // transcript.absorb(b"U", U) (:553-555)
+    std::vector<uint8_t> b = commitment_bytes(&comms[i * rows], rows);
+    const size_t off = b.size();
+    b.resize(off + 32 * d);
+    for (size_t j = 0; j < d; ++j) sp::fe_to_be_bytes<S>(X[i * d + j], b.data() + off + 32 * j);
+    absorb("U", b.data(), b.size());
+  }
+  {
+    uint8_t zero_be[32] = {0};  // T = 0 (:556-557)
+    absorb("T", zero_be, 32);
+  }
+  size_t ell_cons, left, right;
+  compute_tensor_decomp(dims.num_cons, &ell_cons, &left, &right);
+  const size_t total = left * right;
+  const fe_t tau = squeeze("tau");
+  ck(sp_pow_split_evals(u64p(&tau), ell_cons, left, right, out.E_eq), "split_evals");
+  std::vector<fe_t> rhos(ell_b);
+  for (auto& r : rhos) r = squeeze("rho");
+
+  struct Objs {
+    sp_nifs *loc = nullptr, *root = nullptr;
+    std::vector<sp_table*> t;
+    ~Objs() {
+      for (sp_table* x : t) sp_table_free(x);
+      sp_nifs_free(loc);
+      sp_nifs_free(root);
+    }
+  } o;
+  auto keep = [&](sp_table* t) {
+    o.t.push_back(t);
+    return t;
+  };
+  auto dev = [&](const sp_table* t) {
+    void* p = nullptr;
+    ck(sp_table_device_ptr(t, &p, nullptr), "device_ptr");
+    return p;
+  };
+  o.loc = nifs_prepare(ctx, shape, dims, n_local, X_local, Ws_local, small_values);
+  ck(sp_nifs_begin_shard(o.loc, out.E_eq, u64p(rhos.data()), ell_b, rank * n_local, small_values ? 2 : 0), "nifs_begin_shard");
+  std::vector<fe_t> cv_loc(n_local), cv(n);
+  ck(sp_nifs_cvals(o.loc, u64p(cv_loc.data())), "nifs_cvals");
+  comm.allgather(cv_loc.data(), n_local * sizeof(fe_t), cv.data());
+  ck(sp_nifs_set_cvals(o.loc, u64p(cv.data()), n), "nifs_set_cvals");
+
+  std::vector<fe_t> r_bs(ell_b);
+  for (size_t t = 0; t < local_rounds; ++t) {  // the data-parallel rounds: own pairs, two field elements exchanged
+    fe_t sums[2];
+    ck(sp_nifs_round_sums(o.loc, t, u64p(sums)), "nifs_round_sums");
+    comm.field_sum(sums, 2);
+    uint64_t* co = out.polys + 16 * t;
+    ck(sp_nifs_round_finish(o.loc, t, u64p(sums), co), "nifs_round_finish");
+    hook(user, t, co, u64p(&r_bs[t]));
+    ck(sp_nifs_challenge(o.loc, u64p(&r_bs[t])), "nifs_challenge");
+  }
+  sp_nifs* fin = o.loc;
+  if (world > 1) {
+    // hand-off: apply the pending fold; every rank gathers every rank's remaining A / B layer and continues on identical data
+    ck(sp_nifs_fold_pending(o.loc), "nifs_fold_pending");
+    fe_t T_cur, acc_eq;
+    ck(sp_nifs_state(o.loc, u64p(&T_cur), u64p(&acc_eq)), "nifs_state");
+    ck(sp_nifs_create(ctx, world, left, right, &o.root), "nifs_create");
+    ck(sp_ctx_synchronize(ctx), "synchronize");
+    for (int which = 0; which < 2; ++which) {
+      sp_table *src = nullptr, *dst = nullptr;
+      ck(sp_nifs_current_layer(o.loc, which, 0, &src), "nifs_current_layer");
+      keep(src);
+      ck(sp_nifs_layer(o.root, which, 0, &dst), "nifs_layer");  // the root object's layers are contiguous: layer b at offset b * total
+      keep(dst);
+      comm.allgather_device(dev(src), total * sizeof(fe_t), dev(dst));
+    }
+    ck(sp_nifs_resume(o.root, out.E_eq, u64p(rhos.data()), ell_b, local_rounds, u64p(r_bs.data()), u64p(&T_cur), u64p(&acc_eq), u64p(cv.data())), "nifs_resume");
+    for (size_t t = local_rounds; t < ell_b; ++t) {
+      uint64_t* co = out.polys + 16 * t;
+      ck(sp_nifs_round(o.root, t, co), "nifs_round");
+      hook(user, t, co, u64p(&r_bs[t]));
+      ck(sp_nifs_challenge(o.root, u64p(&r_bs[t])), "nifs_challenge");
+    }
+    fin = o.root;
+  }
+  memcpy(out.r_bs, r_bs.data(), ell_b * sizeof(fe_t));
+  std::vector<fe_t> w(n);
+  ck(sp_weights_from_r(u64p(r_bs.data()), ell_b, n, u64p(w.data())), "weights_from_r");
+  std::vector<fe_t> ones(world, fe_one<S>());
+  // sum over ranks of one device vector per rank: gather into `buf` (world x len), fold the windows with unit weights
+  auto sum_over_ranks = [&](const sp_table* part, size_t len, sp_table* dst) {
+    sp_table* buf = nullptr;
+    ck(sp_table_zeros(ctx, world * len, (size_t)-1, (size_t)-1, &buf), "alloc");
+    keep(buf);
+    ck(sp_ctx_synchronize(ctx), "synchronize");
+    comm.allgather_device(dev(part), len * sizeof(fe_t), dev(buf));
+    std::vector<const sp_table*> views(world);
+    for (size_t g = 0; g < world; ++g) {
+      sp_table* v = nullptr;
+      ck(sp_table_view(buf, g * len, len, &v), "view");
+      views[g] = keep(v);
+    }
+    ck(sp_fold_tables(ctx, views.data(), world, u64p(ones.data()), len, dst), "sum over ranks");
+  };
+  if (world == 1) {
+    ck(sp_nifs_finish(fin, out.A, out.B, out.C, out.tail, out.tail + 4), "nifs_finish");
+  } else {
+    ck(sp_nifs_finish(fin, out.A, out.B, nullptr, out.tail, out.tail + 4), "nifs_finish");
+    // Cz = sum_b w_b Cz_b (:1168-1203): the C layers never move; each rank folds its own with its slice of the weights
+    std::vector<const sp_table*> cl(n_local);
+    for (size_t i = 0; i < n_local; ++i) {
+      sp_table* v = nullptr;
+      ck(sp_nifs_layer(o.loc, 2, i, &v), "nifs_layer");
+      cl[i] = keep(v);
+    }
+    sp_table* part = nullptr;
+    ck(sp_table_zeros(ctx, total, (size_t)-1, (size_t)-1, &part), "alloc");
+    keep(part);
+    ck(sp_fold_tables(ctx, cl.data(), n_local, u64p(w.data() + rank * n_local), total, part), "fold C");
+    sum_over_ranks(part, total, out.C);
+  }
+  {
+    uint64_t finw[16] = {0}, ignored[4];
+    memcpy(finw, out.tail, 64);
+    hook(user, ell_b, finw, ignored);
+  }
+  // fold_witnesses (:1212-1231)
+  const size_t effective_len = dims.num_shared + dims.num_precommitted;
+  const bool truncated = effective_len > 0;
+  const size_t dim = truncated ? effective_len : num_vars;
+  if (world == 1) {
+    ck(sp_fold_tables(ctx, Ws_local, n_local, u64p(w.data()), dim, out.folded_W), "fold_multiple");
+  } else {
+    sp_table* part = nullptr;
+    ck(sp_table_zeros(ctx, dim, (size_t)-1, (size_t)-1, &part), "alloc");
+    keep(part);
+    ck(sp_fold_tables(ctx, Ws_local, n_local, u64p(w.data() + rank * n_local), dim, part), "fold_multiple");
+    sum_over_ranks(part, dim, out.folded_W);
+  }
+  if (dim < num_vars) ck(sp_table_zero(ctx, out.folded_W, dim, num_vars - dim), "zero rest");
+  ck(sp_table_set_len(out.folded_W, num_vars, (size_t)-1, (size_t)-1), "set_len");
+  // fold_blinds, X fold, fold_commitments on the gathered instance data: O(n rows) work, done redundantly on every rank
+  std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t r = 0; r < rows; ++r) f_rW[r] = fe_add<S>(f_rW[r], fe_mul<S>(r_W[i * rows + r], w[i]));
+    for (size_t j = 0; j < d; ++j) f_X[j] = fe_add<S>(f_X[j], fe_mul<S>(w[i], X[i * d + j]));
+  }
+  memcpy(out.folded_rW, f_rW.data(), rows * sizeof(fe_t));
+  memcpy(out.folded_X, f_X.data(), d * sizeof(fe_t));
+  size_t data_rows = truncated ? (effective_len + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH : rows;
+  if (data_rows > rows) data_rows = rows;
+  std::vector<aff_t> bases(data_rows * n);
+  for (size_t r = 0; r < data_rows; ++r)
+    for (size_t i = 0; i < n; ++i) bases[r * n + i] = comms[i * rows + r];
+  if (data_rows) ck(sp_msm_shared_weights(ctx, u64p(w.data()), n, (const uint64_t*)bases.data(), data_rows, out.folded_comm), "fold_commitments");
+  if (data_rows < rows) ck(sp_fixed_base_mul_h(ctx, ckey, u64p(f_rW.data() + data_rows), rows - data_rows, out.folded_comm + 8 * data_rows), "rest rows");
+}
+
 }  // namespace spartan2
 
 using namespace spartan2;
@@ -196,6 +395,28 @@ int nn_nifs_prove(sp_ctx* ctx, const sp_shape* S, const uint64_t dims10[10], con
     memcpy(&dims, dims10, sizeof(sp_dims));
     NifsOutputs o{out_polys, out_r_bs, out_E, out_tail, out_folded_rW, out_folded_X, out_folded_comm, out_A, out_B, out_C, out_folded_W};
     nifs_prove(ctx, S, dims, ckey, n, rows, (const aff_t*)comms, (const fe_t*)X, Ws, (const fe_t*)r_W, small_values != 0, prepared, tr, hook, user, o);
+    return SP_OK;
+  } catch (const Error& e) {
+    ss_set_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    ss_set_error(e.what());
+    return SP_ERR_INTERNAL;
+  }
+}
+
+// The sharded form: `comm` is an ssc_comm_* handle; *_local arguments describe this rank's n_local instances; outputs as nn_nifs_prove, identical on
+// every rank (polys / r_bs: ell_b = log2(n_local * world) rounds).
+int nn_nifs_prove_sharded(sp_ctx* ctx, void* comm, const sp_shape* S, const uint64_t dims10[10], const sp_ck* ckey, size_t n_local, size_t rows, const uint64_t* comms_local,
+                          const uint64_t* X_local, const sp_table* const* Ws_local, const uint64_t* r_W_local, int small_values, sp_transcript* tr, nn_round_hook hook, void* user,
+                          uint64_t* out_polys, uint64_t* out_r_bs, uint64_t* out_E, uint64_t* out_tail, uint64_t* out_folded_rW, uint64_t* out_folded_X,
+                          uint64_t* out_folded_comm, sp_table* out_A, sp_table* out_B, sp_table* out_C, sp_table* out_folded_W) {
+  try {
+    sp_dims dims;
+    memcpy(&dims, dims10, sizeof(sp_dims));
+    NifsOutputs o{out_polys, out_r_bs, out_E, out_tail, out_folded_rW, out_folded_X, out_folded_comm, out_A, out_B, out_C, out_folded_W};
+    nifs_prove_sharded(ctx, *(Comm*)comm, S, dims, ckey, n_local, rows, (const aff_t*)comms_local, (const fe_t*)X_local, Ws_local, (const fe_t*)r_W_local, small_values != 0, tr,
+                       hook, user, o);
     return SP_OK;
   } catch (const Error& e) {
     ss_set_error(e.what());

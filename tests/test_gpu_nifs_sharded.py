@@ -83,3 +83,82 @@ def test_two_ranks_on_one_gpu(n_inst, num_cons, small):
 
     res = mp_util.run_ranks(_worker, 2, (n_inst, num_cons, small))
     assert res[1] is None and res[0] == (True,) * 7
+
+
+def _worker_cpp(rank, world, port, q, n_inst, groups, small):
+    """The C++ driver (spartan2_amd/host/neutronnova_nifs.cpp nifs_prove_sharded) over the callback exchange backend: the whole of
+    NeutronNovaNIFS::prove - preamble, layers by SpMV on the rank's own instances, rounds, hand-off, C / witness / commitment folds."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes
+
+    import oracle_lib as ol
+    import test_gpu_nifs_prove as tnp
+    from spartan2_amd import dist as spd, frontend, hip, host
+
+    g = spd.Group(backend="gloo")
+    ctx = hip.Context(0)
+    L = ol.lib()
+    okey = ctypes.c_void_p(L.orc_hyrax_setup(b"ck", ctypes.c_size_t(2048)))
+    ck_aff, h_aff = np.zeros((2048, 8), dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    L.orc_hyrax_key_export(okey, ol.p64(ck_aff), ol.p64(h_aff))
+    ck = hip.CommitmentKey(ctx, ck_aff, h_aff)
+    insts = [frontend.synthetic_circuit(groups, 5, num_public=2, shared_permille=150, precommitted_permille=450, witness_seed=100 + s) for s in range(n_inst)]
+    oshape, shape, dims, Ws, X, r_W, comms = tnp._setup(ctx, okey, insts, np.random.default_rng(77))
+    want = ol.nifs_prove(oshape, okey, comms, X, Ws, r_W, small, ol.Transcript(b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+    n_local = n_inst // world
+    lo = rank * n_local
+    comm = host.Comm(rank, world, "torch")
+    tabs = [hip.Table.from_host(ctx, w) for w in Ws[lo : lo + n_local]]
+    got = host.nifs_prove_sharded(ctx, comm, shape, dims, ck, comms[lo : lo + n_local], X[lo : lo + n_local], tabs, r_W[lo : lo + n_local], small,
+                                  hip.Transcript(ctx, b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+    N, nv = oshape.num_cons, oshape.num_vars
+    ok = [bool((want[k] == got[k]).all()) for k in ("polys", "r_bs", "E_eq", "tail", "folded_rW", "folded_X", "folded_comm")]
+    ok += [bool((want[k] == got[k].read(0, m)).all()) for k, m in (("A", N), ("B", N), ("C", N), ("folded_W", nv))]
+    q.put((rank, (tuple(ok), comm.stats()["exchanges"])))
+    comm.close()
+    ctx.close()
+    g.close()
+
+
+@pytest.mark.parametrize("n_inst,groups,small", [(4, 60, True), (8, 30, False)])
+def test_cpp_driver_two_ranks_on_one_gpu(n_inst, groups, small):
+    import mp_util
+
+    res = mp_util.run_ranks(_worker_cpp, 2, (n_inst, groups, small))
+    for r in (0, 1):
+        ok, exchanges = res[r]
+        assert ok == (True,) * 11, (r, ok)
+    # instance data + c_vals + one exchange per local round + 2 layers + C partial + witness partial
+    assert res[0][1] == res[1][1] == 2 + (n_inst // 2).bit_length() - 1 + 4
+
+
+def test_cpp_driver_one_rank_rccl():
+    """World of one over a real one-rank RCCL communicator: the production exchange backend, every all-gather a device / pinned-host round trip."""
+    import ctypes
+
+    import oracle_lib as ol
+    import test_gpu_nifs_prove as tnp
+    from spartan2_amd import frontend, hip, host
+
+    ctx = hip.Context(0)
+    L = ol.lib()
+    okey = ctypes.c_void_p(L.orc_hyrax_setup(b"ck", ctypes.c_size_t(2048)))
+    ck_aff, h_aff = np.zeros((2048, 8), dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    L.orc_hyrax_key_export(okey, ol.p64(ck_aff), ol.p64(h_aff))
+    ck = hip.CommitmentKey(ctx, ck_aff, h_aff)
+    insts = [frontend.synthetic_circuit(40, 5, num_public=2, precommitted_permille=1000, witness_seed=300 + s) for s in range(4)]
+    oshape, shape, dims, Ws, X, r_W, comms = tnp._setup(ctx, okey, insts, np.random.default_rng(78))
+    want = ol.nifs_prove(oshape, okey, comms, X, Ws, r_W, True, ol.Transcript(b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+    comm = host.Comm(0, 1, "rccl", device=0)
+    tabs = [hip.Table.from_host(ctx, w) for w in Ws]
+    got = host.nifs_prove_sharded(ctx, comm, shape, dims, ck, comms, X, tabs, r_W, True, hip.Transcript(ctx, b"neutronnova_prove"),
+                                  ol.transcript_round_hook(ol.Transcript(b"vc")))
+    for key in ("polys", "r_bs", "E_eq", "tail", "folded_rW", "folded_X", "folded_comm"):
+        assert (want[key] == got[key]).all(), key
+    for key, m in (("A", oshape.num_cons), ("B", oshape.num_cons), ("C", oshape.num_cons), ("folded_W", oshape.num_vars)):
+        assert (want[key] == got[key].read(0, m)).all(), key
+    comm.close()
+    L.orc_hyrax_free(okey)
+    ctx.close()
