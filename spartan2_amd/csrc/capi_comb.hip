@@ -12,12 +12,12 @@ namespace sp {
 
 // ---- fixed-base comb path for many rows over the key (kernels_comb.cuh) ---------------------------------------------------------------------------
 // SPARTAN_COMB_BITS = signed window width C (8, 10, 12, 13 or 14; 0 disables the path): the table takes ceil(257 / C) * num_cols * 2^(C-1) * 64 bytes
-// (C = 12, 2048 bases: 5.9 GB; C = 14: 20 GB). SPARTAN_COMB_MIN_ROWS = how many digit-path rows one commit must have before the table is built.
+// (2048 bases: C = 12: 5.9 GB, C = 13 (default): 10.7 GB, C = 14: 20 GB; measured sweep in profiles/r02_comb_bits_sweep.txt). SPARTAN_COMB_MIN_ROWS = how many digit-path rows one commit must have before the table is built.
 static int comb_bits() {
   static const int v = [] {
     const char* e = getenv("SPARTAN_COMB_BITS");
-    int b = e ? atoi(e) : 12;
-    if (b != 0 && b != 8 && b != 10 && b != 12 && b != 13 && b != 14) b = 12;
+    int b = e ? atoi(e) : 13;
+    if (b != 0 && b != 8 && b != 10 && b != 12 && b != 13 && b != 14) b = 13;
     return b;
   }();
   return v;

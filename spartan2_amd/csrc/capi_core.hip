@@ -993,7 +993,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
         c->timed("bind_stream_quad", 48ull * A->len * 2, [&] {
           hipLaunchKernelGGL(spk::k_bind_eval_quad_stream, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, lp, mref);
         });
-        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
         c->pending_slots = 0;
       } else {
         c->timed("bind", 48ull * A->len * 2, [&] {
@@ -1015,7 +1015,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
         hipLaunchKernelGGL(spk::k_bind_eval_quad_stream_sparse, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, sp::eff_hi(A), sp::eff_hi(B), lp,
                            mref);
       });
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
       c->pending_slots = 0;
       sp::after_bind(A);
       sp::after_bind(B);
@@ -1058,7 +1058,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
           else
             hipLaunchKernelGGL((spk::k_eval_quad_stream<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
         });
-        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, blocks, 2, (const fe_t*)nullptr, c->d_pinned, seq);
+        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, blocks, 2, (const fe_t*)nullptr, c->d_pinned, seq);
         c->pending_slots = 0;
         waiting = true;
       } else if (len > 0) {
@@ -1442,7 +1442,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         else c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
       }
       // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
                          c->d_pinned, seq);
       c->pending_slots = 0;
       sp::after_bind(A);
@@ -1477,7 +1477,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_products_stream<0>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
         else hipLaunchKernelGGL((spk::k_eval_products_stream<1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
       });
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
                          c->d_pinned, seq);
       c->pending_slots = 0;
     } else if (half >= STREAM_MIN_Q && half % 256 == 0 && (e1.mode == 0 || (e1.mode == 1 && e1.s >= 8))) {
@@ -1488,7 +1488,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_cubic_stream<0>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
         else hipLaunchKernelGGL((spk::k_eval_cubic_stream<1>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
       });
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(256), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
+      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
                          c->d_pinned, seq);
       c->pending_slots = 0;
     } else {
