@@ -3,7 +3,7 @@
 (benches/sha256_spartan.rs:166-268: message vec![0u8; 2048], is_small = true, prove timed after warm-up proves on the same prep state). One prove
 per "step"; the prep state (witness, cached Az/Bz/Cz, keys, matrices) is resident in HBM when the timed region starts.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4]
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|c5]
 
 One process per GPU (torch.distributed.run for N > 1); the timed region is bracketed by barrier + torch.cuda.synchronize(), max over ranks.
 
@@ -12,6 +12,9 @@ One process per GPU (torch.distributed.run for N > 1); the timed region is brack
                          prefix is re-hashed in every prove (the cached-prefix variant is reported beside it, never as `value`).
   workload c3            every rank proves its own batch of 32 Sha256StepCircuit instances + the core circuit through NeutronNovaZkSNARK::prove
                          (BASELINE config 3, benches/sha256_neutronnova.rs); "weak", no data-path collective;
+  workload c5            NeutronNovaNIFS::prove over --instances (default 256) step instances of the 2 KiB SHA-256 shape (2^20 padded constraints
+                         each: BASELINE config 5), instances sharded over the N ranks (nifs_prove_sharded: two field elements exchanged per round, one
+                         bulk layer hand-off); the layers are prepared once as prep_prove does; "strong";
   workload c4            ONE proof of the synthetic 2^22 instance (BASELINE config 4, seed 0xDEADBEEF) sharded over the N ranks
                          (spartan2_amd/host/sharded_snark.cpp): rows/N Hyrax commitment, row-sliced Az/Bz/Cz, slice-sharded sum-checks with
                          one RCCL all-gather per round, column-sliced poly_ABC, point-range MSMs ("strong"); value = constraints / time.
@@ -140,7 +143,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=("c2", "c3", "c4"), default="c2")
+    ap.add_argument("--workload", choices=("c2", "c3", "c4", "c5"), default="c2")
+    ap.add_argument("--instances", type=int, default=256, help="workload c5: step instances in the batch (a power of two, >= 2 per rank)")
     ap.add_argument("--message-bytes", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sharded", action="store_true", help="skip the config-4 sharded legs (profiling runs)")
@@ -211,6 +215,83 @@ def main():
                     raise SystemExit("GPU proof differs from the oracle's or fails verification")
             print(json.dumps(out))
         nn.close()
+        comm.close()
+        ctx.close()
+        group.close()
+        return
+
+    if args.workload == "c5":
+        # ---- NeutronNova NIFS at config 5's size: 256 instances x 2^20 constraints, sharded by instance over the ranks
+        n_total = args.instances
+        n_local = n_total // world
+        if n_local < 2 or n_local * world != n_total or n_total & (n_total - 1):
+            raise SystemExit("--instances must be a power of two with at least two instances per rank")
+        CW = 2048  # DEFAULT_COMMITMENT_WIDTH (src/provider/pcs/hyrax_pc.rs)
+        distinct = [frontend.sha256_circuit(bytes([b]) * args.message_bytes) for b in (0, 1)]  # two witnesses, cycled over the batch
+        mats, dims = host.pad_shape(distinct[0])
+        shape = hip.Shape(ctx, mats, dims)
+        nv = dims["num_shared"] + dims["num_precommitted"] + dims["num_rest"]
+        rows = nv // CW
+        g = host.from_label(b"ck", CW + 1)
+        key = hip.CommitmentKey(ctx, g[:CW], g[CW])
+        src = [hip.Table.from_host(ctx, host.padded_witness_limbs(dims, c.witness)) for c in distinct]
+        X2 = [host.mont_limbs_from_u64(c.publics) for c in distinct]
+        rng = np.random.default_rng(0xC5 + rank)
+        tabs, comms, Xs, rWs = [], [], [], []
+        for i in range(n_local):
+            gi = rank * n_local + i
+            t = hip.Table.zeros(ctx, nv)
+            t.copy_from(0, src[gi & 1], 0, nv)
+            bl = rng.integers(0, 1 << 62, size=(rows, 4), dtype=np.uint64)
+            tabs.append(t)
+            comms.append(key.commit(t, 0, nv, bl, True))
+            Xs.append(X2[gi & 1])
+            rWs.append(bl)
+        comms, Xs, rWs = np.stack(comms), np.stack(Xs), np.stack(rWs)
+        prepared = host.nifs_prepare(ctx, shape, dims, Xs, tabs, True)
+        out_tabs = dict(A=hip.Table.zeros(ctx, dims["num_cons"]), B=hip.Table.zeros(ctx, dims["num_cons"]), C=hip.Table.zeros(ctx, dims["num_cons"]),
+                        folded_W=hip.Table.zeros(ctx, nv))
+
+        def one():
+            tr = hip.Transcript(ctx, b"neutronnova_prove")
+            vc = hip.Transcript(ctx, b"vc")  # stand-in for process_round: absorb the round polynomial, squeeze the challenge
+
+            def hook(t, co):
+                vc.absorb(b"p", np.ascontiguousarray(co, dtype=np.uint64).tobytes())
+                return vc.squeeze(b"c")
+
+            return host.nifs_prove_sharded(ctx, comm, shape, dims, key, comms, Xs, tabs, rWs, True, tr, hook, prepared=prepared, out_tabs=out_tabs)
+
+        for _ in range(args.warmup):
+            out = one()
+        ctx.reset_stats(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = one()
+        ctx.synchronize()
+        barrier()
+        elapsed = group.max_over_ranks(time.perf_counter() - t0)
+        names = ("nifs_round0_small", "nifs_round0", "nifs_fold_prove", "nifs_prove_pairs", "nifs_fold", "nifs_cvals", "fold_tables")
+        ks = {k_: ctx.kernel_stats(k_) for k_ in names}
+        ctx.reset_stats(False)
+        if rank == 0:
+            ncons = distinct[0].num_cons * n_total
+            res = {"metric": "NeutronNovaNIFS::prove over the step instances of one batch (layers prepared as prep_prove does): R1CS constraints folded per second",
+                   "value": ncons * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "u256 modular integer (8 x u32 Montgomery limbs); round 0 on the i64 mirrors (small-value mode)",
+                   "data": "synthetic: two distinct SHA-256 witnesses of the 2 KiB shape cycled over the batch, seeded blinds; process_round replaced by a plain transcript",
+                   "config": {"workload": f"NeutronNova NIFS, {n_total} step instances x 2^{dims['num_cons'].bit_length() - 1} constraints (BASELINE config 5), sharded by instance",
+                              "instances": n_total, "instances_per_rank": n_local, "num_cons_unpadded": distinct[0].num_cons, "num_cons": dims["num_cons"],
+                              "parallelism": f"{n_local} instances per rank over {world} ranks; 2 field elements exchanged per round, one layer hand-off",
+                              "rccl_ranks": world, "exchanges_per_prove": comm.stats()["exchanges"] / (args.steps + args.warmup),
+                              "resident_GB_per_rank": round(((4.5 * 32 + 3 * 8) * dims["num_cons"] + 32 * nv) * n_local / 1e9, 1)},
+                   "kernel_ms_per_step": {k_: v_[0] / args.steps for k_, v_ in ks.items() if v_[1]},
+                   "kernel_alg_GBps": {k_: v_[2] / max(v_[0], 1e-9) / 1e6 for k_, v_ in ks.items() if v_[1]},
+                   "sharded": None, "roofline": None, "cpu_baseline": None}
+            print(json.dumps(res))
+        host.nifs_free(prepared)
         comm.close()
         ctx.close()
         group.close()

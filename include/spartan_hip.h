@@ -14,6 +14,12 @@
  *   Host buffers are caller-owned and only read/written during the call. sp_* handles own device memory;
  *   a handle may be used from one thread at a time, distinct handles concurrently.
  *   There is NO CPU fallback: every entry point fails with SP_ERR_NO_DEVICE if no gfx950 device is usable.
+ *
+ * Interoperability: this ABI takes the commitment key (generators) and every transcript byte from its caller, so a Rust caller that derives the
+ * key with the reference's `from_label` and absorbs the reference's vk digest gets reference-compatible group elements and challenges out of
+ * these entry points. The C++ drivers of this repo (spartan2_amd/host/) use documented substitutes for the third-party pieces that are not in the
+ * reference tree (hash_to_curve, the bincode digest): THEIR keys and proofs are not interchangeable with ones produced by the
+ * reference binary, and no such byte equality is claimed anywhere.
  */
 #ifndef SPARTAN_HIP_H
 #define SPARTAN_HIP_H
@@ -301,10 +307,9 @@ int sp_nifs_layer(sp_nifs* n, int which, size_t idx, sp_table** view);
 /* small_values: 0 = field layers only; 1 = build the i64 mirrors now; 2 = use the mirrors sp_nifs_prepare_small built on these layers (the
  * reference's split: cached_step_i64 is made in prep_prove, src/neutronnova_zk.rs:1548-1586, and only consumed by prove) */
 int sp_nifs_begin(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_t ell_b, int small_values);
+/* The rounds only READ the instance layers and their mirrors (folds go to storage of their own), so an object whose layers were written once -
+ * prep_prove's cached_step_matvec / cached_step_i64 (:1520-1590) - serves any number of proves: each starts with sp_nifs_begin. */
 int sp_nifs_prepare_small(sp_nifs* n);
-/* dst <- the prepared layers (and i64 mirrors) of src, same context and geometry: prep_prove's cached_step_matvec / cached_step_i64
- * (src/neutronnova_zk.rs:1520-1590) are built once into `src`; every prove restores a working object from it before sp_nifs_begin. */
-int sp_nifs_restore(sp_nifs* dst, const sp_nifs* src);
 int sp_nifs_round(sp_nifs* n, size_t t, uint64_t out_coeffs[16]);
 int sp_nifs_challenge(sp_nifs* n, const uint64_t r_b[4]);
 int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out, uint64_t out_T_out[4], uint64_t out_eq_rho_at_rb[4]);

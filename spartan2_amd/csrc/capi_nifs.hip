@@ -17,8 +17,10 @@ struct sp_nifs {
   size_t n_padded = 0, left = 0, right = 0, total = 0, ell_b = 0;
   unsigned left_log2 = 0;
   bool factored = false;
-  // ping-pong layer storage for A and B: buf[0] holds n_padded layers (the instances), buf[1] n_padded / 2
-  fe_t *A[2] = {nullptr, nullptr}, *B[2] = {nullptr, nullptr}, *C = nullptr;
+  // layer storage for A and B: buf[0] holds the n_padded instance layers and is only ever READ by the rounds (so the layers prep_prove cached,
+  // cached_step_matvec src/neutronnova_zk.rs:1520-1590, serve every prove without a copy); the folds ping-pong between buf[1] (n_padded / 2
+  // layers) and buf[2] (n_padded / 4)
+  fe_t *A[3] = {nullptr, nullptr, nullptr}, *B[3] = {nullptr, nullptr, nullptr}, *C = nullptr;
   long long *A64 = nullptr, *B64 = nullptr, *C64 = nullptr;  // small-value mirrors (built by sp_nifs_begin(small_values = 1))
   unsigned char* d_flags = nullptr;
   unsigned* d_large = nullptr;
@@ -42,6 +44,7 @@ struct sp_nifs {
 namespace {
 
 fe_t h_one() { return fe_one<SF>(); }
+int next_buf(int cur) { return cur == 1 ? 2 : 1; }  // buf[0] (the instance layers) is never a destination
 fe_t load_fe(const uint64_t* p) {
   fe_t r;
   memcpy(r.v, p, 32);
@@ -126,6 +129,8 @@ int sp_nifs_create(sp_ctx* c, size_t n_padded, size_t left, size_t right, sp_nif
   al((void**)&n->B[0], n_padded * layer);
   al((void**)&n->A[1], n_padded / 2 * layer);
   al((void**)&n->B[1], n_padded / 2 * layer);
+  al((void**)&n->A[2], (n_padded / 4 ? n_padded / 4 : 1) * layer);
+  al((void**)&n->B[2], (n_padded / 4 ? n_padded / 4 : 1) * layer);
   al((void**)&n->C, n_padded * layer);
   al((void**)&n->d_E, (left + right) * sizeof(fe_t));
   al((void**)&n->d_w, n_padded * sizeof(fe_t));
@@ -142,7 +147,7 @@ int sp_nifs_create(sp_ctx* c, size_t n_padded, size_t left, size_t right, sp_nif
 
 void sp_nifs_free(sp_nifs* n) {
   if (!n) return;
-  void* ptrs[] = {n->A[0], n->A[1], n->B[0], n->B[1], n->C, n->A64, n->B64, n->C64, n->d_flags, n->d_large, n->d_E, n->d_w, n->d_part, n->d_part2, n->d_cvals};
+  void* ptrs[] = {n->A[0], n->A[1], n->A[2], n->B[0], n->B[1], n->B[2], n->C, n->A64, n->B64, n->C64, n->d_flags, n->d_large, n->d_E, n->d_w, n->d_part, n->d_part2, n->d_cvals};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete n;
@@ -196,39 +201,6 @@ int sp_nifs_prepare_small(sp_nifs* n) {
     SP_HIP(hipStreamSynchronize(c->stream));
   }
   n->mirrors_ready = true;
-  return SP_OK;
-}
-
-// prep_prove caches the step circuits' (Az, Bz, Cz) and their i64 mirrors when z is fully known (cached_step_matvec / cached_step_i64,
-// src/neutronnova_zk.rs:1520-1590); prove starts from a copy because the rounds fold the layers in place. `dst` and `src` have one geometry.
-int sp_nifs_restore(sp_nifs* dst, const sp_nifs* src) {
-  if (!dst || !src || dst == src || dst->n_padded != src->n_padded || dst->left != src->left || dst->right != src->right || dst->ctx != src->ctx)
-    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_restore: the two objects must share context and geometry");
-  sp_ctx* c = dst->ctx;
-  const size_t np = src->n_padded, bytes = np * src->total * sizeof(fe_t);
-  c->timed("nifs_restore", 2ull * 3 * bytes, [&] {
-    (void)hipMemcpyAsync(dst->A[0], src->A[0], bytes, hipMemcpyDeviceToDevice, c->stream);
-    (void)hipMemcpyAsync(dst->B[0], src->B[0], bytes, hipMemcpyDeviceToDevice, c->stream);
-    (void)hipMemcpyAsync(dst->C, src->C, bytes, hipMemcpyDeviceToDevice, c->stream);
-  });
-  dst->mirrors_ready = false;
-  if (src->mirrors_ready) {
-    if (!dst->A64) {
-      hipError_t e = hipMalloc((void**)&dst->A64, np * src->total * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&dst->B64, np * src->total * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&dst->C64, np * src->total * 8);
-      if (e == hipSuccess) e = hipMalloc((void**)&dst->d_flags, src->total);
-      if (e == hipSuccess) e = hipMalloc((void**)&dst->d_large, src->total * 4);
-      if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("sp_nifs_restore: hipMalloc: ") + hipGetErrorString(e));
-    }
-    SP_HIP(hipMemcpyAsync(dst->A64, src->A64, np * src->total * 8, hipMemcpyDeviceToDevice, c->stream));
-    SP_HIP(hipMemcpyAsync(dst->B64, src->B64, np * src->total * 8, hipMemcpyDeviceToDevice, c->stream));
-    SP_HIP(hipMemcpyAsync(dst->C64, src->C64, np * src->total * 8, hipMemcpyDeviceToDevice, c->stream));
-    SP_HIP(hipMemcpyAsync(dst->d_flags, src->d_flags, src->total, hipMemcpyDeviceToDevice, c->stream));
-    SP_HIP(hipMemcpyAsync(dst->d_large, src->d_large, src->total * 4, hipMemcpyDeviceToDevice, c->stream));
-    dst->nlarge = src->nlarge;
-    dst->mirrors_ready = true;
-  }
   return SP_OK;
 }
 
@@ -350,7 +322,7 @@ int sp_nifs_round_sums(sp_nifs* n, size_t t, uint64_t out_sums[8]) {
     fe_t s[2];
     if (n->fold_pending) {
       const fe_t r = n->r_bs[t - 1];
-      const int src = n->cur, dst = 1 - n->cur;
+      const int src = n->cur, dst = next_buf(n->cur);
       c->timed("nifs_fold_prove", 384ull * prove_pairs * n->total, [&] {
         if (n->factored)
           hipLaunchKernelGGL(spk::k_nifs_fold_prove<true>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst],
@@ -452,7 +424,7 @@ int sp_nifs_fold_pending(sp_nifs* n) {
   if (!n->fold_pending || n->m < 2) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_nifs_fold_pending: nothing to fold");
   const unsigned blocks = (unsigned)((n->total + 255) / 256);
   const size_t pairs = n->m / 2;
-  const int src = n->cur, dst = 1 - n->cur;
+  const int src = n->cur, dst = next_buf(n->cur);
   const fe_t r = n->r_bs.back();
   c->timed("nifs_fold", 96ull * 2 * pairs * n->total, [&] {
     hipLaunchKernelGGL(spk::k_nifs_fold, dim3(blocks, (unsigned)pairs, 2), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst], (unsigned long long)n->total, r);

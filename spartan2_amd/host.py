@@ -207,6 +207,28 @@ def tensor_decomp(n: int):
     return ell, 1 << ((ell + 1) // 2), 1 << (ell // 2)
 
 
+_P256 = 0xFFFFFFFF00000001000000000000000000000000FFFFFFFFFFFFFFFFFFFFFFFF  # scalar field of the bench engine (src/provider/pt256.rs:55)
+
+
+def mont_limbs_from_u64(vals):
+    """(n,) uint64 integers -> (n, 4) Montgomery limbs of the engine's scalar field (harness helper: witness vectors of the integer R1CS generators)."""
+    vals = np.ascontiguousarray(vals, dtype=np.uint64)
+    u, inv = np.unique(vals, return_inverse=True)
+    tab = np.array([[((int(v) << 256) % _P256 >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for v in u], dtype=np.uint64).reshape(-1, 4)
+    return tab[inv]
+
+
+def padded_witness_limbs(dims: dict, witness):
+    """[shared | precommitted | rest] with every segment zero-padded to its padded length (SplitR1CSShape layout, src/r1cs/mod.rs:810-911)."""
+    w = mont_limbs_from_u64(witness)
+    s, p, r = dims["num_shared_unpadded"], dims["num_precommitted_unpadded"], dims["num_rest_unpadded"]
+    out = np.zeros((dims["num_shared"] + dims["num_precommitted"] + dims["num_rest"], 4), dtype=np.uint64)
+    out[:s] = w[:s]
+    out[dims["num_shared"] : dims["num_shared"] + p] = w[s : s + p]
+    out[dims["num_shared"] + dims["num_precommitted"] : dims["num_shared"] + dims["num_precommitted"] + r] = w[s + p : s + p + r]
+    return out
+
+
 def nifs_prepare(ctx: hip.Context, shape: hip.Shape, dims: dict, X, W_tables, small_values: bool):
     """The prep_prove part of the NIFS (cached_step_matvec / cached_step_i64, src/neutronnova_zk.rs:1520-1600): layers (+ i64 mirrors) of the
     instances. Returns an opaque handle for nifs_prove(prepared=...); free with nifs_free."""
@@ -254,7 +276,7 @@ def nifs_prove(ctx: hip.Context, shape: hip.Shape, dims: dict, ck: hip.Commitmen
 
 
 def nifs_prove_sharded(ctx: hip.Context, comm, shape: hip.Shape, dims: dict, ck: hip.CommitmentKey, comms_local, X_local, W_tables_local, r_W_local, small_values: bool,
-                       tr: hip.Transcript, py_hook):
+                       tr: hip.Transcript, py_hook, prepared=None, out_tabs=None):
     """NeutronNovaNIFS::prove with the instances sharded over the ranks of `comm` (spartan2_amd/host/neutronnova_nifs.cpp nifs_prove_sharded,
     SURVEY.md 8(e)): this rank passes its n_local consecutive instances; every rank returns the same outputs as `nifs_prove` on the whole batch."""
     comms_local = np.ascontiguousarray(comms_local, dtype=np.uint64)
@@ -269,13 +291,13 @@ def nifs_prove_sharded(ctx: hip.Context, comm, shape: hip.Shape, dims: dict, ck:
     out = dict(polys=np.zeros((ell_b, 4, 4), dtype=np.uint64), r_bs=np.zeros((ell_b, 4), dtype=np.uint64), E_eq=np.zeros((left + right, 4), dtype=np.uint64),
                tail=np.zeros((2, 4), dtype=np.uint64), folded_rW=np.zeros((rows, 4), dtype=np.uint64), folded_X=np.zeros((max(d, 1), 4), dtype=np.uint64),
                folded_comm=np.zeros((rows, 8), dtype=np.uint64))
-    tabs = dict(A=hip.Table.zeros(ctx, N), B=hip.Table.zeros(ctx, N), C=hip.Table.zeros(ctx, N), folded_W=hip.Table.zeros(ctx, nv))
+    tabs = out_tabs if out_tabs is not None else dict(A=hip.Table.zeros(ctx, N), B=hip.Table.zeros(ctx, N), C=hip.Table.zeros(ctx, N), folded_W=hip.Table.zeros(ctx, nv))
     d10 = (ctypes.c_uint64 * 10)(*[dims[k] for k in DIM_NAMES])
     warr = (ctypes.c_void_p * n_local)(*[t.h for t in W_tables_local])
     cb = _c_hook(py_hook)
     _check(lib().nn_nifs_prove_sharded(ctx.h, comm.h, shape.h, d10, ck.h, ctypes.c_size_t(n_local), ctypes.c_size_t(rows), hip.p64(comms_local.reshape(-1)),
-                                       hip.p64(X_local.reshape(-1)) if d else None, warr, hip.p64(r_W_local.reshape(-1)), 1 if small_values else 0, tr.h, cb, None,
-                                       hip.p64(out["polys"]), hip.p64(out["r_bs"]), hip.p64(out["E_eq"]), hip.p64(out["tail"]), hip.p64(out["folded_rW"]),
+                                       hip.p64(X_local.reshape(-1)) if d else None, warr, hip.p64(r_W_local.reshape(-1)), 1 if small_values else 0, prepared, tr.h, cb,
+                                       None, hip.p64(out["polys"]), hip.p64(out["r_bs"]), hip.p64(out["E_eq"]), hip.p64(out["tail"]), hip.p64(out["folded_rW"]),
                                        hip.p64(out["folded_X"]), hip.p64(out["folded_comm"]), tabs["A"].h, tabs["B"].h, tabs["C"].h, tabs["folded_W"].h))
     out["folded_X"] = out["folded_X"][:d]
     out.update(tabs)
@@ -428,7 +450,7 @@ def sharded_commit(ctx: hip.Context, comm: Comm, key: hip.CommitmentKey, table: 
 
 
 # ---- NeutronNovaZkSNARK (spartan2_amd/host/neutronnova_zk.cpp) ---------------------------------------------------------------------------------
-NN_PHASES = ("instances", "nifs", "outer_sumcheck", "inner_sumcheck", "verifier_circuit_instance", "pcs_prove", "total")
+NN_PHASES = ("instances", "nifs", "outer_sumcheck", "inner_sumcheck", "verifier_circuit_instance", "pcs_prove", "total", "of_which_vc_round_commits")
 
 
 class NeutronNovaZkSNARK:
@@ -467,7 +489,7 @@ class NeutronNovaZkSNARK:
         n = lib().nnz_proof_words(self.pk)
         words = np.zeros(n, dtype=np.uint64)
         used = ctypes.c_size_t(0)
-        ms = (ctypes.c_double * 7)()
+        ms = (ctypes.c_double * 8)()
         _check(lib().nnz_prove(self.pk, self.ps, hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
         return words, used.value, dict(zip(NN_PHASES, list(ms)))
 

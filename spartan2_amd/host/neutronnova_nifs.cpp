@@ -172,8 +172,8 @@ void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const s
 // partial C / witness folds (one layer / one witness per rank) summed on every rank. Results are identical on all ranks and bit-identical to
 // nifs_prove on the whole batch. n must be a power of two and n_local >= 2.
 void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp_dims& dims, const sp_ck* ckey, size_t n_local, size_t rows, const aff_t* comms_local,
-                        const fe_t* X_local, const sp_table* const* Ws_local, const fe_t* r_W_local, bool small_values, sp_transcript* tr, nn_round_hook hook, void* user,
-                        NifsOutputs& out) {
+                        const fe_t* X_local, const sp_table* const* Ws_local, const fe_t* r_W_local, bool small_values, sp_nifs* prepared, sp_transcript* tr,
+                        nn_round_hook hook, void* user, NifsOutputs& out) {
   const size_t world = (size_t)comm.world, rank = (size_t)comm.rank, n = n_local * world;
   if (n_local < 2 || (n_local & (n_local - 1)) || (world & (world - 1)))
     throw Error(SP_ERR_INVALID_INPUT_LENGTH, "sharded NIFS: instances per rank and ranks must be powers of two, at least two instances per rank");
@@ -244,34 +244,35 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
     ck(sp_table_device_ptr(t, &p, nullptr), "device_ptr");
     return p;
   };
-  o.loc = nifs_prepare(ctx, shape, dims, n_local, X_local, Ws_local, small_values);
-  ck(sp_nifs_begin_shard(o.loc, out.E_eq, u64p(rhos.data()), ell_b, rank * n_local, small_values ? 2 : 0), "nifs_begin_shard");
+  // prepared: the rank's layers (+ mirrors) built at prep time (cached_step_matvec, :1520-1590); consumed by the rounds, owned by the caller
+  sp_nifs* const loc = prepared ? prepared : (o.loc = nifs_prepare(ctx, shape, dims, n_local, X_local, Ws_local, small_values));
+  ck(sp_nifs_begin_shard(loc, out.E_eq, u64p(rhos.data()), ell_b, rank * n_local, small_values ? 2 : 0), "nifs_begin_shard");
   std::vector<fe_t> cv_loc(n_local), cv(n);
-  ck(sp_nifs_cvals(o.loc, u64p(cv_loc.data())), "nifs_cvals");
+  ck(sp_nifs_cvals(loc, u64p(cv_loc.data())), "nifs_cvals");
   comm.allgather(cv_loc.data(), n_local * sizeof(fe_t), cv.data());
-  ck(sp_nifs_set_cvals(o.loc, u64p(cv.data()), n), "nifs_set_cvals");
+  ck(sp_nifs_set_cvals(loc, u64p(cv.data()), n), "nifs_set_cvals");
 
   std::vector<fe_t> r_bs(ell_b);
   for (size_t t = 0; t < local_rounds; ++t) {  // the data-parallel rounds: own pairs, two field elements exchanged
     fe_t sums[2];
-    ck(sp_nifs_round_sums(o.loc, t, u64p(sums)), "nifs_round_sums");
+    ck(sp_nifs_round_sums(loc, t, u64p(sums)), "nifs_round_sums");
     comm.field_sum(sums, 2);
     uint64_t* co = out.polys + 16 * t;
-    ck(sp_nifs_round_finish(o.loc, t, u64p(sums), co), "nifs_round_finish");
+    ck(sp_nifs_round_finish(loc, t, u64p(sums), co), "nifs_round_finish");
     hook(user, t, co, u64p(&r_bs[t]));
-    ck(sp_nifs_challenge(o.loc, u64p(&r_bs[t])), "nifs_challenge");
+    ck(sp_nifs_challenge(loc, u64p(&r_bs[t])), "nifs_challenge");
   }
-  sp_nifs* fin = o.loc;
+  sp_nifs* fin = loc;
   if (world > 1) {
     // hand-off: apply the pending fold; every rank gathers every rank's remaining A / B layer and continues on identical data
-    ck(sp_nifs_fold_pending(o.loc), "nifs_fold_pending");
+    ck(sp_nifs_fold_pending(loc), "nifs_fold_pending");
     fe_t T_cur, acc_eq;
-    ck(sp_nifs_state(o.loc, u64p(&T_cur), u64p(&acc_eq)), "nifs_state");
+    ck(sp_nifs_state(loc, u64p(&T_cur), u64p(&acc_eq)), "nifs_state");
     ck(sp_nifs_create(ctx, world, left, right, &o.root), "nifs_create");
     ck(sp_ctx_synchronize(ctx), "synchronize");
     for (int which = 0; which < 2; ++which) {
       sp_table *src = nullptr, *dst = nullptr;
-      ck(sp_nifs_current_layer(o.loc, which, 0, &src), "nifs_current_layer");
+      ck(sp_nifs_current_layer(loc, which, 0, &src), "nifs_current_layer");
       keep(src);
       ck(sp_nifs_layer(o.root, which, 0, &dst), "nifs_layer");  // the root object's layers are contiguous: layer b at offset b * total
       keep(dst);
@@ -313,7 +314,7 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
     std::vector<const sp_table*> cl(n_local);
     for (size_t i = 0; i < n_local; ++i) {
       sp_table* v = nullptr;
-      ck(sp_nifs_layer(o.loc, 2, i, &v), "nifs_layer");
+      ck(sp_nifs_layer(loc, 2, i, &v), "nifs_layer");
       cl[i] = keep(v);
     }
     sp_table* part = nullptr;
@@ -406,17 +407,18 @@ int nn_nifs_prove(sp_ctx* ctx, const sp_shape* S, const uint64_t dims10[10], con
 }
 
 // The sharded form: `comm` is an ssc_comm_* handle; *_local arguments describe this rank's n_local instances; outputs as nn_nifs_prove, identical on
-// every rank (polys / r_bs: ell_b = log2(n_local * world) rounds).
+// every rank (polys / r_bs: ell_b = log2(n_local * world) rounds). prepared: nn_nifs_prepare's object for the rank's instances (or NULL).
 int nn_nifs_prove_sharded(sp_ctx* ctx, void* comm, const sp_shape* S, const uint64_t dims10[10], const sp_ck* ckey, size_t n_local, size_t rows, const uint64_t* comms_local,
-                          const uint64_t* X_local, const sp_table* const* Ws_local, const uint64_t* r_W_local, int small_values, sp_transcript* tr, nn_round_hook hook, void* user,
+                          const uint64_t* X_local, const sp_table* const* Ws_local, const uint64_t* r_W_local, int small_values, sp_nifs* prepared, sp_transcript* tr,
+                          nn_round_hook hook, void* user,
                           uint64_t* out_polys, uint64_t* out_r_bs, uint64_t* out_E, uint64_t* out_tail, uint64_t* out_folded_rW, uint64_t* out_folded_X,
                           uint64_t* out_folded_comm, sp_table* out_A, sp_table* out_B, sp_table* out_C, sp_table* out_folded_W) {
   try {
     sp_dims dims;
     memcpy(&dims, dims10, sizeof(sp_dims));
     NifsOutputs o{out_polys, out_r_bs, out_E, out_tail, out_folded_rW, out_folded_X, out_folded_comm, out_A, out_B, out_C, out_folded_W};
-    nifs_prove_sharded(ctx, *(Comm*)comm, S, dims, ckey, n_local, rows, (const aff_t*)comms_local, (const fe_t*)X_local, Ws_local, (const fe_t*)r_W_local, small_values != 0, tr,
-                       hook, user, o);
+    nifs_prove_sharded(ctx, *(Comm*)comm, S, dims, ckey, n_local, rows, (const aff_t*)comms_local, (const fe_t*)X_local, Ws_local, (const fe_t*)r_W_local, small_values != 0, prepared,
+                       tr, hook, user, o);
     return SP_OK;
   } catch (const Error& e) {
     ss_set_error(e.what());

@@ -41,13 +41,12 @@ struct NNZkPrep {
   std::vector<aff_t> comm_shared;
   std::vector<fe_t> r_shared;
   bool is_small = true;
-  // cached_step_matvec / cached_step_i64 (:1520-1590): the step instances' (Az, Bz, Cz) layers and their i64 mirrors, and the working copy each prove folds
-  sp_nifs *nifs_cached = nullptr, *nifs_work = nullptr;
+  // cached_step_matvec / cached_step_i64 (:1520-1590): the step instances' (Az, Bz, Cz) layers and their i64 mirrors; the rounds only read them
+  sp_nifs* nifs_cached = nullptr;
   ~NNZkPrep() {
     for (auto& s : steps) sp_table_free(s.W);
     sp_table_free(core.W);
     sp_nifs_free(nifs_cached);
-    sp_nifs_free(nifs_work);
   }
 };
 
@@ -155,10 +154,6 @@ static NNZkPrep* nn_prep_prove(const NNZkKey& pk, size_t n, const uint64_t* step
         Ws[i] = ps->steps[i].W;
       }
       ps->nifs_cached = nifs_prepare(ctx, pk.S_step, d, n, X.data(), Ws.data(), true);
-      size_t n_padded = 2, ell, left, right;
-      while (n_padded < n) n_padded <<= 1;
-      compute_tensor_decomp(d.num_cons, &ell, &left, &right);
-      ck(sp_nifs_create(ctx, n_padded, left, right, &ps->nifs_work), "nifs_create");
     }
   } catch (...) {
     delete ps;
@@ -349,8 +344,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   for (sp_table** t : {&A, &B, &C}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc");
   ck(sp_table_zeros(ctx, nv, (size_t)-1, (size_t)-1, &fW), "alloc");
   NifsOutputs no{polys.data(), r_bs.data(), E_eq.data(), tail.data(), f_rW.data(), f_X.data(), (uint64_t*)f_comm.data(), A, B, C, fW};
-  ck(sp_nifs_restore(ps.nifs_work, ps.nifs_cached), "nifs_restore");
-  nifs_prove(ctx, pk.S_step, d, pk.ck, n, rows, comms.data(), X.data(), Ws.data(), r_W.data(), true, ps.nifs_work, tr.t, nifs_hook, &hc, no);
+  nifs_prove(ctx, pk.S_step, d, pk.ck, n, rows, comms.data(), X.data(), Ws.data(), r_W.data(), true, ps.nifs_cached, tr.t, nifs_hook, &hc, no);
   if (hc.err) std::rethrow_exception(hc.err);
   const double t_nifs = now();
 
@@ -672,6 +666,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     phase_ms[4] = t_vc - t_inner;     // verifier-circuit instance: random instance, NovaNIFS, relaxed Spartan
     phase_ms[5] = t_end - t_vc;       // folded opening
     phase_ms[6] = t_end - t_start;
+    phase_ms[7] = vst.commit_ms;  // inside the phases above: the per-round verifier-circuit commitments (process_round)
   }
   return proof;
 }
@@ -741,7 +736,7 @@ int nnz_prep_prove(void* pk, size_t n, const uint64_t* step_wit, size_t wit_len,
   }
 }
 void nnz_prep_free(void* ps) { delete (NNZkPrep*)ps; }
-// phase_ms[7]: instances, nifs, outer, inner, verifier-circuit instance, opening, total
+// phase_ms[8]: instances, nifs, outer, inner, verifier-circuit instance, opening, total, (of which) per-round vc commitments
 int nnz_prove(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words, size_t out_cap, double* phase_ms) {
   try {
     Tape t{tape, tape_blocks};

@@ -6,6 +6,7 @@
 // Synthesis ORDER is the reference's, statement by statement: it fixes the matrices and the layout of the round witnesses.
 #pragma once
 #include <array>
+#include <chrono>
 
 #include "host_common.hpp"
 
@@ -323,6 +324,8 @@ struct State {  // MultiRoundState (bellpepper/r1cs.rs:695-707)
   std::vector<std::vector<fe_t>> blind_per_round;
   std::vector<fe_t> w;
   size_t current = 0;
+  double commit_ms = 0;  // wall time inside the per-round commitments (reported as a phase of its own)
+  size_t commits = 0;
   explicit State(const Shape& s) : w(s.total_vars, fe_zero()) {}
 };
 // process_round (bellpepper/r1cs.rs:734-816): synthesize the round, commit its (padded) variables with the width-32 key, absorb, squeeze
@@ -341,8 +344,11 @@ static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shap
   std::vector<fe_t> blinds(rows);
   for (auto& b : blinds) b = tape.next();
   std::vector<aff_t> comm(rows);
+  const auto tc0 = std::chrono::steady_clock::now();
   for (size_t r = 0; r < rows; ++r)
     ck(sp_hyrax_commit_small(ctx, vc_ck, u64p(st.w.data() + sp_ + r * s.width), s.width, u64p(&blinds[r]), u64p(&comm[r].x)), "commit round witness");
+  st.commit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
+  st.commits += rows;
   const std::vector<uint8_t> b = commitment_bytes(comm.data(), rows);
   tr.absorb("comm_w_round", b.data(), b.size());
   std::vector<fe_t> out(s.chals_per_round[round]);
