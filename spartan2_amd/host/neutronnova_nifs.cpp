@@ -19,6 +19,30 @@ void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right) {
   *right = size_t(1) << (l / 2);
 }
 
+// R1CSInstance transcript bytes = comm_W || X (src/r1cs/mod.rs:728-736)
+static std::vector<uint8_t> instance_bytes(const aff_t* comm, size_t rows, const fe_t* X, size_t d) {
+  std::vector<uint8_t> b = commitment_bytes(comm, rows);
+  const size_t off = b.size();
+  b.resize(off + 32 * d);
+  for (size_t j = 0; j < d; ++j) sp::fe_to_be_bytes<S>(X[j], b.data() + off + 32 * j);
+  return b;
+}
+// sum_i w[i] * M[i][.] for a host matrix of n rows x cols (fold_blinds, the X fold: hyrax_pc.rs:795-818, neutronnova_zk.rs:1236-1245): on the device
+// (bind_with_delayed's kernel) once the matrix is big enough to pay for its upload
+static void fold_rows(sp_ctx* ctx, const fe_t* M, size_t n, size_t cols, const fe_t* w, fe_t* out) {
+  if (cols == 0) return;
+  if (n * cols < 16384) {
+    for (size_t j = 0; j < cols; ++j) out[j] = fe_zero();
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = 0; j < cols; ++j) out[j] = fe_add<S>(out[j], fe_mul<S>(M[i * cols + j], w[i]));
+    return;
+  }
+  sp_table* t = nullptr;
+  ck(sp_table_from_host(ctx, u64p(M), n * cols, (size_t)-1, (size_t)-1, &t), "upload");
+  int rc = sp_rowmat_vec(ctx, t, n, cols, u64p(w), u64p(out));
+  sp_table_free(t);
+  ck(rc, "fold rows");
+}
 // Us: comm rows (n x rows affine) + X (n x d); Ws: resident witness tables (num_vars each) + blinds (n x rows)
 // Layers Az_b, Bz_b, Cz_b of every (padded) instance and, for small_values, their i64 mirrors: the transcript-independent part that the reference
 // caches in prep_prove (cached_step_matvec / cached_step_i64, src/neutronnova_zk.rs:1520-1600).
@@ -88,12 +112,10 @@ void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const s
     ck(sp_transcript_squeeze(tr, (const uint8_t*)label, strlen(label), u64p(&f)), "squeeze");
     return f;
   };
-  for (size_t i = 0; i < n_padded; ++i) {  // transcript.absorb(b"U", U) (:553-555; R1CSInstance bytes = comm_W || X, src/r1cs/mod.rs:728-736)
-    std::vector<uint8_t> b = commitment_bytes(comms + inst(i) * rows, rows);
-    const size_t off = b.size();
-    b.resize(off + 32 * d);
-    for (size_t j = 0; j < d; ++j) sp::fe_to_be_bytes<S>(X[inst(i) * d + j], b.data() + off + 32 * j);
-    absorb("U", b.data(), b.size());
+  {  // transcript.absorb(b"U", U) (:553-555; R1CSInstance bytes = comm_W || X, src/r1cs/mod.rs:728-736): encodings in parallel, the sponge in order
+    std::vector<std::vector<uint8_t>> ub(n);
+    parallel_for(n, rows + d, [&](size_t i) { ub[i] = instance_bytes(comms + i * rows, rows, X + i * d, d); });
+    for (size_t i = 0; i < n_padded; ++i) absorb("U", ub[inst(i)].data(), ub[inst(i)].size());
   }
   {
     uint8_t zero_be[32] = {0};  // T = 0 (:556-557)
@@ -144,9 +166,11 @@ void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const s
   ck(sp_table_set_len(out.folded_W, num_vars, (size_t)-1, (size_t)-1), "set_len");
   lap("fold_multiple");
   std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());  // fold_blinds (hyrax_pc.rs:795-818), X fold (:1236-1245)
-  for (size_t i = 0; i < n_padded; ++i) {
-    for (size_t r = 0; r < rows; ++r) f_rW[r] = fe_add<S>(f_rW[r], fe_mul<S>(r_W[inst(i) * rows + r], w[i]));
-    for (size_t j = 0; j < d; ++j) f_X[j] = fe_add<S>(f_X[j], fe_mul<S>(w[i], X[inst(i) * d + j]));
+  {
+    std::vector<fe_t> wi(n, fe_zero());  // padding clones instance 0: its weights add up
+    for (size_t i = 0; i < n_padded; ++i) wi[inst(i)] = fe_add<S>(wi[inst(i)], w[i]);
+    fold_rows(ctx, r_W, n, rows, wi.data(), f_rW.data());
+    fold_rows(ctx, X, n, d, wi.data(), f_X.data());
   }
   memcpy(out.folded_rW, f_rW.data(), rows * sizeof(fe_t));
   memcpy(out.folded_X, f_X.data(), d * sizeof(fe_t));
@@ -177,6 +201,19 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   const size_t world = (size_t)comm.world, rank = (size_t)comm.rank, n = n_local * world;
   if (n_local < 2 || (n_local & (n_local - 1)) || (world & (world - 1)))
     throw Error(SP_ERR_INVALID_INPUT_LENGTH, "sharded NIFS: instances per rank and ranks must be powers of two, at least two instances per rank");
+  static const bool trace = [] {
+    const char* e = getenv("SPARTAN_HOST_LAPS");
+    return e && e[0] == '1';
+  }();
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_lap = now();
+  auto lap = [&](const char* what) {
+    if (!trace) return;
+    sp_ctx_synchronize(ctx);
+    const double t = now();
+    fprintf(stderr, "nifs(sharded) lap %-28s %8.3f ms\n", what, t - t_lap);
+    t_lap = t;
+  };
   const size_t d = dims.num_public, num_vars = dims.num_shared + dims.num_precommitted + dims.num_rest;
   size_t ell_b = 0, local_rounds = 0;
   while ((size_t(1) << ell_b) < n) ++ell_b;
@@ -200,6 +237,7 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
     if (d) memcpy(&X[i * d], p + rows * sizeof(aff_t), d * sizeof(fe_t));
     memcpy(&r_W[i * rows], p + rows * sizeof(aff_t) + d * sizeof(fe_t), rows * sizeof(fe_t));
   }
+  lap("gather instance data");
 
   auto absorb = [&](const char* label, const uint8_t* b, size_t len) { ck(sp_transcript_absorb(tr, (const uint8_t*)label, strlen(label), b, len), "absorb"); };
   auto squeeze = [&](const char* label) {
@@ -207,12 +245,10 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
     ck(sp_transcript_squeeze(tr, (const uint8_t*)label, strlen(label), u64p(&f)), "squeeze");
     return f;
   };
-  for (size_t i = 0; i < n; ++i) {  // transcript.absorb(b"U", U) (:553-555)
-    std::vector<uint8_t> b = commitment_bytes(&comms[i * rows], rows);
-    const size_t off = b.size();
-    b.resize(off + 32 * d);
-    for (size_t j = 0; j < d; ++j) sp::fe_to_be_bytes<S>(X[i * d + j], b.data() + off + 32 * j);
-    absorb("U", b.data(), b.size());
+  {  // transcript.absorb(b"U", U) (:553-555)
+    std::vector<std::vector<uint8_t>> ub(n);
+    parallel_for(n, rows + d, [&](size_t i) { ub[i] = instance_bytes(&comms[i * rows], rows, X.data() + i * d, d); });
+    for (size_t i = 0; i < n; ++i) absorb("U", ub[i].data(), ub[i].size());
   }
   {
     uint8_t zero_be[32] = {0};  // T = 0 (:556-557)
@@ -225,6 +261,7 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   ck(sp_pow_split_evals(u64p(&tau), ell_cons, left, right, out.E_eq), "split_evals");
   std::vector<fe_t> rhos(ell_b);
   for (auto& r : rhos) r = squeeze("rho");
+  lap("transcript preamble");
 
   struct Objs {
     sp_nifs *loc = nullptr, *root = nullptr;
@@ -251,6 +288,7 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   ck(sp_nifs_cvals(loc, u64p(cv_loc.data())), "nifs_cvals");
   comm.allgather(cv_loc.data(), n_local * sizeof(fe_t), cv.data());
   ck(sp_nifs_set_cvals(loc, u64p(cv.data()), n), "nifs_set_cvals");
+  lap("layers, begin, c_vals");
 
   std::vector<fe_t> r_bs(ell_b);
   for (size_t t = 0; t < local_rounds; ++t) {  // the data-parallel rounds: own pairs, two field elements exchanged
@@ -288,6 +326,7 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
     fin = o.root;
   }
   memcpy(out.r_bs, r_bs.data(), ell_b * sizeof(fe_t));
+  lap("rounds");
   std::vector<fe_t> w(n);
   ck(sp_weights_from_r(u64p(r_bs.data()), ell_b, n, u64p(w.data())), "weights_from_r");
   std::vector<fe_t> ones(world, fe_one<S>());
@@ -343,12 +382,11 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   }
   if (dim < num_vars) ck(sp_table_zero(ctx, out.folded_W, dim, num_vars - dim), "zero rest");
   ck(sp_table_set_len(out.folded_W, num_vars, (size_t)-1, (size_t)-1), "set_len");
+  lap("finish, C and witness folds");
   // fold_blinds, X fold, fold_commitments on the gathered instance data: O(n rows) work, done redundantly on every rank
   std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());
-  for (size_t i = 0; i < n; ++i) {
-    for (size_t r = 0; r < rows; ++r) f_rW[r] = fe_add<S>(f_rW[r], fe_mul<S>(r_W[i * rows + r], w[i]));
-    for (size_t j = 0; j < d; ++j) f_X[j] = fe_add<S>(f_X[j], fe_mul<S>(w[i], X[i * d + j]));
-  }
+  fold_rows(ctx, r_W.data(), n, rows, w.data(), f_rW.data());
+  fold_rows(ctx, X.data(), n, d, w.data(), f_X.data());
   memcpy(out.folded_rW, f_rW.data(), rows * sizeof(fe_t));
   memcpy(out.folded_X, f_X.data(), d * sizeof(fe_t));
   size_t data_rows = truncated ? (effective_len + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH : rows;
@@ -358,6 +396,7 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
     for (size_t i = 0; i < n; ++i) bases[r * n + i] = comms[i * rows + r];
   if (data_rows) ck(sp_msm_shared_weights(ctx, u64p(w.data()), n, (const uint64_t*)bases.data(), data_rows, out.folded_comm), "fold_commitments");
   if (data_rows < rows) ck(sp_fixed_base_mul_h(ctx, ckey, u64p(f_rW.data() + data_rows), rows - data_rows, out.folded_comm + 8 * data_rows), "rest rows");
+  lap("blind / X / commitment folds");
 }
 
 }  // namespace spartan2
