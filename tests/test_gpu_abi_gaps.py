@@ -148,3 +148,34 @@ def test_round0_products_fused_into_the_matrix_vector_product(ctx, n_groups):
     got = hip.sumcheck_cubic3_round0(ctx, claim, taus, *fused, p0, p1, hip.Transcript(ctx, b"r0"))
     for w, g in zip(want, got):
         assert (w == g).all()
+
+
+def test_table_view_and_device_ptr(ctx):
+    """sp_table_view: a non-owning window that the fold / copy entry points accept like a table; sp_table_device_ptr: address + capacity."""
+    rng = np.random.default_rng(21)
+    v = ol.random_field_array(rng, 64)
+    t = hip.Table.from_host(ctx, v)
+    L = hip.lib()
+    views = []
+    for g in range(4):
+        h = ctypes.c_void_p()
+        hip.check(L.sp_table_view(t.h, ctypes.c_size_t(16 * g), ctypes.c_size_t(16), ctypes.byref(h)))
+        views.append(hip.Table(ctx, h))
+    assert all((views[g].read(0, 16) == v[16 * g : 16 * g + 16]).all() for g in range(4))
+    # sum of the four windows with unit weights = fold_multiple over views (the combine step of the sharded NIFS driver)
+    out = hip.Table.zeros(ctx, 16)
+    hip.fold_tables(ctx, views, np.stack([ol.to_mont(1)] * 4), 16, out)
+    want = ol.mont_array([sum(ol.from_mont(v[16 * g + j]) for g in range(4)) % P for j in range(16)])
+    assert (out.read(0, 16) == want).all()
+    # writes through a view land in the parent
+    views[1].write(0, v[:4])
+    assert (t.read(16, 4) == v[:4]).all()
+    ptr, cap = ctypes.c_void_p(), ctypes.c_size_t()
+    hip.check(L.sp_table_device_ptr(t.h, ctypes.byref(ptr), ctypes.byref(cap)))
+    assert ptr.value and cap.value >= 64 * 32
+    bad = ctypes.c_void_p()
+    assert L.sp_table_view(t.h, ctypes.c_size_t(60), ctypes.c_size_t(16), ctypes.byref(bad)) == -1
+    for x in views:
+        x.free()
+    assert (t.read(0, 4) == v[:4]).all()  # freeing views leaves the storage alone
+    t.free()
