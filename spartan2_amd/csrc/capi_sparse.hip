@@ -136,19 +136,6 @@ __global__ void __launch_bounds__(256) k_polyabc_short(PolyAbcArgs a, const fe_t
     out[col] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(a.r, sb)), fe_mul<S>(a.r2, sc));
   }
 }
-// XCD-aware form. Block b runs on XCD b % 8 (observed placement; a performance assumption only), and each XCD has a private 4 MiB L2. `order` is laid
-// out as eight chunks of chunk_len entries - chunk x holds the short columns of the x-th eighth of the column range, longest first, padded with
-// 0xFFFFFFFF - and block b walks chunk b % 8: in an R1CS produced by straight-line synthesis a variable is used by the constraints allocated around
-// it, so an XCD then gathers from ~1/8 of the rx table (4 MiB at config 2: L2-sized) instead of all of it.
-__global__ void __launch_bounds__(256) k_polyabc_short_xcd(PolyAbcArgs a, const fe_t* __restrict__ rx, const unsigned* __restrict__ order, size_t chunk_len,
-                                                           fe_t* __restrict__ out) {
-  const size_t i = (size_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x;
-  if (i >= chunk_len) return;
-  const unsigned col = order[(size_t)(blockIdx.x & 7) * chunk_len + i];
-  if (col == 0xFFFFFFFFu) return;
-  fe_t sa = gather_major_x4(a.m[0], col, rx), sb = gather_major_x4(a.m[1], col, rx), sc = gather_major_x4(a.m[2], col, rx);
-  out[col] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(a.r, sb)), fe_mul<S>(a.r2, sc));
-}
 // Long columns (the constant-1 column has ~one entry per booleanity row): NB blocks share a column, each striding
 // over its entry lists; a second one-block pass per column adds the NB partial triples and applies (1, r, r^2).
 constexpr unsigned LONG_NB_MAX = 128;
@@ -289,8 +276,6 @@ struct sp_shape {
   unsigned* d_long_cols = nullptr;
   unsigned* d_short_order = nullptr;  // short columns by decreasing entry count (k_polyabc_short)
   size_t n_short = 0;
-  unsigned* d_short_order_xcd = nullptr;  // the same columns as eight column-range chunks of xcd_chunk entries (k_polyabc_short_xcd)
-  size_t xcd_chunk = 0;
   fe_t* d_long_partials = nullptr;
   size_t n_long_cols = 0;
   uint64_t nnz[3] = {0, 0, 0}, nnz_filtered[3] = {0, 0, 0};
@@ -367,18 +352,6 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return col_count[x] > col_count[y]; });
     s->n_short = order.size();
     if ((rc = upload(&s->d_short_order, order))) return rc;
-    std::vector<unsigned> chunk[8];
-    for (size_t i = 0; i < s->num_cols; ++i)
-      if (col_count[i] < spk::LONG_COLUMN) chunk[i * 8 / s->num_cols].push_back((unsigned)i);
-    size_t longest = 0;
-    for (auto& ch : chunk) {
-      std::stable_sort(ch.begin(), ch.end(), [&](unsigned x, unsigned y) { return col_count[x] > col_count[y]; });
-      if (ch.size() > longest) longest = ch.size();
-    }
-    s->xcd_chunk = (longest + 255) / 256 * 256;
-    std::vector<unsigned> ox(8 * s->xcd_chunk, 0xFFFFFFFFu);
-    for (int x = 0; x < 8; ++x) std::copy(chunk[x].begin(), chunk[x].end(), ox.begin() + x * s->xcd_chunk);
-    if ((rc = upload(&s->d_short_order_xcd, ox))) return rc;
   }
   SP_HIP(hipMalloc((void**)&s->d_long_partials, (long_cols.size() + 1) * spk::LONG_NB_MAX * 3 * sizeof(fe_t)));
   *out = s;
@@ -393,7 +366,6 @@ void sp_shape_free(sp_shape* s) {
   }
   hipFree(s->d_long_cols);
   hipFree(s->d_short_order);
-  hipFree(s->d_short_order_xcd);
   hipFree(s->d_long_partials);
   delete s;
 }
@@ -481,15 +453,7 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
   if (blocks == 0) blocks = 1;
   uint64_t bytes = 36ull * (s->nnz[0] + s->nnz[1] + s->nnz[2]) + 32ull * out_len;
   c->timed("poly_abc", bytes, [&] {
-    static const bool xcd_off = [] {
-      const char* e = getenv("SPARTAN_POLYABC_XCD");
-      return e && e[0] == '0';
-    }();
-    if (!xcd_off && s->xcd_chunk >= 4096)  // a table that fits one L2 anyway gains nothing from the placement
-      hipLaunchKernelGGL(spk::k_polyabc_short_xcd, dim3((unsigned)(8 * (s->xcd_chunk / 256))), dim3(256), 0, c->stream, a, rx->d, s->d_short_order_xcd, s->xcd_chunk,
-                         out->d);
-    else
-      hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short, out->d);
+    hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short, out->d);
     if (s->n_long_cols) {
       hipLaunchKernelGGL(spk::k_polyabc_long, dim3(spk::LONG_NB_MAX, (unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, rx->d, s->d_long_cols,
                          s->d_long_partials);
