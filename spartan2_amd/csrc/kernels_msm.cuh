@@ -241,102 +241,134 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict_
   if (bucket < total && sub == 0) buckets[bucket] = acc;
 }
 
-// ---- block-cooperative Jacobian addition ----------------------------------------------------------------------------------------------------
-// The MSM tail is a chain of DEPENDENT additions on few points; a lone wave issues the ~16 base-field products of one addition back to back
-// (~1 us each: the SIMD is saturated by one wave's quarter-rate 64-bit multiply-adds), ~15 us per addition. Here FOUR wave groups ("roles", each on
-// its own SIMD) share every addition: the products are scheduled in 5 dependency levels of <= 4, each role computes one product per level for
-// all ITEMS point pairs and the levels meet in LDS. Same add-2007-bl formula, same result; ~2.3x shorter chain.
+// ---- block-cooperative addition in XYZZ coordinates -------------------------------------------------------------------------------------------
+// The MSM tail is a chain of DEPENDENT additions on few points; a lone wave issues the base-field products of one addition back to back (~1 us
+// each: the SIMD is saturated by one wave's quarter-rate 64-bit multiply-adds), ~15 us per Jacobian addition. Here FOUR wave groups ("roles", each
+// on its own SIMD) share every addition: each role computes one product per dependency level for all ITEMS point pairs and the levels meet in LDS.
+// Coordinates are (X, Y, ZZ, ZZZ) with x = X / ZZ, y = Y / ZZZ (add-2008-s): 14 products in FOUR levels of <= 4 - the Jacobian add-2007-bl this
+// replaces needs 16 in five - so a chain of dependent additions is a fifth shorter. Points enter (Jacobian buckets, affine table entries) and leave
+// (Jacobian sums for the host's Horner / normalisation) through two products each; the group element, hence every byte downstream, is the same.
+struct xyzz_t {
+  fe_t x, y, zz, zzz;
+};
+__device__ __forceinline__ bool xyzz_is_identity(const xyzz_t& p) { return fe_is_zero(p.zz); }
+__device__ __forceinline__ xyzz_t xyzz_identity() {
+  xyzz_t r;
+  r.x = r.y = r.zz = r.zzz = fe_zero();
+  return r;
+}
+__device__ __forceinline__ xyzz_t xyzz_from_jac(const jac_t& p) {
+  if (jac_is_identity(p)) return xyzz_identity();
+  xyzz_t r;
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = fe_sqr<B>(p.z);
+  r.zzz = fe_mul<B>(r.zz, p.z);
+  return r;
+}
+__device__ __forceinline__ xyzz_t xyzz_from_affine(const aff_t& p) {
+  if (aff_is_identity(p)) return xyzz_identity();
+  xyzz_t r;
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = r.zzz = fe_one<B>();
+  return r;
+}
+// Jacobian (X ZZ, Y ZZZ, ZZ): x = X ZZ / ZZ^2, y = Y ZZZ / ZZ^3 = Y / ZZZ since ZZ^3 = ZZZ^2
+__device__ __forceinline__ jac_t xyzz_to_jac(const xyzz_t& p) {
+  if (xyzz_is_identity(p)) return jac_identity();
+  jac_t r;
+  r.x = fe_mul<B>(p.x, p.zz);
+  r.y = fe_mul<B>(p.y, p.zzz);
+  r.z = p.zz;
+  return r;
+}
 template <int ITEMS>
 struct CoopAdd {
-  fe_t t[9][ITEMS];   // z1z1 | z2z2 -> m1 | zz -> z3 | a -> s2 | u1 | u2 -> j | s1 | b -> v | i -> m2     (rr2 reuses slot 0)
-  jac_t fix[ITEMS];   // results of the special cases (identity operand, P = +-Q), computed while the inputs are still intact
+  fe_t t[9][ITEMS];   // U1 -> Q | U2 -> P -> Y3a | S1 | S2 -> R | PP -> Y3b | RR | ZZ1 ZZ2 -> ZZ3 | ZZZ1 ZZZ2 -> ZZZ3 | PPP
+  xyzz_t fix[ITEMS];  // results of the special cases (identity operand, P = +-Q), computed while the inputs are still intact
   int flag[ITEMS];
 };
 // All ITEMS * 4 threads of the block call this (it synchronises). role = threadIdx / ITEMS, i = threadIdx % ITEMS; P[i] += Q index given by the
-// caller as pointers into LDS; `active` = this item takes part. The sum is written to dst[i] (may alias P).
+// caller as pointers into LDS; `active` = this item takes part. The sum is written to dst[i] (may alias P: results are stored after the last level).
 template <int ITEMS>
-__device__ __forceinline__ void jac_add_block4(CoopAdd<ITEMS>& L, const jac_t* P, const jac_t* Q, jac_t* dst, int role, int i, bool active) {
+__device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t* P, const xyzz_t* Q, xyzz_t* dst, int role, int i, bool active) {
   fe_t(*t)[ITEMS] = L.t;
-  // level 1
+  // level 1: U1 | U2 | S1 | S2
   if (active) {
     if (role == 0) {
       int f = 0;
-      if (jac_is_identity(*P)) {
+      if (xyzz_is_identity(*P)) {
         L.fix[i] = *Q;
         f = 1;
-      } else if (jac_is_identity(*Q)) {
+      } else if (xyzz_is_identity(*Q)) {
         L.fix[i] = *P;
         f = 1;
       }
       L.flag[i] = f;
-      t[0][i] = fe_sqr<B>(P->z);
+      t[0][i] = fe_mul<B>(P->x, Q->zz);
     } else if (role == 1) {
-      t[1][i] = fe_sqr<B>(Q->z);
+      t[1][i] = fe_mul<B>(Q->x, P->zz);
     } else if (role == 2) {
-      t[2][i] = fe_sqr<B>(fe_add<B>(P->z, Q->z));
+      t[2][i] = fe_mul<B>(P->y, Q->zzz);
     } else {
-      t[3][i] = fe_mul<B>(P->y, Q->z);
+      t[3][i] = fe_mul<B>(Q->y, P->zzz);
     }
   }
   __syncthreads();
-  // level 2
-  if (active) {
-    if (role == 0) t[4][i] = fe_mul<B>(P->x, t[1][i]);
-    else if (role == 1) t[5][i] = fe_mul<B>(Q->x, t[0][i]);
-    else if (role == 2) t[6][i] = fe_mul<B>(t[3][i], t[1][i]);
-    else t[7][i] = fe_mul<B>(Q->y, P->z);
-  }
-  __syncthreads();
-  // level 3: s2 | i | z3
+  // level 2: PP (and P) | RR (and R) | ZZ1 ZZ2 | ZZZ1 ZZZ2
   if (active) {
     if (role == 0) {
-      t[3][i] = fe_mul<B>(t[7][i], t[0][i]);
+      const fe_t pd = fe_sub<B>(t[1][i], t[0][i]);
+      t[4][i] = fe_sqr<B>(pd);
+      t[1][i] = pd;
     } else if (role == 1) {
-      const fe_t h2 = fe_dbl<B>(fe_sub<B>(t[5][i], t[4][i]));
-      t[8][i] = fe_sqr<B>(h2);
+      const fe_t rd = fe_sub<B>(t[3][i], t[2][i]);
+      t[5][i] = fe_sqr<B>(rd);
+      t[3][i] = rd;
     } else if (role == 2) {
-      const fe_t h = fe_sub<B>(t[5][i], t[4][i]);
-      t[2][i] = fe_mul<B>(fe_sub<B>(fe_sub<B>(t[2][i], t[0][i]), t[1][i]), h);
+      t[6][i] = fe_mul<B>(P->zz, Q->zz);
+    } else {
+      t[7][i] = fe_mul<B>(P->zzz, Q->zzz);
     }
   }
   __syncthreads();
-  // level 4: j | v | rr^2  (+ the P = +-Q case, inputs still intact)
+  // level 3: PPP (+ the P = +-Q case) | Q | ZZ3
   if (active) {
     if (role == 0) {
-      const fe_t h = fe_sub<B>(t[5][i], t[4][i]);
-      if (fe_is_zero(h) && !L.flag[i]) {
-        const fe_t rr = fe_sub<B>(t[3][i], t[6][i]);
-        L.fix[i] = fe_is_zero(rr) ? jac_dbl(*P) : jac_identity();
+      if (fe_is_zero(t[1][i]) && !L.flag[i]) {
+        L.fix[i] = fe_is_zero(t[3][i]) ? xyzz_from_jac(jac_dbl(xyzz_to_jac(*P))) : xyzz_identity();
         L.flag[i] = 1;
       }
-      t[5][i] = fe_mul<B>(h, t[8][i]);
+      t[8][i] = fe_mul<B>(t[1][i], t[4][i]);
     } else if (role == 1) {
-      t[7][i] = fe_mul<B>(t[4][i], t[8][i]);
+      t[0][i] = fe_mul<B>(t[0][i], t[4][i]);
     } else if (role == 2) {
-      const fe_t rr = fe_dbl<B>(fe_sub<B>(t[3][i], t[6][i]));
-      t[0][i] = fe_sqr<B>(rr);
+      t[6][i] = fe_mul<B>(t[6][i], t[4][i]);
     }
   }
   __syncthreads();
-  // level 5: m1 | m2
+  // level 4: R (Q - X3) | S1 PPP | ZZZ3
   if (active) {
     if (role == 0) {
-      const fe_t rr = fe_dbl<B>(fe_sub<B>(t[3][i], t[6][i]));
-      const fe_t x3 = fe_sub<B>(fe_sub<B>(t[0][i], t[5][i]), fe_dbl<B>(t[7][i]));
-      t[1][i] = fe_mul<B>(rr, fe_sub<B>(t[7][i], x3));
+      const fe_t x3 = fe_sub<B>(fe_sub<B>(t[5][i], t[8][i]), fe_dbl<B>(t[0][i]));
+      t[1][i] = fe_mul<B>(t[3][i], fe_sub<B>(t[0][i], x3));
     } else if (role == 1) {
-      t[8][i] = fe_mul<B>(t[6][i], t[5][i]);
+      t[4][i] = fe_mul<B>(t[2][i], t[8][i]);
+    } else if (role == 2) {
+      t[7][i] = fe_mul<B>(t[7][i], t[8][i]);
     }
   }
   __syncthreads();
   if (active && role == 0) {
-    jac_t r;
+    xyzz_t r;
     if (L.flag[i]) {
       r = L.fix[i];
     } else {
-      r.x = fe_sub<B>(fe_sub<B>(t[0][i], t[5][i]), fe_dbl<B>(t[7][i]));
-      r.y = fe_sub<B>(t[1][i], fe_dbl<B>(t[8][i]));
-      r.z = t[2][i];
+      r.x = fe_sub<B>(fe_sub<B>(t[5][i], t[8][i]), fe_dbl<B>(t[0][i]));
+      r.y = fe_sub<B>(t[1][i], t[4][i]);
+      r.zz = t[6][i];
+      r.zzz = t[7][i];
     }
     dst[i] = r;
   }
@@ -346,23 +378,23 @@ __device__ __forceinline__ void jac_add_block4(CoopAdd<ITEMS>& L, const jac_t* P
 // per window: W = sum_k k B_k by suffix scan + tree as below, every addition shared by four wave groups (512 threads per window)
 __global__ void __launch_bounds__(4 * MSM_BUCKETS) k_msm_window_reduce_coop(const jac_t* __restrict__ buckets, jac_t* __restrict__ window_sums) {
   __shared__ CoopAdd<MSM_BUCKETS> L;
-  __shared__ jac_t s[MSM_BUCKETS];
+  __shared__ xyzz_t s[MSM_BUCKETS];
   const int w = blockIdx.x + blockIdx.y * gridDim.x;
   // wave -> (role, item block): wave % 4 is the SIMD a wave lands on, so the four roles of an item block sit on four different SIMDs and a level
   // with <= 64 active items costs ONE product time; the second item block rotates its roles by two so the short levels (3 and 2 products) balance.
   const int wave = threadIdx.x >> 6, blk = wave >> 2;
   const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);
-  if (role == 0) s[k] = buckets[(size_t)w * MSM_BUCKETS + k];
+  if (role == 0) s[k] = xyzz_from_jac(buckets[(size_t)w * MSM_BUCKETS + k]);
   __syncthreads();
-  for (int off = 1; off < MSM_BUCKETS; off <<= 1) {  // suffix scan: s_k += s_{k+off}; in place is safe, inputs are read in levels 1-2 only
+  for (int off = 1; off < MSM_BUCKETS; off <<= 1) {  // suffix scan: s_k += s_{k+off}; in place is safe, results are stored after the last level
     const bool active = k + off < MSM_BUCKETS;
-    jac_add_block4<MSM_BUCKETS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+    xyzz_add_block4<MSM_BUCKETS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
   for (int off = MSM_BUCKETS / 2; off >= 1; off >>= 1) {
     const bool active = k < off;
-    jac_add_block4<MSM_BUCKETS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+    xyzz_add_block4<MSM_BUCKETS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
-  if (threadIdx.x == 0) window_sums[w] = s[0];
+  if (threadIdx.x == 0) window_sums[w] = xyzz_to_jac(s[0]);
 }
 
 // per window: W = sum_{k=1..128} k * B_k = sum_k S_k with S_k = sum_{j >= k} B_j (suffix scan, then tree)
@@ -625,30 +657,30 @@ __global__ void __launch_bounds__(256) k_fixed_base_rows(const fe_t* __restrict_
 }
 
 // The same with the block-cooperative addition: four scalars per 512-thread block, their 4 x 32 table entries are the 128 items; the five tree
-// levels cost ~11 us each instead of ~15 (the chain of dependent additions is all there is: 84 scalars do not fill the chip either way).
+// levels cost one cooperative addition each instead of ~15 us (the chain of dependent additions is all there is: 84 scalars do not fill the chip either way).
 __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
                                                                   jac_t* __restrict__ out) {
   __shared__ CoopAdd<128> L;
-  __shared__ jac_t s[128];
+  __shared__ xyzz_t s[128];
   const int wave = threadIdx.x >> 6, blk = wave >> 2;
   const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);  // roles of an item block on four different SIMDs (see k_msm_window_reduce_coop)
   const size_t idx = (size_t)blockIdx.x * 4 + (k >> 5);
   const int j = k & 31;
   if (role == 0) {
-    jac_t acc = jac_identity();
+    xyzz_t acc = xyzz_identity();
     if (idx < n) {
       const fe_t c = fe_to_canonical<SF>(scalars[idx]);
       const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
-      if (digit) acc = jac_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
+      if (digit) acc = xyzz_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
     }
     s[k] = acc;
   }
   __syncthreads();
-  for (int off = 16; off >= 1; off >>= 1) {  // in place is safe: inputs are read in levels 1-2 of the addition only
+  for (int off = 16; off >= 1; off >>= 1) {  // in place is safe: results are stored after the last level of the addition
     const bool active = j < off;
-    jac_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+    xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
-  if (role == 0 && j == 0 && idx < n) out[idx] = s[k];
+  if (role == 0 && j == 0 && idx < n) out[idx] = xyzz_to_jac(s[k]);
 }
 
 // ---- K9: LZ[i] = sum_j L[j] * poly[j*cols + i] ---------------------------------------------------------------------------
