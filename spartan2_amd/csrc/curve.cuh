@@ -122,3 +122,74 @@ SP_HD bool aff_on_curve(const aff_t& p) {
   fe_t rhs = fe_add<B>(fe_sub<B>(x3, fe_add<B>(fe_dbl<B>(p.x), p.x)), T256::b());
   return fe_eq(fe_sqr<B>(p.y), rhs);
 }
+
+// ---- XYZZ coordinates: (X, Y, ZZ, ZZZ) with x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; identity = (., ., 0, 0) ------------------------------------------
+// Chains of additions inside the kernels run in this form (add-2008-s: 12M + 2S in four dependency levels; madd-2008-s: 8M + 2S) instead of
+// Jacobian (add-2007-bl 11M + 5S in five levels; madd-2007-bl 7M + 4S); points enter and leave through two products each. The group element is the
+// same, so every normalised byte downstream is too.
+struct xyzz_t {
+  fe_t x, y, zz, zzz;
+};
+SP_HD bool xyzz_is_identity(const xyzz_t& p) { return fe_is_zero(p.zz); }
+SP_HD xyzz_t xyzz_identity() {
+  xyzz_t r;
+  r.x = r.y = r.zz = r.zzz = fe_zero();
+  return r;
+}
+SP_HD xyzz_t xyzz_from_jac(const jac_t& p) {
+  if (jac_is_identity(p)) return xyzz_identity();
+  xyzz_t r;
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = fe_sqr<B>(p.z);
+  r.zzz = fe_mul<B>(r.zz, p.z);
+  return r;
+}
+SP_HD xyzz_t xyzz_from_affine(const aff_t& p) {
+  if (aff_is_identity(p)) return xyzz_identity();
+  xyzz_t r;
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = r.zzz = fe_one<B>();
+  return r;
+}
+// Jacobian (X ZZ, Y ZZZ, ZZ): x = X ZZ / ZZ^2, y = Y ZZZ / ZZ^3 = Y / ZZZ since ZZ^3 = ZZZ^2
+SP_HD jac_t xyzz_to_jac(const xyzz_t& p) {
+  if (xyzz_is_identity(p)) return jac_identity();
+  jac_t r;
+  r.x = fe_mul<B>(p.x, p.zz);
+  r.y = fe_mul<B>(p.y, p.zzz);
+  r.z = p.zz;
+  return r;
+}
+SP_HD xyzz_t xyzz_dbl(const xyzz_t& p) { return xyzz_from_jac(jac_dbl(xyzz_to_jac(p))); }  // only on the P = Q path of an addition
+// madd-2008-s
+SP_HD xyzz_t xyzz_add_mixed(const xyzz_t& p, const aff_t& q) {
+  if (aff_is_identity(q)) return p;
+  if (xyzz_is_identity(p)) return xyzz_from_affine(q);
+  const fe_t u2 = fe_mul<B>(q.x, p.zz), s2 = fe_mul<B>(q.y, p.zzz);
+  const fe_t pd = fe_sub<B>(u2, p.x), rd = fe_sub<B>(s2, p.y);
+  if (fe_is_zero(pd)) return fe_is_zero(rd) ? xyzz_dbl(p) : xyzz_identity();
+  const fe_t pp = fe_sqr<B>(pd), ppp = fe_mul<B>(pd, pp), qv = fe_mul<B>(p.x, pp);
+  xyzz_t r;
+  r.x = fe_sub<B>(fe_sub<B>(fe_sqr<B>(rd), ppp), fe_dbl<B>(qv));
+  r.y = fe_sub<B>(fe_mul<B>(rd, fe_sub<B>(qv, r.x)), fe_mul<B>(p.y, ppp));
+  r.zz = fe_mul<B>(p.zz, pp);
+  r.zzz = fe_mul<B>(p.zzz, ppp);
+  return r;
+}
+// add-2008-s
+SP_HD xyzz_t xyzz_add(const xyzz_t& p, const xyzz_t& q) {
+  if (xyzz_is_identity(p)) return q;
+  if (xyzz_is_identity(q)) return p;
+  const fe_t u1 = fe_mul<B>(p.x, q.zz), u2 = fe_mul<B>(q.x, p.zz), s1 = fe_mul<B>(p.y, q.zzz), s2 = fe_mul<B>(q.y, p.zzz);
+  const fe_t pd = fe_sub<B>(u2, u1), rd = fe_sub<B>(s2, s1);
+  if (fe_is_zero(pd)) return fe_is_zero(rd) ? xyzz_dbl(p) : xyzz_identity();
+  const fe_t pp = fe_sqr<B>(pd), ppp = fe_mul<B>(pd, pp), qv = fe_mul<B>(u1, pp);
+  xyzz_t r;
+  r.x = fe_sub<B>(fe_sub<B>(fe_sqr<B>(rd), ppp), fe_dbl<B>(qv));
+  r.y = fe_sub<B>(fe_mul<B>(rd, fe_sub<B>(qv, r.x)), fe_mul<B>(s1, ppp));
+  r.zz = fe_mul<B>(fe_mul<B>(p.zz, q.zz), pp);
+  r.zzz = fe_mul<B>(fe_mul<B>(p.zzz, q.zzz), ppp);
+  return r;
+}

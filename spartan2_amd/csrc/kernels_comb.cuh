@@ -84,10 +84,10 @@ __global__ void __launch_bounds__(256, MINW) k_comb_rows(const fe_t* __restrict_
   constexpr int MAXW = (257 + C - 1) / C;
   constexpr unsigned E = 1u << (C - 1);
   __shared__ short dg[MAXW][256];
-  __shared__ jac_t red[256];
+  __shared__ xyzz_t red[256];
   const size_t row = rows[blockIdx.x];
   const unsigned len = comb_row_len(row, cols, n);
-  jac_t acc = jac_identity();
+  xyzz_t acc = xyzz_identity();  // XYZZ: 10 products per mixed addition instead of 11, 14 instead of 16 in the tree
   for (unsigned j = threadIdx.x; j < len; j += 256) {
     const fe_t sc = canon[row * cols + j];
     int carry = 0;
@@ -124,17 +124,17 @@ __global__ void __launch_bounds__(256, MINW) k_comb_rows(const fe_t* __restrict_
       }
       if (d) {
         if (d < 0) q.y = fe_neg<B>(q.y);
-        acc = jac_add_mixed(acc, q);
+        acc = xyzz_add_mixed(acc, q);
       }
     }
   }
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off >= 1; off >>= 1) {
-    if ((int)threadIdx.x < off) red[threadIdx.x] = jac_add(red[threadIdx.x], red[threadIdx.x + off]);
+    if ((int)threadIdx.x < off) red[threadIdx.x] = xyzz_add(red[threadIdx.x], red[threadIdx.x + off]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) out[blockIdx.x] = xyzz_to_jac(red[0]);
 }
 
 

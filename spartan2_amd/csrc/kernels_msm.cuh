@@ -28,6 +28,18 @@ __device__ __forceinline__ jac_t shfl_down_jac(const jac_t& a, int delta) {
   return r;
 }
 
+__device__ __forceinline__ xyzz_t shfl_down_xyzz(const xyzz_t& a, int delta) {
+  xyzz_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r.x.v[i] = __shfl_down(a.x.v[i], delta, 64);
+    r.y.v[i] = __shfl_down(a.y.v[i], delta, 64);
+    r.zz.v[i] = __shfl_down(a.zz.v[i], delta, 64);
+    r.zzz.v[i] = __shfl_down(a.zzz.v[i], delta, 64);
+  }
+  return r;
+}
+
 // canonical (non-Montgomery) limbs of each scalar
 __global__ void __launch_bounds__(256) k_to_canonical(const fe_t* __restrict__ in, size_t n, fe_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = fe_to_canonical<SF>(in[i]);
@@ -222,7 +234,7 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict_
   const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned bucket = gid / MSM_LANES_PER_BUCKET, sub = gid % MSM_LANES_PER_BUCKET;
   const unsigned total = (unsigned)windows * MSM_BUCKETS;
-  jac_t acc = jac_identity();
+  xyzz_t acc = xyzz_identity();
   if (bucket < total) {
     const unsigned w = bucket / MSM_BUCKETS, k = bucket % MSM_BUCKETS;
     const unsigned lo = start[(size_t)w * (MSM_BUCKETS + 1) + k], hi = start[(size_t)w * (MSM_BUCKETS + 1) + k + 1];
@@ -230,15 +242,15 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict_
       const unsigned e = order[(size_t)w * n + p];
       aff_t q = bases[e & 0x7fffffffu];
       if (e & 0x80000000u) q = aff_neg(q);
-      acc = jac_add_mixed(acc, q);
+      acc = xyzz_add_mixed(acc, q);
     }
   }
 #pragma unroll
   for (int d = MSM_LANES_PER_BUCKET / 2; d >= 1; d >>= 1) {
-    jac_t o = shfl_down_jac(acc, d);
-    if (sub < (unsigned)d) acc = jac_add(acc, o);
+    xyzz_t o = shfl_down_xyzz(acc, d);
+    if (sub < (unsigned)d) acc = xyzz_add(acc, o);
   }
-  if (bucket < total && sub == 0) buckets[bucket] = acc;
+  if (bucket < total && sub == 0) buckets[bucket] = xyzz_to_jac(acc);
 }
 
 // ---- block-cooperative addition in XYZZ coordinates -------------------------------------------------------------------------------------------
@@ -248,41 +260,6 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum(const aff_t* __restrict_
 // Coordinates are (X, Y, ZZ, ZZZ) with x = X / ZZ, y = Y / ZZZ (add-2008-s): 14 products in FOUR levels of <= 4 - the Jacobian add-2007-bl this
 // replaces needs 16 in five - so a chain of dependent additions is a fifth shorter. Points enter (Jacobian buckets, affine table entries) and leave
 // (Jacobian sums for the host's Horner / normalisation) through two products each; the group element, hence every byte downstream, is the same.
-struct xyzz_t {
-  fe_t x, y, zz, zzz;
-};
-__device__ __forceinline__ bool xyzz_is_identity(const xyzz_t& p) { return fe_is_zero(p.zz); }
-__device__ __forceinline__ xyzz_t xyzz_identity() {
-  xyzz_t r;
-  r.x = r.y = r.zz = r.zzz = fe_zero();
-  return r;
-}
-__device__ __forceinline__ xyzz_t xyzz_from_jac(const jac_t& p) {
-  if (jac_is_identity(p)) return xyzz_identity();
-  xyzz_t r;
-  r.x = p.x;
-  r.y = p.y;
-  r.zz = fe_sqr<B>(p.z);
-  r.zzz = fe_mul<B>(r.zz, p.z);
-  return r;
-}
-__device__ __forceinline__ xyzz_t xyzz_from_affine(const aff_t& p) {
-  if (aff_is_identity(p)) return xyzz_identity();
-  xyzz_t r;
-  r.x = p.x;
-  r.y = p.y;
-  r.zz = r.zzz = fe_one<B>();
-  return r;
-}
-// Jacobian (X ZZ, Y ZZZ, ZZ): x = X ZZ / ZZ^2, y = Y ZZZ / ZZ^3 = Y / ZZZ since ZZ^3 = ZZZ^2
-__device__ __forceinline__ jac_t xyzz_to_jac(const xyzz_t& p) {
-  if (xyzz_is_identity(p)) return jac_identity();
-  jac_t r;
-  r.x = fe_mul<B>(p.x, p.zz);
-  r.y = fe_mul<B>(p.y, p.zzz);
-  r.z = p.zz;
-  return r;
-}
 template <int ITEMS>
 struct CoopAdd {
   fe_t t[9][ITEMS];   // U1 -> Q | U2 -> P -> Y3a | S1 | S2 -> R | PP -> Y3b | RR | ZZ1 ZZ2 -> ZZ3 | ZZZ1 ZZZ2 -> ZZZ3 | PPP
