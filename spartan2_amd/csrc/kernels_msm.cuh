@@ -376,21 +376,21 @@ __global__ void __launch_bounds__(4 * MSM_BUCKETS) k_msm_window_reduce_coop(cons
 
 // per window: W = sum_{k=1..128} k * B_k = sum_k S_k with S_k = sum_{j >= k} B_j (suffix scan, then tree)
 __global__ void __launch_bounds__(MSM_BUCKETS) k_msm_window_reduce(const jac_t* __restrict__ buckets, jac_t* __restrict__ window_sums) {
-  __shared__ jac_t s[MSM_BUCKETS];
+  __shared__ xyzz_t s[MSM_BUCKETS];
   const int w = blockIdx.x + blockIdx.y * gridDim.x, k = threadIdx.x;  // blockIdx.y = row of a shared-weights batch
-  s[k] = buckets[(size_t)w * MSM_BUCKETS + k];
+  s[k] = xyzz_from_jac(buckets[(size_t)w * MSM_BUCKETS + k]);
   __syncthreads();
   for (int off = 1; off < MSM_BUCKETS; off <<= 1) {  // Hillis-Steele suffix scan
-    jac_t o = (k + off < MSM_BUCKETS) ? s[k + off] : jac_identity();
+    xyzz_t o = (k + off < MSM_BUCKETS) ? s[k + off] : xyzz_identity();
     __syncthreads();
-    if (k + off < MSM_BUCKETS) s[k] = jac_add(s[k], o);
+    if (k + off < MSM_BUCKETS) s[k] = xyzz_add(s[k], o);
     __syncthreads();
   }
   for (int off = MSM_BUCKETS / 2; off >= 1; off >>= 1) {
-    if (k < off) s[k] = jac_add(s[k], s[k + off]);
+    if (k < off) s[k] = xyzz_add(s[k], s[k + off]);
     __syncthreads();
   }
-  if (k == 0) window_sums[w] = s[0];
+  if (k == 0) window_sums[w] = xyzz_to_jac(s[0]);
 }
 
 // ---- batched row MSMs: many rows, ONE base vector, different scalars (PCS::commit on non-small witnesses, hyrax_pc.rs:230-300; the 2048 x 2048
@@ -467,14 +467,14 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum_rows(const aff_t* __rest
   if (b >= total_buckets) return;
   const size_t rw = b / MSM_BUCKETS, k = b % MSM_BUCKETS;  // rw = row-slot * windows + window
   const unsigned lo = start[rw * (MSM_BUCKETS + 1) + k], hi = start[rw * (MSM_BUCKETS + 1) + k + 1];
-  jac_t acc = jac_identity();
+  xyzz_t acc = xyzz_identity();
   for (unsigned p = lo; p < hi; ++p) {
     const unsigned e = order[rw * cols + p];
     aff_t q = bases[e & 0x7fffffffu];
     if (e & 0x80000000u) q = aff_neg(q);
-    acc = jac_add_mixed(acc, q);
+    acc = xyzz_add_mixed(acc, q);
   }
-  buckets[b] = acc;
+  buckets[b] = xyzz_to_jac(acc);
 }
 
 // Window sums for the batched path, work-efficient form: 8 adjacent lanes per (row, window); lane s runs the classical running sum over its 16
@@ -484,32 +484,33 @@ __global__ void __launch_bounds__(256) k_msm_window_reduce_seg(const jac_t* __re
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t win = gid >> 3;
   const int seg = (int)(gid & 7);
-  jac_t run = jac_identity(), acc = jac_identity();
+  xyzz_t run = xyzz_identity(), acc = xyzz_identity();
   if (win < nwin) {
     const jac_t* b = buckets + win * MSM_BUCKETS + seg * 16;
     for (int i = 15; i >= 0; --i) {
-      run = jac_add(run, b[i]);
-      acc = jac_add(acc, run);
+      run = xyzz_add(run, xyzz_from_jac(b[i]));
+      acc = xyzz_add(acc, run);
     }
   }
   // X = sum_s acc_s (3-level tree over the 8 lanes); Y = sum_s s * run_s by a running sum in lane 0 of the group
-  jac_t x = acc;
+  xyzz_t x = acc;
 #pragma unroll
   for (int d = 4; d >= 1; d >>= 1) {
-    jac_t o = shfl_down_jac(x, d);
-    if (seg < d) x = jac_add(x, o);
+    xyzz_t o = shfl_down_xyzz(x, d);
+    if (seg < d) x = xyzz_add(x, o);
   }
-  jac_t rr = jac_identity(), y = jac_identity();
+  xyzz_t rr = xyzz_identity(), y = xyzz_identity();
   for (int s = 7; s >= 1; --s) {
-    jac_t rs = shfl_down_jac(run, s);  // lane 0 of the group receives run_s
+    xyzz_t rs = shfl_down_xyzz(run, s);  // lane 0 of the group receives run_s
     if (seg == 0) {
-      rr = jac_add(rr, rs);
-      y = jac_add(y, rr);
+      rr = xyzz_add(rr, rs);
+      y = xyzz_add(y, rr);
     }
   }
   if (win < nwin && seg == 0) {
-    for (int k = 0; k < 4; ++k) y = jac_dbl(y);
-    window_sums[win] = jac_add(x, y);
+    jac_t yj = xyzz_to_jac(y);
+    for (int k = 0; k < 4; ++k) yj = jac_dbl(yj);
+    window_sums[win] = jac_add(xyzz_to_jac(x), yj);
   }
 }
 
@@ -578,21 +579,21 @@ __global__ void __launch_bounds__(256) k_fold_tables(const fe_t* const* __restri
 // One block per Hyrax row: sum of bases[j] where the canonical scalar of column j equals 1.
 __global__ void __launch_bounds__(256) k_msm_binary_rows(const fe_t* __restrict__ canon, size_t n, size_t cols, const aff_t* __restrict__ bases,
                                                          const unsigned* __restrict__ row_flags, jac_t* __restrict__ out) {
-  __shared__ jac_t s[256];
+  __shared__ xyzz_t s[256];
   const size_t row = blockIdx.x;
   const size_t lo = row * cols, hi = (lo + cols < n) ? lo + cols : n;
-  jac_t acc = jac_identity();
+  xyzz_t acc = xyzz_identity();
   if (row_flags[row] == 1u) {  // only rows that really are 0/1 valued; others are handled by the digit path
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
-      if (canon[i].v[0] & 1u) acc = jac_add_mixed(acc, bases[i - lo]);
+      if (canon[i].v[0] & 1u) acc = xyzz_add_mixed(acc, bases[i - lo]);
   }
   s[threadIdx.x] = acc;
   __syncthreads();
   for (int off = 128; off >= 1; off >>= 1) {
-    if ((int)threadIdx.x < off) s[threadIdx.x] = jac_add(s[threadIdx.x], s[threadIdx.x + off]);
+    if ((int)threadIdx.x < off) s[threadIdx.x] = xyzz_add(s[threadIdx.x], s[threadIdx.x + off]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[row] = s[0];
+  if (threadIdx.x == 0) out[row] = xyzz_to_jac(s[0]);
 }
 
 // ---- K12: fixed-base multiples of h --------------------------------------------------------------------------------------
@@ -619,18 +620,18 @@ __global__ void __launch_bounds__(256) k_fixed_base_rows(const fe_t* __restrict_
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t idx = gid >> 5;
   const int j = (int)(gid & 31);
-  jac_t acc = jac_identity();
+  xyzz_t acc = xyzz_identity();
   if (idx < n) {
     const fe_t c = fe_to_canonical<SF>(scalars[idx]);
     const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
-    if (digit) acc = jac_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
+    if (digit) acc = xyzz_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
   }
 #pragma unroll
   for (int d = 16; d >= 1; d >>= 1) {
-    jac_t o = shfl_down_jac(acc, d);
-    if (j < d) acc = jac_add(acc, o);
+    xyzz_t o = shfl_down_xyzz(acc, d);
+    if (j < d) acc = xyzz_add(acc, o);
   }
-  if (idx < n && j == 0) out[idx] = acc;
+  if (idx < n && j == 0) out[idx] = xyzz_to_jac(acc);
 }
 
 // The same with the block-cooperative addition: four scalars per 512-thread block, their 4 x 32 table entries are the 128 items; the five tree
