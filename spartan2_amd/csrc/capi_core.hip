@@ -163,6 +163,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   for (int i = 0; i < 2; ++i)
     if (c->h_pinned_lane[i]) hipHostFree(c->h_pinned_lane[i]);
   if (c->h_pinned_fb) hipHostFree(c->h_pinned_fb);
+  if (c->h_pinned_fbs) hipHostFree(c->h_pinned_fbs);
   if (c->h_stage) hipHostFree(c->h_stage);
   for (hipEvent_t e : c->stage_ev)
     if (e) hipEventDestroy(e);

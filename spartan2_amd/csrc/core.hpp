@@ -47,6 +47,7 @@ struct sp_ctx {
   void* mail_alloc = nullptr;
   bool mail_dev = false;
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs
+  void* h_pinned_fbs = nullptr;  // pinned staging of the synchronous fixed-base calls (<= 1024 scalars: the per-round commitments of the ZK verifier circuit)
   hipEvent_t fb_ev = nullptr;
   hipEvent_t fb_event() {
     if (!fb_ev) hipEventCreateWithFlags(&fb_ev, hipEventDisableTiming);

@@ -510,47 +510,33 @@ __global__ void __launch_bounds__(256) k_eval_quad_stream_lowhi(const fe_t* __re
   l1 = lazy_add(l1, l0);
   stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
 }
-constexpr int SUM_LAZY_THREADS = 1024;
+constexpr int SUM_LAZY_THREADS = 256;  // a 1024-thread fully lazy form was measured: 16.1 us per call against 12.1 (rocprof averages)
 // Second stage for the streaming kernels: per group of 2^group_log2 consecutive blocks, lazy-sum, reduce mod p, multiply by
 // eq_out[group] (when given), then a modular block sum over groups. One block.
-__global__ void __launch_bounds__(SUM_LAZY_THREADS) k_sum_partials_lazy(const lazy9_t* __restrict__ partials, size_t nparts, int group_log2,
-                                                                        const fe_t* __restrict__ eq_out, fe_t* __restrict__ out, unsigned seq) {
-  // every level of the tree stays lazy (multiword adds): modular work is one reduction (+ the eq_out product) per group and ONE reduction per sum at the
-  // end. 1024 threads: at most one group per thread for the <= 4096 block partials of a 2^20 launch (the 256-thread form spent 7-12 us per call here,
-  // six calls on the critical path of a prove).
-  __shared__ lazy9_t sm[SUM_LAZY_THREADS / 64][2];
+__global__ void __launch_bounds__(256) k_sum_partials_lazy(const lazy9_t* __restrict__ partials, size_t nparts, int group_log2,
+                                                           const fe_t* __restrict__ eq_out, fe_t* __restrict__ out, unsigned seq) {
+  __shared__ fe_t smem[2 * 4];
   const size_t ngroups = nparts >> group_log2, per = (size_t)1 << group_log2;
-  lazy9_t t0 = lazy_from(fe_zero()), t1 = lazy_from(fe_zero());
+  fe_t acc[2] = {fe_zero(), fe_zero()};
   for (size_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
     lazy9_t l0 = partials[(g * per) * 2], l1 = partials[(g * per) * 2 + 1];
     for (size_t k = 1; k < per; ++k) {
       l0 = lazy_add(l0, partials[(g * per + k) * 2]);
       l1 = lazy_add(l1, partials[(g * per + k) * 2 + 1]);
     }
+    fe_t f0 = lazy_reduce(l0), f1 = lazy_reduce(l1);
     if (eq_out) {
       const fe_t eo = eq_out[g];
-      l0 = lazy_from(fe_mul<S>(lazy_reduce(l0), eo));
-      l1 = lazy_from(fe_mul<S>(lazy_reduce(l1), eo));
+      f0 = fe_mul<S>(f0, eo);
+      f1 = fe_mul<S>(f1, eo);
     }
-    t0 = lazy_add(t0, l0);
-    t1 = lazy_add(t1, l1);
+    acc[0] = fe_add<S>(acc[0], f0);
+    acc[1] = fe_add<S>(acc[1], f1);
   }
-  t0 = lazy_wave_sum(t0);
-  t1 = lazy_wave_sum(t1);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
-    sm[wave][0] = t0;
-    sm[wave][1] = t1;
-  }
-  __syncthreads();
+  block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
-    lazy9_t a0 = sm[0][0], a1 = sm[0][1];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
-      a0 = lazy_add(a0, sm[w][0]);
-      a1 = lazy_add(a1, sm[w][1]);
-    }
-    out[0] = lazy_reduce(a0);
-    out[1] = lazy_reduce(a1);
+    out[0] = acc[0];
+    out[1] = acc[1];
     publish_result(out, seq);
   }
 }
