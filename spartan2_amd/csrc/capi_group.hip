@@ -2,6 +2,7 @@
 // Device: digit sort, bucket accumulation, per-window weighted reduction, binary row sums, fixed-base lookups,
 // row-matrix product. Host (inside the library): window Horner, adding the blind term, batch normalisation.
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
@@ -262,6 +263,19 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
     return SP_OK;
   }
   const int windows = spk::MSM_MAX_WINDOWS;
+  static const bool laps = [] {
+    const char* e = getenv("SPARTAN_HOST_LAPS");
+    return e && e[0] == '1';
+  }();
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_lap = now();
+  auto lap = [&](const char* what) {
+    if (!laps) return;
+    (void)hipStreamSynchronize(c->stream);
+    const double t = now();
+    fprintf(stderr, "msm_shared_weights lap %-20s %8.3f ms\n", what, t - t_lap);
+    t_lap = t;
+  };
   fe_t* canon;
   int rc;
   if ((rc = upload_canonical(c, weights, n, &canon))) return rc;
@@ -277,12 +291,24 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
   SP_HIP(hipMemcpyAsync(dbases, bases_rows, rows * n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(spk::k_fold_sign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, canon, n, folded);
   // the digit decomposition / bucket order is shared by every row (msm.rs:266-300); buckets and window sums are per row
+  lap("upload");
   hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, c->stream, folded, (unsigned)n, order, start);
-  unsigned lanes = (unsigned)windows * spk::MSM_BUCKETS * spk::MSM_LANES_PER_BUCKET;
-  c->timed("msm_shared_bucket_sum", 64ull * n * rows, [&] {
-    hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, c->stream, dbases, (unsigned)n, order, start, windows, buckets);
-  });
-  hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
+  if (rows >= 64) {  // throughput regime: one lane per (row, window, bucket), work-efficient window sums
+    const size_t total = rows * (size_t)windows * spk::MSM_BUCKETS, nwin = rows * (size_t)windows;
+    c->timed("msm_shared_bucket_sum", 64ull * n * rows, [&] {
+      hipLaunchKernelGGL(spk::k_msm_bucket_sum_shared, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dbases, (unsigned)n, order, start, windows, total, buckets);
+    });
+    lap("sort + bucket sums");
+    hipLaunchKernelGGL(spk::k_msm_window_reduce_seg, dim3((unsigned)((nwin * 8 + 255) / 256)), dim3(256), 0, c->stream, buckets, nwin, wsum);
+  } else {
+    unsigned lanes = (unsigned)windows * spk::MSM_BUCKETS * spk::MSM_LANES_PER_BUCKET;
+    c->timed("msm_shared_bucket_sum", 64ull * n * rows, [&] {
+      hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, c->stream, dbases, (unsigned)n, order, start, windows, buckets);
+    });
+    lap("sort + bucket sums");
+    hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
+  }
+  lap("window sums");
   std::vector<jac_t> res(rows);
   if (rows <= 64) {
     // few rows: the 256-doubling window Horner is a latency chain (~3 ms for one lane per row on the device, ~60 us per row on the host)
@@ -302,9 +328,11 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
     SP_HIP(hipMemcpyAsync(res.data(), drows, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
     SP_HIP(hipStreamSynchronize(c->stream));
   }
+  lap("horner");
   std::vector<aff_t> a(rows);
   normalize_batch(res, a.data());
   memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
+  lap("normalize");
   return SP_OK;
 }
 

@@ -477,6 +477,28 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum_rows(const aff_t* __rest
   buckets[b] = xyzz_to_jac(acc);
 }
 
+// Shared-weights batch (msm.rs:228-356) in the throughput regime - many rows, few points per bucket (the commitment fold of hundreds of instances:
+// 512 rows x 256 weights at BASELINE config 5): one lane per (row, window, bucket) walks its bucket's entries sequentially; the digit order is
+// shared by every row, the bases are the row's own. (The 8-lanes-per-bucket form with its shuffle tree pays three dependent additions per bucket
+// even when the bucket holds two points: 11.8 ms against 1.4 ms here.)
+__global__ void __launch_bounds__(256) k_msm_bucket_sum_shared(const aff_t* __restrict__ bases /* [rows][n] */, unsigned n, const unsigned* __restrict__ order,
+                                                               const unsigned* __restrict__ start, int windows, size_t total_buckets, jac_t* __restrict__ buckets) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= total_buckets) return;
+  const size_t per_row = (size_t)windows * MSM_BUCKETS, row = b / per_row, wk = b % per_row;
+  const size_t w = wk / MSM_BUCKETS, k = wk % MSM_BUCKETS;
+  const unsigned lo = start[w * (MSM_BUCKETS + 1) + k], hi = start[w * (MSM_BUCKETS + 1) + k + 1];
+  const aff_t* rb = bases + row * n;
+  xyzz_t acc = xyzz_identity();
+  for (unsigned p = lo; p < hi; ++p) {
+    const unsigned e = order[w * n + p];
+    aff_t q = rb[e & 0x7fffffffu];
+    if (e & 0x80000000u) q = aff_neg(q);
+    acc = xyzz_add_mixed(acc, q);
+  }
+  buckets[b] = xyzz_to_jac(acc);
+}
+
 // Window sums for the batched path, work-efficient form: 8 adjacent lanes per (row, window); lane s runs the classical running sum over its 16
 // buckets (acc_s = sum_i (i+1) B_{16s+i}, run_s = sum_i B_{16s+i}: 32 additions), then W = sum_s acc_s + 16 * sum_s s * run_s.
 // ~280 additions per window instead of the 128 x 14 of the scan form (which is the right shape only when a single MSM must finish fast).

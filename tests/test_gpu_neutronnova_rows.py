@@ -50,7 +50,7 @@ def test_fold_tables_matches_fold_multiple(ctx, n_inst, dim, bits):
     assert (out.read() == want).all()
 
 
-@pytest.mark.parametrize("n,rows", [(2, 3), (7, 5), (32, 16), (64, 4)])
+@pytest.mark.parametrize("n,rows", [(2, 3), (7, 5), (32, 16), (64, 4), (16, 80), (5, 130)])  # rows >= 64: the throughput kernels
 def test_msm_shared_weights(ctx, n, rows):
     # msm.rs:228-356; also what fold_commitments computes per Hyrax row (hyrax_pc.rs:775-790)
     rng = np.random.default_rng(SEED + 100 + n)
