@@ -25,7 +25,13 @@ struct SpartanProverKey {  // src/spartan.rs:30-58
   size_t num_vars = 0, num_extra = 0, num_cols = 0;
   uint8_t vk_digest[32];
   std::vector<aff_t> gens, gens_s;
+  // verify()'s device workspaces (T_x, T_y, the three products M T_y): allocated by the first verify on this key and kept - five hipMalloc / hipFree
+  // pairs of 32-64 MB were half of a 3.3 ms verify. One verify at a time per key (as for every handle of the ABI).
+  mutable sp_table *v_Tx = nullptr, *v_Ty = nullptr, *v_mv[3] = {nullptr, nullptr, nullptr};
   ~SpartanProverKey() {
+    sp_table_free(v_Tx);
+    sp_table_free(v_Ty);
+    for (sp_table* t : v_mv) sp_table_free(t);
     sp_shape_free(S);
     sp_ck_free(ck);
     sp_ck_free(ck_s);
@@ -604,15 +610,6 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
 // products with T_x = eq(r_x); comm_LZ = <L, comm rows> (hyrax_pc.rs:480-531) and the IPA check's <z_vec, ck> (ipa.rs:173-221) as device MSMs.
 // The O(log N) parts (transcript, round-polynomial checks, single scalar multiplications) stay on the host. Returns 0 = accept, else the index
 // of the failed check (1 shape, 2 outer sum-check, 3 outer claim, 4 inner sum-check, 5 inner claim, 6 opening) — the oracle's codes.
-static jac_t scalar_mul_host(const jac_t& p, const fe_t& k) {  // double-and-add on the canonical scalar (5 calls per verify)
-  const fe_t c = fe_to_canonical<S>(k);
-  jac_t acc = jac_identity();
-  for (int i = 255; i >= 0; --i) {
-    acc = jac_dbl(acc);
-    if ((c.v[i >> 5] >> (i & 31)) & 1u) acc = jac_add(acc, p);
-  }
-  return acc;
-}
 static bool same_point(const jac_t& a, const jac_t& b) {
   const aff_t x = jac_to_affine(a), y = jac_to_affine(b);
   return fe_eq(x.x, y.x) && fe_eq(x.y, y.y);
@@ -694,6 +691,18 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uin
     if (!aff_on_curve(comm_W[i])) return 1;
   if (!aff_on_curve(delta) || !aff_on_curve(beta)) return 1;
 
+  // <z_vec, ck> (ipa.rs:196-203) depends on nothing but the proof: its device part runs under everything that follows
+  struct ZJob {
+    sp_ctx* ctx;
+    const sp_ck* key;
+    sp_msm_job* job = nullptr;
+    ~ZJob() {
+      uint64_t sink[8];
+      if (job) sp_msm_ck_finish(ctx, key, job, nullptr, sink);  // an early return still owns the job
+    }
+  } zjob{ctx, pk.ck};
+  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(z_vec), nz, &zjob.job), "<z, ck> (begin)");
+
   Tr tr(ctx, "SpartanSNARK");
   tr.absorb("vk", pk.vk_digest, 32);
   tr.absorb_scalars("public_values", publics, d.num_public);
@@ -729,19 +738,17 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uin
   // A(rx,ry), B(rx,ry), C(rx,ry) = T_x^T (M T_y): one SpMV against T_y, three dot products with T_x
   fe_t eabc[3];
   {
-    sp_table *Tx = nullptr, *Ty = nullptr, *mv[3] = {nullptr, nullptr, nullptr};
-    struct Guard {
-      sp_table *&a, *&b, **m;
-      ~Guard() {
-        sp_table_free(a);
-        sp_table_free(b);
-        for (int i = 0; i < 3; ++i) sp_table_free(m[i]);
-      }
-    } guard{Tx, Ty, mv};
-    ck(sp_eq_table(ctx, u64p(r_x.data()), lx, &Tx), "T_x");
-    ck(sp_eq_table(ctx, u64p(r_y.data()), ly, &Ty), "T_y");
+    if (!pk.v_Tx) {
+      ck(sp_table_zeros(ctx, (size_t)1 << lx, (size_t)-1, (size_t)-1, &pk.v_Tx), "T_x alloc");
+      ck(sp_table_zeros(ctx, (size_t)1 << ly, (size_t)-1, (size_t)-1, &pk.v_Ty), "T_y alloc");
+      for (int i = 0; i < 3; ++i) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &pk.v_mv[i]), "M T_y alloc");
+    }
+    sp_table *Tx = pk.v_Tx, *Ty = pk.v_Ty, **mv = pk.v_mv;
+    ck(sp_table_set_len(Tx, (size_t)1 << lx, (size_t)-1, (size_t)-1), "T_x len");
+    ck(sp_table_set_len(Ty, (size_t)1 << ly, (size_t)-1, (size_t)-1), "T_y len");
+    ck(sp_eq_table_into(ctx, u64p(r_x.data()), lx, Tx), "T_x");
+    ck(sp_eq_table_into(ctx, u64p(r_y.data()), ly, Ty), "T_y");
     ck(sp_table_set_len(Ty, pk.num_cols, (size_t)-1, (size_t)-1), "T_y as z");
-    for (int i = 0; i < 3; ++i) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &mv[i]), "M T_y");
     ck(sp_multiply_vec(ctx, pk.S, Ty, mv[0], mv[1], mv[2]), "M T_y");
     for (int i = 0; i < 3; ++i) ck(sp_table_dot(ctx, Tx, mv[i], N, u64p(&eabc[i])), "T_x . (M T_y)");
   }
@@ -779,17 +786,24 @@ int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uin
   }
   const fe_t rr = tr.squeeze("r");
   if (R.size() != nz) return 6;
-  aff_t zc;  // <z_vec, ck> on the device
-  ck(sp_msm_ck(ctx, pk.ck, u64p(z_vec), nz, nullptr, u64p(&zc.x)), "<z, ck>");
-  const jac_t h = jac_from_affine(pk.gens[W_]), h_c = jac_from_affine(pk.gens_s[1]), ck_c = jac_from_affine(pk.gens_s[0]);
-  const jac_t lhs1 = jac_add(scalar_mul_host(jac_from_affine(comm_LZ), rr), jac_from_affine(delta));
-  const jac_t rhs1 = jac_add(jac_from_affine(zc), scalar_mul_host(h, z_delta));
-  if (!same_point(lhs1, rhs1)) return 6;
+  // r * comm_LZ and r * comm_eval_W: one wNAF scalar per pair of points (vartime_scalar_mul, msm.rs:779-867); h * z_delta and
+  // <z_vec, R> * ck_c + z_beta * h_c through the fixed-base tables of the keys (hyrax_pc.rs:81-96)
+  aff_t pr2[2] = {comm_LZ, comm_eval_W}, rp[2], hzd, rhs2;
+  ck(sp_vartime_scalar_mul(ctx, u64p(&pr2[0].x), 2, u64p(&rr), u64p(&rp[0].x)), "r * (comm_LZ, comm_eval_W)");
+  ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(&z_delta), 1, u64p(&hzd.x)), "h * z_delta");
   fe_t ip = fe_zero();
   for (size_t i = 0; i < nz; ++i) ip = fe_add<S>(ip, fe_mul<S>(z_vec[i], R[i]));
-  const jac_t lhs2 = jac_add(scalar_mul_host(jac_from_affine(comm_eval_W), rr), jac_from_affine(beta));
-  const jac_t rhs2 = jac_add(scalar_mul_host(ck_c, ip), scalar_mul_host(h_c, z_beta));
-  if (!same_point(lhs2, rhs2)) return 6;
+  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&z_beta), u64p(&rhs2.x)), "<z, R> * ck_c + z_beta * h_c");
+  aff_t zc;  // <z_vec, ck>: started before the transcript work
+  {
+    sp_msm_job* j = zjob.job;
+    zjob.job = nullptr;
+    ck(sp_msm_ck_finish(ctx, pk.ck, j, nullptr, u64p(&zc.x)), "<z, ck> (finish)");
+  }
+  const jac_t lhs1 = jac_add_mixed(jac_from_affine(rp[0]), delta), rhs1 = jac_add_mixed(jac_from_affine(zc), hzd);
+  if (!same_point(lhs1, rhs1)) return 6;
+  const jac_t lhs2 = jac_add_mixed(jac_from_affine(rp[1]), beta);
+  if (!same_point(lhs2, jac_from_affine(rhs2))) return 6;
   if (out_publics) memcpy(out_publics, publics, d.num_public * sizeof(fe_t));  // verify() returns the public values it accepted (src/spartan.rs:577)
   return 0;
 }
