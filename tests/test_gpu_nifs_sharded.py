@@ -159,6 +159,16 @@ def test_cpp_driver_one_rank_rccl():
         assert (want[key] == got[key]).all(), key
     for key, m in (("A", oshape.num_cons), ("B", oshape.num_cons), ("C", oshape.num_cons), ("folded_W", oshape.num_vars)):
         assert (want[key] == got[key].read(0, m)).all(), key
+    # layers prepared once (prep_prove's cached_step_matvec / cached_step_i64) serve every prove: the rounds only read them
+    prepared = host.nifs_prepare(ctx, shape, dims, X, tabs, True)
+    for _ in range(2):
+        again = host.nifs_prove_sharded(ctx, comm, shape, dims, ck, comms, X, tabs, r_W, True, hip.Transcript(ctx, b"neutronnova_prove"),
+                                        ol.transcript_round_hook(ol.Transcript(b"vc")), prepared=prepared)
+        for key in ("polys", "r_bs", "tail", "folded_rW", "folded_comm"):
+            assert (want[key] == again[key]).all(), key
+        for key, m in (("A", oshape.num_cons), ("C", oshape.num_cons), ("folded_W", oshape.num_vars)):
+            assert (want[key] == again[key].read(0, m)).all(), key
+    host.nifs_free(prepared)
     comm.close()
     L.orc_hyrax_free(okey)
     ctx.close()
