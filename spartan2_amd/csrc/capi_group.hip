@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "core.hpp"
@@ -315,13 +316,26 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
     std::vector<jac_t> ws(rows * windows);
     SP_HIP(hipMemcpyAsync(ws.data(), wsum, ws.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
     SP_HIP(hipStreamSynchronize(c->stream));
-    for (size_t r = 0; r < rows; ++r) {
+    auto horner = [&](size_t r) {
       jac_t acc = jac_identity();
       for (int w = windows - 1; w >= 0; --w) {
         for (int k = 0; k < spk::MSM_C; ++k) acc = jac_dbl(acc);
         acc = jac_add(acc, ws[r * windows + w]);
       }
       res[r] = acc;
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 8) nt = 8;
+    if (nt > rows) nt = (unsigned)rows;
+    if (rows < 4 || nt < 2) {
+      for (size_t r = 0; r < rows; ++r) horner(r);
+    } else {  // ~60 us per row: the 16-row commitment fold of a NeutronNova batch would spend a millisecond here on one core
+      std::vector<std::thread> th;
+      for (unsigned k = 0; k < nt; ++k)
+        th.emplace_back([&, k] {
+          for (size_t r = k; r < rows; r += nt) horner(r);
+        });
+      for (auto& t : th) t.join();
     }
   } else {
     hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, wsum, windows, rows, drows);
@@ -688,7 +702,21 @@ static int scalar_mul_rows(sp_ctx* c, const uint64_t* points_aff, size_t n, cons
   w.len = wnaf5_digits(fe_to_canonical<S>(sc), w.d);
   const aff_t* pts = reinterpret_cast<const aff_t*>(points_aff);
   if (n <= WNAF_HOST_MAX) {
-    for (size_t i = 0; i < n; ++i) out[i] = wnaf_mul_host(pts[i], w.d, w.len);
+    // ~90 us per point on one core (256 doublings + ~51 additions): a handful of points (the 16-row commitment folds of the NeutronNova opening)
+    // go over up to eight short-lived threads
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 8) nt = 8;
+    if (nt > n) nt = (unsigned)n;
+    if (n < 4 || nt < 2) {
+      for (size_t i = 0; i < n; ++i) out[i] = wnaf_mul_host(pts[i], w.d, w.len);
+      return SP_OK;
+    }
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k)
+      th.emplace_back([&, k] {
+        for (size_t i = k; i < n; i += nt) out[i] = wnaf_mul_host(pts[i], w.d, w.len);
+      });
+    for (auto& t : th) t.join();
     return SP_OK;
   }
   DevBuf dp, dout;

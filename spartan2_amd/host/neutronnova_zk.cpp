@@ -612,13 +612,18 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     ck(sp_rowmat_vec(ctx, Wf, L.size(), Rv.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
     fe_t r_LZ = fe_zero();
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], blind[i]));
-    aff_t comm_LZ;
-    ck(sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ");
-    tr.dom_sep("inner product argument (linear)");
+    // the mask d and its blinds do not depend on the transcript (ipa.rs:139-147): delta's MSM runs on the auxiliary stream beside comm_LZ's
     std::vector<fe_t> dv(Rv.size());
     for (auto& x : dv) x = tape.next();
     const fe_t r_delta = tape.next(), r_beta = tape.next();
-    ck(sp_msm_ck(ctx, pk.ck, u64p(dv.data()), dv.size(), u64p(&r_delta), u64p(&delta.x)), "delta");
+    sp_msm_job* dj = nullptr;
+    ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dv.data()), dv.size(), &dj), "delta (begin)");
+    aff_t comm_LZ;
+    int rc_lz = sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x));
+    int rc_d = sp_msm_ck_finish(ctx, pk.ck, dj, u64p(&r_delta), u64p(&delta.x));  // always collected: the job owns device work
+    ck(rc_lz, "comm_LZ");
+    ck(rc_d, "delta (finish)");
+    tr.dom_sep("inner product argument (linear)");
     fe_t ip = fe_zero();
     for (size_t i = 0; i < Rv.size(); ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], dv[i]));
     ck(sp_hyrax_commit_small(ctx, pk.vc_ck, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
