@@ -307,7 +307,10 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
       hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, c->stream, dbases, (unsigned)n, order, start, windows, buckets);
     });
     lap("sort + bucket sums");
-    hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
+    if (rows * (size_t)windows <= 1024)  // few (row, window) pairs: the block-cooperative form (chain latency is all there is)
+      hipLaunchKernelGGL(spk::k_msm_window_reduce_coop, dim3(windows, (unsigned)rows), dim3(4 * spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
+    else
+      hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
   }
   lap("window sums");
   std::vector<jac_t> res(rows);
