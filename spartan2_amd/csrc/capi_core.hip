@@ -380,12 +380,15 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
     __builtin_ia32_pause();
   }
 }
-static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false) {
+// groups > 1 (slot path only): the first nb / groups slots are summed into out_host[0 .. nacc), the next into out_host[nacc .. 2 nacc), ... (the two
+// instances of a batched round evaluated by one launch)
+static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false, unsigned groups = 1) {
   const unsigned want = c->result_seq;
   if (c->pending_slots) {  // per-block slots: add them on the host as they become valid
     const unsigned nb = c->pending_slots;
     c->pending_slots = 0;
-    for (int k = 0; k < nacc; ++k) out_host[k] = fe_zero();
+    const unsigned per_group = nb / groups;
+    for (int k = 0; k < nacc * (int)groups; ++k) out_host[k] = fe_zero();
     if (nb == 1) {
       fe_t v[3];
       long spins = 0;
@@ -419,7 +422,8 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
           spk::slot_chk_add(chk, v[k], k);
         }
         if ((uint32_t)(tags[b] >> 32) != chk.a || (uint32_t)tags2[b] != chk.b) continue;  // data still landing: next pass
-        for (int k = 0; k < nacc; ++k) out_host[k] = fe_add<S>(out_host[k], v[k]);
+        fe_t* dst = out_host + (size_t)(b / per_group) * nacc;
+        for (int k = 0; k < nacc; ++k) dst[k] = fe_add<S>(dst[k], v[k]);
         done[b] = true;
         --remaining;
       }
@@ -1156,6 +1160,88 @@ static int eval_quad_sums(sp_ctx* c, const sp_table* A, const sp_table* B, fe_t 
   return reduce_partials(c, blocks, 2, sums);
 }
 
+// Both instances of a batched round in one launch and one wait (k_eval_*_pair). Returns 1 when done, 0 when the tables are too large for the slot
+// path (the caller then evaluates the instances one after the other), < 0 on error.
+static unsigned pair_pp(size_t len, unsigned* nb_out) {
+  for (unsigned pp = 1; pp <= 8; pp <<= 1) {
+    const size_t nb = (len + 256 * (size_t)pp - 1) / (256 * (size_t)pp);
+    if (2 * nb <= (size_t)spk::HOST_SUM_MAX_BLOCKS) {
+      *nb_out = (unsigned)(nb ? nb : 1);
+      return pp;
+    }
+  }
+  return 0;
+}
+static int eval_quad_sums_pair(sp_ctx* c, sp_table* const A[2], sp_table* const B[2], fe_t sums[2][2]) {
+  const size_t half = A[0]->len / 2;
+  if (A[1]->len != A[0]->len) return 0;
+  spk::QuadPairArgs t;
+  size_t maxlen = 0;
+  for (int b = 0; b < 2; ++b) {
+    size_t len = sp::eff_pairs(A[b]);
+    if (sp::eff_pairs(B[b]) < len) len = sp::eff_pairs(B[b]);
+    if (half < len) len = half;
+    t.A[b] = A[b]->d;
+    t.B[b] = B[b]->d;
+    t.len[b] = len;
+    t.hiA[b] = sp::eff_hi(A[b]);
+    t.hiB[b] = sp::eff_hi(B[b]);
+    if (len > maxlen) maxlen = len;
+  }
+  unsigned nb = 0;
+  const unsigned pp = maxlen ? pair_pp(maxlen, &nb) : 0;
+  if (!pp) return 0;
+  const unsigned seq = next_seq(c);
+  c->timed("eval_quad", 64ull * (t.len[0] + t.len[1]), [&] { hipLaunchKernelGGL(spk::k_eval_quad_pair, dim3(2 * nb), dim3(256), 0, c->stream, t, half, nb, pp, c->d_pinned, seq); });
+  c->pending_slots = 2 * nb;
+  fe_t out[4];
+  int rc = reduce_partials_wait(c, 2, out, false, 2);
+  if (rc) return rc;
+  sums[0][0] = out[0];
+  sums[0][1] = out[1];
+  sums[1][0] = out[2];
+  sums[1][1] = out[3];
+  return 1;
+}
+static int eval_cubic_outer_pow_pair(sp_ctx* c, const sp_table* pl, const sp_table* pr, sp_table* const step[3], sp_table* const core[3], fe_t sums[2][3]) {
+  const size_t len = step[0]->len / 2, left = pl->len;
+  if (core[0]->len != step[0]->len || len == 0) return 0;
+  const bool fallback = len < left;
+  size_t right = 0;
+  if (fallback) {
+    if (left < 2 * len) return 0;
+  } else {
+    if (left == 0 || len % left) return 0;
+    right = len / left;
+    if (pr->len < 2 * right) return 0;
+  }
+  unsigned nb = 0;
+  const unsigned pp = pair_pp(len, &nb);
+  if (!pp) return 0;
+  spk::CubicPairArgs t;
+  for (int b = 0; b < 2; ++b) {
+    sp_table* const* q = b == 0 ? step : core;
+    t.A[b] = q[0]->d;
+    t.B[b] = q[1]->d;
+    t.C[b] = q[2]->d;
+  }
+  const unsigned seq = next_seq(c);
+  c->timed("eval_cubic_pow", 2 * 224ull * len, [&] {
+    if (fallback)
+      hipLaunchKernelGGL((spk::k_eval_cubic_outer_pow_pair<true>), dim3(2 * nb), dim3(256), 0, c->stream, pl->d, left, pr ? pr->d : nullptr, right, t, len, nb, pp, c->d_pinned,
+                         seq);
+    else
+      hipLaunchKernelGGL((spk::k_eval_cubic_outer_pow_pair<false>), dim3(2 * nb), dim3(256), 0, c->stream, pl->d, left, pr->d, right, t, len, nb, pp, c->d_pinned, seq);
+  });
+  c->pending_slots = 2 * nb;
+  fe_t out[6];
+  int rc = reduce_partials_wait(c, 3, out, false, 2);
+  if (rc) return rc;
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 3; ++k) sums[b][k] = out[3 * b + k];
+  return 1;
+}
+
 // prove_quad_batched_zk (src/sumcheck.rs:702-782): two quadratic sum-checks (step, core) driven by one challenge per round; the challenge
 // comes from the caller's `process_round` hook (:747-755).
 int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_rounds, sp_table* A0, sp_table* A1, sp_table* B0, sp_table* B1, size_t start_round,
@@ -1167,10 +1253,20 @@ int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_ro
   for (size_t j = 0; j < num_rounds; ++j) {
     UniPoly poly[2];
     uint64_t co[2][12];
+    fe_t both[2][2];
+    sp_table* const pa[2] = {A0, A1};
+    sp_table* const pb[2] = {B0, B1};
+    const int paired = eval_quad_sums_pair(c, pa, pb, both);
+    if (paired < 0) return paired;
     for (int b = 0; b < 2; ++b) {
       fe_t sums[2];
-      int rc = eval_quad_sums(c, br[b][0], br[b][1], sums);
-      if (rc) return rc;
+      if (paired) {
+        sums[0] = both[b][0];
+        sums[1] = both[b][1];
+      } else {
+        int rc = eval_quad_sums(c, br[b][0], br[b][1], sums);
+        if (rc) return rc;
+      }
       const fe_t e0 = sums[0], tinf = sums[1];
       const fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
       fe_t ev[3] = {e0, fe_sub<S>(claim[b], e0), fe_add<S>(fe_add<S>(fe_sub<S>(fe_add<S>(claim[b], claim[b]), three_e0), tinf), tinf)};
@@ -1218,10 +1314,14 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
   for (size_t i = 0; i < num_rounds; ++i) {
     UniPoly poly[2];
     uint64_t co[2][16];
+    fe_t both[2][3];
+    const int paired = eval_cubic_outer_pow_pair(c, pow_left, pow_right, step, core, both);
+    if (paired < 0) return paired;
     for (int b = 0; b < 2; ++b) {
       sp_table** t = b == 0 ? step : core;
       uint64_t raw[12];
-      if ((rc = sp_eval_cubic_outer_pow(c, pow_left, pow_right, t[0], t[1], t[2], raw))) return rc;
+      if (paired) memcpy(raw, both[b], 96);
+      else if ((rc = sp_eval_cubic_outer_pow(c, pow_left, pow_right, t[0], t[1], t[2], raw))) return rc;
       const fe_t e0 = fe_mul<S>(load_fe(raw), base_tau), e2 = fe_mul<S>(load_fe(raw + 4), base_tau), e3 = fe_mul<S>(load_fe(raw + 8), base_tau);
       fe_t ev[4] = {e0, fe_sub<S>(claim[b], e0), e2, e3};
       poly[b] = from_evals_deg3(ev);

@@ -606,6 +606,70 @@ __global__ void __launch_bounds__(256) k_eval_cubic_outer_pow(const fe_t* __rest
   }
 }
 
+// The two instances (step, core) of a batched NeutronNova round in ONE launch: blocks [0, nb) evaluate instance 0, blocks [nb, 2 nb) instance 1, `pp`
+// pairs per thread so that 2 nb <= HOST_SUM_MAX_BLOCKS and every block lands its sums in a host slot of its own (the host adds the two groups
+// separately). One launch and one wait per round instead of two of each: the rounds of the batched sum-checks are launch / hand-off latency.
+struct CubicPairArgs {
+  const fe_t *A[2], *B[2], *C[2];
+};
+template <bool FALLBACK>
+__global__ void __launch_bounds__(256) k_eval_cubic_outer_pow_pair(const fe_t* __restrict__ pleft, size_t left, const fe_t* __restrict__ pright, size_t right,
+                                                                   CubicPairArgs t, size_t len, unsigned nb, unsigned pp, fe_t* __restrict__ mapped, unsigned seq) {
+  __shared__ fe_t smem[3 * 4];
+  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb;
+  const fe_t* __restrict__ A = t.A[inst];
+  const fe_t* __restrict__ B = t.B[inst];
+  const fe_t* __restrict__ C = t.C[inst];
+  fe_t acc[3] = {fe_zero(), fe_zero(), fe_zero()};
+  for (unsigned k = 0; k < pp; ++k) {
+    const size_t low = ((size_t)bx * pp + k) * blockDim.x + threadIdx.x;
+    if (low >= len) break;
+    fe_t tl, th;
+    if (FALLBACK) {
+      tl = pleft[low];
+      th = pleft[low + len];
+    } else {
+      const size_t i = low % left, j = low / left;
+      const fe_t pl = pleft[i];
+      tl = fe_mul<S>(pl, pright[j]);
+      th = fe_mul<S>(pl, pright[j + right]);
+    }
+    const fe_t al = A[low], ah = A[low + len], bl = B[low], bh = B[low + len], cl = C[low], ch = C[low + len];
+    acc[0] = fe_add<S>(acc[0], fe_mul<S>(tl, fe_sub<S>(fe_mul<S>(al, bl), cl)));
+    fe_t tb = fe_sub<S>(fe_dbl<S>(th), tl), ab = fe_sub<S>(fe_dbl<S>(ah), al), bb = fe_sub<S>(fe_dbl<S>(bh), bl), cb = fe_sub<S>(fe_dbl<S>(ch), cl);
+    acc[1] = fe_add<S>(acc[1], fe_mul<S>(tb, fe_sub<S>(fe_mul<S>(ab, bb), cb)));
+    tb = fe_sub<S>(fe_add<S>(tb, th), tl);
+    ab = fe_sub<S>(fe_add<S>(ab, ah), al);
+    bb = fe_sub<S>(fe_add<S>(bb, bh), bl);
+    cb = fe_sub<S>(fe_add<S>(cb, ch), cl);
+    acc[2] = fe_add<S>(acc[2], fe_mul<S>(tb, fe_sub<S>(fe_mul<S>(ab, bb), cb)));
+  }
+  block_sum<3>(acc, smem);
+  if (threadIdx.x == 0) emit_partials<3>(acc, nullptr, mapped, seq);  // gridDim.x <= HOST_SUM_MAX_BLOCKS by construction: the slot path
+}
+struct QuadPairArgs {
+  const fe_t *A[2], *B[2];
+  size_t len[2], hiA[2], hiB[2];
+};
+__global__ void __launch_bounds__(256) k_eval_quad_pair(QuadPairArgs t, size_t half, unsigned nb, unsigned pp, fe_t* __restrict__ mapped, unsigned seq) {
+  __shared__ fe_t smem[2 * 4];
+  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb;
+  const fe_t* __restrict__ A = t.A[inst];
+  const fe_t* __restrict__ B = t.B[inst];
+  const size_t len = t.len[inst], hiA = t.hiA[inst], hiB = t.hiB[inst];
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+  for (unsigned k = 0; k < pp; ++k) {
+    const size_t id = ((size_t)bx * pp + k) * blockDim.x + threadIdx.x;
+    if (id >= len) break;
+    const fe_t a0 = A[id], b0 = B[id];
+    const fe_t a1 = id < hiA ? A[id + half] : fe_zero(), b1 = id < hiB ? B[id + half] : fe_zero();
+    acc[0] = fe_add<S>(acc[0], fe_mul<S>(a0, b0));
+    acc[1] = fe_add<S>(acc[1], fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)));
+  }
+  block_sum<2>(acc, smem);
+  if (threadIdx.x == 0) emit_partials<2>(acc, nullptr, mapped, seq);
+}
+
 // dot product of the first n elements (value of DelayedReduction::reduce(sum a_i b_i))
 __global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t n, fe_t* __restrict__ partials,
                                              fe_t* __restrict__ single_out, unsigned seq) {
