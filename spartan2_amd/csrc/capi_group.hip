@@ -446,7 +446,7 @@ static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, con
     const char* e = getenv("SPARTAN_FB_COOP");
     return !(e && e[0] == '0');
   }();
-  if (coop && n <= 1024) {
+  if (coop && n <= 2048) {  // 512 blocks of four scalars: one resident wave of blocks at two per CU
     hipLaunchKernelGGL(spk::k_fixed_base_rows_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, tables, ntables, dout);
   } else {
     const size_t threads = n * 32;
@@ -570,25 +570,25 @@ int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, s
     // keys of <= 64 bases: per-base FixedBaseMul tables, as the reference does (hyrax_pc.rs:221-260 -> multi_mul, msm.rs:727-773): every
     // (row, column) scalar and every row blind walks its own table in ONE launch; the cols + 1 points of a row are added on the host side
     const size_t per = cols + 1, total = rows * per;
-    DevBuf ds, dout, dbl;
-    if ((rc = ds.alloc(total * sizeof(fe_t))) || (rc = dout.alloc(total * sizeof(jac_t))) || (rc = dbl.alloc(rows * sizeof(fe_t)))) return rc;
-    SP_HIP(hipMemsetAsync(ds.p, 0, total * sizeof(fe_t), c->stream));
+    // grow-only context workspaces (no hipMalloc / hipFree on the path); the `per` points of a row are added by one wave per row on the device
+    fe_t* ds = (fe_t*)c->workspace(sp_ctx::WS_NARROW_SCALARS, total * sizeof(fe_t));
+    jac_t* dout = (jac_t*)c->workspace(sp_ctx::WS_NARROW_OUT, (total + rows) * sizeof(jac_t));
+    fe_t* dbl = (fe_t*)c->workspace(sp_ctx::WS_NARROW_BLINDS, rows * sizeof(fe_t));
+    if (!ds || !dout || !dbl) return SP_ERR_NO_DEVICE;
+    jac_t* drow = dout + total;
+    SP_HIP(hipMemsetAsync(ds, 0, total * sizeof(fe_t), c->stream));
     const size_t full_rows = n / cols;
-    if (full_rows) SP_HIP(hipMemcpy2DAsync(ds.p, per * sizeof(fe_t), v->d + off, cols * sizeof(fe_t), cols * sizeof(fe_t), full_rows, hipMemcpyDeviceToDevice, c->stream));
-    if (n % cols) SP_HIP(hipMemcpyAsync(ds.as<fe_t>() + full_rows * per, v->d + off + full_rows * cols, (n % cols) * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
-    SP_HIP(hipMemcpyAsync(dbl.p, blinds, rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-    SP_HIP(hipMemcpy2DAsync(ds.as<fe_t>() + cols, per * sizeof(fe_t), dbl.p, sizeof(fe_t), sizeof(fe_t), rows, hipMemcpyDeviceToDevice, c->stream));
-    c->timed("fixed_base", 32ull * total, [&] { launch_fixed_base_rows(c->stream, ds.as<fe_t>(), total, ck->d_cktables, per, dout.as<jac_t>()); });
-    std::vector<jac_t> pts(total);
-    SP_HIP(hipMemcpyAsync(pts.data(), dout.p, total * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(hipStreamSynchronize(c->stream));
+    if (full_rows) SP_HIP(hipMemcpy2DAsync(ds, per * sizeof(fe_t), v->d + off, cols * sizeof(fe_t), cols * sizeof(fe_t), full_rows, hipMemcpyDeviceToDevice, c->stream));
+    if (n % cols) SP_HIP(hipMemcpyAsync(ds + full_rows * per, v->d + off + full_rows * cols, (n % cols) * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
+    SP_HIP(hipMemcpyAsync(dbl, blinds, rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+    SP_HIP(hipMemcpy2DAsync(ds + cols, per * sizeof(fe_t), dbl, sizeof(fe_t), sizeof(fe_t), rows, hipMemcpyDeviceToDevice, c->stream));
+    c->timed("fixed_base", 32ull * total, [&] {
+      launch_fixed_base_rows(c->stream, ds, total, ck->d_cktables, per, dout);
+      hipLaunchKernelGGL(spk::k_sum_rows_of_points, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, dout, rows, (unsigned)per, drow);
+    });
     std::vector<jac_t> sums(rows);
-    for (size_t r = 0; r < rows; ++r) {
-      jac_t acc = jac_identity();
-      for (size_t k = 0; k < per; ++k)
-        if (!jac_is_identity(pts[r * per + k])) acc = jac_add(acc, pts[r * per + k]);
-      sums[r] = acc;
-    }
+    SP_HIP(hipMemcpyAsync(sums.data(), drow, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP(hipStreamSynchronize(c->stream));
     std::vector<aff_t> a(rows);
     normalize_batch(sums, a.data());
     memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));

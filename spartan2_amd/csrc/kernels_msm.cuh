@@ -656,6 +656,22 @@ __global__ void __launch_bounds__(256) k_fixed_base_rows(const fe_t* __restrict_
   if (idx < n && j == 0) out[idx] = xyzz_to_jac(acc);
 }
 
+// Row sums for the narrow-key commit (hyrax_pc.rs:221-260: one commitment = the sum of `per` table walks): one 64-lane wave per row adds the row's
+// `per` <= 65 points with a shuffle tree (6 levels instead of `per` sequential host additions per row).
+__global__ void __launch_bounds__(256) k_sum_rows_of_points(const jac_t* __restrict__ pts, size_t rows, unsigned per, jac_t* __restrict__ out) {
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned lane = threadIdx.x & 63;
+  xyzz_t acc = xyzz_identity();
+  if (row < rows)
+    for (unsigned k = lane; k < per; k += 64) acc = xyzz_add(acc, xyzz_from_jac(pts[row * per + k]));  // per <= 65: at most two per lane
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    xyzz_t o = shfl_down_xyzz(acc, d);
+    if (lane < (unsigned)d) acc = xyzz_add(acc, o);
+  }
+  if (row < rows && lane == 0) out[row] = xyzz_to_jac(acc);
+}
+
 // The same with the block-cooperative addition: four scalars per 512-thread block, their 4 x 32 table entries are the 128 items; the five tree
 // levels cost one cooperative addition each instead of ~15 us (the chain of dependent additions is all there is: 84 scalars do not fill the chip either way).
 __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,

@@ -43,10 +43,15 @@ struct NNZkPrep {
   bool is_small = true;
   // cached_step_matvec / cached_step_i64 (:1520-1590): the step instances' (Az, Bz, Cz) layers and their i64 mirrors; the rounds only read them
   sp_nifs* nifs_cached = nullptr;
+  // small device tables reused by every prove (the verifier-circuit instance is a few thousand elements: its commits and two sum-checks would
+  // otherwise pay eight hipMalloc / hipFree pairs per prove)
+  sp_table* vws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t vws_cap[5] = {0, 0, 0, 0, 0};
   ~NNZkPrep() {
     for (auto& s : steps) sp_table_free(s.W);
     sp_table_free(core.W);
     sp_nifs_free(nifs_cached);
+    for (sp_table* t : vws) sp_table_free(t);
   }
 };
 
@@ -196,13 +201,22 @@ static std::vector<fe_t> eq_evals(const fe_t* r, size_t ell) {  // EqPolynomial:
   return ev;
 }
 // rows of `n` host scalars committed with the width-32 key in one device call (many rows: T, the random instance)
-static std::vector<aff_t> commit_rows32(sp_ctx* ctx, const sp_ck* vc_ck, const std::vector<fe_t>& v, const std::vector<fe_t>& blinds) {
-  sp_table* t = nullptr;
-  ck(sp_table_from_host(ctx, u64p(v.data()), v.size(), (size_t)-1, (size_t)-1, &t), "upload");
+// slot `i` of the prep state's scratch tables holding `n` elements of host data
+static sp_table* stage(sp_ctx* ctx, NNZkPrep& ps, int i, const fe_t* data, size_t n) {
+  if (n > ps.vws_cap[i]) {  // grow-only, per slot: other slots may be in use by the caller
+    sp_table_free(ps.vws[i]);
+    ps.vws[i] = nullptr;
+    ps.vws_cap[i] = n < 4096 ? 4096 : 2 * n;
+  }
+  if (!ps.vws[i]) ck(sp_table_zeros(ctx, ps.vws_cap[i], (size_t)-1, (size_t)-1, &ps.vws[i]), "scratch table");
+  ck(sp_table_set_len(ps.vws[i], n, (size_t)-1, (size_t)-1), "scratch len");
+  ck(sp_table_write(ctx, ps.vws[i], 0, u64p(data), n), "upload");
+  return ps.vws[i];
+}
+static std::vector<aff_t> commit_rows32(sp_ctx* ctx, NNZkPrep& ps, const sp_ck* vc_ck, const std::vector<fe_t>& v, const std::vector<fe_t>& blinds) {
+  sp_table* t = stage(ctx, ps, 0, v.data(), v.size());
   std::vector<aff_t> out(blinds.size());
-  int rc = sp_hyrax_commit(ctx, vc_ck, t, 0, v.size(), u64p(blinds.data()), 0, u64p(&out[0].x));
-  sp_table_free(t);
-  ck(rc, "commit (width 32)");
+  ck(sp_hyrax_commit(ctx, vc_ck, t, 0, v.size(), u64p(blinds.data()), 0, u64p(&out[0].x)), "commit (width 32)");
   return out;
 }
 // prove_direct (hyrax_pc.rs:609-652) on host vectors
@@ -235,6 +249,17 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const size_t rows = rows_sh + rows_pre + rows_rest, dpub = d.num_public;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
+  static const bool laps = [] {
+    const char* e = getenv("SPARTAN_HOST_LAPS");
+    return e && e[0] == '1';
+  }();
+  double t_lap = t_start;
+  auto lap = [&](const char* what) {
+    if (!laps) return;
+    const double t = now();
+    fprintf(stderr, "nn_prove lap %-28s %8.3f ms\n", what, t - t_lap);
+    t_lap = t;
+  };
   ck(sp_ctx_bind_thread(ctx), "device");
   // rerandomize (:1619-1627, hyrax_pc.rs:321-344): core (shared, precommitted), then every step's precommitted commitment. The new blinds are
   // drawn in the reference's order; the row updates are independent, so all of them go through ONE sp_hyrax_rerandomize call.
@@ -456,6 +481,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   for (const auto& c : vst.challenges) Uv_X.insert(Uv_X.end(), c.begin(), c.end());
   Uv_X.insert(Uv_X.end(), vpub.begin(), vpub.end());
   for (const auto& b : vst.blind_per_round) Wv_r.insert(Wv_r.end(), b.begin(), b.end());
+  lap("(up to the vc instance)");
   // sample_random_instance_witness (src/r1cs/mod.rs:474-531) on the verifier-circuit shape
   const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io();
   std::vector<fe_t> Z(vnv + vio + 1);
@@ -468,7 +494,8 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   vs.multiply_vec(Z, mv);
   std::vector<fe_t> rnd_E(vcons), rnd_W(Z.begin(), Z.begin() + vnv), rnd_X(Z.begin() + vnv + 1, Z.end());
   for (size_t i = 0; i < vcons; ++i) rnd_E[i] = fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(rnd_u, mv[2][i]));
-  const std::vector<aff_t> rnd_comm_W = commit_rows32(ctx, pk.vc_ck, rnd_W, rnd_rW), rnd_comm_E = commit_rows32(ctx, pk.vc_ck, rnd_E, rnd_rE);
+  const std::vector<aff_t> rnd_comm_W = commit_rows32(ctx, ps, pk.vc_ck, rnd_W, rnd_rW), rnd_comm_E = commit_rows32(ctx, ps, pk.vc_ck, rnd_E, rnd_rE);
+  lap("random instance + 2 commits");
   // NovaNIFS::prove (src/nifs.rs:34-61)
   {
     std::vector<uint8_t> b = commitment_bytes(rnd_comm_W.data(), rnd_comm_W.size()), e = commitment_bytes(rnd_comm_E.data(), rnd_comm_E.size());
@@ -490,11 +517,12 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   vs.multiply_vec(Zs, mv);
   std::vector<fe_t> T(vcons);
   for (size_t i = 0; i < vcons; ++i) T[i] = fe_sub<S>(fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(u1, mv[2][i])), rnd_E[i]);
-  const std::vector<aff_t> comm_T = commit_rows32(ctx, pk.vc_ck, T, r_T);
+  const std::vector<aff_t> comm_T = commit_rows32(ctx, ps, pk.vc_ck, T, r_T);
   {
     const std::vector<uint8_t> b = commitment_bytes(comm_T.data(), comm_T.size());
     tr.absorb("comm_T", b.data(), b.size());
   }
+  lap("NovaNIFS: T + commit_T");
   const fe_t rf = tr.squeeze("r");
   std::vector<fe_t> Wfold(vnv), Efold(vcons), rWfold(rnd_rW.size()), rEfold(rnd_rE.size()), Xfold(vio);
   for (size_t i = 0; i < vnv; ++i) Wfold[i] = fe_add<S>(rnd_W[i], fe_mul<S>(rf, vst.w[i]));
@@ -518,21 +546,11 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   std::vector<fe_t> v_outer(3 * vlx), v_rx(vlx), v_inner(2 * vly), v_ry(vly);
   fe_t v_claims[3];
   {
-    sp_table *ta = nullptr, *tb = nullptr, *tc = nullptr;
-    struct G {
-      sp_table *&a, *&b, *&c;
-      ~G() {
-        sp_table_free(a);
-        sp_table_free(b);
-        sp_table_free(c);
-      }
-    } g{ta, tb, tc};
-    ck(sp_table_from_host(ctx, u64p(mv[0].data()), vcons, (size_t)-1, (size_t)-1, &ta), "upload");
-    ck(sp_table_from_host(ctx, u64p(mv[1].data()), vcons, (size_t)-1, (size_t)-1, &tb), "upload");
-    ck(sp_table_from_host(ctx, u64p(uczE.data()), vcons, (size_t)-1, (size_t)-1, &tc), "upload");
+    sp_table *ta = stage(ctx, ps, 0, mv[0].data(), vcons), *tb = stage(ctx, ps, 1, mv[1].data(), vcons), *tc = stage(ctx, ps, 2, uczE.data(), vcons);
     const fe_t zero = fe_zero();
     ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(vtau.data()), vlx, ta, tb, tc, tr.t, u64p(v_outer.data()), u64p(v_rx.data()), u64p(v_claims)), "relaxed outer sum-check");
   }
+  lap("folds + relaxed outer sc");
   tr.absorb_scalars("claims_outer", v_claims, 3);
   const fe_t vr = tr.squeeze("r"), vr2 = fe_mul<S>(vr, vr);
   const std::vector<fe_t> v_evals_rx = eq_evals(v_rx.data(), vlx);
@@ -554,27 +572,21 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     const fe_t r2u = fe_mul<S>(vr2, ufold);
     for (size_t i = 0; i < vcols; ++i) vabc[i] = fe_add<S>(fe_add<S>(ev[0][i], fe_mul<S>(vr, ev[1][i])), fe_mul<S>(r2u, ev[2][i]));
   }
+  lap("claim_E + bind_matrix_rows");
   zr.resize(vz_len, fe_zero());
   {
-    sp_table *ta = nullptr, *tb = nullptr;
-    struct G {
-      sp_table *&a, *&b;
-      ~G() {
-        sp_table_free(a);
-        sp_table_free(b);
-      }
-    } g{ta, tb};
-    ck(sp_table_from_host(ctx, u64p(vabc.data()), vz_len, (size_t)-1, (size_t)-1, &ta), "upload");
-    ck(sp_table_from_host(ctx, u64p(zr.data()), vz_len, (size_t)-1, (size_t)-1, &tb), "upload");
+    sp_table *ta = stage(ctx, ps, 3, vabc.data(), vz_len), *tb = stage(ctx, ps, 4, zr.data(), vz_len);
     fe_t ci[2];
     ck(sp_sumcheck_quad(ctx, u64p(&v_claim_inner), vly, ta, tb, tr.t, u64p(v_inner.data()), u64p(v_ry.data()), u64p(ci)), "relaxed inner sum-check");
   }
+  lap("relaxed inner sc");
   std::vector<fe_t> v_W, v_E;
   fe_t blind_vW, blind_vE;
   prove_direct(32, Wfold, rWfold, v_ry.data() + 1, vly - 1, &v_W, &blind_vW);
   prove_direct(32, Efold, rEfold, v_rx.data(), vlx, &v_E, &blind_vE);
   tr.absorb_scalars("v_W", v_W.data(), v_W.size());
   tr.absorb_scalars("v_E", v_E.data(), v_E.size());
+  lap("prove_direct x2");
   const double t_vc = now();
 
   // fold the two evaluation claims (:2019-2051) and open (:2054-2065)
