@@ -249,3 +249,26 @@ def sumcheck_quad_sharded(group: Group, quad_fn, claim, rounds, A, B, make_table
     TA, TB = (make_table(np.ascontiguousarray(gathered[:, q])) for q in range(2))
     polys2, r2, fin, _ = quad_fn(claim1, k, TA, TB, None)
     return np.concatenate([polys1, polys2]), np.concatenate([r1, r2]), fin
+
+
+def cpu_budget() -> int:
+    """CPUs this process may actually burn: the affinity mask capped by the cgroup's CFS quota (cpu.max). Every context in flight keeps one owner
+    thread polling; past the quota the whole cgroup is throttled and a throttled owner cannot answer its resident kernel in time."""
+    import math
+
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()
+            if quota != "max":
+                n = min(n, max(1, math.floor(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // p_))
+    except (OSError, ValueError):
+        pass
+    return n

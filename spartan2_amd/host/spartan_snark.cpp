@@ -38,6 +38,12 @@ struct SpartanProverKey {  // src/spartan.rs:30-58
   }
 };
 
+static std::atomic<int> g_proves_in_flight{0};  // proves running in this process (all contexts): decides how the helper threads wait
+struct ProveInFlight {
+  ProveInFlight() { g_proves_in_flight.fetch_add(1, std::memory_order_relaxed); }
+  ~ProveInFlight() { g_proves_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+};
+
 // Per-prep-state driver options (ss_prep_set_flags; defaults from the environment at prep_prove time).
 //   FLAG_PREFIX_CACHE: the transcript prefix new + vk + public_values + comm_W_shared / comm_W_precommitted is the same for every prove on one prep
 //     state; with this flag its sponge state is computed once and cloned (Keccak256Transcript is Clone, keccak.rs:25) — an API-level optimisation
@@ -184,6 +190,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
   if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
   ck(sp_ctx_bind_thread(ctx), "device");  // the caller may be a thread other than the one that created the context
+  ProveInFlight in_flight;
   const double t_start = now_ms();
   double t_lap = t_start;
   auto lap = [&](const char* name) {
@@ -363,11 +370,16 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       ck(sp_ctx_bind_thread(ctx), "helper thread: device");  // a new thread starts on device 0; the context may live on another GPU
       ck(sp_points_upload(ctx, u64p(&rows[0].x), nrows, &psp->comm_pts), "comm_W (upload)");
       const auto t0 = std::chrono::steady_clock::now();
+      // A lone prove spins here (the helper must react within a microsecond: comm_LZ's MSM is on the critical path). With several proves in flight
+      // in the process the helpers would burn one core each for half of every prove - under a CPU quota (16 cores on the bench boxes) eight such
+      // pairs of spinning threads get the whole cgroup throttled, and a throttled owner cannot answer its resident kernel - so they sleep in
+      // short steps instead: throughput mode does not notice a 50 us later MSM.
       auto wait_for = [&](std::atomic<int>& flag) {
         int st;
         while ((st = flag.load(std::memory_order_acquire)) == 0) {
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return 2;  // the prover never got there
-          __builtin_ia32_pause();
+          if (g_proves_in_flight.load(std::memory_order_relaxed) > 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
+          else __builtin_ia32_pause();
         }
         return st;
       };
