@@ -36,10 +36,24 @@ def load():
 _lib = None
 
 
+def _cpu_budget():
+    """CPUs the process may burn: affinity capped by the cgroup quota (the GPU boxes show 256 CPUs under a 16-CPU quota; 256 OpenMP threads there
+    only get the whole test process throttled, the GPU-side watchdogs included)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         _lib = load()
+        _lib.orc_set_threads(max(1, min(_cpu_budget(), 32)))
     return _lib
 
 
