@@ -38,11 +38,17 @@ struct SpartanProverKey {  // src/spartan.rs:30-58
   }
 };
 
-static std::atomic<int> g_proves_in_flight{0};  // proves running in this process (all contexts): decides how the helper threads wait
-struct ProveInFlight {
-  ProveInFlight() { g_proves_in_flight.fetch_add(1, std::memory_order_relaxed); }
-  ~ProveInFlight() { g_proves_in_flight.fetch_sub(1, std::memory_order_relaxed); }
-};
+// How a helper thread waits for its owner. It sleeps on a condition variable that the owner notifies at each state change: measured at config 2, a
+// lone prove is as fast this way as with a spinning helper (1.29-1.31 ms either way; wake-up ~10 us, off the critical path or under the MSM it
+// starts), and a spinning helper costs one CPU per prove in flight on top of the owner's polling thread - under the 16-CPU CFS quota of the bench
+// boxes eight such pairs got the whole cgroup throttled and resident kernels ran into their watchdog. SPARTAN_HELPER_SPIN=1 restores spinning.
+static bool helper_may_spin() {
+  static const bool v = [] {
+    const char* e = getenv("SPARTAN_HELPER_SPIN");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
 
 // Per-prep-state driver options (ss_prep_set_flags; defaults from the environment at prep_prove time).
 //   FLAG_PREFIX_CACHE: the transcript prefix new + vk + public_values + comm_W_shared / comm_W_precommitted is the same for every prove on one prep
@@ -190,7 +196,6 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
   if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
   ck(sp_ctx_bind_thread(ctx), "device");  // the caller may be a thread other than the one that created the context
-  ProveInFlight in_flight;
   const double t_start = now_ms();
   double t_lap = t_start;
   auto lap = [&](const char* name) {
@@ -350,6 +355,13 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     fe_t r_delta;
     aff_t delta;
     bool delta_done = false;
+    // a helper that may not spin sleeps on this pair; the owner notifies after each state change (a notify without a sleeper is a user-space check)
+    std::mutex mu;
+    std::condition_variable cv;
+    void publish(std::atomic<int>& flag, int v) {
+      flag.store(v, std::memory_order_release);
+      cv.notify_one();
+    }
   } lz;
   lz.r_delta = r_delta_ahead;
   lz.nvr = lz_nvr;
@@ -370,16 +382,17 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       ck(sp_ctx_bind_thread(ctx), "helper thread: device");  // a new thread starts on device 0; the context may live on another GPU
       ck(sp_points_upload(ctx, u64p(&rows[0].x), nrows, &psp->comm_pts), "comm_W (upload)");
       const auto t0 = std::chrono::steady_clock::now();
-      // A lone prove spins here (the helper must react within a microsecond: comm_LZ's MSM is on the critical path). With several proves in flight
-      // in the process the helpers would burn one core each for half of every prove - under a CPU quota (16 cores on the bench boxes) eight such
-      // pairs of spinning threads get the whole cgroup throttled, and a throttled owner cannot answer its resident kernel - so they sleep in
-      // short steps instead: throughput mode does not notice a 50 us later MSM.
+      // sleeps until the owner publishes the state (helper_may_spin above)
       auto wait_for = [&](std::atomic<int>& flag) {
         int st;
         while ((st = flag.load(std::memory_order_acquire)) == 0) {
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return 2;  // the prover never got there
-          if (g_proves_in_flight.load(std::memory_order_relaxed) > 2) std::this_thread::sleep_for(std::chrono::microseconds(20));
-          else __builtin_ia32_pause();
+          if (!helper_may_spin()) {
+            std::unique_lock<std::mutex> lk(lzp->mu);  // woken by publish(); the timeout covers a notify that raced the predicate
+            lzp->cv.wait_for(lk, std::chrono::microseconds(100), [&] { return flag.load(std::memory_order_acquire) != 0; });
+          } else {
+            __builtin_ia32_pause();
+          }
         }
         return st;
       };
@@ -469,7 +482,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   if (lz_ahead) {  // the helper finishes it (see above)
     lz.delta_job = delta_job;
     delta_job = nullptr;
-    lz.delta_state.store(1, std::memory_order_release);
+    lz.publish(lz.delta_state, 1);
   }
   // inner sum-check. The reference runs round 0 by hand on the compact vectors (src/spartan.rs:323-384); that round is
   // value-identical to a generic prove_quad round on the 2M-long tables with (lo_eff, hi_eff) = (M, num_extra).
@@ -485,7 +498,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       Obs* o = (Obs*)u;
       if (!o->on || round == 0 || round > o->lz->nvr) return;
       memcpy(&o->lz->r[round - 1], r, 32);
-      if (round == o->lz->nvr) o->lz->state.store(1, std::memory_order_release);
+      if (round == o->lz->nvr) o->lz->publish(o->lz->state, 1);
     }
   } obs{&lz, lz_ahead};
   ck(sp_sumcheck_quad_observed(ctx, u64p(&claim_inner_joint), num_rounds_y, ps.abc, ps.z, tr.t, &Obs::fn, &obs, u64p(inner_polys.data()), u64p(r_y.data()),
