@@ -349,7 +349,7 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
   hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
 }
 // `resident`: the result comes from the resident tail kernel, which is itself waiting for the host's next challenge — a stream synchronise
-// would never return, so the host keeps polling (bounded by wall-clock; the kernel gives up after 2 s as well).
+// would never return, so the host keeps polling (bounded by wall-clock; the kernel gives up after 8 s as well).
 // one self-validating slot (kernels_poly.cuh slot_store_tag): wait for its sequence word, then re-read until the check word matches the data
 static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t* v, bool resident, long* spins) {
   volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
@@ -358,7 +358,7 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
       if (resident) {        // the tail kernel is itself waiting for the host: keep polling, bounded by wall-clock
         const auto t0 = std::chrono::steady_clock::now();
         while (*fl != want) {
-          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
+          if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(12)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
           __builtin_ia32_pause();
         }
         break;
@@ -435,7 +435,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
         t0 = std::chrono::steady_clock::now();
       } else if (passes > 200000) {
         if (!resident && passes > 200002) return fail(SP_ERR_INTERNAL, "evaluation kernel did not deliver its block sums");
-        if (resident && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4))
+        if (resident && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(12))
           return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
       }
       __builtin_ia32_pause();
@@ -455,7 +455,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
   if (!seen && resident) {
     const auto t0 = std::chrono::steady_clock::now();
     while (*flag != want) {
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(12)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
       __builtin_ia32_pause();
     }
     seen = true;
@@ -511,7 +511,7 @@ static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) 
   if (c->mail_dev) __builtin_ia32_sfence();  // BAR memory is write-combining: push the line out now
 }
 // Error exits of a round loop: kernels issued ahead of their challenge (and the resident tail) are still waiting at the mailbox and would hold
-// their CUs for the 2 s watchdog, then trip the sticky error word under the next, unrelated sum-check. The abort word of the mailbox line makes
+// their CUs for the 8 s watchdog, then trip the sticky error word under the next, unrelated sum-check. The abort word of the mailbox line makes
 // them leave at once; the stream is drained and both words are cleared so that the next sum-check on this context starts clean.
 static void tail_abort(sp_ctx* c) {
   volatile uint32_t* dst = c->h_mail;

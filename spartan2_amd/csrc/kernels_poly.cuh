@@ -72,9 +72,12 @@ __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __r
 // word (sequence * K + position-weighted sum), 11 = the sequence number again, 12 = abort (the host gave the sum-check up: stop waiting). The line lives in
 // fine-grained DEVICE memory that the host writes through the PCIe BAR (capi_core.hip post_challenge) — so a thousand blocks can poll it without
 // touching the bus — or, without a large BAR, in mapped host memory (resident tail only). Lanes 0..12 of wave 0 read the thirteen words in ONE
-// instruction; a poll that straddles the host's stores fails the check and is repeated. Never hangs: after 2 s the error word in the mapped
+// instruction; a poll that straddles the host's stores fails the check and is repeated. Never hangs: after MAIL_WATCHDOG_TICKS (8 s) the error word in the mapped
 // result buffer is set and the kernel carries on with whatever it read.
 constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in the mapped result buffer
+// 8 s at the 100 MHz wall clock. Long on purpose: an owner thread that the host's scheduler keeps away from its CPU (a throttled cgroup: the bench
+// boxes run under a 16-CPU quota) is late, not gone, and a late challenge only costs time while a tripped watchdog costs the proof.
+constexpr unsigned long long MAIL_WATCHDOG_TICKS = 800000000ull;
 struct MailRef {
   const unsigned* mail;  // nullptr: the challenge is the kernel argument
   fe_t* mapped;          // mapped pinned result buffer (error word at TAIL_ERR_ELEM)
@@ -108,7 +111,7 @@ __device__ __forceinline__ bool mail_wait(const unsigned* mail, fe_t* mapped, un
           break;
         }
       }
-      if (wall_clock64() - t0 > 200000000ull) break;  // 2 s at 100 MHz: the host went away; never hang the device
+      if (wall_clock64() - t0 > MAIL_WATCHDOG_TICKS) break;  // the host went away: never hang the device
       __builtin_amdgcn_s_sleep(1);
     }
     if (lane < 8) r_smem->v[lane] = w;
