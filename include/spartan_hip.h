@@ -250,6 +250,8 @@ int sp_rowmat_vec_eq_begin(sp_ctx* ctx, const sp_table* poly, const uint64_t* r,
 int sp_rowmat_vec_eq_finish(sp_ctx* ctx, sp_vec_job* job, uint64_t* out);
 int sp_msm_ck_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_msm_job** job);
 int sp_msm_ck_finish(sp_ctx* ctx, const sp_ck* ck, sp_msm_job* job, const uint64_t* blind, uint64_t out_aff[8]);
+/* the same over the bases [first, first + n) of the key: a rank's point range of a sharded MSM; finish with sp_msm_ck_finish */
+int sp_msm_ck_range_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t first, size_t n, sp_msm_job** job);
 /* PCS::commit for keys of width <= 64, where the reference uses per-base FixedBaseMul tables (hyrax_pc.rs:221-260,
  * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
 int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);

@@ -830,6 +830,19 @@ int sp_msm_ck_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t 
   *out = job;
   return SP_OK;
 }
+int sp_msm_ck_range_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t first, size_t n, sp_msm_job** out) {
+  if (first > ck->num_cols || n > ck->num_cols - first) return fail(SP_ERR_INVALID_INPUT_LENGTH, "MSM: the base range lies outside the key");
+  fe_t* canon;
+  int rc;
+  if ((rc = upload_canonical(c, scalars, n, &canon, 1))) return rc;
+  sp_msm_job* job = new sp_msm_job();
+  if ((rc = msm_launch(c, canon, ck->d_bases + first, n, spk::MSM_MAX_WINDOWS, 1, &job->pend))) {
+    delete job;
+    return rc;
+  }
+  *out = job;
+  return SP_OK;
+}
 int sp_msm_ck_finish(sp_ctx* c, const sp_ck* ck, sp_msm_job* job, const uint64_t* blind, uint64_t out_aff[8]) {
   jac_t r;
   int rc = msm_finish(c, &job->pend, &r);

@@ -17,6 +17,8 @@
 // Everything that does not scale with the instance (transcript, claims, eq tables of the opening) runs redundantly on every rank.
 #include <unistd.h>
 
+#include <thread>
+
 #include "comm.hpp"
 #include "snark_common.hpp"
 
@@ -296,6 +298,53 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   }
   if (comm_W.size() != rows_all) throw Error(SP_ERR_INTERNAL, "sharded prover: every witness segment must be non-empty or absent");
   const double t_wit = now_ms();
+  // What the opening needs that depends on nothing later than the witness commitment runs on a helper thread under the sum-checks: the sponge state
+  // of absorb("poly_com", comm_W) (the first absorb after the inner sum-check's last squeeze), the IPA mask d and its blinds (peeked at their tape
+  // positions: blind_eval_W precedes them), and this rank's point range of delta = <d, ck> as an MSM on the auxiliary stream.
+  struct Ahead {
+    std::thread th;
+    std::exception_ptr err;
+    sp_absorb_state* poly_com = nullptr;
+    std::vector<fe_t> dvec;
+    fe_t r_delta, r_beta;
+    sp_msm_job* delta_job = nullptr;
+    sp_ctx* ctx = nullptr;
+    const sp_ck* key = nullptr;
+    void join() {
+      if (th.joinable()) th.join();
+    }
+    ~Ahead() {  // error exits: the helper's products are still owned here
+      join();
+      uint64_t sink[8];
+      if (delta_job) sp_msm_ck_finish(ctx, key, delta_job, nullptr, sink);
+      if (poly_com) sp_absorb_state_free(poly_com);
+    }
+  } ahead;
+  ahead.ctx = ctx;
+  ahead.key = pk.ck;
+  const size_t ncols_ipa = (size_t)1 << ((log2_ceil(M)) - log2_ceil(rows_all));
+  {
+    Tape peek = tape;
+    const aff_t* rows_ptr = comm_W.data();
+    const size_t nrows = comm_W.size(), cpr0 = ncols_ipa / world;
+    ahead.th = std::thread([&ahead, peek, rows_ptr, nrows, ncols_ipa, cpr0, g, ctx, &pk]() mutable {
+      try {
+        const std::vector<uint8_t> b = commitment_bytes(rows_ptr, nrows);
+        ck(sp_transcript_preabsorb((const uint8_t*)"poly_com", 8, b.data(), b.size(), &ahead.poly_com), "poly_com (prepare)");
+        peek.skip(1);  // blind_eval_W
+        ahead.dvec.resize(ncols_ipa);
+        for (auto& x : ahead.dvec) x = peek.next();
+        ahead.r_delta = peek.next();
+        ahead.r_beta = peek.next();
+        if (cpr0 * (size_t)pk.comm->world == ncols_ipa) {
+          ck(sp_ctx_bind_thread(ctx), "helper thread: device");
+          ck(sp_msm_ck_range_begin(ctx, pk.ck, u64p(ahead.dvec.data() + g * cpr0), g * cpr0, cpr0, &ahead.delta_job), "delta (begin)");
+        }
+      } catch (...) {
+        ahead.err = std::current_exception();
+      }
+    });
+  }
 
   // z = [W | 1 | public | 0 ...] replicated; Az, Bz, Cz of this rank's rows
   ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
@@ -422,14 +471,14 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   const size_t ncols = Rv.size();  // 2048
   aff_t comm_eval_W;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
-  {
-    const std::vector<uint8_t> b = commitment_bytes(comm_W.data(), comm_W.size());
-    tr.absorb("poly_com", b.data(), b.size());
-  }
+  ahead.join();
+  if (ahead.err) std::rethrow_exception(ahead.err);
+  if (ncols != ncols_ipa) throw Error(SP_ERR_INTERNAL, "sharded prover: IPA width mismatch");
+  ck(sp_transcript_absorb_prepared(tr.t, ahead.poly_com), "poly_com");  // the state itself is released by `ahead`
   tr.dom_sep("inner product argument (linear)");
-  std::vector<fe_t> dvec(ncols);
-  for (auto& x : dvec) x = tape.next();
-  const fe_t r_delta = tape.next(), r_beta = tape.next();
+  const std::vector<fe_t>& dvec = ahead.dvec;
+  tape.skip(ncols + 2);  // d, r_delta, r_beta: drawn by the helper from these very positions
+  const fe_t r_delta = ahead.r_delta, r_beta = ahead.r_beta;
   // one exchange: [partial L.W (ncols F) | partial comm_LZ (point) | partial <d, ck> (point)]
   std::vector<fe_t> LZ(ncols);
   aff_t comm_LZ, delta;
@@ -440,7 +489,12 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     ck(sp_msm(ctx, u64p(L.data() + lo), u64p(&comm_W[lo].x), rpr, u64p(&mine[ncols])), "comm_LZ (point range)");
     const size_t cpr = ncols / world;
     if (cpr * world != ncols) throw Error(SP_ERR_INTERNAL, "sharded prover: key width not divisible by the number of ranks");
-    ck(sp_msm(ctx, u64p(dvec.data() + g * cpr), u64p(&pk.gens[g * cpr].x), cpr, u64p(&mine[ncols + 2])), "delta (point range)");
+    {
+      sp_msm_job* j = ahead.delta_job;
+      ahead.delta_job = nullptr;
+      if (j) ck(sp_msm_ck_finish(ctx, pk.ck, j, nullptr, u64p(&mine[ncols + 2])), "delta (point range)");
+      else ck(sp_msm(ctx, u64p(dvec.data() + g * cpr), u64p(&pk.gens[g * cpr].x), cpr, u64p(&mine[ncols + 2])), "delta (point range)");
+    }
     comm.allgather(mine.data(), rec * sizeof(fe_t), all.data());
     std::vector<aff_t> p1(world), p2(world + 1);
     for (size_t rr = 0; rr < world; ++rr) {
