@@ -50,6 +50,7 @@ struct ShardedPrep {
   std::vector<aff_t> comm_W;  // all rows; the fixed ones filled at prep time
   std::vector<fe_t> r_W_fixed;
   size_t rows_shared = 0, rows_precommitted = 0;
+  std::vector<uint8_t> comm_shared_bytes, comm_pre_bytes;  // transcript encodings of the rows committed at prep time (hyrax_pc.rs:714-729)
   bool is_small = true;
   ~ShardedPrep() {
     for (sp_table* t : {W, Wblk, caz, cbz, ccz, az, bz, cz, z, zs, abc, rx}) sp_table_free(t);
@@ -203,6 +204,9 @@ ShardedPrep* sharded_prep_prove(const ShardedKey& pk, const uint64_t* witness_u6
     for (const Seg& sgm : segs)
       if (sgm.on)
         for (size_t r = sgm.a; r < sgm.b; ++r) ps->comm_W[r] = all[r];
+    // the rows' transcript encodings are fixed with them; every prove still hashes them (the reference re-absorbs them in every prove)
+    if (ps->rows_shared) ps->comm_shared_bytes = commitment_bytes(ps->comm_W.data(), ps->rows_shared);
+    if (ps->rows_precommitted) ps->comm_pre_bytes = commitment_bytes(ps->comm_W.data() + d.num_shared / CW, ps->rows_precommitted);
     // z (2M, zero padded so that the inner sum-check's slices exist) and the cached products of this rank's rows on z = [W_shared+precommitted | 0]
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->z), "alloc z");
     ck(sp_table_copy(ctx, ps->z, 0, ps->W, 0, d.num_shared + d.num_precommitted), "copy W");
@@ -248,14 +252,8 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   tr.absorb_scalars("public_values", publics.data(), npub);
   const size_t rows_all = M / CW, rpr = rows_all / world, lo = g * rpr, hi = lo + rpr;
   const size_t rows_fixed = (d.num_shared + d.num_precommitted) / CW, rows_rest = d.num_rest / CW;
-  if (ps.rows_shared) {
-    const std::vector<uint8_t> b = commitment_bytes(ps.comm_W.data(), ps.rows_shared);
-    tr.absorb("comm_W_shared", b.data(), b.size());
-  }
-  if (ps.rows_precommitted) {
-    const std::vector<uint8_t> b = commitment_bytes(ps.comm_W.data() + d.num_shared / CW, ps.rows_precommitted);
-    tr.absorb("comm_W_precommitted", b.data(), b.size());
-  }
+  if (ps.rows_shared) tr.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
+  if (ps.rows_precommitted) tr.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
   // rest rows (bellpepper/r1cs.rs:463-491): every rank draws all blinds, commits the rest rows of its block (commit_zeros = h * blind when the
   // segment is all padding), one all-gather
   std::vector<fe_t> r_W_rest(rows_rest);
