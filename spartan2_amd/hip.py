@@ -365,6 +365,17 @@ class CommitmentKey:
         check(lib().sp_msm_ck(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), b, p64(out)))
         return out
 
+    def msm_range(self, scalars, first: int, blind=None):
+        """<scalars, ck[first : first + n]> through the asynchronous pair sp_msm_ck_range_begin / sp_msm_ck_finish (a rank's point range of a
+        sharded MSM)."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(8, dtype=np.uint64)
+        job = ctypes.c_void_p()
+        check(lib().sp_msm_ck_range_begin(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(first), ctypes.c_size_t(scalars.shape[0]), ctypes.byref(job)))
+        b = None if blind is None else p64(np.ascontiguousarray(blind, dtype=np.uint64).reshape(4))
+        check(lib().sp_msm_ck_finish(self.ctx.h, self.h, job, b, p64(out)))
+        return out
+
     def commit_small(self, scalars, blind):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         blind = np.ascontiguousarray(blind, dtype=np.uint64).reshape(4)

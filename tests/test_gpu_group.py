@@ -182,6 +182,12 @@ def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):
     olib().orc_point_add(p64(msm_part), p64(hb[0]), p64(want))
     assert (key.msm(sc, blind) == want).all()
     assert (key.msm(sc) == msm_part).all()
+    # a rank's point range of the same MSM (sp_msm_ck_range_begin): the four quarters add up to the whole; a range outside the key is refused
+    parts = np.stack([key.msm_range(sc[512 * q : 512 * (q + 1)], 512 * q) for q in range(4)])
+    assert (parts[1] == oracle_msm(sc[512:1024], np.ascontiguousarray(gens[512:1024]))).all()
+    assert (hip.point_sum(parts) == msm_part).all()
+    with pytest.raises(hip.SpartanHipError):
+        key.msm_range(sc[:8], 2045)
     # width-1 key (ck_s of src/spartan.rs:151): value * g + blind * h
     gs = np.zeros((2, 8), dtype=np.uint64)
     olib().orc_from_label(b"ck_s", ctypes.c_size_t(2), p64(gs))
