@@ -270,6 +270,9 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* ctx, uint64_t claim_io[4], uint64_t p_io[
                                uint64_t out_final[12]);
 int sp_sumcheck_quad_sharded(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce,
                              void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
+/* the same with sp_sumcheck_quad_observed's hook: a sharded HyraxPCS::prove starts its rank's part of comm_LZ as soon as the row challenges exist */
+int sp_sumcheck_quad_sharded_observed(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce,
+                                      void* reduce_user, sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
 
 /* ---- NeutronNova batched ZK sum-checks (src/sumcheck.rs:702-917) --------------------------------------------------------------------
  * The reference obtains each round's challenge from the ZK verifier circuit (`SatisfyingAssignment::process_round`, :747-755, :864-872) —

@@ -925,6 +925,11 @@ int sp_sumcheck_quad_sharded(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_
   return quad_impl(c, claim_io, rounds, A, B, tr, reduce, reduce_user, nullptr, nullptr, out_cpolys, out_r, out_final);
 }
 
+int sp_sumcheck_quad_sharded_observed(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce,
+                                      void* reduce_user, sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
+  return quad_impl(c, claim_io, rounds, A, B, tr, reduce, reduce_user, observe, observe_user, out_cpolys, out_r, out_final);
+}
+
 // prove_quad on a slice of the tables (see sp_sumcheck_cubic3_sharded): per round the slice's (eval0, t_inf) are combined across ranks by `reduce`
 static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
                      sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {

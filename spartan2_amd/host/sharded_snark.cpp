@@ -18,6 +18,8 @@
 #include <unistd.h>
 
 #include <thread>
+#include <condition_variable>
+#include <mutex>
 
 #include "comm.hpp"
 #include "snark_common.hpp"
@@ -308,24 +310,47 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     sp_msm_job* delta_job = nullptr;
     sp_ctx* ctx = nullptr;
     const sp_ck* key = nullptr;
+    // comm_LZ ahead: this rank's rows are a contiguous block, i.e. the top k row bits are fixed to the rank: its part of <L, comm_W> is
+    // eq(r[0..k), rank) * sum_j eq(r[k..nvr), j) comm_W[lo + j] - an eq-weighted MSM the helper starts the moment the observer has the row challenges
+    std::mutex mu;
+    std::condition_variable cv;
+    int rows_state = 0;  // 0: not drawn yet, 1: drawn, 2: abandoned
+    fe_t r_rows[32];
+    size_t nvr = 0;
+    sp_points* pts = nullptr;
+    sp_msm_job* lz_job = nullptr;
+    void publish(int v) {
+      {
+        std::lock_guard<std::mutex> l(mu);
+        if (rows_state == 0) rows_state = v;
+      }
+      cv.notify_one();
+    }
     void join() {
       if (th.joinable()) th.join();
     }
     ~Ahead() {  // error exits: the helper's products are still owned here
+      publish(2);
       join();
       uint64_t sink[8];
       if (delta_job) sp_msm_ck_finish(ctx, key, delta_job, nullptr, sink);
+      if (lz_job) sp_msm_job_finish(ctx, lz_job, sink);
       if (poly_com) sp_absorb_state_free(poly_com);
+      sp_points_free(pts);
     }
   } ahead;
   ahead.ctx = ctx;
   ahead.key = pk.ck;
   const size_t ncols_ipa = (size_t)1 << ((log2_ceil(M)) - log2_ceil(rows_all));
+  const size_t nvr_rows = log2_ceil(rows_all), ly_all = log2_ceil(M) + 1;
+  // the row challenges are r_y[1 ..= nvr]: they must all come from the local rounds, and the block must hold at least two rows
+  const bool lz_on = nvr_rows > k && nvr_rows + 1 <= ly_all - k && nvr_rows <= 31 && rpr == ((size_t)1 << (nvr_rows - k));
+  ahead.nvr = nvr_rows;
   {
     Tape peek = tape;
     const aff_t* rows_ptr = comm_W.data();
     const size_t nrows = comm_W.size(), cpr0 = ncols_ipa / world;
-    ahead.th = std::thread([&ahead, peek, rows_ptr, nrows, ncols_ipa, cpr0, g, ctx, &pk]() mutable {
+    ahead.th = std::thread([&ahead, peek, rows_ptr, nrows, ncols_ipa, cpr0, g, ctx, &pk, lz_on, lo, rpr, k]() mutable {
       try {
         const std::vector<uint8_t> b = commitment_bytes(rows_ptr, nrows);
         ck(sp_transcript_preabsorb((const uint8_t*)"poly_com", 8, b.data(), b.size(), &ahead.poly_com), "poly_com (prepare)");
@@ -334,9 +359,18 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
         for (auto& x : ahead.dvec) x = peek.next();
         ahead.r_delta = peek.next();
         ahead.r_beta = peek.next();
-        if (cpr0 * (size_t)pk.comm->world == ncols_ipa) {
-          ck(sp_ctx_bind_thread(ctx), "helper thread: device");
+        ck(sp_ctx_bind_thread(ctx), "helper thread: device");
+        if (cpr0 * (size_t)pk.comm->world == ncols_ipa)
           ck(sp_msm_ck_range_begin(ctx, pk.ck, u64p(ahead.dvec.data() + g * cpr0), g * cpr0, cpr0, &ahead.delta_job), "delta (begin)");
+        if (lz_on) {
+          ck(sp_points_upload(ctx, u64p(&rows_ptr[lo].x), rpr, &ahead.pts), "comm_W block (upload)");
+          int st;
+          {
+            std::unique_lock<std::mutex> lk(ahead.mu);
+            ahead.cv.wait(lk, [&] { return ahead.rows_state != 0; });
+            st = ahead.rows_state;
+          }
+          if (st == 1) ck(sp_msm_eq_begin(ctx, ahead.pts, u64p(ahead.r_rows + k), ahead.nvr - k, &ahead.lz_job), "comm_LZ (begin)");
         }
       } catch (...) {
         ahead.err = std::current_exception();
@@ -423,8 +457,19 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   {
     fe_t claim = claim_inner_joint;
     fe_t fin[2];
-    ck(sp_sumcheck_quad_sharded(ctx, u64p(&claim), ly - k, ps.abc, ps.zs, tr.t, k ? reduce_hook : nullptr, &comm, u64p(inner_polys.data()), u64p(r_y.data()),
-                                u64p(fin)),
+    struct Obs {
+      decltype(ahead)* a;
+      bool on;
+      static void fn(void* u, size_t round, const uint64_t r[4]) {  // r_y[round]; the row variables are r_y[1 ..= nvr] (MSB first)
+        Obs* o = (Obs*)u;
+        if (!o->on || round == 0 || round > o->a->nvr) return;
+        memcpy(&o->a->r_rows[round - 1], r, 32);
+        if (round == o->a->nvr) o->a->publish(1);
+      }
+    } obs{&ahead, lz_on};
+    if (ly != ly_all) throw Error(SP_ERR_INTERNAL, "sharded prover: inner round count");
+    ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), ly - k, ps.abc, ps.zs, tr.t, k ? reduce_hook : nullptr, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
+                                         u64p(r_y.data()), u64p(fin)),
        "inner sum-check (local rounds)");
     if (k) {
       std::vector<fe_t> all(2 * world);
@@ -484,7 +529,21 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     const size_t rec = ncols + 4;  // in field-element units (a point = 2 elements)
     std::vector<fe_t> mine(rec), all(rec * world);
     ck(sp_rowmat_vec(ctx, ps.Wblk, rpr, ncols, u64p(L.data() + lo), u64p(mine.data())), "bind_with_delayed (row block)");
-    ck(sp_msm(ctx, u64p(L.data() + lo), u64p(&comm_W[lo].x), rpr, u64p(&mine[ncols])), "comm_LZ (point range)");
+    if (ahead.lz_job) {  // started by the helper at round nvr: finish, then the rank's factor eq(r[0..k), rank bits)
+      sp_msm_job* j = ahead.lz_job;
+      ahead.lz_job = nullptr;
+      aff_t part;
+      ck(sp_msm_job_finish(ctx, j, u64p(&part.x)), "comm_LZ (finish)");
+      if (k) {
+        fe_t sc = fe_one<S>();
+        for (size_t i = 0; i < k; ++i) sc = fe_mul<S>(sc, ((g >> (k - 1 - i)) & 1) ? point[i] : fe_sub<S>(fe_one<S>(), point[i]));
+        ck(sp_vartime_scalar_mul(ctx, u64p(&part.x), 1, u64p(&sc), u64p(&mine[ncols])), "comm_LZ (rank factor)");
+      } else {
+        memcpy(&mine[ncols], &part, sizeof(aff_t));
+      }
+    } else {
+      ck(sp_msm(ctx, u64p(L.data() + lo), u64p(&comm_W[lo].x), rpr, u64p(&mine[ncols])), "comm_LZ (point range)");
+    }
     const size_t cpr = ncols / world;
     if (cpr * world != ncols) throw Error(SP_ERR_INTERNAL, "sharded prover: key width not divisible by the number of ranks");
     {
