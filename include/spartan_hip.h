@@ -77,6 +77,8 @@ int sp_table_copy(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* sr
 /* dst[dst_off + j] = src[src_off + j * stride], j < cnt (device -> device). The slice of a table sharded on its LAST k variables (rank g of 2^k
  * holds Z[(j << k) | g]: src_off = g, stride = 2^k) — SURVEY.md 8(e), "sum-check by evaluation-table slice". */
 int sp_table_gather_strided(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t stride, size_t cnt);
+/* the inverse: dst[dst_off + j * stride] = src[src_off + j], j < cnt - rank g's gathered slice back into the interleaved table (dst_off = g, stride = 2^k) */
+int sp_table_scatter_strided(sp_ctx* ctx, sp_table* dst, size_t dst_off, size_t stride, const sp_table* src, size_t src_off, size_t cnt);
 /* Index / into_vec (:166-173, :87-89) */
 int sp_table_read(sp_ctx* ctx, const sp_table* t, size_t off, size_t cnt, uint64_t* out);
 int sp_table_info(const sp_table* t, size_t* len, size_t* lo_eff, size_t* hi_eff);
@@ -270,6 +272,15 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* ctx, uint64_t claim_io[4], uint64_t p_io[
                                uint64_t out_final[12]);
 int sp_sumcheck_quad_sharded(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce,
                              void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
+/* The first run_rounds rounds only (0 < run_rounds < ell / rounds): the tables are left bound to 2^(ell - run_rounds) elements and the running claim
+ * (and eq product) go out through claim_io / p_io. A sharded prover exchanges sums only while its slice is large - the rounds where sharding pays -
+ * then gathers the slices into tables of 2^(ell - run_rounds + k) elements (sp_table_scatter_strided) and finishes with an ordinary call on every
+ * rank, instead of one exchange in every round. */
+int sp_sumcheck_cubic3_sharded_partial(sp_ctx* ctx, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus, size_t ell, size_t run_rounds, sp_table* A, sp_table* B,
+                                       sp_table* C, sp_transcript* tr, const uint64_t* scale, sp_reduce_hook reduce, void* reduce_user, uint64_t* out_cpolys,
+                                       uint64_t* out_r);
+int sp_sumcheck_quad_sharded_partial(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, size_t run_rounds, sp_table* A, sp_table* B, sp_transcript* tr,
+                                     sp_reduce_hook reduce, void* reduce_user, sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r);
 /* the same with sp_sumcheck_quad_observed's hook: a sharded HyraxPCS::prove starts its rank's part of comm_LZ as soon as the row challenges exist */
 int sp_sumcheck_quad_sharded_observed(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce,
                                       void* reduce_user, sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);

@@ -284,6 +284,12 @@ int sp_table_set_len(sp_table* t, size_t len, size_t lo_eff, size_t hi_eff) {
   t->hi_eff = hi_eff;
   return SP_OK;
 }
+int sp_table_scatter_strided(sp_ctx* c, sp_table* dst, size_t dst_off, size_t stride, const sp_table* src, size_t src_off, size_t cnt) {
+  if (cnt == 0) return SP_OK;
+  if (stride == 0 || src_off + cnt > src->cap || dst_off + (cnt - 1) * stride >= dst->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_scatter_strided: range outside the tables");
+  SP_HIP(hipMemcpy2DAsync(dst->d + dst_off, stride * sizeof(fe_t), src->d + src_off, sizeof(fe_t), sizeof(fe_t), cnt, hipMemcpyDeviceToDevice, c->stream));
+  return SP_OK;
+}
 int sp_table_view(const sp_table* t, size_t off, size_t len, sp_table** out) {
   if (!t || off > t->cap || len > t->cap - off) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_view: window outside the allocation");
   sp_table* v = new sp_table();
@@ -907,7 +913,7 @@ int sp_eval_cubic_zero_check_round0(sp_ctx* c, const uint64_t* taus_, size_t ell
 static bool table_dense(const sp_table* t) { return sp::eff_lo(t) == t->len / 2 && sp::eff_hi(t) == t->len / 2; }
 
 static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
-                     sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
+                     sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8], size_t run_rounds = 0);
 int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
                      uint64_t* out_r, uint64_t out_final[8]) {
   uint64_t claim_io[4];
@@ -930,11 +936,25 @@ int sp_sumcheck_quad_sharded_observed(sp_ctx* c, uint64_t claim_io[4], size_t ro
   return quad_impl(c, claim_io, rounds, A, B, tr, reduce, reduce_user, observe, observe_user, out_cpolys, out_r, out_final);
 }
 
+int sp_sumcheck_quad_sharded_partial(sp_ctx* c, uint64_t claim_io[4], size_t rounds, size_t run_rounds, sp_table* A, sp_table* B, sp_transcript* tr,
+                                     sp_reduce_hook reduce, void* reduce_user, sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r) {
+  if (run_rounds == 0 || run_rounds >= rounds) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad (partial): 0 < run_rounds < rounds");
+  uint64_t unused[8];
+  return quad_impl(c, claim_io, rounds, A, B, tr, reduce, reduce_user, observe, observe_user, out_cpolys, out_r, unused, run_rounds);
+}
+
 // prove_quad on a slice of the tables (see sp_sumcheck_cubic3_sharded): per round the slice's (eval0, t_inf) are combined across ranks by `reduce`
+// run_rounds (0 = all): stop after that many rounds - the tables are left bound to 2^(rounds - run_rounds) elements, the running claim goes out
+// through claim_io and out_final is not written. A sharded prover runs the rounds whose tables are large (where sharding pays) on its slice and
+// gathers the slices for the rest instead of exchanging sums in every remaining round. The resident tail is not used in a stopped call.
 static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
-                     sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
+                     sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8], size_t run_rounds) {
+  const size_t vars = rounds;  // the tables have 2^vars elements
+  if (run_rounds > vars) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: more rounds to run than variables");
+  const bool stopped = run_rounds != 0 && run_rounds < vars;
+  if (stopped) rounds = run_rounds;
   const uint64_t* claim_ = claim_io;
-  if (A->len != B->len || A->len != ((size_t)1 << rounds)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: tables must have 2^rounds elements");
+  if (A->len != B->len || A->len != ((size_t)1 << vars)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: tables must have 2^rounds elements");
   fe_t claim = load_fe(claim_);
   const uint8_t lbl_c[1] = {'c'};
   const size_t chunk = 256 * spk::EVAL_PPT;
@@ -971,7 +991,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       return rc2 ? rc2 : 1;
     }
     if (ahead && !launch_ahead_ok(c, A->len)) return 0;
-    if (tail_enabled() && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B) && lease.take(tail_blocks(A->len / 2))) {
+    if (!stopped && tail_enabled() && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B) && lease.take(tail_blocks(A->len / 2))) {
       spk::TailArgs ta;
       ta.A = A->d;
       ta.B = B->d;
@@ -1132,6 +1152,10 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       observe(observe_user, round, rw);
     }
     if (round_trace()) fprintf(stderr, "quad round %2zu len %8zu tail %d wait %7.1f us host %6.1f us\n", round, len_now, (int)wait_resident, tr1 - tr0, now_us() - tr1);
+  }
+  if (stopped) {
+    store_fe(claim_io, claim);
+    return tail_check(c);
   }
   if (in_tail) {  // the resident kernel hands the final claims over itself
     fe_t fin[3];
@@ -1352,7 +1376,7 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
 
 static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                       const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
-                      uint64_t* out_r, uint64_t out_final[12]);
+                      uint64_t* out_r, uint64_t out_final[12], size_t run_rounds = 0);
 int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                        uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
   uint64_t claim_io[4], p_io[4];
@@ -1381,9 +1405,20 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
                                uint64_t out_final[12]) {
   return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, scale_, reduce, reduce_user, nullptr, nullptr, out_cpolys, out_r, out_final);
 }
+int sp_sumcheck_cubic3_sharded_partial(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, size_t run_rounds, sp_table* A, sp_table* B,
+                                       sp_table* C, sp_transcript* tr, const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, uint64_t* out_cpolys,
+                                       uint64_t* out_r) {
+  if (run_rounds == 0 || run_rounds >= ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (partial): 0 < run_rounds < ell");
+  uint64_t unused[12];
+  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, scale_, reduce, reduce_user, nullptr, nullptr, out_cpolys, out_r, unused, run_rounds);
+}
 static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                       const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
-                      uint64_t* out_r, uint64_t out_final[12]) {
+                      uint64_t* out_r, uint64_t out_final[12], size_t run_rounds) {
+  // run_rounds (0 = all): see quad_impl - stop after that many of the ell rounds, tables left at 2^(ell - run_rounds) elements
+  if (run_rounds > ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: more rounds to run than variables");
+  const bool stopped = run_rounds != 0 && run_rounds < ell;
+  const size_t last_rnd = stopped ? run_rounds : ell;
   const uint64_t* claim_ = claim_io;
   const bool have_scale = scale_ != nullptr;
   const fe_t scale = have_scale ? load_fe(scale_) : fe_one<S>();
@@ -1497,14 +1532,14 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       }
       return 1;
     }
-    if (rnd >= ell) {
+    if (rnd >= last_rnd) {
       if (ahead) return 0;
       sp_table* tabs[3] = {A, B, C};
       int rc2 = launch_bind(c, tabs, 3, rv);
       return rc2 ? rc2 : 1;
     }
     if (ahead && !launch_ahead_ok(c, A->len)) return 0;
-    if (tail_enabled() && A->len <= TAIL_MAX_LEN && tail_blocks(A->len / 2, true) <= (unsigned)spk::HOST_SUM_MAX_BLOCKS && lease.take(tail_blocks(A->len / 2, true))) {
+    if (!stopped && tail_enabled() && A->len <= TAIL_MAX_LEN && tail_blocks(A->len / 2, true) <= (unsigned)spk::HOST_SUM_MAX_BLOCKS && lease.take(tail_blocks(A->len / 2, true))) {
       spk::TailArgs ta;
       ta.A = A->d;
       ta.B = B->d;
@@ -1620,7 +1655,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     }
   }
   if (round_trace()) fprintf(stderr, "cubic setup %7.1f us\n", now_us() - tr_entry);
-  for (size_t rnd = 1; rnd <= ell; ++rnd) {
+  for (size_t rnd = 1; rnd <= last_rnd; ++rnd) {
     // host work that only needs earlier challenges runs while the device computes this round's sums
     const double tr_top = round_trace() ? now_us() : 0;
     const fe_t tau = taus[rnd - 1];
@@ -1716,6 +1751,11 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
     if (round_trace())
       fprintf(stderr, "cubic round %2zu len %8zu tail %d pre %5.1f wait %7.1f us host %6.1f us\n", rnd, len_now, (int)wait_resident, tr0 - tr_top, tr1 - tr0, now_us() - tr1);
+  }
+  if (stopped) {
+    store_fe(claim_io, claim);
+    store_fe(p_io, eval_eq_left);
+    return tail_check(c);
   }
   if (in_tail) {  // the resident kernel hands the final claims over itself
     fe_t fin[3];

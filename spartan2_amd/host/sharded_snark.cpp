@@ -53,9 +53,11 @@ struct ShardedPrep {
   std::vector<fe_t> r_W_fixed;
   size_t rows_shared = 0, rows_precommitted = 0;
   std::vector<uint8_t> comm_shared_bytes, comm_pre_bytes;  // transcript encodings of the rows committed at prep time (hyrax_pc.rs:714-729)
+  sp_table *gS = nullptr, *gT[3] = {nullptr, nullptr, nullptr};  // staging + gathered tables of the sum-checks' hand-over (2^gather_log2 elements)
+  size_t g_cap = 0;
   bool is_small = true;
   ~ShardedPrep() {
-    for (sp_table* t : {W, Wblk, caz, cbz, ccz, az, bz, cz, z, zs, abc, rx}) sp_table_free(t);
+    for (sp_table* t : {W, Wblk, caz, cbz, ccz, az, bz, cz, z, zs, abc, rx, gS, gT[0], gT[1], gT[2]}) sp_table_free(t);
   }
 };
 
@@ -237,6 +239,50 @@ static int reduce_hook(void* user, uint64_t* sums, size_t count) {
 }
 
 // SpartanSNARK::prove (src/spartan.rs:219-466), one proof over all ranks
+// Where the sharded sum-checks hand over: the slices exchange sums only while the GATHERED tables would still have more than 2^gather_log2 elements
+// (the bandwidth-bound rounds, where sharding pays); then every rank gathers all slices and finishes alone - one bulk exchange instead of one small
+// exchange in each of the remaining ~16 latency-bound rounds. SPARTAN_SHARD_GATHER_LOG2 (default 16; k = one element per rank, the old hand-over).
+static size_t gather_log2() {
+  static const size_t v = [] {
+    const char* e = getenv("SPARTAN_SHARD_GATHER_LOG2");
+    const long x = e ? atol(e) : 16;
+    return (size_t)(x < 0 ? 0 : (x > 24 ? 24 : x));
+  }();
+  return v;
+}
+// rounds the slice runs before the hand-over, for a sum-check of `ell` variables over 2^k ranks
+static size_t local_rounds(size_t ell, size_t k) {
+  if (k == 0) return ell;
+  size_t g2 = gather_log2();
+  if (g2 < k) g2 = k;
+  const size_t loc = ell - k, keep = g2 - k;  // slice variables left unbound at the hand-over
+  return loc > keep ? loc - keep : 0;
+}
+static void* table_dev(const sp_table* t) {
+  void* p = nullptr;
+  ck(sp_table_device_ptr(t, &p, nullptr), "device_ptr");
+  return p;
+}
+// gathered[q][(j << k) | g] = rank g's slice[q][j], j < m: the bound tables in natural order on every rank
+static void gather_slices(sp_ctx* ctx, Comm& comm, ShardedPrep& ps, sp_table* const* slices, int ntab, size_t m) {
+  const size_t world = (size_t)comm.world, total = m * world;
+  if (total > ps.g_cap) {
+    for (sp_table** t : {&ps.gS, &ps.gT[0], &ps.gT[1], &ps.gT[2]}) {
+      sp_table_free(*t);
+      *t = nullptr;
+    }
+    ps.g_cap = total;
+    for (sp_table** t : {&ps.gS, &ps.gT[0], &ps.gT[1], &ps.gT[2]}) ck(sp_table_zeros(ctx, total, (size_t)-1, (size_t)-1, t), "hand-over tables");
+  }
+  for (int q = 0; q < ntab; ++q) {
+    ck(sp_ctx_synchronize(ctx), "synchronize");
+    comm.allgather_device(table_dev(slices[q]), m * sizeof(fe_t), table_dev(ps.gS));
+    for (size_t r = 0; r < world; ++r) ck(sp_table_scatter_strided(ctx, ps.gT[q], r, world, ps.gS, r * m, m), "interleave");
+    ck(sp_table_set_len(ps.gT[q], total, (size_t)-1, (size_t)-1), "gathered len");
+  }
+  ck(sp_ctx_synchronize(ctx), "synchronize");  // gS is reused by the next table / call
+}
+
 SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, double phase_ms[8]) {
   const sp_dims& d = pk.dims;
   sp_ctx* ctx = pk.ctx;
@@ -343,8 +389,8 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   ahead.key = pk.ck;
   const size_t ncols_ipa = (size_t)1 << ((log2_ceil(M)) - log2_ceil(rows_all));
   const size_t nvr_rows = log2_ceil(rows_all), ly_all = log2_ceil(M) + 1;
-  // the row challenges are r_y[1 ..= nvr]: they must all come from the local rounds, and the block must hold at least two rows
-  const bool lz_on = nvr_rows > k && nvr_rows + 1 <= ly_all - k && nvr_rows <= 31 && rpr == ((size_t)1 << (nvr_rows - k));
+  // the row challenges are r_y[1 ..= nvr] (the observer sees every round, slice or gathered); the block must hold at least two rows
+  const bool lz_on = nvr_rows > k && nvr_rows + 1 <= ly_all && nvr_rows <= 31 && rpr == ((size_t)1 << (nvr_rows - k));
   ahead.nvr = nvr_rows;
   {
     Tape peek = tape;
@@ -410,27 +456,40 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
       scale = fe_mul<S>(scale, ((g >> (k - 1 - i)) & 1) ? t : fe_sub<S>(fe_one<S>(), t));
     }
     fe_t fin[3];
-    ck(sp_sumcheck_cubic3_sharded(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), lx - k, ps.az, ps.bz, ps.cz, tr.t, k ? u64p(&scale) : nullptr,
-                                  k ? reduce_hook : nullptr, &comm, u64p(outer_polys.data()), u64p(r_x.data()), u64p(fin)),
-       "outer sum-check (local rounds)");
-    if (k) {
-      std::vector<fe_t> all(3 * world);
-      comm.allgather(fin, sizeof fin, all.data());
-      sp_table* T[3] = {nullptr, nullptr, nullptr};
-      struct Guard {
-        sp_table** t;
-        ~Guard() {
-          for (int i = 0; i < 3; ++i) sp_table_free(t[i]);
+    const size_t loc = lx - k, R = local_rounds(lx, k);
+    if (R == loc) {  // unsharded, or the hand-over at one element per rank
+      ck(sp_sumcheck_cubic3_sharded(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), loc, ps.az, ps.bz, ps.cz, tr.t, k ? u64p(&scale) : nullptr,
+                                    k ? reduce_hook : nullptr, &comm, u64p(outer_polys.data()), u64p(r_x.data()), u64p(fin)),
+         "outer sum-check (local rounds)");
+      if (k) {
+        std::vector<fe_t> all(3 * world);
+        comm.allgather(fin, sizeof fin, all.data());
+        sp_table* T[3] = {nullptr, nullptr, nullptr};
+        struct Guard {
+          sp_table** t;
+          ~Guard() {
+            for (int i = 0; i < 3; ++i) sp_table_free(t[i]);
+          }
+        } guard{T};
+        for (int q = 0; q < 3; ++q) {
+          std::vector<fe_t> col(world);
+          for (size_t r = 0; r < world; ++r) col[r] = all[3 * r + q];
+          ck(sp_table_from_host(ctx, u64p(col.data()), world, (size_t)-1, (size_t)-1, &T[q]), "gathered table");
         }
-      } guard{T};
-      for (int q = 0; q < 3; ++q) {
-        std::vector<fe_t> col(world);
-        for (size_t r = 0; r < world; ++r) col[r] = all[3 * r + q];
-        ck(sp_table_from_host(ctx, u64p(col.data()), world, (size_t)-1, (size_t)-1, &T[q]), "gathered table");
+        ck(sp_sumcheck_cubic3_sharded(ctx, u64p(&claim), u64p(&p), u64p(tau.data() + loc), k, T[0], T[1], T[2], tr.t, nullptr, nullptr, nullptr,
+                                      u64p(outer_polys.data() + 3 * loc), u64p(r_x.data() + loc), u64p(fin)),
+           "outer sum-check (last rounds)");
       }
-      ck(sp_sumcheck_cubic3_sharded(ctx, u64p(&claim), u64p(&p), u64p(tau.data() + (lx - k)), k, T[0], T[1], T[2], tr.t, nullptr, nullptr, nullptr,
-                                    u64p(outer_polys.data() + 3 * (lx - k)), u64p(r_x.data() + (lx - k)), u64p(fin)),
-         "outer sum-check (last rounds)");
+    } else {  // R slice rounds with one exchange each, ONE bulk hand-over, then lx - R rounds on the gathered tables
+      if (R)
+        ck(sp_sumcheck_cubic3_sharded_partial(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), loc, R, ps.az, ps.bz, ps.cz, tr.t, u64p(&scale), reduce_hook, &comm,
+                                              u64p(outer_polys.data()), u64p(r_x.data())),
+           "outer sum-check (slice rounds)");
+      sp_table* const sl[3] = {ps.az, ps.bz, ps.cz};
+      gather_slices(ctx, comm, ps, sl, 3, (size_t)1 << (loc - R));
+      ck(sp_sumcheck_cubic3_sharded(ctx, u64p(&claim), u64p(&p), u64p(tau.data() + R), lx - R, ps.gT[0], ps.gT[1], ps.gT[2], tr.t, nullptr, nullptr, nullptr,
+                                    u64p(outer_polys.data() + 3 * R), u64p(r_x.data() + R), u64p(fin)),
+         "outer sum-check (gathered rounds)");
     }
     for (int i = 0; i < 3; ++i) claims_outer[i] = fin[i];
   }
@@ -460,35 +519,52 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     struct Obs {
       decltype(ahead)* a;
       bool on;
-      static void fn(void* u, size_t round, const uint64_t r[4]) {  // r_y[round]; the row variables are r_y[1 ..= nvr] (MSB first)
+      size_t base;  // rounds already run by an earlier call of this sum-check
+      static void fn(void* u, size_t round, const uint64_t r[4]) {  // r_y[base + round]; the row variables are r_y[1 ..= nvr] (MSB first)
         Obs* o = (Obs*)u;
+        round += o->base;
         if (!o->on || round == 0 || round > o->a->nvr) return;
         memcpy(&o->a->r_rows[round - 1], r, 32);
         if (round == o->a->nvr) o->a->publish(1);
       }
-    } obs{&ahead, lz_on};
+    } obs{&ahead, lz_on, 0};
     if (ly != ly_all) throw Error(SP_ERR_INTERNAL, "sharded prover: inner round count");
-    ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), ly - k, ps.abc, ps.zs, tr.t, k ? reduce_hook : nullptr, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
-                                         u64p(r_y.data()), u64p(fin)),
-       "inner sum-check (local rounds)");
-    if (k) {
-      std::vector<fe_t> all(2 * world);
-      comm.allgather(fin, sizeof fin, all.data());
-      sp_table* T[2] = {nullptr, nullptr};
-      struct Guard {
-        sp_table** t;
-        ~Guard() {
-          for (int i = 0; i < 2; ++i) sp_table_free(t[i]);
+    const size_t loc = ly - k, R = local_rounds(ly, k);
+    if (R == loc) {
+      ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), loc, ps.abc, ps.zs, tr.t, k ? reduce_hook : nullptr, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
+                                           u64p(r_y.data()), u64p(fin)),
+         "inner sum-check (local rounds)");
+      if (k) {
+        std::vector<fe_t> all(2 * world);
+        comm.allgather(fin, sizeof fin, all.data());
+        sp_table* T[2] = {nullptr, nullptr};
+        struct Guard {
+          sp_table** t;
+          ~Guard() {
+            for (int i = 0; i < 2; ++i) sp_table_free(t[i]);
+          }
+        } guard{T};
+        for (int q = 0; q < 2; ++q) {
+          std::vector<fe_t> col(world);
+          for (size_t rr = 0; rr < world; ++rr) col[rr] = all[2 * rr + q];
+          ck(sp_table_from_host(ctx, u64p(col.data()), world, (size_t)-1, (size_t)-1, &T[q]), "gathered table");
         }
-      } guard{T};
-      for (int q = 0; q < 2; ++q) {
-        std::vector<fe_t> col(world);
-        for (size_t rr = 0; rr < world; ++rr) col[rr] = all[2 * rr + q];
-        ck(sp_table_from_host(ctx, u64p(col.data()), world, (size_t)-1, (size_t)-1, &T[q]), "gathered table");
+        obs.base = loc;
+        ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), k, T[0], T[1], tr.t, nullptr, nullptr, &Obs::fn, &obs, u64p(inner_polys.data() + 2 * loc),
+                                             u64p(r_y.data() + loc), u64p(fin)),
+           "inner sum-check (last rounds)");
       }
-      ck(sp_sumcheck_quad_sharded(ctx, u64p(&claim), k, T[0], T[1], tr.t, nullptr, nullptr, u64p(inner_polys.data() + 2 * (ly - k)), u64p(r_y.data() + (ly - k)),
-                                  u64p(fin)),
-         "inner sum-check (last rounds)");
+    } else {
+      if (R)
+        ck(sp_sumcheck_quad_sharded_partial(ctx, u64p(&claim), loc, R, ps.abc, ps.zs, tr.t, reduce_hook, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
+                                            u64p(r_y.data())),
+           "inner sum-check (slice rounds)");
+      sp_table* const sl[2] = {ps.abc, ps.zs};
+      gather_slices(ctx, comm, ps, sl, 2, (size_t)1 << (loc - R));
+      obs.base = R;
+      ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), ly - R, ps.gT[0], ps.gT[1], tr.t, nullptr, nullptr, &Obs::fn, &obs, u64p(inner_polys.data() + 2 * R),
+                                           u64p(r_y.data() + R), u64p(fin)),
+         "inner sum-check (gathered rounds)");
     }
     claims_inner[0] = fin[0];
     claims_inner[1] = fin[1];

@@ -12,10 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q, which):
+def _worker(rank, world, port, q, which, gather_log2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # where the sum-checks hand over from slices (one exchange per round) to gathered tables (no exchange): read once per process by the driver
+    os.environ["SPARTAN_SHARD_GATHER_LOG2"] = str(gather_log2)
     import oracle_lib as ol
     from spartan2_amd import dist as spd, frontend, hip, host
 
@@ -46,13 +48,19 @@ def _worker(rank, world, port, q, which):
     g.close()
 
 
-@pytest.mark.parametrize("world,which", [(2, "synthetic"), (4, "synthetic"), (2, "segments"), (4, "sha256")])
-def test_sharded_prove_is_the_unsharded_proof(world, which):
+# gather_log2: 0 = hand over at one element per rank (an exchange in every slice round: the round-1 protocol); 8 = a few slice rounds, then one bulk
+# hand-over of 2^8-element tables; 16 (the default) = these small instances are gathered at once and every rank runs the sum-checks alone
+@pytest.mark.parametrize("world,which,gather_log2", [(2, "synthetic", 0), (4, "synthetic", 0), (2, "segments", 8), (4, "sha256", 8), (4, "synthetic", 8),
+                                                     (2, "sha256", 16), (4, "segments", 5)])
+def test_sharded_prove_is_the_unsharded_proof(world, which, gather_log2):
     import mp_util
 
-    res = mp_util.run_ranks(_worker, world, (which,))
+    res = mp_util.run_ranks(_worker, world, (which, gather_log2))
     assert res[0][:5] == (True,) * 5, res[0]
-    assert res[0][5] > 20  # one exchange per local sum-check round + commitment + finals + opening
+    if gather_log2 == 0:
+        assert res[0][5] > 20  # one exchange per local sum-check round + commitment + finals + opening
+    elif gather_log2 == 16:
+        assert res[0][5] <= 16  # commitment rows, 3 + 2 table hand-overs, the opening record (per prove): no per-round exchange at all
 
 
 def test_rccl_backend_one_rank_and_world_of_one_prove():
