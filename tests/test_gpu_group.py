@@ -242,3 +242,33 @@ def test_msm_eq_rejects_length_mismatch(ctx, gens):
     r = ol.random_field_array(rng, 3)
     with pytest.raises(hip.SpartanHipError):
         hip.msm_eq(ctx, np.ascontiguousarray(gens[:7]), r)
+
+
+@pytest.mark.parametrize("width", [8, 32, 33, 64])
+def test_commit_small_device_form_matches_oracle(ctx, width):
+    """sp_hyrax_commit_small on keys of <= 64 bases with more than six non-zero scalars (the device form: per-base table walks in one launch, the
+    points added on the host) against the oracle's MSM + blind (hyrax_pc.rs:221-260, msm.rs:727-773).
+    Cases: dense, short (zero-padded) vectors, a zero blind, repeated scalars on one call after the other (sequence numbers), all-equal digits."""
+    rng = np.random.default_rng(SEED + 4100 + width)
+    gs = np.zeros((width + 1, 8), dtype=np.uint64)
+    olib().orc_from_label(b"narrow_key_test", ctypes.c_size_t(width + 1), p64(gs))
+    k = hip.CommitmentKey(ctx, gs[:width], gs[width])
+
+    def want(sc, blind):
+        full = np.zeros((width + 1, 4), dtype=np.uint64)
+        full[: len(sc)] = sc
+        full[width] = blind
+        return oracle_msm(full, np.ascontiguousarray(gs))
+
+    for n in (width, width - 1, 7):
+        sc = ol.random_field_array(rng, n)
+        blind = ol.random_field_array(rng, 1)[0]
+        assert (k.commit_small(sc, blind) == want(sc, blind)).all()
+    sc = ol.random_field_array(rng, width)
+    sc[::3] = 0
+    zero = np.zeros(4, dtype=np.uint64)
+    assert (k.commit_small(sc, zero) == want(sc, zero)).all()
+    ones = np.tile(to_mont(int.from_bytes(b"\x01" * 31, "little")), (width, 1))  # every window of every scalar hits entry 1 of its table
+    blind = ol.random_field_array(rng, 1)[0]
+    for _ in range(3):
+        assert (k.commit_small(ones, blind) == want(ones, blind)).all()
