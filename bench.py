@@ -193,6 +193,14 @@ def main():
         barrier()
         elapsed = group.max_over_ranks(time.perf_counter() - t0)
         ncons = circs[0].num_cons * nsteps + core.num_cons
+        # NeutronNovaZkSNARK::verify on the device-backed driver (outside the timed region): the last proof of the loop
+        verify_rc = nn.verify(words)
+        tv = time.perf_counter()
+        for _ in range(5):
+            verify_rc |= nn.verify(words)
+        verify_ms = (time.perf_counter() - tv) / 5 * 1e3
+        if verify_rc != 0:
+            raise SystemExit(f"the device-backed verifier rejected the proof (check {verify_rc})")
         if rank == 0:
             out = {"metric": "sha256_neutronnova 32 step circuits, NeutronNovaZkSNARK::prove: R1CS constraints/sec (all step + core constraints of one batch per prove)",
                    "value": ncons * world * args.steps / elapsed, "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -202,7 +210,7 @@ def main():
                    "config": {"workload": "sha256_neutronnova 32 step circuits (BASELINE config 3), NeutronNovaZkSNARK::prove", "num_steps": nsteps,
                               "num_cons_unpadded_per_step": circs[0].num_cons, "num_cons_per_step": 1 << nn.info["nx"],
                               "parallelism": f"{world} independent batches, one per GPU"},
-                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "sharded": None, "roofline": None, "cpu_baseline": None}
+                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "verify_ms": verify_ms, "sharded": None, "roofline": None, "cpu_baseline": None}
             if world == 1 and not args.no_cpu_baseline:
                 import oracle_lib as ol  # test infrastructure, used here only as the reported CPU baseline and the bit-exactness check
 

@@ -454,7 +454,7 @@ NN_PHASES = ("instances", "nifs", "outer_sumcheck", "inner_sumcheck", "verifier_
 
 
 class NeutronNovaZkSNARK:
-    """setup -> prep_prove -> prove (src/neutronnova_zk.rs:1394-2093) for step / core circuits of one padded shape without rest variables or challenges
+    """setup -> prep_prove -> prove -> verify (src/neutronnova_zk.rs:1394-2343) for step / core circuits of one padded shape without rest variables or challenges
     (the bench circuits: benches/sha256_neutronnova.rs). step_insts / core_inst: frontend.R1CSInstanceInt."""
 
     def __init__(self, ctx: hip.Context, step_insts, core_inst):
@@ -492,6 +492,15 @@ class NeutronNovaZkSNARK:
         ms = (ctypes.c_double * 8)()
         _check(lib().nnz_prove(self.pk, self.ps, hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
         return words, used.value, dict(zip(NN_PHASES, list(ms)))
+
+    def verify(self, words: np.ndarray) -> int:
+        """NeutronNovaZkSNARK::verify (src/neutronnova_zk.rs:2096-2343) with the commitment fold, the six matrix evaluations and the opening's MSMs on the
+        device: 0 = accept, else the failed check (1 shape / encoding, 2 verifier-circuit instance, 4 relaxed Spartan proof, 5 public values, 6 opening)."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        rc = lib().nnz_verify(self.pk, hip.p64(words), ctypes.c_size_t(words.shape[0]))
+        if rc < 0:
+            _check(rc)
+        return rc
 
     def close(self):
         if self.ps:

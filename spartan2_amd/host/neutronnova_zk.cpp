@@ -1,4 +1,4 @@
-// NeutronNovaZkSNARK::{setup, prep_prove, prove} (src/neutronnova_zk.rs:1394-2093) above the C ABI — SURVEY.md 8(f) rank 1, BASELINE config 3 as a real
+// NeutronNovaZkSNARK::{setup, prep_prove, prove, verify} (src/neutronnova_zk.rs:1394-2343) above the C ABI — SURVEY.md 8(f) rank 1, BASELINE config 3 as a real
 // prove(): rerandomization, the step / core instances, NeutronNovaNIFS::prove with the verifier circuit's `process_round` as its round hook, the batched
 // outer and inner sum-checks (process_round again), the verifier-circuit instance folded with a fresh random relaxed instance (NovaNIFS::prove,
 // src/nifs.rs:34-61 + commit_T, src/r1cs/folds.rs:28-88), RelaxedR1CSSpartanProof::prove (src/spartan_relaxed.rs:98-213) and the folded Hyrax opening.
@@ -22,7 +22,12 @@ struct NNZkKey {
   vcirc::Shape vc;
   size_t nb = 0, nx = 0, ny = 0, num_steps = 0, num_vars = 0;
   uint8_t vk_digest[32];
+  // verify(): eq tables and the three M * T_y products of the matrix evaluations, allocated on first use
+  mutable sp_table *v_Tx = nullptr, *v_Ty = nullptr, *v_mv[3] = {nullptr, nullptr, nullptr};
   ~NNZkKey() {
+    sp_table_free(v_Tx);
+    sp_table_free(v_Ty);
+    for (sp_table* t : v_mv) sp_table_free(t);
     sp_shape_free(S_step);
     sp_shape_free(S_core);
     sp_ck_free(ck);
@@ -688,6 +693,340 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   return proof;
 }
 
+
+// number of 64-bit words of a proof in the canonical layout (NNProof::serialize)
+static size_t proof_words(const NNZkKey& pk) {
+  const sp_dims& d = pk.dims;
+  const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0,
+               rows_rest = d.num_rest / CW;
+  const vcirc::Shape& vs = pk.vc;
+  const size_t vlx = log2_ceil(vs.num_cons), vly = log2_ceil(next_pow2(vs.total_vars)) + 1;
+  size_t w = 8 * rows_sh + pk.num_steps * (8 * (rows_pre + rows_rest) + 4 * d.num_public) + 8 * (rows_pre + rows_rest) + 4 * pk.dims_core.num_public + 16 + 4 * CW + 8;
+  w += 8 * (vs.total_vars / 32) + 4 * vs.num_public + 4 * vs.total_challenges;
+  w += 8 * (vs.num_cons / 32) + 8 * (vs.total_vars / 32) + 8 * (vs.num_cons / 32) + 4 + 4 * vs.num_io();
+  w += 12 * vlx + 12 + 8 * vly + 4 * 32 + 4 + 4 * 32 + 4;
+  return w;
+}
+
+// ---- NeutronNovaZkSNARK::verify (src/neutronnova_zk.rs:2096-2343) — SURVEY 8(f) rank 3 for caller #2 -----------------------------------------------
+// What scales with the step circuits runs on the device through the same ABI: the fold of the step instances' commitments (one shared-weights MSM per
+// Hyrax row, hyrax_pc.rs:737-793), the six matrix evaluations A, B, C (rx, ry) of the step and core shapes (ONE sp_multiply_vec against T_y = eq(r_y)
+// per shape + three dot products with T_x, `evaluate_with_tables_fast` src/r1cs/mod.rs:1216-1226), comm_LZ = <L, comm rows> and the IPA's <z_vec, ck>
+// (hyrax_pc.rs:480-531, ipa.rs:173-221). The verifier-circuit instance (replayed transcript of its per-round commitments, NovaNIFS::verify
+// src/nifs.rs:65-77, RelaxedR1CSSpartanProof::verify src/spartan_relaxed.rs:216-316 with its two direct openings hyrax_pc.rs:654-711) is host algebra
+// over a few hundred constraints plus small MSMs / two-term folds through the ABI. Returns 0 = accept, else the index of the failed check — the
+// oracle's codes (oracle/neutronnova_zk.hpp nn_verify): 1 shape / encoding, 2 verifier-circuit instance does not replay, 4 relaxed Spartan proof,
+// 5 public values of the verifier circuit, 6 folded opening.
+static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
+  sp_ctx* ctx = pk.ctx;
+  const sp_dims& d = pk.dims;
+  const vcirc::Shape& vs = pk.vc;
+  const size_t CW = DEFAULT_COMMITMENT_WIDTH, n = pk.num_steps, nv = pk.num_vars, N = d.num_cons, dpub = d.num_public, cpub = pk.dims_core.num_public;
+  const size_t rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0, rows_rest = d.num_rest / CW;
+  const size_t rows = rows_sh + rows_pre + rows_rest;
+  const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io(), vlx = log2_ceil(vcons), vnvp = next_pow2(vnv), vly = log2_ceil(vnvp) + 1, VW = vs.width;
+  if (n == 0 || nwords != proof_words(pk)) return 1;
+  ck(sp_ctx_bind_thread(ctx), "device");
+  // ---- the proof in its canonical layout; every coordinate and scalar of an untrusted proof must be a canonical residue and every point on the curve
+  const fe_t* w = reinterpret_cast<const fe_t*>(words);
+  size_t o = 0;
+  bool well_formed = true;
+  auto pts = [&](size_t cnt) {
+    const aff_t* p = reinterpret_cast<const aff_t*>(w + o);
+    for (size_t i = 0; i < cnt; ++i)
+      if (!limbs_canonical<B>(p[i].x) || !limbs_canonical<B>(p[i].y) || !aff_on_curve(p[i])) well_formed = false;
+    o += 2 * cnt;
+    return p;
+  };
+  auto fes = [&](size_t cnt) {
+    const fe_t* p = w + o;
+    for (size_t i = 0; i < cnt; ++i)
+      if (!limbs_canonical<S>(p[i])) well_formed = false;
+    o += cnt;
+    return p;
+  };
+  struct Inst {
+    const aff_t *pre, *rest;
+    const fe_t* pub;
+  };
+  const aff_t* comm_shared = pts(rows_sh);
+  std::vector<Inst> steps(n);
+  for (auto& u : steps) {
+    u.pre = pts(rows_pre);
+    u.rest = pts(rows_rest);
+    u.pub = fes(dpub);
+  }
+  Inst core;
+  core.pre = pts(rows_pre);
+  core.rest = pts(rows_rest);
+  core.pub = fes(cpub);
+  const aff_t delta = *pts(1), beta = *pts(1);
+  const fe_t* z_vec = fes(CW);
+  const fe_t z_delta = *fes(1), z_beta = *fes(1);
+  std::vector<const aff_t*> vcomm(vs.num_rounds);
+  for (size_t r = 0; r < vs.num_rounds; ++r) vcomm[r] = pts(vs.vars_padded[r] / VW);
+  const fe_t* vpub = fes(vs.num_public);
+  std::vector<const fe_t*> vchal(vs.num_rounds);
+  for (size_t r = 0; r < vs.num_rounds; ++r) vchal[r] = fes(vs.chals_per_round[r]);
+  const aff_t* comm_T = pts(vcons / VW);
+  const aff_t* rnd_comm_W = pts(vnv / VW);
+  const aff_t* rnd_comm_E = pts(vcons / VW);
+  const fe_t rnd_u = *fes(1);
+  const fe_t* rnd_X = fes(vio);
+  const fe_t* v_outer = fes(3 * vlx);
+  const fe_t* v_claims = fes(3);
+  const fe_t* v_inner = fes(2 * vly);
+  const fe_t* v_W = fes(VW);
+  const fe_t blind_vW = *fes(1);
+  const fe_t* v_E = fes(VW);
+  const fe_t blind_vE = *fes(1);
+  if (4 * o != nwords) throw Error(SP_ERR_INTERNAL, "nn_verify: layout / proof_words disagree");
+  if (!well_formed) return 1;
+
+  // <z_vec, ck> (ipa.rs:196-203) depends on nothing but the proof: its device part runs under everything that follows
+  struct ZJob {
+    sp_ctx* ctx;
+    const sp_ck* key;
+    sp_msm_job* job = nullptr;
+    ~ZJob() {
+      uint64_t sink[8];
+      if (job) sp_msm_ck_finish(ctx, key, job, nullptr, sink);  // an early return still owns the job
+    }
+  } zjob{ctx, pk.ck};
+  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(z_vec), CW, &zjob.job), "<z, ck> (begin)");
+
+  // regular instances: comm_W = shared | precommitted | rest rows, X = the public values (src/r1cs/mod.rs:1723-1760)
+  auto regular = [&](const Inst& u) {
+    std::vector<aff_t> c(rows);
+    std::copy(comm_shared, comm_shared + rows_sh, c.begin());
+    std::copy(u.pre, u.pre + rows_pre, c.begin() + rows_sh);
+    std::copy(u.rest, u.rest + rows_rest, c.begin() + rows_sh + rows_pre);
+    return c;
+  };
+  size_t np = 2;
+  while (np < n) np <<= 1;
+  const size_t nb = pk.nb, nx = pk.nx, ny = pk.ny;
+  if (((size_t)1 << nb) != np) throw Error(SP_ERR_INTERNAL, "nn_verify: a single step instance is not driven by this layer");
+  auto inst = [&](size_t i) { return i < n ? i : 0; };  // padding clones instance 0 (:549-552)
+  std::vector<std::vector<aff_t>> Ucomm(n);
+  for (size_t i = 0; i < n; ++i) Ucomm[i] = regular(steps[i]);
+  const std::vector<aff_t> core_comm = regular(core);
+  const std::vector<fe_t> core_X(core.pub, core.pub + cpub);
+  Tr tr(ctx, "neutronnova_prove");
+  tr.absorb("vk", pk.vk_digest, 32);
+  absorb_instance(tr, "core_instance", core_comm, core_X);
+  for (size_t i = 0; i < np; ++i) absorb_instance(tr, "U", Ucomm[inst(i)], std::vector<fe_t>(steps[inst(i)].pub, steps[inst(i)].pub + dpub));
+  {
+    uint8_t zero_be[32] = {0};  // T = 0 (:556-557)
+    tr.absorb("T", zero_be, 32);
+  }
+  const fe_t tau = tr.squeeze("tau");
+  std::vector<fe_t> rhos(nb);
+  for (auto& x : rhos) x = tr.squeeze("rho");
+  // U_verifier.validate (src/r1cs/mod.rs:1808-1834): the per-round commitments reproduce the challenges the instance carries
+  for (size_t round = 0; round < vs.num_rounds; ++round) {
+    const std::vector<uint8_t> b = commitment_bytes(vcomm[round], vs.vars_padded[round] / VW);
+    tr.absorb("comm_w_round", b.data(), b.size());
+    for (size_t i = 0; i < vs.chals_per_round[round]; ++i)
+      if (!fe_eq(tr.squeeze("challenge"), vchal[round][i])) return 2;
+  }
+  // its regular form: comm_W = the rounds' rows, X = challenges | public values
+  const std::vector<aff_t> Uv_comm(vcomm[0], vcomm[0] + vnv / VW);  // the rounds are consecutive in the layout
+  std::vector<fe_t> Uv_X;
+  for (size_t r = 0; r < vs.num_rounds; ++r) Uv_X.insert(Uv_X.end(), vchal[r], vchal[r] + vs.chals_per_round[r]);
+  Uv_X.insert(Uv_X.end(), vpub, vpub + vs.num_public);
+  const size_t num_chal = nb + nx + 1 + ny;
+  if (vs.total_challenges != num_chal || vs.num_public != 6) return 2;
+  const fe_t *r_b = Uv_X.data(), *r_x = r_b + nb, *r_y = r_x + nx + 1, *pub = Uv_X.data() + num_chal;
+  const fe_t r = Uv_X[nb + nx], r2 = fe_mul<S>(r, r), one = fe_one<S>();
+  // fold_multiple of the step instances (src/r1cs/mod.rs:695-722): X on the host, the commitment rows as shared-weights MSMs
+  std::vector<fe_t> wts(np);
+  ck(sp_weights_from_r(u64p(r_b), nb, np, u64p(wts.data())), "weights_from_r");
+  std::vector<fe_t> Xf(dpub, fe_zero());
+  for (size_t i = 0; i < np; ++i)
+    for (size_t j = 0; j < dpub; ++j) Xf[j] = fe_add<S>(Xf[j], fe_mul<S>(wts[i], steps[inst(i)].pub[j]));
+  std::vector<aff_t> folded_comm(rows);
+  {
+    std::vector<aff_t> bases(rows * np);
+    for (size_t rr = 0; rr < rows; ++rr)
+      for (size_t i = 0; i < np; ++i) bases[rr * np + i] = Ucomm[inst(i)][rr];
+    ck(sp_msm_shared_weights(ctx, u64p(wts.data()), np, reinterpret_cast<const uint64_t*>(bases.data()), rows, reinterpret_cast<uint64_t*>(folded_comm.data())), "fold_commitments");
+  }
+  // NovaNIFS::verify (src/nifs.rs:65-77): the random relaxed instance folded with the verifier-circuit instance
+  {
+    std::vector<uint8_t> b = commitment_bytes(rnd_comm_W, vnv / VW), e = commitment_bytes(rnd_comm_E, vcons / VW);
+    b.insert(b.end(), e.begin(), e.end());
+    const size_t off = b.size();
+    b.resize(off + 32 * (1 + vio));
+    sp::fe_to_be_bytes<S>(rnd_u, b.data() + off);
+    for (size_t j = 0; j < vio; ++j) sp::fe_to_be_bytes<S>(rnd_X[j], b.data() + off + 32 * (1 + j));
+    tr.absorb("U1", b.data(), b.size());
+  }
+  absorb_instance(tr, "U2", Uv_comm, Uv_X);
+  {
+    const std::vector<uint8_t> b = commitment_bytes(comm_T, vcons / VW);
+    tr.absorb("comm_T", b.data(), b.size());
+  }
+  const fe_t rf = tr.squeeze("r");
+  std::vector<aff_t> fU_W(vnv / VW), fU_E(vcons / VW);
+  ck(sp_fold_commitments2(ctx, u64p(&rnd_comm_W[0].x), u64p(&Uv_comm[0].x), fU_W.size(), u64p(&rf), u64p(&fU_W[0].x)), "fold comm_W");
+  ck(sp_fold_commitments2(ctx, u64p(&rnd_comm_E[0].x), u64p(&comm_T[0].x), fU_E.size(), u64p(&rf), u64p(&fU_E[0].x)), "fold comm_E");
+  const fe_t fU_u = fe_add<S>(rnd_u, rf);
+  std::vector<fe_t> fU_X(vio);
+  for (size_t i = 0; i < vio; ++i) fU_X[i] = fe_add<S>(rnd_X[i], fe_mul<S>(rf, Uv_X[i]));
+  // RelaxedR1CSSpartanProof::verify (src/spartan_relaxed.rs:216-316)
+  {
+    // verify_direct (hyrax_pc.rs:654-711) under the width-32 key: <L, comm rows> must equal <v, ck> + cb * h; returns the evaluation <v, R>
+    auto verify_direct = [&](const std::vector<aff_t>& comm, const fe_t* v, const fe_t& cb, const fe_t* point, size_t npoint, fe_t* eval) {
+      const size_t nn = (size_t)1 << npoint, drows = (nn + VW - 1) / VW, nvr = log2_ceil(drows);
+      aff_t comm_LZ;
+      if (nvr == 0) {
+        comm_LZ = comm[0];
+      } else {
+        const std::vector<fe_t> L = eq_evals(point, nvr);
+        if (comm.size() > L.size()) return false;
+        ck(sp_msm(ctx, u64p(L.data()), u64p(&comm[0].x), comm.size(), u64p(&comm_LZ.x)), "direct opening: <L, rows>");
+      }
+      aff_t expected;
+      ck(sp_hyrax_commit_small(ctx, pk.vc_ck, u64p(v), VW, u64p(&cb), u64p(&expected.x)), "direct opening: <v, ck> + cb h");
+      if (!fe_eq(comm_LZ.x, expected.x) || !fe_eq(comm_LZ.y, expected.y)) return false;
+      const std::vector<fe_t> R = eq_evals(point + nvr, npoint - nvr);
+      fe_t e = fe_zero();
+      for (size_t i = 0; i < VW; ++i) e = fe_add<S>(e, fe_mul<S>(v[i], R[i]));
+      *eval = e;
+      return true;
+    };
+    tr.absorb_scalars("u_relaxed", &fU_u, 1);
+    tr.absorb_scalars("X_relaxed", fU_X.data(), fU_X.size());
+    std::vector<fe_t> vtau(vlx);
+    for (auto& t : vtau) t = tr.squeeze("t");
+    fe_t claim_outer_final, claim_inner_final;
+    std::vector<fe_t> vrx, vry;
+    if (!sumcheck_verify(tr, fe_zero(), vlx, 3, v_outer, &claim_outer_final, &vrx)) return 4;
+    fe_t eq_tau = one;  // EqPolynomial::evaluate (src/polys/eq.rs:45-57)
+    for (size_t i = 0; i < vlx; ++i) eq_tau = fe_mul<S>(eq_tau, fe_add<S>(fe_mul<S>(vtau[i], vrx[i]), fe_mul<S>(fe_sub<S>(one, vtau[i]), fe_sub<S>(one, vrx[i]))));
+    if (!fe_eq(claim_outer_final, fe_mul<S>(eq_tau, fe_sub<S>(fe_mul<S>(v_claims[0], v_claims[1]), v_claims[2])))) return 4;
+    tr.absorb_scalars("claims_outer", v_claims, 3);
+    const fe_t vr = tr.squeeze("r"), vr2 = fe_mul<S>(vr, vr);
+    fe_t eval_E, eval_W;
+    if (!verify_direct(fU_E, v_E, blind_vE, vrx.data(), vlx, &eval_E)) return 4;
+    const fe_t claim_inner = fe_add<S>(fe_add<S>(v_claims[0], fe_mul<S>(vr, v_claims[1])), fe_mul<S>(vr2, fe_sub<S>(v_claims[2], eval_E)));
+    if (!sumcheck_verify(tr, claim_inner, vly, 2, v_inner, &claim_inner_final, &vry)) return 4;
+    if (!verify_direct(fU_W, v_W, blind_vW, vry.data() + 1, vly - 1, &eval_W)) return 4;
+    const std::vector<fe_t> Tx = eq_evals(vrx.data(), vlx), Ty = eq_evals(vry.data(), vly);
+    fe_t eval_Z = fe_add<S>(fe_mul<S>(fe_sub<S>(one, vry[0]), eval_W), fe_mul<S>(fU_u, Ty[vnv]));
+    for (size_t j = 0; j < vio; ++j) eval_Z = fe_add<S>(eval_Z, fe_mul<S>(fU_X[j], Ty[vnv + 1 + j]));
+    fe_t em[3];  // evaluate_with_tables on the verifier-circuit matrices (spartan_relaxed.rs:44-67)
+    for (int m = 0; m < 3; ++m) {
+      fe_t acc = fe_zero();
+      for (size_t row = 0; row < vcons; ++row) {
+        if (fe_is_zero(Tx[row])) continue;
+        fe_t rs = fe_zero();
+        for (uint64_t k = vs.M[m].ptr[row]; k < vs.M[m].ptr[row + 1]; ++k) rs = fe_add<S>(rs, fe_mul<S>(Ty[vs.M[m].idx[k]], vs.M[m].data[k]));
+        acc = fe_add<S>(acc, fe_mul<S>(Tx[row], rs));
+      }
+      em[m] = acc;
+    }
+    const fe_t eval_ABC = fe_add<S>(fe_add<S>(em[0], fe_mul<S>(vr, em[1])), fe_mul<S>(fe_mul<S>(vr2, fU_u), em[2]));
+    if (!fe_eq(claim_inner_final, fe_mul<S>(eval_ABC, eval_Z))) return 4;
+    tr.absorb_scalars("v_W", v_W, VW);
+    tr.absorb_scalars("v_E", v_E, VW);
+  }
+  // the six public values of the verifier circuit (:2280-2330): tau(r_x), the X evaluations, eq(r_b, rho) and the matrix evaluations at (r_x, r_y)
+  fe_t eabc[2][3];
+  {
+    if (!pk.v_Tx) {
+      ck(sp_table_zeros(ctx, (size_t)1 << nx, (size_t)-1, (size_t)-1, &pk.v_Tx), "T_x alloc");
+      ck(sp_table_zeros(ctx, (size_t)1 << ny, (size_t)-1, (size_t)-1, &pk.v_Ty), "T_y alloc");
+      for (int i = 0; i < 3; ++i) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &pk.v_mv[i]), "M T_y alloc");
+    }
+    sp_table *Tx = pk.v_Tx, *Ty = pk.v_Ty, **mv = pk.v_mv;
+    ck(sp_table_set_len(Tx, (size_t)1 << nx, (size_t)-1, (size_t)-1), "T_x len");
+    ck(sp_table_set_len(Ty, (size_t)1 << ny, (size_t)-1, (size_t)-1), "T_y len");
+    ck(sp_eq_table_into(ctx, u64p(r_x), nx, Tx), "T_x");
+    ck(sp_eq_table_into(ctx, u64p(r_y), ny, Ty), "T_y");
+    const sp_shape* shapes[2] = {pk.S_step, pk.S_core};
+    const size_t cols[2] = {nv + 1 + dpub, nv + 1 + cpub};
+    for (int s2 = 0; s2 < 2; ++s2) {
+      ck(sp_table_set_len(Ty, cols[s2], (size_t)-1, (size_t)-1), "T_y as z");
+      ck(sp_multiply_vec(ctx, shapes[s2], Ty, mv[0], mv[1], mv[2]), "M T_y");
+      for (int i = 0; i < 3; ++i) ck(sp_table_dot(ctx, Tx, mv[i], N, u64p(&eabc[s2][i])), "T_x . (M T_y)");
+    }
+  }
+  {
+    auto eval_X = [&](const fe_t* Xv, size_t cnt) {
+      std::vector<fe_t> v{one};
+      v.insert(v.end(), Xv, Xv + cnt);
+      return sparse_poly_evaluate(ny - 1, v, r_y + 1);
+    };
+    const fe_t q_step = fe_add<S>(fe_add<S>(eabc[0][0], fe_mul<S>(r, eabc[0][1])), fe_mul<S>(r2, eabc[0][2]));
+    const fe_t q_core = fe_add<S>(fe_add<S>(eabc[1][0], fe_mul<S>(r, eabc[1][1])), fe_mul<S>(r2, eabc[1][2]));
+    fe_t tau_at_rx = one, p = tau;  // PowPolynomial::evaluate (src/polys/power.rs:33-50): tau^(2^i) pairs with the i-th variable from the end
+    for (size_t i = 0; i < nx; ++i) {
+      tau_at_rx = fe_mul<S>(tau_at_rx, fe_add<S>(one, fe_mul<S>(fe_sub<S>(p, one), r_x[nx - 1 - i])));
+      p = fe_mul<S>(p, p);
+    }
+    fe_t eq_rho = one;
+    for (size_t i = 0; i < nb; ++i) eq_rho = fe_mul<S>(eq_rho, fe_add<S>(fe_mul<S>(rhos[i], r_b[i]), fe_mul<S>(fe_sub<S>(one, rhos[i]), fe_sub<S>(one, r_b[i]))));
+    if (!fe_eq(pub[0], tau_at_rx) || !fe_eq(pub[1], eval_X(Xf.data(), dpub)) || !fe_eq(pub[2], eval_X(core.pub, cpub)) || !fe_eq(pub[3], eq_rho) || !fe_eq(pub[4], q_step) ||
+        !fe_eq(pub[5], q_core))
+      return 5;
+  }
+  // the folded opening (:2332-2343): HyraxPCS::verify (hyrax_pc.rs:480-531) + InnerProductArgumentLinear::verify (ipa.rs:173-221)
+  const fe_t c_eval = tr.squeeze("c_eval");
+  const size_t commit_round = nb + 1 + nx + 1 + ny + 1;
+  if (commit_round + 1 >= vs.num_rounds) throw Error(SP_ERR_INTERNAL, "nn_verify: verifier-circuit round layout");
+  std::vector<aff_t> comm(rows);
+  ck(sp_fold_commitments2(ctx, u64p(&folded_comm[0].x), u64p(&core_comm[0].x), rows, u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
+  aff_t comm_eval;
+  ck(sp_fold_commitments2(ctx, u64p(&vcomm[commit_round][0].x), u64p(&vcomm[commit_round + 1][0].x), 1, u64p(&c_eval), u64p(&comm_eval.x)), "fold eval commitments");
+  {
+    const std::vector<uint8_t> b = commitment_bytes(comm.data(), rows);
+    tr.absorb("poly_com", b.data(), b.size());
+  }
+  const fe_t* point = r_y + 1;
+  const size_t npoint = ny - 1, num_rows = (((size_t)1 << npoint) + CW - 1) / CW, nvr = log2_ceil(num_rows);
+  aff_t comm_LZ;
+  std::vector<fe_t> R;
+  if (nvr == 0) {
+    comm_LZ = comm[0];
+    R = eq_evals(point, npoint);
+  } else {
+    const std::vector<fe_t> L = eq_evals(point, nvr);
+    R = eq_evals(point + nvr, npoint - nvr);
+    if (rows < L.size()) return 6;
+    ck(sp_msm(ctx, u64p(L.data()), u64p(&comm[0].x), L.size(), u64p(&comm_LZ.x)), "comm_LZ");
+  }
+  if (R.size() != CW) return 6;
+  tr.dom_sep("inner product argument (linear)");
+  {
+    uint8_t b[128];
+    point_bytes(comm_LZ, b);
+    point_bytes(comm_eval, b + 64);
+    tr.absorb("U", b, 128);
+    point_bytes(delta, b);
+    tr.absorb("delta", b, 64);
+    point_bytes(beta, b);
+    tr.absorb("beta", b, 64);
+  }
+  const fe_t rr = tr.squeeze("r");
+  aff_t pr2[2] = {comm_LZ, comm_eval}, rp[2], hzd, rhs2;
+  ck(sp_vartime_scalar_mul(ctx, u64p(&pr2[0].x), 2, u64p(&rr), u64p(&rp[0].x)), "r * (comm_LZ, comm_eval)");
+  ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(&z_delta), 1, u64p(&hzd.x)), "h * z_delta");
+  fe_t ip = fe_zero();
+  for (size_t i = 0; i < CW; ++i) ip = fe_add<S>(ip, fe_mul<S>(z_vec[i], R[i]));
+  ck(sp_hyrax_commit_small(ctx, pk.vc_ck, u64p(&ip), 1, u64p(&z_beta), u64p(&rhs2.x)), "<z, R> * ck_c + z_beta * h_c");
+  aff_t zc;
+  {
+    sp_msm_job* j = zjob.job;
+    zjob.job = nullptr;
+    ck(sp_msm_ck_finish(ctx, pk.ck, j, nullptr, u64p(&zc.x)), "<z, ck> (finish)");
+  }
+  if (!same_point(jac_add_mixed(jac_from_affine(rp[0]), delta), jac_add_mixed(jac_from_affine(zc), hzd))) return 6;
+  if (!same_point(jac_add_mixed(jac_from_affine(rp[1]), beta), jac_from_affine(rhs2))) return 6;
+  return 0;
+}
+
 }  // namespace spartan2
 
 using namespace spartan2;
@@ -728,19 +1067,7 @@ void nnz_pk_info(void* pk_, uint64_t out[8], uint8_t digest[32]) {
   memcpy(out, v, sizeof v);
   memcpy(digest, pk->vk_digest, 32);
 }
-size_t nnz_proof_words(void* pk_) {
-  auto* pk = (NNZkKey*)pk_;
-  const sp_dims& d = pk->dims;
-  const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0,
-               rows_rest = d.num_rest / CW;
-  const vcirc::Shape& vs = pk->vc;
-  const size_t vlx = log2_ceil(vs.num_cons), vly = log2_ceil(next_pow2(vs.total_vars)) + 1;
-  size_t w = 8 * rows_sh + (pk->num_steps + 1) * (8 * (rows_pre + rows_rest) + 4 * d.num_public) + 16 + 4 * CW + 8;
-  w += 8 * (vs.total_vars / 32) + 4 * vs.num_public + 4 * vs.total_challenges;
-  w += 8 * (vs.num_cons / 32) + 8 * (vs.total_vars / 32) + 8 * (vs.num_cons / 32) + 4 + 4 * vs.num_io();
-  w += 12 * vlx + 12 + 8 * vly + 4 * 32 + 4 + 4 * 32 + 4;
-  return w;
-}
+size_t nnz_proof_words(void* pk_) { return proof_words(*(NNZkKey*)pk_); }
 int nnz_prep_prove(void* pk, size_t n, const uint64_t* step_wit, size_t wit_len, const uint64_t* step_pub, size_t npub, const uint64_t* core_wit, const uint64_t* core_pub,
                    int is_small, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, void** out_ps) {
   try {
@@ -753,6 +1080,14 @@ int nnz_prep_prove(void* pk, size_t n, const uint64_t* step_wit, size_t wit_len,
   }
 }
 void nnz_prep_free(void* ps) { delete (NNZkPrep*)ps; }
+// 0 = accept, 1..6 = the failed check (nn_verify above), < 0 = error
+int nnz_verify(void* pk, const uint64_t* words, size_t nwords) {
+  try {
+    return nn_verify(*(NNZkKey*)pk, words, nwords);
+  } catch (...) {
+    return catch_all_nn();
+  }
+}
 // phase_ms[8]: instances, nifs, outer, inner, verifier-circuit instance, opening, total, (of which) per-round vc commitments
 int nnz_prove(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words, size_t out_cap, double* phase_ms) {
   try {

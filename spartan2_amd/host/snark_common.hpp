@@ -177,6 +177,47 @@ inline fe_t sparse_poly_evaluate(size_t num_vars, const std::vector<fe_t>& Z, co
   return fe_mul<S>(common, partial);
 }
 
+// ---- verifier-side pieces shared by SpartanSNARK::verify and NeutronNovaZkSNARK::verify ------------------------------------------------------
+inline bool same_point(const jac_t& a, const jac_t& b) {
+  const aff_t x = jac_to_affine(a), y = jac_to_affine(b);
+  return fe_eq(x.x, y.x) && fe_eq(x.y, y.y);
+}
+// SumcheckProof::verify (src/sumcheck.rs:67-114) on compressed polynomials of `deg` + 1 coefficients minus the linear one
+inline bool sumcheck_verify(Tr& tr, const fe_t& claim, size_t rounds, size_t deg, const fe_t* cpolys, fe_t* e_out, std::vector<fe_t>* r_out) {
+  fe_t e = claim;
+  r_out->clear();
+  for (size_t i = 0; i < rounds; ++i) {
+    const fe_t* c = cpolys + i * deg;  // c[0] = constant, c[1..] = degree 2.. coefficients
+    fe_t lin = fe_sub<S>(fe_sub<S>(e, c[0]), c[0]);  // CompressedUniPoly::decompress (univariate.rs:166-179)
+    for (size_t k = 1; k < deg; ++k) lin = fe_sub<S>(lin, c[k]);
+    std::vector<uint8_t> b(32 * deg);
+    for (size_t k = 0; k < deg; ++k) sp::fe_to_le_bytes<S>(c[k], b.data() + 32 * k);
+    tr.absorb("p", b.data(), b.size());
+    const fe_t r = tr.squeeze("c");
+    r_out->push_back(r);
+    fe_t eval = c[0], power = r;  // UniPoly::evaluate on (c0, lin, c[1], ...)
+    eval = fe_add<S>(eval, fe_mul<S>(power, lin));
+    for (size_t k = 1; k < deg; ++k) {
+      power = fe_mul<S>(power, r);
+      eval = fe_add<S>(eval, fe_mul<S>(power, c[k]));
+    }
+    e = eval;
+  }
+  *e_out = e;
+  return true;
+}
+
+// every scalar / coordinate of an untrusted proof must be a canonical residue: the reference's deserialisation rejects anything >= the modulus,
+// and x and x + p would otherwise be two encodings of one proof (same transcript bytes, same group elements)
+template <class F>
+inline bool limbs_canonical(const fe_t& v) {
+  for (int i = 7; i >= 0; --i) {
+    if (v.v[i] < F::P(i)) return true;
+    if (v.v[i] > F::P(i)) return false;
+  }
+  return false;  // == p
+}
+
 
 struct SpartanProofBuf {  // SpartanSNARK (src/spartan.rs:130-138) in the canonical flat layout of DESIGN.md
   std::vector<uint64_t> words;

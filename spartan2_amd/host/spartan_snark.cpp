@@ -635,46 +635,6 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
 // products with T_x = eq(r_x); comm_LZ = <L, comm rows> (hyrax_pc.rs:480-531) and the IPA check's <z_vec, ck> (ipa.rs:173-221) as device MSMs.
 // The O(log N) parts (transcript, round-polynomial checks, single scalar multiplications) stay on the host. Returns 0 = accept, else the index
 // of the failed check (1 shape, 2 outer sum-check, 3 outer claim, 4 inner sum-check, 5 inner claim, 6 opening) — the oracle's codes.
-static bool same_point(const jac_t& a, const jac_t& b) {
-  const aff_t x = jac_to_affine(a), y = jac_to_affine(b);
-  return fe_eq(x.x, y.x) && fe_eq(x.y, y.y);
-}
-// SumcheckProof::verify (src/sumcheck.rs:67-114) on compressed polynomials of `deg` + 1 coefficients minus the linear one
-static bool sumcheck_verify(Tr& tr, const fe_t& claim, size_t rounds, size_t deg, const fe_t* cpolys, fe_t* e_out, std::vector<fe_t>* r_out) {
-  fe_t e = claim;
-  r_out->clear();
-  for (size_t i = 0; i < rounds; ++i) {
-    const fe_t* c = cpolys + i * deg;  // c[0] = constant, c[1..] = degree 2.. coefficients
-    fe_t lin = fe_sub<S>(fe_sub<S>(e, c[0]), c[0]);  // CompressedUniPoly::decompress (univariate.rs:166-179)
-    for (size_t k = 1; k < deg; ++k) lin = fe_sub<S>(lin, c[k]);
-    std::vector<uint8_t> b(32 * deg);
-    for (size_t k = 0; k < deg; ++k) sp::fe_to_le_bytes<S>(c[k], b.data() + 32 * k);
-    tr.absorb("p", b.data(), b.size());
-    const fe_t r = tr.squeeze("c");
-    r_out->push_back(r);
-    fe_t eval = c[0], power = r;  // UniPoly::evaluate on (c0, lin, c[1], ...)
-    eval = fe_add<S>(eval, fe_mul<S>(power, lin));
-    for (size_t k = 1; k < deg; ++k) {
-      power = fe_mul<S>(power, r);
-      eval = fe_add<S>(eval, fe_mul<S>(power, c[k]));
-    }
-    e = eval;
-  }
-  *e_out = e;
-  return true;
-}
-
-// every scalar / coordinate of an untrusted proof must be a canonical residue: the reference's deserialisation rejects anything >= the modulus,
-// and x and x + p would otherwise be two encodings of one proof (same transcript bytes, same group elements)
-template <class F>
-static bool limbs_canonical(const fe_t& v) {
-  for (int i = 7; i >= 0; --i) {
-    if (v.v[i] < F::P(i)) return true;
-    if (v.v[i] > F::P(i)) return false;
-  }
-  return false;  // == p
-}
-
 int verify(const SpartanProverKey& pk, const uint64_t* words, size_t nwords, uint64_t* out_publics) {
   sp_ctx* ctx = pk.ctx;
   const sp_dims& d = pk.dims;

@@ -1,4 +1,4 @@
-"""GPU parity for SURVEY 8(f) rank 1: NeutronNovaZkSNARK::{setup, prep_prove, prove} on the device-backed driver (spartan2_amd/host/neutronnova_zk.cpp:
+"""GPU parity for SURVEY 8(f) rank 1: NeutronNovaZkSNARK::{setup, prep_prove, prove, verify} on the device-backed driver (spartan2_amd/host/neutronnova_zk.cpp:
 verifier circuit + process_round commitments, NeutronNovaNIFS, batched outer / inner sum-checks, NovaNIFS with a random relaxed instance,
 RelaxedR1CSSpartanProof, folded Hyrax opening) against the oracle's restatement (oracle/neutronnova_zk.hpp): identical vk digest, identical proof words
 on the same circuits and randomness tape, and the oracle's NeutronNovaZkSNARK::verify accepts the device's proof. BASELINE config 3 at its own size:
@@ -37,13 +37,46 @@ def test_prove_matches_oracle_synthetic_steps(ctx, n, groups):
     core = frontend.synthetic_circuit(groups, 0xA5, num_public=1, witness_seed=999)
     onn, gnn, want, got, tape, used, _ = _both(ctx, steps, core, 60 + n)
     assert (got == want).all()
-    assert onn.verify_words(got) == 0
+    assert onn.verify_words(got) == 0 and gnn.verify(got) == 0
     # the prep state is rerandomized in place by every prove: a second prove is a different, equally valid proof
     got2, _, _ = gnn.prove(tape[used[0] + used[1]:])
-    assert not (got2 == got).all() and onn.verify_words(got2) == 0
+    assert not (got2 == got).all() and onn.verify_words(got2) == 0 and gnn.verify(got2) == 0
     bad = got.copy()
     bad[len(bad) // 2] ^= np.uint64(1 << 9)
-    assert onn.verify_words(bad) != 0
+    assert onn.verify_words(bad) != 0 and gnn.verify(bad) != 0
+    gnn.close()
+
+
+@pytest.mark.parametrize("n,groups", [(2, 8), (5, 30)])
+def test_verify_rejects_what_the_oracle_rejects(ctx, n, groups):
+    """NeutronNovaZkSNARK::verify on the device-backed driver (src/neutronnova_zk.rs:2096-2343): accepts the oracle's proof and its own; a low bit
+    flipped at positions spread over every section of the proof (instances, opening argument, per-round commitments, public values, challenges, NIFS
+    commitment, random instance, both relaxed sum-checks, direct openings) is rejected with the SAME check index the oracle's verifier reports; a
+    truncated proof and a non-canonical scalar are rejected as malformed."""
+    steps = [frontend.synthetic_circuit(groups, 0x3C, num_public=1, witness_seed=150 + i) for i in range(n)]
+    core = frontend.synthetic_circuit(groups, 0x3C, num_public=1, witness_seed=1999)
+    onn, gnn, want, got, _, _, _ = _both(ctx, steps, core, 160 + n)
+    assert (got == want).all() and gnn.verify(want) == 0
+    rng = np.random.default_rng(7 + n)
+    # scalars only: a flipped coordinate bit leaves the curve (the oracle's loader does not check that; the device driver answers 1)
+    positions = sorted(set(int(x) for x in rng.integers(0, len(got), size=60)) | {0, 5, len(got) - 1, len(got) - 5, len(got) // 2})
+    agree, seen = 0, {}
+    for pos in positions:
+        bad = got.copy()
+        bad[pos] ^= np.uint64(1)
+        want_rc, got_rc = onn.verify_words(bad), gnn.verify(bad)
+        assert got_rc != 0, pos
+        assert want_rc != 0, pos
+        if got_rc != 1:  # 1 = the stricter encoding checks (off-curve point, non-canonical limb) fire before the oracle's first check would
+            assert got_rc == want_rc, (pos, got_rc, want_rc)
+            agree += 1
+        seen[got_rc] = seen.get(got_rc, 0) + 1
+    print("verify: failed-check histogram over", len(positions), "tampered proofs:", dict(sorted(seen.items())))
+    assert agree >= 10 and {2, 4, 6} <= set(seen)
+    assert gnn.verify(got[:-4]) == 1
+    bad = got.copy()
+    bad[-4:] = np.uint64(0xFFFFFFFFFFFFFFFF)  # blind_E >= the modulus
+    assert gnn.verify(bad) == 1
     gnn.close()
 
 
@@ -53,7 +86,7 @@ def test_shared_and_precommitted_segments(ctx):
     steps = [mk(5), mk(5), mk(5)]
     core = mk(5)
     onn, gnn, want, got, _, _, _ = _both(ctx, steps, core, 71)
-    assert (got == want).all() and onn.verify_words(got) == 0
+    assert (got == want).all() and onn.verify_words(got) == 0 and gnn.verify(got) == 0
     gnn.close()
 
 
@@ -64,6 +97,6 @@ def test_c3_sha256_neutronnova_32_steps(ctx):
     onn, gnn, want, got, _, _, phases = _both(ctx, steps, core, 3232)
     assert gnn.info["nb"] == 5 and gnn.info["nx"] == 15 and gnn.info["ny"] == 16
     assert (got == want).all()
-    assert onn.verify_words(got) == 0
+    assert onn.verify_words(got) == 0 and gnn.verify(got) == 0
     print("C3 prove phases (ms):", {k: round(v, 3) for k, v in phases.items()})
     gnn.close()
