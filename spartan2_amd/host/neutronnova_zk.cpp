@@ -727,6 +727,18 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io(), vlx = log2_ceil(vcons), vnvp = next_pow2(vnv), vly = log2_ceil(vnvp) + 1, VW = vs.width;
   if (n == 0 || nwords != proof_words(pk)) return 1;
   ck(sp_ctx_bind_thread(ctx), "device");
+  static const bool laps = [] {
+    const char* e = getenv("SPARTAN_HOST_LAPS");
+    return e && e[0] == '1';
+  }();
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_lap = now();
+  auto lap = [&](const char* what) {
+    if (!laps) return;
+    const double t = now();
+    fprintf(stderr, "nn_verify lap %-28s %8.3f ms\n", what, t - t_lap);
+    t_lap = t;
+  };
   // ---- the proof in its canonical layout; every coordinate and scalar of an untrusted proof must be a canonical residue and every point on the curve
   const fe_t* w = reinterpret_cast<const fe_t*>(words);
   size_t o = 0;
@@ -783,6 +795,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   if (4 * o != nwords) throw Error(SP_ERR_INTERNAL, "nn_verify: layout / proof_words disagree");
   if (!well_formed) return 1;
 
+  lap("parse + encoding checks");
   // <z_vec, ck> (ipa.rs:196-203) depends on nothing but the proof: its device part runs under everything that follows
   struct ZJob {
     sp_ctx* ctx;
@@ -823,6 +836,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   const fe_t tau = tr.squeeze("tau");
   std::vector<fe_t> rhos(nb);
   for (auto& x : rhos) x = tr.squeeze("rho");
+  lap("instances absorbed");
   // U_verifier.validate (src/r1cs/mod.rs:1808-1834): the per-round commitments reproduce the challenges the instance carries
   for (size_t round = 0; round < vs.num_rounds; ++round) {
     const std::vector<uint8_t> b = commitment_bytes(vcomm[round], vs.vars_padded[round] / VW);
@@ -839,6 +853,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   if (vs.total_challenges != num_chal || vs.num_public != 6) return 2;
   const fe_t *r_b = Uv_X.data(), *r_x = r_b + nb, *r_y = r_x + nx + 1, *pub = Uv_X.data() + num_chal;
   const fe_t r = Uv_X[nb + nx], r2 = fe_mul<S>(r, r), one = fe_one<S>();
+  lap("vc instance replayed");
   // fold_multiple of the step instances (src/r1cs/mod.rs:695-722): X on the host, the commitment rows as shared-weights MSMs
   std::vector<fe_t> wts(np);
   ck(sp_weights_from_r(u64p(r_b), nb, np, u64p(wts.data())), "weights_from_r");
@@ -852,6 +867,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
       for (size_t i = 0; i < np; ++i) bases[rr * np + i] = Ucomm[inst(i)][rr];
     ck(sp_msm_shared_weights(ctx, u64p(wts.data()), np, reinterpret_cast<const uint64_t*>(bases.data()), rows, reinterpret_cast<uint64_t*>(folded_comm.data())), "fold_commitments");
   }
+  lap("fold_multiple");
   // NovaNIFS::verify (src/nifs.rs:65-77): the random relaxed instance folded with the verifier-circuit instance
   {
     std::vector<uint8_t> b = commitment_bytes(rnd_comm_W, vnv / VW), e = commitment_bytes(rnd_comm_E, vcons / VW);
@@ -874,6 +890,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   const fe_t fU_u = fe_add<S>(rnd_u, rf);
   std::vector<fe_t> fU_X(vio);
   for (size_t i = 0; i < vio; ++i) fU_X[i] = fe_add<S>(rnd_X[i], fe_mul<S>(rf, Uv_X[i]));
+  lap("NovaNIFS::verify");
   // RelaxedR1CSSpartanProof::verify (src/spartan_relaxed.rs:216-316)
   {
     // verify_direct (hyrax_pc.rs:654-711) under the width-32 key: <L, comm rows> must equal <v, ck> + cb * h; returns the evaluation <v, R>
@@ -932,6 +949,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
     tr.absorb_scalars("v_W", v_W, VW);
     tr.absorb_scalars("v_E", v_E, VW);
   }
+  lap("relaxed Spartan verify");
   // the six public values of the verifier circuit (:2280-2330): tau(r_x), the X evaluations, eq(r_b, rho) and the matrix evaluations at (r_x, r_y)
   fe_t eabc[2][3];
   {
@@ -972,6 +990,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
         !fe_eq(pub[5], q_core))
       return 5;
   }
+  lap("matrix evaluations + publics");
   // the folded opening (:2332-2343): HyraxPCS::verify (hyrax_pc.rs:480-531) + InnerProductArgumentLinear::verify (ipa.rs:173-221)
   const fe_t c_eval = tr.squeeze("c_eval");
   const size_t commit_round = nb + 1 + nx + 1 + ny + 1;
@@ -1024,6 +1043,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   }
   if (!same_point(jac_add_mixed(jac_from_affine(rp[0]), delta), jac_add_mixed(jac_from_affine(zc), hzd))) return 6;
   if (!same_point(jac_add_mixed(jac_from_affine(rp[1]), beta), jac_from_affine(rhs2))) return 6;
+  lap("folded opening");
   return 0;
 }
 
