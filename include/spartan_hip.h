@@ -51,6 +51,9 @@ int sp_ctx_create(int device, sp_ctx** out);
 /* Makes the context's device current for the CALLING thread (HIP keeps a current device per thread; a new thread starts on device 0). The thread that
  * created the context needs no call; a helper thread (see sp_points_upload) calls this once before its first call on the context. */
 int sp_ctx_bind_thread(sp_ctx* ctx);
+/* the HIP ordinal the context was created on (a host driver that wants a second context on the same GPU for work it runs beside its main
+ * stream of calls — e.g. transcript-independent commitments under a sum-check — creates it with this) */
+int sp_ctx_device(const sp_ctx* ctx);
 void sp_ctx_destroy(sp_ctx* ctx);
 int sp_ctx_synchronize(sp_ctx* ctx);
 /* time of the most recent instrumented kernel class, measured with hipEvents on the context's stream

@@ -144,6 +144,7 @@ int sp_ctx_bind_thread(sp_ctx* c) {
   SP_HIP(hipSetDevice(c->device));
   return SP_OK;
 }
+int sp_ctx_device(const sp_ctx* c) { return c ? c->device : -1; }
 void sp_ctx_destroy(sp_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);

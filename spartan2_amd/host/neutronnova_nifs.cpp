@@ -180,9 +180,18 @@ void nifs_prove(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, const s
   std::vector<aff_t> bases(data_rows * n_padded);
   for (size_t r = 0; r < data_rows; ++r)
     for (size_t i = 0; i < n_padded; ++i) bases[r * n_padded + i] = comms[inst(i) * rows + r];
-  if (data_rows) ck(sp_msm_shared_weights(ctx, u64p(w.data()), n_padded, (const uint64_t*)bases.data(), data_rows, out.folded_comm), "fold_commitments");
-  if (data_rows < rows)  // rest rows: folded_blind[row] * h
-    ck(sp_fixed_base_mul_h(ctx, ckey, u64p(f_rW.data() + data_rows), rows - data_rows, out.folded_comm + 8 * data_rows), "rest rows");
+  auto fold = [w = std::move(w), bases = std::move(bases), rest = std::vector<fe_t>(f_rW.begin() + data_rows, f_rW.end()), n_padded, data_rows, rows, ckey,
+               dst = out.folded_comm](sp_ctx* on) {
+    if (data_rows) ck(sp_msm_shared_weights(on, u64p(w.data()), n_padded, (const uint64_t*)bases.data(), data_rows, dst), "fold_commitments");
+    if (data_rows < rows)  // rest rows: folded_blind[row] * h
+      ck(sp_fixed_base_mul_h(on, ckey, u64p(rest.data()), rows - data_rows, dst + 8 * data_rows), "rest rows");
+  };
+  if (out.deferred_fold_commitments) {
+    *out.deferred_fold_commitments = std::move(fold);
+    lap("fold_commitments (deferred)");
+    return;
+  }
+  fold(ctx);
   lap("fold_commitments");
 }
 

@@ -1,5 +1,7 @@
 // NeutronNovaNIFS::prove above the C ABI (neutronnova_nifs.cpp), shared with the ZK wrapper's driver (neutronnova_zk.cpp).
 #pragma once
+#include <functional>
+
 #include "host_common.hpp"
 
 namespace spartan2 {
@@ -10,6 +12,10 @@ void compute_tensor_decomp(size_t n, size_t* ell, size_t* left, size_t* right); 
 struct NifsOutputs {
   uint64_t *polys, *r_bs, *E_eq, *tail, *folded_rW, *folded_X, *folded_comm;
   sp_table *A, *B, *C, *folded_W;
+  // when set, nifs_prove does not fold the commitments itself: it leaves the fold here as a job that owns its inputs and writes folded_comm when run
+  // with a context of the caller's choice — the folded commitment is not read by the transcript before the opening (src/neutronnova_zk.rs:2019-2065),
+  // so the ZK driver runs it on a second context beside its sum-checks
+  std::function<void(sp_ctx*)>* deferred_fold_commitments = nullptr;
 };
 // layers (and i64 mirrors) of the instances: the transcript-independent part the reference caches in prep_prove (:1520-1600)
 sp_nifs* nifs_prepare(sp_ctx* ctx, const sp_shape* shape, const sp_dims& dims, size_t n, const fe_t* X, const sp_table* const* Ws, bool small_values);

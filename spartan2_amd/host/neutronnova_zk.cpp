@@ -52,7 +52,29 @@ struct NNZkPrep {
   // otherwise pay eight hipMalloc / hipFree pairs per prove)
   sp_table* vws[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t vws_cap[5] = {0, 0, 0, 0, 0};
+  // Two pieces of prove() read nothing the transcript produces before they are needed: the random relaxed instance of the verifier circuit with its
+  // two commitments (values from the randomness tape only, src/r1cs/mod.rs:474-531) and the fold of the step instances' commitments (read first by the
+  // opening, :2019-2065). They run as jobs of one helper thread on a SECOND context of the same GPU (own streams and workspaces), under the NIFS rounds
+  // and the two batched sum-checks, instead of 0.8 ms each on the critical path. SPARTAN_NN_SIDE=0 keeps them inline.
+  // the sixteen working tables of a prove (layers out of the NIFS, core products, pow / eq tables, both poly_ABC and z pairs, the folded witnesses):
+  // their sizes are the key's, so they are allocated once (a prove used to pay sixteen hipMalloc / hipFree pairs, the frees after its last phase)
+  sp_table* work[16] = {};
+  size_t work_cap[16] = {};
+  sp_ctx* ctx2 = nullptr;
+  Background bg;
+  sp_table* bws[2] = {nullptr, nullptr};
+  size_t bws_cap[2] = {0, 0};
+  struct RandomInstance {
+    std::vector<fe_t> Z, rW, rE, E;
+    std::vector<aff_t> comm_W, comm_E;
+    size_t tape_from = 0, tape_count = 0;
+    bool valid = false;
+  } rnd;
   ~NNZkPrep() {
+    bg.wait_nothrow();
+    for (sp_table* t : bws) sp_table_free(t);
+    for (sp_table* t : work) sp_table_free(t);
+    sp_ctx_destroy(ctx2);
     for (auto& s : steps) sp_table_free(s.W);
     sp_table_free(core.W);
     sp_nifs_free(nifs_cached);
@@ -218,6 +240,32 @@ static sp_table* stage(sp_ctx* ctx, NNZkPrep& ps, int i, const fe_t* data, size_
   ck(sp_table_write(ctx, ps.vws[i], 0, u64p(data), n), "upload");
   return ps.vws[i];
 }
+// working table `i` of the prep state with `len` elements (grow-only; contents are whatever the last prove left: every user writes what it reads)
+static sp_table* work_table(sp_ctx* ctx, NNZkPrep& ps, int i, size_t len) {
+  if (len > ps.work_cap[i]) {
+    sp_table_free(ps.work[i]);
+    ps.work[i] = nullptr;
+    ps.work_cap[i] = len;
+  }
+  if (!ps.work[i]) ck(sp_table_zeros(ctx, ps.work_cap[i], (size_t)-1, (size_t)-1, &ps.work[i]), "working table");
+  ck(sp_table_set_len(ps.work[i], len, (size_t)-1, (size_t)-1), "working table len");
+  return ps.work[i];
+}
+// the same for the helper thread's jobs: tables of their own, on the second context
+static std::vector<aff_t> commit_rows32_side(NNZkPrep& ps, int slot, const sp_ck* vc_ck, const std::vector<fe_t>& v, const std::vector<fe_t>& blinds) {
+  sp_ctx* ctx = ps.ctx2;
+  if (v.size() > ps.bws_cap[slot]) {
+    sp_table_free(ps.bws[slot]);
+    ps.bws[slot] = nullptr;
+    ps.bws_cap[slot] = v.size() < 4096 ? 4096 : 2 * v.size();
+  }
+  if (!ps.bws[slot]) ck(sp_table_zeros(ctx, ps.bws_cap[slot], (size_t)-1, (size_t)-1, &ps.bws[slot]), "scratch table");
+  ck(sp_table_set_len(ps.bws[slot], v.size(), (size_t)-1, (size_t)-1), "scratch len");
+  ck(sp_table_write(ctx, ps.bws[slot], 0, u64p(v.data()), v.size()), "upload");
+  std::vector<aff_t> out(blinds.size());
+  ck(sp_hyrax_commit(ctx, vc_ck, ps.bws[slot], 0, v.size(), u64p(blinds.data()), 0, u64p(&out[0].x)), "commit (width 32)");
+  return out;
+}
 static std::vector<aff_t> commit_rows32(sp_ctx* ctx, NNZkPrep& ps, const sp_ck* vc_ck, const std::vector<fe_t>& v, const std::vector<fe_t>& blinds) {
   sp_table* t = stage(ctx, ps, 0, v.data(), v.size());
   std::vector<aff_t> out(blinds.size());
@@ -266,6 +314,50 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     t_lap = t;
   };
   ck(sp_ctx_bind_thread(ctx), "device");
+  static const bool side = [] {
+    const char* e = getenv("SPARTAN_NN_SIDE");
+    return !(e && e[0] == '0');
+  }();
+  struct SideGuard {  // no exit path leaves a job running on state this call owns
+    NNZkPrep& ps;
+    ~SideGuard() { ps.bg.wait_nothrow(); }
+  } side_guard{ps};
+  ps.rnd.valid = false;
+  if (side) {
+    if (!ps.ctx2) ck(sp_ctx_create(sp_ctx_device(ctx), &ps.ctx2), "second context");
+    // the random relaxed instance: its values sit at a position of the tape that only the shapes determine (the draws in front of it are the
+    // rerandomisation blinds, the rest-row blinds and one blind per committed row of the verifier circuit's rounds); checked again where it is used
+    size_t before = ps.comm_shared.size() + ps.core.comm_pre.size() + (n + 1) * rows_rest + pk.vc.total_vars / 32;
+    for (const auto& st : ps.steps) before += st.comm_pre.size();
+    Tape ahead = tape;
+    ahead.pos = tape.pos + before;
+    ps.bg.submit([&pk, &ps, ahead]() mutable {
+      const vcirc::Shape& vs = pk.vc;
+      const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io();
+      NNZkPrep::RandomInstance& R = ps.rnd;
+      try {
+        ck(sp_ctx_bind_thread(ps.ctx2), "device");
+        R.tape_from = ahead.pos;
+        R.Z.resize(vnv + vio + 1);
+        for (auto& z : R.Z) z = ahead.next();
+        R.rW.resize(vnv / 32);
+        R.rE.resize(vcons / 32);
+        for (auto& b : R.rW) b = ahead.next();
+        for (auto& b : R.rE) b = ahead.next();
+        R.tape_count = ahead.pos - R.tape_from;
+        std::vector<fe_t> mv[3];
+        vs.multiply_vec(R.Z, mv);
+        const fe_t u = R.Z[vnv];
+        R.E.resize(vcons);
+        for (size_t i = 0; i < vcons; ++i) R.E[i] = fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(u, mv[2][i]));
+        R.comm_W = commit_rows32_side(ps, 0, pk.vc_ck, std::vector<fe_t>(R.Z.begin(), R.Z.begin() + vnv), R.rW);
+        R.comm_E = commit_rows32_side(ps, 1, pk.vc_ck, R.E, R.rE);
+        R.valid = true;
+      } catch (...) {
+        R.valid = false;  // the prover computes it inline when it gets there (and reports what fails, if it fails again)
+      }
+    });
+  }
   // rerandomize (:1619-1627, hyrax_pc.rs:321-344): core (shared, precommitted), then every step's precommitted commitment. The new blinds are
   // drawn in the reference's order; the row updates are independent, so all of them go through ONE sp_hyrax_rerandomize call.
   {
@@ -363,35 +455,38 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const size_t nb = pk.nb;
   std::vector<uint64_t> polys(16 * std::max<size_t>(nb, 1)), r_bs(4 * std::max<size_t>(nb, 1)), E_eq(4 * (left + right)), tail(8), f_rW(4 * rows), f_X(4 * std::max<size_t>(dpub, 1));
   std::vector<aff_t> f_comm(rows);
-  sp_table *A = nullptr, *B = nullptr, *C = nullptr, *fW = nullptr, *core_abc[3] = {nullptr, nullptr, nullptr}, *zc = nullptr, *pl = nullptr, *pr = nullptr, *rx = nullptr;
-  sp_table *abc_s = nullptr, *abc_c = nullptr, *zs = nullptr, *zcc = nullptr, *Wf = nullptr;
-  struct Free {
-    std::vector<sp_table**> t;
-    ~Free() {
-      for (sp_table** p : t) sp_table_free(*p);
-    }
-  } freer{{&A, &B, &C, &fW, &core_abc[0], &core_abc[1], &core_abc[2], &zc, &pl, &pr, &rx, &abc_s, &abc_c, &zs, &zcc, &Wf}};
-  for (sp_table** t : {&A, &B, &C}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc");
-  ck(sp_table_zeros(ctx, nv, (size_t)-1, (size_t)-1, &fW), "alloc");
+  sp_table *A = work_table(ctx, ps, 0, N), *B = work_table(ctx, ps, 1, N), *C = work_table(ctx, ps, 2, N), *fW = work_table(ctx, ps, 3, nv);
+  sp_table *core_abc[3] = {work_table(ctx, ps, 4, N), work_table(ctx, ps, 5, N), work_table(ctx, ps, 6, N)}, *zc = work_table(ctx, ps, 7, nv + 1 + dpub);
+  sp_table *pl = work_table(ctx, ps, 8, left), *pr = work_table(ctx, ps, 9, right), *rx = work_table(ctx, ps, 10, N);
+  sp_table *abc_s = work_table(ctx, ps, 11, 2 * nv), *abc_c = work_table(ctx, ps, 12, 2 * nv), *zs = work_table(ctx, ps, 13, 2 * nv), *zcc = work_table(ctx, ps, 14, 2 * nv);
+  sp_table* Wf = work_table(ctx, ps, 15, nv);
   NifsOutputs no{polys.data(), r_bs.data(), E_eq.data(), tail.data(), f_rW.data(), f_X.data(), (uint64_t*)f_comm.data(), A, B, C, fW};
+  std::function<void(sp_ctx*)> fold_job;
+  if (side) no.deferred_fold_commitments = &fold_job;
   nifs_prove(ctx, pk.S_step, d, pk.ck, n, rows, comms.data(), X.data(), Ws.data(), r_W.data(), true, ps.nifs_cached, tr.t, nifs_hook, &hc, no);
   if (hc.err) std::rethrow_exception(hc.err);
+  bool fold_pending = false;
+  if (fold_job) {  // (submit waits for the random-instance job first: one worker, jobs in order)
+    ps.bg.submit([&ps, job = std::move(fold_job)] {
+      ck(sp_ctx_bind_thread(ps.ctx2), "device");
+      job(ps.ctx2);
+    });
+    fold_pending = true;
+  }
   const double t_nifs = now();
 
   // core products, batched outer sum-check (:1786-1850)
   const fe_t one = fe_one<S>();
   {
-    ck(sp_table_zeros(ctx, nv + 1 + dpub, (size_t)-1, (size_t)-1, &zc), "alloc");
     ck(sp_table_copy(ctx, zc, 0, ps.core.W, 0, nv), "z <- W");
     std::vector<fe_t> tl(1 + dpub);
     tl[0] = one;
     std::copy(ps.core.publics.begin(), ps.core.publics.end(), tl.begin() + 1);
     ck(sp_table_write(ctx, zc, nv, u64p(tl.data()), tl.size()), "z tail");
-    for (int q = 0; q < 3; ++q) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &core_abc[q]), "alloc");
     ck(sp_multiply_vec(ctx, pk.S_core, zc, core_abc[0], core_abc[1], core_abc[2]), "multiply_vec (core)");
   }
-  ck(sp_table_from_host(ctx, E_eq.data(), left, (size_t)-1, (size_t)-1, &pl), "pow left");
-  ck(sp_table_from_host(ctx, E_eq.data() + 4 * left, right, (size_t)-1, (size_t)-1, &pr), "pow right");
+  ck(sp_table_write(ctx, pl, 0, E_eq.data(), left), "pow left");
+  ck(sp_table_write(ctx, pr, 0, E_eq.data() + 4 * left, right), "pow right");
   auto batched_hook = [](void* u, size_t round, const uint64_t* cs_, const uint64_t* cc_, size_t ncoeffs, uint64_t r_out[4]) -> int {
     HookCtx* h = (HookCtx*)u;
     try {
@@ -438,8 +533,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   fe_t claims[2] = {fe_add<S>(fe_add<S>(vc.claim_step[0], fe_mul<S>(r, vc.claim_step[1])), fe_mul<S>(r2, vc.claim_step[2])),
                     fe_add<S>(fe_add<S>(vc.claim_core[0], fe_mul<S>(r, vc.claim_core[1])), fe_mul<S>(r2, vc.claim_core[2]))};
   // evals_rx, both poly_ABC, the z tables, batched inner sum-check (:1852-1945)
-  ck(sp_eq_table(ctx, u64p(r_x.data()), pk.nx, &rx), "evals_rx");
-  for (sp_table** t : {&abc_s, &abc_c, &zs, &zcc}) ck(sp_table_zeros(ctx, 2 * nv, (size_t)-1, (size_t)-1, t), "alloc");
+  ck(sp_eq_table_into(ctx, u64p(r_x.data()), pk.nx, rx), "evals_rx");
   ck(sp_poly_abc(ctx, pk.S_step, rx, u64p(&r), 2 * nv, abc_s), "poly_ABC (step)");
   ck(sp_poly_abc(ctx, pk.S_core, rx, u64p(&r), 2 * nv, abc_c), "poly_ABC (core)");
   std::vector<fe_t> folded_X(dpub);
@@ -450,6 +544,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     tl[0] = one;
     std::copy(Xv.begin(), Xv.end(), tl.begin() + 1);
     ck(sp_table_write(ctx, z, nv, u64p(tl.data()), tl.size()), "z tail");
+    ck(sp_table_zero(ctx, z, nv + tl.size(), nv - tl.size()), "z: zero high half");  // a working table: the last prove's rounds were bound in place
   };
   fill_z(zs, fW, folded_X);
   fill_z(zcc, ps.core.W, ps.core.publics);
@@ -489,17 +584,34 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   lap("(up to the vc instance)");
   // sample_random_instance_witness (src/r1cs/mod.rs:474-531) on the verifier-circuit shape
   const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io();
-  std::vector<fe_t> Z(vnv + vio + 1);
-  for (auto& z : Z) z = tape.next();
-  std::vector<fe_t> rnd_rW(vnv / 32), rnd_rE(vcons / 32);
-  for (auto& b : rnd_rW) b = tape.next();
-  for (auto& b : rnd_rE) b = tape.next();
+  if (!fold_pending) ps.bg.wait();  // (with the fold in flight the random-instance job has finished: the worker takes jobs in order)
+  const bool ahead_ok = side && ps.rnd.valid && ps.rnd.tape_from == tape.pos;
+  std::vector<fe_t> Z, rnd_rW, rnd_rE, rnd_E, mv[3];
+  std::vector<aff_t> rnd_comm_W, rnd_comm_E;
+  if (ahead_ok) {
+    Z.swap(ps.rnd.Z);
+    rnd_rW.swap(ps.rnd.rW);
+    rnd_rE.swap(ps.rnd.rE);
+    rnd_E.swap(ps.rnd.E);
+    rnd_comm_W.swap(ps.rnd.comm_W);
+    rnd_comm_E.swap(ps.rnd.comm_E);
+    tape.skip(ps.rnd.tape_count);
+  } else {
+    if (laps && side) fprintf(stderr, "nn_prove: random instance computed inline (job valid %d, tape %zu vs %zu)\n", (int)ps.rnd.valid, ps.rnd.tape_from, tape.pos);
+    Z.resize(vnv + vio + 1);
+    for (auto& z : Z) z = tape.next();
+    rnd_rW.resize(vnv / 32);
+    rnd_rE.resize(vcons / 32);
+    for (auto& b : rnd_rW) b = tape.next();
+    for (auto& b : rnd_rE) b = tape.next();
+    vs.multiply_vec(Z, mv);
+    rnd_E.resize(vcons);
+    for (size_t i = 0; i < vcons; ++i) rnd_E[i] = fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(Z[vnv], mv[2][i]));
+    rnd_comm_W = commit_rows32(ctx, ps, pk.vc_ck, std::vector<fe_t>(Z.begin(), Z.begin() + vnv), rnd_rW);
+    rnd_comm_E = commit_rows32(ctx, ps, pk.vc_ck, rnd_E, rnd_rE);
+  }
   const fe_t rnd_u = Z[vnv];
-  std::vector<fe_t> mv[3];
-  vs.multiply_vec(Z, mv);
-  std::vector<fe_t> rnd_E(vcons), rnd_W(Z.begin(), Z.begin() + vnv), rnd_X(Z.begin() + vnv + 1, Z.end());
-  for (size_t i = 0; i < vcons; ++i) rnd_E[i] = fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(rnd_u, mv[2][i]));
-  const std::vector<aff_t> rnd_comm_W = commit_rows32(ctx, ps, pk.vc_ck, rnd_W, rnd_rW), rnd_comm_E = commit_rows32(ctx, ps, pk.vc_ck, rnd_E, rnd_rE);
+  const std::vector<fe_t> rnd_W(Z.begin(), Z.begin() + vnv), rnd_X(Z.begin() + vnv + 1, Z.end());
   lap("random instance + 2 commits");
   // NovaNIFS::prove (src/nifs.rs:34-61)
   {
@@ -599,6 +711,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const std::vector<aff_t>& comm_eW_c = vst.comm_per_round[inner_final + 2];
   const fe_t c_eval = tr.squeeze("c_eval");
   std::vector<aff_t> comm(rows);
+  if (fold_pending) ps.bg.wait();  // the folded commitment of the step instances: the helper's second job, started behind the NIFS rounds
   ck(sp_fold_commitments2(ctx, u64p(&f_comm[0].x), u64p(&core_comm[0].x), rows, u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
   std::vector<fe_t> blind(rows);
   for (size_t i = 0; i < rows; ++i) {
@@ -606,7 +719,6 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     memcpy(&a, f_rW.data() + 4 * i, 32);
     blind[i] = fe_add<S>(a, fe_mul<S>(c_eval, core_rW[i]));
   }
-  ck(sp_table_zeros(ctx, nv, (size_t)-1, (size_t)-1, &Wf), "alloc");
   {
     const sp_table* two[2] = {fW, ps.core.W};
     const fe_t wts[2] = {one, c_eval};
