@@ -7,11 +7,85 @@
 // two sum-checks (sp_sumcheck_cubic3 / sp_sumcheck_quad).
 // Scope = the bench circuits' class: step and core circuits without rest variables and without verifier challenges (`can_cache_matvec`, :1520).
 // The proof layout is the oracle's NNProof::serialize (oracle/neutronnova_zk.hpp); parity = word-for-word equality on the same inputs and tape.
+#include <deque>
+
 #include "neutronnova_nifs.hpp"
 #include "snark_common.hpp"
 #include "verifier_circuit.hpp"
 
 namespace spartan2 {
+
+// One helper thread taking jobs in order (FIFO). submit() never blocks; a job's failure is kept for the next wait() and does not stop the jobs behind it.
+class Worker {
+  std::thread th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::deque<std::function<void()>> q_;
+  bool stop_ = false;
+  size_t submitted_ = 0;  // written by the submitting thread only
+  std::atomic<size_t> done_{0};
+  std::exception_ptr err_;
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return stop_ || !q_.empty(); });
+        if (q_.empty()) return;
+        f = std::move(q_.front());
+        q_.pop_front();
+      }
+      try {
+        f();
+      } catch (...) {
+        std::lock_guard<std::mutex> l(m_);
+        if (!err_) err_ = std::current_exception();
+      }
+      done_.fetch_add(1, std::memory_order_release);
+    }
+  }
+
+ public:
+  Worker() = default;
+  Worker(const Worker&) = delete;
+  Worker& operator=(const Worker&) = delete;
+  ~Worker() {
+    if (!th_.joinable()) return;
+    drain();
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_one();
+    th_.join();
+  }
+  size_t submit(std::function<void()> f) {  // returns the ticket to wait for
+    size_t t;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      q_.push_back(std::move(f));
+      t = ++submitted_;
+    }
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    cv_.notify_one();
+    return t;
+  }
+  void drain() {  // every job submitted so far has run; drops what they threw (exit paths)
+    while (done_.load(std::memory_order_acquire) < submitted_) __builtin_ia32_pause();
+    std::lock_guard<std::mutex> l(m_);
+    err_ = nullptr;
+  }
+  void wait(size_t ticket) {  // jobs up to `ticket` have run; rethrows the first failure
+    while (done_.load(std::memory_order_acquire) < ticket) __builtin_ia32_pause();
+    std::exception_ptr e;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      e = err_;
+      err_ = nullptr;
+    }
+    if (e) std::rethrow_exception(e);
+  }
+};
 
 struct NNZkKey {
   sp_ctx* ctx = nullptr;
@@ -61,7 +135,7 @@ struct NNZkPrep {
   sp_table* work[16] = {};
   size_t work_cap[16] = {};
   sp_ctx* ctx2 = nullptr;
-  Background bg;
+  Worker wk;
   sp_table* bws[2] = {nullptr, nullptr};
   size_t bws_cap[2] = {0, 0};
   struct RandomInstance {
@@ -70,8 +144,18 @@ struct NNZkPrep {
     size_t tape_from = 0, tape_count = 0;
     bool valid = false;
   } rnd;
+  // two more jobs of the same kind for the opening (hyrax_pc.rs:387-478, ipa.rs:125-170): `delta`, the commitment of the IPA's mask (tape values only), and
+  // - once r_y is known - P_f = <L, folded rows>, P_c = <L, core rows> and beta: comm_LZ = commit(L^T W; <L, blinds>) is the same group element as
+  // P_f + c_eval * P_c (W = folded W + c_eval * core W row by row), so the 2048-point MSM behind the last challenge becomes one scalar multiplication
+  struct OpeningAhead {
+    std::vector<fe_t> dv;
+    fe_t r_delta, r_beta;
+    aff_t delta, beta, P_f, P_c;
+    size_t tape_from = 0, tape_count = 0;
+    bool delta_valid = false, points_valid = false;
+  } open;
   ~NNZkPrep() {
-    bg.wait_nothrow();
+    wk.drain();
     for (sp_table* t : bws) sp_table_free(t);
     for (sp_table* t : work) sp_table_free(t);
     sp_ctx_destroy(ctx2);
@@ -320,9 +404,11 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   }();
   struct SideGuard {  // no exit path leaves a job running on state this call owns
     NNZkPrep& ps;
-    ~SideGuard() { ps.bg.wait_nothrow(); }
+    ~SideGuard() { ps.wk.drain(); }
   } side_guard{ps};
   ps.rnd.valid = false;
+  ps.open.delta_valid = ps.open.points_valid = false;
+  size_t t_rnd = 0, t_fold = 0, t_open = 0;  // tickets of the helper's jobs
   if (side) {
     if (!ps.ctx2) ck(sp_ctx_create(sp_ctx_device(ctx), &ps.ctx2), "second context");
     // the random relaxed instance: its values sit at a position of the tape that only the shapes determine (the draws in front of it are the
@@ -331,7 +417,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     for (const auto& st : ps.steps) before += st.comm_pre.size();
     Tape ahead = tape;
     ahead.pos = tape.pos + before;
-    ps.bg.submit([&pk, &ps, ahead]() mutable {
+    t_rnd = ps.wk.submit([&pk, &ps, ahead]() mutable {
       const vcirc::Shape& vs = pk.vc;
       const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io();
       NNZkPrep::RandomInstance& R = ps.rnd;
@@ -455,6 +541,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const size_t nb = pk.nb;
   std::vector<uint64_t> polys(16 * std::max<size_t>(nb, 1)), r_bs(4 * std::max<size_t>(nb, 1)), E_eq(4 * (left + right)), tail(8), f_rW(4 * rows), f_X(4 * std::max<size_t>(dpub, 1));
   std::vector<aff_t> f_comm(rows);
+  SideGuard side_guard_rows{ps};  // f_comm and core_comm are read and written by the helper's jobs: drained before they go out of scope
   sp_table *A = work_table(ctx, ps, 0, N), *B = work_table(ctx, ps, 1, N), *C = work_table(ctx, ps, 2, N), *fW = work_table(ctx, ps, 3, nv);
   sp_table *core_abc[3] = {work_table(ctx, ps, 4, N), work_table(ctx, ps, 5, N), work_table(ctx, ps, 6, N)}, *zc = work_table(ctx, ps, 7, nv + 1 + dpub);
   sp_table *pl = work_table(ctx, ps, 8, left), *pr = work_table(ctx, ps, 9, right), *rx = work_table(ctx, ps, 10, N);
@@ -465,13 +552,32 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   if (side) no.deferred_fold_commitments = &fold_job;
   nifs_prove(ctx, pk.S_step, d, pk.ck, n, rows, comms.data(), X.data(), Ws.data(), r_W.data(), true, ps.nifs_cached, tr.t, nifs_hook, &hc, no);
   if (hc.err) std::rethrow_exception(hc.err);
-  bool fold_pending = false;
-  if (fold_job) {  // (submit waits for the random-instance job first: one worker, jobs in order)
-    ps.bg.submit([&ps, job = std::move(fold_job)] {
+  if (fold_job) {
+    t_fold = ps.wk.submit([&ps, job = std::move(fold_job)] {
       ck(sp_ctx_bind_thread(ps.ctx2), "device");
       job(ps.ctx2);
     });
-    fold_pending = true;
+    // delta (ipa.rs:139-147): the mask and its blinds follow the random instance and NovaNIFS's r_T on the tape
+    Tape ahead = tape;
+    {
+      const vcirc::Shape& vs = pk.vc;
+      ahead.pos = tape.pos + (pk.vc.total_vars / 32 - vst.commits) + (vs.total_vars + vs.num_io() + 1) + vs.total_vars / 32 + 2 * (vs.num_cons / 32);
+    }
+    ps.wk.submit([&pk, &ps, ahead]() mutable {
+      NNZkPrep::OpeningAhead& O = ps.open;
+      try {
+        O.tape_from = ahead.pos;
+        O.dv.resize(DEFAULT_COMMITMENT_WIDTH);
+        for (auto& x : O.dv) x = ahead.next();
+        O.r_delta = ahead.next();
+        O.r_beta = ahead.next();
+        O.tape_count = ahead.pos - O.tape_from;
+        ck(sp_msm_ck(ps.ctx2, pk.ck, u64p(O.dv.data()), O.dv.size(), u64p(&O.r_delta), u64p(&O.delta.x)), "delta");
+        O.delta_valid = true;
+      } catch (...) {
+        O.delta_valid = false;
+      }
+    });
   }
   const double t_nifs = now();
 
@@ -556,6 +662,24 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     if (hc.err) std::rethrow_exception(hc.err);
     ck(rc, "inner sum-check (batched)");
   }
+  if (t_fold) {  // r_y is known: the halves of comm_LZ and beta, under the verifier-circuit phase
+    const size_t nvr = log2_ceil(rows);
+    t_open = ps.wk.submit([&pk, &ps, &f_comm, &core_comm, rows, L = eq_evals(r_y.data() + 1, nvr), Rv = eq_evals(r_y.data() + 1 + nvr, pk.ny - 1 - nvr)] {
+      NNZkPrep::OpeningAhead& O = ps.open;
+      try {
+        if (!O.delta_valid || Rv.size() != O.dv.size() || L.size() > rows) return;
+        ck(sp_ctx_bind_thread(ps.ctx2), "device");
+        ck(sp_msm(ps.ctx2, u64p(L.data()), u64p(&f_comm[0].x), L.size(), u64p(&O.P_f.x)), "<L, folded rows>");
+        ck(sp_msm(ps.ctx2, u64p(L.data()), u64p(&core_comm[0].x), L.size(), u64p(&O.P_c.x)), "<L, core rows>");
+        fe_t ip = fe_zero();
+        for (size_t i = 0; i < Rv.size(); ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], O.dv[i]));
+        ck(sp_hyrax_commit_small(ps.ctx2, pk.vc_ck, u64p(&ip), 1, u64p(&O.r_beta), u64p(&O.beta.x)), "beta");
+        O.points_valid = true;
+      } catch (...) {
+        O.points_valid = false;
+      }
+    });
+  }
   auto eval_X = [&](const std::vector<fe_t>& Xv) {
     std::vector<fe_t> v{one};
     v.insert(v.end(), Xv.begin(), Xv.end());
@@ -584,7 +708,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   lap("(up to the vc instance)");
   // sample_random_instance_witness (src/r1cs/mod.rs:474-531) on the verifier-circuit shape
   const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io();
-  if (!fold_pending) ps.bg.wait();  // (with the fold in flight the random-instance job has finished: the worker takes jobs in order)
+  if (t_rnd) ps.wk.wait(t_rnd);
   const bool ahead_ok = side && ps.rnd.valid && ps.rnd.tape_from == tape.pos;
   std::vector<fe_t> Z, rnd_rW, rnd_rE, rnd_E, mv[3];
   std::vector<aff_t> rnd_comm_W, rnd_comm_E;
@@ -711,7 +835,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const std::vector<aff_t>& comm_eW_c = vst.comm_per_round[inner_final + 2];
   const fe_t c_eval = tr.squeeze("c_eval");
   std::vector<aff_t> comm(rows);
-  if (fold_pending) ps.bg.wait();  // the folded commitment of the step instances: the helper's second job, started behind the NIFS rounds
+  if (t_fold) ps.wk.wait(t_fold);  // the folded commitment of the step instances: the helper's second job, started behind the NIFS rounds
   ck(sp_fold_commitments2(ctx, u64p(&f_comm[0].x), u64p(&core_comm[0].x), rows, u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
   std::vector<fe_t> blind(rows);
   for (size_t i = 0; i < rows; ++i) {
@@ -741,21 +865,37 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     ck(sp_rowmat_vec(ctx, Wf, L.size(), Rv.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
     fe_t r_LZ = fe_zero();
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], blind[i]));
-    // the mask d and its blinds do not depend on the transcript (ipa.rs:139-147): delta's MSM runs on the auxiliary stream beside comm_LZ's
-    std::vector<fe_t> dv(Rv.size());
-    for (auto& x : dv) x = tape.next();
-    const fe_t r_delta = tape.next(), r_beta = tape.next();
-    sp_msm_job* dj = nullptr;
-    ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dv.data()), dv.size(), &dj), "delta (begin)");
+    std::vector<fe_t> dv;
+    fe_t r_delta, r_beta;
     aff_t comm_LZ;
-    int rc_lz = sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x));
-    int rc_d = sp_msm_ck_finish(ctx, pk.ck, dj, u64p(&r_delta), u64p(&delta.x));  // always collected: the job owns device work
-    ck(rc_lz, "comm_LZ");
-    ck(rc_d, "delta (finish)");
+    if (t_open) ps.wk.wait(t_open);
+    if (t_open && ps.open.delta_valid && ps.open.points_valid && ps.open.tape_from == tape.pos && Rv.size() == ps.open.dv.size()) {
+      // the helper has delta, beta and the two halves of comm_LZ = <L, rows of (folded + c_eval core)> = P_f + c_eval P_c
+      dv.swap(ps.open.dv);
+      r_delta = ps.open.r_delta;
+      r_beta = ps.open.r_beta;
+      tape.skip(ps.open.tape_count);
+      delta = ps.open.delta;
+      beta = ps.open.beta;
+      ck(sp_fold_commitments2(ctx, u64p(&ps.open.P_f.x), u64p(&ps.open.P_c.x), 1, u64p(&c_eval), u64p(&comm_LZ.x)), "comm_LZ = P_f + c_eval P_c");
+    } else {
+      if (laps && side) fprintf(stderr, "nn_prove: opening inputs computed inline (delta %d, points %d, tape %zu vs %zu)\n", (int)ps.open.delta_valid, (int)ps.open.points_valid, ps.open.tape_from, tape.pos);
+      // the mask d and its blinds do not depend on the transcript (ipa.rs:139-147): delta's MSM runs on the auxiliary stream beside comm_LZ's
+      dv.resize(Rv.size());
+      for (auto& x : dv) x = tape.next();
+      r_delta = tape.next();
+      r_beta = tape.next();
+      sp_msm_job* dj = nullptr;
+      ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dv.data()), dv.size(), &dj), "delta (begin)");
+      int rc_lz = sp_msm_ck(ctx, pk.ck, u64p(LZ.data()), LZ.size(), u64p(&r_LZ), u64p(&comm_LZ.x));
+      int rc_d = sp_msm_ck_finish(ctx, pk.ck, dj, u64p(&r_delta), u64p(&delta.x));  // always collected: the job owns device work
+      ck(rc_lz, "comm_LZ");
+      ck(rc_d, "delta (finish)");
+      fe_t ip = fe_zero();
+      for (size_t i = 0; i < Rv.size(); ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], dv[i]));
+      ck(sp_hyrax_commit_small(ctx, pk.vc_ck, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
+    }
     tr.dom_sep("inner product argument (linear)");
-    fe_t ip = fe_zero();
-    for (size_t i = 0; i < Rv.size(); ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], dv[i]));
-    ck(sp_hyrax_commit_small(ctx, pk.vc_ck, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
     uint8_t pb[128];
     point_bytes(comm_LZ, pb);
     point_bytes(comm_eval, pb + 64);
