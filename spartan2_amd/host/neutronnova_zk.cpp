@@ -98,7 +98,13 @@ struct NNZkKey {
   uint8_t vk_digest[32];
   // verify(): eq tables and the three M * T_y products of the matrix evaluations, allocated on first use
   mutable sp_table *v_Tx = nullptr, *v_Ty = nullptr, *v_mv[3] = {nullptr, nullptr, nullptr};
+  // r_b, r_x and r_y are fields of the proof, so the commitment fold and the matrix evaluations can start before the transcript has been replayed:
+  // they run as jobs on a second context of the same GPU beside the replay, NovaNIFS::verify and the relaxed Spartan check (SPARTAN_NN_SIDE=0: inline)
+  mutable sp_ctx* v_ctx2 = nullptr;
+  mutable Worker v_wk;
   ~NNZkKey() {
+    v_wk.drain();
+    sp_ctx_destroy(v_ctx2);
     sp_table_free(v_Tx);
     sp_table_free(v_Ty);
     for (sp_table* t : v_mv) sp_table_free(t);
@@ -1077,6 +1083,66 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   for (size_t i = 0; i < n; ++i) Ucomm[i] = regular(steps[i]);
   const std::vector<aff_t> core_comm = regular(core);
   const std::vector<fe_t> core_X(core.pub, core.pub + cpub);
+  // the verifier-circuit instance in its regular form: comm_W = the rounds' rows, X = challenges | public values; the challenges are checked against the
+  // transcript below, what is computed from them before that is only used after the check
+  const std::vector<aff_t> Uv_comm(vcomm[0], vcomm[0] + vnv / VW);  // the rounds are consecutive in the layout
+  std::vector<fe_t> Uv_X;
+  for (size_t r = 0; r < vs.num_rounds; ++r) Uv_X.insert(Uv_X.end(), vchal[r], vchal[r] + vs.chals_per_round[r]);
+  Uv_X.insert(Uv_X.end(), vpub, vpub + vs.num_public);
+  const size_t num_chal = nb + nx + 1 + ny;
+  if (vs.total_challenges != num_chal || vs.num_public != 6) return 2;
+  const fe_t *r_b = Uv_X.data(), *r_x = r_b + nb, *r_y = r_x + nx + 1, *pub = Uv_X.data() + num_chal;
+  const fe_t r = Uv_X[nb + nx], r2 = fe_mul<S>(r, r), one = fe_one<S>();
+  // fold_multiple of the step instances (src/r1cs/mod.rs:695-722): X on the host, the commitment rows as shared-weights MSMs
+  std::vector<fe_t> wts(np);
+  ck(sp_weights_from_r(u64p(r_b), nb, np, u64p(wts.data())), "weights_from_r");
+  std::vector<fe_t> Xf(dpub, fe_zero());
+  for (size_t i = 0; i < np; ++i)
+    for (size_t j = 0; j < dpub; ++j) Xf[j] = fe_add<S>(Xf[j], fe_mul<S>(wts[i], steps[inst(i)].pub[j]));
+  std::vector<aff_t> folded_comm(rows), fold_bases(rows * np);
+  for (size_t rr = 0; rr < rows; ++rr)
+    for (size_t i = 0; i < np; ++i) fold_bases[rr * np + i] = Ucomm[inst(i)][rr];
+  fe_t eabc[2][3];
+  static const bool side = [] {
+    const char* e = getenv("SPARTAN_NN_SIDE");
+    return !(e && e[0] == '0');
+  }();
+  auto fold_commitments = [&](sp_ctx* on) {
+    ck(sp_msm_shared_weights(on, u64p(wts.data()), np, reinterpret_cast<const uint64_t*>(fold_bases.data()), rows, reinterpret_cast<uint64_t*>(folded_comm.data())), "fold_commitments");
+  };
+  // the matrix evaluations A, B, C (r_x, r_y) of the step and core shapes: T_x^T (M T_y)
+  auto matrix_evaluations = [&](sp_ctx* on) {
+    if (!pk.v_Tx) {
+      ck(sp_table_zeros(on, (size_t)1 << nx, (size_t)-1, (size_t)-1, &pk.v_Tx), "T_x alloc");
+      ck(sp_table_zeros(on, (size_t)1 << ny, (size_t)-1, (size_t)-1, &pk.v_Ty), "T_y alloc");
+      for (int i = 0; i < 3; ++i) ck(sp_table_zeros(on, N, (size_t)-1, (size_t)-1, &pk.v_mv[i]), "M T_y alloc");
+    }
+    sp_table *Tx = pk.v_Tx, *Ty = pk.v_Ty, **mv = pk.v_mv;
+    ck(sp_table_set_len(Tx, (size_t)1 << nx, (size_t)-1, (size_t)-1), "T_x len");
+    ck(sp_table_set_len(Ty, (size_t)1 << ny, (size_t)-1, (size_t)-1), "T_y len");
+    ck(sp_eq_table_into(on, u64p(r_x), nx, Tx), "T_x");
+    ck(sp_eq_table_into(on, u64p(r_y), ny, Ty), "T_y");
+    const sp_shape* shapes[2] = {pk.S_step, pk.S_core};
+    const size_t cols[2] = {nv + 1 + dpub, nv + 1 + cpub};
+    for (int s2 = 0; s2 < 2; ++s2) {
+      ck(sp_table_set_len(Ty, cols[s2], (size_t)-1, (size_t)-1), "T_y as z");
+      ck(sp_multiply_vec(on, shapes[s2], Ty, mv[0], mv[1], mv[2]), "M T_y");
+      for (int i = 0; i < 3; ++i) ck(sp_table_dot(on, Tx, mv[i], N, u64p(&eabc[s2][i])), "T_x . (M T_y)");
+    }
+  };
+  struct Drain {  // the jobs read and write locals of this call
+    Worker& w;
+    ~Drain() { w.drain(); }
+  } drain{pk.v_wk};
+  size_t t_fold = 0, t_mat = 0;
+  if (side) {
+    if (!pk.v_ctx2) ck(sp_ctx_create(sp_ctx_device(ctx), &pk.v_ctx2), "second context");
+    t_fold = pk.v_wk.submit([&] {
+      ck(sp_ctx_bind_thread(pk.v_ctx2), "device");
+      fold_commitments(pk.v_ctx2);
+    });
+    t_mat = pk.v_wk.submit([&] { matrix_evaluations(pk.v_ctx2); });
+  }
   Tr tr(ctx, "neutronnova_prove");
   tr.absorb("vk", pk.vk_digest, 32);
   absorb_instance(tr, "core_instance", core_comm, core_X);
@@ -1096,30 +1162,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
     for (size_t i = 0; i < vs.chals_per_round[round]; ++i)
       if (!fe_eq(tr.squeeze("challenge"), vchal[round][i])) return 2;
   }
-  // its regular form: comm_W = the rounds' rows, X = challenges | public values
-  const std::vector<aff_t> Uv_comm(vcomm[0], vcomm[0] + vnv / VW);  // the rounds are consecutive in the layout
-  std::vector<fe_t> Uv_X;
-  for (size_t r = 0; r < vs.num_rounds; ++r) Uv_X.insert(Uv_X.end(), vchal[r], vchal[r] + vs.chals_per_round[r]);
-  Uv_X.insert(Uv_X.end(), vpub, vpub + vs.num_public);
-  const size_t num_chal = nb + nx + 1 + ny;
-  if (vs.total_challenges != num_chal || vs.num_public != 6) return 2;
-  const fe_t *r_b = Uv_X.data(), *r_x = r_b + nb, *r_y = r_x + nx + 1, *pub = Uv_X.data() + num_chal;
-  const fe_t r = Uv_X[nb + nx], r2 = fe_mul<S>(r, r), one = fe_one<S>();
   lap("vc instance replayed");
-  // fold_multiple of the step instances (src/r1cs/mod.rs:695-722): X on the host, the commitment rows as shared-weights MSMs
-  std::vector<fe_t> wts(np);
-  ck(sp_weights_from_r(u64p(r_b), nb, np, u64p(wts.data())), "weights_from_r");
-  std::vector<fe_t> Xf(dpub, fe_zero());
-  for (size_t i = 0; i < np; ++i)
-    for (size_t j = 0; j < dpub; ++j) Xf[j] = fe_add<S>(Xf[j], fe_mul<S>(wts[i], steps[inst(i)].pub[j]));
-  std::vector<aff_t> folded_comm(rows);
-  {
-    std::vector<aff_t> bases(rows * np);
-    for (size_t rr = 0; rr < rows; ++rr)
-      for (size_t i = 0; i < np; ++i) bases[rr * np + i] = Ucomm[inst(i)][rr];
-    ck(sp_msm_shared_weights(ctx, u64p(wts.data()), np, reinterpret_cast<const uint64_t*>(bases.data()), rows, reinterpret_cast<uint64_t*>(folded_comm.data())), "fold_commitments");
-  }
-  lap("fold_multiple");
   // NovaNIFS::verify (src/nifs.rs:65-77): the random relaxed instance folded with the verifier-circuit instance
   {
     std::vector<uint8_t> b = commitment_bytes(rnd_comm_W, vnv / VW), e = commitment_bytes(rnd_comm_E, vcons / VW);
@@ -1203,26 +1246,10 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   }
   lap("relaxed Spartan verify");
   // the six public values of the verifier circuit (:2280-2330): tau(r_x), the X evaluations, eq(r_b, rho) and the matrix evaluations at (r_x, r_y)
-  fe_t eabc[2][3];
-  {
-    if (!pk.v_Tx) {
-      ck(sp_table_zeros(ctx, (size_t)1 << nx, (size_t)-1, (size_t)-1, &pk.v_Tx), "T_x alloc");
-      ck(sp_table_zeros(ctx, (size_t)1 << ny, (size_t)-1, (size_t)-1, &pk.v_Ty), "T_y alloc");
-      for (int i = 0; i < 3; ++i) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &pk.v_mv[i]), "M T_y alloc");
-    }
-    sp_table *Tx = pk.v_Tx, *Ty = pk.v_Ty, **mv = pk.v_mv;
-    ck(sp_table_set_len(Tx, (size_t)1 << nx, (size_t)-1, (size_t)-1), "T_x len");
-    ck(sp_table_set_len(Ty, (size_t)1 << ny, (size_t)-1, (size_t)-1), "T_y len");
-    ck(sp_eq_table_into(ctx, u64p(r_x), nx, Tx), "T_x");
-    ck(sp_eq_table_into(ctx, u64p(r_y), ny, Ty), "T_y");
-    const sp_shape* shapes[2] = {pk.S_step, pk.S_core};
-    const size_t cols[2] = {nv + 1 + dpub, nv + 1 + cpub};
-    for (int s2 = 0; s2 < 2; ++s2) {
-      ck(sp_table_set_len(Ty, cols[s2], (size_t)-1, (size_t)-1), "T_y as z");
-      ck(sp_multiply_vec(ctx, shapes[s2], Ty, mv[0], mv[1], mv[2]), "M T_y");
-      for (int i = 0; i < 3; ++i) ck(sp_table_dot(ctx, Tx, mv[i], N, u64p(&eabc[s2][i])), "T_x . (M T_y)");
-    }
-  }
+  if (t_mat)
+    pk.v_wk.wait(t_mat);
+  else
+    matrix_evaluations(ctx);
   {
     auto eval_X = [&](const fe_t* Xv, size_t cnt) {
       std::vector<fe_t> v{one};
@@ -1248,6 +1275,10 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   const size_t commit_round = nb + 1 + nx + 1 + ny + 1;
   if (commit_round + 1 >= vs.num_rounds) throw Error(SP_ERR_INTERNAL, "nn_verify: verifier-circuit round layout");
   std::vector<aff_t> comm(rows);
+  if (t_fold)
+    pk.v_wk.wait(t_fold);
+  else
+    fold_commitments(ctx);
   ck(sp_fold_commitments2(ctx, u64p(&folded_comm[0].x), u64p(&core_comm[0].x), rows, u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
   aff_t comm_eval;
   ck(sp_fold_commitments2(ctx, u64p(&vcomm[commit_round][0].x), u64p(&vcomm[commit_round + 1][0].x), 1, u64p(&c_eval), u64p(&comm_eval.x)), "fold eval commitments");
