@@ -206,6 +206,17 @@ int sp_msm_shared_weights(sp_ctx* ctx, const uint64_t* weights, size_t n, const 
  * two-term fold with a unit weight (hyrax_pc.rs:757-776): see sp_fold_commitments2. Few points run on the host side of the library (a dependent
  * chain of ~300 group operations: one CPU core finishes it 40x sooner than one GPU lane), many on the device, one lane per point. */
 int sp_vartime_scalar_mul(sp_ctx* ctx, const uint64_t* points_aff, size_t n, const uint64_t scalar[4], uint64_t* out_aff);
+/* FixedBaseMul over arbitrary points (src/provider/msm.rs:637-773): `precompute` builds 32 x 255 affine window multiples per point (1 <= n <= 512;
+ * 510 KiB per point), `multi_mul` = sum_i scalars[i] * point_i as table lookups added in ONE launch on the context's auxiliary stream (callable from a
+ * helper thread beside the owner's calls on the main stream), scalars and result through mapped memory: no copy, no stream synchronise, no host tail.
+ * Call site: comm_LZ of HyraxPCS::prove (hyrax_pc.rs:387-478) as sum_i L_i * comm_W[i] over the row commitments a prepared witness already holds. */
+typedef struct sp_fbtables sp_fbtables;
+int sp_fbtables_create(sp_ctx* ctx, const uint64_t* points_aff, size_t n, sp_fbtables** out);
+void sp_fbtables_free(sp_fbtables* t);
+int sp_fbtables_multi_mul(sp_ctx* ctx, const sp_fbtables* t, const uint64_t* scalars, size_t n, uint64_t out_aff[8]);
+/* the same in two halves: _begin launches, _finish waits for the result (one multiplication in flight per context) */
+int sp_fbtables_multi_mul_begin(sp_ctx* ctx, const sp_fbtables* t, const uint64_t* scalars, size_t n);
+int sp_fbtables_multi_mul_finish(sp_ctx* ctx, uint64_t out_aff[8]);
 /* FoldingEngineTrait::fold_commitments for two commitments with weights (1, w) (hyrax_pc.rs:757-776): out[i] = p[i] + w * q[i] per row */
 int sp_fold_commitments2(sp_ctx* ctx, const uint64_t* p_rows_aff, const uint64_t* q_rows_aff, size_t rows, const uint64_t w[4], uint64_t* out_rows_aff);
 /* sum of n affine points (host side of the library; the combine step of a point-range-sharded MSM: RCCL has no EC-add reduction,

@@ -1,6 +1,7 @@
 // libspartan_hip.so — group / MSM / Hyrax entry points of include/spartan_hip.h.
 // Device: digit sort, bucket accumulation, per-window weighted reduction, binary row sums, fixed-base lookups,
 // row-matrix product. Host (inside the library): window Horner, adding the blind term, batch normalisation.
+#include <atomic>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
@@ -995,6 +996,97 @@ int sp_rowmat_vec_eq_finish(sp_ctx* c, sp_vec_job* job, uint64_t* out) {
   return SP_OK;
 }
 int sp_msm_job_finish(sp_ctx* c, sp_msm_job* job, uint64_t out_aff[8]) { return sp_msm_ck_finish(c, nullptr, job, nullptr, out_aff); }
+
+// ---- FixedBaseMul tables over arbitrary points (msm.rs:653-689, 727-773) ---------------------------------------------------------------------------
+struct sp_fbtables {
+  size_t n = 0;
+  aff_t* d_tables = nullptr;  // n x 32 x 255 affine multiples
+};
+int sp_fbtables_create(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtables** out) {
+  if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_create: 1 .. 512 points");
+  const size_t per = 32 * 255;
+  DevBuf pts, tj;
+  int rc;
+  if ((rc = pts.alloc(n * sizeof(aff_t))) || (rc = tj.alloc(n * per * sizeof(jac_t)))) return rc;
+  aff_t* tables = nullptr;
+  SP_HIP(hipMalloc((void**)&tables, n * per * sizeof(aff_t)));
+  hipError_t e = hipMemcpyAsync(pts.p, points_aff, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(spk::k_fixed_base_tables, dim3((unsigned)n), dim3(64), 0, c->stream, pts.as<aff_t>(), n, tj.as<jac_t>());
+    hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), n * per, tables);
+    e = hipStreamSynchronize(c->stream);
+  }
+  if (e != hipSuccess) {
+    hipFree(tables);
+    return fail(SP_ERR_NO_DEVICE, std::string("sp_fbtables_create: ") + hipGetErrorString(e));
+  }
+  sp_fbtables* t = new sp_fbtables();
+  t->n = n;
+  t->d_tables = tables;
+  *out = t;
+  return SP_OK;
+}
+void sp_fbtables_free(sp_fbtables* t) {
+  if (!t) return;
+  if (t->d_tables) hipFree(t->d_tables);
+  delete t;
+}
+// sum_i scalars[i] * point_i in one launch on the AUXILIARY stream (callable from a helper thread beside the owner's calls on the main stream, like
+// sp_msm_eq_begin): scalars and result through mapped pinned pages, no copies, no host-side tail (kernels_msm.cuh k_multi_mul_coop). The caller polls
+// the self-validating result slot; a poll that runs long (profiler, debugger) falls back to a stream synchronise, after which the slot must be valid.
+// _begin launches, _finish polls (one multiplication in flight per context).
+int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n) {
+  if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
+  const size_t page = 256 + 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
+  if (!c->h_mm) {
+    SP_HIP(hipHostMalloc(&c->h_mm, page, hipHostMallocMapped));
+    memset(c->h_mm, 0, page);
+    SP_HIP(hipHostGetDevicePointer(&c->d_mm, c->h_mm, 0));
+    SP_HIP(hipMalloc(&c->d_mm_work, 256 + spk::MULTI_MUL_MAX_BLOCKS * sizeof(xyzz_t)));
+    SP_HIP(hipMemsetAsync(c->d_mm_work, 0, 256, c->stream2));  // the ticket; every launch leaves it at zero again
+  }
+  memcpy((char*)c->h_mm + 256, scalars, n * sizeof(fe_t));
+  if (++c->mm_seq == 0) ++c->mm_seq;
+  c->timed_on(c->stream2, "multi_mul", 32ull * n, [&] {
+    hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, c->stream2, reinterpret_cast<const fe_t*>((char*)c->d_mm + 256), n, t->d_tables,
+                       reinterpret_cast<xyzz_t*>((char*)c->d_mm_work + 256), reinterpret_cast<unsigned*>(c->d_mm_work), reinterpret_cast<unsigned*>(c->d_mm), c->mm_seq);
+  });
+  return SP_OK;
+}
+int sp_fbtables_multi_mul_finish(sp_ctx* c, uint64_t out_aff[8]) {
+  if (!c->h_mm || c->mm_seq == 0) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul_finish: nothing in flight");
+  const unsigned seq = c->mm_seq;
+  volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>(c->h_mm);
+  unsigned w[24];
+  bool synced = false;
+  for (long spins = 0;; ++spins) {
+    if (slot[24] == seq) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      unsigned a = seq, b = seq * spk::MULTI_MUL_SLOT_K;
+      for (int i = 0; i < 24; ++i) {
+        w[i] = slot[i];
+        a += w[i];
+        b += (unsigned)(i + 1) * w[i];
+      }
+      if (slot[24] == seq && slot[25] == a && slot[26] == b && slot[27] == seq) break;
+    }
+    if (spins > 4000000) {
+      if (synced) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul: the kernel did not deliver its result slot");
+      SP_HIP(hipStreamSynchronize(c->stream2));  // e.g. under a profiler
+      synced = true;
+      spins = 0;
+    }
+    __builtin_ia32_pause();
+  }
+  jac_t sum;
+  memcpy(&sum, w, sizeof(jac_t));
+  store_aff(out_aff, jac_to_affine(sum));
+  return SP_OK;
+}
+int sp_fbtables_multi_mul(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n, uint64_t out_aff[8]) {
+  int rc = sp_fbtables_multi_mul_begin(c, t, scalars, n);
+  return rc ? rc : sp_fbtables_multi_mul_finish(c, out_aff);
+}
 
 int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]) {
   if (!ck->d_cktables || n > ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_small: key wider than 64 or too many scalars");

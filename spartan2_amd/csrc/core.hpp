@@ -48,6 +48,12 @@ struct sp_ctx {
   bool mail_dev = false;
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs
   void* h_pinned_fbs = nullptr;  // pinned staging of the synchronous fixed-base calls (<= 1024 scalars: the per-round commitments of the ZK verifier circuit)
+  // one-launch FixedBaseMul::multi_mul (sp_fbtables_multi_mul, kernels_msm.cuh k_multi_mul_coop): mapped pinned pages (result slot at byte 0, scalars
+  // at byte 256), their device-side address, device scratch (ticket + block sums) and the sequence number of the result in flight
+  void* h_mm = nullptr;
+  void* d_mm = nullptr;
+  void* d_mm_work = nullptr;
+  unsigned mm_seq = 0;
   hipEvent_t fb_ev = nullptr;
   hipEvent_t fb_event() {
     if (!fb_ev) hipEventCreateWithFlags(&fb_ev, hipEventDisableTiming);

@@ -632,6 +632,22 @@ __global__ void k_fixed_base_table(aff_t h, jac_t* __restrict__ table_jac) {
     table_jac[(size_t)j * 255 + d] = acc;
   }
 }
+// the same for many bases in one launch: block b builds the 32 window rows of bases[b] (FixedBaseMul::precompute for every row commitment of a
+// prepared witness: sp_fbtables_create)
+__global__ void k_fixed_base_tables(const aff_t* __restrict__ bases, size_t n, jac_t* __restrict__ table_jac) {
+  const size_t b = blockIdx.x;
+  const int j = threadIdx.x;
+  if (b >= n || j >= 32) return;
+  jac_t base = jac_from_affine(bases[b]);
+  for (int k = 0; k < 8 * j; ++k) base = jac_dbl(base);
+  jac_t* row = table_jac + (b * 32 + (size_t)j) * 255;
+  jac_t acc = base;
+  row[0] = acc;
+  for (int d = 1; d < 255; ++d) {
+    acc = jac_add(acc, base);
+    row[d] = acc;
+  }
+}
 __global__ void __launch_bounds__(256) k_jac_to_affine(const jac_t* __restrict__ in, size_t n, aff_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = jac_to_affine(in[i]);
 }
@@ -697,6 +713,83 @@ __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __
     xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
   if (role == 0 && j == 0 && idx < n) out[idx] = xyzz_to_jac(s[k]);
+}
+
+// FixedBaseMul::multi_mul (msm.rs:727-773) over per-base tables, sum_i s_i P_i, in ONE launch with no copy on either side and no host-side tail — the
+// latency form behind sp_fbtables_multi_mul. Its call site is comm_LZ of the Hyrax opening (hyrax_pc.rs:387-478): the commitment of L^T W equals
+// sum_i L_i * comm_W[i], the rows of comm_W are known when the witness is prepared, so their window tables are built there and the 512-point MSM
+// (digits, sort, bucket sums, a 14-level window reduction, 256 doublings on the host) that used to follow the last row challenge becomes 14 levels of
+// additions. The scalars are read straight from mapped host memory; block b owns scalars 4b .. 4b+3 (128 table entries, seven cooperative levels down
+// to one point); the last block to take a ticket adds the block sums (<= 128 of them) the same way and publishes the Jacobian sum into a
+// self-validating slot in mapped host memory that the host polls: words 0..23 the point, 24 = sequence, 25 = sequence + plain sum, 26 = sequence * K +
+// position-weighted sum, 27 = sequence again (the order in which the stores land does not matter; the host accepts the slot only when all four agree).
+constexpr unsigned MULTI_MUL_SLOT_K = 0x9E3779B1u;
+constexpr int MULTI_MUL_MAX_BLOCKS = 128;
+__global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, xyzz_t* __restrict__ partial,
+                                                            unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq) {
+  __shared__ CoopAdd<128> L;
+  __shared__ xyzz_t s[128];
+  __shared__ unsigned s_last;
+  const int wave = threadIdx.x >> 6, blk = wave >> 2;
+  const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);  // roles of an item block on four different SIMDs (see k_msm_window_reduce_coop)
+  const size_t idx = (size_t)blockIdx.x * 4 + (k >> 5);
+  const int j = k & 31;
+  if (role == 0) {
+    xyzz_t acc = xyzz_identity();
+    if (idx < n) {
+      const fe_t c = fe_to_canonical<SF>(scalars[idx]);
+      const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      if (digit) acc = xyzz_from_affine(tables[idx * (32 * 255) + (size_t)j * 255 + digit - 1]);
+    }
+    s[k] = acc;
+  }
+  __syncthreads();
+  for (int off = 64; off >= 1; off >>= 1) {  // in place is safe: results are stored after the last level of the addition
+    const bool active = k < off;
+    xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+  }
+  if (gridDim.x > 1) {
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x] = s[0];
+      __threadfence();  // the block sum is visible device-wide before the ticket is taken
+      s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (role == 0) {
+      xyzz_t acc = xyzz_identity();
+      if (k < (int)gridDim.x) {  // other blocks' sums: loads that cannot be served from a stale line of this XCD's caches
+        const unsigned* pw = reinterpret_cast<const unsigned*>(&partial[k]);
+        unsigned* aw = reinterpret_cast<unsigned*>(&acc);
+#pragma unroll
+        for (int w = 0; w < (int)(sizeof(xyzz_t) / 4); ++w) aw[w] = __hip_atomic_load(pw + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s[k] = acc;
+    }
+    __syncthreads();
+    int top = 1;
+    while (2 * top < (int)gridDim.x) top <<= 1;
+    for (int off = top; off >= 1; off >>= 1) {
+      const bool active = k < off;
+      xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+    }
+    if (threadIdx.x == 0) atomicExch(ticket, 0u);  // ready for the next launch (stream order makes it visible)
+  }
+  if (threadIdx.x == 0) {
+    const jac_t r = xyzz_to_jac(s[0]);
+    const unsigned* rw = reinterpret_cast<const unsigned*>(&r);
+    unsigned a = seq, b = seq * MULTI_MUL_SLOT_K;
+#pragma unroll
+    for (int w = 0; w < 24; ++w) {
+      slot[w] = rw[w];
+      a += rw[w];
+      b += (unsigned)(w + 1) * rw[w];
+    }
+    const unsigned long long lo = ((unsigned long long)a << 32) | seq, hi = ((unsigned long long)seq << 32) | b;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 26), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 24), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ---- K9: LZ[i] = sum_j L[j] * poly[j*cols + i] ---------------------------------------------------------------------------

@@ -391,6 +391,33 @@ class CommitmentKey:
             pass
 
 
+class FixedBaseTables:
+    """FixedBaseMul::precompute over n <= 512 points + multi_mul in one launch (src/provider/msm.rs:637-773): sp_fbtables_*."""
+
+    def __init__(self, ctx: Context, points):
+        points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+        self.ctx, self.n = ctx, points.shape[0]
+        self.h = ctypes.c_void_p()
+        check(lib().sp_fbtables_create(ctx.h, p64(points), ctypes.c_size_t(self.n), ctypes.byref(self.h)))
+
+    def multi_mul(self, scalars):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().sp_fbtables_multi_mul(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().sp_fbtables_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def rowmat_vec(ctx, poly: Table, rows, cols, L):
     """bind_with_delayed (src/provider/pcs/hyrax_pc.rs:38-54)."""
     L = np.ascontiguousarray(L, dtype=np.uint64).reshape(rows, 4)

@@ -76,7 +76,12 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   Background bg;                        // hashes comm_W for the PCS transcript step while the sum-checks run, then starts comm_LZ's MSM
   sp_absorb_state* poly_com = nullptr;  // its result
   sp_points* comm_pts = nullptr;        // comm_W on the device: the bases of comm_LZ's MSM
+  // FixedBaseMul tables of the rows committed here (shared, precommitted) and of h (msm.rs:653-689): with no rest variables the remaining rows of
+  // comm_W are h * blind (commit_zeros), so comm_LZ = sum_fixed L_i comm_W[i] + (sum_rest L_i blind_i) h is one multi_mul over these tables
+  // (sp_fbtables_multi_mul: 14 levels of additions in one launch instead of a 512-point MSM behind the last row challenge). SPARTAN_LZ_TABLES=0: off.
+  sp_fbtables* lz_tables = nullptr;
   ~SpartanPrepSNARK() {
+    sp_fbtables_free(lz_tables);
     bg.wait_nothrow();
     bg2.wait_nothrow();
     sp_transcript_free(tr_fresh);
@@ -162,6 +167,15 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
                          u64p(&ps->comm_W_fixed[ps->rows_shared].x)),
          "commit precommitted");
       ps->comm_pre_bytes = commitment_bytes(ps->comm_W_fixed.data() + ps->rows_shared, ps->rows_precommitted);
+    }
+    {
+      const char* e = getenv("SPARTAN_LZ_TABLES");
+      const size_t fixed = ps->comm_W_fixed.size(), rows_all = (M + CW - 1) / CW;
+      if (!(e && e[0] == '0') && !(ps->flags & FLAG_LZ_DIRECT) && d.num_rest_unpadded == 0 && d.num_challenges == 0 && fixed >= 1 && fixed + 1 <= 512 && rows_all > 1) {
+        std::vector<aff_t> pts(ps->comm_W_fixed);
+        pts.push_back(pk.gens[CW]);  // h
+        ck(sp_fbtables_create(ctx, u64p(&pts[0].x), pts.size(), &ps->lz_tables), "tables of the committed rows");
+      }
     }
     // multiply_vec_precommitted (src/r1cs/mod.rs:1112-1128): z = [W_cached | 0 ...]
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->z), "alloc z");
@@ -322,6 +336,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   } draw_join{ps.bg};
   lap("dvec_draw");
 
+  const bool rest_job_used = rest_job != nullptr;  // the rest rows are h * blind (commit_zeros)
   if (rest_job) ck(sp_fixed_base_mul_h_finish(ctx, rest_job, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
   else if (rows_rest)
     ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)),
@@ -355,6 +370,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     fe_t r_delta;
     aff_t delta;
     bool delta_done = false;
+    std::atomic<int> early_done{0};  // poly_com prepared and delta finished: what the PCS phase needs first (1 = done, 2 = gave up)
+    aff_t comm_LZ;                   // the tables path (SpartanPrepSNARK::lz_tables): the helper delivers comm_LZ itself
+    bool have_comm_LZ = false;
     // a helper that may not spin sleeps on this pair; the owner notifies after each state change (a notify without a sleeper is a user-space check)
     std::mutex mu;
     std::condition_variable cv;
@@ -367,6 +385,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   lz.nvr = lz_nvr;
   const bool lz_ahead = !lz_direct && lz_nvr > 0 && lz_nvr <= 20 && comm_W.size() == ((size_t)1 << lz_nvr) && r_W.size() == comm_W.size();
   const size_t lz_cols = (size_t)1 << (log2_ceil(M) - lz_nvr);
+  const bool lz_tables_path = lz_ahead && ps.lz_tables && rest_job_used && ps.comm_W_fixed.size() + rows_rest == comm_W.size();
   {
     const aff_t* rows = comm_W.data();
     const size_t nrows = comm_W.size();
@@ -375,7 +394,10 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     LzAhead* lzp = lz_ahead ? &lz : nullptr;
     const sp_ck* key = pk.ck;
     const size_t cols = lz_cols;
-    ps.bg.submit([ctx, rows, nrows, psp, blinds, lzp, key, cols] {
+    // tables of the fixed rows + h: usable when every other row of comm_W is h * blind (commit_zeros)
+    const sp_fbtables* tabs = lz_tables_path ? ps.lz_tables : nullptr;
+    const size_t nfixed = ps.comm_W_fixed.size();
+    ps.bg.submit([ctx, rows, nrows, psp, blinds, lzp, key, cols, tabs, nfixed] {
       const std::vector<uint8_t> b = commitment_bytes(rows, nrows);
       ck(sp_transcript_preabsorb((const uint8_t*)"poly_com", 8, b.data(), b.size(), &psp->poly_com), "poly_com (prepare)");
       if (!lzp) return;
@@ -401,11 +423,32 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       ck(sp_msm_ck_finish(ctx, key, lzp->delta_job, u64p(&lzp->r_delta), u64p(&lzp->delta.x)), "delta (finish)");
       lzp->delta_job = nullptr;
       lzp->delta_done = true;
+      lzp->early_done.store(1, std::memory_order_release);
       if (wait_for(lzp->state) != 1) return;
+      const size_t hb = lzp->nvr / 2, lb = lzp->nvr - hb;
+      if (tabs) {
+        // comm_LZ = sum_{fixed rows} L_i comm_W[i] + (sum_{zero rows} L_i blind_i) h: one multi_mul over the prepared tables, launched before anything else
+        const std::vector<fe_t> left = eq_evals_host(lzp->r, hb), right = eq_evals_host(lzp->r + hb, lb);
+        std::vector<fe_t> sc(nfixed + 1);
+        fe_t hs = fe_zero(), acc = fe_zero();
+        for (size_t i = 0; i < nrows; ++i) {
+          const fe_t Li = fe_mul<S>(left[i / right.size()], right[i % right.size()]);
+          const fe_t Lb = fe_mul<S>(Li, blinds[i]);
+          acc = fe_add<S>(acc, Lb);
+          if (i < nfixed) sc[i] = Li;
+          else hs = fe_add<S>(hs, Lb);
+        }
+        sc[nfixed] = hs;
+        ck(sp_fbtables_multi_mul_begin(ctx, tabs, u64p(sc.data()), sc.size()), "comm_LZ (begin)");
+        ck(sp_rowmat_vec_eq_begin(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, &lzp->vec), "bind_with_delayed (begin)");
+        lzp->r_LZ = acc;
+        ck(sp_fbtables_multi_mul_finish(ctx, u64p(&lzp->comm_LZ.x)), "comm_LZ (finish)");
+        lzp->have_comm_LZ = true;
+        return;
+      }
       ck(sp_msm_eq_begin(ctx, psp->comm_pts, u64p(lzp->r), lzp->nvr, &lzp->job), "comm_LZ (begin)");
       ck(sp_rowmat_vec_eq_begin(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, &lzp->vec), "bind_with_delayed (begin)");
       // r_LZ = <L, r_W> with L = eq(r) = left (x) right: 2^nvr + 2^(nvr/2) products instead of 2 * 2^nvr
-      const size_t hb = lzp->nvr / 2, lb = lzp->nvr - hb;
       const std::vector<fe_t> left = eq_evals_host(lzp->r, hb), right = eq_evals_host(lzp->r + hb, lb);
       fe_t acc = fe_zero();
       for (size_t a = 0; a < left.size(); ++a) {
@@ -491,16 +534,55 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> inner_polys(2 * num_rounds_y), r_y(num_rounds_y);
   fe_t claims_inner[2];
   // r_y[0] selects W against (1, X); r_y[1 ..= nvr] are the row variables of W (MSB first): once they are drawn the helper can start comm_LZ
+  // <R, d> (ipa.rs:148) with R = eq(point[nvr..]) = left (x) right: the partial sums T[b] = sum_a left[a] d[a |right| + b] need only `left`, whose
+  // variables are bound hb rounds after the row variables - the second helper computes them under the remaining rounds and the prover finishes with
+  // |right| products instead of |R| + |left| after the last round
+  struct IpAhead {
+    size_t first = 0, hb = 0, nright = 0;  // left = eq(r_y[first .. first + hb))
+    fe_t left_r[16];
+    std::vector<fe_t> T;
+    bool submitted = false;
+  } ipa;
+  if (lz_ahead) {
+    const size_t k = (num_rounds_y - 1) - lz_nvr;
+    ipa.first = 1 + lz_nvr;
+    ipa.hb = k / 2;
+    ipa.nright = (size_t)1 << (k - ipa.hb);
+    if (ipa.hb == 0 || ipa.hb > 16 || (((size_t)1 << ipa.hb) * ipa.nright) != n_ipa) ipa.hb = 0;  // (not this shape: the prover computes <R, d> itself)
+  }
   struct Obs {
     decltype(lz)* lz;
     bool on;
+    IpAhead* ipa;
+    Background* bg2;
+    const fe_t* dvec;
     static void fn(void* u, size_t round, const uint64_t r[4]) {
       Obs* o = (Obs*)u;
-      if (!o->on || round == 0 || round > o->lz->nvr) return;
-      memcpy(&o->lz->r[round - 1], r, 32);
-      if (round == o->lz->nvr) o->lz->publish(o->lz->state, 1);
+      if (!o->on || round == 0) return;
+      if (round <= o->lz->nvr) {
+        memcpy(&o->lz->r[round - 1], r, 32);
+        if (round == o->lz->nvr) o->lz->publish(o->lz->state, 1);
+        return;
+      }
+      IpAhead* ip = o->ipa;
+      if (!ip->hb || round < ip->first || round >= ip->first + ip->hb) return;
+      memcpy(&ip->left_r[round - ip->first], r, 32);
+      if (round + 1 == ip->first + ip->hb) {
+        const fe_t* dv = o->dvec;
+        o->bg2->submit([ip, dv] {
+          const std::vector<fe_t> left = eq_evals_host(ip->left_r, ip->hb);
+          ip->T.assign(ip->nright, fe_zero());
+          for (size_t a = 0; a < left.size(); ++a)
+            for (size_t b = 0; b < ip->nright; ++b) ip->T[b] = fe_add<S>(ip->T[b], fe_mul<S>(left[a], dv[a * ip->nright + b]));
+        });
+        ip->submitted = true;
+      }
     }
-  } obs{&lz, lz_ahead};
+  } obs{&lz, lz_ahead, &ipa, &ps.bg2, dvec.data()};
+  struct IpJoin {  // ipa and dvec outlive the job on every exit path
+    Background& b;
+    ~IpJoin() { b.wait_nothrow(); }
+  } ip_join{ps.bg2};
   ck(sp_sumcheck_quad_observed(ctx, u64p(&claim_inner_joint), num_rounds_y, ps.abc, ps.z, tr.t, &Obs::fn, &obs, u64p(inner_polys.data()), u64p(r_y.data()),
                                u64p(claims_inner)),
      "inner sum-check");
@@ -540,11 +622,21 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   } else if (lz_ahead) {
     // comm_LZ's MSM and the row-matrix product have been running since round nvr of the inner sum-check
     LZ.resize(lz_cols);
-    ps.bg.wait();
-    if (!lz.job || !lz.vec || !lz.delta_done) throw Error(SP_ERR_INTERNAL, "comm_LZ was not started");
-    lz_job = lz.job;
-    lz.job = nullptr;
-    r_LZ = lz.r_LZ;
+    if (lz_tables_path) {
+      // the helper delivers comm_LZ itself (one multi_mul over the prepared tables): join it only where comm_LZ is absorbed; what is needed before
+      // that (poly_com, delta) was finished under the inner sum-check
+      const auto t0 = std::chrono::steady_clock::now();
+      while (lz.early_done.load(std::memory_order_acquire) == 0) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) throw Error(SP_ERR_INTERNAL, "the PCS helper did not finish delta");
+        __builtin_ia32_pause();
+      }
+    } else {
+      ps.bg.wait();
+      if (!lz.job || !lz.vec || !lz.delta_done) throw Error(SP_ERR_INTERNAL, "comm_LZ was not started");
+      lz_job = lz.job;
+      lz.job = nullptr;
+      r_LZ = lz.r_LZ;
+    }
     lap("helper_join");
   } else {
     std::vector<fe_t> L = eq_evals_host(point, nvr);
@@ -557,7 +649,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   }
   aff_t comm_eval_W;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
-  ps.bg.wait();
+  if (!lz_tables_path) ps.bg.wait();
   ck(sp_transcript_absorb_prepared(tr.t, ps.poly_com), "poly_com");
   tr.dom_sep("inner product argument (linear)");
   const size_t n = (size_t)1 << (nvr == 0 ? npoint : npoint - nvr);  // |R|
@@ -566,7 +658,13 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t r_delta = tape.next(), r_beta = tape.next();
   // <R, d> (ipa.rs:148) with R = eq(point[nvr..]) = left (x) right: n + sqrt(n) products, R itself is never needed
   fe_t ip = fe_zero();
-  if (R.empty()) {
+  if (R.empty() && ipa.submitted) {
+    ps.bg2.wait();
+    const size_t k = npoint - nvr;
+    const std::vector<fe_t> right = eq_evals_host(point + nvr + ipa.hb, k - ipa.hb);
+    if (right.size() != ipa.T.size()) throw Error(SP_ERR_INTERNAL, "<R, d>: partial sums of the wrong width");
+    for (size_t b = 0; b < right.size(); ++b) ip = fe_add<S>(ip, fe_mul<S>(right[b], ipa.T[b]));
+  } else if (R.empty()) {
     const size_t k = npoint - nvr, hb = k / 2;
     const std::vector<fe_t> left = eq_evals_host(point + nvr, hb), right = eq_evals_host(point + nvr + hb, k - hb);
     for (size_t a = 0; a < left.size(); ++a) {
@@ -588,7 +686,12 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     ck(sp_msm_ck_finish(ctx, pk.ck, delta_job, u64p(&r_delta), u64p(&delta.x)), "delta (finish)");
   }
   lap("host_side_under_msm");
-  if (lz_job && lz_ahead) ck(sp_msm_job_finish(ctx, lz_job, u64p(&comm_LZ.x)), "comm_LZ (finish)");  // the blinds are inside the row commitments
+  if (lz_tables_path) {
+    ps.bg.wait();
+    if (!lz.have_comm_LZ || !lz.vec) throw Error(SP_ERR_INTERNAL, "comm_LZ was not delivered");
+    comm_LZ = lz.comm_LZ;
+    r_LZ = lz.r_LZ;
+  } else if (lz_job && lz_ahead) ck(sp_msm_job_finish(ctx, lz_job, u64p(&comm_LZ.x)), "comm_LZ (finish)");  // the blinds are inside the row commitments
   else if (lz_job) ck(sp_msm_ck_finish(ctx, pk.ck, lz_job, u64p(&r_LZ), u64p(&comm_LZ.x)), "comm_LZ (finish)");
   lap("comm_LZ_finish");
   {

@@ -272,3 +272,25 @@ def test_commit_small_device_form_matches_oracle(ctx, width):
     blind = ol.random_field_array(rng, 1)[0]
     for _ in range(3):
         assert (k.commit_small(ones, blind) == want(ones, blind)).all()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 33, 130, 429, 512])
+def test_fixed_base_tables_multi_mul_matches_oracle_msm(ctx, n):
+    """sp_fbtables_create + sp_fbtables_multi_mul (FixedBaseMul::precompute / multi_mul over arbitrary points, msm.rs:637-773; the one-launch form comm_LZ
+    of the opening uses on the row commitments of a prepared witness) against the oracle's MSM: dense scalars, zeros, repeated calls (sequence numbers),
+    eq-table weights as in the call site."""
+    rng = np.random.default_rng(SEED + 7700 + n)
+    pts = np.zeros((n, 8), dtype=np.uint64)
+    olib().orc_from_label(b"fbtables_test", ctypes.c_size_t(n), p64(pts))
+    t = hip.FixedBaseTables(ctx, pts)
+    for rep in range(3):
+        sc = ol.random_field_array(rng, n)
+        if rep == 1 and n > 2:
+            sc[::2] = 0
+        assert (t.multi_mul(sc) == oracle_msm(sc, np.ascontiguousarray(pts))).all()
+    with pytest.raises(hip.SpartanHipError):
+        t.multi_mul(ol.random_field_array(rng, n + 1))
+    t.close()
+    if n == 4:
+        with pytest.raises(hip.SpartanHipError):
+            hip.FixedBaseTables(ctx, np.zeros((513, 8), dtype=np.uint64))
