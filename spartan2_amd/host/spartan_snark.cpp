@@ -319,15 +319,16 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   // latency-bound rounds leave the device mostly idle (the outer sum-check's streaming rounds are left undisturbed).
   const size_t n_ipa = M < W_ ? M : W_;
   std::vector<fe_t> dvec(n_ipa);
-  fe_t r_delta_ahead;
+  fe_t r_delta_ahead, r_beta_ahead;
   {  // on the helper thread (1024 wide reductions, 70 us): nothing needs d_vec before delta's MSM is issued
     Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
     fe_t* dv = dvec.data();
     const size_t dn = dvec.size();
-    fe_t* rd = &r_delta_ahead;
-    ps.bg.submit([peek, dv, dn, rd]() mutable {
+    fe_t *rd = &r_delta_ahead, *rb = &r_beta_ahead;
+    ps.bg.submit([peek, dv, dn, rd, rb]() mutable {
       for (size_t i = 0; i < dn; ++i) dv[i] = peek.next();
       *rd = peek.next();  // ipa.rs:146: the blind of delta follows d_vec on the tape
+      *rb = peek.next();  // then beta's
     });
   }
   struct DrawJoin {  // dvec must outlive the job on every exit path
@@ -539,15 +540,30 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   // |right| products instead of |R| + |left| after the last round
   struct IpAhead {
     size_t first = 0, hb = 0, nright = 0;  // left = eq(r_y[first .. first + hb))
-    fe_t left_r[16];
+    fe_t left_r[16], right_r[16];
     std::vector<fe_t> T;
     bool submitted = false;
+    // ... and once the last challenge is drawn the same job finishes <R, d> and beta = <R, d> ck_c + r_beta h_c (ipa.rs:148-149) beside the prover's
+    // own work on eval_W; it waits for that challenge with a short bounded spin
+    std::atomic<int> right_ready{0};
+    size_t nright_vars = 0, last_round = 0;
+    fe_t r_beta, ip;
+    aff_t beta;
+    bool beta_ready = false;
+    sp_ctx* ctx = nullptr;
+    const sp_ck* ck_s = nullptr;
   } ipa;
+  ipa.r_beta = r_beta_ahead;
+  ipa.ctx = ctx;
+  ipa.ck_s = pk.ck_s;
   if (lz_ahead) {
     const size_t k = (num_rounds_y - 1) - lz_nvr;
     ipa.first = 1 + lz_nvr;
     ipa.hb = k / 2;
     ipa.nright = (size_t)1 << (k - ipa.hb);
+    ipa.nright_vars = k - ipa.hb;
+    ipa.last_round = num_rounds_y - 1;
+    if (ipa.nright_vars > 16) ipa.hb = 0;
     if (ipa.hb == 0 || ipa.hb > 16 || (((size_t)1 << ipa.hb) * ipa.nright) != n_ipa) ipa.hb = 0;  // (not this shape: the prover computes <R, d> itself)
   }
   struct Obs {
@@ -565,7 +581,12 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
         return;
       }
       IpAhead* ip = o->ipa;
-      if (!ip->hb || round < ip->first || round >= ip->first + ip->hb) return;
+      if (!ip->hb || round < ip->first) return;
+      if (round >= ip->first + ip->hb) {
+        memcpy(&ip->right_r[round - ip->first - ip->hb], r, 32);
+        if (round == ip->last_round) ip->right_ready.store(1, std::memory_order_release);
+        return;
+      }
       memcpy(&ip->left_r[round - ip->first], r, 32);
       if (round + 1 == ip->first + ip->hb) {
         const fe_t* dv = o->dvec;
@@ -574,6 +595,17 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
           ip->T.assign(ip->nright, fe_zero());
           for (size_t a = 0; a < left.size(); ++a)
             for (size_t b = 0; b < ip->nright; ++b) ip->T[b] = fe_add<S>(ip->T[b], fe_mul<S>(left[a], dv[a * ip->nright + b]));
+          const auto t0 = std::chrono::steady_clock::now();
+          while (ip->right_ready.load(std::memory_order_acquire) == 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return;  // (the prover finishes <R, d> and beta itself)
+            __builtin_ia32_pause();
+          }
+          const std::vector<fe_t> right = eq_evals_host(ip->right_r, ip->nright_vars);
+          fe_t acc = fe_zero();
+          for (size_t b = 0; b < right.size(); ++b) acc = fe_add<S>(acc, fe_mul<S>(right[b], ip->T[b]));
+          ip->ip = acc;
+          ck(sp_hyrax_commit_small(ip->ctx, ip->ck_s, u64p(&ip->ip), 1, u64p(&ip->r_beta), u64p(&ip->beta.x)), "beta");
+          ip->beta_ready = true;
         });
         ip->submitted = true;
       }
@@ -658,8 +690,18 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t r_delta = tape.next(), r_beta = tape.next();
   // <R, d> (ipa.rs:148) with R = eq(point[nvr..]) = left (x) right: n + sqrt(n) products, R itself is never needed
   fe_t ip = fe_zero();
+  aff_t delta, beta;
+  bool have_beta = false;
   if (R.empty() && ipa.submitted) {
     ps.bg2.wait();
+    if (ipa.beta_ready && memcmp(&ipa.r_beta, &r_beta, sizeof(fe_t)) == 0) {
+      ip = ipa.ip;
+      beta = ipa.beta;
+      have_beta = true;
+    }
+  }
+  if (have_beta) {
+  } else if (R.empty() && ipa.submitted) {
     const size_t k = npoint - nvr;
     const std::vector<fe_t> right = eq_evals_host(point + nvr + ipa.hb, k - ipa.hb);
     if (right.size() != ipa.T.size()) throw Error(SP_ERR_INTERNAL, "<R, d>: partial sums of the wrong width");
@@ -675,8 +717,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   } else {
     for (size_t i = 0; i < n; ++i) ip = fe_add<S>(ip, fe_mul<S>(R[i], dvec[i]));
   }
-  aff_t delta, beta;
-  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
+  if (!have_beta) ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
   if (lz_ahead) {
     delta = lz.delta;  // finished by the helper with the blind peeked from the same tape position
     if (memcmp(&r_delta, &lz.r_delta, sizeof(fe_t)) != 0) throw Error(SP_ERR_INTERNAL, "tape positions of r_delta disagree");
@@ -715,7 +756,24 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     lz.vec = nullptr;
     ck(sp_rowmat_vec_eq_finish(ctx, vj, u64p(LZ.data())), "bind_with_delayed (finish)");
   }
-  for (size_t i = 0; i < n; ++i) proof.pf(fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]));
+  {
+    // z_vec = r * LZ + d (ipa.rs:160-163): the last step of the prove, split three ways with the two helper threads when it is wide enough to pay
+    std::vector<fe_t> zv(n);
+    auto part = [&zv, &LZ, &dvec, rr](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) zv[i] = fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]);
+    };
+    if (n >= 1024 && lz_ahead) {
+      const size_t a = n * 46 / 100, b = a + (n - a) / 2;  // the owner starts at once, the helpers have to wake up first
+      ps.bg.submit([&part, a, b] { part(a, b); });
+      ps.bg2.submit([&part, b, n] { part(b, n); });
+      part(0, a);
+      ps.bg.wait();
+      ps.bg2.wait();
+    } else {
+      part(0, n);
+    }
+    proof.words.insert(proof.words.end(), u64p(zv.data()), u64p(zv.data()) + 4 * n);
+  }
   proof.pf(fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta));
   proof.pf(fe_add<S>(fe_mul<S>(rr, blind_eval_W), r_beta));
   lap("z_vec");
