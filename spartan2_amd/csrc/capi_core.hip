@@ -166,6 +166,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->h_pinned_fb) hipHostFree(c->h_pinned_fb);
   if (c->h_pinned_fbs) hipHostFree(c->h_pinned_fbs);
   if (c->h_mm) hipHostFree(c->h_mm);
+  for (void* p_ : c->h_fbm)
+    if (p_) hipHostFree(p_);
   if (c->d_mm_work) hipFree(c->d_mm_work);
   if (c->h_stage) hipHostFree(c->h_stage);
   for (hipEvent_t e : c->stage_ev)

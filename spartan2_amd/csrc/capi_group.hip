@@ -457,14 +457,76 @@ static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, con
 static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU core beats the launch + single-wave latency
 
 // table[i % ntables] * scalars[i] on the device (Jacobian results in host memory); ntables == 1 for h
+// <= 128 scalars through mapped memory (kernels_msm.cuh k_fixed_base_rows_coop_mapped): launch on lane 0 = the main stream / lane 1 = the auxiliary stream,
+// then poll the n self-validating result slots. SPARTAN_FB_MAPPED=0 keeps the copy / launch / copy / synchronise form.
+static const size_t FB_MAPPED_MAX = 128;
+static bool fb_mapped_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_FB_MAPPED");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n) {
+  const size_t bytes = FB_MAPPED_MAX * 128 + FB_MAPPED_MAX * sizeof(fe_t);
+  if (!c->h_fbm[lane]) {
+    SP_HIP(hipHostMalloc(&c->h_fbm[lane], bytes, hipHostMallocMapped));
+    memset(c->h_fbm[lane], 0, bytes);
+    SP_HIP(hipHostGetDevicePointer(&c->d_fbm[lane], c->h_fbm[lane], 0));
+  }
+  memcpy((char*)c->h_fbm[lane] + FB_MAPPED_MAX * 128, scalars, n * sizeof(fe_t));
+  if (++c->fbm_seq[lane] == 0) ++c->fbm_seq[lane];
+  hipStream_t st = lane ? c->stream2 : c->stream;
+  c->timed_on(st, "fixed_base", 32ull * n, [&] {
+    hipLaunchKernelGGL(spk::k_fixed_base_rows_coop_mapped, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st,
+                       reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * 128), n, d_tables, ntables, reinterpret_cast<unsigned*>(c->d_fbm[lane]),
+                       c->fbm_seq[lane]);
+  });
+  return SP_OK;
+}
+static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, jac_t* out) {
+  const unsigned seq = c->fbm_seq[lane];
+  hipStream_t st = lane ? c->stream2 : c->stream;
+  bool synced = false;
+  for (size_t i = 0; i < n; ++i) {
+    volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>((char*)c->h_fbm[lane] + 128 * i);
+    unsigned w[24];
+    for (long spins = 0;; ++spins) {
+      if (slot[24] == seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        unsigned a = seq, b = seq * 0x9E3779B1u;
+        for (int k = 0; k < 24; ++k) {
+          w[k] = slot[k];
+          a += w[k];
+          b += (unsigned)(k + 1) * w[k];
+        }
+        if (slot[24] == seq && slot[25] == a && slot[26] == b && slot[27] == seq) break;
+      }
+      if (spins > 4000000) {
+        if (synced) return fail(SP_ERR_INTERNAL, "fixed-base rows: the kernel did not deliver a result slot");
+        SP_HIP(hipStreamSynchronize(st));  // e.g. under a profiler
+        synced = true;
+        spins = 0;
+      }
+      __builtin_ia32_pause();
+    }
+    memcpy(&out[i], w, sizeof(jac_t));
+  }
+  return SP_OK;
+}
+
 static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n, std::vector<jac_t>& out) {
   out.assign(n, jac_identity());
   if (n == 0) return SP_OK;
   fe_t* ds = (fe_t*)c->workspace(sp_ctx::WS_FB_SCALARS, n * sizeof(fe_t));
   jac_t* dout = (jac_t*)c->workspace(sp_ctx::WS_FB_OUT, n * sizeof(jac_t));
   if (!ds || !dout) return SP_ERR_NO_DEVICE;
+  if (n <= FB_MAPPED_MAX && fb_mapped_enabled()) {  // the latency case (one call per round of the ZK verifier circuit): no copies, no synchronise
+    int rc = fb_mapped_launch(c, 0, d_tables, ntables, scalars, n);
+    return rc ? rc : fb_mapped_collect(c, 0, n, out.data());
+  }
   if (n <= 1024) {
-    // the latency case (one call per round of the ZK verifier circuit): both copies through pinned memory, so neither stages through a bounce buffer
+    // both copies through pinned memory, so neither stages through a bounce buffer
     if (!c->h_pinned_fbs) SP_HIP(hipHostMalloc(&c->h_pinned_fbs, 1024 * (sizeof(jac_t) + sizeof(fe_t))));
     jac_t* hp = (jac_t*)c->h_pinned_fbs;
     fe_t* hs = (fe_t*)((char*)c->h_pinned_fbs + 1024 * sizeof(jac_t));
@@ -488,7 +550,7 @@ static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, con
 struct sp_fb_job {
   size_t n = 0;
   std::vector<jac_t> host_pts;  // filled directly for small n
-  bool on_device = false;
+  bool on_device = false, mapped = false;
   jac_t* pinned = nullptr;
 };
 int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_fb_job** out) {
@@ -501,6 +563,13 @@ int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalar
       memcpy(&sc, scalars + 4 * i, 32);
       job->host_pts[i] = fixed_base_mul_host(ck->host_htable(), sc);
     }
+  } else if (n <= FB_MAPPED_MAX && fb_mapped_enabled()) {
+    int rc = fb_mapped_launch(c, 1, ck->d_htable, 1, scalars, n);
+    if (rc) {
+      delete job;
+      return rc;
+    }
+    job->mapped = true;
   } else {
     if (n * sizeof(jac_t) > 4096 * sizeof(jac_t)) {
       delete job;
@@ -528,7 +597,14 @@ int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalar
 }
 int sp_fixed_base_mul_h_finish(sp_ctx* c, sp_fb_job* job, uint64_t* out_aff) {
   std::vector<jac_t> pts;
-  if (job->on_device) {
+  if (job->mapped) {
+    pts.resize(job->n);
+    int rc = fb_mapped_collect(c, 1, job->n, pts.data());
+    if (rc) {
+      delete job;
+      return rc;
+    }
+  } else if (job->on_device) {
     SP_HIP(hipEventSynchronize(c->fb_event()));
     pts.assign(job->pinned, job->pinned + job->n);
   } else {

@@ -50,6 +50,11 @@ struct sp_ctx {
   void* h_pinned_fbs = nullptr;  // pinned staging of the synchronous fixed-base calls (<= 1024 scalars: the per-round commitments of the ZK verifier circuit)
   // one-launch FixedBaseMul::multi_mul (sp_fbtables_multi_mul, kernels_msm.cuh k_multi_mul_coop): mapped pinned pages (result slot at byte 0, scalars
   // at byte 256), their device-side address, device scratch (ticket + block sums) and the sequence number of the result in flight
+  // mapped pages of the <= 128-scalar fixed-base calls (k_fixed_base_rows_coop_mapped): [0] the synchronous calls on the main stream, [1] the job on the
+  // auxiliary stream; each = 128 result slots of 128 B, then 128 scalars
+  void* h_fbm[2] = {nullptr, nullptr};
+  void* d_fbm[2] = {nullptr, nullptr};
+  unsigned fbm_seq[2] = {0, 0};
   void* h_mm = nullptr;
   void* d_mm = nullptr;
   void* d_mm_work = nullptr;

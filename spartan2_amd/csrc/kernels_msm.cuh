@@ -715,6 +715,49 @@ __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __
   if (role == 0 && j == 0 && idx < n) out[idx] = xyzz_to_jac(s[k]);
 }
 
+// k_fixed_base_rows_coop with its inputs and outputs in mapped host memory (<= 128 scalars: a round commitment of the ZK verifier circuit, the blinds of
+// the zero rows): the scalars are read through the bus, scalar i's Jacobian result goes into slot i (32 words: 0..23 the point, 24 = sequence,
+// 25 = sequence + plain sum, 26 = sequence * K + position-weighted sum, 27 = sequence) which the host polls - no copy launch on either side and no
+// stream synchronise around a 50 us kernel.
+__global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop_mapped(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
+                                                                         unsigned* __restrict__ slots, unsigned seq) {
+  __shared__ CoopAdd<128> L;
+  __shared__ xyzz_t s[128];
+  const int wave = threadIdx.x >> 6, blk = wave >> 2;
+  const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);
+  const size_t idx = (size_t)blockIdx.x * 4 + (k >> 5);
+  const int j = k & 31;
+  if (role == 0) {
+    xyzz_t acc = xyzz_identity();
+    if (idx < n) {
+      const fe_t c = fe_to_canonical<SF>(scalars[idx]);
+      const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      if (digit) acc = xyzz_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
+    }
+    s[k] = acc;
+  }
+  __syncthreads();
+  for (int off = 16; off >= 1; off >>= 1) {
+    const bool active = j < off;
+    xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+  }
+  if (role == 0 && j == 0 && idx < n) {
+    const jac_t r = xyzz_to_jac(s[k]);
+    const unsigned* rw = reinterpret_cast<const unsigned*>(&r);
+    unsigned* slot = slots + idx * 32;
+    unsigned a = seq, b = seq * 0x9E3779B1u;
+#pragma unroll
+    for (int w = 0; w < 24; ++w) {
+      slot[w] = rw[w];
+      a += rw[w];
+      b += (unsigned)(w + 1) * rw[w];
+    }
+    const unsigned long long lo = ((unsigned long long)a << 32) | seq, hi = ((unsigned long long)seq << 32) | b;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 26), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 24), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // FixedBaseMul::multi_mul (msm.rs:727-773) over per-base tables, sum_i s_i P_i, in ONE launch with no copy on either side and no host-side tail — the
 // latency form behind sp_fbtables_multi_mul. Its call site is comm_LZ of the Hyrax opening (hyrax_pc.rs:387-478): the commitment of L^T W equals
 // sum_i L_i * comm_W[i], the rows of comm_W are known when the witness is prepared, so their window tables are built there and the 512-point MSM
