@@ -477,10 +477,16 @@ static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t n
   memcpy((char*)c->h_fbm[lane] + FB_MAPPED_MAX * 128, scalars, n * sizeof(fe_t));
   if (++c->fbm_seq[lane] == 0) ++c->fbm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
+  static const bool wide = [] {  // SPARTAN_FB_ITEMS=128: four scalars per 512-thread block (two waves per SIMD)
+    const char* e = getenv("SPARTAN_FB_ITEMS");
+    return e && atoi(e) == 128;
+  }();
+  const fe_t* ds = reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * 128);
+  unsigned* dslots = reinterpret_cast<unsigned*>(c->d_fbm[lane]);
+  const unsigned seq = c->fbm_seq[lane];
   c->timed_on(st, "fixed_base", 32ull * n, [&] {
-    hipLaunchKernelGGL(spk::k_fixed_base_rows_coop_mapped, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st,
-                       reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * 128), n, d_tables, ntables, reinterpret_cast<unsigned*>(c->d_fbm[lane]),
-                       c->fbm_seq[lane]);
+    if (wide) hipLaunchKernelGGL(spk::k_fixed_base_rows_coop_mapped<128>, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, d_tables, ntables, dslots, seq);
+    else hipLaunchKernelGGL(spk::k_fixed_base_rows_coop_mapped<64>, dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
   });
   return SP_OK;
 }

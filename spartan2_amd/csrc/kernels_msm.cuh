@@ -719,13 +719,17 @@ __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __
 // the zero rows): the scalars are read through the bus, scalar i's Jacobian result goes into slot i (32 words: 0..23 the point, 24 = sequence,
 // 25 = sequence + plain sum, 26 = sequence * K + position-weighted sum, 27 = sequence) which the host polls - no copy launch on either side and no
 // stream synchronise around a 50 us kernel.
-__global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop_mapped(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
-                                                                         unsigned* __restrict__ slots, unsigned seq) {
-  __shared__ CoopAdd<128> L;
-  __shared__ xyzz_t s[128];
+// ITEMS = 64: two scalars per 256-thread block, ONE wave per role, so each of the four products of a level has a SIMD to itself. The products are
+// issue-bound (v_mad_u64_u32 at quarter rate: ~136 of them per Montgomery product whatever the number of active lanes), so the 128-item form - two
+// waves per SIMD, both issuing full-length products even when a tree level has two active lanes left - takes twice as long per level.
+template <int ITEMS>
+__global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
+                                                                           unsigned* __restrict__ slots, unsigned seq) {
+  __shared__ CoopAdd<ITEMS> L;
+  __shared__ xyzz_t s[ITEMS];
   const int wave = threadIdx.x >> 6, blk = wave >> 2;
   const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);
-  const size_t idx = (size_t)blockIdx.x * 4 + (k >> 5);
+  const size_t idx = (size_t)blockIdx.x * (ITEMS / 32) + (k >> 5);
   const int j = k & 31;
   if (role == 0) {
     xyzz_t acc = xyzz_identity();
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop_mapped(const f
   __syncthreads();
   for (int off = 16; off >= 1; off >>= 1) {
     const bool active = j < off;
-    xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+    xyzz_add_block4<ITEMS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
   if (role == 0 && j == 0 && idx < n) {
     const jac_t r = xyzz_to_jac(s[k]);
