@@ -321,6 +321,7 @@ void sp_table_free(sp_table* t) {
 
 // bind up to 4 tables with one launch
 static int launch_bind(sp_ctx* c, sp_table** tabs, int nt, const fe_t& r) {
+  if (nt > spk::BIND_MAX_TABLES) return fail(SP_ERR_INTERNAL, "launch_bind: too many tables");
   spk::BindArgs a;
   size_t max_eff = 0;
   uint64_t bytes = 0;
@@ -1368,10 +1369,8 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
     store_fe(out_r + 4 * i, r_i);
     claim[0] = poly_eval(poly[0], r_i);
     claim[1] = poly_eval(poly[1], r_i);
-    sp_table* t1[4] = {A_step, A_core, B_step, B_core};
-    sp_table* t2[2] = {C_step, C_core};
-    if ((rc = launch_bind(c, t1, 4, r_i))) return rc;
-    if ((rc = launch_bind(c, t2, 2, r_i))) return rc;
+    sp_table* t6[6] = {A_step, A_core, B_step, B_core, C_step, C_core};
+    if ((rc = launch_bind(c, t6, 6, r_i))) return rc;
     len_pow_tau >>= 1;
     const fe_t pw = fe_mul<S>(pl[len_pow_tau % left], pr[len_pow_tau / left]);
     base_tau = fe_mul<S>(base_tau, fe_add<S>(fe_mul<S>(fe_sub<S>(pw, one), r_i), one));

@@ -404,10 +404,106 @@ SP_HD fe_t fe_pow(const fe_t& x, const uint32_t e[8]) {
   }
   return acc;
 }
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Host-side inversion by the binary extended Euclidean algorithm on 4 x u64 (the host normalises a point per commitment and per MSM, and the prover
+// divides by 1 - r_y[0]: Fermat's 256 squarings + ~150 products cost 13 us, this about a third). Variable time: every value inverted here is public
+// (proof elements, transcript challenges). Same canonical result as Fermat; inv(0) == 0.
 template <class FP>
-SP_HD fe_t fe_inv(const fe_t& x) {  // Fermat; inv(0) == 0
+inline fe_t fe_inv_host_xgcd(const fe_t& x) {
+  typedef unsigned __int128 u128;
+  struct U4 {
+    uint64_t w[4];
+  };
+  auto is_zero = [](const U4& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; };
+  auto is_one = [](const U4& a) { return a.w[0] == 1 && (a.w[1] | a.w[2] | a.w[3]) == 0; };
+  auto geq = [](const U4& a, const U4& b) {
+    for (int i = 3; i >= 0; --i) {
+      if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+    }
+    return true;
+  };
+  auto sub = [](U4& a, const U4& b) {  // a -= b (a >= b)
+    u128 bw = 0;
+    for (int i = 0; i < 4; ++i) {
+      u128 d = (u128)a.w[i] - b.w[i] - (uint64_t)bw;
+      a.w[i] = (uint64_t)d;
+      bw = (d >> 64) & 1;
+    }
+  };
+  auto shr1 = [](U4& a, uint64_t top) {  // (top : a) >> 1
+    for (int i = 0; i < 3; ++i) a.w[i] = (a.w[i] >> 1) | (a.w[i + 1] << 63);
+    a.w[3] = (a.w[3] >> 1) | (top << 63);
+  };
+  U4 P, u, v, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
+  for (int i = 0; i < 4; ++i) {
+    P.w[i] = (uint64_t)FP::P(2 * i) | ((uint64_t)FP::P(2 * i + 1) << 32);
+    u.w[i] = (uint64_t)x.v[2 * i] | ((uint64_t)x.v[2 * i + 1] << 32);
+  }
+  if (is_zero(u)) return x;
+  v = P;
+  auto halve_mod = [&](U4& a) {  // a / 2 mod p
+    uint64_t top = 0;
+    if (a.w[0] & 1) {
+      u128 c = 0;
+      for (int i = 0; i < 4; ++i) {
+        c += (u128)a.w[i] + P.w[i];
+        a.w[i] = (uint64_t)c;
+        c >>= 64;
+      }
+      top = (uint64_t)c;
+    }
+    shr1(a, top);
+  };
+  auto sub_mod = [&](U4& a, const U4& b) {  // a = a - b mod p
+    if (geq(a, b)) {
+      sub(a, b);
+    } else {  // a + p - b
+      U4 t = P;
+      sub(t, b);  // p - b (b < p)
+      u128 c = 0;
+      for (int i = 0; i < 4; ++i) {
+        c += (u128)a.w[i] + t.w[i];
+        a.w[i] = (uint64_t)c;
+        c >>= 64;
+      }
+    }
+  };
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u.w[0] & 1)) {
+      shr1(u, 0);
+      halve_mod(x1);
+    }
+    while (!(v.w[0] & 1)) {
+      shr1(v, 0);
+      halve_mod(x2);
+    }
+    if (geq(u, v)) {
+      sub(u, v);
+      sub_mod(x1, x2);
+    } else {
+      sub(v, u);
+      sub_mod(x2, x1);
+    }
+  }
+  const U4& inv_raw = is_one(u) ? x1 : x2;  // (x R)^-1 as a plain residue = x^-1 R^-1
+  fe_t y, r2, r3;
+  for (int i = 0; i < 4; ++i) {
+    y.v[2 * i] = (uint32_t)inv_raw.w[i];
+    y.v[2 * i + 1] = (uint32_t)(inv_raw.w[i] >> 32);
+  }
+  for (int i = 0; i < 8; ++i) r2.v[i] = FP::R2(i);
+  r3 = fe_mul_host64<FP>(r2, r2);   // R^2 R^2 / R = R^3
+  return fe_mul_host64<FP>(y, r3);  // x^-1 R^-1 R^3 / R = x^-1 R
+}
+#endif
+template <class FP>
+SP_HD fe_t fe_inv(const fe_t& x) {  // inv(0) == 0; device: Fermat
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return fe_inv_host_xgcd<FP>(x);
+#else
   uint32_t e[8], bw = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) e[i] = sp_subb(FP::P(i), i == 0 ? 2u : 0u, bw);
   return fe_pow<FP>(x, e);
+#endif
 }

@@ -139,12 +139,13 @@ __device__ __forceinline__ fe_t challenge_or(const MailRef& m, const fe_t& r_arg
   return r_sh;
 }
 
-// ---- K1: bind the top variable of up to 4 tables with the same challenge -----------------------------------
+// ---- K1: bind the top variable of up to 8 tables with the same challenge -----------------------------------
+constexpr int BIND_MAX_TABLES = 8;  // (the six tables of a batched outer round go in one launch)
 struct BindArgs {
-  fe_t* z[4];
-  unsigned long long n[4];   // half length of each table
-  unsigned long long lo[4];  // min(lo_eff, n)
-  unsigned long long hi[4];  // min(hi_eff, n)
+  fe_t* z[BIND_MAX_TABLES];
+  unsigned long long n[BIND_MAX_TABLES];   // half length of each table
+  unsigned long long lo[BIND_MAX_TABLES];  // min(lo_eff, n)
+  unsigned long long hi[BIND_MAX_TABLES];  // min(hi_eff, n)
   fe_t r;
   fe_t one_minus_r;
 };

@@ -712,6 +712,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   Uv_X.insert(Uv_X.end(), vpub.begin(), vpub.end());
   for (const auto& b : vst.blind_per_round) Wv_r.insert(Wv_r.end(), b.begin(), b.end());
   lap("(up to the vc instance)");
+  if (laps) fprintf(stderr, "nn_prove: process_round totals: synthesis %.3f ms, commitments %.3f ms, transcript %.3f ms over %zu rounds\n", vst.synth_ms, vst.commit_ms, vst.hash_ms, vst.current);
   // sample_random_instance_witness (src/r1cs/mod.rs:474-531) on the verifier-circuit shape
   const size_t vnv = vs.total_vars, vcons = vs.num_cons, vio = vs.num_io();
   if (t_rnd) ps.wk.wait(t_rnd);

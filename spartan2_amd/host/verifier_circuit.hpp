@@ -325,6 +325,7 @@ struct State {  // MultiRoundState (bellpepper/r1cs.rs:695-707)
   std::vector<fe_t> w;
   size_t current = 0;
   double commit_ms = 0;  // wall time inside the per-round commitments (reported as a phase of its own)
+  double synth_ms = 0, hash_ms = 0;  // diagnostics (SPARTAN_HOST_LAPS): synthesis of the rounds, transcript work of process_round
   size_t commits = 0;
   explicit State(const Shape& s) : w(s.total_vars, fe_zero()) {}
 };
@@ -333,6 +334,7 @@ static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shap
   if (round != st.current) throw Error(SP_ERR_INTERNAL, "process_round: rounds out of order");
   const fe_t* chal = (round > 0 && !st.challenges[round - 1].empty()) ? &st.challenges[round - 1][0] : nullptr;
   std::vector<Num> v, c;
+  const auto ts0 = std::chrono::steady_clock::now();
   vc.rounds(st.cs, round, st.vars_per_round, st.chal_vars_per_round, chal, &v, &c);
   size_t su = 0, sp_ = 0;
   for (size_t r = 0; r < round; ++r) {
@@ -345,10 +347,12 @@ static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shap
   for (auto& b : blinds) b = tape.next();
   std::vector<aff_t> comm(rows);
   const auto tc0 = std::chrono::steady_clock::now();
+  st.synth_ms += std::chrono::duration<double, std::milli>(tc0 - ts0).count();
   for (size_t r = 0; r < rows; ++r)
     ck(sp_hyrax_commit_small(ctx, vc_ck, u64p(st.w.data() + sp_ + r * s.width), s.width, u64p(&blinds[r]), u64p(&comm[r].x)), "commit round witness");
   st.commit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
   st.commits += rows;
+  const auto th0 = std::chrono::steady_clock::now();
   const std::vector<uint8_t> b = commitment_bytes(comm.data(), rows);
   tr.absorb("comm_w_round", b.data(), b.size());
   std::vector<fe_t> out(s.chals_per_round[round]);
@@ -359,6 +363,7 @@ static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shap
   st.blind_per_round.push_back(blinds);
   st.challenges.push_back(out);
   st.current++;
+  st.hash_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
   return out;
 }
 

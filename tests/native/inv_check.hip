@@ -1,0 +1,61 @@
+// Host-only check (no GPU needed): the binary extended-GCD inversion of the host side (field.cuh fe_inv_host_xgcd) against Fermat's little theorem
+// (fe_pow with p - 2) and against x * inv(x) == 1, for both fields: edge values and seeded random residues. Built and run by tests/test_field_host.py.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../spartan2_amd/csrc/field.cuh"
+
+#if !defined(__HIP_DEVICE_COMPILE__)  // (the host-side inversion does not exist in the device pass)
+template <class FP>
+static fe_t fermat(const fe_t& x) {
+  uint32_t e[8], bw = 0;
+  for (int i = 0; i < 8; ++i) e[i] = sp_subb(FP::P(i), i == 0 ? 2u : 0u, bw);
+  return fe_pow<FP>(x, e);
+}
+template <class FP>
+static int check(const char* name, int n) {
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto next = [&] {
+    st ^= st << 13;
+    st ^= st >> 7;
+    st ^= st << 17;
+    return st;
+  };
+  int bad = 0;
+  const fe_t one = fe_one<FP>();
+  for (int k = 0; k < n; ++k) {
+    fe_t x;
+    if (k == 0) x = fe_zero();
+    else if (k == 1) x = one;
+    else if (k == 2) x = fe_neg<FP>(one);
+    else if (k == 3) x = fe_from_u64<FP>(2);
+    else if (k < 40) x = fe_from_u64<FP>(next() >> (k & 63));
+    else {
+      uint8_t b[64];
+      for (int i = 0; i < 8; ++i) {
+        uint64_t w = next();
+        memcpy(b + 8 * i, &w, 8);
+      }
+      x = fe_from_uniform<FP>(b);
+    }
+    const fe_t a = fe_inv_host_xgcd<FP>(x), f = fermat<FP>(x);
+    bool ok = fe_eq(a, f);
+    if (!fe_is_zero(x)) ok = ok && fe_eq(fe_mul<FP>(a, x), one);
+    else ok = ok && fe_is_zero(a);
+    if (!ok) {
+      if (bad < 5) fprintf(stderr, "%s: mismatch at sample %d\n", name, k);
+      ++bad;
+    }
+  }
+  printf("%s: %d samples, %d mismatches\n", name, n, bad);
+  return bad;
+}
+#endif
+int main(int argc, char** argv) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  const int n = argc > 1 ? atoi(argv[1]) : 20000;
+  return (check<FqP>("scalar field", n) + check<FpP>("base field", n)) ? 1 : 0;
+#else
+  return 0;
+#endif
+}

@@ -1,0 +1,19 @@
+"""Host side of the library's field arithmetic, without a GPU: the binary extended-GCD inversion (spartan2_amd/csrc/field.cuh fe_inv_host_xgcd — every
+normalisation of a point on the host and the prover's division by 1 - r_y[0] go through it) against Fermat's little theorem and x * inv(x) == 1, on
+edge values and seeded random residues of both fields (tests/native/inv_check.hip, compiled here with hipcc: host code only, nothing is launched)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_host_inversion_matches_fermat(tmp_path):
+    exe = str(tmp_path / "inv_check")
+    subprocess.run(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-o", exe, os.path.join(HERE, "native", "inv_check.hip")], check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "scalar field: 20000 samples, 0 mismatches" in out.stdout and "base field: 20000 samples, 0 mismatches" in out.stdout
