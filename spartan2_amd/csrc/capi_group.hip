@@ -387,6 +387,8 @@ int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, 
   return SP_OK;
 }
 
+static bool fb_mapped_enabled();
+static int fb_mapped_ensure(sp_ctx* c, int lane);
 int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint64_t h_aff[8], sp_ck** out) {
   if (num_cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_ck_create: empty key");
   sp_ck* k = new sp_ck();
@@ -409,6 +411,7 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
   }
   hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), ntab * per, tables);
   SP_HIP(hipStreamSynchronize(c->stream));
+  if (fb_mapped_enabled() && ((rc = fb_mapped_ensure(c, 0)) || (rc = fb_mapped_ensure(c, 1)))) return rc;
   k->n_tables = ntab;
   k->h_tables.resize(ntab * per);
   SP_HIP(hipMemcpy(k->h_tables.data(), tables, ntab * per * sizeof(aff_t), hipMemcpyDeviceToHost));
@@ -467,13 +470,20 @@ static bool fb_mapped_enabled() {
   }();
   return on;
 }
-static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n) {
+// (allocated when a key is created, not inside a prove: an allocation call can wait for the device, and with it for resident kernels of other contexts
+// that are themselves waiting for host threads the call may be holding up)
+static int fb_mapped_ensure(sp_ctx* c, int lane) {
   const size_t bytes = FB_MAPPED_MAX * 128 + FB_MAPPED_MAX * sizeof(fe_t);
   if (!c->h_fbm[lane]) {
     SP_HIP(hipHostMalloc(&c->h_fbm[lane], bytes, hipHostMallocMapped));
     memset(c->h_fbm[lane], 0, bytes);
     SP_HIP(hipHostGetDevicePointer(&c->d_fbm[lane], c->h_fbm[lane], 0));
   }
+  return SP_OK;
+}
+static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n) {
+  int erc = fb_mapped_ensure(c, lane);
+  if (erc) return erc;
   memcpy((char*)c->h_fbm[lane] + FB_MAPPED_MAX * 128, scalars, n * sizeof(fe_t));
   if (++c->fbm_seq[lane] == 0) ++c->fbm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
@@ -1084,8 +1094,13 @@ struct sp_fbtables {
   size_t n = 0;
   aff_t* d_tables = nullptr;  // n x 32 x 255 affine multiples
 };
+static int multi_mul_ensure(sp_ctx* c);
 int sp_fbtables_create(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtables** out) {
   if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_create: 1 .. 512 points");
+  {
+    int erc = multi_mul_ensure(c);
+    if (erc) return erc;
+  }
   const size_t per = 32 * 255;
   DevBuf pts, tj;
   int rc;
@@ -1117,8 +1132,7 @@ void sp_fbtables_free(sp_fbtables* t) {
 // sp_msm_eq_begin): scalars and result through mapped pinned pages, no copies, no host-side tail (kernels_msm.cuh k_multi_mul_coop). The caller polls
 // the self-validating result slot; a poll that runs long (profiler, debugger) falls back to a stream synchronise, after which the slot must be valid.
 // _begin launches, _finish polls (one multiplication in flight per context).
-int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n) {
-  if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
+static int multi_mul_ensure(sp_ctx* c) {  // (done by sp_fbtables_create: see fb_mapped_ensure)
   const size_t page = 256 + 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
   if (!c->h_mm) {
     SP_HIP(hipHostMalloc(&c->h_mm, page, hipHostMallocMapped));
@@ -1126,7 +1140,14 @@ int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t*
     SP_HIP(hipHostGetDevicePointer(&c->d_mm, c->h_mm, 0));
     SP_HIP(hipMalloc(&c->d_mm_work, 256 + spk::MULTI_MUL_MAX_BLOCKS * sizeof(xyzz_t)));
     SP_HIP(hipMemsetAsync(c->d_mm_work, 0, 256, c->stream2));  // the ticket; every launch leaves it at zero again
+    SP_HIP(hipStreamSynchronize(c->stream2));
   }
+  return SP_OK;
+}
+int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n) {
+  if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
+  int erc = multi_mul_ensure(c);
+  if (erc) return erc;
   memcpy((char*)c->h_mm + 256, scalars, n * sizeof(fe_t));
   if (++c->mm_seq == 0) ++c->mm_seq;
   c->timed_on(c->stream2, "multi_mul", 32ull * n, [&] {

@@ -24,6 +24,8 @@ def test_eight_proofs_in_flight_are_all_the_same_proof():
     for sn in snarks:
         sn.prep_prove(tape)
     ref = snarks[0].prove(step)[0]
+    for sn in snarks[1:]:  # first proves allocate the contexts' workspaces: one at a time, before the proofs in flight
+        assert (sn.prove(step)[0] == ref).all()
     errors, bad = [], []
 
     def worker(i):

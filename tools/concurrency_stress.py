@@ -49,6 +49,8 @@ snarks = [host.SpartanSNARK(c, inst) for c in ctxs]
 for sn in snarks:
     sn.prep_prove(tape)
 ref = snarks[0].prove(step)[0]
+for sn in snarks[1:]:  # every context's first prove allocates its workspaces: outside the concurrent phase
+    assert (sn.prove(step)[0] == ref).all()
 errors, mismatches = [], 0
 lock = threading.Lock()
 
