@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -389,6 +391,22 @@ int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, 
 
 static bool fb_mapped_enabled();
 static int fb_mapped_ensure(sp_ctx* c, int lane);
+// 16-bit window tables of the latency paths (kernels_msm.cuh k_fixed_base_tables16), found by the address of the 8-bit table set they shadow.
+// SPARTAN_FB_WINDOW16=0: not built.
+static std::mutex g_t16_mu;
+static std::map<const aff_t*, const aff_t*> g_t16;
+static bool fb_window16_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_FB_WINDOW16");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+static const aff_t* tables16_of(const aff_t* t8) {
+  std::lock_guard<std::mutex> l(g_t16_mu);
+  auto it = g_t16.find(t8);
+  return it == g_t16.end() ? nullptr : it->second;
+}
 int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint64_t h_aff[8], sp_ck** out) {
   if (num_cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_ck_create: empty key");
   sp_ck* k = new sp_ck();
@@ -421,11 +439,37 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
   } else {
     k->d_htable = tables;
   }
+  if (fb_mapped_enabled() && fb_window16_enabled()) {
+    // the same bases with 16-bit windows (4 MiB per window, 64 MiB per base) for calls of <= 128 scalars: one tree level less per call
+    const size_t per16 = (size_t)16 * 65535;
+    DevBuf pts, tj16;
+    if ((rc = pts.alloc(ntab * sizeof(aff_t))) || (rc = tj16.alloc(ntab * per16 * sizeof(jac_t)))) return rc;
+    std::vector<aff_t> hb(ntab);
+    for (size_t t = 0; t < ntab; ++t) hb[t] = (t + 1 == ntab) ? k->h : load_aff(ck_aff + 8 * t);
+    aff_t* t16 = nullptr;
+    SP_HIP(hipMalloc((void**)&t16, ntab * per16 * sizeof(aff_t)));
+    SP_HIP(hipMemcpyAsync(pts.p, hb.data(), ntab * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(spk::k_fixed_base_tables16, dim3((unsigned)(ntab * 16)), dim3(256), 0, c->stream, pts.as<aff_t>(), ntab, tj16.as<jac_t>());
+    hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per16 + 255) / 256)), dim3(256), 0, c->stream, tj16.as<jac_t>(), ntab * per16, t16);
+    SP_HIP(hipStreamSynchronize(c->stream));
+    k->d_tables16 = t16;
+    std::lock_guard<std::mutex> l(g_t16_mu);
+    if (ntab > 1) g_t16[k->d_cktables] = t16;
+    g_t16[k->d_htable] = t16 + (ntab - 1) * per16;
+  }
   *out = k;
   return SP_OK;
 }
 void sp_ck_free(sp_ck* k) {
   if (!k) return;
+  if (k->d_tables16) {
+    {
+      std::lock_guard<std::mutex> l(g_t16_mu);
+      if (k->d_cktables) g_t16.erase(k->d_cktables);
+      g_t16.erase(k->d_htable);
+    }
+    hipFree(k->d_tables16);
+  }
   if (k->d_bases) hipFree(k->d_bases);
   if (k->d_comb) hipFree(k->d_comb);
   if (k->d_cktables) hipFree(k->d_cktables);
@@ -494,9 +538,11 @@ static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t n
   const fe_t* ds = reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * 128);
   unsigned* dslots = reinterpret_cast<unsigned*>(c->d_fbm[lane]);
   const unsigned seq = c->fbm_seq[lane];
+  const aff_t* t16 = fb_window16_enabled() ? tables16_of(d_tables) : nullptr;
   c->timed_on(st, "fixed_base", 32ull * n, [&] {
-    if (wide) hipLaunchKernelGGL(spk::k_fixed_base_rows_coop_mapped<128>, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, d_tables, ntables, dslots, seq);
-    else hipLaunchKernelGGL(spk::k_fixed_base_rows_coop_mapped<64>, dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
+    if (t16) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 16>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ds, n, t16, ntables, dslots, seq);
+    else if (wide) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<128, 8>), dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, d_tables, ntables, dslots, seq);
+    else hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 8>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
   });
   return SP_OK;
 }

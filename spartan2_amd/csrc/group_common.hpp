@@ -13,6 +13,7 @@ struct sp_ck {
   aff_t h;
   aff_t* d_htable = nullptr;  // 32 * 255 affine multiples of h
   aff_t* d_cktables = nullptr;  // num_cols <= 64: one 32*255 table per base (hyrax_pc.rs:81-96 ck_tables)
+  aff_t* d_tables16 = nullptr;  // the same table set with 16-bit windows (16 x 65535 entries per base) for the latency paths of <= 128 scalars
   std::vector<aff_t> h_tables;  // host copy of all tables (bases..., h): single multiplications are latency-bound -> host
   size_t n_tables = 0;
   const aff_t* host_table(size_t t) const { return h_tables.data() + t * 32 * 255; }

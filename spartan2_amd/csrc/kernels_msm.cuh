@@ -648,6 +648,39 @@ __global__ void k_fixed_base_tables(const aff_t* __restrict__ bases, size_t n, j
     row[d] = acc;
   }
 }
+// FixedBaseMul tables with 16-bit windows for the latency paths (a round commitment of the ZK verifier circuit: 16 table entries per scalar and a
+// four-level tree instead of 32 and five): table[(b * 16 + w) * 65535 + d - 1] = d * 2^(16 w) * bases[b]. One 256-thread block per (base, window):
+// thread 0 walks the 255 giant steps k * 256 * G, then thread t fills multiples 256 t + 1 .. 256 t + 255 from its giant step (~510 dependent
+// additions in all; the 65535 multiples of a window would take a single thread 0.8 s).
+__global__ void __launch_bounds__(256) k_fixed_base_tables16(const aff_t* __restrict__ bases, size_t n, jac_t* __restrict__ table_jac) {
+  const size_t b = blockIdx.x / 16;
+  const int w = blockIdx.x % 16;
+  if (b >= n) return;
+  jac_t* row = table_jac + ((size_t)b * 16 + (size_t)w) * 65535;
+  __shared__ jac_t G_sh;
+  if (threadIdx.x == 0) {
+    jac_t G = jac_from_affine(bases[b]);
+    for (int k = 0; k < 16 * w; ++k) G = jac_dbl(G);
+    G_sh = G;
+    jac_t step = G;
+    for (int k = 0; k < 8; ++k) step = jac_dbl(step);  // 256 G
+    jac_t acc = step;
+    row[256 - 1] = acc;  // multiple 256
+    for (int t = 2; t < 256; ++t) {
+      acc = jac_add(acc, step);
+      row[(size_t)256 * t - 1] = acc;  // multiple 256 t
+    }
+  }
+  __syncthreads();  // (global writes of thread 0 are read back below by the other threads of this block)
+  __threadfence_block();
+  const jac_t G = G_sh;
+  const int t = threadIdx.x;
+  jac_t acc = t == 0 ? jac_identity() : row[(size_t)256 * t - 1];
+  for (int d = 1; d < 256; ++d) {
+    acc = t == 0 && d == 1 ? G : jac_add(acc, G);
+    row[(size_t)256 * t + d - 1] = acc;  // multiple 256 t + d
+  }
+}
 __global__ void __launch_bounds__(256) k_jac_to_affine(const jac_t* __restrict__ in, size_t n, aff_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = jac_to_affine(in[i]);
 }
@@ -722,26 +755,29 @@ __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __
 // ITEMS = 64: two scalars per 256-thread block, ONE wave per role, so each of the four products of a level has a SIMD to itself. The products are
 // issue-bound (v_mad_u64_u32 at quarter rate: ~136 of them per Montgomery product whatever the number of active lanes), so the 128-item form - two
 // waves per SIMD, both issuing full-length products even when a tree level has two active lanes left - takes twice as long per level.
-template <int ITEMS>
+// WBITS = 16: tables of k_fixed_base_tables16 - 16 entries per scalar, four tree levels.
+template <int ITEMS, int WBITS>
 __global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
                                                                            unsigned* __restrict__ slots, unsigned seq) {
+  constexpr int PER = 256 / WBITS;  // table entries (= tree leaves) per scalar
+  constexpr size_t WIN = ((size_t)1 << WBITS) - 1;
   __shared__ CoopAdd<ITEMS> L;
   __shared__ xyzz_t s[ITEMS];
   const int wave = threadIdx.x >> 6, blk = wave >> 2;
   const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);
-  const size_t idx = (size_t)blockIdx.x * (ITEMS / 32) + (k >> 5);
-  const int j = k & 31;
+  const size_t idx = (size_t)blockIdx.x * (ITEMS / PER) + (k / PER);
+  const int j = k % PER;
   if (role == 0) {
     xyzz_t acc = xyzz_identity();
     if (idx < n) {
       const fe_t c = fe_to_canonical<SF>(scalars[idx]);
-      const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
-      if (digit) acc = xyzz_from_affine(tables[(idx % ntables) * (32 * 255) + (size_t)j * 255 + digit - 1]);
+      const unsigned digit = WBITS == 8 ? (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu : (c.v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      if (digit) acc = xyzz_from_affine(tables[(idx % ntables) * (PER * WIN) + (size_t)j * WIN + digit - 1]);
     }
     s[k] = acc;
   }
   __syncthreads();
-  for (int off = 16; off >= 1; off >>= 1) {
+  for (int off = PER / 2; off >= 1; off >>= 1) {
     const bool active = j < off;
     xyzz_add_block4<ITEMS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
