@@ -568,15 +568,15 @@ static unsigned tail_blocks(size_t len, bool cubic = false) {
 // more blocks than the chip holds, each could sit on CUs the other needs for blocks its host is waiting for: a multi-block tail therefore
 // leases its blocks from a process-wide budget and, when the budget is short, the sum-check simply keeps launching ordinary rounds until
 // the tail it needs is small enough. Single-block tails (one per context) are not counted.
-// The budget is HALF the chip (SPARTAN_TAIL_BUDGET overrides it): a resident block needs the whole register file of its CU, so it can only be placed
+// The budget is a QUARTER of the chip - one full-size tail at a time - (SPARTAN_TAIL_BUDGET overrides it): a resident block needs the whole register file of its CU, so it can only be placed
 // on a CU that has drained completely, and with eight contexts in flight - each with thousand-block kernels queued whose blocks fill any slot that
 // frees up - the not-yet-placed blocks of a tail starved behind them while its placed blocks held their CUs (stress: one 8 - 12 s stall per ~3000
-// proofs with a budget of 256; a lone proof's 64-block tails are unaffected).
+// proofs with a budget of 256, rarer but not gone with 128; a lone proof's 64-block tails are unaffected).
 static std::atomic<int> g_tail_resident{0};
 static int tail_block_budget() {
   static const int v = [] {
     const char* e = getenv("SPARTAN_TAIL_BUDGET");
-    const int b = e ? atoi(e) : 128;
+    const int b = e ? atoi(e) : 64;
     return b < 0 ? 0 : b;
   }();
   return v;

@@ -1219,13 +1219,15 @@ int sp_fbtables_multi_mul_finish(sp_ctx* c, uint64_t out_aff[8]) {
       }
       if (slot[24] == seq && slot[25] == a && slot[26] == b && slot[27] == seq) break;
     }
-    if (spins > 4000000) {
+    if (spins > 400000) {
       if (synced) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul: the kernel did not deliver its result slot");
       SP_HIP(hipStreamSynchronize(c->stream2));  // e.g. under a profiler
       synced = true;
       spins = 0;
     }
-    __builtin_ia32_pause();
+    // the caller is a helper thread and the kernel takes ~130 us: past that it is late because the chip is shared, and the poll yields its CPU
+    if (spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    else __builtin_ia32_pause();
   }
   jac_t sum;
   memcpy(&sum, w, sizeof(jac_t));

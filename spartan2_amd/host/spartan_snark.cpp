@@ -597,7 +597,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
             for (size_t b = 0; b < ip->nright; ++b) ip->T[b] = fe_add<S>(ip->T[b], fe_mul<S>(left[a], dv[a * ip->nright + b]));
           const auto t0 = std::chrono::steady_clock::now();
           while (ip->right_ready.load(std::memory_order_acquire) == 0) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return;  // (the prover finishes <R, d> and beta itself)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) return;  // (the prover finishes <R, d> and beta itself; a helper does not sit on a CPU of the quota)
             __builtin_ia32_pause();
           }
           const std::vector<fe_t> right = eq_evals_host(ip->right_r, ip->nright_vars);

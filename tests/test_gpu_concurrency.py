@@ -13,37 +13,21 @@ pytestmark = pytest.mark.gpu
 
 
 def test_eight_proofs_in_flight_are_all_the_same_proof():
-    inst = frontend.sha256_circuit(bytes(2048))
-    tape, step = ol.make_tape(1, 4096), ol.make_tape(2, 4096)
+    """In a process of its own, as bench.py runs the same leg: the library's callers (the C++ drivers, a Rust host) do not carry PyTorch or the
+    oracle's OpenMP pool, whose threads compete with the polling owner threads for the CPU quota of the box."""
+    import json
+    import os
+    import subprocess
+    import sys
+
     from spartan2_amd.dist import cpu_budget
 
-    # one polling owner thread per context (+ a mostly sleeping helper): stay within half of the CPU quota of the box (16 on the bench boxes: 8)
-    P, per = max(2, min(8, cpu_budget() // 2)), 20
-    ctxs = [hip.Context(0) for _ in range(P)]
-    snarks = [host.SpartanSNARK(c, inst) for c in ctxs]
-    for sn in snarks:
-        sn.prep_prove(tape)
-    ref = snarks[0].prove(step)[0]
-    for sn in snarks[1:]:  # first proves allocate the contexts' workspaces: one at a time, before the proofs in flight
-        assert (sn.prove(step)[0] == ref).all()
-    errors, bad = [], []
-
-    def worker(i):
-        for k in range(per):
-            try:
-                if not (snarks[i].prove(step)[0] == ref).all():
-                    bad.append((i, k))
-            except Exception as e:  # noqa: BLE001
-                errors.append((i, k, str(e)))
-
-    ts = [threading.Thread(target=worker, args=(i,)) for i in range(P)]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    for sn in snarks:
-        sn.close()
-    for c in ctxs:
-        c.close()
-    assert not errors, errors[:3]
-    assert not bad, bad[:3]
+    # one polling owner thread per context (+ two mostly sleeping helpers): stay within half of the CPU quota of the box (16 on the bench boxes: 8)
+    P, per = max(2, min(8, cpu_budget() // 2)), 40
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrency_stress.py"), "--contexts", str(P), "--proofs", str(per), "--json"], capture_output=True,
+                       text=True, timeout=900)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert line, (r.stdout + r.stderr)[-2000:]
+    out = json.loads(line[-1])
+    assert out["proofs"] == P * per and not out["errors"] and out["mismatches"] == 0, out
