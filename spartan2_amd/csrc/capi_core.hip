@@ -1357,11 +1357,18 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
   const fe_t one = fe_one<S>();
   fe_t base_tau = one, claim[2] = {load_fe(t_out_step), fe_zero()};
   size_t len_pow_tau = n;
+  static const bool trace = [] {
+    const char* e = getenv("SPARTAN_HOST_LAPS");
+    return e && e[0] == '2';
+  }();
+  auto nowus = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (size_t i = 0; i < num_rounds; ++i) {
     UniPoly poly[2];
     uint64_t co[2][16];
     fe_t both[2][3];
+    const double tr0 = trace ? nowus() : 0;
     const int paired = eval_cubic_outer_pow_pair(c, pow_left, pow_right, step, core, both);
+    const double tr1 = trace ? nowus() : 0;
     if (paired < 0) return paired;
     for (int b = 0; b < 2; ++b) {
       sp_table** t = b == 0 ? step : core;
@@ -1374,7 +1381,9 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
       for (int q = 0; q < 4; ++q) store_fe(co[b] + 4 * q, poly[b].c[q]);
     }
     uint64_t r_raw[4];
+    const double tr2 = trace ? nowus() : 0;
     int hrc = hook(user, start_round + i, co[0], co[1], 4, r_raw);
+    if (trace) fprintf(stderr, "outer batched round %zu (len %zu): eval %.1f us, algebra %.1f us, hook %.1f us\n", i, step[0]->len, tr1 - tr0, tr2 - tr1, nowus() - tr2);
     if (hrc) return fail(hrc, "prove_cubic_batched: the round hook failed");
     const fe_t r_i = load_fe(r_raw);
     store_fe(out_r + 4 * i, r_i);
