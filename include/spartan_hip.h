@@ -206,7 +206,7 @@ int sp_msm_shared_weights(sp_ctx* ctx, const uint64_t* weights, size_t n, const 
  * two-term fold with a unit weight (hyrax_pc.rs:757-776): see sp_fold_commitments2. Few points run on the host side of the library (a dependent
  * chain of ~300 group operations: one CPU core finishes it 40x sooner than one GPU lane), many on the device, one lane per point. */
 int sp_vartime_scalar_mul(sp_ctx* ctx, const uint64_t* points_aff, size_t n, const uint64_t scalar[4], uint64_t* out_aff);
-/* FixedBaseMul over arbitrary points (src/provider/msm.rs:637-773): `precompute` builds 32 x 255 affine window multiples per point (1 <= n <= 512;
+/* FixedBaseMul over arbitrary points (src/provider/msm.rs:637-773): `precompute` builds 32 x 255 affine window multiples per point (1 <= n <= 2048;
  * 510 KiB per point), `multi_mul` = sum_i scalars[i] * point_i as table lookups added in ONE launch on the context's auxiliary stream (callable from a
  * helper thread beside the owner's calls on the main stream), scalars and result through mapped memory: no copy, no stream synchronise, no host tail.
  * Call site: comm_LZ of HyraxPCS::prove (hyrax_pc.rs:387-478) as sum_i L_i * comm_W[i] over the row commitments a prepared witness already holds. */

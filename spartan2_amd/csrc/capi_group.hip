@@ -1142,7 +1142,7 @@ struct sp_fbtables {
 };
 static int multi_mul_ensure(sp_ctx* c);
 int sp_fbtables_create(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtables** out) {
-  if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_create: 1 .. 512 points");
+  if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_create: 1 .. 2048 points");
   {
     int erc = multi_mul_ensure(c);
     if (erc) return erc;

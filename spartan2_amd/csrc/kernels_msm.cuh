@@ -803,15 +803,15 @@ __global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const
 // sum_i L_i * comm_W[i], the rows of comm_W are known when the witness is prepared, so their window tables are built there and the 512-point MSM
 // (digits, sort, bucket sums, a 14-level window reduction, 256 doublings on the host) that used to follow the last row challenge becomes 14 levels of
 // additions. The scalars are read straight from mapped host memory; block b owns scalars 4b .. 4b+3 (128 table entries, seven cooperative levels down
-// to one point); the last block to take a ticket adds the block sums (<= 128 of them) the same way and publishes the Jacobian sum into a
+// to one point); the last block to take a ticket adds the block sums (<= 512 of them) the same way and publishes the Jacobian sum into a
 // self-validating slot in mapped host memory that the host polls: words 0..23 the point, 24 = sequence, 25 = sequence + plain sum, 26 = sequence * K +
 // position-weighted sum, 27 = sequence again (the order in which the stores land does not matter; the host accepts the slot only when all four agree).
 constexpr unsigned MULTI_MUL_SLOT_K = 0x9E3779B1u;
-constexpr int MULTI_MUL_MAX_BLOCKS = 128;
+constexpr int MULTI_MUL_MAX_BLOCKS = 512;  // 2048 scalars (the rows of a 2^22-variable witness)
 __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, xyzz_t* __restrict__ partial,
                                                             unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq) {
   __shared__ CoopAdd<128> L;
-  __shared__ xyzz_t s[128];
+  __shared__ xyzz_t s[128], s2[128];
   __shared__ unsigned s_last;
   const int wave = threadIdx.x >> 6, blk = wave >> 2;
   const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);  // roles of an item block on four different SIMDs (see k_msm_window_reduce_coop)
@@ -851,8 +851,23 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restri
       s[k] = acc;
     }
     __syncthreads();
+    // more than 128 block sums: item k first takes in sums k + 128, k + 256, ... (one cooperative addition each), then the tree
+    for (int base = 128; base < (int)gridDim.x; base += 128) {
+      const bool active = base + k < (int)gridDim.x;
+      if (role == 0 && active) {
+        xyzz_t acc;
+        const unsigned* pw = reinterpret_cast<const unsigned*>(&partial[base + k]);
+        unsigned* aw = reinterpret_cast<unsigned*>(&acc);
+#pragma unroll
+        for (int w = 0; w < (int)(sizeof(xyzz_t) / 4); ++w) aw[w] = __hip_atomic_load(pw + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s2[k] = acc;
+      }
+      __syncthreads();
+      xyzz_add_block4<128>(L, &s[k], &s2[k], s, role, k, active);
+    }
     int top = 1;
-    while (2 * top < (int)gridDim.x) top <<= 1;
+    const int live = (int)gridDim.x < 128 ? (int)gridDim.x : 128;
+    while (2 * top < live) top <<= 1;
     for (int off = top; off >= 1; off >>= 1) {
       const bool active = k < off;
       xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);

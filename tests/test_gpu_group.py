@@ -274,7 +274,7 @@ def test_commit_small_device_form_matches_oracle(ctx, width):
         assert (k.commit_small(ones, blind) == want(ones, blind)).all()
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 33, 130, 429, 512])
+@pytest.mark.parametrize("n", [1, 3, 4, 33, 130, 429, 512, 700, 2048])
 def test_fixed_base_tables_multi_mul_matches_oracle_msm(ctx, n):
     """sp_fbtables_create + sp_fbtables_multi_mul (FixedBaseMul::precompute / multi_mul over arbitrary points, msm.rs:637-773; the one-launch form comm_LZ
     of the opening uses on the row commitments of a prepared witness) against the oracle's MSM: dense scalars, zeros, repeated calls (sequence numbers),
@@ -293,4 +293,4 @@ def test_fixed_base_tables_multi_mul_matches_oracle_msm(ctx, n):
     t.close()
     if n == 4:
         with pytest.raises(hip.SpartanHipError):
-            hip.FixedBaseTables(ctx, np.zeros((513, 8), dtype=np.uint64))
+            hip.FixedBaseTables(ctx, np.zeros((2049, 8), dtype=np.uint64))
