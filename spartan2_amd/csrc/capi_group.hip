@@ -506,7 +506,7 @@ static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU
 // table[i % ntables] * scalars[i] on the device (Jacobian results in host memory); ntables == 1 for h
 // <= 128 scalars through mapped memory (kernels_msm.cuh k_fixed_base_rows_coop_mapped): launch on lane 0 = the main stream / lane 1 = the auxiliary stream,
 // then poll the n self-validating result slots. SPARTAN_FB_MAPPED=0 keeps the copy / launch / copy / synchronise form.
-static const size_t FB_MAPPED_MAX = 128;
+static const size_t FB_MAPPED_MAX = 128, FB_SLOT_BYTES = 4 * spk::FB_SLOT_WORDS;
 static bool fb_mapped_enabled() {
   static const bool on = [] {
     const char* e = getenv("SPARTAN_FB_MAPPED");
@@ -517,7 +517,7 @@ static bool fb_mapped_enabled() {
 // (allocated when a key is created, not inside a prove: an allocation call can wait for the device, and with it for resident kernels of other contexts
 // that are themselves waiting for host threads the call may be holding up)
 static int fb_mapped_ensure(sp_ctx* c, int lane) {
-  const size_t bytes = FB_MAPPED_MAX * 128 + FB_MAPPED_MAX * sizeof(fe_t);
+  const size_t bytes = FB_MAPPED_MAX * FB_SLOT_BYTES + FB_MAPPED_MAX * sizeof(fe_t);
   if (!c->h_fbm[lane]) {
     SP_HIP(hipHostMalloc(&c->h_fbm[lane], bytes, hipHostMallocMapped));
     memset(c->h_fbm[lane], 0, bytes);
@@ -525,44 +525,48 @@ static int fb_mapped_ensure(sp_ctx* c, int lane) {
   }
   return SP_OK;
 }
-static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n) {
+static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n, bool xyzz_out = false) {
   int erc = fb_mapped_ensure(c, lane);
   if (erc) return erc;
-  memcpy((char*)c->h_fbm[lane] + FB_MAPPED_MAX * 128, scalars, n * sizeof(fe_t));
+  memcpy((char*)c->h_fbm[lane] + FB_MAPPED_MAX * FB_SLOT_BYTES, scalars, n * sizeof(fe_t));
   if (++c->fbm_seq[lane] == 0) ++c->fbm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
   static const bool wide = [] {  // SPARTAN_FB_ITEMS=128: four scalars per 512-thread block (two waves per SIMD)
     const char* e = getenv("SPARTAN_FB_ITEMS");
     return e && atoi(e) == 128;
   }();
-  const fe_t* ds = reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * 128);
+  const fe_t* ds = reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * FB_SLOT_BYTES);
   unsigned* dslots = reinterpret_cast<unsigned*>(c->d_fbm[lane]);
   const unsigned seq = c->fbm_seq[lane];
   const aff_t* t16 = fb_window16_enabled() ? tables16_of(d_tables) : nullptr;
   c->timed_on(st, "fixed_base", 32ull * n, [&] {
-    if (t16) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 16>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ds, n, t16, ntables, dslots, seq);
-    else if (wide) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<128, 8>), dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, d_tables, ntables, dslots, seq);
-    else hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 8>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
+    if (t16 && xyzz_out) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 16, true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ds, n, t16, ntables, dslots, seq);
+    else if (t16) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 16, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ds, n, t16, ntables, dslots, seq);
+    else if (xyzz_out) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 8, true>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
+    else if (wide) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<128, 8, false>), dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, d_tables, ntables, dslots, seq);
+    else hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 8, false>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
   });
   return SP_OK;
 }
-static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, jac_t* out) {
+static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, void* out_, int D = 24) {  // D = 24: jac_t results, 32: xyzz_t
+  unsigned* out = reinterpret_cast<unsigned*>(out_);
   const unsigned seq = c->fbm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
   bool synced = false;
+  const int T = spk::FB_SLOT_TAG;
   for (size_t i = 0; i < n; ++i) {
-    volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>((char*)c->h_fbm[lane] + 128 * i);
-    unsigned w[24];
+    volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>((char*)c->h_fbm[lane] + FB_SLOT_BYTES * i);
+    unsigned w[32];
     for (long spins = 0;; ++spins) {
-      if (slot[24] == seq) {
+      if (slot[T] == seq) {
         std::atomic_thread_fence(std::memory_order_acquire);
         unsigned a = seq, b = seq * 0x9E3779B1u;
-        for (int k = 0; k < 24; ++k) {
+        for (int k = 0; k < D; ++k) {
           w[k] = slot[k];
           a += w[k];
           b += (unsigned)(k + 1) * w[k];
         }
-        if (slot[24] == seq && slot[25] == a && slot[26] == b && slot[27] == seq) break;
+        if (slot[T] == seq && slot[T + 1] == a && slot[T + 2] == b && slot[T + 3] == seq) break;
       }
       if (spins > 4000000) {
         if (synced) return fail(SP_ERR_INTERNAL, "fixed-base rows: the kernel did not deliver a result slot");
@@ -572,7 +576,7 @@ static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, jac_t* out) {
       }
       __builtin_ia32_pause();
     }
-    memcpy(&out[i], w, sizeof(jac_t));
+    memcpy(out + (size_t)D * i, w, 4 * (size_t)D);
   }
   return SP_OK;
 }
@@ -1250,6 +1254,15 @@ int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, s
     std::vector<fe_t> sc(cols + 1, fe_zero());
     memcpy(sc.data(), scalars, n * sizeof(fe_t));
     memcpy(&sc[cols], blind, sizeof(fe_t));
+    if (cols + 1 <= FB_MAPPED_MAX && fb_mapped_enabled()) {  // the walks come back as (X, Y, ZZ, ZZZ) and are added in that form
+      std::vector<xyzz_t> xs(cols + 1);
+      int rc = fb_mapped_launch(c, 0, ck->d_cktables, cols + 1, reinterpret_cast<const uint64_t*>(sc.data()), cols + 1, true);
+      if (rc || (rc = fb_mapped_collect(c, 0, cols + 1, xs.data(), 32))) return rc;
+      xyzz_t acc = xyzz_identity();
+      for (const xyzz_t& p : xs) acc = xyzz_add(acc, p);
+      store_aff(out_aff, jac_to_affine(xyzz_to_jac(acc)));
+      return SP_OK;
+    }
     std::vector<jac_t> pts;
     int rc = fixed_base_rows(c, ck->d_cktables, cols + 1, reinterpret_cast<const uint64_t*>(sc.data()), cols + 1, pts);
     if (rc) return rc;

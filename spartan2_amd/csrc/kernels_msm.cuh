@@ -749,14 +749,18 @@ __global__ void __launch_bounds__(4 * 128) k_fixed_base_rows_coop(const fe_t* __
 }
 
 // k_fixed_base_rows_coop with its inputs and outputs in mapped host memory (<= 128 scalars: a round commitment of the ZK verifier circuit, the blinds of
-// the zero rows): the scalars are read through the bus, scalar i's Jacobian result goes into slot i (32 words: 0..23 the point, 24 = sequence,
-// 25 = sequence + plain sum, 26 = sequence * K + position-weighted sum, 27 = sequence) which the host polls - no copy launch on either side and no
+// the zero rows): the scalars are read through the bus, scalar i's result goes into slot i (the point, then the tag: sequence, sequence + plain sum,
+// sequence * K + position-weighted sum, sequence) which the host polls - no copy launch on either side and no
 // stream synchronise around a 50 us kernel.
 // ITEMS = 64: two scalars per 256-thread block, ONE wave per role, so each of the four products of a level has a SIMD to itself. The products are
 // issue-bound (v_mad_u64_u32 at quarter rate: ~136 of them per Montgomery product whatever the number of active lanes), so the 128-item form - two
 // waves per SIMD, both issuing full-length products even when a tree level has two active lanes left - takes twice as long per level.
 // WBITS = 16: tables of k_fixed_base_tables16 - 16 entries per scalar, four tree levels.
-template <int ITEMS, int WBITS>
+// XYZZ_OUT: the result slot carries (X, Y, ZZ, ZZZ) as they are (32 words) instead of the Jacobian form (24) - the caller that adds the points on the
+// host anyway (a commitment = the sum of its scalars' walks) saves the two conversion products per scalar here and two products per addition there.
+// Slots are 48 words apart with the tag at words 32..35 in either form.
+constexpr int FB_SLOT_WORDS = 48, FB_SLOT_TAG = 32;
+template <int ITEMS, int WBITS, bool XYZZ_OUT>
 __global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
                                                                            unsigned* __restrict__ slots, unsigned seq) {
   constexpr int PER = 256 / WBITS;  // table entries (= tree leaves) per scalar
@@ -782,19 +786,30 @@ __global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const
     xyzz_add_block4<ITEMS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
   if (role == 0 && j == 0 && idx < n) {
-    const jac_t r = xyzz_to_jac(s[k]);
-    const unsigned* rw = reinterpret_cast<const unsigned*>(&r);
-    unsigned* slot = slots + idx * 32;
+    constexpr int D = XYZZ_OUT ? 32 : 24;
+    unsigned rw[32];
+    if (XYZZ_OUT) {
+      const xyzz_t r = s[k];
+      const unsigned* p = reinterpret_cast<const unsigned*>(&r);
+#pragma unroll
+      for (int w = 0; w < 32; ++w) rw[w] = p[w];
+    } else {
+      const jac_t r = xyzz_to_jac(s[k]);
+      const unsigned* p = reinterpret_cast<const unsigned*>(&r);
+#pragma unroll
+      for (int w = 0; w < 24; ++w) rw[w] = p[w];
+    }
+    unsigned* slot = slots + idx * FB_SLOT_WORDS;
     unsigned a = seq, b = seq * 0x9E3779B1u;
 #pragma unroll
-    for (int w = 0; w < 24; ++w) {
+    for (int w = 0; w < D; ++w) {
       slot[w] = rw[w];
       a += rw[w];
       b += (unsigned)(w + 1) * rw[w];
     }
     const unsigned long long lo = ((unsigned long long)a << 32) | seq, hi = ((unsigned long long)seq << 32) | b;
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 26), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 24), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + FB_SLOT_TAG + 2), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + FB_SLOT_TAG), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
