@@ -23,7 +23,7 @@ def test_eight_proofs_in_flight_are_all_the_same_proof():
     from spartan2_amd.dist import cpu_budget
 
     # one polling owner thread per context (+ two mostly sleeping helpers): stay within half of the CPU quota of the box (16 on the bench boxes: 8)
-    P, per = max(2, min(8, cpu_budget() // 2)), 40
+    P, per = max(2, min(8, cpu_budget() // 2)), 20
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrency_stress.py"), "--contexts", str(P), "--proofs", str(per), "--json"], capture_output=True,
                        text=True, timeout=900)
