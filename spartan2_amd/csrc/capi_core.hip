@@ -596,6 +596,37 @@ struct TailLease {
     if (n) g_tail_resident.fetch_sub(n);
   }
 };
+// The same reasoning for the large launches issued ahead of their challenge: their blocks spin at the mailbox, and with eight contexts in flight the
+// thousand-block ones together filled the chip while late blocks of other launches waited for a slot (about one 8 s stall per 30 000 proofs; with
+// GPU_MAX_HW_QUEUES=24 - more launches in flight - dozens per 3200). At most SPARTAN_AHEAD_BUDGET (2) launches of more than 64 blocks wait at the
+// mailbox at a time, process-wide; a context that does not get the lease launches that round after its challenge, as before round 1 of this work.
+static std::atomic<int> g_ahead_big{0};
+static int ahead_budget() {
+  static const int v = [] {
+    const char* e = getenv("SPARTAN_AHEAD_BUDGET");
+    const int b = e ? atoi(e) : 2;
+    return b < 0 ? 0 : b;
+  }();
+  return v;
+}
+struct AheadLease {
+  bool held = false;
+  bool take(size_t table_len) {
+    if (table_len <= ((size_t)1 << 15)) return true;  // <= 64 blocks
+    if (held) return true;
+    if (g_ahead_big.fetch_add(1) + 1 > ahead_budget()) {
+      g_ahead_big.fetch_sub(1);
+      return false;
+    }
+    held = true;
+    return true;
+  }
+  void drop() {
+    if (held) g_ahead_big.fetch_sub(1);
+    held = false;
+  }
+  ~AheadLease() { drop(); }
+};
 static int tail_check(sp_ctx* c) {
   volatile uint32_t* err = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM);
   if (*err) {
@@ -981,6 +1012,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
   unsigned last_answered = 0;  // sequence number answered by the most recent challenge
   TailLease lease;
+  AheadLease ahead_lease;
   AheadGuard guard(c);
   *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
   // What follows round `round`'s challenge r: the resident tail takes it from the mailbox, a fused launch binds with it and evaluates round + 1, or
@@ -1120,7 +1152,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
     int issued = 0;
-    if (waiting && (in_tail || (c->mail_dev && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
+    if (waiting && (in_tail || (c->mail_dev && !reduce && ahead_lease.take(A->len)))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(round, nullptr, wait_seq);
       if (issued < 0) return issued;
       guard.armed = issued != 0;
@@ -1162,6 +1194,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       if (issued < 0) return issued;
       if (wait_resident) tail_post_challenge(c, r_i, wait_seq);
     }
+    ahead_lease.drop();  // (the launch has its challenge: its blocks no longer wait)
     guard.armed = in_tail && round + 1 < rounds;  // the resident kernel now waits for the next challenge
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];
@@ -1526,6 +1559,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
   unsigned last_answered = 0;
   TailLease lease;
+  AheadLease ahead_lease;
   AheadGuard guard(c);
   *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
   fe_t eval_eq_left = load_fe(p_io);
@@ -1695,7 +1729,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
     int issued = 0;
-    if (in_tail || (c->mail_dev && invertible && !reduce)) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
+    if (in_tail || (c->mail_dev && invertible && !reduce && ahead_lease.take(A->len))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(rnd, nullptr, wait_seq);
       if (issued < 0) return issued;
       guard.armed = issued != 0;
@@ -1770,6 +1804,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       issued = issue(rnd, &r_i, wait_seq);
       if (issued < 0) return issued;
     }
+    ahead_lease.drop();  // (the launch has its challenge: its blocks no longer wait)
     guard.armed = in_tail && rnd < ell;  // the resident kernel now waits for the next challenge
     // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
