@@ -138,6 +138,48 @@ def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle):
     return out
 
 
+def _scaling_vs_1(world, args, out):
+    """Raw ratios against the N = 1 line of the same command on the same box, when one is cached (a run at N = 1 writes it; the driver runs N = 1, 2, 4, 8
+    back to back). Ratios of measured figures only, no efficiency claim: the driver computes that itself from the per-N values."""
+    import tempfile
+
+    path = os.path.join(tempfile.gettempdir(), f"spartan2_amd_bench_n1_{args.workload}_{args.message_bytes}.json")
+    legs = out.get("sharded") or {}
+    mine = {"value": out["value"], "ms_per_step": out["ms_per_step"],
+            "msm_pairs_per_s": (legs.get("c4_commit") or {}).get("msm_pairs_per_s"), "c4_prove_ms": (legs.get("c4_prove") or {}).get("ms")}
+    try:
+        if world == 1:
+            with open(path, "w") as f:
+                json.dump(mine, f)
+            return None
+        with open(path) as f:
+            one = json.load(f)
+    except OSError:
+        return None
+    ratio = lambda a, b: (a / b) if (a and b) else None
+    return {"source": path, "n1": one, "value_ratio": ratio(mine["value"], one["value"]),
+            "msm_pairs_per_s_ratio": ratio(mine["msm_pairs_per_s"], one["msm_pairs_per_s"]),
+            "c4_prove_speedup": ratio(one["c4_prove_ms"], mine["c4_prove_ms"])}
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py <same flags>` (one rank per GPU; the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    The reference's harness takes its thread count the same way, as a parameter of ONE binary (benches/sha256_spartan.rs:155-164,192-199)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes fails without it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,11 +196,15 @@ def main():
 
     from spartan2_amd import dist as spd
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args.gpus)  # does not return: this process becomes the launcher of the N ranks
     rank, local_rank, world = spd.env_rank()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher's --nproc-per-node must equal --gpus)")
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: libspartan_hip has no CPU fallback")
+        raise SystemExit(f"rank {rank}: bench.py needs {world} MI355X device(s), this node shows none: libspartan_hip has no CPU fallback")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"rank {rank}: --gpus {world} needs {world} devices (one process per GPU), this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     numa_cpus = _pin_to_gpu_numa(local_rank)  # before any pinned allocation or helper thread exists
     group = spd.Group(backend="nccl")  # RCCL: barrier and max-over-ranks of the timed region, and the hand-over of the C++ communicator's id
@@ -564,6 +610,7 @@ def main():
                                    "ms": secs * 1e3, "single_thread_ms": secs1 * 1e3, "gpu_proof_bit_exact_and_verified": ok}
             if not ok:
                 raise SystemExit("GPU proof differs from the oracle's or fails verification")
+        out["scaling_vs_1"] = _scaling_vs_1(world, args, out)
         print(json.dumps(out))
     snark.close()
     if comm is not None:
