@@ -62,6 +62,10 @@ int sp_ctx_kernel_stats(sp_ctx* ctx, const char* what, double* ms, uint64_t* lau
 int sp_ctx_reset_stats(sp_ctx* ctx, int enable_timing);
 /* restrict the instrumentation to one kernel class (NULL or "" = all) */
 int sp_ctx_stats_filter(sp_ctx* ctx, const char* only);
+/* diagnostics of the challenge mailbox (no reference counterpart: the reference's rounds are function calls). out[0] = challenges a waiting kernel took
+ * from the host-memory mirror because its device-memory line had not answered, out[1] = waits ended by the watchdog, out[2] / out[3] = sequence number
+ * wanted / sequence number the device line showed at the most recent mirror answer, out[4] = 1 when the ring lives in device memory. Reads and clears. */
+int sp_ctx_mail_stats(sp_ctx* ctx, uint64_t out[5]);
 
 /* ---- MultilinearPolynomial (src/polys/multilinear.rs:34-164) ------------------------------------- */
 /* MultilinearPolynomial::new / new_with_halves (:62-75). lo_eff/hi_eff = SIZE_MAX for "unknown". */

@@ -114,24 +114,31 @@ int sp_ctx_create(int device, sp_ctx** out) {
   c->device = device;
   SP_HIP(hipStreamCreate(&c->stream));
   SP_HIP(hipStreamCreate(&c->stream2));
-  c->pinned_elems = spk::SLOT_BASE_ELEM + 4 * spk::HOST_SUM_MAX_BLOCKS;
+  c->pinned_elems = spk::MAIL_MIRROR_ELEM + 16;
   SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
   memset(c->h_pinned, 0, c->pinned_elems * sizeof(fe_t));
   SP_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
   SP_HIP(hipHostMalloc(&c->h_pinned_lane[0], 8192));
   SP_HIP(hipHostMalloc(&c->h_pinned_lane[1], 8192));
-  c->h_mail = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_CHAL_ELEM);
-  c->d_mail = reinterpret_cast<const unsigned*>(c->d_pinned + spk::TAIL_CHAL_ELEM);
+  // the mailbox ring: in host memory (the mirror region of the mapped buffer) unless the device-memory form below is available
+  c->h_mail = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::MAIL_MIRROR_ELEM);
+  c->d_mail = reinterpret_cast<const unsigned*>(c->d_pinned + spk::MAIL_MIRROR_ELEM);
   {  // SPARTAN_MAIL_DEV=0 keeps the mailbox in host memory (and with it the launch-after-challenge round loop)
     const char* e = getenv("SPARTAN_MAIL_DEV");
+    const char* mt = getenv("SPARTAN_MAIL_MEMTYPE");  // "uncached": hipDeviceMallocUncached instead of hipDeviceMallocFinegrained (experiment knob)
+    const unsigned flags = (mt && mt[0] == 'u') ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
     int large_bar = 0;
     if (!(e && e[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
-        hipExtMallocWithFlags(&c->mail_alloc, 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+        hipExtMallocWithFlags(&c->mail_alloc, 4096, flags) == hipSuccess) {
       SP_HIP(hipMemset(c->mail_alloc, 0, 4096));
       SP_HIP(hipDeviceSynchronize());
+      c->h_mail_mirror = c->h_mail;  // the host-memory ring becomes the mirror of the device one
+      c->d_mail_mirror = c->d_mail;
       c->h_mail = reinterpret_cast<volatile uint32_t*>(c->mail_alloc);  // the host stores straight into device memory over the BAR
       c->d_mail = reinterpret_cast<const unsigned*>(c->mail_alloc);
       c->mail_dev = true;
+      const char* nm = getenv("SPARTAN_MAIL_MIRROR");  // "0": no second path (the round-2 behaviour, for A/B runs of the stress tool)
+      if (nm && nm[0] == '0') c->d_mail_mirror = nullptr;
     }
   }
   int rc = c->ensure_scratch(1 << 16);
@@ -189,6 +196,18 @@ int sp_ctx_reset_stats(sp_ctx* c, int enable) {
 }
 int sp_ctx_stats_filter(sp_ctx* c, const char* only) {
   c->timing_only = only ? only : "";
+  return SP_OK;
+}
+int sp_ctx_mail_stats(sp_ctx* c, uint64_t out[5]) {
+  for (int i = 0; i < 5; ++i) out[i] = 0;
+  if (!c->mail_dev) return SP_OK;
+  out[4] = 1;
+  uint32_t w[4];
+  SP_HIP(hipSetDevice(c->device));
+  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(hipMemcpy(w, reinterpret_cast<const uint32_t*>(c->mail_alloc) + spk::MAIL_DIAG_WORD, sizeof w, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 4; ++i) out[i] = w[i];
+  SP_HIP(hipMemset(reinterpret_cast<uint32_t*>(c->mail_alloc) + spk::MAIL_DIAG_WORD, 0, sizeof w));
   return SP_OK;
 }
 int sp_ctx_kernel_stats(sp_ctx* c, const char* what, double* ms, uint64_t* launches, uint64_t* alg_bytes) {
@@ -360,8 +379,9 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
   c->pending_slots = 0;
   hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
 }
-// `resident`: the result comes from the resident tail kernel, which is itself waiting for the host's next challenge — a stream synchronise
-// would never return, so the host keeps polling (bounded by wall-clock; the kernel gives up after 8 s as well).
+// `resident`: a kernel on the stream is itself waiting for the host's next challenge (the resident tail that produces the result, or a launch issued
+// ahead of its challenge queued behind the producer) — a stream synchronise would not return before that kernel's watchdog, so the host keeps
+// polling (bounded by wall-clock; the kernel gives up after 8 s as well).
 // one self-validating slot (kernels_poly.cuh slot_store_tag): wait for its sequence word, then re-read until the check word matches the data
 static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t* v, bool resident, long* spins) {
   volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
@@ -507,8 +527,7 @@ static bool tail_enabled() { return tail_max_len() != 0; }
 // mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 / 10 = two independent
 // check words (sequence + plain sum, sequence * K + position-weighted sum), 11 = the sequence number again, so a poll that straddles the host's
 // stores is recognised and retried (mail_wait in kernels_poly.cuh).
-static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) {
-  volatile uint32_t* dst = c->h_mail;
+static void mail_write_line(volatile uint32_t* dst, const fe_t& r, unsigned answers_seq) {
   uint32_t chk = answers_seq, chk2 = answers_seq * spk::SLOT_CHK_K;
   for (int i = 0; i < 8; ++i) {
     dst[i] = r.v[i];
@@ -520,18 +539,27 @@ static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) 
   dst[11] = answers_seq;
   std::atomic_thread_fence(std::memory_order_release);
   dst[8] = answers_seq;
+}
+static void tail_post_challenge(sp_ctx* c, const fe_t& r, unsigned answers_seq) {
+  const size_t off = (size_t)spk::MAIL_LINE_WORDS * (answers_seq & (spk::MAIL_RING - 1));
+  if (c->h_mail_mirror) mail_write_line(c->h_mail_mirror + off, r, answers_seq);  // host memory first: it is the fallback of the line below
+  mail_write_line(c->h_mail + off, r, answers_seq);
   if (c->mail_dev) __builtin_ia32_sfence();  // BAR memory is write-combining: push the line out now
 }
 // Error exits of a round loop: kernels issued ahead of their challenge (and the resident tail) are still waiting at the mailbox and would hold
-// their CUs for the 8 s watchdog, then trip the sticky error word under the next, unrelated sum-check. The abort word of the mailbox line makes
-// them leave at once; the stream is drained and both words are cleared so that the next sum-check on this context starts clean.
+// their CUs for the 8 s watchdog, then trip the sticky error word under the next, unrelated sum-check. The abort word of every mailbox line makes
+// them leave at once; the stream is drained and the words are cleared so that the next sum-check on this context starts clean.
 static void tail_abort(sp_ctx* c) {
-  volatile uint32_t* dst = c->h_mail;
-  dst[12] = 1;
-  if (c->mail_dev) __builtin_ia32_sfence();
+  auto set_all = [&](uint32_t v) {
+    for (int l = 0; l < spk::MAIL_RING; ++l) {
+      if (c->h_mail_mirror) c->h_mail_mirror[spk::MAIL_LINE_WORDS * l + 12] = v;
+      c->h_mail[spk::MAIL_LINE_WORDS * l + 12] = v;
+    }
+    if (c->mail_dev) __builtin_ia32_sfence();
+  };
+  set_all(1);
   hipStreamSynchronize(c->stream);
-  dst[12] = 0;
-  if (c->mail_dev) __builtin_ia32_sfence();
+  set_all(0);
   *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
 }
 // armed while a launch issued ahead of its challenge (or the resident tail) waits at the mailbox; an early return aborts it
@@ -546,6 +574,7 @@ struct AheadGuard {
 static spk::MailRef mail_ref(sp_ctx* c, bool ahead, unsigned answers) {
   spk::MailRef m;
   m.mail = ahead ? c->d_mail : nullptr;
+  m.mirror = c->d_mail_mirror;
   m.mapped = c->d_pinned;
   m.answers = answers;
   return m;
@@ -596,37 +625,6 @@ struct TailLease {
     if (n) g_tail_resident.fetch_sub(n);
   }
 };
-// The same reasoning for the large launches issued ahead of their challenge: their blocks spin at the mailbox, and with eight contexts in flight the
-// thousand-block ones together filled the chip while late blocks of other launches waited for a slot (about one 8 s stall per 30 000 proofs; with
-// GPU_MAX_HW_QUEUES=24 - more launches in flight - dozens per 3200). At most SPARTAN_AHEAD_BUDGET (2) launches of more than 64 blocks wait at the
-// mailbox at a time, process-wide; a context that does not get the lease launches that round after its challenge, as before round 1 of this work.
-static std::atomic<int> g_ahead_big{0};
-static int ahead_budget() {
-  static const int v = [] {
-    const char* e = getenv("SPARTAN_AHEAD_BUDGET");
-    const int b = e ? atoi(e) : 2;
-    return b < 0 ? 0 : b;
-  }();
-  return v;
-}
-struct AheadLease {
-  bool held = false;
-  bool take(size_t table_len) {
-    if (table_len <= ((size_t)1 << 15)) return true;  // <= 64 blocks
-    if (held) return true;
-    if (g_ahead_big.fetch_add(1) + 1 > ahead_budget()) {
-      g_ahead_big.fetch_sub(1);
-      return false;
-    }
-    held = true;
-    return true;
-  }
-  void drop() {
-    if (held) g_ahead_big.fetch_sub(1);
-    held = false;
-  }
-  ~AheadLease() { drop(); }
-};
 static int tail_check(sp_ctx* c) {
   volatile uint32_t* err = reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM);
   if (*err) {
@@ -649,11 +647,11 @@ struct UniPoly {
   int n;
 };
 fe_t two_inv() {
-  static fe_t v = fe_inv<S>(fe_from_u64<S>(2));
+  static fe_t v = fe_inv_vartime<S>(fe_from_u64<S>(2));
   return v;
 }
 fe_t six_inv() {
-  static fe_t v = fe_inv<S>(fe_from_u64<S>(6));
+  static fe_t v = fe_inv_vartime<S>(fe_from_u64<S>(6));
   return v;
 }
 UniPoly from_evals_deg2(const fe_t e[3]) {  // univariate.rs:84-93
@@ -1012,7 +1010,6 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
   unsigned last_answered = 0;  // sequence number answered by the most recent challenge
   TailLease lease;
-  AheadLease ahead_lease;
   AheadGuard guard(c);
   *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
   // What follows round `round`'s challenge r: the resident tail takes it from the mailbox, a fused launch binds with it and evaluates round + 1, or
@@ -1050,6 +1047,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       ta.eq_pl = ta.eq_pr = nullptr;
       ta.ell = ta.first_half = ta.rnd0 = 0;
       ta.mail = c->d_mail;
+      ta.mirror = c->d_mail_mirror;
       ta.r0_from_mail = ahead ? 1 : 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
@@ -1152,7 +1150,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
     int issued = 0;
-    if (waiting && (in_tail || (c->mail_dev && !reduce && ahead_lease.take(A->len)))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
+    if (waiting && (in_tail || (c->mail_dev && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(round, nullptr, wait_seq);
       if (issued < 0) return issued;
       guard.armed = issued != 0;
@@ -1161,7 +1159,10 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
       c->result_seq = wait_seq;
       c->pending_slots = wait_slots;
-      rc = reduce_partials_wait(c, 2, sums, wait_resident);
+      // (a launch issued ahead of its challenge sits on the stream behind these sums: like the resident tail it waits for the host, so the wait must
+      // never fall back to a stream synchronise — that was the rare 8 s stall of round 2: a result a few ms late, the fallback, and host and kernel
+      // waiting for each other until the kernel's watchdog)
+      rc = reduce_partials_wait(c, 2, sums, wait_resident || issued != 0);
       if (issued) {  // back to the state of the launch issued ahead
         c->result_seq = cur_seq;
         c->pending_slots = cur_slots;
@@ -1194,7 +1195,6 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       if (issued < 0) return issued;
       if (wait_resident) tail_post_challenge(c, r_i, wait_seq);
     }
-    ahead_lease.drop();  // (the launch has its challenge: its blocks no longer wait)
     guard.armed = in_tail && round + 1 < rounds;  // the resident kernel now waits for the next challenge
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];
@@ -1559,7 +1559,6 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
   unsigned last_answered = 0;
   TailLease lease;
-  AheadLease ahead_lease;
   AheadGuard guard(c);
   *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
   fe_t eval_eq_left = load_fe(p_io);
@@ -1610,6 +1609,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       ta.first_half = (int)first_half;
       ta.rnd0 = (int)rnd + 1;
       ta.mail = c->d_mail;
+      ta.mirror = c->d_mail_mirror;
       ta.r0_from_mail = ahead ? 1 : 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
@@ -1705,7 +1705,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       pref[i] = run;
       if (!fe_is_zero(taus[i])) run = fe_mul<S>(run, taus[i]);
     }
-    fe_t inv = fe_inv<S>(run);
+    fe_t inv = fe_inv_vartime<S>(run);
     for (size_t i = ell; i-- > 0;) {
       if (fe_is_zero(taus[i])) continue;
       inv_tau[i] = fe_mul<S>(inv, pref[i]);
@@ -1729,7 +1729,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
     int issued = 0;
-    if (in_tail || (c->mail_dev && invertible && !reduce && ahead_lease.take(A->len))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
+    if (in_tail || (c->mail_dev && invertible && !reduce)) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(rnd, nullptr, wait_seq);
       if (issued < 0) return issued;
       guard.armed = issued != 0;
@@ -1740,7 +1740,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     fe_t sums[3];
     const double tr0 = round_trace() ? now_us() : 0;
     const size_t len_now = A->len;
-    rc = reduce_partials_wait(c, wait_resident ? 3 : 2, sums, wait_resident);
+    rc = reduce_partials_wait(c, wait_resident ? 3 : 2, sums, wait_resident || issued != 0);  // never a stream synchronise with a launch waiting at the mailbox
     if (issued) {  // back to the state of the launch issued ahead
       c->result_seq = cur_seq;
       c->pending_slots = cur_slots;
@@ -1804,7 +1804,6 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       issued = issue(rnd, &r_i, wait_seq);
       if (issued < 0) return issued;
     }
-    ahead_lease.drop();  // (the launch has its challenge: its blocks no longer wait)
     guard.armed = in_tail && rnd < ell;  // the resident kernel now waits for the next challenge
     // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));

@@ -369,7 +369,7 @@ int sp_nifs_round_finish(sp_nifs* n, size_t t, const uint64_t sums[8], uint64_t 
   const fe_t one_minus_rho = fe_sub<SF>(one, rho_t), two_rho_minus_one = fe_sub<SF>(rho_t, one_minus_rho);
   const fe_t cc = fe_mul<SF>(e0, n->acc_eq), a = fe_mul<SF>(quad, n->acc_eq);
   if (fe_is_zero(rho_t)) return fail(SP_ERR_DIVISION_BY_ZERO, "sp_nifs_round: rho_t is not invertible");
-  const fe_t a_b_c = fe_mul<SF>(fe_sub<SF>(n->T_cur, fe_mul<SF>(cc, one_minus_rho)), fe_inv<SF>(rho_t));
+  const fe_t a_b_c = fe_mul<SF>(fe_sub<SF>(n->T_cur, fe_mul<SF>(cc, one_minus_rho)), fe_inv_vartime<SF>(rho_t));
   const fe_t b = fe_sub<SF>(fe_sub<SF>(a_b_c, a), cc);
   n->poly[0] = fe_mul<SF>(cc, one_minus_rho);
   n->poly[1] = fe_add<SF>(fe_mul<SF>(cc, two_rho_minus_one), fe_mul<SF>(b, one_minus_rho));
@@ -527,7 +527,7 @@ int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out
     t->lo_eff = t->hi_eff = (size_t)-1;
   }
   if (fe_is_zero(n->acc_eq)) return fail(SP_ERR_DIVISION_BY_ZERO, "sp_nifs_finish: eq(r_b, rho) is not invertible");
-  store_fe(out_T_out, fe_mul<SF>(n->T_cur, fe_inv<SF>(n->acc_eq)));  // :1205-1206
+  store_fe(out_T_out, fe_mul<SF>(n->T_cur, fe_inv_vartime<SF>(n->acc_eq)));  // :1205-1206
   store_fe(out_eq, n->acc_eq);
   n->m = 1;
   return SP_OK;

@@ -41,9 +41,11 @@ struct sp_ctx {
   fe_t* h_pinned = nullptr;  // small result buffer, pinned + mapped
   fe_t* d_pinned = nullptr;  // device-side address of h_pinned
   // challenge mailbox (kernels_poly.cuh mail_wait): in fine-grained device memory written through the PCIe BAR when the system has a large BAR
-  // (mail_dev), otherwise inside h_pinned. h_mail / d_mail = host-side / device-side address of the same 64-byte line.
+  // (mail_dev), otherwise inside h_pinned. h_mail / d_mail = host-side / device-side address of line 0 of the ring (MAIL_RING lines of 64 bytes, line = seq & 7).
   volatile uint32_t* h_mail = nullptr;
   const unsigned* d_mail = nullptr;
+  volatile uint32_t* h_mail_mirror = nullptr;  // mail_dev only: the host-memory copy of the ring (second path of mail_wait)
+  const unsigned* d_mail_mirror = nullptr;
   void* mail_alloc = nullptr;
   bool mail_dev = false;
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs

@@ -15,6 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <sys/random.h>
+#include <sys/types.h>
+#endif
 
 #define SP_HD __host__ __device__ __forceinline__
 
@@ -405,11 +409,13 @@ SP_HD fe_t fe_pow(const fe_t& x, const uint32_t e[8]) {
   return acc;
 }
 #if !defined(__HIP_DEVICE_COMPILE__)
-// Host-side inversion by the binary extended Euclidean algorithm on 4 x u64 (the host normalises a point per commitment and per MSM, and the prover
-// divides by 1 - r_y[0]: Fermat's 256 squarings + ~150 products cost 13 us, this about a third). Variable time: every value inverted here is public
-// (proof elements, transcript challenges). Same canonical result as Fermat; inv(0) == 0.
+// Host-side VARIABLE-TIME inversion by the binary extended Euclidean algorithm on 4 x u64 (Fermat's 256 squarings + ~150 products cost 13 us, this
+// about a third). Its running time depends on the value: call it directly (fe_inv_vartime) only on transcript-public values (1 - r_y[0], rho, acc_eq,
+// the tau_k, anything the verifier inverts); fe_inv below blinds its argument first. The input is canonicalised (one conditional subtraction: the
+// C ABI's load paths do not reduce caller data, and x == p would never leave the inner loop) and the loop is bounded (2 * 256 + 2 subtract steps are
+// enough for coprime values below 2^256); on a bound violation the caller falls back to Fermat. Same canonical result as Fermat; inv(0) == 0.
 template <class FP>
-inline fe_t fe_inv_host_xgcd(const fe_t& x) {
+inline bool fe_inv_host_xgcd(const fe_t& x, fe_t* out) {
   typedef unsigned __int128 u128;
   struct U4 {
     uint64_t w[4];
@@ -439,7 +445,11 @@ inline fe_t fe_inv_host_xgcd(const fe_t& x) {
     P.w[i] = (uint64_t)FP::P(2 * i) | ((uint64_t)FP::P(2 * i + 1) << 32);
     u.w[i] = (uint64_t)x.v[2 * i] | ((uint64_t)x.v[2 * i + 1] << 32);
   }
-  if (is_zero(u)) return x;
+  if (geq(u, P)) sub(u, P);  // non-canonical input (p <= x < 2^256 < 2p): reduce
+  if (is_zero(u)) {
+    *out = fe_zero();
+    return true;
+  }
   v = P;
   auto halve_mod = [&](U4& a) {  // a / 2 mod p
     uint64_t top = 0;
@@ -468,12 +478,16 @@ inline fe_t fe_inv_host_xgcd(const fe_t& x) {
       }
     }
   };
+  int budget = 2 * 256 + 2, halvings = 2 * 256 + 2;  // every subtract step is followed by at least one halving of u or v: bit length u + v falls each time
   while (!is_one(u) && !is_one(v)) {
+    if (--budget < 0) return false;
     while (!(u.w[0] & 1)) {
+      if (--halvings < 0) return false;
       shr1(u, 0);
       halve_mod(x1);
     }
     while (!(v.w[0] & 1)) {
+      if (--halvings < 0) return false;
       shr1(v, 0);
       halve_mod(x2);
     }
@@ -484,6 +498,7 @@ inline fe_t fe_inv_host_xgcd(const fe_t& x) {
       sub(v, u);
       sub_mod(x2, x1);
     }
+    if (is_zero(u) || is_zero(v)) return false;  // gcd != 1: cannot happen for a prime modulus and 0 < x < p
   }
   const U4& inv_raw = is_one(u) ? x1 : x2;  // (x R)^-1 as a plain residue = x^-1 R^-1
   fe_t y, r2, r3;
@@ -493,17 +508,89 @@ inline fe_t fe_inv_host_xgcd(const fe_t& x) {
   }
   for (int i = 0; i < 8; ++i) r2.v[i] = FP::R2(i);
   r3 = fe_mul_host64<FP>(r2, r2);   // R^2 R^2 / R = R^3
-  return fe_mul_host64<FP>(y, r3);  // x^-1 R^-1 R^3 / R = x^-1 R
+  *out = fe_mul_host64<FP>(y, r3);  // x^-1 R^-1 R^3 / R = x^-1 R
+  return true;
+}
+// 256 bits from a per-thread ChaCha20 stream keyed once from the kernel's entropy pool (getrandom(2)): the multiplicative mask of fe_inv. Returns false when
+// no entropy could be read (the caller then takes the constant-time path).
+inline bool sp_blind_mask(uint32_t out[8]) {
+  struct Stream {
+    uint32_t key[8];
+    uint64_t ctr = 0;
+    uint32_t blk[16];
+    int left = 0;
+    bool ok = false;
+    Stream() {
+      size_t got = 0;
+      uint8_t* p = reinterpret_cast<uint8_t*>(key);
+      for (int tries = 0; got < sizeof(key) && tries < 64; ++tries) {
+        ssize_t r = getrandom(p + got, sizeof(key) - got, 0);
+        if (r > 0) got += (size_t)r;
+      }
+      ok = got == sizeof(key);
+    }
+    void refill() {
+      uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+      for (int i = 0; i < 8; ++i) s[4 + i] = key[i];
+      s[12] = (uint32_t)ctr;
+      s[13] = (uint32_t)(ctr >> 32);
+      s[14] = s[15] = 0;
+      ++ctr;
+      uint32_t w[16];
+      for (int i = 0; i < 16; ++i) w[i] = s[i];
+      auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+      auto qr = [&](int a, int b, int c, int d) {
+        w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 16);
+        w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 12);
+        w[a] += w[b]; w[d] = rotl(w[d] ^ w[a], 8);
+        w[c] += w[d]; w[b] = rotl(w[b] ^ w[c], 7);
+      };
+      for (int r = 0; r < 10; ++r) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+      }
+      for (int i = 0; i < 16; ++i) blk[i] = w[i] + s[i];
+      left = 16;
+    }
+  };
+  static thread_local Stream st;
+  if (!st.ok) return false;
+  if (st.left < 8) st.refill();
+  for (int i = 0; i < 8; ++i) out[i] = st.blk[16 - st.left + i];
+  st.left -= 8;
+  return true;
 }
 #endif
+// x^(p-2): constant-time in x (fixed exponent, branch on public exponent bits only); inv(0) == 0
 template <class FP>
-SP_HD fe_t fe_inv(const fe_t& x) {  // inv(0) == 0; device: Fermat
-#if !defined(__HIP_DEVICE_COMPILE__)
-  return fe_inv_host_xgcd<FP>(x);
-#else
+SP_HD fe_t fe_inv_fermat(const fe_t& x) {
   uint32_t e[8], bw = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) e[i] = sp_subb(FP::P(i), i == 0 ? 2u : 0u, bw);
   return fe_pow<FP>(x, e);
+}
+// Inversion of a PUBLIC value (host: variable-time binary xgcd; device: Fermat). inv(0) == 0.
+template <class FP>
+SP_HD fe_t fe_inv_vartime(const fe_t& x) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  fe_t y;
+  if (fe_inv_host_xgcd<FP>(x, &y)) return y;
 #endif
+  return fe_inv_fermat<FP>(x);
+}
+// Inversion of a value that may be SECRET (witness-derived: the verifier circuit's blinded evaluations, the Z coordinates of commitments being
+// normalised). The reference's ff::Field::invert is constant-time. Host: the argument is multiplied by a fresh random mask m first, so the variable-time
+// xgcd runs on x*m — uniformly distributed whatever x is — and the mask is taken off again: (x m)^-1 m = x^-1 exactly; without an entropy source
+// (or a zero mask) it is Fermat's fixed exponentiation. Device: Fermat. inv(0) == 0.
+template <class FP>
+SP_HD fe_t fe_inv(const fe_t& x) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  fe_t m;
+  if (sp_blind_mask(m.v)) {
+    m.v[7] &= 0x7fffffffu;  // < 2^255 < p for both fields: canonical without a comparison
+    fe_t y;
+    if (!fe_is_zero(m) && fe_inv_host_xgcd<FP>(fe_mul_host64<FP>(x, m), &y)) return fe_mul_host64<FP>(y, m);
+  }
+#endif
+  return fe_inv_fermat<FP>(x);
 }

@@ -74,47 +74,89 @@ __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __r
 // touching the bus — or, without a large BAR, in mapped host memory (resident tail only). Lanes 0..12 of wave 0 read the thirteen words in ONE
 // instruction; a poll that straddles the host's stores fails the check and is repeated. Never hangs: after MAIL_WATCHDOG_TICKS (8 s) the error word in the mapped
 // result buffer is set and the kernel carries on with whatever it read.
-constexpr int TAIL_CHAL_ELEM = 8, TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in the mapped result buffer
+constexpr int TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in the mapped result buffer
+// The mailbox is a RING of MAIL_RING 64-byte lines indexed by the sequence number a challenge answers (line = seq & 7): a waiter only ever looks at the
+// line of ITS challenge, which the host does not touch again before eight more results are in. With the ring in device memory the host also keeps a
+// MIRROR of it in the mapped pinned buffer (MAIL_MIRROR_ELEM: written first, by ordinary stores); a waiter whose device line has not answered within
+// MAIL_MIRROR_AFTER_TICKS starts looking at the mirror as well (one PCIe read every MAIL_MIRROR_EVERY_TICKS): a second, independent path for the same
+// 64 bytes. Which path answered is counted in the diagnostics words (device memory, MAIL_DIAG_WORD of the mailbox page; sp_ctx_mail_stats).
+constexpr int MAIL_RING = 8, MAIL_LINE_WORDS = 16;
+constexpr int MAIL_MIRROR_ELEM = SLOT_BASE_ELEM + 4 * HOST_SUM_MAX_BLOCKS;  // 16 elements = 8 lines
+constexpr int MAIL_DIAG_WORD = 256;  // word offset in the device mailbox page: [0] answers taken from the mirror, [1] watchdog trips, [2] / [3] want / device-line seq of the last mirror answer
+constexpr unsigned long long MAIL_MIRROR_AFTER_TICKS = 3000ull, MAIL_MIRROR_EVERY_TICKS = 1000ull;  // 30 us, 10 us at the 100 MHz wall clock
 // 8 s at the 100 MHz wall clock. Long on purpose: an owner thread that the host's scheduler keeps away from its CPU (a throttled cgroup: the bench
 // boxes run under a 16-CPU quota) is late, not gone, and a late challenge only costs time while a tripped watchdog costs the proof.
 constexpr unsigned long long MAIL_WATCHDOG_TICKS = 800000000ull;
 struct MailRef {
-  const unsigned* mail;  // nullptr: the challenge is the kernel argument
-  fe_t* mapped;          // mapped pinned result buffer (error word at TAIL_ERR_ELEM)
-  unsigned answers;      // sequence number of the round result the awaited challenge answers
+  const unsigned* mail;    // nullptr: the challenge is the kernel argument; else word address of line 0 of the ring
+  const unsigned* mirror;  // device-side address of the host-memory mirror of the ring (nullptr when `mail` is in host memory itself)
+  fe_t* mapped;            // mapped pinned result buffer (error word at TAIL_ERR_ELEM)
+  unsigned answers;        // sequence number of the round result the awaited challenge answers
 };
-__device__ __forceinline__ bool mail_wait(const unsigned* mail, fe_t* mapped, unsigned want, fe_t* r_smem) {
+// wave-uniform: does the 13-word line held in lanes 0..12 of `w` carry the challenge answering `want`? (-1: the host aborted)
+__device__ __forceinline__ int mail_line_state(unsigned w, unsigned want, int lane) {
+  const unsigned flag = __shfl(w, 8, 64), chk = __shfl(w, 9, 64), chk2 = __shfl(w, 10, 64), flag2 = __shfl(w, 11, 64);
+  if (__shfl(w, 12, 64) != 0u) return -1;
+  if (flag != want || flag2 != want) return 0;
+  unsigned sum = lane < 8 ? w : 0u, wsum = lane < 8 ? (unsigned)(lane + 1) * w : 0u;
+#pragma unroll
+  for (int m = 4; m >= 1; m >>= 1) {
+    sum += __shfl_xor(sum, m, 64);
+    wsum += __shfl_xor(wsum, m, 64);
+  }
+  sum = __shfl(sum, 0, 64) + flag;
+  wsum = __shfl(wsum, 0, 64) + flag * SLOT_CHK_K;
+  return (sum == chk && wsum == chk2) ? 1 : 0;
+}
+__device__ __forceinline__ bool mail_wait(const unsigned* mail, const unsigned* mirror, fe_t* mapped, unsigned want, fe_t* r_smem) {
   __shared__ int ok;
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
+    const unsigned* line = mail + MAIL_LINE_WORDS * (want & (MAIL_RING - 1));
+    const unsigned* mline = mirror ? mirror + MAIL_LINE_WORDS * (want & (MAIL_RING - 1)) : nullptr;
     const unsigned long long t0 = wall_clock64();
-    int good = 0, aborted = 0;
-    unsigned w = 0;
+    unsigned long long next_mirror = t0 + MAIL_MIRROR_AFTER_TICKS;
+    int good = 0, aborted = 0, from_mirror = 0;
+    unsigned w = 0, wdev = 0;
     while (true) {
-      if (lane < 13) w = __hip_atomic_load(mail + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const unsigned flag = __shfl(w, 8, 64), chk = __shfl(w, 9, 64), chk2 = __shfl(w, 10, 64), flag2 = __shfl(w, 11, 64);
-      if (__shfl(w, 12, 64) != 0u) {  // aborted by the host (error exit of the round loop): leave without raising the watchdog error
+      if (lane < 13) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      int st = mail_line_state(w, want, lane);
+      if (st == 0 && mline) {
+        const unsigned long long now = wall_clock64();
+        if (now >= next_mirror) {  // the second path: the same line in host memory
+          wdev = w;
+          unsigned wm = 0;
+          if (lane < 13) wm = __hip_atomic_load(mline + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          st = mail_line_state(wm, want, lane);
+          if (st != 0) {
+            w = wm;
+            from_mirror = 1;
+          }
+          next_mirror = now + MAIL_MIRROR_EVERY_TICKS;
+        }
+      }
+      if (st < 0) {  // aborted by the host (error exit of the round loop): leave without raising the watchdog error
         aborted = 1;
         break;
       }
-      if (flag == want && flag2 == want) {
-        unsigned sum = lane < 8 ? w : 0u, wsum = lane < 8 ? (unsigned)(lane + 1) * w : 0u;
-#pragma unroll
-        for (int m = 4; m >= 1; m >>= 1) {
-          sum += __shfl_xor(sum, m, 64);
-          wsum += __shfl_xor(wsum, m, 64);
-        }
-        sum = __shfl(sum, 0, 64) + flag;
-        wsum = __shfl(wsum, 0, 64) + flag * SLOT_CHK_K;
-        if (sum == chk && wsum == chk2) {
-          good = 1;
-          break;
-        }
+      if (st > 0) {
+        good = 1;
+        break;
       }
       if (wall_clock64() - t0 > MAIL_WATCHDOG_TICKS) break;  // the host went away: never hang the device
       __builtin_amdgcn_s_sleep(1);
     }
     if (lane < 8) r_smem->v[lane] = w;
+    if (mline && lane == 0 && (from_mirror || (!good && !aborted))) {  // diagnostics (device memory: atomics are fine there)
+      unsigned* diag = const_cast<unsigned*>(mail) + MAIL_DIAG_WORD;
+      if (from_mirror) {
+        atomicAdd(diag + 0, 1u);
+        diag[2] = want;
+      } else {
+        atomicAdd(diag + 1, 1u);
+      }
+    }
+    if (mline && from_mirror && lane == 8) const_cast<unsigned*>(mail)[MAIL_DIAG_WORD + 3] = wdev;  // what the device line showed when the mirror answered
     if (!good && !aborted) {  // watchdog: leave what this poll saw next to the error word (diagnostics for the host's error message)
       const unsigned seen = lane < 13 ? w : 0u;
       if (lane < 13) reinterpret_cast<unsigned*>(mapped + TAIL_ERR_ELEM + 1)[lane] = seen;
@@ -135,7 +177,7 @@ __device__ __forceinline__ bool mail_wait(const unsigned* mail, fe_t* mapped, un
 __device__ __forceinline__ fe_t challenge_or(const MailRef& m, const fe_t& r_arg) {
   if (!m.mail) return r_arg;
   __shared__ fe_t r_sh;
-  mail_wait(m.mail, m.mapped, m.answers, &r_sh);
+  mail_wait(m.mail, m.mirror, m.mapped, m.answers, &r_sh);
   return r_sh;
 }
 
@@ -721,7 +763,7 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
 // sums to mapped pinned host memory (publish_result) and then POLLS a mapped host slot for the next challenge, which the host writes after
 // its transcript step. Cubic mode also delivers the third sum t(-1) (fallback_three_inputs, src/sumcheck.rs:1327-1396): the host uses it only
 // when tau * p is not invertible, otherwise it derives the evaluations from the claim exactly as the reference does (:1276-1324).
-// Slots in the mapped buffer: TAIL_CHAL_ELEM = the 64-byte mailbox line (challenge | sequence | check word), word 0 of TAIL_ERR_ELEM = error.
+// Slots in the mapped buffer: word 0 of TAIL_ERR_ELEM = error, TAIL_FINAL_ELEM = the final claims; the challenges arrive through the mailbox ring.
 constexpr int TAIL_THREADS = 1024;
 constexpr unsigned long long TAIL_WIDE_Q_CUBIC = 128;  // the cubic rounds bind three tables and weight every product: half the pairs per block keep its bind phase to one pass
 constexpr unsigned long long TAIL_WIDE_Q = 256;  // pairs per resident block and round: every product gets its own lane (3 * 256 <= TAIL_THREADS)
@@ -733,7 +775,8 @@ struct TailArgs {
   // rnd0 = 1-based index of the first round this kernel EVALUATES
   const fe_t *eq_pl, *eq_pr;
   int ell, first_half, rnd0;
-  const unsigned* mail;     // the challenge mailbox (see mail_wait)
+  const unsigned* mail;     // the challenge mailbox ring (see mail_wait)
+  const unsigned* mirror;   // its host-memory mirror, or nullptr
   int r0_from_mail;         // launched ahead of r0: the first round waits for the mailbox too
   fe_t* mapped;             // device address of the mapped pinned buffer (per-block result slots at SLOT_BASE_ELEM, error word)
   unsigned seq0;            // sequence number of the first result this kernel publishes
@@ -771,7 +814,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     const unsigned long long q = len / 4;
     if (len > 2 ? base >= q : blockIdx.x != 0) return;
     if (!first || a.r0_from_mail) {
-      if (!mail_wait(a.mail, a.mapped, seq - 1, &r_sh)) return;
+      if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 1, &r_sh)) return;
       r = r_sh;
     }
     // the previous round had 2q pairs: while that is more than one block's worth, the elements bound below were written by other blocks

@@ -89,6 +89,12 @@ class Context:
     def stats_filter(self, only: str = ""):
         check(lib().sp_ctx_stats_filter(self.h, only.encode()))
 
+    def mail_stats(self):
+        """(answers taken from the host-memory mirror, watchdog trips, wanted seq, device-line seq at the last mirror answer, ring in device memory)"""
+        out = (ctypes.c_uint64 * 5)()
+        check(lib().sp_ctx_mail_stats(self.h, out))
+        return tuple(int(v) for v in out)
+
     def kernel_stats(self, what: str):
         ms = ctypes.c_double()
         n = ctypes.c_uint64()

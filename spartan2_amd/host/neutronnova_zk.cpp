@@ -695,7 +695,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   vc.eval_X_core = eval_X(ps.core.publics);
   const fe_t den = fe_sub<S>(one, r_y[0]);
   if (fe_is_zero(den)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
-  const fe_t inv = fe_inv<S>(den);
+  const fe_t inv = fe_inv_vartime<S>(den);
   vc.eval_W_step = fe_mul<S>(fe_sub<S>(fin[2], fe_mul<S>(r_y[0], vc.eval_X_step)), inv);
   vc.eval_W_core = fe_mul<S>(fe_sub<S>(fin[3], fe_mul<S>(r_y[0], vc.eval_X_core)), inv);
   const size_t inner_final = hc.inner_start + pk.ny;

@@ -630,7 +630,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t eval_X = sparse_poly_evaluate(num_rounds_y - 1, X, r_y.data() + 1);
   const fe_t denom = fe_sub<S>(fe_one<S>(), r_y[0]);
   if (fe_is_zero(denom)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
-  const fe_t eval_W = fe_mul<S>(fe_sub<S>(eval_Z, fe_mul<S>(r_y[0], eval_X)), fe_inv<S>(denom));
+  const fe_t eval_W = fe_mul<S>(fe_sub<S>(eval_Z, fe_mul<S>(r_y[0], eval_X)), fe_inv_vartime<S>(denom));
   lap("inner+eval_W");
   const double t_inner = now_ms();
 

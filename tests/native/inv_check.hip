@@ -38,12 +38,38 @@ static int check(const char* name, int n) {
       }
       x = fe_from_uniform<FP>(b);
     }
-    const fe_t a = fe_inv_host_xgcd<FP>(x), f = fermat<FP>(x);
-    bool ok = fe_eq(a, f);
+    // three forms must agree: the raw xgcd (public values), the blinded inversion (possibly secret values) and Fermat's exponentiation
+    fe_t a;
+    const bool in_bound = fe_inv_host_xgcd<FP>(x, &a);
+    const fe_t f = fermat<FP>(x), bl = fe_inv<FP>(x), vt = fe_inv_vartime<FP>(x);
+    bool ok = in_bound && fe_eq(a, f) && fe_eq(bl, f) && fe_eq(vt, f);
     if (!fe_is_zero(x)) ok = ok && fe_eq(fe_mul<FP>(a, x), one);
     else ok = ok && fe_is_zero(a);
     if (!ok) {
       if (bad < 5) fprintf(stderr, "%s: mismatch at sample %d\n", name, k);
+      ++bad;
+    }
+  }
+  // non-canonical inputs (the C ABI does not reduce caller data): x = p is a zero, x = p + 5 is 5; neither may spin or differ
+  {
+    fe_t pp, p5, a, b;
+    uint32_t c = 0;
+    for (int i = 0; i < 8; ++i) pp.v[i] = FP::P(i);
+    for (int i = 0; i < 8; ++i) p5.v[i] = sp_addc(pp.v[i], i == 0 ? 5u : 0u, c);
+    fe_t five;  // the plain residue 5 read as a Montgomery representative, like p + 5
+    for (int i = 0; i < 8; ++i) five.v[i] = i == 0 ? 5u : 0u;
+    bool ok = fe_inv_host_xgcd<FP>(pp, &a) && fe_is_zero(a) && fe_is_zero(fe_inv_vartime<FP>(pp));
+    ok = ok && fe_inv_host_xgcd<FP>(p5, &a) && fe_inv_host_xgcd<FP>(five, &b) && fe_eq(a, b) && fe_eq(fe_inv_vartime<FP>(p5), b);
+    if (!ok) {
+      fprintf(stderr, "%s: non-canonical input mishandled\n", name);
+      ++bad;
+    }
+  }
+  // the blinding masks must differ from call to call (a constant mask would not blind anything)
+  {
+    uint32_t m1[8], m2[8];
+    if (!sp_blind_mask(m1) || !sp_blind_mask(m2) || !memcmp(m1, m2, sizeof(m1))) {
+      fprintf(stderr, "%s: blinding mask source is not producing fresh values\n", name);
       ++bad;
     }
   }

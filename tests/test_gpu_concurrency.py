@@ -25,20 +25,33 @@ def test_eight_proofs_in_flight_are_all_the_same_proof():
     # one polling owner thread per context (+ two mostly sleeping helpers): stay within half of the CPU quota of the box (16 on the bench boxes: 8)
     P, per = max(2, min(8, cpu_budget() // 2)), 20
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    def run():
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrency_stress.py"), "--contexts", str(P), "--proofs", str(per), "--json"],
-                           capture_output=True, text=True, timeout=900)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        assert line, (r.stdout + r.stderr)[-2000:]
-        return json.loads(line[-1])
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrency_stress.py"), "--contexts", str(P), "--proofs", str(per), "--json"],
+                       capture_output=True, text=True, timeout=900)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert line, (r.stdout + r.stderr)[-2000:]
+    out = json.loads(line[-1])
+    # No retry: the rare 8 s stall of round 2 was the host's own fallback — a result a few ms late made the wait call hipStreamSynchronize on a stream
+    # whose last kernel (issued ahead of its challenge) was waiting for that very host thread (capi_core.hip reduce_partials_wait). Any error here is a
+    # regression of the mailbox / slot protocol.
+    assert out["proofs"] == P * per and out["error_count"] == 0 and not out["errors"] and out["mismatches"] == 0, out
+    assert out["mail"]["watchdog_trips"] == 0, out
 
-    out = run()
-    assert out["proofs"] == P * per and out["mismatches"] == 0, out
-    if out["errors"]:
-        # Known and open ("a rarer stall"): with eight contexts in flight about one run of 3200 proofs in ten sees a late block of a
-        # launch issued ahead of its challenge run into its 8 s mailbox watchdog. It costs the proofs in flight then, never a wrong proof. A run of
-        # 160 proofs hits it with ~1 % probability; anything systematic fails the second run too.
-        known = ("timed out waiting for its challenge", "did not deliver", "did not finish delta")
-        assert all(any(k in e for k in known) for e in out["errors"]), out
-        out = run()
-    assert out["proofs"] == P * per and not out["errors"] and out["mismatches"] == 0, out
+
+def test_many_hardware_queues_do_not_stall():
+    """GPU_MAX_HW_QUEUES=24 (default 4) lets every stream of the eight contexts run beside the others: results arrive late far more often, which turned
+    round 2's stall from one per ~30 000 proofs into dozens per 3200. Must be clean now."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from spartan2_amd.dist import cpu_budget
+
+    P, per = max(2, min(8, cpu_budget() // 2)), 150
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "concurrency_stress.py"), "--contexts", str(P), "--proofs", str(per), "--json"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, GPU_MAX_HW_QUEUES="24"))
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert line, (r.stdout + r.stderr)[-2000:]
+    out = json.loads(line[-1])
+    assert out["proofs"] == P * per and out["error_count"] == 0 and out["mismatches"] == 0 and out["mail"]["watchdog_trips"] == 0, out

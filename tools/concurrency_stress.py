@@ -75,6 +75,10 @@ for t in ts:
 for t in ts:
     t.join()
 dt = time.perf_counter() - t0
+# challenge-mailbox diagnostics summed over the contexts: answers taken from the host-memory mirror (the device line had not answered), watchdog trips
+mail = [c.mail_stats() for c in ctxs]
+mail_sum = {"mirror_answers": sum(m[0] for m in mail), "watchdog_trips": sum(m[1] for m in mail), "ring_in_device_memory": bool(mail[0][4]),
+            "last_mirror_answer_wanted_vs_device_line": [(m[2], m[3]) for m in mail if m[0]][:4]}
 for e in errors[:12]:
     print("ERROR ctx %d proof %d: %s" % e)
 n = args.contexts * args.proofs
@@ -82,8 +86,8 @@ if args.json:
     import hashlib
     import json
 
-    print(json.dumps({"proofs_in_flight": args.contexts, "proofs": n, "seconds": dt, "ms_per_proof_amortised": dt / n * 1e3, "errors": [e[2] for e in errors[:3]],
+    print(json.dumps({"proofs_in_flight": args.contexts, "proofs": n, "seconds": dt, "ms_per_proof_amortised": dt / n * 1e3, "errors": [e[2] for e in errors[:3]], "error_count": len(errors), "mail": mail_sum,
                       "mismatches": mismatches, "proof_sha256": hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest(), "num_cons": inst.num_cons}))
     sys.exit(0)
-print(f"{n} proofs, {len(errors)} errors, {mismatches} mismatches, {dt / n * 1e3:.3f} ms per proof amortised")
+print(f"{n} proofs, {len(errors)} errors, {mismatches} mismatches, {dt / n * 1e3:.3f} ms per proof amortised; mailbox {mail_sum}")
 sys.exit(1 if errors or mismatches else 0)
