@@ -430,6 +430,22 @@ def main():
     barrier()
     elapsed_cached = group.max_over_ranks(time.perf_counter() - t0)
     snark.set_flags(prefix_cache=False)
+    # The reference-order driver (spartan_snark.cpp prove_reference_order): ONE thread, no helper jobs, no prep-time tables, only include/spartan_hip.h
+    # entry points called in the order of the statements of src/spartan.rs:226-466 — what an unchanged spartan.rs bound to the ABI gets. Reported beside
+    # the headline in every line; the headline is the C++ driver that arranges more overlap above the ABI.
+    snark.set_flags(reference_order=True)
+    words_r, _, _ = snark.prove(step_tape)
+    snark.prove(step_tape)
+    barrier()
+    t0 = time.perf_counter()
+    ref_phase = {}
+    for _ in range(args.steps):
+        words_r, _, ph_r = snark.prove(step_tape)
+        for k, v in ph_r.items():
+            ref_phase[k] = ref_phase.get(k, 0.0) + v
+    barrier()
+    elapsed_ref = group.max_over_ranks(time.perf_counter() - t0)
+    snark.set_flags(reference_order=False)
     # untimed extra pass with every kernel class instrumented (main and auxiliary streams), for the per-kernel breakdown
     ctx.reset_stats(True)
     ctx.stats_filter("")
@@ -568,6 +584,10 @@ def main():
             "transcript_prefix_cached": {"ms_per_step": elapsed_cached / args.steps * 1e3, "constraints_per_s": world * ncons * args.steps / elapsed_cached,
                                          "proof_identical": bool((words_c == words).all()),
                                          "note": "sponge state of new + vk + public_values + comm_W_precommitted kept across proves (FLAG_PREFIX_CACHE): not the headline"},
+            "reference_order": {"ms_per_step": elapsed_ref / args.steps * 1e3, "constraints_per_s": world * ncons * args.steps / elapsed_ref,
+                                "proof_identical": bool((words_r == words).all()), "phases_ms": {k: v / args.steps for k, v in ref_phase.items()},
+                                "headline_over_reference_order": elapsed / elapsed_ref,
+                                "note": "one thread, statement order of src/spartan.rs:226-466, ABI calls only (PCS::prove = one sp_hyrax_prove): the time of an unchanged spartan.rs over the ABI"},
             "roofline": {"bound": "hbm", "kernel": "k_bind_eval_cubic_stream<1> (outer sum-check: bind round 1 fused with the evaluation of round 2, 3 tables of 2^20)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": traffic_src, "launches": bind_launches, "avg_launch_us": bind_ms / max(bind_launches, 1) * 1e3,

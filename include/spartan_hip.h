@@ -239,7 +239,18 @@ int sp_hyrax_commit(sp_ctx* ctx, const sp_ck* ck, const sp_table* v, size_t off,
 int sp_fixed_base_mul_h(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t* out_aff);
 /* PCS::rerandomize_commitment (hyrax_pc.rs:321-344): out[i] = comm[i] + h * (r_new[i] - r_old[i]) (FixedBaseMul::mul per row) */
 int sp_hyrax_rerandomize(sp_ctx* ctx, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const uint64_t* r_old, const uint64_t* r_new, uint64_t* out_rows_aff);
-/* asynchronous form: begin() enqueues upload + kernel + download and returns, finish() waits and normalises */
+/* HyraxPCS::prove (src/provider/pcs/hyrax_pc.rs:387-478) with InnerProductArgumentLinear::prove (src/provider/pcs/ipa.rs:125-170) inside, the trait
+ * method SpartanSNARK::prove calls at src/spartan.rs:425-435: comm = `rows` affine row commitments of poly (a device-resident table of n = 2^npt
+ * elements, rows x cols), blinds = the rows' blinds, point = the evaluation point (row variables first), comm_eval / blind_eval = the commitment to the
+ * claimed evaluation under ck_eval (narrow key) and its blind. The IPA's randomness is an input (injected randomness): rng_d = the mask
+ * vector d (cols elements, ipa.rs:139-145), rng_rdelta / rng_rbeta = the blinds of delta and beta (:146-149). Absorbs / squeezes on `tr` exactly as the
+ * reference does. out = delta (8 words, affine) | beta (8) | z_vec (4 * cols) | z_delta (4) | z_beta (4): the InnerProductArgumentLinear fields. */
+int sp_hyrax_prove(sp_ctx* ctx, const sp_ck* ck, const sp_ck* ck_eval, sp_transcript* tr, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n,
+                   const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint64_t* rng_d,
+                   const uint64_t rng_rdelta[4], const uint64_t rng_rbeta[4], uint64_t* out);
+/* asynchronous form: begin() enqueues upload + kernel + download and returns, finish() waits and normalises. One job per context at a time: the jobs
+ * share the context's landing area, so begin() fails with SP_ERR_INVALID_INPUT_LENGTH while an earlier job (n above the host threshold) has not been
+ * finished; finish() consumes the job whatever it returns. */
 typedef struct sp_fb_job sp_fb_job;
 int sp_fixed_base_mul_h_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_fb_job** job);
 int sp_fixed_base_mul_h_finish(sp_ctx* ctx, sp_fb_job* job, uint64_t* out_aff);

@@ -288,6 +288,24 @@ int orc_hyrax_commit(void* k, const uint64_t* v, size_t n, const uint64_t* blind
   for (size_t i = 0; i < a.size(); ++i) store_aff(out_rows + 8 * i, a[i]);
   ORC_CATCH
 }
+// HyraxPCS::prove (hyrax_pc.rs:387-478) + the linear IPA (ipa.rs:125-170) as one call, for the ABI-level parity test of sp_hyrax_prove. The tape holds
+// d_vec (cols blocks), r_delta, r_beta in the reference's draw order. out = delta (8) | beta (8) | z_vec (4 * cols) | z_delta (4) | z_beta (4).
+int orc_hyrax_prove(void* k, void* k_eval, void* tr, const uint64_t* comm_rows, size_t rows, const uint64_t* poly, size_t n, const uint64_t* blinds, const uint64_t* point,
+                    size_t npt, const uint64_t* comm_eval, const uint64_t* blind_eval, const uint8_t* tape, size_t tape_blocks, uint64_t* out) {
+  ORC_TRY
+  HyraxKey *key = (HyraxKey*)k, *key_eval = (HyraxKey*)k_eval;
+  HyraxCommitment comm(rows), ce(1);
+  for (size_t i = 0; i < rows; ++i) comm[i] = Jac::from_affine(load_aff(comm_rows + 8 * i));
+  ce[0] = Jac::from_affine(load_aff(comm_eval));
+  Tape tp(tape, tape_blocks);
+  IpaProof p = hyrax_prove(*key, *key_eval, *(Transcript*)tr, comm, load<Fq>(poly, n), load<Fq>(blinds, rows), load<Fq>(point, npt), ce, load<Fq>(blind_eval, 1), tp);
+  store_aff(out, p.delta.to_affine());
+  store_aff(out + 8, p.beta.to_affine());
+  store(out + 16, p.z_vec);
+  std::vector<Fq> tail{p.z_delta, p.z_beta};
+  store(out + 16 + 4 * p.z_vec.size(), tail);
+  ORC_CATCH
+}
 int orc_rowmat_vec(const uint64_t* poly, const uint64_t* l, size_t rows, size_t cols, uint64_t* out) {  // bind_with_delayed
   std::vector<Fq> p = load<Fq>(poly, rows * cols), L = load<Fq>(l, rows);
   store(out, bind_with_delayed(p.data(), L, cols));

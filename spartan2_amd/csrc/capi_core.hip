@@ -172,10 +172,15 @@ void sp_ctx_destroy(sp_ctx* c) {
     if (c->h_pinned_lane[i]) hipHostFree(c->h_pinned_lane[i]);
   if (c->h_pinned_fb) hipHostFree(c->h_pinned_fb);
   if (c->h_pinned_fbs) hipHostFree(c->h_pinned_fbs);
-  if (c->h_mm) hipHostFree(c->h_mm);
+  for (void* p_ : c->h_mm)
+    if (p_) hipHostFree(p_);
+  delete c->pcs_worker;
+  if (c->h_pcs) hipHostFree(c->h_pcs);
+  if (c->pcs_ev) hipEventDestroy(c->pcs_ev);
   for (void* p_ : c->h_fbm)
     if (p_) hipHostFree(p_);
-  if (c->d_mm_work) hipFree(c->d_mm_work);
+  for (void* p_ : c->d_mm_work)
+    if (p_) hipFree(p_);
   if (c->h_stage) hipHostFree(c->h_stage);
   for (hipEvent_t e : c->stage_ev)
     if (e) hipEventDestroy(e);

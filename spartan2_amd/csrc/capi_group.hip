@@ -472,6 +472,7 @@ void sp_ck_free(sp_ck* k) {
   }
   if (k->d_bases) hipFree(k->d_bases);
   if (k->d_comb) hipFree(k->d_comb);
+  if (k->d_keytables) hipFree(k->d_keytables);
   if (k->d_cktables) hipFree(k->d_cktables);
   else if (k->d_htable) hipFree(k->d_htable);
   delete k;
@@ -548,9 +549,9 @@ static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t n
   });
   return SP_OK;
 }
-static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, void* out_, int D = 24) {  // D = 24: jac_t results, 32: xyzz_t
+// `seq` = the sequence number fb_mapped_launch gave the job being collected (c->fbm_seq[lane] right after the launch)
+static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, void* out_, unsigned seq, int D = 24) {  // D = 24: jac_t results, 32: xyzz_t
   unsigned* out = reinterpret_cast<unsigned*>(out_);
-  const unsigned seq = c->fbm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
   bool synced = false;
   const int T = spk::FB_SLOT_TAG;
@@ -589,7 +590,7 @@ static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, con
   if (!ds || !dout) return SP_ERR_NO_DEVICE;
   if (n <= FB_MAPPED_MAX && fb_mapped_enabled()) {  // the latency case (one call per round of the ZK verifier circuit): no copies, no synchronise
     int rc = fb_mapped_launch(c, 0, d_tables, ntables, scalars, n);
-    return rc ? rc : fb_mapped_collect(c, 0, n, out.data());
+    return rc ? rc : fb_mapped_collect(c, 0, n, out.data(), c->fbm_seq[0]);
   }
   if (n <= 1024) {
     // both copies through pinned memory, so neither stages through a bounce buffer
@@ -617,9 +618,14 @@ struct sp_fb_job {
   size_t n = 0;
   std::vector<jac_t> host_pts;  // filled directly for small n
   bool on_device = false, mapped = false;
+  unsigned seq = 0;  // mapped: the sequence number of THIS job's result slots
   jac_t* pinned = nullptr;
 };
 int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_fb_job** out) {
+  // the asynchronous forms share one landing area per context (the mapped scalar / slot page of lane 1, the pinned buffer + event of the copy form):
+  // a second job before the first one's finish would overwrite its scalars and hand the first finish the second job's points
+  if (n > FIXED_BASE_HOST_MAX && c->fb_async_busy)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "fixed_base_mul_h_begin: an asynchronous job is already outstanding on this context (finish it first)");
   sp_fb_job* job = new sp_fb_job();
   job->n = n;
   if (n <= FIXED_BASE_HOST_MAX) {
@@ -636,6 +642,8 @@ int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalar
       return rc;
     }
     job->mapped = true;
+    job->seq = c->fbm_seq[1];
+    c->fb_async_busy = true;
   } else {
     if (n * sizeof(jac_t) > 4096 * sizeof(jac_t)) {
       delete job;
@@ -657,15 +665,17 @@ int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalar
     SP_HIP(hipEventRecord(c->fb_event(), c->stream2));
     job->on_device = true;
     job->pinned = (jac_t*)c->h_pinned_fb;
+    c->fb_async_busy = true;
   }
   *out = job;
   return SP_OK;
 }
 int sp_fixed_base_mul_h_finish(sp_ctx* c, sp_fb_job* job, uint64_t* out_aff) {
   std::vector<jac_t> pts;
+  if (job->mapped || job->on_device) c->fb_async_busy = false;
   if (job->mapped) {
     pts.resize(job->n);
-    int rc = fb_mapped_collect(c, 1, job->n, pts.data());
+    int rc = fb_mapped_collect(c, 1, job->n, pts.data(), job->seq);
     if (rc) {
       delete job;
       return rc;
@@ -920,6 +930,17 @@ int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_a
   return SP_OK;
 }
 
+// bind_with_delayed (hyrax_pc.rs:38-54) on `st`: the one-launch streaming kernel for tall matrices, else the two-stage form
+static void launch_rowmat_vec(hipStream_t st, const fe_t* poly, size_t rows, size_t cols, const fe_t* dL, fe_t* part, size_t splits, fe_t* dout) {
+  const char* e = getenv("SPARTAN_ROWMAT_TALL");  // "0": the two-stage form for every shape (A/B runs, tests)
+  const bool tall_ok = !(e && e[0] == '0');
+  if (tall_ok && rows >= 128 && cols % spk::RMV_COLS == 0) {
+    hipLaunchKernelGGL(spk::k_rowmat_vec_tall, dim3((unsigned)(cols / spk::RMV_COLS)), dim3(1024), 0, st, poly, rows, cols, dL, dout);
+    return;
+  }
+  hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly, rows, cols, dL, part);
+  hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, splits, cols, dout);
+}
 int sp_rowmat_vec(sp_ctx* c, const sp_table* poly, size_t rows, size_t cols, const uint64_t* L, uint64_t* out) {
   if (rows * cols > poly->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed: poly shorter than rows*cols");
   if (rows == 0 || cols == 0) return SP_OK;
@@ -929,11 +950,7 @@ int sp_rowmat_vec(sp_ctx* c, const sp_table* poly, size_t rows, size_t cols, con
   fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, cols * sizeof(fe_t));
   if (!dL || !part || !dout) return SP_ERR_NO_DEVICE;
   SP_HIP(hipMemcpyAsync(dL, L, rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-  c->timed("rowmat_vec", 32ull * (rows * cols + rows + cols), [&] {
-    hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, c->stream, poly->d, rows, cols,
-                       dL, part);
-    hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, c->stream, part, splits, cols, dout);
-  });
+  c->timed("rowmat_vec", 32ull * (rows * cols + rows + cols), [&] { launch_rowmat_vec(c->stream, poly->d, rows, cols, dL, part, splits, dout); });
   SP_HIP(hipMemcpyAsync(out, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
   SP_HIP(hipStreamSynchronize(c->stream));
   return SP_OK;
@@ -1118,10 +1135,7 @@ int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, s
     SP_HIP(hipMemcpyAsync(dL, w.data(), rows * sizeof(fe_t), hipMemcpyHostToDevice, st));
     SP_HIP(hipStreamSynchronize(st));  // w is a local
   }
-  c->timed_on(st, "rowmat_vec", 32ull * (rows * cols + rows + cols), [&] {
-    hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly->d, rows, cols, dL, part);
-    hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, splits, cols, dout);
-  });
+  c->timed_on(st, "rowmat_vec", 32ull * (rows * cols + rows + cols), [&] { launch_rowmat_vec(st, poly->d, rows, cols, dL, part, splits, dout); });
   SP_HIP(hipMemcpyAsync(c->h_pinned_vec, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, st));
   SP_HIP(hipEventRecord(c->vec_ev, st));
   sp_vec_job* job = new sp_vec_job();
@@ -1144,20 +1158,15 @@ struct sp_fbtables {
   size_t n = 0;
   aff_t* d_tables = nullptr;  // n x 32 x 255 affine multiples
 };
-static int multi_mul_ensure(sp_ctx* c);
-int sp_fbtables_create(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtables** out) {
-  if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_create: 1 .. 2048 points");
-  {
-    int erc = multi_mul_ensure(c);
-    if (erc) return erc;
-  }
+// one 32 x 255 table of affine multiples per point (FixedBaseMul::precompute, msm.rs:653-689, for every point), built on the main stream
+static int build_window_tables(sp_ctx* c, const aff_t* host_points, size_t n, aff_t** out_tables) {
   const size_t per = 32 * 255;
   DevBuf pts, tj;
   int rc;
   if ((rc = pts.alloc(n * sizeof(aff_t))) || (rc = tj.alloc(n * per * sizeof(jac_t)))) return rc;
   aff_t* tables = nullptr;
   SP_HIP(hipMalloc((void**)&tables, n * per * sizeof(aff_t)));
-  hipError_t e = hipMemcpyAsync(pts.p, points_aff, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream);
+  hipError_t e = hipMemcpyAsync(pts.p, host_points, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(spk::k_fixed_base_tables, dim3((unsigned)n), dim3(64), 0, c->stream, pts.as<aff_t>(), n, tj.as<jac_t>());
     hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), n * per, tables);
@@ -1165,8 +1174,17 @@ int sp_fbtables_create(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtab
   }
   if (e != hipSuccess) {
     hipFree(tables);
-    return fail(SP_ERR_NO_DEVICE, std::string("sp_fbtables_create: ") + hipGetErrorString(e));
+    return fail(SP_ERR_NO_DEVICE, std::string("window tables: ") + hipGetErrorString(e));
   }
+  *out_tables = tables;
+  return SP_OK;
+}
+int sp_fbtables_create(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtables** out) {
+  if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_create: 1 .. 4096 points");
+  int erc = sp::multi_mul_ensure(c, 1);
+  if (erc) return erc;
+  aff_t* tables = nullptr;
+  if ((erc = build_window_tables(c, reinterpret_cast<const aff_t*>(points_aff), n, &tables))) return erc;
   sp_fbtables* t = new sp_fbtables();
   t->n = n;
   t->d_tables = tables;
@@ -1178,38 +1196,44 @@ void sp_fbtables_free(sp_fbtables* t) {
   if (t->d_tables) hipFree(t->d_tables);
   delete t;
 }
-// sum_i scalars[i] * point_i in one launch on the AUXILIARY stream (callable from a helper thread beside the owner's calls on the main stream, like
-// sp_msm_eq_begin): scalars and result through mapped pinned pages, no copies, no host-side tail (kernels_msm.cuh k_multi_mul_coop). The caller polls
-// the self-validating result slot; a poll that runs long (profiler, debugger) falls back to a stream synchronise, after which the slot must be valid.
-// _begin launches, _finish polls (one multiplication in flight per context).
-static int multi_mul_ensure(sp_ctx* c) {  // (done by sp_fbtables_create: see fb_mapped_ensure)
+}  // extern "C"
+namespace sp {
+// sum_i scalars[i] * point_i in ONE launch (kernels_msm.cuh k_multi_mul_coop): scalars and result through mapped pinned pages, no copies, no host-side
+// tail. Two lanes per context, each with its own pages / ticket / sequence number: lane 1 on the auxiliary stream (callable from a helper thread
+// beside the owner's calls on the main stream, like sp_msm_eq_begin), lane 0 on the main stream. The caller polls the self-validating result slot;
+// a poll that runs long (profiler, debugger) falls back to a stream synchronise, after which the slot must be valid.
+int multi_mul_ensure(sp_ctx* c, int lane) {
   const size_t page = 256 + 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
-  if (!c->h_mm) {
-    SP_HIP(hipHostMalloc(&c->h_mm, page, hipHostMallocMapped));
-    memset(c->h_mm, 0, page);
-    SP_HIP(hipHostGetDevicePointer(&c->d_mm, c->h_mm, 0));
-    SP_HIP(hipMalloc(&c->d_mm_work, 256 + spk::MULTI_MUL_MAX_BLOCKS * sizeof(xyzz_t)));
-    SP_HIP(hipMemsetAsync(c->d_mm_work, 0, 256, c->stream2));  // the ticket; every launch leaves it at zero again
+  if (!c->h_mm[lane]) {
+    SP_HIP(hipHostMalloc(&c->h_mm[lane], page, hipHostMallocMapped));
+    memset(c->h_mm[lane], 0, page);
+    SP_HIP(hipHostGetDevicePointer(&c->d_mm[lane], c->h_mm[lane], 0));
+    SP_HIP(hipMalloc(&c->d_mm_work[lane], 256 + spk::MULTI_MUL_MAX_BLOCKS * sizeof(xyzz_t)));
+    SP_HIP(hipMemsetAsync(c->d_mm_work[lane], 0, 256, c->stream2));  // the ticket; every launch leaves it at zero again
     SP_HIP(hipStreamSynchronize(c->stream2));
   }
   return SP_OK;
 }
-int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n) {
-  if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
-  int erc = multi_mul_ensure(c);
+// `scalars`: n host scalars (copied into the lane's mapped page), or — `d_scalars` given — n - 1 scalars already in device memory followed by `last`
+int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last) {
+  if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multi_mul: 1 .. 4096 scalars");
+  int erc = multi_mul_ensure(c, lane);
   if (erc) return erc;
-  memcpy((char*)c->h_mm + 256, scalars, n * sizeof(fe_t));
-  if (++c->mm_seq == 0) ++c->mm_seq;
-  c->timed_on(c->stream2, "multi_mul", 32ull * n, [&] {
-    hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, c->stream2, reinterpret_cast<const fe_t*>((char*)c->d_mm + 256), n, t->d_tables,
-                       reinterpret_cast<xyzz_t*>((char*)c->d_mm_work + 256), reinterpret_cast<unsigned*>(c->d_mm_work), reinterpret_cast<unsigned*>(c->d_mm), c->mm_seq);
+  if (!d_scalars) memcpy((char*)c->h_mm[lane] + 256, scalars, n * sizeof(fe_t));
+  if (++c->mm_seq[lane] == 0) ++c->mm_seq[lane];
+  const unsigned seq = c->mm_seq[lane];
+  hipStream_t st = lane ? c->stream2 : c->stream;
+  const fe_t* src = d_scalars ? d_scalars : reinterpret_cast<const fe_t*>((char*)c->d_mm[lane] + 256);
+  const fe_t lastv = last ? *last : fe_zero();
+  c->timed_on(st, "multi_mul", 32ull * n, [&] {
+    hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, src, n, d_tables, reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256),
+                       reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq, lastv, last ? 1 : 0);
   });
+  if (seq_out) *seq_out = seq;
   return SP_OK;
 }
-int sp_fbtables_multi_mul_finish(sp_ctx* c, uint64_t out_aff[8]) {
-  if (!c->h_mm || c->mm_seq == 0) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul_finish: nothing in flight");
-  const unsigned seq = c->mm_seq;
-  volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>(c->h_mm);
+int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield) {
+  volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>(c->h_mm[lane]);
   unsigned w[24];
   bool synced = false;
   for (long spins = 0;; ++spins) {
@@ -1224,23 +1248,254 @@ int sp_fbtables_multi_mul_finish(sp_ctx* c, uint64_t out_aff[8]) {
       if (slot[24] == seq && slot[25] == a && slot[26] == b && slot[27] == seq) break;
     }
     if (spins > 400000) {
-      if (synced) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul: the kernel did not deliver its result slot");
-      SP_HIP(hipStreamSynchronize(c->stream2));  // e.g. under a profiler
+      if (synced) return fail(SP_ERR_INTERNAL, "multi_mul: the kernel did not deliver its result slot");
+      SP_HIP(hipStreamSynchronize(lane ? c->stream2 : c->stream));  // e.g. under a profiler
       synced = true;
       spins = 0;
     }
-    // the caller is a helper thread and the kernel takes ~130 us: past that it is late because the chip is shared, and the poll yields its CPU
-    if (spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    // a helper-thread caller: the kernel takes ~130 us; past that it is late because the chip is shared, and the poll yields its CPU
+    if (yield && spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(20));
     else __builtin_ia32_pause();
   }
+  memcpy(out, w, sizeof(jac_t));
+  return SP_OK;
+}
+// window tables of the whole key (num_cols bases, then h), built on first use: every MSM over the key — the IPA mask commitment delta, comm_LZ —
+// becomes one table walk (1.07 GB for the 2048-wide key; 288 GB of HBM make the trade free)
+int ck_key_tables(sp_ctx* c, const sp_ck* ck) {
+  {
+    const char* e = getenv("SPARTAN_KEY_TABLES");  // "0": keep the bucket MSMs (A/B runs, tests of the fallback)
+    if (e && e[0] == '0') return 1;
+  }
+  if (ck->d_keytables) return SP_OK;
+  if (ck->keytables_failed) return 1;
+  if (ck->num_cols + 1 > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return 1;
+  std::vector<aff_t> pts(ck->num_cols + 1);
+  hipError_t e = hipMemcpy(pts.data(), ck->d_bases, ck->num_cols * sizeof(aff_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("key tables: ") + hipGetErrorString(e));
+  pts[ck->num_cols] = ck->h;
+  aff_t* tables = nullptr;
+  int rc = build_window_tables(c, pts.data(), pts.size(), &tables);
+  if (rc) {
+    ck->keytables_failed = true;  // out of memory: the bucket MSM stays
+    return 1;
+  }
+  ck->d_keytables = tables;
+  return SP_OK;
+}
+}  // namespace sp
+extern "C" {
+// _begin launches on the auxiliary stream, _finish polls (one multiplication in flight per context and lane).
+int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n) {
+  if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
+  return sp::multi_mul_launch(c, 1, t->d_tables, scalars, n, nullptr, nullptr, nullptr);
+}
+int sp_fbtables_multi_mul_finish(sp_ctx* c, uint64_t out_aff[8]) {
+  if (!c->h_mm[1] || c->mm_seq[1] == 0) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul_finish: nothing in flight");
   jac_t sum;
-  memcpy(&sum, w, sizeof(jac_t));
+  int rc = sp::multi_mul_collect(c, 1, c->mm_seq[1], &sum, true);
+  if (rc) return rc;
   store_aff(out_aff, jac_to_affine(sum));
   return SP_OK;
 }
 int sp_fbtables_multi_mul(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n, uint64_t out_aff[8]) {
   int rc = sp_fbtables_multi_mul_begin(c, t, scalars, n);
   return rc ? rc : sp_fbtables_multi_mul_finish(c, out_aff);
+}
+
+// ---- HyraxPCS::prove (src/provider/pcs/hyrax_pc.rs:387-478) + InnerProductArgumentLinear::prove (src/provider/pcs/ipa.rs:125-170) ----------------------
+// ONE call in the place where the reference's trait method sits, so that a caller that follows src/spartan.rs:423-437 statement by statement gets the
+// overlap below the ABI that the C++ driver used to arrange above it:
+//   * the 64-byte-per-row transcript encoding of `comm` and the Keccak blocks of absorb(b"poly_com", comm) run on the context's helper thread,
+//   * delta = <d, ck> + r_delta h (ipa.rs:147) and comm_LZ = <LZ, ck> + r_LZ h (hyrax_pc.rs:454-455) are table walks over the window tables of the
+//     whole key (ck_key_tables: one launch each, no digits / sort / buckets / host Horner) on two streams side by side; LZ = L^T poly
+//     (bind_with_delayed, :38-54) stays in device memory in front of its walk and travels to the host only for z_vec,
+//   * the host meanwhile forms r_LZ = <L, blind>, <R, d> (tensor form: n + sqrt(n) products) and beta.
+// Transcript order and every value are the reference's. out = delta (8) | beta (8) | z_vec (4 * cols) | z_delta (4) | z_beta (4) words.
+static void hp_point_bytes(const aff_t& a, uint8_t out[64]) {  // x BE || y BE (src/provider/traits.rs:288-305)
+  sp::fe_to_be_bytes<B>(a.x, out);
+  sp::fe_to_be_bytes<B>(a.y, out + 32);
+}
+int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcript* tr, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n,
+                   const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint64_t* rng_d,
+                   const uint64_t rng_rdelta[4], const uint64_t rng_rbeta[4], uint64_t* out) {
+  typedef spk::SF SF;
+  if (!c || !ck || !ck_eval || !tr || !comm_rows_aff || !poly || !blinds || (!point && npt) || !comm_eval_aff || !blind_eval || !rng_d || !rng_rdelta || !rng_rbeta || !out)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_hyrax_prove: null argument");
+  if (npt > 40 || n != ((size_t)1 << npt) || n > poly->cap)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: Expected 2^point.len() elements in poly");  // hyrax_pc.rs:400-408
+  const size_t num_cols = ck->num_cols, num_rows = (n + num_cols - 1) / num_cols;
+  if (num_rows & (num_rows - 1)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: the row count must be a power of two");
+  if (rows != num_rows) return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: one commitment row and one blind per matrix row");
+  size_t nvr = 0;
+  while (((size_t)1 << nvr) < num_rows) ++nvr;
+  const size_t cols = n / num_rows;  // |R| = |LZ| = |d|
+  if (!ck_eval->d_cktables || ck_eval->num_cols < 1) return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: ck_eval must be a narrow key with tables");
+  SP_HIP(hipSetDevice(c->device));
+  const aff_t* comm = reinterpret_cast<const aff_t*>(comm_rows_aff);
+  const fe_t* blind = reinterpret_cast<const fe_t*>(blinds);
+  const fe_t* pt = reinterpret_cast<const fe_t*>(point);
+  const fe_t* dvec = reinterpret_cast<const fe_t*>(rng_d);
+  fe_t r_delta, r_beta, b_eval;
+  memcpy(&r_delta, rng_rdelta, 32);
+  memcpy(&r_beta, rng_rbeta, 32);
+  memcpy(&b_eval, blind_eval, 32);
+  aff_t comm_eval;
+  memcpy(&comm_eval, comm_eval_aff, sizeof(aff_t));
+
+  // (1) helper thread: transcript.absorb(b"poly_com", comm) (hyrax_pc.rs:410) into a copy of the running hasher, installed at the join below
+  if (!c->pcs_worker) c->pcs_worker = new sp::Worker();
+  sp::Keccak256State hashed = tr->t.h;
+  {
+    sp::Keccak256State* hp = &hashed;
+    c->pcs_worker->submit([hp, comm, rows] {
+      static const char* b = "poly_commitment_begin";  // HyraxCommitment::to_transcript_bytes (hyrax_pc.rs:714-729)
+      static const char* e = "poly_commitment_end";
+      hp->update(reinterpret_cast<const uint8_t*>("poly_com"), 8);
+      hp->update(reinterpret_cast<const uint8_t*>(b), strlen(b));
+      uint8_t buf[64 * 16];
+      for (size_t i = 0; i < rows; i += 16) {
+        const size_t m = rows - i < 16 ? rows - i : 16;
+        for (size_t k = 0; k < m; ++k) hp_point_bytes(comm[i + k], buf + 64 * k);
+        hp->update(buf, 64 * m);
+      }
+      hp->update(reinterpret_cast<const uint8_t*>(e), strlen(e));
+    });
+  }
+  struct Join {
+    sp::Worker* w;
+    ~Join() { w->wait(); }
+  } join{c->pcs_worker};
+
+  // (2) device: delta's walk on the auxiliary stream, LZ and comm_LZ's walk on the main stream
+  const int kt = (nvr == 0 && cols > num_cols) ? 1 : sp::ck_key_tables(c, ck);
+  if (kt < 0) return kt;
+  const bool walk = kt == 0;
+  std::vector<fe_t> LZ(cols);
+  fe_t r_LZ;
+  aff_t comm_LZ, delta;
+  unsigned seq_delta = 0, seq_lz = 0;
+  sp_msm_job* delta_job = nullptr;
+  struct JobGuard {  // an error exit must not leave the asynchronous MSM of the fallback path outstanding
+    sp_ctx* c;
+    sp_msm_job*& j;
+    ~JobGuard() {
+      uint64_t sink[8];
+      if (j) sp_msm_job_finish(c, j, sink);
+      j = nullptr;
+    }
+  } job_guard{c, delta_job};
+  int rc;
+  if (walk) {
+    std::vector<fe_t> sc(num_cols + 1, fe_zero());
+    memcpy(sc.data(), dvec, cols * sizeof(fe_t));
+    sc[num_cols] = r_delta;
+    if ((rc = sp::multi_mul_launch(c, 1, ck->d_keytables, reinterpret_cast<const uint64_t*>(sc.data()), num_cols + 1, &seq_delta, nullptr, nullptr))) return rc;
+  } else {
+    if ((rc = sp_msm_ck_begin(c, ck, rng_d, cols, &delta_job))) return rc;
+  }
+  std::vector<fe_t> L((size_t)1 << nvr);
+  eq_table_host(pt, nvr, L.data());
+  if (nvr == 0) {  // a single row: the commitment is the row itself (hyrax_pc.rs:417-423)
+    comm_LZ = comm[0];
+    if ((rc = sp_table_read(c, poly, 0, n, reinterpret_cast<uint64_t*>(LZ.data())))) return rc;
+    r_LZ = blind[0];
+  } else {
+    r_LZ = fe_zero();
+    for (size_t i = 0; i < num_rows; ++i) r_LZ = fe_add<SF>(r_LZ, fe_mul<SF>(L[i], blind[i]));
+    if (walk) {
+      if (!c->pcs_ev) SP_HIP(hipEventCreateWithFlags(&c->pcs_ev, hipEventDisableTiming));
+      if (c->h_pcs_bytes < cols * sizeof(fe_t)) {
+        if (c->h_pcs) hipHostFree(c->h_pcs);
+        c->h_pcs = nullptr;
+        c->h_pcs_bytes = 0;
+        SP_HIP(hipHostMalloc(&c->h_pcs, cols * sizeof(fe_t)));
+        c->h_pcs_bytes = cols * sizeof(fe_t);
+      }
+      const size_t splits = num_rows < 64 ? num_rows : 64;
+      fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, num_rows * sizeof(fe_t));
+      fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t));
+      fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, (num_cols + 1) * sizeof(fe_t));
+      if (!dL || !part || !dout) return SP_ERR_NO_DEVICE;
+      if (nvr <= 10) {  // L = left (x) right from two half tables passed by value
+        spk::EqTensorArgs a;
+        const size_t hb = nvr / 2, lb = nvr - hb;
+        eq_table_host(pt, hb, a.left);
+        eq_table_host(pt + hb, lb, a.right);
+        a.lo_bits = (int)lb;
+        a.n = (unsigned)num_rows;
+        hipLaunchKernelGGL(spk::k_eq_tensor<false>, dim3((unsigned)((num_rows + 255) / 256)), dim3(256), 0, c->stream, a, dL);
+      } else {
+        SP_HIP(hipMemcpyAsync(dL, L.data(), num_rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));  // (L outlives the stream work: joined below)
+      }
+      if (cols < num_cols) SP_HIP(hipMemsetAsync(dout + cols, 0, (num_cols - cols) * sizeof(fe_t), c->stream));
+      c->timed("rowmat_vec", 32ull * (num_rows * cols + num_rows + cols), [&] { launch_rowmat_vec(c->stream, poly->d, num_rows, cols, dL, part, splits, dout); });
+      SP_HIP(hipMemcpyAsync(c->h_pcs, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
+      SP_HIP(hipEventRecord(c->pcs_ev, c->stream));
+      if ((rc = sp::multi_mul_launch(c, 0, ck->d_keytables, nullptr, num_cols + 1, &seq_lz, dout, &r_LZ))) return rc;
+    } else {
+      if ((rc = sp_rowmat_vec(c, poly, num_rows, cols, reinterpret_cast<const uint64_t*>(L.data()), reinterpret_cast<uint64_t*>(LZ.data())))) return rc;
+    }
+  }
+  // (3) host work under the device's: <R, d> with R = eq(point[nvr..]) = left (x) right (ipa.rs:148), beta = ck_c * <R, d> + h_c * r_beta (:149)
+  fe_t ip = fe_zero();
+  {
+    const size_t k = npt - nvr, hb = k / 2;
+    std::vector<fe_t> left((size_t)1 << hb), right((size_t)1 << (k - hb));
+    eq_table_host(pt + nvr, hb, left.data());
+    eq_table_host(pt + nvr + hb, k - hb, right.data());
+    for (size_t a = 0; a < left.size(); ++a) {
+      fe_t inner = fe_zero();
+      for (size_t b2 = 0; b2 < right.size(); ++b2) inner = fe_add<SF>(inner, fe_mul<SF>(right[b2], dvec[a * right.size() + b2]));
+      ip = fe_add<SF>(ip, fe_mul<SF>(left[a], inner));
+    }
+  }
+  aff_t beta;
+  if ((rc = sp_hyrax_commit_small(c, ck_eval, reinterpret_cast<const uint64_t*>(&ip), 1, rng_rbeta, reinterpret_cast<uint64_t*>(&beta)))) return rc;
+  // (4) joins
+  if (walk) {
+    jac_t dj;
+    if ((rc = sp::multi_mul_collect(c, 1, seq_delta, &dj, false))) return rc;
+    delta = jac_to_affine(dj);
+    if (nvr != 0) {
+      jac_t lj;
+      if ((rc = sp::multi_mul_collect(c, 0, seq_lz, &lj, false))) return rc;
+      comm_LZ = jac_to_affine(lj);
+      SP_HIP(hipEventSynchronize(c->pcs_ev));
+      memcpy(LZ.data(), c->h_pcs, cols * sizeof(fe_t));
+    }
+  } else {
+    if (nvr != 0 && (rc = sp_msm_ck(c, ck, reinterpret_cast<const uint64_t*>(LZ.data()), cols, reinterpret_cast<const uint64_t*>(&r_LZ), reinterpret_cast<uint64_t*>(&comm_LZ))))
+      return rc;
+    sp_msm_job* j = delta_job;
+    delta_job = nullptr;
+    if ((rc = sp_msm_ck_finish(c, ck, j, rng_rdelta, reinterpret_cast<uint64_t*>(&delta)))) return rc;
+  }
+  c->pcs_worker->wait();
+  tr->t.h = hashed;
+  // (5) InnerProductArgumentLinear::prove, transcript part (ipa.rs:132-158)
+  {
+    static const char* ds = "inner product argument (linear)";
+    tr->t.dom_sep(reinterpret_cast<const uint8_t*>(ds), strlen(ds));
+    uint8_t b[128];
+    hp_point_bytes(comm_LZ, b);
+    hp_point_bytes(comm_eval, b + 64);
+    tr->t.absorb(reinterpret_cast<const uint8_t*>("U"), 1, b, 128);
+    hp_point_bytes(delta, b);
+    tr->t.absorb(reinterpret_cast<const uint8_t*>("delta"), 5, b, 64);
+    hp_point_bytes(beta, b);
+    tr->t.absorb(reinterpret_cast<const uint8_t*>("beta"), 4, b, 64);
+  }
+  fe_t rr;
+  if (!tr->t.squeeze<SF>(reinterpret_cast<const uint8_t*>("r"), 1, &rr)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+  // (6) z_vec = r * LZ + d, z_delta = r * r_LZ + r_delta, z_beta = r * blind_eval + r_beta (ipa.rs:160-168)
+  memcpy(out, &delta, sizeof(aff_t));
+  memcpy(out + 8, &beta, sizeof(aff_t));
+  fe_t* zv = reinterpret_cast<fe_t*>(out + 16);
+  for (size_t i = 0; i < cols; ++i) zv[i] = fe_add<SF>(fe_mul<SF>(rr, LZ[i]), dvec[i]);
+  zv[cols] = fe_add<SF>(fe_mul<SF>(rr, r_LZ), r_delta);
+  zv[cols + 1] = fe_add<SF>(fe_mul<SF>(rr, b_eval), r_beta);
+  return SP_OK;
 }
 
 int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]) {
@@ -1257,7 +1512,7 @@ int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, s
     if (cols + 1 <= FB_MAPPED_MAX && fb_mapped_enabled()) {  // the walks come back as (X, Y, ZZ, ZZZ) and are added in that form
       std::vector<xyzz_t> xs(cols + 1);
       int rc = fb_mapped_launch(c, 0, ck->d_cktables, cols + 1, reinterpret_cast<const uint64_t*>(sc.data()), cols + 1, true);
-      if (rc || (rc = fb_mapped_collect(c, 0, cols + 1, xs.data(), 32))) return rc;
+      if (rc || (rc = fb_mapped_collect(c, 0, cols + 1, xs.data(), c->fbm_seq[0], 32))) return rc;
       xyzz_t acc = xyzz_identity();
       for (const xyzz_t& p : xs) acc = xyzz_add(acc, p);
       store_aff(out_aff, jac_to_affine(xyzz_to_jac(acc)));

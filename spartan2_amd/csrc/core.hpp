@@ -4,9 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spartan_hip.h"
@@ -23,6 +27,60 @@ int fail(int code, const std::string& msg);
     hipError_t _e = (expr);                                                                        \
     if (_e != hipSuccess) return sp::fail(SP_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
+
+// One sleeping helper thread of a context for host work that a library call can run beside its own device work (sp_hyrax_prove: the 64 KiB
+// transcript encoding of the commitment and its Keccak blocks while the MSMs run). One job at a time; wait() spins (jobs are tens of microseconds).
+class Worker {
+  std::thread th_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::function<void()> job_;
+  bool posted_ = false, stop_ = false;
+  std::atomic<int> pending_{0};
+  void loop() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return posted_ || stop_; });
+        if (stop_) return;
+        f.swap(job_);
+        posted_ = false;
+      }
+      f();
+      pending_.store(0, std::memory_order_release);
+    }
+  }
+
+ public:
+  Worker() = default;
+  Worker(const Worker&) = delete;
+  Worker& operator=(const Worker&) = delete;
+  ~Worker() {
+    if (!th_.joinable()) return;
+    wait();
+    {
+      std::lock_guard<std::mutex> l(m_);
+      stop_ = true;
+    }
+    cv_.notify_one();
+    th_.join();
+  }
+  void submit(std::function<void()> f) {  // the job must not throw
+    wait();
+    pending_.store(1, std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> l(m_);
+      job_ = std::move(f);
+      posted_ = true;
+    }
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    cv_.notify_one();
+  }
+  void wait() {
+    while (pending_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+  }
+};
 
 struct KStat {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -57,10 +115,12 @@ struct sp_ctx {
   void* h_fbm[2] = {nullptr, nullptr};
   void* d_fbm[2] = {nullptr, nullptr};
   unsigned fbm_seq[2] = {0, 0};
-  void* h_mm = nullptr;
-  void* d_mm = nullptr;
-  void* d_mm_work = nullptr;
-  unsigned mm_seq = 0;
+  bool fb_async_busy = false;  // an sp_fixed_base_mul_h_begin job (mapped or copy form) has not been finished yet
+  // lane 1 = the auxiliary stream (sp_fbtables_multi_mul*), lane 0 = the main stream (second walk of sp_hyrax_prove)
+  void* h_mm[2] = {nullptr, nullptr};
+  void* d_mm[2] = {nullptr, nullptr};
+  void* d_mm_work[2] = {nullptr, nullptr};
+  unsigned mm_seq[2] = {0, 0};
   hipEvent_t fb_ev = nullptr;
   hipEvent_t fb_event() {
     if (!fb_ev) hipEventCreateWithFlags(&fb_ev, hipEventDisableTiming);
@@ -77,6 +137,11 @@ struct sp_ctx {
   void* h_pinned_vec = nullptr;      // pinned landing buffer of sp_rowmat_vec_eq jobs, grow-only
   size_t h_pinned_vec_bytes = 0;
   hipEvent_t vec_ev = nullptr;
+  // sp_hyrax_prove: pinned landing buffer of LZ (main stream), its event, and the helper thread that hashes the commitment
+  void* h_pcs = nullptr;
+  size_t h_pcs_bytes = 0;
+  hipEvent_t pcs_ev = nullptr;
+  sp::Worker* pcs_worker = nullptr;
   void* h_pinned_lane[2] = {nullptr, nullptr};  // pinned landing buffers for per-window MSM sums (one per stream), 8 KiB each
   size_t pinned_elems = 0;
   bool timing = false;

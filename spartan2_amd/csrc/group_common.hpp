@@ -22,6 +22,9 @@ struct sp_ck {
   mutable aff_t* d_comb = nullptr;
   mutable int comb_c = 0, comb_windows = 0;
   mutable bool comb_failed = false;
+  // 8-bit window tables of every base and of h (capi_group.hip ck_key_tables), built on first use by sp_hyrax_prove
+  mutable aff_t* d_keytables = nullptr;
+  mutable bool keytables_failed = false;
 };
 
 
@@ -44,6 +47,11 @@ struct DevBuf {  // RAII device allocation
 
 
 namespace sp {
+// capi_group.hip: one-launch table-walk MSM (k_multi_mul_coop) on lane 0 (main stream) or 1 (auxiliary stream), and the window tables of a key
+int multi_mul_ensure(sp_ctx* c, int lane);
+int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last);
+int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield);
+int ck_key_tables(sp_ctx* c, const sp_ck* ck);  // 0 = ready, 1 = not available (take the bucket MSM), < 0 = error
 // capi_comb.hip: the fixed-base comb table of a key (built on first use) and row commitments over it
 size_t comb_min_rows();
 int comb_ensure(sp_ctx* c, const sp_ck* ck);  // 0 = table ready, 1 = not available (take the bucket path), < 0 = error

@@ -12,6 +12,7 @@
 // Results are group elements; parity is on canonical affine coordinates, so summation order is free.
 #pragma once
 #include "curve.cuh"
+#include "device_utils.cuh"
 
 namespace spk {
 
@@ -822,9 +823,11 @@ __global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const
 // self-validating slot in mapped host memory that the host polls: words 0..23 the point, 24 = sequence, 25 = sequence + plain sum, 26 = sequence * K +
 // position-weighted sum, 27 = sequence again (the order in which the stores land does not matter; the host accepts the slot only when all four agree).
 constexpr unsigned MULTI_MUL_SLOT_K = 0x9E3779B1u;
-constexpr int MULTI_MUL_MAX_BLOCKS = 512;  // 2048 scalars (the rows of a 2^22-variable witness)
+constexpr int MULTI_MUL_MAX_BLOCKS = 1024;  // 4096 scalars (the 2048 bases of a key + h: every MSM over the key as one table walk)
+// `has_last`: scalar n - 1 is the kernel argument `last` instead of scalars[n - 1] (the blind of h, known on the host, behind n - 1 scalars that a
+// kernel earlier on the stream left in device memory: comm_LZ = <LZ, ck> + r_LZ h of hyrax_pc.rs:454-455 without a host round trip for LZ).
 __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, xyzz_t* __restrict__ partial,
-                                                            unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq) {
+                                                            unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq, fe_t last, int has_last) {
   __shared__ CoopAdd<128> L;
   __shared__ xyzz_t s[128], s2[128];
   __shared__ unsigned s_last;
@@ -835,7 +838,7 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restri
   if (role == 0) {
     xyzz_t acc = xyzz_identity();
     if (idx < n) {
-      const fe_t c = fe_to_canonical<SF>(scalars[idx]);
+      const fe_t c = fe_to_canonical<SF>((has_last && idx == n - 1) ? last : scalars[idx]);
       const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
       if (digit) acc = xyzz_from_affine(tables[idx * (32 * 255) + (size_t)j * 255 + digit - 1]);
     }
@@ -922,6 +925,47 @@ __global__ void __launch_bounds__(256) k_rowmat_vec(const fe_t* __restrict__ pol
   if (rl == 0 && col < cols) {
     fe_t t = fe_add<SF>(fe_add<SF>(s[threadIdx.x], s[threadIdx.x + 64]), fe_add<SF>(s[threadIdx.x + 128], s[threadIdx.x + 192]));
     partial[(size_t)blockIdx.y * cols + col] = t;
+  }
+}
+// Streaming form for tall matrices (rows >= 128: 512 x 2048 at BASELINE config 2, a pure 32 MiB read — hyrax_pc.rs:38-54): ONE launch, no partials.
+// A block of 1024 threads owns RMV_COLS = 8 adjacent columns: lane = (row-lane 0..7, column 0..7), so a wave reads eight 256-byte row segments per pass
+// and the 16 waves cover 128 rows; every lane keeps a modular sum of its rows' products, the eight row-lanes of a wave and then the sixteen waves are
+// combined as lazy 9-word sums (shuffles, LDS) with one reduction per column. cols / 8 blocks (256 at config 2: one per CU, all rows in flight at once).
+constexpr int RMV_COLS = 8;
+__global__ void __launch_bounds__(1024) k_rowmat_vec_tall(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L, fe_t* __restrict__ out) {
+  __shared__ lazy9_t sm[16][RMV_COLS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & (RMV_COLS - 1), rl = lane >> 3;
+  const size_t col = (size_t)blockIdx.x * RMV_COLS + c;
+  fe_t acc = fe_zero();
+  if (col < cols) {
+    // two independent chains per lane keep two loads and two products in flight
+    fe_t acc2 = fe_zero();
+    size_t r = (size_t)wave * 8 + rl;
+    for (; r + 128 < rows; r += 256) {
+      const fe_t a = poly[r * cols + col], b = poly[(r + 128) * cols + col];
+      const fe_t la = L[r], lb = L[r + 128];
+      acc = fe_add<SF>(acc, fe_mul<SF>(la, a));
+      acc2 = fe_add<SF>(acc2, fe_mul<SF>(lb, b));
+    }
+    if (r < rows) acc = fe_add<SF>(acc, fe_mul<SF>(L[r], poly[r * cols + col]));
+    acc = fe_add<SF>(acc, acc2);
+  }
+  lazy9_t t = lazy_from(acc);
+#pragma unroll
+  for (int m = 32; m >= 8; m >>= 1) {
+    lazy9_t o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.v[i] = __shfl_xor(t.v[i], m, 64);
+    t = lazy_add(t, o);
+  }
+  if (rl == 0) sm[wave][c] = t;
+  __syncthreads();
+  if (threadIdx.x < RMV_COLS && col < cols) {
+    lazy9_t s = sm[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) s = lazy_add(s, sm[w][threadIdx.x]);
+    out[col] = lazy_reduce(s);
   }
 }
 __global__ void __launch_bounds__(256) k_sum_columns(const fe_t* __restrict__ partial, size_t splits, size_t cols, fe_t* __restrict__ out) {

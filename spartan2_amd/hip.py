@@ -349,6 +349,20 @@ class CommitmentKey:
         check(lib().sp_hyrax_commit(self.ctx.h, self.h, table.h, ctypes.c_size_t(off), ctypes.c_size_t(n), p64(blinds), int(is_small), p64(out)))
         return out
 
+    def prove(self, key_eval, tr, comm_rows, poly, n, blinds, point, comm_eval, blind_eval, rng_d, rng_rdelta, rng_rbeta):
+        """HyraxPCS::prove (hyrax_pc.rs:387-478) as one ABI call (sp_hyrax_prove): returns delta (8) | beta (8) | z_vec | z_delta | z_beta words."""
+        comm_rows = np.ascontiguousarray(comm_rows, dtype=np.uint64).reshape(-1, 8)
+        point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
+        rows = comm_rows.shape[0]
+        cols = n // rows
+        rng_d = np.ascontiguousarray(rng_d, dtype=np.uint64).reshape(cols, 4)
+        out = np.zeros(16 + 4 * cols + 8, dtype=np.uint64)
+        c = lambda a, shape: np.ascontiguousarray(a, dtype=np.uint64).reshape(shape)
+        check(lib().sp_hyrax_prove(self.ctx.h, self.h, key_eval.h, tr.h, p64(comm_rows), ctypes.c_size_t(rows), poly.h, ctypes.c_size_t(n), p64(c(blinds, (rows, 4))),
+                                   p64(point), ctypes.c_size_t(point.shape[0]), p64(c(comm_eval, (8,))), p64(c(blind_eval, (4,))), p64(rng_d), p64(c(rng_rdelta, (4,))),
+                                   p64(c(rng_rbeta, (4,))), p64(out)))
+        return out
+
     def rerandomize(self, comm_rows, r_old, r_new):
         """PCS::rerandomize_commitment (hyrax_pc.rs:321-344)."""
         comm_rows = np.ascontiguousarray(comm_rows, dtype=np.uint64).reshape(-1, 8)
@@ -362,6 +376,19 @@ class CommitmentKey:
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         out = np.zeros((scalars.shape[0], 8), dtype=np.uint64)
         check(lib().sp_fixed_base_mul_h(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(out)))
+        return out
+
+    def fixed_base_mul_h_begin(self, scalars):
+        """asynchronous form (auxiliary stream); returns the job handle for fixed_base_mul_h_finish. One job per context at a time."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        job = ctypes.c_void_p()
+        check(lib().sp_fixed_base_mul_h_begin(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), ctypes.byref(job)))
+        return job, scalars.shape[0]
+
+    def fixed_base_mul_h_finish(self, job_n):
+        job, n = job_n
+        out = np.zeros((n, 8), dtype=np.uint64)
+        check(lib().sp_fixed_base_mul_h_finish(self.ctx.h, job, p64(out)))
         return out
 
     def msm(self, scalars, blind=None):

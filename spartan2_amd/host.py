@@ -109,7 +109,7 @@ class SpartanSNARK:
         self.ps = ps
         return used.value
 
-    def set_flags(self, prefix_cache=None, lz_direct=None):
+    def set_flags(self, prefix_cache=None, lz_direct=None, reference_order=None):
         """Driver options of the current prep state (spartan_snark.cpp FLAG_*): prefix_cache = keep the transcript prefix's sponge state across
         proves instead of re-hashing it in every prove (the reference re-hashes); lz_direct = the opening in the reference's own order."""
         lib().ss_prep_get_flags.restype = ctypes.c_uint
@@ -118,6 +118,8 @@ class SpartanSNARK:
             f = (f | 1) if prefix_cache else (f & ~1)
         if lz_direct is not None:
             f = (f | 2) if lz_direct else (f & ~2)
+        if reference_order is not None:  # one thread, the reference's statement order, only ABI calls (spartan_snark.cpp prove_reference_order)
+            f = (f | 4) if reference_order else (f & ~4)
         lib().ss_prep_set_flags(self.ps, ctypes.c_uint(f))
 
     def prep_export(self):

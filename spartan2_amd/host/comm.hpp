@@ -74,6 +74,7 @@ struct Comm {
   void reserve(size_t bytes) {
     if (bytes <= cap) return;
     size_t want = bytes < 4096 ? 4096 : bytes + bytes / 2;
+    cap = 0;  // until all four allocations below have succeeded the buffers are unusable (a throw in between must not leave a stale capacity)
     if (d_send) (void)hipFree(d_send);
     if (d_recv) (void)hipFree(d_recv);
     if (h_send) (void)hipHostFree(h_send);

@@ -56,7 +56,9 @@ static bool helper_may_spin() {
 //     the reference does not make (it re-hashes the prefix in every prove, src/spartan.rs:226-236, r1cs.rs:422-427). Default OFF: the prefix is
 //     re-hashed inside every prove (on a helper thread, under commit_zeros), so the timed region does the reference's work.
 //   FLAG_LZ_DIRECT: the opening in the reference's own order (bind W with L, then the MSM over the key) instead of the MSM over the row commitments.
-enum : unsigned { FLAG_PREFIX_CACHE = 1u, FLAG_LZ_DIRECT = 2u };
+//   FLAG_REFERENCE_ORDER: prove_reference_order below — ONE thread, no helper jobs, no prep-time tables, only include/spartan_hip.h entry points, called
+//     in the order of the statements of src/spartan.rs:226-466 (what an unchanged spartan.rs bound to the ABI does). bench.py reports it beside the headline.
+enum : unsigned { FLAG_PREFIX_CACHE = 1u, FLAG_LZ_DIRECT = 2u, FLAG_REFERENCE_ORDER = 4u };
 
 struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   sp_table *W = nullptr, *caz = nullptr, *cbz = nullptr, *ccz = nullptr;      // witness + cached partial products
@@ -205,8 +207,11 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 // `synth`: circuit.synthesize(.., Some(&challenges)) for circuits with verifier challenges (bellpepper/r1cs.rs:443-461): receives the challenges and
 // writes the num_rest_unpadded values of the rest segment (Montgomery limbs); non-zero return = SynthesisError
 typedef int (*ss_rest_hook)(void* user, const uint64_t* challenges, size_t num_challenges, uint64_t* out_rest);
+SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, PhaseTimes* pt, ss_rest_hook synth,
+                                      void* synth_user);
 SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, PhaseTimes* pt, ss_rest_hook synth = nullptr,
                       void* synth_user = nullptr) {
+  if (ps.flags & FLAG_REFERENCE_ORDER) return prove_reference_order(pk, ps, publics_u64, npub, tape, pt, synth, synth_user);
   const sp_dims& d = pk.dims;
   sp_ctx* ctx = pk.ctx;
   const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
@@ -231,6 +236,18 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<aff_t> comm_W(rows_pre + rows_rest);
   std::copy(ps.comm_W_fixed.begin(), ps.comm_W_fixed.end(), comm_W.begin());
   sp_fb_job* rest_job = nullptr;
+  struct FbJobGuard {  // an error exit between begin and finish must not leave the context's one asynchronous fixed-base job outstanding
+    sp_ctx* ctx;
+    sp_fb_job*& job;
+    size_t n;
+    ~FbJobGuard() {
+      if (job) {
+        std::vector<uint64_t> sink(8 * n + 8);
+        (void)sp_fixed_base_mul_h_finish(ctx, job, sink.data());
+        job = nullptr;
+      }
+    }
+  } rest_job_guard{ctx, rest_job, rows_rest};
   if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
   lap("commit_zeros_begin");
 
@@ -340,7 +357,11 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   lap("dvec_draw");
 
   const bool rest_job_used = rest_job != nullptr;  // the rest rows are h * blind (commit_zeros)
-  if (rest_job) ck(sp_fixed_base_mul_h_finish(ctx, rest_job, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
+  if (rest_job) {
+    sp_fb_job* j = rest_job;
+    rest_job = nullptr;  // finish() consumes the job whatever it returns
+    ck(sp_fixed_base_mul_h_finish(ctx, j, u64p(&comm_W[rows_pre].x)), "commit_zeros (finish)");
+  }
   else if (rows_rest)
     ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)),
        "commit rest");
@@ -783,6 +804,136 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   if (pt) {
     pt->ms[0] = t_wit - t_start - t_mv_issue;  // the matrix-vector product is issued inside the witness phase and runs under it
     pt->ms[1] = t_mv - t_wit + t_mv_issue;
+    pt->ms[2] = t_outer - t_mv;
+    pt->ms[3] = t_abc - t_outer;
+    pt->ms[4] = t_inner - t_abc;
+    pt->ms[5] = t_end - t_inner;
+    pt->ms[6] = t_end - t_start;
+  }
+  return proof;
+}
+
+// SpartanSNARK::prove exactly as src/spartan.rs:219-466 states it — one statement of the reference per call of the ABI, in its order, on the calling
+// thread alone: no helper threads, nothing issued ahead of where the reference computes it, no tables prepared at prep time. Whatever overlap there is
+// happens BELOW the ABI (the round loops' launch-ahead and resident tails, sp_hyrax_prove's two walks beside its hashing). This is the time an unchanged
+// spartan.rs gets from a shim that binds include/spartan_hip.h; the proof is the same bytes as prove()'s.
+SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, PhaseTimes* pt, ss_rest_hook synth,
+                                      void* synth_user) {
+  const sp_dims& d = pk.dims;
+  sp_ctx* ctx = pk.ctx;
+  const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
+  if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
+  ck(sp_ctx_bind_thread(ctx), "device");
+  const double t_start = now_ms();
+  std::vector<fe_t> publics(npub);
+  for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
+  // :226-236 transcript, vk, public values
+  Tr tr(ctx, "SpartanSNARK");
+  tr.absorb("vk", pk.vk_digest, 32);
+  tr.absorb_scalars("public_values", publics.data(), npub);
+  // r1cs_instance_and_witness (src/bellpepper/r1cs.rs:411-540)
+  if (ps.rows_shared) tr.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
+  if (ps.rows_precommitted) tr.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
+  std::vector<fe_t> challenges(d.num_challenges);
+  if (d.num_challenges) {
+    if (!synth) throw Error(SP_ERR_INTERNAL, "a circuit with verifier challenges needs its synthesize callback");
+    for (auto& c : challenges) c = tr.squeeze("challenge");
+    std::vector<fe_t> rest(d.num_rest_unpadded + 1);
+    if (synth(synth_user, u64p(challenges.data()), challenges.size(), u64p(rest.data())) != 0) throw Error(SP_ERR_INTERNAL, "SynthesisError: the circuit's synthesize callback failed");
+    if (d.num_rest_unpadded) ck(sp_table_write(ctx, ps.W, d.num_shared + d.num_precommitted, u64p(rest.data()), d.num_rest_unpadded), "W rest");
+  }
+  const size_t rows_pre = ps.comm_W_fixed.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
+  std::vector<fe_t> r_W_rest(rows_rest);
+  for (auto& b : r_W_rest) b = tape.next();  // PCS::blind (r1cs.rs:466)
+  std::vector<aff_t> comm_W(rows_pre + rows_rest);
+  std::copy(ps.comm_W_fixed.begin(), ps.comm_W_fixed.end(), comm_W.begin());
+  if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, u64p(&comm_W[rows_pre].x)), "commit_zeros");  // :467-469
+  else if (rows_rest)
+    ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)), "commit rest");
+  {
+    std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
+    tr.absorb("comm_W_rest", b.data(), b.size());
+  }
+  std::vector<fe_t> r_W = ps.r_W_fixed;  // combine_blinds (r1cs.rs:515-524)
+  r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
+  const double t_wit = now_ms();
+  // :246-253 z = [W | 1 | public | challenges]
+  ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
+  ck(sp_table_copy(ctx, ps.z, 0, ps.W, 0, M), "z <- W");
+  {
+    ck(sp_table_zero(ctx, ps.z, M, M), "clear z high half");
+    std::vector<fe_t> tail(pk.num_extra);
+    tail[0] = fe_one<S>();
+    std::copy(publics.begin(), publics.end(), tail.begin() + 1);
+    std::copy(challenges.begin(), challenges.end(), tail.begin() + 1 + npub);
+    if (tail.size() <= 2048) ck(sp_table_write_async(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
+    else ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
+  }
+  ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
+  // :262-264 tau
+  const size_t num_rounds_x = log2_ceil(N), num_rounds_y = log2_ceil(M) + 1;
+  std::vector<fe_t> tau(num_rounds_x);
+  for (auto& t : tau) t = tr.squeeze("t");
+  // :267-283 multiply_vec_incremental_into
+  ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
+  const double t_mv = now_ms();
+  SpartanProofBuf proof;
+  for (const aff_t& a : comm_W) proof.pp(a);
+  for (const fe_t& f : publics) proof.pf(f);
+  for (const fe_t& f : challenges) proof.pf(f);
+  // :291-310 outer sum-check
+  std::vector<fe_t> outer_polys(3 * num_rounds_x), r_x(num_rounds_x);
+  fe_t claims_outer[3];
+  const fe_t zero = fe_zero();
+  ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, tr.t, u64p(outer_polys.data()), u64p(r_x.data()), u64p(claims_outer)),
+     "outer sum-check");
+  tr.absorb_scalars("claims_outer", claims_outer, 3);
+  for (const fe_t& f : outer_polys) proof.pf(f);
+  for (int i = 0; i < 3; ++i) proof.pf(claims_outer[i]);
+  const double t_outer = now_ms();
+  // :311-322 r, evals_rx, bind_and_prepare_poly_ABC
+  const fe_t r = tr.squeeze("r");
+  const fe_t claim_inner_joint = fe_add<S>(fe_add<S>(claims_outer[0], fe_mul<S>(r, claims_outer[1])), fe_mul<S>(fe_mul<S>(r, r), claims_outer[2]));
+  ck(sp_eq_table_into(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");
+  ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
+  const double t_abc = now_ms();
+  // :323-404 inner sum-check (manual round 0 == a generic round on (lo_eff, hi_eff) = (M, num_extra) tables)
+  ck(sp_table_set_len(ps.abc, 2 * M, M, pk.num_extra), "abc len");
+  ck(sp_table_set_len(ps.z, 2 * M, M, pk.num_extra), "z len");
+  std::vector<fe_t> inner_polys(2 * num_rounds_y), r_y(num_rounds_y);
+  fe_t claims_inner[2];
+  ck(sp_sumcheck_quad(ctx, u64p(&claim_inner_joint), num_rounds_y, ps.abc, ps.z, tr.t, u64p(inner_polys.data()), u64p(r_y.data()), u64p(claims_inner)), "inner sum-check");
+  for (const fe_t& f : inner_polys) proof.pf(f);
+  // :405-421 eval_W
+  const fe_t eval_Z = claims_inner[1];
+  std::vector<fe_t> X;
+  X.push_back(fe_one<S>());
+  X.insert(X.end(), publics.begin(), publics.end());
+  X.insert(X.end(), challenges.begin(), challenges.end());
+  const fe_t eval_X = sparse_poly_evaluate(num_rounds_y - 1, X, r_y.data() + 1);
+  const fe_t denom = fe_sub<S>(fe_one<S>(), r_y[0]);
+  if (fe_is_zero(denom)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
+  const fe_t eval_W = fe_mul<S>(fe_sub<S>(eval_Z, fe_mul<S>(r_y[0], eval_X)), fe_inv_vartime<S>(denom));
+  const double t_inner = now_ms();
+  // :423-436 blind, commit to eval_W, PCS::prove
+  const fe_t blind_eval_W = tape.next();
+  aff_t comm_eval_W;
+  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
+  proof.pf(eval_W);
+  proof.pf(blind_eval_W);
+  const size_t num_rows = (M + W_ - 1) / W_, cols = M / num_rows;
+  std::vector<fe_t> dvec(cols);
+  for (auto& x : dvec) x = tape.next();  // ipa.rs:139-145, inside InnerProductArgumentLinear::prove in the reference: the shim draws it for the call
+  const fe_t r_delta = tape.next(), r_beta = tape.next();
+  std::vector<uint64_t> arg(16 + 4 * cols + 8);
+  ck(sp_hyrax_prove(ctx, pk.ck, pk.ck_s, tr.t, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), u64p(r_y.data() + 1), num_rounds_y - 1, u64p(&comm_eval_W.x),
+                    u64p(&blind_eval_W), u64p(dvec.data()), u64p(&r_delta), u64p(&r_beta), arg.data()),
+     "PCS::prove");
+  proof.words.insert(proof.words.end(), arg.begin(), arg.end());
+  const double t_end = now_ms();
+  if (pt) {
+    pt->ms[0] = t_wit - t_start;
+    pt->ms[1] = t_mv - t_wit;
     pt->ms[2] = t_outer - t_mv;
     pt->ms[3] = t_abc - t_outer;
     pt->ms[4] = t_inner - t_abc;

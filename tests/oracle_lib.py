@@ -112,6 +112,16 @@ def random_field_array(rng, n, fid=0):
     return out
 
 
+def tape_field_array(tape, fid=0):
+    """from_uniform of every 64-byte block of a randomness tape (oracle/hyrax.hpp Tape::next), as Montgomery limbs."""
+    tape = np.ascontiguousarray(tape, dtype=np.uint8).reshape(-1, 64)
+    out = np.zeros((tape.shape[0], 4), dtype=np.uint64)
+    L = lib()
+    for i in range(tape.shape[0]):
+        L.orc_field_from_uniform(fid, p8(tape[i]), p64(out[i]))
+    return out
+
+
 class Transcript:
     def __init__(self, label: bytes):
         self.h = ctypes.c_void_p(lib().orc_transcript_new(label))

@@ -109,6 +109,22 @@ def test_fixed_base_mul_h(ctx, key, gens):
     assert (key.fixed_base_mul_h(ks) == want).all()
 
 
+@pytest.mark.parametrize("n", [70, 600])  # the mapped-page form (<= 128 scalars) and the copy form
+def test_fixed_base_mul_h_async_one_job_at_a_time(ctx, key, gens, n):
+    """sp_fixed_base_mul_h_begin / _finish: the result is the synchronous call's, and a second begin before the first finish is refused (the jobs share
+    the context's landing area: ADVICE r2 — the first finish used to return the second job's points)."""
+    rng = np.random.default_rng(SEED + 101 + n)
+    k1, k2 = ol.random_field_array(rng, n), ol.random_field_array(rng, n)
+    want1, want2 = key.fixed_base_mul_h(k1), key.fixed_base_mul_h(k2)
+    job = key.fixed_base_mul_h_begin(k1)
+    with pytest.raises(hip.SpartanHipError) as e:
+        key.fixed_base_mul_h_begin(k2)
+    assert "rc=-1" in str(e.value)
+    assert (key.fixed_base_mul_h_finish(job) == want1).all()
+    job = key.fixed_base_mul_h_begin(k2)  # the lane is free again
+    assert (key.fixed_base_mul_h_finish(job) == want2).all()
+
+
 @pytest.mark.parametrize("kind", ["bits", "small", "full", "mixed_rows"])
 def test_hyrax_commit_matches_oracle(ctx, key, kind):
     # PCS::commit (hyrax_pc.rs:207-303): zero rows, trailing zeros, binary / small / full scalar rows
@@ -162,13 +178,55 @@ def test_hyrax_commit_many_full_rows_take_the_batched_path(ctx, key):
 def test_rowmat_vec(ctx):
     # bind_with_delayed (hyrax_pc.rs:38-54)
     rng = np.random.default_rng(SEED + 300)
-    for rows, cols in ((1, 64), (8, 2048), (37, 256)):
+    for rows, cols in ((1, 64), (8, 2048), (37, 256), (128, 64), (512, 2048), (300, 72), (129, 8)):  # rows >= 128: the one-launch streaming kernel
         poly = ol.random_field_array(rng, rows * cols)
         L = ol.random_field_array(rng, rows)
         want = np.zeros((cols, 4), dtype=np.uint64)
         olib().orc_rowmat_vec(p64(poly), p64(L), ctypes.c_size_t(rows), ctypes.c_size_t(cols), p64(want))
         got = hip.rowmat_vec(ctx, hip.Table.from_host(ctx, poly), rows, cols, L)
         assert (got == want).all()
+
+
+@pytest.mark.parametrize("npt,key_tables", [(11, "1"), (13, "1"), (16, "1"), (16, "0"), (9, "1"), (20, "1")])
+def test_hyrax_prove_is_the_oracles_pcs_prove(ctx, key, gens, npt, key_tables, monkeypatch):
+    """sp_hyrax_prove == HyraxPCS::prove + InnerProductArgumentLinear::prove (hyrax_pc.rs:387-478, ipa.rs:125-170) of the oracle on the same commitment,
+    polynomial, point, blinds and randomness: every output word and the transcript state afterwards. npt = 11: one row; 9: a polynomial narrower than
+    the key; 16 with SPARTAN_KEY_TABLES=0: the bucket-MSM fallback; 20 = 512 rows, BASELINE config 2's opening (one-launch rowmat kernel)."""
+    monkeypatch.setenv("SPARTAN_KEY_TABLES", key_tables)
+    rng = np.random.default_rng(SEED + 900 + npt)
+    n = 1 << npt
+    rows = max(1, n // 2048)
+    cols = n // rows
+    poly = ol.random_field_array(rng, n)
+    blinds = ol.random_field_array(rng, rows)
+    point = ol.random_field_array(rng, npt)
+    okey = oracle_key()
+    okey_s = ctypes.c_void_p(olib().orc_hyrax_setup(b"ck_s", ctypes.c_size_t(1)))
+    g_s = np.zeros((2, 8), dtype=np.uint64)
+    olib().orc_from_label(b"ck_s", ctypes.c_size_t(2), p64(g_s))
+    key_s = hip.CommitmentKey(ctx, g_s[:1], g_s[1])
+    comm = np.zeros((rows, 8), dtype=np.uint64)
+    assert olib().orc_hyrax_commit(okey, p64(poly), ctypes.c_size_t(n), p64(blinds), 0, p64(comm)) == 0
+    ev, b_ev = ol.random_field_array(rng, 1), ol.random_field_array(rng, 1)  # (the prover does not check the claimed evaluation)
+    comm_eval = np.zeros((1, 8), dtype=np.uint64)
+    assert olib().orc_hyrax_commit(okey_s, p64(ev), ctypes.c_size_t(1), p64(b_ev), 0, p64(comm_eval)) == 0
+    tape = ol.make_tape(SEED + npt, cols + 2)
+    want = np.zeros(16 + 4 * cols + 8, dtype=np.uint64)
+    otr = ctypes.c_void_p(olib().orc_transcript_new(b"pcs"))
+    assert olib().orc_transcript_absorb(otr, b"x", b"warm", ctypes.c_size_t(4)) == 0
+    assert olib().orc_hyrax_prove(okey, okey_s, otr, p64(comm), ctypes.c_size_t(rows), p64(poly), ctypes.c_size_t(n), p64(blinds), p64(point), ctypes.c_size_t(npt),
+                                  p64(comm_eval), p64(b_ev), tape.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_size_t(tape.shape[0]), p64(want)) == 0
+    draws = ol.tape_field_array(tape)  # from_uniform of every block, the draw order of ipa.rs:139-149: d_vec, r_delta, r_beta
+    tr = hip.Transcript(ctx, b"pcs")
+    tr.absorb(b"x", b"warm")  # (not a fresh hasher: the general path of the helper's hashing)
+    got = key.prove(key_s, tr, comm, hip.Table.from_host(ctx, poly), n, blinds, point, comm_eval, b_ev, draws[:cols], draws[cols], draws[cols + 1])
+    assert (got == want).all()
+    o_next = np.zeros(4, dtype=np.uint64)
+    assert olib().orc_transcript_squeeze(otr, b"n", 0, p64(o_next)) == 0
+    assert (tr.squeeze(b"n") == o_next).all()
+    olib().orc_transcript_free(otr)
+    olib().orc_hyrax_free(okey)
+    olib().orc_hyrax_free(okey_s)
 
 
 def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):

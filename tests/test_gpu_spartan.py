@@ -110,15 +110,23 @@ def test_prove_is_identical_on_every_driver_path(ctx, monkeypatch):
     inst = frontend.sha256_circuit(bytes(range(150)))
     tape = ol.make_tape(23, 8192)
 
-    def prove_with(c):
+    def prove_with(c, **flags):
         sn = host.SpartanSNARK(c, inst)
         used = sn.prep_prove(tape)
+        if flags:
+            sn.set_flags(**flags)
         words, _, _ = sn.prove(tape[used:])
         again, _, _ = sn.prove(tape[used:])  # the prep state is reusable: second prove on it is the same proof
         assert (words == again).all()
         return words
 
     base = prove_with(ctx)
+    # the reference-order driver: one thread, statement order of src/spartan.rs:226-466, PCS::prove as ONE call of sp_hyrax_prove (table walks over the
+    # window tables of the key beside the commitment's hashing) — and the same call with the bucket MSMs it falls back to
+    assert (prove_with(ctx, reference_order=True) == base).all()
+    monkeypatch.setenv("SPARTAN_KEY_TABLES", "0")
+    assert (prove_with(ctx, reference_order=True) == base).all()
+    monkeypatch.delenv("SPARTAN_KEY_TABLES")
     monkeypatch.setenv("SPARTAN_LZ_DIRECT", "1")
     assert (prove_with(ctx) == base).all()
     monkeypatch.delenv("SPARTAN_LZ_DIRECT")
