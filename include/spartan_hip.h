@@ -242,12 +242,14 @@ int sp_hyrax_rerandomize(sp_ctx* ctx, const sp_ck* ck, const uint64_t* comm_rows
 /* HyraxPCS::prove (src/provider/pcs/hyrax_pc.rs:387-478) with InnerProductArgumentLinear::prove (src/provider/pcs/ipa.rs:125-170) inside, the trait
  * method SpartanSNARK::prove calls at src/spartan.rs:425-435: comm = `rows` affine row commitments of poly (a device-resident table of n = 2^npt
  * elements, rows x cols), blinds = the rows' blinds, point = the evaluation point (row variables first), comm_eval / blind_eval = the commitment to the
- * claimed evaluation under ck_eval (narrow key) and its blind. The IPA's randomness is an input (injected randomness): rng_d = the mask
- * vector d (cols elements, ipa.rs:139-145), rng_rdelta / rng_rbeta = the blinds of delta and beta (:146-149). Absorbs / squeezes on `tr` exactly as the
- * reference does. out = delta (8 words, affine) | beta (8) | z_vec (4 * cols) | z_delta (4) | z_beta (4): the InnerProductArgumentLinear fields. */
+ * claimed evaluation under ck_eval (narrow key) and its blind. The IPA's randomness is an input (injected randomness) in the form the
+ * reference consumes it: `rng` = a stream of 64-byte uniform blocks, one per E::Scalar::random call in draw order — the mask vector d (cols blocks,
+ * ipa.rs:139-145), then the blinds of delta and beta (:146-149) — each reduced as from_uniform (src/provider/traits.rs:275-280); cols + 2 blocks are
+ * consumed. Absorbs / squeezes on `tr` exactly as the reference does. out = delta (8 words, affine) | beta (8) | z_vec (4 * cols) | z_delta (4) |
+ * z_beta (4): the InnerProductArgumentLinear fields. */
 int sp_hyrax_prove(sp_ctx* ctx, const sp_ck* ck, const sp_ck* ck_eval, sp_transcript* tr, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n,
-                   const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint64_t* rng_d,
-                   const uint64_t rng_rdelta[4], const uint64_t rng_rbeta[4], uint64_t* out);
+                   const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint8_t* rng,
+                   size_t rng_blocks, uint64_t* out);
 /* asynchronous form: begin() enqueues upload + kernel + download and returns, finish() waits and normalises. One job per context at a time: the jobs
  * share the context's landing area, so begin() fails with SP_ERR_INVALID_INPUT_LENGTH while an earlier job (n above the host threshold) has not been
  * finished; finish() consumes the job whatever it returns. */

@@ -802,7 +802,32 @@ int sp_transcript_new(sp_ctx*, const uint8_t* label, size_t n, sp_transcript** o
   *out = t;
   return SP_OK;
 }
+// one hashing thread per process for the long absorbs (see sp_transcript): taken by whichever transcript asks first, everyone else hashes inline
+static sp::Worker g_hash_worker;
+static std::atomic<bool> g_hash_taken{false};
+static size_t async_absorb_min() {
+  static const size_t v = [] {
+    const char* e = getenv("SPARTAN_ASYNC_ABSORB_MIN");  // bytes; 0 = never
+    return e ? (size_t)atol(e) : (size_t)4096;
+  }();
+  return v;
+}
 int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n) {
+  t->join();
+  const size_t amin = async_absorb_min();
+  if (amin && n >= amin && !g_hash_taken.exchange(true, std::memory_order_acq_rel)) {
+    t->pend.resize(ln + n);
+    memcpy(t->pend.data(), label, ln);
+    memcpy(t->pend.data() + ln, bytes, n);
+    t->pend_label = ln;
+    t->busy.store(1, std::memory_order_release);
+    g_hash_worker.submit([t] {
+      t->t.absorb(t->pend.data(), t->pend_label, t->pend.data() + t->pend_label, t->pend.size() - t->pend_label);
+      g_hash_taken.store(false, std::memory_order_release);
+      t->busy.store(0, std::memory_order_release);
+    });
+    return SP_OK;
+  }
   t->t.absorb(label, ln, bytes, n);
   return SP_OK;
 }
@@ -817,6 +842,7 @@ int sp_transcript_preabsorb(const uint8_t* label, size_t ln, const uint8_t* byte
 }
 int sp_transcript_absorb_prepared(sp_transcript* t, const sp_absorb_state* s) {
   if (!t || !s) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_transcript_absorb_prepared: null argument");
+  t->join();
   bool fresh = t->t.h.fill == 0;
   for (int i = 0; i < 25 && fresh; ++i) fresh = t->t.h.a[i] == 0;
   if (!fresh) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "sp_transcript_absorb_prepared: the transcript has absorbed input since its last squeeze");
@@ -825,17 +851,22 @@ int sp_transcript_absorb_prepared(sp_transcript* t, const sp_absorb_state* s) {
 }
 void sp_absorb_state_free(sp_absorb_state* s) { delete s; }
 int sp_transcript_dom_sep(sp_transcript* t, const uint8_t* bytes, size_t n) {
+  t->join();
   t->t.dom_sep(bytes, n);
   return SP_OK;
 }
 int sp_transcript_squeeze(sp_transcript* t, const uint8_t* label, size_t ln, uint64_t out[4]) {
+  t->join();
   fe_t f;
   if (!t->t.squeeze<S>(label, ln, &f)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
   store_fe(out, f);
   return SP_OK;
 }
 int sp_transcript_clone(const sp_transcript* t, sp_transcript** out) {
-  *out = new sp_transcript(*t);
+  t->join();
+  sp_transcript* n = new sp_transcript();
+  n->t = t->t;
+  *out = n;
   return SP_OK;
 }
 void sp_transcript_free(sp_transcript* t) { delete t; }
@@ -1001,6 +1032,7 @@ int sp_sumcheck_quad_sharded_partial(sp_ctx* c, uint64_t claim_io[4], size_t rou
 static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
                      sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8], size_t run_rounds) {
   const size_t vars = rounds;  // the tables have 2^vars elements
+  tr->join();  // (a long absorb may still be hashing on the library's thread)
   if (run_rounds > vars) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: more rounds to run than variables");
   const bool stopped = run_rounds != 0 && run_rounds < vars;
   if (stopped) rounds = run_rounds;
@@ -1478,6 +1510,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
                       const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
                       uint64_t* out_r, uint64_t out_final[12], size_t run_rounds) {
   // run_rounds (0 = all): see quad_impl - stop after that many of the ell rounds, tables left at 2^(ell - run_rounds) elements
+  tr->join();
   if (run_rounds > ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: more rounds to run than variables");
   const bool stopped = run_rounds != 0 && run_rounds < ell;
   const size_t last_rnd = stopped ? run_rounds : ell;

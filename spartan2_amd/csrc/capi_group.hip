@@ -1215,19 +1215,40 @@ int multi_mul_ensure(sp_ctx* c, int lane) {
   return SP_OK;
 }
 // `scalars`: n host scalars (copied into the lane's mapped page), or — `d_scalars` given — n - 1 scalars already in device memory followed by `last`
-int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last) {
+// `raw_blocks` > 0: `scalars` are that many 64-byte uniform blocks (scalar i = from_uniform of block i, reduced on the device; scalars beyond them are
+// zero up to `last`): needs the wide kernel (n >= its threshold) and `last`
+size_t multi_mul_wide_min() {  // SPARTAN_MM_WIDE_MIN: scalars from which the 1024-item blocks (k_multi_mul_wide) are used
+  static const size_t v = [] {
+    const char* e = getenv("SPARTAN_MM_WIDE_MIN");
+    return e ? (size_t)atol(e) : (size_t)1024;
+  }();
+  return v;
+}
+int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last,
+                     size_t raw_blocks) {
   if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multi_mul: 1 .. 4096 scalars");
+  if (raw_blocks && n < multi_mul_wide_min()) return fail(SP_ERR_INTERNAL, "multi_mul: raw blocks need the wide kernel");
   int erc = multi_mul_ensure(c, lane);
   if (erc) return erc;
-  if (!d_scalars) memcpy((char*)c->h_mm[lane] + 256, scalars, n * sizeof(fe_t));
+  if (raw_blocks) {
+    if (!last || raw_blocks > n - 1 || 64 * (n - 1) > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multi_mul: raw blocks do not fit");
+    memcpy((char*)c->h_mm[lane] + 256, scalars, 64 * raw_blocks);
+    if (raw_blocks < n - 1) memset((char*)c->h_mm[lane] + 256 + 64 * raw_blocks, 0, 64 * (n - 1 - raw_blocks));  // from_uniform(0) == 0
+  } else if (!d_scalars) memcpy((char*)c->h_mm[lane] + 256, scalars, n * sizeof(fe_t));
   if (++c->mm_seq[lane] == 0) ++c->mm_seq[lane];
   const unsigned seq = c->mm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
   const fe_t* src = d_scalars ? d_scalars : reinterpret_cast<const fe_t*>((char*)c->d_mm[lane] + 256);
   const fe_t lastv = last ? *last : fe_zero();
+  const size_t wide_min = multi_mul_wide_min();
   c->timed_on(st, "multi_mul", 32ull * n, [&] {
-    hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, src, n, d_tables, reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256),
-                       reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq, lastv, last ? 1 : 0);
+    if (n >= wide_min)
+      hipLaunchKernelGGL(spk::k_multi_mul_wide, dim3((unsigned)((n * 32 + spk::MULTI_MUL_WIDE_ITEMS - 1) / spk::MULTI_MUL_WIDE_ITEMS)), dim3(512), 0, st, src, n, d_tables,
+                         reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256), reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq,
+                         lastv, last ? 1 : 0, raw_blocks ? 1 : 0);
+    else
+      hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, src, n, d_tables, reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256),
+                         reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq, lastv, last ? 1 : 0);
   });
   if (seq_out) *seq_out = seq;
   return SP_OK;
@@ -1288,7 +1309,7 @@ extern "C" {
 // _begin launches on the auxiliary stream, _finish polls (one multiplication in flight per context and lane).
 int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n) {
   if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
-  return sp::multi_mul_launch(c, 1, t->d_tables, scalars, n, nullptr, nullptr, nullptr);
+  return sp::multi_mul_launch(c, 1, t->d_tables, scalars, n, nullptr, nullptr, nullptr, 0);
 }
 int sp_fbtables_multi_mul_finish(sp_ctx* c, uint64_t out_aff[8]) {
   if (!c->h_mm[1] || c->mm_seq[1] == 0) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul_finish: nothing in flight");
@@ -1310,17 +1331,18 @@ int sp_fbtables_multi_mul(sp_ctx* c, const sp_fbtables* t, const uint64_t* scala
 //   * delta = <d, ck> + r_delta h (ipa.rs:147) and comm_LZ = <LZ, ck> + r_LZ h (hyrax_pc.rs:454-455) are table walks over the window tables of the
 //     whole key (ck_key_tables: one launch each, no digits / sort / buckets / host Horner) on two streams side by side; LZ = L^T poly
 //     (bind_with_delayed, :38-54) stays in device memory in front of its walk and travels to the host only for z_vec,
-//   * the host meanwhile forms r_LZ = <L, blind>, <R, d> (tensor form: n + sqrt(n) products) and beta.
+//   * the host meanwhile draws d_vec from the randomness stream (the wide reductions of E::Scalar::random), forms r_LZ = <L, blind>, <R, d> (tensor
+//     form: n + sqrt(n) products) and beta.
 // Transcript order and every value are the reference's. out = delta (8) | beta (8) | z_vec (4 * cols) | z_delta (4) | z_beta (4) words.
 static void hp_point_bytes(const aff_t& a, uint8_t out[64]) {  // x BE || y BE (src/provider/traits.rs:288-305)
   sp::fe_to_be_bytes<B>(a.x, out);
   sp::fe_to_be_bytes<B>(a.y, out + 32);
 }
 int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcript* tr, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n,
-                   const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint64_t* rng_d,
-                   const uint64_t rng_rdelta[4], const uint64_t rng_rbeta[4], uint64_t* out) {
+                   const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint8_t* rng,
+                   size_t rng_blocks, uint64_t* out) {
   typedef spk::SF SF;
-  if (!c || !ck || !ck_eval || !tr || !comm_rows_aff || !poly || !blinds || (!point && npt) || !comm_eval_aff || !blind_eval || !rng_d || !rng_rdelta || !rng_rbeta || !out)
+  if (!c || !ck || !ck_eval || !tr || !comm_rows_aff || !poly || !blinds || (!point && npt) || !comm_eval_aff || !blind_eval || !rng || !out)
     return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_hyrax_prove: null argument");
   if (npt > 40 || n != ((size_t)1 << npt) || n > poly->cap)
     return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: Expected 2^point.len() elements in poly");  // hyrax_pc.rs:400-408
@@ -1332,18 +1354,30 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   const size_t cols = n / num_rows;  // |R| = |LZ| = |d|
   if (!ck_eval->d_cktables || ck_eval->num_cols < 1) return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: ck_eval must be a narrow key with tables");
   SP_HIP(hipSetDevice(c->device));
+  static const bool laps = getenv("SPARTAN_HOST_LAPS") != nullptr;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_lap = laps ? now_us() : 0;
+  auto lap = [&](const char* what) {
+    if (!laps) return;
+    const double t = now_us();
+    fprintf(stderr, "  hyrax_prove lap %-24s %8.1f us\n", what, t - t_lap);
+    t_lap = t;
+  };
   const aff_t* comm = reinterpret_cast<const aff_t*>(comm_rows_aff);
   const fe_t* blind = reinterpret_cast<const fe_t*>(blinds);
   const fe_t* pt = reinterpret_cast<const fe_t*>(point);
-  const fe_t* dvec = reinterpret_cast<const fe_t*>(rng_d);
-  fe_t r_delta, r_beta, b_eval;
-  memcpy(&r_delta, rng_rdelta, 32);
-  memcpy(&r_beta, rng_rbeta, 32);
+  if (rng_blocks < cols + 2) return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: the randomness stream holds fewer than cols + 2 blocks");
+  // E::Scalar::random draws (ipa.rs:139-149): d_vec, then the blinds of delta and beta, each the wide reduction of 64 uniform bytes. The two blinds
+  // now, the mask vector further down while the device already works on LZ.
+  std::vector<fe_t> dvec(cols);
+  const fe_t r_delta = fe_from_uniform<SF>(rng + 64 * cols), r_beta = fe_from_uniform<SF>(rng + 64 * (cols + 1));
+  fe_t b_eval;
   memcpy(&b_eval, blind_eval, 32);
   aff_t comm_eval;
   memcpy(&comm_eval, comm_eval_aff, sizeof(aff_t));
 
   // (1) helper thread: transcript.absorb(b"poly_com", comm) (hyrax_pc.rs:410) into a copy of the running hasher, installed at the join below
+  tr->join();
   if (!c->pcs_worker) c->pcs_worker = new sp::Worker();
   sp::Keccak256State hashed = tr->t.h;
   {
@@ -1367,6 +1401,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     ~Join() { w->wait(); }
   } join{c->pcs_worker};
 
+  lap("submit hashing");
   // (2) device: delta's walk on the auxiliary stream, LZ and comm_LZ's walk on the main stream
   const int kt = (nvr == 0 && cols > num_cols) ? 1 : sp::ck_key_tables(c, ck);
   if (kt < 0) return kt;
@@ -1386,14 +1421,10 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     }
   } job_guard{c, delta_job};
   int rc;
-  if (walk) {
-    std::vector<fe_t> sc(num_cols + 1, fe_zero());
-    memcpy(sc.data(), dvec, cols * sizeof(fe_t));
-    sc[num_cols] = r_delta;
-    if ((rc = sp::multi_mul_launch(c, 1, ck->d_keytables, reinterpret_cast<const uint64_t*>(sc.data()), num_cols + 1, &seq_delta, nullptr, nullptr))) return rc;
-  } else {
-    if ((rc = sp_msm_ck_begin(c, ck, rng_d, cols, &delta_job))) return rc;
-  }
+  // delta = <d, ck> + r_delta h first: it needs nothing but the randomness stream, whose blocks the kernel reduces itself
+  const bool delta_raw = walk && num_cols + 1 >= sp::multi_mul_wide_min() && 64 * num_cols <= 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
+  if (delta_raw && (rc = sp::multi_mul_launch(c, 1, ck->d_keytables, reinterpret_cast<const uint64_t*>(rng), num_cols + 1, &seq_delta, nullptr, &r_delta, cols))) return rc;
+  lap("delta launch");
   std::vector<fe_t> L((size_t)1 << nvr);
   eq_table_host(pt, nvr, L.data());
   if (nvr == 0) {  // a single row: the commitment is the row itself (hyrax_pc.rs:417-423)
@@ -1430,12 +1461,23 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
       }
       if (cols < num_cols) SP_HIP(hipMemsetAsync(dout + cols, 0, (num_cols - cols) * sizeof(fe_t), c->stream));
       c->timed("rowmat_vec", 32ull * (num_rows * cols + num_rows + cols), [&] { launch_rowmat_vec(c->stream, poly->d, num_rows, cols, dL, part, splits, dout); });
-      SP_HIP(hipMemcpyAsync(c->h_pcs, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
+      if ((rc = sp::multi_mul_launch(c, 0, ck->d_keytables, nullptr, num_cols + 1, &seq_lz, dout, &r_LZ, 0))) return rc;
+      SP_HIP(hipMemcpyAsync(c->h_pcs, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));  // behind the walk: LZ is needed on the host only for z_vec
       SP_HIP(hipEventRecord(c->pcs_ev, c->stream));
-      if ((rc = sp::multi_mul_launch(c, 0, ck->d_keytables, nullptr, num_cols + 1, &seq_lz, dout, &r_LZ))) return rc;
     } else {
       if ((rc = sp_rowmat_vec(c, poly, num_rows, cols, reinterpret_cast<const uint64_t*>(L.data()), reinterpret_cast<uint64_t*>(LZ.data())))) return rc;
     }
+  }
+  lap("LZ + comm_LZ launch");
+  // d_vec: 2048 wide reductions at config 2, ~65 us of host work beside the device's (delta's walk reduces its own copy of the blocks)
+  for (size_t i = 0; i < cols; ++i) dvec[i] = fe_from_uniform<SF>(rng + 64 * i);
+  lap("d_vec draw");
+  if (!walk && (rc = sp_msm_ck_begin(c, ck, reinterpret_cast<const uint64_t*>(dvec.data()), cols, &delta_job))) return rc;
+  if (walk && !delta_raw) {  // narrow keys: the walk from the drawn scalars
+    std::vector<fe_t> sc(num_cols + 1, fe_zero());
+    memcpy(sc.data(), dvec.data(), cols * sizeof(fe_t));
+    sc[num_cols] = r_delta;
+    if ((rc = sp::multi_mul_launch(c, 1, ck->d_keytables, reinterpret_cast<const uint64_t*>(sc.data()), num_cols + 1, &seq_delta, nullptr, nullptr, 0))) return rc;
   }
   // (3) host work under the device's: <R, d> with R = eq(point[nvr..]) = left (x) right (ipa.rs:148), beta = ck_c * <R, d> + h_c * r_beta (:149)
   fe_t ip = fe_zero();
@@ -1450,8 +1492,10 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
       ip = fe_add<SF>(ip, fe_mul<SF>(left[a], inner));
     }
   }
+  lap("<R, d>");
   aff_t beta;
-  if ((rc = sp_hyrax_commit_small(c, ck_eval, reinterpret_cast<const uint64_t*>(&ip), 1, rng_rbeta, reinterpret_cast<uint64_t*>(&beta)))) return rc;
+  if ((rc = sp_hyrax_commit_small(c, ck_eval, reinterpret_cast<const uint64_t*>(&ip), 1, reinterpret_cast<const uint64_t*>(&r_beta), reinterpret_cast<uint64_t*>(&beta)))) return rc;
+  lap("beta");
   // (4) joins
   if (walk) {
     jac_t dj;
@@ -1469,9 +1513,11 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
       return rc;
     sp_msm_job* j = delta_job;
     delta_job = nullptr;
-    if ((rc = sp_msm_ck_finish(c, ck, j, rng_rdelta, reinterpret_cast<uint64_t*>(&delta)))) return rc;
+    if ((rc = sp_msm_ck_finish(c, ck, j, reinterpret_cast<const uint64_t*>(&r_delta), reinterpret_cast<uint64_t*>(&delta)))) return rc;
   }
+  lap("join walks");
   c->pcs_worker->wait();
+  lap("join hashing");
   tr->t.h = hashed;
   // (5) InnerProductArgumentLinear::prove, transcript part (ipa.rs:132-158)
   {
@@ -1492,9 +1538,19 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   memcpy(out, &delta, sizeof(aff_t));
   memcpy(out + 8, &beta, sizeof(aff_t));
   fe_t* zv = reinterpret_cast<fe_t*>(out + 16);
-  for (size_t i = 0; i < cols; ++i) zv[i] = fe_add<SF>(fe_mul<SF>(rr, LZ[i]), dvec[i]);
+  {
+    const fe_t* lz = LZ.data();
+    const fe_t* dv = dvec.data();
+    const size_t half = cols >= 512 ? cols * 45 / 100 : cols;  // the owner starts at once, the helper has to wake up first
+    if (half < cols) c->pcs_worker->submit([zv, lz, dv, rr, half, cols] {
+      for (size_t i = half; i < cols; ++i) zv[i] = fe_add<SF>(fe_mul<SF>(rr, lz[i]), dv[i]);
+    });
+    for (size_t i = 0; i < half; ++i) zv[i] = fe_add<SF>(fe_mul<SF>(rr, lz[i]), dv[i]);
+    c->pcs_worker->wait();
+  }
   zv[cols] = fe_add<SF>(fe_mul<SF>(rr, r_LZ), r_delta);
   zv[cols + 1] = fe_add<SF>(fe_mul<SF>(rr, b_eval), r_beta);
+  lap("transcript + z_vec");
   return SP_OK;
 }
 

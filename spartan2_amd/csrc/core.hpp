@@ -221,6 +221,19 @@ struct sp_table {
 
 struct sp_transcript {
   sp::Transcript t;
+  // A long absorb (a commitment's 64 bytes per row: hundreds of Keccak blocks) runs on the library's hashing thread while the caller goes on to its
+  // next call — in src/spartan.rs's order that is the commitment of the rest segment and the build of z; every later use of the transcript joins
+  // first (join()), so the sponge sees exactly the reference's byte sequence.
+  std::vector<uint8_t> pend;
+  size_t pend_label = 0;
+  std::atomic<int> busy{0};
+  sp_transcript() = default;
+  sp_transcript(const sp_transcript&) = delete;
+  sp_transcript& operator=(const sp_transcript&) = delete;
+  void join() const {
+    while (busy.load(std::memory_order_acquire)) __builtin_ia32_pause();
+  }
+  ~sp_transcript() { join(); }
 };
 struct sp_absorb_state {
   sp::Keccak256State h;

@@ -49,7 +49,9 @@ struct DevBuf {  // RAII device allocation
 namespace sp {
 // capi_group.hip: one-launch table-walk MSM (k_multi_mul_coop) on lane 0 (main stream) or 1 (auxiliary stream), and the window tables of a key
 int multi_mul_ensure(sp_ctx* c, int lane);
-int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last);
+size_t multi_mul_wide_min();
+int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last,
+                     size_t raw_blocks);
 int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield);
 int ck_key_tables(sp_ctx* c, const sp_ck* ck);  // 0 = ready, 1 = not available (take the bucket MSM), < 0 = error
 // capi_comb.hip: the fixed-base comb table of a key (built on first use) and row commitments over it

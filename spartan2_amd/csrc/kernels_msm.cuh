@@ -908,6 +908,90 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restri
   }
 }
 
+// The same sum for MANY scalars (the 2048 bases of a key + h: delta and comm_LZ of the opening, 65 568 table entries): 1024 (scalar, digit) items per
+// 512-thread block instead of 128, so a walk over the whole key is 65 blocks — two of them run side by side on a quarter of the chip — and the
+// last-block join adds 65 sums instead of 513. Per block: every thread takes TWO entries (one mixed addition on its own lane: all eight waves busy),
+// lanes 32..63 of each wave hand their sum to lanes 0..31 through shuffles (one full addition per lane), and the 256 sums left go down the
+// block-cooperative tree of k_multi_mul_coop (eight levels). Same ticket / slot protocol, same result.
+constexpr int MULTI_MUL_WIDE_ITEMS = 1024;
+__global__ void __launch_bounds__(4 * 128) k_multi_mul_wide(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, xyzz_t* __restrict__ partial,
+                                                            unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq, fe_t last, int has_last, int raw64) {
+  // raw64: `scalars` points at 64-byte uniform blocks, one per scalar, reduced here as from_uniform (src/provider/traits.rs:275-280) - the IPA's mask
+  // vector straight from the randomness stream, so that delta's walk can start before the host has drawn a single element
+  __shared__ CoopAdd<128> L;
+  __shared__ xyzz_t s[256];
+  __shared__ unsigned s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, blk = wave >> 2;
+  {
+    const size_t e0 = (size_t)blockIdx.x * MULTI_MUL_WIDE_ITEMS + 2 * (size_t)threadIdx.x, idx = e0 >> 5;
+    const int j = (int)(e0 & 31);
+    xyzz_t acc = xyzz_identity();
+    if (idx < n) {
+      fe_t sc;
+      if (has_last && idx == n - 1) sc = last;
+      else if (raw64) sc = fe_from_uniform<SF>(reinterpret_cast<const uint8_t*>(scalars) + 64 * idx);
+      else sc = scalars[idx];
+      const fe_t c = fe_to_canonical<SF>(sc);
+      const unsigned d0 = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu, d1 = (c.v[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xffu;
+      const aff_t* tab = tables + idx * (32 * 255);
+      if (d0) acc = xyzz_from_affine(tab[(size_t)j * 255 + d0 - 1]);
+      if (d1) acc = xyzz_add_mixed(acc, tab[(size_t)(j + 1) * 255 + d1 - 1]);
+    }
+    const xyzz_t other = shfl_down_xyzz(acc, 32);
+    if (lane < 32) s[wave * 32 + lane] = xyzz_add(acc, other);
+  }
+  __syncthreads();
+  const int role = (wave + 2 * blk) & 3, k = blk * 64 + lane;  // roles of an item block on four different SIMDs (see k_msm_window_reduce_coop)
+  xyzz_add_block4<128>(L, &s[k], &s[k + 128], s, role, k, true);
+  for (int off = 64; off >= 1; off >>= 1) {
+    const bool active = k < off;
+    xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+  }
+  if (gridDim.x > 1) {
+    if (threadIdx.x == 0) {
+      partial[blockIdx.x] = s[0];
+      __threadfence();  // the block sum is visible device-wide before the ticket is taken
+      s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (role == 0) {
+      xyzz_t acc = xyzz_identity();
+      if (k < (int)gridDim.x) {  // other blocks' sums: loads that cannot be served from a stale line of this XCD's caches
+        const unsigned* pw = reinterpret_cast<const unsigned*>(&partial[k]);
+        unsigned* aw = reinterpret_cast<unsigned*>(&acc);
+#pragma unroll
+        for (int w = 0; w < (int)(sizeof(xyzz_t) / 4); ++w) aw[w] = __hip_atomic_load(pw + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s[k] = acc;
+    }
+    __syncthreads();
+    int top = 1;
+    const int live = (int)gridDim.x < 128 ? (int)gridDim.x : 128;  // (the launcher keeps the grid within 128 blocks = 4096 scalars)
+    while (2 * top < live) top <<= 1;
+    for (int off = top; off >= 1; off >>= 1) {
+      const bool active = k < off;
+      xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+    }
+    if (threadIdx.x == 0) atomicExch(ticket, 0u);  // ready for the next launch (stream order makes it visible)
+  }
+  if (threadIdx.x == 0) {
+    const jac_t r = xyzz_to_jac(s[0]);
+    const unsigned* rw = reinterpret_cast<const unsigned*>(&r);
+    unsigned a = seq, b = seq * MULTI_MUL_SLOT_K;
+#pragma unroll
+    for (int w = 0; w < 24; ++w) {
+      slot[w] = rw[w];
+      a += rw[w];
+      b += (unsigned)(w + 1) * rw[w];
+    }
+    const unsigned long long lo = ((unsigned long long)a << 32) | seq, hi = ((unsigned long long)seq << 32) | b;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 26), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + 24), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---- K9: LZ[i] = sum_j L[j] * poly[j*cols + i] ---------------------------------------------------------------------------
 // grid = (cols/64, row_splits): each block handles 64 columns x a slice of rows with 256 threads = 4 row-lanes per column.
 __global__ void __launch_bounds__(256) k_rowmat_vec(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L,
@@ -939,16 +1023,18 @@ __global__ void __launch_bounds__(1024) k_rowmat_vec_tall(const fe_t* __restrict
   const size_t col = (size_t)blockIdx.x * RMV_COLS + c;
   fe_t acc = fe_zero();
   if (col < cols) {
-    // two independent chains per lane keep two loads and two products in flight
+    // four loads in flight per lane (the 512 rows of config 2 are exactly one such group), two independent accumulation chains
     fe_t acc2 = fe_zero();
     size_t r = (size_t)wave * 8 + rl;
-    for (; r + 128 < rows; r += 256) {
-      const fe_t a = poly[r * cols + col], b = poly[(r + 128) * cols + col];
-      const fe_t la = L[r], lb = L[r + 128];
-      acc = fe_add<SF>(acc, fe_mul<SF>(la, a));
-      acc2 = fe_add<SF>(acc2, fe_mul<SF>(lb, b));
+    for (; r + 384 < rows; r += 512) {
+      const fe_t a0 = poly[r * cols + col], a1 = poly[(r + 128) * cols + col], a2 = poly[(r + 256) * cols + col], a3 = poly[(r + 384) * cols + col];
+      const fe_t l0 = L[r], l1 = L[r + 128], l2 = L[r + 256], l3 = L[r + 384];
+      acc = fe_add<SF>(acc, fe_mul<SF>(l0, a0));
+      acc2 = fe_add<SF>(acc2, fe_mul<SF>(l1, a1));
+      acc = fe_add<SF>(acc, fe_mul<SF>(l2, a2));
+      acc2 = fe_add<SF>(acc2, fe_mul<SF>(l3, a3));
     }
-    if (r < rows) acc = fe_add<SF>(acc, fe_mul<SF>(L[r], poly[r * cols + col]));
+    for (; r < rows; r += 128) acc = fe_add<SF>(acc, fe_mul<SF>(L[r], poly[r * cols + col]));
     acc = fe_add<SF>(acc, acc2);
   }
   lazy9_t t = lazy_from(acc);

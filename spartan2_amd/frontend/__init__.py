@@ -44,6 +44,12 @@ class R1CSInstanceInt:
         lib().spf_dims(self._h, d)
         (self.num_cons, self.num_shared, self.num_precommitted, self.num_rest, self.num_public, self.num_challenges, nnzA, nnzB, nnzC) = [int(x) for x in d]
         self.num_aux = self.num_shared + self.num_precommitted + self.num_rest
+        st = (ctypes.c_uint64 * 2)()
+        lib().spf_multieq_stats(self._h, st)
+        # SHA-256 circuits: the constraint count of the reference's synthesizer, whose MultiEq packs the additions' equality rows (r1cs_builder.hpp
+        # MultiEqSim); this generator emits them one per addition (int64 coefficients)
+        self.addmany_rows, self.multieq_rows = int(st[0]), int(st[1])
+        self.num_cons_bellpepper = self.num_cons - (self.addmany_rows - self.multieq_rows)
         self.csr = []
         for which, nnz in enumerate((nnzA, nnzB, nnzC)):
             data = ctypes.POINTER(ctypes.c_int64)()

@@ -52,6 +52,12 @@ void spf_dims(void* p, uint64_t out[9]) {
                    R->A.data.size(), R->B.data.size(), R->C.data.size()};
   memcpy(out, v, sizeof v);
 }
+// see MultiEqSim (r1cs_builder.hpp): out = equality rows emitted by the SHA-256 compressions' additions, rows bellpepper's MultiEq packs them into
+void spf_multieq_stats(void* p, uint64_t out[2]) {
+  auto* R = (R1CSInstanceInt*)p;
+  out[0] = R->stat_addmany_rows;
+  out[1] = R->stat_multieq_rows;
+}
 void spf_csr(void* p, int which, const int64_t** data, const uint32_t** indices, const uint64_t** indptr) {
   auto* R = (R1CSInstanceInt*)p;
   CsrInt& M = which == 0 ? R->A : which == 1 ? R->B : R->C;

@@ -42,6 +42,9 @@ struct ConstraintSystem {
   std::vector<uint64_t> inputs;  // input assignment, inputs[0] == 1
   CsrInt A, B, C;
   size_t num_constraints = 0;
+  // bookkeeping for the comparison with bellpepper's count (see MultiEqSim): equality rows emitted by UInt32::addmany inside SHA-256 compressions, and
+  // the rows bellpepper's MultiEq would have packed them into
+  size_t stat_addmany_rows = 0, stat_multieq_rows = 0;
   ConstraintSystem() { inputs.push_back(1); }
 
   uint32_t alloc_aux(uint64_t v) {
@@ -243,8 +246,27 @@ inline UInt32 u32_xor(ConstraintSystem& cs, const UInt32& a, const UInt32& b) {
   return u;
 }
 
-// UInt32::addmany: sum operands as an LC, allocate the result bits (with carries), one equality.
-inline UInt32 u32_addmany(ConstraintSystem& cs, const std::vector<UInt32>& ops) {
+// bellpepper's MultiEq (gadgets/multieq.rs; used by sha256_compression_function) packs the equality constraints of successive UInt32::addmany calls
+// into ONE row while the accumulated bit widths stay below the field's CAPACITY (255 for the 256-bit scalar field of the bench engine):
+// enforce_equal(num_bits, lhs, rhs) adds 2^bits_used * (lhs - rhs) to the pending row and flushes it first when CAPACITY <= bits_used + num_bits; the
+// last row is flushed when the compression ends. Packed rows carry coefficients up to 2^254, which this integer frontend (int64 coefficients) cannot
+// represent, so the generator keeps ONE row per addmany — the same equalities, unpacked — and only SIMULATES the packing to count the rows the
+// reference's synthesizer would emit: reference count = num_constraints - (stat_addmany_rows - stat_multieq_rows).
+struct MultiEqSim {
+  static constexpr size_t CAPACITY = 255;
+  size_t bits_used = 0, rows = 0;
+  void enforce_equal(size_t num_bits) {
+    if (CAPACITY <= bits_used + num_bits) flush();
+    bits_used += num_bits;
+  }
+  void flush() {
+    if (bits_used > 0) ++rows;
+    bits_used = 0;
+  }
+};
+
+// UInt32::addmany: sum operands as an LC, allocate the result bits (with carries), one equality (through `me`, when given, as bellpepper does).
+inline UInt32 u32_addmany(ConstraintSystem& cs, const std::vector<UInt32>& ops, MultiEqSim* me = nullptr) {
   bool all_const = true;
   uint64_t sum = 0, max_value = (uint64_t)ops.size() * 0xffffffffULL;
   LC lc;
@@ -265,6 +287,10 @@ inline UInt32 u32_addmany(ConstraintSystem& cs, const std::vector<UInt32>& ops) 
     ++i;
   }
   cs.enforce(lc, {{ConstraintSystem::one(), 1}}, res_lc);
+  if (me) {
+    me->enforce_equal((size_t)i);
+    ++cs.stat_addmany_rows;
+  }
   return out;
 }
 
@@ -277,41 +303,70 @@ static const uint32_t SHA256_K[64] = {
     0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
 static const uint32_t SHA256_IV[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
 
-// one compression: 512 input bits (big-endian words) + current state -> new state
+// one compression: 512 input bits (big-endian words) + current state -> new state. Statement order, deferred additions (`Maybe`) and the operand lists
+// are those of bellpepper::gadgets::sha256::sha256_compression_function (bellpepper 0.4.0, a fork of bellman's gadget; the crate is not under
+// /root/reference): the working variables a and e are kept as operand lists and only become bits at the start of the next round — or, after the last
+// round, together with the chaining value they are added to (h0 and h4 are ONE addition of 8 / 7 operands each).
 inline void sha256_compression(ConstraintSystem& cs, const Boolean* input512, UInt32 state[8]) {
+  MultiEqSim me;
   std::vector<UInt32> w(64);
   for (int i = 0; i < 16; ++i) w[i] = UInt32::from_bits_be(input512 + 32 * i);
   for (int i = 16; i < 64; ++i) {
     UInt32 s0 = u32_xor(cs, u32_xor(cs, w[i - 15].rotr(7), w[i - 15].rotr(18)), w[i - 15].shr(3));
     UInt32 s1 = u32_xor(cs, u32_xor(cs, w[i - 2].rotr(17), w[i - 2].rotr(19)), w[i - 2].shr(10));
-    w[i] = u32_addmany(cs, {w[i - 16], s0, w[i - 7], s1});
+    w[i] = u32_addmany(cs, {w[i - 16], s0, w[i - 7], s1}, &me);
   }
-  // deferred additions, as the gadget does: a and e are kept as operand lists until needed as bits
-  UInt32 a = state[0], b = state[1], c = state[2], d = state[3], e = state[4], f = state[5], g = state[6], h = state[7];
+  struct Maybe {  // Deferred(operands) | Concrete(value)
+    bool deferred = false;
+    std::vector<UInt32> ops;
+    UInt32 value;
+    UInt32 compute(ConstraintSystem& cs, MultiEqSim& me, const std::vector<UInt32>& others) {
+      if (!deferred) return value;
+      std::vector<UInt32> v = ops;
+      v.insert(v.end(), others.begin(), others.end());
+      return u32_addmany(cs, v, &me);
+    }
+  };
+  Maybe a, e;
+  a.value = state[0];
+  e.value = state[4];
+  UInt32 b = state[1], c = state[2], d = state[3], f = state[5], g = state[6], h = state[7];
   for (int i = 0; i < 64; ++i) {
-    UInt32 s1 = u32_xor(cs, u32_xor(cs, e.rotr(6), e.rotr(11)), e.rotr(25));
+    const UInt32 new_e = e.compute(cs, me, {});
+    UInt32 s1 = u32_xor(cs, u32_xor(cs, new_e.rotr(6), new_e.rotr(11)), new_e.rotr(25));
     UInt32 ch;
-    for (int k = 0; k < 32; ++k) ch.bits[k] = sha256_ch(cs, e.bits[k], f.bits[k], g.bits[k]);
-    UInt32 s0 = u32_xor(cs, u32_xor(cs, a.rotr(2), a.rotr(13)), a.rotr(22));
+    for (int k = 0; k < 32; ++k) ch.bits[k] = sha256_ch(cs, new_e.bits[k], f.bits[k], g.bits[k]);
+    const std::vector<UInt32> temp1 = {h, s1, ch, UInt32::constant(SHA256_K[i]), w[i]};
+    const UInt32 new_a = a.compute(cs, me, {});
+    UInt32 s0 = u32_xor(cs, u32_xor(cs, new_a.rotr(2), new_a.rotr(13)), new_a.rotr(22));
     UInt32 maj;
-    for (int k = 0; k < 32; ++k) maj.bits[k] = sha256_maj(cs, a.bits[k], b.bits[k], c.bits[k]);
-    std::vector<UInt32> temp1 = {h, s1, ch, UInt32::constant(SHA256_K[i]), w[i]};
-    std::vector<UInt32> new_e_ops = temp1;
-    new_e_ops.push_back(d);
-    std::vector<UInt32> new_a_ops = temp1;
-    new_a_ops.push_back(s0);
-    new_a_ops.push_back(maj);
+    for (int k = 0; k < 32; ++k) maj.bits[k] = sha256_maj(cs, new_a.bits[k], b.bits[k], c.bits[k]);
     h = g;
     g = f;
-    f = e;
-    e = u32_addmany(cs, new_e_ops);
+    f = new_e;
+    e.deferred = true;
+    e.ops = {d};
+    e.ops.insert(e.ops.end(), temp1.begin(), temp1.end());
     d = c;
     c = b;
-    b = a;
-    a = u32_addmany(cs, new_a_ops);
+    b = new_a;
+    a.deferred = true;
+    a.ops = temp1;
+    a.ops.push_back(s0);
+    a.ops.push_back(maj);
   }
-  UInt32 wv[8] = {a, b, c, d, e, f, g, h};
-  for (int i = 0; i < 8; ++i) state[i] = u32_addmany(cs, {state[i], wv[i]});
+  UInt32 out[8];
+  out[0] = a.compute(cs, me, {state[0]});
+  out[1] = u32_addmany(cs, {state[1], b}, &me);
+  out[2] = u32_addmany(cs, {state[2], c}, &me);
+  out[3] = u32_addmany(cs, {state[3], d}, &me);
+  out[4] = e.compute(cs, me, {state[4]});
+  out[5] = u32_addmany(cs, {state[5], f}, &me);
+  out[6] = u32_addmany(cs, {state[6], g}, &me);
+  out[7] = u32_addmany(cs, {state[7], h}, &me);
+  for (int i = 0; i < 8; ++i) state[i] = out[i];
+  me.flush();
+  cs.stat_multieq_rows += me.rows;
 }
 
 // bellpepper::gadgets::sha256::sha256: pad, iterate compressions, output 256 bits big-endian
@@ -366,6 +421,7 @@ struct R1CSInstanceInt {
   CsrInt A, B, C;                 // indices already mapped: aux j -> j, input i -> num_aux + i
   std::vector<uint64_t> witness;  // aux assignment (shared | precommitted | rest), unpadded
   std::vector<uint64_t> publics;  // input assignment without ONE
+  size_t stat_addmany_rows = 0, stat_multieq_rows = 0;  // see MultiEqSim
 };
 
 inline R1CSInstanceInt finalize(ConstraintSystem& cs, size_t num_shared, size_t num_precommitted) {
@@ -376,6 +432,8 @@ inline R1CSInstanceInt finalize(ConstraintSystem& cs, size_t num_shared, size_t 
   R.num_precommitted = num_precommitted;
   R.num_rest = num_aux - num_shared - num_precommitted;
   R.num_public = cs.inputs.size() - 1;
+  R.stat_addmany_rows = cs.stat_addmany_rows;
+  R.stat_multieq_rows = cs.stat_multieq_rows;
   auto remap = [&](CsrInt& M) {
     for (uint32_t& c : M.indices) c = (c & INPUT_FLAG) ? (uint32_t)(num_aux + (c & ~INPUT_FLAG)) : c;
   };

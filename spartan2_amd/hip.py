@@ -212,6 +212,12 @@ class Transcript:
         check(lib().sp_transcript_squeeze(self.h, p8(la), ln, p64(out)))
         return out
 
+    def clone(self):
+        t = Transcript.__new__(Transcript)
+        t.h = ctypes.c_void_p()
+        check(lib().sp_transcript_clone(self.h, ctypes.byref(t.h)))
+        return t
+
     def __del__(self):
         try:
             if self.h:
@@ -349,18 +355,19 @@ class CommitmentKey:
         check(lib().sp_hyrax_commit(self.ctx.h, self.h, table.h, ctypes.c_size_t(off), ctypes.c_size_t(n), p64(blinds), int(is_small), p64(out)))
         return out
 
-    def prove(self, key_eval, tr, comm_rows, poly, n, blinds, point, comm_eval, blind_eval, rng_d, rng_rdelta, rng_rbeta):
-        """HyraxPCS::prove (hyrax_pc.rs:387-478) as one ABI call (sp_hyrax_prove): returns delta (8) | beta (8) | z_vec | z_delta | z_beta words."""
+    def prove(self, key_eval, tr, comm_rows, poly, n, blinds, point, comm_eval, blind_eval, rng):
+        """HyraxPCS::prove (hyrax_pc.rs:387-478) as one ABI call (sp_hyrax_prove): rng = (>= cols + 2, 64) uniform bytes (d_vec, r_delta, r_beta in draw
+        order); returns delta (8) | beta (8) | z_vec | z_delta | z_beta words."""
         comm_rows = np.ascontiguousarray(comm_rows, dtype=np.uint64).reshape(-1, 8)
         point = np.ascontiguousarray(point, dtype=np.uint64).reshape(-1, 4)
         rows = comm_rows.shape[0]
         cols = n // rows
-        rng_d = np.ascontiguousarray(rng_d, dtype=np.uint64).reshape(cols, 4)
+        rng = np.ascontiguousarray(rng, dtype=np.uint8).reshape(-1, 64)
         out = np.zeros(16 + 4 * cols + 8, dtype=np.uint64)
         c = lambda a, shape: np.ascontiguousarray(a, dtype=np.uint64).reshape(shape)
         check(lib().sp_hyrax_prove(self.ctx.h, self.h, key_eval.h, tr.h, p64(comm_rows), ctypes.c_size_t(rows), poly.h, ctypes.c_size_t(n), p64(c(blinds, (rows, 4))),
-                                   p64(point), ctypes.c_size_t(point.shape[0]), p64(c(comm_eval, (8,))), p64(c(blind_eval, (4,))), p64(rng_d), p64(c(rng_rdelta, (4,))),
-                                   p64(c(rng_rbeta, (4,))), p64(out)))
+                                   p64(point), ctypes.c_size_t(point.shape[0]), p64(c(comm_eval, (8,))), p64(c(blind_eval, (4,))), p8(rng), ctypes.c_size_t(rng.shape[0]),
+                                   p64(out)))
         return out
 
     def rerandomize(self, comm_rows, r_old, r_new):

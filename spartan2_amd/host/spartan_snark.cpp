@@ -922,13 +922,13 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
   proof.pf(eval_W);
   proof.pf(blind_eval_W);
   const size_t num_rows = (M + W_ - 1) / W_, cols = M / num_rows;
-  std::vector<fe_t> dvec(cols);
-  for (auto& x : dvec) x = tape.next();  // ipa.rs:139-145, inside InnerProductArgumentLinear::prove in the reference: the shim draws it for the call
-  const fe_t r_delta = tape.next(), r_beta = tape.next();
+  // (the draws of ipa.rs:139-149 happen inside the call, from the randomness stream at its current position: cols + 2 blocks)
+  if (tape.pos + cols + 2 > tape.blocks) throw Error(SP_ERR_INTERNAL, "random tape exhausted");
   std::vector<uint64_t> arg(16 + 4 * cols + 8);
   ck(sp_hyrax_prove(ctx, pk.ck, pk.ck_s, tr.t, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), u64p(r_y.data() + 1), num_rounds_y - 1, u64p(&comm_eval_W.x),
-                    u64p(&blind_eval_W), u64p(dvec.data()), u64p(&r_delta), u64p(&r_beta), arg.data()),
+                    u64p(&blind_eval_W), tape.bytes + 64 * tape.pos, tape.blocks - tape.pos, arg.data()),
      "PCS::prove");
+  tape.skip(cols + 2);
   proof.words.insert(proof.words.end(), arg.begin(), arg.end());
   const double t_end = now_ms();
   if (pt) {

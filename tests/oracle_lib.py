@@ -134,6 +134,9 @@ class Transcript:
         a = np.ascontiguousarray(limbs, dtype=np.uint64)
         lib().orc_transcript_absorb_scalar(self.h, label, fid, p64(a))
 
+    def dom_sep(self, data: bytes):
+        lib().orc_transcript_dom_sep(self.h, data)
+
     def squeeze(self, label: bytes, fid=0):
         out = np.zeros(4, dtype=np.uint64)
         lib().orc_transcript_squeeze(self.h, label, fid, p64(out))

@@ -179,3 +179,26 @@ def test_table_view_and_device_ptr(ctx):
         x.free()
     assert (t.read(0, 4) == v[:4]).all()  # freeing views leaves the storage alone
     t.free()
+
+
+def test_long_absorbs_hashed_on_the_library_thread_equal_the_oracle_transcript(ctx):
+    """sp_transcript_absorb hands inputs of >= 4 KiB to the library's hashing thread and returns (the caller's next calls run beside the Keccak blocks);
+    every later use of the transcript joins first. The squeezed challenges must be the oracle transcript's (src/provider/keccak.rs:70-99) whatever mix of
+    short / long absorbs, dom_seps, clones and squeezes follows."""
+    rng = np.random.default_rng(77)
+    tr, otr = hip.Transcript(ctx, b"async"), ol.Transcript(b"async")
+    for step, n in enumerate([10, 5000, 70000, 3, 4096, 4095, 200000]):
+        data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        tr.absorb(b"blob", data)
+        otr.absorb(b"blob", data)
+        if step % 3 == 1:
+            tr.dom_sep(b"sep")
+            otr.dom_sep(b"sep")
+        if step % 2 == 0:
+            assert (tr.squeeze(b"c") == otr.squeeze(b"c")).all()
+    big = rng.integers(0, 256, size=100000, dtype=np.uint8).tobytes()
+    tr.absorb(b"last", big)  # still hashing when the clone is taken: the clone must wait for it
+    otr.absorb(b"last", big)
+    want = otr.squeeze(b"z")
+    tr2 = tr.clone()
+    assert (tr2.squeeze(b"z") == want).all() and (tr.squeeze(b"z") == want).all()

@@ -216,10 +216,9 @@ def test_hyrax_prove_is_the_oracles_pcs_prove(ctx, key, gens, npt, key_tables, m
     assert olib().orc_transcript_absorb(otr, b"x", b"warm", ctypes.c_size_t(4)) == 0
     assert olib().orc_hyrax_prove(okey, okey_s, otr, p64(comm), ctypes.c_size_t(rows), p64(poly), ctypes.c_size_t(n), p64(blinds), p64(point), ctypes.c_size_t(npt),
                                   p64(comm_eval), p64(b_ev), tape.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_size_t(tape.shape[0]), p64(want)) == 0
-    draws = ol.tape_field_array(tape)  # from_uniform of every block, the draw order of ipa.rs:139-149: d_vec, r_delta, r_beta
     tr = hip.Transcript(ctx, b"pcs")
     tr.absorb(b"x", b"warm")  # (not a fresh hasher: the general path of the helper's hashing)
-    got = key.prove(key_s, tr, comm, hip.Table.from_host(ctx, poly), n, blinds, point, comm_eval, b_ev, draws[:cols], draws[cols], draws[cols + 1])
+    got = key.prove(key_s, tr, comm, hip.Table.from_host(ctx, poly), n, blinds, point, comm_eval, b_ev, tape)
     assert (got == want).all()
     o_next = np.zeros(4, dtype=np.uint64)
     assert olib().orc_transcript_squeeze(otr, b"n", 0, p64(o_next)) == 0
@@ -332,7 +331,7 @@ def test_commit_small_device_form_matches_oracle(ctx, width):
         assert (k.commit_small(ones, blind) == want(ones, blind)).all()
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 33, 130, 429, 512, 700, 2048])
+@pytest.mark.parametrize("n", [1, 3, 4, 33, 130, 429, 512, 700, 2048, 2049, 2600])
 def test_fixed_base_tables_multi_mul_matches_oracle_msm(ctx, n):
     """sp_fbtables_create + sp_fbtables_multi_mul (FixedBaseMul::precompute / multi_mul over arbitrary points, msm.rs:637-773; the one-launch form comm_LZ
     of the opening uses on the row commitments of a prepared witness) against the oracle's MSM: dense scalars, zeros, repeated calls (sequence numbers),
@@ -351,4 +350,4 @@ def test_fixed_base_tables_multi_mul_matches_oracle_msm(ctx, n):
     t.close()
     if n == 4:
         with pytest.raises(hip.SpartanHipError):
-            hip.FixedBaseTables(ctx, np.zeros((2049, 8), dtype=np.uint64))
+            hip.FixedBaseTables(ctx, np.zeros((4097, 8), dtype=np.uint64))  # more than 1024 blocks of four scalars
