@@ -55,3 +55,23 @@ def test_transcript_entry_points_match_reference_kat_on_cpu():
     t.absorb(b"blob", big)
     o.absorb(b"blob", big)
     assert (t.squeeze(b"r") == o.squeeze(b"r", fid=0)).all()
+
+
+def test_rust_ffi_module_is_generated_from_the_header():
+    """integration/hip_ffi.rs (the `extern "C"` module of the reference-side binding) is what tools/gen_rust_ffi.py emits for the current header, and it
+    declares every function of include/spartan_hip.h."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_rust_ffi", os.path.join(root, "tools", "gen_rust_ffi.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text, names = gen.emit()
+    with open(os.path.join(root, "integration", "hip_ffi.rs")) as f:
+        assert f.read() == text, "run python tools/gen_rust_ffi.py"
+    from spartan2_amd import hip
+
+    assert sorted(names) == hip.declared_symbols()
+    for n in names:
+        assert f"pub fn {n}(" in text
