@@ -456,3 +456,19 @@ class OracleNeutronNova:
         rc = lib().orc_nn_verify(self.k, pf)
         lib().orc_nn_proof_free(pf)
         return rc
+
+
+def verifier_circuit_counts(nb, nx, ny, width=32):
+    """Counts of NeutronNovaVerifierCircuit derived by hand from src/zk.rs (tests/golden/reference_kats.json 'neutronnova_verifier_circuit_counts'):
+    -> dict(rounds, aux, inputs, constraints, vars_padded, public)."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")) as f:
+        pr = json.load(f)["neutronnova_verifier_circuit_counts"]["per_round"]
+    seq = (["nifs_first"] + ["nifs_next"] * (nb - 1) + ["nifs_final", "outer_first"] + ["outer_next"] * (nx - 1) + ["outer_final", "inner_first"]
+           + ["inner_next"] * (ny - 1) + ["inner_final", "commit_w", "commit_w"])
+    num = lambda v: width if isinstance(v, str) else v
+    aux = [num(pr[k]["aux"]) for k in seq]
+    return {"rounds": len(seq), "aux": sum(aux), "inputs": sum(pr[k]["inputs"] for k in seq), "constraints": sum(num(pr[k]["constraints"]) for k in seq),
+            "vars_padded": sum(-(-a // width) * width for a in aux), "public": pr["inner_final"]["public_inputs"]}

@@ -25,6 +25,8 @@ def _both(ctx, steps, core, seed):
     want, used, secs = onn.prove(tape)
     gnn = host.NeutronNovaZkSNARK(ctx, steps, core)
     assert gnn.info == onn.info and (gnn.vk_digest == onn.digest()).all()
+    c = ol.verifier_circuit_counts(gnn.info["nb"], gnn.info["nx"], gnn.info["ny"], 32)  # hand-derived from src/zk.rs (tests/golden/reference_kats.json)
+    assert (gnn.info["vc_rounds"], gnn.info["vc_cons_unpadded"], gnn.info["vc_vars"], gnn.info["vc_public"]) == (c["rounds"], c["constraints"], c["vars_padded"], c["public"])
     assert gnn.prep_prove(tape) == used[0]
     got, used_g, phases = gnn.prove(tape[used[0]:])
     assert used_g == used[1] and len(got) == len(want)

@@ -30,3 +30,29 @@ def test_prove_verify_and_tamper(n):
         bad = words.copy()
         bad[int(pos)] ^= np.uint64(1 << 3)
         assert nn.verify_words(bad) != 0, int(pos)
+
+
+def _assert_counts(info):
+    """The verifier circuit's shape against the counts derived by hand from src/zk.rs (tests/golden/reference_kats.json): what narrows the common-mode
+    hole of two restatements (oracle, product) written from one reading of the reference."""
+    c = ol.verifier_circuit_counts(info["nb"], info["nx"], info["ny"], 32)
+    assert info["vc_rounds"] == c["rounds"]
+    assert info["vc_cons_unpadded"] == c["constraints"]
+    assert info["vc_vars"] == c["vars_padded"]
+    assert info["vc_public"] == c["public"]
+    assert info["vc_cons"] == 1 << (c["constraints"] - 1).bit_length()
+
+
+@pytest.mark.parametrize("n,groups", [(2, 8), (4, 3), (8, 3), (16, 8)])
+def test_verifier_circuit_counts_match_the_hand_derivation(n, groups):
+    steps, core = _insts(n, groups)
+    _assert_counts(ol.OracleNeutronNova(steps, core).info)
+
+
+def test_verifier_circuit_counts_at_config_3():
+    # 32 one-compression SHA-256 step circuits + core (benches/sha256_neutronnova.rs): nb = 5, nx = 15, ny = 16
+    circs = [frontend.sha256_step_circuit(bytes([i]) * 64) for i in range(32)]
+    info = ol.OracleNeutronNova(circs, frontend.sha256_step_circuit(bytes(64))).info
+    assert (info["nb"], info["nx"], info["ny"]) == (5, 15, 16)
+    _assert_counts(info)
+    assert info["vc_cons_unpadded"] == 2 + 4 * 4 + 4 + 3 + 8 * 14 + 10 + 7 + 6 * 15 + 12 + 64
