@@ -368,7 +368,8 @@ class Comm:
     def stats(self):
         s = (ctypes.c_uint64 * 2)()
         lib().ssc_comm_stats(self.h, s)
-        return {"exchanges": int(s[0]), "bytes_gathered": int(s[1])}
+        lib().ssc_comm_small_calls.restype = ctypes.c_uint64
+        return {"exchanges": int(s[0]), "bytes_gathered": int(s[1]), "copy_free_exchanges": int(lib().ssc_comm_small_calls(self.h))}
 
     def close(self):
         if self.h:

@@ -2,14 +2,19 @@
 // record per rank — because nothing this path exchanges is an elementwise reduction RCCL knows: field sums are modular, group sums are elliptic-curve
 // additions. Every rank gathers everyone's record and combines locally in rank order (exact arithmetic: all ranks obtain identical values and run
 // the deterministic transcript redundantly, so nothing is ever broadcast).
-//   * RCCL backend (production: xGMI between the GPUs of a node): ncclAllGather on a device staging buffer on a stream of its own, bracketed by
-//     pinned-host copies. librccl is resolved with dlopen at first use, so the one copy already in the process (torch ships its own) is shared.
+//   * RCCL backend (production: xGMI between the GPUs of a node): ncclAllGather on a stream of its own. Small records (the 64 - 96 bytes of a
+//     sum-check round: the latency case) take the copy-free form: the host writes the record straight into the device send buffer through the PCIe
+//     BAR (fine-grained device memory, as the challenge mailbox does), ncclAllGather runs on it, and a one-block kernel behind it on the same stream
+//     publishes the gathered records into a self-validating slot in mapped host memory that the host polls — no hipMemcpyAsync pair, no stream
+//     synchronise. Larger records keep pinned-host staging copies. librccl is resolved with dlopen at first use, so the one copy already in the
+//     process (torch ships its own) is shared.
 //   * callback backend (tests: gloo ranks that share one GPU; RCCL refuses two ranks on one device).
 #pragma once
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,6 +22,27 @@
 #include "host_common.hpp"
 
 namespace spartan2 {
+
+// gathered records -> mapped host memory, then the tag (sequence number + check word) the host polls for; bytes is a multiple of 8
+static __global__ void __launch_bounds__(256) k_comm_publish(const unsigned long long* __restrict__ src, size_t words, unsigned long long* __restrict__ dst, unsigned seq) {
+  __shared__ unsigned long long part[256];
+  unsigned long long acc = 0;
+  for (size_t i = threadIdx.x; i < words; i += blockDim.x) {
+    const unsigned long long v = src[i];
+    dst[2 + i] = v;
+    acc += v * (2 * i + 1);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(dst + 1, part[0] + seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 typedef int (*ssc_allgather_fn)(void* user, const void* send, size_t bytes_per_rank, void* recv);
 
@@ -59,9 +85,22 @@ struct Comm {
   void *d_send = nullptr, *d_recv = nullptr, *h_send = nullptr, *h_recv = nullptr;
   size_t cap = 0;  // bytes per rank the staging buffers hold
   uint64_t calls = 0, bytes_moved = 0;
+  // small-record path (<= SMALL_MAX bytes per rank)
+  static constexpr size_t SMALL_MAX = 16384;  // (hipMemcpyAsync of a few KiB is the slowest size class of the staging path: 94 - 108 us at 4 KiB)
+  void* d_small_send = nullptr;           // fine-grained device memory; h_small_send = the same bytes through the BAR (nullptr: no large BAR)
+  volatile uint8_t* h_small_send = nullptr;
+  void* d_small_recv = nullptr;           // world * SMALL_MAX
+  unsigned long long* h_slot = nullptr;   // mapped pinned: [seq, check, words...]
+  unsigned long long* d_slot = nullptr;
+  unsigned small_seq = 0;
+  bool small_ready = false, small_failed = false;
+  uint64_t small_calls = 0;
 
   ~Comm() {
     if (nc) RcclApi::get().CommDestroy(nc);
+    if (d_small_send) (void)hipFree(d_small_send);
+    if (d_small_recv) (void)hipFree(d_small_recv);
+    if (h_slot) (void)hipHostFree(h_slot);
     if (d_send) (void)hipFree(d_send);
     if (d_recv) (void)hipFree(d_recv);
     if (h_send) (void)hipHostFree(h_send);
@@ -86,6 +125,29 @@ struct Comm {
     hipck(hipHostMalloc(&h_recv, want * world), "comm: hipHostMalloc");
     cap = want;
   }
+  bool small_setup() {
+    if (small_ready) return true;
+    if (small_failed) return false;
+    const char* e = getenv("SPARTAN_COMM_SMALL");  // "0": staging copies for every size (A/B runs)
+    int large_bar = 0;
+    if ((e && e[0] == '0') || hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar ||
+        hipExtMallocWithFlags(&d_small_send, SMALL_MAX, hipDeviceMallocFinegrained) != hipSuccess) {
+      small_failed = true;
+      return false;
+    }
+    h_small_send = reinterpret_cast<volatile uint8_t*>(d_small_send);
+    const size_t slot_bytes = 16 + SMALL_MAX * (size_t)world;
+    if (hipMalloc(&d_small_recv, SMALL_MAX * (size_t)world) != hipSuccess || hipHostMalloc((void**)&h_slot, slot_bytes, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&d_slot, h_slot, 0) != hipSuccess) {
+      small_failed = true;
+      return false;
+    }
+    memset(h_slot, 0, slot_bytes);
+    (void)hipMemset(d_small_send, 0, SMALL_MAX);
+    (void)hipDeviceSynchronize();
+    small_ready = true;
+    return true;
+  }
   // recv[r * bytes .. (r + 1) * bytes) = rank r's `send`
   void allgather(const void* send, size_t bytes, void* recv) {
     ++calls;
@@ -101,6 +163,36 @@ struct Comm {
       return;
     }
     hipck(hipSetDevice(device), "comm: hipSetDevice");
+    if (bytes <= SMALL_MAX && bytes % 8 == 0 && small_setup()) {
+      // record -> device send buffer through the BAR (write-combining: the fence pushes it out ahead of the launch's doorbell)
+      for (size_t i = 0; i < bytes; i += 8) *reinterpret_cast<volatile uint64_t*>(h_small_send + i) = *reinterpret_cast<const uint64_t*>((const uint8_t*)send + i);
+      __builtin_ia32_sfence();
+      ncclResult_t r = RcclApi::get().AllGather(d_small_send, d_small_recv, bytes, ncclUint8, nc, st);
+      if (r != ncclSuccess) throw Error(SP_ERR_INTERNAL, std::string("ncclAllGather: ") + RcclApi::get().GetErrorString(r));
+      if (++small_seq == 0) ++small_seq;
+      const size_t words = bytes * (size_t)world / 8;
+      hipLaunchKernelGGL(k_comm_publish, dim3(1), dim3(256), 0, st, reinterpret_cast<const unsigned long long*>(d_small_recv), words, d_slot, small_seq);
+      ++small_calls;
+      volatile unsigned long long* slot = h_slot;
+      bool synced = false;
+      for (long spins = 0;; ++spins) {
+        if (slot[0] == small_seq) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          unsigned long long chk = small_seq;
+          for (size_t i = 0; i < words; ++i) chk += slot[2 + i] * (2 * i + 1);
+          if (slot[1] == chk && slot[0] == small_seq) break;
+        }
+        if (spins > 2000000) {  // seconds: a peer is late, or a profiler serialises the stream
+          if (synced) throw Error(SP_ERR_INTERNAL, "comm: the gathered record did not arrive");
+          hipck(hipStreamSynchronize(st), "comm: synchronize");
+          synced = true;
+          spins = 0;
+        }
+        __builtin_ia32_pause();
+      }
+      for (size_t i = 0; i < words; ++i) reinterpret_cast<uint64_t*>(recv)[i] = slot[2 + i];
+      return;
+    }
     reserve(bytes);
     memcpy(h_send, send, bytes);
     hipck(hipMemcpyAsync(d_send, h_send, bytes, hipMemcpyHostToDevice, st), "comm: H2D");

@@ -768,6 +768,8 @@ void ssc_comm_stats(void* comm, uint64_t out[2]) {
   out[0] = ((Comm*)comm)->calls;
   out[1] = ((Comm*)comm)->bytes_moved;
 }
+// exchanges that took the copy-free small-record form (BAR-written send buffer, publish kernel, polled slot)
+uint64_t ssc_comm_small_calls(void* comm) { return ((Comm*)comm)->small_calls; }
 void ssc_comm_free(void* comm) { delete (Comm*)comm; }
 
 int ssd_setup(sp_ctx* ctx, void* comm, size_t num_cons, size_t num_shared, size_t num_precommitted, size_t num_rest, size_t num_public, size_t num_challenges,
