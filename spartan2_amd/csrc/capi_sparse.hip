@@ -349,7 +349,34 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     order.reserve(s->num_cols);
     for (size_t i = 0; i < s->num_cols; ++i)
       if (col_count[i] < spk::LONG_COLUMN) order.push_back((unsigned)i);
-    std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return col_count[x] > col_count[y]; });
+    // Sorted by decreasing entry count WITHIN windows of consecutive columns (SPARTAN_POLYABC_WINDOW, 0 = one global sort as in round 2): the lanes of
+    // a wave still walk columns of (nearly) equal length, but a block's 256 columns now come from one neighbourhood of the matrix, so its pointer
+    // loads are nearly coalesced and its gathers from evals_rx fall into a narrow row range (circuit variables are used near where they are allocated)
+    static const size_t window = [] {
+      const char* e = getenv("SPARTAN_POLYABC_WINDOW");
+      return e ? (size_t)atol(e) : (size_t)0;  // measured (tools/r03_polyabc_window.sh): windows of 1 K - 128 K columns with heaviest-first chunks 115 - 120 us, one global sort 116 - 122 us: locality is not what bounds the kernel
+    }();
+    if (window == 0) {
+      std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return col_count[x] > col_count[y]; });
+    } else {
+      for (size_t lo = 0; lo < order.size(); lo += window) {
+        const size_t hi = lo + window < order.size() ? lo + window : order.size();
+        std::stable_sort(order.begin() + lo, order.begin() + hi, [&](unsigned x, unsigned y) { return col_count[x] > col_count[y]; });
+      }
+      // ... and the 256-column chunks (= blocks of the launch) by decreasing cost, heaviest first, so that the grid does not end on long columns
+      const size_t nchunks = (order.size() + 255) / 256;
+      std::vector<unsigned> chunk(nchunks), cost(nchunks, 0);
+      for (size_t c = 0; c < nchunks; ++c) {
+        chunk[c] = (unsigned)c;
+        for (size_t i = 256 * c; i < order.size() && i < 256 * (c + 1); i += 64) cost[c] += col_count[order[i]];  // the first (longest) column of each wave
+      }
+      std::stable_sort(chunk.begin(), chunk.end(), [&](unsigned x, unsigned y) { return cost[x] > cost[y]; });
+      std::vector<unsigned> re;
+      re.reserve(order.size());
+      for (unsigned c : chunk)
+        for (size_t i = 256 * (size_t)c; i < order.size() && i < 256 * ((size_t)c + 1); ++i) re.push_back(order[i]);
+      order.swap(re);
+    }
     s->n_short = order.size();
     if ((rc = upload(&s->d_short_order, order))) return rc;
   }
