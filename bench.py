@@ -239,6 +239,16 @@ def main():
         barrier()
         elapsed = group.max_over_ranks(time.perf_counter() - t0)
         ncons = circs[0].num_cons * nsteps + core.num_cons
+        # untimed pass with the kernel classes instrumented: the streaming kernels of the NIFS rounds against the HBM roofline (at 32 x 2^15 every launch
+        # is latency-bound: the numbers say how far a 1 MiB-per-layer launch is from the rate the same kernels reach at config 5's size)
+        c3_names = ("nifs_fold_prove", "nifs_round0_small", "nifs_round0", "nifs_fold", "nifs_cvals", "fold_tables", "eval_cubic_pow", "eval_quad", "bind", "poly_abc", "fixed_base")
+        ctx.reset_stats(True)
+        ctx.stats_filter("")
+        nbp = 3
+        for _ in range(nbp):
+            nn.prove(step_tape)
+        c3_stats = {k_: ctx.kernel_stats(k_) for k_ in c3_names}
+        ctx.reset_stats(False)
         # NeutronNovaZkSNARK::verify on the device-backed driver (outside the timed region): the last proof of the loop
         verify_rc = nn.verify(words)
         tv = time.perf_counter()
@@ -257,6 +267,15 @@ def main():
                               "num_cons_unpadded_per_step": circs[0].num_cons, "num_cons_per_step": 1 << nn.info["nx"],
                               "parallelism": f"{world} independent batches, one per GPU"},
                    "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "verify_ms": verify_ms, "sharded": None, "roofline": None, "cpu_baseline": None}
+            fp = c3_stats["nifs_fold_prove"]
+            if fp[1]:
+                ach = (fp[2] / fp[1]) / (fp[0] / fp[1] * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "kernel": "k_nifs_fold_prove (merged fold + prove rounds of NeutronNovaNIFS::prove: 384 B per k and prove pair, SURVEY 8(d))",
+                                   "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "launches": fp[1] / nbp,
+                                   "avg_launch_us": fp[0] / fp[1] * 1e3, "alg_bytes_per_launch": fp[2] / fp[1],
+                                   "note": "HIP events of an untimed instrumented pass; at 32 instances x 2^15 constraints a launch moves ~12 MB and is latency-bound",
+                                   "other_kernels": {k_: {"launches_per_step": v_[1] / nbp, "avg_us": v_[0] / max(v_[1], 1) * 1e3,
+                                                          "alg_GBps": (v_[2] / max(v_[0], 1e-9)) / 1e6} for k_, v_ in c3_stats.items() if v_[1] and k_ != "nifs_fold_prove"}}
             if world == 1 and not args.no_cpu_baseline:
                 import oracle_lib as ol  # test infrastructure, used here only as the reported CPU baseline and the bit-exactness check
 
@@ -553,7 +572,7 @@ def main():
         # HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024); null if absent
         traffic, traffic_src = None, None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.message_bytes == 2048:
                 with open(pmc) as f:
