@@ -207,7 +207,7 @@ def main():
         raise SystemExit(f"rank {rank}: --gpus {world} needs {world} devices (one process per GPU), this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     numa_cpus = _pin_to_gpu_numa(local_rank)  # before any pinned allocation or helper thread exists
-    group = spd.Group(backend="nccl")  # RCCL: barrier and max-over-ranks of the timed region, and the hand-over of the C++ communicator's id
+    group = spd.Group(backend=spd.RCCL_BACKEND)  # RCCL: barrier and max-over-ranks of the timed region, and the hand-over of the C++ communicator's id
 
     from spartan2_amd import frontend, hip, host
 

@@ -108,6 +108,11 @@ int sp_eq_table_into(sp_ctx* ctx, const uint64_t* r, size_t ell, sp_table* out);
 int sp_transcript_new(sp_ctx* ctx, const uint8_t* label, size_t n, sp_transcript** out);
 int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n);
 int sp_transcript_dom_sep(sp_transcript* t, const uint8_t* bytes, size_t n);
+/* on != 0: absorbs of >= 4 KiB (a commitment's 64 bytes per row: hundreds of Keccak blocks) are hashed on the library's hashing thread while the caller
+ * goes on to its next call; every later use of the transcript joins first, so the sponge sees the reference's byte sequence. For single-threaded
+ * callers that follow src/spartan.rs statement by statement (the commitment of the rest segment and the build of z run beside the hashing); a driver
+ * that already hashes on a thread of its own leaves it off (default). */
+int sp_transcript_set_async(sp_transcript* t, int on);
 int sp_transcript_squeeze(sp_transcript* t, const uint8_t* label, size_t ln, uint64_t out[4]);
 /* absorb(label, bytes) (keccak.rs:96-99) split in two for long inputs that are known early (comm_W is 64 KiB = 480 Keccak blocks, 0.2 ms of a
  * 1.9 ms prove): sp_transcript_preabsorb hashes label || bytes into a sponge state on any thread, without a transcript;
@@ -315,6 +320,22 @@ int sp_sumcheck_quad_sharded_partial(sp_ctx* ctx, uint64_t claim_io[4], size_t r
 /* the same with sp_sumcheck_quad_observed's hook: a sharded HyraxPCS::prove starts its rank's part of comm_LZ as soon as the row challenges exist */
 int sp_sumcheck_quad_sharded_observed(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce,
                                       void* reduce_user, sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
+
+/* sp_sumcheck_cubic3 / sp_sumcheck_cubic3_round0 with an observer (see sp_sumcheck_quad_observed): observe(user, round, r) is called after the challenge of
+ * `round` (0-based) has been handed to the device. p0 / p1 = the round-0 product tables or both NULL. */
+int sp_sumcheck_cubic3_observed(sp_ctx* ctx, const uint64_t claim[4], const uint64_t* taus, size_t ell, sp_table* A, sp_table* B, sp_table* C, const sp_table* p0,
+                                const sp_table* p1, sp_transcript* tr, sp_challenge_hook observe, void* user, uint64_t* out_cpolys, uint64_t* out_r,
+                                uint64_t out_final[12]);
+/* bind_and_prepare_poly_ABC (src/r1cs/mod.rs:1235-1398) split at a challenge boundary: eq(r_x, row) = eq(r_hi, row >> n_lo) * eq(r_lo, row & mask) and the
+ * outer sum-check draws r_x top variable first, so `_begin` — given the first n_hi challenges while the sum-check is still running its last, latency-bound
+ * rounds — weights every matrix entry with its eq_hi factor on the auxiliary stream, and `_finish` (all challenges known, plus the joint challenge r of
+ * src/spartan.rs:311) only streams the weights against the small eq_lo table: same poly_ABC as sp_poly_abc, without the 2^ell-entry evals_rx table or
+ * its random gathers on the critical path. n_hi, n_lo <= 12, n_hi + n_lo = log2(num_cons). The workspace holds 32 bytes per matrix entry. */
+typedef struct sp_polyabc_ws sp_polyabc_ws;
+int sp_poly_abc_ws_create(sp_ctx* ctx, const sp_shape* s, sp_polyabc_ws** out);
+void sp_poly_abc_ws_free(sp_polyabc_ws* w);
+int sp_poly_abc_begin(sp_ctx* ctx, sp_polyabc_ws* w, const uint64_t* r_hi, size_t n_hi);
+int sp_poly_abc_finish(sp_ctx* ctx, sp_polyabc_ws* w, const uint64_t* r_lo, size_t n_lo, const uint64_t r[4], size_t out_len, sp_table* out);
 
 /* ---- NeutronNova batched ZK sum-checks (src/sumcheck.rs:702-917) --------------------------------------------------------------------
  * The reference obtains each round's challenge from the ZK verifier circuit (`SatisfyingAssignment::process_round`, :747-755, :864-872) —

@@ -170,6 +170,7 @@ impl<E: Engine> TranscriptEngineTrait<E> for HipTranscript<E> {
     let mut t = ptr::null_mut();
     let rc = unsafe { sp_transcript_new(ctx(), label.as_ptr(), label.len(), &mut t) };
     assert!(rc == SP_OK);
+    unsafe { sp_transcript_set_async(t, 1) }; // spartan.rs is single-threaded around its transcript: long absorbs hash beside its next calls
     Self { t, _p: PhantomData }
   }
   fn squeeze(&mut self, label: &'static [u8]) -> Result<E::Scalar, SpartanError> {

@@ -4,13 +4,13 @@
 #include <cstring>
 
 #include "group_common.hpp"
-#include "kernels_comb.cuh"
+#include "kernels_comb.hpp"
 
 using sp::fail;
 
 namespace sp {
 
-// ---- fixed-base comb path for many rows over the key (kernels_comb.cuh) ---------------------------------------------------------------------------
+// ---- fixed-base comb path for many rows over the key (kernels_comb.hpp) ---------------------------------------------------------------------------
 // SPARTAN_COMB_BITS = signed window width C (8, 10, 12, 13 or 14; 0 disables the path): the table takes ceil(257 / C) * num_cols * 2^(C-1) * 64 bytes
 // (2048 bases: C = 12: 5.9 GB, C = 13 (default): 10.7 GB, C = 14: 20 GB; measured sweep in profiles/r02_comb_bits_sweep.txt). SPARTAN_COMB_MIN_ROWS = how many digit-path rows one commit must have before the table is built.
 static int comb_bits() {

@@ -9,7 +9,7 @@
 #include <cstring>
 
 #include "core.hpp"
-#include "kernels_poly.cuh"
+#include "kernels_poly.hpp"
 
 namespace sp {
 static thread_local std::string g_err;
@@ -387,7 +387,7 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
 // `resident`: a kernel on the stream is itself waiting for the host's next challenge (the resident tail that produces the result, or a launch issued
 // ahead of its challenge queued behind the producer) — a stream synchronise would not return before that kernel's watchdog, so the host keeps
 // polling (bounded by wall-clock; the kernel gives up after 8 s as well).
-// one self-validating slot (kernels_poly.cuh slot_store_tag): wait for its sequence word, then re-read until the check word matches the data
+// one self-validating slot (kernels_poly.hpp slot_store_tag): wait for its sequence word, then re-read until the check word matches the data
 static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t* v, bool resident, long* spins) {
   volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
   while (*fl != want) {
@@ -517,7 +517,7 @@ static bool round_trace() {
 }
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// ---- persistent tail (kernels_poly.cuh k_sumcheck_tail): host half of the mailbox ------------------------------------------------------
+// ---- persistent tail (kernels_poly.hpp k_sumcheck_tail): host half of the mailbox ------------------------------------------------------
 static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident tail, 2..16 caps the table length it takes over
   static const size_t v = [] {
     const char* e = getenv("SPARTAN_TAIL_LOG2");
@@ -531,7 +531,7 @@ static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident t
 static bool tail_enabled() { return tail_max_len() != 0; }
 // mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 / 10 = two independent
 // check words (sequence + plain sum, sequence * K + position-weighted sum), 11 = the sequence number again, so a poll that straddles the host's
-// stores is recognised and retried (mail_wait in kernels_poly.cuh).
+// stores is recognised and retried (mail_wait in kernels_poly.hpp).
 static void mail_write_line(volatile uint32_t* dst, const fe_t& r, unsigned answers_seq) {
   uint32_t chk = answers_seq, chk2 = answers_seq * spk::SLOT_CHK_K;
   for (int i = 0; i < 8; ++i) {
@@ -815,7 +815,7 @@ static size_t async_absorb_min() {
 int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n) {
   t->join();
   const size_t amin = async_absorb_min();
-  if (amin && n >= amin && !g_hash_taken.exchange(true, std::memory_order_acq_rel)) {
+  if (t->async_absorb && amin && n >= amin && !g_hash_taken.exchange(true, std::memory_order_acq_rel)) {
     t->pend.resize(ln + n);
     memcpy(t->pend.data(), label, ln);
     memcpy(t->pend.data() + ln, bytes, n);
@@ -829,6 +829,12 @@ int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, cons
     return SP_OK;
   }
   t->t.absorb(label, ln, bytes, n);
+  return SP_OK;
+}
+int sp_transcript_set_async(sp_transcript* t, int on) {
+  if (!t) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_transcript_set_async: null transcript");
+  t->join();
+  t->async_absorb = on != 0;
   return SP_OK;
 }
 int sp_transcript_preabsorb(const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n, sp_absorb_state** out) {
@@ -866,6 +872,7 @@ int sp_transcript_clone(const sp_transcript* t, sp_transcript** out) {
   t->join();
   sp_transcript* n = new sp_transcript();
   n->t = t->t;
+  n->async_absorb = t->async_absorb;
   *out = n;
   return SP_OK;
 }
@@ -1470,7 +1477,7 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
 
 static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                       const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
-                      uint64_t* out_r, uint64_t out_final[12], size_t run_rounds = 0);
+                      uint64_t* out_r, uint64_t out_final[12], size_t run_rounds = 0, sp_challenge_hook observe = nullptr, void* observe_user = nullptr);
 int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                        uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
   uint64_t claim_io[4], p_io[4];
@@ -1488,6 +1495,20 @@ int sp_sumcheck_cubic3_round0(sp_ctx* c, const uint64_t claim_[4], const uint64_
   const fe_t one = fe_one<S>();
   store_fe(p_io, one);
   return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, p0, p1, out_cpolys, out_r, out_final);
+}
+// the same with an observer called after every challenge has been handed to the device (as sp_sumcheck_quad_observed): lets the caller start work that
+// needs only the first challenges — sp_poly_abc_begin — under the remaining rounds. p0 / p1 may be NULL (plain first evaluation).
+int sp_sumcheck_cubic3_observed(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, const sp_table* p0,
+                                const sp_table* p1, sp_transcript* tr, sp_challenge_hook observe, void* user, uint64_t* out_cpolys, uint64_t* out_r,
+                                uint64_t out_final[12]) {
+  if ((p0 == nullptr) != (p1 == nullptr)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (observed): both product tables or neither");
+  if (p0 && (ell == 0 || p0->len != ((size_t)1 << ell) / 2 || p1->len != p0->len))
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (round-0 products): product tables must have 2^(ell-1) elements");
+  uint64_t claim_io[4], p_io[4];
+  memcpy(claim_io, claim_, 32);
+  const fe_t one = fe_one<S>();
+  store_fe(p_io, one);
+  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, p0, p1, out_cpolys, out_r, out_final, 0, observe, user);
 }
 
 // The same rounds on a SLICE of the tables (tables sharded on their last k variables, rank g holds Z[(j << k) | g]): the slice's
@@ -1508,7 +1529,7 @@ int sp_sumcheck_cubic3_sharded_partial(sp_ctx* c, uint64_t claim_io[4], uint64_t
 }
 static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                       const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
-                      uint64_t* out_r, uint64_t out_final[12], size_t run_rounds) {
+                      uint64_t* out_r, uint64_t out_final[12], size_t run_rounds, sp_challenge_hook observe, void* observe_user) {
   // run_rounds (0 = all): see quad_impl - stop after that many of the ell rounds, tables left at 2^(ell - run_rounds) elements
   tr->join();
   if (run_rounds > ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: more rounds to run than variables");
@@ -1843,6 +1864,11 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       if (issued < 0) return issued;
     }
     guard.armed = in_tail && rnd < ell;  // the resident kernel now waits for the next challenge
+    if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
+      uint64_t rw[4];
+      store_fe(rw, r_i);
+      observe(observe_user, ri, rw);
+    }
     // bound (:1399-1405): p *= 1 - tau - r + 2 r tau
     eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
     if (round_trace())

@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "core.hpp"
-#include "kernels_msm.cuh"
+#include "kernels_msm.hpp"
 
 using sp::fail;
 typedef FqP S;
@@ -126,7 +126,7 @@ int msm_device(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, size_t n, i
   return msm_finish(c, &pend, result);
 }
 
-// Digit-path MSMs of many rows over one base vector (kernels_msm.cuh "batched row MSMs"): rows `sel` of the row-major canonical scalar
+// Digit-path MSMs of many rows over one base vector (kernels_msm.hpp "batched row MSMs"): rows `sel` of the row-major canonical scalar
 // array `canon` (cols per row, n scalars in all), `windows` = 33 (full scalars, signs folded) or 9 (values < 2^64). Results -> out[sel[i]].
 int msm_rows_batched(sp_ctx* c, const fe_t* canon, size_t cols, size_t n, const std::vector<unsigned>& sel, int windows, const aff_t* d_bases,
                      std::vector<jac_t>& out) {
@@ -391,7 +391,7 @@ int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, 
 
 static bool fb_mapped_enabled();
 static int fb_mapped_ensure(sp_ctx* c, int lane);
-// 16-bit window tables of the latency paths (kernels_msm.cuh k_fixed_base_tables16), found by the address of the 8-bit table set they shadow.
+// 16-bit window tables of the latency paths (kernels_msm.hpp k_fixed_base_tables16), found by the address of the 8-bit table set they shadow.
 // SPARTAN_FB_WINDOW16=0: not built.
 static std::mutex g_t16_mu;
 static std::map<const aff_t*, const aff_t*> g_t16;
@@ -505,7 +505,7 @@ static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, con
 static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU core beats the launch + single-wave latency
 
 // table[i % ntables] * scalars[i] on the device (Jacobian results in host memory); ntables == 1 for h
-// <= 128 scalars through mapped memory (kernels_msm.cuh k_fixed_base_rows_coop_mapped): launch on lane 0 = the main stream / lane 1 = the auxiliary stream,
+// <= 128 scalars through mapped memory (kernels_msm.hpp k_fixed_base_rows_coop_mapped): launch on lane 0 = the main stream / lane 1 = the auxiliary stream,
 // then poll the n self-validating result slots. SPARTAN_FB_MAPPED=0 keeps the copy / launch / copy / synchronise form.
 static const size_t FB_MAPPED_MAX = 128, FB_SLOT_BYTES = 4 * spk::FB_SLOT_WORDS;
 static bool fb_mapped_enabled() {
@@ -1198,7 +1198,7 @@ void sp_fbtables_free(sp_fbtables* t) {
 }
 }  // extern "C"
 namespace sp {
-// sum_i scalars[i] * point_i in ONE launch (kernels_msm.cuh k_multi_mul_coop): scalars and result through mapped pinned pages, no copies, no host-side
+// sum_i scalars[i] * point_i in ONE launch (kernels_msm.hpp k_multi_mul_coop): scalars and result through mapped pinned pages, no copies, no host-side
 // tail. Two lanes per context, each with its own pages / ticket / sequence number: lane 1 on the auxiliary stream (callable from a helper thread
 // beside the owner's calls on the main stream, like sp_msm_eq_begin), lane 0 on the main stream. The caller polls the self-validating result slot;
 // a poll that runs long (profiler, debugger) falls back to a stream synchronise, after which the slot must be valid.

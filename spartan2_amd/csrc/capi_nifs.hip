@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "core.hpp"
-#include "kernels_nifs.cuh"
+#include "kernels_nifs.hpp"
 
 using sp::fail;
 typedef FqP SF;

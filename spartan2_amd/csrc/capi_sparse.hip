@@ -11,7 +11,7 @@
 #include <vector>
 
 #include "core.hpp"
-#include "device_utils.cuh"
+#include "device_utils.hpp"
 
 using sp::fail;
 typedef FqP S;
@@ -170,6 +170,125 @@ __global__ void __launch_bounds__(256) k_polyabc_long_final(PolyAbcArgs a, const
   if (threadIdx.x == 0) out[col] = fe_add<S>(fe_add<S>(acc[0], fe_mul<S>(a.r, acc[1])), fe_mul<S>(a.r2, acc[2]));
 }
 
+// ---- poly_ABC split at a challenge boundary (round 3) -----------------------------------------------------------------------------------------
+// poly_ABC[col] = sum_row M[row, col] eq(r_x, row) and eq(r_x, row) = eq_hi[row >> n_lo] * eq_lo[row & mask]: the outer sum-check draws r_x top variable
+// first, so eq_hi is known n_lo rounds before the sum-check ends. k_polyabc_weights then turns every matrix entry into w = coeff * eq_hi[row >> n_lo]
+// (a gather from a table of <= 2^12 entries: cache-resident; 32 bytes written per entry, in the column-major entry order) under the remaining,
+// latency-bound rounds, and after the last challenge k_polyabc_weighted_* only has to stream the weights and multiply by eq_lo (<= 2^10 entries):
+// no 32 MB evals_rx table, no random gathers from it on the critical path.
+struct EqSmallArgs {
+  fe_t v[12];
+  int m;
+  fe_t* out;  // pyramid: the table of all m variables at out + 2^m - 1
+};
+__global__ void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
+  if (threadIdx.x == 0) a.out[0] = fe_one<S>();
+  __syncthreads();
+  for (int k = 0; k < a.m; ++k) {
+    const fe_t r = a.v[a.m - 1 - k];
+    const size_t size = (size_t)1 << k;
+    const fe_t* prev = a.out + (size - 1);
+    fe_t* next = a.out + (2 * size - 1);
+    for (size_t i = threadIdx.x; i < size; i += blockDim.x) {
+      const fe_t e = prev[i], y = fe_mul<S>(e, r);
+      next[size + i] = y;
+      next[i] = fe_sub<S>(e, y);
+    }
+    __syncthreads();
+  }
+}
+// Sliced-ELL copy of the SHORT columns for the split form: the columns of a wave (64 consecutive entries of `order`, i.e. columns of nearly equal
+// length) store their j-th entries side by side — slot = off[wave] + 64 j + lane — so that every load of the final pass is coalesced: 256 bytes of packed
+// (row | matrix << 28 | valid << 31) words and 2 KiB of weights per wave and step. `src` tells the weights pass where an entry's coefficient lives
+// (k | general << 29 | matrix << 30 into the column-major arrays).
+struct EllDev {
+  const uint4* meta;  // per wave: first slot, steps of A, of B, of C (a wave's columns are sorted to have the same per-matrix entry counts, so the
+                      // three segments need next to no padding and the final pass has no per-entry matrix selector)
+  const unsigned* row;
+  const unsigned* src;
+  size_t slots;
+};
+struct EllCoeff {
+  const signed char* scode[3];
+  const fe_t* gval[3];
+};
+__global__ void __launch_bounds__(256) k_polyabc_ell_weights(EllDev e, EllCoeff co, const fe_t* __restrict__ eq_hi, int n_lo, fe_t* __restrict__ w) {
+  for (size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x; slot < e.slots; slot += (size_t)gridDim.x * blockDim.x) {
+    const unsigned packed = e.row[slot];
+    if (!(packed >> 31)) continue;
+    const unsigned src = e.src[slot], k = src & 0x1fffffffu;
+    const int m = (int)(src >> 30);
+    const fe_t h = eq_hi[(packed & 0x0fffffffu) >> n_lo];
+    fe_t v;
+    if (src & 0x20000000u) {
+      v = fe_mul<S>(co.gval[m][k], h);
+    } else {
+      const int code = co.scode[m][k];
+      v = small_mul(code, h);
+      if (code < 0) v = fe_neg<S>(v);
+    }
+    w[slot] = v;
+  }
+}
+__global__ void __launch_bounds__(256) k_polyabc_ell_final(EllDev e, const fe_t* __restrict__ w, const fe_t* __restrict__ eq_lo, unsigned mask, const unsigned* __restrict__ order,
+                                                           size_t n_short, fe_t r, fe_t r2, fe_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t wave = i >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  if (wave * 64 >= n_short) return;
+  const uint4 mt = e.meta[wave];
+  // sum of weight * eq_lo over `steps` slots starting at `base` (this lane's column of the segment), four loads in flight
+  auto segment = [&](size_t base, unsigned steps) {
+    fe_t acc = fe_zero(), acc2 = fe_zero();
+    unsigned j = 0;
+    for (; j + 2 <= steps; j += 2) {
+      const size_t s0 = base + 64 * (size_t)j, s1 = s0 + 64;
+      const unsigned p0 = e.row[s0], p1 = e.row[s1];
+      const fe_t w0 = w[s0], w1 = w[s1];
+      if (p0 >> 31) acc = fe_add<S>(acc, fe_mul<S>(w0, eq_lo[p0 & mask]));
+      if (p1 >> 31) acc2 = fe_add<S>(acc2, fe_mul<S>(w1, eq_lo[p1 & mask]));
+    }
+    if (j < steps) {
+      const size_t s0 = base + 64 * (size_t)j;
+      const unsigned p0 = e.row[s0];
+      if (p0 >> 31) acc = fe_add<S>(acc, fe_mul<S>(w[s0], eq_lo[p0 & mask]));
+    }
+    return fe_add<S>(acc, acc2);
+  };
+  const size_t base = (size_t)mt.x + lane;
+  const fe_t sa = segment(base, mt.y), sb = segment(base + 64 * (size_t)mt.y, mt.z), sc = segment(base + 64 * ((size_t)mt.y + mt.z), mt.w);
+  if (i < n_short) out[order[i]] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(r, sb)), fe_mul<S>(r2, sc));
+}
+// long columns of the split form: no stored weights, the eq factor of an entry is the product of the two small tables
+__device__ __forceinline__ fe_t gather_twotable(const SplitDev& m, size_t major, const fe_t* __restrict__ eq_hi, const fe_t* __restrict__ eq_lo, int n_lo, unsigned mask,
+                                                unsigned first, unsigned step) {
+  fe_t acc = fe_zero();
+  for (unsigned k = m.sptr[major] + first, e = m.sptr[major + 1]; k < e; k += step) {
+    const unsigned idx = m.sidx[k];
+    acc = acc_small(acc, m.scode[k], fe_mul<S>(eq_hi[idx >> n_lo], eq_lo[idx & mask]));
+  }
+  for (unsigned k = m.gptr[major] + first, e = m.gptr[major + 1]; k < e; k += step) {
+    const unsigned idx = m.gidx[k];
+    acc = fe_add<S>(acc, fe_mul<S>(m.gval[k], fe_mul<S>(eq_hi[idx >> n_lo], eq_lo[idx & mask])));
+  }
+  return acc;
+}
+__global__ void __launch_bounds__(256) k_polyabc_long_twotable(PolyAbcArgs a, const fe_t* __restrict__ eq_hi, const fe_t* __restrict__ eq_lo, int n_lo, unsigned mask,
+                                                               const unsigned* __restrict__ long_cols, fe_t* __restrict__ partials) {
+  __shared__ fe_t smem[3 * 4];
+  const size_t col = long_cols[blockIdx.y];
+  const unsigned nb = long_nb(col_len(a, col));
+  if (blockIdx.x >= nb) return;
+  fe_t acc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) acc[i] = gather_twotable(a.m[i], col, eq_hi, eq_lo, n_lo, mask, blockIdx.x * blockDim.x + threadIdx.x, nb * blockDim.x);
+  block_sum<3>(acc, smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) partials[((size_t)blockIdx.y * LONG_NB_MAX + blockIdx.x) * 3 + i] = acc[i];
+  }
+}
+
 }  // namespace spk
 
 // ---- host side: classification and upload ---------------------------------------------------------------------------
@@ -279,6 +398,10 @@ struct sp_shape {
   fe_t* d_long_partials = nullptr;
   size_t n_long_cols = 0;
   uint64_t nnz[3] = {0, 0, 0}, nnz_filtered[3] = {0, 0, 0};
+  // sliced-ELL copy of the short columns (kernels above: EllDev)
+  uint4* d_ell_meta = nullptr;
+  unsigned *d_ell_row = nullptr, *d_ell_src = nullptr;
+  size_t ell_slots = 0;
 };
 
 extern "C" {
@@ -293,6 +416,7 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
   const sp_csr* M[3] = {A, Bm, C};
   Classifier cls;
   std::vector<unsigned> col_count(s->num_cols, 0);
+  std::vector<SplitHost> col_host(3);
   for (int m = 0; m < 3; ++m) {
     const size_t nnz = M[m]->indptr[nrows];
     s->nnz[m] = nnz;
@@ -332,8 +456,9 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     }
     for (size_t i = 0; i < s->num_cols; ++i) col_count[i] += cptr[i + 1] - cptr[i];
     int rc;
+    col_host[m] = build_split(s->num_cols, bycol);
     if ((rc = upload_split(build_split(nrows, all), &s->row[m])) || (rc = upload_split(build_split(nrows, filt), &s->filtered[m])) ||
-        (rc = upload_split(build_split(s->num_cols, bycol), &s->col[m]))) {
+        (rc = upload_split(col_host[m], &s->col[m]))) {
       delete s;
       return rc;
     }
@@ -356,8 +481,17 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
       const char* e = getenv("SPARTAN_POLYABC_WINDOW");
       return e ? (size_t)atol(e) : (size_t)0;  // measured (tools/r03_polyabc_window.sh): windows of 1 K - 128 K columns with heaviest-first chunks 115 - 120 us, one global sort 116 - 122 us: locality is not what bounds the kernel
     }();
+    // (within one total the columns are grouped by their (A, B, C) entry counts: the lanes of a wave then run the same trip counts in each of the
+    // three matrices — no divergence in the one-pass kernel, no padding in the sliced-ELL copy below)
+    auto len_of = [&](int m, unsigned col) { return (col_host[m].sptr[col + 1] - col_host[m].sptr[col]) + (col_host[m].gptr[col + 1] - col_host[m].gptr[col]); };
+    auto by_len = [&](unsigned x, unsigned y) {
+      if (col_count[x] != col_count[y]) return col_count[x] > col_count[y];
+      const unsigned ax = len_of(0, x), ay = len_of(0, y);
+      if (ax != ay) return ax > ay;
+      return len_of(1, x) > len_of(1, y);
+    };
     if (window == 0) {
-      std::stable_sort(order.begin(), order.end(), [&](unsigned x, unsigned y) { return col_count[x] > col_count[y]; });
+      std::stable_sort(order.begin(), order.end(), by_len);
     } else {
       for (size_t lo = 0; lo < order.size(); lo += window) {
         const size_t hi = lo + window < order.size() ? lo + window : order.size();
@@ -379,6 +513,45 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     }
     s->n_short = order.size();
     if ((rc = upload(&s->d_short_order, order))) return rc;
+    // sliced-ELL copy of the short columns in this order (the split poly_ABC): per wave three segments (A, B, C), each as long as the wave's longest
+    // column in that matrix
+    const size_t waves = (order.size() + 63) / 64;
+    std::vector<uint4> meta(waves ? waves : 1);
+    auto len_m = [&](int m, unsigned col) { return (col_host[m].sptr[col + 1] - col_host[m].sptr[col]) + (col_host[m].gptr[col + 1] - col_host[m].gptr[col]); };
+    size_t slots = 0;
+    for (size_t w = 0; w < waves; ++w) {
+      unsigned L[3] = {0, 0, 0};
+      for (size_t i = 64 * w; i < order.size() && i < 64 * (w + 1); ++i)
+        for (int m = 0; m < 3; ++m) L[m] = std::max(L[m], len_m(m, order[i]));
+      meta[w] = make_uint4((unsigned)slots, L[0], L[1], L[2]);
+      slots += 64 * ((size_t)L[0] + L[1] + L[2]);
+    }
+    if (slots >= ((size_t)1 << 31) || nrows > ((size_t)1 << 28)) {
+      s->ell_slots = 0;  // (out of the packed format's range: the split form is then not offered for this shape)
+    } else {
+      std::vector<unsigned> erow(slots ? slots : 1, 0u), esrc(slots ? slots : 1, 0u);
+      for (size_t i = 0; i < order.size(); ++i) {
+        const size_t w = i / 64, lane = i % 64, col = order[i];
+        size_t seg = meta[w].x;
+        for (int m = 0; m < 3; ++m) {
+          const SplitHost& h = col_host[m];
+          unsigned j = 0;
+          for (unsigned k = h.sptr[col]; k < h.sptr[col + 1]; ++k, ++j) {
+            const size_t slot = seg + 64 * (size_t)j + lane;
+            erow[slot] = h.sidx[k] | ((unsigned)m << 28) | 0x80000000u;
+            esrc[slot] = k | ((unsigned)m << 30);
+          }
+          for (unsigned k = h.gptr[col]; k < h.gptr[col + 1]; ++k, ++j) {
+            const size_t slot = seg + 64 * (size_t)j + lane;
+            erow[slot] = h.gidx[k] | ((unsigned)m << 28) | 0x80000000u;
+            esrc[slot] = k | 0x20000000u | ((unsigned)m << 30);
+          }
+          seg += 64 * (size_t)(m == 0 ? meta[w].y : m == 1 ? meta[w].z : meta[w].w);
+        }
+      }
+      s->ell_slots = slots;
+      if ((rc = upload(&s->d_ell_meta, meta)) || (rc = upload(&s->d_ell_row, erow)) || (rc = upload(&s->d_ell_src, esrc))) return rc;
+    }
   }
   SP_HIP(hipMalloc((void**)&s->d_long_partials, (long_cols.size() + 1) * spk::LONG_NB_MAX * 3 * sizeof(fe_t)));
   *out = s;
@@ -394,6 +567,9 @@ void sp_shape_free(sp_shape* s) {
   hipFree(s->d_long_cols);
   hipFree(s->d_short_order);
   hipFree(s->d_long_partials);
+  if (s->d_ell_meta) hipFree(s->d_ell_meta);
+  if (s->d_ell_row) hipFree(s->d_ell_row);
+  if (s->d_ell_src) hipFree(s->d_ell_src);
   delete s;
 }
 
@@ -486,6 +662,108 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
                          s->d_long_partials);
       hipLaunchKernelGGL(spk::k_polyabc_long_final, dim3((unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, s->d_long_cols, s->d_long_partials,
                          out->d);
+    }
+  });
+  return SP_OK;
+}
+
+// ---- bind_and_prepare_poly_ABC split at a challenge boundary (see k_polyabc_ell_weights) --------------------------------------------------------
+struct sp_polyabc_ws {
+  const sp_shape* s = nullptr;
+  fe_t* w = nullptr;                        // one weight per ELL slot
+  fe_t *eq_hi = nullptr, *eq_lo = nullptr;  // pyramids
+  hipEvent_t ready = nullptr;
+  size_t n_hi = 0;
+  bool begun = false;
+};
+int sp_poly_abc_ws_create(sp_ctx* c, const sp_shape* s, sp_polyabc_ws** out) {
+  if (!c || !s || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_poly_abc_ws_create: null argument");
+  if (s->n_short && !s->ell_slots) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_poly_abc_ws_create: the shape is outside the packed entry format (2^28 rows, 2^31 slots)");
+  sp_polyabc_ws* w = new sp_polyabc_ws();
+  w->s = s;
+  auto bail = [&](const char* what, hipError_t e) {
+    sp_poly_abc_ws_free(w);
+    return fail(SP_ERR_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+  };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&w->w, (s->ell_slots + 1) * sizeof(fe_t))) != hipSuccess) return bail("weights", e);
+  if ((e = hipMalloc((void**)&w->eq_hi, ((size_t)2 << 12) * sizeof(fe_t))) != hipSuccess) return bail("eq_hi", e);
+  if ((e = hipMalloc((void**)&w->eq_lo, ((size_t)2 << 12) * sizeof(fe_t))) != hipSuccess) return bail("eq_lo", e);
+  if ((e = hipEventCreateWithFlags(&w->ready, hipEventDisableTiming)) != hipSuccess) return bail("event", e);
+  *out = w;
+  return SP_OK;
+}
+void sp_poly_abc_ws_free(sp_polyabc_ws* w) {
+  if (!w) return;
+  if (w->w) hipFree(w->w);
+  if (w->eq_hi) hipFree(w->eq_hi);
+  if (w->eq_lo) hipFree(w->eq_lo);
+  if (w->ready) hipEventDestroy(w->ready);
+  delete w;
+}
+static spk::EllDev ell_view(const sp_shape* s) { return spk::EllDev{s->d_ell_meta, s->d_ell_row, s->d_ell_src, s->ell_slots}; }
+// r_hi = the first n_hi challenges of the outer sum-check (top variables of the row index). Issued on the auxiliary stream; returns at once.
+int sp_poly_abc_begin(sp_ctx* c, sp_polyabc_ws* w, const uint64_t* r_hi, size_t n_hi) {
+  if (!c || !w || (!r_hi && n_hi)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_poly_abc_begin: null argument");
+  const sp_shape* s = w->s;
+  size_t ell = 0;
+  while (((size_t)1 << ell) < s->dims.num_cons) ++ell;
+  if (n_hi > 12 || n_hi > ell || ell - n_hi > 12) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_poly_abc_begin: both halves of the row index must have at most 12 bits");
+  spk::EqSmallArgs ea;
+  for (size_t i = 0; i < n_hi; ++i) memcpy(&ea.v[i], r_hi + 4 * i, 32);
+  ea.m = (int)n_hi;
+  ea.out = w->eq_hi;
+  hipLaunchKernelGGL(spk::k_eq_small, dim3(1), dim3(1024), 0, c->stream2, ea);
+  if (s->ell_slots) {
+    spk::EllCoeff co;
+    for (int m = 0; m < 3; ++m) {
+      co.scode[m] = s->col[m].scode;
+      co.gval[m] = s->col[m].gval;
+    }
+    size_t blocks = (s->ell_slots + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    c->timed_on(c->stream2, "poly_abc_weights", 40ull * s->ell_slots, [&] {
+      hipLaunchKernelGGL(spk::k_polyabc_ell_weights, dim3((unsigned)blocks), dim3(256), 0, c->stream2, ell_view(s), co, w->eq_hi + (((size_t)1 << n_hi) - 1), (int)(ell - n_hi), w->w);
+    });
+  }
+  SP_HIP(hipEventRecord(w->ready, c->stream2));
+  w->n_hi = n_hi;
+  w->begun = true;
+  return SP_OK;
+}
+// r_lo = the remaining challenges; r = the joint challenge of src/spartan.rs:311. On the main stream, behind the weights.
+int sp_poly_abc_finish(sp_ctx* c, sp_polyabc_ws* w, const uint64_t* r_lo, size_t n_lo, const uint64_t r_[4], size_t out_len, sp_table* out) {
+  if (!c || !w || (!r_lo && n_lo) || !r_ || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_poly_abc_finish: null argument");
+  if (!w->begun) return fail(SP_ERR_INTERNAL, "sp_poly_abc_finish: sp_poly_abc_begin has not run");
+  w->begun = false;
+  const sp_shape* s = w->s;
+  size_t ell = 0;
+  while (((size_t)1 << ell) < s->dims.num_cons) ++ell;
+  if (w->n_hi + n_lo != ell || n_lo > 12) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_poly_abc_finish: the two challenge lists must cover the row variables");
+  if (out_len < s->num_cols || out->cap < out_len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "poly_ABC: output too short");
+  spk::EqSmallArgs ea;
+  for (size_t i = 0; i < n_lo; ++i) memcpy(&ea.v[i], r_lo + 4 * i, 32);
+  ea.m = (int)n_lo;
+  ea.out = w->eq_lo;
+  hipLaunchKernelGGL(spk::k_eq_small, dim3(1), dim3(1024), 0, c->stream, ea);
+  SP_HIP(hipStreamWaitEvent(c->stream, w->ready, 0));
+  spk::PolyAbcArgs a;
+  for (int m = 0; m < 3; ++m) a.m[m] = s->col[m].view();
+  memcpy(&a.r, r_, 32);
+  a.r2 = fe_mul<S>(a.r, a.r);
+  if (out_len > s->num_cols) SP_HIP(hipMemsetAsync(out->d + s->num_cols, 0, (out_len - s->num_cols) * sizeof(fe_t), c->stream));
+  const fe_t* eq_lo = w->eq_lo + (((size_t)1 << n_lo) - 1);
+  const fe_t* eq_hi = w->eq_hi + (((size_t)1 << w->n_hi) - 1);
+  const unsigned mask = (unsigned)(((size_t)1 << n_lo) - 1);
+  const uint64_t bytes = 36ull * (s->nnz[0] + s->nnz[1] + s->nnz[2]) + 32ull * out_len;
+  c->timed("poly_abc_final", bytes, [&] {
+    if (s->n_short)
+      hipLaunchKernelGGL(spk::k_polyabc_ell_final, dim3((unsigned)((s->n_short + 255) / 256)), dim3(256), 0, c->stream, ell_view(s), w->w, eq_lo, mask, s->d_short_order, s->n_short,
+                         a.r, a.r2, out->d);
+    if (s->n_long_cols) {
+      hipLaunchKernelGGL(spk::k_polyabc_long_twotable, dim3(spk::LONG_NB_MAX, (unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, eq_hi, eq_lo, (int)n_lo, mask, s->d_long_cols,
+                         s->d_long_partials);
+      hipLaunchKernelGGL(spk::k_polyabc_long_final, dim3((unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, s->d_long_cols, s->d_long_partials, out->d);
     }
   });
   return SP_OK;

@@ -14,8 +14,8 @@
 #include <vector>
 
 #include "../../include/spartan_hip.h"
-#include "field.cuh"
-#include "keccak.cuh"
+#include "field.hpp"
+#include "keccak.hpp"
 
 namespace sp {
 
@@ -98,7 +98,7 @@ struct sp_ctx {
   size_t scratch_elems = 0;
   fe_t* h_pinned = nullptr;  // small result buffer, pinned + mapped
   fe_t* d_pinned = nullptr;  // device-side address of h_pinned
-  // challenge mailbox (kernels_poly.cuh mail_wait): in fine-grained device memory written through the PCIe BAR when the system has a large BAR
+  // challenge mailbox (kernels_poly.hpp mail_wait): in fine-grained device memory written through the PCIe BAR when the system has a large BAR
   // (mail_dev), otherwise inside h_pinned. h_mail / d_mail = host-side / device-side address of line 0 of the ring (MAIL_RING lines of 64 bytes, line = seq & 7).
   volatile uint32_t* h_mail = nullptr;
   const unsigned* d_mail = nullptr;
@@ -108,7 +108,7 @@ struct sp_ctx {
   bool mail_dev = false;
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs
   void* h_pinned_fbs = nullptr;  // pinned staging of the synchronous fixed-base calls (<= 1024 scalars: the per-round commitments of the ZK verifier circuit)
-  // one-launch FixedBaseMul::multi_mul (sp_fbtables_multi_mul, kernels_msm.cuh k_multi_mul_coop): mapped pinned pages (result slot at byte 0, scalars
+  // one-launch FixedBaseMul::multi_mul (sp_fbtables_multi_mul, kernels_msm.hpp k_multi_mul_coop): mapped pinned pages (result slot at byte 0, scalars
   // at byte 256), their device-side address, device scratch (ticket + block sums) and the sequence number of the result in flight
   // mapped pages of the <= 128-scalar fixed-base calls (k_fixed_base_rows_coop_mapped): [0] the synchronous calls on the main stream, [1] the job on the
   // auxiliary stream; each = 128 result slots of 128 B, then 128 scalars
@@ -129,8 +129,8 @@ struct sp_ctx {
   void* h_stage = nullptr;  // pinned staging of sp_table_write_async: STAGE_SLOTS x 64 KiB, reused round-robin behind an event per slot
   hipEvent_t stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   unsigned stage_next = 0;
-  unsigned pending_slots = 0;  // > 0: the launch in flight delivers per-block sums in that many host slots (kernels_poly.cuh emit_partials)
-  unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.cuh publish_result)
+  unsigned pending_slots = 0;  // > 0: the launch in flight delivers per-block sums in that many host slots (kernels_poly.hpp emit_partials)
+  unsigned result_seq = 0;  // sequence number of the round result currently in flight (see kernels_poly.hpp publish_result)
   unsigned long long msm_jobs_issued[2] = {0, 0};
   hipEvent_t msm_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // completion event of the MSM job in each landing slot
   hipStream_t stream3 = nullptr;     // second auxiliary stream (sp_rowmat_vec_eq_begin), created on first use
@@ -227,6 +227,7 @@ struct sp_transcript {
   std::vector<uint8_t> pend;
   size_t pend_label = 0;
   std::atomic<int> busy{0};
+  bool async_absorb = false;  // sp_transcript_set_async: a single-threaded caller opts in; a driver that already hashes on a thread of its own does not
   sp_transcript() = default;
   sp_transcript(const sp_transcript&) = delete;
   sp_transcript& operator=(const sp_transcript&) = delete;

@@ -5,7 +5,7 @@
 // Replaces CurveExt::{add_mixed_vartime, double, +} and Curve::batch_normalize as used by src/provider/msm.rs:24-57,
 // :150-175 and src/provider/traits.rs:194-198.
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 typedef FpP B;  // base field
 

@@ -1,6 +1,6 @@
 // Cross-lane / block reduction helpers for 256-bit field elements (wave64, gfx950).
 #pragma once
-#include "field.cuh"
+#include "field.hpp"
 
 namespace spk {
 

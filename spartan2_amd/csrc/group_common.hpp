@@ -4,7 +4,7 @@
 #include <vector>
 
 #include "core.hpp"
-#include "curve.cuh"
+#include "curve.hpp"
 
 struct sp_ck {
   sp_ctx* ctx = nullptr;
@@ -18,7 +18,7 @@ struct sp_ck {
   size_t n_tables = 0;
   const aff_t* host_table(size_t t) const { return h_tables.data() + t * 32 * 255; }
   const aff_t* host_htable() const { return host_table(n_tables - 1); }
-  // fixed-base comb table of the whole key (kernels_msm.cuh k_comb_*), built on first use by a commitment of many non-small rows
+  // fixed-base comb table of the whole key (kernels_msm.hpp k_comb_*), built on first use by a commitment of many non-small rows
   mutable aff_t* d_comb = nullptr;
   mutable int comb_c = 0, comb_windows = 0;
   mutable bool comb_failed = false;

@@ -5,7 +5,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "field.cuh"
+#include "field.hpp"
 
 namespace sp {
 

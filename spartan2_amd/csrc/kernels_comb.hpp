@@ -2,7 +2,7 @@
 // THROUGHPUT kernels and want the default scheduler (141 VGPRs, 3 waves per SIMD); capi_group.hip is built for ILP at low occupancy (-amdgpu-sched-strategy=
 // max-ilp: the same kernel takes 313 registers there and runs one wave per SIMD).
 #pragma once
-#include "curve.cuh"
+#include "curve.hpp"
 
 namespace spk {
 

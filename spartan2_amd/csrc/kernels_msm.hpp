@@ -11,8 +11,8 @@
 // of the library (capi_group.hip) — one CPU core is ~20x faster than one GPU lane at a dependent chain.
 // Results are group elements; parity is on canonical affine coordinates, so summation order is free.
 #pragma once
-#include "curve.cuh"
-#include "device_utils.cuh"
+#include "curve.hpp"
+#include "device_utils.hpp"
 
 namespace spk {
 

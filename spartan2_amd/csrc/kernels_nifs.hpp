@@ -8,7 +8,7 @@
 // 2^ceil(ell/2) >= 256 from 2^15 constraints up) the block sum is multiplied by f[i] and by the pair's rho weight ONCE (FACTORED); tiny test
 // sizes take the per-element form.
 #pragma once
-#include "device_utils.cuh"
+#include "device_utils.hpp"
 
 namespace spk {
 

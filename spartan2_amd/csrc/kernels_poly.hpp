@@ -8,7 +8,7 @@
 // anywhere. Tables are arrays of 32-byte elements; lane l touches element base+l, so a wave reads/writes
 // 2 KiB contiguous per table access (two dwordx4 per lane).
 #pragma once
-#include "device_utils.cuh"
+#include "device_utils.hpp"
 
 namespace spk {
 

@@ -10,6 +10,11 @@ import os
 import torch
 
 
+# PyTorch-on-ROCm keeps its upstream spellings: the RCCL backend is registered as "nccl" and HIP devices are device type "cuda". Nothing CUDA is involved.
+RCCL_BACKEND = "nccl"
+HIP_DEVICE_TYPE = "cuda"
+
+
 def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -29,9 +34,9 @@ class Group:
         if self.world > 1:
             import torch.distributed as dist
 
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = backend or (RCCL_BACKEND if torch.cuda.is_available() else "gloo")
             kw = {}
-            if backend == "nccl":
+            if backend == RCCL_BACKEND:
                 kw["device_id"] = torch.device("cuda", self.local_rank)
             dist.init_process_group(backend=backend, **kw)
             self.dist = dist
@@ -45,7 +50,7 @@ class Group:
     def max_over_ranks(self, x: float) -> float:
         if self.dist is None:
             return float(x)
-        dev = "cuda" if (torch.cuda.is_available() and self.dist.get_backend() == "nccl") else "cpu"
+        dev = HIP_DEVICE_TYPE if (torch.cuda.is_available() and self.dist.get_backend() == RCCL_BACKEND) else "cpu"
         t = torch.tensor([x], dtype=torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
@@ -53,7 +58,7 @@ class Group:
     def sum_over_ranks(self, x: float) -> float:
         if self.dist is None:
             return float(x)
-        dev = "cuda" if (torch.cuda.is_available() and self.dist.get_backend() == "nccl") else "cpu"
+        dev = HIP_DEVICE_TYPE if (torch.cuda.is_available() and self.dist.get_backend() == RCCL_BACKEND) else "cpu"
         t = torch.tensor([x], dtype=torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
@@ -79,7 +84,7 @@ def _all_gather_rows(group: Group, local: np.ndarray, counts):
         return local
     width = local.shape[1]
     mx = max(counts) if counts else 0
-    dev = "cuda" if (torch.cuda.is_available() and group.dist.get_backend() == "nccl") else "cpu"
+    dev = HIP_DEVICE_TYPE if (torch.cuda.is_available() and group.dist.get_backend() == RCCL_BACKEND) else "cpu"
     buf = torch.zeros((mx, width), dtype=torch.int64, device=dev)
     if local.shape[0]:
         buf[: local.shape[0]] = torch.from_numpy(local.view(np.int64).copy()).to(dev)

@@ -330,8 +330,8 @@ class Comm:
                 import torch.distributed as dist
 
                 t = torch.from_numpy(uid)
-                if dist.get_backend() == "nccl":
-                    t = t.cuda()
+                if dist.get_backend() == "nccl":  # (PyTorch's name for its RCCL backend on ROCm)
+                    t = t.to("cuda")  # (PyTorch's device-type name for the HIP device)
                 dist.broadcast(t, src=0)
                 uid = t.cpu().numpy().copy()
             _check(lib().ssc_comm_rccl(int(device), int(rank), int(world), hip.p8(uid), ctypes.byref(self.h)))

@@ -16,8 +16,8 @@
 #include <vector>
 
 #include "../../include/spartan_hip.h"
-#include "../csrc/curve.cuh"
-#include "../csrc/keccak.cuh"
+#include "../csrc/curve.hpp"
+#include "../csrc/keccak.hpp"
 
 namespace spartan2 {
 

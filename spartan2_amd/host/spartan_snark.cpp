@@ -84,7 +84,12 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   // Up to 512 rows (2^20 variables): measured at 1024 / 2048 rows the walk (a 17-level chain over 256 / 512 blocks) loses to the MSM it would replace
   // (1.77 vs 1.70 ms, 2.58 vs 2.51 ms): there the sum-check's last rounds no longer cover it and its blocks compete with the streaming rounds.
   sp_fbtables* lz_tables = nullptr;
+  // poly_ABC split at a challenge boundary (sp_poly_abc_begin / _finish): the entries' eq weights over the top variables are formed under the outer
+  // sum-check's last rounds, 32 bytes per matrix entry of workspace (160 MB at config 2). Opt-in with SPARTAN_ABC_SPLIT=1 (see prep_prove).
+  sp_polyabc_ws* abc_ws = nullptr;
+  size_t abc_n_lo = 0;
   ~SpartanPrepSNARK() {
+    sp_poly_abc_ws_free(abc_ws);
     sp_fbtables_free(lz_tables);
     bg.wait_nothrow();
     bg2.wait_nothrow();
@@ -193,6 +198,17 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
       ck(sp_table_zeros(ctx, N / 2, (size_t)-1, (size_t)-1, &ps->p1), "alloc round-0 products");
     }
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->abc), "alloc poly_ABC");
+    {
+      const char* e = getenv("SPARTAN_ABC_SPLIT");
+      const size_t ell = log2_ceil(N);
+      // Opt-in (SPARTAN_ABC_SPLIT=1): measured at config 2 the final pass takes as long as the one-pass kernel (105 - 108 us against 110: both are bound by
+      // dependent latencies at 4 waves per SIMD, not by the gathers the split removes) and the weights pass disturbs the outer sum-check's last rounds
+      // (+10 - 20 us): 1.164 - 1.19 ms against 1.144 ms. Kept behind the ABI with its tests; not the default.
+      if (e && e[0] == '1' && ell >= 16 && ell <= 22) {  // both halves of the row index within 12 bits
+        ps->abc_n_lo = 10;
+        ck(sp_poly_abc_ws_create(ctx, pk.S, &ps->abc_ws), "poly_ABC workspace");
+      }
+    }
     ck(sp_ctx_synchronize(ctx), "sync");
   } catch (...) {
     delete ps;
@@ -524,7 +540,30 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> outer_polys(3 * num_rounds_x), r_x(num_rounds_x);
   fe_t claims_outer[3];
   const fe_t zero = fe_zero();
-  if (ps.p0)
+  // With the split poly_ABC the observer hands the first ell - n_lo challenges (the top variables of the row index) to sp_poly_abc_begin the moment they
+  // exist: the entry weights are formed on the auxiliary stream under the remaining n_lo rounds
+  struct AbcObs {
+    sp_ctx* ctx;
+    sp_polyabc_ws* ws;
+    size_t n_hi;
+    fe_t r[24];
+    int rc = 0;
+    bool begun = false;
+    static void fn(void* u, size_t round, const uint64_t r[4]) {
+      AbcObs* o = (AbcObs*)u;
+      if (round >= o->n_hi) return;
+      memcpy(&o->r[round], r, 32);
+      if (round + 1 == o->n_hi) {
+        o->rc = sp_poly_abc_begin(o->ctx, o->ws, u64p(o->r), o->n_hi);
+        o->begun = o->rc == 0;
+      }
+    }
+  } abc_obs{ctx, ps.abc_ws, ps.abc_ws ? num_rounds_x - ps.abc_n_lo : 0};
+  if (ps.abc_ws)
+    ck(sp_sumcheck_cubic3_observed(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p0 ? ps.p1 : nullptr, tr.t, &AbcObs::fn, &abc_obs,
+                                   u64p(outer_polys.data()), u64p(r_x.data()), u64p(claims_outer)),
+       "outer sum-check");
+  else if (ps.p0)
     ck(sp_sumcheck_cubic3_round0(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p1, tr.t, u64p(outer_polys.data()), u64p(r_x.data()),
                                  u64p(claims_outer)),
        "outer sum-check");
@@ -532,6 +571,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, tr.t, u64p(outer_polys.data()), u64p(r_x.data()),
                           u64p(claims_outer)),
        "outer sum-check");
+  if (abc_obs.rc) throw Error(abc_obs.rc, std::string("poly_ABC (begin): ") + sp_last_error());
   tr.absorb_scalars("claims_outer", claims_outer, 3);
   for (const fe_t& f : outer_polys) proof.pf(f);
   for (int i = 0; i < 3; ++i) proof.pf(claims_outer[i]);
@@ -540,8 +580,12 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t r = tr.squeeze("r");
   const fe_t claim_inner_joint = fe_add<S>(fe_add<S>(claims_outer[0], fe_mul<S>(r, claims_outer[1])), fe_mul<S>(fe_mul<S>(r, r), claims_outer[2]));
   // evals_rx + bind_and_prepare_poly_ABC (src/spartan.rs:316-322)
-  ck(sp_eq_table_into(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");
-  ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
+  if (abc_obs.begun) {
+    ck(sp_poly_abc_finish(ctx, ps.abc_ws, u64p(r_x.data() + abc_obs.n_hi), ps.abc_n_lo, u64p(&r), 2 * M, ps.abc), "poly_ABC (finish)");
+  } else {
+    ck(sp_eq_table_into(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");
+    ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
+  }
   const double t_abc = now_ms();
 
   sp_msm_job* delta_job = nullptr;
@@ -829,6 +873,7 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
   // :226-236 transcript, vk, public values
   Tr tr(ctx, "SpartanSNARK");
+  ck(sp_transcript_set_async(tr.t, 1), "transcript");  // (the shim's TranscriptEngine: long absorbs hashed beside the caller's next calls)
   tr.absorb("vk", pk.vk_digest, 32);
   tr.absorb_scalars("public_values", publics.data(), npub);
   // r1cs_instance_and_witness (src/bellpepper/r1cs.rs:411-540)

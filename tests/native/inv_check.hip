@@ -1,9 +1,9 @@
-// Host-only check (no GPU needed): the binary extended-GCD inversion of the host side (field.cuh fe_inv_host_xgcd) against Fermat's little theorem
+// Host-only check (no GPU needed): the binary extended-GCD inversion of the host side (field.hpp fe_inv_host_xgcd) against Fermat's little theorem
 // (fe_pow with p - 2) and against x * inv(x) == 1, for both fields: edge values and seeded random residues. Built and run by tests/test_field_host.py.
 #include <cstdio>
 #include <cstdlib>
 
-#include "../../spartan2_amd/csrc/field.cuh"
+#include "../../spartan2_amd/csrc/field.hpp"
 
 #if !defined(__HIP_DEVICE_COMPILE__)  // (the host-side inversion does not exist in the device pass)
 template <class FP>

@@ -1,4 +1,4 @@
-"""Host side of the library's field arithmetic, without a GPU: the binary extended-GCD inversion (spartan2_amd/csrc/field.cuh fe_inv_host_xgcd, raw for public values and behind a multiplicative mask in fe_inv — every
+"""Host side of the library's field arithmetic, without a GPU: the binary extended-GCD inversion (spartan2_amd/csrc/field.hpp fe_inv_host_xgcd, raw for public values and behind a multiplicative mask in fe_inv — every
 normalisation of a point on the host and the prover's division by 1 - r_y[0] go through it) against Fermat's little theorem and x * inv(x) == 1, on
 edge values and seeded random residues of both fields (tests/native/inv_check.hip, compiled here with hipcc: host code only, nothing is launched)."""
 import os

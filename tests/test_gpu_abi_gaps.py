@@ -182,11 +182,12 @@ def test_table_view_and_device_ptr(ctx):
 
 
 def test_long_absorbs_hashed_on_the_library_thread_equal_the_oracle_transcript(ctx):
-    """sp_transcript_absorb hands inputs of >= 4 KiB to the library's hashing thread and returns (the caller's next calls run beside the Keccak blocks);
+    """With sp_transcript_set_async, sp_transcript_absorb hands inputs of >= 4 KiB to the library's hashing thread and returns (the caller's next calls run beside the Keccak blocks);
     every later use of the transcript joins first. The squeezed challenges must be the oracle transcript's (src/provider/keccak.rs:70-99) whatever mix of
     short / long absorbs, dom_seps, clones and squeezes follows."""
     rng = np.random.default_rng(77)
     tr, otr = hip.Transcript(ctx, b"async"), ol.Transcript(b"async")
+    tr.set_async(True)
     for step, n in enumerate([10, 5000, 70000, 3, 4096, 4095, 200000]):
         data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
         tr.absorb(b"blob", data)

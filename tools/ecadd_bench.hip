@@ -1,10 +1,10 @@
 // Latency of a chain of dependent Jacobian additions in one wave: the ordinary 16-product formula vs the 4-lane cooperative form
-// (curve.cuh jac_add_coop4). Also checks that both give the same point.
+// (curve.hpp jac_add_coop4). Also checks that both give the same point.
 // Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ispartan2_amd/csrc tools/ecadd_bench.hip -o tools/ecadd_bench
 #include <cstdio>
 #include <vector>
 
-#include "curve.cuh"
+#include "curve.hpp"
 
 // EXPERIMENT (not used by the library): measured 16.3 us (ordinary) vs 10.5 us (cooperative) per dependent addition on MI355X — the
 // selects / modular adds around the five product levels cost as much as four more products, so the gain did not justify replicating points

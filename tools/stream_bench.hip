@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "kernels_poly.cuh"
+#include "kernels_poly.hpp"
 
 using namespace spk;
 

@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "field.cuh"
+#include "field.hpp"
 
 #define CK(x)                                                      \
   do {                                                             \
