@@ -816,15 +816,20 @@ int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, cons
   t->join();
   const size_t amin = async_absorb_min();
   if (t->async_absorb && amin && n >= amin && !g_hash_taken.exchange(true, std::memory_order_acq_rel)) {
-    t->pend.resize(ln + n);
-    memcpy(t->pend.data(), label, ln);
-    memcpy(t->pend.data() + ln, bytes, n);
-    t->pend_label = ln;
-    t->busy.store(1, std::memory_order_release);
-    g_hash_worker.submit([t] {
-      t->t.absorb(t->pend.data(), t->pend_label, t->pend.data() + t->pend_label, t->pend.size() - t->pend_label);
+    auto job = std::make_shared<sp_absorb_job>();
+    job->data.resize(ln + n);
+    memcpy(job->data.data(), label, ln);
+    memcpy(job->data.data() + ln, bytes, n);
+    job->label = ln;
+    job->h = t->t.h;
+    t->pend = job;
+    g_hash_worker.submit([job] {
+      int expect = 1;
+      if (job->state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel)) {
+        job->run();
+        job->state.store(4, std::memory_order_release);
+      }  // (else the caller took the job back)
       g_hash_taken.store(false, std::memory_order_release);
-      t->busy.store(0, std::memory_order_release);
     });
     return SP_OK;
   }

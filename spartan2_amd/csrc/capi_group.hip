@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -1396,9 +1397,12 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
       hp->update(reinterpret_cast<const uint8_t*>(e), strlen(e));
     });
   }
-  struct Join {
+  struct Join {  // the hashing job reads `comm` and writes `hashed`: it must have finished on every exit path (not so the z_vec helper job further down)
     sp::Worker* w;
-    ~Join() { w->wait(); }
+    bool joined = false;
+    ~Join() {
+      if (!joined) w->wait();
+    }
   } join{c->pcs_worker};
 
   lap("submit hashing");
@@ -1517,6 +1521,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   }
   lap("join walks");
   c->pcs_worker->wait();
+  join.joined = true;
   lap("join hashing");
   tr->t.h = hashed;
   // (5) InnerProductArgumentLinear::prove, transcript part (ipa.rs:132-158)
@@ -1539,14 +1544,28 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   memcpy(out + 8, &beta, sizeof(aff_t));
   fe_t* zv = reinterpret_cast<fe_t*>(out + 16);
   {
+    // shared with the helper thread chunk by chunk: whoever is awake takes the next 128 elements. The owner never waits for the helper to WAKE (a sleeping
+    // thread can take milliseconds when the process is at its CPU quota), only for chunks the helper has actually claimed.
+    struct Share {
+      std::atomic<size_t> next{0}, done{0};
+    };
+    auto sh = std::make_shared<Share>();
     const fe_t* lz = LZ.data();
     const fe_t* dv = dvec.data();
-    const size_t half = cols >= 512 ? cols * 45 / 100 : cols;  // the owner starts at once, the helper has to wake up first
-    if (half < cols) c->pcs_worker->submit([zv, lz, dv, rr, half, cols] {
-      for (size_t i = half; i < cols; ++i) zv[i] = fe_add<SF>(fe_mul<SF>(rr, lz[i]), dv[i]);
-    });
-    for (size_t i = 0; i < half; ++i) zv[i] = fe_add<SF>(fe_mul<SF>(rr, lz[i]), dv[i]);
-    c->pcs_worker->wait();
+    constexpr size_t CH = 128;
+    const size_t nch = (cols + CH - 1) / CH;
+    auto work = [sh, zv, lz, dv, rr, cols, nch] {
+      for (;;) {
+        const size_t ci = sh->next.fetch_add(1, std::memory_order_acq_rel);
+        if (ci >= nch) return;
+        const size_t hi = (ci + 1) * CH < cols ? (ci + 1) * CH : cols;
+        for (size_t i = ci * CH; i < hi; ++i) zv[i] = fe_add<SF>(fe_mul<SF>(rr, lz[i]), dv[i]);
+        sh->done.fetch_add(1, std::memory_order_acq_rel);
+      }
+    };
+    if (nch > 2) c->pcs_worker->submit(work);
+    work();
+    while (sh->done.load(std::memory_order_acquire) < nch) __builtin_ia32_pause();
   }
   zv[cols] = fe_add<SF>(fe_mul<SF>(rr, r_LZ), r_delta);
   zv[cols + 1] = fe_add<SF>(fe_mul<SF>(rr, b_eval), r_beta);

@@ -5,9 +5,11 @@
 #include <hip/hip_ext.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -219,20 +221,45 @@ struct sp_table {
   bool view = false;  // non-owning window onto storage owned by another object (sp_nifs layers)
 };
 
+// A long absorb handed to the library's hashing thread (sp_transcript_set_async). The job owns its input and works on a COPY of the running hasher, so the
+// worker never touches the transcript; the transcript installs the result when it next needs the sponge. If the worker has not picked the job up within
+// ~20 us (a sleeping thread's wake-up can take milliseconds when the process is at its CPU quota) the waiting caller takes the job back and hashes inline.
+struct sp_absorb_job {
+  std::atomic<int> state{1};  // 1 posted, 2 running on the worker, 3 taken back by the caller, 4 done
+  std::vector<uint8_t> data;
+  size_t label = 0;
+  sp::Keccak256State h;  // in: the running hasher; out: after the absorb
+  void run() {
+    h.update(data.data(), label);
+    h.update(data.data() + label, data.size() - label);
+  }
+};
 struct sp_transcript {
   sp::Transcript t;
-  // A long absorb (a commitment's 64 bytes per row: hundreds of Keccak blocks) runs on the library's hashing thread while the caller goes on to its
-  // next call — in src/spartan.rs's order that is the commitment of the rest segment and the build of z; every later use of the transcript joins
-  // first (join()), so the sponge sees exactly the reference's byte sequence.
-  std::vector<uint8_t> pend;
-  size_t pend_label = 0;
-  std::atomic<int> busy{0};
+  mutable std::shared_ptr<sp_absorb_job> pend;
   bool async_absorb = false;  // sp_transcript_set_async: a single-threaded caller opts in; a driver that already hashes on a thread of its own does not
   sp_transcript() = default;
   sp_transcript(const sp_transcript&) = delete;
   sp_transcript& operator=(const sp_transcript&) = delete;
   void join() const {
-    while (busy.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    if (!pend) return;
+    sp_absorb_job& j = *pend;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const int st = j.state.load(std::memory_order_acquire);
+      if (st == 4) break;
+      if (st == 1 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(20)) {
+        int expect = 1;
+        if (j.state.compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) {
+          j.run();
+          j.state.store(4, std::memory_order_release);
+          break;
+        }
+      }
+      __builtin_ia32_pause();
+    }
+    const_cast<sp_transcript*>(this)->t.h = j.h;
+    pend.reset();
   }
   ~sp_transcript() { join(); }
 };
