@@ -7,7 +7,9 @@
 // Entries keep the reference's classes: +-1 and |k| in 2..7 as an int8 code (add / sub / double-add chains, sparse.rs:137-155),
 // everything else as a full field coefficient.
 #include <algorithm>
+#include <array>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "core.hpp"
@@ -202,8 +204,9 @@ __global__ void __launch_bounds__(1024) k_eq_small(EqSmallArgs a) {
 // (row | matrix << 28 | valid << 31) words and 2 KiB of weights per wave and step. `src` tells the weights pass where an entry's coefficient lives
 // (k | general << 29 | matrix << 30 into the column-major arrays).
 struct EllDev {
-  const uint4* meta;  // per wave: first slot, steps of A, of B, of C (a wave's columns are sorted to have the same per-matrix entry counts, so the
-                      // three segments need next to no padding and the final pass has no per-entry matrix selector)
+  const uint4* meta;  // per wave TWO words: (first slot, small steps of A, general steps of A, small steps of B), (general steps of B, small of C, general of C, -):
+                      // a wave's columns are sorted to have the same entry counts per matrix and class, so the six segments need next to no padding, the
+                      // final pass has no per-entry matrix selector and the one-pass form multiplies only in its general segments
   const unsigned* row;
   const unsigned* src;
   size_t slots;
@@ -236,7 +239,8 @@ __global__ void __launch_bounds__(256) k_polyabc_ell_final(EllDev e, const fe_t*
   const size_t wave = i >> 6;
   const unsigned lane = threadIdx.x & 63;
   if (wave * 64 >= n_short) return;
-  const uint4 mt = e.meta[wave];
+  const uint4 m0 = e.meta[2 * wave], m1 = e.meta[2 * wave + 1];
+  const uint4 mt = make_uint4(m0.x, m0.y + m0.z, m0.w + m1.x, m1.y + m1.z);  // per-matrix totals
   // sum of weight * eq_lo over `steps` slots starting at `base` (this lane's column of the segment), four loads in flight
   auto segment = [&](size_t base, unsigned steps) {
     fe_t acc = fe_zero(), acc2 = fe_zero();
@@ -257,6 +261,74 @@ __global__ void __launch_bounds__(256) k_polyabc_ell_final(EllDev e, const fe_t*
   };
   const size_t base = (size_t)mt.x + lane;
   const fe_t sa = segment(base, mt.y), sb = segment(base + 64 * (size_t)mt.y, mt.z), sc = segment(base + 64 * ((size_t)mt.y + mt.z), mt.w);
+  if (i < n_short) out[order[i]] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(r, sb)), fe_mul<S>(r2, sc));
+}
+// ONE-PASS poly_ABC over the same sliced-ELL copy: per wave one meta load, then coalesced (row, class) loads, then the gathers from evals_rx — three
+// dependent memory rounds for a short column where the column-major walk of k_polyabc_short needs nine (pointers, indices, gathers, for each of the
+// three matrices in turn). `cls`: 0 = padding, 1..14 = small codes (-7..-1, 1..7 -> 1..14), 15.. = index into the table of the shape's distinct
+// general coefficients (powers of two of the additions' rows: 214 values at config 2), which stays in the L1s.
+__device__ __forceinline__ int cls_code(unsigned cls) { return cls <= 7 ? (int)cls - 8 : (int)cls - 7; }  // 1..7 -> -7..-1, 8..14 -> 1..7
+__global__ void __launch_bounds__(256) k_polyabc_ell_onepass(EllDev e, const unsigned char* __restrict__ cls, const fe_t* __restrict__ gtab, const fe_t* __restrict__ rx,
+                                                             const unsigned* __restrict__ order, size_t n_short, fe_t r, fe_t r2, fe_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t wave = i >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  if (wave * 64 >= n_short) return;
+  const uint4 m0 = e.meta[2 * wave], m1 = e.meta[2 * wave + 1];
+  // small-class segment: gathers and add / sub / double-add chains, four entries in flight
+  auto seg_small = [&](size_t base, unsigned steps) {
+    fe_t acc = fe_zero();
+    unsigned j = 0;
+    for (; j + 4 <= steps; j += 4) {
+      const size_t s0 = base + 64 * (size_t)j;
+      const unsigned p0 = e.row[s0], p1 = e.row[s0 + 64], p2 = e.row[s0 + 128], p3 = e.row[s0 + 192];
+      const unsigned c0 = cls[s0], c1 = cls[s0 + 64], c2 = cls[s0 + 128], c3 = cls[s0 + 192];
+      const fe_t x0 = rx[p0 & 0x0fffffffu], x1 = rx[p1 & 0x0fffffffu], x2 = rx[p2 & 0x0fffffffu], x3 = rx[p3 & 0x0fffffffu];
+      if (c0) acc = acc_small(acc, cls_code(c0), x0);
+      if (c1) acc = acc_small(acc, cls_code(c1), x1);
+      if (c2) acc = acc_small(acc, cls_code(c2), x2);
+      if (c3) acc = acc_small(acc, cls_code(c3), x3);
+    }
+    for (; j < steps; ++j) {
+      const size_t s0 = base + 64 * (size_t)j;
+      const unsigned c0 = cls[s0];
+      const fe_t x0 = rx[e.row[s0] & 0x0fffffffu];
+      if (c0) acc = acc_small(acc, cls_code(c0), x0);
+    }
+    return acc;
+  };
+  // general-class segment: one product per entry, two in flight
+  auto seg_general = [&](size_t base, unsigned steps) {
+    fe_t acc = fe_zero();
+    unsigned j = 0;
+    for (; j + 2 <= steps; j += 2) {
+      const size_t s0 = base + 64 * (size_t)j;
+      const unsigned p0 = e.row[s0], p1 = e.row[s0 + 64];
+      const unsigned c0 = cls[s0], c1 = cls[s0 + 64];
+      const fe_t x0 = rx[p0 & 0x0fffffffu], x1 = rx[p1 & 0x0fffffffu];
+      const fe_t g0 = gtab[c0 >= 15 ? c0 - 15 : 0], g1 = gtab[c1 >= 15 ? c1 - 15 : 0];
+      if (c0) acc = fe_add<S>(acc, fe_mul<S>(g0, x0));
+      if (c1) acc = fe_add<S>(acc, fe_mul<S>(g1, x1));
+    }
+    if (j < steps) {
+      const size_t s0 = base + 64 * (size_t)j;
+      const unsigned c0 = cls[s0];
+      if (c0) acc = fe_add<S>(acc, fe_mul<S>(gtab[c0 - 15], rx[e.row[s0] & 0x0fffffffu]));
+    }
+    return acc;
+  };
+  size_t base = (size_t)m0.x + lane;
+  fe_t sa = seg_small(base, m0.y);
+  base += 64 * (size_t)m0.y;
+  sa = fe_add<S>(sa, seg_general(base, m0.z));
+  base += 64 * (size_t)m0.z;
+  fe_t sb = seg_small(base, m0.w);
+  base += 64 * (size_t)m0.w;
+  sb = fe_add<S>(sb, seg_general(base, m1.x));
+  base += 64 * (size_t)m1.x;
+  fe_t sc = seg_small(base, m1.y);
+  base += 64 * (size_t)m1.y;
+  sc = fe_add<S>(sc, seg_general(base, m1.z));
   if (i < n_short) out[order[i]] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(r, sb)), fe_mul<S>(r2, sc));
 }
 // long columns of the split form: no stored weights, the eq factor of an entry is the product of the two small tables
@@ -401,6 +473,8 @@ struct sp_shape {
   // sliced-ELL copy of the short columns (kernels above: EllDev)
   uint4* d_ell_meta = nullptr;
   unsigned *d_ell_row = nullptr, *d_ell_src = nullptr;
+  unsigned char* d_ell_cls = nullptr;  // one-pass form (k_polyabc_ell_onepass): class of every slot; nullptr when the shape has more than 241 distinct general coefficients
+  fe_t* d_ell_gtab = nullptr;
   size_t ell_slots = 0;
 };
 
@@ -483,12 +557,20 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     }();
     // (within one total the columns are grouped by their (A, B, C) entry counts: the lanes of a wave then run the same trip counts in each of the
     // three matrices — no divergence in the one-pass kernel, no padding in the sliced-ELL copy below)
-    auto len_of = [&](int m, unsigned col) { return (col_host[m].sptr[col + 1] - col_host[m].sptr[col]) + (col_host[m].gptr[col + 1] - col_host[m].gptr[col]); };
+    auto cnt6 = [&](unsigned col, unsigned out6[6]) {  // small / general entry counts of A, B, C
+      for (int m = 0; m < 3; ++m) {
+        out6[2 * m] = col_host[m].sptr[col + 1] - col_host[m].sptr[col];
+        out6[2 * m + 1] = col_host[m].gptr[col + 1] - col_host[m].gptr[col];
+      }
+    };
     auto by_len = [&](unsigned x, unsigned y) {
       if (col_count[x] != col_count[y]) return col_count[x] > col_count[y];
-      const unsigned ax = len_of(0, x), ay = len_of(0, y);
-      if (ax != ay) return ax > ay;
-      return len_of(1, x) > len_of(1, y);
+      unsigned a[6], b[6];
+      cnt6(x, a);
+      cnt6(y, b);
+      for (int k = 0; k < 5; ++k)
+        if (a[k] != b[k]) return a[k] > b[k];
+      return false;
     };
     if (window == 0) {
       std::stable_sort(order.begin(), order.end(), by_len);
@@ -516,15 +598,18 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     // sliced-ELL copy of the short columns in this order (the split poly_ABC): per wave three segments (A, B, C), each as long as the wave's longest
     // column in that matrix
     const size_t waves = (order.size() + 63) / 64;
-    std::vector<uint4> meta(waves ? waves : 1);
-    auto len_m = [&](int m, unsigned col) { return (col_host[m].sptr[col + 1] - col_host[m].sptr[col]) + (col_host[m].gptr[col + 1] - col_host[m].gptr[col]); };
+    std::vector<uint4> meta(2 * (waves ? waves : 1));
     size_t slots = 0;
     for (size_t w = 0; w < waves; ++w) {
-      unsigned L[3] = {0, 0, 0};
-      for (size_t i = 64 * w; i < order.size() && i < 64 * (w + 1); ++i)
-        for (int m = 0; m < 3; ++m) L[m] = std::max(L[m], len_m(m, order[i]));
-      meta[w] = make_uint4((unsigned)slots, L[0], L[1], L[2]);
-      slots += 64 * ((size_t)L[0] + L[1] + L[2]);
+      unsigned L[6] = {0, 0, 0, 0, 0, 0};
+      for (size_t i = 64 * w; i < order.size() && i < 64 * (w + 1); ++i) {
+        unsigned c6[6];
+        cnt6(order[i], c6);
+        for (int k = 0; k < 6; ++k) L[k] = std::max(L[k], c6[k]);
+      }
+      meta[2 * w] = make_uint4((unsigned)slots, L[0], L[1], L[2]);
+      meta[2 * w + 1] = make_uint4(L[3], L[4], L[5], 0u);
+      slots += 64 * ((size_t)L[0] + L[1] + L[2] + L[3] + L[4] + L[5]);
     }
     if (slots >= ((size_t)1 << 31) || nrows > ((size_t)1 << 28)) {
       s->ell_slots = 0;  // (out of the packed format's range: the split form is then not offered for this shape)
@@ -532,7 +617,8 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
       std::vector<unsigned> erow(slots ? slots : 1, 0u), esrc(slots ? slots : 1, 0u);
       for (size_t i = 0; i < order.size(); ++i) {
         const size_t w = i / 64, lane = i % 64, col = order[i];
-        size_t seg = meta[w].x;
+        size_t seg = meta[2 * w].x;
+        const unsigned L[6] = {meta[2 * w].y, meta[2 * w].z, meta[2 * w].w, meta[2 * w + 1].x, meta[2 * w + 1].y, meta[2 * w + 1].z};
         for (int m = 0; m < 3; ++m) {
           const SplitHost& h = col_host[m];
           unsigned j = 0;
@@ -541,16 +627,49 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
             erow[slot] = h.sidx[k] | ((unsigned)m << 28) | 0x80000000u;
             esrc[slot] = k | ((unsigned)m << 30);
           }
+          seg += 64 * (size_t)L[2 * m];
+          j = 0;
           for (unsigned k = h.gptr[col]; k < h.gptr[col + 1]; ++k, ++j) {
             const size_t slot = seg + 64 * (size_t)j + lane;
             erow[slot] = h.gidx[k] | ((unsigned)m << 28) | 0x80000000u;
             esrc[slot] = k | 0x20000000u | ((unsigned)m << 30);
           }
-          seg += 64 * (size_t)(m == 0 ? meta[w].y : m == 1 ? meta[w].z : meta[w].w);
+          seg += 64 * (size_t)L[2 * m + 1];
         }
       }
       s->ell_slots = slots;
       if ((rc = upload(&s->d_ell_meta, meta)) || (rc = upload(&s->d_ell_row, erow)) || (rc = upload(&s->d_ell_src, esrc))) return rc;
+      // classes for the one-pass form: small codes, or an index into the table of distinct general coefficients
+      std::vector<unsigned char> ecls(slots ? slots : 1, 0);
+      std::vector<fe_t> gtab;
+      std::map<std::array<uint32_t, 8>, unsigned> gidx_of;
+      bool fits = true;
+      for (size_t slot = 0; slot < slots && fits; ++slot) {
+        if (!(erow[slot] >> 31)) continue;
+        const unsigned src = esrc[slot], k = src & 0x1fffffffu;
+        const SplitHost& h = col_host[src >> 30];
+        if (src & 0x20000000u) {
+          std::array<uint32_t, 8> key;
+          memcpy(key.data(), &h.gval[k], 32);
+          auto it = gidx_of.find(key);
+          if (it == gidx_of.end()) {
+            if (gtab.size() >= 241) {
+              fits = false;
+              break;
+            }
+            it = gidx_of.emplace(key, (unsigned)gtab.size()).first;
+            gtab.push_back(h.gval[k]);
+          }
+          ecls[slot] = (unsigned char)(15 + it->second);
+        } else {
+          const int code = h.scode[k];
+          ecls[slot] = (unsigned char)(code < 0 ? code + 8 : code + 7);
+        }
+      }
+      if (fits) {
+        if (gtab.empty()) gtab.push_back(fe_zero());
+        if ((rc = upload(&s->d_ell_cls, ecls)) || (rc = upload(&s->d_ell_gtab, gtab))) return rc;
+      }
     }
   }
   SP_HIP(hipMalloc((void**)&s->d_long_partials, (long_cols.size() + 1) * spk::LONG_NB_MAX * 3 * sizeof(fe_t)));
@@ -570,6 +689,8 @@ void sp_shape_free(sp_shape* s) {
   if (s->d_ell_meta) hipFree(s->d_ell_meta);
   if (s->d_ell_row) hipFree(s->d_ell_row);
   if (s->d_ell_src) hipFree(s->d_ell_src);
+  if (s->d_ell_cls) hipFree(s->d_ell_cls);
+  if (s->d_ell_gtab) hipFree(s->d_ell_gtab);
   delete s;
 }
 
@@ -643,6 +764,7 @@ int sp_multiply_vec_incremental_round0(sp_ctx* c, const sp_shape* s, const sp_ta
   return SP_OK;
 }
 
+static spk::EllDev ell_view(const sp_shape* s);
 int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t r_[4], size_t out_len, sp_table* out) {
   if (rx->len != s->dims.num_cons) return fail(SP_ERR_INVALID_INPUT_LENGTH, "poly_ABC: rx must have num_cons elements");
   if (out_len < s->num_cols || out->cap < out_len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "poly_ABC: output too short");
@@ -655,8 +777,17 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
   uint64_t bytes = 36ull * (s->nnz[0] + s->nnz[1] + s->nnz[2]) + 32ull * out_len;
+  // SPARTAN_POLYABC_ELL=1: the short columns from the sliced-ELL copy (k_polyabc_ell_onepass) instead of the column-major walk. Measured equal at config 2
+  // (97.6 - 100.8 us against 101.4 - 102.0 us): with coalesced index loads and three dependent memory rounds instead of nine the kernel still takes
+  // ~100 us, like the split form's final pass without any large gather - the time is the serial latency of a wave's steps at 4 waves per SIMD. Opt-in.
+  const char* ell_env = getenv("SPARTAN_POLYABC_ELL");
+  const bool ell_onepass = ell_env && ell_env[0] == '1';
   c->timed("poly_abc", bytes, [&] {
-    hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short, out->d);
+    if (ell_onepass && s->d_ell_cls && s->ell_slots && s->n_short)
+      hipLaunchKernelGGL(spk::k_polyabc_ell_onepass, dim3((unsigned)((s->n_short + 255) / 256)), dim3(256), 0, c->stream, ell_view(s), s->d_ell_cls, s->d_ell_gtab, rx->d,
+                         s->d_short_order, s->n_short, a.r, a.r2, out->d);
+    else
+      hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short, out->d);
     if (s->n_long_cols) {
       hipLaunchKernelGGL(spk::k_polyabc_long, dim3(spk::LONG_NB_MAX, (unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, rx->d, s->d_long_cols,
                          s->d_long_partials);

@@ -67,6 +67,16 @@ def test_spmv_and_poly_abc(ctx, which):
         out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])  # dirty buffer
         shape.poly_abc(hip.Table.from_host(ctx, rx), r, out_len, out)
         assert (out.read(0, out_len) == want).all()
+    # the short columns from the sliced-ELL copy (k_polyabc_ell_onepass, opt-in): same table
+    import os
+
+    os.environ["SPARTAN_POLYABC_ELL"] = "1"
+    try:
+        out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])
+        shape.poly_abc(hip.Table.from_host(ctx, rx), r, 2 * M, out)
+        assert (out.read(0, 2 * M) == want).all()
+    finally:
+        del os.environ["SPARTAN_POLYABC_ELL"]
     # the same for rx = eq(r_x), split at a challenge boundary (sp_poly_abc_begin / _finish: entries weighted with eq of the top n_hi variables under the
     # outer sum-check's last rounds, the rest in a short final pass) at every admissible split
     ell = N.bit_length() - 1
