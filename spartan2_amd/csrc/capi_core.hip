@@ -103,7 +103,8 @@ const char* sp_last_error(void) { return sp::g_err.c_str(); }
 int sp_ctx_create(int device, sp_ctx** out) {
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
-  if (e != hipSuccess || count == 0) return fail(SP_ERR_NO_DEVICE, "no HIP device visible: libspartan_hip has no CPU fallback");
+  if (e != hipSuccess || count == 0)
+    return fail(SP_ERR_NO_DEVICE, std::string("no HIP device visible: libspartan_hip has no CPU fallback (hipGetDeviceCount: ") + hipGetErrorString(e) + ", " + std::to_string(count) + " devices)");
   if (device < 0 || device >= count) return fail(SP_ERR_NO_DEVICE, "device ordinal out of range");
   SP_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;

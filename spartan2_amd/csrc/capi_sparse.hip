@@ -135,7 +135,11 @@ __global__ void __launch_bounds__(256) k_polyabc_short(PolyAbcArgs a, const fe_t
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_short; i += (size_t)gridDim.x * blockDim.x) {
     const size_t col = order[i];
     fe_t sa = gather_major_x4(a.m[0], col, rx), sb = gather_major_x4(a.m[1], col, rx), sc = gather_major_x4(a.m[2], col, rx);
-    out[col] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(a.r, sb)), fe_mul<S>(a.r2, sc));
+    // two thirds of a SHA circuit's columns have no entry in B: with the columns grouped by their entry counts that is uniform across a wave, and the
+    // skipped product is a third of this kernel's multiplications (the per-column epilogue outweighs the 1.05 M general-coefficient products)
+    if (!fe_is_zero(sb)) sa = fe_add<S>(sa, fe_mul<S>(a.r, sb));
+    if (!fe_is_zero(sc)) sa = fe_add<S>(sa, fe_mul<S>(a.r2, sc));
+    out[col] = sa;
   }
 }
 // Long columns (the constant-1 column has ~one entry per booleanity row): NB blocks share a column, each striding
@@ -260,8 +264,10 @@ __global__ void __launch_bounds__(256) k_polyabc_ell_final(EllDev e, const fe_t*
     return fe_add<S>(acc, acc2);
   };
   const size_t base = (size_t)mt.x + lane;
-  const fe_t sa = segment(base, mt.y), sb = segment(base + 64 * (size_t)mt.y, mt.z), sc = segment(base + 64 * ((size_t)mt.y + mt.z), mt.w);
-  if (i < n_short) out[order[i]] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(r, sb)), fe_mul<S>(r2, sc));
+  fe_t sa = segment(base, mt.y);
+  if (mt.z) sa = fe_add<S>(sa, fe_mul<S>(r, segment(base + 64 * (size_t)mt.y, mt.z)));
+  if (mt.w) sa = fe_add<S>(sa, fe_mul<S>(r2, segment(base + 64 * ((size_t)mt.y + mt.z), mt.w)));
+  if (i < n_short) out[order[i]] = sa;
 }
 // ONE-PASS poly_ABC over the same sliced-ELL copy: per wave one meta load, then coalesced (row, class) loads, then the gathers from evals_rx — three
 // dependent memory rounds for a short column where the column-major walk of k_polyabc_short needs nine (pointers, indices, gathers, for each of the
@@ -329,7 +335,9 @@ __global__ void __launch_bounds__(256) k_polyabc_ell_onepass(EllDev e, const uns
   fe_t sc = seg_small(base, m1.y);
   base += 64 * (size_t)m1.y;
   sc = fe_add<S>(sc, seg_general(base, m1.z));
-  if (i < n_short) out[order[i]] = fe_add<S>(fe_add<S>(sa, fe_mul<S>(r, sb)), fe_mul<S>(r2, sc));
+  if (m0.w + m1.x) sa = fe_add<S>(sa, fe_mul<S>(r, sb));  // (wave-uniform: no B entries in two thirds of a SHA circuit's columns)
+  if (m1.y + m1.z) sa = fe_add<S>(sa, fe_mul<S>(r2, sc));
+  if (i < n_short) out[order[i]] = sa;
 }
 // long columns of the split form: no stored weights, the eq factor of an entry is the product of the two small tables
 __device__ __forceinline__ fe_t gather_twotable(const SplitDev& m, size_t major, const fe_t* __restrict__ eq_hi, const fe_t* __restrict__ eq_lo, int n_lo, unsigned mask,

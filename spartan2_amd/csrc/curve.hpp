@@ -162,7 +162,48 @@ SP_HD jac_t xyzz_to_jac(const xyzz_t& p) {
   r.z = p.zz;
   return r;
 }
-SP_HD xyzz_t xyzz_dbl(const xyzz_t& p) { return xyzz_from_jac(jac_dbl(xyzz_to_jac(p))); }  // only on the P = Q path of an addition
+// dbl-2008-s-1 with a = -3 (M = 3 (X - ZZ)(X + ZZ)): 9 products. Only ever on the P = Q path of an addition, so it is written for SIZE, not speed: one
+// product that a nine-step loop runs on operands picked per step (~5 KB of code). Inlined as nine products (or as the Jacobian round trip it used to be)
+// it put ~30 KB of never-executed code into every addition of every kernel, against a 64 KB instruction cache.
+SP_HD xyzz_t xyzz_dbl(const xyzz_t& p) {
+  if (xyzz_is_identity(p)) return xyzz_identity();
+  const fe_t u = fe_dbl<B>(p.y);
+  fe_t v = u, w = u, sv = u, m = u, x3 = u, y3 = u, wy = u, zz = u, a = u, b = u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+  for (int k = 0; k < 9; ++k) {
+    switch (k) {
+      case 0: a = u; b = u; break;                                          // V = U^2
+      case 1: a = u; b = v; break;                                          // W = U V
+      case 2: a = p.x; b = v; break;                                        // S = X V
+      case 3: a = fe_sub<B>(p.x, p.zz); b = fe_add<B>(p.x, p.zz); break;    // (X - ZZ)(X + ZZ)
+      case 4: a = m; b = m; break;                                          // M^2
+      case 5: a = m; b = fe_sub<B>(sv, x3); break;                          // M (S - X3)
+      case 6: a = w; b = p.y; break;                                        // W Y
+      case 7: a = v; b = p.zz; break;                                       // ZZ3 = V ZZ
+      default: a = w; b = p.zzz; break;                                     // ZZZ3 = W ZZZ
+    }
+    const fe_t r = fe_mul<B>(a, b);
+    switch (k) {
+      case 0: v = r; break;
+      case 1: w = r; break;
+      case 2: sv = r; break;
+      case 3: m = fe_add<B>(fe_dbl<B>(r), r); break;
+      case 4: x3 = fe_sub<B>(r, fe_dbl<B>(sv)); break;
+      case 5: y3 = r; break;
+      case 6: wy = r; break;
+      case 7: zz = r; break;
+      default: a = r; break;
+    }
+  }
+  xyzz_t o;
+  o.x = x3;
+  o.y = fe_sub<B>(y3, wy);
+  o.zz = zz;
+  o.zzz = a;
+  return o;
+}
 // madd-2008-s
 SP_HD xyzz_t xyzz_add_mixed(const xyzz_t& p, const aff_t& q) {
   if (aff_is_identity(q)) return p;

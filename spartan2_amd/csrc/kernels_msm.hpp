@@ -14,6 +14,28 @@
 #include "curve.hpp"
 #include "device_utils.hpp"
 
+// SP_STAMP(i): wall-clock stamps (100 MHz) of block 0 / thread 0 for the latency kernels - compiled in only by tools/fb_stamps.hip
+#ifdef SP_KERNEL_STAMPS
+__device__ unsigned long long sp_stamps[192];
+#define SP_STAMP(i)                                                     \
+  do {                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {                          \
+      sp_stamps[i] = wall_clock64();                                    \
+      sp_stamps[32 + (i)] = clock64();                                  \
+    }                                                                   \
+  } while (0)
+__device__ unsigned sp_stage_ctr[4];
+__device__ unsigned sp_hwid[4];
+__device__ unsigned sp_predelay;  // 10 ns ticks every wave spins for before it starts (is the slow phase tied to time since launch or to the tree level?)
+#define SP_STAGE_STAMP()                                                          \
+  do {                                                                            \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) sp_stamps[64 + 32 * (threadIdx.x >> 6) + (sp_stage_ctr[threadIdx.x >> 6]++ & 31)] = wall_clock64(); \
+  } while (0)
+#else
+#define SP_STAMP(i)
+#define SP_STAGE_STAMP()
+#endif
+
 namespace spk {
 
 typedef FqP SF;  // scalar field
@@ -269,12 +291,23 @@ struct CoopAdd {
 };
 // All ITEMS * 4 threads of the block call this (it synchronises). role = threadIdx / ITEMS, i = threadIdx % ITEMS; P[i] += Q index given by the
 // caller as pointers into LDS; `active` = this item takes part. The sum is written to dst[i] (may alias P: results are stored after the last level).
+// CODE SIZE is what this routine is written around. Every wave of a latency kernel runs each instruction once per tree level, and a product is ~3 KB
+// of straight-line code: with one inlined product per (stage, role) - 14 of them, plus the doubling case - a level was ~100 KB against a 64 KB
+// instruction cache, and the same level took 5 us with its code cached and 10-12 us without (tools/fb_stamps.hip). Here every stage has ONE product that
+// all four roles execute on operands they pick by address, so a level is ~15 KB and stays cached from the second level on. (A real call per product is
+// no way out: 18 us per level with the call ABI's moves and scratch set-up.)
 template <int ITEMS>
 __device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t* P, const xyzz_t* Q, xyzz_t* dst, int role, int i, bool active) {
+  // EXEC stays FULL through the products: items that do not take part compute on whatever their slots hold and only the flag / result stores are
+  // predicated. Measured (tools/fb_stamps.hip, profiles/r03_sparse_exec.txt): the same level of the same tree takes 5.2 us with every lane computing
+  // and, in two launches out of three, 10-13 us once only 8 or 4 lanes of each wave are enabled - the long dependent v_mad_u64_u32 / v_addc chains
+  // run 2.5-3x slower under a sparse EXEC mask on this part.
+  // (A wave none of whose items takes part skips the products altogether: it would only compete with the wave it shares its SIMD with.)
   fe_t(*t)[ITEMS] = L.t;
-  // level 1: U1 | U2 | S1 | S2
-  if (active) {
-    if (role == 0) {
+  const bool run = __ballot(active) != 0;  // wave-uniform
+  // stage 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
+  if (run) {
+    if (active && role == 0) {
       int f = 0;
       if (xyzz_is_identity(*P)) {
         L.fix[i] = *Q;
@@ -284,59 +317,53 @@ __device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t*
         f = 1;
       }
       L.flag[i] = f;
-      t[0][i] = fe_mul<B>(P->x, Q->zz);
-    } else if (role == 1) {
-      t[1][i] = fe_mul<B>(Q->x, P->zz);
-    } else if (role == 2) {
-      t[2][i] = fe_mul<B>(P->y, Q->zzz);
+    }
+    const xyzz_t* a = (role & 1) ? Q : P;
+    const xyzz_t* b = (role & 1) ? P : Q;
+    const fe_t* xp = (role & 2) ? &a->y : &a->x;
+    const fe_t* yp = (role & 2) ? &b->zzz : &b->zz;
+    t[role][i] = fe_mul<B>(*xp, *yp);
+  }
+  SP_STAGE_STAMP();
+  __syncthreads();
+  // stage 2: PP = (U2 - U1)^2, P kept | RR = (S2 - S1)^2, R kept | ZZ1 ZZ2 | ZZZ1 ZZZ2
+  if (run) {
+    fe_t x, y;
+    if (role < 2) {
+      x = fe_sub<B>(t[2 * role + 1][i], t[2 * role][i]);
+      t[2 * role + 1][i] = x;
+      y = x;
     } else {
-      t[3][i] = fe_mul<B>(Q->y, P->zzz);
+      x = *((role & 1) ? &P->zzz : &P->zz);
+      y = *((role & 1) ? &Q->zzz : &Q->zz);
     }
+    t[4 + role][i] = fe_mul<B>(x, y);
   }
+  SP_STAGE_STAMP();
   __syncthreads();
-  // level 2: PP (and P) | RR (and R) | ZZ1 ZZ2 | ZZZ1 ZZZ2
-  if (active) {
-    if (role == 0) {
-      const fe_t pd = fe_sub<B>(t[1][i], t[0][i]);
-      t[4][i] = fe_sqr<B>(pd);
-      t[1][i] = pd;
-    } else if (role == 1) {
-      const fe_t rd = fe_sub<B>(t[3][i], t[2][i]);
-      t[5][i] = fe_sqr<B>(rd);
-      t[3][i] = rd;
-    } else if (role == 2) {
-      t[6][i] = fe_mul<B>(P->zz, Q->zz);
-    } else {
-      t[7][i] = fe_mul<B>(P->zzz, Q->zzz);
+  // stage 3: PPP = P PP (+ the P = +-Q case) | Q = U1 PP | ZZ3 = ZZ1 ZZ2 PP
+  if (run && role < 3) {
+    if (role == 0 && active && __builtin_expect(fe_is_zero(t[1][i]) && !L.flag[i], 0)) {
+      L.fix[i] = fe_is_zero(t[3][i]) ? xyzz_dbl(*P) : xyzz_identity();
+      L.flag[i] = 1;
     }
+    const int xi = role == 0 ? 1 : role == 1 ? 0 : 6, oi = role == 0 ? 8 : role == 1 ? 0 : 6;
+    t[oi][i] = fe_mul<B>(t[xi][i], t[4][i]);
   }
+  SP_STAGE_STAMP();
   __syncthreads();
-  // level 3: PPP (+ the P = +-Q case) | Q | ZZ3
-  if (active) {
+  // stage 4: R (Q - X3) | S1 PPP | ZZZ3 = ZZZ1 ZZZ2 PPP
+  if (run && role < 3) {
+    const int xi = role == 0 ? 3 : role == 1 ? 2 : 7, oi = role == 0 ? 1 : role == 1 ? 4 : 7;
+    fe_t y = t[8][i];
     if (role == 0) {
-      if (fe_is_zero(t[1][i]) && !L.flag[i]) {
-        L.fix[i] = fe_is_zero(t[3][i]) ? xyzz_from_jac(jac_dbl(xyzz_to_jac(*P))) : xyzz_identity();
-        L.flag[i] = 1;
-      }
-      t[8][i] = fe_mul<B>(t[1][i], t[4][i]);
-    } else if (role == 1) {
-      t[0][i] = fe_mul<B>(t[0][i], t[4][i]);
-    } else if (role == 2) {
-      t[6][i] = fe_mul<B>(t[6][i], t[4][i]);
+      const fe_t q = t[0][i];
+      const fe_t x3 = fe_sub<B>(fe_sub<B>(t[5][i], y), fe_dbl<B>(q));
+      y = fe_sub<B>(q, x3);
     }
+    t[oi][i] = fe_mul<B>(t[xi][i], y);
   }
-  __syncthreads();
-  // level 4: R (Q - X3) | S1 PPP | ZZZ3
-  if (active) {
-    if (role == 0) {
-      const fe_t x3 = fe_sub<B>(fe_sub<B>(t[5][i], t[8][i]), fe_dbl<B>(t[0][i]));
-      t[1][i] = fe_mul<B>(t[3][i], fe_sub<B>(t[0][i], x3));
-    } else if (role == 1) {
-      t[4][i] = fe_mul<B>(t[2][i], t[8][i]);
-    } else if (role == 2) {
-      t[7][i] = fe_mul<B>(t[7][i], t[8][i]);
-    }
-  }
+  SP_STAGE_STAMP();
   __syncthreads();
   if (active && role == 0) {
     xyzz_t r;
@@ -772,20 +799,35 @@ __global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const
   const int role = (wave + 2 * blk) & 3, k = blk * 64 + (threadIdx.x & 63);
   const size_t idx = (size_t)blockIdx.x * (ITEMS / PER) + (k / PER);
   const int j = k % PER;
+  SP_STAMP(0);
+#ifdef SP_KERNEL_STAMPS
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) sp_hwid[threadIdx.x >> 6] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+  {
+    const unsigned long long w0 = wall_clock64();
+    while (wall_clock64() - w0 < sp_predelay) __builtin_amdgcn_s_sleep(8);
+  }
+  SP_STAMP(0);
+#endif
   if (role == 0) {
     xyzz_t acc = xyzz_identity();
     if (idx < n) {
       const fe_t c = fe_to_canonical<SF>(scalars[idx]);
+      SP_STAMP(1);
       const unsigned digit = WBITS == 8 ? (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu : (c.v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
       if (digit) acc = xyzz_from_affine(tables[(idx % ntables) * (PER * WIN) + (size_t)j * WIN + digit - 1]);
     }
     s[k] = acc;
   }
   __syncthreads();
+  SP_STAMP(2);
+  int lvl = 0;
   for (int off = PER / 2; off >= 1; off >>= 1) {
     const bool active = j < off;
     xyzz_add_block4<ITEMS>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
+    ++lvl;
+    SP_STAMP(2 + lvl);
   }
+  (void)lvl;
   if (role == 0 && j == 0 && idx < n) {
     constexpr int D = XYZZ_OUT ? 32 : 24;
     unsigned rw[32];
@@ -811,6 +853,7 @@ __global__ void __launch_bounds__(4 * ITEMS) k_fixed_base_rows_coop_mapped(const
     const unsigned long long lo = ((unsigned long long)a << 32) | seq, hi = ((unsigned long long)seq << 32) | b;
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + FB_SLOT_TAG + 2), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(slot + FB_SLOT_TAG), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    SP_STAMP(20);
   }
 }
 

@@ -40,6 +40,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        # One HIP runtime per process. torch ships its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's); whichever copy is mapped first
+        # serves both. Mapped in the other order - this library (-> /opt/rocm) first, torch second - the process ends up with two ROCr instances and the
+        # one initialised second sees no device ("no ROCm-capable device is detected"), so torch goes first wherever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         L.sp_last_error.restype = ctypes.c_char_p
         _lib = L
