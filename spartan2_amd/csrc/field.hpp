@@ -335,8 +335,76 @@ inline fe_t fe_mul_host64(const fe_t& a, const fe_t& b) {
 }
 #endif
 
+// ---- product-scanning Montgomery product for the generic-modulus field (FpP) ----------------------------------------------------------------------
+// Column k of the product and of the reduction is accumulated in ONE 96-bit register triple: every term is a v_mad_u64_u32 into the low 64 bits
+// whose carry-out (VCC) goes into the third word with a v_addc - two instructions per term, no zero-extended addend pairs to prepare. The compiler
+// cannot produce this form (it never uses the multiply-add's carry-out: a 96-bit accumulate written in C costs four instructions per term), and
+// its row-wise product + word-serial reduction came to 444 instructions per base-field product (104 multiply-adds, 138 carry adds, 84 register
+// moves for the {word, 0} addends, 36 hazard nops) on a part that issues about one instruction of a lone wave every four cycles whatever it is.
+// One asm statement per COLUMN (the compiler puts a wait state behind every asm statement whose result the next instruction reads); the terms with
+// the base prime's zero word (word 5) are left out.
+struct acc96_t {
+  uint64_t lo;
+  uint32_t hi;
+};
+SP_HD void acc96_shift(acc96_t& a) {
+  a.lo = (a.lo >> 32) | ((uint64_t)a.hi << 32);
+  a.hi = 0;
+}
+#if !defined(__HIP_DEVICE_COMPILE__)
+// the algorithm in plain C (host only): what the unit test checks against the 64-bit CIOS product; the device form is generated (tools/gen_fips_mul.py)
+template <class FP>
+inline fe_t fe_mul_fips(const fe_t& a, const fe_t& b) {
+  acc96_t acc = {0, 0};
+  auto mac = [&acc](uint32_t x, uint32_t y) {
+    const unsigned __int128 t = (((unsigned __int128)acc.hi << 64) | acc.lo) + (uint64_t)x * y;
+    acc.lo = (uint64_t)t;
+    acc.hi = (uint32_t)(t >> 64);
+  };
+  uint32_t m[8], r[8];
+  for (int i = 0; i < 15; ++i) {
+    const int j0 = i < 8 ? 0 : i - 7, j1 = i < 8 ? i : 7;
+    for (int j = j0; j <= j1; ++j) mac(a.v[j], b.v[i - j]);
+    for (int j = j0; j <= j1; ++j)
+      if (!(i < 8 && j == i)) mac(m[j], FP::P(i - j));
+    if (i < 8) {
+      m[i] = (uint32_t)acc.lo * FP::INV32;
+      mac(m[i], FP::P(0));  // the low word becomes 0
+    } else {
+      r[i - 8] = (uint32_t)acc.lo;
+    }
+    acc96_shift(acc);
+  }
+  r[7] = (uint32_t)acc.lo;
+  return fe_cond_sub_p<FP>(r, (uint32_t)(acc.lo >> 32));
+}
+#endif
+#include "field_fips_device.hpp"
+
 template <class FP>
 SP_HD fe_t fe_mul(const fe_t& a, const fe_t& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return fe_mul_host64<FP>(a, b);
+#else
+#ifdef SP_ROWWISE_BASE_PRODUCT  // A/B switch for tools/fb_stamps.hip and tools/ubench.hip: the compiler-scheduled row-wise product + word-serial reduction
+  if constexpr (true) {
+#else
+  if constexpr (FP::P256_PRIME) {
+#endif
+    uint32_t t[16];
+    fe_mul_wide(t, a, b);
+    return fe_redc<FP>(t);
+  } else {
+    return fe_mul_fips_device<FP>(a, b);
+  }
+#endif
+}
+// The row-wise product + word-serial reduction whatever the field: the form the compiler schedules itself. The block-cooperative point addition keeps
+// it for the base field too - there a level is 4.75 us with this form and 5.4 us with the asm column blocks (which the scheduler cannot interleave
+// with the LDS traffic of a stage), while every throughput kernel gains from the shorter instruction stream (tools/ubench: 116 -> 134-140 G products/s,
+// the config-4 commitment 10.6 -> 9.2 ms).
+template <class FP>
+SP_HD fe_t fe_mul_rowwise(const fe_t& a, const fe_t& b) {
 #if !defined(__HIP_DEVICE_COMPILE__)
   return fe_mul_host64<FP>(a, b);
 #else

@@ -27,10 +27,14 @@ __device__ unsigned long long sp_stamps[192];
 __device__ unsigned sp_stage_ctr[4];
 __device__ unsigned sp_hwid[4];
 __device__ unsigned sp_predelay;  // 10 ns ticks every wave spins for before it starts (is the slow phase tied to time since launch or to the tree level?)
+#ifdef SP_KERNEL_STAGE_STAMPS  // (each stage stamp costs a global counter round trip: only for looking inside a level, not for timing one)
 #define SP_STAGE_STAMP()                                                          \
   do {                                                                            \
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) sp_stamps[64 + 32 * (threadIdx.x >> 6) + (sp_stage_ctr[threadIdx.x >> 6]++ & 31)] = wall_clock64(); \
   } while (0)
+#else
+#define SP_STAGE_STAMP()
+#endif
 #else
 #define SP_STAMP(i)
 #define SP_STAGE_STAMP()
@@ -322,7 +326,7 @@ __device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t*
     const xyzz_t* b = (role & 1) ? P : Q;
     const fe_t* xp = (role & 2) ? &a->y : &a->x;
     const fe_t* yp = (role & 2) ? &b->zzz : &b->zz;
-    t[role][i] = fe_mul<B>(*xp, *yp);
+    t[role][i] = fe_mul_rowwise<B>(*xp, *yp);
   }
   SP_STAGE_STAMP();
   __syncthreads();
@@ -337,7 +341,7 @@ __device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t*
       x = *((role & 1) ? &P->zzz : &P->zz);
       y = *((role & 1) ? &Q->zzz : &Q->zz);
     }
-    t[4 + role][i] = fe_mul<B>(x, y);
+    t[4 + role][i] = fe_mul_rowwise<B>(x, y);
   }
   SP_STAGE_STAMP();
   __syncthreads();
@@ -348,7 +352,7 @@ __device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t*
       L.flag[i] = 1;
     }
     const int xi = role == 0 ? 1 : role == 1 ? 0 : 6, oi = role == 0 ? 8 : role == 1 ? 0 : 6;
-    t[oi][i] = fe_mul<B>(t[xi][i], t[4][i]);
+    t[oi][i] = fe_mul_rowwise<B>(t[xi][i], t[4][i]);
   }
   SP_STAGE_STAMP();
   __syncthreads();
@@ -361,7 +365,7 @@ __device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t*
       const fe_t x3 = fe_sub<B>(fe_sub<B>(t[5][i], y), fe_dbl<B>(q));
       y = fe_sub<B>(q, x3);
     }
-    t[oi][i] = fe_mul<B>(t[xi][i], y);
+    t[oi][i] = fe_mul_rowwise<B>(t[xi][i], y);
   }
   SP_STAGE_STAMP();
   __syncthreads();

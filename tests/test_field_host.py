@@ -17,3 +17,24 @@ def test_host_inversion_matches_fermat(tmp_path):
     out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "scalar field: 20000 samples, 0 mismatches" in out.stdout and "base field: 20000 samples, 0 mismatches" in out.stdout
+
+
+def _build_mul_check(tmp_path):
+    exe = str(tmp_path / "mul_check")
+    subprocess.run(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-w", "-o", exe, os.path.join(HERE, "native", "mul_check.hip")], check=True, capture_output=True, timeout=600)
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_product_scanning_base_field_product_on_the_host(tmp_path):
+    """The base-field product the kernels use (column-wise 96-bit accumulation, field.hpp / field_fips_device.hpp) in its plain-C form and the 32-bit
+    row-wise form against the 64-bit CIOS product: edge values and seeded random residues."""
+    out = subprocess.run([_build_mul_check(tmp_path), "host", "50000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "host: 0 mismatches in 50000 products" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_product_scanning_base_field_product_on_the_device(tmp_path):
+    """The generated asm column blocks on the device (a lone wave, then full blocks; single products and 64-deep dependent chains) against the host."""
+    out = subprocess.run([_build_mul_check(tmp_path), "device", "100000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "device: 0 mismatches in 100064 lanes" in out.stdout, out.stdout + out.stderr

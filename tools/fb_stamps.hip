@@ -196,6 +196,7 @@ int main() {
            (s[2] - s[0]) / 100.0);
     for (int l = 1; l <= 4; ++l) printf(", level %d +%.2f", l, (s[2 + l] - s[0]) / 100.0);
     printf(", slot stored +%.2f us\n", (s[20] - s[0]) / 100.0);
+#ifdef SP_KERNEL_STAGE_STAMPS
     {
       unsigned ctr[4], hw[4];
       CK(hipMemcpyFromSymbol(ctr, HIP_SYMBOL(sp_stage_ctr), 16));
@@ -208,6 +209,7 @@ int main() {
         printf("\n");
       }
     }
+#endif
     printf("       shader clock per level (cycles / us = MHz):");
     for (int l = 1; l <= 4; ++l) printf(" %llu / %.2f = %.0f", s[32 + 2 + l] - s[32 + 1 + l], (s[2 + l] - s[1 + l]) / 100.0, (s[32 + 2 + l] - s[32 + 1 + l]) / ((s[2 + l] - s[1 + l]) / 100.0));
     printf("\n");
