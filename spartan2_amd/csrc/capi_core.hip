@@ -1371,6 +1371,88 @@ static int eval_cubic_outer_pow_pair(sp_ctx* c, const sp_table* pl, const sp_tab
   return 1;
 }
 
+// Small tables (<= 2^13 elements): the bind of round i and the evaluation of round i + 1 of both instances in one launch with one product per lane
+// (k_bind_eval_*_pair_small); dense tables of equal length only. Returns 1 when done (the tables are bound and `sums` holds the next round's), 0 when
+// this form does not apply (the caller binds and evaluates separately), < 0 on error. SPARTAN_BATCHED_SMALL=0: never.
+static bool batched_small_enabled() {
+  const char* e = getenv("SPARTAN_BATCHED_SMALL");
+  return !(e && e[0] == '0');
+}
+static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* const B[2], const fe_t& r, fe_t sums[2][2]) {
+  const size_t len = A[0]->len;
+  if (!batched_small_enabled() || len < 4) return 0;
+  for (int b = 0; b < 2; ++b)
+    if (A[b]->len != len || B[b]->len != len || !table_dense(A[b]) || !table_dense(B[b])) return 0;
+  const size_t q = len / 4, nb = (q + spk::SMALL_PAIR_PPB - 1) / spk::SMALL_PAIR_PPB;
+  if (2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS) return 0;
+  spk::QuadPairBindArgs t;
+  for (int b = 0; b < 2; ++b) {
+    t.A[b] = A[b]->d;
+    t.B[b] = B[b]->d;
+  }
+  const unsigned seq = next_seq(c);
+  c->timed("bind_eval_quad_pair_small", 2 * 192ull * q,
+           [&] { hipLaunchKernelGGL(spk::k_bind_eval_quad_pair_small, dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, t, (unsigned)q, (unsigned)nb, r, c->d_pinned, seq); });
+  for (int b = 0; b < 2; ++b) {
+    sp::after_bind(A[b]);
+    sp::after_bind(B[b]);
+  }
+  c->pending_slots = (unsigned)(2 * nb);
+  fe_t out[4];
+  int rc = reduce_partials_wait(c, 2, out, false, 2);
+  if (rc) return rc;
+  sums[0][0] = out[0];
+  sums[0][1] = out[1];
+  sums[1][0] = out[2];
+  sums[1][1] = out[3];
+  return 1;
+}
+static int bind_eval_cubic_pow_pair_small(sp_ctx* c, const sp_table* pl, const sp_table* pr, sp_table* const step[3], sp_table* const core[3], const fe_t& r,
+                                          fe_t sums[2][3]) {
+  const size_t len = step[0]->len, left = pl->len;
+  if (!batched_small_enabled() || len < 4) return 0;
+  for (int k = 0; k < 3; ++k)
+    if (step[k]->len != len || core[k]->len != len || !table_dense(step[k]) || !table_dense(core[k])) return 0;
+  const size_t q = len / 4, nb = (q + spk::SMALL_PAIR_PPB - 1) / spk::SMALL_PAIR_PPB;
+  if (2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS) return 0;
+  const bool fallback = q < left;  // as eval_cubic_outer_pow_pair, for q pairs
+  size_t right = 0;
+  if (fallback) {
+    if (left < 2 * q) return 0;
+  } else {
+    if (left == 0 || q % left) return 0;
+    right = q / left;
+    if (pr->len < 2 * right) return 0;
+  }
+  spk::CubicPairBindArgs t;
+  for (int b = 0; b < 2; ++b) {
+    sp_table* const* tb = b == 0 ? step : core;
+    t.A[b] = tb[0]->d;
+    t.B[b] = tb[1]->d;
+    t.C[b] = tb[2]->d;
+  }
+  const unsigned seq = next_seq(c);
+  c->timed("bind_eval_cubic_pow_pair_small", 2 * 288ull * q, [&] {
+    if (fallback)
+      hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<true>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr ? pr->d : nullptr, right, t, (unsigned)q,
+                         (unsigned)nb, r, c->d_pinned, seq);
+    else
+      hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<false>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr->d, right, t, (unsigned)q, (unsigned)nb, r,
+                         c->d_pinned, seq);
+  });
+  for (int k = 0; k < 3; ++k) {
+    sp::after_bind(step[k]);
+    sp::after_bind(core[k]);
+  }
+  c->pending_slots = (unsigned)(2 * nb);
+  fe_t out[6];
+  int rc = reduce_partials_wait(c, 3, out, false, 2);
+  if (rc) return rc;
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 3; ++k) sums[b][k] = out[3 * b + k];
+  return 1;
+}
+
 // prove_quad_batched_zk (src/sumcheck.rs:702-782): two quadratic sum-checks (step, core) driven by one challenge per round; the challenge
 // comes from the caller's `process_round` hook (:747-755).
 int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_rounds, sp_table* A0, sp_table* A1, sp_table* B0, sp_table* B1, size_t start_round,
@@ -1379,13 +1461,14 @@ int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_ro
   if (A0->len != n || A1->len != n || B0->len != n || B1->len != n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad_batched: tables must have 2^num_rounds elements");
   fe_t claim[2] = {load_fe(claims_), load_fe(claims_ + 4)};
   sp_table* br[2][2] = {{A0, B0}, {A1, B1}};
+  bool have_next = false;  // `both` already holds this round's sums (the previous round's fused bind + evaluate)
+  fe_t both[2][2];
   for (size_t j = 0; j < num_rounds; ++j) {
     UniPoly poly[2];
     uint64_t co[2][12];
-    fe_t both[2][2];
     sp_table* const pa[2] = {A0, A1};
     sp_table* const pb[2] = {B0, B1};
-    const int paired = eval_quad_sums_pair(c, pa, pb, both);
+    const int paired = have_next ? 1 : eval_quad_sums_pair(c, pa, pb, both);
     if (paired < 0) return paired;
     for (int b = 0; b < 2; ++b) {
       fe_t sums[2];
@@ -1407,11 +1490,19 @@ int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_ro
     if (hrc) return fail(hrc, "prove_quad_batched: the round hook failed");
     const fe_t r_j = load_fe(r_raw);
     store_fe(out_r + 4 * j, r_j);
-    sp_table* tabs[4] = {A0, B0, A1, B1};
-    int rc = launch_bind(c, tabs, 4, r_j);
-    if (rc) return rc;
     claim[0] = poly_eval(poly[0], r_j);
     claim[1] = poly_eval(poly[1], r_j);
+    have_next = false;
+    if (j + 1 < num_rounds) {
+      const int fused = bind_eval_quad_pair_small(c, pa, pb, r_j, both);
+      if (fused < 0) return fused;
+      have_next = fused == 1;
+    }
+    if (!have_next) {
+      sp_table* tabs[4] = {A0, B0, A1, B1};
+      int rc = launch_bind(c, tabs, 4, r_j);
+      if (rc) return rc;
+    }
   }
   sp_table* fin[4] = {A0, A1, B0, B1};
   for (int q = 0; q < 4; ++q) {
@@ -1445,12 +1536,13 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
     return e && e[0] == '2';
   }();
   auto nowus = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  bool have_next = false;  // `both` already holds this round's sums (the previous round's fused bind + evaluate)
+  fe_t both[2][3];
   for (size_t i = 0; i < num_rounds; ++i) {
     UniPoly poly[2];
     uint64_t co[2][16];
-    fe_t both[2][3];
     const double tr0 = trace ? nowus() : 0;
-    const int paired = eval_cubic_outer_pow_pair(c, pow_left, pow_right, step, core, both);
+    const int paired = have_next ? 1 : eval_cubic_outer_pow_pair(c, pow_left, pow_right, step, core, both);
     const double tr1 = trace ? nowus() : 0;
     if (paired < 0) return paired;
     for (int b = 0; b < 2; ++b) {
@@ -1472,8 +1564,18 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
     store_fe(out_r + 4 * i, r_i);
     claim[0] = poly_eval(poly[0], r_i);
     claim[1] = poly_eval(poly[1], r_i);
-    sp_table* t6[6] = {A_step, A_core, B_step, B_core, C_step, C_core};
-    if ((rc = launch_bind(c, t6, 6, r_i))) return rc;
+    have_next = false;
+    if (i + 1 < num_rounds) {
+      const double tf0 = trace ? nowus() : 0;
+      const int fused = bind_eval_cubic_pow_pair_small(c, pow_left, pow_right, step, core, r_i, both);
+      if (fused < 0) return fused;
+      have_next = fused == 1;
+      if (trace) fprintf(stderr, "outer batched round %zu: bind + next evaluation in one launch %s, %.1f us\n", i, have_next ? "taken" : "not applicable", nowus() - tf0);
+    }
+    if (!have_next) {
+      sp_table* t6[6] = {A_step, A_core, B_step, B_core, C_step, C_core};
+      if ((rc = launch_bind(c, t6, 6, r_i))) return rc;
+    }
     len_pow_tau >>= 1;
     const fe_t pw = fe_mul<S>(pl[len_pow_tau % left], pr[len_pow_tau / left]);
     base_tau = fe_mul<S>(base_tau, fe_add<S>(fe_mul<S>(fe_sub<S>(pw, one), r_i), one));

@@ -716,6 +716,108 @@ __global__ void __launch_bounds__(256) k_eval_quad_pair(QuadPairArgs t, size_t h
   if (threadIdx.x == 0) emit_partials<2>(acc, nullptr, mapped, seq);
 }
 
+// ---- batched NeutronNova rounds on SMALL tables: the previous round's bind and this round's evaluation in one launch, one product per lane ----------
+// From 2^13 elements down a batched round is pure latency: bind launch (6.7 us) -> evaluation launch (17 us: every lane runs the two weight products,
+// three evaluation points of two products each and the modular block tree one after the other) -> wait, ~25 us whatever the size. Here a block owns
+// <= 64 pairs of one instance: phase A gives every lane ONE bind (or one weight product) - 8 kinds x pairs items, the bound elements go to memory and
+// to LDS -, phase B gives every lane ONE evaluation point of one pair (two dependent products; wave w = point w, so a wave sum finishes it), and
+// each block's three sums land in a host slot of their own. Dependent chain: 1 + 2 products instead of ~15.
+// q = pairs of the round being evaluated = a quarter of the tables' length before the bind; new element x comes from old x and x + 2q.
+constexpr int SMALL_PAIR_PPB = 64;  // pairs per block
+struct CubicPairBindArgs {
+  fe_t *A[2], *B[2], *C[2];
+};
+template <bool FALLBACK>
+__global__ void __launch_bounds__(256) k_bind_eval_cubic_pow_pair_small(const fe_t* __restrict__ pleft, size_t left, const fe_t* __restrict__ pright, size_t right,
+                                                                        CubicPairBindArgs t, unsigned q, unsigned nb, fe_t r, fe_t* __restrict__ mapped, unsigned seq) {
+  __shared__ fe_t sh[8][SMALL_PAIR_PPB];  // bound A lo/hi, B lo/hi, C lo/hi, weight lo/hi
+  __shared__ fe_t sums[3];
+  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb, base = bx * SMALL_PAIR_PPB;
+  const unsigned np = q - base < (unsigned)SMALL_PAIR_PPB ? q - base : (unsigned)SMALL_PAIR_PPB;
+  for (unsigned i = threadIdx.x; i < 8 * (unsigned)SMALL_PAIR_PPB; i += blockDim.x) {
+    const unsigned kind = i / SMALL_PAIR_PPB, p = i % SMALL_PAIR_PPB;  // kind is wave-uniform
+    if (p >= np) continue;
+    const unsigned low = base + p;
+    fe_t v;
+    if (kind < 6) {
+      fe_t* __restrict__ T = kind < 2 ? t.A[inst] : kind < 4 ? t.B[inst] : t.C[inst];
+      const size_t idx = (size_t)low + (kind & 1u) * (size_t)q;
+      v = bind1(T[idx], T[idx + 2 * (size_t)q], r);
+      T[idx] = v;
+    } else if (FALLBACK) {
+      v = pleft[low + (kind & 1u) * q];
+    } else {
+      v = fe_mul<S>(pleft[low % left], pright[low / left + (kind & 1u) * right]);
+    }
+    sh[kind][p] = v;
+  }
+  __syncthreads();
+  const unsigned pt = threadIdx.x >> 6, p = threadIdx.x & 63u;
+  fe_t v = fe_zero();
+  if (pt < 3 && p < np) {
+    fe_t a = sh[0][p], b = sh[2][p], c = sh[4][p], w = sh[6][p];
+    if (pt) {  // the point 2 (3): 2 hi - lo (3 hi - 2 lo)
+      const fe_t ah = sh[1][p], bh = sh[3][p], ch = sh[5][p], wh = sh[7][p];
+      fe_t a2 = fe_sub<S>(fe_dbl<S>(ah), a), b2 = fe_sub<S>(fe_dbl<S>(bh), b), c2 = fe_sub<S>(fe_dbl<S>(ch), c), w2 = fe_sub<S>(fe_dbl<S>(wh), w);
+      if (pt == 2) {
+        a2 = fe_sub<S>(fe_add<S>(a2, ah), a);
+        b2 = fe_sub<S>(fe_add<S>(b2, bh), b);
+        c2 = fe_sub<S>(fe_add<S>(c2, ch), c);
+        w2 = fe_sub<S>(fe_add<S>(w2, wh), w);
+      }
+      a = a2;
+      b = b2;
+      c = c2;
+      w = w2;
+    }
+    v = fe_mul<S>(w, fe_sub<S>(fe_mul<S>(a, b), c));
+  }
+  if (pt < 3) {
+    v = wave_sum(v);
+    if (p == 0) sums[pt] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const fe_t acc[3] = {sums[0], sums[1], sums[2]};
+    emit_partials<3>(acc, nullptr, mapped, seq);  // gridDim.x <= HOST_SUM_MAX_BLOCKS by construction: the slot path
+  }
+}
+struct QuadPairBindArgs {
+  fe_t *A[2], *B[2];
+};
+__global__ void __launch_bounds__(256) k_bind_eval_quad_pair_small(QuadPairBindArgs t, unsigned q, unsigned nb, fe_t r, fe_t* __restrict__ mapped, unsigned seq) {
+  __shared__ fe_t sh[4][SMALL_PAIR_PPB];  // bound A lo/hi, B lo/hi
+  __shared__ fe_t sums[2];
+  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb, base = bx * SMALL_PAIR_PPB;
+  const unsigned np = q - base < (unsigned)SMALL_PAIR_PPB ? q - base : (unsigned)SMALL_PAIR_PPB;
+  {
+    const unsigned kind = threadIdx.x / SMALL_PAIR_PPB, p = threadIdx.x % SMALL_PAIR_PPB;  // 4 kinds x 64 pairs = the block
+    if (p < np) {
+      fe_t* __restrict__ T = kind < 2 ? t.A[inst] : t.B[inst];
+      const size_t idx = (size_t)(base + p) + (kind & 1u) * (size_t)q;
+      const fe_t v = bind1(T[idx], T[idx + 2 * (size_t)q], r);
+      T[idx] = v;
+      sh[kind][p] = v;
+    }
+  }
+  __syncthreads();
+  const unsigned pt = threadIdx.x >> 6, p = threadIdx.x & 63u;
+  fe_t v = fe_zero();
+  if (pt < 2 && p < np) {
+    const fe_t a0 = sh[0][p], b0 = sh[2][p];
+    v = pt == 0 ? fe_mul<S>(a0, b0) : fe_mul<S>(fe_sub<S>(sh[1][p], a0), fe_sub<S>(sh[3][p], b0));
+  }
+  if (pt < 2) {
+    v = wave_sum(v);
+    if (p == 0) sums[pt] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const fe_t acc[2] = {sums[0], sums[1]};
+    emit_partials<2>(acc, nullptr, mapped, seq);
+  }
+}
+
 // dot product of the first n elements (value of DelayedReduction::reduce(sum a_i b_i))
 __global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t n, fe_t* __restrict__ partials,
                                              fe_t* __restrict__ single_out, unsigned seq) {
