@@ -164,6 +164,63 @@ __global__ void __launch_bounds__(256) k_polyabc_long(PolyAbcArgs a, const fe_t*
     for (int i = 0; i < 3; ++i) partials[((size_t)blockIdx.y * LONG_NB_MAX + blockIdx.x) * 3 + i] = acc[i];
   }
 }
+// The three kernels above in ONE launch: blocks [0, LONG_NB_MAX * n_long) are the long columns' (they are dispatched first and run under the short
+// columns' blocks instead of 17-24 us behind them on the path of the inner sum-check's first round), the rest walk the short columns. The last block
+// of a long column to arrive (one counter per column, <= 128 arrivals, partial triples stored write-through and read back past this XCD's L2) adds the
+// column's partials and applies (1, r, r^2) - k_polyabc_long_final's work, also under the short columns.
+__global__ void __launch_bounds__(256) k_polyabc_short_and_long(PolyAbcArgs a, const fe_t* __restrict__ rx, const unsigned* __restrict__ order, size_t n_short,
+                                                                fe_t* __restrict__ out, const unsigned* __restrict__ long_cols, unsigned n_long,
+                                                                fe_t* __restrict__ partials, unsigned* __restrict__ tickets) {
+  __shared__ fe_t smem[3 * 4];
+  __shared__ unsigned s_last;
+  const unsigned long_blocks = LONG_NB_MAX * n_long;
+  if (blockIdx.x < long_blocks) {
+    const unsigned by = blockIdx.x / LONG_NB_MAX, bx = blockIdx.x % LONG_NB_MAX;
+    const size_t col = long_cols[by];
+    const unsigned nb = long_nb(col_len(a, col));
+    if (bx >= nb) return;
+    fe_t acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[i] = gather_major(a.m[i], col, rx, bx * blockDim.x + threadIdx.x, nb * blockDim.x);
+    block_sum<3>(acc, smem);
+    fe_t* trip = partials + ((size_t)by * LONG_NB_MAX) * 3;
+    if (threadIdx.x == 0) {
+      unsigned* dst = reinterpret_cast<unsigned*>(trip + (size_t)bx * 3);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) __hip_atomic_store(dst + 8 * i + w, acc[i].v[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are acknowledged before the ticket is taken
+      s_last = __hip_atomic_fetch_add(tickets + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      acc[i] = fe_zero();
+      if (threadIdx.x < nb) {
+        const unsigned* src = reinterpret_cast<const unsigned*>(trip + (size_t)threadIdx.x * 3 + i);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc[i].v[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();  // smem reuse
+    block_sum<3>(acc, smem);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(tickets + by, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      out[col] = fe_add<S>(fe_add<S>(acc[0], fe_mul<S>(a.r, acc[1])), fe_mul<S>(a.r2, acc[2]));
+    }
+    return;
+  }
+  const size_t nblk = gridDim.x - long_blocks;
+  for (size_t i = (size_t)(blockIdx.x - long_blocks) * blockDim.x + threadIdx.x; i < n_short; i += nblk * blockDim.x) {
+    const size_t col = order[i];
+    fe_t sa = gather_major_x4(a.m[0], col, rx), sb = gather_major_x4(a.m[1], col, rx), sc = gather_major_x4(a.m[2], col, rx);
+    if (!fe_is_zero(sb)) sa = fe_add<S>(sa, fe_mul<S>(a.r, sb));
+    if (!fe_is_zero(sc)) sa = fe_add<S>(sa, fe_mul<S>(a.r2, sc));
+    out[col] = sa;
+  }
+}
 __global__ void __launch_bounds__(256) k_polyabc_long_final(PolyAbcArgs a, const unsigned* __restrict__ long_cols, const fe_t* __restrict__ partials,
                                                             fe_t* __restrict__ out) {
   __shared__ fe_t smem[3 * 4];
@@ -476,6 +533,7 @@ struct sp_shape {
   unsigned* d_short_order = nullptr;  // short columns by decreasing entry count (k_polyabc_short)
   size_t n_short = 0;
   fe_t* d_long_partials = nullptr;
+  unsigned* d_long_tickets = nullptr;  // one arrival counter per long column (k_polyabc_short_and_long), zero between launches
   size_t n_long_cols = 0;
   uint64_t nnz[3] = {0, 0, 0}, nnz_filtered[3] = {0, 0, 0};
   // sliced-ELL copy of the short columns (kernels above: EllDev)
@@ -681,6 +739,9 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     }
   }
   SP_HIP(hipMalloc((void**)&s->d_long_partials, (long_cols.size() + 1) * spk::LONG_NB_MAX * 3 * sizeof(fe_t)));
+  SP_HIP(hipMalloc((void**)&s->d_long_tickets, (long_cols.size() + 1) * sizeof(unsigned)));
+  SP_HIP(hipMemset(s->d_long_tickets, 0, (long_cols.size() + 1) * sizeof(unsigned)));
+  SP_HIP(hipDeviceSynchronize());
   *out = s;
   return SP_OK;
 }
@@ -694,6 +755,7 @@ void sp_shape_free(sp_shape* s) {
   hipFree(s->d_long_cols);
   hipFree(s->d_short_order);
   hipFree(s->d_long_partials);
+  hipFree(s->d_long_tickets);
   if (s->d_ell_meta) hipFree(s->d_ell_meta);
   if (s->d_ell_row) hipFree(s->d_ell_row);
   if (s->d_ell_src) hipFree(s->d_ell_src);
@@ -788,13 +850,18 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
   // SPARTAN_POLYABC_ELL=1: the short columns from the sliced-ELL copy (k_polyabc_ell_onepass) instead of the column-major walk. Measured equal at config 2
   // (97.6 - 100.8 us against 101.4 - 102.0 us): with coalesced index loads and three dependent memory rounds instead of nine the kernel still takes
   // ~100 us, like the split form's final pass without any large gather - the time is the serial latency of a wave's steps at 4 waves per SIMD. Opt-in.
+  const char* merged_env = getenv("SPARTAN_POLYABC_MERGED");  // "0": the long columns' blocks in a launch of their own behind the short columns' (rounds 1-3)
   const char* ell_env = getenv("SPARTAN_POLYABC_ELL");
   const bool ell_onepass = ell_env && ell_env[0] == '1';
   c->timed("poly_abc", bytes, [&] {
     if (ell_onepass && s->d_ell_cls && s->ell_slots && s->n_short)
       hipLaunchKernelGGL(spk::k_polyabc_ell_onepass, dim3((unsigned)((s->n_short + 255) / 256)), dim3(256), 0, c->stream, ell_view(s), s->d_ell_cls, s->d_ell_gtab, rx->d,
                          s->d_short_order, s->n_short, a.r, a.r2, out->d);
-    else
+    else if (s->n_long_cols && s->n_long_cols <= 64 && !(merged_env && merged_env[0] == '0')) {
+      hipLaunchKernelGGL(spk::k_polyabc_short_and_long, dim3((unsigned)(blocks + spk::LONG_NB_MAX * s->n_long_cols)), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short,
+                         out->d, s->d_long_cols, (unsigned)s->n_long_cols, s->d_long_partials, s->d_long_tickets);
+      return;
+    } else
       hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short, out->d);
     if (s->n_long_cols) {
       hipLaunchKernelGGL(spk::k_polyabc_long, dim3(spk::LONG_NB_MAX, (unsigned)s->n_long_cols), dim3(256), 0, c->stream, a, rx->d, s->d_long_cols,
