@@ -170,10 +170,19 @@ __global__ void __launch_bounds__(256) k_polyabc_long(PolyAbcArgs a, const fe_t*
 // column's partials and applies (1, r, r^2) - k_polyabc_long_final's work, also under the short columns.
 __global__ void __launch_bounds__(256) k_polyabc_short_and_long(PolyAbcArgs a, const fe_t* __restrict__ rx, const unsigned* __restrict__ order, size_t n_short,
                                                                 fe_t* __restrict__ out, const unsigned* __restrict__ long_cols, unsigned n_long,
-                                                                fe_t* __restrict__ partials, unsigned* __restrict__ tickets) {
+                                                                fe_t* __restrict__ partials, unsigned* __restrict__ tickets, unsigned short_blocks,
+                                                                size_t zero_from, size_t zero_n) {
   __shared__ fe_t smem[3 * 4];
   __shared__ unsigned s_last;
   const unsigned long_blocks = LONG_NB_MAX * n_long;
+  if (blockIdx.x >= long_blocks + short_blocks) {
+    // the zero tail of the output (out_len > num_cols: 32 MB at config 2, a 7 us fill launch in front of this kernel until round 3): the last blocks
+    // of the grid stream it out under the column walks
+    uint4* z = reinterpret_cast<uint4*>(out + zero_from);
+    const size_t n16 = zero_n * 2, nb = gridDim.x - long_blocks - short_blocks;
+    for (size_t i = (size_t)(blockIdx.x - long_blocks - short_blocks) * blockDim.x + threadIdx.x; i < n16; i += nb * blockDim.x) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   if (blockIdx.x < long_blocks) {
     const unsigned by = blockIdx.x / LONG_NB_MAX, bx = blockIdx.x % LONG_NB_MAX;
     const size_t col = long_cols[by];
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(256) k_polyabc_short_and_long(PolyAbcArgs a, c
     }
     return;
   }
-  const size_t nblk = gridDim.x - long_blocks;
+  const size_t nblk = short_blocks;
   for (size_t i = (size_t)(blockIdx.x - long_blocks) * blockDim.x + threadIdx.x; i < n_short; i += nblk * blockDim.x) {
     const size_t col = order[i];
     fe_t sa = gather_major_x4(a.m[0], col, rx), sb = gather_major_x4(a.m[1], col, rx), sc = gather_major_x4(a.m[2], col, rx);
@@ -842,7 +851,11 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
   for (int m = 0; m < 3; ++m) a.m[m] = s->col[m].view();
   memcpy(&a.r, r_, 32);
   a.r2 = fe_mul<S>(a.r, a.r);
-  if (out_len > s->num_cols) SP_HIP(hipMemsetAsync(out->d + s->num_cols, 0, (out_len - s->num_cols) * sizeof(fe_t), c->stream));
+  const char* merged_env = getenv("SPARTAN_POLYABC_MERGED");  // "0": fill, short columns, long columns and their final sums as four launches (rounds 1-3)
+  const char* ell_env = getenv("SPARTAN_POLYABC_ELL");
+  const bool ell_onepass = ell_env && ell_env[0] == '1';
+  const bool merged = !ell_onepass && s->n_long_cols && s->n_long_cols <= 64 && !(merged_env && merged_env[0] == '0');
+  if (out_len > s->num_cols && !merged) SP_HIP(hipMemsetAsync(out->d + s->num_cols, 0, (out_len - s->num_cols) * sizeof(fe_t), c->stream));
   size_t blocks = (s->n_short + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
@@ -850,16 +863,16 @@ int sp_poly_abc(sp_ctx* c, const sp_shape* s, const sp_table* rx, const uint64_t
   // SPARTAN_POLYABC_ELL=1: the short columns from the sliced-ELL copy (k_polyabc_ell_onepass) instead of the column-major walk. Measured equal at config 2
   // (97.6 - 100.8 us against 101.4 - 102.0 us): with coalesced index loads and three dependent memory rounds instead of nine the kernel still takes
   // ~100 us, like the split form's final pass without any large gather - the time is the serial latency of a wave's steps at 4 waves per SIMD. Opt-in.
-  const char* merged_env = getenv("SPARTAN_POLYABC_MERGED");  // "0": the long columns' blocks in a launch of their own behind the short columns' (rounds 1-3)
-  const char* ell_env = getenv("SPARTAN_POLYABC_ELL");
-  const bool ell_onepass = ell_env && ell_env[0] == '1';
   c->timed("poly_abc", bytes, [&] {
     if (ell_onepass && s->d_ell_cls && s->ell_slots && s->n_short)
       hipLaunchKernelGGL(spk::k_polyabc_ell_onepass, dim3((unsigned)((s->n_short + 255) / 256)), dim3(256), 0, c->stream, ell_view(s), s->d_ell_cls, s->d_ell_gtab, rx->d,
                          s->d_short_order, s->n_short, a.r, a.r2, out->d);
-    else if (s->n_long_cols && s->n_long_cols <= 64 && !(merged_env && merged_env[0] == '0')) {
-      hipLaunchKernelGGL(spk::k_polyabc_short_and_long, dim3((unsigned)(blocks + spk::LONG_NB_MAX * s->n_long_cols)), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short,
-                         out->d, s->d_long_cols, (unsigned)s->n_long_cols, s->d_long_partials, s->d_long_tickets);
+    else if (merged) {
+      const size_t zero_n = out_len - s->num_cols;
+      size_t zblocks = (2 * zero_n + 256 * 16 - 1) / (256 * 16);  // 16 stores of 16 bytes per thread
+      if (zblocks > 2048) zblocks = 2048;
+      hipLaunchKernelGGL(spk::k_polyabc_short_and_long, dim3((unsigned)(blocks + spk::LONG_NB_MAX * s->n_long_cols + zblocks)), dim3(256), 0, c->stream, a, rx->d, s->d_short_order,
+                         s->n_short, out->d, s->d_long_cols, (unsigned)s->n_long_cols, s->d_long_partials, s->d_long_tickets, (unsigned)blocks, (size_t)s->num_cols, zero_n);
       return;
     } else
       hipLaunchKernelGGL(spk::k_polyabc_short, dim3((unsigned)blocks), dim3(256), 0, c->stream, a, rx->d, s->d_short_order, s->n_short, out->d);
