@@ -217,22 +217,44 @@ __global__ void __launch_bounds__(256) k_bind_top(BindArgs a) {
 // level_offset) is the table over the LAST k variables, with the earliest of them on the index MSB
 // (compute_eq_polynomials, src/sumcheck.rs:960-979; EqPolynomial::evals_from_points, src/polys/eq.rs:66-76).
 __host__ __device__ __forceinline__ size_t eq_level_offset(int k) { return ((size_t)1 << k) - 1; }
-__global__ void __launch_bounds__(1024) k_eq_levels(const fe_t* __restrict__ v, int m, fe_t* __restrict__ out) {
-  if (threadIdx.x == 0) out[0] = fe_one<S>();
+// One level of the pyramid per barrier. The levels of up to 1024 entries are kept in LDS as well (in place: entry i of level k becomes entries i and
+// 2^k + i of level k + 1), so a level costs an LDS round trip + one product instead of a store to and a load from the L2 (1.5 -> 0.7 us per level; the
+// pyramids of tau and of r_x stand in front of the first evaluation of the outer and of the inner sum-check); the global stores are fire-and-forget.
+constexpr int EQ_LDS_ENTRIES = 1024;
+__device__ __forceinline__ void eq_levels_block(const fe_t* v_rev /* v_rev[k] = the challenge of level k */, int m, fe_t* __restrict__ out, fe_t* lv) {
+  if (threadIdx.x == 0) {
+    out[0] = fe_one<S>();
+    lv[0] = fe_one<S>();
+  }
   __syncthreads();
   for (int k = 0; k < m; ++k) {
-    const fe_t r = v[m - 1 - k];
-    const fe_t* prev = out + eq_level_offset(k);
+    const fe_t r = v_rev[-k];
     fe_t* next = out + eq_level_offset(k + 1);
     const size_t size = (size_t)1 << k;
-    for (size_t i = threadIdx.x; i < size; i += blockDim.x) {
-      fe_t e = prev[i];
-      fe_t y = fe_mul<S>(e, r);
-      next[size + i] = y;
-      next[i] = fe_sub<S>(e, y);
+    if (2 * size <= (size_t)EQ_LDS_ENTRIES) {
+      for (size_t i = threadIdx.x; i < size; i += blockDim.x) {
+        const fe_t e = lv[i];
+        const fe_t y = fe_mul<S>(e, r), x = fe_sub<S>(e, y);
+        lv[size + i] = y;
+        lv[i] = x;
+        next[size + i] = y;
+        next[i] = x;
+      }
+    } else {
+      const fe_t* prev = out + eq_level_offset(k);
+      for (size_t i = threadIdx.x; i < size; i += blockDim.x) {
+        const fe_t e = prev[i];
+        const fe_t y = fe_mul<S>(e, r);
+        next[size + i] = y;
+        next[i] = fe_sub<S>(e, y);
+      }
     }
     __syncthreads();
   }
+}
+__global__ void __launch_bounds__(1024) k_eq_levels(const fe_t* __restrict__ v, int m, fe_t* __restrict__ out) {
+  __shared__ fe_t lv[EQ_LDS_ENTRIES];
+  eq_levels_block(v + (m - 1), m, out, lv);
 }
 // both pyramids of EqSumCheckInstance::new (src/sumcheck.rs:956-992) in one launch: block 0 the left one, block 1 the right one, the taus by value
 // (no upload in front of the first evaluation)
@@ -242,24 +264,10 @@ struct EqPairArgs {
   fe_t* out[2];
 };
 __global__ void __launch_bounds__(1024) k_eq_levels_pair(EqPairArgs a) {
+  __shared__ fe_t lv[EQ_LDS_ENTRIES];
   const int b = blockIdx.x;
   const int m = a.m[b];
-  fe_t* out = a.out[b];
-  if (threadIdx.x == 0) out[0] = fe_one<S>();
-  __syncthreads();
-  for (int k = 0; k < m; ++k) {
-    const fe_t r = a.v[b][m - 1 - k];
-    const fe_t* prev = out + eq_level_offset(k);
-    fe_t* next = out + eq_level_offset(k + 1);
-    const size_t size = (size_t)1 << k;
-    for (size_t i = threadIdx.x; i < size; i += blockDim.x) {
-      fe_t e = prev[i];
-      fe_t y = fe_mul<S>(e, r);
-      next[size + i] = y;
-      next[i] = fe_sub<S>(e, y);
-    }
-    __syncthreads();
-  }
+  eq_levels_block(&a.v[b][m - 1], m, a.out[b], lv);
 }
 // out[(hi << lo_bits) | lo] = T_hi[hi] * T_lo[lo]
 __global__ void __launch_bounds__(256) k_eq_outer(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int lo_bits, size_t total,
