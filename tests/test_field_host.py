@@ -38,3 +38,12 @@ def test_product_scanning_base_field_product_on_the_device(tmp_path):
     """The generated asm column blocks on the device (a lone wave, then full blocks; single products and 64-deep dependent chains) against the host."""
     out = subprocess.run([_build_mul_check(tmp_path), "device", "100000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "device: 0 mismatches in 100064 lanes" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_host_keccak_permutation_forms_agree(tmp_path):
+    """The unrolled host permutation (generic and BMI builds) against the loop form the device compiles, plus the Keccak-256 digests of "" and "abc"."""
+    exe = str(tmp_path / "keccak_check")
+    subprocess.run(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-w", "-o", exe, os.path.join(HERE, "native", "keccak_check.hip")], check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "keccak: 0 mismatches" in out.stdout, out.stdout + out.stderr
