@@ -122,17 +122,45 @@ struct Keccak256State {
   SP_HD void block() {
     for (int i = 0; i < 17; ++i) {
       uint64_t w = 0;
+#if !defined(__HIP_DEVICE_COMPILE__)
+      memcpy(&w, buf + 8 * i, 8);  // (x86-64: little-endian)
+#else
       for (int k = 0; k < 8; ++k) w |= (uint64_t)buf[8 * i + k] << (8 * k);
+#endif
       a[i] ^= w;
     }
     keccak_permute(a);
     fill = 0;
   }
   SP_HD void update(const uint8_t* p, size_t n) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host: whole blocks straight from the input (seventeen 64-bit little-endian loads), the rest through the buffer in one copy
+    if (fill) {
+      const size_t take = n < 136 - fill ? n : 136 - fill;
+      memcpy(buf + fill, p, take);
+      fill += (uint32_t)take;
+      p += take;
+      n -= take;
+      if (fill == 136) block();
+    }
+    for (; n >= 136; p += 136, n -= 136) {
+      for (int i = 0; i < 17; ++i) {
+        uint64_t w;
+        memcpy(&w, p + 8 * i, 8);
+        a[i] ^= w;
+      }
+      keccak_permute(a);
+    }
+    if (n) {
+      memcpy(buf, p, n);
+      fill = (uint32_t)n;
+    }
+#else
     for (size_t i = 0; i < n; ++i) {
       buf[fill++] = p[i];
       if (fill == 136) block();
     }
+#endif
   }
   SP_HD void finish(uint8_t out[32]) {
     for (uint32_t i = fill; i < 136; ++i) buf[i] = 0;

@@ -29,6 +29,21 @@ int main() {
   k.update(reinterpret_cast<const uint8_t*>("abc"), 3);
   k.finish(out);
   bad += memcmp(out, abc, 32) != 0;
+  // absorbs of any chunking give one digest (whole blocks go straight from the input, the rest through the buffer)
+  {
+    uint8_t msg[1000], ref[32];
+    for (int i = 0; i < 1000; ++i) msg[i] = (uint8_t)(i * 131 + 7);
+    k.init();
+    for (int i = 0; i < 1000; ++i) k.update(msg + i, 1);
+    k.finish(ref);
+    const int chunks[] = {1000, 7, 135, 136, 137, 272, 300};
+    for (int c : chunks) {
+      k.init();
+      for (int off = 0; off < 1000; off += c) k.update(msg + off, off + c <= 1000 ? c : 1000 - off);
+      k.finish(out);
+      bad += memcmp(out, ref, 32) != 0;
+    }
+  }
   printf("keccak: %d mismatches\n", bad);
   return bad != 0;
 #else
