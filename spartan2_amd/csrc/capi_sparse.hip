@@ -199,8 +199,9 @@ __global__ void __launch_bounds__(256) k_polyabc_short_and_long(PolyAbcArgs a, c
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int w = 0; w < 8; ++w) __hip_atomic_store(dst + 8 * i + w, acc[i].v[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are acknowledged before the ticket is taken
-      s_last = __hip_atomic_fetch_add(tickets + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1 ? 1u : 0u;
+      // release / acquire at agent scope on the ticket (a few hundred long-column blocks at most, all of them under the short columns' walk: the
+      // L2 write-back a release costs does not matter here as it did in a thousand-block streaming launch)
+      s_last = __hip_atomic_fetch_add(tickets + by, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nb - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
