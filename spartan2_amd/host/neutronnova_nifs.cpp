@@ -230,21 +230,32 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
 
   // every instance's U = (comm_W, X) and blinds on every rank (64 rows + 32 d + 32 rows bytes per instance)
   const size_t rec = rows * sizeof(aff_t) + d * sizeof(fe_t) + rows * sizeof(fe_t);
-  std::vector<uint8_t> mine(n_local * rec), all(n * rec);
-  for (size_t i = 0; i < n_local; ++i) {
-    uint8_t* p = mine.data() + i * rec;
-    memcpy(p, comms_local + i * rows, rows * sizeof(aff_t));
-    if (d) memcpy(p + rows * sizeof(aff_t), X_local + i * d, d * sizeof(fe_t));
-    memcpy(p + rows * sizeof(aff_t) + d * sizeof(fe_t), r_W_local + i * rows, rows * sizeof(fe_t));
-  }
-  comm.allgather(mine.data(), mine.size(), all.data());
-  std::vector<aff_t> comms(n * rows);
-  std::vector<fe_t> X(n * d), r_W(n * rows);
-  for (size_t i = 0; i < n; ++i) {
-    const uint8_t* p = all.data() + i * rec;
-    memcpy(&comms[i * rows], p, rows * sizeof(aff_t));
-    if (d) memcpy(&X[i * d], p + rows * sizeof(aff_t), d * sizeof(fe_t));
-    memcpy(&r_W[i * rows], p + rows * sizeof(aff_t) + d * sizeof(fe_t), rows * sizeof(fe_t));
+  std::vector<aff_t> comms_all;
+  std::vector<fe_t> X_all, r_W_all;
+  const aff_t* comms = comms_local;  // one rank: its own instances are all there are, nothing to gather (12.6 MB through the collective and three
+  const fe_t* X = X_local;           // copies took 4-5 ms of a config-5 NIFS at world 1)
+  const fe_t* r_W = r_W_local;
+  if (world > 1) {
+    std::vector<uint8_t> mine(n_local * rec), all(n * rec);
+    for (size_t i = 0; i < n_local; ++i) {
+      uint8_t* p = mine.data() + i * rec;
+      memcpy(p, comms_local + i * rows, rows * sizeof(aff_t));
+      if (d) memcpy(p + rows * sizeof(aff_t), X_local + i * d, d * sizeof(fe_t));
+      memcpy(p + rows * sizeof(aff_t) + d * sizeof(fe_t), r_W_local + i * rows, rows * sizeof(fe_t));
+    }
+    comm.allgather(mine.data(), mine.size(), all.data());
+    comms_all.resize(n * rows);
+    X_all.resize(n * d);
+    r_W_all.resize(n * rows);
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* p = all.data() + i * rec;
+      memcpy(&comms_all[i * rows], p, rows * sizeof(aff_t));
+      if (d) memcpy(&X_all[i * d], p + rows * sizeof(aff_t), d * sizeof(fe_t));
+      memcpy(&r_W_all[i * rows], p + rows * sizeof(aff_t) + d * sizeof(fe_t), rows * sizeof(fe_t));
+    }
+    comms = comms_all.data();
+    X = X_all.data();
+    r_W = r_W_all.data();
   }
   lap("gather instance data");
 
@@ -256,7 +267,7 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   };
   {  // transcript.absorb(b"U", U) (:553-555)
     std::vector<std::vector<uint8_t>> ub(n);
-    parallel_for(n, rows + d, [&](size_t i) { ub[i] = instance_bytes(&comms[i * rows], rows, X.data() + i * d, d); });
+    parallel_for(n, rows + d, [&](size_t i) { ub[i] = instance_bytes(comms + i * rows, rows, X + i * d, d); });
     for (size_t i = 0; i < n; ++i) absorb("U", ub[i].data(), ub[i].size());
   }
   {
@@ -394,8 +405,8 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   lap("finish, C and witness folds");
   // fold_blinds, X fold, fold_commitments on the gathered instance data: O(n rows) work, done redundantly on every rank
   std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());
-  fold_rows(ctx, r_W.data(), n, rows, w.data(), f_rW.data());
-  fold_rows(ctx, X.data(), n, d, w.data(), f_X.data());
+  fold_rows(ctx, r_W, n, rows, w.data(), f_rW.data());
+  fold_rows(ctx, X, n, d, w.data(), f_X.data());
   memcpy(out.folded_rW, f_rW.data(), rows * sizeof(fe_t));
   memcpy(out.folded_X, f_X.data(), d * sizeof(fe_t));
   size_t data_rows = truncated ? (effective_len + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH : rows;
