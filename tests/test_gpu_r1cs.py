@@ -77,6 +77,19 @@ def test_spmv_and_poly_abc(ctx, which):
         assert (out.read(0, 2 * M) == want).all()
     finally:
         del os.environ["SPARTAN_POLYABC_ELL"]
+    # the four-launch form (fill, short columns, long columns, their final sums) the merged launch replaced: same table, twice in a row (the merged
+    # launch's per-column arrival counters must be back at zero after every call)
+    os.environ["SPARTAN_POLYABC_MERGED"] = "0"
+    try:
+        out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])
+        shape.poly_abc(hip.Table.from_host(ctx, rx), r, 2 * M, out)
+        assert (out.read(0, 2 * M) == want).all()
+    finally:
+        del os.environ["SPARTAN_POLYABC_MERGED"]
+    for _ in range(2):
+        out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])
+        shape.poly_abc(hip.Table.from_host(ctx, rx), r, 2 * M, out)
+        assert (out.read(0, 2 * M) == want).all()
     # the same for rx = eq(r_x), split at a challenge boundary (sp_poly_abc_begin / _finish: entries weighted with eq of the top n_hi variables under the
     # outer sum-check's last rounds, the rest in a short final pass) at every admissible split
     ell = N.bit_length() - 1
