@@ -134,6 +134,44 @@ __global__ void __launch_bounds__(256) k_nt(fe_t* __restrict__ A, fe_t* __restri
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
 }
 
+// SPLIT: a pair's work over two lanes 32 apart - the low lane binds (a0, b0, c0) and forms w (a0 b0 - c0), the high lane binds (a1, b1, c1), takes
+// a0 and b0 over the crossbar and forms w (a1 - a0)(b1 - b0): five dependent products per lane instead of ten, twice the waves, half the registers
+// held across the loads. One five-level lazy sum inside each half-wave replaces the two six-level ones.
+__global__ void __launch_bounds__(256) k_split(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in, int s,
+                                               lazy9_t* __restrict__ partials) {
+  __shared__ lazy9_t sm[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, role = lane >> 5;
+  const size_t pair = (size_t)blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const size_t id = pair + (role ? q : 0);
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t la = A[id], ha = A[id + 2 * q], lb = B[id], hb = B[id + 2 * q], lc = C[id], hc = C[id + 2 * q];
+  const fe_t w = eq_in[pair & mask];
+  const fe_t a = bind1(la, ha, r), b = bind1(lb, hb, r), c = bind1(lc, hc, r);
+  A[id] = a;
+  B[id] = b;
+  C[id] = c;
+  fe_t oa, ob;  // the other half-wave's a and b
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    oa.v[i] = __shfl_xor(a.v[i], 32, 64);
+    ob.v[i] = __shfl_xor(b.v[i], 32, 64);
+  }
+  const fe_t x = role ? fe_sub<S>(a, oa) : a, y = role ? fe_sub<S>(b, ob) : b;
+  fe_t v = fe_mul<S>(x, y);
+  if (!role) v = fe_sub<S>(v, c);
+  lazy9_t t = lazy_from(fe_mul<S>(w, v));
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) {
+    lazy9_t o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.v[i] = __shfl_xor(t.v[i], m, 64);
+    t = lazy_add(t, o);
+  }
+  if ((lane & 31) == 0) sm[wave][role] = t;
+  __syncthreads();
+  if (threadIdx.x < 2) partials[(size_t)blockIdx.x * 2 + threadIdx.x] = lazy_add(lazy_add(sm[0][threadIdx.x], sm[1][threadIdx.x]), lazy_add(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+}
+
 template <class L>
 static float time_us(L&& f, int reps) {
   hipEvent_t a, b;
@@ -169,6 +207,7 @@ int main() {
     lazy9_t* lp = reinterpret_cast<lazy9_t*>(part);
     report("library k_bind_eval_cubic<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic<1>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part, part, 1u, nomail); }, 10));
     report("library k_bind_eval_cubic_stream<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic_stream<1, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp, nomail); }, 20));
+    report("pair split over two half-waves", time_us([&] { hipLaunchKernelGGL(k_split, dim3(q / 128), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, plain stores", time_us([&] { hipLaunchKernelGGL((k_nt<false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, non-temporal stores", time_us([&] { hipLaunchKernelGGL((k_nt<true>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, 2 chunks per block", time_us([&] { hipLaunchKernelGGL((k_iter<2, false>), dim3(q / 256 / 2), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
