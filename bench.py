@@ -613,7 +613,10 @@ def main():
                          "alg_bytes_per_launch": bind_bytes / max(bind_launches, 1),
                          "other_kernels": {k: {"launches_per_step": kstats[k][1] / nb, "avg_us": kstats[k][0] / max(kstats[k][1], 1) * 1e3, "alg_GBps": gbps(k)}
                                            for k in ("bind_stream_quad", "bind_stream_quad_sparse", "bind", "eval_cubic", "eval_quad", "spmv_incremental", "poly_abc",
-                                                     "rowmat_vec") if kstats[k][1]}},
+                                                     "rowmat_vec") if kstats[k][1]},
+                         "other_kernels_note": "HIP-event times of an instrumented pass. The 'bind' class (fused bind + evaluate launches on tables <= 2^19 elements) is launched AHEAD of "
+                                               "its challenge and waits for it at the mailbox: its avg_us includes that wait, so its GB/s understate the kernel; the streaming "
+                                               "classes and the roofline kernel (tables >= 2^20) are launched behind their challenge and their times are the kernels' alone."},
             "roofline_hbm": hbm,
             "sparse": {"nnz_A_B_C": si["nnz"], "nnz_filtered_A_B_C": si["nnz_filtered"], "long_columns": si["long_columns"],
                        "spmv_incremental_alg_bytes": kstats["spmv_incremental"][2] / max(kstats["spmv_incremental"][1], 1),
