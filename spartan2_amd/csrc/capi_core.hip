@@ -115,6 +115,9 @@ int sp_ctx_create(int device, sp_ctx** out) {
   c->device = device;
   SP_HIP(hipStreamCreate(&c->stream));
   SP_HIP(hipStreamCreate(&c->stream2));
+  SP_HIP(hipStreamCreateWithFlags(&c->stream_eq, hipStreamNonBlocking));
+  SP_HIP(hipEventCreateWithFlags(&c->eq_ev, hipEventDisableTiming));
+  SP_HIP(hipMalloc((void**)&c->d_eq_ahead, 2 * ((size_t)1 << 11) * sizeof(fe_t)));
   c->pinned_elems = spk::MAIL_MIRROR_ELEM + 16;
   SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
   memset(c->h_pinned, 0, c->pinned_elems * sizeof(fe_t));
@@ -188,6 +191,9 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->fb_ev) hipEventDestroy(c->fb_ev);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->stream_eq) hipStreamDestroy(c->stream_eq);
+  if (c->eq_ev) hipEventDestroy(c->eq_ev);
+  if (c->d_eq_ahead) hipFree(c->d_eq_ahead);
   delete c;
 }
 int sp_ctx_synchronize(sp_ctx* c) {
@@ -793,6 +799,46 @@ int sp_eq_table_into(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
     hipLaunchKernelGGL(spk::k_eq_outer, dim3(8192), dim3(256), 0, c->stream, d_hi + spk::eq_level_offset(hi_bits), d_lowbig, lo_bits, total, t->d);
   }
   SP_HIP(hipStreamSynchronize(c->stream));  // r is a borrowed host buffer
+  return SP_OK;
+}
+
+// EqPolynomial::evals_from_points for a point that a sum-check is still drawing (evals_rx, src/spartan.rs:316): `_begin`, called when all but the last
+// two coordinates exist, builds the two pyramids on a stream of its own under the last two rounds; `_finish` (all coordinates known) is then ONE launch,
+// the outer product with the last two variables applied in it - instead of pyramids (12-14 us behind a launch gap) + outer product behind the last
+// challenge. 12 <= ell <= 20. `_finish` checks that the known prefix has not changed and falls back to sp_eq_table_into when there was no `_begin`.
+int sp_eq_table_begin(sp_ctx* c, const uint64_t* r_known, size_t n_known, size_t ell) {
+  if (ell < 12 || ell > 20 || n_known + 2 != ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table_begin: 12 <= ell <= 20 and exactly ell - 2 known coordinates");
+  const int lo_bits = 10, hi_bits = (int)ell - lo_bits;
+  spk::EqPairArgs ea;
+  for (int i = 0; i < hi_bits; ++i) ea.v[0][i] = load_fe(r_known + 4 * i);
+  for (int i = 0; i < lo_bits - 2; ++i) ea.v[1][i] = load_fe(r_known + 4 * (hi_bits + i));
+  ea.m[0] = hi_bits;
+  ea.m[1] = lo_bits - 2;
+  ea.out[0] = c->d_eq_ahead;
+  ea.out[1] = c->d_eq_ahead + ((size_t)1 << 11);
+  hipLaunchKernelGGL(spk::k_eq_levels_pair, dim3(2), dim3(1024), 0, c->stream_eq, ea);
+  SP_HIP(hipEventRecord(c->eq_ev, c->stream_eq));
+  memcpy(c->eq_ahead_r, r_known, n_known * sizeof(fe_t));
+  c->eq_ahead_ell = ell;
+  c->eq_ahead_known = n_known;
+  return SP_OK;
+}
+int sp_eq_table_finish(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
+  const bool begun = c->eq_ahead_ell == ell && ell != 0 && memcmp(c->eq_ahead_r, r, c->eq_ahead_known * sizeof(fe_t)) == 0;
+  c->eq_ahead_ell = 0;
+  if (!begun) return sp_eq_table_into(c, r, ell, t);
+  const size_t total = (size_t)1 << ell;
+  if (t->cap < total) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table_finish: table too short");
+  t->len = total;
+  t->lo_eff = t->hi_eff = (size_t)-1;
+  const int lo_bits = 10, hi_bits = (int)ell - lo_bits;
+  SP_HIP(hipStreamWaitEvent(c->stream, c->eq_ev, 0));
+  size_t blocks = (total / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  c->timed("eq_table", 32ull * total, [&] {
+    hipLaunchKernelGGL(spk::k_eq_outer_last2, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_eq_ahead + spk::eq_level_offset(hi_bits),
+                       c->d_eq_ahead + ((size_t)1 << 11) + spk::eq_level_offset(lo_bits - 2), lo_bits, total, load_fe(r + 4 * (ell - 2)), load_fe(r + 4 * (ell - 1)), t->d);
+  });
   return SP_OK;
 }
 

@@ -95,6 +95,11 @@ struct KStat {
 struct sp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream_eq = nullptr;  // sp_eq_table_begin's pyramids (a stream of their own: the auxiliary stream may hold a 100 us MSM stage of the helper thread)
+  hipEvent_t eq_ev = nullptr;
+  fe_t* d_eq_ahead = nullptr;     // two pyramids of <= 2^11 entries
+  size_t eq_ahead_ell = 0, eq_ahead_known = 0;  // set by sp_eq_table_begin, consumed by sp_eq_table_finish
+  fe_t eq_ahead_r[32];
   hipStream_t stream2 = nullptr;  // auxiliary stream: work that does not depend on the transcript (ipa.rs:139-147 delta) overlaps the sum-checks
   fe_t* d_scratch = nullptr;  // block partials etc.
   size_t scratch_elems = 0;

@@ -269,6 +269,22 @@ __global__ void __launch_bounds__(1024) k_eq_levels_pair(EqPairArgs a) {
   const int m = a.m[b];
   eq_levels_block(&a.v[b][m - 1], m, a.out[b], lv);
 }
+// The same table with the LAST TWO variables applied here: T_lo covers only the low variables up to them, so both pyramids can be built two rounds
+// before the sum-check that draws the point ends. out[(hi << lo_bits) | (lo' << 2) | (b_a << 1) | b_b] = T_hi[hi] T_lo[lo'] e(b_a, r_a) e(b_b, r_b): four
+// products for four outputs, the rate of the plain outer product.
+__global__ void __launch_bounds__(256) k_eq_outer_last2(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int lo_bits, size_t total, fe_t ra, fe_t rb,
+                                                        fe_t* __restrict__ out) {
+  const size_t quads = total >> 2, mask = ((size_t)1 << (lo_bits - 2)) - 1;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < quads; j += (size_t)gridDim.x * blockDim.x) {
+    const fe_t v = fe_mul<S>(t_hi[j >> (lo_bits - 2)], t_lo[j & mask]);
+    const fe_t v1 = fe_mul<S>(v, ra), v0 = fe_sub<S>(v, v1);
+    const fe_t o1 = fe_mul<S>(v0, rb), o3 = fe_mul<S>(v1, rb);
+    out[4 * j] = fe_sub<S>(v0, o1);
+    out[4 * j + 1] = o1;
+    out[4 * j + 2] = fe_sub<S>(v1, o3);
+    out[4 * j + 3] = o3;
+  }
+}
 // out[(hi << lo_bits) | lo] = T_hi[hi] * T_lo[lo]
 __global__ void __launch_bounds__(256) k_eq_outer(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int lo_bits, size_t total,
                                                   fe_t* __restrict__ out) {

@@ -143,6 +143,17 @@ class Table:
         check(lib().sp_eq_table(ctx.h, p64(r) if r.shape[0] else None, ctypes.c_size_t(r.shape[0]), ctypes.byref(h)))
         return cls(ctx, h)
 
+    @staticmethod
+    def eq_begin(ctx, r_known: np.ndarray, ell: int):
+        """sp_eq_table_begin: the first ell - 2 coordinates of a point still being drawn."""
+        r_known = np.ascontiguousarray(r_known, dtype=np.uint64).reshape(-1, 4)
+        check(lib().sp_eq_table_begin(ctx.h, p64(r_known), ctypes.c_size_t(r_known.shape[0]), ctypes.c_size_t(ell)))
+
+    def eq_finish(self, r: np.ndarray):
+        """sp_eq_table_finish into this table (capacity >= 2^ell)."""
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        check(lib().sp_eq_table_finish(self.ctx.h, p64(r), ctypes.c_size_t(r.shape[0]), self.h))
+
     def info(self):
         n, lo, hi = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
         check(lib().sp_table_info(self.h, ctypes.byref(n), ctypes.byref(lo), ctypes.byref(hi)))

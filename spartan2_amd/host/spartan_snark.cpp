@@ -559,7 +559,34 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       }
     }
   } abc_obs{ctx, ps.abc_ws, ps.abc_ws ? num_rounds_x - ps.abc_n_lo : 0};
-  if (ps.abc_ws)
+  // Without the split: evals_rx started two rounds before r_x is complete (sp_eq_table_begin builds the half tables of the first ell - 2
+  // coordinates on a stream of its own; sp_eq_table_finish behind the last challenge is then one launch). SPARTAN_EQ_AHEAD=0: the plain call.
+  struct EqObs {
+    sp_ctx* ctx;
+    size_t ell;
+    fe_t r[24];
+    int rc = 0;
+    bool begun = false;
+    static void fn(void* u, size_t round, const uint64_t r[4]) {
+      EqObs* o = (EqObs*)u;
+      if (round + 2 >= o->ell) return;  // the last two coordinates are applied by sp_eq_table_finish
+      memcpy(&o->r[round], r, 32);
+      if (round + 3 == o->ell) {
+        o->rc = sp_eq_table_begin(o->ctx, u64p(o->r), o->ell - 2, o->ell);
+        o->begun = o->rc == 0;
+      }
+    }
+  } eq_obs{ctx, num_rounds_x};
+  static const bool eq_ahead = [] {
+    const char* e = getenv("SPARTAN_EQ_AHEAD");
+    return !(e && e[0] == '0');
+  }();
+  const bool use_eq_obs = eq_ahead && !ps.abc_ws && num_rounds_x >= 12 && num_rounds_x <= 20;
+  if (use_eq_obs)
+    ck(sp_sumcheck_cubic3_observed(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p0 ? ps.p1 : nullptr, tr.t, &EqObs::fn, &eq_obs,
+                                   u64p(outer_polys.data()), u64p(r_x.data()), u64p(claims_outer)),
+       "outer sum-check");
+  else if (ps.abc_ws)
     ck(sp_sumcheck_cubic3_observed(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p0 ? ps.p1 : nullptr, tr.t, &AbcObs::fn, &abc_obs,
                                    u64p(outer_polys.data()), u64p(r_x.data()), u64p(claims_outer)),
        "outer sum-check");
@@ -572,6 +599,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
                           u64p(claims_outer)),
        "outer sum-check");
   if (abc_obs.rc) throw Error(abc_obs.rc, std::string("poly_ABC (begin): ") + sp_last_error());
+  if (eq_obs.rc) throw Error(eq_obs.rc, std::string("evals_rx (begin): ") + sp_last_error());
   tr.absorb_scalars("claims_outer", claims_outer, 3);
   for (const fe_t& f : outer_polys) proof.pf(f);
   for (int i = 0; i < 3; ++i) proof.pf(claims_outer[i]);
@@ -583,7 +611,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   if (abc_obs.begun) {
     ck(sp_poly_abc_finish(ctx, ps.abc_ws, u64p(r_x.data() + abc_obs.n_hi), ps.abc_n_lo, u64p(&r), 2 * M, ps.abc), "poly_ABC (finish)");
   } else {
-    ck(sp_eq_table_into(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");
+    ck(sp_eq_table_finish(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");  // (= sp_eq_table_into when nothing was begun)
     ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
   }
   const double t_abc = now_ms();

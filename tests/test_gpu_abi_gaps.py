@@ -203,3 +203,26 @@ def test_long_absorbs_hashed_on_the_library_thread_equal_the_oracle_transcript(c
     want = otr.squeeze(b"z")
     tr2 = tr.clone()
     assert (tr2.squeeze(b"z") == want).all() and (tr.squeeze(b"z") == want).all()
+
+
+@pytest.mark.parametrize("ell", [12, 15, 20])
+def test_eq_table_begun_two_coordinates_early(ctx, ell):
+    """sp_eq_table_begin / _finish (the half tables of the first ell - 2 coordinates built ahead, the last two applied in the one launch behind the
+    last challenge) give the table of sp_eq_table; a `_finish` without a `_begin`, or with a different prefix, is the plain call."""
+    from spartan2_amd import hip
+
+    rng = np.random.default_rng(4200 + ell)
+    r = ol.random_field_array(rng, ell)
+    want = hip.Table.eq(ctx, r).read()
+    out = hip.Table.zeros(ctx, 1 << ell)
+    hip.Table.eq_begin(ctx, r[: ell - 2], ell)
+    out.eq_finish(r)
+    assert (out.read() == want).all()
+    out2 = hip.Table.zeros(ctx, 1 << ell)
+    out2.eq_finish(r)  # nothing begun
+    assert (out2.read() == want).all()
+    r2 = r.copy()
+    r2[0] = ol.random_field_array(rng, 1)[0]
+    hip.Table.eq_begin(ctx, r[: ell - 2], ell)
+    out2.eq_finish(r2)  # another point than the one begun
+    assert (out2.read() == hip.Table.eq(ctx, r2).read()).all()
