@@ -17,9 +17,9 @@
  *
  * Interoperability: this ABI takes the commitment key (generators) and every transcript byte from its caller, so a Rust caller that derives the
  * key with the reference's `from_label` and absorbs the reference's vk digest gets reference-compatible group elements and challenges out of
- * these entry points. The C++ drivers of this repo (spartan2_amd/host/) use documented substitutes for the third-party pieces that are not in the
- * reference tree (hash_to_curve, the bincode digest): THEIR keys and proofs are not interchangeable with ones produced by the
- * reference binary, and no such byte equality is claimed anywhere.
+ * these entry points. The C++ drivers of this repo (spartan2_amd/host/) compute the vk digest and the proof bytes in the reference's own framing
+ * (bincode + SHA-256, "wire formats" below); what stays a documented substitute is the generator derivation (third-party hash_to_curve,
+ * DESIGN.md section 6), so THEIR keys are not the reference binary's keys and no byte equality with a reference-produced proof is claimed.
  */
 #ifndef SPARTAN_HIP_H
 #define SPARTAN_HIP_H
@@ -245,6 +245,13 @@ int sp_ck_create(sp_ctx* ctx, const uint64_t* ck_aff, size_t num_cols, const uin
 void sp_ck_free(sp_ck* ck);
 /* PCS::commit (:207-303) on n elements of a device table starting at `off`; one Aff per row of num_cols */
 int sp_hyrax_commit(sp_ctx* ctx, const sp_ck* ck, const sp_table* v, size_t off, size_t n, const uint64_t* blinds, int is_small, uint64_t* out_rows_aff);
+/* PCS::commit_without_blind (:533-568): the per-row MSMs alone ((0,0) for an all-zero row) — what SpartanZkSNARK caches across proves
+ * (cached_rest_msm, src/spartan_zk.rs:335-366) */
+int sp_hyrax_commit_without_blind(sp_ctx* ctx, const sp_ck* ck, const sp_table* v, size_t off, size_t n, int is_small, uint64_t* out_rows_aff);
+/* PCS::commit_incremental (:570-607): out[i] = raw[i] + MSM(row i of delta) + h * blind[i]; raw rows beyond nraw count as the identity; delta = the
+ * change of the committed vector since `raw` was computed (n elements of a device table at `off`), all-zero rows cost only the blind term */
+int sp_hyrax_commit_incremental(sp_ctx* ctx, const sp_ck* ck, const uint64_t* raw_rows_aff, size_t nraw, const sp_table* delta, size_t off, size_t n,
+                                const uint64_t* blinds, uint64_t* out_rows_aff);
 /* PCS::commit_zeros (:305-319) and the per-row h * blind of rerandomize (:321-344): FixedBaseMul::mul (msm.rs:691-725) */
 int sp_fixed_base_mul_h(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, uint64_t* out_aff);
 /* PCS::rerandomize_commitment (hyrax_pc.rs:321-344): out[i] = comm[i] + h * (r_new[i] - r_old[i]) (FixedBaseMul::mul per row) */
@@ -411,6 +418,62 @@ int sp_nifs_resume(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_
 int sp_to_small_vec_or_zero(sp_ctx* ctx, const sp_table* t, size_t cnt, int64_t* out_i64, uint8_t* out_large);
 /* PowPolynomial::split_evals (src/polys/power.rs:64-87), host side: left | right entries */
 int sp_pow_split_evals(const uint64_t tau[4], size_t ell, size_t left, size_t right, uint64_t* out);
+
+/* ---- wire formats and key digests (src/digest.rs:22-77) ---------------------------------- */
+/* The reference serialises keys and proofs with serde + bincode `DefaultOptions::new().with_little_endian().with_fixint_encoding()` (src/digest.rs:33-41)
+ * and digests keys with SHA-256 over `write_bytes` (DigestComputer, :49-77). Framing: usize = 8 bytes LE; Vec<T> = u64 length + elements; Option<T> = one
+ * tag byte + T; structs / tuples = their fields in order. Third-party element layouts (halo2curves `derive_serde`, Cargo.toml:41-46 — the one documented
+ * assumption): F = its 32 `to_repr()` bytes (canonical, little-endian; >= p is rejected on read); affine point = {x, y}; projective point (`E::GE`) =
+ * {x, y, z}, written normalised as (x, y, 1) / (0, 0, 0) for the identity, read in any Jacobian representative. Host code only. */
+int sp_sha256(const uint8_t* data, size_t n, uint8_t out[32]);
+int sp_sha256_accelerated(void); /* 1 when the x86 SHA extensions are in use */
+/* byte sink in the role of the `io::Write` of Digestible::write_bytes (:24-27): hashing = 0 collects the bytes, 1 streams them into SHA-256 */
+typedef struct sp_wire sp_wire;
+int sp_wire_new(int hashing, sp_wire** out);
+void sp_wire_free(sp_wire* w);
+int sp_wire_raw(sp_wire* w, const uint8_t* bytes, size_t n);
+int sp_wire_u8(sp_wire* w, uint8_t v);                                                /* bool / Option tag */
+int sp_wire_u64s(sp_wire* w, const uint64_t* v, size_t n, int with_len);              /* usize values; with_len: as Vec<usize> */
+int sp_wire_u32s_as_u64(sp_wire* w, const uint32_t* v, size_t n, int with_len);       /* column indices held as u32, usize on the wire */
+int sp_wire_scalars(sp_wire* w, const uint64_t* f, size_t n, int with_len);           /* E::Scalar values / Vec<E::Scalar> */
+int sp_wire_affines(sp_wire* w, const uint64_t* aff, size_t n, int with_len);         /* AffineGroupElement {x, y} */
+int sp_wire_points(sp_wire* w, const uint64_t* aff, size_t n, int with_len);          /* E::GE from its affine form; with_len: HyraxCommitment { comm } */
+/* HyraxCommitmentKey / HyraxVerifierKey { num_cols, ck, h } (src/provider/pcs/hyrax_pc.rs:56-108; the tables are #[serde(skip)]) */
+int sp_wire_hyrax_key(sp_wire* w, const uint64_t* ck, size_t num_cols, const uint64_t* h);
+/* SparseMatrix: digest_form != 0 = write_digest_bytes (src/r1cs/sparse.rs:398-417), 0 = the derived Serialize (:383-394) */
+int sp_wire_matrix(sp_wire* w, const sp_csr* M, size_t rows, size_t cols, int digest_form);
+/* SplitR1CSShape: digest_form != 0 = write_bytes (src/r1cs/mod.rs:775-794), 0 = the derived Serialize (:742-773) */
+int sp_wire_shape(sp_wire* w, const sp_dims* dims, const sp_csr* A, const sp_csr* B, const sp_csr* C, int digest_form);
+size_t sp_wire_len(const sp_wire* w); /* bytes written so far */
+int sp_wire_bytes(sp_wire* w, uint8_t* out, size_t cap);
+int sp_wire_digest(sp_wire* w, uint8_t out[32]);
+/* byte source (borrows `bytes`): what bincode's deserializer does for the same types; every call fails on short input */
+typedef struct sp_unwire sp_unwire;
+int sp_unwire_new(const uint8_t* bytes, size_t n, sp_unwire** out);
+void sp_unwire_free(sp_unwire* r);
+size_t sp_unwire_left(const sp_unwire* r);
+int sp_unwire_u8(sp_unwire* r, uint8_t* out);
+int sp_unwire_u64s(sp_unwire* r, size_t n, uint64_t* out);
+int sp_unwire_len(sp_unwire* r, size_t elem_bytes, size_t* out); /* Vec length, refused when the input cannot hold that many elements */
+int sp_unwire_scalars(sp_unwire* r, size_t n, uint64_t* out);
+int sp_unwire_affines(sp_unwire* r, size_t n, uint64_t* out);    /* on-curve check */
+int sp_unwire_points(sp_unwire* r, size_t n, uint64_t* out_aff); /* any representative -> Aff; on-curve check */
+int sp_unwire_done(const sp_unwire* r);                          /* fails on trailing bytes, as bincode's DefaultOptions do */
+/* DigestHelperTrait::digest of SpartanVerifierKey (src/spartan.rs:73-104): SHA-256(bincode(vk_ee) || bincode(ck_s) || S.write_bytes()).
+ * (ck, num_cols, h) = the witness key (vk_ee holds the same three fields), (ck_s, num_cols_s, h_s) = the width-1 key of src/spartan.rs:152. */
+int sp_vk_digest(const sp_dims* dims, const sp_csr* A, const sp_csr* B, const sp_csr* C, const uint64_t* ck, size_t num_cols, const uint64_t* h,
+                 const uint64_t* ck_s, size_t num_cols_s, const uint64_t* h_s, uint8_t out[32]);
+/* SpartanSNARK (src/spartan.rs:125-137) between bincode bytes and this build's flat word layout:
+ *   comm_W rows (Aff: shared, precommitted, rest) | public_values | challenges | outer polys (rounds_x x 3 F) | claims_outer (3 F) |
+ *   inner polys (rounds_y x 2 F) | eval_W | blind_eval_W | delta | beta (Aff) | z_vec (z_len F) | z_delta | z_beta.
+ * A segment's Option<Commitment> is Some exactly when it has rows. `_serialize`: out may be NULL to learn *len. `_deserialize` fills the layout from
+ * the bytes' own length prefixes (words may be NULL to learn *nwords); the caller compares it with the key's shape before verifying. */
+typedef struct sp_spartan_layout {
+  uint64_t rows_shared, rows_precommitted, rows_rest, num_public, num_challenges, rounds_x, rounds_y, z_len;
+} sp_spartan_layout;
+size_t sp_proof_words(const sp_spartan_layout* layout);
+int sp_proof_serialize(const sp_spartan_layout* layout, const uint64_t* words, size_t nwords, uint8_t* out, size_t cap, size_t* len);
+int sp_proof_deserialize(const uint8_t* bytes, size_t n, sp_spartan_layout* layout, uint64_t* words, size_t cap_words, size_t* nwords);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@
 #include "nifs.hpp"
 #include "spartan.hpp"
 #include "neutronnova_zk.hpp"
+#include "wire_formats.hpp"
 
 using namespace oracle;
 
@@ -285,6 +286,26 @@ int orc_hyrax_commit(void* k, const uint64_t* v, size_t n, const uint64_t* blind
   HyraxBlind b = load<Fq>(blinds, div_ceil(n, key->num_cols));
   HyraxCommitment c = hyrax_commit(*key, vv.data(), n, b, is_small != 0);
   std::vector<Affine> a = batch_affine(c);
+  for (size_t i = 0; i < a.size(); ++i) store_aff(out_rows + 8 * i, a[i]);
+  ORC_CATCH
+}
+// PCS::commit_without_blind / commit_incremental (hyrax_pc.rs:533-607): raw rows cross as affine points, (0,0) = identity
+int orc_hyrax_commit_without_blind(void* k, const uint64_t* v, size_t n, int is_small, uint64_t* out_rows) {
+  ORC_TRY
+  HyraxKey* key = (HyraxKey*)k;
+  std::vector<Fq> vv = load<Fq>(v, n);
+  std::vector<Affine> a = batch_affine(hyrax_commit_without_blind(*key, vv.data(), n, is_small != 0));
+  for (size_t i = 0; i < a.size(); ++i) store_aff(out_rows + 8 * i, a[i]);
+  ORC_CATCH
+}
+int orc_hyrax_commit_incremental(void* k, const uint64_t* raw_rows, size_t nraw, const uint64_t* delta, size_t n, const uint64_t* blinds, uint64_t* out_rows) {
+  ORC_TRY
+  HyraxKey* key = (HyraxKey*)k;
+  std::vector<Jac> raw(nraw);
+  for (size_t i = 0; i < nraw; ++i) raw[i] = Jac::from_affine(load_aff(raw_rows + 8 * i));
+  std::vector<Fq> dv = load<Fq>(delta, n);
+  HyraxBlind b = load<Fq>(blinds, div_ceil(n, key->num_cols));
+  std::vector<Affine> a = batch_affine(hyrax_commit_incremental(*key, raw, dv.data(), n, b));
   for (size_t i = 0; i < a.size(); ++i) store_aff(out_rows + 8 * i, a[i]);
   ORC_CATCH
 }
@@ -825,6 +846,57 @@ void* orc_nn_proof_from_words(void* k, const uint64_t* w, size_t nwords) {
     pf->relaxed.blind_E = gf();
     if (o != nwords) throw std::runtime_error("nn_proof_from_words: trailing words");
     return guard.release();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+
+// ---- wire formats (oracle/wire.hpp, oracle/wire_formats.hpp) ------------------------------------------------------------------------------
+int orc_sha256(const uint8_t* data, size_t n, uint8_t* out32) {
+  sha256(data, n, out32);
+  return 0;
+}
+static long copy_out(const std::vector<uint8_t>& b, uint8_t* out, size_t cap) {
+  if (out && b.size() <= cap) memcpy(out, b.data(), b.size());
+  return (long)b.size();
+}
+// each returns the byte length (call with out = NULL to size the buffer), -1 on error
+long orc_spartan_vk_to_bytes(void* pk, uint8_t* out, size_t cap) {
+  try {
+    return copy_out(spartan_vk_to_bytes(*(SpartanProverKey*)pk), out, cap);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+long orc_spartan_proof_to_bytes(void* pf, uint8_t* out, size_t cap) {
+  try {
+    return copy_out(spartan_proof_to_bytes(*(SpartanProof*)pf), out, cap);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+void* orc_spartan_proof_from_bytes(const uint8_t* b, size_t n) {
+  try {
+    return new SpartanProof(spartan_proof_from_bytes(b, n));
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+long orc_nn_proof_to_bytes(void* pf, uint8_t* out, size_t cap) {
+  try {
+    return copy_out(nn_proof_to_bytes(*(NNProof*)pf), out, cap);
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+void* orc_nn_proof_from_bytes(const uint8_t* b, size_t n) {
+  try {
+    return new NNProof(nn_proof_from_bytes(b, n));
   } catch (const std::exception& e) {
     g_err = e.what();
     return nullptr;

@@ -101,6 +101,50 @@ inline HyraxCommitment hyrax_commit(const HyraxKey& ck, const Fq* v, size_t n, c
   return comm;
 }
 
+// commit_without_blind (hyrax_pc.rs:533-568): the per-row MSMs alone, no blinding term; an all-zero row is the identity
+inline std::vector<Jac> hyrax_commit_without_blind(const HyraxKey& ck, const Fq* v, size_t n, bool is_small) {
+  const size_t num_cols = ck.ck.size(), num_rows = div_ceil(n, num_cols);
+  std::vector<Jac> raw(num_rows);
+#pragma omp parallel for schedule(dynamic) if (num_rows >= 4)
+  for (size_t i = 0; i < num_rows; ++i) {
+    const size_t lower = i * num_cols, upper = std::min(lower + num_cols, n), len = upper - lower;
+    const Fq* row = v + lower;
+    bool all_zero = true;
+    for (size_t k = 0; k < len; ++k) all_zero &= row[k].is_zero();
+    if (all_zero) {
+      raw[i] = Jac::identity();
+    } else if (is_small) {  // the caller's hint is trusted: the low 8 bytes of to_repr (:553-560)
+      std::vector<uint64_t> small(len);
+      for (size_t k = 0; k < len; ++k) {
+        uint64_t c[4];
+        row[k].to_canonical(c);
+        small[k] = c[0];
+      }
+      raw[i] = msm_small(small.data(), ck.ck.data(), len);
+    } else {
+      raw[i] = msm(row, ck.ck.data(), len);
+    }
+  }
+  return raw;
+}
+// commit_incremental (hyrax_pc.rs:570-607): cached raw row MSMs + MSM of the changed entries + h * blind
+inline HyraxCommitment hyrax_commit_incremental(const HyraxKey& ck, const std::vector<Jac>& raw, const Fq* delta, size_t n, const HyraxBlind& blind) {
+  const size_t num_cols = ck.ck.size(), num_rows = div_ceil(n, num_cols);
+  if (blind.size() < num_rows) throw std::runtime_error("commit_incremental: too few blinds");
+  HyraxCommitment comm(num_rows);
+#pragma omp parallel for schedule(dynamic) if (num_rows >= 4)
+  for (size_t i = 0; i < num_rows; ++i) {
+    const size_t lower = i * num_cols, upper = std::min(lower + num_cols, n), len = upper - lower;
+    const Fq* row = delta + lower;
+    bool all_zero = true;
+    for (size_t k = 0; k < len; ++k) all_zero &= row[k].is_zero();
+    Jac point = i < raw.size() ? raw[i] : Jac::identity();
+    if (!all_zero) point = point.add(msm(row, ck.ck.data(), len));
+    comm[i] = point.add(ck.h_table.mul(blind[i]));
+  }
+  return comm;
+}
+
 inline HyraxCommitment hyrax_commit_zeros(const HyraxKey& ck, size_t n, const HyraxBlind& r) {  // hyrax_pc.rs:305-319
   size_t num_rows = div_ceil(n, ck.num_cols);
   HyraxCommitment comm(num_rows);

@@ -16,7 +16,8 @@
 // PARITY UNPINNED against the reference: no golden vector of this wrapper exists in the reference tree and the reference cannot be run here. What
 // holds it in place is the restated verifier (prove -> verify accepts, tampering is rejected) and the pinned pieces underneath (transcript,
 // sum-checks, NIFS rounds, Hyrax: oracle/spartan.hpp, oracle/nifs.hpp).
-// Substitution: the vk digest is Keccak-256 over the digests of S_step, S_core and the vc shape (reference: SHA-256 over bincode, unpinned).
+// The vk digest is the reference's SHA-256 over NeutronNovaVerifierKey::write_bytes (src/neutronnova_zk.rs:1305-1333; wire.hpp states the one
+// third-party layout assumption inside it).
 #pragma once
 #include <array>
 #include <functional>
@@ -625,23 +626,18 @@ struct NNKey {  // prover and verifier key in one
   size_t nb = 0, nx = 0, ny = 0, num_steps = 0;
   uint8_t vk_digest[32];
 };
-inline void multiround_shape_digest(const MultiRoundShape& S, uint8_t out[32]) {
-  Keccak256 h;
-  auto w64 = [&](uint64_t v) { h.update((const uint8_t*)&v, 8); };
-  w64(S.num_cons);
-  w64(S.num_rounds);
-  w64(S.num_public);
-  for (size_t v : S.vars_padded) w64(v);
-  for (const SparseMatrix<Fq>* M : {&S.A, &S.B, &S.C}) {
-    w64(M->data.size());
-    for (const Fq& d : M->data) {
-      uint8_t b[32];
-      d.to_repr(b);
-      h.update(b, 32);
-    }
-    for (size_t i : M->indices) w64(i);
-    for (size_t p : M->indptr) w64(p);
-  }
+// NeutronNovaVerifierKey::write_bytes (src/neutronnova_zk.rs:1305-1333) hashed by DigestComputer::digest (src/digest.rs:62-76)
+inline void nn_vk_digest(const NNKey& k, uint8_t out[32]) {
+  Sha256 h;
+  WireWriter w(&h);
+  w.hyrax_key(k.ck);  // ck
+  w.hyrax_key(k.ck);  // vk_ee: the same generators (SplitR1CSShape::commitment_key returns both from one PCS::setup)
+  w.shape_digest_bytes(k.S_step);
+  w.shape_digest_bytes(k.S_core);
+  w.multiround_shape(*k.vc_shape);
+  w.regular_shape_of(*k.vc_shape);
+  w.hyrax_key(k.vc_ck);  // vc_ck
+  w.hyrax_key(k.vc_ck);  // vc_vk
   h.finalize(out);
 }
 inline std::unique_ptr<NNKey> nn_setup(SplitR1CSShape<Fq> S_step, SplitR1CSShape<Fq> S_core, size_t num_steps) {  // :1394-1475
@@ -660,13 +656,7 @@ inline std::unique_ptr<NNKey> nn_setup(SplitR1CSShape<Fq> S_step, SplitR1CSShape
   NNVerifierCircuit vc(pk->nb, pk->nx, pk->ny, 32);
   pk->vc_shape = std::make_unique<MultiRoundShape>(MultiRoundShape::from_circuit(vc));
   pk->vc_ck = HyraxKey::setup("ck", 32);  // S.commitment_key(): PCS::setup(b"ck", total_vars, width) (:1690-1693)
-  uint8_t d[96];
-  shape_digest(pk->S_step, d);
-  shape_digest(pk->S_core, d + 32);
-  multiround_shape_digest(*pk->vc_shape, d + 64);
-  Keccak256 h;
-  h.update(d, 96);
-  h.finalize(pk->vk_digest);
+  nn_vk_digest(*pk, pk->vk_digest);
   return pk;
 }
 

@@ -7,11 +7,9 @@
 // circuit, src/spartan.rs:587-651, is rest-only), and circuits with verifier challenges (:429-431, :443-461): the challenges are squeezed after
 // the precommitted commitment and the rest of the witness is re-synthesized from them — `circuit.synthesize` is the caller's callback here.
 //
-// Substitution (documented): the verifier-key digest. The reference
-// hashes bincode(vk_ee) || bincode(ck_s) || S.write_bytes() with SHA-256 (src/spartan.rs:73-104,
-// src/digest.rs:49-77); the bincode layout of third-party point types is unpinned, so this build's
-// digest is Keccak-256 over the S.write_bytes() stream only (src/r1cs/mod.rs:775-794,
-// src/r1cs/sparse.rs:398-417), absorbed as 32 raw bytes under the same label "vk".
+// The verifier-key digest is the reference's: SHA-256 over bincode(vk_ee) || bincode(ck_s) || S.write_bytes() (src/spartan.rs:73-104,
+// src/digest.rs:49-77), absorbed as 32 raw bytes under the label "vk". The byte layout of the third-party point / field types inside it is
+// the one documented assumption of wire.hpp (halo2curves derive_serde).
 #pragma once
 #include <chrono>
 #include <cstdio>
@@ -23,6 +21,7 @@
 #include "hyrax.hpp"
 #include "sparse.hpp"
 #include "sumcheck.hpp"
+#include "wire.hpp"
 
 namespace oracle {
 
@@ -32,35 +31,13 @@ struct SpartanProverKey {  // src/spartan.rs:30-58 (pk and vk share everything t
   uint8_t vk_digest[32];
 };
 
-inline void shape_digest(const SplitR1CSShape<Fq>& S, uint8_t out[32]) {
-  Keccak256 h;
-  auto w64 = [&](uint64_t v) { h.update((const uint8_t*)&v, 8); };
-  w64(S.num_cons);
-  w64(S.num_cons_unpadded);
-  w64(S.num_shared_unpadded);
-  w64(S.num_precommitted_unpadded);
-  w64(S.num_rest_unpadded);
-  w64(S.num_shared);
-  w64(S.num_precommitted);
-  w64(S.num_rest);
-  w64(S.num_public);
-  w64(S.num_challenges);
-  auto wm = [&](const SparseMatrix<Fq>& M) {
-    w64(M.data.size());
-    w64(M.indices.size());
-    w64(M.indptr.size());
-    w64(M.cols);
-    for (const Fq& d : M.data) {
-      uint8_t b[32];
-      d.to_repr(b);
-      h.update(b, 32);
-    }
-    for (size_t i : M.indices) w64(i);
-    for (size_t p : M.indptr) w64(p);
-  };
-  wm(S.A);
-  wm(S.B);
-  wm(S.C);
+// SpartanVerifierKey::write_bytes (src/spartan.rs:73-90) hashed by DigestComputer::digest (src/digest.rs:62-76)
+inline void spartan_vk_digest(const SpartanProverKey& vk, uint8_t out[32]) {
+  Sha256 h;
+  WireWriter w(&h);
+  w.hyrax_key(vk.ck);    // vk_ee: the HyraxVerifierKey of the witness key (same num_cols, ck, h)
+  w.hyrax_key(vk.ck_s);  // ck_s: HyraxCommitmentKey of width 1
+  w.shape_digest_bytes(vk.S);
   h.finalize(out);
 }
 
@@ -69,7 +46,7 @@ inline SpartanProverKey spartan_setup(SplitR1CSShape<Fq> S) {  // src/spartan.rs
   pk.S = std::move(S);
   pk.ck = HyraxKey::setup("ck", DEFAULT_COMMITMENT_WIDTH);  // src/r1cs/mod.rs:1031-1043
   pk.ck_s = HyraxKey::setup("ck_s", 1);
-  shape_digest(pk.S, pk.vk_digest);
+  spartan_vk_digest(pk, pk.vk_digest);
   return pk;
 }
 

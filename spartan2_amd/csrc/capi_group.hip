@@ -714,10 +714,12 @@ int sp_fixed_base_mul_h(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, siz
   return SP_OK;
 }
 
-int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, size_t n, const uint64_t* blinds, int /*is_small: auto-detected*/,
-                    uint64_t* out_rows_aff) {
+// The rows of PCS::commit as Jacobian sums: per-row MSM (+ h * blind[row] when blinds are given; without them the raw MSMs of commit_without_blind,
+// hyrax_pc.rs:533-568, an all-zero row being the identity).
+static int commit_rows(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, size_t n, const uint64_t* blinds, std::vector<jac_t>& out_rows) {
   if (off + n > v->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "hyrax commit: range exceeds the table");
   const size_t cols = ck->num_cols, rows = (n + cols - 1) / cols;
+  out_rows.clear();
   if (rows == 0) return SP_OK;
   int rc;
   if (ck->d_cktables) {
@@ -734,18 +736,16 @@ int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, s
     const size_t full_rows = n / cols;
     if (full_rows) SP_HIP(hipMemcpy2DAsync(ds, per * sizeof(fe_t), v->d + off, cols * sizeof(fe_t), cols * sizeof(fe_t), full_rows, hipMemcpyDeviceToDevice, c->stream));
     if (n % cols) SP_HIP(hipMemcpyAsync(ds + full_rows * per, v->d + off + full_rows * cols, (n % cols) * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
-    SP_HIP(hipMemcpyAsync(dbl, blinds, rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+    if (blinds) SP_HIP(hipMemcpyAsync(dbl, blinds, rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+    else SP_HIP(hipMemsetAsync(dbl, 0, rows * sizeof(fe_t), c->stream));
     SP_HIP(hipMemcpy2DAsync(ds + cols, per * sizeof(fe_t), dbl, sizeof(fe_t), sizeof(fe_t), rows, hipMemcpyDeviceToDevice, c->stream));
     c->timed("fixed_base", 32ull * total, [&] {
       launch_fixed_base_rows(c->stream, ds, total, ck->d_cktables, per, dout);
       hipLaunchKernelGGL(spk::k_sum_rows_of_points, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, dout, rows, (unsigned)per, drow);
     });
-    std::vector<jac_t> sums(rows);
-    SP_HIP(hipMemcpyAsync(sums.data(), drow, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
+    out_rows.resize(rows);
+    SP_HIP(hipMemcpyAsync(out_rows.data(), drow, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
     SP_HIP(hipStreamSynchronize(c->stream));
-    std::vector<aff_t> a(rows);
-    normalize_batch(sums, a.data());
-    memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
     return SP_OK;
   }
   fe_t* canon = (fe_t*)c->workspace(sp_ctx::WS_COMMIT_CANON, n * sizeof(fe_t));
@@ -792,13 +792,44 @@ int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, s
       }
     }
   }
-  std::vector<jac_t> hb;
-  if ((rc = fixed_base_rows(c, ck->d_htable, 1, blinds, rows, hb))) return rc;
-  for (size_t r = 0; r < rows; ++r) msm_rows[r] = jac_add(msm_rows[r], hb[r]);
-  std::vector<aff_t> a(rows);
-  normalize_batch(msm_rows, a.data());
-  memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
+  if (blinds) {
+    std::vector<jac_t> hb;
+    if ((rc = fixed_base_rows(c, ck->d_htable, 1, blinds, rows, hb))) return rc;
+    for (size_t r = 0; r < rows; ++r) msm_rows[r] = jac_add(msm_rows[r], hb[r]);
+  }
+  out_rows.swap(msm_rows);
   return SP_OK;
+}
+static int rows_out(std::vector<jac_t>& rows, uint64_t* out_rows_aff) {
+  if (rows.empty()) return SP_OK;
+  std::vector<aff_t> a(rows.size());
+  normalize_batch(rows, a.data());
+  memcpy(out_rows_aff, a.data(), rows.size() * sizeof(aff_t));
+  return SP_OK;
+}
+int sp_hyrax_commit(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, size_t n, const uint64_t* blinds, int /*is_small: auto-detected*/,
+                    uint64_t* out_rows_aff) {
+  if (!blinds && n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "hyrax commit: null blinds");
+  std::vector<jac_t> rows;
+  int rc = commit_rows(c, ck, v, off, n, blinds, rows);
+  return rc ? rc : rows_out(rows, out_rows_aff);
+}
+// PCS::commit_without_blind (hyrax_pc.rs:533-568): the cacheable, randomness-free part of a commitment
+int sp_hyrax_commit_without_blind(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off, size_t n, int /*is_small: auto-detected*/, uint64_t* out_rows_aff) {
+  std::vector<jac_t> rows;
+  int rc = commit_rows(c, ck, v, off, n, nullptr, rows);
+  return rc ? rc : rows_out(rows, out_rows_aff);
+}
+// PCS::commit_incremental (hyrax_pc.rs:570-607): out[i] = raw[i] (identity beyond nraw) + MSM(delta row i) + h * blind[i]
+int sp_hyrax_commit_incremental(sp_ctx* c, const sp_ck* ck, const uint64_t* raw_rows_aff, size_t nraw, const sp_table* delta, size_t off, size_t n,
+                                const uint64_t* blinds, uint64_t* out_rows_aff) {
+  if ((!blinds && n) || (!raw_rows_aff && nraw)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_incremental: null argument");
+  std::vector<jac_t> rows;
+  int rc = commit_rows(c, ck, delta, off, n, blinds, rows);
+  if (rc) return rc;
+  const aff_t* raw = reinterpret_cast<const aff_t*>(raw_rows_aff);
+  for (size_t i = 0; i < rows.size() && i < nraw; ++i) rows[i] = jac_add_mixed(rows[i], raw[i]);
+  return rows_out(rows, out_rows_aff);
 }
 
 // ---- vartime_scalar_mul / two-term fold / rerandomize ---------------------------------------------------------------------------------------

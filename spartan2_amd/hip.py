@@ -376,6 +376,23 @@ class CommitmentKey:
         check(lib().sp_hyrax_commit(self.ctx.h, self.h, table.h, ctypes.c_size_t(off), ctypes.c_size_t(n), p64(blinds), int(is_small), p64(out)))
         return out
 
+    def commit_without_blind(self, table: Table, off, n, is_small=True):
+        """PCS::commit_without_blind (hyrax_pc.rs:533-568): the raw per-row MSMs, (0,0) for an all-zero row"""
+        rows = (n + self.num_cols - 1) // self.num_cols
+        out = np.zeros((rows, 8), dtype=np.uint64)
+        check(lib().sp_hyrax_commit_without_blind(self.ctx.h, self.h, table.h, ctypes.c_size_t(off), ctypes.c_size_t(n), int(is_small), p64(out)))
+        return out
+
+    def commit_incremental(self, raw_rows, delta: Table, off, n, blinds):
+        """PCS::commit_incremental (hyrax_pc.rs:570-607): raw + MSM(delta) + h * blind per row"""
+        rows = (n + self.num_cols - 1) // self.num_cols
+        raw = np.ascontiguousarray(raw_rows, dtype=np.uint64).reshape(-1, 8)
+        blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
+        out = np.zeros((rows, 8), dtype=np.uint64)
+        check(lib().sp_hyrax_commit_incremental(self.ctx.h, self.h, p64(raw) if raw.size else None, ctypes.c_size_t(raw.shape[0]), delta.h, ctypes.c_size_t(off),
+                                                ctypes.c_size_t(n), p64(blinds), p64(out)))
+        return out
+
     def prove(self, key_eval, tr, comm_rows, poly, n, blinds, point, comm_eval, blind_eval, rng):
         """HyraxPCS::prove (hyrax_pc.rs:387-478) as one ABI call (sp_hyrax_prove): rng = (>= cols + 2, 64) uniform bytes (d_vec, r_delta, r_beta in draw
         order); returns delta (8) | beta (8) | z_vec | z_delta | z_beta words."""
@@ -780,3 +797,64 @@ def sumcheck_quad_sharded(ctx, claim, rounds, A: Table, B: Table, tr: Transcript
     check(lib().sp_sumcheck_quad_sharded(ctx.h, p64(claim_io), ctypes.c_size_t(rounds), A.h, B.h, tr.h, cb if cb is not None else ctypes.cast(None, REDUCE_HOOK), None,
                                          p64(polys), p64(r), p64(fin)))
     return polys, r, fin, claim_io
+
+
+# ---- wire formats and key digests (include/spartan_hip.h "wire formats"; host code of the library, no device needed) ------------------------------
+class SpartanLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in ("rows_shared", "rows_precommitted", "rows_rest", "num_public", "num_challenges", "rounds_x", "rounds_y", "z_len")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class CsrView(ctypes.Structure):  # sp_csr
+    _fields_ = [("data", c_u64p), ("indices", ctypes.POINTER(ctypes.c_uint32)), ("indptr", c_u64p)]
+
+
+def sha256(data: bytes) -> bytes:
+    arr, n = _bytes(data)
+    out = np.zeros(32, dtype=np.uint8)
+    check(lib().sp_sha256(p8(arr), n, p8(out)))
+    return out.tobytes()
+
+
+def proof_serialize(layout: dict, words) -> bytes:
+    """flat proof words -> bincode bytes of SpartanSNARK (sp_proof_serialize)"""
+    L = SpartanLayout(**layout)
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    n = ctypes.c_size_t(0)
+    check(lib().sp_proof_serialize(ctypes.byref(L), p64(words), ctypes.c_size_t(len(words)), None, ctypes.c_size_t(0), ctypes.byref(n)))
+    out = np.zeros(max(n.value, 1), dtype=np.uint8)
+    check(lib().sp_proof_serialize(ctypes.byref(L), p64(words), ctypes.c_size_t(len(words)), p8(out), ctypes.c_size_t(n.value), ctypes.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def proof_deserialize(data: bytes):
+    """bincode bytes -> (layout dict, flat proof words); raises SpartanHipError when the bytes do not decode"""
+    arr, n = _bytes(data)
+    L = SpartanLayout()
+    nw = ctypes.c_size_t(0)
+    check(lib().sp_proof_deserialize(p8(arr), n, ctypes.byref(L), None, ctypes.c_size_t(0), ctypes.byref(nw)))
+    words = np.zeros(max(nw.value, 1), dtype=np.uint64)
+    check(lib().sp_proof_deserialize(p8(arr), n, ctypes.byref(L), p64(words), ctypes.c_size_t(nw.value), ctypes.byref(nw)))
+    return L.as_dict(), words[:nw.value]
+
+
+def vk_digest(dims, csr_field, ck, h, ck_s, h_s) -> bytes:
+    """sp_vk_digest. dims: the ten numbers in sp_dims order; csr_field: three (data (nnz, 4) u64, indices u32, indptr u64) of the PADDED shape."""
+    d = (ctypes.c_uint64 * 10)(*[int(x) for x in dims])
+    keep, views = [], []
+    for data, idx, ptr in csr_field:
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        ptr = np.ascontiguousarray(ptr, dtype=np.uint64)
+        keep += [data, idx, ptr]
+        views.append(CsrView(p64(data) if data.size else None, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)) if idx.size else None, p64(ptr)))
+    ck = np.ascontiguousarray(ck, dtype=np.uint64).reshape(-1, 8)
+    ck_s = np.ascontiguousarray(ck_s, dtype=np.uint64).reshape(-1, 8)
+    h = np.ascontiguousarray(h, dtype=np.uint64)
+    h_s = np.ascontiguousarray(h_s, dtype=np.uint64)
+    out = np.zeros(32, dtype=np.uint8)
+    check(lib().sp_vk_digest(d, ctypes.byref(views[0]), ctypes.byref(views[1]), ctypes.byref(views[2]), p64(ck), ctypes.c_size_t(ck.shape[0]), p64(h), p64(ck_s),
+                             ctypes.c_size_t(ck_s.shape[0]), p64(h_s), p8(out)))
+    return out.tobytes()

@@ -172,6 +172,29 @@ class SpartanSNARK:
         self.verified_publics = pub[: self.dims["num_public"]] if rc == 0 else None  # what verify() returns in the reference (src/spartan.rs:577)
         return rc
 
+    # ---- wire formats (bincode framing of the reference's serde types; include/spartan_hip.h "wire formats") ----
+    def proof_layout(self) -> dict:
+        L = hip.SpartanLayout()
+        lib().ss_proof_layout(self.pk, ctypes.byref(L))
+        return L.as_dict()
+
+    def proof_to_bytes(self, words: np.ndarray) -> bytes:
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        _check(lib().ss_proof_to_bytes(self.pk, hip.p64(words), ctypes.c_size_t(len(words)), None, ctypes.c_size_t(0), ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(lib().ss_proof_to_bytes(self.pk, hip.p64(words), ctypes.c_size_t(len(words)), hip.p8(out), ctypes.c_size_t(n.value), ctypes.byref(n)))
+        return out.tobytes()
+
+    def verify_bytes(self, data: bytes) -> int:
+        """verify() on a serialised proof: 0 = accept, 1..6 = failed check (1 also for bytes that do not decode to a proof of this key's shape)."""
+        arr = np.frombuffer(bytes(data), dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
+        pub = np.zeros((max(self.dims["num_public"], 1), 4), dtype=np.uint64)
+        rc = lib().ss_verify_bytes(self.pk, hip.p8(arr), ctypes.c_size_t(len(data)), hip.p64(pub))
+        if rc < 0:
+            _check(rc)
+        return rc
+
     def close(self):
         if self.ps:
             lib().ss_prep_free(self.ps)
@@ -501,6 +524,29 @@ class NeutronNovaZkSNARK:
         device: 0 = accept, else the failed check (1 shape / encoding, 2 verifier-circuit instance, 4 relaxed Spartan proof, 5 public values, 6 opening)."""
         words = np.ascontiguousarray(words, dtype=np.uint64)
         rc = lib().nnz_verify(self.pk, hip.p64(words), ctypes.c_size_t(words.shape[0]))
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def proof_to_bytes(self, words: np.ndarray) -> bytes:
+        """NeutronNovaZkSNARK as bincode bytes (src/neutronnova_zk.rs:1373-1385)"""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        n = ctypes.c_size_t(0)
+        _check(lib().nnz_proof_to_bytes(self.pk, hip.p64(words), ctypes.c_size_t(len(words)), None, ctypes.c_size_t(0), ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        _check(lib().nnz_proof_to_bytes(self.pk, hip.p64(words), ctypes.c_size_t(len(words)), hip.p8(out), ctypes.c_size_t(n.value), ctypes.byref(n)))
+        return out.tobytes()
+
+    def proof_from_bytes(self, data: bytes) -> np.ndarray:
+        arr = np.frombuffer(bytes(data), dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
+        lib().nnz_proof_words.restype = ctypes.c_size_t
+        words = np.zeros(lib().nnz_proof_words(self.pk), dtype=np.uint64)
+        _check(lib().nnz_proof_from_bytes(self.pk, hip.p8(arr), ctypes.c_size_t(len(data)), hip.p64(words), ctypes.c_size_t(len(words))))
+        return words
+
+    def verify_bytes(self, data: bytes) -> int:
+        arr = np.frombuffer(bytes(data), dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
+        rc = lib().nnz_verify_bytes(self.pk, hip.p8(arr), ctypes.c_size_t(len(data)))
         if rc < 0:
             _check(rc)
         return rc

@@ -202,14 +202,26 @@ static NNZkKey* nn_setup(sp_ctx* ctx, const R1CSIntView& Rs, const R1CSIntView& 
     pk->nx = log2_ceil(Ps.dims.num_cons);
     pk->ny = log2_ceil(pk->num_vars) + 1;
     pk->vc = vcirc::Shape::from_circuit(vcirc::Circuit(pk->nb, pk->nx, pk->ny, 32));
-    uint8_t d[96];
-    shape_digest(Ps, d);
-    shape_digest(Pc, d + 32);
-    pk->vc.digest(d + 64);
-    sp::Keccak256State h;
-    h.init();
-    h.update(d, 96);
-    h.finish(pk->vk_digest);
+    {  // NeutronNovaVerifierKey::write_bytes (src/neutronnova_zk.rs:1305-1333) -> SHA-256 (src/digest.rs:62-76)
+      struct Sink {
+        sp_wire* w = nullptr;
+        ~Sink() { sp_wire_free(w); }
+      } sink;
+      ck(sp_wire_new(1, &sink.w), "wire sink");
+      const uint64_t *g = u64p(&pk->gens[0].x), *h = u64p(&pk->gens[DEFAULT_COMMITMENT_WIDTH].x), *vh = u64p(&pk->gens[32].x);
+      ck(sp_wire_hyrax_key(sink.w, g, DEFAULT_COMMITMENT_WIDTH, h), "vk: ck");
+      ck(sp_wire_hyrax_key(sink.w, g, DEFAULT_COMMITMENT_WIDTH, h), "vk: vk_ee");  // the same generators (SplitR1CSShape::commitment_key)
+      sp_csr cs[3];
+      padded_csr(Ps, cs);
+      ck(sp_wire_shape(sink.w, &Ps.dims, &cs[0], &cs[1], &cs[2], 1), "vk: S_step");
+      padded_csr(Pc, cs);
+      ck(sp_wire_shape(sink.w, &Pc.dims, &cs[0], &cs[1], &cs[2], 1), "vk: S_core");
+      pk->vc.write_bincode(sink.w, false);  // vc_shape: SplitMultiRoundR1CSShape
+      pk->vc.write_bincode(sink.w, true);   // vc_shape_regular: R1CSShape (to_regular_shape)
+      ck(sp_wire_hyrax_key(sink.w, g, 32, vh), "vk: vc_ck");
+      ck(sp_wire_hyrax_key(sink.w, g, 32, vh), "vk: vc_vk");
+      ck(sp_wire_digest(sink.w, pk->vk_digest), "vk digest");
+    }
   } catch (...) {
     delete pk;
     throw;
@@ -967,6 +979,166 @@ static size_t proof_words(const NNZkKey& pk) {
   return w;
 }
 
+// ---- NeutronNovaZkSNARK on the wire (src/neutronnova_zk.rs:1373-1385; bincode framing through the library's sink / source) ------------------------
+// flat layout (NNProof::serialize) <-> { comm_W_shared: Option, step_instances: Vec<SplitR1CSInstance>, core_instance, eval_arg, U_verifier:
+// SplitMultiRoundR1CSInstance, nifs: NovaNIFS { comm_T }, random_U: RelaxedR1CSInstance { comm_W, comm_E, X, u }, relaxed_snark }. The instances carry
+// comm_W_shared = None (:2069-2078) and no challenges.
+struct WireSinkGuard {
+  sp_wire* w = nullptr;
+  ~WireSinkGuard() { sp_wire_free(w); }
+};
+static std::vector<uint8_t> nn_proof_to_bytes(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
+  if (nwords != proof_words(pk)) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "nn_proof_to_bytes: the word count does not match the key");
+  const sp_dims& d = pk.dims;
+  const vcirc::Shape& vs = pk.vc;
+  const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0,
+               rows_rest = d.num_rest / CW, VW = vs.width;
+  WireSinkGuard g;
+  ck(sp_wire_new(0, &g.w), "wire sink");
+  sp_wire* w = g.w;
+  const uint64_t* p = words;
+  auto u64v = [&](uint64_t v) { ck(sp_wire_u64s(w, &v, 1, 0), "wire"); };
+  auto commitment = [&](size_t rows) {
+    ck(sp_wire_points(w, p, rows, 1), "wire");
+    p += 8 * rows;
+  };
+  auto option_commitment = [&](size_t rows) {
+    ck(sp_wire_u8(w, rows ? 1 : 0), "wire");
+    if (rows) commitment(rows);
+  };
+  auto scalars = [&](size_t n, int with_len) {
+    ck(sp_wire_scalars(w, p, n, with_len), "wire");
+    p += 4 * n;
+  };
+  auto instance = [&](size_t npub) {
+    ck(sp_wire_u8(w, 0), "wire");
+    option_commitment(rows_pre);
+    commitment(rows_rest);
+    scalars(npub, 1);
+    u64v(0);  // challenges: an empty Vec
+  };
+  auto sumcheck = [&](size_t rounds, size_t per) {
+    u64v(rounds);
+    for (size_t i = 0; i < rounds; ++i) scalars(per, 1);
+  };
+  option_commitment(rows_sh);
+  u64v(pk.num_steps);
+  for (size_t i = 0; i < pk.num_steps; ++i) instance(d.num_public);
+  instance(pk.dims_core.num_public);
+  ck(sp_wire_points(w, p, 2, 0), "wire");  // ipa.delta, ipa.beta
+  p += 16;
+  scalars(CW, 1);
+  scalars(2, 0);
+  u64v(vs.num_rounds);  // U_verifier.comm_w_per_round
+  for (size_t r = 0; r < vs.num_rounds; ++r) commitment(vs.vars_padded[r] / VW);
+  scalars(vs.num_public, 1);
+  u64v(vs.num_rounds);  // challenges_per_round
+  for (size_t r = 0; r < vs.num_rounds; ++r) scalars(vs.chals_per_round[r], 1);
+  commitment(vs.num_cons / VW);    // nifs.comm_T
+  commitment(vs.total_vars / VW);  // random_U.comm_W
+  commitment(vs.num_cons / VW);    // random_U.comm_E
+  const uint64_t* u = p;           // flat: u, then X; on the wire X, then u (src/r1cs/mod.rs:213-218)
+  p += 4;
+  scalars(vs.num_io(), 1);
+  ck(sp_wire_scalars(w, u, 1, 0), "wire");
+  sumcheck(log2_ceil(vs.num_cons), 3);
+  scalars(3, 0);
+  sumcheck(log2_ceil(next_pow2(vs.total_vars)) + 1, 2);
+  scalars(VW, 1);
+  scalars(1, 0);
+  scalars(VW, 1);
+  scalars(1, 0);
+  if ((size_t)(p - words) != nwords) throw Error(SP_ERR_INTERNAL, "nn_proof_to_bytes: layout walk out of step");
+  std::vector<uint8_t> out(sp_wire_len(w));
+  ck(sp_wire_bytes(w, out.data(), out.size()), "wire bytes");
+  return out;
+}
+// the inverse; every length prefix must be the one the key's shape dictates (the flat layout has no room for anything else)
+static std::vector<uint64_t> nn_proof_from_bytes(const NNZkKey& pk, const uint8_t* bytes, size_t n) {
+  const sp_dims& d = pk.dims;
+  const vcirc::Shape& vs = pk.vc;
+  const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0,
+               rows_rest = d.num_rest / CW, VW = vs.width;
+  struct Src {
+    sp_unwire* r = nullptr;
+    ~Src() { sp_unwire_free(r); }
+  } src;
+  ck(sp_unwire_new(bytes, n, &src.r), "wire source");
+  sp_unwire* r = src.r;
+  std::vector<uint64_t> out;
+  out.reserve(proof_words(pk));
+  auto expect_len = [&](size_t want, size_t elem) {
+    size_t got;
+    ck(sp_unwire_len(r, elem, &got), "wire length");
+    if (got != want) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "wire: a length prefix does not match the key's shape");
+  };
+  auto points = [&](size_t cnt) {
+    out.resize(out.size() + 8 * cnt);
+    ck(sp_unwire_points(r, cnt, out.data() + out.size() - 8 * cnt), "wire points");
+  };
+  auto scalars = [&](size_t cnt) {
+    out.resize(out.size() + 4 * cnt);
+    ck(sp_unwire_scalars(r, cnt, out.data() + out.size() - 4 * cnt), "wire scalars");
+  };
+  auto tag = [&](uint8_t want) {
+    uint8_t t;
+    ck(sp_unwire_u8(r, &t), "wire tag");
+    if (t != want) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "wire: an Option tag does not match the key's shape");
+  };
+  auto commitment = [&](size_t rows) {
+    expect_len(rows, 96);
+    points(rows);
+  };
+  auto option_commitment = [&](size_t rows) {
+    tag(rows ? 1 : 0);
+    if (rows) commitment(rows);
+  };
+  auto vec_scalars = [&](size_t cnt) {
+    expect_len(cnt, 32);
+    scalars(cnt);
+  };
+  auto instance = [&](size_t npub) {
+    tag(0);
+    option_commitment(rows_pre);
+    commitment(rows_rest);
+    vec_scalars(npub);
+    expect_len(0, 32);
+  };
+  auto sumcheck = [&](size_t rounds, size_t per) {
+    expect_len(rounds, 8 + 32 * per);
+    for (size_t i = 0; i < rounds; ++i) vec_scalars(per);
+  };
+  option_commitment(rows_sh);
+  expect_len(pk.num_steps, 1 + 1 + 8 + 8 + 8);
+  for (size_t i = 0; i < pk.num_steps; ++i) instance(d.num_public);
+  instance(pk.dims_core.num_public);
+  points(2);
+  vec_scalars(CW);
+  scalars(2);
+  expect_len(vs.num_rounds, 8);
+  for (size_t k = 0; k < vs.num_rounds; ++k) commitment(vs.vars_padded[k] / VW);
+  vec_scalars(vs.num_public);
+  expect_len(vs.num_rounds, 8);
+  for (size_t k = 0; k < vs.num_rounds; ++k) vec_scalars(vs.chals_per_round[k]);
+  commitment(vs.num_cons / VW);
+  commitment(vs.total_vars / VW);
+  commitment(vs.num_cons / VW);
+  const size_t u_at = out.size();
+  out.resize(u_at + 4);  // flat: u in front of X
+  vec_scalars(vs.num_io());
+  ck(sp_unwire_scalars(r, 1, out.data() + u_at), "wire scalars");
+  sumcheck(log2_ceil(vs.num_cons), 3);
+  scalars(3);
+  sumcheck(log2_ceil(next_pow2(vs.total_vars)) + 1, 2);
+  vec_scalars(VW);
+  scalars(1);
+  vec_scalars(VW);
+  scalars(1);
+  ck(sp_unwire_done(r), "wire end");
+  if (out.size() != proof_words(pk)) throw Error(SP_ERR_INTERNAL, "nn_proof_from_bytes: layout walk out of step");
+  return out;
+}
+
 // ---- NeutronNovaZkSNARK::verify (src/neutronnova_zk.rs:2096-2343) — SURVEY 8(f) rank 3 for caller #2 -----------------------------------------------
 // What scales with the step circuits runs on the device through the same ABI: the fold of the step instances' commitments (one shared-weights MSM per
 // Hyrax row, hyrax_pc.rs:737-793), the six matrix evaluations A, B, C (rx, ry) of the step and core shapes (ONE sp_multiply_vec against T_y = eq(r_y)
@@ -1364,7 +1536,7 @@ int nnz_setup(sp_ctx* ctx, size_t num_steps, size_t num_cons, size_t num_shared,
   }
 }
 void nnz_pk_free(void* pk) { delete (NNZkKey*)pk; }
-// out: nb, nx, ny, vc rounds, vc total vars, vc num_cons, vc num_cons_unpadded, vc num_public; digest = the vk digest substitute
+// out: nb, nx, ny, vc rounds, vc total vars, vc num_cons, vc num_cons_unpadded, vc num_public; digest = the vk digest (SHA-256 over NeutronNovaVerifierKey::write_bytes)
 void nnz_pk_info(void* pk_, uint64_t out[8], uint8_t digest[32]) {
   auto* pk = (NNZkKey*)pk_;
   uint64_t v[8] = {pk->nb, pk->nx, pk->ny, pk->vc.num_rounds, pk->vc.total_vars, pk->vc.num_cons, pk->vc.num_cons_unpadded, pk->vc.num_public};
@@ -1401,6 +1573,46 @@ int nnz_prove(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_
     memcpy(out_words, pf.words.data(), pf.words.size() * 8);
     if (tape_used) *tape_used = t.pos;
     return 0;
+  } catch (...) {
+    return catch_all_nn();
+  }
+}
+// NeutronNovaZkSNARK as bincode bytes (the reference's serde framing; include/spartan_hip.h "wire formats"). `_to_bytes`: out may be NULL to learn *len.
+int nnz_proof_to_bytes(void* pk, const uint64_t* words, size_t nwords, uint8_t* out, size_t cap, size_t* len) {
+  try {
+    std::vector<uint8_t> b = nn_proof_to_bytes(*(NNZkKey*)pk, words, nwords);
+    *len = b.size();
+    if (out) {
+      if (cap < b.size()) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "byte buffer too small");
+      memcpy(out, b.data(), b.size());
+    }
+    return 0;
+  } catch (...) {
+    return catch_all_nn();
+  }
+}
+int nnz_proof_from_bytes(void* pk, const uint8_t* bytes, size_t n, uint64_t* out_words, size_t cap_words) {
+  try {
+    std::vector<uint64_t> w = nn_proof_from_bytes(*(NNZkKey*)pk, bytes, n);
+    if (cap_words < w.size()) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "word buffer too small");
+    memcpy(out_words, w.data(), 8 * w.size());
+    return 0;
+  } catch (...) {
+    return catch_all_nn();
+  }
+}
+// verify on the serialised proof: 0 = accept, 1..6 = the failed check (a proof that does not decode fails check 1), < 0 = error
+int nnz_verify_bytes(void* pk, const uint8_t* bytes, size_t n) {
+  try {
+    std::vector<uint64_t> w;
+    try {
+      w = nn_proof_from_bytes(*(NNZkKey*)pk, bytes, n);
+    } catch (const Error& e) {
+      if (e.code != SP_ERR_INVALID_INPUT_LENGTH) throw;
+      ss_set_error(e.what());
+      return 1;
+    }
+    return nn_verify(*(NNZkKey*)pk, w.data(), w.size());
   } catch (...) {
     return catch_all_nn();
   }

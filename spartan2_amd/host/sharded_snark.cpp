@@ -141,7 +141,7 @@ ShardedKey* sharded_setup(sp_ctx* ctx, Comm* comm, const R1CSIntView& R) {
     pk->gens_s = from_label("ck_s", 2);
     ck(sp_ck_create(ctx, u64p(&pk->gens[0].x), DEFAULT_COMMITMENT_WIDTH, u64p(&pk->gens[DEFAULT_COMMITMENT_WIDTH].x), &pk->ck), "ck_create");
     ck(sp_ck_create(ctx, u64p(&pk->gens_s[0].x), 1, u64p(&pk->gens_s[1].x), &pk->ck_s), "ck_s_create");
-    shape_digest(P, pk->vk_digest);
+    spartan_vk_digest(P, pk->gens, pk->gens_s, pk->vk_digest);
   } catch (...) {
     delete pk;
     throw;

@@ -1,5 +1,5 @@
 // Pieces shared by the host-side protocol drivers above the C ABI (spartan_snark.cpp, sharded_snark.cpp): the integer R1CS view and
-// SplitR1CSShape::new padding, this build's generator derivation and vk digest substitute, the O(sqrt N) host-side eq tables.
+// SplitR1CSShape::new padding, this build's generator derivation, the vk digest (the reference's SHA-256 stream), the O(sqrt N) host-side eq tables.
 #pragma once
 #include "host_common.hpp"
 
@@ -78,40 +78,17 @@ inline PaddedShape pad_shape(const R1CSIntView& R) {
   return P;
 }
 
-// vk digest substitute (see oracle/spartan.hpp header): Keccak-256 over S.write_bytes() (src/r1cs/mod.rs:775-794, sparse.rs:398-417)
-inline void shape_digest(const PaddedShape& P, uint8_t out[32]) {
-  sp::Keccak256State h;
-  h.init();
-  auto w64 = [&](uint64_t v) {
-    uint8_t b[8];
-    for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(v >> (8 * i));
-    h.update(b, 8);
-  };
-  const sp_dims& d = P.dims;
-  w64(d.num_cons);
-  w64(d.num_cons_unpadded);
-  w64(d.num_shared_unpadded);
-  w64(d.num_precommitted_unpadded);
-  w64(d.num_rest_unpadded);
-  w64(d.num_shared);
-  w64(d.num_precommitted);
-  w64(d.num_rest);
-  w64(d.num_public);
-  w64(d.num_challenges);
-  for (int m = 0; m < 3; ++m) {
-    w64(P.data[m].size());
-    w64(P.idx[m].size());
-    w64(P.ptr[m].size());
-    w64(P.num_cols());
-    for (const fe_t& f : P.data[m]) {
-      uint8_t b[32];
-      sp::fe_to_le_bytes<S>(f, b);
-      h.update(b, 32);
-    }
-    for (uint32_t i : P.idx[m]) w64(i);
-    for (uint64_t p : P.ptr[m]) w64(p);
-  }
-  h.finish(out);
+// DigestHelperTrait::digest of SpartanVerifierKey (src/spartan.rs:73-104): SHA-256 over bincode(vk_ee) || bincode(ck_s) || S.write_bytes(), through the
+// library's wire sink (include/spartan_hip.h "wire formats"). gens / gens_s = the num_cols + 1 generators of each key, h last.
+inline void padded_csr(const PaddedShape& P, sp_csr cs[3]) {
+  for (int m = 0; m < 3; ++m) cs[m] = sp_csr{u64p(P.data[m].data()), P.idx[m].data(), P.ptr[m].data()};
+}
+inline void spartan_vk_digest(const PaddedShape& P, const std::vector<aff_t>& gens, const std::vector<aff_t>& gens_s, uint8_t out[32]) {
+  sp_csr cs[3];
+  padded_csr(P, cs);
+  ck(sp_vk_digest(&P.dims, &cs[0], &cs[1], &cs[2], u64p(&gens[0].x), gens.size() - 1, u64p(&gens.back().x), u64p(&gens_s[0].x), gens_s.size() - 1,
+                  u64p(&gens_s.back().x), out),
+     "vk digest");
 }
 
 // This build's generator derivation (documented in DESIGN.md; shape of src/provider/traits.rs:205-249):

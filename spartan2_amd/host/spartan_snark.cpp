@@ -123,7 +123,7 @@ SpartanProverKey* setup(sp_ctx* ctx, const R1CSIntView& R) {
     pk->gens_s = from_label("ck_s", 2);                          // PCS::setup(b"ck_s", 1, 1)
     ck(sp_ck_create(ctx, u64p(&pk->gens[0].x), DEFAULT_COMMITMENT_WIDTH, u64p(&pk->gens[DEFAULT_COMMITMENT_WIDTH].x), &pk->ck), "ck_create");
     ck(sp_ck_create(ctx, u64p(&pk->gens_s[0].x), 1, u64p(&pk->gens_s[1].x), &pk->ck_s), "ck_s_create");
-    shape_digest(P, pk->vk_digest);
+    spartan_vk_digest(P, pk->gens, pk->gens_s, pk->vk_digest);
   } catch (...) {
     delete pk;
     throw;
@@ -1282,6 +1282,48 @@ int ss_prep_export(void* pk_, void* ps_, uint64_t* comm_rows, uint64_t* caz, uin
 int ss_verify(void* pk, const uint64_t* words, size_t nwords, uint64_t* out_publics) {
   try {
     return verify(*(SpartanProverKey*)pk, words, nwords, out_publics);
+  } catch (...) {
+    return catch_all();
+  }
+}
+// SpartanSNARK's shape-dependent lengths (what the bincode length prefixes of a proof for this key must say)
+static sp_spartan_layout proof_layout(const SpartanProverKey& pk) {
+  const sp_dims& d = pk.dims;
+  sp_spartan_layout L;
+  L.rows_shared = d.num_shared_unpadded ? (d.num_shared + 2047) / 2048 : 0;
+  L.rows_precommitted = d.num_precommitted_unpadded ? (d.num_precommitted + 2047) / 2048 : 0;
+  L.rows_rest = (d.num_rest + 2047) / 2048;
+  L.num_public = d.num_public;
+  L.num_challenges = d.num_challenges;
+  L.rounds_x = log2_ceil(d.num_cons);
+  L.rounds_y = log2_ceil(pk.num_vars) + 1;
+  L.z_len = pk.num_vars < 2048 ? pk.num_vars : 2048;
+  return L;
+}
+void ss_proof_layout(void* pk, sp_spartan_layout* out) { *out = proof_layout(*(SpartanProverKey*)pk); }
+// the proof as bincode bytes of SpartanSNARK (src/spartan.rs:125-137); out may be NULL to learn *len
+int ss_proof_to_bytes(void* pk, const uint64_t* words, size_t nwords, uint8_t* out, size_t cap, size_t* len) {
+  try {
+    const sp_spartan_layout L = proof_layout(*(SpartanProverKey*)pk);
+    ck(sp_proof_serialize(&L, words, nwords, out, cap, len), "proof_serialize");
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+// verify on the serialised proof (what a verifier that received bytes runs): 0 = accept, 1..6 = the failed check — bytes that do not decode, or decode
+// to a proof of another shape, fail check 1 like a malformed flat proof —, < 0 = error
+int ss_verify_bytes(void* pk_, const uint8_t* bytes, size_t n, uint64_t* out_publics) {
+  try {
+    auto* pk = (SpartanProverKey*)pk_;
+    sp_spartan_layout L;
+    size_t nwords = 0;
+    if (sp_proof_deserialize(bytes, n, &L, nullptr, 0, &nwords) != SP_OK) return 1;
+    const sp_spartan_layout want = proof_layout(*pk);
+    if (memcmp(&L, &want, sizeof L) != 0) return 1;
+    std::vector<uint64_t> words(nwords);
+    ck(sp_proof_deserialize(bytes, n, &L, words.data(), words.size(), &nwords), "proof_deserialize");
+    return verify(*pk, words.data(), nwords, out_publics);
   } catch (...) {
     return catch_all();
   }

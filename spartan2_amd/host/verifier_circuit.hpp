@@ -290,29 +290,26 @@ struct Shape {  // SplitMultiRoundR1CSShape + to_regular_shape
     }
     return sh;
   }
-  void digest(uint8_t out[32]) const {
-    sp::Keccak256State h;
-    h.init();
-    auto w64 = [&](uint64_t v) {
-      uint8_t b[8];
-      for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(v >> (8 * i));
-      h.update(b, 8);
+  // derived Serialize of SplitMultiRoundR1CSShape (src/r1cs/mod.rs:1401-1419), or of the R1CSShape that to_regular_shape (:1659-1672) makes of it,
+  // into a wire sink of the library (bincode framing; the matrices as data / indices / indptr Vecs + cols, src/r1cs/sparse.rs:383-394)
+  void write_bincode(sp_wire* w, bool regular) const {
+    auto u64v = [&](uint64_t v) { ck(sp_wire_u64s(w, &v, 1, 0), "wire"); };
+    auto usizes = [&](const std::vector<size_t>& v) {
+      std::vector<uint64_t> t(v.begin(), v.end());
+      ck(sp_wire_u64s(w, t.data(), t.size(), 1), "wire");
     };
-    w64(num_cons);
-    w64(num_rounds);
-    w64(num_public);
-    for (size_t v : vars_padded) w64(v);
-    for (int m = 0; m < 3; ++m) {
-      w64(M[m].data.size());
-      for (const fe_t& f : M[m].data) {
-        uint8_t b[32];
-        sp::fe_to_le_bytes<S>(f, b);
-        h.update(b, 32);
-      }
-      for (uint32_t i : M[m].idx) w64(i);
-      for (uint64_t p : M[m].ptr) w64(p);
+    const size_t num_io = total_challenges + num_public;
+    if (regular) {
+      u64v(num_cons), u64v(total_vars), u64v(num_io);
+    } else {
+      u64v(num_cons), u64v(num_cons_unpadded), u64v(num_rounds);
+      usizes(vars_unpadded), usizes(vars_padded), usizes(chals_per_round);
+      u64v(num_public), u64v(width);
     }
-    h.finish(out);
+    for (int m = 0; m < 3; ++m) {
+      sp_csr cs{u64p(M[m].data.data()), M[m].idx.data(), M[m].ptr.data()};
+      ck(sp_wire_matrix(w, &cs, num_cons, total_vars + 1 + num_io, 0), "wire matrix");
+    }
   }
 };
 

@@ -71,9 +71,12 @@ def spartan_small():
     used = sp.prep_prove(tape)
     words, used2, _ = sp.prove(tape[used:])
     assert sp.verify_words(words) == 0
-    return {"note": "oracle proof (oracle/spartan.hpp) of frontend.synthetic_circuit(6, 0xDEADBEEF, 3) with tape = SHAKE256('golden-tape')",
+    wire = sp.proof_to_bytes(words)
+    return {"note": "oracle proof (oracle/spartan.hpp) of frontend.synthetic_circuit(6, 0xDEADBEEF, 3) with tape = SHAKE256('golden-tape'); vk_digest = SHA-256 "
+                    "over SpartanVerifierKey::write_bytes, wire_* = the proof as bincode bytes of SpartanSNARK (oracle/wire.hpp states the framing)",
             "num_cons": inst.num_cons, "num_aux": inst.num_aux, "tape_blocks_prep": used, "tape_blocks_prove": used2, "proof_words": len(words),
-            "proof_sha256": hashlib.sha256(words.tobytes()).hexdigest(), "proof_head": _hex(words[:64]), "proof_tail": _hex(words[-16:])}
+            "proof_sha256": hashlib.sha256(words.tobytes()).hexdigest(), "proof_head": _hex(words[:64]), "proof_tail": _hex(words[-16:]),
+            "vk_digest": sp.export_keys()[4].tobytes().hex(), "wire_len": len(wire), "wire_sha256": hashlib.sha256(wire).hexdigest(), "wire_head": wire[:64].hex()}
 
 
 # ---- NeutronNova NIFS rounds (oracle/nifs.hpp) -----------------------------------------------------------------------------------

@@ -253,6 +253,55 @@ class OracleSpartan:
         lib().orc_spartan_proof_free(pf)
         return rc
 
+    # ---- wire formats (oracle/wire_formats.hpp) ----
+    def vk_bytes(self):
+        """bincode of SpartanVerifierKey as a serde value (vk_ee, ck_s, S)."""
+        return _sized_bytes(lambda out, cap: lib().orc_spartan_vk_to_bytes(self.pk, out, cap))
+
+    def proof_to_bytes(self, words):
+        """flat proof words -> bincode bytes of SpartanSNARK"""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        pf = lib().orc_spartan_proof_from_words(self.pk, p64(words), ctypes.c_size_t(len(words)))
+        if not pf:
+            raise RuntimeError(lib().orc_last_error().decode())
+        pf = ctypes.c_void_p(pf)
+        try:
+            return _sized_bytes(lambda out, cap: lib().orc_spartan_proof_to_bytes(pf, out, cap))
+        finally:
+            lib().orc_spartan_proof_free(pf)
+
+    def proof_from_bytes(self, data):
+        """bincode bytes -> flat proof words (None if the bytes do not decode)"""
+        lib().orc_spartan_proof_from_bytes.restype = ctypes.c_void_p
+        buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        pf = lib().orc_spartan_proof_from_bytes(p8(buf) if len(buf) else None, ctypes.c_size_t(len(buf)))
+        if not pf:
+            return None
+        pf = ctypes.c_void_p(pf)
+        words = np.zeros(lib().orc_spartan_proof_words(pf), dtype=np.uint64)
+        lib().orc_spartan_proof_serialize(pf, p64(words))
+        lib().orc_spartan_proof_free(pf)
+        return words
+
+
+def _sized_bytes(call):
+    """call(out, cap) -> length; two-pass sizing protocol of the oracle's wire exports"""
+    for f in ("orc_spartan_vk_to_bytes", "orc_spartan_proof_to_bytes", "orc_nn_proof_to_bytes"):
+        getattr(lib(), f).restype = ctypes.c_long
+    n = call(None, ctypes.c_size_t(0))
+    if n < 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    out = np.zeros(max(n, 1), dtype=np.uint8)
+    assert call(p8(out), ctypes.c_size_t(n)) == n
+    return out[:n].tobytes()
+
+
+def sha256(data: bytes) -> bytes:
+    buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+    out = np.zeros(32, dtype=np.uint8)
+    lib().orc_sha256(p8(buf) if len(buf) else None, ctypes.c_size_t(len(buf)), p8(out))
+    return out.tobytes()
+
 
 # ---- NeutronNova NIFS data path (oracle/nifs.hpp) -----------------------------------------------
 NIFS_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, c_u64p, c_u64p)
@@ -457,6 +506,30 @@ class OracleNeutronNova:
         lib().orc_nn_proof_free(pf)
         return rc
 
+    def proof_to_bytes(self, words):
+        """flat proof words -> bincode bytes of NeutronNovaZkSNARK (oracle/wire_formats.hpp)"""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        pf = lib().orc_nn_proof_from_words(self.k, p64(words), ctypes.c_size_t(len(words)))
+        if not pf:
+            raise RuntimeError(lib().orc_last_error().decode())
+        pf = ctypes.c_void_p(pf)
+        try:
+            return _sized_bytes(lambda out, cap: lib().orc_nn_proof_to_bytes(pf, out, cap))
+        finally:
+            lib().orc_nn_proof_free(pf)
+
+    def proof_from_bytes(self, data):
+        lib().orc_nn_proof_from_bytes.restype = ctypes.c_void_p
+        buf = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        pf = lib().orc_nn_proof_from_bytes(p8(buf) if len(buf) else None, ctypes.c_size_t(len(buf)))
+        if not pf:
+            return None
+        pf = ctypes.c_void_p(pf)
+        words = np.zeros(lib().orc_nn_proof_words(pf), dtype=np.uint64)
+        lib().orc_nn_proof_serialize(pf, p64(words))
+        lib().orc_nn_proof_free(pf)
+        return words
+
 
 def verifier_circuit_counts(nb, nx, ny, width=32):
     """Counts of NeutronNovaVerifierCircuit derived by hand from src/zk.rs (tests/golden/reference_kats.json 'neutronnova_verifier_circuit_counts'):
@@ -472,3 +545,18 @@ def verifier_circuit_counts(nb, nx, ny, width=32):
     aux = [num(pr[k]["aux"]) for k in seq]
     return {"rounds": len(seq), "aux": sum(aux), "inputs": sum(pr[k]["inputs"] for k in seq), "constraints": sum(num(pr[k]["constraints"]) for k in seq),
             "vars_padded": sum(-(-a // width) * width for a in aux), "public": pr["inner_final"]["public_inputs"]}
+
+
+def verifier_circuit_rounds(nb, nx, ny, width=32):
+    """Per-round padded variable counts of NeutronNovaVerifierCircuit from the same hand derivation, and the number of challenges squeezed AFTER each
+    round, stated from MultiRoundCircuit::num_challenges (src/zk.rs:583-598): one after every NIFS round, none after the NIFS final round, one after
+    every outer / outer-final / inner round, none after inner-final and the two commit_w rounds."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")) as f:
+        pr = json.load(f)["neutronnova_verifier_circuit_counts"]["per_round"]
+    seq = (["nifs_first"] + ["nifs_next"] * (nb - 1) + ["nifs_final", "outer_first"] + ["outer_next"] * (nx - 1) + ["outer_final", "inner_first"]
+           + ["inner_next"] * (ny - 1) + ["inner_final", "commit_w", "commit_w"])
+    num = lambda v: width if isinstance(v, str) else v
+    return {"vars_padded": [-(-num(pr[k]["aux"]) // width) * width for k in seq], "challenges": [1] * nb + [0] + [1] * (nx + 1 + ny) + [0, 0, 0]}

@@ -47,6 +47,15 @@ def test_c1_c2_sha256_spartan_prove_bit_exact(ctx, msg_bytes, log_n):
     assert gsp.dims["num_cons"] == 1 << log_n
     assert (got == want).all()
     assert osp.verify_words(got) == 0 and gsp.verify(got) == 0
+    # wire formats at the config's own size: the vk digest both sides absorbed is the reference's SHA-256 stream
+    # (bincode(vk_ee) || bincode(ck_s) || S.write_bytes(), src/spartan.rs:73-104), the serialised proofs are byte-identical, verify accepts the bytes
+    assert gsp.vk_digest.tobytes() == osp.export_keys()[4].tobytes()
+    data = gsp.proof_to_bytes(got)
+    assert data == osp.proof_to_bytes(want)
+    assert gsp.verify_bytes(data) == 0 and osp.verify_words(osp.proof_from_bytes(data)) == 0
+    bad = bytearray(data)
+    bad[len(bad) // 2] ^= 1
+    assert gsp.verify_bytes(bytes(bad)) != 0
     gsp.close()
 
 

@@ -60,6 +60,11 @@ def test_spartan_proof_against_golden(ctx):
     assert (used, used2, len(words)) == (gold["tape_blocks_prep"], gold["tape_blocks_prove"], gold["proof_words"])
     assert hashlib.sha256(words.tobytes()).hexdigest() == gold["proof_sha256"]
     assert words[:64].tobytes().hex() == gold["proof_head"] and words[-16:].tobytes().hex() == gold["proof_tail"]
+    # the wire formats against frozen data: the vk digest (SHA-256 over SpartanVerifierKey::write_bytes) and the proof as bincode bytes
+    assert sn.vk_digest.tobytes().hex() == gold["vk_digest"]
+    wire = sn.proof_to_bytes(words)
+    assert len(wire) == gold["wire_len"] and hashlib.sha256(wire).hexdigest() == gold["wire_sha256"] and wire[:64].hex() == gold["wire_head"]
+    assert sn.verify_bytes(wire) == 0
 
 
 def test_nifs_rounds_against_golden(ctx):

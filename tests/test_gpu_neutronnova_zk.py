@@ -79,6 +79,19 @@ def test_verify_rejects_what_the_oracle_rejects(ctx, n, groups):
     bad = got.copy()
     bad[-4:] = np.uint64(0xFFFFFFFFFFFFFFFF)  # blind_E >= the modulus
     assert gnn.verify(bad) == 1
+    # the same on serialised proofs: every tampered proof that still decodes fails the check its flat form fails; malformed bytes fail check 1
+    data = gnn.proof_to_bytes(got)
+    assert data == onn.proof_to_bytes(got) and gnn.verify_bytes(data) == 0
+    for pos in positions[:12]:
+        bad = got.copy()
+        bad[pos] ^= np.uint64(1)
+        rc = gnn.verify(bad)
+        if rc != 1:
+            assert gnn.verify_bytes(gnn.proof_to_bytes(bad)) == rc, pos
+    assert gnn.verify_bytes(data[:-1]) == 1 and gnn.verify_bytes(data + b"\0") == 1 and gnn.verify_bytes(b"") == 1
+    b = bytearray(data)
+    b[-32:] = bytes([0xFF]) * 32
+    assert gnn.verify_bytes(bytes(b)) == 1
     gnn.close()
 
 
@@ -89,6 +102,8 @@ def test_shared_and_precommitted_segments(ctx):
     core = mk(5)
     onn, gnn, want, got, _, _, _ = _both(ctx, steps, core, 71)
     assert (got == want).all() and onn.verify_words(got) == 0 and gnn.verify(got) == 0
+    data = gnn.proof_to_bytes(got)  # Some(comm_W_shared) on the wire
+    assert data[0] == 1 and data == onn.proof_to_bytes(want) and gnn.verify_bytes(data) == 0
     gnn.close()
 
 
@@ -100,5 +115,11 @@ def test_c3_sha256_neutronnova_32_steps(ctx):
     assert gnn.info["nb"] == 5 and gnn.info["nx"] == 15 and gnn.info["ny"] == 16
     assert (got == want).all()
     assert onn.verify_words(got) == 0 and gnn.verify(got) == 0
-    print("C3 prove phases (ms):", {k: round(v, 3) for k, v in phases.items()})
+    # wire formats at config 3: the vk digest is the reference's SHA-256 stream on both sides (compared in _both), the proof's
+    # bincode bytes equal the oracle's, and verify accepts the deserialised bytes
+    data = gnn.proof_to_bytes(got)
+    assert data == onn.proof_to_bytes(want)
+    assert gnn.verify_bytes(data) == 0 and (gnn.proof_from_bytes(data) == got).all()
+    assert onn.verify_words(onn.proof_from_bytes(data)) == 0
+    print("C3 prove phases (ms):", {k: round(v, 3) for k, v in phases.items()}, "proof bytes:", len(data))
     gnn.close()
