@@ -338,16 +338,6 @@ int sp_sumcheck_quad_sharded_observed(sp_ctx* ctx, uint64_t claim_io[4], size_t 
 int sp_sumcheck_cubic3_observed(sp_ctx* ctx, const uint64_t claim[4], const uint64_t* taus, size_t ell, sp_table* A, sp_table* B, sp_table* C, const sp_table* p0,
                                 const sp_table* p1, sp_transcript* tr, sp_challenge_hook observe, void* user, uint64_t* out_cpolys, uint64_t* out_r,
                                 uint64_t out_final[12]);
-/* bind_and_prepare_poly_ABC (src/r1cs/mod.rs:1235-1398) split at a challenge boundary: eq(r_x, row) = eq(r_hi, row >> n_lo) * eq(r_lo, row & mask) and the
- * outer sum-check draws r_x top variable first, so `_begin` — given the first n_hi challenges while the sum-check is still running its last, latency-bound
- * rounds — weights every matrix entry with its eq_hi factor on the auxiliary stream, and `_finish` (all challenges known, plus the joint challenge r of
- * src/spartan.rs:311) only streams the weights against the small eq_lo table: same poly_ABC as sp_poly_abc, without the 2^ell-entry evals_rx table or
- * its random gathers on the critical path. n_hi, n_lo <= 12, n_hi + n_lo = log2(num_cons). The workspace holds 32 bytes per matrix entry. */
-typedef struct sp_polyabc_ws sp_polyabc_ws;
-int sp_poly_abc_ws_create(sp_ctx* ctx, const sp_shape* s, sp_polyabc_ws** out);
-void sp_poly_abc_ws_free(sp_polyabc_ws* w);
-int sp_poly_abc_begin(sp_ctx* ctx, sp_polyabc_ws* w, const uint64_t* r_hi, size_t n_hi);
-int sp_poly_abc_finish(sp_ctx* ctx, sp_polyabc_ws* w, const uint64_t* r_lo, size_t n_lo, const uint64_t r[4], size_t out_len, sp_table* out);
 
 /* ---- NeutronNova batched ZK sum-checks (src/sumcheck.rs:702-917) --------------------------------------------------------------------
  * The reference obtains each round's challenge from the ZK verifier circuit (`SatisfyingAssignment::process_round`, :747-755, :864-872) —

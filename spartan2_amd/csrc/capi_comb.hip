@@ -12,7 +12,7 @@ namespace sp {
 
 // ---- fixed-base comb path for many rows over the key (kernels_comb.hpp) ---------------------------------------------------------------------------
 // SPARTAN_COMB_BITS = signed window width C (8, 10, 12, 13 or 14; 0 disables the path): the table takes ceil(257 / C) * num_cols * 2^(C-1) * 64 bytes
-// (2048 bases: C = 12: 5.9 GB, C = 13 (default): 10.7 GB, C = 14: 20 GB; measured sweep in profiles/r02_comb_bits_sweep.txt). SPARTAN_COMB_MIN_ROWS = how many digit-path rows one commit must have before the table is built.
+// (2048 bases: C = 12: 5.9 GB, C = 13 (default): 10.7 GB, C = 14: 20 GB; measured sweep in profiles/r02_comb_bits_sweep.txt). A commit must have 256 digit-path rows before the table is built (comb_min_rows).
 static int comb_bits() {
   static const int v = [] {
     const char* e = getenv("SPARTAN_COMB_BITS");
@@ -22,13 +22,7 @@ static int comb_bits() {
   }();
   return v;
 }
-size_t comb_min_rows() {
-  static const size_t v = [] {
-    const char* e = getenv("SPARTAN_COMB_MIN_ROWS");
-    return e ? (size_t)atol(e) : (size_t)256;
-  }();
-  return v;
-}
+size_t comb_min_rows() { return 256; }
 int comb_ensure(sp_ctx* c, const sp_ck* ck) {
   if (ck->d_comb) return SP_OK;
   if (ck->comb_failed || comb_bits() == 0) return 1;  // not available: the caller takes the bucket path
@@ -85,21 +79,12 @@ int comb_rows(sp_ctx* c, const sp_ck* ck, const fe_t* canon, size_t cols, size_t
   if ((rc = dsel.alloc(sel.size() * 4)) || (rc = drows.alloc(sel.size() * sizeof(jac_t)))) return rc;
   SP_HIP(hipMemcpyAsync(dsel.p, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, c->stream));
   const dim3 grid((unsigned)sel.size()), block(256);
-  static const bool occ4 = [] {  // SPARTAN_COMB_OCC4=1: the 128-register build (4 waves per SIMD, a few spills) instead of 141 registers / 3 waves
-    const char* e = getenv("SPARTAN_COMB_OCC4");
-    return e && e[0] == '1';
-  }();
   // 96 B per (scalar, base) pair (+ one 64-byte table entry per window actually gathered)
   c->timed("msm_rows_comb", 96ull * sel.size() * cols, [&] {
     switch (C) {
       case 8: hipLaunchKernelGGL((spk::k_comb_rows<8, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
       case 10: hipLaunchKernelGGL((spk::k_comb_rows<10, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
-      case 12:
-        if (occ4) {
-          hipLaunchKernelGGL((spk::k_comb_rows<12, 4>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>());
-          break;
-        }
-        hipLaunchKernelGGL((spk::k_comb_rows<12, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
+      case 12: hipLaunchKernelGGL((spk::k_comb_rows<12, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
       case 13: hipLaunchKernelGGL((spk::k_comb_rows<13, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
       default: hipLaunchKernelGGL((spk::k_comb_rows<14, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
     }

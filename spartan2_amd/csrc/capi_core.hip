@@ -129,8 +129,7 @@ int sp_ctx_create(int device, sp_ctx** out) {
   c->d_mail = reinterpret_cast<const unsigned*>(c->d_pinned + spk::MAIL_MIRROR_ELEM);
   {  // SPARTAN_MAIL_DEV=0 keeps the mailbox in host memory (and with it the launch-after-challenge round loop)
     const char* e = getenv("SPARTAN_MAIL_DEV");
-    const char* mt = getenv("SPARTAN_MAIL_MEMTYPE");  // "uncached": hipDeviceMallocUncached instead of hipDeviceMallocFinegrained (experiment knob)
-    const unsigned flags = (mt && mt[0] == 'u') ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+    const unsigned flags = hipDeviceMallocFinegrained;
     int large_bar = 0;
     if (!(e && e[0] == '0') && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar &&
         hipExtMallocWithFlags(&c->mail_alloc, 4096, flags) == hipSuccess) {
@@ -141,8 +140,6 @@ int sp_ctx_create(int device, sp_ctx** out) {
       c->h_mail = reinterpret_cast<volatile uint32_t*>(c->mail_alloc);  // the host stores straight into device memory over the BAR
       c->d_mail = reinterpret_cast<const unsigned*>(c->mail_alloc);
       c->mail_dev = true;
-      const char* nm = getenv("SPARTAN_MAIL_MIRROR");  // "0": no second path (the round-2 behaviour, for A/B runs of the stress tool)
-      if (nm && nm[0] == '0') c->d_mail_mirror = nullptr;
     }
   }
   int rc = c->ensure_scratch(1 << 16);
@@ -525,17 +522,10 @@ static bool round_trace() {
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---- persistent tail (kernels_poly.hpp k_sumcheck_tail): host half of the mailbox ------------------------------------------------------
-static size_t tail_max_len() {  // SPARTAN_TAIL_LOG2 = 0 disables the resident tail, 2..16 caps the table length it takes over
-  static const size_t v = [] {
-    const char* e = getenv("SPARTAN_TAIL_LOG2");
-    size_t lg = e ? (size_t)atoi(e) : 15;
-    if (lg > 16) lg = 16;  // 4 * TAIL_WIDE_Q pairs-of-pairs per block, HOST_SUM_MAX_BLOCKS result slots
-    return lg < 2 ? (size_t)0 : (size_t)1 << lg;
-  }();
-  return v;
-}
-#define TAIL_MAX_LEN tail_max_len()
-static bool tail_enabled() { return tail_max_len() != 0; }
+// the resident tail takes a sum-check over from tables of 2^15 elements down (at most 2^16: 4 * TAIL_WIDE_Q pairs-of-pairs per block, HOST_SUM_MAX_BLOCKS
+// result slots; sweeps of 2^13 .. 2^16 measured within 5 us of each other, tools/tail_sweep.sh)
+static constexpr size_t TAIL_MAX_LEN = (size_t)1 << 15;
+static bool tail_enabled() { return true; }
 // mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 / 10 = two independent
 // check words (sequence + plain sum, sequence * K + position-weighted sum), 11 = the sequence number again, so a poll that straddles the host's
 // stores is recognised and retried (mail_wait in kernels_poly.hpp).
@@ -594,11 +584,7 @@ static spk::MailRef mail_ref(sp_ctx* c, bool ahead, unsigned answers) {
 // a fused bind+evaluate launch may be issued AHEAD of its challenge (the kernel waits at the mailbox) when the mailbox is in device memory.
 // The largest tables are left alone: their kernels are the bandwidth-bound ones whose durations the roofline is measured on.
 static bool launch_ahead_ok(sp_ctx* c, size_t table_len) {
-  static const size_t max_len = [] {
-    const char* e = getenv("SPARTAN_AHEAD_LOG2");
-    return (size_t)1 << (e ? atoi(e) : 19);
-  }();
-  return c->mail_dev && table_len <= max_len;
+  return c->mail_dev && table_len <= ((size_t)1 << 19);
 }
 // result slots (= resident blocks still active) of the evaluation over a table of `len` elements
 static unsigned tail_blocks(size_t len, bool cubic = false) {
@@ -852,13 +838,7 @@ int sp_transcript_new(sp_ctx*, const uint8_t* label, size_t n, sp_transcript** o
 // one hashing thread per process for the long absorbs (see sp_transcript): taken by whichever transcript asks first, everyone else hashes inline
 static sp::Worker g_hash_worker;
 static std::atomic<bool> g_hash_taken{false};
-static size_t async_absorb_min() {
-  static const size_t v = [] {
-    const char* e = getenv("SPARTAN_ASYNC_ABSORB_MIN");  // bytes; 0 = never
-    return e ? (size_t)atol(e) : (size_t)4096;
-  }();
-  return v;
-}
+static size_t async_absorb_min() { return 4096; }  // bytes
 int sp_transcript_absorb(sp_transcript* t, const uint8_t* label, size_t ln, const uint8_t* bytes, size_t n) {
   t->join();
   const size_t amin = async_absorb_min();
@@ -1213,20 +1193,11 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       if (len >= STREAM_MIN_Q && len % 1024 == 0) {  // streaming form: lazy sums, lazy second stage
         spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
         const unsigned seq = next_seq(c);
-        static const int lowhi_ppt = [] {
-          const char* e = getenv("SPARTAN_EQ_PPT");
-          const int v = e ? atoi(e) : 4;
-          return v == 1 || v == 2 ? v : 4;
-        }();
         const size_t hi_max = sp::eff_hi(A) > sp::eff_hi(B) ? sp::eff_hi(A) : sp::eff_hi(B);
         const bool lowhi = hi_max <= len / 2;  // short non-zero prefix in the high halves: dot-product form
-        const size_t blocks = len / (256 * (size_t)(lowhi ? lowhi_ppt : 4));
+        const size_t blocks = len / (256 * (size_t)4);
         c->timed("eval_quad", 64ull * len + 32ull * ((sp::eff_hi(A) < len ? sp::eff_hi(A) : len) + (sp::eff_hi(B) < len ? sp::eff_hi(B) : len)), [&] {
-          if (lowhi && lowhi_ppt == 1)
-            hipLaunchKernelGGL((spk::k_eval_quad_stream_lowhi<1>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
-          else if (lowhi && lowhi_ppt == 2)
-            hipLaunchKernelGGL((spk::k_eval_quad_stream_lowhi<2>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
-          else if (lowhi)
+          if (lowhi)
             hipLaunchKernelGGL((spk::k_eval_quad_stream_lowhi<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
           else
             hipLaunchKernelGGL((spk::k_eval_quad_stream<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
@@ -1419,14 +1390,10 @@ static int eval_cubic_outer_pow_pair(sp_ctx* c, const sp_table* pl, const sp_tab
 
 // Small tables (<= 2^13 elements): the bind of round i and the evaluation of round i + 1 of both instances in one launch with one product per lane
 // (k_bind_eval_*_pair_small); dense tables of equal length only. Returns 1 when done (the tables are bound and `sums` holds the next round's), 0 when
-// this form does not apply (the caller binds and evaluates separately), < 0 on error. SPARTAN_BATCHED_SMALL=0: never.
-static bool batched_small_enabled() {
-  const char* e = getenv("SPARTAN_BATCHED_SMALL");
-  return !(e && e[0] == '0');
-}
+// this form does not apply (the caller binds and evaluates separately), < 0 on error.
 static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* const B[2], const fe_t& r, fe_t sums[2][2]) {
   const size_t len = A[0]->len;
-  if (!batched_small_enabled() || len < 4) return 0;
+  if (len < 4) return 0;
   for (int b = 0; b < 2; ++b)
     if (A[b]->len != len || B[b]->len != len || !table_dense(A[b]) || !table_dense(B[b])) return 0;
   const size_t q = len / 4, nb = (q + spk::SMALL_PAIR_PPB - 1) / spk::SMALL_PAIR_PPB;
@@ -1456,7 +1423,7 @@ static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* 
 static int bind_eval_cubic_pow_pair_small(sp_ctx* c, const sp_table* pl, const sp_table* pr, sp_table* const step[3], sp_table* const core[3], const fe_t& r,
                                           fe_t sums[2][3]) {
   const size_t len = step[0]->len, left = pl->len;
-  if (!batched_small_enabled() || len < 4) return 0;
+  if (len < 4) return 0;
   for (int k = 0; k < 3; ++k)
     if (step[k]->len != len || core[k]->len != len || !table_dense(step[k]) || !table_dense(core[k])) return 0;
   const size_t q = len / 4, nb = (q + spk::SMALL_PAIR_PPB - 1) / spk::SMALL_PAIR_PPB;

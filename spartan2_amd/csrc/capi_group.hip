@@ -87,13 +87,8 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
   run("msm_bucket_sum", 96ull * n, [&] {
     hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256), dim3(256), 0, st, d_bases, (unsigned)n, order, start, windows, buckets);
   });
-  static const bool coop = [] {
-    const char* e = getenv("SPARTAN_MSM_COOP");
-    return !(e && e[0] == '0');
-  }();
   run("msm_window_reduce", 0, [&] {
-    if (coop) hipLaunchKernelGGL(spk::k_msm_window_reduce_coop, dim3(windows), dim3(4 * spk::MSM_BUCKETS), 0, st, buckets, wsum);
-    else hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows), dim3(spk::MSM_BUCKETS), 0, st, buckets, wsum);
+    hipLaunchKernelGGL(spk::k_msm_window_reduce_coop, dim3(windows), dim3(4 * spk::MSM_BUCKETS), 0, st, buckets, wsum);
   });
   pend->windows = windows;
   pend->slot = (int)(c->msm_jobs_issued[lane]++ % MSM_LANDING_SLOTS);
@@ -393,16 +388,9 @@ int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, 
 static bool fb_mapped_enabled();
 static int fb_mapped_ensure(sp_ctx* c, int lane);
 // 16-bit window tables of the latency paths (kernels_msm.hpp k_fixed_base_tables16), found by the address of the 8-bit table set they shadow.
-// SPARTAN_FB_WINDOW16=0: not built.
 static std::mutex g_t16_mu;
 static std::map<const aff_t*, const aff_t*> g_t16;
-static bool fb_window16_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("SPARTAN_FB_WINDOW16");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+static bool fb_window16_enabled() { return true; }
 static const aff_t* tables16_of(const aff_t* t8) {
   std::lock_guard<std::mutex> l(g_t16_mu);
   auto it = g_t16.find(t8);
@@ -490,13 +478,8 @@ static jac_t fixed_base_mul_host(const aff_t* table, const fe_t& scalar) {
   return acc;
 }
 // few scalars (the latency case: the blinds of the zero rows): block-cooperative additions; many: one half-wave per scalar (throughput).
-// SPARTAN_FB_COOP=0 forces the half-wave form.
 static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, const aff_t* tables, size_t ntables, jac_t* dout) {
-  static const bool coop = [] {
-    const char* e = getenv("SPARTAN_FB_COOP");
-    return !(e && e[0] == '0');
-  }();
-  if (coop && n <= 2048) {  // 512 blocks of four scalars: one resident wave of blocks at two per CU
+  if (n <= 2048) {  // 512 blocks of four scalars: one resident wave of blocks at two per CU
     hipLaunchKernelGGL(spk::k_fixed_base_rows_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, tables, ntables, dout);
   } else {
     const size_t threads = n * 32;
@@ -507,15 +490,9 @@ static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU
 
 // table[i % ntables] * scalars[i] on the device (Jacobian results in host memory); ntables == 1 for h
 // <= 128 scalars through mapped memory (kernels_msm.hpp k_fixed_base_rows_coop_mapped): launch on lane 0 = the main stream / lane 1 = the auxiliary stream,
-// then poll the n self-validating result slots. SPARTAN_FB_MAPPED=0 keeps the copy / launch / copy / synchronise form.
+// then poll the n self-validating result slots. Larger calls keep the copy / launch / copy / synchronise form.
 static const size_t FB_MAPPED_MAX = 128, FB_SLOT_BYTES = 4 * spk::FB_SLOT_WORDS;
-static bool fb_mapped_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("SPARTAN_FB_MAPPED");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+static bool fb_mapped_enabled() { return true; }
 // (allocated when a key is created, not inside a prove: an allocation call can wait for the device, and with it for resident kernels of other contexts
 // that are themselves waiting for host threads the call may be holding up)
 static int fb_mapped_ensure(sp_ctx* c, int lane) {
@@ -533,10 +510,6 @@ static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t n
   memcpy((char*)c->h_fbm[lane] + FB_MAPPED_MAX * FB_SLOT_BYTES, scalars, n * sizeof(fe_t));
   if (++c->fbm_seq[lane] == 0) ++c->fbm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
-  static const bool wide = [] {  // SPARTAN_FB_ITEMS=128: four scalars per 512-thread block (two waves per SIMD)
-    const char* e = getenv("SPARTAN_FB_ITEMS");
-    return e && atoi(e) == 128;
-  }();
   const fe_t* ds = reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * FB_SLOT_BYTES);
   unsigned* dslots = reinterpret_cast<unsigned*>(c->d_fbm[lane]);
   const unsigned seq = c->fbm_seq[lane];
@@ -545,7 +518,6 @@ static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t n
     if (t16 && xyzz_out) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 16, true>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ds, n, t16, ntables, dslots, seq);
     else if (t16) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 16, false>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ds, n, t16, ntables, dslots, seq);
     else if (xyzz_out) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 8, true>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
-    else if (wide) hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<128, 8, false>), dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, ds, n, d_tables, ntables, dslots, seq);
     else hipLaunchKernelGGL((spk::k_fixed_base_rows_coop_mapped<64, 8, false>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, ds, n, d_tables, ntables, dslots, seq);
   });
   return SP_OK;
@@ -964,9 +936,7 @@ int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_a
 
 // bind_with_delayed (hyrax_pc.rs:38-54) on `st`: the one-launch streaming kernel for tall matrices, else the two-stage form
 static void launch_rowmat_vec(hipStream_t st, const fe_t* poly, size_t rows, size_t cols, const fe_t* dL, fe_t* part, size_t splits, fe_t* dout) {
-  const char* e = getenv("SPARTAN_ROWMAT_TALL");  // "0": the two-stage form for every shape (A/B runs, tests)
-  const bool tall_ok = !(e && e[0] == '0');
-  if (tall_ok && rows >= 128 && cols % spk::RMV_COLS == 0) {
+  if (rows >= 128 && cols % spk::RMV_COLS == 0) {
     hipLaunchKernelGGL(spk::k_rowmat_vec_tall, dim3((unsigned)(cols / spk::RMV_COLS)), dim3(1024), 0, st, poly, rows, cols, dL, dout);
     return;
   }
@@ -1249,13 +1219,7 @@ int multi_mul_ensure(sp_ctx* c, int lane) {
 // `scalars`: n host scalars (copied into the lane's mapped page), or — `d_scalars` given — n - 1 scalars already in device memory followed by `last`
 // `raw_blocks` > 0: `scalars` are that many 64-byte uniform blocks (scalar i = from_uniform of block i, reduced on the device; scalars beyond them are
 // zero up to `last`): needs the wide kernel (n >= its threshold) and `last`
-size_t multi_mul_wide_min() {  // SPARTAN_MM_WIDE_MIN: scalars from which the 1024-item blocks (k_multi_mul_wide) are used
-  static const size_t v = [] {
-    const char* e = getenv("SPARTAN_MM_WIDE_MIN");
-    return e ? (size_t)atol(e) : (size_t)1024;
-  }();
-  return v;
-}
+size_t multi_mul_wide_min() { return 1024; }  // scalars from which the 1024-item blocks (k_multi_mul_wide) are used
 int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last,
                      size_t raw_blocks) {
   if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multi_mul: 1 .. 4096 scalars");

@@ -386,11 +386,7 @@ SP_HD fe_t fe_mul(const fe_t& a, const fe_t& b) {
 #if !defined(__HIP_DEVICE_COMPILE__)
   return fe_mul_host64<FP>(a, b);
 #else
-#ifdef SP_ROWWISE_BASE_PRODUCT  // A/B switch for tools/fb_stamps.hip and tools/ubench.hip: the compiler-scheduled row-wise product + word-serial reduction
-  if constexpr (true) {
-#else
   if constexpr (FP::P256_PRIME) {
-#endif
     uint32_t t[16];
     fe_mul_wide(t, a, b);
     return fe_redc<FP>(t);

@@ -308,11 +308,7 @@ __device__ __forceinline__ void xyzz_add_block4(CoopAdd<ITEMS>& L, const xyzz_t*
   // run 2.5-3x slower under a sparse EXEC mask on this part.
   // (A wave none of whose items takes part skips the products altogether: it would only compete with the wave it shares its SIMD with.)
   fe_t(*t)[ITEMS] = L.t;
-#ifdef SP_COOP_PREDICATED  // (tools/fb_stamps.hip builds this form beside the default one to show the difference)
-  const bool run = active;
-#else
   const bool run = __ballot(active) != 0;  // wave-uniform
-#endif
   // stage 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
   if (run) {
     if (active && role == 0) {

@@ -551,21 +551,6 @@ class Shape:
         r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
         check(lib().sp_poly_abc(self.ctx.h, self.h, rx.h, p64(r), ctypes.c_size_t(out_len), out.h))
 
-    def poly_abc_split(self, r_x, n_hi, r, out_len, out: Table):
-        """the same poly_ABC for rx = eq(r_x), split at a challenge boundary: sp_poly_abc_begin with the first n_hi challenges (auxiliary stream), then
-        sp_poly_abc_finish with the rest."""
-        r_x = np.ascontiguousarray(r_x, dtype=np.uint64).reshape(-1, 4)
-        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
-        ws = ctypes.c_void_p()
-        check(lib().sp_poly_abc_ws_create(self.ctx.h, self.h, ctypes.byref(ws)))
-        try:
-            hi, lo = np.ascontiguousarray(r_x[:n_hi]), np.ascontiguousarray(r_x[n_hi:])
-            check(lib().sp_poly_abc_begin(self.ctx.h, ws, p64(hi) if n_hi else None, ctypes.c_size_t(n_hi)))
-            check(lib().sp_poly_abc_finish(self.ctx.h, ws, p64(lo) if len(lo) else None, ctypes.c_size_t(len(lo)), p64(r), ctypes.c_size_t(out_len), out.h))
-            self.ctx.synchronize()
-        finally:
-            lib().sp_poly_abc_ws_free(ws)
-
     def __del__(self):
         try:
             if self.h:

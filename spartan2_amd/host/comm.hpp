@@ -128,9 +128,8 @@ struct Comm {
   bool small_setup() {
     if (small_ready) return true;
     if (small_failed) return false;
-    const char* e = getenv("SPARTAN_COMM_SMALL");  // "0": staging copies for every size (A/B runs)
     int large_bar = 0;
-    if ((e && e[0] == '0') || hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar ||
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess || !large_bar ||
         hipExtMallocWithFlags(&d_small_send, SMALL_MAX, hipDeviceMallocFinegrained) != hipSuccess) {
       small_failed = true;
       return false;

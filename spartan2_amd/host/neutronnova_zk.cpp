@@ -99,7 +99,7 @@ struct NNZkKey {
   // verify(): eq tables and the three M * T_y products of the matrix evaluations, allocated on first use
   mutable sp_table *v_Tx = nullptr, *v_Ty = nullptr, *v_mv[3] = {nullptr, nullptr, nullptr};
   // r_b, r_x and r_y are fields of the proof, so the commitment fold and the matrix evaluations can start before the transcript has been replayed:
-  // they run as jobs on a second context of the same GPU beside the replay, NovaNIFS::verify and the relaxed Spartan check (SPARTAN_NN_SIDE=0: inline)
+  // they run as jobs on a second context of the same GPU beside the replay, NovaNIFS::verify and the relaxed Spartan check
   mutable sp_ctx* v_ctx2 = nullptr;
   mutable Worker v_wk;
   ~NNZkKey() {
@@ -135,7 +135,7 @@ struct NNZkPrep {
   // Two pieces of prove() read nothing the transcript produces before they are needed: the random relaxed instance of the verifier circuit with its
   // two commitments (values from the randomness tape only, src/r1cs/mod.rs:474-531) and the fold of the step instances' commitments (read first by the
   // opening, :2019-2065). They run as jobs of one helper thread on a SECOND context of the same GPU (own streams and workspaces), under the NIFS rounds
-  // and the two batched sum-checks, instead of 0.8 ms each on the critical path. SPARTAN_NN_SIDE=0 keeps them inline.
+  // and the two batched sum-checks, instead of 0.8 ms each on the critical path.
   // the sixteen working tables of a prove (layers out of the NIFS, core products, pow / eq tables, both poly_ABC and z pairs, the folded witnesses):
   // their sizes are the key's, so they are allocated once (a prove used to pay sixteen hipMalloc / hipFree pairs, the frees after its last phase)
   sp_table* work[16] = {};
@@ -416,10 +416,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     t_lap = t;
   };
   ck(sp_ctx_bind_thread(ctx), "device");
-  static const bool side = [] {
-    const char* e = getenv("SPARTAN_NN_SIDE");
-    return !(e && e[0] == '0');
-  }();
+  const bool side = true;  // (false = everything inline on the caller's context: the order the phase comments describe)
   struct SideGuard {  // no exit path leaves a job running on state this call owns
     NNZkPrep& ps;
     ~SideGuard() { ps.wk.drain(); }
@@ -1276,10 +1273,7 @@ static int nn_verify(const NNZkKey& pk, const uint64_t* words, size_t nwords) {
   for (size_t rr = 0; rr < rows; ++rr)
     for (size_t i = 0; i < np; ++i) fold_bases[rr * np + i] = Ucomm[inst(i)][rr];
   fe_t eabc[2][3];
-  static const bool side = [] {
-    const char* e = getenv("SPARTAN_NN_SIDE");
-    return !(e && e[0] == '0');
-  }();
+  const bool side = true;  // (false = everything inline on the caller's context: the order the phase comments describe)
   auto fold_commitments = [&](sp_ctx* on) {
     ck(sp_msm_shared_weights(on, u64p(wts.data()), np, reinterpret_cast<const uint64_t*>(fold_bases.data()), rows, reinterpret_cast<uint64_t*>(folded_comm.data())), "fold_commitments");
   };

@@ -41,14 +41,8 @@ struct SpartanProverKey {  // src/spartan.rs:30-58
 // How a helper thread waits for its owner. It sleeps on a condition variable that the owner notifies at each state change: measured at config 2, a
 // lone prove is as fast this way as with a spinning helper (1.29-1.31 ms either way; wake-up ~10 us, off the critical path or under the MSM it
 // starts), and a spinning helper costs one CPU per prove in flight on top of the owner's polling thread - under the 16-CPU CFS quota of the bench
-// boxes eight such pairs got the whole cgroup throttled and resident kernels ran into their watchdog. SPARTAN_HELPER_SPIN=1 restores spinning.
-static bool helper_may_spin() {
-  static const bool v = [] {
-    const char* e = getenv("SPARTAN_HELPER_SPIN");
-    return e && e[0] == '1';
-  }();
-  return v;
-}
+// boxes eight such pairs got the whole cgroup throttled and resident kernels ran into their watchdog.
+static bool helper_may_spin() { return false; }
 
 // Per-prep-state driver options (ss_prep_set_flags; defaults from the environment at prep_prove time).
 //   FLAG_PREFIX_CACHE: the transcript prefix new + vk + public_values + comm_W_shared / comm_W_precommitted is the same for every prove on one prep
@@ -80,16 +74,11 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   sp_points* comm_pts = nullptr;        // comm_W on the device: the bases of comm_LZ's MSM
   // FixedBaseMul tables of the rows committed here (shared, precommitted) and of h (msm.rs:653-689): with no rest variables the remaining rows of
   // comm_W are h * blind (commit_zeros), so comm_LZ = sum_fixed L_i comm_W[i] + (sum_rest L_i blind_i) h is one multi_mul over these tables
-  // (sp_fbtables_multi_mul: 14 levels of additions in one launch instead of a 512-point MSM behind the last row challenge). SPARTAN_LZ_TABLES=0: off.
+  // (sp_fbtables_multi_mul: 14 levels of additions in one launch instead of a 512-point MSM behind the last row challenge).
   // Up to 512 rows (2^20 variables): measured at 1024 / 2048 rows the walk (a 17-level chain over 256 / 512 blocks) loses to the MSM it would replace
   // (1.77 vs 1.70 ms, 2.58 vs 2.51 ms): there the sum-check's last rounds no longer cover it and its blocks compete with the streaming rounds.
   sp_fbtables* lz_tables = nullptr;
-  // poly_ABC split at a challenge boundary (sp_poly_abc_begin / _finish): the entries' eq weights over the top variables are formed under the outer
-  // sum-check's last rounds, 32 bytes per matrix entry of workspace (160 MB at config 2). Opt-in with SPARTAN_ABC_SPLIT=1 (see prep_prove).
-  sp_polyabc_ws* abc_ws = nullptr;
-  size_t abc_n_lo = 0;
   ~SpartanPrepSNARK() {
-    sp_poly_abc_ws_free(abc_ws);
     sp_fbtables_free(lz_tables);
     bg.wait_nothrow();
     bg2.wait_nothrow();
@@ -178,9 +167,8 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
       ps->comm_pre_bytes = commitment_bytes(ps->comm_W_fixed.data() + ps->rows_shared, ps->rows_precommitted);
     }
     {
-      const char* e = getenv("SPARTAN_LZ_TABLES");
       const size_t fixed = ps->comm_W_fixed.size(), rows_all = (M + CW - 1) / CW;
-      if (!(e && e[0] == '0') && !(ps->flags & FLAG_LZ_DIRECT) && d.num_rest_unpadded == 0 && d.num_challenges == 0 && fixed >= 1 && fixed + 1 <= 512 && rows_all > 1) {
+      if (!(ps->flags & FLAG_LZ_DIRECT) && d.num_rest_unpadded == 0 && d.num_challenges == 0 && fixed >= 1 && fixed + 1 <= 512 && rows_all > 1) {
         std::vector<aff_t> pts(ps->comm_W_fixed);
         pts.push_back(pk.gens[CW]);  // h
         ck(sp_fbtables_create(ctx, u64p(&pts[0].x), pts.size(), &ps->lz_tables), "tables of the committed rows");
@@ -198,17 +186,6 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
       ck(sp_table_zeros(ctx, N / 2, (size_t)-1, (size_t)-1, &ps->p1), "alloc round-0 products");
     }
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->abc), "alloc poly_ABC");
-    {
-      const char* e = getenv("SPARTAN_ABC_SPLIT");
-      const size_t ell = log2_ceil(N);
-      // Opt-in (SPARTAN_ABC_SPLIT=1): measured at config 2 the final pass takes as long as the one-pass kernel (105 - 108 us against 110: both are bound by
-      // dependent latencies at 4 waves per SIMD, not by the gathers the split removes) and the weights pass disturbs the outer sum-check's last rounds
-      // (+10 - 20 us): 1.164 - 1.19 ms against 1.144 ms. Kept behind the ABI with its tests; not the default.
-      if (e && e[0] == '1' && ell >= 16 && ell <= 22) {  // both halves of the row index within 12 bits
-        ps->abc_n_lo = 10;
-        ck(sp_poly_abc_ws_create(ctx, pk.S, &ps->abc_ws), "poly_ABC workspace");
-      }
-    }
     ck(sp_ctx_synchronize(ctx), "sync");
   } catch (...) {
     delete ps;
@@ -540,27 +517,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> outer_polys(3 * num_rounds_x), r_x(num_rounds_x);
   fe_t claims_outer[3];
   const fe_t zero = fe_zero();
-  // With the split poly_ABC the observer hands the first ell - n_lo challenges (the top variables of the row index) to sp_poly_abc_begin the moment they
-  // exist: the entry weights are formed on the auxiliary stream under the remaining n_lo rounds
-  struct AbcObs {
-    sp_ctx* ctx;
-    sp_polyabc_ws* ws;
-    size_t n_hi;
-    fe_t r[24];
-    int rc = 0;
-    bool begun = false;
-    static void fn(void* u, size_t round, const uint64_t r[4]) {
-      AbcObs* o = (AbcObs*)u;
-      if (round >= o->n_hi) return;
-      memcpy(&o->r[round], r, 32);
-      if (round + 1 == o->n_hi) {
-        o->rc = sp_poly_abc_begin(o->ctx, o->ws, u64p(o->r), o->n_hi);
-        o->begun = o->rc == 0;
-      }
-    }
-  } abc_obs{ctx, ps.abc_ws, ps.abc_ws ? num_rounds_x - ps.abc_n_lo : 0};
-  // Without the split: evals_rx started two rounds before r_x is complete (sp_eq_table_begin builds the half tables of the first ell - 2
-  // coordinates on a stream of its own; sp_eq_table_finish behind the last challenge is then one launch). SPARTAN_EQ_AHEAD=0: the plain call.
+  // evals_rx started two rounds before r_x is complete (sp_eq_table_begin builds the half tables of the first ell - 2 coordinates on a stream of
+  // its own; sp_eq_table_finish behind the last challenge is then one launch).
   struct EqObs {
     sp_ctx* ctx;
     size_t ell;
@@ -577,17 +535,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       }
     }
   } eq_obs{ctx, num_rounds_x};
-  static const bool eq_ahead = [] {
-    const char* e = getenv("SPARTAN_EQ_AHEAD");
-    return !(e && e[0] == '0');
-  }();
-  const bool use_eq_obs = eq_ahead && !ps.abc_ws && num_rounds_x >= 12 && num_rounds_x <= 20;
+  const bool use_eq_obs = num_rounds_x >= 12 && num_rounds_x <= 20;
   if (use_eq_obs)
     ck(sp_sumcheck_cubic3_observed(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p0 ? ps.p1 : nullptr, tr.t, &EqObs::fn, &eq_obs,
-                                   u64p(outer_polys.data()), u64p(r_x.data()), u64p(claims_outer)),
-       "outer sum-check");
-  else if (ps.abc_ws)
-    ck(sp_sumcheck_cubic3_observed(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p0 ? ps.p1 : nullptr, tr.t, &AbcObs::fn, &abc_obs,
                                    u64p(outer_polys.data()), u64p(r_x.data()), u64p(claims_outer)),
        "outer sum-check");
   else if (ps.p0)
@@ -598,7 +548,6 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, tr.t, u64p(outer_polys.data()), u64p(r_x.data()),
                           u64p(claims_outer)),
        "outer sum-check");
-  if (abc_obs.rc) throw Error(abc_obs.rc, std::string("poly_ABC (begin): ") + sp_last_error());
   if (eq_obs.rc) throw Error(eq_obs.rc, std::string("evals_rx (begin): ") + sp_last_error());
   tr.absorb_scalars("claims_outer", claims_outer, 3);
   for (const fe_t& f : outer_polys) proof.pf(f);
@@ -608,12 +557,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t r = tr.squeeze("r");
   const fe_t claim_inner_joint = fe_add<S>(fe_add<S>(claims_outer[0], fe_mul<S>(r, claims_outer[1])), fe_mul<S>(fe_mul<S>(r, r), claims_outer[2]));
   // evals_rx + bind_and_prepare_poly_ABC (src/spartan.rs:316-322)
-  if (abc_obs.begun) {
-    ck(sp_poly_abc_finish(ctx, ps.abc_ws, u64p(r_x.data() + abc_obs.n_hi), ps.abc_n_lo, u64p(&r), 2 * M, ps.abc), "poly_ABC (finish)");
-  } else {
-    ck(sp_eq_table_finish(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");  // (= sp_eq_table_into when nothing was begun)
-    ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
-  }
+  ck(sp_eq_table_finish(ctx, u64p(r_x.data()), num_rounds_x, ps.rx), "evals_rx");  // (= sp_eq_table_into when nothing was begun)
+  ck(sp_poly_abc(ctx, pk.S, ps.rx, u64p(&r), 2 * M, ps.abc), "poly_ABC");
   const double t_abc = now_ms();
 
   sp_msm_job* delta_job = nullptr;

@@ -19,15 +19,9 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(params=["1", "0"], ids=["small_tables_fused", "bind_and_evaluate_separately"])
-def small_form(request, monkeypatch):
-    """SPARTAN_BATCHED_SMALL (read per call): tables <= 2^13 bind + evaluate in one launch with one product per lane (default), or as two launches."""
-    monkeypatch.setenv("SPARTAN_BATCHED_SMALL", request.param)
-    return request.param
-
-
-@pytest.mark.parametrize("num_rounds", [1, 4, 9, 13])
-def test_quad_batched(ctx, num_rounds, small_form):
+# tables <= 2^13 bind + evaluate in one launch with one product per lane, larger ones as two launches: 15 rounds run both forms
+@pytest.mark.parametrize("num_rounds", [1, 4, 9, 13, 15])
+def test_quad_batched(ctx, num_rounds):
     from spartan2_amd import hip
 
     rng = np.random.default_rng(100 + num_rounds)
@@ -52,7 +46,7 @@ def test_quad_batched(ctx, num_rounds, small_form):
 
 
 @pytest.mark.parametrize("num_rounds", [2, 5, 10, 15])
-def test_cubic_outer_pow_batched(ctx, num_rounds, small_form):
+def test_cubic_outer_pow_batched(ctx, num_rounds):
     from spartan2_amd import hip
 
     rng = np.random.default_rng(200 + num_rounds)

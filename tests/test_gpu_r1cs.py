@@ -67,39 +67,8 @@ def test_spmv_and_poly_abc(ctx, which):
         out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])  # dirty buffer
         shape.poly_abc(hip.Table.from_host(ctx, rx), r, out_len, out)
         assert (out.read(0, out_len) == want).all()
-    # the short columns from the sliced-ELL copy (k_polyabc_ell_onepass, opt-in): same table
-    import os
-
-    os.environ["SPARTAN_POLYABC_ELL"] = "1"
-    try:
-        out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])
-        shape.poly_abc(hip.Table.from_host(ctx, rx), r, 2 * M, out)
-        assert (out.read(0, 2 * M) == want).all()
-    finally:
-        del os.environ["SPARTAN_POLYABC_ELL"]
-    # the four-launch form (fill, short columns, long columns, their final sums) the merged launch replaced: same table, twice in a row (the merged
-    # launch's per-column arrival counters must be back at zero after every call)
-    os.environ["SPARTAN_POLYABC_MERGED"] = "0"
-    try:
-        out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])
-        shape.poly_abc(hip.Table.from_host(ctx, rx), r, 2 * M, out)
-        assert (out.read(0, 2 * M) == want).all()
-    finally:
-        del os.environ["SPARTAN_POLYABC_MERGED"]
+    # twice more in a row on a dirty buffer (the per-column arrival counters of the long columns must be back at zero after every call)
     for _ in range(2):
         out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])
         shape.poly_abc(hip.Table.from_host(ctx, rx), r, 2 * M, out)
         assert (out.read(0, 2 * M) == want).all()
-    # the same for rx = eq(r_x), split at a challenge boundary (sp_poly_abc_begin / _finish: entries weighted with eq of the top n_hi variables under the
-    # outer sum-check's last rounds, the rest in a short final pass) at every admissible split
-    ell = N.bit_length() - 1
-    r_x = ol.random_field_array(rng, ell)
-    rx_eq = hip.Table.eq(ctx, r_x).read()
-    want = np.zeros((2 * M, 4), dtype=np.uint64)
-    assert olib().orc_shape_poly_abc(oshape.h, p64(rx_eq), p64(r), ctypes.c_size_t(2 * M), p64(want)) == 0
-    for n_hi in sorted({max(0, ell - 12), ell // 2, min(ell, 12), max(0, ell - 10)}):
-        if n_hi > 12 or ell - n_hi > 12:
-            continue
-        out = hip.Table.from_host(ctx, ol.random_field_array(rng, 16).repeat((2 * M + 15) // 16, axis=0)[: 2 * M])
-        shape.poly_abc_split(r_x, n_hi, r, 2 * M, out)
-        assert (out.read(0, 2 * M) == want).all(), n_hi

@@ -130,11 +130,6 @@ def test_prove_is_identical_on_every_driver_path(ctx, monkeypatch):
     monkeypatch.setenv("SPARTAN_LZ_DIRECT", "1")
     assert (prove_with(ctx) == base).all()
     monkeypatch.delenv("SPARTAN_LZ_DIRECT")
-    # poly_ABC split at a challenge boundary: the entry weights formed under the outer sum-check's last rounds (sp_sumcheck_cubic3_observed +
-    # sp_poly_abc_begin), the rest in sp_poly_abc_finish
-    monkeypatch.setenv("SPARTAN_ABC_SPLIT", "1")
-    assert (prove_with(ctx) == base).all()
-    monkeypatch.delenv("SPARTAN_ABC_SPLIT")
     monkeypatch.setenv("SPARTAN_MAIL_DEV", "0")  # read when a context is created
     c2 = hip.Context(0)
     try:

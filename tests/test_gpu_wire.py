@@ -69,10 +69,10 @@ def test_challenge_circuit_proof_bytes(ctx):
     synth = inst.synthesize(ol.to_mont, ol.from_mont)
     tape = ol.make_tape(17, 8192)
     osp = ol.OracleSpartan(inst)
-    used = osp.prep_prove(tape)
+    used = osp.prep_prove(tape, is_small=False)  # the rest segment (challenge * x) is full-width
     want, _, _ = osp.prove(tape[used:], synthesize=synth)
     gsp = host.SpartanSNARK(ctx, inst)
-    assert gsp.prep_prove(tape) == used
+    assert gsp.prep_prove(tape, is_small=False) == used
     got, _, _ = gsp.prove(tape[used:], synthesize=synth)
     assert (got == want).all() and gsp.proof_layout()["num_challenges"] > 0
     data = gsp.proof_to_bytes(got)

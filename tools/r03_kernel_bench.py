@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Round-3 micro-benchmarks through the C ABI (HIP events of the library's own instrumentation):
   rowmat   bind_with_delayed 512 x 2048 and 2048 x 2048: the one-launch streaming kernel against the two-stage form
-  walk     one table-walk MSM over 2049 window tables (the key + h): k_multi_mul_wide against k_multi_mul_coop (SPARTAN_MM_WIDE_MIN decides, read once
+  walk     one table-walk MSM over 2049 window tables (the key + h): k_multi_mul_wide (decides, read once
            per process: run twice), one walk and two walks side by side (the two lanes)"""
 import argparse
 import os
@@ -31,8 +31,7 @@ if args.what == "rowmat":
     for rows, cols in ((512, 2048), (2048, 2048), (128, 2048)):
         t = hip.Table.from_host(ctx, rand_fe(rows * cols))
         L = rand_fe(rows)
-        for tall in ("1", "0"):
-            os.environ["SPARTAN_ROWMAT_TALL"] = tall
+        for tall in ("1",):
             hip.rowmat_vec(ctx, t, rows, cols, L)
             ctx.reset_stats(True)
             ctx.stats_filter("rowmat_vec")
@@ -61,4 +60,4 @@ else:
     wall = (time.perf_counter() - t0) / 20
     ms, k, _ = ctx.kernel_stats("multi_mul")
     ctx.reset_stats(False)
-    print(f"walk over {n} tables (SPARTAN_MM_WIDE_MIN={os.environ.get('SPARTAN_MM_WIDE_MIN', '1024')}): kernel {ms / k * 1e3:.1f} us, call {wall * 1e6:.1f} us")
+    print(f"walk over {n} tables : kernel {ms / k * 1e3:.1f} us, call {wall * 1e6:.1f} us")
