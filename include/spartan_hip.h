@@ -207,7 +207,8 @@ int sp_multiply_vec_incremental_round0(sp_ctx* ctx, const sp_shape* s, const sp_
 int sp_poly_abc(sp_ctx* ctx, const sp_shape* s, const sp_table* rx, const uint64_t r[4], size_t out_len, sp_table* out);
 
 /* ---- group / MSM (src/provider/traits.rs:118-162 DlogGroupExt, src/provider/msm.rs) --------------------- */
-/* DlogGroupExt::vartime_multiscalar_mul (msm.rs:187-222): sum s_i * g_i. scalars / bases on the host. */
+/* DlogGroupExt::vartime_multiscalar_mul (msm.rs:187-222): sum s_i * g_i. scalars / bases on the host. Below 4096 points the one-block-per-window
+ * latency form of the Hyrax row MSMs, from there on the multi-block Pippenger (window width by n; multi-block counting sort; see sp_msm_points). */
 int sp_msm(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_aff[8]);
 /* DlogGroupExt::vartime_multiscalar_mul_small (msm.rs:367-409) */
 int sp_msm_small_u64(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases, size_t n, uint64_t out_aff[8]);
@@ -291,6 +292,13 @@ typedef struct sp_msm_job sp_msm_job;
 typedef struct sp_points sp_points;
 int sp_points_upload(sp_ctx* ctx, const uint64_t* aff, size_t n, sp_points** io);
 void sp_points_free(sp_points* p);
+/* DlogGroupExt::vartime_multiscalar_mul (msm.rs:187-222) on operands resident in HBM: sum of scalars[off + i] * points[first + i], i < n — what a caller
+ * that keeps its bases on the device between calls uses, and what the point-range sharding of SURVEY 8(e) runs per rank on its range of the points
+ * (the ranks' affine partial sums are then gathered and added). From 4096 points up the multi-block Pippenger (kernels_pippenger.hpp) with the
+ * library's window width; window = 8 / 10 / 12 / 13 / 14 forces that path and width (tests, measurements), 0 = the library's choice. */
+int sp_msm_points(sp_ctx* ctx, const sp_table* scalars, size_t off, size_t n, const sp_points* bases, size_t first, int window, uint64_t out_aff[8]);
+/* the window width the library picks for an n-point MSM (the reference's rule is c = ceil(ln n), msm.rs:201-205; same trade, this kernel's constants) */
+int sp_msm_pippenger_window(size_t n);
 int sp_msm_eq_begin(sp_ctx* ctx, const sp_points* pts, const uint64_t* r, size_t ell, sp_msm_job** job);
 int sp_msm_job_finish(sp_ctx* ctx, sp_msm_job* job, uint64_t out_aff[8]);
 /* bind_with_delayed (hyrax_pc.rs:38-54) with L = eq(r, .) (ell <= 20 row variables; up to 10 formed on the device, more uploaded), on a stream of its own, so that LZ —

@@ -210,7 +210,9 @@ int sp_msm(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, size_t n, 
   if (!dbases) return SP_ERR_NO_DEVICE;
   if (n) SP_HIP(hipMemcpyAsync(dbases, bases, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
   jac_t r;
-  if ((rc = msm_device(c, canon, dbases, n, spk::MSM_MAX_WINDOWS, &r))) return rc;
+  if (n >= sp::PIPPENGER_MIN) rc = sp::msm_pippenger(c, canon, dbases, n, true, 0, &r);
+  else rc = msm_device(c, canon, dbases, n, spk::MSM_MAX_WINDOWS, &r);
+  if (rc) return rc;
   store_aff(out_aff, jac_to_affine(r));
   return SP_OK;
 }
@@ -380,7 +382,9 @@ int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, 
     SP_HIP(hipMemcpyAsync(dbases.p, bases, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
   }
   jac_t r;
-  if ((rc = msm_device(c, canon.as<fe_t>(), dbases.as<aff_t>(), n, 9, &r))) return rc;
+  if (n >= sp::PIPPENGER_MIN) rc = sp::msm_pippenger(c, canon.as<fe_t>(), dbases.as<aff_t>(), n, false, 0, &r);
+  else rc = msm_device(c, canon.as<fe_t>(), dbases.as<aff_t>(), n, 9, &r);
+  if (rc) return rc;
   store_aff(out_aff, jac_to_affine(r));
   return SP_OK;
 }
@@ -1052,6 +1056,25 @@ void sp_points_free(sp_points* p) {
   if (!p) return;
   if (p->d) hipFree(p->d);
   delete p;
+}
+// vartime_multiscalar_mul on operands resident in HBM: scalars = n elements of a table at `off` (Montgomery form), bases = points [first, first + n)
+int sp_msm_points(sp_ctx* c, const sp_table* scalars, size_t off, size_t n, const sp_points* bases, size_t first, int window, uint64_t out_aff[8]) {
+  if (!c || !scalars || !bases || !out_aff) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_msm_points: null argument");
+  if (off + n > scalars->cap || first + n > bases->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_msm_points: range exceeds the operands");
+  jac_t r = jac_identity();
+  if (n) {
+    fe_t* canon = (fe_t*)c->workspace(sp_ctx::WS_SCALARS_CANON, n * sizeof(fe_t));
+    if (!canon) return SP_ERR_NO_DEVICE;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(spk::k_to_canonical, dim3((unsigned)blocks), dim3(256), 0, c->stream, scalars->d + off, n, canon);
+    int rc;
+    if (window || n >= sp::PIPPENGER_MIN) rc = sp::msm_pippenger(c, canon, bases->d + first, n, true, window, &r);
+    else rc = msm_device(c, canon, bases->d + first, n, spk::MSM_MAX_WINDOWS, &r);
+    if (rc) return rc;
+  }
+  store_aff(out_aff, jac_to_affine(r));
+  return SP_OK;
 }
 // eq table of k variables on the host, r[0] on the index MSB (EqPolynomial::evals_from_points, src/polys/eq.rs:59-93)
 static void eq_table_host(const fe_t* r, size_t k, fe_t* out) {

@@ -158,7 +158,7 @@ struct sp_ctx {
 
   // grow-only persistent device buffers, one per slot, so hot-path calls never hipMalloc/hipFree
   enum { WS_MSM_ORDER = 0, WS_MSM_START, WS_MSM_BUCKETS, WS_MSM_WSUM, WS_SCALARS_RAW, WS_SCALARS_CANON, WS_FB_SCALARS, WS_FB_OUT, WS_ROWMAT_L,
-         WS_ROWMAT_PART, WS_ROWMAT_OUT, WS_COMMIT_CANON, WS_COMMIT_FLAGS, WS_COMMIT_ROWS, WS_BASES_TMP, WS_MSM_FOLDED, WS_MSM_DIGITS, WS_NARROW_SCALARS, WS_NARROW_OUT, WS_NARROW_BLINDS, WS_POLYABC_PARTIALS, WS_POLYABC_TICKETS,
+         WS_ROWMAT_PART, WS_ROWMAT_OUT, WS_COMMIT_CANON, WS_COMMIT_FLAGS, WS_COMMIT_ROWS, WS_BASES_TMP, WS_MSM_FOLDED, WS_MSM_DIGITS, WS_NARROW_SCALARS, WS_NARROW_OUT, WS_NARROW_BLINDS, WS_POLYABC_PARTIALS, WS_POLYABC_TICKETS, WS_MSM_TASKS, WS_MSM_PARTIAL,
          WS_PER_LANE,
          WS_SLOTS = 2 * WS_PER_LANE };  // lane 1 = the auxiliary stream used by asynchronous MSM jobs
   void* ws_ptr[WS_SLOTS] = {};

@@ -54,6 +54,10 @@ int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t*
                      size_t raw_blocks);
 int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield);
 int ck_key_tables(sp_ctx* c, const sp_ck* ck);  // 0 = ready, 1 = not available (take the bucket MSM), < 0 = error
+// capi_pippenger.hip: the general (multi-block) Pippenger for caller-supplied bases; window = 0 -> pippenger_window(n)
+int pippenger_window(size_t n);
+int msm_pippenger(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, size_t n, bool full_width, int window, jac_t* result);
+static const size_t PIPPENGER_MIN = 4096;  // below: the one-block-per-window latency form (kernels_msm.hpp), sized for the 2048-wide Hyrax MSMs
 // capi_comb.hip: the fixed-base comb table of a key (built on first use) and row commitments over it
 size_t comb_min_rows();
 int comb_ensure(sp_ctx* c, const sp_ck* ck);  // 0 = table ready, 1 = not available (take the bucket path), < 0 = error

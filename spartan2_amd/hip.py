@@ -299,6 +299,35 @@ def msm(ctx, scalars, bases):
     return out
 
 
+class Points:
+    """affine points resident in HBM (sp_points_upload)"""
+
+    def __init__(self, ctx, points):
+        points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+        self.ctx, self.n = ctx, points.shape[0]
+        self.h = ctypes.c_void_p()
+        lib().sp_points_free.argtypes = [ctypes.c_void_p]
+        check(lib().sp_points_upload(ctx.h, p64(points), ctypes.c_size_t(self.n), ctypes.byref(self.h)))
+
+    def free(self):
+        if self.h:
+            lib().sp_points_free(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def msm_points(ctx, scalars: "Table", off, n, points: Points, first=0, window=0):
+    """sp_msm_points: sum scalars[off + i] * points[first + i] on device-resident operands; window = 0 (library's choice) or a forced Pippenger width."""
+    out = np.zeros(8, dtype=np.uint64)
+    check(lib().sp_msm_points(ctx.h, scalars.h, ctypes.c_size_t(off), ctypes.c_size_t(n), points.h, ctypes.c_size_t(first), int(window), p64(out)))
+    return out
+
+
 def msm_eq(ctx, points, r):
     """sum_i eq(r, i) * points[i] through sp_points_upload + sp_msm_eq_begin + sp_msm_job_finish (the homomorphic form of comm_LZ)."""
     points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)

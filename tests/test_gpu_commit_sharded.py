@@ -45,8 +45,18 @@ def _worker(rank, world, port, q):
     got_rows = spd.commit_rows_sharded(g, rows, lambda lo, hi: key.commit(table, lo * cols, (hi - lo) * cols, blinds[lo:hi]) if hi > lo else np.zeros((0, 8), dtype=np.uint64))
     scal = ol.random_field_array(rng, 2048)
     got_msm = spd.msm_point_range_sharded(g, 2048, lambda lo, hi: hip.msm(ctx, scal[lo:hi], ck_aff[lo:hi]), hip.point_sum)
+    # a large MSM over caller-supplied bases by point range (SURVEY 8(e) "implement point-range for the single-large-MSM case"): each rank runs the
+    # multi-block Pippenger (sp_msm_points) on its range of the device-resident operands, the affine partial sums are gathered and added
+    nbig = 1 << 15
+    big_pts = np.concatenate([key.fixed_base_mul_h(ol.random_field_array(rng, 1 << 14)) for _ in range(nbig >> 14)])
+    big_s = ol.random_field_array(rng, nbig)
+    big_tab, big_dev = hip.Table.from_host(ctx, big_s), hip.Points(ctx, big_pts)
+    got_big = spd.msm_point_range_sharded(g, nbig, lambda lo, hi: hip.msm_points(ctx, big_tab, lo, hi - lo, big_dev, lo), hip.point_sum)
     out = None
     if rank == 0:
+        want_big = np.zeros(8, dtype=np.uint64)
+        assert olib().orc_msm(p64(big_s), p64(np.ascontiguousarray(big_pts)), ctypes.c_size_t(nbig), ctypes.c_size_t(0), p64(want_big)) == 0
+        assert (got_big == want_big).all(), "point-range sharded Pippenger"
         want_rows = np.zeros((rows, 8), dtype=np.uint64)
         assert olib().orc_hyrax_commit(okey, p64(v), ctypes.c_size_t(rows * cols), p64(blinds), 0, p64(want_rows)) == 0
         want_msm = np.zeros(8, dtype=np.uint64)
