@@ -172,6 +172,72 @@ __global__ void __launch_bounds__(256) k_split(fe_t* __restrict__ A, fe_t* __res
   if (threadIdx.x < 2) partials[(size_t)blockIdx.x * 2 + threadIdx.x] = lazy_add(lazy_add(sm[0][threadIdx.x], sm[1][threadIdx.x]), lazy_add(sm[2][threadIdx.x], sm[3][threadIdx.x]));
 }
 
+// FAT: one 1024-thread block per CU at 2^20 (256 blocks), grid-stride over ITER chunks: the "persistent" form. Wave sums meet in LDS; one lazy
+// partial pair per block, reduced and weighted with eq_out IN the block (what a host-summed slot would carry): 256 partial pairs instead of 1024.
+template <int ITER>
+__global__ void __launch_bounds__(1024) k_fat(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in,
+                                              const fe_t* __restrict__ eq_out, int s, fe_t* __restrict__ out) {
+  __shared__ lazy9_t sm[16][2];
+  const size_t mask = ((size_t)1 << s) - 1;
+  lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
+  size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int it = 0; it < ITER; ++it, id += step) {
+    const Chunk cur = load_chunk(A, B, C, id, q);
+    const fe_t a0 = bind1(cur.a0, cur.a2, r), a1 = bind1(cur.a1, cur.a3, r);
+    const fe_t b0 = bind1(cur.b0, cur.b2, r), b1 = bind1(cur.b1, cur.b3, r);
+    const fe_t c0 = bind1(cur.c0, cur.c2, r), c1 = bind1(cur.c1, cur.c3, r);
+    A[id] = a0; A[id + q] = a1; B[id] = b0; B[id + q] = b1; C[id] = c0; C[id + q] = c1;
+    const fe_t w = eq_in[id & mask];
+    const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+    const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+    l0 = lazy_add(l0, lazy_from(fe_mul<S>(w, t0e)));
+    l1 = lazy_add(l1, lazy_from(fe_mul<S>(w, tie)));
+  }
+  l0 = lazy_wave_sum(l0);
+  l1 = lazy_wave_sum(l1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sm[wave][0] = l0;
+    sm[wave][1] = l1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    lazy9_t t = sm[0][threadIdx.x];
+    for (int k = 1; k < 16; ++k) t = lazy_add(t, sm[k][threadIdx.x]);
+    out[(size_t)blockIdx.x * 2 + threadIdx.x] = fe_mul<S>(lazy_reduce(t), eq_out[((size_t)blockIdx.x * blockDim.x) >> s]);
+  }
+}
+
+// W256: the production 256-thread streaming body, but every block reduces its lazy pair and applies eq_out itself (fe partials out): the second stage
+// becomes a plain modular sum (k_sum_partials) instead of k_sum_partials_lazy
+__global__ void __launch_bounds__(256) k_w256(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in,
+                                              const fe_t* __restrict__ eq_out, int s, fe_t* __restrict__ out) {
+  __shared__ lazy9_t sm[4][2];
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const Chunk k = load_chunk(A, B, C, id, q);
+  const fe_t a0 = bind1(k.a0, k.a2, r), a1 = bind1(k.a1, k.a3, r);
+  const fe_t b0 = bind1(k.b0, k.b2, r), b1 = bind1(k.b1, k.b3, r);
+  const fe_t c0 = bind1(k.c0, k.c2, r), c1 = bind1(k.c1, k.c3, r);
+  A[id] = a0; A[id + q] = a1; B[id] = b0; B[id + q] = b1; C[id] = c0; C[id + q] = c1;
+  const fe_t w = eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  const lazy9_t l0 = lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), l1 = lazy_wave_sum(lazy_from(fe_mul<S>(w, tie)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sm[wave][0] = l0;
+    sm[wave][1] = l1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const lazy9_t t = lazy_add(lazy_add(sm[0][threadIdx.x], sm[1][threadIdx.x]), lazy_add(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+    out[(size_t)blockIdx.x * 2 + threadIdx.x] = fe_mul<S>(lazy_reduce(t), eq_out[((size_t)blockIdx.x * blockDim.x) >> s]);
+  }
+}
+
 template <class L>
 static float time_us(L&& f, int reps) {
   hipEvent_t a, b;
@@ -214,6 +280,13 @@ int main() {
     report("stream body, 4 chunks per block", time_us([&] { hipLaunchKernelGGL((k_iter<4, false>), dim3(q / 256 / 4), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, 2 chunks, prefetch", time_us([&] { hipLaunchKernelGGL((k_iter<2, true>), dim3(q / 256 / 2), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, 4 chunks, prefetch", time_us([&] { hipLaunchKernelGGL((k_iter<4, true>), dim3(q / 256 / 4), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("1024-thread blocks, in-block weight", time_us([&] { hipLaunchKernelGGL((k_fat<1>), dim3(q / 1024), dim3(1024), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
+    report("the same, 2 chunks per block", time_us([&] { hipLaunchKernelGGL((k_fat<2>), dim3(q / 2048), dim3(1024), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
+    report("the same, 4 chunks per block", time_us([&] { hipLaunchKernelGGL((k_fat<4>), dim3(q / 4096), dim3(1024), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
+    report("second stage alone (k_sum_partials_lazy)", time_us([&] { hipLaunchKernelGGL(k_sum_partials_lazy, dim3(1), dim3(SUM_LAZY_THREADS), 0, 0, lp, q / 256, 2, eo, part + (q / 64), 7u); }, 20));
+    report("256-thread blocks, in-block weight", time_us([&] { hipLaunchKernelGGL(k_w256, dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
+    report("modular second stage (k_sum_partials), q/256 x 2", time_us([&] { hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, 0, part, q / 256, 2, part + (q / 64), 7u); }, 20));
+    report("modular second stage (k_sum_partials), q/1024 x 2", time_us([&] { hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, 0, part, q / 1024, 2, part + (q / 64), 7u); }, 20));
     report("var0 block256", time_us([&] { hipLaunchKernelGGL((k_var<0, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
     report("var1 nontemporal loads", time_us([&] { hipLaunchKernelGGL((k_var<1, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
     report("var0 block64 (wave-only reduce)", time_us([&] { hipLaunchKernelGGL((k_var<0, 64>), dim3((q + 63) / 64), dim3(64), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
