@@ -533,6 +533,25 @@ def main():
             conc = {"proofs_in_flight": cj["proofs_in_flight"], "proofs": cj["proofs"], "constraints_per_s": cj["proofs"] * inst.num_cons / cj["seconds"],
                     "ms_per_proof_amortised": cj["ms_per_proof_amortised"], "proofs_identical_to_the_timed_one": same, "errors": cj["errors"],
                     "process": "tools/concurrency_stress.py (no PyTorch in the process)"}
+            # the same leg without one spinning CPU per proof: 24 proofs in flight on 6 polling threads, each proof on a stack of its own and the library's
+            # wait hook switching between them (ss_prove_multiplexed). What bounds it is stated with it.
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "multiplex_bench.py"), "--sweep", "24x6", "--proofs", str(per), "--message-bytes",
+                                    str(args.message_bytes), "--device", str(local_rank), "--json"], capture_output=True, text=True, timeout=600,
+                                   env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if not line:
+                    raise RuntimeError((r.stderr or r.stdout)[-400:])
+                mj = json.loads(line[-1])["results"][0]
+                alg_gb = 1.2  # SURVEY 8(d) bytes of one config-2 prove (outer 403 MB + inner 268 MB + incremental SpMV 210 MB + poly_ABC 248 MB + eq / rowmat)
+                conc["multiplexed"] = {"proofs_in_flight": mj["proofs_in_flight"], "polling_threads": mj["polling_threads"], "proofs": mj["proofs"],
+                                       "ms_per_proof_amortised": mj["ms_per_proof_amortised"], "constraints_per_s": inst.num_cons / (mj["ms_per_proof_amortised"] * 1e-3),
+                                       "mismatches": mj["mismatches"], "rc": mj["rc"],
+                                       "aggregate_hbm_roofline_frac": (alg_gb / (mj["ms_per_proof_amortised"] * 1e-3)) / 8000.0 if args.message_bytes == 2048 else None,
+                                       "bound": "GPU time: the kernels of one prove sum to ~0.55 ms when each runs alone (profiles/r04_mux_kernel_stats.md); more proofs in "
+                                                "flight, more polling threads, a larger resident-tail budget or a second process do not move it"}
+            except Exception as exc:
+                conc["multiplexed"] = {"error": repr(exc)}
         except Exception as exc:  # an extra must never cost the bench line
             conc = {"error": repr(exc)}
 

@@ -45,6 +45,13 @@ typedef struct sp_shape sp_shape;           /* SplitR1CSShape with PrecomputedSp
 typedef struct sp_ck sp_ck;                 /* HyraxCommitmentKey: bases + h + FixedBaseMul table of h */
 
 const char* sp_last_error(void);
+/* Cooperative waiting. Every host-side wait of the library for the device — a round's result slot, a mailbox answer, a helper's flag — spins on a
+ * `pause`; a thread that has installed a hook gets the hook called instead, once per poll. A driver that keeps several proofs in flight on ONE thread
+ * (each on a stack of its own) switches to another proof there: what the reference gets from rayon, whose workers take other work while a task
+ * waits. Per calling thread; NULL restores the spin. sp_relax() = one such wait step, for waits a driver above the ABI implements itself. */
+typedef void (*sp_wait_hook)(void* user);
+int sp_set_wait_hook(sp_wait_hook hook, void* user);
+void sp_relax(void);
 
 /* one context per GPU; device = HIP ordinal (LOCAL_RANK under torch.distributed.run). */
 int sp_ctx_create(int device, sp_ctx** out);

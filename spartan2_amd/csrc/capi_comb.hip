@@ -57,7 +57,7 @@ int comb_ensure(sp_ctx* c, const sp_ck* ck) {
     hipLaunchKernelGGL(spk::k_comb_multiples, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, c->stream, ck->d_bases, (unsigned)ncols, C, w0, nw, E, segs, stage);
     hipLaunchKernelGGL(spk::k_comb_normalize, dim3((unsigned)((pts / 8 + 255) / 256 + 1)), dim3(256), 0, c->stream, stage, pts, tab + (size_t)w0 * per_window);
   }
-  hipError_t e = hipStreamSynchronize(c->stream);
+  hipError_t e = sp::stream_sync(c->stream);
   hipFree(stage);
   if (e != hipSuccess) {
     hipFree(tab);
@@ -91,7 +91,7 @@ int comb_rows(sp_ctx* c, const sp_ck* ck, const fe_t* canon, size_t cols, size_t
   });
   std::vector<jac_t> res(sel.size());
   SP_HIP(hipMemcpyAsync(res.data(), drows.p, sel.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   for (size_t i = 0; i < sel.size(); ++i) out[sel[i]] = res[i];
   return SP_OK;
 }

@@ -13,7 +13,25 @@
 
 namespace sp {
 static thread_local std::string g_err;
+static thread_local sp_wait_hook g_wait_hook = nullptr;
+static thread_local void* g_wait_user = nullptr;
 void set_error(const std::string& m) { g_err = m; }
+void relax() {
+  if (g_wait_hook) g_wait_hook(g_wait_user);
+  else __builtin_ia32_pause();
+}
+hipError_t stream_sync(hipStream_t s) {
+  if (!g_wait_hook) return hipStreamSynchronize(s);
+  hipError_t e;
+  while ((e = hipStreamQuery(s)) == hipErrorNotReady) g_wait_hook(g_wait_user);
+  return e;
+}
+hipError_t event_sync(hipEvent_t ev) {
+  if (!g_wait_hook) return hipEventSynchronize(ev);
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) g_wait_hook(g_wait_user);
+  return e;
+}
 int fail(int code, const std::string& m) {
   g_err = m;
   return code;
@@ -60,8 +78,8 @@ void* sp_ctx::workspace(int slot, size_t bytes, int lane) {
   if (bytes == 0) bytes = 16;
   if (bytes <= ws_bytes[slot]) return ws_ptr[slot];
   if (ws_ptr[slot]) {
-    hipStreamSynchronize(stream);
-    hipStreamSynchronize(stream2);
+    sp::stream_sync(stream);
+    sp::stream_sync(stream2);
     hipFree(ws_ptr[slot]);
     ws_ptr[slot] = nullptr;
     ws_bytes[slot] = 0;
@@ -79,7 +97,7 @@ void sp_ctx::drain_stats() {
   for (auto& kv : stats) {
     for (auto& pr : kv.second.pending) {
       float ms = 0;
-      hipEventSynchronize(pr.second);
+      sp::event_sync(pr.second);
       hipEventElapsedTime(&ms, pr.first, pr.second);
       kv.second.ms += ms;
       event_pool.push_back(pr.first);
@@ -98,6 +116,12 @@ static inline void store_fe(uint64_t* p, const fe_t& a) { memcpy(p, &a, 32); }
 
 extern "C" {
 
+int sp_set_wait_hook(sp_wait_hook hook, void* user) {
+  sp::g_wait_hook = hook;
+  sp::g_wait_user = user;
+  return SP_OK;
+}
+void sp_relax(void) { sp::relax(); }
 const char* sp_last_error(void) { return sp::g_err.c_str(); }
 
 int sp_ctx_create(int device, sp_ctx** out) {
@@ -194,7 +218,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   delete c;
 }
 int sp_ctx_synchronize(sp_ctx* c) {
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 int sp_ctx_reset_stats(sp_ctx* c, int enable) {
@@ -213,16 +237,16 @@ int sp_ctx_mail_stats(sp_ctx* c, uint64_t out[5]) {
   out[4] = 1;
   uint32_t w[4];
   SP_HIP(hipSetDevice(c->device));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   SP_HIP(hipMemcpy(w, reinterpret_cast<const uint32_t*>(c->mail_alloc) + spk::MAIL_DIAG_WORD, sizeof w, hipMemcpyDeviceToHost));
   for (int i = 0; i < 4; ++i) out[i] = w[i];
   SP_HIP(hipMemset(reinterpret_cast<uint32_t*>(c->mail_alloc) + spk::MAIL_DIAG_WORD, 0, sizeof w));
   return SP_OK;
 }
 int sp_ctx_kernel_stats(sp_ctx* c, const char* what, double* ms, uint64_t* launches, uint64_t* alg_bytes) {
-  SP_HIP(hipStreamSynchronize(c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream2));
-  if (c->stream3) SP_HIP(hipStreamSynchronize(c->stream3));
+  SP_HIP(sp::stream_sync(c->stream));
+  SP_HIP(sp::stream_sync(c->stream2));
+  if (c->stream3) SP_HIP(sp::stream_sync(c->stream3));
   c->drain_stats();
   auto it = c->stats.find(what);
   if (it == c->stats.end()) {
@@ -245,7 +269,7 @@ int sp_table_from_host(sp_ctx* c, const uint64_t* z, size_t len, size_t lo_eff, 
   t->lo_eff = lo_eff;
   t->hi_eff = hi_eff;
   if (len) SP_HIP(hipMemcpyAsync(t->d, z, len * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   *out = t;
   return SP_OK;
 }
@@ -262,7 +286,7 @@ int sp_table_zeros(sp_ctx* c, size_t len, size_t lo_eff, size_t hi_eff, sp_table
 int sp_table_write(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, size_t cnt) {
   if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write: range exceeds the table");
   if (cnt) SP_HIP(hipMemcpyAsync(t->d + off, z, cnt * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));  // the host buffer is only borrowed for the duration of the call
+  SP_HIP(sp::stream_sync(c->stream));  // the host buffer is only borrowed for the duration of the call
   return SP_OK;
 }
 int sp_table_write_async(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, size_t cnt) {
@@ -274,7 +298,7 @@ int sp_table_write_async(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, 
     for (hipEvent_t& e : c->stage_ev) SP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const unsigned slot = c->stage_next++ & 3u;
-  SP_HIP(hipEventSynchronize(c->stage_ev[slot]));  // the copy that used this slot four writes ago (long finished)
+  SP_HIP(sp::event_sync(c->stage_ev[slot]));  // the copy that used this slot four writes ago (long finished)
   void* stage = (char*)c->h_stage + (size_t)slot * 65536;
   memcpy(stage, z, cnt * sizeof(fe_t));
   SP_HIP(hipMemcpyAsync(t->d + off, stage, cnt * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
@@ -301,7 +325,7 @@ int sp_table_gather_strided(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_t
 int sp_table_read(sp_ctx* c, const sp_table* t, size_t off, size_t cnt, uint64_t* out) {
   if (off + cnt > t->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_read: range exceeds the table");
   if (cnt) SP_HIP(hipMemcpyAsync(out, t->d + off, cnt * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 int sp_table_info(const sp_table* t, size_t* len, size_t* lo_eff, size_t* hi_eff) {
@@ -400,14 +424,14 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
         const auto t0 = std::chrono::steady_clock::now();
         while (*fl != want) {
           if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(12)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
-          __builtin_ia32_pause();
+          sp::relax();
         }
         break;
       }
-      SP_HIP(hipStreamSynchronize(c->stream));  // e.g. under a profiler
+      SP_HIP(sp::stream_sync(c->stream));  // e.g. under a profiler
       if (*fl != want) return fail(SP_ERR_INTERNAL, "evaluation kernel did not deliver its block sums");
     }
-    __builtin_ia32_pause();
+    sp::relax();
   }
   for (long tries = 0;; ++tries) {
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -418,7 +442,7 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
     }
     if (fl[0] == want && fl[1] == chk.a && fl[2] == chk.b && fl[3] == want) return SP_OK;
     if (tries > 4000000) return fail(SP_ERR_INTERNAL, "evaluation kernel delivered an inconsistent result slot");
-    __builtin_ia32_pause();
+    sp::relax();
   }
 }
 // groups > 1 (slot path only): the first nb / groups slots are summed into out_host[0 .. nacc), the next into out_host[nacc .. 2 nacc), ... (the two
@@ -471,7 +495,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
       if (!remaining) break;
       if (++passes == 200000) {  // a few ms without completion
         if (!resident) {
-          SP_HIP(hipStreamSynchronize(c->stream));  // e.g. under a profiler
+          SP_HIP(sp::stream_sync(c->stream));  // e.g. under a profiler
         }
         t0 = std::chrono::steady_clock::now();
       } else if (passes > 200000) {
@@ -479,7 +503,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
         if (resident && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(12))
           return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
       }
-      __builtin_ia32_pause();
+      sp::relax();
     }
     return SP_OK;
   }
@@ -491,17 +515,17 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
       seen = true;
       break;
     }
-    __builtin_ia32_pause();
+    sp::relax();
   }
   if (!seen && resident) {
     const auto t0 = std::chrono::steady_clock::now();
     while (*flag != want) {
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(12)) return fail(SP_ERR_INTERNAL, "sum-check tail kernel did not deliver a round result");
-      __builtin_ia32_pause();
+      sp::relax();
     }
     seen = true;
   }
-  if (!seen) SP_HIP(hipStreamSynchronize(c->stream));
+  if (!seen) SP_HIP(sp::stream_sync(c->stream));
   std::atomic_thread_fence(std::memory_order_acquire);
   for (int k = 0; k < nacc; ++k) out_host[k] = c->h_pinned[k];
   return SP_OK;
@@ -560,7 +584,7 @@ static void tail_abort(sp_ctx* c) {
     if (c->mail_dev) __builtin_ia32_sfence();
   };
   set_all(1);
-  hipStreamSynchronize(c->stream);
+  sp::stream_sync(c->stream);
   set_all(0);
   *reinterpret_cast<volatile uint32_t*>(c->h_pinned + spk::TAIL_ERR_ELEM) = 0;
 }
@@ -784,7 +808,7 @@ int sp_eq_table_into(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
     hipLaunchKernelGGL(spk::k_eq_levels, dim3(1), dim3(1024), 0, c->stream, d_r, hi_bits, d_hi);
     hipLaunchKernelGGL(spk::k_eq_outer, dim3(8192), dim3(256), 0, c->stream, d_hi + spk::eq_level_offset(hi_bits), d_lowbig, lo_bits, total, t->d);
   }
-  SP_HIP(hipStreamSynchronize(c->stream));  // r is a borrowed host buffer
+  SP_HIP(sp::stream_sync(c->stream));  // r is a borrowed host buffer
   return SP_OK;
 }
 

@@ -103,7 +103,7 @@ int msm_launch(sp_ctx* c, const fe_t* d_canon_in, const aff_t* d_bases, size_t n
 int msm_finish(sp_ctx* c, MsmPending* pend, jac_t* result) {
   *result = jac_identity();
   if (pend->windows == 0) return SP_OK;
-  SP_HIP(hipEventSynchronize(c->msm_ev[pend->lane][pend->slot]));
+  SP_HIP(sp::event_sync(c->msm_ev[pend->lane][pend->slot]));
   pend->w.resize(pend->windows);
   memcpy(pend->w.data(), (char*)c->h_pinned_lane[pend->lane] + pend->slot * 4096, pend->windows * sizeof(jac_t));
   // Horner over windows, high to low (msm.rs:150-175): acc = 2^8 acc + W_w
@@ -170,7 +170,7 @@ int msm_rows_batched(sp_ctx* c, const fe_t* canon, size_t cols, size_t n, const 
   });
   std::vector<jac_t> res(sel.size());
   SP_HIP(hipMemcpyAsync(res.data(), drows.p, sel.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   for (size_t i = 0; i < sel.size(); ++i) out[sel[i]] = res[i];
   return SP_OK;
 }
@@ -186,7 +186,7 @@ int upload_canonical(sp_ctx* c, const uint64_t* scalars, size_t n, fe_t** canon_
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(spk::k_to_canonical, dim3((unsigned)blocks), dim3(256), 0, st, raw, n, canon);
   }
-  SP_HIP(hipStreamSynchronize(st));  // `scalars` is a borrowed host buffer (pageable: the copy is staged synchronously anyway)
+  SP_HIP(sp::stream_sync(st));  // `scalars` is a borrowed host buffer (pageable: the copy is staged synchronously anyway)
   *canon_out = canon;
   return SP_OK;
 }
@@ -252,7 +252,7 @@ int sp_fold_tables(sp_ctx* c, const sp_table* const* Ws, size_t n, const uint64_
   c->timed("fold_tables", 32ull * (n + 1) * len, [&] {
     hipLaunchKernelGGL(spk::k_fold_tables, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const fe_t* const*)dp.p, dw.as<fe_t>(), n, len, out->d);
   });
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   out->len = len;
   out->lo_eff = out->hi_eff = (size_t)-1;
   return SP_OK;
@@ -273,7 +273,7 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
   double t_lap = now();
   auto lap = [&](const char* what) {
     if (!laps) return;
-    (void)hipStreamSynchronize(c->stream);
+    (void)sp::stream_sync(c->stream);
     const double t = now();
     fprintf(stderr, "msm_shared_weights lap %-20s %8.3f ms\n", what, t - t_lap);
     t_lap = t;
@@ -319,7 +319,7 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
     // few rows: the 256-doubling window Horner is a latency chain (~3 ms for one lane per row on the device, ~60 us per row on the host)
     std::vector<jac_t> ws(rows * windows);
     SP_HIP(hipMemcpyAsync(ws.data(), wsum, ws.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(hipStreamSynchronize(c->stream));
+    SP_HIP(sp::stream_sync(c->stream));
     auto horner = [&](size_t r) {
       jac_t acc = jac_identity();
       for (int w = windows - 1; w >= 0; --w) {
@@ -344,7 +344,7 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
   } else {
     hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, wsum, windows, rows, drows);
     SP_HIP(hipMemcpyAsync(res.data(), drows, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(hipStreamSynchronize(c->stream));
+    SP_HIP(sp::stream_sync(c->stream));
   }
   lap("horner");
   std::vector<aff_t> a(rows);
@@ -421,7 +421,7 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
     hipLaunchKernelGGL(spk::k_fixed_base_table, dim3(1), dim3(64), 0, c->stream, base, tj.as<jac_t>() + t * per);
   }
   hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), ntab * per, tables);
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   if (fb_mapped_enabled() && ((rc = fb_mapped_ensure(c, 0)) || (rc = fb_mapped_ensure(c, 1)))) return rc;
   k->n_tables = ntab;
   k->h_tables.resize(ntab * per);
@@ -444,7 +444,7 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
     SP_HIP(hipMemcpyAsync(pts.p, hb.data(), ntab * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(spk::k_fixed_base_tables16, dim3((unsigned)(ntab * 16)), dim3(256), 0, c->stream, pts.as<aff_t>(), ntab, tj16.as<jac_t>());
     hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per16 + 255) / 256)), dim3(256), 0, c->stream, tj16.as<jac_t>(), ntab * per16, t16);
-    SP_HIP(hipStreamSynchronize(c->stream));
+    SP_HIP(sp::stream_sync(c->stream));
     k->d_tables16 = t16;
     std::lock_guard<std::mutex> l(g_t16_mu);
     if (ntab > 1) g_t16[k->d_cktables] = t16;
@@ -548,11 +548,11 @@ static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, void* out_, unsigned
       }
       if (spins > 4000000) {
         if (synced) return fail(SP_ERR_INTERNAL, "fixed-base rows: the kernel did not deliver a result slot");
-        SP_HIP(hipStreamSynchronize(st));  // e.g. under a profiler
+        SP_HIP(sp::stream_sync(st));  // e.g. under a profiler
         synced = true;
         spins = 0;
       }
-      __builtin_ia32_pause();
+      sp::relax();
     }
     memcpy(out + (size_t)D * i, w, 4 * (size_t)D);
   }
@@ -578,7 +578,7 @@ static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, con
     SP_HIP(hipMemcpyAsync(ds, hs, n * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
     c->timed("fixed_base", 32ull * n, [&] { launch_fixed_base_rows(c->stream, ds, n, d_tables, ntables, dout); });
     SP_HIP(hipMemcpyAsync(hp, dout, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(hipStreamSynchronize(c->stream));
+    SP_HIP(sp::stream_sync(c->stream));
     memcpy(out.data(), hp, n * sizeof(jac_t));
     return SP_OK;
   }
@@ -587,7 +587,7 @@ static int fixed_base_rows(sp_ctx* c, const aff_t* d_tables, size_t ntables, con
     launch_fixed_base_rows(c->stream, ds, n, d_tables, ntables, dout);
   });
   SP_HIP(hipMemcpyAsync(out.data(), dout, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 
@@ -658,7 +658,7 @@ int sp_fixed_base_mul_h_finish(sp_ctx* c, sp_fb_job* job, uint64_t* out_aff) {
       return rc;
     }
   } else if (job->on_device) {
-    SP_HIP(hipEventSynchronize(c->fb_event()));
+    SP_HIP(sp::event_sync(c->fb_event()));
     pts.assign(job->pinned, job->pinned + job->n);
   } else {
     pts.swap(job->host_pts);
@@ -721,7 +721,7 @@ static int commit_rows(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off
     });
     out_rows.resize(rows);
     SP_HIP(hipMemcpyAsync(out_rows.data(), drow, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(hipStreamSynchronize(c->stream));
+    SP_HIP(sp::stream_sync(c->stream));
     return SP_OK;
   }
   fe_t* canon = (fe_t*)c->workspace(sp_ctx::WS_COMMIT_CANON, n * sizeof(fe_t));
@@ -742,7 +742,7 @@ static int commit_rows(sp_ctx* c, const sp_ck* ck, const sp_table* v, size_t off
   std::vector<jac_t> msm_rows(rows);
   SP_HIP(hipMemcpyAsync(hflags.data(), flags, rows * 4, hipMemcpyDeviceToHost, c->stream));
   SP_HIP(hipMemcpyAsync(msm_rows.data(), rowsum, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   // msm_10 / msm_small_rest / full msm rows (msm.rs:367-409, :187-222): digit path. One or two such rows take the single-MSM (latency) path;
   // more are batched over the row dimension (throughput path).
   std::vector<unsigned> full_rows, narrow_rows;
@@ -889,7 +889,7 @@ static int scalar_mul_rows(sp_ctx* c, const uint64_t* points_aff, size_t n, cons
   SP_HIP(hipMemcpyAsync(dp.p, pts, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
   c->timed("wnaf_rows", 64ull * n, [&] { hipLaunchKernelGGL(spk::k_wnaf_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, dp.as<aff_t>(), n, w, dout.as<jac_t>()); });
   SP_HIP(hipMemcpyAsync(out.data(), dout.p, n * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 int sp_vartime_scalar_mul(sp_ctx* c, const uint64_t* points_aff, size_t n, const uint64_t scalar[4], uint64_t* out_aff) {
@@ -958,7 +958,7 @@ int sp_rowmat_vec(sp_ctx* c, const sp_table* poly, size_t rows, size_t cols, con
   SP_HIP(hipMemcpyAsync(dL, L, rows * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
   c->timed("rowmat_vec", 32ull * (rows * cols + rows + cols), [&] { launch_rowmat_vec(c->stream, poly->d, rows, cols, dL, part, splits, dout); });
   SP_HIP(hipMemcpyAsync(out, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 
@@ -1033,7 +1033,7 @@ int sp_points_upload(sp_ctx* c, const uint64_t* aff, size_t n, sp_points** io) {
   sp_points* p = *io ? *io : new sp_points();
   if (p->cap < n) {
     if (p->d) {
-      hipStreamSynchronize(c->stream2);
+      sp::stream_sync(c->stream2);
       hipFree(p->d);
       p->d = nullptr;
       p->cap = 0;
@@ -1048,7 +1048,7 @@ int sp_points_upload(sp_ctx* c, const uint64_t* aff, size_t n, sp_points** io) {
   *io = p;
   if (n) {
     SP_HIP(hipMemcpyAsync(p->d, aff, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream2));
-    SP_HIP(hipStreamSynchronize(c->stream2));  // `aff` is a borrowed host buffer
+    SP_HIP(sp::stream_sync(c->stream2));  // `aff` is a borrowed host buffer
   }
   return SP_OK;
 }
@@ -1158,7 +1158,7 @@ int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, s
     std::vector<fe_t> w(rows);
     eq_table_host(rr, ell, w.data());
     SP_HIP(hipMemcpyAsync(dL, w.data(), rows * sizeof(fe_t), hipMemcpyHostToDevice, st));
-    SP_HIP(hipStreamSynchronize(st));  // w is a local
+    SP_HIP(sp::stream_sync(st));  // w is a local
   }
   c->timed_on(st, "rowmat_vec", 32ull * (rows * cols + rows + cols), [&] { launch_rowmat_vec(st, poly->d, rows, cols, dL, part, splits, dout); });
   SP_HIP(hipMemcpyAsync(c->h_pinned_vec, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, st));
@@ -1172,7 +1172,7 @@ int sp_rowmat_vec_eq_finish(sp_ctx* c, sp_vec_job* job, uint64_t* out) {
   if (!job || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish: null argument");
   const size_t cols = job->cols;
   delete job;
-  SP_HIP(hipEventSynchronize(c->vec_ev));
+  SP_HIP(sp::event_sync(c->vec_ev));
   memcpy(out, c->h_pinned_vec, cols * sizeof(fe_t));
   return SP_OK;
 }
@@ -1195,7 +1195,7 @@ static int build_window_tables(sp_ctx* c, const aff_t* host_points, size_t n, af
   if (e == hipSuccess) {
     hipLaunchKernelGGL(spk::k_fixed_base_tables, dim3((unsigned)n), dim3(64), 0, c->stream, pts.as<aff_t>(), n, tj.as<jac_t>());
     hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), n * per, tables);
-    e = hipStreamSynchronize(c->stream);
+    e = sp::stream_sync(c->stream);
   }
   if (e != hipSuccess) {
     hipFree(tables);
@@ -1235,7 +1235,7 @@ int multi_mul_ensure(sp_ctx* c, int lane) {
     SP_HIP(hipHostGetDevicePointer(&c->d_mm[lane], c->h_mm[lane], 0));
     SP_HIP(hipMalloc(&c->d_mm_work[lane], 256 + spk::MULTI_MUL_MAX_BLOCKS * sizeof(xyzz_t)));
     SP_HIP(hipMemsetAsync(c->d_mm_work[lane], 0, 256, c->stream2));  // the ticket; every launch leaves it at zero again
-    SP_HIP(hipStreamSynchronize(c->stream2));
+    SP_HIP(sp::stream_sync(c->stream2));
   }
   return SP_OK;
 }
@@ -1289,13 +1289,13 @@ int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield)
     }
     if (spins > 400000) {
       if (synced) return fail(SP_ERR_INTERNAL, "multi_mul: the kernel did not deliver its result slot");
-      SP_HIP(hipStreamSynchronize(lane ? c->stream2 : c->stream));  // e.g. under a profiler
+      SP_HIP(sp::stream_sync(lane ? c->stream2 : c->stream));  // e.g. under a profiler
       synced = true;
       spins = 0;
     }
     // a helper-thread caller: the kernel takes ~130 us; past that it is late because the chip is shared, and the poll yields its CPU
     if (yield && spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(20));
-    else __builtin_ia32_pause();
+    else sp::relax();
   }
   memcpy(out, w, sizeof(jac_t));
   return SP_OK;
@@ -1527,7 +1527,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
       jac_t lj;
       if ((rc = sp::multi_mul_collect(c, 0, seq_lz, &lj, false))) return rc;
       comm_LZ = jac_to_affine(lj);
-      SP_HIP(hipEventSynchronize(c->pcs_ev));
+      SP_HIP(sp::event_sync(c->pcs_ev));
       memcpy(LZ.data(), c->h_pcs, cols * sizeof(fe_t));
     }
   } else {
@@ -1583,7 +1583,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     };
     if (nch > 2) c->pcs_worker->submit(work);
     work();
-    while (sh->done.load(std::memory_order_acquire) < nch) __builtin_ia32_pause();
+    while (sh->done.load(std::memory_order_acquire) < nch) sp::relax();
   }
   zv[cols] = fe_add<SF>(fe_mul<SF>(rr, r_LZ), r_delta);
   zv[cols + 1] = fe_add<SF>(fe_mul<SF>(rr, b_eval), r_beta);

@@ -78,7 +78,7 @@ int sum_partials(sp_nifs* n, size_t rows, size_t cnt, fe_t* out_host) {
     dst = const_cast<fe_t*>(t);
   }
   SP_HIP(hipMemcpyAsync(out_host, dst, rows * NACC * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 
@@ -99,7 +99,7 @@ int upload_weights(sp_nifs* n, size_t t, size_t pairs) {
   std::vector<fe_t> w(pairs);
   for (size_t p = 0; p < pairs; ++p) w[p] = suffix_weight_full(t, n->ell_b, pair_base(n, t) + p, n->rhos);
   SP_HIP(hipMemcpyAsync(n->d_w, w.data(), pairs * sizeof(fe_t), hipMemcpyHostToDevice, n->ctx->stream));
-  SP_HIP(hipStreamSynchronize(n->ctx->stream));  // w is a stack-lifetime host buffer
+  SP_HIP(sp::stream_sync(n->ctx->stream));  // w is a stack-lifetime host buffer
   return SP_OK;
 }
 
@@ -189,7 +189,7 @@ int sp_nifs_prepare_small(sp_nifs* n) {
     });
   std::vector<unsigned char> flags(n->total);
   SP_HIP(hipMemcpyAsync(flags.data(), n->d_flags, n->total, hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   std::vector<unsigned> large;
   for (size_t k = 0; k < n->total; ++k)
     if (flags[k]) large.push_back((unsigned)k);
@@ -198,7 +198,7 @@ int sp_nifs_prepare_small(sp_nifs* n) {
     SP_HIP(hipMemcpyAsync(n->d_large, large.data(), large.size() * 4, hipMemcpyHostToDevice, c->stream));
     for (int q = 0; q < 3; ++q)
       hipLaunchKernelGGL(spk::k_small_mask, dim3(blocks, (unsigned)np), dim3(256), 0, c->stream, dst[q], (unsigned long long)n->total, n->d_flags);
-    SP_HIP(hipStreamSynchronize(c->stream));
+    SP_HIP(sp::stream_sync(c->stream));
   }
   n->mirrors_ready = true;
   return SP_OK;
@@ -485,7 +485,7 @@ int sp_nifs_resume(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_
   n->nlarge = 0;
   // NOTE: weights of round t use pair indices relative to layers of 2^t instances; with first = 0 and m layers of 2^t_start they coincide
   SP_HIP(hipMemcpyAsync(n->d_E, E_eq, (n->left + n->right) * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 
@@ -521,7 +521,7 @@ int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out
   }
   if ((rc = sp_fold_tables(c, ptrs.data(), n->n_padded, w.data(), n->total, C_out))) return rc;
   }
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   for (sp_table* t : {A_out, B_out}) {
     t->len = n->total;
     t->lo_eff = t->hi_eff = (size_t)-1;
@@ -544,7 +544,7 @@ int sp_to_small_vec_or_zero(sp_ctx* c, const sp_table* t, size_t cnt, int64_t* o
   hipLaunchKernelGGL(spk::k_to_small, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, t->d, (unsigned long long)cnt, d_out, d_fl);
   SP_HIP(hipMemcpyAsync(out_i64, d_out, cnt * 8, hipMemcpyDeviceToHost, c->stream));
   SP_HIP(hipMemcpyAsync(out_large, d_fl, cnt, hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(hipStreamSynchronize(c->stream));
+  SP_HIP(sp::stream_sync(c->stream));
   hipFree(d_out);
   hipFree(d_fl);
   return SP_OK;

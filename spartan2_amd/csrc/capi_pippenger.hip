@@ -85,7 +85,7 @@ static int run_pippenger(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, s
   c->timed("msm_big_window", 0, [&] { hipLaunchKernelGGL(spk::k_pip_bitsums, dim3(C, W), dim3(256), 0, st, buckets, E, C, wsum); });
   std::vector<jac_t> ws((size_t)W * C);
   SP_HIP(hipMemcpyAsync(ws.data(), wsum, ws.size() * sizeof(jac_t), hipMemcpyDeviceToHost, st));
-  SP_HIP(hipStreamSynchronize(st));
+  SP_HIP(sp::stream_sync(st));
   // Horner over the windows and, inside a window, over the bits of the bucket weights, high to low (msm.rs:150-175 with the window sums bit-sliced):
   // acc = 2 acc + S[w][bit]
   jac_t acc = jac_identity();

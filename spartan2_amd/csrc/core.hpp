@@ -23,6 +23,14 @@ namespace sp {
 
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+// one iteration of a host-side wait for the device (a result slot, a mailbox answer, a helper's flag): the calling thread's wait hook
+// (sp_set_wait_hook: a driver that runs several proofs on one thread switches to another proof here) or a `pause`
+void relax();
+// hipStreamSynchronize / hipEventSynchronize for library code: on a thread with a wait hook they poll (hipStreamQuery / hipEventQuery) through relax()
+// instead of blocking — a blocked thread could not serve the other proofs it carries, and one of those may own a kernel that sits in front of this
+// stream's work in a shared hardware queue while it waits for its host's next challenge
+hipError_t stream_sync(hipStream_t s);
+hipError_t event_sync(hipEvent_t e);
 
 #define SP_HIP(expr)                                                                               \
   do {                                                                                             \
@@ -80,7 +88,7 @@ class Worker {
     cv_.notify_one();
   }
   void wait() {
-    while (pending_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    while (pending_.load(std::memory_order_acquire)) sp::relax();
   }
 };
 
@@ -262,7 +270,7 @@ struct sp_transcript {
           break;
         }
       }
-      __builtin_ia32_pause();
+      sp::relax();
     }
     const_cast<sp_transcript*>(this)->t.h = j.h;
     pend.reset();

@@ -187,7 +187,7 @@ struct Comm {
           synced = true;
           spins = 0;
         }
-        __builtin_ia32_pause();
+        sp_relax();
       }
       for (size_t i = 0; i < words; ++i) reinterpret_cast<uint64_t*>(recv)[i] = slot[2 + i];
       return;

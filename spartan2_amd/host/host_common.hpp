@@ -156,11 +156,11 @@ class Background {
     cv_.notify_one();
   }
   void wait_nothrow() {  // for exit paths: also drops what the job threw, so that it cannot resurface in a later submit()
-    while (pending_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    while (pending_.load(std::memory_order_acquire)) sp_relax();
     err_ = nullptr;
   }
   void wait() {  // rethrows what the job threw
-    while (pending_.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    while (pending_.load(std::memory_order_acquire)) sp_relax();
     if (err_) {
       std::exception_ptr e = err_;
       err_ = nullptr;

@@ -71,12 +71,12 @@ class Worker {
     return t;
   }
   void drain() {  // every job submitted so far has run; drops what they threw (exit paths)
-    while (done_.load(std::memory_order_acquire) < submitted_) __builtin_ia32_pause();
+    while (done_.load(std::memory_order_acquire) < submitted_) sp_relax();
     std::lock_guard<std::mutex> l(m_);
     err_ = nullptr;
   }
   void wait(size_t ticket) {  // jobs up to `ticket` have run; rethrows the first failure
-    while (done_.load(std::memory_order_acquire) < ticket) __builtin_ia32_pause();
+    while (done_.load(std::memory_order_acquire) < ticket) sp_relax();
     std::exception_ptr e;
     {
       std::lock_guard<std::mutex> l(m_);

@@ -430,7 +430,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
             std::unique_lock<std::mutex> lk(lzp->mu);  // woken by publish(); the timeout covers a notify that raced the predicate
             lzp->cv.wait_for(lk, std::chrono::microseconds(100), [&] { return flag.load(std::memory_order_acquire) != 0; });
           } else {
-            __builtin_ia32_pause();
+            sp_relax();
           }
         }
         return st;
@@ -638,7 +638,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
           const auto t0 = std::chrono::steady_clock::now();
           while (ip->right_ready.load(std::memory_order_acquire) == 0) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) return;  // (the prover finishes <R, d> and beta itself; a helper does not sit on a CPU of the quota)
-            __builtin_ia32_pause();
+            sp_relax();
           }
           const std::vector<fe_t> right = eq_evals_host(ip->right_r, ip->nright_vars);
           fe_t acc = fe_zero();
@@ -700,7 +700,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       const auto t0 = std::chrono::steady_clock::now();
       while (lz.early_done.load(std::memory_order_acquire) == 0) {
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) throw Error(SP_ERR_INTERNAL, "the PCS helper did not finish delta");
-        __builtin_ia32_pause();
+        sp_relax();
       }
     } else {
       ps.bg.wait();
@@ -1302,6 +1302,126 @@ int ss_prove_hook(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, 
     if (getenv("SPARTAN_HOST_LAPS")) {
       for (auto& l : pt.laps) fprintf(stderr, "lap %-28s %.3f ms\n", l.first.c_str(), l.second);
     }
+    return 0;
+  } catch (...) {
+    return catch_all();
+  }
+}
+// ---- several proofs in flight on ONE thread ------------------------------------------------------------------------------------------------------
+// A prove is a chain of ~41 host <-> device round trips whose host side is a few microseconds of hashing and two kernel launches: one CPU spinning
+// per proof in flight wastes the CPU and, under a CPU quota, caps the number of proofs in flight. Here every proof runs on a stack of its own
+// (ucontext) and the library's wait hook (sp_set_wait_hook) hands the thread to the next proof at every poll: `threads` OS threads keep
+// n_ctx proofs in flight, the GPU sees the same launches. The prove code itself is untouched — it blocks, its stack waits.
+}  // extern "C"
+#include <ucontext.h>
+namespace {
+struct Fiber {
+  ucontext_t uc;
+  std::unique_ptr<char[]> stack;
+  std::function<void()> body;
+  bool done = false;
+  std::exception_ptr err;
+};
+struct Scheduler {
+  ucontext_t main;
+  std::vector<Fiber*> fibers;
+  Fiber* cur = nullptr;
+  uint64_t switches = 0;
+  double wait_s = 0;  // wall time the thread's proofs spent in polls (summed over the proofs: what is left of the batch's time is host work)
+  static void hook(void* u) {
+    Scheduler* s = (Scheduler*)u;
+    ++s->switches;
+    const auto t0 = std::chrono::steady_clock::now();
+    swapcontext(&s->cur->uc, &s->main);
+    s->wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  static void entry(unsigned lo, unsigned hi) {
+    Fiber* f = (Fiber*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+    try {
+      f->body();
+    } catch (...) {
+      f->err = std::current_exception();
+    }
+    f->done = true;  // returning resumes uc_link = the scheduler
+  }
+  void add(Fiber* f, size_t stack_bytes) {
+    f->stack.reset(new char[stack_bytes]);
+    getcontext(&f->uc);
+    f->uc.uc_stack.ss_sp = f->stack.get();
+    f->uc.uc_stack.ss_size = stack_bytes;
+    f->uc.uc_link = &main;
+    const uintptr_t p = (uintptr_t)f;
+    makecontext(&f->uc, (void (*)())entry, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+    fibers.push_back(f);
+  }
+  void run() {
+    sp_set_wait_hook(&Scheduler::hook, this);
+    size_t live = fibers.size();
+    while (live) {
+      for (Fiber* f : fibers) {
+        if (f->done) continue;
+        cur = f;
+        swapcontext(&main, &f->uc);
+        if (f->done) --live;
+      }
+    }
+    sp_set_wait_hook(nullptr, nullptr);
+  }
+};
+}  // namespace
+extern "C" {
+// n_ctx prepared states (pks[i], pss[i]: one context each, all on one device) prove `proofs_each` times each, multiplexed over `threads` OS threads.
+// out_words: n_ctx x words_cap, the LAST proof of every state; out_stats: seconds of the whole batch, context switches, proofs, seconds spent inside polls summed over the proofs.
+int ss_prove_multiplexed(void** pks, void** pss, size_t n_ctx, const uint64_t* publics_u64, size_t npub, const uint8_t* tape, size_t tape_blocks, size_t proofs_each,
+                         size_t threads, uint64_t* out_words, size_t words_cap, double out_stats[4]) {
+  try {
+    if (n_ctx == 0 || threads == 0 || proofs_each == 0) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "ss_prove_multiplexed: nothing to do");
+    if (threads > n_ctx) threads = n_ctx;
+    std::vector<Fiber> fibers(n_ctx);
+    std::vector<Scheduler> sched(threads);
+    for (size_t i = 0; i < n_ctx; ++i) {
+      auto* pk = (SpartanProverKey*)pks[i];
+      auto* ps = (SpartanPrepSNARK*)pss[i];
+      uint64_t* dst = out_words + i * words_cap;
+      fibers[i].body = [=] {
+        for (size_t k = 0; k < proofs_each; ++k) {
+          Tape t{tape, tape_blocks};
+          SpartanProofBuf pf = prove(*pk, *ps, publics_u64, npub, t, nullptr, nullptr, nullptr);
+          if (pf.words.size() > words_cap) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "proof buffer too small");
+          if (k + 1 == proofs_each) memcpy(dst, pf.words.data(), pf.words.size() * 8);
+        }
+      };
+      sched[i % threads].add(&fibers[i], (size_t)1 << 20);
+    }
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<std::thread> th;
+    std::vector<int> rc(threads, 0);
+    for (size_t t = 0; t < threads; ++t)
+      th.emplace_back([&, t] {
+        rc[t] = sp_ctx_bind_thread(((SpartanProverKey*)pks[t])->ctx);
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        if (rc[t] == 0) sched[t].run();
+      });
+    while (ready.load() < (int)threads) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (auto& x : th) x.join();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t sw = 0;
+    double waited = 0;
+    for (auto& s : sched) sw += s.switches, waited += s.wait_s;
+    if (out_stats) {
+      out_stats[0] = secs;
+      out_stats[1] = (double)sw;
+      out_stats[2] = (double)(n_ctx * proofs_each);
+      out_stats[3] = waited;
+    }
+    for (size_t t = 0; t < threads; ++t)
+      if (rc[t]) throw Error(rc[t], "ss_prove_multiplexed: could not bind a poller thread to the device");
+    for (auto& f : fibers)
+      if (f.err) std::rethrow_exception(f.err);
     return 0;
   } catch (...) {
     return catch_all();

@@ -37,6 +37,23 @@ def test_eight_proofs_in_flight_are_all_the_same_proof():
     assert out["mail"]["watchdog_trips"] == 0, out
 
 
+def test_proofs_multiplexed_on_few_threads_are_all_the_same_proof():
+    """ss_prove_multiplexed: 12 proofs in flight on 3 polling threads — every proof on a stack of its own, the library's wait hook (sp_set_wait_hook)
+    switching between them at every poll, stream / event synchronisations polled instead of blocking. Every proof equals the plain single prove."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "multiplex_bench.py"), "--sweep", "2x1,12x3", "--proofs", "15", "--json"], capture_output=True, text=True,
+                       timeout=900)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert line, (r.stdout + r.stderr)[-2000:]
+    for res in json.loads(line[-1])["results"]:
+        assert res["rc"] == 0 and res["mismatches"] == 0 and res["proofs"] == res["proofs_in_flight"] * 15, res
+
+
 def test_many_hardware_queues_do_not_stall():
     """GPU_MAX_HW_QUEUES=24 (default 4) lets every stream of the eight contexts run beside the others: results arrive late far more often, which turned
     round 2's stall from one per ~30 000 proofs into dozens per 3200. Must be clean now."""
