@@ -273,6 +273,24 @@ def main():
         barrier()
         elapsed = group.max_over_ranks(time.perf_counter() - t0)
         ncons = circs[0].num_cons * nsteps + core.num_cons
+        # the reference-order driver (one thread, statement order of src/neutronnova_zk.rs:1609-2093, PCS::prove as one sp_hyrax_prove) on a prep state of its
+        # own: its first proof must be the default driver's first proof (every prove rerandomizes its prep state in place), then the same number of steps
+        nn_ref = host.NeutronNovaZkSNARK(ctx, circs, core)
+        assert nn_ref.prep_prove(tape) == used
+        ref_first, _, _ = nn_ref.prove(step_tape, reference_order=True)
+        ref_identical = bool(len(ref_first) == len(first_words) and (ref_first == first_words).all())
+        for _ in range(args.warmup):
+            nn_ref.prove(step_tape, reference_order=True)
+        barrier()
+        t0 = time.perf_counter()
+        acc_ref = {}
+        for _ in range(args.steps):
+            _, _, ph = nn_ref.prove(step_tape, reference_order=True)
+            for k_, v_ in ph.items():
+                acc_ref[k_] = acc_ref.get(k_, 0.0) + v_
+        barrier()
+        elapsed_ref = group.max_over_ranks(time.perf_counter() - t0)
+        nn_ref.close()
         # untimed pass with the kernel classes instrumented: the streaming kernels of the NIFS rounds against the HBM roofline (at 32 x 2^15 every launch
         # is latency-bound: the numbers say how far a 1 MiB-per-layer launch is from the rate the same kernels reach at config 5's size)
         c3_names = ("nifs_fold_prove", "nifs_round0_small", "nifs_round0", "nifs_fold", "nifs_cvals", "fold_tables", "eval_cubic_pow", "eval_quad", "bind", "poly_abc", "fixed_base")
@@ -300,7 +318,12 @@ def main():
                    "config": {"workload": "sha256_neutronnova 32 step circuits (BASELINE config 3), NeutronNovaZkSNARK::prove", "num_steps": nsteps,
                               "num_cons_unpadded_per_step": circs[0].num_cons, "num_cons_per_step": 1 << nn.info["nx"],
                               "parallelism": f"{world} independent batches, one per GPU"},
-                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "verify_ms": verify_ms, "sharded": None, "roofline": None, "cpu_baseline": None}
+                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "verify_ms": verify_ms, "sharded": None, "roofline": None, "cpu_baseline": None,
+                   "reference_order": {"ms_per_step": elapsed_ref / args.steps * 1e3, "constraints_per_s": ncons * world * args.steps / elapsed_ref,
+                                       "proof_identical": ref_identical, "phases_ms": {k_: v_ / args.steps for k_, v_ in acc_ref.items()},
+                                       "headline_over_reference_order": elapsed / elapsed_ref,
+                                       "note": "one thread, statement order of src/neutronnova_zk.rs:1609-2093, ABI calls only (no jobs on a second context, PCS::prove = one "
+                                               "sp_hyrax_prove): the time of an unchanged neutronnova_zk.rs over the ABI"}}
             fp = c3_stats["nifs_fold_prove"]
             if fp[1]:
                 ach = (fp[2] / fp[1]) / (fp[0] / fp[1] * 1e-3) / 1e9

@@ -8,6 +8,9 @@
 //   * `prove_cubic_with_three_inputs` / `prove_quad` bodies   src/sumcheck.rs:190-247, 502-571
 //   * `HyraxPCS::prove` body                        src/provider/pcs/hyrax_pc.rs:387-478 (one call: sp_hyrax_prove)
 //
+// The second half — SplitR1CSShape, the PCS commit / fold functions, NeutronNovaNIFS, the batched ZK sum-checks, the wire formats — is
+// hip_r1cs_pcs.rs.
+//
 // This image has no Rust toolchain, so the file has NOT been compiled here; it is written against the reference's trait definitions as they
 // stand in /root/reference at the surveyed commit and against the generated FFI module, and is the source a maintainer starts from instead of
 // retyping INTEGRATION.md. The same call sequence, compiled and tested, is spartan2_amd/host/spartan_snark.cpp `prove_reference_order`.
@@ -134,6 +137,12 @@ pub struct HipTable<F> {
   _p: PhantomData<F>,
 }
 unsafe impl<F> Send for HipTable<F> {}
+impl<F> HipTable<F> {
+  /// adopt a table handle the library returned (sp_table_zeros, sp_eq_table, sp_nifs_layer ...)
+  pub(crate) fn from_raw(t: *mut sp_table) -> Self {
+    Self { t, _p: PhantomData }
+  }
+}
 impl<F: Copy + Default> HipTable<F> {
   /// MultilinearPolynomial::new (:62-66) / new_with_halves (:68-75): usize::MAX = "unknown" zero structure
   pub fn new(z: &[F], lo_eff: usize, hi_eff: usize) -> Result<Self, SpartanError> {

@@ -511,12 +511,14 @@ class NeutronNovaZkSNARK:
         self.ps = ps
         return used.value
 
-    def prove(self, tape: np.ndarray):
+    def prove(self, tape: np.ndarray, reference_order=False):
+        """reference_order: the one-thread driver in the statement order of src/neutronnova_zk.rs:1609-2093 (no side jobs, the opening as one sp_hyrax_prove)"""
         n = lib().nnz_proof_words(self.pk)
         words = np.zeros(n, dtype=np.uint64)
         used = ctypes.c_size_t(0)
         ms = (ctypes.c_double * 8)()
-        _check(lib().nnz_prove(self.pk, self.ps, hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
+        fn = lib().nnz_prove_reference_order if reference_order else lib().nnz_prove
+        _check(fn(self.pk, self.ps, hip.p8(tape), ctypes.c_size_t(tape.shape[0]), ctypes.byref(used), hip.p64(words), ctypes.c_size_t(n), ms))
         return words, used.value, dict(zip(NN_PHASES, list(ms)))
 
     def verify(self, words: np.ndarray) -> int:

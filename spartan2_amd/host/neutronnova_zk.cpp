@@ -396,7 +396,9 @@ static void prove_direct(size_t num_cols, const std::vector<fe_t>& poly, const s
 }
 
 // prove (:1609-2093)
-static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* phase_ms) {
+// reference_order: ONE thread, the statements of src/neutronnova_zk.rs:1609-2093 in their order, ABI calls only — no jobs on a second context, the folded
+// opening as the single PCS::prove call (sp_hyrax_prove) — what an unchanged neutronnova_zk.rs over the shim of integration/ gets. Same proof.
+static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* phase_ms, bool reference_order = false) {
   sp_ctx* ctx = pk.ctx;
   const sp_dims& d = pk.dims;
   const size_t CW = DEFAULT_COMMITMENT_WIDTH, n = ps.steps.size(), nv = pk.num_vars, N = d.num_cons;
@@ -416,7 +418,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     t_lap = t;
   };
   ck(sp_ctx_bind_thread(ctx), "device");
-  const bool side = true;  // (false = everything inline on the caller's context: the order the phase comments describe)
+  const bool side = !reference_order;  // (false = everything inline on the caller's context: the order the phase comments describe)
   struct SideGuard {  // no exit path leaves a job running on state this call owns
     NNZkPrep& ps;
     ~SideGuard() { ps.wk.drain(); }
@@ -871,7 +873,18 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   aff_t delta, beta;
   std::vector<fe_t> z_vec(CW);
   fe_t z_delta, z_beta;
-  {
+  if (reference_order) {  // PCS::prove(ck, ck_eval = the width-32 key, transcript, comm, W, blind, r_y[1..], comm_eval, blind_eval) (:2067-2080) as one call
+    std::vector<uint64_t> arg(16 + 4 * CW + 8);
+    ck(sp_hyrax_prove(ctx, pk.ck, pk.vc_ck, tr.t, u64p(&comm[0].x), comm.size(), Wf, nv, u64p(blind.data()), u64p(r_y.data() + 1), pk.ny - 1, u64p(&comm_eval.x),
+                      u64p(&blind_eval), tape.bytes + 64 * tape.pos, tape.blocks - tape.pos, arg.data()),
+       "PCS::prove");
+    tape.skip(CW + 2);
+    memcpy(&delta, arg.data(), 64);
+    memcpy(&beta, arg.data() + 8, 64);
+    memcpy(z_vec.data(), arg.data() + 16, 32 * CW);
+    memcpy(&z_delta, arg.data() + 16 + 4 * CW, 32);
+    memcpy(&z_beta, arg.data() + 16 + 4 * CW + 4, 32);
+  } else {
     const std::vector<uint8_t> b = commitment_bytes(comm.data(), comm.size());
     tr.absorb("poly_com", b.data(), b.size());
     const fe_t* point = r_y.data() + 1;
@@ -1559,10 +1572,11 @@ int nnz_verify(void* pk, const uint64_t* words, size_t nwords) {
   }
 }
 // phase_ms[8]: instances, nifs, outer, inner, verifier-circuit instance, opening, total, (of which) per-round vc commitments
-int nnz_prove(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words, size_t out_cap, double* phase_ms) {
+static int nnz_prove_impl(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words, size_t out_cap, double* phase_ms,
+                          bool reference_order) {
   try {
     Tape t{tape, tape_blocks};
-    ProofBuf pf = nn_prove(*(NNZkKey*)pk, *(NNZkPrep*)ps, t, phase_ms);
+    ProofBuf pf = nn_prove(*(NNZkKey*)pk, *(NNZkPrep*)ps, t, phase_ms, reference_order);
     if (pf.words.size() > out_cap) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "proof buffer too small");
     memcpy(out_words, pf.words.data(), pf.words.size() * 8);
     if (tape_used) *tape_used = t.pos;
@@ -1570,6 +1584,13 @@ int nnz_prove(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_
   } catch (...) {
     return catch_all_nn();
   }
+}
+int nnz_prove(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words, size_t out_cap, double* phase_ms) {
+  return nnz_prove_impl(pk, ps, tape, tape_blocks, tape_used, out_words, out_cap, phase_ms, false);
+}
+// the reference-order driver (see nn_prove): the time of an unchanged neutronnova_zk.rs over the ABI; the proof is the same
+int nnz_prove_reference_order(void* pk, void* ps, const uint8_t* tape, size_t tape_blocks, size_t* tape_used, uint64_t* out_words, size_t out_cap, double* phase_ms) {
+  return nnz_prove_impl(pk, ps, tape, tape_blocks, tape_used, out_words, out_cap, phase_ms, true);
 }
 // NeutronNovaZkSNARK as bincode bytes (the reference's serde framing; include/spartan_hip.h "wire formats"). `_to_bytes`: out may be NULL to learn *len.
 int nnz_proof_to_bytes(void* pk, const uint64_t* words, size_t nwords, uint8_t* out, size_t cap, size_t* len) {

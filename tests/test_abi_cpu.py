@@ -75,3 +75,27 @@ def test_rust_ffi_module_is_generated_from_the_header():
     assert sorted(names) == hip.declared_symbols()
     for n in names:
         assert f"pub fn {n}(" in text
+    # the hand-written halves of the binding (uncompiled here: no rustc) at least call functions that exist, with the declared number of arguments
+    import re
+
+    arity = {m.group(1): (0 if not m.group(2).strip() else m.group(2).count(":")) for m in re.finditer(r"pub fn (sp_\w+)\((.*?)\)(?: ->|;)", text)}
+    for fname in ("hip_provider.rs", "hip_r1cs_pcs.rs"):
+        src = open(os.path.join(root, "integration", fname)).read()
+        src = re.sub(r"//[^\n]*", "", src)
+        for m in re.finditer(r"\b(sp_[a-z0-9_]+)\s*\(", src):
+            name = m.group(1)
+            assert name in arity, (fname, name)
+            # argument count of the call: split the balanced parenthesis contents at top-level commas
+            i, depth, args, cur = m.end(), 1, 0, ""
+            while depth:
+                ch = src[i]
+                depth += ch in "([{"
+                depth -= ch in ")]}"
+                if depth == 1 and ch == ",":
+                    args += 1
+                    cur = ""
+                elif depth >= 1:
+                    cur += ch
+                i += 1
+            args += 1 if cur.strip() else 0
+            assert args == arity[name], (fname, name, args, arity[name])

@@ -95,6 +95,23 @@ def test_verify_rejects_what_the_oracle_rejects(ctx, n, groups):
     gnn.close()
 
 
+@pytest.mark.parametrize("n,groups", [(3, 30), (8, 30)])
+def test_reference_order_driver_is_the_same_proof(ctx, n, groups):
+    """nnz_prove_reference_order: one thread, ABI calls in the statement order of src/neutronnova_zk.rs:1609-2093, PCS::prove as ONE sp_hyrax_prove —
+    what an unchanged neutronnova_zk.rs over the shim gets. Word for word the oracle's proof, like the default driver's."""
+    steps = [frontend.synthetic_circuit(groups, 0xA5, num_public=1, witness_seed=50 + i) for i in range(n)]
+    core = frontend.synthetic_circuit(groups, 0xA5, num_public=1, witness_seed=999)
+    onn = ol.OracleNeutronNova(steps, core)
+    tape = ol.make_tape(60 + n, 32768)
+    want, used, _ = onn.prove(tape)
+    gnn = host.NeutronNovaZkSNARK(ctx, steps, core)
+    assert gnn.prep_prove(tape) == used[0]
+    got, used_g, phases = gnn.prove(tape[used[0]:], reference_order=True)
+    assert used_g == used[1] and (got == want).all()
+    assert onn.verify_words(got) == 0 and gnn.verify(got) == 0
+    gnn.close()
+
+
 def test_shared_and_precommitted_segments(ctx):
     mk = lambda ws: frontend.synthetic_circuit(30, 0x77, num_public=2, shared_permille=300, precommitted_permille=1000, witness_seed=ws)
     # every circuit shares step 0's shared witness (src/neutronnova_zk.rs:1485-1488): build the others with the same shared segment
