@@ -275,6 +275,20 @@ int sp_hyrax_rerandomize(sp_ctx* ctx, const sp_ck* ck, const uint64_t* comm_rows
 int sp_hyrax_prove(sp_ctx* ctx, const sp_ck* ck, const sp_ck* ck_eval, sp_transcript* tr, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n,
                    const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint8_t* rng,
                    size_t rng_blocks, uint64_t* out);
+/* PCS::prove announced ahead of its call. src/spartan.rs calls PCS::prove last (:425-435), but the commitment and its blinds exist when
+ * r1cs_instance_and_witness returns (:238-245), the IPA's randomness is independent of everything (the reference draws it inside
+ * InnerProductArgumentLinear::prove, ipa.rs:139-149) and the ROW half of the evaluation point exists once the inner sum-check has drawn it. A caller that
+ * announces the opening here (the shim's r1cs_instance_and_witness wrapper, with the randomness blocks it will later hand to sp_hyrax_prove) lets the
+ * library start under the two sum-checks what sp_hyrax_prove would start behind them: the commitment's transcript encoding + Keccak blocks and the mask
+ * vector's reductions (helper thread), delta's table walk (auxiliary stream), and — when sp_sumcheck_quad on this context reports the row challenges —
+ * L^T W and comm_LZ's walk. sp_hyrax_prove compares what it is given with what was announced (key, table, commitment, blinds, randomness, row
+ * challenges) and then only collects; on any difference the announcement is dropped and everything is computed as without it. Optional, one per context,
+ * consumed by the next sp_hyrax_prove; no proof value depends on it. A key without window tables (narrow keys, SPARTAN_KEY_TABLES=0) ignores it. */
+int sp_hyrax_prove_announce(sp_ctx* ctx, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds,
+                            const uint8_t* rng, size_t rng_blocks);
+/* withdraws an announcement that will not be followed by its sp_hyrax_prove (an error exit of the caller's prove): waits for what it started, frees it.
+ * The announced table and key must stay alive until the announcement is consumed, replaced or retracted. */
+int sp_hyrax_prove_retract(sp_ctx* ctx);
 /* asynchronous form: begin() enqueues upload + kernel + download and returns, finish() waits and normalises. One job per context at a time: the jobs
  * share the context's landing area, so begin() fails with SP_ERR_INVALID_INPUT_LENGTH while an earlier job (n above the host threshold) has not been
  * finished; finish() consumes the job whatever it returns. */

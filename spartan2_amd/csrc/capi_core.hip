@@ -179,6 +179,7 @@ int sp_ctx_bind_thread(sp_ctx* c) {
 int sp_ctx_device(const sp_ctx* c) { return c ? c->device : -1; }
 void sp_ctx_destroy(sp_ctx* c) {
   if (!c) return;
+  sp::pcs_ahead_free(c);
   hipSetDevice(c->device);
   c->drain_stats();
   for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -748,6 +749,8 @@ int sp_eq_table_into(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
   if (ell > 30) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table: ell too large");
   size_t total = (size_t)1 << ell;
   if (t->cap < total) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table_into: table too short");
+  if (c->eq_ahead_ell == ell && ell != 0 && memcmp(c->eq_ahead_r, r, c->eq_ahead_known * sizeof(fe_t)) == 0)
+    return sp_eq_table_finish(c, r, ell, t);  // the pyramids of this point's first ell - 2 coordinates were started under a sum-check
   t->len = total;
   t->lo_eff = t->hi_eff = (size_t)-1;
   int rc;
@@ -1063,7 +1066,8 @@ int sp_sumcheck_quad(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_tabl
                      uint64_t* out_r, uint64_t out_final[8]) {
   uint64_t claim_io[4];
   memcpy(claim_io, claim_, 32);
-  return quad_impl(c, claim_io, rounds, A, B, tr, nullptr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final);
+  // an opening announced on this context (sp_hyrax_prove_announce) learns the row challenges here, ten rounds before PCS::prove is called
+  return quad_impl(c, claim_io, rounds, A, B, tr, nullptr, nullptr, sp::pcs_ahead_wants(c, rounds) ? &sp::pcs_ahead_on_challenge : nullptr, c, out_cpolys, out_r, out_final);
 }
 int sp_sumcheck_quad_observed(sp_ctx* c, const uint64_t claim_[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_challenge_hook observe,
                               void* user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]) {
@@ -1623,13 +1627,30 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
 static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                       const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
                       uint64_t* out_r, uint64_t out_final[12], size_t run_rounds = 0, sp_challenge_hook observe = nullptr, void* observe_user = nullptr);
+struct EqAheadObserver {
+  sp_ctx* c;
+  size_t ell;
+  uint64_t r[4 * 20];
+};
+static void eq_ahead_observe(void* user, size_t round, const uint64_t r[4]) {
+  EqAheadObserver* o = (EqAheadObserver*)user;
+  if (round + 2 >= o->ell) return;
+  memcpy(o->r + 4 * round, r, 32);
+  if (round + 3 == o->ell) sp_eq_table_begin(o->c, o->r, o->ell - 2, o->ell);  // a failure leaves no announcement: sp_eq_table_into builds it all
+}
 int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                        uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
   uint64_t claim_io[4], p_io[4];
   memcpy(claim_io, claim_, 32);
   const fe_t one = fe_one<S>();
   store_fe(p_io, one);
-  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final);
+  // evals_rx (src/spartan.rs:316) follows this sum-check in the reference's order of calls: its two half pyramids are started here, under the last
+  // two rounds, so that the caller's sp_eq_table_into(r_x) is one launch behind the last challenge (as sp_eq_table_begin / _finish for a caller
+  // that announces it itself)
+  EqAheadObserver ea{c, ell, {}};
+  const bool ahead = ell >= 12 && ell <= 20;
+  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final, 0,
+                    ahead ? &eq_ahead_observe : nullptr, &ea);
 }
 int sp_sumcheck_cubic3_round0(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, const sp_table* p0,
                               const sp_table* p1, sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {

@@ -1357,6 +1357,197 @@ static void hp_point_bytes(const aff_t& a, uint8_t out[64]) {  // x BE || y BE (
   sp::fe_to_be_bytes<B>(a.x, out);
   sp::fe_to_be_bytes<B>(a.y, out + 32);
 }
+}  // extern "C"
+// ---- PCS::prove announced ahead ----------------------------------------------------------------------------------------------------------------
+// src/spartan.rs calls PCS::prove last (:425-435), but three of its inputs exist long before: the commitment and its blinds when
+// r1cs_instance_and_witness returns (:238-245), the IPA's randomness whenever the caller draws it (the reference draws inside
+// InnerProductArgumentLinear::prove, ipa.rs:139-149: independent of everything), and the ROW half of the evaluation point when the inner sum-check has
+// drawn it — rounds before its end. A caller (the shim's r1cs_instance_and_witness wrapper; prove_reference_order here) that announces the opening
+// lets the library start under the sum-checks what sp_hyrax_prove would otherwise start behind them: the commitment's transcript encoding and its
+// Keccak blocks + the mask vector's wide reductions (helper thread), delta's table walk (auxiliary stream, at once), and — when sp_sumcheck_quad on the
+// same context reports the row challenges — L^T W and comm_LZ's walk. sp_hyrax_prove checks that what it is given is what was announced and then only
+// collects; anything that does not match is dropped and computed as before. No protocol value changes: same group elements, same transcript bytes.
+struct sp_pcs_ahead {
+  const sp_ck* ck = nullptr;
+  const sp_table* poly = nullptr;
+  size_t n = 0, npt = 0, nvr = 0, cols = 0, num_rows = 0;
+  std::vector<aff_t> comm;
+  std::vector<fe_t> blind, dvec, row_pt;
+  std::vector<uint8_t> rng;
+  fe_t r_delta;
+  sp::Keccak256State hashed;  // "poly_com" || commitment bytes hashed into a fresh sponge (valid when the transcript is fresh at the absorb: checked)
+  bool worker_busy = false, delta_launched = false, delta_collected = false, lz_launched = false, failed = false;
+  // <R, d> (ipa.rs:148) with R = eq(point[nvr..]) = left (x) right: T[b] = sum_a left[a] d[a * nright + b] once the first half of R's variables is drawn
+  std::vector<fe_t> col_pt, T;
+  size_t hb = 0;
+  bool T_ready = false;
+  unsigned seq_delta = 0, seq_lz = 0;
+  jac_t delta_j;
+  fe_t r_LZ;
+};
+namespace sp {
+static void pcs_ahead_drain(sp_ctx* c) {  // no device job of a dropped announcement may outlive it (its mapped result slot is reused)
+  sp_pcs_ahead* S = c->pcs_ahead;
+  if (!S) return;
+  if (S->worker_busy && c->pcs_worker) c->pcs_worker->wait();
+  jac_t sink;
+  if (S->delta_launched && !S->delta_collected) (void)multi_mul_collect(c, 1, S->seq_delta, &sink, false);
+  if (S->lz_launched) {
+    (void)multi_mul_collect(c, 1, S->seq_lz, &sink, false);
+    if (c->pcs_ev) (void)event_sync(c->pcs_ev);
+  }
+}
+bool pcs_ahead_wants(const sp_ctx* c, size_t rounds) { return c->pcs_ahead && !c->pcs_ahead->failed && rounds == c->pcs_ahead->npt + 1; }
+void pcs_ahead_free(sp_ctx* c) {
+  if (!c || !c->pcs_ahead) return;
+  pcs_ahead_drain(c);
+  delete c->pcs_ahead;
+  c->pcs_ahead = nullptr;
+}
+// the inner sum-check's challenges: round 0 binds the variable that separates W from (1, X); rounds 1 .. nvr are the opening's row variables
+void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]) {
+  sp_ctx* c = (sp_ctx*)ctx;
+  sp_pcs_ahead* S = c->pcs_ahead;
+  if (!S || S->failed || S->nvr == 0 || round == 0) return;
+  if (round > S->nvr) {  // a column variable: after the first half of them the helper thread forms the partial sums of <R, d>
+    const size_t k = round - S->nvr - 1;
+    if (k < S->hb) memcpy(&S->col_pt[k], r, 32);
+    if (k + 1 == S->hb && !S->T_ready) {
+      if (S->worker_busy) c->pcs_worker->wait();
+      S->worker_busy = true;
+      c->pcs_worker->submit([S] {
+        const size_t nleft = (size_t)1 << S->hb, nright = S->cols >> S->hb;
+        std::vector<fe_t> left(nleft);
+        eq_table_host(S->col_pt.data(), S->hb, left.data());
+        S->T.assign(nright, fe_zero());
+        for (size_t a = 0; a < nleft; ++a)
+          for (size_t b = 0; b < nright; ++b) S->T[b] = fe_add<spk::SF>(S->T[b], fe_mul<spk::SF>(left[a], S->dvec[a * nright + b]));
+        S->T_ready = true;
+      });
+    }
+    return;
+  }
+  if (S->lz_launched) return;
+  memcpy(&S->row_pt[round - 1], r, 32);
+  if (round != S->nvr) return;
+  if (S->worker_busy) {  // the announcement's helper job (it launched delta's walk on this lane)
+    c->pcs_worker->wait();
+    S->worker_busy = false;
+  }
+  if (S->failed) return;
+  // delta's walk has had the whole outer sum-check: collect it (its lane's result slot is needed again), then L^T W and comm_LZ's walk on the same lane
+  if (S->delta_launched && !S->delta_collected) {
+    if (multi_mul_collect(c, 1, S->seq_delta, &S->delta_j, false)) {
+      S->failed = true;
+      return;
+    }
+    S->delta_collected = true;
+  }
+  const size_t num_rows = S->num_rows, cols = S->cols, num_cols = S->ck->num_cols, nvr = S->nvr;
+  std::vector<fe_t> L(num_rows);
+  eq_table_host(S->row_pt.data(), nvr, L.data());
+  S->r_LZ = fe_zero();
+  for (size_t i = 0; i < num_rows; ++i) S->r_LZ = fe_add<spk::SF>(S->r_LZ, fe_mul<spk::SF>(L[i], S->blind[i]));
+  const size_t splits = num_rows < 64 ? num_rows : 64;
+  fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, num_rows * sizeof(fe_t), 1);
+  fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
+  fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, (num_cols + 1) * sizeof(fe_t), 1);
+  if (!dL || !part || !dout || nvr > 10) {
+    S->failed = true;
+    return;
+  }
+  spk::EqTensorArgs a;
+  const size_t hb = nvr / 2, lb = nvr - hb;
+  eq_table_host(S->row_pt.data(), hb, a.left);
+  eq_table_host(S->row_pt.data() + hb, lb, a.right);
+  a.lo_bits = (int)lb;
+  a.n = (unsigned)num_rows;
+  hipStream_t st = c->stream2;
+  hipLaunchKernelGGL(spk::k_eq_tensor<false>, dim3((unsigned)((num_rows + 255) / 256)), dim3(256), 0, st, a, dL);
+  if (cols < num_cols && hipMemsetAsync(dout + cols, 0, (num_cols - cols) * sizeof(fe_t), st) != hipSuccess) {
+    S->failed = true;
+    return;
+  }
+  c->timed_on(st, "rowmat_vec", 32ull * (num_rows * cols + num_rows + cols), [&] { launch_rowmat_vec(st, S->poly->d, num_rows, cols, dL, part, splits, dout); });
+  if (multi_mul_launch(c, 1, S->ck->d_keytables, nullptr, num_cols + 1, &S->seq_lz, dout, &S->r_LZ, 0) ||
+      hipMemcpyAsync(c->h_pcs, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(c->pcs_ev, st) != hipSuccess) {
+    S->failed = true;  // (a launched walk is still drained by pcs_ahead_drain: lz_launched stays false only if the launch itself failed)
+    return;
+  }
+  S->lz_launched = true;
+}
+}  // namespace sp
+
+extern "C" int sp_hyrax_prove_retract(sp_ctx* c) {
+  if (!c) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_hyrax_prove_retract: null context");
+  sp::pcs_ahead_free(c);
+  return SP_OK;
+}
+extern "C" int sp_hyrax_prove_announce(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds,
+                                       const uint8_t* rng, size_t rng_blocks) {
+  if (!c || !ck || !comm_rows_aff || !poly || !blinds || !rng) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_hyrax_prove_announce: null argument");
+  sp::pcs_ahead_free(c);  // at most one announcement per context; an unconsumed one is dropped
+  size_t npt = 0;
+  while (((size_t)1 << npt) < n) ++npt;
+  const size_t num_cols = ck->num_cols, num_rows = (n + num_cols - 1) / num_cols;
+  if (n != ((size_t)1 << npt) || n > poly->cap || rows != num_rows || (num_rows & (num_rows - 1)) || num_rows < 2) return SP_OK;  // nothing to start ahead: the plain call decides
+  size_t nvr = 0;
+  while (((size_t)1 << nvr) < num_rows) ++nvr;
+  const size_t cols = n / num_rows;
+  if (rng_blocks < cols + 2 || nvr > 10) return SP_OK;
+  SP_HIP(hipSetDevice(c->device));
+  if (sp::ck_key_tables(c, ck) != 0) return SP_OK;  // no window tables of the key: the bucket MSMs have nothing to gain from an early start of this kind
+  const bool delta_raw = num_cols + 1 >= sp::multi_mul_wide_min() && 64 * num_cols <= 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
+  if (!delta_raw) return SP_OK;
+  if (!c->pcs_ev) SP_HIP(hipEventCreateWithFlags(&c->pcs_ev, hipEventDisableTiming));
+  if (c->h_pcs_bytes < cols * sizeof(fe_t)) {
+    if (c->h_pcs) hipHostFree(c->h_pcs);
+    c->h_pcs = nullptr;
+    c->h_pcs_bytes = 0;
+    SP_HIP(hipHostMalloc(&c->h_pcs, cols * sizeof(fe_t)));
+    c->h_pcs_bytes = cols * sizeof(fe_t);
+  }
+  sp_pcs_ahead* S = new sp_pcs_ahead();
+  S->ck = ck;
+  S->poly = poly;
+  S->n = n, S->npt = npt, S->nvr = nvr, S->cols = cols, S->num_rows = num_rows;
+  S->comm.assign(reinterpret_cast<const aff_t*>(comm_rows_aff), reinterpret_cast<const aff_t*>(comm_rows_aff) + rows);
+  S->blind.assign(reinterpret_cast<const fe_t*>(blinds), reinterpret_cast<const fe_t*>(blinds) + rows);
+  S->rng.assign(rng, rng + 64 * (cols + 2));
+  S->row_pt.resize(nvr);
+  S->hb = (npt - nvr) / 2;
+  S->col_pt.resize(S->hb ? S->hb : 1);
+  S->dvec.resize(cols);
+  S->r_delta = fe_from_uniform<spk::SF>(S->rng.data() + 64 * cols);
+  c->pcs_ahead = S;
+  // helper thread: the commitment's transcript bytes into a fresh sponge, then the mask vector's wide reductions
+  if (!c->pcs_worker) c->pcs_worker = new sp::Worker();
+  S->worker_busy = true;
+  c->pcs_worker->submit([S, c, num_cols] {
+    // delta = <d, ck> + r_delta h first: its walk (auxiliary stream) reduces the randomness blocks itself
+    if (hipSetDevice(c->device) != hipSuccess ||
+        sp::multi_mul_launch(c, 1, S->ck->d_keytables, reinterpret_cast<const uint64_t*>(S->rng.data()), num_cols + 1, &S->seq_delta, nullptr, &S->r_delta, S->cols))
+      S->failed = true;
+    else
+      S->delta_launched = true;
+    static const char* b = "poly_commitment_begin";  // HyraxCommitment::to_transcript_bytes (hyrax_pc.rs:714-729)
+    static const char* e = "poly_commitment_end";
+    S->hashed.init();
+    S->hashed.update(reinterpret_cast<const uint8_t*>("poly_com"), 8);
+    S->hashed.update(reinterpret_cast<const uint8_t*>(b), strlen(b));
+    uint8_t buf[64 * 16];
+    for (size_t i = 0; i < S->comm.size(); i += 16) {
+      const size_t m = S->comm.size() - i < 16 ? S->comm.size() - i : 16;
+      for (size_t k = 0; k < m; ++k) hp_point_bytes(S->comm[i + k], buf + 64 * k);
+      S->hashed.update(buf, 64 * m);
+    }
+    S->hashed.update(reinterpret_cast<const uint8_t*>(e), strlen(e));
+    for (size_t i = 0; i < S->cols; ++i) S->dvec[i] = fe_from_uniform<spk::SF>(S->rng.data() + 64 * i);
+  });
+  return SP_OK;
+}
+extern "C" {
+
 int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcript* tr, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n,
                    const uint64_t* blinds, const uint64_t* point, size_t npt, const uint64_t comm_eval_aff[8], const uint64_t blind_eval[4], const uint8_t* rng,
                    size_t rng_blocks, uint64_t* out) {
@@ -1395,11 +1586,42 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   aff_t comm_eval;
   memcpy(&comm_eval, comm_eval_aff, sizeof(aff_t));
 
+  // (0) was this opening announced (sp_hyrax_prove_announce)? Then its commitment hashing, mask vector, delta and — if the inner sum-check reported the row
+  // challenges — L^T W and comm_LZ are done or under way; anything that differs from what was announced drops the announcement.
+  sp_pcs_ahead* S = c->pcs_ahead;
+  bool ahead = S && !S->failed && S->ck == ck && S->poly == poly && S->n == n && S->comm.size() == rows && memcmp(S->comm.data(), comm, rows * sizeof(aff_t)) == 0 &&
+               memcmp(S->blind.data(), blind, rows * sizeof(fe_t)) == 0 && memcmp(S->rng.data(), rng, 64 * (cols + 2)) == 0;
+  if (S && !ahead) {
+    sp::pcs_ahead_free(c);
+    S = nullptr;
+  }
+  struct AheadDone {  // consumed or not, the announcement ends with this call
+    sp_ctx* c;
+    ~AheadDone() { sp::pcs_ahead_free(c); }
+  } ahead_done{c};
   // (1) helper thread: transcript.absorb(b"poly_com", comm) (hyrax_pc.rs:410) into a copy of the running hasher, installed at the join below
   tr->join();
   if (!c->pcs_worker) c->pcs_worker = new sp::Worker();
   sp::Keccak256State hashed = tr->t.h;
-  {
+  bool hashed_ahead = false;
+  if (ahead) {  // the announced hashing started from a fresh sponge: usable exactly when nothing has been absorbed since the last squeeze
+    c->pcs_worker->wait();
+    S->worker_busy = false;
+    if (S->failed || !S->delta_launched) {  // the helper could not launch delta's walk: as if nothing had been announced
+      sp::pcs_ahead_free(c);
+      S = nullptr;
+      ahead = false;
+    }
+  }
+  if (ahead) {
+    bool fresh = tr->t.h.fill == 0;
+    for (int i = 0; i < 25 && fresh; ++i) fresh = tr->t.h.a[i] == 0;
+    if (fresh) {
+      hashed = S->hashed;
+      hashed_ahead = true;
+    }
+  }
+  if (!hashed_ahead) {
     sp::Keccak256State* hp = &hashed;
     c->pcs_worker->submit([hp, comm, rows] {
       static const char* b = "poly_commitment_begin";  // HyraxCommitment::to_transcript_bytes (hyrax_pc.rs:714-729)
@@ -1445,15 +1667,32 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   int rc;
   // delta = <d, ck> + r_delta h first: it needs nothing but the randomness stream, whose blocks the kernel reduces itself
   const bool delta_raw = walk && num_cols + 1 >= sp::multi_mul_wide_min() && 64 * num_cols <= 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
-  if (delta_raw && (rc = sp::multi_mul_launch(c, 1, ck->d_keytables, reinterpret_cast<const uint64_t*>(rng), num_cols + 1, &seq_delta, nullptr, &r_delta, cols))) return rc;
+  if (ahead && !walk) {  // (cannot happen: the announcement needs the key's window tables)
+    sp::pcs_ahead_free(c);
+    S = nullptr;
+    ahead = false;
+  }
+  if (ahead) seq_delta = S->seq_delta;
+  else if (delta_raw && (rc = sp::multi_mul_launch(c, 1, ck->d_keytables, reinterpret_cast<const uint64_t*>(rng), num_cols + 1, &seq_delta, nullptr, &r_delta, cols))) return rc;
   lap("delta launch");
   std::vector<fe_t> L((size_t)1 << nvr);
   eq_table_host(pt, nvr, L.data());
+  bool lz_ahead = false;
   if (nvr == 0) {  // a single row: the commitment is the row itself (hyrax_pc.rs:417-423)
     comm_LZ = comm[0];
     if ((rc = sp_table_read(c, poly, 0, n, reinterpret_cast<uint64_t*>(LZ.data())))) return rc;
     r_LZ = blind[0];
+  } else if (ahead && S->lz_launched && memcmp(S->row_pt.data(), pt, nvr * sizeof(fe_t)) == 0) {
+    lz_ahead = true;  // L^T W and comm_LZ's walk have been running on the auxiliary stream since the inner sum-check drew the row challenges
+    r_LZ = S->r_LZ;
+    seq_lz = S->seq_lz;
   } else {
+    if (ahead && S->lz_launched) {  // started for other row challenges than the point given now: drain it, its lane is needed
+      jac_t sink;
+      (void)sp::multi_mul_collect(c, 1, S->seq_lz, &sink, false);
+      (void)sp::event_sync(c->pcs_ev);
+      S->lz_launched = false;
+    }
     r_LZ = fe_zero();
     for (size_t i = 0; i < num_rows; ++i) r_LZ = fe_add<SF>(r_LZ, fe_mul<SF>(L[i], blind[i]));
     if (walk) {
@@ -1492,10 +1731,12 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   }
   lap("LZ + comm_LZ launch");
   // d_vec: 2048 wide reductions at config 2, ~65 us of host work beside the device's (delta's walk reduces its own copy of the blocks)
-  for (size_t i = 0; i < cols; ++i) dvec[i] = fe_from_uniform<SF>(rng + 64 * i);
+  if (ahead) dvec = S->dvec;  // drawn by the announcement's helper job
+  else
+    for (size_t i = 0; i < cols; ++i) dvec[i] = fe_from_uniform<SF>(rng + 64 * i);
   lap("d_vec draw");
   if (!walk && (rc = sp_msm_ck_begin(c, ck, reinterpret_cast<const uint64_t*>(dvec.data()), cols, &delta_job))) return rc;
-  if (walk && !delta_raw) {  // narrow keys: the walk from the drawn scalars
+  if (walk && !delta_raw && !ahead) {  // narrow keys: the walk from the drawn scalars
     std::vector<fe_t> sc(num_cols + 1, fe_zero());
     memcpy(sc.data(), dvec.data(), cols * sizeof(fe_t));
     sc[num_cols] = r_delta;
@@ -1503,7 +1744,12 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   }
   // (3) host work under the device's: <R, d> with R = eq(point[nvr..]) = left (x) right (ipa.rs:148), beta = ck_c * <R, d> + h_c * r_beta (:149)
   fe_t ip = fe_zero();
-  {
+  if (ahead && S->T_ready && S->hb == (npt - nvr) / 2 && memcmp(S->col_pt.data(), pt + nvr, S->hb * sizeof(fe_t)) == 0) {
+    const size_t k = npt - nvr;
+    std::vector<fe_t> right((size_t)1 << (k - S->hb));
+    eq_table_host(pt + nvr + S->hb, k - S->hb, right.data());
+    for (size_t b2 = 0; b2 < right.size(); ++b2) ip = fe_add<SF>(ip, fe_mul<SF>(right[b2], S->T[b2]));
+  } else {
     const size_t k = npt - nvr, hb = k / 2;
     std::vector<fe_t> left((size_t)1 << hb), right((size_t)1 << (k - hb));
     eq_table_host(pt + nvr, hb, left.data());
@@ -1521,11 +1767,17 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   // (4) joins
   if (walk) {
     jac_t dj;
-    if ((rc = sp::multi_mul_collect(c, 1, seq_delta, &dj, false))) return rc;
+    if (ahead && S->delta_collected) {
+      dj = S->delta_j;
+    } else {
+      if ((rc = sp::multi_mul_collect(c, 1, seq_delta, &dj, false))) return rc;
+      if (ahead) S->delta_collected = true;
+    }
     delta = jac_to_affine(dj);
     if (nvr != 0) {
       jac_t lj;
-      if ((rc = sp::multi_mul_collect(c, 0, seq_lz, &lj, false))) return rc;
+      if ((rc = sp::multi_mul_collect(c, lz_ahead ? 1 : 0, seq_lz, &lj, false))) return rc;
+      if (lz_ahead) S->lz_launched = false;
       comm_LZ = jac_to_affine(lj);
       SP_HIP(sp::event_sync(c->pcs_ev));
       memcpy(LZ.data(), c->h_pcs, cols * sizeof(fe_t));
@@ -1538,7 +1790,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     if ((rc = sp_msm_ck_finish(c, ck, j, reinterpret_cast<const uint64_t*>(&r_delta), reinterpret_cast<uint64_t*>(&delta)))) return rc;
   }
   lap("join walks");
-  c->pcs_worker->wait();
+  if (!hashed_ahead) c->pcs_worker->wait();
   join.joined = true;
   lap("join hashing");
   tr->t.h = hashed;

@@ -29,6 +29,10 @@ void relax();
 // hipStreamSynchronize / hipEventSynchronize for library code: on a thread with a wait hook they poll (hipStreamQuery / hipEventQuery) through relax()
 // instead of blocking — a blocked thread could not serve the other proofs it carries, and one of those may own a kernel that sits in front of this
 // stream's work in a shared hardware queue while it waits for its host's next challenge
+// capi_group.hip: called by sp_sumcheck_quad after the challenge of `round` has gone to the device, when the context holds an announced opening
+void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]);
+void pcs_ahead_free(sp_ctx* c);
+bool pcs_ahead_wants(const sp_ctx* c, size_t rounds);  // is an opening announced whose point a sum-check of this many rounds draws?
 hipError_t stream_sync(hipStream_t s);
 hipError_t event_sync(hipEvent_t e);
 
@@ -157,6 +161,8 @@ struct sp_ctx {
   size_t h_pcs_bytes = 0;
   hipEvent_t pcs_ev = nullptr;
   sp::Worker* pcs_worker = nullptr;
+  // an opening announced ahead of PCS::prove (sp_hyrax_prove_announce, capi_group.hip): the inner sum-check's round loop reports its challenges to it
+  struct sp_pcs_ahead* pcs_ahead = nullptr;
   void* h_pinned_lane[2] = {nullptr, nullptr};  // pinned landing buffers for per-window MSM sums (one per stream), 8 KiB each
   size_t pinned_elems = 0;
   bool timing = false;

@@ -437,6 +437,17 @@ class CommitmentKey:
                                    p64(out)))
         return out
 
+    def prove_announce(self, comm_rows, poly, n, blinds, rng):
+        """sp_hyrax_prove_announce: the opening that the next prove() on this context will be asked for (its delta / hashing / mask vector start now)."""
+        comm_rows = np.ascontiguousarray(comm_rows, dtype=np.uint64).reshape(-1, 8)
+        rows = comm_rows.shape[0]
+        rng = np.ascontiguousarray(rng, dtype=np.uint8).reshape(-1, 64)
+        check(lib().sp_hyrax_prove_announce(self.ctx.h, self.h, p64(comm_rows), ctypes.c_size_t(rows), poly.h, ctypes.c_size_t(n),
+                                            p64(np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)), p8(rng), ctypes.c_size_t(rng.shape[0])))
+
+    def prove_retract(self):
+        check(lib().sp_hyrax_prove_retract(self.ctx.h))
+
     def rerandomize(self, comm_rows, r_old, r_new):
         """PCS::rerandomize_commitment (hyrax_pc.rs:321-344)."""
         comm_rows = np.ascontiguousarray(comm_rows, dtype=np.uint64).reshape(-1, 8)

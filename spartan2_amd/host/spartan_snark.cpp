@@ -874,6 +874,19 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
   }
   std::vector<fe_t> r_W = ps.r_W_fixed;  // combine_blinds (r1cs.rs:515-524)
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
+  // The shim's r1cs_instance_and_witness wrapper ends by announcing the opening PCS::prove will be asked for (sp_hyrax_prove_announce): commitment, blinds
+  // and the IPA's randomness exist here — the reference draws that randomness inside InnerProductArgumentLinear::prove from OsRng; with the injected
+  // tape it is the cols + 2 blocks behind blind_eval_W's one — and the library starts the opening's transcript-independent parts under the sum-checks.
+  struct Announced {  // an error exit must not leave the announcement (it points at ps.W) on the context
+    sp_ctx* ctx;
+    bool done = false;
+    ~Announced() {
+      if (!done) (void)sp_hyrax_prove_retract(ctx);
+    }
+  } announced{ctx};
+  if (tape.pos + 1 < tape.blocks)
+    ck(sp_hyrax_prove_announce(ctx, pk.ck, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), tape.bytes + 64 * (tape.pos + 1), tape.blocks - tape.pos - 1),
+       "PCS::prove (announce)");
   const double t_wit = now_ms();
   // :246-253 z = [W | 1 | public | challenges]
   ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
@@ -946,6 +959,7 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
   ck(sp_hyrax_prove(ctx, pk.ck, pk.ck_s, tr.t, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), u64p(r_y.data() + 1), num_rounds_y - 1, u64p(&comm_eval_W.x),
                     u64p(&blind_eval_W), tape.bytes + 64 * tape.pos, tape.blocks - tape.pos, arg.data()),
      "PCS::prove");
+  announced.done = true;  // consumed
   tape.skip(cols + 2);
   proof.words.insert(proof.words.end(), arg.begin(), arg.end());
   const double t_end = now_ms();

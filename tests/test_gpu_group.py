@@ -228,6 +228,62 @@ def test_hyrax_prove_is_the_oracles_pcs_prove(ctx, key, gens, npt, key_tables, m
     olib().orc_hyrax_free(okey_s)
 
 
+@pytest.mark.parametrize("case", ["match_fresh", "match_warm", "other_blinds", "other_rng", "other_table", "retracted", "replaced", "no_key_tables"])
+def test_hyrax_prove_announced_ahead_is_the_same_opening(ctx, key, gens, case, monkeypatch):
+    """sp_hyrax_prove_announce changes WHEN the opening's first half is computed, never a word of it: an announcement that matches is consumed (fresh
+    transcript: the commitment's hashing too; warm one: delta and the mask vector only), one that differs in blinds / randomness / table is dropped,
+    a retracted or replaced one leaves nothing behind, and a key without window tables ignores it. Every case equals the unannounced sp_hyrax_prove,
+    which test_hyrax_prove_is_the_oracles_pcs_prove pins to the oracle."""
+    if case == "no_key_tables":
+        monkeypatch.setenv("SPARTAN_KEY_TABLES", "0")
+    npt = 14
+    rng = np.random.default_rng(SEED + 950)
+    n = 1 << npt
+    rows = n // 2048
+    cols = n // rows
+    poly = ol.random_field_array(rng, n)
+    blinds = ol.random_field_array(rng, rows)
+    point = ol.random_field_array(rng, npt)
+    g_s = np.zeros((2, 8), dtype=np.uint64)
+    olib().orc_from_label(b"ck_s", ctypes.c_size_t(2), p64(g_s))
+    key_s = hip.CommitmentKey(ctx, g_s[:1], g_s[1])
+    table = hip.Table.from_host(ctx, poly)
+    comm = key.commit(table, 0, n, blinds, is_small=False)
+    ev, b_ev = ol.random_field_array(rng, 1), ol.random_field_array(rng, 1)
+    comm_eval = key_s.msm(ev, b_ev[0])
+    tape = ol.make_tape(SEED + 77, cols + 2)
+
+    def prove(warm):
+        tr = hip.Transcript(ctx, b"pcs")
+        if warm:
+            tr.absorb(b"x", b"warm")
+        out = key.prove(key_s, tr, comm, table, n, blinds, point, comm_eval, b_ev, tape)
+        return out, tr.squeeze(b"n")
+
+    warm = case == "match_warm"
+    want, want_next = prove(warm)
+    other = hip.Table.from_host(ctx, ol.random_field_array(rng, n))
+    if case == "other_blinds":
+        key.prove_announce(comm, table, n, ol.random_field_array(rng, rows), tape)
+    elif case == "other_rng":
+        key.prove_announce(comm, table, n, blinds, ol.make_tape(SEED + 78, cols + 2))
+    elif case == "other_table":
+        key.prove_announce(comm, other, n, blinds, tape)
+    elif case == "replaced":
+        key.prove_announce(comm, other, n, blinds, tape)
+        key.prove_announce(comm, table, n, blinds, tape)
+    else:
+        key.prove_announce(comm, table, n, blinds, tape)
+    if case == "retracted":
+        key.prove_retract()
+        key.prove_retract()  # nothing announced: a no-op
+    got, got_next = prove(warm)
+    assert (got == want).all() and (got_next == want_next).all()
+    # the announcement was consumed or dropped: the next opening on the context is again the plain one
+    again, again_next = prove(warm)
+    assert (again == want).all() and (again_next == want_next).all()
+
+
 def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):
     rng = np.random.default_rng(SEED + 400)
     sc = ol.random_field_array(rng, 2048)
