@@ -648,7 +648,7 @@ def main():
         # HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024); null if absent
         traffic, traffic_src = None, None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.message_bytes == 2048:
                 with open(pmc) as f:
@@ -657,6 +657,22 @@ def main():
                 if keys:
                     traffic, traffic_src = tj[keys[0]]["traffic_bytes"], f"profiles/{name} (separate rocprofv3 --pmc passes of this command)"
                     break
+        # rocprofv3 kernel-only durations of the same call sites, committed under profiles/ (tools/r04_profile_job.sh): inside a prove and with the GPU
+        # otherwise empty. The HIP-event figures below are taken inside a prove, where the auxiliary streams' kernels are resident beside these.
+        rocprof_sites = None
+        sites_path = os.path.join(ROOT, "profiles", "r04_kernel_sites.json")
+        if os.path.exists(sites_path) and args.message_bytes == 2048:
+            with open(sites_path) as f:
+                sj = json.load(f)
+            pick = {"poly_abc": "k_polyabc_short_and_long", "rowmat_vec": "k_rowmat_vec_tall", "eval_quad": "k_eval_quad_stream_lowhi<4>", "eval_cubic": "k_eval_products_stream<1>",
+                    "bind_stream_quad": "k_bind_eval_quad_stream@", "bind_stream_quad_sparse": "k_bind_eval_quad_stream_sparse", "spmv_incremental": "k_spmv3"}
+            rocprof_sites = {}
+            for cls, sub in pick.items():
+                ks = [k for k in sj if k.startswith(sub)]
+                if ks:
+                    v = sj[ks[0]]
+                    rocprof_sites[cls] = {"site": ks[0], "in_prove_us": v["in_prove_median_us"], "alone_us": v["solo_median_us"], "others_resident_frac": v["others_resident_frac"],
+                                          "alone_GBps": (v["alg_bytes"] / v["solo_median_us"] / 1e3) if v["alg_bytes"] and v["solo_median_us"] else None}
         si = snark.shape_info
         gbps = lambda k: (kstats[k][2] / max(kstats[k][0], 1e-9)) / 1e6  # algorithmic bytes / event-timed ms -> GB/s
         out = {
@@ -690,7 +706,11 @@ def main():
                          "other_kernels": {k: {"launches_per_step": kstats[k][1] / nb, "avg_us": kstats[k][0] / max(kstats[k][1], 1) * 1e3, "alg_GBps": gbps(k)}
                                            for k in ("bind_stream_quad", "bind_stream_quad_sparse", "bind", "eval_cubic", "eval_quad", "spmv_incremental", "poly_abc",
                                                      "rowmat_vec") if kstats[k][1]},
-                         "other_kernels_note": "HIP-event times of an instrumented pass. The 'bind' class (fused bind + evaluate launches on tables <= 2^19 elements) is launched AHEAD of "
+                         "other_kernels_rocprof": rocprof_sites,
+                         "other_kernels_note": "avg_us are HIP-event times of an instrumented pass INSIDE a prove: kernels of the auxiliary streams (delta's MSM, the PCS table "
+                                               "walks, the resident sum-check tail) are resident beside them, so they are upper bounds of the kernel's own time; "
+                                               "other_kernels_rocprof (profiles/r04_kernel_stats.md) gives the rocprofv3 kernel-only duration of the same call site inside a prove "
+                                               "and alone. The 'bind' class (fused bind + evaluate launches on tables <= 2^19 elements) is launched AHEAD of "
                                                "its challenge and waits for it at the mailbox: its avg_us includes that wait, so its GB/s understate the kernel; the streaming "
                                                "classes and the roofline kernel (tables >= 2^20) are launched behind their challenge and their times are the kernels' alone."},
             "roofline_hbm": hbm,

@@ -170,6 +170,17 @@ impl HipCommitmentKey {
     check(unsafe { sp_hyrax_commit_incremental(ctx(), self.k, raw_rows.as_ptr(), raw_rows.len() / 8, delta.t, off, n, limbs(blinds), out.as_mut_ptr()) })?;
     Ok(out)
   }
+  /// Announces the opening that PCS::prove will be asked for at the end of SpartanSNARK::prove (src/spartan.rs:425-435). Called by the shim's
+  /// `r1cs_instance_and_witness` wrapper once comm_W and its (combined) blinds exist (:238-245), with the 64-byte randomness blocks that the shim's
+  /// OsRng draw will later hand to `hyrax_prove` (cols + 2 of them, ipa.rs:139-149, drawn here instead of there: the draws are independent of
+  /// everything else). The library then works on the opening under the two sum-checks; `hyrax_prove` finds it by comparing its arguments.
+  /// An `Err` exit of prove between the two calls goes through `retract_opening` (a drop guard in the wrapper).
+  pub fn announce_opening<F>(&self, comm_rows: &[u64], poly: &HipTable<F>, n: usize, blinds: &[F], rng: &[u8]) -> Result<(), SpartanError> {
+    check(unsafe { sp_hyrax_prove_announce(ctx(), self.k, comm_rows.as_ptr(), comm_rows.len() / 8, poly.t, n, limbs(blinds), rng.as_ptr(), rng.len() / 64) })
+  }
+  pub fn retract_opening() -> Result<(), SpartanError> {
+    check(unsafe { sp_hyrax_prove_retract(ctx()) })
+  }
 }
 impl Drop for HipCommitmentKey {
   fn drop(&mut self) {

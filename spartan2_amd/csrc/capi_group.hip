@@ -941,7 +941,8 @@ int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_a
 // bind_with_delayed (hyrax_pc.rs:38-54) on `st`: the one-launch streaming kernel for tall matrices, else the two-stage form
 static void launch_rowmat_vec(hipStream_t st, const fe_t* poly, size_t rows, size_t cols, const fe_t* dL, fe_t* part, size_t splits, fe_t* dout) {
   if (rows >= 128 && cols % spk::RMV_COLS == 0) {
-    hipLaunchKernelGGL(spk::k_rowmat_vec_tall, dim3((unsigned)(cols / spk::RMV_COLS)), dim3(1024), 0, st, poly, rows, cols, dL, dout);
+    const size_t l_bytes = rows <= (size_t)spk::RMV_L_MAX ? rows * sizeof(fe_t) : 0;
+    hipLaunchKernelGGL(spk::k_rowmat_vec_tall, dim3((unsigned)(cols / spk::RMV_COLS)), dim3(spk::RMV_THREADS), l_bytes, st, poly, rows, cols, dL, dout);
     return;
   }
   hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly, rows, cols, dL, part);

@@ -1059,30 +1059,39 @@ __global__ void __launch_bounds__(256) k_rowmat_vec(const fe_t* __restrict__ pol
   }
 }
 // Streaming form for tall matrices (rows >= 128: 512 x 2048 at BASELINE config 2, a pure 32 MiB read — hyrax_pc.rs:38-54): ONE launch, no partials.
-// A block of 1024 threads owns RMV_COLS = 8 adjacent columns: lane = (row-lane 0..7, column 0..7), so a wave reads eight 256-byte row segments per pass
-// and the 16 waves cover 128 rows; every lane keeps a modular sum of its rows' products, the eight row-lanes of a wave and then the sixteen waves are
-// combined as lazy 9-word sums (shuffles, LDS) with one reduction per column. cols / 8 blocks (256 at config 2: one per CU, all rows in flight at once).
+// A block of 512 threads owns RMV_COLS = 8 adjacent columns: lane = (row-lane 0..7, column 0..7), so a wave reads eight 256-byte row segments per pass
+// and the 8 waves cover 64 rows; L sits in LDS (a row's weight is read right before its product instead of being held), every lane keeps a modular sum
+// of its rows' products, the eight row-lanes of a wave and then the eight waves are combined as lazy 9-word sums (shuffles, LDS) with one reduction per
+// column. cols / 8 blocks (256 at config 2: one per CU). 512 threads and not 1024: at 128 VGPRs the four loads in flight + the product's temporaries
+// spilled 31 registers (104 B of scratch per lane = 26 MB of writes for a 33 MB read: PMC WRITE_SIZE of profiles/r04_kernel_stats.md).
 constexpr int RMV_COLS = 8;
-__global__ void __launch_bounds__(1024) k_rowmat_vec_tall(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L, fe_t* __restrict__ out) {
-  __shared__ lazy9_t sm[16][RMV_COLS];
+constexpr int RMV_THREADS = 512;
+constexpr int RMV_ROWS_PER_PASS = RMV_THREADS / RMV_COLS;  // 64
+constexpr int RMV_L_MAX = 1024;                            // rows whose weights fit the block's LDS copy (32 KiB); taller matrices read L from memory
+__global__ void __launch_bounds__(RMV_THREADS) k_rowmat_vec_tall(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L, fe_t* __restrict__ out) {
+  __shared__ lazy9_t sm[RMV_THREADS / 64][RMV_COLS];
+  extern __shared__ fe_t sL[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & (RMV_COLS - 1), rl = lane >> 3;
   const size_t col = (size_t)blockIdx.x * RMV_COLS + c;
+  const bool l_in_lds = rows <= (size_t)RMV_L_MAX;
+  if (l_in_lds) {
+    for (size_t r = threadIdx.x; r < rows; r += RMV_THREADS) sL[r] = L[r];
+    __syncthreads();
+  }
+  const fe_t* Lp = l_in_lds ? sL : L;
   fe_t acc = fe_zero();
   if (col < cols) {
-    // four loads in flight per lane (the 512 rows of config 2 are exactly one such group), two independent accumulation chains
-    fe_t acc2 = fe_zero();
+    constexpr size_t P = RMV_ROWS_PER_PASS;
     size_t r = (size_t)wave * 8 + rl;
-    for (; r + 384 < rows; r += 512) {
-      const fe_t a0 = poly[r * cols + col], a1 = poly[(r + 128) * cols + col], a2 = poly[(r + 256) * cols + col], a3 = poly[(r + 384) * cols + col];
-      const fe_t l0 = L[r], l1 = L[r + 128], l2 = L[r + 256], l3 = L[r + 384];
-      acc = fe_add<SF>(acc, fe_mul<SF>(l0, a0));
-      acc2 = fe_add<SF>(acc2, fe_mul<SF>(l1, a1));
-      acc = fe_add<SF>(acc, fe_mul<SF>(l2, a2));
-      acc2 = fe_add<SF>(acc2, fe_mul<SF>(l3, a3));
+    for (; r + 3 * P < rows; r += 4 * P) {  // four loads in flight per lane
+      const fe_t a0 = poly[r * cols + col], a1 = poly[(r + P) * cols + col], a2 = poly[(r + 2 * P) * cols + col], a3 = poly[(r + 3 * P) * cols + col];
+      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r], a0));
+      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r + P], a1));
+      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r + 2 * P], a2));
+      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r + 3 * P], a3));
     }
-    for (; r < rows; r += 128) acc = fe_add<SF>(acc, fe_mul<SF>(L[r], poly[r * cols + col]));
-    acc = fe_add<SF>(acc, acc2);
+    for (; r < rows; r += P) acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r], poly[r * cols + col]));
   }
   lazy9_t t = lazy_from(acc);
 #pragma unroll
@@ -1097,7 +1106,7 @@ __global__ void __launch_bounds__(1024) k_rowmat_vec_tall(const fe_t* __restrict
   if (threadIdx.x < RMV_COLS && col < cols) {
     lazy9_t s = sm[0][threadIdx.x];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) s = lazy_add(s, sm[w][threadIdx.x]);
+    for (int w = 1; w < RMV_THREADS / 64; ++w) s = lazy_add(s, sm[w][threadIdx.x]);
     out[col] = lazy_reduce(s);
   }
 }

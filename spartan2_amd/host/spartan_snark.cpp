@@ -414,7 +414,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     // tables of the fixed rows + h: usable when every other row of comm_W is h * blind (commit_zeros)
     const sp_fbtables* tabs = lz_tables_path ? ps.lz_tables : nullptr;
     const size_t nfixed = ps.comm_W_fixed.size();
-    ps.bg.submit([ctx, rows, nrows, psp, blinds, lzp, key, cols, tabs, nfixed] {
+    const fe_t* dv = dvec.data();
+    const size_t dn = n_ipa;
+    ps.bg.submit([ctx, rows, nrows, psp, blinds, lzp, key, cols, tabs, nfixed, dv, dn] {
       const std::vector<uint8_t> b = commitment_bytes(rows, nrows);
       ck(sp_transcript_preabsorb((const uint8_t*)"poly_com", 8, b.data(), b.size(), &psp->poly_com), "poly_com (prepare)");
       if (!lzp) return;
@@ -435,10 +437,16 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
         }
         return st;
       };
-      // delta (ipa.rs:147): its MSM was issued before the inner sum-check; the window Horner and h * r_delta run here
+      // delta (ipa.rs:147): issued from here once the outer sum-check has left its streaming rounds (the owner publishes delta_state from its
+      // challenge observer): the MSM then runs under the resident tail kernel, which leaves the device idle, instead of beside the first rounds
+      // of the inner sum-check (measured there: k_eval_quad_stream_lowhi 32 us against 18 us alone, profiles/r04_kernel_stats.md)
       if (wait_for(lzp->delta_state) != 1) return;
-      ck(sp_msm_ck_finish(ctx, key, lzp->delta_job, u64p(&lzp->r_delta), u64p(&lzp->delta.x)), "delta (finish)");
-      lzp->delta_job = nullptr;
+      ck(sp_msm_ck_begin(ctx, key, u64p(dv), dn, &lzp->delta_job), "delta (begin)");
+      {
+        sp_msm_job* j = lzp->delta_job;
+        lzp->delta_job = nullptr;  // finish() consumes the job whatever it returns
+        ck(sp_msm_ck_finish(ctx, key, j, u64p(&lzp->r_delta), u64p(&lzp->delta.x)), "delta (finish)");
+      }
       lzp->delta_done = true;
       lzp->early_done.store(1, std::memory_order_release);
       if (wait_for(lzp->state) != 1) return;
@@ -523,10 +531,12 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     sp_ctx* ctx;
     size_t ell;
     fe_t r[24];
+    LzAhead* lz;  // non-null: delta's MSM is the helper's to issue (see there)
     int rc = 0;
     bool begun = false;
     static void fn(void* u, size_t round, const uint64_t r[4]) {
       EqObs* o = (EqObs*)u;
+      if (o->lz && round + 15 == o->ell) o->lz->publish(o->lz->delta_state, 1);  // tables of 2^14 from here on: the rounds of the resident kernel
       if (round + 2 >= o->ell) return;  // the last two coordinates are applied by sp_eq_table_finish
       memcpy(&o->r[round], r, 32);
       if (round + 3 == o->ell) {
@@ -534,7 +544,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
         o->begun = o->rc == 0;
       }
     }
-  } eq_obs{ctx, num_rounds_x};
+  } eq_obs{ctx, num_rounds_x, {}, lz_ahead ? &lz : nullptr};
   const bool use_eq_obs = num_rounds_x >= 12 && num_rounds_x <= 20;
   if (use_eq_obs)
     ck(sp_sumcheck_cubic3_observed(ctx, u64p(&zero), u64p(tau.data()), num_rounds_x, ps.az, ps.bz, ps.cz, ps.p0, ps.p0 ? ps.p1 : nullptr, tr.t, &EqObs::fn, &eq_obs,
@@ -549,6 +559,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
                           u64p(claims_outer)),
        "outer sum-check");
   if (eq_obs.rc) throw Error(eq_obs.rc, std::string("evals_rx (begin): ") + sp_last_error());
+  if (lz_ahead) lz.publish(lz.delta_state, 1);  // (a sum-check of fewer than 15 rounds, or one without the observer, has not done it)
   tr.absorb_scalars("claims_outer", claims_outer, 3);
   for (const fe_t& f : outer_polys) proof.pf(f);
   for (int i = 0; i < 3; ++i) proof.pf(claims_outer[i]);
@@ -562,12 +573,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const double t_abc = now_ms();
 
   sp_msm_job* delta_job = nullptr;
-  ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
-  if (lz_ahead) {  // the helper finishes it (see above)
-    lz.delta_job = delta_job;
-    delta_job = nullptr;
-    lz.publish(lz.delta_state, 1);
-  }
+  if (!lz_ahead) ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
   // inner sum-check. The reference runs round 0 by hand on the compact vectors (src/spartan.rs:323-384); that round is
   // value-identical to a generic prove_quad round on the 2M-long tables with (lo_eff, hi_eff) = (M, num_extra).
   ck(sp_table_set_len(ps.abc, 2 * M, M, pk.num_extra), "abc len");
