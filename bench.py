@@ -75,12 +75,49 @@ def _c4_instance():
     return frontend.synthetic_circuit(45000, 0xDEADBEEF, num_public=8)  # N = M = 2^22, SHA-like row mix, Bernoulli(1/2) bits
 
 
-def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle):
-    """BASELINE config 4 on the ranks of this run: (1) PCS::commit of 2^22 full-width scalars, rows sharded by row; (2) one sharded prove."""
+class LegDog:
+    """One watchdog per extra leg: arm(name) before a leg, disarm() after the last. A leg that outlives its allowance ends the process - rank 0 first
+    prints the bench line it has (`line`, whose "sharded" object holds the legs that finished) with the leg marked as not finished."""
+
+    def __init__(self, rank, line, legs, seconds):
+        self.rank, self.line, self.legs, self.seconds, self.timer = rank, line, legs, seconds, None
+
+    def _expired(self, name):
+        if self.rank == 0 and self.line is not None:
+            self.legs[name] = {"error": f"did not finish within {self.seconds:.0f} s; the line is printed with the legs that did"}
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def arm(self, name):
+        import threading
+
+        self.disarm()
+        self.timer = threading.Timer(self.seconds, self._expired, args=(name,))
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
+def _leg_done(rank, name, leg):
+    if rank == 0:  # progress on stderr as each leg lands (stdout carries the one JSON line)
+        print(f"[bench] sharded.{name}: {json.dumps(leg)}", file=sys.stderr, flush=True)
+
+
+def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle, out=None, dog=None):
+    """BASELINE config 4 on the ranks of this run: (1) PCS::commit of 2^22 full-width scalars, rows sharded by row - first, before any prove-side
+    collective; (1b) one general 2^20-point MSM sharded by point range; (2) one sharded prove. `out` is filled leg by leg (a watchdog that fires in a
+    later leg still has the earlier ones); `dog` is re-armed before each."""
     from spartan2_amd import hip, host
 
     rank, world = comm.rank, comm.world
-    out = {"rccl_ranks": world, "exchange_backend": comm.backend}
+    out = {} if out is None else out
+    out.update({"rccl_ranks": world, "exchange_backend": comm.backend})
+    if dog:
+        dog.arm("c4_commit")
     # ---- (1) MSM leg: 2048 row MSMs of 2048 points, rows / world per rank, one all-gather of 64-byte rows
     g = host.from_label(b"ck", 2049)
     key = hip.CommitmentKey(ctx, g[:2048], g[2048])
@@ -105,6 +142,9 @@ def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle):
                         "ec_additions_per_s": (1 << 22) * comb_windows / dt,
                         "note": "2048 x 2048 full-width scalars over one key (hyrax_pc.rs:230-300), rows sharded by row, fixed-base comb table of the key with "
                                 f"{comb_bits}-bit signed windows: {comb_windows} mixed additions per (scalar, base) pair (the bucket form of round 1 needed ~36)"}
+    _leg_done(rank, "c4_commit", out["c4_commit"])
+    if dog:
+        dog.arm("msm_general")
     # ---- (1b) one general Pippenger MSM of 2^20 caller-supplied points (no precomputed tables), sharded by POINT RANGE: every rank runs the
     # multi-block Pippenger on its range of the device-resident operands, the affine partial sums are gathered and added
     try:
@@ -138,6 +178,9 @@ def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle):
         dev.free()
     except Exception as exc:  # the leg must not take the commit / prove numbers with it
         out["msm_general"] = {"error": repr(exc)}
+    _leg_done(rank, "msm_general", out["msm_general"])
+    if dog:
+        dog.arm("c4_prove")
     # ---- (2) one proof of the 2^22 instance over all ranks
     inst = _c4_instance()
     t0 = time.time()
@@ -168,6 +211,7 @@ def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle):
         want, _, secs = osp.prove(step_tape)
         out["c4_prove"]["bit_exact_vs_cpu_oracle"] = bool((want == words).all())
         out["c4_prove"]["cpu_oracle_ms"] = secs * 1e3
+    _leg_done(rank, "c4_prove", out["c4_prove"])
     sn.close()
     return out
 
@@ -177,7 +221,18 @@ def _scaling_vs_1(world, args, out):
     back to back). Ratios of measured figures only, no efficiency claim: the driver computes that itself from the per-N values."""
     import tempfile
 
-    path = os.path.join(tempfile.gettempdir(), f"spartan2_amd_bench_n1_{args.workload}_{args.message_bytes}.json")
+    # a directory of this user's own (0700, ownership checked), not a predictable file name in the shared temp directory
+    cache = os.path.join(tempfile.gettempdir(), f"spartan2_amd_bench_{os.getuid()}")
+    try:
+        os.makedirs(cache, mode=0o700, exist_ok=True)
+        st = os.lstat(cache)
+        import stat as _stat
+
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            return None
+    except OSError:
+        return None
+    path = os.path.join(cache, f"n1_{args.workload}_{args.message_bytes}.json")
     legs = out.get("sharded") or {}
     mine = {"value": out["value"], "ms_per_step": out["ms_per_step"],
             "msm_pairs_per_s": (legs.get("c4_commit") or {}).get("msm_pairs_per_s"), "c4_prove_ms": (legs.get("c4_prove") or {}).get("ms")}
@@ -197,18 +252,14 @@ def _scaling_vs_1(world, args, out):
 
 
 def _self_launch(n):
-    """`python bench.py --gpus N` without a launcher around it: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-    --master-addr 127.0.0.1 --master-port P bench.py <same flags>` (one rank per GPU; the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    """`python bench.py --gpus N` without a launcher around it: become `python -m torch.distributed.run --standalone --local-addr 127.0.0.1
+    --nnodes=1 --nproc-per-node N bench.py <same flags>` (one rank per GPU; the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     The reference's harness takes its thread count the same way, as a parameter of ONE binary (benches/sha256_spartan.rs:155-164,192-199)."""
-    import socket
-
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes fails without it on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+    # --standalone: the launcher's own rendezvous store binds a free port itself (nothing is picked here and released for someone else to take)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
            os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     os.execvpe(cmd[0], cmd, env)
@@ -609,37 +660,7 @@ def main():
     v_ok = v_ok and all(snark.verify(words) == 0 for _ in range(3))
     t_verify = (time.perf_counter() - t0) / 3
 
-    legs = None
-    if not args.no_sharded:
-        # The sharded legs are the one part of this run that talks RCCL from C++ across ranks. They come after everything the headline needs, under a
-        # watchdog: if a collective never returns, rank 0 prints the line without them and every rank leaves.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                ms = elapsed / args.steps * 1e3
-                ach = (bind_bytes / bind_launches) / (bind_ms / bind_launches * 1e-3) / 1e9 if bind_launches else 0.0
-                print(json.dumps({"metric": "sha256_spartan prove(): R1CS constraints/sec (prove wall-clock in ms_per_step)",
-                                  "value": spd.whole_job_throughput(inst.num_cons, args.steps, elapsed, world), "unit": "constraints/s", "n_gpus": world,
-                                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                                  "dtype": "u256 modular integer (8 x u32 Montgomery limbs; T256 scalar/base fields)", "data": "synthetic",
-                                  "config": {"workload": f"sha256_spartan {args.message_bytes} B, SpartanSNARK::prove on T256HyraxEngine shapes",
-                                             "parallelism": f"{world} independent proofs (one per GPU)"},
-                                  "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None},
-                                  "cpu_baseline": None, "sharded": {"error": f"the sharded legs did not finish within {args.extras_timeout} s; line printed without them"}}),
-                      flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(args.extras_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            comm = host.Comm(rank, world, "rccl", device=local_rank)
-            legs = sharded_legs(ctx, comm, group, 3, 2, world == 1 and not args.no_cpu_baseline)
-        except Exception as exc:
-            legs = {"error": repr(exc)}
-        dog.cancel()
-
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         ncons = inst.num_cons
@@ -723,7 +744,7 @@ def main():
             "setup_s": t_setup,
             "prep_prove_s": t_prep,
             "concurrent_proofs_extra": conc,
-            "sharded": legs,
+            "sharded": None,
             "verify_ms": t_verify * 1e3,
             "verify_accepts": v_ok,
         }
@@ -748,6 +769,22 @@ def main():
                                    "ms": secs * 1e3, "single_thread_ms": secs1 * 1e3, "gpu_proof_bit_exact_and_verified": ok}
             if not ok:
                 raise SystemExit("GPU proof differs from the oracle's or fails verification")
+    if not args.no_sharded:
+        # The sharded legs are the one part of this run that talks RCCL from C++ across ranks. They come after everything the headline needs, each
+        # under a watchdog of its own (LegDog): a leg that never returns costs only itself - rank 0 prints the line with the legs finished before it
+        # (the commit leg, the north-star's MSM figure, runs first) and every rank leaves.
+        legs = {}
+        if rank == 0:
+            out["sharded"] = legs
+        dog = LegDog(rank, out, legs, args.extras_timeout / 2)
+        try:
+            dog.arm("communicator")
+            comm = host.Comm(rank, world, "rccl", device=local_rank)
+            sharded_legs(ctx, comm, group, 3, 2, world == 1 and not args.no_cpu_baseline, out=legs, dog=dog)
+        except Exception as exc:
+            legs["error"] = repr(exc)
+        dog.disarm()
+    if rank == 0:
         out["scaling_vs_1"] = _scaling_vs_1(world, args, out)
         print(json.dumps(out))
     snark.close()

@@ -24,6 +24,7 @@ static int comb_bits() {
 }
 size_t comb_min_rows() { return 256; }
 int comb_ensure(sp_ctx* c, const sp_ck* ck) {
+  std::lock_guard<std::mutex> lk(ck->lazy_mu);
   if (ck->d_comb) return SP_OK;
   if (ck->comb_failed || comb_bits() == 0) return 1;  // not available: the caller takes the bucket path
   const int C = comb_bits(), windows = (257 + C - 1) / C;

@@ -1308,6 +1308,7 @@ int ck_key_tables(sp_ctx* c, const sp_ck* ck) {
     const char* e = getenv("SPARTAN_KEY_TABLES");  // "0": keep the bucket MSMs (A/B runs, tests of the fallback)
     if (e && e[0] == '0') return 1;
   }
+  std::lock_guard<std::mutex> lk(ck->lazy_mu);  // two contexts / threads sharing the key: one builds, the other finds the tables
   if (ck->d_keytables) return SP_OK;
   if (ck->keytables_failed) return 1;
   if (ck->num_cols + 1 > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return 1;

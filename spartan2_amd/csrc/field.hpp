@@ -646,8 +646,12 @@ SP_HD fe_t fe_inv_vartime(const fe_t& x) {
 // normalised). The reference's ff::Field::invert is constant-time. Host: the argument is multiplied by a fresh random mask m first, so the variable-time
 // xgcd runs on x*m — uniformly distributed whatever x is — and the mask is taken off again: (x m)^-1 m = x^-1 exactly; without an entropy source
 // (or a zero mask) it is Fermat's fixed exponentiation. Device: Fermat. inv(0) == 0.
+// What still shows in the timing: whether x == 0 (x m == 0 leaves the xgcd at once and takes Fermat's path; the reference's callers never invert a
+// secret zero - a zero Z coordinate is the identity, a public fact of the proof). The mask is uniform on [1, 2^255), a subset of the field: x m is
+// then uniform on a set of 2^255 - 1 field elements that does not depend on x != 0, which is all the blinding needs.
 template <class FP>
 SP_HD fe_t fe_inv(const fe_t& x) {
+  static_assert(FP::P(7) >= 0x80000000u, "fe_inv: the 255-bit mask is canonical only below a modulus of 256 bits");
 #if !defined(__HIP_DEVICE_COMPILE__)
   fe_t m;
   if (sp_blind_mask(m.v)) {

@@ -1,5 +1,6 @@
 // Shared by the group-side translation units of libspartan_hip.so (capi_group.hip, capi_comb.hip).
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,8 @@ struct sp_ck {
   // 8-bit window tables of every base and of h (capi_group.hip ck_key_tables), built on first use by sp_hyrax_prove
   mutable aff_t* d_keytables = nullptr;
   mutable bool keytables_failed = false;
+  // the two lazily built table sets above are written through a `const sp_ck*` that several contexts / helper threads may share: first use is serialised
+  mutable std::mutex lazy_mu;
 };
 
 

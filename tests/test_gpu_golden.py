@@ -65,6 +65,19 @@ def test_spartan_proof_against_golden(ctx):
     wire = sn.proof_to_bytes(words)
     assert len(wire) == gold["wire_len"] and hashlib.sha256(wire).hexdigest() == gold["wire_sha256"] and wire[:64].hex() == gold["wire_head"]
     assert sn.verify_bytes(wire) == 0
+    # and the product's proof under the independent Python-integer verifier (tests/pyverify.py: written from src/spartan.rs:469-578, no oracle, no
+    # C++): keys as the product derives them, the vk digest recomputed in Python from the circuit
+    import pyverify
+
+    g, g_s = host.from_label(b"ck", 2049), host.from_label(b"ck_s", 2)
+    lay = sn.proof_layout()
+    lay = dict(rows_shared=lay["rows_shared"], rows_pre=lay["rows_precommitted"], rows_rest=lay["rows_rest"], num_public=lay["num_public"],
+               num_challenges=lay["num_challenges"], lx=lay["rounds_x"], ly=lay["rounds_y"], nz=lay["z_len"])
+    assert pyverify.verify(inst, g[:2048], g[2048], g_s[0], g_s[1], words, lay) == [int(v) for v in inst.publics]
+    bad = words.copy()
+    bad[-1] ^= np.uint64(1)
+    with pytest.raises(pyverify.VerifyError):
+        pyverify.verify(inst, g[:2048], g[2048], g_s[0], g_s[1], bad, lay)
 
 
 def test_nifs_rounds_against_golden(ctx):
