@@ -463,6 +463,23 @@ void* orc_shape_new(size_t num_cons, size_t num_shared, size_t num_precommitted,
   }
 }
 void orc_shape_free(void* s) { delete (SplitR1CSShape<Fq>*)s; }
+// SplitR1CSShape::equalize (src/r1cs/mod.rs:913-971) on two shapes in place; orc_shape_digest = SHA-256 over SplitR1CSShape::write_bytes (:775-794)
+int orc_shape_equalize(void* a, void* b) {
+  try {
+    SplitR1CSShape<Fq>::equalize(*(SplitR1CSShape<Fq>*)a, *(SplitR1CSShape<Fq>*)b);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+int orc_shape_digest(void* s, uint8_t out[32]) {
+  Sha256 h;
+  WireWriter w(&h);
+  w.shape_digest_bytes(*(SplitR1CSShape<Fq>*)s);
+  h.finalize(out);
+  return 0;
+}
 int orc_shape_sizes(void* s, uint64_t* out10) {  // SplitR1CSShape::sizes (src/r1cs/mod.rs:1008-1021)
   auto* S = (SplitR1CSShape<Fq>*)s;
   uint64_t v[10] = {S->num_cons_unpadded, S->num_shared_unpadded, S->num_precommitted_unpadded, S->num_rest_unpadded, S->num_cons,
@@ -758,7 +775,10 @@ void* orc_nn_prove(void* k, size_t n, const uint64_t* step_wit, size_t wit_len, 
       sp[i] = from_u64s(step_pub + i * npub, npub);
     }
     Tape t(tape, tape_blocks);
-    NNPrep ps = nn_prep_prove(*pk, sw, sp, from_u64s(core_wit, wit_len), from_u64s(core_pub, npub), is_small != 0, t);
+    // the core circuit's own lengths (after SplitR1CSShape::equalize the core may have more or fewer variables and public values than a step)
+    const SplitR1CSShape<Fq>& Sc = pk->S_core;
+    NNPrep ps = nn_prep_prove(*pk, sw, sp, from_u64s(core_wit, Sc.num_shared_unpadded + Sc.num_precommitted_unpadded + Sc.num_rest_unpadded), from_u64s(core_pub, Sc.num_public),
+                              is_small != 0, t);
     if (tape_used) tape_used[0] = t.pos;
     auto t0 = std::chrono::steady_clock::now();
     auto* pf = new NNProof(nn_prove(*pk, ps, is_small != 0, t));

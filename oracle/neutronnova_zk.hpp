@@ -642,8 +642,11 @@ inline void nn_vk_digest(const NNKey& k, uint8_t out[32]) {
 }
 inline std::unique_ptr<NNKey> nn_setup(SplitR1CSShape<Fq> S_step, SplitR1CSShape<Fq> S_core, size_t num_steps) {  // :1394-1475
   auto pk = std::make_unique<NNKey>();
-  if (S_step.num_cons != S_core.num_cons || S_step.num_shared != S_core.num_shared || S_step.num_precommitted != S_core.num_precommitted || S_step.num_rest != S_core.num_rest)
-    throw std::runtime_error("NeutronNova: step and core shapes must have equal padded dimensions (SplitR1CSShape::equalize is not restated)");
+  SplitR1CSShape<Fq>::equalize(S_step, S_core);  // :1413
+  // equalize leaves the shared and precommitted segments as they are: this restatement lays out one proof for "a step or the core" and needs them
+  // equal (they are whenever both circuits fill the same number of 2048-wide rows per segment; constraint counts and padding variables may differ)
+  if (S_step.num_shared != S_core.num_shared || S_step.num_precommitted != S_core.num_precommitted)
+    throw std::runtime_error("NeutronNova oracle: step and core circuits with different padded shared / precommitted segments are not restated");
   pk->S_step = std::move(S_step);
   pk->S_core = std::move(S_core);
   pk->num_steps = num_steps;

@@ -197,6 +197,26 @@ struct SplitR1CSShape {  // src/r1cs/mod.rs:743-773
     S.precompute();
     return S;
   }
+  // SplitR1CSShape::equalize (src/r1cs/mod.rs:913-971): both shapes get the larger number of constraints (row pointers extended) and the larger number
+  // of variables (the growth goes to num_rest; columns of the constant, the public values and the challenges move up by it)
+  static void equalize(SplitR1CSShape& SA, SplitR1CSShape& SB) {
+    const size_t cons = std::max(SA.num_cons, SB.num_cons), vars = std::max(SA.num_vars(), SB.num_vars());
+    auto grow = [&](SplitR1CSShape& S) {
+      const size_t orig_cons = S.num_cons, nv = S.num_vars();
+      S.num_cons = cons;
+      if (nv != vars) S.num_rest = vars - (S.num_shared + S.num_precommitted);
+      for (SparseMatrix<F>* M : {&S.A, &S.B, &S.C}) {
+        for (size_t& c : M->indices)
+          if (c >= nv) c += vars - nv;
+        M->cols += vars - nv;
+        const size_t nnz = M->indptr.empty() ? 0 : M->indptr.back();
+        M->indptr.resize(M->indptr.size() + (cons - orig_cons), nnz);
+      }
+      S.precompute();  // (the reference's precomputed forms are built lazily, after this point)
+    };
+    grow(SA);
+    grow(SB);
+  }
   void precompute() {  // src/r1cs/mod.rs:1059-1073
     pa = PrecomputedSparseMatrix<F>::from_sparse(A);
     pb = PrecomputedSparseMatrix<F>::from_sparse(B);

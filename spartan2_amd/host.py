@@ -46,11 +46,26 @@ DIM_NAMES = ("num_cons", "num_cons_unpadded", "num_shared", "num_precommitted", 
              "num_rest_unpadded", "num_public", "num_challenges")
 
 
-def pad_shape(inst):
-    """SplitR1CSShape::new (src/r1cs/mod.rs:810-911): padded CSR matrices with field coefficients + dims dict."""
+def _padded_handle(inst):
     args, keep = _inst_args(inst)
     h = ctypes.c_void_p()
     _check(lib().ss_pad_shape(*args, ctypes.byref(h)))
+    return h
+
+
+def pad_shape(inst):
+    """SplitR1CSShape::new (src/r1cs/mod.rs:810-911): padded CSR matrices with field coefficients + dims dict."""
+    return _padded_export(_padded_handle(inst))
+
+
+def pad_shapes_equalized(inst_a, inst_b):
+    """SplitR1CSShape::new on both, then SplitR1CSShape::equalize (src/r1cs/mod.rs:913-971): -> ((mats, dims), (mats, dims))"""
+    ha, hb = _padded_handle(inst_a), _padded_handle(inst_b)
+    lib().ss_padded_equalize(ha, hb)
+    return _padded_export(ha), _padded_export(hb)
+
+
+def _padded_export(h):
     d = (ctypes.c_uint64 * 10)()
     lib().ss_padded_dims(h, d)
     dims = {k: int(v) for k, v in zip(DIM_NAMES, d)}

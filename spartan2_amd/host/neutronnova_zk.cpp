@@ -178,9 +178,11 @@ static NNZkKey* nn_setup(sp_ctx* ctx, const R1CSIntView& Rs, const R1CSIntView& 
     pk->ctx = ctx;
     pk->num_steps = num_steps;
     PaddedShape Ps = pad_shape(Rs), Pc = pad_shape(Rc);
-    if (Ps.dims.num_cons != Pc.dims.num_cons || Ps.dims.num_shared != Pc.dims.num_shared || Ps.dims.num_precommitted != Pc.dims.num_precommitted ||
-        Ps.dims.num_rest != Pc.dims.num_rest)
-      throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: step and core shapes must have equal padded dimensions (SplitR1CSShape::equalize is not driven here)");
+    equalize(Ps, Pc);  // src/neutronnova_zk.rs:1413
+    // equalize leaves the shared and precommitted segments alone; this driver lays out one proof for "a step or the core" and needs them equal
+    // (constraint counts and padding variables may differ)
+    if (Ps.dims.num_shared != Pc.dims.num_shared || Ps.dims.num_precommitted != Pc.dims.num_precommitted)
+      throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: step and core circuits with different padded shared / precommitted segments are not driven by this layer");
     if (Ps.dims.num_rest_unpadded || Ps.dims.num_challenges || Pc.dims.num_rest_unpadded || Pc.dims.num_challenges)
       throw Error(SP_ERR_INTERNAL, "NeutronNova: step / core circuits with rest variables or verifier challenges are not driven by this layer");
     pk->dims = Ps.dims;

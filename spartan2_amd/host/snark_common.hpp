@@ -78,6 +78,25 @@ inline PaddedShape pad_shape(const R1CSIntView& R) {
   return P;
 }
 
+// SplitR1CSShape::equalize (src/r1cs/mod.rs:913-971): the larger constraint count (row pointers extended with the last offset) and the larger variable
+// count (growth into num_rest; the columns of 1 | public | challenges move up by it) for both shapes
+inline void equalize(PaddedShape& A, PaddedShape& B) {
+  const size_t cons = std::max<size_t>(A.dims.num_cons, B.dims.num_cons), vars = std::max(A.num_vars(), B.num_vars());
+  auto grow = [&](PaddedShape& S) {
+    const size_t orig_cons = S.dims.num_cons, nv = S.num_vars();
+    S.dims.num_cons = cons;
+    if (nv != vars) S.dims.num_rest = vars - (S.dims.num_shared + S.dims.num_precommitted);
+    for (int m = 0; m < 3; ++m) {
+      for (uint32_t& c : S.idx[m])
+        if (c >= nv) c += (uint32_t)(vars - nv);
+      const uint64_t nnz = S.ptr[m].empty() ? 0 : S.ptr[m].back();
+      S.ptr[m].resize(S.ptr[m].size() + (cons - orig_cons), nnz);
+    }
+  };
+  grow(A);
+  grow(B);
+}
+
 // DigestHelperTrait::digest of SpartanVerifierKey (src/spartan.rs:73-104): SHA-256 over bincode(vk_ee) || bincode(ck_s) || S.write_bytes(), through the
 // library's wire sink (include/spartan_hip.h "wire formats"). gens / gens_s = the num_cols + 1 generators of each key, h last.
 inline void padded_csr(const PaddedShape& P, sp_csr cs[3]) {

@@ -1178,6 +1178,7 @@ int ss_pad_shape(size_t num_cons, size_t num_shared, size_t num_precommitted, si
   }
 }
 void ss_padded_free(void* p) { delete (PaddedShape*)p; }
+void ss_padded_equalize(void* a, void* b) { equalize(*(PaddedShape*)a, *(PaddedShape*)b); }  // SplitR1CSShape::equalize (src/r1cs/mod.rs:913-971)
 void ss_padded_dims(void* p, uint64_t out[10]) { memcpy(out, &((PaddedShape*)p)->dims, sizeof(sp_dims)); }
 void ss_padded_csr(void* p, int which, const uint64_t** data, const uint32_t** idx, const uint64_t** ptr, uint64_t* nnz) {
   auto* P = (PaddedShape*)p;

@@ -163,6 +163,26 @@ def pad_shape(inst):
     return dims, mats, nvp + 1 + inst.num_public + inst.num_challenges
 
 
+def equalize(shape_a, shape_b):
+    """SplitR1CSShape::equalize (src/r1cs/mod.rs:913-971) on two results of pad_shape: -> the two (dims, mats, num_cols) after it"""
+    nv = lambda d: d["num_shared"] + d["num_precommitted"] + d["num_rest"]
+    cons, nvars = max(shape_a[0]["num_cons"], shape_b[0]["num_cons"]), max(nv(shape_a[0]), nv(shape_b[0]))
+    out = []
+    for dims, mats, num_cols in (shape_a, shape_b):
+        dims, old_vars, old_cons = dict(dims), nv(dims), dims["num_cons"]
+        dims["num_cons"] = cons
+        if old_vars != nvars:
+            dims["num_rest"] = nvars - (dims["num_shared"] + dims["num_precommitted"])
+        grown = []
+        for data, cols, ptr in mats:
+            cols = np.asarray(cols, dtype=np.int64).copy()
+            cols[cols >= old_vars] += nvars - old_vars  # 1 | public | challenges
+            ptr = list(ptr) + [ptr[-1] if len(ptr) else 0] * (cons - old_cons)
+            grown.append((data, cols, ptr))
+        out.append((dims, grown, num_cols + nvars - old_vars))
+    return out
+
+
 _DIM_ORDER = ("num_cons", "num_cons_unpadded", "num_shared_unpadded", "num_precommitted_unpadded", "num_rest_unpadded", "num_shared", "num_precommitted",
               "num_rest", "num_public", "num_challenges")  # field order of SplitR1CSShape (src/r1cs/mod.rs:743-755) = write order of write_bytes (:777-786)
 

@@ -1,0 +1,96 @@
+"""CPU: SplitR1CSShape::equalize (src/r1cs/mod.rs:913-971, called by NeutronNovaZkSNARK::setup at src/neutronnova_zk.rs:1413) on the oracle and on the
+product's host layer against a Python restatement (tests/pywire.py equalize): dimensions and MATRICES (the digest stream of write_bytes covers the
+coefficients, column indices, row pointers and column count), for shape pairs that differ in constraint count, in variable count, in both, in neither.
+Then the oracle's NeutronNova prove / verify with a core circuit smaller than the step circuit."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import pywire
+from spartan2_amd import frontend, host
+
+PAIRS = {
+    "fewer_constraints_in_core": lambda: (frontend.synthetic_circuit(8, 0xA5, num_public=1), frontend.synthetic_circuit(2, 0xA5, num_public=1)),
+    "fewer_constraints_in_step": lambda: (frontend.synthetic_circuit(1, 0xA5, num_public=2), frontend.synthetic_circuit(9, 0xA7, num_public=1)),
+    "more_variables_in_one": lambda: (frontend.synthetic_circuit(30, 0xB1, num_public=3), frontend.cubic_circuit()),  # 2 x 2048 precommitted vs rest only
+    "segments_differ": lambda: (frontend.synthetic_circuit(9, 0xBEEF, num_public=2, shared_permille=200, precommitted_permille=500), frontend.synthetic_circuit(40, 3, num_public=1)),
+    "equal_already": lambda: (frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=5), frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=9)),
+}
+
+
+def _py_digest(shape):
+    h = hashlib.sha256()
+    pywire.shape_write_bytes(h, *shape)
+    return h.digest()
+
+
+@pytest.mark.parametrize("name", list(PAIRS))
+def test_equalize_three_ways(name):
+    a, b = PAIRS[name]()
+    want = pywire.equalize(pywire.pad_shape(a), pywire.pad_shape(b))
+    assert want[0][0]["num_cons"] == want[1][0]["num_cons"]
+    nv = lambda d: d["num_shared"] + d["num_precommitted"] + d["num_rest"]
+    assert nv(want[0][0]) == nv(want[1][0])
+    # oracle
+    oa, ob = ol.OracleShape(a), ol.OracleShape(b)
+    assert ol.lib().orc_shape_equalize(oa.h, ob.h) == 0
+    for o, w in zip((oa, ob), want):
+        dig = np.zeros(32, dtype=np.uint8)
+        ol.lib().orc_shape_digest(o.h, ol.p8(dig))
+        assert dig.tobytes() == _py_digest(w)
+        s = (ctypes.c_uint64 * 10)()
+        ol.lib().orc_shape_sizes(o.h, s)
+        assert (int(s[4]), int(s[5]), int(s[6]), int(s[7])) == (w[0]["num_cons"], w[0]["num_shared"], w[0]["num_precommitted"], w[0]["num_rest"])
+    # product (host layer: PaddedShape): dims and matrices entry by entry
+    for (mats, dims), w in zip(host.pad_shapes_equalized(a, b), want):
+        assert {k: dims[k] for k in pywire._DIM_ORDER} == {k: w[0][k] for k in pywire._DIM_ORDER}
+        for (data, idx, ptr), (wd, wc, wp) in zip(mats, w[1]):
+            assert (idx.astype(np.int64) == np.asarray(wc, dtype=np.int64)).all() and [int(v) for v in ptr] == [int(v) for v in wp]
+            assert [pywire._canon(row, pywire.P_SCALAR) for row in data] == [int(v) % pywire.P_SCALAR for v in wd]
+
+
+def test_equalize_is_a_no_op_on_equal_shapes_and_idempotent():
+    a, b = PAIRS["equal_already"]()
+    before = [_py_digest(pywire.pad_shape(x)) for x in (a, b)]
+    once = pywire.equalize(pywire.pad_shape(a), pywire.pad_shape(b))
+    assert [_py_digest(x) for x in once] == before
+    a, b = PAIRS["more_variables_in_one"]()
+    once = pywire.equalize(pywire.pad_shape(a), pywire.pad_shape(b))
+    twice = pywire.equalize(*once)
+    assert [_py_digest(x) for x in once] == [_py_digest(x) for x in twice]
+
+
+def test_neutronnova_with_a_smaller_core_circuit():
+    """step circuits of 8 groups, a core circuit of 2 groups: setup equalizes (the core's row pointers grow to the steps' 1024 rows); the proof verifies,
+    a tampered one does not; the vk digest differs from the one of the equal-shape pair"""
+    steps = [frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=50 + i) for i in range(3)]
+    core = frontend.synthetic_circuit(2, 0xA5, num_public=1, witness_seed=7)
+    assert pywire.pad_shape(core)[0]["num_cons"] < pywire.pad_shape(steps[0])[0]["num_cons"]
+    nn = ol.OracleNeutronNova(steps, core)
+    tape = ol.make_tape(91, 16384)
+    words, used, _ = nn.prove(tape)
+    assert nn.verify_words(words) == 0
+    bad = words.copy()
+    bad[len(words) // 2] ^= np.uint64(4)
+    assert nn.verify_words(bad) != 0
+    data = nn.proof_to_bytes(words)
+    assert (nn.proof_from_bytes(data) == words).all()
+
+
+def test_neutronnova_with_a_larger_core_circuit():
+    steps = [frontend.synthetic_circuit(2, 0xA5, num_public=1, witness_seed=50 + i) for i in range(2)]
+    core = frontend.synthetic_circuit(9, 0xA6, num_public=1, witness_seed=7)
+    assert pywire.pad_shape(core)[0]["num_cons"] > pywire.pad_shape(steps[0])[0]["num_cons"]
+    nn = ol.OracleNeutronNova(steps, core)
+    words, _, _ = nn.prove(ol.make_tape(92, 16384))
+    assert nn.verify_words(words) == 0
+
+
+def test_neutronnova_rejects_different_precommitted_segments():
+    steps = [frontend.synthetic_circuit(30, 0xB1, num_public=1, witness_seed=1 + i) for i in range(2)]  # two rows of precommitted variables
+    core = frontend.synthetic_circuit(2, 0xA5, num_public=1)
+    with pytest.raises(RuntimeError, match="different padded shared / precommitted"):
+        ol.OracleNeutronNova(steps, core)

@@ -49,6 +49,27 @@ def test_prove_matches_oracle_synthetic_steps(ctx, n, groups):
     gnn.close()
 
 
+@pytest.mark.parametrize("n,groups,core_groups", [(3, 8, 2), (2, 2, 9)])
+def test_step_and_core_shapes_of_different_size(ctx, n, groups, core_groups):
+    """SplitR1CSShape::equalize in setup (src/neutronnova_zk.rs:1413, src/r1cs/mod.rs:913-971): a core circuit with fewer (or more) constraints than the
+    step circuit. Same vk digest, same proof words as the oracle, both verifiers accept, the wire bytes round-trip; both drivers (side jobs and the
+    reference-order one) produce it. (tests/test_equalize_cpu.py pins the equalized matrices against a Python restatement.)"""
+    steps = [frontend.synthetic_circuit(groups, 0xA5, num_public=1, witness_seed=50 + i) for i in range(n)]
+    core = frontend.synthetic_circuit(core_groups, 0xA5 + (core_groups > groups), num_public=1, witness_seed=7)
+    onn, gnn, want, got, tape, used, _ = _both(ctx, steps, core, 75 + n)
+    assert (got == want).all()
+    assert onn.verify_words(got) == 0 and gnn.verify(got) == 0
+    assert gnn.proof_to_bytes(got) == onn.proof_to_bytes(want) and gnn.verify_bytes(gnn.proof_to_bytes(got)) == 0
+    gnn.close()
+    ref = host.NeutronNovaZkSNARK(ctx, steps, core)
+    assert ref.prep_prove(tape) == used[0]
+    again, _, _ = ref.prove(tape[used[0]:], reference_order=True)
+    assert (again == want).all()
+    ref.close()
+    with pytest.raises(Exception, match="different padded shared / precommitted"):
+        host.NeutronNovaZkSNARK(ctx, [frontend.synthetic_circuit(30, 0xB1, num_public=1, witness_seed=1 + i) for i in range(2)], core)
+
+
 @pytest.mark.parametrize("n,groups", [(2, 8), (5, 30)])
 def test_verify_rejects_what_the_oracle_rejects(ctx, n, groups):
     """NeutronNovaZkSNARK::verify on the device-backed driver (src/neutronnova_zk.rs:2096-2343): accepts the oracle's proof and its own; a low bit
