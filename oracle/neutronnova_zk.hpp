@@ -19,6 +19,7 @@
 // The vk digest is the reference's SHA-256 over NeutronNovaVerifierKey::write_bytes (src/neutronnova_zk.rs:1305-1333; wire.hpp states the one
 // third-party layout assumption inside it).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <functional>
 #include <memory>
@@ -315,7 +316,10 @@ struct MultiRoundShape {
       M[m]->indptr.push_back(0);
       M[m]->cols = total_padded + num_inputs;
       for (const auto& con : cs.cons) {
-        // add_constraint (bellpepper/r1cs.rs helper): terms in the order the linear combination lists them, equal variables merged by the LC type
+        // add_constraint (bellpepper/r1cs.rs:234-287) pushes the terms in the order LinearCombination::iter() yields them. That type is bellpepper-core
+        // 0.4.0's (third-party, absent from /root/reference): it keeps the input terms and the aux terms in two index-sorted lists (equal variables
+        // merged on insertion) and iterates the inputs first, then the aux variables. PARITY UNPINNED for this order; it moves only the bytes of the
+        // verifier-circuit matrices inside the vk digest, no value of a proof.
         std::vector<std::pair<size_t, Fq>> row;
         for (const auto& t : con[m]) {
           size_t c = col_of(t.first);
@@ -327,6 +331,10 @@ struct MultiRoundShape {
             }
           if (!merged) row.push_back({c, t.second});
         }
+        std::stable_sort(row.begin(), row.end(), [&](const std::pair<size_t, Fq>& x, const std::pair<size_t, Fq>& y) {
+          const bool xi = x.first >= total_padded, yi = y.first >= total_padded;  // inputs sit above the padded variables
+          return xi != yi ? xi : x.first < y.first;
+        });
         for (const auto& e : row) {
           if (e.second.is_zero()) continue;
           M[m]->indices.push_back(e.first);

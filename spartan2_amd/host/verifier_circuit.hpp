@@ -5,6 +5,7 @@
 // hyrax_pc.rs:81-96,221-260).
 // Synthesis ORDER is the reference's, statement by statement: it fixes the matrices and the layout of the round witnesses.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <chrono>
 
@@ -279,6 +280,12 @@ struct Shape {  // SplitMultiRoundR1CSShape + to_regular_shape
             }
           if (!merged) row.push_back({c, t.second});
         }
+        // the order add_constraint (bellpepper/r1cs.rs:234-287) sees: bellpepper-core's LinearCombination::iter() yields the input terms first, then
+        // the aux terms, each list sorted by variable index (third-party type: the assumption is stated in oracle/neutronnova_zk.hpp)
+        std::stable_sort(row.begin(), row.end(), [&](const std::pair<uint32_t, fe_t>& x, const std::pair<uint32_t, fe_t>& y) {
+          const bool xi = x.first >= sh.total_vars, yi = y.first >= sh.total_vars;
+          return xi != yi ? xi : x.first < y.first;
+        });
         for (const auto& e : row) {
           if (fe_is_zero(e.second)) continue;
           sh.M[m].idx.push_back(e.first);

@@ -25,6 +25,11 @@ def _both(ctx, steps, core, seed):
     want, used, secs = onn.prove(tape)
     gnn = host.NeutronNovaZkSNARK(ctx, steps, core)
     assert gnn.info == onn.info and (gnn.vk_digest == onn.digest()).all()
+    # ... and equal to the digest recomputed in Python from an independent synthesis of the verifier circuit (tests/pyvcircuit.py, from src/zk.rs:473-943):
+    # the product's verifier-circuit MATRICES, the equalized step / core shapes and the key framing, byte for byte
+    import pyvcircuit
+
+    assert gnn.vk_digest.tobytes() == pyvcircuit.nn_vk_digest(steps[0], core, len(steps), host.from_label(b"ck", 2049))[0]
     c = ol.verifier_circuit_counts(gnn.info["nb"], gnn.info["nx"], gnn.info["ny"], 32)  # hand-derived from src/zk.rs (tests/golden/reference_kats.json)
     assert (gnn.info["vc_rounds"], gnn.info["vc_cons_unpadded"], gnn.info["vc_vars"], gnn.info["vc_public"]) == (c["rounds"], c["constraints"], c["vars_padded"], c["public"])
     assert gnn.prep_prove(tape) == used[0]
