@@ -258,6 +258,139 @@ static float time_us(L&& f, int reps) {
   return best * 1e3f;
 }
 
+// UP: every element load (and the weight) issued before the first product, held there by a scheduling barrier: the compiler otherwise sinks the loads
+// to their uses and the waves of the single generation of a 2^20 launch walk through seven load -> wait -> compute phases in lock step (the memory
+// pipe idles while they all compute). W = waves per SIMD the register budget is sized for (2: 256 VGPRs, 3: 168, 4: 128).
+template <int W>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
+k_up(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t la0 = A[id], la2 = A[id + 2 * q], la1 = A[id + q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb2 = B[id + 2 * q], lb1 = B[id + q], lb3 = B[id + 3 * q];
+  const fe_t lc0 = C[id], lc2 = C[id + 2 * q], lc1 = C[id + q], lc3 = C[id + 3 * q];
+  const fe_t w = eq_in[id & mask];
+  __builtin_amdgcn_sched_barrier(0);
+  const fe_t a0 = bind1(la0, la2, r);
+  A[id] = a0;
+  const fe_t a1 = bind1(la1, la3, r);
+  A[id + q] = a1;
+  const fe_t b0 = bind1(lb0, lb2, r);
+  B[id] = b0;
+  const fe_t b1 = bind1(lb1, lb3, r);
+  B[id + q] = b1;
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  const fe_t ab = fe_mul<S>(a0, b0);
+  const fe_t c0 = bind1(lc0, lc2, r);
+  C[id] = c0;
+  const fe_t c1 = bind1(lc1, lc3, r);
+  C[id + q] = c1;
+  const fe_t t0e = fe_sub<S>(ab, c0);
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+// UP2: two batches - A and B first (16 loads), C's four behind the A / B binds
+template <int W>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))
+k_up2(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t la0 = A[id], la2 = A[id + 2 * q], la1 = A[id + q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb2 = B[id + 2 * q], lb1 = B[id + q], lb3 = B[id + 3 * q];
+  __builtin_amdgcn_sched_barrier(0);
+  const fe_t a0 = bind1(la0, la2, r);
+  A[id] = a0;
+  const fe_t lc0 = C[id], lc2 = C[id + 2 * q], lc1 = C[id + q], lc3 = C[id + 3 * q];
+  const fe_t w = eq_in[id & mask];
+  __builtin_amdgcn_sched_barrier(0);
+  const fe_t a1 = bind1(la1, la3, r);
+  A[id + q] = a1;
+  const fe_t b0 = bind1(lb0, lb2, r);
+  B[id] = b0;
+  const fe_t b1 = bind1(lb1, lb3, r);
+  B[id + q] = b1;
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  const fe_t ab = fe_mul<S>(a0, b0);
+  const fe_t c0 = bind1(lc0, lc2, r);
+  C[id] = c0;
+  const fe_t c1 = bind1(lc1, lc3, r);
+  C[id + q] = c1;
+  const fe_t t0e = fe_sub<S>(ab, c0);
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+
+// wave sum with DPP moves for the four in-row levels (one VALU instruction each, no LDS crossbar) and shuffles for the two across rows
+template <int CTRL>
+__device__ __forceinline__ lazy9_t lazy_dpp_step(const lazy9_t& a) {
+  lazy9_t o;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) o.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.v[i], CTRL, 0xf, 0xf, false);
+  return lazy_add(a, o);
+}
+__device__ __forceinline__ lazy9_t lazy_wave_sum_dpp(lazy9_t a) {
+  a = lazy_dpp_step<0xB1>(a);   // quad_perm [1,0,3,2]
+  a = lazy_dpp_step<0x4E>(a);   // quad_perm [2,3,0,1]
+  a = lazy_dpp_step<0x124>(a);  // row_ror:4
+  a = lazy_dpp_step<0x128>(a);  // row_ror:8
+#pragma unroll
+  for (int m = 16; m <= 32; m <<= 1) {
+    lazy9_t o;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.v[i] = __shfl_xor(a.v[i], m, 64);
+    a = lazy_add(a, o);
+  }
+  return a;
+}
+// W1: the weight's load first (the compiler otherwise issues it behind the stores, where its wait also waits for every store's acknowledgement);
+// DPP: the wave sums with DPP moves
+template <bool W1, bool DPP>
+__global__ void __launch_bounds__(256) k_tail(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in, int s,
+                                              lazy9_t* __restrict__ partials) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  fe_t w;
+  if (W1) {
+    w = eq_in[id & mask];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
+  const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+  const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+  const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
+  A[id] = a0; A[id + q] = a1; B[id] = b0; B[id + q] = b1; C[id] = c0; C[id + q] = c1;
+  if (!W1) w = eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  if (DPP) stream_block_partials(lazy_wave_sum_dpp(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum_dpp(lazy_from(fe_mul<S>(w, tie))), partials);
+  else stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+
+// STAGGER: the waves of a 2^20 launch are one generation that starts together and walks through the same load / compute phases together; a start
+// delay that differs between the blocks sharing a SIMD (SH selects which bits of the block index pick the delay, T its unit in 64-cycle steps)
+// lets one group's loads run under another's products
+template <int SH, int T>
+__global__ void __launch_bounds__(256) k_stagger(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in, int s,
+                                                 lazy9_t* __restrict__ partials) {
+  const int g = (blockIdx.x >> SH) & 3;
+  if (g == 1) __builtin_amdgcn_s_sleep(T);
+  else if (g == 2) __builtin_amdgcn_s_sleep(2 * T);
+  else if (g == 3) __builtin_amdgcn_s_sleep(3 * T);
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
+  const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+  const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+  const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
+  A[id] = a0; A[id + q] = a1; B[id] = b0; B[id + q] = b1; C[id] = c0; C[id + q] = c1;
+  const fe_t w = eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+
 int main() {
   for (int logL : {20, 22}) {
     const size_t L = (size_t)1 << logL, q = L / 4;
@@ -273,6 +406,20 @@ int main() {
     lazy9_t* lp = reinterpret_cast<lazy9_t*>(part);
     report("library k_bind_eval_cubic<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic<1>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part, part, 1u, nomail); }, 10));
     report("library k_bind_eval_cubic_stream<1>", time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic_stream<1, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp, nomail); }, 20));
+    report("all loads up front, 2 waves/SIMD budget", time_us([&] { hipLaunchKernelGGL((k_up<2>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("all loads up front, 3 waves/SIMD budget", time_us([&] { hipLaunchKernelGGL((k_up<3>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("all loads up front, 4 waves/SIMD budget", time_us([&] { hipLaunchKernelGGL((k_up<4>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("A,B then C, 3 waves/SIMD budget", time_us([&] { hipLaunchKernelGGL((k_up2<3>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("A,B then C, 4 waves/SIMD budget", time_us([&] { hipLaunchKernelGGL((k_up2<4>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("weight loaded first", time_us([&] { hipLaunchKernelGGL((k_tail<true, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("DPP wave sums", time_us([&] { hipLaunchKernelGGL((k_tail<false, true>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("weight first + DPP wave sums", time_us([&] { hipLaunchKernelGGL((k_tail<true, true>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stagger blk>>0, 10", time_us([&] { hipLaunchKernelGGL((k_stagger<0, 10>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stagger blk>>3, 10", time_us([&] { hipLaunchKernelGGL((k_stagger<3, 10>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stagger blk>>3, 25", time_us([&] { hipLaunchKernelGGL((k_stagger<3, 25>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stagger blk>>3, 40", time_us([&] { hipLaunchKernelGGL((k_stagger<3, 40>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stagger blk>>8, 25", time_us([&] { hipLaunchKernelGGL((k_stagger<8, 25>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
+    report("stagger blk>>5, 25", time_us([&] { hipLaunchKernelGGL((k_stagger<5, 25>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("pair split over two half-waves", time_us([&] { hipLaunchKernelGGL(k_split, dim3(q / 128), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, plain stores", time_us([&] { hipLaunchKernelGGL((k_nt<false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
     report("stream body, non-temporal stores", time_us([&] { hipLaunchKernelGGL((k_nt<true>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20));
