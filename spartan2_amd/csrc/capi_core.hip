@@ -446,6 +446,15 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
     sp::relax();
   }
 }
+// the result of a two-round trip of the resident tail (kernels_poly.hpp TAIL_WIDE_VALS): nvals sums, three per result slot from slot 0 on
+static int wait_wide(sp_ctx* c, unsigned want, int nvals, fe_t* v) {
+  long spins = 0;
+  for (int s0 = 0; s0 < nvals; s0 += 3) {
+    int rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM + 4 * (s0 / 3), want, nvals - s0 < 3 ? nvals - s0 : 3, v + s0, true, &spins);
+    if (rc) return rc;
+  }
+  return SP_OK;
+}
 // groups > 1 (slot path only): the first nb / groups slots are summed into out_host[0 .. nacc), the next into out_host[nacc .. 2 nacc), ... (the two
 // instances of a batched round evaluated by one launch)
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false, unsigned groups = 1) {
@@ -1244,6 +1253,59 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     // this round's sums are in flight: remember how to wait for them, then issue the next launch ahead of the challenge where that is possible
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
+    if (wait_resident && spk::tail_double(false, len_now)) {
+      // TWO ROUNDS IN THIS TRIP (kernels_poly.hpp TAIL_WIDE_VALS): the resident kernel sent the sums of this round and the coefficient sums, in this
+      // round's challenge, of the next. S0 = sum a0 b0, S1 = a1 b1, S2 = (a2-a0)(b2-b0), S3 = (a3-a1)(b3-b1), S4 = a2 b2, S5 = U V, S6 = dU dV,
+      // S7 = (U+dU)(V+dV) over the quarters a0..a3 of the table.
+      fe_t S8[8];
+      if ((rc = wait_wide(c, wait_seq, spk::TAIL_DOUBLE_SUMS_QUAD, S8))) return rc;
+      if (reduce) {
+        int hrc = reduce(reduce_user, reinterpret_cast<uint64_t*>(S8), 8);
+        if (hrc) return fail(hrc, "prove_quad: the reduce hook failed");
+      }
+      fe_t rr[2];
+      for (int half2 = 0; half2 < 2; ++half2) {
+        fe_t e0, tinf;
+        if (half2 == 0) {
+          e0 = fe_add<S>(S8[0], S8[1]);
+          tinf = fe_add<S>(S8[2], S8[3]);
+        } else {  // eval_0(r) = S0 + r (S4 - S0 - S2) + r^2 S2, t_inf(r) = S5 + r (S7 - S5 - S6) + r^2 S6
+          const fe_t r = rr[0];
+          e0 = fe_add<S>(S8[0], fe_mul<S>(r, fe_add<S>(fe_sub<S>(fe_sub<S>(S8[4], S8[0]), S8[2]), fe_mul<S>(r, S8[2]))));
+          tinf = fe_add<S>(S8[5], fe_mul<S>(r, fe_add<S>(fe_sub<S>(fe_sub<S>(S8[7], S8[5]), S8[6]), fe_mul<S>(r, S8[6]))));
+        }
+        const fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
+        const fe_t e2 = fe_add<S>(fe_add<S>(fe_sub<S>(fe_add<S>(claim, claim), three_e0), tinf), tinf);
+        fe_t ev[3] = {e0, fe_sub<S>(claim, e0), e2};
+        UniPoly poly = from_evals_deg2(ev);
+        absorb_poly(tr->t, poly);
+        if (!tr->t.squeeze<S>(lbl_c, 1, &rr[half2])) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+        store_fe(out_r + 4 * (round + half2), rr[half2]);
+        store_fe(out_cpolys + 8 * (round + half2), poly.c[0]);
+        store_fe(out_cpolys + 8 * (round + half2) + 4, poly.c[2]);
+        claim = poly_eval(poly, rr[half2]);
+        tail_post_challenge(c, rr[half2], wait_seq + half2);  // (the first at once: the kernel's first bind runs under the second round's host step)
+      }
+      // the kernel binds twice and (if rounds are left) evaluates again: its next result is tagged wait_seq + 2
+      for (int k = 0; k < 2; ++k) {
+        sp::after_bind(A);
+        sp::after_bind(B);
+        next_seq(c);
+      }
+      have_sums = round + 2 < rounds;
+      c->pending_slots = have_sums ? 1u : 0u;
+      last_answered = wait_seq + 1;
+      guard.armed = round + 2 < rounds;
+      if (observe)
+        for (int k = 0; k < 2; ++k) {
+          uint64_t rw[4];
+          store_fe(rw, rr[k]);
+          observe(observe_user, round + k, rw);
+        }
+      if (round_trace()) fprintf(stderr, "quad rounds %2zu+%2zu len %8zu tail 2 wait+host %7.1f us\n", round, round + 1, len_now, now_us() - tr0);
+      ++round;
+      continue;
+    }
     int issued = 0;
     if (waiting && (in_tail || (c->mail_dev && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(round, nullptr, wait_seq);
@@ -1953,6 +2015,88 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     // Not when tau * p vanishes: that round re-evaluates with a third sum (fallback_three_inputs), which must not queue behind a waiting kernel.
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
+    if (wait_resident && spk::tail_double(true, A->len)) {
+      // TWO ROUNDS IN THIS TRIP (kernels_poly.hpp TAIL_WIDE_VALS). W[9..12) = t(0), t_inf, t(-1) of round rnd; W[0..9) = the coefficient sums of
+      // round rnd + 1 in this round's challenge r: t'(0) = W0 + r (W1 - W0 - W2) + r^2 W2, t'_inf = W3 + r (W5 - W3 - W4) + r^2 W4,
+      // t'(-1) = W6 + r (W8 - W6 - W7) + r^2 W7 (used by the fallback_three_inputs form only, as in the one-round path).
+      fe_t W[12];
+      const double trd = round_trace() ? now_us() : 0;
+      const size_t len_d = A->len;
+      if ((rc = wait_wide(c, wait_seq, spk::TAIL_DOUBLE_SUMS_CUBIC, W))) return rc;
+      if ((rc = combine(W, 12))) return rc;
+      fe_t rr[2];
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const size_t rd = rnd + h2;
+        const fe_t tau_h = taus[rd - 1];
+        const fe_t q0 = fe_sub<S>(one, tau_h), sl = fe_sub<S>(tau_h, q0), qm1 = fe_sub<S>(q0, sl);
+        const fe_t pp = eval_eq_left;
+        fe_t t0, tinf, tm1;
+        if (h2 == 0) {
+          t0 = W[9];
+          tinf = W[10];
+          tm1 = W[11];
+        } else {
+          const fe_t r = rr[0];
+          auto at_r = [&](const fe_t& k0, const fe_t& mid, const fe_t& k2) {  // k0 + r (mid - k0 - k2) + r^2 k2
+            return fe_add<S>(k0, fe_mul<S>(r, fe_add<S>(fe_sub<S>(fe_sub<S>(mid, k0), k2), fe_mul<S>(r, k2))));
+          };
+          t0 = at_r(W[0], W[1], W[2]);
+          tinf = at_r(W[3], W[5], W[4]);
+          tm1 = at_r(W[6], W[8], W[7]);
+        }
+        // derive_from_claim (:1276-1324) when l(1) p = tau p is invertible - it uses the CLAIM, so a claim that is not the honest sum gives another
+        // polynomial than the three-sum form, and the reference's choice must be followed - else fallback_three_inputs (:1327-1396) with t(-1)
+        const fe_t s_0 = fe_mul<S>(fe_mul<S>(q0, pp), t0);
+        const fe_t s_1 = fe_sub<S>(claim, s_0);
+        const fe_t s_leading = fe_mul<S>(fe_mul<S>(sl, pp), tinf);
+        fe_t s_m1;
+        if (!fe_is_zero(fe_mul<S>(tau_h, pp))) {
+          const fe_t two_sum = fe_add<S>(fe_dbl<S>(tinf), fe_dbl<S>(t0));
+          s_m1 = fe_mul<S>(qm1, fe_sub<S>(fe_mul<S>(pp, two_sum), fe_mul<S>(s_1, inv_tau[rd - 1])));
+        } else {
+          s_m1 = fe_mul<S>(fe_mul<S>(qm1, pp), tm1);
+        }
+        const fe_t halfc = two_inv();
+        const fe_t c1 = fe_sub<S>(fe_mul<S>(fe_sub<S>(s_1, s_m1), halfc), s_leading);
+        const fe_t c2 = fe_sub<S>(fe_mul<S>(fe_add<S>(s_1, s_m1), halfc), s_0);
+        const fe_t inner_2 = fe_add<S>(c2, fe_dbl<S>(s_leading));
+        const fe_t eval_2 = fe_add<S>(s_0, fe_dbl<S>(fe_add<S>(c1, fe_dbl<S>(inner_2))));
+        const fe_t c3_3 = fe_add<S>(fe_dbl<S>(s_leading), s_leading);
+        const fe_t inner_3 = fe_add<S>(c2, c3_3);
+        const fe_t mid_3 = fe_add<S>(fe_add<S>(c1, fe_dbl<S>(inner_3)), inner_3);
+        const fe_t eval_3 = fe_add<S>(fe_add<S>(s_0, fe_dbl<S>(mid_3)), mid_3);
+        fe_t ev[4] = {s_0, s_1, eval_2, eval_3};
+        UniPoly poly = from_evals_deg3(ev);
+        absorb_poly(tr->t, poly);
+        if (!tr->t.squeeze<S>(lbl_c, 1, &rr[h2])) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+        const size_t ri = rd - 1;
+        store_fe(out_r + 4 * ri, rr[h2]);
+        store_fe(out_cpolys + 12 * ri, poly.c[0]);
+        store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
+        store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
+        claim = poly_eval(poly, rr[h2]);
+        tail_post_challenge(c, rr[h2], wait_seq + h2);  // (the first at once: the kernel's first bind runs under the second round's host step)
+        eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau_h), rr[h2]), fe_dbl<S>(fe_mul<S>(rr[h2], tau_h))));
+      }
+      for (int k = 0; k < 2; ++k) {  // the kernel binds twice; its next result (if rounds are left) is tagged wait_seq + 2
+        sp::after_bind(A);
+        sp::after_bind(B);
+        sp::after_bind(C);
+        next_seq(c);
+      }
+      c->pending_slots = rnd + 1 < ell ? 1u : 0u;
+      last_answered = wait_seq + 1;
+      guard.armed = rnd + 1 < ell;
+      if (observe)
+        for (int k = 0; k < 2; ++k) {
+          uint64_t rw[4];
+          store_fe(rw, rr[k]);
+          observe(observe_user, rnd - 1 + k, rw);
+        }
+      if (round_trace()) fprintf(stderr, "cubic rounds %2zu+%2zu len %8zu tail 2 wait+host %7.1f us\n", rnd, rnd + 1, len_d, now_us() - trd);
+      ++rnd;
+      continue;
+    }
     int issued = 0;
     if (in_tail || (c->mail_dev && invertible && !reduce)) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(rnd, nullptr, wait_seq);

@@ -75,6 +75,22 @@ __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __r
 // instruction; a poll that straddles the host's stores fails the check and is repeated. Never hangs: after MAIL_WATCHDOG_TICKS (8 s) the error word in the mapped
 // result buffer is set and the kernel carries on with whatever it read.
 constexpr int TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in the mapped result buffer
+// TWO ROUNDS PER ROUND TRIP. Once the resident tail is down to one block, a trip over the bus (result out, challenge back: 8 - 12 us) carries two
+// rounds: besides the sums of the round over the current table (n entries) the kernel sends the sums of the round AFTER it as polynomials in the
+// challenge r it does not know yet — the bound table is A[x] + r (A[x + n/2] - A[x]), so every sum of the next round is of degree 2 in r: three
+// coefficient sums each, of which the products share most factors with this round's (8 sums for the quadratic sum-check, 12 for the cubic one).
+// The host finishes this round, draws r, evaluates the three coefficients at r, finishes the next round, draws its challenge and posts BOTH;
+// the kernel binds twice. Same polynomials, same transcript, half the trips. The result takes TWO sequence numbers, one per challenge that answers
+// it, and goes out through the result slots of blocks 0..3 (only block 0 is left in this regime): three sums and a tag per 128-byte slot, so every
+// line that carries data also carries a system-scope tag store, which is what pushes a line of the mapped buffer out to host memory (sums in a
+// region of their own, written with plain stores, stayed in the L2 until the kernel ended; system-scope stores for every word cost more than the trip saved).
+constexpr int TAIL_WIDE_VALS = 12;
+constexpr int TAIL_DOUBLE_SUMS_QUAD = 8, TAIL_DOUBLE_SUMS_CUBIC = 12;
+#ifdef SP_TAIL_SINGLE  // A/B builds: one round per trip everywhere
+__host__ __device__ __forceinline__ bool tail_double(bool, unsigned long long) { return false; }
+#else
+__host__ __device__ __forceinline__ bool tail_double(bool cubic, unsigned long long n) { return n >= 4 && n <= (cubic ? 256ull : 512ull); }
+#endif
 // The mailbox is a RING of MAIL_RING 64-byte lines indexed by the sequence number a challenge answers (line = seq & 7): a waiter only ever looks at the
 // line of ITS challenge, which the host does not touch again before eight more results are in. With the ring in device memory the host also keeps a
 // MIRROR of it in the mapped pinned buffer (MAIL_MIRROR_ELEM: written first, by ordinary stores); a waiter whose device line has not answered within
@@ -893,6 +909,13 @@ __global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ p
 constexpr int TAIL_THREADS = 1024;
 constexpr unsigned long long TAIL_WIDE_Q_CUBIC = 128;  // the cubic rounds bind three tables and weight every product: half the pairs per block keep its bind phase to one pass
 constexpr unsigned long long TAIL_WIDE_Q = 256;  // pairs per resident block and round: every product gets its own lane (3 * 256 <= TAIL_THREADS)
+// wave sum when only the first `active` lanes of every wave hold a term (the others hold zero): the levels above `active` add nothing
+__device__ __forceinline__ fe_t wave_sum_low(fe_t a, unsigned active) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+    if ((unsigned)m < active) a = fe_add<S>(a, shfl_xor_fe(a, m));
+  return a;
+}
 struct TailArgs {
   fe_t *A, *B, *C;          // C unused in quadratic mode
   unsigned long long len;   // table length at entry, power of two, 2 <= len <= 4 * TAIL_WIDE_Q * gridDim.x
@@ -928,18 +951,67 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   constexpr unsigned long long WQ = CUBIC ? TAIL_WIDE_Q_CUBIC : TAIL_WIDE_Q;
   __shared__ fe_t smem[16];
   __shared__ fe_t r_sh;
-  __shared__ slot_chk chk_sh[4];
+  __shared__ slot_chk chk_sh[TAIL_WIDE_VALS];
   const unsigned long long base = (unsigned long long)blockIdx.x * WQ;
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
   int rnd = a.rnd0;
   fe_t r = a.r0;
-  bool first = true;
+  bool first = true, pending2 = false;
   fe_t* slot = a.mapped + SLOT_BASE_ELEM + 4 * blockIdx.x;
+  // E(id) of round `rd` (select_eq in capi_core.hip; src/sumcheck.rs:1041-1147)
+  auto weight = [&](int rd, unsigned long long id) -> fe_t {
+    if (rd < a.first_half) {
+      const int s2 = a.ell - a.first_half;
+      return fe_mul<S>(a.eq_pr[eq_level_offset(s2) + (id & ((1ull << s2) - 1))], a.eq_pl[eq_level_offset(a.first_half - rd) + (id >> s2)]);
+    }
+    return a.eq_pr[eq_level_offset(a.ell - rd) + id];
+  };
   while (true) {
+    bool have_r = false;
+    if (pending2) {  // the previous result carried two rounds: two challenges answer it (seq - 2, seq - 1) and the table is bound twice
+      if (blockIdx.x != 0) return;
+      if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 2, &r_sh)) return;
+      const fe_t ra = r_sh;
+      __syncthreads();
+      if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 1, &r_sh)) return;
+      r = r_sh;
+      if (len == 4) {  // both rounds were the last two: the final claims
+        if (threadIdx.x == 0) {
+          fe_t* fin = a.mapped + TAIL_FINAL_ELEM;
+          const fe_t fa = bind1(bind1(a.A[0], a.A[2], ra), bind1(a.A[1], a.A[3], ra), r);
+          const fe_t fb = bind1(bind1(a.B[0], a.B[2], ra), bind1(a.B[1], a.B[3], ra), r);
+          a.A[0] = fa;
+          a.B[0] = fb;
+          slot_store_elem(fin, fa);
+          slot_store_elem(fin + 1, fb);
+          slot_chk chk = {0u, 0u};
+          slot_chk_add(chk, fa, 0);
+          slot_chk_add(chk, fb, 1);
+          if (CUBIC) {
+            const fe_t fc = bind1(bind1(a.C[0], a.C[2], ra), bind1(a.C[1], a.C[3], ra), r);
+            a.C[0] = fc;
+            slot_store_elem(fin + 2, fc);
+            slot_chk_add(chk, fc, 2);
+          }
+          slot_store_tag(fin, seq - 1, chk);
+        }
+        return;
+      }
+      const unsigned h = (unsigned)(len / 2), ntab = CUBIC ? 3u : 2u;  // first of the two binds (one block owns everything here)
+      for (unsigned idx = threadIdx.x; idx < ntab * h; idx += TAIL_THREADS) {
+        fe_t* Z = idx / h == 0 ? a.A : (idx / h == 1 ? a.B : a.C);
+        const unsigned x = idx % h;
+        Z[x] = bind1(Z[x], Z[x + h], ra);
+      }
+      __syncthreads();
+      len /= 2;
+      pending2 = false;
+      have_r = true;  // the ordinary step below binds with the second challenge
+    }
     const unsigned long long q = len / 4;
     if (len > 2 ? base >= q : blockIdx.x != 0) return;
-    if (!first || a.r0_from_mail) {
+    if (!have_r && (!first || a.r0_from_mail)) {
       if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 1, &r_sh)) return;
       r = r_sh;
     }
@@ -979,6 +1051,98 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       Z[x] = foreign ? bind1(load_agent(Z + x), load_agent(Z + x + 2 * q), r) : bind1(Z[x], Z[x + 2 * q], r);
     }
     __syncthreads();
+    if (tail_double(CUBIC, len / 2)) {
+      // the round over the n = len / 2 entries just bound AND the coefficient sums of the round after it (see TAIL_WIDE_VALS). y < qd = n / 4;
+      // a0..a3 = A[y + k qd]. One product per lane, `which` wave-uniform:
+      //   quadratic (8 sums): a0 b0 | a1 b1 | (a2-a0)(b2-b0) | (a3-a1)(b3-b1) | a2 b2 | (a1-a0)(b1-b0) | (a3-a1-a2+a0)(..) | (a3-a2)(b3-b2)
+      //   cubic (12 sums, weights E' = E(rnd + 1, y) for 0..8, E(rnd, x) for 9..11 over x < 2 qd as two lane groups each):
+      //     0: a0 b0 - c0 | 1: a2 b2 - c2 | 2: (a2-a0)(b2-b0) | 3: (a1-a0)(b1-b0) | 4: dU dV | 5: (a3-a2)(b3-b2)
+      //     6: (2a0-a1)(2b0-b1) - (2c0-c1) | 7: dM dN, dM = 2(a2-a0) - (a3-a1) | 8: (2a2-a3)(2b2-b3) - (2c2-c3)
+      //     9: t(0) | 10: t_inf | 11: t(-1) of this round
+      const unsigned qd = (unsigned)(len / 8);
+      const unsigned segd = qd < 64 ? 64u : qd;
+      const unsigned grp = threadIdx.x / segd, il = threadIdx.x % segd;
+      constexpr unsigned NGRP = CUBIC ? 15u : 8u;
+      fe_t v = fe_zero();
+      if (grp < NGRP && il < qd) {
+        if (!CUBIC || grp < 9) {
+          // (every case loads only the quarters it uses: all twelve at once would not fit the 128 registers of a 1024-thread block)
+          auto qa = [&](unsigned k) { return a.A[il + k * qd]; };
+          auto qb2 = [&](unsigned k) { return a.B[il + k * qd]; };
+          auto qc = [&](unsigned k) { return a.C[il + k * qd]; };
+          auto prod_diff = [&](unsigned hi, unsigned lo) { return fe_mul<S>(fe_sub<S>(qa(hi), qa(lo)), fe_sub<S>(qb2(hi), qb2(lo))); };  // (a_hi - a_lo)(b_hi - b_lo)
+          auto prod_2m = [&](unsigned k0, unsigned k1) {  // (2 a_k0 - a_k1)(2 b_k0 - b_k1)
+            return fe_mul<S>(fe_sub<S>(fe_dbl<S>(qa(k0)), qa(k1)), fe_sub<S>(fe_dbl<S>(qb2(k0)), qb2(k1)));
+          };
+          if (!CUBIC) {
+            switch (grp) {
+              case 0: v = fe_mul<S>(qa(0), qb2(0)); break;
+              case 1: v = fe_mul<S>(qa(1), qb2(1)); break;
+              case 2: v = prod_diff(2, 0); break;
+              case 3: v = prod_diff(3, 1); break;
+              case 4: v = fe_mul<S>(qa(2), qb2(2)); break;
+              case 5: v = prod_diff(1, 0); break;
+              case 6: v = fe_mul<S>(fe_sub<S>(fe_sub<S>(qa(3), qa(1)), fe_sub<S>(qa(2), qa(0))), fe_sub<S>(fe_sub<S>(qb2(3), qb2(1)), fe_sub<S>(qb2(2), qb2(0)))); break;
+              default: v = prod_diff(3, 2); break;
+            }
+          } else {
+            switch (grp) {
+              case 0: v = fe_sub<S>(fe_mul<S>(qa(0), qb2(0)), qc(0)); break;
+              case 1: v = fe_sub<S>(fe_mul<S>(qa(2), qb2(2)), qc(2)); break;
+              case 2: v = prod_diff(2, 0); break;
+              case 3: v = prod_diff(1, 0); break;
+              case 4: v = fe_mul<S>(fe_sub<S>(fe_sub<S>(qa(3), qa(1)), fe_sub<S>(qa(2), qa(0))), fe_sub<S>(fe_sub<S>(qb2(3), qb2(1)), fe_sub<S>(qb2(2), qb2(0)))); break;
+              case 5: v = prod_diff(3, 2); break;
+              case 6: v = fe_sub<S>(prod_2m(0, 1), fe_sub<S>(fe_dbl<S>(qc(0)), qc(1))); break;
+              case 7:
+                v = fe_mul<S>(fe_sub<S>(fe_dbl<S>(fe_sub<S>(qa(2), qa(0))), fe_sub<S>(qa(3), qa(1))), fe_sub<S>(fe_dbl<S>(fe_sub<S>(qb2(2), qb2(0))), fe_sub<S>(qb2(3), qb2(1))));
+                break;
+              default: v = fe_sub<S>(prod_2m(2, 3), fe_sub<S>(fe_dbl<S>(qc(2)), qc(3))); break;
+            }
+            v = fe_mul<S>(weight(rnd + 1, il), v);
+          }
+        } else {  // cubic, this round's own three sums over the 2 qd pairs (x, x + n / 2): groups 9.. in pairs (low x, high x)
+          const unsigned k = (grp - 9) / 2, x = il + ((grp - 9) & 1u) * qd, hn = 2 * qd;
+          const fe_t a0 = a.A[x], a1 = a.A[x + hn], b0 = a.B[x], b1 = a.B[x + hn], c0 = a.C[x], c1 = a.C[x + hn];
+          if (k == 0) v = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+          else if (k == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+          else v = fe_sub<S>(fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1)), fe_sub<S>(fe_dbl<S>(c0), c1));
+          v = fe_mul<S>(weight(rnd, x), v);
+        }
+      }
+      v = wave_sum_low(v, qd);  // (qd is a power of two; lanes il >= qd hold zero)
+      const int lane2 = threadIdx.x & 63, wave2 = threadIdx.x >> 6;
+      if (lane2 == 0) smem[wave2] = v;
+      __syncthreads();
+      constexpr unsigned NS = CUBIC ? (unsigned)TAIL_DOUBLE_SUMS_CUBIC : (unsigned)TAIL_DOUBLE_SUMS_QUAD;
+      fe_t* wide = a.mapped + SLOT_BASE_ELEM;  // sum k -> slot k / 3, element k % 3
+      if (threadIdx.x < NS) {  // thread k adds the waves of the lane group(s) of sum k
+        const unsigned wps = segd / 64, k = threadIdx.x;
+        const unsigned g0 = (CUBIC && k >= 9) ? 9 + 2 * (k - 9) : k, ng = (CUBIC && k >= 9) ? 2u : 1u;
+        fe_t t = fe_zero();
+        for (unsigned w = 0; w < ng * wps; ++w) t = fe_add<S>(t, smem[g0 * wps + w]);
+        slot_store_elem(wide + 4 * (k / 3) + k % 3, t);
+        slot_chk ck = {0u, 0u};
+        slot_chk_add(ck, t, (int)(k % 3));
+        chk_sh[k] = ck;
+      }
+      __syncthreads();
+      if (threadIdx.x < (NS + 2) / 3) {  // thread s tags slot s
+        const unsigned sidx = threadIdx.x;
+        slot_chk chk = {0u, 0u};
+        for (unsigned k = 3 * sidx; k < 3 * sidx + 3 && k < NS; ++k) {
+          chk.a += chk_sh[k].a;
+          chk.b += chk_sh[k].b;
+        }
+        slot_store_tag(wide + 4 * sidx, seq, chk);
+      }
+      seq += 2;
+      rnd += 2;
+      len /= 2;
+      pending2 = true;
+      __syncthreads();  // smem reuse
+      continue;
+    }
     // phase B: one (sum, pair) product per lane; `which` is wave-uniform
     const unsigned seg = qb < 64 ? 64u : qb;
     const unsigned which = threadIdx.x / seg, il = threadIdx.x % seg;
@@ -993,18 +1157,10 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
         const fe_t c0 = a.C[id], c1 = a.C[id + q];
         if (which == 0) v = fe_sub<S>(v, c0);
         else if (which == 2) v = fe_sub<S>(v, fe_sub<S>(fe_dbl<S>(c0), c1));
-        // E(id) of round `rnd` (select_eq in capi_core.hip; src/sumcheck.rs:1041-1147)
-        fe_t w;
-        if (rnd < a.first_half) {
-          const int s2 = a.ell - a.first_half;
-          w = fe_mul<S>(a.eq_pr[eq_level_offset(s2) + (id & ((1ull << s2) - 1))], a.eq_pl[eq_level_offset(a.first_half - rnd) + (id >> s2)]);
-        } else {
-          w = a.eq_pr[eq_level_offset(a.ell - rnd) + id];
-        }
-        v = fe_mul<S>(w, v);
+        v = fe_mul<S>(weight(rnd, id), v);
       }
     }
-    v = wave_sum(v);
+    v = wave_sum_low(v, qb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) smem[wave] = v;
     __syncthreads();

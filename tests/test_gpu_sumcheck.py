@@ -195,6 +195,31 @@ def test_sumcheck_cubic_tau_zero_fallback(ctx):
     assert (polys == want_polys).all() and (r == want_r).all() and (fin == want_fin).all()
 
 
+@pytest.mark.parametrize("ell", [3, 4, 9, 10, 13])
+def test_two_round_trips_of_the_resident_tail(ctx, ell):
+    """Once the resident tail is down to one block it sends two rounds per trip (kernels_poly.hpp TAIL_WIDE_VALS: the next round's sums as
+    polynomials in this round's challenge). Both parities of the remaining round count, a dishonest claim (derive_from_claim uses it), and
+    tau = 0 at the first / second round of a pair (fallback_three_inputs from the coefficient sums of t(-1)); the quadratic form too."""
+    rng = np.random.default_rng(SEED + 600 + ell)
+    n = 1 << ell
+    A, B, C = rand_table(rng, n), rand_table(rng, n), rand_table(rng, n)
+    for zero_at in (None, ell - 1, ell - 2, ell - 3 if ell > 3 else 0):
+        taus = rand_table(rng, ell)
+        if zero_at is not None:
+            taus[zero_at] = 0
+        claim = rand_table(rng, 1)[0]
+        want_polys, want_r, want_fin, _ = oracle_cubic(claim, taus, A, B, C)
+        tr = hip.Transcript(ctx, b"sc")
+        polys, r, fin = hip.sumcheck_cubic3(ctx, claim, taus, *(hip.Table.from_host(ctx, x) for x in (A, B, C)), tr)
+        assert (polys == want_polys).all() and (r == want_r).all() and (fin == want_fin).all(), zero_at
+    full = (hip.SIZE_MAX, hip.SIZE_MAX)
+    qclaim = rand_table(rng, 1)[0]
+    want = oracle_quad(qclaim, ell, A, full, B, full)
+    got = hip.sumcheck_quad(ctx, qclaim, ell, hip.Table.from_host(ctx, A), hip.Table.from_host(ctx, B), hip.Transcript(ctx, b"sq"))
+    for g, w in zip(got, want):
+        assert (g == w).all()
+
+
 def oracle_quad(claim, rounds, A, effA, B, effB):
     tr = ol.Transcript(b"sq")
     polys = np.zeros((rounds, 2, 4), dtype=np.uint64)
