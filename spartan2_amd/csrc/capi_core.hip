@@ -1274,10 +1274,13 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
           e0 = fe_add<S>(S8[0], fe_mul<S>(r, fe_add<S>(fe_sub<S>(fe_sub<S>(S8[4], S8[0]), S8[2]), fe_mul<S>(r, S8[2]))));
           tinf = fe_add<S>(S8[5], fe_mul<S>(r, fe_add<S>(fe_sub<S>(fe_sub<S>(S8[7], S8[5]), S8[6]), fe_mul<S>(r, S8[6]))));
         }
-        const fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
-        const fe_t e2 = fe_add<S>(fe_add<S>(fe_sub<S>(fe_add<S>(claim, claim), three_e0), tinf), tinf);
-        fe_t ev[3] = {e0, fe_sub<S>(claim, e0), e2};
-        UniPoly poly = from_evals_deg2(ev);
+        // eval_2 = 2 claim - 3 eval_0 + 2 t_inf and the interpolation of (eval_0, claim - eval_0, eval_2) (src/sumcheck.rs:211-215, univariate.rs:84-93)
+        // give c0 = eval_0, c2 = t_inf, c1 = claim - 2 eval_0 - t_inf: written down directly
+        UniPoly poly;
+        poly.n = 3;
+        poly.c[0] = e0;
+        poly.c[1] = fe_sub<S>(fe_sub<S>(claim, fe_dbl<S>(e0)), tinf);
+        poly.c[2] = tinf;
         absorb_poly(tr->t, poly);
         if (!tr->t.squeeze<S>(lbl_c, 1, &rr[half2])) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
         store_fe(out_r + 4 * (round + half2), rr[half2]);
@@ -1333,10 +1336,12 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     const double tr1 = round_trace() ? now_us() : 0;
     // BDDT: eval_2 = 2 claim - 3 eval_0 + 2 t_inf (src/sumcheck.rs:211-215)
     fe_t e0 = sums[0], tinf = sums[1];
-    fe_t three_e0 = fe_add<S>(fe_add<S>(e0, e0), e0);
-    fe_t e2 = fe_add<S>(fe_add<S>(fe_sub<S>(fe_add<S>(claim, claim), three_e0), tinf), tinf);
-    fe_t ev[3] = {e0, fe_sub<S>(claim, e0), e2};
-    UniPoly poly = from_evals_deg2(ev);
+    // (eval_0, claim - eval_0, eval_2 = 2 claim - 3 eval_0 + 2 t_inf) interpolated (univariate.rs:84-93) = c0 = eval_0, c2 = t_inf, c1 = claim - 2 eval_0 - t_inf
+    UniPoly poly;
+    poly.n = 3;
+    poly.c[0] = e0;
+    poly.c[1] = fe_sub<S>(fe_sub<S>(claim, fe_dbl<S>(e0)), tinf);
+    poly.c[2] = tinf;
     absorb_poly(tr->t, poly);
     fe_t r_i;
     if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
@@ -2059,14 +2064,14 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         const fe_t halfc = two_inv();
         const fe_t c1 = fe_sub<S>(fe_mul<S>(fe_sub<S>(s_1, s_m1), halfc), s_leading);
         const fe_t c2 = fe_sub<S>(fe_mul<S>(fe_add<S>(s_1, s_m1), halfc), s_0);
-        const fe_t inner_2 = fe_add<S>(c2, fe_dbl<S>(s_leading));
-        const fe_t eval_2 = fe_add<S>(s_0, fe_dbl<S>(fe_add<S>(c1, fe_dbl<S>(inner_2))));
-        const fe_t c3_3 = fe_add<S>(fe_dbl<S>(s_leading), s_leading);
-        const fe_t inner_3 = fe_add<S>(c2, c3_3);
-        const fe_t mid_3 = fe_add<S>(fe_add<S>(c1, fe_dbl<S>(inner_3)), inner_3);
-        const fe_t eval_3 = fe_add<S>(fe_add<S>(s_0, fe_dbl<S>(mid_3)), mid_3);
-        fe_t ev[4] = {s_0, s_1, eval_2, eval_3};
-        UniPoly poly = from_evals_deg3(ev);
+        // (s(0), s_leading, s(-1)) -> coefficients: the reference goes through (eval_0, eval_2, eval_3) and an interpolation (:1303-1320,
+        // univariate.rs:102-118); c1 and c2 above ARE the coefficients of that polynomial, the same field elements without the detour
+        UniPoly poly;
+        poly.n = 4;
+        poly.c[0] = s_0;
+        poly.c[1] = c1;
+        poly.c[2] = c2;
+        poly.c[3] = s_leading;
         absorb_poly(tr->t, poly);
         if (!tr->t.squeeze<S>(lbl_c, 1, &rr[h2])) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
         const size_t ri = rd - 1;
@@ -2149,14 +2154,14 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     const fe_t halfc = two_inv();
     const fe_t c1 = fe_sub<S>(fe_mul<S>(fe_sub<S>(s_1, s_m1), halfc), s_leading);
     const fe_t c2 = fe_sub<S>(fe_mul<S>(fe_add<S>(s_1, s_m1), halfc), s_0);
-    const fe_t inner_2 = fe_add<S>(c2, fe_dbl<S>(s_leading));
-    const fe_t eval_2 = fe_add<S>(s_0, fe_dbl<S>(fe_add<S>(c1, fe_dbl<S>(inner_2))));
-    const fe_t c3_3 = fe_add<S>(fe_dbl<S>(s_leading), s_leading);
-    const fe_t inner_3 = fe_add<S>(c2, c3_3);
-    const fe_t mid_3 = fe_add<S>(fe_add<S>(c1, fe_dbl<S>(inner_3)), inner_3);
-    const fe_t eval_3 = fe_add<S>(fe_add<S>(s_0, fe_dbl<S>(mid_3)), mid_3);
-    fe_t ev[4] = {s_0, fe_sub<S>(claim, s_0), eval_2, eval_3};
-    UniPoly poly = from_evals_deg3(ev);
+    // (s(0), s_leading, s(-1)) -> coefficients: the reference goes through (eval_0, eval_2, eval_3) and an interpolation (:1303-1320,
+    // univariate.rs:102-118); c1 and c2 above ARE the coefficients of that polynomial, the same field elements without the detour
+    UniPoly poly;
+    poly.n = 4;
+    poly.c[0] = s_0;
+    poly.c[1] = c1;
+    poly.c[2] = c2;
+    poly.c[3] = s_leading;
     absorb_poly(tr->t, poly);
     fe_t r_i;
     if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
@@ -2207,6 +2212,16 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
   store_fe(claim_io, claim);
   store_fe(p_io, eval_eq_left);
   if (round_trace()) fprintf(stderr, "cubic total %7.1f us\n", now_us() - tr_entry);
+#ifdef SP_TAIL_TRACE
+  if (round_trace()) {  // the last eight one-round steps of the resident kernel: stations 0 top, 1 challenge seen, 2 bound, 3 products, 4 wave sums, 5 block barrier, 6 published
+    const volatile unsigned long long* tt = reinterpret_cast<const volatile unsigned long long*>(c->h_pinned + 32);
+    for (int k = 0; k < 8; ++k) {
+      fprintf(stderr, "  tail step slot %d:", k);
+      for (int i = 1; i < 7; ++i) fprintf(stderr, " %+6.2f", (double)(long long)(tt[8 * k + i] - tt[8 * k + i - 1]) / 100.0);
+      fprintf(stderr, " us | top->top of next %6.2f\n", (double)(long long)(tt[8 * ((k + 1) & 7)] - tt[8 * k]) / 100.0);
+    }
+  }
+#endif
   return tail_check(c);  // also set by a kernel launched ahead that gave up waiting for its challenge
 }
 

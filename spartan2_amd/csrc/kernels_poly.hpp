@@ -916,6 +916,13 @@ __device__ __forceinline__ fe_t wave_sum_low(fe_t a, unsigned active) {
     if ((unsigned)m < active) a = fe_add<S>(a, shfl_xor_fe(a, m));
   return a;
 }
+// -DSP_TAIL_TRACE: thread 0 of block 0 stamps the 100 MHz wall clock at the stations of a one-round step into the mapped buffer (elements 32..47,
+// eight stamps per round, ring of 8 rounds); capi_core.hip prints them under SPARTAN_ROUND_TRACE. Diagnostics only.
+#ifdef SP_TAIL_TRACE
+#define SP_TT(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) reinterpret_cast<unsigned long long*>(a.mapped + 32)[8 * (rnd & 7) + (i)] = wall_clock64(); } while (0)
+#else
+#define SP_TT(i) do { } while (0)
+#endif
 struct TailArgs {
   fe_t *A, *B, *C;          // C unused in quadratic mode
   unsigned long long len;   // table length at entry, power of two, 2 <= len <= 4 * TAIL_WIDE_Q * gridDim.x
@@ -1011,10 +1018,12 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     }
     const unsigned long long q = len / 4;
     if (len > 2 ? base >= q : blockIdx.x != 0) return;
+    SP_TT(0);
     if (!have_r && (!first || a.r0_from_mail)) {
       if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 1, &r_sh)) return;
       r = r_sh;
     }
+    SP_TT(1);
     // the previous round had 2q pairs: while that is more than one block's worth, the elements bound below were written by other blocks
     // (other XCDs, other L2s). They are read with agent-scope loads, which go past this XCD's L2, instead of an acquire fence, which would
     // invalidate it (measured: 4 us per round).
@@ -1051,6 +1060,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       Z[x] = foreign ? bind1(load_agent(Z + x), load_agent(Z + x + 2 * q), r) : bind1(Z[x], Z[x + 2 * q], r);
     }
     __syncthreads();
+    SP_TT(2);
     if (tail_double(CUBIC, len / 2)) {
       // the round over the n = len / 2 entries just bound AND the coefficient sums of the round after it (see TAIL_WIDE_VALS). y < qd = n / 4;
       // a0..a3 = A[y + k qd]. One product per lane, `which` wave-uniform:
@@ -1160,10 +1170,13 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
         v = fe_mul<S>(weight(rnd, id), v);
       }
     }
+    SP_TT(3);
     v = wave_sum_low(v, qb);
+    SP_TT(4);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) smem[wave] = v;
     __syncthreads();
+    SP_TT(5);
     if (threadIdx.x < (unsigned)NACC) {  // thread k adds the waves of sum k into this block's result slot
       const unsigned wps = seg / 64;
       fe_t t = smem[threadIdx.x * wps];
@@ -1188,6 +1201,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       }
       slot_store_tag(slot, seq, chk);
     }
+    SP_TT(6);
     ++seq;
     ++rnd;
     len /= 2;
