@@ -284,22 +284,29 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args.gpus)  # does not return: this process becomes the launcher of the N ranks
     rank, local_rank, world = spd.env_rank()
+    # Rehearsal of the N > 1 control flow on a box with ONE GPU (SPARTAN_BENCH_REHEARSAL=1; never set by the driver): every rank uses device 0,
+    # torch.distributed runs over gloo and the data-path exchange goes through the callback backend (RCCL refuses two ranks on one device).
+    # Its numbers mean nothing (the ranks share the GPU); the line says so. What it exercises is everything between the launcher and the JSON line.
+    rehearsal = os.environ.get("SPARTAN_BENCH_REHEARSAL") == "1" and world > 1
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit(f"rank {rank}: --gpus {args.gpus} but WORLD_SIZE={world} (the launcher's --nproc-per-node must equal --gpus)")
     if not torch.cuda.is_available():
         raise SystemExit(f"rank {rank}: bench.py needs {world} MI355X device(s), this node shows none: libspartan_hip has no CPU fallback")
-    if torch.cuda.device_count() < world:
+    if torch.cuda.device_count() < world and not rehearsal:
         raise SystemExit(f"rank {rank}: --gpus {world} needs {world} devices (one process per GPU), this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     numa_cpus = _pin_to_gpu_numa(local_rank)  # before any pinned allocation or helper thread exists
-    group = spd.Group(backend=spd.RCCL_BACKEND)  # RCCL: barrier and max-over-ranks of the timed region, and the hand-over of the C++ communicator's id
+    comm_backend = "torch" if rehearsal else "rccl"
+    group = spd.Group(backend="gloo" if rehearsal else spd.RCCL_BACKEND)  # RCCL: barrier and max-over-ranks of the timed region, and the hand-over of the C++ communicator's id
 
     from spartan2_amd import frontend, hip, host
 
     ctx = hip.Context(local_rank)
     # the data-path exchange layer (ncclAllGather from C++ on a communicator of its own): created here for the workloads that ARE the sharded path; the
     # default workload creates it only for its extra legs, after the timed region and under a watchdog (see below)
-    comm = host.Comm(rank, world, "rccl", device=local_rank) if args.workload in ("c4", "c5") else None
+    comm = host.Comm(rank, world, comm_backend, device=local_rank) if args.workload in ("c4", "c5") else None
     barrier = group.barrier  # dist.barrier() + torch.cuda.synchronize()
 
     if args.workload == "c3":
@@ -779,13 +786,15 @@ def main():
         dog = LegDog(rank, out, legs, args.extras_timeout / 2)
         try:
             dog.arm("communicator")
-            comm = host.Comm(rank, world, "rccl", device=local_rank)
+            comm = host.Comm(rank, world, comm_backend, device=local_rank)
             sharded_legs(ctx, comm, group, 3, 2, world == 1 and not args.no_cpu_baseline, out=legs, dog=dog)
         except Exception as exc:
             legs["error"] = repr(exc)
         dog.disarm()
     if rank == 0:
-        out["scaling_vs_1"] = _scaling_vs_1(world, args, out)
+        out["scaling_vs_1"] = None if rehearsal else _scaling_vs_1(world, args, out)
+        if rehearsal:
+            out["rehearsal"] = "SPARTAN_BENCH_REHEARSAL=1: all ranks on ONE GPU over gloo + the callback exchange; control flow only, the figures are not measurements"
         print(json.dumps(out))
     snark.close()
     if comm is not None:
