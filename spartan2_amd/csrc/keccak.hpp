@@ -7,6 +7,9 @@
 
 #include "field.hpp"
 
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <immintrin.h>
+#endif
 namespace sp {
 
 SP_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
@@ -51,55 +54,96 @@ constexpr uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800
                              0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
                              0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
 #define SP_KH_INLINE static inline __attribute__((always_inline))
+// The round function over a word type W: uint64_t (one state), or two states side by side in an xmm register (W2 below: the two final permutations of a
+// squeeze - Keccak(.. || 0) and Keccak(.. || 1), keccak.rs:33-54 - are independent and run for the price of one).
+SP_KH_INLINE uint64_t w_xor(uint64_t a, uint64_t b) { return a ^ b; }
+SP_KH_INLINE uint64_t w_chi(uint64_t b0, uint64_t b1, uint64_t b2) { return b0 ^ (~b1 & b2); }
 template <int R>
-SP_KH_INLINE uint64_t rol(uint64_t x) {
+SP_KH_INLINE uint64_t w_rol(uint64_t x) {
   if constexpr (R == 0) return x;
   else return (x << R) | (x >> (64 - R));
 }
+SP_KH_INLINE uint64_t w_rc(uint64_t, uint64_t rc) { return rc; }
+// two independent states at once: word i of both in one 128-bit vector (a generic vector type: inside the AVX-512VL function below the shifts become
+// vprolq and the xor / and-not chains vpternlogq)
+typedef unsigned long long W2 __attribute__((vector_size(16)));
+SP_KH_INLINE W2 w_xor(W2 a, W2 b) { return a ^ b; }
+SP_KH_INLINE W2 w_chi(W2 b0, W2 b1, W2 b2) { return b0 ^ (~b1 & b2); }
+template <int R>
+SP_KH_INLINE W2 w_rol(W2 x) {
+  if constexpr (R == 0) return x;
+  else return (x << R) | (x >> (64 - R));
+}
+SP_KH_INLINE W2 w_rc(W2, uint64_t rc) { return W2{rc, rc}; }
 // lane (X, Y) after rho and pi is lane (x, y) of the input with y = X and 2x + 3y = Y (mod 5), i.e. x = X + 3Y
-template <int X, int Y>
-SP_KH_INLINE uint64_t moved(const uint64_t* a, const uint64_t* d) {
+template <int X, int Y, class W>
+SP_KH_INLINE W moved(const W* a, const W* d) {
   constexpr int x = (X + 3 * Y) % 5, y = X;
-  return rol<RHO[x + 5 * y]>(a[x + 5 * y] ^ d[x]);
+  return w_rol<RHO[x + 5 * y]>(w_xor(a[x + 5 * y], d[x]));
 }
-template <int Y>
-SP_KH_INLINE void plane(const uint64_t* a, const uint64_t* d, uint64_t* e) {
-  const uint64_t b0 = moved<0, Y>(a, d), b1 = moved<1, Y>(a, d), b2 = moved<2, Y>(a, d), b3 = moved<3, Y>(a, d), b4 = moved<4, Y>(a, d);
-  e[0 + 5 * Y] = b0 ^ (~b1 & b2);
-  e[1 + 5 * Y] = b1 ^ (~b2 & b3);
-  e[2 + 5 * Y] = b2 ^ (~b3 & b4);
-  e[3 + 5 * Y] = b3 ^ (~b4 & b0);
-  e[4 + 5 * Y] = b4 ^ (~b0 & b1);
+template <int Y, class W>
+SP_KH_INLINE void plane(const W* a, const W* d, W* e) {
+  const W b0 = moved<0, Y>(a, d), b1 = moved<1, Y>(a, d), b2 = moved<2, Y>(a, d), b3 = moved<3, Y>(a, d), b4 = moved<4, Y>(a, d);
+  e[0 + 5 * Y] = w_chi(b0, b1, b2);
+  e[1 + 5 * Y] = w_chi(b1, b2, b3);
+  e[2 + 5 * Y] = w_chi(b2, b3, b4);
+  e[3 + 5 * Y] = w_chi(b3, b4, b0);
+  e[4 + 5 * Y] = w_chi(b4, b0, b1);
 }
-SP_KH_INLINE void round(const uint64_t* a, uint64_t* e, uint64_t rc) {
-  uint64_t c[5], d[5];
-  for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
-  d[0] = c[4] ^ rol<1>(c[1]);
-  d[1] = c[0] ^ rol<1>(c[2]);
-  d[2] = c[1] ^ rol<1>(c[3]);
-  d[3] = c[2] ^ rol<1>(c[4]);
-  d[4] = c[3] ^ rol<1>(c[0]);
+template <class W>
+SP_KH_INLINE void round(const W* a, W* e, uint64_t rc) {
+  W c[5], d[5];
+  for (int x = 0; x < 5; ++x) c[x] = w_xor(w_xor(w_xor(a[x], a[x + 5]), w_xor(a[x + 10], a[x + 15])), a[x + 20]);
+  d[0] = w_xor(c[4], w_rol<1>(c[1]));
+  d[1] = w_xor(c[0], w_rol<1>(c[2]));
+  d[2] = w_xor(c[1], w_rol<1>(c[3]));
+  d[3] = w_xor(c[2], w_rol<1>(c[4]));
+  d[4] = w_xor(c[3], w_rol<1>(c[0]));
   plane<0>(a, d, e);
   plane<1>(a, d, e);
   plane<2>(a, d, e);
   plane<3>(a, d, e);
   plane<4>(a, d, e);
-  e[0] ^= rc;
+  e[0] = w_xor(e[0], w_rc(e[0], rc));
 }
-SP_KH_INLINE void body(uint64_t a[25]) {
-  uint64_t e[25];
+template <class W>
+SP_KH_INLINE void body(W a[25]) {
+  W e[25];
   for (int r = 0; r < 24; r += 2) {
     round(a, e, RC[r]);
     round(e, a, RC[r + 1]);
   }
 }
-#undef SP_KH_INLINE
 static void permute_generic(uint64_t a[25]) { body(a); }
 __attribute__((target("bmi,bmi2"))) static void permute_bmi(uint64_t a[25]) { body(a); }
 inline void permute(uint64_t a[25]) {
   static void (*const f)(uint64_t*) = (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) ? permute_bmi : permute_generic;
   f(a);
 }
+#if defined(__x86_64__)
+__attribute__((target("avx512f,avx512vl"))) static void permute2_avx512vl(uint64_t a[25], uint64_t b[25]) {
+  W2 s[25];
+  for (int i = 0; i < 25; ++i) s[i] = W2{a[i], b[i]};
+  body(s);
+  for (int i = 0; i < 25; ++i) {
+    a[i] = s[i][0];
+    b[i] = s[i][1];
+  }
+}
+#endif
+// the permutation applied to two independent states
+inline void permute2(uint64_t a[25], uint64_t b[25]) {
+#if defined(__x86_64__)
+  static const bool two_way = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
+  if (two_way) {
+    permute2_avx512vl(a, b);
+    return;
+  }
+#endif
+  permute(a);
+  permute(b);
+}
+#undef SP_KH_INLINE
 }  // namespace keccak_host
 #endif
 SP_HD void keccak_permute(uint64_t a[25]) {
@@ -162,6 +206,28 @@ struct Keccak256State {
     }
 #endif
   }
+#if !defined(__HIP_DEVICE_COMPILE__)
+  // finish() of two states whose last blocks are permuted side by side (host)
+  static void finish2(Keccak256State& x, Keccak256State& y, uint8_t out_x[32], uint8_t out_y[32]) {
+    Keccak256State* st[2] = {&x, &y};
+    for (Keccak256State* k : st) {
+      for (uint32_t i = k->fill; i < 136; ++i) k->buf[i] = 0;
+      k->buf[k->fill] ^= 0x01;
+      k->buf[135] ^= 0x80;
+      for (int i = 0; i < 17; ++i) {
+        uint64_t w;
+        memcpy(&w, k->buf + 8 * i, 8);
+        k->a[i] ^= w;
+      }
+      k->fill = 0;
+    }
+    keccak_host::permute2(x.a, y.a);
+    for (int i = 0; i < 32; ++i) {
+      out_x[i] = (uint8_t)(x.a[i >> 3] >> (8 * (i & 7)));
+      out_y[i] = (uint8_t)(y.a[i >> 3] >> (8 * (i & 7)));
+    }
+  }
+#endif
   SP_HD void finish(uint8_t out[32]) {
     for (uint32_t i = fill; i < 136; ++i) buf[i] = 0;
     buf[fill] ^= 0x01;
@@ -215,8 +281,12 @@ struct Transcript {
     const uint8_t z = 0, o = 1;
     lo.update(&z, 1);
     hi.update(&o, 1);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    Keccak256State::finish2(lo, hi, out, out + 32);
+#else
     lo.finish(out);
     hi.finish(out + 32);
+#endif
   }
   SP_HD void init(const uint8_t* label, size_t n) {  // new (keccak.rs:57-68): state = f("NoTR" || label)
     Keccak256State k;

@@ -2,6 +2,7 @@
 // device compiles, and Keccak-256("") / Keccak-256("abc") against their published digests. Built and run by tests/test_field_host.py.
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 
 #include "../../spartan2_amd/csrc/keccak.hpp"
 
@@ -43,6 +44,59 @@ int main() {
       k.finish(out);
       bad += memcmp(out, ref, 32) != 0;
     }
+  }
+  {  // two states side by side (the two final permutations of a transcript squeeze) against one at a time
+    uint64_t p[25], q[25], p2[25], q2[25];
+    for (int i = 0; i < 25; ++i) {
+      p[i] = p2[i] = (uint64_t)(i + 3) * 0xD1B54A32D192ED03ull;
+      q[i] = q2[i] = ~(uint64_t)i * 0x9E3779B97F4A7C15ull;
+    }
+    for (int it = 0; it < 2000; ++it) {
+      sp::keccak_permute_loop(p);
+      sp::keccak_permute_loop(q);
+      sp::keccak_host::permute2(p2, q2);
+      for (int i = 0; i < 25; ++i) bad += p[i] != p2[i] || q[i] != q2[i];
+    }
+    // and through the transcript: squeeze == the two hashes done one after the other
+    sp::Transcript t;
+    t.init(reinterpret_cast<const uint8_t*>("chk"), 3);
+    uint8_t msg[300];
+    for (int i = 0; i < 300; ++i) msg[i] = (uint8_t)(7 * i + 1);
+    for (int n : {0, 1, 59, 60, 61, 135, 136, 137, 300}) {
+      t.absorb(reinterpret_cast<const uint8_t*>("m"), 1, msg, (size_t)n);
+      sp::Keccak256State base = t.h;
+      uint8_t in[80], want[64], got[64];
+      const uint8_t tag[4] = {'N', 'o', 'D', 'S'};
+      memcpy(in, tag, 4);
+      in[4] = (uint8_t)t.round;
+      in[5] = (uint8_t)(t.round >> 8);
+      memcpy(in + 6, t.state, 64);
+      in[70] = 'c';
+      base.update(in, 71);
+      sp::Keccak256State lo = base, hi = base;
+      const uint8_t z = 0, o = 1;
+      lo.update(&z, 1);
+      hi.update(&o, 1);
+      lo.finish(want);
+      hi.finish(want + 32);
+      bad += !t.squeeze_bytes(reinterpret_cast<const uint8_t*>("c"), 1, got);
+      bad += memcmp(got, want, 64) != 0;
+    }
+  }
+  {  // ns per PAIR of permutations: one after the other, and side by side
+    uint64_t x[25], y[25];
+    for (int i = 0; i < 25; ++i) x[i] = y[i] = i;
+    timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int it = 0; it < 100000; ++it) {
+      sp::keccak_host::permute(x);
+      sp::keccak_host::permute(y);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int it = 0; it < 100000; ++it) sp::keccak_host::permute2(x, y);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    auto ns = [](const timespec& a, const timespec& b) { return ((b.tv_sec - a.tv_sec) * 1e9 + (b.tv_nsec - a.tv_nsec)) / 100000.0; };
+    printf("keccak: two permutations one after the other %.0f ns, side by side %.0f ns (%llx)\n", ns(t0, t1), ns(t1, t2), (unsigned long long)(x[0] ^ y[0]));
   }
   printf("keccak: %d mismatches\n", bad);
   return bad != 0;
