@@ -1283,11 +1283,11 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
         poly.c[2] = tinf;
         absorb_poly(tr->t, poly);
         if (!tr->t.squeeze<S>(lbl_c, 1, &rr[half2])) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+        tail_post_challenge(c, rr[half2], wait_seq + half2);  // (the first at once: the kernel's first bind runs under the second round's host step)
         store_fe(out_r + 4 * (round + half2), rr[half2]);
         store_fe(out_cpolys + 8 * (round + half2), poly.c[0]);
         store_fe(out_cpolys + 8 * (round + half2) + 4, poly.c[2]);
         claim = poly_eval(poly, rr[half2]);
-        tail_post_challenge(c, rr[half2], wait_seq + half2);  // (the first at once: the kernel's first bind runs under the second round's host step)
       }
       // the kernel binds twice and (if rounds are left) evaluates again: its next result is tagged wait_seq + 2
       for (int k = 0; k < 2; ++k) {
@@ -1345,18 +1345,18 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     absorb_poly(tr->t, poly);
     fe_t r_i;
     if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
-    store_fe(out_r + 4 * round, r_i);
-    store_fe(out_cpolys + 8 * round, poly.c[0]);
-    store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
-    claim = poly_eval(poly, r_i);
     last_answered = wait_seq;
     if (issued) {
-      tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this
+      tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this: first, the book-keeping below runs under it
     } else {
       issued = issue(round, &r_i, wait_seq);
       if (issued < 0) return issued;
       if (wait_resident) tail_post_challenge(c, r_i, wait_seq);
     }
+    store_fe(out_r + 4 * round, r_i);
+    store_fe(out_cpolys + 8 * round, poly.c[0]);
+    store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
+    claim = poly_eval(poly, r_i);
     guard.armed = in_tail && round + 1 < rounds;  // the resident kernel now waits for the next challenge
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];
@@ -2075,12 +2075,12 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         absorb_poly(tr->t, poly);
         if (!tr->t.squeeze<S>(lbl_c, 1, &rr[h2])) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
         const size_t ri = rd - 1;
+        tail_post_challenge(c, rr[h2], wait_seq + h2);  // (the first at once: the kernel's first bind runs under the second round's host step)
         store_fe(out_r + 4 * ri, rr[h2]);
         store_fe(out_cpolys + 12 * ri, poly.c[0]);
         store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
         store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
         claim = poly_eval(poly, rr[h2]);
-        tail_post_challenge(c, rr[h2], wait_seq + h2);  // (the first at once: the kernel's first bind runs under the second round's host step)
         eval_eq_left = fe_mul<S>(eval_eq_left, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau_h), rr[h2]), fe_dbl<S>(fe_mul<S>(rr[h2], tau_h))));
       }
       for (int k = 0; k < 2; ++k) {  // the kernel binds twice; its next result (if rounds are left) is tagged wait_seq + 2
@@ -2166,18 +2166,18 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     fe_t r_i;
     if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
     const size_t ri = rnd - 1;
+    last_answered = wait_seq;
+    if (issued) {
+      tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this: first, the book-keeping below runs under it
+    } else {
+      issued = issue(rnd, &r_i, wait_seq);
+      if (issued < 0) return issued;
+    }
     store_fe(out_r + 4 * ri, r_i);
     store_fe(out_cpolys + 12 * ri, poly.c[0]);
     store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
     store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
     claim = poly_eval(poly, r_i);
-    last_answered = wait_seq;
-    if (issued) {
-      tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this
-    } else {
-      issued = issue(rnd, &r_i, wait_seq);
-      if (issued < 0) return issued;
-    }
     guard.armed = in_tail && rnd < ell;  // the resident kernel now waits for the next challenge
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];

@@ -134,10 +134,16 @@ __device__ __forceinline__ bool mail_wait(const unsigned* mail, const unsigned* 
     unsigned long long next_mirror = t0 + MAIL_MIRROR_AFTER_TICKS;
     int good = 0, aborted = 0, from_mirror = 0;
     unsigned w = 0, wdev = 0;
-    while (true) {
+    for (unsigned it = 0;; ++it) {
       if (lane < 13) w = __hip_atomic_load(line + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      int st = mail_line_state(w, want, lane);
-      if (st == 0 && mline) {
+      // the poll that finds nothing must be short - its period is the delay between the host's store and the kernel's start: two lane reads decide
+      // "not this challenge yet" (the sequence words, the abort word); the check sums are only formed for a line that carries the right sequence
+      // number, and the wall clock (mirror path, watchdog) is read every 16th time
+      int st = 0;
+      if (__builtin_amdgcn_readlane((int)w, 12) != 0 || ((unsigned)__builtin_amdgcn_readlane((int)w, 8) == want && (unsigned)__builtin_amdgcn_readlane((int)w, 11) == want))
+        st = mail_line_state(w, want, lane);
+      const bool tick = (it & 15u) == 15u;
+      if (st == 0 && mline && tick) {
         const unsigned long long now = wall_clock64();
         if (now >= next_mirror) {  // the second path: the same line in host memory
           wdev = w;
@@ -159,8 +165,7 @@ __device__ __forceinline__ bool mail_wait(const unsigned* mail, const unsigned* 
         good = 1;
         break;
       }
-      if (wall_clock64() - t0 > MAIL_WATCHDOG_TICKS) break;  // the host went away: never hang the device
-      __builtin_amdgcn_s_sleep(1);
+      if (tick && wall_clock64() - t0 > MAIL_WATCHDOG_TICKS) break;  // the host went away: never hang the device
     }
     if (lane < 8) r_smem->v[lane] = w;
     if (mline && lane == 0 && (from_mirror || (!good && !aborted))) {  // diagnostics (device memory: atomics are fine there)
@@ -959,6 +964,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   __shared__ fe_t smem[16];
   __shared__ fe_t r_sh;
   __shared__ slot_chk chk_sh[TAIL_WIDE_VALS];
+  // the elements a step has just bound, for its own evaluation (a block evaluates exactly the pairs it bound): table t at [t * 2 qb, ..), the low
+  // elements x = base + e first, then their partners x = q + base + e. They go to memory as well - the next step's bind reads them from there.
+  __shared__ fe_t bound[(CUBIC ? 3 : 2) * 2 * (unsigned)WQ];
   const unsigned long long base = (unsigned long long)blockIdx.x * WQ;
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
@@ -1018,6 +1026,19 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     }
     const unsigned long long q = len / 4;
     if (len > 2 ? base >= q : blockIdx.x != 0) return;
+    // the weight of this lane's product does not depend on the challenge: fetched (and, in the first-half rounds, multiplied together) before the wait
+    fe_t w_pre = fe_zero();
+    if (CUBIC && len > 2) {
+      const unsigned qb_p = (unsigned)(q - base < WQ ? q - base : WQ);
+      if (tail_double(CUBIC, len / 2)) {
+        const unsigned qd_p = (unsigned)(len / 8), seg_p = qd_p < 64 ? 64u : qd_p, g_p = threadIdx.x / seg_p, i_p = threadIdx.x % seg_p;
+        if (g_p < 9 && i_p < qd_p) w_pre = weight(rnd + 1, i_p);
+        else if (g_p < 15 && i_p < qd_p) w_pre = weight(rnd, i_p + ((g_p - 9) & 1u) * qd_p);
+      } else {
+        const unsigned seg_p = qb_p < 64 ? 64u : qb_p, wh_p = threadIdx.x / seg_p, i_p = threadIdx.x % seg_p;
+        if (wh_p < (unsigned)NACC && i_p < qb_p) w_pre = weight(rnd, base + i_p);
+      }
+    }
     SP_TT(0);
     if (!have_r && (!first || a.r0_from_mail)) {
       if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 1, &r_sh)) return;
@@ -1057,7 +1078,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       const unsigned t = idx / (2 * qb), e = idx % (2 * qb);
       fe_t* Z = t == 0 ? a.A : (t == 1 ? a.B : a.C);
       const unsigned long long x = e < qb ? base + e : q + base + (e - qb);
-      Z[x] = foreign ? bind1(load_agent(Z + x), load_agent(Z + x + 2 * q), r) : bind1(Z[x], Z[x + 2 * q], r);
+      const fe_t v = foreign ? bind1(load_agent(Z + x), load_agent(Z + x + 2 * q), r) : bind1(Z[x], Z[x + 2 * q], r);
+      Z[x] = v;
+      bound[idx] = v;  // = bound[t * 2 qb + e]
     }
     __syncthreads();
     SP_TT(2);
@@ -1077,9 +1100,10 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       if (grp < NGRP && il < qd) {
         if (!CUBIC || grp < 9) {
           // (every case loads only the quarters it uses: all twelve at once would not fit the 128 registers of a 1024-thread block)
-          auto qa = [&](unsigned k) { return a.A[il + k * qd]; };
-          auto qb2 = [&](unsigned k) { return a.B[il + k * qd]; };
-          auto qc = [&](unsigned k) { return a.C[il + k * qd]; };
+          // (one block here: base = 0, q = qb = 2 qd, so element x of table t is bound[t * 2 qb + x])
+          auto qa = [&](unsigned k) { return bound[il + k * qd]; };
+          auto qb2 = [&](unsigned k) { return bound[2 * qb + il + k * qd]; };
+          auto qc = [&](unsigned k) { return bound[4 * qb + il + k * qd]; };
           auto prod_diff = [&](unsigned hi, unsigned lo) { return fe_mul<S>(fe_sub<S>(qa(hi), qa(lo)), fe_sub<S>(qb2(hi), qb2(lo))); };  // (a_hi - a_lo)(b_hi - b_lo)
           auto prod_2m = [&](unsigned k0, unsigned k1) {  // (2 a_k0 - a_k1)(2 b_k0 - b_k1)
             return fe_mul<S>(fe_sub<S>(fe_dbl<S>(qa(k0)), qa(k1)), fe_sub<S>(fe_dbl<S>(qb2(k0)), qb2(k1)));
@@ -1109,15 +1133,15 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
                 break;
               default: v = fe_sub<S>(prod_2m(2, 3), fe_sub<S>(fe_dbl<S>(qc(2)), qc(3))); break;
             }
-            v = fe_mul<S>(weight(rnd + 1, il), v);
+            v = fe_mul<S>(w_pre, v);
           }
         } else {  // cubic, this round's own three sums over the 2 qd pairs (x, x + n / 2): groups 9.. in pairs (low x, high x)
           const unsigned k = (grp - 9) / 2, x = il + ((grp - 9) & 1u) * qd, hn = 2 * qd;
-          const fe_t a0 = a.A[x], a1 = a.A[x + hn], b0 = a.B[x], b1 = a.B[x + hn], c0 = a.C[x], c1 = a.C[x + hn];
+          const fe_t a0 = bound[x], a1 = bound[x + hn], b0 = bound[2 * qb + x], b1 = bound[2 * qb + x + hn], c0 = bound[4 * qb + x], c1 = bound[4 * qb + x + hn];
           if (k == 0) v = fe_sub<S>(fe_mul<S>(a0, b0), c0);
           else if (k == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
           else v = fe_sub<S>(fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1)), fe_sub<S>(fe_dbl<S>(c0), c1));
-          v = fe_mul<S>(weight(rnd, x), v);
+          v = fe_mul<S>(w_pre, v);
         }
       }
       v = wave_sum_low(v, qd);  // (qd is a power of two; lanes il >= qd hold zero)
@@ -1158,16 +1182,15 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     const unsigned which = threadIdx.x / seg, il = threadIdx.x % seg;
     fe_t v = fe_zero();
     if (which < (unsigned)NACC && il < qb) {
-      const unsigned long long id = base + il;
-      const fe_t a0 = a.A[id], a1 = a.A[id + q], b0 = a.B[id], b1 = a.B[id + q];
+      const fe_t a0 = bound[il], a1 = bound[qb + il], b0 = bound[2 * qb + il], b1 = bound[3 * qb + il];
       if (which == 0) v = fe_mul<S>(a0, b0);
       else if (which == 1) v = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
       else v = fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1));
       if (CUBIC) {
-        const fe_t c0 = a.C[id], c1 = a.C[id + q];
+        const fe_t c0 = bound[4 * qb + il], c1 = bound[5 * qb + il];
         if (which == 0) v = fe_sub<S>(v, c0);
         else if (which == 2) v = fe_sub<S>(v, fe_sub<S>(fe_dbl<S>(c0), c1));
-        v = fe_mul<S>(weight(rnd, id), v);
+        v = fe_mul<S>(w_pre, v);
       }
     }
     SP_TT(3);
