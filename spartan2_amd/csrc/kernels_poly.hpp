@@ -23,7 +23,7 @@ __device__ __forceinline__ void publish_result(fe_t* result, unsigned seq) {
 // Block partials of an evaluation launch. Up to HOST_SUM_MAX_BLOCKS blocks: every block writes its NACC sums and the sequence number into its own
 // 128-byte slot of the mapped pinned buffer and the HOST adds them (a few dozen 256-bit additions) — no second-stage launch on the per-round
 // critical path. Larger grids store to device memory for k_sum_partials.
-constexpr int HOST_SUM_MAX_BLOCKS = 256;
+constexpr int HOST_SUM_MAX_BLOCKS = 64;
 constexpr int SLOT_BASE_ELEM = 64;  // element index of slot 0 in the mapped buffer; slot b = 4 elements: sums[0..3), word 0 of the 4th = sequence
 // A slot is self-validating: element 3 carries the sequence number TWICE (words 0 and 3) and two independent check words over the data
 // (word 1 = sequence + plain sum, word 2 = sequence * K + position-weighted sum), so the host accepts a slot only when all of it has landed,
