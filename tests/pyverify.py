@@ -267,12 +267,100 @@ def parse_proof(words, rows_shared, rows_pre, rows_rest, num_public, num_challen
     return pr
 
 
-def verify(inst, ck, h, ck_s, h_s, words, layout, vk_digest=None):
+class _ByteReader:
+    """bincode DefaultOptions + little-endian + fixint (src/digest.rs:33-41), reading side: u64 lengths, 32-byte little-endian field elements (canonical
+    or rejected), projective points as x | y | z (any representative; z = 0 the identity)"""
+
+    def __init__(self, data: bytes):
+        self.d, self.o = memoryview(data), 0
+
+    def take(self, n):
+        if self.o + n > len(self.d):
+            raise VerifyError("proof bytes: truncated")
+        out = bytes(self.d[self.o:self.o + n])
+        self.o += n
+        return out
+
+    def u8(self):
+        return self.take(1)[0]
+
+    def u64(self):
+        return int.from_bytes(self.take(8), "little")
+
+    def fe(self, modulus):
+        v = int.from_bytes(self.take(32), "little")
+        if v >= modulus:
+            raise VerifyError("proof bytes: non-canonical field element")
+        return v
+
+    def scalar(self):
+        return self.fe(Q)
+
+    def scalars(self):
+        n = self.u64()
+        if n > (len(self.d) - self.o) // 32:
+            raise VerifyError("proof bytes: vector length exceeds the input")
+        return [self.scalar() for _ in range(n)]
+
+    def point(self):
+        x, y, z = self.fe(P), self.fe(P), self.fe(P)
+        if z == 0:
+            return None
+        zi = pow(z, -1, P)
+        return (x * zi * zi % P, y * zi * zi * zi % P)
+
+    def commitment(self):
+        n = self.u64()
+        if n > (len(self.d) - self.o) // 96:
+            raise VerifyError("proof bytes: vector length exceeds the input")
+        return [self.point() for _ in range(n)]
+
+    def option_commitment(self):
+        tag = self.u8()
+        if tag > 1:
+            raise VerifyError("proof bytes: Option tag")
+        return self.commitment() if tag else []
+
+    def sumcheck(self):
+        n = self.u64()
+        if n > (len(self.d) - self.o) // 8:
+            raise VerifyError("proof bytes: vector length exceeds the input")
+        return [self.scalars() for _ in range(n)]
+
+
+def parse_proof_bytes(data: bytes):
+    """SpartanSNARK { U: SplitR1CSInstance { comm_W_shared, comm_W_precommitted, comm_W_rest, public_values, challenges }, sc_proof_outer, claims_outer,
+    sc_proof_inner, eval_W, blind_eval_W, eval_arg: HyraxEvaluationArgument { ipa { delta, beta, z_vec, z_delta, z_beta } } } (src/spartan.rs:125-137,
+    src/r1cs/mod.rs:1423-1437) from its bincode bytes"""
+    rd = _ByteReader(data)
+    pr = {"comm_shared": rd.option_commitment(), "comm_pre": rd.option_commitment(), "comm_rest": rd.commitment(), "public": rd.scalars(), "challenges": rd.scalars(),
+          "outer": rd.sumcheck()}
+    pr["claims_outer"] = [rd.scalar() for _ in range(3)]
+    pr["inner"] = rd.sumcheck()
+    pr["eval_W"] = rd.scalar()
+    blind = rd.scalars()  # HyraxBlind { blind: Vec<Scalar> }, one row
+    if len(blind) != 1:
+        raise VerifyError("proof bytes: blind_eval_W must have one entry")
+    pr["blind_eval_W"] = blind[0]
+    pr["delta"], pr["beta"] = rd.point(), rd.point()
+    pr["z_vec"] = rd.scalars()
+    pr["z_delta"], pr["z_beta"] = rd.scalar(), rd.scalar()
+    if rd.o != len(data):
+        raise VerifyError("proof bytes: trailing bytes")
+    return pr
+
+
+def verify_bytes(inst, ck, h, ck_s, h_s, data: bytes, vk_digest=None):
+    """SpartanSNARK::verify of a proof given as the reference's bincode bytes"""
+    return verify(inst, ck, h, ck_s, h_s, None, None, vk_digest=vk_digest, parsed=parse_proof_bytes(data))
+
+
+def verify(inst, ck, h, ck_s, h_s, words, layout, vk_digest=None, parsed=None):
     """SpartanSNARK::verify. `vk_digest`: the 32 digest bytes, or None to recompute them (tests/pywire.py spartan_vk_digest)."""
     dims, mats, _ = pywire.pad_shape(inst)
     ck_pts = [_pt(w) for w in np.asarray(ck, dtype=np.uint64).reshape(-1, 8)]
     h_pt, cks_pt, hs_pt = _pt(np.asarray(h, dtype=np.uint64)), _pt(np.asarray(ck_s, dtype=np.uint64).reshape(-1)[:8]), _pt(np.asarray(h_s, dtype=np.uint64))
-    pr = parse_proof(words, **layout)
+    pr = parsed if parsed is not None else parse_proof(words, **layout)
     for name in ("comm_shared", "comm_pre", "comm_rest"):
         if not all(on_curve(p_) for p_ in pr[name]):
             raise VerifyError(f"{name}: not on the curve")

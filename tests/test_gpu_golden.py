@@ -74,6 +74,7 @@ def test_spartan_proof_against_golden(ctx):
     lay = dict(rows_shared=lay["rows_shared"], rows_pre=lay["rows_precommitted"], rows_rest=lay["rows_rest"], num_public=lay["num_public"],
                num_challenges=lay["num_challenges"], lx=lay["rounds_x"], ly=lay["rounds_y"], nz=lay["z_len"])
     assert pyverify.verify(inst, g[:2048], g[2048], g_s[0], g_s[1], words, lay) == [int(v) for v in inst.publics]
+    assert pyverify.verify_bytes(inst, g[:2048], g[2048], g_s[0], g_s[1], wire) == [int(v) for v in inst.publics]  # from the product's bincode bytes
     bad = words.copy()
     bad[-1] ^= np.uint64(1)
     with pytest.raises(pyverify.VerifyError):

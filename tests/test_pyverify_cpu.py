@@ -41,6 +41,27 @@ def test_oracle_proofs_pass_the_python_verifier(name):
     assert pv.verify(inst, ck, h, ck_s, h_s, words, lay, vk_digest=dig.tobytes()) == publics
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_python_verifier_reads_the_wire_bytes(name):
+    """the proof as the reference's bincode bytes (oracle writer) read back by an independent Python reader and verified: pins the byte layout in the
+    reading direction too, and the parsed fields equal the ones taken from the flat words"""
+    inst = CASES[name]()
+    sp, words = _prove(inst, 3)
+    ck, h, ck_s, h_s, dig = sp.export_keys()
+    data = sp.proof_to_bytes(words)
+    assert pv.parse_proof_bytes(data) == pv.parse_proof(words, **_layout(sp))
+    assert pv.verify_bytes(inst, ck, h, ck_s, h_s, data, vk_digest=dig.tobytes()) == [int(v) for v in inst.publics]
+    for cut in (1, 33, len(data) // 2):
+        with pytest.raises(pv.VerifyError):
+            pv.verify_bytes(inst, ck, h, ck_s, h_s, data[:-cut], vk_digest=dig.tobytes())
+    bad = bytearray(data)
+    bad[-32:] = pywire.P_SCALAR.to_bytes(32, "little")  # z_beta := p: not canonical
+    with pytest.raises(pv.VerifyError, match="non-canonical"):
+        pv.verify_bytes(inst, ck, h, ck_s, h_s, bytes(bad), vk_digest=dig.tobytes())
+    with pytest.raises(pv.VerifyError):
+        pv.verify_bytes(inst, ck, h, ck_s, h_s, data + b"\x00", vk_digest=dig.tobytes())
+
+
 def test_python_verifier_rejects_what_the_reference_rejects():
     """one flipped bit per proof section: each is caught by the check the reference would fail at (spartan.rs:511-514, :548-551; ipa.rs:200-217)"""
     inst = CASES["all_three_segments"]()
