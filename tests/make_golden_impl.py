@@ -79,6 +79,25 @@ def spartan_small():
             "vk_digest": sp.export_keys()[4].tobytes().hex(), "wire_len": len(wire), "wire_sha256": hashlib.sha256(wire).hexdigest(), "wire_head": wire[:64].hex()}
 
 
+def neutronnova_small():
+    """One NeutronNovaZkSNARK proof: three step circuits of 8 groups and a core circuit of 2 groups (so SplitR1CSShape::equalize is in the path), seeded
+    tape. Pins the vk digest (keys | equalized shapes | verifier-circuit shapes), the proof words and their bincode bytes."""
+    from spartan2_amd import frontend
+
+    steps = [frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=50 + i) for i in range(3)]
+    core = frontend.synthetic_circuit(2, 0xA5, num_public=1, witness_seed=7)
+    tape = np.frombuffer(hashlib.shake_256(b"golden-tape-nn").digest(64 * 32768), dtype=np.uint8).reshape(32768, 64).copy()
+    nn = ol.OracleNeutronNova(steps, core)
+    words, used, _ = nn.prove(tape)
+    assert nn.verify_words(words) == 0
+    wire = nn.proof_to_bytes(words)
+    return {"note": "oracle proof (oracle/neutronnova_zk.hpp) of 3 x synthetic_circuit(8, 0xA5, 1, witness_seed 50 + i) + core synthetic_circuit(2, 0xA5, 1, witness_seed 7), "
+                    "tape = SHAKE256('golden-tape-nn'); vk_digest = SHA-256 over NeutronNovaVerifierKey::write_bytes, wire_* = the proof as bincode bytes",
+            "info": nn.info, "tape_blocks": [int(used[0]), int(used[1])], "proof_words": len(words), "proof_sha256": hashlib.sha256(words.tobytes()).hexdigest(),
+            "proof_head": _hex(words[:64]), "proof_tail": _hex(words[-16:]), "vk_digest": nn.digest().tobytes().hex(), "wire_len": len(wire),
+            "wire_sha256": hashlib.sha256(wire).hexdigest()}
+
+
 # ---- NeutronNova NIFS rounds (oracle/nifs.hpp) -----------------------------------------------------------------------------------
 def nifs_inputs(n_inst, num_cons):
     """Layers with SHA-like small entries (A in {-2..2}, B bits, C = A o B) and a few full-size ones; E from a SHAKE-derived tau."""

@@ -118,3 +118,29 @@ def test_nifs_rounds_against_golden(ctx):
             for name, tab in (("A", oa), ("B", ob), ("C", oc)):
                 assert hashlib.sha256(tab.read(0, total).tobytes()).hexdigest() == case[name + "_sha256"], name
             nifs.free()
+
+
+def test_neutronnova_proof_against_golden(ctx):
+    """NeutronNovaZkSNARK on the device-backed driver against frozen data (no oracle in the process): vk digest - which covers the equalized step / core
+    shapes and the verifier circuit's matrices -, tape use, proof words and their bincode bytes; its own verifier accepts words and bytes."""
+    with open(os.path.join(GOLD, "neutronnova_small.json")) as f:
+        gold = json.load(f)
+    steps = [frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=50 + i) for i in range(3)]
+    core = frontend.synthetic_circuit(2, 0xA5, num_public=1, witness_seed=7)
+    tape = np.frombuffer(hashlib.shake_256(b"golden-tape-nn").digest(64 * 32768), dtype=np.uint8).reshape(32768, 64).copy()
+    nn = host.NeutronNovaZkSNARK(ctx, steps, core)
+    assert nn.info == gold["info"] and nn.vk_digest.tobytes().hex() == gold["vk_digest"]
+    used0 = nn.prep_prove(tape)
+    for reference_order in (False, True):
+        words, used1, _ = nn.prove(tape[used0:], reference_order=reference_order)
+        assert [used0, used1] == gold["tape_blocks"] and len(words) == gold["proof_words"]
+        assert hashlib.sha256(words.tobytes()).hexdigest() == gold["proof_sha256"]
+        assert words[:64].tobytes().hex() == gold["proof_head"] and words[-16:].tobytes().hex() == gold["proof_tail"]
+        if not reference_order:
+            nn.close()
+            nn = host.NeutronNovaZkSNARK(ctx, steps, core)  # (a prove rerandomizes the prep state in place: the second driver starts from a fresh one)
+            assert nn.prep_prove(tape) == used0
+    wire = nn.proof_to_bytes(words)
+    assert len(wire) == gold["wire_len"] and hashlib.sha256(wire).hexdigest() == gold["wire_sha256"]
+    assert nn.verify(words) == 0 and nn.verify_bytes(wire) == 0
+    nn.close()

@@ -73,3 +73,16 @@ def test_the_row_order_is_part_of_the_digest():
         assert p0 == p1
         for r in range(len(p0) - 1):
             assert sorted(zip(i0[p0[r]:p0[r + 1]], d0[p0[r]:p0[r + 1]])) == sorted(zip(i1[p1[r]:p1[r + 1]], d1[p1[r]:p1[r + 1]]))
+
+
+def test_golden_neutronnova_digest_recomputed_in_python(gens):
+    """the frozen vk digest of tests/golden/neutronnova_small.json (which the GPU suite holds the product to, without the oracle) is the SHA-256 that the
+    Python synthesis + Python equalize + Python framing produce"""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "neutronnova_small.json")) as f:
+        gold = json.load(f)
+    steps0 = frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=50)
+    core = frontend.synthetic_circuit(2, 0xA5, num_public=1, witness_seed=7)
+    assert pvc.nn_vk_digest(steps0, core, 3, gens)[0].hex() == gold["vk_digest"]
