@@ -15,7 +15,8 @@
 // vc witness layout and every commitment). bellpepper's AllocatedNum::{mul, square, inputize} are restated as: allocate, then one constraint.
 // PARITY UNPINNED against the reference: no golden vector of this wrapper exists in the reference tree and the reference cannot be run here. What
 // holds it in place is the restated verifier (prove -> verify accepts, tampering is rejected) and the pinned pieces underneath (transcript,
-// sum-checks, NIFS rounds, Hyrax: oracle/spartan.hpp, oracle/nifs.hpp).
+// sum-checks, NIFS rounds, Hyrax: oracle/spartan.hpp, oracle/nifs.hpp), and since round 4 two Python-integer restatements that share no code with this
+// file: tests/pyvcircuit.py (the verifier circuit's matrices, through the vk digest) and tests/pynnverify.py (NeutronNovaZkSNARK::verify end to end).
 // The vk digest is the reference's SHA-256 over NeutronNovaVerifierKey::write_bytes (src/neutronnova_zk.rs:1305-1333; wire.hpp states the one
 // third-party layout assumption inside it).
 #pragma once
@@ -650,6 +651,8 @@ inline void nn_vk_digest(const NNKey& k, uint8_t out[32]) {
 }
 inline std::unique_ptr<NNKey> nn_setup(SplitR1CSShape<Fq> S_step, SplitR1CSShape<Fq> S_core, size_t num_steps) {  // :1394-1475
   auto pk = std::make_unique<NNKey>();
+  // zero NIFS rounds: the reference's verifier circuit indexes prior_round_vars[round_index - 1] at round 0 (src/zk.rs:637-641) and setup panics
+  if (num_steps < 2) throw std::runtime_error("NeutronNova oracle: at least two step circuits");
   SplitR1CSShape<Fq>::equalize(S_step, S_core);  // :1413
   // equalize leaves the shared and precommitted segments as they are: this restatement lays out one proof for "a step or the core" and needs them
   // equal (they are whenever both circuits fill the same number of 2048-wide rows per segment; constraint counts and padding variables may differ)

@@ -177,6 +177,9 @@ static NNZkKey* nn_setup(sp_ctx* ctx, const R1CSIntView& Rs, const R1CSIntView& 
   try {
     pk->ctx = ctx;
     pk->num_steps = num_steps;
+    // one step means zero NIFS rounds, and the reference's verifier circuit then reads prior_round_vars[round_index - 1] at round 0 (src/zk.rs:637-641):
+    // NeutronNovaZkSNARK::setup panics there, this driver refuses
+    if (num_steps < 2) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: at least two step circuits (the verifier circuit has no NIFS round to take its claim from)");
     PaddedShape Ps = pad_shape(Rs), Pc = pad_shape(Rc);
     equalize(Ps, Pc);  // src/neutronnova_zk.rs:1413
     // equalize leaves the shared and precommitted segments alone; this driver lays out one proof for "a step or the core" and needs them equal

@@ -237,6 +237,49 @@ def sparse_poly_evaluate(num_vars, Z, r):  # SparsePolynomial::evaluate (multili
     return common * part % Q
 
 
+def matrix_evals(mats, num_cons, T_x, T_y):
+    """sum over the entries of A[i][j] * T_x[i] * T_y[j], per matrix (data, column indices, row pointers)"""
+    evals = []
+    for data, cols, ptr in mats:
+        acc = 0
+        for row in range(num_cons):
+            lo, hi = ptr[row], ptr[row + 1]
+            if hi > lo:
+                acc += T_x[row] * (sum(int(data[k]) * T_y[int(cols[k])] for k in range(lo, hi)) % Q)
+        evals.append(acc % Q)
+    return evals
+
+
+def hyrax_verify(tr, ck_pts, h_pt, cks_pt, hs_pt, comm, point, comm_eval, ipa):
+    """PCS::verify (hyrax_pc.rs:480-531) + InnerProductArgumentLinear::verify (ipa.rs:173-221). comm: the row commitments (affine); comm_eval: the
+    commitment to the evaluation (Jacobian); ipa: dict(delta, beta, z_vec, z_delta, z_beta); cks_pt / hs_pt: the evaluation key's first generator and h."""
+    tr.absorb(b"poly_com", commitment_bytes(comm))
+    n, num_cols = 1 << len(point), len(ck_pts)
+    num_rows = -(-n // num_cols)
+    nvr = num_rows.bit_length() - 1
+    if nvr == 0:
+        R, comm_LZ = eq_evals(point), to_jac(comm[0])
+    else:
+        L, R = eq_evals(point[:nvr]), eq_evals(point[nvr:])
+        if len(comm) < len(L):
+            raise VerifyError("commitment: fewer rows than the point addresses")
+        comm_LZ = msm(L, comm[:len(L)])
+    tr.dom_sep(b"inner product argument (linear)")
+    tr.absorb(b"U", point_bytes(to_aff(comm_LZ)) + point_bytes(to_aff(comm_eval)))
+    tr.absorb(b"delta", point_bytes(ipa["delta"]))
+    tr.absorb(b"beta", point_bytes(ipa["beta"]))
+    rr = tr.squeeze(b"r")
+    z = ipa["z_vec"]
+    if len(z) != len(R) or num_cols < len(z):
+        raise VerifyError("inner product argument: length of z_vec")
+    lhs = jadd(smul(to_aff(comm_LZ), rr), to_jac(ipa["delta"]))
+    if not jeq(lhs, jadd(msm(z, ck_pts[:len(z)]), smul(h_pt, ipa["z_delta"]))):
+        raise VerifyError("inner product argument: first equation")
+    ip = sum(a * b for a, b in zip(z, R)) % Q
+    if not jeq(jadd(smul(to_aff(comm_eval), rr), to_jac(ipa["beta"])), jadd(smul(cks_pt, ip), smul(hs_pt, ipa["z_beta"]))):
+        raise VerifyError("inner product argument: second equation")
+
+
 # ---- the proof ------------------------------------------------------------------------------------------------------------------------------------
 def _pt(words):
     x, y = pywire._canon(words[:4], P), pywire._canon(words[4:8], P)
@@ -400,42 +443,10 @@ def verify(inst, ck, h, ck_s, h_s, words, layout, vk_digest=None, parsed=None):
     claim_inner_final, r_y = sumcheck_verify(tr, (cA + r * cB + r * r * cC) % Q, ly, 2, pr["inner"])
     eval_X = sparse_poly_evaluate(ly - 1, [1] + X, r_y[1:])
     eval_Z = ((1 - r_y[0]) * pr["eval_W"] + r_y[0] * eval_X) % Q
-    T_x, T_y = eq_evals(r_x), eq_evals(r_y)
-    evals = []
-    for data, cols, ptr in mats:
-        acc = 0
-        for row in range(dims["num_cons"]):
-            lo, hi = ptr[row], ptr[row + 1]
-            if hi > lo:
-                acc += T_x[row] * (sum(int(data[k]) * T_y[int(cols[k])] for k in range(lo, hi)) % Q)
-        evals.append(acc % Q)
+    evals = matrix_evals(mats, dims["num_cons"], eq_evals(r_x), eq_evals(r_y))
     if claim_inner_final != (evals[0] + r * evals[1] + r * r * evals[2]) * eval_Z % Q:
         raise VerifyError("inner sum-check: final claim")
     # PCS::verify (hyrax_pc.rs:480-531) of comm_W at r_y[1..] against commit(ck_s, [eval_W], blind_eval_W)
     comm_eval = jadd(smul(cks_pt, pr["eval_W"]), smul(hs_pt, pr["blind_eval_W"]))
-    tr.absorb(b"poly_com", commitment_bytes(comm_W))
-    point = r_y[1:]
-    n, num_cols = 1 << len(point), len(ck_pts)
-    num_rows = -(-n // num_cols)
-    nvr = num_rows.bit_length() - 1
-    if nvr == 0:
-        R, comm_LZ = eq_evals(point), to_jac(comm_W[0])
-    else:
-        L, R = eq_evals(point[:nvr]), eq_evals(point[nvr:])
-        comm_LZ = msm(L, comm_W[:len(L)])
-    # InnerProductArgumentLinear::verify (ipa.rs:173-221)
-    tr.dom_sep(b"inner product argument (linear)")
-    tr.absorb(b"U", point_bytes(to_aff(comm_LZ)) + point_bytes(to_aff(comm_eval)))
-    tr.absorb(b"delta", point_bytes(pr["delta"]))
-    tr.absorb(b"beta", point_bytes(pr["beta"]))
-    rr = tr.squeeze(b"r")
-    z = pr["z_vec"]
-    if len(z) != len(R) or num_cols < len(z):
-        raise VerifyError("inner product argument: length of z_vec")
-    lhs = jadd(smul(to_aff(comm_LZ), rr), to_jac(pr["delta"]))
-    if not jeq(lhs, jadd(msm(z, ck_pts[:len(z)]), smul(h_pt, pr["z_delta"]))):
-        raise VerifyError("inner product argument: first equation")
-    ip = sum(a * b for a, b in zip(z, R)) % Q
-    if not jeq(jadd(smul(to_aff(comm_eval), rr), to_jac(pr["beta"])), jadd(smul(cks_pt, ip), smul(hs_pt, pr["z_beta"]))):
-        raise VerifyError("inner product argument: second equation")
+    hyrax_verify(tr, ck_pts, h_pt, cks_pt, hs_pt, comm_W, r_y[1:], comm_eval, pr)
     return pr["public"]

@@ -143,4 +143,8 @@ def test_neutronnova_proof_against_golden(ctx):
     wire = nn.proof_to_bytes(words)
     assert len(wire) == gold["wire_len"] and hashlib.sha256(wire).hexdigest() == gold["wire_sha256"]
     assert nn.verify(words) == 0 and nn.verify_bytes(wire) == 0
+    import pynnverify  # NeutronNovaZkSNARK::verify in Python integers (no oracle, no product code beyond the generators)
+
+    pubs = pynnverify.verify_bytes(steps[0], core, len(steps), host.from_label(b"ck", 2049), wire)
+    assert pubs == ([[int(v) for v in s.publics] for s in steps], [int(v) for v in core.publics])
     nn.close()

@@ -65,7 +65,14 @@ def test_step_and_core_shapes_of_different_size(ctx, n, groups, core_groups):
     assert (got == want).all()
     assert onn.verify_words(got) == 0 and gnn.verify(got) == 0
     assert gnn.proof_to_bytes(got) == onn.proof_to_bytes(want) and gnn.verify_bytes(gnn.proof_to_bytes(got)) == 0
+    # ... and a third verifier, Python integers written from the reference's verify alone (tests/pynnverify.py), accepts the product's bytes
+    import pynnverify
+
+    pubs = pynnverify.verify_bytes(steps[0], core, n, host.from_label(b"ck", 2049), gnn.proof_to_bytes(got))
+    assert pubs == ([[int(v) for v in s.publics] for s in steps], [int(v) for v in core.publics])
     gnn.close()
+    with pytest.raises(Exception, match="at least two step circuits"):  # zero NIFS rounds: the reference's setup panics (src/zk.rs:637-641)
+        host.NeutronNovaZkSNARK(ctx, steps[:1], core)
     ref = host.NeutronNovaZkSNARK(ctx, steps, core)
     assert ref.prep_prove(tape) == used[0]
     again, _, _ = ref.prove(tape[used[0]:], reference_order=True)

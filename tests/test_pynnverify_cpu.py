@@ -1,0 +1,131 @@
+"""CPU: proofs of the oracle's NeutronNovaZkSNARK prover verified by an independent Python-integer restatement of NeutronNovaZkSNARK::verify
+(tests/pynnverify.py, written from src/neutronnova_zk.rs:2095-2343, src/nifs.rs, src/spartan_relaxed.rs, src/r1cs/folds.rs and hyrax_pc.rs): the verifier key
+digest, the step / core shapes, the verifier circuit's matrices and every verifier equation are recomputed in Python from the circuits and the generators."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import pynnverify as pnv
+from pyverify import Q, VerifyError
+from spartan2_amd import frontend
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gens():
+    g = np.zeros((2049, 8), dtype=np.uint64)
+    ol.lib().orc_from_label(b"ck", ctypes.c_size_t(2049), ol.p64(g))
+    return g
+
+
+def _tape(label, blocks=32768):
+    return np.frombuffer(hashlib.shake_256(label).digest(64 * blocks), dtype=np.uint8).reshape(blocks, 64).copy()
+
+
+@pytest.fixture(scope="module")
+def golden_case(gens):
+    """the case of tests/golden/neutronnova_small.json: three steps, a smaller core"""
+    steps = [frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=50 + i) for i in range(3)]
+    core = frontend.synthetic_circuit(2, 0xA5, num_public=1, witness_seed=7)
+    nn = ol.OracleNeutronNova(steps, core)
+    words, _, _ = nn.prove(_tape(b"golden-tape-nn"))
+    return steps, core, nn, words, nn.proof_to_bytes(words)
+
+
+def test_python_verifier_accepts_the_golden_proof(gens, golden_case):
+    steps, core, nn, words, wire = golden_case
+    with open(os.path.join(GOLD, "neutronnova_small.json")) as f:
+        gold = json.load(f)
+    assert hashlib.sha256(wire).hexdigest() == gold["wire_sha256"]  # the bytes the GPU suite holds the product to
+    pub_steps, pub_core = pnv.verify_bytes(steps[0], core, len(steps), gens, wire)  # digest recomputed in Python
+    assert pub_steps == [[int(v) for v in s.publics] for s in steps] and pub_core == [int(v) for v in core.publics]
+    assert nn.verify_words(words) == 0
+
+
+def test_python_verifier_rejects_what_the_oracle_rejects(gens, golden_case):
+    """a scalar changed at several depths of the proof: both verifiers refuse it"""
+    steps, core, nn, words, wire = golden_case
+    pr = pnv.parse_proof_bytes(wire)
+    # byte offsets of fields inside the bincode image, found by re-reading: flip one byte of a canonical scalar at each of these places
+    marks = {}
+    rd = pnv.pv._ByteReader(wire)
+    rd.option_commitment()
+    n = rd.u64()
+    for _ in range(n):
+        pnv._split_instance(rd)
+    pnv._split_instance(rd)
+    rd.point(), rd.point()
+    marks["z_vec"] = rd.o + 8
+    rd.scalars()
+    marks["z_delta"] = rd.o
+    rd.scalar(), rd.scalar()
+    for _ in range(rd.u64()):
+        rd.commitment()
+    marks["vc_public"] = rd.o + 8
+    rd.scalars()
+    for _ in range(rd.u64()):
+        rd.scalars()
+    rd.commitment()
+    rd.commitment(), rd.commitment()
+    marks["random_X"] = rd.o + 8
+    rd.scalars()
+    marks["random_u"] = rd.o
+    rd.scalar()
+    marks["relaxed_outer"] = rd.o + 16
+    rd.sumcheck()
+    marks["claims_outer"] = rd.o
+    for _ in range(3):
+        rd.scalar()
+    rd.sumcheck()
+    marks["v_W"] = rd.o + 8
+    rd.scalars()
+    marks["blind_W"] = rd.o
+    rd.scalar()
+    marks["v_E"] = rd.o + 8
+    rd.scalars()
+    marks["blind_E"] = rd.o
+    assert rd.o + 32 == len(wire) and pr["relaxed"]["blind_E"] == int.from_bytes(wire[rd.o:], "little")
+    for name, off in marks.items():
+        bad = bytearray(wire)
+        bad[off] ^= 1
+        with pytest.raises(VerifyError):
+            pnv.verify_bytes(steps[0], core, len(steps), gens, bytes(bad))
+        w = nn.proof_from_bytes(bytes(bad))
+        assert w is None or nn.verify_words(w) != 0, name
+
+
+def test_python_verifier_wrong_key_and_truncation(gens, golden_case):
+    steps, core, nn, words, wire = golden_case
+    with pytest.raises(VerifyError):
+        pnv.verify_bytes(steps[0], core, len(steps), gens, wire, vk_digest=bytes(32))
+    with pytest.raises(VerifyError):
+        pnv.verify_bytes(steps[0], core, len(steps), gens, wire[:-1])
+    with pytest.raises(VerifyError):
+        pnv.verify_bytes(steps[0], core, len(steps), gens, wire + b"\x00")
+    with pytest.raises(VerifyError):
+        pnv.verify_bytes(steps[0], core, 2, gens, wire)
+
+
+@pytest.mark.parametrize("n,groups,core_groups", [(2, 8, 8), (4, 3, 8)])
+def test_python_verifier_other_batches(gens, n, groups, core_groups):
+    """one NIFS round, and a core larger than the step (equalize grows the step shape)"""
+    steps = [frontend.synthetic_circuit(groups, 0xA5, num_public=1, witness_seed=70 + i) for i in range(n)]
+    core = frontend.synthetic_circuit(core_groups, 0xA5, num_public=1, witness_seed=3)
+    nn = ol.OracleNeutronNova(steps, core)
+    words, _, _ = nn.prove(_tape(b"pynn-%d" % n))
+    assert nn.verify_words(words) == 0
+    pub_steps, pub_core = pnv.verify_bytes(steps[0], core, n, gens, nn.proof_to_bytes(words), vk_digest=nn.digest().tobytes())
+    assert pub_steps == [[int(v) for v in s.publics] for s in steps] and pub_core == [int(v) for v in core.publics]
+
+
+def test_one_step_is_refused():
+    """zero NIFS rounds: the reference's verifier circuit reads prior_round_vars[round_index - 1] at round 0 (src/zk.rs:637-641), so its setup panics"""
+    step = frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=1)
+    with pytest.raises(RuntimeError, match="at least two step circuits"):
+        ol.OracleNeutronNova([step], step)
