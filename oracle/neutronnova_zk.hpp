@@ -653,6 +653,11 @@ inline std::unique_ptr<NNKey> nn_setup(SplitR1CSShape<Fq> S_step, SplitR1CSShape
   auto pk = std::make_unique<NNKey>();
   // zero NIFS rounds: the reference's verifier circuit indexes prior_round_vars[round_index - 1] at round 0 (src/zk.rs:637-641) and setup panics
   if (num_steps < 2) throw std::runtime_error("NeutronNova oracle: at least two step circuits");
+  // NeutronNovaNIFS::prove folds only the shared + precommitted prefix of the step witnesses when that prefix is not empty and computes the folded rest rows
+  // from the blinds alone ("the rest portion is all zero for step circuits", src/neutronnova_zk.rs:1215-1261): a step circuit with rest variables BESIDE
+  // shared / precommitted ones loses them in the fold and the reference's own proof does not verify. Rest-only step circuits (its test, :2357-2418) fold in full.
+  if (S_step.num_rest_unpadded > 0 && S_step.num_shared + S_step.num_precommitted > 0)
+    throw std::runtime_error("NeutronNova oracle: step circuits with rest variables beside shared / precommitted ones (the reference's fold drops the rest segment)");
   SplitR1CSShape<Fq>::equalize(S_step, S_core);  // :1413
   // equalize leaves the shared and precommitted segments as they are: this restatement lays out one proof for "a step or the core" and needs them
   // equal (they are whenever both circuits fill the same number of 2048-wide rows per segment; constraint counts and padding variables may differ)
@@ -688,8 +693,9 @@ struct NNPrep {
 inline NNPrep nn_prep_prove(const NNKey& pk, const std::vector<std::vector<Fq>>& step_witness, const std::vector<std::vector<Fq>>& step_publics, const std::vector<Fq>& core_witness,
                             const std::vector<Fq>& core_publics, bool is_small, Tape& tape) {
   const SplitR1CSShape<Fq>& S = pk.S_step;
-  if (S.num_rest_unpadded != 0 || S.num_challenges != 0 || pk.S_core.num_rest_unpadded != 0 || pk.S_core.num_challenges != 0)
-    throw std::runtime_error("NeutronNova oracle: step / core circuits with rest variables or challenges are not restated");
+  // rest variables (SpartanCircuit::synthesize, e.g. the reference's own test circuit, src/neutronnova_zk.rs:2391-2418) are taken with the witness: without
+  // verifier challenges synthesize is a function of the circuit alone, so what prove() would re-synthesize (bellpepper/r1cs.rs:443-461) is known here
+  if (S.num_challenges != 0 || pk.S_core.num_challenges != 0) throw std::runtime_error("NeutronNova oracle: step / core circuits with verifier challenges are not restated");
   NNPrep ps;
   NNPrecommitted shared;
   shared.W.assign(S.num_vars(), Fq::zero());
@@ -701,7 +707,9 @@ inline NNPrep nn_prep_prove(const NNKey& pk, const std::vector<std::vector<Fq>>&
   auto precommit = [&](const SplitR1CSShape<Fq>& Sh, const std::vector<Fq>& wit, const std::vector<Fq>& pub) {
     NNPrecommitted p = shared;
     p.publics = pub;
+    if (wit.size() != Sh.num_shared_unpadded + Sh.num_precommitted_unpadded + Sh.num_rest_unpadded) throw std::runtime_error("InvalidWitnessLength");
     std::copy(wit.begin() + Sh.num_shared_unpadded, wit.begin() + Sh.num_shared_unpadded + Sh.num_precommitted_unpadded, p.W.begin() + Sh.num_shared);
+    std::copy(wit.begin() + Sh.num_shared_unpadded + Sh.num_precommitted_unpadded, wit.end(), p.W.begin() + Sh.num_shared + Sh.num_precommitted);
     if (Sh.num_precommitted_unpadded > 0) {
       p.r_pre = hyrax_blind(pk.ck, Sh.num_precommitted, tape);
       p.comm_pre = hyrax_commit(pk.ck, p.W.data() + Sh.num_shared, Sh.num_precommitted, p.r_pre, is_small);
@@ -798,7 +806,6 @@ inline Fq pow_poly_evaluate(const Fq& t, const std::vector<Fq>& r) {  // power.r
 
 // prove (:1609-2093). The prep state is rerandomized in place, as in the reference.
 inline NNProof nn_prove(const NNKey& pk, NNPrep& ps, bool is_small, Tape& tape) {
-  (void)is_small;
   const SplitR1CSShape<Fq>& S = pk.S_step;
   const size_t n = ps.steps.size();
   // rerandomize (:1619-1627)
@@ -821,14 +828,16 @@ inline NNProof nn_prove(const NNKey& pk, NNPrep& ps, bool is_small, Tape& tape) 
       st.r_pre = rn;
     }
   }
-  // instances and witnesses (:1662-1719): per-instance transcripts only matter for circuits with challenges (none here); rest = commit_zeros
+  // instances and witnesses (:1662-1719): per-instance transcripts only matter for circuits with challenges (none here); the rest rows are commit_zeros for
+  // a circuit without rest variables, a commitment of the rest segment otherwise (bellpepper/r1cs.rs:463-500)
   NNProof proof;
   proof.comm_W_shared = ps.core.comm_shared;
   std::vector<NifsInstance> Us;
   std::vector<NifsWitness> Ws;
-  auto instance = [&](NNPrecommitted& p, NNSplitInstance* out, NifsInstance* U, NifsWitness* W) {
-    HyraxBlind r_rest = hyrax_blind(pk.ck, S.num_rest, tape);
-    HyraxCommitment c_rest = hyrax_commit_zeros(pk.ck, S.num_rest, r_rest);
+  auto instance = [&](NNPrecommitted& p, const SplitR1CSShape<Fq>& Sh, NNSplitInstance* out, NifsInstance* U, NifsWitness* W) {
+    HyraxBlind r_rest = hyrax_blind(pk.ck, Sh.num_rest, tape);
+    HyraxCommitment c_rest = Sh.num_rest_unpadded == 0 ? hyrax_commit_zeros(pk.ck, Sh.num_rest, r_rest)
+                                                       : hyrax_commit(pk.ck, p.W.data() + Sh.num_shared + Sh.num_precommitted, Sh.num_rest, r_rest, is_small);
     out->comm_pre = p.comm_pre;
     out->comm_rest = c_rest;
     out->publics = p.publics;
@@ -841,10 +850,10 @@ inline NNProof nn_prove(const NNKey& pk, NNPrep& ps, bool is_small, Tape& tape) 
   proof.step_instances.resize(n);
   Us.resize(n);
   Ws.resize(n);
-  for (size_t i = 0; i < n; ++i) instance(ps.steps[i], &proof.step_instances[i], &Us[i], &Ws[i]);
+  for (size_t i = 0; i < n; ++i) instance(ps.steps[i], S, &proof.step_instances[i], &Us[i], &Ws[i]);
   NifsInstance core_U;
   NifsWitness core_W;
-  instance(ps.core, &proof.core_instance, &core_U, &core_W);
+  instance(ps.core, pk.S_core, &proof.core_instance, &core_U, &core_W);
 
   Transcript tr("neutronnova_prove");
   tr.absorb_bytes("vk", pk.vk_digest, 32);

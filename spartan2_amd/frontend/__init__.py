@@ -26,6 +26,7 @@ def lib():
         L.spf_synthetic_circuit.restype = ctypes.c_void_p
         L.spf_cubic_circuit.restype = ctypes.c_void_p
         L.spf_sha256_step_circuit.restype = ctypes.c_void_p
+        L.spf_sha256_rest_circuit.restype = ctypes.c_void_p
         L.spf_witness.restype = ctypes.POINTER(ctypes.c_uint64)
         L.spf_publics.restype = ctypes.POINTER(ctypes.c_uint64)
         L.spf_last_error.restype = ctypes.c_char_p
@@ -88,3 +89,9 @@ def sha256_step_circuit(block: bytes) -> R1CSInstanceInt:
     The bench's CoreCircuit (:139-183) is the same shape on bytes(64)."""
     assert len(block) == 64
     return R1CSInstanceInt(lib().spf_sha256_step_circuit(bytes(block)))
+
+
+def sha256_rest_circuit(preimage: bytes) -> R1CSInstanceInt:
+    """Sha256Circuit of the reference's NeutronNova test (src/neutronnova_zk.rs:2357-2418): the whole circuit in synthesize, i.e. REST variables only;
+    preimage bits LSB first per byte, x = 0 inputized."""
+    return R1CSInstanceInt(lib().spf_sha256_rest_circuit(bytes(preimage), ctypes.c_size_t(len(preimage))))

@@ -36,6 +36,14 @@ void* spf_sha256_step_circuit(const uint8_t* block64) {
     return nullptr;
   }
 }
+void* spf_sha256_rest_circuit(const uint8_t* msg, size_t n) {
+  try {
+    return new R1CSInstanceInt(sha256_rest_circuit(std::vector<uint8_t>(msg, msg + n)));
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
 void* spf_cubic_circuit() {
   try {
     return new R1CSInstanceInt(cubic_circuit());

@@ -488,6 +488,21 @@ inline R1CSInstanceInt sha256_step_circuit(const uint8_t block[64]) {
   return finalize(cs, 0, num_aux);
 }
 
+// Sha256Circuit of the reference's own NeutronNova test (src/neutronnova_zk.rs:2357-2418): nothing shared or precommitted — the whole circuit sits in
+// SpartanCircuit::synthesize, so every variable is a REST variable: the preimage bits (LSB first per byte, :2396-2401), the sha256 gadget with padding, then
+// x = 0 allocated and inputized. test_neutron_sha256 (:2480-2503) folds 2, 7, 32 and 64 of them over 32- and 64-byte preimages [i; len].
+inline R1CSInstanceInt sha256_rest_circuit(const std::vector<uint8_t>& preimage) {
+  ConstraintSystem cs;
+  std::vector<Boolean> bits;
+  for (uint8_t byte : preimage)
+    for (int i = 0; i < 8; ++i) bits.push_back(alloc_bit(cs, (byte >> i) & 1));
+  sha256_gadget(cs, bits);
+  const uint32_t x = cs.alloc_aux(0);
+  const uint32_t in = cs.alloc_input(0);
+  cs.enforce({{in, 1}}, {{ConstraintSystem::one(), 1}}, {{x, 1}});
+  return finalize(cs, 0, 0);
+}
+
 // Small seeded synthetic circuit in SHA-like proportions (SURVEY.md 8(d) fallback shapes):
 // booleanity, AND, XOR and 32-bit pack rows over random bits; `n_groups` groups of 100 rows.
 inline uint64_t splitmix64(uint64_t& s) {

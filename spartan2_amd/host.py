@@ -495,8 +495,9 @@ NN_PHASES = ("instances", "nifs", "outer_sumcheck", "inner_sumcheck", "verifier_
 
 
 class NeutronNovaZkSNARK:
-    """setup -> prep_prove -> prove -> verify (src/neutronnova_zk.rs:1394-2343) for step / core circuits of one padded shape without rest variables or challenges
-    (the bench circuits: benches/sha256_neutronnova.rs). step_insts / core_inst: frontend.R1CSInstanceInt."""
+    """setup -> prep_prove -> prove -> verify (src/neutronnova_zk.rs:1394-2343) for step / core circuits without verifier challenges: shared + precommitted
+    variables (the bench circuits, benches/sha256_neutronnova.rs) or rest variables only (the reference's test circuit, src/neutronnova_zk.rs:2357-2418; beside
+    shared / precommitted ones the reference's fold drops them, refused). step_insts / core_inst: frontend.R1CSInstanceInt."""
 
     def __init__(self, ctx: hip.Context, step_insts, core_inst):
         self.ctx, self.steps, self.core = ctx, step_insts, core_inst

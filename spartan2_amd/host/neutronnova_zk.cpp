@@ -140,6 +140,8 @@ struct NNZkPrep {
   // their sizes are the key's, so they are allocated once (a prove used to pay sixteen hipMalloc / hipFree pairs, the frees after its last phase)
   sp_table* work[16] = {};
   size_t work_cap[16] = {};
+  sp_table* rest_stage = nullptr;  // rest segments of several instances side by side (one commitment call for all of them)
+  size_t rest_stage_cap = 0;
   sp_ctx* ctx2 = nullptr;
   Worker wk;
   sp_table* bws[2] = {nullptr, nullptr};
@@ -164,6 +166,7 @@ struct NNZkPrep {
     wk.drain();
     for (sp_table* t : bws) sp_table_free(t);
     for (sp_table* t : work) sp_table_free(t);
+    sp_table_free(rest_stage);
     sp_ctx_destroy(ctx2);
     for (auto& s : steps) sp_table_free(s.W);
     sp_table_free(core.W);
@@ -186,8 +189,13 @@ static NNZkKey* nn_setup(sp_ctx* ctx, const R1CSIntView& Rs, const R1CSIntView& 
     // (constraint counts and padding variables may differ)
     if (Ps.dims.num_shared != Pc.dims.num_shared || Ps.dims.num_precommitted != Pc.dims.num_precommitted)
       throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: step and core circuits with different padded shared / precommitted segments are not driven by this layer");
-    if (Ps.dims.num_rest_unpadded || Ps.dims.num_challenges || Pc.dims.num_rest_unpadded || Pc.dims.num_challenges)
-      throw Error(SP_ERR_INTERNAL, "NeutronNova: step / core circuits with rest variables or verifier challenges are not driven by this layer");
+    if (Ps.dims.num_challenges || Pc.dims.num_challenges) throw Error(SP_ERR_INTERNAL, "NeutronNova: step / core circuits with verifier challenges are not driven by this layer");
+    // Rest variables (SpartanCircuit::synthesize; the reference's own test circuit is nothing else, src/neutronnova_zk.rs:2357-2418) come with the witness:
+    // without challenges, what prove() re-synthesizes (bellpepper/r1cs.rs:443-461) is a function of the circuit alone. BESIDE shared / precommitted variables
+    // they cannot be driven: NeutronNovaNIFS::prove folds only that prefix of the step witnesses when it is non-empty and takes the folded rest rows from the
+    // blinds ("the rest portion is all zero for step circuits", :1215-1261), so the reference's own proof of such a shape does not verify.
+    if (Ps.dims.num_rest_unpadded && Ps.dims.num_shared + Ps.dims.num_precommitted)
+      throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: step circuits with rest variables beside shared / precommitted ones (the reference's fold drops the rest segment)");
     pk->dims = Ps.dims;
     pk->dims_core = Pc.dims;
     pk->num_vars = Ps.num_vars();
@@ -245,6 +253,7 @@ static std::vector<fe_t> padded_witness(const sp_dims& d, const uint64_t* w) {
   };
   put(0, 0, d.num_shared_unpadded);
   put(d.num_shared, d.num_shared_unpadded, d.num_precommitted_unpadded);
+  put(d.num_shared + d.num_precommitted, d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded);
   return W;
 }
 
@@ -252,7 +261,8 @@ static std::vector<fe_t> padded_witness(const sp_dims& d, const uint64_t* w) {
 static NNZkPrep* nn_prep_prove(const NNZkKey& pk, size_t n, const uint64_t* step_wit, size_t wit_len, const uint64_t* step_pub, size_t npub, const uint64_t* core_wit,
                                const uint64_t* core_pub, bool is_small, Tape& tape) {
   const sp_dims& d = pk.dims;
-  if (n != pk.num_steps || wit_len != d.num_shared_unpadded + d.num_precommitted_unpadded || npub != d.num_public) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
+  if (n != pk.num_steps || wit_len != d.num_shared_unpadded + d.num_precommitted_unpadded + d.num_rest_unpadded || npub != d.num_public)
+    throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
   auto* ps = new NNZkPrep();
   try {
     sp_ctx* ctx = pk.ctx;
@@ -492,8 +502,8 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
         }
     }
   }
-  // instances and witnesses (:1662-1719): rest rows = commit_zeros (h * blind) — one sp_fixed_base_mul_h call for the rest rows of all instances;
-  // no challenges for these circuits
+  // instances and witnesses (:1662-1719): rest rows = commit_zeros (h * blind) — one sp_fixed_base_mul_h call for the rest rows of all instances — or, for a
+  // circuit with rest variables, the commitment of its rest segment under the same blinds (bellpepper/r1cs.rs:463-500); no challenges for these circuits
   ProofBuf proof;
   proof.pc(ps.comm_shared);
   std::vector<aff_t> comms(n * rows);
@@ -502,7 +512,42 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   std::vector<fe_t> all_rest((n + 1) * rows_rest);
   for (auto& b : all_rest) b = tape.next();  // steps in order, then the core: the reference's call order
   std::vector<aff_t> all_c_rest(all_rest.size());
-  if (!all_rest.empty()) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(all_rest.data()), all_rest.size(), u64p(&all_c_rest[0].x)), "commit_zeros");
+  if (!all_rest.empty() && !(d.num_rest_unpadded && pk.dims_core.num_rest_unpadded))
+    ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(all_rest.data()), all_rest.size(), u64p(&all_c_rest[0].x)), "commit_zeros");
+  {
+    // the rest segments of several instances side by side in one table are ONE row-wise commitment (a Hyrax commitment is one MSM per 2048-entry row): a call
+    // per instance costs 0.25 ms of fixed work each (64 instances of the reference's two-block test circuit: 15.9 ms of a 23 ms prove)
+    std::vector<std::pair<const NNPre*, size_t>> todo;  // (instance, its index among the rest blinds)
+    if (d.num_rest_unpadded)
+      for (size_t i = 0; i < n; ++i) todo.push_back({&ps.steps[i], i});
+    if (pk.dims_core.num_rest_unpadded) todo.push_back({&ps.core, n});
+    const size_t seg = d.num_rest, seg_off = d.num_shared + d.num_precommitted;  // equal for step and core (nn_setup)
+    const size_t batch = std::max<size_t>(1, ((size_t)1 << 25) / std::max<size_t>(seg, 1));  // <= 1 GiB of staged elements per call
+    for (size_t at = 0; at < todo.size(); at += batch) {
+      const size_t cnt = std::min(batch, todo.size() - at);
+      if (cnt == 1) {
+        const size_t which = todo[at].second;
+        ck(sp_hyrax_commit(ctx, pk.ck, todo[at].first->W, seg_off, seg, u64p(all_rest.data() + which * rows_rest), ps.is_small ? 1 : 0, u64p(&all_c_rest[which * rows_rest].x)),
+           "commit rest");
+        continue;
+      }
+      if (cnt * seg > ps.rest_stage_cap) {
+        sp_table_free(ps.rest_stage);
+        ps.rest_stage = nullptr;
+        ps.rest_stage_cap = cnt * seg;
+        ck(sp_table_zeros(ctx, ps.rest_stage_cap, (size_t)-1, (size_t)-1, &ps.rest_stage), "rest staging table");
+      }
+      ck(sp_table_set_len(ps.rest_stage, cnt * seg, (size_t)-1, (size_t)-1), "rest staging len");
+      std::vector<fe_t> bl(cnt * rows_rest);
+      for (size_t k = 0; k < cnt; ++k) {
+        ck(sp_table_copy(ctx, ps.rest_stage, k * seg, todo[at + k].first->W, seg_off, seg), "stage rest segment");
+        std::copy(all_rest.begin() + todo[at + k].second * rows_rest, all_rest.begin() + (todo[at + k].second + 1) * rows_rest, bl.begin() + k * rows_rest);
+      }
+      std::vector<aff_t> out(cnt * rows_rest);
+      ck(sp_hyrax_commit(ctx, pk.ck, ps.rest_stage, 0, cnt * seg, u64p(bl.data()), ps.is_small ? 1 : 0, u64p(&out[0].x)), "commit rest (batched)");
+      for (size_t k = 0; k < cnt; ++k) std::copy(out.begin() + k * rows_rest, out.begin() + (k + 1) * rows_rest, all_c_rest.begin() + todo[at + k].second * rows_rest);
+    }
+  }
   auto instance = [&](NNPre& p, size_t which, aff_t* comm_out, fe_t* r_out) {
     const fe_t* r_rest = all_rest.data() + which * rows_rest;
     const aff_t* c_rest = all_c_rest.data() + which * rows_rest;

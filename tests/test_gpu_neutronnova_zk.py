@@ -157,6 +157,61 @@ def test_shared_and_precommitted_segments(ctx):
     gnn.close()
 
 
+@pytest.mark.parametrize("kind", ["synthetic_rest_only", "reference_test_circuit_7x32B"])
+def test_rest_variables(ctx, kind):
+    """Circuits that live in SpartanCircuit::synthesize — REST variables, committed inside prove (bellpepper/r1cs.rs:463-500), no matvec cache in the reference
+    (can_cache_matvec, src/neutronnova_zk.rs:1524) — as the reference's own test has them (test_neutron_sha256, :2480-2503: a SHA-256 circuit entirely in
+    synthesize, 2 / 7 / 32 / 64 instances over 32- and 64-byte preimages [i; len], core = the first step circuit): same proof words as the oracle, every
+    verifier accepts (the Python one from the bincode bytes), both drivers agree, and the shape the reference's fold gets wrong is refused."""
+    if kind == "synthetic_rest_only":
+        mk = lambda ws: frontend.synthetic_circuit(8, 0xA5, num_public=1, precommitted_permille=0, witness_seed=ws)
+        steps, core = [mk(11 + i) for i in range(3)], mk(99)
+    else:
+        steps = [frontend.sha256_rest_circuit(bytes([i]) * 32) for i in range(7)]
+        core = steps[0]
+    assert steps[0].num_rest > 0 and steps[0].num_precommitted == 0
+    onn, gnn, want, got, tape, used, _ = _both(ctx, steps, core, 91)
+    assert (got == want).all()
+    assert onn.verify_words(got) == 0 and gnn.verify(got) == 0
+    data = gnn.proof_to_bytes(got)
+    assert data == onn.proof_to_bytes(want) and gnn.verify_bytes(data) == 0
+    import pynnverify
+
+    pubs = pynnverify.verify_bytes(steps[0], core, len(steps), host.from_label(b"ck", 2049), data)
+    assert pubs == ([[int(v) for v in s.publics] for s in steps], [int(v) for v in core.publics])
+    bad = got.copy()
+    bad[3] ^= np.uint64(2)  # a coordinate of the first step's first rest row (no shared / precommitted rows in front of it)
+    assert onn.verify_words(bad) != 0 and gnn.verify(bad) != 0
+    gnn.close()
+    ref = host.NeutronNovaZkSNARK(ctx, steps, core)
+    assert ref.prep_prove(tape) == used[0]
+    again, _, _ = ref.prove(tape[used[0]:], reference_order=True)
+    assert (again == want).all()
+    ref.close()
+    if kind == "synthetic_rest_only":
+        mk3 = lambda ws: frontend.synthetic_circuit(30, 0x77, num_public=2, shared_permille=200, precommitted_permille=500, witness_seed=ws)
+        with pytest.raises(Exception, match="drops the rest segment"):
+            host.NeutronNovaZkSNARK(ctx, [mk3(5), mk3(5)], mk3(5))
+
+
+def test_reference_test_sizes_64_instances(ctx):
+    """the largest case of test_neutron_sha256 (src/neutronnova_zk.rs:2489-2501): 64 instances of the two-block circuit (64-byte preimages), on the device
+    alone: prove, verify, bytes round trip, a tampered proof refused"""
+    steps = [frontend.sha256_rest_circuit(bytes([i]) * 64) for i in range(64)]
+    gnn = host.NeutronNovaZkSNARK(ctx, steps, steps[0])
+    tape = ol.make_tape(6464, 65536)
+    used0 = gnn.prep_prove(tape)
+    words, _, phases = gnn.prove(tape[used0:])
+    assert gnn.info["nb"] == 6 and gnn.verify(words) == 0
+    data = gnn.proof_to_bytes(words)
+    assert gnn.verify_bytes(data) == 0 and (gnn.proof_from_bytes(data) == words).all()
+    bad = words.copy()
+    bad[len(bad) // 3] ^= np.uint64(1 << 5)
+    assert gnn.verify(bad) != 0
+    print("64 x sha256(64 B) in synthesize, prove phases (ms):", {k: round(v, 3) for k, v in phases.items()})
+    gnn.close()
+
+
 def test_c3_sha256_neutronnova_32_steps(ctx):
     """BASELINE config 3: 32 step circuits (block [i; 64], one compression each) + the core circuit, T256HyraxEngine shapes."""
     steps = [frontend.sha256_step_circuit(bytes([i]) * 64) for i in range(32)]

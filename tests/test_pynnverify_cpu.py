@@ -129,3 +129,38 @@ def test_one_step_is_refused():
     step = frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=1)
     with pytest.raises(RuntimeError, match="at least two step circuits"):
         ol.OracleNeutronNova([step], step)
+
+
+@pytest.mark.parametrize("kind", ["rest_only", "reference_test_circuit"])
+def test_rest_variables(gens, kind):
+    """Step / core circuits whose variables (also) live in SpartanCircuit::synthesize — REST variables, committed inside prove (bellpepper/r1cs.rs:463-500) —
+    as in the reference's own test (test_neutron_sha256, src/neutronnova_zk.rs:2480-2503: a SHA-256 circuit entirely in synthesize): the oracle's proof is
+    accepted by its verifier and by the Python one, and a flipped rest witness bit is not provable"""
+    if kind == "rest_only":
+        mk = lambda ws: frontend.synthetic_circuit(8, 0xA5, num_public=1, precommitted_permille=0, witness_seed=ws)
+        steps, core = [mk(11 + i) for i in range(3)], mk(99)
+    else:
+        steps, core = [frontend.sha256_rest_circuit(bytes([i]) * 32) for i in range(2)], frontend.sha256_rest_circuit(bytes(32))
+    assert steps[0].num_rest > 0
+    nn = ol.OracleNeutronNova(steps, core)
+    words, _, _ = nn.prove(_tape(b"rest-" + kind.encode()))
+    assert nn.verify_words(words) == 0
+    pub_steps, pub_core = pnv.verify_bytes(steps[0], core, len(steps), gens, nn.proof_to_bytes(words))
+    assert pub_steps == [[int(v) for v in s.publics] for s in steps] and pub_core == [int(v) for v in core.publics]
+    if kind != "reference_test_circuit":
+        steps[1].witness[steps[1].num_shared + steps[1].num_precommitted + 3] ^= np.uint64(1)  # a rest variable (a bit) flipped: unsatisfied
+        bad = ol.OracleNeutronNova(steps, core)
+        try:
+            w = bad.prove(_tape(b"rest-bad"))[0]
+        except RuntimeError:
+            return
+        assert bad.verify_words(w) != 0
+
+
+def test_rest_variables_beside_precommitted_ones_are_refused():
+    """NeutronNovaNIFS::prove folds only the shared + precommitted prefix of the step witnesses when it is non-empty (src/neutronnova_zk.rs:1215-1231: "the
+    rest portion is all zero for step circuits"): with rest variables behind it the reference's proof does not verify (a restatement that follows it fails its
+    own check 5, the quotient of the step branch) — setup refuses the shape instead"""
+    mk = lambda ws: frontend.synthetic_circuit(30, 0x77, num_public=2, shared_permille=200, precommitted_permille=500, witness_seed=ws)
+    with pytest.raises(RuntimeError, match="drops the rest segment"):
+        ol.OracleNeutronNova([mk(5), mk(5)], mk(5))
