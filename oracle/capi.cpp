@@ -829,15 +829,17 @@ void* orc_nn_proof_from_words(void* k, const uint64_t* w, size_t nwords) {
     auto* pf = new NNProof();
     std::unique_ptr<NNProof> guard(pf);
     pf->comm_W_shared = gc(rows_sh);
-    auto ginst = [&](size_t npub) {
+    (void)rows_pre;
+    (void)rows_rest;
+    auto ginst = [&](const SplitR1CSShape<Fq>& Sh) {  // step and core may split their rows differently (same total after equalize)
       NNSplitInstance u;
-      u.comm_pre = gc(rows_pre);
-      u.comm_rest = gc(rows_rest);
-      for (size_t i = 0; i < npub; ++i) u.publics.push_back(gf());
+      u.comm_pre = gc(div_ceil(Sh.num_precommitted, CW));
+      u.comm_rest = gc(div_ceil(Sh.num_rest, CW));
+      for (size_t i = 0; i < Sh.num_public; ++i) u.publics.push_back(gf());
       return u;
     };
-    for (size_t i = 0; i < pk->num_steps; ++i) pf->step_instances.push_back(ginst(S.num_public));
-    pf->core_instance = ginst(pk->S_core.num_public);
+    for (size_t i = 0; i < pk->num_steps; ++i) pf->step_instances.push_back(ginst(S));
+    pf->core_instance = ginst(pk->S_core);
     HyraxCommitment db = gc(2);
     pf->eval_arg.delta = db[0];
     pf->eval_arg.beta = db[1];

@@ -659,10 +659,11 @@ inline std::unique_ptr<NNKey> nn_setup(SplitR1CSShape<Fq> S_step, SplitR1CSShape
   if (S_step.num_rest_unpadded > 0 && S_step.num_shared + S_step.num_precommitted > 0)
     throw std::runtime_error("NeutronNova oracle: step circuits with rest variables beside shared / precommitted ones (the reference's fold drops the rest segment)");
   SplitR1CSShape<Fq>::equalize(S_step, S_core);  // :1413
-  // equalize leaves the shared and precommitted segments as they are: this restatement lays out one proof for "a step or the core" and needs them
-  // equal (they are whenever both circuits fill the same number of 2048-wide rows per segment; constraint counts and padding variables may differ)
-  if (S_step.num_shared != S_core.num_shared || S_step.num_precommitted != S_core.num_precommitted)
-    throw std::runtime_error("NeutronNova oracle: step and core circuits with different padded shared / precommitted segments are not restated");
+  // equalize leaves the shared and precommitted segments as they are. The precommitted (hence rest) segments of step and core may differ — every fold and
+  // the opening work on the combined rows, whose number equalize has made equal; the SHARED segment is one commitment for all circuits (comm_W_shared of the
+  // proof, checked against S_step and S_core alike, src/neutronnova_zk.rs:2112-2158), so its padded size has to agree
+  if (S_step.num_shared != S_core.num_shared)
+    throw std::runtime_error("NeutronNova oracle: step and core circuits with different padded shared segments (one shared commitment serves both)");
   pk->S_step = std::move(S_step);
   pk->S_core = std::move(S_core);
   pk->num_steps = num_steps;
@@ -815,7 +816,7 @@ inline NNProof nn_prove(const NNKey& pk, NNPrep& ps, bool is_small, Tape& tape) 
     ps.core.r_shared = rn;
   }
   if (!ps.core.comm_pre.empty()) {
-    HyraxBlind rn = hyrax_blind(pk.ck, S.num_precommitted, tape);
+    HyraxBlind rn = hyrax_blind(pk.ck, pk.S_core.num_precommitted, tape);
     ps.core.comm_pre = rerandomize(pk.ck, ps.core.comm_pre, ps.core.r_pre, rn);
     ps.core.r_pre = rn;
   }
@@ -976,8 +977,11 @@ inline int nn_verify(const NNKey& vk, const NNProof& pf) {
   if (n == 0 || n != vk.num_steps) return 1;
   const size_t rows_sh = div_ceil(S.num_shared, DEFAULT_COMMITMENT_WIDTH), rows_pre = div_ceil(S.num_precommitted, DEFAULT_COMMITMENT_WIDTH),
                rows_rest = div_ceil(S.num_rest, DEFAULT_COMMITMENT_WIDTH);
+  (void)rows_pre;
+  (void)rows_rest;
   auto check_inst = [&](const NNSplitInstance& u, const SplitR1CSShape<Fq>& Sh) {
-    return pf.comm_W_shared.size() == rows_sh && u.comm_pre.size() == rows_pre && u.comm_rest.size() == rows_rest && u.publics.size() == Sh.num_public;
+    return pf.comm_W_shared.size() == rows_sh && u.comm_pre.size() == div_ceil(Sh.num_precommitted, DEFAULT_COMMITMENT_WIDTH) &&
+           u.comm_rest.size() == div_ceil(Sh.num_rest, DEFAULT_COMMITMENT_WIDTH) && u.publics.size() == Sh.num_public;
   };
   for (const auto& u : pf.step_instances)
     if (!check_inst(u, S)) return 1;

@@ -185,10 +185,11 @@ static NNZkKey* nn_setup(sp_ctx* ctx, const R1CSIntView& Rs, const R1CSIntView& 
     if (num_steps < 2) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: at least two step circuits (the verifier circuit has no NIFS round to take its claim from)");
     PaddedShape Ps = pad_shape(Rs), Pc = pad_shape(Rc);
     equalize(Ps, Pc);  // src/neutronnova_zk.rs:1413
-    // equalize leaves the shared and precommitted segments alone; this driver lays out one proof for "a step or the core" and needs them equal
-    // (constraint counts and padding variables may differ)
-    if (Ps.dims.num_shared != Pc.dims.num_shared || Ps.dims.num_precommitted != Pc.dims.num_precommitted)
-      throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: step and core circuits with different padded shared / precommitted segments are not driven by this layer");
+    // equalize leaves the shared and precommitted segments alone. Step and core may split their variables into precommitted | rest differently (the folds and
+    // the opening work on the combined rows, whose number equalize has made equal); the SHARED segment is one commitment for every circuit (comm_W_shared of
+    // the proof is checked against S_step and S_core alike, src/neutronnova_zk.rs:2112-2158), so its padded size has to agree
+    if (Ps.dims.num_shared != Pc.dims.num_shared)
+      throw Error(SP_ERR_INVALID_INPUT_LENGTH, "NeutronNova: step and core circuits with different padded shared segments (one shared commitment serves both)");
     if (Ps.dims.num_challenges || Pc.dims.num_challenges) throw Error(SP_ERR_INTERNAL, "NeutronNova: step / core circuits with verifier challenges are not driven by this layer");
     // Rest variables (SpartanCircuit::synthesize; the reference's own test circuit is nothing else, src/neutronnova_zk.rs:2357-2418) come with the witness:
     // without challenges, what prove() re-synthesizes (bellpepper/r1cs.rs:443-461) is a function of the circuit alone. BESIDE shared / precommitted variables
@@ -266,7 +267,7 @@ static NNZkPrep* nn_prep_prove(const NNZkKey& pk, size_t n, const uint64_t* step
   auto* ps = new NNZkPrep();
   try {
     sp_ctx* ctx = pk.ctx;
-    const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared / CW, rows_pre = d.num_precommitted / CW;
+    const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared / CW;
     ps->is_small = is_small;
     ps->steps.resize(n);
     std::vector<fe_t> W0 = padded_witness(d, step_wit);
@@ -287,6 +288,7 @@ static NNZkPrep* nn_prep_prove(const NNZkKey& pk, size_t n, const uint64_t* step
       p->publics.resize(dd.num_public);
       for (size_t i = 0; i < dd.num_public; ++i) p->publics[i] = fe_from_u64<S>(pub[i]);
       if (dd.num_precommitted_unpadded) {
+        const size_t rows_pre = dd.num_precommitted / CW;
         p->r_pre.resize(rows_pre);
         for (auto& b : p->r_pre) b = tape.next();
         p->comm_pre.resize(rows_pre);
@@ -419,6 +421,10 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const size_t CW = DEFAULT_COMMITMENT_WIDTH, n = ps.steps.size(), nv = pk.num_vars, N = d.num_cons;
   const size_t rows_sh = d.num_shared_unpadded ? d.num_shared / CW : 0, rows_pre = d.num_precommitted_unpadded ? d.num_precommitted / CW : 0, rows_rest = d.num_rest / CW;
   const size_t rows = rows_sh + rows_pre + rows_rest, dpub = d.num_public;
+  // the core circuit may split the same number of rows differently (nn_setup: equal shared segment, equal total after equalize)
+  const sp_dims& dc = pk.dims_core;
+  const size_t rows_pre_c = dc.num_precommitted_unpadded ? dc.num_precommitted / CW : 0, rows_rest_c = dc.num_rest / CW;
+  if (rows_sh + rows_pre_c + rows_rest_c != rows) throw Error(SP_ERR_INTERNAL, "NeutronNova: step and core rows differ after equalize");
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = now();
   static const bool laps = [] {
@@ -445,7 +451,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     if (!ps.ctx2) ck(sp_ctx_create(sp_ctx_device(ctx), &ps.ctx2), "second context");
     // the random relaxed instance: its values sit at a position of the tape that only the shapes determine (the draws in front of it are the
     // rerandomisation blinds, the rest-row blinds and one blind per committed row of the verifier circuit's rounds); checked again where it is used
-    size_t before = ps.comm_shared.size() + ps.core.comm_pre.size() + (n + 1) * rows_rest + pk.vc.total_vars / 32;
+    size_t before = ps.comm_shared.size() + ps.core.comm_pre.size() + n * rows_rest + rows_rest_c + pk.vc.total_vars / 32;
     for (const auto& st : ps.steps) before += st.comm_pre.size();
     Tape ahead = tape;
     ahead.pos = tape.pos + before;
@@ -509,7 +515,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   std::vector<aff_t> comms(n * rows);
   std::vector<fe_t> X(n * dpub), r_W(n * rows);
   std::vector<const sp_table*> Ws(n);
-  std::vector<fe_t> all_rest((n + 1) * rows_rest);
+  std::vector<fe_t> all_rest(n * rows_rest + rows_rest_c);
   for (auto& b : all_rest) b = tape.next();  // steps in order, then the core: the reference's call order
   std::vector<aff_t> all_c_rest(all_rest.size());
   if (!all_rest.empty() && !(d.num_rest_unpadded && pk.dims_core.num_rest_unpadded))
@@ -517,48 +523,63 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   {
     // the rest segments of several instances side by side in one table are ONE row-wise commitment (a Hyrax commitment is one MSM per 2048-entry row): a call
     // per instance costs 0.25 ms of fixed work each (64 instances of the reference's two-block test circuit: 15.9 ms of a 23 ms prove)
-    std::vector<std::pair<const NNPre*, size_t>> todo;  // (instance, its index among the rest blinds)
+    struct RestJob {
+      const NNPre* p;
+      size_t off, len, blind_at, nrows;  // the segment inside p->W, its blinds / rows inside all_rest / all_c_rest
+    };
+    std::vector<RestJob> todo;
     if (d.num_rest_unpadded)
-      for (size_t i = 0; i < n; ++i) todo.push_back({&ps.steps[i], i});
-    if (pk.dims_core.num_rest_unpadded) todo.push_back({&ps.core, n});
-    const size_t seg = d.num_rest, seg_off = d.num_shared + d.num_precommitted;  // equal for step and core (nn_setup)
-    const size_t batch = std::max<size_t>(1, ((size_t)1 << 25) / std::max<size_t>(seg, 1));  // <= 1 GiB of staged elements per call
-    for (size_t at = 0; at < todo.size(); at += batch) {
-      const size_t cnt = std::min(batch, todo.size() - at);
+      for (size_t i = 0; i < n; ++i) todo.push_back({&ps.steps[i], d.num_shared + d.num_precommitted, d.num_rest, i * rows_rest, rows_rest});
+    if (dc.num_rest_unpadded) todo.push_back({&ps.core, dc.num_shared + dc.num_precommitted, dc.num_rest, n * rows_rest, rows_rest_c});
+    const size_t cap = (size_t)1 << 25;  // <= 1 GiB of staged elements per call
+    for (size_t at = 0; at < todo.size();) {
+      size_t cnt = 1, elems = todo[at].len;
+      while (at + cnt < todo.size() && elems + todo[at + cnt].len <= cap) elems += todo[at + cnt++].len;
       if (cnt == 1) {
-        const size_t which = todo[at].second;
-        ck(sp_hyrax_commit(ctx, pk.ck, todo[at].first->W, seg_off, seg, u64p(all_rest.data() + which * rows_rest), ps.is_small ? 1 : 0, u64p(&all_c_rest[which * rows_rest].x)),
-           "commit rest");
+        const RestJob& j = todo[at];
+        ck(sp_hyrax_commit(ctx, pk.ck, j.p->W, j.off, j.len, u64p(all_rest.data() + j.blind_at), ps.is_small ? 1 : 0, u64p(&all_c_rest[j.blind_at].x)), "commit rest");
+        at += 1;
         continue;
       }
-      if (cnt * seg > ps.rest_stage_cap) {
+      if (elems > ps.rest_stage_cap) {
         sp_table_free(ps.rest_stage);
         ps.rest_stage = nullptr;
-        ps.rest_stage_cap = cnt * seg;
+        ps.rest_stage_cap = elems;
         ck(sp_table_zeros(ctx, ps.rest_stage_cap, (size_t)-1, (size_t)-1, &ps.rest_stage), "rest staging table");
       }
-      ck(sp_table_set_len(ps.rest_stage, cnt * seg, (size_t)-1, (size_t)-1), "rest staging len");
-      std::vector<fe_t> bl(cnt * rows_rest);
+      ck(sp_table_set_len(ps.rest_stage, elems, (size_t)-1, (size_t)-1), "rest staging len");
+      std::vector<fe_t> bl;
+      size_t pos = 0;
       for (size_t k = 0; k < cnt; ++k) {
-        ck(sp_table_copy(ctx, ps.rest_stage, k * seg, todo[at + k].first->W, seg_off, seg), "stage rest segment");
-        std::copy(all_rest.begin() + todo[at + k].second * rows_rest, all_rest.begin() + (todo[at + k].second + 1) * rows_rest, bl.begin() + k * rows_rest);
+        const RestJob& j = todo[at + k];
+        ck(sp_table_copy(ctx, ps.rest_stage, pos, j.p->W, j.off, j.len), "stage rest segment");
+        pos += j.len;
+        bl.insert(bl.end(), all_rest.begin() + j.blind_at, all_rest.begin() + j.blind_at + j.nrows);
       }
-      std::vector<aff_t> out(cnt * rows_rest);
-      ck(sp_hyrax_commit(ctx, pk.ck, ps.rest_stage, 0, cnt * seg, u64p(bl.data()), ps.is_small ? 1 : 0, u64p(&out[0].x)), "commit rest (batched)");
-      for (size_t k = 0; k < cnt; ++k) std::copy(out.begin() + k * rows_rest, out.begin() + (k + 1) * rows_rest, all_c_rest.begin() + todo[at + k].second * rows_rest);
+      std::vector<aff_t> out(bl.size());
+      ck(sp_hyrax_commit(ctx, pk.ck, ps.rest_stage, 0, elems, u64p(bl.data()), ps.is_small ? 1 : 0, u64p(&out[0].x)), "commit rest (batched)");
+      size_t o = 0;
+      for (size_t k = 0; k < cnt; ++k) {
+        const RestJob& j = todo[at + k];
+        std::copy(out.begin() + o, out.begin() + o + j.nrows, all_c_rest.begin() + j.blind_at);
+        o += j.nrows;
+      }
+      at += cnt;
     }
   }
   auto instance = [&](NNPre& p, size_t which, aff_t* comm_out, fe_t* r_out) {
-    const fe_t* r_rest = all_rest.data() + which * rows_rest;
+    const size_t my_pre = which == n ? rows_pre_c : rows_pre, my_rest = which == n ? rows_rest_c : rows_rest;
+    const fe_t* r_rest = all_rest.data() + which * rows_rest;  // (the core's blinds follow the n steps')
     const aff_t* c_rest = all_c_rest.data() + which * rows_rest;
+    if (p.comm_pre.size() != my_pre) throw Error(SP_ERR_INTERNAL, "NeutronNova: precommitted rows of an instance");
     std::copy(ps.comm_shared.begin(), ps.comm_shared.end(), comm_out);
     std::copy(p.comm_pre.begin(), p.comm_pre.end(), comm_out + rows_sh);
-    std::copy(c_rest, c_rest + rows_rest, comm_out + rows_sh + rows_pre);
+    std::copy(c_rest, c_rest + my_rest, comm_out + rows_sh + my_pre);
     std::copy(ps.r_shared.begin(), ps.r_shared.end(), r_out);
     std::copy(p.r_pre.begin(), p.r_pre.end(), r_out + rows_sh);
-    std::copy(r_rest, r_rest + rows_rest, r_out + rows_sh + rows_pre);
+    std::copy(r_rest, r_rest + my_rest, r_out + rows_sh + my_pre);
     proof.pc(p.comm_pre);
-    for (size_t i = 0; i < rows_rest; ++i) proof.pp(c_rest[i]);
+    for (size_t i = 0; i < my_rest; ++i) proof.pp(c_rest[i]);
     for (const fe_t& f : p.publics) proof.pf(f);
   };
   for (size_t i = 0; i < n; ++i) {
@@ -1070,21 +1091,24 @@ static std::vector<uint8_t> nn_proof_to_bytes(const NNZkKey& pk, const uint64_t*
     ck(sp_wire_scalars(w, p, n, with_len), "wire");
     p += 4 * n;
   };
-  auto instance = [&](size_t npub) {
+  auto instance = [&](size_t npub, size_t my_pre, size_t my_rest) {
     ck(sp_wire_u8(w, 0), "wire");
-    option_commitment(rows_pre);
-    commitment(rows_rest);
+    option_commitment(my_pre);
+    commitment(my_rest);
     scalars(npub, 1);
     u64v(0);  // challenges: an empty Vec
   };
+  // the core circuit may split the same rows into precommitted | rest differently (nn_setup)
+  const sp_dims& dc = pk.dims_core;
+  const size_t rows_pre_c = dc.num_precommitted_unpadded ? dc.num_precommitted / CW : 0, rows_rest_c = dc.num_rest / CW;
   auto sumcheck = [&](size_t rounds, size_t per) {
     u64v(rounds);
     for (size_t i = 0; i < rounds; ++i) scalars(per, 1);
   };
   option_commitment(rows_sh);
   u64v(pk.num_steps);
-  for (size_t i = 0; i < pk.num_steps; ++i) instance(d.num_public);
-  instance(pk.dims_core.num_public);
+  for (size_t i = 0; i < pk.num_steps; ++i) instance(d.num_public, rows_pre, rows_rest);
+  instance(pk.dims_core.num_public, rows_pre_c, rows_rest_c);
   ck(sp_wire_points(w, p, 2, 0), "wire");  // ipa.delta, ipa.beta
   p += 16;
   scalars(CW, 1);
@@ -1157,21 +1181,23 @@ static std::vector<uint64_t> nn_proof_from_bytes(const NNZkKey& pk, const uint8_
     expect_len(cnt, 32);
     scalars(cnt);
   };
-  auto instance = [&](size_t npub) {
+  auto instance = [&](size_t npub, size_t my_pre, size_t my_rest) {
     tag(0);
-    option_commitment(rows_pre);
-    commitment(rows_rest);
+    option_commitment(my_pre);
+    commitment(my_rest);
     vec_scalars(npub);
     expect_len(0, 32);
   };
+  const sp_dims& dc = pk.dims_core;
+  const size_t rows_pre_c = dc.num_precommitted_unpadded ? dc.num_precommitted / CW : 0, rows_rest_c = dc.num_rest / CW;
   auto sumcheck = [&](size_t rounds, size_t per) {
     expect_len(rounds, 8 + 32 * per);
     for (size_t i = 0; i < rounds; ++i) vec_scalars(per);
   };
   option_commitment(rows_sh);
   expect_len(pk.num_steps, 1 + 1 + 8 + 8 + 8);
-  for (size_t i = 0; i < pk.num_steps; ++i) instance(d.num_public);
-  instance(pk.dims_core.num_public);
+  for (size_t i = 0; i < pk.num_steps; ++i) instance(d.num_public, rows_pre, rows_rest);
+  instance(pk.dims_core.num_public, rows_pre_c, rows_rest_c);
   points(2);
   vec_scalars(CW);
   scalars(2);

@@ -89,8 +89,32 @@ def test_neutronnova_with_a_larger_core_circuit():
     assert nn.verify_words(words) == 0
 
 
-def test_neutronnova_rejects_different_precommitted_segments():
-    steps = [frontend.synthetic_circuit(30, 0xB1, num_public=1, witness_seed=1 + i) for i in range(2)]  # two rows of precommitted variables
+def test_neutronnova_with_different_precommitted_segments():
+    """two rows of precommitted step variables against one row in the core: after equalize the core carries 2048 | 2048 (precommitted | rest) where a step
+    carries 4096 | 0 — every fold and the opening work on the combined rows, so the proof exists; the Python verifier (tests/pynnverify.py), which reads each
+    instance against its own shape, accepts it"""
+    import ctypes
+
+    import numpy as np
+
+    import pynnverify
+
+    steps = [frontend.synthetic_circuit(30, 0xB1, num_public=1, witness_seed=1 + i) for i in range(2)]
     core = frontend.synthetic_circuit(2, 0xA5, num_public=1)
-    with pytest.raises(RuntimeError, match="different padded shared / precommitted"):
-        ol.OracleNeutronNova(steps, core)
+    Ss, Sc = pywire.equalize(pywire.pad_shape(steps[0]), pywire.pad_shape(core))
+    assert (Ss[0]["num_precommitted"], Ss[0]["num_rest"], Sc[0]["num_precommitted"], Sc[0]["num_rest"]) == (4096, 0, 2048, 2048)
+    nn = ol.OracleNeutronNova(steps, core)
+    words, _, _ = nn.prove(ol.make_tape(93, 16384))
+    assert nn.verify_words(words) == 0
+    data = nn.proof_to_bytes(words)
+    assert (nn.proof_from_bytes(data) == words).all()
+    gens = np.zeros((2049, 8), dtype=np.uint64)
+    ol.lib().orc_from_label(b"ck", ctypes.c_size_t(2049), ol.p64(gens))
+    pynnverify.verify_bytes(steps[0], core, 2, gens, data)
+
+
+def test_neutronnova_rejects_different_shared_segments():
+    """comm_W_shared is ONE commitment for all circuits (src/neutronnova_zk.rs:2112-2158)"""
+    sh = lambda g: frontend.synthetic_circuit(g, 0x77, num_public=1, shared_permille=900, precommitted_permille=1000, witness_seed=5)
+    with pytest.raises(RuntimeError, match="different padded shared segments"):
+        ol.OracleNeutronNova([sh(30), sh(30)], sh(8))

@@ -54,10 +54,11 @@ def test_prove_matches_oracle_synthetic_steps(ctx, n, groups):
     gnn.close()
 
 
-@pytest.mark.parametrize("n,groups,core_groups", [(3, 8, 2), (2, 2, 9)])
+@pytest.mark.parametrize("n,groups,core_groups", [(3, 8, 2), (2, 2, 9), (2, 30, 2), (3, 2, 30)])
 def test_step_and_core_shapes_of_different_size(ctx, n, groups, core_groups):
     """SplitR1CSShape::equalize in setup (src/neutronnova_zk.rs:1413, src/r1cs/mod.rs:913-971): a core circuit with fewer (or more) constraints than the
-    step circuit. Same vk digest, same proof words as the oracle, both verifiers accept, the wire bytes round-trip; both drivers (side jobs and the
+    step circuit — in the last two cases by more than a commitment row, so that step and core split the equalized variables into precommitted | rest
+    segments of different sizes (4096 | 0 against 2048 | 2048). Same vk digest, same proof words as the oracle, both verifiers accept, the wire bytes round-trip; both drivers (side jobs and the
     reference-order one) produce it. (tests/test_equalize_cpu.py pins the equalized matrices against a Python restatement.)"""
     steps = [frontend.synthetic_circuit(groups, 0xA5, num_public=1, witness_seed=50 + i) for i in range(n)]
     core = frontend.synthetic_circuit(core_groups, 0xA5 + (core_groups > groups), num_public=1, witness_seed=7)
@@ -78,8 +79,10 @@ def test_step_and_core_shapes_of_different_size(ctx, n, groups, core_groups):
     again, _, _ = ref.prove(tape[used[0]:], reference_order=True)
     assert (again == want).all()
     ref.close()
-    with pytest.raises(Exception, match="different padded shared / precommitted"):
-        host.NeutronNovaZkSNARK(ctx, [frontend.synthetic_circuit(30, 0xB1, num_public=1, witness_seed=1 + i) for i in range(2)], core)
+    # one shared commitment serves every circuit: a different padded shared segment cannot be equalized
+    sh = lambda g: frontend.synthetic_circuit(g, 0x77, num_public=1, shared_permille=900, precommitted_permille=1000, witness_seed=5)
+    with pytest.raises(Exception, match="different padded shared segments"):
+        host.NeutronNovaZkSNARK(ctx, [sh(30), sh(30)], sh(8))
 
 
 @pytest.mark.parametrize("n,groups", [(2, 8), (5, 30)])
