@@ -222,23 +222,24 @@ def spartan_vk_digest(inst, ck, h, ck_s, h_s):
 
 
 def nn_proof_bytes(words, rows_sh, rows_pre, rows_rest, n_steps, npub_step, npub_core, nz, vc_rows_per_round, vc_public, vc_chals_per_round, vc_cons_rows, vc_io,
-                   lx, ly, width):
-    """NeutronNovaZkSNARK (src/neutronnova_zk.rs:1373-1385) from the flat layout of oracle NNProof::serialize"""
+                   lx, ly, width, rows_pre_core=None, rows_rest_core=None):
+    """NeutronNovaZkSNARK (src/neutronnova_zk.rs:1373-1385) from the flat layout of oracle NNProof::serialize. rows_*_core: the core circuit's own split of
+    its rows into precommitted | rest (default: the step's)"""
     c = _Cursor(words)
     w = Writer()
     w.option_commitment(c.take(rows_sh, 8))
 
-    def inst(npub):  # SplitR1CSInstance, comm_W_shared = None (:2069-2078)
+    def inst(npub, r_pre, r_rest):  # SplitR1CSInstance, comm_W_shared = None (:2069-2078)
         w.u8(0)
-        w.option_commitment(c.take(rows_pre, 8))
-        w.commitment(c.take(rows_rest, 8))
+        w.option_commitment(c.take(r_pre, 8))
+        w.commitment(c.take(r_rest, 8))
         w.scalars(c.take(npub, 4))
         w.scalars(np.zeros((0, 4), dtype=np.uint64))
 
     w.u64(n_steps)
     for _ in range(n_steps):
-        inst(npub_step)
-    inst(npub_core)
+        inst(npub_step, rows_pre, rows_rest)
+    inst(npub_core, rows_pre if rows_pre_core is None else rows_pre_core, rows_rest if rows_rest_core is None else rows_rest_core)
     w.point(c.take(1, 8)[0])
     w.point(c.take(1, 8)[0])
     w.scalars(c.take(nz, 4))

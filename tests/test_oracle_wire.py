@@ -122,9 +122,11 @@ def test_vk_digest_separates_keys_and_shapes():
     assert a == c and a != b
 
 
-def test_neutronnova_proof_bytes_match_the_python_writer_and_round_trip():
-    steps = [frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=50 + i) for i in range(3)]
-    core = frontend.synthetic_circuit(8, 0xA5, num_public=1, witness_seed=999)
+@pytest.mark.parametrize("groups,core_groups", [(8, 8), (30, 2)])
+def test_neutronnova_proof_bytes_match_the_python_writer_and_round_trip(groups, core_groups):
+    """(30, 2): two rows of precommitted step variables against one in the core — after equalize the core's rows split 1 | 1 where a step's split 2 | 0"""
+    steps = [frontend.synthetic_circuit(groups, 0xA5, num_public=1, witness_seed=50 + i) for i in range(3)]
+    core = frontend.synthetic_circuit(core_groups, 0xA5, num_public=1, witness_seed=999)
     nn = ol.OracleNeutronNova(steps, core)
     words, _, _ = nn.prove(ol.make_tape(23, 16384))
     assert nn.verify_words(words) == 0
@@ -132,11 +134,13 @@ def test_neutronnova_proof_bytes_match_the_python_writer_and_round_trip():
     back = nn.proof_from_bytes(data)
     assert back is not None and (back == words).all()
     assert nn.proof_from_bytes(data[:-1]) is None and nn.proof_from_bytes(data + b"\1") is None
-    sh, info, W = nn.shape_step, nn.info, 32
+    info, W = nn.info, 32
     rows = lambda n: -(-n // 2048)
+    (ds, _, _), (dc, _, _) = pywire.equalize(pywire.pad_shape(steps[0]), pywire.pad_shape(core))
     vc = ol.verifier_circuit_rounds(info["nb"], info["nx"], info["ny"], W)
     want = pywire.nn_proof_bytes(
-        words, rows(sh.num_shared), rows(sh.num_precommitted), rows(sh.num_rest), len(steps), sh.num_public, nn.shape_core.num_public, min(2048, sh.num_vars),
+        words, rows(ds["num_shared"]), rows(ds["num_precommitted"]), rows(ds["num_rest"]), len(steps), ds["num_public"], dc["num_public"],
+        min(2048, ds["num_shared"] + ds["num_precommitted"] + ds["num_rest"]), rows_pre_core=rows(dc["num_precommitted"]), rows_rest_core=rows(dc["num_rest"]),
         vc_rows_per_round=[v // W for v in vc["vars_padded"]], vc_public=info["vc_public"], vc_chals_per_round=vc["challenges"], vc_cons_rows=info["vc_cons"] // W,
         vc_io=sum(vc["challenges"]) + info["vc_public"], lx=info["vc_cons"].bit_length() - 1, ly=(1 << (info["vc_vars"] - 1).bit_length()).bit_length(), width=W)
     assert data == want
