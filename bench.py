@@ -75,15 +75,67 @@ def _c4_instance():
     return frontend.synthetic_circuit(45000, 0xDEADBEEF, num_public=8)  # N = M = 2^22, SHA-like row mix, Bernoulli(1/2) bits
 
 
+_GUARDIAN = r"""
+import signal, sys
+for s in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+    signal.signal(s, signal.SIG_IGN)  # the launcher ends the ranks when one of them dies: this process outlives them by one write
+last, done = None, False
+for ln in sys.stdin:
+    ln = ln.rstrip("\n")
+    if ln == "done":
+        done = True
+        break
+    if ln:
+        last = ln
+if not done and last is not None:
+    sys.stdout.write(last + "\n")
+    sys.stdout.flush()
+"""
+
+
+class LineGuardian:
+    """Rank 0's bench line, kept by a small child process while the sharded legs run: a watchdog covers a leg that never returns, not a process that
+    DIES in one (a signal inside native collective code that has never run on this pool; the launcher's SIGTERM after another rank died). The child
+    (a fresh interpreter: no GPU state) holds the latest snapshot of the line — the headline and the legs finished so far — and prints it if its input ends
+    without the closing word; on a normal end it prints nothing."""
+
+    def __init__(self):
+        import subprocess
+
+        sys.stdout.flush()
+        self.p = subprocess.Popen([sys.executable, "-c", _GUARDIAN], stdin=subprocess.PIPE, text=True)
+
+    def snapshot(self, line, legs, name):
+        marked = dict(legs)
+        marked[name] = {"error": "the process ended inside this leg; the line was printed by its guardian with the legs finished before it"}
+        snap = dict(line)
+        snap["sharded"] = marked
+        try:
+            self.p.stdin.write(json.dumps(snap) + "\n")
+            self.p.stdin.flush()
+        except Exception:
+            pass
+
+    def done(self):
+        try:
+            self.p.stdin.write("done\n")
+            self.p.stdin.close()
+            self.p.wait(timeout=10)
+        except Exception:
+            pass
+
+
 class LegDog:
     """One watchdog per extra leg: arm(name) before a leg, disarm() after the last. A leg that outlives its allowance ends the process - rank 0 first
     prints the bench line it has (`line`, whose "sharded" object holds the legs that finished) with the leg marked as not finished."""
 
-    def __init__(self, rank, line, legs, seconds):
-        self.rank, self.line, self.legs, self.seconds, self.timer = rank, line, legs, seconds, None
+    def __init__(self, rank, line, legs, seconds, guardian=None):
+        self.rank, self.line, self.legs, self.seconds, self.timer, self.guardian = rank, line, legs, seconds, None, guardian
 
     def _expired(self, name):
         if self.rank == 0 and self.line is not None:
+            if self.guardian:
+                self.guardian.done()
             self.legs[name] = {"error": f"did not finish within {self.seconds:.0f} s; the line is printed with the legs that did"}
             print(json.dumps(self.line), flush=True)
         os._exit(0)
@@ -92,6 +144,12 @@ class LegDog:
         import threading
 
         self.disarm()
+        if self.guardian and self.line is not None:
+            self.guardian.snapshot(self.line, self.legs, name)
+        if os.environ.get("SPARTAN_BENCH_DIE_IN") == name:  # test switch of this script (tests/test_gpu_bench_rehearsal.py): what a crash in native code does
+            import signal
+
+            os.kill(os.getpid(), signal.SIGKILL)
         self.timer = threading.Timer(self.seconds, self._expired, args=(name,))
         self.timer.daemon = True
         self.timer.start()
@@ -783,7 +841,8 @@ def main():
         legs = {}
         if rank == 0:
             out["sharded"] = legs
-        dog = LegDog(rank, out, legs, args.extras_timeout / 2)
+        guardian = LineGuardian() if rank == 0 else None
+        dog = LegDog(rank, out if rank == 0 else None, legs, args.extras_timeout / 2, guardian)
         try:
             dog.arm("communicator")
             comm = host.Comm(rank, world, comm_backend, device=local_rank)
@@ -791,6 +850,8 @@ def main():
         except Exception as exc:
             legs["error"] = repr(exc)
         dog.disarm()
+        if guardian:
+            guardian.done()
     if rank == 0:
         out["scaling_vs_1"] = None if rehearsal else _scaling_vs_1(world, args, out)
         if rehearsal:
