@@ -56,6 +56,13 @@ def test_c1_c2_sha256_spartan_prove_bit_exact(ctx, msg_bytes, log_n):
     bad = bytearray(data)
     bad[len(bad) // 2] ^= 1
     assert gsp.verify_bytes(bytes(bad)) != 0
+    if msg_bytes == 2048:
+        # the headline configuration's proof under the third verifier (tests/pyverify.py: Python integers from src/spartan.rs:469-578 alone), reading the
+        # product's bincode bytes; the generators are the product's own derivation of the labels
+        import pyverify
+
+        g, g_s = host.from_label(b"ck", 2049), host.from_label(b"ck_s", 2)
+        assert pyverify.verify_bytes(inst, g[:2048], g[2048], g_s[0], g_s[1], data, vk_digest=gsp.vk_digest.tobytes()) == [int(v) for v in inst.publics]
     gsp.close()
 
 

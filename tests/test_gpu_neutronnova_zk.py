@@ -229,5 +229,10 @@ def test_c3_sha256_neutronnova_32_steps(ctx):
     assert data == onn.proof_to_bytes(want)
     assert gnn.verify_bytes(data) == 0 and (gnn.proof_from_bytes(data) == got).all()
     assert onn.verify_words(onn.proof_from_bytes(data)) == 0
+    # the third verifier at the benchmark's own size: Python integers from the reference's verify alone, vk digest recomputed from the 33 SHA shapes
+    import pynnverify
+
+    pubs = pynnverify.verify_bytes(steps[0], core, 32, host.from_label(b"ck", 2049), data)
+    assert pubs == ([[0]] * 32, [0])
     print("C3 prove phases (ms):", {k: round(v, 3) for k, v in phases.items()}, "proof bytes:", len(data))
     gnn.close()

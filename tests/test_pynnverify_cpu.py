@@ -164,3 +164,14 @@ def test_rest_variables_beside_precommitted_ones_are_refused():
     mk = lambda ws: frontend.synthetic_circuit(30, 0x77, num_public=2, shared_permille=200, precommitted_permille=500, witness_seed=ws)
     with pytest.raises(RuntimeError, match="drops the rest segment"):
         ol.OracleNeutronNova([mk(5), mk(5)], mk(5))
+
+
+def test_config_3_proof_of_the_oracle(gens):
+    """BASELINE config 3 (32 Sha256StepCircuit instances + the core circuit, benches/sha256_neutronnova.rs) at its own size: the oracle's proof, the vk
+    digest recomputed in Python from the SHA shapes, every verifier equation in Python integers"""
+    steps = [frontend.sha256_step_circuit(bytes([i]) * 64) for i in range(32)]
+    core = frontend.sha256_step_circuit(bytes(64))
+    nn = ol.OracleNeutronNova(steps, core)
+    words, _, _ = nn.prove(_tape(b"c3"))
+    assert nn.info["nb"] == 5 and nn.info["nx"] == 15 and nn.info["ny"] == 16
+    assert pnv.verify_bytes(steps[0], core, 32, gens, nn.proof_to_bytes(words)) == ([[0]] * 32, [0])

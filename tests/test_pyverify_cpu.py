@@ -129,3 +129,13 @@ def test_golden_proof_passes_the_python_verifier():
     ck, h, ck_s, h_s, dig = sp.export_keys()
     assert dig.tobytes().hex() == gold["vk_digest"]
     pv.verify(inst, ck, h, ck_s, h_s, words, _layout(sp))
+
+
+def test_config_2_proof_of_the_oracle_at_its_own_size():
+    """BASELINE config 2 (sha256_spartan, 2048-byte message, 2^20 constraints): the oracle's proof under the Python verifier, vk digest recomputed in Python
+    over the 62 MB of matrix bytes"""
+    inst = frontend.sha256_circuit(bytes(2048))
+    sp, words = _prove(inst, 3)
+    ck, h, ck_s, h_s, dig = sp.export_keys()
+    assert pywire.spartan_vk_digest(inst, ck, h, ck_s, h_s) == dig.tobytes()
+    assert pv.verify(inst, ck, h, ck_s, h_s, words, _layout(sp), vk_digest=dig.tobytes()) == [int(v) for v in inst.publics]
