@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import make_golden_impl as g  # noqa: E402
 
 for name, fn in (("sumcheck_small.json", g.sumcheck_small), ("spartan_small.json", g.spartan_small), ("nifs_small.json", g.nifs_small),
-                 ("neutronnova_small.json", g.neutronnova_small)):
+                 ("neutronnova_small.json", g.neutronnova_small), ("neutronnova_rest.json", g.neutronnova_rest)):
     with open(os.path.join(HERE, name), "w") as f:
         json.dump(fn(), f, indent=1)
     print("wrote", name)

@@ -98,6 +98,23 @@ def neutronnova_small():
             "wire_sha256": hashlib.sha256(wire).hexdigest()}
 
 
+def neutronnova_rest():
+    """The reference's own NeutronNova test in small (test_neutron_sha256, src/neutronnova_zk.rs:2357-2503: circuits that live in synthesize): two SHA-256
+    circuits over 32-byte preimages [i; 32] with REST variables only, core = the first one. Pins what the rest-segment path adds: the rest rows committed
+    inside prove, the full-width witness fold."""
+    from spartan2_amd import frontend
+
+    steps = [frontend.sha256_rest_circuit(bytes([i]) * 32) for i in range(2)]
+    tape = np.frombuffer(hashlib.shake_256(b"golden-tape-nn-rest").digest(64 * 32768), dtype=np.uint8).reshape(32768, 64).copy()
+    nn = ol.OracleNeutronNova(steps, steps[0])
+    words, used, _ = nn.prove(tape)
+    assert nn.verify_words(words) == 0
+    wire = nn.proof_to_bytes(words)
+    return {"note": "oracle proof of 2 x sha256_rest_circuit([i; 32]) + core = the first, tape = SHAKE256('golden-tape-nn-rest')",
+            "info": nn.info, "tape_blocks": [int(used[0]), int(used[1])], "proof_words": len(words), "proof_sha256": hashlib.sha256(words.tobytes()).hexdigest(),
+            "vk_digest": nn.digest().tobytes().hex(), "wire_len": len(wire), "wire_sha256": hashlib.sha256(wire).hexdigest()}
+
+
 # ---- NeutronNova NIFS rounds (oracle/nifs.hpp) -----------------------------------------------------------------------------------
 def nifs_inputs(n_inst, num_cons):
     """Layers with SHA-like small entries (A in {-2..2}, B bits, C = A o B) and a few full-size ones; E from a SHAKE-derived tau."""

@@ -148,3 +148,25 @@ def test_neutronnova_proof_against_golden(ctx):
     pubs = pynnverify.verify_bytes(steps[0], core, len(steps), host.from_label(b"ck", 2049), wire)
     assert pubs == ([[int(v) for v in s.publics] for s in steps], [int(v) for v in core.publics])
     nn.close()
+
+
+def test_neutronnova_rest_variables_against_golden(ctx):
+    """The reference's own NeutronNova test in small (circuits that live in synthesize: REST variables, src/neutronnova_zk.rs:2357-2503) on the device-backed
+    driver against frozen data, no oracle in the process: vk digest, tape use, proof words, bincode bytes; its own verifier and the Python one accept."""
+    with open(os.path.join(GOLD, "neutronnova_rest.json")) as f:
+        gold = json.load(f)
+    steps = [frontend.sha256_rest_circuit(bytes([i]) * 32) for i in range(2)]
+    tape = np.frombuffer(hashlib.shake_256(b"golden-tape-nn-rest").digest(64 * 32768), dtype=np.uint8).reshape(32768, 64).copy()
+    nn = host.NeutronNovaZkSNARK(ctx, steps, steps[0])
+    assert nn.info == gold["info"] and nn.vk_digest.tobytes().hex() == gold["vk_digest"]
+    used0 = nn.prep_prove(tape)
+    words, used1, _ = nn.prove(tape[used0:])
+    assert [used0, used1] == gold["tape_blocks"] and len(words) == gold["proof_words"]
+    assert hashlib.sha256(words.tobytes()).hexdigest() == gold["proof_sha256"]
+    wire = nn.proof_to_bytes(words)
+    assert len(wire) == gold["wire_len"] and hashlib.sha256(wire).hexdigest() == gold["wire_sha256"]
+    assert nn.verify(words) == 0 and nn.verify_bytes(wire) == 0
+    import pynnverify
+
+    assert pynnverify.verify_bytes(steps[0], steps[0], 2, host.from_label(b"ck", 2049), wire) == ([[0], [0]], [0])
+    nn.close()
