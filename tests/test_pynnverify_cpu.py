@@ -175,3 +175,16 @@ def test_config_3_proof_of_the_oracle(gens):
     words, _, _ = nn.prove(_tape(b"c3"))
     assert nn.info["nb"] == 5 and nn.info["nx"] == 15 and nn.info["ny"] == 16
     assert pnv.verify_bytes(steps[0], core, 32, gens, nn.proof_to_bytes(words)) == ([[0]] * 32, [0])
+
+
+def test_golden_rest_fixture_is_a_proof_the_python_verifier_accepts(gens):
+    """tests/golden/neutronnova_rest.json (what the GPU suite holds the product to without the oracle): the bytes with that hash are a proof the independent
+    verifier accepts, under a vk digest it recomputes itself"""
+    with open(os.path.join(GOLD, "neutronnova_rest.json")) as f:
+        gold = json.load(f)
+    steps = [frontend.sha256_rest_circuit(bytes([i]) * 32) for i in range(2)]
+    nn = ol.OracleNeutronNova(steps, steps[0])
+    words, _, _ = nn.prove(_tape(b"golden-tape-nn-rest"))
+    wire = nn.proof_to_bytes(words)
+    assert hashlib.sha256(wire).hexdigest() == gold["wire_sha256"] and nn.digest().tobytes().hex() == gold["vk_digest"]
+    assert pnv.verify_bytes(steps[0], steps[0], 2, gens, wire) == ([[0], [0]], [0])
