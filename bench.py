@@ -323,6 +323,16 @@ def _self_launch(n):
     os.execvpe(cmd[0], cmd, env)
 
 
+def dist(ms):
+    """min / median / max of the per-step times of rank 0 (ms): ms_per_step is the mean the contract asks for, this shows what it is made of"""
+    a = sorted(ms)
+    if not a:
+        return None
+    med = a[len(a) // 2]
+    return {"min": a[0], "median": med, "p90": a[(9 * len(a)) // 10], "max": a[-1], "over_2x_median": sum(1 for x in a if x > 2 * med),
+            "steps_over_2x_median": [i for i, x in enumerate(ms) if x > 2 * med][:16], "n": len(a)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -595,6 +605,14 @@ def main():
     step_tape = np.random.default_rng(rng_seed + 1).integers(0, 256, size=(4096, 64), dtype=np.uint8)
     snark.set_flags(prefix_cache=False)  # the timed prove() re-hashes the transcript prefix, as the reference's prove does
 
+    # The harness, not the prover: with PyTorch imported, one full collection of CPython's cyclic GC walks a few million objects - 50-70 ms, once
+    # every ~100 proves (the ctypes calls allocate), which a mean over 20 steps either misses or takes as +3 ms per step. Collect now, then keep
+    # the collector out of the timed loops; step_ms_distribution shows what remains.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for _ in range(args.warmup):
         words, _, _ = snark.prove(step_tape)
     ctx.reset_stats(True)
@@ -602,8 +620,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     phase_acc = {}
+    step_ms = []  # each prove's own wall time around the call: shows an outlier the mean would hide
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         words, _, phases = snark.prove(step_tape)
+        step_ms.append((time.perf_counter() - t_s) * 1e3)
+        if step_ms[-1] >= max(step_ms):
+            slowest = dict(phases)
         for k, v in phases.items():
             phase_acc[k] = phase_acc.get(k, 0.0) + v
     barrier()
@@ -631,13 +654,19 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ref_phase = {}
+    ref_step_ms = []
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         words_r, _, ph_r = snark.prove(step_tape)
+        ref_step_ms.append((time.perf_counter() - t_s) * 1e3)
+        if ref_step_ms[-1] >= max(ref_step_ms):
+            ref_slowest = dict(ph_r)
         for k, v in ph_r.items():
             ref_phase[k] = ref_phase.get(k, 0.0) + v
     barrier()
     elapsed_ref = group.max_over_ranks(time.perf_counter() - t0)
     snark.set_flags(reference_order=False)
+    gc.enable()
     # untimed extra pass with every kernel class instrumented (main and auxiliary streams), for the per-kernel breakdown
     ctx.reset_stats(True)
     ctx.stats_filter("")
@@ -781,7 +810,9 @@ def main():
             "transcript_prefix_cached": {"ms_per_step": elapsed_cached / args.steps * 1e3, "constraints_per_s": world * ncons * args.steps / elapsed_cached,
                                          "proof_identical": bool((words_c == words).all()),
                                          "note": "sponge state of new + vk + public_values + comm_W_precommitted kept across proves (FLAG_PREFIX_CACHE): not the headline"},
+            "step_ms_distribution": dict(dist(step_ms), slowest_step_phases_ms=slowest),
             "reference_order": {"ms_per_step": elapsed_ref / args.steps * 1e3, "constraints_per_s": world * ncons * args.steps / elapsed_ref,
+                                "step_ms_distribution": dict(dist(ref_step_ms), slowest_step_phases_ms=ref_slowest),
                                 "proof_identical": bool((words_r == words).all()), "phases_ms": {k: v / args.steps for k, v in ref_phase.items()},
                                 "headline_over_reference_order": elapsed / elapsed_ref,
                                 "note": "one thread, statement order of src/spartan.rs:226-466, ABI calls only (PCS::prove = one sp_hyrax_prove): the time of an unchanged spartan.rs over the ABI"},

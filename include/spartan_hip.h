@@ -111,8 +111,9 @@ int sp_eq_table(sp_ctx* ctx, const uint64_t* r, size_t ell, sp_table** out);
 /* the `_into` form (src/polys/eq.rs:96-117) reusing an existing allocation of at least 2^ell elements */
 int sp_eq_table_into(sp_ctx* ctx, const uint64_t* r, size_t ell, sp_table* out);
 /* The same table for a point a sum-check is still drawing (evals_rx of src/spartan.rs:316 needs r_x, whose last coordinate is the outer sum-check's last
- * challenge): `_begin`, given the first ell - 2 coordinates (12 <= ell <= 20), builds the half tables on a stream of its own under the last two rounds;
- * `_finish`, given all of them, is one launch. Without a matching `_begin` (or with a different prefix) `_finish` is sp_eq_table_into. */
+ * challenge): `_begin`, given all but the last two, three or four coordinates (ell - 4 <= n_known <= ell - 2, 12 <= ell <= 20), builds the half tables
+ * on a stream of its own under the remaining rounds; `_finish`, given all of them, is one launch. Without a matching `_begin` (or with a different
+ * prefix) `_finish` is sp_eq_table_into. */
 int sp_eq_table_begin(sp_ctx* ctx, const uint64_t* r_known, size_t n_known, size_t ell);
 int sp_eq_table_finish(sp_ctx* ctx, const uint64_t* r, size_t ell, sp_table* out);
 

@@ -23,23 +23,14 @@ static int comb_bits() {
   return v;
 }
 size_t comb_min_rows() { return 256; }
-int comb_ensure(sp_ctx* c, const sp_ck* ck) {
-  std::lock_guard<std::mutex> lk(ck->lazy_mu);
-  if (ck->d_comb) return SP_OK;
-  if (ck->comb_failed || comb_bits() == 0) return 1;  // not available: the caller takes the bucket path
+static int comb_build(sp_ctx* c, const sp_ck* ck, aff_t** out_tab, int* out_c, int* out_windows) {  // 0 = built, 1 = not available, < 0 = error
   const int C = comb_bits(), windows = (257 + C - 1) / C;
   const unsigned E = 1u << (C - 1);
   const size_t ncols = ck->num_cols, per_window = ncols * E, total = per_window * windows;
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total * sizeof(aff_t) + ((size_t)4 << 30)) {
-    ck->comb_failed = true;
-    return 1;
-  }
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < total * sizeof(aff_t) + ((size_t)4 << 30)) return 1;
   aff_t* tab = nullptr;
-  if (hipMalloc((void**)&tab, total * sizeof(aff_t)) != hipSuccess) {
-    ck->comb_failed = true;
-    return 1;
-  }
+  if (hipMalloc((void**)&tab, total * sizeof(aff_t)) != hipSuccess) return 1;
   // Jacobian staging for a group of windows (<= 8 GiB), then Montgomery's trick per 8 points
   size_t gw = ((size_t)8 << 30) / (per_window * sizeof(jac_t));
   if (gw < 1) gw = 1;
@@ -48,7 +39,6 @@ int comb_ensure(sp_ctx* c, const sp_ck* ck) {
   jac_t* stage = nullptr;
   if (hipMalloc((void**)&stage, gw * per_window * sizeof(jac_t)) != hipSuccess) {
     hipFree(tab);
-    ck->comb_failed = true;
     return 1;
   }
   const unsigned segs = E >= 64 ? 8 : 1;
@@ -62,12 +52,38 @@ int comb_ensure(sp_ctx* c, const sp_ck* ck) {
   hipFree(stage);
   if (e != hipSuccess) {
     hipFree(tab);
-    ck->comb_failed = true;
     return fail(SP_ERR_NO_DEVICE, std::string("comb table build: ") + hipGetErrorString(e));
   }
-  ck->d_comb = tab;
+  *out_tab = tab;
+  *out_c = C;
+  *out_windows = windows;
+  return SP_OK;
+}
+int comb_ensure(sp_ctx* c, const sp_ck* ck) {
+  for (;;) {  // claim the build, find it done, or wait for the builder outside the lock (group_common.hpp: no mutex is held across a stream wait)
+    {
+      std::lock_guard<std::mutex> lk(ck->lazy_mu);
+      if (ck->d_comb) return SP_OK;
+      if (ck->comb_failed || comb_bits() == 0) return 1;  // not available: the caller takes the bucket path
+      if (!ck->comb_building) {
+        ck->comb_building = true;
+        break;
+      }
+    }
+    sp::relax();
+  }
+  aff_t* tab = nullptr;
+  int C = 0, windows = 0;
+  const int rc = comb_build(c, ck, &tab, &C, &windows);
+  std::lock_guard<std::mutex> lk(ck->lazy_mu);
+  ck->comb_building = false;
+  if (rc) {
+    ck->comb_failed = true;
+    return rc;
+  }
   ck->comb_c = C;
   ck->comb_windows = windows;
+  ck->d_comb = tab;
   return SP_OK;
 }
 // rows `sel` of canon (values < 2^nbits) against the comb table -> out[sel[i]]

@@ -20,6 +20,10 @@ void relax() {
   if (g_wait_hook) g_wait_hook(g_wait_user);
   else __builtin_ia32_pause();
 }
+void slow_note(const char* site, long spins) {
+  static const bool on = getenv("SPARTAN_SLOWPATH_LOG") != nullptr;
+  if (on) fprintf(stderr, "[slow path] %s after %ld polls\n", site, spins);
+}
 hipError_t stream_sync(hipStream_t s) {
   if (!g_wait_hook) return hipStreamSynchronize(s);
   hipError_t e;
@@ -141,6 +145,7 @@ int sp_ctx_create(int device, sp_ctx** out) {
   SP_HIP(hipStreamCreate(&c->stream2));
   SP_HIP(hipStreamCreateWithFlags(&c->stream_eq, hipStreamNonBlocking));
   SP_HIP(hipEventCreateWithFlags(&c->eq_ev, hipEventDisableTiming));
+  SP_HIP(hipEventCreateWithFlags(&c->eq_read_ev, hipEventDisableTiming));
   SP_HIP(hipMalloc((void**)&c->d_eq_ahead, 2 * ((size_t)1 << 11) * sizeof(fe_t)));
   c->pinned_elems = spk::MAIL_MIRROR_ELEM + 16;
   SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
@@ -215,6 +220,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream_eq) hipStreamDestroy(c->stream_eq);
   if (c->eq_ev) hipEventDestroy(c->eq_ev);
+  if (c->eq_read_ev) hipEventDestroy(c->eq_read_ev);
   if (c->d_eq_ahead) hipFree(c->d_eq_ahead);
   delete c;
 }
@@ -421,6 +427,7 @@ static int wait_slot(sp_ctx* c, const fe_t* slot, unsigned want, int nvals, fe_t
   volatile const unsigned* fl = reinterpret_cast<volatile const unsigned*>(slot + 3);
   while (*fl != want) {
     if (++*spins > 400000) {  // a few ms
+      sp::slow_note("wait_slot", *spins);
       if (resident) {        // the tail kernel is itself waiting for the host: keep polling, bounded by wall-clock
         const auto t0 = std::chrono::steady_clock::now();
         while (*fl != want) {
@@ -454,6 +461,26 @@ static int wait_wide(sp_ctx* c, unsigned want, int nvals, fe_t* v) {
     if (rc) return rc;
   }
   return SP_OK;
+}
+// The tables of a hand-over (kernels_poly.hpp tail_hand_over): nvals elements, three per result slot from slot 0 on. Slot 0 is polled; once it has
+// landed the other lines are on their way: their cache misses are started together before the slots are validated one by one.
+static int wait_hand_over(sp_ctx* c, unsigned want, int nvals, fe_t* v) {
+  long spins = 0;
+  int rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM, want, nvals < 3 ? nvals : 3, v, true, &spins);
+  if (rc) return rc;
+  for (int s0 = 3; s0 < nvals; s0 += 3) {
+    const char* line = reinterpret_cast<const char*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * (s0 / 3));
+    __builtin_prefetch(line);
+    __builtin_prefetch(line + 64);
+  }
+  for (int s0 = 3; s0 < nvals; s0 += 3)
+    if ((rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM + 4 * (s0 / 3), want, nvals - s0 < 3 ? nvals - s0 : 3, v + s0, true, &spins))) return rc;
+  return SP_OK;
+}
+// bind_poly_var_top (src/polys/multilinear.rs:95-164) on a host table of n entries: the rounds the host runs itself after a hand-over
+static void host_bind_top(fe_t* Z, size_t n, const fe_t& r) {
+  const size_t h = n / 2;
+  for (size_t x = 0; x < h; ++x) Z[x] = fe_add<S>(Z[x], fe_mul<S>(r, fe_sub<S>(Z[x + h], Z[x])));
 }
 // groups > 1 (slot path only): the first nb / groups slots are summed into out_host[0 .. nacc), the next into out_host[nacc .. 2 nacc), ... (the two
 // instances of a batched round evaluated by one launch)
@@ -504,6 +531,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
       }
       if (!remaining) break;
       if (++passes == 200000) {  // a few ms without completion
+        sp::slow_note("reduce_partials_wait (slots)", passes);
         if (!resident) {
           SP_HIP(sp::stream_sync(c->stream));  // e.g. under a profiler
         }
@@ -527,6 +555,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
     }
     sp::relax();
   }
+  if (!seen) sp::slow_note("reduce_partials_wait (flag)", 200000);
   if (!seen && resident) {
     const auto t0 = std::chrono::steady_clock::now();
     while (*flag != want) {
@@ -825,19 +854,26 @@ int sp_eq_table_into(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
 }
 
 // EqPolynomial::evals_from_points for a point that a sum-check is still drawing (evals_rx, src/spartan.rs:316): `_begin`, called when all but the last
-// two coordinates exist, builds the two pyramids on a stream of its own under the last two rounds; `_finish` (all coordinates known) is then ONE launch,
-// the outer product with the last two variables applied in it - instead of pyramids (12-14 us behind a launch gap) + outer product behind the last
-// challenge. 12 <= ell <= 20. `_finish` checks that the known prefix has not changed and falls back to sp_eq_table_into when there was no `_begin`.
+// K coordinates exist (2 <= K <= 4), builds the two pyramids on a stream of its own under the last K rounds; `_finish` (all coordinates known) is then
+// ONE launch, the outer product with the last K variables applied in it - instead of pyramids (12-14 us behind a launch gap) + outer product behind the
+// last challenge. K = 4 is the moment the sum-check's resident kernel hands its last rounds to the host (kernels_poly.hpp tail_hand_over): the
+// pyramids then have those rounds' whole host time. 12 <= ell <= 20. `_finish` checks that the known prefix has not changed and falls back to
+// sp_eq_table_into when there was no `_begin`.
 int sp_eq_table_begin(sp_ctx* c, const uint64_t* r_known, size_t n_known, size_t ell) {
-  if (ell < 12 || ell > 20 || n_known + 2 != ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table_begin: 12 <= ell <= 20 and exactly ell - 2 known coordinates");
-  const int lo_bits = 10, hi_bits = (int)ell - lo_bits;
+  if (ell < 12 || ell > 20 || n_known + 2 > ell || n_known + 4 < ell)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table_begin: 12 <= ell <= 20 and all but the last two to four coordinates known");
+  const int K = (int)(ell - n_known), lo_bits = 10, hi_bits = (int)ell - lo_bits;
   spk::EqPairArgs ea;
   for (int i = 0; i < hi_bits; ++i) ea.v[0][i] = load_fe(r_known + 4 * i);
-  for (int i = 0; i < lo_bits - 2; ++i) ea.v[1][i] = load_fe(r_known + 4 * (hi_bits + i));
+  for (int i = 0; i < lo_bits - K; ++i) ea.v[1][i] = load_fe(r_known + 4 * (hi_bits + i));
   ea.m[0] = hi_bits;
-  ea.m[1] = lo_bits - 2;
+  ea.m[1] = lo_bits - K;
   ea.out[0] = c->d_eq_ahead;
   ea.out[1] = c->d_eq_ahead + ((size_t)1 << 11);
+  if (c->eq_read_pending) {  // an outer product of an earlier _finish may still be reading the buffer on the main stream: the streams are not otherwise ordered
+    SP_HIP(hipStreamWaitEvent(c->stream_eq, c->eq_read_ev, 0));
+    c->eq_read_pending = false;
+  }
   hipLaunchKernelGGL(spk::k_eq_levels_pair, dim3(2), dim3(1024), 0, c->stream_eq, ea);
   SP_HIP(hipEventRecord(c->eq_ev, c->stream_eq));
   memcpy(c->eq_ahead_r, r_known, n_known * sizeof(fe_t));
@@ -853,14 +889,17 @@ int sp_eq_table_finish(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
   if (t->cap < total) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_eq_table_finish: table too short");
   t->len = total;
   t->lo_eff = t->hi_eff = (size_t)-1;
-  const int lo_bits = 10, hi_bits = (int)ell - lo_bits;
+  const int lo_bits = 10, hi_bits = (int)ell - lo_bits, K = (int)(ell - c->eq_ahead_known);
   SP_HIP(hipStreamWaitEvent(c->stream, c->eq_ev, 0));
-  size_t blocks = (total / 4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  const size_t n_hi = (size_t)1 << hi_bits;
+  spk::EqLastK rk;
+  for (int i = 0; i < 4; ++i) rk.r[i] = i < K ? load_fe(r + 4 * (ell - K + i)) : fe_zero();
   c->timed("eq_table", 32ull * total, [&] {
-    hipLaunchKernelGGL(spk::k_eq_outer_last2, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_eq_ahead + spk::eq_level_offset(hi_bits),
-                       c->d_eq_ahead + ((size_t)1 << 11) + spk::eq_level_offset(lo_bits - 2), lo_bits, total, load_fe(r + 4 * (ell - 2)), load_fe(r + 4 * (ell - 1)), t->d);
+    hipLaunchKernelGGL(spk::k_eq_outer_lastk, dim3((unsigned)((n_hi + spk::EQ_LASTK_HPB - 1) / spk::EQ_LASTK_HPB)), dim3(256), 0, c->stream,
+                       c->d_eq_ahead + spk::eq_level_offset(hi_bits), c->d_eq_ahead + ((size_t)1 << 11) + spk::eq_level_offset(lo_bits - K), K, n_hi, rk, t->d);
   });
+  SP_HIP(hipEventRecord(c->eq_read_ev, c->stream));
+  c->eq_read_pending = true;
   return SP_OK;
 }
 
@@ -1121,6 +1160,10 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
   if (rc) return rc;
   bool have_sums = false;  // true when a launch already in flight produces this round's sums
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
+  bool host_mode = false;  // ... and has handed the tables over: the remaining rounds run on the host (kernels_poly.hpp tail_hand_over)
+  std::vector<fe_t> hA;    // host tables after a hand-over: A, then B
+  fe_t* hB = nullptr;
+  unsigned hand_seq = 0;
   unsigned last_answered = 0;  // sequence number answered by the most recent challenge
   TailLease lease;
   AheadGuard guard(c);
@@ -1223,7 +1266,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     const double tr0 = round_trace() ? now_us() : 0;
     fe_t sums[2] = {fe_zero(), fe_zero()};
     bool waiting = have_sums;
-    if (!have_sums) {  // compute_eval_points_quad on the current tables (src/sumcheck.rs:128-174)
+    if (!have_sums && !host_mode) {  // compute_eval_points_quad on the current tables (src/sumcheck.rs:128-174)
       size_t len = sp::eff_pairs(A);
       if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
       if (half < len) len = half;
@@ -1253,7 +1296,22 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     // this round's sums are in flight: remember how to wait for them, then issue the next launch ahead of the challenge where that is possible
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
-    if (wait_resident && spk::tail_double(false, len_now)) {
+    if (wait_resident && !host_mode && spk::tail_hand_over(false, len_now)) {
+      // HAND-OVER (kernels_poly.hpp tail_hand_over): the resident kernel sent the tables themselves; this round and the ones after it run here
+      hA.resize(2 * len_now);
+      if ((rc = wait_hand_over(c, wait_seq, (int)(2 * len_now), hA.data()))) return rc;
+      hB = hA.data() + len_now;
+      host_mode = true;
+      hand_seq = wait_seq;
+    }
+    if (host_mode) {  // compute_eval_points_quad (src/sumcheck.rs:128-174) on the host tables; dense by construction (the tail only takes dense tables)
+      for (size_t x = 0; x < half; ++x) {
+        sums[0] = fe_add<S>(sums[0], fe_mul<S>(hA[x], hB[x]));
+        sums[1] = fe_add<S>(sums[1], fe_mul<S>(fe_sub<S>(hA[x + half], hA[x]), fe_sub<S>(hB[x + half], hB[x])));
+      }
+      waiting = false;
+    }
+    if (!host_mode && wait_resident && spk::tail_double(false, len_now)) {
       // TWO ROUNDS IN THIS TRIP (kernels_poly.hpp TAIL_WIDE_VALS): the resident kernel sent the sums of this round and the coefficient sums, in this
       // round's challenge, of the next. S0 = sum a0 b0, S1 = a1 b1, S2 = (a2-a0)(b2-b0), S3 = (a3-a1)(b3-b1), S4 = a2 b2, S5 = U V, S6 = dU dV,
       // S7 = (U+dU)(V+dV) over the quarters a0..a3 of the table.
@@ -1310,7 +1368,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       continue;
     }
     int issued = 0;
-    if (waiting && (in_tail || (c->mail_dev && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
+    if (!host_mode && waiting && (in_tail || (c->mail_dev && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(round, nullptr, wait_seq);
       if (issued < 0) return issued;
       guard.armed = issued != 0;
@@ -1346,7 +1404,13 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     fe_t r_i;
     if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
     last_answered = wait_seq;
-    if (issued) {
+    if (host_mode) {
+      host_bind_top(hA.data(), len_now, r_i);
+      host_bind_top(hB, len_now, r_i);
+      sp::after_bind(A);
+      sp::after_bind(B);
+      have_sums = false;
+    } else if (issued) {
       tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this: first, the book-keeping below runs under it
     } else {
       issued = issue(round, &r_i, wait_seq);
@@ -1357,7 +1421,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     store_fe(out_cpolys + 8 * round, poly.c[0]);
     store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
     claim = poly_eval(poly, r_i);
-    guard.armed = in_tail && round + 1 < rounds;  // the resident kernel now waits for the next challenge
+    guard.armed = in_tail && (host_mode || round + 1 < rounds);  // the resident kernel now waits for the next challenge (after a hand-over: for the final claims)
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];
       store_fe(rw, r_i);
@@ -1369,7 +1433,14 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     store_fe(claim_io, claim);
     return tail_check(c);
   }
-  if (in_tail) {  // the resident kernel hands the final claims over itself
+  if (host_mode) {  // the final claims are here; the kernel, waiting at the mailbox, stores them into element 0 of its tables and leaves
+    store_fe(out_final, hA[0]);
+    store_fe(out_final + 4, hB[0]);
+    tail_post_challenge(c, hA[0], hand_seq);
+    tail_post_challenge(c, hB[0], hand_seq + 1);
+    c->result_seq = hand_seq + 1;  // the two lines took sequence numbers of their own
+    guard.armed = false;
+  } else if (in_tail) {  // the resident kernel hands the final claims over itself
     fe_t fin[3];
     long spins = 0;
     if ((rc = wait_slot(c, c->h_pinned + spk::TAIL_FINAL_ELEM, last_answered, 2, fin, true, &spins))) return rc;
@@ -1701,9 +1772,9 @@ struct EqAheadObserver {
 };
 static void eq_ahead_observe(void* user, size_t round, const uint64_t r[4]) {
   EqAheadObserver* o = (EqAheadObserver*)user;
-  if (round + 2 >= o->ell) return;
+  if (round + 4 >= o->ell) return;
   memcpy(o->r + 4 * round, r, 32);
-  if (round + 3 == o->ell) sp_eq_table_begin(o->c, o->r, o->ell - 2, o->ell);  // a failure leaves no announcement: sp_eq_table_into builds it all
+  if (round + 5 == o->ell) sp_eq_table_begin(o->c, o->r, o->ell - 4, o->ell);  // a failure leaves no announcement: sp_eq_table_into builds it all
 }
 int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, sp_transcript* tr,
                        uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
@@ -1712,7 +1783,7 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   const fe_t one = fe_one<S>();
   store_fe(p_io, one);
   // evals_rx (src/spartan.rs:316) follows this sum-check in the reference's order of calls: its two half pyramids are started here, under the last
-  // two rounds, so that the caller's sp_eq_table_into(r_x) is one launch behind the last challenge (as sp_eq_table_begin / _finish for a caller
+  // four rounds (the ones the host runs itself after the resident kernel's hand-over), so that the caller's sp_eq_table_into(r_x) is one launch behind the last challenge (as sp_eq_table_begin / _finish for a caller
   // that announces it itself)
   EqAheadObserver ea{c, ell, {}};
   const bool ahead = ell >= 12 && ell <= 20;
@@ -1849,6 +1920,10 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
 
   fe_t claim = load_fe(claim_);
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
+  bool host_mode = false;  // ... and has handed the tables over: the remaining rounds run on the host (kernels_poly.hpp tail_hand_over)
+  std::vector<fe_t> hT, hE;  // host tables after a hand-over (A | B | C, n0 entries each) and the round's eq weights
+  size_t n0 = 0;
+  unsigned hand_seq = 0;
   unsigned last_answered = 0;
   TailLease lease;
   AheadGuard guard(c);
@@ -2020,7 +2095,15 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     // Not when tau * p vanishes: that round re-evaluates with a third sum (fallback_three_inputs), which must not queue behind a waiting kernel.
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
-    if (wait_resident && spk::tail_double(true, A->len)) {
+    if (wait_resident && !host_mode && spk::tail_hand_over(true, A->len)) {
+      // HAND-OVER (kernels_poly.hpp tail_hand_over): the resident kernel sent the tables themselves; this round and the ones after it run here
+      n0 = A->len;
+      hT.resize(3 * n0);
+      if ((rc = wait_hand_over(c, wait_seq, (int)(3 * n0), hT.data()))) return rc;
+      host_mode = true;
+      hand_seq = wait_seq;
+    }
+    if (!host_mode && wait_resident && spk::tail_double(true, A->len)) {
       // TWO ROUNDS IN THIS TRIP (kernels_poly.hpp TAIL_WIDE_VALS). W[9..12) = t(0), t_inf, t(-1) of round rnd; W[0..9) = the coefficient sums of
       // round rnd + 1 in this round's challenge r: t'(0) = W0 + r (W1 - W0 - W2) + r^2 W2, t'_inf = W3 + r (W5 - W3 - W4) + r^2 W4,
       // t'(-1) = W6 + r (W8 - W6 - W7) + r^2 W7 (used by the fallback_three_inputs form only, as in the one-round path).
@@ -2103,23 +2186,50 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       continue;
     }
     int issued = 0;
-    if (in_tail || (c->mail_dev && invertible && !reduce)) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
+    if (!host_mode && (in_tail || (c->mail_dev && invertible && !reduce))) {  // not with a reduce hook: it may run device work (a collective) beside the waiting kernel
       issued = issue(rnd, nullptr, wait_seq);
       if (issued < 0) return issued;
       guard.armed = issued != 0;
     }
-    const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
-    c->result_seq = wait_seq;
-    c->pending_slots = wait_slots;
     fe_t sums[3];
     const double tr0 = round_trace() ? now_us() : 0;
     const size_t len_now = A->len;
-    rc = reduce_partials_wait(c, wait_resident ? 3 : 2, sums, wait_resident || issued != 0);  // never a stream synchronise with a launch waiting at the mailbox
-    if (issued) {  // back to the state of the launch issued ahead
-      c->result_seq = cur_seq;
-      c->pending_slots = cur_slots;
+    if (host_mode) {
+      // evaluation_points_cubic_with_three_inputs + t(-1) (src/sumcheck.rs:1025-1156, :1327-1396) on the host tables: pairs (x, x + n / 2) weighted with
+      // E(rnd, x) = eq(taus[rnd ..), x) - what the split tables of either half multiply out to (select_eq)
+      const size_t n = len_now, hn = n / 2;
+      const fe_t *ha = hT.data(), *hb = ha + n0, *hc = hb + n0;
+      hE.assign(1, one);
+      for (size_t i = rnd; i < ell; ++i) {  // first variable = most significant bit of x
+        const size_t m = hE.size();
+        hE.resize(2 * m);
+        for (size_t j = m; j-- > 0;) {
+          const fe_t hi = fe_mul<S>(hE[j], taus[i]);
+          hE[2 * j] = fe_sub<S>(hE[j], hi);
+          hE[2 * j + 1] = hi;
+        }
+      }
+      sums[0] = sums[1] = sums[2] = fe_zero();
+      for (size_t x = 0; x < hn; ++x) {
+        const fe_t a0 = ha[x], a1 = ha[x + hn], b0 = hb[x], b1 = hb[x + hn], c0 = hc[x], c1 = hc[x + hn];
+        const fe_t v0 = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+        const fe_t v1 = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+        const fe_t v2 = fe_sub<S>(fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1)), fe_sub<S>(fe_dbl<S>(c0), c1));
+        sums[0] = fe_add<S>(sums[0], fe_mul<S>(hE[x], v0));
+        sums[1] = fe_add<S>(sums[1], fe_mul<S>(hE[x], v1));
+        sums[2] = fe_add<S>(sums[2], fe_mul<S>(hE[x], v2));
+      }
+    } else {
+      const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
+      c->result_seq = wait_seq;
+      c->pending_slots = wait_slots;
+      rc = reduce_partials_wait(c, wait_resident ? 3 : 2, sums, wait_resident || issued != 0);  // never a stream synchronise with a launch waiting at the mailbox
+      if (issued) {  // back to the state of the launch issued ahead
+        c->result_seq = cur_seq;
+        c->pending_slots = cur_slots;
+      }
+      if (rc) return rc;
     }
-    if (rc) return rc;
     const double tr1 = round_trace() ? now_us() : 0;
     if ((rc = combine(sums, wait_resident ? 3 : 2))) return rc;
     const fe_t t0 = sums[0], tinf = sums[1];
@@ -2167,7 +2277,12 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
     const size_t ri = rnd - 1;
     last_answered = wait_seq;
-    if (issued) {
+    if (host_mode) {
+      for (int t = 0; t < 3; ++t) host_bind_top(hT.data() + t * n0, len_now, r_i);
+      sp::after_bind(A);
+      sp::after_bind(B);
+      sp::after_bind(C);
+    } else if (issued) {
       tail_post_challenge(c, r_i, wait_seq);  // whatever was issued ahead is waiting for exactly this: first, the book-keeping below runs under it
     } else {
       issued = issue(rnd, &r_i, wait_seq);
@@ -2178,7 +2293,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
     store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
     claim = poly_eval(poly, r_i);
-    guard.armed = in_tail && rnd < ell;  // the resident kernel now waits for the next challenge
+    guard.armed = in_tail && (host_mode || rnd < ell);  // the resident kernel now waits for the next challenge (after a hand-over: for the final claims)
     if (observe) {  // after the device has been given this round's challenge: the observer's work runs under the next round
       uint64_t rw[4];
       store_fe(rw, r_i);
@@ -2194,7 +2309,14 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     store_fe(p_io, eval_eq_left);
     return tail_check(c);
   }
-  if (in_tail) {  // the resident kernel hands the final claims over itself
+  if (host_mode) {  // the final claims are here; the kernel, waiting at the mailbox, stores them into element 0 of its tables and leaves
+    for (int t = 0; t < 3; ++t) {
+      store_fe(out_final + 4 * t, hT[t * n0]);
+      tail_post_challenge(c, hT[t * n0], hand_seq + (unsigned)t);
+    }
+    c->result_seq = hand_seq + 2;  // the three lines took sequence numbers of their own
+    guard.armed = false;
+  } else if (in_tail) {  // the resident kernel hands the final claims over itself
     fe_t fin[3];
     long spins = 0;
     if ((rc = wait_slot(c, c->h_pinned + spk::TAIL_FINAL_ELEM, last_answered, 3, fin, true, &spins))) return rc;

@@ -547,6 +547,7 @@ static int fb_mapped_collect(sp_ctx* c, int lane, size_t n, void* out_, unsigned
         if (slot[T] == seq && slot[T + 1] == a && slot[T + 2] == b && slot[T + 3] == seq) break;
       }
       if (spins > 4000000) {
+        sp::slow_note("fb_mapped_collect", spins);
         if (synced) return fail(SP_ERR_INTERNAL, "fixed-base rows: the kernel did not deliver a result slot");
         SP_HIP(sp::stream_sync(st));  // e.g. under a profiler
         synced = true;
@@ -1254,7 +1255,11 @@ int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t*
     if (!last || raw_blocks > n - 1 || 64 * (n - 1) > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multi_mul: raw blocks do not fit");
     memcpy((char*)c->h_mm[lane] + 256, scalars, 64 * raw_blocks);
     if (raw_blocks < n - 1) memset((char*)c->h_mm[lane] + 256 + 64 * raw_blocks, 0, 64 * (n - 1 - raw_blocks));  // from_uniform(0) == 0
-  } else if (!d_scalars) memcpy((char*)c->h_mm[lane] + 256, scalars, n * sizeof(fe_t));
+    c->mm_host_bytes[lane] = 64 * raw_blocks;
+  } else if (!d_scalars) {
+    memcpy((char*)c->h_mm[lane] + 256, scalars, n * sizeof(fe_t));
+    c->mm_host_bytes[lane] = n * sizeof(fe_t);
+  }
   if (++c->mm_seq[lane] == 0) ++c->mm_seq[lane];
   const unsigned seq = c->mm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
@@ -1289,6 +1294,7 @@ int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield)
       if (slot[24] == seq && slot[25] == a && slot[26] == b && slot[27] == seq) break;
     }
     if (spins > 400000) {
+      sp::slow_note("multi_mul_collect", spins);
       if (synced) return fail(SP_ERR_INTERNAL, "multi_mul: the kernel did not deliver its result slot");
       SP_HIP(sp::stream_sync(lane ? c->stream2 : c->stream));  // e.g. under a profiler
       synced = true;
@@ -1299,6 +1305,10 @@ int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield)
     else sp::relax();
   }
   memcpy(out, w, sizeof(jac_t));
+  if (c->mm_host_bytes[lane]) {  // the kernel has finished with the scalars (randomness blocks, blinds) it read from the mapped page
+    explicit_bzero((char*)c->h_mm[lane] + 256, c->mm_host_bytes[lane]);
+    c->mm_host_bytes[lane] = 0;
+  }
   return SP_OK;
 }
 // window tables of the whole key (num_cols bases, then h), built on first use: every MSM over the key — the IPA mask commitment delta, comm_LZ —
@@ -1308,20 +1318,35 @@ int ck_key_tables(sp_ctx* c, const sp_ck* ck) {
     const char* e = getenv("SPARTAN_KEY_TABLES");  // "0": keep the bucket MSMs (A/B runs, tests of the fallback)
     if (e && e[0] == '0') return 1;
   }
-  std::lock_guard<std::mutex> lk(ck->lazy_mu);  // two contexts / threads sharing the key: one builds, the other finds the tables
-  if (ck->d_keytables) return SP_OK;
-  if (ck->keytables_failed) return 1;
-  if (ck->num_cols + 1 > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return 1;
-  std::vector<aff_t> pts(ck->num_cols + 1);
-  hipError_t e = hipMemcpy(pts.data(), ck->d_bases, ck->num_cols * sizeof(aff_t), hipMemcpyDeviceToHost);
-  if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("key tables: ") + hipGetErrorString(e));
-  pts[ck->num_cols] = ck->h;
-  aff_t* tables = nullptr;
-  int rc = build_window_tables(c, pts.data(), pts.size(), &tables);
-  if (rc) {
-    ck->keytables_failed = true;  // out of memory: the bucket MSM stays
-    return 1;
+  for (;;) {  // claim the build, find it done, or wait for the builder outside the lock (group_common.hpp)
+    {
+      std::lock_guard<std::mutex> lk(ck->lazy_mu);
+      if (ck->d_keytables) return SP_OK;
+      if (ck->keytables_failed) return 1;
+      if (ck->num_cols + 1 > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return 1;
+      if (!ck->keytables_building) {
+        ck->keytables_building = true;
+        break;
+      }
+    }
+    relax();
   }
+  aff_t* tables = nullptr;
+  int rc = SP_OK;
+  {
+    std::vector<aff_t> pts(ck->num_cols + 1);
+    hipError_t e = hipMemcpy(pts.data(), ck->d_bases, ck->num_cols * sizeof(aff_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+      rc = fail(SP_ERR_NO_DEVICE, std::string("key tables: ") + hipGetErrorString(e));
+    } else {
+      pts[ck->num_cols] = ck->h;
+      if (build_window_tables(c, pts.data(), pts.size(), &tables)) rc = 1;  // out of memory: the bucket MSM stays
+    }
+  }
+  std::lock_guard<std::mutex> lk(ck->lazy_mu);
+  ck->keytables_building = false;
+  if (rc == 1) ck->keytables_failed = true;
+  if (rc) return rc;
   ck->d_keytables = tables;
   return SP_OK;
 }
@@ -1380,9 +1405,11 @@ struct sp_pcs_ahead {
   sp::Keccak256State hashed;  // "poly_com" || commitment bytes hashed into a fresh sponge (valid when the transcript is fresh at the absorb: checked)
   bool worker_busy = false, delta_launched = false, delta_collected = false, lz_launched = false, failed = false;
   // <R, d> (ipa.rs:148) with R = eq(point[nvr..]) = left (x) right: T[b] = sum_a left[a] d[a * nright + b] once the first half of R's variables is drawn
-  std::vector<fe_t> col_pt, T;
+  // col_pt collects the column challenges as they arrive; col_pt_T is the snapshot T was built from (frozen when the job is submitted): sp_hyrax_prove
+  // compares ITS point with col_pt_T, so a later sum-check of the same length on this context — which overwrites col_pt — cannot make a stale T pass
+  std::vector<fe_t> col_pt, col_pt_T, T;
   size_t hb = 0;
-  bool T_ready = false;
+  bool T_submitted = false, T_ready = false;
   unsigned seq_delta = 0, seq_lz = 0;
   jac_t delta_j;
   fe_t r_LZ;
@@ -1400,10 +1427,23 @@ static void pcs_ahead_drain(sp_ctx* c) {  // no device job of a dropped announce
   }
 }
 bool pcs_ahead_wants(const sp_ctx* c, size_t rounds) { return c->pcs_ahead && !c->pcs_ahead->failed && rounds == c->pcs_ahead->npt + 1; }
+// The announcement holds zero-knowledge material for the span of both sum-checks (the commitment's blinds, the IPA's randomness blocks and the mask
+// vector drawn from them, the partial sums of <R, d>, r_delta, r_LZ): wiped before the memory goes back to the allocator.
+template <class T>
+static void wipe_vec(std::vector<T>& v) {
+  if (!v.empty()) explicit_bzero(v.data(), v.size() * sizeof(T));
+}
 void pcs_ahead_free(sp_ctx* c) {
   if (!c || !c->pcs_ahead) return;
   pcs_ahead_drain(c);
-  delete c->pcs_ahead;
+  sp_pcs_ahead* S = c->pcs_ahead;
+  wipe_vec(S->blind);
+  wipe_vec(S->dvec);
+  wipe_vec(S->rng);
+  wipe_vec(S->T);
+  explicit_bzero(&S->r_delta, sizeof(fe_t));
+  explicit_bzero(&S->r_LZ, sizeof(fe_t));
+  delete S;
   c->pcs_ahead = nullptr;
 }
 // the inner sum-check's challenges: round 0 binds the variable that separates W from (1, X); rounds 1 .. nvr are the opening's row variables
@@ -1414,13 +1454,15 @@ void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]) {
   if (round > S->nvr) {  // a column variable: after the first half of them the helper thread forms the partial sums of <R, d>
     const size_t k = round - S->nvr - 1;
     if (k < S->hb) memcpy(&S->col_pt[k], r, 32);
-    if (k + 1 == S->hb && !S->T_ready) {
+    if (k + 1 == S->hb && !S->T_submitted) {
       if (S->worker_busy) c->pcs_worker->wait();
       S->worker_busy = true;
+      S->T_submitted = true;
+      S->col_pt_T = S->col_pt;
       c->pcs_worker->submit([S] {
         const size_t nleft = (size_t)1 << S->hb, nright = S->cols >> S->hb;
         std::vector<fe_t> left(nleft);
-        eq_table_host(S->col_pt.data(), S->hb, left.data());
+        eq_table_host(S->col_pt_T.data(), S->hb, left.data());
         S->T.assign(nright, fe_zero());
         for (size_t a = 0; a < nleft; ++a)
           for (size_t b = 0; b < nright; ++b) S->T[b] = fe_add<spk::SF>(S->T[b], fe_mul<spk::SF>(left[a], S->dvec[a * nright + b]));
@@ -1746,7 +1788,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   }
   // (3) host work under the device's: <R, d> with R = eq(point[nvr..]) = left (x) right (ipa.rs:148), beta = ck_c * <R, d> + h_c * r_beta (:149)
   fe_t ip = fe_zero();
-  if (ahead && S->T_ready && S->hb == (npt - nvr) / 2 && memcmp(S->col_pt.data(), pt + nvr, S->hb * sizeof(fe_t)) == 0) {
+  if (ahead && S->T_ready && S->hb == (npt - nvr) / 2 && S->col_pt_T.size() >= S->hb && memcmp(S->col_pt_T.data(), pt + nvr, S->hb * sizeof(fe_t)) == 0) {
     const size_t k = npt - nvr;
     std::vector<fe_t> right((size_t)1 << (k - S->hb));
     eq_table_host(pt + nvr + S->hb, k - S->hb, right.data());

@@ -218,8 +218,8 @@ int sp_wire_points(sp_wire* w, const uint64_t* aff, size_t n, int with_len) {
 int sp_wire_hyrax_key(sp_wire* w, const uint64_t* ck, size_t num_cols, const uint64_t* h) {
   if (!w || !ck || !h) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_wire_hyrax_key: null argument");
   w->u64(num_cols);
-  sp_wire_affines(w, ck, num_cols, 1);
-  return sp_wire_points(w, h, 1, 0);
+  int rc = sp_wire_affines(w, ck, num_cols, 1);
+  return rc ? rc : sp_wire_points(w, h, 1, 0);
 }
 // SparseMatrix: digest_form != 0 -> write_digest_bytes (src/r1cs/sparse.rs:398-417: the three lengths and cols, then the raw arrays);
 // digest_form == 0 -> the derived Serialize (data, indices, indptr as length-prefixed Vecs, then cols; :383-394)
@@ -227,15 +227,12 @@ int sp_wire_matrix(sp_wire* w, const sp_csr* M, size_t rows, size_t cols, int di
   if (!w || !M || !M->indptr) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_wire_matrix: null argument");
   const size_t nnz = (size_t)M->indptr[rows];
   if (nnz && (!M->data || !M->indices)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_wire_matrix: null entries");
+  int rc;
   if (digest_form) {
     w->u64(nnz), w->u64(nnz), w->u64(rows + 1), w->u64(cols);
-    sp_wire_scalars(w, M->data, nnz, 0);
-    sp_wire_u32s_as_u64(w, M->indices, nnz, 0);
-    sp_wire_u64s(w, M->indptr, rows + 1, 0);
+    if ((rc = sp_wire_scalars(w, M->data, nnz, 0)) || (rc = sp_wire_u32s_as_u64(w, M->indices, nnz, 0)) || (rc = sp_wire_u64s(w, M->indptr, rows + 1, 0))) return rc;
   } else {
-    sp_wire_scalars(w, M->data, nnz, 1);
-    sp_wire_u32s_as_u64(w, M->indices, nnz, 1);
-    sp_wire_u64s(w, M->indptr, rows + 1, 1);
+    if ((rc = sp_wire_scalars(w, M->data, nnz, 1)) || (rc = sp_wire_u32s_as_u64(w, M->indices, nnz, 1)) || (rc = sp_wire_u64s(w, M->indptr, rows + 1, 1))) return rc;
     w->u64(cols);
   }
   return SP_OK;
@@ -365,15 +362,19 @@ int sp_proof_serialize(const sp_spartan_layout* L, const uint64_t* words, size_t
   if (!L || !words || !len) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_proof_serialize: null argument");
   if (nwords != spartan_flat_words(L)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_proof_serialize: the word count does not match the layout");
   sp_wire* w = nullptr;
-  sp_wire_new(0, &w);
+  int rc = sp_wire_new(0, &w);
+  if (rc) return rc;
   const uint64_t* p = words;
+  auto keep = [&rc](int r) {  // the first failure of a nested sink call is the call's result: a truncated stream is never returned as a proof
+    if (!rc) rc = r;
+  };
   auto option_commitment = [&](size_t rows) {  // Option<HyraxCommitment { comm: Vec<GE> }>: Some exactly when the segment has rows
-    sp_wire_u8(w, rows ? 1 : 0);
-    if (rows) sp_wire_points(w, p, rows, 1);
+    keep(sp_wire_u8(w, rows ? 1 : 0));
+    if (rows) keep(sp_wire_points(w, p, rows, 1));
     p += 8 * rows;
   };
   auto scalars = [&](size_t n, int with_len) {
-    sp_wire_scalars(w, p, n, with_len);
+    keep(sp_wire_scalars(w, p, n, with_len));
     p += 4 * n;
   };
   auto sumcheck = [&](size_t rounds, size_t per) {  // Vec<CompressedUniPoly { coeffs_except_linear_term: Vec<Scalar> }>
@@ -383,7 +384,7 @@ int sp_proof_serialize(const sp_spartan_layout* L, const uint64_t* words, size_t
   // U: SplitR1CSInstance (src/r1cs/mod.rs:797-806)
   option_commitment(L->rows_shared);
   option_commitment(L->rows_precommitted);
-  sp_wire_points(w, p, L->rows_rest, 1);
+  keep(sp_wire_points(w, p, L->rows_rest, 1));
   p += 8 * L->rows_rest;
   scalars(L->num_public, 1);
   scalars(L->num_challenges, 1);
@@ -393,13 +394,12 @@ int sp_proof_serialize(const sp_spartan_layout* L, const uint64_t* words, size_t
   scalars(1, 0);  // eval_W
   scalars(1, 1);  // blind_eval_W: HyraxBlind { blind: Vec<Scalar> }, one row
   // eval_arg: HyraxEvaluationArgument { ipa: InnerProductArgumentLinear { delta, beta, z_vec, z_delta, z_beta } } (src/provider/pcs/ipa.rs:103-114)
-  sp_wire_points(w, p, 2, 0);
+  keep(sp_wire_points(w, p, 2, 0));
   p += 16;
   scalars(L->z_len, 1);
   scalars(2, 0);
   *len = sp_wire_len(w);
-  int rc = SP_OK;
-  if (out) rc = sp_wire_bytes(w, out, cap);
+  if (!rc && out) rc = sp_wire_bytes(w, out, cap);
   sp_wire_free(w);
   return rc;
 }

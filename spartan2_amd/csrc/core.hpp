@@ -28,13 +28,17 @@ int fail(int code, const std::string& msg);
 void relax();
 // hipStreamSynchronize / hipEventSynchronize for library code: on a thread with a wait hook they poll (hipStreamQuery / hipEventQuery) through relax()
 // instead of blocking — a blocked thread could not serve the other proofs it carries, and one of those may own a kernel that sits in front of this
-// stream's work in a shared hardware queue while it waits for its host's next challenge
+// stream's work in a shared hardware queue while it waits for its host's next challenge. Never call them (or relax()) with a library mutex held.
+hipError_t stream_sync(hipStream_t s);
+hipError_t event_sync(hipEvent_t e);
+// A host-side poll gave up and takes its slow path (a stream synchronise, the mirror, a sleep): with SPARTAN_SLOWPATH_LOG set, one line on stderr per
+// event - these are the places a rare multi-millisecond prove comes from (a profiler serialising the streams, a result that only became visible at
+// the end of its kernel, a helper's job queued behind a waiting kernel)
+void slow_note(const char* site, long spins);
 // capi_group.hip: called by sp_sumcheck_quad after the challenge of `round` has gone to the device, when the context holds an announced opening
 void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]);
 void pcs_ahead_free(sp_ctx* c);
 bool pcs_ahead_wants(const sp_ctx* c, size_t rounds);  // is an opening announced whose point a sum-check of this many rounds draws?
-hipError_t stream_sync(hipStream_t s);
-hipError_t event_sync(hipEvent_t e);
 
 #define SP_HIP(expr)                                                                               \
   do {                                                                                             \
@@ -44,6 +48,8 @@ hipError_t event_sync(hipEvent_t e);
 
 // One sleeping helper thread of a context for host work that a library call can run beside its own device work (sp_hyrax_prove: the 64 KiB
 // transcript encoding of the commitment and its Keccak blocks while the MSMs run). One job at a time; wait() spins (jobs are tens of microseconds).
+// A sleeping thread's wake-up is the scheduler's to time - usually 5-50 us, now and then milliseconds (one prove in a few thousand was 4 ms long for
+// it): a waiter that finds the job still UNCLAIMED 30 us after it was posted takes it back and runs it itself; a job the helper has begun is waited for.
 class Worker {
   std::thread th_;
   std::mutex m_;
@@ -51,6 +57,7 @@ class Worker {
   std::function<void()> job_;
   bool posted_ = false, stop_ = false;
   std::atomic<int> pending_{0};
+  std::chrono::steady_clock::time_point posted_at_;
   void loop() {
     for (;;) {
       std::function<void()> f;
@@ -87,12 +94,30 @@ class Worker {
       std::lock_guard<std::mutex> l(m_);
       job_ = std::move(f);
       posted_ = true;
+      posted_at_ = std::chrono::steady_clock::now();
     }
     if (!th_.joinable()) th_ = std::thread([this] { loop(); });
     cv_.notify_one();
   }
   void wait() {
-    while (pending_.load(std::memory_order_acquire)) sp::relax();
+    for (unsigned spins = 0; pending_.load(std::memory_order_acquire); ++spins) {
+      if ((spins & 63u) == 63u) {
+        std::function<void()> f;
+        {
+          std::lock_guard<std::mutex> l(m_);
+          if (posted_ && std::chrono::steady_clock::now() - posted_at_ > std::chrono::microseconds(30)) {
+            f.swap(job_);
+            posted_ = false;  // the helper, when it does wake, finds nothing posted and sleeps on
+          }
+        }
+        if (f) {
+          f();
+          pending_.store(0, std::memory_order_release);
+          return;
+        }
+      }
+      sp::relax();
+    }
   }
 };
 
@@ -109,6 +134,8 @@ struct sp_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream_eq = nullptr;  // sp_eq_table_begin's pyramids (a stream of their own: the auxiliary stream may hold a 100 us MSM stage of the helper thread)
   hipEvent_t eq_ev = nullptr;
+  hipEvent_t eq_read_ev = nullptr;  // recorded behind the last k_eq_outer_lastk that READS d_eq_ahead: the next pyramids wait for it before rewriting the buffer
+  bool eq_read_pending = false;
   fe_t* d_eq_ahead = nullptr;     // two pyramids of <= 2^11 entries
   size_t eq_ahead_ell = 0, eq_ahead_known = 0;  // set by sp_eq_table_begin, consumed by sp_eq_table_finish
   fe_t eq_ahead_r[32];
@@ -140,6 +167,7 @@ struct sp_ctx {
   void* d_mm[2] = {nullptr, nullptr};
   void* d_mm_work[2] = {nullptr, nullptr};
   unsigned mm_seq[2] = {0, 0};
+  size_t mm_host_bytes[2] = {0, 0};  // scalars the last launch of the lane copied into its mapped page (mask / blind material): wiped when the result is collected
   hipEvent_t fb_ev = nullptr;
   hipEvent_t fb_event() {
     if (!fb_ev) hipEventCreateWithFlags(&fb_ev, hipEventDisableTiming);

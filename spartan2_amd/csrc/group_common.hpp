@@ -22,11 +22,14 @@ struct sp_ck {
   // fixed-base comb table of the whole key (kernels_msm.hpp k_comb_*), built on first use by a commitment of many non-small rows
   mutable aff_t* d_comb = nullptr;
   mutable int comb_c = 0, comb_windows = 0;
-  mutable bool comb_failed = false;
+  mutable bool comb_failed = false, comb_building = false;
   // 8-bit window tables of every base and of h (capi_group.hip ck_key_tables), built on first use by sp_hyrax_prove
   mutable aff_t* d_keytables = nullptr;
-  mutable bool keytables_failed = false;
-  // the two lazily built table sets above are written through a `const sp_ck*` that several contexts / helper threads may share: first use is serialised
+  mutable bool keytables_failed = false, keytables_building = false;
+  // The two lazily built table sets above are written through a `const sp_ck*` that several contexts / helper threads may share. lazy_mu guards the
+  // pointers and flags ONLY: the builder claims the build under the lock (`*_building`), builds with the lock released, and publishes under the lock
+  // again; everybody else waits through sp::relax() without holding it. A build synchronises with its stream, and on a thread that carries several
+  // proofs that wait is the wait hook (a switch to another proof, which may ask for the same key): no library mutex is ever held across it.
   mutable std::mutex lazy_mu;
 };
 

@@ -86,10 +86,21 @@ constexpr int TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in t
 // region of their own, written with plain stores, stayed in the L2 until the kernel ended; system-scope stores for every word cost more than the trip saved).
 constexpr int TAIL_WIDE_VALS = 12;
 constexpr int TAIL_DOUBLE_SUMS_QUAD = 8, TAIL_DOUBLE_SUMS_CUBIC = 12;
+// HAND-OVER OF THE LAST ROUNDS. Once a bind leaves tables of n <= TAIL_HAND_OVER entries (cubic 16: four rounds left; quadratic 32: five), a round is
+// ~10 products a pair on the device against a trip over the bus of 6 - 9 us: the kernel sends the TABLES instead of sums (n elements per table, three
+// per result slot like the two-round trips), the host binds and evaluates the remaining rounds itself (~100 products, 3 us for all of them beside its
+// transcript steps) and hands the final claims back through the mailbox - three lines answering seq, seq + 1, seq + 2 - which the kernel, otherwise
+// idle, stores into element 0 of the tables (the ABI's "bound in place down to length 1") before it leaves. Same polynomials, same transcript.
+#ifdef SP_TAIL_NO_HAND_OVER  // A/B builds
+__host__ __device__ __forceinline__ bool tail_hand_over(bool, unsigned long long) { return false; }
+#else
+__host__ __device__ __forceinline__ bool tail_hand_over(bool cubic, unsigned long long n) { return n >= 2 && n <= (cubic ? 16ull : 32ull); }
+#endif
+constexpr int TAIL_HAND_OVER_MAX_VALS = 64;  // 3 x 16 or 2 x 32 elements: 22 result slots at most (of HOST_SUM_MAX_BLOCKS)
 #ifdef SP_TAIL_SINGLE  // A/B builds: one round per trip everywhere
 __host__ __device__ __forceinline__ bool tail_double(bool, unsigned long long) { return false; }
 #else
-__host__ __device__ __forceinline__ bool tail_double(bool cubic, unsigned long long n) { return n >= 4 && n <= (cubic ? 256ull : 512ull); }
+__host__ __device__ __forceinline__ bool tail_double(bool cubic, unsigned long long n) { return !tail_hand_over(cubic, n) && n >= 4 && n <= (cubic ? 256ull : 512ull); }
 #endif
 // The mailbox is a RING of MAIL_RING 64-byte lines indexed by the sequence number a challenge answers (line = seq & 7): a waiter only ever looks at the
 // line of ITS challenge, which the host does not touch again before eight more results are in. With the ring in device memory the host also keeps a
@@ -290,20 +301,36 @@ __global__ void __launch_bounds__(1024) k_eq_levels_pair(EqPairArgs a) {
   const int m = a.m[b];
   eq_levels_block(&a.v[b][m - 1], m, a.out[b], lv);
 }
-// The same table with the LAST TWO variables applied here: T_lo covers only the low variables up to them, so both pyramids can be built two rounds
-// before the sum-check that draws the point ends. out[(hi << lo_bits) | (lo' << 2) | (b_a << 1) | b_b] = T_hi[hi] T_lo[lo'] e(b_a, r_a) e(b_b, r_b): four
-// products for four outputs, the rate of the plain outer product.
-__global__ void __launch_bounds__(256) k_eq_outer_last2(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int lo_bits, size_t total, fe_t ra, fe_t rb,
+// The same table with the LAST K variables (2 <= K <= 4) applied here: T_lo covers only the low variables up to them, so both pyramids can be built K
+// rounds before the sum-check that draws the point ends (K = 4: when its resident kernel hands the last rounds to the host).
+// out[(hi << 10) | lo] = T_hi[hi] (T_lo[lo >> K] e_K[lo & (2^K - 1)]), lo_bits = 10. A thread keeps its four low factors (lo = 256 k + t: the same
+// low K bits for every k, so ONE e_K weight per thread, K - 1 products) in registers and walks EQ_LASTK_HPB high entries: 7 + 4 HPB products for
+// 4 HPB outputs, every store a wave-contiguous 2 KiB (the two-variable form of round 3 wrote 128 bytes per lane at a 128-byte stride: 18 us for 2^20).
+constexpr int EQ_LASTK_HPB = 2;
+struct EqLastK {
+  fe_t r[4];  // the last K coordinates, in order
+};
+__global__ void __launch_bounds__(256) k_eq_outer_lastk(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqLastK rk,
                                                         fe_t* __restrict__ out) {
-  const size_t quads = total >> 2, mask = ((size_t)1 << (lo_bits - 2)) - 1;
-  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < quads; j += (size_t)gridDim.x * blockDim.x) {
-    const fe_t v = fe_mul<S>(t_hi[j >> (lo_bits - 2)], t_lo[j & mask]);
-    const fe_t v1 = fe_mul<S>(v, ra), v0 = fe_sub<S>(v, v1);
-    const fe_t o1 = fe_mul<S>(v0, rb), o3 = fe_mul<S>(v1, rb);
-    out[4 * j] = fe_sub<S>(v0, o1);
-    out[4 * j + 1] = o1;
-    out[4 * j + 2] = fe_sub<S>(v1, o3);
-    out[4 * j + 3] = o3;
+  const unsigned t = threadIdx.x;
+  const fe_t one = fe_one<S>();
+  fe_t w = one;
+  for (int i = 0; i < K; ++i) {  // first of the K variables = most significant of the K bits
+    const fe_t f = ((t >> (K - 1 - i)) & 1u) ? rk.r[i] : fe_sub<S>(one, rk.r[i]);
+    w = i == 0 ? f : fe_mul<S>(w, f);
+  }
+  fe_t lo[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) lo[k] = fe_mul<S>(t_lo[(256u * k + t) >> K], w);
+  for (size_t hi = (size_t)blockIdx.x * EQ_LASTK_HPB; hi < n_hi; hi += (size_t)gridDim.x * EQ_LASTK_HPB) {
+#pragma unroll
+    for (int h = 0; h < EQ_LASTK_HPB; ++h) {
+      if (hi + h >= n_hi) break;
+      const fe_t th = t_hi[hi + h];
+      fe_t* o = out + ((hi + h) << 10);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[256 * k + t] = fe_mul<S>(th, lo[k]);
+    }
   }
 }
 // out[(hi << lo_bits) | lo] = T_hi[hi] * T_lo[lo]
@@ -963,7 +990,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   constexpr unsigned long long WQ = CUBIC ? TAIL_WIDE_Q_CUBIC : TAIL_WIDE_Q;
   __shared__ fe_t smem[16];
   __shared__ fe_t r_sh;
-  __shared__ slot_chk chk_sh[TAIL_WIDE_VALS];
+  __shared__ slot_chk chk_sh[TAIL_HAND_OVER_MAX_VALS];
   // the elements a step has just bound, for its own evaluation (a block evaluates exactly the pairs it bound): table t at [t * 2 qb, ..), the low
   // elements x = base + e first, then their partners x = q + base + e. They go to memory as well - the next step's bind reads them from there.
   __shared__ fe_t bound[(CUBIC ? 3 : 2) * 2 * (unsigned)WQ];
@@ -1084,6 +1111,38 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     }
     __syncthreads();
     SP_TT(2);
+    if (tail_hand_over(CUBIC, len / 2)) {
+      // the host takes the remaining rounds (see tail_hand_over). One block is left here (q <= 8: base = 0, qb = q), so bound[t * n + x] is element x
+      // of table t, n = len / 2: value k = t * n + x goes to slot k / 3, element k % 3, tagged with this result's sequence number.
+      const unsigned n = (unsigned)(len / 2), nv = nt * n;
+      fe_t* wide = a.mapped + SLOT_BASE_ELEM;
+      if (threadIdx.x < nv) {
+        const unsigned k = threadIdx.x;
+        const fe_t t = bound[k];
+        slot_store_elem(wide + 4 * (k / 3) + k % 3, t);
+        slot_chk ck = {0u, 0u};
+        slot_chk_add(ck, t, (int)(k % 3));
+        chk_sh[k] = ck;
+      }
+      __syncthreads();
+      if (threadIdx.x < (nv + 2) / 3) {
+        const unsigned sidx = threadIdx.x;
+        slot_chk chk = {0u, 0u};
+        for (unsigned k = 3 * sidx; k < 3 * sidx + 3 && k < nv; ++k) {
+          chk.a += chk_sh[k].a;
+          chk.b += chk_sh[k].b;
+        }
+        slot_store_tag(wide + 4 * sidx, seq, chk);
+      }
+      // the final claims come back as the "challenges" answering seq, seq + 1 (, seq + 2): element 0 of every table, as a kernel that had run all
+      // rounds itself would have left it
+      for (unsigned t = 0; t < nt; ++t) {
+        __syncthreads();
+        if (!mail_wait(a.mail, a.mirror, a.mapped, seq + t, &r_sh)) return;
+        if (threadIdx.x == 0) (t == 0 ? a.A : (t == 1 ? a.B : a.C))[0] = r_sh;
+      }
+      return;
+    }
     if (tail_double(CUBIC, len / 2)) {
       // the round over the n = len / 2 entries just bound AND the coefficient sums of the round after it (see TAIL_WIDE_VALS). y < qd = n / 4;
       // a0..a3 = A[y + k qd]. One product per lane, `which` wave-uniform:

@@ -111,6 +111,25 @@ class Background {
   bool posted_ = false, stop_ = false;
   std::atomic<int> pending_{0};
   std::exception_ptr err_;
+  std::chrono::steady_clock::time_point posted_at_;
+  // A sleeping thread's wake-up is the scheduler's to time - usually 5-50 us, now and then milliseconds (one prove in a few thousand was 4 ms long
+  // for it): a waiter that finds the job still UNCLAIMED 30 us after it was posted takes it back and runs it itself.
+  bool steal_and_run() {
+    std::function<void()> f;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      if (!posted_ || std::chrono::steady_clock::now() - posted_at_ <= std::chrono::microseconds(30)) return false;
+      f.swap(job_);
+      posted_ = false;  // the helper, when it does wake, finds nothing posted and sleeps on
+    }
+    try {
+      f();
+    } catch (...) {
+      err_ = std::current_exception();
+    }
+    pending_.store(0, std::memory_order_release);
+    return true;
+  }
   void loop() {
     for (;;) {
       std::function<void()> f;
@@ -151,16 +170,23 @@ class Background {
       std::lock_guard<std::mutex> l(m_);
       job_ = std::move(f);
       posted_ = true;
+      posted_at_ = std::chrono::steady_clock::now();
     }
     if (!th_.joinable()) th_ = std::thread([this] { loop(); });
     cv_.notify_one();
   }
   void wait_nothrow() {  // for exit paths: also drops what the job threw, so that it cannot resurface in a later submit()
-    while (pending_.load(std::memory_order_acquire)) sp_relax();
+    for (unsigned spins = 0; pending_.load(std::memory_order_acquire); ++spins) {
+      if ((spins & 63u) == 63u && steal_and_run()) break;
+      sp_relax();
+    }
     err_ = nullptr;
   }
   void wait() {  // rethrows what the job threw
-    while (pending_.load(std::memory_order_acquire)) sp_relax();
+    for (unsigned spins = 0; pending_.load(std::memory_order_acquire); ++spins) {
+      if ((spins & 63u) == 63u && steal_and_run()) break;
+      sp_relax();
+    }
     if (err_) {
       std::exception_ptr e = err_;
       err_ = nullptr;

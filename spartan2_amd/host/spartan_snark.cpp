@@ -525,7 +525,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> outer_polys(3 * num_rounds_x), r_x(num_rounds_x);
   fe_t claims_outer[3];
   const fe_t zero = fe_zero();
-  // evals_rx started two rounds before r_x is complete (sp_eq_table_begin builds the half tables of the first ell - 2 coordinates on a stream of
+  // evals_rx started four rounds before r_x is complete (sp_eq_table_begin builds the half tables of the first ell - 4 coordinates on a stream of
   // its own; sp_eq_table_finish behind the last challenge is then one launch).
   struct EqObs {
     sp_ctx* ctx;
@@ -537,10 +537,10 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     static void fn(void* u, size_t round, const uint64_t r[4]) {
       EqObs* o = (EqObs*)u;
       if (o->lz && round + 15 == o->ell) o->lz->publish(o->lz->delta_state, 1);  // tables of 2^14 from here on: the rounds of the resident kernel
-      if (round + 2 >= o->ell) return;  // the last two coordinates are applied by sp_eq_table_finish
+      if (round + 4 >= o->ell) return;  // the last four coordinates (the rounds the host runs itself after the hand-over) are applied by sp_eq_table_finish
       memcpy(&o->r[round], r, 32);
-      if (round + 3 == o->ell) {
-        o->rc = sp_eq_table_begin(o->ctx, u64p(o->r), o->ell - 2, o->ell);
+      if (round + 5 == o->ell) {
+        o->rc = sp_eq_table_begin(o->ctx, u64p(o->r), o->ell - 4, o->ell);
         o->begun = o->rc == 0;
       }
     }
@@ -1322,6 +1322,15 @@ int ss_prove_hook(void* pk, void* ps, const uint64_t* publics_u64, size_t npub, 
     if (phase_ms) memcpy(phase_ms, pt.ms, 7 * sizeof(double));
     if (getenv("SPARTAN_HOST_LAPS")) {
       for (auto& l : pt.laps) fprintf(stderr, "lap %-28s %.3f ms\n", l.first.c_str(), l.second);
+    }
+    // SPARTAN_SLOW_PROVE_MS=<t>: a prove that took longer than t ms leaves its phases and laps on stderr (diagnostics for rare stalls)
+    static const double slow_ms = [] {
+      const char* e = getenv("SPARTAN_SLOW_PROVE_MS");
+      return e ? atof(e) : 0.0;
+    }();
+    if (slow_ms > 0 && pt.ms[6] > slow_ms) {
+      fprintf(stderr, "[slow prove] %.3f ms: witness %.3f mv %.3f outer %.3f abc %.3f inner %.3f pcs %.3f\n", pt.ms[6], pt.ms[0], pt.ms[1], pt.ms[2], pt.ms[3], pt.ms[4], pt.ms[5]);
+      for (auto& l : pt.laps) fprintf(stderr, "[slow prove]   lap %-28s %.3f ms\n", l.first.c_str(), l.second);
     }
     return 0;
   } catch (...) {

@@ -207,17 +207,25 @@ def test_long_absorbs_hashed_on_the_library_thread_equal_the_oracle_transcript(c
 
 @pytest.mark.parametrize("ell", [12, 15, 20])
 def test_eq_table_begun_two_coordinates_early(ctx, ell):
-    """sp_eq_table_begin / _finish (the half tables of the first ell - 2 coordinates built ahead, the last two applied in the one launch behind the
-    last challenge) give the table of sp_eq_table; a `_finish` without a `_begin`, or with a different prefix, is the plain call."""
+    """sp_eq_table_begin / _finish (the half tables of the first ell - K coordinates built ahead, K = 2, 3, 4, the last K applied in the one launch
+    behind the last challenge) give the table of sp_eq_table; a `_finish` without a `_begin`, or with a different prefix, is the plain call; fewer
+    than two or more than four missing coordinates are refused."""
     from spartan2_amd import hip
 
     rng = np.random.default_rng(4200 + ell)
     r = ol.random_field_array(rng, ell)
+    r[ell - 1] = 0  # a zero and a one among the late coordinates
+    r[ell - 3] = ol.to_mont(1)
     want = hip.Table.eq(ctx, r).read()
     out = hip.Table.zeros(ctx, 1 << ell)
-    hip.Table.eq_begin(ctx, r[: ell - 2], ell)
-    out.eq_finish(r)
-    assert (out.read() == want).all()
+    for k in (2, 3, 4):
+        out.write(0, np.zeros((1 << ell, 4), dtype=np.uint64))
+        hip.Table.eq_begin(ctx, r[: ell - k], ell)
+        out.eq_finish(r)
+        assert (out.read() == want).all(), k
+    for k in (1, 5):
+        with pytest.raises(hip.SpartanHipError):
+            hip.Table.eq_begin(ctx, r[: ell - k], ell)
     out2 = hip.Table.zeros(ctx, 1 << ell)
     out2.eq_finish(r)  # nothing begun
     assert (out2.read() == want).all()

@@ -284,6 +284,54 @@ def test_hyrax_prove_announced_ahead_is_the_same_opening(ctx, key, gens, case, m
     assert (again == want).all() and (again_next == want_next).all()
 
 
+def test_hyrax_prove_announced_then_two_sumchecks_of_the_openings_length(ctx, key, gens):
+    """An announced opening listens to the challenges of every sp_sumcheck_quad whose round count is the opening's point length + 1. Two such
+    sum-checks before sp_hyrax_prove: the row half of the point is frozen when comm_LZ's walk starts, and the partial sums of <R, d> are tied to the
+    column challenges they were built from — whichever sum-check's point the caller then opens at, the opening is the unannounced one."""
+    npt = 14
+    rng = np.random.default_rng(SEED + 951)
+    n = 1 << npt
+    rows = n // 2048
+    cols = n // rows
+    poly = ol.random_field_array(rng, n)
+    blinds = ol.random_field_array(rng, rows)
+    g_s = np.zeros((2, 8), dtype=np.uint64)
+    olib().orc_from_label(b"ck_s", ctypes.c_size_t(2), p64(g_s))
+    key_s = hip.CommitmentKey(ctx, g_s[:1], g_s[1])
+    table = hip.Table.from_host(ctx, poly)
+    comm = key.commit(table, 0, n, blinds, is_small=False)
+    ev, b_ev = ol.random_field_array(rng, 1), ol.random_field_array(rng, 1)
+    comm_eval = key_s.msm(ev, b_ev[0])
+    tape = ol.make_tape(SEED + 79, cols + 2)
+    claim = ol.random_field_array(rng, 1)[0]
+
+    def sumcheck(seed):  # a quadratic sum-check of npt + 1 rounds on tables of its own: only its challenges matter here
+        r2 = np.random.default_rng(seed)
+        A = hip.Table.from_host(ctx, ol.random_field_array(r2, 2 * n))
+        Bt = hip.Table.from_host(ctx, ol.random_field_array(r2, 2 * n))
+        tr = hip.Transcript(ctx, b"sc")
+        tr.absorb(b"s", bytes([seed & 255]))
+        _, r, _ = hip.sumcheck_quad(ctx, claim, npt + 1, A, Bt, tr)
+        A.free()
+        Bt.free()
+        return np.ascontiguousarray(r[1:])  # round 0 binds the variable in front of the opening's point
+
+    def prove(point):
+        tr = hip.Transcript(ctx, b"pcs")
+        out = key.prove(key_s, tr, comm, table, n, blinds, point, comm_eval, b_ev, tape)
+        return out, tr.squeeze(b"n")
+
+    # the two points, drawn without an announcement on the context (the transcripts make them reproducible)
+    p1, p2 = sumcheck(1), sumcheck(2)
+    assert not (p1 == p2).all()
+    want1, want2 = prove(p1), prove(p2)
+    for opened, want in ((p1, want1), (p2, want2)):
+        key.prove_announce(comm, table, n, blinds, tape)
+        assert (sumcheck(1) == p1).all() and (sumcheck(2) == p2).all()
+        got = prove(opened)
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+
+
 def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):
     rng = np.random.default_rng(SEED + 400)
     sc = ol.random_field_array(rng, 2048)
