@@ -171,6 +171,7 @@ int sp_ctx_create(int device, sp_ctx** out) {
       c->mail_dev = true;
     }
   }
+  SP_HIP(hipMalloc((void**)&c->d_gate, spk::MAIL_RING * sizeof(fe_t)));
   int rc = c->ensure_scratch(1 << 16);
   if (rc) return rc;
   *out = c;
@@ -193,6 +194,7 @@ void sp_ctx_destroy(sp_ctx* c) {
     if (c->ws_ptr[i]) hipFree(c->ws_ptr[i]);
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->mail_alloc) hipFree(c->mail_alloc);
+  if (c->d_gate) hipFree(c->d_gate);
   if (c->h_pinned_vec) hipHostFree(c->h_pinned_vec);
   if (c->vec_ev) hipEventDestroy(c->vec_ev);
   if (c->stream3) hipStreamDestroy(c->stream3);
@@ -416,8 +418,27 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
     c->pending_slots = (unsigned)nblocks;
     return;
   }
-  c->pending_slots = 0;
-  hipLaunchKernelGGL(spk::k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
+  // more producer blocks than slots: single-wave second-stage blocks, one slot each (kernels_poly.hpp k_sum_partials)
+  size_t b2 = (nblocks + 63) / 64;
+  if (b2 > (size_t)spk::HOST_SUM_MAX_BLOCKS) b2 = spk::HOST_SUM_MAX_BLOCKS;
+  c->pending_slots = (unsigned)b2;
+  hipLaunchKernelGGL(spk::k_sum_partials, dim3((unsigned)b2), dim3(64), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
+}
+// second stage of a streaming launch (kernels_poly.hpp k_sum_partials_lazy): groups of 2^gl consecutive producer blocks, eq_out[group] applied when given
+static void sum_lazy_launch(sp_ctx* c, const spk::lazy9_t* lp, size_t nparts, int gl, const fe_t* eq_out, unsigned seq) {
+  const uint32_t* P = reinterpret_cast<const uint32_t*>(lp);
+  const size_t ngroups = nparts >> gl;
+  size_t b2 = (ngroups + 63) / 64;
+  if (b2 < 1) b2 = 1;
+  if (b2 > (size_t)spk::HOST_SUM_MAX_BLOCKS) b2 = spk::HOST_SUM_MAX_BLOCKS;
+  const dim3 g((unsigned)b2), b(64);
+  const bool vec_ok = nparts % 8 == 0;  // the vector loads of the templated forms need their 16-byte alignment
+  if (vec_ok && gl == 0) hipLaunchKernelGGL((spk::k_sum_partials_lazy<0>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
+  else if (vec_ok && gl == 1) hipLaunchKernelGGL((spk::k_sum_partials_lazy<1>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
+  else if (vec_ok && gl == 2) hipLaunchKernelGGL((spk::k_sum_partials_lazy<2>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
+  else if (vec_ok && gl == 3) hipLaunchKernelGGL((spk::k_sum_partials_lazy<3>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
+  else hipLaunchKernelGGL((spk::k_sum_partials_lazy<-1>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
+  c->pending_slots = (unsigned)b2;
 }
 // `resident`: a kernel on the stream is itself waiting for the host's next challenge (the resident tail that produces the result, or a launch issued
 // ahead of its challenge queued behind the producer) — a stream synchronise would not return before that kernel's watchdog, so the host keeps
@@ -642,7 +663,27 @@ static spk::MailRef mail_ref(sp_ctx* c, bool ahead, unsigned answers) {
   m.mirror = c->d_mail_mirror;
   m.mapped = c->d_pinned;
   m.answers = answers;
+  m.gated = nullptr;
   return m;
+}
+// A launch too large to wait at the mailbox itself (launch_ahead_ok: a grid that fills the chip while it polls starves every other stream) is queued
+// AHEAD of its challenge all the same, behind a one-wave gate: k_mail_gate waits at the mailbox and leaves the challenge in device memory, the launch
+// behind it in the stream starts when the gate ends and reads it there. The challenge then reaches the kernel through the command processor's
+// in-queue dependency (2-3 us) instead of a host launch behind the challenge (two launch calls of 3 us each on the host's critical path + the
+// dispatch latency), and nothing but one wave waits. Returns the reference the gated launch takes (mail = nullptr: it does not poll).
+static spk::MailRef gate_launch(sp_ctx* c, unsigned answers) {
+  fe_t* slot = c->d_gate + (answers & (spk::MAIL_RING - 1));
+  hipLaunchKernelGGL(spk::k_mail_gate, dim3(1), dim3(64), 0, c->stream, mail_ref(c, true, answers), slot);
+  spk::MailRef m = mail_ref(c, false, answers);
+  m.gated = slot;
+  return m;
+}
+static bool gate_ok(sp_ctx* c) {
+  static const bool off = [] {
+    const char* e = getenv("SPARTAN_GATE");  // "0": streaming launches behind their challenge, as before (A/B)
+    return e && e[0] == '0';
+  }();
+  return c->mail_dev && !off;
 }
 // a fused bind+evaluate launch may be issued AHEAD of its challenge (the kernel waits at the mailbox) when the mailbox is in device memory.
 // The largest tables are left alone: their kernels are the bandwidth-bound ones whose durations the roofline is measured on.
@@ -1192,7 +1233,8 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       int rc2 = launch_bind(c, tabs, 2, rv);
       return rc2 ? rc2 : 1;
     }
-    if (ahead && !launch_ahead_ok(c, A->len)) return 0;
+    const bool gated = ahead && !launch_ahead_ok(c, A->len);
+    if (gated && !gate_ok(c)) return 0;
     if (!stopped && tail_enabled() && A->len <= TAIL_MAX_LEN && table_dense(A) && table_dense(B) && lease.take(tail_blocks(A->len / 2))) {
       spk::TailArgs ta;
       ta.A = A->d;
@@ -1215,8 +1257,11 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       c->pending_slots = tail_blocks(A->len);
       return 1;
     }
-    const spk::MailRef mref = mail_ref(c, ahead, answers);
-    if (table_dense(A) && table_dense(B)) {
+    const bool dense = table_dense(A) && table_dense(B);
+    const bool sparse_stream = !dense && A->len / 4 >= STREAM_MIN_Q && sp::eff_lo(A) == A->len / 2 && sp::eff_lo(B) == B->len / 2 && sp::eff_hi(A) <= A->len / 4 && sp::eff_hi(B) <= B->len / 4;
+    if (gated && !dense && !sparse_stream) return 0;  // (the plain bind that follows takes its challenge as an argument)
+    const spk::MailRef mref = gated ? gate_launch(c, answers) : mail_ref(c, ahead, answers);
+    if (dense) {
       // fused: bind this round, evaluate the next (K1 + K3 in one pass over the tables)
       const size_t q = A->len / 4;
       size_t blocks = (q + chunk - 1) / chunk;
@@ -1226,8 +1271,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
         c->timed("bind_stream_quad", 48ull * A->len * 2, [&] {
           hipLaunchKernelGGL(spk::k_bind_eval_quad_stream, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, lp, mref);
         });
-        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
-        c->pending_slots = 0;
+        sum_lazy_launch(c, lp, q / 256, 2, (const fe_t*)nullptr, seq);
       } else {
         c->timed("bind", 48ull * A->len * 2, [&] {
           hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, rv, c->d_scratch, c->d_pinned, next_seq(c), mref);
@@ -1239,7 +1283,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       have_sums = true;
       return 1;
     }
-    if (A->len / 4 >= STREAM_MIN_Q && sp::eff_lo(A) == A->len / 2 && sp::eff_lo(B) == B->len / 2 && sp::eff_hi(A) <= A->len / 4 && sp::eff_hi(B) <= B->len / 4) {
+    if (sparse_stream) {
       // full low half, (almost) empty high half: bind without reading the zeros, evaluate the next round from registers
       const size_t q = A->len / 4;
       spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
@@ -1248,8 +1292,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
         hipLaunchKernelGGL(spk::k_bind_eval_quad_stream_sparse, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, sp::eff_hi(A), sp::eff_hi(B), lp,
                            mref);
       });
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, q / 256, 2, (const fe_t*)nullptr, c->d_pinned, seq);
-      c->pending_slots = 0;
+      sum_lazy_launch(c, lp, q / 256, 2, (const fe_t*)nullptr, seq);
       sp::after_bind(A);
       sp::after_bind(B);
       have_sums = true;
@@ -1282,8 +1325,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
           else
             hipLaunchKernelGGL((spk::k_eval_quad_stream<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
         });
-        hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, blocks, 2, (const fe_t*)nullptr, c->d_pinned, seq);
-        c->pending_slots = 0;
+        sum_lazy_launch(c, lp, blocks, 2, (const fe_t*)nullptr, seq);
         waiting = true;
       } else if (len > 0) {
         size_t blocks = (len + chunk - 1) / chunk;
@@ -1962,7 +2004,8 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       int rc2 = launch_bind(c, tabs, 3, rv);
       return rc2 ? rc2 : 1;
     }
-    if (ahead && !launch_ahead_ok(c, A->len)) return 0;
+    const bool gated = ahead && !launch_ahead_ok(c, A->len);
+    if (gated && !gate_ok(c)) return 0;
     if (!stopped && tail_enabled() && A->len <= TAIL_MAX_LEN && tail_blocks(A->len / 2, true) <= (unsigned)spk::HOST_SUM_MAX_BLOCKS && lease.take(tail_blocks(A->len / 2, true))) {
       spk::TailArgs ta;
       ta.A = A->d;
@@ -1989,7 +2032,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       return 1;
     }
     // K1 fused with next round's K2: bind with r, evaluate round rnd+1 from registers
-    const spk::MailRef mref = mail_ref(c, ahead, answers);
+    const spk::MailRef mref = gated ? gate_launch(c, answers) : mail_ref(c, ahead, answers);
     const size_t q = A->len / 4;
     const EqSel e = select_eq(rnd + 1);
     dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
@@ -2002,15 +2045,16 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         fe_t *pa = A->d, *pb = B->d, *pc = C->d;
         // tables of 2^23 and more (3 x 256 MiB: past the 256 MiB Infinity Cache) are accounted separately: their GB/s is unambiguously HBM
         const char* kname = A->len >= ((size_t)1 << 23) ? "bind_stream_cubic_hbm" : "bind_stream_cubic";
-        if (e.mode == 0 && ahead) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<0, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        const bool polls = ahead && !gated;
+        if (e.mode == 0 && gated) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<0, false, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else if (gated) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, false, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else if (e.mode == 0 && polls) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<0, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
         else if (e.mode == 0) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<0, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
-        else if (ahead) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
+        else if (polls) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
         else c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
       }
       // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr,
-                         c->d_pinned, seq);
-      c->pending_slots = 0;
+      sum_lazy_launch(c, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr, seq);
       sp::after_bind(A);
       sp::after_bind(B);
       sp::after_bind(C);
@@ -2043,9 +2087,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_products_stream<0>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
         else hipLaunchKernelGGL((spk::k_eval_products_stream<1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
       });
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
-                         c->d_pinned, seq);
-      c->pending_slots = 0;
+      sum_lazy_launch(c, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
     } else if (half >= STREAM_MIN_Q && half % 256 == 0 && (e1.mode == 0 || (e1.mode == 1 && e1.s >= 8))) {
       spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
       const unsigned seq = next_seq(c);
@@ -2054,9 +2096,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_cubic_stream<0>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
         else hipLaunchKernelGGL((spk::k_eval_cubic_stream<1>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
       });
-      hipLaunchKernelGGL(spk::k_sum_partials_lazy, dim3(1), dim3(spk::SUM_LAZY_THREADS), 0, c->stream, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr,
-                         c->d_pinned, seq);
-      c->pending_slots = 0;
+      sum_lazy_launch(c, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
     } else {
       size_t blocks = 0;
       c->timed("eval_cubic", 160ull * (A->len / 2), [&] { blocks = launch_eval(1, false); });

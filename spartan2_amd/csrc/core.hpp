@@ -152,6 +152,7 @@ struct sp_ctx {
   const unsigned* d_mail_mirror = nullptr;
   void* mail_alloc = nullptr;
   bool mail_dev = false;
+  fe_t* d_gate = nullptr;  // MAIL_RING challenge slots written by k_mail_gate (a streaming launch queued behind its gate reads its challenge here)
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs
   void* h_pinned_fbs = nullptr;  // pinned staging of the synchronous fixed-base calls (<= 1024 scalars: the per-round commitments of the ZK verifier circuit)
   // one-launch FixedBaseMul::multi_mul (sp_fbtables_multi_mul, kernels_msm.hpp k_multi_mul_coop): mapped pinned pages (result slot at byte 0, scalars

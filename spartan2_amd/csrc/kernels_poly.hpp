@@ -119,6 +119,7 @@ struct MailRef {
   const unsigned* mirror;  // device-side address of the host-memory mirror of the ring (nullptr when `mail` is in host memory itself)
   fe_t* mapped;            // mapped pinned result buffer (error word at TAIL_ERR_ELEM)
   unsigned answers;        // sequence number of the round result the awaited challenge answers
+  const fe_t* gated;       // non-null: the launch sits behind k_mail_gate in its stream and finds its challenge here (no polling)
 };
 // wave-uniform: does the 13-word line held in lanes 0..12 of `w` carry the challenge answering `want`? (-1: the host aborted)
 __device__ __forceinline__ int mail_line_state(unsigned w, unsigned want, int lane) {
@@ -206,11 +207,30 @@ __device__ __forceinline__ bool mail_wait(const unsigned* mail, const unsigned* 
   return ok != 0;
 }
 // the challenge of a fused bind+evaluate kernel: its argument, or the mailbox when it was launched ahead (all threads of the block must call)
+// (read through the constant address space: a wave-uniform scalar load - the eight words arrive in scalar registers like a challenge passed as a
+// kernel argument, and the scalar cache starts every kernel empty, so the gate's store is what is read)
+__device__ __forceinline__ fe_t gated_challenge(const fe_t* p) {
+  typedef const __attribute__((address_space(4))) uint32_t* const_words;
+  const_words q = (const_words)(uintptr_t)p;
+  fe_t r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = q[i];
+  return r;
+}
 __device__ __forceinline__ fe_t challenge_or(const MailRef& m, const fe_t& r_arg) {
+  if (m.gated) return gated_challenge(m.gated);
   if (!m.mail) return r_arg;
   __shared__ fe_t r_sh;
   mail_wait(m.mail, m.mirror, m.mapped, m.answers, &r_sh);
   return r_sh;
+}
+
+// The gate of a streaming launch (capi_core.hip gate_launch): one wave waits at the mailbox and stores the challenge for the launch queued behind it.
+// On an abort or a watchdog trip the slot gets whatever was read: the launch behind it computes garbage on tables the host has given up.
+__global__ void __launch_bounds__(64) k_mail_gate(MailRef m, fe_t* __restrict__ out) {
+  __shared__ fe_t r_sh;
+  mail_wait(m.mail, m.mirror, m.mapped, m.answers, &r_sh);
+  if (threadIdx.x < 8) out->v[threadIdx.x] = r_sh.v[threadIdx.x];
 }
 
 // ---- K1: bind the top variable of up to 8 tables with the same challenge -----------------------------------
@@ -407,40 +427,41 @@ __global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __rest
 // reads 4 elements and writes 2 per table (in place, disjoint across threads), i.e. exactly the 48 L bytes/table of an
 // unfused bind; the next round's sums come from registers for free.
 __device__ __forceinline__ fe_t bind1(const fe_t& lo, const fe_t& hi, const fe_t& r) { return fe_add<S>(lo, fe_mul<S>(r, fe_sub<S>(hi, lo))); }
+// One pair per lane (EVAL_PPT == 1). Everything that does not depend on the challenge - the twelve element loads, the weight - is issued BEFORE the
+// challenge is taken: a launch issued ahead of its challenge then waits at the mailbox with its operands in registers, and the 2-3 us of memory
+// latency are off the round's critical path.
+static_assert(EVAL_PPT == 1, "the fused bind + evaluate kernels below hold one pair per lane across the mailbox wait");
 template <int MODE>
 __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r_arg,
                                                          const fe_t* __restrict__ eq_in, const fe_t* __restrict__ eq_out, int s,
                                                          fe_t* __restrict__ partials, fe_t* __restrict__ single_out, unsigned seq, MailRef mref) {
   __shared__ fe_t smem[2 * 4];
-  const fe_t r = challenge_or(mref, r_arg);
-  const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
-  const size_t base = (size_t)blockIdx.x * chunk;
+  const size_t base = (size_t)blockIdx.x * blockDim.x;
   const size_t mask = ((size_t)1 << s) - 1;
+  const size_t id = base + threadIdx.x;
+  const bool live = id < q;
+  const size_t ld = live ? id : 0;  // (dead lanes of the last block load element 0: no branch around the loads)
+  const fe_t la0 = A[ld], la1 = A[ld + q], la2 = A[ld + 2 * q], la3 = A[ld + 3 * q];
+  const fe_t lb0 = B[ld], lb1 = B[ld + q], lb2 = B[ld + 2 * q], lb3 = B[ld + 3 * q];
+  const fe_t lc0 = C[ld], lc1 = C[ld + q], lc2 = C[ld + 2 * q], lc3 = C[ld + 3 * q];
+  fe_t w = (MODE == 0) ? eq_in[ld] : eq_in[ld & mask];
+  if (MODE == 2) w = fe_mul<S>(w, eq_out[ld >> s]);
+  const fe_t r = challenge_or(mref, r_arg);
   fe_t acc[2] = {fe_zero(), fe_zero()};
-#pragma unroll 1
-  for (int k = 0; k < EVAL_PPT; ++k) {
-    const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
-    if (id < q) {
-      // issue all twelve element loads before any arithmetic: memory-level parallelism per lane is what fills HBM
-      const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
-      const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
-      const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
-      const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
-      const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
-      const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
-      A[id] = a0;
-      A[id + q] = a1;
-      B[id] = b0;
-      B[id + q] = b1;
-      C[id] = c0;
-      C[id + q] = c1;
-      fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
-      if (MODE == 2) w = fe_mul<S>(w, eq_out[id >> s]);
-      const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
-      const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
-      acc[0] = fe_add<S>(acc[0], fe_mul<S>(w, t0e));
-      acc[1] = fe_add<S>(acc[1], fe_mul<S>(w, tie));
-    }
+  if (live) {
+    const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+    const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+    const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
+    A[id] = a0;
+    A[id + q] = a1;
+    B[id] = b0;
+    B[id + q] = b1;
+    C[id] = c0;
+    C[id + q] = c1;
+    const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+    const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+    acc[0] = fe_mul<S>(w, t0e);
+    acc[1] = fe_mul<S>(w, tie);
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
@@ -456,25 +477,22 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic(fe_t* __restrict__ A, f
 __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, fe_t* __restrict__ partials,
                                                         fe_t* __restrict__ single_out, unsigned seq, MailRef mref) {
   __shared__ fe_t smem[2 * 4];
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = id < q;
+  const size_t ld = live ? id : 0;
+  const fe_t la0 = A[ld], la1 = A[ld + q], la2 = A[ld + 2 * q], la3 = A[ld + 3 * q];
+  const fe_t lb0 = B[ld], lb1 = B[ld + q], lb2 = B[ld + 2 * q], lb3 = B[ld + 3 * q];
   const fe_t r = challenge_or(mref, r_arg);
-  const size_t chunk = (size_t)blockDim.x * EVAL_PPT;
-  const size_t base = (size_t)blockIdx.x * chunk;
   fe_t acc[2] = {fe_zero(), fe_zero()};
-#pragma unroll 1
-  for (int k = 0; k < EVAL_PPT; ++k) {
-    const size_t id = base + (size_t)k * blockDim.x + threadIdx.x;
-    if (id < q) {
-      const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
-      const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
-      const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
-      const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
-      A[id] = a0;
-      A[id + q] = a1;
-      B[id] = b0;
-      B[id + q] = b1;
-      acc[0] = fe_add<S>(acc[0], fe_mul<S>(a0, b0));
-      acc[1] = fe_add<S>(acc[1], fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0)));
-    }
+  if (live) {
+    const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+    const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+    A[id] = a0;
+    A[id + q] = a1;
+    B[id] = b0;
+    B[id + q] = b1;
+    acc[0] = fe_mul<S>(a0, b0);
+    acc[1] = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
   }
   block_sum<2>(acc, smem);
   if (threadIdx.x == 0) {
@@ -486,7 +504,11 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe
 // Same data movement as the fused kernels above; the reduction is per WAVE and lazy (9-word sums, no modular adds, no LDS, no
 // barrier), and the eq_left factor / modular reduction happen once per x_out group in k_sum_partials_lazy. On a 30 us kernel the
 // block-level modular tree was a quarter of the time (tools/fused_bench.hip).
-// wave sums -> LDS -> one lazy block partial pair per 256-thread block (plain multiword adds: no modular arithmetic here)
+// wave sums -> LDS -> one lazy block partial pair per 256-thread block (plain multiword adds: no modular arithmetic here).
+// Layout of the partials (nparts = gridDim.x blocks, two accumulators of nine words): word w of accumulator a of block b at
+// P[(2 w + a) nparts + b] - word-major, so that the second stage's lane, which owns a group of consecutive blocks, fetches each word of its whole
+// group with ONE vector load and a wave's loads are contiguous (block-major 72-byte records cost the old second stage one dependent, uncoalesced
+// load per block and word: 8-10 us for 150 KB).
 __device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const lazy9_t& s1, lazy9_t* __restrict__ partials) {
   __shared__ lazy9_t sm[4][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -496,13 +518,17 @@ __device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const l
   }
   __syncthreads();
   if (threadIdx.x < 2) {  // thread 0 -> accumulator 0, thread 1 -> accumulator 1
-    lazy9_t t = lazy_add(lazy_add(sm[0][threadIdx.x], sm[1][threadIdx.x]), lazy_add(sm[2][threadIdx.x], sm[3][threadIdx.x]));
-    partials[(size_t)blockIdx.x * 2 + threadIdx.x] = t;
+    const lazy9_t t = lazy_add(lazy_add(sm[0][threadIdx.x], sm[1][threadIdx.x]), lazy_add(sm[2][threadIdx.x], sm[3][threadIdx.x]));
+    uint32_t* P = reinterpret_cast<uint32_t*>(partials);
+#pragma unroll
+    for (int w = 0; w < 9; ++w) P[(size_t)(2 * w + threadIdx.x) * gridDim.x + blockIdx.x] = t.v[w];
   }
 }
 // AHEAD: launched before its challenge is known (waits at the mailbox). A separate instantiation so that the ordinary form keeps its register
 // budget (128 VGPRs, 4 waves per SIMD): holding the twelve loaded elements across the mailbox barrier costs 20 more.
-template <int MODE, bool AHEAD>
+// GATED: queued behind k_mail_gate (capi_core.hip gate_launch): the challenge is in device memory when the kernel starts. Its own instantiation too,
+// so that the ordinary form stays the code it was.
+template <int MODE, bool AHEAD, bool GATED = false>
 __global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r_arg,
                                                                 const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials, MailRef mref) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // q is a multiple of the block size here
@@ -512,6 +538,7 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict
   const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
   fe_t r = r_arg;
   if (AHEAD) r = challenge_or(mref, r_arg);  // after the loads: a kernel launched ahead fetches its tables while the host draws the challenge
+  if (GATED) r = gated_challenge(mref.gated);
   const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
   const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
   const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
@@ -628,35 +655,64 @@ __global__ void __launch_bounds__(256) k_eval_quad_stream_lowhi(const fe_t* __re
   l1 = lazy_add(l1, l0);
   stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
 }
-constexpr int SUM_LAZY_THREADS = 256;  // a 1024-thread fully lazy form was measured: 16.1 us per call against 12.1 (rocprof averages)
-// Second stage for the streaming kernels: per group of 2^group_log2 consecutive blocks, lazy-sum, reduce mod p, multiply by
-// eq_out[group] (when given), then a modular block sum over groups. One block.
-__global__ void __launch_bounds__(256) k_sum_partials_lazy(const lazy9_t* __restrict__ partials, size_t nparts, int group_log2,
-                                                           const fe_t* __restrict__ eq_out, fe_t* __restrict__ out, unsigned seq) {
-  __shared__ fe_t smem[2 * 4];
-  const size_t ngroups = nparts >> group_log2, per = (size_t)1 << group_log2;
+// Second stage for the streaming kernels: per group of 2^GL consecutive blocks the lazy sum, ONE reduction mod p and the product with eq_out[group]
+// (when given), then a modular wave sum. Single-wave blocks, a group per lane, at most HOST_SUM_MAX_BLOCKS of them: every block lands its two sums
+// in a host result slot of its own and the host adds the 4-8 slots (no LDS, no barrier, no cross-wave stage; the loads of a lane are 18 vector
+// loads issued together). GL < 0: group size 2^gl_rt from the argument (scalar loads; shapes the templates do not cover).
+template <int GL>
+__global__ void __launch_bounds__(64) k_sum_partials_lazy(const uint32_t* __restrict__ P, size_t nparts, int gl_rt, const fe_t* __restrict__ eq_out,
+                                                          fe_t* __restrict__ mapped, unsigned seq) {
+  const int gl = GL >= 0 ? GL : gl_rt;
+  const size_t ngroups = nparts >> gl, per = (size_t)1 << gl;
   fe_t acc[2] = {fe_zero(), fe_zero()};
-  for (size_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
-    lazy9_t l0 = partials[(g * per) * 2], l1 = partials[(g * per) * 2 + 1];
-    for (size_t k = 1; k < per; ++k) {
-      l0 = lazy_add(l0, partials[(g * per + k) * 2]);
-      l1 = lazy_add(l1, partials[(g * per + k) * 2 + 1]);
+  for (size_t g = (size_t)blockIdx.x * 64 + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * 64) {
+    unsigned long long col[2][9];
+#pragma unroll
+    for (int w = 0; w < 9; ++w)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const uint32_t* src = P + (size_t)(2 * w + a) * nparts + g * per;
+        if constexpr (GL == 0) {
+          col[a][w] = src[0];
+        } else if constexpr (GL == 1) {
+          const uint2 v = *reinterpret_cast<const uint2*>(src);
+          col[a][w] = (unsigned long long)v.x + v.y;
+        } else if constexpr (GL == 2) {
+          const uint4 v = *reinterpret_cast<const uint4*>(src);
+          col[a][w] = ((unsigned long long)v.x + v.y) + ((unsigned long long)v.z + v.w);
+        } else if constexpr (GL == 3) {
+          const uint4 v = *reinterpret_cast<const uint4*>(src), u = *reinterpret_cast<const uint4*>(src + 4);
+          col[a][w] = (((unsigned long long)v.x + v.y) + ((unsigned long long)v.z + v.w)) + (((unsigned long long)u.x + u.y) + ((unsigned long long)u.z + u.w));
+        } else {
+          unsigned long long t = 0;
+          for (size_t k = 0; k < per; ++k) t += src[k];
+          col[a][w] = t;
+        }
+      }
+    fe_t f[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {  // column sums -> nine words (a block's sum is below 2^264, a group's below 2^288 for up to 2^24 blocks)
+      lazy9_t l;
+      unsigned long long carry = 0;
+#pragma unroll
+      for (int w = 0; w < 9; ++w) {
+        const unsigned long long t = col[a][w] + carry;
+        l.v[w] = (uint32_t)t;
+        carry = t >> 32;
+      }
+      f[a] = lazy_reduce(l);
     }
-    fe_t f0 = lazy_reduce(l0), f1 = lazy_reduce(l1);
     if (eq_out) {
       const fe_t eo = eq_out[g];
-      f0 = fe_mul<S>(f0, eo);
-      f1 = fe_mul<S>(f1, eo);
+      f[0] = fe_mul<S>(f[0], eo);
+      f[1] = fe_mul<S>(f[1], eo);
     }
-    acc[0] = fe_add<S>(acc[0], f0);
-    acc[1] = fe_add<S>(acc[1], f1);
+    acc[0] = fe_add<S>(acc[0], f[0]);
+    acc[1] = fe_add<S>(acc[1], f[1]);
   }
-  block_sum<2>(acc, smem);
-  if (threadIdx.x == 0) {
-    out[0] = acc[0];
-    out[1] = acc[1];
-    publish_result(out, seq);
-  }
+  acc[0] = wave_sum(acc[0]);
+  acc[1] = wave_sum(acc[1]);
+  if (threadIdx.x == 0) emit_partials<2>(acc, nullptr, mapped, seq);  // gridDim.x <= HOST_SUM_MAX_BLOCKS: the slot path
 }
 
 // ---- K3: quadratic evaluation sums ---------------------------------------------------------------------------------
@@ -903,32 +959,24 @@ __global__ void __launch_bounds__(256) k_dot(const fe_t* __restrict__ A, const f
   }
 }
 
-// out[k] = sum_b partials[b * nacc + k], nacc <= 3; one block. The tree is lazy (multiword adds through the wave shuffles and LDS), one modular
-// reduction per sum at the end: this second stage sits on the critical path of every mid-size round.
-__global__ void __launch_bounds__(256) k_sum_partials(const fe_t* __restrict__ partials, size_t nblocks, int nacc, fe_t* __restrict__ out, unsigned seq) {
-  __shared__ lazy9_t sm[4][3];
+// Second stage of the mid-size rounds: sum_b partials[b * nacc + k], nacc <= 3, over more than HOST_SUM_MAX_BLOCKS producer blocks. Single-wave
+// blocks (at most HOST_SUM_MAX_BLOCKS), lazy multiword adds through the wave shuffles, one modular reduction per sum, then the block's result
+// slot: the host adds the 2-8 slots. This stage sits on the critical path of every mid-size round; its one-block form with an LDS stage and a
+// serial tail took 5-6 us.
+__global__ void __launch_bounds__(64) k_sum_partials(const fe_t* __restrict__ partials, size_t nblocks, int nacc, fe_t* __restrict__ mapped, unsigned seq) {
   lazy9_t t[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) t[k] = lazy_from(fe_zero());
-  for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) {
+  for (size_t b = (size_t)blockIdx.x * 64 + threadIdx.x; b < nblocks; b += (size_t)gridDim.x * 64) {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (k < nacc) t[k] = lazy_add(t[k], lazy_from(partials[b * nacc + k]));
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  fe_t acc[3] = {fe_zero(), fe_zero(), fe_zero()};
 #pragma unroll
   for (int k = 0; k < 3; ++k)
-    if (k < nacc) {
-      t[k] = lazy_wave_sum(t[k]);
-      if (lane == 0) sm[wave][k] = t[k];
-    }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (k < nacc) out[k] = lazy_reduce(lazy_add(lazy_add(sm[0][k], sm[1][k]), lazy_add(sm[2][k], sm[3][k])));
-    publish_result(out, seq);
-  }
+    if (k < nacc) acc[k] = lazy_reduce(lazy_wave_sum(t[k]));
+  if (threadIdx.x == 0) emit_partials<3>(acc, nullptr, mapped, seq);  // gridDim.x <= HOST_SUM_MAX_BLOCKS: the slot path (the host reads nacc of the three)
 }
 
 // ---- persistent tail of a sum-check: the last log2(len) rounds in ONE single-block launch ---------------------------------------------

@@ -175,6 +175,8 @@ class Background {
     if (!th_.joinable()) th_ = std::thread([this] { loop(); });
     cv_.notify_one();
   }
+  // for a waiter that polls something the job produces rather than the job's end: takes the job back if the helper has not begun it (see above)
+  bool try_steal() { return pending_.load(std::memory_order_acquire) && steal_and_run(); }
   void wait_nothrow() {  // for exit paths: also drops what the job threw, so that it cannot resurface in a later submit()
     for (unsigned spins = 0; pending_.load(std::memory_order_acquire); ++spins) {
       if ((spins & 63u) == 63u && steal_and_run()) break;

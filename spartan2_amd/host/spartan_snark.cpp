@@ -42,7 +42,17 @@ struct SpartanProverKey {  // src/spartan.rs:30-58
 // lone prove is as fast this way as with a spinning helper (1.29-1.31 ms either way; wake-up ~10 us, off the critical path or under the MSM it
 // starts), and a spinning helper costs one CPU per prove in flight on top of the owner's polling thread - under the 16-CPU CFS quota of the bench
 // boxes eight such pairs got the whole cgroup throttled and resident kernels ran into their watchdog.
-static bool helper_may_spin() { return false; }
+// A helper that waits INSIDE a prove for the owner's next notification (the opening's helper: delta once the outer sum-check is in its resident rounds,
+// comm_LZ once the row challenges are drawn) may spin while few proves are in flight in the process: a sleeping thread's wake-up is the scheduler's
+// to time - usually tens of microseconds, now and then milliseconds (one prove in 50 - 2000 was 2 - 5 ms long for it on the bench boxes). With many
+// proves in flight (the 8-context throughput mode under a 16-CPU quota) the helpers sleep: a CPU per helper is then worth more than the odd late one.
+static std::atomic<int> g_active_proves{0};
+static constexpr int HELPER_SPIN_MAX_PROVES = 4;
+static bool helper_may_spin() { return g_active_proves.load(std::memory_order_relaxed) <= HELPER_SPIN_MAX_PROVES; }
+struct ActiveProve {
+  ActiveProve() { g_active_proves.fetch_add(1, std::memory_order_relaxed); }
+  ~ActiveProve() { g_active_proves.fetch_sub(1, std::memory_order_relaxed); }
+};
 
 // Per-prep-state driver options (ss_prep_set_flags; defaults from the environment at prep_prove time).
 //   FLAG_PREFIX_CACHE: the transcript prefix new + vk + public_values + comm_W_shared / comm_W_precommitted is the same for every prove on one prep
@@ -210,6 +220,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const size_t M = pk.num_vars, N = d.num_cons, W_ = DEFAULT_COMMITMENT_WIDTH;
   if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
   ck(sp_ctx_bind_thread(ctx), "device");  // the caller may be a thread other than the one that created the context
+  const ActiveProve active_prove;
   const double t_start = now_ms();
   double t_lap = t_start;
   auto lap = [&](const char* name) {
@@ -704,8 +715,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       // the helper delivers comm_LZ itself (one multi_mul over the prepared tables): join it only where comm_LZ is absorbed; what is needed before
       // that (poly_com, delta) was finished under the inner sum-check
       const auto t0 = std::chrono::steady_clock::now();
-      while (lz.early_done.load(std::memory_order_acquire) == 0) {
+      for (unsigned spins = 0; lz.early_done.load(std::memory_order_acquire) == 0; ++spins) {
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) throw Error(SP_ERR_INTERNAL, "the PCS helper did not finish delta");
+        if ((spins & 63u) == 63u) ps.bg.try_steal();  // the helper thread never woke for this prove: its whole job runs here (every state it waits for is published)
         sp_relax();
       }
     } else {
