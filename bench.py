@@ -763,7 +763,7 @@ def main():
         # HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024); null if absent
         traffic, traffic_src = None, None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.message_bytes == 2048:
                 with open(pmc) as f:
@@ -772,10 +772,10 @@ def main():
                 if keys:
                     traffic, traffic_src = tj[keys[0]]["traffic_bytes"], f"profiles/{name} (separate rocprofv3 --pmc passes of this command)"
                     break
-        # rocprofv3 kernel-only durations of the same call sites, committed under profiles/ (tools/r04_profile_job.sh): inside a prove and with the GPU
+        # rocprofv3 kernel-only durations of the same call sites, committed under profiles/ (tools/profile_job.sh): inside a prove and with the GPU
         # otherwise empty. The HIP-event figures below are taken inside a prove, where the auxiliary streams' kernels are resident beside these.
         rocprof_sites = None
-        sites_path = os.path.join(ROOT, "profiles", "r04_kernel_sites.json")
+        sites_path = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_kernel_sites.json", "r04_kernel_sites.json")) if os.path.exists(p_)), "")
         if os.path.exists(sites_path) and args.message_bytes == 2048:
             with open(sites_path) as f:
                 sj = json.load(f)
@@ -826,7 +826,7 @@ def main():
                          "other_kernels_rocprof": rocprof_sites,
                          "other_kernels_note": "avg_us are HIP-event times of an instrumented pass INSIDE a prove: kernels of the auxiliary streams (delta's MSM, the PCS table "
                                                "walks, the resident sum-check tail) are resident beside them, so they are upper bounds of the kernel's own time; "
-                                               "other_kernels_rocprof (profiles/r04_kernel_stats.md) gives the rocprofv3 kernel-only duration of the same call site inside a prove "
+                                               "other_kernels_rocprof (profiles/r05_kernel_stats.md) gives the rocprofv3 kernel-only duration of the same call site inside a prove "
                                                "and alone. The 'bind' class (fused bind + evaluate launches on tables <= 2^19 elements) is launched AHEAD of "
                                                "its challenge and waits for it at the mailbox: its avg_us includes that wait, so its GB/s understate the kernel; the streaming "
                                                "classes and the roofline kernel (tables >= 2^20) are launched behind their challenge and their times are the kernels' alone."},

@@ -430,10 +430,17 @@ int main() {
     report("1024-thread blocks, in-block weight", time_us([&] { hipLaunchKernelGGL((k_fat<1>), dim3(q / 1024), dim3(1024), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
     report("the same, 2 chunks per block", time_us([&] { hipLaunchKernelGGL((k_fat<2>), dim3(q / 2048), dim3(1024), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
     report("the same, 4 chunks per block", time_us([&] { hipLaunchKernelGGL((k_fat<4>), dim3(q / 4096), dim3(1024), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
-    report("second stage alone (k_sum_partials_lazy)", time_us([&] { hipLaunchKernelGGL(k_sum_partials_lazy, dim3(1), dim3(SUM_LAZY_THREADS), 0, 0, lp, q / 256, 2, eo, part + (q / 64), 7u); }, 20));
+    // the second stages as the library launches them since round 5: single-wave blocks, one host result slot each (mapped pinned memory)
+    fe_t* slots_h = nullptr;
+    fe_t* slots_d = nullptr;
+    hipHostMalloc((void**)&slots_h, (SLOT_BASE_ELEM + 4 * HOST_SUM_MAX_BLOCKS + 16) * sizeof(fe_t), hipHostMallocMapped);
+    hipHostGetDevicePointer((void**)&slots_d, slots_h, 0);
+    const size_t ngroups = (q / 256) >> 2, b2 = (ngroups + 63) / 64 > HOST_SUM_MAX_BLOCKS ? HOST_SUM_MAX_BLOCKS : (ngroups + 63) / 64;
+    report("second stage alone (k_sum_partials_lazy<2>)", time_us([&] { hipLaunchKernelGGL((k_sum_partials_lazy<2>), dim3((unsigned)b2), dim3(64), 0, 0, reinterpret_cast<const uint32_t*>(lp), q / 256, 2, eo, slots_d, 7u); }, 20));
     report("256-thread blocks, in-block weight", time_us([&] { hipLaunchKernelGGL(k_w256, dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 20));
-    report("modular second stage (k_sum_partials), q/256 x 2", time_us([&] { hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, 0, part, q / 256, 2, part + (q / 64), 7u); }, 20));
-    report("modular second stage (k_sum_partials), q/1024 x 2", time_us([&] { hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, 0, part, q / 1024, 2, part + (q / 64), 7u); }, 20));
+    report("second stage of the mid rounds (k_sum_partials), 512 x 2", time_us([&] { hipLaunchKernelGGL(k_sum_partials, dim3(8), dim3(64), 0, 0, part, (size_t)512, 2, slots_d, 7u); }, 20));
+    report("second stage of the mid rounds (k_sum_partials), 128 x 2", time_us([&] { hipLaunchKernelGGL(k_sum_partials, dim3(2), dim3(64), 0, 0, part, (size_t)128, 2, slots_d, 7u); }, 20));
+    hipHostFree(slots_h);
     report("var0 block256", time_us([&] { hipLaunchKernelGGL((k_var<0, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
     report("var1 nontemporal loads", time_us([&] { hipLaunchKernelGGL((k_var<1, 256>), dim3((q + 255) / 256), dim3(256), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));
     report("var0 block64 (wave-only reduce)", time_us([&] { hipLaunchKernelGGL((k_var<0, 64>), dim3((q + 63) / 64), dim3(64), 0, 0, A, B, C, q, r, eq, eo, 10, part); }, 10));

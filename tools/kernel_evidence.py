@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 4: the command behind profiles/r04_kernel_stats.md (run under rocprofv3 --kernel-trace, and under the two --pmc passes).
+"""The command behind profiles/<round>_kernel_stats.md (tools/profile_job.sh) (run under rocprofv3 --kernel-trace, and under the two --pmc passes).
   prove   config-2 (sha256 2048 B) SpartanSNARK::prove only, the headline driver: 2 warm-up + N proves. Nothing else in the process, so
           every launch in the trace belongs to a C2 prove and a (kernel, grid) pair names ONE call site.
   solo    the same kernels at the same sizes, one ABI call at a time with a device sync in between: nothing else on the GPU while a kernel

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r04_kernel_stats.md from the rocprofv3 CSVs of tools/r04_profile_job.sh.
+"""profiles/<round>_kernel_stats.md from the rocprofv3 CSVs of tools/profile_job.sh.
 For every kernel VERDICT r3 item 7 names (and the roofline kernel), selected by (kernel, grid size) so that a row is ONE call site of the config-2 prove:
 the kernel-only duration inside a prove (headline driver and reference-order driver), the same launch run alone, how much of the in-prove duration other
 kernels were resident on the GPU (from the trace's own timestamps), the SURVEY 8(d) algorithmic bytes, GB/s, and PMC traffic."""
@@ -64,7 +64,9 @@ def overlap_stats(ls, idxs):
 # len / 4 threads, the evaluation kernels one thread per pair (len / 2) or per four pairs (lowhi<4>).
 def sites(M_):
     return [
-        ("k_bind_eval_cubic_stream<1, false>", None, "outer: bind round r + evaluate round r+1 (ROOFLINE kernel at grid 262144)", lambda g: 48 * (4 * g) * 3,
+        ("k_bind_eval_cubic_stream<1, false, true>", None, "outer: bind round r + evaluate round r+1, queued behind its mailbox gate (ROOFLINE kernel at grid 262144)",
+         lambda g: 48 * (4 * g) * 3, "3 tables of len = 4 grid: read 32 len, write 16 len each"),
+        ("k_bind_eval_cubic_stream<1, false, false>", None, "the same launched behind its challenge (reference order without a device mailbox; the streaming probe)", lambda g: 48 * (4 * g) * 3,
          "3 tables of len = 4 grid: read 32 len, write 16 len each"),
         ("k_eval_cubic_stream<1>", None, "outer round 0 evaluation (no round-0 products: reference order)", lambda g: 160 * g, "grid = pairs; A, B, C pairs + eq: 160 B per pair"),
         ("k_eval_products_stream<1>", None, "outer round 0 from the round-0 products (headline driver)", lambda g: 64 * g, "grid = pairs; p0, p1: 64 B per pair"),
@@ -83,6 +85,7 @@ def main():
     ap = argparse.ArgumentParser()
     for k in ("prove", "reford", "solo", "fetch", "write", "out", "pmc-json", "sites-json"):
         ap.add_argument("--" + k)
+    ap.add_argument("--round", default="r05")
     ap.add_argument("--bench-json", help="a bench.py line: poly_abc / spmv bytes (the library's 8(d) accounting) are read from its other_kernels")
     a = ap.parse_args()
     P, R, S = launches(a.prove), launches(a.reford), launches(a.solo)
@@ -107,8 +110,8 @@ def main():
     fmt = lambda v: "-" if v is None else f"{v:.1f}"
     pmc, site_rows = {}, {}
     with open(a.out, "w") as f:
-        f.write("# round 4: per-kernel evidence for the config-2 prove (sha256 2048 B, num_cons = num_vars = 2^20)\n\n"
-                "Commands (tools/r04_profile_job.sh): `rocprofv3 --kernel-trace --stats -- python tools/r04_kernel_evidence.py prove` (headline driver, 12 proves, nothing else "
+        f.write(f"# {a.round}: per-kernel evidence for the config-2 prove (sha256 2048 B, num_cons = num_vars = 2^20)\n\n"
+                "Commands (tools/profile_job.sh): `rocprofv3 --kernel-trace --stats -- python tools/kernel_evidence.py prove` (headline driver, 12 proves, nothing else "
                 "in the process), `... prove --reference-order`, `... solo` (the same kernels, one ABI call at a time with a device sync in between), and two `--pmc` passes "
                 "(FETCH_SIZE, WRITE_SIZE) of the first command.\n\n"
                 "A row is ONE call site: kernel name + grid size (threads). `in prove` = rocprofv3 kernel-only duration (End - Start of the dispatch) inside the headline prove; "
