@@ -121,6 +121,7 @@ class Background {
       if (!posted_ || std::chrono::steady_clock::now() - posted_at_ <= std::chrono::microseconds(30)) return false;
       f.swap(job_);
       posted_ = false;  // the helper, when it does wake, finds nothing posted and sleeps on
+      posted_hint_.store(0, std::memory_order_relaxed);
     }
     try {
       f();
@@ -130,12 +131,24 @@ class Background {
     pending_.store(0, std::memory_order_release);
     return true;
   }
+  // a helper that has just finished a job looks for the next one for a short while before it goes to sleep (while the driver allows helpers to spin:
+  // few proves in flight): in a stream of proves the next job is tens of microseconds away, a sleeper's wake-up 10 - 50 us on top of that
+  bool (*may_spin_)() = nullptr;
+  std::atomic<int> posted_hint_{0};
   void loop() {
     for (;;) {
       std::function<void()> f;
+      if (may_spin_) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; !posted_hint_.load(std::memory_order_acquire); ++spins) {
+          if ((spins & 255u) == 255u && (!may_spin_() || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250))) break;
+          sp_relax();
+        }
+      }
       {
         std::unique_lock<std::mutex> l(m_);
         cv_.wait(l, [&] { return posted_ || stop_; });
+        posted_hint_.store(0, std::memory_order_relaxed);
         if (stop_) return;
         f.swap(job_);
         posted_ = false;
@@ -172,9 +185,11 @@ class Background {
       posted_ = true;
       posted_at_ = std::chrono::steady_clock::now();
     }
+    posted_hint_.store(1, std::memory_order_release);
     if (!th_.joinable()) th_ = std::thread([this] { loop(); });
     cv_.notify_one();
   }
+  void set_spin_policy(bool (*may_spin)()) { may_spin_ = may_spin; }
   // for a waiter that polls something the job produces rather than the job's end: takes the job back if the helper has not begun it (see above)
   bool try_steal() { return pending_.load(std::memory_order_acquire) && steal_and_run(); }
   void wait_nothrow() {  // for exit paths: also drops what the job threw, so that it cannot resurface in a later submit()

@@ -46,6 +46,16 @@ struct SpartanProverKey {  // src/spartan.rs:30-58
 // comm_LZ once the row challenges are drawn) may spin while few proves are in flight in the process: a sleeping thread's wake-up is the scheduler's
 // to time - usually tens of microseconds, now and then milliseconds (one prove in 50 - 2000 was 2 - 5 ms long for it on the bench boxes). With many
 // proves in flight (the 8-context throughput mode under a 16-CPU quota) the helpers sleep: a CPU per helper is then worth more than the odd late one.
+// delta's MSM (ipa.rs:147; ~175 us of bucket kernels on the auxiliary stream) is issued by the opening's helper when the outer sum-check has this many
+// rounds left (SPARTAN_DELTA_ROUNDS_LEFT, A/B): late enough to stay clear of the streaming rounds, early enough to be done before poly_ABC starts
+static size_t delta_rounds_before_end() {
+  static const size_t v = [] {
+    const char* e = getenv("SPARTAN_DELTA_ROUNDS_LEFT");
+    const int k = e ? atoi(e) : 17;
+    return (size_t)(k < 1 ? 1 : k);
+  }();
+  return v;
+}
 static std::atomic<int> g_active_proves{0};
 static constexpr int HELPER_SPIN_MAX_PROVES = 4;
 static bool helper_may_spin() { return g_active_proves.load(std::memory_order_relaxed) <= HELPER_SPIN_MAX_PROVES; }
@@ -135,6 +145,8 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
   const sp_dims& d = pk.dims;
   if (n_witness != d.num_shared_unpadded + d.num_precommitted_unpadded + d.num_rest_unpadded) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
   auto* ps = new SpartanPrepSNARK();
+  ps->bg.set_spin_policy(&helper_may_spin);
+  ps->bg2.set_spin_policy(&helper_may_spin);
   try {
     sp_ctx* ctx = pk.ctx;
     const size_t M = pk.num_vars, N = d.num_cons;
@@ -547,7 +559,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     bool begun = false;
     static void fn(void* u, size_t round, const uint64_t r[4]) {
       EqObs* o = (EqObs*)u;
-      if (o->lz && round + 15 == o->ell) o->lz->publish(o->lz->delta_state, 1);  // tables of 2^14 from here on: the rounds of the resident kernel
+      if (o->lz && round + delta_rounds_before_end() == o->ell) o->lz->publish(o->lz->delta_state, 1);
       if (round + 4 >= o->ell) return;  // the last four coordinates (the rounds the host runs itself after the hand-over) are applied by sp_eq_table_finish
       memcpy(&o->r[round], r, 32);
       if (round + 5 == o->ell) {
