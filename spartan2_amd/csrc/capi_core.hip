@@ -936,7 +936,7 @@ int sp_eq_table_finish(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
   spk::EqLastK rk;
   for (int i = 0; i < 4; ++i) rk.r[i] = i < K ? load_fe(r + 4 * (ell - K + i)) : fe_zero();
   c->timed("eq_table", 32ull * total, [&] {
-    hipLaunchKernelGGL(spk::k_eq_outer_lastk, dim3((unsigned)((n_hi + spk::EQ_LASTK_HPB - 1) / spk::EQ_LASTK_HPB)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(spk::k_eq_outer_lastk, dim3((unsigned)((n_hi + spk::EQ_LASTK_HPB - 1) / spk::EQ_LASTK_HPB)), dim3(1024), 0, c->stream,
                        c->d_eq_ahead + spk::eq_level_offset(hi_bits), c->d_eq_ahead + ((size_t)1 << 11) + spk::eq_level_offset(lo_bits - K), K, n_hi, rk, t->d);
   });
   SP_HIP(hipEventRecord(c->eq_read_ev, c->stream));

@@ -323,33 +323,35 @@ __global__ void __launch_bounds__(1024) k_eq_levels_pair(EqPairArgs a) {
 }
 // The same table with the LAST K variables (2 <= K <= 4) applied here: T_lo covers only the low variables up to them, so both pyramids can be built K
 // rounds before the sum-check that draws the point ends (K = 4: when its resident kernel hands the last rounds to the host).
-// out[(hi << 10) | lo] = T_hi[hi] (T_lo[lo >> K] e_K[lo & (2^K - 1)]), lo_bits = 10. A thread keeps its four low factors (lo = 256 k + t: the same
-// low K bits for every k, so ONE e_K weight per thread, K - 1 products) in registers and walks EQ_LASTK_HPB high entries: 7 + 4 HPB products for
-// 4 HPB outputs, every store a wave-contiguous 2 KiB (the two-variable form of round 3 wrote 128 bytes per lane at a 128-byte stride: 18 us for 2^20).
-constexpr int EQ_LASTK_HPB = 2;
+// out[(hi << 10) | lo] = T_hi[hi] (T_lo[lo >> K] e_K[lo & (2^K - 1)]), lo_bits = 10. A block of 1024 threads, thread = lo: the 2^K weights e_K are formed
+// by the first 2^K threads (K - 1 products each) and shared through LDS, every thread forms ITS low factor once (one product) and then walks
+// EQ_LASTK_HPB high entries, one product and one 32-byte store each - 1 + 1 / HPB products per output, every store of a wave 2 KiB contiguous, 256
+// blocks of 16 waves at 2^20 (the two-variable form of round 3 wrote 128 bytes per lane at a 128-byte stride: 18 us for 2^20).
+constexpr int EQ_LASTK_HPB = 4;
 struct EqLastK {
   fe_t r[4];  // the last K coordinates, in order
 };
-__global__ void __launch_bounds__(256) k_eq_outer_lastk(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqLastK rk,
-                                                        fe_t* __restrict__ out) {
+__global__ void __launch_bounds__(1024) k_eq_outer_lastk(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqLastK rk,
+                                                         fe_t* __restrict__ out) {
+  __shared__ fe_t wsh[16];
   const unsigned t = threadIdx.x;
-  const fe_t one = fe_one<S>();
-  fe_t w = one;
-  for (int i = 0; i < K; ++i) {  // first of the K variables = most significant of the K bits
-    const fe_t f = ((t >> (K - 1 - i)) & 1u) ? rk.r[i] : fe_sub<S>(one, rk.r[i]);
-    w = i == 0 ? f : fe_mul<S>(w, f);
+  if (t < (1u << K)) {
+    const fe_t one = fe_one<S>();
+    fe_t w = one;
+    for (int i = 0; i < K; ++i) {  // first of the K variables = most significant of the K bits
+      const fe_t f = ((t >> (K - 1 - i)) & 1u) ? rk.r[i] : fe_sub<S>(one, rk.r[i]);
+      w = i == 0 ? f : fe_mul<S>(w, f);
+    }
+    wsh[t] = w;
   }
-  fe_t lo[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) lo[k] = fe_mul<S>(t_lo[(256u * k + t) >> K], w);
+  const fe_t tl = t_lo[t >> K];
+  __syncthreads();
+  const fe_t lo = fe_mul<S>(tl, wsh[t & ((1u << K) - 1)]);
   for (size_t hi = (size_t)blockIdx.x * EQ_LASTK_HPB; hi < n_hi; hi += (size_t)gridDim.x * EQ_LASTK_HPB) {
 #pragma unroll
     for (int h = 0; h < EQ_LASTK_HPB; ++h) {
       if (hi + h >= n_hi) break;
-      const fe_t th = t_hi[hi + h];
-      fe_t* o = out + ((hi + h) << 10);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o[256 * k + t] = fe_mul<S>(th, lo[k]);
+      out[((hi + h) << 10) + t] = fe_mul<S>(t_hi[hi + h], lo);
     }
   }
 }
