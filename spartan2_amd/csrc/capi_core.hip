@@ -223,6 +223,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->stream_eq) hipStreamDestroy(c->stream_eq);
   if (c->eq_ev) hipEventDestroy(c->eq_ev);
   if (c->eq_read_ev) hipEventDestroy(c->eq_read_ev);
+  if (c->cubic_ev) hipEventDestroy(c->cubic_ev);
+  if (c->d_cubic_eq) hipFree(c->d_cubic_eq);
   if (c->d_eq_ahead) hipFree(c->d_eq_ahead);
   delete c;
 }
@@ -1898,16 +1900,25 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
   const size_t chunk = 256 * spk::EVAL_PPT;
   size_t max_blocks = (N / 2 + chunk - 1) / chunk + 1;
   if (max_blocks * 3 * 32 < (N / 4 / 64) * 72 + 64) max_blocks = ((N / 4 / 64) * 72 + 64 + 95) / 96;  // room for lazy wave partials too
-  size_t need = ell + pyr_left + pyr_right + max_blocks * 3 + 32;
-  int rc = c->ensure_scratch(need);
-  if (rc) return rc;
-  // layout: [partials (max_blocks*3)] [taus_left][taus_right][pyr_left][pyr_right]
-  fe_t* d_part = c->d_scratch;
-  fe_t* d_tl = d_part + max_blocks * 3;
-  fe_t* d_trt = d_tl + nleft;
-  fe_t* d_pl = d_trt + second_half;
-  fe_t* d_pr = d_pl + pyr_left;
   if (nleft > 16 || second_half > 16) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sum-check over more than 2^32 rows");
+  int rc = c->ensure_scratch(max_blocks * 3 + 32);  // the block partials
+  if (rc) return rc;
+  fe_t* d_part = c->d_scratch;
+  // The two eq pyramids live in a buffer of their own (not in the scratch every launch shares): they are built on the eq stream beside whatever the
+  // main stream still has queued in front of this sum-check, so nothing else may be using their memory then. Its only readers are the kernels of a
+  // cubic sum-check on this context, and the previous one has delivered its last result to the host before this call can be made.
+  if (c->cubic_eq_elems < pyr_left + pyr_right) {
+    if (c->d_cubic_eq) {
+      SP_HIP(sp::stream_sync(c->stream));  // (growing: once per context and size)
+      hipFree(c->d_cubic_eq);
+    }
+    c->d_cubic_eq = nullptr;
+    c->cubic_eq_elems = 0;
+    SP_HIP(hipMalloc((void**)&c->d_cubic_eq, (pyr_left + pyr_right) * sizeof(fe_t)));
+    c->cubic_eq_elems = pyr_left + pyr_right;
+  }
+  fe_t* d_pl = c->d_cubic_eq;
+  fe_t* d_pr = d_pl + pyr_left;
   {
     spk::EqPairArgs ea;
     for (size_t i = 0; i < nleft; ++i) ea.v[0][i] = taus[1 + i];
@@ -1916,7 +1927,12 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     ea.m[1] = (int)second_half;
     ea.out[0] = d_pl;
     ea.out[1] = d_pr;
-    hipLaunchKernelGGL(spk::k_eq_levels_pair, dim3(2), dim3(1024), 0, c->stream, ea);
+    // On the eq stream, beside whatever the main stream still has queued in front of this sum-check (the matrix-vector product and its round-0
+    // products at the start of a prove: ~70 us): the pyramids need nothing but the taus; the main stream waits for them before the first evaluation.
+    if (!c->cubic_ev) SP_HIP(hipEventCreateWithFlags(&c->cubic_ev, hipEventDisableTiming));
+    hipLaunchKernelGGL(spk::k_eq_levels_pair, dim3(2), dim3(1024), 0, c->stream_eq, ea);
+    SP_HIP(hipEventRecord(c->cubic_ev, c->stream_eq));
+    SP_HIP(hipStreamWaitEvent(c->stream, c->cubic_ev, 0));
   }
 
   // eq tables of round `rnd` (1-based, src/sumcheck.rs:1011) for `half` pairs

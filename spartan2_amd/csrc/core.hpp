@@ -136,6 +136,9 @@ struct sp_ctx {
   hipEvent_t eq_ev = nullptr;
   hipEvent_t eq_read_ev = nullptr;  // recorded behind the last k_eq_outer_lastk that READS d_eq_ahead: the next pyramids wait for it before rewriting the buffer
   bool eq_read_pending = false;
+  fe_t* d_cubic_eq = nullptr;     // the cubic sum-check's two eq pyramids (EqSumCheckInstance::new tables)
+  size_t cubic_eq_elems = 0;
+  hipEvent_t cubic_ev = nullptr;  // the cubic sum-check's eq pyramids (built on the eq stream beside the main stream's queue) -> its first evaluation
   fe_t* d_eq_ahead = nullptr;     // two pyramids of <= 2^11 entries
   size_t eq_ahead_ell = 0, eq_ahead_known = 0;  // set by sp_eq_table_begin, consumed by sp_eq_table_finish
   fe_t eq_ahead_r[32];

@@ -203,7 +203,8 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
     for (sp_table** t : {&ps->caz, &ps->cbz, &ps->ccz, &ps->az, &ps->bz, &ps->cz}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc Az");
     ck(sp_multiply_vec(ctx, pk.S, ps->z, ps->caz, ps->cbz, ps->ccz), "multiply_vec_precommitted");
     ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &ps->rx), "alloc rx");
-    if (N >= 2) {
+    const char* no_p0 = getenv("SPARTAN_ROUND0_PRODUCTS");  // "0": round 1 of the outer sum-check evaluates straight from Az, Bz, Cz (A/B)
+    if (N >= 2 && !(no_p0 && no_p0[0] == '0')) {
       ck(sp_table_zeros(ctx, N / 2, (size_t)-1, (size_t)-1, &ps->p0), "alloc round-0 products");
       ck(sp_table_zeros(ctx, N / 2, (size_t)-1, (size_t)-1, &ps->p1), "alloc round-0 products");
     }
@@ -244,6 +245,79 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   std::vector<fe_t> publics(npub);
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
 
+  // ONE job for the second helper, submitted before anything else, carries the two host chains nothing on this thread depends on until much later:
+  //   (1) the transcript prefix (src/spartan.rs:226-236, bellpepper/r1cs.rs:422-427): new + vk + public_values + comm_W_shared + comm_W_precommitted -
+  //       about 300 Keccak blocks at config 2, ~45 us. Re-hashed in every prove, as the reference does (FLAG_PREFIX_CACHE keeps the sponge state
+  //       across proves instead). Needed when comm_W_rest is absorbed, i.e. after commit_zeros has come back from the device: `prefix_ready`.
+  //   (2) the IPA mask d_vec (ipa.rs:139-145) and the blinds of delta and beta, which do not depend on the transcript: 2048 wide reductions from their
+  //       tape position, ~70 us. Needed when delta's MSM is issued (a third of the way into the outer sum-check): `dvec_ready`.
+  // The first helper stays free for the opening's job, which is posted the moment comm_W is complete.
+  const size_t n_ipa = M < W_ ? M : W_;
+  std::vector<fe_t> dvec(n_ipa);
+  fe_t r_delta_ahead, r_beta_ahead;
+  std::atomic<int> prefix_ready{0}, dvec_ready{0};
+  const bool prefix_cached = (ps.flags & FLAG_PREFIX_CACHE) != 0;
+  if (prefix_cached) {
+    if (!ps.tr_prefix) {
+      Tr t0(ctx, "SpartanSNARK");
+      t0.absorb("vk", pk.vk_digest, 32);
+      t0.absorb_scalars("public_values", publics.data(), npub);
+      if (ps.rows_shared) t0.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
+      if (ps.rows_precommitted) t0.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
+      ps.tr_prefix = t0.t;
+      t0.t = nullptr;
+      ps.tr_publics = publics;
+    } else if (ps.tr_publics.size() != publics.size() || memcmp(ps.tr_publics.data(), publics.data(), publics.size() * sizeof(fe_t)) != 0) {
+      throw Error(SP_ERR_INTERNAL, "public values changed between proves on one prep state");
+    }
+  }
+  {
+    SpartanPrepSNARK* psp = &ps;
+    const SpartanProverKey* pkp = &pk;
+    const fe_t* pub = publics.data();
+    // tape order: the rest-row blinds (drawn below), blind_eval_W, then d_vec, r_delta, r_beta
+    Tape peek{tape.bytes, tape.blocks, tape.pos + (d.num_rest + W_ - 1) / W_ + 1};
+    fe_t* dv = dvec.data();
+    const size_t dn = dvec.size();
+    fe_t *rd = &r_delta_ahead, *rb = &r_beta_ahead;
+    std::atomic<int>*pr = &prefix_ready, *dr = &dvec_ready;
+    ps.bg2.submit([ctx, psp, pkp, pub, npub, prefix_cached, peek, dv, dn, rd, rb, pr, dr]() mutable {
+      struct Flags {  // whatever happens in here, a waiter must not spin for ever (an exception resurfaces at the next wait())
+        std::atomic<int>*a, *b;
+        ~Flags() {
+          a->store(1, std::memory_order_release);
+          b->store(1, std::memory_order_release);
+        }
+      } flags{pr, dr};
+      if (!prefix_cached) {
+        sp_transcript_free(psp->tr_fresh);
+        psp->tr_fresh = nullptr;
+        Tr t0(ctx, "SpartanSNARK");
+        t0.absorb("vk", pkp->vk_digest, 32);
+        t0.absorb_scalars("public_values", pub, npub);
+        if (psp->rows_shared) t0.absorb("comm_W_shared", psp->comm_shared_bytes.data(), psp->comm_shared_bytes.size());
+        if (psp->rows_precommitted) t0.absorb("comm_W_precommitted", psp->comm_pre_bytes.data(), psp->comm_pre_bytes.size());
+        psp->tr_fresh = t0.t;
+        t0.t = nullptr;
+      }
+      pr->store(1, std::memory_order_release);
+      for (size_t i = 0; i < dn; ++i) dv[i] = peek.next();
+      *rd = peek.next();  // ipa.rs:146: the blind of delta follows d_vec on the tape
+      *rb = peek.next();  // then beta's
+      dr->store(1, std::memory_order_release);
+    });
+  }
+  // a flag the second helper's job raises; if the helper has not even begun the job 30 us after it was posted, the job runs here (Background::try_steal)
+  auto await_flag = [&ps](std::atomic<int>& flag) {
+    for (unsigned spins = 0; flag.load(std::memory_order_acquire) == 0; ++spins) {
+      if ((spins & 63u) == 63u) ps.bg2.try_steal();
+      sp_relax();
+    }
+  };
+  struct PrefixJoin {  // publics must outlive the job on every exit path
+    Background& b;
+    ~PrefixJoin() { b.wait_nothrow(); }
+  } prefix_join{ps.bg2};
   // commitment to the rest segment (bellpepper/r1cs.rs:463-491): commit_zeros (hyrax_pc.rs:305-319) when it is all padding —
   // started first on the auxiliary stream, collected after the host work below — else PCS::commit on the resident witness.
   const size_t rows_pre = ps.comm_W_fixed.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
@@ -267,53 +341,19 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
   lap("commit_zeros_begin");
 
-  // transcript prefix (src/spartan.rs:226-236, bellpepper/r1cs.rs:422-427): new + vk + public_values + comm_W_shared + comm_W_precommitted — about 300
-  // Keccak blocks at config 2. Re-hashed in every prove, as the reference does, on the second helper thread: nothing needs the transcript before
-  // comm_W_rest is absorbed, i.e. before commit_zeros has come back from the device. FLAG_PREFIX_CACHE keeps the sponge state across proves instead.
-  const bool prefix_cached = (ps.flags & FLAG_PREFIX_CACHE) != 0;
-  if (prefix_cached) {
-    if (!ps.tr_prefix) {
-      Tr t0(ctx, "SpartanSNARK");
-      t0.absorb("vk", pk.vk_digest, 32);
-      t0.absorb_scalars("public_values", publics.data(), npub);
-      if (ps.rows_shared) t0.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
-      if (ps.rows_precommitted) t0.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
-      ps.tr_prefix = t0.t;
-      t0.t = nullptr;
-      ps.tr_publics = publics;
-    } else if (ps.tr_publics.size() != publics.size() || memcmp(ps.tr_publics.data(), publics.data(), publics.size() * sizeof(fe_t)) != 0) {
-      throw Error(SP_ERR_INTERNAL, "public values changed between proves on one prep state");
-    }
-  } else {
-    SpartanPrepSNARK* psp = &ps;
-    const SpartanProverKey* pkp = &pk;
-    const fe_t* pub = publics.data();
-    ps.bg2.submit([ctx, psp, pkp, pub, npub] {
-      sp_transcript_free(psp->tr_fresh);
-      psp->tr_fresh = nullptr;
-      Tr t0(ctx, "SpartanSNARK");
-      t0.absorb("vk", pkp->vk_digest, 32);
-      t0.absorb_scalars("public_values", pub, npub);
-      if (psp->rows_shared) t0.absorb("comm_W_shared", psp->comm_shared_bytes.data(), psp->comm_shared_bytes.size());
-      if (psp->rows_precommitted) t0.absorb("comm_W_precommitted", psp->comm_pre_bytes.data(), psp->comm_pre_bytes.size());
-      psp->tr_fresh = t0.t;
-      t0.t = nullptr;
-    });
-  }
-  struct PrefixJoin {  // publics must outlive the job on every exit path
-    Background& b;
-    ~PrefixJoin() { b.wait_nothrow(); }
-  } prefix_join{ps.bg2};
   lap("transcript_prefix");
   Tr tr(nullptr, Tr::Adopt{});
   auto acquire_transcript = [&] {
     if (tr.t) return;
     if (prefix_cached) ck(sp_transcript_clone(ps.tr_prefix, &tr.t), "transcript_clone");
     else {
-      ps.bg2.wait();
+      await_flag(prefix_ready);
       tr.t = ps.tr_fresh;
       ps.tr_fresh = nullptr;
-      if (!tr.t) throw Error(SP_ERR_INTERNAL, "transcript prefix was not prepared");
+      if (!tr.t) {
+        ps.bg2.wait();  // (rethrows what the job threw)
+        throw Error(SP_ERR_INTERNAL, "transcript prefix was not prepared");
+      }
     }
   };
   // verifier challenges (bellpepper/r1cs.rs:429-431) and the rest of the witness that depends on them (:443-461): squeezed right after the
@@ -349,27 +389,6 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   else ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
   const double t_mv_issue = now_ms() - t_mv0;
 
-  // The IPA mask d_vec (ipa.rs:139-145) does not depend on the transcript: draw it now from its tape position (host work that
-  // overlaps commit_zeros); delta's MSM (ipa.rs:147) is issued on the auxiliary stream right before the inner sum-check, whose
-  // latency-bound rounds leave the device mostly idle (the outer sum-check's streaming rounds are left undisturbed).
-  const size_t n_ipa = M < W_ ? M : W_;
-  std::vector<fe_t> dvec(n_ipa);
-  fe_t r_delta_ahead, r_beta_ahead;
-  {  // on the helper thread (1024 wide reductions, 70 us): nothing needs d_vec before delta's MSM is issued
-    Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // skip blind_eval_W, drawn before d_vec in call order
-    fe_t* dv = dvec.data();
-    const size_t dn = dvec.size();
-    fe_t *rd = &r_delta_ahead, *rb = &r_beta_ahead;
-    ps.bg.submit([peek, dv, dn, rd, rb]() mutable {
-      for (size_t i = 0; i < dn; ++i) dv[i] = peek.next();
-      *rd = peek.next();  // ipa.rs:146: the blind of delta follows d_vec on the tape
-      *rb = peek.next();  // then beta's
-    });
-  }
-  struct DrawJoin {  // dvec must outlive the job on every exit path
-    Background& b;
-    ~DrawJoin() { b.wait_nothrow(); }
-  } draw_join{ps.bg};
   lap("dvec_draw");
 
   const bool rest_job_used = rest_job != nullptr;  // the rest rows are h * blind (commit_zeros)
@@ -381,17 +400,19 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   else if (rows_rest)
     ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)),
        "commit rest");
+  lap("commit_zeros_finish");
   acquire_transcript();
+  lap("prefix_join");
   {
     std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
   }
-  lap("commit_zeros_finish+absorb");
+  lap("absorb_comm_W_rest");
   std::vector<fe_t> r_W = ps.r_W_fixed;  // combine_blinds (bellpepper/r1cs.rs:515-524)
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
   // comm_W is complete: its transcript encoding (64 B per row, Montgomery -> canonical) and the Keccak blocks of absorb("poly_com", ..), the
   // first absorb after the inner sum-check's last squeeze (hyrax_pc.rs:387-400), are computed on the helper thread from here on
-  ps.bg.wait();  // d_vec and r_delta are drawn
+  ps.bg.wait();  // (idle: nothing has been posted to the first helper in this prove yet)
   sp_absorb_state_free(ps.poly_com);
   ps.poly_com = nullptr;
   // The same helper then computes comm_LZ = sum_i L[i] comm_W[i] (= commit(L . W; <L, r_W>), hyrax_pc.rs:430-455, by the homomorphism of the
@@ -421,7 +442,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       cv.notify_one();
     }
   } lz;
-  lz.r_delta = r_delta_ahead;
+  // (lz.r_delta is set by the opening's job once d_vec and the blinds are drawn: dvec_ready)
   lz.nvr = lz_nvr;
   const bool lz_ahead = !lz_direct && lz_nvr > 0 && lz_nvr <= 20 && comm_W.size() == ((size_t)1 << lz_nvr) && r_W.size() == comm_W.size();
   const size_t lz_cols = (size_t)1 << (log2_ceil(M) - lz_nvr);
@@ -439,7 +460,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     const size_t nfixed = ps.comm_W_fixed.size();
     const fe_t* dv = dvec.data();
     const size_t dn = n_ipa;
-    ps.bg.submit([ctx, rows, nrows, psp, blinds, lzp, key, cols, tabs, nfixed, dv, dn] {
+    std::atomic<int>* dvr = &dvec_ready;
+    const fe_t* rda = &r_delta_ahead;
+    ps.bg.submit([ctx, rows, nrows, psp, blinds, lzp, key, cols, tabs, nfixed, dv, dn, dvr, rda] {
       const std::vector<uint8_t> b = commitment_bytes(rows, nrows);
       ck(sp_transcript_preabsorb((const uint8_t*)"poly_com", 8, b.data(), b.size(), &psp->poly_com), "poly_com (prepare)");
       if (!lzp) return;
@@ -464,6 +487,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       // challenge observer): the MSM then runs under the resident tail kernel, which leaves the device idle, instead of beside the first rounds
       // of the inner sum-check (measured there: k_eval_quad_stream_lowhi 32 us against 18 us alone, profiles/r04_kernel_stats.md)
       if (wait_for(lzp->delta_state) != 1) return;
+      while (dvr->load(std::memory_order_acquire) == 0) sp_relax();  // d_vec, r_delta (the second helper's job, posted first thing in the prove: long done)
+      lzp->r_delta = *rda;
       ck(sp_msm_ck_begin(ctx, key, u64p(dv), dn, &lzp->delta_job), "delta (begin)");
       {
         sp_msm_job* j = lzp->delta_job;
@@ -596,6 +621,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const double t_abc = now_ms();
 
   sp_msm_job* delta_job = nullptr;
+  await_flag(dvec_ready);  // d_vec, r_delta, r_beta from here on
   if (!lz_ahead) ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
   // inner sum-check. The reference runs round 0 by hand on the compact vectors (src/spartan.rs:323-384); that round is
   // value-identical to a generic prove_quad round on the 2M-long tables with (lo_eff, hi_eff) = (M, num_extra).

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel timeline of ONE config-2 prove (headline driver): every kernel's start offset, duration and the idle gap in front of it, from rocprofv3 --kernel-trace.
-# Output: gpurun_out/r03_timeline.txt
+# Output: gpurun_out/timeline.txt
 R=$(pwd); O=$R/gpurun_out/tl; rm -rf $O; mkdir -p $O
 cat > /tmp/tl_prove.py <<'PY'
 import sys, os, time
@@ -15,7 +15,6 @@ sn.prep_prove(tape)
 for i in range(5): sn.prove(tape)
 time.sleep(0.05)   # a visible gap in the trace in front of the prove that is listed
 w, u, ph = sn.prove(tape)
-time.sleep(0.05)
 print(ph)
 PY
 cd /tmp && export TMPDIR=/tmp
@@ -29,18 +28,18 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 starts = [int(r['Start_Timestamp']) for r in rows]
 ends = [int(r['End_Timestamp']) for r in rows]
 cuts = [i for i in range(1, len(rows)) if starts[i] - ends[i - 1] > 30_000_000]
-lo, hi = (cuts[-2], cuts[-1]) if len(cuts) >= 2 else (cuts[-1], len(rows))
+lo, hi = (cuts[-1], len(rows)) if cuts else (0, len(rows))  # the prove behind the last pause
 t0 = starts[lo]
-out = open('gpurun_out/r03_timeline.txt', 'w')
+out = open('gpurun_out/timeline.txt', 'w')
 out.write("offset_us  dur_us  gap_us  kernel\n")
 prev_end = t0
 for i in range(lo, hi):
     n = rows[i]['Kernel_Name'].split('(')[0][:60]
-    out.write(f"{(starts[i]-t0)/1e3:9.1f} {(ends[i]-starts[i])/1e3:7.1f} {(starts[i]-prev_end)/1e3:7.1f}  {n}\n")
+    out.write(f"{(starts[i]-t0)/1e3:9.1f} {(ends[i]-starts[i])/1e3:7.1f} {(starts[i]-prev_end)/1e3:7.1f}  q{rows[i].get('Queue_Id','?')}  {n}\n")
     prev_end = max(prev_end, ends[i])
 busy = sum(ends[i] - starts[i] for i in range(lo, hi))
 out.write(f"kernels {hi-lo}, span {(max(ends[lo:hi])-t0)/1e3:.1f} us, sum of kernel durations {busy/1e3:.1f} us\n")
 out.close()
-print(open('gpurun_out/r03_timeline.txt').read())
+print(open('gpurun_out/timeline.txt').read())
 PY
 rm -rf $O
