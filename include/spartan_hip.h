@@ -88,6 +88,14 @@ int sp_table_write_async(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* z
 int sp_table_zero(sp_ctx* ctx, sp_table* t, size_t off, size_t cnt);
 /* device -> device copy */
 int sp_table_copy(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt);
+/* dst[dst_off, dst_off + cnt) = src[src_off, ..) and dst[zero_off, zero_off + zero_cnt) = 0 (device -> device, one launch) on a stream BESIDE the context's
+ * main one: for table contents no call reads for a while (the bulk of z = [W | 1 | public | 0...], src/spartan.rs:246-253, whose next reader after the
+ * matrix-vector product is the inner sum-check). behind_queued != 0: it runs behind whatever the context had queued when it was called; 0: the caller
+ * vouches that no queued work reads or writes the two ranges of dst (or writes the range of src). Calls that follow are NOT ordered behind it until
+ * sp_ctx_aside_join, which makes everything queued after the join wait for all earlier `_aside` work. */
+int sp_table_assemble_aside(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt, size_t zero_off, size_t zero_cnt,
+                            int behind_queued);
+int sp_ctx_aside_join(sp_ctx* ctx);
 /* dst[dst_off + j] = src[src_off + j * stride], j < cnt (device -> device). The slice of a table sharded on its LAST k variables (rank g of 2^k
  * holds Z[(j << k) | g]: src_off = g, stride = 2^k) — SURVEY.md 8(e), "sum-check by evaluation-table slice". */
 int sp_table_gather_strided(sp_ctx* ctx, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t stride, size_t cnt);

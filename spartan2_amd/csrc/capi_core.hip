@@ -220,6 +220,8 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->fb_ev) hipEventDestroy(c->fb_ev);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->aside_ev) hipEventDestroy(c->aside_ev);
+  if (c->aside_main_ev) hipEventDestroy(c->aside_main_ev);
   if (c->stream_eq) hipStreamDestroy(c->stream_eq);
   if (c->eq_ev) hipEventDestroy(c->eq_ev);
   if (c->eq_read_ev) hipEventDestroy(c->eq_read_ev);
@@ -324,6 +326,46 @@ int sp_table_zero(sp_ctx* c, sp_table* t, size_t off, size_t cnt) {
 int sp_table_copy(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt) {
   if (dst_off + cnt > dst->cap || src_off + cnt > src->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_copy: range exceeds a table");
   if (cnt) SP_HIP(hipMemcpyAsync(dst->d + dst_off, src->d + src_off, cnt * sizeof(fe_t), hipMemcpyDeviceToDevice, c->stream));
+  return SP_OK;
+}
+// dst[dst_off, dst_off + cnt) = src[src_off, ..) and dst[zero_off, zero_off + zero_cnt) = 0 in ONE launch on the eq stream, beside the main stream: the
+// bulk of z = [W | 1 | public | challenges | 0 ...] (src/spartan.rs:246-253) has no reader before the inner sum-check, so its 96 MB at config 2 need not
+// sit in front of the matrix-vector product on the main stream (three blit launches with gaps: 34 us). behind_queued != 0 orders it behind whatever the main
+// stream held at the call; with 0 the caller vouches that nothing queued touches the two ranges (the headline driver: the previous prove on the state has
+// delivered all its results, and the product queued in front reads other columns). Nothing on the main stream is ordered behind it until sp_ctx_aside_join.
+namespace {
+__global__ void __launch_bounds__(256) k_copy_and_zero(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t ncopy, uint4* __restrict__ zdst, size_t nzero) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = t0; i < ncopy; i += stride) dst[i] = src[i];
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = t0; i < nzero; i += stride) zdst[i] = z;
+}
+}  // namespace
+int sp_table_assemble_aside(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t cnt, size_t zero_off, size_t zero_cnt,
+                            int behind_queued) {
+  if (dst_off + cnt > dst->cap || src_off + cnt > src->cap || zero_off + zero_cnt > dst->cap)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_assemble_aside: range exceeds a table");
+  if (!c->aside_ev) SP_HIP(hipEventCreateWithFlags(&c->aside_ev, hipEventDisableTiming));
+  if (behind_queued) {
+    if (!c->aside_main_ev) SP_HIP(hipEventCreateWithFlags(&c->aside_main_ev, hipEventDisableTiming));
+    SP_HIP(hipEventRecord(c->aside_main_ev, c->stream));
+    SP_HIP(hipStreamWaitEvent(c->stream_eq, c->aside_main_ev, 0));
+  }
+  if (cnt || zero_cnt) {
+    const size_t work = 2 * (cnt > zero_cnt ? cnt : zero_cnt);  // uint4 per element: 2
+    size_t blocks = (work + 4 * 256 - 1) / (4 * 256);           // ~4 vectors per thread and range
+    if (blocks > 8192) blocks = 8192;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(k_copy_and_zero, dim3((unsigned)blocks), dim3(256), 0, c->stream_eq, reinterpret_cast<uint4*>(dst->d + dst_off),
+                       reinterpret_cast<const uint4*>(src->d + src_off), 2 * cnt, reinterpret_cast<uint4*>(dst->d + zero_off), 2 * zero_cnt);
+  }
+  SP_HIP(hipEventRecord(c->aside_ev, c->stream_eq));
+  c->aside_pending = true;
+  return SP_OK;
+}
+int sp_ctx_aside_join(sp_ctx* c) {
+  if (c->aside_pending) SP_HIP(hipStreamWaitEvent(c->stream, c->aside_ev, 0));
+  c->aside_pending = false;
   return SP_OK;
 }
 int sp_table_gather_strided(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_table* src, size_t src_off, size_t stride, size_t cnt) {

@@ -134,6 +134,8 @@ struct sp_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream_eq = nullptr;  // sp_eq_table_begin's pyramids (a stream of their own: the auxiliary stream may hold a 100 us MSM stage of the helper thread)
   hipEvent_t eq_ev = nullptr;
+  hipEvent_t aside_ev = nullptr, aside_main_ev = nullptr;  // sp_table_assemble_aside: its end / what the main stream held when it was issued
+  bool aside_pending = false;
   hipEvent_t eq_read_ev = nullptr;  // recorded behind the last k_eq_outer_lastk that READS d_eq_ahead: the next pyramids wait for it before rewriting the buffer
   bool eq_read_pending = false;
   fe_t* d_cubic_eq = nullptr;     // the cubic sum-check's two eq pyramids (EqSumCheckInstance::new tables)

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -131,6 +132,9 @@ class Background {
     pending_.store(0, std::memory_order_release);
     return true;
   }
+  // (HELPER_LOOKOUT_US: longer than a config-2 prove, so that in a stream of proves the helper whose one job sits at the START of a prove - the transcript
+  // prefix - is still awake when the next prove posts it: a sleeper costs the poster a futex wake, ~10 us, and itself the wake-up)
+  static constexpr int HELPER_LOOKOUT_US = 1500;
   // a helper that has just finished a job looks for the next one for a short while before it goes to sleep (while the driver allows helpers to spin:
   // few proves in flight): in a stream of proves the next job is tens of microseconds away, a sleeper's wake-up 10 - 50 us on top of that
   bool (*may_spin_)() = nullptr;
@@ -141,7 +145,7 @@ class Background {
       if (may_spin_) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0; !posted_hint_.load(std::memory_order_acquire); ++spins) {
-          if ((spins & 255u) == 255u && (!may_spin_() || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250))) break;
+          if ((spins & 255u) == 255u && (!may_spin_() || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(HELPER_LOOKOUT_US))) break;
           sp_relax();
         }
       }

@@ -242,8 +242,31 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     pt->laps.emplace_back(name, t - t_lap);
     t_lap = t;
   };
+  // First thing: the commitment to the rest segment (bellpepper/r1cs.rs:463-491) when it is all padding, i.e. commit_zeros (hyrax_pc.rs:305-319) = h * blind
+  // per row. Its kernel (~30 us of dependent point additions) + the host's batch normalisation + the absorb of the rows + the squeeze of tau is the chain
+  // the outer sum-check's first evaluation waits for, so the blinds are drawn and the kernel launched before anything else on this thread.
+  const size_t rows_pre = ps.comm_W_fixed.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
+  std::vector<fe_t> r_W_rest(rows_rest);
+  for (auto& b : r_W_rest) b = tape.next();
+  lap("rest_blinds");
+  sp_fb_job* rest_job = nullptr;
+  struct FbJobGuard {  // an error exit between begin and finish must not leave the context's one asynchronous fixed-base job outstanding
+    sp_ctx* ctx;
+    sp_fb_job*& job;
+    size_t n;
+    ~FbJobGuard() {
+      if (job) {
+        std::vector<uint64_t> sink(8 * n + 8);
+        (void)sp_fixed_base_mul_h_finish(ctx, job, sink.data());
+        job = nullptr;
+      }
+    }
+  } rest_job_guard{ctx, rest_job, rows_rest};
+  if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
+  lap("commit_zeros_begin");
   std::vector<fe_t> publics(npub);
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
+  lap("publics");
 
   // ONE job for the second helper, submitted before anything else, carries the two host chains nothing on this thread depends on until much later:
   //   (1) the transcript prefix (src/spartan.rs:226-236, bellpepper/r1cs.rs:422-427): new + vk + public_values + comm_W_shared + comm_W_precommitted -
@@ -253,7 +276,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   //       tape position, ~70 us. Needed when delta's MSM is issued (a third of the way into the outer sum-check): `dvec_ready`.
   // The first helper stays free for the opening's job, which is posted the moment comm_W is complete.
   const size_t n_ipa = M < W_ ? M : W_;
-  std::vector<fe_t> dvec(n_ipa);
+  const std::unique_ptr<fe_t[]> dvec_store(new fe_t[n_ipa]);  // (not value-initialised: the helper's draw writes every element; a zeroed vector was 12 us here)
+  fe_t* const dvec = dvec_store.get();
   fe_t r_delta_ahead, r_beta_ahead;
   std::atomic<int> prefix_ready{0}, dvec_ready{0};
   const bool prefix_cached = (ps.flags & FLAG_PREFIX_CACHE) != 0;
@@ -276,9 +300,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     const SpartanProverKey* pkp = &pk;
     const fe_t* pub = publics.data();
     // tape order: the rest-row blinds (drawn below), blind_eval_W, then d_vec, r_delta, r_beta
-    Tape peek{tape.bytes, tape.blocks, tape.pos + (d.num_rest + W_ - 1) / W_ + 1};
-    fe_t* dv = dvec.data();
-    const size_t dn = dvec.size();
+    Tape peek{tape.bytes, tape.blocks, tape.pos + 1};  // (the rest-row blinds have been drawn above)
+    fe_t* dv = dvec;
+    const size_t dn = n_ipa;
     fe_t *rd = &r_delta_ahead, *rb = &r_beta_ahead;
     std::atomic<int>*pr = &prefix_ready, *dr = &dvec_ready;
     ps.bg2.submit([ctx, psp, pkp, pub, npub, prefix_cached, peek, dv, dn, rd, rb, pr, dr]() mutable {
@@ -307,6 +331,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       dr->store(1, std::memory_order_release);
     });
   }
+  lap("helper_submit");
   // a flag the second helper's job raises; if the helper has not even begun the job 30 us after it was posted, the job runs here (Background::try_steal)
   auto await_flag = [&ps](std::atomic<int>& flag) {
     for (unsigned spins = 0; flag.load(std::memory_order_acquire) == 0; ++spins) {
@@ -318,29 +343,6 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     Background& b;
     ~PrefixJoin() { b.wait_nothrow(); }
   } prefix_join{ps.bg2};
-  // commitment to the rest segment (bellpepper/r1cs.rs:463-491): commit_zeros (hyrax_pc.rs:305-319) when it is all padding —
-  // started first on the auxiliary stream, collected after the host work below — else PCS::commit on the resident witness.
-  const size_t rows_pre = ps.comm_W_fixed.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
-  std::vector<fe_t> r_W_rest(rows_rest);
-  for (auto& b : r_W_rest) b = tape.next();
-  std::vector<aff_t> comm_W(rows_pre + rows_rest);
-  std::copy(ps.comm_W_fixed.begin(), ps.comm_W_fixed.end(), comm_W.begin());
-  sp_fb_job* rest_job = nullptr;
-  struct FbJobGuard {  // an error exit between begin and finish must not leave the context's one asynchronous fixed-base job outstanding
-    sp_ctx* ctx;
-    sp_fb_job*& job;
-    size_t n;
-    ~FbJobGuard() {
-      if (job) {
-        std::vector<uint64_t> sink(8 * n + 8);
-        (void)sp_fixed_base_mul_h_finish(ctx, job, sink.data());
-        job = nullptr;
-      }
-    }
-  } rest_job_guard{ctx, rest_job, rows_rest};
-  if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, &rest_job), "commit_zeros (begin)");
-  lap("commit_zeros_begin");
-
   lap("transcript_prefix");
   Tr tr(nullptr, Tr::Adopt{});
   auto acquire_transcript = [&] {
@@ -369,10 +371,14 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   }
 
   // z = [W | 1 | public | challenges]   (src/spartan.rs:246-253); the table is 2M long so the inner sum-check can run in place
+  // The matrix-vector product below reads only the rest / public / challenge columns of z (multiply_vec_incremental_into, src/r1cs/mod.rs:1170-1211: the
+  // precommitted part is cached), so only those go through the main stream in front of it; the bulk - the shared and precommitted columns and the zeros
+  // of the high half, 96 MB at config 2 - is assembled beside the main stream and joined in front of the outer sum-check (its first reader is the inner one).
   ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
-  ck(sp_table_copy(ctx, ps.z, 0, ps.W, 0, M), "z <- W");
+  // (a rest segment that is all padding has no matrix entries in its columns: it goes with the bulk)
+  const size_t z_fixed = d.num_rest_unpadded ? d.num_shared + d.num_precommitted : M;
+  if (M > z_fixed) ck(sp_table_copy(ctx, ps.z, z_fixed, ps.W, z_fixed, M - z_fixed), "z <- W rest");
   {
-    ck(sp_table_zero(ctx, ps.z, M, M), "clear z high half");  // what the previous prove left there
     std::vector<fe_t> tail(pk.num_extra);
     tail[0] = fe_one<S>();
     std::copy(publics.begin(), publics.end(), tail.begin() + 1);
@@ -387,9 +393,15 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const double t_mv0 = now_ms();
   if (ps.p0) ck(sp_multiply_vec_incremental_round0(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz, ps.p0, ps.p1), "multiply_vec_incremental");
   else ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
+  lap("spmv_issue");
+  ck(sp_table_assemble_aside(ctx, ps.z, 0, ps.W, 0, z_fixed, M + pk.num_extra, M - pk.num_extra, 0), "z bulk");
+  ck(sp_ctx_aside_join(ctx), "z bulk (join)");  // queued behind the product: by the time the main stream gets there the bulk of z has long been written
   const double t_mv_issue = now_ms() - t_mv0;
-
-  lap("dvec_draw");
+  // (the rest segment's commitment: commit_zeros was started at the top and is collected here, after everything the device can be given in the meantime has
+  // been issued; a segment with values takes PCS::commit on the resident witness)
+  std::vector<aff_t> comm_W(rows_pre + rows_rest);
+  std::copy(ps.comm_W_fixed.begin(), ps.comm_W_fixed.end(), comm_W.begin());
+  lap("z_bulk_issue");
 
   const bool rest_job_used = rest_job != nullptr;  // the rest rows are h * blind (commit_zeros)
   if (rest_job) {
@@ -458,7 +470,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     // tables of the fixed rows + h: usable when every other row of comm_W is h * blind (commit_zeros)
     const sp_fbtables* tabs = lz_tables_path ? ps.lz_tables : nullptr;
     const size_t nfixed = ps.comm_W_fixed.size();
-    const fe_t* dv = dvec.data();
+    const fe_t* dv = dvec;
     const size_t dn = n_ipa;
     std::atomic<int>* dvr = &dvec_ready;
     const fe_t* rda = &r_delta_ahead;
@@ -622,7 +634,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
 
   sp_msm_job* delta_job = nullptr;
   await_flag(dvec_ready);  // d_vec, r_delta, r_beta from here on
-  if (!lz_ahead) ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec.data()), n_ipa, &delta_job), "delta (begin)");
+  if (!lz_ahead) ck(sp_msm_ck_begin(ctx, pk.ck, u64p(dvec), n_ipa, &delta_job), "delta (begin)");
   // inner sum-check. The reference runs round 0 by hand on the compact vectors (src/spartan.rs:323-384); that round is
   // value-identical to a generic prove_quad round on the 2M-long tables with (lo_eff, hi_eff) = (M, num_extra).
   ck(sp_table_set_len(ps.abc, 2 * M, M, pk.num_extra), "abc len");
@@ -705,7 +717,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
         ip->submitted = true;
       }
     }
-  } obs{&lz, lz_ahead, &ipa, &ps.bg2, dvec.data()};
+  } obs{&lz, lz_ahead, &ipa, &ps.bg2, dvec};
   struct IpJoin {  // ipa and dvec outlive the job on every exit path
     Background& b;
     ~IpJoin() { b.wait_nothrow(); }
@@ -855,7 +867,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   {
     // z_vec = r * LZ + d (ipa.rs:160-163): the last step of the prove, split three ways with the two helper threads when it is wide enough to pay
     std::vector<fe_t> zv(n);
-    auto part = [&zv, &LZ, &dvec, rr](size_t lo, size_t hi) {
+    auto part = [&zv, &LZ, dvec, rr](size_t lo, size_t hi) {
       for (size_t i = lo; i < hi; ++i) zv[i] = fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]);
     };
     if (n >= 1024 && lz_ahead) {
