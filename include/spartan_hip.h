@@ -335,6 +335,11 @@ int sp_msm_job_finish(sp_ctx* ctx, sp_msm_job* job, uint64_t out_aff[8]);
  * needed only for the IPA's z vector — is computed beside comm_LZ's MSM rather than before it. One job at a time; same threading rule as above. */
 typedef struct sp_vec_job sp_vec_job;
 int sp_rowmat_vec_eq_begin(sp_ctx* ctx, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** job);
+/* The same with the IPA's mask along: `addend` (cols elements, or NULL) is uploaded behind the product, and _finish_scaled returns scale * LZ + addend
+ * - z_vec = r * LZ + d of InnerProductArgumentLinear::prove (ipa.rs:160-163), the last step of a prove - formed on the device and delivered through
+ * mapped memory, instead of LZ for the caller to scale (2048 products on the host). A job takes ONE of the two finishes. */
+int sp_rowmat_vec_eq_begin_with(sp_ctx* ctx, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, const uint64_t* addend, sp_vec_job** job);
+int sp_rowmat_vec_eq_finish_scaled(sp_ctx* ctx, sp_vec_job* job, const uint64_t scale[4], uint64_t* out);
 int sp_rowmat_vec_eq_finish(sp_ctx* ctx, sp_vec_job* job, uint64_t* out);
 int sp_msm_ck_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, sp_msm_job** job);
 int sp_msm_ck_finish(sp_ctx* ctx, const sp_ck* ck, sp_msm_job* job, const uint64_t* blind, uint64_t out_aff[8]);
@@ -343,6 +348,9 @@ int sp_msm_ck_range_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars,
 /* PCS::commit for keys of width <= 64, where the reference uses per-base FixedBaseMul tables (hyrax_pc.rs:221-260,
  * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
 int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);
+/* the same with the blind's term h * blind handed in as an affine point the caller computed beforehand (sp_fixed_base_mul_h: blinds come from the
+ * randomness stream and are known long before the scalars); n <= 6; identity = all-zero coordinates */
+int sp_hyrax_commit_small_with_term(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind_term_aff[8], uint64_t out_aff[8]);
 
 /* ---- sum-checks on a table slice ("sum-check by evaluation-table slice, one reduce per round") -----------------------------
  * Tables sharded on their LAST k variables: rank g holds Z_g[j] = Z[(j << k) | g], so the pairs (i, i + n/2) of the first ell - k rounds are

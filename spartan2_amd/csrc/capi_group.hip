@@ -490,6 +490,7 @@ static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, con
     hipLaunchKernelGGL(spk::k_fixed_base_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, ds, n, tables, ntables, dout);
   }
 }
+static const size_t VEC_FLAG_BYTES = 4096;  // per-block arrival flags of sp_rowmat_vec_eq_finish_scaled (1024 blocks of 256 columns)
 static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU core beats the launch + single-wave latency
 
 // table[i % ntables] * scalars[i] on the device (Jacobian results in host memory); ntables == 1 for h
@@ -1125,25 +1126,49 @@ int sp_msm_eq_begin(sp_ctx* c, const sp_points* pts, const uint64_t* r, size_t e
 // bind_with_delayed with L = eq(r, .) generated on the device, on a stream of its own; the result lands in pinned memory
 struct sp_vec_job {
   size_t cols = 0;
+  const fe_t* d_out = nullptr;  // the product on the device
+  const fe_t* d_add = nullptr;  // the addend of the _scaled finish on the device (null: none given)
 };
+namespace {
+// out[i] = scale * x[i] + add[i] straight into mapped pinned host memory, one flag per block behind a system-scope fence: the host polls the flags, no
+// stream synchronisation (z_vec = r * LZ + d of InnerProductArgumentLinear::prove, ipa.rs:160-163, is the last step of a prove: 2048 products were 33 us
+// on three host threads)
+__global__ void __launch_bounds__(256) k_scale_add_to_host(const fe_t* __restrict__ x, const fe_t* __restrict__ add, fe_t scale, size_t n, fe_t* __restrict__ out,
+                                                           volatile unsigned* __restrict__ flags, unsigned seq) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fe_add<S>(fe_mul<S>(scale, x[i]), add[i]);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) flags[blockIdx.x] = seq;
+}
+}  // namespace
 int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** out) {
+  return sp_rowmat_vec_eq_begin_with(c, poly, r, ell, cols, nullptr, out);
+}
+int sp_rowmat_vec_eq_begin_with(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, const uint64_t* addend, sp_vec_job** out) {
   if (!poly || !out || (!r && ell)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: null argument");
   if (ell > 20) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: more than 2^20 rows");
   const size_t rows = (size_t)1 << ell;
   if (rows * cols > poly->cap || cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed: poly shorter than rows*cols");
   if (!c->stream3) SP_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
   if (!c->vec_ev) SP_HIP(hipEventCreateWithFlags(&c->vec_ev, hipEventDisableTiming));
-  if (c->h_pinned_vec_bytes < cols * sizeof(fe_t)) {
-    if (c->h_pinned_vec) hipHostFree(c->h_pinned_vec);
+  // landing buffer of the product | staging of the addend | landing of the scaled sum | its per-block flags: one mapped pinned allocation, grow-only
+  if (c->h_pinned_vec_bytes < 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES) {
+    if (c->h_pinned_vec) {
+      SP_HIP(sp::stream_sync(c->stream3));
+      hipHostFree(c->h_pinned_vec);
+    }
     c->h_pinned_vec = nullptr;
     c->h_pinned_vec_bytes = 0;
-    SP_HIP(hipHostMalloc(&c->h_pinned_vec, cols * sizeof(fe_t)));
-    c->h_pinned_vec_bytes = cols * sizeof(fe_t);
+    SP_HIP(hipHostMalloc(&c->h_pinned_vec, 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES, hipHostMallocMapped));
+    memset(c->h_pinned_vec, 0, 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES);
+    c->h_pinned_vec_bytes = 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES;
+    c->h_pinned_vec_cols = cols;
   }
   const size_t splits = rows < 64 ? rows : 64;
   fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, rows * sizeof(fe_t), 1);
   fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
-  fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, cols * sizeof(fe_t), 1);
+  fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, 2 * cols * sizeof(fe_t), 1);  // the product | the addend
   if (!dL || !part || !dout) return SP_ERR_NO_DEVICE;
   fe_t rr[20];
   for (size_t i = 0; i < ell; ++i) memcpy(&rr[i], r + 4 * i, 32);
@@ -1167,6 +1192,13 @@ int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, s
   SP_HIP(hipEventRecord(c->vec_ev, st));
   sp_vec_job* job = new sp_vec_job();
   job->cols = cols;
+  job->d_out = dout;
+  if (addend) {  // staged in the pinned block (the caller's buffer is free on return), uploaded behind the product: nowhere near anybody's critical path
+    fe_t* stage = reinterpret_cast<fe_t*>(c->h_pinned_vec) + c->h_pinned_vec_cols;
+    memcpy(stage, addend, cols * sizeof(fe_t));
+    SP_HIP(hipMemcpyAsync(dout + cols, stage, cols * sizeof(fe_t), hipMemcpyHostToDevice, st));
+    job->d_add = dout + cols;
+  }
   *out = job;
   return SP_OK;
 }
@@ -1176,6 +1208,43 @@ int sp_rowmat_vec_eq_finish(sp_ctx* c, sp_vec_job* job, uint64_t* out) {
   delete job;
   SP_HIP(sp::event_sync(c->vec_ev));
   memcpy(out, c->h_pinned_vec, cols * sizeof(fe_t));
+  return SP_OK;
+}
+int sp_rowmat_vec_eq_finish_scaled(sp_ctx* c, sp_vec_job* job, const uint64_t scale[4], uint64_t* out) {
+  if (!job || !out || !scale) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: null argument");
+  const size_t cols = job->cols;
+  const fe_t *dx = job->d_out, *da = job->d_add;
+  delete job;
+  if (!da) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: the job was begun without an addend");
+  const size_t nblocks = (cols + 255) / 256;
+  if (nblocks * sizeof(unsigned) > VEC_FLAG_BYTES) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: more than 2^18 columns");
+  fe_t sc;
+  memcpy(&sc, scale, 32);
+  if (++c->vec_seq == 0) ++c->vec_seq;
+  const unsigned seq = c->vec_seq;
+  fe_t* h_out = reinterpret_cast<fe_t*>(c->h_pinned_vec) + 2 * c->h_pinned_vec_cols;
+  volatile unsigned* h_flags = reinterpret_cast<volatile unsigned*>(reinterpret_cast<fe_t*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols);
+  void* d_base = nullptr;
+  SP_HIP(hipHostGetDevicePointer(&d_base, c->h_pinned_vec, 0));
+  fe_t* d_hout = reinterpret_cast<fe_t*>(d_base) + 2 * c->h_pinned_vec_cols;
+  unsigned* d_flags = reinterpret_cast<unsigned*>(reinterpret_cast<fe_t*>(d_base) + 3 * c->h_pinned_vec_cols);
+  // on the job's own stream: behind the product and the upload of the addend, which ended long ago
+  hipLaunchKernelGGL(k_scale_add_to_host, dim3((unsigned)nblocks), dim3(256), 0, c->stream3, dx, da, sc, cols, d_hout, d_flags, seq);
+  bool synced = false;
+  for (size_t b = 0; b < nblocks; ++b) {
+    for (long spins = 0; h_flags[b] != seq; ++spins) {
+      if (spins > 4000000) {
+        sp::slow_note("rowmat_vec_eq_finish_scaled", spins);
+        if (synced) return fail(SP_ERR_INTERNAL, "bind_with_delayed: the scaled sum did not arrive");
+        SP_HIP(sp::stream_sync(c->stream3));  // e.g. under a profiler
+        synced = true;
+        spins = 0;
+      }
+      sp::relax();
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  memcpy(out, h_out, cols * sizeof(fe_t));
   return SP_OK;
 }
 int sp_msm_job_finish(sp_ctx* c, sp_msm_job* job, uint64_t out_aff[8]) { return sp_msm_ck_finish(c, nullptr, job, nullptr, out_aff); }
@@ -1892,6 +1961,24 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   return SP_OK;
 }
 
+// sum_i scalars[i] * ck[i] + blind_term, blind_term = h * blind computed by the caller beforehand (sp_fixed_base_mul_h[_begin]: the blind comes from the
+// randomness stream and is known long before the scalars - the commitment of eval_W behind the inner sum-check, src/spartan.rs:423-437): the host walk of
+// h's table (32 additions, ~11 us) is off the path. Identity = both coordinates zero.
+int sp_hyrax_commit_small_with_term(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind_term_aff[8], uint64_t out_aff[8]) {
+  if (!ck->d_cktables || n > ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_small: key wider than 64 or too many scalars");
+  if (n > 6) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_small_with_term: at most 6 scalars (the host-walk case)");
+  aff_t term;
+  memcpy(&term, blind_term_aff, sizeof(aff_t));
+  jac_t acc = (fe_is_zero(term.x) && fe_is_zero(term.y)) ? jac_identity() : jac_from_affine(term);
+  for (size_t i = 0; i < n; ++i) {
+    fe_t sc;
+    memcpy(&sc, scalars + 4 * i, 32);
+    acc = jac_add(acc, fixed_base_mul_host(ck->host_table(i), sc));
+  }
+  (void)c;
+  store_aff(out_aff, jac_to_affine(acc));
+  return SP_OK;
+}
 int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]) {
   if (!ck->d_cktables || n > ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_small: key wider than 64 or too many scalars");
   // FixedBaseMul::multi_mul (msm.rs:727-773) + h_table.mul(blind). A handful of scalars: host (single lookup chains). More (a round of the ZK

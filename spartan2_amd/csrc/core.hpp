@@ -188,7 +188,8 @@ struct sp_ctx {
   hipEvent_t msm_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // completion event of the MSM job in each landing slot
   hipStream_t stream3 = nullptr;     // second auxiliary stream (sp_rowmat_vec_eq_begin), created on first use
   void* h_pinned_vec = nullptr;      // pinned landing buffer of sp_rowmat_vec_eq jobs, grow-only
-  size_t h_pinned_vec_bytes = 0;
+  size_t h_pinned_vec_bytes = 0, h_pinned_vec_cols = 0;
+  unsigned vec_seq = 0;  // sequence number of sp_rowmat_vec_eq_finish_scaled's arrival flags
   hipEvent_t vec_ev = nullptr;
   // sp_hyrax_prove: pinned landing buffer of LZ (main stream), its event, and the helper thread that hashes the commitment
   void* h_pcs = nullptr;

@@ -501,6 +501,13 @@ class CommitmentKey:
         check(lib().sp_hyrax_commit_small(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(blind), p64(out)))
         return out
 
+    def commit_small_with_term(self, scalars, blind_term_aff):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        term = np.ascontiguousarray(blind_term_aff, dtype=np.uint64).reshape(8)
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().sp_hyrax_commit_small_with_term(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(term), p64(out)))
+        return out
+
     def __del__(self):
         try:
             if self.h:
@@ -541,6 +548,25 @@ def rowmat_vec(ctx, poly: Table, rows, cols, L):
     L = np.ascontiguousarray(L, dtype=np.uint64).reshape(rows, 4)
     out = np.zeros((cols, 4), dtype=np.uint64)
     check(lib().sp_rowmat_vec(ctx.h, poly.h, ctypes.c_size_t(rows), ctypes.c_size_t(cols), p64(L), p64(out)))
+    return out
+
+
+def rowmat_vec_eq(ctx, poly: Table, r, cols, addend=None, scale=None):
+    """bind_with_delayed with L = eq(r, .) as an asynchronous job (sp_rowmat_vec_eq_begin[_with] / _finish[_scaled]): LZ, or scale * LZ + addend
+    (z_vec of InnerProductArgumentLinear::prove, ipa.rs:160-163) when both are given."""
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    job = ctypes.c_void_p()
+    out = np.zeros((cols, 4), dtype=np.uint64)
+    if addend is None:
+        check(lib().sp_rowmat_vec_eq_begin(ctx.h, poly.h, p64(r), ctypes.c_size_t(len(r)), ctypes.c_size_t(cols), ctypes.byref(job)))
+    else:
+        addend = np.ascontiguousarray(addend, dtype=np.uint64).reshape(cols, 4)
+        check(lib().sp_rowmat_vec_eq_begin_with(ctx.h, poly.h, p64(r), ctypes.c_size_t(len(r)), ctypes.c_size_t(cols), p64(addend), ctypes.byref(job)))
+    if scale is None:
+        check(lib().sp_rowmat_vec_eq_finish(ctx.h, job, p64(out)))
+    else:
+        scale = np.ascontiguousarray(scale, dtype=np.uint64).reshape(4)
+        check(lib().sp_rowmat_vec_eq_finish_scaled(ctx.h, job, p64(scale), p64(out)))
     return out
 
 

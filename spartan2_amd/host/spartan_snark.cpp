@@ -278,8 +278,9 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const size_t n_ipa = M < W_ ? M : W_;
   const std::unique_ptr<fe_t[]> dvec_store(new fe_t[n_ipa]);  // (not value-initialised: the helper's draw writes every element; a zeroed vector was 12 us here)
   fe_t* const dvec = dvec_store.get();
-  fe_t r_delta_ahead, r_beta_ahead;
-  std::atomic<int> prefix_ready{0}, dvec_ready{0};
+  fe_t r_delta_ahead, r_beta_ahead, eval_W_term_blind;
+  aff_t eval_W_term, beta_term;  // h_s * blind_eval_W, h_s * r_beta (valid once eval_W_term_ready is set)
+  std::atomic<int> prefix_ready{0}, dvec_ready{0}, eval_W_term_ready{0};
   const bool prefix_cached = (ps.flags & FLAG_PREFIX_CACHE) != 0;
   if (prefix_cached) {
     if (!ps.tr_prefix) {
@@ -305,7 +306,14 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     const size_t dn = n_ipa;
     fe_t *rd = &r_delta_ahead, *rb = &r_beta_ahead;
     std::atomic<int>*pr = &prefix_ready, *dr = &dvec_ready;
-    ps.bg2.submit([ctx, psp, pkp, pub, npub, prefix_cached, peek, dv, dn, rd, rb, pr, dr]() mutable {
+    // (3) the blind's term of comm_eval_W (src/spartan.rs:423-437): blind_eval_W is the next block of the tape, h_s * blind a host walk of 32 additions
+    //     that otherwise stands between the inner sum-check's last round and the opening's transcript
+    const fe_t bew = fe_from_uniform<S>(tape.bytes + 64 * (tape.pos < tape.blocks ? tape.pos : 0));
+    aff_t* ewt = &eval_W_term;
+    fe_t* ewb = &eval_W_term_blind;
+    std::atomic<int>* ewr = &eval_W_term_ready;
+    aff_t* btt = &beta_term;
+    ps.bg2.submit([ctx, psp, pkp, pub, npub, prefix_cached, peek, dv, dn, rd, rb, pr, dr, bew, ewt, ewb, ewr, btt]() mutable {
       struct Flags {  // whatever happens in here, a waiter must not spin for ever (an exception resurfaces at the next wait())
         std::atomic<int>*a, *b;
         ~Flags() {
@@ -329,6 +337,15 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       *rd = peek.next();  // ipa.rs:146: the blind of delta follows d_vec on the tape
       *rb = peek.next();  // then beta's
       dr->store(1, std::memory_order_release);
+      // (both blind terms of the opening's one-value commitments: comm_eval_W above and beta = <R, d> g_s + r_beta h_s, ipa.rs:148-149)
+      aff_t two[2];
+      const fe_t bl[2] = {bew, *rb};
+      if (sp_fixed_base_mul_h(ctx, pkp->ck_s, u64p(bl), 2, u64p(&two[0].x)) == SP_OK) {
+        *ewt = two[0];
+        *ewb = bew;
+        *btt = two[1];
+        ewr->store(1, std::memory_order_release);
+      }
     });
   }
   lap("helper_submit");
@@ -433,6 +450,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const bool lz_direct = (ps.flags & FLAG_LZ_DIRECT) != 0;  // the reference's own order (bind W with L first, then the MSM over the key)
   struct LzAhead {
     std::atomic<int> state{0};  // 0: row challenges not drawn yet, 1: drawn, 2: abandoned
+    std::atomic<int> rows_known{0};  // how many of them r[] holds so far (the helper expands eq(r, .) a level per challenge, as they arrive)
     size_t nvr = 0;
     fe_t r[24];
     sp_msm_job* job = nullptr;
@@ -509,30 +527,63 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       }
       lzp->delta_done = true;
       lzp->early_done.store(1, std::memory_order_release);
-      if (wait_for(lzp->state) != 1) return;
-      const size_t hb = lzp->nvr / 2, lb = lzp->nvr - hb;
-      if (tabs) {
-        // comm_LZ = sum_{fixed rows} L_i comm_W[i] + (sum_{zero rows} L_i blind_i) h: one multi_mul over the prepared tables, launched before anything else
-        const std::vector<fe_t> left = eq_evals_host(lzp->r, hb), right = eq_evals_host(lzp->r + hb, lb);
-        std::vector<fe_t> sc(nfixed + 1);
-        fe_t hs = fe_zero(), acc = fe_zero();
-        for (size_t i = 0; i < nrows; ++i) {
-          const fe_t Li = fe_mul<S>(left[i / right.size()], right[i % right.size()]);
-          const fe_t Lb = fe_mul<S>(Li, blinds[i]);
-          acc = fe_add<S>(acc, Lb);
-          if (i < nfixed) sc[i] = Li;
-          else hs = fe_add<S>(hs, Lb);
+      if (tabs && lzp->nvr >= 1 && nrows == ((size_t)1 << lzp->nvr)) {
+        // comm_LZ = sum_{fixed rows} L_i comm_W[i] + (sum_{zero rows} L_i blind_i) h, L = eq(r_rows, .): one multi_mul over the prepared tables. Its ~100 us
+        // of dependent point additions are the critical path of the opening, so everything in front of the launch is kept off the last row challenge:
+        // eq(r, .) is expanded a level per challenge as the inner sum-check draws them (the observer counts them in rows_known), and what the last
+        // challenge r leaves to do is the last level (2^(nvr-1) products) and h's scalar, (1 - r) S0 + r S1 with S_c = sum over the zero rows of parity c
+        // of P[i >> 1] blind_i taken one level up; <L, r_W> for z_delta follows the launch. (All of it at once behind the last challenge was ~40 us.)
+        const size_t nvr = lzp->nvr;
+        std::vector<fe_t> P(1, fe_one<S>());
+        for (size_t known = 0; known + 1 < nvr; ++known) {
+          const auto w0 = std::chrono::steady_clock::now();
+          while ((size_t)lzp->rows_known.load(std::memory_order_acquire) <= known) {
+            if (lzp->state.load(std::memory_order_acquire) == 2 || std::chrono::steady_clock::now() - w0 > std::chrono::seconds(20)) return;
+            if (!helper_may_spin()) {
+              std::unique_lock<std::mutex> lk(lzp->mu);
+              lzp->cv.wait_for(lk, std::chrono::microseconds(50), [&] { return (size_t)lzp->rows_known.load(std::memory_order_acquire) > known; });
+            } else {
+              sp_relax();
+            }
+          }
+          const fe_t rk = lzp->r[known];
+          std::vector<fe_t> Q(2 * P.size());
+          for (size_t i = 0; i < P.size(); ++i) {  // the new variable is the index LSB (eq.rs:66-76)
+            const fe_t hi = fe_mul<S>(P[i], rk);
+            Q[2 * i + 1] = hi;
+            Q[2 * i] = fe_sub<S>(P[i], hi);
+          }
+          P.swap(Q);
         }
+        fe_t S0 = fe_zero(), S1 = fe_zero();
+        for (size_t i = nfixed; i < nrows; ++i) {
+          const fe_t t = fe_mul<S>(P[i >> 1], blinds[i]);
+          if (i & 1) S1 = fe_add<S>(S1, t);
+          else S0 = fe_add<S>(S0, t);
+        }
+        if (wait_for(lzp->state) != 1) return;
+        const fe_t rl = lzp->r[nvr - 1];
+        std::vector<fe_t> sc(nfixed + 1);
+        for (size_t h = 0; h < P.size(); ++h) {
+          const fe_t hi = fe_mul<S>(P[h], rl), lo = fe_sub<S>(P[h], hi);
+          if (2 * h < nfixed) sc[2 * h] = lo;
+          if (2 * h + 1 < nfixed) sc[2 * h + 1] = hi;
+        }
+        const fe_t hs = fe_add<S>(S0, fe_mul<S>(rl, fe_sub<S>(S1, S0)));
         sc[nfixed] = hs;
         ck(sp_fbtables_multi_mul_begin(ctx, tabs, u64p(sc.data()), sc.size()), "comm_LZ (begin)");
-        ck(sp_rowmat_vec_eq_begin(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, &lzp->vec), "bind_with_delayed (begin)");
+        ck(sp_rowmat_vec_eq_begin_with(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, dn == cols ? u64p(dv) : nullptr, &lzp->vec), "bind_with_delayed (begin)");
+        fe_t acc = hs;  // r_LZ = <L, r_W> (hyrax_pc.rs:446-455)
+        for (size_t i = 0; i < nfixed; ++i) acc = fe_add<S>(acc, fe_mul<S>(sc[i], blinds[i]));
         lzp->r_LZ = acc;
         ck(sp_fbtables_multi_mul_finish(ctx, u64p(&lzp->comm_LZ.x)), "comm_LZ (finish)");
         lzp->have_comm_LZ = true;
         return;
       }
+      if (wait_for(lzp->state) != 1) return;
+      const size_t hb = lzp->nvr / 2, lb = lzp->nvr - hb;
       ck(sp_msm_eq_begin(ctx, psp->comm_pts, u64p(lzp->r), lzp->nvr, &lzp->job), "comm_LZ (begin)");
-      ck(sp_rowmat_vec_eq_begin(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, &lzp->vec), "bind_with_delayed (begin)");
+      ck(sp_rowmat_vec_eq_begin_with(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, dn == cols ? u64p(dv) : nullptr, &lzp->vec), "bind_with_delayed (begin)");
       // r_LZ = <L, r_W> with L = eq(r) = left (x) right: 2^nvr + 2^(nvr/2) products instead of 2 * 2^nvr
       const std::vector<fe_t> left = eq_evals_host(lzp->r, hb), right = eq_evals_host(lzp->r + hb, lb);
       fe_t acc = fe_zero();
@@ -659,7 +710,11 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     bool beta_ready = false;
     sp_ctx* ctx = nullptr;
     const sp_ck* ck_s = nullptr;
+    const aff_t* beta_term = nullptr;           // h_s * r_beta from the first helper job ...
+    const std::atomic<int>* term_ready = nullptr;  // ... valid when this is set
   } ipa;
+  ipa.beta_term = &beta_term;
+  ipa.term_ready = &eval_W_term_ready;
   ipa.r_beta = r_beta_ahead;
   ipa.ctx = ctx;
   ipa.ck_s = pk.ck_s;
@@ -684,6 +739,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       if (!o->on || round == 0) return;
       if (round <= o->lz->nvr) {
         memcpy(&o->lz->r[round - 1], r, 32);
+        o->lz->rows_known.store((int)round, std::memory_order_release);
         if (round == o->lz->nvr) o->lz->publish(o->lz->state, 1);
         return;
       }
@@ -711,7 +767,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
           fe_t acc = fe_zero();
           for (size_t b = 0; b < right.size(); ++b) acc = fe_add<S>(acc, fe_mul<S>(right[b], ip->T[b]));
           ip->ip = acc;
-          ck(sp_hyrax_commit_small(ip->ctx, ip->ck_s, u64p(&ip->ip), 1, u64p(&ip->r_beta), u64p(&ip->beta.x)), "beta");
+          if (ip->term_ready->load(std::memory_order_acquire)) ck(sp_hyrax_commit_small_with_term(ip->ctx, ip->ck_s, u64p(&ip->ip), 1, u64p(&ip->beta_term->x), u64p(&ip->beta.x)), "beta");
+          else ck(sp_hyrax_commit_small(ip->ctx, ip->ck_s, u64p(&ip->ip), 1, u64p(&ip->r_beta), u64p(&ip->beta.x)), "beta");
           ip->beta_ready = true;
         });
         ip->submitted = true;
@@ -788,9 +845,14 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], r_W[i]));
   }
   aff_t comm_eval_W;
-  ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
+  if (eval_W_term_ready.load(std::memory_order_acquire) && memcmp(&eval_W_term_blind, &blind_eval_W, sizeof(fe_t)) == 0)
+    ck(sp_hyrax_commit_small_with_term(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&eval_W_term.x), u64p(&comm_eval_W.x)), "commit eval_W");
+  else
+    ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
+  lap("comm_eval_W");
   if (!lz_tables_path) ps.bg.wait();
   ck(sp_transcript_absorb_prepared(tr.t, ps.poly_com), "poly_com");
+  lap("poly_com");
   tr.dom_sep("inner product argument (linear)");
   const size_t n = (size_t)1 << (nvr == 0 ? npoint : npoint - nvr);  // |R|
   if (n != n_ipa) throw Error(SP_ERR_INTERNAL, "IPA width mismatch");
@@ -808,6 +870,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
       have_beta = true;
     }
   }
+  lap("ipa_join");
   if (have_beta) {
   } else if (R.empty() && ipa.submitted) {
     const size_t k = npoint - nvr;
@@ -859,13 +922,22 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   const fe_t rr = tr.squeeze("r");
   proof.pp(delta);
   proof.pp(beta);
-  if (lz_ahead) {
+  const bool zvec_on_device = lz_ahead && n == lz_cols && n == n_ipa;  // the helper's job gave d_vec to the product's job (begin_with)
+  if (zvec_on_device) {
+    // z_vec = r * LZ + d (ipa.rs:160-163), the last step of the prove: one launch behind the product the device already holds, delivered through mapped
+    // memory straight into the proof (2048 products were 33 us on this thread and the two helpers)
     sp_vec_job* vj = lz.vec;
     lz.vec = nullptr;
-    ck(sp_rowmat_vec_eq_finish(ctx, vj, u64p(LZ.data())), "bind_with_delayed (finish)");
-  }
-  {
-    // z_vec = r * LZ + d (ipa.rs:160-163): the last step of the prove, split three ways with the two helper threads when it is wide enough to pay
+    const size_t at = proof.words.size();
+    proof.words.resize(at + 4 * n);
+    ck(sp_rowmat_vec_eq_finish_scaled(ctx, vj, u64p(&rr), proof.words.data() + at), "z_vec");
+  } else {
+    if (lz_ahead) {
+      sp_vec_job* vj = lz.vec;
+      lz.vec = nullptr;
+      ck(sp_rowmat_vec_eq_finish(ctx, vj, u64p(LZ.data())), "bind_with_delayed (finish)");
+    }
+    // z_vec = r * LZ + d: split three ways with the two helper threads when it is wide enough to pay
     std::vector<fe_t> zv(n);
     auto part = [&zv, &LZ, dvec, rr](size_t lo, size_t hi) {
       for (size_t i = lo; i < hi; ++i) zv[i] = fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]);

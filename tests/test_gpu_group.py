@@ -187,6 +187,33 @@ def test_rowmat_vec(ctx):
         assert (got == want).all()
 
 
+def test_rowmat_vec_eq_job_and_its_scaled_finish(ctx):
+    """sp_rowmat_vec_eq_begin[_with] / _finish[_scaled]: LZ = eq(r, .)^T poly against the oracle's bind_with_delayed over the oracle's eq table, and
+    z_vec = scale * LZ + addend (ipa.rs:160-163) against Python integers; twice on one context (the arrival flags carry a sequence number), and a job
+    begun without an addend refuses the scaled finish."""
+    rng = np.random.default_rng(SEED + 310)
+    for ell, cols in ((9, 2048), (4, 256), (9, 2048), (11, 300)):
+        rows = 1 << ell
+        poly = ol.random_field_array(rng, rows * cols)
+        r = ol.random_field_array(rng, ell)
+        L = np.zeros((rows, 4), dtype=np.uint64)
+        assert olib().orc_eq_evals(p64(r), ctypes.c_size_t(ell), p64(L)) == 0
+        want = np.zeros((cols, 4), dtype=np.uint64)
+        olib().orc_rowmat_vec(p64(poly), p64(L), ctypes.c_size_t(rows), ctypes.c_size_t(cols), p64(want))
+        t = hip.Table.from_host(ctx, poly)
+        assert (hip.rowmat_vec_eq(ctx, t, r, cols) == want).all()
+        d = ol.random_field_array(rng, cols)
+        scale = ol.random_field_array(rng, 1)
+        got = hip.rowmat_vec_eq(ctx, t, r, cols, addend=d, scale=scale)
+        lz, dv, sc = ol.ints_of(want), ol.ints_of(d), ol.ints_of(scale)[0]
+        mod = ol.MODULI[0]
+        assert ol.ints_of(got) == [(sc * a + b) % mod for a, b in zip(lz, dv)]
+        # the plain finish of a job that carried an addend still returns LZ
+        assert (hip.rowmat_vec_eq(ctx, t, r, cols, addend=d) == want).all()
+    with pytest.raises(hip.SpartanHipError):
+        hip.rowmat_vec_eq(ctx, t, r, cols, scale=scale)
+
+
 @pytest.mark.parametrize("npt,key_tables", [(11, "1"), (13, "1"), (16, "1"), (16, "0"), (9, "1"), (20, "1")])
 def test_hyrax_prove_is_the_oracles_pcs_prove(ctx, key, gens, npt, key_tables, monkeypatch):
     """sp_hyrax_prove == HyraxPCS::prove + InnerProductArgumentLinear::prove (hyrax_pc.rs:387-478, ipa.rs:125-170) of the oracle on the same commitment,
@@ -360,6 +387,11 @@ def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):
     olib().orc_point_mul(p64(np.ascontiguousarray(gs[1])), p64(blind), p64(b))
     olib().orc_point_add(p64(a), p64(b), p64(want))
     assert (ks.commit_small(val, blind) == want).all()
+    # the blind's term handed in (sp_hyrax_commit_small_with_term: h * blind computed beforehand), the identity term, more scalars than the host walk takes
+    assert (ks.commit_small_with_term(val, ks.fixed_base_mul_h(blind.reshape(1, 4))[0]) == want).all()
+    assert (ks.commit_small_with_term(val, np.zeros(8, dtype=np.uint64)) == a).all()
+    with pytest.raises(hip.SpartanHipError):
+        ks.commit_small_with_term(ol.random_field_array(rng, 7), b)
 
 
 def test_row_range_commits_and_point_sum_compose(ctx, key, gens):
