@@ -295,6 +295,14 @@ int sp_hyrax_prove(sp_ctx* ctx, const sp_ck* ck, const sp_ck* ck_eval, sp_transc
  * consumed by the next sp_hyrax_prove; no proof value depends on it. A key without window tables (narrow keys, SPARTAN_KEY_TABLES=0) ignores it. */
 int sp_hyrax_prove_announce(sp_ctx* ctx, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds,
                             const uint8_t* rng, size_t rng_blocks);
+/* The same when the caller holds FixedBaseMul tables (sp_fbtables_create, msm.rs:653-689) of the first `nfixed` commitment rows followed by one of the key's h
+ * - a shim builds them in prep_prove, where the precommitted rows are committed (src/spartan.rs:173-217), and keeps them in its PrepSNARK - and every row
+ * from `nfixed` on is blind_i * h (commit_zeros, hyrax_pc.rs:230-300: no rest variables): comm_LZ = sum_{i < nfixed} L_i comm[i] + (sum_{i >= nfixed}
+ * L_i blind_i) h is then one walk over those tables that needs eq(r_rows, .) alone, so it starts right behind the last row challenge instead of behind
+ * L^T W. row_tables->n must be nfixed + 1; the tables must stay alive like the key. The result is the same group element (the rows ARE the
+ * commitments of W's rows); sp_hyrax_prove's checks are those of sp_hyrax_prove_announce. */
+int sp_hyrax_prove_announce_tables(sp_ctx* ctx, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds,
+                                   const uint8_t* rng, size_t rng_blocks, const sp_fbtables* row_tables, size_t nfixed);
 /* withdraws an announcement that will not be followed by its sp_hyrax_prove (an error exit of the caller's prove): waits for what it started, frees it.
  * The announced table and key must stay alive until the announcement is consumed, replaced or retracted. */
 int sp_hyrax_prove_retract(sp_ctx* ctx);

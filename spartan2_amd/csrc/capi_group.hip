@@ -1142,20 +1142,14 @@ __global__ void __launch_bounds__(256) k_scale_add_to_host(const fe_t* __restric
   if (threadIdx.x == 0) flags[blockIdx.x] = seq;
 }
 }  // namespace
-int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** out) {
-  return sp_rowmat_vec_eq_begin_with(c, poly, r, ell, cols, nullptr, out);
-}
-int sp_rowmat_vec_eq_begin_with(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, const uint64_t* addend, sp_vec_job** out) {
-  if (!poly || !out || (!r && ell)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: null argument");
-  if (ell > 20) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: more than 2^20 rows");
-  const size_t rows = (size_t)1 << ell;
-  if (rows * cols > poly->cap || cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed: poly shorter than rows*cols");
+// landing buffer of the product | staging of the addend | landing of the scaled sum | its per-block flags: one mapped pinned allocation, grow-only
+static int ensure_pinned_vec(sp_ctx* c, size_t cols) {
   if (!c->stream3) SP_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
   if (!c->vec_ev) SP_HIP(hipEventCreateWithFlags(&c->vec_ev, hipEventDisableTiming));
-  // landing buffer of the product | staging of the addend | landing of the scaled sum | its per-block flags: one mapped pinned allocation, grow-only
   if (c->h_pinned_vec_bytes < 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES) {
     if (c->h_pinned_vec) {
       SP_HIP(sp::stream_sync(c->stream3));
+      SP_HIP(sp::stream_sync(c->stream2));
       hipHostFree(c->h_pinned_vec);
     }
     c->h_pinned_vec = nullptr;
@@ -1165,6 +1159,48 @@ int sp_rowmat_vec_eq_begin_with(sp_ctx* c, const sp_table* poly, const uint64_t*
     c->h_pinned_vec_bytes = 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES;
     c->h_pinned_vec_cols = cols;
   }
+  return SP_OK;
+}
+// scale * x + addend -> mapped host memory, polled through the per-block arrival flags (the tail of sp_rowmat_vec_eq_finish_scaled and of an announced opening)
+static int scale_add_to_host(sp_ctx* c, hipStream_t st, const fe_t* dx, const fe_t* da, const fe_t& sc, size_t cols, uint64_t* out, const char* site) {
+  const size_t nblocks = (cols + 255) / 256;
+  if (nblocks * sizeof(unsigned) > VEC_FLAG_BYTES) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed (scaled): more than 2^18 columns");
+  if (++c->vec_seq == 0) ++c->vec_seq;
+  const unsigned seq = c->vec_seq;
+  fe_t* h_out = reinterpret_cast<fe_t*>(c->h_pinned_vec) + 2 * c->h_pinned_vec_cols;
+  volatile unsigned* h_flags = reinterpret_cast<volatile unsigned*>(reinterpret_cast<fe_t*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols);
+  void* d_base = nullptr;
+  SP_HIP(hipHostGetDevicePointer(&d_base, c->h_pinned_vec, 0));
+  fe_t* d_hout = reinterpret_cast<fe_t*>(d_base) + 2 * c->h_pinned_vec_cols;
+  unsigned* d_flags = reinterpret_cast<unsigned*>(reinterpret_cast<fe_t*>(d_base) + 3 * c->h_pinned_vec_cols);
+  hipLaunchKernelGGL(k_scale_add_to_host, dim3((unsigned)nblocks), dim3(256), 0, st, dx, da, sc, cols, d_hout, d_flags, seq);
+  bool synced = false;
+  for (size_t b = 0; b < nblocks; ++b) {
+    for (long spins = 0; h_flags[b] != seq; ++spins) {
+      if (spins > 4000000) {
+        sp::slow_note(site, spins);
+        if (synced) return fail(SP_ERR_INTERNAL, "bind_with_delayed: the scaled sum did not arrive");
+        SP_HIP(sp::stream_sync(st));  // e.g. under a profiler
+        synced = true;
+        spins = 0;
+      }
+      sp::relax();
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  memcpy(out, h_out, cols * sizeof(fe_t));
+  return SP_OK;
+}
+int sp_rowmat_vec_eq_begin(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, sp_vec_job** out) {
+  return sp_rowmat_vec_eq_begin_with(c, poly, r, ell, cols, nullptr, out);
+}
+int sp_rowmat_vec_eq_begin_with(sp_ctx* c, const sp_table* poly, const uint64_t* r, size_t ell, size_t cols, const uint64_t* addend, sp_vec_job** out) {
+  if (!poly || !out || (!r && ell)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: null argument");
+  if (ell > 20) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_begin: more than 2^20 rows");
+  const size_t rows = (size_t)1 << ell;
+  if (rows * cols > poly->cap || cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed: poly shorter than rows*cols");
+  int rc_pin;
+  if ((rc_pin = ensure_pinned_vec(c, cols))) return rc_pin;
   const size_t splits = rows < 64 ? rows : 64;
   fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, rows * sizeof(fe_t), 1);
   fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
@@ -1216,36 +1252,10 @@ int sp_rowmat_vec_eq_finish_scaled(sp_ctx* c, sp_vec_job* job, const uint64_t sc
   const fe_t *dx = job->d_out, *da = job->d_add;
   delete job;
   if (!da) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: the job was begun without an addend");
-  const size_t nblocks = (cols + 255) / 256;
-  if (nblocks * sizeof(unsigned) > VEC_FLAG_BYTES) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: more than 2^18 columns");
   fe_t sc;
   memcpy(&sc, scale, 32);
-  if (++c->vec_seq == 0) ++c->vec_seq;
-  const unsigned seq = c->vec_seq;
-  fe_t* h_out = reinterpret_cast<fe_t*>(c->h_pinned_vec) + 2 * c->h_pinned_vec_cols;
-  volatile unsigned* h_flags = reinterpret_cast<volatile unsigned*>(reinterpret_cast<fe_t*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols);
-  void* d_base = nullptr;
-  SP_HIP(hipHostGetDevicePointer(&d_base, c->h_pinned_vec, 0));
-  fe_t* d_hout = reinterpret_cast<fe_t*>(d_base) + 2 * c->h_pinned_vec_cols;
-  unsigned* d_flags = reinterpret_cast<unsigned*>(reinterpret_cast<fe_t*>(d_base) + 3 * c->h_pinned_vec_cols);
   // on the job's own stream: behind the product and the upload of the addend, which ended long ago
-  hipLaunchKernelGGL(k_scale_add_to_host, dim3((unsigned)nblocks), dim3(256), 0, c->stream3, dx, da, sc, cols, d_hout, d_flags, seq);
-  bool synced = false;
-  for (size_t b = 0; b < nblocks; ++b) {
-    for (long spins = 0; h_flags[b] != seq; ++spins) {
-      if (spins > 4000000) {
-        sp::slow_note("rowmat_vec_eq_finish_scaled", spins);
-        if (synced) return fail(SP_ERR_INTERNAL, "bind_with_delayed: the scaled sum did not arrive");
-        SP_HIP(sp::stream_sync(c->stream3));  // e.g. under a profiler
-        synced = true;
-        spins = 0;
-      }
-      sp::relax();
-    }
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  memcpy(out, h_out, cols * sizeof(fe_t));
-  return SP_OK;
+  return scale_add_to_host(c, c->stream3, dx, da, sc, cols, out, "rowmat_vec_eq_finish_scaled");
 }
 int sp_msm_job_finish(sp_ctx* c, sp_msm_job* job, uint64_t out_aff[8]) { return sp_msm_ck_finish(c, nullptr, job, nullptr, out_aff); }
 
@@ -1482,6 +1492,21 @@ struct sp_pcs_ahead {
   unsigned seq_delta = 0, seq_lz = 0;
   jac_t delta_j;
   fe_t r_LZ;
+  // r_LZ = <eq(r_rows, .), blinds> is the blinds' multilinear extension at r_rows: the vector is folded by its top variable with every row challenge
+  // (2^(nvr-k) products behind challenge k, under the device's next round), so that the last challenge leaves one product (hyrax_pc.rs:446-455)
+  std::vector<fe_t> bfold;
+  size_t rows_folded = 0;
+  // With FixedBaseMul tables of the first `nfixed` commitment rows and of h (sp_hyrax_prove_announce_tables; the other rows are blind_i h by the caller's
+  // word) comm_LZ = sum_{i < nfixed} L_i comm[i] + (sum_{i >= nfixed} L_i blind_i) h is ONE walk over those tables that needs L alone, not L^T W: it goes
+  // out right behind the last row challenge instead of behind the 17-50 us matrix-vector product. eq(r_rows, .) is expanded a level per challenge
+  // (P, new variable = index LSB, eq.rs:66-76); zfold = the zero rows' blinds folded like bfold gives h's scalar.
+  const aff_t* row_tables = nullptr;
+  size_t nfixed = 0;
+  std::vector<fe_t> P, zfold;
+  bool lz_submitted = false;  // the launches behind the last row challenge are a job of the helper thread (the sum-check's thread goes on with its rounds)
+  // z_vec = r LZ + d on the device (ipa.rs:160-163): the mask vector is uploaded behind delta's walk, the scaled sum lands in mapped memory
+  fe_t* d_out = nullptr;      // [LZ (num_cols) | - | d (cols)] in the auxiliary lane's WS_ROWMAT_OUT
+  bool dvec_uploaded = false;
 };
 namespace sp {
 static void pcs_ahead_drain(sp_ctx* c) {  // no device job of a dropped announcement may outlive it (its mapped result slot is reused)
@@ -1512,6 +1537,8 @@ void pcs_ahead_free(sp_ctx* c) {
     wipe_vec(S->dvec);
     wipe_vec(S->rng);
     wipe_vec(S->T);
+    wipe_vec(S->bfold);
+    wipe_vec(S->zfold);
     explicit_bzero(&S->r_delta, sizeof(fe_t));
     explicit_bzero(&S->r_LZ, sizeof(fe_t));
     delete S;
@@ -1545,54 +1572,107 @@ void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]) {
     }
     return;
   }
-  if (S->lz_launched) return;
+  if (S->lz_launched || S->lz_submitted) return;
+  if (round != S->rows_folded + 1) {  // (challenges arrive in order, once each; anything else and the plain call computes everything itself)
+    S->failed = true;
+    return;
+  }
   memcpy(&S->row_pt[round - 1], r, 32);
+  if (round == 1 && c->pcs_worker) c->pcs_worker->keep_hot(700);  // the jobs below and the opening's own are claimed without a wake-up
+  {
+    const fe_t rk = S->row_pt[round - 1];
+    const size_t h = S->bfold.size() / 2;
+    for (size_t j = 0; j < h; ++j) S->bfold[j] = fe_add<spk::SF>(S->bfold[j], fe_mul<spk::SF>(rk, fe_sub<spk::SF>(S->bfold[j + h], S->bfold[j])));
+    explicit_bzero(S->bfold.data() + h, h * sizeof(fe_t));
+    S->bfold.resize(h);
+    S->rows_folded = round;
+    if (S->row_tables) {
+      for (size_t j = 0; j < h; ++j) S->zfold[j] = fe_add<spk::SF>(S->zfold[j], fe_mul<spk::SF>(rk, fe_sub<spk::SF>(S->zfold[j + h], S->zfold[j])));
+      explicit_bzero(S->zfold.data() + h, h * sizeof(fe_t));
+      S->zfold.resize(h);
+      if (round < S->nvr) {  // (the last level is the helper job's: 2^(nvr-1) products)
+        std::vector<fe_t> Q(2 * S->P.size());
+        for (size_t i = 0; i < S->P.size(); ++i) {
+          const fe_t hi = fe_mul<spk::SF>(S->P[i], rk);
+          Q[2 * i + 1] = hi;
+          Q[2 * i] = fe_sub<spk::SF>(S->P[i], hi);
+        }
+        S->P.swap(Q);
+      }
+    }
+  }
   if (round != S->nvr) return;
+  S->r_LZ = S->bfold[0];
   if (S->worker_busy) {  // the announcement's helper job (it launched delta's walk on this lane)
     c->pcs_worker->wait();
     S->worker_busy = false;
   }
-  if (S->failed) return;
-  // delta's walk has had the whole outer sum-check: collect it (its lane's result slot is needed again), then L^T W and comm_LZ's walk on the same lane
-  if (S->delta_launched && !S->delta_collected) {
-    if (multi_mul_collect(c, 1, S->seq_delta, &S->delta_j, false)) {
+  if (S->failed || S->nvr > 10) {
+    S->failed = true;
+    return;
+  }
+  // Behind the last row challenge: delta's walk has had the whole outer sum-check and is collected (its lane's result slot is needed again), then L^T W and
+  // comm_LZ's walk go out on the same lane - half a dozen runtime calls, ~20 us, on the helper thread: this thread's next round is not held up by them.
+  S->lz_submitted = true;
+  S->worker_busy = true;
+  c->pcs_worker->submit([S, c] {
+    if (hipSetDevice(c->device) != hipSuccess) {
       S->failed = true;
       return;
     }
-    S->delta_collected = true;
-  }
-  const size_t num_rows = S->num_rows, cols = S->cols, num_cols = S->ck->num_cols, nvr = S->nvr;
-  std::vector<fe_t> L(num_rows);
-  eq_table_host(S->row_pt.data(), nvr, L.data());
-  S->r_LZ = fe_zero();
-  for (size_t i = 0; i < num_rows; ++i) S->r_LZ = fe_add<spk::SF>(S->r_LZ, fe_mul<spk::SF>(L[i], S->blind[i]));
-  const size_t splits = num_rows < 64 ? num_rows : 64;
-  fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, num_rows * sizeof(fe_t), 1);
-  fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
-  fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, (num_cols + 1) * sizeof(fe_t), 1);
-  if (!dL || !part || !dout || nvr > 10) {
-    S->failed = true;
-    return;
-  }
-  spk::EqTensorArgs a;
-  const size_t hb = nvr / 2, lb = nvr - hb;
-  eq_table_host(S->row_pt.data(), hb, a.left);
-  eq_table_host(S->row_pt.data() + hb, lb, a.right);
-  a.lo_bits = (int)lb;
-  a.n = (unsigned)num_rows;
-  hipStream_t st = c->stream2;
-  hipLaunchKernelGGL(spk::k_eq_tensor<false>, dim3((unsigned)((num_rows + 255) / 256)), dim3(256), 0, st, a, dL);
-  if (cols < num_cols && hipMemsetAsync(dout + cols, 0, (num_cols - cols) * sizeof(fe_t), st) != hipSuccess) {
-    S->failed = true;
-    return;
-  }
-  c->timed_on(st, "rowmat_vec", 32ull * (num_rows * cols + num_rows + cols), [&] { launch_rowmat_vec(st, S->poly->d, num_rows, cols, dL, part, splits, dout); });
-  if (multi_mul_launch(c, 1, S->ck->d_keytables, nullptr, num_cols + 1, &S->seq_lz, dout, &S->r_LZ, 0) ||
-      hipMemcpyAsync(c->h_pcs, dout, cols * sizeof(fe_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(c->pcs_ev, st) != hipSuccess) {
-    S->failed = true;  // (a launched walk is still drained by pcs_ahead_drain: lz_launched stays false only if the launch itself failed)
-    return;
-  }
-  S->lz_launched = true;
+    if (S->delta_launched && !S->delta_collected) {
+      if (multi_mul_collect(c, 1, S->seq_delta, &S->delta_j, false)) {
+        S->failed = true;
+        return;
+      }
+      S->delta_collected = true;
+    }
+    const size_t num_rows = S->num_rows, cols = S->cols, num_cols = S->ck->num_cols, nvr = S->nvr;
+    const size_t splits = num_rows < 64 ? num_rows : 64;
+    fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, num_rows * sizeof(fe_t), 1);
+    fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
+    fe_t* dout = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, (num_cols + 1 + cols) * sizeof(fe_t), 1);
+    if (!dL || !part || !dout || dout != S->d_out) {  // (sized by the announcement: a buffer that moved since would have lost the uploaded mask)
+      S->failed = true;
+      return;
+    }
+    hipStream_t st = c->stream2;
+    bool walk_out = false;
+    if (S->row_tables) {  // comm_LZ from the rows' own tables: the walk first, L^T W (needed for z_vec only) behind it
+      const fe_t rl = S->row_pt[nvr - 1];
+      std::vector<fe_t> sc(S->nfixed + 1);
+      for (size_t h2 = 0; h2 < S->P.size(); ++h2) {
+        const fe_t hi = fe_mul<spk::SF>(S->P[h2], rl), lo = fe_sub<spk::SF>(S->P[h2], hi);
+        if (2 * h2 < S->nfixed) sc[2 * h2] = lo;
+        if (2 * h2 + 1 < S->nfixed) sc[2 * h2 + 1] = hi;
+      }
+      sc[S->nfixed] = S->zfold[0];
+      if (multi_mul_launch(c, 1, S->row_tables, reinterpret_cast<const uint64_t*>(sc.data()), S->nfixed + 1, &S->seq_lz, nullptr, nullptr, 0)) {
+        S->failed = true;
+        return;
+      }
+      walk_out = true;
+    }
+    spk::EqTensorArgs a;
+    const size_t hb = nvr / 2, lb = nvr - hb;
+    eq_table_host(S->row_pt.data(), hb, a.left);
+    eq_table_host(S->row_pt.data() + hb, lb, a.right);
+    a.lo_bits = (int)lb;
+    a.n = (unsigned)num_rows;
+    hipLaunchKernelGGL(spk::k_eq_tensor<false>, dim3((unsigned)((num_rows + 255) / 256)), dim3(256), 0, st, a, dL);
+    if (cols < num_cols && hipMemsetAsync(dout + cols, 0, (num_cols - cols) * sizeof(fe_t), st) != hipSuccess) {
+      S->failed = true;
+      S->lz_launched = walk_out;  // (still drained)
+      return;
+    }
+    c->timed_on(st, "rowmat_vec", 32ull * (num_rows * cols + num_rows + cols), [&] { launch_rowmat_vec(st, S->poly->d, num_rows, cols, dL, part, splits, dout); });
+    if ((!walk_out && multi_mul_launch(c, 1, S->ck->d_keytables, nullptr, num_cols + 1, &S->seq_lz, dout, &S->r_LZ, 0)) || hipEventRecord(c->pcs_ev, st) != hipSuccess) {
+      S->failed = true;  // (a launched walk is still drained by pcs_ahead_drain: lz_launched stays false only if the launch itself failed)
+      S->lz_launched = walk_out;
+      return;
+    }
+    S->lz_launched = true;
+  });
 }
 }  // namespace sp
 
@@ -1601,8 +1681,20 @@ extern "C" int sp_hyrax_prove_retract(sp_ctx* c) {
   sp::pcs_ahead_free(c);
   return SP_OK;
 }
+static int announce_impl(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds, const uint8_t* rng,
+                         size_t rng_blocks, const sp_fbtables* row_tables, size_t nfixed);
 extern "C" int sp_hyrax_prove_announce(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds,
                                        const uint8_t* rng, size_t rng_blocks) {
+  return announce_impl(c, ck, comm_rows_aff, rows, poly, n, blinds, rng, rng_blocks, nullptr, 0);
+}
+extern "C" int sp_hyrax_prove_announce_tables(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds,
+                                              const uint8_t* rng, size_t rng_blocks, const sp_fbtables* row_tables, size_t nfixed) {
+  if (!row_tables || row_tables->n != nfixed + 1 || nfixed > rows)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_hyrax_prove_announce_tables: one table per fixed row and one of h");
+  return announce_impl(c, ck, comm_rows_aff, rows, poly, n, blinds, rng, rng_blocks, row_tables, nfixed);
+}
+static int announce_impl(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const sp_table* poly, size_t n, const uint64_t* blinds, const uint8_t* rng,
+                         size_t rng_blocks, const sp_fbtables* row_tables, size_t nfixed) {
   if (!c || !ck || !comm_rows_aff || !poly || !blinds || !rng) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_hyrax_prove_announce: null argument");
   sp::pcs_ahead_free(c);  // at most one announcement per context; an unconsumed one is dropped
   size_t npt = 0;
@@ -1637,6 +1729,25 @@ extern "C" int sp_hyrax_prove_announce(sp_ctx* c, const sp_ck* ck, const uint64_
   S->col_pt.resize(S->hb ? S->hb : 1);
   S->dvec.resize(cols);
   S->r_delta = fe_from_uniform<spk::SF>(S->rng.data() + 64 * cols);
+  S->bfold = S->blind;
+  if (row_tables && nfixed >= 1 && nfixed + 1 <= 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) {
+    S->row_tables = row_tables->d_tables;
+    S->nfixed = nfixed;
+    S->zfold = S->blind;
+    for (size_t i = 0; i < nfixed; ++i) S->zfold[i] = fe_zero();
+    S->P.assign(1, fe_one<spk::SF>());
+  }
+  {  // the buffers of the launches behind the last row challenge and of z_vec, sized here: the helper thread's workspace() calls are then plain look-ups
+    const size_t splits = num_rows < 64 ? num_rows : 64;
+    int rc_pin = ensure_pinned_vec(c, cols);
+    fe_t* dL = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_L, num_rows * sizeof(fe_t), 1);
+    fe_t* part = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_PART, splits * cols * sizeof(fe_t), 1);
+    S->d_out = (fe_t*)c->workspace(sp_ctx::WS_ROWMAT_OUT, (num_cols + 1 + cols) * sizeof(fe_t), 1);
+    if (rc_pin || !dL || !part || !S->d_out) {
+      delete S;
+      return SP_OK;  // the plain call will report what is wrong
+    }
+  }
   c->pcs_ahead = S;
   // helper thread: the commitment's transcript bytes into a fresh sponge, then the mask vector's wide reductions
   if (!c->pcs_worker) c->pcs_worker = new sp::Worker();
@@ -1661,6 +1772,10 @@ extern "C" int sp_hyrax_prove_announce(sp_ctx* c, const sp_ck* ck, const uint64_
     }
     S->hashed.update(reinterpret_cast<const uint8_t*>(e), strlen(e));
     for (size_t i = 0; i < S->cols; ++i) S->dvec[i] = fe_from_uniform<spk::SF>(S->rng.data() + 64 * i);
+    // the mask vector to the device, behind delta's walk on the auxiliary stream (needed when the IPA's challenge is drawn: z_vec = r LZ + d)
+    fe_t* stage = reinterpret_cast<fe_t*>(c->h_pinned_vec) + c->h_pinned_vec_cols;
+    memcpy(stage, S->dvec.data(), S->cols * sizeof(fe_t));
+    if (!S->failed && hipMemcpyAsync(S->d_out + num_cols + 1, stage, S->cols * sizeof(fe_t), hipMemcpyHostToDevice, c->stream2) == hipSuccess) S->dvec_uploaded = true;
   });
   return SP_OK;
 }
@@ -1697,7 +1812,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   if (rng_blocks < cols + 2) return fail(SP_ERR_INVALID_INPUT_LENGTH, "Hyrax prove: the randomness stream holds fewer than cols + 2 blocks");
   // E::Scalar::random draws (ipa.rs:139-149): d_vec, then the blinds of delta and beta, each the wide reduction of 64 uniform bytes. The two blinds
   // now, the mask vector further down while the device already works on LZ.
-  std::vector<fe_t> dvec(cols);
+  std::vector<fe_t> dvec_own;
   const fe_t r_delta = fe_from_uniform<SF>(rng + 64 * cols), r_beta = fe_from_uniform<SF>(rng + 64 * (cols + 1));
   fe_t b_eval;
   memcpy(&b_eval, blind_eval, 32);
@@ -1768,7 +1883,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   const int kt = (nvr == 0 && cols > num_cols) ? 1 : sp::ck_key_tables(c, ck);
   if (kt < 0) return kt;
   const bool walk = kt == 0;
-  std::vector<fe_t> LZ(cols);
+  std::vector<fe_t> LZ;
   fe_t r_LZ;
   aff_t comm_LZ, delta;
   unsigned seq_delta = 0, seq_lz = 0;
@@ -1793,11 +1908,11 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   if (ahead) seq_delta = S->seq_delta;
   else if (delta_raw && (rc = sp::multi_mul_launch(c, 1, ck->d_keytables, reinterpret_cast<const uint64_t*>(rng), num_cols + 1, &seq_delta, nullptr, &r_delta, cols))) return rc;
   lap("delta launch");
-  std::vector<fe_t> L((size_t)1 << nvr);
-  eq_table_host(pt, nvr, L.data());
+  std::vector<fe_t> L;
   bool lz_ahead = false;
   if (nvr == 0) {  // a single row: the commitment is the row itself (hyrax_pc.rs:417-423)
     comm_LZ = comm[0];
+    LZ.resize(cols);
     if ((rc = sp_table_read(c, poly, 0, n, reinterpret_cast<uint64_t*>(LZ.data())))) return rc;
     r_LZ = blind[0];
   } else if (ahead && S->lz_launched && memcmp(S->row_pt.data(), pt, nvr * sizeof(fe_t)) == 0) {
@@ -1805,6 +1920,9 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     r_LZ = S->r_LZ;
     seq_lz = S->seq_lz;
   } else {
+    L.resize((size_t)1 << nvr);
+    eq_table_host(pt, nvr, L.data());
+    LZ.resize(cols);
     if (ahead && S->lz_launched) {  // started for other row challenges than the point given now: drain it, its lane is needed
       jac_t sink;
       (void)sp::multi_mul_collect(c, 1, S->seq_lz, &sink, false);
@@ -1849,9 +1967,11 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   }
   lap("LZ + comm_LZ launch");
   // d_vec: 2048 wide reductions at config 2, ~65 us of host work beside the device's (delta's walk reduces its own copy of the blocks)
-  if (ahead) dvec = S->dvec;  // drawn by the announcement's helper job
-  else
-    for (size_t i = 0; i < cols; ++i) dvec[i] = fe_from_uniform<SF>(rng + 64 * i);
+  if (!ahead) {  // (an announcement's helper job has drawn it)
+    dvec_own.resize(cols);
+    for (size_t i = 0; i < cols; ++i) dvec_own[i] = fe_from_uniform<SF>(rng + 64 * i);
+  }
+  const std::vector<fe_t>& dvec = ahead ? S->dvec : dvec_own;
   lap("d_vec draw");
   if (!walk && (rc = sp_msm_ck_begin(c, ck, reinterpret_cast<const uint64_t*>(dvec.data()), cols, &delta_job))) return rc;
   if (walk && !delta_raw && !ahead) {  // narrow keys: the walk from the drawn scalars
@@ -1897,8 +2017,15 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
       if ((rc = sp::multi_mul_collect(c, lz_ahead ? 1 : 0, seq_lz, &lj, false))) return rc;
       if (lz_ahead) S->lz_launched = false;
       comm_LZ = jac_to_affine(lj);
-      SP_HIP(sp::event_sync(c->pcs_ev));
-      memcpy(LZ.data(), c->h_pcs, cols * sizeof(fe_t));
+      if (!(lz_ahead && S->dvec_uploaded)) {  // (an announced opening forms z_vec on the device: LZ never comes to the host)
+        if (lz_ahead) {
+          LZ.resize(cols);
+          SP_HIP(hipMemcpyAsync(c->h_pcs, S->d_out, cols * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream2));
+          SP_HIP(hipEventRecord(c->pcs_ev, c->stream2));
+        }
+        SP_HIP(sp::event_sync(c->pcs_ev));
+        memcpy(LZ.data(), c->h_pcs, cols * sizeof(fe_t));
+      }
     }
   } else {
     if (nvr != 0 && (rc = sp_msm_ck(c, ck, reinterpret_cast<const uint64_t*>(LZ.data()), cols, reinterpret_cast<const uint64_t*>(&r_LZ), reinterpret_cast<uint64_t*>(&comm_LZ))))
@@ -1931,7 +2058,13 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   memcpy(out, &delta, sizeof(aff_t));
   memcpy(out + 8, &beta, sizeof(aff_t));
   fe_t* zv = reinterpret_cast<fe_t*>(out + 16);
-  {
+  if (lz_ahead && S->dvec_uploaded) {
+    // on the device, behind comm_LZ's walk on the auxiliary stream (collected above): one launch, the sum lands in mapped memory (2048 products on this
+    // thread and its helper were ~32 us)
+    if ((rc = scale_add_to_host(c, c->stream2, S->d_out, S->d_out + num_cols + 1, rr, cols, out + 16, "hyrax_prove z_vec"))) return rc;
+    explicit_bzero(reinterpret_cast<fe_t*>(c->h_pinned_vec) + c->h_pinned_vec_cols, cols * sizeof(fe_t));  // the mask's staging copy
+    (void)hipMemsetAsync(S->d_out + num_cols + 1, 0, cols * sizeof(fe_t), c->stream2);                       // and its device copy
+  } else {
     // shared with the helper thread chunk by chunk: whoever is awake takes the next 128 elements. The owner never waits for the helper to WAKE (a sleeping
     // thread can take milliseconds when the process is at its CPU quota), only for chunks the helper has actually claimed.
     struct Share {
@@ -2008,17 +2141,29 @@ int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, s
     return SP_OK;
   }
   std::vector<jac_t> parts;
+  fe_t b;
+  memcpy(&b, blind, 32);
+  // h's walk beside the scalars' when the context's helper thread is polling for work (an announced opening keeps it so: the commitment of eval_W and
+  // beta, ~11 us a walk); a job the helper has not claimed within a microsecond is taken back and run here
+  jac_t hpart;
+  const bool beside = n >= 1 && c && c->pcs_worker && c->pcs_worker->hot();
+  if (beside) {
+    const aff_t* ht = ck->host_htable();
+    jac_t* hp = &hpart;
+    const fe_t* bp = &b;
+    c->pcs_worker->submit([ht, hp, bp] { *hp = fixed_base_mul_host(ht, *bp); });
+  }
   for (size_t i = 0; i < n; ++i) {
     fe_t sc;
     memcpy(&sc, scalars + 4 * i, 32);
     parts.push_back(fixed_base_mul_host(ck->host_table(i), sc));
   }
-  {
-    fe_t b;
-    memcpy(&b, blind, 32);
+  if (beside) {
+    c->pcs_worker->wait(1);
+    parts.push_back(hpart);
+  } else {
     parts.push_back(fixed_base_mul_host(ck->host_htable(), b));
   }
-  (void)c;
   jac_t acc = jac_identity();
   for (const jac_t& p : parts) acc = jac_add(acc, p);
   store_aff(out_aff, jac_to_affine(acc));

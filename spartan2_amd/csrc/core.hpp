@@ -57,20 +57,29 @@ class Worker {
   std::function<void()> job_;
   bool posted_ = false, stop_ = false;
   std::atomic<int> pending_{0};
+  std::atomic<bool> has_job_{false};      // mirror of posted_ for the spinning phase (no lock taken while polling)
+  std::atomic<long long> hot_until_{0};   // steady-clock nanoseconds: until then the thread polls for its next job instead of sleeping
   std::chrono::steady_clock::time_point posted_at_;
+  static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   void loop() {
     for (;;) {
       std::function<void()> f;
+      while (!has_job_.load(std::memory_order_acquire) && now_ns() < hot_until_.load(std::memory_order_relaxed)) sp::relax();
       {
         std::unique_lock<std::mutex> l(m_);
-        cv_.wait(l, [&] { return posted_ || stop_; });
+        cv_.wait(l, [&] { return posted_ || stop_ || now_ns() < hot_until_.load(std::memory_order_relaxed); });
         if (stop_) return;
+        if (!posted_) continue;  // woken to poll (keep_hot)
         f.swap(job_);
         posted_ = false;
+        has_job_.store(false, std::memory_order_relaxed);
       }
       f();
       pending_.store(0, std::memory_order_release);
     }
+  }
+  void start() {
+    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
   }
 
  public:
@@ -87,6 +96,15 @@ class Worker {
     cv_.notify_one();
     th_.join();
   }
+  // The caller expects to post short jobs within the next `us` microseconds: the thread is woken now and polls for them (a job is then claimed within a
+  // fraction of a microsecond instead of a wake-up's 5-50 us). Bounded: the thread goes back to sleep when the time is up.
+  void keep_hot(long us) {
+    const long long until = now_ns() + 1000ll * us;
+    if (until > hot_until_.load(std::memory_order_relaxed)) hot_until_.store(until, std::memory_order_relaxed);
+    start();
+    cv_.notify_one();
+  }
+  bool hot() const { return th_.joinable() && now_ns() < hot_until_.load(std::memory_order_relaxed); }
   void submit(std::function<void()> f) {  // the job must not throw
     wait();
     pending_.store(1, std::memory_order_relaxed);
@@ -94,20 +112,23 @@ class Worker {
       std::lock_guard<std::mutex> l(m_);
       job_ = std::move(f);
       posted_ = true;
+      has_job_.store(true, std::memory_order_release);
       posted_at_ = std::chrono::steady_clock::now();
     }
-    if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+    start();
     cv_.notify_one();
   }
-  void wait() {
+  // take_back_us: how long a job may stay unclaimed before the waiter runs it itself
+  void wait(long take_back_us = 30) {
     for (unsigned spins = 0; pending_.load(std::memory_order_acquire); ++spins) {
-      if ((spins & 63u) == 63u) {
+      if ((spins & 63u) == 63u || take_back_us < 5) {
         std::function<void()> f;
         {
           std::lock_guard<std::mutex> l(m_);
-          if (posted_ && std::chrono::steady_clock::now() - posted_at_ > std::chrono::microseconds(30)) {
+          if (posted_ && std::chrono::steady_clock::now() - posted_at_ > std::chrono::microseconds(take_back_us)) {
             f.swap(job_);
             posted_ = false;  // the helper, when it does wake, finds nothing posted and sleeps on
+            has_job_.store(false, std::memory_order_relaxed);
           }
         }
         if (f) {

@@ -445,6 +445,15 @@ class CommitmentKey:
         check(lib().sp_hyrax_prove_announce(self.ctx.h, self.h, p64(comm_rows), ctypes.c_size_t(rows), poly.h, ctypes.c_size_t(n),
                                             p64(np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)), p8(rng), ctypes.c_size_t(rng.shape[0])))
 
+    def prove_announce_tables(self, comm_rows, poly, n, blinds, rng, row_tables, nfixed):
+        """sp_hyrax_prove_announce_tables: the same with FixedBaseMul tables (FbTables) of the first nfixed rows and of h; rows from nfixed on are blind * h."""
+        comm_rows = np.ascontiguousarray(comm_rows, dtype=np.uint64).reshape(-1, 8)
+        rows = comm_rows.shape[0]
+        rng = np.ascontiguousarray(rng, dtype=np.uint8).reshape(-1, 64)
+        check(lib().sp_hyrax_prove_announce_tables(self.ctx.h, self.h, p64(comm_rows), ctypes.c_size_t(rows), poly.h, ctypes.c_size_t(n),
+                                                   p64(np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)), p8(rng), ctypes.c_size_t(rng.shape[0]),
+                                                   row_tables.h, ctypes.c_size_t(nfixed)))
+
     def prove_retract(self):
         check(lib().sp_hyrax_prove_retract(self.ctx.h))
 

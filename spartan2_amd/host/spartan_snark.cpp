@@ -70,7 +70,8 @@ struct ActiveProve {
 //     the reference does not make (it re-hashes the prefix in every prove, src/spartan.rs:226-236, r1cs.rs:422-427). Default OFF: the prefix is
 //     re-hashed inside every prove (on a helper thread, under commit_zeros), so the timed region does the reference's work.
 //   FLAG_LZ_DIRECT: the opening in the reference's own order (bind W with L, then the MSM over the key) instead of the MSM over the row commitments.
-//   FLAG_REFERENCE_ORDER: prove_reference_order below — ONE thread, no helper jobs, no prep-time tables, only include/spartan_hip.h entry points, called
+//   FLAG_REFERENCE_ORDER: prove_reference_order below — ONE thread, no helper jobs, only include/spartan_hip.h entry points (the one prep-time product it uses
+//     is the FixedBaseMul table set of the committed rows, handed to sp_hyrax_prove_announce_tables), called
 //     in the order of the statements of src/spartan.rs:226-466 (what an unchanged spartan.rs bound to the ABI does). bench.py reports it beside the headline.
 enum : unsigned { FLAG_PREFIX_CACHE = 1u, FLAG_LZ_DIRECT = 2u, FLAG_REFERENCE_ORDER = 4u };
 
@@ -971,7 +972,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
 }
 
 // SpartanSNARK::prove exactly as src/spartan.rs:219-466 states it — one statement of the reference per call of the ABI, in its order, on the calling
-// thread alone: no helper threads, nothing issued ahead of where the reference computes it, no tables prepared at prep time. Whatever overlap there is
+// thread alone: no helper threads, nothing issued ahead of where the reference computes it; of prep_prove's products only the FixedBaseMul tables of the rows it
+// committed are used (the shim keeps them in its PrepSNARK and names them when it announces the opening). Whatever overlap there is
 // happens BELOW the ABI (the round loops' launch-ahead and resident tails, sp_hyrax_prove's two walks beside its hashing). This is the time an unchanged
 // spartan.rs gets from a shim that binds include/spartan_hip.h; the proof is the same bytes as prove()'s.
 SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const uint64_t* publics_u64, size_t npub, Tape& tape, PhaseTimes* pt, ss_rest_hook synth,
@@ -1024,9 +1026,16 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
       if (!done) (void)sp_hyrax_prove_retract(ctx);
     }
   } announced{ctx};
-  if (tape.pos + 1 < tape.blocks)
-    ck(sp_hyrax_prove_announce(ctx, pk.ck, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), tape.bytes + 64 * (tape.pos + 1), tape.blocks - tape.pos - 1),
-       "PCS::prove (announce)");
+  if (tape.pos + 1 < tape.blocks) {
+    // (with the tables of the committed rows the shim's prep_prove built - ps.lz_tables: the precommitted rows and h - when the remaining rows are commit_zeros)
+    if (ps.lz_tables && rows_rest && d.num_rest_unpadded == 0)
+      ck(sp_hyrax_prove_announce_tables(ctx, pk.ck, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), tape.bytes + 64 * (tape.pos + 1), tape.blocks - tape.pos - 1,
+                                        ps.lz_tables, rows_pre),
+         "PCS::prove (announce)");
+    else
+      ck(sp_hyrax_prove_announce(ctx, pk.ck, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), tape.bytes + 64 * (tape.pos + 1), tape.blocks - tape.pos - 1),
+         "PCS::prove (announce)");
+  }
   const double t_wit = now_ms();
   // :246-253 z = [W | 1 | public | challenges]
   ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");

@@ -359,6 +359,67 @@ def test_hyrax_prove_announced_then_two_sumchecks_of_the_openings_length(ctx, ke
         assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
 
 
+@pytest.mark.parametrize("nfixed", [5, 8])
+def test_hyrax_prove_announced_with_row_tables(ctx, key, gens, nfixed):
+    """sp_hyrax_prove_announce_tables: with FixedBaseMul tables of the first nfixed commitment rows and of h, and the other rows commitments of zero rows
+    (blind * h), comm_LZ is one walk over those tables behind the last row challenge - the same opening, word for word, as the unannounced call's
+    <L^T W, ck> + r_LZ h. nfixed = rows: no zero row (h's scalar is zero)."""
+    npt = 14
+    rng = np.random.default_rng(SEED + 952 + nfixed)
+    n = 1 << npt
+    rows = n // 2048
+    cols = n // rows
+    poly = ol.random_field_array(rng, n)
+    poly[nfixed * cols :] = 0
+    blinds = ol.random_field_array(rng, rows)
+    g_s = np.zeros((2, 8), dtype=np.uint64)
+    olib().orc_from_label(b"ck_s", ctypes.c_size_t(2), p64(g_s))
+    key_s = hip.CommitmentKey(ctx, g_s[:1], g_s[1])
+    table = hip.Table.from_host(ctx, poly)
+    comm = key.commit(table, 0, n, blinds, is_small=False)
+    if nfixed < rows:  # the zero rows' commitments are blind * h
+        assert (comm[nfixed:] == key.fixed_base_mul_h(blinds[nfixed:])).all()
+    tabs = hip.FixedBaseTables(ctx, np.concatenate([comm[:nfixed], np.ascontiguousarray(gens[2048:2049])]))
+    ev, b_ev = ol.random_field_array(rng, 1), ol.random_field_array(rng, 1)
+    comm_eval = key_s.msm(ev, b_ev[0])
+    tape = ol.make_tape(SEED + 80, cols + 2)
+    claim = ol.random_field_array(rng, 1)[0]
+
+    def sumcheck(seed):
+        r2 = np.random.default_rng(seed)
+        A = hip.Table.from_host(ctx, ol.random_field_array(r2, 2 * n))
+        Bt = hip.Table.from_host(ctx, ol.random_field_array(r2, 2 * n))
+        tr = hip.Transcript(ctx, b"sc")
+        tr.absorb(b"s", bytes([seed & 255]))
+        _, r, _ = hip.sumcheck_quad(ctx, claim, npt + 1, A, Bt, tr)
+        A.free()
+        Bt.free()
+        return np.ascontiguousarray(r[1:])
+
+    def prove(point):
+        tr = hip.Transcript(ctx, b"pcs")
+        out = key.prove(key_s, tr, comm, table, n, blinds, point, comm_eval, b_ev, tape)
+        return out, tr.squeeze(b"n")
+
+    p1 = sumcheck(3)
+    want = prove(p1)
+    for _ in range(2):
+        key.prove_announce_tables(comm, table, n, blinds, tape, tabs, nfixed)
+        assert (sumcheck(3) == p1).all()
+        got = prove(p1)
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    # opened at another point than the sum-check drew: the announcement's walk is dropped, the opening is the plain one
+    p2 = sumcheck(4)
+    want2 = prove(p2)
+    key.prove_announce_tables(comm, table, n, blinds, tape, tabs, nfixed)
+    assert (sumcheck(3) == p1).all()
+    got2 = prove(p2)
+    assert (got2[0] == want2[0]).all() and (got2[1] == want2[1]).all()
+    with pytest.raises(hip.SpartanHipError):
+        key.prove_announce_tables(comm, table, n, blinds, tape, tabs, nfixed - 1)  # one table per fixed row and one of h
+    tabs.close()
+
+
 def test_msm_ck_with_blind_and_commit_small(ctx, key, gens):
     rng = np.random.default_rng(SEED + 400)
     sc = ol.random_field_array(rng, 2048)
