@@ -2140,12 +2140,18 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       // the per-pair products came with the matrix-vector product: weight them with the eq tables (2 x 32 B per pair instead of 5 x 32 B)
       spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
       const unsigned seq = next_seq(c);
-      const dim3 gs((unsigned)(half / 256)), bs(256);
+      // four chunks of 256 pairs per block where the table and, in factored mode, the x_out group (2^s pairs) hold them; else one
+      const bool four = half % 1024 == 0 && half >= ((size_t)1 << 16) && (e1.mode == 0 || e1.s >= 10);
+      const size_t nblk = four ? half / 1024 : half / 256;
+      const int gsh = four ? 10 : 8;  // log2 of the pairs of a block
+      const dim3 gs((unsigned)nblk), bs(256);
       c->timed("eval_cubic", 64ull * half, [&] {
-        if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_products_stream<0>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
-        else hipLaunchKernelGGL((spk::k_eval_products_stream<1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
+        if (e1.mode == 0 && four) hipLaunchKernelGGL((spk::k_eval_products_stream<0, 4>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
+        else if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_products_stream<0, 1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
+        else if (four) hipLaunchKernelGGL((spk::k_eval_products_stream<1, 4>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
+        else hipLaunchKernelGGL((spk::k_eval_products_stream<1, 1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
       });
-      sum_lazy_launch(c, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
+      sum_lazy_launch(c, lp, nblk, e1.mode == 1 ? e1.s - gsh : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
     } else if (half >= STREAM_MIN_Q && half % 256 == 0 && (e1.mode == 0 || (e1.mode == 1 && e1.s >= 8))) {
       spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
       const unsigned seq = next_seq(c);

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
 // Round 1 of the cubic sum-check from precomputed per-pair products (k_spmv3_pairs): t0 = sum E(id) P0[id], t_inf = sum E(id) P1[id].
 // Streaming form (lazy wave sums, second stage k_sum_partials_lazy applies eq_out per group): half must be a multiple of 256 and, in factored
 // mode, 2^s >= 256.
-template <int MODE>
+template <int MODE, int PPT>
 __global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __restrict__ P0, const fe_t* __restrict__ P1, const fe_t* __restrict__ eq_in, int s,
                                                               lazy9_t* __restrict__ partials);
 
@@ -569,14 +569,36 @@ __global__ void __launch_bounds__(256) k_eval_cubic_stream(const fe_t* __restric
   const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
 }
-template <int MODE>
+// PPT consecutive 256-pair chunks per block (the block stays inside one x_out group: 256 PPT <= 2^s in factored mode), all 2 PPT element loads and the
+// PPT weights of a lane issued before the first product, one lazy sum per lane and accumulator and ONE wave sum each. A wave whose P0 entries are all
+// zero - every wave when the instance is satisfied: Az o Bz - Cz vanishes on the hypercube - skips that accumulator's products and its wave sum (the
+// entries are still read: nothing is assumed about the table).
+template <int MODE, int PPT>
 __global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __restrict__ P0, const fe_t* __restrict__ P1, const fe_t* __restrict__ eq_in, int s,
                                                               lazy9_t* __restrict__ partials) {
-  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t id0 = (size_t)blockIdx.x * (256 * PPT) + threadIdx.x;
   const size_t mask = ((size_t)1 << s) - 1;
-  const fe_t p0 = P0[id], p1 = P1[id];
-  const fe_t w = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
-  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, p0))), lazy_wave_sum(lazy_from(fe_mul<S>(w, p1))), partials);
+  fe_t p0[PPT], p1[PPT], w[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const size_t id = id0 + 256 * (size_t)k;
+    p0[k] = P0[id];
+    p1[k] = P1[id];
+    w[k] = (MODE == 0) ? eq_in[id] : eq_in[id & mask];
+  }
+  bool nz = false;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) nz |= !fe_is_zero(p0[k]);
+  lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) l1 = lazy_add(l1, lazy_from(fe_mul<S>(w[k], p1[k])));
+  l1 = lazy_wave_sum(l1);
+  if (__any(nz)) {  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) l0 = lazy_add(l0, lazy_from(fe_mul<S>(w[k], p0[k])));
+    l0 = lazy_wave_sum(l0);
+  }
+  stream_block_partials(l0, l1, partials);
 }
 __global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, lazy9_t* __restrict__ partials,
                                                                MailRef mref) {
