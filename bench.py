@@ -392,8 +392,13 @@ def main():
         barrier()
         t0 = time.perf_counter()
         acc = {}
+        c3_step_ms, c3_slowest = [], None
         for _ in range(args.steps):
+            ts = time.perf_counter()
             words, _, ph = nn.prove(step_tape)
+            c3_step_ms.append((time.perf_counter() - ts) * 1e3)
+            if c3_step_ms[-1] >= max(c3_step_ms):
+                c3_slowest = dict(ph)
             for k_, v_ in ph.items():
                 acc[k_] = acc.get(k_, 0.0) + v_
         barrier()
@@ -444,7 +449,8 @@ def main():
                    "config": {"workload": "sha256_neutronnova 32 step circuits (BASELINE config 3), NeutronNovaZkSNARK::prove", "num_steps": nsteps,
                               "num_cons_unpadded_per_step": circs[0].num_cons, "num_cons_per_step": 1 << nn.info["nx"],
                               "parallelism": f"{world} independent batches, one per GPU"},
-                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "verify_ms": verify_ms, "sharded": None, "roofline": None, "cpu_baseline": None,
+                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "step_ms_distribution": dict(dist(c3_step_ms), slowest_step_phases_ms=c3_slowest),
+                   "verify_ms": verify_ms, "sharded": None, "roofline": None, "cpu_baseline": None,
                    "reference_order": {"ms_per_step": elapsed_ref / args.steps * 1e3, "constraints_per_s": ncons * world * args.steps / elapsed_ref,
                                        "proof_identical": ref_identical, "phases_ms": {k_: v_ / args.steps for k_, v_ in acc_ref.items()},
                                        "headline_over_reference_order": elapsed / elapsed_ref,

@@ -178,8 +178,32 @@ impl HipCommitmentKey {
   pub fn announce_opening<F>(&self, comm_rows: &[u64], poly: &HipTable<F>, n: usize, blinds: &[F], rng: &[u8]) -> Result<(), SpartanError> {
     check(unsafe { sp_hyrax_prove_announce(ctx(), self.k, comm_rows.as_ptr(), comm_rows.len() / 8, poly.t, n, limbs(blinds), rng.as_ptr(), rng.len() / 64) })
   }
+  /// The same when prep_prove built FixedBaseMul tables of the rows it committed (`RowTables::new` over the shared + precommitted rows of comm_W, then
+  /// the key's h; kept in the shim's PrepSNARK) and the remaining rows are commit_zeros rows (no rest variables: each is blind * h,
+  /// hyrax_pc.rs:230-300): comm_LZ = <L, comm_W> is then one walk over those tables behind the last row challenge, independent of L^T W.
+  pub fn announce_opening_with_tables<F>(&self, comm_rows: &[u64], poly: &HipTable<F>, n: usize, blinds: &[F], rng: &[u8], tables: &RowTables, nfixed: usize) -> Result<(), SpartanError> {
+    check(unsafe {
+      sp_hyrax_prove_announce_tables(ctx(), self.k, comm_rows.as_ptr(), comm_rows.len() / 8, poly.t, n, limbs(blinds), rng.as_ptr(), rng.len() / 64, tables.t, nfixed)
+    })
+  }
   pub fn retract_opening() -> Result<(), SpartanError> {
     check(unsafe { sp_hyrax_prove_retract(ctx()) })
+  }
+}
+/// FixedBaseMul::precompute over a list of points (msm.rs:653-689): the committed rows of comm_W followed by h, built once in prep_prove.
+pub struct RowTables {
+  pub(crate) t: *mut sp_fbtables,
+}
+impl RowTables {
+  pub fn new(points_aff: &[u64]) -> Result<Self, SpartanError> {
+    let mut t = std::ptr::null_mut();
+    check(unsafe { sp_fbtables_create(ctx(), points_aff.as_ptr(), points_aff.len() / 8, &mut t) })?;
+    Ok(Self { t })
+  }
+}
+impl Drop for RowTables {
+  fn drop(&mut self) {
+    unsafe { sp_fbtables_free(self.t) }
   }
 }
 impl Drop for HipCommitmentKey {

@@ -1870,6 +1870,11 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
       hp->update(reinterpret_cast<const uint8_t*>(e), strlen(e));
     });
   }
+  // beta = ck_c <R, d> + h r_beta (ipa.rs:149) is two table walks on the host, ~11 us each. With the helper thread polling (an announced opening keeps it
+  // so) and not busy with the commitment's hashing, h's walk runs beside this thread's compare / <R, d> and ck_c's beside its collection of the two device
+  // walks; otherwise both are this thread's (sp_hyrax_commit_small). The jobs write here: declared in front of `join`, which waits on every exit path.
+  jac_t beta_h = jac_identity(), beta_c = jac_identity();
+  const bool beta_beside = hashed_ahead && ck_eval->n_tables >= 2 && ck_eval->num_cols >= 1 && c->pcs_worker->hot();
   struct Join {  // the hashing job reads `comm` and writes `hashed`: it must have finished on every exit path (not so the z_vec helper job further down)
     sp::Worker* w;
     bool joined = false;
@@ -1878,6 +1883,12 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     }
   } join{c->pcs_worker};
 
+  if (beta_beside) {
+    const aff_t* ht = ck_eval->host_htable();
+    jac_t* dst = &beta_h;
+    const fe_t rb = r_beta;
+    c->pcs_worker->submit([ht, dst, rb] { *dst = fixed_base_mul_host(ht, rb); });
+  }
   lap("submit hashing");
   // (2) device: delta's walk on the auxiliary stream, LZ and comm_LZ's walk on the main stream
   const int kt = (nvr == 0 && cols > num_cols) ? 1 : sp::ck_key_tables(c, ck);
@@ -2000,7 +2011,15 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   }
   lap("<R, d>");
   aff_t beta;
-  if ((rc = sp_hyrax_commit_small(c, ck_eval, reinterpret_cast<const uint64_t*>(&ip), 1, reinterpret_cast<const uint64_t*>(&r_beta), reinterpret_cast<uint64_t*>(&beta)))) return rc;
+  if (beta_beside) {
+    c->pcs_worker->wait(1);  // h's walk (an unclaimed job is taken back and run here)
+    const aff_t* ct = ck_eval->host_table(0);
+    jac_t* dst = &beta_c;
+    const fe_t ipv = ip;
+    c->pcs_worker->submit([ct, dst, ipv] { *dst = fixed_base_mul_host(ct, ipv); });
+  } else if ((rc = sp_hyrax_commit_small(c, ck_eval, reinterpret_cast<const uint64_t*>(&ip), 1, reinterpret_cast<const uint64_t*>(&r_beta), reinterpret_cast<uint64_t*>(&beta)))) {
+    return rc;
+  }
   lap("beta");
   // (4) joins
   if (walk) {
@@ -2033,6 +2052,10 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     sp_msm_job* j = delta_job;
     delta_job = nullptr;
     if ((rc = sp_msm_ck_finish(c, ck, j, reinterpret_cast<const uint64_t*>(&r_delta), reinterpret_cast<uint64_t*>(&delta)))) return rc;
+  }
+  if (beta_beside) {
+    c->pcs_worker->wait(1);
+    beta = jac_to_affine(jac_add(beta_c, beta_h));
   }
   lap("join walks");
   if (!hashed_ahead) c->pcs_worker->wait();

@@ -984,6 +984,14 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
   if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
   ck(sp_ctx_bind_thread(ctx), "device");
   const double t_start = now_ms();
+  static const bool laps_on = getenv("SPARTAN_HOST_LAPS") != nullptr;
+  double t_lap = t_start;
+  auto lap = [&](const char* name) {
+    if (!laps_on) return;
+    const double t = now_ms();
+    fprintf(stderr, "ref lap %-28s %.3f ms\n", name, t - t_lap);
+    t_lap = t;
+  };
   std::vector<fe_t> publics(npub);
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
   // :226-236 transcript, vk, public values
@@ -1002,6 +1010,7 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
     if (synth(synth_user, u64p(challenges.data()), challenges.size(), u64p(rest.data())) != 0) throw Error(SP_ERR_INTERNAL, "SynthesisError: the circuit's synthesize callback failed");
     if (d.num_rest_unpadded) ck(sp_table_write(ctx, ps.W, d.num_shared + d.num_precommitted, u64p(rest.data()), d.num_rest_unpadded), "W rest");
   }
+  lap("transcript prefix");
   const size_t rows_pre = ps.comm_W_fixed.size(), rows_rest = (d.num_rest + W_ - 1) / W_;
   std::vector<fe_t> r_W_rest(rows_rest);
   for (auto& b : r_W_rest) b = tape.next();  // PCS::blind (r1cs.rs:466)
@@ -1010,10 +1019,12 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
   if (rows_rest && d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_W_rest.data()), rows_rest, u64p(&comm_W[rows_pre].x)), "commit_zeros");  // :467-469
   else if (rows_rest)
     ck(sp_hyrax_commit(ctx, pk.ck, ps.W, d.num_shared + d.num_precommitted, d.num_rest, u64p(r_W_rest.data()), ps.is_small ? 1 : 0, u64p(&comm_W[rows_pre].x)), "commit rest");
+  lap("commit rest rows");
   {
     std::vector<uint8_t> b = commitment_bytes(comm_W.data() + rows_pre, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
   }
+  lap("absorb comm_W_rest");
   std::vector<fe_t> r_W = ps.r_W_fixed;  // combine_blinds (r1cs.rs:515-524)
   r_W.insert(r_W.end(), r_W_rest.begin(), r_W_rest.end());
   // The shim's r1cs_instance_and_witness wrapper ends by announcing the opening PCS::prove will be asked for (sp_hyrax_prove_announce): commitment, blinds
@@ -1036,6 +1047,7 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
       ck(sp_hyrax_prove_announce(ctx, pk.ck, u64p(&comm_W[0].x), comm_W.size(), ps.W, M, u64p(r_W.data()), tape.bytes + 64 * (tape.pos + 1), tape.blocks - tape.pos - 1),
          "PCS::prove (announce)");
   }
+  lap("announce");
   const double t_wit = now_ms();
   // :246-253 z = [W | 1 | public | challenges]
   ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
@@ -1050,12 +1062,15 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
     else ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
   }
   ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
+  lap("z");
   // :262-264 tau
   const size_t num_rounds_x = log2_ceil(N), num_rounds_y = log2_ceil(M) + 1;
   std::vector<fe_t> tau(num_rounds_x);
   for (auto& t : tau) t = tr.squeeze("t");
+  lap("tau");
   // :267-283 multiply_vec_incremental_into
   ck(sp_multiply_vec_incremental(ctx, pk.S, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental");
+  lap("multiply_vec_incremental");
   const double t_mv = now_ms();
   SpartanProofBuf proof;
   for (const aff_t& a : comm_W) proof.pp(a);
@@ -1094,11 +1109,13 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
   const fe_t denom = fe_sub<S>(fe_one<S>(), r_y[0]);
   if (fe_is_zero(denom)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
   const fe_t eval_W = fe_mul<S>(fe_sub<S>(eval_Z, fe_mul<S>(r_y[0], eval_X)), fe_inv_vartime<S>(denom));
+  lap("eval_W");
   const double t_inner = now_ms();
   // :423-436 blind, commit to eval_W, PCS::prove
   const fe_t blind_eval_W = tape.next();
   aff_t comm_eval_W;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
+  lap("commit eval_W");
   proof.pf(eval_W);
   proof.pf(blind_eval_W);
   const size_t num_rows = (M + W_ - 1) / W_, cols = M / num_rows;
