@@ -566,8 +566,14 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
     }
     // Several slots: every pass first reads the tags of all outstanding slots (independent loads: their cache misses — the lines were just written
     // by the device — overlap instead of costing 0.2 us each in turn), then takes the ones that are complete.
+    // A slot is two 64-byte lines the device has just written (elements 0, 1 | element 2, tag): both are touched for every outstanding slot before any is
+    // read, so the misses of a pass overlap (with the data line fetched only behind its tag a slot cost ~90 ns, 64 of them 6 us behind the last arrival -
+    // the resident tail's local regime delivers all its slots at the same moment). The sums are accumulated limb-wise (64 slots: < 2^38 per limb) and
+    // reduced once.
     bool done[spk::HOST_SUM_MAX_BLOCKS] = {};
     uint64_t tags[spk::HOST_SUM_MAX_BLOCKS], tags2[spk::HOST_SUM_MAX_BLOCKS];
+    uint64_t lazy[2][3][8] = {};  // [group][sum][limb] (groups <= 2)
+    const bool lazy_ok = groups <= 2;
     unsigned remaining = nb;
     long passes = 0;
     std::chrono::steady_clock::time_point t0;
@@ -575,6 +581,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
       for (unsigned b = 0; b < nb; ++b)
         if (!done[b]) {
           const volatile uint64_t* tg = reinterpret_cast<volatile const uint64_t*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b + 3);
+          __builtin_prefetch(reinterpret_cast<const void*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b), 0, 3);
           tags[b] = tg[0];
           tags2[b] = tg[1];
         }
@@ -585,16 +592,31 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
         fe_t v[3];
         spk::slot_chk chk = {want, want * spk::SLOT_CHK_K};
         for (int k = 0; k < nacc; ++k) {
-          for (int i = 0; i < 8; ++i) v[k].v[i] = reinterpret_cast<volatile const uint32_t*>(slot + k)[i];
+          for (int i = 0; i < 4; ++i) {
+            const uint64_t w = reinterpret_cast<volatile const uint64_t*>(slot + k)[i];
+            v[k].v[2 * i] = (uint32_t)w;
+            v[k].v[2 * i + 1] = (uint32_t)(w >> 32);
+          }
           spk::slot_chk_add(chk, v[k], k);
         }
         if ((uint32_t)(tags[b] >> 32) != chk.a || (uint32_t)tags2[b] != chk.b) continue;  // data still landing: next pass
-        fe_t* dst = out_host + (size_t)(b / per_group) * nacc;
-        for (int k = 0; k < nacc; ++k) dst[k] = fe_add<S>(dst[k], v[k]);
+        if (lazy_ok) {
+          uint64_t(*dst)[8] = lazy[b / per_group];
+          for (int k = 0; k < nacc; ++k)
+            for (int i = 0; i < 8; ++i) dst[k][i] += v[k].v[i];
+        } else {
+          fe_t* dst = out_host + (size_t)(b / per_group) * nacc;
+          for (int k = 0; k < nacc; ++k) dst[k] = fe_add<S>(dst[k], v[k]);
+        }
         done[b] = true;
         --remaining;
       }
-      if (!remaining) break;
+      if (!remaining) {
+        if (lazy_ok)
+          for (unsigned g = 0; g < groups; ++g)
+            for (int k = 0; k < nacc; ++k) out_host[(size_t)g * nacc + k] = fe_from_limb_sums<S>(lazy[g][k]);
+        break;
+      }
       if (++passes == 200000) {  // a few ms without completion
         sp::slow_note("reduce_partials_wait (slots)", passes);
         if (!resident) {
@@ -1248,6 +1270,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
   if (rc) return rc;
   bool have_sums = false;  // true when a launch already in flight produces this round's sums
   bool in_tail = false;    // the persistent tail kernel owns the remaining rounds
+  unsigned tail_nb0 = 1;  // blocks of the resident launch
   bool host_mode = false;  // ... and has handed the tables over: the remaining rounds run on the host (kernels_poly.hpp tail_hand_over)
   std::vector<fe_t> hA;    // host tables after a hand-over: A, then B
   fe_t* hB = nullptr;
@@ -1269,7 +1292,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       if (round + 1 < rounds) {
         next_seq(c);
         have_sums = true;
-        c->pending_slots = tail_blocks(A->len);
+        c->pending_slots = tail_blocks(A->len) > 1 ? tail_nb0 : 1u;  // every block of the launch publishes while more than one would (the kernel's local regime)
       }
       return 1;
     }
@@ -1296,7 +1319,8 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       ta.r0_from_mail = ahead ? 1 : 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
-      hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(tail_blocks(A->len / 2)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      tail_nb0 = tail_blocks(A->len / 2);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(tail_nb0), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
       in_tail = true;
       have_sums = true;
       sp::after_bind(A);
@@ -2023,6 +2047,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
 
   fe_t claim = load_fe(claim_);
   bool in_tail = false;  // the persistent tail kernel owns the remaining rounds
+  unsigned tail_nb0 = 1;  // blocks of the resident launch
   bool host_mode = false;  // ... and has handed the tables over: the remaining rounds run on the host (kernels_poly.hpp tail_hand_over)
   std::vector<fe_t> hT, hE;  // host tables after a hand-over (A | B | C, n0 entries each) and the round's eq weights
   size_t n0 = 0;
@@ -2055,7 +2080,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       sp::after_bind(C);
       if (rnd < ell) {
         next_seq(c);
-        c->pending_slots = tail_blocks(A->len, true);
+        c->pending_slots = tail_blocks(A->len, true) > 1 ? tail_nb0 : 1u;  // every block of the launch publishes while more than one would (the kernel's local regime)
       }
       return 1;
     }
@@ -2084,7 +2109,8 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       ta.r0_from_mail = ahead ? 1 : 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
-      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_blocks(A->len / 2, true)), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      tail_nb0 = tail_blocks(A->len / 2, true);
+      hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_nb0), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
       in_tail = true;
       sp::after_bind(A);
       sp::after_bind(B);

@@ -1572,7 +1572,7 @@ void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]) {
     }
     return;
   }
-  if (S->lz_launched || S->lz_submitted) return;
+  if (S->lz_submitted || S->lz_launched) return;  // (lz_submitted first: while it is false no helper job is writing lz_launched)
   if (round != S->rows_folded + 1) {  // (challenges arrive in order, once each; anything else and the plain call computes everything itself)
     S->failed = true;
     return;

@@ -89,6 +89,7 @@ class Worker {
   ~Worker() {
     if (!th_.joinable()) return;
     wait();
+    hot_until_.store(0, std::memory_order_relaxed);  // a polling thread falls through to the wait below and sees stop_
     {
       std::lock_guard<std::mutex> l(m_);
       stop_ = true;

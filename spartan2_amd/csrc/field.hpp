@@ -154,6 +154,33 @@ SP_HD fe_t fe_sub(const fe_t& a, const fe_t& b) {
   for (int i = 0; i < 8; ++i) r.v[i] = sp_addc(d[i], FP::P(i) & mask, c);
   return r;
 }
+// The canonical value of sum_i limb[i] 2^(32 i) mod p for limb-wise sums of up to 2^31 canonical elements (each limb < 2^63): carries propagated into
+// a ninth and tenth word, the part above 2^256 folded back with 2^256 mod p (twice), then conditional subtractions.
+template <class FP>
+SP_HD fe_t fe_from_limb_sums(const uint64_t limb[8]) {
+  uint32_t t[8];
+  uint64_t carry = 0;
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t x = (limb[i] & 0xffffffffull) + carry;
+    t[i] = (uint32_t)x;
+    carry = (x >> 32) + (limb[i] >> 32);
+  }
+  uint64_t hi = carry;  // < 2^32 for the sums this is used on (<= 2^31 elements below 2^256)
+  for (int pass = 0; pass < 2; ++pass) {
+    uint64_t c2 = 0;
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t x = hi * FP::R1(i) + t[i] + c2;
+      t[i] = (uint32_t)x;
+      c2 = x >> 32;
+    }
+    hi = c2;
+  }
+  uint32_t top = (uint32_t)hi;  // <= 1 after two folds
+  for (int k = 0; k < 3; ++k) fe_cond_sub_p_top<FP>(t, top);
+  fe_t r;
+  for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+  return r;
+}
 template <class FP>
 SP_HD fe_t fe_neg(const fe_t& a) {
   return fe_sub<FP>(fe_zero(), a);

@@ -1067,6 +1067,15 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   // elements x = base + e first, then their partners x = q + base + e. They go to memory as well - the next step's bind reads them from there.
   __shared__ fe_t bound[(CUBIC ? 3 : 2) * 2 * (unsigned)WQ];
   const unsigned long long base = (unsigned long long)blockIdx.x * WQ;
+  // LOCAL REGIME (while more than one block is active, q > WQ): every block of the launch stays active and owns the pairs whose index y has
+  // (y / 4) mod gridDim.x == blockIdx.x - local pair e <-> y = ((e / 4) gridDim.x + blockIdx.x) 4 + e % 4 (128-byte groups). The round's pairings are at
+  // offsets q and 2q, multiples of 4 gridDim.x as long as a block holds m = q / gridDim.x >= 4 pairs (it does down to q = 2 WQ: m = 2 WQ^2 / q0 >= 4), so a
+  // block's elements form a sub-table of their own that is bound and evaluated like the whole - from LDS: after the first step no block reads an element
+  // that another one wrote, there is no table traffic, no release and no wait for stores between rounds. The last local step (q = 2 WQ) writes the bound
+  // tables back in their natural layout behind a release; block 0 then owns everything, as before. (Contiguous ranges whose owners halved every round made
+  // half of every bind's inputs another XCD's: 2.2 us of agent-scope loads at the head of each step, 1.2 us of store acknowledgement + release at its end.)
+  const unsigned nb0 = gridDim.x;
+  auto local_y = [&](unsigned e) -> unsigned long long { return ((unsigned long long)((e >> 2) * nb0 + blockIdx.x) << 2) | (e & 3u); };
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
   int rnd = a.rnd0;
@@ -1124,18 +1133,19 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       have_r = true;  // the ordinary step below binds with the second challenge
     }
     const unsigned long long q = len / 4;
-    if (len > 2 ? base >= q : blockIdx.x != 0) return;
+    const bool local = nb0 > 1 && q > WQ;  // (q > WQ holds exactly while the launch is in its multi-block rounds: gridDim.x = q0 / WQ)
+    if (!local && (len > 2 ? base >= q : blockIdx.x != 0)) return;
     // the weight of this lane's product does not depend on the challenge: fetched (and, in the first-half rounds, multiplied together) before the wait
     fe_t w_pre = fe_zero();
     if (CUBIC && len > 2) {
-      const unsigned qb_p = (unsigned)(q - base < WQ ? q - base : WQ);
+      const unsigned qb_p = local ? (unsigned)(q / nb0) : (unsigned)(q - base < WQ ? q - base : WQ);
       if (tail_double(CUBIC, len / 2)) {
         const unsigned qd_p = (unsigned)(len / 8), seg_p = qd_p < 64 ? 64u : qd_p, g_p = threadIdx.x / seg_p, i_p = threadIdx.x % seg_p;
         if (g_p < 9 && i_p < qd_p) w_pre = weight(rnd + 1, i_p);
         else if (g_p < 15 && i_p < qd_p) w_pre = weight(rnd, i_p + ((g_p - 9) & 1u) * qd_p);
       } else {
         const unsigned seg_p = qb_p < 64 ? 64u : qb_p, wh_p = threadIdx.x / seg_p, i_p = threadIdx.x % seg_p;
-        if (wh_p < (unsigned)NACC && i_p < qb_p) w_pre = weight(rnd, base + i_p);
+        if (wh_p < (unsigned)NACC && i_p < qb_p) w_pre = weight(rnd, local ? local_y(i_p) : base + i_p);
       }
     }
     SP_TT(0);
@@ -1147,7 +1157,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     // the previous round had 2q pairs: while that is more than one block's worth, the elements bound below were written by other blocks
     // (other XCDs, other L2s). They are read with agent-scope loads, which go past this XCD's L2, instead of an acquire fence, which would
     // invalidate it (measured: 4 us per round).
-    const bool foreign = 2 * q > WQ;
+    const bool foreign = !local && 2 * q > WQ;
+    const bool from_lds = local && !first;  // a local step after the first: its inputs are the elements this block bound in the step before, in `bound`
     first = false;
     if (len == 2) {  // last round: bind only; the final claims also go to the host in a slot of their own (saves three synchronous reads)
       if (threadIdx.x == 0) {
@@ -1170,16 +1181,32 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       }
       return;
     }
-    const unsigned qb = (unsigned)(q - base < WQ ? q - base : WQ);  // pairs of this block (a power of two)
-    // phase A: one bind per lane. New element x takes old x and x + 2q; this block owns x in [base, base + qb) and [q + base, q + base + qb).
+    const unsigned qb = local ? (unsigned)(q / nb0) : (unsigned)(q - base < WQ ? q - base : WQ);  // pairs of this block (a power of two)
+    const bool last_local = local && q == 2 * WQ;  // the next step is block 0's alone: the bound tables go back to memory
+    // phase A: one bind per lane. New element x takes old x and x + 2q; this block owns x in [base, base + qb) and [q + base, q + base + qb) - in the
+    // local regime the x of its sub-table (local_y), whose element e of the step before sits at bound[t * 4 qb + e].
     const unsigned nt = CUBIC ? 3 : 2;
-    for (unsigned idx = threadIdx.x; idx < nt * 2 * qb; idx += TAIL_THREADS) {
-      const unsigned t = idx / (2 * qb), e = idx % (2 * qb);
+    if (local) {  // (nt * 2 qb <= TAIL_THREADS: one element per lane, so the in-place LDS update needs one barrier between its reads and its writes)
+      const unsigned idx = threadIdx.x, t = idx / (2 * qb), e = idx % (2 * qb);
+      const bool has = idx < nt * 2 * qb;
+      fe_t v = fe_zero();
       fe_t* Z = t == 0 ? a.A : (t == 1 ? a.B : a.C);
-      const unsigned long long x = e < qb ? base + e : q + base + (e - qb);
-      const fe_t v = foreign ? bind1(load_agent(Z + x), load_agent(Z + x + 2 * q), r) : bind1(Z[x], Z[x + 2 * q], r);
-      Z[x] = v;
-      bound[idx] = v;  // = bound[t * 2 qb + e]
+      const unsigned long long x = e < qb ? local_y(e) : q + local_y(e - qb);
+      if (has) v = from_lds ? bind1(bound[t * 4 * qb + e], bound[t * 4 * qb + 2 * qb + e], r) : bind1(Z[x], Z[x + 2 * q], r);
+      if (from_lds) __syncthreads();
+      if (has) {
+        bound[idx] = v;
+        if (last_local) Z[x] = v;
+      }
+    } else {
+      for (unsigned idx = threadIdx.x; idx < nt * 2 * qb; idx += TAIL_THREADS) {
+        const unsigned t = idx / (2 * qb), e = idx % (2 * qb);
+        fe_t* Z = t == 0 ? a.A : (t == 1 ? a.B : a.C);
+        const unsigned long long x = e < qb ? base + e : q + base + (e - qb);
+        const fe_t v = foreign ? bind1(load_agent(Z + x), load_agent(Z + x + 2 * q), r) : bind1(Z[x], Z[x + 2 * q], r);
+        Z[x] = v;
+        bound[idx] = v;  // = bound[t * 2 qb + e]
+      }
     }
     __syncthreads();
     SP_TT(2);
@@ -1344,10 +1371,11 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     // table stores of phase A have been acknowledged by the L2 (outside tgsplit mode the workgroup barrier alone does not wait for other
     // waves' stores), then — behind the barrier — thread 0 issues ONE agent-scope release (L2 write-back) for the whole block before the host
     // can see this block's slot. The single-block rounds need no fence at all.
-    if (q > WQ) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool release = local ? last_local : q > WQ;  // (a contiguous multi-block step only exists when the launch has one block per WQ pairs: never with `local`)
+    if (release) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (q > WQ) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      if (release) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
       slot_chk chk = {0u, 0u};
       for (int k = 0; k < NACC; ++k) {
         chk.a += chk_sh[k].a;
