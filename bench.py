@@ -785,7 +785,7 @@ def main():
         if os.path.exists(sites_path) and args.message_bytes == 2048:
             with open(sites_path) as f:
                 sj = json.load(f)
-            pick = {"poly_abc": "k_polyabc_short_and_long", "rowmat_vec": "k_rowmat_vec_tall", "eval_quad": "k_eval_quad_stream_lowhi<4>", "eval_cubic": "k_eval_products_stream<1>",
+            pick = {"poly_abc": "k_polyabc_short_and_long", "rowmat_vec": "k_rowmat_vec_tall", "eval_quad": "k_eval_quad_stream_lowhi<4>", "eval_cubic": "k_eval_products_stream<1",
                     "bind_stream_quad": "k_bind_eval_quad_stream@", "bind_stream_quad_sparse": "k_bind_eval_quad_stream_sparse", "spmv_incremental": "k_spmv3"}
             rocprof_sites = {}
             for cls, sub in pick.items():

@@ -69,7 +69,7 @@ def sites(M_):
         ("k_bind_eval_cubic_stream<1, false, false>", None, "the same launched behind its challenge (reference order without a device mailbox; the streaming probe)", lambda g: 48 * (4 * g) * 3,
          "3 tables of len = 4 grid: read 32 len, write 16 len each"),
         ("k_eval_cubic_stream<1>", None, "outer round 0 evaluation (no round-0 products: reference order)", lambda g: 160 * g, "grid = pairs; A, B, C pairs + eq: 160 B per pair"),
-        ("k_eval_products_stream<1>", None, "outer round 0 from the round-0 products (headline driver)", lambda g: 64 * g, "grid = pairs; p0, p1: 64 B per pair"),
+        ("k_eval_products_stream<1, 4>", None, "outer round 0 from the round-0 products (headline driver; four 256-pair chunks per block)", lambda g: 64 * (4 * g), "grid = pairs / 4; p0, p1: 64 B per pair"),
         ("k_bind_eval_quad_stream_sparse", None, "inner: first bind (effective ranges) + evaluate", lambda g: 64 * (4 * g), "len = 4 grid; live low halves only: 64 B per entry of len / 2, x 2 tables"),
         ("k_bind_eval_quad_stream", None, "inner: bind round r + evaluate round r+1", lambda g: 48 * (4 * g) * 2, "2 tables of len = 4 grid: read 32 len, write 16 len each"),
         ("k_eval_quad_stream_lowhi<4>", None, "inner round 0 evaluation (effective ranges)", lambda g: 64 * (4 * g), "grid = pairs / 4; 64 B per live pair (+ 32 B per live high entry, < 1 KB here)"),
