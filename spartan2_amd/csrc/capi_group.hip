@@ -490,6 +490,7 @@ static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, con
     hipLaunchKernelGGL(spk::k_fixed_base_rows, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, ds, n, tables, ntables, dout);
   }
 }
+static const size_t VEC_CTRL_BYTES = 64;    // control line of an armed scaled sum (k_scale_add_wait), behind the flags
 static const size_t VEC_FLAG_BYTES = 4096;  // per-block arrival flags of sp_rowmat_vec_eq_finish_scaled (1024 blocks of 256 columns)
 static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU core beats the launch + single-wave latency
 
@@ -1128,6 +1129,7 @@ struct sp_vec_job {
   size_t cols = 0;
   const fe_t* d_out = nullptr;  // the product on the device
   const fe_t* d_add = nullptr;  // the addend of the _scaled finish on the device (null: none given)
+  unsigned armed = 0;           // != 0: a k_scale_add_wait with this sequence number is queued behind the product and waits for the scale
 };
 namespace {
 // out[i] = scale * x[i] + add[i] straight into mapped pinned host memory, one flag per block behind a system-scope fence: the host polls the flags, no
@@ -1141,12 +1143,64 @@ __global__ void __launch_bounds__(256) k_scale_add_to_host(const fe_t* __restric
   __syncthreads();
   if (threadIdx.x == 0) flags[blockIdx.x] = seq;
 }
+// The same launched AHEAD of its scale: queued behind the product (and the upload of the addend), every block's first wave waits for the scale in the
+// mapped control line - words 0..7 the scale, 8 = sequence number, 9 = sequence + sum of the words (a poll that straddles the host's stores fails the
+// check and is repeated), 10 = abort (a sequence number: the job was finished without a scale) - and the sum goes out as above. The launch call, the
+// dispatch and the kernel's start-up (~10 us of the 20 that z_vec took behind the IPA's challenge, the last step of a prove) happen while the opening's
+// walks still run. Gives up after SCALE_WAIT_TICKS (flag = ~seq: the host then launches the ordinary kernel).
+// 20 ms at the 100 MHz wall clock. Short on purpose: the scale normally follows within a few hundred microseconds, a waiter that gives up only costs the
+// ordinary launch behind the scale (scale_add_fire falls back to it), and while it waits every device-wide synchronisation of the process - a hipFree
+// between the sum-check and the opening, say - waits with it.
+constexpr unsigned long long SCALE_WAIT_TICKS = 2000000ull;
+__global__ void __launch_bounds__(256) k_scale_add_wait(const fe_t* __restrict__ x, const fe_t* __restrict__ add, const unsigned* __restrict__ ctrl, size_t n,
+                                                        fe_t* __restrict__ out, volatile unsigned* __restrict__ flags, unsigned seq) {
+  __shared__ fe_t sc_sh;
+  __shared__ int ok_sh;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  fe_t xv = fe_zero(), av = fe_zero();
+  if (i < n) {  // operands first: they are in registers when the scale arrives
+    xv = x[i];
+    av = add[i];
+  }
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    int ok = 0;
+    for (;;) {
+      unsigned w = 0;
+      if (lane < 11) w = __hip_atomic_load(ctrl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned sq = __shfl(w, 8, 64), chk = __shfl(w, 9, 64), ab = __shfl(w, 10, 64);
+      unsigned sum = lane < 8 ? w : 0u;
+#pragma unroll
+      for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+      sum = __shfl(sum, 0, 64);
+      if (sq == seq && chk == seq + sum) {
+        if (lane < 8) sc_sh.v[lane] = w;
+        ok = 1;
+        break;
+      }
+      if (ab == seq || wall_clock64() - t0 > SCALE_WAIT_TICKS) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (lane == 0) ok_sh = ok;
+  }
+  __syncthreads();
+  if (!ok_sh) {
+    if (threadIdx.x == 0) flags[blockIdx.x] = ~seq;
+    return;
+  }
+  const fe_t scale = sc_sh;
+  if (i < n) out[i] = fe_add<S>(fe_mul<S>(scale, xv), av);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) flags[blockIdx.x] = seq;
+}
 }  // namespace
 // landing buffer of the product | staging of the addend | landing of the scaled sum | its per-block flags: one mapped pinned allocation, grow-only
 static int ensure_pinned_vec(sp_ctx* c, size_t cols) {
   if (!c->stream3) SP_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
   if (!c->vec_ev) SP_HIP(hipEventCreateWithFlags(&c->vec_ev, hipEventDisableTiming));
-  if (c->h_pinned_vec_bytes < 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES) {
+  if (c->h_pinned_vec_bytes < 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES + VEC_CTRL_BYTES) {
     if (c->h_pinned_vec) {
       SP_HIP(sp::stream_sync(c->stream3));
       SP_HIP(sp::stream_sync(c->stream2));
@@ -1154,11 +1208,80 @@ static int ensure_pinned_vec(sp_ctx* c, size_t cols) {
     }
     c->h_pinned_vec = nullptr;
     c->h_pinned_vec_bytes = 0;
-    SP_HIP(hipHostMalloc(&c->h_pinned_vec, 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES, hipHostMallocMapped));
-    memset(c->h_pinned_vec, 0, 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES);
-    c->h_pinned_vec_bytes = 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES;
+    SP_HIP(hipHostMalloc(&c->h_pinned_vec, 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES + VEC_CTRL_BYTES, hipHostMallocMapped));
+    memset(c->h_pinned_vec, 0, 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES + VEC_CTRL_BYTES);
+    c->h_pinned_vec_bytes = 3 * cols * sizeof(fe_t) + VEC_FLAG_BYTES + VEC_CTRL_BYTES;
     c->h_pinned_vec_cols = cols;
   }
+  return SP_OK;
+}
+// The armed form: _arm queues k_scale_add_wait on `st` (behind whatever produces x and add there) and returns its sequence number; _fire hands it the
+// scale through the control line and collects the sum; _abort releases a waiter whose scale will never come. One armed job per context at a time.
+static volatile unsigned* vec_ctrl(sp_ctx* c) {
+  return reinterpret_cast<volatile unsigned*>(reinterpret_cast<char*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols * sizeof(fe_t) + VEC_FLAG_BYTES);
+}
+static bool scale_add_armed_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_ZVEC_ARMED");  // "0": launch behind the scale (A/B)
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+static unsigned scale_add_arm(sp_ctx* c, hipStream_t st, const fe_t* dx, const fe_t* da, size_t cols) {
+  const size_t nblocks = (cols + 255) / 256;
+  if (!scale_add_armed_enabled() || nblocks * sizeof(unsigned) > VEC_FLAG_BYTES || cols > c->h_pinned_vec_cols) return 0;
+  if (++c->vec_seq == 0) ++c->vec_seq;
+  const unsigned seq = c->vec_seq;
+  void* d_base = nullptr;
+  if (hipHostGetDevicePointer(&d_base, c->h_pinned_vec, 0) != hipSuccess) return 0;
+  fe_t* d_hout = reinterpret_cast<fe_t*>(d_base) + 2 * c->h_pinned_vec_cols;
+  unsigned* d_flags = reinterpret_cast<unsigned*>(reinterpret_cast<fe_t*>(d_base) + 3 * c->h_pinned_vec_cols);
+  const unsigned* d_ctrl = reinterpret_cast<const unsigned*>(reinterpret_cast<char*>(d_flags) + VEC_FLAG_BYTES);
+  hipLaunchKernelGGL(k_scale_add_wait, dim3((unsigned)nblocks), dim3(256), 0, st, dx, da, d_ctrl, cols, d_hout, d_flags, seq);
+  return seq;
+}
+static void scale_add_abort(sp_ctx* c, unsigned seq) {
+  if (!seq || !c->h_pinned_vec) return;
+  volatile unsigned* ctl = vec_ctrl(c);
+  ctl[10] = seq;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+static int scale_add_to_host(sp_ctx* c, hipStream_t st, const fe_t* dx, const fe_t* da, const fe_t& sc, size_t cols, uint64_t* out, const char* site);
+static int scale_add_fire(sp_ctx* c, hipStream_t st, unsigned seq, const fe_t* dx, const fe_t* da, const fe_t& sc, size_t cols, uint64_t* out, const char* site) {
+  const size_t nblocks = (cols + 255) / 256;
+  volatile unsigned* ctl = vec_ctrl(c);
+  unsigned sum = 0;
+  for (int i = 0; i < 8; ++i) {
+    ctl[i] = sc.v[i];
+    sum += sc.v[i];
+  }
+  ctl[9] = seq + sum;
+  std::atomic_thread_fence(std::memory_order_release);
+  ctl[8] = seq;
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+  fe_t* h_out = reinterpret_cast<fe_t*>(c->h_pinned_vec) + 2 * c->h_pinned_vec_cols;
+  volatile unsigned* h_flags = reinterpret_cast<volatile unsigned*>(reinterpret_cast<fe_t*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols);
+  bool synced = false;
+  for (size_t b = 0; b < nblocks; ++b) {
+    for (long spins = 0; h_flags[b] != seq; ++spins) {
+      if (h_flags[b] == ~seq) {  // the waiter's watchdog ran out before the scale came (a late caller): the ordinary launch behind the scale
+        for (int i = 0; i < 10; ++i) ctl[i] = 0;
+        sp::slow_note(site, -1);
+        return scale_add_to_host(c, st, dx, da, sc, cols, out, site);
+      }
+      if (spins > 4000000) {
+        sp::slow_note(site, spins);
+        if (synced) return fail(SP_ERR_INTERNAL, "bind_with_delayed: the scaled sum did not arrive");
+        SP_HIP(sp::stream_sync(st));  // e.g. under a profiler
+        synced = true;
+        spins = 0;
+      }
+      sp::relax();
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  memcpy(out, h_out, cols * sizeof(fe_t));
+  for (int i = 0; i < 10; ++i) ctl[i] = 0;  // (the scale is the IPA's public challenge; cleared all the same)
   return SP_OK;
 }
 // scale * x + addend -> mapped host memory, polled through the per-block arrival flags (the tail of sp_rowmat_vec_eq_finish_scaled and of an announced opening)
@@ -1234,6 +1357,7 @@ int sp_rowmat_vec_eq_begin_with(sp_ctx* c, const sp_table* poly, const uint64_t*
     memcpy(stage, addend, cols * sizeof(fe_t));
     SP_HIP(hipMemcpyAsync(dout + cols, stage, cols * sizeof(fe_t), hipMemcpyHostToDevice, st));
     job->d_add = dout + cols;
+    job->armed = scale_add_arm(c, st, dout, dout + cols, cols);  // waits on the stream, behind the product and the upload, for _finish_scaled's scale
   }
   *out = job;
   return SP_OK;
@@ -1241,6 +1365,7 @@ int sp_rowmat_vec_eq_begin_with(sp_ctx* c, const sp_table* poly, const uint64_t*
 int sp_rowmat_vec_eq_finish(sp_ctx* c, sp_vec_job* job, uint64_t* out) {
   if (!job || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish: null argument");
   const size_t cols = job->cols;
+  scale_add_abort(c, job->armed);  // (a job begun with an addend and finished without its scale: the waiting kernel leaves)
   delete job;
   SP_HIP(sp::event_sync(c->vec_ev));
   memcpy(out, c->h_pinned_vec, cols * sizeof(fe_t));
@@ -1250,8 +1375,14 @@ int sp_rowmat_vec_eq_finish_scaled(sp_ctx* c, sp_vec_job* job, const uint64_t sc
   if (!job || !out || !scale) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: null argument");
   const size_t cols = job->cols;
   const fe_t *dx = job->d_out, *da = job->d_add;
+  const unsigned armed = job->armed;
   delete job;
   if (!da) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: the job was begun without an addend");
+  if (armed) {
+    fe_t sca;
+    memcpy(&sca, scale, 32);
+    return scale_add_fire(c, c->stream3, armed, dx, da, sca, cols, out, "rowmat_vec_eq_finish_scaled");
+  }
   fe_t sc;
   memcpy(&sc, scale, 32);
   // on the job's own stream: behind the product and the upload of the addend, which ended long ago
@@ -1507,12 +1638,18 @@ struct sp_pcs_ahead {
   // z_vec = r LZ + d on the device (ipa.rs:160-163): the mask vector is uploaded behind delta's walk, the scaled sum lands in mapped memory
   fe_t* d_out = nullptr;      // [LZ (num_cols) | - | d (cols)] in the auxiliary lane's WS_ROWMAT_OUT
   bool dvec_uploaded = false;
+  unsigned z_armed = 0;       // sequence number of the k_scale_add_wait queued behind L^T W (0: none), released by sp_hyrax_prove's challenge or aborted
+  bool z_fired = false;
 };
 namespace sp {
 static void pcs_ahead_drain(sp_ctx* c) {  // no device job of a dropped announcement may outlive it (its mapped result slot is reused)
   sp_pcs_ahead* S = c->pcs_ahead;
   if (!S) return;
   if (S->worker_busy && c->pcs_worker) c->pcs_worker->wait();
+  if (S->z_armed && !S->z_fired) {
+    scale_add_abort(c, S->z_armed);
+    S->z_fired = true;
+  }
   jac_t sink;
   if (S->delta_launched && !S->delta_collected) (void)multi_mul_collect(c, 1, S->seq_delta, &sink, false);
   if (S->lz_launched) {
@@ -1671,6 +1808,11 @@ void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]) {
       S->lz_launched = walk_out;
       return;
     }
+    // z_vec's kernel waits for the IPA's challenge on the second auxiliary stream, behind this one's work so far. That stream is non-blocking: a waiting
+    // kernel on a blocking stream would hold up every legacy default-stream operation of the process (a synchronous hipMemcpy between the sum-check and
+    // the opening) until its watchdog.
+    if (S->dvec_uploaded && c->stream3 && hipStreamWaitEvent(c->stream3, c->pcs_ev, 0) == hipSuccess)
+      S->z_armed = scale_add_arm(c, c->stream3, dout, dout + num_cols + 1, cols);
     S->lz_launched = true;
   });
 }
@@ -1935,6 +2077,10 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     eq_table_host(pt, nvr, L.data());
     LZ.resize(cols);
     if (ahead && S->lz_launched) {  // started for other row challenges than the point given now: drain it, its lane is needed
+      if (S->z_armed && !S->z_fired) {
+        scale_add_abort(c, S->z_armed);
+        S->z_fired = true;
+      }
       jac_t sink;
       (void)sp::multi_mul_collect(c, 1, S->seq_lz, &sink, false);
       (void)sp::event_sync(c->pcs_ev);
@@ -2084,7 +2230,12 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   if (lz_ahead && S->dvec_uploaded) {
     // on the device, behind comm_LZ's walk on the auxiliary stream (collected above): one launch, the sum lands in mapped memory (2048 products on this
     // thread and its helper were ~32 us)
-    if ((rc = scale_add_to_host(c, c->stream2, S->d_out, S->d_out + num_cols + 1, rr, cols, out + 16, "hyrax_prove z_vec"))) return rc;
+    if (S->z_armed && !S->z_fired) {
+      S->z_fired = true;
+      if ((rc = scale_add_fire(c, c->stream3, S->z_armed, S->d_out, S->d_out + num_cols + 1, rr, cols, out + 16, "hyrax_prove z_vec"))) return rc;
+    } else if ((rc = scale_add_to_host(c, c->stream2, S->d_out, S->d_out + num_cols + 1, rr, cols, out + 16, "hyrax_prove z_vec"))) {
+      return rc;
+    }
     explicit_bzero(reinterpret_cast<fe_t*>(c->h_pinned_vec) + c->h_pinned_vec_cols, cols * sizeof(fe_t));  // the mask's staging copy
     (void)hipMemsetAsync(S->d_out + num_cols + 1, 0, cols * sizeof(fe_t), c->stream2);                       // and its device copy
   } else {
