@@ -247,6 +247,11 @@ void sp_fbtables_free(sp_fbtables* t);
 int sp_fbtables_multi_mul(sp_ctx* ctx, const sp_fbtables* t, const uint64_t* scalars, size_t n, uint64_t out_aff[8]);
 /* the same in two halves: _begin launches, _finish waits for the result (one multiplication in flight per context) */
 int sp_fbtables_multi_mul_begin(sp_ctx* ctx, const sp_fbtables* t, const uint64_t* scalars, size_t n);
+/* the same for scalars eq(r_1 .. r_k, .) over the first nfixed tables and one more scalar for the last table (comm_LZ = <L, comm_W> with the zero rows folded
+ * into h, hyrax_pc.rs:446-455), handed over ONE LEVEL SHORT: P = eq(r_1 .. r_(k-1), .) (ceil(nfixed / 2) elements, EqPolynomial::evals_from_points order,
+ * src/polys/eq.rs:66-76), S01 = S0 | S1 (the last scalar is S0 + r_k (S1 - S0)) and r_k; the kernel forms the last level (one product per scalar instead of
+ * 2^(k-1) host products between the challenge and the launch). t->n must be nfixed + 1 <= 1023. Collected by sp_fbtables_multi_mul_finish. */
+int sp_fbtables_multi_mul_begin_eq(sp_ctx* ctx, const sp_fbtables* t, const uint64_t* P, size_t nfixed, const uint64_t S01[8], const uint64_t r_last[4]);
 int sp_fbtables_multi_mul_finish(sp_ctx* ctx, uint64_t out_aff[8]);
 /* FoldingEngineTrait::fold_commitments for two commitments with weights (1, w) (hyrax_pc.rs:757-776): out[i] = p[i] + w * q[i] per row */
 int sp_fold_commitments2(sp_ctx* ctx, const uint64_t* p_rows_aff, const uint64_t* q_rows_aff, size_t rows, const uint64_t w[4], uint64_t* out_rows_aff);

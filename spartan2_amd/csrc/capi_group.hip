@@ -1456,7 +1456,8 @@ int multi_mul_ensure(sp_ctx* c, int lane) {
 // zero up to `last`): needs the wide kernel (n >= its threshold) and `last`
 size_t multi_mul_wide_min() { return 1024; }  // scalars from which the 1024-item blocks (k_multi_mul_wide) are used
 int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last,
-                     size_t raw_blocks) {
+                     size_t raw_blocks, bool expand) {
+  if (expand && (raw_blocks || d_scalars || !last || !scalars || n >= multi_mul_wide_min())) return fail(SP_ERR_INTERNAL, "multi_mul: the expanding form takes host scalars below the wide size");
   if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "multi_mul: 1 .. 4096 scalars");
   if (raw_blocks && n < multi_mul_wide_min()) return fail(SP_ERR_INTERNAL, "multi_mul: raw blocks need the wide kernel");
   int erc = multi_mul_ensure(c, lane);
@@ -1466,6 +1467,9 @@ int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t*
     memcpy((char*)c->h_mm[lane] + 256, scalars, 64 * raw_blocks);
     if (raw_blocks < n - 1) memset((char*)c->h_mm[lane] + 256 + 64 * raw_blocks, 0, 64 * (n - 1 - raw_blocks));  // from_uniform(0) == 0
     c->mm_host_bytes[lane] = 64 * raw_blocks;
+  } else if (expand) {
+    memcpy((char*)c->h_mm[lane] + 256, scalars, (n / 2 + 2) * sizeof(fe_t));
+    c->mm_host_bytes[lane] = (n / 2 + 2) * sizeof(fe_t);
   } else if (!d_scalars) {
     memcpy((char*)c->h_mm[lane] + 256, scalars, n * sizeof(fe_t));
     c->mm_host_bytes[lane] = n * sizeof(fe_t);
@@ -1483,7 +1487,7 @@ int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t*
                          lastv, last ? 1 : 0, raw_blocks ? 1 : 0);
     else
       hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, src, n, d_tables, reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256),
-                         reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq, lastv, last ? 1 : 0);
+                         reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq, lastv, expand ? 2 : (last ? 1 : 0));
   });
   if (seq_out) *seq_out = seq;
   return SP_OK;
@@ -1567,6 +1571,20 @@ int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t*
   if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
   return sp::multi_mul_launch(c, 1, t->d_tables, scalars, n, nullptr, nullptr, nullptr, 0);
 }
+// the same walk with its scalars one level short of eq(r, .): P = eq(r_1 .. r_(k-1), .) (ceil(nfixed / 2) entries), S0 | S1 (h's scalar is S0 + r_k (S1 - S0))
+// and r_k - the kernel forms the last level itself (k_multi_mul_coop EXPAND). n = nfixed + 1 tables; below the wide kernel's size only.
+int sp_fbtables_multi_mul_begin_eq(sp_ctx* c, const sp_fbtables* t, const uint64_t* P, size_t nfixed, const uint64_t S01[8], const uint64_t r_last[4]) {
+  if (!t || !P || !S01 || !r_last) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul_begin_eq: null argument");
+  const size_t n = nfixed + 1, np = n / 2;
+  if (n != t->n || nfixed == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul_begin_eq: one table per fixed row and one of h");
+  if (n >= sp::multi_mul_wide_min()) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul_begin_eq: at most 1022 fixed rows");
+  std::vector<fe_t> buf(np + 2);
+  memcpy(buf.data(), P, np * sizeof(fe_t));
+  memcpy(buf.data() + np, S01, 2 * sizeof(fe_t));
+  fe_t rl;
+  memcpy(&rl, r_last, 32);
+  return sp::multi_mul_launch(c, 1, t->d_tables, reinterpret_cast<const uint64_t*>(buf.data()), n, nullptr, nullptr, &rl, 0, true);
+}
 int sp_fbtables_multi_mul_finish(sp_ctx* c, uint64_t out_aff[8]) {
   if (!c->h_mm[1] || c->mm_seq[1] == 0) return fail(SP_ERR_INTERNAL, "sp_fbtables_multi_mul_finish: nothing in flight");
   jac_t sum;
@@ -1633,7 +1651,7 @@ struct sp_pcs_ahead {
   // (P, new variable = index LSB, eq.rs:66-76); zfold = the zero rows' blinds folded like bfold gives h's scalar.
   const aff_t* row_tables = nullptr;
   size_t nfixed = 0;
-  std::vector<fe_t> P, zfold;
+  std::vector<fe_t> P, zfold, zfold_prev;
   bool lz_submitted = false;  // the launches behind the last row challenge are a job of the helper thread (the sum-check's thread goes on with its rounds)
   // z_vec = r LZ + d on the device (ipa.rs:160-163): the mask vector is uploaded behind delta's walk, the scaled sum lands in mapped memory
   fe_t* d_out = nullptr;      // [LZ (num_cols) | - | d (cols)] in the auxiliary lane's WS_ROWMAT_OUT
@@ -1676,6 +1694,7 @@ void pcs_ahead_free(sp_ctx* c) {
     wipe_vec(S->T);
     wipe_vec(S->bfold);
     wipe_vec(S->zfold);
+    wipe_vec(S->zfold_prev);
     explicit_bzero(&S->r_delta, sizeof(fe_t));
     explicit_bzero(&S->r_LZ, sizeof(fe_t));
     delete S;
@@ -1724,6 +1743,7 @@ void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]) {
     S->bfold.resize(h);
     S->rows_folded = round;
     if (S->row_tables) {
+      if (h == 1) S->zfold_prev = S->zfold;  // (S0, S1): h's scalar is S0 + r (S1 - S0), which the walk's kernel can form itself
       for (size_t j = 0; j < h; ++j) S->zfold[j] = fe_add<spk::SF>(S->zfold[j], fe_mul<spk::SF>(rk, fe_sub<spk::SF>(S->zfold[j + h], S->zfold[j])));
       explicit_bzero(S->zfold.data() + h, h * sizeof(fe_t));
       S->zfold.resize(h);
@@ -1777,14 +1797,27 @@ void pcs_ahead_on_challenge(void* ctx, size_t round, const uint64_t r[4]) {
     bool walk_out = false;
     if (S->row_tables) {  // comm_LZ from the rows' own tables: the walk first, L^T W (needed for z_vec only) behind it
       const fe_t rl = S->row_pt[nvr - 1];
-      std::vector<fe_t> sc(S->nfixed + 1);
-      for (size_t h2 = 0; h2 < S->P.size(); ++h2) {
-        const fe_t hi = fe_mul<spk::SF>(S->P[h2], rl), lo = fe_sub<spk::SF>(S->P[h2], hi);
-        if (2 * h2 < S->nfixed) sc[2 * h2] = lo;
-        if (2 * h2 + 1 < S->nfixed) sc[2 * h2 + 1] = hi;
+      int mrc;
+      if (S->nfixed + 1 < multi_mul_wide_min() && S->zfold_prev.size() == 2) {  // the last level of eq(r_rows, .) on the device (k_multi_mul_coop EXPAND)
+        const size_t np = (S->nfixed + 1) / 2;
+        std::vector<fe_t> buf(np + 2);
+        memcpy(buf.data(), S->P.data(), np * sizeof(fe_t));
+        buf[np] = S->zfold_prev[0];
+        buf[np + 1] = S->zfold_prev[1];
+        mrc = multi_mul_launch(c, 1, S->row_tables, reinterpret_cast<const uint64_t*>(buf.data()), S->nfixed + 1, &S->seq_lz, nullptr, &rl, 0, true);
+        wipe_vec(buf);
+      } else {
+        std::vector<fe_t> sc(S->nfixed + 1);
+        for (size_t h2 = 0; h2 < S->P.size(); ++h2) {
+          const fe_t hi = fe_mul<spk::SF>(S->P[h2], rl), lo = fe_sub<spk::SF>(S->P[h2], hi);
+          if (2 * h2 < S->nfixed) sc[2 * h2] = lo;
+          if (2 * h2 + 1 < S->nfixed) sc[2 * h2 + 1] = hi;
+        }
+        sc[S->nfixed] = S->zfold[0];
+        mrc = multi_mul_launch(c, 1, S->row_tables, reinterpret_cast<const uint64_t*>(sc.data()), S->nfixed + 1, &S->seq_lz, nullptr, nullptr, 0);
+        wipe_vec(sc);
       }
-      sc[S->nfixed] = S->zfold[0];
-      if (multi_mul_launch(c, 1, S->row_tables, reinterpret_cast<const uint64_t*>(sc.data()), S->nfixed + 1, &S->seq_lz, nullptr, nullptr, 0)) {
+      if (mrc) {
         S->failed = true;
         return;
       }

@@ -57,7 +57,7 @@ namespace sp {
 int multi_mul_ensure(sp_ctx* c, int lane);
 size_t multi_mul_wide_min();
 int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t* scalars, size_t n, unsigned* seq_out, const fe_t* d_scalars, const fe_t* last,
-                     size_t raw_blocks);
+                     size_t raw_blocks, bool expand = false);
 int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield);
 int ck_key_tables(sp_ctx* c, const sp_ck* ck);  // 0 = ready, 1 = not available (take the bucket MSM), < 0 = error
 // capi_pippenger.hip: the general (multi-block) Pippenger for caller-supplied bases; window = 0 -> pippenger_window(n)

@@ -873,6 +873,10 @@ constexpr unsigned MULTI_MUL_SLOT_K = 0x9E3779B1u;
 constexpr int MULTI_MUL_MAX_BLOCKS = 1024;  // 4096 scalars (the 2048 bases of a key + h: every MSM over the key as one table walk)
 // `has_last`: scalar n - 1 is the kernel argument `last` instead of scalars[n - 1] (the blind of h, known on the host, behind n - 1 scalars that a
 // kernel earlier on the stream left in device memory: comm_LZ = <LZ, ck> + r_LZ h of hyrax_pc.rs:454-455 without a host round trip for LZ).
+// `has_last` == 2 (EXPAND): the scalars are eq(r_1 .. r_k, .) one level short - `scalars` holds P = eq(r_1 .. r_(k-1), .) (ceil((n - 1) / 2) entries, the
+// new variable is the index LSB, eq.rs:66-76) followed by S0, S1, and `last` is r_k: scalar idx < n - 1 is P[idx / 2] r_k or P[idx / 2] (1 - r_k), scalar
+// n - 1 is S0 + r_k (S1 - S0). One product per scalar here instead of 2^(k-1) on the host between the challenge and the launch (comm_LZ's walk, the chain
+// the end of a prove waits for, starts ~8 us earlier).
 __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, xyzz_t* __restrict__ partial,
                                                             unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq, fe_t last, int has_last) {
   __shared__ CoopAdd<128> L;
@@ -885,7 +889,20 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restri
   if (role == 0) {
     xyzz_t acc = xyzz_identity();
     if (idx < n) {
-      const fe_t c = fe_to_canonical<SF>((has_last && idx == n - 1) ? last : scalars[idx]);
+      fe_t sc;
+      if (has_last == 2) {
+        const size_t np = n / 2;  // = ceil((n - 1) / 2)
+        if (idx == n - 1) {
+          const fe_t s0 = scalars[np], s1 = scalars[np + 1];
+          sc = fe_add<SF>(s0, fe_mul<SF>(last, fe_sub<SF>(s1, s0)));
+        } else {
+          const fe_t base = scalars[idx >> 1], hi = fe_mul<SF>(base, last);
+          sc = (idx & 1) ? hi : fe_sub<SF>(base, hi);
+        }
+      } else {
+        sc = (has_last && idx == n - 1) ? last : scalars[idx];
+      }
+      const fe_t c = fe_to_canonical<SF>(sc);
       const unsigned digit = (c.v[j >> 2] >> (8 * (j & 3))) & 0xffu;
       if (digit) acc = xyzz_from_affine(tables[idx * (32 * 255) + (size_t)j * 255 + digit - 1]);
     }

@@ -540,6 +540,17 @@ class FixedBaseTables:
         check(lib().sp_fbtables_multi_mul(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(out)))
         return out
 
+    def multi_mul_eq(self, P, nfixed, s01, r_last):
+        """sp_fbtables_multi_mul_begin_eq + _finish: the scalars are eq(r_1..r_k, .) handed over one level short (P = eq(r_1..r_(k-1), .)), the last table's
+        scalar is S0 + r_k (S1 - S0)."""
+        P = np.ascontiguousarray(P, dtype=np.uint64).reshape(-1, 4)
+        s01 = np.ascontiguousarray(s01, dtype=np.uint64).reshape(2, 4)
+        r_last = np.ascontiguousarray(r_last, dtype=np.uint64).reshape(4)
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().sp_fbtables_multi_mul_begin_eq(self.ctx.h, self.h, p64(P), ctypes.c_size_t(nfixed), p64(s01), p64(r_last)))
+        check(lib().sp_fbtables_multi_mul_finish(self.ctx.h, p64(out)))
+        return out
+
     def close(self):
         if self.h:
             lib().sp_fbtables_free(self.h)

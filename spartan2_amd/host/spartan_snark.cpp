@@ -564,6 +564,13 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
         }
         if (wait_for(lzp->state) != 1) return;
         const fe_t rl = lzp->r[nvr - 1];
+        bool launched = false;
+        if (nfixed + 1 < 1024) {  // the last level on the device (k_multi_mul_coop EXPAND): the launch goes out before this thread forms it for r_LZ
+          const fe_t s01[2] = {S0, S1};
+          ck(sp_fbtables_multi_mul_begin_eq(ctx, tabs, u64p(P.data()), nfixed, u64p(s01), u64p(&rl)), "comm_LZ (begin)");
+          ck(sp_rowmat_vec_eq_begin_with(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, dn == cols ? u64p(dv) : nullptr, &lzp->vec), "bind_with_delayed (begin)");
+          launched = true;
+        }
         std::vector<fe_t> sc(nfixed + 1);
         for (size_t h = 0; h < P.size(); ++h) {
           const fe_t hi = fe_mul<S>(P[h], rl), lo = fe_sub<S>(P[h], hi);
@@ -572,8 +579,10 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
         }
         const fe_t hs = fe_add<S>(S0, fe_mul<S>(rl, fe_sub<S>(S1, S0)));
         sc[nfixed] = hs;
-        ck(sp_fbtables_multi_mul_begin(ctx, tabs, u64p(sc.data()), sc.size()), "comm_LZ (begin)");
-        ck(sp_rowmat_vec_eq_begin_with(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, dn == cols ? u64p(dv) : nullptr, &lzp->vec), "bind_with_delayed (begin)");
+        if (!launched) {
+          ck(sp_fbtables_multi_mul_begin(ctx, tabs, u64p(sc.data()), sc.size()), "comm_LZ (begin)");
+          ck(sp_rowmat_vec_eq_begin_with(ctx, psp->W, u64p(lzp->r), lzp->nvr, cols, dn == cols ? u64p(dv) : nullptr, &lzp->vec), "bind_with_delayed (begin)");
+        }
         fe_t acc = hs;  // r_LZ = <L, r_W> (hyrax_pc.rs:446-455)
         for (size_t i = 0; i < nfixed; ++i) acc = fe_add<S>(acc, fe_mul<S>(sc[i], blinds[i]));
         lzp->r_LZ = acc;

@@ -528,6 +528,31 @@ def test_commit_small_device_form_matches_oracle(ctx, width):
         assert (k.commit_small(ones, blind) == want(ones, blind)).all()
 
 
+@pytest.mark.parametrize("k,nfixed", [(1, 2), (3, 5), (3, 8), (9, 425), (9, 512), (10, 1022)])
+def test_fixed_base_tables_multi_mul_with_the_last_eq_level_on_the_device(ctx, k, nfixed):
+    """sp_fbtables_multi_mul_begin_eq: the walk's scalars handed over one level short of eq(r_1..r_k, .) - the kernel's own last level gives the same point
+    as sp_fbtables_multi_mul over the full table (odd and even counts of fixed rows, a partial last pair, the largest size below the wide kernel)."""
+    rng = np.random.default_rng(SEED + 7800 + nfixed)
+    n = nfixed + 1
+    pts = np.zeros((n, 8), dtype=np.uint64)
+    olib().orc_from_label(b"fbtables_eq_test", ctypes.c_size_t(n), p64(pts))
+    t = hip.FixedBaseTables(ctx, pts)
+    r = ol.random_field_array(rng, k)
+    full = hip.Table.eq(ctx, r).read()  # eq(r_1..r_k, .): 2^k elements, r_1 on the index MSB
+    prev = hip.Table.eq(ctx, r[: k - 1]).read() if k > 1 else ol.mont_array([1])
+    s01 = ol.random_field_array(rng, 2)
+    p = ol.MODULI[0]
+    hs = (ol.from_mont(s01[0]) + ol.from_mont(r[k - 1]) * (ol.from_mont(s01[1]) - ol.from_mont(s01[0]))) % p
+    sc = np.concatenate([full[:nfixed], ol.mont_array([hs])])
+    want = t.multi_mul(sc)
+    assert (want == oracle_msm(sc, np.ascontiguousarray(pts))).all()
+    for _ in range(2):
+        assert (t.multi_mul_eq(prev[: (nfixed + 1) // 2], nfixed, s01, r[k - 1]) == want).all()
+    with pytest.raises(hip.SpartanHipError):
+        t.multi_mul_eq(prev[: (nfixed + 1) // 2], nfixed - 1, s01, r[k - 1])  # one table per fixed row and one of h
+    t.close()
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 33, 130, 429, 512, 700, 2048, 2049, 2600])
 def test_fixed_base_tables_multi_mul_matches_oracle_msm(ctx, n):
     """sp_fbtables_create + sp_fbtables_multi_mul (FixedBaseMul::precompute / multi_mul over arbitrary points, msm.rs:637-773; the one-launch form comm_LZ
