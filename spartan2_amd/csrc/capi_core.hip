@@ -16,6 +16,8 @@ static thread_local std::string g_err;
 static thread_local sp_wait_hook g_wait_hook = nullptr;
 static thread_local void* g_wait_user = nullptr;
 void set_error(const std::string& m) { g_err = m; }
+static std::atomic<int> g_live_contexts{0};
+int live_contexts() { return g_live_contexts.load(std::memory_order_relaxed); }
 void relax() {
   if (g_wait_hook) g_wait_hook(g_wait_user);
   else __builtin_ia32_pause();
@@ -174,6 +176,7 @@ int sp_ctx_create(int device, sp_ctx** out) {
   SP_HIP(hipMalloc((void**)&c->d_gate, spk::MAIL_RING * sizeof(fe_t)));
   int rc = c->ensure_scratch(1 << 16);
   if (rc) return rc;
+  sp::g_live_contexts.fetch_add(1, std::memory_order_relaxed);
   *out = c;
   return SP_OK;
 }
@@ -185,6 +188,7 @@ int sp_ctx_bind_thread(sp_ctx* c) {
 int sp_ctx_device(const sp_ctx* c) { return c ? c->device : -1; }
 void sp_ctx_destroy(sp_ctx* c) {
   if (!c) return;
+  sp::g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
   sp::pcs_ahead_free(c);
   hipSetDevice(c->device);
   c->drain_stats();

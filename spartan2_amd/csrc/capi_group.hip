@@ -1217,8 +1217,17 @@ static int ensure_pinned_vec(sp_ctx* c, size_t cols) {
 }
 // The armed form: _arm queues k_scale_add_wait on `st` (behind whatever produces x and add there) and returns its sequence number; _fire hands it the
 // scale through the control line and collects the sum; _abort releases a waiter whose scale will never come. One armed job per context at a time.
+// The control line lives where the challenge mailbox does (core.hpp): in fine-grained DEVICE memory that the host writes through the PCIe BAR when the
+// system has a large BAR - the waiting blocks then poll their own memory - and otherwise in the mapped page (every poll a bus read: eight contexts'
+// waiters polling host memory took a third off the eight-context throughput, 0.62 -> 0.84 ms per proof).
+static const size_t VEC_CTRL_MAIL_WORD = 512;  // word offset of the line in the 4 KiB mailbox page (ring: words 0..127, diagnostics: 256..259)
 static volatile unsigned* vec_ctrl(sp_ctx* c) {
+  if (c->mail_dev) return reinterpret_cast<volatile unsigned*>(c->h_mail) + VEC_CTRL_MAIL_WORD;
   return reinterpret_cast<volatile unsigned*>(reinterpret_cast<char*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols * sizeof(fe_t) + VEC_FLAG_BYTES);
+}
+static void vec_ctrl_flush(sp_ctx* c) {
+  if (c->mail_dev) __builtin_ia32_sfence();  // BAR memory is write-combining: push the line out now
+  else std::atomic_thread_fence(std::memory_order_seq_cst);
 }
 static bool scale_add_armed_enabled() {
   static const bool on = [] {
@@ -1229,14 +1238,16 @@ static bool scale_add_armed_enabled() {
 }
 static unsigned scale_add_arm(sp_ctx* c, hipStream_t st, const fe_t* dx, const fe_t* da, size_t cols) {
   const size_t nblocks = (cols + 255) / 256;
-  if (!scale_add_armed_enabled() || nblocks * sizeof(unsigned) > VEC_FLAG_BYTES || cols > c->h_pinned_vec_cols) return 0;
+  // One context in the process = one prove at a time (the latency case this is for). With several, streams of different contexts share hardware queues and
+  // a kernel that WAITS in one holds up whatever another context queued behind it: eight contexts went from 0.61 to 0.83-0.94 ms per proof with it.
+  if (!scale_add_armed_enabled() || sp::live_contexts() != 1 || nblocks * sizeof(unsigned) > VEC_FLAG_BYTES || cols > c->h_pinned_vec_cols) return 0;
   if (++c->vec_seq == 0) ++c->vec_seq;
   const unsigned seq = c->vec_seq;
   void* d_base = nullptr;
   if (hipHostGetDevicePointer(&d_base, c->h_pinned_vec, 0) != hipSuccess) return 0;
   fe_t* d_hout = reinterpret_cast<fe_t*>(d_base) + 2 * c->h_pinned_vec_cols;
   unsigned* d_flags = reinterpret_cast<unsigned*>(reinterpret_cast<fe_t*>(d_base) + 3 * c->h_pinned_vec_cols);
-  const unsigned* d_ctrl = reinterpret_cast<const unsigned*>(reinterpret_cast<char*>(d_flags) + VEC_FLAG_BYTES);
+  const unsigned* d_ctrl = c->mail_dev ? c->d_mail + VEC_CTRL_MAIL_WORD : reinterpret_cast<const unsigned*>(reinterpret_cast<char*>(d_flags) + VEC_FLAG_BYTES);
   hipLaunchKernelGGL(k_scale_add_wait, dim3((unsigned)nblocks), dim3(256), 0, st, dx, da, d_ctrl, cols, d_hout, d_flags, seq);
   return seq;
 }
@@ -1244,7 +1255,7 @@ static void scale_add_abort(sp_ctx* c, unsigned seq) {
   if (!seq || !c->h_pinned_vec) return;
   volatile unsigned* ctl = vec_ctrl(c);
   ctl[10] = seq;
-  std::atomic_thread_fence(std::memory_order_seq_cst);
+  vec_ctrl_flush(c);
 }
 static int scale_add_to_host(sp_ctx* c, hipStream_t st, const fe_t* dx, const fe_t* da, const fe_t& sc, size_t cols, uint64_t* out, const char* site);
 static int scale_add_fire(sp_ctx* c, hipStream_t st, unsigned seq, const fe_t* dx, const fe_t* da, const fe_t& sc, size_t cols, uint64_t* out, const char* site) {
@@ -1258,7 +1269,7 @@ static int scale_add_fire(sp_ctx* c, hipStream_t st, unsigned seq, const fe_t* d
   ctl[9] = seq + sum;
   std::atomic_thread_fence(std::memory_order_release);
   ctl[8] = seq;
-  std::atomic_thread_fence(std::memory_order_seq_cst);
+  vec_ctrl_flush(c);
   fe_t* h_out = reinterpret_cast<fe_t*>(c->h_pinned_vec) + 2 * c->h_pinned_vec_cols;
   volatile unsigned* h_flags = reinterpret_cast<volatile unsigned*>(reinterpret_cast<fe_t*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols);
   bool synced = false;

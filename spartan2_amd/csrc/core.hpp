@@ -25,6 +25,7 @@ void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
 // one iteration of a host-side wait for the device (a result slot, a mailbox answer, a helper's flag): the calling thread's wait hook
 // (sp_set_wait_hook: a driver that runs several proofs on one thread switches to another proof here) or a `pause`
+int live_contexts();  // contexts of this process between sp_ctx_create and sp_ctx_destroy
 void relax();
 // hipStreamSynchronize / hipEventSynchronize for library code: on a thread with a wait hook they poll (hipStreamQuery / hipEventQuery) through relax()
 // instead of blocking — a blocked thread could not serve the other proofs it carries, and one of those may own a kernel that sits in front of this
