@@ -446,6 +446,10 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
     hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per16 + 255) / 256)), dim3(256), 0, c->stream, tj16.as<jac_t>(), ntab * per16, t16);
     SP_HIP(sp::stream_sync(c->stream));
     k->d_tables16 = t16;
+    if (ntab <= 2) {  // host copy for the single multiplications (commitments of one value: eval_W, beta, a blind's term)
+      k->h_tables16.resize(ntab * per16);
+      SP_HIP(hipMemcpy(k->h_tables16.data(), t16, ntab * per16 * sizeof(aff_t), hipMemcpyDeviceToHost));
+    }
     std::lock_guard<std::mutex> l(g_t16_mu);
     if (ntab > 1) g_t16[k->d_cktables] = t16;
     g_t16[k->d_htable] = t16 + (ntab - 1) * per16;
@@ -480,6 +484,25 @@ static jac_t fixed_base_mul_host(const aff_t* table, const fe_t& scalar) {
     if (digit) acc = jac_add_mixed(acc, table[(size_t)j * 255 + digit - 1]);
   }
   return acc;
+}
+// The same over the 16-bit-window tables: 16 mixed additions; the sixteen entries (each a miss in a 64 MiB table) are requested before the first is used.
+static jac_t fixed_base_mul_host16(const aff_t* table16, const fe_t& scalar) {
+  const fe_t c = fe_to_canonical<S>(scalar);
+  const aff_t* ent[16];
+  for (int j = 0; j < 16; ++j) {
+    const unsigned digit = (c.v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+    ent[j] = digit ? table16 + (size_t)j * 65535 + digit - 1 : nullptr;
+    if (ent[j]) __builtin_prefetch(ent[j], 0, 0);
+  }
+  jac_t acc = jac_identity();
+  for (int j = 0; j < 16; ++j)
+    if (ent[j]) acc = jac_add_mixed(acc, *ent[j]);
+  return acc;
+}
+// table t of a key (t = n_tables - 1: h) times a scalar, on the host: over the 16-bit windows when the key keeps them here
+static jac_t ck_mul_host(const sp_ck* ck, size_t t, const fe_t& scalar) {
+  const aff_t* t16 = ck->host_table16(t);
+  return t16 ? fixed_base_mul_host16(t16, scalar) : fixed_base_mul_host(ck->host_table(t), scalar);
 }
 // few scalars (the latency case: the blinds of the zero rows): block-cooperative additions; many: one half-wave per scalar (throughput).
 static void launch_fixed_base_rows(hipStream_t st, const fe_t* ds, size_t n, const aff_t* tables, size_t ntables, jac_t* dout) {
@@ -613,7 +636,7 @@ int sp_fixed_base_mul_h_begin(sp_ctx* c, const sp_ck* ck, const uint64_t* scalar
     for (size_t i = 0; i < n; ++i) {
       fe_t sc;
       memcpy(&sc, scalars + 4 * i, 32);
-      job->host_pts[i] = fixed_base_mul_host(ck->host_htable(), sc);
+      job->host_pts[i] = ck_mul_host(ck, ck->n_tables - 1, sc);
     }
   } else if (n <= FB_MAPPED_MAX && fb_mapped_enabled()) {
     int rc = fb_mapped_launch(c, 1, ck->d_htable, 1, scalars, n);
@@ -681,7 +704,7 @@ int sp_fixed_base_mul_h(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, siz
     for (size_t i = 0; i < n; ++i) {
       fe_t sc;
       memcpy(&sc, scalars + 4 * i, 32);
-      pts[i] = fixed_base_mul_host(ck->host_htable(), sc);
+      pts[i] = ck_mul_host(ck, ck->n_tables - 1, sc);
     }
   } else {
     int rc = fixed_base_rows(c, ck->d_htable, 1, scalars, n, pts);
@@ -928,7 +951,7 @@ int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_a
   }
   std::vector<jac_t> pts(rows);
   if (rows <= FIXED_BASE_HOST_MAX) {
-    for (size_t i = 0; i < rows; ++i) pts[i] = fixed_base_mul_host(ck->host_htable(), diff[i]);
+    for (size_t i = 0; i < rows; ++i) pts[i] = ck_mul_host(ck, ck->n_tables - 1, diff[i]);
   } else {
     int rc = fixed_base_rows(c, ck->d_htable, 1, reinterpret_cast<const uint64_t*>(diff.data()), rows, pts);
     if (rc) return rc;
@@ -976,7 +999,7 @@ int sp_msm_ck(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, con
   if (blind) {
     fe_t b;
     memcpy(&b, blind, 32);
-    r = jac_add(r, fixed_base_mul_host(ck->host_htable(), b));
+    r = jac_add(r, ck_mul_host(ck, ck->n_tables - 1, b));
   }
   store_aff(out_aff, jac_to_affine(r));
   return SP_OK;
@@ -1021,7 +1044,7 @@ int sp_msm_ck_finish(sp_ctx* c, const sp_ck* ck, sp_msm_job* job, const uint64_t
   if (blind) {
     fe_t b;
     memcpy(&b, blind, 32);
-    r = jac_add(r, fixed_base_mul_host(ck->host_htable(), b));
+    r = jac_add(r, ck_mul_host(ck, ck->n_tables - 1, b));
   }
   store_aff(out_aff, jac_to_affine(r));
   return SP_OK;
@@ -1450,8 +1473,19 @@ namespace sp {
 // tail. Two lanes per context, each with its own pages / ticket / sequence number: lane 1 on the auxiliary stream (callable from a helper thread
 // beside the owner's calls on the main stream, like sp_msm_eq_begin), lane 0 on the main stream. The caller polls the self-validating result slot;
 // a poll that runs long (profiler, debugger) falls back to a stream synchronise, after which the slot must be valid.
+// GROUPS (k_multi_mul_coop): the blocks of a walk of >= MM_GROUP_MIN_BLOCKS blocks join in MM_GROUPS groups, each with a result slot of its own (128 bytes
+// apart, behind the scalars of the lane's mapped page); multi_mul_collect adds the groups' sums on the host.
+static const unsigned MM_GROUPS = 8, MM_GROUP_MIN_BLOCKS = 32;
+static const size_t MM_GROUP_SLOTS_OFF = 256 + 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
+static bool mm_groups_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_WALK_GROUPS");  // "0": one join on the device (A/B)
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 int multi_mul_ensure(sp_ctx* c, int lane) {
-  const size_t page = 256 + 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS * sizeof(fe_t);
+  const size_t page = MM_GROUP_SLOTS_OFF + 128 * MM_GROUPS;
   if (!c->h_mm[lane]) {
     SP_HIP(hipHostMalloc(&c->h_mm[lane], page, hipHostMallocMapped));
     memset(c->h_mm[lane], 0, page);
@@ -1491,19 +1525,67 @@ int multi_mul_launch(sp_ctx* c, int lane, const aff_t* d_tables, const uint64_t*
   const fe_t* src = d_scalars ? d_scalars : reinterpret_cast<const fe_t*>((char*)c->d_mm[lane] + 256);
   const fe_t lastv = last ? *last : fe_zero();
   const size_t wide_min = multi_mul_wide_min();
+  const unsigned nblk = (unsigned)((n + 3) / 4);
+  const unsigned gblocks = (n < wide_min && nblk >= MM_GROUP_MIN_BLOCKS && mm_groups_enabled()) ? (nblk + MM_GROUPS - 1) / MM_GROUPS : 0u;
   c->timed_on(st, "multi_mul", 32ull * n, [&] {
     if (n >= wide_min)
       hipLaunchKernelGGL(spk::k_multi_mul_wide, dim3((unsigned)((n * 32 + spk::MULTI_MUL_WIDE_ITEMS - 1) / spk::MULTI_MUL_WIDE_ITEMS)), dim3(512), 0, st, src, n, d_tables,
                          reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256), reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq,
                          lastv, last ? 1 : 0, raw_blocks ? 1 : 0);
     else
-      hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3((unsigned)((n + 3) / 4)), dim3(512), 0, st, src, n, d_tables, reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256),
-                         reinterpret_cast<unsigned*>(c->d_mm_work[lane]), reinterpret_cast<unsigned*>(c->d_mm[lane]), seq, lastv, expand ? 2 : (last ? 1 : 0));
+      hipLaunchKernelGGL(spk::k_multi_mul_coop, dim3(nblk), dim3(512), 0, st, src, n, d_tables, reinterpret_cast<xyzz_t*>((char*)c->d_mm_work[lane] + 256),
+                         reinterpret_cast<unsigned*>(c->d_mm_work[lane]),
+                         reinterpret_cast<unsigned*>((char*)c->d_mm[lane] + (gblocks ? MM_GROUP_SLOTS_OFF : 0)), seq, lastv, expand ? 2 : (last ? 1 : 0), gblocks);
   });
+  c->mm_groups[lane] = gblocks ? (nblk + gblocks - 1) / gblocks : 0;
   if (seq_out) *seq_out = seq;
   return SP_OK;
 }
 int multi_mul_collect(sp_ctx* c, int lane, unsigned seq, jac_t* out, bool yield) {
+  const unsigned groups = c->mm_groups[lane];
+  if (groups) {  // one slot per group, added here (the top of the tree: ~0.5 us an addition on the host against ~4.8 us a level on the device)
+    jac_t acc = jac_identity();
+    bool done[MM_GROUPS] = {};
+    unsigned remaining = groups;
+    bool synced = false;
+    for (long spins = 0; remaining; ++spins) {
+      for (unsigned g = 0; g < groups; ++g) __builtin_prefetch((const char*)c->h_mm[lane] + MM_GROUP_SLOTS_OFF + 128 * g, 0, 3);
+      for (unsigned g = 0; g < groups; ++g) {
+        if (done[g]) continue;
+        volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>((const char*)c->h_mm[lane] + MM_GROUP_SLOTS_OFF + 128 * g);
+        if (slot[24] != seq) continue;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        unsigned w[24], a = seq, b = seq * spk::MULTI_MUL_SLOT_K;
+        for (int i = 0; i < 24; ++i) {
+          w[i] = slot[i];
+          a += w[i];
+          b += (unsigned)(i + 1) * w[i];
+        }
+        if (!(slot[24] == seq && slot[25] == a && slot[26] == b && slot[27] == seq)) continue;
+        jac_t p;
+        memcpy(&p, w, sizeof(jac_t));
+        acc = jac_add(acc, p);
+        done[g] = true;
+        --remaining;
+      }
+      if (!remaining) break;
+      if (spins > 400000) {
+        sp::slow_note("multi_mul_collect (groups)", spins);
+        if (synced) return fail(SP_ERR_INTERNAL, "multi_mul: the kernel did not deliver its result slots");
+        SP_HIP(sp::stream_sync(lane ? c->stream2 : c->stream));  // e.g. under a profiler
+        synced = true;
+        spins = 0;
+      }
+      if (yield && spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else sp::relax();
+    }
+    *out = acc;
+    if (c->mm_host_bytes[lane]) {
+      explicit_bzero((char*)c->h_mm[lane] + 256, c->mm_host_bytes[lane]);
+      c->mm_host_bytes[lane] = 0;
+    }
+    return SP_OK;
+  }
   volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>(c->h_mm[lane]);
   unsigned w[24];
   bool synced = false;
@@ -2070,10 +2152,9 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   } join{c->pcs_worker};
 
   if (beta_beside) {
-    const aff_t* ht = ck_eval->host_htable();
     jac_t* dst = &beta_h;
     const fe_t rb = r_beta;
-    c->pcs_worker->submit([ht, dst, rb] { *dst = fixed_base_mul_host(ht, rb); });
+    c->pcs_worker->submit([ck_eval, dst, rb] { *dst = ck_mul_host(ck_eval, ck_eval->n_tables - 1, rb); });
   }
   lap("submit hashing");
   // (2) device: delta's walk on the auxiliary stream, LZ and comm_LZ's walk on the main stream
@@ -2203,10 +2284,9 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   aff_t beta;
   if (beta_beside) {
     c->pcs_worker->wait(1);  // h's walk (an unclaimed job is taken back and run here)
-    const aff_t* ct = ck_eval->host_table(0);
     jac_t* dst = &beta_c;
     const fe_t ipv = ip;
-    c->pcs_worker->submit([ct, dst, ipv] { *dst = fixed_base_mul_host(ct, ipv); });
+    c->pcs_worker->submit([ck_eval, dst, ipv] { *dst = ck_mul_host(ck_eval, 0, ipv); });
   } else if ((rc = sp_hyrax_commit_small(c, ck_eval, reinterpret_cast<const uint64_t*>(&ip), 1, reinterpret_cast<const uint64_t*>(&r_beta), reinterpret_cast<uint64_t*>(&beta)))) {
     return rc;
   }
@@ -2324,7 +2404,7 @@ int sp_hyrax_commit_small_with_term(sp_ctx* c, const sp_ck* ck, const uint64_t* 
   for (size_t i = 0; i < n; ++i) {
     fe_t sc;
     memcpy(&sc, scalars + 4 * i, 32);
-    acc = jac_add(acc, fixed_base_mul_host(ck->host_table(i), sc));
+    acc = jac_add(acc, ck_mul_host(ck, i, sc));
   }
   (void)c;
   store_aff(out_aff, jac_to_affine(acc));
@@ -2366,21 +2446,20 @@ int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, s
   jac_t hpart;
   const bool beside = n >= 1 && c && c->pcs_worker && c->pcs_worker->hot();
   if (beside) {
-    const aff_t* ht = ck->host_htable();
     jac_t* hp = &hpart;
     const fe_t* bp = &b;
-    c->pcs_worker->submit([ht, hp, bp] { *hp = fixed_base_mul_host(ht, *bp); });
+    c->pcs_worker->submit([ck, hp, bp] { *hp = ck_mul_host(ck, ck->n_tables - 1, *bp); });
   }
   for (size_t i = 0; i < n; ++i) {
     fe_t sc;
     memcpy(&sc, scalars + 4 * i, 32);
-    parts.push_back(fixed_base_mul_host(ck->host_table(i), sc));
+    parts.push_back(ck_mul_host(ck, i, sc));
   }
   if (beside) {
     c->pcs_worker->wait(1);
     parts.push_back(hpart);
   } else {
-    parts.push_back(fixed_base_mul_host(ck->host_htable(), b));
+    parts.push_back(ck_mul_host(ck, ck->n_tables - 1, b));
   }
   jac_t acc = jac_identity();
   for (const jac_t& p : parts) acc = jac_add(acc, p);

@@ -196,6 +196,7 @@ struct sp_ctx {
   void* d_mm[2] = {nullptr, nullptr};
   void* d_mm_work[2] = {nullptr, nullptr};
   unsigned mm_seq[2] = {0, 0};
+  unsigned mm_groups[2] = {0, 0};  // result slots of the launch in flight on the lane when its blocks join in groups (0: one slot at the head of the page)
   size_t mm_host_bytes[2] = {0, 0};  // scalars the last launch of the lane copied into its mapped page (mask / blind material): wiped when the result is collected
   hipEvent_t fb_ev = nullptr;
   hipEvent_t fb_event() {

@@ -19,6 +19,10 @@ struct sp_ck {
   size_t n_tables = 0;
   const aff_t* host_table(size_t t) const { return h_tables.data() + t * 32 * 255; }
   const aff_t* host_htable() const { return host_table(n_tables - 1); }
+  // keys of <= 2 tables (the width-1 key of eval_W / beta, h of the wide key): a host copy of the 16-bit-window tables too (16 x 65535 entries a table,
+  // 64 MiB each) - a single multiplication on the host is then 16 mixed additions instead of 32 (capi_group.hip ck_mul_host)
+  std::vector<aff_t> h_tables16;
+  const aff_t* host_table16(size_t t) const { return h_tables16.empty() ? nullptr : h_tables16.data() + t * ((size_t)16 * 65535); }
   // fixed-base comb table of the whole key (kernels_msm.hpp k_comb_*), built on first use by a commitment of many non-small rows
   mutable aff_t* d_comb = nullptr;
   mutable int comb_c = 0, comb_windows = 0;

@@ -877,8 +877,12 @@ constexpr int MULTI_MUL_MAX_BLOCKS = 1024;  // 4096 scalars (the 2048 bases of a
 // new variable is the index LSB, eq.rs:66-76) followed by S0, S1, and `last` is r_k: scalar idx < n - 1 is P[idx / 2] r_k or P[idx / 2] (1 - r_k), scalar
 // n - 1 is S0 + r_k (S1 - S0). One product per scalar here instead of 2^(k-1) on the host between the challenge and the launch (comm_LZ's walk, the chain
 // the end of a prove waits for, starts ~8 us earlier).
+// `gblocks` > 0 (GROUPS): every `gblocks` consecutive blocks form a group with a ticket and a result slot of its own (slot + 32 g words); the host adds
+// the groups' sums. A cooperative addition is ~4.8 us of dependent products on the device and ~0.5 us on the host, so the top levels of the tree are
+// the host's: with 8 groups over 107 blocks the join is 4 levels instead of 7 (-14 us) for 7 host additions (+3.5 us).
 __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, xyzz_t* __restrict__ partial,
-                                                            unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq, fe_t last, int has_last) {
+                                                            unsigned* __restrict__ ticket, unsigned* __restrict__ slot, unsigned seq, fe_t last, int has_last,
+                                                            unsigned gblocks) {
   __shared__ CoopAdd<128> L;
   __shared__ xyzz_t s[128], s2[128];
   __shared__ unsigned s_last;
@@ -913,18 +917,26 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restri
     const bool active = k < off;
     xyzz_add_block4<128>(L, &s[k], &s[active ? k + off : k], s, role, k, active);
   }
-  if (gridDim.x > 1) {
+  // the group this block joins: all blocks (gblocks == 0) or blocks [g0, g0 + nbg)
+  const unsigned grp = gblocks ? blockIdx.x / gblocks : 0u, g0 = grp * gblocks;
+  const unsigned nbg = gblocks ? (gridDim.x - g0 < gblocks ? gridDim.x - g0 : gblocks) : gridDim.x;
+  if (gblocks) {
+    ticket += grp;
+    slot += 32 * grp;
+    partial += g0;
+  }
+  if (nbg > 1) {
     if (threadIdx.x == 0) {
-      partial[blockIdx.x] = s[0];
+      partial[gblocks ? blockIdx.x - g0 : blockIdx.x] = s[0];
       __threadfence();  // the block sum is visible device-wide before the ticket is taken
-      s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+      s_last = atomicAdd(ticket, 1u) == nbg - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();
     if (role == 0) {
       xyzz_t acc = xyzz_identity();
-      if (k < (int)gridDim.x) {  // other blocks' sums: loads that cannot be served from a stale line of this XCD's caches
+      if (k < (int)nbg) {  // other blocks' sums: loads that cannot be served from a stale line of this XCD's caches
         const unsigned* pw = reinterpret_cast<const unsigned*>(&partial[k]);
         unsigned* aw = reinterpret_cast<unsigned*>(&acc);
 #pragma unroll
@@ -934,8 +946,8 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restri
     }
     __syncthreads();
     // more than 128 block sums: item k first takes in sums k + 128, k + 256, ... (one cooperative addition each), then the tree
-    for (int base = 128; base < (int)gridDim.x; base += 128) {
-      const bool active = base + k < (int)gridDim.x;
+    for (int base = 128; base < (int)nbg; base += 128) {
+      const bool active = base + k < (int)nbg;
       if (role == 0 && active) {
         xyzz_t acc;
         const unsigned* pw = reinterpret_cast<const unsigned*>(&partial[base + k]);
@@ -948,7 +960,7 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_coop(const fe_t* __restri
       xyzz_add_block4<128>(L, &s[k], &s2[k], s, role, k, active);
     }
     int top = 1;
-    const int live = (int)gridDim.x < 128 ? (int)gridDim.x : 128;
+    const int live = (int)nbg < 128 ? (int)nbg : 128;
     while (2 * top < live) top <<= 1;
     for (int off = top; off >= 1; off >>= 1) {
       const bool active = k < off;
