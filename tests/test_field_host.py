@@ -47,3 +47,14 @@ def test_host_keccak_permutation_forms_agree(tmp_path):
     subprocess.run(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-w", "-o", exe, os.path.join(HERE, "native", "keccak_check.hip")], check=True, capture_output=True, timeout=600)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "keccak: 0 mismatches" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_limb_sum_reduction_matches_modular_additions(tmp_path):
+    """fe_from_limb_sums (the one reduction behind the host's limb-wise gathering of up to 64 result slots per round) against a chain of modular additions:
+    1..64 random, all-ones, zero and near-p summands, both fields."""
+    exe = str(tmp_path / "limb_sum_check")
+    subprocess.run(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-w", "-o", exe, os.path.join(HERE, "native", "limb_sum_check.hip")], check=True, capture_output=True, timeout=600)
+    out = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "scalar field: 20000 sums, 0 mismatches" in out.stdout and "base field: 20000 sums, 0 mismatches" in out.stdout
