@@ -676,9 +676,13 @@ static bool round_trace() {
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---- persistent tail (kernels_poly.hpp k_sumcheck_tail): host half of the mailbox ------------------------------------------------------
-// the resident tail takes a sum-check over from tables of 2^15 elements down (at most 2^16: 4 * TAIL_WIDE_Q pairs-of-pairs per block, HOST_SUM_MAX_BLOCKS
+// the resident tail takes a sum-check over from tables of 2^16 elements down (64 blocks: 256 pairs a block in its first step, HOST_SUM_MAX_BLOCKS
 // result slots; sweeps of 2^13 .. 2^16 measured within 5 us of each other, tools/tail_sweep.sh)
-static constexpr size_t TAIL_MAX_LEN = (size_t)1 << 15;
+static const size_t TAIL_MAX_LEN = [] {
+  const char* e = getenv("SPARTAN_TAIL_LOG2");  // A/B: table length from which the resident tail takes over (13 .. 16)
+  const int k = e ? atoi(e) : 16;  // 2^16 since the local regime (round 5): 0.8675 -> 0.8641 ms against 2^15 on one box, outer sum-check -5.6 us
+  return (size_t)1 << (k < 10 ? 10 : (k > 16 ? 16 : k));
+}();
 static bool tail_enabled() { return true; }
 // mailbox line (64-byte aligned, one PCIe read for the device): words 0..7 = challenge, 8 = sequence number it answers, 9 / 10 = two independent
 // check words (sequence + plain sum, sequence * K + position-weighted sum), 11 = the sequence number again, so a poll that straddles the host's
@@ -761,9 +765,13 @@ static bool launch_ahead_ok(sp_ctx* c, size_t table_len) {
   return c->mail_dev && table_len <= ((size_t)1 << 19);
 }
 // result slots (= resident blocks still active) of the evaluation over a table of `len` elements
+// (cubic: at most HOST_SUM_MAX_BLOCKS blocks - a table of twice the pairs they take at TAIL_WIDE_Q_CUBIC each gives every block a first step of twice
+// the share, two passes of its bind phase; the kernel's LDS is sized for that)
 static unsigned tail_blocks(size_t len, bool cubic = false) {
   const size_t q = len / 2, wq = cubic ? spk::TAIL_WIDE_Q_CUBIC : spk::TAIL_WIDE_Q;
-  return q <= wq ? 1u : (unsigned)(q / wq);
+  if (q <= wq) return 1u;
+  const size_t nb = q / wq;
+  return (unsigned)(cubic && nb == 2 * (size_t)spk::HOST_SUM_MAX_BLOCKS ? nb / 2 : nb);
 }
 // Resident blocks occupy their CU (1024 threads) until the host has driven every round. If the tails of several contexts together asked for
 // more blocks than the chip holds, each could sit on CUs the other needs for blocks its host is waiting for: a multi-block tail therefore

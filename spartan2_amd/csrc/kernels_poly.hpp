@@ -1065,7 +1065,8 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   __shared__ slot_chk chk_sh[TAIL_HAND_OVER_MAX_VALS];
   // the elements a step has just bound, for its own evaluation (a block evaluates exactly the pairs it bound): table t at [t * 2 qb, ..), the low
   // elements x = base + e first, then their partners x = q + base + e. They go to memory as well - the next step's bind reads them from there.
-  __shared__ fe_t bound[(CUBIC ? 3 : 2) * 2 * (unsigned)WQ];
+  // (cubic: room for a first step of 2 WQ pairs per block - a launch over twice the pairs its 64 blocks take at WQ each, see tail_blocks in capi_core.hip)
+  __shared__ fe_t bound[(CUBIC ? 3 * 2 : 2) * 2 * (unsigned)WQ];
   const unsigned long long base = (unsigned long long)blockIdx.x * WQ;
   // LOCAL REGIME (while more than one block is active, q > WQ): every block of the launch stays active and owns the pairs whose index y has
   // (y / 4) mod gridDim.x == blockIdx.x - local pair e <-> y = ((e / 4) gridDim.x + blockIdx.x) 4 + e % 4 (128-byte groups). The round's pairings are at
@@ -1186,14 +1187,23 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     // phase A: one bind per lane. New element x takes old x and x + 2q; this block owns x in [base, base + qb) and [q + base, q + base + qb) - in the
     // local regime the x of its sub-table (local_y), whose element e of the step before sits at bound[t * 4 qb + e].
     const unsigned nt = CUBIC ? 3 : 2;
-    if (local) {  // (nt * 2 qb <= TAIL_THREADS: one element per lane, so the in-place LDS update needs one barrier between its reads and its writes)
+    if (local && !from_lds) {  // the launch's first step, from the tables in memory (a share of 2 WQ pairs takes two passes over the lanes)
+      for (unsigned idx = threadIdx.x; idx < nt * 2 * qb; idx += TAIL_THREADS) {
+        const unsigned t = idx / (2 * qb), e = idx % (2 * qb);
+        fe_t* Z = t == 0 ? a.A : (t == 1 ? a.B : a.C);
+        const unsigned long long x = e < qb ? local_y(e) : q + local_y(e - qb);
+        const fe_t v = bind1(Z[x], Z[x + 2 * q], r);
+        bound[idx] = v;
+        if (last_local) Z[x] = v;
+      }
+    } else if (local) {  // (nt * 2 qb <= TAIL_THREADS: one element per lane, so the in-place LDS update needs one barrier between its reads and its writes)
       const unsigned idx = threadIdx.x, t = idx / (2 * qb), e = idx % (2 * qb);
       const bool has = idx < nt * 2 * qb;
       fe_t v = fe_zero();
       fe_t* Z = t == 0 ? a.A : (t == 1 ? a.B : a.C);
       const unsigned long long x = e < qb ? local_y(e) : q + local_y(e - qb);
-      if (has) v = from_lds ? bind1(bound[t * 4 * qb + e], bound[t * 4 * qb + 2 * qb + e], r) : bind1(Z[x], Z[x + 2 * q], r);
-      if (from_lds) __syncthreads();
+      if (has) v = bind1(bound[t * 4 * qb + e], bound[t * 4 * qb + 2 * qb + e], r);
+      __syncthreads();
       if (has) {
         bound[idx] = v;
         if (last_local) Z[x] = v;
