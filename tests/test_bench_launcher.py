@@ -15,7 +15,9 @@ def test_self_launch_reaches_rank_code():
                        timeout=600, env=env)
     assert r.returncode != 0
     text = r.stdout + r.stderr
-    assert "rank 0: bench.py needs 2 MI355X device(s)" in text and "rank 1: bench.py needs 2 MI355X device(s)" in text, text[-2000:]
+    # the launcher ends the other rank as soon as one has failed, so on a cold machine (first `import torch` of a rank takes a minute) only the faster
+    # rank gets to print: one rank's message is the evidence that rank code was reached
+    assert any(f"rank {r}: bench.py needs 2 MI355X device(s)" in text for r in (0, 1)), text[-2000:]
     assert "launch with torch.distributed.run" not in text
 
 
