@@ -1011,11 +1011,24 @@ int sp_eq_table_finish(sp_ctx* c, const uint64_t* r, size_t ell, sp_table* t) {
   const int lo_bits = 10, hi_bits = (int)ell - lo_bits, K = (int)(ell - c->eq_ahead_known);
   SP_HIP(hipStreamWaitEvent(c->stream, c->eq_ev, 0));
   const size_t n_hi = (size_t)1 << hi_bits;
-  spk::EqLastK rk;
-  for (int i = 0; i < 4; ++i) rk.r[i] = i < K ? load_fe(r + 4 * (ell - K + i)) : fe_zero();
+  spk::EqLastK wk;  // the 2^K weights of the last K coordinates, formed here (host products) level by level
+  {
+    const fe_t one = fe_one<S>();
+    wk.w[0] = one;
+    for (int i = 0; i < K; ++i) {
+      const fe_t r_i = load_fe(r + 4 * (ell - K + i));
+      for (int j = (1 << i) - 1; j >= 0; --j) {  // e[2 j + 1] = e[j] r_i, e[2 j] = e[j] - e[2 j + 1]
+        const fe_t y = i == 0 ? r_i : fe_mul<S>(wk.w[j], r_i);
+        wk.w[2 * j] = fe_sub<S>(wk.w[j], y);
+        wk.w[2 * j + 1] = y;
+      }
+    }
+    for (int j = 1 << K; j < 16; ++j) wk.w[j] = fe_zero();
+  }
+  const unsigned blocks = (unsigned)((n_hi + spk::EQ_LASTK_HPB - 1) / spk::EQ_LASTK_HPB) * (1024 / spk::EQ_LASTK_BLOCK);
   c->timed("eq_table", 32ull * total, [&] {
-    hipLaunchKernelGGL(spk::k_eq_outer_lastk, dim3((unsigned)((n_hi + spk::EQ_LASTK_HPB - 1) / spk::EQ_LASTK_HPB)), dim3(1024), 0, c->stream,
-                       c->d_eq_ahead + spk::eq_level_offset(hi_bits), c->d_eq_ahead + ((size_t)1 << 11) + spk::eq_level_offset(lo_bits - K), K, n_hi, rk, t->d);
+    hipLaunchKernelGGL(spk::k_eq_outer_lastk, dim3(blocks), dim3(spk::EQ_LASTK_BLOCK), 0, c->stream, c->d_eq_ahead + spk::eq_level_offset(hi_bits),
+                       c->d_eq_ahead + ((size_t)1 << 11) + spk::eq_level_offset(lo_bits - K), K, n_hi, wk, t->d);
   });
   SP_HIP(hipEventRecord(c->eq_read_ev, c->stream));
   c->eq_read_pending = true;

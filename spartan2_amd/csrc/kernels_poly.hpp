@@ -323,36 +323,30 @@ __global__ void __launch_bounds__(1024) k_eq_levels_pair(EqPairArgs a) {
 }
 // The same table with the LAST K variables (2 <= K <= 4) applied here: T_lo covers only the low variables up to them, so both pyramids can be built K
 // rounds before the sum-check that draws the point ends (K = 4: when its resident kernel hands the last rounds to the host).
-// out[(hi << 10) | lo] = T_hi[hi] (T_lo[lo >> K] e_K[lo & (2^K - 1)]), lo_bits = 10. A block of 1024 threads, thread = lo: the 2^K weights e_K are formed
-// by the first 2^K threads (K - 1 products each) and shared through LDS, every thread forms ITS low factor once (one product) and then walks
-// EQ_LASTK_HPB high entries, one product and one 32-byte store each - 1 + 1 / HPB products per output, every store of a wave 2 KiB contiguous, 256
-// blocks of 16 waves at 2^20 (the two-variable form of round 3 wrote 128 bytes per lane at a 128-byte stride: 18 us for 2^20).
-constexpr int EQ_LASTK_HPB = 4;
+// out[(hi << 10) | lo] = T_hi[hi] (T_lo[lo >> K] e_K[lo & (2^K - 1)]), lo_bits = 10. The 2^K weights e_K arrive BY VALUE (the host forms them: 2^(K+1) - 4
+// products, ~0.5 us, where a block's first 2^K threads spent K - 1 dependent device products and a barrier in front of every other wave: 19.8 -> 16.2 us
+// at 2^20). A block of EQ_LASTK_BLOCK threads = one half of the 1024 low indices, thread = lo: it forms ITS low factor once (one product), then EQ_LASTK_HPB
+// high entries (uniform loads, issued before the first product), one product and one 32-byte store each - 1 + 1 / HPB products per output, every store of
+// a wave 2 KiB contiguous. 512 x 8 measured best of {256, 512, 1024} x {1, 2, 4, 8, 16}: 14.6 us at 2^20, 1.3 us above the same stores without arithmetic
+// (tools/eq_bench.hip, profiles/r05_eq_bench.txt; lane-contiguous 16-byte stores through the wave's LDS: no gain).
+constexpr int EQ_LASTK_HPB = 8;
+constexpr int EQ_LASTK_BLOCK = 512;
 struct EqLastK {
-  fe_t r[4];  // the last K coordinates, in order
+  fe_t w[16];  // e_K[j], j < 2^K: first of the K variables = most significant of the K bits
 };
-__global__ void __launch_bounds__(1024) k_eq_outer_lastk(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqLastK rk,
-                                                         fe_t* __restrict__ out) {
-  __shared__ fe_t wsh[16];
-  const unsigned t = threadIdx.x;
-  if (t < (1u << K)) {
-    const fe_t one = fe_one<S>();
-    fe_t w = one;
-    for (int i = 0; i < K; ++i) {  // first of the K variables = most significant of the K bits
-      const fe_t f = ((t >> (K - 1 - i)) & 1u) ? rk.r[i] : fe_sub<S>(one, rk.r[i]);
-      w = i == 0 ? f : fe_mul<S>(w, f);
-    }
-    wsh[t] = w;
-  }
-  const fe_t tl = t_lo[t >> K];
-  __syncthreads();
-  const fe_t lo = fe_mul<S>(tl, wsh[t & ((1u << K) - 1)]);
-  for (size_t hi = (size_t)blockIdx.x * EQ_LASTK_HPB; hi < n_hi; hi += (size_t)gridDim.x * EQ_LASTK_HPB) {
+__global__ void __launch_bounds__(EQ_LASTK_BLOCK) k_eq_outer_lastk(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqLastK wk,
+                                                                   fe_t* __restrict__ out) {
+  constexpr unsigned SLICES = 1024 / EQ_LASTK_BLOCK;
+  const unsigned t = threadIdx.x + (blockIdx.x % SLICES) * EQ_LASTK_BLOCK;
+  const size_t hi0 = (size_t)(blockIdx.x / SLICES) * EQ_LASTK_HPB;
+  fe_t th[EQ_LASTK_HPB];
 #pragma unroll
-    for (int h = 0; h < EQ_LASTK_HPB; ++h) {
-      if (hi + h >= n_hi) break;
-      out[((hi + h) << 10) + t] = fe_mul<S>(t_hi[hi + h], lo);
-    }
+  for (int h = 0; h < EQ_LASTK_HPB; ++h) th[h] = t_hi[hi0 + h < n_hi ? hi0 + h : 0];
+  const fe_t lo = fe_mul<S>(t_lo[t >> K], wk.w[t & ((1u << K) - 1)]);
+#pragma unroll
+  for (int h = 0; h < EQ_LASTK_HPB; ++h) {
+    if (hi0 + h >= n_hi) break;
+    out[((hi0 + h) << 10) + t] = fe_mul<S>(th[h], lo);
   }
 }
 // out[(hi << lo_bits) | lo] = T_hi[hi] * T_lo[lo]

@@ -1,0 +1,312 @@
+// Experiment harness for the evals_rx outer product (k_eq_outer_lastk: 2^20 outputs = 32 MiB written, one product per output): variants of the block
+// shape and of where the 2^K last-variable weights come from. Prints the best of 20 launches (HIP events) and whether the output equals the library's.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ispartan2_amd/csrc -Iinclude tools/eq_bench.hip -o tools/eq_bench
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "kernels_poly.hpp"
+
+using namespace spk;
+
+template <class L>
+static float time_us(L&& f, int reps) {
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  f();
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int i = 0; i < reps; ++i) {
+    hipEventRecord(a);
+    f();
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    if (ms < best) best = ms;
+  }
+  return best * 1e3f;
+}
+
+// floor: the same stores with no arithmetic
+template <int BLOCK, int HPB>
+__global__ void __launch_bounds__(BLOCK) k_store_only(const fe_t* __restrict__ t_hi, size_t n_hi, fe_t* __restrict__ out) {
+  const unsigned t = threadIdx.x + (blockIdx.x % (1024 / BLOCK)) * BLOCK;
+  const size_t hb = blockIdx.x / (1024 / BLOCK);
+  fe_t v = t_hi[hb & 1023];
+  v.v[0] += t;
+#pragma unroll
+  for (int h = 0; h < HPB; ++h) out[((hb * HPB + h) << 10) + t] = v;
+}
+
+// BLOCK threads = a slice of the 1024 low indices; HPB high entries per block; the 2^K weights formed in the block (WB = false) or passed by value
+// (WB = true: the host forms them, 14 products)
+struct EqW16 {
+  fe_t w[16];
+};
+template <int BLOCK, int HPB, bool WB>
+__global__ void __launch_bounds__(BLOCK) k_var(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqLastK rk, EqW16 wv,
+                                              fe_t* __restrict__ out) {
+  __shared__ fe_t wsh[16];
+  constexpr unsigned SLICES = 1024 / BLOCK;
+  const unsigned t = threadIdx.x + (blockIdx.x % SLICES) * BLOCK;
+  const size_t hb = blockIdx.x / SLICES;
+  fe_t th[HPB];
+#pragma unroll
+  for (int h = 0; h < HPB; ++h) th[h] = t_hi[hb * HPB + h];  // issued before the weights: uniform loads
+  const fe_t tl = t_lo[t >> K];
+  fe_t wk;
+  if (WB) {
+    wk = wv.w[t & ((1u << K) - 1)];
+  } else {
+    if (threadIdx.x < (1u << K)) {
+      const fe_t one = fe_one<S>();
+      fe_t w = one;
+      for (int i = 0; i < K; ++i) {
+        const fe_t f = ((threadIdx.x >> (K - 1 - i)) & 1u) ? rk.r[i] : fe_sub<S>(one, rk.r[i]);
+        w = i == 0 ? f : fe_mul<S>(w, f);
+      }
+      wsh[threadIdx.x] = w;
+    }
+    __syncthreads();
+    wk = wsh[t & ((1u << K) - 1)];
+  }
+  const fe_t lo = fe_mul<S>(tl, wk);
+#pragma unroll
+  for (int h = 0; h < HPB; ++h) out[((hb * HPB + h) << 10) + t] = fe_mul<S>(th[h], lo);
+}
+
+// ---- access-pattern floors: a lane's 32-byte element as two 16-byte accesses at a 32-byte lane stride (AoS: what every table kernel does) against
+// the same bytes moved with lane-contiguous 16-byte accesses (a wave's instruction covers 1 KiB contiguous)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_store_strided(fe_t* __restrict__ out, unsigned seed) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  v4u* o = reinterpret_cast<v4u*>(out + id);
+  const v4u v = {seed, (unsigned)id, seed, seed};
+  o[0] = v;
+  o[1] = v;
+}
+__global__ void __launch_bounds__(256) k_store_coalesced(fe_t* __restrict__ out, unsigned seed) {
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  v4u* o = reinterpret_cast<v4u*>(out + wave * 64);  // the wave's 2 KiB
+  const v4u v = {seed, lane, seed, seed};
+  o[lane] = v;
+  o[64 + lane] = v;
+}
+__global__ void __launch_bounds__(256) k_load_strided(const fe_t* __restrict__ in, unsigned* __restrict__ sink) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const v4u* p = reinterpret_cast<const v4u*>(in + id);
+  const v4u a = p[0], b = p[1];
+  if ((a.x ^ b.y) == 0x13579bdfu) sink[0] = a.z;
+}
+__global__ void __launch_bounds__(256) k_load_coalesced(const fe_t* __restrict__ in, unsigned* __restrict__ sink) {
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  const v4u* p = reinterpret_cast<const v4u*>(in + wave * 64);
+  const v4u a = p[lane], b = p[64 + lane];
+  if ((a.x ^ b.y) == 0x13579bdfu) sink[0] = a.z;
+}
+// the bind's traffic without its arithmetic: out[id] = in[id] ^ in[id + half] over one table (read two, write one), strided and coalesced
+__global__ void __launch_bounds__(256) k_copy_strided(const fe_t* __restrict__ in, size_t half, fe_t* __restrict__ out) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const v4u* p = reinterpret_cast<const v4u*>(in + id);
+  const v4u* q = reinterpret_cast<const v4u*>(in + id + half);
+  const v4u a = p[0], b = p[1], c = q[0], d = q[1];
+  v4u* o = reinterpret_cast<v4u*>(out + id);
+  o[0] = a ^ c;
+  o[1] = b ^ d;
+}
+__global__ void __launch_bounds__(256) k_copy_coalesced(const fe_t* __restrict__ in, size_t half, fe_t* __restrict__ out) {
+  const size_t wave = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const unsigned lane = threadIdx.x & 63;
+  const v4u* p = reinterpret_cast<const v4u*>(in + wave * 64);
+  const v4u* q = reinterpret_cast<const v4u*>(in + half + wave * 64);
+  const v4u a = p[lane], b = p[64 + lane], c = q[lane], d = q[64 + lane];
+  v4u* o = reinterpret_cast<v4u*>(out + wave * 64);
+  o[lane] = a ^ c;
+  o[64 + lane] = b ^ d;
+}
+// a wave's 64 consecutive 32-byte elements stored with lane-contiguous 16-byte stores: transposed through the wave's own 2 KiB of LDS (no block
+// barrier: LDS operations of a wave execute in order)
+__device__ __forceinline__ void wave_store_coalesced(fe_t* __restrict__ wave_out, const fe_t& v, v4u* __restrict__ lds) {
+  const unsigned lane = threadIdx.x & 63;
+  const v4u lo = {v.v[0], v.v[1], v.v[2], v.v[3]}, hi = {v.v[4], v.v[5], v.v[6], v.v[7]};
+  lds[2 * lane] = lo;
+  lds[2 * lane + 1] = hi;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const v4u a = lds[lane], b = lds[64 + lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  v4u* o = reinterpret_cast<v4u*>(wave_out);
+  o[lane] = a;
+  o[64 + lane] = b;
+}
+template <int BLOCK, int HPB>
+__global__ void __launch_bounds__(BLOCK) k_var_c(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqW16 wv, fe_t* __restrict__ out) {
+  __shared__ v4u lds[BLOCK / 64][128];
+  constexpr unsigned SLICES = 1024 / BLOCK;
+  const unsigned t = threadIdx.x + (blockIdx.x % SLICES) * BLOCK;
+  const size_t hb = blockIdx.x / SLICES;
+  fe_t th[HPB];
+#pragma unroll
+  for (int h = 0; h < HPB; ++h) th[h] = t_hi[hb * HPB + h];
+  const fe_t tl = t_lo[t >> K];
+  const fe_t lo = fe_mul<S>(tl, wv.w[t & ((1u << K) - 1)]);
+  const unsigned t0 = t & ~63u;
+#pragma unroll
+  for (int h = 0; h < HPB; ++h) wave_store_coalesced(out + ((hb * HPB + h) << 10) + t0, fe_mul<S>(th[h], lo), lds[threadIdx.x >> 6]);
+}
+__global__ void __launch_bounds__(256) k_cubic_c(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in,
+                                                 int s, lazy9_t* __restrict__ partials) {
+  __shared__ v4u lds[4][128];
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
+  const fe_t a0 = bind1(la0, la2, r), a1 = bind1(la1, la3, r);
+  const fe_t b0 = bind1(lb0, lb2, r), b1 = bind1(lb1, lb3, r);
+  const fe_t c0 = bind1(lc0, lc2, r), c1 = bind1(lc1, lc3, r);
+  const size_t w0 = id & ~(size_t)63;
+  v4u* l = lds[threadIdx.x >> 6];
+  wave_store_coalesced(A + w0, a0, l);
+  wave_store_coalesced(A + w0 + q, a1, l);
+  wave_store_coalesced(B + w0, b0, l);
+  wave_store_coalesced(B + w0 + q, b1, l);
+  wave_store_coalesced(C + w0, c0, l);
+  wave_store_coalesced(C + w0 + q, c1, l);
+  const fe_t w = eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+static void cubic() {
+  for (int logL : {20, 22}) {
+    const size_t L = (size_t)1 << logL, q = L / 4;
+    fe_t *A, *B, *C, *A2, *B2, *C2, *eq, *part;
+    hipMalloc(&A, L * 32); hipMalloc(&B, L * 32); hipMalloc(&C, L * 32);
+    hipMalloc(&A2, L * 32); hipMalloc(&B2, L * 32); hipMalloc(&C2, L * 32);
+    hipMalloc(&eq, 1024 * 32); hipMalloc(&part, (q / 64 + 16) * 96);
+    hipMemset(eq, 0x05, 1024 * 32);
+    fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = 0x01234567u * (i + 1);
+    auto fill = [&] { hipMemset(A, 0x11, L * 32); hipMemset(B, 0x22, L * 32); hipMemset(C, 0x33, L * 32); hipMemset(A2, 0x11, L * 32); hipMemset(B2, 0x22, L * 32); hipMemset(C2, 0x33, L * 32); };
+    lazy9_t* lp = reinterpret_cast<lazy9_t*>(part);
+    const MailRef nomail{nullptr, nullptr, 0u};
+    // equality of one launch on equal inputs
+    fill();
+    hipLaunchKernelGGL((k_bind_eval_cubic_stream<1, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp, nomail);
+    hipLaunchKernelGGL(k_cubic_c, dim3(q / 256), dim3(256), 0, 0, A2, B2, C2, q, r, eq, 10, lp);
+    std::vector<char> x(L * 16), y(L * 16);
+    bool same = true;
+    for (auto pr : {std::make_pair(A, A2), std::make_pair(B, B2), std::make_pair(C, C2)}) {
+      hipMemcpy(x.data(), pr.first, L * 16, hipMemcpyDeviceToHost);
+      hipMemcpy(y.data(), pr.second, L * 16, hipMemcpyDeviceToHost);
+      same = same && memcmp(x.data(), y.data(), L * 16) == 0;
+    }
+    const double bytes = 48.0 * L * 3;
+    for (int rep = 0; rep < 2; ++rep) {
+      float u1 = time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic_stream<1, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp, nomail); }, 20);
+      float u2 = time_us([&] { hipLaunchKernelGGL(k_cubic_c, dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20);
+      printf("L=2^%d cubic stream: library %6.1f us (%5.0f GB/s)   coalesced stores %6.1f us (%5.0f GB/s)  %s\n", logL, u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3, same ? "equal" : "DIFFERENT");
+    }
+    hipFree(A); hipFree(B); hipFree(C); hipFree(A2); hipFree(B2); hipFree(C2); hipFree(eq); hipFree(part);
+  }
+}
+static void floors() {
+  for (int lg : {20, 21, 23}) {
+    const size_t n = (size_t)1 << lg;
+    fe_t *in, *out;
+    unsigned* sink;
+    hipMalloc(&in, n * 32);
+    hipMalloc(&out, n * 32);
+    hipMalloc(&sink, 64);
+    hipMemset(in, 0x5a, n * 32);
+    auto rep = [&](const char* name, double bytes, float us) { printf("2^%d %-40s %7.1f us  %6.0f GB/s\n", lg, name, us, bytes / us / 1e3); };
+    rep("store 32 B/lane, strided (AoS)", 32.0 * n, time_us([&] { hipLaunchKernelGGL(k_store_strided, dim3((unsigned)(n / 256)), dim3(256), 0, 0, out, 7u); }, 20));
+    rep("store 2 x 16 B/lane, lane-contiguous", 32.0 * n, time_us([&] { hipLaunchKernelGGL(k_store_coalesced, dim3((unsigned)(n / 256)), dim3(256), 0, 0, out, 7u); }, 20));
+    rep("load 32 B/lane, strided (AoS)", 32.0 * n, time_us([&] { hipLaunchKernelGGL(k_load_strided, dim3((unsigned)(n / 256)), dim3(256), 0, 0, in, sink); }, 20));
+    rep("load 2 x 16 B/lane, lane-contiguous", 32.0 * n, time_us([&] { hipLaunchKernelGGL(k_load_coalesced, dim3((unsigned)(n / 256)), dim3(256), 0, 0, in, sink); }, 20));
+    rep("read 2 write 1 (bind traffic), strided", 48.0 * n, time_us([&] { hipLaunchKernelGGL(k_copy_strided, dim3((unsigned)(n / 512)), dim3(256), 0, 0, in, n / 2, out); }, 20));
+    rep("read 2 write 1 (bind traffic), lane-contiguous", 48.0 * n, time_us([&] { hipLaunchKernelGGL(k_copy_coalesced, dim3((unsigned)(n / 512)), dim3(256), 0, 0, in, n / 2, out); }, 20));
+    hipFree(in);
+    hipFree(out);
+    hipFree(sink);
+  }
+}
+
+int main() {
+  floors();
+  cubic();
+  const int ell = 20, K = 4, hi_bits = 10;
+  const size_t n_hi = (size_t)1 << hi_bits, total = (size_t)1 << ell;
+  fe_t *thi, *tlo, *out, *ref;
+  hipMalloc(&thi, n_hi * 32);
+  hipMalloc(&tlo, 64 * 32);
+  hipMalloc(&out, total * 32);
+  hipMalloc(&ref, total * 32);
+  std::vector<fe_t> h(n_hi);
+  for (size_t i = 0; i < n_hi; ++i)
+    for (int w = 0; w < 8; ++w) h[i].v[w] = (uint32_t)(0x9e3779b9u * (i * 8 + w + 1)) >> (w == 7 ? 2 : 0);
+  hipMemcpy(thi, h.data(), n_hi * 32, hipMemcpyHostToDevice);
+  hipMemcpy(tlo, h.data() + 100, 64 * 32, hipMemcpyHostToDevice);
+  EqLastK rk;
+  for (int i = 0; i < 4; ++i) rk.r[i] = h[200 + i];
+  EqW16 wv;  // host-formed weights (Montgomery products on the host side of field.hpp)
+  for (unsigned t = 0; t < 16; ++t) {
+    const fe_t one = fe_one<S>();
+    fe_t w = one;
+    for (int i = 0; i < K; ++i) {
+      const fe_t f = ((t >> (K - 1 - i)) & 1u) ? rk.r[i] : fe_sub<S>(one, rk.r[i]);
+      w = i == 0 ? f : fe_mul<S>(w, f);
+    }
+    wv.w[t] = w;
+  }
+  const double bytes = 32.0 * total;
+  std::vector<fe_t> a(total), b(total);
+  auto report = [&](const char* name, float us, bool check) {
+    bool same = true;
+    if (check) {
+      hipMemcpy(b.data(), out, total * 32, hipMemcpyDeviceToHost);
+      same = memcmp(a.data(), b.data(), total * 32) == 0;
+    }
+    printf("%-52s %7.1f us  %6.0f GB/s  %s\n", name, us, bytes / us / 1e3, check ? (same ? "equal" : "DIFFERENT") : "");
+    hipMemset(out, 0, total * 32);
+  };
+  float us = time_us([&] { hipLaunchKernelGGL(k_eq_outer_lastk, dim3((unsigned)(n_hi / EQ_LASTK_HPB)), dim3(1024), 0, 0, thi, tlo, K, n_hi, rk, ref); }, 20);
+  hipMemcpy(a.data(), ref, total * 32, hipMemcpyDeviceToHost);
+  printf("%-52s %7.1f us  %6.0f GB/s\n", "library k_eq_outer_lastk (1024 threads, 4 high/block)", us, bytes / us / 1e3);
+#define RUN(B, H, W)                                                                                                                                 \
+  report("block " #B ", " #H " high/block, weights " #W,                                                                                             \
+         time_us([&] { hipLaunchKernelGGL((k_var<B, H, W>), dim3((unsigned)(n_hi / H * (1024 / B))), dim3(B), 0, 0, thi, tlo, K, n_hi, rk, wv, out); }, 20), \
+         true)
+  RUN(1024, 4, false);
+  RUN(1024, 4, true);
+  RUN(1024, 2, true);
+  RUN(1024, 8, true);
+  RUN(512, 4, true);
+  RUN(512, 8, true);
+  RUN(256, 4, false);
+  RUN(256, 4, true);
+  RUN(256, 8, true);
+  RUN(256, 16, true);
+  RUN(256, 2, true);
+  RUN(256, 1, true);
+#define RUNC(B, H) \
+  report("coalesced stores, block " #B ", " #H " high/block", time_us([&] { hipLaunchKernelGGL((k_var_c<B, H>), dim3((unsigned)(n_hi / H * (1024 / B))), dim3(B), 0, 0, thi, tlo, K, n_hi, wv, out); }, 20), true)
+  RUNC(1024, 4);
+  RUNC(512, 4);
+  RUNC(512, 8);
+  RUNC(256, 4);
+  RUNC(256, 8);
+#define FLOOR(B, H) \
+  report("stores only, block " #B ", " #H " high/block", time_us([&] { hipLaunchKernelGGL((k_store_only<B, H>), dim3((unsigned)(n_hi / H * (1024 / B))), dim3(B), 0, 0, thi, n_hi, out); }, 20), false)
+  FLOOR(1024, 4);
+  FLOOR(256, 4);
+  FLOOR(256, 1);
+  FLOOR(256, 16);
+  return 0;
+}

@@ -76,7 +76,7 @@ def sites(M_):
         ("k_rowmat_vec_tall", None, "PCS::prove L^T W (512 x 2048)", lambda g: 32 * (M_ + 512 + 2048), "reads W once: 32 (rows cols + rows + cols)"),
         ("k_polyabc_short_and_long", None, "bind_and_prepare_poly_ABC", None, "8(d) as the library accounts it: 12 B per nonzero + 32 B per live row of eq(r_x) + 32 B per output column"),
         ("k_spmv3", None, "multiply_vec (incremental: rest columns only)", None, "8(d) as the library accounts it: 12 B per nonzero + 3 x 32 B per row written + witness gathers"),
-        ("k_eq_outer_lastk", None, "evals_rx outer product (pyramids started under the last four rounds)", lambda g: 32 * (4 * g), "grid = entries / 4 (1024 threads per 4096 entries); writes 32 B per entry"),
+        ("k_eq_outer_lastk", None, "evals_rx outer product (pyramids started under the last four rounds)", lambda g: 32 * (8 * g), "grid = entries / 8 (512 threads per 4096 entries); writes 32 B per entry"),
         ("k_round0_products", None, "round-0 products of the outer sum-check (headline driver)", lambda g: 224 * (M_ // 2), "reads Az, Bz, Cz (96 B per row), writes p0, p1 (32 B per row)"),
     ]
 
