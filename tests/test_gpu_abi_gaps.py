@@ -205,7 +205,7 @@ def test_long_absorbs_hashed_on_the_library_thread_equal_the_oracle_transcript(c
     assert (tr2.squeeze(b"z") == want).all() and (tr.squeeze(b"z") == want).all()
 
 
-@pytest.mark.parametrize("ell", [12, 15, 20])
+@pytest.mark.parametrize("ell", [12, 13, 15, 20])  # 2^(ell - 10) high entries: fewer than, exactly and more than one block's eight
 def test_eq_table_begun_two_coordinates_early(ctx, ell):
     """sp_eq_table_begin / _finish (the half tables of the first ell - K coordinates built ahead, K = 2, 3, 4, the last K applied in the one launch
     behind the last challenge) give the table of sp_eq_table; a `_finish` without a `_begin`, or with a different prefix, is the plain call; fewer
