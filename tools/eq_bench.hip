@@ -45,8 +45,11 @@ __global__ void __launch_bounds__(BLOCK) k_store_only(const fe_t* __restrict__ t
 struct EqW16 {
   fe_t w[16];
 };
+struct EqR4 {  // the last K coordinates themselves (the library's form until round 5: a block's first 2^K threads formed the weights)
+  fe_t r[4];
+};
 template <int BLOCK, int HPB, bool WB>
-__global__ void __launch_bounds__(BLOCK) k_var(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqLastK rk, EqW16 wv,
+__global__ void __launch_bounds__(BLOCK) k_var(const fe_t* __restrict__ t_hi, const fe_t* __restrict__ t_lo, int K, size_t n_hi, EqR4 rk, EqW16 wv,
                                               fe_t* __restrict__ out) {
   __shared__ fe_t wsh[16];
   constexpr unsigned SLICES = 1024 / BLOCK;
@@ -184,6 +187,107 @@ __global__ void __launch_bounds__(256) k_cubic_c(fe_t* __restrict__ A, fe_t* __r
   const fe_t tie = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
 }
+// N elements of a wave stored with lane-contiguous 16-byte stores in ONE LDS round trip (N x 2 KiB of LDS per wave): all writes, one wait, all reads, one
+// wait, all global stores
+template <int N>
+__device__ __forceinline__ void wave_store_coalesced_n(fe_t* const (&wave_out)[N], const fe_t (&v)[N], v4u* __restrict__ lds) {
+  const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const v4u lo = {v[k].v[0], v[k].v[1], v[k].v[2], v[k].v[3]}, hi = {v[k].v[4], v[k].v[5], v[k].v[6], v[k].v[7]};
+    lds[128 * k + 2 * lane] = lo;
+    lds[128 * k + 2 * lane + 1] = hi;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  v4u a[N], b[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    a[k] = lds[128 * k + lane];
+    b[k] = lds[128 * k + 64 + lane];
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    v4u* o = reinterpret_cast<v4u*>(wave_out[k]);
+    o[lane] = a[k];
+    o[64 + lane] = b[k];
+  }
+}
+__global__ void __launch_bounds__(256) k_quad_sparse_c(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, size_t hiA, size_t hiB, lazy9_t* __restrict__ partials) {
+  __shared__ v4u lds[4][4 * 128];
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const fe_t la0 = A[id], la1 = A[id + q], lb0 = B[id], lb1 = B[id + q];
+  const fe_t one_minus_r = fe_sub<S>(fe_one<S>(), r);
+  fe_t o[4];
+  o[0] = id < hiA ? bind1(la0, A[id + 2 * q], r) : fe_mul<S>(la0, one_minus_r);
+  o[2] = id < hiB ? bind1(lb0, B[id + 2 * q], r) : fe_mul<S>(lb0, one_minus_r);
+  o[1] = fe_mul<S>(la1, one_minus_r);
+  o[3] = fe_mul<S>(lb1, one_minus_r);
+  const size_t w0 = id & ~(size_t)63;
+  fe_t* const outs[4] = {A + w0, A + w0 + q, B + w0, B + w0 + q};
+  wave_store_coalesced_n<4>(outs, o, lds[threadIdx.x >> 6]);
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(o[0], o[2]))), lazy_wave_sum(lazy_from(fe_mul<S>(fe_sub<S>(o[1], o[0]), fe_sub<S>(o[3], o[2])))), partials);
+}
+__global__ void __launch_bounds__(256) k_quad_c(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, lazy9_t* __restrict__ partials) {
+  __shared__ v4u lds[4][4 * 128];
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  fe_t o[4];
+  o[0] = bind1(la0, la2, r);
+  o[1] = bind1(la1, la3, r);
+  o[2] = bind1(lb0, lb2, r);
+  o[3] = bind1(lb1, lb3, r);
+  const size_t w0 = id & ~(size_t)63;
+  fe_t* const outs[4] = {A + w0, A + w0 + q, B + w0, B + w0 + q};
+  wave_store_coalesced_n<4>(outs, o, lds[threadIdx.x >> 6]);
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(o[0], o[2]))), lazy_wave_sum(lazy_from(fe_mul<S>(fe_sub<S>(o[1], o[0]), fe_sub<S>(o[3], o[2])))), partials);
+}
+__global__ void __launch_bounds__(256) k_cubic_c6(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r, const fe_t* __restrict__ eq_in,
+                                                  int s, lazy9_t* __restrict__ partials) {
+  __shared__ v4u lds[4][6 * 128];
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t mask = ((size_t)1 << s) - 1;
+  const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
+  const fe_t lb0 = B[id], lb1 = B[id + q], lb2 = B[id + 2 * q], lb3 = B[id + 3 * q];
+  const fe_t lc0 = C[id], lc1 = C[id + q], lc2 = C[id + 2 * q], lc3 = C[id + 3 * q];
+  fe_t o[6];
+  o[0] = bind1(la0, la2, r);
+  o[1] = bind1(la1, la3, r);
+  o[2] = bind1(lb0, lb2, r);
+  o[3] = bind1(lb1, lb3, r);
+  o[4] = bind1(lc0, lc2, r);
+  o[5] = bind1(lc1, lc3, r);
+  const size_t w0 = id & ~(size_t)63;
+  fe_t* const outs[6] = {A + w0, A + w0 + q, B + w0, B + w0 + q, C + w0, C + w0 + q};
+  wave_store_coalesced_n<6>(outs, o, lds[threadIdx.x >> 6]);
+  const fe_t w = eq_in[id & mask];
+  const fe_t t0e = fe_sub<S>(fe_mul<S>(o[0], o[2]), o[4]);
+  const fe_t tie = fe_mul<S>(fe_sub<S>(o[1], o[0]), fe_sub<S>(o[3], o[2]));
+  stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
+}
+static void quads() {
+  // the inner sum-check's two streaming binds at config 2: tables of 2^21 (first bind, high halves zero beyond hi) and 2^20
+  const size_t L = (size_t)1 << 21;
+  fe_t *A, *B, *part;
+  hipMalloc(&A, L * 32); hipMalloc(&B, L * 32); hipMalloc(&part, (L / 4 / 64 + 16) * 96);
+  hipMemset(A, 0x11, L * 32); hipMemset(B, 0x22, L * 32);
+  fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = 0x01234567u * (i + 1);
+  lazy9_t* lp = reinterpret_cast<lazy9_t*>(part);
+  const MailRef nomail{nullptr, nullptr, 0u};
+  for (int rep = 0; rep < 2; ++rep) {
+    { const size_t q = L / 4; const double bytes = 32.0 * 8 * q;  // reads 4 q, writes 4 q elements
+      float u1 = time_us([&] { hipLaunchKernelGGL(k_bind_eval_quad_stream_sparse, dim3(q / 256), dim3(256), 0, 0, A, B, q, r, (size_t)1000, (size_t)300, lp, nomail); }, 20);
+      float u2 = time_us([&] { hipLaunchKernelGGL(k_quad_sparse_c, dim3(q / 256), dim3(256), 0, 0, A, B, q, r, (size_t)1000, (size_t)300, lp); }, 20);
+      printf("quad sparse 2^21: library %6.1f us (%5.0f GB/s)   one-trip coalesced stores %6.1f us (%5.0f GB/s)\n", u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3); }
+    { const size_t q = L / 8; const double bytes = 48.0 * 4 * q * 2;
+      float u1 = time_us([&] { hipLaunchKernelGGL(k_bind_eval_quad_stream, dim3(q / 256), dim3(256), 0, 0, A, B, q, r, lp, nomail); }, 20);
+      float u2 = time_us([&] { hipLaunchKernelGGL(k_quad_c, dim3(q / 256), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+      printf("quad 2^20:        library %6.1f us (%5.0f GB/s)   one-trip coalesced stores %6.1f us (%5.0f GB/s)\n", u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3); }
+  }
+  hipFree(A); hipFree(B); hipFree(part);
+}
 static void cubic() {
   for (int logL : {20, 22}) {
     const size_t L = (size_t)1 << logL, q = L / 4;
@@ -211,7 +315,8 @@ static void cubic() {
     for (int rep = 0; rep < 2; ++rep) {
       float u1 = time_us([&] { hipLaunchKernelGGL((k_bind_eval_cubic_stream<1, false>), dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp, nomail); }, 20);
       float u2 = time_us([&] { hipLaunchKernelGGL(k_cubic_c, dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20);
-      printf("L=2^%d cubic stream: library %6.1f us (%5.0f GB/s)   coalesced stores %6.1f us (%5.0f GB/s)  %s\n", logL, u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3, same ? "equal" : "DIFFERENT");
+      float u3 = time_us([&] { hipLaunchKernelGGL(k_cubic_c6, dim3(q / 256), dim3(256), 0, 0, A, B, C, q, r, eq, 10, lp); }, 20);
+      printf("L=2^%d cubic stream: library %6.1f us (%5.0f GB/s)   coalesced stores %6.1f us (%5.0f GB/s)  %s   one LDS trip for the six %6.1f us\n", logL, u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3, same ? "equal" : "DIFFERENT", u3);
     }
     hipFree(A); hipFree(B); hipFree(C); hipFree(A2); hipFree(B2); hipFree(C2); hipFree(eq); hipFree(part);
   }
@@ -241,6 +346,7 @@ static void floors() {
 int main() {
   floors();
   cubic();
+  quads();
   const int ell = 20, K = 4, hi_bits = 10;
   const size_t n_hi = (size_t)1 << hi_bits, total = (size_t)1 << ell;
   fe_t *thi, *tlo, *out, *ref;
@@ -253,7 +359,7 @@ int main() {
     for (int w = 0; w < 8; ++w) h[i].v[w] = (uint32_t)(0x9e3779b9u * (i * 8 + w + 1)) >> (w == 7 ? 2 : 0);
   hipMemcpy(thi, h.data(), n_hi * 32, hipMemcpyHostToDevice);
   hipMemcpy(tlo, h.data() + 100, 64 * 32, hipMemcpyHostToDevice);
-  EqLastK rk;
+  EqR4 rk;
   for (int i = 0; i < 4; ++i) rk.r[i] = h[200 + i];
   EqW16 wv;  // host-formed weights (Montgomery products on the host side of field.hpp)
   for (unsigned t = 0; t < 16; ++t) {
@@ -276,9 +382,11 @@ int main() {
     printf("%-52s %7.1f us  %6.0f GB/s  %s\n", name, us, bytes / us / 1e3, check ? (same ? "equal" : "DIFFERENT") : "");
     hipMemset(out, 0, total * 32);
   };
-  float us = time_us([&] { hipLaunchKernelGGL(k_eq_outer_lastk, dim3((unsigned)(n_hi / EQ_LASTK_HPB)), dim3(1024), 0, 0, thi, tlo, K, n_hi, rk, ref); }, 20);
+  EqLastK lk;
+  for (int t = 0; t < 16; ++t) lk.w[t] = wv.w[t];
+  float us = time_us([&] { hipLaunchKernelGGL(k_eq_outer_lastk, dim3((unsigned)(n_hi / EQ_LASTK_HPB * (1024 / EQ_LASTK_BLOCK))), dim3(EQ_LASTK_BLOCK), 0, 0, thi, tlo, K, n_hi, lk, ref); }, 20);
   hipMemcpy(a.data(), ref, total * 32, hipMemcpyDeviceToHost);
-  printf("%-52s %7.1f us  %6.0f GB/s\n", "library k_eq_outer_lastk (1024 threads, 4 high/block)", us, bytes / us / 1e3);
+  printf("%-52s %7.1f us  %6.0f GB/s\n", "library k_eq_outer_lastk (512 x 8, weights by value)", us, bytes / us / 1e3);
 #define RUN(B, H, W)                                                                                                                                 \
   report("block " #B ", " #H " high/block, weights " #W,                                                                                             \
          time_us([&] { hipLaunchKernelGGL((k_var<B, H, W>), dim3((unsigned)(n_hi / H * (1024 / B))), dim3(B), 0, 0, thi, tlo, K, n_hi, rk, wv, out); }, 20), \
