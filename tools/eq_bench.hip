@@ -267,6 +267,37 @@ __global__ void __launch_bounds__(256) k_cubic_c6(fe_t* __restrict__ A, fe_t* __
   const fe_t tie = fe_mul<S>(fe_sub<S>(o[1], o[0]), fe_sub<S>(o[3], o[2]));
   stream_block_partials(lazy_wave_sum(lazy_from(fe_mul<S>(w, t0e))), lazy_wave_sum(lazy_from(fe_mul<S>(w, tie))), partials);
 }
+// U units of 256 ids per block, every unit's eight loads issued before the first product: unit u's products run while unit u + 1's loads are still in
+// flight and its stores drain under unit u + 1's products (one generation of fewer, fatter waves)
+template <int U, bool FORCE = false>
+__global__ void __launch_bounds__(256) k_quad_units(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, lazy9_t* __restrict__ partials) {
+  const size_t id0 = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+  fe_t la[U][4], lb[U][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t id = id0 + 256 * (size_t)u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      la[u][k] = A[id + k * q];
+      lb[u][k] = B[id + k * q];
+    }
+  }
+  if (FORCE) __builtin_amdgcn_sched_barrier(0);  // the scheduler sinks the later units' loads below the first products otherwise
+  lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t id = id0 + 256 * (size_t)u;
+    const fe_t a0 = bind1(la[u][0], la[u][2], r), a1 = bind1(la[u][1], la[u][3], r);
+    const fe_t b0 = bind1(lb[u][0], lb[u][2], r), b1 = bind1(lb[u][1], lb[u][3], r);
+    A[id] = a0;
+    A[id + q] = a1;
+    B[id] = b0;
+    B[id + q] = b1;
+    l0 = lazy_add(l0, lazy_from(fe_mul<S>(a0, b0)));
+    l1 = lazy_add(l1, lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0))));
+  }
+  stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
+}
 static void quads() {
   // the inner sum-check's two streaming binds at config 2: tables of 2^21 (first bind, high halves zero beyond hi) and 2^20
   const size_t L = (size_t)1 << 21;
@@ -284,7 +315,12 @@ static void quads() {
     { const size_t q = L / 8; const double bytes = 48.0 * 4 * q * 2;
       float u1 = time_us([&] { hipLaunchKernelGGL(k_bind_eval_quad_stream, dim3(q / 256), dim3(256), 0, 0, A, B, q, r, lp, nomail); }, 20);
       float u2 = time_us([&] { hipLaunchKernelGGL(k_quad_c, dim3(q / 256), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
-      printf("quad 2^20:        library %6.1f us (%5.0f GB/s)   one-trip coalesced stores %6.1f us (%5.0f GB/s)\n", u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3); }
+      float u3 = time_us([&] { hipLaunchKernelGGL(k_quad_units<2>, dim3(q / 512), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+      float u4 = time_us([&] { hipLaunchKernelGGL(k_quad_units<3>, dim3(q / 768), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+      float u5 = time_us([&] { hipLaunchKernelGGL(k_quad_units<4>, dim3(q / 1024), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+      float u6 = time_us([&] { hipLaunchKernelGGL((k_quad_units<2, true>), dim3(q / 512), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+      float u7 = time_us([&] { hipLaunchKernelGGL((k_quad_units<4, true>), dim3(q / 1024), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+      printf("quad 2^20:        library %6.1f us (%5.0f GB/s)   one-trip coalesced stores %6.1f us (%5.0f GB/s)   2 / 3 / 4 units per block %6.1f / %6.1f / %6.1f us; loads forced up front, 2 / 4 units %6.1f / %6.1f us\n", u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3, u3, u4, u5, u6, u7); }
   }
   hipFree(A); hipFree(B); hipFree(part);
 }
