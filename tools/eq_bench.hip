@@ -298,6 +298,61 @@ __global__ void __launch_bounds__(256) k_quad_units(fe_t* __restrict__ A, fe_t* 
   }
   stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
 }
+// The same two units with the loads as inline asm (the compiler cannot sink them) and hand-placed waits: all 32 loads of a lane issued first, unit 0's
+// products under unit 1's loads, unit 0's stores under unit 1's products. 128 VGPRs of loaded data: 2 waves per SIMD, 512 blocks = one generation.
+__device__ __forceinline__ v4u gload16(const void* p) {
+  v4u r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ v4u gload16_hi(const void* p) {
+  v4u r;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ fe_t fe_of(const v4u& lo, const v4u& hi) {
+  fe_t f;
+  f.v[0] = lo.x; f.v[1] = lo.y; f.v[2] = lo.z; f.v[3] = lo.w;
+  f.v[4] = hi.x; f.v[5] = hi.y; f.v[6] = hi.z; f.v[7] = hi.w;
+  return f;
+}
+__global__ void __launch_bounds__(256) k_quad_pipe(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r, lazy9_t* __restrict__ partials) {
+  const size_t id0 = (size_t)blockIdx.x * 512 + threadIdx.x;
+  v4u lo[2][8], hi[2][8];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const size_t id = id0 + 256 * (size_t)u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lo[u][k] = gload16(A + id + k * q);
+      hi[u][k] = gload16_hi(A + id + k * q);
+      lo[u][4 + k] = gload16(B + id + k * q);
+      hi[u][4 + k] = gload16_hi(B + id + k * q);
+    }
+  }
+  lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    // unit 0: the 16 loads of unit 1 may still be out; unit 1: everything (its loads and unit 0's stores, which count in vmcnt as well)
+    if (u == 0) {
+      asm volatile("s_waitcnt vmcnt(16)" : "+v"(lo[0][0]), "+v"(lo[0][1]), "+v"(lo[0][2]), "+v"(lo[0][3]), "+v"(lo[0][4]), "+v"(lo[0][5]), "+v"(lo[0][6]), "+v"(lo[0][7]));
+      asm volatile("" : "+v"(hi[0][0]), "+v"(hi[0][1]), "+v"(hi[0][2]), "+v"(hi[0][3]), "+v"(hi[0][4]), "+v"(hi[0][5]), "+v"(hi[0][6]), "+v"(hi[0][7]));
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo[1][0]), "+v"(lo[1][1]), "+v"(lo[1][2]), "+v"(lo[1][3]), "+v"(lo[1][4]), "+v"(lo[1][5]), "+v"(lo[1][6]), "+v"(lo[1][7]));
+      asm volatile("" : "+v"(hi[1][0]), "+v"(hi[1][1]), "+v"(hi[1][2]), "+v"(hi[1][3]), "+v"(hi[1][4]), "+v"(hi[1][5]), "+v"(hi[1][6]), "+v"(hi[1][7]));
+    }
+    const size_t id = id0 + 256 * (size_t)u;
+    const fe_t a0 = bind1(fe_of(lo[u][0], hi[u][0]), fe_of(lo[u][2], hi[u][2]), r), a1 = bind1(fe_of(lo[u][1], hi[u][1]), fe_of(lo[u][3], hi[u][3]), r);
+    const fe_t b0 = bind1(fe_of(lo[u][4], hi[u][4]), fe_of(lo[u][6], hi[u][6]), r), b1 = bind1(fe_of(lo[u][5], hi[u][5]), fe_of(lo[u][7], hi[u][7]), r);
+    A[id] = a0;
+    A[id + q] = a1;
+    B[id] = b0;
+    B[id + q] = b1;
+    l0 = lazy_add(l0, lazy_from(fe_mul<S>(a0, b0)));
+    l1 = lazy_add(l1, lazy_from(fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0))));
+  }
+  stream_block_partials(lazy_wave_sum(l0), lazy_wave_sum(l1), partials);
+}
 static void quads() {
   // the inner sum-check's two streaming binds at config 2: tables of 2^21 (first bind, high halves zero beyond hi) and 2^20
   const size_t L = (size_t)1 << 21;
@@ -320,6 +375,21 @@ static void quads() {
       float u5 = time_us([&] { hipLaunchKernelGGL(k_quad_units<4>, dim3(q / 1024), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
       float u6 = time_us([&] { hipLaunchKernelGGL((k_quad_units<2, true>), dim3(q / 512), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
       float u7 = time_us([&] { hipLaunchKernelGGL((k_quad_units<4, true>), dim3(q / 1024), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+      {  // equality of the asm-pipelined form with the library's on equal inputs, then its time
+        fe_t *A2, *B2;
+        hipMalloc(&A2, L * 32); hipMalloc(&B2, L * 32);
+        hipMemset(A, 0x11, L * 32); hipMemset(B, 0x22, L * 32); hipMemset(A2, 0x11, L * 32); hipMemset(B2, 0x22, L * 32);
+        hipLaunchKernelGGL(k_bind_eval_quad_stream, dim3(q / 256), dim3(256), 0, 0, A, B, q, r, lp, nomail);
+        hipLaunchKernelGGL(k_quad_pipe, dim3(q / 512), dim3(256), 0, 0, A2, B2, q, r, lp);
+        std::vector<char> x(2 * q * 32), y(2 * q * 32);
+        hipMemcpy(x.data(), A, 2 * q * 32, hipMemcpyDeviceToHost); hipMemcpy(y.data(), A2, 2 * q * 32, hipMemcpyDeviceToHost);
+        bool same = memcmp(x.data(), y.data(), 2 * q * 32) == 0;
+        hipMemcpy(x.data(), B, 2 * q * 32, hipMemcpyDeviceToHost); hipMemcpy(y.data(), B2, 2 * q * 32, hipMemcpyDeviceToHost);
+        same = same && memcmp(x.data(), y.data(), 2 * q * 32) == 0;
+        float u8 = time_us([&] { hipLaunchKernelGGL(k_quad_pipe, dim3(q / 512), dim3(256), 0, 0, A, B, q, r, lp); }, 20);
+        printf("quad 2^20: two units, asm loads up front + hand-placed waits %6.1f us  %s\n", u8, same ? "equal" : "DIFFERENT");
+        hipFree(A2); hipFree(B2);
+      }
       printf("quad 2^20:        library %6.1f us (%5.0f GB/s)   one-trip coalesced stores %6.1f us (%5.0f GB/s)   2 / 3 / 4 units per block %6.1f / %6.1f / %6.1f us; loads forced up front, 2 / 4 units %6.1f / %6.1f us\n", u1, bytes / u1 / 1e3, u2, bytes / u2 / 1e3, u3, u4, u5, u6, u7); }
   }
   hipFree(A); hipFree(B); hipFree(part);
