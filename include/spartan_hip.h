@@ -77,6 +77,13 @@ int sp_ctx_mail_stats(sp_ctx* ctx, uint64_t out[5]);
 /* ---- MultilinearPolynomial (src/polys/multilinear.rs:34-164) ------------------------------------- */
 /* MultilinearPolynomial::new / new_with_halves (:62-75). lo_eff/hi_eff = SIZE_MAX for "unknown". */
 int sp_table_from_host(sp_ctx* ctx, const uint64_t* z, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out);
+/* Witness upload in the form the reference's frontend holds it for is_small circuits (machine words, src/bellpepper/r1cs.rs:303-409; msm_small takes them as
+ * such, src/provider/pcs/hyrax_pc.rs:266-292): t[off + i] = vals[i] as a field element for i < cnt - 8 bytes a value cross the bus instead of 32 and the
+ * Montgomery form is produced on the device (one product by R^2 per value that is neither 0 nor 1). Ordered on the context's stream; `vals` is free on return. */
+int sp_table_write_u64(sp_ctx* ctx, sp_table* t, size_t off, const uint64_t* vals, size_t cnt);
+/* the same for a 0/1 witness packed 8 values a byte, value i = bit (i & 7) of bits[i >> 3] (the booleanised form of a SHA-256 / bit-decomposition witness:
+ * 128 KiB for 2^20 values) */
+int sp_table_write_bits(sp_ctx* ctx, sp_table* t, size_t off, const uint8_t* bits, size_t cnt);
 /* zero-filled table of `len` elements with the given zero-structure hints */
 int sp_table_zeros(sp_ctx* ctx, size_t len, size_t lo_eff, size_t hi_eff, sp_table** out);
 /* host -> device write of cnt elements at element offset off */
@@ -243,6 +250,14 @@ int sp_vartime_scalar_mul(sp_ctx* ctx, const uint64_t* points_aff, size_t n, con
  * Call site: comm_LZ of HyraxPCS::prove (hyrax_pc.rs:387-478) as sum_i L_i * comm_W[i] over the row commitments a prepared witness already holds. */
 typedef struct sp_fbtables sp_fbtables;
 int sp_fbtables_create(sp_ctx* ctx, const uint64_t* points_aff, size_t n, sp_fbtables** out);
+/* the same, returning once the build is QUEUED on a lowest-priority stream of the context's own: what a shim's prep_prove (src/spartan.rs:176-216) calls
+ * for the rows it has just committed - the tables are first read at the end of the first prove on the state. sp_fbtables_ready: 1 = built, 0 = still
+ * building (wait != 0: blocks until built), < 0 = error. sp_fbtables_multi_mul* wait by themselves; sp_hyrax_prove_announce_tables does NOT wait - an
+ * opening announced before the tables have landed walks the key's tables instead (same proof). */
+int sp_fbtables_create_async(sp_ctx* ctx, const uint64_t* points_aff, size_t n, sp_fbtables** out);
+int sp_fbtables_ready(const sp_fbtables* t, int wait);
+/* test / diagnostic access: `count` entries (affine points, 8 words each) from entry `first` of the n x 32 x 255 array; entry (i, j, d - 1) = d 2^(8j) point_i */
+int sp_fbtables_read(const sp_fbtables* t, size_t first, size_t count, uint64_t* out);
 void sp_fbtables_free(sp_fbtables* t);
 int sp_fbtables_multi_mul(sp_ctx* ctx, const sp_fbtables* t, const uint64_t* scalars, size_t n, uint64_t out_aff[8]);
 /* the same in two halves: _begin launches, _finish waits for the result (one multiplication in flight per context) */

@@ -224,6 +224,11 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->fb_ev) hipEventDestroy(c->fb_ev);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->stream_tab) {
+    hipStreamSynchronize(c->stream_tab);
+    hipStreamDestroy(c->stream_tab);
+  }
+  if (c->tab_scratch) hipFree(c->tab_scratch);
   if (c->aside_ev) hipEventDestroy(c->aside_ev);
   if (c->aside_main_ev) hipEventDestroy(c->aside_main_ev);
   if (c->stream_eq) hipStreamDestroy(c->stream_eq);
@@ -320,6 +325,56 @@ int sp_table_write_async(sp_ctx* c, sp_table* t, size_t off, const uint64_t* z, 
   memcpy(stage, z, cnt * sizeof(fe_t));
   SP_HIP(hipMemcpyAsync(t->d + off, stage, cnt * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
   SP_HIP(hipEventRecord(c->stage_ev[slot], c->stream));
+  return SP_OK;
+}
+// ---- witness upload as machine words / bits (sp_table_write_u64, sp_table_write_bits) ----------------------------------------------------------------
+namespace {
+// out[i] = vals[i] as a Montgomery-form element: 0 and 1 (almost every entry of a booleanised witness) are constants, anything else one product by R^2
+__global__ void __launch_bounds__(256) k_expand_u64(const uint64_t* __restrict__ vals, size_t n, fe_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t v = vals[i];
+  out[i] = v == 0 ? fe_zero() : (v == 1 ? fe_one<S>() : fe_from_u64<S>(v));
+}
+// out[i] = bit (i & 7) of bits[i >> 3]: a thread expands one byte into eight elements (a wave writes 16 KiB contiguous)
+__global__ void __launch_bounds__(256) k_expand_bits(const uint8_t* __restrict__ bits, size_t n, fe_t* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // element index: lanes write consecutive elements, eight lanes share a byte
+  if (e >= n) return;
+  out[e] = ((bits[e >> 3] >> (e & 7)) & 1u) ? fe_one<S>() : fe_zero();
+}
+}  // namespace
+// device staging of the raw words (grow-only workspace) behind a host -> device copy on the context's stream
+static int upload_raw(sp_ctx* c, const void* src, size_t bytes, void** d_raw) {
+  void* d = c->workspace(sp_ctx::WS_SCALARS_RAW, bytes);
+  if (!d) return SP_ERR_NO_DEVICE;
+  SP_HIP(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, c->stream));
+  *d_raw = d;
+  return SP_OK;
+}
+int sp_table_write_u64(sp_ctx* c, sp_table* t, size_t off, const uint64_t* vals, size_t cnt) {
+  if (!t || off > t->cap || cnt > t->cap - off) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write_u64: range exceeds the table");
+  if (cnt == 0) return SP_OK;
+  if (!vals) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write_u64: null values");
+  void* d_raw = nullptr;
+  int rc = upload_raw(c, vals, cnt * sizeof(uint64_t), &d_raw);
+  if (rc) return rc;
+  c->timed("expand_witness", 40ull * cnt, [&] {
+    hipLaunchKernelGGL(k_expand_u64, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, (const uint64_t*)d_raw, cnt, t->d + off);
+  });
+  SP_HIP(sp::stream_sync(c->stream));  // the caller's buffer is only borrowed, and the staging workspace is shared with the MSM entry points
+  return SP_OK;
+}
+int sp_table_write_bits(sp_ctx* c, sp_table* t, size_t off, const uint8_t* bits, size_t cnt) {
+  if (!t || off > t->cap || cnt > t->cap - off) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write_bits: range exceeds the table");
+  if (cnt == 0) return SP_OK;
+  if (!bits) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_table_write_bits: null values");
+  void* d_raw = nullptr;
+  int rc = upload_raw(c, bits, (cnt + 7) / 8, &d_raw);
+  if (rc) return rc;
+  c->timed("expand_witness", 32ull * cnt, [&] {
+    hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t*)d_raw, cnt, t->d + off);
+  });
+  SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
 int sp_table_zero(sp_ctx* c, sp_table* t, size_t off, size_t cnt) {

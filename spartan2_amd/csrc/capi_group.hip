@@ -389,6 +389,13 @@ int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, 
   return SP_OK;
 }
 
+static bool fbtables_old_build() {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_FBTABLES_OLD");  // "1": the round-5 build (k_fixed_base_tables + one inversion per entry) for A/B runs and the parity test
+    return e && e[0] == '1';
+  }();
+  return on;
+}
 static bool fb_mapped_enabled();
 static int fb_mapped_ensure(sp_ctx* c, int lane);
 // 16-bit window tables of the latency paths (kernels_msm.hpp k_fixed_base_tables16), found by the address of the 8-bit table set they shadow.
@@ -411,17 +418,26 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
   // FixedBaseMul::precompute(., 8) (msm.rs:653-689): always for h; for every base too when the key is narrow (<= 64)
   const size_t ntab = (num_cols <= 64) ? num_cols + 1 : 1;
   const size_t per = 32 * 255;
-  DevBuf tj;
   int rc;
-  if ((rc = tj.alloc(ntab * per * sizeof(jac_t)))) return rc;
+  std::vector<aff_t> hb(ntab);  // the tables' bases: the key's (narrow keys only), then h
+  for (size_t t = 0; t < ntab; ++t) hb[t] = (t + 1 == ntab) ? k->h : load_aff(ck_aff + 8 * t);
+  DevBuf dpts;
+  if ((rc = dpts.alloc(ntab * sizeof(aff_t)))) return rc;
+  SP_HIP(hipMemcpyAsync(dpts.p, hb.data(), ntab * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
   aff_t* tables;
   SP_HIP(hipMalloc((void**)&tables, ntab * per * sizeof(aff_t)));
-  for (size_t t = 0; t < ntab; ++t) {
-    aff_t base = (t + 1 == ntab) ? k->h : load_aff(ck_aff + 8 * t);
-    hipLaunchKernelGGL(spk::k_fixed_base_table, dim3(1), dim3(64), 0, c->stream, base, tj.as<jac_t>() + t * per);
+  if (fbtables_old_build()) {
+    DevBuf tj;
+    if ((rc = tj.alloc(ntab * per * sizeof(jac_t)))) return rc;
+    for (size_t t = 0; t < ntab; ++t) sp::launch_fixed_base_table(c->stream, hb[t], tj.as<jac_t>() + t * per);
+    sp::launch_jac_to_affine(c->stream, tj.as<jac_t>(), ntab * per, tables);
+    SP_HIP(sp::stream_sync(c->stream));
+  } else {  // the three-launch build for all bases at once (capi_bulk.hip launch_window_tables)
+    DevBuf scratch;
+    if ((rc = scratch.alloc(sp::window_tables_scratch(ntab < sp::WT_CHUNK ? ntab : sp::WT_CHUNK)))) return rc;
+    sp::launch_window_tables(c->stream, dpts.as<aff_t>(), ntab, (char*)scratch.p, tables);
+    SP_HIP(sp::stream_sync(c->stream));
   }
-  hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), ntab * per, tables);
-  SP_HIP(sp::stream_sync(c->stream));
   if (fb_mapped_enabled() && ((rc = fb_mapped_ensure(c, 0)) || (rc = fb_mapped_ensure(c, 1)))) return rc;
   k->n_tables = ntab;
   k->h_tables.resize(ntab * per);
@@ -435,15 +451,12 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
   if (fb_mapped_enabled() && fb_window16_enabled()) {
     // the same bases with 16-bit windows (4 MiB per window, 64 MiB per base) for calls of <= 128 scalars: one tree level less per call
     const size_t per16 = (size_t)16 * 65535;
-    DevBuf pts, tj16;
-    if ((rc = pts.alloc(ntab * sizeof(aff_t))) || (rc = tj16.alloc(ntab * per16 * sizeof(jac_t)))) return rc;
-    std::vector<aff_t> hb(ntab);
-    for (size_t t = 0; t < ntab; ++t) hb[t] = (t + 1 == ntab) ? k->h : load_aff(ck_aff + 8 * t);
+    DevBuf tj16, pre16;
+    if ((rc = tj16.alloc(ntab * per16 * sizeof(jac_t))) || (rc = pre16.alloc(ntab * per16 * sizeof(fe_t)))) return rc;
     aff_t* t16 = nullptr;
     SP_HIP(hipMalloc((void**)&t16, ntab * per16 * sizeof(aff_t)));
-    SP_HIP(hipMemcpyAsync(pts.p, hb.data(), ntab * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(spk::k_fixed_base_tables16, dim3((unsigned)(ntab * 16)), dim3(256), 0, c->stream, pts.as<aff_t>(), ntab, tj16.as<jac_t>());
-    hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((ntab * per16 + 255) / 256)), dim3(256), 0, c->stream, tj16.as<jac_t>(), ntab * per16, t16);
+    sp::launch_fixed_base_tables16(c->stream, dpts.as<aff_t>(), ntab, tj16.as<jac_t>());
+    sp::launch_jac_to_affine(c->stream, tj16.as<jac_t>(), ntab * per16, t16, fbtables_old_build() ? nullptr : pre16.as<fe_t>());
     SP_HIP(sp::stream_sync(c->stream));
     k->d_tables16 = t16;
     if (ntab <= 2) {  // host copy for the single multiplications (commitments of one value: eval_W, beta, a blind's term)
@@ -964,16 +977,7 @@ int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_a
   return SP_OK;
 }
 
-// bind_with_delayed (hyrax_pc.rs:38-54) on `st`: the one-launch streaming kernel for tall matrices, else the two-stage form
-static void launch_rowmat_vec(hipStream_t st, const fe_t* poly, size_t rows, size_t cols, const fe_t* dL, fe_t* part, size_t splits, fe_t* dout) {
-  if (rows >= 128 && cols % spk::RMV_COLS == 0) {
-    const size_t l_bytes = rows <= (size_t)spk::RMV_L_MAX ? rows * sizeof(fe_t) : 0;
-    hipLaunchKernelGGL(spk::k_rowmat_vec_tall, dim3((unsigned)(cols / spk::RMV_COLS)), dim3(spk::RMV_THREADS), l_bytes, st, poly, rows, cols, dL, dout);
-    return;
-  }
-  hipLaunchKernelGGL(spk::k_rowmat_vec, dim3((unsigned)((cols + 63) / 64), (unsigned)splits), dim3(256), 0, st, poly, rows, cols, dL, part);
-  hipLaunchKernelGGL(spk::k_sum_columns, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, part, splits, cols, dout);
-}
+using sp::launch_rowmat_vec;  // bind_with_delayed (hyrax_pc.rs:38-54): capi_bulk.hip
 int sp_rowmat_vec(sp_ctx* c, const sp_table* poly, size_t rows, size_t cols, const uint64_t* L, uint64_t* out) {
   if (rows * cols > poly->cap) return fail(SP_ERR_INVALID_INPUT_LENGTH, "bind_with_delayed: poly shorter than rows*cols");
   if (rows == 0 || cols == 0) return SP_OK;
@@ -1428,20 +1432,63 @@ int sp_msm_job_finish(sp_ctx* c, sp_msm_job* job, uint64_t out_aff[8]) { return 
 struct sp_fbtables {
   size_t n = 0;
   aff_t* d_tables = nullptr;  // n x 32 x 255 affine multiples
+  // sp_fbtables_create_async: the build is queued on the context's table stream; `ready_ev` is recorded behind it and `ready` remembers that it was seen
+  int device = 0;
+  hipEvent_t ready_ev = nullptr;
+  mutable std::atomic<int> ready{1};
+  aff_t* d_points = nullptr;        // the bases on the device (the build's input; freed with the tables)
+  std::vector<aff_t> h_points;      // the source of their (possibly still running) upload
 };
-// one 32 x 255 table of affine multiples per point (FixedBaseMul::precompute, msm.rs:653-689, for every point), built on the main stream
+// the context's table stream (lowest priority: a build runs beside whatever the context proves) and its grow-only scratch
+static int table_stream_scratch(sp_ctx* c, size_t bytes, char** scratch) {
+  if (!c->stream_tab) {
+    int lo = 0, hi = 0;
+    SP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    SP_HIP(hipStreamCreateWithPriority(&c->stream_tab, hipStreamNonBlocking, lo));
+  }
+  if (bytes > c->tab_scratch_bytes) {
+    SP_HIP(sp::stream_sync(c->stream_tab));  // a build still running reads the old scratch
+    if (c->tab_scratch) hipFree(c->tab_scratch);
+    c->tab_scratch = nullptr;
+    c->tab_scratch_bytes = 0;
+    SP_HIP(hipMalloc(&c->tab_scratch, bytes));
+    c->tab_scratch_bytes = bytes;
+  }
+  *scratch = (char*)c->tab_scratch;
+  return SP_OK;
+}
 static int build_window_tables(sp_ctx* c, const aff_t* host_points, size_t n, aff_t** out_tables) {
   const size_t per = 32 * 255;
-  DevBuf pts, tj;
-  int rc;
-  if ((rc = pts.alloc(n * sizeof(aff_t))) || (rc = tj.alloc(n * per * sizeof(jac_t)))) return rc;
   aff_t* tables = nullptr;
+  if (fbtables_old_build()) {
+    DevBuf pts, tj;
+    int rc;
+    if ((rc = pts.alloc(n * sizeof(aff_t))) || (rc = tj.alloc(n * per * sizeof(jac_t)))) return rc;
+    SP_HIP(hipMalloc((void**)&tables, n * per * sizeof(aff_t)));
+    hipError_t e = hipMemcpyAsync(pts.p, host_points, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      sp::launch_fixed_base_tables(c->stream, pts.as<aff_t>(), n, tj.as<jac_t>());
+      sp::launch_jac_to_affine(c->stream, tj.as<jac_t>(), n * per, tables);
+      e = sp::stream_sync(c->stream);
+    }
+    if (e != hipSuccess) {
+      hipFree(tables);
+      return fail(SP_ERR_NO_DEVICE, std::string("window tables: ") + hipGetErrorString(e));
+    }
+    *out_tables = tables;
+    return SP_OK;
+  }
+  std::lock_guard<std::mutex> lk(c->tab_mu);
+  char* scratch = nullptr;
+  int rc = table_stream_scratch(c, sp::window_tables_scratch(n < sp::WT_CHUNK ? n : sp::WT_CHUNK), &scratch);
+  if (rc) return rc;
+  DevBuf pts;
+  if ((rc = pts.alloc(n * sizeof(aff_t)))) return rc;
   SP_HIP(hipMalloc((void**)&tables, n * per * sizeof(aff_t)));
-  hipError_t e = hipMemcpyAsync(pts.p, host_points, n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream);
+  hipError_t e = hipMemcpy(pts.p, host_points, n * sizeof(aff_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(spk::k_fixed_base_tables, dim3((unsigned)n), dim3(64), 0, c->stream, pts.as<aff_t>(), n, tj.as<jac_t>());
-    hipLaunchKernelGGL(spk::k_jac_to_affine, dim3((unsigned)((n * per + 255) / 256)), dim3(256), 0, c->stream, tj.as<jac_t>(), n * per, tables);
-    e = sp::stream_sync(c->stream);
+    sp::launch_window_tables(c->stream_tab, pts.as<aff_t>(), n, scratch, tables);
+    e = sp::stream_sync(c->stream_tab);
   }
   if (e != hipSuccess) {
     hipFree(tables);
@@ -1458,14 +1505,68 @@ int sp_fbtables_create(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtab
   if ((erc = build_window_tables(c, reinterpret_cast<const aff_t*>(points_aff), n, &tables))) return erc;
   sp_fbtables* t = new sp_fbtables();
   t->n = n;
+  t->device = c->device;
   t->d_tables = tables;
   *out = t;
   return SP_OK;
 }
+// The same, returning as soon as the build is QUEUED (on the context's lowest-priority table stream, beside whatever else the context runs): the tables of a
+// prepared witness's row commitments are first read at the end of the first prove on it, ~2 ms of device work that prep_prove need not wait for.
+// sp_fbtables_ready tells (or waits); every entry point that takes tables waits by itself, so a caller that never asks stays correct.
+int sp_fbtables_create_async(sp_ctx* c, const uint64_t* points_aff, size_t n, sp_fbtables** out) {
+  if (fbtables_old_build()) return sp_fbtables_create(c, points_aff, n, out);
+  if (n == 0 || n > 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_create_async: 1 .. 4096 points");
+  int rc = sp::multi_mul_ensure(c, 1);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(c->tab_mu);
+  char* scratch = nullptr;
+  if ((rc = table_stream_scratch(c, sp::window_tables_scratch(n < sp::WT_CHUNK ? n : sp::WT_CHUNK), &scratch))) return rc;
+  std::unique_ptr<sp_fbtables> t(new sp_fbtables());
+  t->n = n;
+  t->device = c->device;
+  t->h_points.assign(reinterpret_cast<const aff_t*>(points_aff), reinterpret_cast<const aff_t*>(points_aff) + n);
+  hipError_t e = hipMalloc((void**)&t->d_points, n * sizeof(aff_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&t->d_tables, n * 32 * 255 * sizeof(aff_t));
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&t->ready_ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->d_points, t->h_points.data(), n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream_tab);
+  if (e == hipSuccess) {
+    sp::launch_window_tables(c->stream_tab, t->d_points, n, scratch, t->d_tables);
+    e = hipEventRecord(t->ready_ev, c->stream_tab);
+  }
+  if (e != hipSuccess) {
+    sp_fbtables_free(t.release());
+    return fail(SP_ERR_NO_DEVICE, std::string("sp_fbtables_create_async: ") + hipGetErrorString(e));
+  }
+  t->ready.store(0, std::memory_order_release);
+  *out = t.release();
+  return SP_OK;
+}
+int sp_fbtables_ready(const sp_fbtables* t, int wait) {
+  if (!t) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_ready: null tables");
+  if (t->ready.load(std::memory_order_acquire)) return 1;
+  hipError_t e = wait ? sp::event_sync(t->ready_ev) : hipEventQuery(t->ready_ev);
+  if (e == hipErrorNotReady) return 0;
+  if (e != hipSuccess) return fail(SP_ERR_NO_DEVICE, std::string("sp_fbtables_ready: ") + hipGetErrorString(e));
+  t->ready.store(1, std::memory_order_release);
+  return 1;
+}
 void sp_fbtables_free(sp_fbtables* t) {
   if (!t) return;
+  if (t->ready_ev) {
+    if (!t->ready.load(std::memory_order_acquire)) sp::event_sync(t->ready_ev);  // the build writes d_tables and reads d_points / the host copy until then
+    hipEventDestroy(t->ready_ev);
+  }
   if (t->d_tables) hipFree(t->d_tables);
+  if (t->d_points) hipFree(t->d_points);
   delete t;
+}
+// test / diagnostic access: `count` table entries (affine points, 64 bytes each) starting at entry `first` of the n x 32 x 255 array
+int sp_fbtables_read(const sp_fbtables* t, size_t first, size_t count, uint64_t* out) {
+  if (!t || !out || first + count > t->n * 32 * 255) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_read: range outside the tables");
+  int r = sp_fbtables_ready(t, 1);
+  if (r < 0) return r;
+  SP_HIP(hipMemcpy(out, t->d_tables + first, count * sizeof(aff_t), hipMemcpyDeviceToHost));
+  return SP_OK;
 }
 }  // extern "C"
 namespace sp {
@@ -1662,6 +1763,7 @@ extern "C" {
 // _begin launches on the auxiliary stream, _finish polls (one multiplication in flight per context and lane).
 int sp_fbtables_multi_mul_begin(sp_ctx* c, const sp_fbtables* t, const uint64_t* scalars, size_t n) {
   if (n != t->n) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul: one scalar per table");
+  if (int r = sp_fbtables_ready(t, 1); r < 0) return r;  // (tables of sp_fbtables_create_async whose build has not ended: waited for here)
   return sp::multi_mul_launch(c, 1, t->d_tables, scalars, n, nullptr, nullptr, nullptr, 0);
 }
 // the same walk with its scalars one level short of eq(r, .): P = eq(r_1 .. r_(k-1), .) (ceil(nfixed / 2) entries), S0 | S1 (h's scalar is S0 + r_k (S1 - S0))
@@ -1671,6 +1773,7 @@ int sp_fbtables_multi_mul_begin_eq(sp_ctx* c, const sp_fbtables* t, const uint64
   const size_t n = nfixed + 1, np = n / 2;
   if (n != t->n || nfixed == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul_begin_eq: one table per fixed row and one of h");
   if (n >= sp::multi_mul_wide_min()) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fbtables_multi_mul_begin_eq: at most 1022 fixed rows");
+  if (int r = sp_fbtables_ready(t, 1); r < 0) return r;
   std::vector<fe_t> buf(np + 2);
   memcpy(buf.data(), P, np * sizeof(fe_t));
   memcpy(buf.data() + np, S01, 2 * sizeof(fe_t));
@@ -1998,7 +2101,8 @@ static int announce_impl(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_a
   S->dvec.resize(cols);
   S->r_delta = fe_from_uniform<spk::SF>(S->rng.data() + 64 * cols);
   S->bfold = S->blind;
-  if (row_tables && nfixed >= 1 && nfixed + 1 <= 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS) {
+  // (tables still being built - sp_fbtables_create_async a moment ago - are not waited for: this opening takes the walk over the key instead)
+  if (row_tables && nfixed >= 1 && nfixed + 1 <= 4 * (size_t)spk::MULTI_MUL_MAX_BLOCKS && sp_fbtables_ready(row_tables, 0) == 1) {
     S->row_tables = row_tables->d_tables;
     S->nfixed = nfixed;
     S->zfold = S->blind;

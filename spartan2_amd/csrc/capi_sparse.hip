@@ -89,15 +89,39 @@ struct Spmv3Args {
   const fe_t* base[3];  // cached products to add (nullptr for a plain multiply_vec)
   fe_t* out[3];
 };
+// One lane per row, four entries in flight (gather_major_x4). A row longer than SPMV_LONG_ROW entries - the 32-bit additions of a SHA-256 round: ~6000 rows of
+// 33 .. 225 entries among 880 K of one to three at config 2 - would keep its wave waiting on one lane's chain of dependent (index, then element) loads
+// (the per-wave longest rows of A sum to 958 K such steps against 2 M entries in all: 0.75 ms for the cached product of prep_prove): those are walked by
+// the whole wave, an entry per lane, and added with a shuffle tree; the owner lane keeps the sum.
+constexpr unsigned SPMV_LONG_ROW = 24;
 __global__ void __launch_bounds__(256) k_spmv3(Spmv3Args a, const fe_t* __restrict__ z, size_t nrows) {
   const int which = blockIdx.y;
   const SplitDev m = a.m[which];
   const fe_t* base = a.base[which];
   fe_t* out = a.out[which];
-  for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
-    fe_t acc = gather_major(m, row, z, 0, 1);
-    if (base) acc = fe_add<S>(acc, base[row]);
-    out[row] = acc;
+  const unsigned lane = threadIdx.x & 63u;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t wbase = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < nrows; wbase += stride) {  // (uniform over a wave)
+    const size_t row = wbase + lane;
+    const bool valid = row < nrows;
+    bool is_long = false;
+    fe_t acc = fe_zero();
+    if (valid) {
+      is_long = (m.sptr[row + 1] - m.sptr[row]) + (m.gptr[row + 1] - m.gptr[row]) > SPMV_LONG_ROW;
+      if (!is_long) acc = gather_major_x4(m, row, z);
+    }
+    unsigned long long pending = __ballot(is_long);
+    while (pending) {
+      const int owner = __ffsll((long long)pending) - 1;
+      pending &= pending - 1;
+      const size_t r = wbase + (size_t)owner;
+      const fe_t part = wave_sum(gather_major(m, r, z, lane, 64));
+      if ((int)lane == owner) acc = part;
+    }
+    if (valid) {
+      if (base) acc = fe_add<S>(acc, base[row]);
+      out[row] = acc;
+    }
   }
 }
 

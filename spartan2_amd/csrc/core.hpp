@@ -211,6 +211,12 @@ struct sp_ctx {
   unsigned long long msm_jobs_issued[2] = {0, 0};
   hipEvent_t msm_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // completion event of the MSM job in each landing slot
   hipStream_t stream3 = nullptr;     // second auxiliary stream (sp_rowmat_vec_eq_begin), created on first use
+  // window-table builds (capi_group.hip launch_window_tables): a lowest-priority stream of their own and its grow-only scratch; tab_mu orders the
+  // enqueueing threads (the stream orders the builds, which share the scratch)
+  hipStream_t stream_tab = nullptr;
+  void* tab_scratch = nullptr;
+  size_t tab_scratch_bytes = 0;
+  std::mutex tab_mu;
   void* h_pinned_vec = nullptr;      // pinned landing buffer of sp_rowmat_vec_eq jobs, grow-only
   size_t h_pinned_vec_bytes = 0, h_pinned_vec_cols = 0;
   unsigned vec_seq = 0;  // sequence number of sp_rowmat_vec_eq_finish_scaled's arrival flags

@@ -57,6 +57,15 @@ struct DevBuf {  // RAII device allocation
 
 
 namespace sp {
+// capi_bulk.hip (default scheduler): FixedBaseMul::precompute, Curve::batch_normalize and bind_with_delayed launchers
+static const size_t WT_CHUNK = 1024;  // bases per pass of launch_window_tables
+void launch_fixed_base_table(hipStream_t st, const aff_t& base, jac_t* table_jac);
+void launch_fixed_base_tables(hipStream_t st, const aff_t* d_bases, size_t n, jac_t* table_jac);
+void launch_fixed_base_tables16(hipStream_t st, const aff_t* d_bases, size_t n, jac_t* table_jac);
+void launch_jac_to_affine(hipStream_t st, const jac_t* in, size_t n, aff_t* out, fe_t* pre = nullptr);
+size_t window_tables_scratch(size_t nb);
+void launch_window_tables(hipStream_t st, const aff_t* d_points, size_t n, char* scratch, aff_t* tables);
+void launch_rowmat_vec(hipStream_t st, const fe_t* poly, size_t rows, size_t cols, const fe_t* dL, fe_t* part, size_t splits, fe_t* dout);
 // capi_group.hip: one-launch table-walk MSM (k_multi_mul_coop) on lane 0 (main stream) or 1 (auxiliary stream), and the window tables of a key
 int multi_mul_ensure(sp_ctx* c, int lane);
 size_t multi_mul_wide_min();

@@ -650,72 +650,8 @@ __global__ void __launch_bounds__(256) k_msm_binary_rows(const fe_t* __restrict_
   if (threadIdx.x == 0) out[row] = xyzz_to_jac(s[0]);
 }
 
-// ---- K12: fixed-base multiples of h --------------------------------------------------------------------------------------
-// table[j*255 + d-1] = d * 2^(8j) * h (affine). Stage 1: thread j builds its window's 255 Jacobian multiples.
-__global__ void k_fixed_base_table(aff_t h, jac_t* __restrict__ table_jac) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= 32) return;
-  jac_t base = jac_from_affine(h);
-  for (int k = 0; k < 8 * j; ++k) base = jac_dbl(base);
-  jac_t acc = base;
-  table_jac[(size_t)j * 255] = acc;
-  for (int d = 1; d < 255; ++d) {
-    acc = jac_add(acc, base);
-    table_jac[(size_t)j * 255 + d] = acc;
-  }
-}
-// the same for many bases in one launch: block b builds the 32 window rows of bases[b] (FixedBaseMul::precompute for every row commitment of a
-// prepared witness: sp_fbtables_create)
-__global__ void k_fixed_base_tables(const aff_t* __restrict__ bases, size_t n, jac_t* __restrict__ table_jac) {
-  const size_t b = blockIdx.x;
-  const int j = threadIdx.x;
-  if (b >= n || j >= 32) return;
-  jac_t base = jac_from_affine(bases[b]);
-  for (int k = 0; k < 8 * j; ++k) base = jac_dbl(base);
-  jac_t* row = table_jac + (b * 32 + (size_t)j) * 255;
-  jac_t acc = base;
-  row[0] = acc;
-  for (int d = 1; d < 255; ++d) {
-    acc = jac_add(acc, base);
-    row[d] = acc;
-  }
-}
-// FixedBaseMul tables with 16-bit windows for the latency paths (a round commitment of the ZK verifier circuit: 16 table entries per scalar and a
-// four-level tree instead of 32 and five): table[(b * 16 + w) * 65535 + d - 1] = d * 2^(16 w) * bases[b]. One 256-thread block per (base, window):
-// thread 0 walks the 255 giant steps k * 256 * G, then thread t fills multiples 256 t + 1 .. 256 t + 255 from its giant step (~510 dependent
-// additions in all; the 65535 multiples of a window would take a single thread 0.8 s).
-__global__ void __launch_bounds__(256) k_fixed_base_tables16(const aff_t* __restrict__ bases, size_t n, jac_t* __restrict__ table_jac) {
-  const size_t b = blockIdx.x / 16;
-  const int w = blockIdx.x % 16;
-  if (b >= n) return;
-  jac_t* row = table_jac + ((size_t)b * 16 + (size_t)w) * 65535;
-  __shared__ jac_t G_sh;
-  if (threadIdx.x == 0) {
-    jac_t G = jac_from_affine(bases[b]);
-    for (int k = 0; k < 16 * w; ++k) G = jac_dbl(G);
-    G_sh = G;
-    jac_t step = G;
-    for (int k = 0; k < 8; ++k) step = jac_dbl(step);  // 256 G
-    jac_t acc = step;
-    row[256 - 1] = acc;  // multiple 256
-    for (int t = 2; t < 256; ++t) {
-      acc = jac_add(acc, step);
-      row[(size_t)256 * t - 1] = acc;  // multiple 256 t
-    }
-  }
-  __syncthreads();  // (global writes of thread 0 are read back below by the other threads of this block)
-  __threadfence_block();
-  const jac_t G = G_sh;
-  const int t = threadIdx.x;
-  jac_t acc = t == 0 ? jac_identity() : row[(size_t)256 * t - 1];
-  for (int d = 1; d < 256; ++d) {
-    acc = t == 0 && d == 1 ? G : jac_add(acc, G);
-    row[(size_t)256 * t + d - 1] = acc;  // multiple 256 t + d
-  }
-}
-__global__ void __launch_bounds__(256) k_jac_to_affine(const jac_t* __restrict__ in, size_t n, aff_t* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = jac_to_affine(in[i]);
-}
+// (K12, FixedBaseMul::precompute for one and for many bases, Curve::batch_normalize: kernels_bulk.hpp / capi_bulk.hip - throughput kernels, compiled without
+// this translation unit's max-ilp scheduling, under which they spill)
 // One 32-lane half-wave per scalar: lane j adds table[j][byte j], then a 5-level tree.
 // `tables` holds ntables consecutive 32*255-entry tables; scalar idx uses table idx % ntables.
 __global__ void __launch_bounds__(256) k_fixed_base_rows(const fe_t* __restrict__ scalars, size_t n, const aff_t* __restrict__ tables, size_t ntables,
@@ -1068,83 +1004,6 @@ __global__ void __launch_bounds__(4 * 128) k_multi_mul_wide(const fe_t* __restri
   }
 }
 
-// ---- K9: LZ[i] = sum_j L[j] * poly[j*cols + i] ---------------------------------------------------------------------------
-// grid = (cols/64, row_splits): each block handles 64 columns x a slice of rows with 256 threads = 4 row-lanes per column.
-__global__ void __launch_bounds__(256) k_rowmat_vec(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L,
-                                                    fe_t* __restrict__ partial /* [row_splits][cols] */) {
-  __shared__ fe_t s[256];
-  const size_t col = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;  // 0..3
-  const size_t splits = gridDim.y, per = (rows + splits - 1) / splits;
-  const size_t r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
-  fe_t acc = fe_zero();
-  if (col < cols)
-    for (size_t r = r0 + rl; r < r1; r += 4) acc = fe_add<SF>(acc, fe_mul<SF>(L[r], poly[r * cols + col]));
-  s[threadIdx.x] = acc;
-  __syncthreads();
-  if (rl == 0 && col < cols) {
-    fe_t t = fe_add<SF>(fe_add<SF>(s[threadIdx.x], s[threadIdx.x + 64]), fe_add<SF>(s[threadIdx.x + 128], s[threadIdx.x + 192]));
-    partial[(size_t)blockIdx.y * cols + col] = t;
-  }
-}
-// Streaming form for tall matrices (rows >= 128: 512 x 2048 at BASELINE config 2, a pure 32 MiB read — hyrax_pc.rs:38-54): ONE launch, no partials.
-// A block of 512 threads owns RMV_COLS = 8 adjacent columns: lane = (row-lane 0..7, column 0..7), so a wave reads eight 256-byte row segments per pass
-// and the 8 waves cover 64 rows; L sits in LDS (a row's weight is read right before its product instead of being held), every lane keeps a modular sum
-// of its rows' products, the eight row-lanes of a wave and then the eight waves are combined as lazy 9-word sums (shuffles, LDS) with one reduction per
-// column. cols / 8 blocks (256 at config 2: one per CU). 512 threads and not 1024: at 128 VGPRs the four loads in flight + the product's temporaries
-// spilled 31 registers (104 B of scratch per lane = 26 MB of writes for a 33 MB read: PMC WRITE_SIZE of profiles/r04_kernel_stats.md).
-constexpr int RMV_COLS = 8;
-constexpr int RMV_THREADS = 512;
-constexpr int RMV_ROWS_PER_PASS = RMV_THREADS / RMV_COLS;  // 64
-constexpr int RMV_L_MAX = 1024;                            // rows whose weights fit the block's LDS copy (32 KiB); taller matrices read L from memory
-__global__ void __launch_bounds__(RMV_THREADS) k_rowmat_vec_tall(const fe_t* __restrict__ poly, size_t rows, size_t cols, const fe_t* __restrict__ L, fe_t* __restrict__ out) {
-  __shared__ lazy9_t sm[RMV_THREADS / 64][RMV_COLS];
-  extern __shared__ fe_t sL[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & (RMV_COLS - 1), rl = lane >> 3;
-  const size_t col = (size_t)blockIdx.x * RMV_COLS + c;
-  const bool l_in_lds = rows <= (size_t)RMV_L_MAX;
-  if (l_in_lds) {
-    for (size_t r = threadIdx.x; r < rows; r += RMV_THREADS) sL[r] = L[r];
-    __syncthreads();
-  }
-  const fe_t* Lp = l_in_lds ? sL : L;
-  fe_t acc = fe_zero();
-  if (col < cols) {
-    constexpr size_t P = RMV_ROWS_PER_PASS;
-    size_t r = (size_t)wave * 8 + rl;
-    for (; r + 3 * P < rows; r += 4 * P) {  // four loads in flight per lane
-      const fe_t a0 = poly[r * cols + col], a1 = poly[(r + P) * cols + col], a2 = poly[(r + 2 * P) * cols + col], a3 = poly[(r + 3 * P) * cols + col];
-      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r], a0));
-      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r + P], a1));
-      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r + 2 * P], a2));
-      acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r + 3 * P], a3));
-    }
-    for (; r < rows; r += P) acc = fe_add<SF>(acc, fe_mul<SF>(Lp[r], poly[r * cols + col]));
-  }
-  lazy9_t t = lazy_from(acc);
-#pragma unroll
-  for (int m = 32; m >= 8; m >>= 1) {
-    lazy9_t o;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o.v[i] = __shfl_xor(t.v[i], m, 64);
-    t = lazy_add(t, o);
-  }
-  if (rl == 0) sm[wave][c] = t;
-  __syncthreads();
-  if (threadIdx.x < RMV_COLS && col < cols) {
-    lazy9_t s = sm[0][threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < RMV_THREADS / 64; ++w) s = lazy_add(s, sm[w][threadIdx.x]);
-    out[col] = lazy_reduce(s);
-  }
-}
-__global__ void __launch_bounds__(256) k_sum_columns(const fe_t* __restrict__ partial, size_t splits, size_t cols, fe_t* __restrict__ out) {
-  const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= cols) return;
-  fe_t acc = partial[col];
-  for (size_t s = 1; s < splits; ++s) acc = fe_add<SF>(acc, partial[s * cols + col]);
-  out[col] = acc;
-}
+// (K9, bind_with_delayed: kernels_bulk.hpp)
 
 }  // namespace spk

@@ -173,6 +173,17 @@ class Table:
         z = np.ascontiguousarray(z, dtype=np.uint64).reshape(-1, 4)
         check(lib().sp_table_write(self.ctx.h, self.h, ctypes.c_size_t(off), p64(z), ctypes.c_size_t(z.shape[0])))
 
+    def write_u64(self, off, vals):
+        """sp_table_write_u64: machine words in, Montgomery-form elements formed on the device (the is_small witness path)"""
+        vals = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1)
+        check(lib().sp_table_write_u64(self.ctx.h, self.h, ctypes.c_size_t(off), p64(vals) if len(vals) else None, ctypes.c_size_t(len(vals))))
+
+    def write_bits(self, off, bits, cnt):
+        """sp_table_write_bits: cnt 0/1 values packed 8 a byte (value i = bit i & 7 of byte i >> 3)"""
+        bits = np.ascontiguousarray(bits, dtype=np.uint8).reshape(-1)
+        assert len(bits) * 8 >= cnt
+        check(lib().sp_table_write_bits(self.ctx.h, self.h, ctypes.c_size_t(off), bits.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)) if len(bits) else None, ctypes.c_size_t(cnt)))
+
     def set_len(self, n, lo_eff=SIZE_MAX, hi_eff=SIZE_MAX):
         """logical length + MultilinearPolynomial::new_with_halves bounds (src/polys/multilinear.rs:62-76)"""
         check(lib().sp_table_set_len(self.h, ctypes.c_size_t(n), ctypes.c_size_t(lo_eff), ctypes.c_size_t(hi_eff)))
@@ -528,11 +539,25 @@ class CommitmentKey:
 class FixedBaseTables:
     """FixedBaseMul::precompute over n <= 512 points + multi_mul in one launch (src/provider/msm.rs:637-773): sp_fbtables_*."""
 
-    def __init__(self, ctx: Context, points):
+    def __init__(self, ctx: Context, points, queued=False):
+        """queued: sp_fbtables_create_async - returns once the build is queued on the context's table stream (ready() tells / waits)"""
         points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
         self.ctx, self.n = ctx, points.shape[0]
         self.h = ctypes.c_void_p()
-        check(lib().sp_fbtables_create(ctx.h, p64(points), ctypes.c_size_t(self.n), ctypes.byref(self.h)))
+        fn = lib().sp_fbtables_create_async if queued else lib().sp_fbtables_create
+        check(fn(ctx.h, p64(points), ctypes.c_size_t(self.n), ctypes.byref(self.h)))
+
+    def ready(self, wait=False):
+        r = lib().sp_fbtables_ready(self.h, int(wait))
+        if r < 0:
+            check(r)
+        return r == 1
+
+    def read(self, first, count):
+        """count table entries (affine points) from entry `first` of the n x 32 x 255 array: entry (i, j, d - 1) = d 2^(8j) point_i"""
+        out = np.zeros((count, 8), dtype=np.uint64)
+        check(lib().sp_fbtables_read(self.h, ctypes.c_size_t(first), ctypes.c_size_t(count), p64(out)))
+        return out
 
     def multi_mul(self, scalars):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)

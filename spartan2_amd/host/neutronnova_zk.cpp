@@ -243,19 +243,14 @@ static NNZkKey* nn_setup(sp_ctx* ctx, const R1CSIntView& Rs, const R1CSIntView& 
   return pk;
 }
 
-static std::vector<fe_t> padded_witness(const sp_dims& d, const uint64_t* w) {
-  std::vector<fe_t> W(d.num_shared + d.num_precommitted + d.num_rest, fe_zero());
-  const fe_t one = fe_one<S>();
-  auto put = [&](size_t dst, size_t src, size_t cnt) {
-    for (size_t i = 0; i < cnt; ++i) {
-      const uint64_t v = w[src + i];
-      W[dst + i] = v == 0 ? fe_zero() : (v == 1 ? one : fe_from_u64<S>(v));
-    }
-  };
-  put(0, 0, d.num_shared_unpadded);
-  put(d.num_shared, d.num_shared_unpadded, d.num_precommitted_unpadded);
-  put(d.num_shared + d.num_precommitted, d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded);
-  return W;
+// The witness of one circuit as a device table [shared | precommitted | rest] at the padded offsets (bellpepper/r1cs.rs:306-409): the machine words cross the bus
+// as they are and become Montgomery-form elements on the device (sp_table_write_u64). `shared_words`: step 0's shared segment - every circuit of a batch
+// carries it (src/neutronnova_zk.rs:1485-1488).
+static void upload_witness(sp_ctx* ctx, const sp_dims& d, const uint64_t* w, const uint64_t* shared_words, size_t shared_count, sp_table** out) {
+  ck(sp_table_zeros(ctx, d.num_shared + d.num_precommitted + d.num_rest, (size_t)-1, (size_t)-1, out), "alloc W");
+  ck(sp_table_write_u64(ctx, *out, 0, shared_words, shared_count), "upload W (shared)");
+  ck(sp_table_write_u64(ctx, *out, d.num_shared, w + d.num_shared_unpadded, d.num_precommitted_unpadded), "upload W (precommitted)");
+  ck(sp_table_write_u64(ctx, *out, d.num_shared + d.num_precommitted, w + d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded), "upload W (rest)");
 }
 
 // prep_prove (:1477-1603): shared commitment from step 0's witness, one precommitted commitment per step and for the core
@@ -270,21 +265,19 @@ static NNZkPrep* nn_prep_prove(const NNZkKey& pk, size_t n, const uint64_t* step
     const size_t CW = DEFAULT_COMMITMENT_WIDTH, rows_sh = d.num_shared / CW;
     ps->is_small = is_small;
     ps->steps.resize(n);
-    std::vector<fe_t> W0 = padded_witness(d, step_wit);
     if (d.num_shared_unpadded) {
       ps->r_shared.resize(rows_sh);
       for (auto& b : ps->r_shared) b = tape.next();
       sp_table* t = nullptr;
-      ck(sp_table_from_host(ctx, u64p(W0.data()), d.num_shared, (size_t)-1, (size_t)-1, &t), "upload shared");
+      ck(sp_table_zeros(ctx, d.num_shared, (size_t)-1, (size_t)-1, &t), "alloc shared");
+      int rc = sp_table_write_u64(ctx, t, 0, step_wit, d.num_shared_unpadded);
       ps->comm_shared.resize(rows_sh);
-      int rc = sp_hyrax_commit(ctx, pk.ck, t, 0, d.num_shared, u64p(ps->r_shared.data()), is_small ? 1 : 0, u64p(&ps->comm_shared[0].x));
+      if (!rc) rc = sp_hyrax_commit(ctx, pk.ck, t, 0, d.num_shared, u64p(ps->r_shared.data()), is_small ? 1 : 0, u64p(&ps->comm_shared[0].x));
       sp_table_free(t);
       ck(rc, "commit shared");
     }
     auto precommit = [&](const sp_dims& dd, const uint64_t* wit, const uint64_t* pub, NNPre* p) {
-      std::vector<fe_t> W = padded_witness(dd, wit);
-      std::copy(W0.begin(), W0.begin() + dd.num_shared, W.begin());  // every circuit shares step 0's shared witness (:1485-1488)
-      ck(sp_table_from_host(ctx, u64p(W.data()), W.size(), (size_t)-1, (size_t)-1, &p->W), "upload W");
+      upload_witness(ctx, dd, wit, step_wit, d.num_shared_unpadded, &p->W);  // every circuit shares step 0's shared witness (:1485-1488)
       p->publics.resize(dd.num_public);
       for (size_t i = 0; i < dd.num_public; ++i) p->publics[i] = fe_from_u64<S>(pub[i]);
       if (dd.num_precommitted_unpadded) {

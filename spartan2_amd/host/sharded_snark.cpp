@@ -165,18 +165,12 @@ ShardedPrep* sharded_prep_prove(const ShardedKey& pk, const uint64_t* witness_u6
     const size_t world = (size_t)comm.world, g = (size_t)comm.rank;
     const size_t M = pk.num_vars, N = d.num_cons, CW = DEFAULT_COMMITMENT_WIDTH;
     ps->is_small = is_small;
-    std::vector<fe_t> W(M, fe_zero());
-    const fe_t one = fe_one<S>();
-    auto put = [&](size_t dst, size_t src, size_t cnt) {
-      for (size_t i = 0; i < cnt; ++i) {
-        const uint64_t v = witness_u64[src + i];
-        W[dst + i] = v == 0 ? fe_zero() : (v == 1 ? one : fe_from_u64<S>(v));
-      }
-    };
+    // machine words in, Montgomery-form elements formed on the device (sp_table_write_u64; spartan_snark.cpp prep_prove)
+    ck(sp_table_zeros(ctx, M, (size_t)-1, (size_t)-1, &ps->W), "alloc W");
+    auto put = [&](size_t dst, size_t src, size_t cnt) { ck(sp_table_write_u64(ctx, ps->W, dst, witness_u64 + src, cnt), "upload W"); };
     put(0, 0, d.num_shared_unpadded);
     put(d.num_shared, d.num_shared_unpadded, d.num_precommitted_unpadded);
     put(d.num_shared + d.num_precommitted, d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded);
-    ck(sp_table_from_host(ctx, u64p(W.data()), M, (size_t)-1, (size_t)-1, &ps->W), "upload W");
     const size_t blk = M / world;
     ck(sp_table_zeros(ctx, blk, (size_t)-1, (size_t)-1, &ps->Wblk), "alloc W block");
     ck(sp_table_copy(ctx, ps->Wblk, 0, ps->W, g * blk, blk), "W block");

@@ -99,6 +99,16 @@ struct SpartanPrepSNARK {  // src/spartan.rs:107-124
   // Up to 512 rows (2^20 variables): measured at 1024 / 2048 rows the walk (a 17-level chain over 256 / 512 blocks) loses to the MSM it would replace
   // (1.77 vs 1.70 ms, 2.58 vs 2.51 ms): there the sum-check's last rounds no longer cover it and its blocks compete with the streaming rounds.
   sp_fbtables* lz_tables = nullptr;
+  std::vector<aff_t> lz_points;  // their bases (the committed rows, then h) while the build is still to be queued
+  int lz_mode = 0;               // 1: queue the build behind the first prove on this state (prep_prove, SPARTAN_PREP_TABLES)
+  void queue_lz_tables(sp_ctx* ctx) {  // end of a prove
+    if (lz_mode != 1 || lz_tables || lz_points.empty()) return;
+    lz_mode = 0;
+    if (sp_fbtables_create_async(ctx, u64p(&lz_points[0].x), lz_points.size(), &lz_tables) != SP_OK) lz_tables = nullptr;  // (the MSM over the rows stays)
+  }
+  // host wall-clock of prep_prove's phases, ms (ss_prep_phases): witness (u64 -> elements on the device), commit (PCS::commit of the shared and
+  // precommitted rows), tables (FixedBaseMul tables of the committed rows), matvec (multiply_vec_precommitted), scratch (allocations), total
+  double prep_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ~SpartanPrepSNARK() {
     sp_fbtables_free(lz_tables);
     bg.wait_nothrow();
@@ -141,6 +151,8 @@ SpartanProverKey* setup(sp_ctx* ctx, const R1CSIntView& R) {
   return pk;
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // SpartanSNARK::prep_prove (src/spartan.rs:176-216)
 SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness_u64, size_t n_witness, bool is_small, Tape& tape) {
   const sp_dims& d = pk.dims;
@@ -152,6 +164,13 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
     sp_ctx* ctx = pk.ctx;
     const size_t M = pk.num_vars, N = d.num_cons;
     ps->is_small = is_small;
+    const double t_begin = now_ms();
+    double t_last = t_begin;
+    auto phase = [&](int k) {
+      const double t = now_ms();
+      ps->prep_ms[k] += t - t_last;
+      t_last = t;
+    };
     {
       const char* e = getenv("SPARTAN_LZ_DIRECT");
       if (e && e[0] == '1') ps->flags |= FLAG_LZ_DIRECT;
@@ -160,19 +179,15 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
     }
     // shared_witness / precommitted_witness (bellpepper/r1cs.rs:306-409): each segment starts at its padded offset. The rest
     // segment is filled here as well: without verifier challenges it does not change between proves.
-    std::vector<fe_t> W(M, fe_zero());
-    const fe_t one = fe_one<S>();
-    auto put = [&](size_t dst, size_t src, size_t cnt) {
-      for (size_t i = 0; i < cnt; ++i) {
-        uint64_t v = witness_u64[src + i];
-        W[dst + i] = v == 0 ? fe_zero() : (v == 1 ? one : fe_from_u64<S>(v));
-      }
-    };
+    // The words go to the device as they are (8 bytes a value) and become Montgomery-form elements there: sp_table_write_u64 (the reference hands the same
+    // machine words to msm_small, hyrax_pc.rs:266-292, and never builds wide scalars for the commitment either).
+    ck(sp_table_zeros(ctx, M, (size_t)-1, (size_t)-1, &ps->W), "alloc W");
+    auto put = [&](size_t dst, size_t src, size_t cnt) { ck(sp_table_write_u64(ctx, ps->W, dst, witness_u64 + src, cnt), "upload W"); };
     put(0, 0, d.num_shared_unpadded);
     put(d.num_shared, d.num_shared_unpadded, d.num_precommitted_unpadded);
     // (with verifier challenges the rest segment is synthesized inside every prove, after the challenges are drawn: bellpepper/r1cs.rs:443-461)
     if (d.num_challenges == 0) put(d.num_shared + d.num_precommitted, d.num_shared_unpadded + d.num_precommitted_unpadded, d.num_rest_unpadded);
-    ck(sp_table_from_host(ctx, u64p(W.data()), M, (size_t)-1, (size_t)-1, &ps->W), "upload W");
+    phase(0);
     const size_t CW = DEFAULT_COMMITMENT_WIDTH;
     ps->rows_shared = d.num_shared_unpadded ? (d.num_shared + CW - 1) / CW : 0;
     ps->rows_precommitted = d.num_precommitted_unpadded ? (d.num_precommitted + CW - 1) / CW : 0;
@@ -189,20 +204,31 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
          "commit precommitted");
       ps->comm_pre_bytes = commitment_bytes(ps->comm_W_fixed.data() + ps->rows_shared, ps->rows_precommitted);
     }
+    phase(1);
     {
       const size_t fixed = ps->comm_W_fixed.size(), rows_all = (M + CW - 1) / CW;
       if (!(ps->flags & FLAG_LZ_DIRECT) && d.num_rest_unpadded == 0 && d.num_challenges == 0 && fixed >= 1 && fixed + 1 <= 512 && rows_all > 1) {
-        std::vector<aff_t> pts(ps->comm_W_fixed);
-        pts.push_back(pk.gens[CW]);  // h
-        ck(sp_fbtables_create(ctx, u64p(&pts[0].x), pts.size(), &ps->lz_tables), "tables of the committed rows");
+        // WHEN they are built (SPARTAN_PREP_TABLES): the build is ~3 ms of device work (profiles/r06_prep_prove.md) that pays for itself from the second prove
+        // on a state onwards (50-100 us a prove) and slows whatever proves beside it. "lazy" (default): queued behind the FIRST prove on the state - a state
+        // that is proven once (the reference's own use: prep_prove, prove, drop) never pays, the bench's repeated proves get them from the third on;
+        // "prep": queued here; "sync": built here and waited for (round 5); "off": never.
+        const char* mode = getenv("SPARTAN_PREP_TABLES");
+        ps->lz_points.assign(ps->comm_W_fixed.begin(), ps->comm_W_fixed.end());
+        ps->lz_points.push_back(pk.gens[CW]);  // h
+        ps->lz_mode = !mode || !strcmp(mode, "lazy") ? 1 : (!strcmp(mode, "off") ? 0 : 2);
+        if (mode && !strcmp(mode, "sync")) ck(sp_fbtables_create(ctx, u64p(&ps->lz_points[0].x), ps->lz_points.size(), &ps->lz_tables), "tables of the committed rows");
+        else if (ps->lz_mode == 2) ck(sp_fbtables_create_async(ctx, u64p(&ps->lz_points[0].x), ps->lz_points.size(), &ps->lz_tables), "tables of the committed rows");
       }
     }
+    phase(2);
     // multiply_vec_precommitted (src/r1cs/mod.rs:1112-1128): z = [W_cached | 0 ...]
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->z), "alloc z");
     ck(sp_table_copy(ctx, ps->z, 0, ps->W, 0, d.num_shared + d.num_precommitted), "copy W");
     ck(sp_table_set_len(ps->z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
     for (sp_table** t : {&ps->caz, &ps->cbz, &ps->ccz, &ps->az, &ps->bz, &ps->cz}) ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, t), "alloc Az");
     ck(sp_multiply_vec(ctx, pk.S, ps->z, ps->caz, ps->cbz, ps->ccz), "multiply_vec_precommitted");
+    if (getenv("SPARTAN_PREP_TRACE")) ck(sp_ctx_synchronize(ctx), "sync");
+    phase(3);
     ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &ps->rx), "alloc rx");
     const char* no_p0 = getenv("SPARTAN_ROUND0_PRODUCTS");  // "0": round 1 of the outer sum-check evaluates straight from Az, Bz, Cz (A/B)
     if (N >= 2 && !(no_p0 && no_p0[0] == '0')) {
@@ -211,6 +237,11 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
     }
     ck(sp_table_zeros(ctx, 2 * M, (size_t)-1, (size_t)-1, &ps->abc), "alloc poly_ABC");
     ck(sp_ctx_synchronize(ctx), "sync");
+    phase(4);
+    ps->prep_ms[6] = now_ms() - t_begin;
+    if (getenv("SPARTAN_PREP_TRACE"))
+      fprintf(stderr, "prep_prove: witness %.3f commit %.3f tables %.3f matvec %.3f scratch %.3f total %.3f ms\n", ps->prep_ms[0], ps->prep_ms[1], ps->prep_ms[2], ps->prep_ms[3],
+              ps->prep_ms[4], ps->prep_ms[6]);
   } catch (...) {
     delete ps;
     throw;
@@ -218,7 +249,6 @@ SpartanPrepSNARK* prep_prove(const SpartanProverKey& pk, const uint64_t* witness
   return ps;
 }
 
-static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // SpartanSNARK::prove (src/spartan.rs:219-466)
 // `synth`: circuit.synthesize(.., Some(&challenges)) for circuits with verifier challenges (bellpepper/r1cs.rs:443-461): receives the challenges and
@@ -477,7 +507,8 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
   lz.nvr = lz_nvr;
   const bool lz_ahead = !lz_direct && lz_nvr > 0 && lz_nvr <= 20 && comm_W.size() == ((size_t)1 << lz_nvr) && r_W.size() == comm_W.size();
   const size_t lz_cols = (size_t)1 << (log2_ceil(M) - lz_nvr);
-  const bool lz_tables_path = lz_ahead && ps.lz_tables && rest_job_used && ps.comm_W_fixed.size() + rows_rest == comm_W.size();
+  // (tables whose build - queued by prep_prove a moment ago - has not ended are not waited for: this prove takes the MSM over the row commitments)
+  const bool lz_tables_path = lz_ahead && ps.lz_tables && rest_job_used && ps.comm_W_fixed.size() + rows_rest == comm_W.size() && sp_fbtables_ready(ps.lz_tables, 0) == 1;
   {
     const aff_t* rows = comm_W.data();
     const size_t nrows = comm_W.size();
@@ -977,6 +1008,7 @@ SpartanProofBuf prove(const SpartanProverKey& pk, SpartanPrepSNARK& ps, const ui
     pt->ms[5] = t_end - t_inner;
     pt->ms[6] = t_end - t_start;
   }
+  ps.queue_lz_tables(ctx);
   return proof;
 }
 
@@ -1147,6 +1179,7 @@ SpartanProofBuf prove_reference_order(const SpartanProverKey& pk, SpartanPrepSNA
     pt->ms[5] = t_end - t_inner;
     pt->ms[6] = t_end - t_start;
   }
+  ps.queue_lz_tables(ctx);
   return proof;
 }
 
@@ -1394,6 +1427,13 @@ int ss_prep_prove(void* pk, const uint64_t* witness_u64, size_t n, int is_small,
   }
 }
 void ss_prep_free(void* ps) { delete (SpartanPrepSNARK*)ps; }
+// host wall-clock of the last prep_prove's phases, ms: witness, commit, tables, matvec, scratch, (spare), total, (spare)
+// the FixedBaseMul tables of the committed rows (queued by prep_prove): 1 = built, 0 = still building (wait != 0: blocks), -1 = this state has none
+int ss_prep_tables_ready(void* ps, int wait) {
+  auto* p = (SpartanPrepSNARK*)ps;
+  return p->lz_tables ? sp_fbtables_ready(p->lz_tables, wait) : -1;
+}
+void ss_prep_phases(void* ps, double out[8]) { memcpy(out, ((SpartanPrepSNARK*)ps)->prep_ms, sizeof(double) * 8); }
 // driver options of one prep state: bit 0 = cache the transcript prefix across proves, bit 1 = opening in the reference's order (see FLAG_*)
 void ss_prep_set_flags(void* ps, unsigned flags) { ((SpartanPrepSNARK*)ps)->flags = flags; }
 unsigned ss_prep_get_flags(void* ps) { return ((SpartanPrepSNARK*)ps)->flags; }

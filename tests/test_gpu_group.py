@@ -573,3 +573,58 @@ def test_fixed_base_tables_multi_mul_matches_oracle_msm(ctx, n):
     if n == 4:
         with pytest.raises(hip.SpartanHipError):
             hip.FixedBaseTables(ctx, np.zeros((4097, 8), dtype=np.uint64))  # more than 1024 blocks of four scalars
+
+
+@pytest.mark.parametrize("queued", [False, True])
+def test_fbtables_every_entry(ctx, queued):
+    """FixedBaseMul::precompute (msm.rs:653-689) as the three-launch build of round 6 (doubling ladder, batch-normalised ladder, 32-entry parts normalised
+    with one inversion each): EVERY entry (i, j, d - 1) of the tables of a generator-derived point, of the identity and of a second point is the canonical
+    affine d * 2^(8j) * P_i - checked against the oracle's scalar multiplication entry by entry for one point and at sampled entries for the others."""
+    rng = np.random.default_rng(SEED + 9100)
+    pts = np.zeros((3, 8), dtype=np.uint64)
+    olib().orc_from_label(b"fbtables_entries", ctypes.c_size_t(3), p64(pts))
+    pts[1] = 0  # the identity: every multiple is the identity, written as (0, 0)
+    t = hip.FixedBaseTables(ctx, pts, queued=queued)
+    assert t.ready(wait=True)
+    per = 32 * 255
+    got = t.read(0, 3 * per)
+    assert (got[per : 2 * per] == 0).all()
+    p = ol.MODULI[0]
+
+    def want(i, j, d):
+        c = (d << (8 * j)) % p  # (the group order is p: multiples of the top window beyond it wrap)
+        return oracle_msm(ol.mont_array([c]), np.ascontiguousarray(pts[i : i + 1]))
+
+    for j in range(32):
+        for d in range(1, 256):
+            assert (got[j * 255 + d - 1] == want(0, j, d)).all(), (j, d)
+    for _ in range(200):
+        j, d = int(rng.integers(0, 32)), int(rng.integers(1, 256))
+        assert (got[2 * per + j * 255 + d - 1] == want(2, j, d)).all(), (j, d)
+    t.close()
+
+
+def test_table_write_u64_and_bits(ctx):
+    """sp_table_write_u64 / sp_table_write_bits (the is_small witness upload, src/bellpepper/r1cs.rs:303-409 + hyrax_pc.rs:266-292): machine words and packed
+    bits become the same Montgomery-form elements sp_table_write would have been given, at an offset, leaving the rest of the table alone."""
+    rng = np.random.default_rng(SEED + 9200)
+    n = 5000
+    vals = rng.integers(0, 2, size=n, dtype=np.uint64)
+    vals[::7] = rng.integers(0, 2**63, size=len(vals[::7]), dtype=np.uint64) * 2 + 1
+    vals[3] = 2**64 - 1
+    vals[4] = 0
+    t = hip.Table.zeros(ctx, 8192)
+    filler = ol.random_field_array(rng, 8192)
+    t.write(0, filler)
+    t.write_u64(100, vals)
+    got = t.read()
+    assert (got[:100] == filler[:100]).all() and (got[100 + n :] == filler[100 + n :]).all()
+    assert (got[100 : 100 + n] == ol.mont_array([int(v) for v in vals])).all()
+    bits = rng.integers(0, 2, size=3001, dtype=np.uint8)
+    packed = np.packbits(bits, bitorder="little")
+    t.write_bits(7, packed, len(bits))
+    got = t.read()
+    assert (got[7 : 7 + len(bits)] == ol.mont_array([int(b) for b in bits])).all()
+    assert (got[:7] == filler[:7]).all() and (got[7 + len(bits) : 100] == filler[7 + len(bits) : 100]).all()
+    with pytest.raises(hip.SpartanHipError):
+        t.write_u64(8000, vals)  # range exceeds the table
