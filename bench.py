@@ -333,6 +333,68 @@ def dist(ms):
             "steps_over_2x_median": [i for i, x in enumerate(ms) if x > 2 * med][:16], "n": len(a)}
 
 
+def prep_prove_leg(snark, inst, tape, step_tape, words, calls=6, oracle=None, used=None):
+    """SpartanSNARK::prep_prove as a phase of its own, the protocol of benches/sha256_spartan.rs:206-222: setup outside, a FRESH prep_prove inside the timed
+    routine, its output dropped outside (Criterion's iter_batched). min / median over `calls` calls of the C entry point, the driver's own phases
+    (witness upload + expansion on the device, Hyrax commit of the precommitted rows, the queueing of the row tables, multiply_vec_precommitted, scratch), the
+    first prove on each fresh state, the same with the FixedBaseMul tables of the committed rows built and waited for INSIDE prep_prove (round 5's
+    behaviour; SPARTAN_PREP_TABLES=sync), and the CPU oracle's prep_prove of the same instance beside it. Every prove on every state is the timed proof."""
+    import ctypes
+
+    from spartan2_amd import host as _host
+
+    names = ["witness", "commit", "tables", "matvec", "scratch", None, "total", None]
+
+    def run(mode, n):
+        prev = os.environ.get("SPARTAN_PREP_TABLES")
+        if mode:
+            os.environ["SPARTAN_PREP_TABLES"] = mode
+        elif prev is not None:
+            del os.environ["SPARTAN_PREP_TABLES"]
+        rows, same = [], True
+        try:
+            for _ in range(n):
+                tf = time.perf_counter()
+                if snark.ps:
+                    _host.lib().ss_prep_free(snark.ps)
+                    snark.ps = None
+                t0 = time.perf_counter()
+                u = snark.prep_prove(tape)
+                t1 = time.perf_counter()
+                assert used is None or u == used
+                ms = (ctypes.c_double * 8)()
+                _host.lib().ss_prep_phases(snark.ps, ms)
+                snark.set_flags(prefix_cache=False)
+                w1, _, _ = snark.prove(step_tape)
+                t2 = time.perf_counter()
+                same = same and bool((np.asarray(w1) == np.asarray(words)).all())
+                rows.append({"prep_ms": (t1 - t0) * 1e3, "first_prove_ms": (t2 - t1) * 1e3, "drop_previous_ms": (t0 - tf) * 1e3,
+                             "phases_ms": {k: v for k, v in zip(names, ms) if k}})
+        finally:
+            if prev is None:
+                os.environ.pop("SPARTAN_PREP_TABLES", None)
+            else:
+                os.environ["SPARTAN_PREP_TABLES"] = prev
+        rows = rows[1:] if len(rows) > 2 else rows  # (the first call of a mode also pays one-off allocations of the context's workspaces)
+        pm = sorted(r["prep_ms"] for r in rows)
+        med = rows[[r["prep_ms"] for r in rows].index(pm[len(pm) // 2])]
+        return {"calls": len(rows), "min_ms": pm[0], "median_ms": pm[len(pm) // 2], "max_ms": pm[-1], "median_call_phases_ms": med["phases_ms"],
+                "first_prove_after_ms_median": sorted(r["first_prove_ms"] for r in rows)[len(rows) // 2],
+                "drop_of_previous_state_ms_median": sorted(r["drop_previous_ms"] for r in rows)[len(rows) // 2], "proofs_identical_to_the_timed_one": same}
+
+    leg = {"protocol": "fresh prep_prove per call on one key, previous state dropped outside the timed call (benches/sha256_spartan.rs:206-222); inputs are the "
+                       "witness as machine words in pageable host memory (8 B a value: the PCIe transfer is inside the figure)",
+           "default": run(None, calls + 1), "tables_built_inside_prep": run("sync", 4), "no_tables": run("off", 4),
+           "note": "default = the row tables (FixedBaseMul of the committed rows, for comm_LZ) are queued behind the FIRST prove on a state and used from "
+                   "the first prove that finds them built; tables_built_inside_prep = round 5's behaviour with round 6's build (three launches, batch inversion)"}
+    if oracle is not None:
+        t0 = time.perf_counter()
+        ou = oracle.prep_prove(tape)
+        leg["cpu_oracle_prep_prove_ms"] = (time.perf_counter() - t0) * 1e3
+        assert used is None or ou == used
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -871,6 +933,10 @@ def main():
                                    "ms": secs * 1e3, "single_thread_ms": secs1 * 1e3, "gpu_proof_bit_exact_and_verified": ok}
             if not ok:
                 raise SystemExit("GPU proof differs from the oracle's or fails verification")
+            out["prep_prove"] = prep_prove_leg(snark, inst, tape, step_tape, words, oracle=osp, used=used)
+            out["prep_prove"]["cpu_oracle_threads"] = cores
+        elif world == 1:
+            out["prep_prove"] = prep_prove_leg(snark, inst, tape, step_tape, words, used=used)
     if not args.no_sharded:
         # The sharded legs are the one part of this run that talks RCCL from C++ across ranks. They come after everything the headline needs, each
         # under a watchdog of its own (LegDog): a leg that never returns costs only itself - rank 0 prints the line with the legs finished before it

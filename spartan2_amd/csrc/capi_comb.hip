@@ -8,6 +8,9 @@
 
 using sp::fail;
 
+#ifndef COMB_MINW_DEFAULT
+#define COMB_MINW_DEFAULT 3
+#endif
 namespace sp {
 
 // ---- fixed-base comb path for many rows over the key (kernels_comb.hpp) ---------------------------------------------------------------------------
@@ -86,6 +89,15 @@ int comb_ensure(sp_ctx* c, const sp_ck* ck) {
   ck->d_comb = tab;
   return SP_OK;
 }
+// waves per SIMD k_comb_rows is compiled for: 2 = 256 registers a lane, no spills; 3 = 168 registers, 67 spilled (tools/spill_report.py). SPARTAN_COMB_MINW picks
+// (A/B: profiles/r06_spills.md)
+static int comb_minw() {
+  static const int v = [] {
+    const char* e = getenv("SPARTAN_COMB_MINW");
+    return e && e[0] == '3' ? 3 : (e && e[0] == '2' ? 2 : COMB_MINW_DEFAULT);
+  }();
+  return v;
+}
 // rows `sel` of canon (values < 2^nbits) against the comb table -> out[sel[i]]
 int comb_rows(sp_ctx* c, const sp_ck* ck, const fe_t* canon, size_t cols, size_t n, const std::vector<unsigned>& sel, int nbits, std::vector<jac_t>& out) {
   const int C = ck->comb_c;
@@ -98,13 +110,26 @@ int comb_rows(sp_ctx* c, const sp_ck* ck, const fe_t* canon, size_t cols, size_t
   const dim3 grid((unsigned)sel.size()), block(256);
   // 96 B per (scalar, base) pair (+ one 64-byte table entry per window actually gathered)
   c->timed("msm_rows_comb", 96ull * sel.size() * cols, [&] {
-    switch (C) {
-      case 8: hipLaunchKernelGGL((spk::k_comb_rows<8, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
-      case 10: hipLaunchKernelGGL((spk::k_comb_rows<10, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
-      case 12: hipLaunchKernelGGL((spk::k_comb_rows<12, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
-      case 13: hipLaunchKernelGGL((spk::k_comb_rows<13, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
-      default: hipLaunchKernelGGL((spk::k_comb_rows<14, 3>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>()); break;
+#define COMB_ROWS(CC, MW) \
+  hipLaunchKernelGGL((spk::k_comb_rows<CC, MW>), grid, block, 0, c->stream, canon, dsel.as<unsigned>(), cols, n, ck->d_comb, windows, drows.as<jac_t>())
+    if (comb_minw() == 2) {
+      switch (C) {
+        case 8: COMB_ROWS(8, 2); break;
+        case 10: COMB_ROWS(10, 2); break;
+        case 12: COMB_ROWS(12, 2); break;
+        case 13: COMB_ROWS(13, 2); break;
+        default: COMB_ROWS(14, 2); break;
+      }
+    } else {
+      switch (C) {
+        case 8: COMB_ROWS(8, 3); break;
+        case 10: COMB_ROWS(10, 3); break;
+        case 12: COMB_ROWS(12, 3); break;
+        case 13: COMB_ROWS(13, 3); break;
+        default: COMB_ROWS(14, 3); break;
+      }
     }
+#undef COMB_ROWS
   });
   std::vector<jac_t> res(sel.size());
   SP_HIP(hipMemcpyAsync(res.data(), drows.p, sel.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));

@@ -174,6 +174,8 @@ int sp_ctx_create(int device, sp_ctx** out) {
     }
   }
   SP_HIP(hipMalloc((void**)&c->d_gate, spk::MAIL_RING * sizeof(fe_t)));
+  SP_HIP(hipMalloc((void**)&c->d_fold_tickets, spk::HOST_SUM_MAX_BLOCKS * sizeof(unsigned)));  // arrival counters of the folded second stage: zero between launches
+  SP_HIP(hipMemset(c->d_fold_tickets, 0, spk::HOST_SUM_MAX_BLOCKS * sizeof(unsigned)));
   int rc = c->ensure_scratch(1 << 16);
   if (rc) return rc;
   sp::g_live_contexts.fetch_add(1, std::memory_order_relaxed);
@@ -199,6 +201,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   if (c->h_pinned) hipHostFree(c->h_pinned);
   if (c->mail_alloc) hipFree(c->mail_alloc);
   if (c->d_gate) hipFree(c->d_gate);
+  if (c->d_fold_tickets) hipFree(c->d_fold_tickets);
   if (c->h_pinned_vec) hipHostFree(c->h_pinned_vec);
   if (c->vec_ev) hipEventDestroy(c->vec_ev);
   if (c->stream3) hipStreamDestroy(c->stream3);
@@ -230,6 +233,7 @@ void sp_ctx_destroy(sp_ctx* c) {
   }
   if (c->tab_scratch) hipFree(c->tab_scratch);
   if (c->aside_ev) hipEventDestroy(c->aside_ev);
+  if (c->tail_ev) hipEventDestroy(c->tail_ev);
   if (c->aside_main_ev) hipEventDestroy(c->aside_main_ev);
   if (c->stream_eq) hipStreamDestroy(c->stream_eq);
   if (c->eq_ev) hipEventDestroy(c->eq_ev);
@@ -409,6 +413,11 @@ int sp_table_assemble_aside(sp_ctx* c, sp_table* dst, size_t dst_off, const sp_t
     if (!c->aside_main_ev) SP_HIP(hipEventCreateWithFlags(&c->aside_main_ev, hipEventDisableTiming));
     SP_HIP(hipEventRecord(c->aside_main_ev, c->stream));
     SP_HIP(hipStreamWaitEvent(c->stream_eq, c->aside_main_ev, 0));
+  } else if (c->tail_ev_pending) {
+    // not behind the main stream's queue, but behind the last resident quadratic tail: its final store into element 0 of its tables (z among them, when
+    // the caller is a prove that reuses the state of the one before) may come after that sum-check returned. The event is long complete in practice.
+    SP_HIP(hipStreamWaitEvent(c->stream_eq, c->tail_ev, 0));
+    c->tail_ev_pending = false;
   }
   if (cnt || zero_cnt) {
     const size_t work = 2 * (cnt > zero_cnt ? cnt : zero_cnt);  // uint4 per element: 2
@@ -527,21 +536,49 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
   c->pending_slots = (unsigned)b2;
   hipLaunchKernelGGL(spk::k_sum_partials, dim3((unsigned)b2), dim3(64), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
 }
-// second stage of a streaming launch (kernels_poly.hpp k_sum_partials_lazy): groups of 2^gl consecutive producer blocks, eq_out[group] applied when given
-static void sum_lazy_launch(sp_ctx* c, const spk::lazy9_t* lp, size_t nparts, int gl, const fe_t* eq_out, unsigned seq) {
-  const uint32_t* P = reinterpret_cast<const uint32_t*>(lp);
+// Second stage of a streaming launch: groups of 2^gl consecutive producer blocks, eq_out[group] applied when given. FOLDED into the producer when the
+// shape allows (kernels_poly.hpp stream_block_partials: the last block to arrive at a slot's ticket does the slot's sums - no second launch on the round's
+// critical path); otherwise k_sum_partials_lazy behind it. lazy_out() builds the kernel's argument before the launch, sum_lazy_launch() finishes after it.
+static bool fold_stage2_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_FOLD_STAGE2");  // "0": always the separate second-stage launch (A/B)
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+static spk::LazyOut lazy_out(sp_ctx* c, spk::lazy9_t* lp, size_t nparts, int gl, const fe_t* eq_out, unsigned seq) {
+  spk::LazyOut lo(lp);
   const size_t ngroups = nparts >> gl;
   size_t b2 = (ngroups + 63) / 64;
   if (b2 < 1) b2 = 1;
   if (b2 > (size_t)spk::HOST_SUM_MAX_BLOCKS) b2 = spk::HOST_SUM_MAX_BLOCKS;
-  const dim3 g((unsigned)b2), b(64);
+  lo.eq_out = eq_out;
+  lo.mapped = c->d_pinned;
+  lo.seq = seq;
+  lo.nslots = (unsigned)b2;
+  lo.gl = gl;
+  // every slot must see the same number of blocks (power-of-two shapes do), and a group's words must be readable as 8-byte pairs
+  const bool even = ngroups > 0 && ((size_t)ngroups << gl) == nparts && (ngroups <= 64 || ngroups % (64 * b2) == 0) && (gl == 0 || nparts % 2 == 0);
+  if (fold_stage2_enabled() && even && c->d_fold_tickets) {
+    lo.tickets = c->d_fold_tickets;
+    lo.per_slot = (unsigned)(nparts / b2);
+  }
+  return lo;
+}
+static void sum_lazy_launch(sp_ctx* c, const spk::LazyOut& lo, size_t nparts) {
+  const int gl = lo.gl;
+  const unsigned seq = lo.seq;
+  const fe_t* eq_out = lo.eq_out;
+  c->pending_slots = lo.nslots;
+  if (lo.tickets) return;  // the producer's last blocks deliver the slots
+  const uint32_t* P = reinterpret_cast<const uint32_t*>(lo.P);
+  const dim3 g(lo.nslots), b(64);
   const bool vec_ok = nparts % 8 == 0;  // the vector loads of the templated forms need their 16-byte alignment
   if (vec_ok && gl == 0) hipLaunchKernelGGL((spk::k_sum_partials_lazy<0>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
   else if (vec_ok && gl == 1) hipLaunchKernelGGL((spk::k_sum_partials_lazy<1>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
   else if (vec_ok && gl == 2) hipLaunchKernelGGL((spk::k_sum_partials_lazy<2>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
   else if (vec_ok && gl == 3) hipLaunchKernelGGL((spk::k_sum_partials_lazy<3>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
   else hipLaunchKernelGGL((spk::k_sum_partials_lazy<-1>), g, b, 0, c->stream, P, nparts, gl, eq_out, c->d_pinned, seq);
-  c->pending_slots = (unsigned)b2;
 }
 // `resident`: a kernel on the stream is itself waiting for the host's next challenge (the resident tail that produces the result, or a launch issued
 // ahead of its challenge queued behind the producer) — a stream synchronise would not return before that kernel's watchdog, so the host keeps
@@ -1401,6 +1438,10 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       ta.seq0 = next_seq(c);
       tail_nb0 = tail_blocks(A->len / 2);
       hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(tail_nb0), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
+      // the resident kernel stores the final claims into element 0 of its tables AFTER the host has them and has returned (hand-over): whoever rewrites
+      // those tables on another stream - the next prove's sp_table_assemble_aside of z - orders itself behind this event
+      if (!c->tail_ev) (void)hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming);
+      if (c->tail_ev && hipEventRecord(c->tail_ev, c->stream) == hipSuccess) c->tail_ev_pending = true;
       in_tail = true;
       have_sums = true;
       sp::after_bind(A);
@@ -1417,12 +1458,12 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       const size_t q = A->len / 4;
       size_t blocks = (q + chunk - 1) / chunk;
       if (q >= STREAM_MIN_Q) {  // streaming regime: wave-level lazy partials + lazy second stage
-        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
         const unsigned seq = next_seq(c);
+        const spk::LazyOut lp = lazy_out(c, reinterpret_cast<spk::lazy9_t*>(c->d_scratch), q / 256, 2, nullptr, seq);
         c->timed("bind_stream_quad", 48ull * A->len * 2, [&] {
           hipLaunchKernelGGL(spk::k_bind_eval_quad_stream, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, lp, mref);
         });
-        sum_lazy_launch(c, lp, q / 256, 2, (const fe_t*)nullptr, seq);
+        sum_lazy_launch(c, lp, q / 256);
       } else {
         c->timed("bind", 48ull * A->len * 2, [&] {
           hipLaunchKernelGGL(spk::k_bind_eval_quad, dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, q, rv, c->d_scratch, c->d_pinned, next_seq(c), mref);
@@ -1437,13 +1478,13 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     if (sparse_stream) {
       // full low half, (almost) empty high half: bind without reading the zeros, evaluate the next round from registers
       const size_t q = A->len / 4;
-      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
       const unsigned seq = next_seq(c);
+      const spk::LazyOut lp = lazy_out(c, reinterpret_cast<spk::lazy9_t*>(c->d_scratch), q / 256, 2, nullptr, seq);
       c->timed("bind_stream_quad_sparse", 64ull * (A->len / 2) * 2, [&] {
         hipLaunchKernelGGL(spk::k_bind_eval_quad_stream_sparse, dim3((unsigned)(q / 256)), dim3(256), 0, c->stream, A->d, B->d, q, rv, sp::eff_hi(A), sp::eff_hi(B), lp,
                            mref);
       });
-      sum_lazy_launch(c, lp, q / 256, 2, (const fe_t*)nullptr, seq);
+      sum_lazy_launch(c, lp, q / 256);
       sp::after_bind(A);
       sp::after_bind(B);
       have_sums = true;
@@ -1465,18 +1506,18 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       if (sp::eff_pairs(B) < len) len = sp::eff_pairs(B);
       if (half < len) len = half;
       if (len >= STREAM_MIN_Q && len % 1024 == 0) {  // streaming form: lazy sums, lazy second stage
-        spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(c->d_scratch);
         const unsigned seq = next_seq(c);
         const size_t hi_max = sp::eff_hi(A) > sp::eff_hi(B) ? sp::eff_hi(A) : sp::eff_hi(B);
         const bool lowhi = hi_max <= len / 2;  // short non-zero prefix in the high halves: dot-product form
         const size_t blocks = len / (256 * (size_t)4);
+        const spk::LazyOut lp = lazy_out(c, reinterpret_cast<spk::lazy9_t*>(c->d_scratch), blocks, 2, nullptr, seq);
         c->timed("eval_quad", 64ull * len + 32ull * ((sp::eff_hi(A) < len ? sp::eff_hi(A) : len) + (sp::eff_hi(B) < len ? sp::eff_hi(B) : len)), [&] {
           if (lowhi)
             hipLaunchKernelGGL((spk::k_eval_quad_stream_lowhi<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
           else
             hipLaunchKernelGGL((spk::k_eval_quad_stream<4>), dim3((unsigned)blocks), dim3(256), 0, c->stream, A->d, B->d, half, sp::eff_hi(A), sp::eff_hi(B), lp);
         });
-        sum_lazy_launch(c, lp, blocks, 2, (const fe_t*)nullptr, seq);
+        sum_lazy_launch(c, lp, blocks);
         waiting = true;
       } else if (len > 0) {
         size_t blocks = (len + chunk - 1) / chunk;
@@ -2205,7 +2246,8 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     dim3 g((unsigned)((q + chunk - 1) / chunk)), b(256);
     const unsigned seq = next_seq(c);
     if (q >= STREAM_MIN_Q && (e.mode == 0 || (e.mode == 1 && e.s >= 8))) {
-      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
+      // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
+      const spk::LazyOut lp = lazy_out(c, reinterpret_cast<spk::lazy9_t*>(d_part), q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr, seq);
       {
         const dim3 gs((unsigned)(q / 256));
         const uint64_t bytes = 48ull * A->len * 3;
@@ -2220,8 +2262,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         else if (polls) c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, true>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
         else c->timed_kernel(kname, bytes, spk::k_bind_eval_cubic_stream<1, false>, gs, b, pa, pb, pc, q, rv, e.eq_in, e.s, lp, mref);
       }
-      // factored mode: 2^(s-8) consecutive blocks share one x_out; single-table mode: any grouping, no factor
-      sum_lazy_launch(c, lp, q / 256, e.mode == 1 ? e.s - 8 : 2, e.mode == 1 ? e.eq_out : (const fe_t*)nullptr, seq);
+      sum_lazy_launch(c, lp, q / 256);
       sp::after_bind(A);
       sp::after_bind(B);
       sp::after_bind(C);
@@ -2247,12 +2288,12 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     const EqSel e1 = select_eq(1);
     if (prod0 && prod1 && half % 256 == 0 && (e1.mode == 0 || (e1.mode == 1 && e1.s >= 8))) {
       // the per-pair products came with the matrix-vector product: weight them with the eq tables (2 x 32 B per pair instead of 5 x 32 B)
-      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
       const unsigned seq = next_seq(c);
       // four chunks of 256 pairs per block where the table and, in factored mode, the x_out group (2^s pairs) hold them; else one
       const bool four = half % 1024 == 0 && half >= ((size_t)1 << 16) && (e1.mode == 0 || e1.s >= 10);
       const size_t nblk = four ? half / 1024 : half / 256;
       const int gsh = four ? 10 : 8;  // log2 of the pairs of a block
+      const spk::LazyOut lp = lazy_out(c, reinterpret_cast<spk::lazy9_t*>(d_part), nblk, e1.mode == 1 ? e1.s - gsh : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
       const dim3 gs((unsigned)nblk), bs(256);
       c->timed("eval_cubic", 64ull * half, [&] {
         if (e1.mode == 0 && four) hipLaunchKernelGGL((spk::k_eval_products_stream<0, 4>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
@@ -2260,16 +2301,16 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
         else if (four) hipLaunchKernelGGL((spk::k_eval_products_stream<1, 4>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
         else hipLaunchKernelGGL((spk::k_eval_products_stream<1, 1>), gs, bs, 0, c->stream, prod0->d, prod1->d, e1.eq_in, e1.s, lp);
       });
-      sum_lazy_launch(c, lp, nblk, e1.mode == 1 ? e1.s - gsh : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
+      sum_lazy_launch(c, lp, nblk);
     } else if (half >= STREAM_MIN_Q && half % 256 == 0 && (e1.mode == 0 || (e1.mode == 1 && e1.s >= 8))) {
-      spk::lazy9_t* lp = reinterpret_cast<spk::lazy9_t*>(d_part);
       const unsigned seq = next_seq(c);
+      const spk::LazyOut lp = lazy_out(c, reinterpret_cast<spk::lazy9_t*>(d_part), half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
       const dim3 gs((unsigned)(half / 256)), bs(256);
       c->timed("eval_cubic", 160ull * half, [&] {
         if (e1.mode == 0) hipLaunchKernelGGL((spk::k_eval_cubic_stream<0>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
         else hipLaunchKernelGGL((spk::k_eval_cubic_stream<1>), gs, bs, 0, c->stream, A->d, B->d, C->d, half, e1.eq_in, e1.s, lp);
       });
-      sum_lazy_launch(c, lp, half / 256, e1.mode == 1 ? e1.s - 8 : 2, e1.mode == 1 ? e1.eq_out : (const fe_t*)nullptr, seq);
+      sum_lazy_launch(c, lp, half / 256);
     } else {
       size_t blocks = 0;
       c->timed("eval_cubic", 160ull * (A->len / 2), [&] { blocks = launch_eval(1, false); });

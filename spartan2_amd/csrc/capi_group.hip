@@ -407,6 +407,35 @@ static const aff_t* tables16_of(const aff_t* t8) {
   auto it = g_t16.find(t8);
   return it == g_t16.end() ? nullptr : it->second;
 }
+// The host copy of a key's 16-bit-window tables (64 MiB a table): one per distinct base set and process - the contexts of a multi-context run create the same
+// keys, and ck / ck_s are the same labels in every one - held weakly here and strongly by the keys, so that the last key to go frees it. Filled by one
+// device -> host copy into memory that is not value-initialised first (1.5 GB of zero-filled vectors in the eight-context mode).
+static int host_tables16_of(const std::vector<aff_t>& bases, const aff_t* d_t16, size_t entries, std::shared_ptr<aff_t[]>* out) {
+  static const bool on = [] {
+    const char* e = getenv("SPARTAN_HOST_T16");
+    return !(e && e[0] == '0');
+  }();
+  out->reset();
+  if (!on) return SP_OK;
+  static std::mutex mu;
+  static std::map<std::string, std::weak_ptr<aff_t[]>> cache;
+  const std::string key(reinterpret_cast<const char*>(bases.data()), bases.size() * sizeof(aff_t));
+  std::lock_guard<std::mutex> l(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) {
+    if (auto sp = it->second.lock()) {
+      *out = sp;
+      return SP_OK;
+    }
+    cache.erase(it);
+  }
+  std::shared_ptr<aff_t[]> buf(new (std::nothrow) aff_t[entries]);
+  if (!buf) return SP_OK;  // (no host copy: the 8-bit tables serve)
+  SP_HIP(hipMemcpy(buf.get(), d_t16, entries * sizeof(aff_t), hipMemcpyDeviceToHost));
+  cache[key] = buf;
+  *out = buf;
+  return SP_OK;
+}
 int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint64_t h_aff[8], sp_ck** out) {
   if (num_cols == 0) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_ck_create: empty key");
   sp_ck* k = new sp_ck();
@@ -460,8 +489,7 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
     SP_HIP(sp::stream_sync(c->stream));
     k->d_tables16 = t16;
     if (ntab <= 2) {  // host copy for the single multiplications (commitments of one value: eval_W, beta, a blind's term)
-      k->h_tables16.resize(ntab * per16);
-      SP_HIP(hipMemcpy(k->h_tables16.data(), t16, ntab * per16 * sizeof(aff_t), hipMemcpyDeviceToHost));
+      if ((rc = host_tables16_of(hb, t16, ntab * per16, &k->h_tables16))) return rc;
     }
     std::lock_guard<std::mutex> l(g_t16_mu);
     if (ntab > 1) g_t16[k->d_cktables] = t16;
@@ -1171,14 +1199,16 @@ __global__ void __launch_bounds__(256) k_scale_add_to_host(const fe_t* __restric
   if (threadIdx.x == 0) flags[blockIdx.x] = seq;
 }
 // The same launched AHEAD of its scale: queued behind the product (and the upload of the addend), every block's first wave waits for the scale in the
-// mapped control line - words 0..7 the scale, 8 = sequence number, 9 = sequence + sum of the words (a poll that straddles the host's stores fails the
-// check and is repeated), 10 = abort (a sequence number: the job was finished without a scale) - and the sum goes out as above. The launch call, the
+// mapped control line - words 0..7 the scale, 8 = sequence number, 9 = sequence + sum of the words, 11 = sequence * K + position-weighted sum, 12 = the
+// sequence number again (a poll that straddles the host's stores fails a check and is repeated), 10 = abort (a sequence number: the job was finished
+// without a scale) - and the sum goes out as above. The launch call, the
 // dispatch and the kernel's start-up (~10 us of the 20 that z_vec took behind the IPA's challenge, the last step of a prove) happen while the opening's
 // walks still run. Gives up after SCALE_WAIT_TICKS (flag = ~seq: the host then launches the ordinary kernel).
 // 20 ms at the 100 MHz wall clock. Short on purpose: the scale normally follows within a few hundred microseconds, a waiter that gives up only costs the
 // ordinary launch behind the scale (scale_add_fire falls back to it), and while it waits every device-wide synchronisation of the process - a hipFree
 // between the sum-check and the opening, say - waits with it.
 constexpr unsigned long long SCALE_WAIT_TICKS = 2000000ull;
+constexpr unsigned SCALE_CHK_K = 0x9E3779B1u;
 __global__ void __launch_bounds__(256) k_scale_add_wait(const fe_t* __restrict__ x, const fe_t* __restrict__ add, const unsigned* __restrict__ ctrl, size_t n,
                                                         fe_t* __restrict__ out, volatile unsigned* __restrict__ flags, unsigned seq) {
   __shared__ fe_t sc_sh;
@@ -1195,13 +1225,19 @@ __global__ void __launch_bounds__(256) k_scale_add_wait(const fe_t* __restrict__
     int ok = 0;
     for (;;) {
       unsigned w = 0;
-      if (lane < 11) w = __hip_atomic_load(ctrl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      const unsigned sq = __shfl(w, 8, 64), chk = __shfl(w, 9, 64), ab = __shfl(w, 10, 64);
-      unsigned sum = lane < 8 ? w : 0u;
+      if (lane < 13) w = __hip_atomic_load(ctrl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned sq = __shfl(w, 8, 64), chk = __shfl(w, 9, 64), ab = __shfl(w, 10, 64), chk2 = __shfl(w, 11, 64), sq2 = __shfl(w, 12, 64);
+      unsigned sum = lane < 8 ? w : 0u, wsum = lane < 8 ? (unsigned)(lane + 1) * w : 0u;
 #pragma unroll
-      for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+      for (int m = 4; m >= 1; m >>= 1) {
+        sum += __shfl_xor(sum, m, 64);
+        wsum += __shfl_xor(wsum, m, 64);
+      }
       sum = __shfl(sum, 0, 64);
-      if (sq == seq && chk == seq + sum) {
+      wsum = __shfl(wsum, 0, 64);
+      // the challenge mailbox's line format (kernels_poly.hpp): the sequence number twice, around the payload, and two independent check words - a torn
+      // read of the write-combined line would have to keep both sums (one additive word let words that cancel mod 2^32 through)
+      if (sq == seq && sq2 == seq && chk == seq + sum && chk2 == seq * SCALE_CHK_K + wsum) {
         if (lane < 8) sc_sh.v[lane] = w;
         ok = 1;
         break;
@@ -1288,14 +1324,19 @@ static int scale_add_to_host(sp_ctx* c, hipStream_t st, const fe_t* dx, const fe
 static int scale_add_fire(sp_ctx* c, hipStream_t st, unsigned seq, const fe_t* dx, const fe_t* da, const fe_t& sc, size_t cols, uint64_t* out, const char* site) {
   const size_t nblocks = (cols + 255) / 256;
   volatile unsigned* ctl = vec_ctrl(c);
-  unsigned sum = 0;
+  unsigned sum = 0, wsum = 0;
   for (int i = 0; i < 8; ++i) {
     ctl[i] = sc.v[i];
     sum += sc.v[i];
+    wsum += (unsigned)(i + 1) * sc.v[i];
   }
   ctl[9] = seq + sum;
-  std::atomic_thread_fence(std::memory_order_release);
+  ctl[11] = seq * SCALE_CHK_K + wsum;
+  // the payload before the sequence words: a C++ fence does not order write-combined stores to BAR memory, sfence does
+  if (c->mail_dev) __builtin_ia32_sfence();
+  else std::atomic_thread_fence(std::memory_order_release);
   ctl[8] = seq;
+  ctl[12] = seq;
   vec_ctrl_flush(c);
   fe_t* h_out = reinterpret_cast<fe_t*>(c->h_pinned_vec) + 2 * c->h_pinned_vec_cols;
   volatile unsigned* h_flags = reinterpret_cast<volatile unsigned*>(reinterpret_cast<fe_t*>(c->h_pinned_vec) + 3 * c->h_pinned_vec_cols);
@@ -1303,7 +1344,8 @@ static int scale_add_fire(sp_ctx* c, hipStream_t st, unsigned seq, const fe_t* d
   for (size_t b = 0; b < nblocks; ++b) {
     for (long spins = 0; h_flags[b] != seq; ++spins) {
       if (h_flags[b] == ~seq) {  // the waiter's watchdog ran out before the scale came (a late caller): the ordinary launch behind the scale
-        for (int i = 0; i < 10; ++i) ctl[i] = 0;
+        for (int i = 0; i < 13; ++i)
+          if (i != 10) ctl[i] = 0;
         sp::slow_note(site, -1);
         return scale_add_to_host(c, st, dx, da, sc, cols, out, site);
       }
@@ -1319,7 +1361,8 @@ static int scale_add_fire(sp_ctx* c, hipStream_t st, unsigned seq, const fe_t* d
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   memcpy(out, h_out, cols * sizeof(fe_t));
-  for (int i = 0; i < 10; ++i) ctl[i] = 0;  // (the scale is the IPA's public challenge; cleared all the same)
+  for (int i = 0; i < 13; ++i)
+    if (i != 10) ctl[i] = 0;  // (the scale is the IPA's public challenge; cleared all the same)
   return SP_OK;
 }
 // scale * x + addend -> mapped host memory, polled through the per-block arrival flags (the tail of sp_rowmat_vec_eq_finish_scaled and of an announced opening)
@@ -1400,13 +1443,23 @@ int sp_rowmat_vec_eq_begin_with(sp_ctx* c, const sp_table* poly, const uint64_t*
   *out = job;
   return SP_OK;
 }
+// The addend of a job begun with one is the IPA's mask d (ipa.rs:139-149): together with the public z = r LZ + d it gives LZ away, so neither its pinned staging
+// copy nor its device copy outlives the job (the announced opening wipes its copies the same way). Called when nothing reads them any more.
+static void vec_addend_wipe(sp_ctx* c, const fe_t* d_add, size_t cols, bool upload_may_be_running) {
+  if (!d_add) return;
+  if (upload_may_be_running) (void)sp::stream_sync(c->stream3);
+  explicit_bzero(reinterpret_cast<fe_t*>(c->h_pinned_vec) + c->h_pinned_vec_cols, cols * sizeof(fe_t));
+  (void)hipMemsetAsync(const_cast<fe_t*>(d_add), 0, cols * sizeof(fe_t), c->stream3);
+}
 int sp_rowmat_vec_eq_finish(sp_ctx* c, sp_vec_job* job, uint64_t* out) {
   if (!job || !out) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish: null argument");
   const size_t cols = job->cols;
+  const fe_t* da = job->d_add;
   scale_add_abort(c, job->armed);  // (a job begun with an addend and finished without its scale: the waiting kernel leaves)
   delete job;
   SP_HIP(sp::event_sync(c->vec_ev));
   memcpy(out, c->h_pinned_vec, cols * sizeof(fe_t));
+  vec_addend_wipe(c, da, cols, true);
   return SP_OK;
 }
 int sp_rowmat_vec_eq_finish_scaled(sp_ctx* c, sp_vec_job* job, const uint64_t scale[4], uint64_t* out) {
@@ -1416,15 +1469,13 @@ int sp_rowmat_vec_eq_finish_scaled(sp_ctx* c, sp_vec_job* job, const uint64_t sc
   const unsigned armed = job->armed;
   delete job;
   if (!da) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_rowmat_vec_eq_finish_scaled: the job was begun without an addend");
-  if (armed) {
-    fe_t sca;
-    memcpy(&sca, scale, 32);
-    return scale_add_fire(c, c->stream3, armed, dx, da, sca, cols, out, "rowmat_vec_eq_finish_scaled");
-  }
   fe_t sc;
   memcpy(&sc, scale, 32);
-  // on the job's own stream: behind the product and the upload of the addend, which ended long ago
-  return scale_add_to_host(c, c->stream3, dx, da, sc, cols, out, "rowmat_vec_eq_finish_scaled");
+  // (unarmed: on the job's own stream, behind the product and the upload of the addend, which ended long ago)
+  const int rc = armed ? scale_add_fire(c, c->stream3, armed, dx, da, sc, cols, out, "rowmat_vec_eq_finish_scaled")
+                       : scale_add_to_host(c, c->stream3, dx, da, sc, cols, out, "rowmat_vec_eq_finish_scaled");
+  vec_addend_wipe(c, da, cols, rc != SP_OK);  // (the sum has arrived: the kernel that read the addend is done, and so is its upload)
+  return rc;
 }
 int sp_msm_job_finish(sp_ctx* c, sp_msm_job* job, uint64_t out_aff[8]) { return sp_msm_ck_finish(c, nullptr, job, nullptr, out_aff); }
 
@@ -1827,7 +1878,10 @@ struct sp_pcs_ahead {
   std::vector<uint8_t> rng;
   fe_t r_delta;
   sp::Keccak256State hashed;  // "poly_com" || commitment bytes hashed into a fresh sponge (valid when the transcript is fresh at the absorb: checked)
-  bool worker_busy = false, delta_launched = false, delta_collected = false, lz_launched = false, failed = false;
+  bool worker_busy = false, delta_launched = false, delta_collected = false;
+  // written by the helper thread's jobs (the launches behind the last row challenge, the announcement's own job) and read by the sum-check's thread between
+  // its rounds without waiting for the worker: atomics, sequentially consistent - these are a handful of accesses per prove
+  std::atomic<bool> lz_launched{false}, failed{false};
   // <R, d> (ipa.rs:148) with R = eq(point[nvr..]) = left (x) right: T[b] = sum_a left[a] d[a * nright + b] once the first half of R's variables is drawn
   // col_pt collects the column challenges as they arrive; col_pt_T is the snapshot T was built from (frozen when the job is submitted): sp_hyrax_prove
   // compares ITS point with col_pt_T, so a later sum-check of the same length on this context — which overwrites col_pt — cannot make a stale T pass
@@ -1851,8 +1905,8 @@ struct sp_pcs_ahead {
   bool lz_submitted = false;  // the launches behind the last row challenge are a job of the helper thread (the sum-check's thread goes on with its rounds)
   // z_vec = r LZ + d on the device (ipa.rs:160-163): the mask vector is uploaded behind delta's walk, the scaled sum lands in mapped memory
   fe_t* d_out = nullptr;      // [LZ (num_cols) | - | d (cols)] in the auxiliary lane's WS_ROWMAT_OUT
-  bool dvec_uploaded = false;
-  unsigned z_armed = 0;       // sequence number of the k_scale_add_wait queued behind L^T W (0: none), released by sp_hyrax_prove's challenge or aborted
+  std::atomic<bool> dvec_uploaded{false};
+  std::atomic<unsigned> z_armed{0};      // sequence number of the k_scale_add_wait queued behind L^T W (0: none), released by sp_hyrax_prove's challenge or aborted
   bool z_fired = false;
 };
 namespace sp {
@@ -1883,6 +1937,13 @@ void pcs_ahead_free(sp_ctx* c) {
   pcs_ahead_drain(c);
   sp_pcs_ahead* S = c->pcs_ahead;
   c->pcs_ahead = nullptr;
+  if (S->dvec_uploaded && S->d_out && c->h_pinned_vec) {
+    // a dropped or retracted announcement had staged the mask vector (pinned block) and uploaded it (auxiliary stream): neither copy outlives it.
+    // (a consumed one has wiped both already - sp_hyrax_prove - and wiping zeros again costs a 64 KiB memset off everybody's path)
+    (void)sp::stream_sync(c->stream2);
+    explicit_bzero(reinterpret_cast<fe_t*>(c->h_pinned_vec) + c->h_pinned_vec_cols, S->cols * sizeof(fe_t));
+    (void)hipMemsetAsync(S->d_out + S->ck->num_cols + 1, 0, S->cols * sizeof(fe_t), c->stream2);
+  }
   auto wipe = [S] {
     wipe_vec(S->blind);
     wipe_vec(S->dvec);
@@ -2466,6 +2527,7 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
     }
     explicit_bzero(reinterpret_cast<fe_t*>(c->h_pinned_vec) + c->h_pinned_vec_cols, cols * sizeof(fe_t));  // the mask's staging copy
     (void)hipMemsetAsync(S->d_out + num_cols + 1, 0, cols * sizeof(fe_t), c->stream2);                       // and its device copy
+    S->dvec_uploaded = false;  // (both copies are gone: pcs_ahead_free has nothing left to wipe)
   } else {
     // shared with the helper thread chunk by chunk: whoever is awake takes the next 128 elements. The owner never waits for the helper to WAKE (a sleeping
     // thread can take milliseconds when the process is at its CPU quota), only for chunks the helper has actually claimed.

@@ -22,6 +22,18 @@ int pippenger_window(size_t n) {
   return 14;
 }
 
+// waves per SIMD k_pip_bucket_tasks is compiled for: 2 = 256 registers a lane, no spills; 3 = 168 registers, 54-66 spilled (tools/spill_report.py). SPARTAN_PIP_MINW
+// picks (A/B: profiles/r06_spills.md)
+#ifndef PIP_MINW_DEFAULT
+#define PIP_MINW_DEFAULT 3
+#endif
+static int pip_minw() {
+  static const int v = [] {
+    const char* e = getenv("SPARTAN_PIP_MINW");
+    return e && e[0] == '3' ? 3 : (e && e[0] == '2' ? 2 : PIP_MINW_DEFAULT);
+  }();
+  return v;
+}
 template <int C>
 static int run_pippenger(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, size_t n, bool full_width, jac_t* result) {
   hipStream_t st = c->stream;
@@ -67,16 +79,28 @@ static int run_pippenger(sp_ctx* c, const fe_t* d_canon, const aff_t* d_bases, s
   c->timed("msm_big_buckets", 96ull * n, [&] {
     hipLaunchKernelGGL(spk::k_pip_tasks_scan, dim3(1), dim3(1024), 0, st, start, E, total, chunk, task_first, tcounts);
     hipLaunchKernelGGL(spk::k_pip_tasks_fill, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, task_first, total, task_bucket, multi_list, tcounts);
-#define PIP_TASKS(L) \
-  hipLaunchKernelGGL((spk::k_pip_bucket_tasks<L>), grid, block, 0, st, d_bases, (unsigned)n, E, order, start, chunk, task_first, task_bucket, tcounts, buckets, partial)
-    switch (lpb) {
-      case 1: PIP_TASKS(1); break;
-      case 2: PIP_TASKS(2); break;
-      case 4: PIP_TASKS(4); break;
-      case 8: PIP_TASKS(8); break;
-      case 16: PIP_TASKS(16); break;
-      case 32: PIP_TASKS(32); break;
-      default: PIP_TASKS(64); break;
+#define PIP_TASKS(L, MW) \
+  hipLaunchKernelGGL((spk::k_pip_bucket_tasks<L, MW>), grid, block, 0, st, d_bases, (unsigned)n, E, order, start, chunk, task_first, task_bucket, tcounts, buckets, partial)
+    if (pip_minw() == 2) {
+      switch (lpb) {
+        case 1: PIP_TASKS(1, 2); break;
+        case 2: PIP_TASKS(2, 2); break;
+        case 4: PIP_TASKS(4, 2); break;
+        case 8: PIP_TASKS(8, 2); break;
+        case 16: PIP_TASKS(16, 2); break;
+        case 32: PIP_TASKS(32, 2); break;
+        default: PIP_TASKS(64, 2); break;
+      }
+    } else {
+      switch (lpb) {
+        case 1: PIP_TASKS(1, 3); break;
+        case 2: PIP_TASKS(2, 3); break;
+        case 4: PIP_TASKS(4, 3); break;
+        case 8: PIP_TASKS(8, 3); break;
+        case 16: PIP_TASKS(16, 3); break;
+        case 32: PIP_TASKS(32, 3); break;
+        default: PIP_TASKS(64, 3); break;
+      }
     }
 #undef PIP_TASKS
     const size_t max_multi = (size_t)W * n / chunk + 1;  // a bucket needs more than `chunk` entries to be cut

@@ -159,6 +159,8 @@ struct sp_ctx {
   hipEvent_t eq_ev = nullptr;
   hipEvent_t aside_ev = nullptr, aside_main_ev = nullptr;  // sp_table_assemble_aside: its end / what the main stream held when it was issued
   bool aside_pending = false;
+  hipEvent_t tail_ev = nullptr;  // recorded behind the last resident quadratic tail (sp_table_assemble_aside with behind_queued = 0 waits for it)
+  bool tail_ev_pending = false;
   hipEvent_t eq_read_ev = nullptr;  // recorded behind the last k_eq_outer_lastk that READS d_eq_ahead: the next pyramids wait for it before rewriting the buffer
   bool eq_read_pending = false;
   fe_t* d_cubic_eq = nullptr;     // the cubic sum-check's two eq pyramids (EqSumCheckInstance::new tables)
@@ -180,6 +182,7 @@ struct sp_ctx {
   const unsigned* d_mail_mirror = nullptr;
   void* mail_alloc = nullptr;
   bool mail_dev = false;
+  unsigned* d_fold_tickets = nullptr;  // per-slot arrival counters of a streaming launch that finishes its own second stage (kernels_poly.hpp LazyOut)
   fe_t* d_gate = nullptr;  // MAIL_RING challenge slots written by k_mail_gate (a streaming launch queued behind its gate reads its challenge here)
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs
   void* h_pinned_fbs = nullptr;  // pinned staging of the synchronous fixed-base calls (<= 1024 scalars: the per-round commitments of the ZK verifier circuit)

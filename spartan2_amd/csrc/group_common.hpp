@@ -1,5 +1,6 @@
 // Shared by the group-side translation units of libspartan_hip.so (capi_group.hip, capi_comb.hip).
 #pragma once
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -21,8 +22,10 @@ struct sp_ck {
   const aff_t* host_htable() const { return host_table(n_tables - 1); }
   // keys of <= 2 tables (the width-1 key of eval_W / beta, h of the wide key): a host copy of the 16-bit-window tables too (16 x 65535 entries a table,
   // 64 MiB each) - a single multiplication on the host is then 16 mixed additions instead of 32 (capi_group.hip ck_mul_host)
-  std::vector<aff_t> h_tables16;
-  const aff_t* host_table16(size_t t) const { return h_tables16.empty() ? nullptr : h_tables16.data() + t * ((size_t)16 * 65535); }
+  // ONE copy per distinct base set and process (capi_group.hip host_tables16_of: eight contexts on one key share it), allocated without value-initialising;
+  // SPARTAN_HOST_T16=0 keeps none (the single multiplications then walk the 8-bit tables: 32 mixed additions instead of 16)
+  std::shared_ptr<aff_t[]> h_tables16;
+  const aff_t* host_table16(size_t t) const { return h_tables16 ? h_tables16.get() + t * ((size_t)16 * 65535) : nullptr; }
   // fixed-base comb table of the whole key (kernels_msm.hpp k_comb_*), built on first use by a commitment of many non-small rows
   mutable aff_t* d_comb = nullptr;
   mutable int comb_c = 0, comb_windows = 0;

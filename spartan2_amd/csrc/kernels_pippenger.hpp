@@ -217,8 +217,8 @@ __global__ void __launch_bounds__(256) k_pip_tasks_fill(const unsigned* __restri
   if (hi - lo > 1) multi_list[atomicAdd(&counts->multi, 1u)] = (unsigned)b;
 }
 // buckets[] must be zero (= the identity in XYZZ form) on entry: empty buckets are never written
-template <int LPB>
-__global__ void __launch_bounds__(256, 3) k_pip_bucket_tasks(const aff_t* __restrict__ bases, unsigned n, unsigned E, const unsigned* __restrict__ order,
+template <int LPB, int MINW>
+__global__ void __launch_bounds__(256, MINW) k_pip_bucket_tasks(const aff_t* __restrict__ bases, unsigned n, unsigned E, const unsigned* __restrict__ order,
                                                              const unsigned* __restrict__ start, unsigned chunk, const unsigned* __restrict__ task_first,
                                                              const unsigned* __restrict__ task_bucket, const PipTaskCounts* __restrict__ counts,
                                                              xyzz_t* __restrict__ buckets, xyzz_t* __restrict__ partial) {

@@ -35,11 +35,16 @@ struct slot_chk {
 constexpr unsigned SLOT_CHK_K = 0x9E3779B1u;
 // the same arithmetic on the host side of capi_core.hip (wait_slot / reduce_partials_wait)
 __host__ __device__ __forceinline__ void slot_chk_add(slot_chk& c, const fe_t& v, int k) {
+  // c.b += sum_i (8k + i + 1) v_i, written as (8k + 1) sum_i v_i + sum_i i v_i (the same value mod 2^32): with a run-time k the weights are ONE per-lane
+  // value instead of eight - the resident tail's compiler hoisted the eight out of its round loop and spilled them (tools/spill_report.py)
+  unsigned plain = 0, ramp = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    c.a += v.v[i];
-    c.b += (unsigned)(8 * k + i + 1) * v.v[i];
+    plain += v.v[i];
+    ramp += (unsigned)i * v.v[i];
   }
+  c.a += plain;
+  c.b += (unsigned)(8 * k + 1) * plain + ramp;
 }
 // (mapped host memory is uncached on the device side: plain stores go straight out, as two 16-byte writes per element and two 8-byte tag halves)
 __device__ __forceinline__ void slot_store_elem(fe_t* dst, const fe_t& v) { *dst = v; }
@@ -65,6 +70,21 @@ __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __r
     for (int k = 0; k < NACC; ++k) partials[(size_t)blockIdx.x * NACC + k] = acc[k];
   }
 }
+
+
+// Where a streaming launch leaves its block partials (stream_block_partials below) and, when `tickets` is set, how the LAST block of each slot finishes them:
+// the second stage (k_sum_partials_lazy) folded into its producer. nslots host result slots; group g = block >> gl belongs to slot (g / 64) % nslots, a lane
+// per group, exactly the second-stage kernel's split; per_slot blocks arrive at a slot's ticket (left at zero again by the last one).
+struct LazyOut {
+  lazy9_t* P;
+  unsigned* tickets;  // nullptr: partials only, a second-stage launch follows
+  const fe_t* eq_out;
+  fe_t* mapped;
+  unsigned seq, nslots, per_slot;
+  int gl;
+  LazyOut() = default;
+  __host__ __device__ LazyOut(lazy9_t* p) : P(p), tickets(nullptr), eq_out(nullptr), mapped(nullptr), seq(0), nslots(0), per_slot(0), gl(0) {}
+};
 
 // ---- challenge mailbox ------------------------------------------------------------------------------------------------------------------
 // A kernel that binds with a challenge the host has not drawn yet is launched AHEAD of it and picks the challenge up from a 64-byte mailbox line:
@@ -415,7 +435,7 @@ __global__ void __launch_bounds__(256) k_eval_cubic(const fe_t* __restrict__ A, 
 // mode, 2^s >= 256.
 template <int MODE, int PPT>
 __global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __restrict__ P0, const fe_t* __restrict__ P1, const fe_t* __restrict__ eq_in, int s,
-                                                              lazy9_t* __restrict__ partials);
+                                                              LazyOut partials);
 
 // ---- K1+K2 fused: bind round i with challenge r, evaluate round i+1 on the values just produced ------------------------
 // Tables have length L = 4q before the bind. Thread id in [0, q) owns the new pair (Z'[id], Z'[id+q]):
@@ -505,20 +525,95 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad(fe_t* __restrict__ A, fe
 // P[(2 w + a) nparts + b] - word-major, so that the second stage's lane, which owns a group of consecutive blocks, fetches each word of its whole
 // group with ONE vector load and a wave's loads are contiguous (block-major 72-byte records cost the old second stage one dependent, uncoalesced
 // load per block and word: 8-10 us for 150 KB).
-__device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const lazy9_t& s1, lazy9_t* __restrict__ partials) {
+// The second stage's work for result slot `slot` of `nslots` (k_sum_partials_lazy's body): a lane per group of 2^gl consecutive blocks, the lazy sum of
+// the group, ONE reduction mod p, the product with eq_out[group] when given, a modular wave sum, the slot store. AGENT: the partials were written by other
+// blocks of the SAME launch on other XCDs - read past this XCD's L2 (agent-scope loads), as the resident tail reads what its neighbours bound.
+template <bool AGENT>
+__device__ __forceinline__ void lazy_slot_sums(const uint32_t* __restrict__ P, size_t nparts, int gl, const fe_t* __restrict__ eq_out, fe_t* __restrict__ mapped, unsigned seq,
+                                               unsigned slot, unsigned nslots, int lane) {
+  const size_t ngroups = nparts >> gl, per = (size_t)1 << gl;
+  fe_t acc[2] = {fe_zero(), fe_zero()};
+  for (size_t g = (size_t)slot * 64 + lane; g < ngroups; g += (size_t)nslots * 64) {
+    fe_t f[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      lazy9_t l;
+      unsigned long long carry = 0;
+#pragma unroll
+      for (int w = 0; w < 9; ++w) {
+        const uint32_t* src = P + (size_t)(2 * w + a) * nparts + g * per;
+        unsigned long long t = carry;
+        if (per == 1) {
+          t += AGENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : src[0];
+        } else {  // (per is a power of two >= 2 and the group's words are 8-byte aligned: pairs of words per load)
+          const unsigned long long* s2 = reinterpret_cast<const unsigned long long*>(src);
+          for (size_t k = 0; k < per / 2; ++k) {
+            const unsigned long long v = AGENT ? __hip_atomic_load(s2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s2[k];
+            t += (v & 0xffffffffull) + (v >> 32);
+          }
+        }
+        l.v[w] = (uint32_t)t;
+        carry = t >> 32;
+      }
+      f[a] = lazy_reduce(l);
+    }
+    if (eq_out) {
+      const fe_t eo = eq_out[g];
+      f[0] = fe_mul<S>(f[0], eo);
+      f[1] = fe_mul<S>(f[1], eo);
+    }
+    acc[0] = fe_add<S>(acc[0], f[0]);
+    acc[1] = fe_add<S>(acc[1], f[1]);
+  }
+  acc[0] = wave_sum(acc[0]);
+  acc[1] = wave_sum(acc[1]);
+  if (lane == 0) {
+    fe_t* sl = mapped + SLOT_BASE_ELEM + 4 * slot;
+    slot_chk chk = {0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      slot_store_elem(sl + k, acc[k]);
+      slot_chk_add(chk, acc[k], k);
+    }
+    slot_store_tag(sl, seq, chk);
+  }
+}
+__device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const lazy9_t& s1, LazyOut partials) {
   __shared__ lazy9_t sm[4][2];
+  __shared__ unsigned last_sh;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     sm[wave][0] = s0;
     sm[wave][1] = s1;
   }
   __syncthreads();
+  const bool fold = partials.tickets != nullptr;
   if (threadIdx.x < 2) {  // thread 0 -> accumulator 0, thread 1 -> accumulator 1
     const lazy9_t t = lazy_add(lazy_add(sm[0][threadIdx.x], sm[1][threadIdx.x]), lazy_add(sm[2][threadIdx.x], sm[3][threadIdx.x]));
-    uint32_t* P = reinterpret_cast<uint32_t*>(partials);
+    uint32_t* P = reinterpret_cast<uint32_t*>(partials.P);
+    if (fold) {
+      // written through to where every XCD sees them (agent scope) and ACKNOWLEDGED before this block takes its ticket: no release fence - a release
+      // would write back this XCD's whole L2, i.e. wait for every block's table stores
 #pragma unroll
-    for (int w = 0; w < 9; ++w) P[(size_t)(2 * w + threadIdx.x) * gridDim.x + blockIdx.x] = t.v[w];
+      for (int w = 0; w < 9; ++w) __hip_atomic_store(P + (size_t)(2 * w + threadIdx.x) * gridDim.x + blockIdx.x, t.v[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+#pragma unroll
+      for (int w = 0; w < 9; ++w) P[(size_t)(2 * w + threadIdx.x) * gridDim.x + blockIdx.x] = t.v[w];
+    }
   }
+  if (!fold) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned slot = (unsigned)(((size_t)blockIdx.x >> partials.gl) / 64) % partials.nslots;
+    const unsigned old = __hip_atomic_fetch_add(partials.tickets + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_sh = old + 1 == partials.per_slot ? slot + 1 : 0u;
+  }
+  __syncthreads();
+  if (last_sh == 0 || threadIdx.x >= 64) return;
+  const unsigned slot = last_sh - 1;
+  if (threadIdx.x == 0) __hip_atomic_store(partials.tickets + slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  lazy_slot_sums<true>(reinterpret_cast<const uint32_t*>(partials.P), gridDim.x, partials.gl, partials.eq_out, partials.mapped, partials.seq, slot, partials.nslots, lane);
 }
 // AHEAD: launched before its challenge is known (waits at the mailbox). A separate instantiation so that the ordinary form keeps its register
 // budget (128 VGPRs, 4 waves per SIMD): holding the twelve loaded elements across the mailbox barrier costs 20 more.
@@ -526,7 +621,7 @@ __device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const l
 // so that the ordinary form stays the code it was.
 template <int MODE, bool AHEAD, bool GATED = false>
 __global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, fe_t* __restrict__ C, size_t q, fe_t r_arg,
-                                                                const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials, MailRef mref) {
+                                                                const fe_t* __restrict__ eq_in, int s, LazyOut partials, MailRef mref) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // q is a multiple of the block size here
   const size_t mask = ((size_t)1 << s) - 1;
   const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
@@ -554,7 +649,7 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic_stream(fe_t* __restrict
 // block tree and 8-pair loop leave it at 42-44 % of the HBM rate. half must be a multiple of 256 and, in factored mode, 2^s >= 256.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_eval_cubic_stream(const fe_t* __restrict__ A, const fe_t* __restrict__ B, const fe_t* __restrict__ C, size_t half,
-                                                           const fe_t* __restrict__ eq_in, int s, lazy9_t* __restrict__ partials) {
+                                                           const fe_t* __restrict__ eq_in, int s, LazyOut partials) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t mask = ((size_t)1 << s) - 1;
   const fe_t a0 = A[id], a1 = A[id + half], b0 = B[id], b1 = B[id + half], c0 = C[id];
@@ -569,7 +664,7 @@ __global__ void __launch_bounds__(256) k_eval_cubic_stream(const fe_t* __restric
 // entries are still read: nothing is assumed about the table).
 template <int MODE, int PPT>
 __global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __restrict__ P0, const fe_t* __restrict__ P1, const fe_t* __restrict__ eq_in, int s,
-                                                              lazy9_t* __restrict__ partials) {
+                                                              LazyOut partials) {
   const size_t id0 = (size_t)blockIdx.x * (256 * PPT) + threadIdx.x;
   const size_t mask = ((size_t)1 << s) - 1;
   fe_t p0[PPT], p1[PPT], w[PPT];
@@ -594,7 +689,7 @@ __global__ void __launch_bounds__(256) k_eval_products_stream(const fe_t* __rest
   }
   stream_block_partials(l0, l1, partials);
 }
-__global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, lazy9_t* __restrict__ partials,
+__global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, LazyOut partials,
                                                                MailRef mref) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const fe_t la0 = A[id], la1 = A[id + q], la2 = A[id + 2 * q], la3 = A[id + 3 * q];
@@ -612,7 +707,7 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad_stream(fe_t* __restrict_
 // (2M long, non-zero up to M + num_extra; bind_poly_var_top's `hi <= lo` branch, src/polys/multilinear.rs:118-141). The high half is not read at
 // all except for those few entries, and the evaluation of the next round still comes from registers.
 __global__ void __launch_bounds__(256) k_bind_eval_quad_stream_sparse(fe_t* __restrict__ A, fe_t* __restrict__ B, size_t q, fe_t r_arg, size_t hiA, size_t hiB,
-                                                                      lazy9_t* __restrict__ partials, MailRef mref) {
+                                                                      LazyOut partials, MailRef mref) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const fe_t la0 = A[id], la1 = A[id + q], lb0 = B[id], lb1 = B[id + q];
   const fe_t r = challenge_or(mref, r_arg);
@@ -631,7 +726,7 @@ __global__ void __launch_bounds__(256) k_bind_eval_quad_stream_sparse(fe_t* __re
 // a pair (50 us for 2^20 pairs, compute-bound); this form is bound by the 64 MB it reads. len must be a multiple of 256 * PPT.
 template <int PPT>
 __global__ void __launch_bounds__(256) k_eval_quad_stream(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t hiA, size_t hiB,
-                                                          lazy9_t* __restrict__ partials) {
+                                                          LazyOut partials) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   lazy9_t l0 = lazy_from(fe_zero()), l1 = lazy_from(fe_zero());
@@ -650,7 +745,7 @@ __global__ void __launch_bounds__(256) k_eval_quad_stream(const fe_t* __restrict
 // dot is added to the second accumulator once at the end. All 2 PPT element loads of a lane are issued before the first product.
 template <int PPT>
 __global__ void __launch_bounds__(256) k_eval_quad_stream_lowhi(const fe_t* __restrict__ A, const fe_t* __restrict__ B, size_t half, size_t hiA, size_t hiB,
-                                                                lazy9_t* __restrict__ partials) {
+                                                                LazyOut partials) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t id0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   fe_t a0[PPT], b0[PPT];
@@ -1074,7 +1169,10 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
   unsigned long long len = a.len;
   unsigned seq = a.seq0;
   int rnd = a.rnd0;
-  fe_t r = a.r0;
+  // the challenge in hand lives in r_sh (LDS), not in eight registers carried around the loop: a.r0 at first, then whatever the last mail_wait delivered;
+  // the binds read it where they use it (the 128-register budget of a 1024-thread block spilled it, tools/spill_report.py)
+  if (threadIdx.x == 0) r_sh = a.r0;
+  __syncthreads();
   bool first = true, pending2 = false;
   fe_t* slot = a.mapped + SLOT_BASE_ELEM + 4 * blockIdx.x;
   // E(id) of round `rd` (select_eq in capi_core.hip; src/sumcheck.rs:1041-1147)
@@ -1093,9 +1191,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       const fe_t ra = r_sh;
       __syncthreads();
       if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 1, &r_sh)) return;
-      r = r_sh;
       if (len == 4) {  // both rounds were the last two: the final claims
         if (threadIdx.x == 0) {
+          const fe_t r = r_sh;
           fe_t* fin = a.mapped + TAIL_FINAL_ELEM;
           const fe_t fa = bind1(bind1(a.A[0], a.A[2], ra), bind1(a.A[1], a.A[3], ra), r);
           const fe_t fb = bind1(bind1(a.B[0], a.B[2], ra), bind1(a.B[1], a.B[3], ra), r);
@@ -1146,9 +1244,9 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     SP_TT(0);
     if (!have_r && (!first || a.r0_from_mail)) {
       if (!mail_wait(a.mail, a.mirror, a.mapped, seq - 1, &r_sh)) return;
-      r = r_sh;
     }
     SP_TT(1);
+    const fe_t r = r_sh;
     // the previous round had 2q pairs: while that is more than one block's worth, the elements bound below were written by other blocks
     // (other XCDs, other L2s). They are read with agent-scope loads, which go past this XCD's L2, instead of an acquire fence, which would
     // invalidate it (measured: 4 us per round).

@@ -37,6 +37,18 @@ def _prove_both(ctx, inst, seed, tape_blocks=8192):
     used_g = gsp.prep_prove(tape)
     got, used_g2, phases = gsp.prove(tape[used_g:])
     assert (used_g, used_g2) == (used_o, used_o2)
+    # the same state three more times: the second prove queues the row tables (SPARTAN_PREP_TABLES=lazy), a later one finds them built; then the
+    # reference-order driver (what an unchanged src/spartan.rs gets over the ABI) at this configuration's own size - every proof is the oracle's
+    for _ in range(2):
+        again, used_again, _ = gsp.prove(tape[used_g:])
+        assert used_again == used_o2 and (again == want).all()
+    host.lib().ss_prep_tables_ready(gsp.ps, 1)
+    again, _, _ = gsp.prove(tape[used_g:])
+    assert (again == want).all()
+    gsp.set_flags(reference_order=True)
+    ref, used_ref, _ = gsp.prove(tape[used_g:])
+    assert used_ref == used_o2 and (ref == want).all(), "the reference-order driver's proof differs from the oracle's"
+    gsp.set_flags(reference_order=False)
     return osp, gsp, want, got, phases
 
 

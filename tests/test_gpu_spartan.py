@@ -121,6 +121,16 @@ def test_prove_is_identical_on_every_driver_path(ctx, monkeypatch):
         return words
 
     base = prove_with(ctx)
+    osp = ol.OracleSpartan(inst)  # ... and every path is compared with the ORACLE's proof, not only with each other
+    used_o = osp.prep_prove(tape)
+    want, _, _ = osp.prove(tape[used_o:])
+    assert (base == want).all()
+    # the row tables of the prepared witness at each of their build times (prep_prove's SPARTAN_PREP_TABLES): never, inside prep_prove, queued there
+    for mode in ("off", "sync", "prep"):
+        monkeypatch.setenv("SPARTAN_PREP_TABLES", mode)
+        assert (prove_with(ctx) == want).all()
+        assert (prove_with(ctx, reference_order=True) == want).all()
+    monkeypatch.delenv("SPARTAN_PREP_TABLES")
     # the reference-order driver: one thread, statement order of src/spartan.rs:226-466, PCS::prove as ONE call of sp_hyrax_prove (table walks over the
     # window tables of the key beside the commitment's hashing) — and the same call with the bucket MSMs it falls back to
     assert (prove_with(ctx, reference_order=True) == base).all()
