@@ -536,13 +536,17 @@ static void reduce_partials_launch(sp_ctx* c, size_t nblocks, int nacc) {
   c->pending_slots = (unsigned)b2;
   hipLaunchKernelGGL(spk::k_sum_partials, dim3((unsigned)b2), dim3(64), 0, c->stream, c->d_scratch, nblocks, nacc, c->d_pinned, c->result_seq);
 }
-// Second stage of a streaming launch: groups of 2^gl consecutive producer blocks, eq_out[group] applied when given. FOLDED into the producer when the
-// shape allows (kernels_poly.hpp stream_block_partials: the last block to arrive at a slot's ticket does the slot's sums - no second launch on the round's
-// critical path); otherwise k_sum_partials_lazy behind it. lazy_out() builds the kernel's argument before the launch, sum_lazy_launch() finishes after it.
+// Second stage of a streaming launch: groups of 2^gl consecutive producer blocks, eq_out[group] applied when given: k_sum_partials_lazy behind the producer,
+// or - SPARTAN_FOLD_STAGE2=1, measured and not kept as the default - FOLDED into the producer (kernels_poly.hpp stream_block_partials: the last block to
+// arrive at a slot's ticket does the slot's sums). lazy_out() builds the kernel's argument before the launch, sum_lazy_launch() finishes after it.
 static bool fold_stage2_enabled() {
   static const bool on = [] {
-    const char* e = getenv("SPARTAN_FOLD_STAGE2");  // "0": always the separate second-stage launch (A/B)
-    return !(e && e[0] == '0');
+    // "1": fold. OFF by default - measured behind the separate launch on the same box (tools/ab/run_env.sh, 3 x 200 proves each; profiles/r06_fold_stage2.txt):
+    // 0.906 (64 slots) / 0.934 (16) / 0.931 (4) against 0.873 ms - every block ends on a write-through store's acknowledgement and an agent-scope
+    // atomic (1-2 us each, and a streaming launch is ONE generation of blocks, so its end IS the kernel's end), and the last block reads the partials past
+    // its L2: together more than the 5-7 us second-stage launch they replace.
+    const char* e = getenv("SPARTAN_FOLD_STAGE2");
+    return e && e[0] == '1';
   }();
   return on;
 }
@@ -557,11 +561,20 @@ static spk::LazyOut lazy_out(sp_ctx* c, spk::lazy9_t* lp, size_t nparts, int gl,
   lo.seq = seq;
   lo.nslots = (unsigned)b2;
   lo.gl = gl;
-  // every slot must see the same number of blocks (power-of-two shapes do), and a group's words must be readable as 8-byte pairs
-  const bool even = ngroups > 0 && ((size_t)ngroups << gl) == nparts && (ngroups <= 64 || ngroups % (64 * b2) == 0) && (gl == 0 || nparts % 2 == 0);
+  // folded: as many slots as the host adds without a second stage (HOST_SUM_MAX_BLOCKS), each the contiguous run of per_slot blocks = a whole number of
+  // groups - a ticket is then contended by nparts / 64 blocks (16 at 1024) instead of 256; a group's words must be readable as 8-byte pairs
+  static const unsigned fold_slots = [] {
+    const char* e = getenv("SPARTAN_FOLD_SLOTS");
+    const int v = e ? atoi(e) : spk::HOST_SUM_MAX_BLOCKS;
+    return (unsigned)(v < 1 ? 1 : (v > spk::HOST_SUM_MAX_BLOCKS ? spk::HOST_SUM_MAX_BLOCKS : v));
+  }();
+  size_t fs = fold_slots;
+  while (fs > 1 && (fs > ngroups || ngroups % fs)) fs >>= 1;
+  const bool even = ngroups > 0 && ((size_t)ngroups << gl) == nparts && ngroups % fs == 0 && (gl == 0 || nparts % 2 == 0);
   if (fold_stage2_enabled() && even && c->d_fold_tickets) {
     lo.tickets = c->d_fold_tickets;
-    lo.per_slot = (unsigned)(nparts / b2);
+    lo.nslots = (unsigned)fs;
+    lo.per_slot = (unsigned)(nparts / fs);
   }
   return lo;
 }

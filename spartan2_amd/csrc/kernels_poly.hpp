@@ -533,7 +533,9 @@ __device__ __forceinline__ void lazy_slot_sums(const uint32_t* __restrict__ P, s
                                                unsigned slot, unsigned nslots, int lane) {
   const size_t ngroups = nparts >> gl, per = (size_t)1 << gl;
   fe_t acc[2] = {fe_zero(), fe_zero()};
-  for (size_t g = (size_t)slot * 64 + lane; g < ngroups; g += (size_t)nslots * 64) {
+  // slot s owns the contiguous groups [s G, (s + 1) G), G = ngroups / nslots (G = 64 k: the second-stage kernel's split when nslots = ngroups / 64)
+  const size_t G = ngroups / nslots;
+  for (size_t g = (size_t)slot * G + lane; g < (size_t)(slot + 1) * G; g += 64) {
     fe_t f[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -605,7 +607,7 @@ __device__ __forceinline__ void stream_block_partials(const lazy9_t& s0, const l
   if (!fold) return;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned slot = (unsigned)(((size_t)blockIdx.x >> partials.gl) / 64) % partials.nslots;
+    const unsigned slot = (unsigned)(blockIdx.x / partials.per_slot);  // (contiguous: per_slot blocks = a whole number of groups)
     const unsigned old = __hip_atomic_fetch_add(partials.tickets + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     last_sh = old + 1 == partials.per_slot ? slot + 1 : 0u;
   }

@@ -2,6 +2,7 @@
 vartime_scalar_mul (wNAF-5, msm.rs:779-867), the two-term fold_commitments (hyrax_pc.rs:757-776), rerandomize_commitment (hyrax_pc.rs:321-344),
 multiply_vec_batched (r1cs/mod.rs:1130-1166), evaluation_points_zero_check_round0 (sumcheck.rs:1163-1271)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -234,3 +235,26 @@ def test_eq_table_begun_two_coordinates_early(ctx, ell):
     hip.Table.eq_begin(ctx, r[: ell - 2], ell)
     out2.eq_finish(r2)  # another point than the one begun
     assert (out2.read() == hip.Table.eq(ctx, r2).read()).all()
+
+
+@pytest.mark.parametrize("env,targets", [
+    ("SPARTAN_FOLD_STAGE2=1", "tests/test_gpu_configs.py tests/test_gpu_sumcheck.py -k 'c1_c2 or 2_pow_21 or streaming'"),
+    ("SPARTAN_PIP_MINW=2", "tests/test_gpu_msm_big.py -k 'msm_points_matches_oracle or ragged'"),
+    ("SPARTAN_COMB_MINW=2", "tests/test_gpu_configs.py::test_c4_full_scalar_commit_2048_rows_matches_oracle"),
+    ("SPARTAN_FBTABLES_OLD=1", "tests/test_gpu_group.py -k 'fbtables_every_entry or fixed_base_tables_multi_mul_matches'"),
+])
+def test_switched_code_paths_in_a_process_of_their_own(env, targets):
+    """Code paths behind switches that are read once per process - the second stage folded into the streaming producers (measured, off by default), the
+    two-waves-per-SIMD forms of the comb / Pippenger bucket kernels (spill-free, measured behind the three-wave forms), round 5's table build - run the parity
+    tests that exercise them in a child process with the switch set: they stay bit-exact against the oracle although no default run takes them."""
+    import shlex
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    k, v = env.split("=")
+    child_env = dict(os.environ, **{k: v})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + shlex.split(targets), cwd=root, env=child_env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout or "")[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail and "no tests ran" not in tail, tail
