@@ -643,6 +643,25 @@ def main():
         barrier()
         elapsed = group.max_over_ranks(time.perf_counter() - t0)
         legs = None if args.no_sharded else sharded_legs(ctx, comm, group, 1, 2, False)
+        unsharded = None
+        if world == 1:
+            # the SAME instance through the unsharded driver (host/spartan_snark.cpp) next to the sharded one at world 1 - are the
+            # synthetic matrices that much heavier than sha256's at the same padded size, or does the sharded driver lack the latency work?
+            us = host.SpartanSNARK(ctx, inst)
+            assert us.prep_prove(tape) == used
+            us.set_flags(prefix_cache=False)
+            for _ in range(max(args.warmup, 3)):
+                uw, _, _ = us.prove(step_tape)
+            uacc, t1 = {}, time.perf_counter()
+            for _ in range(args.steps):
+                uw, _, uph = us.prove(step_tape)
+                for k_, v_ in uph.items():
+                    uacc[k_] = uacc.get(k_, 0.0) + v_
+            ums = (time.perf_counter() - t1) / args.steps * 1e3
+            unsharded = {"driver": "SpartanSNARK (host/spartan_snark.cpp), same instance, same tapes", "ms_per_step": ums,
+                         "phases_ms": {k_: v_ / args.steps for k_, v_ in uacc.items()}, "proof_identical_to_the_sharded_one": bool((np.asarray(uw) == np.asarray(words)).all()),
+                         "sharded_over_unsharded": (elapsed / args.steps * 1e3) / ums}
+            us.close()
         if rank == 0:
             out = {"metric": "synthetic R1CS 2^22 prove(), one proof sharded over the GPUs: R1CS constraints/sec", "value": inst.num_cons * args.steps / elapsed,
                    "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -652,7 +671,8 @@ def main():
                    "config": {"workload": "synthetic R1CS 2^22 (BASELINE config 4), SpartanSNARK::prove sharded by row / table slice / column / point range",
                               "num_cons_unpadded": inst.num_cons, "num_cons": sn.dims["num_cons"], "parallelism": f"one proof over {world} ranks, RCCL all-gather per round",
                               "rccl_ranks": world, "exchanges_per_prove": (comm.stats()["exchanges"] - ex0) / args.steps},
-                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items() if k_ != "exchanges"}, "sharded": legs, "roofline": None, "cpu_baseline": None}
+                   "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items() if k_ != "exchanges"}, "unsharded_same_instance": unsharded, "sharded": legs, "roofline": None,
+                   "cpu_baseline": None}
             print(json.dumps(out))
         sn.close()
         comm.close()

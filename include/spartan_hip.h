@@ -398,6 +398,11 @@ int sp_sumcheck_quad_sharded(sp_ctx* ctx, uint64_t claim_io[4], size_t rounds, s
  * (and eq product) go out through claim_io / p_io. A sharded prover exchanges sums only while its slice is large - the rounds where sharding pays -
  * then gathers the slices into tables of 2^(ell - run_rounds + k) elements (sp_table_scatter_strided) and finishes with an ordinary call on every
  * rank, instead of one exchange in every round. */
+/* the slice form with the round-0 products of the slice's own pairs (sp_multiply_vec_incremental_round0 on the row-slice shape; src/sumcheck.rs:1041-1105 first
+ * evaluation); run_rounds = 0 or ell: every round, else the first run_rounds only */
+int sp_sumcheck_cubic3_sharded_round0(sp_ctx* ctx, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus, size_t ell, size_t run_rounds, sp_table* A, sp_table* B,
+                                      sp_table* C, const sp_table* p0, const sp_table* p1, sp_transcript* tr, const uint64_t* scale, sp_reduce_hook reduce,
+                                      void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]);
 int sp_sumcheck_cubic3_sharded_partial(sp_ctx* ctx, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus, size_t ell, size_t run_rounds, sp_table* A, sp_table* B,
                                        sp_table* C, sp_transcript* tr, const uint64_t* scale, sp_reduce_hook reduce, void* reduce_user, uint64_t* out_cpolys,
                                        uint64_t* out_r);

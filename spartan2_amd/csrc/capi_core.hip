@@ -2071,6 +2071,20 @@ int sp_sumcheck_cubic3_sharded(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4]
                                uint64_t out_final[12]) {
   return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, scale_, reduce, reduce_user, nullptr, nullptr, out_cpolys, out_r, out_final);
 }
+// The slice form with the tau-independent halves of the FIRST evaluation handed in (sp_multiply_vec_incremental_round0 on the slice's rows: the pairs
+// (i, i + n/2) of a slice are the slice's own): round 1 reads 2 x 32 B a pair instead of 5 x 32. run_rounds = 0 / ell: all rounds (out_final written);
+// otherwise the first run_rounds only, as sp_sumcheck_cubic3_sharded_partial.
+int sp_sumcheck_cubic3_sharded_round0(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, size_t run_rounds, sp_table* A, sp_table* B,
+                                      sp_table* C, const sp_table* p0, const sp_table* p1, sp_transcript* tr, const uint64_t* scale_, sp_reduce_hook reduce,
+                                      void* reduce_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
+  if (!p0 || !p1 || ell == 0 || p0->len != ((size_t)1 << ell) / 2 || p1->len != p0->len)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (slice, round-0 products): product tables must have 2^(ell-1) elements");
+  if (run_rounds > ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (slice, round-0 products): run_rounds <= ell");
+  uint64_t unused[12];
+  const bool all = run_rounds == 0 || run_rounds == ell;
+  if (all && !out_final) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (slice, round-0 products): out_final");
+  return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, scale_, reduce, reduce_user, p0, p1, out_cpolys, out_r, all ? out_final : unused, all ? 0 : run_rounds);
+}
 int sp_sumcheck_cubic3_sharded_partial(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const uint64_t* taus_, size_t ell, size_t run_rounds, sp_table* A, sp_table* B,
                                        sp_table* C, sp_transcript* tr, const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, uint64_t* out_cpolys,
                                        uint64_t* out_r) {

@@ -48,6 +48,7 @@ struct ShardedPrep {
   sp_table *W = nullptr, *Wblk = nullptr;                        // replicated witness; this rank's row block (for bind_with_delayed)
   sp_table *caz = nullptr, *cbz = nullptr, *ccz = nullptr;      // cached partial products of this rank's rows
   sp_table *az = nullptr, *bz = nullptr, *cz = nullptr;
+  sp_table *p0 = nullptr, *p1 = nullptr;  // per-pair products of the outer sum-check's first round on this rank's rows (sp_multiply_vec_incremental_round0)
   sp_table *z = nullptr, *zs = nullptr, *abc = nullptr, *rx = nullptr;  // z replicated (2M), its slice, poly_ABC slice, evals_rx
   std::vector<aff_t> comm_W;  // all rows; the fixed ones filled at prep time
   std::vector<fe_t> r_W_fixed;
@@ -57,7 +58,7 @@ struct ShardedPrep {
   size_t g_cap = 0;
   bool is_small = true;
   ~ShardedPrep() {
-    for (sp_table* t : {W, Wblk, caz, cbz, ccz, az, bz, cz, z, zs, abc, rx, gS, gT[0], gT[1], gT[2]}) sp_table_free(t);
+    for (sp_table* t : {W, Wblk, caz, cbz, ccz, az, bz, cz, p0, p1, z, zs, abc, rx, gS, gT[0], gT[1], gT[2]}) sp_table_free(t);
   }
 };
 
@@ -212,6 +213,10 @@ ShardedPrep* sharded_prep_prove(const ShardedKey& pk, const uint64_t* witness_u6
     for (sp_table** t : {&ps->caz, &ps->cbz, &ps->ccz, &ps->az, &ps->bz, &ps->cz}) ck(sp_table_zeros(ctx, N / world, (size_t)-1, (size_t)-1, t), "alloc Az");
     ck(sp_multiply_vec(ctx, pk.S_rows, ps->z, ps->caz, ps->cbz, ps->ccz), "multiply_vec_precommitted (row slice)");
     ck(sp_table_zeros(ctx, N, (size_t)-1, (size_t)-1, &ps->rx), "alloc rx");
+    if (N / world >= 2) {
+      ck(sp_table_zeros(ctx, N / world / 2, (size_t)-1, (size_t)-1, &ps->p0), "alloc round-0 products");
+      ck(sp_table_zeros(ctx, N / world / 2, (size_t)-1, (size_t)-1, &ps->p1), "alloc round-0 products");
+    }
     ck(sp_table_zeros(ctx, 2 * M / world, (size_t)-1, (size_t)-1, &ps->abc), "alloc poly_ABC slice");
     ck(sp_table_zeros(ctx, 2 * M / world, (size_t)-1, (size_t)-1, &ps->zs), "alloc z slice");
     ck(sp_ctx_synchronize(ctx), "sync");
@@ -286,35 +291,92 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   if (npub != d.num_public) throw Error(SP_ERR_INVALID_INPUT_LENGTH, "public_values length");
   ck(sp_ctx_bind_thread(ctx), "device");
   const double t_start = now_ms();
+  static const bool laps_on = getenv("SPARTAN_HOST_LAPS") != nullptr;  // statement laps on stderr (diagnostics, as the unsharded drivers')
+  double t_lap = t_start;
+  auto lap = [&](const char* name) {
+    if (!laps_on) return;
+    const double t = now_ms();
+    fprintf(stderr, "sharded lap %-28s %.3f ms\n", name, t - t_lap);
+    t_lap = t;
+  };
   std::vector<fe_t> publics(npub);
   for (size_t i = 0; i < npub; ++i) publics[i] = fe_from_u64<S>(publics_u64[i]);
 
+  // The rest rows of this rank's block when the segment is all padding (commit_zeros = h * blind, hyrax_pc.rs:305-319): their blinds are drawn and the
+  // fixed-base job launched before anything else, as the unsharded driver does - the chain commitment -> absorb -> tau is what the outer sum-check waits
+  // for, and queued behind the matrix-vector product below it waited for that too (0.44 ms at config 4).
+  const size_t rows_all = M / CW, rpr = rows_all / world, lo = g * rpr, hi = lo + rpr;
+  const size_t rows_fixed = (d.num_shared + d.num_precommitted) / CW, rows_rest = d.num_rest / CW;
+  std::vector<fe_t> r_W_rest(rows_rest);
+  for (auto& b : r_W_rest) b = tape.next();
+  size_t rest_first = 0, rest_cnt = 0;
+  block_overlap(lo, hi, rows_fixed, rows_all, &rest_first, &rest_cnt);
+  sp_fb_job* rest_job = nullptr;
+  struct RestGuard {  // an error exit must not leave the context's one asynchronous fixed-base job outstanding
+    sp_ctx* ctx;
+    sp_fb_job*& job;
+    size_t n;
+    ~RestGuard() {
+      if (job) {
+        std::vector<uint64_t> sink(8 * n + 8);
+        sp_fixed_base_mul_h_finish(ctx, job, sink.data());
+      }
+    }
+  } rest_guard{ctx, rest_job, rest_cnt};
+  if (rest_cnt && d.num_rest_unpadded == 0)
+    ck(sp_fixed_base_mul_h_begin(ctx, pk.ck, u64p(r_W_rest.data() + (rest_first - rows_fixed)), rest_cnt, &rest_job), "commit_zeros (row block, begin)");
+  // z = [W | 1 | public | 0 ...] replicated; Az, Bz, Cz of this rank's rows and the round-0 products of its pairs. Issued next: the products depend on
+  // the witness and the publics alone and run under the rest rows' commitment, the transcript's absorbs and the helper's start (round 6: the product sat
+  // behind all of that, 0.23 ms of the phase clock at config 4); the slice of z the inner sum-check binds is cut out right behind it, off its path too.
+  ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
+  ck(sp_table_copy(ctx, ps.z, 0, ps.W, 0, M), "z <- W");
+  {
+    ck(sp_table_zero(ctx, ps.z, M, M), "clear z high half");
+    std::vector<fe_t> tail(pk.num_extra);
+    tail[0] = fe_one<S>();
+    std::copy(publics.begin(), publics.end(), tail.begin() + 1);
+    if (tail.size() <= 2048) ck(sp_table_write_async(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
+    else ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
+  }
+  ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
+  if (ps.p0) ck(sp_multiply_vec_incremental_round0(ctx, pk.S_rows, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz, ps.p0, ps.p1), "multiply_vec_incremental (row slice)");
+  else ck(sp_multiply_vec_incremental(ctx, pk.S_rows, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental (row slice)");
+  // the inner sum-check's z: one rank binds z itself (it is rebuilt from W by the next prove), several take their interleaved slice
+  sp_table* const z_inner = world == 1 ? ps.z : ps.zs;
+  if (world > 1) {
+    ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
+    ck(sp_table_gather_strided(ctx, ps.zs, 0, ps.z, g, world, 2 * M / world), "z slice");
+    ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
+  }
+
+  lap("z_and_spmv_issue");
   Tr tr(ctx, "SpartanSNARK");
   tr.absorb("vk", pk.vk_digest, 32);
   tr.absorb_scalars("public_values", publics.data(), npub);
-  const size_t rows_all = M / CW, rpr = rows_all / world, lo = g * rpr, hi = lo + rpr;
-  const size_t rows_fixed = (d.num_shared + d.num_precommitted) / CW, rows_rest = d.num_rest / CW;
   if (ps.rows_shared) tr.absorb("comm_W_shared", ps.comm_shared_bytes.data(), ps.comm_shared_bytes.size());
   if (ps.rows_precommitted) tr.absorb("comm_W_precommitted", ps.comm_pre_bytes.data(), ps.comm_pre_bytes.size());
   // rest rows (bellpepper/r1cs.rs:463-491): every rank draws all blinds, commits the rest rows of its block (commit_zeros = h * blind when the
   // segment is all padding), one all-gather
-  std::vector<fe_t> r_W_rest(rows_rest);
-  for (auto& b : r_W_rest) b = tape.next();
   {
     std::vector<aff_t> mine(rpr, aff_t{fe_zero(), fe_zero()});
-    size_t first, cnt;
-    block_overlap(lo, hi, rows_fixed, rows_all, &first, &cnt);
+    const size_t first = rest_first, cnt = rest_cnt;
     if (cnt) {
-      if (d.num_rest_unpadded == 0) ck(sp_fixed_base_mul_h(ctx, pk.ck, u64p(r_W_rest.data() + (first - rows_fixed)), cnt, u64p(&mine[first - lo].x)), "commit_zeros (row block)");
-      else
+      if (rest_job) {
+        sp_fb_job* j = rest_job;
+        rest_job = nullptr;
+        ck(sp_fixed_base_mul_h_finish(ctx, j, u64p(&mine[first - lo].x)), "commit_zeros (row block)");
+      } else
         ck(sp_hyrax_commit(ctx, pk.ck, ps.W, first * CW, cnt * CW, u64p(r_W_rest.data() + (first - rows_fixed)), ps.is_small ? 1 : 0, u64p(&mine[first - lo].x)),
            "commit rest (row block)");
     }
+    lap("commit_rest_rows");
     std::vector<aff_t> all;
     gather_rows(comm, mine, &all);
+    lap("gather_rows");
     for (size_t r = rows_fixed; r < rows_all; ++r) ps.comm_W[r] = all[r];
     const std::vector<uint8_t> b = commitment_bytes(ps.comm_W.data() + rows_fixed, rows_rest);
     tr.absorb("comm_W_rest", b.data(), b.size());
+    lap("absorb_rest_rows");
   }
   // the proof's comm_W omits the rows of empty segments (there are none in the padded layout: a segment with no variables has no rows)
   std::vector<aff_t> comm_W;
@@ -359,6 +421,40 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     size_t nvr = 0;
     sp_points* pts = nullptr;
     sp_msm_job* lz_job = nullptr;
+    // behind the row challenges too (round 6): this rank's part of L^T W (bind_with_delayed with eq(r[k..nvr), .) formed on the device, a stream of its own)
+    // and r_LZ = <eq(r_rows, .), r_W> (2 x 2^nvr host products) - both used to sit behind the LAST challenge on the proving thread
+    sp_vec_job* vec_job = nullptr;
+    const sp_table* Wblk = nullptr;
+    const fe_t* r_W = nullptr;
+    size_t n_rW = 0;
+    fe_t r_LZ;
+    bool have_r_LZ = false;
+    // ... and behind the COLUMN challenges (state 3, published after the last round): <R, d> of ipa.rs:148 (2 x 2048 host products) beside the proving
+    // thread's own end-of-prove work
+    int cols_state = 0;
+    bool rows_stage_done = false;  // everything the helper starts before it waits for the column challenges is in place (or it has given up): set under mu
+    void mark_rows_stage_done() {
+      {
+        std::lock_guard<std::mutex> l(mu);
+        rows_stage_done = true;
+      }
+      cv.notify_all();
+    }
+    void wait_rows_stage() {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return rows_stage_done; });
+    }
+    const fe_t* col_point = nullptr;
+    size_t n_col = 0;
+    fe_t ip;
+    bool have_ip = false;
+    void publish_cols(int v) {
+      {
+        std::lock_guard<std::mutex> l(mu);
+        if (cols_state == 0) cols_state = v;
+      }
+      cv.notify_one();
+    }
     void publish(int v) {
       {
         std::lock_guard<std::mutex> l(mu);
@@ -371,8 +467,13 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     }
     ~Ahead() {  // error exits: the helper's products are still owned here
       publish(2);
+      publish_cols(2);
       join();
       uint64_t sink[8];
+      if (vec_job) {
+        std::vector<uint64_t> vs(4 * 4096);
+        sp_rowmat_vec_eq_finish(ctx, vec_job, vs.data());
+      }
       if (delta_job) sp_msm_ck_finish(ctx, key, delta_job, nullptr, sink);
       if (lz_job) sp_msm_job_finish(ctx, lz_job, sink);
       if (poly_com) sp_absorb_state_free(poly_com);
@@ -381,6 +482,9 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   } ahead;
   ahead.ctx = ctx;
   ahead.key = pk.ck;
+  ahead.Wblk = ps.Wblk;
+  ahead.r_W = r_W.data();
+  ahead.n_rW = r_W.size();
   const size_t ncols_ipa = (size_t)1 << ((log2_ceil(M)) - log2_ceil(rows_all));
   const size_t nvr_rows = log2_ceil(rows_all), ly_all = log2_ceil(M) + 1;
   // the row challenges are r_y[1 ..= nvr] (the observer sees every round, slice or gathered); the block must hold at least two rows
@@ -410,31 +514,47 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
             ahead.cv.wait(lk, [&] { return ahead.rows_state != 0; });
             st = ahead.rows_state;
           }
-          if (st == 1) ck(sp_msm_eq_begin(ctx, ahead.pts, u64p(ahead.r_rows + k), ahead.nvr - k, &ahead.lz_job), "comm_LZ (begin)");
+          if (st == 1) {
+            ck(sp_msm_eq_begin(ctx, ahead.pts, u64p(ahead.r_rows + k), ahead.nvr - k, &ahead.lz_job), "comm_LZ (begin)");
+            if (ncols_ipa <= 4096 && ahead.nvr - k <= 20)
+              ck(sp_rowmat_vec_eq_begin(ctx, ahead.Wblk, u64p(ahead.r_rows + k), ahead.nvr - k, ncols_ipa, &ahead.vec_job), "bind_with_delayed (begin)");
+            const std::vector<fe_t> Lh = eq_evals_host(ahead.r_rows, ahead.nvr);
+            if (Lh.size() == ahead.n_rW) {
+              fe_t acc = fe_zero();
+              for (size_t i = 0; i < Lh.size(); ++i) acc = fe_add<S>(acc, fe_mul<S>(Lh[i], ahead.r_W[i]));
+              ahead.r_LZ = acc;
+              ahead.have_r_LZ = true;
+            }
+            ahead.mark_rows_stage_done();
+            int cs;
+            {
+              std::unique_lock<std::mutex> lk(ahead.mu);
+              ahead.cv.wait(lk, [&] { return ahead.cols_state != 0; });
+              cs = ahead.cols_state;
+            }
+            if (cs == 1) {
+              const std::vector<fe_t> Rh = eq_evals_host(ahead.col_point, ahead.n_col);
+              if (Rh.size() == ahead.dvec.size()) {
+                fe_t acc = fe_zero();
+                for (size_t i = 0; i < Rh.size(); ++i) acc = fe_add<S>(acc, fe_mul<S>(Rh[i], ahead.dvec[i]));
+                ahead.ip = acc;
+                ahead.have_ip = true;
+              }
+            }
+          }
         }
       } catch (...) {
         ahead.err = std::current_exception();
       }
+      ahead.mark_rows_stage_done();
     });
   }
-
-  // z = [W | 1 | public | 0 ...] replicated; Az, Bz, Cz of this rank's rows
-  ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
-  ck(sp_table_copy(ctx, ps.z, 0, ps.W, 0, M), "z <- W");
-  {
-    ck(sp_table_zero(ctx, ps.z, M, M), "clear z high half");
-    std::vector<fe_t> tail(pk.num_extra);
-    tail[0] = fe_one<S>();
-    std::copy(publics.begin(), publics.end(), tail.begin() + 1);
-    ck(sp_table_write(ctx, ps.z, M, u64p(tail.data()), tail.size()), "z tail");
-  }
-  ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
-  ck(sp_multiply_vec_incremental(ctx, pk.S_rows, ps.z, ps.caz, ps.cbz, ps.ccz, ps.az, ps.bz, ps.cz), "multiply_vec_incremental (row slice)");
 
   const size_t lx = log2_ceil(N), ly = log2_ceil(M) + 1;
   std::vector<fe_t> tau(lx);
   for (auto& t : tau) t = tr.squeeze("t");
   const double t_mv = now_ms();
+  lap("helper_start_and_tau");
 
   SpartanProofBuf proof;
   for (const aff_t& a : comm_W) proof.pp(a);
@@ -452,9 +572,14 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     fe_t fin[3];
     const size_t loc = lx - k, R = local_rounds(lx, k);
     if (R == loc) {  // unsharded, or the hand-over at one element per rank
-      ck(sp_sumcheck_cubic3_sharded(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), loc, ps.az, ps.bz, ps.cz, tr.t, k ? u64p(&scale) : nullptr,
-                                    k ? reduce_hook : nullptr, &comm, u64p(outer_polys.data()), u64p(r_x.data()), u64p(fin)),
-         "outer sum-check (local rounds)");
+      if (ps.p0)
+        ck(sp_sumcheck_cubic3_sharded_round0(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), loc, 0, ps.az, ps.bz, ps.cz, ps.p0, ps.p1, tr.t, k ? u64p(&scale) : nullptr,
+                                             k ? reduce_hook : nullptr, &comm, u64p(outer_polys.data()), u64p(r_x.data()), u64p(fin)),
+           "outer sum-check (local rounds)");
+      else
+        ck(sp_sumcheck_cubic3_sharded(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), loc, ps.az, ps.bz, ps.cz, tr.t, k ? u64p(&scale) : nullptr,
+                                      k ? reduce_hook : nullptr, &comm, u64p(outer_polys.data()), u64p(r_x.data()), u64p(fin)),
+           "outer sum-check (local rounds)");
       if (k) {
         std::vector<fe_t> all(3 * world);
         comm.allgather(fin, sizeof fin, all.data());
@@ -475,7 +600,11 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
            "outer sum-check (last rounds)");
       }
     } else {  // R slice rounds with one exchange each, ONE bulk hand-over, then lx - R rounds on the gathered tables
-      if (R)
+      if (R && ps.p0)
+        ck(sp_sumcheck_cubic3_sharded_round0(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), loc, R, ps.az, ps.bz, ps.cz, ps.p0, ps.p1, tr.t, u64p(&scale), reduce_hook, &comm,
+                                             u64p(outer_polys.data()), u64p(r_x.data()), nullptr),
+           "outer sum-check (slice rounds)");
+      else if (R)
         ck(sp_sumcheck_cubic3_sharded_partial(ctx, u64p(&claim), u64p(&p), u64p(tau.data()), loc, R, ps.az, ps.bz, ps.cz, tr.t, u64p(&scale), reduce_hook, &comm,
                                               u64p(outer_polys.data()), u64p(r_x.data())),
            "outer sum-check (slice rounds)");
@@ -491,20 +620,18 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   for (const fe_t& f : outer_polys) proof.pf(f);
   for (int i = 0; i < 3; ++i) proof.pf(claims_outer[i]);
   const double t_outer = now_ms();
+  lap("outer");
 
   const fe_t r = tr.squeeze("r");
   const fe_t claim_inner_joint = fe_add<S>(fe_add<S>(claims_outer[0], fe_mul<S>(r, claims_outer[1])), fe_mul<S>(fe_mul<S>(r, r), claims_outer[2]));
   ck(sp_eq_table_into(ctx, u64p(r_x.data()), lx, ps.rx), "evals_rx");
   ck(sp_poly_abc(ctx, pk.S_cols, ps.rx, u64p(&r), 2 * M / world, ps.abc), "poly_ABC (column slice)");
-  ck(sp_table_set_len(ps.z, 2 * M, (size_t)-1, (size_t)-1), "z len");
-  ck(sp_table_gather_strided(ctx, ps.zs, 0, ps.z, g, world, 2 * M / world), "z slice");
-  ck(sp_table_set_len(ps.z, pk.num_cols, (size_t)-1, (size_t)-1), "z len");
   const double t_abc = now_ms();
 
   // inner sum-check on slices of the 2M-long tables: (lo_eff, hi_eff) = (M / world, this slice's share of the num_extra entries)
   const size_t extra_here = ceil_slice(pk.num_extra, g, world);
   ck(sp_table_set_len(ps.abc, 2 * M / world, M / world, extra_here), "abc len");
-  ck(sp_table_set_len(ps.zs, 2 * M / world, M / world, extra_here), "z len");
+  ck(sp_table_set_len(z_inner, 2 * M / world, M / world, extra_here), "z len");
   std::vector<fe_t> inner_polys(2 * ly), r_y(ly);
   fe_t claims_inner[2];
   {
@@ -525,7 +652,7 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     if (ly != ly_all) throw Error(SP_ERR_INTERNAL, "sharded prover: inner round count");
     const size_t loc = ly - k, R = local_rounds(ly, k);
     if (R == loc) {
-      ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), loc, ps.abc, ps.zs, tr.t, k ? reduce_hook : nullptr, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
+      ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), loc, ps.abc, z_inner, tr.t, k ? reduce_hook : nullptr, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
                                            u64p(r_y.data()), u64p(fin)),
          "inner sum-check (local rounds)");
       if (k) {
@@ -550,10 +677,10 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
       }
     } else {
       if (R)
-        ck(sp_sumcheck_quad_sharded_partial(ctx, u64p(&claim), loc, R, ps.abc, ps.zs, tr.t, reduce_hook, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
+        ck(sp_sumcheck_quad_sharded_partial(ctx, u64p(&claim), loc, R, ps.abc, z_inner, tr.t, reduce_hook, &comm, &Obs::fn, &obs, u64p(inner_polys.data()),
                                             u64p(r_y.data())),
            "inner sum-check (slice rounds)");
-      sp_table* const sl[2] = {ps.abc, ps.zs};
+      sp_table* const sl[2] = {ps.abc, z_inner};
       gather_slices(ctx, comm, ps, sl, 2, (size_t)1 << (loc - R));
       obs.base = R;
       ck(sp_sumcheck_quad_sharded_observed(ctx, u64p(&claim), ly - R, ps.gT[0], ps.gT[1], tr.t, nullptr, nullptr, &Obs::fn, &obs, u64p(inner_polys.data() + 2 * R),
@@ -573,6 +700,7 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   if (fe_is_zero(denom)) throw Error(SP_ERR_DIVISION_BY_ZERO, "DivisionByZero");
   const fe_t eval_W = fe_mul<S>(fe_sub<S>(eval_Z, fe_mul<S>(r_y[0], eval_X)), fe_inv_vartime<S>(denom));
   const double t_inner = now_ms();
+  lap("abc_and_inner");
 
   // HyraxPCS::prove (hyrax_pc.rs:387-478) + InnerProductArgumentLinear::prove (ipa.rs:125-170)
   const fe_t blind_eval_W = tape.next();
@@ -580,12 +708,19 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   proof.pf(blind_eval_W);
   const fe_t* point = r_y.data() + 1;
   const size_t npoint = ly - 1, nvr = log2_ceil(rows_all);
-  const std::vector<fe_t> L = eq_evals_host(point, nvr), Rv = eq_evals_host(point + nvr, npoint - nvr);
-  const size_t ncols = Rv.size();  // 2048
+  ahead.col_point = point + nvr;
+  ahead.n_col = npoint - nvr;
+  ahead.publish_cols(1);  // the helper forms <R, d> from here on (when it got as far as the row challenges; otherwise below)
+  const size_t ncols = (size_t)1 << (npoint - nvr);  // 2048
   aff_t comm_eval_W;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&eval_W), 1, u64p(&blind_eval_W), u64p(&comm_eval_W.x)), "commit eval_W");
-  ahead.join();
-  if (ahead.err) std::rethrow_exception(ahead.err);
+  lap("comm_eval_W");
+  ahead.wait_rows_stage();  // (the helper may still be forming <R, d>: joined in front of beta)
+  if (ahead.err) {
+    ahead.publish_cols(2);
+    ahead.join();
+    std::rethrow_exception(ahead.err);
+  }
   if (ncols != ncols_ipa) throw Error(SP_ERR_INTERNAL, "sharded prover: IPA width mismatch");
   ck(sp_transcript_absorb_prepared(tr.t, ahead.poly_com), "poly_com");  // the state itself is released by `ahead`
   tr.dom_sep("inner product argument (linear)");
@@ -598,7 +733,21 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
   {
     const size_t rec = ncols + 4;  // in field-element units (a point = 2 elements)
     std::vector<fe_t> mine(rec), all(rec * world);
-    ck(sp_rowmat_vec(ctx, ps.Wblk, rpr, ncols, u64p(L.data() + lo), u64p(mine.data())), "bind_with_delayed (row block)");
+    std::vector<fe_t> L;  // eq(r_rows, .): only the paths the helper did not take ahead need it on this thread
+    if (ahead.vec_job) {  // begun by the helper behind the row challenges, weights eq(r[k..nvr), .): finish, then the rank's factor
+      sp_vec_job* j = ahead.vec_job;
+      ahead.vec_job = nullptr;
+      ck(sp_rowmat_vec_eq_finish(ctx, j, u64p(mine.data())), "bind_with_delayed (finish)");
+      if (k) {
+        fe_t sc = fe_one<S>();
+        for (size_t i = 0; i < k; ++i) sc = fe_mul<S>(sc, ((g >> (k - 1 - i)) & 1) ? point[i] : fe_sub<S>(fe_one<S>(), point[i]));
+        for (size_t i = 0; i < ncols; ++i) mine[i] = fe_mul<S>(mine[i], sc);
+      }
+    } else {
+      L = eq_evals_host(point, nvr);
+      ck(sp_rowmat_vec(ctx, ps.Wblk, rpr, ncols, u64p(L.data() + lo), u64p(mine.data())), "bind_with_delayed (row block)");
+    }
+    lap("LtW_finish");
     if (ahead.lz_job) {  // started by the helper at round nvr: finish, then the rank's factor eq(r[0..k), rank bits)
       sp_msm_job* j = ahead.lz_job;
       ahead.lz_job = nullptr;
@@ -612,8 +761,10 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
         memcpy(&mine[ncols], &part, sizeof(aff_t));
       }
     } else {
+      if (L.empty()) L = eq_evals_host(point, nvr);
       ck(sp_msm(ctx, u64p(L.data() + lo), u64p(&comm_W[lo].x), rpr, u64p(&mine[ncols])), "comm_LZ (point range)");
     }
+    lap("comm_LZ_finish");
     const size_t cpr = ncols / world;
     if (cpr * world != ncols) throw Error(SP_ERR_INTERNAL, "sharded prover: key width not divisible by the number of ranks");
     {
@@ -622,7 +773,9 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
       if (j) ck(sp_msm_ck_finish(ctx, pk.ck, j, nullptr, u64p(&mine[ncols + 2])), "delta (point range)");
       else ck(sp_msm(ctx, u64p(dvec.data() + g * cpr), u64p(&pk.gens[g * cpr].x), cpr, u64p(&mine[ncols + 2])), "delta (point range)");
     }
+    lap("lz_delta_finish");
     comm.allgather(mine.data(), rec * sizeof(fe_t), all.data());
+    lap("pcs_exchange");
     std::vector<aff_t> p1(world), p2(world + 1);
     for (size_t rr = 0; rr < world; ++rr) {
       const fe_t* rp = all.data() + rr * rec;
@@ -634,9 +787,23 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     ck(sp_point_sum(u64p(&p1[0].x), world, u64p(&comm_LZ.x)), "comm_LZ (sum)");
     ck(sp_point_sum(u64p(&p2[0].x), world + 1, u64p(&delta.x)), "delta (sum)");
   }
+  lap("point_sums");
+  ahead.join();
+  if (ahead.err) std::rethrow_exception(ahead.err);
+  lap("join_helper");
   fe_t r_LZ = fe_zero(), ip = fe_zero();
-  for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], r_W[i]));
-  for (size_t i = 0; i < ncols; ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], dvec[i]));
+  if (ahead.have_r_LZ) {
+    r_LZ = ahead.r_LZ;
+  } else {
+    const std::vector<fe_t> L = eq_evals_host(point, nvr);
+    for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], r_W[i]));
+  }
+  if (ahead.have_ip) {
+    ip = ahead.ip;
+  } else {
+    const std::vector<fe_t> Rv = eq_evals_host(point + nvr, npoint - nvr);
+    for (size_t i = 0; i < ncols; ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], dvec[i]));
+  }
   aff_t beta;
   ck(sp_hyrax_commit_small(ctx, pk.ck_s, u64p(&ip), 1, u64p(&r_beta), u64p(&beta.x)), "beta");
   {
@@ -650,12 +817,14 @@ SpartanProofBuf sharded_prove(const ShardedKey& pk, ShardedPrep& ps, const uint6
     tr.absorb("beta", b, 64);
   }
   const fe_t rr = tr.squeeze("r");
+  lap("beta_and_transcript");
   proof.pp(delta);
   proof.pp(beta);
   for (size_t i = 0; i < ncols; ++i) proof.pf(fe_add<S>(fe_mul<S>(rr, LZ[i]), dvec[i]));
   proof.pf(fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta));
   proof.pf(fe_add<S>(fe_mul<S>(rr, blind_eval_W), r_beta));
   const double t_end = now_ms();
+  lap("z_vec");
   if (phase_ms) {
     phase_ms[0] = t_wit - t_start;
     phase_ms[1] = t_mv - t_wit;
