@@ -616,6 +616,36 @@ def main():
                    "kernel_ms_per_step": {k_: v_[0] / args.steps for k_, v_ in ks.items() if v_[1]},
                    "kernel_alg_GBps": {k_: v_[2] / max(v_[0], 1e-9) / 1e6 for k_, v_ in ks.items() if v_[1]},
                    "sharded": None, "roofline": None, "cpu_baseline": None}
+            fp = ks["nifs_fold_prove"]
+            if fp[1]:
+                ach = (fp[2] / fp[1]) / (fp[0] / fp[1] * 1e-3) / 1e9
+                res["roofline"] = {"bound": "hbm", "kernel": "k_nifs_fold_prove (merged fold + prove rounds of NeutronNovaNIFS::prove: 384 B per k and prove pair, SURVEY 8(d))",
+                                   "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "launches": fp[1] / args.steps,
+                                   "avg_launch_us": fp[0] / fp[1] * 1e3, "alg_bytes_per_launch": fp[2] / fp[1],
+                                   "note": "HIP events on the launching stream inside the timed proves (ctx.kernel_stats); per-round launches of the data-parallel rounds"}
+            res["host_serial_ms_note"] = ("~14.8 ms of every step is ONE Keccak-256 sponge absorbing the 256 instances' commitments (8.4 MB, 61.7 K dependent permutations: "
+                                          "transcript.absorb(b\"U\", U) for every U, src/neutronnova_zk.rs:553-555) before tau exists; nothing on the device can start "
+                                          "before tau (tools: SPARTAN_HOST_LAPS=1). The reference pays the same sponge on its CPU")
+            if world == 1 and not args.no_cpu_baseline:
+                import ctypes as _ct
+
+                import oracle_lib as ol  # test infrastructure, used here only as the reported CPU baseline (a bounded sample: 4 instances of the same shape)
+
+                cores = ol.lib().orc_set_threads(min(spd.cpu_budget(), 32))
+                n_cpu = 4
+                oshape = ol.OracleShape(distinct[0])
+                okey = _ct.c_void_p(ol.lib().orc_hyrax_setup(b"ck", _ct.c_size_t(CW)))
+                Wc = np.stack([host.padded_witness_limbs(dims, distinct[i & 1].witness) for i in range(n_cpu)])
+                Xc = np.stack([X2[i & 1] for i in range(n_cpu)])
+                rc_ = np.stack([rWs[i] for i in range(n_cpu)])
+                cc = np.stack([comms[i] for i in range(n_cpu)])
+                t1 = time.perf_counter()
+                ol.nifs_prove(oshape, okey, cc, Xc, Wc, rc_, True, ol.Transcript(b"neutronnova_prove"), ol.transcript_round_hook(ol.Transcript(b"vc")))
+                secs = time.perf_counter() - t1
+                res["cpu_baseline"] = {"value": distinct[0].num_cons * n_cpu / secs, "unit": "constraints/s", "cores": cores, "kind": "port",
+                                       "sample": f"NeutronNovaNIFS::prove of {n_cpu} of the {n_total} instances (same 2^{dims['num_cons'].bit_length() - 1}-constraint shape, layers "
+                                                 f"built inside the call) on the CPU oracle (C++ restatement, OpenMP over {cores} threads): {secs * 1e3:.0f} ms",
+                                       "ms": secs * 1e3, "instances": n_cpu}
             print(json.dumps(res))
         host.nifs_free(prepared)
         comm.close()

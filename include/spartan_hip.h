@@ -240,6 +240,9 @@ int sp_msm_small_u64(sp_ctx* ctx, const uint64_t* scalars, const uint64_t* bases
  * `rows` base rows of n affine points each (row-major); one affine result per row. FoldingEngineTrait::fold_commitments
  * (hyrax_pc.rs:737-793) is this call on the instances' commitment rows. */
 int sp_msm_shared_weights(sp_ctx* ctx, const uint64_t* weights, size_t n, const uint64_t* bases_rows_aff, size_t rows, uint64_t* out_rows_aff);
+/* the same on the context's auxiliary stream and its workspaces: callable from a helper thread beside the owner's calls on the main stream (fold_commitments,
+ * src/neutronnova_zk.rs:1204-1211, beside fold_witnesses / the layer folds: the group work needs the weights alone) */
+int sp_msm_shared_weights_aux(sp_ctx* ctx, const uint64_t* weights, size_t n, const uint64_t* bases_rows_aff, size_t rows, uint64_t* out_rows_aff);
 /* vartime_scalar_mul (src/provider/msm.rs:779-867, width-5 wNAF) of n points by ONE scalar: out[i] = scalar * points[i]. The call site is the
  * two-term fold with a unit weight (hyrax_pc.rs:757-776): see sp_fold_commitments2. Few points run on the host side of the library (a dependent
  * chain of ~300 group operations: one CPU core finishes it 40x sooner than one GPU lane), many on the device, one lane per point. */

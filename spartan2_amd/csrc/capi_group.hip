@@ -258,7 +258,10 @@ int sp_fold_tables(sp_ctx* c, const sp_table* const* Ws, size_t n, const uint64_
   return SP_OK;
 }
 
-int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const uint64_t* bases_rows, size_t rows, uint64_t* out_rows_aff) {
+// lane 0: the context's main stream and workspaces (the owner's thread); lane 1: the auxiliary stream and its workspaces - callable from a helper thread
+// beside the owner's calls on the main stream (sp_msm_shared_weights_aux: the commitment fold of a NIFS beside its witness and layer folds)
+static int msm_shared_weights_on(sp_ctx* c, int lane, const uint64_t* weights, size_t n, const uint64_t* bases_rows, size_t rows, uint64_t* out_rows_aff) {
+  hipStream_t const st = lane ? c->stream2 : c->stream;
   if (rows == 0) return SP_OK;
   if (n == 0) {
     memset(out_rows_aff, 0, rows * sizeof(aff_t));
@@ -273,53 +276,53 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
   double t_lap = now();
   auto lap = [&](const char* what) {
     if (!laps) return;
-    (void)sp::stream_sync(c->stream);
+    (void)sp::stream_sync(st);
     const double t = now();
     fprintf(stderr, "msm_shared_weights lap %-20s %8.3f ms\n", what, t - t_lap);
     t_lap = t;
   };
   fe_t* canon;
   int rc;
-  if ((rc = upload_canonical(c, weights, n, &canon))) return rc;
+  if ((rc = upload_canonical(c, weights, n, &canon, lane))) return rc;
   // grow-only context workspaces (no hipMalloc / hipFree on the path)
-  aff_t* dbases = (aff_t*)c->workspace(sp_ctx::WS_BASES_TMP, rows * n * sizeof(aff_t));
-  fe_t* folded = (fe_t*)c->workspace(sp_ctx::WS_MSM_FOLDED, n * sizeof(fe_t));
-  unsigned* order = (unsigned*)c->workspace(sp_ctx::WS_MSM_ORDER, (size_t)windows * n * 4);
-  unsigned* start = (unsigned*)c->workspace(sp_ctx::WS_MSM_START, (size_t)windows * (spk::MSM_BUCKETS + 1) * 4);
-  jac_t* buckets = (jac_t*)c->workspace(sp_ctx::WS_MSM_BUCKETS, rows * windows * spk::MSM_BUCKETS * sizeof(jac_t));
-  jac_t* wsum = (jac_t*)c->workspace(sp_ctx::WS_MSM_WSUM, rows * windows * sizeof(jac_t));
-  jac_t* drows = (jac_t*)c->workspace(sp_ctx::WS_COMMIT_ROWS, rows * sizeof(jac_t));
+  aff_t* dbases = (aff_t*)c->workspace(sp_ctx::WS_BASES_TMP, rows * n * sizeof(aff_t), lane);
+  fe_t* folded = (fe_t*)c->workspace(sp_ctx::WS_MSM_FOLDED, n * sizeof(fe_t), lane);
+  unsigned* order = (unsigned*)c->workspace(sp_ctx::WS_MSM_ORDER, (size_t)windows * n * 4, lane);
+  unsigned* start = (unsigned*)c->workspace(sp_ctx::WS_MSM_START, (size_t)windows * (spk::MSM_BUCKETS + 1) * 4, lane);
+  jac_t* buckets = (jac_t*)c->workspace(sp_ctx::WS_MSM_BUCKETS, rows * windows * spk::MSM_BUCKETS * sizeof(jac_t), lane);
+  jac_t* wsum = (jac_t*)c->workspace(sp_ctx::WS_MSM_WSUM, rows * windows * sizeof(jac_t), lane);
+  jac_t* drows = (jac_t*)c->workspace(sp_ctx::WS_COMMIT_ROWS, rows * sizeof(jac_t), lane);
   if (!dbases || !folded || !order || !start || !buckets || !wsum || !drows) return SP_ERR_NO_DEVICE;
-  SP_HIP(hipMemcpyAsync(dbases, bases_rows, rows * n * sizeof(aff_t), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(spk::k_fold_sign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, canon, n, folded);
+  SP_HIP(hipMemcpyAsync(dbases, bases_rows, rows * n * sizeof(aff_t), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(spk::k_fold_sign, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, canon, n, folded);
   // the digit decomposition / bucket order is shared by every row (msm.rs:266-300); buckets and window sums are per row
   lap("upload");
-  hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, c->stream, folded, (unsigned)n, order, start);
+  hipLaunchKernelGGL(spk::k_msm_sort, dim3(windows), dim3(256), 0, st, folded, (unsigned)n, order, start);
   if (rows >= 64) {  // throughput regime: one lane per (row, window, bucket), work-efficient window sums
     const size_t total = rows * (size_t)windows * spk::MSM_BUCKETS, nwin = rows * (size_t)windows;
-    c->timed("msm_shared_bucket_sum", 64ull * n * rows, [&] {
-      hipLaunchKernelGGL(spk::k_msm_bucket_sum_shared, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dbases, (unsigned)n, order, start, windows, total, buckets);
+    c->timed_on(st, "msm_shared_bucket_sum", 64ull * n * rows, [&] {
+      hipLaunchKernelGGL(spk::k_msm_bucket_sum_shared, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dbases, (unsigned)n, order, start, windows, total, buckets);
     });
     lap("sort + bucket sums");
-    hipLaunchKernelGGL(spk::k_msm_window_reduce_seg, dim3((unsigned)((nwin * 8 + 255) / 256)), dim3(256), 0, c->stream, buckets, nwin, wsum);
+    hipLaunchKernelGGL(spk::k_msm_window_reduce_seg, dim3((unsigned)((nwin * 8 + 255) / 256)), dim3(256), 0, st, buckets, nwin, wsum);
   } else {
     unsigned lanes = (unsigned)windows * spk::MSM_BUCKETS * spk::MSM_LANES_PER_BUCKET;
-    c->timed("msm_shared_bucket_sum", 64ull * n * rows, [&] {
-      hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, c->stream, dbases, (unsigned)n, order, start, windows, buckets);
+    c->timed_on(st, "msm_shared_bucket_sum", 64ull * n * rows, [&] {
+      hipLaunchKernelGGL(spk::k_msm_bucket_sum, dim3((lanes + 255) / 256, (unsigned)rows), dim3(256), 0, st, dbases, (unsigned)n, order, start, windows, buckets);
     });
     lap("sort + bucket sums");
     if (rows * (size_t)windows <= 1024)  // few (row, window) pairs: the block-cooperative form (chain latency is all there is)
-      hipLaunchKernelGGL(spk::k_msm_window_reduce_coop, dim3(windows, (unsigned)rows), dim3(4 * spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
+      hipLaunchKernelGGL(spk::k_msm_window_reduce_coop, dim3(windows, (unsigned)rows), dim3(4 * spk::MSM_BUCKETS), 0, st, buckets, wsum);
     else
-      hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, c->stream, buckets, wsum);
+      hipLaunchKernelGGL(spk::k_msm_window_reduce, dim3(windows, (unsigned)rows), dim3(spk::MSM_BUCKETS), 0, st, buckets, wsum);
   }
   lap("window sums");
   std::vector<jac_t> res(rows);
   if (rows <= 64) {
     // few rows: the 256-doubling window Horner is a latency chain (~3 ms for one lane per row on the device, ~60 us per row on the host)
     std::vector<jac_t> ws(rows * windows);
-    SP_HIP(hipMemcpyAsync(ws.data(), wsum, ws.size() * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(sp::stream_sync(c->stream));
+    SP_HIP(hipMemcpyAsync(ws.data(), wsum, ws.size() * sizeof(jac_t), hipMemcpyDeviceToHost, st));
+    SP_HIP(sp::stream_sync(st));
     auto horner = [&](size_t r) {
       jac_t acc = jac_identity();
       for (int w = windows - 1; w >= 0; --w) {
@@ -342,9 +345,9 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
       for (auto& t : th) t.join();
     }
   } else {
-    hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, c->stream, wsum, windows, rows, drows);
-    SP_HIP(hipMemcpyAsync(res.data(), drows, rows * sizeof(jac_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(sp::stream_sync(c->stream));
+    hipLaunchKernelGGL(spk::k_msm_horner_rows, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, wsum, windows, rows, drows);
+    SP_HIP(hipMemcpyAsync(res.data(), drows, rows * sizeof(jac_t), hipMemcpyDeviceToHost, st));
+    SP_HIP(sp::stream_sync(st));
   }
   lap("horner");
   std::vector<aff_t> a(rows);
@@ -352,6 +355,13 @@ int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const ui
   memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
   lap("normalize");
   return SP_OK;
+}
+
+int sp_msm_shared_weights(sp_ctx* c, const uint64_t* weights, size_t n, const uint64_t* bases_rows, size_t rows, uint64_t* out_rows_aff) {
+  return msm_shared_weights_on(c, 0, weights, n, bases_rows, rows, out_rows_aff);
+}
+int sp_msm_shared_weights_aux(sp_ctx* c, const uint64_t* weights, size_t n, const uint64_t* bases_rows, size_t rows, uint64_t* out_rows_aff) {
+  return msm_shared_weights_on(c, 1, weights, n, bases_rows, rows, out_rows_aff);
 }
 
 int sp_point_sum(const uint64_t* points_aff, size_t n, uint64_t out_aff[8]) {

@@ -349,6 +349,41 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   lap("rounds");
   std::vector<fe_t> w(n);
   ck(sp_weights_from_r(u64p(r_bs.data()), ell_b, n, u64p(w.data())), "weights_from_r");
+  // fold_blinds, X fold, fold_commitments on the gathered instance data (O(n rows) work, done redundantly on every rank) need the weights alone: they run on a
+  // helper thread and the context's AUXILIARY stream (sp_msm_shared_weights_aux) beside this thread's layer and witness folds on the main stream - a bucket
+  // MSM per commitment row and its host-side Horner under 3 ms of bandwidth-bound fold kernels (round 6; the two used to run one after the other)
+  const size_t effective_len = dims.num_shared + dims.num_precommitted;
+  const bool truncated = effective_len > 0;
+  struct CommFold {
+    std::thread th;
+    std::exception_ptr err;
+    ~CommFold() {
+      if (th.joinable()) th.join();
+    }
+  } cf;
+  {
+    const fe_t* wp = w.data();
+    NifsOutputs* op = &out;
+    cf.th = std::thread([&cf, ctx, wp, n, rows, comms, truncated, effective_len, op] {
+      try {
+        ck(sp_ctx_bind_thread(ctx), "helper thread: device");
+        size_t data_rows = truncated ? (effective_len + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH : rows;
+        if (data_rows > rows) data_rows = rows;
+        std::vector<aff_t> bases(data_rows * n);
+        for (size_t r = 0; r < data_rows; ++r)
+          for (size_t i = 0; i < n; ++i) bases[r * n + i] = comms[i * rows + r];
+        if (data_rows) ck(sp_msm_shared_weights_aux(ctx, u64p(wp), n, (const uint64_t*)bases.data(), data_rows, op->folded_comm), "fold_commitments");
+      } catch (...) {
+        cf.err = std::current_exception();
+      }
+    });
+  }
+  // (the two small row folds use the main stream's bind_with_delayed kernel and workspaces: they stay on this thread)
+  std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());
+  fold_rows(ctx, r_W, n, rows, w.data(), f_rW.data());
+  fold_rows(ctx, X, n, d, w.data(), f_X.data());
+  memcpy(out.folded_rW, f_rW.data(), rows * sizeof(fe_t));
+  memcpy(out.folded_X, f_X.data(), d * sizeof(fe_t));
   std::vector<fe_t> ones(world, fe_one<S>());
   // sum over ranks of one device vector per rank: gather into `buf` (world x len), fold the windows with unit weights
   auto sum_over_ranks = [&](const sp_table* part, size_t len, sp_table* dst) {
@@ -388,8 +423,6 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
     hook(user, ell_b, finw, ignored);
   }
   // fold_witnesses (:1212-1231)
-  const size_t effective_len = dims.num_shared + dims.num_precommitted;
-  const bool truncated = effective_len > 0;
   const size_t dim = truncated ? effective_len : num_vars;
   if (world == 1) {
     ck(sp_fold_tables(ctx, Ws_local, n_local, u64p(w.data()), dim, out.folded_W), "fold_multiple");
@@ -403,19 +436,13 @@ void nifs_prove_sharded(sp_ctx* ctx, Comm& comm, const sp_shape* shape, const sp
   if (dim < num_vars) ck(sp_table_zero(ctx, out.folded_W, dim, num_vars - dim), "zero rest");
   ck(sp_table_set_len(out.folded_W, num_vars, (size_t)-1, (size_t)-1), "set_len");
   lap("finish, C and witness folds");
-  // fold_blinds, X fold, fold_commitments on the gathered instance data: O(n rows) work, done redundantly on every rank
-  std::vector<fe_t> f_rW(rows, fe_zero()), f_X(d, fe_zero());
-  fold_rows(ctx, r_W, n, rows, w.data(), f_rW.data());
-  fold_rows(ctx, X, n, d, w.data(), f_X.data());
-  memcpy(out.folded_rW, f_rW.data(), rows * sizeof(fe_t));
-  memcpy(out.folded_X, f_X.data(), d * sizeof(fe_t));
-  size_t data_rows = truncated ? (effective_len + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH : rows;
-  if (data_rows > rows) data_rows = rows;
-  std::vector<aff_t> bases(data_rows * n);
-  for (size_t r = 0; r < data_rows; ++r)
-    for (size_t i = 0; i < n; ++i) bases[r * n + i] = comms[i * rows + r];
-  if (data_rows) ck(sp_msm_shared_weights(ctx, u64p(w.data()), n, (const uint64_t*)bases.data(), data_rows, out.folded_comm), "fold_commitments");
-  if (data_rows < rows) ck(sp_fixed_base_mul_h(ctx, ckey, u64p(f_rW.data() + data_rows), rows - data_rows, out.folded_comm + 8 * data_rows), "rest rows");
+  cf.th.join();
+  if (cf.err) std::rethrow_exception(cf.err);
+  {
+    size_t data_rows = truncated ? (effective_len + DEFAULT_COMMITMENT_WIDTH - 1) / DEFAULT_COMMITMENT_WIDTH : rows;
+    if (data_rows > rows) data_rows = rows;
+    if (data_rows < rows) ck(sp_fixed_base_mul_h(ctx, ckey, u64p(f_rW.data() + data_rows), rows - data_rows, out.folded_comm + 8 * data_rows), "rest rows");
+  }
   lap("blind / X / commitment folds");
 }
 
