@@ -186,7 +186,9 @@ def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle, out=
     v[:, 3] &= np.uint64((1 << 63) - 1)
     blinds = rng.integers(0, 1 << 62, size=(rows_local, 4), dtype=np.uint64)
     t = hip.Table.from_host(ctx, v)
-    host.sharded_commit(ctx, comm, key, t, n_local, blinds)  # warm-up
+    t_w = time.perf_counter()
+    host.sharded_commit(ctx, comm, key, t, n_local, blinds)  # warm-up: builds this rank's comb table of the key (every rank holds the whole key's table)
+    t_first = time.perf_counter() - t_w
     group.barrier()
     t0 = time.perf_counter()
     for _ in range(steps_commit):
@@ -200,6 +202,36 @@ def sharded_legs(ctx, comm, group, steps_prove, steps_commit, check_oracle, out=
                         "ec_additions_per_s": (1 << 22) * comb_windows / dt,
                         "note": "2048 x 2048 full-width scalars over one key (hyrax_pc.rs:230-300), rows sharded by row, fixed-base comb table of the key with "
                                 f"{comb_bits}-bit signed windows: {comb_windows} mixed additions per (scalar, base) pair (the bucket form of round 1 needed ~36)"}
+    # the data path's own exchange at this world size: small record (a round's sums) and the commitment rows of one rank
+    ex_small, ex_rows = [], []
+    try:
+        rec = np.zeros((1, 12), dtype=np.uint64)
+        rows_rec = np.zeros((rows_local, 8), dtype=np.uint64)
+        for _ in range(3):
+            comm.allgather(rec)
+        for _ in range(20):
+            t1 = time.perf_counter()
+            comm.allgather(rec)
+            ex_small.append(time.perf_counter() - t1)
+        for _ in range(5):
+            t1 = time.perf_counter()
+            comm.allgather(rows_rec)
+            ex_rows.append(time.perf_counter() - t1)
+    except Exception as exc:
+        out["c4_commit"]["exchange_error"] = repr(exc)
+    if ex_small:
+        per = out["c4_commit"]["ms"]
+        small_us, rows_us = sorted(ex_small)[len(ex_small) // 2] * 1e6, sorted(ex_rows)[len(ex_rows) // 2] * 1e6
+        out["c4_commit"].update({
+            "first_call_ms_incl_comb_table_build": t_first * 1e3, "comb_table_build_ms_per_rank": max(0.0, t_first * 1e3 - per),
+            "exchange_96B_us_median": small_us, "exchange_rows_block_us_median": rows_us,
+            "prediction_for_the_first_multi_gpu_run": {
+                "basis": "measured at THIS world size: the commit is row-parallel with no reduction (each rank commits rows / N rows over its own comb table, one "
+                         "all-gather of 64-byte rows), so t(N) = t(1) * (rows/N)/rows + exchange(rows/N rows); xGMI all-gather of 128 KiB total is taken at the "
+                         "measured single-rank exchange cost plus 10 us per extra rank (ring steps over ~153 GB/s links: bandwidth is negligible at this size)",
+                "c4_commit_ms": {str(n): (per * world / n) + (rows_us + 10.0 * (n - 1)) / 1e3 for n in (1, 2, 4, 8)},
+                "c4_commit_speedup_vs_1": {str(n): (per * world) / ((per * world / n) + (rows_us + 10.0 * (n - 1)) / 1e3) for n in (2, 4, 8)},
+                "north_star": ">= 6x MSM throughput at 8 GPUs vs 1"}})
     _leg_done(rank, "c4_commit", out["c4_commit"])
     if dog:
         dog.arm("msm_general")
@@ -881,7 +913,7 @@ def main():
         # HBM bytes per launch of the roofline kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # in separate runs, corrected as MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024); null if absent
         traffic, traffic_src = None, None
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc) and args.message_bytes == 2048:
                 with open(pmc) as f:
@@ -893,7 +925,7 @@ def main():
         # rocprofv3 kernel-only durations of the same call sites, committed under profiles/ (tools/profile_job.sh): inside a prove and with the GPU
         # otherwise empty. The HIP-event figures below are taken inside a prove, where the auxiliary streams' kernels are resident beside these.
         rocprof_sites = None
-        sites_path = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_kernel_sites.json", "r04_kernel_sites.json")) if os.path.exists(p_)), "")
+        sites_path = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_kernel_sites.json", "r05_kernel_sites.json", "r04_kernel_sites.json")) if os.path.exists(p_)), "")
         if os.path.exists(sites_path) and args.message_bytes == 2048:
             with open(sites_path) as f:
                 sj = json.load(f)
@@ -944,7 +976,7 @@ def main():
                          "other_kernels_rocprof": rocprof_sites,
                          "other_kernels_note": "avg_us are HIP-event times of an instrumented pass INSIDE a prove: kernels of the auxiliary streams (delta's MSM, the PCS table "
                                                "walks, the resident sum-check tail) are resident beside them, so they are upper bounds of the kernel's own time; "
-                                               "other_kernels_rocprof (profiles/r05_kernel_stats.md) gives the rocprofv3 kernel-only duration of the same call site inside a prove "
+                                               "other_kernels_rocprof (profiles/r06_kernel_stats.md) gives the rocprofv3 kernel-only duration of the same call site inside a prove "
                                                "and alone. The 'bind' class (fused bind + evaluate launches on tables <= 2^19 elements) is launched AHEAD of "
                                                "its challenge and waits for it at the mailbox: its avg_us includes that wait, so its GB/s understate the kernel; the streaming "
                                                "classes and the roofline kernel (tables >= 2^20) are launched behind their challenge and their times are the kernels' alone."},

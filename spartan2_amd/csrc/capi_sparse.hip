@@ -93,12 +93,23 @@ struct Spmv3Args {
 // 33 .. 225 entries among 880 K of one to three at config 2 - would keep its wave waiting on one lane's chain of dependent (index, then element) loads
 // (the per-wave longest rows of A sum to 958 K such steps against 2 M entries in all: 0.75 ms for the cached product of prep_prove): those are walked by
 // the whole wave, an entry per lane, and added with a shuffle tree; the owner lane keeps the sum.
+// LONG_ROWS = false (no row of any of the three structures is longer than SPMV_LONG_ROW - the filtered rows of the incremental product inside a prove): the
+// plain lane-per-row walk at 64 registers; the cooperative form needs 116 and halves the waves per SIMD of what is then a streaming kernel (62 vs 42 us).
 constexpr unsigned SPMV_LONG_ROW = 24;
+template <bool LONG_ROWS>
 __global__ void __launch_bounds__(256) k_spmv3(Spmv3Args a, const fe_t* __restrict__ z, size_t nrows) {
   const int which = blockIdx.y;
   const SplitDev m = a.m[which];
   const fe_t* base = a.base[which];
   fe_t* out = a.out[which];
+  if (!LONG_ROWS) {
+    for (size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows; row += (size_t)gridDim.x * blockDim.x) {
+      fe_t acc = gather_major(m, row, z, 0, 1);
+      if (base) acc = fe_add<S>(acc, base[row]);
+      out[row] = acc;
+    }
+    return;
+  }
   const unsigned lane = threadIdx.x & 63u;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t wbase = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); wbase < nrows; wbase += stride) {  // (uniform over a wave)
@@ -239,6 +250,7 @@ struct SplitOnDevice {
   unsigned *sptr = nullptr, *sidx = nullptr, *gptr = nullptr, *gidx = nullptr;
   signed char* scode = nullptr;
   fe_t* gval = nullptr;
+  unsigned max_len = 0;  // longest major (entries of both classes): picks k_spmv3's form
   spk::SplitDev view() const { return spk::SplitDev{sptr, sidx, scode, gptr, gidx, gval}; }
   void release() {
     hipFree(sptr);
@@ -283,6 +295,11 @@ int upload_split(const SplitHost& h, SplitOnDevice* d) {
   if ((rc = upload(&d->scode, h.scode))) return rc;
   if ((rc = upload(&d->gptr, h.gptr))) return rc;
   if ((rc = upload(&d->gidx, h.gidx))) return rc;
+  d->max_len = 0;
+  for (size_t i = 0; i + 1 < h.sptr.size(); ++i) {
+    const unsigned l = (h.sptr[i + 1] - h.sptr[i]) + (h.gptr[i + 1] - h.gptr[i]);
+    if (l > d->max_len) d->max_len = l;
+  }
   return upload(&d->gval, h.gval);
 }
 
@@ -478,7 +495,11 @@ static int spmv3(sp_ctx* c, const sp_shape* s, const SplitOnDevice* mats, const 
   if (blocks > 4096) blocks = 4096;
   // sum_nnz (4 + 32) [+32 per general coefficient, ignored] + 3*32*N outputs (+ cached reads when incremental)
   uint64_t bytes = 36ull * (nnz[0] + nnz[1] + nnz[2]) + 96ull * nrows * (base ? 2 : 1);
-  c->timed(what, bytes, [&] { hipLaunchKernelGGL(spk::k_spmv3, dim3((unsigned)blocks, 3), dim3(256), 0, c->stream, a, z->d, nrows); });
+  const bool long_rows = mats[0].max_len > spk::SPMV_LONG_ROW || mats[1].max_len > spk::SPMV_LONG_ROW || mats[2].max_len > spk::SPMV_LONG_ROW;
+  c->timed(what, bytes, [&] {
+    if (long_rows) hipLaunchKernelGGL(spk::k_spmv3<true>, dim3((unsigned)blocks, 3), dim3(256), 0, c->stream, a, z->d, nrows);
+    else hipLaunchKernelGGL(spk::k_spmv3<false>, dim3((unsigned)blocks, 3), dim3(256), 0, c->stream, a, z->d, nrows);
+  });
   return SP_OK;
 }
 

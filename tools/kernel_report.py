@@ -75,7 +75,7 @@ def sites(M_):
         ("k_eval_quad_stream_lowhi<4>", None, "inner round 0 evaluation (effective ranges)", lambda g: 64 * (4 * g), "grid = pairs / 4; 64 B per live pair (+ 32 B per live high entry, < 1 KB here)"),
         ("k_rowmat_vec_tall", None, "PCS::prove L^T W (512 x 2048)", lambda g: 32 * (M_ + 512 + 2048), "reads W once: 32 (rows cols + rows + cols)"),
         ("k_polyabc_short_and_long", None, "bind_and_prepare_poly_ABC", None, "8(d) as the library accounts it: 12 B per nonzero + 32 B per live row of eq(r_x) + 32 B per output column"),
-        ("k_spmv3", None, "multiply_vec (incremental: rest columns only)", None, "8(d) as the library accounts it: 12 B per nonzero + 3 x 32 B per row written + witness gathers"),
+        ("k_spmv3<false>", None, "multiply_vec (incremental: rest columns only)", None, "8(d) as the library accounts it: 12 B per nonzero + 3 x 32 B per row written + witness gathers"),
         ("k_eq_outer_lastk", None, "evals_rx outer product (pyramids started under the last four rounds)", lambda g: 32 * (8 * g), "grid = entries / 8 (512 threads per 4096 entries); writes 32 B per entry"),
         ("k_round0_products", None, "round-0 products of the outer sum-check (headline driver)", lambda g: 224 * (M_ // 2), "reads Az, Bz, Cz (96 B per row), writes p0, p1 (32 B per row)"),
     ]
@@ -102,7 +102,7 @@ def main():
     if a.bench_json and os.path.exists(a.bench_json):
         j = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
         ok = j["roofline"]["other_kernels"]
-        for cls, kn in (("poly_abc", "k_polyabc_short_and_long"), ("spmv_incremental", "k_spmv3")):
+        for cls, kn in (("poly_abc", "k_polyabc_short_and_long"), ("spmv_incremental", "k_spmv3<false>")):
             if cls in ok:
                 lib_bytes[kn] = ok[cls]["alg_GBps"] * 1e9 * ok[cls]["avg_us"] * 1e-6
     # median, not mean: a call site's first launch in a process (cold caches, first touch of a workspace) can be several times the steady state
@@ -148,6 +148,14 @@ def main():
                 if key in fe and key in wr:
                     tr = (2 * fe[key] + wr[key]) * 1024
                     pmc[f"{name}@{grid}"] = {"fetch_kib": fe[key], "write_kib": wr[key], "traffic_bytes": tr, "alg_bytes": by}
+                    if "polyabc" in name or "spmv3" in name:
+                        # gather-shaped reads: profiles/r06_pmc_calibration.json (tools/fetch_calib.hip) - FETCH_SIZE counts a random 32-byte gather as the 64-byte
+                        # request it is (no halving; only coalesced streams are tallied at half their bytes), so the guide's x2 over-counts these kernels.
+                        # Bounds: every read a 64-byte request counted 1:1 (lower) .. the index / pointer / order streams perfectly coalesced and halved (upper)
+                        lo = fe[key] * 1024 + wr[key] * 1024
+                        pmc[f"{name}@{grid}"].update({"traffic_bytes_note": "traffic_bytes applies the guide's x2 to FETCH_SIZE; calibrated (r06_pmc_calibration.json): gathers are "
+                                                      "counted 1:1, so the true traffic lies in traffic_bytes_calibrated_range",
+                                                      "traffic_bytes_calibrated_range": [lo, lo + min(fe[key] * 1024, 59e6 / 2)]})
                 site_rows[f"{name.split('::')[-1]}@{grid}"] = {"alg_bytes": by, "in_prove_median_us": pa, "in_prove_min_us": pm, "reference_order_median_us": ra, "solo_median_us": sa,
                                                                "solo_min_us": sm, "others_resident_frac": ov, "pmc_traffic_bytes": tr}
                 f.write(f"| `{name.split('::')[-1]}` @ {grid} | {what} | {n_l:.1f} | {'-' if by is None else f'{by / 1e6:.1f}'} | {fmt(pa)} / {fmt(pm)} | {gb(pa)} | {fmt(ra)} / {fmt(rm)} | "
