@@ -110,6 +110,15 @@ impl<E: Engine> Drop for HipShape<E> {
 }
 
 impl<F: Copy + Default> HipTable<F> {
+  /// Round 6 - the witness as the frontend holds it for `is_small` circuits (machine words, src/bellpepper/r1cs.rs:303-409): written at its padded
+  /// offset, the Montgomery form is produced on the device (8 bytes a value over PCIe instead of 32, no host loop over 2^20 values)
+  pub fn write_u64(&mut self, off: usize, vals: &[u64]) -> Result<(), SpartanError> {
+    check(unsafe { sp_table_write_u64(ctx(), self.t, off, vals.as_ptr(), vals.len()) })
+  }
+  /// ... and a 0/1 witness packed 8 values a byte (value i = bit i & 7 of byte i >> 3)
+  pub fn write_bits(&mut self, off: usize, bits: &[u8], count: usize) -> Result<(), SpartanError> {
+    check(unsafe { sp_table_write_bits(ctx(), self.t, off, bits.as_ptr(), count) })
+  }
   pub fn zeros(len: usize) -> Result<Self, SpartanError> {
     let mut t = ptr::null_mut();
     check(unsafe { sp_table_zeros(ctx(), len, usize::MAX, usize::MAX, &mut t) })?;
@@ -199,6 +208,19 @@ impl RowTables {
     let mut t = std::ptr::null_mut();
     check(unsafe { sp_fbtables_create(ctx(), points_aff.as_ptr(), points_aff.len() / 8, &mut t) })?;
     Ok(Self { t })
+  }
+  /// Round 6: the build is only QUEUED (a lowest-priority stream of the context's own; ~3 ms of device time for the 513 rows of a 2^20-variable
+  /// witness) - what prep_prove calls, so that it returns without waiting for tables that are first read at the end of the first prove.
+  /// `announce_opening_with_tables` takes them when they have landed and the key's own tables otherwise (same proof).
+  pub fn new_queued(points_aff: &[u64]) -> Result<Self, SpartanError> {
+    let mut t = std::ptr::null_mut();
+    check(unsafe { sp_fbtables_create_async(ctx(), points_aff.as_ptr(), points_aff.len() / 8, &mut t) })?;
+    Ok(Self { t })
+  }
+  pub fn ready(&self, wait: bool) -> Result<bool, SpartanError> {
+    let r = unsafe { sp_fbtables_ready(self.t, wait as c_int) };
+    if r < 0 { check(r)?; }
+    Ok(r == 1)
   }
 }
 impl Drop for RowTables {
