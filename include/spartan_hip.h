@@ -382,6 +382,21 @@ int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars,
 /* the same with the blind's term h * blind handed in as an affine point the caller computed beforehand (sp_fixed_base_mul_h: blinds come from the
  * randomness stream and are known long before the scalars); n <= 6; identity = all-zero coordinates */
 int sp_hyrax_commit_small_with_term(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind_term_aff[8], uint64_t out_aff[8]);
+/* PCS::commit on a narrow key in TWO calls (round 6): the commitment of a round of the ZK verifier circuit (src/bellpepper/r1cs.rs:735-816
+ * process_round -> PCS::commit, hyrax_pc.rs:221-260 -> FixedBaseMul::multi_mul, msm.rs:727-773) is sum_i row[i] * ck[i] + blind * h, linear in the
+ * row, and most of a round's row does not depend on the round's own prover message: the Horner steps of the PREVIOUS polynomial at its challenge and
+ * the blind are known one device round earlier. _begin posts those terms (columns `cols[i]` with `scalars[i]`, and `blind` unless NULL) to the
+ * process's table walkers - polling host threads that add 16-bit-window table entries (SPARTAN_WALKERS, default 8; spartan2_amd/csrc/walk_pool.hpp
+ * says why this one commitment is host work) - and returns at once; _finish adds the remaining terms, walked by the caller and the walkers together,
+ * and returns the affine commitment. The result equals sp_hyrax_commit_small on the assembled row for any split. Columns must lie below the number
+ * sp_hyrax_commit_split_available was asked about (the key keeps host tables of its first 16 columns and of h). One _finish or _drop per _begin. */
+typedef struct sp_split_commit sp_split_commit;
+int sp_walkers(void);                              /* polling walker threads of this process (0: the split form is not offered) */
+int sp_walkers_keep_hot(uint64_t microseconds);    /* a prove starts: wake the walkers and keep them polling for this long */
+int sp_hyrax_commit_split_available(const sp_ck* ck, size_t cols_used);
+int sp_hyrax_commit_split_begin(sp_ctx* ctx, const sp_ck* ck, const uint32_t* cols, const uint64_t* scalars, size_t n, const uint64_t* blind, sp_split_commit** job);
+int sp_hyrax_commit_split_finish(sp_ctx* ctx, sp_split_commit* job, const uint32_t* cols, const uint64_t* scalars, size_t n, uint64_t out_aff[8]);
+void sp_hyrax_commit_split_drop(sp_split_commit* job);
 
 /* ---- sum-checks on a table slice ("sum-check by evaluation-table slice, one reduce per round") -----------------------------
  * Tables sharded on their LAST k variables: rank g holds Z_g[j] = Z[(j << k) | g], so the pairs (i, i + n/2) of the first ell - k rounds are

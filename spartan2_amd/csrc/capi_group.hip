@@ -18,6 +18,8 @@ using sp::fail;
 typedef FqP S;
 
 #include "group_common.hpp"
+#include "walk_pool.hpp"
+#include <sys/mman.h>
 
 namespace {
 
@@ -399,6 +401,7 @@ int sp_msm_small_u64(sp_ctx* c, const uint64_t* scalars, const uint64_t* bases, 
   return SP_OK;
 }
 
+static const size_t HOST16_BASES = 16;  // leading bases of a narrow key whose 16-bit-window tables are kept on the host too (64 MiB each)
 static bool fbtables_old_build() {
   static const bool on = [] {
     const char* e = getenv("SPARTAN_FBTABLES_OLD");  // "1": the round-5 build (k_fixed_base_tables + one inversion per entry) for A/B runs and the parity test
@@ -420,16 +423,17 @@ static const aff_t* tables16_of(const aff_t* t8) {
 // The host copy of a key's 16-bit-window tables (64 MiB a table): one per distinct base set and process - the contexts of a multi-context run create the same
 // keys, and ck / ck_s are the same labels in every one - held weakly here and strongly by the keys, so that the last key to go frees it. Filled by one
 // device -> host copy into memory that is not value-initialised first (1.5 GB of zero-filled vectors in the eight-context mode).
-static int host_tables16_of(const std::vector<aff_t>& bases, const aff_t* d_t16, size_t entries, std::shared_ptr<aff_t[]>* out) {
+static int host_tables16_of(const std::vector<aff_t>& bases, const aff_t* d_t16, const std::vector<size_t>& which, std::shared_ptr<aff_t[]>* out) {
   static const bool on = [] {
     const char* e = getenv("SPARTAN_HOST_T16");
     return !(e && e[0] == '0');
   }();
   out->reset();
-  if (!on) return SP_OK;
+  if (!on || which.empty()) return SP_OK;
   static std::mutex mu;
   static std::map<std::string, std::weak_ptr<aff_t[]>> cache;
-  const std::string key(reinterpret_cast<const char*>(bases.data()), bases.size() * sizeof(aff_t));
+  std::string key;
+  for (size_t t : which) key.append(reinterpret_cast<const char*>(&bases[t]), sizeof(aff_t));
   std::lock_guard<std::mutex> l(mu);
   auto it = cache.find(key);
   if (it != cache.end()) {
@@ -439,9 +443,18 @@ static int host_tables16_of(const std::vector<aff_t>& bases, const aff_t* d_t16,
     }
     cache.erase(it);
   }
-  std::shared_ptr<aff_t[]> buf(new (std::nothrow) aff_t[entries]);
-  if (!buf) return SP_OK;  // (no host copy: the 8-bit tables serve)
-  SP_HIP(hipMemcpy(buf.get(), d_t16, entries * sizeof(aff_t), hipMemcpyDeviceToHost));
+  const size_t per16 = (size_t)16 * 65535, bytes = which.size() * per16 * sizeof(aff_t);
+  // 2 MiB-aligned and advised for huge pages: a walk touches 16 random lines of a 64 MiB table (4 KiB pages: a TLB miss each)
+  void* raw = aligned_alloc((size_t)2 << 20, (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
+  if (!raw) return SP_OK;  // (no host copy: the 8-bit tables / the device form serve)
+  madvise(raw, bytes, MADV_HUGEPAGE);
+  std::shared_ptr<aff_t[]> buf(static_cast<aff_t*>(raw), [](aff_t* p) { free(p); });
+  for (size_t k = 0; k < which.size(); ++k) {
+    size_t run = 1;  // consecutive tables in one copy
+    while (k + run < which.size() && which[k + run] == which[k] + run) ++run;
+    SP_HIP(hipMemcpy(buf.get() + k * per16, d_t16 + which[k] * per16, run * per16 * sizeof(aff_t), hipMemcpyDeviceToHost));
+    k += run - 1;
+  }
   cache[key] = buf;
   *out = buf;
   return SP_OK;
@@ -498,8 +511,16 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
     sp::launch_jac_to_affine(c->stream, tj16.as<jac_t>(), ntab * per16, t16, fbtables_old_build() ? nullptr : pre16.as<fe_t>());
     SP_HIP(sp::stream_sync(c->stream));
     k->d_tables16 = t16;
-    if (ntab <= 2) {  // host copy for the single multiplications (commitments of one value: eval_W, beta, a blind's term)
-      if ((rc = host_tables16_of(hb, t16, ntab * per16, &k->h_tables16))) return rc;
+    {
+      // host copy: every table of a key of <= 2 (the single multiplications: commitments of one value - eval_W, beta, a blind's term); of a narrow key
+      // the leading bases and h when the process keeps table walkers (walk_pool.hpp: the round commitments of the ZK verifier circuit use <= 15 columns)
+      std::vector<size_t> which;
+      k->h16_bases = ntab <= 2 ? ntab - 1 : (sp::WalkPool::get().walkers() > 0 ? std::min(ntab - 1, HOST16_BASES) : (size_t)0);
+      if (ntab <= 2 || k->h16_bases) {
+        for (size_t t = 0; t < k->h16_bases; ++t) which.push_back(t);
+        which.push_back(ntab - 1);
+      }
+      if ((rc = host_tables16_of(hb, t16, which, &k->h_tables16))) return rc;
     }
     std::lock_guard<std::mutex> l(g_t16_mu);
     if (ntab > 1) g_t16[k->d_cktables] = t16;
@@ -2642,5 +2663,102 @@ int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, s
   store_aff(out_aff, jac_to_affine(acc));
   return SP_OK;
 }
+
+// ---- a narrow commitment in two calls: the terms known early, then the rest (walk_pool.hpp) -------------------------------------------------------------
+// commit(row, blind) = sum_i row[i] ck[i] + blind h (hyrax_pc.rs:221-260 on a key with per-base tables, msm.rs:727-773) is linear in the row: the terms
+// that do not depend on the newest prover message (the Horner steps of the previous round's polynomial at its challenge, the blind) are walked while the
+// device computes that message; what the transcript then waits for is the walk of the message's own few scalars.
+struct sp_split_commit {
+  const sp_ck* ck = nullptr;
+  sp::WalkPool::Batch* early = nullptr;  // posted at begin (nullptr: the pool had no free slot - the terms are kept and walked at finish)
+  std::vector<const aff_t*> kept;
+  bool any_early = false;
+};
+static int split_entries(const sp_ck* ck, const uint32_t* cols, const uint64_t* scalars, size_t n, const uint64_t* blind, std::vector<const aff_t*>& ents) {
+  auto walk = [&](size_t table, const uint64_t* sc4) -> int {
+    fe_t s;
+    memcpy(&s, sc4, 32);
+    if (fe_is_zero(s)) return SP_OK;
+    const aff_t* t16 = ck->host_table16(table);
+    if (!t16) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_split: no host table for this column (the key keeps its first 16 columns and h)");
+    const fe_t c = fe_to_canonical<S>(s);
+    for (int j = 0; j < 16; ++j) {
+      const unsigned digit = (c.v[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      if (digit) ents.push_back(t16 + (size_t)j * 65535 + digit - 1);
+    }
+    return SP_OK;
+  };
+  int rc;
+  for (size_t i = 0; i < n; ++i) {
+    if (cols[i] >= ck->num_cols) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_split: column outside the key");
+    if ((rc = walk(cols[i], scalars + 4 * i))) return rc;
+  }
+  if (blind && (rc = walk(ck->n_tables - 1, blind))) return rc;
+  return SP_OK;
+}
+static unsigned split_parts(size_t n_ents) {  // ~12 entries a part: the owner adds the parts' sums one after the other (0.4 us each)
+  const unsigned w = (unsigned)sp::WalkPool::get().walkers() + 1;
+  unsigned p = (unsigned)((n_ents + 11) / 12);
+  if (p > w) p = w;
+  return p ? p : 1;
+}
+int sp_walkers(void) { return sp::WalkPool::get().walkers(); }
+int sp_walkers_keep_hot(uint64_t microseconds) {
+  sp::WalkPool::get().keep_hot((long)microseconds);
+  return SP_OK;
+}
+int sp_hyrax_commit_split_available(const sp_ck* ck, size_t cols_used) {
+  return ck && ck->d_cktables && ck->h_tables16 && ck->h16_bases >= cols_used && cols_used <= ck->num_cols && sp::WalkPool::get().walkers() > 0;
+}
+int sp_hyrax_commit_split_begin(sp_ctx* c, const sp_ck* ck, const uint32_t* cols, const uint64_t* scalars, size_t n, const uint64_t* blind, sp_split_commit** out) {
+  (void)c;
+  if (!ck->d_cktables || !ck->h_tables16) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_split: the key has no host-side window tables");
+  std::unique_ptr<sp_split_commit> job(new sp_split_commit());
+  job->ck = ck;
+  int rc = split_entries(ck, cols, scalars, n, blind, job->kept);
+  if (rc) return rc;
+  sp::WalkPool& pool = sp::WalkPool::get();
+  pool.keep_hot(2000);
+  if (!job->kept.empty() && job->kept.size() <= (size_t)sp::WalkPool::MAX_ENTS && (job->early = pool.acquire())) {
+    memcpy(job->early->ents, job->kept.data(), job->kept.size() * sizeof(const aff_t*));
+    job->early->n_ents = (unsigned)job->kept.size();
+    pool.post(job->early, split_parts(job->kept.size()));
+    job->kept.clear();
+  }
+  *out = job.release();
+  return SP_OK;
+}
+int sp_hyrax_commit_split_finish(sp_ctx* c, sp_split_commit* job_, const uint32_t* cols, const uint64_t* scalars, size_t n, uint64_t out_aff[8]) {
+  (void)c;
+  std::unique_ptr<sp_split_commit> job(job_);
+  sp::WalkPool& pool = sp::WalkPool::get();
+  std::vector<const aff_t*>& ents = job->kept;  // (the early terms too when they could not be posted)
+  int rc = split_entries(job->ck, cols, scalars, n, nullptr, ents);
+  if (rc) {
+    if (job->early) (void)pool.finish(job->early);
+    return rc;
+  }
+  pool.keep_hot(2000);
+  xyzz_t acc = xyzz_identity();
+  sp::WalkPool::Batch* late = nullptr;
+  if (ents.size() > 8 && ents.size() <= (size_t)sp::WalkPool::MAX_ENTS && (late = pool.acquire())) {
+    memcpy(late->ents, ents.data(), ents.size() * sizeof(const aff_t*));
+    late->n_ents = (unsigned)ents.size();
+    pool.post(late, split_parts(ents.size()));
+    acc = pool.finish(late);
+  } else {
+    for (const aff_t* e : ents) __builtin_prefetch(e, 0, 0);
+    for (const aff_t* e : ents) acc = xyzz_add_mixed(acc, *e);
+  }
+  if (job->early) acc = xyzz_add(acc, pool.finish(job->early));
+  store_aff(out_aff, jac_to_affine(xyzz_to_jac(acc)));
+  return SP_OK;
+}
+void sp_hyrax_commit_split_drop(sp_split_commit* job) {
+  if (!job) return;
+  if (job->early) (void)sp::WalkPool::get().finish(job->early);
+  delete job;
+}
+
 
 }  // extern "C"

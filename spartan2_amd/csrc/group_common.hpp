@@ -25,7 +25,12 @@ struct sp_ck {
   // ONE copy per distinct base set and process (capi_group.hip host_tables16_of: eight contexts on one key share it), allocated without value-initialising;
   // SPARTAN_HOST_T16=0 keeps none (the single multiplications then walk the 8-bit tables: 32 mixed additions instead of 16)
   std::shared_ptr<aff_t[]> h_tables16;
-  const aff_t* host_table16(size_t t) const { return h_tables16 ? h_tables16.get() + t * ((size_t)16 * 65535) : nullptr; }
+  size_t h16_bases = 0;  // leading bases that have a host copy (h's table follows them): all of a key of <= 2 tables, the first 16 of a narrow key
+  const aff_t* host_table16(size_t t) const {
+    if (!h_tables16) return nullptr;
+    if (t + 1 == n_tables) return h_tables16.get() + h16_bases * ((size_t)16 * 65535);
+    return t < h16_bases ? h_tables16.get() + t * ((size_t)16 * 65535) : nullptr;
+  }
   // fixed-base comb table of the whole key (kernels_msm.hpp k_comb_*), built on first use by a commitment of many non-small rows
   mutable aff_t* d_comb = nullptr;
   mutable int comb_c = 0, comb_windows = 0;

@@ -1,0 +1,178 @@
+// Host-side table walks for the commitments that sit in a transcript chain (capi_group.hip sp_hyrax_commit_split_*): a process-wide set of polling
+// threads that add window-table entries into (X, Y, ZZ, ZZZ) accumulators.
+//
+// Why the host: a round commitment of the ZK verifier circuit (src/bellpepper/r1cs.rs:735-816 -> PCS::commit on the width-32 key,
+// hyrax_pc.rs:221-260) is ~10 fixed-base multiplications whose result the transcript needs before the device may start the next sum-check round. Over
+// the 16-bit-window tables that is ~130 dependent-free mixed additions. One addition is ~4.8 us on the device however many lanes are active (a chain of
+// 256-bit products on a part built for throughput: kernels_msm.hpp, the cooperative addition) and ~0.35 us on a host core, so the device form is four
+// tree levels + launch + PCIe = 26 us and a further 17 us of host work, while eight host cores walk 16 entries each in ~6 us. The device keeps every
+// commitment that is wide (the witness rows, the MSMs of the opening); the host takes the ones that are narrow AND on the critical path.
+//
+// A batch is a list of table entries cut into `nparts` contiguous parts; part p is claimed by whoever gets there first (a polling walker or the owner
+// itself, which never waits for a part nobody has claimed). The walkers poll one cache line of batch states while `keep_hot` says a prove is in
+// flight and sleep on a condition variable otherwise.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "curve.hpp"
+
+namespace sp {
+
+class WalkPool {
+ public:
+  static constexpr int MAX_BATCHES = 8, MAX_PARTS = 32, MAX_ENTS = 16 * 40;
+  struct Batch {
+    const aff_t* ents[MAX_ENTS];
+    unsigned n_ents = 0, nparts = 0;
+    xyzz_t part[MAX_PARTS];
+    std::atomic<unsigned> done{0};
+    unsigned gen = 0;
+    int slot = -1;
+  };
+
+ private:
+  // state word of batch slot i: generation (32) | nparts (16) | next unclaimed part (16); 0 = nothing posted
+  alignas(64) std::atomic<uint64_t> states_[MAX_BATCHES];
+  alignas(64) std::atomic<long long> hot_until_{0};
+  Batch batches_[MAX_BATCHES];
+  bool in_use_[MAX_BATCHES] = {};
+  unsigned gen_ = 0;
+  std::mutex mu_;  // slot allocation, thread start, sleeping walkers
+  std::condition_variable cv_;
+  std::vector<std::thread> th_;
+  bool stop_ = false, started_ = false;
+  int want_ = 0;
+
+  static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  static void cpu_pause() { __builtin_ia32_pause(); }
+
+  // claims one part of batch slot i; -1 when none is left (or nothing is posted)
+  int claim(int i, unsigned* gen_out) {
+    uint64_t s = states_[i].load(std::memory_order_acquire);
+    for (;;) {
+      const unsigned next = (unsigned)(s & 0xffffu), np = (unsigned)((s >> 16) & 0xffffu);
+      if (next >= np) return -1;
+      if (states_[i].compare_exchange_weak(s, s + 1, std::memory_order_acq_rel, std::memory_order_acquire)) {
+        *gen_out = (unsigned)(s >> 32);
+        return (int)next;
+      }
+    }
+  }
+  static void run_part(Batch& b, unsigned p) {
+    const unsigned lo = (unsigned)((uint64_t)b.n_ents * p / b.nparts), hi = (unsigned)((uint64_t)b.n_ents * (p + 1) / b.nparts);
+    for (unsigned k = lo; k < hi; ++k) __builtin_prefetch(b.ents[k], 0, 0);  // each entry is a miss in a table of 64 MiB
+    xyzz_t acc = xyzz_identity();
+    for (unsigned k = lo; k < hi; ++k) acc = xyzz_add_mixed(acc, *b.ents[k]);
+    b.part[p] = acc;
+    b.done.fetch_add(1, std::memory_order_acq_rel);
+  }
+  void loop() {
+    for (;;) {
+      bool worked = false;
+      for (int i = 0; i < MAX_BATCHES; ++i) {
+        unsigned g;
+        const int p = claim(i, &g);
+        if (p >= 0) {
+          run_part(batches_[i], (unsigned)p);  // the owner recycles a slot only after `done` has reached nparts: the batch is ours to read
+          worked = true;
+        }
+      }
+      if (worked) continue;
+      for (int spin = 0; spin < 64; ++spin) cpu_pause();
+      if (now_ns() < hot_until_.load(std::memory_order_relaxed)) continue;
+      std::unique_lock<std::mutex> l(mu_);
+      cv_.wait(l, [&] { return stop_ || now_ns() < hot_until_.load(std::memory_order_relaxed); });
+      if (stop_) return;
+    }
+  }
+  WalkPool() {
+    for (auto& s : states_) s.store(0, std::memory_order_relaxed);
+    const char* e = getenv("SPARTAN_WALKERS");  // polling host threads for the split commitments; 0 = none (the callers keep the device form)
+    int n = e ? atoi(e) : 8;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (!e && hw && (int)hw / 4 < n) n = (int)hw / 4;  // default: at most a quarter of the machine
+    if (n < 0) n = 0;
+    if (n > MAX_PARTS - 1) n = MAX_PARTS - 1;
+    want_ = n;
+  }
+  ~WalkPool() {
+    {
+      std::lock_guard<std::mutex> l(mu_);
+      stop_ = true;
+      hot_until_.store(0, std::memory_order_relaxed);
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+
+ public:
+  static WalkPool& get() {
+    static WalkPool p;
+    return p;
+  }
+  int walkers() const { return want_; }
+  // a prove is in flight for the next `us` microseconds: the walkers poll
+  void keep_hot(long us) {
+    if (!want_) return;
+    const long long until = now_ns() + 1000ll * us, cur = hot_until_.load(std::memory_order_relaxed);
+    const bool cold = cur < now_ns();
+    if (until > cur) hot_until_.store(until, std::memory_order_relaxed);
+    if (!started_ || cold) {
+      std::lock_guard<std::mutex> l(mu_);
+      if (!started_) {
+        started_ = true;
+        for (int i = 0; i < want_; ++i) th_.emplace_back([this] { loop(); });
+      }
+      cv_.notify_all();
+    }
+  }
+  // a free batch to fill (ents, n_ents), or nullptr when all slots are taken (the caller then walks on its own thread)
+  Batch* acquire() {
+    std::lock_guard<std::mutex> l(mu_);
+    for (int i = 0; i < MAX_BATCHES; ++i)
+      if (!in_use_[i]) {
+        in_use_[i] = true;
+        Batch& b = batches_[i];
+        b.slot = i;
+        b.n_ents = 0;
+        b.nparts = 0;
+        b.done.store(0, std::memory_order_relaxed);
+        if (++gen_ == 0) ++gen_;
+        b.gen = gen_;
+        return &b;
+      }
+    return nullptr;
+  }
+  // cut into parts and make them claimable
+  void post(Batch* b, unsigned nparts) {
+    if (nparts < 1) nparts = 1;
+    if (nparts > (unsigned)MAX_PARTS) nparts = MAX_PARTS;
+    if (nparts > b->n_ents) nparts = b->n_ents ? b->n_ents : 1;
+    b->nparts = nparts;
+    states_[b->slot].store(((uint64_t)b->gen << 32) | ((uint64_t)nparts << 16), std::memory_order_release);
+  }
+  // the owner takes whatever is unclaimed, waits for the claimed rest, adds the parts and gives the slot back
+  xyzz_t finish(Batch* b) {
+    unsigned g;
+    for (int p; (p = claim(b->slot, &g)) >= 0;) run_part(*b, (unsigned)p);
+    while (b->done.load(std::memory_order_acquire) < b->nparts) cpu_pause();
+    xyzz_t acc = xyzz_identity();
+    for (unsigned p = 0; p < b->nparts; ++p) acc = xyzz_add(acc, b->part[p]);
+    release(b);
+    return acc;
+  }
+  bool finished(const Batch* b) const { return b->done.load(std::memory_order_acquire) >= b->nparts; }
+  void release(Batch* b) {
+    states_[b->slot].store(0, std::memory_order_release);
+    std::lock_guard<std::mutex> l(mu_);
+    in_use_[b->slot] = false;
+  }
+};
+
+}  // namespace sp

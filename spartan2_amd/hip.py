@@ -521,6 +521,27 @@ class CommitmentKey:
         check(lib().sp_hyrax_commit_small(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(scalars.shape[0]), p64(blind), p64(out)))
         return out
 
+    def commit_split_available(self, cols_used=16):
+        return bool(lib().sp_hyrax_commit_split_available(self.h, ctypes.c_size_t(cols_used)))
+
+    def commit_split(self, early_cols, early_scalars, blind, late_cols, late_scalars, drop=False):
+        """sp_hyrax_commit_split_begin (terms known early, the blind or None) + _finish (the rest): the commitment of the assembled row."""
+        ec = np.ascontiguousarray(early_cols, dtype=np.uint32).reshape(-1)
+        es = np.ascontiguousarray(early_scalars, dtype=np.uint64).reshape(-1, 4)
+        lc = np.ascontiguousarray(late_cols, dtype=np.uint32).reshape(-1)
+        ls = np.ascontiguousarray(late_scalars, dtype=np.uint64).reshape(-1, 4)
+        assert ec.shape[0] == es.shape[0] and lc.shape[0] == ls.shape[0]
+        bp = None if blind is None else p64(np.ascontiguousarray(blind, dtype=np.uint64).reshape(4))
+        job = ctypes.c_void_p()
+        pu32 = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        check(lib().sp_hyrax_commit_split_begin(self.ctx.h, self.h, pu32(ec), p64(es), ctypes.c_size_t(ec.shape[0]), bp, ctypes.byref(job)))
+        if drop:
+            lib().sp_hyrax_commit_split_drop(job)
+            return None
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().sp_hyrax_commit_split_finish(self.ctx.h, job, pu32(lc), p64(ls), ctypes.c_size_t(lc.shape[0]), p64(out)))
+        return out
+
     def commit_small_with_term(self, scalars, blind_term_aff):
         scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
         term = np.ascontiguousarray(blind_term_aff, dtype=np.uint64).reshape(8)

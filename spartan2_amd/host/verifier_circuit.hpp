@@ -121,6 +121,52 @@ struct Circuit {
     if (round == nb()) return 0;
     return round < idx_inner_final() ? 1 : 0;
   }
+  // The variables of a sum-check round in allocation order: first the round's own prover message (the coefficients of its polynomials: `fresh_vars`),
+  // then values that are functions of EARLIER rounds' messages and of the previous challenge alone (`early_values`: the Horner steps of the previous
+  // polynomials at that challenge, the joint claims in front of the inner sum-check). The second group's part of the round commitment can be walked while
+  // the device still computes the first (process_round below). 0 = not a sum-check round (everything counts as fresh).
+  size_t fresh_vars(size_t round) const {
+    if (round < nb()) return 4;
+    if (round > nb() && round < idx_outer_final()) return 8;
+    if (round >= idx_inner_start() && round < idx_inner_final()) return 6;
+    return 0;
+  }
+  static void horner_values(const fe_t* co, size_t n, const fe_t& x, std::vector<fe_t>* out) {  // the allocations of horner() above
+    fe_t acc = co[n - 1];
+    for (size_t k = n - 1; k-- > 0;) {
+      acc = fe_add<S>(fe_mul<S>(acc, x), co[k]);
+      out->push_back(acc);
+    }
+  }
+  // mirrors rounds() for the rounds with fresh_vars != 0; process_round compares the result with what rounds() allocated before it relies on it
+  void early_values(size_t round, const fe_t& c0, std::vector<fe_t>* out) const {
+    out->clear();
+    if (round < nb()) {
+      if (round == 0) out->push_back(fe_zero());
+      else horner_values(nifs_polys[round - 1].data(), 4, c0, out);
+    } else if (round > nb() && round < idx_outer_final()) {
+      const size_t i = round - idx_outer_start();
+      if (i == 0) out->push_back(fe_zero());
+      else {
+        horner_values(outer_step[i - 1].data(), 4, c0, out);
+        horner_values(outer_core[i - 1].data(), 4, c0, out);
+      }
+    } else if (round >= idx_inner_start() && round < idx_inner_final()) {
+      const size_t idx = round - idx_inner_start();
+      if (idx == 0) {
+        const fe_t r_sq = fe_mul<S>(c0, c0);
+        out->push_back(r_sq);
+        for (const fe_t* cl : {claim_step, claim_core}) {
+          const fe_t rB = fe_mul<S>(c0, cl[1]);
+          out->push_back(rB);
+          out->push_back(fe_add<S>(fe_add<S>(cl[0], rB), fe_mul<S>(r_sq, cl[2])));
+        }
+      } else {
+        horner_values(inner_step[idx - 1].data(), 3, c0, out);
+        horner_values(inner_core[idx - 1].data(), 3, c0, out);
+      }
+    }
+  }
   void rounds(CS& cs, size_t round, const std::vector<std::vector<Num>>& prior, const std::vector<std::vector<Num>>& prev_chals, const fe_t* chal, std::vector<Num>* vars,
               std::vector<Num>* chals) const {
     const fe_t c0 = chal ? *chal : fe_zero();
@@ -330,9 +376,45 @@ struct State {  // MultiRoundState (bellpepper/r1cs.rs:695-707)
   size_t current = 0;
   double commit_ms = 0;  // wall time inside the per-round commitments (reported as a phase of its own)
   double synth_ms = 0, hash_ms = 0;  // diagnostics (SPARTAN_HOST_LAPS): synthesis of the rounds, transcript work of process_round
-  size_t commits = 0;
+  size_t commits = 0, split_commits = 0;
+  // the NEXT round's commitment, begun when this round's challenge was drawn (sp_hyrax_commit_split_begin: the blind's term and the early values)
+  struct Ahead {
+    sp_split_commit* job = nullptr;
+    size_t round = 0, tape_pos = 0, fresh = 0;
+    std::vector<fe_t> vals;
+  } ahead;
   explicit State(const Shape& s) : w(s.total_vars, fe_zero()) {}
+  State(const State&) = delete;
+  State& operator=(const State&) = delete;
+  ~State() { sp_hyrax_commit_split_drop(ahead.job); }
 };
+// Round `next`'s commitment, as far as it is known once round `next - 1` has drawn its challenge `c0`: h * blind (the tape's next value: only process_round
+// draws between the rounds - it is PEEKED here and checked against the tape position when the round comes) and the early values of a sum-check round.
+// The terms go to the library's table walkers (sp_hyrax_commit_split_begin) and are added under the device's work on the round's polynomials.
+static const size_t SPLIT_COLS = 16;
+static inline void begin_next_commitment(sp_ctx* ctx, State& st, const Shape& s, const sp_ck* vc_ck, const Circuit& vc, size_t next, const fe_t& c0, const Tape& tape) {
+  static const bool off = [] {
+    const char* e = getenv("SPARTAN_VC_SPLIT");  // "0": every round commitment through sp_hyrax_commit_small (the device walk), for A/B runs and tests
+    return e && e[0] == '0';
+  }();
+  if (off || next >= s.num_rounds || s.vars_padded[next] != s.width || tape.pos >= tape.blocks) return;
+  if (!sp_hyrax_commit_split_available(vc_ck, SPLIT_COLS)) return;
+  State::Ahead& a = st.ahead;
+  sp_hyrax_commit_split_drop(a.job);
+  a.job = nullptr;
+  a.round = next;
+  a.tape_pos = tape.pos;
+  a.fresh = vc.fresh_vars(next);
+  if (a.fresh) vc.early_values(next, c0, &a.vals);
+  else {
+    a.vals.clear();
+    a.fresh = s.vars_unpadded[next];  // not a sum-check round: only the blind's term is early
+  }
+  const fe_t blind = fe_from_uniform<S>(tape.bytes + 64 * tape.pos);
+  uint32_t cols[64];
+  for (size_t k = 0; k < a.vals.size() && k < 64; ++k) cols[k] = (uint32_t)(a.fresh + k);
+  if (a.fresh + a.vals.size() > 64 || sp_hyrax_commit_split_begin(ctx, vc_ck, cols, u64p(a.vals.data()), a.vals.size(), u64p(&blind), &a.job) != SP_OK) a.job = nullptr;
+}
 // process_round (bellpepper/r1cs.rs:734-816): synthesize the round, commit its (padded) variables with the width-32 key, absorb, squeeze
 static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shape& s, const sp_ck* vc_ck, const Circuit& vc, size_t round, Tr& tr, Tape& tape) {
   if (round != st.current) throw Error(SP_ERR_INTERNAL, "process_round: rounds out of order");
@@ -352,8 +434,29 @@ static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shap
   std::vector<aff_t> comm(rows);
   const auto tc0 = std::chrono::steady_clock::now();
   st.synth_ms += std::chrono::duration<double, std::milli>(tc0 - ts0).count();
-  for (size_t r = 0; r < rows; ++r)
-    ck(sp_hyrax_commit_small(ctx, vc_ck, u64p(st.w.data() + sp_ + r * s.width), s.width, u64p(&blinds[r]), u64p(&comm[r].x)), "commit round witness");
+  // the commitment begun behind the previous challenge, if it is this round's and the tape and the synthesis agree with what it assumed
+  bool split = false;
+  if (st.ahead.job) {
+    State::Ahead& a = st.ahead;
+    const size_t nu = s.vars_unpadded[round];
+    bool ok = a.round == round && rows == 1 && a.tape_pos + 1 == tape.pos && a.fresh + a.vals.size() == nu;
+    for (size_t k = 0; ok && k < a.vals.size(); ++k) ok = fe_eq(a.vals[k], st.cs.aux[su + a.fresh + k]);
+    for (size_t k = SPLIT_COLS; ok && k < nu; ++k) ok = fe_is_zero(st.cs.aux[su + k]);  // the library keeps host tables of the leading columns only
+    sp_split_commit* job = a.job;
+    a.job = nullptr;
+    if (ok) {
+      uint32_t cols[64];
+      for (size_t k = 0; k < a.fresh && k < 64; ++k) cols[k] = (uint32_t)k;
+      ck(sp_hyrax_commit_split_finish(ctx, job, cols, u64p(st.w.data() + sp_), a.fresh, u64p(&comm[0].x)), "commit round witness (split)");
+      split = true;
+      st.split_commits++;
+    } else {
+      sp_hyrax_commit_split_drop(job);
+    }
+  }
+  if (!split)
+    for (size_t r = 0; r < rows; ++r)
+      ck(sp_hyrax_commit_small(ctx, vc_ck, u64p(st.w.data() + sp_ + r * s.width), s.width, u64p(&blinds[r]), u64p(&comm[r].x)), "commit round witness");
   st.commit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
   st.commits += rows;
   const auto th0 = std::chrono::steady_clock::now();
@@ -368,6 +471,7 @@ static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shap
   st.challenges.push_back(out);
   st.current++;
   st.hash_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count();
+  begin_next_commitment(ctx, st, s, vc_ck, vc, round + 1, out.empty() ? fe_zero() : out[0], tape);
   return out;
 }
 

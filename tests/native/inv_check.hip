@@ -1,4 +1,4 @@
-// Host-only check (no GPU needed): the binary extended-GCD inversion of the host side (field.hpp fe_inv_host_xgcd) against Fermat's little theorem
+// Host-only check (no GPU needed): the host side's inversions (field.hpp fe_inv_host_safegcd, fe_inv_host_xgcd) against Fermat's little theorem
 // (fe_pow with p - 2) and against x * inv(x) == 1, for both fields: edge values and seeded random residues. Built and run by tests/test_field_host.py.
 #include <cstdio>
 #include <cstdlib>
@@ -41,8 +41,10 @@ static int check(const char* name, int n) {
     // three forms must agree: the raw xgcd (public values), the blinded inversion (possibly secret values) and Fermat's exponentiation
     fe_t a;
     const bool in_bound = fe_inv_host_xgcd<FP>(x, &a);
+    fe_t sg;
+    const bool sg_bound = fe_inv_host_safegcd<FP>(x, &sg);  // the division-step form (what fe_inv / fe_inv_vartime run first)
     const fe_t f = fermat<FP>(x), bl = fe_inv<FP>(x), vt = fe_inv_vartime<FP>(x);
-    bool ok = in_bound && fe_eq(a, f) && fe_eq(bl, f) && fe_eq(vt, f);
+    bool ok = in_bound && sg_bound && fe_eq(a, f) && fe_eq(sg, f) && fe_eq(bl, f) && fe_eq(vt, f);
     if (!fe_is_zero(x)) ok = ok && fe_eq(fe_mul<FP>(a, x), one);
     else ok = ok && fe_is_zero(a);
     if (!ok) {
@@ -60,6 +62,11 @@ static int check(const char* name, int n) {
     for (int i = 0; i < 8; ++i) five.v[i] = i == 0 ? 5u : 0u;
     bool ok = fe_inv_host_xgcd<FP>(pp, &a) && fe_is_zero(a) && fe_is_zero(fe_inv_vartime<FP>(pp));
     ok = ok && fe_inv_host_xgcd<FP>(p5, &a) && fe_inv_host_xgcd<FP>(five, &b) && fe_eq(a, b) && fe_eq(fe_inv_vartime<FP>(p5), b);
+    fe_t c0, c5;
+    ok = ok && fe_inv_host_safegcd<FP>(pp, &c0) && fe_is_zero(c0) && fe_inv_host_safegcd<FP>(p5, &c5) && fe_eq(c5, b);
+    fe_t top;  // 2^256 - 1: the largest non-canonical input
+    for (int i = 0; i < 8; ++i) top.v[i] = 0xffffffffu;
+    ok = ok && fe_inv_host_safegcd<FP>(top, &c0) && fe_inv_host_xgcd<FP>(top, &c5) && fe_eq(c0, c5);
     if (!ok) {
       fprintf(stderr, "%s: non-canonical input mishandled\n", name);
       ++bad;

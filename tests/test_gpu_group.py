@@ -528,6 +528,63 @@ def test_commit_small_device_form_matches_oracle(ctx, width):
         assert (k.commit_small(ones, blind) == want(ones, blind)).all()
 
 
+@pytest.mark.parametrize("width", [32, 8])
+def test_commit_split_equals_commit_small_and_the_oracle(ctx, width):
+    """sp_hyrax_commit_split_begin / _finish (the round commitments of the ZK verifier circuit: the terms known early and the blind are posted to the host
+    table walkers, the round's own scalars follow) against sp_hyrax_commit_small on the assembled row and the oracle's MSM + blind, for every way of
+    cutting the row: nothing early but the blind, everything early, a blind handed over as NULL (no blind's term), zero scalars on either side, a dropped
+    job, many jobs one after the other (slot reuse), and a column that has no host table (refused, not mis-computed)."""
+    rng = np.random.default_rng(SEED + 4300 + width)
+    gs = np.zeros((width + 1, 8), dtype=np.uint64)
+    olib().orc_from_label(b"narrow_key_test", ctypes.c_size_t(width + 1), p64(gs))
+    k = hip.CommitmentKey(ctx, gs[:width], gs[width])
+    if hip.lib().sp_walkers() == 0:
+        assert not k.commit_split_available()
+        pytest.skip("SPARTAN_WALKERS=0: the split form is not offered")
+    ncols = min(width, 16)
+    assert k.commit_split_available(ncols) and not k.commit_split_available(width + 1)
+
+    def want(row, blind):
+        full = np.zeros((width + 1, 4), dtype=np.uint64)
+        full[: len(row)] = row
+        if blind is not None:
+            full[width] = blind
+        return oracle_msm(full, np.ascontiguousarray(gs))
+
+    zero = np.zeros(4, dtype=np.uint64)
+    for trial in range(24):
+        row = ol.random_field_array(rng, ncols)
+        if trial % 3 == 1:
+            row[rng.integers(0, ncols, size=3)] = 0
+        if trial == 5:
+            row[:] = 0
+        blind = None if trial % 4 == 3 else ol.random_field_array(rng, 1)[0]
+        cut = [0, ncols, ncols // 2, 3][trial % 4] if trial < 8 else int(rng.integers(0, ncols + 1))
+        cols = np.arange(ncols, dtype=np.uint32)
+        if trial % 5 == 4:  # an arbitrary subset early, not a prefix
+            perm = rng.permutation(ncols).astype(np.uint32)
+            late, early = perm[:cut], perm[cut:]
+        else:
+            late, early = cols[:cut], cols[cut:]
+        got = k.commit_split(early, row[early], blind, late, row[late])
+        w = want(row, blind)
+        assert (got == w).all(), (trial, cut)
+        assert (k.commit_small(row, zero if blind is None else blind) == w).all()
+    # a dropped job leaves nothing behind: the next one is served
+    row = ol.random_field_array(rng, ncols)
+    blind = ol.random_field_array(rng, 1)[0]
+    cols = np.arange(ncols, dtype=np.uint32)
+    assert k.commit_split(cols[2:], row[2:], blind, cols[:2], row[:2], drop=True) is None
+    assert (k.commit_split(cols[2:], row[2:], blind, cols[:2], row[:2]) == want(row, blind)).all()
+    if width > 16:  # column 16 has no host table: a non-zero scalar there is refused, a zero one is skipped
+        with pytest.raises(hip.SpartanHipError):
+            k.commit_split(np.array([16], dtype=np.uint32), row[:1], blind, cols[:1], row[:1])
+        z = np.zeros((1, 4), dtype=np.uint64)
+        one_col = np.zeros((ncols, 4), dtype=np.uint64)
+        one_col[0] = row[0]
+        assert (k.commit_split(np.array([16], dtype=np.uint32), z, blind, cols[:1], row[:1]) == want(one_col, blind)).all()
+
+
 @pytest.mark.parametrize("k,nfixed", [(1, 2), (3, 5), (3, 8), (9, 425), (9, 512), (10, 1022)])
 def test_fixed_base_tables_multi_mul_with_the_last_eq_level_on_the_device(ctx, k, nfixed):
     """sp_fbtables_multi_mul_begin_eq: the walk's scalars handed over one level short of eq(r_1..r_k, .) - the kernel's own last level gives the same point
