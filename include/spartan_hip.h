@@ -393,6 +393,11 @@ int sp_hyrax_commit_small_with_term(sp_ctx* ctx, const sp_ck* ck, const uint64_t
 typedef struct sp_split_commit sp_split_commit;
 int sp_walkers(void);                              /* polling walker threads of this process (0: the split form is not offered) */
 int sp_walkers_keep_hot(uint64_t microseconds);    /* a prove starts: wake the walkers and keep them polling for this long */
+/* fn(arg, part, nparts) for part = 0 .. nparts - 1 on the walkers and the calling thread; returns when every part has run (parts nobody claims are the
+ * caller's). What `par_iter` is to the reference's host loops over a few hundred to a few thousand field elements (the verifier-circuit instance of
+ * NeutronNovaZkSNARK::prove, src/neutronnova_zk.rs:1948-2017: multiply_vec, the NovaNIFS cross term, the folds). nparts <= 32. */
+typedef void (*sp_part_fn)(void* arg, unsigned part, unsigned nparts);
+int sp_host_parallel_for(unsigned nparts, sp_part_fn fn, void* arg);
 int sp_hyrax_commit_split_available(const sp_ck* ck, size_t cols_used);
 int sp_hyrax_commit_split_begin(sp_ctx* ctx, const sp_ck* ck, const uint32_t* cols, const uint64_t* scalars, size_t n, const uint64_t* blind, sp_split_commit** job);
 int sp_hyrax_commit_split_finish(sp_ctx* ctx, sp_split_commit* job, const uint32_t* cols, const uint64_t* scalars, size_t n, uint64_t out_aff[8]);

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "core.hpp"
+#include "walk_pool.hpp"
 #include "kernels_poly.hpp"
 
 namespace sp {
@@ -149,7 +150,7 @@ int sp_ctx_create(int device, sp_ctx** out) {
   SP_HIP(hipEventCreateWithFlags(&c->eq_ev, hipEventDisableTiming));
   SP_HIP(hipEventCreateWithFlags(&c->eq_read_ev, hipEventDisableTiming));
   SP_HIP(hipMalloc((void**)&c->d_eq_ahead, 2 * ((size_t)1 << 11) * sizeof(fe_t)));
-  c->pinned_elems = spk::MAIL_MIRROR_ELEM + 16;
+  c->pinned_elems = spk::MAPPED_ELEMS;
   SP_HIP(hipHostMalloc((void**)&c->h_pinned, c->pinned_elems * sizeof(fe_t), hipHostMallocMapped));
   memset(c->h_pinned, 0, c->pinned_elems * sizeof(fe_t));
   SP_HIP(hipHostGetDevicePointer((void**)&c->d_pinned, c->h_pinned, 0));
@@ -636,26 +637,191 @@ static int wait_wide(sp_ctx* c, unsigned want, int nvals, fe_t* v) {
   }
   return SP_OK;
 }
-// The tables of a hand-over (kernels_poly.hpp tail_hand_over): nvals elements, three per result slot from slot 0 on. Slot 0 is polled; once it has
-// landed the other lines are on their way: their cache misses are started together before the slots are validated one by one.
+static unsigned host_parts(size_t items, size_t min_per_part) {
+  const size_t w = (size_t)sp::WalkPool::get().walkers() + 1;
+  size_t p = items / min_per_part;
+  if (p > w) p = w;
+  if (p > (size_t)sp::WalkPool::MAX_PARTS) p = sp::WalkPool::MAX_PARTS;
+  return p ? (unsigned)p : 1u;
+}
+// The tables of a hand-over (kernels_poly.hpp tail_hand_over): nvals elements, three per slot of the hand-over area from slot 0 on. Slot 0 is polled;
+// once it has landed the other lines are on their way (one burst of posted writes): their cache misses are started together before the slots are
+// validated one by one (a slot whose tag or check words are not there yet is polled like any result slot).
 static int wait_hand_over(sp_ctx* c, unsigned want, int nvals, fe_t* v) {
   long spins = 0;
-  int rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM, want, nvals < 3 ? nvals : 3, v, true, &spins);
+  const fe_t* area = c->h_pinned + spk::HAND_BASE_ELEM;
+  int rc = wait_slot(c, area, want, nvals < 3 ? nvals : 3, v, true, &spins);
   if (rc) return rc;
   for (int s0 = 3; s0 < nvals; s0 += 3) {
-    const char* line = reinterpret_cast<const char*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * (s0 / 3));
+    const char* line = reinterpret_cast<const char*>(area + 4 * (s0 / 3));
     __builtin_prefetch(line);
     __builtin_prefetch(line + 64);
   }
+  const int nslots = (nvals + 2) / 3;
+  if (nslots > 48 && sp::WalkPool::get().walkers() > 0) {  // a large hand-over: the slots are checked (and copied out) by the walkers, 16+ slots a part
+    struct Check {
+      sp_ctx* c;
+      const fe_t* area;
+      unsigned want;
+      int nvals, nslots;
+      fe_t* v;
+      std::atomic<int> rc{SP_OK};
+    } ck{c, area, want, nvals, nslots, v};
+    auto part = [](void* arg, unsigned p, unsigned np) {
+      Check& k = *static_cast<Check*>(arg);
+      const int lo = 1 + (int)((long)(k.nslots - 1) * p / np), hi = 1 + (int)((long)(k.nslots - 1) * (p + 1) / np);
+      long sp_ = 0;
+      for (int sl = lo; sl < hi; ++sl) {
+        const int s0 = 3 * sl;
+        const int r = wait_slot(k.c, k.area + 4 * sl, k.want, k.nvals - s0 < 3 ? k.nvals - s0 : 3, k.v + s0, true, &sp_);
+        if (r) k.rc.store(r, std::memory_order_relaxed);
+      }
+    };
+    sp::WalkPool::get().run(host_parts((size_t)nslots, 16), part, &ck);
+    return ck.rc.load(std::memory_order_relaxed);
+  }
   for (int s0 = 3; s0 < nvals; s0 += 3)
-    if ((rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM + 4 * (s0 / 3), want, nvals - s0 < 3 ? nvals - s0 : 3, v + s0, true, &spins))) return rc;
+    if ((rc = wait_slot(c, area + 4 * (s0 / 3), want, nvals - s0 < 3 ? nvals - s0 : 3, v + s0, true, &spins))) return rc;
   return SP_OK;
 }
-// bind_poly_var_top (src/polys/multilinear.rs:95-164) on a host table of n entries: the rounds the host runs itself after a hand-over
-static void host_bind_top(fe_t* Z, size_t n, const fe_t& r) {
-  const size_t h = n / 2;
-  for (size_t x = 0; x < h; ++x) Z[x] = fe_add<S>(Z[x], fe_mul<S>(r, fe_sub<S>(Z[x + h], Z[x])));
+// ---- the host's rounds behind a hand-over, spread over the process's polling threads (walk_pool.hpp) ---------------------------------------------------
+// Entries a table may still have when the resident tail hands it to the host (TailArgs::hand_n): 16 (cubic) / 32 (quadratic), the rounds one thread runs
+// in ~3 us. SPARTAN_HAND_N_CUBIC / SPARTAN_HAND_N_QUAD move it up to the tail's first one-block step (256 / 512: 24 / 32 KiB of tables in one burst, the
+// host's rounds spread over the walkers) - built and measured in round 6, NOT the default: the burst and its validation make that trip 15-19 us instead
+// of 9-10, a parallel region costs ~2 us of hand-shakes even with the walkers on the caller's L3, and the rounds it replaces were already two to a trip -
+// outer sum-check -3 us, inner +2 us at config 2 (profiles/r06_hand_over.txt).
+static unsigned tail_hand_n(bool cubic) {
+  static const unsigned v[2] = {
+      [] {
+        const char* e = getenv("SPARTAN_HAND_N_QUAD");
+        unsigned n = e ? (unsigned)atoi(e) : 32u;
+        return n > spk::TAIL_HAND_N_MAX_QUAD ? (unsigned)spk::TAIL_HAND_N_MAX_QUAD : n;
+      }(),
+      [] {
+        const char* e = getenv("SPARTAN_HAND_N_CUBIC");
+        unsigned n = e ? (unsigned)atoi(e) : 16u;
+        return n > spk::TAIL_HAND_N_MAX_CUBIC ? (unsigned)spk::TAIL_HAND_N_MAX_CUBIC : n;
+      }()};
+  return v[cubic ? 1 : 0];
 }
+// bind_poly_var_top (src/polys/multilinear.rs:95-164) on `ntab` host tables of n entries, `stride` apart
+struct HostBind {
+  fe_t* base;
+  size_t stride, n, ntab;
+  fe_t r;
+};
+static void host_bind_part(void* arg, unsigned p, unsigned np) {
+  const HostBind& b = *static_cast<const HostBind*>(arg);
+  const size_t h = b.n / 2, total = b.ntab * h, lo = total * p / np, hi = total * (p + 1) / np;
+  for (size_t i = lo; i < hi; ++i) {
+    fe_t* Z = b.base + (i / h) * b.stride;
+    const size_t x = i % h;
+    Z[x] = fe_add<S>(Z[x], fe_mul<S>(b.r, fe_sub<S>(Z[x + h], Z[x])));
+  }
+}
+static void host_bind_tables(fe_t* base, size_t stride, size_t ntab, size_t n, const fe_t& r) {
+  HostBind b{base, stride, n, ntab, r};
+  const unsigned np = host_parts(ntab * (n / 2), 24);
+  if (np > 1) sp::WalkPool::get().run(np, host_bind_part, &b);
+  else host_bind_part(&b, 0, 1);
+}
+// compute_eval_points_quad (src/sumcheck.rs:128-174) on host tables
+struct HostQuadEval {
+  const fe_t *a, *b;
+  size_t half;
+  fe_t out[sp::WalkPool::MAX_PARTS][2];
+};
+static void host_quad_part(void* arg, unsigned p, unsigned np) {
+  HostQuadEval& q = *static_cast<HostQuadEval*>(arg);
+  const size_t lo = q.half * p / np, hi = q.half * (p + 1) / np;
+  fe_t s0 = fe_zero(), s1 = fe_zero();
+  for (size_t x = lo; x < hi; ++x) {
+    s0 = fe_add<S>(s0, fe_mul<S>(q.a[x], q.b[x]));
+    s1 = fe_add<S>(s1, fe_mul<S>(fe_sub<S>(q.a[x + q.half], q.a[x]), fe_sub<S>(q.b[x + q.half], q.b[x])));
+  }
+  q.out[p][0] = s0;
+  q.out[p][1] = s1;
+}
+static void host_quad_eval(const fe_t* a, const fe_t* b, size_t half, fe_t sums[2]) {
+  HostQuadEval q;
+  q.a = a;
+  q.b = b;
+  q.half = half;
+  const unsigned np = host_parts(half, 24);
+  if (np > 1) sp::WalkPool::get().run(np, host_quad_part, &q);
+  else host_quad_part(&q, 0, 1);
+  sums[0] = sums[1] = fe_zero();
+  for (unsigned p = 0; p < np; ++p) {
+    sums[0] = fe_add<S>(sums[0], q.out[p][0]);
+    sums[1] = fe_add<S>(sums[1], q.out[p][1]);
+  }
+}
+// evaluation_points_cubic_with_three_inputs + t(-1) (src/sumcheck.rs:1025-1156, :1327-1396) on host tables: pairs (x, x + n / 2) weighted with E[x]
+struct HostCubicEval {
+  const fe_t *a, *b, *c, *E;
+  size_t hn;
+  fe_t out[sp::WalkPool::MAX_PARTS][3];
+};
+static void host_cubic_part(void* arg, unsigned p, unsigned np) {
+  HostCubicEval& q = *static_cast<HostCubicEval*>(arg);
+  const size_t hn = q.hn, lo = hn * p / np, hi = hn * (p + 1) / np;
+  fe_t s[3] = {fe_zero(), fe_zero(), fe_zero()};
+  for (size_t x = lo; x < hi; ++x) {
+    const fe_t a0 = q.a[x], a1 = q.a[x + hn], b0 = q.b[x], b1 = q.b[x + hn], c0 = q.c[x], c1 = q.c[x + hn];
+    const fe_t v0 = fe_sub<S>(fe_mul<S>(a0, b0), c0);
+    const fe_t v1 = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
+    const fe_t v2 = fe_sub<S>(fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1)), fe_sub<S>(fe_dbl<S>(c0), c1));
+    s[0] = fe_add<S>(s[0], fe_mul<S>(q.E[x], v0));
+    s[1] = fe_add<S>(s[1], fe_mul<S>(q.E[x], v1));
+    s[2] = fe_add<S>(s[2], fe_mul<S>(q.E[x], v2));
+  }
+  for (int k = 0; k < 3; ++k) q.out[p][k] = s[k];
+}
+static void host_cubic_eval(const fe_t* a, const fe_t* b, const fe_t* cc, const fe_t* E, size_t hn, fe_t sums[3]) {
+  HostCubicEval q;
+  q.a = a;
+  q.b = b;
+  q.c = cc;
+  q.E = E;
+  q.hn = hn;
+  const unsigned np = host_parts(hn, 12);
+  if (np > 1) sp::WalkPool::get().run(np, host_cubic_part, &q);
+  else host_cubic_part(&q, 0, 1);
+  for (int k = 0; k < 3; ++k) sums[k] = fe_zero();
+  for (unsigned p = 0; p < np; ++p)
+    for (int k = 0; k < 3; ++k) sums[k] = fe_add<S>(sums[k], q.out[p][k]);
+}
+// E(rnd, .) = eq(taus[rnd ..), .) of every round the host may run after a hand-over (tables of <= hand_n entries: rounds rnd >= ell - log2(hand_n) + 1),
+// first variable = most significant bit: level k (covering taus[k ..)) is level k + 1 with tau_k in front. Level k sits at offset 2^(ell - k) - 1 ... laid
+// out as a pyramid: size-1 level first. Built once, under the device's first rounds (the cubic loop's first wait).
+struct HostEqLevels {
+  std::vector<fe_t> v;  // level for taus[k ..): m = 2^(ell - k) entries at offset m - 1
+  size_t ell = 0, max_m = 0;
+  bool built = false;
+  void build(const fe_t* taus, size_t ell_, size_t max_entries) {
+    ell = ell_;
+    max_m = 1;
+    while (max_m < max_entries && max_m < ((size_t)1 << ell)) max_m <<= 1;
+    v.assign(2 * max_m, fe_zero());
+    v[0] = fe_one<S>();
+    size_t m = 1;
+    for (size_t k = ell; k-- > 0 && m < max_m;) {  // level k from level k + 1
+      const fe_t* prev = v.data() + (m - 1);
+      fe_t* cur = v.data() + (2 * m - 1);
+      for (size_t j = 0; j < m; ++j) {
+        const fe_t hi = fe_mul<S>(prev[j], taus[k]);
+        cur[j] = fe_sub<S>(prev[j], hi);
+        cur[m + j] = hi;
+      }
+      m *= 2;
+    }
+    built = true;
+  }
+  const fe_t* level(size_t k) const {  // taus[k ..): 2^(ell - k) entries, or nullptr when it was not built
+    const size_t m = (size_t)1 << (ell - k);
+    return built && m <= max_m ? v.data() + (m - 1) : nullptr;
+  }
+};
 // groups > 1 (slot path only): the first nb / groups slots are summed into out_host[0 .. nacc), the next into out_host[nacc .. 2 nacc), ... (the two
 // instances of a batched round evaluated by one launch)
 static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false, unsigned groups = 1) {
@@ -1387,6 +1553,7 @@ int sp_sumcheck_quad_sharded_partial(sp_ctx* c, uint64_t claim_io[4], size_t rou
 static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, sp_reduce_hook reduce, void* reduce_user,
                      sp_challenge_hook observe, void* observe_user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8], size_t run_rounds) {
   const size_t vars = rounds;  // the tables have 2^vars elements
+  if (tail_hand_n(false) > 32) sp::WalkPool::get().keep_hot(3000);  // the host's share of the rounds is spread over the polling threads: awake by then
   tr->join();  // (a long absorb may still be hashing on the library's thread)
   if (run_rounds > vars) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad: more rounds to run than variables");
   const bool stopped = run_rounds != 0 && run_rounds < vars;
@@ -1449,6 +1616,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       ta.r0_from_mail = ahead ? 1 : 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
+      ta.hand_n = tail_hand_n(false);
       tail_nb0 = tail_blocks(A->len / 2);
       hipLaunchKernelGGL((spk::k_sumcheck_tail<false>), dim3(tail_nb0), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
       // the resident kernel stores the final claims into element 0 of its tables AFTER the host has them and has returned (hand-over): whoever rewrites
@@ -1543,7 +1711,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     // this round's sums are in flight: remember how to wait for them, then issue the next launch ahead of the challenge where that is possible
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
-    if (wait_resident && !host_mode && spk::tail_hand_over(false, len_now)) {
+    if (wait_resident && !host_mode && spk::tail_hand_over(len_now, tail_hand_n(false))) {
       // HAND-OVER (kernels_poly.hpp tail_hand_over): the resident kernel sent the tables themselves; this round and the ones after it run here
       hA.resize(2 * len_now);
       if ((rc = wait_hand_over(c, wait_seq, (int)(2 * len_now), hA.data()))) return rc;
@@ -1552,13 +1720,10 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
       hand_seq = wait_seq;
     }
     if (host_mode) {  // compute_eval_points_quad (src/sumcheck.rs:128-174) on the host tables; dense by construction (the tail only takes dense tables)
-      for (size_t x = 0; x < half; ++x) {
-        sums[0] = fe_add<S>(sums[0], fe_mul<S>(hA[x], hB[x]));
-        sums[1] = fe_add<S>(sums[1], fe_mul<S>(fe_sub<S>(hA[x + half], hA[x]), fe_sub<S>(hB[x + half], hB[x])));
-      }
+      host_quad_eval(hA.data(), hB, half, sums);
       waiting = false;
     }
-    if (!host_mode && wait_resident && spk::tail_double(false, len_now)) {
+    if (!host_mode && wait_resident && spk::tail_double(false, len_now, tail_hand_n(false))) {
       // TWO ROUNDS IN THIS TRIP (kernels_poly.hpp TAIL_WIDE_VALS): the resident kernel sent the sums of this round and the coefficient sums, in this
       // round's challenge, of the next. S0 = sum a0 b0, S1 = a1 b1, S2 = (a2-a0)(b2-b0), S3 = (a3-a1)(b3-b1), S4 = a2 b2, S5 = U V, S6 = dU dV,
       // S7 = (U+dU)(V+dV) over the quarters a0..a3 of the table.
@@ -1652,8 +1817,7 @@ static int quad_impl(sp_ctx* c, uint64_t claim_io[4], size_t rounds, sp_table* A
     if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
     last_answered = wait_seq;
     if (host_mode) {
-      host_bind_top(hA.data(), len_now, r_i);
-      host_bind_top(hB, len_now, r_i);
+      host_bind_tables(hA.data(), (size_t)(hB - hA.data()), 2, len_now, r_i);
       sp::after_bind(A);
       sp::after_bind(B);
       have_sums = false;
@@ -2096,6 +2260,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
                       const uint64_t* scale_, sp_reduce_hook reduce, void* reduce_user, const sp_table* prod0, const sp_table* prod1, uint64_t* out_cpolys,
                       uint64_t* out_r, uint64_t out_final[12], size_t run_rounds, sp_challenge_hook observe, void* observe_user) {
   // run_rounds (0 = all): see quad_impl - stop after that many of the ell rounds, tables left at 2^(ell - run_rounds) elements
+  if (tail_hand_n(true) > 16) sp::WalkPool::get().keep_hot(3000);
   tr->join();
   if (run_rounds > ell) return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs: more rounds to run than variables");
   const bool stopped = run_rounds != 0 && run_rounds < ell;
@@ -2198,6 +2363,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
   unsigned tail_nb0 = 1;  // blocks of the resident launch
   bool host_mode = false;  // ... and has handed the tables over: the remaining rounds run on the host (kernels_poly.hpp tail_hand_over)
   std::vector<fe_t> hT, hE;  // host tables after a hand-over (A | B | C, n0 entries each) and the round's eq weights
+  HostEqLevels heq;           // ... of every host round, built once (under the first wait for the device)
   size_t n0 = 0;
   unsigned hand_seq = 0;
   unsigned last_answered = 0;
@@ -2257,6 +2423,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       ta.r0_from_mail = ahead ? 1 : 0;
       ta.mapped = c->d_pinned;
       ta.seq0 = next_seq(c);
+      ta.hand_n = tail_hand_n(true);
       tail_nb0 = tail_blocks(A->len / 2, true);
       hipLaunchKernelGGL((spk::k_sumcheck_tail<true>), dim3(tail_nb0), dim3(spk::TAIL_THREADS), 0, c->stream, ta);
       in_tail = true;
@@ -2376,7 +2543,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     // Not when tau * p vanishes: that round re-evaluates with a third sum (fallback_three_inputs), which must not queue behind a waiting kernel.
     const unsigned wait_seq = c->result_seq, wait_slots = c->pending_slots;
     const bool wait_resident = in_tail;
-    if (wait_resident && !host_mode && spk::tail_hand_over(true, A->len)) {
+    if (wait_resident && !host_mode && spk::tail_hand_over(A->len, tail_hand_n(true))) {
       // HAND-OVER (kernels_poly.hpp tail_hand_over): the resident kernel sent the tables themselves; this round and the ones after it run here
       n0 = A->len;
       hT.resize(3 * n0);
@@ -2384,7 +2551,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       host_mode = true;
       hand_seq = wait_seq;
     }
-    if (!host_mode && wait_resident && spk::tail_double(true, A->len)) {
+    if (!host_mode && wait_resident && spk::tail_double(true, A->len, tail_hand_n(true))) {
       // TWO ROUNDS IN THIS TRIP (kernels_poly.hpp TAIL_WIDE_VALS). W[9..12) = t(0), t_inf, t(-1) of round rnd; W[0..9) = the coefficient sums of
       // round rnd + 1 in this round's challenge r: t'(0) = W0 + r (W1 - W0 - W2) + r^2 W2, t'_inf = W3 + r (W5 - W3 - W4) + r^2 W4,
       // t'(-1) = W6 + r (W8 - W6 - W7) + r^2 W7 (used by the fallback_three_inputs form only, as in the one-round path).
@@ -2480,30 +2647,26 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
       // E(rnd, x) = eq(taus[rnd ..), x) - what the split tables of either half multiply out to (select_eq)
       const size_t n = len_now, hn = n / 2;
       const fe_t *ha = hT.data(), *hb = ha + n0, *hc = hb + n0;
-      hE.assign(1, one);
-      for (size_t i = rnd; i < ell; ++i) {  // first variable = most significant bit of x
-        const size_t m = hE.size();
-        hE.resize(2 * m);
-        for (size_t j = m; j-- > 0;) {
-          const fe_t hi = fe_mul<S>(hE[j], taus[i]);
-          hE[2 * j] = fe_sub<S>(hE[j], hi);
-          hE[2 * j + 1] = hi;
+      const fe_t* E = heq.level(rnd);
+      if (!E) {  // (not built: a hand-over the first wait did not foresee)
+        hE.assign(1, one);
+        for (size_t i = rnd; i < ell; ++i) {  // first variable = most significant bit of x
+          const size_t m = hE.size();
+          hE.resize(2 * m);
+          for (size_t j = m; j-- > 0;) {
+            const fe_t hi = fe_mul<S>(hE[j], taus[i]);
+            hE[2 * j] = fe_sub<S>(hE[j], hi);
+            hE[2 * j + 1] = hi;
+          }
         }
+        E = hE.data();
       }
-      sums[0] = sums[1] = sums[2] = fe_zero();
-      for (size_t x = 0; x < hn; ++x) {
-        const fe_t a0 = ha[x], a1 = ha[x + hn], b0 = hb[x], b1 = hb[x + hn], c0 = hc[x], c1 = hc[x + hn];
-        const fe_t v0 = fe_sub<S>(fe_mul<S>(a0, b0), c0);
-        const fe_t v1 = fe_mul<S>(fe_sub<S>(a1, a0), fe_sub<S>(b1, b0));
-        const fe_t v2 = fe_sub<S>(fe_mul<S>(fe_sub<S>(fe_dbl<S>(a0), a1), fe_sub<S>(fe_dbl<S>(b0), b1)), fe_sub<S>(fe_dbl<S>(c0), c1));
-        sums[0] = fe_add<S>(sums[0], fe_mul<S>(hE[x], v0));
-        sums[1] = fe_add<S>(sums[1], fe_mul<S>(hE[x], v1));
-        sums[2] = fe_add<S>(sums[2], fe_mul<S>(hE[x], v2));
-      }
+      host_cubic_eval(ha, hb, hc, E, hn, sums);
     } else {
       const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
       c->result_seq = wait_seq;
       c->pending_slots = wait_slots;
+      if (!heq.built && tail_hand_n(true) > 16) heq.build(taus.data(), ell, tail_hand_n(true) / 2);  // under the device's round: the weights of the host's rounds
       rc = reduce_partials_wait(c, wait_resident ? 3 : 2, sums, wait_resident || issued != 0);  // never a stream synchronise with a launch waiting at the mailbox
       if (issued) {  // back to the state of the launch issued ahead
         c->result_seq = cur_seq;
@@ -2559,7 +2722,7 @@ static int cubic_impl(sp_ctx* c, uint64_t claim_io[4], uint64_t p_io[4], const u
     const size_t ri = rnd - 1;
     last_answered = wait_seq;
     if (host_mode) {
-      for (int t = 0; t < 3; ++t) host_bind_top(hT.data() + t * n0, len_now, r_i);
+      host_bind_tables(hT.data(), n0, 3, len_now, r_i);
       sp::after_bind(A);
       sp::after_bind(B);
       sp::after_bind(C);

@@ -2707,6 +2707,11 @@ int sp_walkers_keep_hot(uint64_t microseconds) {
   sp::WalkPool::get().keep_hot((long)microseconds);
   return SP_OK;
 }
+int sp_host_parallel_for(unsigned nparts, sp_part_fn fn, void* arg) {
+  if (!fn) return fail(SP_ERR_INVALID_INPUT_LENGTH, "parallel_for: no function");
+  sp::WalkPool::get().run(nparts ? nparts : 1u, fn, arg);
+  return SP_OK;
+}
 int sp_hyrax_commit_split_available(const sp_ck* ck, size_t cols_used) {
   return ck && ck->d_cktables && ck->h_tables16 && ck->h16_bases >= cols_used && cols_used <= ck->num_cols && sp::WalkPool::get().walkers() > 0;
 }

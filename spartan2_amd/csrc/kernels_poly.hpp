@@ -106,21 +106,27 @@ constexpr int TAIL_ERR_ELEM = 10, TAIL_FINAL_ELEM = 16;  // element indices in t
 // region of their own, written with plain stores, stayed in the L2 until the kernel ended; system-scope stores for every word cost more than the trip saved).
 constexpr int TAIL_WIDE_VALS = 12;
 constexpr int TAIL_DOUBLE_SUMS_QUAD = 8, TAIL_DOUBLE_SUMS_CUBIC = 12;
-// HAND-OVER OF THE LAST ROUNDS. Once a bind leaves tables of n <= TAIL_HAND_OVER entries (cubic 16: four rounds left; quadratic 32: five), a round is
-// ~10 products a pair on the device against a trip over the bus of 6 - 9 us: the kernel sends the TABLES instead of sums (n elements per table, three
-// per result slot like the two-round trips), the host binds and evaluates the remaining rounds itself (~100 products, 3 us for all of them beside its
-// transcript steps) and hands the final claims back through the mailbox - three lines answering seq, seq + 1, seq + 2 - which the kernel, otherwise
-// idle, stores into element 0 of the tables (the ABI's "bound in place down to length 1") before it leaves. Same polynomials, same transcript.
+// HAND-OVER OF THE LAST ROUNDS. Once a bind leaves tables of n <= hand_n entries, the kernel sends the TABLES instead of sums (n elements per table, three
+// per 128-byte slot of the hand-over area, each slot tagged like a result slot), the host binds and evaluates the remaining rounds itself and hands the
+// final claims back through the mailbox - lines answering seq, seq + 1 (, seq + 2) - which the kernel, otherwise idle, stores into element 0 of the tables
+// (the ABI's "bound in place down to length 1") before it leaves. Same polynomials, same transcript.
+// hand_n is the launch's (TailArgs::hand_n, chosen by the host: capi_core.hip tail_hand_n): 16 (cubic) / 32 (quadratic) entries - the rounds a single host
+// thread runs in ~3 us; above that a trip carries two rounds (tail_double). Round 6 built the larger form - the hand-over at the moment ONE block is left,
+// n = 256 / 512, the host's rounds spread over the process's polling threads (walk_pool.hpp) - and measured it behind this one (see tail_hand_n); the
+// kernel takes either.
+constexpr int TAIL_HAND_OVER_MAX_VALS = 1024;  // 3 x 256 or 2 x 512 elements: 342 slots of the hand-over area
+constexpr unsigned long long TAIL_HAND_N_MAX_CUBIC = 256, TAIL_HAND_N_MAX_QUAD = 512;  // one block left (q <= TAIL_WIDE_Q[_CUBIC]): its LDS holds the tables
 #ifdef SP_TAIL_NO_HAND_OVER  // A/B builds
-__host__ __device__ __forceinline__ bool tail_hand_over(bool, unsigned long long) { return false; }
+__host__ __device__ __forceinline__ bool tail_hand_over(unsigned long long, unsigned long long) { return false; }
 #else
-__host__ __device__ __forceinline__ bool tail_hand_over(bool cubic, unsigned long long n) { return n >= 2 && n <= (cubic ? 16ull : 32ull); }
+__host__ __device__ __forceinline__ bool tail_hand_over(unsigned long long n, unsigned long long hand_n) { return n >= 2 && n <= hand_n; }
 #endif
-constexpr int TAIL_HAND_OVER_MAX_VALS = 64;  // 3 x 16 or 2 x 32 elements: 22 result slots at most (of HOST_SUM_MAX_BLOCKS)
 #ifdef SP_TAIL_SINGLE  // A/B builds: one round per trip everywhere
-__host__ __device__ __forceinline__ bool tail_double(bool, unsigned long long) { return false; }
+__host__ __device__ __forceinline__ bool tail_double(bool, unsigned long long, unsigned long long) { return false; }
 #else
-__host__ __device__ __forceinline__ bool tail_double(bool cubic, unsigned long long n) { return !tail_hand_over(cubic, n) && n >= 4 && n <= (cubic ? 256ull : 512ull); }
+__host__ __device__ __forceinline__ bool tail_double(bool cubic, unsigned long long n, unsigned long long hand_n) {
+  return !tail_hand_over(n, hand_n) && n >= 4 && n <= (cubic ? 256ull : 512ull);
+}
 #endif
 // The mailbox is a RING of MAIL_RING 64-byte lines indexed by the sequence number a challenge answers (line = seq & 7): a waiter only ever looks at the
 // line of ITS challenge, which the host does not touch again before eight more results are in. With the ring in device memory the host also keeps a
@@ -129,6 +135,8 @@ __host__ __device__ __forceinline__ bool tail_double(bool cubic, unsigned long l
 // 64 bytes. Which path answered is counted in the diagnostics words (device memory, MAIL_DIAG_WORD of the mailbox page; sp_ctx_mail_stats).
 constexpr int MAIL_RING = 8, MAIL_LINE_WORDS = 16;
 constexpr int MAIL_MIRROR_ELEM = SLOT_BASE_ELEM + 4 * HOST_SUM_MAX_BLOCKS;  // 16 elements = 8 lines
+constexpr int HAND_BASE_ELEM = MAIL_MIRROR_ELEM + 16;  // the hand-over area: (TAIL_HAND_OVER_MAX_VALS + 2) / 3 slots of 4 elements
+constexpr int MAPPED_ELEMS = HAND_BASE_ELEM + 4 * ((TAIL_HAND_OVER_MAX_VALS + 2) / 3);
 constexpr int MAIL_DIAG_WORD = 256;  // word offset in the device mailbox page: [0] answers taken from the mirror, [1] watchdog trips, [2] / [3] want / device-line seq of the last mirror answer
 constexpr unsigned long long MAIL_MIRROR_AFTER_TICKS = 3000ull, MAIL_MIRROR_EVERY_TICKS = 1000ull;  // 30 us, 10 us at the 100 MHz wall clock
 // 8 s at the 100 MHz wall clock. Long on purpose: an owner thread that the host's scheduler keeps away from its CPU (a throttled cgroup: the bench
@@ -1131,6 +1139,7 @@ struct TailArgs {
   int r0_from_mail;         // launched ahead of r0: the first round waits for the mailbox too
   fe_t* mapped;             // device address of the mapped pinned buffer (per-block result slots at SLOT_BASE_ELEM, error word)
   unsigned seq0;            // sequence number of the first result this kernel publishes
+  unsigned hand_n;          // tables of <= hand_n entries go to the host (tail_hand_over)
 };
 __device__ __forceinline__ fe_t load_agent(const fe_t* p) {
   fe_t v;
@@ -1234,7 +1243,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     fe_t w_pre = fe_zero();
     if (CUBIC && len > 2) {
       const unsigned qb_p = local ? (unsigned)(q / nb0) : (unsigned)(q - base < WQ ? q - base : WQ);
-      if (tail_double(CUBIC, len / 2)) {
+      if (tail_double(CUBIC, len / 2, a.hand_n)) {
         const unsigned qd_p = (unsigned)(len / 8), seg_p = qd_p < 64 ? 64u : qd_p, g_p = threadIdx.x / seg_p, i_p = threadIdx.x % seg_p;
         if (g_p < 9 && i_p < qd_p) w_pre = weight(rnd + 1, i_p);
         else if (g_p < 15 && i_p < qd_p) w_pre = weight(rnd, i_p + ((g_p - 9) & 1u) * qd_p);
@@ -1314,11 +1323,11 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
     }
     __syncthreads();
     SP_TT(2);
-    if (tail_hand_over(CUBIC, len / 2)) {
-      // the host takes the remaining rounds (see tail_hand_over). One block is left here (q <= 8: base = 0, qb = q), so bound[t * n + x] is element x
+    if (tail_hand_over(len / 2, a.hand_n)) {
+      // the host takes the remaining rounds (see tail_hand_over). One block is left here (q <= WQ: base = 0, qb = q), so bound[t * n + x] is element x
       // of table t, n = len / 2: value k = t * n + x goes to slot k / 3, element k % 3, tagged with this result's sequence number.
       const unsigned n = (unsigned)(len / 2), nv = nt * n;
-      fe_t* wide = a.mapped + SLOT_BASE_ELEM;
+      fe_t* wide = a.mapped + HAND_BASE_ELEM;
       if (threadIdx.x < nv) {
         const unsigned k = threadIdx.x;
         const fe_t t = bound[k];
@@ -1346,7 +1355,7 @@ __global__ void __launch_bounds__(TAIL_THREADS) k_sumcheck_tail(TailArgs a) {
       }
       return;
     }
-    if (tail_double(CUBIC, len / 2)) {
+    if (tail_double(CUBIC, len / 2, a.hand_n)) {
       // the round over the n = len / 2 entries just bound AND the coefficient sums of the round after it (see TAIL_WIDE_VALS). y < qd = n / 4;
       // a0..a3 = A[y + k qd]. One product per lane, `which` wave-uniform:
       //   quadratic (8 sums): a0 b0 | a1 b1 | (a2-a0)(b2-b0) | (a3-a1)(b3-b1) | a2 b2 | (a1-a0)(b1-b0) | (a3-a1-a2+a0)(..) | (a3-a2)(b3-b2)

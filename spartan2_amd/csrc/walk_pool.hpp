@@ -12,9 +12,13 @@
 // itself, which never waits for a part nobody has claimed). The walkers poll one cache line of batch states while `keep_hot` says a prove is in
 // flight and sleep on a condition variable otherwise.
 #pragma once
+#include <pthread.h>
+#include <sched.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -27,7 +31,10 @@ namespace sp {
 class WalkPool {
  public:
   static constexpr int MAX_BATCHES = 8, MAX_PARTS = 32, MAX_ENTS = 16 * 40;
+  typedef void (*PartFn)(void* arg, unsigned part, unsigned nparts);
   struct Batch {
+    PartFn fn = nullptr;  // a parallel-for over the parts (run below); nullptr = the table walk over `ents`
+    void* arg = nullptr;
     const aff_t* ents[MAX_ENTS];
     unsigned n_ents = 0, nparts = 0;
     xyzz_t part[MAX_PARTS];
@@ -49,6 +56,51 @@ class WalkPool {
   bool stop_ = false, started_ = false;
   int want_ = 0;
 
+  // the CPUs that share the calling thread's last-level cache, minus the calling thread's own (false: not known, or fewer than three)
+  static bool near_cpus(cpu_set_t* out, int* ncpus) {
+    const char* e = getenv("SPARTAN_WALKERS_PIN");
+    if (e && e[0] == '0') return false;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return false;
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[256] = {0};
+    const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    CPU_ZERO(out);
+    int count = 0;
+    for (const char* p = buf; *p && *p != '\n';) {  // "0-7,128-135"
+      char* end;
+      const long a = strtol(p, &end, 10);
+      long b = a;
+      if (*end == '-') b = strtol(end + 1, &end, 10);
+      for (long k = a; k <= b && k < CPU_SETSIZE; ++k)
+        if (CPU_ISSET(k, &allowed) && first_sibling((int)k) == (int)k && first_sibling(cpu) != (int)k) {  // one logical CPU a core, not the caller's core
+          CPU_SET(k, out);
+          ++count;
+        }
+      p = *end == ',' ? end + 1 : end;
+      if (end == p && *p) break;
+    }
+    if (count < 3) return false;
+    *ncpus = count;
+    return true;
+  }
+  static int first_sibling(int cpu) {  // lowest-numbered hardware thread of the core
+    char path[128];
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+    FILE* f = fopen(path, "r");
+    if (!f) return cpu;
+    long a = cpu;
+    if (fscanf(f, "%ld", &a) != 1) a = cpu;
+    fclose(f);
+    return (int)a;
+  }
   static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   static void cpu_pause() { __builtin_ia32_pause(); }
 
@@ -65,6 +117,11 @@ class WalkPool {
     }
   }
   static void run_part(Batch& b, unsigned p) {
+    if (b.fn) {
+      b.fn(b.arg, p, b.nparts);
+      b.done.fetch_add(1, std::memory_order_acq_rel);
+      return;
+    }
     const unsigned lo = (unsigned)((uint64_t)b.n_ents * p / b.nparts), hi = (unsigned)((uint64_t)b.n_ents * (p + 1) / b.nparts);
     for (unsigned k = lo; k < hi; ++k) __builtin_prefetch(b.ents[k], 0, 0);  // each entry is a miss in a table of 64 MiB
     xyzz_t acc = xyzz_identity();
@@ -127,7 +184,16 @@ class WalkPool {
       std::lock_guard<std::mutex> l(mu_);
       if (!started_) {
         started_ = true;
-        for (int i = 0; i < want_; ++i) th_.emplace_back([this] { loop(); });
+        // the walkers share the L3 of the core that first asks for them: a part's hand-shake is two cache-line transfers, ~25 ns inside a core complex
+        // and 150-500 ns across complexes or sockets (SPARTAN_WALKERS_PIN=0: wherever the scheduler puts them)
+        cpu_set_t set;
+        int ncpus = 0;
+        const bool pin = near_cpus(&set, &ncpus);
+        if (pin && ncpus < want_) want_ = ncpus;  // a core each
+        for (int i = 0; i < want_; ++i) {
+          th_.emplace_back([this] { loop(); });
+          if (pin) (void)pthread_setaffinity_np(th_.back().native_handle(), sizeof(set), &set);
+        }
       }
       cv_.notify_all();
     }
@@ -140,6 +206,8 @@ class WalkPool {
         in_use_[i] = true;
         Batch& b = batches_[i];
         b.slot = i;
+        b.fn = nullptr;
+        b.arg = nullptr;
         b.n_ents = 0;
         b.nparts = 0;
         b.done.store(0, std::memory_order_relaxed);
@@ -154,6 +222,7 @@ class WalkPool {
     if (nparts < 1) nparts = 1;
     if (nparts > (unsigned)MAX_PARTS) nparts = MAX_PARTS;
     if (nparts > b->n_ents) nparts = b->n_ents ? b->n_ents : 1;
+    b->fn = nullptr;
     b->nparts = nparts;
     states_[b->slot].store(((uint64_t)b->gen << 32) | ((uint64_t)nparts << 16), std::memory_order_release);
   }
@@ -166,6 +235,25 @@ class WalkPool {
     for (unsigned p = 0; p < b->nparts; ++p) acc = xyzz_add(acc, b->part[p]);
     release(b);
     return acc;
+  }
+  // fn(arg, p, nparts) for p = 0 .. nparts - 1 on the walkers and the calling thread; returns when every part has run. Parts nobody has claimed are the
+  // caller's (a sleeping walker costs nothing but its help), and with no free slot the caller runs them all. The host rounds of the sum-checks behind a
+  // hand-over (capi_core.hip) are loops of a few hundred independent field products: this is their `par_iter`.
+  void run(unsigned nparts, PartFn fn, void* arg) {
+    if (nparts > (unsigned)MAX_PARTS) nparts = MAX_PARTS;
+    Batch* b = nparts > 1 && want_ ? acquire() : nullptr;
+    if (!b) {
+      for (unsigned p = 0; p < nparts; ++p) fn(arg, p, nparts);
+      return;
+    }
+    b->fn = fn;
+    b->arg = arg;
+    b->nparts = nparts;
+    states_[b->slot].store(((uint64_t)b->gen << 32) | ((uint64_t)nparts << 16), std::memory_order_release);
+    unsigned g;
+    for (int p; (p = claim(b->slot, &g)) >= 0;) run_part(*b, (unsigned)p);
+    while (b->done.load(std::memory_order_acquire) < b->nparts) cpu_pause();
+    release(b);
   }
   bool finished(const Batch* b) const { return b->done.load(std::memory_order_acquire) >= b->nparts; }
   void release(Batch* b) {

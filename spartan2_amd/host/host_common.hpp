@@ -1,6 +1,7 @@
 // Helpers shared by the host-side drivers above the C ABI (spartan_snark.cpp, neutronnova_nifs.cpp): error plumbing, the transcript wrapper over
 // sp_transcript_*, the transcript encodings of points / commitments, the randomness tape.
 #pragma once
+#include <type_traits>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -215,6 +216,29 @@ class Background {
     }
   }
 };
+
+// The reference's `par_iter` over a host vector: body(lo, hi) on contiguous ranges, spread over the library's polling threads (sp_host_parallel_for;
+// ranges nobody claims are run by the caller). Field arithmetic is exact, so the partition never shows in a result.
+template <class F>
+static inline void par_for(size_t n, size_t min_chunk, F&& body) {
+  size_t parts = min_chunk ? n / min_chunk : 1;
+  const size_t w = (size_t)sp_walkers() + 1;
+  if (parts > w) parts = w;
+  if (parts > 32) parts = 32;
+  if (parts <= 1) {
+    if (n) body((size_t)0, n);
+    return;
+  }
+  struct Ctx {
+    typename std::remove_reference<F>::type* f;
+    size_t n;
+  } c{&body, n};
+  ck(sp_host_parallel_for((unsigned)parts, [](void* a, unsigned p, unsigned np) {
+       Ctx& x = *static_cast<Ctx*>(a);
+       (*x.f)(x.n * p / np, x.n * (p + 1) / np);
+     }, &c),
+     "parallel_for");
+}
 
 struct Tape {
   const uint8_t* bytes;

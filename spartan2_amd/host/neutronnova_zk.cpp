@@ -432,6 +432,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     t_lap = t;
   };
   ck(sp_ctx_bind_thread(ctx), "device");
+  ck(sp_walkers_keep_hot(20000), "walkers");  // the round commitments and the host loops of the verifier-circuit instance are spread over them
   const bool side = !reference_order;  // (false = everything inline on the caller's context: the order the phase comments describe)
   struct SideGuard {  // no exit path leaves a job running on state this call owns
     NNZkPrep& ps;
@@ -833,13 +834,17 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   std::vector<fe_t> r_T(vcons / 32);
   for (auto& b : r_T) b = tape.next();
   std::vector<fe_t> Zs(vnv + 1 + vio);
-  for (size_t i = 0; i < vnv; ++i) Zs[i] = fe_add<S>(rnd_W[i], vst.w[i]);
+  par_for(vnv, 256, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) Zs[i] = fe_add<S>(rnd_W[i], vst.w[i]);
+  });
   const fe_t u1 = fe_add<S>(rnd_u, one);
   Zs[vnv] = u1;
   for (size_t i = 0; i < vio; ++i) Zs[vnv + 1 + i] = fe_add<S>(rnd_X[i], Uv_X[i]);
   vs.multiply_vec(Zs, mv);
   std::vector<fe_t> T(vcons);
-  for (size_t i = 0; i < vcons; ++i) T[i] = fe_sub<S>(fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(u1, mv[2][i])), rnd_E[i]);
+  par_for(vcons, 48, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) T[i] = fe_sub<S>(fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(u1, mv[2][i])), rnd_E[i]);
+  });
   const std::vector<aff_t> comm_T = commit_rows32(ctx, ps, pk.vc_ck, T, r_T);
   {
     const std::vector<uint8_t> b = commitment_bytes(comm_T.data(), comm_T.size());
@@ -848,8 +853,12 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   lap("NovaNIFS: T + commit_T");
   const fe_t rf = tr.squeeze("r");
   std::vector<fe_t> Wfold(vnv), Efold(vcons), rWfold(rnd_rW.size()), rEfold(rnd_rE.size()), Xfold(vio);
-  for (size_t i = 0; i < vnv; ++i) Wfold[i] = fe_add<S>(rnd_W[i], fe_mul<S>(rf, vst.w[i]));
-  for (size_t i = 0; i < vcons; ++i) Efold[i] = fe_add<S>(rnd_E[i], fe_mul<S>(rf, T[i]));
+  par_for(vnv + vcons, 96, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) {
+      if (i < vnv) Wfold[i] = fe_add<S>(rnd_W[i], fe_mul<S>(rf, vst.w[i]));
+      else Efold[i - vnv] = fe_add<S>(rnd_E[i - vnv], fe_mul<S>(rf, T[i - vnv]));
+    }
+  });
   for (size_t i = 0; i < rWfold.size(); ++i) rWfold[i] = fe_add<S>(rnd_rW[i], fe_mul<S>(rf, Wv_r[i]));
   for (size_t i = 0; i < rEfold.size(); ++i) rEfold[i] = fe_add<S>(rnd_rE[i], fe_mul<S>(rf, r_T[i]));
   for (size_t i = 0; i < vio; ++i) Xfold[i] = fe_add<S>(rnd_X[i], fe_mul<S>(rf, Uv_X[i]));
@@ -865,7 +874,9 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   std::vector<fe_t> vtau(vlx);
   for (auto& t : vtau) t = tr.squeeze("t");
   std::vector<fe_t> uczE(vcons);
-  for (size_t i = 0; i < vcons; ++i) uczE[i] = fe_add<S>(fe_mul<S>(ufold, mv[2][i]), Efold[i]);
+  par_for(vcons, 96, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; ++i) uczE[i] = fe_add<S>(fe_mul<S>(ufold, mv[2][i]), Efold[i]);
+  });
   std::vector<fe_t> v_outer(3 * vlx), v_rx(vlx), v_inner(2 * vly), v_ry(vly);
   fe_t v_claims[3];
   {
@@ -878,22 +889,37 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const fe_t vr = tr.squeeze("r"), vr2 = fe_mul<S>(vr, vr);
   const std::vector<fe_t> v_evals_rx = eq_evals(v_rx.data(), vlx);
   fe_t claim_E = fe_zero();
-  for (size_t i = 0; i < vcons; ++i) claim_E = fe_add<S>(claim_E, fe_mul<S>(Efold[i], v_evals_rx[i]));
+  {
+    fe_t partial[32];
+    for (auto& x : partial) x = fe_zero();
+    std::atomic<unsigned> slot{0};
+    par_for(vcons, 64, [&](size_t lo, size_t hi) {
+      fe_t acc = fe_zero();
+      for (size_t i = lo; i < hi; ++i) acc = fe_add<S>(acc, fe_mul<S>(Efold[i], v_evals_rx[i]));
+      partial[slot.fetch_add(1) & 31u] = acc;
+    });
+    for (const auto& x : partial) claim_E = fe_add<S>(claim_E, x);
+  }
   const fe_t v_claim_inner = fe_add<S>(fe_add<S>(v_claims[0], fe_mul<S>(vr, v_claims[1])), fe_mul<S>(vr2, fe_sub<S>(v_claims[2], claim_E)));
   const size_t vcols = vs.num_cols();
   std::vector<fe_t> vabc(vz_len, fe_zero());
   {
     std::vector<fe_t> ev[3];
-    for (int m = 0; m < 3; ++m) {  // bind_matrix_row_vars (:22-41)
-      ev[m].assign(vcols, fe_zero());
-      for (size_t row = 0; row < vcons; ++row) {
-        if (fe_is_zero(v_evals_rx[row])) continue;
-        for (uint64_t k = vs.M[m].ptr[row]; k < vs.M[m].ptr[row + 1]; ++k)
-          ev[m][vs.M[m].idx[k]] = fe_add<S>(ev[m][vs.M[m].idx[k]], fe_mul<S>(v_evals_rx[row], vs.M[m].data[k]));
+    // bind_matrix_row_vars (:22-41): a scatter into the columns of one matrix - the three matrices side by side
+    par_for(3, 1, [&](size_t lo, size_t hi) {
+      for (size_t m = lo; m < hi; ++m) {
+        ev[m].assign(vcols, fe_zero());
+        for (size_t row = 0; row < vcons; ++row) {
+          if (fe_is_zero(v_evals_rx[row])) continue;
+          for (uint64_t k = vs.M[m].ptr[row]; k < vs.M[m].ptr[row + 1]; ++k)
+            ev[m][vs.M[m].idx[k]] = fe_add<S>(ev[m][vs.M[m].idx[k]], fe_mul<S>(v_evals_rx[row], vs.M[m].data[k]));
+        }
       }
-    }
+    });
     const fe_t r2u = fe_mul<S>(vr2, ufold);
-    for (size_t i = 0; i < vcols; ++i) vabc[i] = fe_add<S>(fe_add<S>(ev[0][i], fe_mul<S>(vr, ev[1][i])), fe_mul<S>(r2u, ev[2][i]));
+    par_for(vcols, 128, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) vabc[i] = fe_add<S>(fe_add<S>(ev[0][i], fe_mul<S>(vr, ev[1][i])), fe_mul<S>(r2u, ev[2][i]));
+    });
   }
   lap("claim_E + bind_matrix_rows");
   zr.resize(vz_len, fe_zero());

@@ -269,14 +269,16 @@ struct Shape {  // SplitMultiRoundR1CSShape + to_regular_shape
   size_t num_cols() const { return total_vars + 1 + num_io(); }
   void multiply_vec(const std::vector<fe_t>& z, std::vector<fe_t> out[3]) const {
     if (z.size() != num_cols()) throw Error(SP_ERR_INVALID_WITNESS_LENGTH, "InvalidWitnessLength");
-    for (int m = 0; m < 3; ++m) {
-      out[m].assign(num_cons, fe_zero());
-      for (size_t r = 0; r < num_cons; ++r) {
+    for (int m = 0; m < 3; ++m) out[m].assign(num_cons, fe_zero());
+    par_for(3 * num_cons, 96, [&](size_t lo, size_t hi) {  // rows of the three matrices as one range
+      for (size_t i = lo; i < hi; ++i) {
+        const int m = (int)(i / num_cons);
+        const size_t r = i % num_cons;
         fe_t acc = fe_zero();
         for (uint64_t k = M[m].ptr[r]; k < M[m].ptr[r + 1]; ++k) acc = fe_add<S>(acc, fe_mul<S>(M[m].data[k], z[M[m].idx[k]]));
         out[m][r] = acc;
       }
-    }
+    });
   }
   static Shape from_circuit(const Circuit& vc) {
     Shape sh;

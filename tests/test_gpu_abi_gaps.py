@@ -242,18 +242,23 @@ def test_eq_table_begun_two_coordinates_early(ctx, ell):
     ("SPARTAN_PIP_MINW=2", "tests/test_gpu_msm_big.py -k 'msm_points_matches_oracle or ragged'"),
     ("SPARTAN_COMB_MINW=2", "tests/test_gpu_configs.py::test_c4_full_scalar_commit_2048_rows_matches_oracle"),
     ("SPARTAN_FBTABLES_OLD=1", "tests/test_gpu_group.py -k 'fbtables_every_entry or fixed_base_tables_multi_mul_matches'"),
+    ("SPARTAN_HAND_N_CUBIC=256 SPARTAN_HAND_N_QUAD=512", "tests/test_gpu_sumcheck.py tests/test_gpu_configs.py -k 'cubic or quad or c1_c2 or randomised or two_round'"),
+    ("SPARTAN_HAND_N_CUBIC=64 SPARTAN_HAND_N_QUAD=128 SPARTAN_WALKERS=0", "tests/test_gpu_sumcheck.py -k 'cubic or quad'"),
+    ("SPARTAN_VC_SPLIT=0", "tests/test_gpu_neutronnova_zk.py -k 'oracle'"),
+    ("SPARTAN_WALKERS=0", "tests/test_gpu_neutronnova_zk.py tests/test_gpu_group.py -k 'oracle or commit_split'"),
 ])
 def test_switched_code_paths_in_a_process_of_their_own(env, targets):
     """Code paths behind switches that are read once per process - the second stage folded into the streaming producers (measured, off by default), the
-    two-waves-per-SIMD forms of the comb / Pippenger bucket kernels (spill-free, measured behind the three-wave forms), round 5's table build - run the parity
+    two-waves-per-SIMD forms of the comb / Pippenger bucket kernels (spill-free, measured behind the three-wave forms), round 5's table build, the resident
+    tail's hand-over at its first one-block step with the host's rounds on the walkers (and an intermediate size without walkers), the round commitments of
+    the ZK verifier circuit through the device walk, a process without walkers - run the parity
     tests that exercise them in a child process with the switch set: they stay bit-exact against the oracle although no default run takes them."""
     import shlex
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    k, v = env.split("=")
-    child_env = dict(os.environ, **{k: v})
+    child_env = dict(os.environ, **dict(kv.split("=") for kv in env.split()))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + shlex.split(targets), cwd=root, env=child_env, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout or "")[-1500:]
     assert r.returncode == 0, tail
