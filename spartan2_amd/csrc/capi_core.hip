@@ -824,7 +824,8 @@ struct HostEqLevels {
 };
 // groups > 1 (slot path only): the first nb / groups slots are summed into out_host[0 .. nacc), the next into out_host[nacc .. 2 nacc), ... (the two
 // instances of a batched round evaluated by one launch)
-static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false, unsigned groups = 1) {
+static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool resident = false, unsigned groups = 1, bool wide = false) {
+  const int slot_base = wide ? spk::HAND_BASE_ELEM : spk::SLOT_BASE_ELEM;  // wide: up to WIDE_SLOTS slots in the hand-over area (emit_partials_wide)
   const unsigned want = c->result_seq;
   if (c->pending_slots) {  // per-block slots: add them on the host as they become valid
     const unsigned nb = c->pending_slots;
@@ -834,7 +835,7 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
     if (nb == 1) {
       fe_t v[3];
       long spins = 0;
-      int rc = wait_slot(c, c->h_pinned + spk::SLOT_BASE_ELEM, want, nacc, v, resident, &spins);
+      int rc = wait_slot(c, c->h_pinned + slot_base, want, nacc, v, resident, &spins);
       if (rc) return rc;
       for (int k = 0; k < nacc; ++k) out_host[k] = v[k];
       return SP_OK;
@@ -845,8 +846,8 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
     // read, so the misses of a pass overlap (with the data line fetched only behind its tag a slot cost ~90 ns, 64 of them 6 us behind the last arrival -
     // the resident tail's local regime delivers all its slots at the same moment). The sums are accumulated limb-wise (64 slots: < 2^38 per limb) and
     // reduced once.
-    bool done[spk::HOST_SUM_MAX_BLOCKS] = {};
-    uint64_t tags[spk::HOST_SUM_MAX_BLOCKS], tags2[spk::HOST_SUM_MAX_BLOCKS];
+    bool done[spk::WIDE_SLOTS] = {};
+    uint64_t tags[spk::WIDE_SLOTS], tags2[spk::WIDE_SLOTS];
     uint64_t lazy[2][3][8] = {};  // [group][sum][limb] (groups <= 2)
     const bool lazy_ok = groups <= 2;
     unsigned remaining = nb;
@@ -855,15 +856,15 @@ static int reduce_partials_wait(sp_ctx* c, int nacc, fe_t* out_host, bool reside
     while (remaining) {
       for (unsigned b = 0; b < nb; ++b)
         if (!done[b]) {
-          const volatile uint64_t* tg = reinterpret_cast<volatile const uint64_t*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b + 3);
-          __builtin_prefetch(reinterpret_cast<const void*>(c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b), 0, 3);
+          const volatile uint64_t* tg = reinterpret_cast<volatile const uint64_t*>(c->h_pinned + slot_base + 4 * b + 3);
+          __builtin_prefetch(reinterpret_cast<const void*>(c->h_pinned + slot_base + 4 * b), 0, 3);
           tags[b] = tg[0];
           tags2[b] = tg[1];
         }
       std::atomic_thread_fence(std::memory_order_acquire);
       for (unsigned b = 0; b < nb; ++b) {
         if (done[b] || (uint32_t)tags[b] != want || (uint32_t)(tags2[b] >> 32) != want) continue;
-        const fe_t* slot = c->h_pinned + spk::SLOT_BASE_ELEM + 4 * b;
+        const fe_t* slot = c->h_pinned + slot_base + 4 * b;
         fe_t v[3];
         spk::slot_chk chk = {want, want * spk::SLOT_CHK_K};
         for (int k = 0; k < nacc; ++k) {
@@ -1968,13 +1969,32 @@ static int eval_cubic_outer_pow_pair(sp_ctx* c, const sp_table* pl, const sp_tab
 // Small tables (<= 2^13 elements): the bind of round i and the evaluation of round i + 1 of both instances in one launch with one product per lane
 // (k_bind_eval_*_pair_small); dense tables of equal length only. Returns 1 when done (the tables are bound and `sums` holds the next round's), 0 when
 // this form does not apply (the caller binds and evaluates separately), < 0 on error.
+// groups of 64 pairs a block of the fused small-table launches takes one after the other (kernels_poly.hpp `chunks`; measured: a group is 8-10 us of
+// latency, so more than one only loses - 1 unless SPARTAN_SMALL_PAIR_CHUNKS says otherwise), and whether the launch fits the result slots: the 64 ordinary
+// ones up to q = 2048 pairs, the wide area (WIDE_SLOTS, added by the host) up to q = 8192. 0 = too large for the form.
+static size_t small_pair_chunks(size_t q) {
+  static const size_t cap = [] {
+    const char* e = getenv("SPARTAN_SMALL_PAIR_CHUNKS");
+    const int v = e ? atoi(e) : 1;
+    return (size_t)(v < 1 ? 1 : (v > 16 ? 16 : v));
+  }();
+  static const bool wide_ok = [] {
+    const char* e = getenv("SPARTAN_SMALL_PAIR_WIDE");  // "0": the round-5 reach (q <= 2048)
+    return !(e && e[0] == '0');
+  }();
+  const size_t max_slots = wide_ok ? (size_t)spk::WIDE_SLOTS : (size_t)spk::HOST_SUM_MAX_BLOCKS;
+  for (size_t ch = 1; ch <= cap; ch *= 2)
+    if (2 * ((q + spk::SMALL_PAIR_PPB * ch - 1) / (spk::SMALL_PAIR_PPB * ch)) <= max_slots) return ch;
+  return 0;
+}
 static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* const B[2], const fe_t& r, fe_t sums[2][2]) {
   const size_t len = A[0]->len;
   if (len < 4) return 0;
   for (int b = 0; b < 2; ++b)
     if (A[b]->len != len || B[b]->len != len || !table_dense(A[b]) || !table_dense(B[b])) return 0;
-  const size_t q = len / 4, nb = (q + spk::SMALL_PAIR_PPB - 1) / spk::SMALL_PAIR_PPB;
-  if (2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS) return 0;
+  const size_t q = len / 4, chunks = small_pair_chunks(q);
+  if (!chunks) return 0;
+  const size_t nb = (q + spk::SMALL_PAIR_PPB * chunks - 1) / (spk::SMALL_PAIR_PPB * chunks);
   spk::QuadPairBindArgs t;
   for (int b = 0; b < 2; ++b) {
     t.A[b] = A[b]->d;
@@ -1982,14 +2002,14 @@ static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* 
   }
   const unsigned seq = next_seq(c);
   c->timed("bind_eval_quad_pair_small", 2 * 192ull * q,
-           [&] { hipLaunchKernelGGL(spk::k_bind_eval_quad_pair_small, dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, t, (unsigned)q, (unsigned)nb, r, c->d_pinned, seq); });
+           [&] { hipLaunchKernelGGL(spk::k_bind_eval_quad_pair_small, dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, t, (unsigned)q, (unsigned)nb, (unsigned)chunks, r, c->d_pinned, seq); });
   for (int b = 0; b < 2; ++b) {
     sp::after_bind(A[b]);
     sp::after_bind(B[b]);
   }
   c->pending_slots = (unsigned)(2 * nb);
   fe_t out[4];
-  int rc = reduce_partials_wait(c, 2, out, false, 2);
+  int rc = reduce_partials_wait(c, 2, out, false, 2, 2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS);
   if (rc) return rc;
   sums[0][0] = out[0];
   sums[0][1] = out[1];
@@ -2003,8 +2023,9 @@ static int bind_eval_cubic_pow_pair_small(sp_ctx* c, const sp_table* pl, const s
   if (len < 4) return 0;
   for (int k = 0; k < 3; ++k)
     if (step[k]->len != len || core[k]->len != len || !table_dense(step[k]) || !table_dense(core[k])) return 0;
-  const size_t q = len / 4, nb = (q + spk::SMALL_PAIR_PPB - 1) / spk::SMALL_PAIR_PPB;
-  if (2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS) return 0;
+  const size_t q = len / 4, chunks = small_pair_chunks(q);
+  if (!chunks) return 0;
+  const size_t nb = (q + spk::SMALL_PAIR_PPB * chunks - 1) / (spk::SMALL_PAIR_PPB * chunks);
   const bool fallback = q < left;  // as eval_cubic_outer_pow_pair, for q pairs
   size_t right = 0;
   if (fallback) {
@@ -2025,9 +2046,9 @@ static int bind_eval_cubic_pow_pair_small(sp_ctx* c, const sp_table* pl, const s
   c->timed("bind_eval_cubic_pow_pair_small", 2 * 288ull * q, [&] {
     if (fallback)
       hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<true>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr ? pr->d : nullptr, right, t, (unsigned)q,
-                         (unsigned)nb, r, c->d_pinned, seq);
+                         (unsigned)nb, (unsigned)chunks, r, c->d_pinned, seq);
     else
-      hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<false>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr->d, right, t, (unsigned)q, (unsigned)nb, r,
+      hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<false>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr->d, right, t, (unsigned)q, (unsigned)nb, (unsigned)chunks, r,
                          c->d_pinned, seq);
   });
   for (int k = 0; k < 3; ++k) {
@@ -2036,7 +2057,7 @@ static int bind_eval_cubic_pow_pair_small(sp_ctx* c, const sp_table* pl, const s
   }
   c->pending_slots = (unsigned)(2 * nb);
   fe_t out[6];
-  int rc = reduce_partials_wait(c, 3, out, false, 2);
+  int rc = reduce_partials_wait(c, 3, out, false, 2, 2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS);
   if (rc) return rc;
   for (int b = 0; b < 2; ++b)
     for (int k = 0; k < 3; ++k) sums[b][k] = out[3 * b + k];
@@ -2076,7 +2097,13 @@ int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_ro
       for (int q = 0; q < 3; ++q) store_fe(co[b] + 4 * q, poly[b].c[q]);
     }
     uint64_t r_raw[4];
+    static const bool trace = [] {
+      const char* e = getenv("SPARTAN_HOST_LAPS");
+      return e && e[0] == '2';
+    }();
+    const double tq0 = trace ? now_us() : 0;
     int hrc = hook(user, start_round + j, co[0], co[1], 3, r_raw);
+    if (trace) fprintf(stderr, "inner batched round %zu (len %zu, %s): hook %.1f us\n", j, A0->len, have_next ? "fused" : "separate launches", now_us() - tq0);
     if (hrc) return fail(hrc, "prove_quad_batched: the round hook failed");
     const fe_t r_j = load_fe(r_raw);
     store_fe(out_r + 4 * j, r_j);

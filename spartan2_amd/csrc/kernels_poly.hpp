@@ -54,6 +54,9 @@ __device__ __forceinline__ void slot_store_tag(fe_t* slot, unsigned seq, const s
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot[3].v[2]), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(reinterpret_cast<unsigned long long*>(&slot[3].v[0]), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// the same slot format in the hand-over area (HAND_BASE_ELEM: 342 slots) for a launch of more than HOST_SUM_MAX_BLOCKS blocks whose sums the host adds itself
+template <int NACC>
+__device__ __forceinline__ void emit_partials_wide(const fe_t (&acc)[NACC], fe_t* __restrict__ mapped, unsigned seq);
 template <int NACC>
 __device__ __forceinline__ void emit_partials(const fe_t (&acc)[NACC], fe_t* __restrict__ partials, fe_t* __restrict__ mapped, unsigned seq) {
   if (gridDim.x <= HOST_SUM_MAX_BLOCKS) {
@@ -137,6 +140,18 @@ constexpr int MAIL_RING = 8, MAIL_LINE_WORDS = 16;
 constexpr int MAIL_MIRROR_ELEM = SLOT_BASE_ELEM + 4 * HOST_SUM_MAX_BLOCKS;  // 16 elements = 8 lines
 constexpr int HAND_BASE_ELEM = MAIL_MIRROR_ELEM + 16;  // the hand-over area: (TAIL_HAND_OVER_MAX_VALS + 2) / 3 slots of 4 elements
 constexpr int MAPPED_ELEMS = HAND_BASE_ELEM + 4 * ((TAIL_HAND_OVER_MAX_VALS + 2) / 3);
+constexpr int WIDE_SLOTS = (TAIL_HAND_OVER_MAX_VALS + 2) / 3;
+template <int NACC>
+__device__ __forceinline__ void emit_partials_wide(const fe_t (&acc)[NACC], fe_t* __restrict__ mapped, unsigned seq) {
+  fe_t* slot = mapped + HAND_BASE_ELEM + 4 * blockIdx.x;
+  slot_chk chk = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    slot_store_elem(slot + k, acc[k]);
+    slot_chk_add(chk, acc[k], k);
+  }
+  slot_store_tag(slot, seq, chk);
+}
 constexpr int MAIL_DIAG_WORD = 256;  // word offset in the device mailbox page: [0] answers taken from the mirror, [1] watchdog trips, [2] / [3] want / device-line seq of the last mirror answer
 constexpr unsigned long long MAIL_MIRROR_AFTER_TICKS = 3000ull, MAIL_MIRROR_EVERY_TICKS = 1000ull;  // 30 us, 10 us at the 100 MHz wall clock
 // 8 s at the 100 MHz wall clock. Long on purpose: an owner thread that the host's scheduler keeps away from its CPU (a throttled cgroup: the bench
@@ -978,94 +993,111 @@ constexpr int SMALL_PAIR_PPB = 64;  // pairs per block
 struct CubicPairBindArgs {
   fe_t *A[2], *B[2], *C[2];
 };
+// `chunks` (round 6): a block takes that many consecutive groups of 64 pairs one after the other, its lanes carrying their point's running sum - so the
+// launch stays within the 64 result slots up to q = 2^14 pairs (tables of 2^16 elements: the first rounds of config 3's batched sum-checks, which used to
+// be a bind launch, an evaluation launch and a second stage each).
 template <bool FALLBACK>
 __global__ void __launch_bounds__(256) k_bind_eval_cubic_pow_pair_small(const fe_t* __restrict__ pleft, size_t left, const fe_t* __restrict__ pright, size_t right,
-                                                                        CubicPairBindArgs t, unsigned q, unsigned nb, fe_t r, fe_t* __restrict__ mapped, unsigned seq) {
+                                                                        CubicPairBindArgs t, unsigned q, unsigned nb, unsigned chunks, fe_t r, fe_t* __restrict__ mapped,
+                                                                        unsigned seq) {
   __shared__ fe_t sh[8][SMALL_PAIR_PPB];  // bound A lo/hi, B lo/hi, C lo/hi, weight lo/hi
   __shared__ fe_t sums[3];
-  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb, base = bx * SMALL_PAIR_PPB;
-  const unsigned np = q - base < (unsigned)SMALL_PAIR_PPB ? q - base : (unsigned)SMALL_PAIR_PPB;
-  for (unsigned i = threadIdx.x; i < 8 * (unsigned)SMALL_PAIR_PPB; i += blockDim.x) {
-    const unsigned kind = i / SMALL_PAIR_PPB, p = i % SMALL_PAIR_PPB;  // kind is wave-uniform
-    if (p >= np) continue;
-    const unsigned low = base + p;
-    fe_t v;
-    if (kind < 6) {
-      fe_t* __restrict__ T = kind < 2 ? t.A[inst] : kind < 4 ? t.B[inst] : t.C[inst];
-      const size_t idx = (size_t)low + (kind & 1u) * (size_t)q;
-      v = bind1(T[idx], T[idx + 2 * (size_t)q], r);
-      T[idx] = v;
-    } else if (FALLBACK) {
-      v = pleft[low + (kind & 1u) * q];
-    } else {
-      v = fe_mul<S>(pleft[low % left], pright[low / left + (kind & 1u) * right]);
-    }
-    sh[kind][p] = v;
-  }
-  __syncthreads();
+  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb;
   const unsigned pt = threadIdx.x >> 6, p = threadIdx.x & 63u;
-  fe_t v = fe_zero();
-  if (pt < 3 && p < np) {
-    fe_t a = sh[0][p], b = sh[2][p], c = sh[4][p], w = sh[6][p];
-    if (pt) {  // the point 2 (3): 2 hi - lo (3 hi - 2 lo)
-      const fe_t ah = sh[1][p], bh = sh[3][p], ch = sh[5][p], wh = sh[7][p];
-      fe_t a2 = fe_sub<S>(fe_dbl<S>(ah), a), b2 = fe_sub<S>(fe_dbl<S>(bh), b), c2 = fe_sub<S>(fe_dbl<S>(ch), c), w2 = fe_sub<S>(fe_dbl<S>(wh), w);
-      if (pt == 2) {
-        a2 = fe_sub<S>(fe_add<S>(a2, ah), a);
-        b2 = fe_sub<S>(fe_add<S>(b2, bh), b);
-        c2 = fe_sub<S>(fe_add<S>(c2, ch), c);
-        w2 = fe_sub<S>(fe_add<S>(w2, wh), w);
+  fe_t vsum = fe_zero();
+  for (unsigned ch = 0; ch < chunks; ++ch) {
+    const unsigned base = (bx * chunks + ch) * SMALL_PAIR_PPB;
+    if (base >= q) break;  // (block-uniform)
+    const unsigned np = q - base < (unsigned)SMALL_PAIR_PPB ? q - base : (unsigned)SMALL_PAIR_PPB;
+    if (ch) __syncthreads();  // the previous group's points have been read
+    for (unsigned i = threadIdx.x; i < 8 * (unsigned)SMALL_PAIR_PPB; i += blockDim.x) {
+      const unsigned kind = i / SMALL_PAIR_PPB, pp = i % SMALL_PAIR_PPB;  // kind is wave-uniform
+      if (pp >= np) continue;
+      const unsigned low = base + pp;
+      fe_t v;
+      if (kind < 6) {
+        fe_t* __restrict__ T = kind < 2 ? t.A[inst] : kind < 4 ? t.B[inst] : t.C[inst];
+        const size_t idx = (size_t)low + (kind & 1u) * (size_t)q;
+        v = bind1(T[idx], T[idx + 2 * (size_t)q], r);
+        T[idx] = v;
+      } else if (FALLBACK) {
+        v = pleft[low + (kind & 1u) * q];
+      } else {
+        v = fe_mul<S>(pleft[low % left], pright[low / left + (kind & 1u) * right]);
       }
-      a = a2;
-      b = b2;
-      c = c2;
-      w = w2;
+      sh[kind][pp] = v;
     }
-    v = fe_mul<S>(w, fe_sub<S>(fe_mul<S>(a, b), c));
+    __syncthreads();
+    if (pt < 3 && p < np) {
+      fe_t a = sh[0][p], b = sh[2][p], c = sh[4][p], w = sh[6][p];
+      if (pt) {  // the point 2 (3): 2 hi - lo (3 hi - 2 lo)
+        const fe_t ah = sh[1][p], bh = sh[3][p], chh = sh[5][p], wh = sh[7][p];
+        fe_t a2 = fe_sub<S>(fe_dbl<S>(ah), a), b2 = fe_sub<S>(fe_dbl<S>(bh), b), c2 = fe_sub<S>(fe_dbl<S>(chh), c), w2 = fe_sub<S>(fe_dbl<S>(wh), w);
+        if (pt == 2) {
+          a2 = fe_sub<S>(fe_add<S>(a2, ah), a);
+          b2 = fe_sub<S>(fe_add<S>(b2, bh), b);
+          c2 = fe_sub<S>(fe_add<S>(c2, chh), c);
+          w2 = fe_sub<S>(fe_add<S>(w2, wh), w);
+        }
+        a = a2;
+        b = b2;
+        c = c2;
+        w = w2;
+      }
+      vsum = fe_add<S>(vsum, fe_mul<S>(w, fe_sub<S>(fe_mul<S>(a, b), c)));
+    }
   }
   if (pt < 3) {
-    v = wave_sum(v);
+    const fe_t v = wave_sum(vsum);
     if (p == 0) sums[pt] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     const fe_t acc[3] = {sums[0], sums[1], sums[2]};
-    emit_partials<3>(acc, nullptr, mapped, seq);  // gridDim.x <= HOST_SUM_MAX_BLOCKS by construction: the slot path
+    if (gridDim.x <= HOST_SUM_MAX_BLOCKS) emit_partials<3>(acc, nullptr, mapped, seq);  // the slot path
+    else emit_partials_wide<3>(acc, mapped, seq);  // q = 2^12, 2^13 pairs: 128 / 256 blocks, the wide slot area (gridDim.x <= WIDE_SLOTS by construction)
   }
 }
 struct QuadPairBindArgs {
   fe_t *A[2], *B[2];
 };
-__global__ void __launch_bounds__(256) k_bind_eval_quad_pair_small(QuadPairBindArgs t, unsigned q, unsigned nb, fe_t r, fe_t* __restrict__ mapped, unsigned seq) {
+__global__ void __launch_bounds__(256) k_bind_eval_quad_pair_small(QuadPairBindArgs t, unsigned q, unsigned nb, unsigned chunks, fe_t r, fe_t* __restrict__ mapped,
+                                                                   unsigned seq) {
   __shared__ fe_t sh[4][SMALL_PAIR_PPB];  // bound A lo/hi, B lo/hi
   __shared__ fe_t sums[2];
-  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb, base = bx * SMALL_PAIR_PPB;
-  const unsigned np = q - base < (unsigned)SMALL_PAIR_PPB ? q - base : (unsigned)SMALL_PAIR_PPB;
-  {
-    const unsigned kind = threadIdx.x / SMALL_PAIR_PPB, p = threadIdx.x % SMALL_PAIR_PPB;  // 4 kinds x 64 pairs = the block
-    if (p < np) {
-      fe_t* __restrict__ T = kind < 2 ? t.A[inst] : t.B[inst];
-      const size_t idx = (size_t)(base + p) + (kind & 1u) * (size_t)q;
-      const fe_t v = bind1(T[idx], T[idx + 2 * (size_t)q], r);
-      T[idx] = v;
-      sh[kind][p] = v;
+  const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb;
+  const unsigned pt = threadIdx.x >> 6, p = threadIdx.x & 63u;
+  fe_t vsum = fe_zero();
+  for (unsigned ch = 0; ch < chunks; ++ch) {  // (see k_bind_eval_cubic_pow_pair_small)
+    const unsigned base = (bx * chunks + ch) * SMALL_PAIR_PPB;
+    if (base >= q) break;
+    const unsigned np = q - base < (unsigned)SMALL_PAIR_PPB ? q - base : (unsigned)SMALL_PAIR_PPB;
+    if (ch) __syncthreads();
+    {
+      const unsigned kind = threadIdx.x / SMALL_PAIR_PPB, pp = threadIdx.x % SMALL_PAIR_PPB;  // 4 kinds x 64 pairs = the block
+      if (pp < np) {
+        fe_t* __restrict__ T = kind < 2 ? t.A[inst] : t.B[inst];
+        const size_t idx = (size_t)(base + pp) + (kind & 1u) * (size_t)q;
+        const fe_t v = bind1(T[idx], T[idx + 2 * (size_t)q], r);
+        T[idx] = v;
+        sh[kind][pp] = v;
+      }
+    }
+    __syncthreads();
+    if (pt < 2 && p < np) {
+      const fe_t a0 = sh[0][p], b0 = sh[2][p];
+      vsum = fe_add<S>(vsum, pt == 0 ? fe_mul<S>(a0, b0) : fe_mul<S>(fe_sub<S>(sh[1][p], a0), fe_sub<S>(sh[3][p], b0)));
     }
   }
-  __syncthreads();
-  const unsigned pt = threadIdx.x >> 6, p = threadIdx.x & 63u;
-  fe_t v = fe_zero();
-  if (pt < 2 && p < np) {
-    const fe_t a0 = sh[0][p], b0 = sh[2][p];
-    v = pt == 0 ? fe_mul<S>(a0, b0) : fe_mul<S>(fe_sub<S>(sh[1][p], a0), fe_sub<S>(sh[3][p], b0));
-  }
   if (pt < 2) {
-    v = wave_sum(v);
+    const fe_t v = wave_sum(vsum);
     if (p == 0) sums[pt] = v;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     const fe_t acc[2] = {sums[0], sums[1]};
-    emit_partials<2>(acc, nullptr, mapped, seq);
+    if (gridDim.x <= HOST_SUM_MAX_BLOCKS) emit_partials<2>(acc, nullptr, mapped, seq);
+    else emit_partials_wide<2>(acc, mapped, seq);
   }
 }
 
