@@ -542,7 +542,10 @@ def main():
                    "data": "synthetic: Sha256StepCircuit over constant 64-byte blocks, seeded randomness tape",
                    "config": {"workload": "sha256_neutronnova 32 step circuits (BASELINE config 3), NeutronNovaZkSNARK::prove", "num_steps": nsteps,
                               "num_cons_unpadded_per_step": circs[0].num_cons, "num_cons_per_step": 1 << nn.info["nx"],
-                              "parallelism": f"{world} independent batches, one per GPU"},
+                              "parallelism": f"{world} independent batches, one per GPU",
+                              "host_walkers": int(hip.lib().sp_walkers()),
+                              "host_walkers_note": "polling host threads of the process (SPARTAN_WALKERS): the round commitments of the verifier circuit "
+                                                   "(sp_hyrax_commit_split_*) and the host loops of its instance are spread over them; 0 = the device walk, one host thread"},
                    "phases_ms": {k_: v_ / args.steps for k_, v_ in acc.items()}, "step_ms_distribution": dict(dist(c3_step_ms), slowest_step_phases_ms=c3_slowest),
                    "verify_ms": verify_ms, "sharded": None, "roofline": None, "cpu_baseline": None,
                    "reference_order": {"ms_per_step": elapsed_ref / args.steps * 1e3, "constraints_per_s": ncons * world * args.steps / elapsed_ref,

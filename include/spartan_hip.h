@@ -61,6 +61,12 @@ int sp_ctx_bind_thread(sp_ctx* ctx);
 /* the HIP ordinal the context was created on (a host driver that wants a second context on the same GPU for work it runs beside its main
  * stream of calls — e.g. transcript-independent commitments under a sum-check — creates it with this) */
 int sp_ctx_device(const sp_ctx* ctx);
+/* A promise about the round hooks handed to the batched sum-checks (sp_sumcheck_cubic_outer_pow_batched, sp_sumcheck_quad_batched) on this context: they
+ * do NOT queue work on the context's main stream or wait for it (the reference's hook is `process_round`, src/sumcheck.rs:747-755 - synthesis, a narrow
+ * commitment, transcript: host work when the commitment goes through sp_hyrax_commit_split_*). With the promise the library queues the next round's fused
+ * bind + evaluate launch BEFORE it calls the hook; the kernel waits at the challenge mailbox, so its launch and dispatch run under the hook's host time.
+ * A hook that breaks the promise would queue behind that waiting kernel: it is released by the mailbox watchdog after 8 s and the call fails. Default off. */
+int sp_ctx_round_hooks_host_only(sp_ctx* ctx, int on);
 void sp_ctx_destroy(sp_ctx* ctx);
 int sp_ctx_synchronize(sp_ctx* ctx);
 /* time of the most recent instrumented kernel class, measured with hipEvents on the context's stream

@@ -189,6 +189,11 @@ int sp_ctx_bind_thread(sp_ctx* c) {
   return SP_OK;
 }
 int sp_ctx_device(const sp_ctx* c) { return c ? c->device : -1; }
+int sp_ctx_round_hooks_host_only(sp_ctx* c, int on) {
+  if (!c) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_ctx_round_hooks_host_only: null context");
+  c->hooks_host_only = on != 0;
+  return SP_OK;
+}
 void sp_ctx_destroy(sp_ctx* c) {
   if (!c) return;
   sp::g_live_contexts.fetch_sub(1, std::memory_order_relaxed);
@@ -1987,7 +1992,25 @@ static size_t small_pair_chunks(size_t q) {
     if (2 * ((q + spk::SMALL_PAIR_PPB * ch - 1) / (spk::SMALL_PAIR_PPB * ch)) <= max_slots) return ch;
   return 0;
 }
-static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* const B[2], const fe_t& r, fe_t sums[2][2]) {
+// The fused bind + evaluate of a batched round in two halves. _issue launches (returns 0 when the form does not apply: nothing was launched); with
+// `r` == nullptr the launch is queued AHEAD of its challenge - the kernel waits at the mailbox for the challenge that answers the result in hand
+// (`*answers` = its sequence number; the caller posts it with tail_post_challenge once its hook has drawn it). _collect waits for the sums.
+struct SmallPairLaunch {
+  size_t nb = 0;
+  unsigned answers = 0, seq = 0;  // the result its challenge answers; the result it publishes
+  bool ahead = false, valid = false;
+};
+// waits for the slots of launch L although a later launch may have been issued since (its sequence number and slot count are put back afterwards)
+static int small_pair_wait(sp_ctx* c, const SmallPairLaunch& L, int nacc, fe_t* out) {
+  const unsigned cur_seq = c->result_seq, cur_slots = c->pending_slots;
+  c->result_seq = L.seq;
+  c->pending_slots = (unsigned)(2 * L.nb);
+  const int rc = reduce_partials_wait(c, nacc, out, true, 2, 2 * L.nb > (size_t)spk::HOST_SUM_MAX_BLOCKS);  // (resident: a later launch may be waiting at the mailbox)
+  c->result_seq = cur_seq;
+  c->pending_slots = cur_seq == L.seq ? 0u : cur_slots;
+  return rc;
+}
+static int bind_eval_quad_pair_small_issue(sp_ctx* c, sp_table* const A[2], sp_table* const B[2], const fe_t* r, SmallPairLaunch* L) {
   const size_t len = A[0]->len;
   if (len < 4) return 0;
   for (int b = 0; b < 2; ++b)
@@ -2000,16 +2023,27 @@ static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* 
     t.A[b] = A[b]->d;
     t.B[b] = B[b]->d;
   }
+  L->nb = nb;
+  L->ahead = r == nullptr;
+  L->answers = c->result_seq;
+  const spk::MailRef m = mail_ref(c, L->ahead, L->answers);
+  const fe_t rv = r ? *r : fe_zero();
   const unsigned seq = next_seq(c);
-  c->timed("bind_eval_quad_pair_small", 2 * 192ull * q,
-           [&] { hipLaunchKernelGGL(spk::k_bind_eval_quad_pair_small, dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, t, (unsigned)q, (unsigned)nb, (unsigned)chunks, r, c->d_pinned, seq); });
+  L->seq = seq;
+  L->valid = true;
+  c->timed("bind_eval_quad_pair_small", 2 * 192ull * q, [&] {
+    hipLaunchKernelGGL(spk::k_bind_eval_quad_pair_small, dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, t, (unsigned)q, (unsigned)nb, (unsigned)chunks, rv, m, c->d_pinned, seq);
+  });
   for (int b = 0; b < 2; ++b) {
     sp::after_bind(A[b]);
     sp::after_bind(B[b]);
   }
   c->pending_slots = (unsigned)(2 * nb);
+  return 1;
+}
+static int bind_eval_quad_pair_small_collect(sp_ctx* c, const SmallPairLaunch& L, fe_t sums[2][2]) {
   fe_t out[4];
-  int rc = reduce_partials_wait(c, 2, out, false, 2, 2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS);
+  int rc = small_pair_wait(c, L, 2, out);
   if (rc) return rc;
   sums[0][0] = out[0];
   sums[0][1] = out[1];
@@ -2017,8 +2051,8 @@ static int bind_eval_quad_pair_small(sp_ctx* c, sp_table* const A[2], sp_table* 
   sums[1][1] = out[3];
   return 1;
 }
-static int bind_eval_cubic_pow_pair_small(sp_ctx* c, const sp_table* pl, const sp_table* pr, sp_table* const step[3], sp_table* const core[3], const fe_t& r,
-                                          fe_t sums[2][3]) {
+static int bind_eval_cubic_pow_pair_small_issue(sp_ctx* c, const sp_table* pl, const sp_table* pr, sp_table* const step[3], sp_table* const core[3], const fe_t* r,
+                                                SmallPairLaunch* L) {
   const size_t len = step[0]->len, left = pl->len;
   if (len < 4) return 0;
   for (int k = 0; k < 3; ++k)
@@ -2042,26 +2076,45 @@ static int bind_eval_cubic_pow_pair_small(sp_ctx* c, const sp_table* pl, const s
     t.B[b] = tb[1]->d;
     t.C[b] = tb[2]->d;
   }
+  L->nb = nb;
+  L->ahead = r == nullptr;
+  L->answers = c->result_seq;
+  const spk::MailRef m = mail_ref(c, L->ahead, L->answers);
+  const fe_t rv = r ? *r : fe_zero();
   const unsigned seq = next_seq(c);
+  L->seq = seq;
+  L->valid = true;
   c->timed("bind_eval_cubic_pow_pair_small", 2 * 288ull * q, [&] {
     if (fallback)
       hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<true>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr ? pr->d : nullptr, right, t, (unsigned)q,
-                         (unsigned)nb, (unsigned)chunks, r, c->d_pinned, seq);
+                         (unsigned)nb, (unsigned)chunks, rv, m, c->d_pinned, seq);
     else
-      hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<false>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr->d, right, t, (unsigned)q, (unsigned)nb, (unsigned)chunks, r,
-                         c->d_pinned, seq);
+      hipLaunchKernelGGL((spk::k_bind_eval_cubic_pow_pair_small<false>), dim3((unsigned)(2 * nb)), dim3(256), 0, c->stream, pl->d, left, pr->d, right, t, (unsigned)q, (unsigned)nb,
+                         (unsigned)chunks, rv, m, c->d_pinned, seq);
   });
   for (int k = 0; k < 3; ++k) {
     sp::after_bind(step[k]);
     sp::after_bind(core[k]);
   }
   c->pending_slots = (unsigned)(2 * nb);
+  return 1;
+}
+static int bind_eval_cubic_pow_pair_small_collect(sp_ctx* c, const SmallPairLaunch& L, fe_t sums[2][3]) {
   fe_t out[6];
-  int rc = reduce_partials_wait(c, 3, out, false, 2, 2 * nb > (size_t)spk::HOST_SUM_MAX_BLOCKS);
+  int rc = small_pair_wait(c, L, 3, out);
   if (rc) return rc;
   for (int b = 0; b < 2; ++b)
     for (int k = 0; k < 3; ++k) sums[b][k] = out[3 * b + k];
   return 1;
+}
+// may the next round's launch be queued ahead of the caller's round hook? (sp_ctx_round_hooks_host_only; the mailbox must be in device memory: a grid
+// of up to 256 blocks polls it. SPARTAN_BATCHED_AHEAD=0: never, for A/B runs)
+static bool batched_ahead_ok(const sp_ctx* c) {
+  static const bool off = [] {
+    const char* e = getenv("SPARTAN_BATCHED_AHEAD");
+    return e && e[0] == '0';
+  }();
+  return c->hooks_host_only && c->mail_dev && !off;
 }
 
 // prove_quad_batched_zk (src/sumcheck.rs:702-782): two quadratic sum-checks (step, core) driven by one challenge per round; the challenge
@@ -2074,6 +2127,8 @@ int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_ro
   sp_table* br[2][2] = {{A0, B0}, {A1, B1}};
   bool have_next = false;  // `both` already holds this round's sums (the previous round's fused bind + evaluate)
   fe_t both[2][2];
+  AheadGuard guard(c);  // a launch queued ahead of the hook is released on every early return
+  SmallPairLaunch pre;  // the next round's fused launch when it was queued while the current one ran
   for (size_t j = 0; j < num_rounds; ++j) {
     UniPoly poly[2];
     uint64_t co[2][12];
@@ -2102,18 +2157,46 @@ int sp_sumcheck_quad_batched(sp_ctx* c, const uint64_t claims_[8], size_t num_ro
       return e && e[0] == '2';
     }();
     const double tq0 = trace ? now_us() : 0;
+    // the next round's fused launch, queued ahead of the hook when the caller has promised a host-only hook: it waits at the mailbox for r_j
+    SmallPairLaunch L;
+    int issued = 0;
+    if (pre.valid) {  // queued during the previous round, while that round's launch ran
+      L = pre;
+      pre.valid = false;
+      issued = 1;
+    } else if (j + 1 < num_rounds && batched_ahead_ok(c)) {
+      issued = bind_eval_quad_pair_small_issue(c, pa, pb, nullptr, &L);
+      if (issued < 0) return issued;
+    }
+    guard.armed = issued == 1;
     int hrc = hook(user, start_round + j, co[0], co[1], 3, r_raw);
-    if (trace) fprintf(stderr, "inner batched round %zu (len %zu, %s): hook %.1f us\n", j, A0->len, have_next ? "fused" : "separate launches", now_us() - tq0);
+    if (trace) fprintf(stderr, "inner batched round %zu (len %zu, %s%s): hook %.1f us\n", j, A0->len, have_next ? "fused" : "separate launches", issued ? ", next queued ahead" : "", now_us() - tq0);
     if (hrc) return fail(hrc, "prove_quad_batched: the round hook failed");
     const fe_t r_j = load_fe(r_raw);
+    if (issued) {
+      tail_post_challenge(c, r_j, L.answers);
+      guard.armed = false;
+    }
     store_fe(out_r + 4 * j, r_j);
     claim[0] = poly_eval(poly[0], r_j);
     claim[1] = poly_eval(poly[1], r_j);
     have_next = false;
     if (j + 1 < num_rounds) {
-      const int fused = bind_eval_quad_pair_small(c, pa, pb, r_j, both);
-      if (fused < 0) return fused;
-      have_next = fused == 1;
+      if (!issued) {
+        issued = bind_eval_quad_pair_small_issue(c, pa, pb, &r_j, &L);
+        if (issued < 0) return issued;
+      }
+      if (issued) {
+        if (j + 2 < num_rounds && batched_ahead_ok(c)) {  // the launch AFTER this one goes into the queue while this one runs: it waits for round j + 1's challenge
+          const int more = bind_eval_quad_pair_small_issue(c, pa, pb, nullptr, &pre);
+          if (more < 0) return more;
+          if (more == 0) pre.valid = false;
+          guard.armed = pre.valid;
+        }
+        const int fused = bind_eval_quad_pair_small_collect(c, L, both);
+        if (fused < 0) return fused;
+        have_next = true;
+      }
     }
     if (!have_next) {
       sp_table* tabs[4] = {A0, B0, A1, B1};
@@ -2155,6 +2238,8 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
   auto nowus = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   bool have_next = false;  // `both` already holds this round's sums (the previous round's fused bind + evaluate)
   fe_t both[2][3];
+  AheadGuard guard(c);
+  SmallPairLaunch pre;
   for (size_t i = 0; i < num_rounds; ++i) {
     UniPoly poly[2];
     uint64_t co[2][16];
@@ -2174,19 +2259,46 @@ int sp_sumcheck_cubic_outer_pow_batched(sp_ctx* c, size_t num_rounds, sp_table* 
     }
     uint64_t r_raw[4];
     const double tr2 = trace ? nowus() : 0;
+    SmallPairLaunch L;
+    int issued = 0;
+    if (pre.valid) {  // queued during the previous round (see sp_sumcheck_quad_batched)
+      L = pre;
+      pre.valid = false;
+      issued = 1;
+    } else if (i + 1 < num_rounds && batched_ahead_ok(c)) {  // queued ahead of the hook
+      issued = bind_eval_cubic_pow_pair_small_issue(c, pow_left, pow_right, step, core, nullptr, &L);
+      if (issued < 0) return issued;
+    }
+    guard.armed = issued == 1;
     int hrc = hook(user, start_round + i, co[0], co[1], 4, r_raw);
-    if (trace) fprintf(stderr, "outer batched round %zu (len %zu): eval %.1f us, algebra %.1f us, hook %.1f us\n", i, step[0]->len, tr1 - tr0, tr2 - tr1, nowus() - tr2);
+    if (trace) fprintf(stderr, "outer batched round %zu (len %zu): eval %.1f us, algebra %.1f us, hook %.1f us%s\n", i, step[0]->len, tr1 - tr0, tr2 - tr1, nowus() - tr2, issued ? " (next round queued ahead)" : "");
     if (hrc) return fail(hrc, "prove_cubic_batched: the round hook failed");
     const fe_t r_i = load_fe(r_raw);
+    if (issued) {
+      tail_post_challenge(c, r_i, L.answers);
+      guard.armed = false;
+    }
     store_fe(out_r + 4 * i, r_i);
     claim[0] = poly_eval(poly[0], r_i);
     claim[1] = poly_eval(poly[1], r_i);
     have_next = false;
     if (i + 1 < num_rounds) {
       const double tf0 = trace ? nowus() : 0;
-      const int fused = bind_eval_cubic_pow_pair_small(c, pow_left, pow_right, step, core, r_i, both);
-      if (fused < 0) return fused;
-      have_next = fused == 1;
+      if (!issued) {
+        issued = bind_eval_cubic_pow_pair_small_issue(c, pow_left, pow_right, step, core, &r_i, &L);
+        if (issued < 0) return issued;
+      }
+      if (issued) {
+        if (i + 2 < num_rounds && batched_ahead_ok(c)) {
+          const int more = bind_eval_cubic_pow_pair_small_issue(c, pow_left, pow_right, step, core, nullptr, &pre);
+          if (more < 0) return more;
+          if (more == 0) pre.valid = false;
+          guard.armed = pre.valid;
+        }
+        const int fused = bind_eval_cubic_pow_pair_small_collect(c, L, both);
+        if (fused < 0) return fused;
+        have_next = true;
+      }
       if (trace) fprintf(stderr, "outer batched round %zu: bind + next evaluation in one launch %s, %.1f us\n", i, have_next ? "taken" : "not applicable", nowus() - tf0);
     }
     if (!have_next) {

@@ -531,6 +531,7 @@ int sp_ck_create(sp_ctx* c, const uint64_t* ck_aff, size_t num_cols, const uint6
 }
 void sp_ck_free(sp_ck* k) {
   if (!k) return;
+  if (k->h_tables16) sp::WalkPool::get().quiesce();  // (a walker that lost its core mid-walk may still be reading the host tables)
   if (k->d_tables16) {
     {
       std::lock_guard<std::mutex> l(g_t16_mu);
@@ -2620,8 +2621,11 @@ int sp_hyrax_commit_small(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, s
     memcpy(&sc[cols], blind, sizeof(fe_t));
     if (cols + 1 <= FB_MAPPED_MAX && fb_mapped_enabled()) {  // the walks come back as (X, Y, ZZ, ZZZ) and are added in that form
       std::vector<xyzz_t> xs(cols + 1);
-      int rc = fb_mapped_launch(c, 0, ck->d_cktables, cols + 1, reinterpret_cast<const uint64_t*>(sc.data()), cols + 1, true);
-      if (rc || (rc = fb_mapped_collect(c, 0, cols + 1, xs.data(), c->fbm_seq[0], 32))) return rc;
+      // on the auxiliary stream while the caller has promised host-only round hooks (sp_ctx_round_hooks_host_only): a batched sum-check may have a launch
+      // waiting for this very hook's challenge on the main stream, and a walk queued behind it would wait for the mailbox watchdog
+      const int lane = c->hooks_host_only && !c->fb_async_busy ? 1 : 0;
+      int rc = fb_mapped_launch(c, lane, ck->d_cktables, cols + 1, reinterpret_cast<const uint64_t*>(sc.data()), cols + 1, true);
+      if (rc || (rc = fb_mapped_collect(c, lane, cols + 1, xs.data(), c->fbm_seq[lane], 32))) return rc;
       xyzz_t acc = xyzz_identity();
       for (const xyzz_t& p : xs) acc = xyzz_add(acc, p);
       store_aff(out_aff, jac_to_affine(xyzz_to_jac(acc)));

@@ -182,6 +182,7 @@ struct sp_ctx {
   const unsigned* d_mail_mirror = nullptr;
   void* mail_alloc = nullptr;
   bool mail_dev = false;
+  bool hooks_host_only = false;  // sp_ctx_round_hooks_host_only: the batched sum-checks may queue a round's launch ahead of the caller's hook
   unsigned* d_fold_tickets = nullptr;  // per-slot arrival counters of a streaming launch that finishes its own second stage (kernels_poly.hpp LazyOut)
   fe_t* d_gate = nullptr;  // MAIL_RING challenge slots written by k_mail_gate (a streaming launch queued behind its gate reads its challenge here)
   void* h_pinned_fb = nullptr;  // pinned staging for asynchronous fixed-base jobs

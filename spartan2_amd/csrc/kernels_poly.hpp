@@ -998,10 +998,11 @@ struct CubicPairBindArgs {
 // be a bind launch, an evaluation launch and a second stage each).
 template <bool FALLBACK>
 __global__ void __launch_bounds__(256) k_bind_eval_cubic_pow_pair_small(const fe_t* __restrict__ pleft, size_t left, const fe_t* __restrict__ pright, size_t right,
-                                                                        CubicPairBindArgs t, unsigned q, unsigned nb, unsigned chunks, fe_t r, fe_t* __restrict__ mapped,
-                                                                        unsigned seq) {
+                                                                        CubicPairBindArgs t, unsigned q, unsigned nb, unsigned chunks, fe_t r_arg, MailRef mref,
+                                                                        fe_t* __restrict__ mapped, unsigned seq) {
   __shared__ fe_t sh[8][SMALL_PAIR_PPB];  // bound A lo/hi, B lo/hi, C lo/hi, weight lo/hi
   __shared__ fe_t sums[3];
+  const fe_t r = challenge_or(mref, r_arg);  // (queued ahead of the caller's round hook: the challenge comes through the mailbox)
   const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb;
   const unsigned pt = threadIdx.x >> 6, p = threadIdx.x & 63u;
   fe_t vsum = fe_zero();
@@ -1061,10 +1062,11 @@ __global__ void __launch_bounds__(256) k_bind_eval_cubic_pow_pair_small(const fe
 struct QuadPairBindArgs {
   fe_t *A[2], *B[2];
 };
-__global__ void __launch_bounds__(256) k_bind_eval_quad_pair_small(QuadPairBindArgs t, unsigned q, unsigned nb, unsigned chunks, fe_t r, fe_t* __restrict__ mapped,
-                                                                   unsigned seq) {
+__global__ void __launch_bounds__(256) k_bind_eval_quad_pair_small(QuadPairBindArgs t, unsigned q, unsigned nb, unsigned chunks, fe_t r_arg, MailRef mref,
+                                                                   fe_t* __restrict__ mapped, unsigned seq) {
   __shared__ fe_t sh[4][SMALL_PAIR_PPB];  // bound A lo/hi, B lo/hi
   __shared__ fe_t sums[2];
+  const fe_t r = challenge_or(mref, r_arg);
   const unsigned inst = blockIdx.x / nb, bx = blockIdx.x % nb;
   const unsigned pt = threadIdx.x >> 6, p = threadIdx.x & 63u;
   fe_t vsum = fe_zero();

@@ -14,6 +14,9 @@
 #pragma once
 #include <pthread.h>
 #include <sched.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -38,6 +41,8 @@ class WalkPool {
     const aff_t* ents[MAX_ENTS];
     unsigned n_ents = 0, nparts = 0;
     xyzz_t part[MAX_PARTS];
+    std::atomic<unsigned char> pdone[MAX_PARTS];  // part p's result is in part[p]
+    std::atomic<bool> orphan{false};              // the owner has left without waiting for every claimed part: the last finisher gives the slot back
     std::atomic<unsigned> done{0};
     unsigned gen = 0;
     int slot = -1;
@@ -54,6 +59,7 @@ class WalkPool {
   std::condition_variable cv_;
   std::vector<std::thread> th_;
   bool stop_ = false, started_ = false;
+  std::atomic<unsigned long> redone_{0};
   int want_ = 0;
 
   // the CPUs that share the calling thread's last-level cache, minus the calling thread's own (false: not known, or fewer than three)
@@ -116,20 +122,34 @@ class WalkPool {
       }
     }
   }
-  static void run_part(Batch& b, unsigned p) {
-    if (b.fn) {
-      b.fn(b.arg, p, b.nparts);
-      b.done.fetch_add(1, std::memory_order_acq_rel);
-      return;
-    }
+  static xyzz_t walk_part(const Batch& b, unsigned p) {
     const unsigned lo = (unsigned)((uint64_t)b.n_ents * p / b.nparts), hi = (unsigned)((uint64_t)b.n_ents * (p + 1) / b.nparts);
     for (unsigned k = lo; k < hi; ++k) __builtin_prefetch(b.ents[k], 0, 0);  // each entry is a miss in a table of 64 MiB
     xyzz_t acc = xyzz_identity();
     for (unsigned k = lo; k < hi; ++k) acc = xyzz_add_mixed(acc, *b.ents[k]);
-    b.part[p] = acc;
-    b.done.fetch_add(1, std::memory_order_acq_rel);
+    return acc;
+  }
+  void run_part(Batch& b, unsigned p) {
+    if (b.fn) {
+      b.fn(b.arg, p, b.nparts);
+    } else {
+      b.part[p] = walk_part(b, p);
+      b.pdone[p].store(1, std::memory_order_release);
+    }
+    // (a claimed part counts once, whoever else may have walked it meanwhile; the slot of a batch its owner has left goes back with its last part)
+    if (b.done.fetch_add(1, std::memory_order_acq_rel) + 1 == b.nparts && b.orphan.exchange(false, std::memory_order_acq_rel)) release(&b);
   }
   void loop() {
+    // Lowest scheduling class: a polling thread must never take a core FROM a thread of the application or of the library (their helper threads sleep and
+    // wake all the time; a waking polling thread that pre-empts one of them, or sits on the core the owner thread has just been moved to, holds it for a
+    // scheduler tick or until the balancer moves the victim - 7-18 ms proves, one in ~500, before this). On an otherwise idle core the class costs nothing.
+    {
+      const char* e = getenv("SPARTAN_WALKERS_IDLE");  // "0": the default class (A/B runs)
+      struct sched_param sp0;
+      sp0.sched_priority = 0;
+      if (!(e && e[0] == '0') && sched_setscheduler(0, SCHED_IDLE, &sp0) != 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 19);
+    }
+    unsigned idle = 0;
     for (;;) {
       bool worked = false;
       for (int i = 0; i < MAX_BATCHES; ++i) {
@@ -140,8 +160,15 @@ class WalkPool {
           worked = true;
         }
       }
-      if (worked) continue;
+      if (worked) {
+        idle = 0;
+        continue;
+      }
       for (int spin = 0; spin < 64; ++spin) cpu_pause();
+      // a polling thread never blocks, and a pinned one never moves: a helper thread of the library that last ran on this core (the contexts' job
+      // threads) would wait in its run queue for the end of a time slice - milliseconds (seen as one 18 ms prove in ~30 at config 3). Every ~30 us of
+      // idle polling the core is offered to whoever is runnable on it.
+      if ((++idle & 31u) == 0) sched_yield();
       if (now_ns() < hot_until_.load(std::memory_order_relaxed)) continue;
       std::unique_lock<std::mutex> l(mu_);
       cv_.wait(l, [&] { return stop_ || now_ns() < hot_until_.load(std::memory_order_relaxed); });
@@ -211,6 +238,8 @@ class WalkPool {
         b.n_ents = 0;
         b.nparts = 0;
         b.done.store(0, std::memory_order_relaxed);
+        b.orphan.store(false, std::memory_order_relaxed);
+        for (auto& f : b.pdone) f.store(0, std::memory_order_relaxed);
         if (++gen_ == 0) ++gen_;
         b.gen = gen_;
         return &b;
@@ -226,15 +255,54 @@ class WalkPool {
     b->nparts = nparts;
     states_[b->slot].store(((uint64_t)b->gen << 32) | ((uint64_t)nparts << 16), std::memory_order_release);
   }
-  // the owner takes whatever is unclaimed, waits for the claimed rest, adds the parts and gives the slot back
+  // The owner takes whatever is unclaimed, waits for the claimed rest, adds the parts and gives the slot back. A part whose walker does not deliver
+  // within ~25 us (it normally takes 3-5: the thread has lost its core - to a helper thread of the library waking up on it, seen as one 8-18 ms prove in
+  // ~500 at config 3) is walked again by the owner; the straggler's result is ignored and the slot goes back when it has finished (a walk only reads the
+  // batch's own entry list and the key's tables: sp_ck_free waits for stragglers, `quiesce`).
   xyzz_t finish(Batch* b) {
     unsigned g;
     for (int p; (p = claim(b->slot, &g)) >= 0;) run_part(*b, (unsigned)p);
-    while (b->done.load(std::memory_order_acquire) < b->nparts) cpu_pause();
     xyzz_t acc = xyzz_identity();
-    for (unsigned p = 0; p < b->nparts; ++p) acc = xyzz_add(acc, b->part[p]);
-    release(b);
+    long long deadline = 0;
+    for (unsigned p = 0; p < b->nparts; ++p) {
+      bool have = b->pdone[p].load(std::memory_order_acquire) != 0;
+      for (unsigned spins = 0; !have; ++spins) {
+        cpu_pause();
+        have = b->pdone[p].load(std::memory_order_acquire) != 0;
+        if (!have && (spins & 63u) == 63u) {
+          const long long t = now_ns();
+          if (!deadline) deadline = t + 25000;
+          else if (t > deadline) break;
+        }
+      }
+      if (have) {
+        acc = xyzz_add(acc, b->part[p]);
+      } else {
+        acc = xyzz_add(acc, walk_part(*b, p));
+        redone_.fetch_add(1, std::memory_order_relaxed);
+      }
+    }
+    if (b->done.load(std::memory_order_acquire) == b->nparts) {
+      release(b);
+    } else {
+      b->orphan.store(true, std::memory_order_release);
+      if (b->done.load(std::memory_order_acquire) == b->nparts && b->orphan.exchange(false, std::memory_order_acq_rel)) release(b);
+    }
     return acc;
+  }
+  unsigned long redone() const { return redone_.load(std::memory_order_relaxed); }  // parts the owners walked again (diagnostics)
+  // no walker is still inside a batch its owner has left (called before tables a walk may read are freed); bounded
+  void quiesce() {
+    const long long until = now_ns() + 2000000000ll;
+    for (;;) {
+      bool busy = false;
+      {
+        std::lock_guard<std::mutex> l(mu_);
+        for (int i = 0; i < MAX_BATCHES; ++i) busy = busy || (in_use_[i] && batches_[i].orphan.load(std::memory_order_acquire));
+      }
+      if (!busy || now_ns() > until) return;
+      std::this_thread::yield();
+    }
   }
   // fn(arg, p, nparts) for p = 0 .. nparts - 1 on the walkers and the calling thread; returns when every part has run. Parts nobody has claimed are the
   // caller's (a sleeping walker costs nothing but its help), and with no free slot the caller runs them all. The host rounds of the sum-checks behind a

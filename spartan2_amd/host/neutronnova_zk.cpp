@@ -433,6 +433,12 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   };
   ck(sp_ctx_bind_thread(ctx), "device");
   ck(sp_walkers_keep_hot(20000), "walkers");  // the round commitments and the host loops of the verifier-circuit instance are spread over them
+  // process_round is host work when its commitments go through the walkers: the batched sum-checks may then queue a round's launch ahead of it
+  struct HookPromise {
+    sp_ctx* c;
+    ~HookPromise() { sp_ctx_round_hooks_host_only(c, 0); }
+  } hook_promise{ctx};
+  ck(sp_ctx_round_hooks_host_only(ctx, vcirc::split_commitments_on(pk.vc_ck) ? 1 : 0), "round hooks");
   const bool side = !reference_order;  // (false = everything inline on the caller's context: the order the phase comments describe)
   struct SideGuard {  // no exit path leaves a job running on state this call owns
     NNZkPrep& ps;

@@ -378,7 +378,7 @@ struct State {  // MultiRoundState (bellpepper/r1cs.rs:695-707)
   size_t current = 0;
   double commit_ms = 0;  // wall time inside the per-round commitments (reported as a phase of its own)
   double synth_ms = 0, hash_ms = 0;  // diagnostics (SPARTAN_HOST_LAPS): synthesis of the rounds, transcript work of process_round
-  size_t commits = 0, split_commits = 0;
+  size_t commits = 0, split_commits = 0, device_commits = 0;
   // the NEXT round's commitment, begun when this round's challenge was drawn (sp_hyrax_commit_split_begin: the blind's term and the early values)
   struct Ahead {
     sp_split_commit* job = nullptr;
@@ -394,13 +394,16 @@ struct State {  // MultiRoundState (bellpepper/r1cs.rs:695-707)
 // draws between the rounds - it is PEEKED here and checked against the tape position when the round comes) and the early values of a sum-check round.
 // The terms go to the library's table walkers (sp_hyrax_commit_split_begin) and are added under the device's work on the round's polynomials.
 static const size_t SPLIT_COLS = 16;
-static inline void begin_next_commitment(sp_ctx* ctx, State& st, const Shape& s, const sp_ck* vc_ck, const Circuit& vc, size_t next, const fe_t& c0, const Tape& tape) {
+// are the round commitments walked on the host (sp_hyrax_commit_split_*: the library keeps walkers and host tables of the key's leading columns)?
+static inline bool split_commitments_on(const sp_ck* vc_ck) {
   static const bool off = [] {
     const char* e = getenv("SPARTAN_VC_SPLIT");  // "0": every round commitment through sp_hyrax_commit_small (the device walk), for A/B runs and tests
     return e && e[0] == '0';
   }();
-  if (off || next >= s.num_rounds || s.vars_padded[next] != s.width || tape.pos >= tape.blocks) return;
-  if (!sp_hyrax_commit_split_available(vc_ck, SPLIT_COLS)) return;
+  return !off && sp_hyrax_commit_split_available(vc_ck, SPLIT_COLS) != 0;
+}
+static inline void begin_next_commitment(sp_ctx* ctx, State& st, const Shape& s, const sp_ck* vc_ck, const Circuit& vc, size_t next, const fe_t& c0, const Tape& tape) {
+  if (next >= s.num_rounds || s.vars_padded[next] != s.width || tape.pos >= tape.blocks || !split_commitments_on(vc_ck)) return;
   State::Ahead& a = st.ahead;
   sp_hyrax_commit_split_drop(a.job);
   a.job = nullptr;
@@ -456,9 +459,27 @@ static inline std::vector<fe_t> process_round(sp_ctx* ctx, State& st, const Shap
       sp_hyrax_commit_split_drop(job);
     }
   }
-  if (!split)
+  if (!split && rows == 1 && split_commitments_on(vc_ck)) {
+    // no commitment was begun for this round (the first round, or one whose early values did not match): the whole row through the table walkers all
+    // the same - the hook stays host-only, which is what nn_prove promises the batched sum-checks (sp_ctx_round_hooks_host_only)
+    bool low = true;
+    for (size_t k = SPLIT_COLS; low && k < s.vars_unpadded[round]; ++k) low = fe_is_zero(st.cs.aux[su + k]);
+    if (low) {
+      const size_t nl = std::min(s.vars_unpadded[round], SPLIT_COLS);
+      uint32_t cols[SPLIT_COLS];
+      for (size_t k = 0; k < nl; ++k) cols[k] = (uint32_t)k;
+      sp_split_commit* job = nullptr;
+      ck(sp_hyrax_commit_split_begin(ctx, vc_ck, cols, nullptr, 0, u64p(&blinds[0]), &job), "commit round witness (walkers)");
+      ck(sp_hyrax_commit_split_finish(ctx, job, cols, u64p(st.w.data() + sp_), nl, u64p(&comm[0].x)), "commit round witness (walkers)");
+      split = true;
+      st.split_commits++;
+    }
+  }
+  if (!split) {
+    st.device_commits++;
     for (size_t r = 0; r < rows; ++r)
       ck(sp_hyrax_commit_small(ctx, vc_ck, u64p(st.w.data() + sp_ + r * s.width), s.width, u64p(&blinds[r]), u64p(&comm[r].x)), "commit round witness");
+  }
   st.commit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
   st.commits += rows;
   const auto th0 = std::chrono::steady_clock::now();
