@@ -200,6 +200,51 @@ impl HipCommitmentKey {
   }
 }
 /// FixedBaseMul::precompute over a list of points (msm.rs:653-689): the committed rows of comm_W followed by h, built once in prep_prove.
+/// Round 6 - a narrow commitment in two calls (src/bellpepper/r1cs.rs:735-816 process_round -> PCS::commit on the width-32 key, hyrax_pc.rs:221-260): the terms
+/// that do not depend on the round's own prover message are posted when the previous challenge is drawn and walked by the library's polling host threads
+/// under the device's round; `finish` adds the rest. `process_round` keeps the job in its MultiRoundState.
+pub struct SplitCommit {
+  job: *mut sp_split_commit,
+}
+impl HipCommitmentKey {
+  pub fn split_available(&self, cols_used: usize) -> bool {
+    unsafe { sp_hyrax_commit_split_available(self.k, cols_used) != 0 }
+  }
+  pub fn commit_split_begin<F>(&self, cols: &[u32], scalars: &[F], blind: Option<&F>) -> Result<SplitCommit, SpartanError> {
+    let mut job = std::ptr::null_mut();
+    let b = blind.map_or(std::ptr::null(), |x| x as *const F as *const u64);
+    check(unsafe { sp_hyrax_commit_split_begin(ctx(), self.k, cols.as_ptr(), scalars.as_ptr() as *const u64, cols.len(), b, &mut job) })?;
+    Ok(SplitCommit { job })
+  }
+}
+impl SplitCommit {
+  pub fn finish<F>(mut self, cols: &[u32], scalars: &[F]) -> Result<[u64; 8], SpartanError> {
+    let mut out = [0u64; 8];
+    let job = std::mem::replace(&mut self.job, std::ptr::null_mut());
+    check(unsafe { sp_hyrax_commit_split_finish(ctx(), job, cols.as_ptr(), scalars.as_ptr() as *const u64, cols.len(), out.as_mut_ptr()) })?;
+    Ok(out)
+  }
+}
+impl Drop for SplitCommit {
+  fn drop(&mut self) {
+    unsafe { sp_hyrax_commit_split_drop(self.job) }  // (null after finish: a no-op)
+  }
+}
+/// for the duration of a prove whose round hooks commit through `SplitCommit`: the batched sum-checks may queue a round's launch ahead of the hook
+pub struct HostOnlyHooks;
+impl HostOnlyHooks {
+  pub fn promise() -> Result<Self, SpartanError> {
+    check(unsafe { sp_walkers_keep_hot(20_000) })?;
+    check(unsafe { sp_ctx_round_hooks_host_only(ctx(), 1) })?;
+    Ok(HostOnlyHooks)
+  }
+}
+impl Drop for HostOnlyHooks {
+  fn drop(&mut self) {
+    unsafe { sp_ctx_round_hooks_host_only(ctx(), 0) };
+  }
+}
+
 pub struct RowTables {
   pub(crate) t: *mut sp_fbtables,
 }
