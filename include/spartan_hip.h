@@ -279,6 +279,15 @@ int sp_fbtables_multi_mul_begin_eq(sp_ctx* ctx, const sp_fbtables* t, const uint
 int sp_fbtables_multi_mul_finish(sp_ctx* ctx, uint64_t out_aff[8]);
 /* FoldingEngineTrait::fold_commitments for two commitments with weights (1, w) (hyrax_pc.rs:757-776): out[i] = p[i] + w * q[i] per row */
 int sp_fold_commitments2(sp_ctx* ctx, const uint64_t* p_rows_aff, const uint64_t* q_rows_aff, size_t rows, const uint64_t w[4], uint64_t* out_rows_aff);
+/* The same in two calls for a weight that is drawn late (round 6). comm = p + w * q of the folded opening (src/neutronnova_zk.rs:2019-2051 -> fold_commitments,
+ * hyrax_pc.rs:757-776) has q - the core instance's commitment rows, the commitment of one evaluation - long before c_eval: _begin starts the doubling ladders
+ * 2^j q_i (j = 0 .. 256, normalised) of every row on the library's polling host threads and returns at once; _finish adds the ladder points of w's
+ * non-adjacent form (~85 mixed additions a row instead of 256 doublings + 51 additions behind the challenge) and p. Same points as sp_fold_commitments2;
+ * without walkers _finish is that call. One _finish or _drop per _begin; q_rows_aff is copied. */
+typedef struct sp_fold2_job sp_fold2_job;
+int sp_fold_commitments2_begin(sp_ctx* ctx, const uint64_t* q_rows_aff, size_t rows, sp_fold2_job** job);
+int sp_fold_commitments2_finish(sp_ctx* ctx, sp_fold2_job* job, const uint64_t* p_rows_aff, const uint64_t w[4], uint64_t* out_rows_aff);
+void sp_fold_commitments2_drop(sp_fold2_job* job);
 /* sum of n affine points (host side of the library; the combine step of a point-range-sharded MSM: RCCL has no EC-add reduction,
  * so ranks all-gather their partial points and add them locally — SURVEY.md 8(e)) */
 int sp_point_sum(const uint64_t* points_aff, size_t n, uint64_t out_aff[8]);

@@ -1013,6 +1013,112 @@ int sp_fold_commitments2(sp_ctx* c, const uint64_t* p_rows_aff, const uint64_t* 
   if (rows) memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
   return SP_OK;
 }
+// ---- the two-term fold with a late weight: doubling ladders of q's rows built ahead on the walkers (walk_pool.hpp) ------------------------------------------
+struct sp_fold2_job {
+  static constexpr size_t LAD = 257;  // 2^j q for j = 0 .. 256: a non-adjacent form of a 256-bit scalar has up to 257 digits
+  size_t rows = 0;
+  std::vector<aff_t> q, ladder;  // ladder[i * LAD + j] = 2^j q_i (affine)
+  sp::WalkPool::Batch* batch = nullptr;
+  bool built = false;
+  // the second region (finish): the weight's digits and the results
+  signed char naf[LAD + 1];
+  int naf_len = 0;
+  std::vector<jac_t> out;
+  const aff_t* p = nullptr;
+};
+static void fold2_ladder_part(void* arg, unsigned part, unsigned np) {
+  sp_fold2_job& J = *static_cast<sp_fold2_job*>(arg);
+  constexpr size_t LAD = sp_fold2_job::LAD;
+  std::vector<jac_t> jp(LAD);
+  for (size_t i = J.rows * part / np; i < J.rows * (part + 1) / np; ++i) {
+    jp[0] = jac_from_affine(J.q[i]);
+    for (size_t j = 1; j < LAD; ++j) jp[j] = jac_dbl(jp[j - 1]);
+    normalize_batch(jp, J.ladder.data() + i * LAD);  // (an identity row stays a row of identities)
+  }
+}
+static void fold2_sum_part(void* arg, unsigned part, unsigned np) {
+  sp_fold2_job& J = *static_cast<sp_fold2_job*>(arg);
+  constexpr size_t LAD = sp_fold2_job::LAD;
+  for (size_t i = J.rows * part / np; i < J.rows * (part + 1) / np; ++i) {
+    const aff_t* L = J.ladder.data() + i * LAD;
+    xyzz_t acc = xyzz_identity();
+    for (int j = 0; j < J.naf_len; ++j)
+      if (J.naf[j]) acc = xyzz_add_mixed(acc, J.naf[j] > 0 ? L[j] : aff_neg(L[j]));
+    if (J.p) acc = xyzz_add_mixed(acc, J.p[i]);
+    J.out[i] = xyzz_to_jac(acc);
+  }
+}
+int sp_fold_commitments2_begin(sp_ctx* c, const uint64_t* q_rows_aff, size_t rows, sp_fold2_job** out) {
+  (void)c;
+  if (rows && !q_rows_aff) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fold_commitments2_begin: null argument");
+  std::unique_ptr<sp_fold2_job> J(new sp_fold2_job());
+  J->rows = rows;
+  J->q.resize(rows);
+  if (rows) memcpy(J->q.data(), q_rows_aff, rows * sizeof(aff_t));
+  sp::WalkPool& pool = sp::WalkPool::get();
+  if (rows && pool.walkers() > 0) {
+    J->ladder.resize(rows * sp_fold2_job::LAD);
+    pool.keep_hot(4000);
+    J->batch = pool.post_fn((unsigned)std::min<size_t>(rows, sp::WalkPool::MAX_PARTS), fold2_ladder_part, J.get());
+    if (!J->batch) J->ladder.clear();  // (no slot: the plain form at finish)
+  }
+  *out = J.release();
+  return SP_OK;
+}
+int sp_fold_commitments2_finish(sp_ctx* c, sp_fold2_job* job, const uint64_t* p_rows_aff, const uint64_t w[4], uint64_t* out_rows_aff) {
+  std::unique_ptr<sp_fold2_job> J(job);
+  sp::WalkPool& pool = sp::WalkPool::get();
+  if (J->batch) {
+    pool.wait_fn(J->batch);
+    J->batch = nullptr;
+    J->built = true;
+  }
+  if (J->rows && (!p_rows_aff || !w || !out_rows_aff)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fold_commitments2_finish: null argument");
+  if (!J->built) return sp_fold_commitments2(c, p_rows_aff, reinterpret_cast<const uint64_t*>(J->q.data()), J->rows, w, out_rows_aff);
+  // non-adjacent form of the canonical weight: digit j in {-1, 0, 1}, no two adjacent non-zero
+  fe_t sc;
+  memcpy(&sc, w, 32);
+  const fe_t k0 = fe_to_canonical<S>(sc);
+  uint32_t k[9];
+  for (int i = 0; i < 8; ++i) k[i] = k0.v[i];
+  k[8] = 0;
+  int len = 0;
+  auto is_zero = [&] {
+    uint32_t o = 0;
+    for (int i = 0; i < 9; ++i) o |= k[i];
+    return o == 0;
+  };
+  while (!is_zero() && len < (int)sp_fold2_job::LAD) {
+    int d = 0;
+    if (k[0] & 1u) {
+      d = 2 - (int)(k[0] & 3u);  // 1 or -1
+      if (d > 0) {
+        k[0] -= 1u;  // (k odd: no borrow)
+      } else {       // k += 1
+        for (int i = 0; i < 9; ++i)
+          if (++k[i] != 0u) break;
+      }
+    }
+    J->naf[len++] = (signed char)d;
+    for (int i = 0; i < 8; ++i) k[i] = (k[i] >> 1) | (k[i + 1] << 31);
+    k[8] >>= 1;
+  }
+  J->naf_len = len;
+  J->out.assign(J->rows, jac_identity());
+  J->p = reinterpret_cast<const aff_t*>(p_rows_aff);
+  pool.keep_hot(2000);
+  pool.run((unsigned)std::min<size_t>(J->rows, (size_t)pool.walkers() + 1), fold2_sum_part, J.get());
+  std::vector<aff_t> a(J->rows);
+  normalize_batch(J->out, a.data());
+  if (J->rows) memcpy(out_rows_aff, a.data(), J->rows * sizeof(aff_t));
+  return SP_OK;
+}
+void sp_fold_commitments2_drop(sp_fold2_job* job) {
+  if (!job) return;
+  if (job->batch) sp::WalkPool::get().wait_fn(job->batch);
+  delete job;
+}
+
 int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const uint64_t* r_old, const uint64_t* r_new, uint64_t* out_rows_aff) {
   if (rows && (!comm_rows_aff || !r_old || !r_new || !out_rows_aff)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "rerandomize_commitment: null argument");
   std::vector<fe_t> diff(rows);

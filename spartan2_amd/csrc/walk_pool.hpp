@@ -323,6 +323,24 @@ class WalkPool {
     while (b->done.load(std::memory_order_acquire) < b->nparts) cpu_pause();
     release(b);
   }
+  // the same region posted and collected in two calls: the parts run on the walkers while the owner does something else; `wait_fn` takes the parts nobody
+  // has claimed and waits for the rest (`arg` must stay alive until then). nullptr: no free slot / no walkers - the caller runs fn itself when it needs it.
+  Batch* post_fn(unsigned nparts, PartFn fn, void* arg) {
+    if (nparts > (unsigned)MAX_PARTS) nparts = MAX_PARTS;
+    Batch* b = nparts >= 1 && want_ ? acquire() : nullptr;
+    if (!b) return nullptr;
+    b->fn = fn;
+    b->arg = arg;
+    b->nparts = nparts;
+    states_[b->slot].store(((uint64_t)b->gen << 32) | ((uint64_t)nparts << 16), std::memory_order_release);
+    return b;
+  }
+  void wait_fn(Batch* b) {
+    unsigned g;
+    for (int p; (p = claim(b->slot, &g)) >= 0;) run_part(*b, (unsigned)p);
+    while (b->done.load(std::memory_order_acquire) < b->nparts) cpu_pause();
+    release(b);
+  }
   bool finished(const Batch* b) const { return b->done.load(std::memory_order_acquire) >= b->nparts; }
   void release(Batch* b) {
     states_[b->slot].store(0, std::memory_order_release);

@@ -382,6 +382,20 @@ def fold_commitments2(ctx, p_rows, q_rows, w):
     return out
 
 
+def fold_commitments2_split(ctx, p_rows, q_rows, w, drop=False):
+    """sp_fold_commitments2_begin (q's doubling ladders on the polling host threads) + _finish: p[i] + w * q[i] for a weight that arrives late."""
+    p_rows = np.ascontiguousarray(p_rows, dtype=np.uint64).reshape(-1, 8)
+    q_rows = np.ascontiguousarray(q_rows, dtype=np.uint64).reshape(-1, 8)
+    job = ctypes.c_void_p()
+    check(lib().sp_fold_commitments2_begin(ctx.h, p64(q_rows), ctypes.c_size_t(q_rows.shape[0]), ctypes.byref(job)))
+    if drop:
+        lib().sp_fold_commitments2_drop(job)
+        return None
+    out = np.zeros_like(p_rows)
+    check(lib().sp_fold_commitments2_finish(ctx.h, job, p64(p_rows), p64(np.ascontiguousarray(w, dtype=np.uint64).reshape(4)), p64(out)))
+    return out
+
+
 def eval_cubic_zero_check_round0(ctx, taus, A, B):
     """EqSumCheckInstance::evaluation_points_zero_check_round0 (src/sumcheck.rs:1163-1271) -> (eval_0, eval_2, eval_3)."""
     taus = np.ascontiguousarray(taus, dtype=np.uint64).reshape(-1, 4)

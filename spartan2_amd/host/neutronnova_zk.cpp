@@ -590,6 +590,16 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   std::vector<aff_t> core_comm(rows);
   std::vector<fe_t> core_rW(rows);
   instance(ps.core, n, core_comm.data(), core_rW.data());
+  // the opening folds comm = folded + c_eval * core rows and comm_eval = eW_step + c_eval * eW_core with a weight drawn at the very end: the doubling
+  // ladders of the core rows (now) and of the core evaluation's commitment (behind its round) are built on the library's polling threads meanwhile
+  struct Fold2Guard {
+    sp_fold2_job *rows = nullptr, *eval = nullptr;
+    ~Fold2Guard() {
+      sp_fold_commitments2_drop(rows);
+      sp_fold_commitments2_drop(eval);
+    }
+  } fold2;
+  if (side) ck(sp_fold_commitments2_begin(ctx, u64p(&core_comm[0].x), rows, &fold2.rows), "fold_commitments (ladders)");
   const double t_inst = now();
 
   Tr tr(ctx, "neutronnova_prove");
@@ -782,6 +792,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   vc.eval_W_core = fe_mul<S>(fe_sub<S>(fin[3], fe_mul<S>(r_y[0], vc.eval_X_core)), inv);
   const size_t inner_final = hc.inner_start + pk.ny;
   for (size_t k = 0; k < 3; ++k) vcirc::process_round(ctx, vst, pk.vc, pk.vc_ck, vc, inner_final + k, tr, tape);
+  if (side) ck(sp_fold_commitments2_begin(ctx, u64p(&vst.comm_per_round[inner_final + 2][0].x), 1, &fold2.eval), "fold eval commitments (ladder)");
   const double t_inner = now();
 
   // finalize_multiround_witness (:1948-1952): U_verifier, its regular form, W_verifier
@@ -950,7 +961,15 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   const fe_t c_eval = tr.squeeze("c_eval");
   std::vector<aff_t> comm(rows);
   if (t_fold) ps.wk.wait(t_fold);  // the folded commitment of the step instances: the helper's second job, started behind the NIFS rounds
-  ck(sp_fold_commitments2(ctx, u64p(&f_comm[0].x), u64p(&core_comm[0].x), rows, u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
+  lap("pcs: wait for the folded commitment");
+  if (fold2.rows) {
+    sp_fold2_job* j = fold2.rows;
+    fold2.rows = nullptr;
+    ck(sp_fold_commitments2_finish(ctx, j, u64p(&f_comm[0].x), u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
+  } else {
+    ck(sp_fold_commitments2(ctx, u64p(&f_comm[0].x), u64p(&core_comm[0].x), rows, u64p(&c_eval), u64p(&comm[0].x)), "fold_commitments");
+  }
+  lap("pcs: fold_commitments2 (rows)");
   std::vector<fe_t> blind(rows);
   for (size_t i = 0; i < rows; ++i) {
     fe_t a;
@@ -963,8 +982,15 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     ck(sp_fold_tables(ctx, two, 2, u64p(wts), nv, Wf), "W = folded_W + c_eval * core_W");
   }
   aff_t comm_eval;
-  ck(sp_fold_commitments2(ctx, u64p(&comm_eW_s[0].x), u64p(&comm_eW_c[0].x), 1, u64p(&c_eval), u64p(&comm_eval.x)), "fold eval commitments");
+  if (fold2.eval) {
+    sp_fold2_job* j = fold2.eval;
+    fold2.eval = nullptr;
+    ck(sp_fold_commitments2_finish(ctx, j, u64p(&comm_eW_s[0].x), u64p(&c_eval), u64p(&comm_eval.x)), "fold eval commitments");
+  } else {
+    ck(sp_fold_commitments2(ctx, u64p(&comm_eW_s[0].x), u64p(&comm_eW_c[0].x), 1, u64p(&c_eval), u64p(&comm_eval.x)), "fold eval commitments");
+  }
   const fe_t blind_eval = fe_add<S>(vst.blind_per_round[inner_final + 1][0], fe_mul<S>(c_eval, vst.blind_per_round[inner_final + 2][0]));
+  lap("pcs: W fold + eval commitment fold");
   // HyraxPCS::prove (hyrax_pc.rs:387-478) + InnerProductArgumentLinear::prove (ipa.rs:125-170); ck_eval = the width-32 key (ck_c = its first base, its h)
   aff_t delta, beta;
   std::vector<fe_t> z_vec(CW);
@@ -983,17 +1009,20 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   } else {
     const std::vector<uint8_t> b = commitment_bytes(comm.data(), comm.size());
     tr.absorb("poly_com", b.data(), b.size());
+    lap("pcs: absorb poly_com");
     const fe_t* point = r_y.data() + 1;
     const size_t npoint = pk.ny - 1, nvr = log2_ceil(rows);
     const std::vector<fe_t> L = eq_evals(point, nvr), Rv = eq_evals(point + nvr, npoint - nvr);
     std::vector<fe_t> LZ(Rv.size());
     ck(sp_rowmat_vec(ctx, Wf, L.size(), Rv.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
+    lap("pcs: eq + rowmat_vec");
     fe_t r_LZ = fe_zero();
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], blind[i]));
     std::vector<fe_t> dv;
     fe_t r_delta, r_beta;
     aff_t comm_LZ;
     if (t_open) ps.wk.wait(t_open);
+    lap("pcs: wait for the opening's points");
     if (t_open && ps.open.delta_valid && ps.open.points_valid && ps.open.tape_from == tape.pos && Rv.size() == ps.open.dv.size()) {
       // the helper has delta, beta and the two halves of comm_LZ = <L, rows of (folded + c_eval core)> = P_f + c_eval P_c
       dv.swap(ps.open.dv);
@@ -1030,9 +1059,11 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     point_bytes(beta, pb);
     tr.absorb("beta", pb, 64);
     const fe_t rr = tr.squeeze("r");
+    lap("pcs: comm_LZ + transcript");
     for (size_t i = 0; i < Rv.size(); ++i) z_vec[i] = fe_add<S>(fe_mul<S>(rr, LZ[i]), dv[i]);
     z_delta = fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta);
     z_beta = fe_add<S>(fe_mul<S>(rr, blind_eval), r_beta);
+    lap("pcs: z_vec");
   }
   const double t_end = now();
   // the rest of the proof in the canonical layout

@@ -54,6 +54,26 @@ def test_vartime_scalar_mul_and_two_term_fold(ctx, n):
         assert (fold == np.stack([_add(q, m) for q, m in zip(qs, want)])).all()
 
 
+@pytest.mark.parametrize("n", [1, 16, 17, 40])
+def test_two_term_fold_with_ladders_built_ahead(ctx, n):
+    """sp_fold_commitments2_begin / _finish (the doubling ladders of q's rows built on the polling host threads before the weight is known, the weight's
+    non-adjacent form walked over them) against the oracle's p + w q and the one-call form: random weights, 0, 1, p - 1 (the longest NAF), 2^200, a weight
+    with long runs of ones (carries through the NAF), identity rows on either side, a dropped job."""
+    rng = np.random.default_rng(1900 + n)
+    pts, qs = _points(rng, n), _points(rng, n)
+    if n > 2:
+        pts[1] = 0  # q row = the identity
+        qs[2] = 0   # p row = the identity
+    ones = ol.to_mont((1 << 255) - (1 << 13) + 5)
+    for w in (ol.random_field_array(rng, 1)[0], ol.to_mont(1), ol.to_mont(0), ol.to_mont(P - 1), ol.to_mont(1 << 200), ones, ol.to_mont(3)):
+        got = hip.fold_commitments2_split(ctx, qs, pts, w)
+        want = np.stack([_add(q, _mul(pt, w)) for q, pt in zip(qs, pts)])
+        assert (got == want).all()
+        assert (hip.fold_commitments2(ctx, qs, pts, w) == want).all()
+    assert hip.fold_commitments2_split(ctx, qs, pts, ones, drop=True) is None
+    assert (hip.fold_commitments2_split(ctx, qs, pts, ones) == np.stack([_add(q, _mul(pt, ones)) for q, pt in zip(qs, pts)])).all()
+
+
 def test_rerandomize_commitment(ctx):
     rng = np.random.default_rng(31)
     g = host.from_label(b"ck", 65)
@@ -245,7 +265,7 @@ def test_eq_table_begun_two_coordinates_early(ctx, ell):
     ("SPARTAN_HAND_N_CUBIC=256 SPARTAN_HAND_N_QUAD=512", "tests/test_gpu_sumcheck.py tests/test_gpu_configs.py -k 'cubic or quad or c1_c2 or randomised or two_round'"),
     ("SPARTAN_HAND_N_CUBIC=64 SPARTAN_HAND_N_QUAD=128 SPARTAN_WALKERS=0", "tests/test_gpu_sumcheck.py -k 'cubic or quad'"),
     ("SPARTAN_VC_SPLIT=0", "tests/test_gpu_neutronnova_zk.py -k 'oracle'"),
-    ("SPARTAN_WALKERS=0", "tests/test_gpu_neutronnova_zk.py tests/test_gpu_group.py -k 'oracle or commit_split'"),
+    ("SPARTAN_WALKERS=0", "tests/test_gpu_neutronnova_zk.py tests/test_gpu_group.py tests/test_gpu_abi_gaps.py -k '(oracle or commit_split or ladders) and not switched'"),
 ])
 def test_switched_code_paths_in_a_process_of_their_own(env, targets):
     """Code paths behind switches that are read once per process - the second stage folded into the streaming producers (measured, off by default), the
@@ -258,7 +278,9 @@ def test_switched_code_paths_in_a_process_of_their_own(env, targets):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    child_env = dict(os.environ, **dict(kv.split("=") for kv in env.split()))
+    if os.environ.get("SPARTAN_TEST_CHILD"):
+        pytest.skip("already inside a child process of this test (a -k expression matched its own parameter id)")
+    child_env = dict(os.environ, SPARTAN_TEST_CHILD="1", **dict(kv.split("=") for kv in env.split()))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + shlex.split(targets), cwd=root, env=child_env, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout or "")[-1500:]
     assert r.returncode == 0, tail
