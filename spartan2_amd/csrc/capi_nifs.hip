@@ -26,6 +26,12 @@ struct sp_nifs {
   unsigned* d_large = nullptr;
   unsigned nlarge = 0;
   fe_t *d_E = nullptr, *d_w = nullptr, *d_part = nullptr, *d_part2 = nullptr, *d_cvals = nullptr;
+  // the pair weights of every round depend on the rhos alone: computed and uploaded once at begin (offsets w_off, counts w_pairs), a round only picks its
+  // range (d_w_cur); a round whose pair count differs from what begin assumed uploads into the second half of d_w as before
+  fe_t* d_w_cur = nullptr;
+  std::vector<fe_t> h_w;
+  std::vector<size_t> w_off, w_pairs;
+  fe_t* h_pin = nullptr;  // pinned landing area of the rounds' sums (a copy into pageable memory goes through the runtime's staging buffer)
   size_t part_elems = 0;
   // round state
   int cur = 0;       // buffer holding the current layers
@@ -77,7 +83,15 @@ int sum_partials(sp_nifs* n, size_t rows, size_t cnt, fe_t* out_host) {
     src = dst;
     dst = const_cast<fe_t*>(t);
   }
-  SP_HIP(hipMemcpyAsync(out_host, dst, rows * NACC * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
+  const size_t cnt_out = rows * NACC;
+  if (cnt_out <= 64) {
+    if (!n->h_pin) SP_HIP(hipHostMalloc((void**)&n->h_pin, 64 * sizeof(fe_t)));
+    SP_HIP(hipMemcpyAsync(n->h_pin, dst, cnt_out * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP(sp::stream_sync(c->stream));
+    memcpy(out_host, n->h_pin, cnt_out * sizeof(fe_t));
+    return SP_OK;
+  }
+  SP_HIP(hipMemcpyAsync(out_host, dst, cnt_out * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
   SP_HIP(sp::stream_sync(c->stream));
   return SP_OK;
 }
@@ -96,10 +110,32 @@ fe_t suffix_weight_full(size_t t, size_t ell_b, size_t pair_idx, const std::vect
 size_t pair_base(const sp_nifs* n, size_t t) { return n->first >> (t + 1); }
 
 int upload_weights(sp_nifs* n, size_t t, size_t pairs) {
+  if (t < n->w_pairs.size() && n->w_pairs[t] == pairs) {  // uploaded at begin
+    n->d_w_cur = n->d_w + n->w_off[t];
+    return SP_OK;
+  }
   std::vector<fe_t> w(pairs);
   for (size_t p = 0; p < pairs; ++p) w[p] = suffix_weight_full(t, n->ell_b, pair_base(n, t) + p, n->rhos);
-  SP_HIP(hipMemcpyAsync(n->d_w, w.data(), pairs * sizeof(fe_t), hipMemcpyHostToDevice, n->ctx->stream));
+  n->d_w_cur = n->d_w + n->n_padded;
+  SP_HIP(hipMemcpyAsync(n->d_w_cur, w.data(), pairs * sizeof(fe_t), hipMemcpyHostToDevice, n->ctx->stream));
   SP_HIP(sp::stream_sync(n->ctx->stream));  // w is a stack-lifetime host buffer
+  return SP_OK;
+}
+// every round's weights in one upload (the rounds of an unsharded or local run halve their pairs: n_padded / 2, / 4, ...)
+int upload_all_weights(sp_nifs* n) {
+  n->w_off.clear();
+  n->w_pairs.clear();
+  n->h_w.clear();
+  for (size_t t = 0; t < n->ell_b; ++t) {
+    const size_t pairs = n->n_padded >> (t + 1);
+    if (pairs == 0) break;
+    n->w_off.push_back(n->h_w.size());
+    n->w_pairs.push_back(pairs);
+    for (size_t p = 0; p < pairs; ++p) n->h_w.push_back(suffix_weight_full(t, n->ell_b, pair_base(n, t) + p, n->rhos));
+  }
+  if (n->h_w.empty()) return SP_OK;
+  // (h_w lives in the object: no synchronise for the buffer's sake; the stream orders the copy in front of the rounds' kernels)
+  SP_HIP(hipMemcpyAsync(n->d_w, n->h_w.data(), n->h_w.size() * sizeof(fe_t), hipMemcpyHostToDevice, n->ctx->stream));
   return SP_OK;
 }
 
@@ -133,7 +169,7 @@ int sp_nifs_create(sp_ctx* c, size_t n_padded, size_t left, size_t right, sp_nif
   al((void**)&n->B[2], (n_padded / 4 ? n_padded / 4 : 1) * layer);
   al((void**)&n->C, n_padded * layer);
   al((void**)&n->d_E, (left + right) * sizeof(fe_t));
-  al((void**)&n->d_w, n_padded * sizeof(fe_t));
+  al((void**)&n->d_w, 2 * n_padded * sizeof(fe_t));
   al((void**)&n->d_part, n->part_elems * sizeof(fe_t));
   al((void**)&n->d_part2, n->part_elems * sizeof(fe_t));
   al((void**)&n->d_cvals, n_padded * sizeof(fe_t));
@@ -150,6 +186,7 @@ void sp_nifs_free(sp_nifs* n) {
   void* ptrs[] = {n->A[0], n->A[1], n->A[2], n->B[0], n->B[1], n->B[2], n->C, n->A64, n->B64, n->C64, n->d_flags, n->d_large, n->d_E, n->d_w, n->d_part, n->d_part2, n->d_cvals};
   for (void* p : ptrs)
     if (p) hipFree(p);
+  if (n->h_pin) hipHostFree(n->h_pin);
   delete n;
 }
 
@@ -228,6 +265,10 @@ int sp_nifs_begin_shard(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, 
   n->acc_eq = h_one();
   n->small = small_values != 0;
   SP_HIP(hipMemcpyAsync(n->d_E, E_eq, (n->left + n->right) * sizeof(fe_t), hipMemcpyHostToDevice, c->stream));
+  {
+    int wrc = upload_all_weights(n);
+    if (wrc) return wrc;
+  }
   const spk::NifsGeom g = geom(n);
   const unsigned blocks = (unsigned)((n->total + 255) / 256);
   const size_t np = n->n_padded;
@@ -292,15 +333,15 @@ int sp_nifs_round_sums(sp_nifs* n, size_t t, uint64_t out_sums[8]) {
       const unsigned sblocks = (unsigned)((n->total + 256 * ppt - 1) / (256 * ppt));
       c->timed("nifs_round0_small", 32ull * pairs * n->total, [&] {
         if (n->factored)
-          hipLaunchKernelGGL(spk::k_nifs_round0_small<true>, dim3(sblocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w, n->d_part, ppt);
+          hipLaunchKernelGGL(spk::k_nifs_round0_small<true>, dim3(sblocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w_cur, n->d_part, ppt);
         else
-          hipLaunchKernelGGL(spk::k_nifs_round0_small<false>, dim3(sblocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w, n->d_part, ppt);
+          hipLaunchKernelGGL(spk::k_nifs_round0_small<false>, dim3(sblocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A64, n->B64, g, n->d_w_cur, n->d_part, ppt);
       });
       if ((rc = sum_partials<1>(n, 1, (size_t)sblocks * pairs, q))) return rc;
       quad = q[0];
       if (n->nlarge) {
         const unsigned lb = (n->nlarge + 255) / 256;
-        hipLaunchKernelGGL(spk::k_nifs_round0_large, dim3(lb, (unsigned)pairs), dim3(256), 0, c->stream, n->A[0], n->B[0], g, n->d_large, n->nlarge, n->d_w,
+        hipLaunchKernelGGL(spk::k_nifs_round0_large, dim3(lb, (unsigned)pairs), dim3(256), 0, c->stream, n->A[0], n->B[0], g, n->d_large, n->nlarge, n->d_w_cur,
                            n->d_part);
         if ((rc = sum_partials<1>(n, 1, (size_t)lb * pairs, q))) return rc;
         quad = fe_add<SF>(quad, q[0]);
@@ -308,9 +349,9 @@ int sp_nifs_round_sums(sp_nifs* n, size_t t, uint64_t out_sums[8]) {
     } else {
       c->timed("nifs_round0", 128ull * pairs * n->total, [&] {
         if (n->factored)
-          hipLaunchKernelGGL(spk::k_nifs_round0<true>, dim3(blocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A[0], n->B[0], g, n->d_w, n->d_part);
+          hipLaunchKernelGGL(spk::k_nifs_round0<true>, dim3(blocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A[0], n->B[0], g, n->d_w_cur, n->d_part);
         else
-          hipLaunchKernelGGL(spk::k_nifs_round0<false>, dim3(blocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A[0], n->B[0], g, n->d_w, n->d_part);
+          hipLaunchKernelGGL(spk::k_nifs_round0<false>, dim3(blocks, (unsigned)pairs), dim3(256), 0, c->stream, n->A[0], n->B[0], g, n->d_w_cur, n->d_part);
       });
       if ((rc = sum_partials<1>(n, 1, (size_t)blocks * pairs, q))) return rc;
       quad = q[0];
@@ -326,10 +367,10 @@ int sp_nifs_round_sums(sp_nifs* n, size_t t, uint64_t out_sums[8]) {
       c->timed("nifs_fold_prove", 384ull * prove_pairs * n->total, [&] {
         if (n->factored)
           hipLaunchKernelGGL(spk::k_nifs_fold_prove<true>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst],
-                             g, r, n->d_w, n->d_part);
+                             g, r, n->d_w_cur, n->d_part);
         else
           hipLaunchKernelGGL(spk::k_nifs_fold_prove<false>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[src], n->B[src], n->A[dst], n->B[dst],
-                             g, r, n->d_w, n->d_part);
+                             g, r, n->d_w_cur, n->d_part);
       });
       n->cur = dst;
       n->m = fold_pairs;
@@ -337,9 +378,9 @@ int sp_nifs_round_sums(sp_nifs* n, size_t t, uint64_t out_sums[8]) {
     } else {  // the layers are already folded (sp_nifs_fold_pending / sp_nifs_resume): evaluate only
       c->timed("nifs_prove_pairs", 128ull * prove_pairs * n->total, [&] {
         if (n->factored)
-          hipLaunchKernelGGL(spk::k_nifs_prove_pairs<true>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[n->cur], n->B[n->cur], g, n->d_w, n->d_part);
+          hipLaunchKernelGGL(spk::k_nifs_prove_pairs<true>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[n->cur], n->B[n->cur], g, n->d_w_cur, n->d_part);
         else
-          hipLaunchKernelGGL(spk::k_nifs_prove_pairs<false>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[n->cur], n->B[n->cur], g, n->d_w, n->d_part);
+          hipLaunchKernelGGL(spk::k_nifs_prove_pairs<false>, dim3(blocks, (unsigned)prove_pairs), dim3(256), 0, c->stream, n->A[n->cur], n->B[n->cur], g, n->d_w_cur, n->d_part);
       });
     }
     if ((rc = sum_partials<2>(n, 1, (size_t)blocks * prove_pairs, s))) return rc;
@@ -461,6 +502,8 @@ int sp_nifs_resume(sp_nifs* n, const uint64_t* E_eq, const uint64_t* rhos, size_
   n->first = 0;
   n->rhos.resize(ell_b);
   for (size_t i = 0; i < ell_b; ++i) n->rhos[i] = load_fe(rhos + 4 * i);
+  n->w_pairs.clear();  // (a resumed object starts at round t_start with its own pair counts: its rounds upload their weights themselves)
+  n->w_off.clear();
   n->r_bs.resize(t_start);
   for (size_t i = 0; i < t_start; ++i) n->r_bs[i] = load_fe(r_bs + 4 * i);
   n->c_vals.resize(size_t(1) << ell_b);

@@ -161,9 +161,11 @@ struct NNZkPrep {
     aff_t delta, beta, P_f, P_c;
     size_t tape_from = 0, tape_count = 0;
     bool delta_valid = false, points_valid = false;
+    sp_fold2_job* lz_fold = nullptr;  // comm_LZ = P_f + c_eval P_c: P_c's doubling ladder, begun by the helper when it has the point
   } open;
   ~NNZkPrep() {
     wk.drain();
+    sp_fold_commitments2_drop(open.lz_fold);
     for (sp_table* t : bws) sp_table_free(t);
     for (sp_table* t : work) sp_table_free(t);
     sp_table_free(rest_stage);
@@ -772,6 +774,9 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
         fe_t ip = fe_zero();
         for (size_t i = 0; i < Rv.size(); ++i) ip = fe_add<S>(ip, fe_mul<S>(Rv[i], O.dv[i]));
         ck(sp_hyrax_commit_small(ps.ctx2, pk.vc_ck, u64p(&ip), 1, u64p(&O.r_beta), u64p(&O.beta.x)), "beta");
+        sp_fold_commitments2_drop(O.lz_fold);
+        O.lz_fold = nullptr;
+        if (sp_fold_commitments2_begin(ps.ctx2, u64p(&O.P_c.x), 1, &O.lz_fold) != SP_OK) O.lz_fold = nullptr;
         O.points_valid = true;
       } catch (...) {
         O.points_valid = false;
@@ -1031,7 +1036,13 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
       tape.skip(ps.open.tape_count);
       delta = ps.open.delta;
       beta = ps.open.beta;
-      ck(sp_fold_commitments2(ctx, u64p(&ps.open.P_f.x), u64p(&ps.open.P_c.x), 1, u64p(&c_eval), u64p(&comm_LZ.x)), "comm_LZ = P_f + c_eval P_c");
+      if (ps.open.lz_fold) {
+        sp_fold2_job* j = ps.open.lz_fold;
+        ps.open.lz_fold = nullptr;
+        ck(sp_fold_commitments2_finish(ctx, j, u64p(&ps.open.P_f.x), u64p(&c_eval), u64p(&comm_LZ.x)), "comm_LZ = P_f + c_eval P_c");
+      } else {
+        ck(sp_fold_commitments2(ctx, u64p(&ps.open.P_f.x), u64p(&ps.open.P_c.x), 1, u64p(&c_eval), u64p(&comm_LZ.x)), "comm_LZ = P_f + c_eval P_c");
+      }
     } else {
       if (laps && side) fprintf(stderr, "nn_prove: opening inputs computed inline (delta %d, points %d, tape %zu vs %zu)\n", (int)ps.open.delta_valid, (int)ps.open.points_valid, ps.open.tape_from, tape.pos);
       // the mask d and its blinds do not depend on the transcript (ipa.rs:139-147): delta's MSM runs on the auxiliary stream beside comm_LZ's
