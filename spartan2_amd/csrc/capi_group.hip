@@ -1020,20 +1020,30 @@ struct sp_fold2_job {
   std::vector<aff_t> q, ladder;  // ladder[i * LAD + j] = 2^j q_i (affine)
   sp::WalkPool::Batch* batch = nullptr;
   bool built = false;
-  // the second region (finish): the weight's digits and the results
+  // the second region (finish): the weight's digits, p's rows (copied: a straggler may still read them) and the results
   signed char naf[LAD + 1];
   int naf_len = 0;
   std::vector<jac_t> out;
-  const aff_t* p = nullptr;
+  std::vector<aff_t> p;
+  // one reference for the owner and one for every region a straggler may still be inside (walk_pool.hpp collect_fn / end_fn)
+  std::atomic<int> refs{1};
 };
+static void fold2_unref(void* a) {
+  sp_fold2_job* J = static_cast<sp_fold2_job*>(a);
+  if (J->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete J;
+}
+static const long long FOLD2_LATE_NS = 60000;  // a part is ~13-60 us of arithmetic: one that is later than this has lost its core
+// (both part functions are idempotent: a late part that the owner runs again writes the same values to the same places as its straggler)
 static void fold2_ladder_part(void* arg, unsigned part, unsigned np) {
   sp_fold2_job& J = *static_cast<sp_fold2_job*>(arg);
   constexpr size_t LAD = sp_fold2_job::LAD;
   std::vector<jac_t> jp(LAD);
+  std::vector<aff_t> row(LAD);
   for (size_t i = J.rows * part / np; i < J.rows * (part + 1) / np; ++i) {
     jp[0] = jac_from_affine(J.q[i]);
     for (size_t j = 1; j < LAD; ++j) jp[j] = jac_dbl(jp[j - 1]);
-    normalize_batch(jp, J.ladder.data() + i * LAD);  // (an identity row stays a row of identities)
+    normalize_batch(jp, row.data());  // (an identity row stays a row of identities)
+    memcpy(J.ladder.data() + i * LAD, row.data(), LAD * sizeof(aff_t));
   }
 }
 static void fold2_sum_part(void* arg, unsigned part, unsigned np) {
@@ -1044,14 +1054,14 @@ static void fold2_sum_part(void* arg, unsigned part, unsigned np) {
     xyzz_t acc = xyzz_identity();
     for (int j = 0; j < J.naf_len; ++j)
       if (J.naf[j]) acc = xyzz_add_mixed(acc, J.naf[j] > 0 ? L[j] : aff_neg(L[j]));
-    if (J.p) acc = xyzz_add_mixed(acc, J.p[i]);
+    acc = xyzz_add_mixed(acc, J.p[i]);
     J.out[i] = xyzz_to_jac(acc);
   }
 }
 int sp_fold_commitments2_begin(sp_ctx* c, const uint64_t* q_rows_aff, size_t rows, sp_fold2_job** out) {
   (void)c;
   if (rows && !q_rows_aff) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fold_commitments2_begin: null argument");
-  std::unique_ptr<sp_fold2_job> J(new sp_fold2_job());
+  sp_fold2_job* J = new sp_fold2_job();
   J->rows = rows;
   J->q.resize(rows);
   if (rows) memcpy(J->q.data(), q_rows_aff, rows * sizeof(aff_t));
@@ -1059,20 +1069,29 @@ int sp_fold_commitments2_begin(sp_ctx* c, const uint64_t* q_rows_aff, size_t row
   if (rows && pool.walkers() > 0) {
     J->ladder.resize(rows * sp_fold2_job::LAD);
     pool.keep_hot(4000);
-    J->batch = pool.post_fn((unsigned)std::min<size_t>(rows, sp::WalkPool::MAX_PARTS), fold2_ladder_part, J.get());
-    if (!J->batch) J->ladder.clear();  // (no slot: the plain form at finish)
+    J->batch = pool.post_fn((unsigned)std::min<size_t>(rows, sp::WalkPool::MAX_PARTS), fold2_ladder_part, J);
+    if (J->batch) J->refs.fetch_add(1, std::memory_order_relaxed);  // the ladder region's
+    else J->ladder.clear();                                         // (no slot: the plain form at finish)
   }
-  *out = J.release();
+  *out = J;
   return SP_OK;
 }
-int sp_fold_commitments2_finish(sp_ctx* c, sp_fold2_job* job, const uint64_t* p_rows_aff, const uint64_t w[4], uint64_t* out_rows_aff) {
-  std::unique_ptr<sp_fold2_job> J(job);
+// the ladders are in (late parts built again by the caller); the region's reference goes with its last straggler
+static void fold2_collect_ladders(sp_fold2_job* J) {
+  if (!J->batch) return;
   sp::WalkPool& pool = sp::WalkPool::get();
-  if (J->batch) {
-    pool.wait_fn(J->batch);
-    J->batch = nullptr;
-    J->built = true;
-  }
+  (void)pool.collect_fn(J->batch, FOLD2_LATE_NS);
+  pool.end_fn(J->batch, fold2_unref, J);
+  J->batch = nullptr;
+  J->built = true;
+}
+int sp_fold_commitments2_finish(sp_ctx* c, sp_fold2_job* J, const uint64_t* p_rows_aff, const uint64_t w[4], uint64_t* out_rows_aff) {
+  struct Unref {
+    sp_fold2_job* j;
+    ~Unref() { fold2_unref(j); }
+  } owner{J};
+  sp::WalkPool& pool = sp::WalkPool::get();
+  fold2_collect_ladders(J);
   if (J->rows && (!p_rows_aff || !w || !out_rows_aff)) return fail(SP_ERR_INVALID_INPUT_LENGTH, "sp_fold_commitments2_finish: null argument");
   if (!J->built) return sp_fold_commitments2(c, p_rows_aff, reinterpret_cast<const uint64_t*>(J->q.data()), J->rows, w, out_rows_aff);
   // non-adjacent form of the canonical weight: digit j in {-1, 0, 1}, no two adjacent non-zero
@@ -1105,18 +1124,35 @@ int sp_fold_commitments2_finish(sp_ctx* c, sp_fold2_job* job, const uint64_t* p_
   }
   J->naf_len = len;
   J->out.assign(J->rows, jac_identity());
-  J->p = reinterpret_cast<const aff_t*>(p_rows_aff);
+  J->p.resize(J->rows);
+  if (J->rows) memcpy(J->p.data(), p_rows_aff, J->rows * sizeof(aff_t));
   pool.keep_hot(2000);
-  pool.run((unsigned)std::min<size_t>(J->rows, (size_t)pool.walkers() + 1), fold2_sum_part, J.get());
+  const unsigned np = (unsigned)std::min<size_t>(J->rows, (size_t)pool.walkers() + 1);
+  sp::WalkPool::Batch* b2 = np > 1 ? pool.post_fn(np, fold2_sum_part, J) : nullptr;
+  std::vector<jac_t> res;
+  if (b2) {
+    J->refs.fetch_add(1, std::memory_order_relaxed);
+    (void)pool.collect_fn(b2, FOLD2_LATE_NS);
+    res = J->out;  // (every entry has been written by now - by its part or by the caller's second run of it; a straggler rewrites the same values)
+    pool.end_fn(b2, fold2_unref, J);
+  } else {
+    for (unsigned p = 0; p < (np ? np : 1u); ++p) fold2_sum_part(J, p, np ? np : 1u);
+    res = J->out;
+  }
   std::vector<aff_t> a(J->rows);
-  normalize_batch(J->out, a.data());
+  normalize_batch(res, a.data());
   if (J->rows) memcpy(out_rows_aff, a.data(), J->rows * sizeof(aff_t));
   return SP_OK;
 }
-void sp_fold_commitments2_drop(sp_fold2_job* job) {
-  if (!job) return;
-  if (job->batch) sp::WalkPool::get().wait_fn(job->batch);
-  delete job;
+void sp_fold_commitments2_drop(sp_fold2_job* J) {
+  if (!J) return;
+  if (J->batch) {
+    sp::WalkPool& pool = sp::WalkPool::get();
+    (void)pool.collect_fn(J->batch, FOLD2_LATE_NS);
+    pool.end_fn(J->batch, fold2_unref, J);
+    J->batch = nullptr;
+  }
+  fold2_unref(J);
 }
 
 int sp_hyrax_rerandomize(sp_ctx* c, const sp_ck* ck, const uint64_t* comm_rows_aff, size_t rows, const uint64_t* r_old, const uint64_t* r_new, uint64_t* out_rows_aff) {

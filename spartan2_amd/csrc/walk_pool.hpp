@@ -43,6 +43,8 @@ class WalkPool {
     xyzz_t part[MAX_PARTS];
     std::atomic<unsigned char> pdone[MAX_PARTS];  // part p's result is in part[p]
     std::atomic<bool> orphan{false};              // the owner has left without waiting for every claimed part: the last finisher gives the slot back
+    void (*on_last)(void*) = nullptr;             // ... and calls this (the owner's reference on what the parts read and write)
+    void* on_last_arg = nullptr;
     std::atomic<unsigned> done{0};
     unsigned gen = 0;
     int slot = -1;
@@ -130,24 +132,27 @@ class WalkPool {
     return acc;
   }
   void run_part(Batch& b, unsigned p) {
-    if (b.fn) {
-      b.fn(b.arg, p, b.nparts);
-    } else {
-      b.part[p] = walk_part(b, p);
-      b.pdone[p].store(1, std::memory_order_release);
+    if (b.fn) b.fn(b.arg, p, b.nparts);
+    else b.part[p] = walk_part(b, p);
+    b.pdone[p].store(1, std::memory_order_release);
+    // (a claimed part counts once, whoever else may have run it meanwhile; the slot of a batch its owner has left goes back with its last part)
+    if (b.done.fetch_add(1, std::memory_order_acq_rel) + 1 == b.nparts && b.orphan.exchange(false, std::memory_order_acq_rel)) {
+      void (*f)(void*) = b.on_last;
+      void* a = b.on_last_arg;
+      release(&b);
+      if (f) f(a);
     }
-    // (a claimed part counts once, whoever else may have walked it meanwhile; the slot of a batch its owner has left goes back with its last part)
-    if (b.done.fetch_add(1, std::memory_order_acq_rel) + 1 == b.nparts && b.orphan.exchange(false, std::memory_order_acq_rel)) release(&b);
   }
   void loop() {
-    // Lowest scheduling class: a polling thread must never take a core FROM a thread of the application or of the library (their helper threads sleep and
-    // wake all the time; a waking polling thread that pre-empts one of them, or sits on the core the owner thread has just been moved to, holds it for a
-    // scheduler tick or until the balancer moves the victim - 7-18 ms proves, one in ~500, before this). On an otherwise idle core the class costs nothing.
+    // SPARTAN_WALKERS_IDLE=1 puts the walkers into the lowest scheduling class (they then never take a core from a thread of the application or of the
+    // library). Not the default: a walker of that class that holds a claimed part of a parallel region loses its core to ANY runnable thread for whole
+    // scheduler ticks - 3.5-6.8 ms proves, 1 % of them at config 3 (tools/c3_soak.py, 3000 proves), against ~0.2 % of 7-18 ms proves (a helper thread
+    // kept off its core) in the default class, which the run without walkers shows too. Idle polling offers the core every ~30 us in either class.
     {
-      const char* e = getenv("SPARTAN_WALKERS_IDLE");  // "0": the default class (A/B runs)
+      const char* e = getenv("SPARTAN_WALKERS_IDLE");
       struct sched_param sp0;
       sp0.sched_priority = 0;
-      if (!(e && e[0] == '0') && sched_setscheduler(0, SCHED_IDLE, &sp0) != 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 19);
+      if (e && e[0] == '1' && sched_setscheduler(0, SCHED_IDLE, &sp0) != 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 19);
     }
     unsigned idle = 0;
     for (;;) {
@@ -239,6 +244,8 @@ class WalkPool {
         b.nparts = 0;
         b.done.store(0, std::memory_order_relaxed);
         b.orphan.store(false, std::memory_order_relaxed);
+        b.on_last = nullptr;
+        b.on_last_arg = nullptr;
         for (auto& f : b.pdone) f.store(0, std::memory_order_relaxed);
         if (++gen_ == 0) ++gen_;
         b.gen = gen_;
@@ -334,6 +341,46 @@ class WalkPool {
     b->nparts = nparts;
     states_[b->slot].store(((uint64_t)b->gen << 32) | ((uint64_t)nparts << 16), std::memory_order_release);
     return b;
+  }
+  // The same for a region whose parts are IDEMPOTENT and whose data the caller can keep alive: the owner takes what is unclaimed, gives every claimed part
+  // `timeout_ns` (from its first wait) and runs the late ones again itself - a walker that has lost its core (to a helper thread of the library waking
+  // on it: milliseconds) no longer holds the owner. Returns true when stragglers are still out; `end_fn` then leaves the slot - and `on_last(arg)`, the
+  // caller's reference on the region's data - to the last of them, and otherwise does both at once.
+  bool collect_fn(Batch* b, long long timeout_ns) {
+    unsigned g;
+    for (int p; (p = claim(b->slot, &g)) >= 0;) run_part(*b, (unsigned)p);
+    long long deadline = 0;
+    for (unsigned p = 0; p < b->nparts; ++p) {
+      bool have = b->pdone[p].load(std::memory_order_acquire) != 0;
+      for (unsigned spins = 0; !have; ++spins) {
+        cpu_pause();
+        have = b->pdone[p].load(std::memory_order_acquire) != 0;
+        if (!have && (spins & 63u) == 63u) {
+          const long long t = now_ns();
+          if (!deadline) deadline = t + timeout_ns;
+          else if (t > deadline) break;
+        }
+      }
+      if (!have) {
+        b->fn(b->arg, p, b->nparts);
+        redone_.fetch_add(1, std::memory_order_relaxed);
+      }
+    }
+    return b->done.load(std::memory_order_acquire) < b->nparts;
+  }
+  void end_fn(Batch* b, void (*on_last)(void*), void* arg) {
+    if (b->done.load(std::memory_order_acquire) == b->nparts) {
+      release(b);
+      if (on_last) on_last(arg);
+      return;
+    }
+    b->on_last = on_last;
+    b->on_last_arg = arg;
+    b->orphan.store(true, std::memory_order_release);
+    if (b->done.load(std::memory_order_acquire) == b->nparts && b->orphan.exchange(false, std::memory_order_acq_rel)) {
+      release(b);
+      if (on_last) on_last(arg);
+    }
   }
   void wait_fn(Batch* b) {
     unsigned g;
