@@ -88,6 +88,46 @@ int main(int argc, char** argv) {
       bad += !(fe_eq(a1.x, a2.x) && fe_eq(a1.y, a2.y));
     }
   }
+  // a region of idempotent parts with a straggler: whoever runs part 1 FIRST sleeps 20 ms inside it (a walker that has lost its core); the owner's
+  // collect_fn must not wait for it (it runs the part again), the results must be complete, and the data's reference must be dropped exactly once -
+  // by the owner when nobody is late, by the straggler otherwise
+  {
+    struct Shared {
+      std::atomic<int> first{0}, refs{0}, dropped{0};
+      std::atomic<unsigned> out[8];
+    };
+    sp::WalkPool& pool = sp::WalkPool::get();
+    for (int rep = 0; rep < 6; ++rep) {
+      Shared* S = new Shared();
+      for (auto& o : S->out) o.store(0);
+      if (hot) pool.keep_hot(50000);
+      auto fn = [](void* a, unsigned p, unsigned) {
+        Shared* s = static_cast<Shared*>(a);
+        if (p == 1 && s->first.fetch_add(1) == 0) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        s->out[p].store(100 + p);
+      };
+      auto drop = [](void* a) {
+        Shared* s = static_cast<Shared*>(a);
+        s->dropped.fetch_add(1);
+      };
+      sp::WalkPool::Batch* b = pool.post_fn(8, fn, S);
+      if (!b) {  // no walkers: nothing to test
+        delete S;
+        break;
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(1));  // let the walkers claim (the sleeper among them, when there are walkers awake)
+      const auto t0 = std::chrono::steady_clock::now();
+      const bool late = pool.collect_fn(b, 200000);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      for (unsigned p = 0; p < 8; ++p) bad += S->out[p].load() != 100 + p;
+      // a walker slept inside part 1: the owner came back within a few ms without it; the owner itself slept (it claimed part 1 first): no straggler
+      if (late && ms > 15.0) ++bad;
+      pool.end_fn(b, drop, S);
+      std::this_thread::sleep_for(std::chrono::milliseconds(40));  // the straggler has finished by now
+      bad += S->dropped.load() != 1;
+      delete S;
+    }
+  }
   printf("walk pool (%d walkers, %s): %d mismatches\n", sp::WalkPool::get().walkers(), hot ? "polling" : "asleep", bad);
   return bad ? 1 : 0;
 #else
