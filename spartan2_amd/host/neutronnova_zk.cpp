@@ -162,6 +162,7 @@ struct NNZkPrep {
     size_t tape_from = 0, tape_count = 0;
     bool delta_valid = false, points_valid = false;
     sp_fold2_job* lz_fold = nullptr;  // comm_LZ = P_f + c_eval P_c: P_c's doubling ladder, begun by the helper when it has the point
+
   } open;
   ~NNZkPrep() {
     wk.drain();
@@ -778,11 +779,43 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
         O.lz_fold = nullptr;
         if (sp_fold_commitments2_begin(ps.ctx2, u64p(&O.P_c.x), 1, &O.lz_fold) != SP_OK) O.lz_fold = nullptr;
         O.points_valid = true;
+
       } catch (...) {
         O.points_valid = false;
       }
     });
   }
+  // The opening's W = folded_W + c_eval core_W exists only once c_eval is drawn, at the very end - but L^T W (bind_with_delayed, hyrax_pc.rs:38-54) is linear in
+  // the table: LZ = L^T folded_W + c_eval L^T core_W, and L = eq(r_y[1..]) is known now. The two products run as jobs of the library's vector stream under the
+  // verifier-circuit phase (one job at a time: the second is begun where the first is collected).
+  struct LzAhead {
+    sp_ctx* ctx;
+    sp_vec_job* job = nullptr;
+    size_t cols = 0;
+    std::vector<fe_t> f, c;
+    int have = 0;  // 1: f, 2: f and c
+    ~LzAhead() {
+      if (job) {
+        std::vector<fe_t> sink(cols);
+        (void)sp_rowmat_vec_eq_finish(ctx, job, u64p(sink.data()));
+      }
+    }
+  } lz{ctx};
+  if (side) {
+    const size_t nvr = log2_ceil(rows);
+    lz.cols = (size_t)1 << (pk.ny - 1 - nvr);
+    if (sp_rowmat_vec_eq_begin(ctx, fW, u64p(r_y.data() + 1), nvr, lz.cols, &lz.job) != SP_OK) lz.job = nullptr;
+  }
+  auto lz_step = [&] {  // collect the product in flight, begin the next
+    if (!lz.job) return;
+    const size_t nvr = log2_ceil(rows);
+    std::vector<fe_t>& dst = lz.have == 0 ? lz.f : lz.c;
+    dst.resize(lz.cols);
+    sp_vec_job* j = lz.job;
+    lz.job = nullptr;
+    if (sp_rowmat_vec_eq_finish(ctx, j, u64p(dst.data())) != SP_OK) return;
+    if (++lz.have == 1 && sp_rowmat_vec_eq_begin(ctx, ps.core.W, u64p(r_y.data() + 1), nvr, lz.cols, &lz.job) != SP_OK) lz.job = nullptr;
+  };
   auto eval_X = [&](const std::vector<fe_t>& Xv) {
     std::vector<fe_t> v{one};
     v.insert(v.end(), Xv.begin(), Xv.end());
@@ -872,6 +905,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     const std::vector<uint8_t> b = commitment_bytes(comm_T.data(), comm_T.size());
     tr.absorb("comm_T", b.data(), b.size());
   }
+  lz_step();  // L^T folded_W is in; L^T core_W goes out
   lap("NovaNIFS: T + commit_T");
   const fe_t rf = tr.squeeze("r");
   std::vector<fe_t> Wfold(vnv), Efold(vcons), rWfold(rnd_rW.size()), rEfold(rnd_rE.size()), Xfold(vio);
@@ -981,11 +1015,11 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     memcpy(&a, f_rW.data() + 4 * i, 32);
     blind[i] = fe_add<S>(a, fe_mul<S>(c_eval, core_rW[i]));
   }
-  {
+  auto fold_W = [&] {  // W = folded_W + c_eval * core_W as a table: only where the opening's halves were not computed ahead
     const sp_table* two[2] = {fW, ps.core.W};
     const fe_t wts[2] = {one, c_eval};
     ck(sp_fold_tables(ctx, two, 2, u64p(wts), nv, Wf), "W = folded_W + c_eval * core_W");
-  }
+  };
   aff_t comm_eval;
   if (fold2.eval) {
     sp_fold2_job* j = fold2.eval;
@@ -1001,6 +1035,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   std::vector<fe_t> z_vec(CW);
   fe_t z_delta, z_beta;
   if (reference_order) {  // PCS::prove(ck, ck_eval = the width-32 key, transcript, comm, W, blind, r_y[1..], comm_eval, blind_eval) (:2067-2080) as one call
+    fold_W();
     std::vector<uint64_t> arg(16 + 4 * CW + 8);
     ck(sp_hyrax_prove(ctx, pk.ck, pk.vc_ck, tr.t, u64p(&comm[0].x), comm.size(), Wf, nv, u64p(blind.data()), u64p(r_y.data() + 1), pk.ny - 1, u64p(&comm_eval.x),
                       u64p(&blind_eval), tape.bytes + 64 * tape.pos, tape.blocks - tape.pos, arg.data()),
@@ -1017,18 +1052,29 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     lap("pcs: absorb poly_com");
     const fe_t* point = r_y.data() + 1;
     const size_t npoint = pk.ny - 1, nvr = log2_ceil(rows);
-    const std::vector<fe_t> L = eq_evals(point, nvr), Rv = eq_evals(point + nvr, npoint - nvr);
-    std::vector<fe_t> LZ(Rv.size());
-    ck(sp_rowmat_vec(ctx, Wf, L.size(), Rv.size(), u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
-    lap("pcs: eq + rowmat_vec");
+    const std::vector<fe_t> L = eq_evals(point, nvr);
+    const size_t ncols = (size_t)1 << (npoint - nvr);
+    if (t_open) ps.wk.wait(t_open);
+    lap("pcs: wait for the opening's points");
+    const bool open_ahead = t_open && ps.open.delta_valid && ps.open.points_valid && ps.open.tape_from == tape.pos && ncols == ps.open.dv.size();
+    std::vector<fe_t> LZ(ncols), Rv;
+    lz_step();
+    if (lz.have == 2 && lz.f.size() == ncols && lz.c.size() == ncols) {
+      const fe_t *lf = lz.f.data(), *lc = lz.c.data();
+      par_for(ncols, 256, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) LZ[i] = fe_add<S>(lf[i], fe_mul<S>(c_eval, lc[i]));
+      });
+    } else {
+      fold_W();
+      ck(sp_rowmat_vec(ctx, Wf, L.size(), ncols, u64p(L.data()), u64p(LZ.data())), "bind_with_delayed");
+    }
+    lap("pcs: L^T W");
     fe_t r_LZ = fe_zero();
     for (size_t i = 0; i < L.size(); ++i) r_LZ = fe_add<S>(r_LZ, fe_mul<S>(L[i], blind[i]));
     std::vector<fe_t> dv;
     fe_t r_delta, r_beta;
     aff_t comm_LZ;
-    if (t_open) ps.wk.wait(t_open);
-    lap("pcs: wait for the opening's points");
-    if (t_open && ps.open.delta_valid && ps.open.points_valid && ps.open.tape_from == tape.pos && Rv.size() == ps.open.dv.size()) {
+    if (open_ahead) {
       // the helper has delta, beta and the two halves of comm_LZ = <L, rows of (folded + c_eval core)> = P_f + c_eval P_c
       dv.swap(ps.open.dv);
       r_delta = ps.open.r_delta;
@@ -1046,6 +1092,7 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     } else {
       if (laps && side) fprintf(stderr, "nn_prove: opening inputs computed inline (delta %d, points %d, tape %zu vs %zu)\n", (int)ps.open.delta_valid, (int)ps.open.points_valid, ps.open.tape_from, tape.pos);
       // the mask d and its blinds do not depend on the transcript (ipa.rs:139-147): delta's MSM runs on the auxiliary stream beside comm_LZ's
+      Rv = eq_evals(point + nvr, npoint - nvr);
       dv.resize(Rv.size());
       for (auto& x : dv) x = tape.next();
       r_delta = tape.next();
@@ -1071,7 +1118,9 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
     tr.absorb("beta", pb, 64);
     const fe_t rr = tr.squeeze("r");
     lap("pcs: comm_LZ + transcript");
-    for (size_t i = 0; i < Rv.size(); ++i) z_vec[i] = fe_add<S>(fe_mul<S>(rr, LZ[i]), dv[i]);
+    par_for(ncols, 256, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) z_vec[i] = fe_add<S>(fe_mul<S>(rr, LZ[i]), dv[i]);
+    });
     z_delta = fe_add<S>(fe_mul<S>(rr, r_LZ), r_delta);
     z_beta = fe_add<S>(fe_mul<S>(rr, blind_eval), r_beta);
     lap("pcs: z_vec");
