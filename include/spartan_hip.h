@@ -394,6 +394,10 @@ int sp_msm_ck_range_begin(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars,
 /* PCS::commit for keys of width <= 64, where the reference uses per-base FixedBaseMul tables (hyrax_pc.rs:221-260,
  * msm.rs:727-773 multi_mul): sum_i scalars[i] * ck[i] + h * blind, host scalars, n <= num_cols <= 64 */
 int sp_hyrax_commit_small(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind[4], uint64_t out_aff[8]);
+/* PCS::commit of a HOST vector of n scalars on a narrow key (<= 64 columns; rows x (num_cols + 1) <= 640), one blind a row, the latency form: one launch of
+ * the cooperative table walk through mapped memory, the rows' points added by the polling host threads (hyrax_pc.rs:221-260; the cross term of NovaNIFS,
+ * src/nifs.rs:34-61, is 512 scalars = 16 rows of the width-32 key and sits in the transcript chain). Same rows as sp_hyrax_commit on a staged table. */
+int sp_hyrax_commit_rows_host(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t* blinds, uint64_t* out_rows_aff);
 /* the same with the blind's term h * blind handed in as an affine point the caller computed beforehand (sp_fixed_base_mul_h: blinds come from the
  * randomness stream and are known long before the scalars); n <= 6; identity = all-zero coordinates */
 int sp_hyrax_commit_small_with_term(sp_ctx* ctx, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t blind_term_aff[8], uint64_t out_aff[8]);

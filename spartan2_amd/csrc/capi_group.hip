@@ -594,11 +594,12 @@ static const size_t FIXED_BASE_HOST_MAX = 8;  // below this many scalars one CPU
 // <= 128 scalars through mapped memory (kernels_msm.hpp k_fixed_base_rows_coop_mapped): launch on lane 0 = the main stream / lane 1 = the auxiliary stream,
 // then poll the n self-validating result slots. Larger calls keep the copy / launch / copy / synchronise form.
 static const size_t FB_MAPPED_MAX = 128, FB_SLOT_BYTES = 4 * spk::FB_SLOT_WORDS;
+static const size_t FB_MAPPED_CAP = 640;  // slots the mapped pages hold: the row commitments of host vectors on a narrow key take up to 16 rows x 33 (sp_hyrax_commit_rows_host)
 static bool fb_mapped_enabled() { return true; }
 // (allocated when a key is created, not inside a prove: an allocation call can wait for the device, and with it for resident kernels of other contexts
 // that are themselves waiting for host threads the call may be holding up)
 static int fb_mapped_ensure(sp_ctx* c, int lane) {
-  const size_t bytes = FB_MAPPED_MAX * FB_SLOT_BYTES + FB_MAPPED_MAX * sizeof(fe_t);
+  const size_t bytes = FB_MAPPED_CAP * FB_SLOT_BYTES + FB_MAPPED_CAP * sizeof(fe_t);
   if (!c->h_fbm[lane]) {
     SP_HIP(hipHostMalloc(&c->h_fbm[lane], bytes, hipHostMallocMapped));
     memset(c->h_fbm[lane], 0, bytes);
@@ -609,10 +610,10 @@ static int fb_mapped_ensure(sp_ctx* c, int lane) {
 static int fb_mapped_launch(sp_ctx* c, int lane, const aff_t* d_tables, size_t ntables, const uint64_t* scalars, size_t n, bool xyzz_out = false) {
   int erc = fb_mapped_ensure(c, lane);
   if (erc) return erc;
-  memcpy((char*)c->h_fbm[lane] + FB_MAPPED_MAX * FB_SLOT_BYTES, scalars, n * sizeof(fe_t));
+  memcpy((char*)c->h_fbm[lane] + FB_MAPPED_CAP * FB_SLOT_BYTES, scalars, n * sizeof(fe_t));
   if (++c->fbm_seq[lane] == 0) ++c->fbm_seq[lane];
   hipStream_t st = lane ? c->stream2 : c->stream;
-  const fe_t* ds = reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_MAX * FB_SLOT_BYTES);
+  const fe_t* ds = reinterpret_cast<const fe_t*>((char*)c->d_fbm[lane] + FB_MAPPED_CAP * FB_SLOT_BYTES);
   unsigned* dslots = reinterpret_cast<unsigned*>(c->d_fbm[lane]);
   const unsigned seq = c->fbm_seq[lane];
   const aff_t* t16 = fb_window16_enabled() ? tables16_of(d_tables) : nullptr;
@@ -2729,6 +2730,88 @@ int sp_hyrax_prove(sp_ctx* c, const sp_ck* ck, const sp_ck* ck_eval, sp_transcri
   zv[cols] = fe_add<SF>(fe_mul<SF>(rr, r_LZ), r_delta);
   zv[cols + 1] = fe_add<SF>(fe_mul<SF>(rr, b_eval), r_beta);
   lap("transcript + z_vec");
+  return SP_OK;
+}
+
+// PCS::commit of a HOST vector on a narrow key (hyrax_pc.rs:221-260: every row a FixedBaseMul::multi_mul + h * blind), the latency form: the (row, column)
+// scalars and the row blinds go to the device through the mapped page as ONE launch of the cooperative table walk over the 16-bit windows (four tree
+// levels, ~26-30 us for up to 640 scalars: the chain of dependent additions is all there is), every scalar's point comes back as (X, Y, ZZ, ZZZ) in a
+// self-validating slot, and a row's cols + 1 points are added by the polling host threads, a row each (~33 additions, 10 us). Against the device-table
+// form (upload, three device-to-device copies, two kernels - the second a shuffle tree of plain additions - a copy back, a synchronise): 232 -> ~75 us for
+// the 16 rows of NovaNIFS's cross term at config 3.
+struct RowsHostJob {
+  sp_ctx* c;
+  int lane;
+  unsigned seq;
+  size_t per, rows;
+  std::vector<jac_t> out;
+  std::atomic<int> rc{SP_OK};
+};
+static void rows_host_part(void* arg, unsigned part, unsigned np) {
+  RowsHostJob& J = *static_cast<RowsHostJob*>(arg);
+  std::vector<xyzz_t> xs(J.per);
+  for (size_t r = J.rows * part / np; r < J.rows * (part + 1) / np; ++r) {
+    // the slots of row r: scalars r * per .. (r + 1) * per - 1
+    unsigned* out = reinterpret_cast<unsigned*>(xs.data());
+    const int T = spk::FB_SLOT_TAG;
+    for (size_t i = 0; i < J.per; ++i) {
+      volatile const unsigned* slot = reinterpret_cast<volatile const unsigned*>((char*)J.c->h_fbm[J.lane] + FB_SLOT_BYTES * (r * J.per + i));
+      unsigned w[32];
+      long spins = 0;
+      for (;; ++spins) {
+        if (slot[T] == J.seq) {
+          std::atomic_thread_fence(std::memory_order_acquire);
+          unsigned a = J.seq, b = J.seq * 0x9E3779B1u;
+          for (int k = 0; k < 32; ++k) {
+            w[k] = slot[k];
+            a += w[k];
+            b += (unsigned)(k + 1) * w[k];
+          }
+          if (slot[T] == J.seq && slot[T + 1] == a && slot[T + 2] == b && slot[T + 3] == J.seq) break;
+        }
+        if (spins > 40000000) {  // seconds: the kernel never delivered (the caller synchronises and reports)
+          J.rc.store(SP_ERR_INTERNAL, std::memory_order_relaxed);
+          return;
+        }
+        __builtin_ia32_pause();
+      }
+      memcpy(out + 32 * i, w, 128);
+    }
+    xyzz_t acc = xyzz_identity();
+    for (size_t i = 0; i < J.per; ++i) acc = xyzz_add(acc, xs[i]);
+    J.out[r] = xyzz_to_jac(acc);
+  }
+}
+int sp_hyrax_commit_rows_host(sp_ctx* c, const sp_ck* ck, const uint64_t* scalars, size_t n, const uint64_t* blinds, uint64_t* out_rows_aff) {
+  if (!ck->d_cktables) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_rows_host: the key is wider than 64");
+  const size_t cols = ck->num_cols, rows = (n + cols - 1) / cols, per = cols + 1;
+  if (rows == 0) return SP_OK;
+  if (!scalars || !blinds || !out_rows_aff) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_rows_host: null argument");
+  const aff_t* t16 = fb_window16_enabled() ? tables16_of(ck->d_cktables) : nullptr;
+  if (rows * per > FB_MAPPED_CAP || !fb_mapped_enabled() || !t16 || c->fb_async_busy) return fail(SP_ERR_INVALID_INPUT_LENGTH, "commit_rows_host: too many rows for the mapped form (stage the vector and call sp_hyrax_commit)");
+  std::vector<fe_t> sc(rows * per, fe_zero());
+  for (size_t r = 0; r < rows; ++r) {
+    const size_t lo = r * cols, len = lo + cols <= n ? cols : n - lo;
+    memcpy(&sc[r * per], scalars + 4 * lo, len * sizeof(fe_t));
+    memcpy(&sc[r * per + cols], blinds + 4 * r, sizeof(fe_t));
+  }
+  // table of scalar i = i % per: the key's columns, then h - the layout of the per-base table set (ntables = per)
+  const int lane = c->hooks_host_only ? 1 : 0;  // (see sp_hyrax_commit_small)
+  int rc = fb_mapped_launch(c, lane, ck->d_cktables, per, reinterpret_cast<const uint64_t*>(sc.data()), rows * per, true);
+  if (rc) return rc;
+  RowsHostJob J{c, lane, c->fbm_seq[lane], per, rows};
+  J.out.assign(rows, jac_identity());
+  sp::WalkPool& pool = sp::WalkPool::get();
+  pool.keep_hot(2000);
+  const unsigned np = (unsigned)std::min<size_t>(rows, (size_t)pool.walkers() + 1);
+  pool.run(np ? np : 1u, rows_host_part, &J);
+  if (J.rc.load() != SP_OK) {
+    (void)sp::stream_sync(lane ? c->stream2 : c->stream);
+    return fail(SP_ERR_INTERNAL, "commit_rows_host: the table walk did not deliver its result slots");
+  }
+  std::vector<aff_t> a(rows);
+  normalize_batch(J.out, a.data());
+  memcpy(out_rows_aff, a.data(), rows * sizeof(aff_t));
   return SP_OK;
 }
 

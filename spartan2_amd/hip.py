@@ -430,6 +430,16 @@ class CommitmentKey:
         check(lib().sp_hyrax_commit(self.ctx.h, self.h, table.h, ctypes.c_size_t(off), ctypes.c_size_t(n), p64(blinds), int(is_small), p64(out)))
         return out
 
+    def commit_rows_host(self, scalars, blinds):
+        """sp_hyrax_commit_rows_host: PCS::commit of a host vector on a narrow key, the latency form (one launch through mapped memory, rows added on the host)."""
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        n = scalars.shape[0]
+        rows = (n + self.num_cols - 1) // self.num_cols
+        blinds = np.ascontiguousarray(blinds, dtype=np.uint64).reshape(rows, 4)
+        out = np.zeros((rows, 8), dtype=np.uint64)
+        check(lib().sp_hyrax_commit_rows_host(self.ctx.h, self.h, p64(scalars), ctypes.c_size_t(n), p64(blinds), p64(out)))
+        return out
+
     def commit_without_blind(self, table: Table, off, n, is_small=True):
         """PCS::commit_without_blind (hyrax_pc.rs:533-568): the raw per-row MSMs, (0,0) for an all-zero row"""
         rows = (n + self.num_cols - 1) // self.num_cols

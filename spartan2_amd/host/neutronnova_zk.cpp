@@ -381,9 +381,13 @@ static std::vector<aff_t> commit_rows32_side(NNZkPrep& ps, int slot, const sp_ck
   ck(sp_hyrax_commit(ctx, vc_ck, ps.bws[slot], 0, v.size(), u64p(blinds.data()), 0, u64p(&out[0].x)), "commit (width 32)");
   return out;
 }
-static std::vector<aff_t> commit_rows32(sp_ctx* ctx, NNZkPrep& ps, const sp_ck* vc_ck, const std::vector<fe_t>& v, const std::vector<fe_t>& blinds) {
-  sp_table* t = stage(ctx, ps, 0, v.data(), v.size());
+static std::vector<aff_t> commit_rows32(sp_ctx* ctx, NNZkPrep& ps, const sp_ck* vc_ck, const std::vector<fe_t>& v, const std::vector<fe_t>& blinds, bool latency = false) {
   std::vector<aff_t> out(blinds.size());
+  // the latency form (one launch through mapped memory, the rows added by the library's polling threads) where the commitment sits in the transcript chain
+  if (latency && sp_walkers() > 0 && v.size() <= 32 * blinds.size() && blinds.size() * 33 <= 640 &&
+      sp_hyrax_commit_rows_host(ctx, vc_ck, u64p(v.data()), v.size(), u64p(blinds.data()), u64p(&out[0].x)) == SP_OK)
+    return out;
+  sp_table* t = stage(ctx, ps, 0, v.data(), v.size());
   ck(sp_hyrax_commit(ctx, vc_ck, t, 0, v.size(), u64p(blinds.data()), 0, u64p(&out[0].x)), "commit (width 32)");
   return out;
 }
@@ -900,7 +904,9 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   par_for(vcons, 48, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; ++i) T[i] = fe_sub<S>(fe_sub<S>(fe_mul<S>(mv[0][i], mv[1][i]), fe_mul<S>(u1, mv[2][i])), rnd_E[i]);
   });
-  const std::vector<aff_t> comm_T = commit_rows32(ctx, ps, pk.vc_ck, T, r_T);
+  lap("NovaNIFS: absorbs, Z, multiply_vec, T");
+  const std::vector<aff_t> comm_T = commit_rows32(ctx, ps, pk.vc_ck, T, r_T, side);
+  lap("NovaNIFS: commit_T");
   {
     const std::vector<uint8_t> b = commitment_bytes(comm_T.data(), comm_T.size());
     tr.absorb("comm_T", b.data(), b.size());

@@ -528,6 +528,36 @@ def test_commit_small_device_form_matches_oracle(ctx, width):
         assert (k.commit_small(ones, blind) == want(ones, blind)).all()
 
 
+@pytest.mark.parametrize("width,n", [(32, 512), (32, 32), (32, 100), (8, 70), (64, 576)])
+def test_commit_rows_host_equals_the_staged_commit_and_the_oracle(ctx, width, n):
+    """sp_hyrax_commit_rows_host (a host vector on a narrow key through ONE launch of the cooperative table walk in mapped memory, the rows' points added by
+    the polling host threads) against sp_hyrax_commit on the staged table and the oracle's MSM + blind, row by row: full rows, a ragged last row, zero
+    scalars, an all-zero row, repeated calls (sequence numbers), and a vector too long for the mapped form (refused: the caller stages it)."""
+    rng = np.random.default_rng(SEED + 4700 + width + n)
+    gs = np.zeros((width + 1, 8), dtype=np.uint64)
+    olib().orc_from_label(b"narrow_key_test", ctypes.c_size_t(width + 1), p64(gs))
+    k = hip.CommitmentKey(ctx, gs[:width], gs[width])
+    rows = (n + width - 1) // width
+    for trial in range(3):
+        v = ol.random_field_array(rng, n)
+        v[rng.integers(0, n, size=max(1, n // 7))] = 0
+        if rows > 2:
+            v[width : 2 * width] = 0  # an all-zero row: its commitment is h * blind
+        blinds = ol.random_field_array(rng, rows)
+        got = k.commit_rows_host(v, blinds)
+        t = hip.Table.from_host(ctx, v)
+        assert (got == k.commit(t, 0, n, blinds)).all()
+        for r in range(rows):
+            full = np.zeros((width + 1, 4), dtype=np.uint64)
+            seg = v[r * width : (r + 1) * width]
+            full[: len(seg)] = seg
+            full[width] = blinds[r]
+            assert (got[r] == oracle_msm(full, np.ascontiguousarray(gs))).all(), (trial, r)
+    too_many = (640 // (width + 1) + 1) * width
+    with pytest.raises(hip.SpartanHipError):
+        k.commit_rows_host(ol.random_field_array(rng, too_many), ol.random_field_array(rng, too_many // width))
+
+
 @pytest.mark.parametrize("width", [32, 8])
 def test_commit_split_equals_commit_small_and_the_oracle(ctx, width):
     """sp_hyrax_commit_split_begin / _finish (the round commitments of the ZK verifier circuit: the terms known early and the blind are posted to the host
