@@ -230,6 +230,37 @@ impl Drop for SplitCommit {
     unsafe { sp_hyrax_commit_split_drop(self.job) }  // (null after finish: a no-op)
   }
 }
+/// Round 6 - fold_commitments with weights (1, w) where w is drawn late (src/neutronnova_zk.rs:2019-2051): the doubling ladders of q's rows are built ahead
+pub struct Fold2 {
+  job: *mut sp_fold2_job,
+}
+impl Fold2 {
+  pub fn begin(q_rows_aff: &[u64]) -> Result<Self, SpartanError> {
+    let mut job = std::ptr::null_mut();
+    check(unsafe { sp_fold_commitments2_begin(ctx(), q_rows_aff.as_ptr(), q_rows_aff.len() / 8, &mut job) })?;
+    Ok(Fold2 { job })
+  }
+  pub fn finish<F>(mut self, p_rows_aff: &[u64], w: &F) -> Result<Vec<u64>, SpartanError> {
+    let mut out = vec![0u64; p_rows_aff.len()];
+    let job = std::mem::replace(&mut self.job, std::ptr::null_mut());
+    check(unsafe { sp_fold_commitments2_finish(ctx(), job, p_rows_aff.as_ptr(), w as *const F as *const u64, out.as_mut_ptr()) })?;
+    Ok(out)
+  }
+}
+impl Drop for Fold2 {
+  fn drop(&mut self) {
+    unsafe { sp_fold_commitments2_drop(self.job) }
+  }
+}
+impl HipCommitmentKey {
+  /// PCS::commit of a host vector on a narrow key, the latency form (src/nifs.rs:34-61 comm_T)
+  pub fn commit_rows_host<F>(&self, v: &[F], blinds: &[F]) -> Result<Vec<u64>, SpartanError> {
+    let mut out = vec![0u64; 8 * blinds.len()];
+    check(unsafe { sp_hyrax_commit_rows_host(ctx(), self.k, v.as_ptr() as *const u64, v.len(), blinds.as_ptr() as *const u64, out.as_mut_ptr()) })?;
+    Ok(out)
+  }
+}
+
 /// for the duration of a prove whose round hooks commit through `SplitCommit`: the batched sum-checks may queue a round's launch ahead of the hook
 pub struct HostOnlyHooks;
 impl HostOnlyHooks {

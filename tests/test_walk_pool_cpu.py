@@ -44,3 +44,46 @@ def test_parallel_for_through_the_abi():
         assert sorted(hits) == [(p, nparts) for p in range(nparts)]
     assert L.sp_host_parallel_for(ctypes.c_uint(4), FN(), None) != 0  # a null function is refused
     assert L.sp_walkers() >= 0
+
+
+def test_two_term_fold_over_ladders_without_a_gpu():
+    """sp_fold_commitments2_begin / _finish is host work when the process has walkers (the doubling ladders and the non-adjacent-form walk run on the polling
+    threads): p + w q against the oracle's point arithmetic, no context, no device."""
+    import numpy as np
+
+    import oracle_lib as ol
+
+    L = hip.lib()
+    if L.sp_walkers() == 0:
+        pytest.skip("no walkers in this process: the call falls back to the device form")
+    rng = np.random.default_rng(77)
+
+    def points(n, label):
+        g = np.zeros((n, 8), dtype=np.uint64)
+        ol.lib().orc_from_label(label, ctypes.c_size_t(n), ol.p64(g))
+        return g
+
+    def mul(pt, k):
+        o = np.zeros(8, dtype=np.uint64)
+        ol.lib().orc_point_mul(ol.p64(np.ascontiguousarray(pt)), ol.p64(np.ascontiguousarray(k)), ol.p64(o))
+        return o
+
+    def add(a, b):
+        o = np.zeros(8, dtype=np.uint64)
+        ol.lib().orc_point_add(ol.p64(np.ascontiguousarray(a)), ol.p64(np.ascontiguousarray(b)), ol.p64(o))
+        return o
+
+    for n in (1, 5, 17):
+        q, p = points(n, b"fold2_q"), points(n, b"fold2_p")
+        if n > 2:
+            q[1] = 0
+            p[2] = 0
+        for w in (ol.random_field_array(rng, 1)[0], ol.to_mont(0), ol.to_mont(1), ol.to_mont((1 << 255) - (1 << 13) + 5)):
+            job = ctypes.c_void_p()
+            assert L.sp_fold_commitments2_begin(None, hip.p64(q), ctypes.c_size_t(n), ctypes.byref(job)) == 0
+            out = np.zeros_like(p)
+            assert L.sp_fold_commitments2_finish(None, job, hip.p64(p), hip.p64(np.ascontiguousarray(w)), hip.p64(out)) == 0
+            assert (out == np.stack([add(pp, mul(qq, w)) for pp, qq in zip(p, q)])).all()
+    job = ctypes.c_void_p()
+    assert L.sp_fold_commitments2_begin(None, hip.p64(points(3, b"fold2_q")), ctypes.c_size_t(3), ctypes.byref(job)) == 0
+    L.sp_fold_commitments2_drop(job)
