@@ -179,6 +179,14 @@ int sp_sumcheck_quad_observed(sp_ctx* ctx, const uint64_t claim[4], size_t round
                               void* user, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[8]);
 int sp_sumcheck_quad(sp_ctx* ctx, const uint64_t claim[4], size_t rounds, sp_table* A, sp_table* B, sp_transcript* tr, uint64_t* out_cpolys,
                      uint64_t* out_r, uint64_t out_final[8]);
+/* The same two provers on HOST tables of 2^ell / 2^rounds elements (bound in place), every round on the calling thread and the library's polling host
+ * threads (round 6): for the small sum-checks whose tables the caller holds on the host anyway - RelaxedR1CSSpartanProof::prove over the ZK verifier
+ * circuit's instance (src/spartan_relaxed.rs:98-213: 2^9 and 2^12 elements), where a round is ~10 n products against ~10 us a round of launch and bus
+ * latency on the device. Same polynomials, transcript and final claims as the device forms. `ctx` is not used (may be NULL). */
+int sp_sumcheck_cubic3_host(sp_ctx* ctx, const uint64_t claim[4], const uint64_t* taus, size_t ell, uint64_t* A, uint64_t* B, uint64_t* C, sp_transcript* tr,
+                            uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]);
+int sp_sumcheck_quad_host(sp_ctx* ctx, const uint64_t claim[4], size_t rounds, uint64_t* A, uint64_t* B, sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r,
+                          uint64_t out_final[8]);
 /* EqSumCheckInstance::evaluation_points_zero_check_round0 (src/sumcheck.rs:1163-1271; the round-0 shortcut of the *_zk cubic provers, :595): on a
  * zero-check (claim 0, A o B = C on the hypercube) t(0) vanishes, so only t_inf = sum E(x) (A1 - A0)(B1 - B0) is computed (C is not read) and the
  * evaluations (s(0), s(2), s(3)) of the round polynomial are derived from it (derive_from_claim :1276-1324, or the tau = 0 fallback :1244-1268).

@@ -2340,6 +2340,140 @@ int sp_sumcheck_cubic3(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus
   return cubic_impl(c, claim_io, p_io, taus_, ell, A, B, C, tr, nullptr, nullptr, nullptr, nullptr, nullptr, out_cpolys, out_r, out_final, 0,
                     ahead ? &eq_ahead_observe : nullptr, &ea);
 }
+// ---- the same provers on HOST tables (round 6) ------------------------------------------------------------------------------------------------------
+// The relaxed-Spartan sum-checks over the ZK verifier circuit's instance (src/spartan_relaxed.rs:98-213 inside NeutronNovaZkSNARK::prove) run on tables of
+// 2^9 (outer) and 2^12 (inner) elements that the driver holds on the HOST: staged to the device they cost three uploads, a resident kernel and a trip over
+// the bus per round (~10 us each, whatever the size) - 0.16 + 0.12 ms at config 3 - for ~10 n products a round, which the process's polling host threads
+// do in 1-3 us (walk_pool.hpp). These entry points run every round here: the same polynomials, the same transcript, the same final claims as
+// sp_sumcheck_cubic3 / sp_sumcheck_quad on device copies of the tables (tests: against the oracle on the CPU, against the device provers on the GPU).
+// The tables are bound in place (element 0 of each = the final claim).
+int sp_sumcheck_cubic3_host(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, uint64_t* A, uint64_t* B, uint64_t* C, sp_transcript* tr,
+                            uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
+  (void)c;
+  if (!claim_ || !taus_ || !A || !B || !C || !tr || !out_cpolys || !out_r || !out_final || ell == 0 || ell > 24)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_cubic_with_three_inputs (host tables): null argument or more than 2^24 elements");
+  tr->join();
+  sp::WalkPool::get().keep_hot(2000);
+  const size_t N = (size_t)1 << ell;
+  fe_t *ha = reinterpret_cast<fe_t*>(A), *hb = reinterpret_cast<fe_t*>(B), *hc = reinterpret_cast<fe_t*>(C);
+  std::vector<fe_t> taus(ell);
+  for (size_t i = 0; i < ell; ++i) taus[i] = load_fe(taus_ + 4 * i);
+  const fe_t one = fe_one<S>();
+  const uint8_t lbl_c[1] = {'c'};
+  // 1 / tau_k by one inversion; zeros stay zero (those rounds take the three-sum form), as in cubic_impl
+  std::vector<fe_t> inv_tau(ell, fe_zero());
+  {
+    std::vector<fe_t> pref(ell);
+    fe_t run = one;
+    for (size_t i = 0; i < ell; ++i) {
+      pref[i] = run;
+      if (!fe_is_zero(taus[i])) run = fe_mul<S>(run, taus[i]);
+    }
+    fe_t inv = fe_inv_vartime<S>(run);
+    for (size_t i = ell; i-- > 0;) {
+      if (fe_is_zero(taus[i])) continue;
+      inv_tau[i] = fe_mul<S>(inv, pref[i]);
+      inv = fe_mul<S>(inv, taus[i]);
+    }
+  }
+  HostEqLevels heq;
+  heq.build(taus.data(), ell, N / 2 ? N / 2 : 1);
+  fe_t claim = load_fe(claim_), p = one;
+  for (size_t rnd = 1; rnd <= ell; ++rnd) {
+    const size_t n = N >> (rnd - 1), hn = n / 2;
+    const fe_t tau = taus[rnd - 1];
+    const fe_t eq0 = fe_sub<S>(one, tau), slope = fe_sub<S>(tau, eq0), eqm1 = fe_sub<S>(eq0, slope);
+    const fe_t* E = heq.level(rnd);
+    if (!E) return fail(SP_ERR_INTERNAL, "prove_cubic_with_three_inputs (host tables): eq weights");
+    fe_t sums[3];
+    {  // the three tables are separate arrays here: the evaluation takes base pointers
+      HostCubicEval q;
+      q.a = ha;
+      q.b = hb;
+      q.c = hc;
+      q.E = E;
+      q.hn = hn;
+      const unsigned np = host_parts(hn, 12);
+      if (np > 1) sp::WalkPool::get().run(np, host_cubic_part, &q);
+      else host_cubic_part(&q, 0, 1);
+      for (int k = 0; k < 3; ++k) sums[k] = fe_zero();
+      for (unsigned pp = 0; pp < np; ++pp)
+        for (int k = 0; k < 3; ++k) sums[k] = fe_add<S>(sums[k], q.out[pp][k]);
+    }
+    const fe_t t0 = sums[0], tinf = sums[1];
+    const fe_t l_1_p = fe_mul<S>(fe_add<S>(eq0, slope), p);
+    fe_t s_0, s_1, s_leading, s_m1;
+    if (!fe_is_zero(l_1_p)) {  // derive_from_claim (src/sumcheck.rs:1276-1324), the division by l(1) p = tau p through 1 / tau
+      s_0 = fe_mul<S>(fe_mul<S>(eq0, p), t0);
+      s_1 = fe_sub<S>(claim, s_0);
+      s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
+      const fe_t two_sum = fe_add<S>(fe_dbl<S>(tinf), fe_dbl<S>(t0));
+      s_m1 = fe_mul<S>(eqm1, fe_sub<S>(fe_mul<S>(p, two_sum), fe_mul<S>(s_1, inv_tau[rnd - 1])));
+    } else {  // fallback_three_inputs (:1327-1396)
+      s_0 = fe_mul<S>(fe_mul<S>(eq0, p), t0);
+      s_1 = fe_sub<S>(claim, s_0);
+      s_leading = fe_mul<S>(fe_mul<S>(slope, p), tinf);
+      s_m1 = fe_mul<S>(fe_mul<S>(eqm1, p), sums[2]);
+    }
+    const fe_t halfc = two_inv();
+    UniPoly poly;
+    poly.n = 4;
+    poly.c[0] = s_0;
+    poly.c[1] = fe_sub<S>(fe_mul<S>(fe_sub<S>(s_1, s_m1), halfc), s_leading);
+    poly.c[2] = fe_sub<S>(fe_mul<S>(fe_add<S>(s_1, s_m1), halfc), s_0);
+    poly.c[3] = s_leading;
+    absorb_poly(tr->t, poly);
+    fe_t r_i;
+    if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+    const size_t ri = rnd - 1;
+    store_fe(out_r + 4 * ri, r_i);
+    store_fe(out_cpolys + 12 * ri, poly.c[0]);
+    store_fe(out_cpolys + 12 * ri + 4, poly.c[2]);
+    store_fe(out_cpolys + 12 * ri + 8, poly.c[3]);
+    claim = poly_eval(poly, r_i);
+    for (fe_t* T : {ha, hb, hc}) host_bind_tables(T, 0, 1, n, r_i);
+    p = fe_mul<S>(p, fe_add<S>(fe_sub<S>(fe_sub<S>(one, tau), r_i), fe_dbl<S>(fe_mul<S>(r_i, tau))));
+  }
+  store_fe(out_final, ha[0]);
+  store_fe(out_final + 4, hb[0]);
+  store_fe(out_final + 8, hc[0]);
+  return SP_OK;
+}
+int sp_sumcheck_quad_host(sp_ctx* c, const uint64_t claim_[4], size_t rounds, uint64_t* A, uint64_t* B, sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r,
+                          uint64_t out_final[8]) {
+  (void)c;
+  if (!claim_ || !A || !B || !tr || !out_cpolys || !out_r || !out_final || rounds == 0 || rounds > 24)
+    return fail(SP_ERR_INVALID_INPUT_LENGTH, "prove_quad (host tables): null argument or more than 2^24 elements");
+  tr->join();
+  sp::WalkPool::get().keep_hot(2000);
+  const size_t N = (size_t)1 << rounds;
+  fe_t *ha = reinterpret_cast<fe_t*>(A), *hb = reinterpret_cast<fe_t*>(B);
+  const uint8_t lbl_c[1] = {'c'};
+  fe_t claim = load_fe(claim_);
+  for (size_t round = 0; round < rounds; ++round) {
+    const size_t n = N >> round, half = n / 2;
+    fe_t sums[2];
+    host_quad_eval(ha, hb, half, sums);
+    // BDDT: eval_2 = 2 claim - 3 eval_0 + 2 t_inf and its interpolation (src/sumcheck.rs:211-215, univariate.rs:84-93): c0 = eval_0, c2 = t_inf, c1 = claim - 2 eval_0 - t_inf
+    UniPoly poly;
+    poly.n = 3;
+    poly.c[0] = sums[0];
+    poly.c[1] = fe_sub<S>(fe_sub<S>(claim, fe_dbl<S>(sums[0])), sums[1]);
+    poly.c[2] = sums[1];
+    absorb_poly(tr->t, poly);
+    fe_t r_i;
+    if (!tr->t.squeeze<S>(lbl_c, 1, &r_i)) return fail(SP_ERR_INTERNAL_TRANSCRIPT, "transcript round counter overflow");
+    store_fe(out_r + 4 * round, r_i);
+    store_fe(out_cpolys + 8 * round, poly.c[0]);
+    store_fe(out_cpolys + 8 * round + 4, poly.c[2]);
+    claim = poly_eval(poly, r_i);
+    host_bind_tables(ha, 0, 1, n, r_i);
+    host_bind_tables(hb, 0, 1, n, r_i);
+  }
+  store_fe(out_final, ha[0]);
+  store_fe(out_final + 4, hb[0]);
+  return SP_OK;
+}
 int sp_sumcheck_cubic3_round0(sp_ctx* c, const uint64_t claim_[4], const uint64_t* taus_, size_t ell, sp_table* A, sp_table* B, sp_table* C, const sp_table* p0,
                               const sp_table* p1, sp_transcript* tr, uint64_t* out_cpolys, uint64_t* out_r, uint64_t out_final[12]) {
   if (!p0 || !p1 || ell == 0 || p0->len != ((size_t)1 << ell) / 2 || p1->len != p0->len)

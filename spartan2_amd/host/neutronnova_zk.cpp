@@ -941,7 +941,19 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   });
   std::vector<fe_t> v_outer(3 * vlx), v_rx(vlx), v_inner(2 * vly), v_ry(vly);
   fe_t v_claims[3];
-  {
+  // the two relaxed-Spartan sum-checks run on tables this driver holds on the host (2^9 and 2^12 elements): with polling host threads in the process
+  // every round is run there (sp_sumcheck_*_host); staged to the device they are a trip over the bus a round
+  static const bool host_sc_off = [] {
+    const char* e = getenv("SPARTAN_HOST_SC");  // "0": the device provers on staged tables (A/B runs)
+    return e && e[0] == '0';
+  }();
+  const bool host_sc = side && sp_walkers() > 0 && !host_sc_off;
+  if (host_sc) {
+    const fe_t zero = fe_zero();
+    ck(sp_sumcheck_cubic3_host(ctx, u64p(&zero), u64p(vtau.data()), vlx, u64p(mv[0].data()), u64p(mv[1].data()), u64p(uczE.data()), tr.t, u64p(v_outer.data()),
+                               u64p(v_rx.data()), u64p(v_claims)),
+       "relaxed outer sum-check (host tables)");
+  } else {
     sp_table *ta = stage(ctx, ps, 0, mv[0].data(), vcons), *tb = stage(ctx, ps, 1, mv[1].data(), vcons), *tc = stage(ctx, ps, 2, uczE.data(), vcons);
     const fe_t zero = fe_zero();
     ck(sp_sumcheck_cubic3(ctx, u64p(&zero), u64p(vtau.data()), vlx, ta, tb, tc, tr.t, u64p(v_outer.data()), u64p(v_rx.data()), u64p(v_claims)), "relaxed outer sum-check");
@@ -985,7 +997,11 @@ static ProofBuf nn_prove(const NNZkKey& pk, NNZkPrep& ps, Tape& tape, double* ph
   }
   lap("claim_E + bind_matrix_rows");
   zr.resize(vz_len, fe_zero());
-  {
+  if (host_sc) {
+    fe_t ci[2];
+    ck(sp_sumcheck_quad_host(ctx, u64p(&v_claim_inner), vly, u64p(vabc.data()), u64p(zr.data()), tr.t, u64p(v_inner.data()), u64p(v_ry.data()), u64p(ci)),
+       "relaxed inner sum-check (host tables)");
+  } else {
     sp_table *ta = stage(ctx, ps, 3, vabc.data(), vz_len), *tb = stage(ctx, ps, 4, zr.data(), vz_len);
     fe_t ci[2];
     ck(sp_sumcheck_quad(ctx, u64p(&v_claim_inner), vly, ta, tb, tr.t, u64p(v_inner.data()), u64p(v_ry.data()), u64p(ci)), "relaxed inner sum-check");
