@@ -2902,6 +2902,9 @@ struct sp_split_commit {
   sp::WalkPool::Batch* early = nullptr;  // posted at begin (nullptr: the pool had no free slot - the terms are kept and walked at finish)
   std::vector<const aff_t*> kept;
   bool any_early = false;
+  ~sp_split_commit() {
+    if (!kept.empty()) explicit_bzero(kept.data(), kept.size() * sizeof(kept[0]));  // (entry pointers = digits of the scalars, the blind's among them)
+  }
 };
 static int split_entries(const sp_ck* ck, const uint32_t* cols, const uint64_t* scalars, size_t n, const uint64_t* blind, std::vector<const aff_t*>& ents) {
   auto walk = [&](size_t table, const uint64_t* sc4) -> int {

@@ -23,6 +23,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -390,6 +391,11 @@ class WalkPool {
   }
   bool finished(const Batch* b) const { return b->done.load(std::memory_order_acquire) >= b->nparts; }
   void release(Batch* b) {
+    // (a walk's entry pointers are the digits of its scalars - blinds among them - and its part sums partial commitments: nothing of either stays behind)
+    if (!b->fn && b->n_ents) {
+      explicit_bzero(b->ents, b->n_ents * sizeof(b->ents[0]));
+      explicit_bzero(b->part, b->nparts * sizeof(b->part[0]));
+    }
     states_[b->slot].store(0, std::memory_order_release);
     std::lock_guard<std::mutex> l(mu_);
     in_use_[b->slot] = false;
