@@ -56,6 +56,26 @@ hipError_t stream_sync(hipStream_t s) {
   while ((e = hipStreamQuery(s)) == hipErrorNotReady) g_wait_hook(g_wait_user);
   return e;
 }
+hipError_t stream_sync_short(hipStream_t s) {
+  hipError_t e;
+  if (g_wait_hook) {
+    while ((e = hipStreamQuery(s)) == hipErrorNotReady) g_wait_hook(g_wait_user);
+    return e;
+  }
+  static const bool off = [] {
+    const char* v = getenv("SPARTAN_SYNC_SHORT");  // "0": the runtime's blocking wait (A/B runs)
+    return v && v[0] == '0';
+  }();
+  if (!off) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned k = 0;; ++k) {
+      if ((e = hipStreamQuery(s)) != hipErrorNotReady) return e;
+      if ((k & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) break;
+      __builtin_ia32_pause();
+    }
+  }
+  return hipStreamSynchronize(s);
+}
 hipError_t event_sync(hipEvent_t ev) {
   hipError_t e;
   if (!g_wait_hook) {

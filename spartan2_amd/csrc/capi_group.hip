@@ -336,7 +336,20 @@ static int msm_shared_weights_on(sp_ctx* c, int lane, const uint64_t* weights, s
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 8) nt = 8;
     if (nt > rows) nt = (unsigned)rows;
-    if (rows < 4 || nt < 2) {
+    sp::WalkPool& pool = sp::WalkPool::get();
+    if (rows >= 4 && pool.walkers() > 0) {
+      // on the process's polling threads (no thread is created inside a prove: eight clones and eight 8 MiB stack mappings a call take the address
+      // space's lock against every page fault of the process)
+      struct H {
+        decltype(horner)* f;
+        size_t rows;
+      } h{&horner, rows};
+      pool.keep_hot(2000);
+      pool.run((unsigned)std::min<size_t>(rows, (size_t)pool.walkers() + 1), [](void* a, unsigned p, unsigned np) {
+        H& x = *static_cast<H*>(a);
+        for (size_t r = x.rows * p / np; r < x.rows * (p + 1) / np; ++r) (*x.f)(r);
+      }, &h);
+    } else if (rows < 4 || nt < 2) {
       for (size_t r = 0; r < rows; ++r) horner(r);
     } else {  // ~60 us per row: the 16-row commitment fold of a NeutronNova batch would spend a millisecond here on one core
       std::vector<std::thread> th;
@@ -447,7 +460,13 @@ static int host_tables16_of(const std::vector<aff_t>& bases, const aff_t* d_t16,
   // 2 MiB-aligned and advised for huge pages: a walk touches 16 random lines of a 64 MiB table (4 KiB pages: a TLB miss each)
   void* raw = aligned_alloc((size_t)2 << 20, (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1));
   if (!raw) return SP_OK;  // (no host copy: the 8-bit tables / the device form serve)
-  madvise(raw, bytes, MADV_HUGEPAGE);
+  {
+    static const bool thp = [] {
+      const char* e = getenv("SPARTAN_HOST_T16_THP");  // "0": ordinary pages
+      return !(e && e[0] == '0');
+    }();
+    if (thp) madvise(raw, bytes, MADV_HUGEPAGE);
+  }
   std::shared_ptr<aff_t[]> buf(static_cast<aff_t*>(raw), [](aff_t* p) { free(p); });
   for (size_t k = 0; k < which.size(); ++k) {
     size_t run = 1;  // consecutive tables in one copy
@@ -971,6 +990,21 @@ static int scalar_mul_rows(sp_ctx* c, const uint64_t* points_aff, size_t n, cons
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 8) nt = 8;
     if (nt > n) nt = (unsigned)n;
+    sp::WalkPool& pool = sp::WalkPool::get();
+    if (n >= 4 && pool.walkers() > 0) {  // (the polling threads instead of threads created here: see msm_shared_weights_on)
+      struct M {
+        const aff_t* pts;
+        const spk::WnafArgs* w;
+        std::vector<jac_t>* out;
+        size_t n;
+      } m{pts, &w, &out, n};
+      pool.keep_hot(2000);
+      pool.run((unsigned)std::min<size_t>(n, (size_t)pool.walkers() + 1), [](void* a, unsigned p, unsigned np) {
+        M& x = *static_cast<M*>(a);
+        for (size_t i = x.n * p / np; i < x.n * (p + 1) / np; ++i) (*x.out)[i] = wnaf_mul_host(x.pts[i], x.w->d, x.w->len);
+      }, &m);
+      return SP_OK;
+    }
     if (n < 4 || nt < 2) {
       for (size_t i = 0; i < n; ++i) out[i] = wnaf_mul_host(pts[i], w.d, w.len);
       return SP_OK;

@@ -87,12 +87,12 @@ int sum_partials(sp_nifs* n, size_t rows, size_t cnt, fe_t* out_host) {
   if (cnt_out <= 64) {
     if (!n->h_pin) SP_HIP(hipHostMalloc((void**)&n->h_pin, 64 * sizeof(fe_t)));
     SP_HIP(hipMemcpyAsync(n->h_pin, dst, cnt_out * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP(sp::stream_sync(c->stream));
+    SP_HIP(sp::stream_sync_short(c->stream));
     memcpy(out_host, n->h_pin, cnt_out * sizeof(fe_t));
     return SP_OK;
   }
   SP_HIP(hipMemcpyAsync(out_host, dst, cnt_out * sizeof(fe_t), hipMemcpyDeviceToHost, c->stream));
-  SP_HIP(sp::stream_sync(c->stream));
+  SP_HIP(sp::stream_sync_short(c->stream));
   return SP_OK;
 }
 
@@ -564,7 +564,7 @@ int sp_nifs_finish(sp_nifs* n, sp_table* A_out, sp_table* B_out, sp_table* C_out
   }
   if ((rc = sp_fold_tables(c, ptrs.data(), n->n_padded, w.data(), n->total, C_out))) return rc;
   }
-  SP_HIP(sp::stream_sync(c->stream));
+  SP_HIP(sp::stream_sync_short(c->stream));
   for (sp_table* t : {A_out, B_out}) {
     t->len = n->total;
     t->lo_eff = t->hi_eff = (size_t)-1;

@@ -31,6 +31,10 @@ void relax();
 // instead of blocking — a blocked thread could not serve the other proofs it carries, and one of those may own a kernel that sits in front of this
 // stream's work in a shared hardware queue while it waits for its host's next challenge. Never call them (or relax()) with a library mutex held.
 hipError_t stream_sync(hipStream_t s);
+// the same for waits that are known to be short and sit in a transcript chain (the NIFS rounds): polls hipStreamQuery for up to 2 ms before it lets the
+// runtime block the thread - a thread that sleeps on the completion interrupt is now and then woken 7-30 ms late (one prove in a few hundred at config 3,
+// always here: `nifs lap finish 11.7 ms` under SPARTAN_HOST_LAPS)
+hipError_t stream_sync_short(hipStream_t s);
 hipError_t event_sync(hipEvent_t e);
 // A host-side poll gave up and takes its slow path (a stream synchronise, the mirror, a sleep): with SPARTAN_SLOWPATH_LOG set, one line on stderr per
 // event - these are the places a rare multi-millisecond prove comes from (a profiler serialising the streams, a result that only became visible at
