@@ -450,7 +450,11 @@ int sp_shape_from_csr(sp_ctx* c, const sp_csr* A, const sp_csr* Bm, const sp_csr
     }();
     if (order_mode == 0) std::stable_sort(order.begin(), order.end(), by_len);
     else if (order_mode == 2)
-      for (size_t lo = 0; lo < order.size(); lo += 4096) std::stable_sort(order.begin() + lo, order.begin() + std::min(order.size(), lo + 4096), by_len);
+    {
+      const char* w = getenv("SPARTAN_POLYABC_WINDOW");
+      const size_t win = w && atol(w) > 0 ? (size_t)atol(w) : 4096;
+      for (size_t lo = 0; lo < order.size(); lo += win) std::stable_sort(order.begin() + lo, order.begin() + std::min(order.size(), lo + win), by_len);
+    }
     s->n_short = order.size();
     if ((rc = upload(&s->d_short_order, order))) {
       sp_shape_free(s);
