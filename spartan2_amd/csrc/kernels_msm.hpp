@@ -515,9 +515,14 @@ __global__ void __launch_bounds__(256) k_msm_bucket_sum_rows(const aff_t* __rest
 // even when the bucket holds two points: 11.8 ms against 1.4 ms here.)
 __global__ void __launch_bounds__(256) k_msm_bucket_sum_shared(const aff_t* __restrict__ bases /* [rows][n] */, unsigned n, const unsigned* __restrict__ order,
                                                                const unsigned* __restrict__ start, int windows, size_t total_buckets, jac_t* __restrict__ buckets) {
-  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= total_buckets) return;
-  const size_t per_row = (size_t)windows * MSM_BUCKETS, row = b / per_row, wk = b % per_row;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total_buckets) return;
+  // neighbouring lanes take the SAME (window, bucket) of neighbouring rows (round 6): the bucket's entry list is shared by every row, so a wave runs one
+  // trip count - with the lanes of a wave on 64 buckets of one row it ran the longest of 64 lists (~2 entries on average, 6-7 the longest) - and a wave
+  // whose bucket is empty leaves at once. The result keeps its (row, window, bucket) place.
+  const size_t per_row = (size_t)windows * MSM_BUCKETS, rows = total_buckets / per_row;
+  const size_t row = gid % rows, wk = gid / rows;
+  const size_t b = row * per_row + wk;
   const size_t w = wk / MSM_BUCKETS, k = wk % MSM_BUCKETS;
   const unsigned lo = start[w * (MSM_BUCKETS + 1) + k], hi = start[w * (MSM_BUCKETS + 1) + k + 1];
   const aff_t* rb = bases + row * n;
